@@ -1,0 +1,545 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by RUNNING the imported reference on CPU.
+
+Run in the build container only (needs /root/reference):
+
+    python tools/gen_golden.py            # all cases
+    python tools/gen_golden.py G3 G5      # a subset
+
+Each fixture holds inputs that are not seed-derivable plus the reference's
+outputs (float32). Parameters are never stored: both sides derive them from
+``evdeblurnerf_amd.weights`` (numpy RandomState) and this script
+``load_state_dict``s them into the reference modules. No reference source is
+copied; this script only calls it. Golden ids follow SURVEY.md 8c.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import ref_import  # noqa: E402
+
+ref_import.install()
+
+import torch  # noqa: E402
+
+from evdeblurnerf_amd import weights as W  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_grad_enabled(False)
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+def t(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def n(x):
+    return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    arrays = {k: (np.asarray(v, dtype=np.float32) if np.asarray(v).dtype == np.float64 else np.asarray(v))
+              for k, v in arrays.items()}
+    np.savez_compressed(path, **arrays)
+    print(f"  wrote {os.path.relpath(path, ROOT)}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+# ---------------------------------------------------------------------------
+def G1_embedder():
+    from networks.embedding import get_embedder
+    rs = np.random.RandomState(101)
+    x = rs.uniform(-1.5, 1.5, size=(192, 3)).astype(np.float32)
+    x[:8] = rs.uniform(-40.0, 40.0, size=(8, 3)).astype(np.float32)  # large magnitudes
+    x[8] = 0.0
+    x[9] = [1.0, -1.0, 0.5]
+    e10, d10 = get_embedder(10)
+    e4, d4 = get_embedder(4)
+    e2, d2 = get_embedder(2)
+    assert d10 == 63 and d4 == 27
+    save("G1_embedder", x=x, pe10=n(e10(t(x))), pe4=n(e4(t(x))), pe2=n(e2(t(x))))
+
+
+def _ref_nerf(seed, D=8, Wd=256, rgb_add_bias=True, **kw):
+    from networks.nerf import NeRF
+    net = NeRF(D=D, W=Wd, input_ch=63, input_ch_views=27, output_ch=4, skips=[4], use_viewdirs=True,
+               rgb_add_bias=rgb_add_bias, **kw)
+    sd = W.make_nerf_state_dict(seed, D=D, W=Wd, rgb_add_bias=rgb_add_bias)
+    ref_import.load_np_state_dict(net, sd)
+    net.train(False)
+    return net
+
+
+def G2_nerf_mlp():
+    rs = np.random.RandomState(202)
+    pts = rs.uniform(-1.2, 1.2, size=(384, 3)).astype(np.float32)
+    dirs = rs.standard_normal((384, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    from networks.embedding import get_embedder
+    e10, _ = get_embedder(10)
+    e4, _ = get_embedder(4)
+    x = torch.cat([e10(t(pts)), e4(t(dirs))], -1)
+    out = {}
+    for tag, kw in (("w256", dict(seed=7, D=8, Wd=256, rgb_add_bias=True)),
+                    ("w256_nobias", dict(seed=8, D=8, Wd=256, rgb_add_bias=False)),
+                    ("w64", dict(seed=9, D=8, Wd=64, rgb_add_bias=True))):
+        net = _ref_nerf(**kw)
+        raw, feat = net.eval(x)
+        out[f"raw_{tag}"] = n(raw)
+        out[f"feat_{tag}"] = n(feat)[:, :16]  # first 16 feature columns are enough to pin the layer
+        net_b = _ref_nerf(**kw, extract_feature="before_linear")
+        _, featb = net_b.eval(x)
+        out[f"featb_{tag}"] = n(featb)[:, :16]
+    save("G2_nerf_mlp", pts=pts, dirs=dirs, **out)
+
+
+def _composite_inputs(rs, R, S):
+    raw = rs.standard_normal((R, S, 4)).astype(np.float32)
+    raw[..., 3] = raw[..., 3] * 4.0 + 1.0
+    near = rs.uniform(0.0, 0.1, size=(R, 1)).astype(np.float32)
+    z = np.sort(near + rs.uniform(0.0, 1.0, size=(R, S)).astype(np.float32) * (1.0 - near), axis=-1)
+    rays_d = rs.standard_normal((R, 3)).astype(np.float32)
+    # edge cases per SURVEY 8c G3
+    raw[0, :, 3] = -5.0                     # zero density everywhere (relu clamps)
+    raw[1, :, 3] = 1.0e4                    # huge density: first sample takes everything
+    z[2, 10:20] = z[2, 10]                  # duplicate z => delta 0 => alpha 0
+    raw[3, :, 3] = 0.0                      # exactly zero
+    z[4] = np.linspace(0.0, 1.0, S)         # regular spacing
+    raw[5, : S // 2, 3] = -1.0
+    raw[5, S // 2:, 3] = 50.0               # wall in the middle
+    return raw, z.astype(np.float32), rays_d
+
+
+def G3_nerf_raw2outputs():
+    from networks.nerf import NeRF
+    rs = np.random.RandomState(303)
+    out = {}
+    for S in (64, 128, 33):
+        raw, z, rays_d = _composite_inputs(rs, 20, S)
+        out[f"raw_S{S}"], out[f"z_S{S}"], out[f"d_S{S}"] = raw, z, rays_d
+        for tag, kw, call in (
+                ("plain", {}, {}),
+                ("white", {}, {"white_bkgd": True}),
+                ("rmnear", {"render_rmnearplane": 20}, {}),
+                ("relu_rgb", {"rgb_activate": "relu"}, {}),
+                ("none_rgb", {"rgb_activate": "none"}, {}),
+                ("softplus", {"sigma_activate": "softplus"}, {})):
+            net = NeRF(D=2, W=8, input_ch=3, input_ch_views=3, use_viewdirs=True, **kw)
+            net.train(False)
+            rgb, dens, acc, wts, depth, fmap = net.raw2outputs(t(raw), t(z), t(rays_d), None, 0, **call)
+            assert fmap is None
+            out[f"rgb_S{S}_{tag}"] = n(rgb)
+            out[f"acc_S{S}_{tag}"] = n(acc)
+            out[f"depth_S{S}_{tag}"] = n(depth)
+            out[f"weights_S{S}_{tag}"] = n(wts)
+            if tag == "plain":
+                out[f"density_S{S}"] = n(dens)
+        # feature compositing (composite_feature=True path, nerf.py:119)
+        feat = rs.standard_normal((20, S, 5)).astype(np.float32)
+        net = NeRF(D=2, W=8, input_ch=3, input_ch_views=3, use_viewdirs=True)
+        net.train(False)
+        fmap = net.raw2outputs(t(raw), t(z), t(rays_d), t(feat), 0)[5]
+        out[f"feat_S{S}"], out[f"fmap_S{S}"] = feat, n(fmap)
+    save("G3_nerf_raw2outputs", **out)
+
+
+def G4_voxel_raw2outputs():
+    from networks.pdrf.voxnerf import VoxelNeRFRayFeatures, VoxelNeRFSampleFeatures
+    rs = np.random.RandomState(404)
+    aabb = (torch.tensor([-1.5, -1.5, -1.0]), torch.tensor([1.5, 1.5, 1.0]))
+    out = {}
+    for S in (64, 128):
+        raw4, z, rays_d = _composite_inputs(rs, 12, S)
+        # voxel order: sigma first, rgb after (voxnerf.py:172,179); colours arrive already sigmoided
+        raw = np.concatenate([raw4[..., 3:4], 1.0 / (1.0 + np.exp(-raw4[..., :3]))], -1).astype(np.float32)
+        out[f"raw_S{S}"], out[f"z_S{S}"], out[f"d_S{S}"] = raw, z, rays_d
+        for tag, cls in (("coarse", VoxelNeRFRayFeatures), ("fine", VoxelNeRFSampleFeatures)):
+            net = cls(aabb=aabb, input_ch=95, n_voxels=512, app_n_comp=[4, 2, 2], app_dim=4)
+            rgb, dens, acc, wts, depth = net.raw2outputs(t(raw), t(z), t(rays_d), 0, is_train=False)
+            out[f"rgb_S{S}_{tag}"], out[f"acc_S{S}_{tag}"] = n(rgb), n(acc)
+            out[f"depth_S{S}_{tag}"], out[f"weights_S{S}_{tag}"] = n(depth), n(wts)
+        # 16-channel feature compositing (PBE mode, voxnerf.py:226)
+        raw16 = rs.standard_normal((12, S, 16)).astype(np.float32)
+        net = VoxelNeRFRayFeatures(aabb=aabb, input_ch=95, n_voxels=512, app_n_comp=[4, 2, 2], app_dim=4)
+        fm, _, acc, wts, depth = net.raw2outputs(t(raw16), t(z), t(rays_d), 0, is_train=False)
+        out[f"raw16_S{S}"], out[f"fmap16_S{S}"] = raw16, n(fm)
+    save("G4_voxel_raw2outputs", **out)
+
+
+def G5_sample_pdf():
+    from utils.rays import sample_pdf
+    rs = np.random.RandomState(505)
+    out = {}
+    for S, N in ((64, 64), (64, 128), (128, 64), (17, 9)):
+        R = 40
+        z = np.sort(rs.uniform(0, 1, size=(R, S)).astype(np.float32), -1)
+        z[0] = np.linspace(0, 1, S)
+        bins = (0.5 * (z[:, 1:] + z[:, :-1])).astype(np.float32)
+        w = rs.uniform(0, 1, size=(R, S - 2)).astype(np.float32) ** 4
+        w[0] = 0.0                          # all-zero weights => uniform pdf
+        w[1] = 0.0
+        w[1, (S - 2) // 3] = 1.0            # one spike
+        w[2] = 1.0                          # flat
+        w[3] = 0.0
+        w[3, 0] = 1.0                       # spike in first bin
+        w[4] = 0.0
+        w[4, -1] = 1.0                      # spike in last bin
+        w[5] = 1e-7 * rs.uniform(0, 1, size=S - 2)  # tiny weights: denom guard
+        zs = sample_pdf(t(bins), t(w), N, det=True)
+        u = rs.uniform(0, 1, size=(R, N)).astype(np.float32)
+        # explicit-u variant: patch torch.rand for one call (the reference draws u internally)
+        orig = torch.rand
+        torch.rand = lambda *a, **k: t(u)
+        try:
+            zs_u = sample_pdf(t(bins), t(w), N, det=False)
+        finally:
+            torch.rand = orig
+        key = f"S{S}_N{N}"
+        out[f"bins_{key}"], out[f"w_{key}"], out[f"u_{key}"] = bins, w, u
+        out[f"det_{key}"], out[f"rand_{key}"] = n(zs), n(zs_u)
+    save("G5_sample_pdf", **out)
+
+
+def G6_rays():
+    from utils.rays import get_rays, get_rays_pix, get_ndc_rays
+    K = W.synthetic_camera(400, 400, 400.0)
+    Kn = W.synthetic_camera(60, 80, 95.5)
+    Kn[0, 2] += 1.25
+    Kn[1, 2] -= 0.75
+    c2w = W.synthetic_pose(5)
+    o, d = get_rays(60, 80, t(Kn), t(c2w))
+    rs = np.random.RandomState(606)
+    coords = np.stack([rs.randint(0, 400, 300), rs.randint(0, 400, 300)], -1).astype(np.float32)
+    poses = np.stack([W.synthetic_pose(60 + i) for i in range(300)])
+    op, dp = get_rays_pix(t(coords), t(K), t(poses))
+    on, dn = get_ndc_rays(400, 400, float(K[0, 0]), 1.0, op, dp)
+    save("G6_rays", Kn=Kn, c2w=c2w, rays_o_full=n(o)[::7, ::5], rays_d_full=n(d)[::7, ::5],
+         coords=coords, poses=poses, rays_o_pix=n(op), rays_d_pix=n(dp), ndc_o=n(on), ndc_d=n(dn))
+
+
+def _nerfall(mode, N_importance, seed, **over):
+    from networks.renderer import NeRFAll
+    over.setdefault("rgb_add_bias", True)
+    args = ref_import.blurfactory_args(mode=mode, N_importance=N_importance, **over)
+    import io
+    import contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = NeRFAll(args)
+    return model, args
+
+
+def G7_render_nerf():
+    K = W.synthetic_camera()
+    out = {}
+    # (a) hierarchical 64+64, retraw
+    model, _ = _nerfall("nerf", 64, 0)
+    sd = {}
+    sd.update(W.prefixed(W.make_nerf_state_dict(11), "mlp_coarse"))
+    sd.update(W.prefixed(W.make_nerf_state_dict(12), "mlp_fine"))
+    ref_import.load_np_state_dict(model, sd)
+    model.train(False)
+    rays = W.synthetic_rays(1, 96)
+    rgb, depth, acc, ex = model.render(400, 400, t(K), 1024, rays=t(rays), ndc=True, near=0., far=1.,
+                                       use_viewdirs=True, N_samples=64, N_importance=64, retraw=True,
+                                       perturb=0., raw_noise_std=0.)
+    out.update(a_rgb=n(rgb), a_depth=n(depth), a_acc=n(acc), **{f"a_{k}": n(v) for k, v in ex.items()})
+    # (b) the metric shape at small R: 128 samples, single pass, chunked (chunk < R)
+    model, _ = _nerfall("nerf", 0, 0)
+    ref_import.load_np_state_dict(model, W.prefixed(W.make_nerf_state_dict(13), "mlp_coarse"))
+    model.train(False)
+    rays = W.synthetic_rays(2, 80)
+    rgb, depth, acc, ex = model.render(400, 400, t(K), 32, rays=t(rays), ndc=True, near=0., far=1.,
+                                       use_viewdirs=True, N_samples=128, N_importance=0, retraw=True,
+                                       perturb=0., raw_noise_std=0.)
+    out.update(b_rgb=n(rgb), b_depth=n(depth), b_acc=n(acc), **{f"b_{k}": n(v) for k, v in ex.items()})
+    # (c) config 1: R=1024-ray batch shape scaled down, 64 samples, white background, no ndc
+    rays = W.synthetic_rays(3, 64)
+    rgb, depth, acc, ex = model.render(400, 400, t(K), 1024, rays=t(rays), ndc=False, near=0.5, far=3.5,
+                                       use_viewdirs=True, N_samples=64, N_importance=0, retraw=False,
+                                       perturb=0., raw_noise_std=0., white_bkgd=True, lindisp=True)
+    out.update(c_rgb=n(rgb), c_depth=n(depth), c_acc=n(acc))
+    # (d) explicit randomness: perturb=1 with injected t_rand / u (stratified + sample_pdf draws)
+    model, _ = _nerfall("nerf", 32, 0)
+    sd = {}
+    sd.update(W.prefixed(W.make_nerf_state_dict(11), "mlp_coarse"))
+    sd.update(W.prefixed(W.make_nerf_state_dict(12), "mlp_fine"))
+    ref_import.load_np_state_dict(model, sd)
+    model.train(False)
+    rays = W.synthetic_rays(4, 48)
+    rs = np.random.RandomState(707)
+    t_rand = rs.uniform(0, 1, size=(48, 64)).astype(np.float32)
+    u = rs.uniform(0, 1, size=(48, 32)).astype(np.float32)
+    draws = [t(t_rand), t(u)]
+    orig = torch.rand
+    torch.rand = lambda *a, **k: draws.pop(0)
+    try:
+        rgb, depth, acc, ex = model.render(400, 400, t(K), 1024, rays=t(rays), ndc=True, near=0., far=1.,
+                                           use_viewdirs=True, N_samples=64, N_importance=32, retraw=True,
+                                           perturb=1., raw_noise_std=0.)
+    finally:
+        torch.rand = orig
+    assert not draws
+    out.update(d_t_rand=t_rand, d_u=u, d_rgb=n(rgb), d_depth=n(depth), d_acc=n(acc),
+               **{f"d_{k}": n(v) for k, v in ex.items()})
+    save("G7_render_nerf", **out)
+
+
+PDRF_SMALL = dict(coarse_n_voxels=24 ** 3, fine_n_voxels=48 ** 3)
+
+
+def _pdrf_sds(model, seed_c, seed_f):
+    gc = [int(v) for v in model.mlp_coarse.gridSize]
+    sd = W.prefixed(W.make_pdrf_state_dict(seed_c, gc, input_ch=32 + 63, hidden_dim=64, geo_feat_dim=15),
+                    "mlp_coarse")
+    if model.mlp_fine is not None:
+        gf = [int(v) for v in model.mlp_fine.gridSize]
+        sd.update(W.prefixed(W.make_pdrf_state_dict(seed_f, gf, input_ch=64 + 63, hidden_dim=256,
+                                                    geo_feat_dim=128), "mlp_fine"))
+    return sd
+
+
+def G8_appfeature():
+    model, _ = _nerfall("c2f", 64, 0, rgb_add_bias=False, **PDRF_SMALL)
+    sd = _pdrf_sds(model, 21, 22)
+    ref_import.load_np_state_dict(model, sd)
+    gc = [int(v) for v in model.mlp_coarse.gridSize]
+    gf = [int(v) for v in model.mlp_fine.gridSize]
+    assert gc == W.pdrf_grid_size([-1.5, -1.5, -1.0], [1.5, 1.5, 1.0], 24 ** 3), gc
+    assert gf == W.pdrf_grid_size([-1.5, -1.5, -1.0], [1.5, 1.5, 1.0], 48 ** 3), gf
+    rs = np.random.RandomState(808)
+    pts = rs.uniform(-1.0, 1.0, size=(6, 40, 3)).astype(np.float32) * np.array([1.5, 1.5, 1.0], np.float32)
+    pts[0, :8] *= 1.3                      # outside the box: zero padding
+    pts[1, 0] = [-1.5, -1.5, -1.0]         # exactly on the corners
+    pts[1, 1] = [1.5, 1.5, 1.0]
+    pts[1, 2] = [0.0, 0.0, 0.0]
+    fc = model.mlp_coarse.sample(t(pts))
+    ff = model.mlp_fine.sample(t(pts))
+    save("G8_appfeature", pts=pts, grid_coarse=np.array(gc), grid_fine=np.array(gf), ft_coarse=n(fc), ft_fine=n(ff))
+
+
+def G9_render_c2f():
+    K = W.synthetic_camera()
+    model, _ = _nerfall("c2f", 64, 0, rgb_add_bias=False, **PDRF_SMALL)
+    ref_import.load_np_state_dict(model, _pdrf_sds(model, 31, 32))
+    model.train(False)
+    rays = W.synthetic_rays(9, 64)
+    rgb, depth, acc, ex = model.render(400, 400, t(K), 1024, rays=t(rays), ndc=True, near=0., far=1.,
+                                       use_viewdirs=True, N_samples=64, N_importance=64, retraw=True,
+                                       perturb=0., raw_noise_std=0.)
+    out = dict(rgb=n(rgb), depth=n(depth), acc=n(acc), **{k: n(v) for k, v in ex.items()})
+    # coarse only
+    model0, _ = _nerfall("c2f", 0, 0, rgb_add_bias=False, **PDRF_SMALL)
+    ref_import.load_np_state_dict(model0, _pdrf_sds(model0, 31, 32))
+    model0.train(False)
+    rgb, depth, acc, ex = model0.render(400, 400, t(K), 1024, rays=t(rays), ndc=True, near=0., far=1.,
+                                        use_viewdirs=True, N_samples=64, N_importance=0, retraw=True,
+                                        perturb=0., raw_noise_std=0.)
+    out.update(c_rgb=n(rgb), c_depth=n(depth), c_acc=n(acc), c_weights=n(ex["weights"]))
+    # per-sample features of the fine level (what AWP consumes): first 8 of 128 channels
+    model.use_awp = True
+    rgb, depth, acc, ex = model.render(400, 400, t(K), 1024, rays=t(rays[:16]), ndc=True, near=0., far=1.,
+                                       use_viewdirs=True, N_samples=64, N_importance=64, retraw=True,
+                                       perturb=0., raw_noise_std=0.)
+    out.update(f_depth_feature=n(ex["depth_feature"])[:, :, :8], f_rays_d=n(ex["rays_d"]))
+    save("G9_render_c2f", **out)
+
+
+def G10_rbk_weighted_sum():
+    from networks.dpnerf.blurmodel import RigidBlurringModel
+    rs = np.random.RandomState(1010)
+    R, P, S = 24, 10, 16
+    rgb = rs.uniform(0, 1, size=(R * P, 3)).astype(np.float32)
+    depth = rs.uniform(0, 1, size=(R * P,)).astype(np.float32)
+    acc = rs.uniform(0, 1, size=(R * P,)).astype(np.float32)
+    ex = {"rgb0": rs.uniform(0, 1, size=(R * P, 3)).astype(np.float32),
+          "z_std": rs.uniform(0, 1, size=(R * P,)).astype(np.float32),
+          "weights": rs.uniform(0, 1, size=(R * P, S)).astype(np.float32),
+          "depth_feature": rs.standard_normal((R * P, S, 4)).astype(np.float32)}
+    logits = rs.standard_normal((R, P)).astype(np.float32)
+    ccw = 1.0 / (1.0 + np.exp(-logits))
+    ccw = (ccw / ccw.sum(-1, keepdims=True)).astype(np.float32)
+    fake_self = type("S", (), {"num_motion": P - 1, "use_origin": True})()
+    o_rgb, o_depth, o_acc, o_ex = RigidBlurringModel.rbk_weighted_sum(
+        fake_self, t(rgb), t(depth), t(acc), {k: t(v) for k, v in ex.items()}, t(ccw))
+    save("G10_rbk_weighted_sum", rgb=rgb, depth=depth, acc=acc, ccw=ccw, **{f"ex_{k}": v for k, v in ex.items()},
+         o_rgb=n(o_rgb), o_depth=n(o_depth), o_acc=n(o_acc), **{f"o_{k}": n(v) for k, v in o_ex.items()})
+
+
+def _tonemap(map_rgb, map_ev, extra_ev, seed):
+    from networks.tonemapping import TonemappingTransform
+    tm = TonemappingTransform(map_rgb, map_ev, init_learn_identity=False, extra_features_event=extra_ev)
+    if map_ev == "learn":
+        ref_import.load_np_state_dict(tm.tonemapping_event, W.make_crf_state_dict(seed, extra_ev))
+    if map_rgb == "learn":
+        ref_import.load_np_state_dict(tm.tonemapping_rgb, W.make_crf_state_dict(seed + 1, 0))
+    return tm
+
+
+def G11_crf():
+    rs = np.random.RandomState(1111)
+    x = rs.uniform(0, 1, size=(200, 3)).astype(np.float32)
+    x[0] = 0.0
+    x[1] = 1.0
+    f2 = np.stack([-rs.randint(0, 4, 200), rs.randint(0, 4, 200)], -1).astype(np.float32)
+    f32 = np.stack([-rs.randint(0, 4, (200, 3)), rs.randint(0, 4, (200, 3))], -1).astype(np.float32)
+    out = dict(x=x, f2=f2, f32=f32)
+    tm = _tonemap("gamma", "learn", 2, 41)
+    out["rgb_gamma"] = n(tm(t(x), mode="encode_rgb"))
+    out["luma_learn_f2"] = n(tm(t(x), mode="encode_luma", ev_extra_feat=t(f2)))
+    out["luma_learn_nofeat"] = n(tm(t(x), mode="encode_luma"))
+    out["luma_learn_skip"] = n(tm(t(x), mode="encode_luma", skip_learn_crf=True, ev_extra_feat=t(f2)))
+    out["tone_learn_f32"] = n(tm(t(x), mode="encode_luma", tonemap_only=True, ev_extra_feat=t(f32)))
+    out["luma_learn_keep"] = n(tm(t(x), mode="encode_luma", keep_rgb=True, ev_extra_feat=t(f2)))
+    out["luma_chunked"] = n(tm(t(x), mode="encode_luma", chunk=64, ev_extra_feat=None))
+    tm = _tonemap("none", "learn", 0, 43)
+    out["rgb_none"] = n(tm(t(x), mode="encode_rgb"))
+    out["luma_learn0"] = n(tm(t(x), mode="encode_luma"))
+    tm = _tonemap("gamma", "gamma", 0, 45)
+    out["luma_gamma"] = n(tm(t(x), mode="encode_luma"))
+    for std in ("rec709", "avg"):
+        from networks.tonemapping import TonemappingTransform
+        tm = TonemappingTransform("gamma", "gamma", luma_standard=std)
+        out[f"luma_gamma_{std}"] = n(tm(t(x), mode="encode_luma"))
+    save("G11_crf", **out)
+
+
+def G12_egm_loss():
+    from utils.events import egm_loss
+    rs = np.random.RandomState(1212)
+    N = 300
+    ls = rs.uniform(0.01, 1, size=(N, 1)).astype(np.float32)
+    le = rs.uniform(0.01, 1, size=(N, 1)).astype(np.float32)
+    ls3 = rs.uniform(0.0, 1, size=(N, 3)).astype(np.float32)
+    le3 = rs.uniform(0.0, 1, size=(N, 3)).astype(np.float32)
+    bii = (0.2 * rs.randint(-3, 4, N)).astype(np.float32)
+    cidx = rs.randint(0, 3, N)
+    cmask = np.zeros((N, 3), dtype=bool)
+    cmask[np.arange(N), cidx] = True
+    out = dict(ls=ls, le=le, ls3=ls3, le3=le3, bii=bii, cmask=cmask)
+    out["loss_plain"] = n(egm_loss(t(ls), t(le), t(bii)))
+    out["loss_mask"] = n(egm_loss(t(ls3), t(le3), t(bii), color_mask=t(cmask)))
+    out["loss_mask_w"] = n(egm_loss(t(ls3), t(le3), t(bii), color_mask=t(cmask), color_weight=[0.4, 0.2, 0.4]))
+    save("G12_egm_loss", **out)
+
+
+def G13_edi():
+    from utils import edi
+    rs = np.random.RandomState(1313)
+    H = Wd = 16
+    steps = 9
+    bii = []
+    ev = {}
+    for s in range(steps - 1):
+        ne = rs.randint(20, 60)
+        x = rs.uniform(0, Wd - 1, ne).astype(np.float32)
+        y = rs.uniform(0, H - 1, ne).astype(np.float32)
+        x[:3] = np.floor(x[:3])              # integer coordinates: floor/ceil de-dup rule
+        y[1:4] = np.floor(y[1:4])
+        x[4] = Wd - 1                        # last column: ceil falls outside
+        p = rs.randint(0, 2, ne).astype(np.int8)
+        img = edi.brightness_increment_image(x, y, p, Wd, H, 0.2, 0.25, interpolate=True)
+        img_ni = edi.brightness_increment_image(np.floor(x), np.floor(y), p, Wd, H, 0.2, 0.25, interpolate=False)
+        ev[f"x{s}"], ev[f"y{s}"], ev[f"p{s}"] = x, y, p
+        ev[f"bii_ni{s}"] = img_ni
+        bii.append(img)
+    bii = np.stack(bii)
+    blurry = rs.uniform(0.05, 1, size=(H, Wd)).astype(np.float32)
+    inner = edi.inner_double_integral(bii)
+    sharp = edi.deblur_double_integral(blurry, bii)
+    bii3 = np.stack([bii, 0.5 * bii, -bii], -1)
+    blurry3 = rs.uniform(0.05, 1, size=(H, Wd, 3)).astype(np.float32)
+    sharp3 = edi.deblur_double_integral(blurry3, bii3)
+    slow = np.stack(edi.slowmo_double_integral(sharp, bii))
+    save("G13_edi", bii=bii, blurry=blurry, inner=inner, sharp=sharp, bii3=bii3, blurry3=blurry3, sharp3=sharp3,
+         slowmo=slow, **ev)
+
+
+def G14_loss_assembly():
+    """One synthetic step of the loss block (reference run_nerf.py:443-497, 518-591) with the
+    renderer outputs replaced by given tensors; restates only the *composition order*, every
+    operator is the reference's own (TonemappingTransform, egm_loss, img2mse)."""
+    from utils.events import egm_loss
+    sys.modules.setdefault("skimage", type(sys)("skimage"))
+    sys.modules["skimage"].metrics = None
+    sys.modules.setdefault("networks.lpips", type(sys)("networks.lpips"))
+    sys.modules["networks.lpips"].LPIPS = None
+    from utils.metrics import img2mse
+    rs = np.random.RandomState(1414)
+    out = {}
+    for cfg in ("blender", "cdavis"):
+        R, P, NE = 64, 10, (96 if cfg == "blender" else 80)
+        rgb_p = rs.uniform(0, 1, size=(R * P, 3)).astype(np.float32)     # fine rgb of every sub-exposure ray
+        rgb0_p = rs.uniform(0, 1, size=(R * P, 3)).astype(np.float32)    # coarse
+        logits = rs.standard_normal((2, R, P)).astype(np.float32)
+        ccw = 1.0 / (1.0 + np.exp(-logits))
+        ccw = (ccw / ccw.sum(-1, keepdims=True)).astype(np.float32)      # [0]=weight1, [1]=ccw_fine (AWP)
+        target = rs.uniform(0, 1, size=(R, 3)).astype(np.float32)
+        target_pts0 = rs.uniform(0, 1, size=(R, 3)).astype(np.float32)
+        fine_loss_weight, w_pts0, w_egm, w_tv, tv = 0.1, 0.01, 0.1, 1.0, 0.0
+        tm = _tonemap("gamma" if cfg == "blender" else "none", "learn", 2, 51)
+        crf = lambda x, **k: tm(x, **k)
+        rgb = (t(rgb_p).reshape(R, P, 3) * t(ccw[0])[..., None]).sum(1)
+        rgb1 = (t(rgb0_p).reshape(R, P, 3) * t(ccw[0])[..., None]).sum(1)
+        rgb_awp = (t(rgb_p).reshape(R, P, 3) * t(ccw[1])[..., None]).sum(1)
+        loss = img2mse(crf(rgb, mode="encode_rgb"), t(target)) + img2mse(crf(rgb1, mode="encode_rgb"), t(target))
+        img_fine = img2mse(crf(rgb_awp, mode="encode_rgb"), t(target))
+        loss = loss * (1 - fine_loss_weight) + img_fine * fine_loss_weight
+        pts0 = 0.0
+        for x in (t(rgb_p).reshape(R, P, 3)[:, 0], t(rgb0_p).reshape(R, P, 3)[:, 0]):
+            pts0 = pts0 + img2mse(crf(x, mode="encode_rgb"), t(target_pts0))
+        loss = loss + pts0 * w_pts0
+        # events
+        thr = np.array([0.2, 0.2] if cfg == "blender" else [0.25, 0.25], np.float32)
+        cn = -rs.randint(0, 4, NE).astype(np.float32)
+        cp = rs.randint(0, 4, NE).astype(np.float32)
+        bii = (t(thr) * torch.stack([t(cn), t(cp)], -1)).sum(-1)
+        es, es0, ee, ee0 = (rs.uniform(0.02, 1, size=(NE, 3)).astype(np.float32) for _ in range(4))
+        cidx = rs.randint(0, 3, NE)
+        cmask = np.zeros((NE, 3), dtype=bool)
+        cmask[np.arange(NE), cidx] = True
+        if cfg == "blender":
+            feat = torch.stack([t(cn), t(cp)], -1)
+            kw, cm, cw = {}, None, None
+        else:
+            fn = torch.zeros(NE, 3)
+            fp = torch.zeros(NE, 3)
+            fn[t(cmask)] = t(cn)
+            fp[t(cmask)] = t(cp)
+            feat = torch.stack([fn, fp], -1)
+            kw, cm, cw = {"tonemap_only": True}, t(cmask), [0.4, 0.2, 0.4]
+        l_s = crf(t(es), mode="encode_luma", ev_extra_feat=feat, **kw)
+        l_s0 = crf(t(es0), mode="encode_luma", ev_extra_feat=feat, **kw)
+        l_e = crf(t(ee), mode="encode_luma", ev_extra_feat=feat, **kw)
+        l_e0 = crf(t(ee0), mode="encode_luma", ev_extra_feat=feat, **kw)
+        egm = egm_loss(l_s0, l_e0, bii, color_mask=cm, color_weight=cw) + \
+            egm_loss(l_s, l_e, bii, color_mask=cm, color_weight=cw)
+        total = loss + tv * w_tv + egm * w_egm
+        out.update({f"{cfg}_rgb_p": rgb_p, f"{cfg}_rgb0_p": rgb0_p, f"{cfg}_ccw": ccw, f"{cfg}_target": target,
+                    f"{cfg}_target_pts0": target_pts0, f"{cfg}_cn": cn, f"{cfg}_cp": cp, f"{cfg}_cmask": cmask,
+                    f"{cfg}_es": es, f"{cfg}_es0": es0, f"{cfg}_ee": ee, f"{cfg}_ee0": ee0,
+                    f"{cfg}_img_loss": n(loss), f"{cfg}_pts0": n(pts0), f"{cfg}_egm": n(egm), f"{cfg}_total": n(total),
+                    f"{cfg}_scalars": np.array([fine_loss_weight, w_pts0, w_egm], np.float32)})
+    save("G14_loss_assembly", **out)
+
+
+ALL = [G1_embedder, G2_nerf_mlp, G3_nerf_raw2outputs, G4_voxel_raw2outputs, G5_sample_pdf, G6_rays,
+       G7_render_nerf, G8_appfeature, G9_render_c2f, G10_rbk_weighted_sum, G11_crf, G12_egm_loss, G13_edi,
+       G14_loss_assembly]
+
+if __name__ == "__main__":
+    want = set(sys.argv[1:])
+    for fn in ALL:
+        tag = fn.__name__.split("_")[0]
+        if want and tag not in want:
+            continue
+        print(fn.__name__)
+        fn()
