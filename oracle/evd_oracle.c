@@ -1,0 +1,865 @@
+/*
+ * evd_oracle.c -- CPU restatement of the EvDeblurNeRF renderer + loss path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see evd_oracle.h). Parity pinned by tests/golden/G*.npz,
+ * which tools/gen_golden.py produced by running the imported reference.
+ *
+ * Build: oracle/Makefile  (gcc -O2 -ffp-contract=off -fopenmp; unfused mul/add like torch's
+ * elementwise kernels). Citations are reference paths (file:line).
+ */
+#include "evd_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+int evo_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------ activations */
+static inline float act(int code, float x) {
+    switch (code) {
+    case EVO_ACT_RELU: return x > 0.f ? x : 0.f;
+    case EVO_ACT_SIGMOID: return 1.f / (1.f + expf(-x));
+    case EVO_ACT_EXP: return expf(x);
+    case EVO_ACT_SIGMOID1: return 1.002f / (expf(-x) + 1.f) - 0.001f;  /* nerf.py:32 */
+    case EVO_ACT_SOFTPLUS: {                                           /* nn.Softplus()(x-1), nerf.py:33 */
+        float y = x - 1.f;
+        return y > 20.f ? y : log1pf(expf(y));
+    }
+    case EVO_ACT_TANH: return tanhf(x);
+    default: return x;
+    }
+}
+
+/* ------------------------------------------------------------------ Embedder
+ * networks/embedding.py:88-98: cat([x] + [sin(x*2^k), cos(x*2^k) for k<L]); freq_bands :78 */
+void evo_embed(const float* x, long n, int dim, int L, float* out) {
+    const int od = dim * (1 + 2 * L);
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < n; ++i) {
+        const float* xi = x + i * dim;
+        float* o = out + i * od;
+        for (int c = 0; c < dim; ++c) o[c] = xi[c];
+        float freq = 1.f;
+        for (int k = 0; k < L; ++k) {
+            for (int c = 0; c < dim; ++c) {
+                float a = xi[c] * freq;
+                o[dim + (2 * k) * dim + c] = sinf(a);
+                o[dim + (2 * k + 1) * dim + c] = cosf(a);
+            }
+            freq *= 2.f;
+        }
+    }
+}
+
+/* y[fo] = b + W[fo,:] . x, k ascending.  Wt is the [in,out] transpose so the inner loop vectorises
+ * while every output keeps the same k-ascending summation order. */
+static void linear_t(const float* Wt, const float* b, int in, int out, const float* x, float* y) {
+    if (b) memcpy(y, b, sizeof(float) * out);
+    else memset(y, 0, sizeof(float) * out);
+    for (int k = 0; k < in; ++k) {
+        const float xv = x[k];
+        const float* w = Wt + (long)k * out;
+        for (int j = 0; j < out; ++j) y[j] += xv * w[j];
+    }
+}
+
+static float* transpose_w(const float* W, int out, int in) {
+    float* t = (float*)malloc(sizeof(float) * (size_t)out * in);
+    for (int o = 0; o < out; ++o)
+        for (int k = 0; k < in; ++k) t[(long)k * out + o] = W[(long)o * in + k];
+    return t;
+}
+
+/* ------------------------------------------------------------------ NeRF.eval
+ * networks/nerf.py:131-162.  emb = [n, input_ch + input_ch_views]; raw = cat([rgb, alpha]) :157 */
+void evo_nerf_mlp(const evo_nerf* net, const float* emb, long n, float* raw, float* feat_after, float* feat_before) {
+    const int D = net->D, W = net->W, ic = net->input_ch, icv = net->input_ch_views;
+    float* wt[EVO_MAX_LAYERS];
+    int fin[EVO_MAX_LAYERS];
+    for (int i = 0; i < D; ++i) {
+        fin[i] = (i == 0) ? ic : ((i - 1) == net->skip ? W + ic : W);
+        wt[i] = transpose_w(net->pts_w[i], W, fin[i]);
+    }
+    float *wv = NULL, *wf = NULL, *wa = NULL, *wr = NULL, *wo = NULL;
+    if (net->use_viewdirs) {
+        wv = transpose_w(net->views_w, W / 2, W + icv);
+        wf = transpose_w(net->feature_w, W, W);
+        wa = transpose_w(net->alpha_w, 1, W);
+        wr = transpose_w(net->rgb_w, 3, W / 2);
+    } else {
+        wo = transpose_w(net->output_w, net->output_ch, W);
+    }
+    const int ein = ic + icv;
+#pragma omp parallel
+    {
+        float* h = (float*)malloc(sizeof(float) * (W + ic + icv));
+        float* h2 = (float*)malloc(sizeof(float) * (W + ic + icv));
+#pragma omp for schedule(static)
+        for (long s = 0; s < n; ++s) {
+            const float* x = emb + s * ein;
+            const float* in = x;
+            for (int i = 0; i < D; ++i) {
+                float* o = (i == net->skip) ? h2 + ic : h2;          /* cat([input_pts, h]) nerf.py:137-138 */
+                linear_t(wt[i], net->pts_b[i], fin[i], W, in, o);
+                for (int j = 0; j < W; ++j) o[j] = o[j] > 0.f ? o[j] : 0.f;
+                if (i == net->skip) memcpy(h2, x, sizeof(float) * ic);
+                float* tmp = h; h = h2; h2 = tmp;
+                in = h;
+            }
+            /* h = layer-D activations (W wide unless D-1 == skip) */
+            if (feat_before) memcpy(feat_before + s * W, h, sizeof(float) * W);
+            if (net->use_viewdirs) {
+                float alpha;
+                linear_t(wa, net->alpha_b, W, 1, h, &alpha);
+                linear_t(wf, net->feature_b, W, W, h, h2);
+                if (feat_after) memcpy(feat_after + s * W, h2, sizeof(float) * W);
+                memcpy(h2 + W, x + ic, sizeof(float) * icv);       /* cat([feature, input_views]) :147 */
+                linear_t(wv, net->views_b, W + icv, W / 2, h2, h);
+                for (int j = 0; j < W / 2; ++j) h[j] = h[j] > 0.f ? h[j] : 0.f;
+                float rgb[3];
+                linear_t(wr, net->rgb_b, W / 2, 3, h, rgb);
+                raw[s * 4 + 0] = rgb[0]; raw[s * 4 + 1] = rgb[1]; raw[s * 4 + 2] = rgb[2]; raw[s * 4 + 3] = alpha;
+            } else {
+                linear_t(wo, net->output_b, W, net->output_ch, h, raw + s * net->output_ch);
+            }
+        }
+        free(h); free(h2);
+    }
+    for (int i = 0; i < D; ++i) free(wt[i]);
+    free(wv); free(wf); free(wa); free(wr); free(wo);
+}
+
+/* ------------------------------------------------------------------ raw2outputs
+ * networks/nerf.py:74-129 (sigma_ch = 3, rgb_ch0 = 0, n_rgb = 3) and
+ * networks/pdrf/voxnerf.py:153-201 (sigma_ch = 0, rgb_ch0 = 1, n_rgb = C-1).
+ * Density from the first S-1 samples, last alpha forced to 1 (:106,113-114); T = exclusive cumprod
+ * of (1-alpha); the "+1e-10" of the reference is a no-op in float32.
+ * rmnear_thresh <= 0 disables the eval-time near-plane mask (:107-111). */
+void evo_composite(const float* raw, const float* z, const float* rays_d, long R, int S, int C,
+                   int sigma_ch, int rgb_ch0, int n_rgb, int rgb_act, int sigma_act, int white_bkgd,
+                   float rmnear_thresh, const float* noise,
+                   float* out_map, float* density, float* acc, float* weights, float* depth,
+                   const float* feature, int F, float* fmap) {
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < R; ++r) {
+        const float* rw = raw + r * (long)S * C;
+        const float* zz = z + r * (long)S;
+        const float* d = rays_d + r * 3;
+        const float norm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        float T = 1.f, a_sum = 0.f, d_sum = 0.f;
+        float csum[32];
+        for (int c = 0; c < n_rgb && c < 32; ++c) csum[c] = 0.f;
+        float* fm = fmap ? fmap + r * F : NULL;
+        if (fm) for (int f = 0; f < F; ++f) fm[f] = 0.f;
+        for (int i = 0; i < S; ++i) {
+            float alpha;
+            if (i < S - 1) {
+                float dist = (zz[i + 1] - zz[i]) * norm;
+                float sraw = rw[(long)i * C + sigma_ch] + (noise ? noise[r * (long)(S - 1) + i] : 0.f);
+                float dens = act(sigma_act, sraw);
+                if (rmnear_thresh > 0.f) dens = (zz[i + 1] > rmnear_thresh ? 1.f : 0.f) * dens;
+                if (density) density[r * (long)(S - 1) + i] = dens;
+                alpha = -expf(-dens * dist) + 1.f;
+            } else {
+                alpha = 1.f;
+            }
+            const float w = alpha * T;
+            T = T * (-alpha + 1.f);
+            if (weights) weights[r * (long)S + i] = w;
+            a_sum += w;
+            d_sum += w * zz[i];
+            for (int c = 0; c < n_rgb && c < 32; ++c) csum[c] += w * act(rgb_act, rw[(long)i * C + rgb_ch0 + c]);
+            if (fm) {
+                const float* ff = feature + (r * (long)S + i) * F;
+                for (int f = 0; f < F; ++f) fm[f] += w * ff[f];
+            }
+        }
+        if (out_map)
+            for (int c = 0; c < n_rgb && c < 32; ++c)
+                out_map[r * n_rgb + c] = white_bkgd ? csum[c] + (1.f - a_sum) : csum[c];
+        if (acc) acc[r] = a_sum;
+        if (depth) depth[r] = d_sum;
+    }
+}
+
+/* torch.linspace (ATen RangeFactories): symmetric fill, step = (end-start)/(steps-1) */
+void evo_linspace(float start, float end, int steps, float* out) {
+    if (steps == 1) { out[0] = start; return; }
+    const float step = (end - start) / (float)(steps - 1);
+    const int half = steps / 2;
+    for (int i = 0; i < steps; ++i)
+        out[i] = (i < half) ? start + step * (float)i : end - step * (float)(steps - i - 1);
+}
+
+/* ------------------------------------------------------------------ sample_pdf
+ * utils/rays.py:149-193.  bins [R,nb], w [R,nb-1]; det => u = linspace(0,1,N), else u given.
+ * searchsorted(right=True) :176; below/above clamps :177-178; denom guard :187. */
+void evo_sample_pdf(const float* bins, const float* w, long R, int nb, int N, int det, const float* u, float* out) {
+    float* ulin = (float*)malloc(sizeof(float) * N);
+    evo_linspace(0.f, 1.f, N, ulin);
+#pragma omp parallel
+    {
+        float* cdf = (float*)malloc(sizeof(float) * nb);
+#pragma omp for schedule(static)
+        for (long r = 0; r < R; ++r) {
+            const float* wr = w + r * (long)(nb - 1);
+            const float* br = bins + r * (long)nb;
+            /* torch.sum's float summation order is backend/ISA specific; the oracle uses the correctly rounded
+             * sum (double accumulation is exact for <= 2^29 dynamic range), which any parallel order reproduces */
+            double dsum = 0.0;
+            for (int i = 0; i < nb - 1; ++i) dsum += (double)(wr[i] + 1e-5f);
+            const float sum = (float)dsum;
+            cdf[0] = 0.f;
+            /* torch.cumsum on the CPU backend accumulates float inputs in double (acc_type<float,false>) and
+             * rounds every prefix to float; the sums are exact in double, so any scan order gives these bits */
+            double c = 0.0;
+            for (int i = 0; i < nb - 1; ++i) { c += (double)((wr[i] + 1e-5f) / sum); cdf[i + 1] = (float)c; }
+            for (int j = 0; j < N; ++j) {
+                const float uu = det ? ulin[j] : u[r * (long)N + j];
+                int lo = 0, hi = nb;                 /* first index with cdf[idx] > uu */
+                while (lo < hi) { int mid = (lo + hi) >> 1; if (cdf[mid] <= uu) lo = mid + 1; else hi = mid; }
+                int below = lo - 1 > 0 ? lo - 1 : 0;
+                int above = lo < nb - 1 ? lo : nb - 1;
+                float denom = cdf[above] - cdf[below];
+                if (denom < 1e-5f) denom = 1.f;
+                float t = (uu - cdf[below]) / denom;
+                out[r * (long)N + j] = br[below] + t * (br[above] - br[below]);
+            }
+        }
+        free(cdf);
+    }
+    free(ulin);
+}
+
+/* ------------------------------------------------------------------ rays
+ * utils/rays.py:8-22 get_rays; output [H,W,3] each. */
+void evo_get_rays(int H, int W, const float* K, const float* c2w, int add_halfpix, float* rays_o, float* rays_d) {
+    const float hp = add_halfpix ? 0.5f : 0.f;
+    for (int j = 0; j < H; ++j)
+        for (int i = 0; i < W; ++i) {
+            float dir[3] = {((float)i + (hp - K[2])) / K[0], -((float)j + (hp - K[5])) / K[4], -1.f};
+            float* o = rays_o + ((long)j * W + i) * 3;
+            float* d = rays_d + ((long)j * W + i) * 3;
+            for (int r = 0; r < 3; ++r) {
+                d[r] = dir[0] * c2w[r * 4 + 0] + dir[1] * c2w[r * 4 + 1] + dir[2] * c2w[r * 4 + 2];
+                o[r] = c2w[r * 4 + 3];
+            }
+        }
+}
+
+/* utils/rays.py:25-36 get_rays_pix; coords [n,2] (x,y), c2ws [n,3,4] */
+void evo_get_rays_pix(const float* coords, const float* K, const float* c2ws, long n, int add_halfpix,
+                      float* rays_o, float* rays_d) {
+    const float hp = add_halfpix ? 0.5f : 0.f;
+    for (long p = 0; p < n; ++p) {
+        const float* c2w = c2ws + p * 12;
+        float dir[3] = {(coords[p * 2] + (hp - K[2])) / K[0], -(coords[p * 2 + 1] + (hp - K[5])) / K[4], -1.f};
+        for (int r = 0; r < 3; ++r) {
+            rays_d[p * 3 + r] = dir[0] * c2w[r * 4 + 0] + dir[1] * c2w[r * 4 + 1] + dir[2] * c2w[r * 4 + 2];
+            rays_o[p * 3 + r] = c2w[r * 4 + 3];
+        }
+    }
+}
+
+/* utils/rays.py:104-145 get_ndc_rays.  The W/(2 focal) scalars are Python doubles in the
+ * reference (K is a numpy array there), rounded to float32 when they meet the tensor. */
+void evo_ndc_rays(int H, int W, float focal, float near, const float* o, const float* d, long n, float* oo, float* od) {
+    const float cw = (float)(-1.0 / ((double)W / (2.0 * (double)focal)));
+    const float ch = (float)(-1.0 / ((double)H / (2.0 * (double)focal)));
+    const float two_near = (float)(2.0 * (double)near);
+    for (long i = 0; i < n; ++i) {
+        const float dx = d[i * 3], dy = d[i * 3 + 1], dz = d[i * 3 + 2];
+        const float t = -(near + o[i * 3 + 2]) / dz;
+        const float ox = o[i * 3] + t * dx, oy = o[i * 3 + 1] + t * dy, oz = o[i * 3 + 2] + t * dz;
+        const float ox_oz = ox / oz, oy_oz = oy / oz;
+        const float o2 = 1.f + two_near / oz;
+        oo[i * 3] = cw * ox_oz;
+        oo[i * 3 + 1] = ch * oy_oz;
+        oo[i * 3 + 2] = o2;
+        od[i * 3] = cw * (dx / dz - ox_oz);
+        od[i * 3 + 1] = ch * (dy / dz - oy_oz);
+        od[i * 3 + 2] = 1.f - o2;
+    }
+}
+
+/* NeRFAll.render, ray packing part: networks/renderer.py:423-446.  rays [R,3,2] (o|d interleaved in the
+ * last axis).  ray_batch [R, 8 or 11] = o, d, near, far, [viewdirs]; viewdirs normalised BEFORE ndc. */
+void evo_ray_batch(const evo_render_cfg* cfg, const float* rays, long R, float* ray_batch, int* ncol) {
+    const int nc = cfg->use_viewdirs ? 11 : 8;
+    if (ncol) *ncol = nc;
+    float* o = (float*)malloc(sizeof(float) * 3 * (R > 0 ? R : 1));
+    float* d = (float*)malloc(sizeof(float) * 3 * (R > 0 ? R : 1));
+    for (long i = 0; i < R; ++i)
+        for (int c = 0; c < 3; ++c) { o[i * 3 + c] = rays[i * 6 + c * 2]; d[i * 3 + c] = rays[i * 6 + c * 2 + 1]; }
+    for (long i = 0; i < R; ++i) {
+        float* rb = ray_batch + i * nc;
+        if (cfg->use_viewdirs) {
+            const float nrm = sqrtf(d[i * 3] * d[i * 3] + d[i * 3 + 1] * d[i * 3 + 1] + d[i * 3 + 2] * d[i * 3 + 2]);
+            for (int c = 0; c < 3; ++c) rb[8 + c] = d[i * 3 + c] / nrm;
+        }
+        rb[6] = cfg->near; rb[7] = cfg->far;
+    }
+    if (cfg->ndc) {
+        float* o2 = (float*)malloc(sizeof(float) * 3 * (R > 0 ? R : 1));
+        float* d2 = (float*)malloc(sizeof(float) * 3 * (R > 0 ? R : 1));
+        evo_ndc_rays(cfg->H, cfg->W, cfg->focal, 1.f, o, d, R, o2, d2);
+        free(o); free(d); o = o2; d = d2;
+    }
+    for (long i = 0; i < R; ++i)
+        for (int c = 0; c < 3; ++c) { ray_batch[i * nc + c] = o[i * 3 + c]; ray_batch[i * nc + 3 + c] = d[i * 3 + c]; }
+    free(o); free(d);
+}
+
+/* z stratification: networks/renderer.py:163-178 */
+static void make_z(const evo_render_cfg* cfg, const float* ray_batch, int nc, long R, const float* t_rand, float* z) {
+    const int S = cfg->N_samples;
+    float* tv = (float*)malloc(sizeof(float) * S);
+    evo_linspace(0.f, 1.f, S, tv);
+    for (long r = 0; r < R; ++r) {
+        const float near = ray_batch[r * nc + 6], far = ray_batch[r * nc + 7];
+        float* zr = z + r * (long)S;
+        for (int i = 0; i < S; ++i)
+            zr[i] = cfg->lindisp ? 1.f / (1.f / near * (1.f - tv[i]) + 1.f / far * tv[i])
+                                 : near * (1.f - tv[i]) + far * tv[i];
+        if (cfg->perturb > 0.f) {
+            float* tmp = (float*)malloc(sizeof(float) * S);
+            for (int i = 0; i < S; ++i) {
+                float upper = (i < S - 1) ? .5f * (zr[i + 1] + zr[i]) : zr[S - 1];
+                float lower = (i > 0) ? .5f * (zr[i] + zr[i - 1]) : zr[0];
+                tmp[i] = lower + (upper - lower) * t_rand[r * (long)S + i];
+            }
+            memcpy(zr, tmp, sizeof(float) * S);
+            free(tmp);
+        }
+    }
+    free(tv);
+}
+
+static int cmp_float(const void* a, const void* b) {
+    float x = *(const float*)a, y = *(const float*)b;
+    return (x > y) - (x < y);
+}
+
+/* one backbone pass of mode='nerf': NeRF.forward, networks/nerf.py:164-175 (+ mlpforward :46-72) */
+static void nerf_pass(const evo_nerf* net, const evo_render_cfg* cfg, const float* ray_batch, int nc, long R, int S,
+                      const float* z, float* rgb, float* depth, float* acc, float* weights, float* raw_out, float* feat_out) {
+    const int L = cfg->multires, Lv = cfg->multires_views;
+    const int ic = 3 * (1 + 2 * L), icv = cfg->use_viewdirs ? 3 * (1 + 2 * Lv) : 0;
+    const long n = R * S;
+    float* pts = (float*)malloc(sizeof(float) * 3 * (n > 0 ? n : 1));
+    float* emb = (float*)malloc(sizeof(float) * (size_t)(ic + icv) * (n > 0 ? n : 1));
+    float* raw = raw_out ? raw_out : (float*)malloc(sizeof(float) * 4 * (n > 0 ? n : 1));
+    float* rd = (float*)malloc(sizeof(float) * 3 * (R > 0 ? R : 1));
+    for (long r = 0; r < R; ++r) {
+        const float* rb = ray_batch + r * nc;
+        for (int c = 0; c < 3; ++c) rd[r * 3 + c] = rb[3 + c];
+        for (int i = 0; i < S; ++i)
+            for (int c = 0; c < 3; ++c) pts[(r * S + i) * 3 + c] = rb[c] + rb[3 + c] * z[r * (long)S + i];  /* renderer.py:180 */
+    }
+    {
+        float* pe = (float*)malloc(sizeof(float) * (size_t)ic * (n > 0 ? n : 1));
+        evo_embed(pts, n, 3, L, pe);
+        float* pev = NULL;
+        if (icv) {
+            float* vd = (float*)malloc(sizeof(float) * 3 * (R > 0 ? R : 1));
+            for (long r = 0; r < R; ++r) for (int c = 0; c < 3; ++c) vd[r * 3 + c] = ray_batch[r * nc + 8 + c];
+            pev = (float*)malloc(sizeof(float) * (size_t)icv * (R > 0 ? R : 1));
+            evo_embed(vd, R, 3, Lv, pev);
+            free(vd);
+        }
+        for (long s = 0; s < n; ++s) {
+            memcpy(emb + s * (ic + icv), pe + s * ic, sizeof(float) * ic);
+            if (icv) memcpy(emb + s * (ic + icv) + ic, pev + (s / S) * icv, sizeof(float) * icv);
+        }
+        free(pe); free(pev);
+    }
+    evo_nerf_mlp(net, emb, n, raw, feat_out, NULL);
+    const float thr = (!cfg->is_train && net->rmnear > 0.f) ? (float)((double)net->rmnear / 128.0) : 0.f;
+    evo_composite(raw, z, rd, R, S, 4, 3, 0, 3, net->rgb_act, net->sigma_act, cfg->white_bkgd, thr, NULL,
+                  rgb, NULL, acc, weights, depth, NULL, 0, NULL);
+    free(pts); free(emb); free(rd);
+    if (!raw_out) free(raw);
+}
+
+static void zstd(const float* zs, long R, int N, float* out) {
+    for (long r = 0; r < R; ++r) {
+        double m = 0; for (int j = 0; j < N; ++j) m += zs[r * (long)N + j]; m /= N;
+        double v = 0; for (int j = 0; j < N; ++j) { double dd = zs[r * (long)N + j] - m; v += dd * dd; }
+        out[r] = (float)sqrt(v / N);
+    }
+}
+
+/* NeRFAll.render + render_rays for mode='nerf': networks/renderer.py:399-466, 129-264 (else-branch :218-240). */
+void evo_render_nerf(const evo_nerf* coarse, const evo_nerf* fine, const evo_render_cfg* cfg,
+                     const float* rays, long R, const float* t_rand, const float* u, evo_render_out* out) {
+    const int S = cfg->N_samples, Ni = cfg->N_importance, St = S + Ni;
+    const long Rn = R > 0 ? R : 1;
+    int nc;
+    float* rb = (float*)malloc(sizeof(float) * 11 * Rn);
+    evo_ray_batch(cfg, rays, R, rb, &nc);
+    float* z = (float*)malloc(sizeof(float) * Rn * St);
+    float* w0 = (float*)malloc(sizeof(float) * Rn * S);
+    make_z(cfg, rb, nc, R, t_rand, z);
+    if (Ni <= 0) {
+        nerf_pass(coarse, cfg, rb, nc, R, S, z, out->rgb, out->depth, out->acc, w0, out->raw, out->feature);
+        if (out->z_vals) memcpy(out->z_vals, z, sizeof(float) * R * S);
+        if (out->weights) memcpy(out->weights, w0, sizeof(float) * R * S);
+    } else {
+        nerf_pass(coarse, cfg, rb, nc, R, S, z, out->rgb0, out->depth0, out->acc0, w0, NULL, NULL);
+        if (out->z_vals0) memcpy(out->z_vals0, z, sizeof(float) * R * S);
+        if (out->weights0) memcpy(out->weights0, w0, sizeof(float) * R * S);
+        float* zmid = (float*)malloc(sizeof(float) * Rn * (S - 1));
+        float* wmid = (float*)malloc(sizeof(float) * Rn * (S - 2));
+        float* zs = (float*)malloc(sizeof(float) * Rn * Ni);
+        for (long r = 0; r < R; ++r) {
+            for (int i = 0; i < S - 1; ++i) zmid[r * (long)(S - 1) + i] = .5f * (z[r * (long)S + i + 1] + z[r * (long)S + i]);
+            for (int i = 0; i < S - 2; ++i) wmid[r * (long)(S - 2) + i] = w0[r * (long)S + i + 1];   /* weights[...,1:-1] */
+        }
+        evo_sample_pdf(zmid, wmid, R, S - 1, Ni, cfg->perturb == 0.f, u, zs);
+        if (out->z_std) zstd(zs, R, Ni, out->z_std);
+        float* z2 = (float*)malloc(sizeof(float) * Rn * St);
+        for (long r = 0; r < R; ++r) {
+            memcpy(z2 + r * (long)St, z + r * (long)S, sizeof(float) * S);
+            memcpy(z2 + r * (long)St + S, zs + r * (long)Ni, sizeof(float) * Ni);
+            qsort(z2 + r * (long)St, St, sizeof(float), cmp_float);                              /* renderer.py:234 */
+        }
+        float* w1 = (float*)malloc(sizeof(float) * Rn * St);
+        nerf_pass(fine, cfg, rb, nc, R, St, z2, out->rgb, out->depth, out->acc, w1, out->raw, out->feature);
+        if (out->z_vals) memcpy(out->z_vals, z2, sizeof(float) * R * St);
+        if (out->weights) memcpy(out->weights, w1, sizeof(float) * R * St);
+        free(zmid); free(wmid); free(zs); free(z2); free(w1);
+    }
+    free(rb); free(z); free(w0);
+}
+
+/* ------------------------------------------------------------------ PDRF tri-plane features
+ * networks/pdrf/voxnerf.py:203-208 sample() + :132-151 compute_appfeature().
+ * F.grid_sample(bilinear, zeros padding, align_corners=True); interpolation weights follow the
+ * ATen CPU kernel (w = x - floor(x), e = 1 - w).  plane i: [C_i, grid[m1], grid[m0]] sampled at
+ * (x = xyz[m0], y = xyz[m1]), matMode [[0,1],[0,2],[1,2]]; line i: [C_i, grid[vec]] at xyz[vec],
+ * vecMode [2,1,0] (its width-1 axis sits at x = 0 where the east tap has weight 0). */
+static inline float unnorm(float c, int size) { return ((c + 1.f) / 2.f) * (float)(size - 1); }
+
+void evo_appfeature(const evo_voxel* v, const float* pts, long n, float* out) {
+    static const int mat[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+    static const int vec[3] = {2, 1, 0};
+    const int nc_tot = v->n_comp[0] + v->n_comp[1] + v->n_comp[2];
+    float* bt = transpose_w(v->basis, v->app_dim, nc_tot);
+#pragma omp parallel
+    {
+        float* coef = (float*)malloc(sizeof(float) * nc_tot);
+#pragma omp for schedule(static)
+        for (long p = 0; p < n; ++p) {
+            float xyz[3];
+            for (int c = 0; c < 3; ++c) {
+                const float inv = 2.0f / (v->aabb[3 + c] - v->aabb[c]);          /* invaabbSize :91 */
+                xyz[c] = (pts[p * 3 + c] - v->aabb[c]) * inv - 1.f;             /* :205 */
+            }
+            int off = 0;
+            for (int i = 0; i < 3; ++i) {
+                const int Wp = v->grid[mat[i][0]], Hp = v->grid[mat[i][1]], Lp = v->grid[vec[i]];
+                const float ix = unnorm(xyz[mat[i][0]], Wp), iy = unnorm(xyz[mat[i][1]], Hp);
+                const float fx = floorf(ix), fy = floorf(iy);
+                const float ww = ix - fx, ee = 1.f - ww, nn = iy - fy, ss = 1.f - nn;
+                const long x0 = (long)fx, y0 = (long)fy, x1 = x0 + 1, y1 = y0 + 1;
+                const int vx0 = x0 >= 0 && x0 < Wp, vx1 = x1 >= 0 && x1 < Wp, vy0 = y0 >= 0 && y0 < Hp, vy1 = y1 >= 0 && y1 < Hp;
+                const float il = unnorm(xyz[vec[i]], Lp);
+                const float fl = floorf(il);
+                const float ln = il - fl, ls = 1.f - ln;
+                const long l0 = (long)fl, l1 = l0 + 1;
+                const int vl0 = l0 >= 0 && l0 < Lp, vl1 = l1 >= 0 && l1 < Lp;
+                for (int c = 0; c < v->n_comp[i]; ++c) {
+                    const float* pl = v->plane[i] + (long)c * Hp * Wp;
+                    float pv = 0.f;
+                    if (vy0 && vx0) pv += pl[y0 * Wp + x0] * (ee * ss);
+                    if (vy0 && vx1) pv += pl[y0 * Wp + x1] * (ww * ss);
+                    if (vy1 && vx0) pv += pl[y1 * Wp + x0] * (ee * nn);
+                    if (vy1 && vx1) pv += pl[y1 * Wp + x1] * (ww * nn);
+                    const float* li = v->line[i] + (long)c * Lp;
+                    float lv = 0.f;
+                    if (vl0) lv += li[l0] * ls;      /* x = 0: west weight e = 1, east w = 0 */
+                    if (vl1) lv += li[l1] * ln;
+                    coef[off + c] = pv * lv;
+                }
+                off += v->n_comp[i];
+            }
+            float* o = out + p * v->app_dim;
+            linear_t(bt, NULL, nc_tot, v->app_dim, coef, o);                    /* basis_mat :151 */
+            for (int j = 0; j < v->app_dim; ++j) o[j] = act(v->app_act, o[j]);
+        }
+        free(coef);
+    }
+    free(bt);
+}
+
+/* VoxelNeRFBase.forward: networks/pdrf/voxnerf.py:210-259.  fts [R,S,F]; feature out [R,S,geo]. */
+void evo_voxel_forward(const evo_voxel* v, const float* pts, const float* viewdirs, const float* fts, int F,
+                       const float* z, const float* rays_d, long R, int S, int multires, int multires_views,
+                       int is_train, float* color, float* depth, float* acc, float* weights, float* feature) {
+    const int ic = 3 * (1 + 2 * multires), icv = 3 * (1 + 2 * multires_views);
+    const long n = R * S, nn1 = n > 0 ? n : 1, Rn = R > 0 ? R : 1;
+    const int G = v->geo_feat_dim, HD = v->hidden_dim;
+    float* sw[EVO_MAX_LAYERS]; int sin_[EVO_MAX_LAYERS], sout[EVO_MAX_LAYERS];
+    for (int l = 0; l < v->num_layers; ++l) {
+        sin_[l] = l == 0 ? v->input_ch : HD;
+        sout[l] = l == v->num_layers - 1 ? 1 + G : HD;
+        sw[l] = transpose_w(v->sigma_w[l], sout[l], sin_[l]);
+    }
+    float* cw[EVO_MAX_LAYERS]; int cin[EVO_MAX_LAYERS], cout[EVO_MAX_LAYERS];
+    for (int l = 0; l < v->num_layers_color; ++l) {
+        cin[l] = l == 0 ? v->input_ch_views + G : HD;      /* hidden_dim, not hidden_dim_color: voxnerf.py:73,78 */
+        cout[l] = l == v->num_layers_color - 1 ? 3 : HD;
+        cw[l] = transpose_w(v->color_w[l], cout[l], cin[l]);
+    }
+    float* pe = (float*)malloc(sizeof(float) * (size_t)ic * nn1);
+    float* pev = (float*)malloc(sizeof(float) * (size_t)icv * Rn);
+    evo_embed(pts, n, 3, multires, pe);
+    evo_embed(viewdirs, R, 3, multires_views, pev);
+    float* hbuf = (float*)malloc(sizeof(float) * (size_t)(1 + G) * nn1);
+    const int wide = (v->input_ch > HD ? v->input_ch : HD) + G + icv + 8;
+#pragma omp parallel
+    {
+        float* a = (float*)malloc(sizeof(float) * wide);
+        float* b = (float*)malloc(sizeof(float) * wide);
+#pragma omp for schedule(static)
+        for (long s = 0; s < n; ++s) {
+            memcpy(a, fts + s * F, sizeof(float) * F);                           /* cat([fts, PE(pts)]) :214 */
+            memcpy(a + F, pe + s * ic, sizeof(float) * ic);
+            for (int l = 0; l < v->num_layers; ++l) {
+                linear_t(sw[l], NULL, sin_[l], sout[l], a, b);
+                if (l != v->num_layers - 1) for (int j = 0; j < sout[l]; ++j) b[j] = b[j] > 0.f ? b[j] : 0.f;
+                float* t = a; a = b; b = t;
+            }
+            memcpy(hbuf + s * (1 + G), a, sizeof(float) * (1 + G));
+            if (feature) memcpy(feature + s * G, a + 1, sizeof(float) * G);      /* feature_map = h[...,1:] :221 */
+        }
+        free(a); free(b);
+    }
+    const float thr = (!is_train && v->rmnear > 0.f) ? (float)((double)v->rmnear / 128.0) : 0.f;
+    if (v->composite_feature) {
+        /* composite the (1+G)-channel h first (:223-229), then colour net per ray (:231-239) */
+        float* fm = (float*)malloc(sizeof(float) * (size_t)G * Rn);
+        evo_composite(hbuf, z, rays_d, R, S, 1 + G, 0, 1, G, v->rgb_act, v->sigma_act, 0, thr, NULL,
+                      fm, NULL, acc, weights, depth, NULL, 0, NULL);
+#pragma omp parallel
+        {
+            float* a = (float*)malloc(sizeof(float) * wide);
+            float* b = (float*)malloc(sizeof(float) * wide);
+#pragma omp for schedule(static)
+            for (long r = 0; r < R; ++r) {
+                memcpy(a, fm + r * G, sizeof(float) * G);
+                memcpy(a + G, pev + r * icv, sizeof(float) * icv);
+                for (int l = 0; l < v->num_layers_color; ++l) {
+                    linear_t(cw[l], v->color_b[l], cin[l], cout[l], a, b);
+                    if (l != v->num_layers_color - 1) for (int j = 0; j < cout[l]; ++j) b[j] = b[j] > 0.f ? b[j] : 0.f;
+                    float* t = a; a = b; b = t;
+                }
+                for (int c = 0; c < 3; ++c) color[r * 3 + c] = 1.f / (1.f + expf(-a[c]));
+            }
+            free(a); free(b);
+        }
+        free(fm);
+    } else {
+        /* per-sample colour then composite (:240-257); raw = cat([sigma, sigmoid(colour)]) */
+        float* raw = (float*)malloc(sizeof(float) * 4 * nn1);
+#pragma omp parallel
+        {
+            float* a = (float*)malloc(sizeof(float) * wide);
+            float* b = (float*)malloc(sizeof(float) * wide);
+#pragma omp for schedule(static)
+            for (long s = 0; s < n; ++s) {
+                const float* h = hbuf + s * (1 + G);
+                memcpy(a, h + 1, sizeof(float) * G);
+                memcpy(a + G, pev + (s / S) * icv, sizeof(float) * icv);
+                for (int l = 0; l < v->num_layers_color; ++l) {
+                    linear_t(cw[l], v->color_b[l], cin[l], cout[l], a, b);
+                    if (l != v->num_layers_color - 1) for (int j = 0; j < cout[l]; ++j) b[j] = b[j] > 0.f ? b[j] : 0.f;
+                    float* t = a; a = b; b = t;
+                }
+                raw[s * 4] = h[0];
+                for (int c = 0; c < 3; ++c) raw[s * 4 + 1 + c] = 1.f / (1.f + expf(-a[c]));
+            }
+            free(a); free(b);
+        }
+        evo_composite(raw, z, rays_d, R, S, 4, 0, 1, 3, v->rgb_act, v->sigma_act, 0, thr, NULL,
+                      color, NULL, acc, weights, depth, NULL, 0, NULL);
+        free(raw);
+    }
+    for (int l = 0; l < v->num_layers; ++l) free(sw[l]);
+    for (int l = 0; l < v->num_layers_color; ++l) free(cw[l]);
+    free(pe); free(pev); free(hbuf);
+}
+
+typedef struct { float z; int idx; } zi_t;
+static int cmp_zi(const void* a, const void* b) {
+    const zi_t *x = (const zi_t*)a, *y = (const zi_t*)b;
+    if (x->z < y->z) return -1;
+    if (x->z > y->z) return 1;
+    return (x->idx > y->idx) - (x->idx < y->idx);
+}
+
+/* NeRFAll.render + render_rays for mode='c2f': networks/renderer.py:182-217.  Features of the merged
+ * sample set are gathered by the sort order, not re-sampled (:205-213). */
+void evo_render_c2f(const evo_voxel* coarse, const evo_voxel* fine, const evo_render_cfg* cfg,
+                    const float* rays, long R, const float* t_rand, const float* u, evo_render_out* out) {
+    const int S = cfg->N_samples, Ni = cfg->N_importance, St = S + Ni;
+    const long Rn = R > 0 ? R : 1;
+    const int Fc = coarse->app_dim, Ff = fine ? fine->app_dim : 0;
+    int nc;
+    float* rb = (float*)malloc(sizeof(float) * 11 * Rn);
+    evo_ray_batch(cfg, rays, R, rb, &nc);
+    float* z = (float*)malloc(sizeof(float) * Rn * S);
+    make_z(cfg, rb, nc, R, t_rand, z);
+    float* rd = (float*)malloc(sizeof(float) * 3 * Rn);
+    float* vd = (float*)malloc(sizeof(float) * 3 * Rn);
+    float* pts = (float*)malloc(sizeof(float) * 3 * Rn * S);
+    for (long r = 0; r < R; ++r) {
+        for (int c = 0; c < 3; ++c) { rd[r * 3 + c] = rb[r * nc + 3 + c]; vd[r * 3 + c] = rb[r * nc + 8 + c]; }
+        for (int i = 0; i < S; ++i)
+            for (int c = 0; c < 3; ++c) pts[(r * S + i) * 3 + c] = rb[r * nc + c] + rd[r * 3 + c] * z[r * (long)S + i];
+    }
+    float* ftc = (float*)malloc(sizeof(float) * (size_t)Fc * Rn * S);
+    evo_appfeature(coarse, pts, R * S, ftc);
+    float* w0 = (float*)malloc(sizeof(float) * Rn * S);
+    if (Ni <= 0) {
+        evo_voxel_forward(coarse, pts, vd, ftc, Fc, z, rd, R, S, cfg->multires, cfg->multires_views, cfg->is_train,
+                          out->rgb, out->depth, out->acc, w0, out->feature);
+        if (out->z_vals) memcpy(out->z_vals, z, sizeof(float) * R * S);
+        if (out->weights) memcpy(out->weights, w0, sizeof(float) * R * S);
+    } else {
+        evo_voxel_forward(coarse, pts, vd, ftc, Fc, z, rd, R, S, cfg->multires, cfg->multires_views, cfg->is_train,
+                          out->rgb0, out->depth0, out->acc0, w0, NULL);
+        if (out->z_vals0) memcpy(out->z_vals0, z, sizeof(float) * R * S);
+        if (out->weights0) memcpy(out->weights0, w0, sizeof(float) * R * S);
+        const int Fm = Fc + Ff;
+        float* ftf = (float*)malloc(sizeof(float) * (size_t)Ff * Rn * S);
+        evo_appfeature(fine, pts, R * S, ftf);
+        float* zmid = (float*)malloc(sizeof(float) * Rn * (S - 1));
+        float* wmid = (float*)malloc(sizeof(float) * Rn * (S - 2));
+        float* zs = (float*)malloc(sizeof(float) * Rn * Ni);
+        for (long r = 0; r < R; ++r) {
+            for (int i = 0; i < S - 1; ++i) zmid[r * (long)(S - 1) + i] = .5f * (z[r * (long)S + i + 1] + z[r * (long)S + i]);
+            for (int i = 0; i < S - 2; ++i) wmid[r * (long)(S - 2) + i] = w0[r * (long)S + i + 1];
+        }
+        evo_sample_pdf(zmid, wmid, R, S - 1, Ni, cfg->perturb == 0.f, u, zs);
+        if (out->z_std) zstd(zs, R, Ni, out->z_std);
+        float* pts1 = (float*)malloc(sizeof(float) * 3 * Rn * Ni);
+        for (long r = 0; r < R; ++r)
+            for (int i = 0; i < Ni; ++i)
+                for (int c = 0; c < 3; ++c) pts1[(r * Ni + i) * 3 + c] = rb[r * nc + c] + rd[r * 3 + c] * zs[r * (long)Ni + i];
+        float* ftc1 = (float*)malloc(sizeof(float) * (size_t)Fc * Rn * Ni);
+        float* ftf1 = (float*)malloc(sizeof(float) * (size_t)Ff * Rn * Ni);
+        evo_appfeature(coarse, pts1, R * Ni, ftc1);
+        evo_appfeature(fine, pts1, R * Ni, ftf1);
+        float* z2 = (float*)malloc(sizeof(float) * Rn * St);
+        float* pts2 = (float*)malloc(sizeof(float) * 3 * Rn * St);
+        float* ft2 = (float*)malloc(sizeof(float) * (size_t)Fm * Rn * St);
+        zi_t* zi = (zi_t*)malloc(sizeof(zi_t) * St);
+        for (long r = 0; r < R; ++r) {
+            for (int i = 0; i < S; ++i) { zi[i].z = z[r * (long)S + i]; zi[i].idx = i; }
+            for (int i = 0; i < Ni; ++i) { zi[S + i].z = zs[r * (long)Ni + i]; zi[S + i].idx = S + i; }
+            qsort(zi, St, sizeof(zi_t), cmp_zi);
+            for (int k = 0; k < St; ++k) {
+                const int id = zi[k].idx;
+                z2[r * (long)St + k] = zi[k].z;
+                float* fo = ft2 + (r * (long)St + k) * Fm;
+                if (id < S) {
+                    memcpy(pts2 + (r * (long)St + k) * 3, pts + (r * (long)S + id) * 3, sizeof(float) * 3);
+                    memcpy(fo, ftc + (r * (long)S + id) * Fc, sizeof(float) * Fc);
+                    memcpy(fo + Fc, ftf + (r * (long)S + id) * Ff, sizeof(float) * Ff);
+                } else {
+                    memcpy(pts2 + (r * (long)St + k) * 3, pts1 + (r * (long)Ni + id - S) * 3, sizeof(float) * 3);
+                    memcpy(fo, ftc1 + (r * (long)Ni + id - S) * Fc, sizeof(float) * Fc);
+                    memcpy(fo + Fc, ftf1 + (r * (long)Ni + id - S) * Ff, sizeof(float) * Ff);
+                }
+            }
+        }
+        float* w1 = (float*)malloc(sizeof(float) * Rn * St);
+        evo_voxel_forward(fine, pts2, vd, ft2, Fm, z2, rd, R, St, cfg->multires, cfg->multires_views, cfg->is_train,
+                          out->rgb, out->depth, out->acc, w1, out->feature);
+        if (out->z_vals) memcpy(out->z_vals, z2, sizeof(float) * R * St);
+        if (out->weights) memcpy(out->weights, w1, sizeof(float) * R * St);
+        free(ftf); free(zmid); free(wmid); free(zs); free(pts1); free(ftc1); free(ftf1);
+        free(z2); free(pts2); free(ft2); free(zi); free(w1);
+    }
+    free(rb); free(z); free(rd); free(vd); free(pts); free(ftc); free(w0);
+}
+
+/* ------------------------------------------------------------------ loss-side pixel ops
+ * RigidBlurringModel.rbk_weighted_sum, networks/dpnerf/blurmodel.py:112-127: out[r] = sum_p ccw[r,p] x[r*P+p] */
+void evo_weighted_sum(const float* x, const float* ccw, long R, int P, int C, float* out) {
+    for (long r = 0; r < R; ++r)
+        for (int c = 0; c < C; ++c) {
+            float s = 0.f;
+            for (int p = 0; p < P; ++p) s += x[(r * P + p) * (long)C + c] * ccw[r * P + p];
+            out[r * C + c] = s;
+        }
+}
+
+/* CRF.forward, networks/tonemapping.py:59-93.  x [n,3]; feat NULL, [n,E] (feat_per_channel=0, repeated for
+ * the 3 channels :75-76) or [n,3,E] (feat_per_channel=1).  Missing features are zero padded (:82-85). */
+void evo_crf_forward(const evo_crf* crf, const float* x, const float* feat, int feat_per_channel,
+                     int skip_learn, long n, float* out) {
+    const int E = crf->extra_features;
+    for (long i = 0; i < n * 3; ++i) {
+        float v = x[i];
+        if (crf->map_type == 0) { out[i] = v; continue; }                        /* 'none' :64-65 */
+        if (crf->map_type == 1) v = powf(v, (float)(1.0 / (double)crf->gamma));   /* 'gamma' in map_type :67-68 */
+        if (!skip_learn && crf->map_type == 2) {
+            float in[1 + 16], h[16], h2[16];
+            in[0] = v;
+            for (int e = 0; e < E; ++e)
+                in[1 + e] = feat ? (feat_per_channel ? feat[i * E + e] : feat[(i / 3) * E + e]) : 0.f;
+            for (int j = 0; j < 16; ++j) {
+                float s = crf->b[0][j];
+                for (int k = 0; k < 1 + E; ++k) s += crf->w[0][j * (1 + E) + k] * in[k];
+                h[j] = s > 0.f ? s : 0.f;
+            }
+            for (int l = 1; l <= 2; ++l) {
+                for (int j = 0; j < 16; ++j) {
+                    float s = crf->b[l][j];
+                    for (int k = 0; k < 16; ++k) s += crf->w[l][j * 16 + k] * h[k];
+                    h2[j] = s > 0.f ? s : 0.f;
+                }
+                memcpy(h, h2, sizeof(h));
+            }
+            float s = crf->b[3][0];
+            for (int k = 0; k < 16; ++k) s += crf->w[3][k] * h[k];
+            v = 1.f / (1.f + expf(-(s * 0.1f + v)));                              /* sigmoid(0.1 mlp + x) :87-88 */
+        }
+        out[i] = v;
+    }
+}
+
+/* TonemappingTransform.encode_luma tail, networks/tonemapping.py:127-136; standard 0 rec601, 1 rec709, 2 avg */
+void evo_luma(const float* x, long n, int standard, float* out) {
+    for (long i = 0; i < n; ++i) {
+        const float r = x[i * 3], g = x[i * 3 + 1], b = x[i * 3 + 2];
+        if (standard == 0) out[i] = 0.299f * r + 0.587f * g + 0.114f * b;
+        else if (standard == 1) out[i] = 0.2126f * r + 0.7152f * g + 0.0722f * b;
+        else out[i] = (r + g + b) / 3.f;
+    }
+}
+
+/* img2mse, utils/metrics.py:7 */
+double evo_mse(const float* a, const float* b, long n) {
+    double s = 0;
+    for (long i = 0; i < n; ++i) { double d = (double)(a[i] - b[i]); s += d * d; }
+    return n > 0 ? s / (double)n : NAN;
+}
+
+/* egm_loss, utils/events.py:260-284.  luma [n,C]; C = 1 (no mask) or 3 with one-hot color_mask [n,3]. */
+double evo_egm_loss(const float* luma_start, const float* luma_end, const float* bii, long n, int C,
+                    const unsigned char* color_mask, const float* color_weight) {
+    double num = 0, den = 0;
+    for (long i = 0; i < n; ++i) {
+        int ch = 0;
+        if (color_mask) for (int c = 0; c < 3; ++c) if (color_mask[i * 3 + c]) ch = c;
+        const float pred = logf(luma_end[i * C + ch] + 1e-5f) - logf(luma_start[i * C + ch] + 1e-5f);
+        const float w = (color_mask && color_weight) ? color_weight[ch] : 1.f;
+        const float d = pred - bii[i];
+        num += (double)(d * d * w);
+        den += (double)w;
+    }
+    return num / den;
+}
+
+/* ------------------------------------------------------------------ EDI (utils/edi.py)
+ * interpolate_subpixel :7-41 + brightness_increment_image :44-70 (grey events only). */
+static void splat(const float* x, const float* y, const signed char* p, long n, int want_pos, int w, int h,
+                  int interpolate, float* img) {
+    for (long i = 0; i < n; ++i) {
+        if ((p[i] > 0) != want_pos) continue;
+        if (!interpolate) { img[(long)y[i] * w + (long)x[i]] += 1.f; continue; }
+        for (int xr = 0; xr < 2; ++xr)
+            for (int yr = 0; yr < 2; ++yr) {
+                const float xf = xr ? ceilf(x[i]) : floorf(x[i]);
+                const float yf = yr ? ceilf(y[i]) : floorf(y[i]);
+                if (!((xf != x[i] || xr == 0) && (yf != y[i] || yr == 0) && xf < (float)w && yf < (float)h)) continue;
+                const float kx = fmaxf(0.f, 1.f - fabsf(xf - x[i])), ky = fmaxf(0.f, 1.f - fabsf(yf - y[i]));
+                img[(long)yf * w + (long)xf] += 1.f * kx * ky;
+            }
+    }
+}
+
+void evo_bii_image(const float* x, const float* y, const signed char* p, long n, int w, int h,
+                   float c_pos, float c_neg, int interpolate, float* image) {
+    float* ip = (float*)calloc((size_t)w * h, sizeof(float));
+    float* in = (float*)calloc((size_t)w * h, sizeof(float));
+    /* the reference accumulates the 4 taps as 4 passes over all events (product(floor/ceil)): keep that order */
+    if (interpolate) {
+        for (int pass = 0; pass < 4; ++pass) {
+            const int xr = pass >> 1, yr = pass & 1;
+            for (long i = 0; i < n; ++i) {
+                const float xf = xr ? ceilf(x[i]) : floorf(x[i]);
+                const float yf = yr ? ceilf(y[i]) : floorf(y[i]);
+                if (!((xf != x[i] || xr == 0) && (yf != y[i] || yr == 0) && xf < (float)w && yf < (float)h)) continue;
+                const float kx = fmaxf(0.f, 1.f - fabsf(xf - x[i])), ky = fmaxf(0.f, 1.f - fabsf(yf - y[i]));
+                float* img = p[i] > 0 ? ip : in;
+                img[(long)yf * w + (long)xf] += 1.f * kx * ky;
+            }
+        }
+    } else {
+        splat(x, y, p, n, 1, w, h, 0, ip);
+        splat(x, y, p, n, 0, w, h, 0, in);
+    }
+    for (long i = 0; i < (long)w * h; ++i) image[i] = ip[i] * c_pos - in[i] * c_neg;   /* :69 */
+    free(ip); free(in);
+}
+
+/* inner_double_integral, utils/edi.py:73-88.  bii [steps-1, npix] -> images [steps, npix], N = (steps-1)/2 */
+void evo_inner_double_integral(const float* bii, int steps, long npix, float* images) {
+    const int N = (steps - 1) / 2;
+    for (long px = 0; px < npix; ++px) {
+        for (int i = 0; i < N; ++i) {
+            float s = 0.f;
+            for (int j = i; j < N; ++j) s += bii[(long)j * npix + px];
+            images[(long)i * npix + px] = -s;
+        }
+        images[(long)N * npix + px] = 0.f;
+        for (int i = 0; i < N; ++i) {
+            float s = 0.f;
+            for (int j = N; j < N + 1 + i; ++j) s += bii[(long)j * npix + px];
+            images[(long)(N + 1 + i) * npix + px] = s;
+        }
+    }
+}
+
+/* deblur_double_integral, utils/edi.py:91-95: sharp = (2N+1) blurry / sum_k exp(E_k) */
+void evo_deblur_double_integral(const float* blurry, const float* bii, int steps, long npix, float* sharp) {
+    float* im = (float*)malloc(sizeof(float) * (size_t)steps * npix);
+    evo_inner_double_integral(bii, steps, npix, im);
+    const int N = (steps - 1) / 2;
+    for (long px = 0; px < npix; ++px) {
+        float s = 0.f;
+        for (int k = 0; k < steps; ++k) s += expf(im[(long)k * npix + px]);
+        sharp[px] = (float)(2 * N + 1) * blurry[px] / s;
+    }
+    free(im);
+}
+
+/* TVLoss.forward, networks/pdrf/voxnerf.py:306-324 for x [1,C,H,W] */
+double evo_tv_loss(const float* x, int C, int H, int W) {
+    double h_tv = 0, w_tv = 0;
+    for (int c = 0; c < C; ++c)
+        for (int i = 0; i < H; ++i)
+            for (int j = 0; j < W; ++j) {
+                const float v = x[((long)c * H + i) * W + j];
+                if (i + 1 < H) { float d = x[((long)c * H + i + 1) * W + j] - v; h_tv += (double)(d * d); }
+                if (j + 1 < W) { float d = x[((long)c * H + i) * W + j + 1] - v; w_tv += (double)(d * d); }
+            }
+    double count_h = (double)C * (H - 1) * W;
+    double count_w = (double)C * H * (W - 1);
+    if (count_w < 1) count_w = 1;
+    return 2.0 * (h_tv / count_h + w_tv / count_w);
+}

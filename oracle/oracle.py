@@ -1,0 +1,374 @@
+"""ctypes front-end of the CPU oracle (oracle/evd_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: import from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg, never from the evdeblurnerf_amd package. numpy in,
+numpy out; every function is a thin call into the C restatement, whose
+comments cite the reference file:line it follows.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "build", "libevd_oracle.so")
+MAXL = 16
+
+ACT = {"none": 0, "relu": 1, "sigmoid": 2, "exp": 3, "sigmoid1": 4, "softplus": 5, "tanh": 6}
+_fp = C.POINTER(C.c_float)
+
+
+def build(force: bool = False) -> str:
+    src = [os.path.join(_HERE, f) for f in ("evd_oracle.c", "evd_oracle.h", "Makefile")]
+    stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src)
+    if force or stale:
+        subprocess.run(["make", "-C", _HERE] + (["-B"] if force else []), check=True, capture_output=True)
+    return _SO
+
+
+class NerfStruct(C.Structure):
+    _fields_ = [("D", C.c_int), ("W", C.c_int), ("input_ch", C.c_int), ("input_ch_views", C.c_int),
+                ("skip", C.c_int), ("use_viewdirs", C.c_int), ("output_ch", C.c_int),
+                ("pts_w", _fp * MAXL), ("pts_b", _fp * MAXL),
+                ("views_w", _fp), ("views_b", _fp), ("feature_w", _fp), ("feature_b", _fp),
+                ("alpha_w", _fp), ("alpha_b", _fp), ("rgb_w", _fp), ("rgb_b", _fp),
+                ("output_w", _fp), ("output_b", _fp),
+                ("rgb_act", C.c_int), ("sigma_act", C.c_int), ("rmnear", C.c_float)]
+
+
+class VoxelStruct(C.Structure):
+    _fields_ = [("num_layers", C.c_int), ("hidden_dim", C.c_int), ("geo_feat_dim", C.c_int),
+                ("num_layers_color", C.c_int), ("input_ch", C.c_int), ("input_ch_views", C.c_int),
+                ("app_dim", C.c_int), ("n_comp", C.c_int * 3), ("grid", C.c_int * 3), ("app_act", C.c_int),
+                ("rgb_act", C.c_int), ("sigma_act", C.c_int), ("composite_feature", C.c_int),
+                ("aabb", C.c_float * 6),
+                ("sigma_w", _fp * MAXL), ("color_w", _fp * MAXL), ("color_b", _fp * MAXL),
+                ("plane", _fp * 3), ("line", _fp * 3), ("basis", _fp), ("rmnear", C.c_float)]
+
+
+class CrfStruct(C.Structure):
+    _fields_ = [("map_type", C.c_int), ("gamma", C.c_float), ("extra_features", C.c_int),
+                ("w", _fp * 4), ("b", _fp * 4)]
+
+
+class RenderCfg(C.Structure):
+    _fields_ = [("H", C.c_int), ("W", C.c_int), ("focal", C.c_float),
+                ("ndc", C.c_int), ("use_viewdirs", C.c_int), ("lindisp", C.c_int), ("N_samples", C.c_int),
+                ("N_importance", C.c_int), ("white_bkgd", C.c_int), ("multires", C.c_int),
+                ("multires_views", C.c_int), ("near", C.c_float), ("far", C.c_float), ("perturb", C.c_float),
+                ("is_train", C.c_int)]
+
+
+class RenderOut(C.Structure):
+    _fields_ = [(k, _fp) for k in ("rgb", "depth", "acc", "z_vals", "weights", "rgb0", "depth0", "acc0", "z_std",
+                                   "z_vals0", "weights0", "feature", "raw")]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.evo_mse.restype = C.c_double
+        _lib.evo_egm_loss.restype = C.c_double
+        _lib.evo_tv_loss.restype = C.c_double
+        _lib.evo_num_threads.restype = C.c_int
+    return _lib
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return a.ctypes.data_as(_fp) if a is not None else None
+
+
+class Nerf:
+    """Holds an evo_nerf struct and keeps the numpy parameter arrays alive."""
+
+    def __init__(self, sd, prefix="", D=8, W=256, input_ch=63, input_ch_views=27, skip=4, use_viewdirs=True,
+                 rgb_act="sigmoid", sigma_act="relu", rmnear=0.0, output_ch=4):
+        g = lambda k: _f(sd[prefix + k]) if (prefix + k) in sd else None
+        self.keep = []
+        s = NerfStruct()
+        s.D, s.W, s.input_ch, s.input_ch_views, s.skip = D, W, input_ch, input_ch_views, skip
+        s.use_viewdirs, s.output_ch = int(use_viewdirs), output_ch
+        for i in range(D):
+            w, b = g(f"pts_linears.{i}.weight"), g(f"pts_linears.{i}.bias")
+            self.keep += [w, b]
+            s.pts_w[i], s.pts_b[i] = _p(w), _p(b)
+        for name in ("views", "feature", "alpha", "rgb", "output"):
+            key = {"views": "views_linears.0"}.get(name, f"{name}_linear")
+            w, b = g(key + ".weight"), g(key + ".bias")
+            self.keep += [w, b]
+            setattr(s, name + "_w", _p(w))
+            setattr(s, name + "_b", _p(b))
+        s.rgb_act, s.sigma_act, s.rmnear = ACT[rgb_act], ACT[sigma_act], float(rmnear)
+        self.s = s
+
+
+class Voxel:
+    def __init__(self, sd, prefix, grid, aabb, input_ch, num_layers=2, hidden_dim=64, geo_feat_dim=15,
+                 num_layers_color=3, input_ch_views=27, app_dim=32, n_comp=(64, 16, 16), app_act="none",
+                 rgb_act="relu", sigma_act="relu", composite_feature=False, rmnear=0.0):
+        g = lambda k: _f(sd[prefix + k]) if (prefix + k) in sd else None
+        self.keep = []
+        s = VoxelStruct()
+        s.num_layers, s.hidden_dim, s.geo_feat_dim, s.num_layers_color = num_layers, hidden_dim, geo_feat_dim, num_layers_color
+        s.input_ch, s.input_ch_views, s.app_dim = input_ch, input_ch_views, app_dim
+        for i in range(3):
+            s.n_comp[i], s.grid[i] = n_comp[i], int(grid[i])
+        for i in range(6):
+            s.aabb[i] = float(aabb[i])
+        s.app_act, s.rgb_act, s.sigma_act = ACT[app_act], ACT[rgb_act], ACT[sigma_act]
+        s.composite_feature, s.rmnear = int(composite_feature), float(rmnear)
+        for l in range(num_layers):
+            w = g(f"sigma_net.{l}.weight")
+            self.keep.append(w)
+            s.sigma_w[l] = _p(w)
+        for l in range(num_layers_color):
+            w, b = g(f"color_net.{l}.weight"), g(f"color_net.{l}.bias")
+            self.keep += [w, b]
+            s.color_w[l], s.color_b[l] = _p(w), _p(b)
+        for i in range(3):
+            pl, li = g(f"app_plane.{i}"), g(f"app_line.{i}")
+            self.keep += [pl, li]
+            s.plane[i], s.line[i] = _p(pl), _p(li)
+        b = g("basis_mat.weight")
+        self.keep.append(b)
+        s.basis = _p(b)
+        self.s = s
+
+
+class Crf:
+    def __init__(self, map_type, sd=None, extra_features=0, gamma=2.2):
+        s = CrfStruct()
+        s.map_type = {"none": 0, "gamma": 1, "learn": 2}[map_type]
+        s.gamma, s.extra_features = gamma, extra_features
+        self.keep = []
+        if map_type == "learn":
+            for j, idx in enumerate((0, 2, 4, 6)):
+                w, b = _f(sd[f"linear.{idx}.weight"]), _f(sd[f"linear.{idx}.bias"])
+                self.keep += [w, b]
+                s.w[j], s.b[j] = _p(w), _p(b)
+        self.s = s
+
+
+def embed(x, L):
+    x = _f(x)
+    n, dim = x.shape
+    out = np.empty((n, dim * (1 + 2 * L)), np.float32)
+    lib().evo_embed(_p(x), C.c_long(n), dim, L, _p(out))
+    return out
+
+
+def nerf_mlp(net: Nerf, emb, want_after=False, want_before=False):
+    emb = _f(emb)
+    n = emb.shape[0]
+    raw = np.empty((n, 4 if net.s.use_viewdirs else net.s.output_ch), np.float32)
+    fa = np.empty((n, net.s.W), np.float32) if want_after else None
+    fb = np.empty((n, net.s.W), np.float32) if want_before else None
+    lib().evo_nerf_mlp(C.byref(net.s), _p(emb), C.c_long(n), _p(raw), _p(fa), _p(fb))
+    return raw, fa, fb
+
+
+def composite(raw, z, rays_d, sigma_ch=3, rgb_ch0=0, n_rgb=3, rgb_act="sigmoid", sigma_act="relu",
+              white_bkgd=False, rmnear_thresh=0.0, noise=None, feature=None):
+    raw, z, rays_d = _f(raw), _f(z), _f(rays_d)
+    R, S, Cc = raw.shape
+    out = np.empty((R, n_rgb), np.float32)
+    dens = np.empty((R, S - 1), np.float32)
+    acc = np.empty((R,), np.float32)
+    wts = np.empty((R, S), np.float32)
+    depth = np.empty((R,), np.float32)
+    noise = _f(noise) if noise is not None else None
+    F = 0
+    fmap = None
+    if feature is not None:
+        feature = _f(feature)
+        F = feature.shape[-1]
+        fmap = np.empty((R, F), np.float32)
+    lib().evo_composite(_p(raw), _p(z), _p(rays_d), C.c_long(R), S, Cc, sigma_ch, rgb_ch0, n_rgb,
+                        ACT[rgb_act], ACT[sigma_act], int(white_bkgd), C.c_float(rmnear_thresh), _p(noise),
+                        _p(out), _p(dens), _p(acc), _p(wts), _p(depth), _p(feature), F, _p(fmap))
+    return dict(rgb=out, density=dens, acc=acc, weights=wts, depth=depth, fmap=fmap)
+
+
+def sample_pdf(bins, w, N, det=True, u=None):
+    bins, w = _f(bins), _f(w)
+    R, nb = bins.shape
+    out = np.empty((R, N), np.float32)
+    u = _f(u) if u is not None else None
+    lib().evo_sample_pdf(_p(bins), _p(w), C.c_long(R), nb, N, int(det), _p(u), _p(out))
+    return out
+
+
+def get_rays(H, W, K, c2w):
+    K, c2w = _f(K), _f(c2w)
+    o = np.empty((H, W, 3), np.float32)
+    d = np.empty((H, W, 3), np.float32)
+    lib().evo_get_rays(H, W, _p(K), _p(c2w), 1, _p(o), _p(d))
+    return o, d
+
+
+def get_rays_pix(coords, K, c2ws):
+    coords, K, c2ws = _f(coords), _f(K), _f(c2ws)
+    n = coords.shape[0]
+    o = np.empty((n, 3), np.float32)
+    d = np.empty((n, 3), np.float32)
+    lib().evo_get_rays_pix(_p(coords), _p(K), _p(c2ws), C.c_long(n), 1, _p(o), _p(d))
+    return o, d
+
+
+def ndc_rays(H, W, focal, near, o, d):
+    o, d = _f(o), _f(d)
+    n = o.shape[0]
+    oo = np.empty_like(o)
+    od = np.empty_like(d)
+    lib().evo_ndc_rays(H, W, C.c_float(focal), C.c_float(near), _p(o), _p(d), C.c_long(n), _p(oo), _p(od))
+    return oo, od
+
+
+def make_cfg(H=400, W=400, focal=400.0, ndc=True, use_viewdirs=True, lindisp=False, N_samples=64, N_importance=0,
+             white_bkgd=False, multires=10, multires_views=4, near=0.0, far=1.0, perturb=0.0, is_train=False):
+    c = RenderCfg()
+    c.H, c.W, c.focal = H, W, focal
+    c.ndc, c.use_viewdirs, c.lindisp = int(ndc), int(use_viewdirs), int(lindisp)
+    c.N_samples, c.N_importance, c.white_bkgd = N_samples, N_importance, int(white_bkgd)
+    c.multires, c.multires_views = multires, multires_views
+    c.near, c.far, c.perturb, c.is_train = near, far, perturb, int(is_train)
+    return c
+
+
+def ray_batch(cfg, rays):
+    rays = _f(rays)
+    R = rays.shape[0]
+    rb = np.empty((R, 11), np.float32)
+    nc = C.c_int(0)
+    lib().evo_ray_batch(C.byref(cfg), _p(rays), C.c_long(R), _p(rb), C.byref(nc))
+    return rb.reshape(-1)[: R * nc.value].reshape(R, nc.value).copy()
+
+
+def _render(fn, coarse, fine, cfg, rays, t_rand, u, feat_dim, want_raw):
+    rays = _f(rays)
+    R = rays.shape[0]
+    S, Ni = cfg.N_samples, cfg.N_importance
+    St = S + Ni
+    res = dict(rgb=np.empty((R, 3), np.float32), depth=np.empty((R,), np.float32), acc=np.empty((R,), np.float32),
+               z_vals=np.empty((R, St), np.float32), weights=np.empty((R, St), np.float32))
+    if Ni > 0:
+        res.update(rgb0=np.empty((R, 3), np.float32), depth0=np.empty((R,), np.float32),
+                   acc0=np.empty((R,), np.float32), z_std=np.empty((R,), np.float32),
+                   z_vals0=np.empty((R, S), np.float32), weights0=np.empty((R, S), np.float32))
+    if feat_dim:
+        res["feature"] = np.empty((R, St, feat_dim), np.float32)
+    if want_raw:
+        res["raw"] = np.empty((R, St, 4), np.float32)
+    out = RenderOut()
+    for k, v in res.items():
+        setattr(out, k, _p(v))
+    t_rand = _f(t_rand) if t_rand is not None else None
+    u = _f(u) if u is not None else None
+    fn(C.byref(coarse.s), C.byref(fine.s) if fine is not None else None, C.byref(cfg), _p(rays), C.c_long(R),
+       _p(t_rand), _p(u), C.byref(out))
+    return res
+
+
+def render_nerf(coarse: Nerf, fine, cfg, rays, t_rand=None, u=None, want_feature=False, want_raw=False):
+    return _render(lib().evo_render_nerf, coarse, fine, cfg, rays, t_rand, u,
+                   coarse.s.W if want_feature else 0, want_raw)
+
+
+def render_c2f(coarse: Voxel, fine, cfg, rays, t_rand=None, u=None, want_feature=False):
+    fd = (fine.s.geo_feat_dim if (fine is not None and cfg.N_importance > 0) else coarse.s.geo_feat_dim)
+    return _render(lib().evo_render_c2f, coarse, fine, cfg, rays, t_rand, u, fd if want_feature else 0, False)
+
+
+def appfeature(v: Voxel, pts):
+    pts = _f(pts).reshape(-1, 3)
+    out = np.empty((pts.shape[0], v.s.app_dim), np.float32)
+    lib().evo_appfeature(C.byref(v.s), _p(pts), C.c_long(pts.shape[0]), _p(out))
+    return out
+
+
+def weighted_sum(x, ccw):
+    x, ccw = _f(x), _f(ccw)
+    R, P = ccw.shape
+    Cc = int(np.prod(x.shape[1:])) if x.ndim > 1 else 1
+    out = np.empty((R, Cc), np.float32)
+    lib().evo_weighted_sum(_p(x), _p(ccw), C.c_long(R), P, Cc, _p(out))
+    return out.reshape((R,) + tuple(x.shape[1:]))
+
+
+def crf_forward(crf: Crf, x, feat=None, skip_learn=False):
+    x = _f(x)
+    n = x.shape[0]
+    per_ch = 0
+    if feat is not None:
+        feat = _f(feat)
+        per_ch = int(feat.ndim == 3)
+    out = np.empty_like(x)
+    lib().evo_crf_forward(C.byref(crf.s), _p(x), _p(feat), per_ch, int(skip_learn), C.c_long(n), _p(out))
+    return out
+
+
+def luma(x, standard="rec601"):
+    x = _f(x)
+    out = np.empty((x.shape[0], 1), np.float32)
+    lib().evo_luma(_p(x), C.c_long(x.shape[0]), {"rec601": 0, "rec709": 1, "avg": 2}[standard], _p(out))
+    return out
+
+
+def mse(a, b):
+    a, b = _f(a), _f(b)
+    return lib().evo_mse(_p(a), _p(b), C.c_long(a.size))
+
+
+def egm_loss(ls, le, bii, color_mask=None, color_weight=None):
+    ls, le, bii = _f(ls), _f(le), _f(bii)
+    n, Cc = ls.shape
+    cm = np.ascontiguousarray(color_mask, dtype=np.uint8) if color_mask is not None else None
+    cw = _f(color_weight) if color_weight is not None else None
+    return lib().evo_egm_loss(_p(ls), _p(le), _p(bii), C.c_long(n), Cc,
+                              cm.ctypes.data_as(C.POINTER(C.c_ubyte)) if cm is not None else None, _p(cw))
+
+
+def bii_image(x, y, p, w, h, c_pos, c_neg, interpolate=True):
+    x, y = _f(x), _f(y)
+    p = np.ascontiguousarray(p, dtype=np.int8)
+    img = np.empty((h, w), np.float32)
+    lib().evo_bii_image(_p(x), _p(y), p.ctypes.data_as(C.POINTER(C.c_byte)), C.c_long(x.shape[0]), w, h,
+                        C.c_float(c_pos), C.c_float(c_neg), int(interpolate), _p(img))
+    return img
+
+
+def inner_double_integral(bii):
+    bii = _f(bii)
+    steps = bii.shape[0] + 1
+    npix = int(np.prod(bii.shape[1:]))
+    out = np.empty((steps,) + bii.shape[1:], np.float32)
+    lib().evo_inner_double_integral(_p(bii), steps, C.c_long(npix), _p(out))
+    return out
+
+
+def deblur_double_integral(blurry, bii):
+    blurry, bii = _f(blurry), _f(bii)
+    out = np.empty_like(blurry)
+    lib().evo_deblur_double_integral(_p(blurry), _p(bii), bii.shape[0] + 1, C.c_long(blurry.size), _p(out))
+    return out
+
+
+def tv_loss(x):
+    x = _f(x)
+    _, Cc, H, W = x.shape
+    return lib().evo_tv_loss(_p(x), Cc, H, W)
+
+
+def num_threads():
+    return lib().evo_num_threads()
