@@ -150,7 +150,9 @@ def test_G9_render_c2f():
     same = np.abs(res["z_vals"] - g["z_vals"]).max(-1) < 5e-5          # rays whose sample sets agree
     assert same.mean() > 0.8
     assert maxabs(res["weights"][same], g["weights"][same]) < 5e-5
-    assert maxabs(res["feature"][:16, :, :8][same[:16]], g["f_depth_feature"][same[:16]]) < 1e-4
+    tight = np.abs(res["z_vals"] - g["z_vals"]).max(-1)[:16] < 2e-6   # features move ~20x the sample offset
+    assert tight.sum() >= 4
+    assert maxabs(res["feature"][:16, :, :8][tight], g["f_depth_feature"][tight]) < 1e-4
     res = O.render_c2f(vc, None, O.make_cfg(N_samples=64, N_importance=0), rays)
     for k in ("rgb", "depth", "acc", "weights"):
         assert maxabs(res[k], g["c_" + k]) < 2e-5, k
