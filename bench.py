@@ -1,0 +1,176 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: rays/s for 4096 rays x 128 samples through the 8x256 NeRF MLP (PE + MLP + composite).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision f16x3|f32|bf16]
+
+One JSON line on rank 0 (contract in the task statement). A "step" = one pass of the render path
+(ray packing -> z stratification -> fused PE+MLP kernel -> compositing scan) over one batch of 4096
+synthetic LLFF-shaped rays already resident in HBM; with N > 1 every rank renders its own 4096 rays
+(weak scaling) and the step ends with the packed blur-loss partial all-reduce over RCCL, the only
+exchange the path has. The headline precision is the float32-grade split-float16 mode (RGB parity
+<= 1e-4 vs the reference); bf16 and exact-f32 rates are reported beside it in "modes".
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+FLOP_PER_SAMPLE = 2 * 593408          # GEMM terms of the 8x256 net with skip and view branch
+PEAK_TFLOPS = {"bf16": 2500.0, "f16x3": 2500.0, "f32": 157.3}   # dense MFMA peaks (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f32", "bf16"])
+    ap.add_argument("--rays", type=int, default=4096)
+    ap.add_argument("--samples", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-modes", action="store_true")
+    return ap.parse_args()
+
+
+def make_model(precision):
+    from types import SimpleNamespace
+    from evdeblurnerf_amd import weights as W
+    from evdeblurnerf_amd.renderer import NeRFAll
+    sd = W.prefixed(W.make_nerf_state_dict(21), "mlp_coarse")
+    args = SimpleNamespace(mode="nerf", netdepth=8, netwidth=256, multires=10, multires_views=4, use_viewdirs=True,
+                           rgb_activate="sigmoid", sigma_activate="relu", N_importance=0)
+    return NeRFAll(args, sd, precision=precision).eval(), sd
+
+
+def time_steps(fn, steps, warmup, barrier):
+    for _ in range(warmup):
+        fn()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    barrier()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def kernel_ms(fn, steps, warmup=3):
+    """Average duration of one launch, HIP events on the stream the kernel runs on (torch's current stream)."""
+    for _ in range(warmup):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / steps
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP library has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_.init_process_group("nccl", rank=rank, world_size=world)
+        dist = dist_
+    barrier = (lambda: dist.barrier()) if dist else (lambda: None)
+
+    from evdeblurnerf_amd import _lib as L, weights as W
+    from evdeblurnerf_amd.losses import blur_loss_partials
+    from evdeblurnerf_amd.tonemapping import CRF
+
+    R, S = a.rays, a.samples
+    K = W.synthetic_camera()
+    rays = torch.as_tensor(W.synthetic_rays(100 + rank, R), device="cuda")
+    target = torch.rand((R, 3), device="cuda")
+    ones = torch.ones((R, 1), device="cuda")
+    crf = CRF("gamma")
+    model, sd = make_model(a.precision)
+    kw = dict(ndc=True, near=0., far=1., use_viewdirs=True, N_samples=S, N_importance=0, retraw=False)
+
+    def step():
+        rgb, depth, acc, _ = model.render(400, 400, K, rays=rays, **kw)
+        if dist:   # the path's one exchange: packed loss partials (evdeblurnerf_amd/dist.py)
+            p, _ = blur_loss_partials(crf, rgb, ones, target)
+            dist.all_reduce(p)
+        return rgb
+
+    dt = time_steps(step, a.steps, a.warmup, barrier)
+    if dist:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    rays_per_s = world * R * a.steps / dt
+
+    result = {
+        "metric": "rays/sec (4096x128 samples, 8x256 MLP)", "value": rays_per_s, "unit": "rays/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": {"f16x3": "f16x3-split (3 f16 MFMA products, f32 accumulate; f32-grade)", "f32": "f32", "bf16": "bf16"}[a.precision],
+        "data": "synthetic",
+        "config": {"workload": f"nerf8x256 render: {R} rays x {S} samples per GPU, PE(10,4)+MLP+composite, ndc, viewdirs",
+                   "rays_per_gpu": R, "samples": S, "precision": a.precision},
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel (fused PE+MLP), measured live with HIP events
+        rb = torch.empty((R, 11), device="cuda")
+        z = torch.empty((R, S), device="cuda")
+        cfg = model._cfg(400, 400, float(K[0][0]), True, 0., 1., S, 0, False, 0., False)
+        import ctypes as C
+        L.check(L.lib().evd_ray_batch(C.byref(cfg), L.ptr(rays), R, L.ptr(rb), L.stream_ptr()))
+        L.check(L.lib().evd_sample_z(C.byref(cfg), L.ptr(rb), 11, R, None, L.ptr(z), L.stream_ptr()))
+        modes = {}
+        for prec in ([a.precision] if a.no_modes else ["f16x3", "bf16", "f32"]):
+            net = model.mlp_coarse
+            ksteps = max(3, a.steps // (10 if prec == "f32" else 1))
+            ms = kernel_ms(lambda: net.mlpforward(rb, z, precision=prec), ksteps)
+            tf = R * S * FLOP_PER_SAMPLE / (ms * 1e-3) / 1e12
+            modes[prec] = {"kernel": "k_nerf_mlp", "ms": ms, "achieved": tf, "peak": PEAK_TFLOPS[prec], "unit": "TFLOP/s",
+                           "frac": tf / PEAK_TFLOPS[prec], "rays_per_s_kernel": R / (ms * 1e-3)}
+        m = modes[a.precision]
+        result["roofline"] = {"bound": "mfma", "achieved": m["achieved"], "peak": m["peak"], "unit": "TFLOP/s",
+                              "frac": m["frac"], "traffic": None, "kernel": "k_nerf_mlp", "kernel_ms": m["ms"],
+                              "note": "algorithmic GEMM flops (1 186 816/sample); f16x3 issues 3 MFMA products per algorithmic one"}
+        result["modes"] = modes
+        if not a.no_cpu_baseline:
+            from oracle import oracle as O
+            onet = O.Nerf(sd, "mlp_coarse.")
+            ocfg = O.make_cfg(N_samples=S)
+            sample = W.synthetic_rays(100, R)
+            O.render_nerf(onet, None, ocfg, sample[:64])
+            n_cpu, t_cpu = 0, 0.0
+            t0 = time.perf_counter()
+            while t_cpu < 12.0 and n_cpu < R:
+                O.render_nerf(onet, None, ocfg, sample[n_cpu:n_cpu + 512])
+                n_cpu += 512
+                t_cpu = time.perf_counter() - t0
+            result["cpu_baseline"] = {"value": n_cpu / t_cpu, "unit": "rays/s", "cores": O.num_threads(), "kind": "port",
+                                      "sample": f"first {n_cpu} rays of the same {R}x{S} workload, C oracle (OpenMP over rays)"}
+        print(json.dumps(result))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,132 @@
+"""ctypes binding of libevdnerf.so (include/evdnerf.h).
+
+The library is the product: there is no CPU or PyTorch fallback. If the shared
+object is missing or a call fails this module raises, loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libevdnerf.so")
+MAXL = 16
+
+PREC = {"f32": 0, "f16x3": 1, "bf16": 2}
+ACT = {"none": 0, "relu": 1, "sigmoid": 2, "exp": 3, "sigmoid1": 4, "softplus": 5, "tanh": 6}
+
+_fp = C.POINTER(C.c_float)
+_vp = C.c_void_p
+
+
+class EvdError(RuntimeError):
+    pass
+
+
+class RenderCfg(C.Structure):
+    _fields_ = [("H", C.c_int), ("W", C.c_int), ("focal", C.c_float),
+                ("ndc", C.c_int), ("use_viewdirs", C.c_int), ("lindisp", C.c_int), ("N_samples", C.c_int),
+                ("N_importance", C.c_int), ("white_bkgd", C.c_int),
+                ("near", C.c_float), ("far", C.c_float), ("perturb", C.c_float),
+                ("is_train", C.c_int), ("precision", C.c_int)]
+
+
+class NerfDesc(C.Structure):
+    _fields_ = [("D", C.c_int), ("W", C.c_int), ("multires", C.c_int), ("multires_views", C.c_int), ("skip", C.c_int),
+                ("rgb_act", C.c_int), ("sigma_act", C.c_int), ("rmnear", C.c_float),
+                ("pts_w", _fp * MAXL), ("pts_b", _fp * MAXL),
+                ("views_w", _fp), ("views_b", _fp), ("feature_w", _fp), ("feature_b", _fp),
+                ("alpha_w", _fp), ("alpha_b", _fp), ("rgb_w", _fp), ("rgb_b", _fp)]
+
+
+class VoxelDesc(C.Structure):
+    _fields_ = [("num_layers", C.c_int), ("hidden_dim", C.c_int), ("geo_feat_dim", C.c_int),
+                ("num_layers_color", C.c_int), ("input_ch", C.c_int), ("multires", C.c_int), ("multires_views", C.c_int),
+                ("app_dim", C.c_int), ("n_comp", C.c_int * 3), ("grid", C.c_int * 3), ("app_act", C.c_int),
+                ("rgb_act", C.c_int), ("sigma_act", C.c_int), ("composite_feature", C.c_int),
+                ("aabb", C.c_float * 6), ("rmnear", C.c_float),
+                ("sigma_w", _fp * MAXL), ("color_w", _fp * MAXL), ("color_b", _fp * MAXL),
+                ("plane", _fp * 3), ("line", _fp * 3), ("basis", _fp)]
+
+
+class CrfDesc(C.Structure):
+    _fields_ = [("map_type", C.c_int), ("gamma", C.c_float), ("extra_features", C.c_int),
+                ("w", _fp * 4), ("b", _fp * 4)]
+
+
+class RenderOut(C.Structure):
+    _fields_ = [(k, _vp) for k in ("rgb", "depth", "acc", "z_vals", "weights", "rgb0", "depth0", "acc0", "z_std",
+                                   "z_vals0", "weights0", "feature", "raw")] + [("feature_kind", C.c_int)]
+
+
+# name -> (restype, argtypes); every symbol include/evdnerf.h declares
+_L, _I, _F, _S = C.c_long, C.c_int, C.c_float, C.c_size_t
+SIGNATURES = {
+    "evd_last_error": (C.c_char_p, []),
+    "evd_version": (_I, []),
+    "evd_device_count": (_I, []),
+    "evd_get_rays": (_I, [_I, _I, _fp, _fp, _vp, _vp, _vp]),
+    "evd_get_rays_pix": (_I, [_vp, _fp, _vp, _L, _vp, _vp, _vp]),
+    "evd_ndc_rays": (_I, [_I, _I, _F, _F, _vp, _vp, _L, _vp, _vp, _vp]),
+    "evd_embed": (_I, [_vp, _L, _I, _I, _vp, _vp]),
+    "evd_ray_batch": (_I, [C.POINTER(RenderCfg), _vp, _L, _vp, _vp]),
+    "evd_sample_z": (_I, [C.POINTER(RenderCfg), _vp, _I, _L, _vp, _vp, _vp]),
+    "evd_nerf_create": (_I, [C.POINTER(NerfDesc), C.POINTER(_vp)]),
+    "evd_nerf_destroy": (None, [_vp]),
+    "evd_nerf_stream_bytes": (_S, [_vp, _I]),
+    "evd_nerf_mlp": (_I, [_vp, _I, _vp, _vp, _L, _I, _vp, _vp, _I, _vp]),
+    "evd_raw2outputs": (_I, [_vp, _vp, _vp, _I, _L, _I, _I, _I, _I, _I, _I, _I, _I, _F, _vp,
+                             _vp, _vp, _vp, _vp, _vp, _vp, _I, _vp, _vp]),
+    "evd_sample_pdf_merge": (_I, [_vp, _vp, _L, _I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "evd_nerf_render_workspace_bytes": (_S, [C.POINTER(RenderCfg), _L]),
+    "evd_nerf_render_rays": (_I, [_vp, _vp, C.POINTER(RenderCfg), _vp, _L, _vp, _vp, _vp, _vp,
+                                  C.POINTER(RenderOut), _vp, _S, _vp]),
+    "evd_nerf_render": (_I, [_vp, _vp, C.POINTER(RenderCfg), _vp, _L, _vp, _vp, _vp, _vp,
+                             C.POINTER(RenderOut), _vp, _S, _vp]),
+    "evd_weighted_sum": (_I, [_vp, _vp, _L, _I, _I, _vp, _vp]),
+    "evd_crf_create": (_I, [C.POINTER(CrfDesc), C.POINTER(_vp)]),
+    "evd_crf_destroy": (None, [_vp]),
+    "evd_crf_forward": (_I, [_vp, _vp, _vp, _I, _I, _I, _L, _vp, _vp]),
+    "evd_blur_loss_reduce": (_I, [_vp, _I, _vp, _vp, _vp, _vp, _vp, _vp, _L, _I, _vp, _vp, _vp, _vp, _vp]),
+    "evd_event_loss_reduce": (_I, [_vp, _I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _F, _F, _vp, _fp, _L, _vp, _vp]),
+    "evd_edi_deblur": (_I, [_vp, _vp, _I, _L, _vp, _vp]),
+    "evd_edi_bii_image": (_I, [_vp, _vp, _vp, _L, _I, _I, _F, _F, _vp, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises EvdError if it is missing (no fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EvdError(f"{LIB_PATH} not found: build it with `python -m evdeblurnerf_amd.build` "
+                           "(hipcc, --offload-arch=gfx950). There is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)   # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().evd_last_error()
+        raise EvdError(f"{what or 'libevdnerf'} failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous float32/int32/uint8 torch tensor (or None)."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise EvdError("tensor must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,82 @@
+"""Builds libevdnerf.so (HIP, gfx950 only) in-tree with hipcc.
+
+    python -m evdeblurnerf_amd.build [--force]
+
+Every csrc/*.hip is compiled to an object next to the library and linked into
+evdeblurnerf_amd/lib/libevdnerf.so; the .so travels to the GPU box with the
+repo snapshot (it is git-ignored, not gpurun-ignored).
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libevdnerf.so")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off",
+         "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: libevdnerf.so cannot be built")
+    return exe
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs.append(os.path.join(os.path.dirname(HERE), "include", "evdnerf.h"))
+    return hs
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src, obj, extra):
+    cmd = [hipcc(), *FLAGS, *extra, "-c", src, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {os.path.basename(src)}:\n{r.stdout}\n{r.stderr}")
+    return r.stderr
+
+
+def build(force: bool = False, verbose: bool = False, extra=()) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    hs = headers()
+    jobs = []
+    objs = []
+    for src in sources():
+        obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + hs):
+            jobs.append((src, obj))
+    if jobs:
+        with cf.ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            for (src, _), warn in zip(jobs, ex.map(lambda j: _compile(j[0], j[1], list(extra)), jobs)):
+                if verbose and warn.strip():
+                    print(f"[{os.path.basename(src)}]\n{warn}", file=sys.stderr)
+    if jobs or _stale(LIB, objs):
+        cmd = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,268 @@
+// C-ABI entry points of the NeRF backbone: weight packing, fused MLP launch, render_rays orchestration.
+#include "evd_common.h"
+#include "nerf_mlp.h"
+
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+
+namespace evd {
+
+char* err_buf() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int nerf_mlp_dispatch(int prec, int W, const MlpParams& p, hipStream_t st);
+
+// ------------------------------------------------------------------------------------------------
+// host-side packing of nn.Linear weights into the MFMA fragment stream (contract: nerf_mlp.h)
+static inline uint16_t f32_to_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                            // round to nearest even
+    return (uint16_t)(u >> 16);
+}
+
+struct StreamBuilder {
+    int prec;
+    std::vector<uint8_t> bytes;
+    explicit StreamBuilder(int p) : prec(p) {}
+    // one fragment: rows = 32 output features of `tile`, k-step j; col(kk) -> source column or -1
+    template <class ColFn>
+    void frag(const float* Wm, int out_dim, int in_dim, int tile, int j, ColFn col) {
+        const int fb = frag_bytes(prec);
+        const size_t base = bytes.size();
+        bytes.resize(base + fb, 0);
+        uint8_t* dst = bytes.data() + base;
+        for (int l = 0; l < 64; ++l) {
+            const int row = 32 * tile + (l & 31);
+            for (int e = 0; e < 8; ++e) {
+                const int kk = 8 * (l >> 5) + e;
+                const int c = col(j, kk);
+                const float w = (row < out_dim && c >= 0 && c < in_dim) ? Wm[(size_t)row * in_dim + c] : 0.f;
+                if (prec == EVD_PREC_BF16) {
+                    const uint16_t b = f32_to_bf16(w);
+                    memcpy(dst + l * 16 + e * 2, &b, 2);
+                } else if (prec == EVD_PREC_F16X3) {
+                    const _Float16 hi = (_Float16)w;
+                    const _Float16 lo = (_Float16)((w - (float)hi) * 2048.f);
+                    memcpy(dst + l * 16 + e * 2, &hi, 2);
+                    memcpy(dst + 1024 + l * 16 + e * 2, &lo, 2);
+                } else {
+                    memcpy(dst + (e < 4 ? 0 : 1024) + l * 16 + (e & 3) * 4, &w, 4);
+                }
+            }
+        }
+    }
+    template <class ColFn>
+    void layer(const float* Wm, int out_dim, int in_dim, int tiles, int ksteps, bool pad_end, ColFn col) {
+        const int G = tiles >= 2 ? 2 : 1;
+        for (int p = 0; p < tiles / G; ++p)
+            for (int j = 0; j < ksteps; ++j)
+                for (int t = 0; t < G; ++t) frag(Wm, out_dim, in_dim, p * G + t, j, col);
+        if (pad_end) pad();
+    }
+    void pad() {
+        const size_t cb = chunk_bytes(prec);
+        bytes.resize(cdiv((long)bytes.size(), (long)cb) * cb, 0);
+    }
+};
+
+}  // namespace evd
+
+using namespace evd;
+
+struct evd_nerf {
+    int D, W, skip, rgb_act, sigma_act;
+    float rmnear;
+    DevBuf stream[3];
+    int nchunks[3];
+    DevBuf bias;
+};
+
+extern "C" {
+
+const char* evd_last_error(void) { return evd::err_buf(); }
+int evd_version(void) { return 100; }
+
+int evd_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return fail(EVD_E_NODEVICE, "hipGetDeviceCount failed");
+    return n;
+}
+
+int evd_nerf_create(const evd_nerf_desc* d, evd_nerf** out) {
+    EVD_REQUIRE(d && out, "evd_nerf_create: null argument");
+    EVD_REQUIRE(d->multires == PE_L && d->multires_views == PE_LV,
+                "evd_nerf_create: only multires=%d, multires_views=%d are built (got %d, %d)", PE_L, PE_LV, d->multires, d->multires_views);
+    EVD_REQUIRE(d->W == 256 || d->W == 64, "evd_nerf_create: netwidth %d not built (64, 256)", d->W);
+    EVD_REQUIRE(d->D >= 1 && d->D <= EVD_MAX_LAYERS, "evd_nerf_create: netdepth %d out of range", d->D);
+    EVD_REQUIRE(d->views_w && d->feature_w && d->alpha_w && d->rgb_w, "evd_nerf_create: use_viewdirs=False networks are not supported");
+    const int W = d->W, T = W / 32, KS = W / 16, IC = 3 * (1 + 2 * PE_L), ICV = 3 * (1 + 2 * PE_LV);
+    evd_nerf* n = new evd_nerf();
+    n->D = d->D; n->W = W; n->skip = d->skip; n->rgb_act = d->rgb_act; n->sigma_act = d->sigma_act; n->rmnear = d->rmnear;
+
+    auto pe_col = [](int j, int kk) { return pe_src_col(PE_L, 8 * j + (kk & 7), kk >> 3); };
+    auto hid_col = [](int j, int kk) { return 16 * j + phi(kk); };
+    for (int prec = 0; prec < 3; ++prec) {
+        StreamBuilder sb(prec);
+        sb.layer(d->pts_w[0], W, IC, T, PE_KS, true, pe_col);
+        for (int l = 1; l < d->D; ++l) {
+            if (l - 1 == d->skip) {
+                auto wide_col = [&](int j, int kk) { return j < PE_KS ? pe_col(j, kk) : IC + hid_col(j - PE_KS, kk); };
+                sb.layer(d->pts_w[l], W, W + IC, T, PE_KS + KS, true, wide_col);
+            } else {
+                sb.layer(d->pts_w[l], W, W, T, KS, true, hid_col);
+            }
+        }
+        sb.layer(d->alpha_w, 1, W, 1, KS, false, hid_col);
+        sb.layer(d->feature_w, W, W, T, KS, false, hid_col);
+        auto views_col = [&](int j, int kk) {
+            if (j < KS) return hid_col(j, kk);
+            const int c = pe_src_col(PE_LV, 8 * (j - KS) + (kk & 7), kk >> 3);
+            return c < 0 ? -1 : W + c;
+        };
+        sb.layer(d->views_w, W / 2, W + ICV, T / 2, KS + PEV_KS, false, views_col);
+        sb.layer(d->rgb_w, 3, W / 2, 1, KS / 2, true, hid_col);
+        n->nchunks[prec] = (int)(sb.bytes.size() / chunk_bytes(prec));
+        int rc = n->stream[prec].upload(sb.bytes.data(), sb.bytes.size());
+        if (rc) { evd_nerf_destroy(n); return rc; }
+    }
+    // biases, one 32-float row block per output tile, in stream order
+    std::vector<float> b;
+    auto push = [&](const float* src, int out_dim, int tiles) {
+        for (int i = 0; i < tiles * 32; ++i) b.push_back((src && i < out_dim) ? src[i] : 0.f);
+    };
+    for (int l = 0; l < d->D; ++l) push(d->pts_b[l], W, T);
+    push(d->alpha_b, 1, 1);
+    push(d->feature_b, W, T);
+    push(d->views_b, W / 2, T / 2);
+    push(d->rgb_b, 3, 1);
+    int rc = n->bias.upload(b.data(), b.size() * sizeof(float));
+    if (rc) { evd_nerf_destroy(n); return rc; }
+    *out = n;
+    return EVD_OK;
+}
+
+void evd_nerf_destroy(evd_nerf* n) {
+    if (!n) return;
+    for (int i = 0; i < 3; ++i) n->stream[i].release();
+    n->bias.release();
+    delete n;
+}
+
+size_t evd_nerf_stream_bytes(const evd_nerf* net, int precision) {
+    if (!net || precision < 0 || precision > 2) return 0;
+    return net->stream[precision].bytes;
+}
+
+int evd_nerf_mlp(const evd_nerf* net, int precision, const float* ray_batch, const float* z, long R, int S,
+                 float* raw, float* feature, int feature_kind, void* stream) {
+    EVD_REQUIRE(net && ray_batch && z && raw, "evd_nerf_mlp: null argument");
+    EVD_REQUIRE(precision >= 0 && precision <= 2, "evd_nerf_mlp: unknown precision %d", precision);
+    EVD_REQUIRE(R >= 0 && S >= 1, "evd_nerf_mlp: bad shape R=%ld S=%d", R, S);
+    EVD_REQUIRE(!feature || feature_kind == 1 || feature_kind == 2, "evd_nerf_mlp: feature_kind must be 1 or 2");
+    if (R == 0) return EVD_OK;
+    MlpParams p;
+    p.wstream = (const char*)net->stream[precision].p;
+    p.bias = (const float*)net->bias.p;
+    p.ray_batch = ray_batch; p.z = z; p.nsamp = R * (long)S; p.S = S; p.ncol = 11;
+    p.D = net->D; p.skip = net->skip; p.nchunks = net->nchunks[precision];
+    p.raw = raw; p.feature = feature; p.feature_kind = feature ? feature_kind : 0;
+    return nerf_mlp_dispatch(precision, net->W, p, as_stream(stream));
+}
+
+// ------------------------------------------------------------------------------------------------
+// NeRFAll.render + render_rays, mode='nerf' (networks/renderer.py:399-466, 129-264 else-branch)
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+size_t evd_nerf_render_workspace_bytes(const evd_render_cfg* cfg, long R) {
+    if (!cfg || R < 0) return 0;
+    const size_t S = cfg->N_samples, Ni = cfg->N_importance > 0 ? cfg->N_importance : 0, St = S + Ni, r = (size_t)R;
+    size_t b = 0;
+    b += align256(r * 11 * 4);          // ray_batch
+    b += align256(r * St * 4);          // z (merged)
+    b += align256(r * S * 4);           // z0
+    b += align256(r * St * 16);         // raw
+    b += align256(r * St * 4);          // weights
+    b += align256(r * S * 4);           // weights0
+    b += align256(r * (Ni ? Ni : 1) * 4);  // z_samples
+    return b + 256;
+}
+
+int evd_nerf_render_rays(const evd_nerf* coarse, const evd_nerf* fine, const evd_render_cfg* cfg, const float* rb,
+                         long R, const float* t_rand, const float* u, const float* noise0, const float* noise1,
+                         evd_render_out* out, void* workspace, size_t workspace_bytes, void* stream) {
+    EVD_REQUIRE(coarse && cfg && out && (rb || R == 0), "evd_nerf_render_rays: null argument");
+    EVD_REQUIRE(cfg->use_viewdirs, "evd_nerf_render_rays: use_viewdirs=False is not supported");
+    EVD_REQUIRE(cfg->N_samples >= 1, "evd_nerf_render_rays: N_samples must be >= 1");
+    EVD_REQUIRE(cfg->N_importance <= 0 || fine, "evd_nerf_render_rays: N_importance > 0 needs the fine network");
+    EVD_REQUIRE(cfg->N_importance <= 0 || cfg->N_samples >= 3, "evd_nerf_render_rays: hierarchical sampling needs N_samples >= 3");
+    EVD_REQUIRE(!(cfg->perturb > 0.f) || (t_rand && (cfg->N_importance <= 0 || u)),
+                "evd_nerf_render_rays: perturb > 0 needs explicit t_rand (and u) draws");
+    if (R == 0) return EVD_OK;
+    const size_t need = evd_nerf_render_workspace_bytes(cfg, R);
+    if (!workspace || workspace_bytes < need)
+        return fail(EVD_E_WORKSPACE, "evd_nerf_render_rays: workspace %zu < %zu bytes", workspace_bytes, need);
+    const int S = cfg->N_samples, Ni = cfg->N_importance > 0 ? cfg->N_importance : 0, St = S + Ni;
+    char* w = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    auto take = [&](size_t bytes) { char* p = w; w += align256(bytes); return (float*)p; };
+    const size_t r = (size_t)R;
+    (void)take(r * 11 * 4);             // ray_batch slot (used by evd_nerf_render)
+    float* z2 = take(r * St * 4);
+    float* z0 = take(r * S * 4);
+    float* raw = take(r * St * 16);
+    float* wts = take(r * St * 4);
+    float* wts0 = take(r * S * 4);
+    float* zs = take(r * (Ni ? Ni : 1) * 4);
+    int rc;
+    float* zc = (Ni ? (out->z_vals0 ? out->z_vals0 : z0) : (out->z_vals ? out->z_vals : z0));
+    if ((rc = evd_sample_z(cfg, rb, 11, R, t_rand, zc, stream))) return rc;
+
+    auto pass = [&](const evd_nerf* net, const float* z, int Sp, const float* noise, float* rgb, float* depth, float* acc,
+                    float* weights, float* raw_out, float* feat) -> int {
+        int rc2 = evd_nerf_mlp(net, cfg->precision, rb, z, R, Sp, raw_out, feat, out->feature_kind ? out->feature_kind : 1, stream);
+        if (rc2) return rc2;
+        const float thr = (!cfg->is_train && net->rmnear > 0.f) ? (float)((double)net->rmnear / 128.0) : 0.f;
+        return evd_raw2outputs(raw_out, z, rb + 3, 11, R, Sp, 4, 3, 0, 3, net->rgb_act, net->sigma_act, cfg->white_bkgd, thr,
+                               noise, rgb, nullptr, acc, weights, depth, nullptr, 0, nullptr, stream);
+    };
+    if (!Ni) {
+        float* wo = out->weights ? out->weights : wts;
+        float* ro = out->raw ? out->raw : raw;
+        return pass(coarse, zc, S, noise0, out->rgb, out->depth, out->acc, wo, ro, out->feature);
+    }
+    float* w0 = out->weights0 ? out->weights0 : wts0;
+    if ((rc = pass(coarse, zc, S, noise0, out->rgb0, out->depth0, out->acc0, w0, raw, nullptr))) return rc;
+    float* zm = out->z_vals ? out->z_vals : z2;
+    if ((rc = evd_sample_pdf_merge(zc, w0, R, S, Ni, cfg->perturb == 0.f, u, zs, zm, nullptr, out->z_std, stream))) return rc;
+    float* wo = out->weights ? out->weights : wts;
+    float* ro = out->raw ? out->raw : raw;
+    return pass(fine, zm, St, noise1, out->rgb, out->depth, out->acc, wo, ro, out->feature);
+}
+
+int evd_nerf_render(const evd_nerf* coarse, const evd_nerf* fine, const evd_render_cfg* cfg, const float* rays, long R,
+                    const float* t_rand, const float* u, const float* noise0, const float* noise1,
+                    evd_render_out* out, void* workspace, size_t workspace_bytes, void* stream) {
+    EVD_REQUIRE(cfg && (rays || R == 0), "evd_nerf_render: null argument");
+    if (R == 0) return EVD_OK;
+    const size_t need = evd_nerf_render_workspace_bytes(cfg, R);
+    if (!workspace || workspace_bytes < need)
+        return fail(EVD_E_WORKSPACE, "evd_nerf_render: workspace %zu < %zu bytes", workspace_bytes, need);
+    float* rb = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    int rc = evd_ray_batch(cfg, rays, R, rb, stream);
+    if (rc) return rc;
+    return evd_nerf_render_rays(coarse, fine, cfg, rb, R, t_rand, u, noise0, noise1, out, workspace, workspace_bytes, stream);
+}
+
+}  // extern "C"

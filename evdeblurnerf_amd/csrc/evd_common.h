@@ -1,0 +1,82 @@
+// Shared helpers of libevdnerf.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/evdnerf.h"
+
+namespace evd {
+
+// thread-local last-error message behind evd_last_error()
+char* err_buf();
+int fail(int code, const char* fmt, ...);
+
+#define EVD_HIP(call)                                                                               \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess) return evd::fail(EVD_E_HIP, "%s failed: %s (%s:%d)", #call,           \
+                                               hipGetErrorString(e_), __FILE__, __LINE__);          \
+    } while (0)
+
+#define EVD_REQUIRE(cond, ...)                                                  \
+    do {                                                                        \
+        if (!(cond)) return evd::fail(EVD_E_INVALID, __VA_ARGS__);              \
+    } while (0)
+
+#define EVD_LAUNCH_CHECK() EVD_HIP(hipGetLastError())
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline long cdiv(long a, long b) { return (a + b - 1) / b; }
+
+// activations: reference networks/nerf.py:31-33, networks/pdrf/voxnerf.py:28-30
+__device__ __forceinline__ float act(int code, float x) {
+    switch (code) {
+    case EVD_ACT_RELU: return fmaxf(x, 0.f);
+    case EVD_ACT_SIGMOID: return 1.f / (1.f + expf(-x));
+    case EVD_ACT_EXP: return expf(x);
+    case EVD_ACT_SIGMOID1: return 1.002f / (expf(-x) + 1.f) - 0.001f;
+    case EVD_ACT_SOFTPLUS: {
+        float y = x - 1.f;
+        return y > 20.f ? y : log1pf(expf(y));
+    }
+    case EVD_ACT_TANH: return tanhf(x);
+    default: return x;
+    }
+}
+
+// torch.linspace(start, end, steps)[i] (ATen RangeFactories: symmetric fill)
+__host__ __device__ __forceinline__ float linspace_at(float start, float end, int steps, int i) {
+    if (steps == 1) return start;
+    const float step = (end - start) / (float)(steps - 1);
+    return (i < steps / 2) ? start + step * (float)i : end - step * (float)(steps - i - 1);
+}
+
+// simple device buffer owned by a handle
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int alloc(size_t n) {
+        bytes = n;
+        EVD_HIP(hipMalloc(&p, n ? n : 1));
+        return EVD_OK;
+    }
+    int upload(const void* host, size_t n) {
+        int rc = alloc(n);
+        if (rc) return rc;
+        EVD_HIP(hipMemcpy(p, host, n, hipMemcpyHostToDevice));
+        return EVD_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+}  // namespace evd

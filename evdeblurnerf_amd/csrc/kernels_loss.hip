@@ -1,0 +1,353 @@
+// Loss-side pixel ops: sub-exposure weighted sums, camera response functions, fused blur / event loss
+// reductions, EDI prior.  All HBM-bound and tiny; the point of fusing them is one launch + one packed
+// partial-sum vector per step (which is what the ranks all-reduce) instead of dozens of ATen launches.
+#include "evd_common.h"
+
+namespace evd {
+
+// CRF parameters travel as a kernel argument (scalar loads, wave-uniform).  networks/tonemapping.py:16-22
+constexpr int CRF_MAX_IN = 8;
+struct CrfParams {
+    int map_type;       // 0 none, 1 gamma, 2 learn
+    int E;              // extra features
+    float inv_gamma;
+    float b3;
+    float w0[16 * CRF_MAX_IN], b0[16], w1[256], b1[16], w2[256], b2[16], w3[16];
+};
+
+// CRF.forward for one channel value, networks/tonemapping.py:59-93
+__device__ __forceinline__ float crf_apply(const CrfParams& c, float v, const float* feat, bool skip_learn) {
+    if (c.map_type == 0) return v;
+    if (c.map_type == 1) v = powf(v, c.inv_gamma);
+    if (!skip_learn && c.map_type == 2) {
+        float in[CRF_MAX_IN];
+        in[0] = v;
+        for (int e = 0; e < c.E; ++e) in[1 + e] = feat ? feat[e] : 0.f;
+        float h[16], h2[16];
+        const int nin = 1 + c.E;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float s = c.b0[j];
+            for (int k = 0; k < nin; ++k) s = fmaf(c.w0[j * nin + k], in[k], s);
+            h[j] = fmaxf(s, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float s = c.b1[j];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s = fmaf(c.w1[j * 16 + k], h[k], s);
+            h2[j] = fmaxf(s, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float s = c.b2[j];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s = fmaf(c.w2[j * 16 + k], h2[k], s);
+            h[j] = fmaxf(s, 0.f);
+        }
+        float s = c.b3;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s = fmaf(c.w3[k], h[k], s);
+        v = 1.f / (1.f + expf(-(s * 0.1f + v)));
+    }
+    return v;
+}
+
+__device__ __forceinline__ float luma_of(int standard, float r, float g, float b) {
+    if (standard == 0) return 0.299f * r + 0.587f * g + 0.114f * b;        // rec601, tonemapping.py:128-129
+    if (standard == 1) return 0.2126f * r + 0.7152f * g + 0.0722f * b;     // rec709
+    return (r + g + b) / 3.f;                                              // avg
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int i = 0; i < nw; ++i) s += red[i];
+    return s;
+}
+
+// rbk_weighted_sum, networks/dpnerf/blurmodel.py:112-127
+__global__ void k_weighted_sum(const float* __restrict__ x, const float* __restrict__ ccw, long R, int P, int C,
+                               float* __restrict__ out) {
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (idx >= R * C) return;
+    const long r = idx / C;
+    const int c = idx % C;
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += x[(r * P + p) * (long)C + c] * ccw[r * P + p];
+    out[idx] = s;
+}
+
+__global__ void k_crf_forward(const CrfParams crf, const float* __restrict__ x, const float* __restrict__ feat,
+                              int feat_per_channel, int skip_learn, int luma, long n, float* __restrict__ out) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float* f = feat ? (feat_per_channel ? feat + (i * 3 + c) * crf.E : feat + i * crf.E) : nullptr;
+        v[c] = crf_apply(crf, x[i * 3 + c], f, skip_learn);
+    }
+    if (luma < 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[i * 3 + c] = v[c];
+    } else {
+        out[i] = luma_of(luma, v[0], v[1], v[2]);
+    }
+}
+
+// spec: run_nerf.py:443-497 + networks/renderer.py:327-336
+__global__ __launch_bounds__(256) void k_blur_loss(const CrfParams crf, int skip_learn, const float* __restrict__ rgb_p,
+                                                   const float* __restrict__ rgb0_p, const float* __restrict__ w1,
+                                                   const float* __restrict__ w2, const float* __restrict__ tgt,
+                                                   const float* __restrict__ tgt0, long R, int P, float* __restrict__ partial,
+                                                   float* __restrict__ o_rgb, float* __restrict__ o_rgb1, float* __restrict__ o_awp) {
+    __shared__ float red[8];
+    const long r = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    float se[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (r < R) {
+        float a[3] = {0, 0, 0}, b[3] = {0, 0, 0}, c[3] = {0, 0, 0};
+        for (int p = 0; p < P; ++p) {
+            const float wa = w1[r * P + p], wb = w2 ? w2[r * P + p] : 0.f;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const float f = rgb_p[(r * P + p) * 3 + ch];
+                a[ch] += f * wa;
+                c[ch] += f * wb;
+                if (rgb0_p) b[ch] += rgb0_p[(r * P + p) * 3 + ch] * wa;
+            }
+        }
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float t = tgt[r * 3 + ch];
+            float d = crf_apply(crf, a[ch], nullptr, skip_learn) - t;
+            se[0] += d * d;
+            if (o_rgb) o_rgb[r * 3 + ch] = a[ch];
+            if (rgb0_p) {
+                d = crf_apply(crf, b[ch], nullptr, skip_learn) - t;
+                se[1] += d * d;
+                if (o_rgb1) o_rgb1[r * 3 + ch] = b[ch];
+            }
+            if (w2) {
+                d = crf_apply(crf, c[ch], nullptr, skip_learn) - t;
+                se[2] += d * d;
+                if (o_awp) o_awp[r * 3 + ch] = c[ch];
+            }
+            if (tgt0) {
+                const float t0 = tgt0[r * 3 + ch];
+                d = crf_apply(crf, rgb_p[(r * P) * 3 + ch], nullptr, skip_learn) - t0;     // rgb_pts[:, 0] renderer.py:374
+                se[3] += d * d;
+                if (rgb0_p) {
+                    d = crf_apply(crf, rgb0_p[(r * P) * 3 + ch], nullptr, skip_learn) - t0;
+                    se[4] += d * d;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const float s = block_sum(se[k], red);
+        if (threadIdx.x == 0 && s != 0.f) atomicAdd(partial + k, s);
+    }
+    if (threadIdx.x == 0) {
+        const long lo = blockIdx.x * (long)blockDim.x;
+        const long cnt = (R - lo) < (long)blockDim.x ? (R - lo) : (long)blockDim.x;
+        atomicAdd(partial + 5, 3.f * (float)cnt);
+    }
+}
+
+// spec: run_nerf.py:518-570 + utils/events.py:260-284
+__global__ __launch_bounds__(256) void k_event_loss(const CrfParams crf, int skip_learn, int add_bii_feat, int tonemap_only,
+                                                    const float* __restrict__ start, const float* __restrict__ end,
+                                                    const float* __restrict__ start0, const float* __restrict__ end0,
+                                                    const float* __restrict__ cum_neg, const float* __restrict__ cum_pos,
+                                                    float thr_neg, float thr_pos, const unsigned char* __restrict__ cmask,
+                                                    float cw0, float cw1, float cw2, int has_cw, long N, float* __restrict__ partial) {
+    __shared__ float red[8];
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    float s_f = 0.f, s_c = 0.f, s_w = 0.f;
+    if (i < N) {
+        const float cn = cum_neg[i], cp = cum_pos[i];
+        const float bii = __fadd_rn(__fmul_rn(thr_neg, cn), __fmul_rn(thr_pos, cp));   // run_nerf.py:518-519
+        int ch = 0;
+        if (cmask) for (int c = 0; c < 3; ++c) if (cmask[i * 3 + c]) ch = c;
+        const float cw[3] = {cw0, cw1, cw2};
+        const float w = (cmask && has_cw) ? cw[ch] : 1.f;
+        auto luma = [&](const float* rgb) {
+            float v[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float f[2] = {cn, cp};
+                const float* fp = nullptr;
+                if (add_bii_feat == 1) fp = f;                                            // 'pos-neg' :522-523
+                else if (add_bii_feat == 2) { if (c != ch) { f[0] = 0.f; f[1] = 0.f; } fp = f; }   // 'color-pos-neg' :524-531
+                v[c] = crf_apply(crf, rgb[i * 3 + c], fp, skip_learn);
+            }
+            return tonemap_only ? v[ch] : luma_of(0, v[0], v[1], v[2]);
+        };
+        const float pred = logf(luma(end) + 1e-5f) - logf(luma(start) + 1e-5f);
+        const float d = pred - bii;
+        s_f = d * d * w;
+        s_w = w;
+        if (start0 && end0) {
+            const float pred0 = logf(luma(end0) + 1e-5f) - logf(luma(start0) + 1e-5f);
+            const float d0 = pred0 - bii;
+            s_c = d0 * d0 * w;
+        }
+    }
+    const float a = block_sum(s_f, red), b = block_sum(s_c, red), c = block_sum(s_w, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(partial + 0, a);
+        atomicAdd(partial + 1, b);
+        atomicAdd(partial + 2, c);
+    }
+}
+
+// utils/edi.py:73-95: E_k = -sum_{j=k}^{N-1} bii_j (k<N), 0 (k=N), +sum_{j=N}^{k-1} bii_j (k>N); sharp = (2N+1) blurry / sum exp(E_k)
+__global__ void k_edi_deblur(const float* __restrict__ blurry, const float* __restrict__ bii, int steps, long npix,
+                             float* __restrict__ sharp) {
+    const long px = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (px >= npix) return;
+    const int N = (steps - 1) / 2;
+    float s = 1.f;       // exp(0) of the frame at f
+    float run = 0.f;
+    // left part: E_i = -(bii_i + ... + bii_{N-1}); accumulate in the reference's order (i ascending inside each sum)
+    for (int i = 0; i < N; ++i) {
+        float e = 0.f;
+        for (int j = i; j < N; ++j) e += bii[(long)j * npix + px];
+        s += expf(-e);
+    }
+    for (int i = 0; i < N; ++i) {
+        run += bii[(long)(N + i) * npix + px];
+        s += expf(run);
+    }
+    sharp[px] = (float)(2 * N + 1) * blurry[px] / s;
+}
+
+// utils/edi.py:7-41,44-70: bilinear sub-pixel splat of +-1 events, grey sensor
+__global__ void k_edi_splat(const float* __restrict__ x, const float* __restrict__ y, const signed char* __restrict__ p, long n,
+                            int w, int h, float c_pos, float c_neg, float* __restrict__ image) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float xv = x[i], yv = y[i];
+    const float sc = p[i] > 0 ? c_pos : -c_neg;
+#pragma unroll
+    for (int xr = 0; xr < 2; ++xr)
+#pragma unroll
+        for (int yr = 0; yr < 2; ++yr) {
+            const float xf = xr ? ceilf(xv) : floorf(xv), yf = yr ? ceilf(yv) : floorf(yv);
+            if (!((xf != xv || xr == 0) && (yf != yv || yr == 0) && xf < (float)w && yf < (float)h)) continue;
+            const float kx = fmaxf(0.f, 1.f - fabsf(xf - xv)), ky = fmaxf(0.f, 1.f - fabsf(yf - yv));
+            atomicAdd(image + (long)yf * w + (long)xf, sc * (kx * ky));
+        }
+}
+
+}  // namespace evd
+
+using namespace evd;
+
+struct evd_crf {
+    CrfParams p;
+};
+
+extern "C" {
+
+int evd_weighted_sum(const float* x, const float* ccw, long R, int P, int C, float* out, void* stream) {
+    EVD_REQUIRE(R >= 0 && P >= 1 && C >= 1 && out, "evd_weighted_sum: bad arguments");
+    if (R == 0) return EVD_OK;
+    k_weighted_sum<<<cdiv(R * C, 256), 256, 0, as_stream(stream)>>>(x, ccw, R, P, C, out);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+int evd_crf_create(const evd_crf_desc* d, evd_crf** out) {
+    EVD_REQUIRE(d && out, "evd_crf_create: null argument");
+    EVD_REQUIRE(d->map_type >= 0 && d->map_type <= 2, "evd_crf_create: map_type %d", d->map_type);
+    EVD_REQUIRE(d->extra_features >= 0 && d->extra_features < CRF_MAX_IN, "evd_crf_create: extra_features %d", d->extra_features);
+    evd_crf* c = new evd_crf();
+    memset(&c->p, 0, sizeof(c->p));
+    c->p.map_type = d->map_type;
+    c->p.E = d->extra_features;
+    c->p.inv_gamma = (float)(1.0 / (double)(d->gamma != 0.f ? d->gamma : 2.2f));   // x ** (1. / gamma), tonemapping.py:68
+    if (d->map_type == 2) {
+        for (int k = 0; k < 4; ++k)
+            if (!d->w[k] || !d->b[k]) { delete c; return fail(EVD_E_INVALID, "evd_crf_create: learn CRF needs 4 weight/bias pairs"); }
+        const int nin = 1 + d->extra_features;
+        memcpy(c->p.w0, d->w[0], sizeof(float) * 16 * nin);
+        memcpy(c->p.b0, d->b[0], sizeof(float) * 16);
+        memcpy(c->p.w1, d->w[1], sizeof(float) * 256);
+        memcpy(c->p.b1, d->b[1], sizeof(float) * 16);
+        memcpy(c->p.w2, d->w[2], sizeof(float) * 256);
+        memcpy(c->p.b2, d->b[2], sizeof(float) * 16);
+        memcpy(c->p.w3, d->w[3], sizeof(float) * 16);
+        c->p.b3 = d->b[3][0];
+    }
+    *out = c;
+    return EVD_OK;
+}
+
+void evd_crf_destroy(evd_crf* c) { delete c; }
+
+int evd_crf_forward(const evd_crf* crf, const float* x, const float* feat, int feat_per_channel, int skip_learn,
+                    int luma, long n, float* out, void* stream) {
+    EVD_REQUIRE(crf && n >= 0 && out && luma <= 2, "evd_crf_forward: bad arguments");
+    if (n == 0) return EVD_OK;
+    k_crf_forward<<<cdiv(n, 256), 256, 0, as_stream(stream)>>>(crf->p, x, feat, feat_per_channel, skip_learn, luma, n, out);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+int evd_blur_loss_reduce(const evd_crf* crf_rgb, int skip_learn, const float* rgb_p, const float* rgb0_p,
+                         const float* w1, const float* w2, const float* tgt, const float* tgt0, long R, int P,
+                         float* partial, float* out_rgb, float* out_rgb1, float* out_awp, void* stream) {
+    EVD_REQUIRE(crf_rgb && rgb_p && w1 && tgt && partial && R >= 0 && P >= 1, "evd_blur_loss_reduce: bad arguments");
+    if (R == 0) return EVD_OK;
+    k_blur_loss<<<cdiv(R, 256), 256, 0, as_stream(stream)>>>(crf_rgb->p, skip_learn, rgb_p, rgb0_p, w1, w2, tgt, tgt0, R, P, partial,
+                                                             out_rgb, out_rgb1, out_awp);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+int evd_event_loss_reduce(const evd_crf* crf_ev, int skip_learn, int add_bii_feat, int tonemap_only,
+                          const float* start, const float* end, const float* start0, const float* end0,
+                          const float* cum_neg, const float* cum_pos, float thr_neg, float thr_pos,
+                          const unsigned char* color_mask, const float* color_weight, long N,
+                          float* partial, void* stream) {
+    EVD_REQUIRE(crf_ev && start && end && cum_neg && cum_pos && partial && N >= 0, "evd_event_loss_reduce: bad arguments");
+    EVD_REQUIRE(add_bii_feat >= 0 && add_bii_feat <= 2, "evd_event_loss_reduce: add_bii_feat %d", add_bii_feat);
+    EVD_REQUIRE(add_bii_feat == 0 || crf_ev->p.map_type != 2 || crf_ev->p.E == 2, "evd_event_loss_reduce: bii features need extra_features == 2");
+    EVD_REQUIRE(!color_mask || tonemap_only, "evd_event_loss_reduce: a colour mask needs tonemap_only (3-channel luma, utils/events.py:262)");
+    EVD_REQUIRE(add_bii_feat != 2 || color_mask, "evd_event_loss_reduce: color-pos-neg features need the colour mask");
+    if (N == 0) return EVD_OK;
+    const float c0 = color_weight ? color_weight[0] : 1.f, c1 = color_weight ? color_weight[1] : 1.f, c2 = color_weight ? color_weight[2] : 1.f;
+    k_event_loss<<<cdiv(N, 256), 256, 0, as_stream(stream)>>>(crf_ev->p, skip_learn, add_bii_feat, tonemap_only, start, end, start0, end0,
+                                                              cum_neg, cum_pos, thr_neg, thr_pos, color_mask, c0, c1, c2,
+                                                              color_weight != nullptr, N, partial);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+int evd_edi_deblur(const float* blurry, const float* bii, int steps, long npix, float* sharp, void* stream) {
+    EVD_REQUIRE(blurry && bii && sharp && steps >= 3 && (steps & 1) && npix >= 0, "evd_edi_deblur: steps must be odd >= 3");
+    if (npix == 0) return EVD_OK;
+    k_edi_deblur<<<cdiv(npix, 256), 256, 0, as_stream(stream)>>>(blurry, bii, steps, npix, sharp);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+int evd_edi_bii_image(const float* x, const float* y, const signed char* p, long n, int w, int h,
+                      float c_pos, float c_neg, float* image, void* stream) {
+    EVD_REQUIRE(image && w > 0 && h > 0 && n >= 0, "evd_edi_bii_image: bad arguments");
+    EVD_HIP(hipMemsetAsync(image, 0, sizeof(float) * (size_t)w * h, as_stream(stream)));
+    if (n == 0) return EVD_OK;
+    k_edi_splat<<<cdiv(n, 256), 256, 0, as_stream(stream)>>>(x, y, p, n, w, h, c_pos, c_neg, image);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+}  // extern "C"

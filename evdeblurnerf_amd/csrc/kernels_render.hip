@@ -1,0 +1,446 @@
+// Ray setup, z stratification, alpha compositing scan, inverse-CDF resampling + merge.
+// All HBM-bound elementwise / per-ray kernels of the render path (everything except the MLP GEMMs).
+#include "evd_common.h"
+
+namespace evd {
+
+constexpr int WAVE = 64;
+
+// ------------------------------------------------------------------------------------------------
+// wave-level helpers (64-wide wavefronts)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;
+}
+// inclusive product scan over the 64 lanes
+__device__ __forceinline__ float wave_scan_mul(float v, int lane) {
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        float o = __shfl_up(v, off, WAVE);
+        if (lane >= off) v *= o;
+    }
+    return v;
+}
+__device__ __forceinline__ double wave_scan_add_d(double v, int lane) {
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        double o = __shfl_up(v, off, WAVE);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// reference utils/rays.py:8-22
+struct Pose34 { float m[12]; };
+__global__ void k_get_rays(int H, int W, float k00, float k02, float k11, float k12, const Pose34 pose,
+                           float* __restrict__ ro, float* __restrict__ rd) {
+    const float* c2w = pose.m;
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (idx >= (long)H * W) return;
+    const int j = idx / W, i = idx % W;
+    const float d0 = ((float)i + (0.5f - k02)) / k00, d1 = -((float)j + (0.5f - k12)) / k11, d2 = -1.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        rd[idx * 3 + r] = __fadd_rn(__fadd_rn(__fmul_rn(d0, c2w[r * 4]), __fmul_rn(d1, c2w[r * 4 + 1])), __fmul_rn(d2, c2w[r * 4 + 2]));
+        ro[idx * 3 + r] = c2w[r * 4 + 3];
+    }
+}
+
+// reference utils/rays.py:25-36
+__global__ void k_get_rays_pix(const float* __restrict__ coords, float k00, float k02, float k11, float k12,
+                               const float* __restrict__ c2ws, long n, float* __restrict__ ro, float* __restrict__ rd) {
+    const long p = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const float* c2w = c2ws + p * 12;
+    const float d0 = (coords[p * 2] + (0.5f - k02)) / k00, d1 = -(coords[p * 2 + 1] + (0.5f - k12)) / k11, d2 = -1.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        rd[p * 3 + r] = __fadd_rn(__fadd_rn(__fmul_rn(d0, c2w[r * 4]), __fmul_rn(d1, c2w[r * 4 + 1])), __fmul_rn(d2, c2w[r * 4 + 2]));
+        ro[p * 3 + r] = c2w[r * 4 + 3];
+    }
+}
+
+// reference utils/rays.py:104-145 (unfused mul/add like the reference's elementwise tensor ops)
+__device__ __forceinline__ void ndc_one(float cw, float ch, float near, float two_near, const float o[3], const float d[3],
+                                        float oo[3], float od[3]) {
+    const float t = -__fadd_rn(near, o[2]) / d[2];
+    const float ox = __fadd_rn(o[0], __fmul_rn(t, d[0])), oy = __fadd_rn(o[1], __fmul_rn(t, d[1])),
+                oz = __fadd_rn(o[2], __fmul_rn(t, d[2]));
+    const float ox_oz = ox / oz, oy_oz = oy / oz;
+    const float o2 = __fadd_rn(1.f, two_near / oz);
+    oo[0] = __fmul_rn(cw, ox_oz);
+    oo[1] = __fmul_rn(ch, oy_oz);
+    oo[2] = o2;
+    od[0] = __fmul_rn(cw, __fsub_rn(d[0] / d[2], ox_oz));
+    od[1] = __fmul_rn(ch, __fsub_rn(d[1] / d[2], oy_oz));
+    od[2] = __fsub_rn(1.f, o2);
+}
+
+__global__ void k_ndc(float cw, float ch, float near, float two_near, const float* __restrict__ o, const float* __restrict__ d,
+                      long n, float* __restrict__ oo, float* __restrict__ od) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a[3] = {o[i * 3], o[i * 3 + 1], o[i * 3 + 2]}, b[3] = {d[i * 3], d[i * 3 + 1], d[i * 3 + 2]}, x[3], y[3];
+    ndc_one(cw, ch, near, two_near, a, b, x, y);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { oo[i * 3 + c] = x[c]; od[i * 3 + c] = y[c]; }
+}
+
+// reference networks/renderer.py:423-446: rays [R,3,2] -> ray_batch [R,ncol]
+__global__ void k_ray_batch(const float* __restrict__ rays, long R, int ndc, int use_viewdirs, float cw, float ch,
+                            float near, float far, float* __restrict__ rb) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    const int nc = use_viewdirs ? 11 : 8;
+    float o[3], d[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { o[c] = rays[i * 6 + c * 2]; d[c] = rays[i * 6 + c * 2 + 1]; }
+    float* out = rb + i * nc;
+    if (use_viewdirs) {
+        const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[8 + c] = d[c] / nrm;
+    }
+    if (ndc) {
+        float x[3], y[3];
+        ndc_one(cw, ch, 1.f, 2.f, o, d, x, y);   // get_ndc_rays(H, W, K[0][0], 1., ...) renderer.py:437
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { o[c] = x[c]; d[c] = y[c]; }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { out[c] = o[c]; out[3 + c] = d[c]; }
+    out[6] = near;
+    out[7] = far;
+}
+
+// reference networks/renderer.py:163-178
+__global__ void k_sample_z(const float* __restrict__ rb, int nc, long R, int S, int lindisp, int perturb,
+                           const float* __restrict__ t_rand, float* __restrict__ z) {
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (idx >= R * S) return;
+    const long r = idx / S;
+    const int i = idx % S;
+    const float near = rb[r * nc + 6], far = rb[r * nc + 7];
+    auto zat = [&](int k) {
+        const float t = linspace_at(0.f, 1.f, S, k);
+        return lindisp ? 1.f / __fadd_rn(__fmul_rn(1.f / near, __fsub_rn(1.f, t)), __fmul_rn(1.f / far, t))
+                       : __fadd_rn(__fmul_rn(near, __fsub_rn(1.f, t)), __fmul_rn(far, t));
+    };
+    float zi = zat(i);
+    if (perturb) {
+        const float upper = (i < S - 1) ? __fmul_rn(.5f, __fadd_rn(zat(i + 1), zi)) : zi;
+        const float lower = (i > 0) ? __fmul_rn(.5f, __fadd_rn(zi, zat(i - 1))) : zi;
+        zi = __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), t_rand[idx]));
+    }
+    z[idx] = zi;
+}
+
+// reference networks/embedding.py:88-98
+__global__ void k_embed(const float* __restrict__ x, long n, int dim, int L, float* __restrict__ out) {
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (idx >= n * dim) return;
+    const long i = idx / dim;
+    const int c = idx % dim;
+    const int od = dim * (1 + 2 * L);
+    const float v = x[idx];
+    float* o = out + i * od;
+    o[c] = v;
+    float f = 1.f;
+    for (int k = 0; k < L; ++k) {
+        const float a = v * f;
+        o[dim + 2 * k * dim + c] = sinf(a);
+        o[dim + (2 * k + 1) * dim + c] = cosf(a);
+        f *= 2.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// raw2outputs: one wavefront per ray, 64 samples per pass, transmittance carried across passes.
+// HBM-bound: reads raw (4C B) + z (4 B), writes weights (4 B) per sample.  reference networks/nerf.py:74-129,
+// networks/pdrf/voxnerf.py:153-201: density on the first S-1 samples, last alpha forced to 1,
+// T = exclusive cumprod(1 - alpha) done as a wavefront product scan.
+template <int NRGB>
+__global__ __launch_bounds__(256) void k_composite(const float* __restrict__ raw, const float* __restrict__ z,
+                                                   const float* __restrict__ rays_d, int rd_stride, long R, int S, int C,
+                                                   int sigma_ch, int rgb_ch0, int n_rgb, int rgb_act, int sigma_act,
+                                                   int white_bkgd, float rmnear, const float* __restrict__ noise,
+                                                   float* __restrict__ out_map, float* __restrict__ density,
+                                                   float* __restrict__ acc, float* __restrict__ weights,
+                                                   float* __restrict__ depth) {
+    const int lane = threadIdx.x & 63;
+    const long r = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float* d = rays_d + r * rd_stride;
+    const float norm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
+    const float* rw = raw + r * (long)S * C;
+    const float* zz = z + r * (long)S;
+    float carry = 1.f, a_sum = 0.f, d_sum = 0.f;
+    float csum[NRGB > 0 ? NRGB : 1];
+#pragma unroll
+    for (int c = 0; c < NRGB; ++c) csum[c] = 0.f;
+    for (int base = 0; base < S; base += 64) {
+        const int i = base + lane;
+        const bool valid = i < S;
+        float alpha = 0.f, zi = 0.f;
+        float rgbv[NRGB > 0 ? NRGB : 1];
+        if (valid) {
+            zi = zz[i];
+            float sraw;
+            if (NRGB == 3 && C == 4) {   // fast path: one 16-byte load per sample
+                const float4 v = reinterpret_cast<const float4*>(rw)[i];
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+                sraw = vv[sigma_ch];
+#pragma unroll
+                for (int c = 0; c < NRGB; ++c) rgbv[c] = vv[rgb_ch0 + c];
+            } else {
+                sraw = rw[(long)i * C + sigma_ch];
+#pragma unroll
+                for (int c = 0; c < NRGB; ++c) rgbv[c] = rw[(long)i * C + rgb_ch0 + c];
+            }
+            if (i < S - 1) {
+                const float dist = __fmul_rn(__fsub_rn(zz[i + 1], zi), norm);
+                if (noise) sraw = __fadd_rn(sraw, noise[r * (long)(S - 1) + i]);
+                float dens = act(sigma_act, sraw);
+                if (rmnear > 0.f) dens = (zz[i + 1] > rmnear ? 1.f : 0.f) * dens;
+                if (density) density[r * (long)(S - 1) + i] = dens;
+                alpha = __fadd_rn(-expf(-__fmul_rn(dens, dist)), 1.f);
+            } else {
+                alpha = 1.f;
+            }
+        }
+        const float om = valid ? __fadd_rn(-alpha, 1.f) : 1.f;
+        const float incl = wave_scan_mul(om, lane);
+        float excl = __shfl_up(incl, 1, WAVE);
+        if (lane == 0) excl = 1.f;
+        const float T = carry * excl;
+        const float w = valid ? alpha * T : 0.f;
+        carry *= __shfl(incl, 63, WAVE);
+        if (valid && weights) weights[r * (long)S + i] = w;
+        a_sum += w;
+        d_sum += w * zi;
+#pragma unroll
+        for (int c = 0; c < NRGB; ++c) csum[c] += valid ? w * act(rgb_act, rgbv[c]) : 0.f;
+    }
+    a_sum = wave_sum(a_sum);
+    d_sum = wave_sum(d_sum);
+#pragma unroll
+    for (int c = 0; c < NRGB; ++c) csum[c] = wave_sum(csum[c]);
+    if (lane == 0) {
+        if (acc) acc[r] = a_sum;
+        if (depth) depth[r] = d_sum;
+        if (out_map) {
+#pragma unroll
+            for (int c = 0; c < NRGB; ++c) out_map[r * n_rgb + c] = white_bkgd ? csum[c] + (1.f - a_sum) : csum[c];
+        }
+    }
+}
+
+// out[r, f] = sum_s w[r, s] * x[r, s, ch0 + f] (optionally through an activation): used for n_rgb != 3 colour
+// maps (PBE 15-channel features, voxnerf.py:226) and for feature compositing (nerf.py:119).  One block per ray.
+__global__ void k_weighted_channels(const float* __restrict__ x, const float* __restrict__ w, long R, int S, int Cx, int ch0,
+                                    int F, int act_code, int add_white, float* __restrict__ out) {
+    const long r = blockIdx.x;
+    for (int f = threadIdx.x; f < F; f += blockDim.x) {
+        float s = 0.f, a = 0.f;
+        for (int i = 0; i < S; ++i) {
+            const float wi = w[r * (long)S + i];
+            s += wi * act(act_code, x[(r * (long)S + i) * Cx + ch0 + f]);
+            a += wi;
+        }
+        out[r * (long)F + f] = add_white ? s + (1.f - a) : s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sample_pdf (utils/rays.py:149-193) on bins = z_mid, weights[1:-1] + merge (renderer.py:205,234) + z_std (:250).
+// One wavefront per ray; cdf staged in LDS.  The normalising sum and the cdf prefix sums are accumulated in
+// float64: for <= 2^29 dynamic range those sums are exact, hence independent of the scan order and bitwise equal
+// to torch's CPU cumsum (double accumulator).
+__global__ __launch_bounds__(256) void k_sample_pdf_merge(const float* __restrict__ z, const float* __restrict__ wts, long R, int S,
+                                                          int N, int det, const float* __restrict__ u,
+                                                          float* __restrict__ z_samples, float* __restrict__ z_merged,
+                                                          int* __restrict__ order, float* __restrict__ z_std) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long r = blockIdx.x * (long)(blockDim.x >> 6) + wv;
+    const int nb = S - 1;                       // bins (z_mid) = cdf entries
+    const int per = 2 * S + N + 2;              // floats of LDS per wave: z[S], cdf[nb]+pad, zs[N]
+    float* zs0 = smem_f + (long)wv * per;       // z of the coarse pass
+    float* cdf = zs0 + S;                       // [nb]
+    float* zsm = cdf + S;                       // new samples [N]
+    if (r >= R) return;
+    const float* zr = z + r * (long)S;
+    const float* wr = wts + r * (long)S;
+    for (int i = lane; i < S; i += 64) zs0[i] = zr[i];
+    // sum of (w + 1e-5) over weights[1:-1]
+    double part = 0.0;
+    for (int i = lane; i < nb - 1; i += 64) part += (double)__fadd_rn(wr[i + 1], 1e-5f);
+    const float sum = (float)wave_sum_d(part);
+    // cdf[0] = 0, cdf[k+1] = float(prefix_double(pdf))
+    double carry = 0.0;
+    for (int base = 0; base < nb - 1; base += 64) {
+        const int i = base + lane;
+        const double p = (i < nb - 1) ? (double)(__fadd_rn(wr[i + 1], 1e-5f) / sum) : 0.0;
+        const double incl = wave_scan_add_d(p, lane);
+        if (i < nb - 1) cdf[i + 1] = (float)(carry + incl);
+        carry += __shfl(incl, 63, WAVE);
+    }
+    if (lane == 0) cdf[0] = 0.f;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // invert the cdf
+    double m1 = 0.0;
+    for (int j = lane; j < N; j += 64) {
+        const float uu = det ? linspace_at(0.f, 1.f, N, j) : u[r * (long)N + j];
+        int lo = 0, hi = nb;                    // first index with cdf[idx] > uu  (searchsorted right=True)
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] <= uu) lo = mid + 1; else hi = mid; }
+        const int below = max(lo - 1, 0), above = min(lo, nb - 1);
+        float denom = __fsub_rn(cdf[above], cdf[below]);
+        if (denom < 1e-5f) denom = 1.f;
+        const float t = __fsub_rn(uu, cdf[below]) / denom;
+        const float b0 = __fmul_rn(.5f, __fadd_rn(zs0[below + 1], zs0[below]));   // z_mid on the fly (renderer.py:200)
+        const float b1 = __fmul_rn(.5f, __fadd_rn(zs0[above + 1], zs0[above]));
+        const float s = __fadd_rn(b0, __fmul_rn(t, __fsub_rn(b1, b0)));
+        zsm[j] = s;
+        if (z_samples) z_samples[r * (long)N + j] = s;
+        m1 += (double)s;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (z_std) {                                // torch.std(unbiased=False)
+        const double mean = wave_sum_d(m1) / (double)N;
+        double v = 0.0;
+        for (int j = lane; j < N; j += 64) { const double dd = (double)zsm[j] - mean; v += dd * dd; }
+        v = wave_sum_d(v);
+        if (lane == 0) z_std[r] = (float)sqrt(v / (double)N);
+    }
+    if (z_merged || order) {
+        // stable rank of every element of cat(z, z_samples): #smaller + #equal-with-lower-index
+        const int St = S + N;
+        for (int e = lane; e < St; e += 64) {
+            const float v = e < S ? zs0[e] : zsm[e - S];
+            int rank = 0;
+            for (int k = 0; k < S; ++k) { const float o = zs0[k]; rank += (o < v) || (o == v && k < e); }
+            for (int k = 0; k < N; ++k) { const float o = zsm[k]; rank += (o < v) || (o == v && (k + S) < e); }
+            if (z_merged) z_merged[r * (long)St + rank] = v;
+            if (order) order[r * (long)St + rank] = e;
+        }
+    }
+}
+
+}  // namespace evd
+
+using namespace evd;
+
+extern "C" {
+
+int evd_get_rays(int H, int W, const float* K, const float* c2w, float* rays_o, float* rays_d, void* stream) {
+    EVD_REQUIRE(H > 0 && W > 0 && K && c2w && rays_o && rays_d, "evd_get_rays: bad arguments");
+    Pose34 pose;
+    memcpy(pose.m, c2w, sizeof(pose.m));
+    const long n = (long)H * W;
+    k_get_rays<<<cdiv(n, 256), 256, 0, as_stream(stream)>>>(H, W, K[0], K[2], K[4], K[5], pose, rays_o, rays_d);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+int evd_get_rays_pix(const float* coords, const float* K, const float* c2ws, long n, float* rays_o, float* rays_d, void* stream) {
+    EVD_REQUIRE(n >= 0 && K && rays_o && rays_d, "evd_get_rays_pix: bad arguments");
+    if (n == 0) return EVD_OK;
+    k_get_rays_pix<<<cdiv(n, 256), 256, 0, as_stream(stream)>>>(coords, K[0], K[2], K[4], K[5], c2ws, n, rays_o, rays_d);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+static void ndc_coeffs(int H, int W, float focal, float* cw, float* ch) {
+    // Python doubles in the reference (utils/rays.py:135-140), rounded to float32 when they meet the tensor
+    *cw = (float)(-1.0 / ((double)W / (2.0 * (double)focal)));
+    *ch = (float)(-1.0 / ((double)H / (2.0 * (double)focal)));
+}
+
+int evd_ndc_rays(int H, int W, float focal, float near, const float* rays_o, const float* rays_d, long n,
+                 float* out_o, float* out_d, void* stream) {
+    EVD_REQUIRE(n >= 0 && out_o && out_d, "evd_ndc_rays: bad arguments");
+    if (n == 0) return EVD_OK;
+    float cw, ch;
+    ndc_coeffs(H, W, focal, &cw, &ch);
+    k_ndc<<<cdiv(n, 256), 256, 0, as_stream(stream)>>>(cw, ch, near, (float)(2.0 * (double)near), rays_o, rays_d, n, out_o, out_d);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+int evd_embed(const float* x, long n, int dim, int L, float* out, void* stream) {
+    EVD_REQUIRE(n >= 0 && dim > 0 && L >= 0 && out, "evd_embed: bad arguments");
+    if (n == 0) return EVD_OK;
+    k_embed<<<cdiv(n * dim, 256), 256, 0, as_stream(stream)>>>(x, n, dim, L, out);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+int evd_ray_batch(const evd_render_cfg* cfg, const float* rays, long R, float* ray_batch, void* stream) {
+    EVD_REQUIRE(cfg && R >= 0 && ray_batch, "evd_ray_batch: bad arguments");
+    if (R == 0) return EVD_OK;
+    float cw, ch;
+    ndc_coeffs(cfg->H, cfg->W, cfg->focal, &cw, &ch);
+    k_ray_batch<<<cdiv(R, 256), 256, 0, as_stream(stream)>>>(rays, R, cfg->ndc, cfg->use_viewdirs, cw, ch, cfg->near, cfg->far, ray_batch);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+int evd_sample_z(const evd_render_cfg* cfg, const float* ray_batch, int ncol, long R, const float* t_rand, float* z, void* stream) {
+    EVD_REQUIRE(cfg && R >= 0 && z && cfg->N_samples > 0, "evd_sample_z: bad arguments");
+    EVD_REQUIRE(!(cfg->perturb > 0.f) || t_rand, "evd_sample_z: perturb > 0 needs the explicit t_rand draw");
+    if (R == 0) return EVD_OK;
+    k_sample_z<<<cdiv(R * cfg->N_samples, 256), 256, 0, as_stream(stream)>>>(ray_batch, ncol, R, cfg->N_samples, cfg->lindisp,
+                                                                           cfg->perturb > 0.f, t_rand, z);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+int evd_raw2outputs(const float* raw, const float* z, const float* rays_d, int rays_d_stride, long R, int S, int C,
+                    int sigma_ch, int rgb_ch0, int n_rgb, int rgb_act, int sigma_act, int white_bkgd,
+                    float rmnear_thresh, const float* noise,
+                    float* out_map, float* density, float* acc, float* weights, float* depth,
+                    const float* feature, int F, float* fmap, void* stream) {
+    EVD_REQUIRE(raw && z && rays_d && R >= 0 && S >= 1 && C >= 1, "evd_raw2outputs: bad arguments");
+    EVD_REQUIRE(sigma_ch >= 0 && sigma_ch < C && rgb_ch0 >= 0 && rgb_ch0 + n_rgb <= C, "evd_raw2outputs: channel layout out of range");
+    EVD_REQUIRE(!(fmap || (n_rgb != 3 && out_map)) || weights, "evd_raw2outputs: weights output required for feature maps");
+    if (R == 0) return EVD_OK;
+    hipStream_t st = as_stream(stream);
+    if (n_rgb == 3) {
+        k_composite<3><<<cdiv(R, 4), 256, 0, st>>>(raw, z, rays_d, rays_d_stride, R, S, C, sigma_ch, rgb_ch0, n_rgb, rgb_act, sigma_act,
+                                                   white_bkgd, rmnear_thresh, noise, out_map, density, acc, weights, depth);
+    } else {
+        k_composite<0><<<cdiv(R, 4), 256, 0, st>>>(raw, z, rays_d, rays_d_stride, R, S, C, sigma_ch, rgb_ch0, n_rgb, rgb_act, sigma_act,
+                                                   white_bkgd, rmnear_thresh, noise, nullptr, density, acc, weights, depth);
+        if (out_map && n_rgb > 0)
+            k_weighted_channels<<<R, 64, 0, st>>>(raw, weights, R, S, C, rgb_ch0, n_rgb, rgb_act, white_bkgd, out_map);
+    }
+    EVD_LAUNCH_CHECK();
+    if (fmap && feature && F > 0) {
+        k_weighted_channels<<<R, F >= 256 ? 256 : 64, 0, st>>>(feature, weights, R, S, F, 0, F, EVD_ACT_NONE, 0, fmap);
+        EVD_LAUNCH_CHECK();
+    }
+    return EVD_OK;
+}
+
+int evd_sample_pdf_merge(const float* z, const float* weights, long R, int S, int N, int det, const float* u,
+                         float* z_samples, float* z_merged, int* order, float* z_std, void* stream) {
+    EVD_REQUIRE(z && weights && R >= 0 && S >= 3 && N >= 1, "evd_sample_pdf_merge: bad arguments");
+    EVD_REQUIRE(det || u, "evd_sample_pdf_merge: det == 0 needs the explicit u draw");
+    if (R == 0) return EVD_OK;
+    const size_t lds = 4 * sizeof(float) * (size_t)(2 * S + N + 2);
+    EVD_REQUIRE(lds <= 64 * 1024, "evd_sample_pdf_merge: S + N too large for the LDS staging (%zu bytes)", lds);
+    k_sample_pdf_merge<<<cdiv(R, 4), 256, lds, as_stream(stream)>>>(z, weights, R, S, N, det, u, z_samples, z_merged, order, z_std);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+}  // extern "C"

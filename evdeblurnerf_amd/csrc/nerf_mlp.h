@@ -1,0 +1,56 @@
+// Layout contract between the host-side weight packer (nerf_pack.cpp part of evd_api.hip) and the fused
+// NeRF MLP kernel (kernel_nerf_mlp.hip).
+//
+// The kernel computes every layer TRANSPOSED:  D[out_feature, sample] = W[out, in] * X[in, sample]
+//   A operand (32 x 16 per MFMA k-step) = a 32-row tile of the weight matrix       -> streamed through LDS
+//   B operand (16 x 32)                 = the activations of 32 samples            -> live in registers
+//   C/D (32 x 32, v_mfma_*_32x32x*)     : lane l, reg r holds D[(r&3) + 8(r>>2) + 4(l>>5)][l&31]
+// so a lane owns ONE sample (n = l & 31) and the half h = l >> 5 of the features.  The D fragment of
+// output tile mt is, after bias/activation/convert, directly the B fragment of the next layer's k-steps
+// 2mt and 2mt+1 (k-step j <-> features 16j..16j+15) if the K index inside a k-step is permuted:
+//      B position kk = 8h + e  (e = 0..7)   <->   feature 16j + phi(kk),  phi(kk) = 8((kk&7)>>2) + 4(kk>>3) + (kk&3)
+// The packer applies the same permutation to the weight columns, so no LDS transpose or cross-lane
+// shuffle is ever needed between layers.
+//
+// Positional-encoding inputs use a second arrangement chosen so both lane halves run the same code:
+// position q = 8j + e holds, for q < 3L: frequency k = q/3, component c = q%3 -> h=0: sin(x_c 2^k), h=1: cos(x_c 2^k);
+// q = 3L: (x_0 | x_1);  q = 3L+1: (x_2 | pad);  further positions: pad.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+
+namespace evd {
+
+constexpr int PE_L = 10;        // multires (reference options.py: --multires 10)
+constexpr int PE_LV = 4;        // multires_views
+constexpr int PE_KS = (3 * PE_L + 2 + 7) / 8;    // 4 k-steps hold the 63-wide point encoding
+constexpr int PEV_KS = (3 * PE_LV + 2 + 7) / 8;  // 2 k-steps hold the 27-wide direction encoding
+
+__host__ __device__ constexpr int phi(int kk) { return 8 * ((kk & 7) >> 2) + 4 * (kk >> 3) + (kk & 3); }
+
+// source column of the reference PE vector ([x, sin(x f0), cos(x f0), ...], networks/embedding.py:88-98)
+// for arrangement position (q, h); -1 = zero padding
+__host__ __device__ constexpr int pe_src_col(int L, int q, int h) {
+    return q < 3 * L ? 3 + 6 * (q / 3) + 3 * h + (q % 3) : (q == 3 * L ? h : (q == 3 * L + 1 ? (h == 0 ? 2 : -1) : -1));
+}
+
+constexpr int frag_bytes(int prec) { return prec == 2 /*BF16*/ ? 1024 : 2048; }
+constexpr int mlp_threads(int prec) { return prec == 2 ? 512 : 256; }
+constexpr int chunk_bytes(int prec) { return mlp_threads(prec) * 64; }
+constexpr int frags_per_chunk(int prec) { return chunk_bytes(prec) / frag_bytes(prec); }
+
+// kernel arguments of k_nerf_mlp
+struct MlpParams {
+    const char* wstream;    // packed fragment stream of the chosen precision
+    const float* bias;      // 32 floats per output tile, stream order
+    const float* ray_batch; // [R, ncol]
+    const float* z;         // [R, S]
+    long nsamp;             // R * S
+    int S, ncol, D, skip, nchunks;
+    float* raw;             // [R, S, 4]
+    float* feature;         // [R, S, W] or null
+    int feature_kind;       // 0 none, 1 after_linear, 2 before_linear
+};
+
+}  // namespace evd

@@ -1,0 +1,139 @@
+"""Loss-side pixel ops of the path: rbk_weighted_sum (networks/dpnerf/blurmodel.py:112-127), img2mse
+(utils/metrics.py:7), egm_loss (utils/events.py:260-284) and the two fused per-step reductions whose
+packed partial sums are what data-parallel ranks all-reduce (spec: run_nerf.py:443-497, 518-591)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+BLUR_PARTIALS = 8    # [se_rgb, se_rgb1, se_awp, se_pts0_fine, se_pts0_coarse, n_elem, -, -]
+EVENT_PARTIALS = 4   # [sum w (pred-bii)^2 fine, same coarse, sum w, -]
+
+
+def weighted_sum(x, ccw):
+    """out[r] = sum_p ccw[r,p] x[r*P+p]; x [R*P, ...] -> [R, ...]."""
+    ccw = ccw.contiguous().float()
+    R, P = ccw.shape
+    xx = x.contiguous().float()
+    Cc = int(np.prod(xx.shape[1:])) if xx.ndim > 1 else 1
+    out = torch.empty((R, Cc), dtype=torch.float32, device=xx.device)
+    L.check(L.lib().evd_weighted_sum(L.ptr(xx), L.ptr(ccw), R, P, Cc, L.ptr(out), L.stream_ptr()), "evd_weighted_sum")
+    return out.reshape((R,) + tuple(xx.shape[1:]))
+
+
+def rbk_weighted_sum(rgb, depth, acc, extras, ccw):
+    """networks/dpnerf/blurmodel.py:112-127 (same return tuple; every extras entry reduced)."""
+    out = {k: weighted_sum(v, ccw) for k, v in extras.items()}
+    return weighted_sum(rgb, ccw), weighted_sum(depth, ccw), weighted_sum(acc, ccw), out
+
+
+def blur_loss_partials(crf_rgb, rgb_p, w1, target, rgb0_p=None, w2=None, target_pts0=None, skip_learn_crf=False,
+                       partial=None, want_colours=False):
+    """One launch for the whole image-loss block. Returns (partial [8], colours dict)."""
+    w1 = w1.contiguous().float()
+    R, P = w1.shape
+    dev = w1.device
+    if partial is None:
+        partial = torch.zeros((BLUR_PARTIALS,), dtype=torch.float32, device=dev)
+    c = lambda t: t.contiguous().float() if t is not None else None
+    rgb_p, rgb0_p, w2, target, target_pts0 = c(rgb_p), c(rgb0_p), c(w2), c(target), c(target_pts0)
+    cols = {}
+    if want_colours:
+        cols = {"rgb": torch.empty((R, 3), dtype=torch.float32, device=dev)}
+        if rgb0_p is not None:
+            cols["rgb1"] = torch.empty((R, 3), dtype=torch.float32, device=dev)
+        if w2 is not None:
+            cols["rgb_awp"] = torch.empty((R, 3), dtype=torch.float32, device=dev)
+    L.check(L.lib().evd_blur_loss_reduce(crf_rgb.handle, int(bool(skip_learn_crf)), L.ptr(rgb_p), L.ptr(rgb0_p), L.ptr(w1),
+                                         L.ptr(w2), L.ptr(target), L.ptr(target_pts0), R, P, L.ptr(partial),
+                                         L.ptr(cols.get("rgb")), L.ptr(cols.get("rgb1")), L.ptr(cols.get("rgb_awp")),
+                                         L.stream_ptr()), "evd_blur_loss_reduce")
+    return partial, cols
+
+
+def blur_loss_from_partials(p, fine_loss_weight=None, w_pts0=0.0):
+    """Assemble run_nerf.py:451-497 from the (all-reduced) partial vector. Returns (loss, dict of terms)."""
+    n = p[5]
+    img = p[0] / n + p[1] / n
+    terms = {"img_loss": img}
+    loss = img
+    if fine_loss_weight is not None:
+        fine = p[2] / n
+        terms["img_fine_loss"] = fine
+        loss = loss * (1 - fine_loss_weight) + fine * fine_loss_weight
+    pts0 = p[3] / n + p[4] / n
+    terms["pts0"] = pts0
+    loss = loss + pts0 * w_pts0
+    return loss, terms
+
+
+def event_loss_partials(crf_ev, start, end, cum_neg, cum_pos, thr_neg, thr_pos, start0=None, end0=None,
+                        add_bii="pos-neg", tonemap_only=False, color_mask=None, color_weight=None,
+                        skip_learn_crf=False, partial=None):
+    dev = start.device
+    if partial is None:
+        partial = torch.zeros((EVENT_PARTIALS,), dtype=torch.float32, device=dev)
+    c = lambda t: t.contiguous().float() if t is not None else None
+    start, end, start0, end0, cum_neg, cum_pos = c(start), c(end), c(start0), c(end0), c(cum_neg), c(cum_pos)
+    N = start.shape[0]
+    cm = color_mask.contiguous().to(torch.uint8) if color_mask is not None else None
+    cw = np.ascontiguousarray(color_weight, dtype=np.float32) if color_weight is not None else None
+    mode = {None: 0, "none": 0, "pos-neg": 1, "color-pos-neg": 2}[add_bii]
+    L.check(L.lib().evd_event_loss_reduce(crf_ev.handle, int(bool(skip_learn_crf)), mode, int(bool(tonemap_only)),
+                                          L.ptr(start), L.ptr(end), L.ptr(start0), L.ptr(end0), L.ptr(cum_neg), L.ptr(cum_pos),
+                                          float(thr_neg), float(thr_pos), L.ptr(cm),
+                                          cw.ctypes.data_as(C.POINTER(C.c_float)) if cw is not None else None, N,
+                                          L.ptr(partial), L.stream_ptr()), "evd_event_loss_reduce")
+    return partial
+
+
+def event_loss_from_partials(p, stages=("stage0", "stage1")):
+    """extra_loss['event_egm'] of run_nerf.py:559-572 from the (all-reduced) partials."""
+    loss = 0.0
+    if "stage0" in stages:
+        loss = loss + p[1] / p[2]
+    if "stage1" in stages:
+        loss = loss + p[0] / p[2]
+    return loss
+
+
+def img2mse(x, y):
+    """utils/metrics.py:7 through the fused reduction (identity CRF, P = 1)."""
+    from .tonemapping import CRF
+    xx = x.reshape(-1, 3)
+    ones = torch.ones((xx.shape[0], 1), dtype=torch.float32, device=xx.device)
+    p, _ = blur_loss_partials(_identity_crf(), xx, ones, y.reshape(-1, 3))
+    return p[0] / p[5]
+
+
+_ID_CRF = None
+
+
+def _identity_crf():
+    global _ID_CRF
+    if _ID_CRF is None:
+        from .tonemapping import CRF
+        _ID_CRF = CRF("none")
+    return _ID_CRF
+
+
+def egm_loss(luma_start, luma_end, bii, color_mask=None, color_weight=None, log_eps=1e-5):
+    """utils/events.py:260-284 on already tone-mapped lumas ([N,1] or [N,3] + one-hot mask)."""
+    assert log_eps == 1e-5
+    N = luma_start.shape[0]
+    if luma_start.shape[-1] == 1:
+        ls, le = luma_start.expand(N, 3), luma_end.expand(N, 3)
+        cm = torch.zeros((N, 3), dtype=torch.uint8, device=ls.device)
+        cm[:, 0] = 1
+        cw = None
+    else:
+        ls, le, cm, cw = luma_start, luma_end, color_mask, color_weight
+    zeros = torch.zeros((N,), dtype=torch.float32, device=ls.device)
+    # bii enters as thr_neg * cum_neg with thr_neg = 1, cum_neg = bii
+    p = event_loss_partials(_identity_crf(), ls, le, bii, zeros, 1.0, 0.0, add_bii=None, tonemap_only=True,
+                            color_mask=cm, color_weight=cw)
+    return p[0] / p[2]

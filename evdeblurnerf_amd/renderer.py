@@ -1,0 +1,258 @@
+"""Mirror of the reference ``networks/renderer.py`` ``NeRFAll`` on libevdnerf.so.
+
+Same method names, argument meaning, return conventions and result-dict keys as the reference
+(render :399, render_rays :129, render_path :594, forward :266), so ``run_nerf.py`` can call this object
+where it calls ``NeRFAll``. Differences, all forced by moving the random draws and the MLP into kernels:
+
+* random draws are explicit: ``t_rand`` / ``u`` / noise tensors may be passed (keyword-only); when omitted
+  and needed they are drawn with torch on the GPU (same distributions as renderer.py:176, rays.py:162,
+  nerf.py:99);
+* the NaN/Inf guard of render_rays (:259-263, two host syncs per key) is opt-in (``check_numerics=True``);
+* ``chunk`` is accepted and honoured, but defaults large: 288 GB of HBM make the reference's memory
+  chunking unnecessary.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+import types
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .nerf import NeRF
+from .rays import get_rays
+
+
+def _args_get(args, name, default):
+    return getattr(args, name, default)
+
+
+class NeRFAll:
+    """mode='nerf' renderer (two NeRF MLPs). mode='c2f' (PDRF) lives in renderer_c2f once built."""
+
+    def __init__(self, args, state_dict, kernelsnet=None, awpnet=None, precision="f16x3", device=None):
+        self.args = args
+        self.mode = args.mode
+        if self.mode != "nerf":
+            raise NotImplementedError(f"mode {self.mode!r}: only 'nerf' is built in this round (see DESIGN.md)")
+        self.kernel_type = _args_get(args, "kernel_type", None)
+        self.kernelsnet = kernelsnet
+        self.awpnet = awpnet
+        self.use_awp = bool(_args_get(args, "kernel_use_awp", False)) and awpnet is not None
+        self.extract_feature = "before_linear" if self.use_awp else "after_linear"
+        self.precision = precision
+        self.training = False
+        self.device = torch.device(device or "cuda")
+        common = dict(D=args.netdepth, W=args.netwidth, multires=args.multires, multires_views=args.multires_views,
+                      rgb_activate=args.rgb_activate, sigma_activate=args.sigma_activate,
+                      render_rmnearplane=_args_get(args, "render_rmnearplane", 0),
+                      extract_feature=self.extract_feature, composite_feature=False, precision=precision)
+        if not args.use_viewdirs:
+            raise NotImplementedError("use_viewdirs=False networks are not supported (no shipped config uses them)")
+        self.mlp_coarse = NeRF(state_dict, "mlp_coarse.", **common)
+        self.mlp_fine = None
+        if args.N_importance > 0:
+            common_f = dict(common, D=_args_get(args, "netdepth_fine", args.netdepth), W=_args_get(args, "netwidth_fine", args.netwidth))
+            self.mlp_fine = NeRF(state_dict, "mlp_fine.", **common_f)
+        self._ws = None
+
+    # nn.Module-like switches used by run_nerf.py
+    def train(self, mode=True):
+        self.training = mode
+        self.mlp_coarse.train(mode)
+        if self.mlp_fine is not None:
+            self.mlp_fine.train(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def _cfg(self, H, W, focal, ndc, near, far, N_samples, N_importance, lindisp, perturb, white_bkgd):
+        c = L.RenderCfg()
+        c.H, c.W, c.focal = int(H), int(W), float(focal)
+        c.ndc, c.use_viewdirs, c.lindisp = int(bool(ndc)), 1, int(bool(lindisp))
+        c.N_samples, c.N_importance, c.white_bkgd = int(N_samples), int(N_importance), int(bool(white_bkgd))
+        c.near, c.far, c.perturb = float(near), float(far), float(perturb)
+        c.is_train, c.precision = int(self.training), L.PREC[self.precision]
+        return c
+
+    def _workspace(self, cfg, R):
+        need = int(L.lib().evd_nerf_render_workspace_bytes(C.byref(cfg), R))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty((need,), dtype=torch.uint8, device=self.device)
+        return self._ws, need
+
+    # ------------------------------------------------------------------ render_rays, renderer.py:129-264
+    def render_rays(self, ray_batch, N_samples, retraw=False, lindisp=False, perturb=0., N_importance=0,
+                    white_bkgd=False, raw_noise_std=0., pytest=False, force_naive=False, inference=False, *,
+                    t_rand=None, u=None, noise0=None, noise1=None, check_numerics=False, _cfg=None, _rays=None):
+        dev = self.device
+        if _rays is None:
+            rb = ray_batch.contiguous().float()
+            R = rb.shape[0]
+            if rb.shape[1] != 11:
+                raise L.EvdError("render_rays needs the 11-column ray batch (o, d, near, far, viewdirs)")
+        else:
+            rb, R = None, _rays.shape[0]
+        cfg = _cfg or self._cfg(0, 0, 1.0, False, 0., 1., N_samples, N_importance, lindisp, perturb, white_bkgd)
+        cfg.N_samples, cfg.N_importance, cfg.lindisp = int(N_samples), int(N_importance), int(bool(lindisp))
+        cfg.perturb, cfg.white_bkgd, cfg.is_train = float(perturb), int(bool(white_bkgd)), int(self.training)
+        S, Ni = int(N_samples), int(N_importance)
+        St = S + Ni
+        f32 = dict(dtype=torch.float32, device=dev)
+        if perturb > 0.:
+            if t_rand is None:
+                t_rand = torch.rand((R, S), **f32)
+            if Ni > 0 and u is None:
+                u = torch.rand((R, Ni), **f32)
+        if raw_noise_std > 0.:
+            if noise0 is None:
+                noise0 = torch.randn((R, S - 1), **f32) * raw_noise_std
+            if Ni > 0 and noise1 is None:
+                noise1 = torch.randn((R, St - 1), **f32) * raw_noise_std
+        want_feat = self.use_awp and not force_naive and not inference
+        ret = {"rgb_map": torch.empty((R, 3), **f32), "depth_map": torch.empty((R,), **f32),
+               "acc_map": torch.empty((R,), **f32)}
+        out = L.RenderOut()
+        out.rgb, out.depth, out.acc = L.ptr(ret["rgb_map"]), L.ptr(ret["depth_map"]), L.ptr(ret["acc_map"])
+        if retraw or want_feat:
+            ret["z_vals"] = torch.empty((R, St), **f32)
+            out.z_vals = L.ptr(ret["z_vals"])
+        if retraw:
+            ret["weights"] = torch.empty((R, St), **f32)
+            out.weights = L.ptr(ret["weights"])
+        if Ni > 0:
+            ret["rgb0"], ret["depth0"], ret["acc0"] = torch.empty((R, 3), **f32), torch.empty((R,), **f32), torch.empty((R,), **f32)
+            ret["z_std"] = torch.empty((R,), **f32)
+            out.rgb0, out.depth0, out.acc0, out.z_std = (L.ptr(ret["rgb0"]), L.ptr(ret["depth0"]), L.ptr(ret["acc0"]),
+                                                         L.ptr(ret["z_std"]))
+            if retraw:
+                ret["z_vals0"], ret["weights0"] = torch.empty((R, S), **f32), torch.empty((R, S), **f32)
+                out.z_vals0, out.weights0 = L.ptr(ret["z_vals0"]), L.ptr(ret["weights0"])
+        if want_feat:
+            ret["depth_feature"] = torch.empty((R, St, (self.mlp_fine or self.mlp_coarse).W), **f32)
+            out.feature = L.ptr(ret["depth_feature"])
+        out.feature_kind = 2 if self.extract_feature == "before_linear" else 1
+        ws, need = self._workspace(cfg, R)
+        fine = self.mlp_fine.handle if (Ni > 0 and self.mlp_fine is not None) else None
+        tr = t_rand.contiguous().float() if t_rand is not None else None
+        uu = u.contiguous().float() if u is not None else None
+        n0 = noise0.contiguous().float() if noise0 is not None else None
+        n1 = noise1.contiguous().float() if noise1 is not None else None
+        if _rays is None:
+            L.check(L.lib().evd_nerf_render_rays(self.mlp_coarse.handle, fine, C.byref(cfg), L.ptr(rb), R, L.ptr(tr), L.ptr(uu),
+                                                 L.ptr(n0), L.ptr(n1), C.byref(out), L.ptr(ws), need, L.stream_ptr()),
+                    "evd_nerf_render_rays")
+        else:
+            L.check(L.lib().evd_nerf_render(self.mlp_coarse.handle, fine, C.byref(cfg), L.ptr(_rays), R, L.ptr(tr), L.ptr(uu),
+                                            L.ptr(n0), L.ptr(n1), C.byref(out), L.ptr(ws), need, L.stream_ptr()),
+                    "evd_nerf_render")
+        if not retraw and "z_vals" in ret and not want_feat:
+            del ret["z_vals"]
+        if check_numerics:
+            for k in ret:
+                if torch.isnan(ret[k]).any():
+                    print(f"! [Numerical Error] {k} contains nan.")
+                if torch.isinf(ret[k]).any():
+                    print(f"! [Numerical Error] {k} contains inf.")
+        return ret
+
+    # ------------------------------------------------------------------ render, renderer.py:399-466
+    def render(self, H, W, K, chunk=1 << 22, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,
+               c2w_staticcam=None, **kwargs):
+        if not use_viewdirs:
+            raise NotImplementedError("use_viewdirs=False is not supported")
+        if c2w_staticcam is not None:
+            raise NotImplementedError("c2w_staticcam (viewdir visualisation) is not supported")
+        focal = float(K[0][0])
+        rays = rays.to(self.device).float()
+        sh = rays.shape[:-2]                      # [..., 3, 2]
+        flat = rays.reshape(-1, 3, 2).contiguous()
+        R = flat.shape[0]
+        N_samples = kwargs.get("N_samples")
+        cfg = self._cfg(H, W, focal, ndc, near, far, N_samples, kwargs.get("N_importance", 0), kwargs.get("lindisp", False),
+                        kwargs.get("perturb", 0.), kwargs.get("white_bkgd", False))
+        all_ret = {}
+        rand_keys = ("t_rand", "u", "noise0", "noise1")
+        for i in range(0, max(1, R), chunk):
+            kw = dict(kwargs)
+            for k in rand_keys:
+                if kw.get(k) is not None:
+                    kw[k] = kw[k][i:i + chunk]
+            ret = self.render_rays(None, _cfg=cfg, _rays=flat[i:i + chunk], **kw)
+            for k, v in ret.items():
+                all_ret.setdefault(k, []).append(v)
+        all_ret = {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in all_ret.items()}
+        for k in all_ret:
+            all_ret[k] = all_ret[k].reshape(list(sh) + list(all_ret[k].shape[1:]))
+        k_extract = ["rgb_map", "depth_map", "acc_map"]
+        ret_list = [all_ret[k] for k in k_extract]
+        ret_dict = {k: all_ret[k] for k in all_ret if k not in k_extract}
+        if self.use_awp:
+            # NDC ray directions, renderer.py:464-465
+            from .rays import get_ndc_rays
+            rd = flat[..., 1]
+            if ndc:
+                _, rd = get_ndc_rays(H, W, focal, 1., flat[..., 0].contiguous(), rd.contiguous())
+            ret_dict["rays_d"] = rd.reshape(-1, 3)
+        return ret_list + [ret_dict]
+
+    # ------------------------------------------------------------------ render_path, renderer.py:594-626
+    def render_path(self, H, W, K, chunk, render_poses, render_kwargs, render_factor=0):
+        if render_factor != 0:
+            H, W = H // render_factor, W // render_factor
+        rgbs, depths = [], []
+        for c2w in render_poses:
+            dev = c2w.device if isinstance(c2w, torch.Tensor) else torch.device("cpu")
+            o, d = get_rays(H, W, K, c2w if isinstance(c2w, torch.Tensor) else torch.as_tensor(c2w))
+            rays = torch.stack([o, d], dim=-1)
+            rgb, depth, acc, extras = self.render(H, W, K, chunk=chunk, rays=rays, **render_kwargs)
+            rgbs.append(rgb.to(dev))
+            depths.append(depth.to(dev))
+        return torch.stack(rgbs, 0), torch.stack(depths, 0)
+
+    # ------------------------------------------------------------------ forward, renderer.py:266-397
+    def forward(self, H, W, K, chunk=1 << 22, rays=None, rays_info=None, poses=None, **kwargs):
+        if not self.training:
+            assert poses is not None, "Please specify poses when in the eval model"
+            return self.render_path(H, W, K, chunk, poses, **kwargs)
+        assert rays is not None, "Please specify rays when in the training mode"
+        force_baseline = kwargs.pop("force_naive", True)
+        return_pts0_rgb = kwargs.pop("return_pts0_rgb", False)
+        N_importance = kwargs.get("N_importance", 0)
+        other_loss, other_tensors = {}, {}
+        if self.kernelsnet is not None and not force_baseline:
+            if self.kernel_type != "RBK":
+                raise NotImplementedError("only the RBK kernel of the shipped configs is supported")
+            from .losses import weighted_sum
+            new_rays, weight1, align_loss, extra1 = self.kernelsnet(H, W, K, rays, rays_info, feats=None,
+                                                                    return_img_embed=self.use_awp)
+            extra1 = {f"stage1_{k}": v for k, v in extra1.items()}
+            ray_num, pt_num = new_rays.shape[:2]
+            rgb, depth, acc, extras = self.render(H, W, K, chunk, new_rays.reshape(-1, 3, 2), **kwargs)
+            rgb_pts = rgb.reshape(ray_num, pt_num, 3)
+            rgb1_pts = extras["rgb0"].reshape(ray_num, pt_num, 3) if N_importance > 0 else None
+            if self.use_awp:
+                ccw_fine = self.awpnet(extras["depth_feature"], extras["z_vals"], extras["rays_d"], extra1["stage1_img_embed"])
+                ccw_fine = ccw_fine + ccw_fine * self.awpnet.ccw_fine_scale
+                ccw_fine = ccw_fine / torch.sum(ccw_fine, -1, keepdim=True)
+                other_tensors["rgb_awp"] = weighted_sum(rgb, ccw_fine)
+            rgb_out = weighted_sum(rgb, weight1)
+            rgb1 = weighted_sum(extras["rgb0"], weight1) if N_importance > 0 else None
+            if align_loss is not None:
+                other_loss["align"] = align_loss.reshape(1, 1)
+            other_tensors.update(extra1)
+            if return_pts0_rgb:
+                other_tensors["stage1_rgb_pts0"] = rgb_pts[:, 0]
+                if N_importance > 0:
+                    other_tensors["stage1_rgb1_pts0"] = rgb1_pts[:, 0]
+            return rgb_out, rgb1, other_loss, other_tensors
+        rgb, depth, acc, extras = self.render(H, W, K, chunk, rays, **kwargs)
+        other_tensors["stage1_rgb_pts0"] = rgb
+        if N_importance > 0:
+            other_tensors["stage1_rgb1_pts0"] = extras["rgb0"]
+        return rgb, extras["rgb0"] if "rgb0" in extras else None, other_loss, other_tensors
+
+    __call__ = forward

@@ -1,0 +1,205 @@
+/*
+ * evdnerf.h -- C ABI of libevdnerf.so: the MI355X (gfx950) renderer + blur/event-loss hot path of
+ * EvDeblurNeRF, written as HIP kernels.  This is the drop-in boundary: the reference has no FFI
+ * layer (it is pure PyTorch), so every entry point below replaces one Python function of the reference
+ * (cited as file:line, paths relative to the reference checkout) and the Python mirror in
+ * evdeblurnerf_amd/ binds them with ctypes (INTEGRATION.md shows the stub a maintainer would add).
+ *
+ * Conventions
+ *   - every pointer marked "dev" is device memory (HBM) owned by the caller; tensors are float32,
+ *     contiguous, row-major; "host" pointers are plain host memory read during the call only.
+ *   - every entry returns 0 (EVD_OK) or a negative EVD_E* code; evd_last_error() gives the message
+ *     of the last failure on the calling thread.
+ *   - kernels are enqueued on the caller's HIP stream (void* = hipStream_t); no entry synchronises,
+ *     allocates in the hot path, or touches global mutable state.  Scratch memory comes from the caller
+ *     (evd_*_workspace_bytes).  Opaque handles own only their packed parameters.
+ *   - NULL output pointers mean "not wanted".
+ */
+#ifndef EVDNERF_H
+#define EVDNERF_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EVD_OK 0
+#define EVD_E_INVALID (-1)      /* bad argument / unsupported configuration */
+#define EVD_E_HIP (-2)          /* a HIP runtime call failed */
+#define EVD_E_WORKSPACE (-3)    /* workspace too small */
+#define EVD_E_NODEVICE (-4)     /* no gfx950 device */
+
+#define EVD_MAX_LAYERS 16
+
+/* arithmetic of the per-sample MLP GEMMs (accumulation is always float32) */
+#define EVD_PREC_F32 0      /* v_mfma_f32_32x32x2_f32: exact float32 products (bitwise an fmaf chain) */
+#define EVD_PREC_F16X3 1    /* operands split hi+lo into two float16, 3 x v_mfma_f32_32x32x16_f16: ~2^-21 products */
+#define EVD_PREC_BF16 2     /* v_mfma_f32_32x32x16_bf16: throughput mode, ~2^-8 operands */
+
+/* activation codes: reference networks/nerf.py:31-33, networks/pdrf/voxnerf.py:28-30 */
+#define EVD_ACT_NONE 0
+#define EVD_ACT_RELU 1
+#define EVD_ACT_SIGMOID 2
+#define EVD_ACT_EXP 3
+#define EVD_ACT_SIGMOID1 4
+#define EVD_ACT_SOFTPLUS 5
+#define EVD_ACT_TANH 6
+
+const char* evd_last_error(void);
+int evd_version(void);
+/* number of gfx950 devices visible; <0 on error */
+int evd_device_count(void);
+
+/* ---------------------------------------------------------------- rays (reference utils/rays.py) */
+/* get_rays, utils/rays.py:8-22.  K host[9], c2w host[12] -> rays_o/rays_d dev [H,W,3] */
+int evd_get_rays(int H, int W, const float* K, const float* c2w, float* rays_o, float* rays_d, void* stream);
+/* get_rays_pix, utils/rays.py:25-36.  coords dev [n,2], c2ws dev [n,3,4], K host[9] */
+int evd_get_rays_pix(const float* coords, const float* K, const float* c2ws, long n,
+                     float* rays_o, float* rays_d, void* stream);
+/* get_ndc_rays, utils/rays.py:104-145 */
+int evd_ndc_rays(int H, int W, float focal, float near, const float* rays_o, const float* rays_d, long n,
+                 float* out_o, float* out_d, void* stream);
+/* Embedder.forward, networks/embedding.py:88-98.  x dev [n,dim] -> out dev [n, dim*(1+2L)] */
+int evd_embed(const float* x, long n, int dim, int L, float* out, void* stream);
+
+/* ---------------------------------------------------------------- render configuration
+ * arguments of NeRFAll.render / render_rays (networks/renderer.py:399-466, 129-264) */
+typedef struct {
+    int H, W;
+    float focal;            /* K[0][0] */
+    int ndc, use_viewdirs, lindisp, N_samples, N_importance, white_bkgd;
+    float near, far, perturb;
+    int is_train;           /* nn.Module.training: gates render_rmnearplane (nerf.py:107) */
+    int precision;          /* EVD_PREC_* for the MLP GEMMs */
+} evd_render_cfg;
+
+/* NeRFAll.render ray packing, networks/renderer.py:423-446: rays dev [R,3,2] -> ray_batch dev [R,11]
+ * = o(3) d(3) near far viewdir(3); viewdir = d/|d| before the NDC warp.  (8 columns when !use_viewdirs) */
+int evd_ray_batch(const evd_render_cfg* cfg, const float* rays, long R, float* ray_batch, void* stream);
+/* z stratification, networks/renderer.py:163-178.  t_rand dev [R,S] is the explicit torch.rand draw
+ * (required when cfg->perturb > 0).  -> z dev [R,S] */
+int evd_sample_z(const evd_render_cfg* cfg, const float* ray_batch, int ncol, long R, const float* t_rand,
+                 float* z, void* stream);
+
+/* ---------------------------------------------------------------- NeRF backbone (networks/nerf.py) */
+typedef struct evd_nerf evd_nerf;   /* opaque: packed MFMA-fragment weight streams on one device */
+
+typedef struct {                    /* host float32 pointers, nn.Linear layout [out,in] (state_dict arrays) */
+    int D, W, multires, multires_views, skip;
+    int rgb_act, sigma_act;         /* EVD_ACT_* (nerf.py:34-35) */
+    float rmnear;                   /* render_rmnearplane */
+    const float *pts_w[EVD_MAX_LAYERS], *pts_b[EVD_MAX_LAYERS];
+    const float *views_w, *views_b, *feature_w, *feature_b, *alpha_w, *alpha_b, *rgb_w, *rgb_b; /* rgb_b may be NULL */
+} evd_nerf_desc;
+
+int evd_nerf_create(const evd_nerf_desc* desc, evd_nerf** out);
+void evd_nerf_destroy(evd_nerf* net);
+/* bytes of the packed weight stream for a precision (what one workgroup streams per sample tile) */
+size_t evd_nerf_stream_bytes(const evd_nerf* net, int precision);
+
+/* NeRF.mlpforward + NeRF.eval, networks/nerf.py:46-72,131-162, fused with the point computation
+ * pts = o + d z (renderer.py:180) and both positional encodings.  ray_batch dev [R,11], z dev [R,S]
+ * -> raw dev [R,S,4] = (rgb, alpha);  feature dev [R,S,W] optional: feature_kind 1 = "after_linear"
+ * (nerf.py:149-150), 2 = "before_linear" (:141-142). */
+int evd_nerf_mlp(const evd_nerf* net, int precision, const float* ray_batch, const float* z, long R, int S,
+                 float* raw, float* feature, int feature_kind, void* stream);
+
+/* raw2outputs: networks/nerf.py:74-129 (sigma_ch 3, rgb_ch0 0) and networks/pdrf/voxnerf.py:153-201
+ * (sigma_ch 0, rgb_ch0 1).  raw dev [R,S,C], z dev [R,S], rays_d dev rows of rays_d_stride floats.
+ * noise dev [R,S-1] optional (explicit randn*raw_noise_std draw).  rmnear_thresh <= 0 disables the
+ * eval near-plane mask.  Outputs: out_map [R,n_rgb], density [R,S-1], acc [R], weights [R,S],
+ * depth [R], fmap [R,F] = sum_s w feature[R,S,F]. */
+int evd_raw2outputs(const float* raw, const float* z, const float* rays_d, int rays_d_stride, long R, int S, int C,
+                    int sigma_ch, int rgb_ch0, int n_rgb, int rgb_act, int sigma_act, int white_bkgd,
+                    float rmnear_thresh, const float* noise,
+                    float* out_map, float* density, float* acc, float* weights, float* depth,
+                    const float* feature, int F, float* fmap, void* stream);
+
+/* sample_pdf, utils/rays.py:149-193, called as in renderer.py:200-201,230-231 with bins = z_mid and
+ * weights[...,1:-1]: z dev [R,S], weights dev [R,S] -> z_samples dev [R,N].  det != 0 => u = linspace;
+ * else u dev [R,N].  Also returns, fused: z_merged dev [R,S+N] = sort(cat(z, z_samples)) (renderer.py:205,234),
+ * order dev int32 [R,S+N] (index into the concatenation, as torch.sort's second result), z_std dev [R]
+ * (renderer.py:250). */
+int evd_sample_pdf_merge(const float* z, const float* weights, long R, int S, int N, int det, const float* u,
+                         float* z_samples, float* z_merged, int* order, float* z_std, void* stream);
+
+typedef struct {        /* result dict of render_rays, networks/renderer.py:242-257; dev pointers or NULL */
+    float *rgb, *depth, *acc;                   /* rgb_map [R,3], depth_map [R], acc_map [R] */
+    float *z_vals, *weights;                    /* [R, N_samples+N_importance] */
+    float *rgb0, *depth0, *acc0, *z_std;        /* coarse pass (N_importance > 0) */
+    float *z_vals0, *weights0;                  /* [R, N_samples] */
+    float *feature;                             /* per-sample feature of the last pass [R,S_final,F] */
+    float *raw;                                 /* raw network output of the last pass [R,S_final,4] */
+    int feature_kind;                           /* NeRF: 1 after_linear, 2 before_linear */
+} evd_render_out;
+
+size_t evd_nerf_render_workspace_bytes(const evd_render_cfg* cfg, long R);
+/* NeRFAll.render_rays for mode='nerf' (networks/renderer.py:129-264, else-branch :218-240): ray_batch dev [R,11].
+ * fine may be NULL iff N_importance == 0.  Explicit random draws (the reference calls torch.rand / randn
+ * inside): t_rand dev [R,N_samples] and u dev [R,N_importance] when perturb > 0; noise0 dev [R,N_samples-1] /
+ * noise1 dev [R,N_samples+N_importance-1] = randn * raw_noise_std (NULL = no density noise). */
+int evd_nerf_render_rays(const evd_nerf* coarse, const evd_nerf* fine, const evd_render_cfg* cfg, const float* ray_batch,
+                         long R, const float* t_rand, const float* u, const float* noise0, const float* noise1,
+                         evd_render_out* out, void* workspace, size_t workspace_bytes, void* stream);
+/* NeRFAll.render (networks/renderer.py:399-466) = evd_ray_batch + evd_nerf_render_rays: rays dev [R,3,2] */
+int evd_nerf_render(const evd_nerf* coarse, const evd_nerf* fine, const evd_render_cfg* cfg, const float* rays, long R,
+                    const float* t_rand, const float* u, const float* noise0, const float* noise1,
+                    evd_render_out* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------- loss-side pixel ops */
+/* RigidBlurringModel.rbk_weighted_sum, networks/dpnerf/blurmodel.py:112-127 (and renderer.py:299,332-354):
+ * out[r,c] = sum_p ccw[r,p] x[r*P+p, c] */
+int evd_weighted_sum(const float* x, const float* ccw, long R, int P, int C, float* out, void* stream);
+
+typedef struct evd_crf evd_crf;     /* opaque: CRF MLP parameters (networks/tonemapping.py:7-93) */
+typedef struct {
+    int map_type;                   /* 0 none, 1 gamma, 2 learn */
+    float gamma;
+    int extra_features;
+    const float *w[4], *b[4];       /* host: linear.{0,2,4,6}.{weight,bias} when map_type == 2 */
+} evd_crf_desc;
+int evd_crf_create(const evd_crf_desc* desc, evd_crf** out);
+void evd_crf_destroy(evd_crf* crf);
+/* CRF.forward (+ rec601/rec709/avg luma of TonemappingTransform.encode_luma, tonemapping.py:120-139).
+ * x dev [n,3]; feat dev NULL | [n,E] (feat_per_channel 0) | [n,3,E] (1).  luma < 0: out [n,3];
+ * luma 0/1/2 = rec601/rec709/avg: out [n,1]. */
+int evd_crf_forward(const evd_crf* crf, const float* x, const float* feat, int feat_per_channel, int skip_learn,
+                    int luma, long n, float* out, void* stream);
+
+/* Fused blur-loss reduction for one pixel batch (spec: run_nerf.py:443-497 + rbk_weighted_sum):
+ *   rgb   = sum_p w1[r,p] rgb_p[r,p]       rgb1 = sum_p w1[r,p] rgb0_p[r,p]     awp = sum_p w2[r,p] rgb_p[r,p]
+ *   partial[0..2] = sum_r |crf(rgb)-tgt|^2, |crf(rgb1)-tgt|^2, |crf(awp)-tgt|^2   (3 channels summed)
+ *   partial[3..4] = sum_r |crf(rgb_p[r,0])-tgt0|^2, |crf(rgb0_p[r,0])-tgt0|^2     (pts0 / EDI prior terms)
+ *   partial[5]    = 3 R  (element count)
+ * rgb0_p, w2, tgt0 may be NULL (their partials stay 0).  Accumulates (atomicAdd) into partial dev [8]:
+ * zero it once per step; ranks all-reduce the 8 floats (evdeblurnerf_amd/dist.py).  Optionally writes
+ * the blended colours rgb/rgb1/awp dev [R,3]. */
+int evd_blur_loss_reduce(const evd_crf* crf_rgb, int skip_learn, const float* rgb_p, const float* rgb0_p,
+                         const float* w1, const float* w2, const float* tgt, const float* tgt0, long R, int P,
+                         float* partial, float* out_rgb, float* out_rgb1, float* out_awp, void* stream);
+
+/* Fused event-loss reduction (spec: run_nerf.py:518-570, utils/events.py:260-284):
+ *   bii = thr_neg*cum_neg + thr_pos*cum_pos;  feat = (cum_neg, cum_pos) per event ("pos-neg") or scattered to the
+ *   event's colour channel ("color-pos-neg", color_mask != NULL); luma = CRF_event(rgb) -> rec601 luma, or the
+ *   masked channel when tonemap_only;  pred = log(l_end+1e-5) - log(l_start+1e-5);
+ *   partial[0] += sum w (pred-bii)^2 (fine), partial[1] += same for the coarse pair, partial[2] += sum w.
+ * start/end/start0/end0 dev [N,3] linear rgb; cum_neg/cum_pos dev [N]; color_mask dev uint8 [N,3] or NULL;
+ * color_weight host[3] or NULL.  start0/end0 may be NULL. */
+int evd_event_loss_reduce(const evd_crf* crf_ev, int skip_learn, int add_bii_feat, int tonemap_only,
+                          const float* start, const float* end, const float* start0, const float* end0,
+                          const float* cum_neg, const float* cum_pos, float thr_neg, float thr_pos,
+                          const unsigned char* color_mask, const float* color_weight, long N,
+                          float* partial, void* stream);
+
+/* EDI prior (utils/edi.py:73-95): bii dev [steps-1, npix], blurry dev [npix] -> sharp dev [npix] */
+int evd_edi_deblur(const float* blurry, const float* bii, int steps, long npix, float* sharp, void* stream);
+/* brightness_increment_image with bilinear sub-pixel splat (utils/edi.py:7-70, grey events):
+ * x,y dev [n] float, p dev int8 [n] -> image dev [h,w] (overwritten) */
+int evd_edi_bii_image(const float* x, const float* y, const signed char* p, long n, int w, int h,
+                      float c_pos, float c_neg, float* image, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVDNERF_H */

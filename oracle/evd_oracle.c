@@ -80,6 +80,31 @@ static float* transpose_w(const float* W, int out, int in) {
     return t;
 }
 
+/* Blocked variant of linear_t: NB samples share every weight row load (cache/register reuse, the CPU
+ * baseline's GEMM); each output still sums k ascending, so results are bitwise those of linear_t. */
+#define EVO_NB 8
+typedef float evo_v8 __attribute__((vector_size(32), aligned(4)));
+static void linear_blk(const float* Wt, const float* b, int in, int out, const float* x, int xs, float* y, int ys, int nb) {
+    if (nb == EVO_NB && (out & 7) == 0) {
+        /* 8 samples x 8 outputs register tile: the weight vector of row k is loaded once for 8 samples */
+        for (int jb = 0; jb < out; jb += 8) {
+            evo_v8 a0, a1, a2, a3, a4, a5, a6, a7;
+            if (b) a0 = *(const evo_v8*)(b + jb); else a0 = (evo_v8){0, 0, 0, 0, 0, 0, 0, 0};
+            a1 = a2 = a3 = a4 = a5 = a6 = a7 = a0;
+            for (int k = 0; k < in; ++k) {
+                const evo_v8 w = *(const evo_v8*)(Wt + (long)k * out + jb);
+                a0 += w * x[k];          a1 += w * x[xs + k];     a2 += w * x[2 * xs + k]; a3 += w * x[3 * xs + k];
+                a4 += w * x[4 * xs + k]; a5 += w * x[5 * xs + k]; a6 += w * x[6 * xs + k]; a7 += w * x[7 * xs + k];
+            }
+            *(evo_v8*)(y + jb) = a0;          *(evo_v8*)(y + ys + jb) = a1;     *(evo_v8*)(y + 2 * ys + jb) = a2;
+            *(evo_v8*)(y + 3 * ys + jb) = a3; *(evo_v8*)(y + 4 * ys + jb) = a4; *(evo_v8*)(y + 5 * ys + jb) = a5;
+            *(evo_v8*)(y + 6 * ys + jb) = a6; *(evo_v8*)(y + 7 * ys + jb) = a7;
+        }
+        return;
+    }
+    for (int s = 0; s < nb; ++s) linear_t(Wt, b, in, out, x + (long)s * xs, y + (long)s * ys);
+}
+
 /* ------------------------------------------------------------------ NeRF.eval
  * networks/nerf.py:131-162.  emb = [n, input_ch + input_ch_views]; raw = cat([rgb, alpha]) :157 */
 void evo_nerf_mlp(const evo_nerf* net, const float* emb, long n, float* raw, float* feat_after, float* feat_before) {
@@ -100,37 +125,54 @@ void evo_nerf_mlp(const evo_nerf* net, const float* emb, long n, float* raw, flo
         wo = transpose_w(net->output_w, net->output_ch, W);
     }
     const int ein = ic + icv;
+    const int hs = W + ic + icv;     /* row stride of the activation blocks */
+    const long nblk = (n + EVO_NB - 1) / EVO_NB;
 #pragma omp parallel
     {
-        float* h = (float*)malloc(sizeof(float) * (W + ic + icv));
-        float* h2 = (float*)malloc(sizeof(float) * (W + ic + icv));
+        float* h = (float*)malloc(sizeof(float) * hs * EVO_NB);
+        float* h2 = (float*)malloc(sizeof(float) * hs * EVO_NB);
 #pragma omp for schedule(static)
-        for (long s = 0; s < n; ++s) {
-            const float* x = emb + s * ein;
+        for (long blk = 0; blk < nblk; ++blk) {
+            const long s0 = blk * EVO_NB;
+            const int nb = (int)((n - s0) < EVO_NB ? (n - s0) : EVO_NB);
+            const float* x = emb + s0 * ein;
             const float* in = x;
+            int is = ein;
             for (int i = 0; i < D; ++i) {
                 float* o = (i == net->skip) ? h2 + ic : h2;          /* cat([input_pts, h]) nerf.py:137-138 */
-                linear_t(wt[i], net->pts_b[i], fin[i], W, in, o);
-                for (int j = 0; j < W; ++j) o[j] = o[j] > 0.f ? o[j] : 0.f;
-                if (i == net->skip) memcpy(h2, x, sizeof(float) * ic);
+                linear_blk(wt[i], net->pts_b[i], fin[i], W, in, is, o, hs, nb);
+                for (int s = 0; s < nb; ++s) {
+                    float* os = o + (long)s * hs;
+                    for (int j = 0; j < W; ++j) os[j] = os[j] > 0.f ? os[j] : 0.f;
+                    if (i == net->skip) memcpy(h2 + (long)s * hs, x + (long)s * ein, sizeof(float) * ic);
+                }
                 float* tmp = h; h = h2; h2 = tmp;
                 in = h;
+                is = hs;
             }
             /* h = layer-D activations (W wide unless D-1 == skip) */
-            if (feat_before) memcpy(feat_before + s * W, h, sizeof(float) * W);
+            if (feat_before) for (int s = 0; s < nb; ++s) memcpy(feat_before + (s0 + s) * W, h + (long)s * hs, sizeof(float) * W);
             if (net->use_viewdirs) {
-                float alpha;
-                linear_t(wa, net->alpha_b, W, 1, h, &alpha);
-                linear_t(wf, net->feature_b, W, W, h, h2);
-                if (feat_after) memcpy(feat_after + s * W, h2, sizeof(float) * W);
-                memcpy(h2 + W, x + ic, sizeof(float) * icv);       /* cat([feature, input_views]) :147 */
-                linear_t(wv, net->views_b, W + icv, W / 2, h2, h);
-                for (int j = 0; j < W / 2; ++j) h[j] = h[j] > 0.f ? h[j] : 0.f;
-                float rgb[3];
-                linear_t(wr, net->rgb_b, W / 2, 3, h, rgb);
-                raw[s * 4 + 0] = rgb[0]; raw[s * 4 + 1] = rgb[1]; raw[s * 4 + 2] = rgb[2]; raw[s * 4 + 3] = alpha;
+                float alpha[EVO_NB];
+                linear_blk(wa, net->alpha_b, W, 1, h, hs, alpha, 1, nb);
+                linear_blk(wf, net->feature_b, W, W, h, hs, h2, hs, nb);
+                for (int s = 0; s < nb; ++s) {
+                    if (feat_after) memcpy(feat_after + (s0 + s) * W, h2 + (long)s * hs, sizeof(float) * W);
+                    memcpy(h2 + (long)s * hs + W, x + (long)s * ein + ic, sizeof(float) * icv);   /* cat([feature, input_views]) :147 */
+                }
+                linear_blk(wv, net->views_b, W + icv, W / 2, h2, hs, h, hs, nb);
+                for (int s = 0; s < nb; ++s) {
+                    float* hh = h + (long)s * hs;
+                    for (int j = 0; j < W / 2; ++j) hh[j] = hh[j] > 0.f ? hh[j] : 0.f;
+                }
+                float rgb[EVO_NB * 3];
+                linear_blk(wr, net->rgb_b, W / 2, 3, h, hs, rgb, 3, nb);
+                for (int s = 0; s < nb; ++s) {
+                    float* r4 = raw + (s0 + s) * 4;
+                    r4[0] = rgb[s * 3]; r4[1] = rgb[s * 3 + 1]; r4[2] = rgb[s * 3 + 2]; r4[3] = alpha[s];
+                }
             } else {
-                linear_t(wo, net->output_b, W, net->output_ch, h, raw + s * net->output_ch);
+                linear_blk(wo, net->output_b, W, net->output_ch, h, hs, raw + s0 * net->output_ch, net->output_ch, nb);
             }
         }
         free(h); free(h2);

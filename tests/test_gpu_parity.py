@@ -1,0 +1,359 @@
+"""GPU parity tests: the HIP path (through the C ABI, via the Python mirror) against the CPU oracle on the same
+seeded inputs, against the committed reference goldens, and -- at BASELINE.json's full sizes -- through
+size-independent properties. Tolerances are stated next to each assert; the float32-grade modes
+(f32, f16x3) are held to the north-star bound of 1e-4 RGB L-inf, bf16 is reported and loosely bounded."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, maxabs, sample_pdf_flip_report, z_mismatch
+from evdeblurnerf_amd import weights as W
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def T(x):
+    return torch.as_tensor(np.ascontiguousarray(x), device=DEV)
+
+
+def N(x):
+    return x.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def test_library_loads_and_sees_gpu():
+    from evdeblurnerf_amd import _lib as L
+    assert L.lib().evd_device_count() >= 1
+
+
+def test_embed_matches_golden_and_oracle(O):
+    from evdeblurnerf_amd.embedding import get_embedder
+    g = load_golden("G1_embedder")
+    for Lf, key in ((10, "pe10"), (4, "pe4"), (2, "pe2")):
+        e, dim = get_embedder(Lf)
+        out = N(e(T(g["x"])))
+        assert out.shape[-1] == dim
+        assert maxabs(out, g[key]) < 2e-6          # ocml sinf/cosf vs SLEEF, args up to 40*512
+        assert maxabs(out, O.embed(g["x"], Lf)) < 2e-6
+
+
+def test_rays_match_golden(O):
+    from evdeblurnerf_amd.rays import get_rays, get_rays_pix, get_ndc_rays
+    g = load_golden("G6_rays")
+    o, d = get_rays(60, 80, g["Kn"], torch.as_tensor(g["c2w"]))
+    assert maxabs(N(o)[::7, ::5], g["rays_o_full"]) == 0.0
+    assert maxabs(N(d)[::7, ::5], g["rays_d_full"]) < 1e-6
+    K = W.synthetic_camera()
+    op, dp = get_rays_pix(T(g["coords"]), K, T(g["poses"]))
+    assert maxabs(N(op), g["rays_o_pix"]) == 0.0
+    assert maxabs(N(dp), g["rays_d_pix"]) < 1e-6
+    on, dn = get_ndc_rays(400, 400, float(K[0, 0]), 1.0, T(g["rays_o_pix"]), T(g["rays_d_pix"]))
+    assert maxabs(N(on), g["ndc_o"]) < 2e-6
+    assert maxabs(N(dn), g["ndc_d"]) < 2e-6
+    # bit-exact against the oracle's unfused float32 arithmetic
+    oo, od = O.ndc_rays(400, 400, float(K[0, 0]), 1.0, g["rays_o_pix"], g["rays_d_pix"])
+    assert maxabs(N(on), oo) <= 1e-7 and maxabs(N(dn), od) <= 1e-7
+
+
+def _nerf_pair(seed_c=11, seed_f=12, **kw):
+    from evdeblurnerf_amd.nerf import NeRF
+    return (NeRF(W.make_nerf_state_dict(seed_c), **kw), NeRF(W.make_nerf_state_dict(seed_f), **kw))
+
+
+@pytest.mark.parametrize("S", [64, 128, 33])
+def test_raw2outputs_matches_golden(S, O):
+    from evdeblurnerf_amd.nerf import NeRF
+    g = load_golden("G3_nerf_raw2outputs")
+    raw, z, d = g[f"raw_S{S}"], g[f"z_S{S}"], g[f"d_S{S}"]
+    sd = W.make_nerf_state_dict(1)
+    cases = {"plain": ({}, {}), "white": ({}, dict(white_bkgd=True)), "rmnear": (dict(render_rmnearplane=20), {}),
+             "relu_rgb": (dict(rgb_activate="relu"), {}), "none_rgb": (dict(rgb_activate="none"), {}),
+             "softplus": (dict(sigma_activate="softplus"), {})}
+    for tag, (ckw, call) in cases.items():
+        net = NeRF(sd, **ckw)
+        rgb, dens, acc, wts, depth, fmap = net.raw2outputs(T(raw), T(z), T(d), None, 0, **call)
+        # wavefront product scan vs sequential cumprod: a few ulp on O(1) values
+        assert maxabs(N(rgb), g[f"rgb_S{S}_{tag}"]) < 5e-6, tag
+        assert maxabs(N(acc), g[f"acc_S{S}_{tag}"]) < 5e-6, tag
+        assert maxabs(N(depth), g[f"depth_S{S}_{tag}"]) < 5e-6, tag
+        assert maxabs(N(wts), g[f"weights_S{S}_{tag}"]) < 5e-6, tag
+        if tag == "plain":
+            assert maxabs(N(dens), g[f"density_S{S}"]) < 2e-6
+    net = NeRF(sd)
+    fmap = net.raw2outputs(T(raw), T(z), T(d), T(g[f"feat_S{S}"]), 0)[5]
+    assert maxabs(N(fmap), g[f"fmap_S{S}"]) < 5e-6
+
+
+@pytest.mark.parametrize("S", [64, 128])
+def test_voxel_channel_order_raw2outputs(S):
+    """sigma first / rgb after (voxnerf.py:172,179) through the same C entry."""
+    from evdeblurnerf_amd import _lib as L
+    g = load_golden("G4_voxel_raw2outputs")
+    raw, z, d = T(g[f"raw_S{S}"]), T(g[f"z_S{S}"]), T(g[f"d_S{S}"])
+    R = raw.shape[0]
+    for tag, act in (("coarse", "relu"), ("fine", "none")):
+        rgb = torch.empty((R, 3), device=DEV)
+        acc = torch.empty((R,), device=DEV)
+        depth = torch.empty((R,), device=DEV)
+        wts = torch.empty((R, S), device=DEV)
+        L.check(L.lib().evd_raw2outputs(L.ptr(raw), L.ptr(z), L.ptr(d), 3, R, S, 4, 0, 1, 3, L.ACT[act], L.ACT["relu"], 0, 0.0, None,
+                                        L.ptr(rgb), None, L.ptr(acc), L.ptr(wts), L.ptr(depth), None, 0, None, L.stream_ptr()))
+        assert maxabs(N(rgb), g[f"rgb_S{S}_{tag}"]) < 5e-6
+        assert maxabs(N(wts), g[f"weights_S{S}_{tag}"]) < 5e-6
+        assert maxabs(N(depth), g[f"depth_S{S}_{tag}"]) < 5e-6
+    raw16 = T(g[f"raw16_S{S}"])
+    fm = torch.empty((R, 15), device=DEV)
+    wts = torch.empty((R, S), device=DEV)
+    L.check(L.lib().evd_raw2outputs(L.ptr(raw16), L.ptr(z), L.ptr(d), 3, R, S, 16, 0, 1, 15, L.ACT["relu"], L.ACT["relu"], 0, 0.0, None,
+                                    L.ptr(fm), None, None, L.ptr(wts), None, None, 0, None, L.stream_ptr()))
+    assert maxabs(N(fm), g[f"fmap16_S{S}"]) < 5e-6
+
+
+@pytest.mark.parametrize("S,Ns", [(64, 64), (64, 128), (128, 64), (17, 9)])
+def test_sample_pdf_merge(S, Ns, O):
+    from evdeblurnerf_amd.rays import sample_pdf_merge
+    g = load_golden("G5_sample_pdf")
+    key = f"S{S}_N{Ns}"
+    bins, w, u = g[f"bins_{key}"], g[f"w_{key}"], g[f"u_{key}"]
+    R = bins.shape[0]
+    # rebuild a z row whose mid-points are the golden bins (z[0] = bins[0] - small) and full-width weights
+    z = np.zeros((R, S), np.float64)
+    z[:, 0] = bins[:, 0].astype(np.float64) - 1e-3
+    for i in range(S - 1):
+        z[:, i + 1] = 2.0 * bins[:, i].astype(np.float64) - z[:, i]
+    z = z.astype(np.float32)
+    mid = (0.5 * (z[:, 1:] + z[:, :-1])).astype(np.float32)
+    wf = np.zeros((R, S), np.float32)
+    wf[:, 1:-1] = w
+    for det, uu, ref_key in ((True, None, "det"), (False, u, "rand")):
+        zs, zm, order, zstd = sample_pdf_merge(T(z), T(wf), Ns, det=det, u=T(uu) if uu is not None else None, want_order=True)
+        zs, zm, order, zstd = N(zs), N(zm), N(order), N(zstd)
+        ora = O.sample_pdf(mid, w, Ns, det=det, u=uu)
+        # same algorithm, same double-accumulated cdf: the HIP kernel reproduces the oracle to rounding of the lerp
+        assert maxabs(zs, ora) < 2e-6
+        if np.abs(mid - bins).max() == 0.0:       # mid-points exactly representable: compare with the reference golden
+            ulin = np.linspace(0, 1, Ns).astype(np.float32)
+            nbad, unexplained = sample_pdf_flip_report(zs, g[f"{ref_key}_{key}"], bins, w, ulin if det else uu)
+            assert unexplained == 0 and nbad <= 0.01 * zs.size
+        cat = np.concatenate([z, zs], -1)
+        assert np.array_equal(zm, np.sort(cat, -1))                      # sortedness
+        assert np.array_equal(np.take_along_axis(cat, order.astype(np.int64), -1), zm)   # order is the sort permutation
+        assert np.array_equal(np.sort(order, -1), np.tile(np.arange(S + Ns), (R, 1)))
+        assert maxabs(zstd, zs.astype(np.float64).std(-1)) < 1e-6
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("f16x3", 2e-5), ("bf16", 6e-2)])
+@pytest.mark.parametrize("Wd,seed,bias", [(256, 7, True), (256, 8, False), (64, 9, True)])
+def test_nerf_mlp_matches_oracle_and_golden(prec, tol, Wd, seed, bias, O):
+    """Fused pts + PE + MLP kernel vs NeRF.eval (golden G2 from the reference; oracle for the features)."""
+    from evdeblurnerf_amd.nerf import NeRF
+    g = load_golden("G2_nerf_mlp")
+    tag = {7: "w256", 8: "w256_nobias", 9: "w64"}[seed]
+    sd = W.make_nerf_state_dict(seed, W=Wd, rgb_add_bias=bias)
+    pts, dirs = g["pts"], g["dirs"]
+    n = pts.shape[0]
+    # express the golden's free points/dirs as rays with z = 1: o = 0, d = pts, viewdir = dirs
+    rb = np.zeros((n, 11), np.float32)
+    rb[:, 3:6] = pts
+    rb[:, 6], rb[:, 7] = 0.0, 1.0
+    rb[:, 8:11] = dirs
+    z = np.ones((n, 1), np.float32)
+    for ef in ("after_linear", "before_linear"):
+        net = NeRF(sd, W=Wd, precision=prec, extract_feature=ef)
+        raw, feat = net.mlpforward(T(rb), T(z), want_feature=True)
+        raw, feat = N(raw).reshape(n, 4), N(feat).reshape(n, Wd)
+        err = maxabs(raw, g[f"raw_{tag}"])
+        print(f"[{prec} W={Wd} {tag}] raw L-inf vs reference golden = {err:.3e}")
+        assert err < tol
+        key = "feat_" if ef == "after_linear" else "featb_"
+        assert maxabs(feat[:, :16], g[key + tag]) < tol
+    # ragged sizes: 1 sample, and a count that is not a multiple of the workgroup tile
+    net = NeRF(sd, W=Wd, precision=prec)
+    onet = O.Nerf(sd, W=Wd)
+    emb = np.concatenate([O.embed(pts, 10), O.embed(dirs, 4)], -1)
+    ref, _, _ = O.nerf_mlp(onet, emb)
+    for m in (1, 33, 257, 383):
+        raw, _ = net.mlpforward(T(rb[:m]), T(z[:m]))
+        assert maxabs(N(raw).reshape(m, 4), ref[:m]) < tol
+
+
+def _render_cases():
+    return [("a", dict(N_samples=64, N_importance=64), 1, 96, 11, 12),
+            ("b", dict(N_samples=128, N_importance=0), 2, 80, 13, None),
+            ("d", dict(N_samples=64, N_importance=32, perturb=1.0), 4, 48, 11, 12)]
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 1e-4), ("f16x3", 1e-4), ("bf16", 3e-2)])
+def test_render_matches_reference_golden(prec, tol, O):
+    """NeRFAll.render end to end vs the goldens produced by the reference (G7). RGB L-inf <= 1e-4 is the
+    north-star bound for the float32-grade modes."""
+    from types import SimpleNamespace
+    from evdeblurnerf_amd.renderer import NeRFAll
+    g = load_golden("G7_render_nerf")
+    K = W.synthetic_camera()
+    for tag, kw, ray_seed, R, sc, sf in _render_cases():
+        sd = dict(W.prefixed(W.make_nerf_state_dict(sc), "mlp_coarse"))
+        if sf is not None:
+            sd.update(W.prefixed(W.make_nerf_state_dict(sf), "mlp_fine"))
+        args = SimpleNamespace(mode="nerf", netdepth=8, netwidth=256, multires=10, multires_views=4, use_viewdirs=True,
+                               rgb_activate="sigmoid", sigma_activate="relu", N_importance=kw["N_importance"])
+        model = NeRFAll(args, sd, precision=prec).eval()
+        rays = T(W.synthetic_rays(ray_seed, R))
+        extra = {}
+        if kw.get("perturb", 0) > 0:
+            extra = dict(t_rand=T(g["d_t_rand"]), u=T(g["d_u"]))
+        rgb, depth, acc, ex = model.render(400, 400, K, chunk=1 << 20 if tag != "b" else 32, rays=rays, ndc=True, near=0., far=1.,
+                                           use_viewdirs=True, retraw=True, raw_noise_std=0., **kw, **extra)
+        e_rgb = maxabs(N(rgb), g[f"{tag}_rgb"])
+        print(f"[{prec} case {tag}] RGB L-inf vs reference = {e_rgb:.3e}, depth {maxabs(N(depth), g[f'{tag}_depth']):.3e}")
+        assert e_rgb < tol
+        assert maxabs(N(acc), g[f"{tag}_acc"]) < tol
+        assert maxabs(N(depth), g[f"{tag}_depth"]) < 3 * tol
+        if kw["N_importance"] > 0:
+            assert maxabs(N(ex["rgb0"]), g[f"{tag}_rgb0"]) < tol
+            assert maxabs(N(ex["z_vals0"]), g[f"{tag}_z_vals0"]) < 1e-6
+            assert maxabs(N(ex["weights0"]), g[f"{tag}_weights0"]) < tol
+            frac, worst = z_mismatch(N(ex["z_vals"]), g[f"{tag}_z_vals"], tol=5e-5 if prec != "bf16" else 5e-3)
+            assert frac < (0.01 if prec != "bf16" else 0.2) and worst < 1.0 / 63 + 1e-3, (frac, worst)
+        else:
+            assert maxabs(N(ex["z_vals"]), g[f"{tag}_z_vals"]) < 1e-6
+            assert maxabs(N(ex["weights"]), g[f"{tag}_weights"]) < tol
+
+
+def test_render_config1_white_bkgd_lindisp_no_ndc(O):
+    """BASELINE config 1 shape (single pass, 64 samples) with the non-default switches, vs golden G7c."""
+    from types import SimpleNamespace
+    from evdeblurnerf_amd.renderer import NeRFAll
+    g = load_golden("G7_render_nerf")
+    sd = W.prefixed(W.make_nerf_state_dict(13), "mlp_coarse")
+    args = SimpleNamespace(mode="nerf", netdepth=8, netwidth=256, multires=10, multires_views=4, use_viewdirs=True,
+                           rgb_activate="sigmoid", sigma_activate="relu", N_importance=0)
+    model = NeRFAll(args, sd, precision="f16x3").eval()
+    rgb, depth, acc, ex = model.render(400, 400, W.synthetic_camera(), rays=T(W.synthetic_rays(3, 64)), ndc=False, near=0.5, far=3.5,
+                                       use_viewdirs=True, N_samples=64, N_importance=0, retraw=False, perturb=0., raw_noise_std=0.,
+                                       white_bkgd=True, lindisp=True)
+    assert maxabs(N(rgb), g["c_rgb"]) < 1e-4
+    assert maxabs(N(depth), g["c_depth"]) < 3e-4
+    assert set(ex.keys()) == set()
+    # empty batch: the reference returns empty tensors (renderer.py:450 "max(1, .)")
+    rgb, depth, acc, ex = model.render(400, 400, W.synthetic_camera(), rays=torch.empty((0, 3, 2), device=DEV), ndc=True, near=0., far=1.,
+                                       use_viewdirs=True, N_samples=64, N_importance=0, retraw=True)
+    assert rgb.shape == (0, 3) and ex["weights"].shape == (0, 64)
+
+
+def test_full_size_metric_config_properties():
+    """BASELINE.json metric shape: 4096 rays x 128 samples through the 8x256 MLP. Size-independent properties:
+    acc == 1 (last alpha forced to 1), weights >= 0 and sum to acc, rgb in [0,1], depth within [near,far],
+    ray-permutation equivariance, chunk invariance, and agreement of the three arithmetic modes."""
+    from types import SimpleNamespace
+    from evdeblurnerf_amd.renderer import NeRFAll
+    sd = W.prefixed(W.make_nerf_state_dict(21), "mlp_coarse")
+    args = SimpleNamespace(mode="nerf", netdepth=8, netwidth=256, multires=10, multires_views=4, use_viewdirs=True,
+                           rgb_activate="sigmoid", sigma_activate="relu", N_importance=0)
+    rays = T(W.synthetic_rays(7, 4096))
+    K = W.synthetic_camera()
+    kw = dict(ndc=True, near=0., far=1., use_viewdirs=True, N_samples=128, N_importance=0, retraw=True)
+    out = {}
+    for prec in ("f32", "f16x3", "bf16"):
+        model = NeRFAll(args, sd, precision=prec).eval()
+        rgb, depth, acc, ex = model.render(400, 400, K, rays=rays, **kw)
+        out[prec] = N(rgb)
+        assert np.allclose(N(acc), 1.0, atol=2e-5)
+        w = N(ex["weights"])
+        assert (w >= -1e-7).all() and np.allclose(w.sum(-1), N(acc), atol=2e-5)
+        assert out[prec].min() >= 0.0 and out[prec].max() <= 1.0
+        assert N(depth).min() >= -1e-6 and N(depth).max() <= 1.0 + 1e-5
+        if prec == "f16x3":
+            perm = torch.randperm(4096, device=DEV)
+            rgb_p = model.render(400, 400, K, rays=rays[perm], **kw)[0]
+            assert torch.equal(rgb_p, rgb[perm])                      # rays are independent
+            rgb_c = model.render(400, 400, K, chunk=1000, rays=rays, **kw)[0]
+            assert torch.equal(rgb_c, rgb)                            # chunking does not change results (renderer.py:406)
+    assert maxabs(out["f16x3"], out["f32"]) < 1e-4
+    print(f"bf16 vs f32 RGB L-inf at full size: {maxabs(out['bf16'], out['f32']):.3e}")
+    assert maxabs(out["bf16"], out["f32"]) < 3e-2
+
+
+def test_weighted_sum_and_crf_and_losses(O):
+    from evdeblurnerf_amd.losses import (weighted_sum, rbk_weighted_sum, blur_loss_partials, blur_loss_from_partials,
+                                          event_loss_partials, event_loss_from_partials, egm_loss, img2mse)
+    from evdeblurnerf_amd.tonemapping import TonemappingTransform, CRF
+    g = load_golden("G10_rbk_weighted_sum")
+    ccw = T(g["ccw"])
+    o_rgb, o_depth, o_acc, o_ex = rbk_weighted_sum(T(g["rgb"]), T(g["depth"]), T(g["acc"]),
+                                                   {k: T(g["ex_" + k]) for k in ("rgb0", "z_std", "weights", "depth_feature")}, ccw)
+    assert maxabs(N(o_rgb), g["o_rgb"]) < 1e-6 and maxabs(N(o_depth), g["o_depth"]) < 1e-6 and maxabs(N(o_acc), g["o_acc"]) < 1e-6
+    for k, v in o_ex.items():
+        assert maxabs(N(v), g["o_" + k]) < 1e-6, k
+
+    g = load_golden("G11_crf")
+    x, f2, f32 = T(g["x"]), T(g["f2"]), T(g["f32"])
+    sd = dict(W.prefixed(W.make_crf_state_dict(41, 2), "tonemapping_event"))
+    tm = TonemappingTransform("gamma", "learn", state_dict=sd, extra_features_event=2)
+    assert maxabs(N(tm(x, mode="encode_rgb")), g["rgb_gamma"]) < 2e-6
+    assert maxabs(N(tm(x, mode="encode_luma", ev_extra_feat=f2)), g["luma_learn_f2"]) < 2e-6
+    assert maxabs(N(tm(x, mode="encode_luma")), g["luma_learn_nofeat"]) < 2e-6
+    assert maxabs(N(tm(x, mode="encode_luma", skip_learn_crf=True, ev_extra_feat=f2)), g["luma_learn_skip"]) < 2e-6
+    assert maxabs(N(tm(x, mode="encode_luma", tonemap_only=True, ev_extra_feat=f32)), g["tone_learn_f32"]) < 2e-6
+    assert maxabs(N(tm(x, mode="encode_luma", keep_rgb=True, ev_extra_feat=f2)), g["luma_learn_keep"]) < 2e-6
+    sd0 = dict(W.prefixed(W.make_crf_state_dict(43, 0), "tonemapping_event"))
+    tm0 = TonemappingTransform("none", "learn", state_dict=sd0)
+    assert maxabs(N(tm0(x, mode="encode_rgb")), g["rgb_none"]) == 0.0
+    assert maxabs(N(tm0(x, mode="encode_luma")), g["luma_learn0"]) < 2e-6
+    for std in ("rec601", "rec709", "avg"):
+        tmg = TonemappingTransform("gamma", "gamma", luma_standard=std)
+        key = "luma_gamma" if std == "rec601" else f"luma_gamma_{std}"
+        assert maxabs(N(tmg(x, mode="encode_luma")), g[key]) < 2e-6
+
+    g = load_golden("G12_egm_loss")
+    rel = lambda a, b: abs(float(a) - float(b)) / max(abs(float(b)), 1e-12)
+    assert rel(egm_loss(T(g["ls"]), T(g["le"]), T(g["bii"])), g["loss_plain"]) < 1e-5
+    assert rel(egm_loss(T(g["ls3"]), T(g["le3"]), T(g["bii"]), color_mask=T(g["cmask"])), g["loss_mask"]) < 1e-5
+    assert rel(egm_loss(T(g["ls3"]), T(g["le3"]), T(g["bii"]), color_mask=T(g["cmask"]), color_weight=[0.4, 0.2, 0.4]), g["loss_mask_w"]) < 1e-5
+    assert rel(img2mse(T(g["ls3"]), T(g["le3"])), O.mse(g["ls3"], g["le3"])) < 1e-5
+
+    g = load_golden("G14_loss_assembly")
+    for cfg in ("blender", "cdavis"):
+        flw, w_pts0, w_egm = [float(v) for v in g[f"{cfg}_scalars"]]
+        crf_rgb = CRF("gamma" if cfg == "blender" else "none")
+        crf_ev = CRF("learn", state_dict=W.make_crf_state_dict(51, 2), extra_features=2)
+        ccw = g[f"{cfg}_ccw"]
+        p, cols = blur_loss_partials(crf_rgb, T(g[f"{cfg}_rgb_p"]), T(ccw[0]), T(g[f"{cfg}_target"]), rgb0_p=T(g[f"{cfg}_rgb0_p"]),
+                                     w2=T(ccw[1]), target_pts0=T(g[f"{cfg}_target_pts0"]), want_colours=True)
+        loss, terms = blur_loss_from_partials(p, fine_loss_weight=flw, w_pts0=w_pts0)
+        assert abs(float(loss) - float(g[f"{cfg}_img_loss"])) < 2e-6
+        assert abs(float(terms["pts0"]) - float(g[f"{cfg}_pts0"])) < 2e-6
+        assert maxabs(N(cols["rgb"]), O.weighted_sum(g[f"{cfg}_rgb_p"], ccw[0])) < 1e-6
+        thr = 0.2 if cfg == "blender" else 0.25
+        kw = dict(add_bii="pos-neg") if cfg == "blender" else dict(add_bii="color-pos-neg", tonemap_only=True,
+                                                                   color_mask=T(g[f"{cfg}_cmask"]), color_weight=[0.4, 0.2, 0.4])
+        pe = event_loss_partials(crf_ev, T(g[f"{cfg}_es"]), T(g[f"{cfg}_ee"]), T(g[f"{cfg}_cn"]), T(g[f"{cfg}_cp"]), thr, thr,
+                                 start0=T(g[f"{cfg}_es0"]), end0=T(g[f"{cfg}_ee0"]), **kw)
+        egm = event_loss_from_partials(pe)
+        assert rel(egm, g[f"{cfg}_egm"]) < 2e-5
+        total = float(loss) + float(egm) * w_egm
+        assert abs(total - float(g[f"{cfg}_total"])) < 1e-5 * max(1.0, float(g[f"{cfg}_total"]))
+    # linearity of the sub-exposure reduction (size-independent property, config-3 shape: 1024 px x P=10)
+    rs = np.random.RandomState(5)
+    xa, xb = T(rs.rand(10240, 3).astype(np.float32)), T(rs.rand(10240, 3).astype(np.float32))
+    cc = T(rs.dirichlet(np.ones(10), 1024).astype(np.float32))
+    assert maxabs(N(weighted_sum(xa + xb, cc)), N(weighted_sum(xa, cc) + weighted_sum(xb, cc))) < 1e-6
+
+
+def test_edi_matches_golden():
+    from evdeblurnerf_amd.edi import brightness_increment_image, deblur_double_integral
+    g = load_golden("G13_edi")
+    for s in range(8):
+        img = brightness_increment_image(T(g[f"x{s}"]), T(g[f"y{s}"]), T(g[f"p{s}"]), 16, 16, 0.2, 0.25, True)
+        assert maxabs(N(img), g["bii"][s]) < 2e-6
+        img = brightness_increment_image(T(g[f"x{s}"]), T(g[f"y{s}"]), T(g[f"p{s}"]), 16, 16, 0.2, 0.25, False)
+        assert maxabs(N(img), g[f"bii_ni{s}"]) < 2e-6
+    assert maxabs(N(deblur_double_integral(T(g["blurry"]), T(g["bii"]))), g["sharp"]) < 2e-6
+    assert maxabs(N(deblur_double_integral(T(g["blurry3"]), T(g["bii3"]))), g["sharp3"]) < 2e-6
