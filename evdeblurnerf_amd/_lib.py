@@ -96,6 +96,16 @@ SIGNATURES = {
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """libevdnerf.so takes torch's device pointers and HIP streams, so it must run on the SAME HIP runtime
+    instance as torch. PyTorch-ROCm bundles its own libamdhip64.so.7 (same SONAME as /opt/rocm's): load torch's
+    copy into the process first, then our DT_NEEDED entry resolves to it instead of a second runtime."""
+    import torch  # noqa: F401  (pulls in torch/lib/libamdhip64.so when built for ROCm)
+    tl = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(tl):
+        C.CDLL(tl, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """The loaded library; raises EvdError if it is missing (no fallback exists)."""
     global _lib
@@ -103,6 +113,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise EvdError(f"{LIB_PATH} not found: build it with `python -m evdeblurnerf_amd.build` "
                            "(hipcc, --offload-arch=gfx950). There is no CPU fallback.")
+        _share_torch_hip_runtime()
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)   # AttributeError here = header/library mismatch
