@@ -83,6 +83,18 @@ SIGNATURES = {
                                   C.POINTER(RenderOut), _vp, _S, _vp]),
     "evd_nerf_render": (_I, [_vp, _vp, C.POINTER(RenderCfg), _vp, _L, _vp, _vp, _vp, _vp,
                              C.POINTER(RenderOut), _vp, _S, _vp]),
+    "evd_voxel_create": (_I, [C.POINTER(VoxelDesc), C.POINTER(_vp)]),
+    "evd_voxel_destroy": (None, [_vp]),
+    "evd_voxel_sample": (_I, [_vp, _vp, _L, _vp, _I, _I, _vp]),
+    "evd_voxel_forward": (_I, [_vp, _I, _vp, _vp, _I, _vp, _I, _vp, _vp, _I, _L, _I, _I,
+                               _vp, _vp, _vp, _vp, _vp, _vp, _S, _vp]),
+    "evd_voxel_forward_workspace_bytes": (_S, [_vp, _L, _I]),
+    "evd_c2f_render_workspace_bytes": (_S, [_vp, _vp, C.POINTER(RenderCfg), _L]),
+    "evd_c2f_render_rays": (_I, [_vp, _vp, C.POINTER(RenderCfg), _vp, _L, _vp, _vp, _vp, _vp,
+                                 C.POINTER(RenderOut), _vp, _S, _vp]),
+    "evd_c2f_render": (_I, [_vp, _vp, C.POINTER(RenderCfg), _vp, _L, _vp, _vp, _vp, _vp,
+                            C.POINTER(RenderOut), _vp, _S, _vp]),
+    "evd_voxel_tv_loss": (_I, [_vp, _vp, _vp]),
     "evd_weighted_sum": (_I, [_vp, _vp, _L, _I, _I, _vp, _vp]),
     "evd_crf_create": (_I, [C.POINTER(CrfDesc), C.POINTER(_vp)]),
     "evd_crf_destroy": (None, [_vp]),

@@ -1,6 +1,7 @@
 // C-ABI entry points of the NeRF backbone: weight packing, fused MLP launch, render_rays orchestration.
 #include "evd_common.h"
 #include "nerf_mlp.h"
+#include "pack.h"
 
 #include <cmath>
 #include <cstdint>
@@ -22,61 +23,6 @@ int fail(int code, const char* fmt, ...) {
 }
 
 int nerf_mlp_dispatch(int prec, int W, const MlpParams& p, hipStream_t st);
-
-// ------------------------------------------------------------------------------------------------
-// host-side packing of nn.Linear weights into the MFMA fragment stream (contract: nerf_mlp.h)
-static inline uint16_t f32_to_bf16(float f) {
-    uint32_t u;
-    memcpy(&u, &f, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN
-    u += 0x7fffu + ((u >> 16) & 1u);                                            // round to nearest even
-    return (uint16_t)(u >> 16);
-}
-
-struct StreamBuilder {
-    int prec;
-    std::vector<uint8_t> bytes;
-    explicit StreamBuilder(int p) : prec(p) {}
-    // one fragment: rows = 32 output features of `tile`, k-step j; col(kk) -> source column or -1
-    template <class ColFn>
-    void frag(const float* Wm, int out_dim, int in_dim, int tile, int j, ColFn col) {
-        const int fb = frag_bytes(prec);
-        const size_t base = bytes.size();
-        bytes.resize(base + fb, 0);
-        uint8_t* dst = bytes.data() + base;
-        for (int l = 0; l < 64; ++l) {
-            const int row = 32 * tile + (l & 31);
-            for (int e = 0; e < 8; ++e) {
-                const int kk = 8 * (l >> 5) + e;
-                const int c = col(j, kk);
-                const float w = (row < out_dim && c >= 0 && c < in_dim) ? Wm[(size_t)row * in_dim + c] : 0.f;
-                if (prec == EVD_PREC_BF16) {
-                    const uint16_t b = f32_to_bf16(w);
-                    memcpy(dst + l * 16 + e * 2, &b, 2);
-                } else if (prec == EVD_PREC_F16X3) {
-                    const _Float16 hi = (_Float16)w;
-                    const _Float16 lo = (_Float16)((w - (float)hi) * 2048.f);
-                    memcpy(dst + l * 16 + e * 2, &hi, 2);
-                    memcpy(dst + 1024 + l * 16 + e * 2, &lo, 2);
-                } else {
-                    memcpy(dst + (e < 4 ? 0 : 1024) + l * 16 + (e & 3) * 4, &w, 4);
-                }
-            }
-        }
-    }
-    template <class ColFn>
-    void layer(const float* Wm, int out_dim, int in_dim, int tiles, int ksteps, bool pad_end, ColFn col) {
-        const int G = tiles >= 2 ? 2 : 1;
-        for (int p = 0; p < tiles / G; ++p)
-            for (int j = 0; j < ksteps; ++j)
-                for (int t = 0; t < G; ++t) frag(Wm, out_dim, in_dim, p * G + t, j, col);
-        if (pad_end) pad();
-    }
-    void pad() {
-        const size_t cb = chunk_bytes(prec);
-        bytes.resize(cdiv((long)bytes.size(), (long)cb) * cb, 0);
-    }
-};
 
 }  // namespace evd
 

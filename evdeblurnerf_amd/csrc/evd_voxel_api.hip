@@ -1,0 +1,273 @@
+// C-ABI entry points of the PDRF backbone and the mode='c2f' renderer (reference networks/pdrf/voxnerf.py,
+// networks/renderer.py:182-217).
+#include "evd_common.h"
+#include "nerf_mlp.h"
+#include "pack.h"
+#include "voxel.h"
+
+#include <cmath>
+#include <cstdint>
+
+using namespace evd;
+
+struct evd_voxel {
+    int num_layers, hidden_dim, geo, num_layers_color, input_ch, ft_dim, app_dim;
+    int n_comp[3], grid[3], app_act, rgb_act, sigma_act, composite_feature;
+    float aabb[6], rmnear;
+    DevBuf plane[3], line[3], basis, stream[3], bias, tv_acc;
+    int nchunks[3];
+    GridParams gp;
+};
+
+static const int kMat0[3] = {0, 0, 1}, kMat1[3] = {1, 2, 2}, kVec[3] = {2, 1, 0};
+
+extern "C" {
+
+void evd_voxel_destroy(evd_voxel* v) {
+    if (!v) return;
+    for (int i = 0; i < 3; ++i) { v->plane[i].release(); v->line[i].release(); v->stream[i].release(); }
+    v->basis.release(); v->bias.release(); v->tv_acc.release();
+    delete v;
+}
+
+int evd_voxel_create(const evd_voxel_desc* d, evd_voxel** out) {
+    EVD_REQUIRE(d && out, "evd_voxel_create: null argument");
+    EVD_REQUIRE(d->multires == PE_L && d->multires_views == PE_LV, "evd_voxel_create: only multires=%d/%d are built", PE_L, PE_LV);
+    EVD_REQUIRE(d->num_layers == 2 && d->num_layers_color == 3, "evd_voxel_create: only 2 sigma + 3 colour layers are built (all shipped configs)");
+    EVD_REQUIRE(!d->composite_feature, "evd_voxel_create: composite_feature=True (PBE kernel) is not built; shipped configs use RBK");
+    const int IC = 3 * (1 + 2 * PE_L), ICV = 3 * (1 + 2 * PE_LV);
+    const int FT = d->input_ch - IC, HD = d->hidden_dim, G = d->geo_feat_dim;
+    EVD_REQUIRE((HD == 64 && G == 15 && FT == 32) || (HD == 256 && G == 128 && FT == 64),
+                "evd_voxel_create: (hidden %d, geo %d, features %d) not built: coarse 64/15/32 or fine 256/128/64", HD, G, FT);
+    const int ctot = d->n_comp[0] + d->n_comp[1] + d->n_comp[2];
+    EVD_REQUIRE(ctot <= 128 && d->n_comp[0] % 4 == 0 && d->n_comp[1] % 4 == 0 && d->n_comp[2] % 4 == 0 && d->app_dim <= 64,
+                "evd_voxel_create: n_comp must be multiples of 4 with sum <= 128, app_dim <= 64");
+    for (int i = 0; i < 3; ++i) EVD_REQUIRE(d->plane[i] && d->line[i] && d->grid[i] >= 1, "evd_voxel_create: missing grid %d", i);
+    EVD_REQUIRE(d->basis && d->sigma_w[0] && d->sigma_w[1] && d->color_w[0] && d->color_w[1] && d->color_w[2], "evd_voxel_create: missing weights");
+
+    evd_voxel* v = new evd_voxel();
+    v->num_layers = 2; v->hidden_dim = HD; v->geo = G; v->num_layers_color = 3; v->input_ch = d->input_ch; v->ft_dim = FT;
+    v->app_dim = d->app_dim; v->app_act = d->app_act; v->rgb_act = d->rgb_act; v->sigma_act = d->sigma_act;
+    v->composite_feature = 0; v->rmnear = d->rmnear;
+    memcpy(v->aabb, d->aabb, sizeof(v->aabb));
+    int rc = EVD_OK;
+    // planes/lines: [1,C,H,W] -> channel-last [H][W][C]
+    for (int i = 0; i < 3 && !rc; ++i) {
+        v->n_comp[i] = d->n_comp[i]; v->grid[i] = d->grid[i];
+        const int C = d->n_comp[i], Wp = d->grid[kMat0[i]], Hp = d->grid[kMat1[i]], Lp = d->grid[kVec[i]];
+        std::vector<float> cl((size_t)C * Hp * Wp);
+        for (int c = 0; c < C; ++c)
+            for (long hw = 0; hw < (long)Hp * Wp; ++hw) cl[(size_t)hw * C + c] = d->plane[i][(size_t)c * Hp * Wp + hw];
+        rc = v->plane[i].upload(cl.data(), cl.size() * sizeof(float));
+        if (rc) break;
+        std::vector<float> ll((size_t)C * Lp);
+        for (int c = 0; c < C; ++c)
+            for (int l = 0; l < Lp; ++l) ll[(size_t)l * C + c] = d->line[i][(size_t)c * Lp + l];
+        rc = v->line[i].upload(ll.data(), ll.size() * sizeof(float));
+    }
+    if (!rc) rc = v->basis.upload(d->basis, sizeof(float) * (size_t)d->app_dim * ctot);
+    if (!rc) rc = v->tv_acc.alloc(12 * sizeof(double));
+    if (rc) { evd_voxel_destroy(v); return rc; }
+    GridParams& g = v->gp;
+    for (int i = 0; i < 3; ++i) {
+        g.plane[i] = (const float*)v->plane[i].p; g.line[i] = (const float*)v->line[i].p;
+        g.n_comp[i] = d->n_comp[i]; g.grid[i] = d->grid[i];
+        g.aabb_min[i] = d->aabb[i];
+        g.inv[i] = 2.0f / (d->aabb[3 + i] - d->aabb[i]);
+    }
+    g.basis = (const float*)v->basis.p; g.app_dim = d->app_dim; g.app_act = d->app_act;
+
+    // weight streams (order = kernel_voxel.hip k_voxel_mlp)
+    const int T = HD / 32, KS = HD / 16, KF = FT / 16;
+    const bool small = (1 + G) <= 32;
+    auto hid_col = [](int j, int kk) { return 16 * j + phi(kk); };
+    auto in0_col = [&](int j, int kk) {            // cat([fts, PE(pts)]): natural feature k-steps then the PE arrangement
+        if (j < KF) return 16 * j + kk;
+        const int c = pe_src_col(PE_L, 8 * (j - KF) + (kk & 7), kk >> 3);
+        return c < 0 ? -1 : FT + c;
+    };
+    auto c0_col = [&](int j, int kk) {             // cat([h[...,1:], PE(dirs)]) voxnerf.py:248
+        const int gk = small ? 1 : G / 16;
+        if (j < gk) {
+            const int row = 16 * j + phi(kk);      // index into the sigma-layer output tile(s)
+            return small ? (row >= 1 && row <= G ? row - 1 : -1) : row;
+        }
+        const int c = pe_src_col(PE_LV, 8 * (j - gk) + (kk & 7), kk >> 3);
+        return c < 0 ? -1 : G + c;
+    };
+    for (int prec = 0; prec < 3; ++prec) {
+        StreamBuilder sb(prec);
+        sb.layer(d->sigma_w[0], HD, d->input_ch, T, KF + PE_KS, false, in0_col);
+        if (small) {
+            sb.layer(d->sigma_w[1], 1 + G, HD, 1, KS, false, hid_col);
+        } else {
+            sb.layer_rc(d->sigma_w[1], HD, 1, KS, false, [](int, int r) { return r == 0 ? 0 : -1; }, hid_col);       // sigma row
+            sb.layer_rc(d->sigma_w[1], HD, G / 32, KS, false, [](int t, int r) { return 1 + 32 * t + r; }, hid_col); // geo rows
+        }
+        sb.layer(d->color_w[0], HD, G + ICV, T, (small ? 1 : G / 16) + PEV_KS, false, c0_col);
+        sb.layer(d->color_w[1], HD, HD, T, KS, false, hid_col);
+        sb.layer(d->color_w[2], 3, HD, 1, KS, true, hid_col);
+        v->nchunks[prec] = (int)(sb.bytes.size() / chunk_bytes(prec));
+        rc = v->stream[prec].upload(sb.bytes.data(), sb.bytes.size());
+        if (rc) { evd_voxel_destroy(v); return rc; }
+    }
+    std::vector<float> b(32 * 16, 0.f);            // zero block shared by the bias-free sigma layers
+    auto push = [&](const float* src, int out_dim, int tiles) {
+        for (int i = 0; i < tiles * 32; ++i) b.push_back((src && i < out_dim) ? src[i] : 0.f);
+    };
+    push(d->color_b[0], HD, T);
+    push(d->color_b[1], HD, T);
+    push(d->color_b[2], 3, 1);
+    rc = v->bias.upload(b.data(), b.size() * sizeof(float));
+    if (rc) { evd_voxel_destroy(v); return rc; }
+    *out = v;
+    return EVD_OK;
+}
+
+int evd_voxel_sample(const evd_voxel* v, const float* pts, long n, float* out, int out_stride, int out_col, void* stream) {
+    EVD_REQUIRE(v && out && n >= 0 && out_stride >= out_col + v->app_dim, "evd_voxel_sample: bad arguments");
+    if (n == 0) return EVD_OK;
+    return launch_voxel_sample(v->gp, pts, n, out, out_stride, out_col, as_stream(stream));
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+size_t evd_voxel_forward_workspace_bytes(const evd_voxel* v, long R, int S) {
+    if (!v || R < 0 || S < 1) return 0;
+    return align256((size_t)R * S * 16) + 512;
+}
+
+static int voxel_pass(const evd_voxel* v, int precision, const float* pts, const float* viewdirs, int vd_stride, const float* fts,
+                      int ft_stride, const float* z, const float* rays_d, int rd_stride, long R, int S, int is_train,
+                      const float* noise, float* color, float* depth, float* acc, float* weights, float* feature, float* raw,
+                      void* stream) {
+    VoxMlpParams p;
+    p.wstream = (const char*)v->stream[precision].p;
+    p.bias = (const float*)v->bias.p;
+    p.pts = pts; p.viewdirs = viewdirs; p.fts = fts; p.nsamp = R * (long)S; p.S = S; p.vd_stride = vd_stride; p.ft_stride = ft_stride;
+    p.nchunks = v->nchunks[precision]; p.raw = raw; p.feature = feature;
+    int rc = voxel_mlp_dispatch(precision, v->hidden_dim, v->geo, v->ft_dim, p, as_stream(stream));
+    if (rc) return rc;
+    const float thr = (!is_train && v->rmnear > 0.f) ? (float)((double)v->rmnear / 128.0) : 0.f;
+    return evd_raw2outputs(raw, z, rays_d, rd_stride, R, S, 4, 0, 1, 3, v->rgb_act, v->sigma_act, 0, thr, noise,
+                           color, nullptr, acc, weights, depth, nullptr, 0, nullptr, stream);
+}
+
+int evd_voxel_forward(const evd_voxel* v, int precision, const float* pts, const float* viewdirs, int vd_stride, const float* fts, int F,
+                      const float* z, const float* rays_d, int rays_d_stride, long R, int S, int is_train,
+                      float* color, float* depth, float* acc, float* weights, float* feature,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+    EVD_REQUIRE(v && pts && viewdirs && fts && z && rays_d, "evd_voxel_forward: null argument");
+    EVD_REQUIRE(precision >= 0 && precision <= 2, "evd_voxel_forward: unknown precision %d", precision);
+    EVD_REQUIRE(F == v->ft_dim, "evd_voxel_forward: fts has %d channels, this level takes %d", F, v->ft_dim);
+    EVD_REQUIRE(weights, "evd_voxel_forward: the weights output is required");
+    if (R == 0) return EVD_OK;
+    const size_t need = evd_voxel_forward_workspace_bytes(v, R, S);
+    if (!workspace || workspace_bytes < need) return fail(EVD_E_WORKSPACE, "evd_voxel_forward: workspace %zu < %zu bytes", workspace_bytes, need);
+    float* raw = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    return voxel_pass(v, precision, pts, viewdirs, vd_stride, fts, F, z, rays_d, rays_d_stride, R, S, is_train, nullptr,
+                      color, depth, acc, weights, feature, raw, stream);
+}
+
+size_t evd_c2f_render_workspace_bytes(const evd_voxel* coarse, const evd_voxel* fine, const evd_render_cfg* cfg, long R) {
+    if (!coarse || !cfg || R < 0) return 0;
+    const size_t S = cfg->N_samples, Ni = cfg->N_importance > 0 ? cfg->N_importance : 0, St = S + Ni, r = (size_t)R;
+    size_t b = 0;
+    b += align256(r * 11 * 4);              // ray_batch
+    b += align256(r * S * 4);               // z0
+    b += align256(r * St * 4);              // z merged
+    b += align256(r * St * 12);             // pts
+    b += align256(r * St * 64 * 4);         // features [n,64]
+    b += align256(r * St * 16);             // raw
+    b += align256(r * S * 4);               // weights0
+    b += align256(r * St * 4);              // weights
+    b += align256(r * (Ni ? Ni : 1) * 4);   // z_samples
+    return b + 512;
+}
+
+int evd_c2f_render_rays(const evd_voxel* coarse, const evd_voxel* fine, const evd_render_cfg* cfg, const float* rb, long R,
+                        const float* t_rand, const float* u, const float* noise0, const float* noise1,
+                        evd_render_out* out, void* workspace, size_t workspace_bytes, void* stream) {
+    EVD_REQUIRE(coarse && cfg && out && (rb || R == 0), "evd_c2f_render_rays: null argument");
+    EVD_REQUIRE(cfg->use_viewdirs, "evd_c2f_render_rays: use_viewdirs=False is not supported");
+    EVD_REQUIRE(cfg->N_importance <= 0 || fine, "evd_c2f_render_rays: N_importance > 0 needs the fine level");
+    EVD_REQUIRE(cfg->N_importance <= 0 || cfg->N_samples >= 3, "evd_c2f_render_rays: hierarchical sampling needs N_samples >= 3");
+    EVD_REQUIRE(!(cfg->perturb > 0.f) || (t_rand && (cfg->N_importance <= 0 || u)), "evd_c2f_render_rays: perturb > 0 needs explicit draws");
+    EVD_REQUIRE(coarse->ft_dim == coarse->app_dim && (!fine || fine->ft_dim == coarse->app_dim + fine->app_dim),
+                "evd_c2f_render_rays: feature widths do not chain (coarse app_dim %d, fine input %d)", coarse->app_dim, fine ? fine->ft_dim : -1);
+    if (R == 0) return EVD_OK;
+    const size_t need = evd_c2f_render_workspace_bytes(coarse, fine, cfg, R);
+    if (!workspace || workspace_bytes < need) return fail(EVD_E_WORKSPACE, "evd_c2f_render_rays: workspace %zu < %zu bytes", workspace_bytes, need);
+    const int S = cfg->N_samples, Ni = cfg->N_importance > 0 ? cfg->N_importance : 0, St = S + Ni;
+    hipStream_t st = as_stream(stream);
+    char* w = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    auto take = [&](size_t bytes) { char* p = w; w += align256(bytes); return (float*)p; };
+    const size_t r = (size_t)R;
+    (void)take(r * 11 * 4);
+    float* z0 = take(r * S * 4);
+    float* z2 = take(r * St * 4);
+    float* pts = take(r * St * 12);
+    float* ft = take(r * St * 64 * 4);
+    float* raw = take(r * St * 16);
+    float* wts0 = take(r * S * 4);
+    float* wts = take(r * St * 4);
+    float* zs = take(r * (Ni ? Ni : 1) * 4);
+    const int FS = 64;      // feature row stride: coarse features at column 0, fine at column coarse->app_dim (renderer.py:195)
+    int rc;
+    float* zc = (Ni ? (out->z_vals0 ? out->z_vals0 : z0) : (out->z_vals ? out->z_vals : z0));
+    if ((rc = evd_sample_z(cfg, rb, 11, R, t_rand, zc, stream))) return rc;
+    if ((rc = launch_points(rb, 11, zc, R * (long)S, S, pts, st))) return rc;
+    if ((rc = evd_voxel_sample(coarse, pts, R * (long)S, ft, FS, 0, stream))) return rc;          // renderer.py:183
+    if (!Ni) {
+        float* wo = out->weights ? out->weights : wts;
+        return voxel_pass(coarse, cfg->precision, pts, rb + 8, 11, ft, FS, zc, rb + 3, 11, R, S, cfg->is_train, noise0,
+                          out->rgb, out->depth, out->acc, wo, out->feature, out->raw ? out->raw : raw, stream);
+    }
+    float* w0 = out->weights0 ? out->weights0 : wts0;
+    if ((rc = voxel_pass(coarse, cfg->precision, pts, rb + 8, 11, ft, FS, zc, rb + 3, 11, R, S, cfg->is_train, noise0,
+                         out->rgb0, out->depth0, out->acc0, w0, nullptr, raw, stream))) return rc;
+    float* zm = out->z_vals ? out->z_vals : z2;
+    if ((rc = evd_sample_pdf_merge(zc, w0, R, S, Ni, cfg->perturb == 0.f, u, zs, zm, nullptr, out->z_std, stream))) return rc;
+    // merged sample set (renderer.py:205-213).  The reference re-orders the features it sampled at the old and
+    // the new points; features are a pure function of the point, so sampling both levels at the merged points
+    // yields the same values without the gather by `order`.
+    const long n2 = R * (long)St;
+    if ((rc = launch_points(rb, 11, zm, n2, St, pts, st))) return rc;
+    if ((rc = evd_voxel_sample(coarse, pts, n2, ft, FS, 0, stream))) return rc;
+    if ((rc = evd_voxel_sample(fine, pts, n2, ft, FS, coarse->app_dim, stream))) return rc;
+    float* wo = out->weights ? out->weights : wts;
+    return voxel_pass(fine, cfg->precision, pts, rb + 8, 11, ft, FS, zm, rb + 3, 11, R, St, cfg->is_train, noise1,
+                      out->rgb, out->depth, out->acc, wo, out->feature, out->raw ? out->raw : raw, stream);
+}
+
+int evd_c2f_render(const evd_voxel* coarse, const evd_voxel* fine, const evd_render_cfg* cfg, const float* rays, long R,
+                   const float* t_rand, const float* u, const float* noise0, const float* noise1,
+                   evd_render_out* out, void* workspace, size_t workspace_bytes, void* stream) {
+    EVD_REQUIRE(cfg && coarse && (rays || R == 0), "evd_c2f_render: null argument");
+    if (R == 0) return EVD_OK;
+    const size_t need = evd_c2f_render_workspace_bytes(coarse, fine, cfg, R);
+    if (!workspace || workspace_bytes < need) return fail(EVD_E_WORKSPACE, "evd_c2f_render: workspace %zu < %zu bytes", workspace_bytes, need);
+    float* rb = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    int rc = evd_ray_batch(cfg, rays, R, rb, stream);
+    if (rc) return rc;
+    return evd_c2f_render_rays(coarse, fine, cfg, rb, R, t_rand, u, noise0, noise1, out, workspace, workspace_bytes, stream);
+}
+
+int evd_voxel_tv_loss(const evd_voxel* v, float* out, void* stream) {
+    EVD_REQUIRE(v && out, "evd_voxel_tv_loss: null argument");
+    hipStream_t st = as_stream(stream);
+    double* acc = (double*)v->tv_acc.p;
+    EVD_HIP(hipMemsetAsync(acc, 0, 12 * sizeof(double), st));
+    TvShape s;
+    for (int i = 0; i < 3; ++i) {
+        const int C = v->n_comp[i], Wp = v->grid[kMat0[i]], Hp = v->grid[kMat1[i]], Lp = v->grid[kVec[i]];
+        s.C[i] = C; s.H[i] = Hp; s.W[i] = Wp;
+        s.C[3 + i] = C; s.H[3 + i] = Lp; s.W[3 + i] = 1;
+        int rc = launch_tv((const float*)v->plane[i].p, Hp, Wp, C, acc + 2 * i, st);
+        if (!rc) rc = launch_tv((const float*)v->line[i].p, Lp, 1, C, acc + 2 * (3 + i), st);
+        if (rc) return rc;
+    }
+    return launch_tv_finish(acc, s, out, st);
+}
+
+}  // extern "C"

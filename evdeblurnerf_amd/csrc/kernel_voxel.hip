@@ -1,0 +1,274 @@
+// PDRF backbone (reference networks/pdrf/voxnerf.py): tri-plane feature gather + sigma/colour MLPs + TV reg.
+//
+//   k_points        pts = o + d z                                      (renderer.py:180,206)
+//   k_voxel_sample  VoxelNeRFBase.sample / compute_appfeature          (voxnerf.py:203-208,132-151)
+//                   planes are kept CHANNEL-LAST on the device ([H][W][C], lines [L][C]) so that one bilinear
+//                   tap of one plane is one contiguous 64..256-byte read instead of C strided ones.
+//   k_voxel_mlp     VoxelNeRFBase.forward, per-sample part             (voxnerf.py:210-221,240-254)
+//                   sigma net + colour net on the same transposed-MFMA machinery as the NeRF backbone.
+//   k_tv            TVLoss.forward over one plane/line                 (voxnerf.py:306-324)
+#include "mlp_device.h"
+#include "voxel.h"
+
+namespace evd {
+
+__global__ void k_points(const float* __restrict__ rb, int nc, const float* __restrict__ z, long n, int S, float* __restrict__ pts) {
+    const long s = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const float* r = rb + (s / S) * nc;
+    const float zv = z[s];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) pts[s * 3 + c] = __fadd_rn(r[c], __fmul_rn(r[3 + c], zv));
+}
+
+__device__ __forceinline__ float unnorm(float c, int size) { return __fmul_rn(__fadd_rn(c, 1.f) / 2.f, (float)(size - 1)); }
+
+constexpr int VS_SAMPLES = 32;      // samples per 256-thread block
+constexpr int VS_MAXC = 128;        // max sum(n_comp)
+
+// F.grid_sample(bilinear, zeros, align_corners=True) x 6, product, basis_mat.  Arithmetic order and the
+// interpolation-weight form (w = x - floor x, e = 1 - w) follow the ATen CPU kernel, unfused.
+__global__ __launch_bounds__(256) void k_voxel_sample(const GridParams g, const float* __restrict__ pts, long n,
+                                                      float* __restrict__ out, int out_stride, int out_col) {
+    __shared__ __attribute__((aligned(16))) float coef[VS_SAMPLES][VS_MAXC + 4];
+    const int mat0[3] = {0, 0, 1}, mat1[3] = {1, 2, 2}, vec[3] = {2, 1, 0};
+    const int ctot = g.n_comp[0] + g.n_comp[1] + g.n_comp[2];
+    const int ng = ctot / 4;
+    const long s0 = blockIdx.x * (long)VS_SAMPLES;
+    for (int t = threadIdx.x; t < VS_SAMPLES * ng; t += blockDim.x) {
+        const int sl = t / ng, grp = t % ng;
+        const long s = s0 + sl;
+        if (s >= n) continue;
+        int i = 0, c4 = grp * 4;
+        if (c4 >= g.n_comp[0]) { c4 -= g.n_comp[0]; i = 1; if (c4 >= g.n_comp[1]) { c4 -= g.n_comp[1]; i = 2; } }
+        float xyz[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) xyz[c] = __fsub_rn(__fmul_rn(__fsub_rn(pts[s * 3 + c], g.aabb_min[c]), g.inv[c]), 1.f);   // voxnerf.py:205
+        const int C = g.n_comp[i];
+        const int Wp = g.grid[mat0[i]], Hp = g.grid[mat1[i]], Lp = g.grid[vec[i]];
+        const float ix = unnorm(xyz[mat0[i]], Wp), iy = unnorm(xyz[mat1[i]], Hp);
+        const float fx = floorf(ix), fy = floorf(iy);
+        const float ww = __fsub_rn(ix, fx), ee = __fsub_rn(1.f, ww), nn = __fsub_rn(iy, fy), ss = __fsub_rn(1.f, nn);
+        const long x0 = (long)fx, y0 = (long)fy, x1 = x0 + 1, y1 = y0 + 1;
+        const bool vx0 = x0 >= 0 && x0 < Wp, vx1 = x1 >= 0 && x1 < Wp, vy0 = y0 >= 0 && y0 < Hp, vy1 = y1 >= 0 && y1 < Hp;
+        const float* pl = g.plane[i] + c4;
+        f32x4 pv = {0.f, 0.f, 0.f, 0.f};
+        auto tap = [&](long yy, long xx, float wgt) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(pl + (yy * Wp + xx) * C);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pv[k] = __fadd_rn(pv[k], __fmul_rn(v[k], wgt));
+        };
+        if (vy0 && vx0) tap(y0, x0, __fmul_rn(ee, ss));
+        if (vy0 && vx1) tap(y0, x1, __fmul_rn(ww, ss));
+        if (vy1 && vx0) tap(y1, x0, __fmul_rn(ee, nn));
+        if (vy1 && vx1) tap(y1, x1, __fmul_rn(ww, nn));
+        const float il = unnorm(xyz[vec[i]], Lp);
+        const float fl = floorf(il);
+        const float ln = __fsub_rn(il, fl), ls = __fsub_rn(1.f, ln);
+        const long l0 = (long)fl, l1 = l0 + 1;
+        f32x4 lv = {0.f, 0.f, 0.f, 0.f};
+        const float* li = g.line[i] + c4;
+        if (l0 >= 0 && l0 < Lp) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(li + l0 * C);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) lv[k] = __fadd_rn(lv[k], __fmul_rn(v[k], ls));
+        }
+        if (l1 >= 0 && l1 < Lp) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(li + l1 * C);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) lv[k] = __fadd_rn(lv[k], __fmul_rn(v[k], ln));
+        }
+        f32x4 cf;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cf[k] = __fmul_rn(pv[k], lv[k]);
+        *reinterpret_cast<f32x4*>(&coef[sl][grp * 4]) = cf;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < VS_SAMPLES * g.app_dim; t += blockDim.x) {
+        const int sl = t / g.app_dim, f = t % g.app_dim;
+        const long s = s0 + sl;
+        if (s >= n) continue;
+        const float* bw = g.basis + (long)f * ctot;
+        float acc = 0.f;
+        for (int k = 0; k < ctot; ++k) acc = __fadd_rn(acc, __fmul_rn(coef[sl][k], bw[k]));     // basis_mat, voxnerf.py:151
+        out[s * (long)out_stride + out_col + f] = act(g.app_act, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// HD hidden width, G geo_feat_dim, FT feature channels read per sample (32 coarse, 64 fine)
+template <int PREC, int HD, int G, int FT>
+__global__ __launch_bounds__(mlp_threads(PREC), PREC == EVD_PREC_BF16 ? 2 : 1) void k_voxel_mlp(const VoxMlpParams p) {
+    typedef Ops<PREC> O;
+    typedef typename O::B B;
+    constexpr int NT = mlp_threads(PREC);
+    constexpr int T = HD / 32, KS = HD / 16, KF = FT / 16;
+    constexpr int FPC = Stream<PREC>::FPC;
+    constexpr bool kSmallGeo = (1 + G) <= 32;          // coarse level: [sigma, geo] fits one tile
+    constexpr int GT = kSmallGeo ? 1 : G / 32;         // geo tiles
+    constexpr int GK = kSmallGeo ? 1 : G / 16;         // geo k-steps fed to the colour net
+    static_assert(kSmallGeo || G % 32 == 0, "geo_feat_dim must be < 32 or a multiple of 32");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, h = lane >> 5;
+    const long s = (long)blockIdx.x * (NT / 2) + wave * 32 + n;
+    const bool valid = s < p.nsamp;
+    const long sc = valid ? s : p.nsamp - 1;
+    float pts[3], vd[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        pts[c] = p.pts[sc * 3 + c];
+        vd[c] = p.viewdirs[(sc / p.S) * p.vd_stride + c];
+    }
+    // layer-0 input = cat([fts, PE(pts)])  (voxnerf.py:214): FT/16 natural k-steps + the PE arrangement
+    B in0[KF + PE_KS], in_dir[PEV_KS];
+    {
+        const float* f = p.fts + sc * (long)p.ft_stride + 8 * h;
+#pragma unroll
+        for (int j = 0; j < KF; ++j) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(f + 16 * j), b = *reinterpret_cast<const f32x4*>(f + 16 * j + 4);
+            const f32x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+            in0[j] = O::make_b(v);
+        }
+        B pe[PE_KS];
+        encode_b<PREC, PE_L, PE_KS>(pts, h, pe);
+#pragma unroll
+        for (int j = 0; j < PE_KS; ++j) in0[KF + j] = pe[j];
+        encode_b<PREC, PE_LV, PEV_KS>(vd, h, in_dir);
+    }
+    Stream<PREC> st;
+    st.start(p.wstream, smem, p.nchunks, tid);
+    const float* zero_bias = p.bias;       // first 32*max tiles floats of the bias block are zeros (sigma net: bias=False)
+    const float* cbias = p.bias + 32 * 16;
+
+    constexpr int F0 = T * (KF + PE_KS);
+    B hid[KS];
+    layer<PREC, KF + PE_KS, T, true, OUT_B, 0, false>(st, in0, hid, nullptr, zero_bias, lane, nullptr, HD);
+    constexpr int OFF1 = F0 % FPC;
+    float sig[16];
+    B cin[GK + PEV_KS];
+    float* frow = (p.feature && valid) ? p.feature + s * G : nullptr;
+    if constexpr (kSmallGeo) {
+        // one tile holds [sigma, geo_1..G]; it is both the sigma output and (k-step 0) the colour-net input
+        B tmp[2];
+        layer<PREC, KS, 1, false, OUT_BOTH, OFF1, false>(st, hid, tmp, sig, zero_bias, lane, nullptr, HD);
+        cin[0] = tmp[0];
+        if (frow) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row >= 1 && row <= G) frow[row - 1] = sig[r];
+            }
+        }
+    } else {
+        layer<PREC, KS, 1, false, OUT_F32, OFF1, false>(st, hid, nullptr, sig, zero_bias, lane, nullptr, HD);
+        constexpr int OFF1b = (F0 + KS) % FPC;
+        layer<PREC, KS, GT, false, OUT_B, OFF1b, false>(st, hid, cin, nullptr, zero_bias, lane, frow, G);
+    }
+    constexpr int F1 = kSmallGeo ? KS : KS + GT * KS;
+#pragma unroll
+    for (int j = 0; j < PEV_KS; ++j) cin[GK + j] = in_dir[j];
+    constexpr int OFF2 = (F0 + F1) % FPC;
+    B c0[KS], c1[KS];
+    layer<PREC, GK + PEV_KS, T, true, OUT_B, OFF2, false>(st, cin, c0, nullptr, cbias, lane, nullptr, HD);
+    constexpr int F2 = T * (GK + PEV_KS);
+    constexpr int OFF3 = (F0 + F1 + F2) % FPC;
+    layer<PREC, KS, T, true, OUT_B, OFF3, false>(st, c0, c1, nullptr, cbias + 32 * T, lane, nullptr, HD);
+    constexpr int OFF4 = (F0 + F1 + F2 + T * KS) % FPC;
+    float col[16];
+    layer<PREC, KS, 1, false, OUT_F32, OFF4, true>(st, c1, nullptr, col, cbias + 64 * T, lane, nullptr, HD);
+    if (h == 0 && valid) {
+        f32x4 o;
+        o[0] = sig[0];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[1 + c] = 1.f / (1.f + expf(-col[c]));      // torch.sigmoid(h) voxnerf.py:252
+        *reinterpret_cast<f32x4*>(p.raw + s * 4) = o;
+    }
+}
+
+template <int PREC, int HD, int G, int FT>
+static int launch_vox(const VoxMlpParams& p, hipStream_t st) {
+    constexpr int NT = mlp_threads(PREC);
+    const long blocks = cdiv(p.nsamp, NT / 2);
+    const size_t lds = 2 * (size_t)chunk_bytes(PREC);
+    hipLaunchKernelGGL((k_voxel_mlp<PREC, HD, G, FT>), dim3((unsigned)blocks), dim3(NT), lds, st, p);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+int voxel_mlp_dispatch(int prec, int HD, int G, int FT, const VoxMlpParams& p, hipStream_t st) {
+#define EVD_CASE(P, H_, G_, F_) if (prec == P && HD == H_ && G == G_ && FT == F_) return launch_vox<P, H_, G_, F_>(p, st)
+    EVD_CASE(EVD_PREC_BF16, 64, 15, 32);
+    EVD_CASE(EVD_PREC_F16X3, 64, 15, 32);
+    EVD_CASE(EVD_PREC_F32, 64, 15, 32);
+    EVD_CASE(EVD_PREC_BF16, 256, 128, 64);
+    EVD_CASE(EVD_PREC_F16X3, 256, 128, 64);
+    EVD_CASE(EVD_PREC_F32, 256, 128, 64);
+#undef EVD_CASE
+    return fail(EVD_E_INVALID, "evd_voxel: no kernel for precision %d hidden %d geo %d features %d "
+                "(built: coarse 64/15/32, fine 256/128/64)", prec, HD, G, FT);
+}
+
+// TVLoss.forward (voxnerf.py:306-324) on a channel-last tensor [H][W][C]; accumulates sum dh^2, sum dw^2
+__global__ __launch_bounds__(256) void k_tv(const float* __restrict__ x, int H, int W, int C, double* __restrict__ acc2) {
+    __shared__ double red[2][4];
+    const long n = (long)H * W * C;
+    double sh = 0.0, sw = 0.0;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+        const long hw = idx / C;
+        const int hh = hw / W, wq = hw % W;
+        const float v = x[idx];
+        if (hh + 1 < H) { const float d = x[idx + (long)W * C] - v; sh += (double)(d * d); }
+        if (wq + 1 < W) { const float d = x[idx + C] - v; sw += (double)(d * d); }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { sh += __shfl_xor(sh, off, 64); sw += __shfl_xor(sw, off, 64); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sh; red[1][threadIdx.x >> 6] = sw; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(acc2, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomicAdd(acc2 + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+}
+
+__global__ void k_tv_finish(const double* __restrict__ acc, TvShape s, float* __restrict__ out) {
+    // total = sum_i reg(plane_i) * 1e-2 + reg(line_i) * 1e-3,  reg = 2 (h_tv / count_h + w_tv / count_w)  (voxnerf.py:126-130)
+    double total = 0.0;
+    for (int i = 0; i < 6; ++i) {
+        const double ch = (double)s.C[i] * (s.H[i] - 1) * s.W[i];
+        double cw = (double)s.C[i] * s.H[i] * (s.W[i] - 1);
+        if (cw < 1.0) cw = 1.0;
+        const double reg = 2.0 * (acc[2 * i] / ch + acc[2 * i + 1] / cw);
+        total += reg * (i < 3 ? 1e-2 : 1e-3);
+    }
+    out[0] = (float)total;
+}
+
+int launch_points(const float* rb, int nc, const float* z, long n, int S, float* pts, hipStream_t st) {
+    k_points<<<cdiv(n, 256), 256, 0, st>>>(rb, nc, z, n, S, pts);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+int launch_voxel_sample(const GridParams& g, const float* pts, long n, float* out, int out_stride, int out_col, hipStream_t st) {
+    k_voxel_sample<<<cdiv(n, VS_SAMPLES), 256, 0, st>>>(g, pts, n, out, out_stride, out_col);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+int launch_tv(const float* x, int H, int W, int C, double* acc2, hipStream_t st) {
+    const long n = (long)H * W * C;
+    const long blocks = cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048;
+    k_tv<<<(unsigned)blocks, 256, 0, st>>>(x, H, W, C, acc2);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+int launch_tv_finish(const double* acc, const TvShape& s, float* out, hipStream_t st) {
+    k_tv_finish<<<1, 1, 0, st>>>(acc, s, out);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+}  // namespace evd

@@ -1,0 +1,36 @@
+// Shared between kernel_voxel.hip (kernels + launchers) and evd_voxel_api.hip (C ABI).
+#pragma once
+
+#include "evd_common.h"
+
+namespace evd {
+
+struct GridParams {
+    const float* plane[3];      // channel-last [grid[m1]][grid[m0]][C_i]
+    const float* line[3];       // [grid[vec]][C_i]
+    const float* basis;         // [app_dim][Ctot]
+    int n_comp[3], grid[3], app_dim, app_act;
+    float aabb_min[3], inv[3];  // inv = 2 / (max - min)  (invaabbSize, voxnerf.py:91)
+};
+
+struct VoxMlpParams {
+    const char* wstream;
+    const float* bias;          // 512 zero floats (bias-free sigma net) then the colour-net biases, 32 per output tile
+    const float* pts;           // [n,3]
+    const float* viewdirs;      // rows of vd_stride floats, one per ray
+    const float* fts;           // [n, ft_stride]
+    long nsamp;
+    int S, vd_stride, ft_stride, nchunks;
+    float* raw;                 // [n,4] = (sigma, sigmoid(colour))  voxnerf.py:254
+    float* feature;             // [n,G] or null
+};
+
+struct TvShape { int C[6], H[6], W[6]; };
+
+int launch_points(const float* rb, int nc, const float* z, long n, int S, float* pts, hipStream_t st);
+int launch_voxel_sample(const GridParams& g, const float* pts, long n, float* out, int out_stride, int out_col, hipStream_t st);
+int launch_tv(const float* x, int H, int W, int C, double* acc2, hipStream_t st);
+int launch_tv_finish(const double* acc, const TvShape& s, float* out, hipStream_t st);
+int voxel_mlp_dispatch(int prec, int HD, int G, int FT, const VoxMlpParams& p, hipStream_t st);
+
+}  // namespace evd

@@ -30,13 +30,13 @@ def _args_get(args, name, default):
 
 
 class NeRFAll:
-    """mode='nerf' renderer (two NeRF MLPs). mode='c2f' (PDRF) lives in renderer_c2f once built."""
+    """mode='nerf' (two NeRF MLPs, renderer.py:82-100) or mode='c2f' (PDRF coarse/fine levels, :46-81)."""
 
     def __init__(self, args, state_dict, kernelsnet=None, awpnet=None, precision="f16x3", device=None):
         self.args = args
         self.mode = args.mode
-        if self.mode != "nerf":
-            raise NotImplementedError(f"mode {self.mode!r}: only 'nerf' is built in this round (see DESIGN.md)")
+        if self.mode not in ("nerf", "c2f"):
+            raise NotImplementedError(f"{self.mode} for rendering network is not implemented")
         self.kernel_type = _args_get(args, "kernel_type", None)
         self.kernelsnet = kernelsnet
         self.awpnet = awpnet
@@ -45,17 +45,37 @@ class NeRFAll:
         self.precision = precision
         self.training = False
         self.device = torch.device(device or "cuda")
-        common = dict(D=args.netdepth, W=args.netwidth, multires=args.multires, multires_views=args.multires_views,
-                      rgb_activate=args.rgb_activate, sigma_activate=args.sigma_activate,
-                      render_rmnearplane=_args_get(args, "render_rmnearplane", 0),
-                      extract_feature=self.extract_feature, composite_feature=False, precision=precision)
         if not args.use_viewdirs:
             raise NotImplementedError("use_viewdirs=False networks are not supported (no shipped config uses them)")
-        self.mlp_coarse = NeRF(state_dict, "mlp_coarse.", **common)
         self.mlp_fine = None
-        if args.N_importance > 0:
-            common_f = dict(common, D=_args_get(args, "netdepth_fine", args.netdepth), W=_args_get(args, "netwidth_fine", args.netwidth))
-            self.mlp_fine = NeRF(state_dict, "mlp_fine.", **common_f)
+        if self.mode == "nerf":
+            common = dict(D=args.netdepth, W=args.netwidth, multires=args.multires, multires_views=args.multires_views,
+                          rgb_activate=args.rgb_activate, sigma_activate=args.sigma_activate,
+                          render_rmnearplane=_args_get(args, "render_rmnearplane", 0),
+                          extract_feature=self.extract_feature, composite_feature=False, precision=precision)
+            self.mlp_coarse = NeRF(state_dict, "mlp_coarse.", **common)
+            if args.N_importance > 0:
+                common_f = dict(common, D=_args_get(args, "netdepth_fine", args.netdepth), W=_args_get(args, "netwidth_fine", args.netwidth))
+                self.mlp_fine = NeRF(state_dict, "mlp_fine.", **common_f)
+        else:
+            from .voxnerf import VoxelNeRFRayFeatures, VoxelNeRFSampleFeatures
+            if self.kernel_type == "PBE":
+                raise NotImplementedError("kernel_type PBE (composite_feature=True) is not built; shipped configs use RBK")
+            ic = 3 * (1 + 2 * args.multires)
+            rm = _args_get(args, "render_rmnearplane", 0)
+            self.mlp_coarse = VoxelNeRFRayFeatures(
+                state_dict, "mlp_coarse.", args.bounding_box, num_layers=args.coarse_num_layers, hidden_dim=args.coarse_hidden_dim,
+                geo_feat_dim=_args_get(args, "kernel_feat_cnl", 15), num_layers_color=args.coarse_num_layers_color,
+                input_ch=args.coarse_app_dim + ic, multires=args.multires, multires_views=args.multires_views,
+                render_rmnearplane=rm, app_dim=args.coarse_app_dim, app_n_comp=args.coarse_app_n_comp, n_voxels=args.coarse_n_voxels,
+                app_actfn=_args_get(args, "coarse_app_actfn", "none"), precision=precision)
+            if args.N_importance > 0:
+                self.mlp_fine = VoxelNeRFSampleFeatures(
+                    state_dict, "mlp_fine.", args.bounding_box, num_layers=args.fine_num_layers, hidden_dim=args.fine_hidden_dim,
+                    geo_feat_dim=args.fine_geo_feat_dim, num_layers_color=args.fine_num_layers_color,
+                    input_ch=args.coarse_app_dim + args.fine_app_dim + ic, multires=args.multires, multires_views=args.multires_views,
+                    render_rmnearplane=rm, app_dim=args.fine_app_dim, app_n_comp=args.fine_app_n_comp, n_voxels=args.fine_n_voxels,
+                    app_actfn=_args_get(args, "fine_app_actfn", "none"), precision=precision)
         self._ws = None
 
     # nn.Module-like switches used by run_nerf.py
@@ -79,7 +99,11 @@ class NeRFAll:
         return c
 
     def _workspace(self, cfg, R):
-        need = int(L.lib().evd_nerf_render_workspace_bytes(C.byref(cfg), R))
+        if self.mode == "c2f":
+            need = int(L.lib().evd_c2f_render_workspace_bytes(self.mlp_coarse.handle, self.mlp_fine.handle if self.mlp_fine else None,
+                                                              C.byref(cfg), R))
+        else:
+            need = int(L.lib().evd_nerf_render_workspace_bytes(C.byref(cfg), R))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty((need,), dtype=torch.uint8, device=self.device)
         return self._ws, need
@@ -132,7 +156,8 @@ class NeRFAll:
                 ret["z_vals0"], ret["weights0"] = torch.empty((R, S), **f32), torch.empty((R, S), **f32)
                 out.z_vals0, out.weights0 = L.ptr(ret["z_vals0"]), L.ptr(ret["weights0"])
         if want_feat:
-            ret["depth_feature"] = torch.empty((R, St, (self.mlp_fine or self.mlp_coarse).W), **f32)
+            last = self.mlp_fine if (Ni > 0 and self.mlp_fine is not None) else self.mlp_coarse
+            ret["depth_feature"] = torch.empty((R, St, last.W if self.mode == "nerf" else last.geo_feat_dim), **f32)
             out.feature = L.ptr(ret["depth_feature"])
         out.feature_kind = 2 if self.extract_feature == "before_linear" else 1
         ws, need = self._workspace(cfg, R)
@@ -141,14 +166,16 @@ class NeRFAll:
         uu = u.contiguous().float() if u is not None else None
         n0 = noise0.contiguous().float() if noise0 is not None else None
         n1 = noise1.contiguous().float() if noise1 is not None else None
+        fn_rays, fn_render = ((L.lib().evd_nerf_render_rays, L.lib().evd_nerf_render) if self.mode == "nerf" else
+                              (L.lib().evd_c2f_render_rays, L.lib().evd_c2f_render))
         if _rays is None:
-            L.check(L.lib().evd_nerf_render_rays(self.mlp_coarse.handle, fine, C.byref(cfg), L.ptr(rb), R, L.ptr(tr), L.ptr(uu),
+            L.check(fn_rays(self.mlp_coarse.handle, fine, C.byref(cfg), L.ptr(rb), R, L.ptr(tr), L.ptr(uu),
                                                  L.ptr(n0), L.ptr(n1), C.byref(out), L.ptr(ws), need, L.stream_ptr()),
-                    "evd_nerf_render_rays")
+                    "render_rays")
         else:
-            L.check(L.lib().evd_nerf_render(self.mlp_coarse.handle, fine, C.byref(cfg), L.ptr(_rays), R, L.ptr(tr), L.ptr(uu),
+            L.check(fn_render(self.mlp_coarse.handle, fine, C.byref(cfg), L.ptr(_rays), R, L.ptr(tr), L.ptr(uu),
                                             L.ptr(n0), L.ptr(n1), C.byref(out), L.ptr(ws), need, L.stream_ptr()),
-                    "evd_nerf_render")
+                    "render")
         if not retraw and "z_vals" in ret and not want_feat:
             del ret["z_vals"]
         if check_numerics:
@@ -241,6 +268,7 @@ class NeRFAll:
                 other_tensors["rgb_awp"] = weighted_sum(rgb, ccw_fine)
             rgb_out = weighted_sum(rgb, weight1)
             rgb1 = weighted_sum(extras["rgb0"], weight1) if N_importance > 0 else None
+            self._tv(other_loss, N_importance)
             if align_loss is not None:
                 other_loss["align"] = align_loss.reshape(1, 1)
             other_tensors.update(extra1)
@@ -253,6 +281,15 @@ class NeRFAll:
         other_tensors["stage1_rgb_pts0"] = rgb
         if N_importance > 0:
             other_tensors["stage1_rgb1_pts0"] = extras["rgb0"]
+        self._tv(other_loss, N_importance)
         return rgb, extras["rgb0"] if "rgb0" in extras else None, other_loss, other_tensors
+
+    def _tv(self, other_loss, N_importance):
+        """TV regulariser of the tri-planes, renderer.py:361-365 / :385-389."""
+        if self.mode == "c2f":
+            tv = self.mlp_coarse.TV_loss_app()
+            if N_importance > 0 and self.mlp_fine is not None:
+                tv = tv + self.mlp_fine.TV_loss_app()
+            other_loss["TV"] = tv * 5
 
     __call__ = forward

@@ -1,0 +1,123 @@
+"""Mirror of the reference ``networks/pdrf/voxnerf.py`` (VoxelNeRFBase :6, VoxelNeRFRayFeatures :262,
+VoxelNeRFSampleFeatures :284) on libevdnerf.so: tri-plane feature gather, sigma/colour MLPs, TV regulariser."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .weights import pdrf_grid_size
+
+
+def _np32(v):
+    if isinstance(v, torch.Tensor):
+        v = v.detach().cpu().numpy()
+    return np.ascontiguousarray(v, dtype=np.float32)
+
+
+class VoxelNeRFBase:
+    def __init__(self, state_dict, prefix, aabb, num_layers=2, hidden_dim=64, geo_feat_dim=15, num_layers_color=3,
+                 hidden_dim_color=64, input_ch=95, multires=10, multires_views=4, render_rmnearplane=0, app_dim=32,
+                 app_n_comp=(64, 16, 16), n_voxels=134217984, rgb_activate="sigmoid", sigma_activate="relu",
+                 composite_feature=False, app_actfn="none", precision="f16x3"):
+        lo, hi = [float(v) for v in aabb[0]], [float(v) for v in aabb[1]]
+        self.gridSize = pdrf_grid_size(lo, hi, n_voxels)
+        self.hidden_dim, self.geo_feat_dim, self.app_dim = hidden_dim, geo_feat_dim, app_dim
+        self.input_ch, self.precision = input_ch, precision
+        self.rgb_activate, self.sigma_activate = rgb_activate, sigma_activate
+        self.render_rmnearplane = render_rmnearplane
+        self.composite_feature = composite_feature
+        self.training = False
+        g = lambda k: _np32(state_dict[prefix + k]) if (prefix + k) in state_dict else None
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
+        keep = []
+        d = L.VoxelDesc()
+        d.num_layers, d.hidden_dim, d.geo_feat_dim, d.num_layers_color = num_layers, hidden_dim, geo_feat_dim, num_layers_color
+        d.input_ch, d.multires, d.multires_views, d.app_dim = input_ch, multires, multires_views, app_dim
+        for i in range(3):
+            d.n_comp[i], d.grid[i] = int(app_n_comp[i]), int(self.gridSize[i])
+            d.aabb[i], d.aabb[3 + i] = lo[i], hi[i]
+        d.app_act, d.rgb_act, d.sigma_act = L.ACT[app_actfn], L.ACT[rgb_activate], L.ACT[sigma_activate]
+        d.composite_feature, d.rmnear = int(bool(composite_feature)), float(render_rmnearplane)
+        for l in range(num_layers):
+            w = g(f"sigma_net.{l}.weight")
+            keep.append(w)
+            d.sigma_w[l] = fp(w)
+        for l in range(num_layers_color):
+            w, b = g(f"color_net.{l}.weight"), g(f"color_net.{l}.bias")
+            keep += [w, b]
+            d.color_w[l], d.color_b[l] = fp(w), fp(b)
+        mat, vec = [[0, 1], [0, 2], [1, 2]], [2, 1, 0]
+        for i in range(3):
+            pl, li = g(f"app_plane.{i}"), g(f"app_line.{i}")
+            exp_p = (1, app_n_comp[i], self.gridSize[mat[i][1]], self.gridSize[mat[i][0]])
+            if pl is None or tuple(pl.shape) != exp_p:
+                raise L.EvdError(f"{prefix}app_plane.{i}: expected shape {exp_p}, got {None if pl is None else pl.shape}")
+            keep += [pl, li]
+            d.plane[i], d.line[i] = fp(pl), fp(li)
+        b = g("basis_mat.weight")
+        keep.append(b)
+        d.basis = fp(b)
+        h = C.c_void_p()
+        L.check(L.lib().evd_voxel_create(C.byref(d), C.byref(h)), "evd_voxel_create")
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            L.lib().evd_voxel_destroy(h)
+            self._h = None
+
+    @property
+    def handle(self):
+        return self._h
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    # voxnerf.py:203-208
+    def sample(self, pts):
+        sh = pts.shape
+        p = pts.reshape(-1, 3).contiguous().float()
+        out = torch.empty((p.shape[0], self.app_dim), dtype=torch.float32, device=p.device)
+        L.check(L.lib().evd_voxel_sample(self._h, L.ptr(p), p.shape[0], L.ptr(out), self.app_dim, 0, L.stream_ptr()), "evd_voxel_sample")
+        return out.reshape(sh[0], sh[1], self.app_dim) if len(sh) == 3 else out
+
+    # voxnerf.py:210-259; returns (color, depth_map, acc_map, weights, feature_map)
+    def forward(self, pts, viewdirs, fts, z_vals, rays_d, raw_noise_std=0., is_train=False, precision=None):
+        if raw_noise_std > 0:
+            raise NotImplementedError("density noise goes through render_rays(noise0=..., noise1=...)")
+        p = pts.contiguous().float()
+        R, S = p.shape[:2]
+        vd, ft, z, rd = viewdirs.contiguous().float(), fts.contiguous().float(), z_vals.contiguous().float(), rays_d.contiguous().float()
+        dev = p.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        color, depth, acc = torch.empty((R, 3), **f32), torch.empty((R,), **f32), torch.empty((R,), **f32)
+        wts, feat = torch.empty((R, S), **f32), torch.empty((R, S, self.geo_feat_dim), **f32)
+        need = int(L.lib().evd_voxel_forward_workspace_bytes(self._h, R, S))
+        ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+        L.check(L.lib().evd_voxel_forward(self._h, L.PREC[precision or self.precision], L.ptr(p), L.ptr(vd), 3, L.ptr(ft), ft.shape[-1],
+                                          L.ptr(z), L.ptr(rd), 3, R, S, int(bool(is_train)), L.ptr(color), L.ptr(depth), L.ptr(acc),
+                                          L.ptr(wts), L.ptr(feat), L.ptr(ws), need, L.stream_ptr()), "evd_voxel_forward")
+        return color, depth, acc, wts, feat
+
+    __call__ = forward
+
+    # voxnerf.py:126-130
+    def TV_loss_app(self):
+        out = torch.empty((1,), dtype=torch.float32, device="cuda")
+        L.check(L.lib().evd_voxel_tv_loss(self._h, L.ptr(out), L.stream_ptr()), "evd_voxel_tv_loss")
+        return out[0]
+
+
+class VoxelNeRFRayFeatures(VoxelNeRFBase):
+    def __init__(self, *a, n_voxels=16777248, rgb_activate="relu", **kw):
+        super().__init__(*a, n_voxels=n_voxels, rgb_activate=rgb_activate, **kw)
+
+
+class VoxelNeRFSampleFeatures(VoxelNeRFBase):
+    def __init__(self, *a, n_voxels=134217984, rgb_activate="none", **kw):
+        super().__init__(*a, n_voxels=n_voxels, rgb_activate=rgb_activate, **kw)

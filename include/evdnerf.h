@@ -147,6 +147,43 @@ int evd_nerf_render(const evd_nerf* coarse, const evd_nerf* fine, const evd_rend
                     const float* t_rand, const float* u, const float* noise0, const float* noise1,
                     evd_render_out* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------- PDRF backbone (networks/pdrf/voxnerf.py) */
+typedef struct evd_voxel evd_voxel; /* opaque: channel-last tri-plane grids + packed MLPs on one device */
+
+typedef struct {                    /* host float32 pointers */
+    int num_layers, hidden_dim, geo_feat_dim, num_layers_color, input_ch, multires, multires_views;
+    int app_dim, n_comp[3], grid[3], app_act, rgb_act, sigma_act, composite_feature;
+    float aabb[6], rmnear;
+    const float *sigma_w[EVD_MAX_LAYERS];
+    const float *color_w[EVD_MAX_LAYERS], *color_b[EVD_MAX_LAYERS];
+    const float *plane[3], *line[3], *basis;
+} evd_voxel_desc;
+
+int evd_voxel_create(const evd_voxel_desc* desc, evd_voxel** out);
+void evd_voxel_destroy(evd_voxel* v);
+/* VoxelNeRFBase.sample / compute_appfeature, voxnerf.py:203-208,132-151.  pts dev [n,3] -> out dev [n,out_stride]
+ * written at column out_col (so coarse and fine features can share one [n,64] buffer, renderer.py:195) */
+int evd_voxel_sample(const evd_voxel* v, const float* pts, long n, float* out, int out_stride, int out_col, void* stream);
+/* VoxelNeRFBase.forward, voxnerf.py:210-259.  pts dev [R,S,3], viewdirs dev rows of vd_stride floats,
+ * fts dev [R,S,F] -> color [R,3], depth [R], acc [R], weights [R,S], feature [R,S,geo] */
+int evd_voxel_forward(const evd_voxel* v, int precision, const float* pts, const float* viewdirs, int vd_stride, const float* fts, int F,
+                      const float* z, const float* rays_d, int rays_d_stride, long R, int S, int is_train,
+                      float* color, float* depth, float* acc, float* weights, float* feature,
+                      void* workspace, size_t workspace_bytes, void* stream);
+size_t evd_voxel_forward_workspace_bytes(const evd_voxel* v, long R, int S);
+size_t evd_c2f_render_workspace_bytes(const evd_voxel* coarse, const evd_voxel* fine, const evd_render_cfg* cfg, long R);
+/* NeRFAll.render_rays for mode='c2f' (networks/renderer.py:182-217); arguments as evd_nerf_render_rays.
+ * out->feature receives the fine level's per-sample geo features [R,S_final,geo_feat_dim] (what AWP consumes). */
+int evd_c2f_render_rays(const evd_voxel* coarse, const evd_voxel* fine, const evd_render_cfg* cfg, const float* ray_batch, long R,
+                        const float* t_rand, const float* u, const float* noise0, const float* noise1,
+                        evd_render_out* out, void* workspace, size_t workspace_bytes, void* stream);
+/* NeRFAll.render for mode='c2f' = evd_ray_batch + evd_c2f_render_rays */
+int evd_c2f_render(const evd_voxel* coarse, const evd_voxel* fine, const evd_render_cfg* cfg, const float* rays, long R,
+                   const float* t_rand, const float* u, const float* noise0, const float* noise1,
+                   evd_render_out* out, void* workspace, size_t workspace_bytes, void* stream);
+/* TV_loss_app, voxnerf.py:126-130 (TVLoss :306-324): sum over planes*1e-2 + lines*1e-3 -> out dev [1] (float) */
+int evd_voxel_tv_loss(const evd_voxel* v, float* out, void* stream);
+
 /* ---------------------------------------------------------------- loss-side pixel ops */
 /* RigidBlurringModel.rbk_weighted_sum, networks/dpnerf/blurmodel.py:112-127 (and renderer.py:299,332-354):
  * out[r,c] = sum_p ccw[r,p] x[r*P+p, c] */

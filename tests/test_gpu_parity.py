@@ -357,3 +357,101 @@ def test_edi_matches_golden():
         assert maxabs(N(img), g[f"bii_ni{s}"]) < 2e-6
     assert maxabs(N(deblur_double_integral(T(g["blurry"]), T(g["bii"]))), g["sharp"]) < 2e-6
     assert maxabs(N(deblur_double_integral(T(g["blurry3"]), T(g["bii3"]))), g["sharp3"]) < 2e-6
+
+
+# ----------------------------------------------------------------------------------------------- PDRF (mode='c2f')
+AABB = ([-1.5, -1.5, -1.0], [1.5, 1.5, 1.0])
+
+
+def _c2f_args(N_importance=64):
+    from types import SimpleNamespace
+    return SimpleNamespace(mode="c2f", multires=10, multires_views=4, use_viewdirs=True, N_importance=N_importance,
+                           kernel_type="RBK", kernel_use_awp=False, rgb_activate="sigmoid", sigma_activate="relu",
+                           bounding_box=AABB, coarse_num_layers=2, coarse_num_layers_color=3, coarse_hidden_dim=64,
+                           coarse_hidden_dim_color=64, coarse_app_dim=32, coarse_app_n_comp=[64, 16, 16], coarse_n_voxels=24 ** 3,
+                           kernel_feat_cnl=15, fine_num_layers=2, fine_num_layers_color=3, fine_hidden_dim=256,
+                           fine_hidden_dim_color=256, fine_geo_feat_dim=128, fine_app_dim=32, fine_app_n_comp=[64, 16, 16],
+                           fine_n_voxels=48 ** 3)
+
+
+def _c2f_sd(seed_c, seed_f):
+    gc = W.pdrf_grid_size(AABB[0], AABB[1], 24 ** 3)
+    gf = W.pdrf_grid_size(AABB[0], AABB[1], 48 ** 3)
+    sd = dict(W.prefixed(W.make_pdrf_state_dict(seed_c, gc, input_ch=95, hidden_dim=64, geo_feat_dim=15), "mlp_coarse"))
+    sd.update(W.prefixed(W.make_pdrf_state_dict(seed_f, gf, input_ch=127, hidden_dim=256, geo_feat_dim=128), "mlp_fine"))
+    return sd, gc, gf
+
+
+def test_voxel_sample_matches_golden(O):
+    from evdeblurnerf_amd.renderer import NeRFAll
+    g = load_golden("G8_appfeature")
+    sd, gc, gf = _c2f_sd(21, 22)
+    model = NeRFAll(_c2f_args(), sd).eval()
+    assert model.mlp_coarse.gridSize == list(g["grid_coarse"]) and model.mlp_fine.gridSize == list(g["grid_fine"])
+    pts = T(g["pts"])
+    # bilinear taps + basis matmul in the ATen-CPU operation order: float32 rounding only
+    assert maxabs(N(model.mlp_coarse.sample(pts)), g["ft_coarse"]) < 2e-6
+    assert maxabs(N(model.mlp_fine.sample(pts)), g["ft_fine"]) < 2e-6
+    # large batch incl. points far outside the box (zero padding) against the oracle
+    rs = np.random.RandomState(3)
+    big = (rs.uniform(-2.2, 2.2, size=(20000, 3)) * np.array([1.0, 1.0, 0.7])).astype(np.float32)
+    aabb6 = AABB[0] + AABB[1]
+    vc = O.Voxel(sd, "mlp_coarse.", gc, aabb6, input_ch=95)
+    assert maxabs(N(model.mlp_coarse.sample(T(big))), O.appfeature(vc, big)) < 2e-6
+    # TV regulariser (voxnerf.py:126-130) vs the oracle's TVLoss restatement
+    tv_ref = sum(O.tv_loss(sd[f"mlp_coarse.app_plane.{i}"]) * 1e-2 + O.tv_loss(sd[f"mlp_coarse.app_line.{i}"]) * 1e-3 for i in range(3))
+    assert abs(float(model.mlp_coarse.TV_loss_app()) - tv_ref) < 1e-5 * tv_ref
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 1e-4), ("f16x3", 1e-4), ("bf16", 3e-2)])
+def test_c2f_render_matches_reference_golden(prec, tol, O):
+    """NeRFAll.render mode='c2f' (PDRF coarse + fine level) vs goldens produced by the reference (G9)."""
+    from evdeblurnerf_amd.renderer import NeRFAll
+    g = load_golden("G9_render_c2f")
+    sd, gc, gf = _c2f_sd(31, 32)
+    K = W.synthetic_camera()
+    rays = T(W.synthetic_rays(9, 64))
+    kw = dict(ndc=True, near=0., far=1., use_viewdirs=True, N_samples=64, retraw=True, perturb=0., raw_noise_std=0.)
+    model = NeRFAll(_c2f_args(), sd, precision=prec).eval()
+    rgb, depth, acc, ex = model.render(400, 400, K, rays=rays, N_importance=64, **kw)
+    e = maxabs(N(rgb), g["rgb"])
+    print(f"[c2f {prec}] RGB L-inf vs reference = {e:.3e}; coarse rgb0 {maxabs(N(ex['rgb0']), g['rgb0']):.3e}")
+    assert e < tol
+    assert maxabs(N(ex["rgb0"]), g["rgb0"]) < tol
+    assert maxabs(N(acc), g["acc"]) < tol and maxabs(N(depth), g["depth"]) < 3 * tol
+    assert maxabs(N(ex["z_vals0"]), g["z_vals0"]) < 1e-6
+    assert maxabs(N(ex["weights0"]), g["weights0"]) < tol
+    frac, worst = z_mismatch(N(ex["z_vals"]), g["z_vals"], tol=5e-5 if prec != "bf16" else 5e-3)
+    assert frac < (0.01 if prec != "bf16" else 0.3) and worst < 1.0 / 63 + 1e-3, (frac, worst)
+    model0 = NeRFAll(_c2f_args(0), sd, precision=prec).eval()
+    rgb, depth, acc, ex = model0.render(400, 400, K, rays=rays, N_importance=0, **kw)
+    assert maxabs(N(rgb), g["c_rgb"]) < tol and maxabs(N(ex["weights"]), g["c_weights"]) < tol
+    if prec == "f16x3":
+        # per-sample fine-level features (AWP input) and the NDC ray directions returned with them
+        from types import SimpleNamespace
+        model.use_awp = True
+        rgb, depth, acc, ex = model.render(400, 400, K, rays=rays[:16], N_importance=64, **kw)
+        assert ex["depth_feature"].shape == (16, 128, 128)
+        tight = np.abs(N(ex["z_vals"]) - g["z_vals"][:16]).max(-1) < 2e-6
+        assert tight.sum() >= 4
+        assert maxabs(N(ex["depth_feature"])[:, :, :8][tight], g["f_depth_feature"][tight]) < 2e-4
+        assert maxabs(N(ex["rays_d"]), g["f_rays_d"]) < 2e-6
+        # VoxelNeRFBase.forward entry on its own, against the oracle
+        aabb6 = AABB[0] + AABB[1]
+        vf = O.Voxel(sd, "mlp_fine.", gf, aabb6, input_ch=127, hidden_dim=256, geo_feat_dim=128, rgb_act="none")
+        rs = np.random.RandomState(4)
+        R, S = 24, 40
+        pts = rs.uniform(-1, 1, size=(R, S, 3)).astype(np.float32)
+        vd = rs.standard_normal((R, 3)).astype(np.float32)
+        vd /= np.linalg.norm(vd, axis=-1, keepdims=True)
+        fts = rs.standard_normal((R, S, 64)).astype(np.float32) * 0.3
+        z = np.sort(rs.uniform(0, 1, size=(R, S)).astype(np.float32), -1)
+        rd = rs.standard_normal((R, 3)).astype(np.float32)
+        col, dep, ac, wt, ft = model.mlp_fine(T(pts), T(vd), T(fts), T(z), T(rd))
+        import ctypes as C
+        oc, od, oa, ow = (np.empty((R, 3), np.float32), np.empty((R,), np.float32), np.empty((R,), np.float32), np.empty((R, S), np.float32))
+        of = np.empty((R, S, 128), np.float32)
+        fpp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        O.lib().evo_voxel_forward(C.byref(vf.s), fpp(pts), fpp(vd), fpp(fts), 64, fpp(z), fpp(rd), C.c_long(R), S, 10, 4, 0,
+                                  fpp(oc), fpp(od), fpp(oa), fpp(ow), fpp(of))
+        assert maxabs(N(col), oc) < 2e-5 and maxabs(N(wt), ow) < 2e-5 and maxabs(N(ft), of) < 5e-5
