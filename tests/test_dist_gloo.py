@@ -1,0 +1,90 @@
+"""N > 1 path on CPU: world_size-2 gloo processes exercise the sharding + the single packed loss all-reduce and the
+row-tile gather of evdeblurnerf_amd/dist.py (the HIP kernels themselves need a GPU; here the per-shard partials
+come from a numpy stand-in with the same packed layout, which is what the collective sees)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _partials_numpy(pred, tgt):
+    """packed layout of losses.blur_loss_partials: [se_rgb, 0, 0, 0, 0, n_elem, 0, 0]"""
+    p = np.zeros(8, np.float32)
+    p[0] = ((pred - tgt) ** 2).sum()
+    p[5] = pred.size
+    return p
+
+
+def _worker(rank, world, port, R, P, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from evdeblurnerf_amd import dist as D
+    r, w, _ = D.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    rs = np.random.RandomState(0)
+    pred = rs.rand(R, 3).astype(np.float32)
+    tgt = rs.rand(R, 3).astype(np.float32)
+    ev = rs.rand(4).astype(np.float32)
+    (plo, phi), (rlo, rhi) = D.shard_pixels(R, P, rank, world)
+    assert (rlo, rhi) == (plo * P, phi * P)
+    blur = torch.from_numpy(_partials_numpy(pred[plo:phi], tgt[plo:phi]))
+    event = torch.from_numpy(ev * (rank + 1))
+    D.all_reduce_partials(blur, event)
+    rows = torch.from_numpy(pred[plo:phi])
+    full = D.gather_rows(rows, R)
+    q.put((rank, blur.numpy().copy(), event.numpy().copy(), full.numpy().copy()))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("R", [1024, 7, 1])
+def test_two_rank_loss_allreduce_and_gather(R):
+    world, P = 2, 10
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, R, P, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rs = np.random.RandomState(0)
+    pred = rs.rand(R, 3).astype(np.float32)
+    tgt = rs.rand(R, 3).astype(np.float32)
+    ev = rs.rand(4).astype(np.float32)
+    ref = _partials_numpy(pred, tgt)
+    for rank, blur, event, full in res:
+        assert np.allclose(blur, ref, rtol=1e-5)                       # global sums on every rank
+        assert blur[5] == 3 * R
+        assert np.allclose(event, ev * 3, rtol=1e-6)
+        assert np.array_equal(full, pred)                              # row tiles reassemble the frame, ragged shards included
+        mse = blur[0] / blur[5]
+        assert abs(mse - ((pred - tgt) ** 2).mean()) < 1e-6
+
+
+def test_shard_range_partitions():
+    from evdeblurnerf_amd.dist import shard_range
+    for n in (0, 1, 7, 8, 4096, 160000):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
