@@ -123,7 +123,7 @@ int evd_nerf_mlp(const evd_nerf* net, int precision, const float* ray_batch, con
     p.wstream = (const char*)net->stream[precision].p;
     p.bias = (const float*)net->bias.p;
     p.ray_batch = ray_batch; p.z = z; p.nsamp = R * (long)S; p.S = S; p.ncol = 11;
-    p.D = net->D; p.skip = net->skip; p.nchunks = net->nchunks[precision];
+    p.D = net->D; p.skip = net->skip; p.nchunks = net->nchunks[precision]; p.nbias = (int)(net->bias.bytes / sizeof(float));
     p.raw = raw; p.feature = feature; p.feature_kind = feature ? feature_kind : 0;
     return nerf_mlp_dispatch(precision, net->W, p, as_stream(stream));
 }

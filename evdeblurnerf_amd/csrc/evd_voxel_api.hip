@@ -145,7 +145,7 @@ static int voxel_pass(const evd_voxel* v, int precision, const float* pts, const
     p.wstream = (const char*)v->stream[precision].p;
     p.bias = (const float*)v->bias.p;
     p.pts = pts; p.viewdirs = viewdirs; p.fts = fts; p.nsamp = R * (long)S; p.S = S; p.vd_stride = vd_stride; p.ft_stride = ft_stride;
-    p.nchunks = v->nchunks[precision]; p.raw = raw; p.feature = feature;
+    p.nchunks = v->nchunks[precision]; p.nbias = (int)(v->bias.bytes / sizeof(float)); p.raw = raw; p.feature = feature;
     int rc = voxel_mlp_dispatch(precision, v->hidden_dim, v->geo, v->ft_dim, p, as_stream(stream));
     if (rc) return rc;
     const float thr = (!is_train && v->rmnear > 0.f) ? (float)((double)v->rmnear / 128.0) : 0.f;

@@ -38,18 +38,26 @@ __global__ __launch_bounds__(mlp_threads(PREC), PREC == EVD_PREC_BF16 ? 2 : 1) v
         vd[c] = rb[8 + c];
     }
 
-    // positional encodings straight into B-fragment order (nerf_mlp.h)
-    B in_pe[PE_KS], in_dir[PEV_KS];
-    encode_b<PREC, PE_L, PE_KS>(pts, h, in_pe);
-    encode_b<PREC, PE_LV, PEV_KS>(vd, h, in_dir);
-
+    // point encoding straight into B-fragment order (nerf_mlp.h); a copy is parked in this wavefront's LDS stash
+    // for the skip layer instead of occupying registers through layers 1..skip
+    float* bias = stage_bias<PREC>(smem, p.bias, p.nbias, tid);
+    B* stash = reinterpret_cast<B*>(smem + MlpLds<PREC>::RING + MlpLds<PREC>::BIAS_FLOATS * 4 + wave * MlpLds<PREC>::STASH_PER_WAVE) + lane;
+    B act[KS], nxt[KS];
+    {
+        B in_pe[PE_KS];
+        encode_b<PREC, PE_L, PE_KS>(pts, h, in_pe);
+#pragma unroll
+        for (int j = 0; j < PE_KS; ++j) stash[j * 64] = in_pe[j];
+    }
     Stream<PREC> st;
     st.start(p.wstream, smem, p.nchunks, tid);
-    const float* bias = p.bias;
     float* frow = (p.feature && valid) ? p.feature + s * W : nullptr;
-
-    B act[KS], nxt[KS];
-    layer<PREC, PE_KS, T, true, OUT_B, 0, true>(st, in_pe, nxt, nullptr, bias, lane, (p.feature_kind == 2 && p.D == 1) ? frow : nullptr, W);
+    {
+        B in_pe[PE_KS];
+#pragma unroll
+        for (int j = 0; j < PE_KS; ++j) in_pe[j] = stash[j * 64];
+        layer<PREC, PE_KS, T, true, OUT_B, 0, true>(st, in_pe, nxt, nullptr, bias, lane, (p.feature_kind == 2 && p.D == 1) ? frow : nullptr, W);
+    }
     bias += T * 32;
 #pragma unroll
     for (int j = 0; j < KS; ++j) act[j] = nxt[j];
@@ -60,7 +68,7 @@ __global__ __launch_bounds__(mlp_threads(PREC), PREC == EVD_PREC_BF16 ? 2 : 1) v
         if (l - 1 == p.skip) {      // h = cat([input_pts, h]) feeds this layer (nerf.py:137-138)
             B wide[PE_KS + KS];
 #pragma unroll
-            for (int j = 0; j < PE_KS; ++j) wide[j] = in_pe[j];
+            for (int j = 0; j < PE_KS; ++j) wide[j] = stash[j * 64];
 #pragma unroll
             for (int j = 0; j < KS; ++j) wide[PE_KS + j] = act[j];
             layer<PREC, PE_KS + KS, T, true, OUT_B, 0, true>(st, wide, nxt, nullptr, bias, lane, fr, W);
@@ -84,8 +92,12 @@ __global__ __launch_bounds__(mlp_threads(PREC), PREC == EVD_PREC_BF16 ? 2 : 1) v
         B vin[KS + PEV_KS];
 #pragma unroll
         for (int j = 0; j < KS; ++j) vin[j] = nxt[j];
+        {
+            B in_dir[PEV_KS];
+            encode_b<PREC, PE_LV, PEV_KS>(vd, h, in_dir);
 #pragma unroll
-        for (int j = 0; j < PEV_KS; ++j) vin[KS + j] = in_dir[j];
+            for (int j = 0; j < PEV_KS; ++j) vin[KS + j] = in_dir[j];
+        }
         layer<PREC, KS + PEV_KS, T / 2, true, OUT_B, OFF_VIEWS, false>(st, vin, act, nullptr, bias, lane, nullptr, W);
         bias += (T / 2) * 32;
     }
@@ -105,7 +117,13 @@ template <int PREC, int W>
 static int launch_mlp(const MlpParams& p, hipStream_t st) {
     constexpr int NT = mlp_threads(PREC);
     const long blocks = cdiv(p.nsamp, NT / 2);
-    const size_t lds = 2 * (size_t)chunk_bytes(PREC);
+    const size_t lds = MlpLds<PREC>::TOTAL;
+    static bool attr_set = false;
+    if (!attr_set) {
+        EVD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nerf_mlp<PREC, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    if (p.nbias > MlpLds<PREC>::BIAS_FLOATS) return fail(EVD_E_INVALID, "evd_nerf_mlp: %d bias floats exceed the LDS bias block", p.nbias);
     hipLaunchKernelGGL((k_nerf_mlp<PREC, W>), dim3((unsigned)blocks), dim3(NT), lds, st, p);
     EVD_LAUNCH_CHECK();
     return EVD_OK;

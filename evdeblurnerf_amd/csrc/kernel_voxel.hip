@@ -137,10 +137,11 @@ __global__ __launch_bounds__(mlp_threads(PREC), PREC == EVD_PREC_BF16 ? 2 : 1) v
         for (int j = 0; j < PE_KS; ++j) in0[KF + j] = pe[j];
         encode_b<PREC, PE_LV, PEV_KS>(vd, h, in_dir);
     }
+    const float* lbias = stage_bias<PREC>(smem, p.bias, p.nbias, tid);
     Stream<PREC> st;
     st.start(p.wstream, smem, p.nchunks, tid);
-    const float* zero_bias = p.bias;       // first 32*max tiles floats of the bias block are zeros (sigma net: bias=False)
-    const float* cbias = p.bias + 32 * 16;
+    const float* zero_bias = lbias;        // first 512 floats of the bias block are zeros (sigma net: bias=False)
+    const float* cbias = lbias + 32 * 16;
 
     constexpr int F0 = T * (KF + PE_KS);
     B hid[KS];
@@ -191,7 +192,12 @@ template <int PREC, int HD, int G, int FT>
 static int launch_vox(const VoxMlpParams& p, hipStream_t st) {
     constexpr int NT = mlp_threads(PREC);
     const long blocks = cdiv(p.nsamp, NT / 2);
-    const size_t lds = 2 * (size_t)chunk_bytes(PREC);
+    const size_t lds = MlpLds<PREC>::TOTAL;
+    static bool attr_set = false;
+    if (!attr_set) {
+        EVD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_voxel_mlp<PREC, HD, G, FT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
     hipLaunchKernelGGL((k_voxel_mlp<PREC, HD, G, FT>), dim3((unsigned)blocks), dim3(NT), lds, st, p);
     EVD_LAUNCH_CHECK();
     return EVD_OK;

@@ -73,84 +73,126 @@ template <> struct Ops<EVD_PREC_F32> {
 };
 
 // ---------------------------------------------------------------------------------------------
-// weight stream: chunk c of the packed fragments is resident in LDS slot c&1 while chunk c+1 travels
-// global -> registers (issued at the start of chunk c) -> LDS (committed at its end, then one barrier).
+// Weight stream.  The packed fragments travel global -> LDS by LDS-DMA (global_load_lds_dwordx4: one wavefront
+// instruction copies 64 x 16 B = one 1 KiB piece straight into LDS, no staging registers) into a ring of
+// NSLOT chunks shared by all wavefronts of the workgroup.  Protocol, chunk c resident in slot c % 3:
+//   chunk_begin(c): issue the DMA of chunk c+2 (its slot held chunk c-1, which every wavefront finished
+//                   reading before the barrier that ended chunk c-1)
+//   chunk_end(c):   counted s_waitcnt vmcnt(4) -- this wavefront's pieces of chunk c+1 have landed while the
+//                   4 pieces of chunk c+2 stay in flight -- then ONE s_barrier.
+// The DMA and the waits are inline asm, so hipcc neither drains them early nor orders them; the "memory"
+// clobbers keep its LDS reads on the right side of the barrier.
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+__device__ __forceinline__ unsigned lds_offset_of(const void* p) {
+    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)p;
+}
+
 template <int PREC> struct Stream {
     static constexpr int NT = mlp_threads(PREC);
     static constexpr int CB = chunk_bytes(PREC);
     static constexpr int FB = frag_bytes(PREC);
     static constexpr int FPC = frags_per_chunk(PREC);
-    const char* g;
-    char* lds;
-    int nchunks, cur, tid;
-    f32x4 stg[4];
-    __device__ __forceinline__ void issue(int c) {
+    static constexpr int NSLOT = 3;
+    static constexpr int PIECES = CB / 1024 / (NT / 64);   // 1 KiB DMA pieces per wavefront per chunk
+    static_assert(PIECES == 4, "the counted vmcnt below assumes 4 pieces per wavefront per chunk");
+    const char* gsrc;       // this lane's source address of piece 0 of chunk 0
+    const char* lds;        // ring base (generic pointer, for the fragment reads)
+    unsigned dst0;          // LDS byte offset of this wavefront's piece 0 in slot 0 (wave-uniform)
+    int nchunks, cur, slot; // current chunk and its slot
+    __device__ __forceinline__ void issue(int c, int sl) {
         if (c < nchunks) {
-            const char* src = g + (size_t)c * CB + tid * 16;
+            const char* src = gsrc + (size_t)c * CB;
+            const unsigned dst = dst0 + sl * CB;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) stg[t] = *reinterpret_cast<const f32x4*>(src + t * NT * 16);
+            for (int t = 0; t < PIECES; ++t) dma16(src + t * 1024, dst + t * 1024);
         }
     }
-    __device__ __forceinline__ void commit(int c) {
-        if (c < nchunks) {
-            char* dst = lds + (c & 1) * CB + tid * 16;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(dst + t * NT * 16) = stg[t];
-        }
-    }
-    __device__ __forceinline__ void start(const char* gsrc, char* l, int n, int t) {
-        g = gsrc; lds = l; nchunks = n; tid = t; cur = 0;
-        issue(0);
-        commit(0);
+    __device__ __forceinline__ void start(const char* g, char* ring, int n, int tid) {
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+        gsrc = g + wave * (PIECES * 1024) + lane * 16;
+        lds = ring;
+        dst0 = lds_offset_of(ring) + wave * (PIECES * 1024);
+        nchunks = n; cur = 0; slot = 0;
+        issue(0, 0);
+        issue(1, 1);
+        if (n > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
     // fragment fc of the resident chunk, this lane's 16 bytes
-    __device__ __forceinline__ const char* frag(int fc, int lane) const { return lds + (cur & 1) * CB + fc * FB + lane * 16; }
-    __device__ __forceinline__ void chunk_begin() { issue(cur + 1); }
+    __device__ __forceinline__ const char* frag(int fc, int lane) const { return lds + slot * CB + fc * FB + lane * 16; }
+    __device__ __forceinline__ void chunk_begin() { issue(cur + 2, slot == 0 ? 2 : slot - 1); }   // (slot + 2) % 3
     __device__ __forceinline__ void chunk_end() {
-        commit(cur + 1);
-        __syncthreads();
+        if (cur + 2 < nchunks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         ++cur;
+        slot = slot == 2 ? 0 : slot + 1;
     }
 };
 
 enum { OUT_B = 1, OUT_F32 = 2, OUT_BOTH = 3 };
 
-// One linear layer on the wavefront's 32 samples.  in[KSTEPS] are B fragments; the output is either the next
-// layer's B fragments (OUT_B: out[2*TILES]) or the raw float32 D fragment of the (single) tile (OUT_F32).
+// One linear layer on the wavefront's 32 samples.  in[KSTEPS] are B fragments; the output is the next layer's
+// B fragments (OUT_B: out[2*TILES]) and/or the raw float32 D fragment of the (single) tile (OUT_F32).
 // FOFF = fragment offset inside the current chunk at entry (static); the layer leaves the stream at
-// (FOFF + TILES*KSTEPS) % FPC, or chunk-aligned when PAD_END.
+// (FOFF + TILES*KSTEPS) % FPC, or chunk-aligned when PAD_END.  bias points into LDS.
+// A fragments are read PD fragments ahead of their MFMA (never across a chunk boundary: the next chunk is only
+// guaranteed resident after the barrier), so LDS latency hides behind the previous MFMAs.
 template <int PREC, int KSTEPS, int TILES, bool RELU, int OUT, int FOFF, bool PAD_END>
 __device__ __forceinline__ void layer(Stream<PREC>& st, const typename Ops<PREC>::B (&in)[KSTEPS],
                                       typename Ops<PREC>::B* __restrict__ out, float* __restrict__ out_f32,
                                       const float* __restrict__ bias, int lane, float* __restrict__ feat_row, int W) {
     typedef Ops<PREC> O;
+    typedef typename O::A A;
     constexpr int FPC = Stream<PREC>::FPC;
     constexpr int G = TILES >= 2 ? 2 : 1;
+    constexpr int NF = TILES * KSTEPS;
+    constexpr int PD = PREC == EVD_PREC_F32 ? 2 : 4;        // prefetch depth in fragments
     static_assert(TILES % G == 0, "tile count must be a multiple of the accumulation group");
     const int h = lane >> 5;
+    A abuf[PD];
+    f32x16 acc[G], accx[G];
+    // fragments [0, need(f)) have been requested once step f is reached
+    auto need = [](int f) constexpr {
+        int lim = f + PD;
+        const int chunk_end_excl = ((FOFF + f) / FPC + 1) * FPC - FOFF;
+        if (lim > chunk_end_excl) lim = chunk_end_excl;
+        return lim > NF ? NF : lim;
+    };
 #pragma unroll
     for (int p = 0; p < TILES / G; ++p) {
-        f32x16 acc[G], accx[G];
-#pragma unroll
-        for (int t = 0; t < G; ++t) {
-            const float* bt = bias + (p * G + t) * 32 + 4 * h;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(bt + 8 * q);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { acc[t][4 * q + e] = bv[e]; accx[t][4 * q + e] = 0.f; }
-            }
-        }
 #pragma unroll
         for (int j = 0; j < KSTEPS; ++j) {
 #pragma unroll
             for (int t = 0; t < G; ++t) {
-                const int f = FOFF + (p * KSTEPS + j) * G + t;      // static after unrolling
-                const int fc = f % FPC;
+                const int f = (p * KSTEPS + j) * G + t;             // static after unrolling
+                const int fc = (FOFF + f) % FPC;
                 if (fc == 0) st.chunk_begin();
-                const typename O::A a = O::load_a(st.frag(fc, lane));
-                O::mma(acc[t], accx[t], a, in[j]);
+                const int lo = f == 0 ? 0 : need(f - 1), hi = need(f);
+#pragma unroll
+                for (int gq = 0; gq < PD; ++gq) {
+                    const int gf = lo + gq;
+                    if (gf < hi) abuf[gf % PD] = O::load_a(st.frag((FOFF + gf) % FPC, lane));
+                }
+                if (j == 0) {        // accumulators start from the bias (C layout rows (r&3) + 8(r>>2) + 4h)
+                    const float* bt = bias + (p * G + t) * 32 + 4 * h;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(bt + 8 * q);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { acc[t][4 * q + e] = bv[e]; accx[t][4 * q + e] = 0.f; }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);      // keep the prefetch reads ABOVE this MFMA (hipcc sinks them otherwise)
+                O::mma(acc[t], accx[t], abuf[f % PD], in[j]);
                 if (fc == FPC - 1) st.chunk_end();
             }
         }
@@ -178,17 +220,44 @@ __device__ __forceinline__ void layer(Stream<PREC>& st, const typename Ops<PREC>
             }
         }
     }
-    if (PAD_END && ((FOFF + TILES * KSTEPS) % FPC) != 0) st.chunk_end();
+    if (PAD_END && ((FOFF + NF) % FPC) != 0) st.chunk_end();
+}
+
+// LDS carve-up of the fused MLP kernels: [weight ring | biases | per-wavefront B-fragment stash]
+template <int PREC> struct MlpLds {
+    static constexpr int RING = Stream<PREC>::NSLOT * Stream<PREC>::CB;
+    static constexpr int BIAS_FLOATS = 4096;                              // 16 KiB: enough for D <= 12 at W = 256
+    static constexpr int STASH_PER_WAVE = PE_KS * 64 * (int)sizeof(typename Ops<PREC>::B);
+    static constexpr int STASH = (mlp_threads(PREC) / 64) * STASH_PER_WAVE;
+    static constexpr int TOTAL = RING + BIAS_FLOATS * 4 + STASH;
+};
+
+// cooperative copy of the bias block into LDS (before Stream::start, whose barrier publishes it)
+template <int PREC>
+__device__ __forceinline__ float* stage_bias(char* smem, const float* gbias, int nfloats, int tid) {
+    float* b = reinterpret_cast<float*>(smem + MlpLds<PREC>::RING);
+    for (int i = tid; i < nfloats; i += mlp_threads(PREC)) b[i] = gbias[i];
+    return b;
 }
 
 // sin(a) for h == 0, cos(a) for h == 1, with one shared code path: Cody-Waite reduction to [-pi/4, pi/4]
-// (3 fmaf terms, good for |a| < 1e5) and a quadrant-selected minimax polynomial; ocml beyond that.
+// (3 fmaf terms, good for |a| < 1e5; beyond that the reduction runs in float64, accurate to ~1e-7 up to
+// |a| ~ 1e9 -- positional-encoding arguments are 2^k x with x inside the scene box) and a quadrant-selected
+// minimax polynomial (max error 7e-8 against float64 sin/cos on the fast path).
 __device__ __forceinline__ float sin_or_cos(float a, int h) {
-    if (fabsf(a) > 1.0e5f || !(a == a)) return h ? cosf(a) : sinf(a);
-    const float j = rintf(a * 0.636619772f);
-    float r = fmaf(-j, 1.57079601e+00f, a);
-    r = fmaf(-j, 3.13916473e-07f, r);
-    r = fmaf(-j, 5.39030253e-15f, r);
+    float j, r;
+    if (__builtin_expect(fabsf(a) <= 1.0e5f, 1)) {
+        j = rintf(a * 0.636619772f);
+        r = fmaf(-j, 1.57079601e+00f, a);
+        r = fmaf(-j, 3.13916473e-07f, r);
+        r = fmaf(-j, 5.39030253e-15f, r);
+    } else {
+        const double ad = (double)a;
+        const double jd = rint(ad * 0.63661977236758134308);
+        const double rd = fma(-jd, 6.123233995736766036e-17, fma(-jd, 1.57079632679489655800, ad));
+        r = (float)rd;
+        j = (float)fmod(jd, 4.0);
+    }
     const int q = ((int)j + h) & 3;
     const float s = r * r;
     const bool use_cos = q & 1;

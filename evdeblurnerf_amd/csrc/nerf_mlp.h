@@ -47,7 +47,7 @@ struct MlpParams {
     const float* ray_batch; // [R, ncol]
     const float* z;         // [R, S]
     long nsamp;             // R * S
-    int S, ncol, D, skip, nchunks;
+    int S, ncol, D, skip, nchunks, nbias;
     float* raw;             // [R, S, 4]
     float* feature;         // [R, S, W] or null
     int feature_kind;       // 0 none, 1 after_linear, 2 before_linear

@@ -20,7 +20,7 @@ struct VoxMlpParams {
     const float* viewdirs;      // rows of vd_stride floats, one per ray
     const float* fts;           // [n, ft_stride]
     long nsamp;
-    int S, vd_stride, ft_stride, nchunks;
+    int S, vd_stride, ft_stride, nchunks, nbias;
     float* raw;                 // [n,4] = (sigma, sigmoid(colour))  voxnerf.py:254
     float* feature;             // [n,G] or null
 };
