@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libevdnerf.so")
+LIB_PATH = os.environ.get("EVD_LIB_PATH") or os.path.join(_HERE, "lib", "libevdnerf.so")
 MAXL = 16
 
 PREC = {"f32": 0, "f16x3": 1, "bf16": 2}

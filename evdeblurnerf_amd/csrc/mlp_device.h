@@ -131,7 +131,9 @@ template <int PREC> struct Stream {
         if (cur + 2 < nchunks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef EVD_ABLATE_BARRIER
         __builtin_amdgcn_s_barrier();
+#endif
         asm volatile("" ::: "memory");
         ++cur;
         slot = slot == 2 ? 0 : slot + 1;
@@ -155,7 +157,11 @@ __device__ __forceinline__ void layer(Stream<PREC>& st, const typename Ops<PREC>
     constexpr int FPC = Stream<PREC>::FPC;
     constexpr int G = TILES >= 2 ? 2 : 1;
     constexpr int NF = TILES * KSTEPS;
+#ifdef EVD_PD
+    constexpr int PD = PREC == EVD_PREC_F32 ? 2 : EVD_PD;
+#else
     constexpr int PD = PREC == EVD_PREC_F32 ? 2 : 4;        // prefetch depth in fragments
+#endif
     static_assert(TILES % G == 0, "tile count must be a multiple of the accumulation group");
     const int h = lane >> 5;
     A abuf[PD];
@@ -180,7 +186,11 @@ __device__ __forceinline__ void layer(Stream<PREC>& st, const typename Ops<PREC>
 #pragma unroll
                 for (int gq = 0; gq < PD; ++gq) {
                     const int gf = lo + gq;
+#ifdef EVD_ABLATE_LDS
+                    if (gf < hi && gf < PD) abuf[gf % PD] = O::load_a(st.frag((FOFF + gf) % FPC, lane));
+#else
                     if (gf < hi) abuf[gf % PD] = O::load_a(st.frag((FOFF + gf) % FPC, lane));
+#endif
                 }
                 if (j == 0) {        // accumulators start from the bias (C layout rows (r&3) + 8(r>>2) + 4h)
                     const float* bt = bias + (p * G + t) * 32 + 4 * h;
@@ -215,8 +225,14 @@ __device__ __forceinline__ void layer(Stream<PREC>& st, const typename Ops<PREC>
                 }
             }
             if (OUT & OUT_B) {
+#ifdef EVD_ABLATE_EPI
+                out[2 * tile] = in[0];
+                out[2 * tile + 1] = in[1];
+                asm volatile("" :: "v"(v[0][0]), "v"(v[1][7]));
+#else
                 out[2 * tile] = O::make_b(v[0]);
                 out[2 * tile + 1] = O::make_b(v[1]);
+#endif
             }
         }
     }
@@ -280,7 +296,11 @@ __device__ __forceinline__ void encode_b(const float (&x)[3], int h, typename Op
 #pragma unroll
     for (int q = 0; q < KSN * 8; ++q) {
         float y;
+#ifdef EVD_ABLATE_PE
+        if (q < 3 * L) y = x[q % 3] * (float)(1 << (q / 3));
+#else
         if (q < 3 * L) y = sin_or_cos(x[q % 3] * (float)(1 << (q / 3)), h);
+#endif
         else if (q == 3 * L) y = h ? x[1] : x[0];
         else if (q == 3 * L + 1) y = h ? 0.f : x[2];
         else y = 0.f;
