@@ -1,6 +1,7 @@
 // C-ABI entry points of the NeRF backbone: weight packing, fused MLP launch, render_rays orchestration.
 #include "evd_common.h"
 #include "nerf_mlp.h"
+#include "nerf_mlp_kernel.h"
 #include "pack.h"
 
 #include <cmath>
@@ -22,7 +23,8 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
-int nerf_mlp_dispatch(int prec, int W, const MlpParams& p, hipStream_t st);
+int nerf_mlp_generic_dispatch(int prec, int W, const MlpParams& p, hipStream_t st);
+int nerf_mlp_pipe_dispatch(int prec, const MlpParams& p, hipStream_t st);
 
 }  // namespace evd
 
@@ -31,8 +33,10 @@ using namespace evd;
 struct evd_nerf {
     int D, W, skip, rgb_act, sigma_act;
     float rmnear;
-    DevBuf stream[3];
-    int nchunks[3];
+    DevBuf stream[EVD_NUM_PREC];        // generic kernel: fragment streams per precision
+    int nchunks[EVD_NUM_PREC];
+    DevBuf pipe[EVD_NUM_PREC];          // software-pipelined kernel (where built): its own fragment order and chunking
+    int pipe_chunks[EVD_NUM_PREC];
     DevBuf bias;
 };
 
@@ -60,12 +64,23 @@ int evd_nerf_create(const evd_nerf_desc* d, evd_nerf** out) {
 
     auto pe_col = [](int j, int kk) { return pe_src_col(PE_L, 8 * j + (kk & 7), kk >> 3); };
     auto hid_col = [](int j, int kk) { return 16 * j + phi(kk); };
-    for (int prec = 0; prec < 3; ++prec) {
-        StreamBuilder sb(prec);
+    auto views_col = [&](int j, int kk) {
+        if (j < KS) return hid_col(j, kk);
+        const int c = pe_src_col(PE_LV, 8 * (j - KS) + (kk & 7), kk >> 3);
+        return c < 0 ? -1 : W + c;
+    };
+    // pdh < 0: the skip layer's k-steps are [pe_0..3 | h_0..h_{KS-1}] (generic kernel);
+    // else [h_0..h_{pdh-1} | pe_0..3 | h_pdh..h_{KS-1}] (pipelined kernel, nerf_mlp_kernel.h)
+    auto build = [&](StreamBuilder& sb, int pdh) {
         sb.layer(d->pts_w[0], W, IC, T, PE_KS, true, pe_col);
         for (int l = 1; l < d->D; ++l) {
             if (l - 1 == d->skip) {
-                auto wide_col = [&](int j, int kk) { return j < PE_KS ? pe_col(j, kk) : IC + hid_col(j - PE_KS, kk); };
+                auto wide_col = [&](int j, int kk) {
+                    if (pdh < 0) return j < PE_KS ? pe_col(j, kk) : IC + hid_col(j - PE_KS, kk);
+                    if (j < pdh) return IC + hid_col(j, kk);
+                    if (j < pdh + PE_KS) return pe_col(j - pdh, kk);
+                    return IC + hid_col(j - PE_KS, kk);
+                };
                 sb.layer(d->pts_w[l], W, W + IC, T, PE_KS + KS, true, wide_col);
             } else {
                 sb.layer(d->pts_w[l], W, W, T, KS, true, hid_col);
@@ -73,16 +88,24 @@ int evd_nerf_create(const evd_nerf_desc* d, evd_nerf** out) {
         }
         sb.layer(d->alpha_w, 1, W, 1, KS, false, hid_col);
         sb.layer(d->feature_w, W, W, T, KS, false, hid_col);
-        auto views_col = [&](int j, int kk) {
-            if (j < KS) return hid_col(j, kk);
-            const int c = pe_src_col(PE_LV, 8 * (j - KS) + (kk & 7), kk >> 3);
-            return c < 0 ? -1 : W + c;
-        };
         sb.layer(d->views_w, W / 2, W + ICV, T / 2, KS + PEV_KS, false, views_col);
         sb.layer(d->rgb_w, 3, W / 2, 1, KS / 2, true, hid_col);
+    };
+    for (int prec = 0; prec < EVD_NUM_PREC; ++prec) {
+        StreamBuilder sb(prec);
+        build(sb, -1);
         n->nchunks[prec] = (int)(sb.bytes.size() / chunk_bytes(prec));
         int rc = n->stream[prec].upload(sb.bytes.data(), sb.bytes.size());
         if (rc) { evd_nerf_destroy(n); return rc; }
+        n->pipe_chunks[prec] = 0;
+        if (nerf_pipe_built(prec, W, d->D, d->skip)) {
+            StreamBuilder sp(prec, PIPE_CB);
+            sp.group = nerf_group(prec);
+            build(sp, KS - 2 * nerf_group(prec));
+            n->pipe_chunks[prec] = (int)(sp.bytes.size() / PIPE_CB);
+            rc = n->pipe[prec].upload(sp.bytes.data(), sp.bytes.size());
+            if (rc) { evd_nerf_destroy(n); return rc; }
+        }
     }
     // biases, one 32-float row block per output tile, in stream order
     std::vector<float> b;
@@ -102,30 +125,32 @@ int evd_nerf_create(const evd_nerf_desc* d, evd_nerf** out) {
 
 void evd_nerf_destroy(evd_nerf* n) {
     if (!n) return;
-    for (int i = 0; i < 3; ++i) n->stream[i].release();
+    for (int i = 0; i < EVD_NUM_PREC; ++i) { n->stream[i].release(); n->pipe[i].release(); }
     n->bias.release();
     delete n;
 }
 
 size_t evd_nerf_stream_bytes(const evd_nerf* net, int precision) {
-    if (!net || precision < 0 || precision > 2) return 0;
-    return net->stream[precision].bytes;
+    if (!net || precision < 0 || precision >= EVD_NUM_PREC) return 0;
+    return net->pipe_chunks[precision] ? net->pipe[precision].bytes : net->stream[precision].bytes;
 }
 
 int evd_nerf_mlp(const evd_nerf* net, int precision, const float* ray_batch, const float* z, long R, int S,
                  float* raw, float* feature, int feature_kind, void* stream) {
     EVD_REQUIRE(net && ray_batch && z && raw, "evd_nerf_mlp: null argument");
-    EVD_REQUIRE(precision >= 0 && precision <= 2, "evd_nerf_mlp: unknown precision %d", precision);
+    EVD_REQUIRE(precision >= 0 && precision < EVD_NUM_PREC, "evd_nerf_mlp: unknown precision %d", precision);
     EVD_REQUIRE(R >= 0 && S >= 1, "evd_nerf_mlp: bad shape R=%ld S=%d", R, S);
     EVD_REQUIRE(!feature || feature_kind == 1 || feature_kind == 2, "evd_nerf_mlp: feature_kind must be 1 or 2");
     if (R == 0) return EVD_OK;
     MlpParams p;
-    p.wstream = (const char*)net->stream[precision].p;
+    const bool piped = net->pipe_chunks[precision] > 0 && !getenv("EVD_NO_PIPE");
+    p.wstream = (const char*)(piped ? net->pipe[precision].p : net->stream[precision].p);
     p.bias = (const float*)net->bias.p;
     p.ray_batch = ray_batch; p.z = z; p.nsamp = R * (long)S; p.S = S; p.ncol = 11;
-    p.D = net->D; p.skip = net->skip; p.nchunks = net->nchunks[precision]; p.nbias = (int)(net->bias.bytes / sizeof(float));
+    p.D = net->D; p.skip = net->skip; p.nchunks = piped ? net->pipe_chunks[precision] : net->nchunks[precision]; p.nbias = (int)(net->bias.bytes / sizeof(float));
     p.raw = raw; p.feature = feature; p.feature_kind = feature ? feature_kind : 0;
-    return nerf_mlp_dispatch(precision, net->W, p, as_stream(stream));
+    if (piped) return nerf_mlp_pipe_dispatch(precision, p, as_stream(stream));
+    return nerf_mlp_generic_dispatch(precision, net->W, p, as_stream(stream));
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -14,8 +14,8 @@ struct evd_voxel {
     int num_layers, hidden_dim, geo, num_layers_color, input_ch, ft_dim, app_dim;
     int n_comp[3], grid[3], app_act, rgb_act, sigma_act, composite_feature;
     float aabb[6], rmnear;
-    DevBuf plane[3], line[3], basis, stream[3], bias, tv_acc;
-    int nchunks[3];
+    DevBuf plane[3], line[3], basis, stream[EVD_NUM_PREC], bias, tv_acc;
+    int nchunks[EVD_NUM_PREC];
     GridParams gp;
 };
 
@@ -25,7 +25,8 @@ extern "C" {
 
 void evd_voxel_destroy(evd_voxel* v) {
     if (!v) return;
-    for (int i = 0; i < 3; ++i) { v->plane[i].release(); v->line[i].release(); v->stream[i].release(); }
+    for (int i = 0; i < 3; ++i) { v->plane[i].release(); v->line[i].release(); }
+    for (int i = 0; i < EVD_NUM_PREC; ++i) v->stream[i].release();
     v->basis.release(); v->bias.release(); v->tv_acc.release();
     delete v;
 }
@@ -95,7 +96,7 @@ int evd_voxel_create(const evd_voxel_desc* d, evd_voxel** out) {
         const int c = pe_src_col(PE_LV, 8 * (j - gk) + (kk & 7), kk >> 3);
         return c < 0 ? -1 : G + c;
     };
-    for (int prec = 0; prec < 3; ++prec) {
+    for (int prec = 0; prec < EVD_NUM_PREC; ++prec) {
         StreamBuilder sb(prec);
         sb.layer(d->sigma_w[0], HD, d->input_ch, T, KF + PE_KS, false, in0_col);
         if (small) {
@@ -158,7 +159,7 @@ int evd_voxel_forward(const evd_voxel* v, int precision, const float* pts, const
                       float* color, float* depth, float* acc, float* weights, float* feature,
                       void* workspace, size_t workspace_bytes, void* stream) {
     EVD_REQUIRE(v && pts && viewdirs && fts && z && rays_d, "evd_voxel_forward: null argument");
-    EVD_REQUIRE(precision >= 0 && precision <= 2, "evd_voxel_forward: unknown precision %d", precision);
+    EVD_REQUIRE(precision >= 0 && precision < EVD_NUM_PREC, "evd_voxel_forward: unknown precision %d", precision);
     EVD_REQUIRE(F == v->ft_dim, "evd_voxel_forward: fts has %d channels, this level takes %d", F, v->ft_dim);
     EVD_REQUIRE(weights, "evd_voxel_forward: the weights output is required");
     if (R == 0) return EVD_OK;

@@ -1,4 +1,6 @@
-// Fused NeRF backbone: pts = o + d z -> positional encodings -> 8x256 MLP (skip + view branch) -> raw.
+// Generic fused NeRF backbone (any depth / skip index, all four arithmetic modes; the float32 and split-float16
+// modes always run here) + the dispatch to the software-pipelined kernels of nerf_mlp_kernel.h where they are built.
+// pts = o + d z -> positional encodings -> D x W MLP (skip + view branch) -> raw.
 // reference: networks/nerf.py:46-72 (mlpforward), :131-162 (eval), networks/embedding.py:88-98, renderer.py:180.
 //
 // Design (see nerf_mlp.h for the fragment/permutation contract):
@@ -9,12 +11,12 @@
 //     (one barrier per chunk), read back conflict-free with ds_read_b128 (lane-linear fragments),
 //   * three arithmetic modes share the code: bf16 (32x32x16), split-float16 x3 (32x32x16, hi/lo operands,
 //     2^11-scaled cross terms in a second accumulator) and exact float32 (32x32x2).
-#include "mlp_device.h"
+#include "nerf_mlp_kernel.h"
 
 namespace evd {
 
 template <int PREC, int W>
-__global__ __launch_bounds__(mlp_threads(PREC), PREC == EVD_PREC_BF16 ? 2 : 1) void k_nerf_mlp(const MlpParams p) {
+__global__ __launch_bounds__(mlp_threads(PREC), is_half_prec(PREC) ? 2 : 1) void k_nerf_mlp_generic(const MlpParams p) {
     typedef Ops<PREC> O;
     typedef typename O::B B;
     constexpr int NT = mlp_threads(PREC);
@@ -120,25 +122,34 @@ static int launch_mlp(const MlpParams& p, hipStream_t st) {
     const size_t lds = MlpLds<PREC>::TOTAL;
     static bool attr_set = false;
     if (!attr_set) {
-        EVD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nerf_mlp<PREC, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        EVD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nerf_mlp_generic<PREC, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     if (p.nbias > MlpLds<PREC>::BIAS_FLOATS) return fail(EVD_E_INVALID, "evd_nerf_mlp: %d bias floats exceed the LDS bias block", p.nbias);
-    hipLaunchKernelGGL((k_nerf_mlp<PREC, W>), dim3((unsigned)blocks), dim3(NT), lds, st, p);
+    hipLaunchKernelGGL((k_nerf_mlp_generic<PREC, W>), dim3((unsigned)blocks), dim3(NT), lds, st, p);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }
 
-int nerf_mlp_dispatch(int prec, int W, const MlpParams& p, hipStream_t st) {
+int nerf_mlp_generic_dispatch(int prec, int W, const MlpParams& p, hipStream_t st) {
 #define EVD_CASE(P, WW) if (prec == P && W == WW) return launch_mlp<P, WW>(p, st)
     EVD_CASE(EVD_PREC_BF16, 256);
+    EVD_CASE(EVD_PREC_F16, 256);
     EVD_CASE(EVD_PREC_F16X3, 256);
     EVD_CASE(EVD_PREC_F32, 256);
     EVD_CASE(EVD_PREC_BF16, 64);
+    EVD_CASE(EVD_PREC_F16, 64);
     EVD_CASE(EVD_PREC_F16X3, 64);
     EVD_CASE(EVD_PREC_F32, 64);
 #undef EVD_CASE
     return fail(EVD_E_INVALID, "evd_nerf_mlp: no kernel for precision %d, width %d (built: W in {64,256})", prec, W);
+}
+
+int nerf_mlp_pipe_dispatch(int prec, const MlpParams& p, hipStream_t st) {
+    const bool feat = p.feature != nullptr;
+    if (prec == EVD_PREC_BF16) return launch_nerf_pipe_bf16(feat, p, st);
+    if (prec == EVD_PREC_F16) return launch_nerf_pipe_f16(feat, p, st);
+    return fail(EVD_E_INVALID, "evd_nerf_mlp: no pipelined kernel for precision %d", prec);
 }
 
 }  // namespace evd

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void k_voxel_sample(const GridParams g, const 
 // ------------------------------------------------------------------------------------------------
 // HD hidden width, G geo_feat_dim, FT feature channels read per sample (32 coarse, 64 fine)
 template <int PREC, int HD, int G, int FT>
-__global__ __launch_bounds__(mlp_threads(PREC), PREC == EVD_PREC_BF16 ? 2 : 1) void k_voxel_mlp(const VoxMlpParams p) {
+__global__ __launch_bounds__(mlp_threads(PREC), is_half_prec(PREC) ? 2 : 1) void k_voxel_mlp(const VoxMlpParams p) {
     typedef Ops<PREC> O;
     typedef typename O::B B;
     constexpr int NT = mlp_threads(PREC);
@@ -206,9 +206,11 @@ static int launch_vox(const VoxMlpParams& p, hipStream_t st) {
 int voxel_mlp_dispatch(int prec, int HD, int G, int FT, const VoxMlpParams& p, hipStream_t st) {
 #define EVD_CASE(P, H_, G_, F_) if (prec == P && HD == H_ && G == G_ && FT == F_) return launch_vox<P, H_, G_, F_>(p, st)
     EVD_CASE(EVD_PREC_BF16, 64, 15, 32);
+    EVD_CASE(EVD_PREC_F16, 64, 15, 32);
     EVD_CASE(EVD_PREC_F16X3, 64, 15, 32);
     EVD_CASE(EVD_PREC_F32, 64, 15, 32);
     EVD_CASE(EVD_PREC_BF16, 256, 128, 64);
+    EVD_CASE(EVD_PREC_F16, 256, 128, 64);
     EVD_CASE(EVD_PREC_F16X3, 256, 128, 64);
     EVD_CASE(EVD_PREC_F32, 256, 128, 64);
 #undef EVD_CASE

@@ -30,6 +30,22 @@ template <> struct Ops<EVD_PREC_BF16> {
     static __device__ __forceinline__ B make_b(const f32x8& v) { return __builtin_convertvector(v, bf16x8); }
 };
 
+template <> struct Ops<EVD_PREC_F16> {
+    typedef f16x8 B;
+    typedef f16x8 A;
+    static constexpr bool kSplit = false;
+    static __device__ __forceinline__ A load_a(const char* p) { return *reinterpret_cast<const f16x8*>(p); }
+    static __device__ __forceinline__ void mma(f32x16& acc, f32x16&, const A& a, const B& b) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+    }
+    static __device__ __forceinline__ B make_b(const f32x8& v) {
+        f32x8 c;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c[i] = fminf(fmaxf(v[i], -65000.f), 65000.f);   // float16 range guard
+        return __builtin_convertvector(c, f16x8);
+    }
+};
+
 template <> struct Ops<EVD_PREC_F16X3> {
     struct B { f16x8 hi, lo; };
     struct A { f16x8 hi, lo; };

@@ -35,10 +35,14 @@ __host__ __device__ constexpr int pe_src_col(int L, int q, int h) {
     return q < 3 * L ? 3 + 6 * (q / 3) + 3 * h + (q % 3) : (q == 3 * L ? h : (q == 3 * L + 1 ? (h == 0 ? 2 : -1) : -1));
 }
 
-constexpr int frag_bytes(int prec) { return prec == 2 /*BF16*/ ? 1024 : 2048; }
-constexpr int mlp_threads(int prec) { return prec == 2 ? 512 : 256; }
+constexpr bool is_half_prec(int prec) { return prec == 2 /*BF16*/ || prec == 3 /*F16*/; }   // one 2-byte operand per value
+constexpr int frag_bytes(int prec) { return is_half_prec(prec) ? 1024 : 2048; }
+constexpr int mlp_threads(int prec) { return is_half_prec(prec) ? 512 : 256; }
 constexpr int chunk_bytes(int prec) { return mlp_threads(prec) * 64; }
 constexpr int frags_per_chunk(int prec) { return chunk_bytes(prec) / frag_bytes(prec); }
+
+// tile-group size of the pipelined NeRF kernel = fragment order of its stream (groups of G tiles, k-steps, tiles innermost)
+constexpr int nerf_group(int prec) { return 1; }
 
 // kernel arguments of k_nerf_mlp
 struct MlpParams {

@@ -20,8 +20,10 @@ static inline uint16_t f32_to_bf16(float f) {
 
 struct StreamBuilder {
     int prec;
+    int group = 2;                  // tiles per group (kernel's G); 1-tile layers are always their own group
+    size_t cb;                      // chunk bytes: layers flagged pad_end are zero-padded to a multiple of it
     std::vector<uint8_t> bytes;
-    explicit StreamBuilder(int p) : prec(p) {}
+    explicit StreamBuilder(int p, size_t chunk = 0) : prec(p), cb(chunk ? chunk : (size_t)chunk_bytes(p)) {}
     // one fragment of output tile `tile`, k-step j.  row(tile, r) -> source row of Wm or -1 (zero row);
     // col(j, kk) -> source column or -1 (zero padding)
     template <class RowFn, class ColFn>
@@ -39,6 +41,9 @@ struct StreamBuilder {
                 if (prec == EVD_PREC_BF16) {
                     const uint16_t b = f32_to_bf16(w);
                     memcpy(dst + l * 16 + e * 2, &b, 2);
+                } else if (prec == EVD_PREC_F16) {
+                    const _Float16 hv = (_Float16)w;
+                    memcpy(dst + l * 16 + e * 2, &hv, 2);
                 } else if (prec == EVD_PREC_F16X3) {
                     const _Float16 hi = (_Float16)w;
                     const _Float16 lo = (_Float16)((w - (float)hi) * 2048.f);
@@ -53,7 +58,7 @@ struct StreamBuilder {
     // fragments in kernel order: tile groups of 2 (or 1), k-steps inside, tiles of the group innermost
     template <class RowFn, class ColFn>
     void layer_rc(const float* Wm, int in_dim, int tiles, int ksteps, bool pad_end, RowFn row, ColFn col) {
-        const int G = tiles >= 2 ? 2 : 1;
+        const int G = (tiles % group == 0) ? group : 1;
         for (int p = 0; p < tiles / G; ++p)
             for (int j = 0; j < ksteps; ++j)
                 for (int t = 0; t < G; ++t) frag(Wm, in_dim, p * G + t, j, row, col);
@@ -65,7 +70,6 @@ struct StreamBuilder {
         layer_rc(Wm, in_dim, tiles, ksteps, pad_end, [out_dim](int t, int r) { return 32 * t + r < out_dim ? 32 * t + r : -1; }, col);
     }
     void pad() {
-        const size_t cb = chunk_bytes(prec);
         bytes.resize(cdiv((long)bytes.size(), (long)cb) * cb, 0);
     }
 };

@@ -36,6 +36,8 @@ extern "C" {
 #define EVD_PREC_F32 0      /* v_mfma_f32_32x32x2_f32: exact float32 products (bitwise an fmaf chain) */
 #define EVD_PREC_F16X3 1    /* operands split hi+lo into two float16, 3 x v_mfma_f32_32x32x16_f16: ~2^-21 products */
 #define EVD_PREC_BF16 2     /* v_mfma_f32_32x32x16_bf16: throughput mode, ~2^-8 operands */
+#define EVD_PREC_F16 3      /* v_mfma_f32_32x32x16_f16, one product: bf16 speed, ~2^-11 operands, float16 range */
+#define EVD_NUM_PREC 4
 
 /* activation codes: reference networks/nerf.py:31-33, networks/pdrf/voxnerf.py:28-30 */
 #define EVD_ACT_NONE 0

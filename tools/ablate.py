@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Build ablation variants of the fused MLP kernel (compile-time -D switches in csrc/mlp_device.h) next to the
+"""Build ablation variants of the fused MLP kernel (compile-time -DEVD_* switches in csrc/mlp_pipe.h / mlp_device.h;
+EVD_ABLATE_FILE selects the translation unit, default the bf16 pipelined kernel) next to the
 product library.  Ablated variants compute WRONG results on purpose; they exist to price one part of the kernel.
 
     python tools/ablate.py build VARIANT[=VALUE] ...     (here, cross-compiles)
@@ -20,15 +21,21 @@ def lib_of(v):
 
 def build(variants):
     B.build()
-    others = [os.path.join(B.LIBDIR, os.path.basename(s)[:-4] + ".o") for s in B.sources() if not s.endswith("kernel_nerf_mlp.hip")]
-    src = os.path.join(B.CSRC, "kernel_nerf_mlp.hip")
-    for v in variants:
+    target = os.environ.get("EVD_ABLATE_FILE", "kernel_nerf_mlp_pipe_bf16.hip")
+    others = [os.path.join(B.LIBDIR, os.path.basename(s)[:-4] + ".o") for s in B.sources() if not s.endswith(target)]
+    src = os.path.join(B.CSRC, target)
+
+    def one(v):
         obj = os.path.join(B.LIBDIR, "abl_" + v.replace("=", "_") + ".o")
         defs = [] if v == "baseline" else ["-DEVD_" + d for d in v.split("+")]
         subprocess.check_call([B.hipcc(), *B.FLAGS, *defs, "-c", src, "-o", obj])
         subprocess.check_call([B.hipcc(), "-shared", "-fPIC", f"--offload-arch={B.ARCH}", obj, *others, "-o", lib_of(v)])
         os.remove(obj)
-        print("built", lib_of(v))
+        print("built", lib_of(v), flush=True)
+
+    import concurrent.futures as cf
+    with cf.ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(one, variants))
 
 
 def run(variants, extra):

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--precs", default="f32,f16x3,bf16,f16")
     a = ap.parse_args()
     R, S = a.rays, a.samples
     net = NeRF(W.make_nerf_state_dict(21))
@@ -36,7 +37,7 @@ def main():
     rb = torch.as_tensor(rb, device="cuda")
     z = torch.linspace(0, 1, S, device="cuda").expand(R, S).contiguous()
     ref = None
-    for prec in ("f32", "f16x3", "bf16"):
+    for prec in a.precs.split(","):
         it = max(3, a.iters // (6 if prec == "f32" else 1))
         for _ in range(3):
             raw, _ = net.mlpforward(rb, z, precision=prec)
@@ -50,7 +51,7 @@ def main():
         ms = e0.elapsed_time(e1) / it
         tf = R * S * FLOP / (ms * 1e-3) / 1e12
         if ref is None:
-            ref = raw.clone()
+            ref = raw.clone() if prec == "f32" else net.mlpforward(rb, z, precision="f32")[0].clone()
         err = float((raw - ref).abs().max())
         print(f"{prec:6s} {ms:8.3f} ms  {tf:7.1f} TFLOP/s (algorithmic)  {R / (ms * 1e-3) / 1e6:6.2f} M rays/s   max|raw - f32| = {err:.2e}")
 
