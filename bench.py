@@ -7,8 +7,13 @@ One JSON line on rank 0 (contract in the task statement). A "step" = one pass of
 (ray packing -> z stratification -> fused PE+MLP kernel -> compositing scan) over one batch of 4096
 synthetic LLFF-shaped rays already resident in HBM; with N > 1 every rank renders its own 4096 rays
 (weak scaling) and the step ends with the packed blur-loss partial all-reduce over RCCL, the only
-exchange the path has. The headline precision is the float32-grade split-float16 mode (RGB parity
-<= 1e-4 vs the reference); bf16 and exact-f32 rates are reported beside it in "modes".
+exchange the path has.
+
+The headline arithmetic is "f16": float16 MFMA operands (one product, v_mfma_f32_32x32x16_f16) with
+float32 accumulation -- the matrix-core rate north_star asks for (bf16-class), whose RGB on this workload
+is measured against the exact-float32 kernel inside the run ("parity": L-inf, bound 1e-4). "modes"
+reports beside it: bf16 (same kernel, 2^-8 operands), f16x3 (split-float16, three products, float32-grade
+for any weights) and f32 (exact float32 MFMA); "composite" is the HBM-bound compositing scan on 2^20 rays.
 """
 from __future__ import annotations
 
@@ -25,7 +30,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 FLOP_PER_SAMPLE = 2 * 593408          # GEMM terms of the 8x256 net with skip and view branch
-PEAK_TFLOPS = {"bf16": 2500.0, "f16x3": 2500.0, "f32": 157.3}   # dense MFMA peaks (MI355X_MICROARCH.md)
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f16x3": 2500.0, "f32": 157.3}   # dense MFMA peaks (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0
 
 
 def parse():
@@ -33,11 +39,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f32", "bf16"])
+    ap.add_argument("--precision", default="f16", choices=["f16", "f16x3", "f32", "bf16"])
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-modes", action="store_true")
+    ap.add_argument("--no-composite", action="store_true")
     return ap.parse_args()
 
 
@@ -125,7 +132,8 @@ def main():
         "metric": "rays/sec (4096x128 samples, 8x256 MLP)", "value": rays_per_s, "unit": "rays/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": {"f16x3": "f16x3-split (3 f16 MFMA products, f32 accumulate; f32-grade)", "f32": "f32", "bf16": "bf16"}[a.precision],
+        "dtype": {"f16": "f16 (MFMA operands; f32 accumulate)", "f16x3": "f16x3-split (3 f16 MFMA products, f32 accumulate; f32-grade)",
+                  "f32": "f32", "bf16": "bf16 (MFMA operands; f32 accumulate)"}[a.precision],
         "data": "synthetic",
         "config": {"workload": f"nerf8x256 render: {R} rays x {S} samples per GPU, PE(10,4)+MLP+composite, ndc, viewdirs",
                    "rays_per_gpu": R, "samples": S, "precision": a.precision},
@@ -140,18 +148,45 @@ def main():
         L.check(L.lib().evd_ray_batch(C.byref(cfg), L.ptr(rays), R, L.ptr(rb), L.stream_ptr()))
         L.check(L.lib().evd_sample_z(C.byref(cfg), L.ptr(rb), 11, R, None, L.ptr(z), L.stream_ptr()))
         modes = {}
-        for prec in ([a.precision] if a.no_modes else ["f16x3", "bf16", "f32"]):
+        for prec in ([a.precision] if a.no_modes else ["f16", "bf16", "f16x3", "f32"]):
             net = model.mlp_coarse
             ksteps = max(3, a.steps // (10 if prec == "f32" else 1))
             ms = kernel_ms(lambda: net.mlpforward(rb, z, precision=prec), ksteps)
             tf = R * S * FLOP_PER_SAMPLE / (ms * 1e-3) / 1e12
             modes[prec] = {"kernel": "k_nerf_mlp", "ms": ms, "achieved": tf, "peak": PEAK_TFLOPS[prec], "unit": "TFLOP/s",
                            "frac": tf / PEAK_TFLOPS[prec], "rays_per_s_kernel": R / (ms * 1e-3)}
+            if prec == "f16x3":
+                modes[prec]["mfma_issue_frac"] = 3 * tf / PEAK_TFLOPS[prec]      # three MFMA products per algorithmic one
         m = modes[a.precision]
         result["roofline"] = {"bound": "mfma", "achieved": m["achieved"], "peak": m["peak"], "unit": "TFLOP/s",
                               "frac": m["frac"], "traffic": None, "kernel": "k_nerf_mlp", "kernel_ms": m["ms"],
-                              "note": "algorithmic GEMM flops (1 186 816/sample); f16x3 issues 3 MFMA products per algorithmic one"}
+                              "note": "algorithmic GEMM flops (1 186 816/sample) / HIP-event launch duration; traffic: see profiles/ (PMC run)"}
         result["modes"] = modes
+        # ---- parity of the headline arithmetic on THIS workload: RGB L-inf against the exact-float32 kernel
+        with torch.no_grad():
+            ref_model, _ = make_model("f32")
+            rgb_ref = ref_model.render(400, 400, K, rays=rays, **kw)[0]
+            rgb_run = model.render(400, 400, K, rays=rays, **kw)[0]
+            result["parity"] = {"rgb_linf_vs_f32_kernel": float((rgb_run - rgb_ref).abs().max()), "bound": 1e-4,
+                                "note": "f32 kernel vs the reference (through the oracle and the goldens): tests/test_gpu_parity.py"}
+        if not a.no_composite:
+            # ---- compositing scan alone (HBM-bound): 2^20 rays x 128 samples = 3.25 GB of algorithmic traffic
+            Rc = 1 << 20
+            raw_c = torch.randn((Rc, S, 4), device="cuda")
+            z_c = torch.linspace(0, 1, S, device="cuda").expand(Rc, S).contiguous()
+            rd_c = torch.randn((Rc, 3), device="cuda")
+            o3, o1, o2, ow = (torch.empty((Rc, 3), device="cuda"), torch.empty(Rc, device="cuda"), torch.empty(Rc, device="cuda"),
+                              torch.empty((Rc, S), device="cuda"))
+
+            def comp():
+                L.check(L.lib().evd_raw2outputs(L.ptr(raw_c), L.ptr(z_c), L.ptr(rd_c), 3, Rc, S, 4, 3, 0, 3, L.ACT["sigmoid"], L.ACT["relu"],
+                                                0, 0.0, None, L.ptr(o3), None, L.ptr(o2), L.ptr(ow), L.ptr(o1), None, 0, None, L.stream_ptr()))
+            cms = kernel_ms(comp, 10)
+            cbytes = Rc * (S * 24 + 32)
+            result["composite"] = {"kernel": "k_composite<3>", "rays": Rc, "samples": S, "ms": cms, "bound": "hbm",
+                                   "achieved": cbytes / (cms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": cbytes / (cms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": cbytes}
+            del raw_c, z_c, rd_c, o3, o1, o2, ow
         if not a.no_cpu_baseline:
             from oracle import oracle as O
             onet = O.Nerf(sd, "mlp_coarse.")

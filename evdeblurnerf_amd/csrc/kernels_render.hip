@@ -1,5 +1,7 @@
 // Ray setup, z stratification, alpha compositing scan, inverse-CDF resampling + merge.
 // All HBM-bound elementwise / per-ray kernels of the render path (everything except the MLP GEMMs).
+#include <cstdlib>
+
 #include "evd_common.h"
 
 namespace evd {
@@ -242,6 +244,141 @@ __global__ __launch_bounds__(256) void k_composite(const float* __restrict__ raw
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// DPP (data-parallel primitive) wave operations: register-to-register lane exchange inside the VALU, no LDS
+// crossbar round trip (which is what __shfl / ds_bpermute costs).  dpp_ctrl codes: quad_perm 0x00-0xFF,
+// row_shr:n 0x110+n, wave_shl:1 0x130, wave_shr:1 0x138, row_mirror 0x140, row_half_mirror 0x141,
+// row_bcast:15 0x142, row_bcast:31 0x143 (gfx9 family).
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_f32(float old, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL, ROW_MASK, 0xf, false));
+}
+// inclusive product scan over the 64 lanes (Kogge-Stone inside rows of 16, then row broadcasts)
+__device__ __forceinline__ float wave_scan_mul_dpp(float v) {
+    v *= dpp_f32<0x111>(1.f, v);
+    v *= dpp_f32<0x112>(1.f, v);
+    v *= dpp_f32<0x114>(1.f, v);
+    v *= dpp_f32<0x118>(1.f, v);
+    v *= dpp_f32<0x142, 0xa>(1.f, v);     // rows 1, 3 <- lane 15 of the row below
+    v *= dpp_f32<0x143, 0xc>(1.f, v);     // rows 2, 3 <- lane 31
+    return v;
+}
+// sum over the 64 lanes, result uniform (in an SGPR-backed value)
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += dpp_f32<0xb1>(0.f, v);           // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4e>(0.f, v);           // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141>(0.f, v);          // row_half_mirror
+    v += dpp_f32<0x140>(0.f, v);          // row_mirror: every lane now holds its row's sum
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+}
+
+// raw2outputs, bandwidth form (C == 4, three colour channels, S <= 64 * SPL): one wavefront per ray, every lane owns
+// SPL CONSECUTIVE samples, so all of a ray's loads (SPL float4 of raw + SPL floats of z per lane, 2.5 KiB per
+// wavefront at S = 128) are issued before the first dependent instruction; the transmittance is a lane-local
+// product followed by one DPP scan of the 64 lane totals.  Same arithmetic per sample as k_composite.
+template <int SPL, int RPW>
+__global__ __launch_bounds__(256) void k_composite_rows(const float* __restrict__ raw, const float* __restrict__ z,
+                                                        const float* __restrict__ rays_d, int rd_stride, long R, int S,
+                                                        int sigma_ch, int rgb_ch0, int rgb_act, int sigma_act, int white_bkgd,
+                                                        float rmnear, const float* __restrict__ noise,
+                                                        float* __restrict__ out_map, float* __restrict__ density,
+                                                        float* __restrict__ acc, float* __restrict__ weights, float* __restrict__ depth) {
+    const int lane = threadIdx.x & 63;
+    const long r0 = (blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6)) * RPW;   // RPW consecutive rays per wavefront
+    if (r0 >= R) return;
+    const int i0 = lane * SPL;
+    float4 v[RPW][SPL];
+    float zi[RPW][SPL + 1];
+    float dd[RPW][3];
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {             // every load of the wavefront's rays first
+        const long r = min(r0 + q, R - 1);
+        const float4* rw = reinterpret_cast<const float4*>(raw + r * (long)S * 4);
+        const float* zz = z + r * (long)S;
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) {
+            const int i = min(i0 + j, S - 1);
+            v[q][j] = rw[i];
+            zi[q][j] = zz[i];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dd[q][c] = rays_d[r * rd_stride + c];
+    }
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {
+        const long r = r0 + q;
+        if (r >= R) break;
+        const float* d = dd[q];
+        const float norm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
+        zi[q][SPL] = dpp_f32<0x130>(0.f, zi[q][0]);          // wave_shl:1 -- the next lane's first z
+        float alpha[SPL], om[SPL];
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) {
+            const int i = i0 + j;
+            const float vv[4] = {v[q][j].x, v[q][j].y, v[q][j].z, v[q][j].w};
+            float sraw = vv[sigma_ch];
+            if (i < S - 1) {
+                const float dist = __fmul_rn(__fsub_rn(zi[q][j + 1], zi[q][j]), norm);
+                if (noise) sraw = __fadd_rn(sraw, noise[r * (long)(S - 1) + i]);
+                float dens = act(sigma_act, sraw);
+                if (rmnear > 0.f) dens = (zi[q][j + 1] > rmnear ? 1.f : 0.f) * dens;
+                if (density) density[r * (long)(S - 1) + i] = dens;
+                alpha[j] = __fadd_rn(-expf(-__fmul_rn(dens, dist)), 1.f);
+            } else {
+                alpha[j] = i == S - 1 ? 1.f : 0.f;     // last sample: alpha forced to 1 (nerf.py:113-114); beyond S: nothing
+            }
+            om[j] = i < S ? __fadd_rn(-alpha[j], 1.f) : 1.f;
+        }
+        float local = om[0];
+#pragma unroll
+        for (int j = 1; j < SPL; ++j) local *= om[j];
+        const float incl = wave_scan_mul_dpp(local);
+        float T = dpp_f32<0x138>(1.f, incl);           // wave_shr:1 -> exclusive product; lane 0 keeps 1
+        float a_sum = 0.f, d_sum = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+        float w[SPL];
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) {
+            const float vv[4] = {v[q][j].x, v[q][j].y, v[q][j].z, v[q][j].w};
+            w[j] = (i0 + j < S) ? alpha[j] * T : 0.f;
+            T *= om[j];
+            a_sum += w[j];
+            d_sum += w[j] * zi[q][j];
+            c0 += w[j] * act(rgb_act, vv[rgb_ch0]);
+            c1 += w[j] * act(rgb_act, vv[rgb_ch0 + 1]);
+            c2 += w[j] * act(rgb_act, vv[rgb_ch0 + 2]);
+        }
+        if (weights) {
+            float* wo = weights + r * (long)S + i0;
+            if (SPL == 2 && (S & 1) == 0) {
+                if (i0 < S) *reinterpret_cast<float2*>(wo) = make_float2(w[0], w[1]);
+            } else if (SPL == 4 && (S & 3) == 0) {
+                if (i0 < S) *reinterpret_cast<float4*>(wo) = make_float4(w[0], w[1], w[2], w[3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < SPL; ++j) if (i0 + j < S) wo[j] = w[j];
+            }
+        }
+        a_sum = wave_sum_dpp(a_sum);
+        d_sum = wave_sum_dpp(d_sum);
+        c0 = wave_sum_dpp(c0);
+        c1 = wave_sum_dpp(c1);
+        c2 = wave_sum_dpp(c2);
+        if (lane == 0) {
+            if (acc) acc[r] = a_sum;
+            if (depth) depth[r] = d_sum;
+            if (out_map) {
+                const float bg = white_bkgd ? 1.f - a_sum : 0.f;
+                out_map[r * 3] = white_bkgd ? c0 + bg : c0;
+                out_map[r * 3 + 1] = white_bkgd ? c1 + bg : c1;
+                out_map[r * 3 + 2] = white_bkgd ? c2 + bg : c2;
+            }
+        }
+    }
+}
+
 // out[r, f] = sum_s w[r, s] * x[r, s, ch0 + f] (optionally through an activation): used for n_rgb != 3 colour
 // maps (PBE 15-channel features, voxnerf.py:226) and for feature compositing (nerf.py:119).  One block per ray.
 __global__ void k_weighted_channels(const float* __restrict__ x, const float* __restrict__ w, long R, int S, int Cx, int ch0,
@@ -414,7 +551,21 @@ int evd_raw2outputs(const float* raw, const float* z, const float* rays_d, int r
     EVD_REQUIRE(!(fmap || (n_rgb != 3 && out_map)) || weights, "evd_raw2outputs: weights output required for feature maps");
     if (R == 0) return EVD_OK;
     hipStream_t st = as_stream(stream);
-    if (n_rgb == 3) {
+    if (n_rgb == 3 && C == 4 && S <= 256) {
+        // bandwidth form: every lane owns SPL consecutive samples
+        static const int rpw = [] { const char* e = getenv("EVD_COMPOSITE_RPW"); return e ? atoi(e) : 2; }();
+#define EVD_ROWS(SPL) if (rpw == 4) k_composite_rows<SPL, 4><<<cdiv(R, 16), 256, 0, st>>>(raw, z, rays_d, rays_d_stride, R, S, sigma_ch, rgb_ch0, rgb_act, sigma_act, \
+                                                                      white_bkgd, rmnear_thresh, noise, out_map, density, acc, weights, depth); \
+                      else if (rpw == 2) k_composite_rows<SPL, 2><<<cdiv(R, 8), 256, 0, st>>>(raw, z, rays_d, rays_d_stride, R, S, sigma_ch, rgb_ch0, rgb_act, sigma_act, \
+                                                                      white_bkgd, rmnear_thresh, noise, out_map, density, acc, weights, depth); \
+                      else k_composite_rows<SPL, 1><<<cdiv(R, 4), 256, 0, st>>>(raw, z, rays_d, rays_d_stride, R, S, sigma_ch, rgb_ch0, rgb_act, sigma_act, \
+                                                                      white_bkgd, rmnear_thresh, noise, out_map, density, acc, weights, depth)
+        if (S <= 64) EVD_ROWS(1);
+        else if (S <= 128) EVD_ROWS(2);
+        else if (S <= 192) EVD_ROWS(3);
+        else EVD_ROWS(4);
+#undef EVD_ROWS
+    } else if (n_rgb == 3) {
         k_composite<3><<<cdiv(R, 4), 256, 0, st>>>(raw, z, rays_d, rays_d_stride, R, S, C, sigma_ch, rgb_ch0, n_rgb, rgb_act, sigma_act,
                                                    white_bkgd, rmnear_thresh, noise, out_map, density, acc, weights, depth);
     } else {

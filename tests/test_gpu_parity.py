@@ -149,7 +149,7 @@ def test_sample_pdf_merge(S, Ns, O):
         assert maxabs(zstd, zs.astype(np.float64).std(-1)) < 1e-6
 
 
-@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("f16x3", 2e-5), ("bf16", 6e-2)])
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("f16x3", 2e-5), ("f16", 2e-3), ("bf16", 6e-2)])
 @pytest.mark.parametrize("Wd,seed,bias", [(256, 7, True), (256, 8, False), (64, 9, True)])
 def test_nerf_mlp_matches_oracle_and_golden(prec, tol, Wd, seed, bias, O):
     """Fused pts + PE + MLP kernel vs NeRF.eval (golden G2 from the reference; oracle for the features)."""
@@ -190,7 +190,7 @@ def _render_cases():
             ("d", dict(N_samples=64, N_importance=32, perturb=1.0), 4, 48, 11, 12)]
 
 
-@pytest.mark.parametrize("prec,tol", [("f32", 1e-4), ("f16x3", 1e-4), ("bf16", 3e-2)])
+@pytest.mark.parametrize("prec,tol", [("f32", 1e-4), ("f16x3", 1e-4), ("f16", 1e-4), ("bf16", 3e-2)])
 def test_render_matches_reference_golden(prec, tol, O):
     """NeRFAll.render end to end vs the goldens produced by the reference (G7). RGB L-inf <= 1e-4 is the
     north-star bound for the float32-grade modes."""
@@ -220,8 +220,8 @@ def test_render_matches_reference_golden(prec, tol, O):
             assert maxabs(N(ex["rgb0"]), g[f"{tag}_rgb0"]) < tol
             assert maxabs(N(ex["z_vals0"]), g[f"{tag}_z_vals0"]) < 1e-6
             assert maxabs(N(ex["weights0"]), g[f"{tag}_weights0"]) < tol
-            frac, worst = z_mismatch(N(ex["z_vals"]), g[f"{tag}_z_vals"], tol=5e-5 if prec != "bf16" else 5e-3)
-            assert frac < (0.01 if prec != "bf16" else 0.2) and worst < 1.0 / 63 + 1e-3, (frac, worst)
+            frac, worst = z_mismatch(N(ex["z_vals"]), g[f"{tag}_z_vals"], tol={"bf16": 5e-3, "f16": 5e-4}.get(prec, 5e-5))
+            assert frac < {"bf16": 0.2, "f16": 0.05}.get(prec, 0.01) and worst < 1.0 / 63 + 1e-3, (frac, worst)
         else:
             assert maxabs(N(ex["z_vals"]), g[f"{tag}_z_vals"]) < 1e-6
             assert maxabs(N(ex["weights"]), g[f"{tag}_weights"]) < tol
@@ -251,7 +251,7 @@ def test_render_config1_white_bkgd_lindisp_no_ndc(O):
 def test_full_size_metric_config_properties():
     """BASELINE.json metric shape: 4096 rays x 128 samples through the 8x256 MLP. Size-independent properties:
     acc == 1 (last alpha forced to 1), weights >= 0 and sum to acc, rgb in [0,1], depth within [near,far],
-    ray-permutation equivariance, chunk invariance, and agreement of the three arithmetic modes."""
+    ray-permutation equivariance, chunk invariance, and agreement of the four arithmetic modes."""
     from types import SimpleNamespace
     from evdeblurnerf_amd.renderer import NeRFAll
     sd = W.prefixed(W.make_nerf_state_dict(21), "mlp_coarse")
@@ -261,7 +261,7 @@ def test_full_size_metric_config_properties():
     K = W.synthetic_camera()
     kw = dict(ndc=True, near=0., far=1., use_viewdirs=True, N_samples=128, N_importance=0, retraw=True)
     out = {}
-    for prec in ("f32", "f16x3", "bf16"):
+    for prec in ("f32", "f16x3", "f16", "bf16"):
         model = NeRFAll(args, sd, precision=prec).eval()
         rgb, depth, acc, ex = model.render(400, 400, K, rays=rays, **kw)
         out[prec] = N(rgb)
@@ -277,6 +277,8 @@ def test_full_size_metric_config_properties():
             rgb_c = model.render(400, 400, K, chunk=1000, rays=rays, **kw)[0]
             assert torch.equal(rgb_c, rgb)                            # chunking does not change results (renderer.py:406)
     assert maxabs(out["f16x3"], out["f32"]) < 1e-4
+    print(f"f16 vs f32 RGB L-inf at full size: {maxabs(out['f16'], out['f32']):.3e}")
+    assert maxabs(out["f16"], out["f32"]) < 1e-4        # single-product float16 (software-pipelined kernel) on these weights
     print(f"bf16 vs f32 RGB L-inf at full size: {maxabs(out['bf16'], out['f32']):.3e}")
     assert maxabs(out["bf16"], out["f32"]) < 3e-2
 
@@ -403,7 +405,7 @@ def test_voxel_sample_matches_golden(O):
     assert abs(float(model.mlp_coarse.TV_loss_app()) - tv_ref) < 1e-5 * tv_ref
 
 
-@pytest.mark.parametrize("prec,tol", [("f32", 1e-4), ("f16x3", 1e-4), ("bf16", 3e-2)])
+@pytest.mark.parametrize("prec,tol", [("f32", 1e-4), ("f16x3", 1e-4), ("f16", 2e-4), ("bf16", 3e-2)])
 def test_c2f_render_matches_reference_golden(prec, tol, O):
     """NeRFAll.render mode='c2f' (PDRF coarse + fine level) vs goldens produced by the reference (G9)."""
     from evdeblurnerf_amd.renderer import NeRFAll
@@ -418,11 +420,12 @@ def test_c2f_render_matches_reference_golden(prec, tol, O):
     print(f"[c2f {prec}] RGB L-inf vs reference = {e:.3e}; coarse rgb0 {maxabs(N(ex['rgb0']), g['rgb0']):.3e}")
     assert e < tol
     assert maxabs(N(ex["rgb0"]), g["rgb0"]) < tol
-    assert maxabs(N(acc), g["acc"]) < tol and maxabs(N(depth), g["depth"]) < 3 * tol
+    # depth follows the resampled z positions, which move when a coarse weight changes in its 4th digit: float16 gets 2e-3
+    assert maxabs(N(acc), g["acc"]) < tol and maxabs(N(depth), g["depth"]) < (2e-3 if prec == "f16" else 3 * tol)
     assert maxabs(N(ex["z_vals0"]), g["z_vals0"]) < 1e-6
     assert maxabs(N(ex["weights0"]), g["weights0"]) < tol
-    frac, worst = z_mismatch(N(ex["z_vals"]), g["z_vals"], tol=5e-5 if prec != "bf16" else 5e-3)
-    assert frac < (0.01 if prec != "bf16" else 0.3) and worst < 1.0 / 63 + 1e-3, (frac, worst)
+    frac, worst = z_mismatch(N(ex["z_vals"]), g["z_vals"], tol={"bf16": 5e-3, "f16": 5e-4}.get(prec, 5e-5))
+    assert frac < {"bf16": 0.3, "f16": 0.05}.get(prec, 0.01) and worst < 1.0 / 63 + 1e-3, (frac, worst)
     model0 = NeRFAll(_c2f_args(0), sd, precision=prec).eval()
     rgb, depth, acc, ex = model0.render(400, 400, K, rays=rays, N_importance=0, **kw)
     assert maxabs(N(rgb), g["c_rgb"]) < tol and maxabs(N(ex["weights"]), g["c_weights"]) < tol
