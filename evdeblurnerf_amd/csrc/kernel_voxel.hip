@@ -26,72 +26,131 @@ __device__ __forceinline__ float unnorm(float c, int size) { return __fmul_rn(__
 constexpr int VS_SAMPLES = 32;      // samples per 256-thread block
 constexpr int VS_MAXC = 128;        // max sum(n_comp)
 
-// F.grid_sample(bilinear, zeros, align_corners=True) x 6, product, basis_mat.  Arithmetic order and the
-// interpolation-weight form (w = x - floor x, e = 1 - w) follow the ATen CPU kernel, unfused.
+// F.grid_sample(bilinear, zeros, align_corners=True) x 6, product, basis_mat.  The interpolation-weight form
+// (w = x - floor x, e = 1 - w) and the tap order follow the ATen CPU kernel, unfused.
+//
+// Phase 1 (gather): work item = (sample, group of 4 channels); the 4 plane taps and 2 line taps of an item are
+// loaded BRANCH-FREE (out-of-range taps read a clamped address and get weight 0 -- the zero padding) and all items of
+// a thread are issued before the first use, so ~18 independent 16-byte loads per lane are in flight (the grids are
+// far larger than L2: this phase is a random gather served by Infinity Cache / HBM).
+// Phase 2 (basis_mat, voxnerf.py:151): out^T[f, sample] = basis[f, :] . coef[sample, :] for the block's 32 samples on
+// the exact-float32 MFMA (v_mfma_f32_32x32x2_f32 = an fmaf chain in k order), by wavefront 0 of the block.
+constexpr int VS_STRIDE = VS_MAXC + 1;      // odd row stride: conflict-free column reads in phase 2
+
+struct VsItem { f32x4 p[4], l[2]; float wp[4], wl[2]; };
+
+__device__ __forceinline__ void vs_issue(const GridParams& g, const float* __restrict__ pts, long s, int grp, VsItem& it) {
+    const int mat0[3] = {0, 0, 1}, mat1[3] = {1, 2, 2}, vec[3] = {2, 1, 0};
+    int i = 0, c4 = grp * 4;
+    if (c4 >= g.n_comp[0]) { c4 -= g.n_comp[0]; i = 1; if (c4 >= g.n_comp[1]) { c4 -= g.n_comp[1]; i = 2; } }
+    float xyz[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) xyz[c] = __fsub_rn(__fmul_rn(__fsub_rn(pts[s * 3 + c], g.aabb_min[c]), g.inv[c]), 1.f);   // voxnerf.py:205
+    const int C = g.n_comp[i];
+    const int Wp = g.grid[mat0[i]], Hp = g.grid[mat1[i]], Lp = g.grid[vec[i]];
+    const float ix = unnorm(xyz[mat0[i]], Wp), iy = unnorm(xyz[mat1[i]], Hp);
+    // clamp far-away points before the float -> int conversion (everything beyond one cell outside is zero padding)
+    const float fx = fminf(fmaxf(floorf(ix), -2.f), (float)Wp), fy = fminf(fmaxf(floorf(iy), -2.f), (float)Hp);
+    const float ww = __fsub_rn(ix, floorf(ix)), ee = __fsub_rn(1.f, ww), nn = __fsub_rn(iy, floorf(iy)), ss = __fsub_rn(1.f, nn);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const bool vx0 = x0 >= 0 && x0 < Wp, vx1 = x1 >= 0 && x1 < Wp, vy0 = y0 >= 0 && y0 < Hp, vy1 = y1 >= 0 && y1 < Hp;
+    const int cx0 = min(max(x0, 0), Wp - 1), cx1 = min(max(x1, 0), Wp - 1), cy0 = min(max(y0, 0), Hp - 1), cy1 = min(max(y1, 0), Hp - 1);
+    const float* pl = g.plane[i] + c4;
+    it.p[0] = *reinterpret_cast<const f32x4*>(pl + ((long)cy0 * Wp + cx0) * C);
+    it.p[1] = *reinterpret_cast<const f32x4*>(pl + ((long)cy0 * Wp + cx1) * C);
+    it.p[2] = *reinterpret_cast<const f32x4*>(pl + ((long)cy1 * Wp + cx0) * C);
+    it.p[3] = *reinterpret_cast<const f32x4*>(pl + ((long)cy1 * Wp + cx1) * C);
+    it.wp[0] = (vy0 && vx0) ? __fmul_rn(ee, ss) : 0.f;
+    it.wp[1] = (vy0 && vx1) ? __fmul_rn(ww, ss) : 0.f;
+    it.wp[2] = (vy1 && vx0) ? __fmul_rn(ee, nn) : 0.f;
+    it.wp[3] = (vy1 && vx1) ? __fmul_rn(ww, nn) : 0.f;
+    const float il = unnorm(xyz[vec[i]], Lp);
+    const float fl = fminf(fmaxf(floorf(il), -2.f), (float)Lp);
+    const float ln = __fsub_rn(il, floorf(il)), ls = __fsub_rn(1.f, ln);
+    const int l0 = (int)fl, l1 = l0 + 1;
+    const float* li = g.line[i] + c4;
+    it.l[0] = *reinterpret_cast<const f32x4*>(li + (long)min(max(l0, 0), Lp - 1) * C);
+    it.l[1] = *reinterpret_cast<const f32x4*>(li + (long)min(max(l1, 0), Lp - 1) * C);
+    it.wl[0] = (l0 >= 0 && l0 < Lp) ? ls : 0.f;
+    it.wl[1] = (l1 >= 0 && l1 < Lp) ? ln : 0.f;
+}
+
+// invalid taps contribute exactly nothing (the reference skips them): a zero weight times a finite grid value is 0,
+// and 0 added to the running sum changes nothing
+__device__ __forceinline__ f32x4 vs_finish(const VsItem& it) {
+    f32x4 pv = {0.f, 0.f, 0.f, 0.f}, lv = {0.f, 0.f, 0.f, 0.f}, cf;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pv[k] = it.wp[t] != 0.f ? __fadd_rn(pv[k], __fmul_rn(it.p[t][k], it.wp[t])) : pv[k];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lv[k] = it.wl[t] != 0.f ? __fadd_rn(lv[k], __fmul_rn(it.l[t][k], it.wl[t])) : lv[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cf[k] = __fmul_rn(pv[k], lv[k]);
+    return cf;
+}
+
 __global__ __launch_bounds__(256) void k_voxel_sample(const GridParams g, const float* __restrict__ pts, long n,
                                                       float* __restrict__ out, int out_stride, int out_col) {
-    __shared__ __attribute__((aligned(16))) float coef[VS_SAMPLES][VS_MAXC + 4];
-    const int mat0[3] = {0, 0, 1}, mat1[3] = {1, 2, 2}, vec[3] = {2, 1, 0};
+    __shared__ __attribute__((aligned(16))) float coef[VS_SAMPLES * VS_STRIDE];
     const int ctot = g.n_comp[0] + g.n_comp[1] + g.n_comp[2];
     const int ng = ctot / 4;
     const long s0 = blockIdx.x * (long)VS_SAMPLES;
-    for (int t = threadIdx.x; t < VS_SAMPLES * ng; t += blockDim.x) {
-        const int sl = t / ng, grp = t % ng;
-        const long s = s0 + sl;
-        if (s >= n) continue;
-        int i = 0, c4 = grp * 4;
-        if (c4 >= g.n_comp[0]) { c4 -= g.n_comp[0]; i = 1; if (c4 >= g.n_comp[1]) { c4 -= g.n_comp[1]; i = 2; } }
-        float xyz[3];
+    const int items = VS_SAMPLES * ng;
+    constexpr int UNR = 3;                       // 32 samples x 24 groups = 3 items per thread for n_comp (64,16,16)
+    for (int base = threadIdx.x; base < items; base += UNR * 256) {
+        VsItem it[UNR];
+        int sl[UNR], grp[UNR];
+        bool on[UNR];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) xyz[c] = __fsub_rn(__fmul_rn(__fsub_rn(pts[s * 3 + c], g.aabb_min[c]), g.inv[c]), 1.f);   // voxnerf.py:205
-        const int C = g.n_comp[i];
-        const int Wp = g.grid[mat0[i]], Hp = g.grid[mat1[i]], Lp = g.grid[vec[i]];
-        const float ix = unnorm(xyz[mat0[i]], Wp), iy = unnorm(xyz[mat1[i]], Hp);
-        const float fx = floorf(ix), fy = floorf(iy);
-        const float ww = __fsub_rn(ix, fx), ee = __fsub_rn(1.f, ww), nn = __fsub_rn(iy, fy), ss = __fsub_rn(1.f, nn);
-        const long x0 = (long)fx, y0 = (long)fy, x1 = x0 + 1, y1 = y0 + 1;
-        const bool vx0 = x0 >= 0 && x0 < Wp, vx1 = x1 >= 0 && x1 < Wp, vy0 = y0 >= 0 && y0 < Hp, vy1 = y1 >= 0 && y1 < Hp;
-        const float* pl = g.plane[i] + c4;
-        f32x4 pv = {0.f, 0.f, 0.f, 0.f};
-        auto tap = [&](long yy, long xx, float wgt) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(pl + (yy * Wp + xx) * C);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) pv[k] = __fadd_rn(pv[k], __fmul_rn(v[k], wgt));
-        };
-        if (vy0 && vx0) tap(y0, x0, __fmul_rn(ee, ss));
-        if (vy0 && vx1) tap(y0, x1, __fmul_rn(ww, ss));
-        if (vy1 && vx0) tap(y1, x0, __fmul_rn(ee, nn));
-        if (vy1 && vx1) tap(y1, x1, __fmul_rn(ww, nn));
-        const float il = unnorm(xyz[vec[i]], Lp);
-        const float fl = floorf(il);
-        const float ln = __fsub_rn(il, fl), ls = __fsub_rn(1.f, ln);
-        const long l0 = (long)fl, l1 = l0 + 1;
-        f32x4 lv = {0.f, 0.f, 0.f, 0.f};
-        const float* li = g.line[i] + c4;
-        if (l0 >= 0 && l0 < Lp) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(li + l0 * C);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) lv[k] = __fadd_rn(lv[k], __fmul_rn(v[k], ls));
+        for (int q = 0; q < UNR; ++q) {
+            const int t = base + q * 256;
+            on[q] = t < items;
+            sl[q] = on[q] ? t / ng : 0;
+            grp[q] = on[q] ? t % ng : 0;
+            const long s = s0 + sl[q] < n ? s0 + sl[q] : n - 1;
+            vs_issue(g, pts, s, grp[q], it[q]);
         }
-        if (l1 >= 0 && l1 < Lp) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(li + l1 * C);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) lv[k] = __fadd_rn(lv[k], __fmul_rn(v[k], ln));
+        for (int q = 0; q < UNR; ++q) {
+            const f32x4 cf = vs_finish(it[q]);
+            if (on[q]) {
+                float* dst = &coef[sl[q] * VS_STRIDE + grp[q] * 4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dst[k] = cf[k];
+            }
         }
-        f32x4 cf;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) cf[k] = __fmul_rn(pv[k], lv[k]);
-        *reinterpret_cast<f32x4*>(&coef[sl][grp * 4]) = cf;
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < VS_SAMPLES * g.app_dim; t += blockDim.x) {
-        const int sl = t / g.app_dim, f = t % g.app_dim;
-        const long s = s0 + sl;
-        if (s >= n) continue;
-        const float* bw = g.basis + (long)f * ctot;
-        float acc = 0.f;
-        for (int k = 0; k < ctot; ++k) acc = __fadd_rn(acc, __fmul_rn(coef[sl][k], bw[k]));     // basis_mat, voxnerf.py:151
-        out[s * (long)out_stride + out_col + f] = act(g.app_act, acc);
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x, col = lane & 31, hh = lane >> 5;
+    for (int f0 = 0; f0 < g.app_dim; f0 += 32) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const int frow = min(f0 + col, g.app_dim - 1);
+        const float* bw = g.basis + (long)frow * ctot + hh;
+        const float* cf = coef + col * VS_STRIDE + hh;
+        for (int kk = 0; kk < ctot; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bw[kk], cf[kk], acc, 0, 0, 0);
+        const long s = s0 + col;
+        if (s < n) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int f = f0 + 8 * q + 4 * hh;
+                float* o = out + s * (long)out_stride + out_col + f;
+                if (f + 3 < g.app_dim && ((out_stride | out_col) & 3) == 0) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = act(g.app_act, acc[4 * q + e]);
+                    *reinterpret_cast<f32x4*>(o) = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (f + e < g.app_dim) o[e] = act(g.app_act, acc[4 * q + e]);
+                }
+            }
+        }
     }
 }
 
