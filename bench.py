@@ -158,9 +158,23 @@ def main():
             if prec == "f16x3":
                 modes[prec]["mfma_issue_frac"] = 3 * tf / PEAK_TFLOPS[prec]      # three MFMA products per algorithmic one
         m = modes[a.precision]
+        # HBM traffic and the hardware's own MFMA-busy fraction come from the committed PMC passes of this kernel
+        # (rocprofv3 cannot run inside the timed process): profiles/r01_v3_pmc_mlp.json, made by tools/pmc_mlp.sh
+        traffic, busy = None, None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_v3_pmc_mlp.json")))["derived"].get(a.precision)
+            if pmc and R == 4096 and S == 128:
+                traffic, busy = pmc["traffic_bytes"], pmc["mfma_busy_frac"]
+        except (OSError, KeyError, ValueError):
+            pass
         result["roofline"] = {"bound": "mfma", "achieved": m["achieved"], "peak": m["peak"], "unit": "TFLOP/s",
-                              "frac": m["frac"], "traffic": None, "kernel": "k_nerf_mlp", "kernel_ms": m["ms"],
-                              "note": "algorithmic GEMM flops (1 186 816/sample) / HIP-event launch duration; traffic: see profiles/ (PMC run)"}
+                              "frac": m["frac"], "traffic": traffic, "kernel": "k_nerf_mlp", "kernel_ms": m["ms"],
+                              "algorithmic_flop": R * S * FLOP_PER_SAMPLE, "algorithmic_hbm_bytes": R * S * 20 + R * 44,
+                              "mfma_busy_frac_pmc": busy,
+                              "note": "achieved = algorithmic GEMM flops (1 186 816/sample) / HIP-event launch duration, against the 2.4 GHz "
+                                      "dense peak; traffic (bytes per launch) and mfma_busy_frac_pmc (SQ_VALU_MFMA_BUSY_CYCLES over "
+                                      "GRBM_GUI_ACTIVE x SIMDs: the kernel keeps the pipe busier than frac says because the chip clocks "
+                                      "below 2.4 GHz under this load) are from the PMC passes in profiles/r01_v3_pmc_mlp.json"}
         result["modes"] = modes
         # ---- parity of the headline arithmetic on THIS workload: RGB L-inf against the exact-float32 kernel
         with torch.no_grad():

@@ -174,7 +174,9 @@ template <class C, bool STORES, int NCH> struct PStream {
                          "s_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
     }
-    __device__ __forceinline__ void start(const char* g, char* ring, int tid) {
+    // start_issue() goes first in the kernel: the DMA of the first three chunks flies while the prologue stages the
+    // biases, loads the rays and computes the positional encodings; start_wait() closes the prologue.
+    __device__ __forceinline__ void start_issue(const char* g, char* ring, int tid) {
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
         gsrc = g + wave * (C::PIECES * 1024) + lane * 16;
         rd_base = ring + lane * 16;
@@ -182,6 +184,8 @@ template <class C, bool STORES, int NCH> struct PStream {
         issue(0);
         if (NCH > 1) issue(1);
         if (NCH > 2) issue(2);
+    }
+    __device__ __forceinline__ void start_wait() {
         if (NCH > 2 && !STORES) wait_vmcnt<C::PIECES>();
         else wait_vmcnt<0>();
         __syncthreads();

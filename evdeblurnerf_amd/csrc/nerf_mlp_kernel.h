@@ -103,9 +103,23 @@ __global__ __launch_bounds__(NT, NT / 256) void k_nerf_mlp(const MlpParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, h = lane >> 5;
-    float* bias = reinterpret_cast<float*>(smem + C::RING);
-    for (int i = tid; i < p.nbias; i += NT) bias[i] = p.bias[i];
     NerfCtx<C, N, FEAT> cx;
+    cx.st.start_issue(p.wstream, smem, tid);
+    float* bias = reinterpret_cast<float*>(smem + C::RING);
+    {   // bias block -> LDS, all loads of a thread in flight together
+        constexpr int NB = (C::BIAS_FLOATS / 4 + NT - 1) / NT;
+        f32x4 bv[NB];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int i = (tid + q * NT) * 4;
+            bv[q] = i < p.nbias ? *reinterpret_cast<const f32x4*>(p.bias + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int i = (tid + q * NT) * 4;
+            if (i < p.nbias) *reinterpret_cast<f32x4*>(bias + i) = bv[q];
+        }
+    }
     cx.stash = reinterpret_cast<B*>(smem + C::RING + C::BIAS_FLOATS * 4 + wave * C::STASH_PER_WAVE) + lane;
     cx.bias = bias;
     cx.lane = lane;
@@ -147,7 +161,7 @@ __global__ __launch_bounds__(NT, NT / 256) void k_nerf_mlp(const MlpParams p) {
     cx.frow_after = p.feature_kind == 1 ? frow : nofrow;      // "after_linear": feature_linear output
     cx.nofrow = nofrow;
 
-    cx.st.start(p.wstream, smem, tid);
+    cx.st.start_wait();
 #ifdef EVD_PIPE_SHIFT
 #pragma unroll
     for (int i = 0; i < EVD_PIPE_SHIFT; ++i) asm volatile("s_nop 0");
