@@ -4,9 +4,11 @@
 #include "nerf_mlp.h"
 #include "pack.h"
 #include "voxel.h"
+#include "voxel_mlp_kernel.h"
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 
 using namespace evd;
 
@@ -14,8 +16,8 @@ struct evd_voxel {
     int num_layers, hidden_dim, geo, num_layers_color, input_ch, ft_dim, app_dim;
     int n_comp[3], grid[3], app_act, rgb_act, sigma_act, composite_feature;
     float aabb[6], rmnear;
-    DevBuf plane[3], line[3], basis, stream[EVD_NUM_PREC], bias, tv_acc;
-    int nchunks[EVD_NUM_PREC];
+    DevBuf plane[3], line[3], basis, stream[EVD_NUM_PREC], pipe[EVD_NUM_PREC], bias, tv_acc;
+    int nchunks[EVD_NUM_PREC], pipe_chunks[EVD_NUM_PREC];     // pipe: stream of the software-pipelined kernel, where built
     GridParams gp;
 };
 
@@ -26,7 +28,7 @@ extern "C" {
 void evd_voxel_destroy(evd_voxel* v) {
     if (!v) return;
     for (int i = 0; i < 3; ++i) { v->plane[i].release(); v->line[i].release(); }
-    for (int i = 0; i < EVD_NUM_PREC; ++i) v->stream[i].release();
+    for (int i = 0; i < EVD_NUM_PREC; ++i) { v->stream[i].release(); v->pipe[i].release(); }
     v->basis.release(); v->bias.release(); v->tv_acc.release();
     delete v;
 }
@@ -96,8 +98,7 @@ int evd_voxel_create(const evd_voxel_desc* d, evd_voxel** out) {
         const int c = pe_src_col(PE_LV, 8 * (j - gk) + (kk & 7), kk >> 3);
         return c < 0 ? -1 : G + c;
     };
-    for (int prec = 0; prec < EVD_NUM_PREC; ++prec) {
-        StreamBuilder sb(prec);
+    auto build = [&](StreamBuilder& sb) {
         sb.layer(d->sigma_w[0], HD, d->input_ch, T, KF + PE_KS, false, in0_col);
         if (small) {
             sb.layer(d->sigma_w[1], 1 + G, HD, 1, KS, false, hid_col);
@@ -108,9 +109,22 @@ int evd_voxel_create(const evd_voxel_desc* d, evd_voxel** out) {
         sb.layer(d->color_w[0], HD, G + ICV, T, (small ? 1 : G / 16) + PEV_KS, false, c0_col);
         sb.layer(d->color_w[1], HD, HD, T, KS, false, hid_col);
         sb.layer(d->color_w[2], 3, HD, 1, KS, true, hid_col);
+    };
+    for (int prec = 0; prec < EVD_NUM_PREC; ++prec) {
+        StreamBuilder sb(prec);
+        build(sb);
         v->nchunks[prec] = (int)(sb.bytes.size() / chunk_bytes(prec));
         rc = v->stream[prec].upload(sb.bytes.data(), sb.bytes.size());
         if (rc) { evd_voxel_destroy(v); return rc; }
+        v->pipe_chunks[prec] = 0;
+        if (voxel_pipe_built(prec, HD, G, FT)) {        // same layers, single-tile groups, 16 KiB chunks (voxel_mlp_kernel.h)
+            StreamBuilder sp(prec, PIPE_CB);
+            sp.group = 1;
+            build(sp);
+            v->pipe_chunks[prec] = (int)(sp.bytes.size() / PIPE_CB);
+            rc = v->pipe[prec].upload(sp.bytes.data(), sp.bytes.size());
+            if (rc) { evd_voxel_destroy(v); return rc; }
+        }
     }
     std::vector<float> b(32 * 16, 0.f);            // zero block shared by the bias-free sigma layers
     auto push = [&](const float* src, int out_dim, int tiles) {
@@ -143,11 +157,14 @@ static int voxel_pass(const evd_voxel* v, int precision, const float* pts, const
                       const float* noise, float* color, float* depth, float* acc, float* weights, float* feature, float* raw,
                       void* stream) {
     VoxMlpParams p;
-    p.wstream = (const char*)v->stream[precision].p;
+    const bool piped = v->pipe_chunks[precision] > 0 && !getenv("EVD_NO_PIPE");
+    p.wstream = (const char*)(piped ? v->pipe[precision].p : v->stream[precision].p);
     p.bias = (const float*)v->bias.p;
     p.pts = pts; p.viewdirs = viewdirs; p.fts = fts; p.nsamp = R * (long)S; p.S = S; p.vd_stride = vd_stride; p.ft_stride = ft_stride;
-    p.nchunks = v->nchunks[precision]; p.nbias = (int)(v->bias.bytes / sizeof(float)); p.raw = raw; p.feature = feature;
-    int rc = voxel_mlp_dispatch(precision, v->hidden_dim, v->geo, v->ft_dim, p, as_stream(stream));
+    p.nchunks = piped ? v->pipe_chunks[precision] : v->nchunks[precision]; p.nbias = (int)(v->bias.bytes / sizeof(float)); p.raw = raw; p.feature = feature;
+    int rc = piped ? (precision == EVD_PREC_BF16 ? launch_voxel_pipe_bf16(feature != nullptr, p, as_stream(stream))
+                                                 : launch_voxel_pipe_f16(feature != nullptr, p, as_stream(stream)))
+                   : voxel_mlp_dispatch(precision, v->hidden_dim, v->geo, v->ft_dim, p, as_stream(stream));
     if (rc) return rc;
     const float thr = (!is_train && v->rmnear > 0.f) ? (float)((double)v->rmnear / 128.0) : 0.f;
     return evd_raw2outputs(raw, z, rays_d, rd_stride, R, S, 4, 0, 1, 3, v->rgb_act, v->sigma_act, 0, thr, noise,
@@ -179,6 +196,10 @@ size_t evd_c2f_render_workspace_bytes(const evd_voxel* coarse, const evd_voxel* 
     b += align256(r * St * 4);              // z merged
     b += align256(r * St * 12);             // pts
     b += align256(r * St * 64 * 4);         // features [n,64]
+    b += align256(r * S * 32 * 4);          // coarse features at the coarse samples [R*S,32]
+    b += align256(r * (Ni ? Ni : 1) * 32 * 4);   // coarse features at the new samples
+    b += align256(r * (Ni ? Ni : 1) * 12);  // new points
+    b += align256(r * St * 4);              // sort order
     b += align256(r * St * 16);             // raw
     b += align256(r * S * 4);               // weights0
     b += align256(r * St * 4);              // weights
@@ -209,6 +230,10 @@ int evd_c2f_render_rays(const evd_voxel* coarse, const evd_voxel* fine, const ev
     float* z2 = take(r * St * 4);
     float* pts = take(r * St * 12);
     float* ft = take(r * St * 64 * 4);
+    float* ft0 = take(r * S * 32 * 4);
+    float* ftn = take(r * (Ni ? Ni : 1) * 32 * 4);
+    float* ptn = take(r * (Ni ? Ni : 1) * 12);
+    int* order = (int*)take(r * St * 4);
     float* raw = take(r * St * 16);
     float* wts0 = take(r * S * 4);
     float* wts = take(r * St * 4);
@@ -218,23 +243,28 @@ int evd_c2f_render_rays(const evd_voxel* coarse, const evd_voxel* fine, const ev
     float* zc = (Ni ? (out->z_vals0 ? out->z_vals0 : z0) : (out->z_vals ? out->z_vals : z0));
     if ((rc = evd_sample_z(cfg, rb, 11, R, t_rand, zc, stream))) return rc;
     if ((rc = launch_points(rb, 11, zc, R * (long)S, S, pts, st))) return rc;
-    if ((rc = evd_voxel_sample(coarse, pts, R * (long)S, ft, FS, 0, stream))) return rc;          // renderer.py:183
+    const int FC = coarse->app_dim;
+    EVD_REQUIRE(!Ni || (FC == 32 && FC % 4 == 0), "evd_c2f_render_rays: coarse app_dim %d (workspace is sized for 32)", FC);
     if (!Ni) {
+        if ((rc = evd_voxel_sample(coarse, pts, R * (long)S, ft, FS, 0, stream))) return rc;      // renderer.py:183
         float* wo = out->weights ? out->weights : wts;
         return voxel_pass(coarse, cfg->precision, pts, rb + 8, 11, ft, FS, zc, rb + 3, 11, R, S, cfg->is_train, noise0,
                           out->rgb, out->depth, out->acc, wo, out->feature, out->raw ? out->raw : raw, stream);
     }
+    if ((rc = evd_voxel_sample(coarse, pts, R * (long)S, ft0, FC, 0, stream))) return rc;          // renderer.py:183
     float* w0 = out->weights0 ? out->weights0 : wts0;
-    if ((rc = voxel_pass(coarse, cfg->precision, pts, rb + 8, 11, ft, FS, zc, rb + 3, 11, R, S, cfg->is_train, noise0,
+    if ((rc = voxel_pass(coarse, cfg->precision, pts, rb + 8, 11, ft0, FC, zc, rb + 3, 11, R, S, cfg->is_train, noise0,
                          out->rgb0, out->depth0, out->acc0, w0, nullptr, raw, stream))) return rc;
     float* zm = out->z_vals ? out->z_vals : z2;
-    if ((rc = evd_sample_pdf_merge(zc, w0, R, S, Ni, cfg->perturb == 0.f, u, zs, zm, nullptr, out->z_std, stream))) return rc;
-    // merged sample set (renderer.py:205-213).  The reference re-orders the features it sampled at the old and
-    // the new points; features are a pure function of the point, so sampling both levels at the merged points
-    // yields the same values without the gather by `order`.
+    if ((rc = evd_sample_pdf_merge(zc, w0, R, S, Ni, cfg->perturb == 0.f, u, zs, zm, order, out->z_std, stream))) return rc;
+    // merged sample set (renderer.py:205-213), as the reference does it: coarse features are sampled at the NEW points only
+    // (:209) and the rows of the old and new points are gathered by the sort order (:212-213); the fine level is sampled at
+    // all merged points (:211 samples the new ones and :194 the old ones -- a pure function of the point either way).
     const long n2 = R * (long)St;
+    if ((rc = launch_points(rb, 11, zs, R * (long)Ni, Ni, ptn, st))) return rc;
+    if ((rc = evd_voxel_sample(coarse, ptn, R * (long)Ni, ftn, FC, 0, stream))) return rc;
+    if ((rc = launch_merge_features(ft0, ftn, order, R, S, Ni, FC, ft, FS, st))) return rc;
     if ((rc = launch_points(rb, 11, zm, n2, St, pts, st))) return rc;
-    if ((rc = evd_voxel_sample(coarse, pts, n2, ft, FS, 0, stream))) return rc;
     if ((rc = evd_voxel_sample(fine, pts, n2, ft, FS, coarse->app_dim, stream))) return rc;
     float* wo = out->weights ? out->weights : wts;
     return voxel_pass(fine, cfg->precision, pts, rb + 8, 11, ft, FS, zm, rb + 3, 11, R, St, cfg->is_train, noise1,

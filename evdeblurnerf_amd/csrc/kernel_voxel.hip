@@ -21,6 +21,22 @@ __global__ void k_points(const float* __restrict__ rb, int nc, const float* __re
     for (int c = 0; c < 3; ++c) pts[s * 3 + c] = __fadd_rn(r[c], __fmul_rn(r[3 + c], zv));
 }
 
+// merged-sample feature rows of the c2f pass (renderer.py:205-213): out[r, k, 0:F] = order[r, k] < S ? old[r, order] : fresh[r, order - S]
+// -- the reference's gather of cat([ft_comb0, ft_comb1]) by the sort order, 16 bytes per lane
+__global__ void k_merge_features(const float* __restrict__ old, const float* __restrict__ fresh, const int* __restrict__ order,
+                                 long R, int S, int N, int F, float* __restrict__ out, int out_stride) {
+    const int per = F / 4;
+    const long t = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const long St = S + N;
+    if (t >= R * St * per) return;
+    const long smp = t / per;
+    const int q = t % per;
+    const long r = smp / St;
+    const int o = order[smp];
+    const float* src = o < S ? old + (r * S + o) * (long)F : fresh + (r * N + (o - S)) * (long)F;
+    *reinterpret_cast<f32x4*>(out + smp * (long)out_stride + 4 * q) = *reinterpret_cast<const f32x4*>(src + 4 * q);
+}
+
 __device__ __forceinline__ float unnorm(float c, int size) { return __fmul_rn(__fadd_rn(c, 1.f) / 2.f, (float)(size - 1)); }
 
 constexpr int VS_SAMPLES = 32;      // samples per 256-thread block
@@ -314,6 +330,14 @@ __global__ void k_tv_finish(const double* __restrict__ acc, TvShape s, float* __
 
 int launch_points(const float* rb, int nc, const float* z, long n, int S, float* pts, hipStream_t st) {
     k_points<<<cdiv(n, 256), 256, 0, st>>>(rb, nc, z, n, S, pts);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+int launch_merge_features(const float* old, const float* fresh, const int* order, long R, int S, int N, int F, float* out, int out_stride,
+                          hipStream_t st) {
+    const long n = R * (long)(S + N) * (F / 4);
+    k_merge_features<<<cdiv(n, 256), 256, 0, st>>>(old, fresh, order, R, S, N, F, out, out_stride);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }

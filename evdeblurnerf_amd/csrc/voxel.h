@@ -28,6 +28,8 @@ struct VoxMlpParams {
 struct TvShape { int C[6], H[6], W[6]; };
 
 int launch_points(const float* rb, int nc, const float* z, long n, int S, float* pts, hipStream_t st);
+int launch_merge_features(const float* old, const float* fresh, const int* order, long R, int S, int N, int F, float* out, int out_stride,
+                          hipStream_t st);
 int launch_voxel_sample(const GridParams& g, const float* pts, long n, float* out, int out_stride, int out_col, hipStream_t st);
 int launch_tv(const float* x, int H, int W, int C, double* acc2, hipStream_t st);
 int launch_tv_finish(const double* acc, const TvShape& s, float* out, hipStream_t st);

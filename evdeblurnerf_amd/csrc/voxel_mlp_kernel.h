@@ -1,0 +1,151 @@
+// Software-pipelined PDRF fine-level network (hidden 256, geo 128, 64 feature channels in; reference
+// networks/pdrf/voxnerf.py:210-221,240-254 with the blurfactory dimensions): sigma net 127 -> 256 -> 1 + 128,
+// colour net 155 -> 256 -> 256 -> 3 (sigmoid), on the machinery of mlp_pipe.h.  One straight-line stream of 368
+// MFMAs per wavefront; layer table below.  The coarse level (64-wide) stays on kernel_voxel.hip's generic kernel.
+#pragma once
+
+#include "mlp_pipe.h"
+#include "voxel.h"
+
+namespace evd {
+
+template <class C, bool FEAT> struct VoxFineNet {
+    static constexpr int HD = 256, G = 128, FT = 64;
+    static constexpr int T = HD / 32, KS = HD / 16, KF = FT / 16, GT = G / 32, GK = G / 16, FPC = C::FPC, PD = C::PD;
+    // sigma_net.0 on cat([fts, PE(pts)]) (voxnerf.py:214): k-steps [fts_0..3 | pe_0..3]
+    typedef LayerDesc<KF + PE_KS, T, 1, true, false, 0, 0, false, 0, 0, 0, false, 0, -1, false, 1> L0;
+    static constexpr int F1 = T * (KF + PE_KS);
+    // sigma_net.1 row 0 = sigma (float32 out) ...
+    typedef LayerDesc<KS, 1, 1, false, true, 0, F1, false, F1 % PD, L0::PAR_OUT, 1, true, KS - 2, -1, false, 1> Sigma;
+    static constexpr int F2 = F1 + KS;
+    // ... rows 1..128 = geo features (no activation; the per-sample feature AWP consumes, voxnerf.py:221)
+    typedef LayerDesc<KS, GT, 1, false, false, 0, F2, false, F2 % PD, Sigma::PAR_OUT, 0, false, 0, -1, FEAT, 1> Geo;
+    static constexpr int F3 = F2 + GT * KS;
+    // color_net.0 on cat([geo, PE(dirs)]) (voxnerf.py:248): k-steps [geo_0..7 | dir_0..1]; geo's last tile lands at 6, 7
+    typedef LayerDesc<GK + PEV_KS, T, 1, true, false, 0, F3, false, F3 % PD, Geo::PAR_OUT, 1, false, GK - 2, FEAT ? GT - 1 : -1, false, 1> C0;
+    static constexpr int F4 = F3 + T * (GK + PEV_KS);
+    typedef LayerDesc<KS, T, 1, true, false, 0, F4, false, F4 % PD, C0::PAR_OUT, 1, true, KS - 2, -1, false, 1> C1;
+    static constexpr int F5 = F4 + T * KS;
+    typedef LayerDesc<KS, 1, 1, false, true, 0, F5, true, F5 % PD, C1::PAR_OUT, 1, true, KS - 2, -1, false, 0> C2;
+    static constexpr int NCH = cceil(F5 + KS, FPC);
+    // LDS bias image in stream order: the sigma net has no biases (zeros)
+    static constexpr int B_SIG = T * 32, B_GEO = B_SIG + 32, B_C0 = B_GEO + GT * 32, B_C1 = B_C0 + T * 32, B_C2 = B_C1 + T * 32, B_END = B_C2 + 32;
+    static_assert(F1 % PD == 0 && F3 % PD == 0 && F4 % PD == 0, "prefetch ring phase");
+};
+
+template <int PREC, int NS, int NT, bool FEAT>
+__global__ __launch_bounds__(NT, NT / 256) void k_voxel_mlp_pipe(const VoxMlpParams p) {
+    typedef PipeCfg<PREC, NS, NT> C;
+    typedef typename C::O O;
+    typedef typename O::B B;
+    typedef VoxFineNet<C, FEAT> N;
+    constexpr int T = N::T, KS = N::KS, KF = N::KF, GK = N::GK;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef PStream<C, FEAT, N::NCH> ST;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, h = lane >> 5;
+    ST st;
+    st.start_issue(p.wstream, smem, tid);
+    float* bias = reinterpret_cast<float*>(smem + C::RING);
+    // bias image: zeros for the sigma net, then the colour-net biases (p.bias = 512 zeros + colour biases, evd_voxel_api.hip)
+    for (int i = tid; i < N::B_END; i += NT) bias[i] = i < N::B_C0 ? 0.f : p.bias[512 + (i - N::B_C0)];
+    B* stash = reinterpret_cast<B*>(smem + C::RING + C::BIAS_FLOATS * 4 + wave * C::STASH_PER_WAVE) + lane;
+
+    long sidx[NS];
+    bool valid[NS];
+    B in0[NS][KF + PE_KS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const long smp = (long)blockIdx.x * C::SAMPLES + wave * (NS * 32) + s * 32 + n;
+        valid[s] = smp < p.nsamp;
+        sidx[s] = valid[s] ? smp : p.nsamp - 1;
+        float pts[3], vd[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            pts[c] = p.pts[sidx[s] * 3 + c];
+            vd[c] = p.viewdirs[(sidx[s] / p.S) * p.vd_stride + c];
+        }
+        // feature k-steps in natural order: B position 8h + e of k-step j <-> feature 16 j + 8 h + e
+        const float* f = p.fts + sidx[s] * (long)p.ft_stride + 8 * h;
+#pragma unroll
+        for (int j = 0; j < KF; ++j) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(f + 16 * j), b = *reinterpret_cast<const f32x4*>(f + 16 * j + 4);
+            O::template set_pair<false>(in0[s][j], 0, a[0], a[1]);
+            O::template set_pair<false>(in0[s][j], 1, a[2], a[3]);
+            O::template set_pair<false>(in0[s][j], 2, b[0], b[1]);
+            O::template set_pair<false>(in0[s][j], 3, b[2], b[3]);
+        }
+        B pe[PE_KS], pev[PEV_KS];
+        encode_pairs<C, PE_L, PE_KS>(pts, h, pe);
+        encode_pairs<C, PE_LV, PEV_KS>(vd, h, pev);
+#pragma unroll
+        for (int j = 0; j < PE_KS; ++j) in0[s][KF + j] = pe[j];
+#pragma unroll
+        for (int j = 0; j < PEV_KS; ++j) stash[(s * C::STASH_FRAGS + j) * 64] = pev[j];   // parked until the colour net
+    }
+    float* frow[NS];
+    float* nofrow[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        frow[s] = (FEAT && p.feature && valid[s]) ? p.feature + sidx[s] * N::G : nullptr;
+        nofrow[s] = nullptr;
+    }
+    st.start_wait();
+    Pipe<C> pp;
+    pipe_prime<C, typename N::L0>(st, pp, bias, lane);
+
+    B hid[NS][KS], none[NS][1];
+    pipe_layer<C, typename N::L0, ST, KS>(st, pp, in0, hid, nullptr, bias, lane, nofrow);
+    float sig[NS][4], col[NS][4];
+    pipe_layer<C, typename N::Sigma, ST, 1>(st, pp, hid, none, sig, bias + N::B_SIG, lane, nofrow);
+    B cin[NS][GK + PEV_KS];
+    pipe_layer<C, typename N::Geo, ST, GK + PEV_KS>(st, pp, hid, cin, nullptr, bias + N::B_GEO, lane, frow);
+    {
+        const B* sp = stash;
+        asm volatile("" : "+v"(sp));
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int j = 0; j < PEV_KS; ++j) cin[s][GK + j] = sp[(s * C::STASH_FRAGS + j) * 64];
+    }
+    B c0[NS][KS], c1[NS][KS];
+    pipe_layer<C, typename N::C0, ST, KS>(st, pp, cin, c0, nullptr, bias + N::B_C0, lane, frow);
+    pipe_layer<C, typename N::C1, ST, KS>(st, pp, c0, c1, nullptr, bias + N::B_C1, lane, nofrow);
+    pipe_layer<C, typename N::C2, ST, 1>(st, pp, c1, none, col, bias + N::B_C2, lane, nofrow);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (h == 0 && valid[s]) {
+            f32x4 o;
+            o[0] = sig[s][0];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[1 + c] = 1.f / (1.f + expf(-col[s][c]));      // torch.sigmoid(h) voxnerf.py:252
+            *reinterpret_cast<f32x4*>(p.raw + sidx[s] * 4) = o;
+        }
+    }
+}
+
+template <int PREC, bool FEAT>
+static int launch_voxel_pipe(const VoxMlpParams& p, hipStream_t st) {
+    typedef PipeCfg<PREC, 1, 512> C;
+    typedef VoxFineNet<C, FEAT> N;
+    const long blocks = cdiv(p.nsamp, C::SAMPLES);
+    const size_t lds = C::TOTAL;
+    static bool attr_set = false;
+    if (!attr_set) {
+        EVD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_voxel_mlp_pipe<PREC, 1, 512, FEAT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    if (p.nchunks != N::NCH) return fail(EVD_E_INVALID, "evd_voxel: packed stream has %d chunks, kernel expects %d", p.nchunks, N::NCH);
+    hipLaunchKernelGGL((k_voxel_mlp_pipe<PREC, 1, 512, FEAT>), dim3((unsigned)blocks), dim3(512), lds, st, p);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+constexpr bool voxel_pipe_built(int prec, int HD, int G, int FT) {
+    return (prec == EVD_PREC_BF16 || prec == EVD_PREC_F16) && HD == 256 && G == 128 && FT == 64;
+}
+int launch_voxel_pipe_bf16(bool feat, const VoxMlpParams& p, hipStream_t st);
+int launch_voxel_pipe_f16(bool feat, const VoxMlpParams& p, hipStream_t st);
+
+}  // namespace evd
