@@ -16,7 +16,7 @@ struct evd_voxel {
     int num_layers, hidden_dim, geo, num_layers_color, input_ch, ft_dim, app_dim;
     int n_comp[3], grid[3], app_act, rgb_act, sigma_act, composite_feature;
     float aabb[6], rmnear;
-    DevBuf plane[3], line[3], basis, stream[EVD_NUM_PREC], pipe[EVD_NUM_PREC], bias, tv_acc;
+    DevBuf plane[3], line[3], plane_h[3], line_h[3], basis, stream[EVD_NUM_PREC], pipe[EVD_NUM_PREC], bias, tv_acc;
     int nchunks[EVD_NUM_PREC], pipe_chunks[EVD_NUM_PREC];     // pipe: stream of the software-pipelined kernel, where built
     GridParams gp;
 };
@@ -27,7 +27,7 @@ extern "C" {
 
 void evd_voxel_destroy(evd_voxel* v) {
     if (!v) return;
-    for (int i = 0; i < 3; ++i) { v->plane[i].release(); v->line[i].release(); }
+    for (int i = 0; i < 3; ++i) { v->plane[i].release(); v->line[i].release(); v->plane_h[i].release(); v->line_h[i].release(); }
     for (int i = 0; i < EVD_NUM_PREC; ++i) { v->stream[i].release(); v->pipe[i].release(); }
     v->basis.release(); v->bias.release(); v->tv_acc.release();
     delete v;
@@ -63,10 +63,20 @@ int evd_voxel_create(const evd_voxel_desc* d, evd_voxel** out) {
             for (long hw = 0; hw < (long)Hp * Wp; ++hw) cl[(size_t)hw * C + c] = d->plane[i][(size_t)c * Hp * Wp + hw];
         rc = v->plane[i].upload(cl.data(), cl.size() * sizeof(float));
         if (rc) break;
+        {   // float16 copy for the half-precision arithmetic modes
+            std::vector<_Float16> ch(cl.size());
+            for (size_t k = 0; k < cl.size(); ++k) ch[k] = (_Float16)cl[k];
+            rc = v->plane_h[i].upload(ch.data(), ch.size() * sizeof(_Float16));
+            if (rc) break;
+        }
         std::vector<float> ll((size_t)C * Lp);
         for (int c = 0; c < C; ++c)
             for (int l = 0; l < Lp; ++l) ll[(size_t)l * C + c] = d->line[i][(size_t)c * Lp + l];
         rc = v->line[i].upload(ll.data(), ll.size() * sizeof(float));
+        if (rc) break;
+        std::vector<_Float16> lh(ll.size());
+        for (size_t k = 0; k < ll.size(); ++k) lh[k] = (_Float16)ll[k];
+        rc = v->line_h[i].upload(lh.data(), lh.size() * sizeof(_Float16));
     }
     if (!rc) rc = v->basis.upload(d->basis, sizeof(float) * (size_t)d->app_dim * ctot);
     if (!rc) rc = v->tv_acc.alloc(12 * sizeof(double));
@@ -74,6 +84,7 @@ int evd_voxel_create(const evd_voxel_desc* d, evd_voxel** out) {
     GridParams& g = v->gp;
     for (int i = 0; i < 3; ++i) {
         g.plane[i] = (const float*)v->plane[i].p; g.line[i] = (const float*)v->line[i].p;
+        g.plane_h[i] = (const _Float16*)v->plane_h[i].p; g.line_h[i] = (const _Float16*)v->line_h[i].p;
         g.n_comp[i] = d->n_comp[i]; g.grid[i] = d->grid[i];
         g.aabb_min[i] = d->aabb[i];
         g.inv[i] = 2.0f / (d->aabb[3 + i] - d->aabb[i]);
@@ -142,7 +153,13 @@ int evd_voxel_create(const evd_voxel_desc* d, evd_voxel** out) {
 int evd_voxel_sample(const evd_voxel* v, const float* pts, long n, float* out, int out_stride, int out_col, void* stream) {
     EVD_REQUIRE(v && out && n >= 0 && out_stride >= out_col + v->app_dim, "evd_voxel_sample: bad arguments");
     if (n == 0) return EVD_OK;
-    return launch_voxel_sample(v->gp, pts, n, out, out_stride, out_col, as_stream(stream));
+    return launch_voxel_sample(v->gp, false, pts, n, out, out_stride, out_col, as_stream(stream));
+}
+
+// sampling inside the c2f render: the half-precision arithmetic modes read the float16 copies of the grids
+static int sample_for(const evd_voxel* v, int precision, const float* pts, long n, float* out, int out_stride, int out_col, void* stream) {
+    const bool half = (precision == EVD_PREC_BF16 || precision == EVD_PREC_F16) && !getenv("EVD_F32_GRIDS");
+    return launch_voxel_sample(v->gp, half, pts, n, out, out_stride, out_col, as_stream(stream));
 }
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -246,12 +263,12 @@ int evd_c2f_render_rays(const evd_voxel* coarse, const evd_voxel* fine, const ev
     const int FC = coarse->app_dim;
     EVD_REQUIRE(!Ni || (FC == 32 && FC % 4 == 0), "evd_c2f_render_rays: coarse app_dim %d (workspace is sized for 32)", FC);
     if (!Ni) {
-        if ((rc = evd_voxel_sample(coarse, pts, R * (long)S, ft, FS, 0, stream))) return rc;      // renderer.py:183
+        if ((rc = sample_for(coarse, cfg->precision, pts, R * (long)S, ft, FS, 0, stream))) return rc;      // renderer.py:183
         float* wo = out->weights ? out->weights : wts;
         return voxel_pass(coarse, cfg->precision, pts, rb + 8, 11, ft, FS, zc, rb + 3, 11, R, S, cfg->is_train, noise0,
                           out->rgb, out->depth, out->acc, wo, out->feature, out->raw ? out->raw : raw, stream);
     }
-    if ((rc = evd_voxel_sample(coarse, pts, R * (long)S, ft0, FC, 0, stream))) return rc;          // renderer.py:183
+    if ((rc = sample_for(coarse, cfg->precision, pts, R * (long)S, ft0, FC, 0, stream))) return rc;          // renderer.py:183
     float* w0 = out->weights0 ? out->weights0 : wts0;
     if ((rc = voxel_pass(coarse, cfg->precision, pts, rb + 8, 11, ft0, FC, zc, rb + 3, 11, R, S, cfg->is_train, noise0,
                          out->rgb0, out->depth0, out->acc0, w0, nullptr, raw, stream))) return rc;
@@ -262,10 +279,10 @@ int evd_c2f_render_rays(const evd_voxel* coarse, const evd_voxel* fine, const ev
     // all merged points (:211 samples the new ones and :194 the old ones -- a pure function of the point either way).
     const long n2 = R * (long)St;
     if ((rc = launch_points(rb, 11, zs, R * (long)Ni, Ni, ptn, st))) return rc;
-    if ((rc = evd_voxel_sample(coarse, ptn, R * (long)Ni, ftn, FC, 0, stream))) return rc;
+    if ((rc = sample_for(coarse, cfg->precision, ptn, R * (long)Ni, ftn, FC, 0, stream))) return rc;
     if ((rc = launch_merge_features(ft0, ftn, order, R, S, Ni, FC, ft, FS, st))) return rc;
     if ((rc = launch_points(rb, 11, zm, n2, St, pts, st))) return rc;
-    if ((rc = evd_voxel_sample(fine, pts, n2, ft, FS, coarse->app_dim, stream))) return rc;
+    if ((rc = sample_for(fine, cfg->precision, pts, n2, ft, FS, coarse->app_dim, stream))) return rc;
     float* wo = out->weights ? out->weights : wts;
     return voxel_pass(fine, cfg->precision, pts, rb + 8, 11, ft, FS, zm, rb + 3, 11, R, St, cfg->is_train, noise1,
                       out->rgb, out->depth, out->acc, wo, out->feature, out->raw ? out->raw : raw, stream);

@@ -55,6 +55,15 @@ constexpr int VS_STRIDE = VS_MAXC + 1;      // odd row stride: conflict-free col
 
 struct VsItem { f32x4 p[4], l[2]; float wp[4], wl[2]; };
 
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+template <bool HALF>
+__device__ __forceinline__ f32x4 vs_load(const float* base32, const _Float16* base16, long idx) {
+    if (HALF) return __builtin_convertvector(*reinterpret_cast<const f16x4*>(base16 + idx), f32x4);
+    return *reinterpret_cast<const f32x4*>(base32 + idx);
+}
+
+template <bool HALF>
 __device__ __forceinline__ void vs_issue(const GridParams& g, const float* __restrict__ pts, long s, int grp, VsItem& it) {
     const int mat0[3] = {0, 0, 1}, mat1[3] = {1, 2, 2}, vec[3] = {2, 1, 0};
     int i = 0, c4 = grp * 4;
@@ -72,10 +81,11 @@ __device__ __forceinline__ void vs_issue(const GridParams& g, const float* __res
     const bool vx0 = x0 >= 0 && x0 < Wp, vx1 = x1 >= 0 && x1 < Wp, vy0 = y0 >= 0 && y0 < Hp, vy1 = y1 >= 0 && y1 < Hp;
     const int cx0 = min(max(x0, 0), Wp - 1), cx1 = min(max(x1, 0), Wp - 1), cy0 = min(max(y0, 0), Hp - 1), cy1 = min(max(y1, 0), Hp - 1);
     const float* pl = g.plane[i] + c4;
-    it.p[0] = *reinterpret_cast<const f32x4*>(pl + ((long)cy0 * Wp + cx0) * C);
-    it.p[1] = *reinterpret_cast<const f32x4*>(pl + ((long)cy0 * Wp + cx1) * C);
-    it.p[2] = *reinterpret_cast<const f32x4*>(pl + ((long)cy1 * Wp + cx0) * C);
-    it.p[3] = *reinterpret_cast<const f32x4*>(pl + ((long)cy1 * Wp + cx1) * C);
+    const _Float16* plh = g.plane_h[i] + c4;
+    it.p[0] = vs_load<HALF>(pl, plh, ((long)cy0 * Wp + cx0) * C);
+    it.p[1] = vs_load<HALF>(pl, plh, ((long)cy0 * Wp + cx1) * C);
+    it.p[2] = vs_load<HALF>(pl, plh, ((long)cy1 * Wp + cx0) * C);
+    it.p[3] = vs_load<HALF>(pl, plh, ((long)cy1 * Wp + cx1) * C);
     it.wp[0] = (vy0 && vx0) ? __fmul_rn(ee, ss) : 0.f;
     it.wp[1] = (vy0 && vx1) ? __fmul_rn(ww, ss) : 0.f;
     it.wp[2] = (vy1 && vx0) ? __fmul_rn(ee, nn) : 0.f;
@@ -85,8 +95,9 @@ __device__ __forceinline__ void vs_issue(const GridParams& g, const float* __res
     const float ln = __fsub_rn(il, floorf(il)), ls = __fsub_rn(1.f, ln);
     const int l0 = (int)fl, l1 = l0 + 1;
     const float* li = g.line[i] + c4;
-    it.l[0] = *reinterpret_cast<const f32x4*>(li + (long)min(max(l0, 0), Lp - 1) * C);
-    it.l[1] = *reinterpret_cast<const f32x4*>(li + (long)min(max(l1, 0), Lp - 1) * C);
+    const _Float16* lih = g.line_h[i] + c4;
+    it.l[0] = vs_load<HALF>(li, lih, (long)min(max(l0, 0), Lp - 1) * C);
+    it.l[1] = vs_load<HALF>(li, lih, (long)min(max(l1, 0), Lp - 1) * C);
     it.wl[0] = (l0 >= 0 && l0 < Lp) ? ls : 0.f;
     it.wl[1] = (l1 >= 0 && l1 < Lp) ? ln : 0.f;
 }
@@ -108,6 +119,7 @@ __device__ __forceinline__ f32x4 vs_finish(const VsItem& it) {
     return cf;
 }
 
+template <bool HALF>
 __global__ __launch_bounds__(256) void k_voxel_sample(const GridParams g, const float* __restrict__ pts, long n,
                                                       float* __restrict__ out, int out_stride, int out_col) {
     __shared__ __attribute__((aligned(16))) float coef[VS_SAMPLES * VS_STRIDE];
@@ -127,7 +139,7 @@ __global__ __launch_bounds__(256) void k_voxel_sample(const GridParams g, const 
             sl[q] = on[q] ? t / ng : 0;
             grp[q] = on[q] ? t % ng : 0;
             const long s = s0 + sl[q] < n ? s0 + sl[q] : n - 1;
-            vs_issue(g, pts, s, grp[q], it[q]);
+            vs_issue<HALF>(g, pts, s, grp[q], it[q]);
         }
 #pragma unroll
         for (int q = 0; q < UNR; ++q) {
@@ -342,8 +354,9 @@ int launch_merge_features(const float* old, const float* fresh, const int* order
     return EVD_OK;
 }
 
-int launch_voxel_sample(const GridParams& g, const float* pts, long n, float* out, int out_stride, int out_col, hipStream_t st) {
-    k_voxel_sample<<<cdiv(n, VS_SAMPLES), 256, 0, st>>>(g, pts, n, out, out_stride, out_col);
+int launch_voxel_sample(const GridParams& g, bool half_grids, const float* pts, long n, float* out, int out_stride, int out_col, hipStream_t st) {
+    if (half_grids) k_voxel_sample<true><<<cdiv(n, VS_SAMPLES), 256, 0, st>>>(g, pts, n, out, out_stride, out_col);
+    else k_voxel_sample<false><<<cdiv(n, VS_SAMPLES), 256, 0, st>>>(g, pts, n, out, out_stride, out_col);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }

@@ -8,6 +8,8 @@ namespace evd {
 struct GridParams {
     const float* plane[3];      // channel-last [grid[m1]][grid[m0]][C_i]
     const float* line[3];       // [grid[vec]][C_i]
+    const _Float16* plane_h[3]; // float16 copies of the grids (same layout), read by the bf16 / f16 arithmetic modes:
+    const _Float16* line_h[3];  //   half the gather bytes; 2^-11 rounding, the same as those modes' MFMA operands
     const float* basis;         // [app_dim][Ctot]
     int n_comp[3], grid[3], app_dim, app_act;
     float aabb_min[3], inv[3];  // inv = 2 / (max - min)  (invaabbSize, voxnerf.py:91)
@@ -30,7 +32,7 @@ struct TvShape { int C[6], H[6], W[6]; };
 int launch_points(const float* rb, int nc, const float* z, long n, int S, float* pts, hipStream_t st);
 int launch_merge_features(const float* old, const float* fresh, const int* order, long R, int S, int N, int F, float* out, int out_stride,
                           hipStream_t st);
-int launch_voxel_sample(const GridParams& g, const float* pts, long n, float* out, int out_stride, int out_col, hipStream_t st);
+int launch_voxel_sample(const GridParams& g, bool half_grids, const float* pts, long n, float* out, int out_stride, int out_col, hipStream_t st);
 int launch_tv(const float* x, int H, int W, int C, double* acc2, hipStream_t st);
 int launch_tv_finish(const double* acc, const TvShape& s, float* out, hipStream_t st);
 int voxel_mlp_dispatch(int prec, int HD, int G, int FT, const VoxMlpParams& p, hipStream_t st);
