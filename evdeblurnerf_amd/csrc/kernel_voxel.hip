@@ -305,17 +305,31 @@ int voxel_mlp_dispatch(int prec, int HD, int G, int FT, const VoxMlpParams& p, h
                 "(built: coarse 64/15/32, fine 256/128/64)", prec, HD, G, FT);
 }
 
-// TVLoss.forward (voxnerf.py:306-324) on a channel-last tensor [H][W][C]; accumulates sum dh^2, sum dw^2
+// TVLoss.forward (voxnerf.py:306-324) on a channel-last tensor [H][W][C]; accumulates sum dh^2, sum dw^2.
+// HBM-bound (every grid value is read once per training iteration): one thread = 4 channels of one texel, float4
+// loads of the texel, its lower and its right neighbour (both re-read from L1/L2), rows strided over blockIdx.y,
+// double accumulators, one atomic pair per block.
 __global__ __launch_bounds__(256) void k_tv(const float* __restrict__ x, int H, int W, int C, double* __restrict__ acc2) {
     __shared__ double red[2][4];
-    const long n = (long)H * W * C;
+    const int vec_per_row = W * (C / 4);
     double sh = 0.0, sw = 0.0;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
-        const long hw = idx / C;
-        const int hh = hw / W, wq = hw % W;
-        const float v = x[idx];
-        if (hh + 1 < H) { const float d = x[idx + (long)W * C] - v; sh += (double)(d * d); }
-        if (wq + 1 < W) { const float d = x[idx + C] - v; sw += (double)(d * d); }
+    for (int hh = blockIdx.y; hh < H; hh += gridDim.y) {
+        const float* row = x + (long)hh * W * C;
+        for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < vec_per_row; t += gridDim.x * blockDim.x) {
+            const int wq = t / (C / 4);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(row + 4 * (long)t);
+            float ph = 0.f, pw = 0.f;
+            if (hh + 1 < H) {
+                const f32x4 d = *reinterpret_cast<const f32x4*>(row + (long)W * C + 4 * (long)t) - v;
+                ph = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+            }
+            if (wq + 1 < W) {
+                const f32x4 d = *reinterpret_cast<const f32x4*>(row + 4 * (long)t + C) - v;
+                pw = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+            }
+            sh += (double)ph;
+            sw += (double)pw;
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { sh += __shfl_xor(sh, off, 64); sw += __shfl_xor(sw, off, 64); }
@@ -362,9 +376,11 @@ int launch_voxel_sample(const GridParams& g, bool half_grids, const float* pts, 
 }
 
 int launch_tv(const float* x, int H, int W, int C, double* acc2, hipStream_t st) {
-    const long n = (long)H * W * C;
-    const long blocks = cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048;
-    k_tv<<<(unsigned)blocks, 256, 0, st>>>(x, H, W, C, acc2);
+    if (C % 4) return fail(EVD_E_INVALID, "evd_voxel_tv_loss: component count %d is not a multiple of 4", C);
+    const long vec_per_row = (long)W * (C / 4);
+    const unsigned bx = (unsigned)(cdiv(vec_per_row, 256) < 64 ? cdiv(vec_per_row, 256) : 64);
+    const unsigned by = (unsigned)(H < 64 ? H : 64);
+    k_tv<<<dim3(bx, by), 256, 0, st>>>(x, H, W, C, acc2);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }

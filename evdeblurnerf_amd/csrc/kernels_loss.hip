@@ -161,7 +161,15 @@ __global__ __launch_bounds__(256) void k_blur_loss(const CrfParams crf, int skip
     }
 }
 
-// spec: run_nerf.py:518-570 + utils/events.py:260-284
+// spec: run_nerf.py:518-570 + utils/events.py:260-284.  The learnable event-CRF (a 1+E -> 16 -> 16 -> 16 -> 1 MLP per
+// colour value, ~650 FMAs) is evaluated 12 times per event (start/end x fine/coarse x 3 channels): one LANE per
+// evaluation, 16 lanes per event (lane = 4 which + channel, channel 3 idle), the luma / log-difference assembled with
+// quad and row DPP moves; weights are wave-uniform scalar loads from the kernel argument.
+template <int CTRL>
+__device__ __forceinline__ float dppf(float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), CTRL, 0xf, 0xf, true));
+}
+
 __global__ __launch_bounds__(256) void k_event_loss(const CrfParams crf, int skip_learn, int add_bii_feat, int tonemap_only,
                                                     const float* __restrict__ start, const float* __restrict__ end,
                                                     const float* __restrict__ start0, const float* __restrict__ end0,
@@ -169,42 +177,43 @@ __global__ __launch_bounds__(256) void k_event_loss(const CrfParams crf, int ski
                                                     float thr_neg, float thr_pos, const unsigned char* __restrict__ cmask,
                                                     float cw0, float cw1, float cw2, int has_cw, long N, float* __restrict__ partial) {
     __shared__ float red[8];
-    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    float s_f = 0.f, s_c = 0.f, s_w = 0.f;
-    if (i < N) {
-        const float cn = cum_neg[i], cp = cum_pos[i];
-        const float bii = __fadd_rn(__fmul_rn(thr_neg, cn), __fmul_rn(thr_pos, cp));   // run_nerf.py:518-519
-        int ch = 0;
-        if (cmask) for (int c = 0; c < 3; ++c) if (cmask[i * 3 + c]) ch = c;
-        const float cw[3] = {cw0, cw1, cw2};
-        const float w = (cmask && has_cw) ? cw[ch] : 1.f;
-        auto luma = [&](const float* rgb) {
-            float v[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float f[2] = {cn, cp};
-                const float* fp = nullptr;
-                if (add_bii_feat == 1) fp = f;                                            // 'pos-neg' :522-523
-                else if (add_bii_feat == 2) { if (c != ch) { f[0] = 0.f; f[1] = 0.f; } fp = f; }   // 'color-pos-neg' :524-531
-                v[c] = crf_apply(crf, rgb[i * 3 + c], fp, skip_learn);
-            }
-            return tonemap_only ? v[ch] : luma_of(0, v[0], v[1], v[2]);
-        };
-        const float pred = logf(luma(end) + 1e-5f) - logf(luma(start) + 1e-5f);
-        const float d = pred - bii;
-        s_f = d * d * w;
-        s_w = w;
-        if (start0 && end0) {
-            const float pred0 = logf(luma(end0) + 1e-5f) - logf(luma(start0) + 1e-5f);
-            const float d0 = pred0 - bii;
-            s_c = d0 * d0 * w;
-        }
+    const int sub = threadIdx.x & 15, which = sub >> 2, c = sub & 3;      // which: 0 end, 1 start, 2 end0, 3 start0
+    const long i = blockIdx.x * (long)(blockDim.x >> 4) + (threadIdx.x >> 4);
+    const bool on = i < N;
+    const long ii = on ? i : N - 1;
+    const bool have0 = start0 && end0;
+    const float cn = cum_neg[ii], cp = cum_pos[ii];
+    int ch = 0;
+    if (cmask) for (int k = 0; k < 3; ++k) if (cmask[ii * 3 + k]) ch = k;
+    const float* src = which == 0 ? end : which == 1 ? start : which == 2 ? end0 : start0;
+    float v = 0.f;
+    if (c < 3 && (which < 2 || have0)) {
+        float f[2] = {cn, cp};
+        const float* fp = nullptr;
+        if (add_bii_feat == 1) fp = f;                                            // 'pos-neg' :522-523
+        else if (add_bii_feat == 2) { if (c != ch) { f[0] = 0.f; f[1] = 0.f; } fp = f; }   // 'color-pos-neg' :524-531
+        v = crf_apply(crf, src[ii * 3 + c], fp, skip_learn);
     }
-    const float a = block_sum(s_f, red), b = block_sum(s_c, red), c = block_sum(s_w, red);
+    // gather the quad's three channel values into every lane of the quad
+    const float v0 = dppf<0x00>(v), v1 = dppf<0x55>(v), v2 = dppf<0xaa>(v);      // quad_perm broadcasts of lanes 0, 1, 2
+    const float sel[3] = {v0, v1, v2};
+    const float lum = tonemap_only ? sel[ch] : luma_of(0, v0, v1, v2);
+    const float lg = logf(lum + 1e-5f);
+    // pred = log(luma(end)) - log(luma(start)): quads 0 - 1 (fine) and 2 - 3 (coarse) of the 16-lane group
+    const float other = dppf<0x104>(lg);                                         // row_shl:4 -> lane l reads lane l + 4
+    const float pred = lg - other;
+    const float bii = __fadd_rn(__fmul_rn(thr_neg, cn), __fmul_rn(thr_pos, cp));   // run_nerf.py:518-519
+    const float cw[3] = {cw0, cw1, cw2};
+    const float w = (cmask && has_cw) ? cw[ch] : 1.f;
+    const float d = pred - bii;
+    float s_f = 0.f, s_c = 0.f, s_w = 0.f;
+    if (on && sub == 0) { s_f = d * d * w; s_w = w; }
+    if (on && sub == 8 && have0) s_c = d * d * w;
+    const float a = block_sum(s_f, red), b = block_sum(s_c, red), cc = block_sum(s_w, red);
     if (threadIdx.x == 0) {
         atomicAdd(partial + 0, a);
         atomicAdd(partial + 1, b);
-        atomicAdd(partial + 2, c);
+        atomicAdd(partial + 2, cc);
     }
 }
 
@@ -325,7 +334,7 @@ int evd_event_loss_reduce(const evd_crf* crf_ev, int skip_learn, int add_bii_fea
     EVD_REQUIRE(add_bii_feat != 2 || color_mask, "evd_event_loss_reduce: color-pos-neg features need the colour mask");
     if (N == 0) return EVD_OK;
     const float c0 = color_weight ? color_weight[0] : 1.f, c1 = color_weight ? color_weight[1] : 1.f, c2 = color_weight ? color_weight[2] : 1.f;
-    k_event_loss<<<cdiv(N, 256), 256, 0, as_stream(stream)>>>(crf_ev->p, skip_learn, add_bii_feat, tonemap_only, start, end, start0, end0,
+    k_event_loss<<<cdiv(N, 16), 256, 0, as_stream(stream)>>>(crf_ev->p, skip_learn, add_bii_feat, tonemap_only, start, end, start0, end0,
                                                               cum_neg, cum_pos, thr_neg, thr_pos, color_mask, c0, c1, c2,
                                                               color_weight != nullptr, N, partial);
     EVD_LAUNCH_CHECK();
