@@ -180,7 +180,8 @@ static int voxel_pass(const evd_voxel* v, int precision, const float* pts, const
     p.pts = pts; p.viewdirs = viewdirs; p.fts = fts; p.nsamp = R * (long)S; p.S = S; p.vd_stride = vd_stride; p.ft_stride = ft_stride;
     p.nchunks = piped ? v->pipe_chunks[precision] : v->nchunks[precision]; p.nbias = (int)(v->bias.bytes / sizeof(float)); p.raw = raw; p.feature = feature;
     int rc = piped ? (precision == EVD_PREC_BF16 ? launch_voxel_pipe_bf16(feature != nullptr, p, as_stream(stream))
-                                                 : launch_voxel_pipe_f16(feature != nullptr, p, as_stream(stream)))
+                      : precision == EVD_PREC_F16 ? launch_voxel_pipe_f16(feature != nullptr, p, as_stream(stream))
+                                                  : launch_voxel_pipe_f16x3(feature != nullptr, p, as_stream(stream)))
                    : voxel_mlp_dispatch(precision, v->hidden_dim, v->geo, v->ft_dim, p, as_stream(stream));
     if (rc) return rc;
     const float thr = (!is_train && v->rmnear > 0.f) ? (float)((double)v->rmnear / 128.0) : 0.f;

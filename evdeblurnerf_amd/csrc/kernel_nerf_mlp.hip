@@ -149,6 +149,7 @@ int nerf_mlp_pipe_dispatch(int prec, const MlpParams& p, hipStream_t st) {
     const bool feat = p.feature != nullptr;
     if (prec == EVD_PREC_BF16) return launch_nerf_pipe_bf16(feat, p, st);
     if (prec == EVD_PREC_F16) return launch_nerf_pipe_f16(feat, p, st);
+    if (prec == EVD_PREC_F16X3) return launch_nerf_pipe_f16x3(feat, p, st);
     return fail(EVD_E_INVALID, "evd_nerf_mlp: no pipelined kernel for precision %d", prec);
 }
 

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(NT, NT / 256) void k_nerf_mlp(const MlpParams p) {
 
 // chunks of the packed stream the kernel <PREC, W, D, SKIP> expects (checked against the packer's count)
 template <int PREC, int W, int D, int SKIP> constexpr int nerf_pipe_chunks() {
-    return NerfNet<PipeCfg<PREC, 1, 512>, W, D, SKIP, false>::NCH;
+    return NerfNet<PipeCfg<PREC, 1, 256>, W, D, SKIP, false>::NCH;
 }
 
 template <int PREC, int W, int D, int SKIP, int NS, int NT, bool FEAT>
@@ -233,9 +233,10 @@ static int launch_pipe_mlp(const MlpParams& p, hipStream_t st) {
 
 // pipelined kernels are built for these static networks; everything else runs on the generic kernel (kernel_nerf_mlp.hip)
 constexpr bool nerf_pipe_built(int prec, int W, int D, int skip) {
-    return (prec == EVD_PREC_BF16 || prec == EVD_PREC_F16) && W == 256 && D == 8 && skip == 4;
+    return (prec == EVD_PREC_BF16 || prec == EVD_PREC_F16 || prec == EVD_PREC_F16X3) && W == 256 && D == 8 && skip == 4;
 }
 int launch_nerf_pipe_bf16(bool feat, const MlpParams& p, hipStream_t st);
 int launch_nerf_pipe_f16(bool feat, const MlpParams& p, hipStream_t st);
+int launch_nerf_pipe_f16x3(bool feat, const MlpParams& p, hipStream_t st);
 
 }  // namespace evd

@@ -127,25 +127,27 @@ __global__ __launch_bounds__(NT, NT / 256) void k_voxel_mlp_pipe(const VoxMlpPar
 
 template <int PREC, bool FEAT>
 static int launch_voxel_pipe(const VoxMlpParams& p, hipStream_t st) {
-    typedef PipeCfg<PREC, 1, 512> C;
+    constexpr int NT = is_half_prec(PREC) ? 512 : 256;      // two wavefronts per SIMD where the B fragments are 4 registers
+    typedef PipeCfg<PREC, 1, NT> C;
     typedef VoxFineNet<C, FEAT> N;
     const long blocks = cdiv(p.nsamp, C::SAMPLES);
     const size_t lds = C::TOTAL;
     static bool attr_set = false;
     if (!attr_set) {
-        EVD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_voxel_mlp_pipe<PREC, 1, 512, FEAT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        EVD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_voxel_mlp_pipe<PREC, 1, NT, FEAT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     if (p.nchunks != N::NCH) return fail(EVD_E_INVALID, "evd_voxel: packed stream has %d chunks, kernel expects %d", p.nchunks, N::NCH);
-    hipLaunchKernelGGL((k_voxel_mlp_pipe<PREC, 1, 512, FEAT>), dim3((unsigned)blocks), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((k_voxel_mlp_pipe<PREC, 1, NT, FEAT>), dim3((unsigned)blocks), dim3(NT), lds, st, p);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }
 
 constexpr bool voxel_pipe_built(int prec, int HD, int G, int FT) {
-    return (prec == EVD_PREC_BF16 || prec == EVD_PREC_F16) && HD == 256 && G == 128 && FT == 64;
+    return (prec == EVD_PREC_BF16 || prec == EVD_PREC_F16 || prec == EVD_PREC_F16X3) && HD == 256 && G == 128 && FT == 64;
 }
 int launch_voxel_pipe_bf16(bool feat, const VoxMlpParams& p, hipStream_t st);
 int launch_voxel_pipe_f16(bool feat, const VoxMlpParams& p, hipStream_t st);
+int launch_voxel_pipe_f16x3(bool feat, const VoxMlpParams& p, hipStream_t st);
 
 }  // namespace evd

@@ -342,6 +342,16 @@ def test_weighted_sum_and_crf_and_losses(O):
         assert rel(egm, g[f"{cfg}_egm"]) < 2e-5
         total = float(loss) + float(egm) * w_egm
         assert abs(total - float(g[f"{cfg}_total"])) < 1e-5 * max(1.0, float(g[f"{cfg}_total"]))
+    # ragged event counts (the kernel packs 16 events per block): partial sums are additive over any split of the batch
+    rs = np.random.RandomState(6)
+    ev = lambda n: T(rs.rand(n, 3).astype(np.float32) * 0.9 + 0.05)
+    es, ee, es0, ee0 = ev(37), ev(37), ev(37), ev(37)
+    cn, cp = T(-rs.randint(0, 4, 37).astype(np.float32)), T(rs.randint(0, 4, 37).astype(np.float32))
+    full = N(event_loss_partials(crf_ev, es, ee, cn, cp, 0.2, 0.2, start0=es0, end0=ee0))
+    parts = np.zeros_like(full)
+    for lo, hi in ((0, 1), (1, 18), (18, 37)):
+        parts += N(event_loss_partials(crf_ev, es[lo:hi], ee[lo:hi], cn[lo:hi], cp[lo:hi], 0.2, 0.2, start0=es0[lo:hi], end0=ee0[lo:hi]))
+    assert np.allclose(full, parts, rtol=1e-5, atol=1e-6) and full[2] == 37.0
     # linearity of the sub-exposure reduction (size-independent property, config-3 shape: 1024 px x P=10)
     rs = np.random.RandomState(5)
     xa, xb = T(rs.rand(10240, 3).astype(np.float32)), T(rs.rand(10240, 3).astype(np.float32))
