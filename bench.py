@@ -167,14 +167,23 @@ def main():
                 traffic, busy = pmc["traffic_bytes"], pmc["mfma_busy_frac"]
         except (OSError, KeyError, ValueError):
             pass
+        # what the matrix pipe sustains on this chip today (power-limited clock): bare MFMA loop, constant vs random operands
+        sustained = {}
+        for name, rnd in (("constant_operands", 0), ("random_operands", 1)):
+            tfv = C.c_double()
+            L.check(L.lib().evd_probe_mfma_rate(rnd, 2000, C.byref(tfv), L.stream_ptr()))
+            sustained[name] = tfv.value
         result["roofline"] = {"bound": "mfma", "achieved": m["achieved"], "peak": m["peak"], "unit": "TFLOP/s",
                               "frac": m["frac"], "traffic": traffic, "kernel": "k_nerf_mlp", "kernel_ms": m["ms"],
                               "algorithmic_flop": R * S * FLOP_PER_SAMPLE, "algorithmic_hbm_bytes": R * S * 20 + R * 44,
                               "mfma_busy_frac_pmc": busy,
+                              "sustained_mfma_tflops": sustained, "frac_of_sustained_random": m["achieved"] / sustained["random_operands"],
                               "note": "achieved = algorithmic GEMM flops (1 186 816/sample) / HIP-event launch duration, against the 2.4 GHz "
                                       "dense peak; traffic (bytes per launch) and mfma_busy_frac_pmc (SQ_VALU_MFMA_BUSY_CYCLES over "
                                       "GRBM_GUI_ACTIVE x SIMDs: the kernel keeps the pipe busier than frac says because the chip clocks "
-                                      "below 2.4 GHz under this load) are from the PMC passes in profiles/r01_v3_pmc_mlp.json"}
+                                      "below 2.4 GHz under this load) are from the PMC passes in profiles/r01_v3_pmc_mlp.json; "
+                                      "sustained_mfma_tflops = a bare back-to-back MFMA loop on every SIMD, measured in this run "
+                                      "(evd_probe_mfma_rate): the random-operand figure is the practical ceiling for real data"}
         result["modes"] = modes
         # ---- parity of the headline arithmetic on THIS workload: RGB L-inf against the exact-float32 kernel
         with torch.no_grad():

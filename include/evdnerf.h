@@ -238,6 +238,12 @@ int evd_edi_deblur(const float* blurry, const float* bii, int steps, long npix, 
 int evd_edi_bii_image(const float* x, const float* y, const signed char* p, long n, int w, int h,
                       float c_pos, float c_neg, float* image, void* stream);
 
+/* ---------------------------------------------------------------- measurement aid (no reference counterpart)
+ * Sustained rate of back-to-back v_mfma_f32_32x32x16_bf16 issue on every SIMD of the current device, in dense
+ * TFLOP/s, with constant (random_operands == 0) or random operands.  The chip clocks to its power budget, so the
+ * second is the practical ceiling of any bf16/f16 MFMA kernel working on real data.  Synchronises the stream. */
+int evd_probe_mfma_rate(int random_operands, int iters, double* tflops, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

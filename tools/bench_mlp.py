@@ -24,9 +24,13 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--precs", default="f32,f16x3,bf16,f16")
+    ap.add_argument("--zero", action="store_true", help="all-zero weights and rays: same instruction stream, minimal switching power (DVFS evidence)")
     a = ap.parse_args()
     R, S = a.rays, a.samples
-    net = NeRF(W.make_nerf_state_dict(21))
+    sd = W.make_nerf_state_dict(21)
+    if a.zero:
+        sd = {k: np.zeros_like(v) for k, v in sd.items()}
+    net = NeRF(sd)
     rs = np.random.RandomState(0)
     rb = np.zeros((R, 11), np.float32)
     rb[:, :3] = rs.uniform(-1, 1, (R, 3))
@@ -34,6 +38,8 @@ def main():
     rb[:, 7] = 1
     vd = rs.standard_normal((R, 3))
     rb[:, 8:] = vd / np.linalg.norm(vd, axis=-1, keepdims=True)
+    if a.zero:
+        rb[:] = 0
     rb = torch.as_tensor(rb, device="cuda")
     z = torch.linspace(0, 1, S, device="cuda").expand(R, S).contiguous()
     ref = None

@@ -50,11 +50,28 @@ void run(int threads, const bf16x8* a, const bf16x8* b, float* out, long long* c
 int main() {
     bf16x8 *a, *b; float* out; long long* cyc;
     hipMalloc(&a, 64 * 16); hipMalloc(&b, 64 * 16); hipMalloc(&out, 256 * 512 * 4); hipMalloc(&cyc, 8);
-    hipMemset(a, 0x3c, 64 * 16); hipMemset(b, 0x3c, 64 * 16);
-    for (int threads : {256, 512}) {
-        run<1>(threads, a, b, out, cyc);
-        run<2>(threads, a, b, out, cyc);
-        run<4>(threads, a, b, out, cyc);
+    // pass 0: constant operands (minimal switching power); pass 1: random bf16 operands in (-1, 1) -- the chip clocks
+    // to its power budget, so the SAME loop is slower on random data (MI355X_MICROARCH.md, DVFS give-back)
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 0) { hipMemset(a, 0x3c, 64 * 16); hipMemset(b, 0x3c, 64 * 16); printf("-- constant operands\n"); }
+        else {
+            unsigned short h[2][512];
+            unsigned s = 12345u;
+            for (int k = 0; k < 2; ++k)
+                for (int i = 0; i < 512; ++i) {
+                    s = s * 1664525u + 1013904223u;
+                    const float f = ((s >> 8) & 0xffff) / 32768.0f - 1.0f;
+                    unsigned u; __builtin_memcpy(&u, &f, 4);
+                    h[k][i] = (unsigned short)(u >> 16);
+                }
+            hipMemcpy(a, h[0], 1024, hipMemcpyHostToDevice); hipMemcpy(b, h[1], 1024, hipMemcpyHostToDevice);
+            printf("-- random operands\n");
+        }
+        for (int threads : {256, 512}) {
+            run<1>(threads, a, b, out, cyc);
+            run<2>(threads, a, b, out, cyc);
+            run<4>(threads, a, b, out, cyc);
+        }
     }
     return 0;
 }
