@@ -58,7 +58,7 @@ def make_model(precision):
     return NeRFAll(args, sd, precision=precision).eval(), sd
 
 
-def time_steps(fn, steps, warmup, barrier):
+def time_steps(fn, steps, warmup, barrier, drain=None):
     for _ in range(warmup):
         fn()
     barrier()
@@ -66,6 +66,8 @@ def time_steps(fn, steps, warmup, barrier):
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
+    if drain:
+        drain()
     barrier()
     torch.cuda.synchronize()
     return time.perf_counter() - t0
@@ -92,12 +94,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP library has no CPU fallback)")
-    torch.cuda.set_device(local)
+    # EVD_BENCH_SHARE_GPU=1 (validation of the N > 1 code path on a 1-GPU box only): every rank on device 0, gloo collectives
+    share = os.environ.get("EVD_BENCH_SHARE_GPU") == "1"
+    torch.cuda.set_device(0 if share else local)
     dist = None
     if world > 1:
         import torch.distributed as dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_.init_process_group("nccl", rank=rank, world_size=world)
+        dist_.init_process_group("gloo" if share else "nccl", rank=rank, world_size=world)
         dist = dist_
     barrier = (lambda: dist.barrier()) if dist else (lambda: None)
 
@@ -114,14 +118,20 @@ def main():
     model, sd = make_model(a.precision)
     kw = dict(ndc=True, near=0., far=1., use_viewdirs=True, N_samples=S, N_importance=0, retraw=False)
 
+    pending = []
+
     def step():
         rgb, depth, acc, _ = model.render(400, 400, K, rays=rays, **kw)
         if dist:   # the path's one exchange: packed loss partials (evdeblurnerf_amd/dist.py)
             p, _ = blur_loss_partials(crf, rgb, ones, target)
-            dist.all_reduce(p)
+            # the reduced loss is a logging value, nothing in the next step consumes it: the all-reduce (RCCL's own stream)
+            # overlaps the next step's render and is waited for one step later (and after the last step, inside the timed region)
+            if pending:
+                pending.pop().wait()
+            pending.append(dist.all_reduce(p, async_op=True))
         return rgb
 
-    dt = time_steps(step, a.steps, a.warmup, barrier)
+    dt = time_steps(step, a.steps, a.warmup, barrier, drain=lambda: [w.wait() for w in pending])
     if dist:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
