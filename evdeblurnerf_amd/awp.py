@@ -1,0 +1,25 @@
+"""The compositing scan of the AWP consumer (reference ``networks/dpnerf/awp.py``): the one piece of
+``AdaptiveWeightProposal`` that is a scan over the path's per-sample outputs.  The rest of AWP (sample / motion embedding
+MLPs, MotionAggregationModule) stays PyTorch in the reference's caller."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+
+
+def feature_integration(feat, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=False):
+    """awp.py:49-77: feat [N_rays, N_motion, N_samples, C], z_vals [N_rays*N_motion, N_samples], rays_d [N_rays*N_motion, 3]
+    -> [N_rays, N_motion, C].  Restated as written in the reference: every channel is its own density, the last alpha is 0,
+    and the cumprod of awp.py:69-73 runs along the channel axis (dim -1) of the previous sample's row."""
+    n_rays, n_motion, S, Cc = feat.shape
+    f = feat.reshape(-1, S, Cc).contiguous().float()
+    z = z_vals.reshape(-1, S).contiguous().float()
+    d = rays_d.reshape(-1, 3).contiguous().float()
+    N = f.shape[0]
+    if z.shape[0] != N or d.shape[0] != N:
+        raise L.EvdError("feature_integration: z_vals / rays_d need one row per (ray, motion)")
+    out = torch.empty((N, Cc), dtype=torch.float32, device=f.device)
+    L.check(L.lib().evd_awp_feature_integration(L.ptr(f), L.ptr(z), L.ptr(d), N, S, Cc, L.ptr(out), L.stream_ptr()),
+            "evd_awp_feature_integration")
+    return out.reshape(n_rays, n_motion, Cc)

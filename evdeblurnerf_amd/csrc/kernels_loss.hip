@@ -1,6 +1,8 @@
 // Loss-side pixel ops: sub-exposure weighted sums, camera response functions, fused blur / event loss
 // reductions, EDI prior.  All HBM-bound and tiny; the point of fusing them is one launch + one packed
 // partial-sum vector per step (which is what the ranks all-reduce) instead of dozens of ATen launches.
+#include <type_traits>
+
 #include "evd_common.h"
 
 namespace evd {
@@ -217,6 +219,74 @@ __global__ __launch_bounds__(256) void k_event_loss(const CrfParams crf, int ski
     }
 }
 
+// AdaptiveWeightProposal.feature_integration (networks/dpnerf/awp.py:49-77), the AWP consumer's compositing scan, AS WRITTEN
+// in the reference: the cumprod of :69-73 runs along the CHANNEL axis of the previous sample's row,
+//   Q[0, c] = 1,  Q[s, c] = prod_{c' <= c} (1 - alpha[s-1, c'] + 1e-10),  out[c] = sum_s alpha[s, c] Q[s, c] feat[s, c].
+// HBM-bound (reads N x S x C floats once): a wavefront owns one ray, a lane CPL consecutive channels; per sample one
+// inclusive product scan over the lanes (DPP) of the previous row's (1 - alpha); 4 sample rows of loads in flight.
+__device__ __forceinline__ float awp_scan_mul(float v) {
+    auto dpp = [](float old, float src, auto ctrl, auto rmask) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src),
+                                                                     decltype(ctrl)::value, decltype(rmask)::value, 0xf, false));
+    };
+    typedef std::integral_constant<int, 0xf> All;
+    v *= dpp(1.f, v, std::integral_constant<int, 0x111>(), All());
+    v *= dpp(1.f, v, std::integral_constant<int, 0x112>(), All());
+    v *= dpp(1.f, v, std::integral_constant<int, 0x114>(), All());
+    v *= dpp(1.f, v, std::integral_constant<int, 0x118>(), All());
+    v *= dpp(1.f, v, std::integral_constant<int, 0x142>(), std::integral_constant<int, 0xa>());
+    v *= dpp(1.f, v, std::integral_constant<int, 0x143>(), std::integral_constant<int, 0xc>());
+    return v;
+}
+
+template <int CPL>
+__global__ __launch_bounds__(256) void k_awp_integrate(const float* __restrict__ feat, const float* __restrict__ z,
+                                                       const float* __restrict__ rays_d, long N, int S, int C, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long n = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float* d = rays_d + n * 3;
+    const float norm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
+    const float* fr = feat + n * (long)S * C;
+    const float* zz = z + n * (long)S;
+    float acc[CPL], Q[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) { acc[q] = 0.f; Q[q] = 1.f; }
+    constexpr int UN = 4;
+    for (int s0 = 0; s0 < S; s0 += UN) {
+        float f[UN][CPL], dist[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int s = min(s0 + u, S - 1);
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) { const int c = lane * CPL + q; f[u][q] = c < C ? fr[(long)s * C + c] : 0.f; }
+            dist[u] = s < S - 1 ? __fmul_rn(__fsub_rn(zz[s + 1], zz[s]), norm) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int s = s0 + u;
+            if (s < S) {
+                float om[CPL], local = 1.f;
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) {
+                    const int c = lane * CPL + q;
+                    const float alpha = s < S - 1 ? __fadd_rn(-expf(-__fmul_rn(f[u][q], dist[u])), 1.f) : 0.f;   // awp.py:66-67
+                    acc[q] = __fadd_rn(acc[q], __fmul_rn(__fmul_rn(alpha, Q[q]), f[u][q]));
+                    om[q] = c < C ? __fadd_rn(-alpha, 1.f + 1e-10f) : 1.f;
+                    local *= om[q];
+                }
+                // Q of the NEXT sample row: inclusive product over the channels of this row's (1 - alpha)
+                const float incl = awp_scan_mul(local);
+                float excl = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, 1.f), __builtin_bit_cast(int, incl), 0x138, 0xf, 0xf, false));
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) { excl *= om[q]; Q[q] = excl; }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) { const int c = lane * CPL + q; if (c < C) out[n * C + c] = acc[q]; }
+}
+
 // utils/edi.py:73-95: E_k = -sum_{j=k}^{N-1} bii_j (k<N), 0 (k=N), +sum_{j=N}^{k-1} bii_j (k>N); sharp = (2N+1) blurry / sum exp(E_k)
 __global__ void k_edi_deblur(const float* __restrict__ blurry, const float* __restrict__ bii, int steps, long npix,
                              float* __restrict__ sharp) {
@@ -337,6 +407,18 @@ int evd_event_loss_reduce(const evd_crf* crf_ev, int skip_learn, int add_bii_fea
     k_event_loss<<<cdiv(N, 16), 256, 0, as_stream(stream)>>>(crf_ev->p, skip_learn, add_bii_feat, tonemap_only, start, end, start0, end0,
                                                               cum_neg, cum_pos, thr_neg, thr_pos, color_mask, c0, c1, c2,
                                                               color_weight != nullptr, N, partial);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+int evd_awp_feature_integration(const float* feat, const float* z, const float* rays_d, long N, int S, int C, float* out, void* stream) {
+    EVD_REQUIRE(feat && z && rays_d && out && N >= 0 && S >= 1 && C >= 1, "evd_awp_feature_integration: bad arguments");
+    EVD_REQUIRE(C <= 256, "evd_awp_feature_integration: %d channels (built: <= 256)", C);
+    if (N == 0) return EVD_OK;
+    hipStream_t st = as_stream(stream);
+    if (C <= 64) k_awp_integrate<1><<<cdiv(N, 4), 256, 0, st>>>(feat, z, rays_d, N, S, C, out);
+    else if (C <= 128) k_awp_integrate<2><<<cdiv(N, 4), 256, 0, st>>>(feat, z, rays_d, N, S, C, out);
+    else k_awp_integrate<4><<<cdiv(N, 4), 256, 0, st>>>(feat, z, rays_d, N, S, C, out);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }

@@ -231,6 +231,12 @@ int evd_event_loss_reduce(const evd_crf* crf_ev, int skip_learn, int add_bii_fea
                           const unsigned char* color_mask, const float* color_weight, long N,
                           float* partial, void* stream);
 
+/* AdaptiveWeightProposal.feature_integration, networks/dpnerf/awp.py:49-77 (the compositing scan of the AWP consumer of
+ * the path's per-sample features): feat dev [N,S,C] (N = rays x sub-exposures; every channel is its own density),
+ * z dev [N,S], rays_d dev [N,3] -> out dev [N,C].  Restated as written: the last sample gets alpha 0 (awp.py:67) and the
+ * cumprod of awp.py:69-73 runs along the channel axis of the previous sample's row. */
+int evd_awp_feature_integration(const float* feat, const float* z, const float* rays_d, long N, int S, int C, float* out, void* stream);
+
 /* EDI prior (utils/edi.py:73-95): bii dev [steps-1, npix], blurry dev [npix] -> sharp dev [npix] */
 int evd_edi_deblur(const float* blurry, const float* bii, int steps, long npix, float* sharp, void* stream);
 /* brightness_increment_image with bilinear sub-pixel splat (utils/edi.py:7-70, grey events):

@@ -905,3 +905,32 @@ double evo_tv_loss(const float* x, int C, int H, int W) {
     if (count_w < 1) count_w = 1;
     return 2.0 * (h_tv / count_h + w_tv / count_w);
 }
+
+/* ------------------------------------------------------------------ AWP feature integration
+ * networks/dpnerf/awp.py:49-77, restated AS WRITTEN: alpha = 1 - exp(-feat * dist) on the first S-1 samples (:65-66), a
+ * ZERO alpha appended for the last one (:67); the "transmittance" is torch.cumprod(cat([ones, 1 - alpha + 1e-10], -2), -1)
+ * [:, :-1, :] (:69-73) -- a cumulative product along the CHANNEL axis (dim -1) of the previous sample's row, not along the
+ * samples:  Q[0, c] = 1,  Q[s, c] = prod_{c' <= c} (1 - alpha[s-1, c'] + 1e-10);  out[c] = sum_s alpha[s, c] Q[s, c] feat[s, c]. */
+void evo_awp_feature_integration(const float* feat, const float* z, const float* rays_d, long N, int S, int C, float* out) {
+#pragma omp parallel for schedule(static)
+    for (long n = 0; n < N; ++n) {
+        const float* d = rays_d + n * 3;
+        const float norm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        float* o = out + n * C;
+        for (int c = 0; c < C; ++c) o[c] = 0.f;
+        for (int s = 0; s < S; ++s) {
+            float q = 1.f;
+            for (int c = 0; c < C; ++c) {
+                const float f = feat[((size_t)n * S + s) * C + c];
+                float alpha = 0.f;
+                if (s < S - 1) alpha = -expf(-f * ((z[n * S + s + 1] - z[n * S + s]) * norm)) + 1.f;
+                if (s > 0) {
+                    const float fp = feat[((size_t)n * S + s - 1) * C + c];
+                    const float ap = -expf(-fp * ((z[n * S + s] - z[n * S + s - 1]) * norm)) + 1.f;   /* s-1 < S-1 always */
+                    q *= (-ap + (1.f + 1e-10f));
+                }
+                o[c] += (alpha * q) * f;
+            }
+        }
+    }
+}

@@ -306,6 +306,16 @@ def weighted_sum(x, ccw):
     return out.reshape((R,) + tuple(x.shape[1:]))
 
 
+def awp_feature_integration(feat, z, rays_d):
+    """feat [N,S,C] (or [R,P,S,C]), z [N,S], rays_d [N,3] -> [N,C] (awp.py:49-77)"""
+    feat, z, rays_d = _f(feat), _f(z), _f(rays_d)
+    S, Cc = feat.shape[-2], feat.shape[-1]
+    N = z.shape[0]
+    out = np.empty((N, Cc), np.float32)
+    lib().evo_awp_feature_integration(_p(feat), _p(z), _p(rays_d), C.c_long(N), S, Cc, _p(out))
+    return out
+
+
 def crf_forward(crf: Crf, x, feat=None, skip_learn=False):
     x = _f(x)
     n = x.shape[0]

@@ -468,3 +468,27 @@ def test_c2f_render_matches_reference_golden(prec, tol, O):
         O.lib().evo_voxel_forward(C.byref(vf.s), fpp(pts), fpp(vd), fpp(fts), 64, fpp(z), fpp(rd), C.c_long(R), S, 10, 4, 0,
                                   fpp(oc), fpp(od), fpp(oa), fpp(ow), fpp(of))
         assert maxabs(N(col), oc) < 2e-5 and maxabs(N(wt), ow) < 2e-5 and maxabs(N(ft), of) < 5e-5
+
+
+def test_awp_feature_integration(O):
+    """The AWP consumer's compositing scan (awp.py:49-77) vs the reference golden G15 and, at the blurfactory shape
+    (10 240 rays x 128 samples x 64 channels), vs the oracle on a slice + ray-permutation equivariance."""
+    from evdeblurnerf_amd.awp import feature_integration
+    g = load_golden("G15_awp_feature_integration")
+    for tag in ("a", "b"):
+        out = feature_integration(T(g[f"{tag}_feat"]), T(g[f"{tag}_z"]), T(g[f"{tag}_rays_d"]))
+        assert maxabs(N(out), g[f"{tag}_out"]) < 2e-5 * max(1.0, np.abs(g[f"{tag}_out"]).max())
+    rs = np.random.RandomState(8)
+    R, P, S, Cc = 1024, 10, 128, 64
+    feat = T(np.abs(rs.standard_normal((R, P, S, Cc))).astype(np.float32))
+    z = T(np.sort(rs.uniform(0, 1, (R * P, S)).astype(np.float32), -1))
+    rd = T(rs.standard_normal((R * P, 3)).astype(np.float32))
+    out = N(feature_integration(feat, z, rd))
+    ref = O.awp_feature_integration(N(feat).reshape(-1, S, Cc)[:640], N(z)[:640], N(rd)[:640])
+    assert maxabs(out.reshape(-1, Cc)[:640], ref) < 1e-5
+    perm = torch.randperm(R * P, device=DEV)      # rays are independent: permutation equivariance at the full shape
+    out_p = feature_integration(feat.reshape(R * P, 1, S, Cc)[perm], z[perm], rd[perm])
+    assert torch.equal(out_p.reshape(-1, Cc), torch.as_tensor(out, device=DEV).reshape(-1, Cc)[perm])
+    wide = T(np.abs(rs.standard_normal((5, 2, 40, 128))).astype(np.float32))     # 128 channels: two per lane
+    zw, dw = T(np.sort(rs.uniform(0, 1, (10, 40)).astype(np.float32), -1)), T(rs.standard_normal((10, 3)).astype(np.float32))
+    assert maxabs(N(feature_integration(wide, zw, dw)).reshape(-1, 128), O.awp_feature_integration(N(wide).reshape(-1, 40, 128), N(zw), N(dw))) < 1e-5

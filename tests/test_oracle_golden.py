@@ -249,3 +249,12 @@ def test_G14_loss_assembly(cfg):
     assert abs(egm - float(g[f"{cfg}_egm"])) < 1e-5 * max(1.0, float(g[f"{cfg}_egm"]))
     total = loss + egm * w_egm
     assert abs(total - float(g[f"{cfg}_total"])) < 1e-5 * max(1.0, float(g[f"{cfg}_total"]))
+
+
+def test_G15_awp_feature_integration():
+    """G15: AdaptiveWeightProposal.feature_integration of the reference (awp.py:49-77)."""
+    g = load_golden("G15_awp_feature_integration")
+    for tag in ("a", "b"):
+        feat = g[f"{tag}_feat"]
+        out = O.awp_feature_integration(feat.reshape(-1, feat.shape[-2], feat.shape[-1]), g[f"{tag}_z"], g[f"{tag}_rays_d"])
+        assert maxabs(out.reshape(g[f"{tag}_out"].shape), g[f"{tag}_out"]) < 2e-5 * max(1.0, np.abs(g[f"{tag}_out"]).max())

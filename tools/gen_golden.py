@@ -531,9 +531,27 @@ def G14_loss_assembly():
     save("G14_loss_assembly", **out)
 
 
+def G15_awp_feature_integration():
+    """AdaptiveWeightProposal.feature_integration (networks/dpnerf/awp.py:49-77): per-channel compositing scan of the
+    per-sample embedded features (each channel is its own density; a ZERO alpha is appended, not a one)."""
+    from networks.dpnerf.awp import AdaptiveWeightProposal
+    awp = AdaptiveWeightProposal(input_ch=128, num_motion=9, D_sam=4, W_sam=64, D_mot=1, W_mot=32, dir_freq=2, rgb_freq=2,
+                                 depth_freq=3, ray_dir_freq=2, view_feature_ch=32)
+    rs = np.random.RandomState(151)
+    out = {}
+    for tag, (R, P, S, Cc) in {"a": (2, 3, 128, 64), "b": (3, 2, 33, 16)}.items():
+        feat = np.abs(rs.standard_normal((R, P, S, Cc))).astype(np.float32) * rs.choice([0.0, 0.5, 4.0, 60.0], size=(R, P, S, 1)).astype(np.float32)
+        z = np.sort(rs.uniform(0, 1, (R * P, S)).astype(np.float32), -1)
+        z[:, 5] = z[:, 4]                                   # a duplicate z (zero interval)
+        rays_d = rs.standard_normal((R * P, 3)).astype(np.float32)
+        res = awp.feature_integration(t(feat), t(z), t(rays_d))
+        out.update({f"{tag}_feat": feat, f"{tag}_z": z, f"{tag}_rays_d": rays_d, f"{tag}_out": n(res)})
+    save("G15_awp_feature_integration", **out)
+
+
 ALL = [G1_embedder, G2_nerf_mlp, G3_nerf_raw2outputs, G4_voxel_raw2outputs, G5_sample_pdf, G6_rays,
        G7_render_nerf, G8_appfeature, G9_render_c2f, G10_rbk_weighted_sum, G11_crf, G12_egm_loss, G13_edi,
-       G14_loss_assembly]
+       G14_loss_assembly, G15_awp_feature_integration]
 
 if __name__ == "__main__":
     want = set(sys.argv[1:])
