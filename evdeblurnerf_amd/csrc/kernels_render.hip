@@ -95,6 +95,68 @@ __global__ void k_ndc(float cw, float ch, float near, float two_near, const floa
     for (int c = 0; c < 3; ++c) { oo[i * 3 + c] = x[c]; od[i * 3 + c] = y[c]; }
 }
 
+// RigidBlurringModel.rbk_warp (networks/dpnerf/blurmodel.py:51-82; SE3Field.get_transform / warp, RigidBody.exp_se3 /
+// exp_so3 of utils/rigid_warping.py:18-49,72-107): one thread per (ray, sub-exposure slot).  The reference runs ~40 small
+// tensor ops per motion in a Python loop over the 9 motions.
+__global__ void k_rbk_warp(const float* __restrict__ rays, const float* __restrict__ r, const float* __restrict__ v, long R, int M,
+                           int use_origin, float* __restrict__ new_rays, float* __restrict__ transforms) {
+    const int P = M + (use_origin ? 1 : 0);
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (idx >= R * P) return;
+    const long n = idx / P;
+    const int slot = idx % P, i = slot - (use_origin ? 1 : 0);
+    float o[3], d[3], e[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { o[c] = rays[n * 6 + c * 2]; d[c] = rays[n * 6 + c * 2 + 1]; e[c] = __fadd_rn(o[c], d[c]); }
+    float T[16] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f};
+    float wo[3] = {o[0], o[1], o[2]}, wd[3] = {d[0], d[1], d[2]};
+    if (i >= 0) {
+        const float rot[3] = {r[(n * 3 + 0) * M + i], r[(n * 3 + 1) * M + i], r[(n * 3 + 2) * M + i]};
+        const float tr[3] = {v[(n * 3 + 0) * M + i], v[(n * 3 + 1) * M + i], v[(n * 3 + 2) * M + i]};
+        const float theta = __fadd_rn(sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(rot[0], rot[0]), __fmul_rn(rot[1], rot[1])), __fmul_rn(rot[2], rot[2]))), 1.0e-10f);
+        const float w[3] = {rot[0] / theta, rot[1] / theta, rot[2] / theta}, vv[3] = {tr[0] / theta, tr[1] / theta, tr[2] / theta};
+        const float Wm[9] = {0.f, -w[2], w[1], w[2], 0.f, -w[0], -w[1], w[0], 0.f};
+        float W2[9];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) acc = __fadd_rn(acc, __fmul_rn(Wm[a * 3 + k], Wm[k * 3 + b]));
+                W2[a * 3 + b] = acc;
+            }
+        const float st = sinf(theta), omc = __fsub_rn(1.0f, cosf(theta)), tms = __fsub_rn(theta, st);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float p = 0.f;
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const float eye = a == b ? 1.f : 0.f;
+                T[a * 4 + b] = __fadd_rn(__fadd_rn(eye, __fmul_rn(st, Wm[a * 3 + b])), __fmul_rn(omc, W2[a * 3 + b]));
+                const float g = __fadd_rn(__fadd_rn(__fmul_rn(theta, eye), __fmul_rn(omc, Wm[a * 3 + b])), __fmul_rn(tms, W2[a * 3 + b]));
+                p = __fadd_rn(p, __fmul_rn(g, vv[b]));
+            }
+            T[a * 4 + 3] = p;
+        }
+        float we[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            wo[a] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[a * 4], o[0]), __fmul_rn(T[a * 4 + 1], o[1])), __fmul_rn(T[a * 4 + 2], o[2])), T[a * 4 + 3]);
+            we[a] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T[a * 4], e[0]), __fmul_rn(T[a * 4 + 1], e[1])), __fmul_rn(T[a * 4 + 2], e[2])), T[a * 4 + 3]);
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) wd[a] = __fsub_rn(we[a], wo[a]);
+    }
+    float* out = new_rays + idx * 6;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { out[c * 2] = wo[c]; out[c * 2 + 1] = wd[c]; }
+    if (transforms) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) transforms[idx * 16 + k] = T[k];
+    }
+}
+
 // reference networks/renderer.py:423-446: rays [R,3,2] -> ray_batch [R,ncol]
 __global__ void k_ray_batch(const float* __restrict__ rays, long R, int ndc, int use_viewdirs, float cw, float ch,
                             float near, float far, float* __restrict__ rb) {
@@ -526,6 +588,16 @@ int evd_embed(const float* x, long n, int dim, int L, float* out, void* stream) 
     EVD_REQUIRE(n >= 0 && dim > 0 && L >= 0 && out, "evd_embed: bad arguments");
     if (n == 0) return EVD_OK;
     k_embed<<<cdiv(n * dim, 256), 256, 0, as_stream(stream)>>>(x, n, dim, L, out);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+int evd_rbk_warp(const float* rays, const float* r, const float* v, long R, int M, int use_origin, float* new_rays, float* transforms,
+                 void* stream) {
+    EVD_REQUIRE(R >= 0 && M >= 1 && (R == 0 || (rays && r && v && new_rays)), "evd_rbk_warp: bad arguments");
+    if (R == 0) return EVD_OK;
+    const long n = R * (long)(M + (use_origin ? 1 : 0));
+    k_rbk_warp<<<cdiv(n, 256), 256, 0, as_stream(stream)>>>(rays, r, v, R, M, use_origin, new_rays, transforms);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }

@@ -100,3 +100,16 @@ def sample_pdf(bins, weights, N_samples, det=False, pytest=False, u=None):
     w = torch.zeros((R, S), dtype=torch.float32, device=b.device)
     w[:, 1:-1] = weights
     return sample_pdf_merge(z, w, N_samples, det=det, u=u)[0]
+
+
+def rbk_warp(rays, r, v, num_motion, use_origin=True, return_transform=False):
+    """RigidBlurringModel.rbk_warp (networks/dpnerf/blurmodel.py:51-82): rays [R,3,2], r / v [R, 3*num_motion] (the r_linear /
+    v_linear outputs) -> new_rays [R, num_motion (+1), 3, 2] (and the [.., 4, 4] rigid transforms)."""
+    rr = rays.contiguous().float()
+    R = rr.shape[0]
+    P = num_motion + (1 if use_origin else 0)
+    out = torch.empty((R, P, 3, 2), dtype=torch.float32, device=rr.device)
+    tf = torch.empty((R, P, 4, 4), dtype=torch.float32, device=rr.device) if return_transform else None
+    L.check(L.lib().evd_rbk_warp(L.ptr(rr), L.ptr(r.contiguous().float()), L.ptr(v.contiguous().float()), R, int(num_motion), int(bool(use_origin)),
+                                 L.ptr(out), L.ptr(tf), L.stream_ptr()), "evd_rbk_warp")
+    return (out, tf) if return_transform else out

@@ -62,6 +62,12 @@ int evd_get_rays_pix(const float* coords, const float* K, const float* c2ws, lon
 /* get_ndc_rays, utils/rays.py:104-145 */
 int evd_ndc_rays(int H, int W, float focal, float near, const float* rays_o, const float* rays_d, long n,
                  float* out_o, float* out_d, void* stream);
+/* RigidBlurringModel.rbk_warp, networks/dpnerf/blurmodel.py:51-82 (SE3Field / RigidBody of utils/rigid_warping.py): the
+ * sub-exposure rays of the blur batch.  rays dev [R,3,2]; r, v dev [R,3,M] (the r_linear / v_linear outputs viewed as
+ * [R,3,M], blurmodel.py:52-53) -> new_rays dev [R, M + use_origin, 3, 2] (slot 0 = the input ray when use_origin),
+ * transforms dev [R, M + use_origin, 4, 4] or NULL. */
+int evd_rbk_warp(const float* rays, const float* r, const float* v, long R, int M, int use_origin, float* new_rays, float* transforms,
+                 void* stream);
 /* Embedder.forward, networks/embedding.py:88-98.  x dev [n,dim] -> out dev [n, dim*(1+2L)] */
 int evd_embed(const float* x, long n, int dim, int L, float* out, void* stream);
 

@@ -934,3 +934,63 @@ void evo_awp_feature_integration(const float* feat, const float* z, const float*
         }
     }
 }
+
+/* ------------------------------------------------------------------ RBK ray warp
+ * SE3Field.get_transform (rigid_warping.py:18-30): theta = |rot| + 1e-10, screw axis (rot, trans) / theta;
+ * RigidBody.exp_se3 (:72-91): R = I + sin(theta) W + (1 - cos(theta)) W^2 (Rodrigues, :93-107),
+ * p = (theta I + (1 - cos theta) W + (theta - sin theta) W^2) v;  warp (:32-49): homogeneous 4x4 product, divided by w.
+ * rbk_warp (blurmodel.py:51-82): motion i warps the ray origin and the end point o + d; slot 0 keeps the input ray
+ * when use_origin. */
+static void evo_se3(const float rot[3], const float trans[3], float T[16]) {
+    const float theta = sqrtf(rot[0] * rot[0] + rot[1] * rot[1] + rot[2] * rot[2]) + 1.0e-10f;
+    const float w[3] = {rot[0] / theta, rot[1] / theta, rot[2] / theta}, vv[3] = {trans[0] / theta, trans[1] / theta, trans[2] / theta};
+    const float Wm[9] = {0.f, -w[2], w[1], w[2], 0.f, -w[0], -w[1], w[0], 0.f};
+    float W2[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            float s = 0.f;
+            for (int k = 0; k < 3; ++k) s += Wm[i * 3 + k] * Wm[k * 3 + j];
+            W2[i * 3 + j] = s;
+        }
+    const float st = sinf(theta), omc = 1.0f - cosf(theta), tms = theta - st;
+    for (int i = 0; i < 3; ++i) {
+        float p = 0.f;
+        for (int j = 0; j < 3; ++j) {
+            const float eye = i == j ? 1.f : 0.f;
+            T[i * 4 + j] = eye + st * Wm[i * 3 + j] + omc * W2[i * 3 + j];
+            p += (theta * eye + omc * Wm[i * 3 + j] + tms * W2[i * 3 + j]) * vv[j];
+        }
+        T[i * 4 + 3] = p;
+    }
+    T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
+}
+
+static void evo_apply(const float T[16], const float x[3], float y[3]) {
+    float h[4];
+    for (int i = 0; i < 4; ++i) h[i] = T[i * 4] * x[0] + T[i * 4 + 1] * x[1] + T[i * 4 + 2] * x[2] + T[i * 4 + 3] * 1.f;
+    for (int i = 0; i < 3; ++i) y[i] = h[i] / h[3];
+}
+
+void evo_rbk_warp(const float* rays, const float* r, const float* v, long R, int M, int use_origin, float* new_rays, float* transforms) {
+    const int P = M + (use_origin ? 1 : 0);
+#pragma omp parallel for schedule(static)
+    for (long n = 0; n < R; ++n) {
+        float o[3], d[3], e[3];
+        for (int c = 0; c < 3; ++c) { o[c] = rays[n * 6 + c * 2]; d[c] = rays[n * 6 + c * 2 + 1]; e[c] = o[c] + d[c]; }
+        if (use_origin) {
+            for (int c = 0; c < 3; ++c) { new_rays[(n * P) * 6 + c * 2] = o[c]; new_rays[(n * P) * 6 + c * 2 + 1] = d[c]; }
+            if (transforms) for (int k = 0; k < 16; ++k) transforms[(n * P) * 16 + k] = (k % 5 == 0) ? 1.f : 0.f;
+        }
+        for (int i = 0; i < M; ++i) {
+            const float rot[3] = {r[(n * 3 + 0) * M + i], r[(n * 3 + 1) * M + i], r[(n * 3 + 2) * M + i]};
+            const float tr[3] = {v[(n * 3 + 0) * M + i], v[(n * 3 + 1) * M + i], v[(n * 3 + 2) * M + i]};
+            float T[16], wo[3], we[3];
+            evo_se3(rot, tr, T);
+            evo_apply(T, o, wo);
+            evo_apply(T, e, we);
+            const long slot = n * P + i + (use_origin ? 1 : 0);
+            for (int c = 0; c < 3; ++c) { new_rays[slot * 6 + c * 2] = wo[c]; new_rays[slot * 6 + c * 2 + 1] = we[c] - wo[c]; }
+            if (transforms) for (int k = 0; k < 16; ++k) transforms[slot * 16 + k] = T[k];
+        }
+    }
+}

@@ -306,6 +306,17 @@ def weighted_sum(x, ccw):
     return out.reshape((R,) + tuple(x.shape[1:]))
 
 
+def rbk_warp(rays, r, v, num_motion, use_origin=True, want_transform=False):
+    """blurmodel.py:51-82: rays [R,3,2], r/v [R, 3*M] -> new_rays [R, M(+1), 3, 2] (, transforms [R, M(+1), 4, 4])"""
+    rays, r, v = _f(rays), _f(r), _f(v)
+    R = rays.shape[0]
+    P = num_motion + (1 if use_origin else 0)
+    out = np.empty((R, P, 3, 2), np.float32)
+    tf = np.empty((R, P, 4, 4), np.float32) if want_transform else None
+    lib().evo_rbk_warp(_p(rays), _p(r), _p(v), C.c_long(R), num_motion, int(use_origin), _p(out), _p(tf) if tf is not None else None)
+    return (out, tf) if want_transform else out
+
+
 def awp_feature_integration(feat, z, rays_d):
     """feat [N,S,C] (or [R,P,S,C]), z [N,S], rays_d [N,3] -> [N,C] (awp.py:49-77)"""
     feat, z, rays_d = _f(feat), _f(z), _f(rays_d)

@@ -492,3 +492,22 @@ def test_awp_feature_integration(O):
     wide = T(np.abs(rs.standard_normal((5, 2, 40, 128))).astype(np.float32))     # 128 channels: two per lane
     zw, dw = T(np.sort(rs.uniform(0, 1, (10, 40)).astype(np.float32), -1)), T(rs.standard_normal((10, 3)).astype(np.float32))
     assert maxabs(N(feature_integration(wide, zw, dw)).reshape(-1, 128), O.awp_feature_integration(N(wide).reshape(-1, 40, 128), N(zw), N(dw))) < 1e-5
+
+
+def test_rbk_warp(O):
+    """Sub-exposure ray warp (blurmodel.py:51-82) vs the reference golden G16 and, at the blur-batch shape (1024 px x 9
+    motions), vs the oracle; rigid transforms are orthonormal (size-independent property)."""
+    from evdeblurnerf_amd.rays import rbk_warp
+    g = load_golden("G16_rbk_warp")
+    for tag, M, uo in (("a", 9, True), ("b", 4, False), ("c", 9, True)):
+        new_rays, tf = rbk_warp(T(g[f"{tag}_rays"]), T(g[f"{tag}_r"]), T(g[f"{tag}_v"]), M, uo, return_transform=True)
+        assert maxabs(N(new_rays), g[f"{tag}_new_rays"]) < 5e-6, tag
+        assert maxabs(N(tf), g[f"{tag}_transform"]) < 5e-6, tag
+    rs = np.random.RandomState(9)
+    rays = W.synthetic_rays(77, 1024)
+    r, v = (rs.standard_normal((1024, 27)) * 0.05).astype(np.float32), (rs.standard_normal((1024, 27)) * 0.05).astype(np.float32)
+    new_rays, tf = rbk_warp(T(rays), T(r), T(v), 9, True, return_transform=True)
+    assert maxabs(N(new_rays), O.rbk_warp(rays, r, v, 9, True)) < 5e-6
+    Rm = N(tf)[..., :3, :3]
+    assert maxabs(Rm @ np.swapaxes(Rm, -1, -2), np.broadcast_to(np.eye(3, dtype=np.float32), Rm.shape)) < 1e-5
+    assert rbk_warp(torch.empty((0, 3, 2), device=DEV), torch.empty((0, 27), device=DEV), torch.empty((0, 27), device=DEV), 9).shape == (0, 10, 3, 2)

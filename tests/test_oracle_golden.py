@@ -258,3 +258,12 @@ def test_G15_awp_feature_integration():
         feat = g[f"{tag}_feat"]
         out = O.awp_feature_integration(feat.reshape(-1, feat.shape[-2], feat.shape[-1]), g[f"{tag}_z"], g[f"{tag}_rays_d"])
         assert maxabs(out.reshape(g[f"{tag}_out"].shape), g[f"{tag}_out"]) < 2e-5 * max(1.0, np.abs(g[f"{tag}_out"]).max())
+
+
+def test_G16_rbk_warp():
+    """RigidBlurringModel.rbk_warp of the reference (blurmodel.py:51-82, rigid_warping.py)."""
+    g = load_golden("G16_rbk_warp")
+    for tag, M, uo in (("a", 9, True), ("b", 4, False), ("c", 9, True)):
+        new_rays, tf = O.rbk_warp(g[f"{tag}_rays"], g[f"{tag}_r"], g[f"{tag}_v"], M, uo, want_transform=True)
+        assert maxabs(new_rays, g[f"{tag}_new_rays"]) < 5e-6, tag
+        assert maxabs(tf, g[f"{tag}_transform"]) < 5e-6, tag

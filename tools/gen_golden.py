@@ -549,9 +549,28 @@ def G15_awp_feature_integration():
     save("G15_awp_feature_integration", **out)
 
 
+def G16_rbk_warp():
+    """RigidBlurringModel.rbk_warp (networks/dpnerf/blurmodel.py:51-82 with SE3Field / RigidBody of utils/rigid_warping.py):
+    rays [R,3,2] + predicted screw motions r, v [R, 3*M] -> warped rays [R, M(+1), 3, 2] and the 4x4 transforms."""
+    from networks.dpnerf.blurmodel import RigidBlurringModel
+    rs = np.random.RandomState(161)
+    out = {}
+    for tag, (R, M, uo, scale) in {"a": (64, 9, True, 1e-2), "b": (16, 4, False, 1.0), "c": (8, 9, True, 1e-5)}.items():
+        net = RigidBlurringModel(W=32, D_r=1, W_r=16, D_v=1, W_v=16, D_w=1, W_w=16, output_ch_r=3, output_ch_v=3, feat_ch=0,
+                                 rv_window=1.0, view_embed=None, num_motion=M, use_origin=uo, use_view_embed=False)
+        rays = W.synthetic_rays(170 + len(out), R)
+        r = (rs.standard_normal((R, 3 * M)) * scale).astype(np.float32)
+        v = (rs.standard_normal((R, 3 * M)) * scale).astype(np.float32)
+        if tag == "a":
+            r[0] = 0.0                                     # theta = 1e-10: the pure-translation limit
+        new_rays, tf = net.rbk_warp(t(rays), t(r), t(v), return_transform=True)
+        out.update({f"{tag}_rays": rays, f"{tag}_r": r, f"{tag}_v": v, f"{tag}_new_rays": n(new_rays), f"{tag}_transform": n(tf)})
+    save("G16_rbk_warp", **out)
+
+
 ALL = [G1_embedder, G2_nerf_mlp, G3_nerf_raw2outputs, G4_voxel_raw2outputs, G5_sample_pdf, G6_rays,
        G7_render_nerf, G8_appfeature, G9_render_c2f, G10_rbk_weighted_sum, G11_crf, G12_egm_loss, G13_edi,
-       G14_loss_assembly, G15_awp_feature_integration]
+       G14_loss_assembly, G15_awp_feature_integration, G16_rbk_warp]
 
 if __name__ == "__main__":
     want = set(sys.argv[1:])
