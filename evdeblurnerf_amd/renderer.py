@@ -227,15 +227,26 @@ class NeRFAll:
         return ret_list + [ret_dict]
 
     # ------------------------------------------------------------------ render_path, renderer.py:594-626
-    def render_path(self, H, W, K, chunk, render_poses, render_kwargs, render_factor=0):
+    def render_path(self, H, W, K, chunk, render_poses, render_kwargs, render_factor=0, shard_rows=False):
+        """Full-frame renders of ``render_poses``.  ``shard_rows=True`` (new; the reference is single-GPU) splits the H image
+        rows contiguously over the ranks of the initialised process group and all-gathers the row tiles (dist.gather_rows),
+        so every rank returns the whole frames (BASELINE config 5)."""
+        from . import dist as D
         if render_factor != 0:
             H, W = H // render_factor, W // render_factor
+        lo, hi = 0, H
+        if shard_rows:
+            import torch.distributed as tdist
+            if tdist.is_available() and tdist.is_initialized():
+                lo, hi = D.shard_range(H, tdist.get_rank(), tdist.get_world_size())
         rgbs, depths = [], []
         for c2w in render_poses:
             dev = c2w.device if isinstance(c2w, torch.Tensor) else torch.device("cpu")
             o, d = get_rays(H, W, K, c2w if isinstance(c2w, torch.Tensor) else torch.as_tensor(c2w))
-            rays = torch.stack([o, d], dim=-1)
+            rays = torch.stack([o, d], dim=-1)[lo:hi]
             rgb, depth, acc, extras = self.render(H, W, K, chunk=chunk, rays=rays, **render_kwargs)
+            if shard_rows:
+                rgb, depth = D.gather_rows(rgb, H), D.gather_rows(depth, H)
             rgbs.append(rgb.to(dev))
             depths.append(depth.to(dev))
         return torch.stack(rgbs, 0), torch.stack(depths, 0)
