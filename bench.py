@@ -158,7 +158,8 @@ def main():
         L.check(L.lib().evd_ray_batch(C.byref(cfg), L.ptr(rays), R, L.ptr(rb), L.stream_ptr()))
         L.check(L.lib().evd_sample_z(C.byref(cfg), L.ptr(rb), 11, R, None, L.ptr(z), L.stream_ptr()))
         modes = {}
-        for prec in ([a.precision] if a.no_modes else ["f16", "bf16", "f16x3", "f32"]):
+        lean = world > 1          # N > 1 runs: headline kernel only (modes / composite / cpu_baseline are N = 1 legs)
+        for prec in ([a.precision] if (a.no_modes or lean) else ["f16", "bf16", "f16x3", "f32"]):
             net = model.mlp_coarse
             ksteps = max(3, a.steps // (10 if prec == "f32" else 1))
             ms = kernel_ms(lambda: net.mlpforward(rb, z, precision=prec), ksteps)
@@ -202,7 +203,7 @@ def main():
             rgb_run = model.render(400, 400, K, rays=rays, **kw)[0]
             result["parity"] = {"rgb_linf_vs_f32_kernel": float((rgb_run - rgb_ref).abs().max()), "bound": 1e-4,
                                 "note": "f32 kernel vs the reference (through the oracle and the goldens): tests/test_gpu_parity.py"}
-        if not a.no_composite:
+        if not a.no_composite and not lean:
             # ---- compositing scan alone (HBM-bound): 2^20 rays x 128 samples = 3.25 GB of algorithmic traffic
             Rc = 1 << 20
             raw_c = torch.randn((Rc, S, 4), device="cuda")
@@ -220,7 +221,7 @@ def main():
                                    "achieved": cbytes / (cms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": cbytes / (cms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": cbytes}
             del raw_c, z_c, rd_c, o3, o1, o2, ow
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and not lean:
             from oracle import oracle as O
             onet = O.Nerf(sd, "mlp_coarse.")
             ocfg = O.make_cfg(N_samples=S)
