@@ -58,7 +58,7 @@ class NeRF:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and L is not None and getattr(L, "lib", None) is not None:     # module globals may be gone at interpreter shutdown
             L.lib().evd_nerf_destroy(h)
             self._h = None
 

@@ -66,7 +66,7 @@ class VoxelNeRFBase:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and L is not None and getattr(L, "lib", None) is not None:     # module globals may be gone at interpreter shutdown
             L.lib().evd_voxel_destroy(h)
             self._h = None
 
