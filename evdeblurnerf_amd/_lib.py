@@ -64,6 +64,8 @@ _L, _I, _F, _S = C.c_long, C.c_int, C.c_float, C.c_size_t
 SIGNATURES = {
     "evd_last_error": (C.c_char_p, []),
     "evd_version": (_I, []),
+    "evd_compute_successor_workspace_bytes": (_S, [_L]),
+    "evd_compute_successor": (_I, [_vp, _L, _L, _vp, _vp, _vp, _vp, _vp, _S, _vp]),
     "evd_rbk_warp": (_I, [_vp, _vp, _vp, _L, _I, _I, _vp, _vp, _vp]),
     "evd_awp_feature_integration": (_I, [_vp, _vp, _vp, _L, _I, _I, _vp, _vp]),
     "evd_probe_mfma_rate": (_I, [_I, _I, C.POINTER(C.c_double), _vp]),

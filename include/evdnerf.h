@@ -250,6 +250,15 @@ int evd_edi_deblur(const float* blurry, const float* bii, int steps, long npix, 
 int evd_edi_bii_image(const float* x, const float* y, const signed char* p, long n, int w, int h,
                       float c_pos, float c_neg, float* image, void* stream);
 
+/* ---------------------------------------------------------------- event preprocessing
+ * compute_successor, utils/events.py:72-120 (flat_xy = True): pixel_ids dev int32 [N] (y * w + x of every event, in stream
+ * order), HW = number of pixels -> successor dev int64 [N] (index of the next event at the same pixel, or the event itself),
+ * num_successors dev int32 [N], latest_seen dev int64 [HW] (the pixel's first event, -1 if none), first_seen dev int64 [HW]
+ * (its last event).  Bit-identical to the reference loop. */
+size_t evd_compute_successor_workspace_bytes(long N);
+int evd_compute_successor(const int* pixel_ids, long N, long HW, long long* successor, int* num_successors,
+                          long long* latest_seen, long long* first_seen, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------- measurement aid (no reference counterpart)
  * Sustained rate of back-to-back v_mfma_f32_32x32x16_bf16 issue on every SIMD of the current device, in dense
  * TFLOP/s, with constant (random_operands == 0) or random operands.  The chip clocks to its power budget, so the

@@ -994,3 +994,22 @@ void evo_rbk_warp(const float* rays, const float* r, const float* v, long R, int
         }
     }
 }
+
+/* ------------------------------------------------------------------ event successor graph
+ * utils/events.py:72-120, the reverse loop as written: latest_seen_idx ends up holding the FIRST event of each pixel,
+ * first_seen_idx the LAST one; an event without a later event at its pixel is its own successor. */
+void evo_compute_successor(const int* ids, long N, long HW, long long* successor, int* num_successors, long long* latest_seen, long long* first_seen) {
+    for (long k = 0; k < HW; ++k) { latest_seen[k] = -1; first_seen[k] = -1; }
+    for (long i = N - 1; i >= 0; --i) {
+        const int x = ids[i];
+        if (latest_seen[x] != -1) {
+            successor[i] = latest_seen[x];
+            num_successors[i] = num_successors[successor[i]] + 1;
+        } else {
+            successor[i] = i;
+            num_successors[i] = 0;
+        }
+        latest_seen[x] = i;
+        if (first_seen[x] == -1) first_seen[x] = i;
+    }
+}

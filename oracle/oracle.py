@@ -306,6 +306,18 @@ def weighted_sum(x, ccw):
     return out.reshape((R,) + tuple(x.shape[1:]))
 
 
+def compute_successor(ids, hw):
+    """utils/events.py:72-120 on flat pixel ids -> (successor int64 [N], num_successors int32 [N], latest_seen, first_seen int64 [hw])"""
+    ids = np.ascontiguousarray(ids, dtype=np.int32)
+    n = ids.shape[0]
+    succ, nsucc = np.empty(n, np.int64), np.empty(n, np.int32)
+    latest, first = np.empty(hw, np.int64), np.empty(hw, np.int64)
+    ip, lp = C.POINTER(C.c_int), C.POINTER(C.c_longlong)
+    lib().evo_compute_successor(ids.ctypes.data_as(ip), C.c_long(n), C.c_long(hw), succ.ctypes.data_as(lp), nsucc.ctypes.data_as(ip),
+                                latest.ctypes.data_as(lp), first.ctypes.data_as(lp))
+    return succ, nsucc, latest, first
+
+
 def rbk_warp(rays, r, v, num_motion, use_origin=True, want_transform=False):
     """blurmodel.py:51-82: rays [R,3,2], r/v [R, 3*M] -> new_rays [R, M(+1), 3, 2] (, transforms [R, M(+1), 4, 4])"""
     rays, r, v = _f(rays), _f(r), _f(v)

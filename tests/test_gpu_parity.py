@@ -544,3 +544,24 @@ def test_full_frame_eval_path_psnr_parity(O):
         assert maxabs(got, ref) < linf and psnr(got, ref) > db
         sharded = model.render_path(Hh, Ww, K, 1 << 20, [torch.as_tensor(poses[0])], kw, shard_rows=True)[0]   # no process group: identity
         assert torch.equal(sharded[0], rgbs[0])
+
+
+def test_compute_successor_bit_exact(O):
+    """Event successor graph (utils/events.py:72-120): bit-exact vs the reference golden G17, vs the oracle on 2 M events of a
+    346x260 sensor, plus the chain property (following successors visits a pixel's events in increasing order)."""
+    from evdeblurnerf_amd.events import compute_successor
+    g = load_golden("G17_compute_successor")
+    for tag in ("a", "b", "c"):
+        hw = g[f"{tag}_latest"].shape[0]
+        succ, nsucc, latest, first = compute_successor(T(g[f"{tag}_ids"]), hw)
+        assert np.array_equal(N(succ), g[f"{tag}_succ"]) and np.array_equal(N(nsucc), g[f"{tag}_nsucc"]), tag
+        assert np.array_equal(N(latest), g[f"{tag}_latest"]) and np.array_equal(N(first), g[f"{tag}_first"]), tag
+    rs = np.random.RandomState(10)
+    hw, n = 346 * 260, 2_000_000
+    ids = rs.randint(0, hw, size=n).astype(np.int32)
+    succ, nsucc, latest, first = [N(v) for v in compute_successor(T(ids), hw)]
+    rs_, rn, rl, rf = O.compute_successor(ids, hw)
+    assert np.array_equal(succ, rs_) and np.array_equal(nsucc, rn) and np.array_equal(latest, rl) and np.array_equal(first, rf)
+    assert (succ >= np.arange(n)).all() and (ids[succ] == ids).all()
+    empty = compute_successor(torch.empty((0,), dtype=torch.int32, device=DEV), 7)
+    assert empty[0].shape == (0,) and (N(empty[2]) == -1).all()

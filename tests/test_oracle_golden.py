@@ -267,3 +267,12 @@ def test_G16_rbk_warp():
         new_rays, tf = O.rbk_warp(g[f"{tag}_rays"], g[f"{tag}_r"], g[f"{tag}_v"], M, uo, want_transform=True)
         assert maxabs(new_rays, g[f"{tag}_new_rays"]) < 5e-6, tag
         assert maxabs(tf, g[f"{tag}_transform"]) < 5e-6, tag
+
+
+def test_G17_compute_successor():
+    """utils/events.py:72-120: integer outputs, bit-exact."""
+    g = load_golden("G17_compute_successor")
+    for tag in ("a", "b", "c"):
+        succ, nsucc, latest, first = O.compute_successor(g[f"{tag}_ids"], g[f"{tag}_latest"].shape[0])
+        assert np.array_equal(succ, g[f"{tag}_succ"]) and np.array_equal(nsucc, g[f"{tag}_nsucc"])
+        assert np.array_equal(latest, g[f"{tag}_latest"]) and np.array_equal(first, g[f"{tag}_first"])

@@ -568,9 +568,28 @@ def G16_rbk_warp():
     save("G16_rbk_warp", **out)
 
 
+def G17_compute_successor():
+    """utils/events.py:72-120 compute_successor (numba @njit in the reference; run here as plain Python through the njit stub):
+    per event the index of the next event at the same pixel, the number of later events there, and per pixel the first /
+    last event index.  Integer outputs: the parity bar is bit-exact."""
+    from utils.events import compute_successor
+    rs = np.random.RandomState(171)
+    out = {}
+    for tag, (N, hw, flat) in {"a": (6000, 37 * 23, True), "b": (500, 9, True), "c": (1, 4, True)}.items():
+        ids = rs.randint(0, hw, size=N).astype(np.int64)
+        if tag == "a":
+            ids[:200] = 5                                    # a long chain at one pixel
+        ids[-1] = hw - 1                                     # the reference sizes its tables by max(id) + 1
+        ev = np.stack([ids, np.sort(rs.uniform(0, 1, N)), rs.choice([-1, 1], N)], -1).astype(np.float64)
+        succ, nsucc, latest, first = compute_successor(ev, flat_xy=flat)
+        out.update({f"{tag}_ids": ids.astype(np.int32), f"{tag}_succ": succ.astype(np.int64), f"{tag}_nsucc": nsucc.astype(np.int32),
+                    f"{tag}_latest": latest.reshape(-1).astype(np.int64), f"{tag}_first": first.reshape(-1).astype(np.int64)})
+    save("G17_compute_successor", **out)
+
+
 ALL = [G1_embedder, G2_nerf_mlp, G3_nerf_raw2outputs, G4_voxel_raw2outputs, G5_sample_pdf, G6_rays,
        G7_render_nerf, G8_appfeature, G9_render_c2f, G10_rbk_weighted_sum, G11_crf, G12_egm_loss, G13_edi,
-       G14_loss_assembly, G15_awp_feature_integration, G16_rbk_warp]
+       G14_loss_assembly, G15_awp_feature_integration, G16_rbk_warp, G17_compute_successor]
 
 if __name__ == "__main__":
     want = set(sys.argv[1:])
