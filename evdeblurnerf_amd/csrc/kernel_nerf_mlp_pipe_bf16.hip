@@ -1,15 +1,11 @@
 // bf16 instantiations of the software-pipelined NeRF MLP kernel (nerf_mlp_kernel.h): the reference network
-// (netdepth 8, netwidth 256, skips [4]).  Variant 0: two wavefronts of 32 samples per SIMD; variant 1
-// (EVD_MLP_VARIANT=1): one wavefront of 64 samples per SIMD -- every A fragment read from LDS feeds two MFMAs.
-#include <cstdlib>
-
+// (netdepth 8, netwidth 256, skips [4]), two wavefronts of 32 samples per SIMD.  (One wavefront of 64 samples per SIMD,
+// <.., 2, 256, ..>, halves the LDS reads and runs at the same speed: the kernel is clock-limited)
 #include "nerf_mlp_kernel.h"
 
 namespace evd {
 
 int launch_nerf_pipe_bf16(bool feat, const MlpParams& p, hipStream_t st) {
-    static const int variant = [] { const char* e = getenv("EVD_MLP_VARIANT"); return e ? atoi(e) : 0; }();
-    if (variant == 1 && !feat) return launch_pipe_mlp<EVD_PREC_BF16, 256, 8, 4, 2, 256, false>(p, st);
     return feat ? launch_pipe_mlp<EVD_PREC_BF16, 256, 8, 4, 1, 512, true>(p, st) : launch_pipe_mlp<EVD_PREC_BF16, 256, 8, 4, 1, 512, false>(p, st);
 }
 
