@@ -79,7 +79,7 @@ int evd_voxel_create(const evd_voxel_desc* d, evd_voxel** out) {
         rc = v->line_h[i].upload(lh.data(), lh.size() * sizeof(_Float16));
     }
     if (!rc) rc = v->basis.upload(d->basis, sizeof(float) * (size_t)d->app_dim * ctot);
-    if (!rc) rc = v->tv_acc.alloc(12 * sizeof(double));
+    if (!rc) rc = v->tv_acc.alloc((size_t)6 * 2 * TV_MAX_BLOCKS * sizeof(double));
     if (rc) { evd_voxel_destroy(v); return rc; }
     GridParams& g = v->gp;
     for (int i = 0; i < 3; ++i) {
@@ -306,14 +306,13 @@ int evd_voxel_tv_loss(const evd_voxel* v, float* out, void* stream) {
     EVD_REQUIRE(v && out, "evd_voxel_tv_loss: null argument");
     hipStream_t st = as_stream(stream);
     double* acc = (double*)v->tv_acc.p;
-    EVD_HIP(hipMemsetAsync(acc, 0, 12 * sizeof(double), st));
     TvShape s;
     for (int i = 0; i < 3; ++i) {
         const int C = v->n_comp[i], Wp = v->grid[kMat0[i]], Hp = v->grid[kMat1[i]], Lp = v->grid[kVec[i]];
         s.C[i] = C; s.H[i] = Hp; s.W[i] = Wp;
         s.C[3 + i] = C; s.H[3 + i] = Lp; s.W[3 + i] = 1;
-        int rc = launch_tv((const float*)v->plane[i].p, Hp, Wp, C, acc + 2 * i, st);
-        if (!rc) rc = launch_tv((const float*)v->line[i].p, Lp, 1, C, acc + 2 * (3 + i), st);
+        int rc = launch_tv((const float*)v->plane[i].p, Hp, Wp, C, acc + (size_t)i * 2 * TV_MAX_BLOCKS, &s.blocks[i], st);
+        if (!rc) rc = launch_tv((const float*)v->line[i].p, Lp, 1, C, acc + (size_t)(3 + i) * 2 * TV_MAX_BLOCKS, &s.blocks[3 + i], st);
         if (rc) return rc;
     }
     return launch_tv_finish(acc, s, out, st);

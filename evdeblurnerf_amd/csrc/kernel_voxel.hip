@@ -308,7 +308,7 @@ int voxel_mlp_dispatch(int prec, int HD, int G, int FT, const VoxMlpParams& p, h
 // TVLoss.forward (voxnerf.py:306-324) on a channel-last tensor [H][W][C]; accumulates sum dh^2, sum dw^2.
 // HBM-bound (every grid value is read once per training iteration): one thread = 4 channels of one texel, float4
 // loads of the texel, its lower and its right neighbour (both re-read from L1/L2), rows strided over blockIdx.y,
-// double accumulators, one atomic pair per block.
+// double accumulators, one partial pair per block (summed by k_tv_finish).
 __global__ __launch_bounds__(256) void k_tv(const float* __restrict__ x, int H, int W, int C, double* __restrict__ acc2) {
     __shared__ double red[2][4];
     const int vec_per_row = W * (C / 4);
@@ -335,23 +335,33 @@ __global__ __launch_bounds__(256) void k_tv(const float* __restrict__ x, int H, 
     for (int off = 32; off > 0; off >>= 1) { sh += __shfl_xor(sh, off, 64); sw += __shfl_xor(sw, off, 64); }
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sh; red[1][threadIdx.x >> 6] = sw; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicAdd(acc2, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-        atomicAdd(acc2 + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    if (threadIdx.x == 0) {         // one partial pair per block (4096 same-address double atomics serialise for ~0.2 ms)
+        const int b = blockIdx.y * gridDim.x + blockIdx.x;
+        acc2[2 * b] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        acc2[2 * b + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     }
 }
 
-__global__ void k_tv_finish(const double* __restrict__ acc, TvShape s, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_tv_finish(const double* __restrict__ part, TvShape s, float* __restrict__ out) {
     // total = sum_i reg(plane_i) * 1e-2 + reg(line_i) * 1e-3,  reg = 2 (h_tv / count_h + w_tv / count_w)  (voxnerf.py:126-130)
+    __shared__ double red[2][4];
     double total = 0.0;
     for (int i = 0; i < 6; ++i) {
+        const double* p = part + (long)i * 2 * TV_MAX_BLOCKS;
+        double sh = 0.0, sw = 0.0;
+        for (int b = threadIdx.x; b < s.blocks[i]; b += blockDim.x) { sh += p[2 * b]; sw += p[2 * b + 1]; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { sh += __shfl_xor(sh, off, 64); sw += __shfl_xor(sw, off, 64); }
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sh; red[1][threadIdx.x >> 6] = sw; }
+        __syncthreads();
+        const double h_tv = red[0][0] + red[0][1] + red[0][2] + red[0][3], w_tv = red[1][0] + red[1][1] + red[1][2] + red[1][3];
         const double ch = (double)s.C[i] * (s.H[i] - 1) * s.W[i];
         double cw = (double)s.C[i] * s.H[i] * (s.W[i] - 1);
         if (cw < 1.0) cw = 1.0;
-        const double reg = 2.0 * (acc[2 * i] / ch + acc[2 * i + 1] / cw);
-        total += reg * (i < 3 ? 1e-2 : 1e-3);
+        total += 2.0 * (h_tv / ch + w_tv / cw) * (i < 3 ? 1e-2 : 1e-3);
     }
-    out[0] = (float)total;
+    if (threadIdx.x == 0) out[0] = (float)total;
 }
 
 int launch_points(const float* rb, int nc, const float* z, long n, int S, float* pts, hipStream_t st) {
@@ -375,18 +385,19 @@ int launch_voxel_sample(const GridParams& g, bool half_grids, const float* pts, 
     return EVD_OK;
 }
 
-int launch_tv(const float* x, int H, int W, int C, double* acc2, hipStream_t st) {
+int launch_tv(const float* x, int H, int W, int C, double* acc2, int* blocks, hipStream_t st) {
     if (C % 4) return fail(EVD_E_INVALID, "evd_voxel_tv_loss: component count %d is not a multiple of 4", C);
     const long vec_per_row = (long)W * (C / 4);
     const unsigned bx = (unsigned)(cdiv(vec_per_row, 256) < 64 ? cdiv(vec_per_row, 256) : 64);
     const unsigned by = (unsigned)(H < 64 ? H : 64);
+    *blocks = (int)(bx * by);
     k_tv<<<dim3(bx, by), 256, 0, st>>>(x, H, W, C, acc2);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }
 
 int launch_tv_finish(const double* acc, const TvShape& s, float* out, hipStream_t st) {
-    k_tv_finish<<<1, 1, 0, st>>>(acc, s, out);
+    k_tv_finish<<<1, 256, 0, st>>>(acc, s, out);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }

@@ -27,13 +27,14 @@ struct VoxMlpParams {
     float* feature;             // [n,G] or null
 };
 
-struct TvShape { int C[6], H[6], W[6]; };
+constexpr int TV_MAX_BLOCKS = 4096;     // partial (dh^2, dw^2) pairs per tensor
+struct TvShape { int C[6], H[6], W[6], blocks[6]; };
 
 int launch_points(const float* rb, int nc, const float* z, long n, int S, float* pts, hipStream_t st);
 int launch_merge_features(const float* old, const float* fresh, const int* order, long R, int S, int N, int F, float* out, int out_stride,
                           hipStream_t st);
 int launch_voxel_sample(const GridParams& g, bool half_grids, const float* pts, long n, float* out, int out_stride, int out_col, hipStream_t st);
-int launch_tv(const float* x, int H, int W, int C, double* acc2, hipStream_t st);
+int launch_tv(const float* x, int H, int W, int C, double* partials, int* blocks, hipStream_t st);
 int launch_tv_finish(const double* acc, const TvShape& s, float* out, hipStream_t st);
 int voxel_mlp_dispatch(int prec, int HD, int G, int FT, const VoxMlpParams& p, hipStream_t st);
 
