@@ -109,45 +109,44 @@ __global__ __launch_bounds__(256) void k_blur_loss(const CrfParams crf, int skip
                                                    const float* __restrict__ w2, const float* __restrict__ tgt,
                                                    const float* __restrict__ tgt0, long R, int P, float* __restrict__ partial,
                                                    float* __restrict__ o_rgb, float* __restrict__ o_rgb1, float* __restrict__ o_awp) {
+    // one lane per (pixel, colour channel): a 1024-pixel blur batch is 3072 lanes in 48 small blocks instead of 4 busy ones
     __shared__ float red[8];
-    const long r = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const long r = idx / 3;
+    const int ch = (int)(idx % 3);
     float se[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    float cnt = 0.f;
     if (r < R) {
-        float a[3] = {0, 0, 0}, b[3] = {0, 0, 0}, c[3] = {0, 0, 0};
+        cnt = 1.f;
+        float a = 0.f, b = 0.f, c = 0.f;
         for (int p = 0; p < P; ++p) {
             const float wa = w1[r * P + p], wb = w2 ? w2[r * P + p] : 0.f;
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                const float f = rgb_p[(r * P + p) * 3 + ch];
-                a[ch] += f * wa;
-                c[ch] += f * wb;
-                if (rgb0_p) b[ch] += rgb0_p[(r * P + p) * 3 + ch] * wa;
-            }
+            const float f = rgb_p[(r * P + p) * 3 + ch];
+            a += f * wa;
+            c += f * wb;
+            if (rgb0_p) b += rgb0_p[(r * P + p) * 3 + ch] * wa;
         }
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-            const float t = tgt[r * 3 + ch];
-            float d = crf_apply(crf, a[ch], nullptr, skip_learn) - t;
-            se[0] += d * d;
-            if (o_rgb) o_rgb[r * 3 + ch] = a[ch];
+        const float t = tgt[r * 3 + ch];
+        float d = crf_apply(crf, a, nullptr, skip_learn) - t;
+        se[0] = d * d;
+        if (o_rgb) o_rgb[r * 3 + ch] = a;
+        if (rgb0_p) {
+            d = crf_apply(crf, b, nullptr, skip_learn) - t;
+            se[1] = d * d;
+            if (o_rgb1) o_rgb1[r * 3 + ch] = b;
+        }
+        if (w2) {
+            d = crf_apply(crf, c, nullptr, skip_learn) - t;
+            se[2] = d * d;
+            if (o_awp) o_awp[r * 3 + ch] = c;
+        }
+        if (tgt0) {
+            const float t0 = tgt0[r * 3 + ch];
+            d = crf_apply(crf, rgb_p[(r * P) * 3 + ch], nullptr, skip_learn) - t0;     // rgb_pts[:, 0] renderer.py:374
+            se[3] = d * d;
             if (rgb0_p) {
-                d = crf_apply(crf, b[ch], nullptr, skip_learn) - t;
-                se[1] += d * d;
-                if (o_rgb1) o_rgb1[r * 3 + ch] = b[ch];
-            }
-            if (w2) {
-                d = crf_apply(crf, c[ch], nullptr, skip_learn) - t;
-                se[2] += d * d;
-                if (o_awp) o_awp[r * 3 + ch] = c[ch];
-            }
-            if (tgt0) {
-                const float t0 = tgt0[r * 3 + ch];
-                d = crf_apply(crf, rgb_p[(r * P) * 3 + ch], nullptr, skip_learn) - t0;     // rgb_pts[:, 0] renderer.py:374
-                se[3] += d * d;
-                if (rgb0_p) {
-                    d = crf_apply(crf, rgb0_p[(r * P) * 3 + ch], nullptr, skip_learn) - t0;
-                    se[4] += d * d;
-                }
+                d = crf_apply(crf, rgb0_p[(r * P) * 3 + ch], nullptr, skip_learn) - t0;
+                se[4] = d * d;
             }
         }
     }
@@ -156,11 +155,8 @@ __global__ __launch_bounds__(256) void k_blur_loss(const CrfParams crf, int skip
         const float s = block_sum(se[k], red);
         if (threadIdx.x == 0 && s != 0.f) atomicAdd(partial + k, s);
     }
-    if (threadIdx.x == 0) {
-        const long lo = blockIdx.x * (long)blockDim.x;
-        const long cnt = (R - lo) < (long)blockDim.x ? (R - lo) : (long)blockDim.x;
-        atomicAdd(partial + 5, 3.f * (float)cnt);
-    }
+    const float n = block_sum(cnt, red);
+    if (threadIdx.x == 0) atomicAdd(partial + 5, n);
 }
 
 // spec: run_nerf.py:518-570 + utils/events.py:260-284.  The learnable event-CRF (a 1+E -> 16 -> 16 -> 16 -> 1 MLP per
@@ -386,7 +382,7 @@ int evd_blur_loss_reduce(const evd_crf* crf_rgb, int skip_learn, const float* rg
                          float* partial, float* out_rgb, float* out_rgb1, float* out_awp, void* stream) {
     EVD_REQUIRE(crf_rgb && rgb_p && w1 && tgt && partial && R >= 0 && P >= 1, "evd_blur_loss_reduce: bad arguments");
     if (R == 0) return EVD_OK;
-    k_blur_loss<<<cdiv(R, 256), 256, 0, as_stream(stream)>>>(crf_rgb->p, skip_learn, rgb_p, rgb0_p, w1, w2, tgt, tgt0, R, P, partial,
+    k_blur_loss<<<cdiv(3 * R, 64), 64, 0, as_stream(stream)>>>(crf_rgb->p, skip_learn, rgb_p, rgb0_p, w1, w2, tgt, tgt0, R, P, partial,
                                                              out_rgb, out_rgb1, out_awp);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
