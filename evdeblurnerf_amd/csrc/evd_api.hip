@@ -143,7 +143,8 @@ int evd_nerf_mlp(const evd_nerf* net, int precision, const float* ray_batch, con
     EVD_REQUIRE(!feature || feature_kind == 1 || feature_kind == 2, "evd_nerf_mlp: feature_kind must be 1 or 2");
     if (R == 0) return EVD_OK;
     MlpParams p;
-    const bool piped = net->pipe_chunks[precision] > 0 && !getenv("EVD_NO_PIPE");
+    static const bool no_pipe = env_flag("EVD_NO_PIPE");      // developer switch: force the generic kernel
+    const bool piped = net->pipe_chunks[precision] > 0 && !no_pipe;
     p.wstream = (const char*)(piped ? net->pipe[precision].p : net->stream[precision].p);
     p.bias = (const float*)net->bias.p;
     p.ray_batch = ray_batch; p.z = z; p.nsamp = R * (long)S; p.S = S; p.ncol = 11;

@@ -3,7 +3,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -31,6 +33,26 @@ int fail(int code, const char* fmt, ...);
 #define EVD_LAUNCH_CHECK() EVD_HIP(hipGetLastError())
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Raise a kernel's dynamic-LDS limit once per device (the attribute is per device; one process may drive several).
+// `done` is the caller's function-local bitmask of devices already configured.
+#define EVD_SET_MAX_LDS(kernel, bytes)                                                                             \
+    do {                                                                                                           \
+        static std::atomic<unsigned long long> done_{0};                                                           \
+        int dev_ = 0;                                                                                              \
+        EVD_HIP(hipGetDevice(&dev_));                                                                              \
+        const unsigned long long bit_ = 1ull << (dev_ & 63);                                                       \
+        if (!(done_.load(std::memory_order_relaxed) & bit_)) {                                                     \
+            EVD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); \
+            done_.fetch_or(bit_, std::memory_order_relaxed);                                                       \
+        }                                                                                                          \
+    } while (0)
+
+// developer switches read from the environment once per process
+inline bool env_flag(const char* name) {
+    const char* e = getenv(name);
+    return e && e[0] && e[0] != '0';
+}
 
 inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 

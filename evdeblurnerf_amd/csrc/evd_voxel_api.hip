@@ -158,7 +158,8 @@ int evd_voxel_sample(const evd_voxel* v, const float* pts, long n, float* out, i
 
 // sampling inside the c2f render: the half-precision arithmetic modes read the float16 copies of the grids
 static int sample_for(const evd_voxel* v, int precision, const float* pts, long n, float* out, int out_stride, int out_col, void* stream) {
-    const bool half = (precision == EVD_PREC_BF16 || precision == EVD_PREC_F16) && !getenv("EVD_F32_GRIDS");
+    static const bool f32_grids = env_flag("EVD_F32_GRIDS");   // developer switch: float32 grids in every mode
+    const bool half = (precision == EVD_PREC_BF16 || precision == EVD_PREC_F16) && !f32_grids;
     return launch_voxel_sample(v->gp, half, pts, n, out, out_stride, out_col, as_stream(stream));
 }
 
@@ -174,7 +175,8 @@ static int voxel_pass(const evd_voxel* v, int precision, const float* pts, const
                       const float* noise, float* color, float* depth, float* acc, float* weights, float* feature, float* raw,
                       void* stream) {
     VoxMlpParams p;
-    const bool piped = v->pipe_chunks[precision] > 0 && !getenv("EVD_NO_PIPE");
+    static const bool no_pipe = env_flag("EVD_NO_PIPE");
+    const bool piped = v->pipe_chunks[precision] > 0 && !no_pipe;
     p.wstream = (const char*)(piped ? v->pipe[precision].p : v->stream[precision].p);
     p.bias = (const float*)v->bias.p;
     p.pts = pts; p.viewdirs = viewdirs; p.fts = fts; p.nsamp = R * (long)S; p.S = S; p.vd_stride = vd_stride; p.ft_stride = ft_stride;

@@ -120,11 +120,7 @@ static int launch_mlp(const MlpParams& p, hipStream_t st) {
     constexpr int NT = mlp_threads(PREC);
     const long blocks = cdiv(p.nsamp, NT / 2);
     const size_t lds = MlpLds<PREC>::TOTAL;
-    static bool attr_set = false;
-    if (!attr_set) {
-        EVD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nerf_mlp_generic<PREC, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    EVD_SET_MAX_LDS((&k_nerf_mlp_generic<PREC, W>), lds);
     if (p.nbias > MlpLds<PREC>::BIAS_FLOATS) return fail(EVD_E_INVALID, "evd_nerf_mlp: %d bias floats exceed the LDS bias block", p.nbias);
     hipLaunchKernelGGL((k_nerf_mlp_generic<PREC, W>), dim3((unsigned)blocks), dim3(NT), lds, st, p);
     EVD_LAUNCH_CHECK();

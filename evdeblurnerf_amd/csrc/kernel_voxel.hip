@@ -280,11 +280,7 @@ static int launch_vox(const VoxMlpParams& p, hipStream_t st) {
     constexpr int NT = mlp_threads(PREC);
     const long blocks = cdiv(p.nsamp, NT / 2);
     const size_t lds = MlpLds<PREC>::TOTAL;
-    static bool attr_set = false;
-    if (!attr_set) {
-        EVD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_voxel_mlp<PREC, HD, G, FT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    EVD_SET_MAX_LDS((&k_voxel_mlp<PREC, HD, G, FT>), lds);
     hipLaunchKernelGGL((k_voxel_mlp<PREC, HD, G, FT>), dim3((unsigned)blocks), dim3(NT), lds, st, p);
     EVD_LAUNCH_CHECK();
     return EVD_OK;

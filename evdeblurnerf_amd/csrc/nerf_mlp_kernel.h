@@ -218,11 +218,7 @@ static int launch_pipe_mlp(const MlpParams& p, hipStream_t st) {
     typedef PipeCfg<PREC, NS, NT> C;
     const long blocks = cdiv(p.nsamp, C::SAMPLES);
     const size_t lds = C::TOTAL;
-    static bool attr_set = false;
-    if (!attr_set) {
-        EVD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nerf_mlp<PREC, W, D, SKIP, NS, NT, FEAT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    EVD_SET_MAX_LDS((&k_nerf_mlp<PREC, W, D, SKIP, NS, NT, FEAT>), lds);
     if (p.nbias > C::BIAS_FLOATS) return fail(EVD_E_INVALID, "evd_nerf_mlp: %d bias floats exceed the LDS bias block", p.nbias);
     if (p.nchunks != NerfNet<C, W, D, SKIP, FEAT>::NCH)
         return fail(EVD_E_INVALID, "evd_nerf_mlp: packed stream has %d chunks, kernel expects %d", p.nchunks, NerfNet<C, W, D, SKIP, FEAT>::NCH);

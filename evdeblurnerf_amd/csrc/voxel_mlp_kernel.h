@@ -132,11 +132,7 @@ static int launch_voxel_pipe(const VoxMlpParams& p, hipStream_t st) {
     typedef VoxFineNet<C, FEAT> N;
     const long blocks = cdiv(p.nsamp, C::SAMPLES);
     const size_t lds = C::TOTAL;
-    static bool attr_set = false;
-    if (!attr_set) {
-        EVD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_voxel_mlp_pipe<PREC, 1, NT, FEAT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    EVD_SET_MAX_LDS((&k_voxel_mlp_pipe<PREC, 1, NT, FEAT>), lds);
     if (p.nchunks != N::NCH) return fail(EVD_E_INVALID, "evd_voxel: packed stream has %d chunks, kernel expects %d", p.nchunks, N::NCH);
     hipLaunchKernelGGL((k_voxel_mlp_pipe<PREC, 1, NT, FEAT>), dim3((unsigned)blocks), dim3(NT), lds, st, p);
     EVD_LAUNCH_CHECK();
