@@ -73,10 +73,17 @@ template <> struct POps<EVD_PREC_F16> {
     static __device__ __forceinline__ void mma(f32x16& acc, f32x16&, const A& a, const B& b, bool) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
     }
-    // ReLU and the float16 range guard are ONE v_med3_f32 per value
+    // The kernel sets MODE.FP16_OVFL (pipe_fp16_saturate(), tools/probes/fp16_ovfl_probe.hip): a conversion that overflows
+    // saturates to +-65504 instead of inf, so the float16 range guard costs nothing; ReLU is ONE v_pk_max_i16 on the
+    // packed pair (a negative float16 is a negative int16), as in the bf16 mode.
     template <bool RELU> static __device__ __forceinline__ void set_pair(B& b, int e, float x0, float x1) {
-        const f32x2 v = {__builtin_amdgcn_fmed3f(x0, RELU ? 0.f : -65000.f, 65000.f), __builtin_amdgcn_fmed3f(x1, RELU ? 0.f : -65000.f, 65000.f)};
-        b.w[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+        const f32x2 v = {x0, x1};
+        unsigned w = __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+        if (RELU) {
+            const s16x2 zero = {0, 0};
+            w = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, w), zero));
+        }
+        b.w[e] = w;
     }
 };
 
@@ -139,6 +146,12 @@ template <int PREC, int NS_, int NT_> struct PipeCfg {
     static constexpr int TOTAL = RING + BIAS_FLOATS * 4 + NW * STASH_PER_WAVE;
     static_assert(PIECES * NW * 1024 == CB && PD <= FPC, "ring geometry");
 };
+
+// MODE.FP16_OVFL = 1 for this wavefront (hwreg HW_REG_MODE = 1, bit 23, width 1): float16 results that overflow are
+// clamped to +-MAX_FP16 instead of becoming inf.  Called first thing by the kernels of the float16 mode.
+template <int PREC> __device__ __forceinline__ void pipe_fp16_saturate() {
+    if (PREC == EVD_PREC_F16) __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);
+}
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 

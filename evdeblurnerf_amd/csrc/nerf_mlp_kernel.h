@@ -101,6 +101,7 @@ __global__ __launch_bounds__(NT, NT / 256) void k_nerf_mlp(const MlpParams p) {
     constexpr int T = N::T, KS = N::KS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
+    pipe_fp16_saturate<PREC>();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, h = lane >> 5;
     NerfCtx<C, N, FEAT> cx;

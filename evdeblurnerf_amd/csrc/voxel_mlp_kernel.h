@@ -43,6 +43,7 @@ __global__ __launch_bounds__(NT, NT / 256) void k_voxel_mlp_pipe(const VoxMlpPar
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef PStream<C, FEAT, N::NCH> ST;
 
+    pipe_fp16_saturate<PREC>();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, h = lane >> 5;
     ST st;

@@ -586,3 +586,21 @@ def test_precision_modes_under_larger_weights():
     print("RGB L-inf vs the f32 kernel with 1.4x hidden weights:", {k: f"{v:.2e}" for k, v in err.items()})
     assert err["f16x3"] < 1e-4
     assert err["f16"] < 2e-3 and err["bf16"] < 1e-1 and err["f16"] < err["bf16"]
+
+
+def test_float16_modes_saturate_instead_of_overflowing():
+    """Activations beyond the float16 range: the f16 kernels run with MODE.FP16_OVFL (conversions saturate at +-65504) and
+    the split-float16 mode clamps at 65000, so a network whose first layer is scaled by 1e5 still yields finite outputs in
+    every mode (and the exact-f32 kernel, which has no such limit, stays the reference for small activations elsewhere)."""
+    from evdeblurnerf_amd.nerf import NeRF
+    sd = W.make_nerf_state_dict(29)
+    sd["pts_linears.0.weight"] = (sd["pts_linears.0.weight"] * 1e5).astype(np.float32)
+    rs = np.random.RandomState(4)
+    rb = np.zeros((512, 11), np.float32)
+    rb[:, 3:6] = rs.uniform(-1, 1, (512, 3))
+    rb[:, 7] = 1.0
+    rb[:, 8:11] = [0.0, 0.6, 0.8]
+    z = np.ones((512, 1), np.float32)
+    for prec in ("f16", "f16x3", "bf16", "f32"):
+        raw, _ = NeRF(sd, precision=prec).mlpforward(T(rb), T(z))
+        assert torch.isfinite(raw).all(), prec
