@@ -47,7 +47,7 @@ constexpr int VS_MAXC = 128;        // max sum(n_comp)
 //
 // Phase 1 (gather): work item = (sample, group of 4 channels); the 4 plane taps and 2 line taps of an item are
 // loaded BRANCH-FREE (out-of-range taps read a clamped address and get weight 0 -- the zero padding) and all items of
-// a thread are issued before the first use, so ~18 independent 16-byte loads per lane are in flight (the grids are
+// a thread are issued ahead of their use, 6-12 independent 8/16-byte loads per lane in flight at 4 wavefronts per SIMD (the grids are
 // far larger than L2: this phase is a random gather served by Infinity Cache / HBM).
 // Phase 2 (basis_mat, voxnerf.py:151): out^T[f, sample] = basis[f, :] . coef[sample, :] for the block's 32 samples on
 // the exact-float32 MFMA (v_mfma_f32_32x32x2_f32 = an fmaf chain in k order), by wavefront 0 of the block.
@@ -63,25 +63,32 @@ __device__ __forceinline__ f32x4 vs_load(const float* base32, const _Float16* ba
     return *reinterpret_cast<const f32x4*>(base32 + idx);
 }
 
+// pick one of three wave-uniform values by a per-lane index WITHOUT indexing the kernel-argument struct dynamically (that
+// turns every g.plane[i] / g.grid[..] into a dependent vector load from the argument buffer in front of the real loads)
+template <class V> __device__ __forceinline__ V sel3(int i, V a, V b, V c) { return i == 0 ? a : (i == 1 ? b : c); }
+
 template <bool HALF>
-__device__ __forceinline__ void vs_issue(const GridParams& g, const float* __restrict__ pts, long s, int grp, VsItem& it) {
-    const int mat0[3] = {0, 0, 1}, mat1[3] = {1, 2, 2}, vec[3] = {2, 1, 0};
+__device__ __forceinline__ void vs_issue(const GridParams& g, const float (&pt)[3], int grp, VsItem& it) {
+    // matMode = [[0,1],[0,2],[1,2]], vecMode = [2,1,0] (voxnerf.py:99-100)
     int i = 0, c4 = grp * 4;
     if (c4 >= g.n_comp[0]) { c4 -= g.n_comp[0]; i = 1; if (c4 >= g.n_comp[1]) { c4 -= g.n_comp[1]; i = 2; } }
     float xyz[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) xyz[c] = __fsub_rn(__fmul_rn(__fsub_rn(pts[s * 3 + c], g.aabb_min[c]), g.inv[c]), 1.f);   // voxnerf.py:205
-    const int C = g.n_comp[i];
-    const int Wp = g.grid[mat0[i]], Hp = g.grid[mat1[i]], Lp = g.grid[vec[i]];
-    const float ix = unnorm(xyz[mat0[i]], Wp), iy = unnorm(xyz[mat1[i]], Hp);
+    for (int c = 0; c < 3; ++c) xyz[c] = __fsub_rn(__fmul_rn(__fsub_rn(pt[c], g.aabb_min[c]), g.inv[c]), 1.f);   // voxnerf.py:205
+    const int C = sel3(i, g.n_comp[0], g.n_comp[1], g.n_comp[2]);
+    const int Wp = sel3(i, g.grid[0], g.grid[0], g.grid[1]);          // grid[mat0[i]]
+    const int Hp = sel3(i, g.grid[1], g.grid[2], g.grid[2]);          // grid[mat1[i]]
+    const int Lp = sel3(i, g.grid[2], g.grid[1], g.grid[0]);          // grid[vec[i]]
+    const float cx = sel3(i, xyz[0], xyz[0], xyz[1]), cy = sel3(i, xyz[1], xyz[2], xyz[2]), cl = sel3(i, xyz[2], xyz[1], xyz[0]);
+    const float ix = unnorm(cx, Wp), iy = unnorm(cy, Hp);
     // clamp far-away points before the float -> int conversion (everything beyond one cell outside is zero padding)
     const float fx = fminf(fmaxf(floorf(ix), -2.f), (float)Wp), fy = fminf(fmaxf(floorf(iy), -2.f), (float)Hp);
     const float ww = __fsub_rn(ix, floorf(ix)), ee = __fsub_rn(1.f, ww), nn = __fsub_rn(iy, floorf(iy)), ss = __fsub_rn(1.f, nn);
     const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
     const bool vx0 = x0 >= 0 && x0 < Wp, vx1 = x1 >= 0 && x1 < Wp, vy0 = y0 >= 0 && y0 < Hp, vy1 = y1 >= 0 && y1 < Hp;
     const int cx0 = min(max(x0, 0), Wp - 1), cx1 = min(max(x1, 0), Wp - 1), cy0 = min(max(y0, 0), Hp - 1), cy1 = min(max(y1, 0), Hp - 1);
-    const float* pl = g.plane[i] + c4;
-    const _Float16* plh = g.plane_h[i] + c4;
+    const float* pl = sel3(i, g.plane[0], g.plane[1], g.plane[2]) + c4;
+    const _Float16* plh = sel3(i, g.plane_h[0], g.plane_h[1], g.plane_h[2]) + c4;
     it.p[0] = vs_load<HALF>(pl, plh, ((long)cy0 * Wp + cx0) * C);
     it.p[1] = vs_load<HALF>(pl, plh, ((long)cy0 * Wp + cx1) * C);
     it.p[2] = vs_load<HALF>(pl, plh, ((long)cy1 * Wp + cx0) * C);
@@ -90,12 +97,12 @@ __device__ __forceinline__ void vs_issue(const GridParams& g, const float* __res
     it.wp[1] = (vy0 && vx1) ? __fmul_rn(ww, ss) : 0.f;
     it.wp[2] = (vy1 && vx0) ? __fmul_rn(ee, nn) : 0.f;
     it.wp[3] = (vy1 && vx1) ? __fmul_rn(ww, nn) : 0.f;
-    const float il = unnorm(xyz[vec[i]], Lp);
+    const float il = unnorm(cl, Lp);
     const float fl = fminf(fmaxf(floorf(il), -2.f), (float)Lp);
     const float ln = __fsub_rn(il, floorf(il)), ls = __fsub_rn(1.f, ln);
     const int l0 = (int)fl, l1 = l0 + 1;
-    const float* li = g.line[i] + c4;
-    const _Float16* lih = g.line_h[i] + c4;
+    const float* li = sel3(i, g.line[0], g.line[1], g.line[2]) + c4;
+    const _Float16* lih = sel3(i, g.line_h[0], g.line_h[1], g.line_h[2]) + c4;
     it.l[0] = vs_load<HALF>(li, lih, (long)min(max(l0, 0), Lp - 1) * C);
     it.l[1] = vs_load<HALF>(li, lih, (long)min(max(l1, 0), Lp - 1) * C);
     it.wl[0] = (l0 >= 0 && l0 < Lp) ? ls : 0.f;
@@ -132,15 +139,20 @@ __global__ __launch_bounds__(256) void k_voxel_sample(const GridParams g, const 
         VsItem it[UNR];
         int sl[UNR], grp[UNR];
         bool on[UNR];
+        float pt[UNR][3];
 #pragma unroll
-        for (int q = 0; q < UNR; ++q) {
+        for (int q = 0; q < UNR; ++q) {             // the points of all items first: the tap addresses depend on them
             const int t = base + q * 256;
             on[q] = t < items;
             sl[q] = on[q] ? t / ng : 0;
             grp[q] = on[q] ? t % ng : 0;
             const long s = s0 + sl[q] < n ? s0 + sl[q] : n - 1;
-            vs_issue<HALF>(g, pts, s, grp[q], it[q]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) pt[q][c] = pts[s * 3 + c];
         }
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) vs_issue<HALF>(g, pt[q], grp[q], it[q]);      // then all 18 tap loads in flight together
+        // (a sched_barrier here keeps all 18 loads of the thread in flight but costs a wavefront of occupancy: measured 6 % slower)
 #pragma unroll
         for (int q = 0; q < UNR; ++q) {
             const f32x4 cf = vs_finish(it[q]);

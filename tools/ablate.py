@@ -42,7 +42,8 @@ def run(variants, extra):
     for v in variants:
         print("==", v, flush=True)
         env = dict(os.environ, EVD_LIB_PATH=lib_of(v))
-        subprocess.call([sys.executable, os.path.join(ROOT, "tools", "bench_mlp.py"), *extra], env=env)
+        script = os.environ.get("EVD_ABLATE_BENCH", "bench_mlp.py")      # e.g. bench_c2f.py
+        subprocess.call([sys.executable, os.path.join(ROOT, "tools", script), *extra], env=env)
 
 
 if __name__ == "__main__":
