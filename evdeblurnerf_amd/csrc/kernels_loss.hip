@@ -22,15 +22,19 @@ __device__ __forceinline__ float crf_apply(const CrfParams& c, float v, const fl
     if (c.map_type == 0) return v;
     if (c.map_type == 1) v = powf(v, c.inv_gamma);
     if (!skip_learn && c.map_type == 2) {
+        // every index into the parameter block is a compile-time constant (w0 rows are padded to CRF_MAX_IN): the weights
+        // stay scalar loads from the kernel-argument buffer.  (A runtime-strided w0[j * nin + k] made hipcc copy the whole
+        // 2.4 KB block to scratch, per lane.)
         float in[CRF_MAX_IN];
         in[0] = v;
-        for (int e = 0; e < c.E; ++e) in[1 + e] = feat ? feat[e] : 0.f;
+#pragma unroll
+        for (int e = 1; e < CRF_MAX_IN; ++e) in[e] = (feat && e - 1 < c.E) ? feat[e - 1] : 0.f;
         float h[16], h2[16];
-        const int nin = 1 + c.E;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             float s = c.b0[j];
-            for (int k = 0; k < nin; ++k) s = fmaf(c.w0[j * nin + k], in[k], s);
+#pragma unroll
+            for (int k = 0; k < CRF_MAX_IN; ++k) s = fmaf(c.w0[j * CRF_MAX_IN + k], in[k], s);   // padded columns are zero
             h[j] = fmaxf(s, 0.f);
         }
 #pragma unroll
@@ -353,7 +357,8 @@ int evd_crf_create(const evd_crf_desc* d, evd_crf** out) {
         for (int k = 0; k < 4; ++k)
             if (!d->w[k] || !d->b[k]) { delete c; return fail(EVD_E_INVALID, "evd_crf_create: learn CRF needs 4 weight/bias pairs"); }
         const int nin = 1 + d->extra_features;
-        memcpy(c->p.w0, d->w[0], sizeof(float) * 16 * nin);
+        memset(c->p.w0, 0, sizeof(c->p.w0));
+        for (int j = 0; j < 16; ++j) memcpy(c->p.w0 + j * CRF_MAX_IN, d->w[0] + j * nin, sizeof(float) * nin);    // rows padded to CRF_MAX_IN
         memcpy(c->p.b0, d->b[0], sizeof(float) * 16);
         memcpy(c->p.w1, d->w[1], sizeof(float) * 256);
         memcpy(c->p.b1, d->b[1], sizeof(float) * 16);
