@@ -450,6 +450,118 @@ __global__ __launch_bounds__(256) void k_composite_rows(const float* __restrict_
     }
 }
 
+// derivative of evd::act / act_fast at x (y = the activation's value where that is cheaper)
+__device__ __forceinline__ float act_grad(int code, float x) {
+    switch (code) {
+    case EVD_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+    case EVD_ACT_SIGMOID: { const float y = 1.f / (1.f + expf(-x)); return y * (1.f - y); }
+    case EVD_ACT_EXP: return expf(x);
+    case EVD_ACT_SIGMOID1: { const float y = 1.f / (expf(-x) + 1.f); return 1.002f * y * (1.f - y); }
+    case EVD_ACT_SOFTPLUS: { const float t = x - 1.f; return t > 20.f ? 1.f : 1.f / (1.f + expf(-t)); }
+    case EVD_ACT_TANH: { const float y = tanhf(x); return 1.f - y * y; }
+    default: return 1.f;
+    }
+}
+
+__device__ __forceinline__ float wave_scan_add_dpp(float v) {
+    v += dpp_f32<0x111>(0.f, v);
+    v += dpp_f32<0x112>(0.f, v);
+    v += dpp_f32<0x114>(0.f, v);
+    v += dpp_f32<0x118>(0.f, v);
+    v += dpp_f32<0x142, 0xa>(0.f, v);
+    v += dpp_f32<0x143, 0xc>(0.f, v);
+    return v;
+}
+
+// Backward of raw2outputs ("next" row f-1, first slice): d raw from the gradients of (out_map, depth, acc, weights).
+// Same decomposition as k_composite_rows (a wavefront per ray, SPL consecutive samples per lane); the forward quantities
+// are recomputed.  With G_i = dL/dw_i = g_map . rgb_i + g_depth z_i + g_acc + g_w_i (- sum g_map for a white background):
+//   dL/d rgb_i = g_map w_i,      dL/d sigma_i = dist_i (G_i T_{i+1} - sum_{j>i} G_j w_j)      (no division: T_i (1 - alpha_i) = T_{i+1})
+// the suffix sum is total - inclusive prefix (one DPP add scan); the last sample's alpha is the constant 1.
+template <int SPL>
+__global__ __launch_bounds__(256) void k_composite_rows_bwd(const float* __restrict__ raw, const float* __restrict__ z,
+                                                            const float* __restrict__ rays_d, int rd_stride, long R, int S,
+                                                            int sigma_ch, int rgb_ch0, int rgb_act, int sigma_act, int white_bkgd,
+                                                            float rmnear, const float* __restrict__ noise,
+                                                            const float* __restrict__ g_map, const float* __restrict__ g_depth,
+                                                            const float* __restrict__ g_acc, const float* __restrict__ g_w,
+                                                            float* __restrict__ d_raw) {
+    const int lane = threadIdx.x & 63;
+    const long r = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int i0 = lane * SPL;
+    const float4* rw = reinterpret_cast<const float4*>(raw + r * (long)S * 4);
+    const float* zz = z + r * (long)S;
+    float4 v[SPL];
+    float zi[SPL + 1], gw[SPL];
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) {
+        const int i = min(i0 + j, S - 1);
+        v[j] = rw[i];
+        zi[j] = zz[i];
+        gw[j] = g_w ? g_w[r * (long)S + i] : 0.f;
+    }
+    const float* d = rays_d + r * rd_stride;
+    const float norm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
+    const float gm[3] = {g_map ? g_map[r * 3] : 0.f, g_map ? g_map[r * 3 + 1] : 0.f, g_map ? g_map[r * 3 + 2] : 0.f};
+    const float gd = g_depth ? g_depth[r] : 0.f;
+    const float ga = (g_acc ? g_acc[r] : 0.f) - (white_bkgd ? gm[0] + gm[1] + gm[2] : 0.f);
+    zi[SPL] = dpp_f32<0x130>(0.f, zi[0]);
+    float alpha[SPL], om[SPL], dist[SPL], spre[SPL], mask[SPL];
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) {
+        const int i = i0 + j;
+        const float vv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+        dist[j] = 0.f; spre[j] = 0.f; mask[j] = 1.f;
+        if (i < S - 1) {
+            dist[j] = __fmul_rn(__fsub_rn(zi[j + 1], zi[j]), norm);
+            spre[j] = vv[sigma_ch] + (noise ? noise[r * (long)(S - 1) + i] : 0.f);
+            float dens = act(sigma_act, spre[j]);
+            if (rmnear > 0.f) { mask[j] = zi[j + 1] > rmnear ? 1.f : 0.f; dens *= mask[j]; }
+            alpha[j] = __fadd_rn(-expf(-__fmul_rn(dens, dist[j])), 1.f);
+        } else {
+            alpha[j] = i == S - 1 ? 1.f : 0.f;
+        }
+        om[j] = i < S ? __fadd_rn(-alpha[j], 1.f) : 1.f;
+    }
+    float local = om[0];
+#pragma unroll
+    for (int j = 1; j < SPL; ++j) local *= om[j];
+    const float incl = wave_scan_mul_dpp(local);
+    float T = dpp_f32<0x138>(1.f, incl);
+    float w[SPL], G[SPL], Tn[SPL], rgbv[SPL][3], lsum = 0.f;
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) {
+        const float vv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+        w[j] = (i0 + j < S) ? alpha[j] * T : 0.f;
+        T *= om[j];
+        Tn[j] = T;                                          // T_{i+1}
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rgbv[j][c] = act(rgb_act, vv[rgb_ch0 + c]);
+        G[j] = gm[0] * rgbv[j][0] + gm[1] * rgbv[j][1] + gm[2] * rgbv[j][2] + gd * zi[j] + ga + gw[j];
+        lsum += G[j] * w[j];
+    }
+    const float pre_incl = wave_scan_add_dpp(lsum);          // inclusive prefix of the lanes' sums of G w
+    const float total = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pre_incl), 63));
+    float run = pre_incl - lsum;                             // exclusive prefix at this lane's first sample
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) {
+        const int i = i0 + j;
+        run += G[j] * w[j];
+        if (i < S) {
+            const float vv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+            float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[rgb_ch0 + c] = gm[c] * w[j] * act_grad(rgb_act, vv[rgb_ch0 + c]);
+            if (i < S - 1) {
+                const float suffix = total - run;            // sum_{j > i} G_j w_j
+                o[sigma_ch] = dist[j] * (G[j] * Tn[j] - suffix) * mask[j] * act_grad(sigma_act, spre[j]);
+            }
+            reinterpret_cast<float4*>(d_raw + r * (long)S * 4)[i] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
 // out[r, f] = sum_s w[r, s] * x[r, s, ch0 + f] (optionally through an activation): used for n_rgb != 3 colour
 // maps (PBE 15-channel features, voxnerf.py:226) and for feature compositing (nerf.py:119).  One block per ray.
 __global__ void k_weighted_channels(const float* __restrict__ x, const float* __restrict__ w, long R, int S, int Cx, int ch0,
@@ -660,6 +772,27 @@ int evd_raw2outputs(const float* raw, const float* z, const float* rays_d, int r
         k_weighted_channels<<<R, F >= 256 ? 256 : 64, 0, st>>>(feature, weights, R, S, F, 0, F, EVD_ACT_NONE, 0, fmap);
         EVD_LAUNCH_CHECK();
     }
+    return EVD_OK;
+}
+
+int evd_raw2outputs_bwd(const float* raw, const float* z, const float* rays_d, int rays_d_stride, long R, int S, int C,
+                        int sigma_ch, int rgb_ch0, int n_rgb, int rgb_act, int sigma_act, int white_bkgd, float rmnear_thresh,
+                        const float* noise, const float* g_map, const float* g_depth, const float* g_acc, const float* g_weights,
+                        float* d_raw, void* stream) {
+    EVD_REQUIRE(raw && z && rays_d && d_raw && R >= 0 && S >= 1, "evd_raw2outputs_bwd: bad arguments");
+    EVD_REQUIRE(C == 4 && n_rgb == 3 && S <= 256, "evd_raw2outputs_bwd: built for [R,S,4] raw with three colour channels and S <= 256 (got C=%d n_rgb=%d S=%d)", C, n_rgb, S);
+    EVD_REQUIRE(sigma_ch >= 0 && sigma_ch < 4 && rgb_ch0 >= 0 && rgb_ch0 + 3 <= 4 && (sigma_ch < rgb_ch0 || sigma_ch >= rgb_ch0 + 3),
+                "evd_raw2outputs_bwd: channel layout out of range");
+    if (R == 0) return EVD_OK;
+    hipStream_t st = as_stream(stream);
+#define EVD_BWD(SPL) k_composite_rows_bwd<SPL><<<cdiv(R, 4), 256, 0, st>>>(raw, z, rays_d, rays_d_stride, R, S, sigma_ch, rgb_ch0, rgb_act, sigma_act, \
+                                                                          white_bkgd, rmnear_thresh, noise, g_map, g_depth, g_acc, g_weights, d_raw)
+    if (S <= 64) EVD_BWD(1);
+    else if (S <= 128) EVD_BWD(2);
+    else if (S <= 192) EVD_BWD(3);
+    else EVD_BWD(4);
+#undef EVD_BWD
+    EVD_LAUNCH_CHECK();
     return EVD_OK;
 }
 

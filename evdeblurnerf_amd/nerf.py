@@ -20,6 +20,41 @@ def _np32(v):
     return np.ascontiguousarray(v, dtype=np.float32)
 
 
+class _Raw2Outputs(torch.autograd.Function):
+    """raw2outputs as an autograd node (C = 4, three colours): forward = evd_raw2outputs, backward = evd_raw2outputs_bwd
+    (the forward quantities are recomputed in the backward kernel; z / rays_d get no gradient, as in the reference where
+    the sample positions are detached)."""
+
+    @staticmethod
+    def forward(ctx, raw, z, rd, noise, sigma_ch, rgb_ch0, rgb_act, sigma_act, white_bkgd, thr):
+        R, S, Cc = raw.shape
+        dev = raw.device
+        rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
+        dens = torch.empty((R, S - 1), dtype=torch.float32, device=dev)
+        acc = torch.empty((R,), dtype=torch.float32, device=dev)
+        wts = torch.empty((R, S), dtype=torch.float32, device=dev)
+        depth = torch.empty((R,), dtype=torch.float32, device=dev)
+        L.check(L.lib().evd_raw2outputs(L.ptr(raw), L.ptr(z), L.ptr(rd), rd.shape[-1], R, S, Cc, sigma_ch, rgb_ch0, 3, rgb_act, sigma_act,
+                                        int(bool(white_bkgd)), thr, L.ptr(noise), L.ptr(rgb), L.ptr(dens), L.ptr(acc), L.ptr(wts),
+                                        L.ptr(depth), None, 0, None, L.stream_ptr()), "evd_raw2outputs")
+        ctx.save_for_backward(raw, z, rd, noise if noise is not None else torch.empty(0, device=dev))
+        ctx.cfg = (sigma_ch, rgb_ch0, rgb_act, sigma_act, int(bool(white_bkgd)), thr, noise is not None)
+        ctx.mark_non_differentiable(dens)
+        return rgb, dens, acc, wts, depth
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_dens, g_acc, g_wts, g_depth):
+        raw, z, rd, noise = ctx.saved_tensors
+        sigma_ch, rgb_ch0, rgb_act, sigma_act, white, thr, has_noise = ctx.cfg
+        R, S, Cc = raw.shape
+        c = lambda g: g.contiguous().float() if g is not None else None
+        d_raw = torch.empty_like(raw)
+        L.check(L.lib().evd_raw2outputs_bwd(L.ptr(raw), L.ptr(z), L.ptr(rd), rd.shape[-1], R, S, Cc, sigma_ch, rgb_ch0, 3, rgb_act, sigma_act,
+                                            white, thr, L.ptr(noise) if has_noise else None, L.ptr(c(g_rgb)), L.ptr(c(g_depth)),
+                                            L.ptr(c(g_acc)), L.ptr(c(g_wts)), L.ptr(d_raw), L.stream_ptr()), "evd_raw2outputs_bwd")
+        return (d_raw,) + (None,) * 9
+
+
 class NeRF:
     """One reference ``NeRF`` (D x W MLP, skip, view branch) with packed MFMA weight streams on the GPU."""
 
@@ -107,6 +142,11 @@ class NeRF:
         ft = feature.contiguous().float() if feature is not None else None
         thr = float(self.render_rmnearplane) / 128.0 if (not self.training and self.render_rmnearplane > 0) else 0.0
         nz = noise.contiguous().float() if noise is not None else None
+        if raw.requires_grad and torch.is_grad_enabled() and feature is None and Cc == 4:
+            # training through the compositing scan: autograd node backed by evd_raw2outputs_bwd
+            rgb, dens, acc, wts, depth = _Raw2Outputs.apply(raw, z, rd, nz, 3, 0, L.ACT[self.rgb_activate], L.ACT[self.sigma_activate],
+                                                            white_bkgd, thr)
+            return rgb, dens, acc, wts, depth, None
         L.check(L.lib().evd_raw2outputs(L.ptr(raw), L.ptr(z), L.ptr(rd), rd.shape[-1], R, S, Cc, 3, 0, 3,
                                         L.ACT[self.rgb_activate], L.ACT[self.sigma_activate], int(bool(white_bkgd)),
                                         thr, L.ptr(nz), L.ptr(rgb), L.ptr(dens), L.ptr(acc), L.ptr(wts), L.ptr(depth),

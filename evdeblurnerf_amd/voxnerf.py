@@ -78,6 +78,21 @@ class VoxelNeRFBase:
         self.training = mode
         return self
 
+    # voxnerf.py:153-201; returns the reference 5-tuple (rgb_map, density, acc_map, weights, depth_map).  Sigma is channel 0, the
+    # (already sigmoided) colour channels 1..3 (:172,179); rgb_activate is relu (coarse level) or none (fine level).
+    def raw2outputs(self, raw, z_vals, rays_d, raw_noise_std=0., is_train=False, noise=None):
+        from .nerf import _Raw2Outputs
+        raw, z, rd = raw.contiguous().float(), z_vals.contiguous().float(), rays_d.contiguous().float()
+        R, S, Cc = raw.shape
+        if Cc != 4:
+            raise NotImplementedError("composite_feature=True (PBE, 16-channel raw) is not built; shipped configs use RBK")
+        if raw_noise_std > 0. and noise is None:
+            noise = torch.randn((R, S - 1), dtype=torch.float32, device=raw.device) * raw_noise_std
+        nz = noise.contiguous().float() if noise is not None else None
+        thr = float(self.render_rmnearplane) / 128.0 if (not is_train and self.render_rmnearplane > 0) else 0.0
+        rgb, dens, acc, wts, depth = _Raw2Outputs.apply(raw, z, rd, nz, 0, 1, L.ACT[self.rgb_activate], L.ACT[self.sigma_activate], False, thr)
+        return rgb, dens, acc, wts, depth
+
     # voxnerf.py:203-208
     def sample(self, pts):
         sh = pts.shape

@@ -124,6 +124,15 @@ int evd_raw2outputs(const float* raw, const float* z, const float* rays_d, int r
                     float* out_map, float* density, float* acc, float* weights, float* depth,
                     const float* feature, int F, float* fmap, void* stream);
 
+/* Backward of evd_raw2outputs (first slice of the training path; torch autograd provides this in the reference):
+ * g_map dev [R,3], g_depth dev [R], g_acc dev [R], g_weights dev [R,S] = dL/d(out_map, depth, acc, weights), any may be
+ * NULL (= zero) -> d_raw dev [R,S,4] = dL/d raw.  z and rays_d are sampling inputs and get no gradient (sample_pdf is
+ * detached in the reference, renderer.py:201).  Built for C = 4, n_rgb = 3, S <= 256. */
+int evd_raw2outputs_bwd(const float* raw, const float* z, const float* rays_d, int rays_d_stride, long R, int S, int C,
+                        int sigma_ch, int rgb_ch0, int n_rgb, int rgb_act, int sigma_act, int white_bkgd, float rmnear_thresh,
+                        const float* noise, const float* g_map, const float* g_depth, const float* g_acc, const float* g_weights,
+                        float* d_raw, void* stream);
+
 /* sample_pdf, utils/rays.py:149-193, called as in renderer.py:200-201,230-231 with bins = z_mid and
  * weights[...,1:-1]: z dev [R,S], weights dev [R,S] -> z_samples dev [R,N].  det != 0 => u = linspace;
  * else u dev [R,N].  Also returns, fused: z_merged dev [R,S+N] = sort(cat(z, z_samples)) (renderer.py:205,234),
