@@ -125,11 +125,13 @@ template <> struct POps<EVD_PREC_F32> {
 };
 
 // ---------------------------------------------------------------------------------------------
-template <int PREC, int NS_, int NT_> struct PipeCfg {
+// CB_: chunk bytes of the LDS ring (the packed streams are padded to PIPE_CB = 16 KiB; every layer of the built networks is a
+// whole number of 8 KiB chunks too, so a kernel may walk the same stream in 8 KiB chunks: half the ring, two workgroups per CU)
+template <int PREC, int NS_, int NT_, int CB_ = PIPE_CB> struct PipeCfg {
     typedef POps<PREC> O;
     static constexpr int PRECISION = PREC, NS = NS_, NT = NT_, NW = NT_ / 64;
     static constexpr int FB = frag_bytes(PREC);
-    static constexpr int CB = PIPE_CB;
+    static constexpr int CB = CB_;
     static constexpr int FPC = CB / FB;
     static constexpr int NSLOT = 4;
     static constexpr int PIECES = CB / 1024 / NW;        // 1 KiB DMA pieces per wavefront per chunk

@@ -33,9 +33,9 @@ template <class C, bool FEAT> struct VoxFineNet {
     static_assert(F1 % PD == 0 && F3 % PD == 0 && F4 % PD == 0, "prefetch ring phase");
 };
 
-template <int PREC, int NS, int NT, bool FEAT>
-__global__ __launch_bounds__(NT, NT / 256) void k_voxel_mlp_pipe(const VoxMlpParams p) {
-    typedef PipeCfg<PREC, NS, NT> C;
+template <int PREC, int NS, int NT, bool FEAT, int CB, int OCC>
+__global__ __launch_bounds__(NT, OCC) void k_voxel_mlp_pipe(const VoxMlpParams p) {
+    typedef PipeCfg<PREC, NS, NT, CB> C;
     typedef typename C::O O;
     typedef typename O::B B;
     typedef VoxFineNet<C, FEAT> N;
@@ -126,16 +126,21 @@ __global__ __launch_bounds__(NT, NT / 256) void k_voxel_mlp_pipe(const VoxMlpPar
     }
 }
 
+// (Measured and dropped: 256-thread workgroups walking the same stream in 8 KiB chunks -- 72 KiB of LDS, two workgroups per CU
+// overlapping each other's prologue and barrier waits -- run 1 % slower: the overlap is paid back by twice the L2 -> LDS weight
+// traffic and DMA issue.  PipeCfg keeps the chunk size as a parameter.)
 template <int PREC, bool FEAT>
 static int launch_voxel_pipe(const VoxMlpParams& p, hipStream_t st) {
-    constexpr int NT = is_half_prec(PREC) ? 512 : 256;      // two wavefronts per SIMD where the B fragments are 4 registers
+    constexpr bool half = is_half_prec(PREC);
+    constexpr int NT = half ? 512 : 256;      // the split-float16 B fragments need the whole register file: one wavefront per SIMD
+    constexpr int OCC = half ? 2 : 1;
     typedef PipeCfg<PREC, 1, NT> C;
     typedef VoxFineNet<C, FEAT> N;
     const long blocks = cdiv(p.nsamp, C::SAMPLES);
     const size_t lds = C::TOTAL;
-    EVD_SET_MAX_LDS((&k_voxel_mlp_pipe<PREC, 1, NT, FEAT>), lds);
+    EVD_SET_MAX_LDS((&k_voxel_mlp_pipe<PREC, 1, NT, FEAT, PIPE_CB, OCC>), lds);
     if (p.nchunks != N::NCH) return fail(EVD_E_INVALID, "evd_voxel: packed stream has %d chunks, kernel expects %d", p.nchunks, N::NCH);
-    hipLaunchKernelGGL((k_voxel_mlp_pipe<PREC, 1, NT, FEAT>), dim3((unsigned)blocks), dim3(NT), lds, st, p);
+    hipLaunchKernelGGL((k_voxel_mlp_pipe<PREC, 1, NT, FEAT, PIPE_CB, OCC>), dim3((unsigned)blocks), dim3(NT), lds, st, p);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }
