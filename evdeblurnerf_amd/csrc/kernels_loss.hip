@@ -163,6 +163,55 @@ __global__ __launch_bounds__(256) void k_blur_loss(const CrfParams crf, int skip
     if (threadIdx.x == 0) atomicAdd(partial + 5, n);
 }
 
+// d crf(x) / dx for the non-learnable response curves (identity, gamma): tonemapping.py:64-68
+__device__ __forceinline__ float crf_grad_simple(const CrfParams& c, float x) {
+    if (c.map_type == 1) return c.inv_gamma * powf(x, c.inv_gamma - 1.f);
+    return 1.f;
+}
+
+// Backward of k_blur_loss ("next" row f-1, slice): with g[k] = dL/d partial[k] (k = 0..4) and a = sum_p w1 rgb_p etc.
+//   d a = 2 g0 (crf(a) - t) crf'(a),  d b = 2 g1 (..rgb0..),  d c = 2 g2 (..w2..),  pts0 terms act on p = 0;
+//   d rgb_p[p] = d a w1[p] + d c w2[p],   d rgb0_p[p] = d b w1[p],   d w1[p] = d a . rgb_p[p] + d b . rgb0_p[p],   d w2[p] = d c . rgb_p[p].
+// One lane per (pixel, channel); d w1 / d w2 sum the three channels of a pixel with two DPP adds inside the lane triple... the
+// triples straddle wavefront rows, so the channel sum goes through atomicAdd on the zero-initialised outputs instead.
+__global__ __launch_bounds__(64) void k_blur_loss_bwd(const CrfParams crf, int skip_learn, const float* __restrict__ rgb_p,
+                                                      const float* __restrict__ rgb0_p, const float* __restrict__ w1,
+                                                      const float* __restrict__ w2, const float* __restrict__ tgt,
+                                                      const float* __restrict__ tgt0, long R, int P, float g0, float g1, float g2,
+                                                      float g3, float g4, float* __restrict__ d_rgb_p, float* __restrict__ d_rgb0_p,
+                                                      float* __restrict__ d_w1, float* __restrict__ d_w2) {
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const long r = idx / 3;
+    const int ch = (int)(idx % 3);
+    if (r >= R) return;
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (int p = 0; p < P; ++p) {
+        const float wa = w1[r * P + p], wb = w2 ? w2[r * P + p] : 0.f;
+        const float f = rgb_p[(r * P + p) * 3 + ch];
+        a += f * wa;
+        c += f * wb;
+        if (rgb0_p) b += rgb0_p[(r * P + p) * 3 + ch] * wa;
+    }
+    const float t = tgt[r * 3 + ch];
+    const float da = 2.f * g0 * (crf_apply(crf, a, nullptr, skip_learn) - t) * crf_grad_simple(crf, a);
+    const float db = rgb0_p ? 2.f * g1 * (crf_apply(crf, b, nullptr, skip_learn) - t) * crf_grad_simple(crf, b) : 0.f;
+    const float dc = w2 ? 2.f * g2 * (crf_apply(crf, c, nullptr, skip_learn) - t) * crf_grad_simple(crf, c) : 0.f;
+    for (int p = 0; p < P; ++p) {
+        const long q = r * P + p;
+        const float f = rgb_p[q * 3 + ch], f0 = rgb0_p ? rgb0_p[q * 3 + ch] : 0.f;
+        float dr = da * w1[q] + (w2 ? dc * w2[q] : 0.f), dr0 = db * w1[q];
+        if (p == 0 && tgt0) {                           // pts0 / EDI-prior terms on the p = 0 render (renderer.py:374)
+            const float t0 = tgt0[r * 3 + ch];
+            dr += 2.f * g3 * (crf_apply(crf, f, nullptr, skip_learn) - t0) * crf_grad_simple(crf, f);
+            if (rgb0_p) dr0 += 2.f * g4 * (crf_apply(crf, f0, nullptr, skip_learn) - t0) * crf_grad_simple(crf, f0);
+        }
+        d_rgb_p[q * 3 + ch] = dr;
+        if (d_rgb0_p) d_rgb0_p[q * 3 + ch] = dr0;
+        if (d_w1) atomicAdd(d_w1 + q, da * f + db * f0);
+        if (d_w2 && w2) atomicAdd(d_w2 + q, dc * f);
+    }
+}
+
 // spec: run_nerf.py:518-570 + utils/events.py:260-284.  The learnable event-CRF (a 1+E -> 16 -> 16 -> 16 -> 1 MLP per
 // colour value, ~650 FMAs) is evaluated 12 times per event (start/end x fine/coarse x 3 channels): one LANE per
 // evaluation, 16 lanes per event (lane = 4 which + channel, channel 3 idle), the luma / log-difference assembled with
@@ -389,6 +438,21 @@ int evd_blur_loss_reduce(const evd_crf* crf_rgb, int skip_learn, const float* rg
     if (R == 0) return EVD_OK;
     k_blur_loss<<<cdiv(3 * R, 64), 64, 0, as_stream(stream)>>>(crf_rgb->p, skip_learn, rgb_p, rgb0_p, w1, w2, tgt, tgt0, R, P, partial,
                                                              out_rgb, out_rgb1, out_awp);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+int evd_blur_loss_bwd(const evd_crf* crf_rgb, int skip_learn, const float* rgb_p, const float* rgb0_p, const float* w1, const float* w2,
+                      const float* tgt, const float* tgt0, long R, int P, const float* g_partial, float* d_rgb_p, float* d_rgb0_p,
+                      float* d_w1, float* d_w2, void* stream) {
+    EVD_REQUIRE(crf_rgb && rgb_p && w1 && tgt && g_partial && d_rgb_p && R >= 0 && P >= 1, "evd_blur_loss_bwd: bad arguments");
+    EVD_REQUIRE(crf_rgb->p.map_type != 2 || skip_learn, "evd_blur_loss_bwd: learnable CRF on the image branch is not built (shipped configs: gamma / none)");
+    if (R == 0) return EVD_OK;
+    hipStream_t st = as_stream(stream);
+    if (d_w1) EVD_HIP(hipMemsetAsync(d_w1, 0, sizeof(float) * (size_t)R * P, st));
+    if (d_w2) EVD_HIP(hipMemsetAsync(d_w2, 0, sizeof(float) * (size_t)R * P, st));
+    k_blur_loss_bwd<<<cdiv(3 * R, 64), 64, 0, st>>>(crf_rgb->p, skip_learn, rgb_p, rgb0_p, w1, w2, tgt, tgt0, R, P, g_partial[0], g_partial[1],
+                                                    g_partial[2], g_partial[3], g_partial[4], d_rgb_p, rgb0_p ? d_rgb0_p : nullptr, d_w1, d_w2);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }

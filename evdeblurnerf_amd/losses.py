@@ -55,6 +55,41 @@ def blur_loss_partials(crf_rgb, rgb_p, w1, target, rgb0_p=None, w2=None, target_
     return partial, cols
 
 
+class _BlurLoss(torch.autograd.Function):
+    """blur_loss_partials as an autograd node: forward = evd_blur_loss_reduce, backward = evd_blur_loss_bwd (gradients for the
+    sub-exposure colours and for the RBK / AWP composition weights; identity / gamma response curve)."""
+
+    @staticmethod
+    def forward(ctx, crf_rgb, skip_learn, rgb_p, rgb0_p, w1, w2, target, target_pts0):
+        partial, _ = blur_loss_partials(crf_rgb, rgb_p.detach(), w1.detach(), target, rgb0_p=None if rgb0_p is None else rgb0_p.detach(),
+                                        w2=None if w2 is None else w2.detach(), target_pts0=target_pts0, skip_learn_crf=skip_learn)
+        ctx.crf, ctx.skip = crf_rgb, bool(skip_learn)
+        ctx.save_for_backward(*[t if t is not None else torch.empty(0, device=w1.device) for t in (rgb_p, rgb0_p, w1, w2, target, target_pts0)])
+        ctx.has = [t is not None for t in (rgb_p, rgb0_p, w1, w2, target, target_pts0)]
+        return partial
+
+    @staticmethod
+    def backward(ctx, g_partial):
+        ts = [t.contiguous().float() if h else None for t, h in zip(ctx.saved_tensors, ctx.has)]
+        rgb_p, rgb0_p, w1, w2, target, target_pts0 = ts
+        R, P = w1.shape
+        g = np.ascontiguousarray(g_partial.detach().float().cpu().numpy()[:5], dtype=np.float32)     # 5 scalars: one small D2H copy
+        d_rgb = torch.empty_like(rgb_p)
+        d_rgb0 = torch.empty_like(rgb0_p) if rgb0_p is not None else None
+        d_w1 = torch.empty_like(w1)
+        d_w2 = torch.empty_like(w2) if w2 is not None else None
+        L.check(L.lib().evd_blur_loss_bwd(ctx.crf.handle, int(ctx.skip), L.ptr(rgb_p), L.ptr(rgb0_p), L.ptr(w1), L.ptr(w2), L.ptr(target),
+                                          L.ptr(target_pts0), R, P, g.ctypes.data_as(C.POINTER(C.c_float)), L.ptr(d_rgb), L.ptr(d_rgb0),
+                                          L.ptr(d_w1), L.ptr(d_w2), L.stream_ptr()), "evd_blur_loss_bwd")
+        return None, None, d_rgb, d_rgb0, d_w1, d_w2, None, None
+
+
+def blur_loss_partials_autograd(crf_rgb, rgb_p, w1, target, rgb0_p=None, w2=None, target_pts0=None, skip_learn_crf=False):
+    """Differentiable form of blur_loss_partials (rgb_p [R,P,3], rgb0_p, w1 [R,P], w2 may require grad); returns the [8] partials."""
+    c = lambda t: t.contiguous().float() if t is not None else None
+    return _BlurLoss.apply(crf_rgb, skip_learn_crf, c(rgb_p), c(rgb0_p), c(w1), c(w2), c(target), c(target_pts0))
+
+
 def blur_loss_from_partials(p, fine_loss_weight=None, w_pts0=0.0):
     """Assemble run_nerf.py:451-497 from the (all-reduced) partial vector. Returns (loss, dict of terms)."""
     n = p[5]

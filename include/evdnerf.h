@@ -233,6 +233,12 @@ int evd_blur_loss_reduce(const evd_crf* crf_rgb, int skip_learn, const float* rg
                          const float* w1, const float* w2, const float* tgt, const float* tgt0, long R, int P,
                          float* partial, float* out_rgb, float* out_rgb1, float* out_awp, void* stream);
 
+/* Backward of evd_blur_loss_reduce (identity / gamma response on the image branch, as in every shipped config):
+ * g_partial host[5] = dL/d partial[0..4] -> d_rgb_p, d_rgb0_p dev [R,P,3] (d_rgb0_p may be NULL), d_w1, d_w2 dev [R,P] or NULL. */
+int evd_blur_loss_bwd(const evd_crf* crf_rgb, int skip_learn, const float* rgb_p, const float* rgb0_p, const float* w1, const float* w2,
+                      const float* tgt, const float* tgt0, long R, int P, const float* g_partial, float* d_rgb_p, float* d_rgb0_p,
+                      float* d_w1, float* d_w2, void* stream);
+
 /* Fused event-loss reduction (spec: run_nerf.py:518-570, utils/events.py:260-284):
  *   bii = thr_neg*cum_neg + thr_pos*cum_pos;  feat = (cum_neg, cum_pos) per event ("pos-neg") or scattered to the
  *   event's colour channel ("color-pos-neg", color_mask != NULL); luma = CRF_event(rgb) -> rec601 luma, or the

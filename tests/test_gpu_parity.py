@@ -710,3 +710,41 @@ def test_training_through_the_fused_scan_reduces_the_loss():
         losses.append(float(loss.detach()))
     print(f"loss through the fused scan: {losses[0]:.4f} -> {losses[-1]:.4f}")
     assert losses[-1] < 0.2 * losses[0]
+
+
+@pytest.mark.parametrize("crf_kind,with_all", [("gamma", True), ("none", True), ("gamma", False)])
+def test_blur_loss_backward_matches_torch_autograd(crf_kind, with_all):
+    """Backward of the fused blur-loss reduction against torch autograd of a plain-torch restatement of run_nerf.py:443-497
+    (float64): gradients of the assembled image loss w.r.t. the sub-exposure colours and both sets of composition weights."""
+    from evdeblurnerf_amd.losses import blur_loss_partials_autograd, blur_loss_from_partials
+    from evdeblurnerf_amd.tonemapping import CRF
+    rs = np.random.RandomState(31)
+    R, P = 257, 10
+    mk = lambda *sh: torch.as_tensor(rs.uniform(0.05, 0.95, sh).astype(np.float32), device=DEV)
+    rgb_p, rgb0_p, tgt, tgt0 = mk(R, P, 3), mk(R, P, 3), mk(R, 3), mk(R, 3)
+    w1, w2 = torch.softmax(T(rs.standard_normal((R, P)).astype(np.float32)), -1), torch.softmax(T(rs.standard_normal((R, P)).astype(np.float32)), -1)
+    crf = CRF(crf_kind)
+    leaves = [t.clone().requires_grad_(True) for t in (rgb_p, rgb0_p, w1, w2)]
+    kw = dict(rgb0_p=leaves[1], w2=leaves[3], target_pts0=tgt0) if with_all else {}
+    p = blur_loss_partials_autograd(crf, leaves[0], leaves[2], tgt, **kw)
+    loss, _ = blur_loss_from_partials(p, fine_loss_weight=0.3 if with_all else None, w_pts0=0.2)
+    loss.backward()
+    ref_leaves = [t.double().clone().requires_grad_(True) for t in (rgb_p, rgb0_p, w1, w2)]
+    a, b, w1d, w2d = ref_leaves
+    f = (lambda x: x ** (1.0 / 2.2)) if crf_kind == "gamma" else (lambda x: x)
+    mse = lambda x, y: ((f(x) - y.double()) ** 2).mean()
+    rgb = (a * w1d[..., None]).sum(1)
+    if with_all:
+        img = mse(rgb, tgt) + mse((b * w1d[..., None]).sum(1), tgt)
+        fine = mse((a * w2d[..., None]).sum(1), tgt)
+        ref = img * 0.7 + fine * 0.3 + 0.2 * (mse(a[:, 0], tgt0) + mse(b[:, 0], tgt0))
+    else:
+        ref = mse(rgb, tgt)
+    assert abs(float(loss.detach()) - float(ref.detach())) < 1e-6
+    ref.backward()
+    for name, x, y in zip(("rgb_p", "rgb0_p", "w1", "w2"), leaves, ref_leaves):
+        if y.grad is None:
+            assert x.grad is None or float(x.grad.abs().max()) == 0.0, name
+            continue
+        rel = float((x.grad.double() - y.grad).norm() / y.grad.norm())
+        assert rel < 2e-5, (name, rel)
