@@ -268,6 +268,165 @@ __global__ __launch_bounds__(256) void k_event_loss(const CrfParams crf, int ski
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Backward of k_event_loss ("next" row f-1, slice): gradients of  g_f * partial[0] + g_c * partial[1]  w.r.t. the four colour
+// inputs and w.r.t. the parameters of the learnable event-CRF.  Same lane decomposition as the forward kernel (16 lanes per
+// event: which = 0 end, 1 start, 2 end0, 3 start0; channel); every lane re-runs its CRF evaluation keeping the three hidden
+// layers, back-propagates  d out -> d (input, parameters),  the parameter contributions are summed over the wavefront with DPP
+// adds, over the block in LDS and added to the global gradient once per block.
+// Parameter gradient layout (EVD_CRF_NPARAM floats): w0 [16][CRF_MAX_IN] (rows padded), b0 [16], w1 [16][16], b1, w2 [16][16], b2, w3 [16], b3.
+constexpr int CRF_NPARAM = 16 * CRF_MAX_IN + 16 + 256 + 16 + 256 + 16 + 16 + 1;
+
+__device__ __forceinline__ float wave_sum_all(float v) {      // sum over the 64 lanes, valid in lane 63's row ends; returned uniform
+    v += dppf<0xb1>(v);
+    v += dppf<0x4e>(v);
+    v += dppf<0x141>(v);
+    v += dppf<0x140>(v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+}
+
+__global__ __launch_bounds__(256) void k_event_loss_bwd(const CrfParams crf, int skip_learn, int add_bii_feat, int tonemap_only,
+                                                        const float* __restrict__ start, const float* __restrict__ end,
+                                                        const float* __restrict__ start0, const float* __restrict__ end0,
+                                                        const float* __restrict__ cum_neg, const float* __restrict__ cum_pos,
+                                                        float thr_neg, float thr_pos, const unsigned char* __restrict__ cmask,
+                                                        float cw0, float cw1, float cw2, int has_cw, long N, float g_f, float g_c,
+                                                        float* __restrict__ d_start, float* __restrict__ d_end,
+                                                        float* __restrict__ d_start0, float* __restrict__ d_end0,
+                                                        float* __restrict__ d_params) {
+    __shared__ float pacc[CRF_NPARAM];
+    for (int i = threadIdx.x; i < CRF_NPARAM; i += blockDim.x) pacc[i] = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, sub = threadIdx.x & 15, which = sub >> 2, c = sub & 3;
+    const long i = blockIdx.x * (long)(blockDim.x >> 4) + (threadIdx.x >> 4);
+    const bool on = i < N;
+    const long ii = on ? i : N - 1;
+    const bool have0 = start0 && end0;
+    const bool active = on && c < 3 && (which < 2 || have0);
+    const bool learn = crf.map_type == 2 && !skip_learn;
+    const float cn = cum_neg[ii], cp = cum_pos[ii];
+    int ch = 0;
+    if (cmask) for (int k = 0; k < 3; ++k) if (cmask[ii * 3 + k]) ch = k;
+    const float* src = which == 0 ? end : which == 1 ? start : which == 2 ? end0 : start0;
+    // ---- forward of this lane's evaluation, hidden layers kept
+    float in[CRF_MAX_IN], h1[16], h2[16], h3[16];
+#pragma unroll
+    for (int e = 0; e < CRF_MAX_IN; ++e) in[e] = 0.f;
+    float x = 0.f, v = 0.f, xg = 0.f, dgamma = 1.f;
+    if (c < 3 && (which < 2 || have0)) {
+        x = src[ii * 3 + c];
+        xg = x;
+        if (crf.map_type == 1) { xg = powf(x, crf.inv_gamma); dgamma = crf.inv_gamma * powf(x, crf.inv_gamma - 1.f); }
+        v = xg;
+        if (learn) {
+            in[0] = xg;
+            if (add_bii_feat == 1 || (add_bii_feat == 2 && c == ch)) { in[1] = cn; in[2] = cp; }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                float s = crf.b0[j];
+#pragma unroll
+                for (int k = 0; k < CRF_MAX_IN; ++k) s = fmaf(crf.w0[j * CRF_MAX_IN + k], in[k], s);
+                h1[j] = fmaxf(s, 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                float s = crf.b1[j];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) s = fmaf(crf.w1[j * 16 + k], h1[k], s);
+                h2[j] = fmaxf(s, 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                float s = crf.b2[j];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) s = fmaf(crf.w2[j * 16 + k], h2[k], s);
+                h3[j] = fmaxf(s, 0.f);
+            }
+            float s = crf.b3;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s = fmaf(crf.w3[k], h3[k], s);
+            v = 1.f / (1.f + expf(-(s * 0.1f + xg)));
+        }
+    }
+    // ---- luma / log-difference chain (as k_event_loss) and its derivative
+    const float v0 = dppf<0x00>(v), v1 = dppf<0x55>(v), v2 = dppf<0xaa>(v);
+    const float sel[3] = {v0, v1, v2};
+    const float lum = tonemap_only ? sel[ch] : luma_of(0, v0, v1, v2);
+    const float lg = logf(lum + 1e-5f);
+    const float nxt = dppf<0x104>(lg), prv = dppf<0x114>(lg);          // row_shl:4 / row_shr:4: the partner quad's log-luma
+    const bool is_end = (which & 1) == 0;
+    const float pred = is_end ? lg - nxt : prv - lg;
+    const float bii = __fadd_rn(__fmul_rn(thr_neg, cn), __fmul_rn(thr_pos, cp));
+    const float cw[3] = {cw0, cw1, cw2};
+    const float w = (cmask && has_cw) ? cw[ch] : 1.f;
+    const float g = which < 2 ? g_f : g_c;
+    const float d_lg = (is_end ? 1.f : -1.f) * 2.f * g * w * (pred - bii);
+    const float d_lum = d_lg / (lum + 1e-5f);
+    const float coef[3] = {0.299f, 0.587f, 0.114f};
+    float d_v = 0.f;
+    if (active) d_v = tonemap_only ? (c == ch ? d_lum : 0.f) : d_lum * coef[c];
+    // ---- CRF backward
+    float d_x = d_v;
+    if (learn) {
+        const float dz = d_v * v * (1.f - v);          // through the sigmoid of (0.1 s + x)
+        const float ds = 0.1f * dz;
+        float dh3[16], dh2[16], dh1[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) dh3[k] = h3[k] > 0.f ? ds * crf.w3[k] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) a = fmaf(crf.w2[j * 16 + k], dh3[j], a);
+            dh2[k] = h2[k] > 0.f ? a : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) a = fmaf(crf.w1[j * 16 + k], dh2[j], a);
+            dh1[k] = h1[k] > 0.f ? a : 0.f;
+        }
+        float din0 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) din0 = fmaf(crf.w0[j * CRF_MAX_IN], dh1[j], din0);
+        d_x = (dz + din0) * dgamma;
+        // parameter contributions, summed over the wavefront, then into the block's LDS accumulator
+        constexpr int O_B0 = 16 * CRF_MAX_IN, O_W1 = O_B0 + 16, O_B1 = O_W1 + 256, O_W2 = O_B1 + 16, O_B2 = O_W2 + 256, O_W3 = O_B2 + 16, O_B3 = O_W3 + 16;
+        auto add = [&](int idx, float val) {
+            const float t = wave_sum_all(val);
+            if (lane == 0) atomicAdd(&pacc[idx], t);
+        };
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) add(j * CRF_MAX_IN + k, dh1[j] * in[k]);
+            add(O_B0 + j, dh1[j]);
+            add(O_B1 + j, dh2[j]);
+            add(O_B2 + j, dh3[j]);
+            add(O_W3 + j, ds * h3[j]);
+        }
+        add(O_B3, ds);
+#pragma unroll 4
+        for (int j = 0; j < 16; ++j)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { add(O_W1 + j * 16 + k, dh2[j] * h1[k]); add(O_W2 + j * 16 + k, dh3[j] * h2[k]); }
+    } else {
+        d_x = d_v * dgamma;
+    }
+    if (active) {
+        float* dst = which == 0 ? d_end : which == 1 ? d_start : which == 2 ? d_end0 : d_start0;
+        if (dst) dst[ii * 3 + c] = d_x;
+    }
+    if (learn && d_params) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < CRF_NPARAM; k += blockDim.x) if (pacc[k] != 0.f) atomicAdd(d_params + k, pacc[k]);
+    }
+}
+
 // AdaptiveWeightProposal.feature_integration (networks/dpnerf/awp.py:49-77), the AWP consumer's compositing scan, AS WRITTEN
 // in the reference: the cumprod of :69-73 runs along the CHANNEL axis of the previous sample's row,
 //   Q[0, c] = 1,  Q[s, c] = prod_{c' <= c} (1 - alpha[s-1, c'] + 1e-10),  out[c] = sum_s alpha[s, c] Q[s, c] feat[s, c].
@@ -472,6 +631,28 @@ int evd_event_loss_reduce(const evd_crf* crf_ev, int skip_learn, int add_bii_fea
     k_event_loss<<<cdiv(N, 16), 256, 0, as_stream(stream)>>>(crf_ev->p, skip_learn, add_bii_feat, tonemap_only, start, end, start0, end0,
                                                               cum_neg, cum_pos, thr_neg, thr_pos, color_mask, c0, c1, c2,
                                                               color_weight != nullptr, N, partial);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+int evd_crf_param_count(void) { return CRF_NPARAM; }
+
+int evd_event_loss_bwd(const evd_crf* crf_ev, int skip_learn, int add_bii_feat, int tonemap_only,
+                       const float* start, const float* end, const float* start0, const float* end0,
+                       const float* cum_neg, const float* cum_pos, float thr_neg, float thr_pos,
+                       const unsigned char* color_mask, const float* color_weight, long N, float g_fine, float g_coarse,
+                       float* d_start, float* d_end, float* d_start0, float* d_end0, float* d_params, void* stream) {
+    EVD_REQUIRE(crf_ev && start && end && cum_neg && cum_pos && d_start && d_end && N >= 0, "evd_event_loss_bwd: bad arguments");
+    EVD_REQUIRE(add_bii_feat >= 0 && add_bii_feat <= 2, "evd_event_loss_bwd: add_bii_feat %d", add_bii_feat);
+    EVD_REQUIRE(!color_mask || tonemap_only, "evd_event_loss_bwd: a colour mask needs tonemap_only");
+    EVD_REQUIRE(add_bii_feat != 2 || color_mask, "evd_event_loss_bwd: color-pos-neg features need the colour mask");
+    hipStream_t st = as_stream(stream);
+    if (d_params) EVD_HIP(hipMemsetAsync(d_params, 0, sizeof(float) * CRF_NPARAM, st));
+    if (N == 0) return EVD_OK;
+    const float c0 = color_weight ? color_weight[0] : 1.f, c1 = color_weight ? color_weight[1] : 1.f, c2 = color_weight ? color_weight[2] : 1.f;
+    k_event_loss_bwd<<<cdiv(N, 16), 256, 0, st>>>(crf_ev->p, skip_learn, add_bii_feat, tonemap_only, start, end, start0, end0, cum_neg, cum_pos,
+                                                  thr_neg, thr_pos, color_mask, c0, c1, c2, color_weight != nullptr, N, g_fine, g_coarse,
+                                                  d_start, d_end, (start0 && end0) ? d_start0 : nullptr, (start0 && end0) ? d_end0 : nullptr, d_params);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }

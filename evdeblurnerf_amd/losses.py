@@ -126,6 +126,73 @@ def event_loss_partials(crf_ev, start, end, cum_neg, cum_pos, thr_neg, thr_pos, 
     return partial
 
 
+class _EventLoss(torch.autograd.Function):
+    """event_loss_partials as an autograd node: forward = evd_event_loss_reduce, backward = evd_event_loss_bwd (gradients for
+    the four colour inputs and for the learnable event-CRF parameters, returned as ONE flat tensor in the layout of
+    evd_event_loss_bwd; ``crf_param_grads`` splits it into the state-dict shapes)."""
+
+    @staticmethod
+    def forward(ctx, crf_ev, params, start, end, start0, end0, cum_neg, cum_pos, thr_neg, thr_pos, mode, tonemap_only, cm, cw, skip):
+        partial = event_loss_partials(crf_ev, start.detach(), end.detach(), cum_neg, cum_pos, thr_neg, thr_pos,
+                                      start0=None if start0 is None else start0.detach(), end0=None if end0 is None else end0.detach(),
+                                      add_bii={0: None, 1: "pos-neg", 2: "color-pos-neg"}[mode], tonemap_only=tonemap_only, color_mask=cm,
+                                      color_weight=cw, skip_learn_crf=skip)
+        ctx.args = (crf_ev, float(thr_neg), float(thr_pos), int(mode), bool(tonemap_only), cw, bool(skip), start0 is not None)
+        dev = start.device
+        e = torch.empty(0, device=dev)
+        ctx.save_for_backward(start, end, start0 if start0 is not None else e, end0 if end0 is not None else e, cum_neg, cum_pos,
+                              cm if cm is not None else e)
+        ctx.has_cm = cm is not None
+        return partial
+
+    @staticmethod
+    def backward(ctx, g_partial):
+        crf_ev, thr_neg, thr_pos, mode, tonemap_only, cw, skip, have0 = ctx.args
+        start, end, start0, end0, cum_neg, cum_pos, cm = ctx.saved_tensors
+        N = start.shape[0]
+        g = g_partial.detach().float().cpu().numpy()
+        d_start, d_end = torch.zeros_like(start), torch.zeros_like(end)
+        d_start0 = torch.zeros_like(start0) if have0 else None
+        d_end0 = torch.zeros_like(end0) if have0 else None
+        d_params = torch.empty((int(L.lib().evd_crf_param_count()),), dtype=torch.float32, device=start.device)
+        cwa = np.ascontiguousarray(cw, dtype=np.float32) if cw is not None else None
+        L.check(L.lib().evd_event_loss_bwd(crf_ev.handle, int(skip), mode, int(tonemap_only), L.ptr(start), L.ptr(end),
+                                           L.ptr(start0) if have0 else None, L.ptr(end0) if have0 else None, L.ptr(cum_neg), L.ptr(cum_pos),
+                                           thr_neg, thr_pos, L.ptr(cm) if ctx.has_cm else None,
+                                           cwa.ctypes.data_as(C.POINTER(C.c_float)) if cwa is not None else None, N, float(g[0]), float(g[1]),
+                                           L.ptr(d_start), L.ptr(d_end), L.ptr(d_start0), L.ptr(d_end0), L.ptr(d_params), L.stream_ptr()),
+                "evd_event_loss_bwd")
+        return (None, d_params, d_start, d_end, d_start0, d_end0) + (None,) * 9
+
+
+def event_loss_partials_autograd(crf_ev, crf_params, start, end, cum_neg, cum_pos, thr_neg, thr_pos, start0=None, end0=None,
+                                 add_bii="pos-neg", tonemap_only=False, color_mask=None, color_weight=None, skip_learn_crf=False):
+    """Differentiable form of event_loss_partials.  ``crf_params`` is a flat float32 leaf tensor of evd_crf_param_count()
+    elements that stands for the event-CRF's parameters in the autograd graph (its .grad receives dL/d parameters in the layout
+    of evd_event_loss_bwd; ``crf_param_grads`` maps that to the reference's state-dict names); the VALUES are the ones the
+    ``crf_ev`` handle was created with."""
+    c = lambda t: t.contiguous().float() if t is not None else None
+    mode = {None: 0, "none": 0, "pos-neg": 1, "color-pos-neg": 2}[add_bii]
+    cm = color_mask.contiguous().to(torch.uint8) if color_mask is not None else None
+    return _EventLoss.apply(crf_ev, crf_params, c(start), c(end), c(start0), c(end0), c(cum_neg), c(cum_pos), thr_neg, thr_pos, mode,
+                            tonemap_only, cm, color_weight, skip_learn_crf)
+
+
+def crf_param_grads(flat, extra_features):
+    """Split the flat parameter gradient of evd_event_loss_bwd into the reference's ``linear.{0,2,4,6}.{weight,bias}`` shapes."""
+    nin, o = 1 + extra_features, 0
+    out = {}
+    out["linear.0.weight"] = flat[o:o + 128].reshape(16, 8)[:, :nin].clone(); o += 128
+    out["linear.0.bias"] = flat[o:o + 16].clone(); o += 16
+    out["linear.2.weight"] = flat[o:o + 256].reshape(16, 16).clone(); o += 256
+    out["linear.2.bias"] = flat[o:o + 16].clone(); o += 16
+    out["linear.4.weight"] = flat[o:o + 256].reshape(16, 16).clone(); o += 256
+    out["linear.4.bias"] = flat[o:o + 16].clone(); o += 16
+    out["linear.6.weight"] = flat[o:o + 16].reshape(1, 16).clone(); o += 16
+    out["linear.6.bias"] = flat[o:o + 1].clone()
+    return out
+
+
 def event_loss_from_partials(p, stages=("stage0", "stage1")):
     """extra_loss['event_egm'] of run_nerf.py:559-572 from the (all-reduced) partials."""
     loss = 0.0

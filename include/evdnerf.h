@@ -252,6 +252,18 @@ int evd_event_loss_reduce(const evd_crf* crf_ev, int skip_learn, int add_bii_fea
                           const unsigned char* color_mask, const float* color_weight, long N,
                           float* partial, void* stream);
 
+/* Backward of evd_event_loss_reduce: gradients of  g_fine * partial[0] + g_coarse * partial[1]  w.r.t. the colour inputs
+ * (d_start, d_end, d_start0, d_end0 dev [N,3]; the *0 pair may be NULL) and w.r.t. the learnable event-CRF parameters
+ * (d_params dev [evd_crf_param_count()] or NULL; layout: linear.0.weight as [16][8] rows zero-padded from 1 + extra_features,
+ * linear.0.bias [16], linear.2.weight [16][16], linear.2.bias, linear.4.weight [16][16], linear.4.bias, linear.6.weight [16],
+ * linear.6.bias [1]).  d_params is overwritten. */
+int evd_crf_param_count(void);
+int evd_event_loss_bwd(const evd_crf* crf_ev, int skip_learn, int add_bii_feat, int tonemap_only,
+                       const float* start, const float* end, const float* start0, const float* end0,
+                       const float* cum_neg, const float* cum_pos, float thr_neg, float thr_pos,
+                       const unsigned char* color_mask, const float* color_weight, long N, float g_fine, float g_coarse,
+                       float* d_start, float* d_end, float* d_start0, float* d_end0, float* d_params, void* stream);
+
 /* AdaptiveWeightProposal.feature_integration, networks/dpnerf/awp.py:49-77 (the compositing scan of the AWP consumer of
  * the path's per-sample features): feat dev [N,S,C] (N = rays x sub-exposures; every channel is its own density),
  * z dev [N,S], rays_d dev [N,3] -> out dev [N,C].  Restated as written: the last sample gets alpha 0 (awp.py:67) and the

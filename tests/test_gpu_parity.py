@@ -748,3 +748,65 @@ def test_blur_loss_backward_matches_torch_autograd(crf_kind, with_all):
             continue
         rel = float((x.grad.double() - y.grad).norm() / y.grad.norm())
         assert rel < 2e-5, (name, rel)
+
+
+@pytest.mark.parametrize("cfg", ["blender", "cdavis"])
+def test_event_loss_backward_matches_torch_autograd(cfg):
+    """Backward of the fused event-loss reduction (learnable event-CRF included) against torch autograd of a plain-torch
+    restatement of tonemapping.py:59-93 + run_nerf.py:518-570 + events.py:260-284 (float64): gradients w.r.t. the four colour
+    inputs and w.r.t. every CRF parameter.  'blender': pos-neg features + rec601 luma; 'cdavis': colour mask, per-colour
+    features and weights, tonemap_only."""
+    from evdeblurnerf_amd.losses import event_loss_partials_autograd, event_loss_from_partials, crf_param_grads
+    from evdeblurnerf_amd.tonemapping import CRF
+    rs = np.random.RandomState(41)
+    n = 277
+    sd = W.make_crf_state_dict(51, 2)
+    sd = {k: (v * (3.0 if "weight" in k else 1.0)).astype(np.float32) for k, v in sd.items()}      # not-near-identity CRF: real gradients everywhere
+    crf = CRF("learn", state_dict=sd, extra_features=2)
+    mk = lambda: T(rs.uniform(0.05, 0.95, (n, 3)).astype(np.float32))
+    es, ee, es0, ee0 = mk(), mk(), mk(), mk()
+    cn, cp = T(-rs.randint(0, 4, n).astype(np.float32)), T(rs.randint(0, 4, n).astype(np.float32))
+    thr = 0.2 if cfg == "blender" else 0.25
+    cmask = np.zeros((n, 3), np.uint8)
+    cmask[np.arange(n), rs.randint(0, 3, n)] = 1
+    cwt = [0.4, 0.2, 0.4]
+    kw = dict(add_bii="pos-neg") if cfg == "blender" else dict(add_bii="color-pos-neg", tonemap_only=True, color_mask=T(cmask), color_weight=cwt)
+    leaves = [t.clone().requires_grad_(True) for t in (es, ee, es0, ee0)]
+    theta = torch.zeros(705, device=DEV, requires_grad=True)
+    p = event_loss_partials_autograd(crf, theta, leaves[0], leaves[1], cn, cp, thr, thr, start0=leaves[2], end0=leaves[3], **kw)
+    loss = event_loss_from_partials(p)
+    loss.backward()
+    # ---- plain-torch float64 restatement
+    P = {k: torch.as_tensor(v, device=DEV).double().requires_grad_(True) for k, v in sd.items()}
+    ref_leaves = [t.double().clone().requires_grad_(True) for t in (es, ee, es0, ee0)]
+
+    def crf_t(x, feat):                       # x [n,3], feat [n,3,2]
+        xin = torch.cat([x.reshape(-1, 1), feat.reshape(-1, 2)], -1)
+        h = torch.relu(xin @ P["linear.0.weight"].T + P["linear.0.bias"])
+        h = torch.relu(h @ P["linear.2.weight"].T + P["linear.2.bias"])
+        h = torch.relu(h @ P["linear.4.weight"].T + P["linear.4.bias"])
+        res = (h @ P["linear.6.weight"].T + P["linear.6.bias"]) * 0.1
+        return torch.sigmoid(res + x.reshape(-1, 1)).reshape(x.shape)
+
+    f2 = torch.stack([cn, cp], -1).double()
+    cm_t = torch.as_tensor(cmask.astype(bool), device=DEV)
+    if cfg == "blender":
+        feat = f2[:, None, :].expand(n, 3, 2)
+        lum = lambda x: (crf_t(x, feat) * torch.tensor([0.299, 0.587, 0.114], device=DEV, dtype=torch.float64)).sum(-1)
+        wgt = torch.ones(n, device=DEV, dtype=torch.float64)
+    else:
+        feat = f2[:, None, :] * cm_t[..., None].double()
+        lum = lambda x: crf_t(x, feat)[cm_t]
+        wgt = torch.tensor(cwt, device=DEV, dtype=torch.float64)[cm_t.double().argmax(-1)]
+    bii = thr * cn.double() + thr * cp.double()
+    egm = lambda a, b: (wgt * (torch.log(lum(b) + 1e-5) - torch.log(lum(a) + 1e-5) - bii) ** 2).sum() / wgt.sum()
+    ref = egm(ref_leaves[2], ref_leaves[3]) + egm(ref_leaves[0], ref_leaves[1])
+    assert abs(float(loss.detach()) - float(ref.detach())) < 2e-5 * max(1.0, float(ref.detach()))
+    ref.backward()
+    for name, x, y in zip(("start", "end", "start0", "end0"), leaves, ref_leaves):
+        rel = float((x.grad.double() - y.grad).norm() / y.grad.norm())
+        assert rel < 5e-5, (name, rel)
+    got = crf_param_grads(theta.grad, 2)
+    for k, v in P.items():
+        rel = float((got[k].double() - v.grad).norm() / max(float(v.grad.norm()), 1e-12))
+        assert rel < 2e-4, (k, rel)
