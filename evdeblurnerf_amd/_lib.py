@@ -80,6 +80,8 @@ SIGNATURES = {
     "evd_nerf_destroy": (None, [_vp]),
     "evd_nerf_stream_bytes": (_S, [_vp, _I]),
     "evd_nerf_mlp": (_I, [_vp, _I, _vp, _vp, _L, _I, _vp, _vp, _I, _vp]),
+    "evd_nerf_train_store_bytes": (_S, [_L]),
+    "evd_nerf_mlp_train": (_I, [_vp, _I, _vp, _vp, _L, _I, _vp, _vp, _S, _vp]),
     "evd_raw2outputs": (_I, [_vp, _vp, _vp, _I, _L, _I, _I, _I, _I, _I, _I, _I, _I, _F, _vp,
                              _vp, _vp, _vp, _vp, _vp, _vp, _I, _vp, _vp]),
     "evd_raw2outputs_bwd": (_I, [_vp, _vp, _vp, _I, _L, _I, _I, _I, _I, _I, _I, _I, _I, _F, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -2,6 +2,7 @@
 #include "evd_common.h"
 #include "nerf_mlp.h"
 #include "nerf_mlp_kernel.h"
+#include "nerf_net.h"
 #include "pack.h"
 
 #include <cmath>
@@ -29,16 +30,6 @@ int nerf_mlp_pipe_dispatch(int prec, const MlpParams& p, hipStream_t st);
 }  // namespace evd
 
 using namespace evd;
-
-struct evd_nerf {
-    int D, W, skip, rgb_act, sigma_act;
-    float rmnear;
-    DevBuf stream[EVD_NUM_PREC];        // generic kernel: fragment streams per precision
-    int nchunks[EVD_NUM_PREC];
-    DevBuf pipe[EVD_NUM_PREC];          // software-pipelined kernel (where built): its own fragment order and chunking
-    int pipe_chunks[EVD_NUM_PREC];
-    DevBuf bias;
-};
 
 extern "C" {
 
@@ -149,7 +140,7 @@ int evd_nerf_mlp(const evd_nerf* net, int precision, const float* ray_batch, con
     p.bias = (const float*)net->bias.p;
     p.ray_batch = ray_batch; p.z = z; p.nsamp = R * (long)S; p.S = S; p.ncol = 11;
     p.D = net->D; p.skip = net->skip; p.nchunks = piped ? net->pipe_chunks[precision] : net->nchunks[precision]; p.nbias = (int)(net->bias.bytes / sizeof(float));
-    p.raw = raw; p.feature = feature; p.feature_kind = feature ? feature_kind : 0;
+    p.raw = raw; p.feature = feature; p.feature_kind = feature ? feature_kind : 0; p.act = nullptr;
     if (piped) return nerf_mlp_pipe_dispatch(precision, p, as_stream(stream));
     return nerf_mlp_generic_dispatch(precision, net->W, p, as_stream(stream));
 }

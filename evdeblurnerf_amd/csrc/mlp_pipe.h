@@ -245,11 +245,13 @@ constexpr int cceil(int a, int b) { return (a + b - 1) / b; }
 //            PDOFF the k-step of `in` its outputs become; PFEAT_TILE0 >= 0: also store it as feature rows
 //   OWN_FEAT store this layer's outputs as float32 feature rows
 //   NEXT_G   tiles of the next layer's first group (0 = last layer of the kernel: no prefetch beyond)
+//   OSLOT    training kernels: fragment slot of this layer's output in the activation store (-1: not stored);
+//   PSLOT    ... slot of the FIRST fragment of the pending group handed over by the previous layer
 template <int KTOT_, int TILES_, int G_, bool RELU_, bool F32OUT_, int CHUNK0_, int FOFF_, bool PAD_END_, int AOFF_, int PAR_, int PG_,
-          bool PRELU_, int PDOFF_, int PFEAT_TILE0_, bool OWN_FEAT_, int NEXT_G_>
+          bool PRELU_, int PDOFF_, int PFEAT_TILE0_, bool OWN_FEAT_, int NEXT_G_, int OSLOT_ = -1, int PSLOT_ = -1>
 struct LayerDesc {
     static constexpr int KTOT = KTOT_, TILES = TILES_, CHUNK0 = CHUNK0_, FOFF = FOFF_, AOFF = AOFF_, PAR = PAR_, PG = PG_, PDOFF = PDOFF_,
-                         PFEAT_TILE0 = PFEAT_TILE0_, NEXT_G = NEXT_G_;
+                         PFEAT_TILE0 = PFEAT_TILE0_, NEXT_G = NEXT_G_, OSLOT = OSLOT_, PSLOT = PSLOT_;
     static constexpr bool RELU = RELU_, F32OUT = F32OUT_, PAD_END = PAD_END_, PRELU = PRELU_, OWN_FEAT = OWN_FEAT_;
     static constexpr int G = G_;
     static constexpr int NG = TILES_ / G;
@@ -295,10 +297,16 @@ template <class C, class L, bool FIRST, bool LAST> struct GroupSched {
 };
 
 // One tile group p of a layer (see pipe_layer).
-template <class C, class L, class ST, int NOUT, int P>
+// a completed B fragment of the training kernels goes to the activation store (lane-linear: 16 bytes per lane, 1 KiB per fragment)
+template <class B> __device__ __forceinline__ void act_store(char* act_lane, int slot, const B& frag) {
+    static_assert(sizeof(B) == 16, "activation store holds single-product half-precision fragments");
+    *reinterpret_cast<f32x4*>(act_lane + (long)slot * 1024) = __builtin_bit_cast(f32x4, frag);
+}
+
+template <class C, class L, class ST, int NOUT, int P, bool TRAIN>
 __device__ __forceinline__ void pipe_group(ST& st, Pipe<C>& pp, typename C::O::B (&in)[C::NS][L::KTOT],
                                            typename C::O::B (&out)[C::NS][NOUT], const float* __restrict__ bias, int h,
-                                           float* const* frow) {
+                                           float* const* frow, char* const* act) {
     typedef typename C::O O;
     typedef GroupSched<C, L, P == 0, P == L::NG - 1> S;
     constexpr int NS = C::NS, FPC = C::FPC, PD = C::PD, G = L::G, KTOT = L::KTOT, NF = L::NF, NM = S::NM;
@@ -342,10 +350,14 @@ __device__ __forceinline__ void pipe_group(ST& st, Pipe<C>& pp, typename C::O::B
                         if (FIRST) {
                             float* fr = (L::PFEAT_TILE0 >= 0 && frow[ds]) ? frow[ds] + 32 * (L::PFEAT_TILE0 + dt) + 8 * (k >> 1) + 4 * h : nullptr;
                             drain_pair<C, L::PRELU>(pp.acc[oth][dt][ds], pp.accx[oth][dt][ds], k, in[ds][(L::PG > 0 ? L::PDOFF : 0) + 2 * dt + (k >> 2)], fr);
+                            if constexpr (TRAIN && L::PSLOT >= 0)
+                                if ((k & 3) == 3) act_store(act[ds], L::PSLOT + 2 * dt + (k >> 2), in[ds][(L::PG > 0 ? L::PDOFF : 0) + 2 * dt + (k >> 2)]);
                         } else {
                             constexpr int tile0 = P > 0 ? (P - 1) * G : 0;
                             float* fr = (L::OWN_FEAT && frow[ds]) ? frow[ds] + 32 * (tile0 + dt) + 8 * (k >> 1) + 4 * h : nullptr;
                             drain_pair<C, L::RELU>(pp.acc[oth][dt][ds], pp.accx[oth][dt][ds], k, out[ds][2 * (tile0 + dt) + (k >> 2)], fr);
+                            if constexpr (TRAIN && L::OSLOT >= 0)
+                                if ((k & 3) == 3) act_store(act[ds], L::OSLOT + 2 * (tile0 + dt) + (k >> 2), out[ds][2 * (tile0 + dt) + (k >> 2)]);
                         }
                     }
                 }
@@ -381,13 +393,13 @@ __device__ __forceinline__ void pipe_group(ST& st, Pipe<C>& pp, typename C::O::B
     }
 }
 
-template <class C, class L, class ST, int NOUT, int P>
+template <class C, class L, class ST, int NOUT, int P, bool TRAIN>
 struct GroupLoop {
     static __device__ __forceinline__ void run(ST& st, Pipe<C>& pp, typename C::O::B (&in)[C::NS][L::KTOT],
                                                typename C::O::B (&out)[C::NS][NOUT], const float* __restrict__ bias, int h,
-                                               float* const* frow) {
-        pipe_group<C, L, ST, NOUT, P>(st, pp, in, out, bias, h, frow);
-        if constexpr (P + 1 < L::NG) GroupLoop<C, L, ST, NOUT, P + 1>::run(st, pp, in, out, bias, h, frow);
+                                               float* const* frow, char* const* act) {
+        pipe_group<C, L, ST, NOUT, P, TRAIN>(st, pp, in, out, bias, h, frow, act);
+        if constexpr (P + 1 < L::NG) GroupLoop<C, L, ST, NOUT, P + 1, TRAIN>::run(st, pp, in, out, bias, h, frow, act);
     }
 };
 
@@ -395,12 +407,12 @@ struct GroupLoop {
 // k-steps except the pending ones, which this layer produces itself while it runs; `out` receives the B fragments
 // of every group but the last, which stays pending in the accumulators (or, F32OUT, is returned in out_f32).
 // frow[s]: float32 feature row of sample tile s (null lanes = invalid samples), W floats per sample.
-template <class C, class L, class ST, int NOUT>
+template <class C, class L, class ST, int NOUT, bool TRAIN = false>
 __device__ __forceinline__ void pipe_layer(ST& st, Pipe<C>& pp, typename C::O::B (&in)[C::NS][L::KTOT],
                                            typename C::O::B (&out)[C::NS][NOUT], float (*out_f32)[4],
-                                           const float* __restrict__ bias, int lane, float* const* frow) {
+                                           const float* __restrict__ bias, int lane, float* const* frow, char* const* act = nullptr) {
     typedef typename C::O O;
-    GroupLoop<C, L, ST, NOUT, 0>::run(st, pp, in, out, bias, lane >> 5, frow);
+    GroupLoop<C, L, ST, NOUT, 0, TRAIN>::run(st, pp, in, out, bias, lane >> 5, frow, act);
     if (L::PAD_END && ((L::FOFF + L::NF) % C::FPC) != 0) st.chunk_end(L::CHUNK0 + (L::FOFF + L::NF) / C::FPC);
     if (L::F32OUT) {
         constexpr int cur = (L::PAR + L::NG - 1) & 1;
@@ -414,6 +426,18 @@ __device__ __forceinline__ void pipe_layer(ST& st, Pipe<C>& pp, typename C::O::B
                 asm volatile("" : "+v"(out_f32[s][r]));
             }
     }
+}
+
+// Drain the pending last group of layer L into `out` without overlap (kernels that end with a fragment-producing layer)
+template <class C, class L, int NOUT>
+__device__ __forceinline__ void pipe_flush(Pipe<C>& pp, typename C::O::B (&out)[C::NS][NOUT]) {
+    constexpr int cur = (L::PAR + L::NG - 1) & 1, tile0 = (L::NG - 1) * L::G;
+#pragma unroll
+    for (int t = 0; t < L::G; ++t)
+#pragma unroll
+        for (int s = 0; s < C::NS; ++s)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) drain_pair<C, L::RELU>(pp.acc[cur][t][s], pp.accx[cur][t][s], k, out[s][2 * (tile0 + t) + (k >> 2)], nullptr);
 }
 
 // prologue of the pipeline: first PD - 1 fragments of chunk 0 and the bias of the first group of the first layer

@@ -55,6 +55,18 @@ struct MlpParams {
     float* raw;             // [R, S, 4]
     float* feature;         // [R, S, W] or null
     int feature_kind;       // 0 none, 1 after_linear, 2 before_linear
+    char* act;              // training kernels: activation store (act_tile_bytes per 32-sample tile), else null
 };
+
+// Activation / gradient store of the training path, in 1 KiB fragments per 32-sample tile (W = 256, D = 8):
+// what the forward saves for the backward kernels, then the gradient fragments the dgrad chain hands to wgrad.
+namespace astore {
+constexpr int PE = 0, DIR = 4, H0 = 6;                    // H_l at H0 + 16 l: the ReLU output of pts_linears[l]
+constexpr int F = H0 + 16 * 8, HV = F + 16, FWD_END = HV + 8;   // feature_linear output, views hidden
+constexpr int G_RGB = FWD_END, G_ALPHA = G_RGB + 1;       // d raw as two single-k-step fragments
+constexpr int D_HV = G_ALPHA + 1, D_F = D_HV + 8, D_H0 = D_F + 16;    // d (unmasked) w.r.t. hv, feature, h_l at D_H0 + 16 l
+constexpr int TILE_FRAGS = D_H0 + 16 * 8;
+constexpr long TILE_BYTES = (long)TILE_FRAGS * 1024;
+}  // namespace astore
 
 }  // namespace evd

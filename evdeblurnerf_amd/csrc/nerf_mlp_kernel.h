@@ -19,43 +19,47 @@ namespace evd {
 
 // static layer table of the NeRF network: width W (T tiles, KS k-steps), depth D, skip index SKIP (the layer fed by
 // cat([input_pts, h]) is SKIP + 1, nerf.py:137-138), configuration C, FEAT = feature rows wanted
-template <class C, int W, int D, int SKIP, bool FEAT> struct NerfNet {
+template <class C, int W, int D, int SKIP, bool FEAT, bool TRAIN = false> struct NerfNet {
     static constexpr int T = W / 32, KS = W / 16, FPC = C::FPC, PD = C::PD;
     static constexpr int HG = nerf_group(C::PRECISION);            // tile-group size (also the packer's fragment order)
     static constexpr int VG = (T / 2) % HG == 0 ? HG : 1;          // ... of the views layer (T / 2 tiles)
     static constexpr int PDH = KS - 2 * HG;                        // k-step at which a hidden layer's pending group lands
     static constexpr int CH_L0 = cceil(T * PE_KS, FPC), CH_HID = cceil(T * KS, FPC), CH_WIDE = cceil(T * (KS + PE_KS), FPC);
     static constexpr bool is_wide(int l) { return l - 1 == SKIP; }
+    // training kernels: slot of hidden layer l's output in the activation store, and of its last (pending) group
+    static constexpr int oslot(int l) { return TRAIN ? astore::H0 + 16 * l : -1; }
+    static constexpr int pslot(int l) { return TRAIN ? astore::H0 + 16 * l + 2 * (T - HG) : -1; }
+    static_assert(!TRAIN || (W == 256 && D == 8), "the activation store is laid out for the 8 x 256 network");
     static constexpr int chunk0(int l) {                           // first chunk of hidden layer l (l == D: the heads)
         int c = CH_L0;
         for (int i = 1; i < l; ++i) c += is_wide(i) ? CH_WIDE : CH_HID;
         return c;
     }
     // layer 0: PE(pts) -> W
-    typedef LayerDesc<PE_KS, T, HG, true, false, 0, 0, true, 0, 0, 0, false, 0, -1, FEAT && D == 1, HG> L0;
+    typedef LayerDesc<PE_KS, T, HG, true, false, 0, 0, true, 0, 0, 0, false, 0, -1, FEAT && D == 1, HG, oslot(0)> L0;
     static constexpr int par(int l) { return (L0::PAR_OUT + (l - 1) * (T / HG)) & 1; }   // accumulator parity entering hidden layer l
     // hidden layer l (1 .. D-1); the skip layer's k-step order is [h_0..h_{PDH-1} | pe_0..3 | h_PDH..h_{KS-1}]
     template <int l> using Hidden = std::conditional_t<
         is_wide(l),
-        LayerDesc<KS + PE_KS, T, HG, true, false, chunk0(l), 0, true, 0, par(l), HG, true, KS + PE_KS - 2 * HG, -1, FEAT && l == D - 1, HG>,
-        LayerDesc<KS, T, HG, true, false, chunk0(l), 0, true, 0, par(l), HG, true, PDH, -1, FEAT && l == D - 1, HG>>;
+        LayerDesc<KS + PE_KS, T, HG, true, false, chunk0(l), 0, true, 0, par(l), HG, true, KS + PE_KS - 2 * HG, -1, FEAT && l == D - 1, HG, oslot(l), pslot(l - 1)>,
+        LayerDesc<KS, T, HG, true, false, chunk0(l), 0, true, 0, par(l), HG, true, PDH, -1, FEAT && l == D - 1, HG, oslot(l), pslot(l - 1)>>;
     // heads (nerf.py:144-157): alpha_linear, feature_linear, views_linears.0 on cat([feature, PE(dir)]), rgb_linear
     static constexpr int CH_H = chunk0(D);
-    typedef LayerDesc<KS, 1, 1, false, true, CH_H, 0, false, 0, par(D), HG, true, PDH, FEAT ? T - HG : -1, false, HG> Alpha;
+    typedef LayerDesc<KS, 1, 1, false, true, CH_H, 0, false, 0, par(D), HG, true, PDH, FEAT ? T - HG : -1, false, HG, -1, pslot(D - 1)> Alpha;
     static constexpr int F1 = KS;
-    typedef LayerDesc<KS, T, HG, false, false, CH_H, F1, false, F1 % PD, Alpha::PAR_OUT, 0, false, 0, -1, FEAT, VG> Feature;
+    typedef LayerDesc<KS, T, HG, false, false, CH_H, F1, false, F1 % PD, Alpha::PAR_OUT, 0, false, 0, -1, FEAT, VG, TRAIN ? astore::F : -1> Feature;
     static constexpr int F2 = F1 + T * KS;
-    typedef LayerDesc<KS + PEV_KS, T / 2, VG, true, false, CH_H, F2, false, F2 % PD, Feature::PAR_OUT, HG, false, PDH, FEAT ? T - HG : -1, false, 1> Views;
+    typedef LayerDesc<KS + PEV_KS, T / 2, VG, true, false, CH_H, F2, false, F2 % PD, Feature::PAR_OUT, HG, false, PDH, FEAT ? T - HG : -1, false, 1, TRAIN ? astore::HV : -1, TRAIN ? astore::F + 2 * (T - HG) : -1> Views;
     static constexpr int F3 = F2 + (T / 2) * (KS + PEV_KS);
-    typedef LayerDesc<KS / 2, 1, 1, false, true, CH_H, F3, true, F3 % PD, Views::PAR_OUT, VG, true, KS / 2 - 2 * VG, -1, false, 0> Rgb;
+    typedef LayerDesc<KS / 2, 1, 1, false, true, CH_H, F3, true, F3 % PD, Views::PAR_OUT, VG, true, KS / 2 - 2 * VG, -1, false, 0, -1, TRAIN ? astore::HV + 2 * (T / 2 - VG) : -1> Rgb;
     static constexpr int NCH = CH_H + cceil(F3 + KS / 2, FPC);     // chunks of the whole stream
     static_assert(D >= 1 && T % HG == 0 && (T * PE_KS) % PD == 0 && (T * KS) % PD == 0, "fragment counts must keep the prefetch ring phase");
 };
 
 // everything a layer call needs, bundled so that the hidden-layer recursion stays readable
-template <class C, class N, bool FEAT> struct NerfCtx {
+template <class C, class N, bool FEAT, bool TRAIN = false> struct NerfCtx {
     typedef typename C::O::B B;
-    PStream<C, FEAT, N::NCH> st;
+    PStream<C, FEAT || TRAIN, N::NCH> st;
     Pipe<C> pp;
     B buf[2][C::NS][N::KS];         // activations ping-pong: layer l writes buf[l & 1]
     B* stash;                       // this lane's slot of the wavefront's positional-encoding stash
@@ -64,10 +68,11 @@ template <class C, class N, bool FEAT> struct NerfCtx {
     float* const* frow_before;      // feature rows when "before_linear" is wanted, else nulls
     float* const* frow_after;       // ... "after_linear"
     float* const* nofrow;
+    char* const* act;               // training: this lane's 16 bytes in fragment 0 of each sample tile's activation store
 };
 
-template <class C, class N, bool FEAT, int l, int D> struct HiddenLoop {
-    static __device__ __forceinline__ void run(NerfCtx<C, N, FEAT>& cx) {
+template <class C, class N, bool FEAT, bool TRAIN, int l, int D> struct HiddenLoop {
+    static __device__ __forceinline__ void run(NerfCtx<C, N, FEAT, TRAIN>& cx) {
         typedef typename C::O::B B;
         typedef typename N::template Hidden<l> L;
         constexpr int NS = C::NS, KS = N::KS, T = N::T;
@@ -84,27 +89,27 @@ template <class C, class N, bool FEAT, int l, int D> struct HiddenLoop {
 #pragma unroll
                 for (int j = 0; j < PE_KS; ++j) wide[s][N::PDH + j] = sp[(s * C::STASH_FRAGS + j) * 64];
             }
-            pipe_layer<C, L, decltype(cx.st), KS>(cx.st, cx.pp, wide, cx.buf[l & 1], nullptr, lb, cx.lane, fr);
+            pipe_layer<C, L, decltype(cx.st), KS, TRAIN>(cx.st, cx.pp, wide, cx.buf[l & 1], nullptr, lb, cx.lane, fr, cx.act);
         } else {
-            pipe_layer<C, L, decltype(cx.st), KS>(cx.st, cx.pp, cx.buf[(l - 1) & 1], cx.buf[l & 1], nullptr, lb, cx.lane, fr);
+            pipe_layer<C, L, decltype(cx.st), KS, TRAIN>(cx.st, cx.pp, cx.buf[(l - 1) & 1], cx.buf[l & 1], nullptr, lb, cx.lane, fr, cx.act);
         }
-        if constexpr (l + 1 < D) HiddenLoop<C, N, FEAT, l + 1, D>::run(cx);
+        if constexpr (l + 1 < D) HiddenLoop<C, N, FEAT, TRAIN, l + 1, D>::run(cx);
     }
 };
 
-template <int PREC, int W, int D, int SKIP, int NS, int NT, bool FEAT>
+template <int PREC, int W, int D, int SKIP, int NS, int NT, bool FEAT, bool TRAIN = false>
 __global__ __launch_bounds__(NT, NT / 256) void k_nerf_mlp(const MlpParams p) {
     typedef PipeCfg<PREC, NS, NT> C;
     typedef typename C::O O;
     typedef typename O::B B;
-    typedef NerfNet<C, W, D, SKIP, FEAT> N;
+    typedef NerfNet<C, W, D, SKIP, FEAT, TRAIN> N;
     constexpr int T = N::T, KS = N::KS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     pipe_fp16_saturate<PREC>();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, h = lane >> 5;
-    NerfCtx<C, N, FEAT> cx;
+    NerfCtx<C, N, FEAT, TRAIN> cx;
     cx.st.start_issue(p.wstream, smem, tid);
     float* bias = reinterpret_cast<float*>(smem + C::RING);
     {   // bias block -> LDS, all loads of a thread in flight together
@@ -129,9 +134,11 @@ __global__ __launch_bounds__(NT, NT / 256) void k_nerf_mlp(const MlpParams p) {
     // the skip layer and the views layer read them back (nothing of the prologue stays in registers)
     long sidx[NS];
     bool valid[NS];
+    char* actl[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const long smp = (long)blockIdx.x * C::SAMPLES + wave * (NS * 32) + s * 32 + n;
+        actl[s] = TRAIN ? p.act + (smp >> 5) * astore::TILE_BYTES + lane * 16 : nullptr;
         valid[s] = smp < p.nsamp;
         sidx[s] = valid[s] ? smp : p.nsamp - 1;
         const long ray = sidx[s] / p.S;
@@ -150,7 +157,14 @@ __global__ __launch_bounds__(NT, NT / 256) void k_nerf_mlp(const MlpParams p) {
         for (int j = 0; j < PE_KS; ++j) cx.stash[(s * C::STASH_FRAGS + j) * 64] = pe[j];
 #pragma unroll
         for (int j = 0; j < PEV_KS; ++j) cx.stash[(s * C::STASH_FRAGS + PE_KS + j) * 64] = pev[j];
+        if constexpr (TRAIN) {
+#pragma unroll
+            for (int j = 0; j < PE_KS; ++j) act_store(actl[s], astore::PE + j, pe[j]);
+#pragma unroll
+            for (int j = 0; j < PEV_KS; ++j) act_store(actl[s], astore::DIR + j, pev[j]);
+        }
     }
+    cx.act = actl;
     float* frow[NS];
     float* nofrow[NS];
 #pragma unroll
@@ -174,19 +188,19 @@ __global__ __launch_bounds__(NT, NT / 256) void k_nerf_mlp(const MlpParams p) {
         for (int s = 0; s < NS; ++s)
 #pragma unroll
             for (int j = 0; j < PE_KS; ++j) in_pe[s][j] = cx.stash[(s * C::STASH_FRAGS + j) * 64];
-        pipe_layer<C, typename N::L0, decltype(cx.st), KS>(cx.st, cx.pp, in_pe, cx.buf[0], nullptr, bias, lane, D == 1 ? cx.frow_before : nofrow);
+        pipe_layer<C, typename N::L0, decltype(cx.st), KS, TRAIN>(cx.st, cx.pp, in_pe, cx.buf[0], nullptr, bias, lane, D == 1 ? cx.frow_before : nofrow, actl);
     }
-    if constexpr (D > 1) HiddenLoop<C, N, FEAT, 1, D>::run(cx);
+    if constexpr (D > 1) HiddenLoop<C, N, FEAT, TRAIN, 1, D>::run(cx);
 
     // heads
-    B (&act)[NS][KS] = cx.buf[(D - 1) & 1];
+    B (&hact)[NS][KS] = cx.buf[(D - 1) & 1];
     const float* lb = bias + D * T * 32;
     float araw[NS][4], rraw[NS][4];
     B none[NS][1];
-    pipe_layer<C, typename N::Alpha, decltype(cx.st), 1>(cx.st, cx.pp, act, none, araw, lb, lane, cx.frow_before);
+    pipe_layer<C, typename N::Alpha, decltype(cx.st), 1, TRAIN>(cx.st, cx.pp, hact, none, araw, lb, lane, cx.frow_before, actl);
     lb += 32;
     B vin[NS][KS + PEV_KS];
-    pipe_layer<C, typename N::Feature, decltype(cx.st), KS + PEV_KS>(cx.st, cx.pp, act, vin, nullptr, lb, lane, cx.frow_after);
+    pipe_layer<C, typename N::Feature, decltype(cx.st), KS + PEV_KS, TRAIN>(cx.st, cx.pp, hact, vin, nullptr, lb, lane, cx.frow_after, actl);
     lb += T * 32;
     {
         const B* sp = cx.stash;
@@ -197,9 +211,9 @@ __global__ __launch_bounds__(NT, NT / 256) void k_nerf_mlp(const MlpParams p) {
             for (int j = 0; j < PEV_KS; ++j) vin[s][KS + j] = sp[(s * C::STASH_FRAGS + PE_KS + j) * 64];
     }
     B hbuf[NS][KS / 2];
-    pipe_layer<C, typename N::Views, decltype(cx.st), KS / 2>(cx.st, cx.pp, vin, hbuf, nullptr, lb, lane, cx.frow_after);
+    pipe_layer<C, typename N::Views, decltype(cx.st), KS / 2, TRAIN>(cx.st, cx.pp, vin, hbuf, nullptr, lb, lane, cx.frow_after, actl);
     lb += (T / 2) * 32;
-    pipe_layer<C, typename N::Rgb, decltype(cx.st), 1>(cx.st, cx.pp, hbuf, none, rraw, lb, lane, nofrow);
+    pipe_layer<C, typename N::Rgb, decltype(cx.st), 1, TRAIN>(cx.st, cx.pp, hbuf, none, rraw, lb, lane, nofrow, actl);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         if (h == 0 && valid[s]) {
@@ -214,16 +228,17 @@ template <int PREC, int W, int D, int SKIP> constexpr int nerf_pipe_chunks() {
     return NerfNet<PipeCfg<PREC, 1, 256>, W, D, SKIP, false>::NCH;
 }
 
-template <int PREC, int W, int D, int SKIP, int NS, int NT, bool FEAT>
+template <int PREC, int W, int D, int SKIP, int NS, int NT, bool FEAT, bool TRAIN = false>
 static int launch_pipe_mlp(const MlpParams& p, hipStream_t st) {
     typedef PipeCfg<PREC, NS, NT> C;
     const long blocks = cdiv(p.nsamp, C::SAMPLES);
     const size_t lds = C::TOTAL;
-    EVD_SET_MAX_LDS((&k_nerf_mlp<PREC, W, D, SKIP, NS, NT, FEAT>), lds);
+    EVD_SET_MAX_LDS((&k_nerf_mlp<PREC, W, D, SKIP, NS, NT, FEAT, TRAIN>), lds);
     if (p.nbias > C::BIAS_FLOATS) return fail(EVD_E_INVALID, "evd_nerf_mlp: %d bias floats exceed the LDS bias block", p.nbias);
     if (p.nchunks != NerfNet<C, W, D, SKIP, FEAT>::NCH)
         return fail(EVD_E_INVALID, "evd_nerf_mlp: packed stream has %d chunks, kernel expects %d", p.nchunks, NerfNet<C, W, D, SKIP, FEAT>::NCH);
-    hipLaunchKernelGGL((k_nerf_mlp<PREC, W, D, SKIP, NS, NT, FEAT>), dim3((unsigned)blocks), dim3(NT), lds, st, p);
+    if (TRAIN && !p.act) return fail(EVD_E_INVALID, "evd_nerf_mlp: training launch without an activation store");
+    hipLaunchKernelGGL((k_nerf_mlp<PREC, W, D, SKIP, NS, NT, FEAT, TRAIN>), dim3((unsigned)blocks), dim3(NT), lds, st, p);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }
@@ -232,6 +247,7 @@ static int launch_pipe_mlp(const MlpParams& p, hipStream_t st) {
 constexpr bool nerf_pipe_built(int prec, int W, int D, int skip) {
     return (prec == EVD_PREC_BF16 || prec == EVD_PREC_F16 || prec == EVD_PREC_F16X3) && W == 256 && D == 8 && skip == 4;
 }
+// p.act set: the training variant (saves the activations the backward kernels need)
 int launch_nerf_pipe_bf16(bool feat, const MlpParams& p, hipStream_t st);
 int launch_nerf_pipe_f16(bool feat, const MlpParams& p, hipStream_t st);
 int launch_nerf_pipe_f16x3(bool feat, const MlpParams& p, hipStream_t st);

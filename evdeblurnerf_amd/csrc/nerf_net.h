@@ -1,0 +1,19 @@
+// The opaque evd_nerf handle of include/evdnerf.h, shared by evd_api.hip and evd_train_api.hip.
+#pragma once
+
+#include "evd_common.h"
+
+// transposed-weight streams of the dgrad chain (nerf_train_kernel.h), in the order the chain runs them
+enum { EVD_BWD_RGB = 0, EVD_BWD_VIEWS, EVD_BWD_HEAD, EVD_BWD_HIDDEN1, EVD_BWD_NSTREAMS = EVD_BWD_HIDDEN1 + EVD_MAX_LAYERS };
+
+struct evd_nerf {
+    int D, W, skip, rgb_act, sigma_act;
+    float rmnear;
+    evd::DevBuf stream[EVD_NUM_PREC];        // generic kernel: fragment streams per precision
+    int nchunks[EVD_NUM_PREC];
+    evd::DevBuf pipe[EVD_NUM_PREC];          // software-pipelined kernel (where built): its own fragment order and chunking
+    int pipe_chunks[EVD_NUM_PREC];
+    evd::DevBuf bias;
+    evd::DevBuf bwd[EVD_NUM_PREC][EVD_BWD_NSTREAMS];   // training (bf16 / f16, 8 x 256): W^T streams; HIDDEN1 + l - 1 = pts_linears[l]
+    evd::DevBuf wmaps;                       // wgrad index maps (int32), see evd_train_api.hip
+};

@@ -122,6 +122,18 @@ class NeRF:
                                      L.ptr(raw), L.ptr(feat), kind, L.stream_ptr()), "evd_nerf_mlp")
         return raw, feat
 
+    # Training forward: the same raw plus the activation store evd_nerf_mlp_backward consumes (f16 / bf16, 8 x 256 network)
+    def mlpforward_train(self, ray_batch, z_vals, precision=None):
+        rb = ray_batch.contiguous().float()
+        z = z_vals.contiguous().float()
+        R, S = z.shape
+        raw = torch.empty((R, S, 4), dtype=torch.float32, device=z.device)
+        nb = int(L.lib().evd_nerf_train_store_bytes(R * S))
+        store = torch.empty((nb,), dtype=torch.uint8, device=z.device)
+        L.check(L.lib().evd_nerf_mlp_train(self._h, L.PREC[precision or self.precision], L.ptr(rb), L.ptr(z), R, S, L.ptr(raw),
+                                            L.ptr(store), nb, L.stream_ptr()), "evd_nerf_mlp_train")
+        return raw, store
+
     # nerf.py:74-129; returns the reference 6-tuple (rgb_map, density, acc_map, weights, depth_map, feature_map)
     def raw2outputs(self, raw, z_vals, rays_d, feature=None, raw_noise_std=0, white_bkgd=False, pytest=False,
                     noise=None):

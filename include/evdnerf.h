@@ -113,6 +113,14 @@ size_t evd_nerf_stream_bytes(const evd_nerf* net, int precision);
 int evd_nerf_mlp(const evd_nerf* net, int precision, const float* ray_batch, const float* z, long R, int S,
                  float* raw, float* feature, int feature_kind, void* stream);
 
+/* Training variant of evd_nerf_mlp (the forward half of the autograd graph of NeRF.mlpforward, networks/nerf.py:46-72, that
+ * run_nerf.py:1032-1036 differentiates): same raw, and every layer's activations are kept in `store` (device,
+ * evd_nerf_train_store_bytes(R * S) bytes, fragment layout of csrc/nerf_mlp.h) for evd_nerf_mlp_backward.
+ * Built for precision EVD_PREC_F16 / EVD_PREC_BF16 on the netdepth 8, netwidth 256, skips [4] network; EVD_E_INVALID otherwise. */
+size_t evd_nerf_train_store_bytes(long nsamp);
+int evd_nerf_mlp_train(const evd_nerf* net, int precision, const float* ray_batch, const float* z, long R, int S,
+                       float* raw, void* store, size_t store_bytes, void* stream);
+
 /* raw2outputs: networks/nerf.py:74-129 (sigma_ch 3, rgb_ch0 0) and networks/pdrf/voxnerf.py:153-201
  * (sigma_ch 0, rgb_ch0 1).  raw dev [R,S,C], z dev [R,S], rays_d dev rows of rays_d_stride floats.
  * noise dev [R,S-1] optional (explicit randn*raw_noise_std draw).  rmnear_thresh <= 0 disables the

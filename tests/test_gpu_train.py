@@ -1,0 +1,102 @@
+"""NeRF-mode training path on the GPU: the forward that keeps its activations and the backward of the fused MLP, against a
+float64 torch restatement of NeRF.mlpforward (networks/nerf.py:46-72) differentiated by torch autograd."""
+import numpy as np
+import pytest
+import torch
+
+from evdeblurnerf_amd import weights as W
+
+pytestmark = pytest.mark.gpu
+
+# fragment slots of the activation store (csrc/nerf_mlp.h, namespace astore)
+PE, DIR, H0, F, HV, FWD_END = 0, 4, 6, 134, 150, 158
+G_RGB, G_ALPHA, D_HV, D_F, D_H0, TILE_FRAGS = 158, 159, 160, 168, 184, 312
+
+
+def phi(kk):
+    return 8 * ((kk & 7) >> 2) + 4 * (kk >> 3) + (kk & 3)
+
+
+def embed(x, L):
+    out = [x]
+    for k in range(L):
+        out += [torch.sin(x * 2.0 ** k), torch.cos(x * 2.0 ** k)]
+    return torch.cat(out, -1)
+
+
+class TorchNerf(torch.nn.Module):
+    """float64 restatement of the reference network (D = 8, W = 256, skips = [4], use_viewdirs)."""
+
+    def __init__(self, sd):
+        super().__init__()
+        self.p = torch.nn.ParameterDict({k.replace(".", "_"): torch.nn.Parameter(torch.tensor(np.asarray(v), dtype=torch.float64))
+                                         for k, v in sd.items()})
+
+    def lin(self, name, x):
+        return x @ self.p[name + "_weight"].T + self.p[name + "_bias"]
+
+    def forward(self, pts, dirs, keep=None):
+        pe, ped = embed(pts, 10), embed(dirs, 4)
+        h = pe
+        for l in range(8):
+            h = torch.relu(self.lin(f"pts_linears_{l}", h))
+            if keep is not None:
+                keep[f"h{l}"] = h
+            if l == 4:
+                h = torch.cat([pe, h], -1)
+        alpha = self.lin("alpha_linear", h)
+        f = self.lin("feature_linear", h)
+        hv = torch.relu(self.lin("views_linears_0", torch.cat([f, ped], -1)))
+        if keep is not None:
+            keep["f"], keep["hv"] = f, hv
+        return torch.cat([self.lin("rgb_linear", hv), alpha], -1)
+
+
+def decode(store, nsamp, slot, nfrag, dtype):
+    """fragments [slot, slot + nfrag) of every tile -> [nsamp, 16 * nfrag] in the hidden-channel arrangement (channel 16 j + phi(kk))"""
+    tiles = store.numel() // (TILE_FRAGS * 1024)
+    v = store.view(tiles, TILE_FRAGS, 64, 16)[:, slot:slot + nfrag].contiguous().view(dtype).float()   # [tiles, nfrag, lane, 8]
+    v = v.view(tiles, nfrag, 2, 32, 8)                                                                  # lane = n + 32 h
+    out = torch.zeros((tiles, 32, nfrag * 16), dtype=torch.float32, device=store.device)
+    for h in range(2):
+        for e in range(8):
+            out[:, :, torch.arange(nfrag) * 16 + phi(8 * h + e)] = v[:, :, h, :, e].permute(0, 2, 1)
+    return out.reshape(tiles * 32, nfrag * 16)[:nsamp]
+
+
+def make_inputs(R, S, seed):
+    rs = np.random.RandomState(seed)
+    rb = np.zeros((R, 11), np.float32)
+    rb[:, 0:3] = rs.uniform(-0.5, 0.5, (R, 3))
+    d = rs.normal(size=(R, 3))
+    rb[:, 3:6] = d / np.linalg.norm(d, axis=-1, keepdims=True)
+    rb[:, 6], rb[:, 7] = 0.0, 1.0
+    rb[:, 8:11] = rb[:, 3:6]
+    z = np.sort(rs.uniform(0.2, 2.0, (R, S)).astype(np.float32), -1)
+    return rb, z
+
+
+@pytest.mark.parametrize("prec,tol", [("f16", 4e-3), ("bf16", 6e-2)])
+@pytest.mark.parametrize("R,S", [(64, 64), (37, 9)])
+def test_training_forward_keeps_every_activation(prec, tol, R, S):
+    from evdeblurnerf_amd.nerf import NeRF
+    sd = W.make_nerf_state_dict(21)
+    rb, z = make_inputs(R, S, 5)
+    net = NeRF(sd, precision=prec)
+    dev = "cuda"
+    raw, store = net.mlpforward_train(torch.tensor(rb, device=dev), torch.tensor(z, device=dev))
+    raw_inf, _ = net.mlpforward(torch.tensor(rb, device=dev), torch.tensor(z, device=dev))
+    assert torch.equal(raw, raw_inf)                    # the training variant runs the same arithmetic
+    pts = torch.tensor(rb[:, None, 0:3] + rb[:, None, 3:6] * z[..., None], dtype=torch.float64).reshape(-1, 3)
+    dirs = torch.tensor(np.repeat(rb[:, None, 8:11], S, 1), dtype=torch.float64).reshape(-1, 3)
+    keep = {}
+    ref = TorchNerf(sd)(pts, dirs, keep)
+    n = R * S
+    assert (raw.reshape(n, 4).cpu().double() - ref).abs().max().item() < tol
+    dt = torch.float16 if prec == "f16" else torch.bfloat16
+    for l in range(8):
+        got = decode(store, n, H0 + 16 * l, 16, dt).cpu().double()
+        err = (got - keep[f"h{l}"]).abs().max().item()
+        assert err < tol * max(1.0, keep[f"h{l}"].abs().max().item()), (l, err)
+    assert (decode(store, n, F, 16, dt).cpu().double() - keep["f"]).abs().max().item() < tol * max(1.0, keep["f"].abs().max().item())
+    assert (decode(store, n, HV, 8, dt).cpu().double() - keep["hv"]).abs().max().item() < tol * max(1.0, keep["hv"].abs().max().item())
