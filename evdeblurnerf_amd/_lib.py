@@ -39,6 +39,12 @@ class NerfDesc(C.Structure):
                 ("alpha_w", _fp), ("alpha_b", _fp), ("rgb_w", _fp), ("rgb_b", _fp)]
 
 
+class NerfGrads(C.Structure):
+    _fields_ = [("pts_w", _vp * MAXL), ("pts_b", _vp * MAXL),
+                ("views_w", _vp), ("views_b", _vp), ("feature_w", _vp), ("feature_b", _vp),
+                ("alpha_w", _vp), ("alpha_b", _vp), ("rgb_w", _vp), ("rgb_b", _vp)]
+
+
 class VoxelDesc(C.Structure):
     _fields_ = [("num_layers", C.c_int), ("hidden_dim", C.c_int), ("geo_feat_dim", C.c_int),
                 ("num_layers_color", C.c_int), ("input_ch", C.c_int), ("multires", C.c_int), ("multires_views", C.c_int),
@@ -82,6 +88,8 @@ SIGNATURES = {
     "evd_nerf_mlp": (_I, [_vp, _I, _vp, _vp, _L, _I, _vp, _vp, _I, _vp]),
     "evd_nerf_train_store_bytes": (_S, [_L]),
     "evd_nerf_mlp_train": (_I, [_vp, _I, _vp, _vp, _L, _I, _vp, _vp, _S, _vp]),
+    "evd_nerf_backward_workspace_bytes": (_S, []),
+    "evd_nerf_mlp_backward": (_I, [_vp, _I, _vp, _L, _I, _vp, _S, C.POINTER(NerfGrads), _vp, _S, _vp]),
     "evd_raw2outputs": (_I, [_vp, _vp, _vp, _I, _L, _I, _I, _I, _I, _I, _I, _I, _I, _F, _vp,
                              _vp, _vp, _vp, _vp, _vp, _vp, _I, _vp, _vp]),
     "evd_raw2outputs_bwd": (_I, [_vp, _vp, _vp, _I, _L, _I, _I, _I, _I, _I, _I, _I, _I, _F, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -3,6 +3,7 @@
 #include "nerf_mlp.h"
 #include "nerf_mlp_kernel.h"
 #include "nerf_net.h"
+#include "nerf_train.h"
 #include "pack.h"
 
 #include <cmath>
@@ -98,6 +99,50 @@ int evd_nerf_create(const evd_nerf_desc* d, evd_nerf** out) {
             if (rc) { evd_nerf_destroy(n); return rc; }
         }
     }
+    // training path (bf16 / f16 on the pipelined network): W^T streams of the dgrad chain, one per layer (nerf_train_kernel.h)
+    for (int prec = 0; prec < EVD_NUM_PREC; ++prec) {
+        if (!is_half_prec(prec) || !n->pipe_chunks[prec]) continue;
+        // rows = forward inputs col0 .. col0 + nrow of Wm [out, in], columns = forward outputs (+ one extra matrix appended)
+        auto transposed = [](const float* Wm, int out, int in, int col0, int nrow, const float* extra, int extra_out) {
+            std::vector<float> t((size_t)nrow * (out + extra_out), 0.f);
+            for (int r = 0; r < nrow; ++r) {
+                for (int c = 0; c < out; ++c) t[(size_t)r * (out + extra_out) + c] = Wm[(size_t)c * in + col0 + r];
+                for (int c = 0; c < extra_out; ++c) t[(size_t)r * (out + extra_out) + out + c] = extra[(size_t)c * nrow + r];
+            }
+            return t;
+        };
+        auto put = [&](int which, const std::vector<float>& wt, int in_dim, int tiles, int ksteps, auto col) {
+            StreamBuilder sb(prec, PIPE_CB);
+            sb.group = 1;
+            sb.layer(wt.data(), tiles * 32, in_dim, tiles, ksteps, true, col);
+            return n->bwd[prec][which].upload(sb.bytes.data(), sb.bytes.size());
+        };
+        int rc = put(EVD_BWD_RGB, transposed(d->rgb_w, 3, W / 2, 0, W / 2, nullptr, 0), 3, T / 2, 1, [](int, int kk) { return kk < 3 ? kk : -1; });
+        if (!rc) rc = put(EVD_BWD_VIEWS, transposed(d->views_w, W / 2, W + ICV, 0, W, nullptr, 0), W / 2, T, KS / 2, hid_col);
+        if (!rc) rc = put(EVD_BWD_HEAD, transposed(d->feature_w, W, W, 0, W, d->alpha_w, 1), W + 1, T, KS + 1,
+                          [&](int j, int kk) { return j < KS ? hid_col(j, kk) : (kk == 0 ? W : -1); });
+        for (int l = 1; l < d->D && !rc; ++l) {
+            const bool wide = l - 1 == d->skip;
+            rc = put(EVD_BWD_HIDDEN1 + l - 1, transposed(d->pts_w[l], W, wide ? W + IC : W, wide ? IC : 0, W, nullptr, 0), W, T, KS, hid_col);
+        }
+        if (rc) { evd_nerf_destroy(n); return rc; }
+    }
+    {   // wgrad index maps (nerf_train.h): fragment column (fragment j = i / 16, position kk = i % 16) -> parameter row / column
+        std::vector<int> m(MAP_TOTAL, -1);
+        for (int i = 0; i < 256; ++i) {
+            m[MAP_HID + i] = hid_col(i / 16, i % 16);
+            m[MAP_HID_SKIP + i] = IC + hid_col(i / 16, i % 16);
+        }
+        for (int i = 0; i < 64; ++i) m[MAP_PE + i] = pe_col(i / 16, i % 16);
+        for (int i = 0; i < 32; ++i) {
+            const int c = pe_src_col(PE_LV, 8 * (i / 16) + (i % 16 & 7), (i % 16) >> 3);
+            m[MAP_DIR + i] = c < 0 ? -1 : W + c;
+        }
+        for (int i = 0; i < 3; ++i) m[MAP_RGB + i] = i;
+        m[MAP_ALPHA] = 0;
+        int rc = n->wmaps.upload(m.data(), m.size() * sizeof(int));
+        if (rc) { evd_nerf_destroy(n); return rc; }
+    }
     // biases, one 32-float row block per output tile, in stream order
     std::vector<float> b;
     auto push = [&](const float* src, int out_dim, int tiles) {
@@ -116,7 +161,12 @@ int evd_nerf_create(const evd_nerf_desc* d, evd_nerf** out) {
 
 void evd_nerf_destroy(evd_nerf* n) {
     if (!n) return;
-    for (int i = 0; i < EVD_NUM_PREC; ++i) { n->stream[i].release(); n->pipe[i].release(); }
+    for (int i = 0; i < EVD_NUM_PREC; ++i) {
+        n->stream[i].release();
+        n->pipe[i].release();
+        for (int k = 0; k < EVD_BWD_NSTREAMS; ++k) n->bwd[i][k].release();
+    }
+    n->wmaps.release();
     n->bias.release();
     delete n;
 }

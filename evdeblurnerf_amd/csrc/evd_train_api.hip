@@ -5,6 +5,8 @@
 #include "nerf_net.h"
 #include "nerf_train.h"
 
+#include <cstdint>
+
 using namespace evd;
 
 namespace evd {
@@ -34,6 +36,36 @@ int evd_nerf_mlp_train(const evd_nerf* net, int precision, const float* ray_batc
     p.D = net->D; p.skip = net->skip; p.nchunks = net->pipe_chunks[precision]; p.nbias = (int)(net->bias.bytes / sizeof(float));
     p.raw = raw; p.feature = nullptr; p.feature_kind = 0; p.act = (char*)store;
     return precision == EVD_PREC_F16 ? launch_nerf_train_fwd_f16(p, as_stream(stream)) : launch_nerf_train_fwd_bf16(p, as_stream(stream));
+}
+
+// scratch of the backward: the wgrad partial sums of the largest block (8 x 9 accumulator tiles per wavefront group) + the loss-scale word
+static const int WGRAD_BLOCKS = 256;
+size_t evd_nerf_backward_workspace_bytes(void) { return (size_t)WGRAD_BLOCKS * 8 * 9 * 4096 + 512; }
+
+int evd_nerf_mlp_backward(const evd_nerf* net, int precision, const float* d_raw, long R, int S, void* store, size_t store_bytes,
+                          const evd_nerf_grads* grads, void* workspace, size_t workspace_bytes, void* stream) {
+    EVD_REQUIRE(net && d_raw && store && grads && workspace, "evd_nerf_mlp_backward: null argument");
+    EVD_REQUIRE(precision >= 0 && precision < EVD_NUM_PREC && train_built(net, precision),
+                "evd_nerf_mlp_backward: the training path is built for precision f16 / bf16 on the netdepth 8, netwidth 256, skips [4] network");
+    EVD_REQUIRE(R >= 0 && S >= 1, "evd_nerf_mlp_backward: bad shape R=%ld S=%d", R, S);
+    if (R == 0) return EVD_OK;
+    const long nsamp = R * (long)S;
+    if (store_bytes < evd_nerf_train_store_bytes(nsamp))
+        return fail(EVD_E_WORKSPACE, "evd_nerf_mlp_backward: store %zu < %zu bytes", store_bytes, evd_nerf_train_store_bytes(nsamp));
+    if (workspace_bytes < evd_nerf_backward_workspace_bytes())
+        return fail(EVD_E_WORKSPACE, "evd_nerf_mlp_backward: workspace %zu < %zu bytes", workspace_bytes, evd_nerf_backward_workspace_bytes());
+    BwdPlan b;
+    b.d_raw = d_raw; b.nsamp = nsamp; b.tiles = train_tiles(nsamp); b.store = (char*)store;
+    for (int k = 0; k < EVD_BWD_NSTREAMS; ++k) b.wt[k] = (const char*)net->bwd[precision][k].p;
+    b.maps = (const int*)net->wmaps.p;
+    char* w = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    b.maxbits = (unsigned*)w;
+    b.partial = (float*)(w + 256);
+    b.wgrad_blocks = WGRAD_BLOCKS; b.skip = net->skip;
+    for (int l = 0; l < EVD_MAX_LAYERS; ++l) { b.grads.pts_w[l] = l < net->D ? grads->pts_w[l] : nullptr; b.grads.pts_b[l] = l < net->D ? grads->pts_b[l] : nullptr; }
+    b.grads.views_w = grads->views_w; b.grads.views_b = grads->views_b; b.grads.feature_w = grads->feature_w; b.grads.feature_b = grads->feature_b;
+    b.grads.alpha_w = grads->alpha_w; b.grads.alpha_b = grads->alpha_b; b.grads.rgb_w = grads->rgb_w; b.grads.rgb_b = grads->rgb_b;
+    return precision == EVD_PREC_F16 ? run_nerf_backward_f16(b, as_stream(stream)) : run_nerf_backward_bf16(b, as_stream(stream));
 }
 
 }  // extern "C"

@@ -3,10 +3,40 @@
 
 #include "evd_common.h"
 #include "nerf_mlp.h"
+#include "nerf_net.h"
 
 namespace evd {
 
 int launch_nerf_train_fwd_f16(const MlpParams& p, hipStream_t st);
 int launch_nerf_train_fwd_bf16(const MlpParams& p, hipStream_t st);
+
+// index maps of the wgrad reduction (fragment column -> parameter row / column, -1 = padding), offsets into one int32 array
+enum { MAP_HID = 0,                    // 256: hidden arrangement, channel 16 j + phi(kk)
+       MAP_HID_SKIP = MAP_HID + 256,   // 256: the same behind the 63 point-encoding columns of the skip layer
+       MAP_PE = MAP_HID_SKIP + 256,    // 64: point encoding (4 fragments)
+       MAP_DIR = MAP_PE + 64,          // 32: direction encoding (2 fragments), behind the 256 feature columns
+       MAP_RGB = MAP_DIR + 32,         // 32: d rgb fragment
+       MAP_ALPHA = MAP_RGB + 32,       // 32: d alpha fragment
+       MAP_TOTAL = MAP_ALPHA + 32 };
+
+struct BwdGrads {                       // device float32, reference nn.Linear layouts; null = not wanted
+    float *pts_w[EVD_MAX_LAYERS], *pts_b[EVD_MAX_LAYERS];
+    float *views_w, *views_b, *feature_w, *feature_b, *alpha_w, *alpha_b, *rgb_w, *rgb_b;
+};
+
+struct BwdPlan {
+    const float* d_raw;                 // [nsamp, 4]
+    long nsamp, tiles;
+    char* store;
+    const char* wt[EVD_BWD_NSTREAMS];   // W^T fragment streams
+    const int* maps;
+    float* partial;
+    unsigned* maxbits;
+    int wgrad_blocks, skip;
+    BwdGrads grads;
+};
+
+int run_nerf_backward_f16(const BwdPlan& b, hipStream_t st);
+int run_nerf_backward_bf16(const BwdPlan& b, hipStream_t st);
 
 }  // namespace evd

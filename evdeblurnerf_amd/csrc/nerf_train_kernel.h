@@ -1,0 +1,342 @@
+// Backward of the fused NeRF MLP (bf16 / f16 modes, netdepth 8, netwidth 256, skips [4]).
+// reference: the autograd graph of NeRF.mlpforward, networks/nerf.py:46-72, differentiated by run_nerf.py:1032-1036.
+//
+// Everything works on the activation store the training forward filled (nerf_mlp.h, namespace astore): one 1 KiB MFMA
+// B fragment per (32-sample tile, 16 channels), lane-linear, so every access below is a coalesced 16-byte load/store
+// per lane and no kernel ever re-arranges data through LDS.
+//
+//   k_grad_frags   d raw [n,4] (float32) x 2^s  ->  the two gradient fragments G_RGB, G_ALPHA (s: power-of-two loss
+//                  scale that puts max |d raw| in [512, 1024), so float16 gradients neither overflow nor flush)
+//   k_dgrad_layer  d x = W^T (d y . [y > 0]) for ONE layer, on the software pipeline of the forward kernel: W^T is the
+//                  streamed A operand, the incoming gradient fragments are the B operand, the outgoing ones are
+//                  stored un-masked; the masked incoming gradient is written back in place for the wgrad kernel
+//   k_wgrad        dW = d y . x^T over all samples.  Both operands are stored sample-minor, the contraction runs over
+//                  samples: each 32x32 block is first transposed ON THE MATRIX CORE (the stored fragment as the A
+//                  operand against a 0/1 selector as B returns it with samples along the accumulator registers),
+//                  converted back to half precision (exact) and fed to the product MFMAs.  A wavefront owns RPW row
+//                  tiles x all column tiles of dW in accumulators and walks the sample tiles with a grid stride;
+//                  partial sums go to a float32 scratch, bias gradients ride along as a column of ones.
+//   k_wgrad_reduce sums the partials, undoes the fragment permutations through two index maps, removes the loss scale
+#pragma once
+
+#include "mlp_pipe.h"
+#include "nerf_train.h"
+
+namespace evd {
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+// 2^s with max * 2^s in [512, 1024); `bits` = float bits of max |d raw| (0: no gradient at all)
+__device__ __forceinline__ float grad_scale(unsigned bits, bool inverse) {
+    const float m = __uint_as_float(bits);
+    if (!(m > 0.f) || !(m < 3.0e38f)) return 1.f;
+    int e;
+    (void)frexpf(m, &e);                                 // m = f 2^e, f in [0.5, 1)
+    return ldexpf(1.f, inverse ? e - 10 : 10 - e);
+}
+
+static __global__ void k_absmax(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+template <int PREC>
+__global__ __launch_bounds__(256) void k_grad_frags(const float* __restrict__ d_raw, long nsamp, const unsigned* __restrict__ maxbits,
+                                                    char* __restrict__ store, long tiles) {
+    typedef POps<PREC> O;
+    typedef typename O::B B;
+    pipe_fp16_saturate<PREC>();
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x, tile = idx >> 6;
+    if (tile >= tiles) return;
+    const int lane = idx & 63, n = lane & 31, h = lane >> 5;
+    const long smp = tile * 32 + n;
+    const float s = grad_scale(*maxbits, false);
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    if (h == 0 && smp < nsamp) g = *reinterpret_cast<const f32x4*>(d_raw + smp * 4);
+    B rgb, al;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) rgb.w[e] = al.w[e] = 0u;
+    O::template set_pair<false>(rgb, 0, g[0] * s, g[1] * s);
+    O::template set_pair<false>(rgb, 1, g[2] * s, 0.f);
+    O::template set_pair<false>(al, 0, g[3] * s, 0.f);
+    char* a = store + tile * astore::TILE_BYTES + lane * 16;
+    act_store(a, astore::G_RGB, rgb);
+    act_store(a, astore::G_ALPHA, al);
+}
+
+// gradient word . [activation != 0], both halves (activations are post-ReLU: masked <=> the stored half is +0)
+__device__ __forceinline__ unsigned mask_word(unsigned g, unsigned a) {
+    const u16x2 av = __builtin_bit_cast(u16x2, a), zero = {0, 0};
+    return g & __builtin_bit_cast(unsigned, av != zero);
+}
+
+template <class B> __device__ __forceinline__ B frag_load(const char* lane_base, int slot) {
+    return __builtin_bit_cast(B, *reinterpret_cast<const f32x4*>(lane_base + (long)slot * 1024));
+}
+
+struct DgradParams {
+    const char* wstream;    // W^T as a fragment stream (pack.h), one layer
+    char* store;
+    int in_slot, extra_slot, mask_slot, out_slot;
+};
+
+// One dgrad layer: KTOT k-steps in (NIN contiguous fragments from in_slot, masked by the fragments at mask_slot if MASK,
+// plus one more from extra_slot if EXTRA), TILES 32-row tiles out.  8 wavefronts x 32 samples per workgroup.
+template <int PREC, int KTOT, int TILES, int NIN, bool EXTRA, bool MASK, int NT>
+__global__ __launch_bounds__(NT, NT / 256) void k_dgrad_layer(const DgradParams p) {
+    typedef PipeCfg<PREC, 1, NT> C;
+    typedef typename C::O::B B;
+    typedef LayerDesc<KTOT, TILES, 1, false, false, 0, 0, true, 0, 0, 0, false, 0, -1, false, 0, 0, -1> L;
+    constexpr int NCH = cceil(KTOT * TILES, C::FPC);
+    static_assert(NIN + (EXTRA ? 1 : 0) == KTOT && KTOT * TILES >= C::PD - 1, "k-steps of the layer");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    pipe_fp16_saturate<PREC>();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    PStream<C, true, NCH> st;
+    st.start_issue(p.wstream, smem, tid);
+    float* zb = reinterpret_cast<float*>(smem + C::RING);       // the dgrad layers have no bias: a block of zeros
+    for (int i = tid; i < (TILES + 1) * 32; i += NT) zb[i] = 0.f;
+    char* al = p.store + ((long)blockIdx.x * (NT / 64) + wave) * astore::TILE_BYTES + lane * 16;
+
+    B in[1][KTOT], out[1][2 * TILES];
+#pragma unroll
+    for (int j = 0; j < NIN; ++j) in[0][j] = frag_load<B>(al, p.in_slot + j);
+    if constexpr (EXTRA) in[0][NIN] = frag_load<B>(al, p.extra_slot);
+    if constexpr (MASK) {
+#pragma unroll
+        for (int j = 0; j < NIN; ++j) {
+            const B m = frag_load<B>(al, p.mask_slot + j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) in[0][j].w[e] = mask_word(in[0][j].w[e], m.w[e]);
+            act_store(al, p.in_slot + j, in[0][j]);              // wgrad reads the masked gradient
+        }
+    }
+    char* actl[1] = {al + (long)p.out_slot * 1024};
+    float* nofrow[1] = {nullptr};
+    Pipe<C> pp;
+    st.start_wait();
+    pipe_prime<C, L>(st, pp, zb, lane);
+    pipe_layer<C, L, decltype(st), 2 * TILES, true>(st, pp, in, out, nullptr, zb, lane, nofrow, actl);
+    pipe_flush<C, L>(pp, out);
+    act_store(actl[0], 2 * TILES - 2, out[0][2 * TILES - 2]);
+    act_store(actl[0], 2 * TILES - 1, out[0][2 * TILES - 1]);
+}
+
+template <int PREC, int KTOT, int TILES, int NIN, bool EXTRA, bool MASK>
+static int launch_dgrad(const DgradParams& p, long tiles, hipStream_t st) {
+    constexpr int NT = 512;
+    typedef PipeCfg<PREC, 1, NT> C;
+    const size_t lds = C::RING + (TILES + 1) * 128;
+    EVD_SET_MAX_LDS((&k_dgrad_layer<PREC, KTOT, TILES, NIN, EXTRA, MASK, NT>), lds);
+    hipLaunchKernelGGL((k_dgrad_layer<PREC, KTOT, TILES, NIN, EXTRA, MASK, NT>), dim3((unsigned)(tiles / (NT / 64))), dim3(NT), lds, st, p);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct WgradParams {
+    const char* store;
+    long tiles;
+    int y_slot, x_slot, mask_slot;
+    float* partial;         // [gridDim.x * NGRP][RT][CT + BIAS][64][16] float32
+};
+
+constexpr int WGRAD_NT = 256;
+constexpr int wgrad_rpw(int RT) { return RT >= 4 ? RT / 4 : 1; }           // row tiles per wavefront
+constexpr int wgrad_ngrp(int RT) { return 4 / (RT / wgrad_rpw(RT)); }      // wavefront groups walking different sample tiles
+
+struct W4 { unsigned w[4]; };
+
+template <int PREC> __device__ __forceinline__ f32x16 mfma_half(const W4& a, const W4& b, const f32x16& c) {
+    if constexpr (PREC == EVD_PREC_BF16) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// the 32-channel x 32-sample block held by fragments (f0, f1), returned sample-major: operand q (16 samples) of a
+// lane = channel column (lane & 31) of the block; both MFMA operand roles read it the same way
+template <int PREC> __device__ __forceinline__ void transpose_block(const W4& f0, const W4& f1, const W4& sel0, const W4& sel1, W4 (&t)[2]) {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 d = mfma_half<PREC>(f0, sel0, zero);
+    d = mfma_half<PREC>(f1, sel1, d);
+    typename POps<PREC>::B b;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) POps<PREC>::template set_pair<false>(b, e, d[8 * q + 2 * e], d[8 * q + 2 * e + 1]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[q].w[e] = b.w[e];
+    }
+}
+
+template <int PREC> __device__ __forceinline__ unsigned half_one_pair() { return PREC == EVD_PREC_BF16 ? 0x3f803f80u : 0x3c003c00u; }
+
+// RT row tiles (fragments y_slot .. ; YSINGLE: one fragment, 16 channels) x CT column tiles (fragments x_slot ..)
+template <int PREC, int RT, int CT, bool YSINGLE, bool MASK, bool BIAS>
+__global__ __launch_bounds__(WGRAD_NT) void k_wgrad(const WgradParams p) {
+    constexpr int RPW = wgrad_rpw(RT), WPG = RT / RPW, NGRP = wgrad_ngrp(RT), NC = CT + (BIAS ? 1 : 0);
+    static_assert(!YSINGLE || RT == 1, "single-fragment gradients are one row tile");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 31, h = lane >> 5;
+    const int grp = wave / WPG, rt0 = (wave % WPG) * RPW;
+    // selectors: sel0[kk][n] = (n == kk), sel1[kk][n] = (n == 16 + kk); this lane holds kk = 8h .. 8h + 7 of column n
+    W4 sel0, sel1, ones;
+    const unsigned one = half_one_pair<PREC>();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int kk = 8 * h + 2 * e;
+        sel0.w[e] = (n == kk ? (one & 0xffffu) : 0u) | (n == kk + 1 ? (one & 0xffff0000u) : 0u);
+        sel1.w[e] = (n == 16 + kk ? (one & 0xffffu) : 0u) | (n == 17 + kk ? (one & 0xffff0000u) : 0u);
+        ones.w[e] = n == 0 ? one : 0u;
+    }
+    const W4 zf = {{0u, 0u, 0u, 0u}};
+    f32x16 acc[RPW][NC];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[r][c][i] = 0.f;
+
+    for (long t = (long)blockIdx.x * NGRP + grp; t < p.tiles; t += (long)gridDim.x * NGRP) {
+        const char* al = p.store + t * astore::TILE_BYTES + lane * 16;
+        W4 yt[RPW][2];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            W4 y0 = frag_load<W4>(al, p.y_slot + 2 * (rt0 + r)), y1 = zf;
+            if constexpr (!YSINGLE) y1 = frag_load<W4>(al, p.y_slot + 2 * (rt0 + r) + 1);
+            if constexpr (MASK) {
+                const W4 m0 = frag_load<W4>(al, p.mask_slot + 2 * (rt0 + r)), m1 = frag_load<W4>(al, p.mask_slot + 2 * (rt0 + r) + 1);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    y0.w[e] = mask_word(y0.w[e], m0.w[e]);
+                    y1.w[e] = mask_word(y1.w[e], m1.w[e]);
+                }
+            }
+            transpose_block<PREC>(y0, y1, sel0, sel1, yt[r]);
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const W4 x0 = frag_load<W4>(al, p.x_slot + 2 * c), x1 = frag_load<W4>(al, p.x_slot + 2 * c + 1);
+            W4 xt[2];
+            transpose_block<PREC>(x0, x1, sel0, sel1, xt);
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) acc[r][c] = mfma_half<PREC>(yt[r][q], xt[q], acc[r][c]);
+        }
+        if constexpr (BIAS) {
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) acc[r][CT] = mfma_half<PREC>(yt[r][q], ones, acc[r][CT]);
+        }
+    }
+    float* out = p.partial + ((((long)blockIdx.x * NGRP + grp) * RT + rt0) * NC) * 1024 + lane * 16;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = {acc[r][c][4 * q], acc[r][c][4 * q + 1], acc[r][c][4 * q + 2], acc[r][c][4 * q + 3]};
+                *reinterpret_cast<f32x4*>(out + (r * NC + c) * 1024 + 4 * q) = v;
+            }
+}
+
+struct WreduceParams {
+    const float* partial;
+    int nparts, RT, NC, CT;            // NC = CT + 1 when the bias column rides along
+    const int* rowmap;                 // [RT * 32] -> row of dW (or -1)
+    const int* colmap;                 // [CT * 32] -> column of dW (or -1)
+    float* dW;
+    int ld;
+    float* db;                         // or null
+    const unsigned* maxbits;
+};
+
+// one thread per accumulator element (rt, c, lane, i): the partials of consecutive threads are contiguous
+static __global__ __launch_bounds__(256) void k_wgrad_reduce(const WreduceParams p) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x, per = (long)p.RT * p.NC * 1024;
+    if (idx >= per) return;
+    const int i = idx & 15, lane = (idx >> 4) & 63, c = (int)((idx >> 10) % p.NC), rt = (int)((idx >> 10) / p.NC);
+    float s = 0.f;
+    for (int q = 0; q < p.nparts; ++q) s += p.partial[q * per + idx];
+    s *= grad_scale(*p.maxbits, true);
+    const int nr = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5), nc = lane & 31;
+    const int row = p.rowmap[rt * 32 + nr];
+    if (row < 0) return;
+    if (c < p.CT) {
+        const int col = p.colmap[c * 32 + nc];
+        if (col >= 0) p.dW[(long)row * p.ld + col] = s;
+    } else if (nc == 0 && p.db) {
+        p.db[row] = s;
+    }
+}
+
+template <int PREC, int RT, int CT, bool YSINGLE, bool MASK, bool BIAS>
+static int launch_wgrad(const WgradParams& p, int blocks, hipStream_t st) {
+    hipLaunchKernelGGL((k_wgrad<PREC, RT, CT, YSINGLE, MASK, BIAS>), dim3(blocks), dim3(WGRAD_NT), 0, st, p);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The whole backward of one network, in the order the gradients become available.
+template <int PREC> static int run_nerf_backward(const BwdPlan& b, hipStream_t st) {
+    using namespace astore;
+    constexpr int D = 8;
+    int rc;
+    EVD_HIP(hipMemsetAsync(b.maxbits, 0, sizeof(unsigned), st));
+    hipLaunchKernelGGL(k_absmax, dim3(512), dim3(256), 0, st, b.d_raw, b.nsamp * 4, b.maxbits);
+    EVD_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_grad_frags<PREC>), dim3((unsigned)cdiv(b.tiles * 64, 256L)), dim3(256), 0, st, b.d_raw, b.nsamp, b.maxbits, b.store, b.tiles);
+    EVD_LAUNCH_CHECK();
+
+    auto dgrad = [&](int stream, int in_slot, int extra_slot, int mask_slot, int out_slot) {
+        DgradParams p;
+        p.wstream = b.wt[stream]; p.store = b.store; p.in_slot = in_slot; p.extra_slot = extra_slot; p.mask_slot = mask_slot; p.out_slot = out_slot;
+        return p;
+    };
+    // wgrad + reduce of one parameter block: rows from `ymap`, columns from `xmap` (offset into b.maps)
+    auto wgrad = [&](auto launch, int RT, int CT, bool bias, int y_slot, int x_slot, int mask_slot, int ymap, int xmap, float* dW, int ld, float* db) -> int {
+        if (!dW) return EVD_OK;
+        const int ngrp = wgrad_ngrp(RT), blocks = (int)(b.tiles / ngrp < b.wgrad_blocks ? (b.tiles + ngrp - 1) / ngrp : b.wgrad_blocks);
+        WgradParams p;
+        p.store = b.store; p.tiles = b.tiles; p.y_slot = y_slot; p.x_slot = x_slot; p.mask_slot = mask_slot; p.partial = b.partial;
+        int r = launch(p, blocks, st);
+        if (r) return r;
+        WreduceParams q;
+        q.partial = b.partial; q.nparts = blocks * ngrp; q.RT = RT; q.CT = CT; q.NC = CT + (bias ? 1 : 0);
+        q.rowmap = b.maps + ymap; q.colmap = b.maps + xmap; q.dW = dW; q.ld = ld; q.db = bias ? db : nullptr; q.maxbits = b.maxbits;
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)cdiv((long)RT * q.NC * 1024, 256L)), dim3(256), 0, st, q);
+        EVD_LAUNCH_CHECK();
+        return EVD_OK;
+    };
+    const BwdGrads& g = b.grads;
+    // rgb_linear: d hv = Wr^T d rgb;  dWr = d rgb . hv^T
+    if ((rc = launch_dgrad<PREC, 1, 4, 1, false, false>(dgrad(EVD_BWD_RGB, G_RGB, -1, -1, D_HV), b.tiles, st))) return rc;
+    if ((rc = wgrad(launch_wgrad<PREC, 1, 4, true, false, true>, 1, 4, true, G_RGB, HV, -1, MAP_RGB, MAP_HID, g.rgb_w, 128, g.rgb_b))) return rc;
+    // views_linears.0 on cat([feature, PE(dir)])
+    if ((rc = launch_dgrad<PREC, 8, 8, 8, false, true>(dgrad(EVD_BWD_VIEWS, D_HV, -1, HV, D_F), b.tiles, st))) return rc;
+    if ((rc = wgrad(launch_wgrad<PREC, 4, 8, false, false, true>, 4, 8, true, D_HV, F, -1, MAP_HID, MAP_HID, g.views_w, 256 + 27, g.views_b))) return rc;
+    if ((rc = wgrad(launch_wgrad<PREC, 4, 1, false, false, false>, 4, 1, false, D_HV, DIR, -1, MAP_HID, MAP_DIR, g.views_w, 256 + 27, nullptr))) return rc;
+    // feature_linear and alpha_linear both read h_7
+    if ((rc = launch_dgrad<PREC, 17, 8, 16, true, false>(dgrad(EVD_BWD_HEAD, D_F, G_ALPHA, -1, D_H0 + 16 * (D - 1)), b.tiles, st))) return rc;
+    if ((rc = wgrad(launch_wgrad<PREC, 8, 8, false, false, true>, 8, 8, true, D_F, H0 + 16 * (D - 1), -1, MAP_HID, MAP_HID, g.feature_w, 256, g.feature_b))) return rc;
+    if ((rc = wgrad(launch_wgrad<PREC, 1, 8, true, false, true>, 1, 8, true, G_ALPHA, H0 + 16 * (D - 1), -1, MAP_ALPHA, MAP_HID, g.alpha_w, 256, g.alpha_b))) return rc;
+    // pts_linears[l], l = 7 .. 1
+    for (int l = D - 1; l >= 1; --l) {
+        const bool wide = l - 1 == b.skip;
+        if ((rc = launch_dgrad<PREC, 16, 8, 16, false, true>(dgrad(EVD_BWD_HIDDEN1 + l - 1, D_H0 + 16 * l, -1, H0 + 16 * l, D_H0 + 16 * (l - 1)), b.tiles, st))) return rc;
+        if ((rc = wgrad(launch_wgrad<PREC, 8, 8, false, false, true>, 8, 8, true, D_H0 + 16 * l, H0 + 16 * (l - 1), -1, MAP_HID, wide ? MAP_HID_SKIP : MAP_HID,
+                        g.pts_w[l], wide ? 256 + 63 : 256, g.pts_b[l]))) return rc;
+        if (wide && (rc = wgrad(launch_wgrad<PREC, 8, 2, false, false, false>, 8, 2, false, D_H0 + 16 * l, PE, -1, MAP_HID, MAP_PE, g.pts_w[l], 256 + 63, nullptr))) return rc;
+    }
+    // pts_linears[0] on PE(pts): its incoming gradient is masked here (no dgrad beyond the inputs)
+    return wgrad(launch_wgrad<PREC, 8, 2, false, true, true>, 8, 2, true, D_H0, PE, H0, MAP_HID, MAP_PE, g.pts_w[0], 63, g.pts_b[0]);
+}
+
+}  // namespace evd

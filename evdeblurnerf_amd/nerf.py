@@ -134,6 +134,33 @@ class NeRF:
                                             L.ptr(store), nb, L.stream_ptr()), "evd_nerf_mlp_train")
         return raw, store
 
+    # Backward of mlpforward_train: d_raw [R,S,4] -> {state-dict key: gradient} (what autograd gives for nerf.py:46-72)
+    def mlp_backward(self, d_raw, store, precision=None):
+        g = d_raw.contiguous().float()
+        R, S = g.shape[:2]
+        dev = g.device
+        shapes = {f"pts_linears.{i}": (self.W, 63 if i == 0 else (self.W + 63 if i == 5 else self.W)) for i in range(self.D)}
+        shapes.update({"views_linears.0": (self.W // 2, self.W + 27), "feature_linear": (self.W, self.W),
+                       "alpha_linear": (1, self.W), "rgb_linear": (3, self.W // 2)})
+        out = {}
+        gs = L.NerfGrads()
+        for key, (o, i) in shapes.items():
+            w = torch.zeros((o, i), dtype=torch.float32, device=dev)
+            b = torch.zeros((o,), dtype=torch.float32, device=dev)
+            out[key + ".weight"], out[key + ".bias"] = w, b
+            if key.startswith("pts_linears."):
+                k = int(key.split(".")[1])
+                gs.pts_w[k], gs.pts_b[k] = L.ptr(w), L.ptr(b)
+            else:
+                name = {"views_linears.0": "views", "feature_linear": "feature", "alpha_linear": "alpha", "rgb_linear": "rgb"}[key]
+                setattr(gs, name + "_w", L.ptr(w))
+                setattr(gs, name + "_b", L.ptr(b))
+        nb = int(L.lib().evd_nerf_backward_workspace_bytes())
+        ws = torch.empty((nb,), dtype=torch.uint8, device=dev)
+        L.check(L.lib().evd_nerf_mlp_backward(self._h, L.PREC[precision or self.precision], L.ptr(g), R, S, L.ptr(store), store.numel(),
+                                               C.byref(gs), L.ptr(ws), nb, L.stream_ptr()), "evd_nerf_mlp_backward")
+        return out
+
     # nerf.py:74-129; returns the reference 6-tuple (rgb_map, density, acc_map, weights, depth_map, feature_map)
     def raw2outputs(self, raw, z_vals, rays_d, feature=None, raw_noise_std=0, white_bkgd=False, pytest=False,
                     noise=None):

@@ -121,6 +121,22 @@ size_t evd_nerf_train_store_bytes(long nsamp);
 int evd_nerf_mlp_train(const evd_nerf* net, int precision, const float* ray_batch, const float* z, long R, int S,
                        float* raw, void* store, size_t store_bytes, void* stream);
 
+/* Gradients of the network parameters, device float32 in the reference's nn.Linear layouts ([out, in] weights, [out] biases;
+ * the same fields as evd_nerf_desc).  NULL = not wanted.  Every wanted block is overwritten, not accumulated into. */
+typedef struct {
+    float *pts_w[EVD_MAX_LAYERS], *pts_b[EVD_MAX_LAYERS];
+    float *views_w, *views_b, *feature_w, *feature_b, *alpha_w, *alpha_b, *rgb_w, *rgb_b;
+} evd_nerf_grads;
+
+/* Backward of evd_nerf_mlp_train: d_raw dev [R,S,4] (d loss / d raw) -> parameter gradients, what torch autograd computes for
+ * NeRF.mlpforward (networks/nerf.py:46-72) under loss.backward() (run_nerf.py:1032-1036).  `store` is the one the forward
+ * filled (it is consumed: the gradient fragments are written into it).  Arithmetic: MFMA operands in the forward's half
+ * precision under a power-of-two loss scale chosen from max |d_raw|, float32 accumulation; the scale is removed before the
+ * gradients are written.  workspace: evd_nerf_backward_workspace_bytes() device bytes. */
+size_t evd_nerf_backward_workspace_bytes(void);
+int evd_nerf_mlp_backward(const evd_nerf* net, int precision, const float* d_raw, long R, int S, void* store, size_t store_bytes,
+                          const evd_nerf_grads* grads, void* workspace, size_t workspace_bytes, void* stream);
+
 /* raw2outputs: networks/nerf.py:74-129 (sigma_ch 3, rgb_ch0 0) and networks/pdrf/voxnerf.py:153-201
  * (sigma_ch 0, rgb_ch0 1).  raw dev [R,S,C], z dev [R,S], rays_d dev rows of rays_d_stride floats.
  * noise dev [R,S-1] optional (explicit randn*raw_noise_std draw).  rmnear_thresh <= 0 disables the
