@@ -84,6 +84,9 @@ SIGNATURES = {
     "evd_sample_z": (_I, [C.POINTER(RenderCfg), _vp, _I, _L, _vp, _vp, _vp]),
     "evd_nerf_create": (_I, [C.POINTER(NerfDesc), C.POINTER(_vp)]),
     "evd_nerf_destroy": (None, [_vp]),
+    "evd_nerf_param_count": (_L, [_vp]),
+    "evd_nerf_param_blocks": (_I, [_vp, C.POINTER(C.c_long), _I]),
+    "evd_nerf_load_params": (_I, [_vp, _vp, _vp]),
     "evd_nerf_stream_bytes": (_S, [_vp, _I]),
     "evd_nerf_mlp": (_I, [_vp, _I, _vp, _vp, _L, _I, _vp, _vp, _I, _vp]),
     "evd_nerf_train_store_bytes": (_S, [_L]),

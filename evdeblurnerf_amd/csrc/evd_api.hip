@@ -9,6 +9,8 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
+#include <vector>
 
 namespace evd {
 
@@ -43,6 +45,42 @@ int evd_device_count(void) {
     return n;
 }
 
+// Every stream keeps, next to its bytes, the index map element -> parameter arena (pack.h), so that new parameter values
+// are re-packed on the device (evd_nerf_load_params) with the arithmetic the host packer used at creation.
+static int upload_stream(evd_nerf::Packed& dst, const StreamBuilder& sb) {
+    dst.prec = sb.prec;
+    int rc = dst.data.upload(sb.bytes.data(), sb.bytes.size());
+    if (!rc) rc = dst.src.upload(sb.src.data(), sb.src.size() * sizeof(int32_t));
+    return rc;
+}
+
+// canonical parameter order of the arena: pts_linears[l].{weight, bias} for l < D, then views_linears.0, feature_linear,
+// alpha_linear, rgb_linear ({weight, bias} each)
+static void nerf_param_sizes(int D, int W, int skip, long* sz) {
+    const int IC = 3 * (1 + 2 * PE_L), ICV = 3 * (1 + 2 * PE_LV);
+    for (int l = 0; l < D; ++l) {
+        sz[2 * l] = (long)W * (l == 0 ? IC : (l - 1 == skip ? W + IC : W));
+        sz[2 * l + 1] = W;
+    }
+    long* h = sz + 2 * D;
+    h[0] = (long)(W / 2) * (W + ICV); h[1] = W / 2;      // views
+    h[2] = (long)W * W; h[3] = W;                        // feature
+    h[4] = W; h[5] = 1;                                  // alpha
+    h[6] = 3L * (W / 2); h[7] = 3;                       // rgb
+}
+
+static __global__ void k_pack_stream(int prec, const float* __restrict__ arena, const int* __restrict__ src, long n, uint8_t* __restrict__ dst) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int s = src[i];
+    put_element(prec, dst + (i >> 9) * frag_bytes(prec), (int)(i >> 3) & 63, (int)i & 7, s < 0 ? 0.f : arena[s]);
+}
+
+static __global__ void k_gather_f32(const float* __restrict__ arena, const int* __restrict__ src, long n, float* __restrict__ dst) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i] < 0 ? 0.f : arena[src[i]];
+}
+
 int evd_nerf_create(const evd_nerf_desc* d, evd_nerf** out) {
     EVD_REQUIRE(d && out, "evd_nerf_create: null argument");
     EVD_REQUIRE(d->multires == PE_L && d->multires_views == PE_LV,
@@ -50,9 +88,30 @@ int evd_nerf_create(const evd_nerf_desc* d, evd_nerf** out) {
     EVD_REQUIRE(d->W == 256 || d->W == 64, "evd_nerf_create: netwidth %d not built (64, 256)", d->W);
     EVD_REQUIRE(d->D >= 1 && d->D <= EVD_MAX_LAYERS, "evd_nerf_create: netdepth %d out of range", d->D);
     EVD_REQUIRE(d->views_w && d->feature_w && d->alpha_w && d->rgb_w, "evd_nerf_create: use_viewdirs=False networks are not supported");
-    const int W = d->W, T = W / 32, KS = W / 16, IC = 3 * (1 + 2 * PE_L), ICV = 3 * (1 + 2 * PE_LV);
+    const int W = d->W, T = W / 32, KS = W / 16, IC = 3 * (1 + 2 * PE_L), ICV = 3 * (1 + 2 * PE_LV), D = d->D;
     evd_nerf* n = new evd_nerf();
-    n->D = d->D; n->W = W; n->skip = d->skip; n->rgb_act = d->rgb_act; n->sigma_act = d->sigma_act; n->rmnear = d->rmnear;
+    n->D = D; n->W = W; n->skip = d->skip; n->rgb_act = d->rgb_act; n->sigma_act = d->sigma_act; n->rmnear = d->rmnear;
+
+    // host copy of every parameter in one arena (missing biases = zeros); the packers below read from it
+    long sz[2 * EVD_MAX_LAYERS + 8];
+    nerf_param_sizes(D, W, d->skip, sz);
+    n->nparam_blocks = 2 * D + 8;
+    long total = 0;
+    for (int i = 0; i < n->nparam_blocks; ++i) { n->param_off[i] = total; total += sz[i]; }
+    n->param_off[n->nparam_blocks] = total;
+    std::vector<float> arena((size_t)total, 0.f);
+    {
+        const float* srcs[2 * EVD_MAX_LAYERS + 8];
+        for (int l = 0; l < D; ++l) { srcs[2 * l] = d->pts_w[l]; srcs[2 * l + 1] = d->pts_b[l]; }
+        const float* heads[8] = {d->views_w, d->views_b, d->feature_w, d->feature_b, d->alpha_w, d->alpha_b, d->rgb_w, d->rgb_b};
+        for (int i = 0; i < 8; ++i) srcs[2 * D + i] = heads[i];
+        for (int i = 0; i < n->nparam_blocks; ++i)
+            if (srcs[i]) memcpy(arena.data() + n->param_off[i], srcs[i], sz[i] * sizeof(float));
+    }
+    const float* A = arena.data();
+    auto P = [&](int i) { return A + n->param_off[i]; };
+    auto pts_w = [&](int l) { return P(2 * l); };
+    const float *views_w = P(2 * D), *feature_w = P(2 * D + 2), *alpha_w = P(2 * D + 4), *rgb_w = P(2 * D + 6);
 
     auto pe_col = [](int j, int kk) { return pe_src_col(PE_L, 8 * j + (kk & 7), kk >> 3); };
     auto hid_col = [](int j, int kk) { return 16 * j + phi(kk); };
@@ -64,8 +123,8 @@ int evd_nerf_create(const evd_nerf_desc* d, evd_nerf** out) {
     // pdh < 0: the skip layer's k-steps are [pe_0..3 | h_0..h_{KS-1}] (generic kernel);
     // else [h_0..h_{pdh-1} | pe_0..3 | h_pdh..h_{KS-1}] (pipelined kernel, nerf_mlp_kernel.h)
     auto build = [&](StreamBuilder& sb, int pdh) {
-        sb.layer(d->pts_w[0], W, IC, T, PE_KS, true, pe_col);
-        for (int l = 1; l < d->D; ++l) {
+        sb.layer(pts_w(0), W, IC, T, PE_KS, true, pe_col);
+        for (int l = 1; l < D; ++l) {
             if (l - 1 == d->skip) {
                 auto wide_col = [&](int j, int kk) {
                     if (pdh < 0) return j < PE_KS ? pe_col(j, kk) : IC + hid_col(j - PE_KS, kk);
@@ -73,60 +132,52 @@ int evd_nerf_create(const evd_nerf_desc* d, evd_nerf** out) {
                     if (j < pdh + PE_KS) return pe_col(j - pdh, kk);
                     return IC + hid_col(j - PE_KS, kk);
                 };
-                sb.layer(d->pts_w[l], W, W + IC, T, PE_KS + KS, true, wide_col);
+                sb.layer(pts_w(l), W, W + IC, T, PE_KS + KS, true, wide_col);
             } else {
-                sb.layer(d->pts_w[l], W, W, T, KS, true, hid_col);
+                sb.layer(pts_w(l), W, W, T, KS, true, hid_col);
             }
         }
-        sb.layer(d->alpha_w, 1, W, 1, KS, false, hid_col);
-        sb.layer(d->feature_w, W, W, T, KS, false, hid_col);
-        sb.layer(d->views_w, W / 2, W + ICV, T / 2, KS + PEV_KS, false, views_col);
-        sb.layer(d->rgb_w, 3, W / 2, 1, KS / 2, true, hid_col);
+        sb.layer(alpha_w, 1, W, 1, KS, false, hid_col);
+        sb.layer(feature_w, W, W, T, KS, false, hid_col);
+        sb.layer(views_w, W / 2, W + ICV, T / 2, KS + PEV_KS, false, views_col);
+        sb.layer(rgb_w, 3, W / 2, 1, KS / 2, true, hid_col);
     };
-    for (int prec = 0; prec < EVD_NUM_PREC; ++prec) {
+    int rc = EVD_OK;
+    for (int prec = 0; prec < EVD_NUM_PREC && !rc; ++prec) {
         StreamBuilder sb(prec);
+        sb.arena = A;
         build(sb, -1);
         n->nchunks[prec] = (int)(sb.bytes.size() / chunk_bytes(prec));
-        int rc = n->stream[prec].upload(sb.bytes.data(), sb.bytes.size());
-        if (rc) { evd_nerf_destroy(n); return rc; }
+        rc = upload_stream(n->stream[prec], sb);
         n->pipe_chunks[prec] = 0;
-        if (nerf_pipe_built(prec, W, d->D, d->skip)) {
+        if (!rc && nerf_pipe_built(prec, W, D, d->skip)) {
             StreamBuilder sp(prec, PIPE_CB);
+            sp.arena = A;
             sp.group = nerf_group(prec);
             build(sp, KS - 2 * nerf_group(prec));
             n->pipe_chunks[prec] = (int)(sp.bytes.size() / PIPE_CB);
-            rc = n->pipe[prec].upload(sp.bytes.data(), sp.bytes.size());
-            if (rc) { evd_nerf_destroy(n); return rc; }
+            rc = upload_stream(n->pipe[prec], sp);
         }
-    }
-    // training path (bf16 / f16 on the pipelined network): W^T streams of the dgrad chain, one per layer (nerf_train_kernel.h)
-    for (int prec = 0; prec < EVD_NUM_PREC; ++prec) {
-        if (!is_half_prec(prec) || !n->pipe_chunks[prec]) continue;
-        // rows = forward inputs col0 .. col0 + nrow of Wm [out, in], columns = forward outputs (+ one extra matrix appended)
-        auto transposed = [](const float* Wm, int out, int in, int col0, int nrow, const float* extra, int extra_out) {
-            std::vector<float> t((size_t)nrow * (out + extra_out), 0.f);
-            for (int r = 0; r < nrow; ++r) {
-                for (int c = 0; c < out; ++c) t[(size_t)r * (out + extra_out) + c] = Wm[(size_t)c * in + col0 + r];
-                for (int c = 0; c < extra_out; ++c) t[(size_t)r * (out + extra_out) + out + c] = extra[(size_t)c * nrow + r];
-            }
-            return t;
+        // training path (bf16 / f16 on the pipelined network): W^T streams of the dgrad chain, one per layer (nerf_train_kernel.h)
+        if (rc || !is_half_prec(prec) || !n->pipe_chunks[prec]) continue;
+        auto put = [&](int which, auto fill) {
+            StreamBuilder sb2(prec, PIPE_CB);
+            sb2.arena = A;
+            sb2.group = 1;
+            fill(sb2);
+            return upload_stream(n->bwd[prec][which], sb2);
         };
-        auto put = [&](int which, const std::vector<float>& wt, int in_dim, int tiles, int ksteps, auto col) {
-            StreamBuilder sb(prec, PIPE_CB);
-            sb.group = 1;
-            sb.layer(wt.data(), tiles * 32, in_dim, tiles, ksteps, true, col);
-            return n->bwd[prec][which].upload(sb.bytes.data(), sb.bytes.size());
-        };
-        int rc = put(EVD_BWD_RGB, transposed(d->rgb_w, 3, W / 2, 0, W / 2, nullptr, 0), 3, T / 2, 1, [](int, int kk) { return kk < 3 ? kk : -1; });
-        if (!rc) rc = put(EVD_BWD_VIEWS, transposed(d->views_w, W / 2, W + ICV, 0, W, nullptr, 0), W / 2, T, KS / 2, hid_col);
-        if (!rc) rc = put(EVD_BWD_HEAD, transposed(d->feature_w, W, W, 0, W, d->alpha_w, 1), W + 1, T, KS + 1,
-                          [&](int j, int kk) { return j < KS ? hid_col(j, kk) : (kk == 0 ? W : -1); });
-        for (int l = 1; l < d->D && !rc; ++l) {
+        rc = put(EVD_BWD_RGB, [&](StreamBuilder& b) { b.layer_transposed(rgb_w, 3, W / 2, 0, W / 2, nullptr, 0, T / 2, 1, true, [](int, int kk) { return kk < 3 ? kk : -1; }); });
+        if (!rc) rc = put(EVD_BWD_VIEWS, [&](StreamBuilder& b) { b.layer_transposed(views_w, W / 2, W + ICV, 0, W, nullptr, 0, T, KS / 2, true, hid_col); });
+        if (!rc) rc = put(EVD_BWD_HEAD, [&](StreamBuilder& b) {
+            b.layer_transposed(feature_w, W, W, 0, W, alpha_w, 1, T, KS + 1, true, [&](int j, int kk) { return j < KS ? hid_col(j, kk) : (kk == 0 ? W : -1); });
+        });
+        for (int l = 1; l < D && !rc; ++l) {
             const bool wide = l - 1 == d->skip;
-            rc = put(EVD_BWD_HIDDEN1 + l - 1, transposed(d->pts_w[l], W, wide ? W + IC : W, wide ? IC : 0, W, nullptr, 0), W, T, KS, hid_col);
+            rc = put(EVD_BWD_HIDDEN1 + l - 1, [&](StreamBuilder& b) { b.layer_transposed(pts_w(l), W, wide ? W + IC : W, wide ? IC : 0, W, nullptr, 0, T, KS, true, hid_col); });
         }
-        if (rc) { evd_nerf_destroy(n); return rc; }
     }
+    if (rc) { evd_nerf_destroy(n); return rc; }
     {   // wgrad index maps (nerf_train.h): fragment column (fragment j = i / 16, position kk = i % 16) -> parameter row / column
         std::vector<int> m(MAP_TOTAL, -1);
         for (int i = 0; i < 256; ++i) {
@@ -140,20 +191,24 @@ int evd_nerf_create(const evd_nerf_desc* d, evd_nerf** out) {
         }
         for (int i = 0; i < 3; ++i) m[MAP_RGB + i] = i;
         m[MAP_ALPHA] = 0;
-        int rc = n->wmaps.upload(m.data(), m.size() * sizeof(int));
-        if (rc) { evd_nerf_destroy(n); return rc; }
+        if ((rc = n->wmaps.upload(m.data(), m.size() * sizeof(int)))) { evd_nerf_destroy(n); return rc; }
     }
     // biases, one 32-float row block per output tile, in stream order
     std::vector<float> b;
-    auto push = [&](const float* src, int out_dim, int tiles) {
-        for (int i = 0; i < tiles * 32; ++i) b.push_back((src && i < out_dim) ? src[i] : 0.f);
+    std::vector<int32_t> bsrc;
+    auto push = [&](int block, int out_dim, int tiles) {
+        for (int i = 0; i < tiles * 32; ++i) {
+            b.push_back(i < out_dim ? P(block)[i] : 0.f);
+            bsrc.push_back(i < out_dim ? (int32_t)(n->param_off[block] + i) : -1);
+        }
     };
-    for (int l = 0; l < d->D; ++l) push(d->pts_b[l], W, T);
-    push(d->alpha_b, 1, 1);
-    push(d->feature_b, W, T);
-    push(d->views_b, W / 2, T / 2);
-    push(d->rgb_b, 3, 1);
-    int rc = n->bias.upload(b.data(), b.size() * sizeof(float));
+    for (int l = 0; l < D; ++l) push(2 * l + 1, W, T);
+    push(2 * D + 5, 1, 1);
+    push(2 * D + 3, W, T);
+    push(2 * D + 1, W / 2, T / 2);
+    push(2 * D + 7, 3, 1);
+    rc = n->bias.upload(b.data(), b.size() * sizeof(float));
+    if (!rc) rc = n->bias_src.upload(bsrc.data(), bsrc.size() * sizeof(int32_t));
     if (rc) { evd_nerf_destroy(n); return rc; }
     *out = n;
     return EVD_OK;
@@ -168,12 +223,44 @@ void evd_nerf_destroy(evd_nerf* n) {
     }
     n->wmaps.release();
     n->bias.release();
+    n->bias_src.release();
     delete n;
+}
+
+long evd_nerf_param_count(const evd_nerf* net) { return net ? net->param_off[net->nparam_blocks] : 0; }
+
+int evd_nerf_param_blocks(const evd_nerf* net, long* offsets, int capacity) {
+    EVD_REQUIRE(net, "evd_nerf_param_blocks: null network");
+    if (offsets)
+        for (int i = 0; i <= net->nparam_blocks && i < capacity; ++i) offsets[i] = net->param_off[i];
+    return net->nparam_blocks;
+}
+
+int evd_nerf_load_params(evd_nerf* net, const float* params, void* stream) {
+    EVD_REQUIRE(net && params, "evd_nerf_load_params: null argument");
+    hipStream_t st = as_stream(stream);
+    auto repack = [&](evd_nerf::Packed& s) -> int {
+        if (!s.data.p) return EVD_OK;
+        const long nel = (long)(s.src.bytes / sizeof(int32_t));
+        hipLaunchKernelGGL(k_pack_stream, dim3((unsigned)cdiv(nel, 256L)), dim3(256), 0, st, s.prec, params, (const int*)s.src.p, nel, (uint8_t*)s.data.p);
+        EVD_LAUNCH_CHECK();
+        return EVD_OK;
+    };
+    int rc;
+    for (int i = 0; i < EVD_NUM_PREC; ++i) {
+        if ((rc = repack(net->stream[i])) || (rc = repack(net->pipe[i]))) return rc;
+        for (int k = 0; k < EVD_BWD_NSTREAMS; ++k)
+            if ((rc = repack(net->bwd[i][k]))) return rc;
+    }
+    const long nb = (long)(net->bias.bytes / sizeof(float));
+    hipLaunchKernelGGL(k_gather_f32, dim3((unsigned)cdiv(nb, 256L)), dim3(256), 0, st, params, (const int*)net->bias_src.p, nb, (float*)net->bias.p);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
 }
 
 size_t evd_nerf_stream_bytes(const evd_nerf* net, int precision) {
     if (!net || precision < 0 || precision >= EVD_NUM_PREC) return 0;
-    return net->pipe_chunks[precision] ? net->pipe[precision].bytes : net->stream[precision].bytes;
+    return net->pipe_chunks[precision] ? net->pipe[precision].data.bytes : net->stream[precision].data.bytes;
 }
 
 int evd_nerf_mlp(const evd_nerf* net, int precision, const float* ray_batch, const float* z, long R, int S,
@@ -186,7 +273,7 @@ int evd_nerf_mlp(const evd_nerf* net, int precision, const float* ray_batch, con
     MlpParams p;
     static const bool no_pipe = env_flag("EVD_NO_PIPE");      // developer switch: force the generic kernel
     const bool piped = net->pipe_chunks[precision] > 0 && !no_pipe;
-    p.wstream = (const char*)(piped ? net->pipe[precision].p : net->stream[precision].p);
+    p.wstream = (const char*)(piped ? net->pipe[precision].data.p : net->stream[precision].data.p);
     p.bias = (const float*)net->bias.p;
     p.ray_batch = ray_batch; p.z = z; p.nsamp = R * (long)S; p.S = S; p.ncol = 11;
     p.D = net->D; p.skip = net->skip; p.nchunks = piped ? net->pipe_chunks[precision] : net->nchunks[precision]; p.nbias = (int)(net->bias.bytes / sizeof(float));

@@ -30,7 +30,7 @@ int evd_nerf_mlp_train(const evd_nerf* net, int precision, const float* ray_batc
     if (store_bytes < evd_nerf_train_store_bytes(nsamp))
         return fail(EVD_E_WORKSPACE, "evd_nerf_mlp_train: store %zu < %zu bytes", store_bytes, evd_nerf_train_store_bytes(nsamp));
     MlpParams p;
-    p.wstream = (const char*)net->pipe[precision].p;
+    p.wstream = (const char*)net->pipe[precision].data.p;
     p.bias = (const float*)net->bias.p;
     p.ray_batch = ray_batch; p.z = z; p.nsamp = nsamp; p.S = S; p.ncol = 11;
     p.D = net->D; p.skip = net->skip; p.nchunks = net->pipe_chunks[precision]; p.nbias = (int)(net->bias.bytes / sizeof(float));
@@ -56,7 +56,7 @@ int evd_nerf_mlp_backward(const evd_nerf* net, int precision, const float* d_raw
         return fail(EVD_E_WORKSPACE, "evd_nerf_mlp_backward: workspace %zu < %zu bytes", workspace_bytes, evd_nerf_backward_workspace_bytes());
     BwdPlan b;
     b.d_raw = d_raw; b.nsamp = nsamp; b.tiles = train_tiles(nsamp); b.store = (char*)store;
-    for (int k = 0; k < EVD_BWD_NSTREAMS; ++k) b.wt[k] = (const char*)net->bwd[precision][k].p;
+    for (int k = 0; k < EVD_BWD_NSTREAMS; ++k) b.wt[k] = (const char*)net->bwd[precision][k].data.p;
     b.maps = (const int*)net->wmaps.p;
     char* w = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     b.maxbits = (unsigned*)w;

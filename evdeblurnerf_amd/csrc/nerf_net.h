@@ -7,13 +7,21 @@
 enum { EVD_BWD_RGB = 0, EVD_BWD_VIEWS, EVD_BWD_HEAD, EVD_BWD_HIDDEN1, EVD_BWD_NSTREAMS = EVD_BWD_HIDDEN1 + EVD_MAX_LAYERS };
 
 struct evd_nerf {
+    // a packed fragment stream and, per element, the index of its source in the parameter arena (-1: zero)
+    struct Packed {
+        int prec = 0;
+        evd::DevBuf data, src;
+        void release() { data.release(); src.release(); }
+    };
     int D, W, skip, rgb_act, sigma_act;
     float rmnear;
-    evd::DevBuf stream[EVD_NUM_PREC];        // generic kernel: fragment streams per precision
+    Packed stream[EVD_NUM_PREC];             // generic kernel: fragment streams per precision
     int nchunks[EVD_NUM_PREC];
-    evd::DevBuf pipe[EVD_NUM_PREC];          // software-pipelined kernel (where built): its own fragment order and chunking
+    Packed pipe[EVD_NUM_PREC];               // software-pipelined kernel (where built): its own fragment order and chunking
     int pipe_chunks[EVD_NUM_PREC];
-    evd::DevBuf bias;
-    evd::DevBuf bwd[EVD_NUM_PREC][EVD_BWD_NSTREAMS];   // training (bf16 / f16, 8 x 256): W^T streams; HIDDEN1 + l - 1 = pts_linears[l]
-    evd::DevBuf wmaps;                       // wgrad index maps (int32), see evd_train_api.hip
+    evd::DevBuf bias, bias_src;
+    Packed bwd[EVD_NUM_PREC][EVD_BWD_NSTREAMS];   // training (bf16 / f16, 8 x 256): W^T streams; HIDDEN1 + l - 1 = pts_linears[l]
+    evd::DevBuf wmaps;                       // wgrad index maps (int32), nerf_train.h
+    int nparam_blocks;                       // 2 D + 8 parameter tensors, canonical order (evd_api.hip: nerf_param_sizes)
+    long param_off[2 * EVD_MAX_LAYERS + 9];  // arena offset of each, [nparam_blocks] = total
 };

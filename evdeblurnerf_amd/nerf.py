@@ -55,6 +55,22 @@ class _Raw2Outputs(torch.autograd.Function):
         return (d_raw,) + (None,) * 9
 
 
+class _NerfMLP(torch.autograd.Function):
+    """raw = NeRF.mlpforward(rays, z; params) with the hand-written backward kernels (evd_nerf_mlp_train / _backward)"""
+
+    @staticmethod
+    def forward(ctx, flat, ray_batch, z_vals, net, precision):
+        raw, store = net.mlpforward_train(ray_batch, z_vals, precision)
+        ctx.net, ctx.precision, ctx.store = net, precision, store
+        return raw
+
+    @staticmethod
+    def backward(ctx, d_raw):
+        g = ctx.net.mlp_backward_flat(d_raw, ctx.store, ctx.precision)
+        ctx.store = None
+        return g, None, None, None, None
+
+
 class NeRF:
     """One reference ``NeRF`` (D x W MLP, skip, view branch) with packed MFMA weight streams on the GPU."""
 
@@ -134,32 +150,78 @@ class NeRF:
                                             L.ptr(store), nb, L.stream_ptr()), "evd_nerf_mlp_train")
         return raw, store
 
-    # Backward of mlpforward_train: d_raw [R,S,4] -> {state-dict key: gradient} (what autograd gives for nerf.py:46-72)
-    def mlp_backward(self, d_raw, store, precision=None):
+    # ---- training path (f16 / bf16 on the 8 x 256 network) ------------------------------------------------------------
+    # Parameters as ONE flat float32 tensor in the library's canonical order (include/evdnerf.h: evd_nerf_param_blocks).
+    def param_blocks(self):
+        """[(state-dict key, shape, offset)] of the flat parameter tensor"""
+        if getattr(self, "_blocks", None) is None:
+            nb = 2 * self.D + 8
+            off = (C.c_long * (nb + 1))()
+            if L.lib().evd_nerf_param_blocks(self._h, off, nb + 1) != nb:
+                raise L.EvdError("evd_nerf_param_blocks: unexpected parameter block count")
+            W, D = self.W, self.D
+            keys = [(f"pts_linears.{l}", W, None) for l in range(D)] + [("views_linears.0", W // 2, None), ("feature_linear", W, None),
+                                                                       ("alpha_linear", 1, None), ("rgb_linear", 3, None)]
+            blocks = []
+            for i, (k, o, _) in enumerate(keys):
+                nw = off[2 * i + 1] - off[2 * i]
+                blocks.append((k + ".weight", (o, nw // o), off[2 * i]))
+                blocks.append((k + ".bias", (o,), off[2 * i + 1]))
+            self._blocks, self._nparam = blocks, off[nb]
+        return self._blocks
+
+    def flat_params(self, state_dict, prefix="", device="cuda"):
+        """state dict -> flat float32 leaf tensor (requires_grad) for an optimizer; missing biases are zeros"""
+        blocks = self.param_blocks()
+        flat = torch.zeros((self._nparam,), dtype=torch.float32)
+        for key, shape, off in blocks:
+            if prefix + key in state_dict:
+                flat[off:off + int(np.prod(shape))] = torch.as_tensor(_np32(state_dict[prefix + key])).reshape(-1)
+        return flat.to(device).requires_grad_(True)
+
+    def unflatten(self, flat):
+        return {key: flat[off:off + int(np.prod(shape))].view(shape) for key, shape, off in self.param_blocks()}
+
+    def load_params(self, flat):
+        """re-pack every weight stream on the device from new parameter values (after optimizer.step(), run_nerf.py:1036)"""
+        f = flat.detach().contiguous().float()
+        self.param_blocks()
+        if f.numel() != self._nparam:
+            raise L.EvdError(f"flat parameter tensor has {f.numel()} elements, the network {self._nparam}")
+        L.check(L.lib().evd_nerf_load_params(self._h, L.ptr(f), L.stream_ptr()), "evd_nerf_load_params")
+        self._synced = (flat.data_ptr(), flat._version)
+
+    def mlp_train(self, flat, ray_batch, z_vals, precision=None):
+        """NeRF.mlpforward for training: raw [R,S,4] with autograd back to the flat parameter tensor (rays are constants)"""
+        if getattr(self, "_synced", None) != (flat.data_ptr(), flat._version):
+            self.load_params(flat)
+        return _NerfMLP.apply(flat, ray_batch, z_vals, self, precision or self.precision)
+
+    # Backward of mlpforward_train: d_raw [R,S,4] -> flat gradient (what autograd gives for nerf.py:46-72)
+    def mlp_backward_flat(self, d_raw, store, precision=None):
         g = d_raw.contiguous().float()
         R, S = g.shape[:2]
-        dev = g.device
-        shapes = {f"pts_linears.{i}": (self.W, 63 if i == 0 else (self.W + 63 if i == 5 else self.W)) for i in range(self.D)}
-        shapes.update({"views_linears.0": (self.W // 2, self.W + 27), "feature_linear": (self.W, self.W),
-                       "alpha_linear": (1, self.W), "rgb_linear": (3, self.W // 2)})
-        out = {}
+        blocks = self.param_blocks()
+        flat = torch.zeros((self._nparam,), dtype=torch.float32, device=g.device)
         gs = L.NerfGrads()
-        for key, (o, i) in shapes.items():
-            w = torch.zeros((o, i), dtype=torch.float32, device=dev)
-            b = torch.zeros((o,), dtype=torch.float32, device=dev)
-            out[key + ".weight"], out[key + ".bias"] = w, b
-            if key.startswith("pts_linears."):
-                k = int(key.split(".")[1])
-                gs.pts_w[k], gs.pts_b[k] = L.ptr(w), L.ptr(b)
+        base = flat.data_ptr()
+        for key, shape, off in blocks:
+            name, kind = key.rsplit(".", 1)
+            field = "_w" if kind == "weight" else "_b"
+            if name.startswith("pts_linears."):
+                getattr(gs, "pts" + field)[int(name.split(".")[1])] = base + 4 * off
             else:
-                name = {"views_linears.0": "views", "feature_linear": "feature", "alpha_linear": "alpha", "rgb_linear": "rgb"}[key]
-                setattr(gs, name + "_w", L.ptr(w))
-                setattr(gs, name + "_b", L.ptr(b))
+                head = {"views_linears.0": "views", "feature_linear": "feature", "alpha_linear": "alpha", "rgb_linear": "rgb"}[name]
+                setattr(gs, head + field, base + 4 * off)
         nb = int(L.lib().evd_nerf_backward_workspace_bytes())
-        ws = torch.empty((nb,), dtype=torch.uint8, device=dev)
+        ws = torch.empty((nb,), dtype=torch.uint8, device=g.device)
         L.check(L.lib().evd_nerf_mlp_backward(self._h, L.PREC[precision or self.precision], L.ptr(g), R, S, L.ptr(store), store.numel(),
                                                C.byref(gs), L.ptr(ws), nb, L.stream_ptr()), "evd_nerf_mlp_backward")
-        return out
+        return flat
+
+    def mlp_backward(self, d_raw, store, precision=None):
+        """... as {state-dict key: gradient}"""
+        return self.unflatten(self.mlp_backward_flat(d_raw, store, precision))
 
     # nerf.py:74-129; returns the reference 6-tuple (rgb_map, density, acc_map, weights, depth_map, feature_map)
     def raw2outputs(self, raw, z_vals, rays_d, feature=None, raw_noise_std=0, white_bkgd=False, pytest=False,

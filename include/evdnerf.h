@@ -103,6 +103,14 @@ typedef struct {                    /* host float32 pointers, nn.Linear layout [
 
 int evd_nerf_create(const evd_nerf_desc* desc, evd_nerf** out);
 void evd_nerf_destroy(evd_nerf* net);
+/* Parameters live in one float32 arena, canonical order: pts_linears[l].weight, .bias for l < D, then views_linears.0,
+ * feature_linear, alpha_linear, rgb_linear (weight, bias each; reference nn.Linear layouts, networks/nerf.py:14-44).
+ * evd_nerf_param_blocks writes the arena offset of each of the 2 D + 8 tensors plus the total (up to `capacity` longs) and
+ * returns 2 D + 8.  evd_nerf_load_params re-packs every weight stream of the network on the device from new values
+ * (params: device float32 [evd_nerf_param_count]) -- what a training loop calls after optimizer.step() (run_nerf.py:1036). */
+long evd_nerf_param_count(const evd_nerf* net);
+int evd_nerf_param_blocks(const evd_nerf* net, long* offsets, int capacity);
+int evd_nerf_load_params(evd_nerf* net, const float* params, void* stream);
 /* bytes of the packed weight stream for a precision (what one workgroup streams per sample tile) */
 size_t evd_nerf_stream_bytes(const evd_nerf* net, int precision);
 

@@ -144,3 +144,57 @@ def test_mlp_backward_matches_torch_autograd(prec, tol, R, S, gscale):
     assert max(errs2.values()) < 15 * tol, {k: f"{v:.1e}" for k, v in errs2.items()}
     print(f"[{prec} R={R} S={S} g~{gscale:g}] worst relative L2 error of a parameter gradient: {worst:.2e} (same ReLU pattern), "
           f"{max(errs2.values()):.2e} (true network)")
+
+
+def test_load_params_repacks_like_a_fresh_network():
+    """Device re-pack of every stream from new parameter values == the host packer of a network created with those values."""
+    from evdeblurnerf_amd.nerf import NeRF
+    sd_a, sd_b = W.make_nerf_state_dict(31), W.make_nerf_state_dict(32)
+    rb, z = make_inputs(50, 17, 3)
+    rbt, zt = torch.tensor(rb, device="cuda"), torch.tensor(z, device="cuda")
+    net = NeRF(sd_a)
+    fresh = NeRF(sd_b)
+    net.load_params(net.flat_params(sd_b))
+    for prec in ("f32", "f16x3", "f16", "bf16"):
+        assert torch.equal(net.mlpforward(rbt, zt, precision=prec)[0], fresh.mlpforward(rbt, zt, precision=prec)[0]), prec
+    d_raw = torch.randn((50, 17, 4), device="cuda") * 1e-3
+    for prec in ("f16", "bf16"):
+        ga = net.mlp_backward_flat(d_raw, net.mlpforward_train(rbt, zt, precision=prec)[1], precision=prec)
+        gb = fresh.mlp_backward_flat(d_raw, fresh.mlpforward_train(rbt, zt, precision=prec)[1], precision=prec)
+        assert torch.equal(ga, gb), prec
+
+
+def test_training_loop_tracks_the_float64_reference():
+    """Adam on raw -> target regression through the autograd Function, against the same loop on the float64 torch network:
+    the loss goes down and the two trajectories stay together."""
+    from evdeblurnerf_amd.nerf import NeRF
+    sd = W.make_nerf_state_dict(41)
+    R, S = 128, 32
+    rb, z = make_inputs(R, S, 8)
+    rs = np.random.RandomState(4)
+    target = rs.uniform(0, 1, (R, S, 4)).astype(np.float32)
+    net = NeRF(sd, precision="f16")
+    flat = net.flat_params(sd)
+    opt = torch.optim.Adam([flat], lr=5e-4)
+    rbt, zt, tgt = torch.tensor(rb, device="cuda"), torch.tensor(z, device="cuda"), torch.tensor(target, device="cuda")
+    ref = TorchNerf(sd)
+    ropt = torch.optim.Adam(ref.parameters(), lr=5e-4)
+    pts = torch.tensor(rb[:, None, 0:3] + rb[:, None, 3:6] * z[..., None], dtype=torch.float64).reshape(-1, 3)
+    dirs = torch.tensor(np.repeat(rb[:, None, 8:11], S, 1), dtype=torch.float64).reshape(-1, 3)
+    t64 = torch.tensor(target, dtype=torch.float64).reshape(-1, 4)
+    ours, theirs = [], []
+    for it in range(12):
+        opt.zero_grad()
+        loss = ((net.mlp_train(flat, rbt, zt) - tgt) ** 2).mean()
+        loss.backward()
+        opt.step()
+        ours.append(loss.item())
+        ropt.zero_grad()
+        rl = ((ref(pts, dirs) - t64) ** 2).mean()
+        rl.backward()
+        ropt.step()
+        theirs.append(rl.item())
+    print("loss ours  :", " ".join(f"{v:.5f}" for v in ours))
+    print("loss ref64 :", " ".join(f"{v:.5f}" for v in theirs))
+    assert ours[-1] < 0.7 * ours[0]
+    assert max(abs(a - b) / b for a, b in zip(ours, theirs)) < 2e-2
