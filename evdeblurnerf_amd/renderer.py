@@ -186,6 +186,48 @@ class NeRFAll:
                     print(f"! [Numerical Error] {k} contains inf.")
         return ret
 
+    # ------------------------------------------------------------------ render_rays under autograd (mode='nerf')
+    def trainable_parameters(self, state_dict):
+        """(flat_coarse, flat_fine | None): one float32 leaf tensor per network for the optimizer (NeRF.flat_params)"""
+        if self.mode != "nerf":
+            raise NotImplementedError("the training path is built for mode='nerf'")
+        fc = self.mlp_coarse.flat_params(state_dict, "mlp_coarse.", self.device)
+        ff = self.mlp_fine.flat_params(state_dict, "mlp_fine.", self.device) if self.mlp_fine is not None else None
+        return fc, ff
+
+    def render_rays_train(self, ray_batch, flat_coarse, flat_fine, N_samples, N_importance=0, lindisp=False, perturb=0.,
+                          white_bkgd=False, raw_noise_std=0., *, t_rand=None, u=None, noise0=None, noise1=None):
+        """renderer.py:129-264 (else-branch) with gradients to the two flat parameter tensors: stratified z, fused MLP
+        (forward keeps activations, hand-written backward), compositing scan (autograd node), hierarchical resampling on the
+        detached coarse weights (renderer.py:233 z_samples.detach()), fine pass.  Rays are constants (no pose gradients)."""
+        if self.mode != "nerf":
+            raise NotImplementedError("the training path is built for mode='nerf'")
+        from .rays import sample_pdf_merge
+        rb = ray_batch.contiguous().float()
+        R, S, Ni = rb.shape[0], int(N_samples), int(N_importance)
+        f32 = dict(dtype=torch.float32, device=rb.device)
+        cfg = self._cfg(0, 0, 1.0, False, 0., 1., S, Ni, lindisp, perturb, white_bkgd)
+        cfg.is_train = 1
+        if perturb > 0.:
+            t_rand = torch.rand((R, S), **f32) if t_rand is None else t_rand
+            u = torch.rand((R, Ni), **f32) if (Ni > 0 and u is None) else u
+        if raw_noise_std > 0.:
+            noise0 = torch.randn((R, S - 1), **f32) * raw_noise_std if noise0 is None else noise0
+            noise1 = torch.randn((R, S + Ni - 1), **f32) * raw_noise_std if (Ni > 0 and noise1 is None) else noise1
+        z0 = torch.empty((R, S), **f32)
+        tr = t_rand.contiguous().float() if t_rand is not None else None
+        L.check(L.lib().evd_sample_z(C.byref(cfg), L.ptr(rb), 11, R, L.ptr(tr), L.ptr(z0), L.stream_ptr()), "evd_sample_z")
+        rays_d = rb[:, 3:6].contiguous()
+        raw0 = self.mlp_coarse.mlp_train(flat_coarse, rb, z0, self.precision)
+        rgb0, _, acc0, w0, depth0, _ = self.mlp_coarse.raw2outputs(raw0, z0, rays_d, None, 0., white_bkgd, noise=noise0)
+        if Ni <= 0:
+            return {"rgb_map": rgb0, "depth_map": depth0, "acc_map": acc0, "weights": w0, "z_vals": z0}
+        _, zm, _, zstd = sample_pdf_merge(z0, w0.detach(), Ni, det=(perturb == 0.), u=u)
+        raw1 = self.mlp_fine.mlp_train(flat_fine, rb, zm, self.precision)
+        rgb, _, acc, w1, depth, _ = self.mlp_fine.raw2outputs(raw1, zm, rays_d, None, 0., white_bkgd, noise=noise1)
+        return {"rgb_map": rgb, "depth_map": depth, "acc_map": acc, "weights": w1, "z_vals": zm, "rgb0": rgb0, "depth0": depth0,
+                "acc0": acc0, "z_std": zstd}
+
     # ------------------------------------------------------------------ render, renderer.py:399-466
     def render(self, H, W, K, chunk=1 << 22, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,
                c2w_staticcam=None, **kwargs):
