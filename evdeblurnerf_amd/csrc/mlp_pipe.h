@@ -303,10 +303,19 @@ template <class B> __device__ __forceinline__ void act_store(char* act_lane, int
     *reinterpret_cast<f32x4*>(act_lane + (long)slot * 1024) = __builtin_bit_cast(f32x4, frag);
 }
 
-template <class C, class L, class ST, int NOUT, int P, bool TRAIN>
+// gradient word . [activation != 0], both halves (activations are post-ReLU: masked <=> the stored half is +0)
+__device__ __forceinline__ unsigned mask_word(unsigned g, unsigned a) {
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    const u16x2 av = __builtin_bit_cast(u16x2, a), zero = {0, 0};
+    return g & __builtin_bit_cast(unsigned, av != zero);
+}
+
+// OMASK (backward kernels): every stored output fragment is first multiplied by the 0/1 ReLU pattern of the activation
+// fragment omask[sample tile][fragment]
+template <class C, class L, class ST, int NOUT, int P, bool TRAIN, bool OMASK>
 __device__ __forceinline__ void pipe_group(ST& st, Pipe<C>& pp, typename C::O::B (&in)[C::NS][L::KTOT],
                                            typename C::O::B (&out)[C::NS][NOUT], const float* __restrict__ bias, int h,
-                                           float* const* frow, char* const* act) {
+                                           float* const* frow, char* const* act, const typename C::O::B* omask) {
     typedef typename C::O O;
     typedef GroupSched<C, L, P == 0, P == L::NG - 1> S;
     constexpr int NS = C::NS, FPC = C::FPC, PD = C::PD, G = L::G, KTOT = L::KTOT, NF = L::NF, NM = S::NM;
@@ -357,7 +366,14 @@ __device__ __forceinline__ void pipe_group(ST& st, Pipe<C>& pp, typename C::O::B
                             float* fr = (L::OWN_FEAT && frow[ds]) ? frow[ds] + 32 * (tile0 + dt) + 8 * (k >> 1) + 4 * h : nullptr;
                             drain_pair<C, L::RELU>(pp.acc[oth][dt][ds], pp.accx[oth][dt][ds], k, out[ds][2 * (tile0 + dt) + (k >> 2)], fr);
                             if constexpr (TRAIN && L::OSLOT >= 0)
-                                if ((k & 3) == 3) act_store(act[ds], L::OSLOT + 2 * (tile0 + dt) + (k >> 2), out[ds][2 * (tile0 + dt) + (k >> 2)]);
+                                if ((k & 3) == 3) {
+                                    const int fo = 2 * (tile0 + dt) + (k >> 2);
+                                    if constexpr (OMASK) {
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) out[ds][fo].w[e] = mask_word(out[ds][fo].w[e], omask[ds * NOUT + fo].w[e]);
+                                    }
+                                    act_store(act[ds], L::OSLOT + fo, out[ds][fo]);
+                                }
                         }
                     }
                 }
@@ -393,13 +409,13 @@ __device__ __forceinline__ void pipe_group(ST& st, Pipe<C>& pp, typename C::O::B
     }
 }
 
-template <class C, class L, class ST, int NOUT, int P, bool TRAIN>
+template <class C, class L, class ST, int NOUT, int P, bool TRAIN, bool OMASK>
 struct GroupLoop {
     static __device__ __forceinline__ void run(ST& st, Pipe<C>& pp, typename C::O::B (&in)[C::NS][L::KTOT],
                                                typename C::O::B (&out)[C::NS][NOUT], const float* __restrict__ bias, int h,
-                                               float* const* frow, char* const* act) {
-        pipe_group<C, L, ST, NOUT, P, TRAIN>(st, pp, in, out, bias, h, frow, act);
-        if constexpr (P + 1 < L::NG) GroupLoop<C, L, ST, NOUT, P + 1, TRAIN>::run(st, pp, in, out, bias, h, frow, act);
+                                               float* const* frow, char* const* act, const typename C::O::B* omask) {
+        pipe_group<C, L, ST, NOUT, P, TRAIN, OMASK>(st, pp, in, out, bias, h, frow, act, omask);
+        if constexpr (P + 1 < L::NG) GroupLoop<C, L, ST, NOUT, P + 1, TRAIN, OMASK>::run(st, pp, in, out, bias, h, frow, act, omask);
     }
 };
 
@@ -407,12 +423,13 @@ struct GroupLoop {
 // k-steps except the pending ones, which this layer produces itself while it runs; `out` receives the B fragments
 // of every group but the last, which stays pending in the accumulators (or, F32OUT, is returned in out_f32).
 // frow[s]: float32 feature row of sample tile s (null lanes = invalid samples), W floats per sample.
-template <class C, class L, class ST, int NOUT, bool TRAIN = false>
+template <class C, class L, class ST, int NOUT, bool TRAIN = false, bool OMASK = false>
 __device__ __forceinline__ void pipe_layer(ST& st, Pipe<C>& pp, typename C::O::B (&in)[C::NS][L::KTOT],
                                            typename C::O::B (&out)[C::NS][NOUT], float (*out_f32)[4],
-                                           const float* __restrict__ bias, int lane, float* const* frow, char* const* act = nullptr) {
+                                           const float* __restrict__ bias, int lane, float* const* frow, char* const* act = nullptr,
+                                           const typename C::O::B* omask = nullptr) {
     typedef typename C::O O;
-    GroupLoop<C, L, ST, NOUT, 0, TRAIN>::run(st, pp, in, out, bias, lane >> 5, frow, act);
+    GroupLoop<C, L, ST, NOUT, 0, TRAIN, OMASK>::run(st, pp, in, out, bias, lane >> 5, frow, act, omask);
     if (L::PAD_END && ((L::FOFF + L::NF) % C::FPC) != 0) st.chunk_end(L::CHUNK0 + (L::FOFF + L::NF) / C::FPC);
     if (L::F32OUT) {
         constexpr int cur = (L::PAR + L::NG - 1) & 1;

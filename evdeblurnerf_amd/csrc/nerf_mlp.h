@@ -64,7 +64,7 @@ namespace astore {
 constexpr int PE = 0, DIR = 4, H0 = 6;                    // H_l at H0 + 16 l: the ReLU output of pts_linears[l]
 constexpr int F = H0 + 16 * 8, HV = F + 16, FWD_END = HV + 8;   // feature_linear output, views hidden
 constexpr int G_RGB = FWD_END, G_ALPHA = G_RGB + 1;       // d raw as two single-k-step fragments
-constexpr int D_HV = G_ALPHA + 1, D_F = D_HV + 8, D_H0 = D_F + 16;    // d (unmasked) w.r.t. hv, feature, h_l at D_H0 + 16 l
+constexpr int D_HV = G_ALPHA + 1, D_F = D_HV + 8, D_H0 = D_F + 16;    // d loss / d pre-activation of hv, feature, h_l (at D_H0 + 16 l)
 constexpr int TILE_FRAGS = D_H0 + 16 * 8;
 constexpr long TILE_BYTES = (long)TILE_FRAGS * 1024;
 }  // namespace astore

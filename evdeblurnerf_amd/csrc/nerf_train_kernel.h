@@ -7,9 +7,9 @@
 //
 //   k_grad_frags   d raw [n,4] (float32) x 2^s  ->  the two gradient fragments G_RGB, G_ALPHA (s: power-of-two loss
 //                  scale that puts max |d raw| in [512, 1024), so float16 gradients neither overflow nor flush)
-//   k_dgrad_layer  d x = W^T (d y . [y > 0]) for ONE layer, on the software pipeline of the forward kernel: W^T is the
+//   k_dgrad_layer  d x = (W^T d y) . [x > 0] for ONE layer, on the software pipeline of the forward kernel: W^T is the
 //                  streamed A operand, the incoming gradient fragments are the B operand, the outgoing ones are
-//                  stored un-masked; the masked incoming gradient is written back in place for the wgrad kernel
+//                  multiplied by the ReLU pattern of the saved activation in the epilogue and stored
 //   k_wgrad        dW = d y . x^T over all samples.  Both operands are stored sample-minor, the contraction runs over
 //                  samples: each 32x32 block is first transposed ON THE MATRIX CORE (the stored fragment as the A
 //                  operand against a 0/1 selector as B returns it with samples along the accumulator registers),
@@ -23,8 +23,6 @@
 #include "nerf_train.h"
 
 namespace evd {
-
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 // 2^s with max * 2^s in [512, 1024); `bits` = float bits of max |d raw| (0: no gradient at all)
 __device__ __forceinline__ float grad_scale(unsigned bits, bool inverse) {
@@ -67,12 +65,6 @@ __global__ __launch_bounds__(256) void k_grad_frags(const float* __restrict__ d_
     act_store(a, astore::G_ALPHA, al);
 }
 
-// gradient word . [activation != 0], both halves (activations are post-ReLU: masked <=> the stored half is +0)
-__device__ __forceinline__ unsigned mask_word(unsigned g, unsigned a) {
-    const u16x2 av = __builtin_bit_cast(u16x2, a), zero = {0, 0};
-    return g & __builtin_bit_cast(unsigned, av != zero);
-}
-
 template <class B> __device__ __forceinline__ B frag_load(const char* lane_base, int slot) {
     return __builtin_bit_cast(B, *reinterpret_cast<const f32x4*>(lane_base + (long)slot * 1024));
 }
@@ -83,9 +75,11 @@ struct DgradParams {
     int in_slot, extra_slot, mask_slot, out_slot;
 };
 
-// One dgrad layer: KTOT k-steps in (NIN contiguous fragments from in_slot, masked by the fragments at mask_slot if MASK,
-// plus one more from extra_slot if EXTRA), TILES 32-row tiles out.  8 wavefronts x 32 samples per workgroup.
-template <int PREC, int KTOT, int TILES, int NIN, bool EXTRA, bool MASK, int NT>
+// One dgrad layer: KTOT k-steps in (NIN contiguous fragments from in_slot, already masked by their producer, plus one more
+// from extra_slot if EXTRA), TILES 32-row tiles out, multiplied by the ReLU pattern of the activation fragments at mask_slot
+// (OMASK) before they are stored: what the next dgrad layer and the wgrad kernel read is d loss / d pre-activation.
+// 8 wavefronts x 32 samples per workgroup.
+template <int PREC, int KTOT, int TILES, int NIN, bool EXTRA, bool OMASK, int NT>
 __global__ __launch_bounds__(NT, NT / 256) void k_dgrad_layer(const DgradParams p) {
     typedef PipeCfg<PREC, 1, NT> C;
     typedef typename C::O::B B;
@@ -102,37 +96,38 @@ __global__ __launch_bounds__(NT, NT / 256) void k_dgrad_layer(const DgradParams 
     for (int i = tid; i < (TILES + 1) * 32; i += NT) zb[i] = 0.f;
     char* al = p.store + ((long)blockIdx.x * (NT / 64) + wave) * astore::TILE_BYTES + lane * 16;
 
-    B in[1][KTOT], out[1][2 * TILES];
+    B in[1][KTOT], out[1][2 * TILES], om[OMASK ? 2 * TILES : 1];
 #pragma unroll
     for (int j = 0; j < NIN; ++j) in[0][j] = frag_load<B>(al, p.in_slot + j);
     if constexpr (EXTRA) in[0][NIN] = frag_load<B>(al, p.extra_slot);
-    if constexpr (MASK) {
+    if constexpr (OMASK) {
 #pragma unroll
-        for (int j = 0; j < NIN; ++j) {
-            const B m = frag_load<B>(al, p.mask_slot + j);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) in[0][j].w[e] = mask_word(in[0][j].w[e], m.w[e]);
-            act_store(al, p.in_slot + j, in[0][j]);              // wgrad reads the masked gradient
-        }
+        for (int j = 0; j < 2 * TILES; ++j) om[j] = frag_load<B>(al, p.mask_slot + j);
     }
     char* actl[1] = {al + (long)p.out_slot * 1024};
     float* nofrow[1] = {nullptr};
     Pipe<C> pp;
     st.start_wait();
     pipe_prime<C, L>(st, pp, zb, lane);
-    pipe_layer<C, L, decltype(st), 2 * TILES, true>(st, pp, in, out, nullptr, zb, lane, nofrow, actl);
+    pipe_layer<C, L, decltype(st), 2 * TILES, true, OMASK>(st, pp, in, out, nullptr, zb, lane, nofrow, actl, om);
     pipe_flush<C, L>(pp, out);
-    act_store(actl[0], 2 * TILES - 2, out[0][2 * TILES - 2]);
-    act_store(actl[0], 2 * TILES - 1, out[0][2 * TILES - 1]);
+#pragma unroll
+    for (int j = 2 * TILES - 2; j < 2 * TILES; ++j) {
+        if constexpr (OMASK) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[0][j].w[e] = mask_word(out[0][j].w[e], om[j].w[e]);
+        }
+        act_store(actl[0], j, out[0][j]);
+    }
 }
 
-template <int PREC, int KTOT, int TILES, int NIN, bool EXTRA, bool MASK>
+template <int PREC, int KTOT, int TILES, int NIN, bool EXTRA, bool OMASK>
 static int launch_dgrad(const DgradParams& p, long tiles, hipStream_t st) {
     constexpr int NT = 512;
     typedef PipeCfg<PREC, 1, NT> C;
     const size_t lds = C::RING + (TILES + 1) * 128;
-    EVD_SET_MAX_LDS((&k_dgrad_layer<PREC, KTOT, TILES, NIN, EXTRA, MASK, NT>), lds);
-    hipLaunchKernelGGL((k_dgrad_layer<PREC, KTOT, TILES, NIN, EXTRA, MASK, NT>), dim3((unsigned)(tiles / (NT / 64))), dim3(NT), lds, st, p);
+    EVD_SET_MAX_LDS((&k_dgrad_layer<PREC, KTOT, TILES, NIN, EXTRA, OMASK, NT>), lds);
+    hipLaunchKernelGGL((k_dgrad_layer<PREC, KTOT, TILES, NIN, EXTRA, OMASK, NT>), dim3((unsigned)(tiles / (NT / 64))), dim3(NT), lds, st, p);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }
@@ -141,13 +136,12 @@ static int launch_dgrad(const DgradParams& p, long tiles, hipStream_t st) {
 struct WgradParams {
     const char* store;
     long tiles;
-    int y_slot, x_slot, mask_slot;
-    float* partial;         // [gridDim.x * NGRP][RT][CT + BIAS][64][16] float32
+    int y_slot, x_slot;
+    float* partial;         // [gridDim.x][RT][CT + BIAS][64][16] float32
 };
 
-constexpr int WGRAD_NT = 256;
-constexpr int wgrad_rpw(int RT) { return RT >= 4 ? RT / 4 : 1; }           // row tiles per wavefront
-constexpr int wgrad_ngrp(int RT) { return 4 / (RT / wgrad_rpw(RT)); }      // wavefront groups walking different sample tiles
+constexpr int WGRAD_NT = 512, WGRAD_TPI = 2;      // 8 wavefronts; sample tiles per iteration (one barrier each)
+constexpr int wgrad_cpg(int RT, int CT) { return cceil(CT, 8 / RT); }      // column tiles per wavefront group
 
 struct W4 { unsigned w[4]; };
 
@@ -174,13 +168,18 @@ template <int PREC> __device__ __forceinline__ void transpose_block(const W4& f0
 
 template <int PREC> __device__ __forceinline__ unsigned half_one_pair() { return PREC == EVD_PREC_BF16 ? 0x3f803f80u : 0x3c003c00u; }
 
-// RT row tiles (fragments y_slot .. ; YSINGLE: one fragment, 16 channels) x CT column tiles (fragments x_slot ..)
-template <int PREC, int RT, int CT, bool YSINGLE, bool MASK, bool BIAS>
+// RT row tiles (fragments y_slot .. ; YSINGLE: one fragment, 16 channels) x CT column tiles (fragments x_slot ..).
+// The 8 wavefronts of a workgroup share every sample tile: wavefront w owns row tile w % RT and the column tiles of its
+// group w / RT in accumulators; it transposes its own gradient block, and (w < CT) the activation block of column tile w,
+// which it publishes through LDS for the others.  Loads run one iteration (WGRAD_TPI tiles) ahead.
+template <int PREC, int RT, int CT, bool YSINGLE, bool BIAS>
 __global__ __launch_bounds__(WGRAD_NT) void k_wgrad(const WgradParams p) {
-    constexpr int RPW = wgrad_rpw(RT), WPG = RT / RPW, NGRP = wgrad_ngrp(RT), NC = CT + (BIAS ? 1 : 0);
-    static_assert(!YSINGLE || RT == 1, "single-fragment gradients are one row tile");
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 31, h = lane >> 5;
-    const int grp = wave / WPG, rt0 = (wave % WPG) * RPW;
+    constexpr int CPG = wgrad_cpg(RT, CT), NC = CT + (BIAS ? 1 : 0), TPI = WGRAD_TPI;
+    static_assert(8 % RT == 0 && CT <= 8 && (!YSINGLE || RT == 1), "shape of the block");
+    __shared__ __attribute__((aligned(16))) char xs[2][TPI][CT][2][1024];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = lane & 31, h = lane >> 5;
+    const int rt = wave % RT, c0 = (wave / RT) * CPG;
+    const bool xown = wave < CT, bias_own = BIAS && wave < RT;
     // selectors: sel0[kk][n] = (n == kk), sel1[kk][n] = (n == 16 + kk); this lane holds kk = 8h .. 8h + 7 of column n
     W4 sel0, sel1, ones;
     const unsigned one = half_one_pair<PREC>();
@@ -192,58 +191,78 @@ __global__ __launch_bounds__(WGRAD_NT) void k_wgrad(const WgradParams p) {
         ones.w[e] = n == 0 ? one : 0u;
     }
     const W4 zf = {{0u, 0u, 0u, 0u}};
-    f32x16 acc[RPW][NC];
+    f32x16 acc[CPG], accb;
 #pragma unroll
-    for (int r = 0; r < RPW; ++r)
+    for (int i = 0; i < 16; ++i) {
+        accb[i] = 0.f;
 #pragma unroll
-        for (int c = 0; c < NC; ++c)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[r][c][i] = 0.f;
-
-    for (long t = (long)blockIdx.x * NGRP + grp; t < p.tiles; t += (long)gridDim.x * NGRP) {
+        for (int c = 0; c < CPG; ++c) acc[c][i] = 0.f;
+    }
+    struct Frags { W4 y0, y1, x0, x1; };
+    auto load = [&](long t, Frags& f) {
+        f.y0 = f.y1 = f.x0 = f.x1 = zf;
+        if (t >= p.tiles) return;
         const char* al = p.store + t * astore::TILE_BYTES + lane * 16;
-        W4 yt[RPW][2];
+        f.y0 = frag_load<W4>(al, p.y_slot + 2 * rt);
+        if constexpr (!YSINGLE) f.y1 = frag_load<W4>(al, p.y_slot + 2 * rt + 1);
+        if (xown) {
+            f.x0 = frag_load<W4>(al, p.x_slot + 2 * wave);
+            f.x1 = frag_load<W4>(al, p.x_slot + 2 * wave + 1);
+        }
+    };
+    Frags cur[TPI], nxt[TPI];
+    const long stride = (long)gridDim.x * TPI;
+    long t0 = (long)blockIdx.x * TPI;
 #pragma unroll
-        for (int r = 0; r < RPW; ++r) {
-            W4 y0 = frag_load<W4>(al, p.y_slot + 2 * (rt0 + r)), y1 = zf;
-            if constexpr (!YSINGLE) y1 = frag_load<W4>(al, p.y_slot + 2 * (rt0 + r) + 1);
-            if constexpr (MASK) {
-                const W4 m0 = frag_load<W4>(al, p.mask_slot + 2 * (rt0 + r)), m1 = frag_load<W4>(al, p.mask_slot + 2 * (rt0 + r) + 1);
+    for (int k = 0; k < TPI; ++k) load(t0 + k, nxt[k]);
+    for (int it = 0; t0 < p.tiles; t0 += stride, ++it) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    y0.w[e] = mask_word(y0.w[e], m0.w[e]);
-                    y1.w[e] = mask_word(y1.w[e], m1.w[e]);
+        for (int k = 0; k < TPI; ++k) {
+            cur[k] = nxt[k];
+            load(t0 + stride + k, nxt[k]);
+        }
+        W4 yt[TPI][2];
+#pragma unroll
+        for (int k = 0; k < TPI; ++k) {
+            transpose_block<PREC>(cur[k].y0, cur[k].y1, sel0, sel1, yt[k]);
+            if (xown) {
+                W4 xt[2];
+                transpose_block<PREC>(cur[k].x0, cur[k].x1, sel0, sel1, xt);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) *reinterpret_cast<W4*>(&xs[it & 1][k][wave][q][lane * 16]) = xt[q];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < TPI; ++k) {
+#pragma unroll
+            for (int c = 0; c < CPG; ++c) {
+                if (c0 + c < CT) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const W4 xq = *reinterpret_cast<const W4*>(&xs[it & 1][k][c0 + c][q][lane * 16]);
+                        acc[c] = mfma_half<PREC>(yt[k][q], xq, acc[c]);
+                    }
                 }
             }
-            transpose_block<PREC>(y0, y1, sel0, sel1, yt[r]);
-        }
+            if (bias_own) {
 #pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            const W4 x0 = frag_load<W4>(al, p.x_slot + 2 * c), x1 = frag_load<W4>(al, p.x_slot + 2 * c + 1);
-            W4 xt[2];
-            transpose_block<PREC>(x0, x1, sel0, sel1, xt);
-#pragma unroll
-            for (int r = 0; r < RPW; ++r)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) acc[r][c] = mfma_half<PREC>(yt[r][q], xt[q], acc[r][c]);
-        }
-        if constexpr (BIAS) {
-#pragma unroll
-            for (int r = 0; r < RPW; ++r)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) acc[r][CT] = mfma_half<PREC>(yt[r][q], ones, acc[r][CT]);
+                for (int q = 0; q < 2; ++q) accb = mfma_half<PREC>(yt[k][q], ones, accb);
+            }
         }
     }
-    float* out = p.partial + ((((long)blockIdx.x * NGRP + grp) * RT + rt0) * NC) * 1024 + lane * 16;
+    float* out = p.partial + (((long)blockIdx.x * RT + rt) * NC) * 1024 + lane * 16;
+    auto put = [&](int c, const f32x16& a) {
 #pragma unroll
-    for (int r = 0; r < RPW; ++r)
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = {a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+            *reinterpret_cast<f32x4*>(out + c * 1024 + 4 * q) = v;
+        }
+    };
 #pragma unroll
-        for (int c = 0; c < NC; ++c)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 v = {acc[r][c][4 * q], acc[r][c][4 * q + 1], acc[r][c][4 * q + 2], acc[r][c][4 * q + 3]};
-                *reinterpret_cast<f32x4*>(out + (r * NC + c) * 1024 + 4 * q) = v;
-            }
+    for (int c = 0; c < CPG; ++c)
+        if (c0 + c < CT) put(c0 + c, acc[c]);
+    if (bias_own) put(CT, accb);
 }
 
 struct WreduceParams {
@@ -257,28 +276,42 @@ struct WreduceParams {
     const unsigned* maxbits;
 };
 
-// one thread per accumulator element (rt, c, lane, i): the partials of consecutive threads are contiguous
+// A block sums 64 float4 columns of the partials (4 slices of the workgroup list, folded through LDS), then scatters
+// the 256 sums: accumulator element (rt, c, lane, i) -> dW[rowmap[..]][colmap[..]]
 static __global__ __launch_bounds__(256) void k_wgrad_reduce(const WreduceParams p) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x, per = (long)p.RT * p.NC * 1024;
-    if (idx >= per) return;
-    const int i = idx & 15, lane = (idx >> 4) & 63, c = (int)((idx >> 10) % p.NC), rt = (int)((idx >> 10) / p.NC);
-    float s = 0.f;
-    for (int q = 0; q < p.nparts; ++q) s += p.partial[q * per + idx];
-    s *= grad_scale(*p.maxbits, true);
-    const int nr = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5), nc = lane & 31;
-    const int row = p.rowmap[rt * 32 + nr];
-    if (row < 0) return;
-    if (c < p.CT) {
-        const int col = p.colmap[c * 32 + nc];
-        if (col >= 0) p.dW[(long)row * p.ld + col] = s;
-    } else if (nc == 0 && p.db) {
-        p.db[row] = s;
+    __shared__ f32x4 fold[4][64];
+    const long per = (long)p.RT * p.NC * 1024, v4 = (long)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int slice = threadIdx.x >> 6;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (v4 * 4 < per) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(p.partial) + v4;
+#pragma unroll 4
+        for (int q = slice; q < p.nparts; q += 4) s += src[(long)q * (per / 4)];
+    }
+    fold[slice][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (slice != 0 || v4 * 4 >= per) return;
+    s = (fold[0][threadIdx.x] + fold[1][threadIdx.x]) + (fold[2][threadIdx.x] + fold[3][threadIdx.x]);
+    const float inv = grad_scale(*p.maxbits, true);
+    const long idx = v4 * 4;
+    const int lane = (idx >> 4) & 63, c = (int)((idx >> 10) % p.NC), rt = (int)((idx >> 10) / p.NC), nc = lane & 31;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = (int)(idx & 15) + k, nr = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+        const int row = p.rowmap[rt * 32 + nr];
+        if (row < 0) continue;
+        if (c < p.CT) {
+            const int col = p.colmap[c * 32 + nc];
+            if (col >= 0) p.dW[(long)row * p.ld + col] = s[k] * inv;
+        } else if (nc == 0 && p.db) {
+            p.db[row] = s[k] * inv;
+        }
     }
 }
 
-template <int PREC, int RT, int CT, bool YSINGLE, bool MASK, bool BIAS>
+template <int PREC, int RT, int CT, bool YSINGLE, bool BIAS>
 static int launch_wgrad(const WgradParams& p, int blocks, hipStream_t st) {
-    hipLaunchKernelGGL((k_wgrad<PREC, RT, CT, YSINGLE, MASK, BIAS>), dim3(blocks), dim3(WGRAD_NT), 0, st, p);
+    hipLaunchKernelGGL((k_wgrad<PREC, RT, CT, YSINGLE, BIAS>), dim3(blocks), dim3(WGRAD_NT), 0, st, p);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }
@@ -301,42 +334,42 @@ template <int PREC> static int run_nerf_backward(const BwdPlan& b, hipStream_t s
         return p;
     };
     // wgrad + reduce of one parameter block: rows from `ymap`, columns from `xmap` (offset into b.maps)
-    auto wgrad = [&](auto launch, int RT, int CT, bool bias, int y_slot, int x_slot, int mask_slot, int ymap, int xmap, float* dW, int ld, float* db) -> int {
+    auto wgrad = [&](auto launch, int RT, int CT, bool bias, int y_slot, int x_slot, int ymap, int xmap, float* dW, int ld, float* db) -> int {
         if (!dW) return EVD_OK;
-        const int ngrp = wgrad_ngrp(RT), blocks = (int)(b.tiles / ngrp < b.wgrad_blocks ? (b.tiles + ngrp - 1) / ngrp : b.wgrad_blocks);
+        const int blocks = (int)(cdiv(b.tiles, (long)WGRAD_TPI) < b.wgrad_blocks ? cdiv(b.tiles, (long)WGRAD_TPI) : b.wgrad_blocks);
         WgradParams p;
-        p.store = b.store; p.tiles = b.tiles; p.y_slot = y_slot; p.x_slot = x_slot; p.mask_slot = mask_slot; p.partial = b.partial;
+        p.store = b.store; p.tiles = b.tiles; p.y_slot = y_slot; p.x_slot = x_slot; p.partial = b.partial;
         int r = launch(p, blocks, st);
         if (r) return r;
         WreduceParams q;
-        q.partial = b.partial; q.nparts = blocks * ngrp; q.RT = RT; q.CT = CT; q.NC = CT + (bias ? 1 : 0);
+        q.partial = b.partial; q.nparts = blocks; q.RT = RT; q.CT = CT; q.NC = CT + (bias ? 1 : 0);
         q.rowmap = b.maps + ymap; q.colmap = b.maps + xmap; q.dW = dW; q.ld = ld; q.db = bias ? db : nullptr; q.maxbits = b.maxbits;
-        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)cdiv((long)RT * q.NC * 1024, 256L)), dim3(256), 0, st, q);
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((long)RT * q.NC * 4)), dim3(256), 0, st, q);
         EVD_LAUNCH_CHECK();
         return EVD_OK;
     };
     const BwdGrads& g = b.grads;
     // rgb_linear: d hv = Wr^T d rgb;  dWr = d rgb . hv^T
-    if ((rc = launch_dgrad<PREC, 1, 4, 1, false, false>(dgrad(EVD_BWD_RGB, G_RGB, -1, -1, D_HV), b.tiles, st))) return rc;
-    if ((rc = wgrad(launch_wgrad<PREC, 1, 4, true, false, true>, 1, 4, true, G_RGB, HV, -1, MAP_RGB, MAP_HID, g.rgb_w, 128, g.rgb_b))) return rc;
+    if ((rc = launch_dgrad<PREC, 1, 4, 1, false, true>(dgrad(EVD_BWD_RGB, G_RGB, -1, HV, D_HV), b.tiles, st))) return rc;
+    if ((rc = wgrad(launch_wgrad<PREC, 1, 4, true, true>, 1, 4, true, G_RGB, HV, MAP_RGB, MAP_HID, g.rgb_w, 128, g.rgb_b))) return rc;
     // views_linears.0 on cat([feature, PE(dir)])
-    if ((rc = launch_dgrad<PREC, 8, 8, 8, false, true>(dgrad(EVD_BWD_VIEWS, D_HV, -1, HV, D_F), b.tiles, st))) return rc;
-    if ((rc = wgrad(launch_wgrad<PREC, 4, 8, false, false, true>, 4, 8, true, D_HV, F, -1, MAP_HID, MAP_HID, g.views_w, 256 + 27, g.views_b))) return rc;
-    if ((rc = wgrad(launch_wgrad<PREC, 4, 1, false, false, false>, 4, 1, false, D_HV, DIR, -1, MAP_HID, MAP_DIR, g.views_w, 256 + 27, nullptr))) return rc;
+    if ((rc = launch_dgrad<PREC, 8, 8, 8, false, false>(dgrad(EVD_BWD_VIEWS, D_HV, -1, -1, D_F), b.tiles, st))) return rc;
+    if ((rc = wgrad(launch_wgrad<PREC, 4, 8, false, true>, 4, 8, true, D_HV, F, MAP_HID, MAP_HID, g.views_w, 256 + 27, g.views_b))) return rc;
+    if ((rc = wgrad(launch_wgrad<PREC, 4, 1, false, false>, 4, 1, false, D_HV, DIR, MAP_HID, MAP_DIR, g.views_w, 256 + 27, nullptr))) return rc;
     // feature_linear and alpha_linear both read h_7
-    if ((rc = launch_dgrad<PREC, 17, 8, 16, true, false>(dgrad(EVD_BWD_HEAD, D_F, G_ALPHA, -1, D_H0 + 16 * (D - 1)), b.tiles, st))) return rc;
-    if ((rc = wgrad(launch_wgrad<PREC, 8, 8, false, false, true>, 8, 8, true, D_F, H0 + 16 * (D - 1), -1, MAP_HID, MAP_HID, g.feature_w, 256, g.feature_b))) return rc;
-    if ((rc = wgrad(launch_wgrad<PREC, 1, 8, true, false, true>, 1, 8, true, G_ALPHA, H0 + 16 * (D - 1), -1, MAP_ALPHA, MAP_HID, g.alpha_w, 256, g.alpha_b))) return rc;
+    if ((rc = launch_dgrad<PREC, 17, 8, 16, true, true>(dgrad(EVD_BWD_HEAD, D_F, G_ALPHA, H0 + 16 * (D - 1), D_H0 + 16 * (D - 1)), b.tiles, st))) return rc;
+    if ((rc = wgrad(launch_wgrad<PREC, 8, 8, false, true>, 8, 8, true, D_F, H0 + 16 * (D - 1), MAP_HID, MAP_HID, g.feature_w, 256, g.feature_b))) return rc;
+    if ((rc = wgrad(launch_wgrad<PREC, 1, 8, true, true>, 1, 8, true, G_ALPHA, H0 + 16 * (D - 1), MAP_ALPHA, MAP_HID, g.alpha_w, 256, g.alpha_b))) return rc;
     // pts_linears[l], l = 7 .. 1
     for (int l = D - 1; l >= 1; --l) {
         const bool wide = l - 1 == b.skip;
-        if ((rc = launch_dgrad<PREC, 16, 8, 16, false, true>(dgrad(EVD_BWD_HIDDEN1 + l - 1, D_H0 + 16 * l, -1, H0 + 16 * l, D_H0 + 16 * (l - 1)), b.tiles, st))) return rc;
-        if ((rc = wgrad(launch_wgrad<PREC, 8, 8, false, false, true>, 8, 8, true, D_H0 + 16 * l, H0 + 16 * (l - 1), -1, MAP_HID, wide ? MAP_HID_SKIP : MAP_HID,
+        if ((rc = launch_dgrad<PREC, 16, 8, 16, false, true>(dgrad(EVD_BWD_HIDDEN1 + l - 1, D_H0 + 16 * l, -1, H0 + 16 * (l - 1), D_H0 + 16 * (l - 1)), b.tiles, st))) return rc;
+        if ((rc = wgrad(launch_wgrad<PREC, 8, 8, false, true>, 8, 8, true, D_H0 + 16 * l, H0 + 16 * (l - 1), MAP_HID, wide ? MAP_HID_SKIP : MAP_HID,
                         g.pts_w[l], wide ? 256 + 63 : 256, g.pts_b[l]))) return rc;
-        if (wide && (rc = wgrad(launch_wgrad<PREC, 8, 2, false, false, false>, 8, 2, false, D_H0 + 16 * l, PE, -1, MAP_HID, MAP_PE, g.pts_w[l], 256 + 63, nullptr))) return rc;
+        if (wide && (rc = wgrad(launch_wgrad<PREC, 8, 2, false, false>, 8, 2, false, D_H0 + 16 * l, PE, MAP_HID, MAP_PE, g.pts_w[l], 256 + 63, nullptr))) return rc;
     }
-    // pts_linears[0] on PE(pts): its incoming gradient is masked here (no dgrad beyond the inputs)
-    return wgrad(launch_wgrad<PREC, 8, 2, false, true, true>, 8, 2, true, D_H0, PE, H0, MAP_HID, MAP_PE, g.pts_w[0], 63, g.pts_b[0]);
+    // pts_linears[0] on PE(pts) (no dgrad beyond the inputs)
+    return wgrad(launch_wgrad<PREC, 8, 2, false, true>, 8, 2, true, D_H0, PE, MAP_HID, MAP_PE, g.pts_w[0], 63, g.pts_b[0]);
 }
 
 }  // namespace evd
