@@ -45,6 +45,10 @@ class NerfGrads(C.Structure):
                 ("alpha_w", _vp), ("alpha_b", _vp), ("rgb_w", _vp), ("rgb_b", _vp)]
 
 
+class VoxelGridGrads(C.Structure):
+    _fields_ = [("plane", _vp * 3), ("line", _vp * 3), ("basis", _vp)]
+
+
 class VoxelDesc(C.Structure):
     _fields_ = [("num_layers", C.c_int), ("hidden_dim", C.c_int), ("geo_feat_dim", C.c_int),
                 ("num_layers_color", C.c_int), ("input_ch", C.c_int), ("multires", C.c_int), ("multires_views", C.c_int),
@@ -93,6 +97,11 @@ SIGNATURES = {
     "evd_nerf_mlp_train": (_I, [_vp, _I, _vp, _vp, _L, _I, _vp, _vp, _S, _vp]),
     "evd_nerf_backward_workspace_bytes": (_S, []),
     "evd_nerf_mlp_backward": (_I, [_vp, _I, _vp, _L, _I, _vp, _S, C.POINTER(NerfGrads), _vp, _S, _vp]),
+    "evd_voxel_grid_sizes": (_I, [_vp, C.POINTER(C.c_long)]),
+    "evd_voxel_get_grids": (_I, [_vp, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp]),
+    "evd_voxel_load_grids": (_I, [_vp, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp]),
+    "evd_voxel_sample_bwd": (_I, [_vp, _vp, _L, _vp, _I, _I, C.POINTER(VoxelGridGrads), _vp]),
+    "evd_voxel_tv_loss_bwd": (_I, [_vp, _vp, C.POINTER(VoxelGridGrads), _vp]),
     "evd_raw2outputs": (_I, [_vp, _vp, _vp, _I, _L, _I, _I, _I, _I, _I, _I, _I, _I, _F, _vp,
                              _vp, _vp, _vp, _vp, _vp, _vp, _I, _vp, _vp]),
     "evd_raw2outputs_bwd": (_I, [_vp, _vp, _vp, _I, _L, _I, _I, _I, _I, _I, _I, _I, _I, _F, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -304,6 +304,65 @@ int evd_c2f_render(const evd_voxel* coarse, const evd_voxel* fine, const evd_ren
     return evd_c2f_render_rays(coarse, fine, cfg, rb, R, t_rand, u, noise0, noise1, out, workspace, workspace_bytes, stream);
 }
 
+// ---- training: the grids as parameters -------------------------------------------------------------------------------
+int evd_voxel_grid_sizes(const evd_voxel* v, long* sizes) {
+    EVD_REQUIRE(v && sizes, "evd_voxel_grid_sizes: null argument");
+    for (int i = 0; i < 3; ++i) {
+        sizes[i] = (long)(v->plane[i].bytes / sizeof(float));
+        sizes[3 + i] = (long)(v->line[i].bytes / sizeof(float));
+    }
+    sizes[6] = (long)(v->basis.bytes / sizeof(float));
+    return EVD_OK;
+}
+
+int evd_voxel_get_grids(const evd_voxel* v, float* const* plane, float* const* line, float* basis, void* stream) {
+    EVD_REQUIRE(v && plane && line && basis, "evd_voxel_get_grids: null argument");
+    hipStream_t st = as_stream(stream);
+    for (int i = 0; i < 3; ++i) {
+        EVD_HIP(hipMemcpyAsync(plane[i], v->plane[i].p, v->plane[i].bytes, hipMemcpyDeviceToDevice, st));
+        EVD_HIP(hipMemcpyAsync(line[i], v->line[i].p, v->line[i].bytes, hipMemcpyDeviceToDevice, st));
+    }
+    EVD_HIP(hipMemcpyAsync(basis, v->basis.p, v->basis.bytes, hipMemcpyDeviceToDevice, st));
+    return EVD_OK;
+}
+
+int evd_voxel_load_grids(evd_voxel* v, const float* const* plane, const float* const* line, const float* basis, void* stream) {
+    EVD_REQUIRE(v && plane && line && basis, "evd_voxel_load_grids: null argument");
+    hipStream_t st = as_stream(stream);
+    int rc;
+    for (int i = 0; i < 3; ++i) {
+        EVD_HIP(hipMemcpyAsync(v->plane[i].p, plane[i], v->plane[i].bytes, hipMemcpyDeviceToDevice, st));
+        EVD_HIP(hipMemcpyAsync(v->line[i].p, line[i], v->line[i].bytes, hipMemcpyDeviceToDevice, st));
+        if ((rc = launch_f32_to_f16((const float*)v->plane[i].p, (long)(v->plane[i].bytes / 4), (_Float16*)v->plane_h[i].p, st))) return rc;
+        if ((rc = launch_f32_to_f16((const float*)v->line[i].p, (long)(v->line[i].bytes / 4), (_Float16*)v->line_h[i].p, st))) return rc;
+    }
+    EVD_HIP(hipMemcpyAsync(v->basis.p, basis, v->basis.bytes, hipMemcpyDeviceToDevice, st));
+    return EVD_OK;
+}
+
+int evd_voxel_sample_bwd(const evd_voxel* v, const float* pts, long n, const float* d_out, int d_stride, int d_col,
+                         const evd_voxel_grid_grads* g, void* stream) {
+    EVD_REQUIRE(v && pts && d_out && g && n >= 0 && d_stride >= d_col + v->app_dim, "evd_voxel_sample_bwd: bad arguments");
+    EVD_REQUIRE(v->app_act == EVD_ACT_NONE, "evd_voxel_sample_bwd: only app_actfn none is built (all shipped configs)");
+    if (n == 0) return EVD_OK;
+    GridGrads gg;
+    for (int i = 0; i < 3; ++i) { gg.plane[i] = g->plane[i]; gg.line[i] = g->line[i]; }
+    gg.basis = g->basis;
+    return launch_voxel_sample_bwd(v->gp, pts, n, d_out, d_stride, d_col, gg, as_stream(stream));
+}
+
+int evd_voxel_tv_loss_bwd(const evd_voxel* v, const float* d_loss, const evd_voxel_grid_grads* g, void* stream) {
+    EVD_REQUIRE(v && g && d_loss, "evd_voxel_tv_loss_bwd: null argument");
+    hipStream_t st = as_stream(stream);
+    for (int i = 0; i < 3; ++i) {
+        const int C = v->n_comp[i], Wp = v->grid[kMat0[i]], Hp = v->grid[kMat1[i]], Lp = v->grid[kVec[i]];
+        int rc = g->plane[i] ? launch_tv_bwd((const float*)v->plane[i].p, Hp, Wp, C, d_loss, 1e-2f, g->plane[i], st) : EVD_OK;
+        if (!rc && g->line[i]) rc = launch_tv_bwd((const float*)v->line[i].p, Lp, 1, C, d_loss, 1e-3f, g->line[i], st);
+        if (rc) return rc;
+    }
+    return EVD_OK;
+}
+
 int evd_voxel_tv_loss(const evd_voxel* v, float* out, void* stream) {
     EVD_REQUIRE(v && out, "evd_voxel_tv_loss: null argument");
     hipStream_t st = as_stream(stream);

@@ -53,7 +53,12 @@ constexpr int VS_MAXC = 128;        // max sum(n_comp)
 // the exact-float32 MFMA (v_mfma_f32_32x32x2_f32 = an fmaf chain in k order), by wavefront 0 of the block.
 constexpr int VS_STRIDE = VS_MAXC + 1;      // odd row stride: conflict-free column reads in phase 2
 
-struct VsItem { f32x4 p[4], l[2]; float wp[4], wl[2]; };
+struct VsItem {
+    f32x4 p[4], l[2];
+    float wp[4], wl[2];
+    long ip[4], il[2];      // element offsets of the taps (backward: where the gradients are added); unused fields cost the forward nothing
+    int grid_id;
+};
 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
@@ -89,10 +94,13 @@ __device__ __forceinline__ void vs_issue(const GridParams& g, const float (&pt)[
     const int cx0 = min(max(x0, 0), Wp - 1), cx1 = min(max(x1, 0), Wp - 1), cy0 = min(max(y0, 0), Hp - 1), cy1 = min(max(y1, 0), Hp - 1);
     const float* pl = sel3(i, g.plane[0], g.plane[1], g.plane[2]) + c4;
     const _Float16* plh = sel3(i, g.plane_h[0], g.plane_h[1], g.plane_h[2]) + c4;
-    it.p[0] = vs_load<HALF>(pl, plh, ((long)cy0 * Wp + cx0) * C);
-    it.p[1] = vs_load<HALF>(pl, plh, ((long)cy0 * Wp + cx1) * C);
-    it.p[2] = vs_load<HALF>(pl, plh, ((long)cy1 * Wp + cx0) * C);
-    it.p[3] = vs_load<HALF>(pl, plh, ((long)cy1 * Wp + cx1) * C);
+    it.grid_id = i;
+    it.ip[0] = ((long)cy0 * Wp + cx0) * C + c4;
+    it.ip[1] = ((long)cy0 * Wp + cx1) * C + c4;
+    it.ip[2] = ((long)cy1 * Wp + cx0) * C + c4;
+    it.ip[3] = ((long)cy1 * Wp + cx1) * C + c4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) it.p[t] = vs_load<HALF>(pl, plh, it.ip[t] - c4);
     it.wp[0] = (vy0 && vx0) ? __fmul_rn(ee, ss) : 0.f;
     it.wp[1] = (vy0 && vx1) ? __fmul_rn(ww, ss) : 0.f;
     it.wp[2] = (vy1 && vx0) ? __fmul_rn(ee, nn) : 0.f;
@@ -103,15 +111,17 @@ __device__ __forceinline__ void vs_issue(const GridParams& g, const float (&pt)[
     const int l0 = (int)fl, l1 = l0 + 1;
     const float* li = sel3(i, g.line[0], g.line[1], g.line[2]) + c4;
     const _Float16* lih = sel3(i, g.line_h[0], g.line_h[1], g.line_h[2]) + c4;
-    it.l[0] = vs_load<HALF>(li, lih, (long)min(max(l0, 0), Lp - 1) * C);
-    it.l[1] = vs_load<HALF>(li, lih, (long)min(max(l1, 0), Lp - 1) * C);
+    it.il[0] = (long)min(max(l0, 0), Lp - 1) * C + c4;
+    it.il[1] = (long)min(max(l1, 0), Lp - 1) * C + c4;
+    it.l[0] = vs_load<HALF>(li, lih, it.il[0] - c4);
+    it.l[1] = vs_load<HALF>(li, lih, it.il[1] - c4);
     it.wl[0] = (l0 >= 0 && l0 < Lp) ? ls : 0.f;
     it.wl[1] = (l1 >= 0 && l1 < Lp) ? ln : 0.f;
 }
 
 // invalid taps contribute exactly nothing (the reference skips them): a zero weight times a finite grid value is 0,
 // and 0 added to the running sum changes nothing
-__device__ __forceinline__ f32x4 vs_finish(const VsItem& it) {
+__device__ __forceinline__ f32x4 vs_finish(const VsItem& it, f32x4* pv_out = nullptr, f32x4* lv_out = nullptr) {
     f32x4 pv = {0.f, 0.f, 0.f, 0.f}, lv = {0.f, 0.f, 0.f, 0.f}, cf;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -123,6 +133,8 @@ __device__ __forceinline__ f32x4 vs_finish(const VsItem& it) {
         for (int k = 0; k < 4; ++k) lv[k] = it.wl[t] != 0.f ? __fadd_rn(lv[k], __fmul_rn(it.l[t][k], it.wl[t])) : lv[k];
 #pragma unroll
     for (int k = 0; k < 4; ++k) cf[k] = __fmul_rn(pv[k], lv[k]);
+    if (pv_out) *pv_out = pv;
+    if (lv_out) *lv_out = lv;
     return cf;
 }
 
@@ -192,6 +204,118 @@ __global__ __launch_bounds__(256) void k_voxel_sample(const GridParams g, const 
             }
         }
     }
+}
+
+// Backward of k_voxel_sample (app_act none): d out [n, app_dim] -> gradients of the planes, lines (scatter-add, the transpose of
+// the gather: the same 4 + 2 taps with the same weights) and of basis_mat.  Persistent blocks walk 32-sample tiles:
+//   A  d out rows -> LDS;  d coef[s, c] = sum_f d out[s, f] basis[f, c]
+//   B  the forward's gather again (plane value pv, line value lv per 4-channel group), coef = pv lv -> LDS, then
+//      d plane[tap] += w_tap d coef lv,  d line[tap] += w_tap d coef pv   as hardware float32 atomics (global_atomic_add_f32);
+//      like the reference's grid_sample backward (voxnerf.py:144) the summation order, hence the last bits, is not deterministic
+//   C  d basis[f, c] += sum_s d out[s, f] coef[s, c] in registers across tiles, one atomic flush per block at the end
+constexpr int VSB_MAXF = 64;
+__global__ __launch_bounds__(256) void k_voxel_sample_bwd(const GridParams g, const float* __restrict__ pts, long n,
+                                                          const float* __restrict__ d_out, int d_stride, int d_col, GridGrads gg) {
+    __shared__ __attribute__((aligned(16))) float coef[VS_SAMPLES * VS_STRIDE], dco[VS_SAMPLES * VS_STRIDE], dout[VS_SAMPLES * (VSB_MAXF + 1)];
+    const int ctot = g.n_comp[0] + g.n_comp[1] + g.n_comp[2], ng = ctot / 4, F = g.app_dim;
+    const int items = VS_SAMPLES * ng, nbas = F * ctot;
+    constexpr int NB = (VSB_MAXF * VS_MAXC + 255) / 256;
+    float bacc[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) bacc[q] = 0.f;
+    for (long tile = blockIdx.x; tile * VS_SAMPLES < n; tile += gridDim.x) {
+        const long s0 = tile * VS_SAMPLES;
+        for (int o = threadIdx.x; o < VS_SAMPLES * F; o += 256) {
+            const int sl = o / F, f = o % F;
+            dout[sl * (VSB_MAXF + 1) + f] = s0 + sl < n ? d_out[(s0 + sl) * (long)d_stride + d_col + f] : 0.f;
+        }
+        __syncthreads();
+        for (int o = threadIdx.x; o < VS_SAMPLES * ctot; o += 256) {
+            const int sl = o / ctot, c = o % ctot;
+            float a = 0.f;
+            for (int f = 0; f < F; ++f) a = fmaf(dout[sl * (VSB_MAXF + 1) + f], g.basis[(long)f * ctot + c], a);
+            dco[sl * VS_STRIDE + c] = a;
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < items; t += 256) {
+            const int sl = t / ng, grp = t % ng;
+            const long s = s0 + sl < n ? s0 + sl : n - 1;
+            const float pt[3] = {pts[s * 3], pts[s * 3 + 1], pts[s * 3 + 2]};
+            VsItem it;
+            vs_issue<false>(g, pt, grp, it);
+            f32x4 pv, lv;
+            const f32x4 cf = vs_finish(it, &pv, &lv);
+            float* cdst = &coef[sl * VS_STRIDE + grp * 4];
+            const float* dc = &dco[sl * VS_STRIDE + grp * 4];
+            float* gp = sel3(it.grid_id, gg.plane[0], gg.plane[1], gg.plane[2]);
+            float* gl = sel3(it.grid_id, gg.line[0], gg.line[1], gg.line[2]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cdst[k] = cf[k];
+            if (s0 + sl < n) {
+#pragma unroll
+                for (int tp = 0; tp < 4; ++tp)
+                    if (it.wp[tp] != 0.f && gp) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) unsafeAtomicAdd(gp + it.ip[tp] + k, dc[k] * lv[k] * it.wp[tp]);
+                    }
+#pragma unroll
+                for (int tp = 0; tp < 2; ++tp)
+                    if (it.wl[tp] != 0.f && gl) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) unsafeAtomicAdd(gl + it.il[tp] + k, dc[k] * pv[k] * it.wl[tp]);
+                    }
+            }
+        }
+        __syncthreads();
+        if (gg.basis) {
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const int o = threadIdx.x + 256 * q;
+                if (o < nbas) {
+                    const int f = o / ctot, c = o % ctot;
+                    float a = bacc[q];
+                    for (int sl = 0; sl < VS_SAMPLES; ++sl) a = fmaf(dout[sl * (VSB_MAXF + 1) + f], coef[sl * VS_STRIDE + c], a);
+                    bacc[q] = a;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (gg.basis) {
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int o = threadIdx.x + 256 * q;
+            if (o < nbas) unsafeAtomicAdd(gg.basis + o, bacc[q]);
+        }
+    }
+}
+
+// d (TV_loss_app) / d grid, added into `grad` scaled by d loss (a device scalar) x weight (1e-2 planes | 1e-3 lines) (voxnerf.py:126-130, 306-324):
+// reg = 2 (sum dh^2 / count_h + sum dw^2 / count_w)  =>  d reg / d x = 4 ((dh_prev - dh_next) / count_h + (dw_prev - dw_next) / count_w)
+__global__ __launch_bounds__(256) void k_tv_bwd(const float* __restrict__ x, int H, int W, int C, const float* __restrict__ d_loss, float weight, float* __restrict__ grad) {
+    const float scale = d_loss[0] * weight;
+    const long per_row = (long)W * (C / 4), total = per_row * H;
+    const float kh = H > 1 ? 4.f * scale / ((float)C * (H - 1) * W) : 0.f;
+    const float cw = fmaxf((float)C * H * (W - 1), 1.f), kw = 4.f * scale / cw;
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < total; v += (long)gridDim.x * 256) {
+        const int hh = (int)(v / per_row);
+        const long r = v % per_row;
+        const int wq = (int)(r / (C / 4));
+        const float* px = x + v * 4;
+        const f32x4 c = *reinterpret_cast<const f32x4*>(px);
+        f32x4 gsum = {0.f, 0.f, 0.f, 0.f};
+        if (hh > 0) gsum += (c - *reinterpret_cast<const f32x4*>(px - (long)W * C)) * kh;
+        if (hh + 1 < H) gsum -= (*reinterpret_cast<const f32x4*>(px + (long)W * C) - c) * kh;
+        if (wq > 0) gsum += (c - *reinterpret_cast<const f32x4*>(px - C)) * kw;
+        if (wq + 1 < W) gsum -= (*reinterpret_cast<const f32x4*>(px + C) - c) * kw;
+        f32x4* gd = reinterpret_cast<f32x4*>(grad + v * 4);
+        *gd = *gd + gsum;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_f32_to_f16(const float* __restrict__ x, long n4, _Float16* __restrict__ y) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256)
+        *reinterpret_cast<f16x4*>(y + 4 * i) = __builtin_convertvector(*reinterpret_cast<const f32x4*>(x + 4 * i), f16x4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -389,6 +513,27 @@ int launch_merge_features(const float* old, const float* fresh, const int* order
 int launch_voxel_sample(const GridParams& g, bool half_grids, const float* pts, long n, float* out, int out_stride, int out_col, hipStream_t st) {
     if (half_grids) k_voxel_sample<true><<<cdiv(n, VS_SAMPLES), 256, 0, st>>>(g, pts, n, out, out_stride, out_col);
     else k_voxel_sample<false><<<cdiv(n, VS_SAMPLES), 256, 0, st>>>(g, pts, n, out, out_stride, out_col);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+int launch_voxel_sample_bwd(const GridParams& g, const float* pts, long n, const float* d_out, int d_stride, int d_col, const GridGrads& gg, hipStream_t st) {
+    if (g.app_dim > VSB_MAXF) return fail(EVD_E_INVALID, "evd_voxel_sample_bwd: app_dim %d > %d", g.app_dim, VSB_MAXF);
+    const long tiles = cdiv(n, VS_SAMPLES);
+    k_voxel_sample_bwd<<<(unsigned)(tiles < 2048 ? tiles : 2048), 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+int launch_tv_bwd(const float* x, int H, int W, int C, const float* d_loss, float weight, float* grad, hipStream_t st) {
+    const long total = (long)H * W * (C / 4);
+    k_tv_bwd<<<(unsigned)(cdiv(total, 256) < 4096 ? cdiv(total, 256) : 4096), 256, 0, st>>>(x, H, W, C, d_loss, weight, grad);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+int launch_f32_to_f16(const float* x, long n, _Float16* y, hipStream_t st) {
+    k_f32_to_f16<<<(unsigned)(cdiv(n / 4, 256) < 4096 ? cdiv(n / 4, 256) : 4096), 256, 0, st>>>(x, n / 4, y);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }

@@ -15,6 +15,8 @@ struct GridParams {
     float aabb_min[3], inv[3];  // inv = 2 / (max - min)  (invaabbSize, voxnerf.py:91)
 };
 
+struct GridGrads { float *plane[3], *line[3], *basis; };    // channel-last like the grids; null = not wanted
+
 struct VoxMlpParams {
     const char* wstream;
     const float* bias;          // 512 zero floats (bias-free sigma net) then the colour-net biases, 32 per output tile
@@ -34,6 +36,9 @@ int launch_points(const float* rb, int nc, const float* z, long n, int S, float*
 int launch_merge_features(const float* old, const float* fresh, const int* order, long R, int S, int N, int F, float* out, int out_stride,
                           hipStream_t st);
 int launch_voxel_sample(const GridParams& g, bool half_grids, const float* pts, long n, float* out, int out_stride, int out_col, hipStream_t st);
+int launch_voxel_sample_bwd(const GridParams& g, const float* pts, long n, const float* d_out, int d_stride, int d_col, const GridGrads& gg, hipStream_t st);
+int launch_tv_bwd(const float* x, int H, int W, int C, const float* d_loss, float weight, float* grad, hipStream_t st);
+int launch_f32_to_f16(const float* x, long n, _Float16* y, hipStream_t st);
 int launch_tv(const float* x, int H, int W, int C, double* partials, int* blocks, hipStream_t st);
 int launch_tv_finish(const double* acc, const TvShape& s, float* out, hipStream_t st);
 int voxel_mlp_dispatch(int prec, int HD, int G, int FT, const VoxMlpParams& p, hipStream_t st);

@@ -17,6 +17,52 @@ def _np32(v):
     return np.ascontiguousarray(v, dtype=np.float32)
 
 
+def _grid_grads(net, like):
+    """zeroed gradient tensors for the 7 grid parameters + the ctypes struct pointing at them"""
+    grads = [torch.zeros_like(t) for t in like]
+    gs = L.VoxelGridGrads()
+    for i in range(3):
+        gs.plane[i], gs.line[i] = grads[i].data_ptr(), grads[3 + i].data_ptr()
+    gs.basis = grads[6].data_ptr()
+    return grads, gs
+
+
+class _VoxelSample(torch.autograd.Function):
+    """VoxelNeRFBase.sample with gradients to the (channel-last) planes, lines and basis_mat: evd_voxel_sample / _bwd"""
+
+    @staticmethod
+    def forward(ctx, pts, net, *grids):
+        ctx.net, ctx.pts = net, pts
+        ctx.save_for_backward(*grids)
+        return net.sample(pts)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        net, pts = ctx.net, ctx.pts.reshape(-1, 3).contiguous().float()
+        g = d_out.reshape(-1, net.app_dim).contiguous().float()
+        grads, gs = _grid_grads(net, ctx.saved_tensors)
+        L.check(L.lib().evd_voxel_sample_bwd(net._h, L.ptr(pts), pts.shape[0], L.ptr(g), net.app_dim, 0, C.byref(gs), L.stream_ptr()),
+                "evd_voxel_sample_bwd")
+        return (None, None, *grads)
+
+
+class _VoxelTV(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, *grids):
+        ctx.net = net
+        ctx.save_for_backward(*grids)
+        return net.TV_loss_app()
+
+    @staticmethod
+    def backward(ctx, d_loss):
+        net = ctx.net
+        grads, gs = _grid_grads(net, ctx.saved_tensors)
+        gs.basis = None
+        d = d_loss.reshape(1).contiguous().float()
+        L.check(L.lib().evd_voxel_tv_loss_bwd(net._h, L.ptr(d), C.byref(gs), L.stream_ptr()), "evd_voxel_tv_loss_bwd")
+        return (None, *grads)
+
+
 class VoxelNeRFBase:
     def __init__(self, state_dict, prefix, aabb, num_layers=2, hidden_dim=64, geo_feat_dim=15, num_layers_color=3,
                  hidden_dim_color=64, input_ch=95, multires=10, multires_views=4, render_rmnearplane=0, app_dim=32,
@@ -100,6 +146,49 @@ class VoxelNeRFBase:
         out = torch.empty((p.shape[0], self.app_dim), dtype=torch.float32, device=p.device)
         L.check(L.lib().evd_voxel_sample(self._h, L.ptr(p), p.shape[0], L.ptr(out), self.app_dim, 0, L.stream_ptr()), "evd_voxel_sample")
         return out.reshape(sh[0], sh[1], self.app_dim) if len(sh) == 3 else out
+
+    # ---- training the grids (the library's channel-last layout; a permute away from the state dict) ---------------------
+    def grid_params(self):
+        """[plane0..2 [H,W,C], line0..2 [L,C], basis [app_dim, sum C]] as leaf tensors for an optimizer"""
+        sz = (C.c_long * 7)()
+        L.check(L.lib().evd_voxel_grid_sizes(self._h, sz), "evd_voxel_grid_sizes")
+        mat, vec, g = [[0, 1], [0, 2], [1, 2]], [2, 1, 0], self.gridSize
+        shapes = [(g[mat[i][1]], g[mat[i][0]], sz[i] // (g[mat[i][1]] * g[mat[i][0]])) for i in range(3)]
+        shapes += [(g[vec[i]], sz[3 + i] // g[vec[i]]) for i in range(3)]
+        shapes += [(self.app_dim, sz[6] // self.app_dim)]
+        ts = [torch.empty(sh, dtype=torch.float32, device="cuda") for sh in shapes]
+        pl, li = (C.c_void_p * 3)(*[t.data_ptr() for t in ts[:3]]), (C.c_void_p * 3)(*[t.data_ptr() for t in ts[3:6]])
+        L.check(L.lib().evd_voxel_get_grids(self._h, pl, li, L.ptr(ts[6]), L.stream_ptr()), "evd_voxel_get_grids")
+        return [t.requires_grad_(True) for t in ts]
+
+    def load_grids(self, grids):
+        ts = [t.detach().contiguous().float() for t in grids]
+        pl, li = (C.c_void_p * 3)(*[t.data_ptr() for t in ts[:3]]), (C.c_void_p * 3)(*[t.data_ptr() for t in ts[3:6]])
+        L.check(L.lib().evd_voxel_load_grids(self._h, pl, li, L.ptr(ts[6]), L.stream_ptr()), "evd_voxel_load_grids")
+        self._synced = tuple((t.data_ptr(), t._version) for t in grids)
+
+    def _sync(self, grids):
+        if getattr(self, "_synced", None) != tuple((t.data_ptr(), t._version) for t in grids):
+            self.load_grids(grids)
+
+    def sample_train(self, pts, grids):
+        """sample(pts) with autograd to the grid parameters (re-loads them into the library after an optimizer step)"""
+        self._sync(grids)
+        return _VoxelSample.apply(pts, self, *grids)
+
+    def tv_loss_train(self, grids):
+        self._sync(grids)
+        return _VoxelTV.apply(self, *grids)
+
+    @staticmethod
+    def grids_to_state_dict(grids, prefix=""):
+        """channel-last parameters -> reference layouts (app_plane.i [1,C,H,W], app_line.i [1,C,L,1], basis_mat.weight)"""
+        sd = {}
+        for i in range(3):
+            sd[f"{prefix}app_plane.{i}"] = grids[i].detach().permute(2, 0, 1).unsqueeze(0).contiguous()
+            sd[f"{prefix}app_line.{i}"] = grids[3 + i].detach().t().unsqueeze(0).unsqueeze(-1).contiguous()
+        sd[f"{prefix}basis_mat.weight"] = grids[6].detach().clone()
+        return sd
 
     # voxnerf.py:210-259; returns (color, depth_map, acc_map, weights, feature_map)
     def forward(self, pts, viewdirs, fts, z_vals, rays_d, raw_noise_std=0., is_train=False, precision=None):

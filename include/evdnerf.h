@@ -233,6 +233,26 @@ int evd_c2f_render(const evd_voxel* coarse, const evd_voxel* fine, const evd_ren
 /* TV_loss_app, voxnerf.py:126-130 (TVLoss :306-324): sum over planes*1e-2 + lines*1e-3 -> out dev [1] (float) */
 int evd_voxel_tv_loss(const evd_voxel* v, float* out, void* stream);
 
+/* ---- training the PDRF grids (scatter-add into the tri-planes) -----------------------------------------
+ * The library keeps planes / lines CHANNEL-LAST: plane[i] [grid[m1]][grid[m0]][C_i] (reference app_plane.i is [1,C,H,W],
+ * voxnerf.py:112-113), line[i] [grid[vec]][C_i], basis [app_dim][sum C] (= basis_mat.weight).  Parameters and gradients of
+ * the training path use THAT layout (a permute away from the state dict).
+ * evd_voxel_grid_sizes: element counts, sizes[0..2] planes, [3..5] lines, [6] basis.
+ * evd_voxel_get_grids / evd_voxel_load_grids: copy the grids out to / in from caller-owned device buffers (load also
+ * refreshes the float16 copies the half-precision modes read) -- what a training loop calls after optimizer.step(). */
+typedef struct { float *plane[3], *line[3], *basis; } evd_voxel_grid_grads;
+int evd_voxel_grid_sizes(const evd_voxel* v, long* sizes);
+int evd_voxel_get_grids(const evd_voxel* v, float* const* plane, float* const* line, float* basis, void* stream);
+int evd_voxel_load_grids(evd_voxel* v, const float* const* plane, const float* const* line, const float* basis, void* stream);
+/* Backward of evd_voxel_sample (VoxelNeRFBase.sample / compute_appfeature, voxnerf.py:132-151,203-208; app_actfn none):
+ * d_out dev rows of d_stride floats, the app_dim gradient columns start at d_col -> gradients ADDED into g (caller zeroes;
+ * NULL = not wanted) with float32 hardware atomics; like the reference's grid_sample backward (voxnerf.py:144) the summation
+ * order is not deterministic. */
+int evd_voxel_sample_bwd(const evd_voxel* v, const float* pts, long n, const float* d_out, int d_stride, int d_col,
+                         const evd_voxel_grid_grads* g, void* stream);
+/* d_loss[0] * d TV_loss_app / d grid added into g (voxnerf.py:126-130, 306-324); d_loss is a DEVICE scalar (no host sync) */
+int evd_voxel_tv_loss_bwd(const evd_voxel* v, const float* d_loss, const evd_voxel_grid_grads* g, void* stream);
+
 /* ---------------------------------------------------------------- loss-side pixel ops */
 /* RigidBlurringModel.rbk_weighted_sum, networks/dpnerf/blurmodel.py:112-127 (and renderer.py:299,332-354):
  * out[r,c] = sum_p ccw[r,p] x[r*P+p, c] */
