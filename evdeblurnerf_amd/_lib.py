@@ -45,6 +45,10 @@ class NerfGrads(C.Structure):
                 ("alpha_w", _vp), ("alpha_b", _vp), ("rgb_w", _vp), ("rgb_b", _vp)]
 
 
+class VoxelGrads(C.Structure):
+    _fields_ = [("sigma_w", _vp * 2), ("color_w", _vp * 3), ("color_b", _vp * 3)]
+
+
 class VoxelGridGrads(C.Structure):
     _fields_ = [("plane", _vp * 3), ("line", _vp * 3), ("basis", _vp)]
 
@@ -97,6 +101,13 @@ SIGNATURES = {
     "evd_nerf_mlp_train": (_I, [_vp, _I, _vp, _vp, _L, _I, _vp, _vp, _S, _vp]),
     "evd_nerf_backward_workspace_bytes": (_S, []),
     "evd_nerf_mlp_backward": (_I, [_vp, _I, _vp, _L, _I, _vp, _S, C.POINTER(NerfGrads), _vp, _S, _vp]),
+    "evd_voxel_param_count": (_L, [_vp]),
+    "evd_voxel_param_blocks": (_I, [_vp, C.POINTER(C.c_long), _I]),
+    "evd_voxel_load_params": (_I, [_vp, _vp, _vp]),
+    "evd_voxel_train_store_bytes": (_S, [_vp, _L]),
+    "evd_voxel_backward_workspace_bytes": (_S, []),
+    "evd_voxel_mlp_train": (_I, [_vp, _I, _vp, _vp, _I, _vp, _I, _L, _I, _vp, _vp, _S, _vp]),
+    "evd_voxel_mlp_backward": (_I, [_vp, _I, _vp, _vp, _L, _I, _vp, _S, C.POINTER(VoxelGrads), _vp, _I, _vp, _S, _vp]),
     "evd_voxel_grid_sizes": (_I, [_vp, C.POINTER(C.c_long)]),
     "evd_voxel_get_grids": (_I, [_vp, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp]),
     "evd_voxel_load_grids": (_I, [_vp, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp]),

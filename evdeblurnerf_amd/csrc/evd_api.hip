@@ -47,12 +47,7 @@ int evd_device_count(void) {
 
 // Every stream keeps, next to its bytes, the index map element -> parameter arena (pack.h), so that new parameter values
 // are re-packed on the device (evd_nerf_load_params) with the arithmetic the host packer used at creation.
-static int upload_stream(evd_nerf::Packed& dst, const StreamBuilder& sb) {
-    dst.prec = sb.prec;
-    int rc = dst.data.upload(sb.bytes.data(), sb.bytes.size());
-    if (!rc) rc = dst.src.upload(sb.src.data(), sb.src.size() * sizeof(int32_t));
-    return rc;
-}
+static int upload_stream(evd_nerf::Packed& dst, const StreamBuilder& sb) { return dst.upload(sb); }
 
 // canonical parameter order of the arena: pts_linears[l].{weight, bias} for l < D, then views_linears.0, feature_linear,
 // alpha_linear, rgb_linear ({weight, bias} each)
@@ -67,18 +62,6 @@ static void nerf_param_sizes(int D, int W, int skip, long* sz) {
     h[2] = (long)W * W; h[3] = W;                        // feature
     h[4] = W; h[5] = 1;                                  // alpha
     h[6] = 3L * (W / 2); h[7] = 3;                       // rgb
-}
-
-static __global__ void k_pack_stream(int prec, const float* __restrict__ arena, const int* __restrict__ src, long n, uint8_t* __restrict__ dst) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int s = src[i];
-    put_element(prec, dst + (i >> 9) * frag_bytes(prec), (int)(i >> 3) & 63, (int)i & 7, s < 0 ? 0.f : arena[s]);
-}
-
-static __global__ void k_gather_f32(const float* __restrict__ arena, const int* __restrict__ src, long n, float* __restrict__ dst) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) dst[i] = src[i] < 0 ? 0.f : arena[src[i]];
 }
 
 int evd_nerf_create(const evd_nerf_desc* d, evd_nerf** out) {
@@ -239,13 +222,7 @@ int evd_nerf_param_blocks(const evd_nerf* net, long* offsets, int capacity) {
 int evd_nerf_load_params(evd_nerf* net, const float* params, void* stream) {
     EVD_REQUIRE(net && params, "evd_nerf_load_params: null argument");
     hipStream_t st = as_stream(stream);
-    auto repack = [&](evd_nerf::Packed& s) -> int {
-        if (!s.data.p) return EVD_OK;
-        const long nel = (long)(s.src.bytes / sizeof(int32_t));
-        hipLaunchKernelGGL(k_pack_stream, dim3((unsigned)cdiv(nel, 256L)), dim3(256), 0, st, s.prec, params, (const int*)s.src.p, nel, (uint8_t*)s.data.p);
-        EVD_LAUNCH_CHECK();
-        return EVD_OK;
-    };
+    auto repack = [&](evd_nerf::Packed& s) { return repack_stream(s, params, st); };
     int rc;
     for (int i = 0; i < EVD_NUM_PREC; ++i) {
         if ((rc = repack(net->stream[i])) || (rc = repack(net->pipe[i]))) return rc;

@@ -5,6 +5,7 @@
 #include "pack.h"
 #include "voxel.h"
 #include "voxel_mlp_kernel.h"
+#include "voxel_train.h"
 
 #include <cmath>
 #include <cstdint>
@@ -16,8 +17,13 @@ struct evd_voxel {
     int num_layers, hidden_dim, geo, num_layers_color, input_ch, ft_dim, app_dim;
     int n_comp[3], grid[3], app_act, rgb_act, sigma_act, composite_feature;
     float aabb[6], rmnear;
-    DevBuf plane[3], line[3], plane_h[3], line_h[3], basis, stream[EVD_NUM_PREC], pipe[EVD_NUM_PREC], bias, tv_acc;
-    int nchunks[EVD_NUM_PREC], pipe_chunks[EVD_NUM_PREC];     // pipe: stream of the software-pipelined kernel, where built
+    DevBuf plane[3], line[3], plane_h[3], line_h[3], basis, bias, bias_src, tv_acc, wmaps;
+    PackedStream stream[EVD_NUM_PREC], pipe[EVD_NUM_PREC];    // pipe: stream of the software-pipelined kernel, where built
+    int nchunks[EVD_NUM_PREC], pipe_chunks[EVD_NUM_PREC];
+    // training path (bf16 / f16): the level's network on the software pipeline (the fine level shares `pipe`) and its W^T streams
+    PackedStream train[EVD_NUM_PREC], bwd[EVD_NUM_PREC][VBWD_NSTREAMS];
+    int train_chunks[EVD_NUM_PREC];
+    long param_off[9];            // sigma_net.0, sigma_net.1, color_net.{0,1,2}.{weight,bias} in the parameter arena, [8] = total
     GridParams gp;
 };
 
@@ -28,8 +34,11 @@ extern "C" {
 void evd_voxel_destroy(evd_voxel* v) {
     if (!v) return;
     for (int i = 0; i < 3; ++i) { v->plane[i].release(); v->line[i].release(); v->plane_h[i].release(); v->line_h[i].release(); }
-    for (int i = 0; i < EVD_NUM_PREC; ++i) { v->stream[i].release(); v->pipe[i].release(); }
-    v->basis.release(); v->bias.release(); v->tv_acc.release();
+    for (int i = 0; i < EVD_NUM_PREC; ++i) {
+        v->stream[i].release(); v->pipe[i].release(); v->train[i].release();
+        for (int k = 0; k < VBWD_NSTREAMS; ++k) v->bwd[i][k].release();
+    }
+    v->basis.release(); v->bias.release(); v->bias_src.release(); v->tv_acc.release(); v->wmaps.release();
     delete v;
 }
 
@@ -91,9 +100,25 @@ int evd_voxel_create(const evd_voxel_desc* d, evd_voxel** out) {
     }
     g.basis = (const float*)v->basis.p; g.app_dim = d->app_dim; g.app_act = d->app_act;
 
-    // weight streams (order = kernel_voxel.hip k_voxel_mlp)
+    // weight streams (order = kernel_voxel.hip k_voxel_mlp).  The parameters are first copied into one host arena in the
+    // canonical order sigma_net.0, sigma_net.1, color_net.{0,1,2}.{weight,bias}; every packed element records its arena index so that
+    // evd_voxel_load_params can re-pack on the device (pack.h).
     const int T = HD / 32, KS = HD / 16, KF = FT / 16;
+    const long psz[8] = {(long)HD * d->input_ch, (long)(1 + G) * HD, (long)HD * (G + ICV), HD, (long)HD * HD, HD, 3L * HD, 3};
+    long total = 0;
+    for (int i = 0; i < 8; ++i) { v->param_off[i] = total; total += psz[i]; }
+    v->param_off[8] = total;
+    std::vector<float> arena((size_t)total, 0.f);
+    {
+        const float* srcs[8] = {d->sigma_w[0], d->sigma_w[1], d->color_w[0], d->color_b[0], d->color_w[1], d->color_b[1], d->color_w[2], d->color_b[2]};
+        for (int i = 0; i < 8; ++i)
+            if (srcs[i]) memcpy(arena.data() + v->param_off[i], srcs[i], psz[i] * sizeof(float));
+    }
+    const float* A = arena.data();
+    const float *sigma_w0 = A + v->param_off[0], *sigma_w1 = A + v->param_off[1], *color_w0 = A + v->param_off[2], *color_w1 = A + v->param_off[4],
+                *color_w2 = A + v->param_off[6];
     const bool small = (1 + G) <= 32;
+    const int GT = (G + 31) / 32, GK = 2 * GT;
     auto hid_col = [](int j, int kk) { return 16 * j + phi(kk); };
     auto in0_col = [&](int j, int kk) {            // cat([fts, PE(pts)]): natural feature k-steps then the PE arrangement
         if (j < KF) return 16 * j + kk;
@@ -110,41 +135,113 @@ int evd_voxel_create(const evd_voxel_desc* d, evd_voxel** out) {
         return c < 0 ? -1 : G + c;
     };
     auto build = [&](StreamBuilder& sb) {
-        sb.layer(d->sigma_w[0], HD, d->input_ch, T, KF + PE_KS, false, in0_col);
+        sb.layer(sigma_w0, HD, d->input_ch, T, KF + PE_KS, false, in0_col);
         if (small) {
-            sb.layer(d->sigma_w[1], 1 + G, HD, 1, KS, false, hid_col);
+            sb.layer(sigma_w1, 1 + G, HD, 1, KS, false, hid_col);
         } else {
-            sb.layer_rc(d->sigma_w[1], HD, 1, KS, false, [](int, int r) { return r == 0 ? 0 : -1; }, hid_col);       // sigma row
-            sb.layer_rc(d->sigma_w[1], HD, G / 32, KS, false, [](int t, int r) { return 1 + 32 * t + r; }, hid_col); // geo rows
+            sb.layer_rc(sigma_w1, HD, 1, KS, false, [](int, int r) { return r == 0 ? 0 : -1; }, hid_col);       // sigma row
+            sb.layer_rc(sigma_w1, HD, G / 32, KS, false, [](int t, int r) { return 1 + 32 * t + r; }, hid_col); // geo rows
         }
-        sb.layer(d->color_w[0], HD, G + ICV, T, (small ? 1 : G / 16) + PEV_KS, false, c0_col);
-        sb.layer(d->color_w[1], HD, HD, T, KS, false, hid_col);
-        sb.layer(d->color_w[2], 3, HD, 1, KS, true, hid_col);
+        sb.layer(color_w0, HD, G + ICV, T, (small ? 1 : G / 16) + PEV_KS, false, c0_col);
+        sb.layer(color_w1, HD, HD, T, KS, false, hid_col);
+        sb.layer(color_w2, 3, HD, 1, KS, true, hid_col);
+    };
+    // the same network in the layer table of voxel_mlp_kernel.h VoxNet (any level): sigma and geo always separate layers, the
+    // geo channels in GT zero-padded tiles
+    auto build_pipe = [&](StreamBuilder& sb) {
+        auto c0p = [&](int j, int kk) {
+            if (j < GK) { const int c = 16 * j + phi(kk); return c < G ? c : -1; }
+            const int c = pe_src_col(PE_LV, 8 * (j - GK) + (kk & 7), kk >> 3);
+            return c < 0 ? -1 : G + c;
+        };
+        sb.layer(sigma_w0, HD, d->input_ch, T, KF + PE_KS, false, in0_col);
+        sb.layer_rc(sigma_w1, HD, 1, KS, false, [](int, int r) { return r == 0 ? 0 : -1; }, hid_col);
+        sb.layer_rc(sigma_w1, HD, GT, KS, false, [G](int t, int r) { return 32 * t + r < G ? 1 + 32 * t + r : -1; }, hid_col);
+        sb.layer(color_w0, HD, G + ICV, T, GK + PEV_KS, false, c0p);
+        sb.layer(color_w1, HD, HD, T, KS, false, hid_col);
+        sb.layer(color_w2, 3, HD, 1, KS, true, hid_col);
     };
     for (int prec = 0; prec < EVD_NUM_PREC; ++prec) {
         StreamBuilder sb(prec);
+        sb.arena = A;
         build(sb);
         v->nchunks[prec] = (int)(sb.bytes.size() / chunk_bytes(prec));
-        rc = v->stream[prec].upload(sb.bytes.data(), sb.bytes.size());
+        rc = v->stream[prec].upload(sb);
         if (rc) { evd_voxel_destroy(v); return rc; }
         v->pipe_chunks[prec] = 0;
+        v->train_chunks[prec] = 0;
         if (voxel_pipe_built(prec, HD, G, FT)) {        // same layers, single-tile groups, 16 KiB chunks (voxel_mlp_kernel.h)
             StreamBuilder sp(prec, PIPE_CB);
+            sp.arena = A;
             sp.group = 1;
-            build(sp);
+            build_pipe(sp);
             v->pipe_chunks[prec] = (int)(sp.bytes.size() / PIPE_CB);
-            rc = v->pipe[prec].upload(sp.bytes.data(), sp.bytes.size());
+            rc = v->pipe[prec].upload(sp);
             if (rc) { evd_voxel_destroy(v); return rc; }
         }
+        if (!is_half_prec(prec)) continue;
+        {   // training: forward stream of the level (the coarse level has no pipelined inference kernel: its own copy) ...
+            StreamBuilder sp(prec, PIPE_CB);
+            sp.arena = A;
+            sp.group = 1;
+            build_pipe(sp);
+            v->train_chunks[prec] = (int)(sp.bytes.size() / PIPE_CB);
+            if ((rc = v->train[prec].upload(sp))) { evd_voxel_destroy(v); return rc; }
+        }
+        // ... and the W^T streams of the dgrad chain (voxel_train_kernel.h)
+        auto put = [&](int which, auto fill) {
+            StreamBuilder sb2(prec, PIPE_CB);
+            sb2.arena = A;
+            sb2.group = 1;
+            fill(sb2);
+            return v->bwd[prec][which].upload(sb2);
+        };
+        rc = put(VBWD_C2, [&](StreamBuilder& b) { b.layer_transposed(color_w2, 3, HD, 0, HD, nullptr, 0, T, 1, true, [](int, int kk) { return kk < 3 ? kk : -1; }); });
+        if (!rc) rc = put(VBWD_C1, [&](StreamBuilder& b) { b.layer_transposed(color_w1, HD, HD, 0, HD, nullptr, 0, T, KS, true, hid_col); });
+        if (!rc) rc = put(VBWD_C0, [&](StreamBuilder& b) { b.layer_transposed(color_w0, HD, G + ICV, 0, G, nullptr, 0, GT, KS, true, hid_col); });
+        if (!rc) rc = put(VBWD_SIGGEO, [&](StreamBuilder& b) {
+            b.layer_transposed(sigma_w1, 1 + G, HD, 0, HD, nullptr, 0, T, GK + 1, true, [&](int j, int kk) {
+                if (j < GK) { const int c = 16 * j + phi(kk); return c < G ? 1 + c : -1; }
+                return kk == 0 ? 0 : -1;
+            });
+        });
+        if (!rc) rc = put(VBWD_L0, [&](StreamBuilder& b) { b.layer_transposed(sigma_w0, HD, d->input_ch, 0, FT, nullptr, 0, (FT + 31) / 32, KS, true, hid_col); });
+        if (rc) { evd_voxel_destroy(v); return rc; }
+    }
+    {   // wgrad index maps (voxel_train.h)
+        std::vector<int> m(VMAP_TOTAL, -1);
+        for (int i = 0; i < 256; ++i) { const int c = hid_col(i / 16, i % 16); m[VMAP_HID + i] = c < HD ? c : -1; }
+        for (int i = 0; i < 64; ++i) {
+            m[VMAP_FTS + i] = i < FT ? i : -1;
+            const int c = pe_src_col(PE_L, 8 * (i / 16) + (i % 16 & 7), (i % 16) >> 3);
+            m[VMAP_PE + i] = c < 0 ? -1 : FT + c;
+        }
+        for (int i = 0; i < 32; ++i) {
+            const int c = pe_src_col(PE_LV, 8 * (i / 16) + (i % 16 & 7), (i % 16) >> 3);
+            m[VMAP_DIR + i] = c < 0 ? -1 : G + c;
+        }
+        for (int i = 0; i < 128; ++i) {
+            const int c = hid_col(i / 16, i % 16);
+            m[VMAP_GEO_X + i] = c < G ? c : -1;
+            m[VMAP_GEO_Y + i] = c < G ? 1 + c : -1;
+        }
+        for (int i = 0; i < 3; ++i) m[VMAP_COL + i] = i;
+        m[VMAP_SIG] = 0;
+        if ((rc = v->wmaps.upload(m.data(), m.size() * sizeof(int)))) { evd_voxel_destroy(v); return rc; }
     }
     std::vector<float> b(32 * 16, 0.f);            // zero block shared by the bias-free sigma layers
-    auto push = [&](const float* src, int out_dim, int tiles) {
-        for (int i = 0; i < tiles * 32; ++i) b.push_back((src && i < out_dim) ? src[i] : 0.f);
+    std::vector<int32_t> bsrc(32 * 16, -1);
+    auto push = [&](int block, int out_dim, int tiles) {
+        for (int i = 0; i < tiles * 32; ++i) {
+            b.push_back(i < out_dim ? A[v->param_off[block] + i] : 0.f);
+            bsrc.push_back(i < out_dim ? (int32_t)(v->param_off[block] + i) : -1);
+        }
     };
-    push(d->color_b[0], HD, T);
-    push(d->color_b[1], HD, T);
-    push(d->color_b[2], 3, 1);
+    push(3, HD, T);
+    push(5, HD, T);
+    push(7, 3, 1);
     rc = v->bias.upload(b.data(), b.size() * sizeof(float));
+    if (!rc) rc = v->bias_src.upload(bsrc.data(), bsrc.size() * sizeof(int32_t));
     if (rc) { evd_voxel_destroy(v); return rc; }
     *out = v;
     return EVD_OK;
@@ -177,10 +274,10 @@ static int voxel_pass(const evd_voxel* v, int precision, const float* pts, const
     VoxMlpParams p;
     static const bool no_pipe = env_flag("EVD_NO_PIPE");
     const bool piped = v->pipe_chunks[precision] > 0 && !no_pipe;
-    p.wstream = (const char*)(piped ? v->pipe[precision].p : v->stream[precision].p);
+    p.wstream = (const char*)(piped ? v->pipe[precision].data.p : v->stream[precision].data.p);
     p.bias = (const float*)v->bias.p;
     p.pts = pts; p.viewdirs = viewdirs; p.fts = fts; p.nsamp = R * (long)S; p.S = S; p.vd_stride = vd_stride; p.ft_stride = ft_stride;
-    p.nchunks = piped ? v->pipe_chunks[precision] : v->nchunks[precision]; p.nbias = (int)(v->bias.bytes / sizeof(float)); p.raw = raw; p.feature = feature;
+    p.nchunks = piped ? v->pipe_chunks[precision] : v->nchunks[precision]; p.nbias = (int)(v->bias.bytes / sizeof(float)); p.raw = raw; p.feature = feature; p.act = nullptr;
     int rc = piped ? (precision == EVD_PREC_BF16 ? launch_voxel_pipe_bf16(feature != nullptr, p, as_stream(stream))
                       : precision == EVD_PREC_F16 ? launch_voxel_pipe_f16(feature != nullptr, p, as_stream(stream))
                                                   : launch_voxel_pipe_f16x3(feature != nullptr, p, as_stream(stream)))
@@ -302,6 +399,80 @@ int evd_c2f_render(const evd_voxel* coarse, const evd_voxel* fine, const evd_ren
     int rc = evd_ray_batch(cfg, rays, R, rb, stream);
     if (rc) return rc;
     return evd_c2f_render_rays(coarse, fine, cfg, rb, R, t_rand, u, noise0, noise1, out, workspace, workspace_bytes, stream);
+}
+
+// ---- training: the level's sigma / colour networks -----------------------------------------------------
+static const int VOX_WGRAD_BLOCKS = 256;
+static long vox_tiles(long nsamp) { return cdiv(nsamp, 256L) * 8; }
+static bool vox_train_built(const evd_voxel* v, int prec) { return (prec == EVD_PREC_F16 || prec == EVD_PREC_BF16) && v->train_chunks[prec] > 0; }
+
+long evd_voxel_param_count(const evd_voxel* v) { return v ? v->param_off[8] : 0; }
+
+int evd_voxel_param_blocks(const evd_voxel* v, long* offsets, int capacity) {
+    EVD_REQUIRE(v, "evd_voxel_param_blocks: null level");
+    if (offsets)
+        for (int i = 0; i <= 8 && i < capacity; ++i) offsets[i] = v->param_off[i];
+    return 8;
+}
+
+int evd_voxel_load_params(evd_voxel* v, const float* params, void* stream) {
+    EVD_REQUIRE(v && params, "evd_voxel_load_params: null argument");
+    hipStream_t st = as_stream(stream);
+    int rc;
+    for (int i = 0; i < EVD_NUM_PREC; ++i) {
+        if ((rc = repack_stream(v->stream[i], params, st)) || (rc = repack_stream(v->pipe[i], params, st)) || (rc = repack_stream(v->train[i], params, st))) return rc;
+        for (int k = 0; k < VBWD_NSTREAMS; ++k)
+            if ((rc = repack_stream(v->bwd[i][k], params, st))) return rc;
+    }
+    const long nb = (long)(v->bias.bytes / sizeof(float));
+    hipLaunchKernelGGL(k_gather_f32, dim3((unsigned)cdiv(nb, 256L)), dim3(256), 0, st, params, (const int*)v->bias_src.p, nb, (float*)v->bias.p);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+size_t evd_voxel_train_store_bytes(const evd_voxel* v, long nsamp) {
+    return (!v || nsamp < 0) ? 0 : (size_t)vox_tiles(nsamp) * voxel_store_tile_bytes(v->hidden_dim);
+}
+
+size_t evd_voxel_backward_workspace_bytes(void) { return (size_t)VOX_WGRAD_BLOCKS * 8 * 9 * 4096 + 512; }
+
+int evd_voxel_mlp_train(const evd_voxel* v, int precision, const float* pts, const float* viewdirs, int vd_stride, const float* fts, int ft_stride,
+                        long R, int S, float* raw, void* store, size_t store_bytes, void* stream) {
+    EVD_REQUIRE(v && pts && viewdirs && fts && raw && store, "evd_voxel_mlp_train: null argument");
+    EVD_REQUIRE(precision >= 0 && precision < EVD_NUM_PREC && vox_train_built(v, precision), "evd_voxel_mlp_train: the training path is built for precision f16 / bf16");
+    EVD_REQUIRE(R >= 0 && S >= 1 && ft_stride >= v->ft_dim && ft_stride % 4 == 0, "evd_voxel_mlp_train: bad shape");
+    if (R == 0) return EVD_OK;
+    const long nsamp = R * (long)S;
+    if (store_bytes < evd_voxel_train_store_bytes(v, nsamp)) return fail(EVD_E_WORKSPACE, "evd_voxel_mlp_train: store %zu < %zu bytes", store_bytes, evd_voxel_train_store_bytes(v, nsamp));
+    VoxMlpParams p;
+    p.wstream = (const char*)v->train[precision].data.p;
+    p.bias = (const float*)v->bias.p;
+    p.pts = pts; p.viewdirs = viewdirs; p.fts = fts; p.nsamp = nsamp; p.S = S; p.vd_stride = vd_stride; p.ft_stride = ft_stride;
+    p.nchunks = v->train_chunks[precision]; p.nbias = (int)(v->bias.bytes / sizeof(float)); p.raw = raw; p.feature = nullptr; p.act = (char*)store;
+    return launch_voxel_train_fwd_dispatch(precision, v->hidden_dim, p, as_stream(stream));
+}
+
+int evd_voxel_mlp_backward(const evd_voxel* v, int precision, const float* d_raw, const float* raw, long R, int S, void* store, size_t store_bytes,
+                           const evd_voxel_grads* grads, float* d_fts, int d_fts_stride, void* workspace, size_t workspace_bytes, void* stream) {
+    EVD_REQUIRE(v && d_raw && raw && store && grads && workspace, "evd_voxel_mlp_backward: null argument");
+    EVD_REQUIRE(precision >= 0 && precision < EVD_NUM_PREC && vox_train_built(v, precision), "evd_voxel_mlp_backward: the training path is built for precision f16 / bf16");
+    EVD_REQUIRE(R >= 0 && S >= 1 && (!d_fts || d_fts_stride >= v->ft_dim), "evd_voxel_mlp_backward: bad shape");
+    if (R == 0) return EVD_OK;
+    const long nsamp = R * (long)S;
+    if (store_bytes < evd_voxel_train_store_bytes(v, nsamp)) return fail(EVD_E_WORKSPACE, "evd_voxel_mlp_backward: store %zu < %zu bytes", store_bytes, evd_voxel_train_store_bytes(v, nsamp));
+    if (workspace_bytes < evd_voxel_backward_workspace_bytes()) return fail(EVD_E_WORKSPACE, "evd_voxel_mlp_backward: workspace %zu < %zu bytes", workspace_bytes, evd_voxel_backward_workspace_bytes());
+    VoxBwdPlan b;
+    b.d_raw = d_raw; b.raw = raw; b.nsamp = nsamp; b.tiles = vox_tiles(nsamp); b.store = (char*)store;
+    for (int k = 0; k < VBWD_NSTREAMS; ++k) b.wt[k] = (const char*)v->bwd[precision][k].data.p;
+    b.maps = (const int*)v->wmaps.p;
+    char* w = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    b.maxbits = (unsigned*)w;
+    b.partial = (float*)(w + 256);
+    b.wgrad_blocks = VOX_WGRAD_BLOCKS;
+    b.d_fts = d_fts; b.d_fts_stride = d_fts_stride;
+    for (int i = 0; i < 2; ++i) b.grads.sigma_w[i] = grads->sigma_w[i];
+    for (int i = 0; i < 3; ++i) { b.grads.color_w[i] = grads->color_w[i]; b.grads.color_b[i] = grads->color_b[i]; }
+    return run_voxel_backward_dispatch(precision, v->hidden_dim, b, as_stream(stream));
 }
 
 // ---- training: the grids as parameters -------------------------------------------------------------------------------

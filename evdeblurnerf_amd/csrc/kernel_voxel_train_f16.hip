@@ -1,0 +1,16 @@
+// f16 instantiations of the PDRF training kernels, both levels (voxel_mlp_kernel.h TRAIN variant, voxel_train_kernel.h).
+#include "voxel_train_kernel.h"
+
+namespace evd {
+
+int launch_voxel_train_fwd_f16(int HD, const VoxMlpParams& p, hipStream_t st) {
+    return HD == 256 ? launch_voxel_train_fwd<EVD_PREC_F16, 256, 128, 64>(p, st) : launch_voxel_train_fwd<EVD_PREC_F16, 64, 15, 32>(p, st);
+}
+
+int run_voxel_backward_f16(int HD, const VoxBwdPlan& b, hipStream_t st) {
+    return HD == 256 ? run_voxel_backward<EVD_PREC_F16, 256, 128, 64>(b, st) : run_voxel_backward<EVD_PREC_F16, 64, 15, 32>(b, st);
+}
+
+long voxel_store_tile_bytes(int HD) { return HD == 256 ? VStore<256, 128, 64>::TILE_BYTES : VStore<64, 15, 32>::TILE_BYTES; }
+
+}  // namespace evd

@@ -2,17 +2,13 @@
 #pragma once
 
 #include "evd_common.h"
+#include "pack.h"
 
 // transposed-weight streams of the dgrad chain (nerf_train_kernel.h), in the order the chain runs them
 enum { EVD_BWD_RGB = 0, EVD_BWD_VIEWS, EVD_BWD_HEAD, EVD_BWD_HIDDEN1, EVD_BWD_NSTREAMS = EVD_BWD_HIDDEN1 + EVD_MAX_LAYERS };
 
 struct evd_nerf {
-    // a packed fragment stream and, per element, the index of its source in the parameter arena (-1: zero)
-    struct Packed {
-        int prec = 0;
-        evd::DevBuf data, src;
-        void release() { data.release(); src.release(); }
-    };
+    typedef evd::PackedStream Packed;
     int D, W, skip, rgb_act, sigma_act;
     float rmnear;
     Packed stream[EVD_NUM_PREC];             // generic kernel: fragment streams per precision

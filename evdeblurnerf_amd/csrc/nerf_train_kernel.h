@@ -72,6 +72,7 @@ template <class B> __device__ __forceinline__ B frag_load(const char* lane_base,
 struct DgradParams {
     const char* wstream;    // W^T as a fragment stream (pack.h), one layer
     char* store;
+    long tile_bytes;        // stride of a 32-sample tile in the store
     int in_slot, extra_slot, mask_slot, out_slot;
 };
 
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(NT, NT / 256) void k_dgrad_layer(const DgradParams 
     typedef typename C::O::B B;
     typedef LayerDesc<KTOT, TILES, 1, false, false, 0, 0, true, 0, 0, 0, false, 0, -1, false, 0, 0, -1> L;
     constexpr int NCH = cceil(KTOT * TILES, C::FPC);
-    static_assert(NIN + (EXTRA ? 1 : 0) == KTOT && KTOT * TILES >= C::PD - 1, "k-steps of the layer");
+    static_assert(NIN + (EXTRA ? 1 : 0) == KTOT, "k-steps of the layer");    // (a layer shorter than the prefetch depth reads the zero padding of its chunk)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     pipe_fp16_saturate<PREC>();
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(NT, NT / 256) void k_dgrad_layer(const DgradParams 
     st.start_issue(p.wstream, smem, tid);
     float* zb = reinterpret_cast<float*>(smem + C::RING);       // the dgrad layers have no bias: a block of zeros
     for (int i = tid; i < (TILES + 1) * 32; i += NT) zb[i] = 0.f;
-    char* al = p.store + ((long)blockIdx.x * (NT / 64) + wave) * astore::TILE_BYTES + lane * 16;
+    char* al = p.store + ((long)blockIdx.x * (NT / 64) + wave) * p.tile_bytes + lane * 16;
 
     B in[1][KTOT], out[1][2 * TILES], om[OMASK ? 2 * TILES : 1];
 #pragma unroll
@@ -135,8 +136,8 @@ static int launch_dgrad(const DgradParams& p, long tiles, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 struct WgradParams {
     const char* store;
-    long tiles;
-    int y_slot, x_slot;
+    long tiles, tile_bytes;
+    int y_slot, x_slot, bias;       // bias: the bias gradient rides along as column CT
     float* partial;         // [gridDim.x][RT][CT + BIAS][64][16] float32
 };
 
@@ -172,14 +173,15 @@ template <int PREC> __device__ __forceinline__ unsigned half_one_pair() { return
 // The 8 wavefronts of a workgroup share every sample tile: wavefront w owns row tile w % RT and the column tiles of its
 // group w / RT in accumulators; it transposes its own gradient block, and (w < CT) the activation block of column tile w,
 // which it publishes through LDS for the others.  Loads run one iteration (WGRAD_TPI tiles) ahead.
-template <int PREC, int RT, int CT, bool YSINGLE, bool BIAS>
+template <int PREC, int RT, int CT, bool YSINGLE>
 __global__ __launch_bounds__(WGRAD_NT) void k_wgrad(const WgradParams p) {
-    constexpr int CPG = wgrad_cpg(RT, CT), NC = CT + (BIAS ? 1 : 0), TPI = WGRAD_TPI;
+    constexpr int CPG = wgrad_cpg(RT, CT), TPI = WGRAD_TPI;
+    const int NC = CT + (p.bias ? 1 : 0);
     static_assert(8 % RT == 0 && CT <= 8 && (!YSINGLE || RT == 1), "shape of the block");
     __shared__ __attribute__((aligned(16))) char xs[2][TPI][CT][2][1024];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = lane & 31, h = lane >> 5;
     const int rt = wave % RT, c0 = (wave / RT) * CPG;
-    const bool xown = wave < CT, bias_own = BIAS && wave < RT;
+    const bool xown = wave < CT, bias_own = p.bias && wave < RT;
     // selectors: sel0[kk][n] = (n == kk), sel1[kk][n] = (n == 16 + kk); this lane holds kk = 8h .. 8h + 7 of column n
     W4 sel0, sel1, ones;
     const unsigned one = half_one_pair<PREC>();
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(WGRAD_NT) void k_wgrad(const WgradParams p) {
     auto load = [&](long t, Frags& f) {
         f.y0 = f.y1 = f.x0 = f.x1 = zf;
         if (t >= p.tiles) return;
-        const char* al = p.store + t * astore::TILE_BYTES + lane * 16;
+        const char* al = p.store + t * p.tile_bytes + lane * 16;
         f.y0 = frag_load<W4>(al, p.y_slot + 2 * rt);
         if constexpr (!YSINGLE) f.y1 = frag_load<W4>(al, p.y_slot + 2 * rt + 1);
         if (xown) {
@@ -309,9 +311,9 @@ static __global__ __launch_bounds__(256) void k_wgrad_reduce(const WreduceParams
     }
 }
 
-template <int PREC, int RT, int CT, bool YSINGLE, bool BIAS>
+template <int PREC, int RT, int CT, bool YSINGLE>
 static int launch_wgrad(const WgradParams& p, int blocks, hipStream_t st) {
-    hipLaunchKernelGGL((k_wgrad<PREC, RT, CT, YSINGLE, BIAS>), dim3(blocks), dim3(WGRAD_NT), 0, st, p);
+    hipLaunchKernelGGL((k_wgrad<PREC, RT, CT, YSINGLE>), dim3(blocks), dim3(WGRAD_NT), 0, st, p);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }
@@ -330,7 +332,7 @@ template <int PREC> static int run_nerf_backward(const BwdPlan& b, hipStream_t s
 
     auto dgrad = [&](int stream, int in_slot, int extra_slot, int mask_slot, int out_slot) {
         DgradParams p;
-        p.wstream = b.wt[stream]; p.store = b.store; p.in_slot = in_slot; p.extra_slot = extra_slot; p.mask_slot = mask_slot; p.out_slot = out_slot;
+        p.wstream = b.wt[stream]; p.store = b.store; p.tile_bytes = astore::TILE_BYTES; p.in_slot = in_slot; p.extra_slot = extra_slot; p.mask_slot = mask_slot; p.out_slot = out_slot;
         return p;
     };
     // wgrad + reduce of one parameter block: rows from `ymap`, columns from `xmap` (offset into b.maps)
@@ -338,7 +340,7 @@ template <int PREC> static int run_nerf_backward(const BwdPlan& b, hipStream_t s
         if (!dW) return EVD_OK;
         const int blocks = (int)(cdiv(b.tiles, (long)WGRAD_TPI) < b.wgrad_blocks ? cdiv(b.tiles, (long)WGRAD_TPI) : b.wgrad_blocks);
         WgradParams p;
-        p.store = b.store; p.tiles = b.tiles; p.y_slot = y_slot; p.x_slot = x_slot; p.partial = b.partial;
+        p.store = b.store; p.tiles = b.tiles; p.tile_bytes = astore::TILE_BYTES; p.y_slot = y_slot; p.x_slot = x_slot; p.bias = bias ? 1 : 0; p.partial = b.partial;
         int r = launch(p, blocks, st);
         if (r) return r;
         WreduceParams q;
@@ -351,25 +353,25 @@ template <int PREC> static int run_nerf_backward(const BwdPlan& b, hipStream_t s
     const BwdGrads& g = b.grads;
     // rgb_linear: d hv = Wr^T d rgb;  dWr = d rgb . hv^T
     if ((rc = launch_dgrad<PREC, 1, 4, 1, false, true>(dgrad(EVD_BWD_RGB, G_RGB, -1, HV, D_HV), b.tiles, st))) return rc;
-    if ((rc = wgrad(launch_wgrad<PREC, 1, 4, true, true>, 1, 4, true, G_RGB, HV, MAP_RGB, MAP_HID, g.rgb_w, 128, g.rgb_b))) return rc;
+    if ((rc = wgrad(launch_wgrad<PREC, 1, 4, true>, 1, 4, true, G_RGB, HV, MAP_RGB, MAP_HID, g.rgb_w, 128, g.rgb_b))) return rc;
     // views_linears.0 on cat([feature, PE(dir)])
     if ((rc = launch_dgrad<PREC, 8, 8, 8, false, false>(dgrad(EVD_BWD_VIEWS, D_HV, -1, -1, D_F), b.tiles, st))) return rc;
-    if ((rc = wgrad(launch_wgrad<PREC, 4, 8, false, true>, 4, 8, true, D_HV, F, MAP_HID, MAP_HID, g.views_w, 256 + 27, g.views_b))) return rc;
-    if ((rc = wgrad(launch_wgrad<PREC, 4, 1, false, false>, 4, 1, false, D_HV, DIR, MAP_HID, MAP_DIR, g.views_w, 256 + 27, nullptr))) return rc;
+    if ((rc = wgrad(launch_wgrad<PREC, 4, 8, false>, 4, 8, true, D_HV, F, MAP_HID, MAP_HID, g.views_w, 256 + 27, g.views_b))) return rc;
+    if ((rc = wgrad(launch_wgrad<PREC, 4, 1, false>, 4, 1, false, D_HV, DIR, MAP_HID, MAP_DIR, g.views_w, 256 + 27, nullptr))) return rc;
     // feature_linear and alpha_linear both read h_7
     if ((rc = launch_dgrad<PREC, 17, 8, 16, true, true>(dgrad(EVD_BWD_HEAD, D_F, G_ALPHA, H0 + 16 * (D - 1), D_H0 + 16 * (D - 1)), b.tiles, st))) return rc;
-    if ((rc = wgrad(launch_wgrad<PREC, 8, 8, false, true>, 8, 8, true, D_F, H0 + 16 * (D - 1), MAP_HID, MAP_HID, g.feature_w, 256, g.feature_b))) return rc;
-    if ((rc = wgrad(launch_wgrad<PREC, 1, 8, true, true>, 1, 8, true, G_ALPHA, H0 + 16 * (D - 1), MAP_ALPHA, MAP_HID, g.alpha_w, 256, g.alpha_b))) return rc;
+    if ((rc = wgrad(launch_wgrad<PREC, 8, 8, false>, 8, 8, true, D_F, H0 + 16 * (D - 1), MAP_HID, MAP_HID, g.feature_w, 256, g.feature_b))) return rc;
+    if ((rc = wgrad(launch_wgrad<PREC, 1, 8, true>, 1, 8, true, G_ALPHA, H0 + 16 * (D - 1), MAP_ALPHA, MAP_HID, g.alpha_w, 256, g.alpha_b))) return rc;
     // pts_linears[l], l = 7 .. 1
     for (int l = D - 1; l >= 1; --l) {
         const bool wide = l - 1 == b.skip;
         if ((rc = launch_dgrad<PREC, 16, 8, 16, false, true>(dgrad(EVD_BWD_HIDDEN1 + l - 1, D_H0 + 16 * l, -1, H0 + 16 * (l - 1), D_H0 + 16 * (l - 1)), b.tiles, st))) return rc;
-        if ((rc = wgrad(launch_wgrad<PREC, 8, 8, false, true>, 8, 8, true, D_H0 + 16 * l, H0 + 16 * (l - 1), MAP_HID, wide ? MAP_HID_SKIP : MAP_HID,
+        if ((rc = wgrad(launch_wgrad<PREC, 8, 8, false>, 8, 8, true, D_H0 + 16 * l, H0 + 16 * (l - 1), MAP_HID, wide ? MAP_HID_SKIP : MAP_HID,
                         g.pts_w[l], wide ? 256 + 63 : 256, g.pts_b[l]))) return rc;
-        if (wide && (rc = wgrad(launch_wgrad<PREC, 8, 2, false, false>, 8, 2, false, D_H0 + 16 * l, PE, MAP_HID, MAP_PE, g.pts_w[l], 256 + 63, nullptr))) return rc;
+        if (wide && (rc = wgrad(launch_wgrad<PREC, 8, 2, false>, 8, 2, false, D_H0 + 16 * l, PE, MAP_HID, MAP_PE, g.pts_w[l], 256 + 63, nullptr))) return rc;
     }
     // pts_linears[0] on PE(pts) (no dgrad beyond the inputs)
-    return wgrad(launch_wgrad<PREC, 8, 2, false, true>, 8, 2, true, D_H0, PE, MAP_HID, MAP_PE, g.pts_w[0], 63, g.pts_b[0]);
+    return wgrad(launch_wgrad<PREC, 8, 2, false>, 8, 2, true, D_H0, PE, MAP_HID, MAP_PE, g.pts_w[0], 63, g.pts_b[0]);
 }
 
 }  // namespace evd

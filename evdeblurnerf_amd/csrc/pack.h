@@ -95,4 +95,38 @@ struct StreamBuilder {
     }
 };
 
+// a packed fragment stream on the device and, per element, the index of its source in the parameter arena (-1: zero)
+struct PackedStream {
+    int prec = 0;
+    DevBuf data, src;
+    void release() { data.release(); src.release(); }
+    int upload(const StreamBuilder& sb) {
+        prec = sb.prec;
+        int rc = data.upload(sb.bytes.data(), sb.bytes.size());
+        if (!rc) rc = src.upload(sb.src.data(), sb.src.size() * sizeof(int32_t));
+        return rc;
+    }
+};
+
+static __global__ void k_pack_stream(int prec, const float* __restrict__ arena, const int* __restrict__ src, long n, uint8_t* __restrict__ dst) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int s = src[i];
+    put_element(prec, dst + (i >> 9) * frag_bytes(prec), (int)(i >> 3) & 63, (int)i & 7, s < 0 ? 0.f : arena[s]);
+}
+
+static __global__ void k_gather_f32(const float* __restrict__ arena, const int* __restrict__ src, long n, float* __restrict__ dst) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i] < 0 ? 0.f : arena[src[i]];
+}
+
+// re-pack one stream on the device from new parameter values
+static inline int repack_stream(PackedStream& s, const float* params, hipStream_t st) {
+    if (!s.data.p) return EVD_OK;
+    const long nel = (long)(s.src.bytes / sizeof(int32_t));
+    hipLaunchKernelGGL(k_pack_stream, dim3((unsigned)cdiv(nel, 256L)), dim3(256), 0, st, s.prec, params, (const int*)s.src.p, nel, (uint8_t*)s.data.p);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
 }  // namespace evd

@@ -27,6 +27,7 @@ struct VoxMlpParams {
     int S, vd_stride, ft_stride, nchunks, nbias;
     float* raw;                 // [n,4] = (sigma, sigmoid(colour))  voxnerf.py:254
     float* feature;             // [n,G] or null
+    char* act;                  // training kernels: activation store, else null
 };
 
 constexpr int TV_MAX_BLOCKS = 4096;     // partial (dh^2, dw^2) pairs per tensor

@@ -1,4 +1,5 @@
-// Software-pipelined PDRF fine-level network (hidden 256, geo 128, 64 feature channels in; reference
+// Software-pipelined PDRF level network (fine: hidden 256, geo 128, 64 feature channels in; the training path also builds the
+// coarse 64 / 15 / 32 level on it; reference
 // networks/pdrf/voxnerf.py:210-221,240-254 with the blurfactory dimensions): sigma net 127 -> 256 -> 1 + 128,
 // colour net 155 -> 256 -> 256 -> 3 (sigmoid), on the machinery of mlp_pipe.h.  One straight-line stream of 368
 // MFMAs per wavefront; layer table below.  The coarse level (64-wide) stays on kernel_voxel.hip's generic kernel.
@@ -9,39 +10,56 @@
 
 namespace evd {
 
-template <class C, bool FEAT> struct VoxFineNet {
-    static constexpr int HD = 256, G = 128, FT = 64;
-    static constexpr int T = HD / 32, KS = HD / 16, KF = FT / 16, GT = G / 32, GK = G / 16, FPC = C::FPC, PD = C::PD;
-    // sigma_net.0 on cat([fts, PE(pts)]) (voxnerf.py:214): k-steps [fts_0..3 | pe_0..3]
-    typedef LayerDesc<KF + PE_KS, T, 1, true, false, 0, 0, false, 0, 0, 0, false, 0, -1, false, 1> L0;
+// Fragment slots of the PDRF activation / gradient store (training path), per 32-sample tile, for a level with hidden width HD,
+// G geo channels and FT feature channels in: what the forward saves, then the gradients the dgrad chain hands to wgrad.
+template <int HD, int G, int FT> struct VStore {
+    static constexpr int KS = HD / 16, KF = FT / 16, GT = (G + 31) / 32;
+    static constexpr int IN0 = 0, DIRPE = IN0 + KF + PE_KS, HID = DIRPE + PEV_KS, GEO = HID + KS, C0 = GEO + 2 * GT, C1 = C0 + KS, FWD_END = C1 + KS;
+    static constexpr int G_COL = FWD_END, G_SIG = G_COL + 1, D_C1 = G_SIG + 1, D_C0 = D_C1 + KS, D_GEO = D_C0 + KS, D_HID = D_GEO + 2 * GT,
+                         D_FTS = D_HID + KS, TILE_FRAGS = D_FTS + 2 * ((FT + 31) / 32);
+    static constexpr long TILE_BYTES = (long)TILE_FRAGS * 1024;
+};
+
+// layer table of one PDRF level: HD hidden width, G geo channels (15: one zero-padded tile; 128: four), FT feature channels in
+template <class C, int HD_, int G_, int FT_, bool FEAT, bool TRAIN = false> struct VoxNet {
+    static constexpr int HD = HD_, G = G_, FT = FT_;
+    typedef VStore<HD, G, FT> VS;
+    static constexpr int T = HD / 32, KS = HD / 16, KF = FT / 16, GT = (G + 31) / 32, GK = 2 * GT, FPC = C::FPC, PD = C::PD;
+    static constexpr int slot(int s) { return TRAIN ? s : -1; }
+    // sigma_net.0 on cat([fts, PE(pts)]) (voxnerf.py:214): k-steps [fts_0.. | pe_0..3]
+    typedef LayerDesc<KF + PE_KS, T, 1, true, false, 0, 0, false, 0, 0, 0, false, 0, -1, false, 1, slot(VS::HID)> L0;
     static constexpr int F1 = T * (KF + PE_KS);
     // sigma_net.1 row 0 = sigma (float32 out) ...
-    typedef LayerDesc<KS, 1, 1, false, true, 0, F1, false, F1 % PD, L0::PAR_OUT, 1, true, KS - 2, -1, false, 1> Sigma;
+    typedef LayerDesc<KS, 1, 1, false, true, 0, F1, false, F1 % PD, L0::PAR_OUT, 1, true, KS - 2, -1, false, 1, -1, slot(VS::HID + KS - 2)> Sigma;
     static constexpr int F2 = F1 + KS;
-    // ... rows 1..128 = geo features (no activation; the per-sample feature AWP consumes, voxnerf.py:221)
-    typedef LayerDesc<KS, GT, 1, false, false, 0, F2, false, F2 % PD, Sigma::PAR_OUT, 0, false, 0, -1, FEAT, 1> Geo;
+    // ... rows 1..G = geo features (no activation; the per-sample feature AWP consumes, voxnerf.py:221)
+    typedef LayerDesc<KS, GT, 1, false, false, 0, F2, false, F2 % PD, Sigma::PAR_OUT, 0, false, 0, -1, FEAT, 1, slot(VS::GEO)> Geo;
     static constexpr int F3 = F2 + GT * KS;
-    // color_net.0 on cat([geo, PE(dirs)]) (voxnerf.py:248): k-steps [geo_0..7 | dir_0..1]; geo's last tile lands at 6, 7
-    typedef LayerDesc<GK + PEV_KS, T, 1, true, false, 0, F3, false, F3 % PD, Geo::PAR_OUT, 1, false, GK - 2, FEAT ? GT - 1 : -1, false, 1> C0;
+    // color_net.0 on cat([geo, PE(dirs)]) (voxnerf.py:248): k-steps [geo_0.. | dir_0..1]; geo's last tile lands at GK - 2, GK - 1
+    typedef LayerDesc<GK + PEV_KS, T, 1, true, false, 0, F3, false, F3 % PD, Geo::PAR_OUT, 1, false, GK - 2, FEAT ? GT - 1 : -1, false, 1, slot(VS::C0),
+                      slot(VS::GEO + GK - 2)> C0;
     static constexpr int F4 = F3 + T * (GK + PEV_KS);
-    typedef LayerDesc<KS, T, 1, true, false, 0, F4, false, F4 % PD, C0::PAR_OUT, 1, true, KS - 2, -1, false, 1> C1;
+    typedef LayerDesc<KS, T, 1, true, false, 0, F4, false, F4 % PD, C0::PAR_OUT, 1, true, KS - 2, -1, false, 1, slot(VS::C1), slot(VS::C0 + KS - 2)> C1;
     static constexpr int F5 = F4 + T * KS;
-    typedef LayerDesc<KS, 1, 1, false, true, 0, F5, true, F5 % PD, C1::PAR_OUT, 1, true, KS - 2, -1, false, 0> C2;
+    typedef LayerDesc<KS, 1, 1, false, true, 0, F5, true, F5 % PD, C1::PAR_OUT, 1, true, KS - 2, -1, false, 0, -1, slot(VS::C1 + KS - 2)> C2;
     static constexpr int NCH = cceil(F5 + KS, FPC);
     // LDS bias image in stream order: the sigma net has no biases (zeros)
     static constexpr int B_SIG = T * 32, B_GEO = B_SIG + 32, B_C0 = B_GEO + GT * 32, B_C1 = B_C0 + T * 32, B_C2 = B_C1 + T * 32, B_END = B_C2 + 32;
     static_assert(F1 % PD == 0 && F3 % PD == 0 && F4 % PD == 0, "prefetch ring phase");
+    static_assert(!FEAT || G % 32 == 0, "float32 feature rows are written 32 at a time");
 };
+template <class C, bool FEAT> using VoxFineNet = VoxNet<C, 256, 128, 64, FEAT, false>;
 
-template <int PREC, int NS, int NT, bool FEAT, int CB, int OCC>
+template <int PREC, int HD, int G, int FT, int NS, int NT, bool FEAT, int CB, int OCC, bool TRAIN>
 __global__ __launch_bounds__(NT, OCC) void k_voxel_mlp_pipe(const VoxMlpParams p) {
     typedef PipeCfg<PREC, NS, NT, CB> C;
     typedef typename C::O O;
     typedef typename O::B B;
-    typedef VoxFineNet<C, FEAT> N;
+    typedef VoxNet<C, HD, G, FT, FEAT, TRAIN> N;
+    typedef typename N::VS VS;
     constexpr int T = N::T, KS = N::KS, KF = N::KF, GK = N::GK;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef PStream<C, FEAT, N::NCH> ST;
+    typedef PStream<C, FEAT || TRAIN, N::NCH> ST;
 
     pipe_fp16_saturate<PREC>();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -55,12 +73,14 @@ __global__ __launch_bounds__(NT, OCC) void k_voxel_mlp_pipe(const VoxMlpParams p
 
     long sidx[NS];
     bool valid[NS];
+    char* actl[NS];
     B in0[NS][KF + PE_KS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const long smp = (long)blockIdx.x * C::SAMPLES + wave * (NS * 32) + s * 32 + n;
         valid[s] = smp < p.nsamp;
         sidx[s] = valid[s] ? smp : p.nsamp - 1;
+        actl[s] = TRAIN ? p.act + (smp >> 5) * VS::TILE_BYTES + lane * 16 : nullptr;
         float pts[3], vd[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -84,6 +104,12 @@ __global__ __launch_bounds__(NT, OCC) void k_voxel_mlp_pipe(const VoxMlpParams p
         for (int j = 0; j < PE_KS; ++j) in0[s][KF + j] = pe[j];
 #pragma unroll
         for (int j = 0; j < PEV_KS; ++j) stash[(s * C::STASH_FRAGS + j) * 64] = pev[j];   // parked until the colour net
+        if constexpr (TRAIN) {
+#pragma unroll
+            for (int j = 0; j < KF + PE_KS; ++j) act_store(actl[s], VS::IN0 + j, in0[s][j]);
+#pragma unroll
+            for (int j = 0; j < PEV_KS; ++j) act_store(actl[s], VS::DIRPE + j, pev[j]);
+        }
     }
     float* frow[NS];
     float* nofrow[NS];
@@ -97,11 +123,11 @@ __global__ __launch_bounds__(NT, OCC) void k_voxel_mlp_pipe(const VoxMlpParams p
     pipe_prime<C, typename N::L0>(st, pp, bias, lane);
 
     B hid[NS][KS], none[NS][1];
-    pipe_layer<C, typename N::L0, ST, KS>(st, pp, in0, hid, nullptr, bias, lane, nofrow);
+    pipe_layer<C, typename N::L0, ST, KS, TRAIN>(st, pp, in0, hid, nullptr, bias, lane, nofrow, actl);
     float sig[NS][4], col[NS][4];
-    pipe_layer<C, typename N::Sigma, ST, 1>(st, pp, hid, none, sig, bias + N::B_SIG, lane, nofrow);
+    pipe_layer<C, typename N::Sigma, ST, 1, TRAIN>(st, pp, hid, none, sig, bias + N::B_SIG, lane, nofrow, actl);
     B cin[NS][GK + PEV_KS];
-    pipe_layer<C, typename N::Geo, ST, GK + PEV_KS>(st, pp, hid, cin, nullptr, bias + N::B_GEO, lane, frow);
+    pipe_layer<C, typename N::Geo, ST, GK + PEV_KS, TRAIN>(st, pp, hid, cin, nullptr, bias + N::B_GEO, lane, frow, actl);
     {
         const B* sp = stash;
         asm volatile("" : "+v"(sp));
@@ -111,9 +137,9 @@ __global__ __launch_bounds__(NT, OCC) void k_voxel_mlp_pipe(const VoxMlpParams p
             for (int j = 0; j < PEV_KS; ++j) cin[s][GK + j] = sp[(s * C::STASH_FRAGS + j) * 64];
     }
     B c0[NS][KS], c1[NS][KS];
-    pipe_layer<C, typename N::C0, ST, KS>(st, pp, cin, c0, nullptr, bias + N::B_C0, lane, frow);
-    pipe_layer<C, typename N::C1, ST, KS>(st, pp, c0, c1, nullptr, bias + N::B_C1, lane, nofrow);
-    pipe_layer<C, typename N::C2, ST, 1>(st, pp, c1, none, col, bias + N::B_C2, lane, nofrow);
+    pipe_layer<C, typename N::C0, ST, KS, TRAIN>(st, pp, cin, c0, nullptr, bias + N::B_C0, lane, frow, actl);
+    pipe_layer<C, typename N::C1, ST, KS, TRAIN>(st, pp, c0, c1, nullptr, bias + N::B_C1, lane, nofrow, actl);
+    pipe_layer<C, typename N::C2, ST, 1, TRAIN>(st, pp, c1, none, col, bias + N::B_C2, lane, nofrow, actl);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         if (h == 0 && valid[s]) {
@@ -138,9 +164,25 @@ static int launch_voxel_pipe(const VoxMlpParams& p, hipStream_t st) {
     typedef VoxFineNet<C, FEAT> N;
     const long blocks = cdiv(p.nsamp, C::SAMPLES);
     const size_t lds = C::TOTAL;
-    EVD_SET_MAX_LDS((&k_voxel_mlp_pipe<PREC, 1, NT, FEAT, PIPE_CB, OCC>), lds);
+    EVD_SET_MAX_LDS((&k_voxel_mlp_pipe<PREC, 256, 128, 64, 1, NT, FEAT, PIPE_CB, OCC, false>), lds);
     if (p.nchunks != N::NCH) return fail(EVD_E_INVALID, "evd_voxel: packed stream has %d chunks, kernel expects %d", p.nchunks, N::NCH);
-    hipLaunchKernelGGL((k_voxel_mlp_pipe<PREC, 1, NT, FEAT, PIPE_CB, OCC>), dim3((unsigned)blocks), dim3(NT), lds, st, p);
+    hipLaunchKernelGGL((k_voxel_mlp_pipe<PREC, 256, 128, 64, 1, NT, FEAT, PIPE_CB, OCC, false>), dim3((unsigned)blocks), dim3(NT), lds, st, p);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+// training variant (keeps the activations), either level; the stream is the level's pipe stream (evd_voxel_api.hip)
+template <int PREC, int HD, int G, int FT>
+static int launch_voxel_train_fwd(const VoxMlpParams& p, hipStream_t st) {
+    constexpr int NT = 512;
+    typedef PipeCfg<PREC, 1, NT> C;
+    typedef VoxNet<C, HD, G, FT, false, true> N;
+    const long blocks = cdiv(p.nsamp, C::SAMPLES);
+    const size_t lds = C::TOTAL;
+    EVD_SET_MAX_LDS((&k_voxel_mlp_pipe<PREC, HD, G, FT, 1, NT, false, PIPE_CB, 2, true>), lds);
+    if (p.nchunks != N::NCH) return fail(EVD_E_INVALID, "evd_voxel: packed stream has %d chunks, kernel expects %d", p.nchunks, N::NCH);
+    if (!p.act) return fail(EVD_E_INVALID, "evd_voxel: training launch without an activation store");
+    hipLaunchKernelGGL((k_voxel_mlp_pipe<PREC, HD, G, FT, 1, NT, false, PIPE_CB, 2, true>), dim3((unsigned)blocks), dim3(NT), lds, st, p);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }

@@ -1,0 +1,53 @@
+// Launchers / plans of the PDRF training kernels (kernel_voxel_train_*.hip), called by evd_voxel_api.hip.
+#pragma once
+
+#include "evd_common.h"
+#include "voxel.h"
+
+namespace evd {
+
+// W^T streams of the dgrad chain
+enum { VBWD_C2 = 0, VBWD_C1, VBWD_C0, VBWD_SIGGEO, VBWD_L0, VBWD_NSTREAMS };
+
+// wgrad index maps (fragment column -> parameter row / column, -1 = padding), offsets into one int32 array
+enum { VMAP_HID = 0,                    // 256: hidden arrangement 16 j + phi(kk) (-1 beyond the hidden width)
+       VMAP_FTS = VMAP_HID + 256,       // 64: input features, natural arrangement 16 j + kk
+       VMAP_PE = VMAP_FTS + 64,         // 64: point encoding, behind the FT feature columns
+       VMAP_DIR = VMAP_PE + 64,         // 32: direction encoding, behind the G geo columns
+       VMAP_GEO_X = VMAP_DIR + 32,      // 128: geo channels as color_net.0 columns
+       VMAP_GEO_Y = VMAP_GEO_X + 128,   // 128: geo channels as sigma_net.1 rows (1 + channel)
+       VMAP_COL = VMAP_GEO_Y + 128,     // 32: d colour fragment
+       VMAP_SIG = VMAP_COL + 32,        // 32: d sigma fragment (row 0 of sigma_net.1)
+       VMAP_TOTAL = VMAP_SIG + 32 };
+
+struct VoxBwdGrads {                    // device float32, reference nn.Linear layouts; null = not wanted
+    float *sigma_w[2], *color_w[3], *color_b[3];
+};
+
+struct VoxBwdPlan {
+    const float *d_raw, *raw;           // [nsamp, 4]
+    long nsamp, tiles;
+    char* store;
+    const char* wt[VBWD_NSTREAMS];
+    const int* maps;
+    float* partial;
+    unsigned* maxbits;
+    int wgrad_blocks;
+    float* d_fts;                       // [nsamp, d_fts_stride] float32 out, or null
+    int d_fts_stride;
+    VoxBwdGrads grads;
+};
+
+int launch_voxel_train_fwd_f16(int HD, const VoxMlpParams& p, hipStream_t st);
+int launch_voxel_train_fwd_bf16(int HD, const VoxMlpParams& p, hipStream_t st);
+int run_voxel_backward_f16(int HD, const VoxBwdPlan& b, hipStream_t st);
+int run_voxel_backward_bf16(int HD, const VoxBwdPlan& b, hipStream_t st);
+inline int launch_voxel_train_fwd_dispatch(int prec, int HD, const VoxMlpParams& p, hipStream_t st) {
+    return prec == 3 /*EVD_PREC_F16*/ ? launch_voxel_train_fwd_f16(HD, p, st) : launch_voxel_train_fwd_bf16(HD, p, st);
+}
+inline int run_voxel_backward_dispatch(int prec, int HD, const VoxBwdPlan& b, hipStream_t st) {
+    return prec == 3 ? run_voxel_backward_f16(HD, b, st) : run_voxel_backward_bf16(HD, b, st);
+}
+long voxel_store_tile_bytes(int HD);      // fine 256 / 128 / 64 or coarse 64 / 15 / 32 (kernel_voxel_train_f16.hip)
+
+}  // namespace evd

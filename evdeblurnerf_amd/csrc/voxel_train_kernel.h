@@ -1,0 +1,123 @@
+// Backward of one PDRF level's sigma / colour networks (reference: autograd of VoxelNeRFBase.forward, networks/pdrf/voxnerf.py:210-254)
+// on the dgrad / wgrad kernels of nerf_train_kernel.h; slots: voxel_mlp_kernel.h VStore.
+//
+//   raw = (sigma, sigmoid(colour)):  d colour_pre = d raw_c . s (1 - s) is folded into the gradient fragments
+//   C2^T -> d c1 . [c1 > 0];  C1^T -> d c0 . [c0 > 0];  C0^T (geo rows) -> d geo;  [Geo^T | Sigma^T] -> d hid . [hid > 0];
+//   L0^T (feature rows) -> d fts, written out as float32 rows for the tri-plane scatter (kernel_voxel.hip k_voxel_sample_bwd)
+#pragma once
+
+#include "nerf_train_kernel.h"
+#include "voxel_mlp_kernel.h"
+#include "voxel_train.h"
+
+namespace evd {
+
+template <int PREC>
+__global__ __launch_bounds__(256) void k_voxel_grad_frags(const float* __restrict__ d_raw, const float* __restrict__ raw, long nsamp,
+                                                          const unsigned* __restrict__ maxbits, char* __restrict__ store, long tiles,
+                                                          long tile_bytes, int g_col, int g_sig) {
+    typedef POps<PREC> O;
+    typedef typename O::B B;
+    pipe_fp16_saturate<PREC>();
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x, tile = idx >> 6;
+    if (tile >= tiles) return;
+    const int lane = idx & 63, n = lane & 31, h = lane >> 5;
+    const long smp = tile * 32 + n;
+    const float s = grad_scale(*maxbits, false);
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    if (h == 0 && smp < nsamp) {
+        g = *reinterpret_cast<const f32x4*>(d_raw + smp * 4);
+        const f32x4 r = *reinterpret_cast<const f32x4*>(raw + smp * 4);
+#pragma unroll
+        for (int c = 1; c < 4; ++c) g[c] = g[c] * r[c] * (1.f - r[c]);         // through torch.sigmoid (voxnerf.py:252)
+    }
+    B col, sg;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) col.w[e] = sg.w[e] = 0u;
+    O::template set_pair<false>(col, 0, g[1] * s, g[2] * s);
+    O::template set_pair<false>(col, 1, g[3] * s, 0.f);
+    O::template set_pair<false>(sg, 0, g[0] * s, 0.f);
+    char* a = store + tile * tile_bytes + lane * 16;
+    act_store(a, g_col, col);
+    act_store(a, g_sig, sg);
+}
+
+// gradient fragments of the input features -> float32 rows [n, FT] (loss scale removed): fragment j, position kk of the dgrad
+// output <-> feature 16 j + phi(kk)
+template <int PREC>
+__global__ __launch_bounds__(256) void k_frags_to_rows(const char* __restrict__ store, long tile_bytes, int slot, int nfrag, long nsamp,
+                                                       const unsigned* __restrict__ maxbits, float* __restrict__ rows, int stride) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long tile = idx / (64 * nfrag);
+    const int j = (int)((idx / 64) % nfrag), lane = idx & 63, n = lane & 31, h = lane >> 5;
+    const long smp = tile * 32 + n;
+    if (smp >= nsamp) return;
+    const W4 f = frag_load<W4>(store + tile * tile_bytes + lane * 16, slot + j);
+    const float inv = grad_scale(*maxbits, true);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const unsigned short bits = (unsigned short)(f.w[e >> 1] >> (16 * (e & 1)));
+        float v;
+        if constexpr (PREC == EVD_PREC_BF16) v = __uint_as_float((unsigned)bits << 16);
+        else v = (float)__builtin_bit_cast(_Float16, bits);
+        rows[smp * (long)stride + 16 * j + phi(8 * h + e)] = v * inv;
+    }
+}
+
+template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const VoxBwdPlan& b, hipStream_t st) {
+    typedef VStore<HD, G, FT> VS;
+    constexpr int T = HD / 32, KS = HD / 16, KF = FT / 16, GT = VS::GT, FTT = (FT + 31) / 32, IC = 3 * (1 + 2 * PE_L), ICV = 3 * (1 + 2 * PE_LV);
+    int rc;
+    EVD_HIP(hipMemsetAsync(b.maxbits, 0, sizeof(unsigned), st));
+    hipLaunchKernelGGL(k_absmax, dim3(512), dim3(256), 0, st, b.d_raw, b.nsamp * 4, b.maxbits);
+    EVD_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_voxel_grad_frags<PREC>), dim3((unsigned)cdiv(b.tiles * 64, 256L)), dim3(256), 0, st, b.d_raw, b.raw, b.nsamp, b.maxbits, b.store,
+                       b.tiles, VS::TILE_BYTES, VS::G_COL, VS::G_SIG);
+    EVD_LAUNCH_CHECK();
+    auto dgrad = [&](int stream, int in_slot, int extra_slot, int mask_slot, int out_slot) {
+        DgradParams p;
+        p.wstream = b.wt[stream]; p.store = b.store; p.tile_bytes = VS::TILE_BYTES;
+        p.in_slot = in_slot; p.extra_slot = extra_slot; p.mask_slot = mask_slot; p.out_slot = out_slot;
+        return p;
+    };
+    auto wgrad = [&](auto launch, int RT, int CT, bool bias, int y_slot, int x_slot, int ymap, int xmap, float* dW, int ld, float* db) -> int {
+        if (!dW) return EVD_OK;
+        const int blocks = (int)(cdiv(b.tiles, (long)WGRAD_TPI) < b.wgrad_blocks ? cdiv(b.tiles, (long)WGRAD_TPI) : b.wgrad_blocks);
+        WgradParams p;
+        p.store = b.store; p.tiles = b.tiles; p.tile_bytes = VS::TILE_BYTES; p.y_slot = y_slot; p.x_slot = x_slot; p.bias = bias ? 1 : 0; p.partial = b.partial;
+        int r = launch(p, blocks, st);
+        if (r) return r;
+        WreduceParams q;
+        q.partial = b.partial; q.nparts = blocks; q.RT = RT; q.CT = CT; q.NC = CT + (bias ? 1 : 0);
+        q.rowmap = b.maps + ymap; q.colmap = b.maps + xmap; q.dW = dW; q.ld = ld; q.db = bias ? db : nullptr; q.maxbits = b.maxbits;
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((long)RT * q.NC * 4)), dim3(256), 0, st, q);
+        EVD_LAUNCH_CHECK();
+        return EVD_OK;
+    };
+    const VoxBwdGrads& g = b.grads;
+    // color_net.2 (+ sigmoid, folded into the gradient fragment)
+    if ((rc = launch_dgrad<PREC, 1, T, 1, false, true>(dgrad(VBWD_C2, VS::G_COL, -1, VS::C1, VS::D_C1), b.tiles, st))) return rc;
+    if ((rc = wgrad(launch_wgrad<PREC, 1, T, true>, 1, T, true, VS::G_COL, VS::C1, VMAP_COL, VMAP_HID, g.color_w[2], HD, g.color_b[2]))) return rc;
+    // color_net.1
+    if ((rc = launch_dgrad<PREC, KS, T, KS, false, true>(dgrad(VBWD_C1, VS::D_C1, -1, VS::C0, VS::D_C0), b.tiles, st))) return rc;
+    if ((rc = wgrad(launch_wgrad<PREC, T, T, false>, T, T, true, VS::D_C1, VS::C1 - KS, VMAP_HID, VMAP_HID, g.color_w[1], HD, g.color_b[1]))) return rc;
+    // color_net.0 on cat([geo, PE(dirs)])
+    if ((rc = launch_dgrad<PREC, KS, GT, KS, false, false>(dgrad(VBWD_C0, VS::D_C0, -1, -1, VS::D_GEO), b.tiles, st))) return rc;
+    if ((rc = wgrad(launch_wgrad<PREC, T, GT, false>, T, GT, true, VS::D_C0, VS::GEO, VMAP_HID, VMAP_GEO_X, g.color_w[0], G + ICV, g.color_b[0]))) return rc;
+    if ((rc = wgrad(launch_wgrad<PREC, T, 1, false>, T, 1, false, VS::D_C0, VS::DIRPE, VMAP_HID, VMAP_DIR, g.color_w[0], G + ICV, nullptr))) return rc;
+    // sigma_net.1 = [sigma row | geo rows] on hid
+    if ((rc = launch_dgrad<PREC, 2 * GT + 1, T, 2 * GT, true, true>(dgrad(VBWD_SIGGEO, VS::D_GEO, VS::G_SIG, VS::HID, VS::D_HID), b.tiles, st))) return rc;
+    if ((rc = wgrad(launch_wgrad<PREC, GT, T, false>, GT, T, false, VS::D_GEO, VS::HID, VMAP_GEO_Y, VMAP_HID, g.sigma_w[1], HD, nullptr))) return rc;
+    if ((rc = wgrad(launch_wgrad<PREC, 1, T, true>, 1, T, false, VS::G_SIG, VS::HID, VMAP_SIG, VMAP_HID, g.sigma_w[1], HD, nullptr))) return rc;
+    // sigma_net.0 on cat([fts, PE(pts)])
+    if (b.d_fts) {
+        if ((rc = launch_dgrad<PREC, KS, FTT, KS, false, false>(dgrad(VBWD_L0, VS::D_HID, -1, -1, VS::D_FTS), b.tiles, st))) return rc;
+        hipLaunchKernelGGL((k_frags_to_rows<PREC>), dim3((unsigned)cdiv(b.tiles * 64 * KF, 256L)), dim3(256), 0, st, (const char*)b.store, VS::TILE_BYTES,
+                           VS::D_FTS, KF, b.nsamp, b.maxbits, b.d_fts, b.d_fts_stride);
+        EVD_LAUNCH_CHECK();
+    }
+    if ((rc = wgrad(launch_wgrad<PREC, T, FTT, false>, T, FTT, false, VS::D_HID, VS::IN0, VMAP_HID, VMAP_FTS, g.sigma_w[0], FT + IC, nullptr))) return rc;
+    return wgrad(launch_wgrad<PREC, T, 2, false>, T, 2, false, VS::D_HID, VS::IN0 + KF, VMAP_HID, VMAP_PE, g.sigma_w[0], FT + IC, nullptr);
+}
+
+}  // namespace evd

@@ -46,6 +46,25 @@ class _VoxelSample(torch.autograd.Function):
         return (None, None, *grads)
 
 
+class _VoxelMLP(torch.autograd.Function):
+    """per-sample sigma / colour networks of one level (voxnerf.py:210-221,240-254) with the hand-written backward:
+    gradients to the flat parameter tensor and to the sampled features (evd_voxel_mlp_train / _backward)"""
+
+    @staticmethod
+    def forward(ctx, flat, fts, pts, viewdirs, net, precision):
+        raw, store = net.mlpforward_train(pts, viewdirs, fts, precision)
+        ctx.net, ctx.precision, ctx.store, ctx.raw = net, precision, store, raw
+        ctx.need_fts = fts.requires_grad
+        ctx.ft_shape = fts.shape
+        return raw
+
+    @staticmethod
+    def backward(ctx, d_raw):
+        gflat, d_fts = ctx.net.mlp_backward_flat(d_raw, ctx.raw, ctx.store, ctx.precision, want_fts=ctx.need_fts)
+        ctx.store = ctx.raw = None
+        return gflat, (d_fts.reshape(ctx.ft_shape) if d_fts is not None else None), None, None, None, None
+
+
 class _VoxelTV(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, *grids):
@@ -72,6 +91,7 @@ class VoxelNeRFBase:
         self.gridSize = pdrf_grid_size(lo, hi, n_voxels)
         self.hidden_dim, self.geo_feat_dim, self.app_dim = hidden_dim, geo_feat_dim, app_dim
         self.input_ch, self.precision = input_ch, precision
+        self.ft_dim = input_ch - 3 * (1 + 2 * multires)
         self.rgb_activate, self.sigma_activate = rgb_activate, sigma_activate
         self.render_rmnearplane = render_rmnearplane
         self.composite_feature = composite_feature
@@ -146,6 +166,76 @@ class VoxelNeRFBase:
         out = torch.empty((p.shape[0], self.app_dim), dtype=torch.float32, device=p.device)
         L.check(L.lib().evd_voxel_sample(self._h, L.ptr(p), p.shape[0], L.ptr(out), self.app_dim, 0, L.stream_ptr()), "evd_voxel_sample")
         return out.reshape(sh[0], sh[1], self.app_dim) if len(sh) == 3 else out
+
+    # ---- training the sigma / colour networks (f16 / bf16): one flat float32 parameter tensor, library order ----------------
+    PARAM_KEYS = ["sigma_net.0.weight", "sigma_net.1.weight", "color_net.0.weight", "color_net.0.bias", "color_net.1.weight",
+                  "color_net.1.bias", "color_net.2.weight", "color_net.2.bias"]
+
+    def param_blocks(self):
+        if getattr(self, "_blocks", None) is None:
+            off = (C.c_long * 9)()
+            if L.lib().evd_voxel_param_blocks(self._h, off, 9) != 8:
+                raise L.EvdError("evd_voxel_param_blocks: unexpected parameter block count")
+            HD, G = self.hidden_dim, self.geo_feat_dim
+            outs = [HD, 1 + G, HD, HD, HD, HD, 3, 3]
+            blocks = []
+            for i, key in enumerate(self.PARAM_KEYS):
+                n = off[i + 1] - off[i]
+                blocks.append((key, (outs[i], n // outs[i]) if key.endswith("weight") else (n,), off[i]))
+            self._blocks, self._nparam = blocks, off[8]
+        return self._blocks
+
+    def flat_params(self, state_dict, prefix="", device="cuda"):
+        blocks = self.param_blocks()
+        flat = torch.zeros((self._nparam,), dtype=torch.float32)
+        for key, shape, off in blocks:
+            if prefix + key in state_dict:
+                flat[off:off + int(np.prod(shape))] = torch.as_tensor(_np32(state_dict[prefix + key])).reshape(-1)
+        return flat.to(device).requires_grad_(True)
+
+    def unflatten(self, flat):
+        return {key: flat[off:off + int(np.prod(shape))].view(shape) for key, shape, off in self.param_blocks()}
+
+    def load_params(self, flat):
+        f = flat.detach().contiguous().float()
+        self.param_blocks()
+        if f.numel() != self._nparam:
+            raise L.EvdError(f"flat parameter tensor has {f.numel()} elements, the level {self._nparam}")
+        L.check(L.lib().evd_voxel_load_params(self._h, L.ptr(f), L.stream_ptr()), "evd_voxel_load_params")
+        self._synced_net = (flat.data_ptr(), flat._version)
+
+    def mlpforward_train(self, pts, viewdirs, fts, precision=None):
+        p, vd, ft = pts.contiguous().float(), viewdirs.contiguous().float(), fts.contiguous().float()
+        R, S = p.shape[:2]
+        raw = torch.empty((R, S, 4), dtype=torch.float32, device=p.device)
+        nb = int(L.lib().evd_voxel_train_store_bytes(self._h, R * S))
+        store = torch.empty((nb,), dtype=torch.uint8, device=p.device)
+        L.check(L.lib().evd_voxel_mlp_train(self._h, L.PREC[precision or self.precision], L.ptr(p), L.ptr(vd), vd.shape[-1], L.ptr(ft), ft.shape[-1],
+                                             R, S, L.ptr(raw), L.ptr(store), nb, L.stream_ptr()), "evd_voxel_mlp_train")
+        return raw, store
+
+    def mlp_backward_flat(self, d_raw, raw, store, precision=None, want_fts=True):
+        g = d_raw.contiguous().float()
+        R, S = g.shape[:2]
+        blocks = self.param_blocks()
+        flat = torch.zeros((self._nparam,), dtype=torch.float32, device=g.device)
+        gs, base = L.VoxelGrads(), flat.data_ptr()
+        for key, shape, off in blocks:
+            name, idx, kind = key.split(".")
+            arr = getattr(gs, ("sigma_" if name == "sigma_net" else "color_") + ("w" if kind == "weight" else "b"))
+            arr[int(idx)] = base + 4 * off
+        d_fts = torch.zeros((R * S, self.ft_dim), dtype=torch.float32, device=g.device) if want_fts else None
+        nb = int(L.lib().evd_voxel_backward_workspace_bytes())
+        ws = torch.empty((nb,), dtype=torch.uint8, device=g.device)
+        L.check(L.lib().evd_voxel_mlp_backward(self._h, L.PREC[precision or self.precision], L.ptr(g), L.ptr(raw), R, S, L.ptr(store), store.numel(),
+                                                C.byref(gs), L.ptr(d_fts), self.ft_dim, L.ptr(ws), nb, L.stream_ptr()), "evd_voxel_mlp_backward")
+        return flat, d_fts
+
+    def mlp_train(self, flat, pts, viewdirs, fts, precision=None):
+        """raw [R,S,4] = (sigma, sigmoid(colour)) with autograd to the flat parameters and to the sampled features"""
+        if getattr(self, "_synced_net", None) != (flat.data_ptr(), flat._version):
+            self.load_params(flat)
+        return _VoxelMLP.apply(flat, fts, pts, viewdirs, self, precision or self.precision)
 
     # ---- training the grids (the library's channel-last layout; a permute away from the state dict) ---------------------
     def grid_params(self):

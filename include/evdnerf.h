@@ -233,6 +233,27 @@ int evd_c2f_render(const evd_voxel* coarse, const evd_voxel* fine, const evd_ren
 /* TV_loss_app, voxnerf.py:126-130 (TVLoss :306-324): sum over planes*1e-2 + lines*1e-3 -> out dev [1] (float) */
 int evd_voxel_tv_loss(const evd_voxel* v, float* out, void* stream);
 
+/* ---- training one PDRF level's sigma / colour networks -------------------------------------------------
+ * Parameters live in one float32 arena, canonical order sigma_net.0.weight, sigma_net.1.weight, color_net.{0,1,2}.{weight,bias}
+ * (reference nn.Linear layouts, voxnerf.py:60-84); evd_voxel_param_blocks writes the 8 offsets + the total and returns 8;
+ * evd_voxel_load_params re-packs every weight stream of the level on the device (after optimizer.step()).
+ * evd_voxel_mlp_train = the per-sample part of VoxelNeRFBase.forward (voxnerf.py:210-221,240-254): raw dev [R,S,4] =
+ * (sigma, sigmoid(colour)), every layer's activations kept in `store` (evd_voxel_train_store_bytes).
+ * evd_voxel_mlp_backward: d_raw, raw dev [R,S,4] -> parameter gradients (overwritten) and d_fts dev [R*S, d_fts_stride]
+ * (columns 0 .. ft_dim-1 overwritten; NULL = not wanted), the gradient of the sampled features that evd_voxel_sample_bwd
+ * scatters into the grids.  Built for EVD_PREC_F16 / EVD_PREC_BF16, both shipped levels (64/15/32 and 256/128/64). */
+typedef struct { float *sigma_w[2], *color_w[3], *color_b[3]; } evd_voxel_grads;
+long evd_voxel_param_count(const evd_voxel* v);
+int evd_voxel_param_blocks(const evd_voxel* v, long* offsets, int capacity);
+int evd_voxel_load_params(evd_voxel* v, const float* params, void* stream);
+size_t evd_voxel_train_store_bytes(const evd_voxel* v, long nsamp);
+size_t evd_voxel_backward_workspace_bytes(void);
+int evd_voxel_mlp_train(const evd_voxel* v, int precision, const float* pts, const float* viewdirs, int vd_stride, const float* fts,
+                        int ft_stride, long R, int S, float* raw, void* store, size_t store_bytes, void* stream);
+int evd_voxel_mlp_backward(const evd_voxel* v, int precision, const float* d_raw, const float* raw, long R, int S, void* store,
+                           size_t store_bytes, const evd_voxel_grads* grads, float* d_fts, int d_fts_stride, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
 /* ---- training the PDRF grids (scatter-add into the tri-planes) -----------------------------------------
  * The library keeps planes / lines CHANNEL-LAST: plane[i] [grid[m1]][grid[m0]][C_i] (reference app_plane.i is [1,C,H,W],
  * voxnerf.py:112-113), line[i] [grid[vec]][C_i], basis [app_dim][sum C] (= basis_mat.weight).  Parameters and gradients of

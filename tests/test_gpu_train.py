@@ -319,3 +319,85 @@ def test_triplane_sample_and_tv_backward_match_torch_autograd():
     ref2 = _torch_appfeature([sd2[f"app_plane.{i}"].cpu().double() for i in range(3)], [sd2[f"app_line.{i}"].cpu().double() for i in range(3)],
                              sd2["basis_mat.weight"].cpu().double(), torch.tensor(pts, dtype=torch.float64), AABB)
     assert (out2.detach().cpu().double() - ref2).abs().max().item() < 1e-4
+
+
+class TorchVoxLevel(torch.nn.Module):
+    """float64 restatement of the per-sample part of VoxelNeRFBase.forward (voxnerf.py:210-221,240-254)"""
+
+    def __init__(self, sd):
+        super().__init__()
+        keys = ["sigma_net.0.weight", "sigma_net.1.weight", "color_net.0.weight", "color_net.0.bias", "color_net.1.weight",
+                "color_net.1.bias", "color_net.2.weight", "color_net.2.bias"]
+        self.p = torch.nn.ParameterDict({k.replace(".", "_"): torch.nn.Parameter(torch.tensor(np.asarray(sd[k]), dtype=torch.float64)) for k in keys})
+
+    def forward(self, pts, dirs, fts, masks=None):
+        P = self.p
+        act = (lambda x, k: torch.relu(x)) if masks is None else (lambda x, k: x * masks[k])
+        h = act(torch.cat([fts, embed(pts, 10)], -1) @ P["sigma_net_0_weight"].T, "hid")
+        sg = h @ P["sigma_net_1_weight"].T
+        c = act(torch.cat([sg[:, 1:], embed(dirs, 4)], -1) @ P["color_net_0_weight"].T + P["color_net_0_bias"], "c0")
+        c = act(c @ P["color_net_1_weight"].T + P["color_net_1_bias"], "c1")
+        col = torch.sigmoid(c @ P["color_net_2_weight"].T + P["color_net_2_bias"])
+        return torch.cat([sg[:, :1], col], -1)
+
+
+def vdecode(store, nsamp, tile_frags, slot, nfrag, dtype):
+    tiles = store.numel() // (tile_frags * 1024)
+    v = store.view(tiles, tile_frags, 64, 16)[:, slot:slot + nfrag].contiguous().view(dtype).float().view(tiles, nfrag, 2, 32, 8)
+    out = torch.zeros((tiles, 32, nfrag * 16), dtype=torch.float32, device=store.device)
+    for h in range(2):
+        for e in range(8):
+            out[:, :, torch.arange(nfrag) * 16 + phi(8 * h + e)] = v[:, :, h, :, e].permute(0, 2, 1)
+    return out.reshape(tiles * 32, nfrag * 16)[:nsamp]
+
+
+@pytest.mark.parametrize("prec,tol", [("f16", 4e-3), ("bf16", 3e-2)])
+@pytest.mark.parametrize("level", ["coarse", "fine"])
+def test_pdrf_level_networks_backward_match_torch_autograd(level, prec, tol):
+    from evdeblurnerf_amd.voxnerf import VoxelNeRFRayFeatures, VoxelNeRFSampleFeatures
+    if level == "coarse":
+        HD, G, FT, nvox, cls = 64, 15, 32, 24 ** 3, VoxelNeRFRayFeatures
+    else:
+        HD, G, FT, nvox, cls = 256, 128, 64, 48 ** 3, VoxelNeRFSampleFeatures
+    gsz = W.pdrf_grid_size(AABB[0], AABB[1], nvox)
+    sd = W.make_pdrf_state_dict(71, gsz, input_ch=FT + 63, hidden_dim=HD, geo_feat_dim=G, add_bias_color=True)
+    net = cls(sd, "", AABB, num_layers=2, hidden_dim=HD, geo_feat_dim=G, num_layers_color=3, input_ch=FT + 63, app_dim=32,
+              app_n_comp=(64, 16, 16), n_voxels=nvox, precision=prec)
+    R, S = 70, 33
+    rs = np.random.RandomState(11)
+    pts = rs.uniform(-1, 1, (R, S, 3)).astype(np.float32)
+    d = rs.normal(size=(R, 3))
+    vd = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32)
+    fts = (0.3 * rs.normal(size=(R, S, FT))).astype(np.float32)
+    d_raw = (rs.normal(size=(R, S, 4)) * 1e-3 * np.exp(rs.uniform(-3, 0, (R, S, 1)))).astype(np.float32)
+    dev = "cuda"
+    flat = net.flat_params(sd)
+    ft_t = torch.tensor(fts, device=dev, requires_grad=True)
+    raw = net.mlp_train(flat, torch.tensor(pts, device=dev), torch.tensor(vd, device=dev), ft_t)
+    store = raw.grad_fn.store
+    # the fused inference forward of the same level (render path) agrees to the mode's rounding
+    (raw * torch.tensor(d_raw, device=dev)).sum().backward()
+    n = R * S
+    KS, KF, GT = HD // 16, FT // 16, (G + 31) // 32
+    IN0, DIRPE = 0, KF + 4
+    HID = DIRPE + 2
+    GEO = HID + KS
+    C0 = GEO + 2 * GT
+    C1 = C0 + KS
+    TILE_FRAGS = C1 + KS + 2 + KS + KS + 2 * GT + KS + 2 * ((FT + 31) // 32)
+    dt = torch.float16 if prec == "f16" else torch.bfloat16
+    masks = {"hid": (vdecode(store, n, TILE_FRAGS, HID, KS, dt) > 0).cpu().double(),
+             "c0": (vdecode(store, n, TILE_FRAGS, C0, KS, dt) > 0).cpu().double(),
+             "c1": (vdecode(store, n, TILE_FRAGS, C1, KS, dt) > 0).cpu().double()}
+    ref = TorchVoxLevel(sd)
+    p64 = torch.tensor(pts, dtype=torch.float64).reshape(-1, 3)
+    d64 = torch.tensor(np.repeat(vd[:, None], S, 1), dtype=torch.float64).reshape(-1, 3)
+    f64 = torch.tensor(fts, dtype=torch.float64).reshape(-1, FT).requires_grad_(True)
+    rraw = ref(p64, d64, f64, masks=masks)
+    assert (raw.detach().reshape(n, 4).cpu().double() - rraw).abs().max().item() < (2e-2 if prec == "f16" else 1.5e-1)
+    (rraw * torch.tensor(d_raw, dtype=torch.float64).reshape(-1, 4)).sum().backward()
+    got = net.unflatten(flat.grad)
+    errs = {k: rel_l2(v.cpu().double(), ref.p[k.replace(".", "_")].grad) for k, v in got.items()}
+    errs["fts"] = rel_l2(ft_t.grad.reshape(n, FT).cpu().double(), f64.grad)
+    print(f"[{level} {prec}] worst relative L2 error = {max(errs.values()):.2e}")
+    assert max(errs.values()) < tol, {k: f"{v:.1e}" for k, v in errs.items()}
