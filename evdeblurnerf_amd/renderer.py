@@ -188,9 +188,13 @@ class NeRFAll:
 
     # ------------------------------------------------------------------ render_rays under autograd (mode='nerf')
     def trainable_parameters(self, state_dict):
-        """(flat_coarse, flat_fine | None): one float32 leaf tensor per network for the optimizer (NeRF.flat_params)"""
-        if self.mode != "nerf":
-            raise NotImplementedError("the training path is built for mode='nerf'")
+        """mode='nerf': (flat_coarse, flat_fine | None), one float32 leaf tensor per network (NeRF.flat_params).
+        mode='c2f': ({"net": flat, "grids": [plane0..2, line0..2, basis]}, same for the fine level | None) -- the level's
+        sigma/colour parameters as one flat tensor and its tri-plane parameters in the library's channel-last layout."""
+        if self.mode == "c2f":
+            def level(m, prefix):
+                return {"net": m.flat_params(state_dict, prefix, self.device), "grids": m.grid_params()}
+            return level(self.mlp_coarse, "mlp_coarse."), (level(self.mlp_fine, "mlp_fine.") if self.mlp_fine is not None else None)
         fc = self.mlp_coarse.flat_params(state_dict, "mlp_coarse.", self.device)
         ff = self.mlp_fine.flat_params(state_dict, "mlp_fine.", self.device) if self.mlp_fine is not None else None
         return fc, ff
@@ -200,8 +204,6 @@ class NeRFAll:
         """renderer.py:129-264 (else-branch) with gradients to the two flat parameter tensors: stratified z, fused MLP
         (forward keeps activations, hand-written backward), compositing scan (autograd node), hierarchical resampling on the
         detached coarse weights (renderer.py:233 z_samples.detach()), fine pass.  Rays are constants (no pose gradients)."""
-        if self.mode != "nerf":
-            raise NotImplementedError("the training path is built for mode='nerf'")
         from .rays import sample_pdf_merge
         rb = ray_batch.contiguous().float()
         R, S, Ni = rb.shape[0], int(N_samples), int(N_importance)
@@ -218,6 +220,8 @@ class NeRFAll:
         tr = t_rand.contiguous().float() if t_rand is not None else None
         L.check(L.lib().evd_sample_z(C.byref(cfg), L.ptr(rb), 11, R, L.ptr(tr), L.ptr(z0), L.stream_ptr()), "evd_sample_z")
         rays_d = rb[:, 3:6].contiguous()
+        if self.mode == "c2f":
+            return self._render_rays_train_c2f(rb, z0, flat_coarse, flat_fine, S, Ni, perturb, u, noise0, noise1)
         raw0 = self.mlp_coarse.mlp_train(flat_coarse, rb, z0, self.precision)
         rgb0, _, acc0, w0, depth0, _ = self.mlp_coarse.raw2outputs(raw0, z0, rays_d, None, 0., white_bkgd, noise=noise0)
         if Ni <= 0:
@@ -227,6 +231,38 @@ class NeRFAll:
         rgb, _, acc, w1, depth, _ = self.mlp_fine.raw2outputs(raw1, zm, rays_d, None, 0., white_bkgd, noise=noise1)
         return {"rgb_map": rgb, "depth_map": depth, "acc_map": acc, "weights": w1, "z_vals": zm, "rgb0": rgb0, "depth0": depth0,
                 "acc0": acc0, "z_std": zstd}
+
+    def _render_rays_train_c2f(self, rb, z0, pc, pf, S, Ni, perturb, u, noise0, noise1):
+        """renderer.py:182-217 under autograd: tri-plane gathers (scatter-add backward), level networks (fused forward/backward),
+        compositing scans, resampling on the detached coarse weights; coarse features of the merged set are the re-ordered rows
+        of the old and new points (:209-213), fine features are sampled at the merged points."""
+        from .rays import sample_pdf_merge
+        coarse, fine = self.mlp_coarse, self.mlp_fine
+        o, d, vd = rb[:, None, 0:3], rb[:, None, 3:6], rb[:, 8:11].contiguous()
+        rays_d = rb[:, 3:6].contiguous()
+        pts0 = o + d * z0[..., None]
+        ft0 = coarse.sample_train(pts0, pc["grids"])
+        raw0 = coarse.mlp_train(pc["net"], pts0, vd, ft0, self.precision)
+        rgb0, _, acc0, w0, depth0 = coarse.raw2outputs(raw0, z0, rays_d, is_train=True, noise=noise0)
+        if Ni <= 0:
+            return {"rgb_map": rgb0, "depth_map": depth0, "acc_map": acc0, "weights": w0, "z_vals": z0}
+        zs, zm, order, zstd = sample_pdf_merge(z0, w0.detach(), Ni, det=(perturb == 0.), u=u, want_order=True)
+        ftn = coarse.sample_train(o + d * zs[..., None], pc["grids"])
+        fc = coarse.app_dim
+        ftc = torch.cat([ft0, ftn], 1).gather(1, order.long()[..., None].expand(-1, -1, fc))
+        ptm = o + d * zm[..., None]
+        ft = torch.cat([ftc, fine.sample_train(ptm, pf["grids"])], -1)
+        raw1 = fine.mlp_train(pf["net"], ptm, vd, ft, self.precision)
+        rgb, _, acc, w1, depth = fine.raw2outputs(raw1, zm, rays_d, is_train=True, noise=noise1)
+        return {"rgb_map": rgb, "depth_map": depth, "acc_map": acc, "weights": w1, "z_vals": zm, "rgb0": rgb0, "depth0": depth0,
+                "acc0": acc0, "z_std": zstd}
+
+    def tv_loss_train(self, pc, pf=None):
+        """other_loss['TV'] of the training forward (renderer.py:361-365) with gradients to the grids"""
+        tv = self.mlp_coarse.tv_loss_train(pc["grids"])
+        if pf is not None and self.mlp_fine is not None:
+            tv = tv + self.mlp_fine.tv_loss_train(pf["grids"])
+        return tv * 5
 
     # ------------------------------------------------------------------ render, renderer.py:399-466
     def render(self, H, W, K, chunk=1 << 22, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,

@@ -401,3 +401,119 @@ def test_pdrf_level_networks_backward_match_torch_autograd(level, prec, tol):
     errs["fts"] = rel_l2(ft_t.grad.reshape(n, FT).cpu().double(), f64.grad)
     print(f"[{level} {prec}] worst relative L2 error = {max(errs.values()):.2e}")
     assert max(errs.values()) < tol, {k: f"{v:.1e}" for k, v in errs.items()}
+
+
+def _c2f_model(prec, N_importance=32):
+    from types import SimpleNamespace
+    from evdeblurnerf_amd.renderer import NeRFAll
+    gc, gf = W.pdrf_grid_size(AABB[0], AABB[1], 24 ** 3), W.pdrf_grid_size(AABB[0], AABB[1], 48 ** 3)
+    sd = dict(W.prefixed(W.make_pdrf_state_dict(81, gc, input_ch=95, hidden_dim=64, geo_feat_dim=15, add_bias_color=True), "mlp_coarse"))
+    sd.update(W.prefixed(W.make_pdrf_state_dict(82, gf, input_ch=127, hidden_dim=256, geo_feat_dim=128, add_bias_color=True), "mlp_fine"))
+    args = SimpleNamespace(mode="c2f", multires=10, multires_views=4, use_viewdirs=True, N_importance=N_importance, kernel_type="RBK",
+                           kernel_use_awp=False, rgb_activate="sigmoid", sigma_activate="relu", bounding_box=AABB, coarse_num_layers=2,
+                           coarse_num_layers_color=3, coarse_hidden_dim=64, coarse_hidden_dim_color=64, coarse_app_dim=32,
+                           coarse_app_n_comp=[64, 16, 16], coarse_n_voxels=24 ** 3, kernel_feat_cnl=15, fine_num_layers=2, fine_num_layers_color=3,
+                           fine_hidden_dim=256, fine_hidden_dim_color=256, fine_geo_feat_dim=128, fine_app_dim=32, fine_app_n_comp=[64, 16, 16],
+                           fine_n_voxels=48 ** 3)
+    return NeRFAll(args, sd, precision=prec), sd
+
+
+def _c2f_rays(R, seed):
+    rs = np.random.RandomState(seed)
+    rb = np.zeros((R, 11), np.float32)
+    rb[:, 0:3] = rs.uniform(-0.3, 0.3, (R, 3)) + np.array([0, 0, 0.9])
+    d = rs.normal(size=(R, 3)) * 0.35 + np.array([0, 0, -1.0])
+    rb[:, 3:6] = d
+    rb[:, 6], rb[:, 7] = 0.1, 1.7
+    rb[:, 8:11] = d / np.linalg.norm(d, axis=-1, keepdims=True)
+    return rb
+
+
+def _torch_vox_composite(raw, z, rays_d):
+    dists = (z[:, 1:] - z[:, :-1]) * rays_d.norm(dim=-1, keepdim=True)
+    dens = torch.relu(raw[:, :-1, 0])
+    alpha = torch.cat([1 - torch.exp(-dens * dists), torch.ones_like(dens[:, :1])], -1)
+    T = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1 - alpha + 1e-10], -1), -1)[:, :-1]
+    w = alpha * T
+    return (w[..., None] * raw[..., 1:]).sum(-2), w
+
+
+def test_c2f_render_rays_train_end_to_end_gradients():
+    """The whole mode='c2f' training forward (both levels, merged samples) differentiated by the hand-written kernels vs the
+    float64 torch pipeline on the same sample positions; bounded by the half-precision ReLU flips (see the MLP tests)."""
+    model, sd = _c2f_model("f16")
+    model.train()
+    pc, pf = model.trainable_parameters(sd)
+    R, S, Ni = 96, 24, 16
+    rb_np = _c2f_rays(R, 4)
+    rb = torch.tensor(rb_np, device="cuda")
+    rs = np.random.RandomState(5)
+    tgt = rs.uniform(0, 1, (R, 3)).astype(np.float32)
+    out = model.render_rays_train(rb, pc, pf, S, Ni)
+    loss = ((out["rgb_map"] - torch.tensor(tgt, device="cuda")) ** 2).mean() + ((out["rgb0"] - torch.tensor(tgt, device="cuda")) ** 2).mean()
+    loss.backward()
+    # float64 pipeline with the same merged sample positions
+    z0 = torch.tensor(np.linspace(0.1, 1.7, S)[None].repeat(R, 0), dtype=torch.float64)
+    zm = out["z_vals"].detach().cpu().double()
+    o, d = torch.tensor(rb_np[:, None, 0:3], dtype=torch.float64), torch.tensor(rb_np[:, None, 3:6], dtype=torch.float64)
+    vd = torch.tensor(rb_np[:, 8:11], dtype=torch.float64)
+    levels, grids64 = {}, {}
+    for name in ("coarse", "fine"):
+        pre = f"mlp_{name}."
+        lsd = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+        levels[name] = TorchVoxLevel(lsd)
+        grids64[name] = ([torch.tensor(np.asarray(lsd[f"app_plane.{i}"]), dtype=torch.float64, requires_grad=True) for i in range(3)],
+                         [torch.tensor(np.asarray(lsd[f"app_line.{i}"]), dtype=torch.float64, requires_grad=True) for i in range(3)],
+                         torch.tensor(np.asarray(lsd["basis_mat.weight"]), dtype=torch.float64, requires_grad=True))
+
+    def feat(name, pts):
+        pl, li, ba = grids64[name]
+        return _torch_appfeature(pl, li, ba, pts.reshape(-1, 3), AABB)
+
+    pts0 = (o + d * z0[..., None])
+    raw0 = levels["coarse"](pts0.reshape(-1, 3), vd[:, None].expand(-1, S, -1).reshape(-1, 3), feat("coarse", pts0)).reshape(R, S, 4)
+    rgb0, _ = _torch_vox_composite(raw0, z0, d[:, 0])
+    ptm = (o + d * zm[..., None])
+    St = S + Ni
+    ftm = torch.cat([feat("coarse", ptm), feat("fine", ptm)], -1)
+    raw1 = levels["fine"](ptm.reshape(-1, 3), vd[:, None].expand(-1, St, -1).reshape(-1, 3), ftm).reshape(R, St, 4)
+    rgb1, _ = _torch_vox_composite(raw1, zm, d[:, 0])
+    assert (out["rgb0"].detach().cpu().double() - rgb0).abs().max().item() < 5e-3
+    assert (out["rgb_map"].detach().cpu().double() - rgb1).abs().max().item() < 5e-3
+    t64 = torch.tensor(tgt, dtype=torch.float64)
+    (((rgb1 - t64) ** 2).mean() + ((rgb0 - t64) ** 2).mean()).backward()
+    errs = {}
+    for name, prm in (("coarse", pc), ("fine", pf)):
+        lvl = model.mlp_coarse if name == "coarse" else model.mlp_fine
+        for k, v in lvl.unflatten(prm["net"].grad).items():
+            errs[f"{name}.{k}"] = rel_l2(v.cpu().double(), levels[name].p[k.replace(".", "_")].grad)
+        pl, li, ba = grids64[name]
+        for i in range(3):
+            errs[f"{name}.plane{i}"] = rel_l2(prm["grids"][i].grad.cpu().double(), pl[i].grad[0].permute(1, 2, 0))
+            errs[f"{name}.line{i}"] = rel_l2(prm["grids"][3 + i].grad.cpu().double(), li[i].grad[0, :, :, 0].t())
+        errs[f"{name}.basis"] = rel_l2(prm["grids"][6].grad.cpu().double(), ba.grad)
+    print("c2f end-to-end relative L2 errors:", {k: f"{v:.1e}" for k, v in errs.items()})
+    assert max(errs.values()) < 0.15, errs
+
+
+def test_c2f_training_iteration_reduces_the_image_loss():
+    """One full mode='c2f' iteration per step: both levels' tri-plane gathers and networks forward/backward, compositing scans,
+    hierarchical resampling with perturbation, TV regulariser, Adam on networks and grids, device re-pack / grid reload."""
+    model, sd = _c2f_model("f16")
+    model.train()
+    pc, pf = model.trainable_parameters(sd)
+    opt = torch.optim.Adam([{"params": [pc["net"], pf["net"]], "lr": 1e-3}, {"params": pc["grids"] + pf["grids"], "lr": 2e-2}])
+    R = 1024
+    rb = torch.tensor(_c2f_rays(R, 6), device="cuda")
+    target = 0.5 + 0.4 * torch.sin(3.0 * rb[:, 8:11] + torch.tensor([0.0, 1.0, 2.0], device="cuda"))
+    torch.manual_seed(0)
+    losses = []
+    for it in range(60):
+        out = model.render_rays_train(rb, pc, pf, 32, 32, perturb=1.0)
+        loss = ((out["rgb_map"] - target) ** 2).mean() + ((out["rgb0"] - target) ** 2).mean() + 0.01 * model.tv_loss_train(pc, pf)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    print("c2f image loss:", " ".join(f"{v:.4f}" for v in losses[::6]), f"-> {losses[-1]:.4f}")
+    assert np.isfinite(losses).all() and losses[-1] < 0.5 * losses[0]
