@@ -207,74 +207,113 @@ __global__ __launch_bounds__(256) void k_voxel_sample(const GridParams g, const 
 }
 
 // Backward of k_voxel_sample (app_act none): d out [n, app_dim] -> gradients of the planes, lines (scatter-add, the transpose of
-// the gather: the same 4 + 2 taps with the same weights) and of basis_mat.  Persistent blocks walk 32-sample tiles:
-//   A  d out rows -> LDS;  d coef[s, c] = sum_f d out[s, f] basis[f, c]
-//   B  the forward's gather again (plane value pv, line value lv per 4-channel group), coef = pv lv -> LDS, then
-//      d plane[tap] += w_tap d coef lv,  d line[tap] += w_tap d coef pv   as hardware float32 atomics (global_atomic_add_f32);
+// the gather: the same 4 + 2 taps with the same weights) and of basis_mat.  Persistent blocks walk 32-sample tiles; inside a
+// tile the LANES RUN OVER CHANNELS (the grids are channel-last), so every gather and every atomic of a wavefront covers
+// contiguous 64..256-byte runs of one tap:
+//   A  d out rows -> LDS;  d coef[s, c] = sum_f d out[s, f] basis[f, c];  tap table (18 per sample: 3 x 4 plane + 3 x 2 line)
+//   B  plane value pv[s, c], line value lv[s, c] (coalesced gathers), then
+//      d plane[tap, c] += w_tap d coef lv,  d line[tap, c] += w_tap d coef pv  as hardware float32 atomics (global_atomic_add_f32);
 //      like the reference's grid_sample backward (voxnerf.py:144) the summation order, hence the last bits, is not deterministic
-//   C  d basis[f, c] += sum_s d out[s, f] coef[s, c] in registers across tiles, one atomic flush per block at the end
-constexpr int VSB_MAXF = 64;
+//   C  d basis[f, c] += sum_s d out[s, f] pv lv in registers across tiles, one atomic flush per block at the end
+constexpr int VSB_MAXF = 64, VSB_TAPS = 18;
 __global__ __launch_bounds__(256) void k_voxel_sample_bwd(const GridParams g, const float* __restrict__ pts, long n,
                                                           const float* __restrict__ d_out, int d_stride, int d_col, GridGrads gg) {
-    __shared__ __attribute__((aligned(16))) float coef[VS_SAMPLES * VS_STRIDE], dco[VS_SAMPLES * VS_STRIDE], dout[VS_SAMPLES * (VSB_MAXF + 1)];
-    const int ctot = g.n_comp[0] + g.n_comp[1] + g.n_comp[2], ng = ctot / 4, F = g.app_dim;
-    const int items = VS_SAMPLES * ng, nbas = F * ctot;
+    __shared__ __attribute__((aligned(16))) float pvs[VS_SAMPLES * VS_STRIDE], lvs[VS_SAMPLES * VS_STRIDE], dco[VS_SAMPLES * VS_STRIDE],
+        dout[VS_SAMPLES * (VSB_MAXF + 1)], tw[VS_SAMPLES * VSB_TAPS];
+    __shared__ int tix[VS_SAMPLES * VSB_TAPS];
+    const int c0n = g.n_comp[0], c1n = g.n_comp[1], ctot = c0n + c1n + g.n_comp[2], F = g.app_dim, nbas = F * ctot;
+    const int tid = threadIdx.x, ss = tid >> 7, ql = tid & 127;
+    // this thread's channel in the (sample pair, 128 channel slots) sweeps of phase B: component group, channel inside it
+    const int cg = ql < c0n ? 0 : (ql < c0n + c1n ? 1 : 2), cin = ql - (cg == 0 ? 0 : (cg == 1 ? c0n : c0n + c1n));
+    const bool chan_on = ql < ctot;
+    const float* gplane = sel3(cg, g.plane[0], g.plane[1], g.plane[2]);
+    const float* gline = sel3(cg, g.line[0], g.line[1], g.line[2]);
+    // ... and its (tap, channel) entries in the atomic sweeps: q = ql + 128 m over [4 plane taps x ctot | 2 line taps x ctot]
+    constexpr int MQ = (6 * VS_MAXC + 127) / 128;
+    int q_slot[MQ], q_c[MQ];
+    float* q_ptr[MQ];
+    bool q_plane[MQ];
+#pragma unroll
+    for (int m = 0; m < MQ; ++m) {
+        const int q = ql + 128 * m;
+        const bool on = q < 6 * ctot, pl = q < 4 * ctot;
+        const int t = pl ? q / ctot : (q - 4 * ctot) / ctot, c = q % ctot;
+        const int i = c < c0n ? 0 : (c < c0n + c1n ? 1 : 2), ci = c - (i == 0 ? 0 : (i == 1 ? c0n : c0n + c1n));
+        q_plane[m] = pl;
+        q_c[m] = c;
+        q_slot[m] = pl ? 4 * i + t : 12 + 2 * i + t;
+        float* base = pl ? sel3(i, gg.plane[0], gg.plane[1], gg.plane[2]) : sel3(i, gg.line[0], gg.line[1], gg.line[2]);
+        q_ptr[m] = (on && base) ? base + ci : nullptr;
+    }
     constexpr int NB = (VSB_MAXF * VS_MAXC + 255) / 256;
     float bacc[NB];
 #pragma unroll
     for (int q = 0; q < NB; ++q) bacc[q] = 0.f;
     for (long tile = blockIdx.x; tile * VS_SAMPLES < n; tile += gridDim.x) {
         const long s0 = tile * VS_SAMPLES;
-        for (int o = threadIdx.x; o < VS_SAMPLES * F; o += 256) {
+        for (int o = tid; o < VS_SAMPLES * F; o += 256) {
             const int sl = o / F, f = o % F;
             dout[sl * (VSB_MAXF + 1) + f] = s0 + sl < n ? d_out[(s0 + sl) * (long)d_stride + d_col + f] : 0.f;
         }
+        if (tid < VS_SAMPLES * 3) {                // tap table: thread = (sample, component group)
+            const int sl = tid / 3, i = tid % 3;
+            const long s = s0 + sl < n ? s0 + sl : n - 1;
+            const float pt[3] = {pts[s * 3], pts[s * 3 + 1], pts[s * 3 + 2]};
+            VsItem it;
+            const int grp0 = i == 0 ? 0 : (i == 1 ? c0n / 4 : (c0n + c1n) / 4);      // first 4-channel group of component i
+            vs_issue<false>(g, pt, grp0, it);
+            const bool live = s0 + sl < n;          // (the first group of a component has channel offset 0: ip / il address channel 0 of the tap)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                tix[sl * VSB_TAPS + 4 * i + t] = (int)it.ip[t];
+                tw[sl * VSB_TAPS + 4 * i + t] = live ? it.wp[t] : 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                tix[sl * VSB_TAPS + 12 + 2 * i + t] = (int)it.il[t];
+                tw[sl * VSB_TAPS + 12 + 2 * i + t] = live ? it.wl[t] : 0.f;
+            }
+        }
         __syncthreads();
-        for (int o = threadIdx.x; o < VS_SAMPLES * ctot; o += 256) {
+        for (int o = tid; o < VS_SAMPLES * ctot; o += 256) {
             const int sl = o / ctot, c = o % ctot;
             float a = 0.f;
             for (int f = 0; f < F; ++f) a = fmaf(dout[sl * (VSB_MAXF + 1) + f], g.basis[(long)f * ctot + c], a);
             dco[sl * VS_STRIDE + c] = a;
         }
-        __syncthreads();
-        for (int t = threadIdx.x; t < items; t += 256) {
-            const int sl = t / ng, grp = t % ng;
-            const long s = s0 + sl < n ? s0 + sl : n - 1;
-            const float pt[3] = {pts[s * 3], pts[s * 3 + 1], pts[s * 3 + 2]};
-            VsItem it;
-            vs_issue<false>(g, pt, grp, it);
-            f32x4 pv, lv;
-            const f32x4 cf = vs_finish(it, &pv, &lv);
-            float* cdst = &coef[sl * VS_STRIDE + grp * 4];
-            const float* dc = &dco[sl * VS_STRIDE + grp * 4];
-            float* gp = sel3(it.grid_id, gg.plane[0], gg.plane[1], gg.plane[2]);
-            float* gl = sel3(it.grid_id, gg.line[0], gg.line[1], gg.line[2]);
+        if (chan_on) {                              // pv, lv: lanes over channels, two samples per sweep
+            for (int sl = ss; sl < VS_SAMPLES; sl += 2) {
+                const int* ti = tix + sl * VSB_TAPS;
+                const float* w = tw + sl * VSB_TAPS;
+                float pv = 0.f, lv = 0.f;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) cdst[k] = cf[k];
-            if (s0 + sl < n) {
+                for (int t = 0; t < 4; ++t) pv = fmaf(w[4 * cg + t], gplane[ti[4 * cg + t] + cin], pv);
 #pragma unroll
-                for (int tp = 0; tp < 4; ++tp)
-                    if (it.wp[tp] != 0.f && gp) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) unsafeAtomicAdd(gp + it.ip[tp] + k, dc[k] * lv[k] * it.wp[tp]);
-                    }
-#pragma unroll
-                for (int tp = 0; tp < 2; ++tp)
-                    if (it.wl[tp] != 0.f && gl) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) unsafeAtomicAdd(gl + it.il[tp] + k, dc[k] * pv[k] * it.wl[tp]);
-                    }
+                for (int t = 0; t < 2; ++t) lv = fmaf(w[12 + 2 * cg + t], gline[ti[12 + 2 * cg + t] + cin], lv);
+                pvs[sl * VS_STRIDE + ql] = pv;
+                lvs[sl * VS_STRIDE + ql] = lv;
             }
         }
         __syncthreads();
+        for (int sl = ss; sl < VS_SAMPLES; sl += 2) {
+#pragma unroll
+            for (int m = 0; m < MQ; ++m) {
+                if (!q_ptr[m]) continue;
+                const float w = tw[sl * VSB_TAPS + q_slot[m]];
+                if (w == 0.f) continue;
+                const int c = q_c[m];
+                const float other = q_plane[m] ? lvs[sl * VS_STRIDE + c] : pvs[sl * VS_STRIDE + c];
+                unsafeAtomicAdd(q_ptr[m] + tix[sl * VSB_TAPS + q_slot[m]], dco[sl * VS_STRIDE + c] * other * w);
+            }
+        }
         if (gg.basis) {
 #pragma unroll
             for (int q = 0; q < NB; ++q) {
-                const int o = threadIdx.x + 256 * q;
+                const int o = tid + 256 * q;
                 if (o < nbas) {
                     const int f = o / ctot, c = o % ctot;
                     float a = bacc[q];
-                    for (int sl = 0; sl < VS_SAMPLES; ++sl) a = fmaf(dout[sl * (VSB_MAXF + 1) + f], coef[sl * VS_STRIDE + c], a);
+                    for (int sl = 0; sl < VS_SAMPLES; ++sl) a = fmaf(dout[sl * (VSB_MAXF + 1) + f], pvs[sl * VS_STRIDE + c] * lvs[sl * VS_STRIDE + c], a);
                     bacc[q] = a;
                 }
             }
@@ -284,7 +323,7 @@ __global__ __launch_bounds__(256) void k_voxel_sample_bwd(const GridParams g, co
     if (gg.basis) {
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
-            const int o = threadIdx.x + 256 * q;
+            const int o = tid + 256 * q;
             if (o < nbas) unsafeAtomicAdd(gg.basis + o, bacc[q]);
         }
     }
