@@ -79,6 +79,51 @@ def test_two_rank_loss_allreduce_and_gather(R):
         assert abs(mse - ((pred - tgt) ** 2).mean()) < 1e-6
 
 
+def _grad_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from evdeblurnerf_amd import dist as D
+    D.init_from_env("gloo")
+    torch.manual_seed(0)
+    # a stand-in model: the flat NeRF parameter tensor and three grid tensors of different sizes (one larger than a bucket)
+    params = [torch.nn.Parameter(torch.randn(n)) for n in (1000, 70000, 33, 5)]
+    x = torch.randn(64, 8)
+    lo, hi = D.shard_range(64, rank, world)
+    loss = sum((p[:8] * x[lo:hi]).sum() * (i + 1) for i, p in enumerate(params[:3])) / 64      # global normalisation; params[3] unused
+    loss.backward()
+    red = D.GradReducer(params, bucket_bytes=100000)
+    assert len(red.buckets) >= 2
+    red.start()
+    red.wait()
+    q.put((rank, [p.grad.numpy().copy() for p in params]))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_equals_single_process():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.randn(n)) for n in (1000, 70000, 33, 5)]
+    x = torch.randn(64, 8)
+    loss = sum((p[:8] * x).sum() * (i + 1) for i, p in enumerate(params[:3])) / 64
+    loss.backward()
+    for rank, grads in res:
+        for g, p in zip(grads[:3], params[:3]):
+            assert np.allclose(g, p.grad.numpy(), rtol=1e-5, atol=1e-7)
+        assert np.array_equal(grads[3], np.zeros(5, np.float32))        # a parameter without gradient on any rank stays zero
+
+
 def test_shard_range_partitions():
     from evdeblurnerf_amd.dist import shard_range
     for n in (0, 1, 7, 8, 4096, 160000):
