@@ -107,11 +107,11 @@ SIGNATURES = {
     "evd_voxel_train_store_bytes": (_S, [_vp, _L]),
     "evd_voxel_backward_workspace_bytes": (_S, []),
     "evd_voxel_mlp_train": (_I, [_vp, _I, _vp, _vp, _I, _vp, _I, _L, _I, _vp, _vp, _S, _vp]),
-    "evd_voxel_mlp_backward": (_I, [_vp, _I, _vp, _vp, _L, _I, _vp, _S, C.POINTER(VoxelGrads), _vp, _I, _vp, _S, _vp]),
+    "evd_voxel_mlp_backward": (_I, [_vp, _I, _vp, _vp, _L, _I, _vp, _S, C.POINTER(VoxelGrads), _vp, _I, _vp, _vp, _I, _vp, _vp, _vp, _S, _vp]),
     "evd_voxel_grid_sizes": (_I, [_vp, C.POINTER(C.c_long)]),
     "evd_voxel_get_grids": (_I, [_vp, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp]),
     "evd_voxel_load_grids": (_I, [_vp, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp]),
-    "evd_voxel_sample_bwd": (_I, [_vp, _vp, _L, _vp, _I, _I, C.POINTER(VoxelGridGrads), _vp]),
+    "evd_voxel_sample_bwd": (_I, [_vp, _vp, _L, _vp, _I, _I, C.POINTER(VoxelGridGrads), _vp, _vp]),
     "evd_voxel_tv_loss_bwd": (_I, [_vp, _vp, C.POINTER(VoxelGridGrads), _vp]),
     "evd_raw2outputs": (_I, [_vp, _vp, _vp, _I, _L, _I, _I, _I, _I, _I, _I, _I, _I, _F, _vp,
                              _vp, _vp, _vp, _vp, _vp, _vp, _I, _vp, _vp]),

@@ -198,14 +198,26 @@ int evd_voxel_create(const evd_voxel_desc* d, evd_voxel** out) {
         };
         rc = put(VBWD_C2, [&](StreamBuilder& b) { b.layer_transposed(color_w2, 3, HD, 0, HD, nullptr, 0, T, 1, true, [](int, int kk) { return kk < 3 ? kk : -1; }); });
         if (!rc) rc = put(VBWD_C1, [&](StreamBuilder& b) { b.layer_transposed(color_w1, HD, HD, 0, HD, nullptr, 0, T, KS, true, hid_col); });
-        if (!rc) rc = put(VBWD_C0, [&](StreamBuilder& b) { b.layer_transposed(color_w0, HD, G + ICV, 0, G, nullptr, 0, GT, KS, true, hid_col); });
+        // rows of an encoding appended to a W^T layer: output row idx of the extra tiles <-> encoding column, so that the output
+        // fragments come out in the encoding's own arrangement (fragment j, position kk <-> pe_src_col(L, 8 j + (kk & 7), kk >> 3))
+        auto enc_row = [](int L_, int idx) { const int j = idx / 16, kk = phi_inv(idx % 16); return pe_src_col(L_, 8 * j + (kk & 7), kk >> 3); };
+        if (!rc) rc = put(VBWD_C0, [&](StreamBuilder& b) {       // [geo rows | direction-encoding rows] of color_net.0
+            b.layer_at(GT + 1, KS, true,
+                       [&](int t, int r) { if (t < GT) return 32 * t + r < G ? 32 * t + r : -1; const int c = enc_row(PE_LV, r); return c < 0 ? -1 : G + c; },
+                       hid_col, [&](int r, int c) { return color_w0 + (size_t)c * (G + ICV) + r; });
+        });
         if (!rc) rc = put(VBWD_SIGGEO, [&](StreamBuilder& b) {
             b.layer_transposed(sigma_w1, 1 + G, HD, 0, HD, nullptr, 0, T, GK + 1, true, [&](int j, int kk) {
                 if (j < GK) { const int c = 16 * j + phi(kk); return c < G ? 1 + c : -1; }
                 return kk == 0 ? 0 : -1;
             });
         });
-        if (!rc) rc = put(VBWD_L0, [&](StreamBuilder& b) { b.layer_transposed(sigma_w0, HD, d->input_ch, 0, FT, nullptr, 0, (FT + 31) / 32, KS, true, hid_col); });
+        if (!rc) rc = put(VBWD_L0, [&](StreamBuilder& b) {       // [feature rows | point-encoding rows] of sigma_net.0
+            const int FTT = (FT + 31) / 32, in_dim = d->input_ch;
+            b.layer_at(FTT + 2, KS, true,
+                       [&](int t, int r) { if (t < FTT) return 32 * t + r < FT ? 32 * t + r : -1; const int c = enc_row(PE_L, 32 * (t - FTT) + r); return c < 0 ? -1 : FT + c; },
+                       hid_col, [&](int r, int c) { return sigma_w0 + (size_t)c * in_dim + r; });
+        });
         if (rc) { evd_voxel_destroy(v); return rc; }
     }
     {   // wgrad index maps (voxel_train.h)
@@ -453,7 +465,9 @@ int evd_voxel_mlp_train(const evd_voxel* v, int precision, const float* pts, con
 }
 
 int evd_voxel_mlp_backward(const evd_voxel* v, int precision, const float* d_raw, const float* raw, long R, int S, void* store, size_t store_bytes,
-                           const evd_voxel_grads* grads, float* d_fts, int d_fts_stride, void* workspace, size_t workspace_bytes, void* stream) {
+                           const evd_voxel_grads* grads, float* d_fts, int d_fts_stride, const float* pts, const float* viewdirs, int vd_stride,
+                           float* d_pts, float* d_dirs, void* workspace, size_t workspace_bytes, void* stream) {
+    EVD_REQUIRE((!d_pts || pts) && (!d_dirs || viewdirs), "evd_voxel_mlp_backward: d_pts / d_dirs need the forward's pts / viewdirs");
     EVD_REQUIRE(v && d_raw && raw && store && grads && workspace, "evd_voxel_mlp_backward: null argument");
     EVD_REQUIRE(precision >= 0 && precision < EVD_NUM_PREC && vox_train_built(v, precision), "evd_voxel_mlp_backward: the training path is built for precision f16 / bf16");
     EVD_REQUIRE(R >= 0 && S >= 1 && (!d_fts || d_fts_stride >= v->ft_dim), "evd_voxel_mlp_backward: bad shape");
@@ -470,6 +484,7 @@ int evd_voxel_mlp_backward(const evd_voxel* v, int precision, const float* d_raw
     b.partial = (float*)(w + 256);
     b.wgrad_blocks = VOX_WGRAD_BLOCKS;
     b.d_fts = d_fts; b.d_fts_stride = d_fts_stride;
+    b.pts = pts; b.viewdirs = viewdirs; b.vd_stride = vd_stride; b.S = S; b.d_pts = d_pts; b.d_dirs = d_dirs;
     for (int i = 0; i < 2; ++i) b.grads.sigma_w[i] = grads->sigma_w[i];
     for (int i = 0; i < 3; ++i) { b.grads.color_w[i] = grads->color_w[i]; b.grads.color_b[i] = grads->color_b[i]; }
     return run_voxel_backward_dispatch(precision, v->hidden_dim, b, as_stream(stream));
@@ -512,14 +527,14 @@ int evd_voxel_load_grids(evd_voxel* v, const float* const* plane, const float* c
 }
 
 int evd_voxel_sample_bwd(const evd_voxel* v, const float* pts, long n, const float* d_out, int d_stride, int d_col,
-                         const evd_voxel_grid_grads* g, void* stream) {
+                         const evd_voxel_grid_grads* g, float* d_pts, void* stream) {
     EVD_REQUIRE(v && pts && d_out && g && n >= 0 && d_stride >= d_col + v->app_dim, "evd_voxel_sample_bwd: bad arguments");
     EVD_REQUIRE(v->app_act == EVD_ACT_NONE, "evd_voxel_sample_bwd: only app_actfn none is built (all shipped configs)");
     if (n == 0) return EVD_OK;
     GridGrads gg;
     for (int i = 0; i < 3; ++i) { gg.plane[i] = g->plane[i]; gg.line[i] = g->line[i]; }
     gg.basis = g->basis;
-    return launch_voxel_sample_bwd(v->gp, pts, n, d_out, d_stride, d_col, gg, as_stream(stream));
+    return launch_voxel_sample_bwd(v->gp, pts, n, d_out, d_stride, d_col, gg, d_pts, as_stream(stream));
 }
 
 int evd_voxel_tv_loss_bwd(const evd_voxel* v, const float* d_loss, const evd_voxel_grid_grads* g, void* stream) {

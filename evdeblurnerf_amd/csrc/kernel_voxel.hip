@@ -58,6 +58,9 @@ struct VsItem {
     float wp[4], wl[2];
     long ip[4], il[2];      // element offsets of the taps (backward: where the gradients are added); unused fields cost the forward nothing
     int grid_id;
+    float fw, fn, fl;       // fractional positions inside the cell (x, y of the plane; the line)
+    float kx, ky, kl;       // d (pixel coordinate) / d (point coordinate) of the three axes the component reads
+    int ax, ay, al;         // ... and which point axes those are
 };
 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -95,6 +98,11 @@ __device__ __forceinline__ void vs_issue(const GridParams& g, const float (&pt)[
     const float* pl = sel3(i, g.plane[0], g.plane[1], g.plane[2]) + c4;
     const _Float16* plh = sel3(i, g.plane_h[0], g.plane_h[1], g.plane_h[2]) + c4;
     it.grid_id = i;
+    it.fw = ww; it.fn = nn;
+    it.kx = 0.5f * (float)(Wp - 1) * sel3(i, g.inv[0], g.inv[0], g.inv[1]);
+    it.ky = 0.5f * (float)(Hp - 1) * sel3(i, g.inv[1], g.inv[2], g.inv[2]);
+    it.kl = 0.5f * (float)(Lp - 1) * sel3(i, g.inv[2], g.inv[1], g.inv[0]);
+    it.ax = sel3(i, 0, 0, 1); it.ay = sel3(i, 1, 2, 2); it.al = sel3(i, 2, 1, 0);
     it.ip[0] = ((long)cy0 * Wp + cx0) * C + c4;
     it.ip[1] = ((long)cy0 * Wp + cx1) * C + c4;
     it.ip[2] = ((long)cy1 * Wp + cx0) * C + c4;
@@ -111,6 +119,7 @@ __device__ __forceinline__ void vs_issue(const GridParams& g, const float (&pt)[
     const int l0 = (int)fl, l1 = l0 + 1;
     const float* li = sel3(i, g.line[0], g.line[1], g.line[2]) + c4;
     const _Float16* lih = sel3(i, g.line_h[0], g.line_h[1], g.line_h[2]) + c4;
+    it.fl = ln;
     it.il[0] = (long)min(max(l0, 0), Lp - 1) * C + c4;
     it.il[1] = (long)min(max(l1, 0), Lp - 1) * C + c4;
     it.l[0] = vs_load<HALF>(li, lih, it.il[0] - c4);
@@ -221,7 +230,10 @@ __global__ __launch_bounds__(256) void k_voxel_sample(const GridParams g, const 
 // contention.  Fewer adds would need a sort by cell + segmented sum instead of atomics.
 constexpr int VSB_MAXF = 64, VSB_TAPS = 18;
 __global__ __launch_bounds__(256) void k_voxel_sample_bwd(const GridParams g, const float* __restrict__ pts, long n,
-                                                          const float* __restrict__ d_out, int d_stride, int d_col, GridGrads gg) {
+                                                          const float* __restrict__ d_out, int d_stride, int d_col, GridGrads gg,
+                                                          float* __restrict__ d_pts) {
+    __shared__ float tfr[VS_SAMPLES * 3 * 6], dpt[VS_SAMPLES * 3];
+    __shared__ int tax[VS_SAMPLES * 3 * 3];
     __shared__ __attribute__((aligned(16))) float pvs[VS_SAMPLES * VS_STRIDE], lvs[VS_SAMPLES * VS_STRIDE], dco[VS_SAMPLES * VS_STRIDE],
         dout[VS_SAMPLES * (VSB_MAXF + 1)], tw[VS_SAMPLES * VSB_TAPS];
     __shared__ int tix[VS_SAMPLES * VSB_TAPS];
@@ -277,7 +289,12 @@ __global__ __launch_bounds__(256) void k_voxel_sample_bwd(const GridParams g, co
                 tix[sl * VSB_TAPS + 12 + 2 * i + t] = (int)it.il[t];
                 tw[sl * VSB_TAPS + 12 + 2 * i + t] = live ? it.wl[t] : 0.f;
             }
+            float* fr = tfr + (sl * 3 + i) * 6;
+            fr[0] = it.fw; fr[1] = it.fn; fr[2] = it.fl; fr[3] = it.kx; fr[4] = it.ky; fr[5] = it.kl;
+            int* ta = tax + (sl * 3 + i) * 3;
+            ta[0] = it.ax; ta[1] = it.ay; ta[2] = it.al;
         }
+        if (tid < VS_SAMPLES * 3) dpt[tid] = 0.f;
         __syncthreads();
         for (int o = tid; o < VS_SAMPLES * ctot; o += 256) {
             const int sl = o / ctot, c = o % ctot;
@@ -289,13 +306,31 @@ __global__ __launch_bounds__(256) void k_voxel_sample_bwd(const GridParams g, co
             for (int sl = ss; sl < VS_SAMPLES; sl += 2) {
                 const int* ti = tix + sl * VSB_TAPS;
                 const float* w = tw + sl * VSB_TAPS;
-                float pv = 0.f, lv = 0.f;
+                float pv = 0.f, lv = 0.f, P[4], Lt[2];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) pv = fmaf(w[4 * cg + t], gplane[ti[4 * cg + t] + cin], pv);
+                for (int t = 0; t < 4; ++t) { P[t] = gplane[ti[4 * cg + t] + cin]; pv = fmaf(w[4 * cg + t], P[t], pv); }
 #pragma unroll
-                for (int t = 0; t < 2; ++t) lv = fmaf(w[12 + 2 * cg + t], gline[ti[12 + 2 * cg + t] + cin], lv);
+                for (int t = 0; t < 2; ++t) { Lt[t] = gline[ti[12 + 2 * cg + t] + cin]; lv = fmaf(w[12 + 2 * cg + t], Lt[t], lv); }
                 pvs[sl * VS_STRIDE + ql] = pv;
                 lvs[sl * VS_STRIDE + ql] = lv;
+                if (d_pts) {
+                    // d feature / d point through the interpolation weights (the ATen grid_sample backward: taps outside the grid
+                    // contribute nothing), chained with d coef; summed over the channels of the wavefront, then over wavefronts in LDS
+                    const float* fr = tfr + (sl * 3 + cg) * 6;
+                    const float ww = fr[0], nn = fr[1], ee = 1.f - ww, sn = 1.f - nn;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) P[t] = w[4 * cg + t] != 0.f ? P[t] : 0.f;
+                    const float dpx = (P[1] - P[0]) * sn + (P[3] - P[2]) * nn, dpy = (P[2] - P[0]) * ee + (P[3] - P[1]) * ww;
+                    const float dl = (w[12 + 2 * cg + 1] != 0.f ? Lt[1] : 0.f) - (w[12 + 2 * cg] != 0.f ? Lt[0] : 0.f);
+                    const float dc = dco[sl * VS_STRIDE + ql];
+                    float gx = dc * lv * dpx * fr[3], gy = dc * lv * dpy * fr[4], gl = dc * pv * dl * fr[5];
+                    // lanes of one wavefront half belong to the same (sample, component) only for the 64-channel component; reduce
+                    // with LDS float atomics (3 per lane) -- 96 lanes x 32 samples per tile
+                    const int* ta = tax + (sl * 3 + cg) * 3;
+                    atomicAdd(&dpt[sl * 3 + ta[0]], gx);
+                    atomicAdd(&dpt[sl * 3 + ta[1]], gy);
+                    atomicAdd(&dpt[sl * 3 + ta[2]], gl);
+                }
             }
         }
         __syncthreads();
@@ -310,6 +345,7 @@ __global__ __launch_bounds__(256) void k_voxel_sample_bwd(const GridParams g, co
                 unsafeAtomicAdd(q_ptr[m] + tix[sl * VSB_TAPS + q_slot[m]], dco[sl * VS_STRIDE + c] * other * w);
             }
         }
+        if (d_pts && tid < VS_SAMPLES * 3 && s0 + tid / 3 < n) d_pts[(s0 + tid / 3) * 3 + tid % 3] = dpt[tid];
         if (gg.basis) {
 #pragma unroll
             for (int q = 0; q < NB; ++q) {
@@ -560,10 +596,11 @@ int launch_voxel_sample(const GridParams& g, bool half_grids, const float* pts, 
     return EVD_OK;
 }
 
-int launch_voxel_sample_bwd(const GridParams& g, const float* pts, long n, const float* d_out, int d_stride, int d_col, const GridGrads& gg, hipStream_t st) {
+int launch_voxel_sample_bwd(const GridParams& g, const float* pts, long n, const float* d_out, int d_stride, int d_col, const GridGrads& gg,
+                            float* d_pts, hipStream_t st) {
     if (g.app_dim > VSB_MAXF) return fail(EVD_E_INVALID, "evd_voxel_sample_bwd: app_dim %d > %d", g.app_dim, VSB_MAXF);
     const long tiles = cdiv(n, VS_SAMPLES);
-    k_voxel_sample_bwd<<<(unsigned)(tiles < 2048 ? tiles : 2048), 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg);
+    k_voxel_sample_bwd<<<(unsigned)(tiles < 2048 ? tiles : 2048), 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }

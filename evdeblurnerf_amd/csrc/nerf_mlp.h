@@ -28,6 +28,7 @@ constexpr int PE_KS = (3 * PE_L + 2 + 7) / 8;    // 4 k-steps hold the 63-wide p
 constexpr int PEV_KS = (3 * PE_LV + 2 + 7) / 8;  // 2 k-steps hold the 27-wide direction encoding
 
 __host__ __device__ constexpr int phi(int kk) { return 8 * ((kk & 7) >> 2) + 4 * (kk >> 3) + (kk & 3); }
+__host__ __device__ constexpr int phi_inv(int p) { return (p & 3) | ((p >> 3) << 2) | (((p >> 2) & 1) << 3); }
 
 // source column of the reference PE vector ([x, sin(x f0), cos(x f0), ...], networks/embedding.py:88-98)
 // for arrangement position (q, h); -1 = zero padding

@@ -37,7 +37,8 @@ int launch_points(const float* rb, int nc, const float* z, long n, int S, float*
 int launch_merge_features(const float* old, const float* fresh, const int* order, long R, int S, int N, int F, float* out, int out_stride,
                           hipStream_t st);
 int launch_voxel_sample(const GridParams& g, bool half_grids, const float* pts, long n, float* out, int out_stride, int out_col, hipStream_t st);
-int launch_voxel_sample_bwd(const GridParams& g, const float* pts, long n, const float* d_out, int d_stride, int d_col, const GridGrads& gg, hipStream_t st);
+int launch_voxel_sample_bwd(const GridParams& g, const float* pts, long n, const float* d_out, int d_stride, int d_col, const GridGrads& gg,
+                            float* d_pts, hipStream_t st);
 int launch_tv_bwd(const float* x, int H, int W, int C, const float* d_loss, float weight, float* grad, hipStream_t st);
 int launch_f32_to_f16(const float* x, long n, _Float16* y, hipStream_t st);
 int launch_tv(const float* x, int H, int W, int C, double* partials, int* blocks, hipStream_t st);

@@ -15,8 +15,10 @@ namespace evd {
 template <int HD, int G, int FT> struct VStore {
     static constexpr int KS = HD / 16, KF = FT / 16, GT = (G + 31) / 32;
     static constexpr int IN0 = 0, DIRPE = IN0 + KF + PE_KS, HID = DIRPE + PEV_KS, GEO = HID + KS, C0 = GEO + 2 * GT, C1 = C0 + KS, FWD_END = C1 + KS;
-    static constexpr int G_COL = FWD_END, G_SIG = G_COL + 1, D_C1 = G_SIG + 1, D_C0 = D_C1 + KS, D_GEO = D_C0 + KS, D_HID = D_GEO + 2 * GT,
-                         D_FTS = D_HID + KS, TILE_FRAGS = D_FTS + 2 * ((FT + 31) / 32);
+    // gradient slots; D_GEO is followed by the 2 direction-encoding gradient fragments, D_FTS by the 4 point-encoding ones (both
+    // produced by the same dgrad layer as their neighbours, in the encodings' own fragment arrangement)
+    static constexpr int G_COL = FWD_END, G_SIG = G_COL + 1, D_C1 = G_SIG + 1, D_C0 = D_C1 + KS, D_GEO = D_C0 + KS, D_DIRPE = D_GEO + 2 * GT,
+                         D_HID = D_DIRPE + PEV_KS, D_FTS = D_HID + KS, D_PE = D_FTS + 2 * ((FT + 31) / 32), TILE_FRAGS = D_PE + PE_KS;
     static constexpr long TILE_BYTES = (long)TILE_FRAGS * 1024;
 };
 

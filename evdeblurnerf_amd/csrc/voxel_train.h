@@ -35,6 +35,9 @@ struct VoxBwdPlan {
     int wgrad_blocks;
     float* d_fts;                       // [nsamp, d_fts_stride] float32 out, or null
     int d_fts_stride;
+    const float *pts, *viewdirs;        // the forward's inputs (for the encodings' derivatives)
+    int vd_stride, S;
+    float *d_pts, *d_dirs;              // [nsamp, 3] float32 out (through PE(pts) / PE(dirs) only), or null
     VoxBwdGrads grads;
 };
 

@@ -22,8 +22,8 @@ def _np32(v):
 
 class _Raw2Outputs(torch.autograd.Function):
     """raw2outputs as an autograd node (C = 4, three colours): forward = evd_raw2outputs, backward = evd_raw2outputs_bwd
-    (the forward quantities are recomputed in the backward kernel; z / rays_d get no gradient, as in the reference where
-    the sample positions are detached)."""
+    (the forward quantities are recomputed in the backward kernel; z gets no gradient, as in the reference where the sample
+    positions are detached; rays_d gets the one through dists = dz |rays_d| when it requires grad, relu density only)."""
 
     @staticmethod
     def forward(ctx, raw, z, rd, noise, sigma_ch, rgb_ch0, rgb_act, sigma_act, white_bkgd, thr):
@@ -52,7 +52,17 @@ class _Raw2Outputs(torch.autograd.Function):
         L.check(L.lib().evd_raw2outputs_bwd(L.ptr(raw), L.ptr(z), L.ptr(rd), rd.shape[-1], R, S, Cc, sigma_ch, rgb_ch0, 3, rgb_act, sigma_act,
                                             white, thr, L.ptr(noise) if has_noise else None, L.ptr(c(g_rgb)), L.ptr(c(g_depth)),
                                             L.ptr(c(g_acc)), L.ptr(c(g_wts)), L.ptr(d_raw), L.stream_ptr()), "evd_raw2outputs_bwd")
-        return (d_raw,) + (None,) * 9
+        d_rd = None
+        if ctx.needs_input_grad[2]:
+            # alpha_i depends on sigma_i dz_i |d| only: d / d|d| = sum_i (d loss / d sigma_i) sigma_i / |d|, with relu
+            # d loss / d sigma_i = d_raw[i, sigma] wherever sigma_i > 0 (and both sides vanish elsewhere)
+            if sigma_act != L.ACT["relu"]:
+                raise NotImplementedError("rays_d gradient through raw2outputs is built for sigma_activate relu")
+            pre = raw[..., :-1, sigma_ch] + (noise if has_noise else 0.)
+            nrm = rd.norm(dim=-1, keepdim=True)
+            d_nrm = (d_raw[..., :-1, sigma_ch] * torch.relu(pre)).sum(-1, keepdim=True) / nrm
+            d_rd = d_nrm * rd / nrm
+        return (d_raw, None, d_rd) + (None,) * 7
 
 
 class _NerfMLP(torch.autograd.Function):

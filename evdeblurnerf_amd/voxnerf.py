@@ -41,9 +41,10 @@ class _VoxelSample(torch.autograd.Function):
         net, pts = ctx.net, ctx.pts.reshape(-1, 3).contiguous().float()
         g = d_out.reshape(-1, net.app_dim).contiguous().float()
         grads, gs = _grid_grads(net, ctx.saved_tensors)
-        L.check(L.lib().evd_voxel_sample_bwd(net._h, L.ptr(pts), pts.shape[0], L.ptr(g), net.app_dim, 0, C.byref(gs), L.stream_ptr()),
+        d_pts = torch.empty_like(pts) if ctx.needs_input_grad[0] else None
+        L.check(L.lib().evd_voxel_sample_bwd(net._h, L.ptr(pts), pts.shape[0], L.ptr(g), net.app_dim, 0, C.byref(gs), L.ptr(d_pts), L.stream_ptr()),
                 "evd_voxel_sample_bwd")
-        return (None, None, *grads)
+        return (d_pts.reshape(ctx.pts.shape) if d_pts is not None else None, None, *grads)
 
 
 class _VoxelMLP(torch.autograd.Function):
@@ -54,15 +55,18 @@ class _VoxelMLP(torch.autograd.Function):
     def forward(ctx, flat, fts, pts, viewdirs, net, precision):
         raw, store = net.mlpforward_train(pts, viewdirs, fts, precision)
         ctx.net, ctx.precision, ctx.store, ctx.raw = net, precision, store, raw
-        ctx.need_fts = fts.requires_grad
-        ctx.ft_shape = fts.shape
+        ctx.ft_shape, ctx.pts, ctx.viewdirs = fts.shape, pts, viewdirs
         return raw
 
     @staticmethod
     def backward(ctx, d_raw):
-        gflat, d_fts = ctx.net.mlp_backward_flat(d_raw, ctx.raw, ctx.store, ctx.precision, want_fts=ctx.need_fts)
+        need = ctx.needs_input_grad
+        gflat, d_fts, d_pts, d_dirs = ctx.net.mlp_backward_flat(d_raw, ctx.raw, ctx.store, ctx.precision, want_fts=need[1],
+                                                                pts=ctx.pts if need[2] else None, viewdirs=ctx.viewdirs if need[3] else None)
         ctx.store = ctx.raw = None
-        return gflat, (d_fts.reshape(ctx.ft_shape) if d_fts is not None else None), None, None, None, None
+        R, S = ctx.pts.shape[:2]
+        return (gflat, d_fts.reshape(ctx.ft_shape) if d_fts is not None else None, d_pts.reshape(ctx.pts.shape) if d_pts is not None else None,
+                d_dirs.reshape(R, S, 3).sum(1) if d_dirs is not None else None, None, None)
 
 
 class _VoxelTV(torch.autograd.Function):
@@ -214,7 +218,9 @@ class VoxelNeRFBase:
                                              R, S, L.ptr(raw), L.ptr(store), nb, L.stream_ptr()), "evd_voxel_mlp_train")
         return raw, store
 
-    def mlp_backward_flat(self, d_raw, raw, store, precision=None, want_fts=True):
+    def mlp_backward_flat(self, d_raw, raw, store, precision=None, want_fts=True, pts=None, viewdirs=None):
+        """-> (flat parameter gradient, d fts | None, d pts | None, d dirs per sample | None); the last two (through the positional
+        encodings) are computed when the forward's pts / viewdirs are passed"""
         g = d_raw.contiguous().float()
         R, S = g.shape[:2]
         blocks = self.param_blocks()
@@ -227,9 +233,14 @@ class VoxelNeRFBase:
         d_fts = torch.zeros((R * S, self.ft_dim), dtype=torch.float32, device=g.device) if want_fts else None
         nb = int(L.lib().evd_voxel_backward_workspace_bytes())
         ws = torch.empty((nb,), dtype=torch.uint8, device=g.device)
+        p = pts.contiguous().float() if pts is not None else None
+        vd = viewdirs.contiguous().float() if viewdirs is not None else None
+        d_pts = torch.empty((R * S, 3), dtype=torch.float32, device=g.device) if p is not None else None
+        d_dirs = torch.empty((R * S, 3), dtype=torch.float32, device=g.device) if vd is not None else None
         L.check(L.lib().evd_voxel_mlp_backward(self._h, L.PREC[precision or self.precision], L.ptr(g), L.ptr(raw), R, S, L.ptr(store), store.numel(),
-                                                C.byref(gs), L.ptr(d_fts), self.ft_dim, L.ptr(ws), nb, L.stream_ptr()), "evd_voxel_mlp_backward")
-        return flat, d_fts
+                                                C.byref(gs), L.ptr(d_fts), self.ft_dim, L.ptr(p), L.ptr(vd), vd.shape[-1] if vd is not None else 0,
+                                                L.ptr(d_pts), L.ptr(d_dirs), L.ptr(ws), nb, L.stream_ptr()), "evd_voxel_mlp_backward")
+        return flat, d_fts, d_pts, d_dirs
 
     def mlp_train(self, flat, pts, viewdirs, fts, precision=None):
         """raw [R,S,4] = (sigma, sigmoid(colour)) with autograd to the flat parameters and to the sampled features"""

@@ -241,7 +241,9 @@ int evd_voxel_tv_loss(const evd_voxel* v, float* out, void* stream);
  * (sigma, sigmoid(colour)), every layer's activations kept in `store` (evd_voxel_train_store_bytes).
  * evd_voxel_mlp_backward: d_raw, raw dev [R,S,4] -> parameter gradients (overwritten) and d_fts dev [R*S, d_fts_stride]
  * (columns 0 .. ft_dim-1 overwritten; NULL = not wanted), the gradient of the sampled features that evd_voxel_sample_bwd
- * scatters into the grids.  Built for EVD_PREC_F16 / EVD_PREC_BF16, both shipped levels (64/15/32 and 256/128/64). */
+ * scatters into the grids.  d_pts / d_dirs dev [R*S, 3] (NULL = not wanted; need the forward's pts / viewdirs): the gradient
+ * that reaches the sample position through PE(pts) and the view direction through PE(dirs) (per sample: the caller sums over a
+ * ray's samples) -- what carries the loss back to the rays, i.e. to the blur kernel's camera motion.  Built for EVD_PREC_F16 / EVD_PREC_BF16, both shipped levels (64/15/32 and 256/128/64). */
 typedef struct { float *sigma_w[2], *color_w[3], *color_b[3]; } evd_voxel_grads;
 long evd_voxel_param_count(const evd_voxel* v);
 int evd_voxel_param_blocks(const evd_voxel* v, long* offsets, int capacity);
@@ -251,7 +253,8 @@ size_t evd_voxel_backward_workspace_bytes(void);
 int evd_voxel_mlp_train(const evd_voxel* v, int precision, const float* pts, const float* viewdirs, int vd_stride, const float* fts,
                         int ft_stride, long R, int S, float* raw, void* store, size_t store_bytes, void* stream);
 int evd_voxel_mlp_backward(const evd_voxel* v, int precision, const float* d_raw, const float* raw, long R, int S, void* store,
-                           size_t store_bytes, const evd_voxel_grads* grads, float* d_fts, int d_fts_stride, void* workspace,
+                           size_t store_bytes, const evd_voxel_grads* grads, float* d_fts, int d_fts_stride, const float* pts,
+                           const float* viewdirs, int vd_stride, float* d_pts, float* d_dirs, void* workspace,
                            size_t workspace_bytes, void* stream);
 
 /* ---- training the PDRF grids (scatter-add into the tri-planes) -----------------------------------------
@@ -268,9 +271,10 @@ int evd_voxel_load_grids(evd_voxel* v, const float* const* plane, const float* c
 /* Backward of evd_voxel_sample (VoxelNeRFBase.sample / compute_appfeature, voxnerf.py:132-151,203-208; app_actfn none):
  * d_out dev rows of d_stride floats, the app_dim gradient columns start at d_col -> gradients ADDED into g (caller zeroes;
  * NULL = not wanted) with float32 hardware atomics; like the reference's grid_sample backward (voxnerf.py:144) the summation
- * order is not deterministic. */
+ * order is not deterministic.  d_pts dev [n,3] (NULL = not wanted) is OVERWRITTEN with d loss / d pts through the bilinear /
+ * linear interpolation weights (ATen grid_sample backward semantics: taps outside the grid contribute nothing). */
 int evd_voxel_sample_bwd(const evd_voxel* v, const float* pts, long n, const float* d_out, int d_stride, int d_col,
-                         const evd_voxel_grid_grads* g, void* stream);
+                         const evd_voxel_grid_grads* g, float* d_pts, void* stream);
 /* d_loss[0] * d TV_loss_app / d grid added into g (voxnerf.py:126-130, 306-324); d_loss is a DEVICE scalar (no host sync) */
 int evd_voxel_tv_loss_bwd(const evd_voxel* v, const float* d_loss, const evd_voxel_grid_grads* g, void* stream);
 

@@ -295,14 +295,16 @@ def test_triplane_sample_and_tv_backward_match_torch_autograd():
     n = 5000
     pts = (rs.uniform(-1.8, 1.8, (n, 3)) * np.array([1.0, 1.0, 0.7])).astype(np.float32)       # some outside the box (zero padding)
     wgt = rs.normal(size=(n, 32)).astype(np.float32)
-    out = net.sample_train(torch.tensor(pts, device="cuda"), grids)
+    pts_t = torch.tensor(pts, device="cuda", requires_grad=True)
+    out = net.sample_train(pts_t, grids)
     tv = net.tv_loss_train(grids)
     loss = (out * torch.tensor(wgt, device="cuda")).sum() + 3.0 * tv
     loss.backward()
     planes = [torch.tensor(np.asarray(sd[f"app_plane.{i}"]), dtype=torch.float64, requires_grad=True) for i in range(3)]
     lines = [torch.tensor(np.asarray(sd[f"app_line.{i}"]), dtype=torch.float64, requires_grad=True) for i in range(3)]
     basis = torch.tensor(np.asarray(sd["basis_mat.weight"]), dtype=torch.float64, requires_grad=True)
-    ref = _torch_appfeature(planes, lines, basis, torch.tensor(pts, dtype=torch.float64), AABB)
+    p64 = torch.tensor(pts, dtype=torch.float64, requires_grad=True)
+    ref = _torch_appfeature(planes, lines, basis, p64, AABB)
     assert (out.detach().cpu().double() - ref).abs().max().item() < 1e-5
     rtv = sum(_torch_tv(planes[i]) * 1e-2 + _torch_tv(lines[i]) * 1e-3 for i in range(3))
     ((ref * torch.tensor(wgt, dtype=torch.float64)).sum() + 3.0 * rtv).backward()
@@ -310,6 +312,7 @@ def test_triplane_sample_and_tv_backward_match_torch_autograd():
         assert rel_l2(grids[i].grad.cpu().double(), planes[i].grad[0].permute(1, 2, 0)) < 1e-5, f"plane {i}"
         assert rel_l2(grids[3 + i].grad.cpu().double(), lines[i].grad[0, :, :, 0].t()) < 1e-5, f"line {i}"
     assert rel_l2(grids[6].grad.cpu().double(), basis.grad) < 1e-5
+    assert rel_l2(pts_t.grad.cpu().double(), p64.grad) < 1e-4, "d pts through the interpolation weights"
     # one optimizer step: the library sees the new grids on the next call
     with torch.no_grad():
         for g in grids:
@@ -373,7 +376,8 @@ def test_pdrf_level_networks_backward_match_torch_autograd(level, prec, tol):
     dev = "cuda"
     flat = net.flat_params(sd)
     ft_t = torch.tensor(fts, device=dev, requires_grad=True)
-    raw = net.mlp_train(flat, torch.tensor(pts, device=dev), torch.tensor(vd, device=dev), ft_t)
+    pts_t, vd_t = torch.tensor(pts, device=dev, requires_grad=True), torch.tensor(vd, device=dev, requires_grad=True)
+    raw = net.mlp_train(flat, pts_t, vd_t, ft_t)
     store = raw.grad_fn.store
     # the fused inference forward of the same level (render path) agrees to the mode's rounding
     (raw * torch.tensor(d_raw, device=dev)).sum().backward()
@@ -384,14 +388,15 @@ def test_pdrf_level_networks_backward_match_torch_autograd(level, prec, tol):
     GEO = HID + KS
     C0 = GEO + 2 * GT
     C1 = C0 + KS
-    TILE_FRAGS = C1 + KS + 2 + KS + KS + 2 * GT + KS + 2 * ((FT + 31) // 32)
+    TILE_FRAGS = C1 + KS + 2 + KS + KS + (2 * GT + 2) + KS + (2 * ((FT + 31) // 32) + 4)        # VStore: + d PE(dirs), + d PE(pts) fragments
     dt = torch.float16 if prec == "f16" else torch.bfloat16
     masks = {"hid": (vdecode(store, n, TILE_FRAGS, HID, KS, dt) > 0).cpu().double(),
              "c0": (vdecode(store, n, TILE_FRAGS, C0, KS, dt) > 0).cpu().double(),
              "c1": (vdecode(store, n, TILE_FRAGS, C1, KS, dt) > 0).cpu().double()}
     ref = TorchVoxLevel(sd)
-    p64 = torch.tensor(pts, dtype=torch.float64).reshape(-1, 3)
-    d64 = torch.tensor(np.repeat(vd[:, None], S, 1), dtype=torch.float64).reshape(-1, 3)
+    p64 = torch.tensor(pts, dtype=torch.float64).reshape(-1, 3).requires_grad_(True)
+    v64 = torch.tensor(vd, dtype=torch.float64, requires_grad=True)
+    d64 = v64[:, None].expand(-1, S, -1).reshape(-1, 3)
     f64 = torch.tensor(fts, dtype=torch.float64).reshape(-1, FT).requires_grad_(True)
     rraw = ref(p64, d64, f64, masks=masks)
     assert (raw.detach().reshape(n, 4).cpu().double() - rraw).abs().max().item() < (2e-2 if prec == "f16" else 1.5e-1)
@@ -399,6 +404,8 @@ def test_pdrf_level_networks_backward_match_torch_autograd(level, prec, tol):
     got = net.unflatten(flat.grad)
     errs = {k: rel_l2(v.cpu().double(), ref.p[k.replace(".", "_")].grad) for k, v in got.items()}
     errs["fts"] = rel_l2(ft_t.grad.reshape(n, FT).cpu().double(), f64.grad)
+    errs["pts (through PE)"] = rel_l2(pts_t.grad.reshape(n, 3).cpu().double(), p64.grad)
+    errs["viewdirs (through PE)"] = rel_l2(vd_t.grad.cpu().double(), v64.grad)
     print(f"[{level} {prec}] worst relative L2 error = {max(errs.values()):.2e}")
     assert max(errs.values()) < tol, {k: f"{v:.1e}" for k, v in errs.items()}
 
@@ -446,7 +453,7 @@ def test_c2f_render_rays_train_end_to_end_gradients():
     pc, pf = model.trainable_parameters(sd)
     R, S, Ni = 96, 24, 16
     rb_np = _c2f_rays(R, 4)
-    rb = torch.tensor(rb_np, device="cuda")
+    rb = torch.tensor(rb_np, device="cuda", requires_grad=True)         # gradients reach the rays too (the blur kernel's camera motion)
     rs = np.random.RandomState(5)
     tgt = rs.uniform(0, 1, (R, 3)).astype(np.float32)
     out = model.render_rays_train(rb, pc, pf, S, Ni)
@@ -455,8 +462,8 @@ def test_c2f_render_rays_train_end_to_end_gradients():
     # float64 pipeline with the same merged sample positions
     z0 = torch.tensor(np.linspace(0.1, 1.7, S)[None].repeat(R, 0), dtype=torch.float64)
     zm = out["z_vals"].detach().cpu().double()
-    o, d = torch.tensor(rb_np[:, None, 0:3], dtype=torch.float64), torch.tensor(rb_np[:, None, 3:6], dtype=torch.float64)
-    vd = torch.tensor(rb_np[:, 8:11], dtype=torch.float64)
+    rb64 = torch.tensor(rb_np, dtype=torch.float64, requires_grad=True)
+    o, d, vd = rb64[:, None, 0:3], rb64[:, None, 3:6], rb64[:, 8:11]
     levels, grids64 = {}, {}
     for name in ("coarse", "fine"):
         pre = f"mlp_{name}."
@@ -492,6 +499,9 @@ def test_c2f_render_rays_train_end_to_end_gradients():
             errs[f"{name}.plane{i}"] = rel_l2(prm["grids"][i].grad.cpu().double(), pl[i].grad[0].permute(1, 2, 0))
             errs[f"{name}.line{i}"] = rel_l2(prm["grids"][3 + i].grad.cpu().double(), li[i].grad[0, :, :, 0].t())
         errs[f"{name}.basis"] = rel_l2(prm["grids"][6].grad.cpu().double(), ba.grad)
+    got_rb = rb.grad.cpu().double()
+    errs["rays_o"], errs["rays_d"], errs["viewdirs"] = (rel_l2(got_rb[:, 0:3], rb64.grad[:, 0:3]), rel_l2(got_rb[:, 3:6], rb64.grad[:, 3:6]),
+                                                        rel_l2(got_rb[:, 8:11], rb64.grad[:, 8:11]))
     print("c2f end-to-end relative L2 errors:", {k: f"{v:.1e}" for k, v in errs.items()})
     assert max(errs.values()) < 0.15, errs
 
