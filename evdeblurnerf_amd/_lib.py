@@ -100,7 +100,7 @@ SIGNATURES = {
     "evd_nerf_train_store_bytes": (_S, [_L]),
     "evd_nerf_mlp_train": (_I, [_vp, _I, _vp, _vp, _L, _I, _vp, _vp, _S, _vp]),
     "evd_nerf_backward_workspace_bytes": (_S, []),
-    "evd_nerf_mlp_backward": (_I, [_vp, _I, _vp, _L, _I, _vp, _S, C.POINTER(NerfGrads), _vp, _S, _vp]),
+    "evd_nerf_mlp_backward": (_I, [_vp, _I, _vp, _L, _I, _vp, _S, C.POINTER(NerfGrads), _vp, _vp, _I, _vp, _vp, _vp, _S, _vp]),
     "evd_voxel_param_count": (_L, [_vp]),
     "evd_voxel_param_blocks": (_I, [_vp, C.POINTER(C.c_long), _I]),
     "evd_voxel_load_params": (_I, [_vp, _vp, _vp]),

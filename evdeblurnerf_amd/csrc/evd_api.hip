@@ -155,6 +155,16 @@ int evd_nerf_create(const evd_nerf_desc* d, evd_nerf** out) {
         if (!rc) rc = put(EVD_BWD_HEAD, [&](StreamBuilder& b) {
             b.layer_transposed(feature_w, W, W, 0, W, alpha_w, 1, T, KS + 1, true, [&](int j, int kk) { return j < KS ? hid_col(j, kk) : (kk == 0 ? W : -1); });
         });
+        // encoding rows (for the gradient w.r.t. the rays): output row idx <-> encoding column so that the output fragments come out in
+        // the encoding's own arrangement (fragment j, position kk <-> pe_src_col(L, 8 j + (kk & 7), kk >> 3))
+        auto enc_row = [](int L_, int idx) { const int j = idx / 16, kk = phi_inv(idx % 16); return pe_src_col(L_, 8 * j + (kk & 7), kk >> 3); };
+        auto enc_layer = [&](StreamBuilder& b, const float* Wm, int in_dim, int col0, int L_, int tiles, int ksteps) {
+            b.layer_at(tiles, ksteps, true, [&](int t, int r) { const int c = enc_row(L_, 32 * t + r); return c < 0 ? -1 : col0 + c; }, hid_col,
+                       [=](int r, int c) { return Wm + (size_t)c * in_dim + r; });
+        };
+        if (!rc) rc = put(EVD_BWD_PE0, [&](StreamBuilder& b) { enc_layer(b, pts_w(0), IC, 0, PE_L, 2, KS); });
+        if (!rc && d->skip >= 0 && d->skip + 1 < D) rc = put(EVD_BWD_PESKIP, [&](StreamBuilder& b) { enc_layer(b, pts_w(d->skip + 1), W + IC, 0, PE_L, 2, KS); });
+        if (!rc) rc = put(EVD_BWD_DIR, [&](StreamBuilder& b) { enc_layer(b, views_w, W + ICV, W, PE_LV, 1, KS / 2); });
         for (int l = 1; l < D && !rc; ++l) {
             const bool wide = l - 1 == d->skip;
             rc = put(EVD_BWD_HIDDEN1 + l - 1, [&](StreamBuilder& b) { b.layer_transposed(pts_w(l), W, wide ? W + IC : W, wide ? IC : 0, W, nullptr, 0, T, KS, true, hid_col); });

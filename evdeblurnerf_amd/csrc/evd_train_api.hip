@@ -43,7 +43,9 @@ static const int WGRAD_BLOCKS = 256;
 size_t evd_nerf_backward_workspace_bytes(void) { return (size_t)WGRAD_BLOCKS * 8 * 9 * 4096 + 512; }
 
 int evd_nerf_mlp_backward(const evd_nerf* net, int precision, const float* d_raw, long R, int S, void* store, size_t store_bytes,
-                          const evd_nerf_grads* grads, void* workspace, size_t workspace_bytes, void* stream) {
+                          const evd_nerf_grads* grads, const float* pts, const float* viewdirs, int vd_stride, float* d_pts, float* d_dirs,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+    EVD_REQUIRE((!d_pts || pts) && (!d_dirs || viewdirs), "evd_nerf_mlp_backward: d_pts / d_dirs need the forward's pts / viewdirs");
     EVD_REQUIRE(net && d_raw && store && grads && workspace, "evd_nerf_mlp_backward: null argument");
     EVD_REQUIRE(precision >= 0 && precision < EVD_NUM_PREC && train_built(net, precision),
                 "evd_nerf_mlp_backward: the training path is built for precision f16 / bf16 on the netdepth 8, netwidth 256, skips [4] network");
@@ -62,6 +64,7 @@ int evd_nerf_mlp_backward(const evd_nerf* net, int precision, const float* d_raw
     b.maxbits = (unsigned*)w;
     b.partial = (float*)(w + 256);
     b.wgrad_blocks = WGRAD_BLOCKS; b.skip = net->skip;
+    b.pts = pts; b.viewdirs = viewdirs; b.vd_stride = vd_stride; b.S = S; b.d_pts = d_pts; b.d_dirs = d_dirs;
     for (int l = 0; l < EVD_MAX_LAYERS; ++l) { b.grads.pts_w[l] = l < net->D ? grads->pts_w[l] : nullptr; b.grads.pts_b[l] = l < net->D ? grads->pts_b[l] : nullptr; }
     b.grads.views_w = grads->views_w; b.grads.views_b = grads->views_b; b.grads.feature_w = grads->feature_w; b.grads.feature_b = grads->feature_b;
     b.grads.alpha_w = grads->alpha_w; b.grads.alpha_b = grads->alpha_b; b.grads.rgb_w = grads->rgb_w; b.grads.rgb_b = grads->rgb_b;

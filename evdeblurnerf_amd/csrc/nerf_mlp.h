@@ -66,7 +66,8 @@ constexpr int PE = 0, DIR = 4, H0 = 6;                    // H_l at H0 + 16 l: t
 constexpr int F = H0 + 16 * 8, HV = F + 16, FWD_END = HV + 8;   // feature_linear output, views hidden
 constexpr int G_RGB = FWD_END, G_ALPHA = G_RGB + 1;       // d raw as two single-k-step fragments
 constexpr int D_HV = G_ALPHA + 1, D_F = D_HV + 8, D_H0 = D_F + 16;    // d loss / d pre-activation of hv, feature, h_l (at D_H0 + 16 l)
-constexpr int TILE_FRAGS = D_H0 + 16 * 8;
+constexpr int D_PE0 = D_H0 + 16 * 8, D_PE5 = D_PE0 + PE_KS, D_DIRG = D_PE5 + PE_KS;   // d PE(pts) via pts_linears[0] / the skip layer, d PE(dirs): the encodings' own arrangement
+constexpr int TILE_FRAGS = D_DIRG + PEV_KS;
 constexpr long TILE_BYTES = (long)TILE_FRAGS * 1024;
 }  // namespace astore
 

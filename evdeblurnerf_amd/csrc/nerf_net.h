@@ -5,7 +5,7 @@
 #include "pack.h"
 
 // transposed-weight streams of the dgrad chain (nerf_train_kernel.h), in the order the chain runs them
-enum { EVD_BWD_RGB = 0, EVD_BWD_VIEWS, EVD_BWD_HEAD, EVD_BWD_HIDDEN1, EVD_BWD_NSTREAMS = EVD_BWD_HIDDEN1 + EVD_MAX_LAYERS };
+enum { EVD_BWD_RGB = 0, EVD_BWD_VIEWS, EVD_BWD_HEAD, EVD_BWD_PE0, EVD_BWD_PESKIP, EVD_BWD_DIR, EVD_BWD_HIDDEN1, EVD_BWD_NSTREAMS = EVD_BWD_HIDDEN1 + EVD_MAX_LAYERS };
 
 struct evd_nerf {
     typedef evd::PackedStream Packed;

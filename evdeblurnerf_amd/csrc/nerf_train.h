@@ -34,6 +34,9 @@ struct BwdPlan {
     unsigned* maxbits;
     int wgrad_blocks, skip;
     BwdGrads grads;
+    const float *pts, *viewdirs;        // [nsamp,3] sample positions / rows of vd_stride floats per ray (the encodings' derivatives)
+    int vd_stride, S;
+    float *d_pts, *d_dirs;              // [nsamp,3] float32 out (through the positional encodings), or null
 };
 
 int run_nerf_backward_f16(const BwdPlan& b, hipStream_t st);

@@ -318,6 +318,51 @@ static int launch_wgrad(const WgradParams& p, int blocks, hipStream_t st) {
     return EVD_OK;
 }
 
+// Gradient of a positional encoding (embedding.py:88-98) from its gradient fragments (KSN fragments at `slot`, the encoding's own
+// arrangement: position q = 8 j + e holds, for q < 3 L, d sin (lane half 0) / d cos (half 1) of x_{q % 3} 2^{q / 3}; q = 3 L:
+// (d x_0 | d x_1); q = 3 L + 1: (d x_2 | -)) -> d x rows [n, 3] float32, loss scale removed.  x: rows of x_stride floats,
+// one per `per` samples (1: points; S: the ray's view direction).
+template <int PREC, int L, int KSN>
+__global__ __launch_bounds__(256) void k_pe_bwd(const char* __restrict__ store, long tile_bytes, int slot, long nsamp, const float* __restrict__ x,
+                                                int x_stride, int per, const unsigned* __restrict__ maxbits, float* __restrict__ dx, int accumulate) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x, tile = idx >> 6;
+    const int lane = idx & 63, n = lane & 31, h = lane >> 5;
+    const long smp = tile * 32 + n;
+    if (tile * 32 >= nsamp) return;
+    const long sc = smp < nsamp ? smp : nsamp - 1;
+    float xv[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) xv[c] = x[(sc / per) * x_stride + c];
+    float g[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < KSN; ++j) {
+        const W4 f = frag_load<W4>(store + tile * tile_bytes + lane * 16, slot + j);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int q = 8 * j + e;
+            const unsigned short bits = (unsigned short)(f.w[e >> 1] >> (16 * (e & 1)));
+            float v;
+            if constexpr (PREC == EVD_PREC_BF16) v = __uint_as_float((unsigned)bits << 16);
+            else v = (float)__builtin_bit_cast(_Float16, bits);
+            if (q < 3 * L) {
+                const float fr = (float)(1 << (q / 3)), a = xv[q % 3] * fr;
+                g[q % 3] += h == 0 ? v * cosf(a) * fr : -v * sinf(a) * fr;
+            } else if (q == 3 * L) {
+                g[h] += v;                       // (x_0 | x_1)
+            } else if (q == 3 * L + 1 && h == 0) {
+                g[2] += v;
+            }
+        }
+    }
+    const float inv = grad_scale(*maxbits, true);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) g[c] = (g[c] + __shfl_xor(g[c], 32)) * inv;
+    if (h == 0 && smp < nsamp) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dx[smp * 3 + c] = accumulate ? dx[smp * 3 + c] + g[c] : g[c];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // The whole backward of one network, in the order the gradients become available.
 template <int PREC> static int run_nerf_backward(const BwdPlan& b, hipStream_t st) {
@@ -369,6 +414,25 @@ template <int PREC> static int run_nerf_backward(const BwdPlan& b, hipStream_t s
         if ((rc = wgrad(launch_wgrad<PREC, 8, 8, false>, 8, 8, true, D_H0 + 16 * l, H0 + 16 * (l - 1), MAP_HID, wide ? MAP_HID_SKIP : MAP_HID,
                         g.pts_w[l], wide ? 256 + 63 : 256, g.pts_b[l]))) return rc;
         if (wide && (rc = wgrad(launch_wgrad<PREC, 8, 2, false>, 8, 2, false, D_H0 + 16 * l, PE, MAP_HID, MAP_PE, g.pts_w[l], 256 + 63, nullptr))) return rc;
+    }
+    // gradient w.r.t. the rays: the encoding rows of pts_linears[0], of the skip layer and of views_linears.0, then through sin / cos
+    if (b.d_pts) {
+        if ((rc = launch_dgrad<PREC, 16, 2, 16, false, false>(dgrad(EVD_BWD_PE0, D_H0, -1, -1, D_PE0), b.tiles, st))) return rc;
+        hipLaunchKernelGGL((k_pe_bwd<PREC, PE_L, PE_KS>), dim3((unsigned)cdiv(b.tiles * 64, 256L)), dim3(256), 0, st, (const char*)b.store, TILE_BYTES, D_PE0,
+                           b.nsamp, b.pts, 3, 1, b.maxbits, b.d_pts, 0);
+        EVD_LAUNCH_CHECK();
+        if (b.skip >= 0 && b.skip + 1 < D) {
+            if ((rc = launch_dgrad<PREC, 16, 2, 16, false, false>(dgrad(EVD_BWD_PESKIP, D_H0 + 16 * (b.skip + 1), -1, -1, D_PE5), b.tiles, st))) return rc;
+            hipLaunchKernelGGL((k_pe_bwd<PREC, PE_L, PE_KS>), dim3((unsigned)cdiv(b.tiles * 64, 256L)), dim3(256), 0, st, (const char*)b.store, TILE_BYTES, D_PE5,
+                               b.nsamp, b.pts, 3, 1, b.maxbits, b.d_pts, 1);
+            EVD_LAUNCH_CHECK();
+        }
+    }
+    if (b.d_dirs) {
+        if ((rc = launch_dgrad<PREC, 8, 1, 8, false, false>(dgrad(EVD_BWD_DIR, D_HV, -1, -1, D_DIRG), b.tiles, st))) return rc;
+        hipLaunchKernelGGL((k_pe_bwd<PREC, PE_LV, PEV_KS>), dim3((unsigned)cdiv(b.tiles * 64, 256L)), dim3(256), 0, st, (const char*)b.store, TILE_BYTES, D_DIRG,
+                           b.nsamp, b.viewdirs, b.vd_stride, b.S, b.maxbits, b.d_dirs, 0);
+        EVD_LAUNCH_CHECK();
     }
     // pts_linears[0] on PE(pts) (no dgrad beyond the inputs)
     return wgrad(launch_wgrad<PREC, 8, 2, false>, 8, 2, true, D_H0, PE, MAP_HID, MAP_PE, g.pts_w[0], 63, g.pts_b[0]);

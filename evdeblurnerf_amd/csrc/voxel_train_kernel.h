@@ -64,51 +64,6 @@ __global__ __launch_bounds__(256) void k_frags_to_rows(const char* __restrict__ 
     }
 }
 
-// Gradient of a positional encoding (embedding.py:88-98) from its gradient fragments (KSN fragments at `slot`, the encoding's own
-// arrangement: position q = 8 j + e holds, for q < 3 L, d sin (lane half 0) / d cos (half 1) of x_{q % 3} 2^{q / 3}; q = 3 L:
-// (d x_0 | d x_1); q = 3 L + 1: (d x_2 | -)) -> d x rows [n, 3] float32, loss scale removed.  x: rows of x_stride floats,
-// one per `per` samples (1: points; S: the ray's view direction).
-template <int PREC, int L, int KSN>
-__global__ __launch_bounds__(256) void k_pe_bwd(const char* __restrict__ store, long tile_bytes, int slot, long nsamp, const float* __restrict__ x,
-                                                int x_stride, int per, const unsigned* __restrict__ maxbits, float* __restrict__ dx) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x, tile = idx >> 6;
-    const int lane = idx & 63, n = lane & 31, h = lane >> 5;
-    const long smp = tile * 32 + n;
-    if (tile * 32 >= nsamp) return;
-    const long sc = smp < nsamp ? smp : nsamp - 1;
-    float xv[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) xv[c] = x[(sc / per) * x_stride + c];
-    float g[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < KSN; ++j) {
-        const W4 f = frag_load<W4>(store + tile * tile_bytes + lane * 16, slot + j);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int q = 8 * j + e;
-            const unsigned short bits = (unsigned short)(f.w[e >> 1] >> (16 * (e & 1)));
-            float v;
-            if constexpr (PREC == EVD_PREC_BF16) v = __uint_as_float((unsigned)bits << 16);
-            else v = (float)__builtin_bit_cast(_Float16, bits);
-            if (q < 3 * L) {
-                const float fr = (float)(1 << (q / 3)), a = xv[q % 3] * fr;
-                g[q % 3] += h == 0 ? v * cosf(a) * fr : -v * sinf(a) * fr;
-            } else if (q == 3 * L) {
-                g[h] += v;                       // (x_0 | x_1)
-            } else if (q == 3 * L + 1 && h == 0) {
-                g[2] += v;
-            }
-        }
-    }
-    const float inv = grad_scale(*maxbits, true);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) g[c] = (g[c] + __shfl_xor(g[c], 32)) * inv;
-    if (h == 0 && smp < nsamp) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) dx[smp * 3 + c] = g[c];
-    }
-}
-
 template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const VoxBwdPlan& b, hipStream_t st) {
     typedef VStore<HD, G, FT> VS;
     constexpr int T = HD / 32, KS = HD / 16, KF = FT / 16, GT = VS::GT, FTT = (FT + 31) / 32, IC = 3 * (1 + 2 * PE_L), ICV = 3 * (1 + 2 * PE_LV);
@@ -150,7 +105,7 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
     if ((rc = launch_dgrad<PREC, KS, GT + 1, KS, false, false>(dgrad(VBWD_C0, VS::D_C0, -1, -1, VS::D_GEO), b.tiles, st))) return rc;   // d geo | d PE(dirs)
     if (b.d_dirs) {
         hipLaunchKernelGGL((k_pe_bwd<PREC, PE_LV, PEV_KS>), dim3((unsigned)cdiv(b.tiles * 64, 256L)), dim3(256), 0, st, (const char*)b.store, VS::TILE_BYTES,
-                           VS::D_DIRPE, b.nsamp, b.viewdirs, b.vd_stride, b.S, b.maxbits, b.d_dirs);
+                           VS::D_DIRPE, b.nsamp, b.viewdirs, b.vd_stride, b.S, b.maxbits, b.d_dirs, 0);
         EVD_LAUNCH_CHECK();
     }
     if ((rc = wgrad(launch_wgrad<PREC, T, GT, false>, T, GT, true, VS::D_C0, VS::GEO, VMAP_HID, VMAP_GEO_X, g.color_w[0], G + ICV, g.color_b[0]))) return rc;
@@ -169,7 +124,7 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
         }
         if (b.d_pts) {
             hipLaunchKernelGGL((k_pe_bwd<PREC, PE_L, PE_KS>), dim3((unsigned)cdiv(b.tiles * 64, 256L)), dim3(256), 0, st, (const char*)b.store, VS::TILE_BYTES,
-                               VS::D_PE, b.nsamp, b.pts, 3, 1, b.maxbits, b.d_pts);
+                               VS::D_PE, b.nsamp, b.pts, 3, 1, b.maxbits, b.d_pts, 0);
             EVD_LAUNCH_CHECK();
         }
     }

@@ -72,13 +72,26 @@ class _NerfMLP(torch.autograd.Function):
     def forward(ctx, flat, ray_batch, z_vals, net, precision):
         raw, store = net.mlpforward_train(ray_batch, z_vals, precision)
         ctx.net, ctx.precision, ctx.store = net, precision, store
+        ctx.rb, ctx.z = ray_batch, z_vals
         return raw
 
     @staticmethod
     def backward(ctx, d_raw):
-        g = ctx.net.mlp_backward_flat(d_raw, ctx.store, ctx.precision)
+        d_rb = None
+        if ctx.needs_input_grad[1]:
+            # rays: pts = o + d z enters PE(pts) (layer 0 and the skip layer), the view direction PE(dirs); z is a constant
+            rb, z = ctx.rb.detach().contiguous().float(), ctx.z.detach().contiguous().float()
+            pts = (rb[:, None, 0:3] + rb[:, None, 3:6] * z[..., None]).contiguous()
+            g, d_pts, d_dirs = ctx.net.mlp_backward_flat(d_raw, ctx.store, ctx.precision, pts=pts, ray_batch=rb)
+            d_rb = torch.zeros_like(rb)
+            d_pts = d_pts.reshape(pts.shape)
+            d_rb[:, 0:3] = d_pts.sum(1)
+            d_rb[:, 3:6] = (d_pts * z[..., None]).sum(1)
+            d_rb[:, 8:11] = d_dirs.reshape(pts.shape).sum(1)
+        else:
+            g = ctx.net.mlp_backward_flat(d_raw, ctx.store, ctx.precision)
         ctx.store = None
-        return g, None, None, None, None
+        return g, d_rb, None, None, None
 
 
 class NeRF:
@@ -208,7 +221,9 @@ class NeRF:
         return _NerfMLP.apply(flat, ray_batch, z_vals, self, precision or self.precision)
 
     # Backward of mlpforward_train: d_raw [R,S,4] -> flat gradient (what autograd gives for nerf.py:46-72)
-    def mlp_backward_flat(self, d_raw, store, precision=None):
+    def mlp_backward_flat(self, d_raw, store, precision=None, pts=None, ray_batch=None):
+        """flat parameter gradient; with pts [R,S,3] and the ray batch also (flat, d pts [R*S,3], d dirs per sample [R*S,3]), the
+        gradients through the two positional encodings"""
         g = d_raw.contiguous().float()
         R, S = g.shape[:2]
         blocks = self.param_blocks()
@@ -225,9 +240,14 @@ class NeRF:
                 setattr(gs, head + field, base + 4 * off)
         nb = int(L.lib().evd_nerf_backward_workspace_bytes())
         ws = torch.empty((nb,), dtype=torch.uint8, device=g.device)
+        want = pts is not None
+        d_pts = torch.empty((R * S, 3), dtype=torch.float32, device=g.device) if want else None
+        d_dirs = torch.empty((R * S, 3), dtype=torch.float32, device=g.device) if want else None
+        vd = ray_batch[:, 8:11] if want else None              # a strided view: rows of 11 floats
         L.check(L.lib().evd_nerf_mlp_backward(self._h, L.PREC[precision or self.precision], L.ptr(g), R, S, L.ptr(store), store.numel(),
-                                               C.byref(gs), L.ptr(ws), nb, L.stream_ptr()), "evd_nerf_mlp_backward")
-        return flat
+                                               C.byref(gs), L.ptr(pts), C.c_void_p(vd.data_ptr()) if want else None, 11, L.ptr(d_pts), L.ptr(d_dirs),
+                                               L.ptr(ws), nb, L.stream_ptr()), "evd_nerf_mlp_backward")
+        return (flat, d_pts, d_dirs) if want else flat
 
     def mlp_backward(self, d_raw, store, precision=None):
         """... as {state-dict key: gradient}"""

@@ -140,10 +140,13 @@ typedef struct {
  * NeRF.mlpforward (networks/nerf.py:46-72) under loss.backward() (run_nerf.py:1032-1036).  `store` is the one the forward
  * filled (it is consumed: the gradient fragments are written into it).  Arithmetic: MFMA operands in the forward's half
  * precision under a power-of-two loss scale chosen from max |d_raw|, float32 accumulation; the scale is removed before the
- * gradients are written.  workspace: evd_nerf_backward_workspace_bytes() device bytes. */
+ * gradients are written.  d_pts / d_dirs dev [R*S,3] (NULL = not wanted): d loss / d sample position through PE(pts) (both
+ * pts_linears[0] and the skip layer) and / d view direction through PE(dirs), per sample -- they need the forward's positions
+ * pts dev [R*S,3] (= o + d z) and viewdirs (rows of vd_stride floats per ray).  workspace: evd_nerf_backward_workspace_bytes(). */
 size_t evd_nerf_backward_workspace_bytes(void);
 int evd_nerf_mlp_backward(const evd_nerf* net, int precision, const float* d_raw, long R, int S, void* store, size_t store_bytes,
-                          const evd_nerf_grads* grads, void* workspace, size_t workspace_bytes, void* stream);
+                          const evd_nerf_grads* grads, const float* pts, const float* viewdirs, int vd_stride, float* d_pts,
+                          float* d_dirs, void* workspace, size_t workspace_bytes, void* stream);
 
 /* raw2outputs: networks/nerf.py:74-129 (sigma_ch 3, rgb_ch0 0) and networks/pdrf/voxnerf.py:153-201
  * (sigma_ch 0, rgb_ch0 1).  raw dev [R,S,C], z dev [R,S], rays_d dev rows of rays_d_stride floats.

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 # fragment slots of the activation store (csrc/nerf_mlp.h, namespace astore)
 PE, DIR, H0, F, HV, FWD_END = 0, 4, 6, 134, 150, 158
-G_RGB, G_ALPHA, D_HV, D_F, D_H0, TILE_FRAGS = 158, 159, 160, 168, 184, 312
+G_RGB, G_ALPHA, D_HV, D_F, D_H0, TILE_FRAGS = 158, 159, 160, 168, 184, 322
 
 
 def phi(kk):
@@ -527,3 +527,38 @@ def test_c2f_training_iteration_reduces_the_image_loss():
         losses.append(loss.item())
     print("c2f image loss:", " ".join(f"{v:.4f}" for v in losses[::6]), f"-> {losses[-1]:.4f}")
     assert np.isfinite(losses).all() and losses[-1] < 0.5 * losses[0]
+
+
+@pytest.mark.parametrize("prec,tol", [("f16", 4e-3), ("bf16", 3e-2)])
+def test_nerf_mlp_gradients_reach_the_rays(prec, tol):
+    """d loss / d ray batch (origins, directions, view directions) through PE(pts) of layer 0 and the skip layer and PE(dirs),
+    vs float64 autograd with the same ReLU pattern."""
+    from evdeblurnerf_amd.nerf import NeRF
+    sd = W.make_nerf_state_dict(23)
+    R, S = 48, 40
+    rb_np, z_np = make_inputs(R, S, 12)
+    rs = np.random.RandomState(13)
+    wgt = (rs.normal(size=(R, S, 4)) * 1e-2).astype(np.float32)
+    net = NeRF(sd, precision=prec)
+    flat = net.flat_params(sd)
+    rb = torch.tensor(rb_np, device="cuda", requires_grad=True)
+    raw = net.mlp_train(flat, rb, torch.tensor(z_np, device="cuda"))
+    store = raw.grad_fn.store
+    (raw * torch.tensor(wgt, device="cuda")).sum().backward()
+    n = R * S
+    dt = torch.float16 if prec == "f16" else torch.bfloat16
+    masks = {f"h{l}": (decode(store, n, H0 + 16 * l, 16, dt) > 0).cpu().double() for l in range(8)}
+    masks["hv"] = (decode(store, n, HV, 8, dt) > 0).cpu().double()
+    rb64 = torch.tensor(rb_np, dtype=torch.float64, requires_grad=True)
+    z64 = torch.tensor(z_np, dtype=torch.float64)
+    pts = (rb64[:, None, 0:3] + rb64[:, None, 3:6] * z64[..., None]).reshape(-1, 3)
+    dirs = rb64[:, None, 8:11].expand(-1, S, -1).reshape(-1, 3)
+    ref = TorchNerf(sd)
+    (ref(pts, dirs, masks=masks) * torch.tensor(wgt, dtype=torch.float64).reshape(-1, 4)).sum().backward()
+    got = rb.grad.cpu().double()
+    errs = {"rays_o": rel_l2(got[:, 0:3], rb64.grad[:, 0:3]), "rays_d": rel_l2(got[:, 3:6], rb64.grad[:, 3:6]),
+            "viewdirs": rel_l2(got[:, 8:11], rb64.grad[:, 8:11])}
+    assert got[:, 6:8].abs().max().item() == 0.0
+    print(f"[{prec}] ray gradient relative L2 errors: " + ", ".join(f"{k} {v:.1e}" for k, v in errs.items()))
+    assert max(errs.values()) < tol, errs
+    assert rel_l2(flat.grad.cpu().double(), torch.cat([ref.p[k.replace(".", "_")].grad.reshape(-1) for k, _, _ in net.param_blocks()])) < tol
