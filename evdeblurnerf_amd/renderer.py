@@ -257,6 +257,63 @@ class NeRFAll:
         return {"rgb_map": rgb, "depth_map": depth, "acc_map": acc, "weights": w1, "z_vals": zm, "rgb0": rgb0, "depth0": depth0,
                 "acc0": acc0, "z_std": zstd}
 
+    @staticmethod
+    def ray_batch_train(H, W, K, rays, ndc=True, near=0., far=1.):
+        """NeRFAll.render's ray packing (renderer.py:423-446: viewdirs = d / |d| BEFORE the NDC warp of utils/rays.py:104-145 with
+        near plane 1) in differentiable torch arithmetic: rays [R,3,2] -> ray batch [R,11].  Values equal evd_ray_batch to float32
+        rounding; this is what lets the loss reach the blur kernel's warped rays."""
+        o, d = rays[..., 0], rays[..., 1]
+        vd = d / torch.linalg.norm(d, dim=-1, keepdim=True)
+        if ndc:
+            focal = float(K[0][0])
+            cw, ch = -1.0 / (W / (2.0 * focal)), -1.0 / (H / (2.0 * focal))
+            t = -(1.0 + o[..., 2]) / d[..., 2]
+            o = o + t[..., None] * d
+            ox, oy, o2 = o[..., 0] / o[..., 2], o[..., 1] / o[..., 2], 1.0 + 2.0 / o[..., 2]
+            d = torch.stack([cw * (d[..., 0] / d[..., 2] - ox), ch * (d[..., 1] / d[..., 2] - oy), 1.0 - o2], -1)
+            o = torch.stack([cw * ox, ch * oy, o2], -1)
+        nf = torch.tensor([near, far], dtype=o.dtype, device=o.device).expand(o.shape[0], 2)
+        return torch.cat([o, d, nf, vd], -1)
+
+    def forward_train(self, H, W, K, rays, params_coarse, params_fine, rays_info=None, force_naive=True, ndc=True, near=0., far=1.,
+                      N_samples=64, N_importance=0, tv=True, **kw):
+        """The training branch of NeRFAll.forward (renderer.py:266-397) under autograd: [blur kernel -> P warped rays per pixel]
+        -> ray packing -> render_rays_train -> [composition with the kernel's weights] ; returns the reference's
+        (rgb, rgb0, other_loss, other_tensors).  Gradients reach params_coarse / params_fine (trainable_parameters) and, through
+        the rays, the kernelsnet (a PyTorch module, as in the reference).  kw: lindisp, perturb, white_bkgd, raw_noise_std and the
+        explicit random draws of render_rays_train."""
+        other_loss, other_tensors = {}, {}
+        use_kernel = self.kernelsnet is not None and not force_naive
+        if use_kernel:
+            if self.kernel_type != "RBK":
+                raise NotImplementedError("only the RBK kernel of the shipped configs is supported")
+            new_rays, weight1, align_loss, extra1 = self.kernelsnet(H, W, K, rays, rays_info, feats=None, return_img_embed=False)
+            ray_num, pt_num = new_rays.shape[:2]
+            flat_rays = new_rays.reshape(-1, 3, 2)
+        else:
+            flat_rays = rays
+        rb = self.ray_batch_train(H, W, K, flat_rays, ndc, near, far)
+        out = self.render_rays_train(rb, params_coarse, params_fine, N_samples, N_importance, **kw)
+        rgb, rgb0 = out["rgb_map"], out.get("rgb0")
+        if use_kernel:
+            rgb_pts = rgb.reshape(ray_num, pt_num, 3)
+            rgb = (rgb_pts * weight1[..., None]).sum(1)                         # rbk_weighted_sum, blurmodel.py:112-127
+            other_tensors["stage1_rgb_pts0"] = rgb_pts[:, 0]
+            if rgb0 is not None:
+                rgb0_pts = rgb0.reshape(ray_num, pt_num, 3)
+                rgb0 = (rgb0_pts * weight1[..., None]).sum(1)
+                other_tensors["stage1_rgb1_pts0"] = rgb0_pts[:, 0]
+            if align_loss is not None:
+                other_loss["align"] = align_loss.reshape(1, 1)
+            other_tensors.update({f"stage1_{k}": v for k, v in extra1.items()})
+        else:
+            other_tensors["stage1_rgb_pts0"] = rgb
+            if rgb0 is not None:
+                other_tensors["stage1_rgb1_pts0"] = rgb0
+        if tv and self.mode == "c2f":
+            other_loss["TV"] = self.tv_loss_train(params_coarse, params_fine if N_importance > 0 else None)
+        return rgb, rgb0, other_loss, other_tensors
+
     def tv_loss_train(self, pc, pf=None):
         """other_loss['TV'] of the training forward (renderer.py:361-365) with gradients to the grids"""
         tv = self.mlp_coarse.tv_loss_train(pc["grids"])
