@@ -106,8 +106,8 @@ SIGNATURES = {
     "evd_voxel_load_params": (_I, [_vp, _vp, _vp]),
     "evd_voxel_train_store_bytes": (_S, [_vp, _L]),
     "evd_voxel_backward_workspace_bytes": (_S, []),
-    "evd_voxel_mlp_train": (_I, [_vp, _I, _vp, _vp, _I, _vp, _I, _L, _I, _vp, _vp, _S, _vp]),
-    "evd_voxel_mlp_backward": (_I, [_vp, _I, _vp, _vp, _L, _I, _vp, _S, C.POINTER(VoxelGrads), _vp, _I, _vp, _vp, _I, _vp, _vp, _vp, _S, _vp]),
+    "evd_voxel_mlp_train": (_I, [_vp, _I, _vp, _vp, _I, _vp, _I, _L, _I, _vp, _vp, _vp, _S, _vp]),
+    "evd_voxel_mlp_backward": (_I, [_vp, _I, _vp, _vp, _vp, _L, _I, _vp, _S, C.POINTER(VoxelGrads), _vp, _I, _vp, _vp, _I, _vp, _vp, _vp, _S, _vp]),
     "evd_voxel_grid_sizes": (_I, [_vp, C.POINTER(C.c_long)]),
     "evd_voxel_get_grids": (_I, [_vp, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp]),
     "evd_voxel_load_grids": (_I, [_vp, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp]),

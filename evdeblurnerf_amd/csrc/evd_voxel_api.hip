@@ -449,7 +449,7 @@ size_t evd_voxel_train_store_bytes(const evd_voxel* v, long nsamp) {
 size_t evd_voxel_backward_workspace_bytes(void) { return (size_t)VOX_WGRAD_BLOCKS * 8 * 9 * 4096 + 512; }
 
 int evd_voxel_mlp_train(const evd_voxel* v, int precision, const float* pts, const float* viewdirs, int vd_stride, const float* fts, int ft_stride,
-                        long R, int S, float* raw, void* store, size_t store_bytes, void* stream) {
+                        long R, int S, float* raw, float* feature, void* store, size_t store_bytes, void* stream) {
     EVD_REQUIRE(v && pts && viewdirs && fts && raw && store, "evd_voxel_mlp_train: null argument");
     EVD_REQUIRE(precision >= 0 && precision < EVD_NUM_PREC && vox_train_built(v, precision), "evd_voxel_mlp_train: the training path is built for precision f16 / bf16");
     EVD_REQUIRE(R >= 0 && S >= 1 && ft_stride >= v->ft_dim && ft_stride % 4 == 0, "evd_voxel_mlp_train: bad shape");
@@ -460,12 +460,12 @@ int evd_voxel_mlp_train(const evd_voxel* v, int precision, const float* pts, con
     p.wstream = (const char*)v->train[precision].data.p;
     p.bias = (const float*)v->bias.p;
     p.pts = pts; p.viewdirs = viewdirs; p.fts = fts; p.nsamp = nsamp; p.S = S; p.vd_stride = vd_stride; p.ft_stride = ft_stride;
-    p.nchunks = v->train_chunks[precision]; p.nbias = (int)(v->bias.bytes / sizeof(float)); p.raw = raw; p.feature = nullptr; p.act = (char*)store;
+    p.nchunks = v->train_chunks[precision]; p.nbias = (int)(v->bias.bytes / sizeof(float)); p.raw = raw; p.feature = feature; p.act = (char*)store;
     return launch_voxel_train_fwd_dispatch(precision, v->hidden_dim, p, as_stream(stream));
 }
 
-int evd_voxel_mlp_backward(const evd_voxel* v, int precision, const float* d_raw, const float* raw, long R, int S, void* store, size_t store_bytes,
-                           const evd_voxel_grads* grads, float* d_fts, int d_fts_stride, const float* pts, const float* viewdirs, int vd_stride,
+int evd_voxel_mlp_backward(const evd_voxel* v, int precision, const float* d_raw, const float* raw, const float* d_feature, long R, int S, void* store,
+                           size_t store_bytes, const evd_voxel_grads* grads, float* d_fts, int d_fts_stride, const float* pts, const float* viewdirs, int vd_stride,
                            float* d_pts, float* d_dirs, void* workspace, size_t workspace_bytes, void* stream) {
     EVD_REQUIRE((!d_pts || pts) && (!d_dirs || viewdirs), "evd_voxel_mlp_backward: d_pts / d_dirs need the forward's pts / viewdirs");
     EVD_REQUIRE(v && d_raw && raw && store && grads && workspace, "evd_voxel_mlp_backward: null argument");
@@ -476,7 +476,7 @@ int evd_voxel_mlp_backward(const evd_voxel* v, int precision, const float* d_raw
     if (store_bytes < evd_voxel_train_store_bytes(v, nsamp)) return fail(EVD_E_WORKSPACE, "evd_voxel_mlp_backward: store %zu < %zu bytes", store_bytes, evd_voxel_train_store_bytes(v, nsamp));
     if (workspace_bytes < evd_voxel_backward_workspace_bytes()) return fail(EVD_E_WORKSPACE, "evd_voxel_mlp_backward: workspace %zu < %zu bytes", workspace_bytes, evd_voxel_backward_workspace_bytes());
     VoxBwdPlan b;
-    b.d_raw = d_raw; b.raw = raw; b.nsamp = nsamp; b.tiles = vox_tiles(nsamp); b.store = (char*)store;
+    b.d_raw = d_raw; b.raw = raw; b.d_feature = d_feature; b.nsamp = nsamp; b.tiles = vox_tiles(nsamp); b.store = (char*)store;
     for (int k = 0; k < VBWD_NSTREAMS; ++k) b.wt[k] = (const char*)v->bwd[precision][k].data.p;
     b.maps = (const int*)v->wmaps.p;
     char* w = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);

@@ -4,7 +4,9 @@
 namespace evd {
 
 int launch_voxel_train_fwd_f16(int HD, const VoxMlpParams& p, hipStream_t st) {
-    return HD == 256 ? launch_voxel_train_fwd<EVD_PREC_F16, 256, 128, 64>(p, st) : launch_voxel_train_fwd<EVD_PREC_F16, 64, 15, 32>(p, st);
+    if (HD == 256) return p.feature ? launch_voxel_train_fwd<EVD_PREC_F16, 256, 128, 64, true>(p, st) : launch_voxel_train_fwd<EVD_PREC_F16, 256, 128, 64>(p, st);
+    if (p.feature) return fail(EVD_E_INVALID, "evd_voxel_mlp_train: the feature output is built for the fine level (geo 128)");
+    return launch_voxel_train_fwd<EVD_PREC_F16, 64, 15, 32>(p, st);
 }
 
 int run_voxel_backward_f16(int HD, const VoxBwdPlan& b, hipStream_t st) {

@@ -174,17 +174,17 @@ static int launch_voxel_pipe(const VoxMlpParams& p, hipStream_t st) {
 }
 
 // training variant (keeps the activations), either level; the stream is the level's pipe stream (evd_voxel_api.hip)
-template <int PREC, int HD, int G, int FT>
+template <int PREC, int HD, int G, int FT, bool FEAT = false>
 static int launch_voxel_train_fwd(const VoxMlpParams& p, hipStream_t st) {
     constexpr int NT = 512;
     typedef PipeCfg<PREC, 1, NT> C;
-    typedef VoxNet<C, HD, G, FT, false, true> N;
+    typedef VoxNet<C, HD, G, FT, FEAT, true> N;
     const long blocks = cdiv(p.nsamp, C::SAMPLES);
     const size_t lds = C::TOTAL;
-    EVD_SET_MAX_LDS((&k_voxel_mlp_pipe<PREC, HD, G, FT, 1, NT, false, PIPE_CB, 2, true>), lds);
+    EVD_SET_MAX_LDS((&k_voxel_mlp_pipe<PREC, HD, G, FT, 1, NT, FEAT, PIPE_CB, 2, true>), lds);
     if (p.nchunks != N::NCH) return fail(EVD_E_INVALID, "evd_voxel: packed stream has %d chunks, kernel expects %d", p.nchunks, N::NCH);
     if (!p.act) return fail(EVD_E_INVALID, "evd_voxel: training launch without an activation store");
-    hipLaunchKernelGGL((k_voxel_mlp_pipe<PREC, HD, G, FT, 1, NT, false, PIPE_CB, 2, true>), dim3((unsigned)blocks), dim3(NT), lds, st, p);
+    hipLaunchKernelGGL((k_voxel_mlp_pipe<PREC, HD, G, FT, 1, NT, FEAT, PIPE_CB, 2, true>), dim3((unsigned)blocks), dim3(NT), lds, st, p);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }

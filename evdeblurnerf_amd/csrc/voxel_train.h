@@ -26,6 +26,7 @@ struct VoxBwdGrads {                    // device float32, reference nn.Linear l
 
 struct VoxBwdPlan {
     const float *d_raw, *raw;           // [nsamp, 4]
+    const float* d_feature;             // [nsamp, G] gradient of the geo-feature output, or null
     long nsamp, tiles;
     char* store;
     const char* wt[VBWD_NSTREAMS];

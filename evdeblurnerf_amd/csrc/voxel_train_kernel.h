@@ -64,6 +64,35 @@ __global__ __launch_bounds__(256) void k_frags_to_rows(const char* __restrict__ 
     }
 }
 
+// float32 gradient rows (the per-sample geo features' gradient, from the AWP consumer) added into gradient fragments: fragment j,
+// position kk <-> channel 16 j + phi(kk); rows are scaled by the loss scale first
+template <int PREC>
+__global__ __launch_bounds__(256) void k_rows_add_to_frags(char* __restrict__ store, long tile_bytes, int slot, int nfrag, long nsamp,
+                                                           const unsigned* __restrict__ maxbits, const float* __restrict__ rows, int stride) {
+    typedef POps<PREC> O;
+    pipe_fp16_saturate<PREC>();
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long tile = idx / (64 * nfrag);
+    const int j = (int)((idx / 64) % nfrag), lane = idx & 63, n = lane & 31, h = lane >> 5;
+    const long smp = tile * 32 + n;
+    if (smp >= nsamp) return;
+    char* a = store + tile * tile_bytes + lane * 16;
+    const W4 f = frag_load<W4>(a, slot + j);
+    const float s = grad_scale(*maxbits, false);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const unsigned short bits = (unsigned short)(f.w[e >> 1] >> (16 * (e & 1)));
+        if constexpr (PREC == EVD_PREC_BF16) v[e] = __uint_as_float((unsigned)bits << 16);
+        else v[e] = (float)__builtin_bit_cast(_Float16, bits);
+        v[e] += rows[smp * (long)stride + 16 * j + phi(8 * h + e)] * s;
+    }
+    typename O::B b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) O::template set_pair<false>(b, e, v[2 * e], v[2 * e + 1]);
+    act_store(a, slot + j, b);
+}
+
 template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const VoxBwdPlan& b, hipStream_t st) {
     typedef VStore<HD, G, FT> VS;
     constexpr int T = HD / 32, KS = HD / 16, KF = FT / 16, GT = VS::GT, FTT = (FT + 31) / 32, IC = 3 * (1 + 2 * PE_L), ICV = 3 * (1 + 2 * PE_LV);
@@ -71,6 +100,10 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
     EVD_HIP(hipMemsetAsync(b.maxbits, 0, sizeof(unsigned), st));
     hipLaunchKernelGGL(k_absmax, dim3(512), dim3(256), 0, st, b.d_raw, b.nsamp * 4, b.maxbits);
     EVD_LAUNCH_CHECK();
+    if (b.d_feature) {          // the loss scale covers both incoming gradients
+        hipLaunchKernelGGL(k_absmax, dim3(512), dim3(256), 0, st, b.d_feature, b.nsamp * G, b.maxbits);
+        EVD_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL((k_voxel_grad_frags<PREC>), dim3((unsigned)cdiv(b.tiles * 64, 256L)), dim3(256), 0, st, b.d_raw, b.raw, b.nsamp, b.maxbits, b.store,
                        b.tiles, VS::TILE_BYTES, VS::G_COL, VS::G_SIG);
     EVD_LAUNCH_CHECK();
@@ -103,6 +136,12 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
     if ((rc = wgrad(launch_wgrad<PREC, T, T, false>, T, T, true, VS::D_C1, VS::C1 - KS, VMAP_HID, VMAP_HID, g.color_w[1], HD, g.color_b[1]))) return rc;
     // color_net.0 on cat([geo, PE(dirs)])
     if ((rc = launch_dgrad<PREC, KS, GT + 1, KS, false, false>(dgrad(VBWD_C0, VS::D_C0, -1, -1, VS::D_GEO), b.tiles, st))) return rc;   // d geo | d PE(dirs)
+    if (b.d_feature) {          // + the gradient of the geo features as an output of the level (voxnerf.py:221, consumed by AWP)
+        if (G % 16) return fail(EVD_E_INVALID, "evd_voxel_mlp_backward: d_feature is built for the fine level (geo 128)");
+        hipLaunchKernelGGL((k_rows_add_to_frags<PREC>), dim3((unsigned)cdiv(b.tiles * 64 * (G / 16), 256L)), dim3(256), 0, st, b.store, VS::TILE_BYTES, VS::D_GEO,
+                           G / 16, b.nsamp, b.maxbits, b.d_feature, G);
+        EVD_LAUNCH_CHECK();
+    }
     if (b.d_dirs) {
         hipLaunchKernelGGL((k_pe_bwd<PREC, PE_LV, PEV_KS>), dim3((unsigned)cdiv(b.tiles * 64, 256L)), dim3(256), 0, st, (const char*)b.store, VS::TILE_BYTES,
                            VS::D_DIRPE, b.nsamp, b.viewdirs, b.vd_stride, b.S, b.maxbits, b.d_dirs, 0);

@@ -200,7 +200,7 @@ class NeRFAll:
         return fc, ff
 
     def render_rays_train(self, ray_batch, flat_coarse, flat_fine, N_samples, N_importance=0, lindisp=False, perturb=0.,
-                          white_bkgd=False, raw_noise_std=0., *, t_rand=None, u=None, noise0=None, noise1=None):
+                          white_bkgd=False, raw_noise_std=0., *, t_rand=None, u=None, noise0=None, noise1=None, want_feature=False):
         """renderer.py:129-264 (else-branch) with gradients to the two flat parameter tensors: stratified z, fused MLP
         (forward keeps activations, hand-written backward), compositing scan (autograd node), hierarchical resampling on the
         detached coarse weights (renderer.py:233 z_samples.detach()), fine pass.  Rays are constants (no pose gradients)."""
@@ -221,7 +221,9 @@ class NeRFAll:
         L.check(L.lib().evd_sample_z(C.byref(cfg), L.ptr(rb), 11, R, L.ptr(tr), L.ptr(z0), L.stream_ptr()), "evd_sample_z")
         rays_d = rb[:, 3:6].contiguous()
         if self.mode == "c2f":
-            return self._render_rays_train_c2f(rb, z0, flat_coarse, flat_fine, S, Ni, perturb, u, noise0, noise1)
+            return self._render_rays_train_c2f(rb, z0, flat_coarse, flat_fine, S, Ni, perturb, u, noise0, noise1, want_feature)
+        if want_feature:
+            raise NotImplementedError("depth_feature under autograd is built for mode='c2f' (the shipped AWP configs)")
         raw0 = self.mlp_coarse.mlp_train(flat_coarse, rb, z0, self.precision)
         rgb0, _, acc0, w0, depth0, _ = self.mlp_coarse.raw2outputs(raw0, z0, rays_d, None, 0., white_bkgd, noise=noise0)
         if Ni <= 0:
@@ -232,7 +234,7 @@ class NeRFAll:
         return {"rgb_map": rgb, "depth_map": depth, "acc_map": acc, "weights": w1, "z_vals": zm, "rgb0": rgb0, "depth0": depth0,
                 "acc0": acc0, "z_std": zstd}
 
-    def _render_rays_train_c2f(self, rb, z0, pc, pf, S, Ni, perturb, u, noise0, noise1):
+    def _render_rays_train_c2f(self, rb, z0, pc, pf, S, Ni, perturb, u, noise0, noise1, want_feature=False):
         """renderer.py:182-217 under autograd: tri-plane gathers (scatter-add backward), level networks (fused forward/backward),
         compositing scans, resampling on the detached coarse weights; coarse features of the merged set are the re-ordered rows
         of the old and new points (:209-213), fine features are sampled at the merged points."""
@@ -252,10 +254,17 @@ class NeRFAll:
         ftc = torch.cat([ft0, ftn], 1).gather(1, order.long()[..., None].expand(-1, -1, fc))
         ptm = o + d * zm[..., None]
         ft = torch.cat([ftc, fine.sample_train(ptm, pf["grids"])], -1)
-        raw1 = fine.mlp_train(pf["net"], ptm, vd, ft, self.precision)
+        feat = None
+        if want_feature:
+            raw1, feat = fine.mlp_train(pf["net"], ptm, vd, ft, self.precision, want_feature=True)
+        else:
+            raw1 = fine.mlp_train(pf["net"], ptm, vd, ft, self.precision)
         rgb, _, acc, w1, depth = fine.raw2outputs(raw1, zm, rays_d, is_train=True, noise=noise1)
-        return {"rgb_map": rgb, "depth_map": depth, "acc_map": acc, "weights": w1, "z_vals": zm, "rgb0": rgb0, "depth0": depth0,
-                "acc0": acc0, "z_std": zstd}
+        ret = {"rgb_map": rgb, "depth_map": depth, "acc_map": acc, "weights": w1, "z_vals": zm, "rgb0": rgb0, "depth0": depth0,
+               "acc0": acc0, "z_std": zstd}
+        if feat is not None:
+            ret["depth_feature"] = feat                    # the fine level's per-sample geo features (renderer.py:253-256), for AWP
+        return ret
 
     @staticmethod
     def ray_batch_train(H, W, K, rays, ndc=True, near=0., far=1.):
@@ -287,14 +296,20 @@ class NeRFAll:
         if use_kernel:
             if self.kernel_type != "RBK":
                 raise NotImplementedError("only the RBK kernel of the shipped configs is supported")
-            new_rays, weight1, align_loss, extra1 = self.kernelsnet(H, W, K, rays, rays_info, feats=None, return_img_embed=False)
+            new_rays, weight1, align_loss, extra1 = self.kernelsnet(H, W, K, rays, rays_info, feats=None, return_img_embed=self.use_awp)
             ray_num, pt_num = new_rays.shape[:2]
             flat_rays = new_rays.reshape(-1, 3, 2)
         else:
             flat_rays = rays
         rb = self.ray_batch_train(H, W, K, flat_rays, ndc, near, far)
-        out = self.render_rays_train(rb, params_coarse, params_fine, N_samples, N_importance, **kw)
+        awp = use_kernel and self.use_awp
+        out = self.render_rays_train(rb, params_coarse, params_fine, N_samples, N_importance, want_feature=awp, **kw)
         rgb, rgb0 = out["rgb_map"], out.get("rgb0")
+        if awp:         # adaptive weight proposal on the fine level's per-sample features (renderer.py:310-316): a second composition
+            ccw = self.awpnet(out["depth_feature"], out["z_vals"], rb[:, 3:6], extra1["img_embed"])
+            ccw = ccw + ccw * self.awpnet.ccw_fine_scale
+            ccw = ccw / torch.sum(ccw, -1, keepdim=True)
+            other_tensors["rgb_awp"] = (rgb.reshape(ray_num, pt_num, 3) * ccw[..., None]).sum(1)
         if use_kernel:
             rgb_pts = rgb.reshape(ray_num, pt_num, 3)
             rgb = (rgb_pts * weight1[..., None]).sum(1)                         # rbk_weighted_sum, blurmodel.py:112-127

@@ -52,21 +52,24 @@ class _VoxelMLP(torch.autograd.Function):
     gradients to the flat parameter tensor and to the sampled features (evd_voxel_mlp_train / _backward)"""
 
     @staticmethod
-    def forward(ctx, flat, fts, pts, viewdirs, net, precision):
-        raw, store = net.mlpforward_train(pts, viewdirs, fts, precision)
+    def forward(ctx, flat, fts, pts, viewdirs, net, precision, want_feature=False):
+        raw, store, feature = net.mlpforward_train(pts, viewdirs, fts, precision, want_feature=want_feature)
         ctx.net, ctx.precision, ctx.store, ctx.raw = net, precision, store, raw
-        ctx.ft_shape, ctx.pts, ctx.viewdirs = fts.shape, pts, viewdirs
-        return raw
+        ctx.ft_shape, ctx.pts, ctx.viewdirs, ctx.has_feature = fts.shape, pts, viewdirs, want_feature
+        return (raw, feature) if want_feature else raw
 
     @staticmethod
-    def backward(ctx, d_raw):
+    def backward(ctx, d_raw, d_feature=None):
         need = ctx.needs_input_grad
+        if d_raw is None:
+            d_raw = torch.zeros_like(ctx.raw)
         gflat, d_fts, d_pts, d_dirs = ctx.net.mlp_backward_flat(d_raw, ctx.raw, ctx.store, ctx.precision, want_fts=need[1],
-                                                                pts=ctx.pts if need[2] else None, viewdirs=ctx.viewdirs if need[3] else None)
+                                                                pts=ctx.pts if need[2] else None, viewdirs=ctx.viewdirs if need[3] else None,
+                                                                d_feature=d_feature if ctx.has_feature else None)
         ctx.store = ctx.raw = None
         R, S = ctx.pts.shape[:2]
         return (gflat, d_fts.reshape(ctx.ft_shape) if d_fts is not None else None, d_pts.reshape(ctx.pts.shape) if d_pts is not None else None,
-                d_dirs.reshape(R, S, 3).sum(1) if d_dirs is not None else None, None, None)
+                d_dirs.reshape(R, S, 3).sum(1) if d_dirs is not None else None, None, None, None)
 
 
 class _VoxelTV(torch.autograd.Function):
@@ -208,17 +211,18 @@ class VoxelNeRFBase:
         L.check(L.lib().evd_voxel_load_params(self._h, L.ptr(f), L.stream_ptr()), "evd_voxel_load_params")
         self._synced_net = (flat.data_ptr(), flat._version)
 
-    def mlpforward_train(self, pts, viewdirs, fts, precision=None):
+    def mlpforward_train(self, pts, viewdirs, fts, precision=None, want_feature=False):
         p, vd, ft = pts.contiguous().float(), viewdirs.contiguous().float(), fts.contiguous().float()
         R, S = p.shape[:2]
         raw = torch.empty((R, S, 4), dtype=torch.float32, device=p.device)
+        feature = torch.empty((R, S, self.geo_feat_dim), dtype=torch.float32, device=p.device) if want_feature else None
         nb = int(L.lib().evd_voxel_train_store_bytes(self._h, R * S))
         store = torch.empty((nb,), dtype=torch.uint8, device=p.device)
         L.check(L.lib().evd_voxel_mlp_train(self._h, L.PREC[precision or self.precision], L.ptr(p), L.ptr(vd), vd.shape[-1], L.ptr(ft), ft.shape[-1],
-                                             R, S, L.ptr(raw), L.ptr(store), nb, L.stream_ptr()), "evd_voxel_mlp_train")
-        return raw, store
+                                             R, S, L.ptr(raw), L.ptr(feature), L.ptr(store), nb, L.stream_ptr()), "evd_voxel_mlp_train")
+        return raw, store, feature
 
-    def mlp_backward_flat(self, d_raw, raw, store, precision=None, want_fts=True, pts=None, viewdirs=None):
+    def mlp_backward_flat(self, d_raw, raw, store, precision=None, want_fts=True, pts=None, viewdirs=None, d_feature=None):
         """-> (flat parameter gradient, d fts | None, d pts | None, d dirs per sample | None); the last two (through the positional
         encodings) are computed when the forward's pts / viewdirs are passed"""
         g = d_raw.contiguous().float()
@@ -237,16 +241,18 @@ class VoxelNeRFBase:
         vd = viewdirs.contiguous().float() if viewdirs is not None else None
         d_pts = torch.empty((R * S, 3), dtype=torch.float32, device=g.device) if p is not None else None
         d_dirs = torch.empty((R * S, 3), dtype=torch.float32, device=g.device) if vd is not None else None
-        L.check(L.lib().evd_voxel_mlp_backward(self._h, L.PREC[precision or self.precision], L.ptr(g), L.ptr(raw), R, S, L.ptr(store), store.numel(),
+        df = d_feature.contiguous().float() if d_feature is not None else None
+        L.check(L.lib().evd_voxel_mlp_backward(self._h, L.PREC[precision or self.precision], L.ptr(g), L.ptr(raw), L.ptr(df), R, S, L.ptr(store), store.numel(),
                                                 C.byref(gs), L.ptr(d_fts), self.ft_dim, L.ptr(p), L.ptr(vd), vd.shape[-1] if vd is not None else 0,
                                                 L.ptr(d_pts), L.ptr(d_dirs), L.ptr(ws), nb, L.stream_ptr()), "evd_voxel_mlp_backward")
         return flat, d_fts, d_pts, d_dirs
 
-    def mlp_train(self, flat, pts, viewdirs, fts, precision=None):
-        """raw [R,S,4] = (sigma, sigmoid(colour)) with autograd to the flat parameters and to the sampled features"""
+    def mlp_train(self, flat, pts, viewdirs, fts, precision=None, want_feature=False):
+        """raw [R,S,4] = (sigma, sigmoid(colour)) with autograd to the flat parameters, the sampled features and the rays;
+        want_feature (fine level): also the per-sample geo features [R,S,geo] (voxnerf.py:221), an autograd output too"""
         if getattr(self, "_synced_net", None) != (flat.data_ptr(), flat._version):
             self.load_params(flat)
-        return _VoxelMLP.apply(flat, fts, pts, viewdirs, self, precision or self.precision)
+        return _VoxelMLP.apply(flat, fts, pts, viewdirs, self, precision or self.precision, want_feature)
 
     # ---- training the grids (the library's channel-last layout; a permute away from the state dict) ---------------------
     def grid_params(self):

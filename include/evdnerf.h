@@ -241,7 +241,9 @@ int evd_voxel_tv_loss(const evd_voxel* v, float* out, void* stream);
  * (reference nn.Linear layouts, voxnerf.py:60-84); evd_voxel_param_blocks writes the 8 offsets + the total and returns 8;
  * evd_voxel_load_params re-packs every weight stream of the level on the device (after optimizer.step()).
  * evd_voxel_mlp_train = the per-sample part of VoxelNeRFBase.forward (voxnerf.py:210-221,240-254): raw dev [R,S,4] =
- * (sigma, sigmoid(colour)), every layer's activations kept in `store` (evd_voxel_train_store_bytes).
+ * (sigma, sigmoid(colour)), every layer's activations kept in `store` (evd_voxel_train_store_bytes); feature dev [R,S,geo]
+ * (NULL = not wanted; fine level) = the per-sample geo features AWP consumes (voxnerf.py:221), whose gradient
+ * evd_voxel_mlp_backward takes back as d_feature (NULL = none).
  * evd_voxel_mlp_backward: d_raw, raw dev [R,S,4] -> parameter gradients (overwritten) and d_fts dev [R*S, d_fts_stride]
  * (columns 0 .. ft_dim-1 overwritten; NULL = not wanted), the gradient of the sampled features that evd_voxel_sample_bwd
  * scatters into the grids.  d_pts / d_dirs dev [R*S, 3] (NULL = not wanted; need the forward's pts / viewdirs): the gradient
@@ -254,9 +256,9 @@ int evd_voxel_load_params(evd_voxel* v, const float* params, void* stream);
 size_t evd_voxel_train_store_bytes(const evd_voxel* v, long nsamp);
 size_t evd_voxel_backward_workspace_bytes(void);
 int evd_voxel_mlp_train(const evd_voxel* v, int precision, const float* pts, const float* viewdirs, int vd_stride, const float* fts,
-                        int ft_stride, long R, int S, float* raw, void* store, size_t store_bytes, void* stream);
-int evd_voxel_mlp_backward(const evd_voxel* v, int precision, const float* d_raw, const float* raw, long R, int S, void* store,
-                           size_t store_bytes, const evd_voxel_grads* grads, float* d_fts, int d_fts_stride, const float* pts,
+                        int ft_stride, long R, int S, float* raw, float* feature, void* store, size_t store_bytes, void* stream);
+int evd_voxel_mlp_backward(const evd_voxel* v, int precision, const float* d_raw, const float* raw, const float* d_feature, long R, int S,
+                           void* store, size_t store_bytes, const evd_voxel_grads* grads, float* d_fts, int d_fts_stride, const float* pts,
                            const float* viewdirs, int vd_stride, float* d_pts, float* d_dirs, void* workspace,
                            size_t workspace_bytes, void* stream);
 

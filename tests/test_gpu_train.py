@@ -333,7 +333,7 @@ class TorchVoxLevel(torch.nn.Module):
                 "color_net.1.bias", "color_net.2.weight", "color_net.2.bias"]
         self.p = torch.nn.ParameterDict({k.replace(".", "_"): torch.nn.Parameter(torch.tensor(np.asarray(sd[k]), dtype=torch.float64)) for k in keys})
 
-    def forward(self, pts, dirs, fts, masks=None):
+    def forward(self, pts, dirs, fts, masks=None, want_geo=False):
         P = self.p
         act = (lambda x, k: torch.relu(x)) if masks is None else (lambda x, k: x * masks[k])
         h = act(torch.cat([fts, embed(pts, 10)], -1) @ P["sigma_net_0_weight"].T, "hid")
@@ -341,7 +341,8 @@ class TorchVoxLevel(torch.nn.Module):
         c = act(torch.cat([sg[:, 1:], embed(dirs, 4)], -1) @ P["color_net_0_weight"].T + P["color_net_0_bias"], "c0")
         c = act(c @ P["color_net_1_weight"].T + P["color_net_1_bias"], "c1")
         col = torch.sigmoid(c @ P["color_net_2_weight"].T + P["color_net_2_bias"])
-        return torch.cat([sg[:, :1], col], -1)
+        raw = torch.cat([sg[:, :1], col], -1)
+        return (raw, sg[:, 1:]) if want_geo else raw
 
 
 def vdecode(store, nsamp, tile_frags, slot, nfrag, dtype):
@@ -377,10 +378,16 @@ def test_pdrf_level_networks_backward_match_torch_autograd(level, prec, tol):
     flat = net.flat_params(sd)
     ft_t = torch.tensor(fts, device=dev, requires_grad=True)
     pts_t, vd_t = torch.tensor(pts, device=dev, requires_grad=True), torch.tensor(vd, device=dev, requires_grad=True)
-    raw = net.mlp_train(flat, pts_t, vd_t, ft_t)
+    want_geo = level == "fine"               # the fine level's geo features are an output too (AWP consumes them, voxnerf.py:221)
+    wf = (rs.normal(size=(R, S, G)) * 3e-4).astype(np.float32)
+    if want_geo:
+        raw, feat = net.mlp_train(flat, pts_t, vd_t, ft_t, want_feature=True)
+        loss = (raw * torch.tensor(d_raw, device=dev)).sum() + (feat * torch.tensor(wf, device=dev)).sum()
+    else:
+        raw = net.mlp_train(flat, pts_t, vd_t, ft_t)
+        loss = (raw * torch.tensor(d_raw, device=dev)).sum()
     store = raw.grad_fn.store
-    # the fused inference forward of the same level (render path) agrees to the mode's rounding
-    (raw * torch.tensor(d_raw, device=dev)).sum().backward()
+    loss.backward()
     n = R * S
     KS, KF, GT = HD // 16, FT // 16, (G + 31) // 32
     IN0, DIRPE = 0, KF + 4
@@ -398,9 +405,13 @@ def test_pdrf_level_networks_backward_match_torch_autograd(level, prec, tol):
     v64 = torch.tensor(vd, dtype=torch.float64, requires_grad=True)
     d64 = v64[:, None].expand(-1, S, -1).reshape(-1, 3)
     f64 = torch.tensor(fts, dtype=torch.float64).reshape(-1, FT).requires_grad_(True)
-    rraw = ref(p64, d64, f64, masks=masks)
+    rraw, rgeo = ref(p64, d64, f64, masks=masks, want_geo=True)
     assert (raw.detach().reshape(n, 4).cpu().double() - rraw).abs().max().item() < (2e-2 if prec == "f16" else 1.5e-1)
-    (rraw * torch.tensor(d_raw, dtype=torch.float64).reshape(-1, 4)).sum().backward()
+    rloss = (rraw * torch.tensor(d_raw, dtype=torch.float64).reshape(-1, 4)).sum()
+    if want_geo:
+        assert (feat.detach().reshape(n, G).cpu().double() - rgeo).abs().max().item() < (2e-2 if prec == "f16" else 1.5e-1)
+        rloss = rloss + (rgeo * torch.tensor(wf, dtype=torch.float64).reshape(-1, G)).sum()
+    rloss.backward()
     got = net.unflatten(flat.grad)
     errs = {k: rel_l2(v.cpu().double(), ref.p[k.replace(".", "_")].grad) for k, v in got.items()}
     errs["fts"] = rel_l2(ft_t.grad.reshape(n, FT).cpu().double(), f64.grad)
@@ -581,7 +592,22 @@ class _ToyRigidKernel(torch.nn.Module):
         o2 = o[:, None] + self.trans[None]
         d2 = d[:, None] + torch.cross(self.rot[None].expand(d.shape[0], -1, -1), d[:, None].expand(-1, self.P, -1), dim=-1)
         w = torch.softmax(self.logit, 0)[None].expand(o.shape[0], -1)
-        return torch.stack([o2, d2], -1), w, None, {}
+        return torch.stack([o2, d2], -1), w, None, ({"img_embed": torch.ones((o.shape[0], 4), device=o.device)} if return_img_embed else {})
+
+
+class _ToyAWP(torch.nn.Module):
+    """Stand-in for AdaptiveWeightProposal's call contract (awp.py:79-117): per-sample features [R P, S, F] -> weights [R, P]"""
+
+    def __init__(self, P=5, F=128):
+        super().__init__()
+        self.P = P
+        self.lin = torch.nn.Linear(F, 1)
+        self.ccw_fine_scale = 0.5
+
+    def forward(self, depth_feature, z_vals, rays_d, view_feature):
+        h = self.lin(depth_feature).mean(1).reshape(-1, self.P)                  # [R, P]
+        w = torch.sigmoid(h + view_feature.sum(-1, keepdim=True) * 0.0)
+        return w / w.sum(-1, keepdim=True)
 
 
 @pytest.mark.parametrize("mode", ["nerf", "c2f"])
@@ -596,6 +622,10 @@ def test_forward_train_reaches_the_blur_kernel(mode):
     model.train()
     kern = _ToyRigidKernel().cuda()
     model.kernelsnet, model.kernel_type = kern, "RBK"
+    awp = None
+    if mode == "c2f":                    # the shipped configs run AWP on the fine level's per-sample features
+        awp = _ToyAWP().cuda()
+        model.awpnet, model.use_awp = awp, True
     pc, pf = model.trainable_parameters(sd)
     Kmat = W.synthetic_camera()
     R = 64
@@ -614,11 +644,12 @@ def test_forward_train_reaches_the_blur_kernel(mode):
     def loss_of():
         rgb, rgb0, other, tens = model.forward_train(400, 400, Kmat, rays, pc, pf, **kw)
         assert rgb.shape == (R, 3) and tens["stage1_rgb_pts0"].shape == (R, 3)
-        return ((rgb - target) ** 2).mean() + ((rgb0 - target) ** 2).mean() + sum(v.sum() for v in other.values()) * 1e-3
+        extra = ((tens["rgb_awp"] - target) ** 2).mean() if awp is not None else 0.
+        return ((rgb - target) ** 2).mean() + ((rgb0 - target) ** 2).mean() + sum(v.sum() for v in other.values()) * 1e-3 + extra
 
     loss = loss_of()
     loss.backward()
-    for p in kern.parameters():
+    for p in list(kern.parameters()) + (list(awp.parameters()) if awp is not None else []):
         assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().max().item() > 0
     if mode == "nerf":
         # the same composition in float64 torch (coarse pass only: no resampling to diverge): kernel -> packing -> network ->
