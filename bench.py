@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-modes", action="store_true")
     ap.add_argument("--no-composite", action="store_true")
+    ap.add_argument("--no-train", action="store_true")
     return ap.parse_args()
 
 
@@ -221,6 +222,25 @@ def main():
                                    "achieved": cbytes / (cms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": cbytes / (cms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": cbytes}
             del raw_c, z_c, rd_c, o3, o1, o2, ow
+        if not a.no_train and not lean:
+            # ---- the training kernels on the same workload (next row): forward that keeps the activations and the
+            # hand-written backward of the fused MLP (parameter gradients + the gradient reaching the rays); informational
+            from evdeblurnerf_amd.nerf import NeRF
+            tnet = NeRF(sd, "mlp_coarse.", precision=a.precision)
+            rb_t, z_t = rb, z
+            algo_flop = R * S * FLOP_PER_SAMPLE
+            d_raw_t = torch.randn((R, S, 4), device="cuda") * 1e-4
+            pts_t = (rb_t[:, None, 0:3] + rb_t[:, None, 3:6] * z_t[..., None]).contiguous()
+            fwd_ms = kernel_ms(lambda: tnet.mlpforward_train(rb_t, z_t), 10)
+            _, store_t = tnet.mlpforward_train(rb_t, z_t)
+            bwd_ms = kernel_ms(lambda: tnet.mlp_backward_flat(d_raw_t, store_t), 10)
+            bwd_rays_ms = kernel_ms(lambda: tnet.mlp_backward_flat(d_raw_t, store_t, pts=pts_t, ray_batch=rb_t), 10)
+            result["train"] = {"forward_keeping_activations_ms": fwd_ms, "backward_params_ms": bwd_ms, "backward_params_and_rays_ms": bwd_rays_ms,
+                               "activation_store_bytes": int(store_t.numel()), "algorithmic_flop_backward": 2 * algo_flop,
+                               "backward_tflops": 2 * algo_flop / (bwd_ms * 1e-3) / 1e12,
+                               "note": "evd_nerf_mlp_train / evd_nerf_mlp_backward on the metric workload (one network); HBM-bound by "
+                                       "construction (per-layer dgrad + wgrad over the stored fragments), DESIGN.md 7"}
+            del store_t, tnet
         if not a.no_cpu_baseline and not lean:
             from oracle import oracle as O
             onet = O.Nerf(sd, "mlp_coarse.")
