@@ -276,3 +276,91 @@ def test_G17_compute_successor():
         succ, nsucc, latest, first = O.compute_successor(g[f"{tag}_ids"], g[f"{tag}_latest"].shape[0])
         assert np.array_equal(succ, g[f"{tag}_succ"]) and np.array_equal(nsucc, g[f"{tag}_nsucc"])
         assert np.array_equal(latest, g[f"{tag}_latest"]) and np.array_equal(first, g[f"{tag}_first"])
+
+
+# ---- gradients: the float64 torch restatements the GPU training tests compare against (tests/torch_restatement.py) are pinned
+# here to gradients computed by torch.autograd ON THE REFERENCE MODULES (tools/gen_golden.py G18, G19)
+def _check_grad(got, g, key, idx):
+    from torch_restatement import grad_summary
+    sm, head = grad_summary(got, 7000 + idx)
+    ref_sm, ref_head = g[f"g.{key}.summary"], g[f"g.{key}.head"]
+    norm = max(float(ref_sm[0]), 1e-30)
+    assert abs(sm[0] - ref_sm[0]) < 2e-4 * norm, (key, sm[0], ref_sm[0])
+    assert abs(sm[1] - ref_sm[1]) < 1e-3 * norm, (key, sm[1], ref_sm[1])                     # random projection: an O(norm) number
+    assert np.abs(head - ref_head).max() < 2e-4 * max(np.abs(ref_head).max(), norm / np.sqrt(max(np.asarray(got).size, 1))), key
+
+
+def test_G18_nerf_gradients_of_the_restatement_match_the_reference():
+    import torch
+    from torch_restatement import TorchNerf, nerf_composite
+    g = load_golden("G18_nerf_grads")
+    sd = W.make_nerf_state_dict(18, D=8, W=64, rgb_add_bias=True)
+    o = torch.tensor(g["o"], dtype=torch.float64, requires_grad=True)
+    d = torch.tensor(g["d"], dtype=torch.float64, requires_grad=True)
+    z = torch.tensor(g["z"], dtype=torch.float64)
+    R, S = z.shape
+    pts = (o[:, None] + d[:, None] * z[..., None]).reshape(-1, 3)
+    vd = d / d.norm(dim=-1, keepdim=True)
+    net = TorchNerf(sd)
+    raw = net(pts, vd[:, None].expand(-1, S, -1).reshape(-1, 3)).reshape(R, S, 4)
+    rgb_map, _ = nerf_composite(raw, z, d)
+    assert maxabs(rgb_map.detach().numpy(), g["rgb_map"]) < 2e-6
+    (rgb_map * torch.tensor(g["w_rgb"], dtype=torch.float64)).sum().backward()
+    keys = [k[2:-8] for k in g if k.startswith("g.") and k.endswith(".summary")]
+    assert len(keys) == len(sd) + 2
+    for idx, key in enumerate(keys):                                   # the generator's order = named_parameters() then the rays
+        if key == "rays_o":
+            got = o.grad
+        elif key == "rays_d":
+            got = d.grad
+        else:
+            got = net.p[key.replace(".", "_")].grad
+        _check_grad(got.numpy(), g, key, idx)
+
+
+def test_G19_c2f_gradients_of_the_restatement_match_the_reference():
+    """the whole mode='c2f' training forward of the reference (NDC ray packing, both PDRF levels, resampled positions, TV) vs the
+    restated pipeline on the reference's sample positions: every parameter gradient of both levels and the ray gradient"""
+    import torch
+    from evdeblurnerf_amd.renderer import NeRFAll
+    from torch_restatement import TorchVoxLevel, c2f_pipeline, torch_tv
+    g = load_golden("G19_c2f_grads")
+    gc, gf = [int(v) for v in g["grid_coarse"]], [int(v) for v in g["grid_fine"]]
+    sd = dict(W.prefixed(W.make_pdrf_state_dict(91, gc, input_ch=95, hidden_dim=64, geo_feat_dim=15, add_bias_color=True), "mlp_coarse"))
+    sd.update(W.prefixed(W.make_pdrf_state_dict(92, gf, input_ch=127, hidden_dim=256, geo_feat_dim=128, add_bias_color=True), "mlp_fine"))
+    aabb = ([-1.5, -1.5, -1.0], [1.5, 1.5, 1.0])
+    rays = torch.tensor(g["rays"], dtype=torch.float64, requires_grad=True)
+    rb = NeRFAll.ray_batch_train(400, 400, W.synthetic_camera(), rays)
+    levels, grids = {}, {}
+    for name in ("coarse", "fine"):
+        pre = f"mlp_{name}."
+        lsd = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+        levels[name] = TorchVoxLevel(lsd)
+        grids[name] = ([torch.tensor(np.asarray(lsd[f"app_plane.{i}"]), dtype=torch.float64, requires_grad=True) for i in range(3)],
+                       [torch.tensor(np.asarray(lsd[f"app_line.{i}"]), dtype=torch.float64, requires_grad=True) for i in range(3)],
+                       torch.tensor(np.asarray(lsd["basis_mat.weight"]), dtype=torch.float64, requires_grad=True))
+    z0, zm = torch.tensor(g["z_vals0"], dtype=torch.float64), torch.tensor(g["z_vals"], dtype=torch.float64)
+    rgb0, rgb = c2f_pipeline(levels, grids, rb, z0, zm, aabb)
+    assert maxabs(rgb.detach().numpy(), g["rgb"]) < 5e-6 and maxabs(rgb0.detach().numpy(), g["rgb0"]) < 5e-6
+    tv = 5 * sum(torch_tv(grids[n_][0][i]) * 1e-2 + torch_tv(grids[n_][1][i]) * 1e-3 for n_ in ("coarse", "fine") for i in range(3))
+    assert abs(tv.item() - float(g["tv"])) < 1e-5 * float(g["tv"])
+    loss = (rgb * torch.tensor(g["w_rgb"], dtype=torch.float64)).sum() + (rgb0 * torch.tensor(g["w_rgb0"], dtype=torch.float64)).sum() + 0.1 * tv
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * max(1.0, abs(float(g["loss"])))
+    loss.backward()
+    keys = [k[2:-8] for k in g if k.startswith("g.") and k.endswith(".summary")]
+    assert len(keys) == 2 * 15 + 1
+    for idx, key in enumerate(keys):
+        if key == "rays":
+            got = rays.grad
+        else:
+            lvl, rest = key.split(".", 1)
+            name = lvl[len("mlp_"):]
+            if rest.startswith("app_plane."):
+                got = grids[name][0][int(rest[-1])].grad
+            elif rest.startswith("app_line."):
+                got = grids[name][1][int(rest[-1])].grad
+            elif rest == "basis_mat.weight":
+                got = grids[name][2].grad
+            else:
+                got = levels[name].p[rest.replace(".", "_")].grad
+        _check_grad(got.numpy(), g, key, idx)

@@ -587,9 +587,78 @@ def G17_compute_successor():
     save("G17_compute_successor", **out)
 
 
+def _grad_summaries(named_grads, out, prefix):
+    """store (norm, seeded projection) + the first 32 elements of every gradient: full gradients would not fit a small fixture"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from torch_restatement import grad_summary
+    for i, (name, g) in enumerate(named_grads):
+        sm, head = grad_summary(n(g), 7000 + i)
+        out[f"{prefix}{name}.summary"] = sm.astype(np.float64)
+        out[f"{prefix}{name}.head"] = head.astype(np.float64)
+
+
+def G18_nerf_grads():
+    """Gradients of the reference NeRF (D 8, W 64 to keep the fixture small; same code path as W 256) through mlpforward +
+    raw2outputs, w.r.t. every parameter and the inputs: torch.autograd on the reference modules themselves."""
+    from networks.embedding import get_embedder
+    rs = np.random.RandomState(1801)
+    R, S = 12, 10
+    o = rs.uniform(-0.4, 0.4, size=(R, 3)).astype(np.float32)
+    d = rs.standard_normal((R, 3)).astype(np.float32)
+    z = np.sort(rs.uniform(0.2, 1.8, size=(R, S)).astype(np.float32), -1)
+    w_rgb = rs.standard_normal((R, 3)).astype(np.float32)
+    net = _ref_nerf(18, D=8, Wd=64, rgb_add_bias=True)
+    net.train(True)
+    e10, _ = get_embedder(10)
+    e4, _ = get_embedder(4)
+    with torch.enable_grad():
+        ot, dt = t(o).requires_grad_(True), t(d).requires_grad_(True)
+        pts = ot[:, None] + dt[:, None] * t(z)[..., None]
+        vd = dt / torch.norm(dt, dim=-1, keepdim=True)
+        x = torch.cat([e10(pts.reshape(-1, 3)), e4(vd[:, None].expand(-1, S, -1).reshape(-1, 3))], -1)
+        raw, _ = net.eval(x)
+        rgb_map = net.raw2outputs(raw.reshape(R, S, 4), t(z), dt)[0]
+        loss = (rgb_map * t(w_rgb)).sum()
+        params = list(net.named_parameters())
+        grads = torch.autograd.grad(loss, [p for _, p in params] + [ot, dt])
+    out = {}
+    _grad_summaries([(k, g) for (k, _), g in zip(params, grads)] + [("rays_o", grads[-2]), ("rays_d", grads[-1])], out, "g.")
+    save("G18_nerf_grads", o=o, d=d, z=z, w_rgb=w_rgb, rgb_map=n(rgb_map), loss=np.float64(loss.item()), **out)
+
+
+def G19_c2f_grads():
+    """Gradients of the reference's mode='c2f' training forward (NeRFAll.render in train mode: NDC ray packing, both PDRF levels,
+    hierarchical resampling, TV regulariser) w.r.t. every parameter of both levels and the rays."""
+    K = W.synthetic_camera()
+    model, _ = _nerfall("c2f", 16, 0, rgb_add_bias=True, **PDRF_SMALL)
+    gc = [int(v) for v in model.mlp_coarse.gridSize]
+    gf = [int(v) for v in model.mlp_fine.gridSize]
+    sd = W.prefixed(W.make_pdrf_state_dict(91, gc, input_ch=32 + 63, hidden_dim=64, geo_feat_dim=15, add_bias_color=True), "mlp_coarse")
+    sd.update(W.prefixed(W.make_pdrf_state_dict(92, gf, input_ch=64 + 63, hidden_dim=256, geo_feat_dim=128, add_bias_color=True), "mlp_fine"))
+    ref_import.load_np_state_dict(model, sd)
+    model.train(True)
+    R = 24
+    rays = W.synthetic_rays(19, R)
+    rs = np.random.RandomState(1901)
+    w_rgb, w_rgb0 = rs.standard_normal((R, 3)).astype(np.float32), rs.standard_normal((R, 3)).astype(np.float32)
+    with torch.enable_grad():
+        rt = t(rays).requires_grad_(True)
+        rgb, depth, acc, ex = model.render(400, 400, t(K), 1024, rays=rt, ndc=True, near=0., far=1., use_viewdirs=True, N_samples=16,
+                                           N_importance=16, retraw=True, perturb=0., raw_noise_std=0.)
+        tv = (model.mlp_coarse.TV_loss_app() + model.mlp_fine.TV_loss_app()) * 5
+        loss = (rgb * t(w_rgb)).sum() + (ex["rgb0"] * t(w_rgb0)).sum() + 0.1 * tv
+        params = [(k, p) for k, p in model.named_parameters() if p.requires_grad]
+        grads = torch.autograd.grad(loss, [p for _, p in params] + [rt], allow_unused=True)
+    out = {}
+    named = [(k, g) for (k, _), g in zip(params, grads) if g is not None] + [("rays", grads[-1])]
+    _grad_summaries(named, out, "g.")
+    save("G19_c2f_grads", rays=rays, w_rgb=w_rgb, w_rgb0=w_rgb0, rgb=n(rgb), rgb0=n(ex["rgb0"]), z_vals=n(ex["z_vals"]), z_vals0=n(ex["z_vals0"]),
+         tv=np.float64(tv.item()), loss=np.float64(loss.item()), grid_coarse=np.array(gc), grid_fine=np.array(gf), **out)
+
+
 ALL = [G1_embedder, G2_nerf_mlp, G3_nerf_raw2outputs, G4_voxel_raw2outputs, G5_sample_pdf, G6_rays,
        G7_render_nerf, G8_appfeature, G9_render_c2f, G10_rbk_weighted_sum, G11_crf, G12_egm_loss, G13_edi,
-       G14_loss_assembly, G15_awp_feature_integration, G16_rbk_warp, G17_compute_successor]
+       G14_loss_assembly, G15_awp_feature_integration, G16_rbk_warp, G17_compute_successor, G18_nerf_grads, G19_c2f_grads]
 
 if __name__ == "__main__":
     want = set(sys.argv[1:])
