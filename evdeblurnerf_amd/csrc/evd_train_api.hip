@@ -6,6 +6,7 @@
 #include "nerf_train.h"
 
 #include <cstdint>
+#include <cstdlib>
 
 using namespace evd;
 
@@ -13,6 +14,27 @@ namespace evd {
 constexpr int TRAIN_WG_SAMPLES = 256;       // samples per workgroup of the training kernels (8 wavefronts x 32)
 static long train_tiles(long nsamp) { return cdiv(nsamp, (long)TRAIN_WG_SAMPLES) * (TRAIN_WG_SAMPLES / 32); }
 static bool train_built(const evd_nerf* n, int prec) { return (prec == EVD_PREC_F16 || prec == EVD_PREC_BF16) && n->pipe_chunks[prec] > 0; }
+}  // namespace evd
+
+namespace evd {
+// lazily created per-device side stream + event of the backward entries (nerf_train.h BwdPlan::side)
+int side_stream(hipStream_t* side, hipEvent_t* ev, int* wgrad_blocks) {
+    static const char* e = getenv("EVD_BWD_OVERLAP");
+    static hipStream_t streams[64] = {nullptr};
+    static hipEvent_t events[64] = {nullptr};
+    *side = nullptr; *ev = nullptr;
+    const int want = e ? atoi(e) : 192;
+    if (want <= 0) return EVD_OK;
+    int dev = 0;
+    EVD_HIP(hipGetDevice(&dev));
+    dev &= 63;
+    if (!streams[dev]) {
+        EVD_HIP(hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking));
+        EVD_HIP(hipEventCreateWithFlags(&events[dev], hipEventDisableTiming));
+    }
+    *side = streams[dev]; *ev = events[dev]; *wgrad_blocks = want;
+    return EVD_OK;
+}
 }  // namespace evd
 
 extern "C" {
@@ -57,6 +79,7 @@ int evd_nerf_mlp_backward(const evd_nerf* net, int precision, const float* d_raw
     if (workspace_bytes < evd_nerf_backward_workspace_bytes())
         return fail(EVD_E_WORKSPACE, "evd_nerf_mlp_backward: workspace %zu < %zu bytes", workspace_bytes, evd_nerf_backward_workspace_bytes());
     BwdPlan b;
+    int rc0;
     b.d_raw = d_raw; b.nsamp = nsamp; b.tiles = train_tiles(nsamp); b.store = (char*)store;
     for (int k = 0; k < EVD_BWD_NSTREAMS; ++k) b.wt[k] = (const char*)net->bwd[precision][k].data.p;
     b.maps = (const int*)net->wmaps.p;
@@ -64,6 +87,10 @@ int evd_nerf_mlp_backward(const evd_nerf* net, int precision, const float* d_raw
     b.maxbits = (unsigned*)w;
     b.partial = (float*)(w + 256);
     b.wgrad_blocks = WGRAD_BLOCKS; b.skip = net->skip;
+    // the wgrad launches run on a per-device side stream, forked from / joined to the caller's stream with events (stream order
+    // as seen by the caller is unchanged): measured 3.41 -> 3.05 ms at 2^19 samples with 192 persistent wgrad workgroups
+    // (256: 3.14, 128: 3.52).  EVD_BWD_OVERLAP=0 keeps everything on the caller's stream; =N sets the workgroup count.
+    if ((rc0 = side_stream(&b.side, &b.ev, &b.wgrad_blocks))) return rc0;
     b.pts = pts; b.viewdirs = viewdirs; b.vd_stride = vd_stride; b.S = S; b.d_pts = d_pts; b.d_dirs = d_dirs;
     for (int l = 0; l < EVD_MAX_LAYERS; ++l) { b.grads.pts_w[l] = l < net->D ? grads->pts_w[l] : nullptr; b.grads.pts_b[l] = l < net->D ? grads->pts_b[l] : nullptr; }
     b.grads.views_w = grads->views_w; b.grads.views_b = grads->views_b; b.grads.feature_w = grads->feature_w; b.grads.feature_b = grads->feature_b;

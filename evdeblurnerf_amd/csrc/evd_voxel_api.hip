@@ -7,6 +7,8 @@
 #include "voxel_mlp_kernel.h"
 #include "voxel_train.h"
 
+namespace evd { int side_stream(hipStream_t* side, hipEvent_t* ev, int* wgrad_blocks); }    // evd_train_api.hip
+
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -483,6 +485,12 @@ int evd_voxel_mlp_backward(const evd_voxel* v, int precision, const float* d_raw
     b.maxbits = (unsigned*)w;
     b.partial = (float*)(w + 256);
     b.wgrad_blocks = VOX_WGRAD_BLOCKS;
+    b.side = nullptr; b.ev = nullptr;
+    static const bool overlap = env_flag("EVD_BWD_OVERLAP_VOXEL");     // measured: no gain for the level networks (7.70 vs 7.86 ms per c2f iteration), off
+    if (overlap) {
+        int rc0 = side_stream(&b.side, &b.ev, &b.wgrad_blocks);
+        if (rc0) return rc0;
+    }
     b.d_fts = d_fts; b.d_fts_stride = d_fts_stride;
     b.pts = pts; b.viewdirs = viewdirs; b.vd_stride = vd_stride; b.S = S; b.d_pts = d_pts; b.d_dirs = d_dirs;
     for (int i = 0; i < 2; ++i) b.grads.sigma_w[i] = grads->sigma_w[i];

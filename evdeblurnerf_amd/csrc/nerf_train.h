@@ -33,12 +33,15 @@ struct BwdPlan {
     float* partial;
     unsigned* maxbits;
     int wgrad_blocks, skip;
+    hipStream_t side;                   // second stream for the wgrad launches (null: everything on the caller's stream)
+    hipEvent_t ev;
     BwdGrads grads;
     const float *pts, *viewdirs;        // [nsamp,3] sample positions / rows of vd_stride floats per ray (the encodings' derivatives)
     int vd_stride, S;
     float *d_pts, *d_dirs;              // [nsamp,3] float32 out (through the positional encodings), or null
 };
 
+int side_stream(hipStream_t* side, hipEvent_t* ev, int* wgrad_blocks);     // evd_train_api.hip
 int run_nerf_backward_f16(const BwdPlan& b, hipStream_t st);
 int run_nerf_backward_bf16(const BwdPlan& b, hipStream_t st);
 

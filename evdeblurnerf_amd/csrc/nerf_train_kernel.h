@@ -386,34 +386,43 @@ template <int PREC> static int run_nerf_backward(const BwdPlan& b, hipStream_t s
         const int blocks = (int)(cdiv(b.tiles, (long)WGRAD_TPI) < b.wgrad_blocks ? cdiv(b.tiles, (long)WGRAD_TPI) : b.wgrad_blocks);
         WgradParams p;
         p.store = b.store; p.tiles = b.tiles; p.tile_bytes = astore::TILE_BYTES; p.y_slot = y_slot; p.x_slot = x_slot; p.bias = bias ? 1 : 0; p.partial = b.partial;
-        int r = launch(p, blocks, st);
+        hipStream_t ws = st;
+        if (b.side) {                           // everything issued so far on the main stream (the producer of this wgrad's operands) first
+            EVD_HIP(hipEventRecord(b.ev, st));
+            EVD_HIP(hipStreamWaitEvent(b.side, b.ev, 0));
+            ws = b.side;
+        }
+        int r = launch(p, blocks, ws);
         if (r) return r;
         WreduceParams q;
         q.partial = b.partial; q.nparts = blocks; q.RT = RT; q.CT = CT; q.NC = CT + (bias ? 1 : 0);
         q.rowmap = b.maps + ymap; q.colmap = b.maps + xmap; q.dW = dW; q.ld = ld; q.db = bias ? db : nullptr; q.maxbits = b.maxbits;
-        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((long)RT * q.NC * 4)), dim3(256), 0, st, q);
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((long)RT * q.NC * 4)), dim3(256), 0, ws, q);
         EVD_LAUNCH_CHECK();
         return EVD_OK;
     };
     const BwdGrads& g = b.grads;
+    // Every wgrad is issued BEFORE the dgrad layer that reads the same two arrays (incoming gradient, saved activation): the two are
+    // independent, and with a side stream (b.side: developer switch EVD_BWD_OVERLAP) they run concurrently and share those reads in
+    // the Infinity Cache.
     // rgb_linear: d hv = Wr^T d rgb;  dWr = d rgb . hv^T
-    if ((rc = launch_dgrad<PREC, 1, 4, 1, false, true>(dgrad(EVD_BWD_RGB, G_RGB, -1, HV, D_HV), b.tiles, st))) return rc;
     if ((rc = wgrad(launch_wgrad<PREC, 1, 4, true>, 1, 4, true, G_RGB, HV, MAP_RGB, MAP_HID, g.rgb_w, 128, g.rgb_b))) return rc;
+    if ((rc = launch_dgrad<PREC, 1, 4, 1, false, true>(dgrad(EVD_BWD_RGB, G_RGB, -1, HV, D_HV), b.tiles, st))) return rc;
     // views_linears.0 on cat([feature, PE(dir)])
-    if ((rc = launch_dgrad<PREC, 8, 8, 8, false, false>(dgrad(EVD_BWD_VIEWS, D_HV, -1, -1, D_F), b.tiles, st))) return rc;
     if ((rc = wgrad(launch_wgrad<PREC, 4, 8, false>, 4, 8, true, D_HV, F, MAP_HID, MAP_HID, g.views_w, 256 + 27, g.views_b))) return rc;
     if ((rc = wgrad(launch_wgrad<PREC, 4, 1, false>, 4, 1, false, D_HV, DIR, MAP_HID, MAP_DIR, g.views_w, 256 + 27, nullptr))) return rc;
+    if ((rc = launch_dgrad<PREC, 8, 8, 8, false, false>(dgrad(EVD_BWD_VIEWS, D_HV, -1, -1, D_F), b.tiles, st))) return rc;
     // feature_linear and alpha_linear both read h_7
-    if ((rc = launch_dgrad<PREC, 17, 8, 16, true, true>(dgrad(EVD_BWD_HEAD, D_F, G_ALPHA, H0 + 16 * (D - 1), D_H0 + 16 * (D - 1)), b.tiles, st))) return rc;
     if ((rc = wgrad(launch_wgrad<PREC, 8, 8, false>, 8, 8, true, D_F, H0 + 16 * (D - 1), MAP_HID, MAP_HID, g.feature_w, 256, g.feature_b))) return rc;
     if ((rc = wgrad(launch_wgrad<PREC, 1, 8, true>, 1, 8, true, G_ALPHA, H0 + 16 * (D - 1), MAP_ALPHA, MAP_HID, g.alpha_w, 256, g.alpha_b))) return rc;
+    if ((rc = launch_dgrad<PREC, 17, 8, 16, true, true>(dgrad(EVD_BWD_HEAD, D_F, G_ALPHA, H0 + 16 * (D - 1), D_H0 + 16 * (D - 1)), b.tiles, st))) return rc;
     // pts_linears[l], l = 7 .. 1
     for (int l = D - 1; l >= 1; --l) {
         const bool wide = l - 1 == b.skip;
-        if ((rc = launch_dgrad<PREC, 16, 8, 16, false, true>(dgrad(EVD_BWD_HIDDEN1 + l - 1, D_H0 + 16 * l, -1, H0 + 16 * (l - 1), D_H0 + 16 * (l - 1)), b.tiles, st))) return rc;
         if ((rc = wgrad(launch_wgrad<PREC, 8, 8, false>, 8, 8, true, D_H0 + 16 * l, H0 + 16 * (l - 1), MAP_HID, wide ? MAP_HID_SKIP : MAP_HID,
                         g.pts_w[l], wide ? 256 + 63 : 256, g.pts_b[l]))) return rc;
         if (wide && (rc = wgrad(launch_wgrad<PREC, 8, 2, false>, 8, 2, false, D_H0 + 16 * l, PE, MAP_HID, MAP_PE, g.pts_w[l], 256 + 63, nullptr))) return rc;
+        if ((rc = launch_dgrad<PREC, 16, 8, 16, false, true>(dgrad(EVD_BWD_HIDDEN1 + l - 1, D_H0 + 16 * l, -1, H0 + 16 * (l - 1), D_H0 + 16 * (l - 1)), b.tiles, st))) return rc;
     }
     // gradient w.r.t. the rays: the encoding rows of pts_linears[0], of the skip layer and of views_linears.0, then through sin / cos
     if (b.d_pts) {
@@ -435,7 +444,12 @@ template <int PREC> static int run_nerf_backward(const BwdPlan& b, hipStream_t s
         EVD_LAUNCH_CHECK();
     }
     // pts_linears[0] on PE(pts) (no dgrad beyond the inputs)
-    return wgrad(launch_wgrad<PREC, 8, 2, false>, 8, 2, true, D_H0, PE, MAP_HID, MAP_PE, g.pts_w[0], 63, g.pts_b[0]);
+    if ((rc = wgrad(launch_wgrad<PREC, 8, 2, false>, 8, 2, true, D_H0, PE, MAP_HID, MAP_PE, g.pts_w[0], 63, g.pts_b[0]))) return rc;
+    if (b.side) {                               // join the side stream
+        EVD_HIP(hipEventRecord(b.ev, b.side));
+        EVD_HIP(hipStreamWaitEvent(st, b.ev, 0));
+    }
+    return EVD_OK;
 }
 
 }  // namespace evd

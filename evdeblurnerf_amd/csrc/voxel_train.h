@@ -34,6 +34,8 @@ struct VoxBwdPlan {
     float* partial;
     unsigned* maxbits;
     int wgrad_blocks;
+    hipStream_t side;                   // second stream for the wgrad launches (null: none), nerf_train.h
+    hipEvent_t ev;
     float* d_fts;                       // [nsamp, d_fts_stride] float32 out, or null
     int d_fts_stride;
     const float *pts, *viewdirs;        // the forward's inputs (for the encodings' derivatives)

@@ -118,23 +118,32 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
         const int blocks = (int)(cdiv(b.tiles, (long)WGRAD_TPI) < b.wgrad_blocks ? cdiv(b.tiles, (long)WGRAD_TPI) : b.wgrad_blocks);
         WgradParams p;
         p.store = b.store; p.tiles = b.tiles; p.tile_bytes = VS::TILE_BYTES; p.y_slot = y_slot; p.x_slot = x_slot; p.bias = bias ? 1 : 0; p.partial = b.partial;
-        int r = launch(p, blocks, st);
+        hipStream_t ws = st;
+        if (b.side) {                           // fork: everything issued so far on the caller's stream first (nerf_train_kernel.h)
+            EVD_HIP(hipEventRecord(b.ev, st));
+            EVD_HIP(hipStreamWaitEvent(b.side, b.ev, 0));
+            ws = b.side;
+        }
+        int r = launch(p, blocks, ws);
         if (r) return r;
         WreduceParams q;
         q.partial = b.partial; q.nparts = blocks; q.RT = RT; q.CT = CT; q.NC = CT + (bias ? 1 : 0);
         q.rowmap = b.maps + ymap; q.colmap = b.maps + xmap; q.dW = dW; q.ld = ld; q.db = bias ? db : nullptr; q.maxbits = b.maxbits;
-        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((long)RT * q.NC * 4)), dim3(256), 0, st, q);
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((long)RT * q.NC * 4)), dim3(256), 0, ws, q);
         EVD_LAUNCH_CHECK();
         return EVD_OK;
     };
     const VoxBwdGrads& g = b.grads;
+    // (each wgrad is issued before the dgrad layer that reads the same arrays: independent, concurrent on the side stream)
     // color_net.2 (+ sigmoid, folded into the gradient fragment)
-    if ((rc = launch_dgrad<PREC, 1, T, 1, false, true>(dgrad(VBWD_C2, VS::G_COL, -1, VS::C1, VS::D_C1), b.tiles, st))) return rc;
     if ((rc = wgrad(launch_wgrad<PREC, 1, T, true>, 1, T, true, VS::G_COL, VS::C1, VMAP_COL, VMAP_HID, g.color_w[2], HD, g.color_b[2]))) return rc;
+    if ((rc = launch_dgrad<PREC, 1, T, 1, false, true>(dgrad(VBWD_C2, VS::G_COL, -1, VS::C1, VS::D_C1), b.tiles, st))) return rc;
     // color_net.1
-    if ((rc = launch_dgrad<PREC, KS, T, KS, false, true>(dgrad(VBWD_C1, VS::D_C1, -1, VS::C0, VS::D_C0), b.tiles, st))) return rc;
     if ((rc = wgrad(launch_wgrad<PREC, T, T, false>, T, T, true, VS::D_C1, VS::C1 - KS, VMAP_HID, VMAP_HID, g.color_w[1], HD, g.color_b[1]))) return rc;
+    if ((rc = launch_dgrad<PREC, KS, T, KS, false, true>(dgrad(VBWD_C1, VS::D_C1, -1, VS::C0, VS::D_C0), b.tiles, st))) return rc;
     // color_net.0 on cat([geo, PE(dirs)])
+    if ((rc = wgrad(launch_wgrad<PREC, T, GT, false>, T, GT, true, VS::D_C0, VS::GEO, VMAP_HID, VMAP_GEO_X, g.color_w[0], G + ICV, g.color_b[0]))) return rc;
+    if ((rc = wgrad(launch_wgrad<PREC, T, 1, false>, T, 1, false, VS::D_C0, VS::DIRPE, VMAP_HID, VMAP_DIR, g.color_w[0], G + ICV, nullptr))) return rc;
     if ((rc = launch_dgrad<PREC, KS, GT + 1, KS, false, false>(dgrad(VBWD_C0, VS::D_C0, -1, -1, VS::D_GEO), b.tiles, st))) return rc;   // d geo | d PE(dirs)
     if (b.d_feature) {          // + the gradient of the geo features as an output of the level (voxnerf.py:221, consumed by AWP)
         if (G % 16) return fail(EVD_E_INVALID, "evd_voxel_mlp_backward: d_feature is built for the fine level (geo 128)");
@@ -147,13 +156,13 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
                            VS::D_DIRPE, b.nsamp, b.viewdirs, b.vd_stride, b.S, b.maxbits, b.d_dirs, 0);
         EVD_LAUNCH_CHECK();
     }
-    if ((rc = wgrad(launch_wgrad<PREC, T, GT, false>, T, GT, true, VS::D_C0, VS::GEO, VMAP_HID, VMAP_GEO_X, g.color_w[0], G + ICV, g.color_b[0]))) return rc;
-    if ((rc = wgrad(launch_wgrad<PREC, T, 1, false>, T, 1, false, VS::D_C0, VS::DIRPE, VMAP_HID, VMAP_DIR, g.color_w[0], G + ICV, nullptr))) return rc;
     // sigma_net.1 = [sigma row | geo rows] on hid
-    if ((rc = launch_dgrad<PREC, 2 * GT + 1, T, 2 * GT, true, true>(dgrad(VBWD_SIGGEO, VS::D_GEO, VS::G_SIG, VS::HID, VS::D_HID), b.tiles, st))) return rc;
     if ((rc = wgrad(launch_wgrad<PREC, GT, T, false>, GT, T, false, VS::D_GEO, VS::HID, VMAP_GEO_Y, VMAP_HID, g.sigma_w[1], HD, nullptr))) return rc;
     if ((rc = wgrad(launch_wgrad<PREC, 1, T, true>, 1, T, false, VS::G_SIG, VS::HID, VMAP_SIG, VMAP_HID, g.sigma_w[1], HD, nullptr))) return rc;
+    if ((rc = launch_dgrad<PREC, 2 * GT + 1, T, 2 * GT, true, true>(dgrad(VBWD_SIGGEO, VS::D_GEO, VS::G_SIG, VS::HID, VS::D_HID), b.tiles, st))) return rc;
     // sigma_net.0 on cat([fts, PE(pts)])
+    if ((rc = wgrad(launch_wgrad<PREC, T, FTT, false>, T, FTT, false, VS::D_HID, VS::IN0, VMAP_HID, VMAP_FTS, g.sigma_w[0], FT + IC, nullptr))) return rc;
+    if ((rc = wgrad(launch_wgrad<PREC, T, 2, false>, T, 2, false, VS::D_HID, VS::IN0 + KF, VMAP_HID, VMAP_PE, g.sigma_w[0], FT + IC, nullptr))) return rc;
     if (b.d_fts || b.d_pts) {
         if ((rc = launch_dgrad<PREC, KS, FTT + 2, KS, false, false>(dgrad(VBWD_L0, VS::D_HID, -1, -1, VS::D_FTS), b.tiles, st))) return rc;       // d fts | d PE(pts)
         if (b.d_fts) {
@@ -167,8 +176,11 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
             EVD_LAUNCH_CHECK();
         }
     }
-    if ((rc = wgrad(launch_wgrad<PREC, T, FTT, false>, T, FTT, false, VS::D_HID, VS::IN0, VMAP_HID, VMAP_FTS, g.sigma_w[0], FT + IC, nullptr))) return rc;
-    return wgrad(launch_wgrad<PREC, T, 2, false>, T, 2, false, VS::D_HID, VS::IN0 + KF, VMAP_HID, VMAP_PE, g.sigma_w[0], FT + IC, nullptr);
+    if (b.side) {                               // join
+        EVD_HIP(hipEventRecord(b.ev, b.side));
+        EVD_HIP(hipStreamWaitEvent(st, b.ev, 0));
+    }
+    return EVD_OK;
 }
 
 }  // namespace evd
