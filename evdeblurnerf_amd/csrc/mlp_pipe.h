@@ -229,6 +229,7 @@ template <class C> struct Pipe {
     typename C::O::A abuf[C::PD];
     f32x16 acc[2][2][C::NS];
     f32x16 accx[2][2][C::NS];      // cross-term accumulators (split precision only; dead otherwise)
+    unsigned mbits[C::NS][4];      // training kernels: bit mask of the layer output being completed (LayerDesc MSLOT)
 };
 
 constexpr int cmin(int a, int b) { return a < b ? a : b; }
@@ -247,11 +248,16 @@ constexpr int cceil(int a, int b) { return (a + b - 1) / b; }
 //   NEXT_G   tiles of the next layer's first group (0 = last layer of the kernel: no prefetch beyond)
 //   OSLOT    training kernels: fragment slot of this layer's output in the activation store (-1: not stored);
 //   PSLOT    ... slot of the FIRST fragment of the pending group handed over by the previous layer
+//   MSLOT    ... >= 0: the ReLU pattern of this layer's output is also collected as a bit mask (frag_bits) in pp.mbits; the mask
+//            fragment is stored by the NEXT layer when it completes the pending group: its PMSLOT (slot) and PFRAG0 (fragment index
+//            of the first pending fragment inside the producing layer)
 template <int KTOT_, int TILES_, int G_, bool RELU_, bool F32OUT_, int CHUNK0_, int FOFF_, bool PAD_END_, int AOFF_, int PAR_, int PG_,
-          bool PRELU_, int PDOFF_, int PFEAT_TILE0_, bool OWN_FEAT_, int NEXT_G_, int OSLOT_ = -1, int PSLOT_ = -1>
+          bool PRELU_, int PDOFF_, int PFEAT_TILE0_, bool OWN_FEAT_, int NEXT_G_, int OSLOT_ = -1, int PSLOT_ = -1, int MSLOT_ = -1, int PMSLOT_ = -1,
+          int PFRAG0_ = 0>
 struct LayerDesc {
     static constexpr int KTOT = KTOT_, TILES = TILES_, CHUNK0 = CHUNK0_, FOFF = FOFF_, AOFF = AOFF_, PAR = PAR_, PG = PG_, PDOFF = PDOFF_,
-                         PFEAT_TILE0 = PFEAT_TILE0_, NEXT_G = NEXT_G_, OSLOT = OSLOT_, PSLOT = PSLOT_;
+                         PFEAT_TILE0 = PFEAT_TILE0_, NEXT_G = NEXT_G_, OSLOT = OSLOT_, PSLOT = PSLOT_, MSLOT = MSLOT_, PMSLOT = PMSLOT_,
+                         PFRAG0 = PFRAG0_;
     static constexpr bool RELU = RELU_, F32OUT = F32OUT_, PAD_END = PAD_END_, PRELU = PRELU_, OWN_FEAT = OWN_FEAT_;
     static constexpr int G = G_;
     static constexpr int NG = TILES_ / G;
@@ -310,9 +316,36 @@ __device__ __forceinline__ unsigned mask_word(unsigned g, unsigned a) {
     return g & __builtin_bit_cast(unsigned, av != zero);
 }
 
-// OMASK (backward kernels): every stored output fragment is first multiplied by the 0/1 ReLU pattern of the activation
-// fragment omask[sample tile][fragment]
-template <class C, class L, class ST, int NOUT, int P, bool TRAIN, bool OMASK>
+// bit e = (element e of the packed fragment != 0): the ReLU pattern of a stored activation fragment in one byte
+template <class B> __device__ __forceinline__ unsigned frag_bits(const B& f) {
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    const u16x2 one = {1, 1};
+    unsigned b = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {       // v_pk_min_u16 against 1: (half != 0) in bits 0 and 16
+        const unsigned t = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, f.w[e]), one));
+        b |= ((t | (t >> 15)) & 3u) << (2 * e);
+    }
+    return b;
+}
+// ... of NF fragments, byte j = fragment j (NF <= 16): one 16-byte "mask fragment" per lane
+template <class B, int NF> __device__ __forceinline__ B frags_bitmask(const B (&f)[NF]) {
+    B m;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m.w[e] = 0u;
+#pragma unroll
+    for (int j = 0; j < NF; ++j) m.w[j >> 2] |= frag_bits(f[j]) << (8 * (j & 3));
+    return m;
+}
+// packed-pair mask word e of fragment fo from such a mask fragment
+template <class B> __device__ __forceinline__ unsigned mask_from_bits(const B& m, int fo, int e) {
+    const unsigned two = (m.w[fo >> 2] >> (8 * (fo & 3) + 2 * e)) & 3u;
+    return (0u - (two & 1u)) & 0xffffu | (0u - (two >> 1)) & 0xffff0000u;
+}
+
+// OMASK (backward kernels): every stored output fragment is first multiplied by the 0/1 ReLU pattern of the saved activation:
+// 1 = from the activation fragments omask[sample tile][fragment], 2 = from one bit-mask fragment omask[sample tile]
+template <class C, class L, class ST, int NOUT, int P, bool TRAIN, int OMASK>
 __device__ __forceinline__ void pipe_group(ST& st, Pipe<C>& pp, typename C::O::B (&in)[C::NS][L::KTOT],
                                            typename C::O::B (&out)[C::NS][NOUT], const float* __restrict__ bias, int h,
                                            float* const* frow, char* const* act, const typename C::O::B* omask) {
@@ -360,7 +393,20 @@ __device__ __forceinline__ void pipe_group(ST& st, Pipe<C>& pp, typename C::O::B
                             float* fr = (L::PFEAT_TILE0 >= 0 && frow[ds]) ? frow[ds] + 32 * (L::PFEAT_TILE0 + dt) + 8 * (k >> 1) + 4 * h : nullptr;
                             drain_pair<C, L::PRELU>(pp.acc[oth][dt][ds], pp.accx[oth][dt][ds], k, in[ds][(L::PG > 0 ? L::PDOFF : 0) + 2 * dt + (k >> 2)], fr);
                             if constexpr (TRAIN && L::PSLOT >= 0)
-                                if ((k & 3) == 3) act_store(act[ds], L::PSLOT + 2 * dt + (k >> 2), in[ds][(L::PG > 0 ? L::PDOFF : 0) + 2 * dt + (k >> 2)]);
+                                if ((k & 3) == 3) {
+                                    const auto& pf = in[ds][(L::PG > 0 ? L::PDOFF : 0) + 2 * dt + (k >> 2)];
+                                    act_store(act[ds], L::PSLOT + 2 * dt + (k >> 2), pf);
+                                    if constexpr (L::PMSLOT >= 0) {
+                                        const int fi = L::PFRAG0 + 2 * dt + (k >> 2);
+                                        pp.mbits[ds][fi >> 2] |= frag_bits(pf) << (8 * (fi & 3));
+                                        if (dt == L::PG - 1 && k == 7) {         // the producing layer's output is complete: its mask fragment
+                                            typename C::O::B mf;
+#pragma unroll
+                                            for (int e = 0; e < 4; ++e) { mf.w[e] = pp.mbits[ds][e]; pp.mbits[ds][e] = 0u; }
+                                            act_store(act[ds], L::PMSLOT, mf);
+                                        }
+                                    }
+                                }
                         } else {
                             constexpr int tile0 = P > 0 ? (P - 1) * G : 0;
                             float* fr = (L::OWN_FEAT && frow[ds]) ? frow[ds] + 32 * (tile0 + dt) + 8 * (k >> 1) + 4 * h : nullptr;
@@ -368,11 +414,15 @@ __device__ __forceinline__ void pipe_group(ST& st, Pipe<C>& pp, typename C::O::B
                             if constexpr (TRAIN && L::OSLOT >= 0)
                                 if ((k & 3) == 3) {
                                     const int fo = 2 * (tile0 + dt) + (k >> 2);
-                                    if constexpr (OMASK) {
+                                    if constexpr (OMASK == 1) {
 #pragma unroll
                                         for (int e = 0; e < 4; ++e) out[ds][fo].w[e] = mask_word(out[ds][fo].w[e], omask[ds * NOUT + fo].w[e]);
+                                    } else if constexpr (OMASK == 2) {
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) out[ds][fo].w[e] &= mask_from_bits(omask[ds], fo, e);
                                     }
                                     act_store(act[ds], L::OSLOT + fo, out[ds][fo]);
+                                    if constexpr (L::MSLOT >= 0) pp.mbits[ds][fo >> 2] |= frag_bits(out[ds][fo]) << (8 * (fo & 3));
                                 }
                         }
                     }
@@ -409,7 +459,7 @@ __device__ __forceinline__ void pipe_group(ST& st, Pipe<C>& pp, typename C::O::B
     }
 }
 
-template <class C, class L, class ST, int NOUT, int P, bool TRAIN, bool OMASK>
+template <class C, class L, class ST, int NOUT, int P, bool TRAIN, int OMASK>
 struct GroupLoop {
     static __device__ __forceinline__ void run(ST& st, Pipe<C>& pp, typename C::O::B (&in)[C::NS][L::KTOT],
                                                typename C::O::B (&out)[C::NS][NOUT], const float* __restrict__ bias, int h,
@@ -423,7 +473,7 @@ struct GroupLoop {
 // k-steps except the pending ones, which this layer produces itself while it runs; `out` receives the B fragments
 // of every group but the last, which stays pending in the accumulators (or, F32OUT, is returned in out_f32).
 // frow[s]: float32 feature row of sample tile s (null lanes = invalid samples), W floats per sample.
-template <class C, class L, class ST, int NOUT, bool TRAIN = false, bool OMASK = false>
+template <class C, class L, class ST, int NOUT, bool TRAIN = false, int OMASK = 0>
 __device__ __forceinline__ void pipe_layer(ST& st, Pipe<C>& pp, typename C::O::B (&in)[C::NS][L::KTOT],
                                            typename C::O::B (&out)[C::NS][NOUT], float (*out_f32)[4],
                                            const float* __restrict__ bias, int lane, float* const* frow, char* const* act = nullptr,
@@ -461,6 +511,10 @@ __device__ __forceinline__ void pipe_flush(Pipe<C>& pp, typename C::O::B (&out)[
 template <class C, class L, class ST>
 __device__ __forceinline__ void pipe_prime(ST& st, Pipe<C>& pp, const float* __restrict__ bias, int lane) {
     const int h = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < C::NS; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pp.mbits[s][e] = 0u;
 #pragma unroll
     for (int i = 0; i < C::PD - 1; ++i) pp.abuf[(L::AOFF + i) % C::PD] = C::O::load_a(st.frag(L::CHUNK0, L::FOFF + i));
 #pragma unroll

@@ -67,7 +67,10 @@ constexpr int F = H0 + 16 * 8, HV = F + 16, FWD_END = HV + 8;   // feature_linea
 constexpr int G_RGB = FWD_END, G_ALPHA = G_RGB + 1;       // d raw as two single-k-step fragments
 constexpr int D_HV = G_ALPHA + 1, D_F = D_HV + 8, D_H0 = D_F + 16;    // d loss / d pre-activation of hv, feature, h_l (at D_H0 + 16 l)
 constexpr int D_PE0 = D_H0 + 16 * 8, D_PE5 = D_PE0 + PE_KS, D_DIRG = D_PE5 + PE_KS;   // d PE(pts) via pts_linears[0] / the skip layer, d PE(dirs): the encodings' own arrangement
-constexpr int TILE_FRAGS = D_DIRG + PEV_KS;
+// ReLU patterns as bit masks (1 bit per activation: byte j of a lane's 16 bytes = the 8 elements of fragment j): what the dgrad
+// epilogue reads instead of the 16 activation fragments
+constexpr int M_H0 = D_DIRG + PEV_KS, M_HV = M_H0 + 8;
+constexpr int TILE_FRAGS = M_HV + 1;
 constexpr long TILE_BYTES = (long)TILE_FRAGS * 1024;
 }  // namespace astore
 

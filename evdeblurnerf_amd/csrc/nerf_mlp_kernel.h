@@ -29,6 +29,8 @@ template <class C, int W, int D, int SKIP, bool FEAT, bool TRAIN = false> struct
     // training kernels: slot of hidden layer l's output in the activation store, and of its last (pending) group
     static constexpr int oslot(int l) { return TRAIN ? astore::H0 + 16 * l : -1; }
     static constexpr int pslot(int l) { return TRAIN ? astore::H0 + 16 * l + 2 * (T - HG) : -1; }
+    static constexpr int mslot(int l) { return TRAIN ? astore::M_H0 + l : -1; }      // bit mask of hidden layer l's ReLU pattern
+    static constexpr int PF0 = 2 * (T - HG);                                        // first pending fragment of a T-tile layer
     static_assert(!TRAIN || (W == 256 && D == 8), "the activation store is laid out for the 8 x 256 network");
     static constexpr int chunk0(int l) {                           // first chunk of hidden layer l (l == D: the heads)
         int c = CH_L0;
@@ -36,22 +38,22 @@ template <class C, int W, int D, int SKIP, bool FEAT, bool TRAIN = false> struct
         return c;
     }
     // layer 0: PE(pts) -> W
-    typedef LayerDesc<PE_KS, T, HG, true, false, 0, 0, true, 0, 0, 0, false, 0, -1, FEAT && D == 1, HG, oslot(0)> L0;
+    typedef LayerDesc<PE_KS, T, HG, true, false, 0, 0, true, 0, 0, 0, false, 0, -1, FEAT && D == 1, HG, oslot(0), -1, mslot(0)> L0;
     static constexpr int par(int l) { return (L0::PAR_OUT + (l - 1) * (T / HG)) & 1; }   // accumulator parity entering hidden layer l
     // hidden layer l (1 .. D-1); the skip layer's k-step order is [h_0..h_{PDH-1} | pe_0..3 | h_PDH..h_{KS-1}]
     template <int l> using Hidden = std::conditional_t<
         is_wide(l),
-        LayerDesc<KS + PE_KS, T, HG, true, false, chunk0(l), 0, true, 0, par(l), HG, true, KS + PE_KS - 2 * HG, -1, FEAT && l == D - 1, HG, oslot(l), pslot(l - 1)>,
-        LayerDesc<KS, T, HG, true, false, chunk0(l), 0, true, 0, par(l), HG, true, PDH, -1, FEAT && l == D - 1, HG, oslot(l), pslot(l - 1)>>;
+        LayerDesc<KS + PE_KS, T, HG, true, false, chunk0(l), 0, true, 0, par(l), HG, true, KS + PE_KS - 2 * HG, -1, FEAT && l == D - 1, HG, oslot(l), pslot(l - 1), mslot(l), mslot(l - 1), PF0>,
+        LayerDesc<KS, T, HG, true, false, chunk0(l), 0, true, 0, par(l), HG, true, PDH, -1, FEAT && l == D - 1, HG, oslot(l), pslot(l - 1), mslot(l), mslot(l - 1), PF0>>;
     // heads (nerf.py:144-157): alpha_linear, feature_linear, views_linears.0 on cat([feature, PE(dir)]), rgb_linear
     static constexpr int CH_H = chunk0(D);
-    typedef LayerDesc<KS, 1, 1, false, true, CH_H, 0, false, 0, par(D), HG, true, PDH, FEAT ? T - HG : -1, false, HG, -1, pslot(D - 1)> Alpha;
+    typedef LayerDesc<KS, 1, 1, false, true, CH_H, 0, false, 0, par(D), HG, true, PDH, FEAT ? T - HG : -1, false, HG, -1, pslot(D - 1), -1, mslot(D - 1), PF0> Alpha;
     static constexpr int F1 = KS;
     typedef LayerDesc<KS, T, HG, false, false, CH_H, F1, false, F1 % PD, Alpha::PAR_OUT, 0, false, 0, -1, FEAT, VG, TRAIN ? astore::F : -1> Feature;
     static constexpr int F2 = F1 + T * KS;
-    typedef LayerDesc<KS + PEV_KS, T / 2, VG, true, false, CH_H, F2, false, F2 % PD, Feature::PAR_OUT, HG, false, PDH, FEAT ? T - HG : -1, false, 1, TRAIN ? astore::HV : -1, TRAIN ? astore::F + 2 * (T - HG) : -1> Views;
+    typedef LayerDesc<KS + PEV_KS, T / 2, VG, true, false, CH_H, F2, false, F2 % PD, Feature::PAR_OUT, HG, false, PDH, FEAT ? T - HG : -1, false, 1, TRAIN ? astore::HV : -1, TRAIN ? astore::F + 2 * (T - HG) : -1, TRAIN ? astore::M_HV : -1> Views;
     static constexpr int F3 = F2 + (T / 2) * (KS + PEV_KS);
-    typedef LayerDesc<KS / 2, 1, 1, false, true, CH_H, F3, true, F3 % PD, Views::PAR_OUT, VG, true, KS / 2 - 2 * VG, -1, false, 0, -1, TRAIN ? astore::HV + 2 * (T / 2 - VG) : -1> Rgb;
+    typedef LayerDesc<KS / 2, 1, 1, false, true, CH_H, F3, true, F3 % PD, Views::PAR_OUT, VG, true, KS / 2 - 2 * VG, -1, false, 0, -1, TRAIN ? astore::HV + 2 * (T / 2 - VG) : -1, -1, TRAIN ? astore::M_HV : -1, 2 * (T / 2 - VG)> Rgb;
     static constexpr int NCH = CH_H + cceil(F3 + KS / 2, FPC);     // chunks of the whole stream
     static_assert(D >= 1 && T % HG == 0 && (T * PE_KS) % PD == 0 && (T * KS) % PD == 0, "fragment counts must keep the prefetch ring phase");
 };
@@ -214,6 +216,7 @@ __global__ __launch_bounds__(NT, NT / 256) void k_nerf_mlp(const MlpParams p) {
     pipe_layer<C, typename N::Views, decltype(cx.st), KS / 2, TRAIN>(cx.st, cx.pp, vin, hbuf, nullptr, lb, lane, cx.frow_after, actl);
     lb += (T / 2) * 32;
     pipe_layer<C, typename N::Rgb, decltype(cx.st), 1, TRAIN>(cx.st, cx.pp, hbuf, none, rraw, lb, lane, nofrow, actl);
+
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         if (h == 0 && valid[s]) {

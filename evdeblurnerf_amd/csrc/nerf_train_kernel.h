@@ -80,7 +80,7 @@ struct DgradParams {
 // from extra_slot if EXTRA), TILES 32-row tiles out, multiplied by the ReLU pattern of the activation fragments at mask_slot
 // (OMASK) before they are stored: what the next dgrad layer and the wgrad kernel read is d loss / d pre-activation.
 // 8 wavefronts x 32 samples per workgroup.
-template <int PREC, int KTOT, int TILES, int NIN, bool EXTRA, bool OMASK, int NT>
+template <int PREC, int KTOT, int TILES, int NIN, bool EXTRA, int OMASK, int NT>
 __global__ __launch_bounds__(NT, NT / 256) void k_dgrad_layer(const DgradParams p) {
     typedef PipeCfg<PREC, 1, NT> C;
     typedef typename C::O::B B;
@@ -97,13 +97,15 @@ __global__ __launch_bounds__(NT, NT / 256) void k_dgrad_layer(const DgradParams 
     for (int i = tid; i < (TILES + 1) * 32; i += NT) zb[i] = 0.f;
     char* al = p.store + ((long)blockIdx.x * (NT / 64) + wave) * p.tile_bytes + lane * 16;
 
-    B in[1][KTOT], out[1][2 * TILES], om[OMASK ? 2 * TILES : 1];
+    B in[1][KTOT], out[1][2 * TILES], om[OMASK == 1 ? 2 * TILES : 1];
 #pragma unroll
     for (int j = 0; j < NIN; ++j) in[0][j] = frag_load<B>(al, p.in_slot + j);
     if constexpr (EXTRA) in[0][NIN] = frag_load<B>(al, p.extra_slot);
-    if constexpr (OMASK) {
+    if constexpr (OMASK == 1) {
 #pragma unroll
         for (int j = 0; j < 2 * TILES; ++j) om[j] = frag_load<B>(al, p.mask_slot + j);
+    } else if constexpr (OMASK == 2) {
+        om[0] = frag_load<B>(al, p.mask_slot);          // the bit-mask fragment (nerf_mlp.h M_H0 ..)
     }
     char* actl[1] = {al + (long)p.out_slot * 1024};
     float* nofrow[1] = {nullptr};
@@ -114,15 +116,18 @@ __global__ __launch_bounds__(NT, NT / 256) void k_dgrad_layer(const DgradParams 
     pipe_flush<C, L>(pp, out);
 #pragma unroll
     for (int j = 2 * TILES - 2; j < 2 * TILES; ++j) {
-        if constexpr (OMASK) {
+        if constexpr (OMASK == 1) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) out[0][j].w[e] = mask_word(out[0][j].w[e], om[j].w[e]);
+        } else if constexpr (OMASK == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[0][j].w[e] &= mask_from_bits(om[0], j, e);
         }
         act_store(actl[0], j, out[0][j]);
     }
 }
 
-template <int PREC, int KTOT, int TILES, int NIN, bool EXTRA, bool OMASK>
+template <int PREC, int KTOT, int TILES, int NIN, bool EXTRA, int OMASK>
 static int launch_dgrad(const DgradParams& p, long tiles, hipStream_t st) {
     constexpr int NT = 512;
     typedef PipeCfg<PREC, 1, NT> C;
@@ -407,38 +412,38 @@ template <int PREC> static int run_nerf_backward(const BwdPlan& b, hipStream_t s
     // the Infinity Cache.
     // rgb_linear: d hv = Wr^T d rgb;  dWr = d rgb . hv^T
     if ((rc = wgrad(launch_wgrad<PREC, 1, 4, true>, 1, 4, true, G_RGB, HV, MAP_RGB, MAP_HID, g.rgb_w, 128, g.rgb_b))) return rc;
-    if ((rc = launch_dgrad<PREC, 1, 4, 1, false, true>(dgrad(EVD_BWD_RGB, G_RGB, -1, HV, D_HV), b.tiles, st))) return rc;
+    if ((rc = launch_dgrad<PREC, 1, 4, 1, false, 2>(dgrad(EVD_BWD_RGB, G_RGB, -1, M_HV, D_HV), b.tiles, st))) return rc;
     // views_linears.0 on cat([feature, PE(dir)])
     if ((rc = wgrad(launch_wgrad<PREC, 4, 8, false>, 4, 8, true, D_HV, F, MAP_HID, MAP_HID, g.views_w, 256 + 27, g.views_b))) return rc;
     if ((rc = wgrad(launch_wgrad<PREC, 4, 1, false>, 4, 1, false, D_HV, DIR, MAP_HID, MAP_DIR, g.views_w, 256 + 27, nullptr))) return rc;
-    if ((rc = launch_dgrad<PREC, 8, 8, 8, false, false>(dgrad(EVD_BWD_VIEWS, D_HV, -1, -1, D_F), b.tiles, st))) return rc;
+    if ((rc = launch_dgrad<PREC, 8, 8, 8, false, 0>(dgrad(EVD_BWD_VIEWS, D_HV, -1, -1, D_F), b.tiles, st))) return rc;
     // feature_linear and alpha_linear both read h_7
     if ((rc = wgrad(launch_wgrad<PREC, 8, 8, false>, 8, 8, true, D_F, H0 + 16 * (D - 1), MAP_HID, MAP_HID, g.feature_w, 256, g.feature_b))) return rc;
     if ((rc = wgrad(launch_wgrad<PREC, 1, 8, true>, 1, 8, true, G_ALPHA, H0 + 16 * (D - 1), MAP_ALPHA, MAP_HID, g.alpha_w, 256, g.alpha_b))) return rc;
-    if ((rc = launch_dgrad<PREC, 17, 8, 16, true, true>(dgrad(EVD_BWD_HEAD, D_F, G_ALPHA, H0 + 16 * (D - 1), D_H0 + 16 * (D - 1)), b.tiles, st))) return rc;
+    if ((rc = launch_dgrad<PREC, 17, 8, 16, true, 2>(dgrad(EVD_BWD_HEAD, D_F, G_ALPHA, M_H0 + D - 1, D_H0 + 16 * (D - 1)), b.tiles, st))) return rc;
     // pts_linears[l], l = 7 .. 1
     for (int l = D - 1; l >= 1; --l) {
         const bool wide = l - 1 == b.skip;
         if ((rc = wgrad(launch_wgrad<PREC, 8, 8, false>, 8, 8, true, D_H0 + 16 * l, H0 + 16 * (l - 1), MAP_HID, wide ? MAP_HID_SKIP : MAP_HID,
                         g.pts_w[l], wide ? 256 + 63 : 256, g.pts_b[l]))) return rc;
         if (wide && (rc = wgrad(launch_wgrad<PREC, 8, 2, false>, 8, 2, false, D_H0 + 16 * l, PE, MAP_HID, MAP_PE, g.pts_w[l], 256 + 63, nullptr))) return rc;
-        if ((rc = launch_dgrad<PREC, 16, 8, 16, false, true>(dgrad(EVD_BWD_HIDDEN1 + l - 1, D_H0 + 16 * l, -1, H0 + 16 * (l - 1), D_H0 + 16 * (l - 1)), b.tiles, st))) return rc;
+        if ((rc = launch_dgrad<PREC, 16, 8, 16, false, 2>(dgrad(EVD_BWD_HIDDEN1 + l - 1, D_H0 + 16 * l, -1, M_H0 + l - 1, D_H0 + 16 * (l - 1)), b.tiles, st))) return rc;
     }
     // gradient w.r.t. the rays: the encoding rows of pts_linears[0], of the skip layer and of views_linears.0, then through sin / cos
     if (b.d_pts) {
-        if ((rc = launch_dgrad<PREC, 16, 2, 16, false, false>(dgrad(EVD_BWD_PE0, D_H0, -1, -1, D_PE0), b.tiles, st))) return rc;
+        if ((rc = launch_dgrad<PREC, 16, 2, 16, false, 0>(dgrad(EVD_BWD_PE0, D_H0, -1, -1, D_PE0), b.tiles, st))) return rc;
         hipLaunchKernelGGL((k_pe_bwd<PREC, PE_L, PE_KS>), dim3((unsigned)cdiv(b.tiles * 64, 256L)), dim3(256), 0, st, (const char*)b.store, TILE_BYTES, D_PE0,
                            b.nsamp, b.pts, 3, 1, b.maxbits, b.d_pts, 0);
         EVD_LAUNCH_CHECK();
         if (b.skip >= 0 && b.skip + 1 < D) {
-            if ((rc = launch_dgrad<PREC, 16, 2, 16, false, false>(dgrad(EVD_BWD_PESKIP, D_H0 + 16 * (b.skip + 1), -1, -1, D_PE5), b.tiles, st))) return rc;
+            if ((rc = launch_dgrad<PREC, 16, 2, 16, false, 0>(dgrad(EVD_BWD_PESKIP, D_H0 + 16 * (b.skip + 1), -1, -1, D_PE5), b.tiles, st))) return rc;
             hipLaunchKernelGGL((k_pe_bwd<PREC, PE_L, PE_KS>), dim3((unsigned)cdiv(b.tiles * 64, 256L)), dim3(256), 0, st, (const char*)b.store, TILE_BYTES, D_PE5,
                                b.nsamp, b.pts, 3, 1, b.maxbits, b.d_pts, 1);
             EVD_LAUNCH_CHECK();
         }
     }
     if (b.d_dirs) {
-        if ((rc = launch_dgrad<PREC, 8, 1, 8, false, false>(dgrad(EVD_BWD_DIR, D_HV, -1, -1, D_DIRG), b.tiles, st))) return rc;
+        if ((rc = launch_dgrad<PREC, 8, 1, 8, false, 0>(dgrad(EVD_BWD_DIR, D_HV, -1, -1, D_DIRG), b.tiles, st))) return rc;
         hipLaunchKernelGGL((k_pe_bwd<PREC, PE_LV, PEV_KS>), dim3((unsigned)cdiv(b.tiles * 64, 256L)), dim3(256), 0, st, (const char*)b.store, TILE_BYTES, D_DIRG,
                            b.nsamp, b.viewdirs, b.vd_stride, b.S, b.maxbits, b.d_dirs, 0);
         EVD_LAUNCH_CHECK();

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 # fragment slots of the activation store (csrc/nerf_mlp.h, namespace astore)
 PE, DIR, H0, F, HV, FWD_END = 0, 4, 6, 134, 150, 158
-G_RGB, G_ALPHA, D_HV, D_F, D_H0, TILE_FRAGS = 158, 159, 160, 168, 184, 322
+G_RGB, G_ALPHA, D_HV, D_F, D_H0, TILE_FRAGS = 158, 159, 160, 168, 184, 331
 
 
 def phi(kk):
