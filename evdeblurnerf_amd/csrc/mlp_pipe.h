@@ -340,7 +340,7 @@ template <class B, int NF> __device__ __forceinline__ B frags_bitmask(const B (&
 // packed-pair mask word e of fragment fo from such a mask fragment
 template <class B> __device__ __forceinline__ unsigned mask_from_bits(const B& m, int fo, int e) {
     const unsigned two = (m.w[fo >> 2] >> (8 * (fo & 3) + 2 * e)) & 3u;
-    return (0u - (two & 1u)) & 0xffffu | (0u - (two >> 1)) & 0xffff0000u;
+    return ((0u - (two & 1u)) & 0xffffu) | ((0u - (two >> 1)) & 0xffff0000u);
 }
 
 // OMASK (backward kernels): every stored output fragment is first multiplied by the 0/1 ReLU pattern of the saved activation:

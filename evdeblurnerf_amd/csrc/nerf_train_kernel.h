@@ -146,7 +146,7 @@ struct WgradParams {
     float* partial;         // [gridDim.x][RT][CT + BIAS][64][16] float32
 };
 
-constexpr int WGRAD_NT = 512, WGRAD_TPI = 2;      // 8 wavefronts; sample tiles per iteration (one barrier each)
+constexpr int WGRAD_NT = 512, WGRAD_TPI = 1;      // 8 wavefronts; sample tiles per iteration (one barrier each)
 constexpr int wgrad_cpg(int RT, int CT) { return cceil(CT, 8 / RT); }      // column tiles per wavefront group
 
 struct W4 { unsigned w[4]; };
@@ -177,13 +177,22 @@ template <int PREC> __device__ __forceinline__ unsigned half_one_pair() { return
 // RT row tiles (fragments y_slot .. ; YSINGLE: one fragment, 16 channels) x CT column tiles (fragments x_slot ..).
 // The 8 wavefronts of a workgroup share every sample tile: wavefront w owns row tile w % RT and the column tiles of its
 // group w / RT in accumulators; it transposes its own gradient block, and (w < CT) the activation block of column tile w,
-// which it publishes through LDS for the others.  Loads run one iteration (WGRAD_TPI tiles) ahead.
+// which it publishes through LDS for the others.  The stored fragments arrive by LDS-DMA (one global_load_lds_dwordx4 = one
+// 1 KiB fragment, no registers in flight) into a ring of WG_RING tiles per wavefront, WG_RING - 1 tiles ahead of their use,
+// with counted vmcnt waits; only the owning wavefront reads its slots, so the ring needs no barrier.  (Measured: a ring of 4 with a
+// single-buffered exchange runs at the same speed; with the products or the barrier ablated, EVD_ABL_WG_*, the kernel is no faster:
+// it is bound by its stream of fragment loads at ~3.7 TB/s.)
+constexpr int WG_RING = 3;
+constexpr int wgrad_lds_bytes(int CT) { return WG_RING * 8 * 4 * 1024 + 2 * CT * 2 * 1024; }
+
 template <int PREC, int RT, int CT, bool YSINGLE>
 __global__ __launch_bounds__(WGRAD_NT) void k_wgrad(const WgradParams p) {
-    constexpr int CPG = wgrad_cpg(RT, CT), TPI = WGRAD_TPI;
-    const int NC = CT + (p.bias ? 1 : 0);
+    constexpr int CPG = wgrad_cpg(RT, CT);
     static_assert(8 % RT == 0 && CT <= 8 && (!YSINGLE || RT == 1), "shape of the block");
-    __shared__ __attribute__((aligned(16))) char xs[2][TPI][CT][2][1024];
+    extern __shared__ __attribute__((aligned(16))) char wsm[];
+    char* raw = wsm;                                          // [WG_RING][8 wavefronts][4 fragments][1 KiB]
+    char* xs = wsm + WG_RING * 8 * 4 * 1024;                  // [2][CT][2][1 KiB] transposed activation blocks
+    const int NC = CT + (p.bias ? 1 : 0);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = lane & 31, h = lane >> 5;
     const int rt = wave % RT, c0 = (wave / RT) * CPG;
     const bool xown = wave < CT, bias_own = p.bias && wave < RT;
@@ -205,58 +214,69 @@ __global__ __launch_bounds__(WGRAD_NT) void k_wgrad(const WgradParams p) {
 #pragma unroll
         for (int c = 0; c < CPG; ++c) acc[c][i] = 0.f;
     }
-    struct Frags { W4 y0, y1, x0, x1; };
-    auto load = [&](long t, Frags& f) {
-        f.y0 = f.y1 = f.x0 = f.x1 = zf;
+    // this wavefront's four fragments of a tile: y0, y1 (row tile rt), x0, x1 (column tile `wave`); absent ones (single-fragment
+    // gradients, wavefronts beyond CT) re-load y0 so that every tile costs the same four DMA instructions (vmcnt accounting)
+    const long oy0 = (long)(p.y_slot + 2 * rt) * 1024, oy1 = YSINGLE ? oy0 : oy0 + 1024;
+    const long ox0 = xown ? (long)(p.x_slot + 2 * wave) * 1024 : oy0, ox1 = xown ? ox0 + 1024 : oy0;
+    const unsigned ring0 = lds_offset_of(raw) + wave * 4096;
+    auto issue = [&](long t, int stage) {
+#ifdef EVD_ABL_WG_NODMA
+        return;
+#endif
         if (t >= p.tiles) return;
-        const char* al = p.store + t * p.tile_bytes + lane * 16;
-        f.y0 = frag_load<W4>(al, p.y_slot + 2 * rt);
-        if constexpr (!YSINGLE) f.y1 = frag_load<W4>(al, p.y_slot + 2 * rt + 1);
-        if (xown) {
-            f.x0 = frag_load<W4>(al, p.x_slot + 2 * wave);
-            f.x1 = frag_load<W4>(al, p.x_slot + 2 * wave + 1);
-        }
+        const char* g = p.store + t * p.tile_bytes + lane * 16;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(ring0 + stage * (8 * 4096));
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %2, off offset:1024\n\t"
+                     "global_load_lds_dwordx4 %3, off offset:2048\n\tglobal_load_lds_dwordx4 %4, off offset:3072\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(g + oy0), "v"(g + oy1 - 1024), "v"(g + ox0 - 2048), "v"(g + ox1 - 3072), "s"(dst) : "memory");
     };
-    Frags cur[TPI], nxt[TPI];
-    const long stride = (long)gridDim.x * TPI;
-    long t0 = (long)blockIdx.x * TPI;
+    const long stride = gridDim.x;
+    long t = blockIdx.x;
 #pragma unroll
-    for (int k = 0; k < TPI; ++k) load(t0 + k, nxt[k]);
-    for (int it = 0; t0 < p.tiles; t0 += stride, ++it) {
+    for (int k = 0; k < WG_RING - 1; ++k) issue(t + k * stride, k);
+    for (int it = 0; t < p.tiles; t += stride, ++it) {
+        issue(t + (WG_RING - 1) * stride, (it + WG_RING - 1) % WG_RING);
+        // the tile's four loads have landed when at most (tiles issued after it) x 4 are still outstanding
+        const int later = (t + stride < p.tiles ? 1 : 0) + (t + 2 * stride < p.tiles ? 1 : 0);
+        if (later == 2) wait_vmcnt<8>();
+        else if (later == 1) wait_vmcnt<4>();
+        else wait_vmcnt<0>();
+        const char* rw = raw + ((it % WG_RING) * 8 + wave) * 4096 + lane * 16;
+        const W4 y0 = *reinterpret_cast<const W4*>(rw), y1 = YSINGLE ? zf : *reinterpret_cast<const W4*>(rw + 1024);
+        W4 yt[2];
+        transpose_block<PREC>(y0, y1, sel0, sel1, yt);
+        char* xb = xs + (it & 1) * (CT * 2048);
+        if (xown) {
+            const W4 x0 = *reinterpret_cast<const W4*>(rw + 2048), x1 = *reinterpret_cast<const W4*>(rw + 3072);
+            W4 xt[2];
+            transpose_block<PREC>(x0, x1, sel0, sel1, xt);
 #pragma unroll
-        for (int k = 0; k < TPI; ++k) {
-            cur[k] = nxt[k];
-            load(t0 + stride + k, nxt[k]);
+            for (int q = 0; q < 2; ++q) *reinterpret_cast<W4*>(xb + (wave * 2 + q) * 1024 + lane * 16) = xt[q];
         }
-        W4 yt[TPI][2];
-#pragma unroll
-        for (int k = 0; k < TPI; ++k) {
-            transpose_block<PREC>(cur[k].y0, cur[k].y1, sel0, sel1, yt[k]);
-            if (xown) {
-                W4 xt[2];
-                transpose_block<PREC>(cur[k].x0, cur[k].x1, sel0, sel1, xt);
-#pragma unroll
-                for (int q = 0; q < 2; ++q) *reinterpret_cast<W4*>(&xs[it & 1][k][wave][q][lane * 16]) = xt[q];
-            }
-        }
+#ifndef EVD_ABL_WG_NOBAR
         __syncthreads();
+#endif
+#ifndef EVD_ABL_WG_NOPROD
 #pragma unroll
-        for (int k = 0; k < TPI; ++k) {
+        for (int c = 0; c < CPG; ++c) {
+            if (c0 + c < CT) {
 #pragma unroll
-            for (int c = 0; c < CPG; ++c) {
-                if (c0 + c < CT) {
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const W4 xq = *reinterpret_cast<const W4*>(&xs[it & 1][k][c0 + c][q][lane * 16]);
-                        acc[c] = mfma_half<PREC>(yt[k][q], xq, acc[c]);
-                    }
+                for (int q = 0; q < 2; ++q) {
+                    const W4 xq = *reinterpret_cast<const W4*>(xb + ((c0 + c) * 2 + q) * 1024 + lane * 16);
+                    acc[c] = mfma_half<PREC>(yt[q], xq, acc[c]);
                 }
             }
-            if (bias_own) {
-#pragma unroll
-                for (int q = 0; q < 2; ++q) accb = mfma_half<PREC>(yt[k][q], ones, accb);
-            }
         }
+        if (bias_own) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) accb = mfma_half<PREC>(yt[q], ones, accb);
+        }
+#else
+        acc[0] = mfma_half<PREC>(yt[0], yt[1], acc[0]);
+#endif
     }
     float* out = p.partial + (((long)blockIdx.x * RT + rt) * NC) * 1024 + lane * 16;
     auto put = [&](int c, const f32x16& a) {
@@ -318,7 +338,9 @@ static __global__ __launch_bounds__(256) void k_wgrad_reduce(const WreduceParams
 
 template <int PREC, int RT, int CT, bool YSINGLE>
 static int launch_wgrad(const WgradParams& p, int blocks, hipStream_t st) {
-    hipLaunchKernelGGL((k_wgrad<PREC, RT, CT, YSINGLE>), dim3(blocks), dim3(WGRAD_NT), 0, st, p);
+    const size_t lds = wgrad_lds_bytes(CT);
+    EVD_SET_MAX_LDS((&k_wgrad<PREC, RT, CT, YSINGLE>), lds);
+    hipLaunchKernelGGL((k_wgrad<PREC, RT, CT, YSINGLE>), dim3(blocks), dim3(WGRAD_NT), lds, st, p);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }
