@@ -227,7 +227,9 @@ __global__ __launch_bounds__(256) void k_voxel_sample(const GridParams g, const 
 // Measured (fine level, 2^19 samples, 302 M float atomics): 1.80 ms, of which 0.52 ms without the atomics; the atomic part runs
 // at ~250 G adds/s = one dword per clock per L2 channel (128 channels), the hardware rate -- plane-only and line-only variants
 // cost the same per add, and 32 private copies of the (heavily shared) line gradients change nothing: it is the op count, not
-// contention.  Fewer adds would need a sort by cell + segmented sum instead of atomics.
+// contention.  Tried and dropped: a run-length sum over the tile's consecutive samples that hit the same cell before the atomic (one
+// thread per (tap, channel) walking the 32 samples): the sequential walk costs more than the adds it saves (3.1 ms) unless the rays
+// run along a grid axis.  Fewer adds would need a sort by cell + segmented sum instead of atomics.
 constexpr int VSB_MAXF = 64, VSB_TAPS = 18;
 __global__ __launch_bounds__(256) void k_voxel_sample_bwd(const GridParams g, const float* __restrict__ pts, long n,
                                                           const float* __restrict__ d_out, int d_stride, int d_col, GridGrads gg,

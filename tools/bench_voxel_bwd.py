@@ -52,7 +52,7 @@ def main():
         return e0.elapsed_time(e1) / a.iters
 
     fwd = timed(lambda: net.sample(pts))
-    bwd = timed(lambda: L.check(L.lib().evd_voxel_sample_bwd(net._h, L.ptr(pts), n, L.ptr(d_out), 32, 0, C.byref(gs), L.stream_ptr()), "bwd"))
+    bwd = timed(lambda: L.check(L.lib().evd_voxel_sample_bwd(net._h, L.ptr(pts), n, L.ptr(d_out), 32, 0, C.byref(gs), None, L.stream_ptr()), "bwd"))
     atom = n * 6 * 96
     print(f"grid {g}: n = {n} samples | gather forward {fwd:.3f} ms | scatter backward {bwd:.3f} ms = {atom / bwd / 1e6:.1f} G float atomics/s")
 
