@@ -328,16 +328,7 @@ template <class B> __device__ __forceinline__ unsigned frag_bits(const B& f) {
     }
     return b;
 }
-// ... of NF fragments, byte j = fragment j (NF <= 16): one 16-byte "mask fragment" per lane
-template <class B, int NF> __device__ __forceinline__ B frags_bitmask(const B (&f)[NF]) {
-    B m;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) m.w[e] = 0u;
-#pragma unroll
-    for (int j = 0; j < NF; ++j) m.w[j >> 2] |= frag_bits(f[j]) << (8 * (j & 3));
-    return m;
-}
-// packed-pair mask word e of fragment fo from such a mask fragment
+// packed-pair mask word e of fragment fo from a mask fragment (byte j of a lane's 16 bytes = frag_bits of fragment j)
 template <class B> __device__ __forceinline__ unsigned mask_from_bits(const B& m, int fo, int e) {
     const unsigned two = (m.w[fo >> 2] >> (8 * (fo & 3) + 2 * e)) & 3u;
     return ((0u - (two & 1u)) & 0xffffu) | ((0u - (two >> 1)) & 0xffff0000u);
