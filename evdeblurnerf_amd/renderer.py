@@ -79,7 +79,25 @@ class NeRFAll:
         self._ws = None
 
     # nn.Module-like switches used by run_nerf.py
+    def sync_parameters(self):
+        """push the current values of the trainable tensors into the library (re-pack the weight streams, reload the grids); the
+        training forward does this lazily, an evaluation render after optimizer.step() needs it explicitly (train(False) calls it)"""
+        tp = getattr(self, "_train_params", None)
+        if tp is None:
+            return
+        for net, p in ((self.mlp_coarse, tp[0]), (self.mlp_fine, tp[1])):
+            if p is None:
+                continue
+            if isinstance(p, dict):
+                if getattr(net, "_synced_net", None) != (p["net"].data_ptr(), p["net"]._version):
+                    net.load_params(p["net"])
+                net._sync(p["grids"])
+            elif getattr(net, "_synced", None) != (p.data_ptr(), p._version):
+                net.load_params(p)
+
     def train(self, mode=True):
+        if not mode:
+            self.sync_parameters()
         self.training = mode
         self.mlp_coarse.train(mode)
         if self.mlp_fine is not None:
@@ -402,11 +420,52 @@ class NeRFAll:
         return torch.stack(rgbs, 0), torch.stack(depths, 0)
 
     # ------------------------------------------------------------------ forward, renderer.py:266-397
+    # ---- the reference's nn.Module surface for a training loop (run_nerf.py:1000-1040) ----------------------------------
+    def enable_training(self, state_dict):
+        """Create the trainable tensors from a state dict and keep them in the model: afterwards `parameters()` feeds an
+        optimizer and `model(H, W, K, chunk, rays=..., **render_kwargs_train)` in training mode runs forward_train (autograd)."""
+        self._train_params = self.trainable_parameters(state_dict)
+        return self
+
+    def parameters(self):
+        """leaf tensors of the two networks / levels (+ the kernelsnet's and the awpnet's own parameters)"""
+        if getattr(self, "_train_params", None) is None:
+            raise L.EvdError("call enable_training(state_dict) first")
+        out = []
+        for p in self._train_params:
+            if p is None:
+                continue
+            out += ([p["net"]] + list(p["grids"])) if isinstance(p, dict) else [p]
+        for m in (self.kernelsnet, self.awpnet):
+            if isinstance(m, torch.nn.Module):
+                out += list(m.parameters())
+        return out
+
+    def state_dict(self):
+        """current values under the reference's state-dict keys and layouts (checkpointing, run_nerf.py:1078-1090)"""
+        if getattr(self, "_train_params", None) is None:
+            raise L.EvdError("call enable_training(state_dict) first")
+        sd = {}
+        for name, net, p in (("mlp_coarse.", self.mlp_coarse, self._train_params[0]), ("mlp_fine.", self.mlp_fine, self._train_params[1])):
+            if p is None:
+                continue
+            flat = p["net"] if isinstance(p, dict) else p
+            sd.update({name + k: v.detach().clone() for k, v in net.unflatten(flat).items()})
+            if isinstance(p, dict):
+                sd.update(net.grids_to_state_dict(p["grids"], name))
+        return sd
+
     def forward(self, H, W, K, chunk=1 << 22, rays=None, rays_info=None, poses=None, **kwargs):
         if not self.training:
             assert poses is not None, "Please specify poses when in the eval model"
             return self.render_path(H, W, K, chunk, poses, **kwargs)
         assert rays is not None, "Please specify rays when in the training mode"
+        if getattr(self, "_train_params", None) is not None:        # differentiable path (enable_training)
+            kw = dict(kwargs)
+            for k in ("retraw", "use_viewdirs", "c2w", "c2w_staticcam", "pytest", "return_pts0_rgb"):
+                kw.pop(k, None)
+            return self.forward_train(H, W, K, rays, self._train_params[0], self._train_params[1], rays_info=rays_info,
+                                      force_naive=kw.pop("force_naive", True), **kw)
         force_baseline = kwargs.pop("force_naive", True)
         return_pts0_rgb = kwargs.pop("return_pts0_rgb", False)
         N_importance = kwargs.get("N_importance", 0)

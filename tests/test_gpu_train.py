@@ -596,3 +596,33 @@ def test_forward_train_reaches_the_blur_kernel(mode):
     opt = torch.optim.Adam(list(kern.parameters()) + nets, lr=1e-3)
     opt.step()
     assert np.isfinite(loss_of().item())
+
+
+def test_module_surface_trains_like_the_reference_loop():
+    """enable_training / parameters() / model(...) / state_dict(): the calls a run_nerf.py-style loop makes."""
+    model, sd = _c2f_model("f16", 16)
+    model.enable_training(sd).train()
+    opt = torch.optim.Adam(model.parameters(), lr=2e-3)
+    Kmat = W.synthetic_camera()
+    rays = torch.tensor(W.synthetic_rays(4, 256), device="cuda")
+    target = torch.full((256, 3), 0.3, device="cuda")
+    kwargs = dict(ndc=True, near=0., far=1., use_viewdirs=True, N_samples=16, N_importance=16, perturb=1.0, raw_noise_std=0., retraw=True)
+    first = None
+    for it in range(8):
+        rgb, rgb0, other_loss, tensors = model(400, 400, Kmat, 1 << 20, rays=rays, **kwargs)
+        loss = ((rgb - target) ** 2).mean() + ((rgb0 - target) ** 2).mean() + 0.01 * other_loss["TV"].sum()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        first = first if first is not None else loss.item()
+    assert loss.item() < first
+    out = model.state_dict()
+    assert set(out) == set(sd) and all(tuple(out[k].shape) == tuple(np.asarray(sd[k]).shape) for k in sd)
+    # the exported values are what the kernels now use: a fresh inference model built from them renders the same image
+    from evdeblurnerf_amd.renderer import NeRFAll
+    fresh = NeRFAll(model.args, {k: v.cpu().numpy() for k, v in out.items()}, precision="f16").eval()
+    model.eval()
+    kw = dict(ndc=True, near=0., far=1., use_viewdirs=True, N_samples=16, N_importance=16, perturb=0., raw_noise_std=0.)
+    a = model.render(400, 400, Kmat, rays=rays, **kw)[0]
+    b = fresh.render(400, 400, Kmat, rays=rays, **kw)[0]
+    assert (a - b).abs().max().item() < 2e-3            # float16 grid copies are re-derived from the exported float32 grids
