@@ -140,6 +140,8 @@ SIGNATURES = {
     "evd_crf_forward": (_I, [_vp, _vp, _vp, _I, _I, _I, _L, _vp, _vp]),
     "evd_blur_loss_reduce": (_I, [_vp, _I, _vp, _vp, _vp, _vp, _vp, _vp, _L, _I, _vp, _vp, _vp, _vp, _vp]),
     "evd_crf_param_count": (_I, []),
+    "evd_crf_get_params": (_I, [_vp, _vp]),
+    "evd_crf_load_params": (_I, [_vp, _vp]),
     "evd_event_loss_bwd": (_I, [_vp, _I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _F, _F, _vp, _fp, _L, _F, _F, _vp, _vp, _vp, _vp, _vp, _vp]),
     "evd_blur_loss_bwd": (_I, [_vp, _I, _vp, _vp, _vp, _vp, _vp, _vp, _L, _I, _fp, _vp, _vp, _vp, _vp, _vp]),
     "evd_event_loss_reduce": (_I, [_vp, _I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _F, _F, _vp, _fp, _L, _vp, _vp]),

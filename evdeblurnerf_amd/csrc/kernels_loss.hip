@@ -637,6 +637,39 @@ int evd_event_loss_reduce(const evd_crf* crf_ev, int skip_learn, int add_bii_fea
 
 int evd_crf_param_count(void) { return CRF_NPARAM; }
 
+// The handle keeps the (625 + padding) CRF parameters on the HOST (they travel as a kernel argument): get / load exchange them
+// with a host array in the gradient layout of evd_event_loss_bwd, so a caller that trains the event-CRF copies 2.8 KB per step.
+int evd_crf_get_params(const evd_crf* c, float* host) {
+    EVD_REQUIRE(c && host && c->p.map_type == 2, "evd_crf_get_params: needs a learn CRF and a host array");
+    float* o = host;
+    memcpy(o, c->p.w0, sizeof(c->p.w0)); o += 16 * CRF_MAX_IN;
+    memcpy(o, c->p.b0, 64); o += 16;
+    memcpy(o, c->p.w1, 1024); o += 256;
+    memcpy(o, c->p.b1, 64); o += 16;
+    memcpy(o, c->p.w2, 1024); o += 256;
+    memcpy(o, c->p.b2, 64); o += 16;
+    memcpy(o, c->p.w3, 64); o += 16;
+    *o = c->p.b3;
+    return EVD_OK;
+}
+
+int evd_crf_load_params(evd_crf* c, const float* host) {
+    EVD_REQUIRE(c && host && c->p.map_type == 2, "evd_crf_load_params: needs a learn CRF and a host array");
+    const float* o = host;
+    const int nin = 1 + c->p.E;
+    for (int j = 0; j < 16; ++j)
+        for (int k = 0; k < CRF_MAX_IN; ++k) c->p.w0[j * CRF_MAX_IN + k] = k < nin ? o[j * CRF_MAX_IN + k] : 0.f;      // padding columns stay zero
+    o += 16 * CRF_MAX_IN;
+    memcpy(c->p.b0, o, 64); o += 16;
+    memcpy(c->p.w1, o, 1024); o += 256;
+    memcpy(c->p.b1, o, 64); o += 16;
+    memcpy(c->p.w2, o, 1024); o += 256;
+    memcpy(c->p.b2, o, 64); o += 16;
+    memcpy(c->p.w3, o, 64); o += 16;
+    c->p.b3 = *o;
+    return EVD_OK;
+}
+
 int evd_event_loss_bwd(const evd_crf* crf_ev, int skip_learn, int add_bii_feat, int tonemap_only,
                        const float* start, const float* end, const float* start0, const float* end0,
                        const float* cum_neg, const float* cum_pos, float thr_neg, float thr_pos,

@@ -50,6 +50,18 @@ class CRF:
     def handle(self):
         return self._h
 
+    # training the learnable CRF: its parameters as one flat tensor in the layout of evd_event_loss_bwd (losses.crf_param_grads)
+    def flat_params(self, device="cuda"):
+        n = int(L.lib().evd_crf_param_count())
+        host = np.zeros((n,), np.float32)
+        L.check(L.lib().evd_crf_get_params(self._h, host.ctypes.data_as(C.c_void_p)), "evd_crf_get_params")
+        return torch.tensor(host, device=device, requires_grad=True)
+
+    def load_params(self, flat):
+        """after optimizer.step(): 2.8 KB device -> host (the handle keeps the parameters on the host: one small synchronising copy)"""
+        host = np.ascontiguousarray(flat.detach().cpu().numpy(), dtype=np.float32)
+        L.check(L.lib().evd_crf_load_params(self._h, host.ctypes.data_as(C.c_void_p)), "evd_crf_load_params")
+
     def forward(self, x, x_feat=None, skip_learn=False, _luma=-1):
         sh = x.shape
         xx = x.reshape(-1, 3).contiguous().float()

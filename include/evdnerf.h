@@ -340,6 +340,10 @@ int evd_event_loss_reduce(const evd_crf* crf_ev, int skip_learn, int add_bii_fea
  * linear.0.bias [16], linear.2.weight [16][16], linear.2.bias, linear.4.weight [16][16], linear.4.bias, linear.6.weight [16],
  * linear.6.bias [1]).  d_params is overwritten. */
 int evd_crf_param_count(void);
+/* a learn CRF's parameters to / from a HOST array of evd_crf_param_count() floats in that layout (the handle keeps them on the host:
+ * they travel as a kernel argument); load is what a loop that trains the event-CRF calls after optimizer.step() */
+int evd_crf_get_params(const evd_crf* crf, float* host_params);
+int evd_crf_load_params(evd_crf* crf, const float* host_params);
 int evd_event_loss_bwd(const evd_crf* crf_ev, int skip_learn, int add_bii_feat, int tonemap_only,
                        const float* start, const float* end, const float* start0, const float* end0,
                        const float* cum_neg, const float* cum_pos, float thr_neg, float thr_pos,

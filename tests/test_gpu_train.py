@@ -626,3 +626,25 @@ def test_module_surface_trains_like_the_reference_loop():
     a = model.render(400, 400, Kmat, rays=rays, **kw)[0]
     b = fresh.render(400, 400, Kmat, rays=rays, **kw)[0]
     assert (a - b).abs().max().item() < 2e-3            # float16 grid copies are re-derived from the exported float32 grids
+
+
+def test_event_crf_parameters_round_trip_and_train():
+    """evd_crf_get_params / _load_params: the learnable event-CRF's values leave and re-enter the handle in the gradient layout"""
+    from evdeblurnerf_amd.tonemapping import CRF
+    csd = W.make_crf_state_dict(5, extra_features=2)
+    crf = CRF("learn", state_dict=csd, extra_features=2)
+    flat = crf.flat_params()
+    from evdeblurnerf_amd.losses import crf_param_grads
+    back = crf_param_grads(flat.detach(), 2)
+    for k, v in back.items():
+        assert torch.equal(v.cpu(), torch.as_tensor(np.asarray(csd[k])).reshape(v.shape)), k
+    x = torch.rand((100, 3), device="cuda")
+    ft = torch.rand((100, 2), device="cuda")
+    y0 = crf.forward(x, ft)
+    with torch.no_grad():
+        flat *= 1.5
+    crf.load_params(flat)
+    y1 = crf.forward(x, ft)
+    csd2 = {k: v.cpu().numpy() for k, v in crf_param_grads(flat.detach(), 2).items()}
+    y2 = CRF("learn", state_dict=csd2, extra_features=2).forward(x, ft)
+    assert not torch.equal(y0, y1) and torch.equal(y1, y2)
