@@ -648,3 +648,23 @@ def test_event_crf_parameters_round_trip_and_train():
     csd2 = {k: v.cpu().numpy() for k, v in crf_param_grads(flat.detach(), 2).items()}
     y2 = CRF("learn", state_dict=csd2, extra_features=2).forward(x, ft)
     assert not torch.equal(y0, y1) and torch.equal(y1, y2)
+
+
+def test_backward_edge_cases_zero_gradient_and_single_sample():
+    """an all-zero incoming gradient (loss scale falls back to 1) gives exactly zero gradients; one ray x one sample works"""
+    from evdeblurnerf_amd.nerf import NeRF
+    sd = W.make_nerf_state_dict(24)
+    net = NeRF(sd, precision="f16")
+    for R, S in ((5, 3), (1, 1)):
+        rb_np, z_np = make_inputs(R, S, 2)
+        rb, z = torch.tensor(rb_np, device="cuda"), torch.tensor(z_np, device="cuda")
+        raw, store = net.mlpforward_train(rb, z)
+        g0 = net.mlp_backward_flat(torch.zeros((R, S, 4), device="cuda"), store)
+        assert torch.count_nonzero(g0).item() == 0
+        raw, store = net.mlpforward_train(rb, z)
+        g1 = net.mlp_backward_flat(torch.ones((R, S, 4), device="cuda"), store)
+        assert torch.isfinite(g1).all() and g1.abs().max().item() > 0
+        # the rgb_linear bias gradient of a loss sum(raw) is the sample count
+        blocks = {k: (shape, off) for k, shape, off in net.param_blocks()}
+        off = blocks["rgb_linear.bias"][1]
+        assert torch.allclose(g1[off:off + 3], torch.full((3,), float(R * S), device="cuda"), rtol=1e-3)
