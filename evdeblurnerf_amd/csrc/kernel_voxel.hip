@@ -224,7 +224,8 @@ __global__ __launch_bounds__(256) void k_voxel_sample(const GridParams g, const 
 //      d plane[tap, c] += w_tap d coef lv,  d line[tap, c] += w_tap d coef pv  as hardware float32 atomics (global_atomic_add_f32);
 //      like the reference's grid_sample backward (voxnerf.py:144) the summation order, hence the last bits, is not deterministic
 //   C  d basis[f, c] += sum_s d out[s, f] pv lv in registers across tiles, one atomic flush per block at the end
-// Measured (fine level, 2^19 samples, 302 M float atomics): 1.80 ms, of which 0.52 ms without the atomics; the atomic part runs
+// Measured (fine level, 2^19 samples, 302 M float atomics): 1.45 ms (1.80 ms with the two small GEMMs on the VALU, of which 0.52 ms
+// without the atomics); the atomic part runs
 // at ~250 G adds/s = one dword per clock per L2 channel (128 channels), the hardware rate -- plane-only and line-only variants
 // cost the same per add, and 32 private copies of the (heavily shared) line gradients change nothing: it is the op count, not
 // contention.  Tried and dropped: a run-length sum over the tile's consecutive samples that hit the same cell before the atomic (one
@@ -267,6 +268,18 @@ __global__ __launch_bounds__(256) void k_voxel_sample_bwd(const GridParams g, co
     float bacc[NB];
 #pragma unroll
     for (int q = 0; q < NB; ++q) bacc[q] = 0.f;
+    // The two small GEMMs of a tile (d coef = d out . basis and d basis += d out^T . coef: 32 x 32 x ctot each) run on the exact-float32
+    // MFMA when app_dim is 32 and the channels come in 32-wide tiles: wavefront t owns channel tile t for both (on the VALU the second
+    // one costs three LDS reads per multiply-add: 19 GB of LDS traffic per 2^19 samples).
+    const int wv = tid >> 6, ln = tid & 63, mn = ln & 31, kb = ln >> 5;
+    const bool mm = F == 32 && ctot % 32 == 0, mm_wave = mm && wv * 32 < ctot;
+    float bas_reg[16];
+    f32x16 macc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        macc[r] = 0.f;
+        bas_reg[r] = mm_wave ? g.basis[(long)(2 * r + kb) * ctot + 32 * wv + mn] : 0.f;
+    }
     for (long tile = blockIdx.x; tile * VS_SAMPLES < n; tile += gridDim.x) {
         const long s0 = tile * VS_SAMPLES;
         for (int o = tid; o < VS_SAMPLES * F; o += 256) {
@@ -298,12 +311,25 @@ __global__ __launch_bounds__(256) void k_voxel_sample_bwd(const GridParams g, co
         }
         if (tid < VS_SAMPLES * 3) dpt[tid] = 0.f;
         __syncthreads();
-        for (int o = tid; o < VS_SAMPLES * ctot; o += 256) {
-            const int sl = o / ctot, c = o % ctot;
-            float a = 0.f;
-            for (int f = 0; f < F; ++f) a = fmaf(dout[sl * (VSB_MAXF + 1) + f], g.basis[(long)f * ctot + c], a);
-            dco[sl * VS_STRIDE + c] = a;
+        if (mm) {
+            if (mm_wave) {                          // D[sample][channel] = sum_f d out[sample][f] basis[f][channel]
+                f32x16 a16;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a16[r] = 0.f;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) a16 = __builtin_amdgcn_mfma_f32_32x32x2f32(dout[mn * (VSB_MAXF + 1) + 2 * j + kb], bas_reg[j], a16, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dco[((r & 3) + 8 * (r >> 2) + 4 * kb) * VS_STRIDE + 32 * wv + mn] = a16[r];
+            }
+        } else {
+            for (int o = tid; o < VS_SAMPLES * ctot; o += 256) {
+                const int sl = o / ctot, c = o % ctot;
+                float a = 0.f;
+                for (int f = 0; f < F; ++f) a = fmaf(dout[sl * (VSB_MAXF + 1) + f], g.basis[(long)f * ctot + c], a);
+                dco[sl * VS_STRIDE + c] = a;
+            }
         }
+        if (d_pts) __syncthreads();                 // the point gradient below reads d coef
         if (chan_on) {                              // pv, lv: lanes over channels, two samples per sweep
             for (int sl = ss; sl < VS_SAMPLES; sl += 2) {
                 const int* ti = tix + sl * VSB_TAPS;
@@ -348,7 +374,16 @@ __global__ __launch_bounds__(256) void k_voxel_sample_bwd(const GridParams g, co
             }
         }
         if (d_pts && tid < VS_SAMPLES * 3 && s0 + tid / 3 < n) d_pts[(s0 + tid / 3) * 3 + tid % 3] = dpt[tid];
-        if (gg.basis) {
+        if (gg.basis && mm) {
+            if (mm_wave) {                          // D[f][channel] += sum_s d out[s][f] coef[s][channel]
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int sl = 2 * j + kb;
+                    macc = __builtin_amdgcn_mfma_f32_32x32x2f32(dout[sl * (VSB_MAXF + 1) + mn],
+                                                                pvs[sl * VS_STRIDE + 32 * wv + mn] * lvs[sl * VS_STRIDE + 32 * wv + mn], macc, 0, 0, 0);
+                }
+            }
+        } else if (gg.basis) {
 #pragma unroll
             for (int q = 0; q < NB; ++q) {
                 const int o = tid + 256 * q;
@@ -362,7 +397,12 @@ __global__ __launch_bounds__(256) void k_voxel_sample_bwd(const GridParams g, co
         }
         __syncthreads();
     }
-    if (gg.basis) {
+    if (gg.basis && mm) {
+        if (mm_wave) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) unsafeAtomicAdd(gg.basis + (long)((r & 3) + 8 * (r >> 2) + 4 * kb) * ctot + 32 * wv + mn, macc[r]);
+        }
+    } else if (gg.basis) {
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
             const int o = tid + 256 * q;
