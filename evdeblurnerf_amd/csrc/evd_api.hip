@@ -37,7 +37,7 @@ using namespace evd;
 extern "C" {
 
 const char* evd_last_error(void) { return evd::err_buf(); }
-int evd_version(void) { return 100; }
+int evd_version(void) { return 110; }      // 110: training entries (evd_*_train, evd_*_backward, evd_*_load_params, ...)
 
 int evd_device_count(void) {
     int n = 0;
