@@ -18,7 +18,9 @@ template <int HD, int G, int FT> struct VStore {
     // gradient slots; D_GEO is followed by the 2 direction-encoding gradient fragments, D_FTS by the 4 point-encoding ones (both
     // produced by the same dgrad layer as their neighbours, in the encodings' own fragment arrangement)
     static constexpr int G_COL = FWD_END, G_SIG = G_COL + 1, D_C1 = G_SIG + 1, D_C0 = D_C1 + KS, D_GEO = D_C0 + KS, D_DIRPE = D_GEO + 2 * GT,
-                         D_HID = D_DIRPE + PEV_KS, D_FTS = D_HID + KS, D_PE = D_FTS + 2 * ((FT + 31) / 32), TILE_FRAGS = D_PE + PE_KS;
+                         D_HID = D_DIRPE + PEV_KS, D_FTS = D_HID + KS, D_PE = D_FTS + 2 * ((FT + 31) / 32),
+                         M_HID = D_PE + PE_KS, M_C0 = M_HID + 1, M_C1 = M_C0 + 1,      // ReLU patterns as bit masks (mlp_pipe.h frag_bits)
+                         TILE_FRAGS = M_C1 + 1;
     static constexpr long TILE_BYTES = (long)TILE_FRAGS * 1024;
 };
 
@@ -29,21 +31,24 @@ template <class C, int HD_, int G_, int FT_, bool FEAT, bool TRAIN = false> stru
     static constexpr int T = HD / 32, KS = HD / 16, KF = FT / 16, GT = (G + 31) / 32, GK = 2 * GT, FPC = C::FPC, PD = C::PD;
     static constexpr int slot(int s) { return TRAIN ? s : -1; }
     // sigma_net.0 on cat([fts, PE(pts)]) (voxnerf.py:214): k-steps [fts_0.. | pe_0..3]
-    typedef LayerDesc<KF + PE_KS, T, 1, true, false, 0, 0, false, 0, 0, 0, false, 0, -1, false, 1, slot(VS::HID)> L0;
+    typedef LayerDesc<KF + PE_KS, T, 1, true, false, 0, 0, false, 0, 0, 0, false, 0, -1, false, 1, slot(VS::HID), -1, slot(VS::M_HID)> L0;
     static constexpr int F1 = T * (KF + PE_KS);
     // sigma_net.1 row 0 = sigma (float32 out) ...
-    typedef LayerDesc<KS, 1, 1, false, true, 0, F1, false, F1 % PD, L0::PAR_OUT, 1, true, KS - 2, -1, false, 1, -1, slot(VS::HID + KS - 2)> Sigma;
+    typedef LayerDesc<KS, 1, 1, false, true, 0, F1, false, F1 % PD, L0::PAR_OUT, 1, true, KS - 2, -1, false, 1, -1, slot(VS::HID + KS - 2), -1, slot(VS::M_HID),
+                      2 * (T - 1)> Sigma;
     static constexpr int F2 = F1 + KS;
     // ... rows 1..G = geo features (no activation; the per-sample feature AWP consumes, voxnerf.py:221)
     typedef LayerDesc<KS, GT, 1, false, false, 0, F2, false, F2 % PD, Sigma::PAR_OUT, 0, false, 0, -1, FEAT, 1, slot(VS::GEO)> Geo;
     static constexpr int F3 = F2 + GT * KS;
     // color_net.0 on cat([geo, PE(dirs)]) (voxnerf.py:248): k-steps [geo_0.. | dir_0..1]; geo's last tile lands at GK - 2, GK - 1
     typedef LayerDesc<GK + PEV_KS, T, 1, true, false, 0, F3, false, F3 % PD, Geo::PAR_OUT, 1, false, GK - 2, FEAT ? GT - 1 : -1, false, 1, slot(VS::C0),
-                      slot(VS::GEO + GK - 2)> C0;
+                      slot(VS::GEO + GK - 2), slot(VS::M_C0)> C0;
     static constexpr int F4 = F3 + T * (GK + PEV_KS);
-    typedef LayerDesc<KS, T, 1, true, false, 0, F4, false, F4 % PD, C0::PAR_OUT, 1, true, KS - 2, -1, false, 1, slot(VS::C1), slot(VS::C0 + KS - 2)> C1;
+    typedef LayerDesc<KS, T, 1, true, false, 0, F4, false, F4 % PD, C0::PAR_OUT, 1, true, KS - 2, -1, false, 1, slot(VS::C1), slot(VS::C0 + KS - 2), slot(VS::M_C1),
+                      slot(VS::M_C0), 2 * (T - 1)> C1;
     static constexpr int F5 = F4 + T * KS;
-    typedef LayerDesc<KS, 1, 1, false, true, 0, F5, true, F5 % PD, C1::PAR_OUT, 1, true, KS - 2, -1, false, 0, -1, slot(VS::C1 + KS - 2)> C2;
+    typedef LayerDesc<KS, 1, 1, false, true, 0, F5, true, F5 % PD, C1::PAR_OUT, 1, true, KS - 2, -1, false, 0, -1, slot(VS::C1 + KS - 2), -1, slot(VS::M_C1),
+                      2 * (T - 1)> C2;
     static constexpr int NCH = cceil(F5 + KS, FPC);
     // LDS bias image in stream order: the sigma net has no biases (zeros)
     static constexpr int B_SIG = T * 32, B_GEO = B_SIG + 32, B_C0 = B_GEO + GT * 32, B_C1 = B_C0 + T * 32, B_C2 = B_C1 + T * 32, B_END = B_C2 + 32;

@@ -137,10 +137,10 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
     // (each wgrad is issued before the dgrad layer that reads the same arrays: independent, concurrent on the side stream)
     // color_net.2 (+ sigmoid, folded into the gradient fragment)
     if ((rc = wgrad(launch_wgrad<PREC, 1, T, true>, 1, T, true, VS::G_COL, VS::C1, VMAP_COL, VMAP_HID, g.color_w[2], HD, g.color_b[2]))) return rc;
-    if ((rc = launch_dgrad<PREC, 1, T, 1, false, 1>(dgrad(VBWD_C2, VS::G_COL, -1, VS::C1, VS::D_C1), b.tiles, st))) return rc;
+    if ((rc = launch_dgrad<PREC, 1, T, 1, false, 2>(dgrad(VBWD_C2, VS::G_COL, -1, VS::M_C1, VS::D_C1), b.tiles, st))) return rc;
     // color_net.1
     if ((rc = wgrad(launch_wgrad<PREC, T, T, false>, T, T, true, VS::D_C1, VS::C1 - KS, VMAP_HID, VMAP_HID, g.color_w[1], HD, g.color_b[1]))) return rc;
-    if ((rc = launch_dgrad<PREC, KS, T, KS, false, 1>(dgrad(VBWD_C1, VS::D_C1, -1, VS::C0, VS::D_C0), b.tiles, st))) return rc;
+    if ((rc = launch_dgrad<PREC, KS, T, KS, false, 2>(dgrad(VBWD_C1, VS::D_C1, -1, VS::M_C0, VS::D_C0), b.tiles, st))) return rc;
     // color_net.0 on cat([geo, PE(dirs)])
     if ((rc = wgrad(launch_wgrad<PREC, T, GT, false>, T, GT, true, VS::D_C0, VS::GEO, VMAP_HID, VMAP_GEO_X, g.color_w[0], G + ICV, g.color_b[0]))) return rc;
     if ((rc = wgrad(launch_wgrad<PREC, T, 1, false>, T, 1, false, VS::D_C0, VS::DIRPE, VMAP_HID, VMAP_DIR, g.color_w[0], G + ICV, nullptr))) return rc;
@@ -159,7 +159,7 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
     // sigma_net.1 = [sigma row | geo rows] on hid
     if ((rc = wgrad(launch_wgrad<PREC, GT, T, false>, GT, T, false, VS::D_GEO, VS::HID, VMAP_GEO_Y, VMAP_HID, g.sigma_w[1], HD, nullptr))) return rc;
     if ((rc = wgrad(launch_wgrad<PREC, 1, T, true>, 1, T, false, VS::G_SIG, VS::HID, VMAP_SIG, VMAP_HID, g.sigma_w[1], HD, nullptr))) return rc;
-    if ((rc = launch_dgrad<PREC, 2 * GT + 1, T, 2 * GT, true, 1>(dgrad(VBWD_SIGGEO, VS::D_GEO, VS::G_SIG, VS::HID, VS::D_HID), b.tiles, st))) return rc;
+    if ((rc = launch_dgrad<PREC, 2 * GT + 1, T, 2 * GT, true, 2>(dgrad(VBWD_SIGGEO, VS::D_GEO, VS::G_SIG, VS::M_HID, VS::D_HID), b.tiles, st))) return rc;
     // sigma_net.0 on cat([fts, PE(pts)])
     if ((rc = wgrad(launch_wgrad<PREC, T, FTT, false>, T, FTT, false, VS::D_HID, VS::IN0, VMAP_HID, VMAP_FTS, g.sigma_w[0], FT + IC, nullptr))) return rc;
     if ((rc = wgrad(launch_wgrad<PREC, T, 2, false>, T, 2, false, VS::D_HID, VS::IN0 + KF, VMAP_HID, VMAP_PE, g.sigma_w[0], FT + IC, nullptr))) return rc;

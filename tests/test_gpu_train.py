@@ -319,7 +319,7 @@ def test_pdrf_level_networks_backward_match_torch_autograd(level, prec, tol):
     GEO = HID + KS
     C0 = GEO + 2 * GT
     C1 = C0 + KS
-    TILE_FRAGS = C1 + KS + 2 + KS + KS + (2 * GT + 2) + KS + (2 * ((FT + 31) // 32) + 4)        # VStore: + d PE(dirs), + d PE(pts) fragments
+    TILE_FRAGS = C1 + KS + 2 + KS + KS + (2 * GT + 2) + KS + (2 * ((FT + 31) // 32) + 4) + 3   # VStore: + d PE(dirs), + d PE(pts) fragments, + 3 bit-mask fragments
     dt = torch.float16 if prec == "f16" else torch.bfloat16
     masks = {"hid": (vdecode(store, n, TILE_FRAGS, HID, KS, dt) > 0).cpu().double(),
              "c0": (vdecode(store, n, TILE_FRAGS, C0, KS, dt) > 0).cpu().double(),
