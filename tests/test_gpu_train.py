@@ -719,3 +719,37 @@ def test_c2f_training_gradients_against_the_reference_golden():
     print("G19 vs kernels, worst (norm / projection error) / norm:", {k: f"{v:.1e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:6]})
     assert max(worst.values()) < 0.15, worst
     assert max(worst[k] for k in tight) < 0.01
+
+
+def test_nerf_training_gradients_against_the_reference_golden():
+    """G18 (w256 part): torch.autograd on the reference NeRF (8 x 256) + raw2outputs vs the HIP path on the same rays, positions and
+    weights: NeRF.mlp_train + raw2outputs under autograd, gradients of all 24 parameter tensors and of the ray origins / directions."""
+    from conftest import load_golden
+    from evdeblurnerf_amd.nerf import NeRF
+    from torch_restatement import grad_summary
+    g = load_golden("G18_nerf_grads")
+    sd = W.make_nerf_state_dict(19, D=8, W=256, rgb_add_bias=True)
+    net = NeRF(sd, precision="f16").train()
+    flat = net.flat_params(sd)
+    o = torch.tensor(g["o"], device="cuda", requires_grad=True)
+    d = torch.tensor(g["d"], device="cuda", requires_grad=True)
+    z = torch.tensor(g["z"], device="cuda")
+    R = o.shape[0]
+    vd = d / d.norm(dim=-1, keepdim=True)
+    rb = torch.cat([o, d, torch.zeros((R, 1), device="cuda"), torch.ones((R, 1), device="cuda"), vd], -1)
+    raw = net.mlp_train(flat, rb, z)
+    rgb_map = net.raw2outputs(raw, z, d)[0]
+    assert (rgb_map.detach().cpu().numpy() - g["rgb_map_w256"]).__abs__().max() < 3e-3
+    (rgb_map * torch.tensor(g["w_rgb"], device="cuda")).sum().backward()
+    got = dict(net.unflatten(flat.grad))
+    got["rays_o"], got["rays_d"] = o.grad, d.grad
+    keys = [k[5:-8] for k in g if k.startswith("w256.") and k.endswith(".summary")]
+    assert set(keys) == set(got)
+    worst = {}
+    for idx, key in enumerate(keys):
+        sm, _ = grad_summary(got[key].detach().cpu().numpy(), 7000 + idx)
+        ref = g[f"w256.{key}.summary"]
+        worst[key] = max(abs(sm[0] - ref[0]), abs(sm[1] - ref[1])) / float(ref[0])
+    print("G18 (w256) vs kernels, worst (norm / projection error) / norm:", {k: f"{v:.1e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:5]})
+    assert max(worst.values()) < 0.15, worst
+    assert worst["rgb_linear.weight"] < 0.01 and worst["alpha_linear.bias"] < 0.01

@@ -623,7 +623,21 @@ def G18_nerf_grads():
         grads = torch.autograd.grad(loss, [p for _, p in params] + [ot, dt])
     out = {}
     _grad_summaries([(k, g) for (k, _), g in zip(params, grads)] + [("rays_o", grads[-2]), ("rays_d", grads[-1])], out, "g.")
-    save("G18_nerf_grads", o=o, d=d, z=z, w_rgb=w_rgb, rgb_map=n(rgb_map), loss=np.float64(loss.item()), **out)
+    # the same on the full-width network (what the HIP training path is built for): summaries only
+    net2 = _ref_nerf(19, D=8, Wd=256, rgb_add_bias=True)
+    net2.train(True)
+    with torch.enable_grad():
+        ot, dt = t(o).requires_grad_(True), t(d).requires_grad_(True)
+        pts = ot[:, None] + dt[:, None] * t(z)[..., None]
+        vd = dt / torch.norm(dt, dim=-1, keepdim=True)
+        x = torch.cat([e10(pts.reshape(-1, 3)), e4(vd[:, None].expand(-1, S, -1).reshape(-1, 3))], -1)
+        raw2, _ = net2.eval(x)
+        rgb_map2 = net2.raw2outputs(raw2.reshape(R, S, 4), t(z), dt)[0]
+        loss2 = (rgb_map2 * t(w_rgb)).sum()
+        params2 = list(net2.named_parameters())
+        grads2 = torch.autograd.grad(loss2, [p for _, p in params2] + [ot, dt])
+    _grad_summaries([(k, g) for (k, _), g in zip(params2, grads2)] + [("rays_o", grads2[-2]), ("rays_d", grads2[-1])], out, "w256.")
+    save("G18_nerf_grads", o=o, d=d, z=z, w_rgb=w_rgb, rgb_map=n(rgb_map), loss=np.float64(loss.item()), rgb_map_w256=n(rgb_map2), **out)
 
 
 def G19_c2f_grads():
