@@ -753,3 +753,41 @@ def test_nerf_training_gradients_against_the_reference_golden():
     print("G18 (w256) vs kernels, worst (norm / projection error) / norm:", {k: f"{v:.1e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:5]})
     assert max(worst.values()) < 0.15, worst
     assert worst["rgb_linear.weight"] < 0.01 and worst["alpha_linear.bias"] < 0.01
+
+
+@pytest.mark.parametrize("cfg", ["blender", "cdavis"])
+def test_loss_block_gradients_against_the_reference_golden(cfg):
+    """G20: torch.autograd through the REFERENCE's loss block (TonemappingTransform / learnable CRF, egm_loss, img2mse; composition of
+    run_nerf.py:443-497,518-591) vs the fused loss reductions' hand-written backward: gradients w.r.t. the rendered colours, both
+    composition-weight sets, the event colours and every parameter of the event-CRF."""
+    from conftest import load_golden
+    from evdeblurnerf_amd.losses import (blur_loss_from_partials, blur_loss_partials_autograd, crf_param_grads, event_loss_from_partials,
+                                         event_loss_partials_autograd)
+    from evdeblurnerf_amd.tonemapping import CRF
+    g = load_golden("G20_loss_grads")
+    flw, w_pts0, w_egm = [float(v) for v in g[f"{cfg}_scalars"]]
+    csd = {k: (v * (3.0 if v.ndim == 2 else 1.0)).astype(np.float32) for k, v in W.make_crf_state_dict(51, 2).items()}
+    crf_rgb = CRF("gamma" if cfg == "blender" else "none")
+    crf_ev = CRF("learn", state_dict=csd, extra_features=2)
+    theta = crf_ev.flat_params()
+    T_ = lambda a: torch.tensor(np.asarray(a), device="cuda")
+    R = g[f"{cfg}_target"].shape[0]
+    lv = {k: T_(g[f"{cfg}_{k}"]).requires_grad_(True) for k in ("rgb_p", "rgb0_p", "es", "es0", "ee", "ee0")}
+    w1, w2 = T_(g[f"{cfg}_ccw"][0]).requires_grad_(True), T_(g[f"{cfg}_ccw"][1]).requires_grad_(True)
+    pb = blur_loss_partials_autograd(crf_rgb, lv["rgb_p"].reshape(R, -1, 3), w1, T_(g[f"{cfg}_target"]), rgb0_p=lv["rgb0_p"].reshape(R, -1, 3), w2=w2,
+                                     target_pts0=T_(g[f"{cfg}_target_pts0"]))
+    loss, _ = blur_loss_from_partials(pb, fine_loss_weight=flw, w_pts0=w_pts0)
+    thr = 0.2 if cfg == "blender" else 0.25
+    kw = dict(add_bii="pos-neg") if cfg == "blender" else dict(add_bii="color-pos-neg", tonemap_only=True, color_mask=T_(g[f"{cfg}_cmask"]),
+                                                               color_weight=[0.4, 0.2, 0.4])
+    pe = event_loss_partials_autograd(crf_ev, theta, lv["es"], lv["ee"], T_(g[f"{cfg}_cn"]), T_(g[f"{cfg}_cp"]), thr, thr, start0=lv["es0"], end0=lv["ee0"], **kw)
+    total = loss + event_loss_from_partials(pe) * w_egm
+    assert abs(total.item() - float(g[f"{cfg}_total"])) < 2e-5 * max(1.0, abs(float(g[f"{cfg}_total"])))
+    total.backward()
+    got = {k: v.grad for k, v in lv.items()}
+    got["w1"], got["w2"] = w1.grad, w2.grad
+    got.update({"crf." + k: v for k, v in crf_param_grads(theta.grad, 2).items()})
+    for k, v in got.items():
+        ref = torch.tensor(g[f"{cfg}_g.{k}"], dtype=torch.float64)
+        err = rel_l2(v.detach().cpu().double().reshape(ref.shape), ref)
+        assert err < 2e-4, (k, err)

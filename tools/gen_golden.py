@@ -670,9 +670,81 @@ def G19_c2f_grads():
          tv=np.float64(tv.item()), loss=np.float64(loss.item()), grid_coarse=np.array(gc), grid_fine=np.array(gf), **out)
 
 
+def G20_loss_grads():
+    """Gradients of the loss block of G14 (the reference's TonemappingTransform / CRF, egm_loss, img2mse under torch.autograd; only the
+    composition order of run_nerf.py:443-497,518-591 is restated) w.r.t. the rendered colours, both weight sets and every parameter of
+    the learnable event-CRF."""
+    from utils.events import egm_loss
+    sys.modules.setdefault("skimage", type(sys)("skimage"))
+    sys.modules["skimage"].metrics = None
+    sys.modules.setdefault("networks.lpips", type(sys)("networks.lpips"))
+    sys.modules["networks.lpips"].LPIPS = None
+    from utils.metrics import img2mse
+    rs = np.random.RandomState(2020)
+    out = {}
+    for cfg in ("blender", "cdavis"):
+        R, P, NE = 48, 10, (70 if cfg == "blender" else 61)
+        rgb_p = rs.uniform(0.02, 1, size=(R * P, 3)).astype(np.float32)
+        rgb0_p = rs.uniform(0.02, 1, size=(R * P, 3)).astype(np.float32)
+        logits = rs.standard_normal((2, R, P)).astype(np.float32)
+        ccw = 1.0 / (1.0 + np.exp(-logits))
+        ccw = (ccw / ccw.sum(-1, keepdims=True)).astype(np.float32)
+        target = rs.uniform(0, 1, size=(R, 3)).astype(np.float32)
+        target_pts0 = rs.uniform(0, 1, size=(R, 3)).astype(np.float32)
+        fine_loss_weight, w_pts0, w_egm = 0.1, 0.01, 0.1
+        tm = _tonemap("gamma" if cfg == "blender" else "none", "learn", 2, 51)
+        for prm in tm.tonemapping_event.parameters():          # away from the near-identity initialisation: real gradients in every layer
+            if prm.dim() == 2:
+                prm.data.mul_(3.0)
+        thr = np.array([0.2, 0.2] if cfg == "blender" else [0.25, 0.25], np.float32)
+        cn = -rs.randint(0, 4, NE).astype(np.float32)
+        cp = rs.randint(0, 4, NE).astype(np.float32)
+        es, es0, ee, ee0 = (rs.uniform(0.05, 0.95, size=(NE, 3)).astype(np.float32) for _ in range(4))
+        cidx = rs.randint(0, 3, NE)
+        cmask = np.zeros((NE, 3), dtype=bool)
+        cmask[np.arange(NE), cidx] = True
+        with torch.enable_grad():
+            leaves = {k: t(v).requires_grad_(True) for k, v in dict(rgb_p=rgb_p, rgb0_p=rgb0_p, w1=ccw[0], w2=ccw[1], es=es, es0=es0, ee=ee, ee0=ee0).items()}
+            crf = lambda x, **k: tm(x, **k)
+            rp, r0p = leaves["rgb_p"].reshape(R, P, 3), leaves["rgb0_p"].reshape(R, P, 3)
+            rgb = (rp * leaves["w1"][..., None]).sum(1)
+            rgb1 = (r0p * leaves["w1"][..., None]).sum(1)
+            rgb_awp = (rp * leaves["w2"][..., None]).sum(1)
+            loss = img2mse(crf(rgb, mode="encode_rgb"), t(target)) + img2mse(crf(rgb1, mode="encode_rgb"), t(target))
+            img_fine = img2mse(crf(rgb_awp, mode="encode_rgb"), t(target))
+            loss = loss * (1 - fine_loss_weight) + img_fine * fine_loss_weight
+            pts0 = 0.0
+            for x in (rp[:, 0], r0p[:, 0]):
+                pts0 = pts0 + img2mse(crf(x, mode="encode_rgb"), t(target_pts0))
+            loss = loss + pts0 * w_pts0
+            bii = (t(thr) * torch.stack([t(cn), t(cp)], -1)).sum(-1)
+            if cfg == "blender":
+                feat = torch.stack([t(cn), t(cp)], -1)
+                kw, cm, cw = {}, None, None
+            else:
+                fn = torch.zeros(NE, 3)
+                fp = torch.zeros(NE, 3)
+                fn[t(cmask)] = t(cn)
+                fp[t(cmask)] = t(cp)
+                feat = torch.stack([fn, fp], -1)
+                kw, cm, cw = {"tonemap_only": True}, t(cmask), [0.4, 0.2, 0.4]
+            lum = lambda x: crf(x, mode="encode_luma", ev_extra_feat=feat, **kw)
+            egm = egm_loss(lum(leaves["es0"]), lum(leaves["ee0"]), bii, color_mask=cm, color_weight=cw) + \
+                egm_loss(lum(leaves["es"]), lum(leaves["ee"]), bii, color_mask=cm, color_weight=cw)
+            total = loss + egm * w_egm
+            crf_params = list(tm.tonemapping_event.named_parameters())
+            grads = torch.autograd.grad(total, list(leaves.values()) + [p for _, p in crf_params])
+        for (k, _), gr in zip(list(leaves.items()) + [("crf." + kk, vv) for kk, vv in crf_params], grads):
+            out[f"{cfg}_g.{k}"] = n(gr)
+        out.update({f"{cfg}_rgb_p": rgb_p, f"{cfg}_rgb0_p": rgb0_p, f"{cfg}_ccw": ccw, f"{cfg}_target": target, f"{cfg}_target_pts0": target_pts0,
+                    f"{cfg}_cn": cn, f"{cfg}_cp": cp, f"{cfg}_cmask": cmask, f"{cfg}_es": es, f"{cfg}_es0": es0, f"{cfg}_ee": ee, f"{cfg}_ee0": ee0,
+                    f"{cfg}_total": n(total), f"{cfg}_scalars": np.array([fine_loss_weight, w_pts0, w_egm], np.float32)})
+    save("G20_loss_grads", **out)
+
+
 ALL = [G1_embedder, G2_nerf_mlp, G3_nerf_raw2outputs, G4_voxel_raw2outputs, G5_sample_pdf, G6_rays,
        G7_render_nerf, G8_appfeature, G9_render_c2f, G10_rbk_weighted_sum, G11_crf, G12_egm_loss, G13_edi,
-       G14_loss_assembly, G15_awp_feature_integration, G16_rbk_warp, G17_compute_successor, G18_nerf_grads, G19_c2f_grads]
+       G14_loss_assembly, G15_awp_feature_integration, G16_rbk_warp, G17_compute_successor, G18_nerf_grads, G19_c2f_grads, G20_loss_grads]
 
 if __name__ == "__main__":
     want = set(sys.argv[1:])
