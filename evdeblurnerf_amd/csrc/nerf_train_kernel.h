@@ -33,12 +33,17 @@ __device__ __forceinline__ float grad_scale(unsigned bits, bool inverse) {
     return ldexpf(1.f, inverse ? e - 10 : 10 - e);
 }
 
-static __global__ void k_absmax(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
+static __global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
     float m = 0.f;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+    const long n4 = n >> 2, stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {          // float4 body (the gradient rows are 16-byte aligned)
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    for (long i = 4 * n4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) m = fmaxf(m, fabsf(x[i]));
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
 }
 
 template <int PREC>
@@ -397,7 +402,7 @@ template <int PREC> static int run_nerf_backward(const BwdPlan& b, hipStream_t s
     constexpr int D = 8;
     int rc;
     EVD_HIP(hipMemsetAsync(b.maxbits, 0, sizeof(unsigned), st));
-    hipLaunchKernelGGL(k_absmax, dim3(512), dim3(256), 0, st, b.d_raw, b.nsamp * 4, b.maxbits);
+    hipLaunchKernelGGL(k_absmax, dim3(2048), dim3(256), 0, st, b.d_raw, b.nsamp * 4, b.maxbits);
     EVD_LAUNCH_CHECK();
     hipLaunchKernelGGL((k_grad_frags<PREC>), dim3((unsigned)cdiv(b.tiles * 64, 256L)), dim3(256), 0, st, b.d_raw, b.nsamp, b.maxbits, b.store, b.tiles);
     EVD_LAUNCH_CHECK();
