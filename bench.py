@@ -1,40 +1,50 @@
 #!/usr/bin/env python
 """Benchmark of the hot path: rays/s for 4096 rays x 128 samples through the 8x256 NeRF MLP (PE + MLP + composite).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision f16x3|f32|bf16]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision f16|f16x3|f32|bf16]
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment makes this script its own launcher: it re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`, one rank per GPU over RCCL (when a
+launcher already set RANK / LOCAL_RANK / WORLD_SIZE, e.g. the driver's torchrun command, it just joins as that rank).
+EVD_BENCH_SHARE_GPU=1 (validation of the N > 1 code path on a 1-GPU box) puts every rank on device 0 with gloo collectives.
 
 One JSON line on rank 0 (contract in the task statement). A "step" = one pass of the render path
 (ray packing -> z stratification -> fused PE+MLP kernel -> compositing scan) over one batch of 4096
 synthetic LLFF-shaped rays already resident in HBM; with N > 1 every rank renders its own 4096 rays
 (weak scaling) and the step ends with the packed blur-loss partial all-reduce over RCCL, the only
-exchange the path has.
+exchange the path has. Beside the contract keys:
 
-The headline arithmetic is "f16": float16 MFMA operands (one product, v_mfma_f32_32x32x16_f16) with
-float32 accumulation -- the matrix-core rate north_star asks for (bf16-class), whose RGB on this workload
-is measured against the exact-float32 kernel inside the run ("parity": L-inf, bound 1e-4). "modes"
-reports beside it: bf16 (same kernel, 2^-8 operands), f16x3 (split-float16, three products, float32-grade
-for any weights) and f32 (exact float32 MFMA); "composite" is the HBM-bound compositing scan on 2^20 rays.
+  roofline       the dominant kernel (k_nerf_mlp), HIP events on the launch stream
+  modes          the same kernel in every arithmetic mode
+  parity         RGB L-inf of EVERY mode against the CPU oracle at the full 4096 x 128 size, on the seed-derived weights
+                 and on weights trained in this run (tools/trained_weights.py)
+  c2f            the shipped blurfactory configuration (PDRF levels at their real grid sizes): render step + roofline of
+                 its dominant kernel, the tri-plane gather k_voxel_sample
+  strong_scaling one 400x400 frame (160 000 rays, 64 + 128 samples, BASELINE config 5) with rows sharded over the ranks
+  composite      the HBM-bound compositing scan on 2^20 rays;  train: the training kernels;  cpu_baseline: the C oracle
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 FLOP_PER_SAMPLE = 2 * 593408          # GEMM terms of the 8x256 net with skip and view branch
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f16x3": 2500.0, "f32": 157.3}   # dense MFMA peaks (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
+L2_PEAK_GBS = 34500.0                 # aggregate L2 (MI355X_MICROARCH.md, "L2 (per XCD)")
+DTYPE_NAME = {"f16": "f16 (MFMA operands; f32 accumulate)", "f16x3": "f16x3-split (3 f16 MFMA products, f32 accumulate; f32-grade)",
+              "f32": "f32", "bf16": "bf16 (MFMA operands; f32 accumulate)"}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -42,40 +52,131 @@ def parse():
     ap.add_argument("--precision", default="f16", choices=["f16", "f16x3", "f32", "bf16"])
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--samples", type=int, default=128)
+    ap.add_argument("--train-iters", type=int, default=600, help="iterations of the in-run training that makes the 'trained' weights")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-modes", action="store_true")
     ap.add_argument("--no-composite", action="store_true")
     ap.add_argument("--no-train", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-c2f", action="store_true")
+    ap.add_argument("--no-strong", action="store_true")
+    return ap.parse_args(argv)
 
 
-def make_model(precision):
+# ---------------------------------------------------------------------------------------------------------------------
+# launcher: --gpus N without a launcher's environment
+# ---------------------------------------------------------------------------------------------------------------------
+
+def launch_command(n, argv, port=None, script=None):
+    """The command line `bench.py --gpus n` re-executes itself with (one rank per GPU; the same form the driver uses)."""
+    if port is None:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
+
+
+def needs_launch(a, env=None):
+    env = os.environ if env is None else env
+    return a.gpus > 1 and "WORLD_SIZE" not in env
+
+
+def launch(a, argv):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    env["EVD_BENCH_SELF_LAUNCH"] = "1"
+    return subprocess.call(launch_command(a.gpus, argv), env=env)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# helpers
+# ---------------------------------------------------------------------------------------------------------------------
+
+def nerf_args(n_importance=0):
     from types import SimpleNamespace
+    return SimpleNamespace(mode="nerf", netdepth=8, netwidth=256, multires=10, multires_views=4, use_viewdirs=True,
+                           rgb_activate="sigmoid", sigma_activate="relu", N_importance=n_importance)
+
+
+def make_model(precision, sd=None):
     from evdeblurnerf_amd import weights as W
     from evdeblurnerf_amd.renderer import NeRFAll
-    sd = W.prefixed(W.make_nerf_state_dict(21), "mlp_coarse")
-    args = SimpleNamespace(mode="nerf", netdepth=8, netwidth=256, multires=10, multires_views=4, use_viewdirs=True,
-                           rgb_activate="sigmoid", sigma_activate="relu", N_importance=0)
-    return NeRFAll(args, sd, precision=precision).eval(), sd
+    sd = sd if sd is not None else W.prefixed(W.make_nerf_state_dict(21), "mlp_coarse")
+    return NeRFAll(nerf_args(), sd, precision=precision).eval(), sd
 
 
-def time_steps(fn, steps, warmup, barrier, drain=None):
+def _sync():
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
+def init_ranks():
+    """(rank, world, local, dist | None, backend | None, device) from the launcher's environment; one process per GPU with RCCL
+    ("nccl"), or -- EVD_BENCH_SHARE_GPU=1 / no GPU at all (the CPU test of this scaffolding) -- gloo."""
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    have_gpu = torch.cuda.is_available()
+    share = os.environ.get("EVD_BENCH_SHARE_GPU") == "1"
+    if have_gpu:
+        if world > torch.cuda.device_count() and not share:
+            raise SystemExit(f"bench.py: {world} ranks but {torch.cuda.device_count()} visible GPU(s) "
+                             "(EVD_BENCH_SHARE_GPU=1 shares device 0 for validation)")
+        torch.cuda.set_device(0 if share else local)
+    dist, backend = None, None
+    if world > 1:
+        import torch.distributed as dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "nccl" if (have_gpu and not share) else "gloo"
+        dist_.init_process_group(backend, rank=rank, world_size=world)
+        dist = dist_
+    return rank, world, local, dist, backend, ("cuda" if have_gpu else "cpu")
+
+
+def time_steps(fn, steps, warmup, dist=None, drain=None, device="cuda"):
+    """W untimed warm-up steps, then EXACTLY `steps` steps bracketed by barrier + device synchronize on both sides;
+    returns the MAX over ranks of the elapsed seconds."""
+    import torch
+    barrier = (lambda: dist.barrier()) if dist else (lambda: None)
     for _ in range(warmup):
         fn()
     barrier()
-    torch.cuda.synchronize()
+    _sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
     if drain:
         drain()
     barrier()
-    torch.cuda.synchronize()
-    return time.perf_counter() - t0
+    _sync()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def headline(rays_per_rank, samples, world, steps, warmup, dt, precision):
+    """the contract keys of the JSON line (value = whole-job rays/s over all ranks)"""
+    return {
+        "metric": "rays/sec (4096x128 samples, 8x256 MLP)", "value": world * rays_per_rank * steps / dt, "unit": "rays/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": DTYPE_NAME[precision],
+        "data": "synthetic",
+        "config": {"workload": f"nerf8x256 render: {rays_per_rank} rays x {samples} samples per GPU, PE(10,4)+MLP+composite, ndc, viewdirs",
+                   "rays_per_gpu": rays_per_rank, "samples": samples, "precision": precision},
+    }
 
 
 def kernel_ms(fn, steps, warmup=3):
     """Average duration of one launch, HIP events on the stream the kernel runs on (torch's current stream)."""
+    import torch
     for _ in range(warmup):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -88,23 +189,118 @@ def kernel_ms(fn, steps, warmup=3):
     return e0.elapsed_time(e1) / steps
 
 
-def main():
-    a = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+def per_step_ms(fn, steps):
+    """HIP-event duration of every single step (for the median: steadier than one wall-clock mean over a 10-30 ms region)"""
+    import torch
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    torch.cuda.synchronize()
+    ev[0].record()
+    for i in range(steps):
+        fn()
+        ev[i + 1].record()
+    ev[-1].synchronize()
+    return sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+
+
+def oracle_parity(sd, rays, S, K, precisions):
+    """RGB L-inf of each arithmetic mode's full render against the CPU oracle (oracle/evd_oracle.c) on the SAME rays and weights."""
+    import numpy as np
+    import torch
+    from oracle import oracle as O
+    ref = O.render_nerf(O.Nerf(sd, "mlp_coarse."), None, O.make_cfg(N_samples=S), rays.cpu().numpy())["rgb"]
+    kw = dict(ndc=True, near=0., far=1., use_viewdirs=True, N_samples=S, N_importance=0, retraw=False)
+    out = {}
+    for prec in precisions:
+        m, _ = make_model(prec, sd)
+        rgb = m.render(400, 400, K, rays=rays, **kw)[0]
+        torch.cuda.synchronize()
+        out[prec] = float(np.abs(rgb.cpu().numpy().astype(np.float64) - ref).max())
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the shipped configuration: PDRF coarse-to-fine levels at the blurfactory grid sizes
+# ---------------------------------------------------------------------------------------------------------------------
+
+def c2f_leg(precision, steps):
+    """BASELINE configs 2/3: one c2f render step (4096 event rays, 64 + 64 samples) and the roofline of its dominant kernel,
+    the tri-plane gather (k_voxel_sample) of the FINE level over the step's 4096 x 128 merged samples."""
+    import torch
+    from evdeblurnerf_amd import weights as W
+    from evdeblurnerf_amd.renderer import NeRFAll
+    sd = W.make_blurfactory_state_dict(31)
+    model = NeRFAll(W.blurfactory_args(64), sd, precision=precision).eval()
+    del sd
+    K = W.synthetic_camera()
+    R = 4096
+    rays = torch.as_tensor(W.synthetic_rays(5, R), device="cuda")
+    kw = dict(ndc=True, near=0., far=1., use_viewdirs=True, N_samples=64, N_importance=64, retraw=False, perturb=0., raw_noise_std=0.)
+    step_ms = kernel_ms(lambda: model.render(400, 400, K, rays=rays, **kw), steps)
+    # the gather alone, on the points of such a step: NDC points of the same rays at 128 depths
+    rb = NeRFAll.ray_batch_train(400, 400, K, rays)
+    z = torch.linspace(0, 1, 128, device="cuda")
+    pts = (rb[:, None, 0:3] + rb[:, None, 3:6] * z[None, :, None]).contiguous()
+    fine = model.mlp_fine
+    g_ms = kernel_ms(lambda: fine.sample(pts), steps)
+    n = R * 128
+    esz = 4 if precision in ("f32", "f16x3") else 2            # the half-precision modes gather float16 copies of the grids
+    taps = 4 * 96 + 2 * 96                                      # 4 plane taps + 2 line taps x 96 channels = 576 gathered values per sample
+    algo = n * (taps * esz + 12 + 4 * fine.app_dim)             # + the point in, app_dim floats out
+    out = {"workload": "blurfactory c2f render: 4096 rays x (64 coarse + 64 importance) samples, grids 293x293x195 / 586x586x390, n_comp (64,16,16)",
+           "precision": precision, "ms_per_step": step_ms, "rays_per_s": R / (step_ms * 1e-3),
+           "roofline": {"kernel": "k_voxel_sample (fine level, 4096 x 128 samples)", "bound": "hbm", "kernel_ms": g_ms,
+                        "algorithmic_bytes": algo, "bytes_per_sample": algo / n, "achieved": algo / (g_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": algo / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "frac_of_l2_peak": algo / (g_ms * 1e-3) / 1e9 / L2_PEAK_GBS,
+                        "note": "algorithmic bytes = 576 gathered grid values (4 taps x 96 plane channels + 2 taps x 96 line channels) x the "
+                                "grid element size + the point in + 32 floats out, per sample; the fine grids (41 M values) exceed the 32 MB of "
+                                "L2 and sit in the 256 MB Infinity Cache, so the bound is the cache-line gather rate, quoted against both the "
+                                "HBM and the aggregate-L2 peak; counted FETCH_SIZE / TCC hits: profiles/ (tools/pmc_voxel.sh)"}}
+    return out, model
+
+
+def strong_leg(model_c2f, precision, world, rank, frames=3):
+    """BASELINE config 5: full 400x400 frames (160 000 rays each, 64 + 128 samples, render_kwargs_test) through
+    render_path(shard_rows=True): the image rows are split over the ranks and all-gathered (strong scaling: fixed total work)."""
+    import numpy as np
+    import torch
+    from evdeblurnerf_amd import weights as W
+    K = W.synthetic_camera()
+    poses = [torch.as_tensor(W.synthetic_pose(40 + i)[:3, :4].astype(np.float32), device="cuda") for i in range(frames)]
+    kw = dict(ndc=True, near=0., far=1., use_viewdirs=True, N_samples=64, N_importance=128, perturb=0., raw_noise_std=0.)
+    model_c2f.render_path(400, 400, K, 1 << 22, poses[:1], kw, shard_rows=world > 1)
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    t0 = time.perf_counter()
+    rgbs, _ = model_c2f.render_path(400, 400, K, 1 << 22, poses, kw, shard_rows=world > 1)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return {"workload": "full-frame 400x400 render (160 000 rays, 64 + 128 samples), blurfactory c2f, rows sharded over ranks + all_gather",
+            "scaling": "strong", "n_gpus": world, "frames": frames, "ms_per_frame": 1e3 * dt / frames, "rays_per_s": frames * 160000 / dt,
+            "precision": precision, "frame_mean": float(rgbs.mean())}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    a = parse(argv)
+    if needs_launch(a):
+        sys.exit(launch(a, argv))
+    import ctypes as C
+    import numpy as np
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP library has no CPU fallback)")
-    # EVD_BENCH_SHARE_GPU=1 (validation of the N > 1 code path on a 1-GPU box only): every rank on device 0, gloo collectives
-    share = os.environ.get("EVD_BENCH_SHARE_GPU") == "1"
-    torch.cuda.set_device(0 if share else local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_.init_process_group("gloo" if share else "nccl", rank=rank, world_size=world)
-        dist = dist_
-    barrier = (lambda: dist.barrier()) if dist else (lambda: None)
+    rank, world, local, dist, backend, _ = init_ranks()
 
     from evdeblurnerf_amd import _lib as L, weights as W
     from evdeblurnerf_amd.losses import blur_loss_partials
@@ -132,34 +328,23 @@ def main():
             pending.append(dist.all_reduce(p, async_op=True))
         return rgb
 
-    dt = time_steps(step, a.steps, a.warmup, barrier, drain=lambda: [w.wait() for w in pending])
-    if dist:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    rays_per_s = world * R * a.steps / dt
-
-    result = {
-        "metric": "rays/sec (4096x128 samples, 8x256 MLP)", "value": rays_per_s, "unit": "rays/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": {"f16": "f16 (MFMA operands; f32 accumulate)", "f16x3": "f16x3-split (3 f16 MFMA products, f32 accumulate; f32-grade)",
-                  "f32": "f32", "bf16": "bf16 (MFMA operands; f32 accumulate)"}[a.precision],
-        "data": "synthetic",
-        "config": {"workload": f"nerf8x256 render: {R} rays x {S} samples per GPU, PE(10,4)+MLP+composite, ndc, viewdirs",
-                   "rays_per_gpu": R, "samples": S, "precision": a.precision},
-    }
+    dt = time_steps(step, a.steps, a.warmup, dist, drain=lambda: [w.wait() for w in pending])
+    med = per_step_ms(lambda: model.render(400, 400, K, rays=rays, **kw), max(20, min(a.steps, 200)))
+    result = headline(R, S, world, a.steps, a.warmup, dt, a.precision)
+    result["ms_per_step_median"] = med[len(med) // 2]
+    result["ranks"] = {"world_size": world, "backend": backend,
+                       "launcher": ("bench.py self-launch" if os.environ.get("EVD_BENCH_SELF_LAUNCH") else
+                                    "external torchrun" if world > 1 else "none")}
+    lean = world > 1          # N > 1 runs: headline kernel + the strong-scaling leg (the other legs are N = 1 measurements)
 
     if rank == 0:
         # ---- roofline of the dominant kernel (fused PE+MLP), measured live with HIP events
         rb = torch.empty((R, 11), device="cuda")
         z = torch.empty((R, S), device="cuda")
         cfg = model._cfg(400, 400, float(K[0][0]), True, 0., 1., S, 0, False, 0., False)
-        import ctypes as C
         L.check(L.lib().evd_ray_batch(C.byref(cfg), L.ptr(rays), R, L.ptr(rb), L.stream_ptr()))
         L.check(L.lib().evd_sample_z(C.byref(cfg), L.ptr(rb), 11, R, None, L.ptr(z), L.stream_ptr()))
         modes = {}
-        lean = world > 1          # N > 1 runs: headline kernel only (modes / composite / cpu_baseline are N = 1 legs)
         for prec in ([a.precision] if (a.no_modes or lean) else ["f16", "bf16", "f16x3", "f32"]):
             net = model.mlp_coarse
             ksteps = max(3, a.steps // (10 if prec == "f32" else 1))
@@ -191,19 +376,30 @@ def main():
                               "mfma_busy_frac_pmc": busy,
                               "sustained_mfma_tflops": sustained, "frac_of_sustained_random": m["achieved"] / sustained["random_operands"],
                               "note": "achieved = algorithmic GEMM flops (1 186 816/sample) / HIP-event launch duration, against the 2.4 GHz "
-                                      "dense peak; traffic (bytes per launch) and mfma_busy_frac_pmc (SQ_VALU_MFMA_BUSY_CYCLES over "
+                                      "dense peak; traffic (bytes per launch: 2.0x the algorithmic bytes, the weight stream is fetched once per "
+                                      "XCD L2) and mfma_busy_frac_pmc (SQ_VALU_MFMA_BUSY_CYCLES over "
                                       "GRBM_GUI_ACTIVE x SIMDs: the kernel keeps the pipe busier than frac says because the chip clocks "
                                       "below 2.4 GHz under this load) are from the PMC passes in profiles/r01_v3_pmc_mlp.json; "
                                       "sustained_mfma_tflops = a bare back-to-back MFMA loop on every SIMD, measured in this run "
                                       "(evd_probe_mfma_rate): the random-operand figure is the practical ceiling for real data"}
         result["modes"] = modes
-        # ---- parity of the headline arithmetic on THIS workload: RGB L-inf against the exact-float32 kernel
-        with torch.no_grad():
-            ref_model, _ = make_model("f32")
-            rgb_ref = ref_model.render(400, 400, K, rays=rays, **kw)[0]
-            rgb_run = model.render(400, 400, K, rays=rays, **kw)[0]
-            result["parity"] = {"rgb_linf_vs_f32_kernel": float((rgb_run - rgb_ref).abs().max()), "bound": 1e-4,
-                                "note": "f32 kernel vs the reference (through the oracle and the goldens): tests/test_gpu_parity.py"}
+        if not a.no_parity and not lean:
+            # ---- parity of EVERY arithmetic mode at the full metric size against the CPU oracle (not against another kernel of
+            # this library), on the seed-derived weights and on weights trained in this run
+            precs = ["f32", "f16x3", "f16", "bf16"]
+            par = {"bound": 1e-4, "reference": "oracle/evd_oracle.c render (pinned to the imported reference by tests/golden G1-G20), same rays and weights",
+                   "rays": R, "samples": S, "rgb_linf_vs_oracle": {"seed_weights": oracle_parity(sd, rays, S, K, precs)}}
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import trained_weights as TW
+            t0 = time.perf_counter()
+            sd_tr, rep = TW.train_nerf(iters=a.train_iters)
+            rep["train_seconds"] = time.perf_counter() - t0
+            par["rgb_linf_vs_oracle"]["trained_weights"] = oracle_parity(sd_tr, rays, S, K, precs)
+            par["trained_weights"] = rep
+            par["headline_mode"] = a.precision
+            par["headline_within_bound"] = {k: v[a.precision] <= 1e-4 for k, v in par["rgb_linf_vs_oracle"].items()}
+            result["parity"] = par
+            del sd_tr
         if not a.no_composite and not lean:
             # ---- compositing scan alone (HBM-bound): 2^20 rays x 128 samples = 3.25 GB of algorithmic traffic
             Rc = 1 << 20
@@ -218,7 +414,7 @@ def main():
                                                 0, 0.0, None, L.ptr(o3), None, L.ptr(o2), L.ptr(ow), L.ptr(o1), None, 0, None, L.stream_ptr()))
             cms = kernel_ms(comp, 10)
             cbytes = Rc * (S * 24 + 32)
-            result["composite"] = {"kernel": "k_composite<3>", "rays": Rc, "samples": S, "ms": cms, "bound": "hbm",
+            result["composite"] = {"kernel": "k_composite_rows", "rays": Rc, "samples": S, "ms": cms, "bound": "hbm",
                                    "achieved": cbytes / (cms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": cbytes / (cms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": cbytes}
             del raw_c, z_c, rd_c, o3, o1, o2, ow
@@ -226,7 +422,7 @@ def main():
             # ---- the training kernels on the same workload (next row): forward that keeps the activations and the
             # hand-written backward of the fused MLP (parameter gradients + the gradient reaching the rays); informational
             from evdeblurnerf_amd.nerf import NeRF
-            tnet = NeRF(sd, "mlp_coarse.", precision=a.precision)
+            tnet = NeRF(sd, "mlp_coarse.", precision=a.precision if a.precision in ("f16", "bf16") else "f16")
             rb_t, z_t = rb, z
             algo_flop = R * S * FLOP_PER_SAMPLE
             d_raw_t = torch.randn((R, S, 4), device="cuda") * 1e-4
@@ -241,6 +437,23 @@ def main():
                                "note": "evd_nerf_mlp_train / evd_nerf_mlp_backward on the metric workload (one network); HBM-bound by "
                                        "construction (per-layer dgrad + wgrad over the stored fragments), DESIGN.md 7"}
             del store_t, tnet
+
+    # ---- the shipped configuration (every rank builds the model: the strong-scaling leg shards one frame's rows over the ranks)
+    c2f_model = None
+    if not a.no_c2f or not a.no_strong:
+        c2f_prec = a.precision
+        if rank == 0 and not a.no_c2f and not lean:
+            result["c2f"], c2f_model = c2f_leg(c2f_prec, max(5, a.steps // 2))
+        if not a.no_strong:
+            if c2f_model is None:
+                from evdeblurnerf_amd.renderer import NeRFAll
+                c2f_model = NeRFAll(W.blurfactory_args(128), W.make_blurfactory_state_dict(31), precision=c2f_prec).eval()
+            strong = strong_leg(c2f_model, c2f_prec, world, rank)
+            if rank == 0:
+                result["strong_scaling"] = strong
+        del c2f_model
+
+    if rank == 0:
         if not a.no_cpu_baseline and not lean:
             from oracle import oracle as O
             onet = O.Nerf(sd, "mlp_coarse.")
@@ -256,7 +469,7 @@ def main():
                 t_cpu = time.perf_counter() - t0
             result["cpu_baseline"] = {"value": n_cpu / t_cpu, "unit": "rays/s", "cores": O.num_threads(), "kind": "port",
                                       "sample": f"{n_cpu} rays (the workload's {R} rays x {S} samples, cycled for {t_cpu:.1f} s) through the C oracle, OpenMP over rays on all host cores"}
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if dist:
         dist.barrier()
         dist.destroy_process_group()

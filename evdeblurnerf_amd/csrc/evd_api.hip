@@ -217,6 +217,7 @@ void evd_nerf_destroy(evd_nerf* n) {
     n->wmaps.release();
     n->bias.release();
     n->bias_src.release();
+    n->side.release();
     delete n;
 }
 

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "../../include/evdnerf.h"
@@ -100,5 +101,44 @@ struct DevBuf {
         bytes = 0;
     }
 };
+
+// Side stream + join event of a handle's backward entry (the wgrad launches overlap the dgrad chain; nerf_train.h BwdPlan::side).
+// PER-HANDLE state, created on first use under the handle's own mutex and destroyed with the handle: two host threads may run
+// their first backward concurrently, on the same or on different handles, and the library keeps no process-wide table.
+struct SideStream {
+    std::mutex mu;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev = nullptr;
+    int get(hipStream_t* s, hipEvent_t* e) {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!stream) {
+            hipStream_t ns = nullptr;
+            hipEvent_t ne = nullptr;
+            EVD_HIP(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
+            hipError_t er = hipEventCreateWithFlags(&ne, hipEventDisableTiming);
+            if (er != hipSuccess) {
+                (void)hipStreamDestroy(ns);
+                return fail(EVD_E_HIP, "hipEventCreateWithFlags failed: %s", hipGetErrorString(er));
+            }
+            ev = ne;
+            stream = ns;
+        }
+        *s = stream;
+        *e = ev;
+        return EVD_OK;
+    }
+    void release() {
+        std::lock_guard<std::mutex> lock(mu);
+        if (ev) (void)hipEventDestroy(ev);
+        if (stream) (void)hipStreamDestroy(stream);
+        ev = nullptr;
+        stream = nullptr;
+    }
+};
+// number of persistent wgrad workgroups next to the dgrad chain (EVD_BWD_OVERLAP = 0: no side stream; N: that many, at most `cap`)
+inline int bwd_overlap_blocks(int cap) {
+    static const int want = [] { const char* e = getenv("EVD_BWD_OVERLAP"); return e ? atoi(e) : 192; }();
+    return want <= 0 ? 0 : (want > cap ? cap : want);
+}
 
 }  // namespace evd

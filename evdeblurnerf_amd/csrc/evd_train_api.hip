@@ -1,5 +1,5 @@
 // C-ABI entry points of the NeRF-mode training path: forward that keeps the activations, backward of the fused MLP
-// (reference: the autograd graph of networks/nerf.py:46-72 NeRF.mlpforward, driven by run_nerf.py:1032-1036 loss.backward()).
+// (reference: the autograd graph of networks/nerf.py:46-72 NeRF.mlpforward, driven by run_nerf.py:593-601 loss.backward()).
 #include "evd_common.h"
 #include "nerf_mlp.h"
 #include "nerf_net.h"
@@ -16,26 +16,6 @@ static long train_tiles(long nsamp) { return cdiv(nsamp, (long)TRAIN_WG_SAMPLES)
 static bool train_built(const evd_nerf* n, int prec) { return (prec == EVD_PREC_F16 || prec == EVD_PREC_BF16) && n->pipe_chunks[prec] > 0; }
 }  // namespace evd
 
-namespace evd {
-// lazily created per-device side stream + event of the backward entries (nerf_train.h BwdPlan::side)
-int side_stream(hipStream_t* side, hipEvent_t* ev, int* wgrad_blocks) {
-    static const char* e = getenv("EVD_BWD_OVERLAP");
-    static hipStream_t streams[64] = {nullptr};
-    static hipEvent_t events[64] = {nullptr};
-    *side = nullptr; *ev = nullptr;
-    const int want = e ? atoi(e) : 192;
-    if (want <= 0) return EVD_OK;
-    int dev = 0;
-    EVD_HIP(hipGetDevice(&dev));
-    dev &= 63;
-    if (!streams[dev]) {
-        EVD_HIP(hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking));
-        EVD_HIP(hipEventCreateWithFlags(&events[dev], hipEventDisableTiming));
-    }
-    *side = streams[dev]; *ev = events[dev]; *wgrad_blocks = want;
-    return EVD_OK;
-}
-}  // namespace evd
 
 extern "C" {
 
@@ -87,10 +67,15 @@ int evd_nerf_mlp_backward(const evd_nerf* net, int precision, const float* d_raw
     b.maxbits = (unsigned*)w;
     b.partial = (float*)(w + 256);
     b.wgrad_blocks = WGRAD_BLOCKS; b.skip = net->skip;
-    // the wgrad launches run on a per-device side stream, forked from / joined to the caller's stream with events (stream order
+    // the wgrad launches run on the handle's side stream, forked from / joined to the caller's stream with events (stream order
     // as seen by the caller is unchanged): measured 3.41 -> 3.05 ms at 2^19 samples with 192 persistent wgrad workgroups
-    // (256: 3.14, 128: 3.52).  EVD_BWD_OVERLAP=0 keeps everything on the caller's stream; =N sets the workgroup count.
-    if ((rc0 = side_stream(&b.side, &b.ev, &b.wgrad_blocks))) return rc0;
+    // (256: 3.14, 128: 3.52).  EVD_BWD_OVERLAP=0 keeps everything on the caller's stream; =N sets the workgroup count (at most
+    // WGRAD_BLOCKS, what the workspace is sized for).
+    b.side = nullptr; b.ev = nullptr;
+    if (const int nb = bwd_overlap_blocks(WGRAD_BLOCKS)) {
+        if ((rc0 = net->side.get(&b.side, &b.ev))) return rc0;
+        b.wgrad_blocks = nb;
+    }
     b.pts = pts; b.viewdirs = viewdirs; b.vd_stride = vd_stride; b.S = S; b.d_pts = d_pts; b.d_dirs = d_dirs;
     for (int l = 0; l < EVD_MAX_LAYERS; ++l) { b.grads.pts_w[l] = l < net->D ? grads->pts_w[l] : nullptr; b.grads.pts_b[l] = l < net->D ? grads->pts_b[l] : nullptr; }
     b.grads.views_w = grads->views_w; b.grads.views_b = grads->views_b; b.grads.feature_w = grads->feature_w; b.grads.feature_b = grads->feature_b;

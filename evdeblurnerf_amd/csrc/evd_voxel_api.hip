@@ -7,7 +7,6 @@
 #include "voxel_mlp_kernel.h"
 #include "voxel_train.h"
 
-namespace evd { int side_stream(hipStream_t* side, hipEvent_t* ev, int* wgrad_blocks); }    // evd_train_api.hip
 
 #include <cmath>
 #include <cstdint>
@@ -27,6 +26,7 @@ struct evd_voxel {
     int train_chunks[EVD_NUM_PREC];
     long param_off[9];            // sigma_net.0, sigma_net.1, color_net.{0,1,2}.{weight,bias} in the parameter arena, [8] = total
     GridParams gp;
+    mutable SideStream side;      // backward entry: wgrad side stream of THIS handle (created on first use)
 };
 
 static const int kMat0[3] = {0, 0, 1}, kMat1[3] = {1, 2, 2}, kVec[3] = {2, 1, 0};
@@ -41,6 +41,7 @@ void evd_voxel_destroy(evd_voxel* v) {
         for (int k = 0; k < VBWD_NSTREAMS; ++k) v->bwd[i][k].release();
     }
     v->basis.release(); v->bias.release(); v->bias_src.release(); v->tv_acc.release(); v->wmaps.release();
+    v->side.release();
     delete v;
 }
 
@@ -376,6 +377,8 @@ int evd_c2f_render_rays(const evd_voxel* coarse, const evd_voxel* fine, const ev
     if ((rc = launch_points(rb, 11, zc, R * (long)S, S, pts, st))) return rc;
     const int FC = coarse->app_dim;
     EVD_REQUIRE(!Ni || (FC == 32 && FC % 4 == 0), "evd_c2f_render_rays: coarse app_dim %d (workspace is sized for 32)", FC);
+    EVD_REQUIRE(FC <= FS && (!Ni || !fine || FC + fine->app_dim <= FS),
+                "evd_c2f_render_rays: app_dim %d + %d exceeds the feature row stride %d", FC, (Ni && fine) ? fine->app_dim : 0, FS);
     if (!Ni) {
         if ((rc = sample_for(coarse, cfg->precision, pts, R * (long)S, ft, FS, 0, stream))) return rc;      // renderer.py:183
         float* wo = out->weights ? out->weights : wts;
@@ -488,8 +491,11 @@ int evd_voxel_mlp_backward(const evd_voxel* v, int precision, const float* d_raw
     b.side = nullptr; b.ev = nullptr;
     static const bool overlap = env_flag("EVD_BWD_OVERLAP_VOXEL");     // measured: no gain for the level networks (7.70 vs 7.86 ms per c2f iteration), off
     if (overlap) {
-        int rc0 = side_stream(&b.side, &b.ev, &b.wgrad_blocks);
-        if (rc0) return rc0;
+        if (const int nb = bwd_overlap_blocks(VOX_WGRAD_BLOCKS)) {
+            int rc0 = v->side.get(&b.side, &b.ev);
+            if (rc0) return rc0;
+            b.wgrad_blocks = nb;
+        }
     }
     b.d_fts = d_fts; b.d_fts_stride = d_fts_stride;
     b.pts = pts; b.viewdirs = viewdirs; b.vd_stride = vd_stride; b.S = S; b.d_pts = d_pts; b.d_dirs = d_dirs;

@@ -1,5 +1,7 @@
 // Ray setup, z stratification, alpha compositing scan, inverse-CDF resampling + merge.
 // All HBM-bound elementwise / per-ray kernels of the render path (everything except the MLP GEMMs).
+#include <algorithm>
+#include <cstdint>
 #include <cstdlib>
 
 #include "evd_common.h"
@@ -655,6 +657,44 @@ __global__ __launch_bounds__(256) void k_sample_pdf_merge(const float* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// reference networks/renderer.py:259-263: the per-key isnan / isinf guard of render_rays (two host syncs per key there).
+// Here: one launch over all keys, flags[k] |= 1 (NaN) | 2 (Inf), no sync; the caller reads the word when it wants to.
+constexpr int NUMERICS_MAX_KEYS = 16;
+struct NumericsKeys {
+    const float* p[NUMERICS_MAX_KEYS];
+    long n[NUMERICS_MAX_KEYS];
+    int keys;
+};
+__global__ void k_numerics_flags(const NumericsKeys a, unsigned* __restrict__ flags) {
+    const int k = blockIdx.y;
+    if (k >= a.keys) return;
+    const float* __restrict__ x = a.p[k];
+    const long n = a.n[k];
+    unsigned f = 0;
+    // exponent all ones: mantissa != 0 -> NaN, == 0 -> Inf
+    auto look = [&](float v) {
+        const unsigned u = __float_as_uint(v);
+        if ((u & 0x7f800000u) == 0x7f800000u) f |= (u & 0x007fffffu) ? 1u : 2u;
+    };
+    const long stride = (long)gridDim.x * blockDim.x;
+    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x);
+        for (long j = i; j < n / 4; j += stride) {
+            const float4 v = x4[j];
+            look(v.x); look(v.y); look(v.z); look(v.w);
+        }
+        for (long j = (n / 4) * 4 + i; j < n; j += stride) look(x[j]);
+    } else {
+        for (long j = i; j < n; j += stride) look(x[j]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) f |= __shfl_xor(f, off, WAVE);
+    if ((threadIdx.x & 63) == 0 && f) atomicOr(&flags[k], f);
+}
+
+
 }  // namespace evd
 
 using namespace evd;
@@ -804,6 +844,27 @@ int evd_sample_pdf_merge(const float* z, const float* weights, long R, int S, in
     const size_t lds = 4 * sizeof(float) * (size_t)(2 * S + N + 2);
     EVD_REQUIRE(lds <= 64 * 1024, "evd_sample_pdf_merge: S + N too large for the LDS staging (%zu bytes)", lds);
     k_sample_pdf_merge<<<cdiv(R, 4), 256, lds, as_stream(stream)>>>(z, weights, R, S, N, det, u, z_samples, z_merged, order, z_std);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+int evd_numerics_flags(const float* const* ptrs, const long* counts, int n_keys, unsigned* flags, void* stream) {
+    using namespace evd;
+    EVD_REQUIRE(n_keys >= 0 && n_keys <= NUMERICS_MAX_KEYS, "evd_numerics_flags: n_keys %d (max %d)", n_keys, NUMERICS_MAX_KEYS);
+    if (n_keys == 0) return EVD_OK;
+    EVD_REQUIRE(ptrs && counts && flags, "evd_numerics_flags: null argument");
+    NumericsKeys a{};
+    a.keys = n_keys;
+    long most = 0;
+    for (int k = 0; k < n_keys; ++k) {
+        EVD_REQUIRE(counts[k] >= 0 && (ptrs[k] || counts[k] == 0), "evd_numerics_flags: key %d is null", k);
+        a.p[k] = ptrs[k];
+        a.n[k] = counts[k];
+        most = counts[k] > most ? counts[k] : most;
+    }
+    EVD_HIP(hipMemsetAsync(flags, 0, sizeof(unsigned) * n_keys, as_stream(stream)));
+    const int bx = (int)std::min<long>(std::max<long>(cdiv(most, 256 * 16), 1), 1024);
+    hipLaunchKernelGGL(k_numerics_flags, dim3(bx, n_keys), dim3(256), 0, as_stream(stream), a, flags);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }

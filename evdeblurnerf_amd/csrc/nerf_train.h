@@ -41,7 +41,6 @@ struct BwdPlan {
     float *d_pts, *d_dirs;              // [nsamp,3] float32 out (through the positional encodings), or null
 };
 
-int side_stream(hipStream_t* side, hipEvent_t* ev, int* wgrad_blocks);     // evd_train_api.hip
 int run_nerf_backward_f16(const BwdPlan& b, hipStream_t st);
 int run_nerf_backward_bf16(const BwdPlan& b, hipStream_t st);
 

@@ -1,5 +1,5 @@
 // Backward of the fused NeRF MLP (bf16 / f16 modes, netdepth 8, netwidth 256, skips [4]).
-// reference: the autograd graph of NeRF.mlpforward, networks/nerf.py:46-72, differentiated by run_nerf.py:1032-1036.
+// reference: the autograd graph of NeRF.mlpforward, networks/nerf.py:46-72, differentiated by run_nerf.py:593-601.
 //
 // Everything works on the activation store the training forward filled (nerf_mlp.h, namespace astore): one 1 KiB MFMA
 // B fragment per (32-sample tile, 16 channels), lane-linear, so every access below is a coalesced 16-byte load/store

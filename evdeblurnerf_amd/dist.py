@@ -44,13 +44,38 @@ def init_from_env(backend: str | None = None):
     return rank, world, local
 
 
+class _AllReduceSum(torch.autograd.Function):
+    """sum over ranks as an autograd node.  Every rank goes on to compute the SAME global loss from the reduced vector and
+    back-propagates it through its own shard only, so the backward is the identity (d global sum / d local partial = 1); the
+    parameter gradients of the shards are then summed over ranks (GradReducer), which gives the single-process gradient."""
+
+    @staticmethod
+    def forward(ctx, flat):
+        import torch.distributed as dist
+        out = flat.detach().clone()
+        dist.all_reduce(out, op=dist.ReduceOp.SUM)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
 def all_reduce_partials(*partials):
-    """Sum the packed loss partial vectors over ranks with ONE collective. Tensors are updated in place and
-    returned; a no-op without an initialised process group."""
+    """Sum the packed loss partial vectors over ranks with ONE collective and return them (use the returned tensors).
+    Plain tensors are also updated in place; tensors that carry an autograd graph (the outputs of the fused loss nodes
+    of losses.py) come back as new tensors behind a differentiable all-reduce.  A no-op without an initialised process group."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return partials
     flat = torch.cat([p.reshape(-1) for p in partials])
+    if flat.requires_grad:
+        red = _AllReduceSum.apply(flat)
+        out, off = [], 0
+        for p in partials:
+            out.append(red[off:off + p.numel()].reshape(p.shape))
+            off += p.numel()
+        return tuple(out)
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     off = 0
     for p in partials:
@@ -124,8 +149,12 @@ def gather_rows(local_rows: torch.Tensor, n_total: int):
     per = -(-n_total // world)
     pad = torch.zeros((per,) + tuple(local_rows.shape[1:]), dtype=local_rows.dtype, device=local_rows.device)
     pad[: local_rows.shape[0]] = local_rows
+    dev = pad.device
+    if dist.get_backend() == "gloo" and pad.is_cuda:          # gloo has no device all_gather (CPU tests, 1-GPU validation runs)
+        pad = pad.cpu()
     tiles = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(tiles, pad)
+    tiles = [t.to(dev) for t in tiles]
     out = []
     for r in range(world):
         lo, hi = shard_range(n_total, r, world)

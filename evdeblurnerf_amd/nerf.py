@@ -206,7 +206,7 @@ class NeRF:
         return {key: flat[off:off + int(np.prod(shape))].view(shape) for key, shape, off in self.param_blocks()}
 
     def load_params(self, flat):
-        """re-pack every weight stream on the device from new parameter values (after optimizer.step(), run_nerf.py:1036)"""
+        """re-pack every weight stream on the device from new parameter values (after optimizer.step(), run_nerf.py:601)"""
         f = flat.detach().contiguous().float()
         self.param_blocks()
         if f.numel() != self._nparam:

@@ -82,17 +82,17 @@ class NeRFAll:
     def sync_parameters(self):
         """push the current values of the trainable tensors into the library (re-pack the weight streams, reload the grids); the
         training forward does this lazily, an evaluation render after optimizer.step() needs it explicitly (train(False) calls it)"""
-        tp = getattr(self, "_train_params", None)
-        if tp is None:
+        if getattr(self, "_levels", None) is None:
             return
+        with torch.no_grad():
+            tp = self._current_params()
         for net, p in ((self.mlp_coarse, tp[0]), (self.mlp_fine, tp[1])):
             if p is None:
                 continue
             if isinstance(p, dict):
-                if getattr(net, "_synced_net", None) != (p["net"].data_ptr(), p["net"]._version):
-                    net.load_params(p["net"])
+                net.load_params(p["net"])
                 net._sync(p["grids"])
-            elif getattr(net, "_synced", None) != (p.data_ptr(), p._version):
+            else:
                 net.load_params(p)
 
     def train(self, mode=True):
@@ -197,12 +197,31 @@ class NeRFAll:
         if not retraw and "z_vals" in ret and not want_feat:
             del ret["z_vals"]
         if check_numerics:
-            for k in ret:
-                if torch.isnan(ret[k]).any():
-                    print(f"! [Numerical Error] {k} contains nan.")
-                if torch.isinf(ret[k]).any():
-                    print(f"! [Numerical Error] {k} contains inf.")
+            # renderer.py:259-263 as ONE launch over all keys into a device flag word per key (evd_numerics_flags).
+            # check_numerics="device": no synchronisation, the int32 tensor is returned as ret["numerics_flags"] (key order =
+            # ret["numerics_keys"]); check_numerics=True: read it back (one sync instead of two per key) and print the
+            # reference's messages
+            keys = [k for k in ret if ret[k].dtype == torch.float32]
+            flags = self.numerics_flags([ret[k] for k in keys])
+            if check_numerics == "device":
+                ret["numerics_flags"], ret["numerics_keys"] = flags, keys
+            else:
+                for k, f in zip(keys, flags.tolist()):
+                    if f & 1:
+                        print(f"! [Numerical Error] {k} contains nan.")
+                    if f & 2:
+                        print(f"! [Numerical Error] {k} contains inf.")
         return ret
+
+    def numerics_flags(self, tensors):
+        """int32 [len(tensors)] on the device: bit 0 = NaN present, bit 1 = Inf present (no host synchronisation)"""
+        ts = [t.contiguous() for t in tensors]
+        n = len(ts)
+        flags = torch.empty((n,), dtype=torch.int32, device=self.device)
+        ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+        counts = (C.c_long * n)(*[t.numel() for t in ts])
+        L.check(L.lib().evd_numerics_flags(ptrs, counts, n, L.ptr(flags), L.stream_ptr()), "evd_numerics_flags")
+        return flags
 
     # ------------------------------------------------------------------ render_rays under autograd (mode='nerf')
     def trainable_parameters(self, state_dict):
@@ -357,11 +376,18 @@ class NeRFAll:
     # ------------------------------------------------------------------ render, renderer.py:399-466
     def render(self, H, W, K, chunk=1 << 22, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,
                c2w_staticcam=None, **kwargs):
+        """renderer.py:399-466.  `rays` [..., 3, 2]; as in the reference, `c2w` is not read when rays are given (render_path passes
+        both, :614) -- without rays the full H x W image of `c2w` is generated on the device (evd_get_rays).  `c2w_staticcam`
+        (:427-430): origins / directions of that camera, view directions of the given rays.  use_viewdirs=False (the 8-column
+        batch of :443-446) is rejected: the library's networks are built with the view branch, like every shipped config."""
         if not use_viewdirs:
-            raise NotImplementedError("use_viewdirs=False is not supported")
-        if c2w_staticcam is not None:
-            raise NotImplementedError("c2w_staticcam (viewdir visualisation) is not supported")
+            raise NotImplementedError("use_viewdirs=False (8-column ray batch) is not supported: networks are built with view directions")
         focal = float(K[0][0])
+        if rays is None:
+            if c2w is None:
+                raise L.EvdError("render needs rays or c2w")
+            o, d = get_rays(H, W, K, torch.as_tensor(c2w, device=self.device))
+            rays = torch.stack([o, d], dim=-1)
         rays = rays.to(self.device).float()
         sh = rays.shape[:-2]                      # [..., 3, 2]
         flat = rays.reshape(-1, 3, 2).contiguous()
@@ -369,14 +395,31 @@ class NeRFAll:
         N_samples = kwargs.get("N_samples")
         cfg = self._cfg(H, W, focal, ndc, near, far, N_samples, kwargs.get("N_importance", 0), kwargs.get("lindisp", False),
                         kwargs.get("perturb", 0.), kwargs.get("white_bkgd", False))
+        batch = None
+        if c2w_staticcam is not None:
+            so, sd_ = get_rays(H, W, K, torch.as_tensor(c2w_staticcam, device=self.device))
+            cam = torch.stack([so, sd_], dim=-1).reshape(-1, 3, 2).contiguous().float()
+            if cam.shape[0] != R:
+                raise L.EvdError(f"c2w_staticcam gives {cam.shape[0]} rays, the batch has {R}")
+            batch = torch.empty((R, 11), dtype=torch.float32, device=self.device)
+            L.check(L.lib().evd_ray_batch(C.byref(cfg), L.ptr(cam), R, L.ptr(batch), L.stream_ptr()), "evd_ray_batch")
+            vd = flat[..., 1]
+            batch[:, 8:11] = vd / torch.norm(vd, dim=-1, keepdim=True)
         all_ret = {}
+        numerics = None
         rand_keys = ("t_rand", "u", "noise0", "noise1")
         for i in range(0, max(1, R), chunk):
             kw = dict(kwargs)
             for k in rand_keys:
                 if kw.get(k) is not None:
                     kw[k] = kw[k][i:i + chunk]
-            ret = self.render_rays(None, _cfg=cfg, _rays=flat[i:i + chunk], **kw)
+            if batch is not None:
+                ret = self.render_rays(batch[i:i + chunk], _cfg=cfg, **kw)
+            else:
+                ret = self.render_rays(None, _cfg=cfg, _rays=flat[i:i + chunk], **kw)
+            if "numerics_flags" in ret:                  # check_numerics="device": OR the chunks' flag words, stay on the device
+                nf, nk = ret.pop("numerics_flags"), ret.pop("numerics_keys")
+                numerics = ((nf if numerics is None else numerics[0] | nf), nk)
             for k, v in ret.items():
                 all_ret.setdefault(k, []).append(v)
         all_ret = {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in all_ret.items()}
@@ -385,6 +428,8 @@ class NeRFAll:
         k_extract = ["rgb_map", "depth_map", "acc_map"]
         ret_list = [all_ret[k] for k in k_extract]
         ret_dict = {k: all_ret[k] for k in all_ret if k not in k_extract}
+        if numerics is not None:
+            ret_dict["numerics_flags"], ret_dict["numerics_keys"] = numerics
         if self.use_awp:
             # NDC ray directions, renderer.py:464-465
             from .rays import get_ndc_rays
@@ -420,39 +465,128 @@ class NeRFAll:
         return torch.stack(rgbs, 0), torch.stack(depths, 0)
 
     # ------------------------------------------------------------------ forward, renderer.py:266-397
-    # ---- the reference's nn.Module surface for a training loop (run_nerf.py:1000-1040) ----------------------------------
+    # ---- the reference's nn.Module surface for a training loop (optimizer groups run_nerf.py:245-263, iteration :423-613,
+    # ---- checkpoint :617-638) ---------------------------------------------------------------------------------------------
     def enable_training(self, state_dict):
-        """Create the trainable tensors from a state dict and keep them in the model: afterwards `parameters()` feeds an
-        optimizer and `model(H, W, K, chunk, rays=..., **render_kwargs_train)` in training mode runs forward_train (autograd)."""
-        self._train_params = self.trainable_parameters(state_dict)
+        """Create the trainable tensors from a state dict and keep them in the model: ONE LEAF PER REFERENCE PARAMETER
+        (`named_parameters()` yields the reference's names), so that `parameters()`, `get_parameters(type, match_re, not_match_re)`,
+        `grad_vars` and `grad_vars_vol` feed optimizer groups exactly like renderer.py:58-79,112-127 / run_nerf.py:245-263, and
+        `model(H, W, K, chunk, rays=..., **render_kwargs_train)` in training mode runs forward_train (autograd).  The library's
+        kernels consume one flat float32 tensor per network: it is the concatenation of the leaves (autograd's cat splits the
+        flat gradient back); the tri-plane tensors are leaves in the library's channel-last layout ([H,W,C], [L,C]; an
+        element-wise optimizer does not care, `state_dict()` returns the reference layouts)."""
+        from collections import OrderedDict
+        levels = []
+        for prefix, net, p in (("mlp_coarse.", self.mlp_coarse, None), ("mlp_fine.", self.mlp_fine, None)):
+            if net is None:
+                levels.append(None)
+                continue
+            flat = net.flat_params(state_dict, prefix, self.device).detach()
+            blocks = sorted(net.param_blocks(), key=lambda b: b[2])
+            off = 0
+            for key, shape, o in blocks:             # the leaves tile the flat tensor exactly, in this order
+                if o != off:
+                    raise L.EvdError(f"parameter blocks of {prefix} are not contiguous at {key}")
+                off += int(np.prod(shape))
+            if off != flat.numel():
+                raise L.EvdError(f"parameter blocks of {prefix} do not cover the flat tensor")
+            leaves = OrderedDict((prefix + key, flat[o:o + int(np.prod(shape))].reshape(shape).clone().requires_grad_(True))
+                                 for key, shape, o in blocks)
+            grids = None
+            if self.mode == "c2f":
+                g = net.grid_params()
+                grids = OrderedDict([(f"{prefix}app_plane.{i}", g[i]) for i in range(3)] + [(f"{prefix}app_line.{i}", g[3 + i]) for i in range(3)]
+                                    + [(f"{prefix}basis_mat.weight", g[6])])
+            levels.append({"leaves": leaves, "grids": grids})
+        self._levels = levels
         return self
 
-    def parameters(self):
-        """leaf tensors of the two networks / levels (+ the kernelsnet's and the awpnet's own parameters)"""
-        if getattr(self, "_train_params", None) is None:
-            raise L.EvdError("call enable_training(state_dict) first")
+    def _current_params(self):
+        """(params_coarse, params_fine) in the form forward_train / render_rays_train take, from the per-tensor leaves"""
         out = []
-        for p in self._train_params:
-            if p is None:
+        for lv in self._levels:
+            if lv is None:
+                out.append(None)
                 continue
-            out += ([p["net"]] + list(p["grids"])) if isinstance(p, dict) else [p]
+            flat = torch.cat([t.reshape(-1) for t in lv["leaves"].values()])
+            net = self.mlp_coarse if len(out) == 0 else self.mlp_fine
+            net._synced = net._synced_net = None        # a fresh flat tensor: never trust an address / version match, re-pack
+            out.append({"net": flat, "grids": list(lv["grids"].values())} if lv["grids"] is not None else flat)
+        return tuple(out)
+
+    @property
+    def _train_params(self):
+        return self._current_params() if getattr(self, "_levels", None) is not None else None
+
+    def _require_training(self):
+        if getattr(self, "_levels", None) is None:
+            raise L.EvdError("call enable_training(state_dict) first")
+
+    def named_parameters(self):
+        """[(reference state-dict name, leaf tensor)]: mlp_{coarse,fine}.* (+ kernelsnet.* / awpnet.* of the PyTorch modules)"""
+        self._require_training()
+        out = []
+        for lv in self._levels:
+            if lv is None:
+                continue
+            out += list(lv["leaves"].items())
+            if lv["grids"] is not None:
+                out += list(lv["grids"].items())
+        for name, m in (("kernelsnet", self.kernelsnet), ("awpnet", self.awpnet)):
+            if isinstance(m, torch.nn.Module):
+                out += [(f"{name}.{k}", v) for k, v in m.named_parameters()]
+        return out
+
+    def parameters(self):
+        return [v for _, v in self.named_parameters()]
+
+    def get_parameters(self, type, match_re=None, not_match_re=None):
+        """renderer.py:112-127: the 'net' or 'vol' (app_plane / app_line) parameters whose names match / do not match a regex,
+        e.g. get_parameters("net", match_re=r"\\.color_net\\.[0-9]+\\.weight") for the weight-decay group of run_nerf.py:246-250"""
+        import re
+        is_vol = lambda k: "app_plane" in k or "app_line" in k
+        ok = lambda k: ((match_re is None or len(re.findall(match_re, k)) > 0) and
+                        (not_match_re is None or not len(re.findall(not_match_re, k)) > 0))
+        return [v for k, v in self.named_parameters() if ok(k) and ((type == "net" and not is_vol(k)) or (type == "vol" and is_vol(k)))]
+
+    @property
+    def grad_vars_vol(self):
+        """renderer.py:60,79 / voxnerf.py:121: lines then planes of the coarse level, then of the fine level"""
+        self._require_training()
+        out = []
+        for lv in self._levels:
+            if lv is not None and lv["grids"] is not None:
+                g = list(lv["grids"].values())
+                out += g[3:6] + g[0:3]
+        return out
+
+    @property
+    def grad_vars(self):
+        """renderer.py:60-64,77-78 / voxnerf.py:122-123: basis_mat, color_net, sigma_net of the coarse level, the kernelsnet's and
+        the awpnet's parameters, then the fine level's"""
+        self._require_training()
+        def level(lv):
+            if lv is None or lv["grids"] is None:
+                return []
+            names = lv["leaves"]
+            return ([list(lv["grids"].values())[6]] + [v for k, v in names.items() if ".color_net." in k] +
+                    [v for k, v in names.items() if ".sigma_net." in k])
+        out = level(self._levels[0])
         for m in (self.kernelsnet, self.awpnet):
             if isinstance(m, torch.nn.Module):
                 out += list(m.parameters())
-        return out
+        return out + level(self._levels[1])
 
     def state_dict(self):
-        """current values under the reference's state-dict keys and layouts (checkpointing, run_nerf.py:1078-1090)"""
-        if getattr(self, "_train_params", None) is None:
-            raise L.EvdError("call enable_training(state_dict) first")
+        """current values under the reference's state-dict keys and layouts (checkpointing, run_nerf.py:617-638)"""
+        self._require_training()
         sd = {}
-        for name, net, p in (("mlp_coarse.", self.mlp_coarse, self._train_params[0]), ("mlp_fine.", self.mlp_fine, self._train_params[1])):
-            if p is None:
+        for name, net, lv in (("mlp_coarse.", self.mlp_coarse, self._levels[0]), ("mlp_fine.", self.mlp_fine, self._levels[1])):
+            if lv is None:
                 continue
-            flat = p["net"] if isinstance(p, dict) else p
-            sd.update({name + k: v.detach().clone() for k, v in net.unflatten(flat).items()})
-            if isinstance(p, dict):
-                sd.update(net.grids_to_state_dict(p["grids"], name))
+            sd.update({k: v.detach().clone() for k, v in lv["leaves"].items()})
+            if lv["grids"] is not None:
+                sd.update(net.grids_to_state_dict(list(lv["grids"].values()), name))
         return sd
 
     def forward(self, H, W, K, chunk=1 << 22, rays=None, rays_info=None, poses=None, **kwargs):
@@ -460,12 +594,17 @@ class NeRFAll:
             assert poses is not None, "Please specify poses when in the eval model"
             return self.render_path(H, W, K, chunk, poses, **kwargs)
         assert rays is not None, "Please specify rays when in the training mode"
-        if getattr(self, "_train_params", None) is not None:        # differentiable path (enable_training)
+        if getattr(self, "_levels", None) is not None:              # differentiable path (enable_training)
             kw = dict(kwargs)
+            # keys of the reference's render_kwargs_train / call site (run_nerf.py:306-314,438-442) that select nothing here:
+            # retraw (the dict always carries weights / z_vals), return_pts0_rgb (always returned), pytest, c2w, use_viewdirs
+            # (networks are built with view directions); `inference` gates the AWP feature output as in renderer.py:255
             for k in ("retraw", "use_viewdirs", "c2w", "c2w_staticcam", "pytest", "return_pts0_rgb"):
                 kw.pop(k, None)
-            return self.forward_train(H, W, K, rays, self._train_params[0], self._train_params[1], rays_info=rays_info,
-                                      force_naive=kw.pop("force_naive", True), **kw)
+            if kw.pop("inference", False):
+                raise L.EvdError("inference=True in training mode: use eval() + render_path / render (renderer.py:394-397)")
+            pc, pf = self._current_params()
+            return self.forward_train(H, W, K, rays, pc, pf, rays_info=rays_info, force_naive=kw.pop("force_naive", True), **kw)
         force_baseline = kwargs.pop("force_naive", True)
         return_pts0_rgb = kwargs.pop("return_pts0_rgb", False)
         N_importance = kwargs.get("N_importance", 0)

@@ -20,17 +20,19 @@ def _np32(v):
 class CRF:
     """map_type in {'none','gamma','learn'}; 'learn' takes the ``linear.{0,2,4,6}.{weight,bias}`` arrays."""
 
-    def __init__(self, map_type: str, gamma: float = 2.2, state_dict=None, prefix="", extra_features=0):
+    def __init__(self, map_type: str, gamma: float = 2.2, state_dict=None, prefix="", extra_features=0, init_identity=False,
+                 init_seed=42):
         assert map_type in ("none", "gamma", "learn")
         self.map_type, self.gamma, self.extra_features = map_type, gamma, extra_features
+        if map_type == "learn" and state_dict is None and init_identity:
+            state_dict, prefix = self.identity_state_dict(extra_features, init_seed), ""
         d = L.CrfDesc()
         d.map_type = {"none": 0, "gamma": 1, "learn": 2}[map_type]
         d.gamma, d.extra_features = float(gamma), int(extra_features)
         keep = []
         if map_type == "learn":
             if state_dict is None:
-                raise L.EvdError("learn CRF needs its parameters (the reference's init_identity training is the "
-                                 "caller's job: tonemapping.py:29-57)")
+                raise L.EvdError("learn CRF needs its parameters: pass state_dict or init_identity=True (tonemapping.py:29-57)")
             for j, idx in enumerate((0, 2, 4, 6)):
                 w, b = _np32(state_dict[f"{prefix}linear.{idx}.weight"]), _np32(state_dict[f"{prefix}linear.{idx}.bias"])
                 keep += [w, b]
@@ -49,6 +51,40 @@ class CRF:
     @property
     def handle(self):
         return self._h
+
+    @staticmethod
+    def identity_state_dict(extra_features=0, seed=42, steps=3000, device="cuda"):
+        """CRF.init_identity (tonemapping.py:29-57; `tone_mapping_learn_init_identity = True` in the shipped configs, wired at
+        run_nerf.py:239): a freshly initialised 1+F -> 16 -> 16 -> 16 -> 1 MLP is pre-trained so that sigmoid(0.1 mlp([x, 0]) + x)
+        reproduces x -- 3000 Adam steps (lr 1e-2) on batches of 64 x 3 uniform samples from a generator seeded with 42, the extra
+        features held at zero.  A one-off initialiser of 625 parameters, run as the reference runs it (torch ops on the device);
+        the result enters the library through evd_crf_create like any other state dict.  The reference's own draw (torch 1.13
+        CUDA generator + nn.Linear default init) is not reproducible bit for bit: the PROCEDURE is the contract."""
+        from torch import nn
+        gen = torch.Generator(device=device).manual_seed(int(seed))
+        cpu_gen = torch.Generator().manual_seed(int(seed))
+        dims = [(1 + extra_features, 16), (16, 16), (16, 16), (16, 1)]
+        layers = []
+        for fi, fo in dims:
+            lin = nn.Linear(fi, fo)
+            bound = 1.0 / np.sqrt(fi)                    # nn.Linear's default: kaiming_uniform(a=sqrt(5)) = U(+-1/sqrt(fan_in))
+            with torch.no_grad():
+                lin.weight.copy_((torch.rand((fo, fi), generator=cpu_gen) * 2 - 1) * bound)
+                lin.bias.copy_((torch.rand((fo,), generator=cpu_gen) * 2 - 1) * bound)
+            layers += [lin, nn.ReLU()]
+        mlp = nn.Sequential(*layers[:-1]).to(device)
+        optim = torch.optim.Adam(mlp.parameters(), lr=1e-2)
+        for _ in range(steps):
+            x = torch.rand((64, 3), generator=gen, device=device)
+            x_in = x.reshape(-1, 1)
+            x_feat = torch.cat([x_in, torch.zeros((x_in.shape[0], extra_features), device=device)], -1) if extra_features > 0 else x_in
+            y = torch.sigmoid(mlp(x_feat) * 0.1 + x_in).reshape(x.shape)
+            loss = torch.mean((y - x) ** 2)
+            optim.zero_grad()
+            loss.backward()
+            optim.step()
+        return {f"linear.{i}.{k}": v.detach().cpu().numpy().astype(np.float32) for i in (0, 2, 4, 6)
+                for k, v in (("weight", mlp[i].weight), ("bias", mlp[i].bias))}
 
     # training the learnable CRF: its parameters as one flat tensor in the layout of evd_event_loss_bwd (losses.crf_param_grads)
     def flat_params(self, device="cuda"):
@@ -81,10 +117,13 @@ class CRF:
 
 class TonemappingTransform:
     def __init__(self, map_type_rgb: str, map_type_event: str, gamma: float = 2.2, luma_standard="rec601",
-                 state_dict=None, extra_features_event=0, extra_features_rgb=0):
+                 init_learn_identity=False, extra_features_event=0, extra_features_rgb=0, state_dict=None):
+        """tonemapping.py:98-109 (same positional order); `state_dict` (crf_state_dict of a checkpoint, run_nerf.py:631) is the
+        extra way in for trained parameters; without it a 'learn' CRF needs init_learn_identity=True"""
         assert luma_standard in _LUMA
-        self.tonemapping_rgb = CRF(map_type_rgb, gamma, state_dict, "tonemapping_rgb.", extra_features_rgb)
-        self.tonemapping_event = CRF(map_type_event, gamma, state_dict, "tonemapping_event.", extra_features_event)
+        self.tonemapping_rgb = CRF(map_type_rgb, gamma, state_dict, "tonemapping_rgb.", extra_features_rgb, init_identity=init_learn_identity)
+        self.tonemapping_event = CRF(map_type_event, gamma, state_dict, "tonemapping_event.", extra_features_event,
+                                     init_identity=init_learn_identity)
         self.luma_standard = luma_standard
 
     def train(self, mode=True):

@@ -169,3 +169,41 @@ def synthetic_rays(seed: int, n_rays: int, H: int = 400, W: int = 400, focal: fl
     rays_d = np.sum(dirs[:, None, :] * c2w[:, :3, :3], -1).astype(np.float32)
     rays_o = c2w[:, :3, 3].astype(np.float32)
     return np.stack([rays_o, rays_d], -1).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------
+# the shipped 'blurfactory' configuration (BASELINE configs 2, 3, 5): PDRF coarse-to-fine levels at their real grid sizes
+# (configs/evdeblurnerf_blender/tx_blurfactory_evdeblurnerf_ediprior_evcrf.txt:61-80)
+# ---------------------------------------------------------------------------
+
+BLURFACTORY_AABB = ([-1.5, -1.5, -1.0], [1.5, 1.5, 1.0])
+BLURFACTORY_COARSE_VOXELS = 16777248
+BLURFACTORY_FINE_VOXELS = 134217984
+
+
+def blurfactory_args(N_importance: int = 64, coarse_voxels: int = BLURFACTORY_COARSE_VOXELS,
+                     fine_voxels: int = BLURFACTORY_FINE_VOXELS, use_awp: bool = False):
+    """The argument namespace NeRFAll reads for mode='c2f' with the config's network sizes."""
+    from types import SimpleNamespace
+    return SimpleNamespace(mode="c2f", multires=10, multires_views=4, use_viewdirs=True, N_importance=N_importance,
+                           kernel_type="RBK", kernel_use_awp=use_awp, rgb_activate="sigmoid", sigma_activate="relu",
+                           bounding_box=BLURFACTORY_AABB, coarse_num_layers=2, coarse_num_layers_color=3, coarse_hidden_dim=64,
+                           coarse_hidden_dim_color=64, coarse_app_dim=32, coarse_app_n_comp=[64, 16, 16], coarse_n_voxels=coarse_voxels,
+                           kernel_feat_cnl=15, fine_num_layers=2, fine_num_layers_color=3, fine_hidden_dim=256,
+                           fine_hidden_dim_color=256, fine_geo_feat_dim=128, fine_app_dim=32, fine_app_n_comp=[64, 16, 16],
+                           fine_n_voxels=fine_voxels)
+
+
+def make_blurfactory_state_dict(seed: int = 31, coarse_voxels: int = BLURFACTORY_COARSE_VOXELS,
+                                fine_voxels: int = BLURFACTORY_FINE_VOXELS, sigma_gain: float = 1.0):
+    """Seed-derived parameters of both PDRF levels at the given voxel budgets (the full sizes: grids 293x293x195 and
+    586x586x390, 41 M floats).  ``sigma_gain`` scales the last sigma layer so that rays are not all transparent."""
+    lo, hi = BLURFACTORY_AABB
+    gc, gf = pdrf_grid_size(lo, hi, coarse_voxels), pdrf_grid_size(lo, hi, fine_voxels)
+    sd = OrderedDict(prefixed(make_pdrf_state_dict(seed, gc, input_ch=95, hidden_dim=64, geo_feat_dim=15), "mlp_coarse"))
+    sd.update(prefixed(make_pdrf_state_dict(seed + 1, gf, input_ch=127, hidden_dim=256, geo_feat_dim=128), "mlp_fine"))
+    if sigma_gain != 1.0:
+        for k in list(sd):
+            if k.endswith("sigma_net.1.weight"):
+                sd[k] = (sd[k] * np.float32(sigma_gain)).astype(np.float32)
+    return sd

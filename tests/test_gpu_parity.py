@@ -559,6 +559,23 @@ def test_full_frame_eval_path_psnr_parity(O):
         assert maxabs(got, ref) < linf and psnr(got, ref) > db
         sharded = model.render_path(Hh, Ww, K, 1 << 20, [torch.as_tensor(poses[0])], kw, shard_rows=True)[0]   # no process group: identity
         assert torch.equal(sharded[0], rgbs[0])
+        if prec == "f16x3":
+            # render(c2w=...) without rays generates the image's rays on the device; with rays, c2w is not read (renderer.py:423)
+            a = model.render(Hh, Ww, K, c2w=poses[0], **kw)[0]
+            assert a.shape == (Hh, Ww, 3) and torch.equal(a, rgbs[0])
+            o, d = O.get_rays(Hh, Ww, K, poses[1])
+            r1 = T(np.stack([o, d], -1))
+            assert torch.equal(model.render(Hh, Ww, K, rays=r1, c2w=poses[0], **kw)[0], rgbs[1])
+            # c2w_staticcam (renderer.py:427-430): camera 0's origins / directions, view directions of camera 1's rays
+            sc = model.render(Hh, Ww, K, rays=r1, c2w_staticcam=poses[0], **kw)[0]
+            o0, d0 = O.get_rays(Hh, Ww, K, poses[0])
+            rb = NeRFAll.ray_batch_train(Hh, Ww, K, T(np.stack([o0, d0], -1).reshape(-1, 3, 2)))
+            vd = r1.reshape(-1, 3, 2)[..., 1]
+            rb[:, 8:11] = vd / vd.norm(dim=-1, keepdim=True)
+            want = model.render_rays(rb, 24, N_importance=40)["rgb_map"].reshape(Hh, Ww, 3)
+            assert maxabs(N(sc), N(want)) < 2e-5
+            with pytest.raises(NotImplementedError):
+                model.render(Hh, Ww, K, rays=r1, use_viewdirs=False, N_samples=24)
 
 
 def test_compute_successor_bit_exact(O):
@@ -810,3 +827,55 @@ def test_event_loss_backward_matches_torch_autograd(cfg):
     for k, v in P.items():
         rel = float((got[k].double() - v.grad).norm() / max(float(v.grad.norm()), 1e-12))
         assert rel < 2e-4, (k, rel)
+
+
+def test_device_side_numerics_flags(capsys):
+    """renderer.py:259-263 (isnan / isinf per key, two host syncs each) as one launch into a device flag word per key
+    (evd_numerics_flags): exact against torch on arrays with planted NaN / Inf (aligned, unaligned, empty), through
+    render_rays without a sync (check_numerics="device"), and with the reference's printed messages (check_numerics=True)."""
+    from types import SimpleNamespace
+    from evdeblurnerf_amd.renderer import NeRFAll
+    sd = dict(W.prefixed(W.make_nerf_state_dict(11), "mlp_coarse"))
+    args = SimpleNamespace(mode="nerf", netdepth=8, netwidth=256, multires=10, multires_views=4, use_viewdirs=True,
+                           rgb_activate="sigmoid", sigma_activate="relu", N_importance=0)
+    model = NeRFAll(args, sd, precision="f16x3").eval()
+    rs = np.random.RandomState(0)
+    a = rs.standard_normal(100003).astype(np.float32)
+    b = a.copy(); b[77777] = np.nan
+    c = a.copy(); c[100002] = np.inf; c[5] = -np.inf
+    d = a.copy(); d[0] = np.nan; d[99] = np.inf
+    tens = [T(a), T(b), T(c), T(d), T(b)[1:], T(c)[100000:], torch.empty((0,), device=DEV), T(a)[3:50001]]
+    got = model.numerics_flags(tens).tolist()
+    want = [int(torch.isnan(t).any()) | 2 * int(torch.isinf(t).any()) for t in tens]
+    assert got == want == [0, 1, 2, 3, 1, 2, 0, 0]
+    rays = T(W.synthetic_rays(3, 200))
+    kw = dict(ndc=True, near=0., far=1., use_viewdirs=True, N_samples=32, N_importance=0, retraw=True)
+    ex = model.render(400, 400, W.synthetic_camera(), rays=rays, check_numerics="device", chunk=64, **kw)[3]
+    assert ex["numerics_flags"].is_cuda and ex["numerics_flags"].tolist() == [0] * len(ex["numerics_keys"])
+    assert {"rgb_map", "depth_map", "acc_map", "weights", "z_vals"} <= set(ex["numerics_keys"])
+    bad = dict(sd)
+    bad["mlp_coarse.rgb_linear.bias"] = np.array([np.nan, 0.0, 0.0], np.float32)
+    mb = NeRFAll(args, bad, precision="f32").eval()
+    ex = mb.render(400, 400, W.synthetic_camera(), rays=rays, check_numerics="device", **kw)[3]
+    flags = dict(zip(ex["numerics_keys"], ex["numerics_flags"].tolist()))
+    assert flags["rgb_map"] & 1 and flags["acc_map"] == 0 and flags["z_vals"] == 0
+    mb.render(400, 400, W.synthetic_camera(), rays=rays, check_numerics=True, **kw)
+    assert "! [Numerical Error] rgb_map contains nan." in capsys.readouterr().out
+
+
+def test_crf_init_identity():
+    """CRF.init_identity (tonemapping.py:29-57, `tone_mapping_learn_init_identity` of the shipped configs): after the 3000-step
+    pre-training the learnable CRF -- evaluated by the library's own kernel -- is close to the identity on (0, 1) with the extra
+    features at zero, deterministic for a seed, and its parameters round-trip through the handle."""
+    from evdeblurnerf_amd.tonemapping import TonemappingTransform
+    tm = TonemappingTransform("gamma", "learn", init_learn_identity=True, extra_features_event=2)
+    x = torch.rand((4096, 3), device=DEV) * 0.9 + 0.05
+    y = tm.tonemapping_event(x, x_feat=torch.zeros((4096, 2), device=DEV))
+    err = (y - x).abs()
+    print(f"CRF init_identity: mean |crf(x) - x| = {float(err.mean()):.4f}, max = {float(err.max()):.4f}")
+    assert float(err.mean()) < 0.01 and float(err.max()) < 0.05
+    sd1 = tm.tonemapping_event.identity_state_dict(2, 42, steps=50)
+    sd2 = tm.tonemapping_event.identity_state_dict(2, 42, steps=50)
+    assert all(np.array_equal(sd1[k], sd2[k]) for k in sd1) and set(sd1) == {f"linear.{i}.{k}" for i in (0, 2, 4, 6) for k in ("weight", "bias")}
+    with pytest.raises(Exception):
+        TonemappingTransform("gamma", "learn")               # neither parameters nor init_learn_identity

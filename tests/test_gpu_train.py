@@ -199,7 +199,7 @@ def test_render_rays_train_equals_inference_render_rays():
 
 
 def test_nerf_mode_training_iteration_reduces_the_image_loss():
-    """One full NeRF-mode iteration per step (run_nerf.py:1020-1036 without the blur/event terms): stratified + hierarchical
+    """One full NeRF-mode iteration per step (run_nerf.py:423-601 without the blur/event terms): stratified + hierarchical
     sampling with perturbation, both networks' fused forward/backward, compositing scan backward, Adam, device re-pack."""
     model, sd = _nerfall("f16", 32)
     model.train()
@@ -599,14 +599,28 @@ def test_forward_train_reaches_the_blur_kernel(mode):
 
 
 def test_module_surface_trains_like_the_reference_loop():
-    """enable_training / parameters() / model(...) / state_dict(): the calls a run_nerf.py-style loop makes."""
+    """enable_training / get_parameters / grad_vars / grad_vars_vol / model(...) / state_dict(): the calls a run_nerf.py-style loop
+    makes, with the reference's own optimizer groups (run_nerf.py:245-250, the colornet_weightdecay variant) and the exact key
+    set of its call site (render_kwargs_train, run_nerf.py:306-314,328-329 + :438-442: inference, retraw, force_naive,
+    return_pts0_rgb included)."""
     model, sd = _c2f_model("f16", 16)
     model.enable_training(sd).train()
-    opt = torch.optim.Adam(model.parameters(), lr=2e-3)
+    names = [k for k, _ in model.named_parameters()]
+    assert set(names) == set(sd) and len(names) == len(set(names))                  # one leaf per reference parameter
+    wd = model.get_parameters("net", match_re=r"\.color_net\.[0-9]+\.weight")
+    rest = model.get_parameters("net", not_match_re=r"\.color_net\.[0-9]+\.weight")
+    vol = model.grad_vars_vol
+    assert len(wd) == 6 and len(vol) == 12 and len(wd) + len(rest) + len(vol) == len(names)
+    assert {id(t) for t in vol} == {id(t) for t in model.get_parameters("vol")}
+    assert {id(t) for t in model.grad_vars} == {id(t) for t in wd + rest}
+    assert {id(t) for t in model.parameters()} == {id(t) for t in wd + rest + vol}
+    opt = torch.optim.Adam([{"params": wd, "lr": 2e-3, "weight_decay": 1e-4}, {"params": rest, "lr": 2e-3}, {"params": vol, "lr": 2e-3}])
     Kmat = W.synthetic_camera()
     rays = torch.tensor(W.synthetic_rays(4, 256), device="cuda")
     target = torch.full((256, 3), 0.3, device="cuda")
-    kwargs = dict(ndc=True, near=0., far=1., use_viewdirs=True, N_samples=16, N_importance=16, perturb=1.0, raw_noise_std=0., retraw=True)
+    render_kwargs_train = {"perturb": 1.0, "N_importance": 16, "N_samples": 16, "use_viewdirs": True, "white_bkgd": False,
+                           "raw_noise_std": 0., "inference": False, "near": 0., "far": 1.}
+    kwargs = dict(render_kwargs_train, retraw=True, force_naive=True, return_pts0_rgb=True)
     first = None
     for it in range(8):
         rgb, rgb0, other_loss, tensors = model(400, 400, Kmat, 1 << 20, rays=rays, **kwargs)
@@ -698,15 +712,14 @@ def test_c2f_training_gradients_against_the_reference_golden():
     assert abs(other["TV"].item() - float(g["tv"])) < 1e-4 * float(g["tv"])
     loss = (rgb * torch.tensor(g["w_rgb"], device="cuda")).sum() + (rgb0 * torch.tensor(g["w_rgb0"], device="cuda")).sum() + 0.1 * other["TV"].sum()
     loss.backward()
-    pc, pf = model._train_params
     got = {"rays": rays.grad}
-    for name, lvl, p in (("mlp_coarse", model.mlp_coarse, pc), ("mlp_fine", model.mlp_fine, pf)):
-        for k, v in lvl.unflatten(p["net"].grad).items():
-            got[f"{name}.{k}"] = v
-        for i in range(3):
-            got[f"{name}.app_plane.{i}"] = p["grids"][i].grad.permute(2, 0, 1).unsqueeze(0)                # reference layout [1,C,H,W]
-            got[f"{name}.app_line.{i}"] = p["grids"][3 + i].grad.t().unsqueeze(0).unsqueeze(-1)
-        got[f"{name}.basis_mat.weight"] = p["grids"][6].grad
+    for k, v in model.named_parameters():                 # one leaf per reference parameter; grids in the channel-last layout
+        if ".app_plane." in k:
+            got[k] = v.grad.permute(2, 0, 1).unsqueeze(0)                                                  # reference layout [1,C,H,W]
+        elif ".app_line." in k:
+            got[k] = v.grad.t().unsqueeze(0).unsqueeze(-1)
+        else:
+            got[k] = v.grad
     keys = [k[2:-8] for k in g if k.startswith("g.") and k.endswith(".summary")]
     assert set(keys) == set(got)
     worst = {}

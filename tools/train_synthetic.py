@@ -54,8 +54,8 @@ def main():
     teacher.eval()
     student, sd = make(202, a.coarse_voxels, a.fine_voxels, a.precision)
     student.enable_training(sd).train()
-    nets = [p["net"] for p in student._train_params]
-    grids = [g for p in student._train_params for g in p["grids"]]
+    nets = student.get_parameters("net", not_match_re=r"basis_mat")
+    grids = student.grad_vars_vol + student.get_parameters("net", match_re=r"basis_mat")
     opt = torch.optim.Adam([{"params": nets, "lr": 1e-3}, {"params": grids, "lr": 2e-2}])
     kw = dict(ndc=True, near=0., far=1., use_viewdirs=True, N_samples=64, N_importance=64, raw_noise_std=0.)
     held = torch.as_tensor(W.synthetic_rays(999, 4096), device="cuda")
