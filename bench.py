@@ -52,7 +52,7 @@ def parse(argv=None):
     ap.add_argument("--precision", default="f16", choices=["f16", "f16x3", "f32", "bf16"])
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--samples", type=int, default=128)
-    ap.add_argument("--train-iters", type=int, default=600, help="iterations of the in-run training that makes the 'trained' weights")
+    ap.add_argument("--train-iters", type=int, default=1000, help="iterations of the in-run training that makes the 'trained' weights")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-modes", action="store_true")
     ap.add_argument("--no-composite", action="store_true")

@@ -7,7 +7,7 @@ trained network has densities of tens to hundreds and saturated colours.  There 
 TRAINS one, with the library's own training path (forward keeping activations, hand-written backward, Adam, device re-pack),
 on an analytic scene in NDC space:
 
-    sigma(p)  = sum_j A_j exp(-|p - c_j|^2 / (2 s_j^2))          8 blobs, A_j in [30, 400]
+    sigma(p)  = sum_j A_j exp(-|p - c_j|^2 / (2 s_j^2))          16 blobs, A_j in [30, 400], s_j in [0.03, 0.15]
     colour(p) = 0.5 + 0.5 sin(F_j p + phi_j)  blended by the blobs' densities, tinted by the view direction
 
 rendered by the reference's compositing rule (nerf.py:74-129, through evd_raw2outputs) on the same stratified samples.
@@ -33,10 +33,10 @@ NERF_ARGS = dict(mode="nerf", netdepth=8, netwidth=256, multires=10, multires_vi
                  rgb_activate="sigmoid", sigma_activate="relu")
 
 
-def scene(seed=7, n_blobs=8, device="cuda"):
+def scene(seed=7, n_blobs=16, device="cuda", smin=0.03, smax=0.15):
     rs = np.random.RandomState(seed)
     t = lambda a: torch.as_tensor(np.asarray(a, np.float32), device=device)
-    return {"c": t(rs.uniform([-0.8, -0.8, -0.6], [0.8, 0.8, 0.9], (n_blobs, 3))), "s": t(rs.uniform(0.08, 0.3, n_blobs)),
+    return {"c": t(rs.uniform([-0.8, -0.8, -0.6], [0.8, 0.8, 0.9], (n_blobs, 3))), "s": t(rs.uniform(smin, smax, n_blobs)),
             "A": t(rs.uniform(30.0, 400.0, n_blobs)), "F": t(rs.uniform(-6.0, 6.0, (n_blobs, 3, 3))),
             "phi": t(rs.uniform(0, 6.28, (n_blobs, 3))), "tint": t(rs.uniform(-0.6, 0.6, (3, 3)))}
 
@@ -52,7 +52,7 @@ def scene_raw(sc, pts, viewdirs):
     return torch.cat([torch.log(col / (1 - col)), dens.sum(-1, keepdim=True)], -1).contiguous()
 
 
-def train_nerf(iters=600, rays_per_iter=4096, samples=128, seed=21, precision="f16", lr=5e-4, verbose=False):
+def train_nerf(iters=1000, rays_per_iter=4096, samples=128, seed=21, precision="f16", lr=5e-4, verbose=False):
     """-> (state dict with 'mlp_coarse.' keys, report dict).  Starts from the seed-derived parameters the bench uses."""
     from evdeblurnerf_amd.renderer import NeRFAll
     dev = "cuda"
@@ -98,7 +98,7 @@ def train_nerf(iters=600, rays_per_iter=4096, samples=128, seed=21, precision="f
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--iters", type=int, default=600)
+    ap.add_argument("--iters", type=int, default=1000)
     a = ap.parse_args()
     sd, rep = train_nerf(a.iters, verbose=True)
     print(rep)
