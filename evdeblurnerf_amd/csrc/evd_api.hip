@@ -29,6 +29,8 @@ int fail(int code, const char* fmt, ...) {
 
 int nerf_mlp_generic_dispatch(int prec, int W, const MlpParams& p, hipStream_t st);
 int nerf_mlp_pipe_dispatch(int prec, const MlpParams& p, hipStream_t st);
+int nerf_mlp_c_dispatch(int W, int D, int skip, const MlpParams& p, hipStream_t st);       // kernel_nerf_mlp.hip: compensated float16 mode
+int nerf_mlp_c_chunks(int W, int D, int skip);                                             // 0: not built for this network
 
 }  // namespace evd
 
@@ -127,6 +129,34 @@ int evd_nerf_create(const evd_nerf_desc* d, evd_nerf** out) {
     };
     int rc = EVD_OK;
     for (int prec = 0; prec < EVD_NUM_PREC && !rc; ++prec) {
+        if (prec == EVD_PREC_F16C) {      // compensated float16 mode: its own stream (float16 + fp6 fragments) and row scales; pipelined kernel only
+            n->nchunks[prec] = n->pipe_chunks[prec] = 0;
+            if (!nerf_mlp_c_chunks(W, D, d->skip)) continue;
+            StreamBuilderC sc(PIPE_CB);
+            const int KB = KS / 4;
+            sc.layer(pts_w(0), W, IC, T, PE_KS, 2, pe_col);
+            for (int l = 1; l < D; ++l) {
+                if (l - 1 == d->skip) {       // blocks [h_0 .. h_{KB-2} | pe | h_{KB-1}]
+                    auto wide_col = [&](int j, int kk) {
+                        if (j < 4 * (KB - 1)) return IC + hid_col(j, kk);
+                        if (j < 4 * (KB - 1) + PE_KS) return pe_col(j - 4 * (KB - 1), kk);
+                        return IC + hid_col(j - PE_KS, kk);
+                    };
+                    sc.layer(pts_w(l), W, W + IC, T, PE_KS + KS, 2, wide_col);
+                } else {
+                    sc.layer(pts_w(l), W, W, T, KS, 2, hid_col);
+                }
+            }
+            sc.layer(alpha_w, 1, W, 1, KS, 1, hid_col);
+            sc.layer(feature_w, W, W, T, KS, 2, hid_col);
+            sc.layer(views_w, W / 2, W + ICV, T / 2, KS + PEV_KS, 2, views_col);
+            sc.layer(rgb_w, 3, W / 2, 1, KS / 2, 1, hid_col);
+            n->pipe_chunks[prec] = (int)(sc.bytes.size() / PIPE_CB);
+            if (n->pipe_chunks[prec] != nerf_mlp_c_chunks(W, D, d->skip)) rc = fail(EVD_E_INVALID, "evd_nerf_create: f16c stream has %d chunks, kernel expects %d", n->pipe_chunks[prec], nerf_mlp_c_chunks(W, D, d->skip));
+            if (!rc) rc = n->pipe[prec].data.upload(sc.bytes.data(), sc.bytes.size());
+            if (!rc) rc = n->wscale_c.upload(sc.scales.data(), sc.scales.size() * sizeof(uint32_t));
+            continue;
+        }
         StreamBuilder sb(prec);
         sb.arena = A;
         build(sb, -1);
@@ -217,6 +247,7 @@ void evd_nerf_destroy(evd_nerf* n) {
     n->wmaps.release();
     n->bias.release();
     n->bias_src.release();
+    n->wscale_c.release();
     n->side.release();
     delete n;
 }
@@ -265,7 +296,15 @@ int evd_nerf_mlp(const evd_nerf* net, int precision, const float* ray_batch, con
     p.bias = (const float*)net->bias.p;
     p.ray_batch = ray_batch; p.z = z; p.nsamp = R * (long)S; p.S = S; p.ncol = 11;
     p.D = net->D; p.skip = net->skip; p.nchunks = piped ? net->pipe_chunks[precision] : net->nchunks[precision]; p.nbias = (int)(net->bias.bytes / sizeof(float));
-    p.raw = raw; p.feature = feature; p.feature_kind = feature ? feature_kind : 0; p.act = nullptr;
+    p.raw = raw; p.feature = feature; p.feature_kind = feature ? feature_kind : 0; p.act = nullptr; p.wscale = nullptr;
+    if (precision == EVD_PREC_F16C) {
+        EVD_REQUIRE(net->pipe_chunks[precision] > 0, "evd_nerf_mlp: EVD_PREC_F16C is built for netdepth 8, netwidth 256, skips [4] only");
+        EVD_REQUIRE(!feature, "evd_nerf_mlp: EVD_PREC_F16C has no feature-row variant (use EVD_PREC_F16X3)");
+        p.wstream = (const char*)net->pipe[precision].data.p;
+        p.nchunks = net->pipe_chunks[precision];
+        p.wscale = (const unsigned*)net->wscale_c.p;
+        return nerf_mlp_c_dispatch(net->W, net->D, net->skip, p, as_stream(stream));
+    }
     if (piped) return nerf_mlp_pipe_dispatch(precision, p, as_stream(stream));
     return nerf_mlp_generic_dispatch(precision, net->W, p, as_stream(stream));
 }

@@ -12,6 +12,9 @@
 #include <cstdint>
 #include <cstdlib>
 
+// the PDRF level networks are built for the first four arithmetic modes (EVD_PREC_F16C is a NeRF-MLP mode: evd_nerf_mlp)
+#define EVD_VOX_NUM_PREC EVD_PREC_F16C
+
 using namespace evd;
 
 struct evd_voxel {
@@ -19,11 +22,11 @@ struct evd_voxel {
     int n_comp[3], grid[3], app_act, rgb_act, sigma_act, composite_feature;
     float aabb[6], rmnear;
     DevBuf plane[3], line[3], plane_h[3], line_h[3], basis, bias, bias_src, tv_acc, wmaps;
-    PackedStream stream[EVD_NUM_PREC], pipe[EVD_NUM_PREC];    // pipe: stream of the software-pipelined kernel, where built
-    int nchunks[EVD_NUM_PREC], pipe_chunks[EVD_NUM_PREC];
+    PackedStream stream[EVD_VOX_NUM_PREC], pipe[EVD_VOX_NUM_PREC];    // pipe: stream of the software-pipelined kernel, where built
+    int nchunks[EVD_VOX_NUM_PREC], pipe_chunks[EVD_VOX_NUM_PREC];
     // training path (bf16 / f16): the level's network on the software pipeline (the fine level shares `pipe`) and its W^T streams
-    PackedStream train[EVD_NUM_PREC], bwd[EVD_NUM_PREC][VBWD_NSTREAMS];
-    int train_chunks[EVD_NUM_PREC];
+    PackedStream train[EVD_VOX_NUM_PREC], bwd[EVD_VOX_NUM_PREC][VBWD_NSTREAMS];
+    int train_chunks[EVD_VOX_NUM_PREC];
     long param_off[9];            // sigma_net.0, sigma_net.1, color_net.{0,1,2}.{weight,bias} in the parameter arena, [8] = total
     GridParams gp;
     mutable SideStream side;      // backward entry: wgrad side stream of THIS handle (created on first use)
@@ -36,7 +39,7 @@ extern "C" {
 void evd_voxel_destroy(evd_voxel* v) {
     if (!v) return;
     for (int i = 0; i < 3; ++i) { v->plane[i].release(); v->line[i].release(); v->plane_h[i].release(); v->line_h[i].release(); }
-    for (int i = 0; i < EVD_NUM_PREC; ++i) {
+    for (int i = 0; i < EVD_VOX_NUM_PREC; ++i) {
         v->stream[i].release(); v->pipe[i].release(); v->train[i].release();
         for (int k = 0; k < VBWD_NSTREAMS; ++k) v->bwd[i][k].release();
     }
@@ -164,7 +167,7 @@ int evd_voxel_create(const evd_voxel_desc* d, evd_voxel** out) {
         sb.layer(color_w1, HD, HD, T, KS, false, hid_col);
         sb.layer(color_w2, 3, HD, 1, KS, true, hid_col);
     };
-    for (int prec = 0; prec < EVD_NUM_PREC; ++prec) {
+    for (int prec = 0; prec < EVD_VOX_NUM_PREC; ++prec) {
         StreamBuilder sb(prec);
         sb.arena = A;
         build(sb);
@@ -308,7 +311,7 @@ int evd_voxel_forward(const evd_voxel* v, int precision, const float* pts, const
                       float* color, float* depth, float* acc, float* weights, float* feature,
                       void* workspace, size_t workspace_bytes, void* stream) {
     EVD_REQUIRE(v && pts && viewdirs && fts && z && rays_d, "evd_voxel_forward: null argument");
-    EVD_REQUIRE(precision >= 0 && precision < EVD_NUM_PREC, "evd_voxel_forward: unknown precision %d", precision);
+    EVD_REQUIRE(precision >= 0 && precision < EVD_VOX_NUM_PREC, "evd_voxel_forward: unknown precision %d", precision);
     EVD_REQUIRE(F == v->ft_dim, "evd_voxel_forward: fts has %d channels, this level takes %d", F, v->ft_dim);
     EVD_REQUIRE(weights, "evd_voxel_forward: the weights output is required");
     if (R == 0) return EVD_OK;
@@ -436,7 +439,7 @@ int evd_voxel_load_params(evd_voxel* v, const float* params, void* stream) {
     EVD_REQUIRE(v && params, "evd_voxel_load_params: null argument");
     hipStream_t st = as_stream(stream);
     int rc;
-    for (int i = 0; i < EVD_NUM_PREC; ++i) {
+    for (int i = 0; i < EVD_VOX_NUM_PREC; ++i) {
         if ((rc = repack_stream(v->stream[i], params, st)) || (rc = repack_stream(v->pipe[i], params, st)) || (rc = repack_stream(v->train[i], params, st))) return rc;
         for (int k = 0; k < VBWD_NSTREAMS; ++k)
             if ((rc = repack_stream(v->bwd[i][k], params, st))) return rc;
@@ -456,7 +459,7 @@ size_t evd_voxel_backward_workspace_bytes(void) { return (size_t)VOX_WGRAD_BLOCK
 int evd_voxel_mlp_train(const evd_voxel* v, int precision, const float* pts, const float* viewdirs, int vd_stride, const float* fts, int ft_stride,
                         long R, int S, float* raw, float* feature, void* store, size_t store_bytes, void* stream) {
     EVD_REQUIRE(v && pts && viewdirs && fts && raw && store, "evd_voxel_mlp_train: null argument");
-    EVD_REQUIRE(precision >= 0 && precision < EVD_NUM_PREC && vox_train_built(v, precision), "evd_voxel_mlp_train: the training path is built for precision f16 / bf16");
+    EVD_REQUIRE(precision >= 0 && precision < EVD_VOX_NUM_PREC && vox_train_built(v, precision), "evd_voxel_mlp_train: the training path is built for precision f16 / bf16");
     EVD_REQUIRE(R >= 0 && S >= 1 && ft_stride >= v->ft_dim && ft_stride % 4 == 0, "evd_voxel_mlp_train: bad shape");
     if (R == 0) return EVD_OK;
     const long nsamp = R * (long)S;
@@ -474,7 +477,7 @@ int evd_voxel_mlp_backward(const evd_voxel* v, int precision, const float* d_raw
                            float* d_pts, float* d_dirs, void* workspace, size_t workspace_bytes, void* stream) {
     EVD_REQUIRE((!d_pts || pts) && (!d_dirs || viewdirs), "evd_voxel_mlp_backward: d_pts / d_dirs need the forward's pts / viewdirs");
     EVD_REQUIRE(v && d_raw && raw && store && grads && workspace, "evd_voxel_mlp_backward: null argument");
-    EVD_REQUIRE(precision >= 0 && precision < EVD_NUM_PREC && vox_train_built(v, precision), "evd_voxel_mlp_backward: the training path is built for precision f16 / bf16");
+    EVD_REQUIRE(precision >= 0 && precision < EVD_VOX_NUM_PREC && vox_train_built(v, precision), "evd_voxel_mlp_backward: the training path is built for precision f16 / bf16");
     EVD_REQUIRE(R >= 0 && S >= 1 && (!d_fts || d_fts_stride >= v->ft_dim), "evd_voxel_mlp_backward: bad shape");
     if (R == 0) return EVD_OK;
     const long nsamp = R * (long)S;

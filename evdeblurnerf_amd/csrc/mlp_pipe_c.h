@@ -1,0 +1,416 @@
+// Software-pipelined fused-MLP machinery of the COMPENSATED float16 mode (EVD_PREC_F16C).
+//
+// Arithmetic.  Every linear layer is  D = W x  with
+//     W x  ~=  f16(W) f16(x)                       v_mfma_f32_32x32x16_f16, as in the float16 mode
+//           +  fp6(W - f16(W)) fp6(f16(x))         v_mfma_scale_f32_32x32x64_f8f6f4 (e2m3 operands, e8m0 block scales)
+//           +  fp6(W)          fp6(x - f16(x))     the same instruction
+// all three accumulating into the same float32 registers.  The float16 product carries the value, the two fp6 products remove the
+// rounding error of either operand down to the fp6 resolution of the RESIDUALS (2^-4 of 2^-11): operand error ~2^-15 instead of
+// 2^-11, for 1 + 2 x (1/4 the k-steps at 1.25x the rate) = 1.4x the matrix-pipe time of the float16 mode (the split-float16 mode,
+// three float16 products, costs 3x).  tools/experiments/precision_anatomy.py is the CPU emulation this design was chosen with:
+// RGB L-inf vs float64 on trained weights 2.9e-4 (f16) -> 7.6e-6 (this mode); tools/probes/mx_fp6_probe2.hip pins the hardware
+// semantics used here (operand k order of the two conversions, scale byte selection, rounding).
+//
+// Structure (differences to mlp_pipe.h, whose weight ring PStream is reused):
+//   * one wavefront per SIMD (256-thread workgroups, up to 512 registers per lane): a layer's input lives in registers three times
+//     (float16 fragments, fp6 of the values, fp6 of the residuals);
+//   * tile groups of TWO output tiles: the 2 x 16 float32 results a lane holds after a group are exactly one 32-value fp6 block of the
+//     next layer (k-steps 4b .. 4b+3).  The group's epilogue (ReLU, float16 convert, residual IN PLACE in the accumulator registers,
+//     running maximum for the block scale, then v_cvt_scalef32_pk32_fp6_f16 on the four new fragments and
+//     v_cvt_scalef32_2xpk16_fp6_f32 on the two accumulators) is issued between the MFMAs of the next group, also across layers;
+//   * the weight stream interleaves, per group and block, 4 x G float16 fragments with the G x 2 fp6 operands (24 bytes per lane each,
+//     stored as a 16-byte and an 8-byte part so that both are read with aligned ds_read_b128 / ds_read_b64): 7 G KiB per block;
+//     row scales (one e8m0 byte per weight row, layer and fp6 operand) sit next to the biases in LDS.
+#pragma once
+
+#include "mlp_pipe.h"
+
+namespace evd {
+
+// developer ablations (tools/ablate_c.sh compiles variants): 1 / 2 skip the first / second fp6 product, 4 drain every chunk end fully,
+// 8 no weight DMA, 16 no barrier, 32 no epilogue, 64 no float16 fragment reads, 128 no fp6 operand reads
+#ifdef EVD_C_ABL
+constexpr int kAbl = EVD_C_ABL;
+#else
+constexpr int kAbl = 0;
+#endif
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x6 __attribute__((ext_vector_type(6)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
+
+struct CCfg {
+    static constexpr int NT = 256, NW = 4, CB = PIPE_CB, FB = 1024, UPC = CB / 1024, NSLOT = 4, PIECES = CB / 1024 / NW;
+    static constexpr int SAMPLES = NW * 32;
+    static constexpr int RING = NSLOT * CB;
+    static constexpr int BIAS_WORDS = 5120;                  // biases (32 floats per tile) followed by the row-scale words (32 per tile)
+    static constexpr int STASH_ITEMS = 14;                   // per lane: point encoding 8 x 16 B, direction encoding 6 x 16 B (XStash)
+    static constexpr int STASH_PER_WAVE = STASH_ITEMS * 1024;
+    static constexpr int TOTAL = RING + BIAS_WORDS * 4 + NW * STASH_PER_WAVE;
+};
+
+// one k-block (4 k-steps = 64 input features) of a layer's input as a lane holds it
+struct XBlk {
+    u32x16 h;        // the four float16 B fragments
+    i32x8 qh, ql;    // fp6 (e2m3) of the float16 values / of the residuals x - f16(x); words 6, 7 unused
+    unsigned sc;     // byte 0: e8m0 scale of qh, byte 1: of ql
+};
+
+__device__ __forceinline__ f16x8 xblk_frag(const XBlk& x, int jj) {
+    u32x4 w;
+    w[0] = x.h[4 * jj]; w[1] = x.h[4 * jj + 1]; w[2] = x.h[4 * jj + 2]; w[3] = x.h[4 * jj + 3];
+    return __builtin_bit_cast(f16x8, w);
+}
+
+// running maximum of the float16 magnitudes of a block (as packed 16-bit integers: for non-negative halves integer order = float order)
+template <bool SIGNED> __device__ __forceinline__ unsigned c_max_acc(unsigned m, unsigned w) {
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    if (SIGNED) w &= 0x7fff7fffu;
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, m), __builtin_bit_cast(u16x2, w)));
+}
+
+// Block scales from the packed maximum: with E the exponent of the largest float16 magnitude, the values are divided by 2^(E-2)
+// (largest in [4, 8): the top of the e2m3 range, 7.5) and the residuals (|r| <= 2^(E-11)) by 2^(E-13).  The e8m0 byte of a scale is
+// the exponent field of the float32 the conversion instructions take.  Returns byte 0 = values, byte 1 = residuals.
+__device__ __forceinline__ unsigned c_scales(unsigned m) {
+    const unsigned ma = m & 0xffffu, mb = m >> 16;
+    const unsigned mm = ma > mb ? ma : mb;                        // max of the two halves
+    const unsigned e16 = (mm >> 10) & 31u;                        // biased float16 exponent (0 for zero / subnormal blocks)
+    const unsigned bh = e16 + 110u;                               // (e16 - 15) - 2 + 127
+    return bh | ((bh - 11u) << 8);
+}
+
+// finish a block: fp6 of the four float16 fragments and of the 2 x 16 residuals
+__device__ __forceinline__ void c_finish(XBlk& x, unsigned m, const f32x16& r0, const f32x16& r1) {
+    const unsigned sc = c_scales(m);
+    x.sc = sc;
+    const float sh = __builtin_bit_cast(float, (sc & 255u) << 23), sl = __builtin_bit_cast(float, ((sc >> 8) & 255u) << 23);
+    // inline asm with an EARLY-CLOBBER destination: these multi-pass conversions write their first result registers before they have
+    // read their last sources, and hipcc (builtin form) is free to overlap the two (it did: v[18:23] <- v[18:33], v[34:49] -- garbage)
+    i32x6 qh, ql;
+    asm("v_cvt_scalef32_pk32_fp6_f16 %0, %1, %2" : "=&v"(qh) : "v"(x.h), "v"(sh));
+    asm("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(ql) : "v"(r0), "v"(r1), "v"(sl));
+#pragma unroll
+    for (int e = 0; e < 6; ++e) { x.qh[e] = qh[e]; x.ql[e] = ql[e]; }
+    x.qh[6] = x.qh[7] = x.ql[6] = x.ql[7] = 0;
+}
+
+// one epilogue unit: accumulator values 2k, 2k+1 of a tile -> ReLU, float16 pair into the block, residuals in place
+template <bool RELU>
+__device__ __forceinline__ void c_drain_pair(f32x16& a, int k, XBlk& x, int word, unsigned& m) {
+    float x0 = a[2 * k], x1 = a[2 * k + 1];
+    if (RELU) { x0 = relu_f32(x0); x1 = relu_f32(x1); }
+    const f32x2 v = {x0, x1};
+    const f16x2 hv = __builtin_convertvector(v, f16x2);           // MODE.FP16_OVFL: saturates at +-65504
+    const unsigned w = __builtin_bit_cast(unsigned, hv);
+    x.h[word] = w;
+    m = c_max_acc<!RELU>(m, w);
+    float r0, r1;                                                  // x - float(f16(x)): v_fma_mix_f32 reads the half straight from the pair
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(w), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(w), "v"(x1));
+    a[2 * k] = r0;
+    a[2 * k + 1] = r1;
+}
+
+// Static description of one layer.
+//   NBLK    k-blocks of the input; LASTK k-steps of the last one (4, or 2: the direction-encoding block of the views layer)
+//   TILES   32-row output tiles in groups of G (2; 1 for the float32 heads)        RELU / F32OUT as in mlp_pipe.h
+//   CHUNK0  first chunk of the layer (every layer is chunk-aligned)               PAR  accumulator set of the first group
+//   PG      tiles of the pending group handed over by the previous layer (0 / 2); PRELU its activation; PDB the input block it becomes
+//   NEXT_G  group size of the next layer (0: last layer)                          NCHUNKS chunks of this layer
+template <int NBLK_, int LASTK_, int TILES_, int G_, bool RELU_, bool F32OUT_, int CHUNK0_, int PAR_, int PG_, bool PRELU_, int PDB_, int NEXT_G_>
+struct CLayer {
+    static constexpr int NBLK = NBLK_, LASTK = LASTK_, TILES = TILES_, G = G_, CHUNK0 = CHUNK0_, PAR = PAR_, PG = PG_, PDB = PDB_, NEXT_G = NEXT_G_;
+    static constexpr bool RELU = RELU_, F32OUT = F32OUT_, PRELU = PRELU_;
+    static constexpr int NG = TILES_ / G_;
+    static constexpr int KSTEPS = 4 * (NBLK_ - 1) + LASTK_;
+    static constexpr int nk(int b) { return b == NBLK_ - 1 ? LASTK_ : 4; }
+    static constexpr int blk_units(int b) { return nk(b) * G_ + 3 * G_; }                  // 1 KiB units of block b of one group
+    static constexpr int blk_slots(int b) { return nk(b) * G_ + 2 * G_; }                  // MFMAs
+    static constexpr int GROUP_UNITS = (NBLK_ - 1) * (4 * G_ + 3 * G_) + LASTK_ * G_ + 3 * G_;
+    static constexpr int GROUP_SLOTS = (NBLK_ - 1) * (4 * G_ + 2 * G_) + LASTK_ * G_ + 2 * G_;
+    static constexpr int UNITS = NG * GROUP_UNITS;
+    static constexpr int NCHUNKS = cceil(UNITS, CCfg::UPC);
+    static constexpr int PAR_OUT = (PAR_ + NG) & 1;
+    // unit (from the layer start) of float16 fragment mi of group p = the count of units consumed when its MFMA slot starts
+    static constexpr int main_pos(int p, int mi) { return p * GROUP_UNITS + (mi / (4 * G_)) * 7 * G_ + mi % (4 * G_); }
+    static constexpr int NMAIN = KSTEPS * TILES_;
+    static_assert(TILES_ % G_ == 0 && (G_ == 1 || G_ == 2), "groups of one or two tiles");
+    static_assert(NMAIN % 4 == 0, "the float16 fragment ring keeps its phase across layers");
+    static_assert(UNITS % CCfg::UPC == 0 || UNITS % CCfg::UPC >= 2, "a layer's last chunk must reach its chunk_begin");
+};
+
+// register state that flows from layer to layer
+struct CPipe {
+    f16x8 am[4];             // ring of prefetched float16 A fragments
+    i32x8 ac[2][2];          // fp6 A operands of the current block: [kind][tile of the group]
+    f32x16 acc[2][2];        // two accumulator sets of up to two tiles
+    unsigned wsc[2][2];      // row-scale words of the tiles in acc[set][t]
+    unsigned m;              // running maximum of the block being drained
+};
+
+// byte offset of unit u of a layer (units count from the layer's first chunk) inside the ring, for this lane's rd_base
+template <class L> __device__ __forceinline__ constexpr int c_ring_off(int u) { return ((L::CHUNK0 + u / CCfg::UPC) & 3) * CCfg::CB + (u % CCfg::UPC) * 1024; }
+
+// One tile group P of layer L.  in[]: input blocks; the pending group of the previous layer is drained into in[L::PDB]; this layer's
+// groups are drained into out[p].  bias: LDS bias block of this layer (tile-major, 32 floats per tile) with the row-scale words
+// SC_OFF words behind it.  NXT: the next layer (for the prefetch across the layer boundary), void for the last.
+template <class L, class NXT, class ST, int NIN, int NOUT, int P>
+__device__ __forceinline__ void c_group(ST& st, CPipe& pp, XBlk (&in)[NIN], XBlk (&out)[NOUT], const float* __restrict__ bias, int lane) {
+    constexpr int G = L::G, NS = L::GROUP_SLOTS;
+    constexpr int cur = (L::PAR + P) & 1, oth = cur ^ 1;
+    constexpr bool FIRST = P == 0, LAST = P == L::NG - 1;
+    constexpr int DG = FIRST ? L::PG : G;                       // tiles to drain
+    constexpr int QU = DG > 0 ? DG * 8 + 1 : 0;                 // pair units + the finishing unit
+    constexpr int s_dep = (FIRST && L::PG > 0) ? L::PDB * (4 * G + 2 * G) : NS;     // first slot that needs the drained block
+    constexpr int dend = cmin(s_dep, NS / 2 + 2);
+    constexpr bool drain_first = QU > 0 && dend - 2 < 1;
+    constexpr int drate = (QU > 0 && !drain_first) ? cceil(QU, dend - 2) : (drain_first ? QU : 0);
+    constexpr int BG = LAST ? L::NEXT_G : G;                    // tiles whose bias / scales are fetched for the next group
+    constexpr int NBL = BG * 5;                                 // 4 bias reads + 1 scale word per tile
+    constexpr int b0 = cmin(cmax(drain_first ? 0 : dend - 1, NS / 2), NS - 1);
+    constexpr int brate = NBL > 0 ? cceil(NBL, NS - b0) : 0;
+    auto units_thru = [](int s) constexpr { return (QU == 0 || s < 0) ? 0 : (drain_first ? QU : (s < 2 ? 0 : cmin(QU, (s - 1) * drate))); };
+    auto bias_thru = [](int s) constexpr { return (NBL == 0 || s <= b0) ? 0 : (s >= NS ? NBL : cmin(NBL, (s - b0) * brate)); };
+    const int h = lane >> 5;
+    const float* bias_next = bias + (LAST ? L::TILES : (P + 1) * G) * 32;
+    constexpr int SC_OFF = CCfg::BIAS_WORDS / 2;
+    constexpr int ubase = P * L::GROUP_UNITS;                   // first unit of this group
+    constexpr int mbase = P * L::KSTEPS * G;                    // first float16 MFMA of this group (ring phase)
+
+    // one filler step: everything that is issued in front of MFMA slot s
+    auto filler = [&](int s) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < drate; ++i) {
+            const int u = units_thru(s - 1) + i;
+            if (u < units_thru(s) && !(kAbl & 32)) {
+                XBlk& dst = FIRST ? in[L::PDB] : out[P > 0 ? P - 1 : 0];
+                if (u < DG * 8) {
+                    const int dt = u / 8, k = u % 8;
+                    if (u == 0) pp.m = 0u;
+                    if (FIRST) c_drain_pair<L::PRELU>(pp.acc[oth][dt], k, dst, 8 * dt + k, pp.m);
+                    else c_drain_pair<L::RELU>(pp.acc[oth][dt], k, dst, 8 * dt + k, pp.m);
+                } else {
+                    c_finish(dst, pp.m, pp.acc[oth][0], pp.acc[oth][1]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < brate; ++i) {
+            const int b = bias_thru(s - 1) + i;
+            if (b < bias_thru(s)) {
+                const int bt = b / 5, q = b % 5;
+                if (q < 4) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_next + bt * 32 + 8 * q + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pp.acc[oth][bt][4 * q + e] = bv[e];
+                } else {
+                    pp.wsc[oth][bt] = reinterpret_cast<const unsigned*>(bias_next)[SC_OFF + bt * 32 + (lane & 31)];
+                }
+            }
+        }
+    };
+    // chunk protocol after a slot that raised the count of consumed units from t0 to t1
+    auto chunks = [&](int t0, int t1) __attribute__((always_inline)) {
+        if (t0 / CCfg::UPC != t1 / CCfg::UPC || (t0 % CCfg::UPC < 2 && t1 % CCfg::UPC >= 2)) {
+            if (t0 % CCfg::UPC < 2 && t1 % CCfg::UPC >= 2 && t0 / CCfg::UPC == t1 / CCfg::UPC && !(kAbl & 8)) st.chunk_begin(L::CHUNK0 + t1 / CCfg::UPC);
+            if (t0 / CCfg::UPC != t1 / CCfg::UPC) {
+                if (kAbl & 4) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+                if (!(kAbl & 16)) st.chunk_end(L::CHUNK0 + t0 / CCfg::UPC);
+                if (t1 % CCfg::UPC >= 2 && !(kAbl & 8)) st.chunk_begin(L::CHUNK0 + t1 / CCfg::UPC);
+            }
+        }
+    };
+
+    int s = 0, ub = ubase, mm = mbase;      // all three are compile-time constants after unrolling
+#pragma unroll
+    for (int b = 0; b < L::NBLK; ++b) {
+        const int nk = L::nk(b);
+        const int lo16 = ub + nk * G, hi8 = lo16 + 2 * G;        // unit offsets of the fp6 parts of this block
+        const int ncl = 4 * G;                                  // fp6 part loads of this block: (kind, tile) x (16-byte, 8-byte part)
+        const int per_slot = cceil(ncl, nk * G);
+#pragma unroll
+        for (int jj = 0; jj < nk; ++jj) {
+#pragma unroll
+            for (int t = 0; t < G; ++t) {
+                const int i = jj * G + t;                       // main slot inside the block
+                filler(s);
+                {   // float16 fragment of the main MFMA three ahead (possibly in the next block, group or layer)
+                    const int idx = mm + 3 - mbase;             // main index inside this group
+                    int u = -1, ringoff = 0;
+                    if (idx < L::KSTEPS * G) {                  // same group: block b2 = idx / (4 G) (all blocks before the last are full)
+                        const int b2 = idx / (4 * G), i2 = idx % (4 * G);
+                        u = ubase + b2 * 7 * G + i2;
+                        ringoff = c_ring_off<L>(u);
+                    } else if (!LAST) {
+                        u = ubase + L::GROUP_UNITS + (idx - L::KSTEPS * G);
+                        ringoff = c_ring_off<L>(u);
+                    } else if constexpr (!std::is_void<NXT>::value) {
+                        // the next layer starts in the chunk behind this layer's last one, which is resident only once that last
+                        // chunk is the current one; fragments wanted earlier are fetched by c_layer after the layer's last barrier
+                        if ((ub + i) / CCfg::UPC >= L::NCHUNKS - 1) {
+                            u = idx - L::KSTEPS * G;
+                            ringoff = c_ring_off<NXT>(u);
+                        }
+                    }
+                    if (u >= 0 && !(kAbl & 64)) pp.am[(mm + 3) & 3] = *reinterpret_cast<const f16x8*>(st.rd_base + ringoff);
+                }
+#pragma unroll
+                for (int q = 0; q < per_slot; ++q) {            // fp6 parts of this block, consumed by its last 2 G slots
+                    const int c = i * per_slot + q;
+                    if (c < ncl && !(kAbl & 128)) {
+                        const int kt = c >> 1, part = c & 1;    // kt = kind * G + tile
+                        const int kind = kt / G, tt = kt % G;
+                        if (part == 0) {
+                            const u32x4 w = *reinterpret_cast<const u32x4*>(st.rd_base + c_ring_off<L>(lo16 + kt));
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) pp.ac[kind][tt][e] = (int)w[e];
+                        } else {
+                            const int uo = hi8 + kt / 2;
+                            const u32x2 w = *reinterpret_cast<const u32x2*>(st.rd_base + c_ring_off<L>(uo) - 8 * lane + (kt & 1) * 512);
+                            pp.ac[kind][tt][4] = (int)w[0];
+                            pp.ac[kind][tt][5] = (int)w[1];
+                            pp.ac[kind][tt][6] = 0;
+                            pp.ac[kind][tt][7] = 0;
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                pp.acc[cur][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pp.am[mm & 3], xblk_frag(in[b], jj), pp.acc[cur][t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                chunks(ub + i, ub + i + 1);
+                ++s;
+                ++mm;
+            }
+        }
+#pragma unroll
+        for (int kind = 0; kind < 2; ++kind) {
+#pragma unroll
+            for (int t = 0; t < G; ++t) {
+                const int i = kind * G + t;
+                filler(s);
+                __builtin_amdgcn_sched_barrier(0);
+                // kind 0: fp6(Wl) x fp6(f16(x)), scale bytes 0 / 0; kind 1: fp6(W) x fp6(x - f16(x)), scale bytes 1 / 1
+                if (kind == 0 && (kAbl & 1)) {}
+                else if (kind == 1 && (kAbl & 2)) {}
+                else if (kind == 0)
+                    pp.acc[cur][t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(pp.ac[0][t], in[b].qh, pp.acc[cur][t], 2, 2, 0, (int)pp.wsc[cur][t], 0, (int)in[b].sc);
+                else
+                    pp.acc[cur][t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(pp.ac[1][t], in[b].ql, pp.acc[cur][t], 2, 2, 1, (int)pp.wsc[cur][t], 1, (int)in[b].sc);
+                __builtin_amdgcn_sched_barrier(0);
+                const int last = 2 * G - 1;
+                chunks(lo16 + i, i == last ? hi8 + G : lo16 + i + 1);
+                ++s;
+            }
+        }
+        ub = hi8 + G;
+    }
+#pragma unroll
+    for (int i = 0; i < NBL; ++i) {                             // bias rows that did not fit between the MFMAs
+        const int bq = bias_thru(NS - 1) + i;
+        if (bq < NBL) {
+            const int bt = bq / 5, q = bq % 5;
+            if (q < 4) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_next + bt * 32 + 8 * q + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pp.acc[oth][bt][4 * q + e] = bv[e];
+            } else {
+                pp.wsc[oth][bt] = reinterpret_cast<const unsigned*>(bias_next)[SC_OFF + bt * 32 + (lane & 31)];
+            }
+        }
+    }
+}
+
+template <class L, class NXT, class ST, int NIN, int NOUT, int P> struct CGroupLoop {
+    static __device__ __forceinline__ void run(ST& st, CPipe& pp, XBlk (&in)[NIN], XBlk (&out)[NOUT], const float* __restrict__ bias, int lane) {
+        c_group<L, NXT, ST, NIN, NOUT, P>(st, pp, in, out, bias, lane);
+        if constexpr (P + 1 < L::NG) CGroupLoop<L, NXT, ST, NIN, NOUT, P + 1>::run(st, pp, in, out, bias, lane);
+    }
+};
+
+// One linear layer on the wavefront's 32 samples.  `out` receives the blocks of every group but the last, which stays pending in the
+// accumulators (F32OUT: rows 0..3 of the single tile are returned in out_f32).
+template <class L, class NXT, class ST, int NIN, int NOUT>
+__device__ __forceinline__ void c_layer(ST& st, CPipe& pp, XBlk (&in)[NIN], XBlk (&out)[NOUT], float* out_f32, const float* __restrict__ bias, int lane) {
+    static_assert(NIN >= L::NBLK, "input blocks");
+    CGroupLoop<L, NXT, ST, NIN, NOUT, 0>::run(st, pp, in, out, bias, lane);
+    if (L::UNITS % CCfg::UPC != 0) st.chunk_end(L::CHUNK0 + L::UNITS / CCfg::UPC);      // the zero-padded tail of the layer's last chunk
+    if constexpr (!std::is_void<NXT>::value) {       // first fragments of the next layer that the last group could not prefetch (c_group)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (L::main_pos(L::NG - 1, L::KSTEPS * L::G - 3 + k) / CCfg::UPC < L::NCHUNKS - 1)
+                pp.am[k] = *reinterpret_cast<const f16x8*>(st.rd_base + c_ring_off<NXT>(k));
+    }
+    if (L::F32OUT) {
+        constexpr int cur = (L::PAR + L::NG - 1) & 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            out_f32[r] = pp.acc[cur][0][r];
+            asm volatile("" : "+v"(out_f32[r]));       // pin (mlp_pipe.h): else hipcc sinks the head's MFMA chain to the end of the kernel
+        }
+    }
+}
+
+// prologue: first three float16 fragments of the first layer, bias and row scales of its first group
+template <class L, class ST> __device__ __forceinline__ void c_prime(ST& st, CPipe& pp, const float* __restrict__ bias, int lane) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pp.am[i] = *reinterpret_cast<const f16x8*>(st.rd_base + c_ring_off<L>(i));
+#pragma unroll
+    for (int t = 0; t < L::G; ++t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + t * 32 + 8 * q + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pp.acc[L::PAR][t][4 * q + e] = bv[e];
+        }
+        pp.wsc[L::PAR][t] = reinterpret_cast<const unsigned*>(bias)[CCfg::BIAS_WORDS / 2 + t * 32 + (lane & 31)];
+    }
+    pp.m = 0u;
+}
+
+// sin(2 pi t) / cos(2 pi t) of the revolution count t = (frac + lo): v_sin_f32 takes revolutions
+__device__ __forceinline__ float c_sin_rev(float thi, float tlo, float scale, int h) {
+    // 2^k t: the product with the high part and its fract are exact; the low part rides along
+    const float f = __builtin_amdgcn_fractf(thi * scale);
+    return __builtin_amdgcn_sinf(fmaf(tlo, scale, f + (h ? 0.25f : 0.f)));
+}
+
+// positional encoding of a 3-vector as one input block (arrangement of nerf_mlp.h: position q = 8 j + e of lane half h), all three
+// representations.  KSN = 4 (point encoding) or 2 (direction encoding: the upper half of the block is zero).
+template <int L, int KSN> __device__ __forceinline__ void c_encode(const float (&x)[3], int h, XBlk& out) {
+    float thi[3], tlo[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {      // x / 2 pi in two floats
+        thi[c] = x[c] * 0.15915494309189535f;                                                  // the float nearest 1 / 2 pi ...
+        tlo[c] = fmaf(x[c], 0.15915494309189535f, -thi[c]) + x[c] * 6.4206383e-09f;            // ... is 6.42e-9 below it
+    }
+    f32x16 r[2];
+    unsigned m = 0u;
+#pragma unroll
+    for (int q = 0; q < 32; q += 2) {
+        float y[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int qq = q + i;
+            if (qq >= KSN * 8) y[i] = 0.f;
+            else if (qq < 3 * L) y[i] = c_sin_rev(thi[qq % 3], tlo[qq % 3], (float)(1 << (qq / 3)), h);
+            else if (qq == 3 * L) y[i] = h ? x[1] : x[0];
+            else if (qq == 3 * L + 1) y[i] = h ? 0.f : x[2];
+            else y[i] = 0.f;
+        }
+        r[q >> 4][q & 15] = y[0];
+        r[q >> 4][(q & 15) + 1] = y[1];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {       // "tile" t = k / 8 holds k-steps 2t, 2t+1: the same unit as the layers' epilogue
+        const int t = k >> 3, kk = k & 7;
+        c_drain_pair<false>(r[t], kk, out, 8 * t + kk, m);
+    }
+    c_finish(out, m, r[0], r[1]);
+}
+
+}  // namespace evd

@@ -57,6 +57,7 @@ struct MlpParams {
     float* feature;         // [R, S, W] or null
     int feature_kind;       // 0 none, 1 after_linear, 2 before_linear
     char* act;              // training kernels: activation store (act_tile_bytes per 32-sample tile), else null
+    const unsigned* wscale; // compensated float16 mode: row-scale words, 32 per output tile in bias order (pack.h StreamBuilderC), else null
 };
 
 // Activation / gradient store of the training path, in 1 KiB fragments per 32-sample tile (W = 256, D = 8):

@@ -1,0 +1,221 @@
+// Fused NeRF backbone in the compensated float16 mode (EVD_PREC_F16C): pts = o + d z -> positional encodings -> 8 x 256 MLP (skip +
+// view branch) -> raw.  reference: networks/nerf.py:46-72 (mlpforward), :131-162 (eval), networks/embedding.py:88-98, renderer.py:180.
+// Machinery and arithmetic: mlp_pipe_c.h.  Built for the reference network (netdepth 8, netwidth 256, skips [4]); no feature rows,
+// no training variant (those run in the other modes).
+#pragma once
+
+#include "mlp_pipe_c.h"
+
+namespace evd {
+
+// static layer table: width W (T tiles, KB k-blocks), depth D, skip index SKIP
+template <int W, int D, int SKIP> struct NerfNetC {
+    static constexpr int T = W / 32, KB = W / 64;
+    static_assert(PE_KS == 4 && PEV_KS == 2 && T % 2 == 0 && KB >= 2, "block structure of the encodings and the hidden width");
+    static constexpr bool is_wide(int l) { return l - 1 == SKIP; }
+    typedef CLayer<1, 4, T, 2, true, false, 0, 0, 0, false, 0, 2> L0;
+    static constexpr int CH_HID = CLayer<KB, 4, T, 2, true, false, 0, 0, 2, true, KB - 1, 2>::NCHUNKS;
+    static constexpr int CH_WIDE = CLayer<KB + 1, 4, T, 2, true, false, 0, 0, 2, true, KB, 2>::NCHUNKS;
+    static constexpr int chunk0(int l) {                           // first chunk of hidden layer l (l == D: the heads)
+        int c = L0::NCHUNKS;
+        for (int i = 1; i < l; ++i) c += is_wide(i) ? CH_WIDE : CH_HID;
+        return c;
+    }
+    static constexpr int PARH = L0::PAR_OUT;                       // T / 2 groups per hidden layer: the parity is kept when T / 2 is even
+    static_assert((T / 2) % 2 == 0, "accumulator parity");
+    // hidden layer l (1 .. D-1); the skip layer's blocks are [h_0 .. h_{KB-2} | pe | h_{KB-1}]
+    template <int l> using Hidden = std::conditional_t<is_wide(l),
+        CLayer<KB + 1, 4, T, 2, true, false, chunk0(l), PARH, 2, true, KB, l == D - 1 ? 1 : 2>,
+        CLayer<KB, 4, T, 2, true, false, chunk0(l), PARH, 2, true, KB - 1, l == D - 1 ? 1 : 2>>;
+    // heads (nerf.py:144-157): alpha_linear, feature_linear, views_linears.0 on cat([feature, PE(dir)]), rgb_linear
+    typedef CLayer<KB, 4, 1, 1, false, true, chunk0(D), PARH, 2, true, KB - 1, 2> Alpha;
+    typedef CLayer<KB, 4, T, 2, false, false, Alpha::CHUNK0 + Alpha::NCHUNKS, Alpha::PAR_OUT, 0, false, 0, 2> Feature;
+    typedef CLayer<KB + 1, 2, T / 2, 2, true, false, Feature::CHUNK0 + Feature::NCHUNKS, Feature::PAR_OUT, 2, false, KB - 1, 1> Views;
+    typedef CLayer<KB / 2, 4, 1, 1, false, true, Views::CHUNK0 + Views::NCHUNKS, Views::PAR_OUT, 2, true, KB / 2 - 1, 0> Rgb;
+    static constexpr int NCH = Rgb::CHUNK0 + Rgb::NCHUNKS;
+    static constexpr int NTILES = D * T + 1 + T + T / 2 + 1;
+    static_assert(D >= 2 && NTILES * 32 <= CCfg::BIAS_WORDS / 2, "bias / row-scale block");
+};
+
+// an input block <-> this lane's slots of the wavefront's LDS stash (items of 16 bytes per lane, 1 KiB apart)
+template <int KSN> __device__ __forceinline__ void c_stash_put(char* base, const XBlk& x) {
+#pragma unroll
+    for (int j = 0; j < KSN; ++j) {
+        const u32x4 w = {x.h[4 * j], x.h[4 * j + 1], x.h[4 * j + 2], x.h[4 * j + 3]};
+        *reinterpret_cast<u32x4*>(base + j * 1024) = w;
+    }
+    const u32x4 a = {(unsigned)x.qh[0], (unsigned)x.qh[1], (unsigned)x.qh[2], (unsigned)x.qh[3]};
+    const u32x4 b = {(unsigned)x.qh[4], (unsigned)x.qh[5], (unsigned)x.ql[0], (unsigned)x.ql[1]};
+    const u32x4 c = {(unsigned)x.ql[2], (unsigned)x.ql[3], (unsigned)x.ql[4], (unsigned)x.ql[5]};
+    *reinterpret_cast<u32x4*>(base + (KSN + 0) * 1024) = a;
+    *reinterpret_cast<u32x4*>(base + (KSN + 1) * 1024) = b;
+    *reinterpret_cast<u32x4*>(base + (KSN + 2) * 1024) = c;
+    *reinterpret_cast<unsigned*>(base + (KSN + 3) * 1024) = x.sc;
+}
+template <int KSN> __device__ __forceinline__ void c_stash_get(const char* base, XBlk& x) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        u32x4 w = {0u, 0u, 0u, 0u};
+        if (j < KSN) w = *reinterpret_cast<const u32x4*>(base + j * 1024);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x.h[4 * j + e] = w[e];
+    }
+    const u32x4 a = *reinterpret_cast<const u32x4*>(base + (KSN + 0) * 1024);
+    const u32x4 b = *reinterpret_cast<const u32x4*>(base + (KSN + 1) * 1024);
+    const u32x4 c = *reinterpret_cast<const u32x4*>(base + (KSN + 2) * 1024);
+    x.qh[0] = (int)a[0]; x.qh[1] = (int)a[1]; x.qh[2] = (int)a[2]; x.qh[3] = (int)a[3]; x.qh[4] = (int)b[0]; x.qh[5] = (int)b[1];
+    x.ql[0] = (int)b[2]; x.ql[1] = (int)b[3]; x.ql[2] = (int)c[0]; x.ql[3] = (int)c[1]; x.ql[4] = (int)c[2]; x.ql[5] = (int)c[3];
+    x.qh[6] = x.qh[7] = x.ql[6] = x.ql[7] = 0;
+    x.sc = *reinterpret_cast<const unsigned*>(base + (KSN + 3) * 1024);
+}
+
+template <class N, class ST> struct NerfCtxC {
+    ST st;
+    CPipe pp;
+    XBlk buf[2][N::KB];             // activations ping-pong: layer l writes buf[l & 1]
+    const char* stash;              // this lane's slot of the wavefront's positional-encoding stash
+    const float* bias;              // LDS bias block
+    int lane;
+};
+
+template <class N, class ST, int l, int D> struct HiddenLoopC {
+    static __device__ __forceinline__ void run(NerfCtxC<N, ST>& cx) {
+        typedef typename N::template Hidden<l> L;
+        constexpr int KB = N::KB, T = N::T;
+        const float* lb = cx.bias + l * T * 32;
+        if constexpr (l + 1 < D) {
+            typedef typename N::template Hidden<l + 1> NX;
+            step<L, NX>(cx, lb);
+            HiddenLoopC<N, ST, l + 1, D>::run(cx);
+        } else {
+            step<L, typename N::Alpha>(cx, lb);
+        }
+    }
+    template <class L, class NX> static __device__ __forceinline__ void step(NerfCtxC<N, ST>& cx, const float* lb) {
+        constexpr int KB = N::KB;
+        if constexpr (N::is_wide(l)) {
+            XBlk wide[KB + 1];
+            const char* sp = cx.stash;
+            asm volatile("" : "+v"(sp));    // opaque: the stash is re-read here, not kept in registers since layer 0
+#pragma unroll
+            for (int j = 0; j < KB - 1; ++j) wide[j] = cx.buf[(l - 1) & 1][j];
+            c_stash_get<PE_KS>(sp, wide[KB - 1]);
+            c_layer<L, NX, ST, KB + 1, KB>(cx.st, cx.pp, wide, cx.buf[l & 1], nullptr, lb, cx.lane);
+        } else {
+            c_layer<L, NX, ST, KB, KB>(cx.st, cx.pp, cx.buf[(l - 1) & 1], cx.buf[l & 1], nullptr, lb, cx.lane);
+        }
+    }
+};
+
+template <int W, int D, int SKIP>
+__global__ __launch_bounds__(CCfg::NT, 1) void k_nerf_mlp_c(const MlpParams p) {
+    typedef NerfNetC<W, D, SKIP> N;
+    typedef PStream<CCfg, false, N::NCH> ST;
+    constexpr int T = N::T, KB = N::KB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    pipe_fp16_saturate<EVD_PREC_F16>();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, h = lane >> 5;
+    NerfCtxC<N, ST> cx;
+    cx.st.start_issue(p.wstream, smem, tid);
+    float* bias = reinterpret_cast<float*>(smem + CCfg::RING);
+    {   // biases and row-scale words -> LDS
+        constexpr int NB = (CCfg::BIAS_WORDS / 2 / 4 + CCfg::NT - 1) / CCfg::NT;
+        f32x4 bv[NB];
+        u32x4 sv[NB];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int i = (tid + q * CCfg::NT) * 4;
+            bv[q] = i < p.nbias ? *reinterpret_cast<const f32x4*>(p.bias + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+            sv[q] = i < p.nbias ? *reinterpret_cast<const u32x4*>(p.wscale + i) : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int i = (tid + q * CCfg::NT) * 4;
+            if (i < p.nbias) {
+                *reinterpret_cast<f32x4*>(bias + i) = bv[q];
+                *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned*>(bias) + CCfg::BIAS_WORDS / 2 + i) = sv[q];
+            }
+        }
+    }
+    char* stash = smem + CCfg::RING + CCfg::BIAS_WORDS * 4 + wave * CCfg::STASH_PER_WAVE + lane * 16;
+    cx.stash = stash;
+    cx.bias = bias;
+    cx.lane = lane;
+
+    const long smp = (long)blockIdx.x * CCfg::SAMPLES + wave * 32 + n;
+    const bool valid = smp < p.nsamp;
+    const long sidx = valid ? smp : p.nsamp - 1;
+    {   // both positional encodings as input blocks, parked in the stash until layer 0, the skip layer and the views layer read them
+        const long ray = sidx / p.S;
+        const float* rb = p.ray_batch + ray * p.ncol;
+        const float zv = p.z[sidx];
+        float pts[3], vd[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            pts[c] = __fadd_rn(rb[c], __fmul_rn(rb[3 + c], zv));   // renderer.py:180
+            vd[c] = rb[8 + c];
+        }
+        XBlk pe, pev;
+        c_encode<PE_L, PE_KS>(pts, h, pe);
+        c_stash_put<PE_KS>(stash, pe);
+        c_encode<PE_LV, PEV_KS>(vd, h, pev);
+        c_stash_put<PEV_KS>(stash + (PE_KS + 4) * 1024, pev);
+    }
+
+    cx.st.start_wait();
+    c_prime<typename N::L0>(cx.st, cx.pp, bias, lane);
+    {
+        XBlk in_pe[1];
+        c_stash_get<PE_KS>(stash, in_pe[0]);
+        c_layer<typename N::L0, typename N::template Hidden<1>, ST, 1, KB>(cx.st, cx.pp, in_pe, cx.buf[0], nullptr, bias, lane);
+    }
+    HiddenLoopC<N, ST, 1, D>::run(cx);
+
+    // heads
+    XBlk (&hact)[KB] = cx.buf[(D - 1) & 1];
+    const float* lb = bias + D * T * 32;
+    float araw[4], rraw[4];
+    XBlk none[1];
+    c_layer<typename N::Alpha, typename N::Feature, ST, KB, 1>(cx.st, cx.pp, hact, none, araw, lb, lane);
+    lb += 32;
+    XBlk vin[KB + 1];
+    c_layer<typename N::Feature, typename N::Views, ST, KB, KB + 1>(cx.st, cx.pp, hact, vin, nullptr, lb, lane);
+    lb += T * 32;
+    {
+        const char* sp = stash;
+        asm volatile("" : "+v"(sp));        // opaque: these loads must not be hoisted above the feature layer
+        c_stash_get<PEV_KS>(sp + (PE_KS + 4) * 1024, vin[KB]);
+    }
+    XBlk hbuf[KB / 2];
+    c_layer<typename N::Views, typename N::Rgb, ST, KB + 1, KB / 2>(cx.st, cx.pp, vin, hbuf, nullptr, lb, lane);
+    lb += (T / 2) * 32;
+    c_layer<typename N::Rgb, void, ST, KB / 2, 1>(cx.st, cx.pp, hbuf, none, rraw, lb, lane);
+
+    if (h == 0 && valid) {
+        const f32x4 o = {rraw[0], rraw[1], rraw[2], araw[0]};   // cat([rgb, alpha]) nerf.py:157
+        *reinterpret_cast<f32x4*>(p.raw + sidx * 4) = o;
+    }
+}
+
+template <int W, int D, int SKIP> constexpr int nerf_c_chunks() { return NerfNetC<W, D, SKIP>::NCH; }
+
+template <int W, int D, int SKIP>
+static int launch_nerf_c(const MlpParams& p, hipStream_t st) {
+    typedef NerfNetC<W, D, SKIP> N;
+    const long blocks = cdiv(p.nsamp, CCfg::SAMPLES);
+    const size_t lds = CCfg::TOTAL;
+    EVD_SET_MAX_LDS((&k_nerf_mlp_c<W, D, SKIP>), lds);
+    if (p.nbias != N::NTILES * 32) return fail(EVD_E_INVALID, "evd_nerf_mlp (f16c): %d bias floats, kernel expects %d", p.nbias, N::NTILES * 32);
+    if (p.nchunks != N::NCH) return fail(EVD_E_INVALID, "evd_nerf_mlp (f16c): packed stream has %d chunks, kernel expects %d", p.nchunks, N::NCH);
+    if (!p.wscale) return fail(EVD_E_INVALID, "evd_nerf_mlp (f16c): no row scales");
+    hipLaunchKernelGGL((k_nerf_mlp_c<W, D, SKIP>), dim3((unsigned)blocks), dim3(CCfg::NT), lds, st, p);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+constexpr bool nerf_c_built(int W, int D, int skip) { return W == 256 && D == 8 && skip == 4; }
+
+
+}  // namespace evd

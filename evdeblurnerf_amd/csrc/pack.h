@@ -2,6 +2,7 @@
 #pragma once
 
 #include <cstdint>
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -95,6 +96,115 @@ struct StreamBuilder {
     }
 };
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Compensated float16 mode (EVD_PREC_F16C, mlp_pipe_c.h): every float16 fragment stream is accompanied by block-scaled fp6 (e2m3)
+// fragments of the weights' rounding residual  Wl = W - f16(W)  and of the weights themselves, consumed by
+// v_mfma_scale_f32_32x32x64_f8f6f4 against fp6 copies of the activations resp. of THEIR rounding residuals:
+//     W x  ~=  f16(W) f16(x)  +  fp6(Wl) fp6(f16(x))  +  fp6(W) fp6(x - f16(x))
+// One power-of-two scale per weight row and layer for each of the two fp6 operands (e8m0 bytes, `scales`).
+
+// magnitude code (5 bits) of |v| on the e2m3 grid {0, 1/8 .. 7/8, 1 .. 7.5}: round to nearest even, saturate at 7.5
+__host__ __device__ static inline int e2m3_mag(float a) {
+    if (!(a < 7.5f)) return 31;
+    if (a < 1.f) return (int)rintf(a * 8.f);                 // subnormals, step 1/8; 8 = the code of 1.0
+    int e = a < 2.f ? 1 : (a < 4.f ? 2 : 3);
+    const float step = (e == 1 ? 0.125f : (e == 2 ? 0.25f : 0.5f));
+    const int q = (int)rintf(a / step);                       // 8 .. 16
+    return q == 16 ? ((e + 1) << 3) : ((e << 3) | (q - 8));
+}
+__host__ __device__ static inline int e2m3_code(float v) { return e2m3_mag(v < 0.f ? -v : v) | (v < 0.f ? 32 : 0); }
+__host__ __device__ static inline float e2m3_value(int code) {
+    const int e = (code >> 3) & 3, m = code & 7;
+    const float a = e == 0 ? m * 0.125f : (8 + m) * (e == 1 ? 0.125f : (e == 2 ? 0.25f : 0.5f));
+    return (code & 32) ? -a : a;
+}
+// e8m0 byte of the smallest power of two s with amax / s <= 7.5
+__host__ __device__ static inline int e8m0_for_max(float amax) {
+    if (!(amax > 0.f)) return 64;
+    int x;
+    const float m = frexpf(amax, &x);                         // amax = m 2^x, m in [0.5, 1)
+    int e = x - 3 + (m > 0.9375f ? 1 : 0);                    // 7.5 * 2^(x-3) = 0.9375 * 2^x
+    e += 127;
+    return e < 1 ? 1 : (e > 254 ? 254 : e);
+}
+__host__ __device__ static inline float e8m0_value(int byte) { return ldexpf(1.f, byte - 127); }
+// position i (0..31) of an fp6 operand of lane half h  ->  (k-step inside the 4-k-step block, position kk = 8 h + e of that k-step)
+//   kind 0 (pairs with fp6(f16(x)), v_cvt_scalef32_pk32_fp6_f16 of the block's four float16 fragments): sequential
+//   kind 1 (pairs with fp6(x - f16(x)), v_cvt_scalef32_2xpk16_fp6_f32 of two 16-value float32 sources): the two sources interleave
+__host__ __device__ constexpr int c_pos_kstep(int kind, int i) { return kind == 0 ? (i >> 3) : 2 * (i & 1) + (i >> 4); }
+__host__ __device__ constexpr int c_pos_elem(int kind, int i) { return kind == 0 ? (i & 7) : ((i >> 1) & 7); }
+
+struct StreamBuilderC {
+    size_t cb;
+    std::vector<uint8_t> bytes;
+    std::vector<uint32_t> scales;   // per output tile (stream order) 32 words: byte 0 = scale of the Wl operand of that row, byte 1 = of the W operand
+    explicit StreamBuilderC(size_t chunk) : cb(chunk) {}
+    // One layer: groups of G tiles; per group, per block of <= 4 k-steps:  [float16 fragments: k-step major, tile minor]
+    // [first 16 bytes per lane of the fp6 operands: kind major, tile minor][last 8 bytes per lane: kind major, tile minor]; zero-padded
+    // to a chunk boundary at the end.  row(tile, r) -> source row or -1; col(j, kk) -> source column or -1; at(row, col) -> address or null.
+    template <class RowFn, class ColFn, class AtFn>
+    void layer_at(int tiles, int ksteps, int G, RowFn row, ColFn col, AtFn at) {
+        auto wt = [&](int tile, int r, int j, int kk) -> float {
+            if (j >= ksteps) return 0.f;
+            const int rr = row(tile, r), c = col(j, kk);
+            const float* w = (rr >= 0 && c >= 0) ? at(rr, c) : nullptr;
+            return w ? *w : 0.f;
+        };
+        const int nblk = (ksteps + 3) / 4;
+        // row scales over the whole layer
+        std::vector<int> sc((size_t)tiles * 32 * 2);
+        for (int tile = 0; tile < tiles; ++tile)
+            for (int r = 0; r < 32; ++r) {
+                float ml = 0.f, mh = 0.f;
+                for (int j = 0; j < ksteps; ++j)
+                    for (int kk = 0; kk < 16; ++kk) {
+                        const float w = wt(tile, r, j, kk), wl = w - (float)(_Float16)w;
+                        ml = fmaxf(ml, fabsf(wl));
+                        mh = fmaxf(mh, fabsf(w));
+                    }
+                sc[(tile * 32 + r) * 2] = e8m0_for_max(ml);
+                sc[(tile * 32 + r) * 2 + 1] = e8m0_for_max(mh);
+                scales.push_back((uint32_t)sc[(tile * 32 + r) * 2] | ((uint32_t)sc[(tile * 32 + r) * 2 + 1] << 8));
+            }
+        for (int p = 0; p < tiles / G; ++p)
+            for (int b = 0; b < nblk; ++b) {
+                const int nk = ksteps - 4 * b < 4 ? ksteps - 4 * b : 4;
+                for (int jj = 0; jj < nk; ++jj)
+                    for (int t = 0; t < G; ++t) {
+                        const size_t base = bytes.size();
+                        bytes.resize(base + 1024, 0);
+                        for (int l = 0; l < 64; ++l)
+                            for (int e = 0; e < 8; ++e)
+                                *reinterpret_cast<_Float16*>(bytes.data() + base + l * 16 + e * 2) = (_Float16)wt(p * G + t, l & 31, 4 * b + jj, 8 * (l >> 5) + e);
+                    }
+                const size_t lo = bytes.size(), hi = lo + (size_t)2 * G * 1024;
+                bytes.resize(hi + (size_t)2 * G * 512, 0);
+                for (int kind = 0; kind < 2; ++kind)
+                    for (int t = 0; t < G; ++t)
+                        for (int l = 0; l < 64; ++l) {
+                            const int tile = p * G + t, r = l & 31, h = l >> 5;
+                            const float s = e8m0_value(sc[(tile * 32 + r) * 2 + kind]);
+                            uint8_t packed[24] = {0};
+                            for (int i = 0; i < 32; ++i) {
+                                const float w = wt(tile, r, 4 * b + c_pos_kstep(kind, i), 8 * h + c_pos_elem(kind, i));
+                                const float v = kind == 0 ? w - (float)(_Float16)w : w;
+                                const int code = e2m3_code(v / s);
+                                for (int q = 0; q < 6; ++q)
+                                    if ((code >> q) & 1) packed[(6 * i + q) >> 3] |= (uint8_t)(1u << ((6 * i + q) & 7));
+                            }
+                            memcpy(bytes.data() + lo + (size_t)(kind * G + t) * 1024 + l * 16, packed, 16);
+                            memcpy(bytes.data() + hi + (size_t)(kind * G + t) * 512 + l * 8, packed + 16, 8);
+                        }
+            }
+        bytes.resize(cdiv((long)bytes.size(), (long)cb) * cb, 0);
+    }
+    template <class ColFn>
+    void layer(const float* Wm, int out_dim, int in_dim, int tiles, int ksteps, int G, ColFn col) {
+        layer_at(tiles, ksteps, G, [out_dim](int t, int r) { return 32 * t + r < out_dim ? 32 * t + r : -1; }, col,
+                 [=](int r, int c) { return c < in_dim ? Wm + (size_t)r * in_dim + c : nullptr; });
+    }
+};
+
 // a packed fragment stream on the device and, per element, the index of its source in the parameter arena (-1: zero)
 struct PackedStream {
     int prec = 0;
@@ -124,6 +234,7 @@ static __global__ void k_gather_f32(const float* __restrict__ arena, const int* 
 static inline int repack_stream(PackedStream& s, const float* params, hipStream_t st) {
     if (!s.data.p) return EVD_OK;
     const long nel = (long)(s.src.bytes / sizeof(int32_t));
+    if (!nel) return EVD_OK;
     hipLaunchKernelGGL(k_pack_stream, dim3((unsigned)cdiv(nel, 256L)), dim3(256), 0, st, s.prec, params, (const int*)s.src.p, nel, (uint8_t*)s.data.p);
     EVD_LAUNCH_CHECK();
     return EVD_OK;

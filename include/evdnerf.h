@@ -38,7 +38,10 @@ extern "C" {
 #define EVD_PREC_F16X3 1    /* operands split hi+lo into two float16, 3 x v_mfma_f32_32x32x16_f16: ~2^-21 products */
 #define EVD_PREC_BF16 2     /* v_mfma_f32_32x32x16_bf16: throughput mode, ~2^-8 operands */
 #define EVD_PREC_F16 3      /* v_mfma_f32_32x32x16_f16, one product: bf16 speed, ~2^-11 operands, float16 range */
-#define EVD_NUM_PREC 4
+#define EVD_PREC_F16C 4     /* compensated float16: the float16 product + two block-scaled fp6 (e2m3) products of the operands' rounding
+                             * residuals on v_mfma_scale_f32_32x32x64_f8f6f4: ~2^-15 operands at 1.4x the matrix-pipe time of EVD_PREC_F16.
+                             * Built for the netdepth 8, netwidth 256, skips [4] NeRF network without feature rows; EVD_E_INVALID otherwise. */
+#define EVD_NUM_PREC 5
 
 /* activation codes: reference networks/nerf.py:31-33, networks/pdrf/voxnerf.py:28-30 */
 #define EVD_ACT_NONE 0
