@@ -189,6 +189,15 @@ template <class C, bool STORES, int NCH> struct PStream {
                          "s_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
     }
+    static constexpr int kChunks = NCH;
+    // one 1 KiB piece k of chunk c (kernels that spread a chunk's DMA over several MFMA gaps, mlp_pipe_c.h)
+    __device__ __forceinline__ void issue_piece(int c, int k) {
+        const char* src = gsrc + (size_t)c * C::CB + k * 1024;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(dst0 + (c & 3) * C::CB + k * 1024);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    }
     // start_issue() goes first in the kernel: the DMA of the first three chunks flies while the prologue stages the
     // biases, loads the rays and computes the positional encodings; start_wait() closes the prologue.
     __device__ __forceinline__ void start_issue(const char* g, char* ring, int tid) {

@@ -28,12 +28,17 @@
 namespace evd {
 
 // developer ablations (tools/ablate_c.sh compiles variants): 1 / 2 skip the first / second fp6 product, 4 drain every chunk end fully,
-// 8 no weight DMA, 16 no barrier, 32 no epilogue, 64 no float16 fragment reads, 128 no fp6 operand reads
+// 8 no weight DMA, 16 no barrier, 32 no epilogue, 64 no float16 fragment reads, 128 no fp6 operand reads, 256 no fp6 conversions, 512 no epilogue pairs
 #ifdef EVD_C_ABL
 constexpr int kAbl = EVD_C_ABL;
 #else
 constexpr int kAbl = 0;
 #endif
+
+// pointers into LDS that keep their address space when they are rebuilt from a (laundered) byte offset: ds_read with immediate offsets
+typedef const __attribute__((address_space(3))) float* lds_f32_p;
+typedef const __attribute__((address_space(3))) f32x4* lds_f32x4_p;
+typedef const __attribute__((address_space(3))) unsigned* lds_u32_p;
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x6 __attribute__((ext_vector_type(6)));
@@ -43,13 +48,76 @@ typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
 
 struct CCfg {
-    static constexpr int NT = 256, NW = 4, CB = PIPE_CB, FB = 1024, UPC = CB / 1024, NSLOT = 4, PIECES = CB / 1024 / NW;
+    static constexpr int NT = 256, NW = 4, CB = PIPE_CB, FB = 1024, UPC = CB / 1024, PIECES = CB / 1024 / NW;
+#ifdef EVD_C_NSLOT
+    static constexpr int NSLOT = EVD_C_NSLOT;
+#else
+    static constexpr int NSLOT = 4;                          // ring slots: 2 chunks resident, NSLOT - 2 in flight (8 slots measured: no faster, the kernel is LDS-bandwidth-bound)
+#endif
+    static constexpr int PDM = 4;                            // ring of prefetched float16 A fragments: PDM - 1 MFMAs ahead (8: no faster)
     static constexpr int SAMPLES = NW * 32;
     static constexpr int RING = NSLOT * CB;
     static constexpr int BIAS_WORDS = 5120;                  // biases (32 floats per tile) followed by the row-scale words (32 per tile)
-    static constexpr int STASH_ITEMS = 14;                   // per lane: point encoding 8 x 16 B, direction encoding 6 x 16 B (XStash)
-    static constexpr int STASH_PER_WAVE = STASH_ITEMS * 1024;
-    static constexpr int TOTAL = RING + BIAS_WORDS * 4 + NW * STASH_PER_WAVE;
+    static constexpr int TOTAL = RING + BIAS_WORDS * 4;
+    static_assert((NSLOT & (NSLOT - 1)) == 0 && NSLOT >= 4 && TOTAL <= 160 * 1024, "ring geometry");
+};
+
+// Weight stream of this mode: the ring protocol of mlp_pipe.h's PStream (two chunks resident, counted vmcnt, one barrier per 16 KiB
+// chunk) with a deeper ring and a cheaper issue.  NSLOT slots: at the top of chunk c (behind the barrier that ended chunk c-1) chunks
+// c and c+1 are resident, c+2 .. c+NSLOT-2 in flight, the slot of c-1 is free; chunk_begin(c) issues chunk c+NSLOT-1 into it,
+// chunk_end(c) waits until this wavefront's pieces of chunk c+2 have landed (everything younger stays in flight) and crosses the barrier.
+// With one wavefront per SIMD nothing else hides the L2 -> LDS latency (under load well above the 2 chunk-times a 4-slot ring gives).
+// Issue: the chunk's source is  SGPR base + 32-bit lane offset  (one v_add per chunk instead of a 64-bit add per piece); M0 is set and
+// not restored (nothing else in the kernel reads M0): 8 instructions per chunk and wavefront.
+template <int NCH> struct CStream {
+    static constexpr int kChunks = NCH, NSLOT = CCfg::NSLOT;
+    const char* gbase;      // stream base (wave-uniform)
+    const char* rd_base;    // ring base + 16 * lane (fragment reads)
+    unsigned voff;          // this lane's byte offset of piece 0 of chunk 0
+    unsigned dst0;          // LDS byte offset of this wavefront's piece 0 in slot 0 (wave-uniform)
+    static_assert(CCfg::PIECES == 4, "four 1 KiB pieces per wavefront per chunk");
+    __device__ __forceinline__ void issue(int c) {          // c is a compile-time constant at every call site
+        const unsigned off = voff + (unsigned)c * CCfg::CB;
+        const unsigned dst = dst0 + (unsigned)(c & (NSLOT - 1)) * CCfg::CB;
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %0, %1 offset:2048\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072"
+                     : : "v"(off), "s"(gbase), "s"(dst) : "memory", "m0");
+    }
+    // wait until at most `chunks` chunks (PIECES loads each) of this wavefront are outstanding
+    static __device__ __forceinline__ void wait_chunks(int chunks) {
+        switch (chunks) {
+        case 0: wait_vmcnt<0>(); break;
+        case 1: wait_vmcnt<4>(); break;
+        case 2: wait_vmcnt<8>(); break;
+        case 3: wait_vmcnt<12>(); break;
+        case 4: wait_vmcnt<16>(); break;
+        case 5: wait_vmcnt<20>(); break;
+        case 6: wait_vmcnt<24>(); break;
+        default: wait_vmcnt<28>(); break;
+        }
+    }
+    __device__ __forceinline__ void start_issue(const char* g, char* ring, int tid) {
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+        gbase = g;
+        voff = wave * (CCfg::PIECES * 1024) + lane * 16;
+        rd_base = ring + lane * 16;
+        dst0 = __builtin_amdgcn_readfirstlane(lds_offset_of(ring) + wave * (CCfg::PIECES * 1024));
+#pragma unroll
+        for (int c = 0; c < NSLOT - 1; ++c)
+            if (c < NCH) issue(c);
+    }
+    __device__ __forceinline__ void start_wait() {      // chunks 0 and 1 landed
+        wait_chunks(cmax(0, cmin(NSLOT - 1, NCH) - 2));
+        __syncthreads();
+    }
+    __device__ __forceinline__ void chunk_begin(int c) { if (c + NSLOT - 1 < NCH && !(kAbl & 8)) issue(c + NSLOT - 1); }
+    __device__ __forceinline__ void chunk_end(int c) {
+        if (kAbl & 4) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        wait_chunks((kAbl & 8) ? 0 : cmax(0, cmin(c + NSLOT - 1, NCH - 1) - (c + 2)));
+        if (!(kAbl & 16)) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
 };
 
 // one k-block (4 k-steps = 64 input features) of a layer's input as a lane holds it
@@ -73,14 +141,19 @@ template <bool SIGNED> __device__ __forceinline__ unsigned c_max_acc(unsigned m,
 }
 
 // Block scales from the packed maximum: with E the exponent of the largest float16 magnitude, the values are divided by 2^(E-2)
-// (largest in [4, 8): the top of the e2m3 range, 7.5) and the residuals (|r| <= 2^(E-11)) by 2^(E-13).  The e8m0 byte of a scale is
+// (largest in [4, 8): the top of the e2m3 range, 7.5) and the residuals (truncation: |r| < 2^(E-10); EVD_C_RNE: <= 2^(E-11)) by
+// 2^(E-12) (2^(E-13)).  The e8m0 byte of a scale is
 // the exponent field of the float32 the conversion instructions take.  Returns byte 0 = values, byte 1 = residuals.
 __device__ __forceinline__ unsigned c_scales(unsigned m) {
     const unsigned ma = m & 0xffffu, mb = m >> 16;
     const unsigned mm = ma > mb ? ma : mb;                        // max of the two halves
     const unsigned e16 = (mm >> 10) & 31u;                        // biased float16 exponent (0 for zero / subnormal blocks)
     const unsigned bh = e16 + 110u;                               // (e16 - 15) - 2 + 127
+#ifdef EVD_C_RNE
     return bh | ((bh - 11u) << 8);
+#else
+    return bh | ((bh - 10u) << 8);
+#endif
 }
 
 // finish a block: fp6 of the four float16 fragments and of the 2 x 16 residuals
@@ -98,19 +171,39 @@ __device__ __forceinline__ void c_finish(XBlk& x, unsigned m, const f32x16& r0, 
     x.qh[6] = x.qh[7] = x.ql[6] = x.ql[7] = 0;
 }
 
-// one epilogue unit: accumulator values 2k, 2k+1 of a tile -> ReLU, float16 pair into the block, residuals in place
+// one epilogue unit: accumulator values 2k, 2k+1 of a tile -> ReLU, float16 pair into the block, residuals in place.
+// The float16 pair is TRUNCATED (v_cvt_pkrtz_f16_f32): the residual x - f16(x) then has the sign of x, so for a ReLU layer the
+// activation is one v_pk_max_i16 on the pair (a negative half is a negative int16) plus the [0, 1] clamp of the residual's
+// v_fma_mix_f32 (x < 0: f16 -> 0, residual = x -> clamped to 0; x >= 0: residual in [0, ulp) is untouched) -- 5 VALU per pair.  The
+// truncation error of the float16 product is what the second fp6 product removes; its residuals are one bit larger (c_scales).
+// -DEVD_C_RNE: round to nearest + explicit ReLU of the two floats (6 VALU): RGB error 9.5e-6 instead of 1.8e-5 on the trained weights,
+// kernel 3-5 % slower.
 template <bool RELU>
 __device__ __forceinline__ void c_drain_pair(f32x16& a, int k, XBlk& x, int word, unsigned& m) {
     float x0 = a[2 * k], x1 = a[2 * k + 1];
+#ifdef EVD_C_RNE
     if (RELU) { x0 = relu_f32(x0); x1 = relu_f32(x1); }
     const f32x2 v = {x0, x1};
-    const f16x2 hv = __builtin_convertvector(v, f16x2);           // MODE.FP16_OVFL: saturates at +-65504
-    const unsigned w = __builtin_bit_cast(unsigned, hv);
+    const unsigned w = __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));     // MODE.FP16_OVFL: saturates at +-65504
+    constexpr bool CLAMP = false;
+#else
+    unsigned w = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+    if (RELU) {
+        const s16x2 zero = {0, 0};
+        w = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, w), zero));
+    }
+    constexpr bool CLAMP = RELU;
+#endif
     x.h[word] = w;
     m = c_max_acc<!RELU>(m, w);
     float r0, r1;                                                  // x - float(f16(x)): v_fma_mix_f32 reads the half straight from the pair
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(w), "v"(x0));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(w), "v"(x1));
+    if (CLAMP) {
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0] clamp" : "=v"(r0) : "v"(w), "v"(x0));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp" : "=v"(r1) : "v"(w), "v"(x1));
+    } else {
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(w), "v"(x0));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(w), "v"(x1));
+    }
     a[2 * k] = r0;
     a[2 * k + 1] = r1;
 }
@@ -139,13 +232,13 @@ struct CLayer {
     static constexpr int main_pos(int p, int mi) { return p * GROUP_UNITS + (mi / (4 * G_)) * 7 * G_ + mi % (4 * G_); }
     static constexpr int NMAIN = KSTEPS * TILES_;
     static_assert(TILES_ % G_ == 0 && (G_ == 1 || G_ == 2), "groups of one or two tiles");
-    static_assert(NMAIN % 4 == 0, "the float16 fragment ring keeps its phase across layers");
+    static_assert(NMAIN % CCfg::PDM == 0, "the float16 fragment ring keeps its phase across layers");
     static_assert(UNITS % CCfg::UPC == 0 || UNITS % CCfg::UPC >= 2, "a layer's last chunk must reach its chunk_begin");
 };
 
 // register state that flows from layer to layer
 struct CPipe {
-    f16x8 am[4];             // ring of prefetched float16 A fragments
+    f16x8 am[CCfg::PDM];     // ring of prefetched float16 A fragments
     i32x8 ac[2][2];          // fp6 A operands of the current block: [kind][tile of the group]
     f32x16 acc[2][2];        // two accumulator sets of up to two tiles
     unsigned wsc[2][2];      // row-scale words of the tiles in acc[set][t]
@@ -153,30 +246,31 @@ struct CPipe {
 };
 
 // byte offset of unit u of a layer (units count from the layer's first chunk) inside the ring, for this lane's rd_base
-template <class L> __device__ __forceinline__ constexpr int c_ring_off(int u) { return ((L::CHUNK0 + u / CCfg::UPC) & 3) * CCfg::CB + (u % CCfg::UPC) * 1024; }
+template <class L> __device__ __forceinline__ constexpr int c_ring_off(int u) { return ((L::CHUNK0 + u / CCfg::UPC) & (CCfg::NSLOT - 1)) * CCfg::CB + (u % CCfg::UPC) * 1024; }
 
 // One tile group P of layer L.  in[]: input blocks; the pending group of the previous layer is drained into in[L::PDB]; this layer's
 // groups are drained into out[p].  bias: LDS bias block of this layer (tile-major, 32 floats per tile) with the row-scale words
 // SC_OFF words behind it.  NXT: the next layer (for the prefetch across the layer boundary), void for the last.
 template <class L, class NXT, class ST, int NIN, int NOUT, int P>
-__device__ __forceinline__ void c_group(ST& st, CPipe& pp, XBlk (&in)[NIN], XBlk (&out)[NOUT], const float* __restrict__ bias, int lane) {
+__device__ __forceinline__ void c_group(ST& st, CPipe& pp, XBlk (&in)[NIN], XBlk (&out)[NOUT], lds_f32_p bias, int lane) {
     constexpr int G = L::G, NS = L::GROUP_SLOTS;
     constexpr int cur = (L::PAR + P) & 1, oth = cur ^ 1;
     constexpr bool FIRST = P == 0, LAST = P == L::NG - 1;
     constexpr int DG = FIRST ? L::PG : G;                       // tiles to drain
     constexpr int QU = DG > 0 ? DG * 8 + 1 : 0;                 // pair units + the finishing unit
+    constexpr int NBL0 = (P == L::NG - 1 ? L::NEXT_G : G) * 5;
     constexpr int s_dep = (FIRST && L::PG > 0) ? L::PDB * (4 * G + 2 * G) : NS;     // first slot that needs the drained block
-    constexpr int dend = cmin(s_dep, NS / 2 + 2);
+    constexpr int dend = cmin(s_dep, NS - cceil(NBL0, 3) - 1);       // the epilogue is spread over the whole group; the bias reads follow it
     constexpr bool drain_first = QU > 0 && dend - 2 < 1;
     constexpr int drate = (QU > 0 && !drain_first) ? cceil(QU, dend - 2) : (drain_first ? QU : 0);
     constexpr int BG = LAST ? L::NEXT_G : G;                    // tiles whose bias / scales are fetched for the next group
     constexpr int NBL = BG * 5;                                 // 4 bias reads + 1 scale word per tile
-    constexpr int b0 = cmin(cmax(drain_first ? 0 : dend - 1, NS / 2), NS - 1);
+    constexpr int b0 = cmin(drain_first ? 0 : dend - 1, NS - 1);
     constexpr int brate = NBL > 0 ? cceil(NBL, NS - b0) : 0;
-    auto units_thru = [](int s) constexpr { return (QU == 0 || s < 0) ? 0 : (drain_first ? QU : (s < 2 ? 0 : cmin(QU, (s - 1) * drate))); };
+    auto units_thru = [](int s) constexpr { return (QU == 0 || s < 0) ? 0 : (drain_first ? QU : (s < 2 ? 0 : cmin(QU, ((s - 1) * QU) / (dend - 2)))); };
     auto bias_thru = [](int s) constexpr { return (NBL == 0 || s <= b0) ? 0 : (s >= NS ? NBL : cmin(NBL, (s - b0) * brate)); };
     const int h = lane >> 5;
-    const float* bias_next = bias + (LAST ? L::TILES : (P + 1) * G) * 32;
+    lds_f32_p bias_next = bias + (LAST ? L::TILES : (P + 1) * G) * 32;
     constexpr int SC_OFF = CCfg::BIAS_WORDS / 2;
     constexpr int ubase = P * L::GROUP_UNITS;                   // first unit of this group
     constexpr int mbase = P * L::KSTEPS * G;                    // first float16 MFMA of this group (ring phase)
@@ -189,11 +283,12 @@ __device__ __forceinline__ void c_group(ST& st, CPipe& pp, XBlk (&in)[NIN], XBlk
             if (u < units_thru(s) && !(kAbl & 32)) {
                 XBlk& dst = FIRST ? in[L::PDB] : out[P > 0 ? P - 1 : 0];
                 if (u < DG * 8) {
+                    if (kAbl & 512) continue;
                     const int dt = u / 8, k = u % 8;
                     if (u == 0) pp.m = 0u;
                     if (FIRST) c_drain_pair<L::PRELU>(pp.acc[oth][dt], k, dst, 8 * dt + k, pp.m);
                     else c_drain_pair<L::RELU>(pp.acc[oth][dt], k, dst, 8 * dt + k, pp.m);
-                } else {
+                } else if (!(kAbl & 256)) {
                     c_finish(dst, pp.m, pp.acc[oth][0], pp.acc[oth][1]);
                 }
             }
@@ -204,24 +299,24 @@ __device__ __forceinline__ void c_group(ST& st, CPipe& pp, XBlk (&in)[NIN], XBlk
             if (b < bias_thru(s)) {
                 const int bt = b / 5, q = b % 5;
                 if (q < 4) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_next + bt * 32 + 8 * q + 4 * h);
+                    const f32x4 bv = *(lds_f32x4_p)(bias_next + bt * 32 + 8 * q + 4 * h);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) pp.acc[oth][bt][4 * q + e] = bv[e];
                 } else {
-                    pp.wsc[oth][bt] = reinterpret_cast<const unsigned*>(bias_next)[SC_OFF + bt * 32 + (lane & 31)];
+                    pp.wsc[oth][bt] = ((lds_u32_p)bias_next)[SC_OFF + bt * 32 + (lane & 31)];
                 }
             }
         }
     };
-    // chunk protocol after a slot that raised the count of consumed units from t0 to t1
+    // chunk protocol after a slot that raised the count of consumed units from t0 to t1: the DMA of chunk c + 3 follows the second unit
+    // of chunk c (the matrix pipe has restarted behind the barrier by then), the barrier that releases chunk c its last unit
     auto chunks = [&](int t0, int t1) __attribute__((always_inline)) {
-        if (t0 / CCfg::UPC != t1 / CCfg::UPC || (t0 % CCfg::UPC < 2 && t1 % CCfg::UPC >= 2)) {
-            if (t0 % CCfg::UPC < 2 && t1 % CCfg::UPC >= 2 && t0 / CCfg::UPC == t1 / CCfg::UPC && !(kAbl & 8)) st.chunk_begin(L::CHUNK0 + t1 / CCfg::UPC);
-            if (t0 / CCfg::UPC != t1 / CCfg::UPC) {
-                if (kAbl & 4) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
-                if (!(kAbl & 16)) st.chunk_end(L::CHUNK0 + t0 / CCfg::UPC);
-                if (t1 % CCfg::UPC >= 2 && !(kAbl & 8)) st.chunk_begin(L::CHUNK0 + t1 / CCfg::UPC);
-            }
+        const int c0 = t0 / CCfg::UPC, c1 = t1 / CCfg::UPC;
+        if (c0 == c1) {
+            if (t0 % CCfg::UPC < 2 && t1 % CCfg::UPC >= 2) st.chunk_begin(L::CHUNK0 + c0);
+        } else {
+            st.chunk_end(L::CHUNK0 + c0);
+            if (t1 % CCfg::UPC >= 2) st.chunk_begin(L::CHUNK0 + c1);
         }
     };
 
@@ -238,25 +333,25 @@ __device__ __forceinline__ void c_group(ST& st, CPipe& pp, XBlk (&in)[NIN], XBlk
             for (int t = 0; t < G; ++t) {
                 const int i = jj * G + t;                       // main slot inside the block
                 filler(s);
-                {   // float16 fragment of the main MFMA three ahead (possibly in the next block, group or layer)
-                    const int idx = mm + 3 - mbase;             // main index inside this group
+                {   // float16 fragment of the main MFMA PDM - 1 ahead (possibly in the next block, group or layer)
+                    constexpr int LA = CCfg::PDM - 1;
+                    const int idx = mm + LA - mbase;            // main index inside this group
                     int u = -1, ringoff = 0;
-                    if (idx < L::KSTEPS * G) {                  // same group: block b2 = idx / (4 G) (all blocks before the last are full)
-                        const int b2 = idx / (4 * G), i2 = idx % (4 * G);
-                        u = ubase + b2 * 7 * G + i2;
+                    if (idx < L::KSTEPS * G) {
+                        u = L::main_pos(P, idx);
                         ringoff = c_ring_off<L>(u);
                     } else if (!LAST) {
-                        u = ubase + L::GROUP_UNITS + (idx - L::KSTEPS * G);
+                        u = L::main_pos(P + 1, idx - L::KSTEPS * G);
                         ringoff = c_ring_off<L>(u);
                     } else if constexpr (!std::is_void<NXT>::value) {
                         // the next layer starts in the chunk behind this layer's last one, which is resident only once that last
                         // chunk is the current one; fragments wanted earlier are fetched by c_layer after the layer's last barrier
                         if ((ub + i) / CCfg::UPC >= L::NCHUNKS - 1) {
-                            u = idx - L::KSTEPS * G;
+                            u = NXT::main_pos(0, idx - L::KSTEPS * G);
                             ringoff = c_ring_off<NXT>(u);
                         }
                     }
-                    if (u >= 0 && !(kAbl & 64)) pp.am[(mm + 3) & 3] = *reinterpret_cast<const f16x8*>(st.rd_base + ringoff);
+                    if (u >= 0 && !(kAbl & 64)) pp.am[(mm + LA) % CCfg::PDM] = *reinterpret_cast<const f16x8*>(st.rd_base + ringoff);
                 }
 #pragma unroll
                 for (int q = 0; q < per_slot; ++q) {            // fp6 parts of this block, consumed by its last 2 G slots
@@ -279,7 +374,7 @@ __device__ __forceinline__ void c_group(ST& st, CPipe& pp, XBlk (&in)[NIN], XBlk
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                pp.acc[cur][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pp.am[mm & 3], xblk_frag(in[b], jj), pp.acc[cur][t], 0, 0, 0);
+                pp.acc[cur][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pp.am[mm % CCfg::PDM], xblk_frag(in[b], jj), pp.acc[cur][t], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 chunks(ub + i, ub + i + 1);
                 ++s;
@@ -314,18 +409,18 @@ __device__ __forceinline__ void c_group(ST& st, CPipe& pp, XBlk (&in)[NIN], XBlk
         if (bq < NBL) {
             const int bt = bq / 5, q = bq % 5;
             if (q < 4) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_next + bt * 32 + 8 * q + 4 * h);
+                const f32x4 bv = *(lds_f32x4_p)(bias_next + bt * 32 + 8 * q + 4 * h);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) pp.acc[oth][bt][4 * q + e] = bv[e];
             } else {
-                pp.wsc[oth][bt] = reinterpret_cast<const unsigned*>(bias_next)[SC_OFF + bt * 32 + (lane & 31)];
+                pp.wsc[oth][bt] = ((lds_u32_p)bias_next)[SC_OFF + bt * 32 + (lane & 31)];
             }
         }
     }
 }
 
 template <class L, class NXT, class ST, int NIN, int NOUT, int P> struct CGroupLoop {
-    static __device__ __forceinline__ void run(ST& st, CPipe& pp, XBlk (&in)[NIN], XBlk (&out)[NOUT], const float* __restrict__ bias, int lane) {
+    static __device__ __forceinline__ void run(ST& st, CPipe& pp, XBlk (&in)[NIN], XBlk (&out)[NOUT], lds_f32_p bias, int lane) {
         c_group<L, NXT, ST, NIN, NOUT, P>(st, pp, in, out, bias, lane);
         if constexpr (P + 1 < L::NG) CGroupLoop<L, NXT, ST, NIN, NOUT, P + 1>::run(st, pp, in, out, bias, lane);
     }
@@ -334,15 +429,15 @@ template <class L, class NXT, class ST, int NIN, int NOUT, int P> struct CGroupL
 // One linear layer on the wavefront's 32 samples.  `out` receives the blocks of every group but the last, which stays pending in the
 // accumulators (F32OUT: rows 0..3 of the single tile are returned in out_f32).
 template <class L, class NXT, class ST, int NIN, int NOUT>
-__device__ __forceinline__ void c_layer(ST& st, CPipe& pp, XBlk (&in)[NIN], XBlk (&out)[NOUT], float* out_f32, const float* __restrict__ bias, int lane) {
+__device__ __forceinline__ void c_layer(ST& st, CPipe& pp, XBlk (&in)[NIN], XBlk (&out)[NOUT], float* out_f32, lds_f32_p bias, int lane) {
     static_assert(NIN >= L::NBLK, "input blocks");
     CGroupLoop<L, NXT, ST, NIN, NOUT, 0>::run(st, pp, in, out, bias, lane);
     if (L::UNITS % CCfg::UPC != 0) st.chunk_end(L::CHUNK0 + L::UNITS / CCfg::UPC);      // the zero-padded tail of the layer's last chunk
     if constexpr (!std::is_void<NXT>::value) {       // first fragments of the next layer that the last group could not prefetch (c_group)
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-            if (L::main_pos(L::NG - 1, L::KSTEPS * L::G - 3 + k) / CCfg::UPC < L::NCHUNKS - 1)
-                pp.am[k] = *reinterpret_cast<const f16x8*>(st.rd_base + c_ring_off<NXT>(k));
+        for (int k = 0; k < CCfg::PDM - 1; ++k)
+            if (L::main_pos(L::NG - 1, L::KSTEPS * L::G - (CCfg::PDM - 1) + k) / CCfg::UPC < L::NCHUNKS - 1)
+                pp.am[k] = *reinterpret_cast<const f16x8*>(st.rd_base + c_ring_off<NXT>(NXT::main_pos(0, k)));
     }
     if (L::F32OUT) {
         constexpr int cur = (L::PAR + L::NG - 1) & 1;
@@ -354,20 +449,20 @@ __device__ __forceinline__ void c_layer(ST& st, CPipe& pp, XBlk (&in)[NIN], XBlk
     }
 }
 
-// prologue: first three float16 fragments of the first layer, bias and row scales of its first group
-template <class L, class ST> __device__ __forceinline__ void c_prime(ST& st, CPipe& pp, const float* __restrict__ bias, int lane) {
+// prologue: first PDM - 1 float16 fragments of the first layer, bias and row scales of its first group
+template <class L, class ST> __device__ __forceinline__ void c_prime(ST& st, CPipe& pp, lds_f32_p bias, int lane) {
     const int h = lane >> 5;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) pp.am[i] = *reinterpret_cast<const f16x8*>(st.rd_base + c_ring_off<L>(i));
+    for (int i = 0; i < CCfg::PDM - 1; ++i) pp.am[i] = *reinterpret_cast<const f16x8*>(st.rd_base + c_ring_off<L>(L::main_pos(0, i)));
 #pragma unroll
     for (int t = 0; t < L::G; ++t) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + t * 32 + 8 * q + 4 * h);
+            const f32x4 bv = *(lds_f32x4_p)(bias + t * 32 + 8 * q + 4 * h);
 #pragma unroll
             for (int e = 0; e < 4; ++e) pp.acc[L::PAR][t][4 * q + e] = bv[e];
         }
-        pp.wsc[L::PAR][t] = reinterpret_cast<const unsigned*>(bias)[CCfg::BIAS_WORDS / 2 + t * 32 + (lane & 31)];
+        pp.wsc[L::PAR][t] = ((lds_u32_p)bias)[CCfg::BIAS_WORDS / 2 + t * 32 + (lane & 31)];
     }
     pp.m = 0u;
 }

@@ -37,44 +37,12 @@ template <int W, int D, int SKIP> struct NerfNetC {
     static_assert(D >= 2 && NTILES * 32 <= CCfg::BIAS_WORDS / 2, "bias / row-scale block");
 };
 
-// an input block <-> this lane's slots of the wavefront's LDS stash (items of 16 bytes per lane, 1 KiB apart)
-template <int KSN> __device__ __forceinline__ void c_stash_put(char* base, const XBlk& x) {
-#pragma unroll
-    for (int j = 0; j < KSN; ++j) {
-        const u32x4 w = {x.h[4 * j], x.h[4 * j + 1], x.h[4 * j + 2], x.h[4 * j + 3]};
-        *reinterpret_cast<u32x4*>(base + j * 1024) = w;
-    }
-    const u32x4 a = {(unsigned)x.qh[0], (unsigned)x.qh[1], (unsigned)x.qh[2], (unsigned)x.qh[3]};
-    const u32x4 b = {(unsigned)x.qh[4], (unsigned)x.qh[5], (unsigned)x.ql[0], (unsigned)x.ql[1]};
-    const u32x4 c = {(unsigned)x.ql[2], (unsigned)x.ql[3], (unsigned)x.ql[4], (unsigned)x.ql[5]};
-    *reinterpret_cast<u32x4*>(base + (KSN + 0) * 1024) = a;
-    *reinterpret_cast<u32x4*>(base + (KSN + 1) * 1024) = b;
-    *reinterpret_cast<u32x4*>(base + (KSN + 2) * 1024) = c;
-    *reinterpret_cast<unsigned*>(base + (KSN + 3) * 1024) = x.sc;
-}
-template <int KSN> __device__ __forceinline__ void c_stash_get(const char* base, XBlk& x) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        u32x4 w = {0u, 0u, 0u, 0u};
-        if (j < KSN) w = *reinterpret_cast<const u32x4*>(base + j * 1024);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) x.h[4 * j + e] = w[e];
-    }
-    const u32x4 a = *reinterpret_cast<const u32x4*>(base + (KSN + 0) * 1024);
-    const u32x4 b = *reinterpret_cast<const u32x4*>(base + (KSN + 1) * 1024);
-    const u32x4 c = *reinterpret_cast<const u32x4*>(base + (KSN + 2) * 1024);
-    x.qh[0] = (int)a[0]; x.qh[1] = (int)a[1]; x.qh[2] = (int)a[2]; x.qh[3] = (int)a[3]; x.qh[4] = (int)b[0]; x.qh[5] = (int)b[1];
-    x.ql[0] = (int)b[2]; x.ql[1] = (int)b[3]; x.ql[2] = (int)c[0]; x.ql[3] = (int)c[1]; x.ql[4] = (int)c[2]; x.ql[5] = (int)c[3];
-    x.qh[6] = x.qh[7] = x.ql[6] = x.ql[7] = 0;
-    x.sc = *reinterpret_cast<const unsigned*>(base + (KSN + 3) * 1024);
-}
-
 template <class N, class ST> struct NerfCtxC {
     ST st;
     CPipe pp;
     XBlk buf[2][N::KB];             // activations ping-pong: layer l writes buf[l & 1]
-    const char* stash;              // this lane's slot of the wavefront's positional-encoding stash
-    const float* bias;              // LDS bias block
+    XBlk pe, pev;                   // the two positional encodings as input blocks (registers: one wavefront per SIMD has room)
+    lds_f32_p bias;                 // LDS bias block
     int lane;
 };
 
@@ -82,7 +50,7 @@ template <class N, class ST, int l, int D> struct HiddenLoopC {
     static __device__ __forceinline__ void run(NerfCtxC<N, ST>& cx) {
         typedef typename N::template Hidden<l> L;
         constexpr int KB = N::KB, T = N::T;
-        const float* lb = cx.bias + l * T * 32;
+        lds_f32_p lb = cx.bias + l * T * 32;
         if constexpr (l + 1 < D) {
             typedef typename N::template Hidden<l + 1> NX;
             step<L, NX>(cx, lb);
@@ -91,15 +59,13 @@ template <class N, class ST, int l, int D> struct HiddenLoopC {
             step<L, typename N::Alpha>(cx, lb);
         }
     }
-    template <class L, class NX> static __device__ __forceinline__ void step(NerfCtxC<N, ST>& cx, const float* lb) {
+    template <class L, class NX> static __device__ __forceinline__ void step(NerfCtxC<N, ST>& cx, lds_f32_p lb) {
         constexpr int KB = N::KB;
         if constexpr (N::is_wide(l)) {
             XBlk wide[KB + 1];
-            const char* sp = cx.stash;
-            asm volatile("" : "+v"(sp));    // opaque: the stash is re-read here, not kept in registers since layer 0
 #pragma unroll
             for (int j = 0; j < KB - 1; ++j) wide[j] = cx.buf[(l - 1) & 1][j];
-            c_stash_get<PE_KS>(sp, wide[KB - 1]);
+            wide[KB - 1] = cx.pe;
             c_layer<L, NX, ST, KB + 1, KB>(cx.st, cx.pp, wide, cx.buf[l & 1], nullptr, lb, cx.lane);
         } else {
             c_layer<L, NX, ST, KB, KB>(cx.st, cx.pp, cx.buf[(l - 1) & 1], cx.buf[l & 1], nullptr, lb, cx.lane);
@@ -110,7 +76,7 @@ template <class N, class ST, int l, int D> struct HiddenLoopC {
 template <int W, int D, int SKIP>
 __global__ __launch_bounds__(CCfg::NT, 1) void k_nerf_mlp_c(const MlpParams p) {
     typedef NerfNetC<W, D, SKIP> N;
-    typedef PStream<CCfg, false, N::NCH> ST;
+    typedef CStream<N::NCH> ST;
     constexpr int T = N::T, KB = N::KB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -139,15 +105,16 @@ __global__ __launch_bounds__(CCfg::NT, 1) void k_nerf_mlp_c(const MlpParams p) {
             }
         }
     }
-    char* stash = smem + CCfg::RING + CCfg::BIAS_WORDS * 4 + wave * CCfg::STASH_PER_WAVE + lane * 16;
-    cx.stash = stash;
-    cx.bias = bias;
+    unsigned bias_off = lds_offset_of(bias);
+    asm volatile("" : "+v"(bias_off));     // opaque base: the bias / row-scale reads then take immediate offsets (the block sits above 64 KiB)
+    const lds_f32_p lbias = (lds_f32_p)(unsigned long)bias_off;
+    cx.bias = lbias;
     cx.lane = lane;
 
     const long smp = (long)blockIdx.x * CCfg::SAMPLES + wave * 32 + n;
     const bool valid = smp < p.nsamp;
     const long sidx = valid ? smp : p.nsamp - 1;
-    {   // both positional encodings as input blocks, parked in the stash until layer 0, the skip layer and the views layer read them
+    {   // both positional encodings as input blocks
         const long ray = sidx / p.S;
         const float* rb = p.ray_batch + ray * p.ncol;
         const float zv = p.z[sidx];
@@ -157,25 +124,22 @@ __global__ __launch_bounds__(CCfg::NT, 1) void k_nerf_mlp_c(const MlpParams p) {
             pts[c] = __fadd_rn(rb[c], __fmul_rn(rb[3 + c], zv));   // renderer.py:180
             vd[c] = rb[8 + c];
         }
-        XBlk pe, pev;
-        c_encode<PE_L, PE_KS>(pts, h, pe);
-        c_stash_put<PE_KS>(stash, pe);
-        c_encode<PE_LV, PEV_KS>(vd, h, pev);
-        c_stash_put<PEV_KS>(stash + (PE_KS + 4) * 1024, pev);
+        c_encode<PE_L, PE_KS>(pts, h, cx.pe);
+        c_encode<PE_LV, PEV_KS>(vd, h, cx.pev);
     }
 
     cx.st.start_wait();
-    c_prime<typename N::L0>(cx.st, cx.pp, bias, lane);
+    c_prime<typename N::L0>(cx.st, cx.pp, lbias, lane);
     {
         XBlk in_pe[1];
-        c_stash_get<PE_KS>(stash, in_pe[0]);
-        c_layer<typename N::L0, typename N::template Hidden<1>, ST, 1, KB>(cx.st, cx.pp, in_pe, cx.buf[0], nullptr, bias, lane);
+        in_pe[0] = cx.pe;
+        c_layer<typename N::L0, typename N::template Hidden<1>, ST, 1, KB>(cx.st, cx.pp, in_pe, cx.buf[0], nullptr, lbias, lane);
     }
     HiddenLoopC<N, ST, 1, D>::run(cx);
 
     // heads
     XBlk (&hact)[KB] = cx.buf[(D - 1) & 1];
-    const float* lb = bias + D * T * 32;
+    lds_f32_p lb = lbias + D * T * 32;
     float araw[4], rraw[4];
     XBlk none[1];
     c_layer<typename N::Alpha, typename N::Feature, ST, KB, 1>(cx.st, cx.pp, hact, none, araw, lb, lane);
@@ -183,11 +147,7 @@ __global__ __launch_bounds__(CCfg::NT, 1) void k_nerf_mlp_c(const MlpParams p) {
     XBlk vin[KB + 1];
     c_layer<typename N::Feature, typename N::Views, ST, KB, KB + 1>(cx.st, cx.pp, hact, vin, nullptr, lb, lane);
     lb += T * 32;
-    {
-        const char* sp = stash;
-        asm volatile("" : "+v"(sp));        // opaque: these loads must not be hoisted above the feature layer
-        c_stash_get<PEV_KS>(sp + (PE_KS + 4) * 1024, vin[KB]);
-    }
+    vin[KB] = cx.pev;
     XBlk hbuf[KB / 2];
     c_layer<typename N::Views, typename N::Rgb, ST, KB + 1, KB / 2>(cx.st, cx.pp, vin, hbuf, nullptr, lb, lane);
     lb += (T / 2) * 32;

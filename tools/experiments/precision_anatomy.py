@@ -45,8 +45,8 @@ def q_block(x, grid, block=32, dim=-1):
 
 class Mode:
     """y = W x with: main product f16(W) f16(x) [or exact], + optional corrections"""
-    def __init__(s, name, w="h", x="h", cw=None, cx=None, grid=E2M3, layers=None, wblock=32, rtz=False):
-        s.name, s.w, s.x, s.cw, s.cx, s.grid, s.layers, s.wblock, s.rtz = name, w, x, cw, cx, grid, layers, wblock, rtz
+    def __init__(s, name, w="h", x="h", cw=None, cx=None, grid=E2M3, layers=None, wblock=32, rtz=False, wgrid=None):
+        s.name, s.w, s.x, s.cw, s.cx, s.grid, s.layers, s.wblock, s.rtz, s.wgrid = name, w, x, cw, cx, grid, layers, wblock, rtz, (wgrid if wgrid is not None else grid)
     def lin(s, Wt, b, x, li):
         full = s.layers is None or li in s.layers
         Wh = h(Wt) if s.w == "h" else Wt
@@ -55,11 +55,11 @@ class Mode:
         if full and s.cw:     # correction for the weight rounding: (W - Wh) x
             Wl = Wt - Wh
             if s.cw == "exact": y = y + xh @ Wl.T
-            else: y = y + q_block(xh, s.grid) @ q_block(Wl, s.grid, block=s.wblock or Wl.shape[-1]).T
+            else: y = y + q_block(xh, s.grid) @ q_block(Wl, s.wgrid, block=s.wblock or Wl.shape[-1]).T
         if full and s.cx:     # correction for the activation rounding: W (x - xh)
             xl = x - xh
             if s.cx == "exact": y = y + xl @ Wh.T
-            else: y = y + q_block(xl, s.grid) @ q_block(Wh, s.grid, block=s.wblock or Wh.shape[-1]).T
+            else: y = y + q_block(xl, s.grid) @ q_block(Wh, s.wgrid, block=s.wblock or Wh.shape[-1]).T
         return y
 
 def embed(x, L):
@@ -114,6 +114,7 @@ modes = [Mode("f16 (Wh Xh)"),
          Mode("f16 + fp6 e3m2 both", cw="q", cx="q", grid=E3M2),
          Mode("f16 + fp4 e2m1 both", cw="q", cx="q", grid=E2M1),
          Mode("fp6 e2m3 both, W scale per row", cw="q", cx="q", wblock=0),
+         Mode("W operands fp4 per row, X fp6", cw="q", cx="q", wblock=0, wgrid=E2M1),
          Mode("f16 + fp6 e2m3 Wh.Xl only", cx="q"),
          Mode("f16 + fp6 e2m3 Wl.Xh only", cw="q"),
          ]
