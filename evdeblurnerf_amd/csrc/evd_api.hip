@@ -133,6 +133,7 @@ int evd_nerf_create(const evd_nerf_desc* d, evd_nerf** out) {
             n->nchunks[prec] = n->pipe_chunks[prec] = 0;
             if (!nerf_mlp_c_chunks(W, D, d->skip)) continue;
             StreamBuilderC sc(PIPE_CB);
+            sc.arena = A;
             const int KB = KS / 4;
             sc.layer(pts_w(0), W, IC, T, PE_KS, 2, pe_col);
             for (int l = 1; l < D; ++l) {
@@ -153,8 +154,7 @@ int evd_nerf_create(const evd_nerf_desc* d, evd_nerf** out) {
             sc.layer(rgb_w, 3, W / 2, 1, KS / 2, 1, hid_col);
             n->pipe_chunks[prec] = (int)(sc.bytes.size() / PIPE_CB);
             if (n->pipe_chunks[prec] != nerf_mlp_c_chunks(W, D, d->skip)) rc = fail(EVD_E_INVALID, "evd_nerf_create: f16c stream has %d chunks, kernel expects %d", n->pipe_chunks[prec], nerf_mlp_c_chunks(W, D, d->skip));
-            if (!rc) rc = n->pipe[prec].data.upload(sc.bytes.data(), sc.bytes.size());
-            if (!rc) rc = n->wscale_c.upload(sc.scales.data(), sc.scales.size() * sizeof(uint32_t));
+            if (!rc) rc = n->pipe_c.upload(sc);
             continue;
         }
         StreamBuilder sb(prec);
@@ -247,7 +247,7 @@ void evd_nerf_destroy(evd_nerf* n) {
     n->wmaps.release();
     n->bias.release();
     n->bias_src.release();
-    n->wscale_c.release();
+    n->pipe_c.release();
     n->side.release();
     delete n;
 }
@@ -271,6 +271,7 @@ int evd_nerf_load_params(evd_nerf* net, const float* params, void* stream) {
         for (int k = 0; k < EVD_BWD_NSTREAMS; ++k)
             if ((rc = repack(net->bwd[i][k]))) return rc;
     }
+    if ((rc = repack_stream_c(net->pipe_c, params, st))) return rc;
     const long nb = (long)(net->bias.bytes / sizeof(float));
     hipLaunchKernelGGL(k_gather_f32, dim3((unsigned)cdiv(nb, 256L)), dim3(256), 0, st, params, (const int*)net->bias_src.p, nb, (float*)net->bias.p);
     EVD_LAUNCH_CHECK();
@@ -279,6 +280,7 @@ int evd_nerf_load_params(evd_nerf* net, const float* params, void* stream) {
 
 size_t evd_nerf_stream_bytes(const evd_nerf* net, int precision) {
     if (!net || precision < 0 || precision >= EVD_NUM_PREC) return 0;
+    if (precision == EVD_PREC_F16C) return net->pipe_c.data.bytes;
     return net->pipe_chunks[precision] ? net->pipe[precision].data.bytes : net->stream[precision].data.bytes;
 }
 
@@ -300,9 +302,9 @@ int evd_nerf_mlp(const evd_nerf* net, int precision, const float* ray_batch, con
     if (precision == EVD_PREC_F16C) {
         EVD_REQUIRE(net->pipe_chunks[precision] > 0, "evd_nerf_mlp: EVD_PREC_F16C is built for netdepth 8, netwidth 256, skips [4] only");
         EVD_REQUIRE(!feature, "evd_nerf_mlp: EVD_PREC_F16C has no feature-row variant (use EVD_PREC_F16X3)");
-        p.wstream = (const char*)net->pipe[precision].data.p;
+        p.wstream = (const char*)net->pipe_c.data.p;
         p.nchunks = net->pipe_chunks[precision];
-        p.wscale = (const unsigned*)net->wscale_c.p;
+        p.wscale = (const unsigned*)net->pipe_c.scales.p;
         return nerf_mlp_c_dispatch(net->W, net->D, net->skip, p, as_stream(stream));
     }
     if (piped) return nerf_mlp_pipe_dispatch(precision, p, as_stream(stream));

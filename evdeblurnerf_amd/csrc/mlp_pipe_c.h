@@ -82,7 +82,7 @@ template <int NCH> struct CStream {
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
                      "global_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\t"
                      "global_load_lds_dwordx4 %0, %1 offset:2048\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072"
-                     : : "v"(off), "s"(gbase), "s"(dst) : "memory", "m0");
+                     : : "v"(off), "s"(gbase), "s"(dst) : "memory");      // M0 is left changed: hipcc keeps nothing in M0 in this kernel (no other user)
     }
     // wait until at most `chunks` chunks (PIECES loads each) of this wavefront are outstanding
     static __device__ __forceinline__ void wait_chunks(int chunks) {

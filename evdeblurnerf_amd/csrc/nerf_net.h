@@ -16,7 +16,7 @@ struct evd_nerf {
     Packed pipe[EVD_NUM_PREC];               // software-pipelined kernel (where built): its own fragment order and chunking
     int pipe_chunks[EVD_NUM_PREC];
     evd::DevBuf bias, bias_src;
-    evd::DevBuf wscale_c;                    // EVD_PREC_F16C: row-scale words of the fp6 weight operands, 32 per output tile in bias order
+    evd::PackedStreamC pipe_c;               // EVD_PREC_F16C: float16 + fp6 fragment stream, row-scale words (32 per output tile in bias order), re-pack maps
     Packed bwd[EVD_NUM_PREC][EVD_BWD_NSTREAMS];   // training (bf16 / f16, 8 x 256): W^T streams; HIDDEN1 + l - 1 = pts_linears[l]
     evd::DevBuf wmaps;                       // wgrad index maps (int32), nerf_train.h
     int nparam_blocks;                       // 2 D + 8 parameter tensors, canonical order (evd_api.hip: nerf_param_sizes)

@@ -134,23 +134,48 @@ __host__ __device__ static inline float e8m0_value(int byte) { return ldexpf(1.f
 __host__ __device__ constexpr int c_pos_kstep(int kind, int i) { return kind == 0 ? (i >> 3) : 2 * (i & 1) + (i >> 4); }
 __host__ __device__ constexpr int c_pos_elem(int kind, int i) { return kind == 0 ? (i & 7) : ((i >> 1) & 7); }
 
+// one lane's 32 values of an fp6 operand (kind 0: the float16 rounding residuals of the weights, kind 1: the weights) -> 24 packed bytes,
+// the first 16 at lo16, the last 8 at hi8; shared by the host packer and the device re-packer
+__host__ __device__ static inline void c_pack_operand(int kind, const float* w, int scale_byte, uint8_t* lo16, uint8_t* hi8) {
+    const float s = e8m0_value(scale_byte);
+    uint32_t words[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 32; ++i) {
+        const float v = kind == 0 ? w[i] - (float)(_Float16)w[i] : w[i];
+        const uint32_t code = (uint32_t)e2m3_code(v / s);
+        const int bit = 6 * i;
+        words[bit >> 5] |= code << (bit & 31);
+        if ((bit & 31) > 26) words[(bit >> 5) + 1] |= code >> (32 - (bit & 31));
+    }
+    for (int q = 0; q < 4; ++q) reinterpret_cast<uint32_t*>(lo16)[q] = words[q];
+    reinterpret_cast<uint32_t*>(hi8)[0] = words[4];
+    reinterpret_cast<uint32_t*>(hi8)[1] = words[5];
+}
+
 struct StreamBuilderC {
     size_t cb;
     std::vector<uint8_t> bytes;
     std::vector<uint32_t> scales;   // per output tile (stream order) 32 words: byte 0 = scale of the Wl operand of that row, byte 1 = of the W operand
+    // for the device re-pack (repack_stream_c): where every element comes from in the parameter arena (-1: zero) and where it goes
+    const float* arena = nullptr;
+    std::vector<int32_t> main_src;  // [float16 fragment][lane][8]
+    std::vector<uint32_t> main_dst; // byte offset of each float16 fragment
+    std::vector<int32_t> op_src;    // [fp6 operand][lane][32]
+    std::vector<uint32_t> op_meta;  // per fp6 operand: byte offset of its 16-byte parts, of its 8-byte parts, first scale word of its tile, kind
     explicit StreamBuilderC(size_t chunk) : cb(chunk) {}
     // One layer: groups of G tiles; per group, per block of <= 4 k-steps:  [float16 fragments: k-step major, tile minor]
     // [first 16 bytes per lane of the fp6 operands: kind major, tile minor][last 8 bytes per lane: kind major, tile minor]; zero-padded
     // to a chunk boundary at the end.  row(tile, r) -> source row or -1; col(j, kk) -> source column or -1; at(row, col) -> address or null.
     template <class RowFn, class ColFn, class AtFn>
     void layer_at(int tiles, int ksteps, int G, RowFn row, ColFn col, AtFn at) {
-        auto wt = [&](int tile, int r, int j, int kk) -> float {
-            if (j >= ksteps) return 0.f;
+        auto wp = [&](int tile, int r, int j, int kk) -> const float* {
+            if (j >= ksteps) return nullptr;
             const int rr = row(tile, r), c = col(j, kk);
-            const float* w = (rr >= 0 && c >= 0) ? at(rr, c) : nullptr;
-            return w ? *w : 0.f;
+            return (rr >= 0 && c >= 0) ? at(rr, c) : nullptr;
         };
+        auto wt = [&](int tile, int r, int j, int kk) -> float { const float* w = wp(tile, r, j, kk); return w ? *w : 0.f; };
+        auto idx = [&](const float* w) -> int32_t { return (w && arena) ? (int32_t)(w - arena) : -1; };
         const int nblk = (ksteps + 3) / 4;
+        const uint32_t scale0 = (uint32_t)scales.size();       // first scale word of this layer
         // row scales over the whole layer
         std::vector<int> sc((size_t)tiles * 32 * 2);
         for (int tile = 0; tile < tiles; ++tile)
@@ -173,28 +198,34 @@ struct StreamBuilderC {
                     for (int t = 0; t < G; ++t) {
                         const size_t base = bytes.size();
                         bytes.resize(base + 1024, 0);
+                        main_dst.push_back((uint32_t)base);
                         for (int l = 0; l < 64; ++l)
-                            for (int e = 0; e < 8; ++e)
+                            for (int e = 0; e < 8; ++e) {
                                 *reinterpret_cast<_Float16*>(bytes.data() + base + l * 16 + e * 2) = (_Float16)wt(p * G + t, l & 31, 4 * b + jj, 8 * (l >> 5) + e);
+                                main_src.push_back(idx(wp(p * G + t, l & 31, 4 * b + jj, 8 * (l >> 5) + e)));
+                            }
                     }
                 const size_t lo = bytes.size(), hi = lo + (size_t)2 * G * 1024;
                 bytes.resize(hi + (size_t)2 * G * 512, 0);
                 for (int kind = 0; kind < 2; ++kind)
-                    for (int t = 0; t < G; ++t)
+                    for (int t = 0; t < G; ++t) {
+                        const int tile = p * G + t;
+                        op_meta.push_back((uint32_t)(lo + (size_t)(kind * G + t) * 1024));
+                        op_meta.push_back((uint32_t)(hi + (size_t)(kind * G + t) * 512));
+                        op_meta.push_back(scale0 + (uint32_t)tile * 32);
+                        op_meta.push_back((uint32_t)kind);
                         for (int l = 0; l < 64; ++l) {
-                            const int tile = p * G + t, r = l & 31, h = l >> 5;
-                            const float s = e8m0_value(sc[(tile * 32 + r) * 2 + kind]);
-                            uint8_t packed[24] = {0};
+                            const int r = l & 31, h = l >> 5;
+                            float v[32];
                             for (int i = 0; i < 32; ++i) {
-                                const float w = wt(tile, r, 4 * b + c_pos_kstep(kind, i), 8 * h + c_pos_elem(kind, i));
-                                const float v = kind == 0 ? w - (float)(_Float16)w : w;
-                                const int code = e2m3_code(v / s);
-                                for (int q = 0; q < 6; ++q)
-                                    if ((code >> q) & 1) packed[(6 * i + q) >> 3] |= (uint8_t)(1u << ((6 * i + q) & 7));
+                                const float* w = wp(tile, r, 4 * b + c_pos_kstep(kind, i), 8 * h + c_pos_elem(kind, i));
+                                v[i] = w ? *w : 0.f;
+                                op_src.push_back(idx(w));
                             }
-                            memcpy(bytes.data() + lo + (size_t)(kind * G + t) * 1024 + l * 16, packed, 16);
-                            memcpy(bytes.data() + hi + (size_t)(kind * G + t) * 512 + l * 8, packed + 16, 8);
+                            c_pack_operand(kind, v, sc[(tile * 32 + r) * 2 + kind], bytes.data() + lo + (size_t)(kind * G + t) * 1024 + l * 16,
+                                           bytes.data() + hi + (size_t)(kind * G + t) * 512 + l * 8);
                         }
+                    }
             }
         bytes.resize(cdiv((long)bytes.size(), (long)cb) * cb, 0);
     }
@@ -204,6 +235,76 @@ struct StreamBuilderC {
                  [=](int r, int c) { return c < in_dim ? Wm + (size_t)r * in_dim + c : nullptr; });
     }
 };
+
+// the compensated-float16 stream on the device with everything its re-pack from new parameter values needs
+struct PackedStreamC {
+    DevBuf data, scales, main_src, main_dst, op_src, op_meta, rowmax;
+    long nmain = 0, nops = 0, nrows = 0;
+    void release() { data.release(); scales.release(); main_src.release(); main_dst.release(); op_src.release(); op_meta.release(); rowmax.release(); }
+    int upload(const StreamBuilderC& sb) {
+        nmain = (long)sb.main_dst.size(); nops = (long)sb.op_meta.size() / 4; nrows = (long)sb.scales.size();
+        int rc = data.upload(sb.bytes.data(), sb.bytes.size());
+        if (!rc) rc = scales.upload(sb.scales.data(), sb.scales.size() * sizeof(uint32_t));
+        if (!rc) rc = main_src.upload(sb.main_src.data(), sb.main_src.size() * sizeof(int32_t));
+        if (!rc) rc = main_dst.upload(sb.main_dst.data(), sb.main_dst.size() * sizeof(uint32_t));
+        if (!rc) rc = op_src.upload(sb.op_src.data(), sb.op_src.size() * sizeof(int32_t));
+        if (!rc) rc = op_meta.upload(sb.op_meta.data(), sb.op_meta.size() * sizeof(uint32_t));
+        if (!rc) rc = rowmax.alloc((size_t)nrows * 2 * sizeof(float));
+        return rc;
+    }
+};
+
+static __global__ void k_c_main(const float* __restrict__ arena, const int* __restrict__ src, const uint32_t* __restrict__ fdst, long n, uint8_t* __restrict__ dst) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int s = src[i];
+    *reinterpret_cast<_Float16*>(dst + fdst[i >> 9] + ((i >> 3) & 63) * 16 + (i & 7) * 2) = (_Float16)(s < 0 ? 0.f : arena[s]);
+}
+// thread = (operand, lane): maxima of the lane's 32 values into the row's slot (non-negative floats order like their bit patterns)
+static __global__ void k_c_rowmax(const float* __restrict__ arena, const int* __restrict__ src, const uint32_t* __restrict__ meta, long n, unsigned* __restrict__ rowmax) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long op = i >> 6;
+    const int lane = (int)(i & 63), kind = (int)meta[op * 4 + 3];
+    float m = 0.f;
+    for (int e = 0; e < 32; ++e) {
+        const int s = src[i * 32 + e];
+        const float w = s < 0 ? 0.f : arena[s];
+        m = fmaxf(m, fabsf(kind == 0 ? w - (float)(_Float16)w : w));
+    }
+    atomicMax(rowmax + ((long)meta[op * 4 + 2] + (lane & 31)) * 2 + kind, __float_as_uint(m));
+}
+static __global__ void k_c_scales(const unsigned* __restrict__ rowmax, long nrows, uint32_t* __restrict__ scales) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < nrows) scales[i] = (uint32_t)e8m0_for_max(__uint_as_float(rowmax[2 * i])) | ((uint32_t)e8m0_for_max(__uint_as_float(rowmax[2 * i + 1])) << 8);
+}
+static __global__ void k_c_ops(const float* __restrict__ arena, const int* __restrict__ src, const uint32_t* __restrict__ meta, const uint32_t* __restrict__ scales, long n,
+                               uint8_t* __restrict__ dst) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long op = i >> 6;
+    const int lane = (int)(i & 63), kind = (int)meta[op * 4 + 3];
+    float w[32];
+    for (int e = 0; e < 32; ++e) {
+        const int s = src[i * 32 + e];
+        w[e] = s < 0 ? 0.f : arena[s];
+    }
+    const int sb = (int)((scales[meta[op * 4 + 2] + (lane & 31)] >> (8 * kind)) & 255u);
+    c_pack_operand(kind, w, sb, dst + meta[op * 4] + lane * 16, dst + meta[op * 4 + 1] + lane * 8);
+}
+// re-pack the compensated-float16 stream and its row scales on the device from new parameter values (stream-ordered, no host sync)
+static inline int repack_stream_c(PackedStreamC& s, const float* params, hipStream_t st) {
+    if (!s.data.p) return EVD_OK;
+    EVD_HIP(hipMemsetAsync(s.rowmax.p, 0, s.rowmax.bytes, st));
+    const long nm = s.nmain * 512, no = s.nops * 64;
+    hipLaunchKernelGGL(k_c_main, dim3((unsigned)cdiv(nm, 256L)), dim3(256), 0, st, params, (const int*)s.main_src.p, (const uint32_t*)s.main_dst.p, nm, (uint8_t*)s.data.p);
+    hipLaunchKernelGGL(k_c_rowmax, dim3((unsigned)cdiv(no, 256L)), dim3(256), 0, st, params, (const int*)s.op_src.p, (const uint32_t*)s.op_meta.p, no, (unsigned*)s.rowmax.p);
+    hipLaunchKernelGGL(k_c_scales, dim3((unsigned)cdiv(s.nrows, 256L)), dim3(256), 0, st, (const unsigned*)s.rowmax.p, s.nrows, (uint32_t*)s.scales.p);
+    hipLaunchKernelGGL(k_c_ops, dim3((unsigned)cdiv(no, 256L)), dim3(256), 0, st, params, (const int*)s.op_src.p, (const uint32_t*)s.op_meta.p, (const uint32_t*)s.scales.p, no,
+                       (uint8_t*)s.data.p);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
 
 // a packed fragment stream on the device and, per element, the index of its source in the parameter arena (-1: zero)
 struct PackedStream {
