@@ -250,14 +250,20 @@ def c2f_leg(precision, steps):
     algo = n * (taps * esz + 12 + 4 * fine.app_dim)             # + the point in, app_dim floats out
     out = {"workload": "blurfactory c2f render: 4096 rays x (64 coarse + 64 importance) samples, grids 293x293x195 / 586x586x390, n_comp (64,16,16)",
            "precision": precision, "ms_per_step": step_ms, "rays_per_s": R / (step_ms * 1e-3),
-           "roofline": {"kernel": "k_voxel_sample (fine level, 4096 x 128 samples)", "bound": "hbm", "kernel_ms": g_ms,
+           "roofline": {"kernel": "k_voxel_sample_w (fine level, 4096 x 128 samples)", "bound": "hbm", "kernel_ms": g_ms,
                         "algorithmic_bytes": algo, "bytes_per_sample": algo / n, "achieved": algo / (g_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": algo / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "frac_of_l2_peak": algo / (g_ms * 1e-3) / 1e9 / L2_PEAK_GBS,
+                        "pmc": {"source": "profiles/r02_pmc_voxel.txt (tools/pmc_voxel.sh, f16 grids, per launch of 524 288 samples)",
+                                "l2_requests_per_sample": 10.2, "l2_miss_lines_per_sample": 3.8, "fetch_size_bytes_per_sample": 346,
+                                "gather_ceiling_lines_per_s": {"l2_resident": 146e9, "infinity_cache": 58e9, "hbm": 54e9,
+                                                               "probe": "tools/probes/gather_probe.hip (128-byte records, 16-byte lane loads)"}},
                         "note": "algorithmic bytes = 576 gathered grid values (4 taps x 96 plane channels + 2 taps x 96 line channels) x the "
                                 "grid element size + the point in + 32 floats out, per sample; the fine grids (41 M values) exceed the 32 MB of "
-                                "L2 and sit in the 256 MB Infinity Cache, so the bound is the cache-line gather rate, quoted against both the "
-                                "HBM and the aggregate-L2 peak; counted FETCH_SIZE / TCC hits: profiles/ (tools/pmc_voxel.sh)"}}
+                                "L2 and sit in the 256 MB Infinity Cache.  Counted (PMC): 10.2 L2 line requests per sample of which 3.8 miss to "
+                                "the Infinity Cache; at this launch duration that is ~45 G lines/s at L2 and ~16 G lines/s behind it, 30 % resp. "
+                                "28 % of what a bare random gather of 128-byte records sustains on this chip -- the kernel is a latency chain "
+                                "(points -> tap geometry -> gather -> basis GEMM -> store) per wavefront, not bandwidth-bound (DESIGN.md 3.3)"}}
     return out, model
 
 

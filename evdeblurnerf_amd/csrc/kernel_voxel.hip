@@ -52,6 +52,7 @@ constexpr int VS_MAXC = 128;        // max sum(n_comp)
 // Phase 2 (basis_mat, voxnerf.py:151): out^T[f, sample] = basis[f, :] . coef[sample, :] for the block's 32 samples on
 // the exact-float32 MFMA (v_mfma_f32_32x32x2_f32 = an fmaf chain in k order), by wavefront 0 of the block.
 constexpr int VS_STRIDE = VS_MAXC + 1;      // odd row stride: conflict-free column reads in phase 2
+static_assert(VS_SAMPLES * VS_STRIDE >= 3 * 16 * 64 + 32 * 33, "the coefficient array doubles as the reduction buffer + output tile");
 
 struct VsItem {
     f32x4 p[4], l[2];
@@ -147,44 +148,206 @@ __device__ __forceinline__ f32x4 vs_finish(const VsItem& it, f32x4* pv_out = nul
     return cf;
 }
 
-template <bool HALF>
-__global__ __launch_bounds__(256) void k_voxel_sample(const GridParams g, const float* __restrict__ pts, long n,
+// Tap geometry of one sample in one of its three components (plane i x line i): element offsets of channel 0 and the interpolation
+// weights of the 4 plane taps and the 2 line taps.  Computed ONCE per (sample, component) by the forward gather's phase 0 and shared
+// through LDS by the component's channel groups -- the first version recomputed it in every (sample, channel group) item: 320 VALU
+// instructions per item, the kernel was VALU-bound (PMC: profiles/r02_pmc_voxel.txt).  Same formulas, same order as vs_issue.
+struct VsTaps {
+    long ip[4], il[2];
+    float wp[4], wl[2];
+};
+
+__device__ __forceinline__ void vs_geometry(const GridParams& g, const float (&pt)[3], int i, VsTaps& tp) {
+    float xyz[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) xyz[c] = __fsub_rn(__fmul_rn(__fsub_rn(pt[c], g.aabb_min[c]), g.inv[c]), 1.f);   // voxnerf.py:205
+    const int C = sel3(i, g.n_comp[0], g.n_comp[1], g.n_comp[2]);
+    const int Wp = sel3(i, g.grid[0], g.grid[0], g.grid[1]);          // grid[mat0[i]]
+    const int Hp = sel3(i, g.grid[1], g.grid[2], g.grid[2]);          // grid[mat1[i]]
+    const int Lp = sel3(i, g.grid[2], g.grid[1], g.grid[0]);          // grid[vec[i]]
+    const float cx = sel3(i, xyz[0], xyz[0], xyz[1]), cy = sel3(i, xyz[1], xyz[2], xyz[2]), cl = sel3(i, xyz[2], xyz[1], xyz[0]);
+    const float ix = unnorm(cx, Wp), iy = unnorm(cy, Hp);
+    const float fx = fminf(fmaxf(floorf(ix), -2.f), (float)Wp), fy = fminf(fmaxf(floorf(iy), -2.f), (float)Hp);
+    const float ww = __fsub_rn(ix, floorf(ix)), ee = __fsub_rn(1.f, ww), nn = __fsub_rn(iy, floorf(iy)), ss = __fsub_rn(1.f, nn);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const bool vx0 = x0 >= 0 && x0 < Wp, vx1 = x1 >= 0 && x1 < Wp, vy0 = y0 >= 0 && y0 < Hp, vy1 = y1 >= 0 && y1 < Hp;
+    const int cx0 = min(max(x0, 0), Wp - 1), cx1 = min(max(x1, 0), Wp - 1), cy0 = min(max(y0, 0), Hp - 1), cy1 = min(max(y1, 0), Hp - 1);
+    tp.ip[0] = ((long)cy0 * Wp + cx0) * C;
+    tp.ip[1] = ((long)cy0 * Wp + cx1) * C;
+    tp.ip[2] = ((long)cy1 * Wp + cx0) * C;
+    tp.ip[3] = ((long)cy1 * Wp + cx1) * C;
+    tp.wp[0] = (vy0 && vx0) ? __fmul_rn(ee, ss) : 0.f;
+    tp.wp[1] = (vy0 && vx1) ? __fmul_rn(ww, ss) : 0.f;
+    tp.wp[2] = (vy1 && vx0) ? __fmul_rn(ee, nn) : 0.f;
+    tp.wp[3] = (vy1 && vx1) ? __fmul_rn(ww, nn) : 0.f;
+    const float il = unnorm(cl, Lp);
+    const float fl = fminf(fmaxf(floorf(il), -2.f), (float)Lp);
+    const float ln = __fsub_rn(il, floorf(il)), ls = __fsub_rn(1.f, ln);
+    const int l0 = (int)fl, l1 = l0 + 1;
+    tp.il[0] = (long)min(max(l0, 0), Lp - 1) * C;
+    tp.il[1] = (long)min(max(l1, 0), Lp - 1) * C;
+    tp.wl[0] = (l0 >= 0 && l0 < Lp) ? ls : 0.f;
+    tp.wl[1] = (l1 >= 0 && l1 < Lp) ? ln : 0.f;
+}
+
+// GC channels per work item (4, or 8 when every n_comp is a multiple of 8): the gather is bound by the rate at which the texture
+// path takes lane addresses (PMC: TCP_TOTAL_CACHE_ACCESSES = one per lane and load; 1171 per wavefront, 300 k cycles per CU), so
+// the wider the per-lane load, the fewer of them: 8 float16 channels = one 16-byte load per tap.
+#ifdef EVD_VS_TRACE
+__device__ long long evd_vs_trace[8 * 8192];
+#define VS_STAMP(k) if (threadIdx.x == 0 && blockIdx.x < 8192) evd_vs_trace[blockIdx.x * 8 + (k)] = (long long)__builtin_readcyclecounter()
+extern "C" int evd_debug_vs_trace(long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(evd_vs_trace), sizeof(evd_vs_trace)); }
+#else
+#define VS_STAMP(k)
+#endif
+#ifndef EVD_VS_WAVES
+#define EVD_VS_WAVES 4
+#endif
+template <bool HALF, int GC>
+__global__ __launch_bounds__(256, EVD_VS_WAVES) void k_voxel_sample(const GridParams g, const float* __restrict__ pts, long n,
                                                       float* __restrict__ out, int out_stride, int out_col) {
     __shared__ __attribute__((aligned(16))) float coef[VS_SAMPLES * VS_STRIDE];
+    __shared__ __attribute__((aligned(16))) VsTaps taps[VS_SAMPLES * 3];
+    constexpr int NV = GC / 4;                   // 4-channel vectors per item
     const int ctot = g.n_comp[0] + g.n_comp[1] + g.n_comp[2];
-    const int ng = ctot / 4;
+    const int ng = ctot / GC;
     const long s0 = blockIdx.x * (long)VS_SAMPLES;
     const int items = VS_SAMPLES * ng;
-    constexpr int UNR = 3;                       // 32 samples x 24 groups = 3 items per thread for n_comp (64,16,16)
+    VS_STAMP(0);
+    // phase 2's operand, fetched first so that its latency hides behind the gather: the basis_mat GEMM of the block's 32 samples is
+    // split along k over the four wavefronts (a quarter of the components each), every lane keeps its <= 16 basis values in registers
+    const bool ksplit = g.app_dim <= 32 && ctot % 8 == 0;
+    const int wv = threadIdx.x >> 6, kq = ctot / 4;
+    float bq[VS_MAXC / 8];
+    if (ksplit) {
+        const int lane = threadIdx.x & 63, frow = min(lane & 31, g.app_dim - 1);
+        const float* bw = g.basis + (long)frow * ctot + wv * kq + (lane >> 5);
+#pragma unroll
+        for (int j = 0; j < VS_MAXC / 8; ++j) bq[j] = 2 * j < kq ? bw[2 * j] : 0.f;
+    }
+    if (threadIdx.x < VS_SAMPLES * 3) {          // phase 0: the tap geometry of every (sample, component) of the block, once
+        const int sl = threadIdx.x / 3, i = threadIdx.x % 3;
+        const long s = s0 + sl < n ? s0 + sl : n - 1;
+        const float pt[3] = {pts[s * 3], pts[s * 3 + 1], pts[s * 3 + 2]};
+        VsTaps tp;
+        vs_geometry(g, pt, i, tp);
+        taps[threadIdx.x] = tp;
+    }
+    __syncthreads();
+    VS_STAMP(1);
+    constexpr int UNR = GC == 8 ? 2 : 3;         // n_comp (64,16,16): 32 samples x 12 (24) groups = 1.5 (3) items per thread
     for (int base = threadIdx.x; base < items; base += UNR * 256) {
-        VsItem it[UNR];
+        VsItem it[UNR][NV];
         int sl[UNR], grp[UNR];
         bool on[UNR];
-        float pt[UNR][3];
 #pragma unroll
-        for (int q = 0; q < UNR; ++q) {             // the points of all items first: the tap addresses depend on them
+        for (int q = 0; q < UNR; ++q) {             // all tap loads of the thread's items in flight together
             const int t = base + q * 256;
             on[q] = t < items;
             sl[q] = on[q] ? t / ng : 0;
             grp[q] = on[q] ? t % ng : 0;
-            const long s = s0 + sl[q] < n ? s0 + sl[q] : n - 1;
+            int i = 0, c4 = grp[q] * GC;
+            if (c4 >= g.n_comp[0]) { c4 -= g.n_comp[0]; i = 1; if (c4 >= g.n_comp[1]) { c4 -= g.n_comp[1]; i = 2; } }
+            const VsTaps& tp = taps[sl[q] * 3 + i];
+            const float* pl = sel3(i, g.plane[0], g.plane[1], g.plane[2]) + c4;
+            const _Float16* plh = sel3(i, g.plane_h[0], g.plane_h[1], g.plane_h[2]) + c4;
+            const float* li = sel3(i, g.line[0], g.line[1], g.line[2]) + c4;
+            const _Float16* lih = sel3(i, g.line_h[0], g.line_h[1], g.line_h[2]) + c4;
+#ifdef EVD_VS_ABL_NOLOAD
+            const long zero_ = (long)(threadIdx.x & 0);
+#define VS_IDX(x) (zero_ + ((x) & 0))
+#else
+#define VS_IDX(x) (x)
+#endif
+            if (HALF && GC == 8) {                  // one 16-byte load per tap
+                typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
 #pragma unroll
-            for (int c = 0; c < 3; ++c) pt[q][c] = pts[s * 3 + c];
+                for (int k = 0; k < 4; ++k) {
+                    const f16x8v v = *reinterpret_cast<const f16x8v*>(plh + VS_IDX(tp.ip[k]));
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) it[q][e >> 2].p[k][e & 3] = (float)v[e];
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const f16x8v v = *reinterpret_cast<const f16x8v*>(lih + VS_IDX(tp.il[k]));
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) it[q][e >> 2].l[k][e & 3] = (float)v[e];
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) it[q][v].p[k] = vs_load<HALF>(pl, plh, tp.ip[k] + 4 * v);
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) it[q][v].l[k] = vs_load<HALF>(li, lih, tp.il[k] + 4 * v);
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) it[q][v].wp[k] = tp.wp[k];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) it[q][v].wl[k] = tp.wl[k];
+            }
         }
 #pragma unroll
-        for (int q = 0; q < UNR; ++q) vs_issue<HALF>(g, pt[q], grp[q], it[q]);      // then all 18 tap loads in flight together
-        // (a sched_barrier here keeps all 18 loads of the thread in flight but costs a wavefront of occupancy: measured 6 % slower)
-#pragma unroll
         for (int q = 0; q < UNR; ++q) {
-            const f32x4 cf = vs_finish(it[q]);
-            if (on[q]) {
-                float* dst = &coef[sl[q] * VS_STRIDE + grp[q] * 4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) dst[k] = cf[k];
+            for (int v = 0; v < NV; ++v) {
+                const f32x4 cf = vs_finish(it[q][v]);
+                if (on[q]) {
+                    float* dst = &coef[sl[q] * VS_STRIDE + grp[q] * GC + 4 * v];      // odd row stride: scalar stores
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) dst[k] = cf[k];
+                }
             }
         }
     }
+    VS_STAMP(2);
     __syncthreads();
+    VS_STAMP(3);
+#ifdef EVD_VS_ABL_NOPHASE2
+    if (threadIdx.x < 32 && s0 + threadIdx.x < n) out[(s0 + threadIdx.x) * (long)out_stride + out_col] = coef[threadIdx.x * VS_STRIDE];
+    return;
+#endif
+    if (ksplit) {
+        const int lane = threadIdx.x & 63, col = lane & 31, hh = lane >> 5;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* cf = coef + col * VS_STRIDE + wv * kq + hh;
+#pragma unroll
+        for (int j = 0; j < VS_MAXC / 8; ++j)
+            if (2 * j < kq) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[j], cf[2 * j], acc, 0, 0, 0);
+        VS_STAMP(4);
+        __syncthreads();                         // every wavefront has read its coefficients: the array becomes the reduction buffer
+        if (wv > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) coef[((wv - 1) * 16 + r) * 64 + lane] = acc[r];
+        }
+        __syncthreads();
+        // wavefront 0 sums the four partial tiles, applies the activation and transposes the tile through LDS; then ALL threads store:
+        // a lane per (sample, feature), 128-byte runs per sample row (the rows of the level's input matrix are 380 / 508 bytes apart:
+        // stored straight from the accumulator layout they were 16.8 M scattered 4-byte writes per launch -- 100 us of a 160 us kernel)
+        float* ot = coef + 3 * 16 * 64;           // [32 samples][33]
+        if (wv == 0) {
+#pragma unroll
+            for (int w = 0; w < 3; ++w)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] += coef[(w * 16 + r) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[col * 33 + (r & 3) + 8 * (r >> 2) + 4 * hh] = act(g.app_act, acc[r]);
+        }
+        VS_STAMP(5);
+        __syncthreads();
+        VS_STAMP(6);
+        for (int t = threadIdx.x; t < VS_SAMPLES * 32; t += 256) {
+            const int sl = t >> 5, f = t & 31;
+            if (s0 + sl < n && f < g.app_dim) out[(s0 + sl) * (long)out_stride + out_col + f] = ot[sl * 33 + f];
+        }
+        VS_STAMP(7);
+        return;
+    }
     if (threadIdx.x >= 64) return;
     const int lane = threadIdx.x, col = lane & 31, hh = lane >> 5;
     for (int f0 = 0; f0 < g.app_dim; f0 += 32) {
@@ -213,6 +376,169 @@ __global__ __launch_bounds__(256) void k_voxel_sample(const GridParams g, const 
             }
         }
     }
+}
+
+// Wavefront-autonomous form of the gather (the one the shipped levels run: every n_comp a multiple of 8, app_dim <= 32).
+// PMC + in-kernel stamps of the block-cooperative kernel above (profiles/r02_pmc_voxel.txt): it is neither bandwidth- nor VALU-bound
+// but a chain of latencies separated by block barriers (points -> geometry | barrier | gather | barrier | basis GEMM | barrier | reduce |
+// barrier | store: 22 k cycles per 32 samples, 4 blocks per CU) -- with L2-resident toy grids it runs at the same speed.  Here a
+// WAVEFRONT owns 16 samples from the point load to the store and never waits for another wavefront: geometry of its 48 (sample,
+// component) pairs on 48 lanes -> its own LDS slice -> 3 items per lane (16 samples x 12 groups of 8 channels, 18 16-byte loads in
+// flight) -> coefficients in LDS -> out^T = basis . coef^T on v_mfma_f32_16x16x4_f32 (2 feature tiles x ctot / 4 steps) -> transposed
+// through LDS -> 128-byte runs per sample row.  The 4 wavefronts of a SIMD run their chains independently, so one wavefront's
+// matrix work and stores overlap the others' gathers.
+constexpr int VW_SAMPLES = 16;                  // samples per wavefront
+constexpr int VW_WAVES = 4;                     // wavefronts per block
+// LDS slice of one wavefront: tap table, then the coefficient rows [16][ctot + 1] (later the output tile [16][33])
+__host__ __device__ constexpr size_t vw_basis_bytes(int ctot) { return (size_t)32 * (ctot + 1) * 4 + 16 - ((size_t)32 * (ctot + 1) * 4) % 16; }
+__host__ __device__ constexpr size_t vw_slice_bytes(int ctot) { return ((VW_SAMPLES * 3 * sizeof(VsTaps) + (size_t)VW_SAMPLES * (ctot + 1 > 33 ? ctot + 1 : 33) * 4) + 15) & ~(size_t)15; }
+template <bool HALF>
+__global__ __launch_bounds__(64 * VW_WAVES) void k_voxel_sample_w(const GridParams g, const float* __restrict__ pts, long n,
+                                                                float* __restrict__ out, int out_stride, int out_col) {
+    extern __shared__ __attribute__((aligned(16))) char vw_smem[];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ctot = g.n_comp[0] + g.n_comp[1] + g.n_comp[2];
+    const int cstride = ctot + 1;                // odd row stride (ctot is a multiple of 8): conflict-free column reads of the GEMM
+    float* bs = reinterpret_cast<float*>(vw_smem);                       // basis_mat [32][ctot + 1], shared by the block
+    char* slice = vw_smem + vw_basis_bytes(ctot) + (size_t)wv * vw_slice_bytes(ctot);
+    VsTaps* taps = reinterpret_cast<VsTaps*>(slice);
+    float* coef = reinterpret_cast<float*>(slice + VW_SAMPLES * 3 * sizeof(VsTaps));
+    const int ng = ctot / 8;
+    const long s0 = ((long)blockIdx.x * VW_WAVES + wv) * VW_SAMPLES;
+    // basis_mat -> LDS: the loads are issued first and land while the geometry is computed
+    constexpr int NBV = (32 * VS_MAXC / 4 + 64 * VW_WAVES - 1) / (64 * VW_WAVES);
+    f32x4 bv[NBV];
+    const int nb4 = g.app_dim * ctot / 4;
+#pragma unroll
+    for (int q = 0; q < NBV; ++q) {
+        const int i4 = threadIdx.x + q * 64 * VW_WAVES;
+        bv[q] = i4 < nb4 ? *reinterpret_cast<const f32x4*>(g.basis + 4 * i4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    VS_STAMP(0);
+    if (s0 < n && lane < VW_SAMPLES * 3) {       // geometry of this wavefront's (sample, component) pairs
+        const int sl = lane / 3, i = lane % 3;
+        const long s = s0 + sl < n ? s0 + sl : n - 1;
+        const float pt[3] = {pts[s * 3], pts[s * 3 + 1], pts[s * 3 + 2]};
+        VsTaps tp;
+        vs_geometry(g, pt, i, tp);
+        taps[lane] = tp;
+    }
+#pragma unroll
+    for (int q = 0; q < NBV; ++q) {
+        const int i4 = threadIdx.x + q * 64 * VW_WAVES;
+        if (i4 < nb4) {
+            const int f = (4 * i4) / ctot, c = (4 * i4) % ctot;      // ctot is a multiple of 4: the 4 values stay in one row
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bs[f * cstride + c + e] = bv[q][e];
+        }
+    }
+    __syncthreads();                             // the only block-wide barrier: basis_mat visible (also orders the tap tables)
+    if (s0 >= n) return;
+    VS_STAMP(1);
+    const int items = VW_SAMPLES * ng;
+    typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+    constexpr int UNR = 3;                       // 16 samples x 12 groups = 3 items per lane
+    constexpr int NRAW = HALF ? 1 : 2;           // 16-byte loads per tap
+    for (int base = lane; base < items; base += UNR * 64) {
+        f32x4 rawp[UNR][4][NRAW], rawl[UNR][2][NRAW];    // the taps as loaded (float16 x 8 in one f32x4 register quad, or 2 x float32 x 4)
+        int sl[UNR], grp[UNR], comp[UNR];
+        bool on[UNR];
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) {
+            const int t = base + q * 64;
+            on[q] = t < items;
+            sl[q] = on[q] ? t / ng : 0;
+            grp[q] = on[q] ? t % ng : 0;
+            int i = 0, c8 = grp[q] * 8;
+            if (c8 >= g.n_comp[0]) { c8 -= g.n_comp[0]; i = 1; if (c8 >= g.n_comp[1]) { c8 -= g.n_comp[1]; i = 2; } }
+            comp[q] = i;
+            const VsTaps& tp = taps[sl[q] * 3 + i];
+            if (HALF) {
+                const _Float16* plh = sel3(i, g.plane_h[0], g.plane_h[1], g.plane_h[2]) + c8;
+                const _Float16* lih = sel3(i, g.line_h[0], g.line_h[1], g.line_h[2]) + c8;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) rawp[q][k][0] = *reinterpret_cast<const f32x4*>(plh + tp.ip[k]);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) rawl[q][k][0] = *reinterpret_cast<const f32x4*>(lih + tp.il[k]);
+            } else {
+                const float* pl = sel3(i, g.plane[0], g.plane[1], g.plane[2]) + c8;
+                const float* li = sel3(i, g.line[0], g.line[1], g.line[2]) + c8;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int v = 0; v < NRAW; ++v) rawp[q][k][v] = *reinterpret_cast<const f32x4*>(pl + tp.ip[k] + 4 * v);
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int v = 0; v < NRAW; ++v) rawl[q][k][v] = *reinterpret_cast<const f32x4*>(li + tp.il[k] + 4 * v);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) {
+            const VsTaps& tp = taps[sl[q] * 3 + comp[q]];
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                VsItem it;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (HALF) {
+                        const f16x8v h8 = __builtin_bit_cast(f16x8v, rawp[q][k][0]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) it.p[k][e] = (float)h8[4 * v + e];
+                    } else {
+                        it.p[k] = rawp[q][k][HALF ? 0 : v];
+                    }
+                    it.wp[k] = tp.wp[k];
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    if (HALF) {
+                        const f16x8v h8 = __builtin_bit_cast(f16x8v, rawl[q][k][0]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) it.l[k][e] = (float)h8[4 * v + e];
+                    } else {
+                        it.l[k] = rawl[q][k][HALF ? 0 : v];
+                    }
+                    it.wl[k] = tp.wl[k];
+                }
+                const f32x4 cf = vs_finish(it);
+                if (on[q]) {
+                    float* dst = &coef[sl[q] * cstride + grp[q] * 8 + 4 * v];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) dst[k] = cf[k];
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // this wavefront's LDS writes before its own reads: program order
+    __builtin_amdgcn_wave_barrier();
+    VS_STAMP(2);
+    // out^T[f, sample] = sum_k basis[f, k] coef[sample, k]:  D lane l, reg r = feature 16 tile + 4 (l / 16) + r, sample l % 16
+    const int col = lane & 15, kh = lane >> 4;
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const float* b0 = bs + min(col, g.app_dim - 1) * cstride + kh;
+    const float* b1 = bs + min(16 + col, g.app_dim - 1) * cstride + kh;
+    const float* cf = coef + col * cstride + kh;
+#pragma unroll 4
+    for (int kk = 0; kk < ctot; kk += 4) {
+        const float c = cf[kk];
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[kk], c, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[kk], c, acc[1], 0, 0, 0);
+    }
+    VS_STAMP(3);
+    __builtin_amdgcn_wave_barrier();             // every lane has read its coefficients: the slice becomes the output tile [16][33]
+#pragma unroll
+    for (int tile = 0; tile < 2; ++tile)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) coef[col * 33 + 16 * tile + 4 * kh + r] = (16 * tile + 4 * kh + r) < g.app_dim ? act(g.app_act, acc[tile][r]) : 0.f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int t = lane; t < VW_SAMPLES * 32; t += 64) {
+        const int sl = t >> 5, f = t & 31;
+        if (s0 + sl < n && f < g.app_dim) out[(s0 + sl) * (long)out_stride + out_col + f] = coef[sl * 33 + f];
+    }
+    VS_STAMP(4);
+    VS_STAMP(5); VS_STAMP(6); VS_STAMP(7);
 }
 
 // Backward of k_voxel_sample (app_act none): d out [n, app_dim] -> gradients of the planes, lines (scatter-add, the transpose of
@@ -632,8 +958,21 @@ int launch_merge_features(const float* old, const float* fresh, const int* order
 }
 
 int launch_voxel_sample(const GridParams& g, bool half_grids, const float* pts, long n, float* out, int out_stride, int out_col, hipStream_t st) {
-    if (half_grids) k_voxel_sample<true><<<cdiv(n, VS_SAMPLES), 256, 0, st>>>(g, pts, n, out, out_stride, out_col);
-    else k_voxel_sample<false><<<cdiv(n, VS_SAMPLES), 256, 0, st>>>(g, pts, n, out, out_stride, out_col);
+    const bool wide = (g.n_comp[0] % 8 == 0) && (g.n_comp[1] % 8 == 0) && (g.n_comp[2] % 8 == 0);
+    static const bool no_w = env_flag("EVD_VS_BLOCK");      // developer switch: the block-cooperative kernel
+    if (wide && g.app_dim <= 32 && !no_w) {
+        const unsigned blocks = (unsigned)cdiv(n, (long)VW_SAMPLES * VW_WAVES);
+        const int ct = g.n_comp[0] + g.n_comp[1] + g.n_comp[2];
+        const size_t lds = vw_basis_bytes(ct) + VW_WAVES * vw_slice_bytes(ct);
+        if (half_grids) k_voxel_sample_w<true><<<blocks, 64 * VW_WAVES, lds, st>>>(g, pts, n, out, out_stride, out_col);
+        else k_voxel_sample_w<false><<<blocks, 64 * VW_WAVES, lds, st>>>(g, pts, n, out, out_stride, out_col);
+        EVD_LAUNCH_CHECK();
+        return EVD_OK;
+    }
+    if (half_grids && wide) k_voxel_sample<true, 8><<<cdiv(n, VS_SAMPLES), 256, 0, st>>>(g, pts, n, out, out_stride, out_col);
+    else if (half_grids) k_voxel_sample<true, 4><<<cdiv(n, VS_SAMPLES), 256, 0, st>>>(g, pts, n, out, out_stride, out_col);
+    else if (wide) k_voxel_sample<false, 8><<<cdiv(n, VS_SAMPLES), 256, 0, st>>>(g, pts, n, out, out_stride, out_col);
+    else k_voxel_sample<false, 4><<<cdiv(n, VS_SAMPLES), 256, 0, st>>>(g, pts, n, out, out_stride, out_col);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }
