@@ -291,7 +291,7 @@ int evd_nerf_mlp(const evd_nerf* net, int precision, const float* ray_batch, con
     EVD_REQUIRE(R >= 0 && S >= 1, "evd_nerf_mlp: bad shape R=%ld S=%d", R, S);
     EVD_REQUIRE(!feature || feature_kind == 1 || feature_kind == 2, "evd_nerf_mlp: feature_kind must be 1 or 2");
     if (R == 0) return EVD_OK;
-    MlpParams p;
+    MlpParams p{};
     static const bool no_pipe = env_flag("EVD_NO_PIPE");      // developer switch: force the generic kernel
     const bool piped = net->pipe_chunks[precision] > 0 && !no_pipe;
     p.wstream = (const char*)(piped ? net->pipe[precision].data.p : net->stream[precision].data.p);
@@ -329,9 +329,19 @@ size_t evd_nerf_render_workspace_bytes(const evd_render_cfg* cfg, long R) {
     return b + 256;
 }
 
-int evd_nerf_render_rays(const evd_nerf* coarse, const evd_nerf* fine, const evd_render_cfg* cfg, const float* rb,
-                         long R, const float* t_rand, const float* u, const float* noise0, const float* noise1,
-                         evd_render_out* out, void* workspace, size_t workspace_bytes, void* stream) {
+}  // extern "C"
+int evd_ray_batch_z(const evd_render_cfg* cfg, const float* rays, long R, const float* t_rand, float* ray_batch, float* z, void* stream);   // kernels_render.hip
+// where the first pass's z lives (an output the caller asked for, else the workspace slot): shared by the two entries below
+static float* render_z_slot(const evd_render_cfg* cfg, long R, const evd_render_out* out, void* workspace) {
+    const int S = cfg->N_samples, Ni = cfg->N_importance > 0 ? cfg->N_importance : 0, St = S + Ni;
+    char* w = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    w += align256((size_t)R * 11 * 4) + align256((size_t)R * St * 4);
+    float* z0 = (float*)w;
+    return Ni ? (out->z_vals0 ? out->z_vals0 : z0) : (out->z_vals ? out->z_vals : z0);
+}
+static int render_rays_impl(const evd_nerf* coarse, const evd_nerf* fine, const evd_render_cfg* cfg, const float* rb,
+                            long R, const float* t_rand, const float* u, const float* noise0, const float* noise1,
+                            evd_render_out* out, void* workspace, size_t workspace_bytes, void* stream, bool z_done) {
     EVD_REQUIRE(coarse && cfg && out && (rb || R == 0), "evd_nerf_render_rays: null argument");
     EVD_REQUIRE(cfg->use_viewdirs, "evd_nerf_render_rays: use_viewdirs=False is not supported");
     EVD_REQUIRE(cfg->N_samples >= 1, "evd_nerf_render_rays: N_samples must be >= 1");
@@ -356,8 +366,27 @@ int evd_nerf_render_rays(const evd_nerf* coarse, const evd_nerf* fine, const evd
     float* zs = take(r * (Ni ? Ni : 1) * 4);
     int rc;
     float* zc = (Ni ? (out->z_vals0 ? out->z_vals0 : z0) : (out->z_vals ? out->z_vals : z0));
-    if ((rc = evd_sample_z(cfg, rb, 11, R, t_rand, zc, stream))) return rc;
-
+    // the whole step in ONE launch where the compensated float16 kernel can take it: z stratification in its prologue, raw2outputs in
+    // its epilogue (nerf_mlp_c_kernel.h FUSE); z / raw / weights reach HBM only where the caller asked for them
+    // Measured (4096 x 128): 0.869 ms per step against 0.864 with the separate kernels -- at one wavefront per SIMD the serial prologue /
+    // epilogue costs more than the two small launches it saves, so it is opt-in (EVD_FUSE_STEP=1); tests/test_gpu_fullsize.py covers it.
+    const bool no_fuse = !env_flag("EVD_FUSE_STEP") || z_done;
+    if (!Ni && cfg->precision == EVD_PREC_F16C && coarse->pipe_chunks[EVD_PREC_F16C] > 0 && (S == 32 || S == 64 || S == 128) && !noise0 &&
+        !out->feature && !no_fuse && !(!cfg->is_train && coarse->rmnear > 0.f)) {
+        MlpParams p{};
+        p.wstream = (const char*)coarse->pipe_c.data.p;
+        p.nchunks = coarse->pipe_chunks[EVD_PREC_F16C];
+        p.wscale = (const unsigned*)coarse->pipe_c.scales.p;
+        p.bias = (const float*)coarse->bias.p;
+        p.nbias = (int)(coarse->bias.bytes / sizeof(float));
+        p.ray_batch = rb; p.z = nullptr; p.nsamp = R * (long)S; p.S = S; p.ncol = 11; p.D = coarse->D; p.skip = coarse->skip;
+        p.raw = out->raw; p.feature = nullptr; p.feature_kind = 0; p.act = nullptr;
+        p.fuse = 1; p.lindisp = cfg->lindisp; p.perturb = cfg->perturb > 0.f; p.t_rand = t_rand;
+        p.rgb_act = coarse->rgb_act; p.sigma_act = coarse->sigma_act; p.white_bkgd = cfg->white_bkgd;
+        p.z_out = out->z_vals; p.rgb_map = out->rgb; p.depth_map = out->depth; p.acc_map = out->acc; p.weights = out->weights;
+        return nerf_mlp_c_dispatch(coarse->W, coarse->D, coarse->skip, p, as_stream(stream));
+    }
+    if (!z_done && (rc = evd_sample_z(cfg, rb, 11, R, t_rand, zc, stream))) return rc;
     auto pass = [&](const evd_nerf* net, const float* z, int Sp, const float* noise, float* rgb, float* depth, float* acc,
                     float* weights, float* raw_out, float* feat) -> int {
         int rc2 = evd_nerf_mlp(net, cfg->precision, rb, z, R, Sp, raw_out, feat, out->feature_kind ? out->feature_kind : 1, stream);
@@ -380,18 +409,27 @@ int evd_nerf_render_rays(const evd_nerf* coarse, const evd_nerf* fine, const evd
     return pass(fine, zm, St, noise1, out->rgb, out->depth, out->acc, wo, ro, out->feature);
 }
 
+extern "C" {
+int evd_nerf_render_rays(const evd_nerf* coarse, const evd_nerf* fine, const evd_render_cfg* cfg, const float* rb,
+                         long R, const float* t_rand, const float* u, const float* noise0, const float* noise1,
+                         evd_render_out* out, void* workspace, size_t workspace_bytes, void* stream) {
+    return render_rays_impl(coarse, fine, cfg, rb, R, t_rand, u, noise0, noise1, out, workspace, workspace_bytes, stream, false);
+}
+
 int evd_nerf_render(const evd_nerf* coarse, const evd_nerf* fine, const evd_render_cfg* cfg, const float* rays, long R,
                     const float* t_rand, const float* u, const float* noise0, const float* noise1,
                     evd_render_out* out, void* workspace, size_t workspace_bytes, void* stream) {
-    EVD_REQUIRE(cfg && (rays || R == 0), "evd_nerf_render: null argument");
+    EVD_REQUIRE(cfg && out && (rays || R == 0), "evd_nerf_render: null argument");
     if (R == 0) return EVD_OK;
     const size_t need = evd_nerf_render_workspace_bytes(cfg, R);
     if (!workspace || workspace_bytes < need)
         return fail(EVD_E_WORKSPACE, "evd_nerf_render: workspace %zu < %zu bytes", workspace_bytes, need);
     float* rb = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-    int rc = evd_ray_batch(cfg, rays, R, rb, stream);
+    // ray packing and z stratification in ONE launch (they are 44 B per ray and 4 B per sample), unless the step-fusing kernel wants z itself
+    const bool fused_z = cfg->use_viewdirs && cfg->N_samples >= 1 && !env_flag("EVD_FUSE_STEP");
+    int rc = fused_z ? evd_ray_batch_z(cfg, rays, R, t_rand, rb, render_z_slot(cfg, R, out, workspace), stream) : evd_ray_batch(cfg, rays, R, rb, stream);
     if (rc) return rc;
-    return evd_nerf_render_rays(coarse, fine, cfg, rb, R, t_rand, u, noise0, noise1, out, workspace, workspace_bytes, stream);
+    return render_rays_impl(coarse, fine, cfg, rb, R, t_rand, u, noise0, noise1, out, workspace, workspace_bytes, stream, fused_z);
 }
 
 }  // extern "C"

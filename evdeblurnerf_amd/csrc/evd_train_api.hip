@@ -31,7 +31,7 @@ int evd_nerf_mlp_train(const evd_nerf* net, int precision, const float* ray_batc
     const long nsamp = R * (long)S;
     if (store_bytes < evd_nerf_train_store_bytes(nsamp))
         return fail(EVD_E_WORKSPACE, "evd_nerf_mlp_train: store %zu < %zu bytes", store_bytes, evd_nerf_train_store_bytes(nsamp));
-    MlpParams p;
+    MlpParams p{};
     p.wstream = (const char*)net->pipe[precision].data.p;
     p.bias = (const float*)net->bias.p;
     p.ray_batch = ray_batch; p.z = z; p.nsamp = nsamp; p.S = S; p.ncol = 11;

@@ -8,7 +8,7 @@ namespace evd {
 int nerf_mlp_c_chunks(int W, int D, int skip) { return nerf_c_built(W, D, skip) ? nerf_c_chunks<256, 8, 4>() : 0; }
 
 int nerf_mlp_c_dispatch(int W, int D, int skip, const MlpParams& p, hipStream_t st) {
-    if (nerf_c_built(W, D, skip)) return launch_nerf_c<256, 8, 4>(p, st);
+    if (nerf_c_built(W, D, skip)) return p.fuse ? launch_nerf_c<256, 8, 4, true>(p, st) : launch_nerf_c<256, 8, 4, false>(p, st);
     return fail(EVD_E_INVALID, "evd_nerf_mlp: EVD_PREC_F16C is built for netdepth 8, netwidth 256, skips [4] only");
 }
 

@@ -5,6 +5,7 @@
 #include <cstdlib>
 
 #include "evd_common.h"
+#include "wave_ops.h"
 
 namespace evd {
 
@@ -208,6 +209,46 @@ __global__ void k_sample_z(const float* __restrict__ rb, int nc, long R, int S, 
     z[idx] = zi;
 }
 
+// k_ray_batch + k_sample_z in one launch (evd_nerf_render: near / far are the configuration's scalars, so z does not depend on the packed
+// row): thread = (ray, sample); the sample-0 thread also packs the ray's row.  Same arithmetic as the two kernels.
+__global__ void k_ray_batch_z(const float* __restrict__ rays, long R, int ndc, float cw, float ch, float near, float far, int S, int lindisp, int perturb,
+                              const float* __restrict__ t_rand, float* __restrict__ rb, float* __restrict__ z) {
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (idx >= R * S) return;
+    const long r = idx / S;
+    const int i = idx % S;
+    auto zat = [&](int k) {
+        const float t = linspace_at(0.f, 1.f, S, k);
+        return lindisp ? 1.f / __fadd_rn(__fmul_rn(1.f / near, __fsub_rn(1.f, t)), __fmul_rn(1.f / far, t))
+                       : __fadd_rn(__fmul_rn(near, __fsub_rn(1.f, t)), __fmul_rn(far, t));
+    };
+    float zi = zat(i);
+    if (perturb) {
+        const float upper = (i < S - 1) ? __fmul_rn(.5f, __fadd_rn(zat(i + 1), zi)) : zi;
+        const float lower = (i > 0) ? __fmul_rn(.5f, __fadd_rn(zi, zat(i - 1))) : zi;
+        zi = __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), t_rand[idx]));
+    }
+    z[idx] = zi;
+    if (i != 0) return;
+    float o[3], d[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { o[c] = rays[r * 6 + c * 2]; d[c] = rays[r * 6 + c * 2 + 1]; }
+    float* out = rb + r * 11;
+    const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[8 + c] = d[c] / nrm;
+    if (ndc) {
+        float x[3], y[3];
+        ndc_one(cw, ch, 1.f, 2.f, o, d, x, y);   // get_ndc_rays(H, W, K[0][0], 1., ...) renderer.py:437
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { o[c] = x[c]; d[c] = y[c]; }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { out[c] = o[c]; out[3 + c] = d[c]; }
+    out[6] = near;
+    out[7] = far;
+}
+
 // reference networks/embedding.py:88-98
 __global__ void k_embed(const float* __restrict__ x, long n, int dim, int L, float* __restrict__ out) {
     const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
@@ -306,46 +347,6 @@ __global__ __launch_bounds__(256) void k_composite(const float* __restrict__ raw
             for (int c = 0; c < NRGB; ++c) out_map[r * n_rgb + c] = white_bkgd ? csum[c] + (1.f - a_sum) : csum[c];
         }
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// DPP (data-parallel primitive) wave operations: register-to-register lane exchange inside the VALU, no LDS
-// crossbar round trip (which is what __shfl / ds_bpermute costs).  dpp_ctrl codes: quad_perm 0x00-0xFF,
-// row_shr:n 0x110+n, wave_shl:1 0x130, wave_shr:1 0x138, row_mirror 0x140, row_half_mirror 0x141,
-// row_bcast:15 0x142, row_bcast:31 0x143 (gfx9 family).
-template <int CTRL, int ROW_MASK = 0xf>
-__device__ __forceinline__ float dpp_f32(float old, float src) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL, ROW_MASK, 0xf, false));
-}
-// inclusive product scan over the 64 lanes (Kogge-Stone inside rows of 16, then row broadcasts)
-__device__ __forceinline__ float wave_scan_mul_dpp(float v) {
-    v *= dpp_f32<0x111>(1.f, v);
-    v *= dpp_f32<0x112>(1.f, v);
-    v *= dpp_f32<0x114>(1.f, v);
-    v *= dpp_f32<0x118>(1.f, v);
-    v *= dpp_f32<0x142, 0xa>(1.f, v);     // rows 1, 3 <- lane 15 of the row below
-    v *= dpp_f32<0x143, 0xc>(1.f, v);     // rows 2, 3 <- lane 31
-    return v;
-}
-// sum over the 64 lanes, result uniform (in an SGPR-backed value)
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-    v += dpp_f32<0xb1>(0.f, v);           // quad_perm [1,0,3,2]
-    v += dpp_f32<0x4e>(0.f, v);           // quad_perm [2,3,0,1]
-    v += dpp_f32<0x141>(0.f, v);          // row_half_mirror
-    v += dpp_f32<0x140>(0.f, v);          // row_mirror: every lane now holds its row's sum
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0)) +
-           __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16)) +
-           __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32)) +
-           __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
-}
-
-// activations of the bandwidth-form scan: sigmoid with the hardware exp2 and reciprocal (relative error ~3e-7; the
-// IEEE expf + division of evd::act() made the scan VALU-bound: 3.8 instead of 5.2 TB/s)
-__device__ __forceinline__ float act_fast(int code, float x) {
-    if (code == EVD_ACT_SIGMOID) return __builtin_amdgcn_rcpf(1.f + __expf(-x));
-    if (code == EVD_ACT_RELU) return fmaxf(x, 0.f);
-    if (code == EVD_ACT_NONE) return x;
-    return act(code, x);
 }
 
 // raw2outputs, bandwidth form (C == 4, three colour channels, S <= 64 * SPL): one wavefront per ray, every lane owns
@@ -763,6 +764,21 @@ int evd_ray_batch(const evd_render_cfg* cfg, const float* rays, long R, float* r
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }
+
+}  // extern "C"
+// internal (evd_api.hip, C++ linkage: not part of the ABI): ray packing + z stratification of evd_nerf_render in one launch
+int evd_ray_batch_z(const evd_render_cfg* cfg, const float* rays, long R, const float* t_rand, float* ray_batch, float* z, void* stream) {
+    EVD_REQUIRE(cfg && R >= 0 && ray_batch && z && cfg->N_samples > 0 && cfg->use_viewdirs, "evd_ray_batch_z: bad arguments");
+    EVD_REQUIRE(!(cfg->perturb > 0.f) || t_rand, "evd_nerf_render: perturb > 0 needs the explicit t_rand draw");
+    if (R == 0) return EVD_OK;
+    float cw, ch;
+    ndc_coeffs(cfg->H, cfg->W, cfg->focal, &cw, &ch);
+    k_ray_batch_z<<<cdiv(R * cfg->N_samples, 256), 256, 0, as_stream(stream)>>>(rays, R, cfg->ndc, cw, ch, cfg->near, cfg->far, cfg->N_samples, cfg->lindisp,
+                                                                               cfg->perturb > 0.f, t_rand, ray_batch, z);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+extern "C" {
 
 int evd_sample_z(const evd_render_cfg* cfg, const float* ray_batch, int ncol, long R, const float* t_rand, float* z, void* stream) {
     EVD_REQUIRE(cfg && R >= 0 && z && cfg->N_samples > 0, "evd_sample_z: bad arguments");

@@ -58,6 +58,11 @@ struct MlpParams {
     int feature_kind;       // 0 none, 1 after_linear, 2 before_linear
     char* act;              // training kernels: activation store (act_tile_bytes per 32-sample tile), else null
     const unsigned* wscale; // compensated float16 mode: row-scale words, 32 per output tile in bias order (pack.h StreamBuilderC), else null
+    // fused render step of the compensated float16 kernel (nerf_mlp_c_kernel.h, FUSE): z stratification in the prologue (renderer.py:163-178),
+    // raw2outputs in the epilogue (nerf.py:74-129); z / raw / weights are written only where a pointer is given
+    int fuse, lindisp, perturb, rgb_act, sigma_act, white_bkgd;
+    const float* t_rand;    // [R, S] or null
+    float *z_out, *rgb_map, *depth_map, *acc_map, *weights;
 };
 
 // Activation / gradient store of the training path, in 1 KiB fragments per 32-sample tile (W = 256, D = 8):

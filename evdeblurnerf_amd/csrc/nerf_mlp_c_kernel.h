@@ -5,6 +5,7 @@
 #pragma once
 
 #include "mlp_pipe_c.h"
+#include "wave_ops.h"
 
 namespace evd {
 
@@ -73,7 +74,27 @@ template <class N, class ST, int l, int D> struct HiddenLoopC {
     }
 };
 
-template <int W, int D, int SKIP>
+// z of sample i of a ray (renderer.py:163-178; the arithmetic of k_sample_z)
+__device__ __forceinline__ float c_z_at(float near, float far, int S, int lindisp, int k) {
+    const float t = linspace_at(0.f, 1.f, S, k);
+    return lindisp ? 1.f / __fadd_rn(__fmul_rn(1.f / near, __fsub_rn(1.f, t)), __fmul_rn(1.f / far, t))
+                   : __fadd_rn(__fmul_rn(near, __fsub_rn(1.f, t)), __fmul_rn(far, t));
+}
+__device__ __forceinline__ float c_z_sample(float near, float far, int S, int lindisp, int perturb, const float* t_rand, long ray, int i) {
+    float zi = c_z_at(near, far, S, lindisp, i);
+    if (perturb) {
+        const float upper = (i < S - 1) ? __fmul_rn(.5f, __fadd_rn(c_z_at(near, far, S, lindisp, i + 1), zi)) : zi;
+        const float lower = (i > 0) ? __fmul_rn(.5f, __fadd_rn(zi, c_z_at(near, far, S, lindisp, i - 1))) : zi;
+        zi = __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), t_rand[ray * S + i]));
+    }
+    return zi;
+}
+
+// FUSE: the whole render step of mode='nerf' without importance samples in this one launch (S = 32, 64 or 128: a workgroup's 128
+// samples are whole rays): z stratification in the prologue, raw2outputs in the epilogue -- the per-sample (rgb, sigma) never leave
+// registers unless `raw` is wanted; transmittance = DPP product scan over a wavefront's 32 samples, carried across the ray's wavefronts
+// through 4 words of LDS.
+template <int W, int D, int SKIP, bool FUSE>
 __global__ __launch_bounds__(CCfg::NT, 1) void k_nerf_mlp_c(const MlpParams p) {
     typedef NerfNetC<W, D, SKIP> N;
     typedef CStream<N::NCH> ST;
@@ -114,10 +135,21 @@ __global__ __launch_bounds__(CCfg::NT, 1) void k_nerf_mlp_c(const MlpParams p) {
     const long smp = (long)blockIdx.x * CCfg::SAMPLES + wave * 32 + n;
     const bool valid = smp < p.nsamp;
     const long sidx = valid ? smp : p.nsamp - 1;
+    float z_own = 0.f, z_next = 0.f, dnorm = 0.f;
     {   // both positional encodings as input blocks
         const long ray = sidx / p.S;
         const float* rb = p.ray_batch + ray * p.ncol;
-        const float zv = p.z[sidx];
+        float zv;
+        if constexpr (FUSE) {
+            const int si = (int)(sidx - ray * p.S);
+            zv = c_z_sample(rb[6], rb[7], p.S, p.lindisp, p.perturb, p.t_rand, ray, si);
+            z_next = si < p.S - 1 ? c_z_sample(rb[6], rb[7], p.S, p.lindisp, p.perturb, p.t_rand, ray, si + 1) : zv;
+            z_own = zv;
+            dnorm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(rb[3], rb[3]), __fmul_rn(rb[4], rb[4])), __fmul_rn(rb[5], rb[5])));
+            if (p.z_out && valid && h == 0) p.z_out[sidx] = zv;
+        } else {
+            zv = p.z[sidx];
+        }
         float pts[3], vd[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -153,24 +185,71 @@ __global__ __launch_bounds__(CCfg::NT, 1) void k_nerf_mlp_c(const MlpParams p) {
     lb += (T / 2) * 32;
     c_layer<typename N::Rgb, void, ST, KB / 2, 1>(cx.st, cx.pp, hbuf, none, rraw, lb, lane);
 
-    if (h == 0 && valid) {
+    if (h == 0 && valid && (!FUSE || p.raw)) {
         const f32x4 o = {rraw[0], rraw[1], rraw[2], araw[0]};   // cat([rgb, alpha]) nerf.py:157
         *reinterpret_cast<f32x4*>(p.raw + sidx * 4) = o;
+    }
+    if constexpr (FUSE) {
+        // raw2outputs (nerf.py:74-129; the per-sample arithmetic of k_composite_rows) on the values in registers
+        const long ray = sidx / p.S;
+        const int si = (int)(sidx - ray * p.S);
+        const bool live = h == 0 && valid;                      // lanes 32..63 mirror the samples: neutral elements
+        float alpha = 0.f;
+        if (live) {
+            if (si < p.S - 1) {
+                const float dist = __fmul_rn(__fsub_rn(z_next, z_own), dnorm);
+                alpha = __fadd_rn(-expf(-__fmul_rn(act_fast(p.sigma_act, araw[0]), dist)), 1.f);
+            } else {
+                alpha = 1.f;                                    // last sample: alpha forced to 1 (nerf.py:113-114)
+            }
+        }
+        const float om = live ? __fadd_rn(-alpha, 1.f) : 1.f;
+        const float incl = wave_scan_mul_dpp(om);
+        float T = dpp_f32<0x138>(1.f, incl);                    // wave_shr:1 -> exclusive product; lane 0 keeps 1
+        float* xw = reinterpret_cast<float*>(smem + CCfg::RING) + CCfg::BIAS_WORDS - 64;    // 64 spare words behind the row scales
+        const int wpr = p.S / 32, wr = wave % wpr, w0 = wave - wr;                           // wavefronts per ray, this one's rank
+        if (lane == 31) xw[wave] = incl;                        // the wavefront's total
+        __syncthreads();
+        float Tb = 1.f;
+        for (int k = 0; k < wr; ++k) Tb *= xw[w0 + k];          // the transmittance the ray arrives with
+        const float wgt = live ? alpha * (Tb * T) : 0.f;
+        if (p.weights && live) p.weights[sidx] = wgt;
+        float part[5] = {wgt, wgt * z_own, wgt * act_fast(p.rgb_act, rraw[0]), wgt * act_fast(p.rgb_act, rraw[1]), wgt * act_fast(p.rgb_act, rraw[2])};
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            part[q] = wave_sum_dpp(part[q]);
+            if (lane == 0) xw[8 + wave * 5 + q] = part[q];
+        }
+        __syncthreads();
+        if (wr == 0 && lane == 0 && valid) {
+            float tot[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < wpr; ++k)
+#pragma unroll
+                for (int q = 0; q < 5; ++q) tot[q] += xw[8 + (w0 + k) * 5 + q];
+            if (p.acc_map) p.acc_map[ray] = tot[0];
+            if (p.depth_map) p.depth_map[ray] = tot[1];
+            if (p.rgb_map) {
+                const float bg = p.white_bkgd ? 1.f - tot[0] : 0.f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) p.rgb_map[ray * 3 + c] = tot[2 + c] + bg;
+            }
+        }
     }
 }
 
 template <int W, int D, int SKIP> constexpr int nerf_c_chunks() { return NerfNetC<W, D, SKIP>::NCH; }
 
-template <int W, int D, int SKIP>
+template <int W, int D, int SKIP, bool FUSE>
 static int launch_nerf_c(const MlpParams& p, hipStream_t st) {
     typedef NerfNetC<W, D, SKIP> N;
     const long blocks = cdiv(p.nsamp, CCfg::SAMPLES);
     const size_t lds = CCfg::TOTAL;
-    EVD_SET_MAX_LDS((&k_nerf_mlp_c<W, D, SKIP>), lds);
+    EVD_SET_MAX_LDS((&k_nerf_mlp_c<W, D, SKIP, FUSE>), lds);
     if (p.nbias != N::NTILES * 32) return fail(EVD_E_INVALID, "evd_nerf_mlp (f16c): %d bias floats, kernel expects %d", p.nbias, N::NTILES * 32);
     if (p.nchunks != N::NCH) return fail(EVD_E_INVALID, "evd_nerf_mlp (f16c): packed stream has %d chunks, kernel expects %d", p.nchunks, N::NCH);
     if (!p.wscale) return fail(EVD_E_INVALID, "evd_nerf_mlp (f16c): no row scales");
-    hipLaunchKernelGGL((k_nerf_mlp_c<W, D, SKIP>), dim3((unsigned)blocks), dim3(CCfg::NT), lds, st, p);
+    if (FUSE && !(p.S == 32 || p.S == 64 || p.S == 128)) return fail(EVD_E_INVALID, "evd_nerf_mlp (f16c, fused step): N_samples must be 32, 64 or 128");
+    hipLaunchKernelGGL((k_nerf_mlp_c<W, D, SKIP, FUSE>), dim3((unsigned)blocks), dim3(CCfg::NT), lds, st, p);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }

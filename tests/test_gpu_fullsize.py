@@ -229,3 +229,40 @@ def test_f16c_ragged_sizes_goldens_and_rejections(O):
         net.mlpforward(T(rb), T(z), want_feature=True, precision="f16c")
     with pytest.raises(L.EvdError):
         NeRF(W.make_nerf_state_dict(1, D=4, W=64, skips=(2,)), D=4, W=64, skips=(2,)).mlpforward(T(rb), T(z), precision="f16c")
+
+
+@pytest.mark.parametrize("S,white,perturb", [(128, False, 0.0), (64, True, 1.0), (32, False, 1.0)])
+def test_f16c_fused_step_matches_the_separate_kernels(S, white, perturb, monkeypatch):
+    """mode='nerf' without importance samples in precision f16c can run the whole step in ONE launch (z stratification in the MLP kernel's
+    prologue, raw2outputs in its epilogue: nerf_mlp_c_kernel.h FUSE).  Every output of render() -- rgb / depth / acc, and with retraw
+    z_vals / weights -- must equal what the separate entries give on the same inputs (evd_sample_z -> evd_nerf_mlp ->
+    evd_raw2outputs): z bit-exact, the composited values to 2e-6 (scan association)."""
+    from evdeblurnerf_amd.renderer import NeRFAll
+    from evdeblurnerf_amd import _lib as L
+    import ctypes as C
+    monkeypatch.setenv("EVD_FUSE_STEP", "1")        # opt-in: measured 0.5 % slower than the separate kernels at 4096 x 128 (evd_api.hip)
+    sd = W.prefixed(W.make_nerf_state_dict(21), "mlp_coarse")
+    K = W.synthetic_camera()
+    R = 1000 if S == 128 else 777
+    rays = T(W.synthetic_rays(9, R))
+    model = NeRFAll(_nerf_args(), sd, precision="f16c").eval()
+    torch.manual_seed(3)
+    t_rand = torch.rand((R, S), device=DEV) if perturb else None
+    kw = dict(ndc=True, near=0., far=1., use_viewdirs=True, N_samples=S, N_importance=0, white_bkgd=white, perturb=perturb, retraw=True)
+    if t_rand is not None:
+        kw["t_rand"] = t_rand
+    rgb, depth, acc, extras = model.render(400, 400, K, rays=rays, **kw)
+    # the separate entries
+    net = model.mlp_coarse
+    cfg = model._cfg(400, 400, float(K[0][0]), True, 0., 1., S, 0, False, perturb, white)
+    rb = torch.empty((R, 11), device=DEV)
+    z = torch.empty((R, S), device=DEV)
+    L.check(L.lib().evd_ray_batch(C.byref(cfg), L.ptr(rays), R, L.ptr(rb), L.stream_ptr()))
+    L.check(L.lib().evd_sample_z(C.byref(cfg), L.ptr(rb), 11, R, L.ptr(t_rand) if t_rand is not None else None, L.ptr(z), L.stream_ptr()))
+    raw, _ = net.mlpforward(rb, z, precision="f16c")
+    r_rgb, _, r_acc, r_w, r_depth, _ = net.raw2outputs(raw, z, rb[:, 3:6].contiguous(), white_bkgd=white)
+    assert torch.equal(extras["z_vals"], z)
+    for name, a, b in (("rgb", rgb, r_rgb), ("depth", depth, r_depth), ("acc", acc, r_acc), ("weights", extras["weights"], r_w)):
+        d = maxabs(N(a), N(b))
+        print(f"[fused step S={S}] {name}: {d:.2e}")
+        assert d < 2e-6, name
