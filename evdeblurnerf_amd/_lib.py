@@ -82,6 +82,7 @@ SIGNATURES = {
     "evd_compute_successor": (_I, [_vp, _L, _L, _vp, _vp, _vp, _vp, _vp, _S, _vp]),
     "evd_rbk_warp": (_I, [_vp, _vp, _vp, _L, _I, _I, _vp, _vp, _vp]),
     "evd_awp_feature_integration": (_I, [_vp, _vp, _vp, _L, _I, _I, _vp, _vp]),
+    "evd_awp_feature_integration_bwd": (_I, [_vp, _vp, _vp, _vp, _L, _I, _I, _vp, _vp, _vp, _vp]),
     "evd_probe_mfma_rate": (_I, [_I, _I, C.POINTER(C.c_double), _vp]),
     "evd_device_count": (_I, []),
     "evd_get_rays": (_I, [_I, _I, _fp, _fp, _vp, _vp, _vp]),

@@ -1,11 +1,38 @@
 """The compositing scan of the AWP consumer (reference ``networks/dpnerf/awp.py``): the one piece of
-``AdaptiveWeightProposal`` that is a scan over the path's per-sample outputs.  The rest of AWP (sample / motion embedding
-MLPs, MotionAggregationModule) stays PyTorch in the reference's caller."""
+``AdaptiveWeightProposal`` that is a scan over the path's per-sample outputs, forward and backward (an autograd node on
+hand-written kernels).  The rest of AWP (sample / motion embedding MLPs, MotionAggregationModule) stays PyTorch in the
+reference's caller."""
 from __future__ import annotations
 
 import torch
 
 from . import _lib as L
+
+
+class _FeatureIntegration(torch.autograd.Function):
+    """evd_awp_feature_integration / evd_awp_feature_integration_bwd as one autograd node: gradients to the per-sample features (the
+    AWP embedding MLP and, through it, the fine level), to z_vals and to rays_d (the blur kernel's ray directions)."""
+
+    @staticmethod
+    def forward(ctx, f, z, d):
+        N, S, Cc = f.shape
+        out = torch.empty((N, Cc), dtype=torch.float32, device=f.device)
+        L.check(L.lib().evd_awp_feature_integration(L.ptr(f), L.ptr(z), L.ptr(d), N, S, Cc, L.ptr(out), L.stream_ptr()),
+                "evd_awp_feature_integration")
+        ctx.save_for_backward(f, z, d)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        f, z, d = ctx.saved_tensors
+        N, S, Cc = f.shape
+        g = g.contiguous().float()
+        df = torch.empty_like(f)
+        dz = torch.empty_like(z) if ctx.needs_input_grad[1] else None
+        dd = torch.empty_like(d) if ctx.needs_input_grad[2] else None
+        L.check(L.lib().evd_awp_feature_integration_bwd(L.ptr(f), L.ptr(z), L.ptr(d), L.ptr(g), N, S, Cc, L.ptr(df), L.ptr(dz), L.ptr(dd),
+                                                        L.stream_ptr()), "evd_awp_feature_integration_bwd")
+        return df, dz, dd
 
 
 def feature_integration(feat, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=False):
@@ -19,7 +46,4 @@ def feature_integration(feat, z_vals, rays_d, raw_noise_std=0, white_bkgd=False,
     N = f.shape[0]
     if z.shape[0] != N or d.shape[0] != N:
         raise L.EvdError("feature_integration: z_vals / rays_d need one row per (ray, motion)")
-    out = torch.empty((N, Cc), dtype=torch.float32, device=f.device)
-    L.check(L.lib().evd_awp_feature_integration(L.ptr(f), L.ptr(z), L.ptr(d), N, S, Cc, L.ptr(out), L.stream_ptr()),
-            "evd_awp_feature_integration")
-    return out.reshape(n_rays, n_motion, Cc)
+    return _FeatureIntegration.apply(f, z, d).reshape(n_rays, n_motion, Cc)

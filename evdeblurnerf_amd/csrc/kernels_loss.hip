@@ -495,6 +495,105 @@ __global__ __launch_bounds__(256) void k_awp_integrate(const float* __restrict__
     for (int q = 0; q < CPL; ++q) { const int c = lane * CPL + q; if (c < C) out[n * C + c] = acc[q]; }
 }
 
+// Backward of k_awp_integrate (the autograd node behind AdaptiveWeightProposal.feature_integration under training, awp.py:98-104):
+//   out[c] = sum_s a[s,c] Q[s,c] f[s,c],   a = 1 - e, e = exp(-f dist[s]) (a = 0 on the last sample),   om = e + 1e-10,
+//   Q[s+1,c] = prod_{c' <= c} om[s,c'] (the reference's cumprod runs along the CHANNEL axis, awp.py:69-73), Q[0,c] = 1.
+// With g[c] = d out[c]:
+//   d f[s,c]  = g[c] Q[s,c] (a + f dist e)                                   direct
+//             - dist e Sfx[s+1,c] / om[s,c],  Sfx[s+1,c] = sum_{c'' >= c} g[c''] a[s+1,c''] f[s+1,c''] Q[s+1,c'']      through Q of the next row
+//   d dist[s] = sum_c (g[c] Q[s,c] f - Sfx[s+1,c] / om[s,c]) f e             -> d z (dist = (z[s+1] - z[s]) |d|), d rays_d
+// Same decomposition as the forward: a wavefront per ray, CPL consecutive channels per lane; per sample row one inclusive product
+// scan (Q of the next row) and one suffix sum over the lanes (DPP); one row of lookahead.
+__device__ __forceinline__ float awp_scan_add(float v) {
+    auto dpp = [](float src, auto ctrl, auto rmask) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), decltype(ctrl)::value, decltype(rmask)::value, 0xf, false));
+    };
+    typedef std::integral_constant<int, 0xf> All;
+    v += dpp(v, std::integral_constant<int, 0x111>(), All());
+    v += dpp(v, std::integral_constant<int, 0x112>(), All());
+    v += dpp(v, std::integral_constant<int, 0x114>(), All());
+    v += dpp(v, std::integral_constant<int, 0x118>(), All());
+    v += dpp(v, std::integral_constant<int, 0x142>(), std::integral_constant<int, 0xa>());
+    v += dpp(v, std::integral_constant<int, 0x143>(), std::integral_constant<int, 0xc>());
+    return v;
+}
+
+template <int CPL>
+__global__ __launch_bounds__(256) void k_awp_integrate_bwd(const float* __restrict__ feat, const float* __restrict__ z, const float* __restrict__ rays_d,
+                                                           const float* __restrict__ d_out, long N, int S, int C, float* __restrict__ d_feat,
+                                                           float* __restrict__ d_z, float* __restrict__ d_rays_d) {
+    const int lane = threadIdx.x & 63;
+    const long n = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float* d = rays_d + n * 3;
+    const float norm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
+    const float* fr = feat + n * (long)S * C;
+    const float* zz = z + n * (long)S;
+    float g[CPL], Q[CPL], fc[CPL], fn[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+        const int c = lane * CPL + q;
+        g[q] = c < C ? d_out[n * C + c] : 0.f;
+        Q[q] = 1.f;
+        fc[q] = c < C ? fr[c] : 0.f;
+    }
+    float dnorm = 0.f, dz_prev = 0.f;                    // d z[s] carried from the previous interval (+ d dist[s-1] |d|)
+    for (int s = 0; s < S; ++s) {
+        const bool last = s == S - 1;
+        const float dz = last ? 0.f : __fsub_rn(zz[s + 1], zz[s]);
+        const float dist = __fmul_rn(dz, norm);
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) { const int c = lane * CPL + q; fn[q] = (!last && c < C) ? fr[(long)(s + 1) * C + c] : 0.f; }
+        const float dist_n = s + 2 < S ? __fmul_rn(__fsub_rn(zz[s + 2], zz[s + 1]), norm) : 0.f;
+        // this row: e, a, om; Q of the next row
+        float e[CPL], om[CPL], Qn[CPL], local = 1.f;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            const int c = lane * CPL + q;
+            e[q] = last ? 1.f : expf(-__fmul_rn(fc[q], dist));
+            om[q] = c < C ? __fadd_rn(last ? 1.f : e[q], 1e-10f) : 1.f;      // the last row's alpha is 0
+            local *= om[q];
+        }
+        const float incl = awp_scan_mul(local);
+        float excl = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, 1.f), __builtin_bit_cast(int, incl), 0x138, 0xf, 0xf, false));
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) { excl *= om[q]; Qn[q] = excl; }
+        // suffix sums over the channels of G[s+1, c] = g a f Q of the next row
+        float G[CPL], lsum = 0.f;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            const float an = s + 2 < S ? __fadd_rn(-expf(-__fmul_rn(fn[q], dist_n)), 1.f) : 0.f;     // alpha of row s+1 (0 when it is the last row)
+            G[q] = last ? 0.f : g[q] * an * fn[q] * Qn[q];
+            lsum += G[q];
+        }
+        const float pre_incl = awp_scan_add(lsum);                                   // sum over lanes <= this one
+        const float total = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pre_incl), 63));
+        float sfx = total - pre_incl;                                                 // lanes > this one
+        float ddist = 0.f;
+#pragma unroll
+        for (int q = CPL - 1; q >= 0; --q) {
+            const int c = lane * CPL + q;
+            sfx += G[q];                                                              // channels >= c
+            const float a = last ? 0.f : __fadd_rn(-e[q], 1.f);
+            const float through = last ? 0.f : sfx / om[q];
+            const float ga = g[q] * Q[q] * fc[q] - through;                           // d out / d a[s,c]
+            const float df = last ? 0.f : g[q] * Q[q] * a + ga * dist * e[q];
+            if (c < C) d_feat[(n * (long)S + s) * C + c] = df;
+            ddist += last ? 0.f : ga * fc[q] * e[q];
+        }
+        if (d_z || d_rays_d) {
+            ddist = awp_scan_add(ddist);
+            ddist = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ddist), 63));
+            if (d_z && lane == 0) d_z[n * (long)S + s] = dz_prev - ddist * norm;
+            dz_prev = ddist * norm;
+            dnorm += ddist * dz;
+        }
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) { Q[q] = Qn[q]; fc[q] = fn[q]; }
+    }
+    if (d_rays_d && lane < 3) d_rays_d[n * 3 + lane] = norm > 0.f ? dnorm * d[lane] / norm : 0.f;
+}
+
 // utils/edi.py:73-95: E_k = -sum_{j=k}^{N-1} bii_j (k<N), 0 (k=N), +sum_{j=N}^{k-1} bii_j (k>N); sharp = (2N+1) blurry / sum exp(E_k)
 __global__ void k_edi_deblur(const float* __restrict__ blurry, const float* __restrict__ bii, int steps, long npix,
                              float* __restrict__ sharp) {
@@ -698,6 +797,19 @@ int evd_awp_feature_integration(const float* feat, const float* z, const float* 
     if (C <= 64) k_awp_integrate<1><<<cdiv(N, 4), 256, 0, st>>>(feat, z, rays_d, N, S, C, out);
     else if (C <= 128) k_awp_integrate<2><<<cdiv(N, 4), 256, 0, st>>>(feat, z, rays_d, N, S, C, out);
     else k_awp_integrate<4><<<cdiv(N, 4), 256, 0, st>>>(feat, z, rays_d, N, S, C, out);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+int evd_awp_feature_integration_bwd(const float* feat, const float* z, const float* rays_d, const float* d_out, long N, int S, int C,
+                                    float* d_feat, float* d_z, float* d_rays_d, void* stream) {
+    EVD_REQUIRE(feat && z && rays_d && d_out && d_feat && N >= 0 && S >= 1 && C >= 1, "evd_awp_feature_integration_bwd: bad arguments");
+    EVD_REQUIRE(C <= 256, "evd_awp_feature_integration_bwd: %d channels (built: <= 256)", C);
+    if (N == 0) return EVD_OK;
+    hipStream_t st = as_stream(stream);
+    if (C <= 64) k_awp_integrate_bwd<1><<<cdiv(N, 4), 256, 0, st>>>(feat, z, rays_d, d_out, N, S, C, d_feat, d_z, d_rays_d);
+    else if (C <= 128) k_awp_integrate_bwd<2><<<cdiv(N, 4), 256, 0, st>>>(feat, z, rays_d, d_out, N, S, C, d_feat, d_z, d_rays_d);
+    else k_awp_integrate_bwd<4><<<cdiv(N, 4), 256, 0, st>>>(feat, z, rays_d, d_out, N, S, C, d_feat, d_z, d_rays_d);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }

@@ -364,6 +364,10 @@ int evd_event_loss_bwd(const evd_crf* crf_ev, int skip_learn, int add_bii_feat, 
  * z dev [N,S], rays_d dev [N,3] -> out dev [N,C].  Restated as written: the last sample gets alpha 0 (awp.py:67) and the
  * cumprod of awp.py:69-73 runs along the channel axis of the previous sample's row. */
 int evd_awp_feature_integration(const float* feat, const float* z, const float* rays_d, long N, int S, int C, float* out, void* stream);
+/* Its backward (what torch.autograd does behind awp.py:98-104 during training, run_nerf.py:593-601): d out dev [N,C] -> d feat dev
+ * [N,S,C]; d z dev [N,S] and d rays_d dev [N,3] where wanted (null: skipped; the distances are (z[s+1] - z[s]) |rays_d|, awp.py:61-63). */
+int evd_awp_feature_integration_bwd(const float* feat, const float* z, const float* rays_d, const float* d_out, long N, int S, int C,
+                                    float* d_feat, float* d_z, float* d_rays_d, void* stream);
 
 /* EDI prior (utils/edi.py:73-95): bii dev [steps-1, npix], blurry dev [npix] -> sharp dev [npix] */
 int evd_edi_deblur(const float* blurry, const float* bii, int steps, long npix, float* sharp, void* stream);

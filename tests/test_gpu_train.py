@@ -804,3 +804,39 @@ def test_loss_block_gradients_against_the_reference_golden(cfg):
         ref = torch.tensor(g[f"{cfg}_g.{k}"], dtype=torch.float64)
         err = rel_l2(v.detach().cpu().double().reshape(ref.shape), ref)
         assert err < 2e-4, (k, err)
+
+
+@pytest.mark.parametrize("S,Cc", [(40, 64), (128, 64), (33, 128), (7, 20)])
+def test_awp_feature_integration_backward_matches_torch_autograd(S, Cc):
+    """Backward of the AWP consumer's compositing scan (evd_awp_feature_integration_bwd behind awp.feature_integration's autograd node)
+    against torch autograd of the reference's lines restated in float64 (awp.py:58-75, AS WRITTEN: zeros appended, cumprod along the
+    channel axis): gradients w.r.t. the per-sample features, z_vals and rays_d; relative L2 <= 1e-5."""
+    from evdeblurnerf_amd.awp import feature_integration
+    T = lambda x: torch.as_tensor(np.ascontiguousarray(x), device="cuda")
+    rs = np.random.RandomState(S + Cc)
+    n_rays, n_motion = 6, 5
+    N = n_rays * n_motion
+    feat_np = np.abs(rs.standard_normal((n_rays, n_motion, S, Cc))).astype(np.float32) * rs.choice([0.05, 1.0, 8.0], size=(n_rays, n_motion, 1, 1)).astype(np.float32)
+    z_np = np.sort(rs.uniform(0, 1, (N, S)).astype(np.float32), -1)
+    rd_np = rs.standard_normal((N, 3)).astype(np.float32)
+    g_np = rs.standard_normal((n_rays, n_motion, Cc)).astype(np.float32)
+
+    def ref(feat, z_vals, rays_d):          # awp.py:58-75 in float64
+        f = feat.reshape(-1, S, Cc)
+        dists = (z_vals[..., 1:] - z_vals[..., :-1]) * torch.norm(rays_d[..., None, :], dim=-1)
+        alpha = -torch.exp(-f[..., :-1, :] * dists[..., None]) + 1
+        alpha = torch.cat([alpha, torch.zeros_like(alpha[:, 0:1])], dim=-2)
+        w = alpha * torch.cumprod(torch.cat([torch.ones((alpha.shape[0], 1, alpha.shape[-1]), dtype=f.dtype, device=f.device), -alpha + (1. + 1e-10)], -2), -1)[:, :-1, :]
+        return torch.sum(w * f, dim=-2).reshape(n_rays, n_motion, Cc)
+
+    a = [T(feat_np).requires_grad_(True), T(z_np).requires_grad_(True), T(rd_np).requires_grad_(True)]
+    out = feature_integration(*a)
+    (out * T(g_np)).sum().backward()
+    b = [T(feat_np).double().requires_grad_(True), T(z_np).double().requires_grad_(True), T(rd_np).double().requires_grad_(True)]
+    r = ref(*b)
+    (r * T(g_np).double()).sum().backward()
+    assert float((out.double() - r).abs().max()) < 1e-5 * max(1.0, float(r.abs().max()))
+    for name, x, y in zip(("d feat", "d z", "d rays_d"), a, b):
+        rel = float((x.grad.double() - y.grad).norm() / max(float(y.grad.norm()), 1e-30))
+        print(f"[awp scan bwd S={S} C={Cc}] {name}: relative L2 {rel:.2e}")
+        assert rel < 1e-5, name
