@@ -688,6 +688,9 @@ __global__ __launch_bounds__(256) void k_voxel_sample_bwd(const GridParams g, co
             }
         }
         __syncthreads();
+        // (Re-measured in round 2 with the half-tile walk that keeps a ray's runs together -- successive samples of an NDC ray address
+        // ~12 distinct x-y cells and ~7 x / y line cells per 32 samples --: summing the run in a register before ONE atomic is 1.5-1.9x
+        // SLOWER, 2.76 vs 1.46 ms at 2^19 samples: the walk is a chain of dependent LDS reads, the sweep below is not.)
         for (int sl = ss; sl < VS_SAMPLES; sl += 2) {
 #pragma unroll
             for (int m = 0; m < MQ; ++m) {
