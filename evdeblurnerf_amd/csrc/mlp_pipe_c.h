@@ -84,6 +84,13 @@ template <int NCH> struct CStream {
                      "global_load_lds_dwordx4 %0, %1 offset:2048\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072"
                      : : "v"(off), "s"(gbase), "s"(dst) : "memory");      // M0 is left changed: hipcc keeps nothing in M0 in this kernel (no other user)
     }
+    // one 1 KiB piece k of chunk c (the pieces of a chunk go out one at a time, three consumed units apart: the LDS takes the DMA writes in
+    // four short bursts between the fragment reads instead of one long one)
+    __device__ __forceinline__ void issue_piece(int c, int k) {
+        const unsigned off = voff + (unsigned)c * CCfg::CB + (unsigned)k * 1024;
+        const unsigned dst = dst0 + (unsigned)(c & (NSLOT - 1)) * CCfg::CB + (unsigned)k * 1024;
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(gbase), "s"(dst) : "memory");
+    }
     // wait until at most `chunks` chunks (PIECES loads each) of this wavefront are outstanding
     static __device__ __forceinline__ void wait_chunks(int chunks) {
         switch (chunks) {
@@ -312,12 +319,29 @@ __device__ __forceinline__ void c_group(ST& st, CPipe& pp, XBlk (&in)[NIN], XBlk
     // of chunk c (the matrix pipe has restarted behind the barrier by then), the barrier that releases chunk c its last unit
     auto chunks = [&](int t0, int t1) __attribute__((always_inline)) {
         const int c0 = t0 / CCfg::UPC, c1 = t1 / CCfg::UPC;
+#ifndef EVD_C_NOSPREAD      // (all four pieces at the chunk's second unit: 1.4 % slower)
+        auto due = [](int t) constexpr { return cmin(CCfg::PIECES, (t + 1) / 3); };      // pieces issued once t units of the chunk are consumed: at 2, 5, 8, 11
+        auto pieces = [&](int c, int k0, int k1) __attribute__((always_inline)) {
+            if (c + ST::NSLOT - 1 >= ST::kChunks || (kAbl & 8)) return;
+#pragma unroll
+            for (int k = 0; k < CCfg::PIECES; ++k)
+                if (k >= k0 && k < k1) st.issue_piece(c + ST::NSLOT - 1, k);
+        };
+        if (c0 == c1) {
+            pieces(L::CHUNK0 + c0, due(t0 % CCfg::UPC), due(t1 % CCfg::UPC));
+        } else {
+            pieces(L::CHUNK0 + c0, due(t0 % CCfg::UPC), CCfg::PIECES);
+            st.chunk_end(L::CHUNK0 + c0);
+            pieces(L::CHUNK0 + c1, 0, due(t1 % CCfg::UPC));
+        }
+#else
         if (c0 == c1) {
             if (t0 % CCfg::UPC < 2 && t1 % CCfg::UPC >= 2) st.chunk_begin(L::CHUNK0 + c0);
         } else {
             st.chunk_end(L::CHUNK0 + c0);
             if (t1 % CCfg::UPC >= 2) st.chunk_begin(L::CHUNK0 + c1);
         }
+#endif
     };
 
     int s = 0, ub = ubase, mm = mbase;      // all three are compile-time constants after unrolling
@@ -432,7 +456,16 @@ template <class L, class NXT, class ST, int NIN, int NOUT>
 __device__ __forceinline__ void c_layer(ST& st, CPipe& pp, XBlk (&in)[NIN], XBlk (&out)[NOUT], float* out_f32, lds_f32_p bias, int lane) {
     static_assert(NIN >= L::NBLK, "input blocks");
     CGroupLoop<L, NXT, ST, NIN, NOUT, 0>::run(st, pp, in, out, bias, lane);
-    if (L::UNITS % CCfg::UPC != 0) st.chunk_end(L::CHUNK0 + L::UNITS / CCfg::UPC);      // the zero-padded tail of the layer's last chunk
+    if (L::UNITS % CCfg::UPC != 0) {             // the zero-padded tail of the layer's last chunk
+#ifndef EVD_C_NOSPREAD
+        constexpr int c = L::CHUNK0 + L::UNITS / CCfg::UPC, k0 = cmin(CCfg::PIECES, (L::UNITS % CCfg::UPC + 1) / 3);
+        if (c + ST::NSLOT - 1 < ST::kChunks && !(kAbl & 8)) {
+#pragma unroll
+            for (int k = k0; k < CCfg::PIECES; ++k) st.issue_piece(c + ST::NSLOT - 1, k);
+        }
+#endif
+        st.chunk_end(L::CHUNK0 + L::UNITS / CCfg::UPC);
+    }
     if constexpr (!std::is_void<NXT>::value) {       // first fragments of the next layer that the last group could not prefetch (c_group)
 #pragma unroll
         for (int k = 0; k < CCfg::PDM - 1; ++k)
