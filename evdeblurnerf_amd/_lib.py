@@ -49,6 +49,10 @@ class VoxelGrads(C.Structure):
     _fields_ = [("sigma_w", _vp * 2), ("color_w", _vp * 3), ("color_b", _vp * 3)]
 
 
+class AwpEmbedGrads(C.Structure):
+    _fields_ = [("w", _vp * 4), ("b", _vp * 4)]
+
+
 class VoxelGridGrads(C.Structure):
     _fields_ = [("plane", _vp * 3), ("line", _vp * 3), ("basis", _vp)]
 
@@ -83,6 +87,14 @@ SIGNATURES = {
     "evd_rbk_warp": (_I, [_vp, _vp, _vp, _L, _I, _I, _vp, _vp, _vp]),
     "evd_awp_feature_integration": (_I, [_vp, _vp, _vp, _L, _I, _I, _vp, _vp]),
     "evd_awp_feature_integration_bwd": (_I, [_vp, _vp, _vp, _vp, _L, _I, _I, _vp, _vp, _vp, _vp]),
+    "evd_awp_embed_create": (_I, [C.POINTER(_fp), C.POINTER(_fp), _I, _I, _I, C.POINTER(_vp)]),
+    "evd_awp_embed_destroy": (None, [_vp]),
+    "evd_awp_embed_param_count": (_L, [_vp]),
+    "evd_awp_embed_load_params": (_I, [_vp, _vp, _vp]),
+    "evd_awp_embed_store_bytes": (_S, [_vp, _L]),
+    "evd_awp_embed_backward_workspace_bytes": (_S, []),
+    "evd_awp_embed_forward": (_I, [_vp, _I, _vp, _vp, _vp, _S, _L, _vp, _vp, _S, _vp]),
+    "evd_awp_embed_backward": (_I, [_vp, _I, _vp, _L, _vp, _S, C.POINTER(AwpEmbedGrads), _vp, _vp, _S, _vp]),
     "evd_probe_mfma_rate": (_I, [_I, _I, C.POINTER(C.c_double), _vp]),
     "evd_device_count": (_I, []),
     "evd_get_rays": (_I, [_I, _I, _fp, _fp, _vp, _vp, _vp]),
@@ -108,7 +120,8 @@ SIGNATURES = {
     "evd_voxel_train_store_bytes": (_S, [_vp, _L]),
     "evd_voxel_backward_workspace_bytes": (_S, []),
     "evd_voxel_mlp_train": (_I, [_vp, _I, _vp, _vp, _I, _vp, _I, _L, _I, _vp, _vp, _vp, _S, _vp]),
-    "evd_voxel_mlp_backward": (_I, [_vp, _I, _vp, _vp, _vp, _L, _I, _vp, _S, C.POINTER(VoxelGrads), _vp, _I, _vp, _vp, _I, _vp, _vp, _vp, _S, _vp]),
+    "evd_voxel_geo_feat_dim": (_I, [_vp]),
+    "evd_voxel_mlp_backward": (_I, [_vp, _I, _vp, _vp, _vp, _vp, _S, _L, _I, _vp, _S, C.POINTER(VoxelGrads), _vp, _I, _vp, _vp, _I, _vp, _vp, _vp, _S, _vp]),
     "evd_voxel_grid_sizes": (_I, [_vp, C.POINTER(C.c_long)]),
     "evd_voxel_get_grids": (_I, [_vp, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp]),
     "evd_voxel_load_grids": (_I, [_vp, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp]),

@@ -1,12 +1,16 @@
-"""The compositing scan of the AWP consumer (reference ``networks/dpnerf/awp.py``): the one piece of
-``AdaptiveWeightProposal`` that is a scan over the path's per-sample outputs, forward and backward (an autograd node on
-hand-written kernels).  The rest of AWP (sample / motion embedding MLPs, MotionAggregationModule) stays PyTorch in the
-reference's caller."""
+"""The AWP consumer of the path's per-sample outputs (reference ``networks/dpnerf/awp.py``): the per-sample part of
+``AdaptiveWeightProposal`` -- ``sample_feature_embed_layer`` (awp.py:36-37,98-100: 4 x Linear + ReLU over every sample of every
+sub-exposure ray) and the ``feature_integration`` scan (awp.py:49-77) -- on hand-written kernels, forward and backward, as autograd
+nodes.  ``FusedAWP`` wraps the reference's module: the per-ray remainder (motion embedding, MotionAggregationModule, ``w_linear``:
+[R, P, 32]-sized tensors) stays its PyTorch submodules, as in the reference's caller."""
 from __future__ import annotations
+
+import ctypes as C
 
 import torch
 
 from . import _lib as L
+from .voxnerf import GeoFragments
 
 
 class _FeatureIntegration(torch.autograd.Function):
@@ -47,3 +51,130 @@ def feature_integration(feat, z_vals, rays_d, raw_noise_std=0, white_bkgd=False,
     if z.shape[0] != N or d.shape[0] != N:
         raise L.EvdError("feature_integration: z_vals / rays_d need one row per (ray, motion)")
     return _FeatureIntegration.apply(f, z, d).reshape(n_rays, n_motion, Cc)
+
+
+class _SampleEmbed(torch.autograd.Function):
+    """evd_awp_embed_forward / _backward.  `src` is either the GeoFragments token (the geo features are read as the fragments of the
+    fine level's store, and their gradient is left as fragments for the level's backward) or a float32 tensor [n, 128]."""
+
+    @staticmethod
+    def forward(ctx, src, flat, embed, geo):
+        lib, prec = L.lib(), L.PREC[embed.precision]
+        if geo is not None:
+            n, rows, dev = geo.R * geo.S, None, geo.store.device
+        else:
+            rows = src.reshape(-1, embed.input_ch).contiguous().float()
+            n, dev = rows.shape[0], rows.device
+        nb = int(lib.evd_awp_embed_store_bytes(embed._h, n))
+        store = torch.empty((nb,), dtype=torch.uint8, device=dev)
+        h_local = torch.empty((n, embed.width), dtype=torch.float32, device=dev)
+        L.check(lib.evd_awp_embed_forward(embed._h, prec, L.ptr(rows), geo.level._h if geo is not None else None,
+                                          L.ptr(geo.store) if geo is not None else None, geo.store.numel() if geo is not None else 0, n,
+                                          L.ptr(h_local), L.ptr(store), nb, L.stream_ptr()), "evd_awp_embed_forward")
+        ctx.embed, ctx.geo, ctx.store, ctx.n, ctx.src_shape = embed, geo, store, n, src.shape
+        return h_local
+
+    @staticmethod
+    def backward(ctx, d_h):
+        embed, lib, n = ctx.embed, L.lib(), ctx.n
+        g = d_h.contiguous().float()
+        gflat = torch.zeros((embed.nparam,), dtype=torch.float32, device=g.device)
+        gs, base = L.AwpEmbedGrads(), gflat.data_ptr()
+        for l, (wo, bo) in enumerate(embed.offsets):
+            gs.w[l], gs.b[l] = base + 4 * wo, base + 4 * bo
+        d_rows = torch.empty((n, embed.input_ch), dtype=torch.float32, device=g.device) if (ctx.geo is None and ctx.needs_input_grad[0]) else None
+        nb = int(lib.evd_awp_embed_backward_workspace_bytes())
+        ws = torch.empty((nb,), dtype=torch.uint8, device=g.device)
+        L.check(lib.evd_awp_embed_backward(embed._h, L.PREC[embed.precision], L.ptr(g), n, L.ptr(ctx.store), ctx.store.numel(), C.byref(gs),
+                                           L.ptr(d_rows), L.ptr(ws), nb, L.stream_ptr()), "evd_awp_embed_backward")
+        if ctx.geo is not None:
+            ctx.geo.awp_store = ctx.store          # the level's backward (which autograd runs after this node) adds the d geo fragments
+            d_src = torch.zeros(ctx.src_shape, dtype=torch.float32, device=g.device)
+        else:
+            d_src = d_rows.reshape(ctx.src_shape) if d_rows is not None else None
+        ctx.store = None
+        return d_src, gflat, None, None
+
+
+class SampleFeatureEmbed:
+    """sample_feature_embed_layer (awp.py:36-37) as a library handle: weights[l] [64, in_l], biases[l] [64] (nn.Linear layouts)."""
+
+    def __init__(self, weights, biases, precision="f16"):
+        ws = [torch.as_tensor(w).detach().float().cpu().contiguous() for w in weights]
+        bs = [torch.as_tensor(b).detach().float().cpu().contiguous() for b in biases]
+        self.depth, self.width, self.input_ch, self.precision = len(ws), ws[0].shape[0], ws[0].shape[1], precision
+        fp = C.POINTER(C.c_float)
+        wa = (fp * len(ws))(*[C.cast(w.data_ptr(), fp) for w in ws])
+        ba = (fp * len(bs))(*[C.cast(b.data_ptr(), fp) for b in bs])
+        h = C.c_void_p()
+        L.check(L.lib().evd_awp_embed_create(wa, ba, self.input_ch, self.width, self.depth, C.byref(h)), "evd_awp_embed_create")
+        self._h = h
+        self.nparam = int(L.lib().evd_awp_embed_param_count(h))
+        self.offsets, off = [], 0
+        for w, b in zip(ws, bs):
+            self.offsets.append((off, off + w.numel()))
+            off += w.numel() + b.numel()
+        self._synced = None
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            L.lib().evd_awp_embed_destroy(self._h)
+            self._h = None
+
+    def load_params(self, flat):
+        f = flat.detach().contiguous().float()
+        if f.numel() != self.nparam:
+            raise L.EvdError(f"flat parameter tensor has {f.numel()} elements, the embedding {self.nparam}")
+        L.check(L.lib().evd_awp_embed_load_params(self._h, L.ptr(f), L.stream_ptr()), "evd_awp_embed_load_params")
+
+    def __call__(self, flat, geo):
+        """flat: the parameters W0, b0, W1, b1, ... (re-packed into the library's streams before the launch); geo: GeoFragments or a
+        float32 tensor [..., 128] -> h_local [n, 64] with autograd to flat and to the geo features"""
+        self.load_params(flat)
+        if isinstance(geo, GeoFragments):
+            return _SampleEmbed.apply(geo.token, flat, self, geo)
+        return _SampleEmbed.apply(geo, flat, self, None)
+
+
+class FusedAWP(torch.nn.Module):
+    """Drop-in for the reference's AdaptiveWeightProposal in NeRFAll(awpnet=...): wraps THAT module (its parameters stay where the
+    optimizer and the state dict expect them) and runs awp.py:79-117 with the per-sample part on the library:
+
+        sample_feature_embed_layer   awp.py:98-100   -> evd_awp_embed_forward / _backward (reads the fine level's geo fragments)
+        feature_integration          awp.py:102      -> evd_awp_feature_integration / _bwd
+        motion embedding, MAM, w_linear, normalisation  awp.py:104-117 -> the wrapped module's own submodules (per-ray sized)
+
+    `depth_feature` is the GeoFragments handle NeRFAll.forward_train passes when its awpnet is a FusedAWP (a float32 tensor
+    [R P, S, 128] is accepted too)."""
+
+    def __init__(self, awpnet, precision="f16"):
+        super().__init__()
+        self.ref = awpnet
+        layers = list(awpnet.sample_feature_embed_layer)
+        self.embed = SampleFeatureEmbed([l.weight for l in layers], [l.bias for l in layers], precision)
+        self.output_ch = awpnet.output_ch
+
+    @property
+    def ccw_fine_scale(self):
+        return self.ref.ccw_fine_scale
+
+    def _flat(self):
+        return torch.cat([t.reshape(-1) for l in self.ref.sample_feature_embed_layer for t in (l.weight, l.bias)])
+
+    def forward(self, depth_feature, z_vals, rays_d, view_feature):
+        m, P = self.ref, self.output_ch
+        n_ray, S = z_vals.shape[0] // P, z_vals.shape[-1]
+        dirs = rays_d.reshape(n_ray, P, -1)[:, 0, :]
+        dirs = (dirs / torch.norm(dirs, dim=-1, keepdim=True)).reshape(-1, 3).float()
+        view = m.ray_dirs_embed_fn(dirs)                                          # awp.py:89-95
+        if view_feature is not None:
+            view = torch.cat([view_feature, view], dim=-1)
+        h_local = self.embed(self._flat(), depth_feature).reshape(n_ray * P, S, self.embed.width)     # awp.py:98-100
+        h = feature_integration(h_local.reshape(n_ray, P, S, -1), z_vals, rays_d)                      # awp.py:102
+        h = torch.cat([h, view.unsqueeze(1).repeat(1, P, 1)], dim=-1)
+        for layer in m.motion_feature_embed_layer:                                # awp.py:107-109
+            h = torch.relu(layer(h))
+        h = m.MAM(h, h_local)                                                     # awp.py:111
+        h = torch.nn.functional.adaptive_avg_pool1d(h.transpose(1, 2), 1).squeeze(-1)
+        w = torch.sigmoid(m.w_linear(h))
+        return w / torch.sum(w, -1, keepdim=True)

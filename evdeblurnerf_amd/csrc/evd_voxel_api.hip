@@ -6,7 +6,7 @@
 #include "voxel.h"
 #include "voxel_mlp_kernel.h"
 #include "voxel_train.h"
-
+#include "awp_embed.h"
 
 #include <cmath>
 #include <cstdint>
@@ -472,7 +472,10 @@ int evd_voxel_mlp_train(const evd_voxel* v, int precision, const float* pts, con
     return launch_voxel_train_fwd_dispatch(precision, v->hidden_dim, p, as_stream(stream));
 }
 
-int evd_voxel_mlp_backward(const evd_voxel* v, int precision, const float* d_raw, const float* raw, const float* d_feature, long R, int S, void* store,
+int evd_voxel_geo_feat_dim(const evd_voxel* v) { return v ? v->geo : 0; }
+
+int evd_voxel_mlp_backward(const evd_voxel* v, int precision, const float* d_raw, const float* raw, const float* d_feature, const void* awp_store,
+                           size_t awp_store_bytes, long R, int S, void* store,
                            size_t store_bytes, const evd_voxel_grads* grads, float* d_fts, int d_fts_stride, const float* pts, const float* viewdirs, int vd_stride,
                            float* d_pts, float* d_dirs, void* workspace, size_t workspace_bytes, void* stream) {
     EVD_REQUIRE((!d_pts || pts) && (!d_dirs || viewdirs), "evd_voxel_mlp_backward: d_pts / d_dirs need the forward's pts / viewdirs");
@@ -485,6 +488,14 @@ int evd_voxel_mlp_backward(const evd_voxel* v, int precision, const float* d_raw
     if (workspace_bytes < evd_voxel_backward_workspace_bytes()) return fail(EVD_E_WORKSPACE, "evd_voxel_mlp_backward: workspace %zu < %zu bytes", workspace_bytes, evd_voxel_backward_workspace_bytes());
     VoxBwdPlan b;
     b.d_raw = d_raw; b.raw = raw; b.d_feature = d_feature; b.nsamp = nsamp; b.tiles = vox_tiles(nsamp); b.store = (char*)store;
+    b.awp_store = nullptr; b.awp_tile_bytes = 0; b.awp_slot = 0; b.awp_words = nullptr;
+    if (awp_store) {            // the fused AWP embedding ran its backward on this sample set: its d geo fragments join this level's
+        const size_t need = (size_t)awp_tiles(nsamp) * awpstore::TILE_BYTES + awpstore::TRAILER_BYTES;
+        EVD_REQUIRE(v->geo == AWP_IN, "evd_voxel_mlp_backward: awp_store goes with the fine level (geo %d)", AWP_IN);
+        if (awp_store_bytes < need) return fail(EVD_E_WORKSPACE, "evd_voxel_mlp_backward: awp_store %zu < %zu bytes", awp_store_bytes, need);
+        b.awp_store = (const char*)awp_store; b.awp_tile_bytes = awpstore::TILE_BYTES; b.awp_slot = awpstore::D_GEO;
+        b.awp_words = (const unsigned*)(b.awp_store + awp_tiles(nsamp) * awpstore::TILE_BYTES);
+    }
     for (int k = 0; k < VBWD_NSTREAMS; ++k) b.wt[k] = (const char*)v->bwd[precision][k].data.p;
     b.maps = (const int*)v->wmaps.p;
     char* w = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);

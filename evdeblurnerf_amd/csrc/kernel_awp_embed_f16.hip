@@ -1,0 +1,9 @@
+// f16 instantiation of the AWP sample-feature embedding kernels (awp_embed_kernel.h).
+#include "awp_embed_kernel.h"
+
+namespace evd {
+
+int launch_awp_embed_f16(bool train, const AwpFwdParams& p, hipStream_t st) { return launch_awp_embed<EVD_PREC_F16>(train, p, st); }
+int run_awp_backward_f16(const AwpBwdPlan& b, hipStream_t st) { return run_awp_backward<EVD_PREC_F16>(b, st); }
+
+}  // namespace evd

@@ -27,6 +27,10 @@ struct VoxBwdGrads {                    // device float32, reference nn.Linear l
 struct VoxBwdPlan {
     const float *d_raw, *raw;           // [nsamp, 4]
     const float* d_feature;             // [nsamp, G] gradient of the geo-feature output, or null
+    const char* awp_store;              // the AWP embedding's store after ITS backward (awp_embed.h): d geo fragments to add, or null
+    long awp_tile_bytes;
+    int awp_slot;
+    const unsigned* awp_words;          // its trailer: loss-scale word, max |d geo| in true units
     long nsamp, tiles;
     char* store;
     const char* wt[VBWD_NSTREAMS];
@@ -54,6 +58,7 @@ inline int launch_voxel_train_fwd_dispatch(int prec, int HD, const VoxMlpParams&
 inline int run_voxel_backward_dispatch(int prec, int HD, const VoxBwdPlan& b, hipStream_t st) {
     return prec == 3 ? run_voxel_backward_f16(HD, b, st) : run_voxel_backward_bf16(HD, b, st);
 }
+int voxel_store_geo_slot(int HD);         // first of the geo fragments the training forward keeps (fine level: 8 fragments)
 long voxel_store_tile_bytes(int HD);      // fine 256 / 128 / 64 or coarse 64 / 15 / 32 (kernel_voxel_train_f16.hip)
 
 }  // namespace evd

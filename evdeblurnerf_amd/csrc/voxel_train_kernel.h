@@ -93,6 +93,35 @@ __global__ __launch_bounds__(256) void k_rows_add_to_frags(char* __restrict__ st
     act_store(a, slot + j, b);
 }
 
+// *dst = max(*dst, *src) on float bits (both non-negative): the loss scale also covers a gradient that arrives as fragments
+static __global__ void k_max_word(unsigned* __restrict__ dst, const unsigned* __restrict__ src) { atomicMax(dst, *src); }
+
+// gradient fragments of ANOTHER store (the AWP embedding's d geo, awp_embed.h: its own loss-scale word) added into this level's
+template <int PREC>
+__global__ __launch_bounds__(256) void k_frags_add_scaled(char* __restrict__ store, long tile_bytes, int slot, const char* __restrict__ src, long src_tile_bytes,
+                                                          int src_slot, int nfrag, long tiles, const unsigned* __restrict__ maxbits,
+                                                          const unsigned* __restrict__ src_maxbits) {
+    typedef POps<PREC> O;
+    pipe_fp16_saturate<PREC>();
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x, tile = idx / (64 * nfrag);
+    if (tile >= tiles) return;
+    const int j = (int)((idx / 64) % nfrag), lane = idx & 63;
+    char* a = store + tile * tile_bytes + lane * 16;
+    const W4 f = frag_load<W4>(a, slot + j), g = frag_load<W4>(src + tile * src_tile_bytes + lane * 16, src_slot + j);
+    const float s = grad_scale(*maxbits, false) * grad_scale(*src_maxbits, true);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const unsigned short fb = (unsigned short)(f.w[e >> 1] >> (16 * (e & 1))), gb = (unsigned short)(g.w[e >> 1] >> (16 * (e & 1)));
+        if constexpr (PREC == EVD_PREC_BF16) v[e] = __uint_as_float((unsigned)fb << 16) + __uint_as_float((unsigned)gb << 16) * s;
+        else v[e] = (float)__builtin_bit_cast(_Float16, fb) + (float)__builtin_bit_cast(_Float16, gb) * s;
+    }
+    typename O::B b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) O::template set_pair<false>(b, e, v[2 * e], v[2 * e + 1]);
+    act_store(a, slot + j, b);
+}
+
 template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const VoxBwdPlan& b, hipStream_t st) {
     typedef VStore<HD, G, FT> VS;
     constexpr int T = HD / 32, KS = HD / 16, KF = FT / 16, GT = VS::GT, FTT = (FT + 31) / 32, IC = 3 * (1 + 2 * PE_L), ICV = 3 * (1 + 2 * PE_LV);
@@ -102,6 +131,10 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
     EVD_LAUNCH_CHECK();
     if (b.d_feature) {          // the loss scale covers both incoming gradients
         hipLaunchKernelGGL(k_absmax, dim3(2048), dim3(256), 0, st, b.d_feature, b.nsamp * G, b.maxbits);
+        EVD_LAUNCH_CHECK();
+    }
+    if (b.awp_store) {          // ... and the d geo fragments of the AWP embedding's backward (true-unit maximum in its trailer)
+        hipLaunchKernelGGL(k_max_word, dim3(1), dim3(1), 0, st, b.maxbits, b.awp_words + 1);
         EVD_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL((k_voxel_grad_frags<PREC>), dim3((unsigned)cdiv(b.tiles * 64, 256L)), dim3(256), 0, st, b.d_raw, b.raw, b.nsamp, b.maxbits, b.store,
@@ -149,6 +182,12 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
         if (G % 16) return fail(EVD_E_INVALID, "evd_voxel_mlp_backward: d_feature is built for the fine level (geo 128)");
         hipLaunchKernelGGL((k_rows_add_to_frags<PREC>), dim3((unsigned)cdiv(b.tiles * 64 * (G / 16), 256L)), dim3(256), 0, st, b.store, VS::TILE_BYTES, VS::D_GEO,
                            G / 16, b.nsamp, b.maxbits, b.d_feature, G);
+        EVD_LAUNCH_CHECK();
+    }
+    if (b.awp_store) {          // + the gradient that reached the geo features through the fused AWP embedding (awp_embed_kernel.h)
+        if (G % 16) return fail(EVD_E_INVALID, "evd_voxel_mlp_backward: the AWP embedding reads the fine level (geo 128)");
+        hipLaunchKernelGGL((k_frags_add_scaled<PREC>), dim3((unsigned)cdiv(b.tiles * 64 * (G / 16), 256L)), dim3(256), 0, st, b.store, VS::TILE_BYTES, VS::D_GEO,
+                           b.awp_store, b.awp_tile_bytes, b.awp_slot, G / 16, b.tiles, b.maxbits, b.awp_words);
         EVD_LAUNCH_CHECK();
     }
     if (b.d_dirs) {

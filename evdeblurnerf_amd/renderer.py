@@ -292,7 +292,11 @@ class NeRFAll:
         ptm = o + d * zm[..., None]
         ft = torch.cat([ftc, fine.sample_train(ptm, pf["grids"])], -1)
         feat = None
-        if want_feature:
+        if want_feature == "fragments":                     # fused AWP consumer: the geo features stay in the level's store (awp.FusedAWP)
+            from .voxnerf import GeoFragments
+            feat = GeoFragments()
+            raw1, feat.token = fine.mlp_train(pf["net"], ptm, vd, ft, self.precision, want_feature=feat)
+        elif want_feature:
             raw1, feat = fine.mlp_train(pf["net"], ptm, vd, ft, self.precision, want_feature=True)
         else:
             raw1 = fine.mlp_train(pf["net"], ptm, vd, ft, self.precision)
@@ -340,7 +344,9 @@ class NeRFAll:
             flat_rays = rays
         rb = self.ray_batch_train(H, W, K, flat_rays, ndc, near, far)
         awp = use_kernel and self.use_awp
-        out = self.render_rays_train(rb, params_coarse, params_fine, N_samples, N_importance, want_feature=awp, **kw)
+        from .awp import FusedAWP
+        fused = awp and isinstance(self.awpnet, FusedAWP) and self.mode == "c2f"
+        out = self.render_rays_train(rb, params_coarse, params_fine, N_samples, N_importance, want_feature="fragments" if fused else awp, **kw)
         rgb, rgb0 = out["rgb_map"], out.get("rgb0")
         if awp:         # adaptive weight proposal on the fine level's per-sample features (renderer.py:310-316): a second composition
             ccw = self.awpnet(out["depth_feature"], out["z_vals"], rb[:, 3:6], extra1["img_embed"])

@@ -47,26 +47,46 @@ class _VoxelSample(torch.autograd.Function):
         return (d_pts.reshape(ctx.pts.shape) if d_pts is not None else None, None, *grads)
 
 
+class GeoFragments:
+    """The fine level's per-sample geo features of ONE training forward, left where the level's kernel keeps them for its own
+    backward: float16 / bfloat16 MFMA fragments in its activation store.  This is what `depth_feature` (renderer.py:253-256) becomes
+    when the AWP consumer is the fused one (awp.FusedAWP): the float32 tensor [R P, S, 128] is never written.  `token` ties the
+    consumer into the autograd graph; `awp_store` is set by the consumer's backward (its d geo fragments, picked up by
+    evd_voxel_mlp_backward)."""
+
+    def __init__(self):
+        self.level = self.store = self.token = self.awp_store = self.precision = None
+        self.R = self.S = 0
+
+
 class _VoxelMLP(torch.autograd.Function):
     """per-sample sigma / colour networks of one level (voxnerf.py:210-221,240-254) with the hand-written backward:
     gradients to the flat parameter tensor and to the sampled features (evd_voxel_mlp_train / _backward)"""
 
     @staticmethod
     def forward(ctx, flat, fts, pts, viewdirs, net, precision, want_feature=False):
-        raw, store, feature = net.mlpforward_train(pts, viewdirs, fts, precision, want_feature=want_feature)
+        geo = want_feature if isinstance(want_feature, GeoFragments) else None
+        rows = bool(want_feature) and geo is None
+        raw, store, feature = net.mlpforward_train(pts, viewdirs, fts, precision, want_feature=rows)
         ctx.net, ctx.precision, ctx.store, ctx.raw = net, precision, store, raw
-        ctx.ft_shape, ctx.pts, ctx.viewdirs, ctx.has_feature = fts.shape, pts, viewdirs, want_feature
-        return (raw, feature) if want_feature else raw
+        ctx.ft_shape, ctx.pts, ctx.viewdirs, ctx.has_feature, ctx.geo = fts.shape, pts, viewdirs, rows, geo
+        if geo is not None:
+            geo.level, geo.store, geo.precision, geo.R, geo.S = net, store, precision, pts.shape[0], pts.shape[1]
+            return raw, torch.zeros((1,), dtype=torch.float32, device=raw.device)
+        return (raw, feature) if rows else raw
 
     @staticmethod
     def backward(ctx, d_raw, d_feature=None):
         need = ctx.needs_input_grad
         if d_raw is None:
             d_raw = torch.zeros_like(ctx.raw)
+        awp_store = ctx.geo.awp_store if ctx.geo is not None else None
         gflat, d_fts, d_pts, d_dirs = ctx.net.mlp_backward_flat(d_raw, ctx.raw, ctx.store, ctx.precision, want_fts=need[1],
                                                                 pts=ctx.pts if need[2] else None, viewdirs=ctx.viewdirs if need[3] else None,
-                                                                d_feature=d_feature if ctx.has_feature else None)
+                                                                d_feature=d_feature if ctx.has_feature else None, awp_store=awp_store)
         ctx.store = ctx.raw = None
+        if ctx.geo is not None:
+            ctx.geo.store = ctx.geo.awp_store = None
         R, S = ctx.pts.shape[:2]
         return (gflat, d_fts.reshape(ctx.ft_shape) if d_fts is not None else None, d_pts.reshape(ctx.pts.shape) if d_pts is not None else None,
                 d_dirs.reshape(R, S, 3).sum(1) if d_dirs is not None else None, None, None, None)
@@ -222,7 +242,7 @@ class VoxelNeRFBase:
                                              R, S, L.ptr(raw), L.ptr(feature), L.ptr(store), nb, L.stream_ptr()), "evd_voxel_mlp_train")
         return raw, store, feature
 
-    def mlp_backward_flat(self, d_raw, raw, store, precision=None, want_fts=True, pts=None, viewdirs=None, d_feature=None):
+    def mlp_backward_flat(self, d_raw, raw, store, precision=None, want_fts=True, pts=None, viewdirs=None, d_feature=None, awp_store=None):
         """-> (flat parameter gradient, d fts | None, d pts | None, d dirs per sample | None); the last two (through the positional
         encodings) are computed when the forward's pts / viewdirs are passed"""
         g = d_raw.contiguous().float()
@@ -242,14 +262,16 @@ class VoxelNeRFBase:
         d_pts = torch.empty((R * S, 3), dtype=torch.float32, device=g.device) if p is not None else None
         d_dirs = torch.empty((R * S, 3), dtype=torch.float32, device=g.device) if vd is not None else None
         df = d_feature.contiguous().float() if d_feature is not None else None
-        L.check(L.lib().evd_voxel_mlp_backward(self._h, L.PREC[precision or self.precision], L.ptr(g), L.ptr(raw), L.ptr(df), R, S, L.ptr(store), store.numel(),
+        L.check(L.lib().evd_voxel_mlp_backward(self._h, L.PREC[precision or self.precision], L.ptr(g), L.ptr(raw), L.ptr(df), L.ptr(awp_store),
+                                                awp_store.numel() if awp_store is not None else 0, R, S, L.ptr(store), store.numel(),
                                                 C.byref(gs), L.ptr(d_fts), self.ft_dim, L.ptr(p), L.ptr(vd), vd.shape[-1] if vd is not None else 0,
                                                 L.ptr(d_pts), L.ptr(d_dirs), L.ptr(ws), nb, L.stream_ptr()), "evd_voxel_mlp_backward")
         return flat, d_fts, d_pts, d_dirs
 
     def mlp_train(self, flat, pts, viewdirs, fts, precision=None, want_feature=False):
         """raw [R,S,4] = (sigma, sigmoid(colour)) with autograd to the flat parameters, the sampled features and the rays;
-        want_feature (fine level): also the per-sample geo features [R,S,geo] (voxnerf.py:221), an autograd output too"""
+        want_feature (fine level): also the per-sample geo features [R,S,geo] (voxnerf.py:221), an autograd output too; a
+        GeoFragments instance instead of True: the features stay fragments in the level's store, the second output is its token"""
         if getattr(self, "_synced_net", None) != (flat.data_ptr(), flat._version):
             self.load_params(flat)
         return _VoxelMLP.apply(flat, fts, pts, viewdirs, self, precision or self.precision, want_feature)

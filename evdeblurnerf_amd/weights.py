@@ -118,6 +118,15 @@ def make_crf_state_dict(seed: int, extra_features: int = 0):
     return sd
 
 
+def make_awp_embed_state_dict(seed: int, input_ch: int = 128, W_sam: int = 64, D_sam: int = 4):
+    """``sample_feature_embed_layer.{l}.{weight,bias}`` of the reference's AdaptiveWeightProposal (networks/dpnerf/awp.py:36-37)."""
+    rs = np.random.RandomState(seed)
+    sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    for l in range(D_sam):
+        _linear(rs, sd, f"sample_feature_embed_layer.{l}", input_ch if l == 0 else W_sam, W_sam)
+    return sd
+
+
 def prefixed(sd, prefix: str):
     """``{prefix}.{name}`` view of a state dict (e.g. ``mlp_coarse``)."""
     return OrderedDict((f"{prefix}.{k}", v) for k, v in sd.items())

@@ -257,8 +257,12 @@ int evd_voxel_tv_loss(const evd_voxel* v, float* out, void* stream);
  * (columns 0 .. ft_dim-1 overwritten; NULL = not wanted), the gradient of the sampled features that evd_voxel_sample_bwd
  * scatters into the grids.  d_pts / d_dirs dev [R*S, 3] (NULL = not wanted; need the forward's pts / viewdirs): the gradient
  * that reaches the sample position through PE(pts) and the view direction through PE(dirs) (per sample: the caller sums over a
- * ray's samples) -- what carries the loss back to the rays, i.e. to the blur kernel's camera motion.  Built for EVD_PREC_F16 / EVD_PREC_BF16, both shipped levels (64/15/32 and 256/128/64). */
+ * ray's samples) -- what carries the loss back to the rays, i.e. to the blur kernel's camera motion.  awp_store (NULL = none; fine
+ * level): the store of the fused AWP embedding AFTER evd_awp_embed_backward ran on the same samples -- its d geo fragments are added
+ * to the geo features' gradient without ever becoming a float32 [R*S,128] tensor (below).
+ * Built for EVD_PREC_F16 / EVD_PREC_BF16, both shipped levels (64/15/32 and 256/128/64). */
 typedef struct { float *sigma_w[2], *color_w[3], *color_b[3]; } evd_voxel_grads;
+int evd_voxel_geo_feat_dim(const evd_voxel* v);
 long evd_voxel_param_count(const evd_voxel* v);
 int evd_voxel_param_blocks(const evd_voxel* v, long* offsets, int capacity);
 int evd_voxel_load_params(evd_voxel* v, const float* params, void* stream);
@@ -266,8 +270,8 @@ size_t evd_voxel_train_store_bytes(const evd_voxel* v, long nsamp);
 size_t evd_voxel_backward_workspace_bytes(void);
 int evd_voxel_mlp_train(const evd_voxel* v, int precision, const float* pts, const float* viewdirs, int vd_stride, const float* fts,
                         int ft_stride, long R, int S, float* raw, float* feature, void* store, size_t store_bytes, void* stream);
-int evd_voxel_mlp_backward(const evd_voxel* v, int precision, const float* d_raw, const float* raw, const float* d_feature, long R, int S,
-                           void* store, size_t store_bytes, const evd_voxel_grads* grads, float* d_fts, int d_fts_stride, const float* pts,
+int evd_voxel_mlp_backward(const evd_voxel* v, int precision, const float* d_raw, const float* raw, const float* d_feature,
+                           const void* awp_store, size_t awp_store_bytes, long R, int S, void* store, size_t store_bytes, const evd_voxel_grads* grads, float* d_fts, int d_fts_stride, const float* pts,
                            const float* viewdirs, int vd_stride, float* d_pts, float* d_dirs, void* workspace,
                            size_t workspace_bytes, void* stream);
 
@@ -368,6 +372,34 @@ int evd_awp_feature_integration(const float* feat, const float* z, const float* 
  * [N,S,C]; d z dev [N,S] and d rays_d dev [N,3] where wanted (null: skipped; the distances are (z[s+1] - z[s]) |rays_d|, awp.py:61-63). */
 int evd_awp_feature_integration_bwd(const float* feat, const float* z, const float* rays_d, const float* d_out, long N, int S, int C,
                                     float* d_feat, float* d_z, float* d_rays_d, void* stream);
+
+/* AdaptiveWeightProposal.sample_feature_embed_layer (networks/dpnerf/awp.py:36-37: D_sam x nn.Linear; :98-100: each followed by ReLU)
+ * fused into one MFMA kernel that reads the fine level's geo features WHERE THEY ALREADY ARE: the reference writes them as
+ * depth_feature [R P, S, 128] float32 (renderer.py:253-256) and runs four torch Linear + ReLU passes over it (:314); here the
+ * training forward of the fine level keeps the geo features as MFMA fragments for its own backward (evd_voxel_mlp_train's store),
+ * evd_awp_embed_forward reads those fragments and writes only h_local dev [n, W_sam] float32 -- the tensor awp.py:102
+ * (feature_integration) and :113 (the MAM) consume.  Built for input_ch 128, W_sam 64, D_sam 4 (fine_geo_feat_dim,
+ * kernel_awp_sam_emb_width / _depth of the shipped configs; EVD_E_INVALID otherwise), EVD_PREC_F16 / EVD_PREC_BF16.
+ *   weights[l] host [W_sam, in_l] / biases[l] host [W_sam]: sample_feature_embed_layer.l.{weight,bias}
+ *   evd_awp_embed_load_params: flat dev float32 arena W0, b0, W1, b1, ... (evd_awp_embed_param_count elements) -> every stream
+ *   evd_awp_embed_forward: geo features EITHER as geo_rows dev [n,128] float32 OR as (fine, fine_store) = the fine level and the
+ *     store its evd_voxel_mlp_train filled for the same n = R*S samples.  store (NULL: inference) keeps the activations for
+ *     evd_awp_embed_backward (evd_awp_embed_store_bytes).
+ *   evd_awp_embed_backward: d_h_local dev [n, W_sam] -> parameter gradients (overwritten; NULL = not wanted) and the geo features'
+ *     gradient, left as fragments in `store` for evd_voxel_mlp_backward(awp_store = store) and, where wanted, written as
+ *     d_geo_rows dev [n,128] float32 (NULL = not wanted). */
+typedef struct evd_awp_embed evd_awp_embed;
+typedef struct { float *w[4], *b[4]; } evd_awp_embed_grads;
+int evd_awp_embed_create(const float* const* weights, const float* const* biases, int input_ch, int width, int depth, evd_awp_embed** out);
+void evd_awp_embed_destroy(evd_awp_embed* a);
+long evd_awp_embed_param_count(const evd_awp_embed* a);
+int evd_awp_embed_load_params(evd_awp_embed* a, const float* params, void* stream);
+size_t evd_awp_embed_store_bytes(const evd_awp_embed* a, long nsamp);
+size_t evd_awp_embed_backward_workspace_bytes(void);
+int evd_awp_embed_forward(const evd_awp_embed* a, int precision, const float* geo_rows, const evd_voxel* fine, const void* fine_store,
+                          size_t fine_store_bytes, long nsamp, float* h_local, void* store, size_t store_bytes, void* stream);
+int evd_awp_embed_backward(const evd_awp_embed* a, int precision, const float* d_h_local, long nsamp, void* store, size_t store_bytes,
+                           const evd_awp_embed_grads* grads, float* d_geo_rows, void* workspace, size_t workspace_bytes, void* stream);
 
 /* EDI prior (utils/edi.py:73-95): bii dev [steps-1, npix], blurry dev [npix] -> sharp dev [npix] */
 int evd_edi_deblur(const float* blurry, const float* bii, int steps, long npix, float* sharp, void* stream);

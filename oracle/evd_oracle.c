@@ -935,6 +935,27 @@ void evo_awp_feature_integration(const float* feat, const float* z, const float*
     }
 }
 
+/* awp.py:98-100: for l in sample_feature_embed_layer: h = relu(l(h)).  nn.Linear = x W^T + b (float32 accumulation in input order) */
+void evo_awp_sample_embed(const float* x, const float* const* W, const float* const* b, long n, int in_dim, int width, int depth, float* out) {
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < n; ++i) {
+        float cur[512], nxt[512];
+        int d = in_dim;
+        for (int c = 0; c < in_dim; ++c) cur[c] = x[(size_t)i * in_dim + c];
+        for (int l = 0; l < depth; ++l) {
+            for (int o = 0; o < width; ++o) {
+                float acc = 0.f;
+                for (int c = 0; c < d; ++c) acc += cur[c] * W[l][(size_t)o * d + c];
+                acc += b[l][o];
+                nxt[o] = acc > 0.f ? acc : 0.f;
+            }
+            d = width;
+            for (int o = 0; o < width; ++o) cur[o] = nxt[o];
+        }
+        for (int o = 0; o < width; ++o) out[(size_t)i * width + o] = cur[o];
+    }
+}
+
 /* ------------------------------------------------------------------ RBK ray warp
  * SE3Field.get_transform (rigid_warping.py:18-30): theta = |rot| + 1e-10, screw axis (rot, trans) / theta;
  * RigidBody.exp_se3 (:72-91): R = I + sin(theta) W + (1 - cos(theta)) W^2 (Rodrigues, :93-107),

@@ -339,6 +339,21 @@ def awp_feature_integration(feat, z, rays_d):
     return out
 
 
+def awp_sample_embed(x, weights, biases):
+    """x [n, in], weights[l] [W, in_l], biases[l] [W] -> [n, W] (awp.py:98-100: depth x Linear + ReLU)"""
+    x = _f(x).reshape(-1, np.asarray(weights[0]).shape[1])
+    ws, bs = [_f(w) for w in weights], [_f(b) for b in biases]
+    fp = C.POINTER(C.c_float)
+    wa = (fp * len(ws))(*[w.ctypes.data_as(fp) for w in ws])
+    ba = (fp * len(bs))(*[b.ctypes.data_as(fp) for b in bs])
+    n, width = x.shape[0], ws[0].shape[0]
+    if x.shape[1] > 512 or width > 512:
+        raise ValueError("evo_awp_sample_embed: widths up to 512")
+    out = np.empty((n, width), np.float32)
+    lib().evo_awp_sample_embed(_p(x), wa, ba, C.c_long(n), x.shape[1], width, len(ws), _p(out))
+    return out
+
+
 def crf_forward(crf: Crf, x, feat=None, skip_learn=False):
     x = _f(x)
     n = x.shape[0]

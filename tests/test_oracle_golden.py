@@ -260,6 +260,45 @@ def test_G15_awp_feature_integration():
         assert maxabs(out.reshape(g[f"{tag}_out"].shape), g[f"{tag}_out"]) < 2e-5 * max(1.0, np.abs(g[f"{tag}_out"]).max())
 
 
+
+def test_G21_awp_sample_embed():
+    """G21: AdaptiveWeightProposal.forward of the reference up to the input of motion_feature_embed_layer (awp.py:98-105): the oracle's
+    sample embedding (evo_awp_sample_embed) and scan against the module's own intermediates; the float64 torch restatement the GPU
+    tests differentiate (tests/test_gpu_awp.py _mlp64 / _scan64 restate the same lines) against the reference's autograd gradients."""
+    import torch
+    g = load_golden("G21_awp_sample_embed")
+    sd = W.make_awp_embed_state_dict(211)
+    ws = [sd[f"sample_feature_embed_layer.{l}.weight"] for l in range(4)]
+    bs = [sd[f"sample_feature_embed_layer.{l}.bias"] for l in range(4)]
+    x = g["depth_feature"]
+    N, S, _ = x.shape
+    h_local = O.awp_sample_embed(x, ws, bs).reshape(N, S, 64)
+    assert maxabs(h_local, g["h_local"]) < 2e-5 * max(1.0, np.abs(g["h_local"]).max())
+    h = O.awp_feature_integration(h_local, g["z"], g["rays_d"])
+    assert maxabs(h.reshape(g["h"][..., :64].shape), g["h"][..., :64]) < 2e-5 * max(1.0, np.abs(g["h"]).max())
+    # gradients: float64 restatement of awp.py:98-102 under torch.autograd vs the reference module's
+    w64 = [torch.tensor(w, dtype=torch.float64, requires_grad=True) for w in ws]
+    b64 = [torch.tensor(b, dtype=torch.float64, requires_grad=True) for b in bs]
+    x64 = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    hh = x64
+    for l in range(4):
+        hh = torch.relu(hh @ w64[l].t() + b64[l])
+    z, d = torch.tensor(g["z"], dtype=torch.float64), torch.tensor(g["rays_d"], dtype=torch.float64)
+    dists = (z[..., 1:] - z[..., :-1]) * torch.norm(d[..., None, :], dim=-1)
+    alpha = -torch.exp(-hh[..., :-1, :] * dists[..., None]) + 1
+    alpha = torch.cat([alpha, torch.zeros_like(alpha[:, 0:1])], dim=-2)
+    wts = alpha * torch.cumprod(torch.cat([torch.ones((N, 1, 64), dtype=torch.float64), -alpha + (1. + 1e-10)], -2), -1)[:, :-1, :]
+    hint = torch.sum(wts * hh, dim=-2).reshape(g["proj"].shape)
+    loss = (hint * torch.tensor(g["proj"], dtype=torch.float64)).sum()
+    assert abs(loss.item() - float(g["loss"])) < 1e-4 * max(1.0, abs(float(g["loss"])))
+    loss.backward()
+
+    def rel(a, b):
+        return float(np.linalg.norm(np.asarray(a, np.float64) - b) / max(np.linalg.norm(b), 1e-30))
+    assert rel(x64.grad.numpy(), g["g.depth_feature"]) < 2e-4
+    for l in range(4):
+        assert rel(w64[l].grad.numpy(), g[f"g.w{l}"]) < 2e-4 and rel(b64[l].grad.numpy(), g[f"g.b{l}"]) < 2e-4
+
 def test_G16_rbk_warp():
     """RigidBlurringModel.rbk_warp of the reference (blurmodel.py:51-82, rigid_warping.py)."""
     g = load_golden("G16_rbk_warp")

@@ -742,9 +742,47 @@ def G20_loss_grads():
     save("G20_loss_grads", **out)
 
 
+def G21_awp_sample_embed():
+    """AdaptiveWeightProposal.forward (networks/dpnerf/awp.py:79-117) up to the input of motion_feature_embed_layer: the per-sample
+    embedding MLP (:98-100), feature_integration (:102) and the concatenation with the view embedding (:104-105), run as the
+    reference runs them (forward hooks capture the intermediates of the real forward), plus torch.autograd gradients of a fixed
+    projection of the integrated features w.r.t. depth_feature and the embedding's parameters (what run_nerf.py:593-601 computes)."""
+    from networks.dpnerf.awp import AdaptiveWeightProposal
+    torch.manual_seed(21)
+    M = 2
+    awp = AdaptiveWeightProposal(input_ch=128, num_motion=M, D_sam=4, W_sam=64, D_mot=1, W_mot=32, dir_freq=2, rgb_freq=2,
+                                 depth_freq=3, ray_dir_freq=2, view_feature_ch=32)
+    awp.load_state_dict({k: t(v) for k, v in W.make_awp_embed_state_dict(211).items()}, strict=False)
+    rs = np.random.RandomState(212)
+    R, P, S = 3, M + 1, 24
+    depth_feature = (rs.standard_normal((R * P, S, 128)) * 0.7).astype(np.float32)
+    z = np.sort(rs.uniform(0, 1, (R * P, S)).astype(np.float32), -1)
+    rays_d = rs.standard_normal((R * P, 3)).astype(np.float32)
+    view_feature = rs.standard_normal((R, 32)).astype(np.float32)
+    proj = rs.standard_normal((R, P, 64)).astype(np.float32)
+    cap = {}
+    h1 = awp.sample_feature_embed_layer[-1].register_forward_hook(lambda m, i, o: cap.__setitem__("pre", o))
+    h2 = awp.motion_feature_embed_layer[0].register_forward_pre_hook(lambda m, i: cap.__setitem__("h", i[0]))
+    with torch.enable_grad():
+        df = t(depth_feature).requires_grad_(True)
+        out = awp(df, t(z), t(rays_d), t(view_feature))
+        h = cap["h"]                                           # [R, P, 64 + 32 + ray_dirs_embed_ch]
+        loss = (h[..., :64] * t(proj)).sum()
+        params = [p for l in awp.sample_feature_embed_layer for p in (l.weight, l.bias)]
+        grads = torch.autograd.grad(loss, [df] + params)
+    h1.remove()
+    h2.remove()
+    res = {"depth_feature": depth_feature, "z": z, "rays_d": rays_d, "view_feature": view_feature, "proj": proj,
+           "h_local": n(torch.relu(cap["pre"])), "h": n(h), "out": n(out), "loss": n(loss), "g.depth_feature": n(grads[0])}
+    for l in range(4):
+        res[f"g.w{l}"], res[f"g.b{l}"] = n(grads[1 + 2 * l]), n(grads[2 + 2 * l])
+    save("G21_awp_sample_embed", **res)
+
+
 ALL = [G1_embedder, G2_nerf_mlp, G3_nerf_raw2outputs, G4_voxel_raw2outputs, G5_sample_pdf, G6_rays,
        G7_render_nerf, G8_appfeature, G9_render_c2f, G10_rbk_weighted_sum, G11_crf, G12_egm_loss, G13_edi,
-       G14_loss_assembly, G15_awp_feature_integration, G16_rbk_warp, G17_compute_successor, G18_nerf_grads, G19_c2f_grads, G20_loss_grads]
+       G14_loss_assembly, G15_awp_feature_integration, G16_rbk_warp, G17_compute_successor, G18_nerf_grads, G19_c2f_grads, G20_loss_grads,
+       G21_awp_sample_embed]
 
 if __name__ == "__main__":
     want = set(sys.argv[1:])
