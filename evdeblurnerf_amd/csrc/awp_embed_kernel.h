@@ -143,13 +143,16 @@ __global__ __launch_bounds__(256) void k_awp_rows_to_frags(const float* __restri
     act_store(a, dlast + j, b);
 }
 
-// max |v| of nfrag gradient fragments per tile, in true units (loss scale removed) -> out (float bits, atomicMax)
+// max |v| of nfrag gradient fragments per tile, in true units (loss scale removed) -> out (float bits).  Grid-stride over the
+// (tile, fragment, lane) items, one atomicMax per block (one per wavefront on a single word cost 3.7 ms at 1.3 M samples).
 template <int PREC>
 __global__ __launch_bounds__(256) void k_frag_absmax(const char* __restrict__ store, long tile_bytes, int slot, int nfrag, long tiles,
                                                      const unsigned* __restrict__ maxbits, unsigned* __restrict__ out) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x, tile = idx / (64 * nfrag);
+    __shared__ float part[4];
+    const long total = tiles * 64 * nfrag;
     float m = 0.f;
-    if (tile < tiles) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long tile = idx / (64 * nfrag);
         const int j = (int)((idx / 64) % nfrag), lane = idx & 63;
         const W4 f = frag_load<W4>(store + tile * tile_bytes + lane * 16, slot + j);
 #pragma unroll
@@ -163,7 +166,12 @@ __global__ __launch_bounds__(256) void k_frag_absmax(const char* __restrict__ st
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m * grad_scale(*maxbits, true)));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+        if (m > 0.f) atomicMax(out, __float_as_uint(m * grad_scale(*maxbits, true)));
+    }
 }
 
 template <int PREC> static int run_awp_backward(const AwpBwdPlan& b, hipStream_t st) {
@@ -203,7 +211,7 @@ template <int PREC> static int run_awp_backward(const AwpBwdPlan& b, hipStream_t
     }
     if ((rc = wgrad(launch_wgrad<PREC, T, AWP_IN / 32, false>, T, AWP_IN / 32, D_E0, GEO, AMAP_GEO, g.w[0], AWP_IN, g.b[0]))) return rc;
     if ((rc = launch_dgrad<PREC, KW, AWP_IN / 32, KW, false, 0>(dgrad(0, D_E0, -1, D_GEO), b.tiles, st))) return rc;     // d geo (no activation)
-    hipLaunchKernelGGL((k_frag_absmax<PREC>), dim3((unsigned)cdiv(b.tiles * 64 * (AWP_IN / 16), 256L)), dim3(256), 0, st, (const char*)b.store, TILE_BYTES, D_GEO,
+    hipLaunchKernelGGL((k_frag_absmax<PREC>), dim3((unsigned)(cdiv(b.tiles * 64 * (AWP_IN / 16), 256L) < 2048 ? cdiv(b.tiles * 64 * (AWP_IN / 16), 256L) : 2048)), dim3(256), 0, st, (const char*)b.store, TILE_BYTES, D_GEO,
                        AWP_IN / 16, b.tiles, words, words + 1);
     EVD_LAUNCH_CHECK();
     if (b.d_geo_rows) {
