@@ -111,6 +111,7 @@ SIGNATURES = {
     "evd_nerf_stream_bytes": (_S, [_vp, _I]),
     "evd_nerf_mlp": (_I, [_vp, _I, _vp, _vp, _L, _I, _vp, _vp, _I, _vp]),
     "evd_nerf_train_store_bytes": (_S, [_L]),
+    "evd_nerf_train_store_bytes_prec": (_S, [_I, _L]),
     "evd_nerf_mlp_train": (_I, [_vp, _I, _vp, _vp, _L, _I, _vp, _vp, _S, _vp]),
     "evd_nerf_backward_workspace_bytes": (_S, []),
     "evd_nerf_mlp_backward": (_I, [_vp, _I, _vp, _L, _I, _vp, _S, C.POINTER(NerfGrads), _vp, _vp, _I, _vp, _vp, _vp, _S, _vp]),

@@ -171,8 +171,8 @@ int evd_nerf_create(const evd_nerf_desc* d, evd_nerf** out) {
             n->pipe_chunks[prec] = (int)(sp.bytes.size() / PIPE_CB);
             rc = upload_stream(n->pipe[prec], sp);
         }
-        // training path (bf16 / f16 on the pipelined network): W^T streams of the dgrad chain, one per layer (nerf_train_kernel.h)
-        if (rc || !is_half_prec(prec) || !n->pipe_chunks[prec]) continue;
+        // training path (bf16 / f16 / split-f16 on the pipelined network): W^T streams of the dgrad chain, one per layer (nerf_train_kernel.h)
+        if (rc || !is_train_prec(prec) || !n->pipe_chunks[prec]) continue;
         auto put = [&](int which, auto fill) {
             StreamBuilder sb2(prec, PIPE_CB);
             sb2.arena = A;

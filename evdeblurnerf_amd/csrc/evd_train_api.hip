@@ -13,31 +13,35 @@ using namespace evd;
 namespace evd {
 constexpr int TRAIN_WG_SAMPLES = 256;       // samples per workgroup of the training kernels (8 wavefronts x 32)
 static long train_tiles(long nsamp) { return cdiv(nsamp, (long)TRAIN_WG_SAMPLES) * (TRAIN_WG_SAMPLES / 32); }
-static bool train_built(const evd_nerf* n, int prec) { return (prec == EVD_PREC_F16 || prec == EVD_PREC_BF16) && n->pipe_chunks[prec] > 0; }
+static bool train_built(const evd_nerf* n, int prec) { return is_train_prec(prec) && n->pipe_chunks[prec] > 0; }
 }  // namespace evd
 
 
 extern "C" {
 
 size_t evd_nerf_train_store_bytes(long nsamp) { return nsamp < 0 ? 0 : (size_t)train_tiles(nsamp) * astore::TILE_BYTES; }
+size_t evd_nerf_train_store_bytes_prec(int precision, long nsamp) {
+    return (nsamp < 0 || precision < 0 || precision >= EVD_NUM_PREC || !is_train_prec(precision)) ? 0 : (size_t)train_tiles(nsamp) * astore::tile_bytes(precision);
+}
 
 int evd_nerf_mlp_train(const evd_nerf* net, int precision, const float* ray_batch, const float* z, long R, int S, float* raw,
                        void* store, size_t store_bytes, void* stream) {
     EVD_REQUIRE(net && ray_batch && z && raw && store, "evd_nerf_mlp_train: null argument");
     EVD_REQUIRE(precision >= 0 && precision < EVD_NUM_PREC && train_built(net, precision),
-                "evd_nerf_mlp_train: the training path is built for precision f16 / bf16 on the netdepth 8, netwidth 256, skips [4] network");
+                "evd_nerf_mlp_train: the training path is built for precision f16 / bf16 / f16x3 on the netdepth 8, netwidth 256, skips [4] network");
     EVD_REQUIRE(R >= 0 && S >= 1, "evd_nerf_mlp_train: bad shape R=%ld S=%d", R, S);
     if (R == 0) return EVD_OK;
     const long nsamp = R * (long)S;
-    if (store_bytes < evd_nerf_train_store_bytes(nsamp))
-        return fail(EVD_E_WORKSPACE, "evd_nerf_mlp_train: store %zu < %zu bytes", store_bytes, evd_nerf_train_store_bytes(nsamp));
+    if (store_bytes < evd_nerf_train_store_bytes_prec(precision, nsamp))
+        return fail(EVD_E_WORKSPACE, "evd_nerf_mlp_train: store %zu < %zu bytes", store_bytes, evd_nerf_train_store_bytes_prec(precision, nsamp));
     MlpParams p{};
     p.wstream = (const char*)net->pipe[precision].data.p;
     p.bias = (const float*)net->bias.p;
     p.ray_batch = ray_batch; p.z = z; p.nsamp = nsamp; p.S = S; p.ncol = 11;
     p.D = net->D; p.skip = net->skip; p.nchunks = net->pipe_chunks[precision]; p.nbias = (int)(net->bias.bytes / sizeof(float));
     p.raw = raw; p.feature = nullptr; p.feature_kind = 0; p.act = (char*)store;
-    return precision == EVD_PREC_F16 ? launch_nerf_train_fwd_f16(p, as_stream(stream)) : launch_nerf_train_fwd_bf16(p, as_stream(stream));
+    return precision == EVD_PREC_F16 ? launch_nerf_train_fwd_f16(p, as_stream(stream))
+           : precision == EVD_PREC_BF16 ? launch_nerf_train_fwd_bf16(p, as_stream(stream)) : launch_nerf_train_fwd_f16x3(p, as_stream(stream));
 }
 
 // scratch of the backward: the wgrad partial sums of the largest block (8 x 9 accumulator tiles per wavefront group) + the loss-scale word
@@ -50,12 +54,12 @@ int evd_nerf_mlp_backward(const evd_nerf* net, int precision, const float* d_raw
     EVD_REQUIRE((!d_pts || pts) && (!d_dirs || viewdirs), "evd_nerf_mlp_backward: d_pts / d_dirs need the forward's pts / viewdirs");
     EVD_REQUIRE(net && d_raw && store && grads && workspace, "evd_nerf_mlp_backward: null argument");
     EVD_REQUIRE(precision >= 0 && precision < EVD_NUM_PREC && train_built(net, precision),
-                "evd_nerf_mlp_backward: the training path is built for precision f16 / bf16 on the netdepth 8, netwidth 256, skips [4] network");
+                "evd_nerf_mlp_backward: the training path is built for precision f16 / bf16 / f16x3 on the netdepth 8, netwidth 256, skips [4] network");
     EVD_REQUIRE(R >= 0 && S >= 1, "evd_nerf_mlp_backward: bad shape R=%ld S=%d", R, S);
     if (R == 0) return EVD_OK;
     const long nsamp = R * (long)S;
-    if (store_bytes < evd_nerf_train_store_bytes(nsamp))
-        return fail(EVD_E_WORKSPACE, "evd_nerf_mlp_backward: store %zu < %zu bytes", store_bytes, evd_nerf_train_store_bytes(nsamp));
+    if (store_bytes < evd_nerf_train_store_bytes_prec(precision, nsamp))
+        return fail(EVD_E_WORKSPACE, "evd_nerf_mlp_backward: store %zu < %zu bytes", store_bytes, evd_nerf_train_store_bytes_prec(precision, nsamp));
     if (workspace_bytes < evd_nerf_backward_workspace_bytes())
         return fail(EVD_E_WORKSPACE, "evd_nerf_mlp_backward: workspace %zu < %zu bytes", workspace_bytes, evd_nerf_backward_workspace_bytes());
     BwdPlan b;
@@ -80,7 +84,8 @@ int evd_nerf_mlp_backward(const evd_nerf* net, int precision, const float* d_raw
     for (int l = 0; l < EVD_MAX_LAYERS; ++l) { b.grads.pts_w[l] = l < net->D ? grads->pts_w[l] : nullptr; b.grads.pts_b[l] = l < net->D ? grads->pts_b[l] : nullptr; }
     b.grads.views_w = grads->views_w; b.grads.views_b = grads->views_b; b.grads.feature_w = grads->feature_w; b.grads.feature_b = grads->feature_b;
     b.grads.alpha_w = grads->alpha_w; b.grads.alpha_b = grads->alpha_b; b.grads.rgb_w = grads->rgb_w; b.grads.rgb_b = grads->rgb_b;
-    return precision == EVD_PREC_F16 ? run_nerf_backward_f16(b, as_stream(stream)) : run_nerf_backward_bf16(b, as_stream(stream));
+    return precision == EVD_PREC_F16 ? run_nerf_backward_f16(b, as_stream(stream))
+           : precision == EVD_PREC_BF16 ? run_nerf_backward_bf16(b, as_stream(stream)) : run_nerf_backward_f16x3(b, as_stream(stream));
 }
 
 }  // extern "C"

@@ -44,8 +44,25 @@ __device__ __forceinline__ float relu_f32(float x) {
 // precision policies with pair-wise B-fragment construction (set_pair<RELU>: activation, range guard, convert)
 template <int PREC> struct POps;
 
+struct MaskFrag { unsigned w[4]; };      // one lane's 16 bytes of a bit-mask fragment (frag_bits / mask_from_bits below)
+__device__ __forceinline__ unsigned mask_word(unsigned g, unsigned a);
+__device__ __forceinline__ unsigned bits_of_words(const unsigned (&w)[4]);
+__device__ __forceinline__ unsigned mask_from_bits(const MaskFrag& m, int fo, int e);
+
+// Every policy also says how the TRAINING kernels treat a B fragment: mask_act (gradient . [saved activation != 0]), mask_bits (the
+// same from a bit-mask fragment), bits (the ReLU pattern of a completed fragment as one byte), zero.
 template <> struct POps<EVD_PREC_BF16> {
     struct B { unsigned w[4]; };
+    static __device__ __forceinline__ void mask_act(B& g, const B& a) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g.w[e] = mask_word(g.w[e], a.w[e]);
+    }
+    static __device__ __forceinline__ void mask_bits(B& g, const MaskFrag& m, int fo) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g.w[e] &= mask_from_bits(m, fo, e);
+    }
+    static __device__ __forceinline__ unsigned bits(const B& f) { return bits_of_words(f.w); }
+    static __device__ __forceinline__ void zero(B& b) { b.w[0] = b.w[1] = b.w[2] = b.w[3] = 0u; }
     typedef bf16x8 A;
     static constexpr bool kSplit = false, kFastTrig = true;
     static __device__ __forceinline__ A load_a(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
@@ -67,6 +84,16 @@ template <> struct POps<EVD_PREC_BF16> {
 
 template <> struct POps<EVD_PREC_F16> {
     struct B { unsigned w[4]; };
+    static __device__ __forceinline__ void mask_act(B& g, const B& a) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g.w[e] = mask_word(g.w[e], a.w[e]);
+    }
+    static __device__ __forceinline__ void mask_bits(B& g, const MaskFrag& m, int fo) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g.w[e] &= mask_from_bits(m, fo, e);
+    }
+    static __device__ __forceinline__ unsigned bits(const B& f) { return bits_of_words(f.w); }
+    static __device__ __forceinline__ void zero(B& b) { b.w[0] = b.w[1] = b.w[2] = b.w[3] = 0u; }
     typedef f16x8 A;
     static constexpr bool kSplit = false, kFastTrig = true;
     static __device__ __forceinline__ A load_a(const char* p) { return *reinterpret_cast<const f16x8*>(p); }
@@ -89,6 +116,31 @@ template <> struct POps<EVD_PREC_F16> {
 
 template <> struct POps<EVD_PREC_F16X3> {
     struct B { unsigned hi[4], lo[4]; };
+    // a value is hi + lo / 2048: it is zero iff both halves are (a ReLU output has hi >= 0; lo, the scaled residual, has either sign)
+    static __device__ __forceinline__ void mask_act(B& g, const B& a) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned any = a.hi[e] | a.lo[e];
+            g.hi[e] = mask_word(g.hi[e], any);
+            g.lo[e] = mask_word(g.lo[e], any);
+        }
+    }
+    static __device__ __forceinline__ void mask_bits(B& g, const MaskFrag& m, int fo) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned k = mask_from_bits(m, fo, e);
+            g.hi[e] &= k;
+            g.lo[e] &= k;
+        }
+    }
+    static __device__ __forceinline__ unsigned bits(const B& f) {
+        const unsigned any[4] = {f.hi[0] | f.lo[0], f.hi[1] | f.lo[1], f.hi[2] | f.lo[2], f.hi[3] | f.lo[3]};
+        return bits_of_words(any);
+    }
+    static __device__ __forceinline__ void zero(B& b) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b.hi[e] = b.lo[e] = 0u;
+    }
     typedef Ops<EVD_PREC_F16X3>::A A;
     static constexpr bool kSplit = true, kFastTrig = false;
     static __device__ __forceinline__ A load_a(const char* p) { return Ops<EVD_PREC_F16X3>::load_a(p); }
@@ -312,10 +364,18 @@ template <class C, class L, bool FIRST, bool LAST> struct GroupSched {
 };
 
 // One tile group p of a layer (see pipe_layer).
-// a completed B fragment of the training kernels goes to the activation store (lane-linear: 16 bytes per lane, 1 KiB per fragment)
-template <class B> __device__ __forceinline__ void act_store(char* act_lane, int slot, const B& frag) {
-    static_assert(sizeof(B) == 16, "activation store holds single-product half-precision fragments");
-    *reinterpret_cast<f32x4*>(act_lane + (long)slot * 1024) = __builtin_bit_cast(f32x4, frag);
+// a completed B fragment of the training kernels goes to the activation store (lane-linear: 16 bytes per lane, 1 KiB per fragment;
+// the split-float16 mode's fragments are two such halves, hi then lo, in a 2 KiB slot).  FB: bytes of a fragment slot of the store.
+template <int FB = 1024, class F> __device__ __forceinline__ void act_store(char* act_lane, int slot, const F& frag) {
+    static_assert(sizeof(F) == 16 || (sizeof(F) == 32 && FB == 2048), "16-byte fragments, or hi / lo pairs in 2 KiB slots");
+    if constexpr (sizeof(F) == 16) {
+        *reinterpret_cast<f32x4*>(act_lane + (long)slot * FB) = __builtin_bit_cast(f32x4, frag);
+    } else {
+        struct Two { f32x4 a, b; };
+        const Two t = __builtin_bit_cast(Two, frag);
+        *reinterpret_cast<f32x4*>(act_lane + (long)slot * FB) = t.a;
+        *reinterpret_cast<f32x4*>(act_lane + (long)slot * FB + 1024) = t.b;
+    }
 }
 
 // gradient word . [activation != 0], both halves (activations are post-ReLU: masked <=> the stored half is +0)
@@ -326,21 +386,25 @@ __device__ __forceinline__ unsigned mask_word(unsigned g, unsigned a) {
 }
 
 // bit e = (element e of the packed fragment != 0): the ReLU pattern of a stored activation fragment in one byte
-template <class B> __device__ __forceinline__ unsigned frag_bits(const B& f) {
+__device__ __forceinline__ unsigned bits_of_words(const unsigned (&w)[4]) {
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
     const u16x2 one = {1, 1};
     unsigned b = 0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {       // v_pk_min_u16 against 1: (half != 0) in bits 0 and 16
-        const unsigned t = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, f.w[e]), one));
+        const unsigned t = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, w[e]), one));
         b |= ((t | (t >> 15)) & 3u) << (2 * e);
     }
     return b;
 }
+template <class B> __device__ __forceinline__ unsigned frag_bits(const B& f) { return bits_of_words(f.w); }
 // packed-pair mask word e of fragment fo from a mask fragment (byte j of a lane's 16 bytes = frag_bits of fragment j)
-template <class B> __device__ __forceinline__ unsigned mask_from_bits(const B& m, int fo, int e) {
+__device__ __forceinline__ unsigned mask_from_bits(const MaskFrag& m, int fo, int e) {
     const unsigned two = (m.w[fo >> 2] >> (8 * (fo & 3) + 2 * e)) & 3u;
     return ((0u - (two & 1u)) & 0xffffu) | ((0u - (two >> 1)) & 0xffff0000u);
+}
+template <class B> __device__ __forceinline__ unsigned mask_from_bits(const B& m, int fo, int e) {
+    return mask_from_bits(__builtin_bit_cast(MaskFrag, m), fo, e);
 }
 
 // OMASK (backward kernels): every stored output fragment is first multiplied by the 0/1 ReLU pattern of the saved activation:
@@ -348,9 +412,10 @@ template <class B> __device__ __forceinline__ unsigned mask_from_bits(const B& m
 template <class C, class L, class ST, int NOUT, int P, bool TRAIN, int OMASK>
 __device__ __forceinline__ void pipe_group(ST& st, Pipe<C>& pp, typename C::O::B (&in)[C::NS][L::KTOT],
                                            typename C::O::B (&out)[C::NS][NOUT], const float* __restrict__ bias, int h,
-                                           float* const* frow, char* const* act, const typename C::O::B* omask) {
+                                           float* const* frow, char* const* act, const void* omask) {
     typedef typename C::O O;
     typedef GroupSched<C, L, P == 0, P == L::NG - 1> S;
+    constexpr int FB = C::FB;
     constexpr int NS = C::NS, FPC = C::FPC, PD = C::PD, G = L::G, KTOT = L::KTOT, NF = L::NF, NM = S::NM;
     constexpr int ENDV = L::PAD_END ? cceil(L::FOFF + NF, FPC) * FPC : L::FOFF + NF;
     constexpr int cur = (L::PAR + P) & 1, oth = cur ^ 1;
@@ -395,15 +460,15 @@ __device__ __forceinline__ void pipe_group(ST& st, Pipe<C>& pp, typename C::O::B
                             if constexpr (TRAIN && L::PSLOT >= 0)
                                 if ((k & 3) == 3) {
                                     const auto& pf = in[ds][(L::PG > 0 ? L::PDOFF : 0) + 2 * dt + (k >> 2)];
-                                    act_store(act[ds], L::PSLOT + 2 * dt + (k >> 2), pf);
+                                    act_store<FB>(act[ds], L::PSLOT + 2 * dt + (k >> 2), pf);
                                     if constexpr (L::PMSLOT >= 0) {
                                         const int fi = L::PFRAG0 + 2 * dt + (k >> 2);
-                                        pp.mbits[ds][fi >> 2] |= frag_bits(pf) << (8 * (fi & 3));
+                                        pp.mbits[ds][fi >> 2] |= O::bits(pf) << (8 * (fi & 3));
                                         if (dt == L::PG - 1 && k == 7) {         // the producing layer's output is complete: its mask fragment
-                                            typename C::O::B mf;
+                                            MaskFrag mf;
 #pragma unroll
                                             for (int e = 0; e < 4; ++e) { mf.w[e] = pp.mbits[ds][e]; pp.mbits[ds][e] = 0u; }
-                                            act_store(act[ds], L::PMSLOT, mf);
+                                            act_store<FB>(act[ds], L::PMSLOT, mf);
                                         }
                                     }
                                 }
@@ -414,15 +479,10 @@ __device__ __forceinline__ void pipe_group(ST& st, Pipe<C>& pp, typename C::O::B
                             if constexpr (TRAIN && L::OSLOT >= 0)
                                 if ((k & 3) == 3) {
                                     const int fo = 2 * (tile0 + dt) + (k >> 2);
-                                    if constexpr (OMASK == 1) {
-#pragma unroll
-                                        for (int e = 0; e < 4; ++e) out[ds][fo].w[e] = mask_word(out[ds][fo].w[e], omask[ds * NOUT + fo].w[e]);
-                                    } else if constexpr (OMASK == 2) {
-#pragma unroll
-                                        for (int e = 0; e < 4; ++e) out[ds][fo].w[e] &= mask_from_bits(omask[ds], fo, e);
-                                    }
-                                    act_store(act[ds], L::OSLOT + fo, out[ds][fo]);
-                                    if constexpr (L::MSLOT >= 0) pp.mbits[ds][fo >> 2] |= frag_bits(out[ds][fo]) << (8 * (fo & 3));
+                                    if constexpr (OMASK == 1) O::mask_act(out[ds][fo], static_cast<const typename O::B*>(omask)[ds * NOUT + fo]);
+                                    else if constexpr (OMASK == 2) O::mask_bits(out[ds][fo], static_cast<const MaskFrag*>(omask)[ds], fo);
+                                    act_store<FB>(act[ds], L::OSLOT + fo, out[ds][fo]);
+                                    if constexpr (L::MSLOT >= 0) pp.mbits[ds][fo >> 2] |= O::bits(out[ds][fo]) << (8 * (fo & 3));
                                 }
                         }
                     }
@@ -463,7 +523,7 @@ template <class C, class L, class ST, int NOUT, int P, bool TRAIN, int OMASK>
 struct GroupLoop {
     static __device__ __forceinline__ void run(ST& st, Pipe<C>& pp, typename C::O::B (&in)[C::NS][L::KTOT],
                                                typename C::O::B (&out)[C::NS][NOUT], const float* __restrict__ bias, int h,
-                                               float* const* frow, char* const* act, const typename C::O::B* omask) {
+                                               float* const* frow, char* const* act, const void* omask) {
         pipe_group<C, L, ST, NOUT, P, TRAIN, OMASK>(st, pp, in, out, bias, h, frow, act, omask);
         if constexpr (P + 1 < L::NG) GroupLoop<C, L, ST, NOUT, P + 1, TRAIN, OMASK>::run(st, pp, in, out, bias, h, frow, act, omask);
     }
@@ -477,7 +537,7 @@ template <class C, class L, class ST, int NOUT, bool TRAIN = false, int OMASK = 
 __device__ __forceinline__ void pipe_layer(ST& st, Pipe<C>& pp, typename C::O::B (&in)[C::NS][L::KTOT],
                                            typename C::O::B (&out)[C::NS][NOUT], float (*out_f32)[4],
                                            const float* __restrict__ bias, int lane, float* const* frow, char* const* act = nullptr,
-                                           const typename C::O::B* omask = nullptr) {
+                                           const void* omask = nullptr) {
     typedef typename C::O O;
     GroupLoop<C, L, ST, NOUT, 0, TRAIN, OMASK>::run(st, pp, in, out, bias, lane >> 5, frow, act, omask);
     if (L::PAD_END && ((L::FOFF + L::NF) % C::FPC) != 0) st.chunk_end(L::CHUNK0 + (L::FOFF + L::NF) / C::FPC);

@@ -37,6 +37,7 @@ __host__ __device__ constexpr int pe_src_col(int L, int q, int h) {
 }
 
 constexpr bool is_half_prec(int prec) { return prec == 2 /*BF16*/ || prec == 3 /*F16*/; }   // one 2-byte operand per value
+constexpr bool is_train_prec(int prec) { return is_half_prec(prec) || prec == 1 /*F16X3*/; }  // modes the training kernels are built for
 constexpr int frag_bytes(int prec) { return is_half_prec(prec) ? 1024 : 2048; }
 constexpr int mlp_threads(int prec) { return is_half_prec(prec) ? 512 : 256; }
 constexpr int chunk_bytes(int prec) { return mlp_threads(prec) * 64; }
@@ -77,7 +78,9 @@ constexpr int D_PE0 = D_H0 + 16 * 8, D_PE5 = D_PE0 + PE_KS, D_DIRG = D_PE5 + PE_
 // epilogue reads instead of the 16 activation fragments
 constexpr int M_H0 = D_DIRG + PEV_KS, M_HV = M_H0 + 8;
 constexpr int TILE_FRAGS = M_HV + 1;
-constexpr long TILE_BYTES = (long)TILE_FRAGS * 1024;
+constexpr long TILE_BYTES = (long)TILE_FRAGS * 1024;      // the single-product half-precision modes
+// bytes of a tile in arithmetic mode `prec`: the split-float16 mode keeps every fragment as a (hi, lo) pair in a 2 KiB slot
+constexpr long tile_bytes(int prec) { return (long)TILE_FRAGS * frag_bytes(prec); }
 }  // namespace astore
 
 }  // namespace evd

@@ -9,6 +9,7 @@ namespace evd {
 
 int launch_nerf_train_fwd_f16(const MlpParams& p, hipStream_t st);
 int launch_nerf_train_fwd_bf16(const MlpParams& p, hipStream_t st);
+int launch_nerf_train_fwd_f16x3(const MlpParams& p, hipStream_t st);
 
 // index maps of the wgrad reduction (fragment column -> parameter row / column, -1 = padding), offsets into one int32 array
 enum { MAP_HID = 0,                    // 256: hidden arrangement, channel 16 j + phi(kk)
@@ -43,5 +44,6 @@ struct BwdPlan {
 
 int run_nerf_backward_f16(const BwdPlan& b, hipStream_t st);
 int run_nerf_backward_bf16(const BwdPlan& b, hipStream_t st);
+int run_nerf_backward_f16x3(const BwdPlan& b, hipStream_t st);
 
 }  // namespace evd

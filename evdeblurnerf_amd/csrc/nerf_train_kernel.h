@@ -60,18 +60,48 @@ __global__ __launch_bounds__(256) void k_grad_frags(const float* __restrict__ d_
     f32x4 g = {0.f, 0.f, 0.f, 0.f};
     if (h == 0 && smp < nsamp) g = *reinterpret_cast<const f32x4*>(d_raw + smp * 4);
     B rgb, al;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) rgb.w[e] = al.w[e] = 0u;
+    O::zero(rgb);
+    O::zero(al);
     O::template set_pair<false>(rgb, 0, g[0] * s, g[1] * s);
     O::template set_pair<false>(rgb, 1, g[2] * s, 0.f);
     O::template set_pair<false>(al, 0, g[3] * s, 0.f);
-    char* a = store + tile * astore::TILE_BYTES + lane * 16;
-    act_store(a, astore::G_RGB, rgb);
-    act_store(a, astore::G_ALPHA, al);
+    constexpr int FB = frag_bytes(PREC);
+    char* a = store + tile * astore::tile_bytes(PREC) + lane * 16;
+    act_store<FB>(a, astore::G_RGB, rgb);
+    act_store<FB>(a, astore::G_ALPHA, al);
 }
 
-template <class B> __device__ __forceinline__ B frag_load(const char* lane_base, int slot) {
-    return __builtin_bit_cast(B, *reinterpret_cast<const f32x4*>(lane_base + (long)slot * 1024));
+template <class B, int FB = 1024> __device__ __forceinline__ B frag_load(const char* lane_base, int slot) {
+    static_assert(sizeof(B) == 16 || (sizeof(B) == 32 && FB == 2048), "16-byte fragments, or hi / lo pairs in 2 KiB slots");
+    if constexpr (sizeof(B) == 16) {
+        return __builtin_bit_cast(B, *reinterpret_cast<const f32x4*>(lane_base + (long)slot * FB));
+    } else {
+        struct Two { f32x4 a, b; };
+        Two t;
+        t.a = *reinterpret_cast<const f32x4*>(lane_base + (long)slot * FB);
+        t.b = *reinterpret_cast<const f32x4*>(lane_base + (long)slot * FB + 1024);
+        return __builtin_bit_cast(B, t);
+    }
+}
+
+// the 8 values of one lane of a stored fragment as float32 (split mode: hi + lo / 2048)
+template <int PREC> __device__ __forceinline__ void frag_values(const char* lane_base, int slot, float (&v)[8]) {
+    constexpr int FB = frag_bytes(PREC);
+    const MaskFrag f = frag_load<MaskFrag, FB>(lane_base, slot);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const unsigned short bits = (unsigned short)(f.w[e >> 1] >> (16 * (e & 1)));
+        if constexpr (PREC == EVD_PREC_BF16) v[e] = __uint_as_float((unsigned)bits << 16);
+        else v[e] = (float)__builtin_bit_cast(_Float16, bits);
+    }
+    if constexpr (PREC == EVD_PREC_F16X3) {
+        const MaskFrag l = __builtin_bit_cast(MaskFrag, *reinterpret_cast<const f32x4*>(lane_base + (long)slot * FB + 1024));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const unsigned short bits = (unsigned short)(l.w[e >> 1] >> (16 * (e & 1)));
+            v[e] = fmaf((float)__builtin_bit_cast(_Float16, bits), 4.8828125e-4f, v[e]);
+        }
+    }
 }
 
 struct DgradParams {
@@ -88,9 +118,10 @@ struct DgradParams {
 template <int PREC, int KTOT, int TILES, int NIN, bool EXTRA, int OMASK, int NT>
 __global__ __launch_bounds__(NT, NT / 256) void k_dgrad_layer(const DgradParams p) {
     typedef PipeCfg<PREC, 1, NT> C;
-    typedef typename C::O::B B;
+    typedef typename C::O O;
+    typedef typename O::B B;
     typedef LayerDesc<KTOT, TILES, 1, false, false, 0, 0, true, 0, 0, 0, false, 0, -1, false, 0, 0, -1> L;
-    constexpr int NCH = cceil(KTOT * TILES, C::FPC);
+    constexpr int NCH = cceil(KTOT * TILES, C::FPC), FB = C::FB;
     static_assert(NIN + (EXTRA ? 1 : 0) == KTOT, "k-steps of the layer");    // (a layer shorter than the prefetch depth reads the zero padding of its chunk)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -102,17 +133,19 @@ __global__ __launch_bounds__(NT, NT / 256) void k_dgrad_layer(const DgradParams 
     for (int i = tid; i < (TILES + 1) * 32; i += NT) zb[i] = 0.f;
     char* al = p.store + ((long)blockIdx.x * (NT / 64) + wave) * p.tile_bytes + lane * 16;
 
-    B in[1][KTOT], out[1][2 * TILES], om[OMASK == 1 ? 2 * TILES : 1];
+    B in[1][KTOT], out[1][2 * TILES], oma[OMASK == 1 ? 2 * TILES : 1];
+    MaskFrag omb[1];
 #pragma unroll
-    for (int j = 0; j < NIN; ++j) in[0][j] = frag_load<B>(al, p.in_slot + j);
-    if constexpr (EXTRA) in[0][NIN] = frag_load<B>(al, p.extra_slot);
+    for (int j = 0; j < NIN; ++j) in[0][j] = frag_load<B, FB>(al, p.in_slot + j);
+    if constexpr (EXTRA) in[0][NIN] = frag_load<B, FB>(al, p.extra_slot);
     if constexpr (OMASK == 1) {
 #pragma unroll
-        for (int j = 0; j < 2 * TILES; ++j) om[j] = frag_load<B>(al, p.mask_slot + j);
+        for (int j = 0; j < 2 * TILES; ++j) oma[j] = frag_load<B, FB>(al, p.mask_slot + j);
     } else if constexpr (OMASK == 2) {
-        om[0] = frag_load<B>(al, p.mask_slot);          // the bit-mask fragment (nerf_mlp.h M_H0 ..)
+        omb[0] = frag_load<MaskFrag, FB>(al, p.mask_slot);          // the bit-mask fragment (nerf_mlp.h M_H0 ..)
     }
-    char* actl[1] = {al + (long)p.out_slot * 1024};
+    const void* om = OMASK == 1 ? static_cast<const void*>(oma) : static_cast<const void*>(omb);
+    char* actl[1] = {al + (long)p.out_slot * FB};
     float* nofrow[1] = {nullptr};
     Pipe<C> pp;
     st.start_wait();
@@ -121,20 +154,15 @@ __global__ __launch_bounds__(NT, NT / 256) void k_dgrad_layer(const DgradParams 
     pipe_flush<C, L>(pp, out);
 #pragma unroll
     for (int j = 2 * TILES - 2; j < 2 * TILES; ++j) {
-        if constexpr (OMASK == 1) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) out[0][j].w[e] = mask_word(out[0][j].w[e], om[j].w[e]);
-        } else if constexpr (OMASK == 2) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) out[0][j].w[e] &= mask_from_bits(om[0], j, e);
-        }
-        act_store(actl[0], j, out[0][j]);
+        if constexpr (OMASK == 1) O::mask_act(out[0][j], oma[j]);
+        else if constexpr (OMASK == 2) O::mask_bits(out[0][j], omb[0], j);
+        act_store<FB>(actl[0], j, out[0][j]);
     }
 }
 
 template <int PREC, int KTOT, int TILES, int NIN, bool EXTRA, int OMASK>
 static int launch_dgrad(const DgradParams& p, long tiles, hipStream_t st) {
-    constexpr int NT = 512;
+    constexpr int NT = is_half_prec(PREC) ? 512 : 256;          // the split mode's fragments need the whole register file: one wavefront per SIMD
     typedef PipeCfg<PREC, 1, NT> C;
     const size_t lds = C::RING + (TILES + 1) * 128;
     EVD_SET_MAX_LDS((&k_dgrad_layer<PREC, KTOT, TILES, NIN, EXTRA, OMASK, NT>), lds);
@@ -341,11 +369,111 @@ static __global__ __launch_bounds__(256) void k_wgrad_reduce(const WreduceParams
     }
 }
 
+// The split-float16 (float32-grade) form: both operands are (hi, lo) pairs; each half is transposed on its own (exact), the products
+// are yh xh into acc and yh xl + yl xh into a second accumulator (scaled by 2^11, like the forward's cross terms).  Plain global loads
+// (no DMA ring: this mode is for gradient fidelity, the half-precision kernel above is the fast one).  Blocks whose accumulators
+// would not fit (RT x CT = 8 x 8) walk the sample tiles once per half of their columns.
+template <int RT, int CT, bool YSINGLE>
+__global__ __launch_bounds__(WGRAD_NT) void k_wgrad_split(const WgradParams p) {
+    constexpr int CPG = wgrad_cpg(RT, CT), PASSES = CPG > 4 ? 2 : 1, CPP = CPG / PASSES, FB = 2048, PREC = EVD_PREC_F16;
+    static_assert(8 % RT == 0 && CT <= 8 && (!YSINGLE || RT == 1) && CPG % PASSES == 0, "shape of the block");
+    extern __shared__ __attribute__((aligned(16))) char wsm[];
+    char* xs = wsm;                                           // [2][CT][hi q0, hi q1, lo q0, lo q1][1 KiB]
+    const int NC = CT + (p.bias ? 1 : 0);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = lane & 31, h = lane >> 5;
+    const int rt = wave % RT, c0 = (wave / RT) * CPG;
+    const bool xown = wave < CT, bias_own = p.bias && wave < RT;
+    W4 sel0, sel1, ones;
+    const unsigned one = half_one_pair<PREC>();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int kk = 8 * h + 2 * e;
+        sel0.w[e] = (n == kk ? (one & 0xffffu) : 0u) | (n == kk + 1 ? (one & 0xffff0000u) : 0u);
+        sel1.w[e] = (n == 16 + kk ? (one & 0xffffu) : 0u) | (n == 17 + kk ? (one & 0xffff0000u) : 0u);
+        ones.w[e] = n == 0 ? one : 0u;
+    }
+    const W4 zf = {{0u, 0u, 0u, 0u}};
+    float* out = p.partial + (((long)blockIdx.x * RT + rt) * NC) * 1024 + lane * 16;
+    auto put = [&](int c, const f32x16& a, const f32x16& ax) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = fmaf(ax[4 * q + i], 4.8828125e-4f, a[4 * q + i]);
+            *reinterpret_cast<f32x4*>(out + c * 1024 + 4 * q) = v;
+        }
+    };
+    int it = 0;
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+        f32x16 acc[CPP], accx[CPP], accb, accbx;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            accb[i] = accbx[i] = 0.f;
+#pragma unroll
+            for (int c = 0; c < CPP; ++c) acc[c][i] = accx[c][i] = 0.f;
+        }
+        for (long t = blockIdx.x; t < p.tiles; t += gridDim.x, ++it) {
+            const char* g = p.store + t * p.tile_bytes + lane * 16;
+            const W4 y0h = frag_load<W4, FB>(g, p.y_slot + 2 * rt), y0l = frag_load<W4, FB>(g + 1024, p.y_slot + 2 * rt);
+            const W4 y1h = YSINGLE ? zf : frag_load<W4, FB>(g, p.y_slot + 2 * rt + 1), y1l = YSINGLE ? zf : frag_load<W4, FB>(g + 1024, p.y_slot + 2 * rt + 1);
+            W4 yth[2], ytl[2];
+            transpose_block<PREC>(y0h, y1h, sel0, sel1, yth);
+            transpose_block<PREC>(y0l, y1l, sel0, sel1, ytl);
+            char* xb = xs + (it & 1) * (CT * 4096);
+            if (xown) {
+                const W4 x0h = frag_load<W4, FB>(g, p.x_slot + 2 * wave), x0l = frag_load<W4, FB>(g + 1024, p.x_slot + 2 * wave);
+                const W4 x1h = frag_load<W4, FB>(g, p.x_slot + 2 * wave + 1), x1l = frag_load<W4, FB>(g + 1024, p.x_slot + 2 * wave + 1);
+                W4 xth[2], xtl[2];
+                transpose_block<PREC>(x0h, x1h, sel0, sel1, xth);
+                transpose_block<PREC>(x0l, x1l, sel0, sel1, xtl);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    *reinterpret_cast<W4*>(xb + (wave * 4 + q) * 1024 + lane * 16) = xth[q];
+                    *reinterpret_cast<W4*>(xb + (wave * 4 + 2 + q) * 1024 + lane * 16) = xtl[q];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < CPP; ++c) {
+                const int col = c0 + ps * CPP + c;
+                if (col < CT) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const W4 xh = *reinterpret_cast<const W4*>(xb + (col * 4 + q) * 1024 + lane * 16);
+                        const W4 xl = *reinterpret_cast<const W4*>(xb + (col * 4 + 2 + q) * 1024 + lane * 16);
+                        acc[c] = mfma_half<PREC>(yth[q], xh, acc[c]);
+                        accx[c] = mfma_half<PREC>(yth[q], xl, accx[c]);
+                        accx[c] = mfma_half<PREC>(ytl[q], xh, accx[c]);
+                    }
+                }
+            }
+            if (bias_own && ps == 0) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    accb = mfma_half<PREC>(yth[q], ones, accb);
+                    accbx = mfma_half<PREC>(ytl[q], ones, accbx);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CPP; ++c)
+            if (c0 + ps * CPP + c < CT) put(c0 + ps * CPP + c, acc[c], accx[c]);
+        if (bias_own && ps == 0) put(CT, accb, accbx);
+    }
+}
+
 template <int PREC, int RT, int CT, bool YSINGLE>
 static int launch_wgrad(const WgradParams& p, int blocks, hipStream_t st) {
-    const size_t lds = wgrad_lds_bytes(CT);
-    EVD_SET_MAX_LDS((&k_wgrad<PREC, RT, CT, YSINGLE>), lds);
-    hipLaunchKernelGGL((k_wgrad<PREC, RT, CT, YSINGLE>), dim3(blocks), dim3(WGRAD_NT), lds, st, p);
+    if constexpr (PREC == EVD_PREC_F16X3) {
+        const size_t lds = (size_t)2 * CT * 4096;
+        EVD_SET_MAX_LDS((&k_wgrad_split<RT, CT, YSINGLE>), lds);
+        hipLaunchKernelGGL((k_wgrad_split<RT, CT, YSINGLE>), dim3(blocks), dim3(WGRAD_NT), lds, st, p);
+    } else {
+        const size_t lds = wgrad_lds_bytes(CT);
+        EVD_SET_MAX_LDS((&k_wgrad<PREC, RT, CT, YSINGLE>), lds);
+        hipLaunchKernelGGL((k_wgrad<PREC, RT, CT, YSINGLE>), dim3(blocks), dim3(WGRAD_NT), lds, st, p);
+    }
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }
@@ -368,14 +496,12 @@ __global__ __launch_bounds__(256) void k_pe_bwd(const char* __restrict__ store, 
     float g[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < KSN; ++j) {
-        const W4 f = frag_load<W4>(store + tile * tile_bytes + lane * 16, slot + j);
+        float fv[8];
+        frag_values<PREC>(store + tile * tile_bytes + lane * 16, slot + j, fv);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int q = 8 * j + e;
-            const unsigned short bits = (unsigned short)(f.w[e >> 1] >> (16 * (e & 1)));
-            float v;
-            if constexpr (PREC == EVD_PREC_BF16) v = __uint_as_float((unsigned)bits << 16);
-            else v = (float)__builtin_bit_cast(_Float16, bits);
+            const float v = fv[e];
             if (q < 3 * L) {
                 const float fr = (float)(1 << (q / 3)), a = xv[q % 3] * fr;
                 g[q % 3] += h == 0 ? v * cosf(a) * fr : -v * sinf(a) * fr;
@@ -409,7 +535,7 @@ template <int PREC> static int run_nerf_backward(const BwdPlan& b, hipStream_t s
 
     auto dgrad = [&](int stream, int in_slot, int extra_slot, int mask_slot, int out_slot) {
         DgradParams p;
-        p.wstream = b.wt[stream]; p.store = b.store; p.tile_bytes = astore::TILE_BYTES; p.in_slot = in_slot; p.extra_slot = extra_slot; p.mask_slot = mask_slot; p.out_slot = out_slot;
+        p.wstream = b.wt[stream]; p.store = b.store; p.tile_bytes = astore::tile_bytes(PREC); p.in_slot = in_slot; p.extra_slot = extra_slot; p.mask_slot = mask_slot; p.out_slot = out_slot;
         return p;
     };
     // wgrad + reduce of one parameter block: rows from `ymap`, columns from `xmap` (offset into b.maps)
@@ -417,7 +543,7 @@ template <int PREC> static int run_nerf_backward(const BwdPlan& b, hipStream_t s
         if (!dW) return EVD_OK;
         const int blocks = (int)(cdiv(b.tiles, (long)WGRAD_TPI) < b.wgrad_blocks ? cdiv(b.tiles, (long)WGRAD_TPI) : b.wgrad_blocks);
         WgradParams p;
-        p.store = b.store; p.tiles = b.tiles; p.tile_bytes = astore::TILE_BYTES; p.y_slot = y_slot; p.x_slot = x_slot; p.bias = bias ? 1 : 0; p.partial = b.partial;
+        p.store = b.store; p.tiles = b.tiles; p.tile_bytes = astore::tile_bytes(PREC); p.y_slot = y_slot; p.x_slot = x_slot; p.bias = bias ? 1 : 0; p.partial = b.partial;
         hipStream_t ws = st;
         if (b.side) {                           // everything issued so far on the main stream (the producer of this wgrad's operands) first
             EVD_HIP(hipEventRecord(b.ev, st));
@@ -459,19 +585,19 @@ template <int PREC> static int run_nerf_backward(const BwdPlan& b, hipStream_t s
     // gradient w.r.t. the rays: the encoding rows of pts_linears[0], of the skip layer and of views_linears.0, then through sin / cos
     if (b.d_pts) {
         if ((rc = launch_dgrad<PREC, 16, 2, 16, false, 0>(dgrad(EVD_BWD_PE0, D_H0, -1, -1, D_PE0), b.tiles, st))) return rc;
-        hipLaunchKernelGGL((k_pe_bwd<PREC, PE_L, PE_KS>), dim3((unsigned)cdiv(b.tiles * 64, 256L)), dim3(256), 0, st, (const char*)b.store, TILE_BYTES, D_PE0,
+        hipLaunchKernelGGL((k_pe_bwd<PREC, PE_L, PE_KS>), dim3((unsigned)cdiv(b.tiles * 64, 256L)), dim3(256), 0, st, (const char*)b.store, astore::tile_bytes(PREC), D_PE0,
                            b.nsamp, b.pts, 3, 1, b.maxbits, b.d_pts, 0);
         EVD_LAUNCH_CHECK();
         if (b.skip >= 0 && b.skip + 1 < D) {
             if ((rc = launch_dgrad<PREC, 16, 2, 16, false, 0>(dgrad(EVD_BWD_PESKIP, D_H0 + 16 * (b.skip + 1), -1, -1, D_PE5), b.tiles, st))) return rc;
-            hipLaunchKernelGGL((k_pe_bwd<PREC, PE_L, PE_KS>), dim3((unsigned)cdiv(b.tiles * 64, 256L)), dim3(256), 0, st, (const char*)b.store, TILE_BYTES, D_PE5,
+            hipLaunchKernelGGL((k_pe_bwd<PREC, PE_L, PE_KS>), dim3((unsigned)cdiv(b.tiles * 64, 256L)), dim3(256), 0, st, (const char*)b.store, astore::tile_bytes(PREC), D_PE5,
                                b.nsamp, b.pts, 3, 1, b.maxbits, b.d_pts, 1);
             EVD_LAUNCH_CHECK();
         }
     }
     if (b.d_dirs) {
         if ((rc = launch_dgrad<PREC, 8, 1, 8, false, 0>(dgrad(EVD_BWD_DIR, D_HV, -1, -1, D_DIRG), b.tiles, st))) return rc;
-        hipLaunchKernelGGL((k_pe_bwd<PREC, PE_LV, PEV_KS>), dim3((unsigned)cdiv(b.tiles * 64, 256L)), dim3(256), 0, st, (const char*)b.store, TILE_BYTES, D_DIRG,
+        hipLaunchKernelGGL((k_pe_bwd<PREC, PE_LV, PEV_KS>), dim3((unsigned)cdiv(b.tiles * 64, 256L)), dim3(256), 0, st, (const char*)b.store, astore::tile_bytes(PREC), D_DIRG,
                            b.nsamp, b.viewdirs, b.vd_stride, b.S, b.maxbits, b.d_dirs, 0);
         EVD_LAUNCH_CHECK();
     }

@@ -161,13 +161,16 @@ class NeRF:
                                      L.ptr(raw), L.ptr(feat), kind, L.stream_ptr()), "evd_nerf_mlp")
         return raw, feat
 
-    # Training forward: the same raw plus the activation store evd_nerf_mlp_backward consumes (f16 / bf16, 8 x 256 network)
+    # Training forward: the same raw plus the activation store evd_nerf_mlp_backward consumes (f16 / bf16, or f16x3 = the float32-grade
+    # mode with (hi, lo) fragments; 8 x 256 network)
     def mlpforward_train(self, ray_batch, z_vals, precision=None):
         rb = ray_batch.contiguous().float()
         z = z_vals.contiguous().float()
         R, S = z.shape
         raw = torch.empty((R, S, 4), dtype=torch.float32, device=z.device)
-        nb = int(L.lib().evd_nerf_train_store_bytes(R * S))
+        nb = int(L.lib().evd_nerf_train_store_bytes_prec(L.PREC[precision or self.precision], R * S))
+        if nb == 0 and R * S > 0:
+            raise L.EvdError(f"the training path is built for precision f16 / bf16 / f16x3, not {precision or self.precision}")
         store = torch.empty((nb,), dtype=torch.uint8, device=z.device)
         L.check(L.lib().evd_nerf_mlp_train(self._h, L.PREC[precision or self.precision], L.ptr(rb), L.ptr(z), R, S, L.ptr(raw),
                                             L.ptr(store), nb, L.stream_ptr()), "evd_nerf_mlp_train")

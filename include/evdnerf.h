@@ -133,8 +133,13 @@ int evd_nerf_mlp(const evd_nerf* net, int precision, const float* ray_batch, con
 /* Training variant of evd_nerf_mlp (the forward half of the autograd graph of NeRF.mlpforward, networks/nerf.py:46-72, that
  * run_nerf.py:593-601 differentiates): same raw, and every layer's activations are kept in `store` (device,
  * evd_nerf_train_store_bytes(R * S) bytes, fragment layout of csrc/nerf_mlp.h) for evd_nerf_mlp_backward.
- * Built for precision EVD_PREC_F16 / EVD_PREC_BF16 on the netdepth 8, netwidth 256, skips [4] network; EVD_E_INVALID otherwise. */
+ * Built for precision EVD_PREC_F16 / EVD_PREC_BF16 and EVD_PREC_F16X3 on the netdepth 8, netwidth 256, skips [4] network;
+ * EVD_E_INVALID otherwise.  EVD_PREC_F16X3 is the float32-grade training mode (the reference trains in float32, run_nerf.py:593-601):
+ * every stored fragment is a (hi, lo) float16 pair, every product of the forward, the dgrad and the wgrad kernels is the 3-MFMA
+ * split product -- twice the store (evd_nerf_train_store_bytes_prec), gradients equal to float32 autograd to ~1e-5.
+ * evd_nerf_train_store_bytes = the half-precision size (kept for existing callers). */
 size_t evd_nerf_train_store_bytes(long nsamp);
+size_t evd_nerf_train_store_bytes_prec(int precision, long nsamp);
 int evd_nerf_mlp_train(const evd_nerf* net, int precision, const float* ray_batch, const float* z, long R, int S,
                        float* raw, void* store, size_t store_bytes, void* stream);
 
