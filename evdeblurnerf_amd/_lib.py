@@ -119,6 +119,7 @@ SIGNATURES = {
     "evd_voxel_param_blocks": (_I, [_vp, C.POINTER(C.c_long), _I]),
     "evd_voxel_load_params": (_I, [_vp, _vp, _vp]),
     "evd_voxel_train_store_bytes": (_S, [_vp, _L]),
+    "evd_voxel_train_store_bytes_prec": (_S, [_vp, _I, _L]),
     "evd_voxel_backward_workspace_bytes": (_S, []),
     "evd_voxel_mlp_train": (_I, [_vp, _I, _vp, _vp, _I, _vp, _I, _L, _I, _vp, _vp, _vp, _S, _vp]),
     "evd_voxel_geo_feat_dim": (_I, [_vp]),

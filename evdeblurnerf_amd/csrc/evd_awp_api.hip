@@ -132,7 +132,7 @@ int evd_awp_embed_forward(const evd_awp_embed* a, int precision, const float* ge
     p.geo_frags = nullptr; p.geo_tile_bytes = 0; p.geo_slot = 0;
     if (fine_store) {
         EVD_REQUIRE(fine, "evd_awp_embed_forward: the fine level's store needs the level handle");
-        const size_t need = evd_voxel_train_store_bytes(fine, nsamp);
+        const size_t need = evd_voxel_train_store_bytes(fine, nsamp);      // half-precision layout: the level must have run in THIS precision
         EVD_REQUIRE(evd_voxel_geo_feat_dim(fine) == AWP_IN, "evd_awp_embed_forward: the level has %d geo channels, the embedding reads %d", evd_voxel_geo_feat_dim(fine), AWP_IN);
         if (fine_store_bytes < need) return fail(EVD_E_WORKSPACE, "evd_awp_embed_forward: fine store %zu < %zu bytes", fine_store_bytes, need);
         p.geo_frags = (const char*)fine_store; p.geo_tile_bytes = voxel_store_tile_bytes(256); p.geo_slot = voxel_store_geo_slot(256);

@@ -185,7 +185,7 @@ int evd_voxel_create(const evd_voxel_desc* d, evd_voxel** out) {
             rc = v->pipe[prec].upload(sp);
             if (rc) { evd_voxel_destroy(v); return rc; }
         }
-        if (!is_half_prec(prec)) continue;
+        if (!is_train_prec(prec)) continue;
         {   // training: forward stream of the level (the coarse level has no pipelined inference kernel: its own copy) ...
             StreamBuilder sp(prec, PIPE_CB);
             sp.arena = A;
@@ -424,7 +424,7 @@ int evd_c2f_render(const evd_voxel* coarse, const evd_voxel* fine, const evd_ren
 // ---- training: the level's sigma / colour networks -----------------------------------------------------
 static const int VOX_WGRAD_BLOCKS = 256;
 static long vox_tiles(long nsamp) { return cdiv(nsamp, 256L) * 8; }
-static bool vox_train_built(const evd_voxel* v, int prec) { return (prec == EVD_PREC_F16 || prec == EVD_PREC_BF16) && v->train_chunks[prec] > 0; }
+static bool vox_train_built(const evd_voxel* v, int prec) { return is_train_prec(prec) && v->train_chunks[prec] > 0; }
 
 long evd_voxel_param_count(const evd_voxel* v) { return v ? v->param_off[8] : 0; }
 
@@ -453,17 +453,22 @@ int evd_voxel_load_params(evd_voxel* v, const float* params, void* stream) {
 size_t evd_voxel_train_store_bytes(const evd_voxel* v, long nsamp) {
     return (!v || nsamp < 0) ? 0 : (size_t)vox_tiles(nsamp) * voxel_store_tile_bytes(v->hidden_dim);
 }
+size_t evd_voxel_train_store_bytes_prec(const evd_voxel* v, int precision, long nsamp) {
+    return (!v || nsamp < 0 || precision < 0 || precision >= EVD_VOX_NUM_PREC || !is_train_prec(precision)) ? 0
+           : (size_t)vox_tiles(nsamp) * voxel_store_tile_bytes_prec(v->hidden_dim, precision);
+}
 
 size_t evd_voxel_backward_workspace_bytes(void) { return (size_t)VOX_WGRAD_BLOCKS * 8 * 9 * 4096 + 512; }
 
 int evd_voxel_mlp_train(const evd_voxel* v, int precision, const float* pts, const float* viewdirs, int vd_stride, const float* fts, int ft_stride,
                         long R, int S, float* raw, float* feature, void* store, size_t store_bytes, void* stream) {
     EVD_REQUIRE(v && pts && viewdirs && fts && raw && store, "evd_voxel_mlp_train: null argument");
-    EVD_REQUIRE(precision >= 0 && precision < EVD_VOX_NUM_PREC && vox_train_built(v, precision), "evd_voxel_mlp_train: the training path is built for precision f16 / bf16");
+    EVD_REQUIRE(precision >= 0 && precision < EVD_VOX_NUM_PREC && vox_train_built(v, precision), "evd_voxel_mlp_train: the training path is built for precision f16 / bf16 / f16x3");
     EVD_REQUIRE(R >= 0 && S >= 1 && ft_stride >= v->ft_dim && ft_stride % 4 == 0, "evd_voxel_mlp_train: bad shape");
     if (R == 0) return EVD_OK;
     const long nsamp = R * (long)S;
-    if (store_bytes < evd_voxel_train_store_bytes(v, nsamp)) return fail(EVD_E_WORKSPACE, "evd_voxel_mlp_train: store %zu < %zu bytes", store_bytes, evd_voxel_train_store_bytes(v, nsamp));
+    if (store_bytes < evd_voxel_train_store_bytes_prec(v, precision, nsamp))
+        return fail(EVD_E_WORKSPACE, "evd_voxel_mlp_train: store %zu < %zu bytes", store_bytes, evd_voxel_train_store_bytes_prec(v, precision, nsamp));
     VoxMlpParams p;
     p.wstream = (const char*)v->train[precision].data.p;
     p.bias = (const float*)v->bias.p;
@@ -480,11 +485,12 @@ int evd_voxel_mlp_backward(const evd_voxel* v, int precision, const float* d_raw
                            float* d_pts, float* d_dirs, void* workspace, size_t workspace_bytes, void* stream) {
     EVD_REQUIRE((!d_pts || pts) && (!d_dirs || viewdirs), "evd_voxel_mlp_backward: d_pts / d_dirs need the forward's pts / viewdirs");
     EVD_REQUIRE(v && d_raw && raw && store && grads && workspace, "evd_voxel_mlp_backward: null argument");
-    EVD_REQUIRE(precision >= 0 && precision < EVD_VOX_NUM_PREC && vox_train_built(v, precision), "evd_voxel_mlp_backward: the training path is built for precision f16 / bf16");
+    EVD_REQUIRE(precision >= 0 && precision < EVD_VOX_NUM_PREC && vox_train_built(v, precision), "evd_voxel_mlp_backward: the training path is built for precision f16 / bf16 / f16x3");
     EVD_REQUIRE(R >= 0 && S >= 1 && (!d_fts || d_fts_stride >= v->ft_dim), "evd_voxel_mlp_backward: bad shape");
     if (R == 0) return EVD_OK;
     const long nsamp = R * (long)S;
-    if (store_bytes < evd_voxel_train_store_bytes(v, nsamp)) return fail(EVD_E_WORKSPACE, "evd_voxel_mlp_backward: store %zu < %zu bytes", store_bytes, evd_voxel_train_store_bytes(v, nsamp));
+    if (store_bytes < evd_voxel_train_store_bytes_prec(v, precision, nsamp))
+        return fail(EVD_E_WORKSPACE, "evd_voxel_mlp_backward: store %zu < %zu bytes", store_bytes, evd_voxel_train_store_bytes_prec(v, precision, nsamp));
     if (workspace_bytes < evd_voxel_backward_workspace_bytes()) return fail(EVD_E_WORKSPACE, "evd_voxel_mlp_backward: workspace %zu < %zu bytes", workspace_bytes, evd_voxel_backward_workspace_bytes());
     VoxBwdPlan b;
     b.d_raw = d_raw; b.raw = raw; b.d_feature = d_feature; b.nsamp = nsamp; b.tiles = vox_tiles(nsamp); b.store = (char*)store;
@@ -492,6 +498,7 @@ int evd_voxel_mlp_backward(const evd_voxel* v, int precision, const float* d_raw
     if (awp_store) {            // the fused AWP embedding ran its backward on this sample set: its d geo fragments join this level's
         const size_t need = (size_t)awp_tiles(nsamp) * awpstore::TILE_BYTES + awpstore::TRAILER_BYTES;
         EVD_REQUIRE(v->geo == AWP_IN, "evd_voxel_mlp_backward: awp_store goes with the fine level (geo %d)", AWP_IN);
+        EVD_REQUIRE(is_half_prec(precision), "evd_voxel_mlp_backward: awp_store goes with the f16 / bf16 modes (in f16x3 pass the geo gradient as d_feature rows)");
         if (awp_store_bytes < need) return fail(EVD_E_WORKSPACE, "evd_voxel_mlp_backward: awp_store %zu < %zu bytes", awp_store_bytes, need);
         b.awp_store = (const char*)awp_store; b.awp_tile_bytes = awpstore::TILE_BYTES; b.awp_slot = awpstore::D_GEO;
         b.awp_words = (const unsigned*)(b.awp_store + awp_tiles(nsamp) * awpstore::TILE_BYTES);

@@ -14,6 +14,7 @@ int run_voxel_backward_f16(int HD, const VoxBwdPlan& b, hipStream_t st) {
 }
 
 int voxel_store_geo_slot(int HD) { return HD == 256 ? VStore<256, 128, 64>::GEO : VStore<64, 15, 32>::GEO; }
+long voxel_store_tile_bytes_prec(int HD, int prec) { return HD == 256 ? VStore<256, 128, 64>::tile_bytes(prec) : VStore<64, 15, 32>::tile_bytes(prec); }
 long voxel_store_tile_bytes(int HD) { return HD == 256 ? VStore<256, 128, 64>::TILE_BYTES : VStore<64, 15, 32>::TILE_BYTES; }
 
 }  // namespace evd

@@ -21,7 +21,8 @@ template <int HD, int G, int FT> struct VStore {
                          D_HID = D_DIRPE + PEV_KS, D_FTS = D_HID + KS, D_PE = D_FTS + 2 * ((FT + 31) / 32),
                          M_HID = D_PE + PE_KS, M_C0 = M_HID + 1, M_C1 = M_C0 + 1,      // ReLU patterns as bit masks (mlp_pipe.h frag_bits)
                          TILE_FRAGS = M_C1 + 1;
-    static constexpr long TILE_BYTES = (long)TILE_FRAGS * 1024;
+    static constexpr long TILE_BYTES = (long)TILE_FRAGS * 1024;          // the single-product half-precision modes
+    static constexpr long tile_bytes(int prec) { return (long)TILE_FRAGS * frag_bytes(prec); }   // split-float16: (hi, lo) pairs in 2 KiB slots
 };
 
 // layer table of one PDRF level: HD hidden width, G geo channels (15: one zero-padded tile; 128: four), FT feature channels in
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(NT, OCC) void k_voxel_mlp_pipe(const VoxMlpParams p
         const long smp = (long)blockIdx.x * C::SAMPLES + wave * (NS * 32) + s * 32 + n;
         valid[s] = smp < p.nsamp;
         sidx[s] = valid[s] ? smp : p.nsamp - 1;
-        actl[s] = TRAIN ? p.act + (smp >> 5) * VS::TILE_BYTES + lane * 16 : nullptr;
+        actl[s] = TRAIN ? p.act + (smp >> 5) * VS::tile_bytes(PREC) + lane * 16 : nullptr;
         float pts[3], vd[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -113,9 +114,9 @@ __global__ __launch_bounds__(NT, OCC) void k_voxel_mlp_pipe(const VoxMlpParams p
         for (int j = 0; j < PEV_KS; ++j) stash[(s * C::STASH_FRAGS + j) * 64] = pev[j];   // parked until the colour net
         if constexpr (TRAIN) {
 #pragma unroll
-            for (int j = 0; j < KF + PE_KS; ++j) act_store(actl[s], VS::IN0 + j, in0[s][j]);
+            for (int j = 0; j < KF + PE_KS; ++j) act_store<C::FB>(actl[s], VS::IN0 + j, in0[s][j]);
 #pragma unroll
-            for (int j = 0; j < PEV_KS; ++j) act_store(actl[s], VS::DIRPE + j, pev[j]);
+            for (int j = 0; j < PEV_KS; ++j) act_store<C::FB>(actl[s], VS::DIRPE + j, pev[j]);
         }
     }
     float* frow[NS];
@@ -178,18 +179,19 @@ static int launch_voxel_pipe(const VoxMlpParams& p, hipStream_t st) {
     return EVD_OK;
 }
 
-// training variant (keeps the activations), either level; the stream is the level's pipe stream (evd_voxel_api.hip)
+// training variant (keeps the activations), either level; the stream is the level's pipe stream (evd_voxel_api.hip).  The store is
+// tiled in groups of 8 tiles (256 samples) and the backward walks all of them: the grid covers the padding tiles too.
 template <int PREC, int HD, int G, int FT, bool FEAT = false>
 static int launch_voxel_train_fwd(const VoxMlpParams& p, hipStream_t st) {
-    constexpr int NT = 512;
+    constexpr int NT = is_half_prec(PREC) ? 512 : 256, OCC = is_half_prec(PREC) ? 2 : 1;     // split-float16: one wavefront per SIMD
     typedef PipeCfg<PREC, 1, NT> C;
     typedef VoxNet<C, HD, G, FT, FEAT, true> N;
-    const long blocks = cdiv(p.nsamp, C::SAMPLES);
+    const long blocks = cdiv(p.nsamp, 256L) * (256 / C::SAMPLES);
     const size_t lds = C::TOTAL;
-    EVD_SET_MAX_LDS((&k_voxel_mlp_pipe<PREC, HD, G, FT, 1, NT, FEAT, PIPE_CB, 2, true>), lds);
+    EVD_SET_MAX_LDS((&k_voxel_mlp_pipe<PREC, HD, G, FT, 1, NT, FEAT, PIPE_CB, OCC, true>), lds);
     if (p.nchunks != N::NCH) return fail(EVD_E_INVALID, "evd_voxel: packed stream has %d chunks, kernel expects %d", p.nchunks, N::NCH);
     if (!p.act) return fail(EVD_E_INVALID, "evd_voxel: training launch without an activation store");
-    hipLaunchKernelGGL((k_voxel_mlp_pipe<PREC, HD, G, FT, 1, NT, FEAT, PIPE_CB, 2, true>), dim3((unsigned)blocks), dim3(NT), lds, st, p);
+    hipLaunchKernelGGL((k_voxel_mlp_pipe<PREC, HD, G, FT, 1, NT, FEAT, PIPE_CB, OCC, true>), dim3((unsigned)blocks), dim3(NT), lds, st, p);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }

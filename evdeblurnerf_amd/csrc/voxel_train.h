@@ -50,15 +50,19 @@ struct VoxBwdPlan {
 
 int launch_voxel_train_fwd_f16(int HD, const VoxMlpParams& p, hipStream_t st);
 int launch_voxel_train_fwd_bf16(int HD, const VoxMlpParams& p, hipStream_t st);
+int launch_voxel_train_fwd_f16x3(int HD, const VoxMlpParams& p, hipStream_t st);
 int run_voxel_backward_f16(int HD, const VoxBwdPlan& b, hipStream_t st);
 int run_voxel_backward_bf16(int HD, const VoxBwdPlan& b, hipStream_t st);
+int run_voxel_backward_f16x3(int HD, const VoxBwdPlan& b, hipStream_t st);
 inline int launch_voxel_train_fwd_dispatch(int prec, int HD, const VoxMlpParams& p, hipStream_t st) {
-    return prec == 3 /*EVD_PREC_F16*/ ? launch_voxel_train_fwd_f16(HD, p, st) : launch_voxel_train_fwd_bf16(HD, p, st);
+    return prec == 3 /*EVD_PREC_F16*/ ? launch_voxel_train_fwd_f16(HD, p, st)
+           : prec == 2 /*EVD_PREC_BF16*/ ? launch_voxel_train_fwd_bf16(HD, p, st) : launch_voxel_train_fwd_f16x3(HD, p, st);
 }
 inline int run_voxel_backward_dispatch(int prec, int HD, const VoxBwdPlan& b, hipStream_t st) {
-    return prec == 3 ? run_voxel_backward_f16(HD, b, st) : run_voxel_backward_bf16(HD, b, st);
+    return prec == 3 ? run_voxel_backward_f16(HD, b, st) : prec == 2 ? run_voxel_backward_bf16(HD, b, st) : run_voxel_backward_f16x3(HD, b, st);
 }
 int voxel_store_geo_slot(int HD);         // first of the geo fragments the training forward keeps (fine level: 8 fragments)
-long voxel_store_tile_bytes(int HD);      // fine 256 / 128 / 64 or coarse 64 / 15 / 32 (kernel_voxel_train_f16.hip)
+long voxel_store_tile_bytes(int HD);      // fine 256 / 128 / 64 or coarse 64 / 15 / 32 (kernel_voxel_train_f16.hip); half-precision modes
+long voxel_store_tile_bytes_prec(int HD, int prec);
 
 }  // namespace evd

@@ -32,14 +32,15 @@ __global__ __launch_bounds__(256) void k_voxel_grad_frags(const float* __restric
         for (int c = 1; c < 4; ++c) g[c] = g[c] * r[c] * (1.f - r[c]);         // through torch.sigmoid (voxnerf.py:252)
     }
     B col, sg;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) col.w[e] = sg.w[e] = 0u;
+    O::zero(col);
+    O::zero(sg);
     O::template set_pair<false>(col, 0, g[1] * s, g[2] * s);
     O::template set_pair<false>(col, 1, g[3] * s, 0.f);
     O::template set_pair<false>(sg, 0, g[0] * s, 0.f);
+    constexpr int FB = frag_bytes(PREC);
     char* a = store + tile * tile_bytes + lane * 16;
-    act_store(a, g_col, col);
-    act_store(a, g_sig, sg);
+    act_store<FB>(a, g_col, col);
+    act_store<FB>(a, g_sig, sg);
 }
 
 // gradient fragments of the input features -> float32 rows [n, FT] (loss scale removed): fragment j, position kk of the dgrad
@@ -52,16 +53,11 @@ __global__ __launch_bounds__(256) void k_frags_to_rows(const char* __restrict__ 
     const int j = (int)((idx / 64) % nfrag), lane = idx & 63, n = lane & 31, h = lane >> 5;
     const long smp = tile * 32 + n;
     if (smp >= nsamp) return;
-    const W4 f = frag_load<W4>(store + tile * tile_bytes + lane * 16, slot + j);
+    float fv[8];
+    frag_values<PREC>(store + tile * tile_bytes + lane * 16, slot + j, fv);
     const float inv = grad_scale(*maxbits, true);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const unsigned short bits = (unsigned short)(f.w[e >> 1] >> (16 * (e & 1)));
-        float v;
-        if constexpr (PREC == EVD_PREC_BF16) v = __uint_as_float((unsigned)bits << 16);
-        else v = (float)__builtin_bit_cast(_Float16, bits);
-        rows[smp * (long)stride + 16 * j + phi(8 * h + e)] = v * inv;
-    }
+    for (int e = 0; e < 8; ++e) rows[smp * (long)stride + 16 * j + phi(8 * h + e)] = fv[e] * inv;
 }
 
 // float32 gradient rows (the per-sample geo features' gradient, from the AWP consumer) added into gradient fragments: fragment j,
@@ -77,20 +73,15 @@ __global__ __launch_bounds__(256) void k_rows_add_to_frags(char* __restrict__ st
     const long smp = tile * 32 + n;
     if (smp >= nsamp) return;
     char* a = store + tile * tile_bytes + lane * 16;
-    const W4 f = frag_load<W4>(a, slot + j);
     const float s = grad_scale(*maxbits, false);
     float v[8];
+    frag_values<PREC>(a, slot + j, v);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const unsigned short bits = (unsigned short)(f.w[e >> 1] >> (16 * (e & 1)));
-        if constexpr (PREC == EVD_PREC_BF16) v[e] = __uint_as_float((unsigned)bits << 16);
-        else v[e] = (float)__builtin_bit_cast(_Float16, bits);
-        v[e] += rows[smp * (long)stride + 16 * j + phi(8 * h + e)] * s;
-    }
+    for (int e = 0; e < 8; ++e) v[e] += rows[smp * (long)stride + 16 * j + phi(8 * h + e)] * s;
     typename O::B b;
 #pragma unroll
     for (int e = 0; e < 4; ++e) O::template set_pair<false>(b, e, v[2 * e], v[2 * e + 1]);
-    act_store(a, slot + j, b);
+    act_store<frag_bytes(PREC)>(a, slot + j, b);
 }
 
 // *dst = max(*dst, *src) on float bits (both non-negative): the loss scale also covers a gradient that arrives as fragments
@@ -107,15 +98,13 @@ __global__ __launch_bounds__(256) void k_frags_add_scaled(char* __restrict__ sto
     if (tile >= tiles) return;
     const int j = (int)((idx / 64) % nfrag), lane = idx & 63;
     char* a = store + tile * tile_bytes + lane * 16;
-    const W4 f = frag_load<W4>(a, slot + j), g = frag_load<W4>(src + tile * src_tile_bytes + lane * 16, src_slot + j);
+    static_assert(is_half_prec(PREC), "the AWP embedding's store is half precision: both stores share one fragment format");
     const float s = grad_scale(*maxbits, false) * grad_scale(*src_maxbits, true);
-    float v[8];
+    float v[8], g[8];
+    frag_values<PREC>(a, slot + j, v);
+    frag_values<PREC>(src + tile * src_tile_bytes + lane * 16, src_slot + j, g);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const unsigned short fb = (unsigned short)(f.w[e >> 1] >> (16 * (e & 1))), gb = (unsigned short)(g.w[e >> 1] >> (16 * (e & 1)));
-        if constexpr (PREC == EVD_PREC_BF16) v[e] = __uint_as_float((unsigned)fb << 16) + __uint_as_float((unsigned)gb << 16) * s;
-        else v[e] = (float)__builtin_bit_cast(_Float16, fb) + (float)__builtin_bit_cast(_Float16, gb) * s;
-    }
+    for (int e = 0; e < 8; ++e) v[e] = fmaf(g[e], s, v[e]);
     typename O::B b;
 #pragma unroll
     for (int e = 0; e < 4; ++e) O::template set_pair<false>(b, e, v[2 * e], v[2 * e + 1]);
@@ -138,11 +127,11 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
         EVD_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL((k_voxel_grad_frags<PREC>), dim3((unsigned)cdiv(b.tiles * 64, 256L)), dim3(256), 0, st, b.d_raw, b.raw, b.nsamp, b.maxbits, b.store,
-                       b.tiles, VS::TILE_BYTES, VS::G_COL, VS::G_SIG);
+                       b.tiles, VS::tile_bytes(PREC), VS::G_COL, VS::G_SIG);
     EVD_LAUNCH_CHECK();
     auto dgrad = [&](int stream, int in_slot, int extra_slot, int mask_slot, int out_slot) {
         DgradParams p;
-        p.wstream = b.wt[stream]; p.store = b.store; p.tile_bytes = VS::TILE_BYTES;
+        p.wstream = b.wt[stream]; p.store = b.store; p.tile_bytes = VS::tile_bytes(PREC);
         p.in_slot = in_slot; p.extra_slot = extra_slot; p.mask_slot = mask_slot; p.out_slot = out_slot;
         return p;
     };
@@ -150,7 +139,7 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
         if (!dW) return EVD_OK;
         const int blocks = (int)(cdiv(b.tiles, (long)WGRAD_TPI) < b.wgrad_blocks ? cdiv(b.tiles, (long)WGRAD_TPI) : b.wgrad_blocks);
         WgradParams p;
-        p.store = b.store; p.tiles = b.tiles; p.tile_bytes = VS::TILE_BYTES; p.y_slot = y_slot; p.x_slot = x_slot; p.bias = bias ? 1 : 0; p.partial = b.partial;
+        p.store = b.store; p.tiles = b.tiles; p.tile_bytes = VS::tile_bytes(PREC); p.y_slot = y_slot; p.x_slot = x_slot; p.bias = bias ? 1 : 0; p.partial = b.partial;
         hipStream_t ws = st;
         if (b.side) {                           // fork: everything issued so far on the caller's stream first (nerf_train_kernel.h)
             EVD_HIP(hipEventRecord(b.ev, st));
@@ -180,18 +169,19 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
     if ((rc = launch_dgrad<PREC, KS, GT + 1, KS, false, 0>(dgrad(VBWD_C0, VS::D_C0, -1, -1, VS::D_GEO), b.tiles, st))) return rc;   // d geo | d PE(dirs)
     if (b.d_feature) {          // + the gradient of the geo features as an output of the level (voxnerf.py:221, consumed by AWP)
         if (G % 16) return fail(EVD_E_INVALID, "evd_voxel_mlp_backward: d_feature is built for the fine level (geo 128)");
-        hipLaunchKernelGGL((k_rows_add_to_frags<PREC>), dim3((unsigned)cdiv(b.tiles * 64 * (G / 16), 256L)), dim3(256), 0, st, b.store, VS::TILE_BYTES, VS::D_GEO,
+        hipLaunchKernelGGL((k_rows_add_to_frags<PREC>), dim3((unsigned)cdiv(b.tiles * 64 * (G / 16), 256L)), dim3(256), 0, st, b.store, VS::tile_bytes(PREC), VS::D_GEO,
                            G / 16, b.nsamp, b.maxbits, b.d_feature, G);
         EVD_LAUNCH_CHECK();
     }
     if (b.awp_store) {          // + the gradient that reached the geo features through the fused AWP embedding (awp_embed_kernel.h)
         if (G % 16) return fail(EVD_E_INVALID, "evd_voxel_mlp_backward: the AWP embedding reads the fine level (geo 128)");
-        hipLaunchKernelGGL((k_frags_add_scaled<PREC>), dim3((unsigned)cdiv(b.tiles * 64 * (G / 16), 256L)), dim3(256), 0, st, b.store, VS::TILE_BYTES, VS::D_GEO,
+        if constexpr (!is_half_prec(PREC)) return fail(EVD_E_INVALID, "evd_voxel_mlp_backward: awp_store goes with the f16 / bf16 modes (pass d_feature rows in f16x3)");
+        else hipLaunchKernelGGL((k_frags_add_scaled<PREC>), dim3((unsigned)cdiv(b.tiles * 64 * (G / 16), 256L)), dim3(256), 0, st, b.store, VS::tile_bytes(PREC), VS::D_GEO,
                            b.awp_store, b.awp_tile_bytes, b.awp_slot, G / 16, b.tiles, b.maxbits, b.awp_words);
         EVD_LAUNCH_CHECK();
     }
     if (b.d_dirs) {
-        hipLaunchKernelGGL((k_pe_bwd<PREC, PE_LV, PEV_KS>), dim3((unsigned)cdiv(b.tiles * 64, 256L)), dim3(256), 0, st, (const char*)b.store, VS::TILE_BYTES,
+        hipLaunchKernelGGL((k_pe_bwd<PREC, PE_LV, PEV_KS>), dim3((unsigned)cdiv(b.tiles * 64, 256L)), dim3(256), 0, st, (const char*)b.store, VS::tile_bytes(PREC),
                            VS::D_DIRPE, b.nsamp, b.viewdirs, b.vd_stride, b.S, b.maxbits, b.d_dirs, 0);
         EVD_LAUNCH_CHECK();
     }
@@ -205,12 +195,12 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
     if (b.d_fts || b.d_pts) {
         if ((rc = launch_dgrad<PREC, KS, FTT + 2, KS, false, 0>(dgrad(VBWD_L0, VS::D_HID, -1, -1, VS::D_FTS), b.tiles, st))) return rc;       // d fts | d PE(pts)
         if (b.d_fts) {
-            hipLaunchKernelGGL((k_frags_to_rows<PREC>), dim3((unsigned)cdiv(b.tiles * 64 * KF, 256L)), dim3(256), 0, st, (const char*)b.store, VS::TILE_BYTES,
+            hipLaunchKernelGGL((k_frags_to_rows<PREC>), dim3((unsigned)cdiv(b.tiles * 64 * KF, 256L)), dim3(256), 0, st, (const char*)b.store, VS::tile_bytes(PREC),
                                VS::D_FTS, KF, b.nsamp, b.maxbits, b.d_fts, b.d_fts_stride);
             EVD_LAUNCH_CHECK();
         }
         if (b.d_pts) {
-            hipLaunchKernelGGL((k_pe_bwd<PREC, PE_L, PE_KS>), dim3((unsigned)cdiv(b.tiles * 64, 256L)), dim3(256), 0, st, (const char*)b.store, VS::TILE_BYTES,
+            hipLaunchKernelGGL((k_pe_bwd<PREC, PE_L, PE_KS>), dim3((unsigned)cdiv(b.tiles * 64, 256L)), dim3(256), 0, st, (const char*)b.store, VS::tile_bytes(PREC),
                                VS::D_PE, b.nsamp, b.pts, 3, 1, b.maxbits, b.d_pts, 0);
             EVD_LAUNCH_CHECK();
         }

@@ -345,7 +345,9 @@ class NeRFAll:
         rb = self.ray_batch_train(H, W, K, flat_rays, ndc, near, far)
         awp = use_kernel and self.use_awp
         from .awp import FusedAWP
-        fused = awp and isinstance(self.awpnet, FusedAWP) and self.mode == "c2f"
+        # (the fragment coupling is a half-precision one: in the float32-grade mode the fused module takes the feature rows)
+        fused = awp and isinstance(self.awpnet, FusedAWP) and self.mode == "c2f" and self.precision in ("f16", "bf16") and \
+            self.awpnet.embed.precision == self.precision
         out = self.render_rays_train(rb, params_coarse, params_fine, N_samples, N_importance, want_feature="fragments" if fused else awp, **kw)
         rgb, rgb0 = out["rgb_map"], out.get("rgb0")
         if awp:         # adaptive weight proposal on the fine level's per-sample features (renderer.py:310-316): a second composition

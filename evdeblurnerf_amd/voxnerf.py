@@ -236,7 +236,9 @@ class VoxelNeRFBase:
         R, S = p.shape[:2]
         raw = torch.empty((R, S, 4), dtype=torch.float32, device=p.device)
         feature = torch.empty((R, S, self.geo_feat_dim), dtype=torch.float32, device=p.device) if want_feature else None
-        nb = int(L.lib().evd_voxel_train_store_bytes(self._h, R * S))
+        nb = int(L.lib().evd_voxel_train_store_bytes_prec(self._h, L.PREC[precision or self.precision], R * S))
+        if nb == 0 and R * S > 0:
+            raise L.EvdError(f"the training path is built for precision f16 / bf16 / f16x3, not {precision or self.precision}")
         store = torch.empty((nb,), dtype=torch.uint8, device=p.device)
         L.check(L.lib().evd_voxel_mlp_train(self._h, L.PREC[precision or self.precision], L.ptr(p), L.ptr(vd), vd.shape[-1], L.ptr(ft), ft.shape[-1],
                                              R, S, L.ptr(raw), L.ptr(feature), L.ptr(store), nb, L.stream_ptr()), "evd_voxel_mlp_train")

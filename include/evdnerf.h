@@ -265,13 +265,15 @@ int evd_voxel_tv_loss(const evd_voxel* v, float* out, void* stream);
  * ray's samples) -- what carries the loss back to the rays, i.e. to the blur kernel's camera motion.  awp_store (NULL = none; fine
  * level): the store of the fused AWP embedding AFTER evd_awp_embed_backward ran on the same samples -- its d geo fragments are added
  * to the geo features' gradient without ever becoming a float32 [R*S,128] tensor (below).
- * Built for EVD_PREC_F16 / EVD_PREC_BF16, both shipped levels (64/15/32 and 256/128/64). */
+ * Built for EVD_PREC_F16 / EVD_PREC_BF16 and the float32-grade EVD_PREC_F16X3 (as evd_nerf_mlp_train; awp_store is a half-precision
+ * coupling: in f16x3 the AWP consumer's gradient comes back as d_feature rows), both shipped levels (64/15/32 and 256/128/64). */
 typedef struct { float *sigma_w[2], *color_w[3], *color_b[3]; } evd_voxel_grads;
 int evd_voxel_geo_feat_dim(const evd_voxel* v);
 long evd_voxel_param_count(const evd_voxel* v);
 int evd_voxel_param_blocks(const evd_voxel* v, long* offsets, int capacity);
 int evd_voxel_load_params(evd_voxel* v, const float* params, void* stream);
-size_t evd_voxel_train_store_bytes(const evd_voxel* v, long nsamp);
+size_t evd_voxel_train_store_bytes(const evd_voxel* v, long nsamp);         /* the f16 / bf16 size */
+size_t evd_voxel_train_store_bytes_prec(const evd_voxel* v, int precision, long nsamp);   /* EVD_PREC_F16X3: (hi, lo) fragments, twice that */
 size_t evd_voxel_backward_workspace_bytes(void);
 int evd_voxel_mlp_train(const evd_voxel* v, int precision, const float* pts, const float* viewdirs, int vd_stride, const float* fts,
                         int ft_stride, long R, int S, float* raw, float* feature, void* store, size_t store_bytes, void* stream);

@@ -685,6 +685,10 @@ def test_backward_edge_cases_zero_gradient_and_single_sample():
 
 
 def test_c2f_training_gradients_against_the_reference_golden():
+    _g19_check("f16", 0.15, 0.01, 3e-3)
+
+
+def _g19_check(prec, tol, tol_tight, rgb_tol):
     """G19: gradients computed by torch.autograd ON THE REFERENCE (its whole mode='c2f' training forward: NDC ray packing, both
     levels, resampling, TV) vs the HIP training path run on the same rays and weights.  Bounded by the half-precision ReLU flips and
     the slightly different resampled positions (the kernels' own coarse weights feed sample_pdf): norms and seeded projections of all
@@ -703,12 +707,12 @@ def test_c2f_training_gradients_against_the_reference_golden():
                            coarse_hidden_dim=64, coarse_hidden_dim_color=64, coarse_app_dim=32, coarse_app_n_comp=[64, 16, 16], coarse_n_voxels=24 ** 3,
                            kernel_feat_cnl=15, fine_num_layers=2, fine_num_layers_color=3, fine_hidden_dim=256, fine_hidden_dim_color=256,
                            fine_geo_feat_dim=128, fine_app_dim=32, fine_app_n_comp=[64, 16, 16], fine_n_voxels=48 ** 3)
-    model = NeRFAll(args, sd, precision="f16").enable_training(sd).train()
+    model = NeRFAll(args, sd, precision=prec).enable_training(sd).train()
     assert model.mlp_coarse.gridSize == gc and model.mlp_fine.gridSize == gf
     rays = torch.tensor(g["rays"], device="cuda", requires_grad=True)
     rgb, rgb0, other, _ = model(400, 400, W.synthetic_camera(), 1 << 20, rays=rays, ndc=True, near=0., far=1., N_samples=16, N_importance=16,
                                 perturb=0., raw_noise_std=0.)
-    assert (rgb.detach().cpu().numpy() - g["rgb"]).__abs__().max() < 3e-3 and (rgb0.detach().cpu().numpy() - g["rgb0"]).__abs__().max() < 3e-3
+    assert (rgb.detach().cpu().numpy() - g["rgb"]).__abs__().max() < rgb_tol and (rgb0.detach().cpu().numpy() - g["rgb0"]).__abs__().max() < rgb_tol
     assert abs(other["TV"].item() - float(g["tv"])) < 1e-4 * float(g["tv"])
     loss = (rgb * torch.tensor(g["w_rgb"], device="cuda")).sum() + (rgb0 * torch.tensor(g["w_rgb0"], device="cuda")).sum() + 0.1 * other["TV"].sum()
     loss.backward()
@@ -729,9 +733,9 @@ def test_c2f_training_gradients_against_the_reference_golden():
         norm = float(ref[0])
         worst[key] = max(abs(sm[0] - ref[0]), abs(sm[1] - ref[1])) / norm
     tight = [k for k in keys if k.endswith("color_net.2.weight") or k.endswith("color_net.2.bias")]
-    print("G19 vs kernels, worst (norm / projection error) / norm:", {k: f"{v:.1e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:6]})
-    assert max(worst.values()) < 0.15, worst
-    assert max(worst[k] for k in tight) < 0.01
+    print(f"G19 vs kernels ({prec}), worst (norm / projection error) / norm:", {k: f"{v:.1e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:6]})
+    assert max(worst.values()) < tol, worst
+    assert max(worst[k] for k in tight) < tol_tight
 
 
 def test_nerf_training_gradients_against_the_reference_golden():

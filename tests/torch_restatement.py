@@ -70,9 +70,15 @@ class TorchVoxLevel(torch.nn.Module):
         y = x @ self.p[f"color_net_{i}_weight"].T
         return y + self.p[f"color_net_{i}_bias"] if f"color_net_{i}_bias" in self.p else y
 
-    def forward(self, pts, dirs, fts, masks=None, want_geo=False):
+    def forward(self, pts, dirs, fts, masks=None, want_geo=False, keep=None):
+        """masks: 0/1 ReLU patterns to use instead of the own ones; keep: dict that receives the pre-activations of hid / c0 / c1"""
         P = self.p
-        act = (lambda x, k: torch.relu(x)) if masks is None else (lambda x, k: x * masks[k])
+
+        def act(x, k):
+            if keep is not None:
+                keep[k] = x.detach()
+            return torch.relu(x) if masks is None else x * masks[k]
+
         h = act(torch.cat([fts, embed(pts, 10)], -1) @ P["sigma_net_0_weight"].T, "hid")
         sg = h @ P["sigma_net_1_weight"].T
         c = act(self.cl(0, torch.cat([sg[:, 1:], embed(dirs, 4)], -1)), "c0")
