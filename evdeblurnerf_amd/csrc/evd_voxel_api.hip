@@ -572,6 +572,21 @@ int evd_voxel_sample_bwd(const evd_voxel* v, const float* pts, long n, const flo
     return launch_voxel_sample_bwd(v->gp, pts, n, d_out, d_stride, d_col, gg, d_pts, as_stream(stream));
 }
 
+size_t evd_voxel_sample_bwd_workspace_bytes(const evd_voxel* v, long n) { return (!v || n <= 0) ? 0 : voxel_scatter_workspace_bytes(v->gp, n); }
+
+int evd_voxel_sample_bwd_ws(const evd_voxel* v, const float* pts, long n, const float* d_out, int d_stride, int d_col,
+                            const evd_voxel_grid_grads* g, float* d_pts, void* workspace, size_t workspace_bytes, void* stream) {
+    EVD_REQUIRE(v && pts && d_out && g && n >= 0 && d_stride >= d_col + v->app_dim, "evd_voxel_sample_bwd_ws: bad arguments");
+    EVD_REQUIRE(v->app_act == EVD_ACT_NONE, "evd_voxel_sample_bwd_ws: only app_actfn none is built (all shipped configs)");
+    if (n == 0) return EVD_OK;
+    GridGrads gg;
+    for (int i = 0; i < 3; ++i) { gg.plane[i] = g->plane[i]; gg.line[i] = g->line[i]; }
+    gg.basis = g->basis;
+    if (workspace && workspace_bytes > 0 && voxel_scatter_binned_ok(v->gp, gg, n))
+        return launch_voxel_sample_bwd_binned(v->gp, pts, n, d_out, d_stride, d_col, gg, d_pts, workspace, workspace_bytes, as_stream(stream));
+    return launch_voxel_sample_bwd(v->gp, pts, n, d_out, d_stride, d_col, gg, d_pts, as_stream(stream));
+}
+
 int evd_voxel_tv_loss_bwd(const evd_voxel* v, const float* d_loss, const evd_voxel_grid_grads* g, void* stream) {
     EVD_REQUIRE(v && g && d_loss, "evd_voxel_tv_loss_bwd: null argument");
     hipStream_t st = as_stream(stream);

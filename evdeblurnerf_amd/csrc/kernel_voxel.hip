@@ -557,10 +557,13 @@ __global__ __launch_bounds__(64 * VW_WAVES) void k_voxel_sample_w(const GridPara
 // contention.  Tried and dropped: a run-length sum over the tile's consecutive samples that hit the same cell before the atomic (one
 // thread per (tap, channel) walking the 32 samples): the sequential walk costs more than the adds it saves (3.1 ms) unless the rays
 // run along a grid axis.  Fewer adds would need a sort by cell + segmented sum instead of atomics.
+// BINNED (kernel_voxel_scatter.hip): the atomics of phase B are replaced by one row of per-channel contributions per sample and the
+// tap records; a second pass adds them tile by tile in LDS.  d basis and d pts are computed here either way.
 constexpr int VSB_MAXF = 64, VSB_TAPS = 18;
+template <bool BINNED>
 __global__ __launch_bounds__(256) void k_voxel_sample_bwd(const GridParams g, const float* __restrict__ pts, long n,
                                                           const float* __restrict__ d_out, int d_stride, int d_col, GridGrads gg,
-                                                          float* __restrict__ d_pts) {
+                                                          float* __restrict__ d_pts, const BinOut bo) {
     __shared__ float tfr[VS_SAMPLES * 3 * 6], dpt[VS_SAMPLES * 3];
     __shared__ int tax[VS_SAMPLES * 3 * 3];
     __shared__ __attribute__((aligned(16))) float pvs[VS_SAMPLES * VS_STRIDE], lvs[VS_SAMPLES * VS_STRIDE], dco[VS_SAMPLES * VS_STRIDE],
@@ -634,6 +637,24 @@ __global__ __launch_bounds__(256) void k_voxel_sample_bwd(const GridParams g, co
             fr[0] = it.fw; fr[1] = it.fn; fr[2] = it.fl; fr[3] = it.kx; fr[4] = it.ky; fr[5] = it.kl;
             int* ta = tax + (sl * 3 + i) * 3;
             ta[0] = it.ax; ta[1] = it.ay; ta[2] = it.al;
+            if constexpr (BINNED) {
+                if (live) {                         // tap records + the plane's tile key of this (sample, component)
+                    const int C = sel3(i, g.n_comp[0], g.n_comp[1], g.n_comp[2]), Wp = sel3(i, g.grid[0], g.grid[0], g.grid[1]);
+                    const int cell0 = (int)(it.ip[0] / C), cell3 = (int)(it.ip[3] / C);
+                    const int cy0 = cell0 / Wp, cx0 = cell0 - cy0 * Wp, cy1 = cell3 / Wp, cx1 = cell3 - cy1 * Wp;
+                    PTap pt_;
+                    pt_.cx0 = (unsigned short)cx0; pt_.cx1 = (unsigned short)cx1; pt_.cy0 = (unsigned short)cy0; pt_.cy1 = (unsigned short)cy1;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) pt_.w[t] = it.wp[t];
+                    bo.ptap[s * 3 + i] = pt_;
+                    LTap lt_;
+                    lt_.c0 = (int)(it.il[0] / C); lt_.c1 = (int)(it.il[1] / C); lt_.w0 = it.wl[0]; lt_.w1 = it.wl[1];
+                    bo.ltap[s * 3 + i] = lt_;
+                    unsigned* kp = sel3(i, bo.keys[0], bo.keys[1], bo.keys[2]);
+                    kp[s] = (unsigned)((cy0 / SC_TS) * sel3(i, bo.tiles_x[0], bo.tiles_x[1], bo.tiles_x[2]) + cx0 / SC_TS);
+                    if (i == 0) bo.ids[s] = (unsigned)s;
+                }
+            }
         }
         if (tid < VS_SAMPLES * 3) dpt[tid] = 0.f;
         __syncthreads();
@@ -691,15 +712,25 @@ __global__ __launch_bounds__(256) void k_voxel_sample_bwd(const GridParams g, co
         // (Re-measured in round 2 with the half-tile walk that keeps a ray's runs together -- successive samples of an NDC ray address
         // ~12 distinct x-y cells and ~7 x / y line cells per 32 samples --: summing the run in a register before ONE atomic is 1.5-1.9x
         // SLOWER, 2.76 vs 1.46 ms at 2^19 samples: the walk is a chain of dependent LDS reads, the sweep below is not.)
-        for (int sl = ss; sl < VS_SAMPLES; sl += 2) {
+        if constexpr (BINNED) {
+            if (chan_on) {
+                for (int sl = ss; sl < VS_SAMPLES && s0 + sl < n; sl += 2) {
+                    const float dc = dco[sl * VS_STRIDE + ql];
+                    bo.rows_p[(s0 + sl) * ctot + ql] = dc * lvs[sl * VS_STRIDE + ql];
+                    bo.rows_l[(s0 + sl) * ctot + ql] = dc * pvs[sl * VS_STRIDE + ql];
+                }
+            }
+        } else {
+            for (int sl = ss; sl < VS_SAMPLES; sl += 2) {
 #pragma unroll
-            for (int m = 0; m < MQ; ++m) {
-                if (!q_ptr[m]) continue;
-                const float w = tw[sl * VSB_TAPS + q_slot[m]];
-                if (w == 0.f) continue;
-                const int c = q_c[m];
-                const float other = q_plane[m] ? lvs[sl * VS_STRIDE + c] : pvs[sl * VS_STRIDE + c];
-                unsafeAtomicAdd(q_ptr[m] + tix[sl * VSB_TAPS + q_slot[m]], dco[sl * VS_STRIDE + c] * other * w);
+                for (int m = 0; m < MQ; ++m) {
+                    if (!q_ptr[m]) continue;
+                    const float w = tw[sl * VSB_TAPS + q_slot[m]];
+                    if (w == 0.f) continue;
+                    const int c = q_c[m];
+                    const float other = q_plane[m] ? lvs[sl * VS_STRIDE + c] : pvs[sl * VS_STRIDE + c];
+                    unsafeAtomicAdd(q_ptr[m] + tix[sl * VSB_TAPS + q_slot[m]], dco[sl * VS_STRIDE + c] * other * w);
+                }
             }
         }
         if (d_pts && tid < VS_SAMPLES * 3 && s0 + tid / 3 < n) d_pts[(s0 + tid / 3) * 3 + tid % 3] = dpt[tid];
@@ -984,7 +1015,16 @@ int launch_voxel_sample_bwd(const GridParams& g, const float* pts, long n, const
                             float* d_pts, hipStream_t st) {
     if (g.app_dim > VSB_MAXF) return fail(EVD_E_INVALID, "evd_voxel_sample_bwd: app_dim %d > %d", g.app_dim, VSB_MAXF);
     const long tiles = cdiv(n, VS_SAMPLES);
-    k_voxel_sample_bwd<<<(unsigned)(tiles < 2048 ? tiles : 2048), 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts);
+    k_voxel_sample_bwd<false><<<(unsigned)(tiles < 2048 ? tiles : 2048), 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, BinOut{});
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+int launch_voxel_sample_bwd_pass1(const GridParams& g, const float* pts, long n, const float* d_out, int d_stride, int d_col, const GridGrads& gg,
+                                  float* d_pts, const BinOut& bo, hipStream_t st) {
+    if (g.app_dim > VSB_MAXF) return fail(EVD_E_INVALID, "evd_voxel_sample_bwd: app_dim %d > %d", g.app_dim, VSB_MAXF);
+    const long tiles = cdiv(n, VS_SAMPLES);
+    k_voxel_sample_bwd<true><<<(unsigned)(tiles < 2048 ? tiles : 2048), 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }

@@ -30,6 +30,26 @@ struct VoxMlpParams {
     char* act;                  // training kernels: activation store, else null
 };
 
+// ---- binned scatter (kernel_voxel_scatter.hip): what the first pass of the tri-plane backward leaves per sample for the second
+struct PTap { unsigned short cx0, cx1, cy0, cy1; float w[4]; };     // clamped cell coordinates of the 4 bilinear taps of one plane + weights (0 = outside)
+struct LTap { int c0, c1; float w0, w1; };                          // the 2 taps of one line
+constexpr int SC_TS = 16;                                           // plane tiles of 16 x 16 cells (+ 1 halo row / column in LDS)
+struct BinOut {
+    float* rows_p;          // [n, ctot]  d coef x line value: what every plane tap adds, times its weight
+    float* rows_l;          // [n, ctot]  d coef x plane value, for the line taps
+    PTap* ptap;             // [n, 3]
+    LTap* ltap;             // [n, 3]
+    unsigned* keys[3];      // [n] tile of tap 0 in plane i
+    unsigned* ids;          // [n] 0 .. n-1 (the sort's values)
+    int tiles_x[3];
+};
+bool voxel_scatter_binned_ok(const GridParams& g, const GridGrads& gg, long n);
+size_t voxel_scatter_workspace_bytes(const GridParams& g, long n);
+int launch_voxel_sample_bwd_pass1(const GridParams& g, const float* pts, long n, const float* d_out, int d_stride, int d_col, const GridGrads& gg,
+                                  float* d_pts, const BinOut& bo, hipStream_t st);
+int launch_voxel_sample_bwd_binned(const GridParams& g, const float* pts, long n, const float* d_out, int d_stride, int d_col, const GridGrads& gg,
+                                   float* d_pts, void* workspace, size_t workspace_bytes, hipStream_t st);
+
 constexpr int TV_MAX_BLOCKS = 4096;     // partial (dh^2, dw^2) pairs per tensor
 struct TvShape { int C[6], H[6], W[6], blocks[6]; };
 

@@ -3,6 +3,7 @@ VoxelNeRFSampleFeatures :284) on libevdnerf.so: tri-plane feature gather, sigma/
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -42,8 +43,12 @@ class _VoxelSample(torch.autograd.Function):
         g = d_out.reshape(-1, net.app_dim).contiguous().float()
         grads, gs = _grid_grads(net, ctx.saved_tensors)
         d_pts = torch.empty_like(pts) if ctx.needs_input_grad[0] else None
-        L.check(L.lib().evd_voxel_sample_bwd(net._h, L.ptr(pts), pts.shape[0], L.ptr(g), net.app_dim, 0, C.byref(gs), L.ptr(d_pts), L.stream_ptr()),
-                "evd_voxel_sample_bwd")
+        # EVD_SCATTER=1: the experimental binned form (taps sorted by plane tile, summed in LDS; csrc/kernel_voxel_scatter.hip) -- it gets
+        # scratch; by default none is passed and the direct-atomics kernel runs
+        nb = int(L.lib().evd_voxel_sample_bwd_workspace_bytes(net._h, pts.shape[0])) if os.environ.get("EVD_SCATTER") == "1" else 0
+        ws = torch.empty((nb,), dtype=torch.uint8, device=pts.device) if nb else None
+        L.check(L.lib().evd_voxel_sample_bwd_ws(net._h, L.ptr(pts), pts.shape[0], L.ptr(g), net.app_dim, 0, C.byref(gs), L.ptr(d_pts), L.ptr(ws), nb,
+                                                L.stream_ptr()), "evd_voxel_sample_bwd_ws")
         return (d_pts.reshape(ctx.pts.shape) if d_pts is not None else None, None, *grads)
 
 

@@ -54,7 +54,20 @@ def main():
     fwd = timed(lambda: net.sample(pts))
     bwd = timed(lambda: L.check(L.lib().evd_voxel_sample_bwd(net._h, L.ptr(pts), n, L.ptr(d_out), 32, 0, C.byref(gs), None, L.stream_ptr()), "bwd"))
     atom = n * 6 * 96
-    print(f"grid {g}: n = {n} samples | gather forward {fwd:.3f} ms | scatter backward {bwd:.3f} ms = {atom / bwd / 1e6:.1f} G float atomics/s")
+    nb = int(L.lib().evd_voxel_sample_bwd_workspace_bytes(net._h, n))
+    ws = torch.empty((nb,), dtype=torch.uint8, device="cuda")
+    binned = timed(lambda: L.check(L.lib().evd_voxel_sample_bwd_ws(net._h, L.ptr(pts), n, L.ptr(d_out), 32, 0, C.byref(gs), None, L.ptr(ws), nb, L.stream_ptr()), "bwd_ws"))
+    # agreement of the two forms (both sum in a non-deterministic order)
+    for t in grads:
+        t.zero_()
+    L.check(L.lib().evd_voxel_sample_bwd(net._h, L.ptr(pts), n, L.ptr(d_out), 32, 0, C.byref(gs), None, L.stream_ptr()), "bwd")
+    ref = [t.clone() for t in grads]
+    for t in grads:
+        t.zero_()
+    L.check(L.lib().evd_voxel_sample_bwd_ws(net._h, L.ptr(pts), n, L.ptr(d_out), 32, 0, C.byref(gs), None, L.ptr(ws), nb, L.stream_ptr()), "bwd_ws")
+    err = max(((a - b).norm() / b.norm().clamp_min(1e-30)).item() for a, b in zip(grads, ref))
+    print(f"grid {g}: n = {n} samples | gather forward {fwd:.3f} ms | scatter backward: direct atomics {bwd:.3f} ms = {atom / bwd / 1e6:.1f} G float atomics/s | "
+          f"binned (sort + LDS tiles) {binned:.3f} ms | relative L2 difference of the two {err:.1e} | scratch {nb / 2**20:.0f} MiB")
 
 
 if __name__ == "__main__":
