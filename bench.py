@@ -448,7 +448,18 @@ def main(argv=None):
                                "backward_tflops": 2 * algo_flop / (bwd_ms * 1e-3) / 1e12,
                                "note": "evd_nerf_mlp_train / evd_nerf_mlp_backward on the metric workload (one network); HBM-bound by "
                                        "construction (per-layer dgrad + wgrad over the stored fragments), DESIGN.md 7"}
-            del store_t, tnet
+            del store_t
+            # the float32-grade training mode (EVD_PREC_F16X3: (hi, lo) fragments, 3-MFMA products; the reference trains in float32)
+            f32g = NeRF(sd, "mlp_coarse.", precision="f16x3")
+            fwd3_ms = kernel_ms(lambda: f32g.mlpforward_train(rb_t, z_t), 5)
+            _, store3 = f32g.mlpforward_train(rb_t, z_t)
+            bwd3_ms = kernel_ms(lambda: f32g.mlp_backward_flat(d_raw_t, store3), 5)
+            result["train"]["float32_grade"] = {"precision": "f16x3", "forward_keeping_activations_ms": fwd3_ms, "backward_params_ms": bwd3_ms,
+                                                "activation_store_bytes": int(store3.numel()),
+                                                "note": "gradients equal float64 autograd to 1e-7..1e-4 and the reference's own autograd goldens "
+                                                        "(G18 / G19) to 2e-4 of the norm (tests/test_gpu_train_f32grade.py); the half-precision "
+                                                        "figures above are the throughput modes"}
+            del store3, f32g, tnet
 
     # ---- the shipped configuration (every rank builds the model: the strong-scaling leg shards one frame's rows over the ranks)
     c2f_model = None

@@ -556,7 +556,10 @@ __global__ __launch_bounds__(64 * VW_WAVES) void k_voxel_sample_w(const GridPara
 // cost the same per add, and 32 private copies of the (heavily shared) line gradients change nothing: it is the op count, not
 // contention.  Tried and dropped: a run-length sum over the tile's consecutive samples that hit the same cell before the atomic (one
 // thread per (tap, channel) walking the 32 samples): the sequential walk costs more than the adds it saves (3.1 ms) unless the rays
-// run along a grid axis.  Fewer adds would need a sort by cell + segmented sum instead of atomics.
+// run along a grid axis.  Also tried and dropped (round 2): per-tile LDS windows (8 x 8 plane cells / 32 line cells around the tile's
+// taps, ds_add_f32, one global atomic per touched cell) for the components whose taps stay together along a ray -- the bounding-box
+// atomics, the per-tap window index and the flush add ~0.5 ms per 2^19 samples to this one-wavefront-per-SIMD kernel and the whole
+// blurfactory iteration went from 33.2 to 42.1 ms; and the sort + LDS-tile form of kernel_voxel_scatter.hip (2 x slower as built).
 // BINNED (kernel_voxel_scatter.hip): the atomics of phase B are replaced by one row of per-channel contributions per sample and the
 // tap records; a second pass adds them tile by tile in LDS.  d basis and d pts are computed here either way.
 constexpr int VSB_MAXF = 64, VSB_TAPS = 18;

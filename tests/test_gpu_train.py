@@ -874,4 +874,4 @@ def test_binned_scatter_equals_the_direct_scatter():
     L.check(L.lib().evd_voxel_sample_bwd_ws(net._h, L.ptr(pts), n, L.ptr(d_out), 32, 0, C.byref(gs), L.ptr(dp_b), L.ptr(ws), nb, L.stream_ptr()), "bwd_ws")
     errs = [rel_l2(a.double(), b.double()) for a, b in zip(grads, ref)]
     assert max(errs) < 1e-5, errs
-    assert torch.equal(dp_a, dp_b)
+    assert rel_l2(dp_b.double(), dp_a.double()) < 1e-5          # (the point gradient is summed over channels with LDS atomics: order-dependent rounding)
