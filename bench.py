@@ -61,6 +61,7 @@ def parse(argv=None):
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-c2f", action="store_true")
+    ap.add_argument("--no-awp", action="store_true")
     ap.add_argument("--no-strong", action="store_true")
     return ap.parse_args(argv)
 
@@ -267,6 +268,70 @@ def c2f_leg(precision, steps):
     return out, model
 
 
+def awp_leg(precision):
+    """the AWP consumer's per-sample part at the blurfactory blur-batch shape (10 240 sub-exposure rays x 128 samples):
+    what it adds to the fine level's training forward + backward as torch Linear layers on depth_feature (the reference's way) and
+    fused on the level's geo fragments (evd_awp_embed_forward / _backward), and the HBM roofline of the embedding kernel."""
+    import numpy as np
+    import torch
+    from evdeblurnerf_amd import weights as W
+    from evdeblurnerf_amd.awp import SampleFeatureEmbed, feature_integration
+    from evdeblurnerf_amd.voxnerf import GeoFragments, VoxelNeRFSampleFeatures
+    aabb = ((-1.5, -1.5, -1.0), (1.5, 1.5, 1.0))
+    R, S, dev, nvox = 10240, 128, "cuda", 48 ** 3
+    sd = W.make_pdrf_state_dict(71, W.pdrf_grid_size(aabb[0], aabb[1], nvox), input_ch=64 + 63, hidden_dim=256, geo_feat_dim=128, add_bias_color=True)
+    net = VoxelNeRFSampleFeatures(sd, "", aabb, num_layers=2, hidden_dim=256, geo_feat_dim=128, num_layers_color=3, input_ch=64 + 63, app_dim=32,
+                                  app_n_comp=(64, 16, 16), n_voxels=nvox, precision=precision)
+    flat = net.flat_params(sd)
+    esd = W.make_awp_embed_state_dict(211)
+    ws = [esd[f"sample_feature_embed_layer.{l}.weight"] for l in range(4)]
+    bs = [esd[f"sample_feature_embed_layer.{l}.bias"] for l in range(4)]
+    emb = SampleFeatureEmbed(ws, bs, precision=precision)
+    eflat = torch.cat([torch.tensor(t).reshape(-1) for l in range(4) for t in (ws[l], bs[l])]).to(dev).requires_grad_(True)
+    lin = torch.nn.ModuleList([torch.nn.Linear(128, 64)] + [torch.nn.Linear(64, 64) for _ in range(3)]).to(dev)
+    rs = np.random.RandomState(0)
+    pts = torch.tensor(rs.uniform(-1, 1, (R, S, 3)).astype(np.float32), device=dev)
+    d = rs.normal(size=(R, 3))
+    vd = torch.tensor((d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32), device=dev)
+    fts = torch.tensor((0.3 * rs.normal(size=(R, S, 64))).astype(np.float32), device=dev)
+    z = torch.sort(torch.rand((R, S), device=dev), -1)[0]
+    rd = torch.randn((R, 3), device=dev)
+    gh, graw = torch.randn((R, 64), device=dev) * 1e-3, torch.randn((R, S, 4), device=dev) * 1e-3
+
+    def level_only():
+        (net.mlp_train(flat, pts, vd, fts) * graw).sum().backward()
+
+    def torch_path():
+        raw, feat = net.mlp_train(flat, pts, vd, fts, want_feature=True)
+        h = feat
+        for layer in lin:
+            h = torch.relu(layer(h))
+        ((raw * graw).sum() + (feature_integration(h.reshape(R, 1, S, 64), z, rd).reshape(R, 64) * gh).sum()).backward()
+
+    def fused_path():
+        geo = GeoFragments()
+        raw, geo.token = net.mlp_train(flat, pts, vd, fts, want_feature=geo)
+        ((raw * graw).sum() + (feature_integration(emb(eflat, geo).reshape(R, 1, S, 64), z, rd).reshape(R, 64) * gh).sum()).backward()
+
+    t0, t1, t2 = kernel_ms(level_only, 5), kernel_ms(torch_path, 5), kernel_ms(fused_path, 5)
+    geo = GeoFragments()
+    with torch.no_grad():
+        _, geo.token = net.mlp_train(flat.detach().requires_grad_(True), pts, vd, fts, want_feature=geo)
+    emb.load_params(eflat)
+    from evdeblurnerf_amd.awp import _SampleEmbed
+    k_ms = kernel_ms(lambda: _SampleEmbed.apply(geo.token, eflat.detach(), emb, geo), 10)
+    n = R * S
+    tile_bytes = (8 + 8 + 16) * 1024 + 32 * 64 * 4            # geo fragments in, geo copy + 4 activations out (training), h_local rows out
+    algo = (n // 32) * tile_bytes
+    return {"workload": "AWP consumer, blurfactory blur batch: 10 240 sub-exposure rays x 128 samples, sample_feature_embed_layer 128-64-64-64-64 + feature_integration",
+            "precision": precision, "fine_level_fwd_bwd_ms": t0, "with_awp_torch_linear_on_depth_feature_ms": t1, "with_awp_fused_on_geo_fragments_ms": t2,
+            "awp_addon_ms": {"torch": t1 - t0, "fused": t2 - t0}, "depth_feature_tensor_avoided_bytes": n * 128 * 4,
+            "roofline": {"kernel": "k_awp_embed (training forward, geo fragments in)", "bound": "hbm", "kernel_ms": k_ms, "algorithmic_bytes": algo,
+                         "achieved": algo / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "note": "per 32-sample tile: 8 KiB geo fragments read from the fine level's store; 8 KiB geo copy + 16 KiB activation "
+                                 "fragments + 8 KiB float32 h_local rows written; 40 MFMAs per wavefront (arithmetic intensity ~ 25 FLOP/B: HBM-bound)"}}
+
+
 def strong_leg(model_c2f, precision, world, rank, frames=3):
     """BASELINE config 5: full 400x400 frames (160 000 rays each, 64 + 128 samples, render_kwargs_test) through
     render_path(shard_rows=True): the image rows are split over the ranks and all-gathered (strong scaling: fixed total work)."""
@@ -467,6 +532,8 @@ def main(argv=None):
         c2f_prec = "f16" if a.precision == "f16c" else a.precision      # the PDRF levels are not built in the compensated mode (NeRF-MLP only)
         if rank == 0 and not a.no_c2f and not lean:
             result["c2f"], c2f_model = c2f_leg(c2f_prec, max(5, a.steps // 2))
+        if rank == 0 and not a.no_awp and not lean:
+            result["awp"] = awp_leg(c2f_prec)
         if not a.no_strong:
             if c2f_model is None:
                 from evdeblurnerf_amd.renderer import NeRFAll

@@ -152,6 +152,8 @@ SIGNATURES = {
     "evd_c2f_render": (_I, [_vp, _vp, C.POINTER(RenderCfg), _vp, _L, _vp, _vp, _vp, _vp,
                             C.POINTER(RenderOut), _vp, _S, _vp]),
     "evd_voxel_tv_loss": (_I, [_vp, _vp, _vp]),
+    "evd_merge_features": (_I, [_vp, _vp, _vp, _L, _I, _I, _I, _vp, _I, _vp]),
+    "evd_merge_features_bwd": (_I, [_vp, _I, _vp, _L, _I, _I, _I, _vp, _vp, _vp]),
     "evd_weighted_sum": (_I, [_vp, _vp, _L, _I, _I, _vp, _vp]),
     "evd_crf_create": (_I, [C.POINTER(CrfDesc), C.POINTER(_vp)]),
     "evd_crf_destroy": (None, [_vp]),

@@ -421,6 +421,21 @@ int evd_c2f_render(const evd_voxel* coarse, const evd_voxel* fine, const evd_ren
     return evd_c2f_render_rays(coarse, fine, cfg, rb, R, t_rand, u, noise0, noise1, out, workspace, workspace_bytes, stream);
 }
 
+// ---- the coarse feature rows of the merged sample set (renderer.py:209-213), as an operation of its own for the training path
+int evd_merge_features(const float* old, const float* fresh, const int* order, long R, int S, int N, int F, float* out, int out_stride, void* stream) {
+    EVD_REQUIRE(old && fresh && order && out && R >= 0 && S >= 1 && N >= 1 && F >= 4 && F % 4 == 0 && out_stride >= F && out_stride % 4 == 0,
+                "evd_merge_features: bad arguments (F and out_stride multiples of 4)");
+    if (R == 0) return EVD_OK;
+    return launch_merge_features(old, fresh, order, R, S, N, F, out, out_stride, as_stream(stream));
+}
+
+int evd_merge_features_bwd(const float* d_out, int d_stride, const int* order, long R, int S, int N, int F, float* d_old, float* d_fresh, void* stream) {
+    EVD_REQUIRE(d_out && order && d_old && d_fresh && R >= 0 && S >= 1 && N >= 1 && F >= 4 && F % 4 == 0 && d_stride >= F && d_stride % 4 == 0,
+                "evd_merge_features_bwd: bad arguments (F and d_stride multiples of 4)");
+    if (R == 0) return EVD_OK;
+    return launch_merge_features_bwd(d_out, d_stride, order, R, S, N, F, d_old, d_fresh, as_stream(stream));
+}
+
 // ---- training: the level's sigma / colour networks -----------------------------------------------------
 static const int VOX_WGRAD_BLOCKS = 256;
 static long vox_tiles(long nsamp) { return cdiv(nsamp, 256L) * 8; }

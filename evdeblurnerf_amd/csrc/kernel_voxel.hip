@@ -37,6 +37,21 @@ __global__ void k_merge_features(const float* __restrict__ old, const float* __r
     *reinterpret_cast<f32x4*>(out + smp * (long)out_stride + 4 * q) = *reinterpret_cast<const f32x4*>(src + 4 * q);
 }
 
+// its backward: the gather is a permutation of the rows of cat([old, fresh]), so every gradient row has exactly one destination
+__global__ void k_merge_features_bwd(const float* __restrict__ d_out, int d_stride, const int* __restrict__ order, long R, int S, int N, int F,
+                                     float* __restrict__ d_old, float* __restrict__ d_fresh) {
+    const int per = F / 4;
+    const long t = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const long St = S + N;
+    if (t >= R * St * per) return;
+    const long smp = t / per;
+    const int q = t % per;
+    const long r = smp / St;
+    const int o = order[smp];
+    float* dst = o < S ? d_old + (r * S + o) * (long)F : d_fresh + (r * N + (o - S)) * (long)F;
+    *reinterpret_cast<f32x4*>(dst + 4 * q) = *reinterpret_cast<const f32x4*>(d_out + smp * (long)d_stride + 4 * q);
+}
+
 __device__ __forceinline__ float unnorm(float c, int size) { return __fmul_rn(__fadd_rn(c, 1.f) / 2.f, (float)(size - 1)); }
 
 constexpr int VS_SAMPLES = 32;      // samples per 256-thread block
@@ -990,6 +1005,13 @@ int launch_merge_features(const float* old, const float* fresh, const int* order
                           hipStream_t st) {
     const long n = R * (long)(S + N) * (F / 4);
     k_merge_features<<<cdiv(n, 256), 256, 0, st>>>(old, fresh, order, R, S, N, F, out, out_stride);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+int launch_merge_features_bwd(const float* d_out, int d_stride, const int* order, long R, int S, int N, int F, float* d_old, float* d_fresh, hipStream_t st) {
+    const long n = R * (long)(S + N) * (F / 4);
+    k_merge_features_bwd<<<cdiv(n, 256), 256, 0, st>>>(d_out, d_stride, order, R, S, N, F, d_old, d_fresh);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }

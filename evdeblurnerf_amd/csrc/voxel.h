@@ -56,6 +56,7 @@ struct TvShape { int C[6], H[6], W[6], blocks[6]; };
 int launch_points(const float* rb, int nc, const float* z, long n, int S, float* pts, hipStream_t st);
 int launch_merge_features(const float* old, const float* fresh, const int* order, long R, int S, int N, int F, float* out, int out_stride,
                           hipStream_t st);
+int launch_merge_features_bwd(const float* d_out, int d_stride, const int* order, long R, int S, int N, int F, float* d_old, float* d_fresh, hipStream_t st);
 int launch_voxel_sample(const GridParams& g, bool half_grids, const float* pts, long n, float* out, int out_stride, int out_col, hipStream_t st);
 int launch_voxel_sample_bwd(const GridParams& g, const float* pts, long n, const float* d_out, int d_stride, int d_col, const GridGrads& gg,
                             float* d_pts, hipStream_t st);

@@ -29,6 +29,33 @@ def _args_get(args, name, default):
     return getattr(args, name, default)
 
 
+class _MergeFeatures(torch.autograd.Function):
+    """renderer.py:209-213 + :195 for the training path: out[r, k] = cat([cat([ft0, ftn], 1)[r, order[r, k]], ft_fine[r, k]], -1)
+    (evd_merge_features / _bwd; the fine columns are a strided copy)"""
+
+    @staticmethod
+    def forward(ctx, ft0, ftn, order, ft_fine):
+        a, b, f = ft0.contiguous().float(), ftn.contiguous().float(), ft_fine.contiguous().float()
+        R, S, F = a.shape
+        N, Ff = b.shape[1], f.shape[-1]
+        out = torch.empty((R, S + N, F + Ff), dtype=torch.float32, device=a.device)
+        L.check(L.lib().evd_merge_features(L.ptr(a), L.ptr(b), L.ptr(order), R, S, N, F, L.ptr(out), F + Ff, L.stream_ptr()), "evd_merge_features")
+        out[..., F:] = f
+        ctx.save_for_backward(order)
+        ctx.dims = (R, S, N, F, Ff)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (order,) = ctx.saved_tensors
+        R, S, N, F, Ff = ctx.dims
+        g = g.contiguous().float()
+        d0 = torch.empty((R, S, F), dtype=torch.float32, device=g.device)
+        dn = torch.empty((R, N, F), dtype=torch.float32, device=g.device)
+        L.check(L.lib().evd_merge_features_bwd(L.ptr(g), F + Ff, L.ptr(order), R, S, N, F, L.ptr(d0), L.ptr(dn), L.stream_ptr()), "evd_merge_features_bwd")
+        return d0, dn, None, g[..., F:]
+
+
 class NeRFAll:
     """mode='nerf' (two NeRF MLPs, renderer.py:82-100) or mode='c2f' (PDRF coarse/fine levels, :46-81)."""
 
@@ -287,10 +314,10 @@ class NeRFAll:
             return {"rgb_map": rgb0, "depth_map": depth0, "acc_map": acc0, "weights": w0, "z_vals": z0}
         zs, zm, order, zstd = sample_pdf_merge(z0, w0.detach(), Ni, det=(perturb == 0.), u=u, want_order=True)
         ftn = coarse.sample_train(o + d * zs[..., None], pc["grids"])
-        fc = coarse.app_dim
-        ftc = torch.cat([ft0, ftn], 1).gather(1, order.long()[..., None].expand(-1, -1, fc))
         ptm = o + d * zm[..., None]
-        ft = torch.cat([ftc, fine.sample_train(ptm, pf["grids"])], -1)
+        # cat([coarse features re-ordered by the sort (:209-213), fine features at the merged points]) in one row buffer: the merge is a
+        # library kernel writing columns 0..fc-1 (a row permutation: its backward is one too), the fine features land behind them
+        ft = _MergeFeatures.apply(ft0, ftn, order, fine.sample_train(ptm, pf["grids"]))
         feat = None
         if want_feature == "fragments":                     # fused AWP consumer: the geo features stay in the level's store (awp.FusedAWP)
             from .voxnerf import GeoFragments

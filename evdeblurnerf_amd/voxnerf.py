@@ -18,14 +18,30 @@ def _np32(v):
     return np.ascontiguousarray(v, dtype=np.float32)
 
 
-def _grid_grads(net, like):
-    """zeroed gradient tensors for the 7 grid parameters + the ctypes struct pointing at them"""
-    grads = [torch.zeros_like(t) for t in like]
+# the grid gradients of the training path accumulate straight into the leaves' .grad (see _grid_grads); EVD_GRADS_IN_PLACE=0 restores
+# the plain autograd returns
+_GRADS_IN_PLACE = os.environ.get("EVD_GRADS_IN_PLACE", "1") != "0"
+
+
+def _grid_grads(net, like, in_place=False):
+    """gradient tensors for the 7 grid parameters + the ctypes struct pointing at them.  The scatter / TV backward kernels ADD into
+    what they are given.  in_place (every grid a leaf tensor, float32, contiguous): they add straight into the leaves' .grad -- a
+    whole blurfactory iteration runs 9 scatters and 2 TV backwards, each of which would otherwise zero 7 fresh tensors (165 MB for
+    the fine level) and have autograd add them to .grad again; the returned list is then all None (nothing left for autograd to do)."""
+    if in_place and all(t.is_leaf and t.requires_grad and t.dtype == torch.float32 and t.is_contiguous() for t in like):
+        for t in like:
+            if t.grad is None:
+                t.grad = torch.zeros_like(t)
+        tgt, ret = [t.grad for t in like], [None] * len(like)
+        if not all(g.is_contiguous() and g.dtype == torch.float32 for g in tgt):
+            return _grid_grads(net, like, False)
+    else:
+        tgt = ret = [torch.zeros_like(t) for t in like]
     gs = L.VoxelGridGrads()
     for i in range(3):
-        gs.plane[i], gs.line[i] = grads[i].data_ptr(), grads[3 + i].data_ptr()
-    gs.basis = grads[6].data_ptr()
-    return grads, gs
+        gs.plane[i], gs.line[i] = tgt[i].data_ptr(), tgt[3 + i].data_ptr()
+    gs.basis = tgt[6].data_ptr()
+    return ret, gs
 
 
 class _VoxelSample(torch.autograd.Function):
@@ -41,7 +57,7 @@ class _VoxelSample(torch.autograd.Function):
     def backward(ctx, d_out):
         net, pts = ctx.net, ctx.pts.reshape(-1, 3).contiguous().float()
         g = d_out.reshape(-1, net.app_dim).contiguous().float()
-        grads, gs = _grid_grads(net, ctx.saved_tensors)
+        grads, gs = _grid_grads(net, ctx.saved_tensors, in_place=_GRADS_IN_PLACE)
         d_pts = torch.empty_like(pts) if ctx.needs_input_grad[0] else None
         # EVD_SCATTER=1: the experimental binned form (taps sorted by plane tile, summed in LDS; csrc/kernel_voxel_scatter.hip) -- it gets
         # scratch; by default none is passed and the direct-atomics kernel runs
@@ -107,7 +123,7 @@ class _VoxelTV(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_loss):
         net = ctx.net
-        grads, gs = _grid_grads(net, ctx.saved_tensors)
+        grads, gs = _grid_grads(net, ctx.saved_tensors, in_place=_GRADS_IN_PLACE)
         gs.basis = None
         d = d_loss.reshape(1).contiguous().float()
         L.check(L.lib().evd_voxel_tv_loss_bwd(net._h, L.ptr(d), C.byref(gs), L.stream_ptr()), "evd_voxel_tv_loss_bwd")

@@ -247,6 +247,12 @@ int evd_c2f_render_rays(const evd_voxel* coarse, const evd_voxel* fine, const ev
 int evd_c2f_render(const evd_voxel* coarse, const evd_voxel* fine, const evd_render_cfg* cfg, const float* rays, long R,
                    const float* t_rand, const float* u, const float* noise0, const float* noise1,
                    evd_render_out* out, void* workspace, size_t workspace_bytes, void* stream);
+/* The coarse feature rows of the merged sample set, renderer.py:209-213: torch.cat([ft_comb0, ft_comb1], 1) gathered by the sort order
+ * (`order` of evd_sample_pdf_merge): old dev [R,S,F], fresh dev [R,N,F], order dev int32 [R,S+N] -> out dev rows of out_stride floats
+ * (columns 0..F-1 written).  evd_c2f_render_rays does this internally; the entry (and its backward: a permutation, d_out rows of
+ * d_stride floats -> d_old dev [R,S,F], d_fresh dev [R,N,F], every row written once) serves the training path under autograd. */
+int evd_merge_features(const float* old, const float* fresh, const int* order, long R, int S, int N, int F, float* out, int out_stride, void* stream);
+int evd_merge_features_bwd(const float* d_out, int d_stride, const int* order, long R, int S, int N, int F, float* d_old, float* d_fresh, void* stream);
 /* TV_loss_app, voxnerf.py:126-130 (TVLoss :306-324): sum over planes*1e-2 + lines*1e-3 -> out dev [1] (float) */
 int evd_voxel_tv_loss(const evd_voxel* v, float* out, void* stream);
 
