@@ -565,9 +565,12 @@ __global__ __launch_bounds__(64 * VW_WAVES) void k_voxel_sample_w(const GridPara
 //      d plane[tap, c] += w_tap d coef lv,  d line[tap, c] += w_tap d coef pv  as hardware float32 atomics (global_atomic_add_f32);
 //      like the reference's grid_sample backward (voxnerf.py:144) the summation order, hence the last bits, is not deterministic
 //   C  d basis[f, c] += sum_s d out[s, f] pv lv in registers across tiles, one atomic flush per block at the end
-// Measured (fine level, 2^19 samples, 302 M float atomics): 1.45 ms (1.80 ms with the two small GEMMs on the VALU, of which 0.52 ms
-// without the atomics); the atomic part runs
-// at ~250 G adds/s = one dword per clock per L2 channel (128 channels), the hardware rate -- plane-only and line-only variants
+// Measured (fine level, 2^19 samples, 302 M float atomics): **1.23 ms = 246 G adds/s**, the hardware rate of one dword per clock per L2
+// channel (128 channels).  Round 1: 1.45 ms (1.80 ms with the two small GEMMs on the VALU).  Round 2: the kernel compiled to 256 VGPRs
+// + 109 AGPRs under a loose launch bound, i.e. ONE block per CU, and its non-atomic work (0.98 ms: per-tile latency chain of point
+// load, tap table, GEMM, gathers) barely hid under the atomics; with the VALU fallback's accumulators templated out (MM) and
+// __launch_bounds__(256, 2) it takes 172 VGPRs, two blocks per CU share the latency, and the gather sweep is unrolled 4 x:
+// 1.43 -> 1.23 ms, whole blurfactory iteration 32.6 -> 28.9 ms.  Plane-only and line-only variants
 // cost the same per add, and 32 private copies of the (heavily shared) line gradients change nothing: it is the op count, not
 // contention.  Tried and dropped: a run-length sum over the tile's consecutive samples that hit the same cell before the atomic (one
 // thread per (tap, channel) walking the 32 samples): the sequential walk costs more than the adds it saves (3.1 ms) unless the rays
@@ -578,8 +581,8 @@ __global__ __launch_bounds__(64 * VW_WAVES) void k_voxel_sample_w(const GridPara
 // BINNED (kernel_voxel_scatter.hip): the atomics of phase B are replaced by one row of per-channel contributions per sample and the
 // tap records; a second pass adds them tile by tile in LDS.  d basis and d pts are computed here either way.
 constexpr int VSB_MAXF = 64, VSB_TAPS = 18;
-template <bool BINNED>
-__global__ __launch_bounds__(256) void k_voxel_sample_bwd(const GridParams g, const float* __restrict__ pts, long n,
+template <bool BINNED, bool MM>
+__global__ __launch_bounds__(256, MM ? 2 : 1) void k_voxel_sample_bwd(const GridParams g, const float* __restrict__ pts, long n,
                                                           const float* __restrict__ d_out, int d_stride, int d_col, GridGrads gg,
                                                           float* __restrict__ d_pts, const BinOut bo) {
     __shared__ float tfr[VS_SAMPLES * 3 * 6], dpt[VS_SAMPLES * 3];
@@ -619,7 +622,8 @@ __global__ __launch_bounds__(256) void k_voxel_sample_bwd(const GridParams g, co
     // MFMA when app_dim is 32 and the channels come in 32-wide tiles: wavefront t owns channel tile t for both (on the VALU the second
     // one costs three LDS reads per multiply-add: 19 GB of LDS traffic per 2^19 samples).
     const int wv = tid >> 6, ln = tid & 63, mn = ln & 31, kb = ln >> 5;
-    const bool mm = F == 32 && ctot % 32 == 0, mm_wave = mm && wv * 32 < ctot;
+    // MM (template: keeps the VALU fallback's 32 accumulators out of the common instantiation, which then fits two blocks per CU)
+    const bool mm = MM, mm_wave = mm && wv * 32 < ctot;
     float bas_reg[16];
     f32x16 macc;
 #pragma unroll
@@ -696,6 +700,7 @@ __global__ __launch_bounds__(256) void k_voxel_sample_bwd(const GridParams g, co
         }
         if (d_pts) __syncthreads();                 // the point gradient below reads d coef
         if (chan_on) {                              // pv, lv: lanes over channels, two samples per sweep
+#pragma unroll 4
             for (int sl = ss; sl < VS_SAMPLES; sl += 2) {
                 const int* ti = tix + sl * VSB_TAPS;
                 const float* w = tw + sl * VSB_TAPS;
@@ -1040,7 +1045,9 @@ int launch_voxel_sample_bwd(const GridParams& g, const float* pts, long n, const
                             float* d_pts, hipStream_t st) {
     if (g.app_dim > VSB_MAXF) return fail(EVD_E_INVALID, "evd_voxel_sample_bwd: app_dim %d > %d", g.app_dim, VSB_MAXF);
     const long tiles = cdiv(n, VS_SAMPLES);
-    k_voxel_sample_bwd<false><<<(unsigned)(tiles < 2048 ? tiles : 2048), 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, BinOut{});
+    const bool mm = g.app_dim == 32 && (g.n_comp[0] + g.n_comp[1] + g.n_comp[2]) % 32 == 0;
+    if (mm) k_voxel_sample_bwd<false, true><<<(unsigned)(tiles < 2048 ? tiles : 2048), 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, BinOut{});
+    else k_voxel_sample_bwd<false, false><<<(unsigned)(tiles < 2048 ? tiles : 2048), 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, BinOut{});
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }
@@ -1049,7 +1056,9 @@ int launch_voxel_sample_bwd_pass1(const GridParams& g, const float* pts, long n,
                                   float* d_pts, const BinOut& bo, hipStream_t st) {
     if (g.app_dim > VSB_MAXF) return fail(EVD_E_INVALID, "evd_voxel_sample_bwd: app_dim %d > %d", g.app_dim, VSB_MAXF);
     const long tiles = cdiv(n, VS_SAMPLES);
-    k_voxel_sample_bwd<true><<<(unsigned)(tiles < 2048 ? tiles : 2048), 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo);
+    const bool mm = g.app_dim == 32 && (g.n_comp[0] + g.n_comp[1] + g.n_comp[2]) % 32 == 0;
+    if (mm) k_voxel_sample_bwd<true, true><<<(unsigned)(tiles < 2048 ? tiles : 2048), 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo);
+    else k_voxel_sample_bwd<true, false><<<(unsigned)(tiles < 2048 ? tiles : 2048), 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }
