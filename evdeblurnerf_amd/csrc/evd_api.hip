@@ -245,6 +245,7 @@ void evd_nerf_destroy(evd_nerf* n) {
         for (int k = 0; k < EVD_BWD_NSTREAMS; ++k) n->bwd[i][k].release();
     }
     n->wmaps.release();
+    n->batch.release();
     n->bias.release();
     n->bias_src.release();
     n->pipe_c.release();
@@ -264,13 +265,14 @@ int evd_nerf_param_blocks(const evd_nerf* net, long* offsets, int capacity) {
 int evd_nerf_load_params(evd_nerf* net, const float* params, void* stream) {
     EVD_REQUIRE(net && params, "evd_nerf_load_params: null argument");
     hipStream_t st = as_stream(stream);
-    auto repack = [&](evd_nerf::Packed& s) { return repack_stream(s, params, st); };
     int rc;
+    std::vector<PackedStream*> all;
     for (int i = 0; i < EVD_NUM_PREC; ++i) {
-        if ((rc = repack(net->stream[i])) || (rc = repack(net->pipe[i]))) return rc;
-        for (int k = 0; k < EVD_BWD_NSTREAMS; ++k)
-            if ((rc = repack(net->bwd[i][k]))) return rc;
+        all.push_back(&net->stream[i]);
+        all.push_back(&net->pipe[i]);
+        for (int k = 0; k < EVD_BWD_NSTREAMS; ++k) all.push_back(&net->bwd[i][k]);
     }
+    if ((rc = repack_batch(net->batch, all, params, st))) return rc;
     if ((rc = repack_stream_c(net->pipe_c, params, st))) return rc;
     const long nb = (long)(net->bias.bytes / sizeof(float));
     hipLaunchKernelGGL(k_gather_f32, dim3((unsigned)cdiv(nb, 256L)), dim3(256), 0, st, params, (const int*)net->bias_src.p, nb, (float*)net->bias.p);

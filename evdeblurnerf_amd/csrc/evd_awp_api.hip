@@ -15,6 +15,7 @@ struct evd_awp_embed {
     long param_off[2 * AWP_D + 1];           // W0, b0, W1, b1, ... in the flat parameter arena; [8] = total
     PackedStream fwd[2], bwd[2][AWP_D];      // [0] bf16, [1] f16
     DevBuf bias, bias_src, maps;
+    RepackBatch batch;
 };
 
 static int prec_index(int precision) { return precision == EVD_PREC_BF16 ? 0 : (precision == EVD_PREC_F16 ? 1 : -1); }
@@ -28,6 +29,7 @@ void evd_awp_embed_destroy(evd_awp_embed* a) {
         for (int l = 0; l < AWP_D; ++l) a->bwd[i][l].release();
     }
     a->bias.release(); a->bias_src.release(); a->maps.release();
+    a->batch.release();
     delete a;
 }
 
@@ -102,11 +104,12 @@ int evd_awp_embed_load_params(evd_awp_embed* a, const float* params, void* strea
     EVD_REQUIRE(a && params, "evd_awp_embed_load_params: null argument");
     hipStream_t st = as_stream(stream);
     int rc;
+    std::vector<PackedStream*> all;
     for (int i = 0; i < 2; ++i) {
-        if ((rc = repack_stream(a->fwd[i], params, st))) return rc;
-        for (int l = 0; l < AWP_D; ++l)
-            if ((rc = repack_stream(a->bwd[i][l], params, st))) return rc;
+        all.push_back(&a->fwd[i]);
+        for (int l = 0; l < AWP_D; ++l) all.push_back(&a->bwd[i][l]);
     }
+    if ((rc = repack_batch(a->batch, all, params, st))) return rc;
     const long nb = (long)(a->bias.bytes / sizeof(float));
     hipLaunchKernelGGL(k_gather_f32, dim3((unsigned)cdiv(nb, 256L)), dim3(256), 0, st, params, (const int*)a->bias_src.p, nb, (float*)a->bias.p);
     EVD_LAUNCH_CHECK();

@@ -29,6 +29,7 @@ struct evd_voxel {
     int train_chunks[EVD_VOX_NUM_PREC];
     long param_off[9];            // sigma_net.0, sigma_net.1, color_net.{0,1,2}.{weight,bias} in the parameter arena, [8] = total
     GridParams gp;
+    RepackBatch batch;            // table of every fragment stream, for the one-launch re-pack of evd_voxel_load_params
     mutable SideStream side;      // backward entry: wgrad side stream of THIS handle (created on first use)
 };
 
@@ -45,6 +46,7 @@ void evd_voxel_destroy(evd_voxel* v) {
     }
     v->basis.release(); v->bias.release(); v->bias_src.release(); v->tv_acc.release(); v->wmaps.release();
     v->side.release();
+    v->batch.release();
     delete v;
 }
 
@@ -454,11 +456,14 @@ int evd_voxel_load_params(evd_voxel* v, const float* params, void* stream) {
     EVD_REQUIRE(v && params, "evd_voxel_load_params: null argument");
     hipStream_t st = as_stream(stream);
     int rc;
+    std::vector<PackedStream*> all;
     for (int i = 0; i < EVD_VOX_NUM_PREC; ++i) {
-        if ((rc = repack_stream(v->stream[i], params, st)) || (rc = repack_stream(v->pipe[i], params, st)) || (rc = repack_stream(v->train[i], params, st))) return rc;
-        for (int k = 0; k < VBWD_NSTREAMS; ++k)
-            if ((rc = repack_stream(v->bwd[i][k], params, st))) return rc;
+        all.push_back(&v->stream[i]);
+        all.push_back(&v->pipe[i]);
+        all.push_back(&v->train[i]);
+        for (int k = 0; k < VBWD_NSTREAMS; ++k) all.push_back(&v->bwd[i][k]);
     }
+    if ((rc = repack_batch(v->batch, all, params, st))) return rc;
     const long nb = (long)(v->bias.bytes / sizeof(float));
     hipLaunchKernelGGL(k_gather_f32, dim3((unsigned)cdiv(nb, 256L)), dim3(256), 0, st, params, (const int*)v->bias_src.p, nb, (float*)v->bias.p);
     EVD_LAUNCH_CHECK();

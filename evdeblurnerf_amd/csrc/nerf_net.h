@@ -21,5 +21,6 @@ struct evd_nerf {
     evd::DevBuf wmaps;                       // wgrad index maps (int32), nerf_train.h
     int nparam_blocks;                       // 2 D + 8 parameter tensors, canonical order (evd_api.hip: nerf_param_sizes)
     long param_off[2 * EVD_MAX_LAYERS + 9];  // arena offset of each, [nparam_blocks] = total
+    evd::RepackBatch batch;                  // table of every fragment stream, for the one-launch re-pack of evd_nerf_load_params
     mutable evd::SideStream side;            // backward entry: wgrad side stream of THIS handle (created on first use)
 };

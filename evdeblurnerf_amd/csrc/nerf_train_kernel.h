@@ -34,6 +34,7 @@ __device__ __forceinline__ float grad_scale(unsigned bits, bool inverse) {
 }
 
 static __global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
+    __shared__ float part[4];
     float m = 0.f;
     const long n4 = n >> 2, stride = (long)gridDim.x * 256;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {          // float4 body (the gradient rows are 16-byte aligned)
@@ -43,7 +44,14 @@ static __global__ __launch_bounds__(256) void k_absmax(const float* __restrict__
     for (long i = 4 * n4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) m = fmaxf(m, fabsf(x[i]));
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+    // one atomic per block: thousands of same-address atomicMax (one per wavefront, as first written) serialise at the L2 and cost
+    // more than the read of the whole array
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+        if (m > 0.f) atomicMax(out, __float_as_uint(m));
+    }
 }
 
 template <int PREC>
@@ -528,7 +536,7 @@ template <int PREC> static int run_nerf_backward(const BwdPlan& b, hipStream_t s
     constexpr int D = 8;
     int rc;
     EVD_HIP(hipMemsetAsync(b.maxbits, 0, sizeof(unsigned), st));
-    hipLaunchKernelGGL(k_absmax, dim3(2048), dim3(256), 0, st, b.d_raw, b.nsamp * 4, b.maxbits);
+    hipLaunchKernelGGL(k_absmax, dim3(512), dim3(256), 0, st, b.d_raw, b.nsamp * 4, b.maxbits);
     EVD_LAUNCH_CHECK();
     hipLaunchKernelGGL((k_grad_frags<PREC>), dim3((unsigned)cdiv(b.tiles * 64, 256L)), dim3(256), 0, st, b.d_raw, b.nsamp, b.maxbits, b.store, b.tiles);
     EVD_LAUNCH_CHECK();

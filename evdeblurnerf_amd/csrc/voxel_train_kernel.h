@@ -116,10 +116,10 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
     constexpr int T = HD / 32, KS = HD / 16, KF = FT / 16, GT = VS::GT, FTT = (FT + 31) / 32, IC = 3 * (1 + 2 * PE_L), ICV = 3 * (1 + 2 * PE_LV);
     int rc;
     EVD_HIP(hipMemsetAsync(b.maxbits, 0, sizeof(unsigned), st));
-    hipLaunchKernelGGL(k_absmax, dim3(2048), dim3(256), 0, st, b.d_raw, b.nsamp * 4, b.maxbits);
+    hipLaunchKernelGGL(k_absmax, dim3(512), dim3(256), 0, st, b.d_raw, b.nsamp * 4, b.maxbits);
     EVD_LAUNCH_CHECK();
     if (b.d_feature) {          // the loss scale covers both incoming gradients
-        hipLaunchKernelGGL(k_absmax, dim3(2048), dim3(256), 0, st, b.d_feature, b.nsamp * G, b.maxbits);
+        hipLaunchKernelGGL(k_absmax, dim3(512), dim3(256), 0, st, b.d_feature, b.nsamp * G, b.maxbits);
         EVD_LAUNCH_CHECK();
     }
     if (b.awp_store) {          // ... and the d geo fragments of the AWP embedding's backward (true-unit maximum in its trailer)
