@@ -332,6 +332,47 @@ def awp_leg(precision):
                                  "fragments + 8 KiB float32 h_local rows written; 40 MFMAs per wavefront (arithmetic intensity ~ 25 FLOP/B: HBM-bound)"}}
 
 
+def train_iteration_leg(precision):
+    """One WHOLE blurfactory training iteration (tools/bench_train_step.py: blur batch of 1024 pixels x 10 sub-exposure rays + 2 x 4096
+    event rays, 64 + 64 samples, fused losses, TV, backward on the hand-written kernels, Adam, parameter re-pack) and the roofline of its
+    dominant kernel, the tri-plane scatter: bound by the rate of float atomics at the L2 (one dword per clock and channel)."""
+    import ctypes as C
+    import types
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import bench_train_step as BT
+    from evdeblurnerf_amd import _lib as L, weights as W
+    from evdeblurnerf_amd.voxnerf import VoxelNeRFSampleFeatures, _grid_grads
+    ms, nrays, _ = BT.run(types.SimpleNamespace(precision=precision, iters=10, pixels=1024, events=4096, P=10))
+    torch.cuda.empty_cache()
+    aabb = ([-1.5, -1.5, -1.0], [1.5, 1.5, 1.0])
+    fv = 134217984
+    g = W.pdrf_grid_size(aabb[0], aabb[1], fv)
+    net = VoxelNeRFSampleFeatures(W.make_pdrf_state_dict(32, g, input_ch=127, hidden_dim=256, geo_feat_dim=128), "", aabb, num_layers=2, hidden_dim=256,
+                                  geo_feat_dim=128, num_layers_color=3, input_ch=127, app_dim=32, app_n_comp=(64, 16, 16), n_voxels=fv)
+    rs = np.random.RandomState(0)
+    R, S = 4096, 128
+    o = rs.uniform(-0.3, 0.3, (R, 1, 3)) + np.array([0, 0, 0.9])
+    d = rs.normal(size=(R, 1, 3)) * 0.35 + np.array([0, 0, -1.0])
+    z = np.sort(rs.uniform(0.1, 1.7, (R, S, 1)), 1)
+    pts = torch.as_tensor((o + d * z).astype(np.float32), device="cuda").reshape(-1, 3).contiguous()
+    n = pts.shape[0]
+    d_out = torch.randn((n, 32), device="cuda")
+    grads, gs = _grid_grads(net, net.grid_params())
+    k_ms = kernel_ms(lambda: L.check(L.lib().evd_voxel_sample_bwd(net._h, L.ptr(pts), n, L.ptr(d_out), 32, 0, C.byref(gs), None, L.stream_ptr()), "bwd"), 10)
+    atomics = n * 6 * 96                                        # (4 plane + 2 line taps) x 96 channels float adds per sample
+    peak = 128 * 2.1                                            # G adds/s: 128 L2 channels x one dword per clock at ~2.1 GHz
+    return {"workload": "blurfactory training iteration: 1024 pixels x 10 sub-exposure rays + 2 x 4096 event rays, 64 + 64 samples, losses, TV, "
+                        "backward, Adam, parameter re-pack", "precision": precision, "ms_per_iteration": ms, "rays_per_iteration": nrays,
+            "rays_per_s": nrays / (ms * 1e-3),
+            "roofline": {"kernel": "k_voxel_sample_bwd (fine level 586 x 586 x 390, 4096 x 128 samples): ~47 % of the iteration's kernel time over its 9 launches",
+                         "bound": "l2-atomics", "kernel_ms": k_ms, "float_atomics": atomics, "achieved": atomics / (k_ms * 1e-3) / 1e9, "peak": peak,
+                         "unit": "G float atomic adds/s", "frac": atomics / (k_ms * 1e-3) / 1e9 / peak,
+                         "note": "the scatter-add of the tri-plane gather's backward issues 576 global float atomics per sample; they execute at the L2, "
+                                 "one dword per clock and channel -- the kernel runs at that rate (DESIGN.md 7, profiles/r02_scatter_binned.txt)"}}
+
+
 def strong_leg(model_c2f, precision, world, rank, frames=3):
     """BASELINE config 5: full 400x400 frames (160 000 rays each, 64 + 128 samples, render_kwargs_test) through
     render_path(shard_rows=True): the image rows are split over the ranks and all-gathered (strong scaling: fixed total work)."""
@@ -534,6 +575,8 @@ def main(argv=None):
             result["c2f"], c2f_model = c2f_leg(c2f_prec, max(5, a.steps // 2))
         if rank == 0 and not a.no_awp and not lean:
             result["awp"] = awp_leg(c2f_prec)
+        if rank == 0 and not a.no_train and not lean:
+            result["train_iteration"] = train_iteration_leg(c2f_prec)
         if not a.no_strong:
             if c2f_model is None:
                 from evdeblurnerf_amd.renderer import NeRFAll

@@ -48,6 +48,13 @@ def main():
     ap.add_argument("--events", type=int, default=4096)
     ap.add_argument("--P", type=int, default=10)
     a = ap.parse_args()
+    ms, nr, loss = run(a)
+    print(f"blurfactory TRAINING iteration [{a.precision}]: {nr} rays x (64 + 64) samples, losses, TV, backward, Adam, re-pack: {ms:.2f} ms "
+          f"({nr / ms / 1e3:.2f} M rays/s); loss = {loss:.5f}")
+
+
+def run(a):
+    """a: namespace with precision, iters, pixels, events, P -> (ms per iteration, rays per iteration, last loss)"""
     cv, fv = 16777248, 134217984
     gc, gf = W.pdrf_grid_size(AABB[0], AABB[1], cv), W.pdrf_grid_size(AABB[0], AABB[1], fv)
     sd = dict(W.prefixed(W.make_pdrf_state_dict(31, gc, input_ch=95, hidden_dim=64, geo_feat_dim=15), "mlp_coarse"))
@@ -100,9 +107,7 @@ def main():
     e1.record()
     e1.synchronize()
     ms = e0.elapsed_time(e1) / a.iters
-    nr = R * a.P + 2 * E
-    print(f"blurfactory TRAINING iteration [{a.precision}]: {nr} rays x (64 + 64) samples, losses, TV, backward, Adam, re-pack: {ms:.2f} ms "
-          f"({nr / ms / 1e3:.2f} M rays/s); loss = {float(l.detach()):.5f}")
+    return ms, R * a.P + 2 * E, float(l.detach())
 
 
 if __name__ == "__main__":
