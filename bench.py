@@ -362,15 +362,16 @@ def train_iteration_leg(precision):
     grads, gs = _grid_grads(net, net.grid_params())
     k_ms = kernel_ms(lambda: L.check(L.lib().evd_voxel_sample_bwd(net._h, L.ptr(pts), n, L.ptr(d_out), 32, 0, C.byref(gs), None, L.stream_ptr()), "bwd"), 10)
     atomics = n * 6 * 96                                        # (4 plane + 2 line taps) x 96 channels float adds per sample
-    peak = 128 * 2.1                                            # G adds/s: 128 L2 channels x one dword per clock at ~2.1 GHz
+    peak = 320.0                                                # G adds/s: what a bare kernel of coalesced float atomics sustains (tools/probes/atomic_probe.hip: 318-328)
     return {"workload": "blurfactory training iteration: 1024 pixels x 10 sub-exposure rays + 2 x 4096 event rays, 64 + 64 samples, losses, TV, "
                         "backward, Adam, parameter re-pack", "precision": precision, "ms_per_iteration": ms, "rays_per_iteration": nrays,
             "rays_per_s": nrays / (ms * 1e-3),
             "roofline": {"kernel": "k_voxel_sample_bwd (fine level 586 x 586 x 390, 4096 x 128 samples): ~47 % of the iteration's kernel time over its 9 launches",
-                         "bound": "l2-atomics", "kernel_ms": k_ms, "float_atomics": atomics, "achieved": atomics / (k_ms * 1e-3) / 1e9, "peak": peak,
+                         "bound": "memory-side atomics", "kernel_ms": k_ms, "float_atomics": atomics, "achieved": atomics / (k_ms * 1e-3) / 1e9, "peak": peak,
                          "unit": "G float atomic adds/s", "frac": atomics / (k_ms * 1e-3) / 1e9 / peak,
-                         "note": "the scatter-add of the tri-plane gather's backward issues 576 global float atomics per sample; they execute at the L2, "
-                                 "one dword per clock and channel -- the kernel runs at that rate (DESIGN.md 7, profiles/r02_scatter_binned.txt)"}}
+                         "note": "the scatter-add of the tri-plane gather's backward issues 576 global float atomics per sample = 18.6 M 64-byte requests "
+                                 "per 2^19 samples, every one forwarded to the memory side (PMC: TCC_EA0_ATOMIC == TCC_ATOMIC, profiles/r02_pmc_scatter.txt); "
+                                 "peak = the rate of a bare atomic kernel on this chip (tools/probes/atomic_probe.hip, 20 G requests/s whatever the table size)"}}
 
 
 def strong_leg(model_c2f, precision, world, rank, frames=3):

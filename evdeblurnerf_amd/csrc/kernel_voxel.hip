@@ -581,14 +581,21 @@ __global__ __launch_bounds__(64 * VW_WAVES) void k_voxel_sample_w(const GridPara
 // BINNED (kernel_voxel_scatter.hip): the atomics of phase B are replaced by one row of per-channel contributions per sample and the
 // tap records; a second pass adds them tile by tile in LDS.  d basis and d pts are computed here either way.
 constexpr int VSB_MAXF = 64, VSB_TAPS = 18;
-template <bool BINNED, bool MM>
-__global__ __launch_bounds__(256, MM ? 2 : 1) void k_voxel_sample_bwd(const GridParams g, const float* __restrict__ pts, long n,
+// CT: the channel capacity the LDS rows are laid out for (MM: ctot <= CT, a multiple of 32).  With the shipped 96 channels and
+// app_dim 32 the block needs 50 KB of LDS and 168 VGPRs = three blocks per CU.  (Measured: three blocks run at the speed of two,
+// 1.21 ms = 249 G adds/s; a bare kernel of coalesced float atomics on random 64-byte runs sustains 318 - 328 G adds/s = 20 G requests/s
+// regardless of the table size, tools/probes/atomic_probe.hip, and the counters show EVERY atomic request of this kernel travelling to
+// the memory side, TCC_EA0_ATOMIC == TCC_ATOMIC = 18.6 M 64-byte requests per 2^19 samples: device-scope float atomics are not
+// executed in the XCD's L2.  The kernel is at 78 % of that ceiling; the gap is the repeated hits on the same few line cells.)
+template <bool BINNED, bool MM, int CT>
+__global__ __launch_bounds__(256, MM ? (CT <= 96 ? 3 : 2) : 1) void k_voxel_sample_bwd(const GridParams g, const float* __restrict__ pts, long n,
                                                           const float* __restrict__ d_out, int d_stride, int d_col, GridGrads gg,
                                                           float* __restrict__ d_pts, const BinOut bo) {
+    constexpr int STRD = CT + 1, FSTR = MM ? 33 : VSB_MAXF + 1;      // odd row strides (conflict-free column access)
     __shared__ float tfr[VS_SAMPLES * 3 * 6], dpt[VS_SAMPLES * 3];
     __shared__ int tax[VS_SAMPLES * 3 * 3];
-    __shared__ __attribute__((aligned(16))) float pvs[VS_SAMPLES * VS_STRIDE], lvs[VS_SAMPLES * VS_STRIDE], dco[VS_SAMPLES * VS_STRIDE],
-        dout[VS_SAMPLES * (VSB_MAXF + 1)], tw[VS_SAMPLES * VSB_TAPS];
+    __shared__ __attribute__((aligned(16))) float pvs[VS_SAMPLES * STRD], lvs[VS_SAMPLES * STRD], dco[VS_SAMPLES * STRD],
+        dout[VS_SAMPLES * FSTR], tw[VS_SAMPLES * VSB_TAPS];
     __shared__ int tix[VS_SAMPLES * VSB_TAPS];
     const int c0n = g.n_comp[0], c1n = g.n_comp[1], ctot = c0n + c1n + g.n_comp[2], F = g.app_dim, nbas = F * ctot;
     const int tid = threadIdx.x, ss = tid >> 7, ql = tid & 127;
@@ -635,7 +642,7 @@ __global__ __launch_bounds__(256, MM ? 2 : 1) void k_voxel_sample_bwd(const Grid
         const long s0 = tile * VS_SAMPLES;
         for (int o = tid; o < VS_SAMPLES * F; o += 256) {
             const int sl = o / F, f = o % F;
-            dout[sl * (VSB_MAXF + 1) + f] = s0 + sl < n ? d_out[(s0 + sl) * (long)d_stride + d_col + f] : 0.f;
+            dout[sl * FSTR + f] = s0 + sl < n ? d_out[(s0 + sl) * (long)d_stride + d_col + f] : 0.f;
         }
         if (tid < VS_SAMPLES * 3) {                // tap table: thread = (sample, component group)
             const int sl = tid / 3, i = tid % 3;
@@ -686,16 +693,16 @@ __global__ __launch_bounds__(256, MM ? 2 : 1) void k_voxel_sample_bwd(const Grid
 #pragma unroll
                 for (int r = 0; r < 16; ++r) a16[r] = 0.f;
 #pragma unroll
-                for (int j = 0; j < 16; ++j) a16 = __builtin_amdgcn_mfma_f32_32x32x2f32(dout[mn * (VSB_MAXF + 1) + 2 * j + kb], bas_reg[j], a16, 0, 0, 0);
+                for (int j = 0; j < 16; ++j) a16 = __builtin_amdgcn_mfma_f32_32x32x2f32(dout[mn * FSTR + 2 * j + kb], bas_reg[j], a16, 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dco[((r & 3) + 8 * (r >> 2) + 4 * kb) * VS_STRIDE + 32 * wv + mn] = a16[r];
+                for (int r = 0; r < 16; ++r) dco[((r & 3) + 8 * (r >> 2) + 4 * kb) * STRD + 32 * wv + mn] = a16[r];
             }
         } else {
             for (int o = tid; o < VS_SAMPLES * ctot; o += 256) {
                 const int sl = o / ctot, c = o % ctot;
                 float a = 0.f;
-                for (int f = 0; f < F; ++f) a = fmaf(dout[sl * (VSB_MAXF + 1) + f], g.basis[(long)f * ctot + c], a);
-                dco[sl * VS_STRIDE + c] = a;
+                for (int f = 0; f < F; ++f) a = fmaf(dout[sl * FSTR + f], g.basis[(long)f * ctot + c], a);
+                dco[sl * STRD + c] = a;
             }
         }
         if (d_pts) __syncthreads();                 // the point gradient below reads d coef
@@ -709,8 +716,8 @@ __global__ __launch_bounds__(256, MM ? 2 : 1) void k_voxel_sample_bwd(const Grid
                 for (int t = 0; t < 4; ++t) { P[t] = gplane[ti[4 * cg + t] + cin]; pv = fmaf(w[4 * cg + t], P[t], pv); }
 #pragma unroll
                 for (int t = 0; t < 2; ++t) { Lt[t] = gline[ti[12 + 2 * cg + t] + cin]; lv = fmaf(w[12 + 2 * cg + t], Lt[t], lv); }
-                pvs[sl * VS_STRIDE + ql] = pv;
-                lvs[sl * VS_STRIDE + ql] = lv;
+                pvs[sl * STRD + ql] = pv;
+                lvs[sl * STRD + ql] = lv;
                 if (d_pts) {
                     // d feature / d point through the interpolation weights (the ATen grid_sample backward: taps outside the grid
                     // contribute nothing), chained with d coef; summed over the channels of the wavefront, then over wavefronts in LDS
@@ -720,7 +727,7 @@ __global__ __launch_bounds__(256, MM ? 2 : 1) void k_voxel_sample_bwd(const Grid
                     for (int t = 0; t < 4; ++t) P[t] = w[4 * cg + t] != 0.f ? P[t] : 0.f;
                     const float dpx = (P[1] - P[0]) * sn + (P[3] - P[2]) * nn, dpy = (P[2] - P[0]) * ee + (P[3] - P[1]) * ww;
                     const float dl = (w[12 + 2 * cg + 1] != 0.f ? Lt[1] : 0.f) - (w[12 + 2 * cg] != 0.f ? Lt[0] : 0.f);
-                    const float dc = dco[sl * VS_STRIDE + ql];
+                    const float dc = dco[sl * STRD + ql];
                     float gx = dc * lv * dpx * fr[3], gy = dc * lv * dpy * fr[4], gl = dc * pv * dl * fr[5];
                     // lanes of one wavefront half belong to the same (sample, component) only for the 64-channel component; reduce
                     // with LDS float atomics (3 per lane) -- 96 lanes x 32 samples per tile
@@ -738,9 +745,9 @@ __global__ __launch_bounds__(256, MM ? 2 : 1) void k_voxel_sample_bwd(const Grid
         if constexpr (BINNED) {
             if (chan_on) {
                 for (int sl = ss; sl < VS_SAMPLES && s0 + sl < n; sl += 2) {
-                    const float dc = dco[sl * VS_STRIDE + ql];
-                    bo.rows_p[(s0 + sl) * ctot + ql] = dc * lvs[sl * VS_STRIDE + ql];
-                    bo.rows_l[(s0 + sl) * ctot + ql] = dc * pvs[sl * VS_STRIDE + ql];
+                    const float dc = dco[sl * STRD + ql];
+                    bo.rows_p[(s0 + sl) * ctot + ql] = dc * lvs[sl * STRD + ql];
+                    bo.rows_l[(s0 + sl) * ctot + ql] = dc * pvs[sl * STRD + ql];
                 }
             }
         } else {
@@ -751,8 +758,8 @@ __global__ __launch_bounds__(256, MM ? 2 : 1) void k_voxel_sample_bwd(const Grid
                     const float w = tw[sl * VSB_TAPS + q_slot[m]];
                     if (w == 0.f) continue;
                     const int c = q_c[m];
-                    const float other = q_plane[m] ? lvs[sl * VS_STRIDE + c] : pvs[sl * VS_STRIDE + c];
-                    unsafeAtomicAdd(q_ptr[m] + tix[sl * VSB_TAPS + q_slot[m]], dco[sl * VS_STRIDE + c] * other * w);
+                    const float other = q_plane[m] ? lvs[sl * STRD + c] : pvs[sl * STRD + c];
+                    unsafeAtomicAdd(q_ptr[m] + tix[sl * VSB_TAPS + q_slot[m]], dco[sl * STRD + c] * other * w);
                 }
             }
         }
@@ -762,8 +769,8 @@ __global__ __launch_bounds__(256, MM ? 2 : 1) void k_voxel_sample_bwd(const Grid
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     const int sl = 2 * j + kb;
-                    macc = __builtin_amdgcn_mfma_f32_32x32x2f32(dout[sl * (VSB_MAXF + 1) + mn],
-                                                                pvs[sl * VS_STRIDE + 32 * wv + mn] * lvs[sl * VS_STRIDE + 32 * wv + mn], macc, 0, 0, 0);
+                    macc = __builtin_amdgcn_mfma_f32_32x32x2f32(dout[sl * FSTR + mn],
+                                                                pvs[sl * STRD + 32 * wv + mn] * lvs[sl * STRD + 32 * wv + mn], macc, 0, 0, 0);
                 }
             }
         } else if (gg.basis) {
@@ -773,7 +780,7 @@ __global__ __launch_bounds__(256, MM ? 2 : 1) void k_voxel_sample_bwd(const Grid
                 if (o < nbas) {
                     const int f = o / ctot, c = o % ctot;
                     float a = bacc[q];
-                    for (int sl = 0; sl < VS_SAMPLES; ++sl) a = fmaf(dout[sl * (VSB_MAXF + 1) + f], pvs[sl * VS_STRIDE + c] * lvs[sl * VS_STRIDE + c], a);
+                    for (int sl = 0; sl < VS_SAMPLES; ++sl) a = fmaf(dout[sl * FSTR + f], pvs[sl * STRD + c] * lvs[sl * STRD + c], a);
                     bacc[q] = a;
                 }
             }
@@ -1046,8 +1053,11 @@ int launch_voxel_sample_bwd(const GridParams& g, const float* pts, long n, const
     if (g.app_dim > VSB_MAXF) return fail(EVD_E_INVALID, "evd_voxel_sample_bwd: app_dim %d > %d", g.app_dim, VSB_MAXF);
     const long tiles = cdiv(n, VS_SAMPLES);
     const bool mm = g.app_dim == 32 && (g.n_comp[0] + g.n_comp[1] + g.n_comp[2]) % 32 == 0;
-    if (mm) k_voxel_sample_bwd<false, true><<<(unsigned)(tiles < 2048 ? tiles : 2048), 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, BinOut{});
-    else k_voxel_sample_bwd<false, false><<<(unsigned)(tiles < 2048 ? tiles : 2048), 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, BinOut{});
+    const int ct = g.n_comp[0] + g.n_comp[1] + g.n_comp[2];
+    const unsigned blocks = (unsigned)(tiles < 3072 ? tiles : 3072);
+    if (mm && ct <= 96) k_voxel_sample_bwd<false, true, 96><<<blocks, 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, BinOut{});
+    else if (mm) k_voxel_sample_bwd<false, true, VS_MAXC><<<blocks, 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, BinOut{});
+    else k_voxel_sample_bwd<false, false, VS_MAXC><<<blocks, 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, BinOut{});
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }
@@ -1057,8 +1067,11 @@ int launch_voxel_sample_bwd_pass1(const GridParams& g, const float* pts, long n,
     if (g.app_dim > VSB_MAXF) return fail(EVD_E_INVALID, "evd_voxel_sample_bwd: app_dim %d > %d", g.app_dim, VSB_MAXF);
     const long tiles = cdiv(n, VS_SAMPLES);
     const bool mm = g.app_dim == 32 && (g.n_comp[0] + g.n_comp[1] + g.n_comp[2]) % 32 == 0;
-    if (mm) k_voxel_sample_bwd<true, true><<<(unsigned)(tiles < 2048 ? tiles : 2048), 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo);
-    else k_voxel_sample_bwd<true, false><<<(unsigned)(tiles < 2048 ? tiles : 2048), 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo);
+    const int ct = g.n_comp[0] + g.n_comp[1] + g.n_comp[2];
+    const unsigned blocks = (unsigned)(tiles < 3072 ? tiles : 3072);
+    if (mm && ct <= 96) k_voxel_sample_bwd<true, true, 96><<<blocks, 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo);
+    else if (mm) k_voxel_sample_bwd<true, true, VS_MAXC><<<blocks, 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo);
+    else k_voxel_sample_bwd<true, false, VS_MAXC><<<blocks, 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }
