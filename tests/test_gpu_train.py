@@ -345,18 +345,18 @@ def test_pdrf_level_networks_backward_match_torch_autograd(level, prec, tol):
     assert max(errs.values()) < tol, {k: f"{v:.1e}" for k, v in errs.items()}
 
 
-def _c2f_model(prec, N_importance=32):
+def _c2f_model(prec, N_importance=32, coarse_voxels=24 ** 3, fine_voxels=48 ** 3):
     from types import SimpleNamespace
     from evdeblurnerf_amd.renderer import NeRFAll
-    gc, gf = W.pdrf_grid_size(AABB[0], AABB[1], 24 ** 3), W.pdrf_grid_size(AABB[0], AABB[1], 48 ** 3)
+    gc, gf = W.pdrf_grid_size(AABB[0], AABB[1], coarse_voxels), W.pdrf_grid_size(AABB[0], AABB[1], fine_voxels)
     sd = dict(W.prefixed(W.make_pdrf_state_dict(81, gc, input_ch=95, hidden_dim=64, geo_feat_dim=15, add_bias_color=True), "mlp_coarse"))
     sd.update(W.prefixed(W.make_pdrf_state_dict(82, gf, input_ch=127, hidden_dim=256, geo_feat_dim=128, add_bias_color=True), "mlp_fine"))
     args = SimpleNamespace(mode="c2f", multires=10, multires_views=4, use_viewdirs=True, N_importance=N_importance, kernel_type="RBK",
                            kernel_use_awp=False, rgb_activate="sigmoid", sigma_activate="relu", bounding_box=AABB, coarse_num_layers=2,
                            coarse_num_layers_color=3, coarse_hidden_dim=64, coarse_hidden_dim_color=64, coarse_app_dim=32,
-                           coarse_app_n_comp=[64, 16, 16], coarse_n_voxels=24 ** 3, kernel_feat_cnl=15, fine_num_layers=2, fine_num_layers_color=3,
+                           coarse_app_n_comp=[64, 16, 16], coarse_n_voxels=coarse_voxels, kernel_feat_cnl=15, fine_num_layers=2, fine_num_layers_color=3,
                            fine_hidden_dim=256, fine_hidden_dim_color=256, fine_geo_feat_dim=128, fine_app_dim=32, fine_app_n_comp=[64, 16, 16],
-                           fine_n_voxels=48 ** 3)
+                           fine_n_voxels=fine_voxels)
     return NeRFAll(args, sd, precision=prec), sd
 
 
@@ -374,7 +374,11 @@ def _c2f_rays(R, seed):
 def test_c2f_render_rays_train_end_to_end_gradients():
     """The whole mode='c2f' training forward (both levels, merged samples) differentiated by the hand-written kernels vs the
     float64 torch pipeline on the same sample positions; bounded by the half-precision ReLU flips (see the MLP tests)."""
-    model, sd = _c2f_model("f16")
+    _c2f_end_to_end("f16", 24 ** 3, 48 ** 3, 5e-3, 0.15)
+
+
+def _c2f_end_to_end(prec, coarse_voxels, fine_voxels, rgb_tol, tol):
+    model, sd = _c2f_model(prec, 32, coarse_voxels, fine_voxels)
     model.train()
     pc, pf = model.trainable_parameters(sd)
     R, S, Ni = 96, 24, 16
@@ -411,8 +415,8 @@ def test_c2f_render_rays_train_end_to_end_gradients():
     ftm = torch.cat([feat("coarse", ptm), feat("fine", ptm)], -1)
     raw1 = levels["fine"](ptm.reshape(-1, 3), vd[:, None].expand(-1, St, -1).reshape(-1, 3), ftm).reshape(R, St, 4)
     rgb1, _ = _torch_vox_composite(raw1, zm, d[:, 0])
-    assert (out["rgb0"].detach().cpu().double() - rgb0).abs().max().item() < 5e-3
-    assert (out["rgb_map"].detach().cpu().double() - rgb1).abs().max().item() < 5e-3
+    assert (out["rgb0"].detach().cpu().double() - rgb0).abs().max().item() < rgb_tol
+    assert (out["rgb_map"].detach().cpu().double() - rgb1).abs().max().item() < rgb_tol
     t64 = torch.tensor(tgt, dtype=torch.float64)
     (((rgb1 - t64) ** 2).mean() + ((rgb0 - t64) ** 2).mean()).backward()
     errs = {}
@@ -428,8 +432,9 @@ def test_c2f_render_rays_train_end_to_end_gradients():
     got_rb = rb.grad.cpu().double()
     errs["rays_o"], errs["rays_d"], errs["viewdirs"] = (rel_l2(got_rb[:, 0:3], rb64.grad[:, 0:3]), rel_l2(got_rb[:, 3:6], rb64.grad[:, 3:6]),
                                                         rel_l2(got_rb[:, 8:11], rb64.grad[:, 8:11]))
-    print("c2f end-to-end relative L2 errors:", {k: f"{v:.1e}" for k, v in errs.items()})
-    assert max(errs.values()) < 0.15, errs
+    print(f"c2f end-to-end relative L2 errors ({prec}, grids {model.mlp_coarse.gridSize} / {model.mlp_fine.gridSize}):",
+          {k: f"{v:.1e}" for k, v in sorted(errs.items(), key=lambda kv: -kv[1])[:8]})
+    assert max(errs.values()) < tol, errs
 
 
 def test_c2f_training_iteration_reduces_the_image_loss():

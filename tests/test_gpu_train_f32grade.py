@@ -213,3 +213,12 @@ def test_f16x3_c2f_training_gradients_against_the_reference_golden():
     and the rays within 1e-3 of the gradient norm (the half-precision run of the same check: 15 %), rendered colours within 2e-5."""
     from test_gpu_train import _g19_check
     _g19_check("f16x3", 1e-3, 1e-3, 2e-5)
+
+
+def test_f16x3_c2f_end_to_end_gradients_at_the_blurfactory_grid_sizes():
+    """The whole c2f training forward + backward at the SHIPPED grid sizes (coarse_n_voxels 16 777 248 -> 293 x 293 x 195, fine_n_voxels
+    134 217 984 -> 586 x 586 x 390: 165 MB of grids, the tri-plane scatter's index arithmetic at full range) in the float32-grade mode,
+    against the float64 torch pipeline (F.grid_sample + the restated levels + compositing) on the same sample positions: every one of
+    the 30 parameter gradients and the ray gradient; the half-precision run of the same comparison (small grids) is bounded at 15 %."""
+    from test_gpu_train import _c2f_end_to_end
+    _c2f_end_to_end("f16x3", 16777248, 134217984, 2e-5, 2e-3)
