@@ -401,7 +401,9 @@ __global__ __launch_bounds__(256, EVD_VS_WAVES) void k_voxel_sample(const GridPa
 // component) pairs on 48 lanes -> its own LDS slice -> 3 items per lane (16 samples x 12 groups of 8 channels, 18 16-byte loads in
 // flight) -> coefficients in LDS -> out^T = basis . coef^T on v_mfma_f32_16x16x4_f32 (2 feature tiles x ctot / 4 steps) -> transposed
 // through LDS -> 128-byte runs per sample row.  The 4 wavefronts of a SIMD run their chains independently, so one wavefront's
-// matrix work and stores overlap the others' gathers.
+// matrix work and stores overlap the others' gathers.  (Measured and dropped: persistent wavefronts walking 8 sample groups each so
+// that the block's basis_mat load is paid once -- 0.539 / 0.516 / 0.530 ms per c2f render with 1024 / 2048 / 512 blocks against
+// 0.521 ms for one group per wavefront: the other wavefronts already hide that prologue.)
 constexpr int VW_SAMPLES = 16;                  // samples per wavefront
 constexpr int VW_WAVES = 4;                     // wavefronts per block
 // LDS slice of one wavefront: tap table, then the coefficient rows [16][ctot + 1] (later the output tile [16][33])
