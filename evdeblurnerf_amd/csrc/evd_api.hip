@@ -39,7 +39,7 @@ using namespace evd;
 extern "C" {
 
 const char* evd_last_error(void) { return evd::err_buf(); }
-int evd_version(void) { return 110; }      // 110: training entries (evd_*_train, evd_*_backward, evd_*_load_params, ...)
+int evd_version(void) { return 120; }      // 110: training entries (evd_*_train, evd_*_backward, evd_*_load_params, ...); 120: evd_awp_embed_*, the f16x3 training mode (evd_*_train_store_bytes_prec), evd_voxel_mlp_backward(awp_store), evd_voxel_sample_bwd_ws, evd_merge_features
 
 int evd_device_count(void) {
     int n = 0;
