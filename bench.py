@@ -590,6 +590,11 @@ def main(argv=None):
     if rank == 0:
         if not a.no_cpu_baseline and not lean:
             from oracle import oracle as O
+            fast = True
+            try:
+                O.use_fast_build()                   # the same C file built for throughput on THIS host (-O3 -march=native, FMA allowed)
+            except Exception:                         # no compiler on the box: the checker build that travelled with the repo
+                fast = False
             onet = O.Nerf(sd, "mlp_coarse.")
             ocfg = O.make_cfg(N_samples=S)
             sample = W.synthetic_rays(100, R)
@@ -602,7 +607,9 @@ def main(argv=None):
                 n_cpu += 512
                 t_cpu = time.perf_counter() - t0
             result["cpu_baseline"] = {"value": n_cpu / t_cpu, "unit": "rays/s", "cores": O.num_threads(), "kind": "port",
-                                      "sample": f"{n_cpu} rays (the workload's {R} rays x {S} samples, cycled for {t_cpu:.1f} s) through the C oracle, OpenMP over rays on all host cores"}
+                                      "sample": f"{n_cpu} rays (the workload's {R} rays x {S} samples, cycled for {t_cpu:.1f} s) through the C oracle, OpenMP over rays on all host cores",
+                                      "build": "-O3 -march=native -ffp-contract=fast (throughput build of oracle/evd_oracle.c, compiled on this host)" if fast
+                                               else "-O2 -march=x86-64-v3 -ffp-contract=off (the parity-checker build)"}
         print(json.dumps(result), flush=True)
     if dist:
         dist.barrier()

@@ -29,6 +29,17 @@ def build(force: bool = False) -> str:
     return _SO
 
 
+def use_fast_build() -> str:
+    """Switch this module to the THROUGHPUT build of the same C file (make fast: -O3 -march=native, fused multiply-adds allowed),
+    compiled for the host it runs on.  For bench.py's cpu_baseline leg only: the checker build above keeps mul / add unfused
+    (-ffp-contract=off) so that the restatement rounds like torch's float32 ops; a baseline should not be handicapped by that."""
+    global _lib
+    subprocess.run(["make", "-C", _HERE, "-B", "fast"], check=True, capture_output=True)      # always rebuilt: -march=native of THIS host
+    _lib = None
+    globals()["_SO_ACTIVE"] = os.path.join(_HERE, "build", "libevd_oracle_fast.so")
+    return globals()["_SO_ACTIVE"]
+
+
 class NerfStruct(C.Structure):
     _fields_ = [("D", C.c_int), ("W", C.c_int), ("input_ch", C.c_int), ("input_ch_views", C.c_int),
                 ("skip", C.c_int), ("use_viewdirs", C.c_int), ("output_ch", C.c_int),
@@ -73,7 +84,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        _lib = C.CDLL(build())
+        _lib = C.CDLL(globals().get("_SO_ACTIVE") or build())
         _lib.evo_mse.restype = C.c_double
         _lib.evo_egm_loss.restype = C.c_double
         _lib.evo_tv_loss.restype = C.c_double
