@@ -143,6 +143,7 @@ SIGNATURES = {
     "evd_voxel_create": (_I, [C.POINTER(VoxelDesc), C.POINTER(_vp)]),
     "evd_voxel_destroy": (None, [_vp]),
     "evd_voxel_sample": (_I, [_vp, _vp, _L, _vp, _I, _I, _vp]),
+    "evd_voxel_sample_prec": (_I, [_vp, _I, _vp, _L, _vp, _I, _I, _vp]),
     "evd_voxel_forward": (_I, [_vp, _I, _vp, _vp, _I, _vp, _I, _vp, _vp, _I, _L, _I, _I,
                                _vp, _vp, _vp, _vp, _vp, _vp, _S, _vp]),
     "evd_voxel_forward_workspace_bytes": (_S, [_vp, _L, _I]),

@@ -280,6 +280,13 @@ static int sample_for(const evd_voxel* v, int precision, const float* pts, long 
     return launch_voxel_sample(v->gp, half, pts, n, out, out_stride, out_col, as_stream(stream));
 }
 
+int evd_voxel_sample_prec(const evd_voxel* v, int precision, const float* pts, long n, float* out, int out_stride, int out_col, void* stream) {
+    EVD_REQUIRE(v && out && n >= 0 && out_stride >= out_col + v->app_dim, "evd_voxel_sample_prec: bad arguments");
+    EVD_REQUIRE(precision >= 0 && precision < EVD_VOX_NUM_PREC, "evd_voxel_sample_prec: unknown precision %d", precision);
+    if (n == 0) return EVD_OK;
+    return sample_for(v, precision, pts, n, out, out_stride, out_col, stream);
+}
+
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 size_t evd_voxel_forward_workspace_bytes(const evd_voxel* v, long R, int S) {

@@ -307,17 +307,17 @@ class NeRFAll:
         o, d, vd = rb[:, None, 0:3], rb[:, None, 3:6], rb[:, 8:11].contiguous()
         rays_d = rb[:, 3:6].contiguous()
         pts0 = o + d * z0[..., None]
-        ft0 = coarse.sample_train(pts0, pc["grids"])
+        ft0 = coarse.sample_train(pts0, pc["grids"], self.precision)
         raw0 = coarse.mlp_train(pc["net"], pts0, vd, ft0, self.precision)
         rgb0, _, acc0, w0, depth0 = coarse.raw2outputs(raw0, z0, rays_d, is_train=True, noise=noise0)
         if Ni <= 0:
             return {"rgb_map": rgb0, "depth_map": depth0, "acc_map": acc0, "weights": w0, "z_vals": z0}
         zs, zm, order, zstd = sample_pdf_merge(z0, w0.detach(), Ni, det=(perturb == 0.), u=u, want_order=True)
-        ftn = coarse.sample_train(o + d * zs[..., None], pc["grids"])
+        ftn = coarse.sample_train(o + d * zs[..., None], pc["grids"], self.precision)
         ptm = o + d * zm[..., None]
         # cat([coarse features re-ordered by the sort (:209-213), fine features at the merged points]) in one row buffer: the merge is a
         # library kernel writing columns 0..fc-1 (a row permutation: its backward is one too), the fine features land behind them
-        ft = _MergeFeatures.apply(ft0, ftn, order, fine.sample_train(ptm, pf["grids"]))
+        ft = _MergeFeatures.apply(ft0, ftn, order, fine.sample_train(ptm, pf["grids"], self.precision))
         feat = None
         if want_feature == "fragments":                     # fused AWP consumer: the geo features stay in the level's store (awp.FusedAWP)
             from .voxnerf import GeoFragments

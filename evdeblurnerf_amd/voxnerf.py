@@ -48,10 +48,10 @@ class _VoxelSample(torch.autograd.Function):
     """VoxelNeRFBase.sample with gradients to the (channel-last) planes, lines and basis_mat: evd_voxel_sample / _bwd"""
 
     @staticmethod
-    def forward(ctx, pts, net, *grids):
+    def forward(ctx, pts, net, precision, *grids):
         ctx.net, ctx.pts = net, pts
         ctx.save_for_backward(*grids)
-        return net.sample(pts)
+        return net.sample(pts, precision)
 
     @staticmethod
     def backward(ctx, d_out):
@@ -65,7 +65,7 @@ class _VoxelSample(torch.autograd.Function):
         ws = torch.empty((nb,), dtype=torch.uint8, device=pts.device) if nb else None
         L.check(L.lib().evd_voxel_sample_bwd_ws(net._h, L.ptr(pts), pts.shape[0], L.ptr(g), net.app_dim, 0, C.byref(gs), L.ptr(d_pts), L.ptr(ws), nb,
                                                 L.stream_ptr()), "evd_voxel_sample_bwd_ws")
-        return (d_pts.reshape(ctx.pts.shape) if d_pts is not None else None, None, *grads)
+        return (d_pts.reshape(ctx.pts.shape) if d_pts is not None else None, None, None, *grads)
 
 
 class GeoFragments:
@@ -208,11 +208,17 @@ class VoxelNeRFBase:
         return rgb, dens, acc, wts, depth
 
     # voxnerf.py:203-208
-    def sample(self, pts):
+    def sample(self, pts, precision=None):
+        """voxnerf.py:203-208.  precision None: the float32 grids (the reference's arithmetic); a mode name: as the c2f renderer samples
+        in that mode (f16 / bf16 read the float16 copies of the grids)"""
         sh = pts.shape
         p = pts.reshape(-1, 3).contiguous().float()
         out = torch.empty((p.shape[0], self.app_dim), dtype=torch.float32, device=p.device)
-        L.check(L.lib().evd_voxel_sample(self._h, L.ptr(p), p.shape[0], L.ptr(out), self.app_dim, 0, L.stream_ptr()), "evd_voxel_sample")
+        if precision is None:
+            L.check(L.lib().evd_voxel_sample(self._h, L.ptr(p), p.shape[0], L.ptr(out), self.app_dim, 0, L.stream_ptr()), "evd_voxel_sample")
+        else:
+            L.check(L.lib().evd_voxel_sample_prec(self._h, L.PREC[precision], L.ptr(p), p.shape[0], L.ptr(out), self.app_dim, 0, L.stream_ptr()),
+                    "evd_voxel_sample_prec")
         return out.reshape(sh[0], sh[1], self.app_dim) if len(sh) == 3 else out
 
     # ---- training the sigma / colour networks (f16 / bf16): one flat float32 parameter tensor, library order ----------------
@@ -323,10 +329,13 @@ class VoxelNeRFBase:
         if getattr(self, "_synced", None) != tuple((t.data_ptr(), t._version) for t in grids):
             self.load_grids(grids)
 
-    def sample_train(self, pts, grids):
-        """sample(pts) with autograd to the grid parameters (re-loads them into the library after an optimizer step)"""
+    def sample_train(self, pts, grids, precision=None):
+        """sample(pts) with autograd to the grid parameters (re-loads them into the library after an optimizer step).  precision: the
+        arithmetic mode of the training forward -- f16 / bf16 gather the float16 grid copies exactly as the inference render of that mode
+        does (the copies are refreshed by the re-load); None / the float32-grade modes read the float32 grids.  The backward (scatter-add,
+        the interpolation-weight derivative) always works on the float32 grids."""
         self._sync(grids)
-        return _VoxelSample.apply(pts, self, *grids)
+        return _VoxelSample.apply(pts, self, precision, *grids)
 
     def tv_loss_train(self, grids):
         self._sync(grids)

@@ -230,6 +230,10 @@ void evd_voxel_destroy(evd_voxel* v);
 /* VoxelNeRFBase.sample / compute_appfeature, voxnerf.py:203-208,132-151.  pts dev [n,3] -> out dev [n,out_stride]
  * written at column out_col (so coarse and fine features can share one [n,64] buffer, renderer.py:195) */
 int evd_voxel_sample(const evd_voxel* v, const float* pts, long n, float* out, int out_stride, int out_col, void* stream);
+/* The same as the c2f renderer runs it in arithmetic mode `precision`: EVD_PREC_F16 / EVD_PREC_BF16 gather the float16 copies of the
+ * grids (half the bytes; the level networks round their inputs to 2^-11 / 2^-8 anyway), the float32-grade modes the float32 grids.
+ * What the training forward calls, so that it is the inference render's arithmetic. */
+int evd_voxel_sample_prec(const evd_voxel* v, int precision, const float* pts, long n, float* out, int out_stride, int out_col, void* stream);
 /* VoxelNeRFBase.forward, voxnerf.py:210-259.  pts dev [R,S,3], viewdirs dev rows of vd_stride floats,
  * fts dev [R,S,F] -> color [R,3], depth [R], acc [R], weights [R,S], feature [R,S,geo] */
 int evd_voxel_forward(const evd_voxel* v, int precision, const float* pts, const float* viewdirs, int vd_stride, const float* fts, int F,

@@ -880,3 +880,21 @@ def test_binned_scatter_equals_the_direct_scatter():
     errs = [rel_l2(a.double(), b.double()) for a, b in zip(grads, ref)]
     assert max(errs) < 1e-5, errs
     assert rel_l2(dp_b.double(), dp_a.double()) < 1e-5          # (the point gradient is summed over channels with LDS atomics: order-dependent rounding)
+
+
+@pytest.mark.parametrize("prec,tol", [("f16", 5e-5), ("f16x3", 5e-6)])
+def test_c2f_render_rays_train_equals_inference_render_rays(prec, tol):
+    """mode='c2f': the training forward (gathers in the mode's grid precision -- the float16 grid copies in f16, like the inference
+    render --, level networks keeping their activations, scans under autograd) renders what the inference entry renders.  Not bit for
+    bit as in mode='nerf': the coarse level's inference runs on the generic kernel, its training forward on the software pipeline
+    (another summation order); measured 5e-6 in f16."""
+    model, sd = _c2f_model(prec, 16)
+    pc, pf = model.trainable_parameters(sd)
+    rb = torch.tensor(_c2f_rays(200, 3), device="cuda")
+    model.train()
+    out = model.render_rays_train(rb, pc, pf, 24, 16)
+    ref = model.render_rays(rb, 24, N_importance=16, retraw=True)
+    for k in ("rgb_map", "acc_map", "rgb0", "depth_map"):
+        err = (out[k].detach() - ref[k]).abs().max().item()
+        # (the depth follows the importance samples, an ill-conditioned function of the coarse weights: conftest.z_mismatch)
+        assert err < (40 * tol if k == "depth_map" else tol) * max(1.0, ref[k].abs().max().item()), (k, err)
