@@ -361,12 +361,20 @@ def train_iteration_leg(precision):
     d_out = torch.randn((n, 32), device="cuda")
     grads, gs = _grid_grads(net, net.grid_params())
     k_ms = kernel_ms(lambda: L.check(L.lib().evd_voxel_sample_bwd(net._h, L.ptr(pts), n, L.ptr(d_out), 32, 0, C.byref(gs), None, L.stream_ptr()), "bwd"), 10)
+    nb = int(L.lib().evd_voxel_sample_bwd_workspace_bytes(net._h, n))
+    ws = torch.empty((nb,), dtype=torch.uint8, device="cuda")
+    h_ms = kernel_ms(lambda: L.check(L.lib().evd_voxel_sample_bwd_ws(net._h, L.ptr(pts), n, L.ptr(d_out), 32, 0, C.byref(gs), None, L.ptr(ws), nb,
+                                                                      L.stream_ptr()), "bwd_ws"), 10)
     atomics = n * 6 * 96                                        # (4 plane + 2 line taps) x 96 channels float adds per sample
     peak = 320.0                                                # G adds/s: what a bare kernel of coalesced float atomics sustains (tools/probes/atomic_probe.hip: 318-328)
     return {"workload": "blurfactory training iteration: 1024 pixels x 10 sub-exposure rays + 2 x 4096 event rays, 64 + 64 samples, losses, TV, "
                         "backward, Adam, parameter re-pack", "precision": precision, "ms_per_iteration": ms, "rays_per_iteration": nrays,
             "rays_per_s": nrays / (ms * 1e-3),
-            "roofline": {"kernel": "k_voxel_sample_bwd (fine level 586 x 586 x 390, 4096 x 128 samples): ~47 % of the iteration's kernel time over its 9 launches",
+            "scatter_hybrid_ms": h_ms,
+            "scatter_note": "what the iteration runs: plane taps by direct float atomics (384 per sample), line taps through 64-bit fixed-point LDS "
+                            "slices of the line gradients (k_scatter_lines; ds_add_f32 is ~6 x slower than integer LDS atomics on this chip) -- "
+                            "a third fewer atomic requests than the all-atomics form whose roofline follows",
+            "roofline": {"kernel": "k_voxel_sample_bwd, all taps by atomics (fine level 586 x 586 x 390, 4096 x 128 samples)",
                          "bound": "memory-side atomics", "kernel_ms": k_ms, "float_atomics": atomics, "achieved": atomics / (k_ms * 1e-3) / 1e9, "peak": peak,
                          "unit": "G float atomic adds/s", "frac": atomics / (k_ms * 1e-3) / 1e9 / peak,
                          "note": "the scatter-add of the tri-plane gather's backward issues 576 global float atomics per sample = 18.6 M 64-byte requests "

@@ -599,7 +599,12 @@ int evd_voxel_sample_bwd(const evd_voxel* v, const float* pts, long n, const flo
     return launch_voxel_sample_bwd(v->gp, pts, n, d_out, d_stride, d_col, gg, d_pts, as_stream(stream));
 }
 
-size_t evd_voxel_sample_bwd_workspace_bytes(const evd_voxel* v, long n) { return (!v || n <= 0) ? 0 : voxel_scatter_workspace_bytes(v->gp, n); }
+// developer switch: EVD_SCATTER=binned selects the sort + LDS-tile form behind evd_voxel_sample_bwd_ws (default: the hybrid form)
+static bool scatter_binned() { static const bool b = [] { const char* e = getenv("EVD_SCATTER"); return e && !strcmp(e, "binned"); }(); return b; }
+size_t evd_voxel_sample_bwd_workspace_bytes(const evd_voxel* v, long n) {
+    if (!v || n <= 0) return 0;
+    return scatter_binned() ? voxel_scatter_workspace_bytes(v->gp, n) : voxel_scatter_hybrid_workspace_bytes(v->gp, n);
+}
 
 int evd_voxel_sample_bwd_ws(const evd_voxel* v, const float* pts, long n, const float* d_out, int d_stride, int d_col,
                             const evd_voxel_grid_grads* g, float* d_pts, void* workspace, size_t workspace_bytes, void* stream) {
@@ -609,8 +614,10 @@ int evd_voxel_sample_bwd_ws(const evd_voxel* v, const float* pts, long n, const 
     GridGrads gg;
     for (int i = 0; i < 3; ++i) { gg.plane[i] = g->plane[i]; gg.line[i] = g->line[i]; }
     gg.basis = g->basis;
-    if (workspace && workspace_bytes > 0 && voxel_scatter_binned_ok(v->gp, gg, n))
-        return launch_voxel_sample_bwd_binned(v->gp, pts, n, d_out, d_stride, d_col, gg, d_pts, workspace, workspace_bytes, as_stream(stream));
+    if (workspace && workspace_bytes > 0 && voxel_scatter_binned_ok(v->gp, gg, n)) {
+        if (scatter_binned()) return launch_voxel_sample_bwd_binned(v->gp, pts, n, d_out, d_stride, d_col, gg, d_pts, workspace, workspace_bytes, as_stream(stream));
+        return launch_voxel_sample_bwd_hybrid(v->gp, pts, n, d_out, d_stride, d_col, gg, d_pts, workspace, workspace_bytes, as_stream(stream));
+    }
     return launch_voxel_sample_bwd(v->gp, pts, n, d_out, d_stride, d_col, gg, d_pts, as_stream(stream));
 }
 

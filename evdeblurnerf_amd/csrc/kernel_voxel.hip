@@ -589,11 +589,15 @@ constexpr int VSB_MAXF = 64, VSB_TAPS = 18;
 // regardless of the table size, tools/probes/atomic_probe.hip, and the counters show EVERY atomic request of this kernel travelling to
 // the memory side, TCC_EA0_ATOMIC == TCC_ATOMIC = 18.6 M 64-byte requests per 2^19 samples: device-scope float atomics are not
 // executed in the XCD's L2.  The kernel is at 78 % of that ceiling; the gap is the repeated hits on the same few line cells.)
-template <bool BINNED, bool MM, int CT>
+// MODE: 0 = every tap by a direct atomic; 1 = pass 1 of the binned form (rows + tap records + keys, no atomics); 2 = HYBRID: the plane
+// taps by direct atomics, the line taps deferred -- their rows and tap records are written and k_scatter_lines adds them through
+// privatised LDS slices of the (small) line gradients: a third of the kernel's atomic requests go away.
+template <int MODE, bool MM, int CT>
 __global__ __launch_bounds__(256, MM ? (CT <= 96 ? 3 : 2) : 1) void k_voxel_sample_bwd(const GridParams g, const float* __restrict__ pts, long n,
                                                           const float* __restrict__ d_out, int d_stride, int d_col, GridGrads gg,
                                                           float* __restrict__ d_pts, const BinOut bo) {
     constexpr int STRD = CT + 1, FSTR = MM ? 33 : VSB_MAXF + 1;      // odd row strides (conflict-free column access)
+    constexpr bool BINNED = MODE == 1, HYBRID = MODE == 2;
     __shared__ float tfr[VS_SAMPLES * 3 * 6], dpt[VS_SAMPLES * 3];
     __shared__ int tax[VS_SAMPLES * 3 * 3];
     __shared__ __attribute__((aligned(16))) float pvs[VS_SAMPLES * STRD], lvs[VS_SAMPLES * STRD], dco[VS_SAMPLES * STRD],
@@ -668,6 +672,14 @@ __global__ __launch_bounds__(256, MM ? (CT <= 96 ? 3 : 2) : 1) void k_voxel_samp
             fr[0] = it.fw; fr[1] = it.fn; fr[2] = it.fl; fr[3] = it.kx; fr[4] = it.ky; fr[5] = it.kl;
             int* ta = tax + (sl * 3 + i) * 3;
             ta[0] = it.ax; ta[1] = it.ay; ta[2] = it.al;
+            if constexpr (HYBRID) {
+                if (live) {                         // the line taps of this (sample, component), for k_scatter_lines
+                    const int C = sel3(i, g.n_comp[0], g.n_comp[1], g.n_comp[2]);
+                    LTap lt_;
+                    lt_.c0 = (int)it.il[0] / C; lt_.c1 = (int)it.il[1] / C; lt_.w0 = it.wl[0]; lt_.w1 = it.wl[1];
+                    bo.ltap[s * 3 + i] = lt_;
+                }
+            }
             if constexpr (BINNED) {
                 if (live) {                         // tap records + the plane's tile key of this (sample, component)
                     const int C = sel3(i, g.n_comp[0], g.n_comp[1], g.n_comp[2]), Wp = sel3(i, g.grid[0], g.grid[0], g.grid[1]);
@@ -753,10 +765,15 @@ __global__ __launch_bounds__(256, MM ? (CT <= 96 ? 3 : 2) : 1) void k_voxel_samp
                 }
             }
         } else {
+            if constexpr (HYBRID) {
+                if (chan_on) {
+                    for (int sl = ss; sl < VS_SAMPLES && s0 + sl < n; sl += 2) bo.rows_l[(s0 + sl) * ctot + ql] = dco[sl * STRD + ql] * pvs[sl * STRD + ql];
+                }
+            }
             for (int sl = ss; sl < VS_SAMPLES; sl += 2) {
 #pragma unroll
                 for (int m = 0; m < MQ; ++m) {
-                    if (!q_ptr[m]) continue;
+                    if (!q_ptr[m] || (HYBRID && !q_plane[m])) continue;
                     const float w = tw[sl * VSB_TAPS + q_slot[m]];
                     if (w == 0.f) continue;
                     const int c = q_c[m];
@@ -1057,9 +1074,9 @@ int launch_voxel_sample_bwd(const GridParams& g, const float* pts, long n, const
     const bool mm = g.app_dim == 32 && (g.n_comp[0] + g.n_comp[1] + g.n_comp[2]) % 32 == 0;
     const int ct = g.n_comp[0] + g.n_comp[1] + g.n_comp[2];
     const unsigned blocks = (unsigned)(tiles < 3072 ? tiles : 3072);
-    if (mm && ct <= 96) k_voxel_sample_bwd<false, true, 96><<<blocks, 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, BinOut{});
-    else if (mm) k_voxel_sample_bwd<false, true, VS_MAXC><<<blocks, 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, BinOut{});
-    else k_voxel_sample_bwd<false, false, VS_MAXC><<<blocks, 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, BinOut{});
+    if (mm && ct <= 96) k_voxel_sample_bwd<0, true, 96><<<blocks, 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, BinOut{});
+    else if (mm) k_voxel_sample_bwd<0, true, VS_MAXC><<<blocks, 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, BinOut{});
+    else k_voxel_sample_bwd<0, false, VS_MAXC><<<blocks, 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, BinOut{});
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }
@@ -1071,9 +1088,24 @@ int launch_voxel_sample_bwd_pass1(const GridParams& g, const float* pts, long n,
     const bool mm = g.app_dim == 32 && (g.n_comp[0] + g.n_comp[1] + g.n_comp[2]) % 32 == 0;
     const int ct = g.n_comp[0] + g.n_comp[1] + g.n_comp[2];
     const unsigned blocks = (unsigned)(tiles < 3072 ? tiles : 3072);
-    if (mm && ct <= 96) k_voxel_sample_bwd<true, true, 96><<<blocks, 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo);
-    else if (mm) k_voxel_sample_bwd<true, true, VS_MAXC><<<blocks, 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo);
-    else k_voxel_sample_bwd<true, false, VS_MAXC><<<blocks, 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo);
+    if (mm && ct <= 96) k_voxel_sample_bwd<1, true, 96><<<blocks, 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo);
+    else if (mm) k_voxel_sample_bwd<1, true, VS_MAXC><<<blocks, 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo);
+    else k_voxel_sample_bwd<1, false, VS_MAXC><<<blocks, 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+// hybrid: plane taps by direct atomics here, line taps left as rows + tap records (bo.rows_l, bo.ltap) for k_scatter_lines
+int launch_voxel_sample_bwd_planes(const GridParams& g, const float* pts, long n, const float* d_out, int d_stride, int d_col, const GridGrads& gg,
+                                   float* d_pts, const BinOut& bo, hipStream_t st) {
+    if (g.app_dim > VSB_MAXF) return fail(EVD_E_INVALID, "evd_voxel_sample_bwd: app_dim %d > %d", g.app_dim, VSB_MAXF);
+    const long tiles = cdiv(n, VS_SAMPLES);
+    const bool mm = g.app_dim == 32 && (g.n_comp[0] + g.n_comp[1] + g.n_comp[2]) % 32 == 0;
+    const int ct = g.n_comp[0] + g.n_comp[1] + g.n_comp[2];
+    const unsigned blocks = (unsigned)(tiles < 3072 ? tiles : 3072);
+    if (mm && ct <= 96) k_voxel_sample_bwd<2, true, 96><<<blocks, 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo);
+    else if (mm) k_voxel_sample_bwd<2, true, VS_MAXC><<<blocks, 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo);
+    else k_voxel_sample_bwd<2, false, VS_MAXC><<<blocks, 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }

@@ -15,13 +15,19 @@
 // All loads of the second pass are streaming or row gathers issued several samples ahead (the first cut of this idea walked a
 // dependent chain per sample and was latency-bound by two orders of magnitude).
 //
-// MEASURED (MI355X, fine level 586 x 586 x 390, 2^19 samples, profiles/r02_scatter_binned.txt): results equal the direct kernel's to
+// WHAT RUNS BY DEFAULT is the HYBRID at the end of this file (evd_voxel_sample_bwd_ws with scratch): the plane taps stay direct float
+// atomics, only the line taps -- a third of the requests, onto <= 586 cells -- go through LDS (k_scatter_lines, 64-bit fixed-point
+// accumulators): 1.19 -> 0.90 ms at 2^19 fine-level samples, 1.50 -> 1.10 ms at 655 k coarse-level samples, same sums to 1.2e-6.
+// The full binned form below is kept behind EVD_SCATTER=binned.
+//
+// MEASURED, full binned form (MI355X, fine level 586 x 586 x 390, 2^19 samples, profiles/r02_scatter_binned.txt): results equal the direct kernel's to
 // 1.2e-6, global atomics drop as designed -- and the whole thing takes 2.99 ms against 1.43 ms: pass 1 alone is 0.98 ms (the direct
 // kernel's block-cooperative structure at one wavefront per SIMD: its gathers and two small GEMMs were HIDDEN under the atomics
 // there, they are exposed here), planes 1.14 ms (two 74 KB workgroups per CU, a barrier-separated zero / search / accumulate / flush
 // sequence per tile run), lines 0.50 ms, 27 merge-sort launches 0.34 ms.  So the direct form stays the default; this one is what
-// evd_voxel_sample_bwd_ws runs when the caller passes scratch (the Python mirror does under EVD_SCATTER=1), kept because it is
-// verified and because what it needs next is known: pass 1 rebuilt wavefront-autonomous like the forward gather (k_voxel_sample_w:
+// selected by EVD_SCATTER=binned, kept because it is verified and because what it needs next is known: its LDS tiles used
+// ds_add_f32, which turned out to run at ~0.4 lane-operations per clock and CU (k_scatter_lines below: 497 us with float, 81 us with
+// integer LDS atomics) -- fixed-point tiles are the next thing to try --, then pass 1 rebuilt wavefront-autonomous like the forward gather (k_voxel_sample_w:
 // 0.12 ms for the same taps), 32-channel plane slices (4 workgroups per CU), a counting sort on the 11-bit tile keys.
 #include <hipcub/hipcub.hpp>
 
@@ -30,6 +36,7 @@
 
 namespace evd {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int SC_TW = SC_TS + 1, SC_CH = 512, SC_NT = 512, SC_LCH = 2048, SC_LDS_MAX = 150 * 1024;
 
 struct PlaneJob {
@@ -108,46 +115,104 @@ struct LineJob {
     float* grad;
     int C, Lp, coff, comp, c_lo, cg;        // channels [c_lo, c_lo + cg) of component comp
 };
-struct LineJobs { LineJob j[8]; };
+struct LineJobs { LineJob j[12]; };
 
+// The line taps.  A workgroup keeps a cg-channel slice of a WHOLE line gradient (<= 586 cells) in LDS for SC_LCH samples and adds
+// it to the gradient once.  The LDS accumulators are 64-bit FIXED POINT, not float: ds_add_f32 executes at ~0.4 lane-operations per
+// clock and CU on this chip (100 M of them took 445 us here -- no faster than the global float atomics they were to replace), integer
+// LDS atomics run 6 x faster.  The scale is a power of two chosen per workgroup from the largest contribution of its chunk
+// (max |row| 2^k < 2^49, at most 2^13 terms per accumulator: no overflow), so a float32 contribution converts EXACTLY unless it is
+// below 2^-49 of the chunk's maximum: the sums are more accurate than float32 atomics, and deterministic inside the workgroup.
 __global__ __launch_bounds__(SC_NT) void k_scatter_lines(const LineJobs jobs, const float* __restrict__ rows_l, const LTap* __restrict__ ltap, long n, int ctot) {
     const LineJob jb = jobs.j[blockIdx.y];
     if (!jb.grad) return;
-    extern __shared__ __attribute__((aligned(16))) float line[];       // [Lp][cg]
+    extern __shared__ __attribute__((aligned(16))) unsigned long long lacc[];       // [Lp][cg]
+    __shared__ float wmax[SC_NT / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cg = jb.cg, total = jb.Lp * cg;
-    for (int o = tid; o < total; o += SC_NT) line[o] = 0.f;
-    __syncthreads();
+    for (int o = tid; o < total; o += SC_NT) lacc[o] = 0ull;
     const long base = (long)blockIdx.x * SC_LCH, end = base + SC_LCH < n ? base + SC_LCH : n;
-    const int spw = 64 / cg, c = lane % cg, sub = lane / cg, step = (SC_NT / 64) * spw;
+    // a lane owns 4 consecutive channels of a sample (one 16-byte load): cg / 4 lanes per sample
+    const int lps = cg >> 2, spw = 64 / lps, c4 = (lane % lps) * 4, sub = lane / lps, step = (SC_NT / 64) * spw;
+    const float* col = rows_l + jb.coff + jb.c_lo + c4;
+    float m = 0.f;
+    for (long s = base + wave * spw + sub; s < end; s += step) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(col + s * ctot);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) wmax[wave] = m;
+    __syncthreads();
+    m = 0.f;
+#pragma unroll
+    for (int w = 0; w < SC_NT / 64; ++w) m = fmaxf(m, wmax[w]);
+    if (!(m > 0.f) || !(m < 3.0e38f)) return;          // nothing to add (or non-finite input: leave the gradient untouched)
+    int e;
+    (void)frexpf(m, &e);                                // m = f 2^e, f in [0.5, 1)
+    const float up = ldexpf(1.f, 49 - e);               // |w v| up <= 2^49
     constexpr int UN = 4;
     for (long s0 = base + wave * spw + sub; s0 < end; s0 += UN * step) {
         LTap t[UN];
-        float v[UN];
+        f32x4 v[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const long s = s0 + u * step;
             if (s < end) {
                 t[u] = ltap[s * 3 + jb.comp];
-                v[u] = rows_l[s * ctot + jb.coff + jb.c_lo + c];
+                v[u] = *reinterpret_cast<const f32x4*>(col + s * ctot);
             } else {
-                t[u].c0 = t[u].c1 = 0; t[u].w0 = t[u].w1 = 0.f; v[u] = 0.f;
+                t[u].c0 = t[u].c1 = 0; t[u].w0 = t[u].w1 = 0.f; v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            if (t[u].w0 != 0.f) atomicAdd(&line[t[u].c0 * cg + c], t[u].w0 * v[u]);
-            if (t[u].w1 != 0.f) atomicAdd(&line[t[u].c1 * cg + c], t[u].w1 * v[u]);
+            if (t[u].w0 != 0.f) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) atomicAdd(&lacc[t[u].c0 * cg + c4 + k], (unsigned long long)__float2ll_rn((t[u].w0 * v[u][k]) * up));
+            }
+            if (t[u].w1 != 0.f) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) atomicAdd(&lacc[t[u].c1 * cg + c4 + k], (unsigned long long)__float2ll_rn((t[u].w1 * v[u][k]) * up));
+            }
         }
     }
     __syncthreads();
+    const double down = ldexp(1.0, e - 49);
     for (int o = tid; o < total; o += SC_NT) {
-        const float a = line[o];
-        if (a != 0.f) unsafeAtomicAdd(jb.grad + (long)(o / cg) * jb.C + jb.c_lo + (o % cg), a);
+        const long long a = (long long)lacc[o];
+        if (a != 0) unsafeAtomicAdd(jb.grad + (long)(o / cg) * jb.C + jb.c_lo + (o % cg), (float)((double)a * down));
     }
 }
 
 static const int kM0[3] = {0, 0, 1}, kM1[3] = {1, 2, 2}, kV[3] = {2, 1, 0};
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static int launch_lines(const GridParams& g, const GridGrads& gg, const float* rows_l, const LTap* ltap, long n, hipStream_t st) {
+    const int ctot = g.n_comp[0] + g.n_comp[1] + g.n_comp[2];
+    LineJobs lj;
+    int nj = 0, coff = 0;
+    size_t llds = 0;
+    for (int i = 0; i < 3; ++i) {
+        const int C = g.n_comp[i], Lp = g.grid[kV[i]];
+        int cg = 16;                                      // 64-bit accumulators: 16-channel slices (586 cells: 75 KB)
+        while (cg > 4 && (size_t)Lp * cg * 8 > (size_t)SC_LDS_MAX / 2) cg /= 2;
+        for (int c_lo = 0; c_lo < C && gg.line[i]; c_lo += cg) {
+            if (nj >= 12) return fail(EVD_E_INVALID, "evd_voxel_sample_bwd: too many line channel groups");
+            LineJob& j = lj.j[nj++];
+            j.grad = gg.line[i]; j.C = C; j.Lp = Lp; j.coff = coff; j.comp = i; j.c_lo = c_lo; j.cg = cg;
+            const size_t l = (size_t)Lp * cg * 8;
+            llds = l > llds ? l : llds;
+        }
+        coff += C;
+    }
+    for (int k = nj; k < 12; ++k) lj.j[k].grad = nullptr;
+    if (nj) {
+        EVD_SET_MAX_LDS(k_scatter_lines, (size_t)SC_LDS_MAX);
+        hipLaunchKernelGGL(k_scatter_lines, dim3((unsigned)cdiv(n, (long)SC_LCH), nj), dim3(SC_NT), llds, st, lj, rows_l, ltap, n, ctot);
+        EVD_LAUNCH_CHECK();
+    }
+    return EVD_OK;
+}
 
 static size_t sort_temp_bytes(long n) {
     size_t b = 0;
@@ -219,30 +284,29 @@ int launch_voxel_sample_bwd_binned(const GridParams& g, const float* pts, long n
         hipLaunchKernelGGL(k_scatter_planes, dim3((unsigned)cdiv(n, (long)SC_CH), 3), dim3(SC_NT), plds, st, pj, (const float*)bo.rows_p, (const PTap*)bo.ptap, n, ctot);
         EVD_LAUNCH_CHECK();
     }
-    LineJobs lj;
-    int nj = 0;
-    size_t llds = 0;
-    coff = 0;
-    for (int i = 0; i < 3; ++i) {
-        const int C = g.n_comp[i], Lp = g.grid[kV[i]];
-        int cg = C < 32 ? C : 32;
-        while ((size_t)Lp * cg * 4 > (size_t)SC_LDS_MAX) cg /= 2;
-        for (int c_lo = 0; c_lo < C && gg.line[i]; c_lo += cg) {
-            if (nj >= 8) return fail(EVD_E_INVALID, "evd_voxel_sample_bwd: too many line channel groups");
-            LineJob& j = lj.j[nj++];
-            j.grad = gg.line[i]; j.C = C; j.Lp = Lp; j.coff = coff; j.comp = i; j.c_lo = c_lo; j.cg = cg;
-            const size_t l = (size_t)Lp * cg * 4;
-            llds = l > llds ? l : llds;
-        }
-        coff += C;
-    }
-    for (int k = nj; k < 8; ++k) lj.j[k].grad = nullptr;
-    if (nj) {
-        EVD_SET_MAX_LDS(k_scatter_lines, (size_t)SC_LDS_MAX);
-        hipLaunchKernelGGL(k_scatter_lines, dim3((unsigned)cdiv(n, (long)SC_LCH), nj), dim3(SC_NT), llds, st, lj, (const float*)bo.rows_l, (const LTap*)bo.ltap, n, ctot);
-        EVD_LAUNCH_CHECK();
-    }
+    if ((rc = launch_lines(g, gg, (const float*)bo.rows_l, (const LTap*)bo.ltap, n, st))) return rc;
     return EVD_OK;
+}
+
+// ---- hybrid: the plane taps by direct atomics (k_voxel_sample_bwd<2>), the line taps through k_scatter_lines ------------------------
+size_t voxel_scatter_hybrid_workspace_bytes(const GridParams& g, long n) {
+    if (n <= 0) return 0;
+    const size_t ctot = (size_t)(g.n_comp[0] + g.n_comp[1] + g.n_comp[2]);
+    return al256((size_t)n * ctot * 4) + al256((size_t)n * 3 * sizeof(LTap)) + 512;
+}
+
+int launch_voxel_sample_bwd_hybrid(const GridParams& g, const float* pts, long n, const float* d_out, int d_stride, int d_col, const GridGrads& gg,
+                                   float* d_pts, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    if (workspace_bytes < voxel_scatter_hybrid_workspace_bytes(g, n))
+        return fail(EVD_E_WORKSPACE, "evd_voxel_sample_bwd: workspace %zu < %zu bytes", workspace_bytes, voxel_scatter_hybrid_workspace_bytes(g, n));
+    const size_t ctot = (size_t)(g.n_comp[0] + g.n_comp[1] + g.n_comp[2]);
+    char* w = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    BinOut bo{};
+    bo.rows_l = (float*)w;
+    bo.ltap = (LTap*)(w + al256((size_t)n * ctot * 4));
+    int rc = launch_voxel_sample_bwd_planes(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo, st);
+    if (rc) return rc;
+    return launch_lines(g, gg, (const float*)bo.rows_l, (const LTap*)bo.ltap, n, st);
 }
 
 }  // namespace evd

@@ -59,9 +59,9 @@ class _VoxelSample(torch.autograd.Function):
         g = d_out.reshape(-1, net.app_dim).contiguous().float()
         grads, gs = _grid_grads(net, ctx.saved_tensors, in_place=_GRADS_IN_PLACE)
         d_pts = torch.empty_like(pts) if ctx.needs_input_grad[0] else None
-        # EVD_SCATTER=1: the experimental binned form (taps sorted by plane tile, summed in LDS; csrc/kernel_voxel_scatter.hip) -- it gets
-        # scratch; by default none is passed and the direct-atomics kernel runs
-        nb = int(L.lib().evd_voxel_sample_bwd_workspace_bytes(net._h, pts.shape[0])) if os.environ.get("EVD_SCATTER") == "1" else 0
+        # scratch for the hybrid form of the scatter (csrc/kernel_voxel_scatter.hip: plane taps by direct float atomics, line taps through
+        # fixed-point LDS slices -- a third fewer atomic requests, 24-27 % faster); EVD_SCATTER=direct passes none: every tap an atomic
+        nb = int(L.lib().evd_voxel_sample_bwd_workspace_bytes(net._h, pts.shape[0])) if os.environ.get("EVD_SCATTER") != "direct" else 0
         ws = torch.empty((nb,), dtype=torch.uint8, device=pts.device) if nb else None
         L.check(L.lib().evd_voxel_sample_bwd_ws(net._h, L.ptr(pts), pts.shape[0], L.ptr(g), net.app_dim, 0, C.byref(gs), L.ptr(d_pts), L.ptr(ws), nb,
                                                 L.stream_ptr()), "evd_voxel_sample_bwd_ws")

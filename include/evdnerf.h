@@ -310,11 +310,12 @@ int evd_voxel_load_grids(evd_voxel* v, const float* const* plane, const float* c
  * linear interpolation weights (ATen grid_sample backward semantics: taps outside the grid contribute nothing). */
 int evd_voxel_sample_bwd(const evd_voxel* v, const float* pts, long n, const float* d_out, int d_stride, int d_col,
                          const evd_voxel_grid_grads* g, float* d_pts, void* stream);
-/* The same with caller scratch (evd_voxel_sample_bwd_workspace_bytes(v, n), ~1 KB per sample; n_comp in {16, 32, 64}): the taps are
- * first binned by 16 x 16-cell plane tile (radix sort) and summed tile by tile in LDS, so each touched grid cell receives ONE global
- * atomic per tile run instead of one per sample and tap (5-25 x fewer float atomics).  Same results to float32 rounding of the
- * summation order.  EXPERIMENTAL: measured 2 x slower than the direct form as built (csrc/kernel_voxel_scatter.hip has the
- * breakdown and what it needs); with workspace NULL / 0 bytes, or shapes it does not handle, this IS evd_voxel_sample_bwd. */
+/* The same with caller scratch (evd_voxel_sample_bwd_workspace_bytes(v, n), ~430 B per sample; n_comp in {16, 32, 64}, else the
+ * call is evd_voxel_sample_bwd): the HYBRID form -- the plane taps stay direct float atomics, the line taps (a third of the atomic
+ * requests, onto a few hundred cells) are summed per 2048 samples in LDS slices of the line gradients (64-bit fixed point, exact
+ * conversion of every float32 contribution above 2^-49 of the chunk's maximum) and added once: 24-27 % faster, same sums to float32
+ * rounding of the summation order.  With workspace NULL / 0 bytes this IS evd_voxel_sample_bwd.  (Developer switch EVD_SCATTER=binned:
+ * the experimental sort + LDS-tile form, csrc/kernel_voxel_scatter.hip.) */
 size_t evd_voxel_sample_bwd_workspace_bytes(const evd_voxel* v, long n);
 int evd_voxel_sample_bwd_ws(const evd_voxel* v, const float* pts, long n, const float* d_out, int d_stride, int d_col,
                             const evd_voxel_grid_grads* g, float* d_pts, void* workspace, size_t workspace_bytes, void* stream);

@@ -67,7 +67,7 @@ def main():
     L.check(L.lib().evd_voxel_sample_bwd_ws(net._h, L.ptr(pts), n, L.ptr(d_out), 32, 0, C.byref(gs), None, L.ptr(ws), nb, L.stream_ptr()), "bwd_ws")
     err = max(((a - b).norm() / b.norm().clamp_min(1e-30)).item() for a, b in zip(grads, ref))
     print(f"grid {g}: n = {n} samples | gather forward {fwd:.3f} ms | scatter backward: direct atomics {bwd:.3f} ms = {atom / bwd / 1e6:.1f} G float atomics/s | "
-          f"binned (sort + LDS tiles) {binned:.3f} ms | relative L2 difference of the two {err:.1e} | scratch {nb / 2**20:.0f} MiB")
+          f"with scratch (hybrid: lines through LDS slices; EVD_SCATTER=binned: sort + LDS tiles) {binned:.3f} ms | relative L2 difference of the two {err:.1e} | scratch {nb / 2**20:.0f} MiB")
 
 
 if __name__ == "__main__":
