@@ -589,6 +589,18 @@ constexpr int VSB_MAXF = 64, VSB_TAPS = 18;
 // regardless of the table size, tools/probes/atomic_probe.hip, and the counters show EVERY atomic request of this kernel travelling to
 // the memory side, TCC_EA0_ATOMIC == TCC_ATOMIC = 18.6 M 64-byte requests per 2^19 samples: device-scope float atomics are not
 // executed in the XCD's L2.  The kernel is at 78 % of that ceiling; the gap is the repeated hits on the same few line cells.)
+// sum over the 16 lanes of a DPP row, left in every lane of the row (lanes that are switched off contribute 0)
+__device__ __forceinline__ float row_sum_dpp(float v) {
+    auto d = [](float src, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), decltype(ctrl)::value, 0xf, 0xf, false));
+    };
+    v += d(v, std::integral_constant<int, 0xb1>());      // quad_perm [1,0,3,2]
+    v += d(v, std::integral_constant<int, 0x4e>());      // quad_perm [2,3,0,1]
+    v += d(v, std::integral_constant<int, 0x141>());     // row_half_mirror
+    v += d(v, std::integral_constant<int, 0x140>());     // row_mirror
+    return v;
+}
+
 // MODE: 0 = every tap by a direct atomic; 1 = pass 1 of the binned form (rows + tap records + keys, no atomics); 2 = HYBRID: the plane
 // taps by direct atomics, the line taps deferred -- their rows and tap records are written and k_scatter_lines adds them through
 // privatised LDS slices of the (small) line gradients: a third of the kernel's atomic requests go away.
@@ -608,6 +620,7 @@ __global__ __launch_bounds__(256, MM ? (CT <= 96 ? 3 : 2) : 1) void k_voxel_samp
     // this thread's channel in the (sample pair, 128 channel slots) sweeps of phase B: component group, channel inside it
     const int cg = ql < c0n ? 0 : (ql < c0n + c1n ? 1 : 2), cin = ql - (cg == 0 ? 0 : (cg == 1 ? c0n : c0n + c1n));
     const bool chan_on = ql < ctot;
+    const bool rows16 = (c0n % 16 == 0) && (c1n % 16 == 0) && (g.n_comp[2] % 16 == 0);     // components = whole 16-lane DPP rows
     const float* gplane = sel3(cg, g.plane[0], g.plane[1], g.plane[2]);
     const float* gline = sel3(cg, g.line[0], g.line[1], g.line[2]);
     // ... and its (tap, channel) entries in the atomic sweeps: q = ql + 128 m over [4 plane taps x ctot | 2 line taps x ctot]
@@ -743,12 +756,23 @@ __global__ __launch_bounds__(256, MM ? (CT <= 96 ? 3 : 2) : 1) void k_voxel_samp
                     const float dl = (w[12 + 2 * cg + 1] != 0.f ? Lt[1] : 0.f) - (w[12 + 2 * cg] != 0.f ? Lt[0] : 0.f);
                     const float dc = dco[sl * STRD + ql];
                     float gx = dc * lv * dpx * fr[3], gy = dc * lv * dpy * fr[4], gl = dc * pv * dl * fr[5];
-                    // lanes of one wavefront half belong to the same (sample, component) only for the 64-channel component; reduce
-                    // with LDS float atomics (3 per lane) -- 96 lanes x 32 samples per tile
+                    // sum over the component's channels.  When every component is a whole number of 16-lane rows (the shipped 64 / 16 / 16)
+                    // the rows are summed in registers (DPP) and ONE lane per row adds to LDS: 18 LDS float atomics per sample instead of
+                    // 288 -- ds_add_f32 runs at ~0.4 lane-operations per clock and CU on this chip (kernel_voxel_scatter.hip), so the
+                    // 9216 of a tile cost more than everything else the tile does
                     const int* ta = tax + (sl * 3 + cg) * 3;
-                    atomicAdd(&dpt[sl * 3 + ta[0]], gx);
-                    atomicAdd(&dpt[sl * 3 + ta[1]], gy);
-                    atomicAdd(&dpt[sl * 3 + ta[2]], gl);
+                    if (rows16) {
+                        gx = row_sum_dpp(gx); gy = row_sum_dpp(gy); gl = row_sum_dpp(gl);
+                        if ((tid & 15) == 0) {
+                            atomicAdd(&dpt[sl * 3 + ta[0]], gx);
+                            atomicAdd(&dpt[sl * 3 + ta[1]], gy);
+                            atomicAdd(&dpt[sl * 3 + ta[2]], gl);
+                        }
+                    } else {
+                        atomicAdd(&dpt[sl * 3 + ta[0]], gx);
+                        atomicAdd(&dpt[sl * 3 + ta[1]], gy);
+                        atomicAdd(&dpt[sl * 3 + ta[2]], gl);
+                    }
                 }
             }
         }
