@@ -283,7 +283,7 @@ class VoxelNeRFBase:
             name, idx, kind = key.split(".")
             arr = getattr(gs, ("sigma_" if name == "sigma_net" else "color_") + ("w" if kind == "weight" else "b"))
             arr[int(idx)] = base + 4 * off
-        d_fts = torch.zeros((R * S, self.ft_dim), dtype=torch.float32, device=g.device) if want_fts else None
+        d_fts = torch.empty((R * S, self.ft_dim), dtype=torch.float32, device=g.device) if want_fts else None      # every column is written (k_frags_to_rows)
         nb = int(L.lib().evd_voxel_backward_workspace_bytes())
         ws = torch.empty((nb,), dtype=torch.uint8, device=g.device)
         p = pts.contiguous().float() if pts is not None else None
