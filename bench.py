@@ -346,6 +346,12 @@ def train_iteration_leg(precision):
     from evdeblurnerf_amd.voxnerf import VoxelNeRFSampleFeatures, _grid_grads
     ms, nrays, _ = BT.run(types.SimpleNamespace(precision=precision, iters=10, pixels=1024, events=4096, P=10))
     torch.cuda.empty_cache()
+    # the same iteration with the shipped configs' adaptive weight proposal on the blur batch (kernel_use_awp): the per-sample part fused
+    # on the fine level's geo fragments (awp.FusedAWP) vs the module's plain PyTorch forward on depth_feature [R P, S, 128]
+    ms_awp_f, _, _ = BT.run(types.SimpleNamespace(precision=precision, iters=5, pixels=1024, events=4096, P=10, awp="fused"))
+    torch.cuda.empty_cache()
+    ms_awp_t, _, _ = BT.run(types.SimpleNamespace(precision=precision, iters=5, pixels=1024, events=4096, P=10, awp="torch"))
+    torch.cuda.empty_cache()
     aabb = ([-1.5, -1.5, -1.0], [1.5, 1.5, 1.0])
     fv = 134217984
     g = W.pdrf_grid_size(aabb[0], aabb[1], fv)
@@ -370,6 +376,8 @@ def train_iteration_leg(precision):
     return {"workload": "blurfactory training iteration: 1024 pixels x 10 sub-exposure rays + 2 x 4096 event rays, 64 + 64 samples, losses, TV, "
                         "backward, Adam, parameter re-pack", "precision": precision, "ms_per_iteration": ms, "rays_per_iteration": nrays,
             "rays_per_s": nrays / (ms * 1e-3),
+            "with_awp_ms_per_iteration": {"fused_on_geo_fragments": ms_awp_f, "torch_module_on_depth_feature": ms_awp_t,
+                                          "note": "AWP module = tools/awp_standin.py (the reference module's surface; its per-sample embedding is the reference's)"},
             "scatter_hybrid_ms": h_ms,
             "scatter_note": "what the iteration runs: plane taps by direct float atomics (384 per sample), line taps through 64-bit fixed-point LDS "
                             "slices of the line gradients (k_scatter_lines; ds_add_f32 is ~6 x slower than integer LDS atomics on this chip) -- "

@@ -567,9 +567,18 @@ class NeRFAll:
             out += list(lv["leaves"].items())
             if lv["grids"] is not None:
                 out += list(lv["grids"].items())
+        for name, m in self._torch_children():
+            out += [(f"{name}.{k}", v) for k, v in m.named_parameters()]
+        return out
+
+    def _torch_children(self):
+        """the PyTorch modules NeRFAll holds in the reference (renderer.py:24-43), under the reference's attribute names; a FusedAWP
+        wrapper is looked through, so parameter and state-dict keys stay `awpnet.sample_feature_embed_layer.0.weight` etc."""
+        out = []
         for name, m in (("kernelsnet", self.kernelsnet), ("awpnet", self.awpnet)):
+            m = getattr(m, "ref", m) if type(m).__name__ == "FusedAWP" else m
             if isinstance(m, torch.nn.Module):
-                out += [(f"{name}.{k}", v) for k, v in m.named_parameters()]
+                out.append((name, m))
         return out
 
     def parameters(self):
@@ -622,6 +631,8 @@ class NeRFAll:
             sd.update({k: v.detach().clone() for k, v in lv["leaves"].items()})
             if lv["grids"] is not None:
                 sd.update(net.grids_to_state_dict(list(lv["grids"].values()), name))
+        for name, m in self._torch_children():              # the reference's NeRFAll is an nn.Module: its state dict carries these too
+            sd.update({f"{name}.{k}": v.detach().clone() for k, v in m.state_dict().items()})
         return sd
 
     def forward(self, H, W, K, chunk=1 << 22, rays=None, rays_info=None, poses=None, **kwargs):

@@ -37,7 +37,8 @@ class RigidKernel(torch.nn.Module):
         o, d = rays[..., 0], rays[..., 1]
         o2 = o[:, None] + self.trans[None]
         d2 = d[:, None] + torch.cross(self.rot[None].expand(d.shape[0], -1, -1), d[:, None].expand(-1, self.P, -1), dim=-1)
-        return torch.stack([o2, d2], -1), torch.softmax(self.logit, 0)[None].expand(o.shape[0], -1), None, {}
+        extra = {"img_embed": torch.ones((o.shape[0], 4), device=o.device)} if return_img_embed else {}
+        return torch.stack([o2, d2], -1), torch.softmax(self.logit, 0)[None].expand(o.shape[0], -1), None, extra
 
 
 def main():
@@ -47,6 +48,9 @@ def main():
     ap.add_argument("--pixels", type=int, default=1024)
     ap.add_argument("--events", type=int, default=4096)
     ap.add_argument("--P", type=int, default=10)
+    ap.add_argument("--awp", choices=["none", "fused", "torch"], default="none",
+                    help="the shipped configs' adaptive weight proposal on the blur batch (kernel_use_awp): fused = evdeblurnerf_amd.awp.FusedAWP around a "
+                         "module with the reference's surface (tools/awp_standin.py), torch = that module's plain PyTorch forward on depth_feature")
     a = ap.parse_args()
     ms, nr, loss = run(a)
     print(f"blurfactory TRAINING iteration [{a.precision}]: {nr} rays x (64 + 64) samples, losses, TV, backward, Adam, re-pack: {ms:.2f} ms "
@@ -66,7 +70,16 @@ def run(a):
                            fine_geo_feat_dim=128, fine_app_dim=32, fine_app_n_comp=[64, 16, 16], fine_n_voxels=fv)
     dev = "cuda"
     kern = RigidKernel(a.P).to(dev)
-    model = NeRFAll(args, sd, kernelsnet=kern, precision=a.precision).enable_training(sd).train()
+    awp_mode = getattr(a, "awp", "none")
+    awpnet = None
+    if awp_mode != "none":
+        from awp_standin import RefLikeAWP
+        from evdeblurnerf_amd.awp import FusedAWP
+        awpnet = RefLikeAWP(P=a.P, view_ch=4).to(dev)
+        if awp_mode == "fused":
+            awpnet = FusedAWP(awpnet, precision=a.precision if a.precision in ("f16", "bf16") else "f16")
+    model = NeRFAll(args, sd, kernelsnet=kern, awpnet=awpnet, precision=a.precision).enable_training(sd).train()
+    model.use_awp = awpnet is not None
     crf_rgb = CRF("gamma")
     crf_ev = CRF("learn", state_dict=W.make_crf_state_dict(5, extra_features=2), extra_features=2)
     crf_flat = crf_ev.flat_params(dev)
@@ -90,6 +103,8 @@ def run(a):
         s2, s20, _, _ = model(400, 400, K, 1 << 22, rays=ev_end, force_naive=True, tv=False, **kw)
         pe = event_loss_partials_autograd(crf_ev, crf_flat, s1, s2, cum_neg, cum_pos, 0.2, 0.2, start0=s10, end0=s20, add_bii="pos-neg")
         loss, _ = blur_loss_from_partials(pb, fine_loss_weight=0.5, w_pts0=0.1)
+        if "rgb_awp" in tens:               # the AWP composition's image term (run_nerf.py:470-480)
+            loss = loss + ((tens["rgb_awp"] - tgt) ** 2).mean()
         loss = loss + 0.1 * event_loss_from_partials(pe) + 0.01 * other["TV"].sum()
         opt.zero_grad(set_to_none=True)
         loss.backward()
