@@ -137,7 +137,11 @@ __global__ __launch_bounds__(SC_NT) void k_scatter_lines(const LineJobs jobs, co
     float m = 0.f;
     for (long s = base + wave * spw + sub; s < end; s += step) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(col + s * ctot);
-        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float a = fabsf(v[k]);
+            m = a != a ? __builtin_huge_valf() : fmaxf(m, a);          // (fmaxf drops NaNs: they are recorded as +inf)
+        }
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
@@ -146,7 +150,19 @@ __global__ __launch_bounds__(SC_NT) void k_scatter_lines(const LineJobs jobs, co
     m = 0.f;
 #pragma unroll
     for (int w = 0; w < SC_NT / 64; ++w) m = fmaxf(m, wmax[w]);
-    if (!(m > 0.f) || !(m < 3.0e38f)) return;          // nothing to add (or non-finite input: leave the gradient untouched)
+    if (m > 3.0e38f) {                                  // a NaN / Inf contribution: no fixed-point scale exists -- add this chunk's taps
+        for (long s = base + wave * spw + sub; s < end; s += step) {       // directly, so that the gradient shows it as the direct form would
+            const LTap t = ltap[s * 3 + jb.comp];
+            const f32x4 v = *reinterpret_cast<const f32x4*>(col + s * ctot);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (t.w0 != 0.f) unsafeAtomicAdd(jb.grad + (long)t.c0 * jb.C + jb.c_lo + c4 + k, t.w0 * v[k]);
+                if (t.w1 != 0.f) unsafeAtomicAdd(jb.grad + (long)t.c1 * jb.C + jb.c_lo + c4 + k, t.w1 * v[k]);
+            }
+        }
+        return;
+    }
+    if (!(m > 0.f)) return;                             // nothing to add
     int e;
     (void)frexpf(m, &e);                                // m = f 2^e, f in [0.5, 1)
     const float up = ldexpf(1.f, 49 - e);               // |w v| up <= 2^49

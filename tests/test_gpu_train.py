@@ -898,3 +898,24 @@ def test_c2f_render_rays_train_equals_inference_render_rays(prec, tol):
         err = (out[k].detach() - ref[k]).abs().max().item()
         # (the depth follows the importance samples, an ill-conditioned function of the coarse weights: conftest.z_mismatch)
         assert err < (40 * tol if k == "depth_map" else tol) * max(1.0, ref[k].abs().max().item()), (k, err)
+
+
+def test_hybrid_scatter_propagates_non_finite_gradients():
+    """A NaN in the incoming gradient reaches the line gradients in the hybrid form too (its fixed-point LDS path has no scale for it:
+    the chunk falls back to direct atomics) -- a diverged loss must not be silently zeroed."""
+    import ctypes as C
+    from evdeblurnerf_amd import _lib as L
+    from evdeblurnerf_amd.voxnerf import VoxelNeRFSampleFeatures, _grid_grads
+    nvox = 48 ** 3
+    g = W.pdrf_grid_size(AABB[0], AABB[1], nvox)
+    net = VoxelNeRFSampleFeatures(W.make_pdrf_state_dict(32, g, input_ch=127, hidden_dim=256, geo_feat_dim=128), "", AABB, num_layers=2, hidden_dim=256,
+                                  geo_feat_dim=128, num_layers_color=3, input_ch=127, app_dim=32, app_n_comp=(64, 16, 16), n_voxels=nvox)
+    n = 5000
+    pts = torch.tensor(np.random.RandomState(1).uniform(-1, 1, (n, 3)).astype(np.float32), device="cuda")
+    d_out = torch.randn((n, 32), device="cuda")
+    d_out[1234, 7] = float("nan")
+    grads, gs = _grid_grads(net, net.grid_params())
+    nb = int(L.lib().evd_voxel_sample_bwd_workspace_bytes(net._h, n))
+    ws = torch.empty((nb,), dtype=torch.uint8, device="cuda")
+    L.check(L.lib().evd_voxel_sample_bwd_ws(net._h, L.ptr(pts), n, L.ptr(d_out), 32, 0, C.byref(gs), None, L.ptr(ws), nb, L.stream_ptr()), "bwd_ws")
+    assert all(torch.isnan(t).any().item() for t in grads[:6]), [torch.isnan(t).any().item() for t in grads]
