@@ -580,6 +580,10 @@ __global__ __launch_bounds__(64 * VW_WAVES) void k_voxel_sample_w(const GridPara
 // taps, ds_add_f32, one global atomic per touched cell) for the components whose taps stay together along a ray -- the bounding-box
 // atomics, the per-tap window index and the flush add ~0.5 ms per 2^19 samples to this one-wavefront-per-SIMD kernel and the whole
 // blurfactory iteration went from 33.2 to 42.1 ms; and the sort + LDS-tile form of kernel_voxel_scatter.hip (2 x slower as built).
+// And, once ds_add_f32 was known to be the slow part (kernel_voxel_scatter.hip), the same window for the 64-channel x-y plane WITHOUT
+// atomics (lane = channel, a window cell owned by one wavefront, every wavefront walks the tile's 128 (sample, tap) entries in order;
+// the box of the benchmark's NDC rays is 42-60 cells, 22-28 of them touched by the 128 taps): correct, and 0.92 -> 1.43 ms per 2^19
+// samples, iteration 22.6 -> 30.3 ms -- the walk is a chain of dependent LDS read-modify-writes, again.
 // BINNED (kernel_voxel_scatter.hip): the atomics of phase B are replaced by one row of per-channel contributions per sample and the
 // tap records; a second pass adds them tile by tile in LDS.  d basis and d pts are computed here either way.
 constexpr int VSB_MAXF = 64, VSB_TAPS = 18;
