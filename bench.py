@@ -588,12 +588,22 @@ def main(argv=None):
     c2f_model = None
     if not a.no_c2f or not a.no_strong:
         c2f_prec = "f16" if a.precision == "f16c" else a.precision      # the PDRF levels are not built in the compensated mode (NeRF-MLP only)
+        # the informational legs below must never cost the contract line: a failure is recorded in its place
+        def guarded(name, fn):
+            try:
+                return fn()
+            except Exception as e:      # noqa: BLE001
+                import traceback
+                sys.stderr.write(f"[bench] leg '{name}' failed:\n{traceback.format_exc()}\n")
+                torch.cuda.empty_cache()
+                return {"error": f"{type(e).__name__}: {e}"}
         if rank == 0 and not a.no_c2f and not lean:
-            result["c2f"], c2f_model = c2f_leg(c2f_prec, max(5, a.steps // 2))
+            r = guarded("c2f", lambda: c2f_leg(c2f_prec, max(5, a.steps // 2)))
+            result["c2f"], c2f_model = r if isinstance(r, tuple) else (r, None)
         if rank == 0 and not a.no_awp and not lean:
-            result["awp"] = awp_leg(c2f_prec)
+            result["awp"] = guarded("awp", lambda: awp_leg(c2f_prec))
         if rank == 0 and not a.no_train and not lean:
-            result["train_iteration"] = train_iteration_leg(c2f_prec)
+            result["train_iteration"] = guarded("train_iteration", lambda: train_iteration_leg(c2f_prec))
         if not a.no_strong:
             if c2f_model is None:
                 from evdeblurnerf_amd.renderer import NeRFAll
