@@ -242,7 +242,7 @@ bool voxel_scatter_binned_ok(const GridParams& g, const GridGrads& gg, long n) {
         const int C = g.n_comp[i];
         if (C != 16 && C != 32 && C != 64) return false;
         const int Wp = g.grid[kM0[i]], Hp = g.grid[kM1[i]], Lp = g.grid[kV[i]];
-        if (Wp > 65535 || Hp > 65535 || (size_t)Lp * 16 * 4 > (size_t)SC_LDS_MAX) return false;
+        if (Wp > 65535 || Hp > 65535 || (size_t)Lp * 16 * 8 > (size_t)SC_LDS_MAX / 2) return false;      // a 16-channel slice of a whole line (64-bit accumulators) must fit half the LDS
     }
     return n > 0 && n < (1L << 31);
 }
