@@ -87,6 +87,8 @@ SIGNATURES = {
     "evd_rbk_warp": (_I, [_vp, _vp, _vp, _L, _I, _I, _vp, _vp, _vp]),
     "evd_awp_feature_integration": (_I, [_vp, _vp, _vp, _L, _I, _I, _vp, _vp]),
     "evd_awp_feature_integration_bwd": (_I, [_vp, _vp, _vp, _vp, _L, _I, _I, _vp, _vp, _vp, _vp]),
+    "evd_mam_local_forward": (_I, [_vp, _vp, _L, _I, _I, _I, _vp, _vp, _vp, _vp, _vp]),
+    "evd_mam_local_backward": (_I, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _L, _I, _I, _I, _vp, _vp, _vp]),
     "evd_awp_embed_create": (_I, [C.POINTER(_fp), C.POINTER(_fp), _I, _I, _I, C.POINTER(_vp)]),
     "evd_awp_embed_destroy": (None, [_vp]),
     "evd_awp_embed_param_count": (_L, [_vp]),

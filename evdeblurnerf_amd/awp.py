@@ -1,8 +1,9 @@
 """The AWP consumer of the path's per-sample outputs (reference ``networks/dpnerf/awp.py``): the per-sample part of
 ``AdaptiveWeightProposal`` -- ``sample_feature_embed_layer`` (awp.py:36-37,98-100: 4 x Linear + ReLU over every sample of every
 sub-exposure ray) and the ``feature_integration`` scan (awp.py:49-77) -- on hand-written kernels, forward and backward, as autograd
-nodes.  ``FusedAWP`` wraps the reference's module: the per-ray remainder (motion embedding, MotionAggregationModule, ``w_linear``:
-[R, P, 32]-sized tensors) stays its PyTorch submodules, as in the reference's caller."""
+nodes, and the per-sample part of the ``MotionAggregationModule`` (mam.py:72-74 ``linear`` on h_local, :29-33 attention logit, the two
+softmaxes and weighted sums) as one more.  ``FusedAWP`` wraps the reference's module: the per-ray remainder (motion embedding, the rest
+of the CorrelationModule, ``w_linear``: [R, P, 32] / [R, 32, S]-sized tensors) stays its PyTorch submodules, as in the reference's caller."""
 from __future__ import annotations
 
 import ctypes as C
@@ -96,6 +97,47 @@ class _SampleEmbed(torch.autograd.Function):
         return d_src, gflat, None, None
 
 
+class _MamLocal(torch.autograd.Function):
+    """evd_mam_local_forward / _backward: h_local [R P, S, 64], u [64] -> (h_inter [R, P, 64], h_intra [R, S, 64]), the softmax-weighted
+    sums of h_local along the samples / along the sub-exposures with the logits u . h_local (mam.py:29-33 before the 64 -> 32 map)."""
+
+    @staticmethod
+    def forward(ctx, h_local, u, R, P, S):
+        h, uu = h_local.contiguous().float(), u.contiguous().float()
+        Cc = h.shape[-1]
+        if h.numel() != R * P * S * Cc:
+            raise L.EvdError(f"mam_local: h_local has {h.numel()} elements, expected {R} x {P} x {S} x {Cc}")
+        dev = h.device
+        h_inter = torch.empty((R, P, Cc), dtype=torch.float32, device=dev)
+        h_intra = torch.empty((R, S, Cc), dtype=torch.float32, device=dev)
+        alpha = torch.empty((R, P, S), dtype=torch.float32, device=dev)
+        beta = torch.empty((R, P, S), dtype=torch.float32, device=dev)
+        L.check(L.lib().evd_mam_local_forward(L.ptr(h), L.ptr(uu), R, P, S, Cc, L.ptr(h_inter), L.ptr(h_intra), L.ptr(alpha), L.ptr(beta),
+                                              L.stream_ptr()), "evd_mam_local_forward")
+        ctx.save_for_backward(h, uu, alpha, beta, h_inter, h_intra)
+        ctx.dims, ctx.h_shape = (R, P, S, Cc), h_local.shape
+        return h_inter, h_intra
+
+    @staticmethod
+    def backward(ctx, g_inter, g_intra):
+        h, uu, alpha, beta, h_inter, h_intra = ctx.saved_tensors
+        R, P, S, Cc = ctx.dims
+        d_h = torch.empty_like(h)
+        d_u = torch.empty((R, Cc), dtype=torch.float32, device=h.device)
+        L.check(L.lib().evd_mam_local_backward(L.ptr(h), L.ptr(uu), L.ptr(alpha), L.ptr(beta), L.ptr(h_inter), L.ptr(h_intra),
+                                               L.ptr(g_inter.contiguous().float()), L.ptr(g_intra.contiguous().float()), R, P, S, Cc,
+                                               L.ptr(d_h), L.ptr(d_u), L.stream_ptr()), "evd_mam_local_backward")
+        return d_h.reshape(ctx.h_shape), d_u.sum(0), None, None, None
+
+
+def mam_local(h_local, linear_weight, att_weight, R, P, S):
+    """The per-sample part of MotionAggregationModule.forward + CorrelationModule.forward (mam.py:72-74, 29-33): h_local [R P, S, 64],
+    MAM.linear.weight [M, 64], Corr.line_conv_att.weight [1, M, 1, 1] -> (h_inter [R, P, 64], h_intra [R, S, 64]);
+    curver_inter = (h_inter W^T + b)^T and curves_intra = (h_intra W^T + b)^T are the caller's (per-ray sized)."""
+    u = att_weight.reshape(1, -1) @ linear_weight                     # the logit of a sample is (W^T v) . h + const
+    return _MamLocal.apply(h_local, u.reshape(-1), R, P, S)
+
+
 class SampleFeatureEmbed:
     """sample_feature_embed_layer (awp.py:36-37) as a library handle: weights[l] [64, in_l], biases[l] [64] (nn.Linear layouts)."""
 
@@ -161,6 +203,25 @@ class FusedAWP(torch.nn.Module):
     def _flat(self):
         return torch.cat([t.reshape(-1) for l in self.ref.sample_feature_embed_layer for t in (l.weight, l.bias)])
 
+    def _mam(self, x_global, h_local, n_ray, P, S):
+        """MotionAggregationModule.forward (mam.py:66-83) with its per-sample part on the library (mam_local) and the per-ray remainder
+        of CorrelationModule.forward (mam.py:35-53) on the wrapped module's own layers.  A MAM without the reference's structure
+        (no `Corr` / `linear`) is simply called."""
+        mam = self.ref.MAM
+        corr, lin = getattr(mam, "Corr", None), getattr(mam, "linear", None)
+        if corr is None or lin is None or h_local.shape[-1] != 64 or P > 16 or S > 512:
+            return mam(x_global, h_local)
+        F = torch.nn.functional
+        h_inter, h_intra = mam_local(h_local, lin.weight, corr.line_conv_att.weight, n_ray, P, S)
+        k_inter = corr.conva(F.linear(h_inter, lin.weight, lin.bias).transpose(1, 2))         # [R, mid, P]
+        k_intra = corr.convb(F.linear(h_intra, lin.weight, lin.bias).transpose(1, 2))         # [R, mid, S]
+        x = x_global.transpose(1, 2)                                                          # [R, C, P]
+        q = corr.convc(x).transpose(1, 2)
+        a_inter = torch.softmax(torch.bmm(q, k_inter), dim=-1)
+        a_intra = torch.softmax(torch.bmm(q, k_intra), dim=-1)
+        f = torch.cat([torch.bmm(a_inter, corr.convn(k_inter).transpose(1, 2)), torch.bmm(a_intra, corr.convl(k_intra).transpose(1, 2))], dim=-1)
+        return F.leaky_relu(x + corr.convd(f.transpose(1, 2)), negative_slope=0.2).transpose(1, 2)
+
     def forward(self, depth_feature, z_vals, rays_d, view_feature):
         m, P = self.ref, self.output_ch
         n_ray, S = z_vals.shape[0] // P, z_vals.shape[-1]
@@ -174,7 +235,7 @@ class FusedAWP(torch.nn.Module):
         h = torch.cat([h, view.unsqueeze(1).repeat(1, P, 1)], dim=-1)
         for layer in m.motion_feature_embed_layer:                                # awp.py:107-109
             h = torch.relu(layer(h))
-        h = m.MAM(h, h_local)                                                     # awp.py:111
+        h = self._mam(h, h_local, n_ray, P, S)                                    # awp.py:111
         h = torch.nn.functional.adaptive_avg_pool1d(h.transpose(1, 2), 1).squeeze(-1)
         w = torch.sigmoid(m.w_linear(h))
         return w / torch.sum(w, -1, keepdim=True)

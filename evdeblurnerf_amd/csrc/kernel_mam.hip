@@ -1,0 +1,208 @@
+// AWP consumer, the per-sample part of the MotionAggregationModule: reference networks/dpnerf/mam.py:72-74 (x_local ->
+// self.linear, 64 -> 32 on EVERY sample of every sub-exposure ray) and CorrelationModule.forward :29-33 (a 1x1 attention logit per sample,
+// one softmax along the samples and one along the sub-exposures, the two softmax-weighted sums of the `curves`).  As written that is a
+// Linear over [R P S, 64], a Conv2d, two softmaxes, two multiplies and two reductions over [R, 32, P, S] tensors -- and the same again
+// in the backward.  Because the linear map commutes with the weighted sums (the softmax weights of a row / a column sum to 1) and a
+// constant added to every logit leaves a softmax unchanged,
+//
+//      logit[p,s]         = v . (W h[p,s] + b)         = u . h[p,s] + const,        u = W^T v   (64 floats)
+//      curver_inter[:,p]  = sum_s alpha[p,s] (W h[p,s] + b) = W (sum_s alpha[p,s] h[p,s]) + b,   alpha = softmax over s
+//      curves_intra[:,s]  = sum_p beta[p,s]  (W h[p,s] + b) = W (sum_p beta[p,s]  h[p,s]) + b,   beta  = softmax over p
+//
+// so the per-sample work is ONE dot product and two weighted sums of h_local itself; the 64 -> 32 map is applied by the caller to the
+// [R, P, 64] and [R, S, 64] results (per-ray sized).  h_local [R P, S, 64] float32 is the AWP embedding's output (awp_embed_kernel.h).
+//
+// HBM-bound: the forward reads h_local twice (logits, then sums: the softmax needs every logit of the ray first; a ray's 64 P S floats
+// -- 320 KiB at P = 10, S = 128 -- do not fit the LDS), the backward reads it once and writes d h_local once.
+#include "evd_common.h"
+#include "wave_ops.h"
+
+namespace evd {
+
+constexpr int MAM_C = 64, MAM_MAXP = 16, MAM_MAXS = 512;
+
+// sum over the 16 lanes of a DPP row, left in every lane of the row
+__device__ __forceinline__ float row_sum16(float v) {
+    v += dpp_f32<0xb1>(0.f, v);
+    v += dpp_f32<0x4e>(0.f, v);
+    v += dpp_f32<0x141>(0.f, v);
+    v += dpp_f32<0x140>(0.f, v);
+    return v;
+}
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+__device__ __forceinline__ void fma4(float4& acc, float s, float4 v) {
+    acc.x = fmaf(s, v.x, acc.x); acc.y = fmaf(s, v.y, acc.y); acc.z = fmaf(s, v.z, acc.z); acc.w = fmaf(s, v.w, acc.w);
+}
+
+// One workgroup per ray; 16 row-groups of 16 lanes, a row-group owns the samples s = g, g + 16, ... of EVERY sub-exposure p (so the
+// softmax over p and the intra sum stay inside the group) and a lane 4 of the 64 channels.  A wavefront's four groups read four
+// consecutive samples: 1 KiB contiguous per load instruction.
+__global__ __launch_bounds__(256) void k_mam_local_fwd(const float* __restrict__ h, const float* __restrict__ u, int P, int S,
+                                                       float* __restrict__ h_inter, float* __restrict__ h_intra,
+                                                       float* __restrict__ alpha, float* __restrict__ beta) {
+    extern __shared__ float lds[];
+    float* A = lds;                         // [P][S] logits, then alpha
+    float* Bt = A + P * S;                  // [P][S] beta
+    float* rmax = Bt + P * S;               // [P] row max, [P] row sum
+    float* rsum = rmax + MAM_MAXP;
+    float* red = rsum + MAM_MAXP;           // [4 waves][P][64] partial inter sums
+    const long b = blockIdx.x;
+    const int tid = threadIdx.x, g = tid >> 4, l = tid & 15, wave = tid >> 6, lane = tid & 63;
+    const float4* h4 = reinterpret_cast<const float4*>(h) + b * (long)P * S * 16;
+    const float4 u4 = reinterpret_cast<const float4*>(u)[l];
+
+    for (int s = g; s < S; s += 16) {
+#pragma unroll
+        for (int p = 0; p < MAM_MAXP; ++p)
+            if (p < P) {
+                const float d = row_sum16(dot4(h4[((long)p * S + s) * 16 + l], u4));
+                if (l == 0) A[p * S + s] = d;
+            }
+    }
+    __syncthreads();
+    // the softmax along the samples: one wavefront per sub-exposure
+    for (int p = wave; p < P; p += 4) {
+        float m = -INFINITY;
+        for (int s = lane; s < S; s += 64) m = fmaxf(m, A[p * S + s]);
+        for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float t = 0.f;
+        for (int s = lane; s < S; s += 64) t += __expf(A[p * S + s] - m);
+        t = wave_sum_dpp(t);
+        if (lane == 0) { rmax[p] = m; rsum[p] = t; }
+    }
+    __syncthreads();
+    // the softmax along the sub-exposures: one thread per sample; both weights to LDS and to the saved tensors
+    for (int s = tid; s < S; s += 256) {
+        float m = -INFINITY, t = 0.f;
+        for (int p = 0; p < P; ++p) m = fmaxf(m, A[p * S + s]);
+        for (int p = 0; p < P; ++p) t += __expf(A[p * S + s] - m);
+        const float it = 1.f / t;
+        for (int p = 0; p < P; ++p) {
+            const float a = A[p * S + s];
+            const float al = __expf(a - rmax[p]) / rsum[p], be = __expf(a - m) * it;
+            A[p * S + s] = al;
+            Bt[p * S + s] = be;
+            alpha[(b * P + p) * S + s] = al;
+            beta[(b * P + p) * S + s] = be;
+        }
+    }
+    __syncthreads();
+    float4 accP[MAM_MAXP];
+#pragma unroll
+    for (int p = 0; p < MAM_MAXP; ++p) accP[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = g; s < S; s += 16) {
+        float4 accI = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int p = 0; p < MAM_MAXP; ++p)
+            if (p < P) {
+                const float4 v = h4[((long)p * S + s) * 16 + l];
+                fma4(accI, Bt[p * S + s], v);
+                fma4(accP[p], A[p * S + s], v);
+            }
+        reinterpret_cast<float4*>(h_intra)[(b * S + s) * 16 + l] = accI;
+    }
+    // inter sums: the wavefront's four groups by lane exchange, the four wavefronts through LDS
+#pragma unroll
+    for (int p = 0; p < MAM_MAXP; ++p)
+        if (p < P) {
+            float4 a = accP[p];
+            a.x += __shfl_xor(a.x, 16); a.y += __shfl_xor(a.y, 16); a.z += __shfl_xor(a.z, 16); a.w += __shfl_xor(a.w, 16);
+            a.x += __shfl_xor(a.x, 32); a.y += __shfl_xor(a.y, 32); a.z += __shfl_xor(a.z, 32); a.w += __shfl_xor(a.w, 32);
+            if (lane < 16) reinterpret_cast<float4*>(red)[(wave * P + p) * 16 + l] = a;
+        }
+    __syncthreads();
+    for (int i = tid; i < P * MAM_C; i += 256)
+        h_inter[b * P * MAM_C + i] = red[i] + red[P * MAM_C + i] + red[2 * P * MAM_C + i] + red[3 * P * MAM_C + i];
+}
+
+// Backward.  With gA[p,s] = d_inter[p] . h[p,s], gB[p,s] = d_intra[s] . h[p,s] the two softmax backwards need sum_s alpha gA = d_inter[p] .
+// h_inter[p] and sum_p beta gB = d_intra[s] . h_intra[s]: dots of the SAVED outputs, so h_local is read once:
+//      d logit = alpha (gA - cP[p]) + beta (gB - cI[s]);   d h = alpha d_inter[p] + beta d_intra[s] + d logit u;   d u = sum d logit h
+__global__ __launch_bounds__(256) void k_mam_local_bwd(const float* __restrict__ h, const float* __restrict__ u,
+                                                       const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                       const float* __restrict__ h_inter, const float* __restrict__ h_intra,
+                                                       const float* __restrict__ d_inter, const float* __restrict__ d_intra, int P, int S,
+                                                       float* __restrict__ d_h, float* __restrict__ d_u_partial) {
+    extern __shared__ float lds[];
+    float* dP = lds;                        // [P][64]
+    float* cP = dP + MAM_MAXP * MAM_C;      // [P]
+    float* red = cP + MAM_MAXP;             // [4][64]
+    const long b = blockIdx.x;
+    const int tid = threadIdx.x, g = tid >> 4, l = tid & 15, wave = tid >> 6, lane = tid & 63;
+    const float4* h4 = reinterpret_cast<const float4*>(h) + b * (long)P * S * 16;
+    float4* dh4 = reinterpret_cast<float4*>(d_h) + b * (long)P * S * 16;
+    const float4 u4 = reinterpret_cast<const float4*>(u)[l];
+    for (int i = tid; i < P * MAM_C; i += 256) dP[i] = d_inter[b * P * MAM_C + i];
+    __syncthreads();
+    for (int p = g; p < P; p += 16) {
+        const float c = row_sum16(dot4(reinterpret_cast<const float4*>(dP)[p * 16 + l],
+                                       reinterpret_cast<const float4*>(h_inter)[(b * P + p) * 16 + l]));
+        if (l == 0) cP[p] = c;
+    }
+    __syncthreads();
+    float4 du = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = g; s < S; s += 16) {
+        const float4 dI = reinterpret_cast<const float4*>(d_intra)[(b * S + s) * 16 + l];
+        const float cI = row_sum16(dot4(dI, reinterpret_cast<const float4*>(h_intra)[(b * S + s) * 16 + l]));
+#pragma unroll
+        for (int p = 0; p < MAM_MAXP; ++p)
+            if (p < P) {
+                const long at = ((long)p * S + s) * 16 + l;
+                const float4 v = h4[at];
+                const float4 dp = reinterpret_cast<const float4*>(dP)[p * 16 + l];
+                const float al = alpha[(b * P + p) * S + s], be = beta[(b * P + p) * S + s];
+                const float gA = row_sum16(dot4(dp, v)), gB = row_sum16(dot4(dI, v));
+                const float da = al * (gA - cP[p]) + be * (gB - cI);
+                float4 o;
+                o.x = al * dp.x + be * dI.x + da * u4.x;
+                o.y = al * dp.y + be * dI.y + da * u4.y;
+                o.z = al * dp.z + be * dI.z + da * u4.z;
+                o.w = al * dp.w + be * dI.w + da * u4.w;
+                dh4[at] = o;
+                fma4(du, da, v);
+            }
+    }
+    du.x += __shfl_xor(du.x, 16); du.y += __shfl_xor(du.y, 16); du.z += __shfl_xor(du.z, 16); du.w += __shfl_xor(du.w, 16);
+    du.x += __shfl_xor(du.x, 32); du.y += __shfl_xor(du.y, 32); du.z += __shfl_xor(du.z, 32); du.w += __shfl_xor(du.w, 32);
+    if (lane < 16) reinterpret_cast<float4*>(red)[wave * 16 + l] = du;
+    __syncthreads();
+    if (tid < MAM_C) d_u_partial[b * MAM_C + tid] = red[tid] + red[MAM_C + tid] + red[2 * MAM_C + tid] + red[3 * MAM_C + tid];
+}
+
+}  // namespace evd
+
+using namespace evd;
+
+static int mam_check(const char* who, long R, int P, int S, int C) {
+    EVD_REQUIRE(R >= 0 && P >= 1 && S >= 1, "%s: bad sizes", who);
+    EVD_REQUIRE(C == MAM_C, "%s: %d channels (built: the embedding's %d)", who, C, MAM_C);
+    EVD_REQUIRE(P <= MAM_MAXP && S <= MAM_MAXS, "%s: P = %d, S = %d (built: P <= %d, S <= %d)", who, P, S, MAM_MAXP, MAM_MAXS);
+    return EVD_OK;
+}
+
+int evd_mam_local_forward(const float* h_local, const float* u, long R, int P, int S, int C, float* h_inter, float* h_intra, float* alpha,
+                          float* beta, void* stream) {
+    EVD_REQUIRE(h_local && u && h_inter && h_intra && alpha && beta, "evd_mam_local_forward: null argument");
+    if (int e = mam_check("evd_mam_local_forward", R, P, S, C)) return e;
+    if (R == 0) return EVD_OK;
+    const size_t lds = sizeof(float) * ((size_t)2 * P * S + 2 * MAM_MAXP + (size_t)4 * P * MAM_C);
+    constexpr size_t lds_max = sizeof(float) * ((size_t)2 * MAM_MAXP * MAM_MAXS + 2 * MAM_MAXP + (size_t)4 * MAM_MAXP * MAM_C);
+    EVD_SET_MAX_LDS(k_mam_local_fwd, lds_max);
+    k_mam_local_fwd<<<(unsigned)R, 256, lds, as_stream(stream)>>>(h_local, u, P, S, h_inter, h_intra, alpha, beta);
+    EVD_HIP(hipGetLastError());
+    return EVD_OK;
+}
+
+int evd_mam_local_backward(const float* h_local, const float* u, const float* alpha, const float* beta, const float* h_inter,
+                           const float* h_intra, const float* d_inter, const float* d_intra, long R, int P, int S, int C, float* d_h_local,
+                           float* d_u_partial, void* stream) {
+    EVD_REQUIRE(h_local && u && alpha && beta && h_inter && h_intra && d_inter && d_intra && d_h_local && d_u_partial,
+                "evd_mam_local_backward: null argument");
+    if (int e = mam_check("evd_mam_local_backward", R, P, S, C)) return e;
+    if (R == 0) return EVD_OK;
+    const size_t lds = sizeof(float) * (MAM_MAXP * MAM_C + MAM_MAXP + 4 * MAM_C);
+    k_mam_local_bwd<<<(unsigned)R, 256, lds, as_stream(stream)>>>(h_local, u, alpha, beta, h_inter, h_intra, d_inter, d_intra, P, S, d_h_local,
+                                                                  d_u_partial);
+    EVD_HIP(hipGetLastError());
+    return EVD_OK;
+}

@@ -399,6 +399,21 @@ int evd_awp_feature_integration(const float* feat, const float* z, const float* 
 int evd_awp_feature_integration_bwd(const float* feat, const float* z, const float* rays_d, const float* d_out, long N, int S, int C,
                                     float* d_feat, float* d_z, float* d_rays_d, void* stream);
 
+/* MotionAggregationModule / CorrelationModule, the per-sample part (networks/dpnerf/mam.py:72-74: self.linear on x_local = h_local
+ * [R P, S, 64]; :29-33: line_conv_att, softmax over the samples (dim -1) and over the sub-exposures (dim -2), the two weighted sums).
+ * The linear map commutes with the softmax-weighted sums and a constant leaves a softmax unchanged, so with u = W^T v dev [64]
+ * (W = MAM.linear.weight [32,64], v = Corr.line_conv_att.weight [32]):  logit = u . h_local;  alpha = softmax_s, beta = softmax_p;
+ * h_inter dev [R,P,64] = sum_s alpha h_local, h_intra dev [R,S,64] = sum_p beta h_local -- the caller applies W, b to those
+ * (curver_inter = W h_inter + b, curves_intra = W h_intra + b, mam.py:31-32).  alpha, beta dev [R,P,S] are kept for the backward.
+ * C must be 64 (the embedding's width), P <= 16, S <= 512. */
+int evd_mam_local_forward(const float* h_local, const float* u, long R, int P, int S, int C, float* h_inter, float* h_intra, float* alpha,
+                          float* beta, void* stream);
+/* Its backward (torch.autograd behind mam.py:29-33,72-74 in training, run_nerf.py:593-601): d h_inter dev [R,P,64], d h_intra dev
+ * [R,S,64] -> d h_local dev [R P, S, 64] (written, not accumulated) and d u as per-ray partials dev [R,64] (the caller sums them). */
+int evd_mam_local_backward(const float* h_local, const float* u, const float* alpha, const float* beta, const float* h_inter,
+                           const float* h_intra, const float* d_inter, const float* d_intra, long R, int P, int S, int C, float* d_h_local,
+                           float* d_u_partial, void* stream);
+
 /* AdaptiveWeightProposal.sample_feature_embed_layer (networks/dpnerf/awp.py:36-37: D_sam x nn.Linear; :98-100: each followed by ReLU)
  * fused into one MFMA kernel that reads the fine level's geo features WHERE THEY ALREADY ARE: the reference writes them as
  * depth_feature [R P, S, 128] float32 (renderer.py:253-256) and runs four torch Linear + ReLU passes over it (:314); here the

@@ -956,6 +956,54 @@ void evo_awp_sample_embed(const float* x, const float* const* W, const float* co
     }
 }
 
+/* MotionAggregationModule.forward, mam.py:72-74 (curves = self.linear(x_local), [R, P, S, 64] -> [R, P, S, M]) and CorrelationModule.forward,
+ * mam.py:29-33, AS WRITTEN: curves_att = line_conv_att(curves) (a 1x1 convolution without bias: v . curves), softmax over the samples
+ * (dim -1) and over the sub-exposures (dim -2), curver_inter [R, M, P] = sum_s curves softmax_s, curves_intra [R, M, S] = sum_p curves
+ * softmax_p.  x_local [R P, S, C]; W [M, C], b [M] (nn.Linear), v [M]. */
+void evo_mam_local(const float* x_local, const float* W, const float* b, const float* v, long R, int P, int S, int Cc, int M, float* inter,
+                   float* intra) {
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < R; ++r) {
+        float* cur = (float*)malloc(sizeof(float) * (size_t)P * S * M);
+        float* att = (float*)malloc(sizeof(float) * (size_t)P * S);
+        for (int p = 0; p < P; ++p)
+            for (int s = 0; s < S; ++s) {
+                const float* x = x_local + (((size_t)r * P + p) * S + s) * Cc;
+                float a = 0.f;
+                for (int m = 0; m < M; ++m) {
+                    float acc = 0.f;
+                    for (int c = 0; c < Cc; ++c) acc += x[c] * W[(size_t)m * Cc + c];
+                    acc += b[m];
+                    cur[((size_t)p * S + s) * M + m] = acc;
+                    a += v[m] * acc;
+                }
+                att[p * S + s] = a;
+            }
+        for (int p = 0; p < P; ++p) {                       /* softmax(dim=-1), sum over the samples */
+            float mx = -INFINITY, den = 0.f;
+            for (int s = 0; s < S; ++s) mx = fmaxf(mx, att[p * S + s]);
+            for (int s = 0; s < S; ++s) den += expf(att[p * S + s] - mx);
+            for (int m = 0; m < M; ++m) {
+                float acc = 0.f;
+                for (int s = 0; s < S; ++s) acc += cur[((size_t)p * S + s) * M + m] * (expf(att[p * S + s] - mx) / den);
+                inter[((size_t)r * M + m) * P + p] = acc;
+            }
+        }
+        for (int s = 0; s < S; ++s) {                       /* softmax(dim=-2), sum over the sub-exposures */
+            float mx = -INFINITY, den = 0.f;
+            for (int p = 0; p < P; ++p) mx = fmaxf(mx, att[p * S + s]);
+            for (int p = 0; p < P; ++p) den += expf(att[p * S + s] - mx);
+            for (int m = 0; m < M; ++m) {
+                float acc = 0.f;
+                for (int p = 0; p < P; ++p) acc += cur[((size_t)p * S + s) * M + m] * (expf(att[p * S + s] - mx) / den);
+                intra[((size_t)r * M + m) * S + s] = acc;
+            }
+        }
+        free(cur);
+        free(att);
+    }
+}
+
 /* ------------------------------------------------------------------ RBK ray warp
  * SE3Field.get_transform (rigid_warping.py:18-30): theta = |rot| + 1e-10, screw axis (rot, trans) / theta;
  * RigidBody.exp_se3 (:72-91): R = I + sin(theta) W + (1 - cos(theta)) W^2 (Rodrigues, :93-107),

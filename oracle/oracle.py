@@ -365,6 +365,17 @@ def awp_sample_embed(x, weights, biases):
     return out
 
 
+def mam_local(x_local, W, b, v, P):
+    """x_local [R P, S, C], MAM.linear W [M, C] / b [M], Corr.line_conv_att v [M] -> curver_inter [R, M, P], curves_intra [R, M, S]
+    (mam.py:72-74, 29-33 as written)"""
+    x, W, b, v = _f(x_local), _f(W), _f(b), _f(np.asarray(v).reshape(-1))
+    RP, S, Cc = x.shape
+    R, M = RP // P, W.shape[0]
+    inter, intra = np.empty((R, M, P), np.float32), np.empty((R, M, S), np.float32)
+    lib().evo_mam_local(_p(x), _p(W), _p(b), _p(v), C.c_long(R), P, S, Cc, M, _p(inter), _p(intra))
+    return inter, intra
+
+
 def crf_forward(crf: Crf, x, feat=None, skip_learn=False):
     x = _f(x)
     n = x.shape[0]

@@ -266,3 +266,116 @@ def test_fused_awp_module_in_the_training_forward():
             p.mul_(1.5)
     w1, w1_ref = fused(x, z, rd, vf), ref(x, z, rd, vf)
     assert (w1 - w0).abs().max().item() > 1e-4 and (w1 - w1_ref).abs().max().item() < 2e-3
+
+
+# ------------------------------------------------------------------------------------------------ the MAM's per-sample part
+from awp_standin import MAMLike as _MAMLike  # noqa: E402  (pinned to the reference's module by tests/test_oracle_golden.py::test_G22_mam)
+
+
+def _t(a):
+    return torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+
+
+_rel = rel_l2
+
+
+def _mam_inputs(seed, R, P, S):
+    rs = np.random.RandomState(seed)
+    x_local = np.maximum(rs.standard_normal((R * P, S, 64)), 0).astype(np.float32)
+    Wl = (rs.standard_normal((32, 64)) * 0.125).astype(np.float32)
+    bl = (rs.standard_normal((32,)) * 0.1).astype(np.float32)
+    v = (rs.standard_normal((1, 32, 1, 1)) * 0.5).astype(np.float32)
+    return x_local, Wl, bl, v
+
+
+@pytest.mark.parametrize("R,P,S", [(7, 10, 128), (3, 5, 64), (2, 1, 33), (2, 16, 200)])
+def test_mam_local_equals_the_oracle(O, R, P, S):
+    """evd_mam_local_forward + the caller's 64 -> 32 map against the oracle's as-written linear / logit / softmax / sums (mam.py:72-74,
+    29-33); the kept softmax weights sum to 1 along their axis.  Float32: 2e-5 of the largest value."""
+    from evdeblurnerf_amd.awp import mam_local
+    x_local, Wl, bl, v = _mam_inputs(31 + P, R, P, S)
+    hi, hs = mam_local(_t(x_local), _t(Wl), _t(v), R, P, S)
+    inter = torch.nn.functional.linear(hi, _t(Wl), _t(bl)).transpose(1, 2).cpu().numpy()
+    intra = torch.nn.functional.linear(hs, _t(Wl), _t(bl)).transpose(1, 2).cpu().numpy()
+    o_inter, o_intra = O.mam_local(x_local, Wl, bl, v, P)
+    assert np.abs(inter - o_inter).max() < 2e-5 * max(1.0, np.abs(o_inter).max())
+    assert np.abs(intra - o_intra).max() < 2e-5 * max(1.0, np.abs(o_intra).max())
+
+
+def test_mam_local_against_the_reference_golden():
+    """G22 (the reference's MotionAggregationModule, run by tools/gen_golden.py): the kernel's sums through the module's own linear
+    against the tensors the real module handed to Corr.conva / Corr.convb, and FusedAWP's restatement of the whole MAM (per-sample part
+    on the library, the rest on the module's layers) against its output and autograd gradients."""
+    from evdeblurnerf_amd.awp import mam_local, FusedAWP
+    g = load_golden("G22_mam")
+    R, P = g["x_global"].shape[:2]
+    S = g["x_local"].shape[1]
+    Wl, bl, v = _t(g["sd.linear.weight"]), _t(g["sd.linear.bias"]), _t(g["sd.Corr.line_conv_att.weight"])
+    hi, hs = mam_local(_t(g["x_local"]), Wl, v, R, P, S)
+    inter = torch.nn.functional.linear(hi, Wl, bl).transpose(1, 2).cpu().numpy()
+    intra = torch.nn.functional.linear(hs, Wl, bl).transpose(1, 2).cpu().numpy()
+    assert np.abs(inter - g["inter"]).max() < 2e-5 * max(1.0, np.abs(g["inter"]).max())
+    assert np.abs(intra - g["intra"]).max() < 2e-5 * max(1.0, np.abs(g["intra"]).max())
+    mam = _MAMLike(32, P - 1).train()
+    mam.load_state_dict({k[3:]: torch.tensor(g[k]) for k in g if k.startswith("sd.")}, strict=True)
+    holder = _RefLikeAWP(P=P, mam="corr").cuda()
+    holder.MAM = mam.cuda()
+    fused = FusedAWP(holder, "f16")
+    xg, xl = _t(g["x_global"]).requires_grad_(True), _t(g["x_local"]).requires_grad_(True)
+    out = fused._mam(xg, xl, R, P, S)
+    assert np.abs(out.detach().cpu().numpy() - g["out"]).max() < 5e-5
+    ps = [mam.linear.weight, mam.Corr.line_conv_att.weight]
+    grads = torch.autograd.grad((out * _t(g["proj"])).sum(), [xg, xl] + ps)
+    for got, key in zip(grads, ["g.x_global", "g.x_local", "g.linear.weight", "g.line_conv_att.weight"]):
+        assert _rel(got.cpu().numpy(), g[key]) < 5e-5, key
+
+
+@pytest.mark.parametrize("R,P,S", [(5, 10, 128), (3, 4, 40)])
+def test_mam_local_backward_equals_float64_autograd(R, P, S):
+    """evd_mam_local_backward against torch.autograd of the as-written float64 formula (linear, logit, two softmaxes, two sums) for
+    d x_local, d linear.weight and d line_conv_att.weight.  Float32 kernels: 2e-5 relative L2."""
+    from evdeblurnerf_amd.awp import mam_local
+    x_local, Wl, bl, v = _mam_inputs(57 + P, R, P, S)
+    rs = np.random.RandomState(5)
+    pi, ps_ = rs.standard_normal((R, 32, P)), rs.standard_normal((R, 32, S))
+    x64 = torch.tensor(x_local, dtype=torch.float64, requires_grad=True)
+    W64 = torch.tensor(Wl, dtype=torch.float64, requires_grad=True)
+    b64 = torch.tensor(bl, dtype=torch.float64)
+    v64 = torch.tensor(v.reshape(-1), dtype=torch.float64, requires_grad=True)
+    cur = (x64.reshape(R, P, S, 64) @ W64.t() + b64).permute(0, 3, 1, 2)                 # [R, 32, P, S]
+    att = (cur * v64[None, :, None, None]).sum(1, keepdim=True)
+    l64 = ((cur * att.softmax(-1)).sum(-1) * torch.tensor(pi)).sum() + ((cur * att.softmax(-2)).sum(-2) * torch.tensor(ps_)).sum()
+    want = torch.autograd.grad(l64, [x64, W64, v64])
+    xg, Wg, vg = _t(x_local).requires_grad_(True), _t(Wl).requires_grad_(True), _t(v).requires_grad_(True)
+    hi, hs = mam_local(xg, Wg, vg, R, P, S)
+    inter = torch.nn.functional.linear(hi, Wg, _t(bl)).transpose(1, 2)
+    intra = torch.nn.functional.linear(hs, Wg, _t(bl)).transpose(1, 2)
+    got = torch.autograd.grad((inter * _t(pi.astype(np.float32))).sum() + (intra * _t(ps_.astype(np.float32))).sum(), [xg, Wg, vg])
+    for a, b, name in zip(got, want, ("x_local", "linear.weight", "line_conv_att.weight")):
+        assert _rel(a.cpu().numpy().reshape(-1), b.numpy().reshape(-1)) < 2e-5, name
+
+
+def test_fused_awp_with_the_reference_mam_structure_equals_plain_torch():
+    """FusedAWP around a module with the reference's MotionAggregationModule structure (MAMLike): output and parameter gradients
+    against the same module run in plain float32 torch on the float32 depth_feature tensor.  Half-precision embedding: 2e-2."""
+    from evdeblurnerf_amd.awp import FusedAWP
+    torch.manual_seed(3)
+    P, R, S = 5, 64, 64
+    ref = _RefLikeAWP(P=P, mam="corr").cuda()
+    rs = np.random.RandomState(9)
+    df = _t((rs.standard_normal((R * P, S, 128)) * 0.5).astype(np.float32))
+    z = _t(np.sort(rs.uniform(0, 1, (R * P, S)).astype(np.float32), -1))
+    d = _t(rs.standard_normal((R * P, 3)).astype(np.float32))
+    vf = _t(rs.standard_normal((R, 4)).astype(np.float32))
+    proj = _t(rs.standard_normal((R, P)).astype(np.float32))
+    names = [n_ for n_, _ in ref.named_parameters()]
+    want_out = ref(df, z, d, vf)
+    want = torch.autograd.grad((want_out * proj).sum(), list(ref.parameters()), allow_unused=True)
+    fused = FusedAWP(ref, "f16")
+    got_out = fused(df, z, d, vf)
+    got = torch.autograd.grad((got_out * proj).sum(), list(ref.parameters()), allow_unused=True)
+    assert np.abs((got_out - want_out).detach().cpu().numpy()).max() < 2e-3
+    for n_, a, b in zip(names, got, want):
+        if b is None or float(b.abs().max()) < 1e-6:
+            continue
+        assert _rel(a.cpu().numpy(), b.cpu().numpy()) < 2e-2, n_

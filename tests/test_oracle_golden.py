@@ -403,3 +403,33 @@ def test_G19_c2f_gradients_of_the_restatement_match_the_reference():
             else:
                 got = levels[name].p[rest.replace(".", "_")].grad
         _check_grad(got.numpy(), g, key, idx)
+
+
+def test_G22_mam():
+    """G22: the reference's MotionAggregationModule run in training mode.  (a) the oracle's per-sample part (evo_mam_local: mam.py:72-74,
+    29-33 as written) against the inputs the real module handed to Corr.conva / Corr.convb; (b) tools/awp_standin.py MAMLike -- the
+    plain-torch module the GPU tests compare FusedAWP with, where the reference cannot be imported -- loads the reference's state dict
+    and reproduces its output and its autograd gradients."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from awp_standin import MAMLike
+    g = load_golden("G22_mam")
+    R, P = g["x_global"].shape[:2]
+    inter, intra = O.mam_local(g["x_local"], g["sd.linear.weight"], g["sd.linear.bias"], g["sd.Corr.line_conv_att.weight"], P)
+    assert maxabs(inter, g["inter"]) < 1e-5 * max(1.0, np.abs(g["inter"]).max())
+    assert maxabs(intra, g["intra"]) < 1e-5 * max(1.0, np.abs(g["intra"]).max())
+    mam = MAMLike(32, P - 1).train()
+    mam.load_state_dict({k[3:]: torch.tensor(g[k]) for k in g if k.startswith("sd.")}, strict=True)
+    xg = torch.tensor(g["x_global"], requires_grad=True)
+    xl = torch.tensor(g["x_local"], requires_grad=True)
+    out = mam(xg, xl)
+    assert maxabs(out.detach().numpy(), g["out"]) < 2e-5
+    ps = [mam.linear.weight, mam.linear.bias, mam.Corr.line_conv_att.weight]
+    grads = torch.autograd.grad((out * torch.tensor(g["proj"])).sum(), [xg, xl] + ps)
+    for got, key in zip(grads, ["g.x_global", "g.x_local", "g.linear.weight", "g.linear.bias", "g.line_conv_att.weight"]):
+        if key == "g.linear.bias":      # analytically zero (a constant added to every curve is removed by the training-mode BatchNorm): noise
+            assert np.abs(got.numpy()).max() < 1e-4 and np.abs(g[key]).max() < 1e-4
+            continue
+        assert np.linalg.norm(got.numpy() - g[key]) < 2e-5 * np.linalg.norm(g[key]), key

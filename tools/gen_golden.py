@@ -779,10 +779,45 @@ def G21_awp_sample_embed():
     save("G21_awp_sample_embed", **res)
 
 
+def G22_mam():
+    """MotionAggregationModule.forward (networks/dpnerf/mam.py:66-83, CorrelationModule.forward :27-53) in training mode (BatchNorm on
+    the batch statistics, as under run_nerf.py's train loop): x_global [R, P, 32], x_local [R P, S, 64] -> [R, P, 32].  Forward
+    pre-hooks on Corr.conva / Corr.convb capture curver_inter [R, 32, P] and curves_intra [R, 32, S] (the results of the per-sample
+    part, mam.py:29-33); torch.autograd gradients of a fixed projection of the output w.r.t. both inputs and the per-sample part's
+    parameters."""
+    from networks.dpnerf.mam import MotionAggregationModule
+    torch.manual_seed(22)
+    M = 3
+    mam = MotionAggregationModule(in_channels=32, k=3, num_motion=M)
+    mam.train()
+    rs = np.random.RandomState(221)
+    R, P, S = 5, M + 1, 24
+    x_global = rs.standard_normal((R, P, 32)).astype(np.float32)
+    x_local = np.maximum(rs.standard_normal((R * P, S, 64)), 0).astype(np.float32)        # a ReLU output, like h_local
+    proj = rs.standard_normal((R, P, 32)).astype(np.float32)
+    cap = {}
+    h1 = mam.Corr.conva.register_forward_pre_hook(lambda m, i: cap.__setitem__("inter", i[0]))
+    h2 = mam.Corr.convb.register_forward_pre_hook(lambda m, i: cap.__setitem__("intra", i[0]))
+    with torch.enable_grad():
+        xg, xl = t(x_global).requires_grad_(True), t(x_local).requires_grad_(True)
+        out = mam(xg, xl)
+        loss = (out * t(proj)).sum()
+        params = [mam.linear.weight, mam.linear.bias, mam.Corr.line_conv_att.weight]
+        grads = torch.autograd.grad(loss, [xg, xl] + params)
+    h1.remove()
+    h2.remove()
+    res = {"x_global": x_global, "x_local": x_local, "proj": proj, "out": n(out), "inter": n(cap["inter"]), "intra": n(cap["intra"]),
+           "g.x_global": n(grads[0]), "g.x_local": n(grads[1]), "g.linear.weight": n(grads[2]), "g.linear.bias": n(grads[3]),
+           "g.line_conv_att.weight": n(grads[4])}
+    for k, v in mam.state_dict().items():
+        res["sd." + k] = n(v)
+    save("G22_mam", **res)
+
+
 ALL = [G1_embedder, G2_nerf_mlp, G3_nerf_raw2outputs, G4_voxel_raw2outputs, G5_sample_pdf, G6_rays,
        G7_render_nerf, G8_appfeature, G9_render_c2f, G10_rbk_weighted_sum, G11_crf, G12_egm_loss, G13_edi,
        G14_loss_assembly, G15_awp_feature_integration, G16_rbk_warp, G17_compute_successor, G18_nerf_grads, G19_c2f_grads, G20_loss_grads,
-       G21_awp_sample_embed]
+       G21_awp_sample_embed, G22_mam]
 
 if __name__ == "__main__":
     want = set(sys.argv[1:])
