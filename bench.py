@@ -147,6 +147,9 @@ def time_steps(fn, steps, warmup, dist=None, drain=None, device="cuda"):
     barrier = (lambda: dist.barrier()) if dist else (lambda: None)
     for _ in range(warmup):
         fn()
+    import gc
+    gc.collect()
+    gc.disable()                 # the timed region is tens of milliseconds: one collector pause inside it would be a visible fraction
     barrier()
     _sync()
     t0 = time.perf_counter()
@@ -157,6 +160,7 @@ def time_steps(fn, steps, warmup, dist=None, drain=None, device="cuda"):
     barrier()
     _sync()
     dt = time.perf_counter() - t0
+    gc.enable()
     if dist:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -323,7 +327,15 @@ def awp_leg(precision):
     n = R * S
     tile_bytes = (8 + 8 + 16) * 1024 + 32 * 64 * 4            # geo fragments in, geo copy + 4 activations out (training), h_local rows out
     algo = (n // 32) * tile_bytes
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import bench_mam
+    mam = bench_mam.run(1024, 10, 128)                           # the MotionAggregationModule's per-sample part (mam.py:72-74, 29-33)
+    mam["roofline"] = {"kernel": "k_mam_local_fwd / k_mam_local_bwd", "bound": "hbm", "algorithmic_bytes": 2 * mam["h_local_bytes"],
+                       "achieved": [mam["fwd_GBps"], mam["bwd_GBps"]], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": [mam["fwd_GBps"] / HBM_PEAK_GBS, mam["bwd_GBps"] / HBM_PEAK_GBS],
+                       "note": "forward: h_local read twice (logits, then the two softmax-weighted sums); backward: read once, d h_local written once"}
     return {"workload": "AWP consumer, blurfactory blur batch: 10 240 sub-exposure rays x 128 samples, sample_feature_embed_layer 128-64-64-64-64 + feature_integration",
+            "mam_per_sample_part": mam,
             "precision": precision, "fine_level_fwd_bwd_ms": t0, "with_awp_torch_linear_on_depth_feature_ms": t1, "with_awp_fused_on_geo_fragments_ms": t2,
             "awp_addon_ms": {"torch": t1 - t0, "fused": t2 - t0}, "depth_feature_tensor_avoided_bytes": n * 128 * 4,
             "roofline": {"kernel": "k_awp_embed (training forward, geo fragments in)", "bound": "hbm", "kernel_ms": k_ms, "algorithmic_bytes": algo,
@@ -347,10 +359,11 @@ def train_iteration_leg(precision):
     ms, nrays, _ = BT.run(types.SimpleNamespace(precision=precision, iters=10, pixels=1024, events=4096, P=10))
     torch.cuda.empty_cache()
     # the same iteration with the shipped configs' adaptive weight proposal on the blur batch (kernel_use_awp): the per-sample part fused
-    # on the fine level's geo fragments (awp.FusedAWP) vs the module's plain PyTorch forward on depth_feature [R P, S, 128]
-    ms_awp_f, _, _ = BT.run(types.SimpleNamespace(precision=precision, iters=5, pixels=1024, events=4096, P=10, awp="fused"))
+    # on the fine level's geo fragments (awp.FusedAWP: embedding MLP, scan, the MotionAggregationModule's per-sample part) vs the module's
+    # plain PyTorch forward on depth_feature [R P, S, 128]; the module has the reference's structure (tools/awp_standin.py, mam="corr")
+    ms_awp_f, _, _ = BT.run(types.SimpleNamespace(precision=precision, iters=5, pixels=1024, events=4096, P=10, awp="fused", mam="corr"))
     torch.cuda.empty_cache()
-    ms_awp_t, _, _ = BT.run(types.SimpleNamespace(precision=precision, iters=5, pixels=1024, events=4096, P=10, awp="torch"))
+    ms_awp_t, _, _ = BT.run(types.SimpleNamespace(precision=precision, iters=5, pixels=1024, events=4096, P=10, awp="torch", mam="corr"))
     torch.cuda.empty_cache()
     aabb = ([-1.5, -1.5, -1.0], [1.5, 1.5, 1.0])
     fv = 134217984

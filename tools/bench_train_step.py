@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--awp", choices=["none", "fused", "torch"], default="none",
                     help="the shipped configs' adaptive weight proposal on the blur batch (kernel_use_awp): fused = evdeblurnerf_amd.awp.FusedAWP around a "
                          "module with the reference's surface (tools/awp_standin.py), torch = that module's plain PyTorch forward on depth_feature")
+    ap.add_argument("--mam", choices=["mean", "corr"], default="corr",
+                    help="the AWP module's motion aggregation: corr = the reference's MotionAggregationModule structure (MAMLike), mean = a small stand-in")
     a = ap.parse_args()
     ms, nr, loss = run(a)
     print(f"blurfactory TRAINING iteration [{a.precision}]: {nr} rays x (64 + 64) samples, losses, TV, backward, Adam, re-pack: {ms:.2f} ms "
@@ -75,7 +77,7 @@ def run(a):
     if awp_mode != "none":
         from awp_standin import RefLikeAWP
         from evdeblurnerf_amd.awp import FusedAWP
-        awpnet = RefLikeAWP(P=a.P, view_ch=4).to(dev)
+        awpnet = RefLikeAWP(P=a.P, view_ch=4, mam=getattr(a, "mam", "mean")).to(dev)
         if awp_mode == "fused":
             awpnet = FusedAWP(awpnet, precision=a.precision if a.precision in ("f16", "bf16") else "f16")
     model = NeRFAll(args, sd, kernelsnet=kern, awpnet=awpnet, precision=a.precision).enable_training(sd).train()
