@@ -21,6 +21,13 @@ LIB = os.path.join(LIBDIR, "libevdnerf.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
+# Per-file flags.  The one-wavefront-per-SIMD MLP kernels (f16c: 386 registers, f16x3: 420) keep part of their state in AGPRs; by default
+# hipcc puts the MFMA accumulators there, and every epilogue value then costs a v_accvgpr_read (plus a write-back for the values that stay).
+# With the MFMAs in VGPR form the accumulators live in VGPRs and the MFMA-only operands (fp6 blocks, weight fragments) go to the AGPRs, which
+# the matrix core reads directly: f16c 5708 -> 4802 VALU instructions per wavefront, 0.879 -> 0.857 ms; f16x3 1.58 -> 1.53 ms
+# (tools/run_lib_variants.sh; the two-wavefront kernels and the training / scatter kernels do not change or get slower with it).
+VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+PER_FILE = {"kernel_nerf_mlp_pipe_f16c.hip": VGPR_FORM, "kernel_nerf_mlp_pipe_f16x3.hip": VGPR_FORM}
 
 
 def hipcc() -> str:
@@ -37,6 +44,7 @@ def sources():
 def headers():
     hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hs.append(os.path.join(os.path.dirname(HERE), "include", "evdnerf.h"))
+    hs.append(os.path.abspath(__file__))          # the flags live here
     return hs
 
 
@@ -48,7 +56,7 @@ def _stale(target, deps):
 
 
 def _compile(src, obj, extra):
-    cmd = [hipcc(), *FLAGS, *extra, "-c", src, "-o", obj]
+    cmd = [hipcc(), *FLAGS, *PER_FILE.get(os.path.basename(src), []), *extra, "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {os.path.basename(src)}:\n{r.stdout}\n{r.stderr}")

@@ -54,12 +54,17 @@ struct CCfg {
 #else
     static constexpr int NSLOT = 4;                          // ring slots: 2 chunks resident, NSLOT - 2 in flight (8 slots measured: no faster, the kernel is LDS-bandwidth-bound)
 #endif
+#ifdef EVD_C_BARP
+    static constexpr int BARP = EVD_C_BARP;
+#else
+    static constexpr int BARP = 1;                           // chunks per barrier (2 needs NSLOT >= 8)
+#endif
     static constexpr int PDM = 4;                            // ring of prefetched float16 A fragments: PDM - 1 MFMAs ahead (8: no faster)
     static constexpr int SAMPLES = NW * 32;
     static constexpr int RING = NSLOT * CB;
     static constexpr int BIAS_WORDS = 5120;                  // biases (32 floats per tile) followed by the row-scale words (32 per tile)
     static constexpr int TOTAL = RING + BIAS_WORDS * 4;
-    static_assert((NSLOT & (NSLOT - 1)) == 0 && NSLOT >= 4 && TOTAL <= 160 * 1024, "ring geometry");
+    static_assert((NSLOT & (NSLOT - 1)) == 0 && NSLOT >= 4 && NSLOT - BARP >= BARP + 1 && NSLOT - BARP >= 3 && TOTAL <= 160 * 1024, "ring geometry");
 };
 
 // Weight stream of this mode: the ring protocol of mlp_pipe.h's PStream (two chunks resident, counted vmcnt, one barrier per 16 KiB
@@ -70,11 +75,18 @@ struct CCfg {
 // Issue: the chunk's source is  SGPR base + 32-bit lane offset  (one v_add per chunk instead of a 64-bit add per piece); M0 is set and
 // not restored (nothing else in the kernel reads M0): 8 instructions per chunk and wavefront.
 template <int NCH> struct CStream {
-    static constexpr int kChunks = NCH, NSLOT = CCfg::NSLOT;
+    static constexpr int kChunks = NCH, NSLOT = CCfg::NSLOT, BARP = CCfg::BARP;
+    // BARP chunks per barrier: the barrier behind chunk c (c + 1 a multiple of BARP) releases the slots of every chunk <= c and must find
+    // chunks c + 1 .. c + BARP + 1 landed (chunk c + BARP reads ahead into c + BARP + 1 before the next barrier); the DMA runs AHEAD =
+    // NSLOT - BARP chunks in front, into the slot of chunk c - BARP, which the last barrier has released whatever c's phase.
+    static constexpr int AHEAD = NSLOT - BARP;
     const char* gbase;      // stream base (wave-uniform)
     const char* rd_base;    // ring base + 16 * lane (fragment reads)
     unsigned voff;          // this lane's byte offset of piece 0 of chunk 0
     unsigned dst0;          // LDS byte offset of this wavefront's piece 0 in slot 0 (wave-uniform)
+#ifdef EVD_C_STAMP          // developer build: shader-clock cycles this wavefront spends in the vmcnt wait / in the barrier of chunk_end
+    long long tw = 0, tb = 0;
+#endif
     static_assert(CCfg::PIECES == 4, "four 1 KiB pieces per wavefront per chunk");
     __device__ __forceinline__ void issue(int c) {          // c is a compile-time constant at every call site
         const unsigned off = voff + (unsigned)c * CCfg::CB;
@@ -111,18 +123,29 @@ template <int NCH> struct CStream {
         rd_base = ring + lane * 16;
         dst0 = __builtin_amdgcn_readfirstlane(lds_offset_of(ring) + wave * (CCfg::PIECES * 1024));
 #pragma unroll
-        for (int c = 0; c < NSLOT - 1; ++c)
+        for (int c = 0; c < AHEAD; ++c)
             if (c < NCH) issue(c);
     }
-    __device__ __forceinline__ void start_wait() {      // chunks 0 and 1 landed
-        wait_chunks(cmax(0, cmin(NSLOT - 1, NCH) - 2));
+    __device__ __forceinline__ void start_wait() {      // chunks 0 .. BARP landed
+        wait_chunks(cmax(0, cmin(AHEAD, NCH) - (BARP + 1)));
         __syncthreads();
     }
-    __device__ __forceinline__ void chunk_begin(int c) { if (c + NSLOT - 1 < NCH && !(kAbl & 8)) issue(c + NSLOT - 1); }
+    __device__ __forceinline__ void chunk_begin(int c) { if (c + AHEAD < NCH && !(kAbl & 8)) issue(c + AHEAD); }
     __device__ __forceinline__ void chunk_end(int c) {
+        if ((c + 1) % BARP != 0) return;
         if (kAbl & 4) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        wait_chunks((kAbl & 8) ? 0 : cmax(0, cmin(c + NSLOT - 1, NCH - 1) - (c + 2)));
+#ifdef EVD_C_STAMP
+        const long long t0 = __builtin_readcyclecounter();
+#endif
+        wait_chunks((kAbl & 8) ? 0 : cmax(0, cmin(c + AHEAD, NCH - 1) - (c + BARP + 1)));
+#ifdef EVD_C_STAMP
+        const long long t1 = __builtin_readcyclecounter();
+#endif
         if (!(kAbl & 16)) __builtin_amdgcn_s_barrier();
+#ifdef EVD_C_STAMP
+        const long long t2 = __builtin_readcyclecounter();
+        tw += t1 - t0; tb += t2 - t1;
+#endif
         asm volatile("" ::: "memory");
     }
 };
@@ -322,10 +345,10 @@ __device__ __forceinline__ void c_group(ST& st, CPipe& pp, XBlk (&in)[NIN], XBlk
 #ifndef EVD_C_NOSPREAD      // (all four pieces at the chunk's second unit: 1.4 % slower)
         auto due = [](int t) constexpr { return cmin(CCfg::PIECES, (t + 1) / 3); };      // pieces issued once t units of the chunk are consumed: at 2, 5, 8, 11
         auto pieces = [&](int c, int k0, int k1) __attribute__((always_inline)) {
-            if (c + ST::NSLOT - 1 >= ST::kChunks || (kAbl & 8)) return;
+            if (c + ST::AHEAD >= ST::kChunks || (kAbl & 8)) return;
 #pragma unroll
             for (int k = 0; k < CCfg::PIECES; ++k)
-                if (k >= k0 && k < k1) st.issue_piece(c + ST::NSLOT - 1, k);
+                if (k >= k0 && k < k1) st.issue_piece(c + ST::AHEAD, k);
         };
         if (c0 == c1) {
             pieces(L::CHUNK0 + c0, due(t0 % CCfg::UPC), due(t1 % CCfg::UPC));
@@ -459,9 +482,9 @@ __device__ __forceinline__ void c_layer(ST& st, CPipe& pp, XBlk (&in)[NIN], XBlk
     if (L::UNITS % CCfg::UPC != 0) {             // the zero-padded tail of the layer's last chunk
 #ifndef EVD_C_NOSPREAD
         constexpr int c = L::CHUNK0 + L::UNITS / CCfg::UPC, k0 = cmin(CCfg::PIECES, (L::UNITS % CCfg::UPC + 1) / 3);
-        if (c + ST::NSLOT - 1 < ST::kChunks && !(kAbl & 8)) {
+        if (c + ST::AHEAD < ST::kChunks && !(kAbl & 8)) {
 #pragma unroll
-            for (int k = k0; k < CCfg::PIECES; ++k) st.issue_piece(c + ST::NSLOT - 1, k);
+            for (int k = k0; k < CCfg::PIECES; ++k) st.issue_piece(c + ST::AHEAD, k);
         }
 #endif
         st.chunk_end(L::CHUNK0 + L::UNITS / CCfg::UPC);

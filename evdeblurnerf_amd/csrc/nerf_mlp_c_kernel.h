@@ -102,6 +102,9 @@ __global__ __launch_bounds__(CCfg::NT, 1) void k_nerf_mlp_c(const MlpParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     pipe_fp16_saturate<EVD_PREC_F16>();
+#ifdef EVD_C_STAMP
+    const long long t_start = __builtin_readcyclecounter();
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, h = lane >> 5;
     NerfCtxC<N, ST> cx;
@@ -186,7 +189,10 @@ __global__ __launch_bounds__(CCfg::NT, 1) void k_nerf_mlp_c(const MlpParams p) {
     c_layer<typename N::Rgb, void, ST, KB / 2, 1>(cx.st, cx.pp, hbuf, none, rraw, lb, lane);
 
     if (h == 0 && valid && (!FUSE || p.raw)) {
-        const f32x4 o = {rraw[0], rraw[1], rraw[2], araw[0]};   // cat([rgb, alpha]) nerf.py:157
+        f32x4 o = {rraw[0], rraw[1], rraw[2], araw[0]};   // cat([rgb, alpha]) nerf.py:157
+#ifdef EVD_C_STAMP      // lane 0 of every wavefront reports (cycles in the vmcnt waits, in the barriers, in the kernel) instead of its sample
+        if (lane == 0) o = f32x4{(float)cx.st.tw, (float)cx.st.tb, (float)(__builtin_readcyclecounter() - t_start), -1.f};
+#endif
         *reinterpret_cast<f32x4*>(p.raw + sidx * 4) = o;
     }
     if constexpr (FUSE) {

@@ -40,6 +40,7 @@ class _Raw2Outputs(torch.autograd.Function):
         ctx.save_for_backward(raw, z, rd, noise if noise is not None else torch.empty(0, device=dev))
         ctx.cfg = (sigma_ch, rgb_ch0, rgb_act, sigma_act, int(bool(white_bkgd)), thr, noise is not None)
         ctx.mark_non_differentiable(dens)
+        ctx.set_materialize_grads(False)       # unused outputs (depth, acc, often the weights) arrive as None, not as freshly zeroed tensors
         return rgb, dens, acc, wts, depth
 
     @staticmethod

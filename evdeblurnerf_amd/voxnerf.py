@@ -91,6 +91,7 @@ class _VoxelMLP(torch.autograd.Function):
         raw, store, feature = net.mlpforward_train(pts, viewdirs, fts, precision, want_feature=rows)
         ctx.net, ctx.precision, ctx.store, ctx.raw = net, precision, store, raw
         ctx.ft_shape, ctx.pts, ctx.viewdirs, ctx.has_feature, ctx.geo = fts.shape, pts, viewdirs, rows, geo
+        ctx.set_materialize_grads(False)
         if geo is not None:
             geo.level, geo.store, geo.precision, geo.R, geo.S = net, store, precision, pts.shape[0], pts.shape[1]
             return raw, torch.zeros((1,), dtype=torch.float32, device=raw.device)
