@@ -608,12 +608,22 @@ __device__ __forceinline__ float row_sum_dpp(float v) {
 // MODE: 0 = every tap by a direct atomic; 1 = pass 1 of the binned form (rows + tap records + keys, no atomics); 2 = HYBRID: the plane
 // taps by direct atomics, the line taps deferred -- their rows and tap records are written and k_scatter_lines adds them through
 // privatised LDS slices of the (small) line gradients: a third of the kernel's atomic requests go away.
+// MODE 3 (opt-in, EVD_SCATTER_WIN=1) = the hybrid form with the x-y plane's taps deferred as well (k_scatter_xy, kernel_voxel_scatter.hip):
+// their rows (64 channels) and tap records are written here and this kernel's atomics are the two 16-channel planes only.  Measured at 2^19
+// fine-level samples: this kernel 0.89 -> 0.76 ms although two thirds of its atomic requests are gone -- it is a latency chain per tile (point
+// load, tap table, GEMM, gathers, barriers), not atomic-bound any more -- plus 0.10 ms for k_scatter_xy on rays along z: 1.08 -> 1.02 ms in
+// total, but 0.89 -> 1.35 ms on oblique rays (k_scatter_xy's tap-by-tap path runs after this kernel instead of under it).  Deciding per tile
+// HERE which form a tile takes (window test in the tap-table phase) cost this kernel 0.3 ms and lost everywhere.  (The same reduction INSIDE this kernel --
+// window, M in LDS, 16 MFMAs per wavefront, between the gather phase and the sweep -- was built first and measured 1.09 -> 1.47 ms: the
+// kernel is a latency chain per tile that lives on three blocks per CU, and the extra phase with its two barriers, or the spills it forces
+// at 168 registers, costs more than the atomics it saves.)
 template <int MODE, bool MM, int CT>
 __global__ __launch_bounds__(256, MM ? (CT <= 96 ? 3 : 2) : 1) void k_voxel_sample_bwd(const GridParams g, const float* __restrict__ pts, long n,
                                                           const float* __restrict__ d_out, int d_stride, int d_col, GridGrads gg,
                                                           float* __restrict__ d_pts, const BinOut bo) {
     constexpr int STRD = CT + 1, FSTR = MM ? 33 : VSB_MAXF + 1;      // odd row strides (conflict-free column access)
-    constexpr bool BINNED = MODE == 1, HYBRID = MODE == 2;
+    constexpr bool BINNED = MODE == 1, HYBRID = MODE == 2 || MODE == 3, XYDEF = MODE == 3;
+
     __shared__ float tfr[VS_SAMPLES * 3 * 6], dpt[VS_SAMPLES * 3];
     __shared__ int tax[VS_SAMPLES * 3 * 3];
     __shared__ __attribute__((aligned(16))) float pvs[VS_SAMPLES * STRD], lvs[VS_SAMPLES * STRD], dco[VS_SAMPLES * STRD],
@@ -695,6 +705,18 @@ __global__ __launch_bounds__(256, MM ? (CT <= 96 ? 3 : 2) : 1) void k_voxel_samp
                     LTap lt_;
                     lt_.c0 = (int)it.il[0] / C; lt_.c1 = (int)it.il[1] / C; lt_.w0 = it.wl[0]; lt_.w1 = it.wl[1];
                     bo.ltap[s * 3 + i] = lt_;
+                }
+            }
+            if constexpr (XYDEF) {
+                if (i == 0) {                       // the x-y plane's taps of this sample, for k_scatter_xy (dead samples: zero weights)
+                    const int Wp = g.grid[0];
+                    const int cell0 = (int)(it.ip[0] / c0n), cell3 = (int)(it.ip[3] / c0n);
+                    const int cy0 = cell0 / Wp, cx0 = cell0 - cy0 * Wp, cy1 = cell3 / Wp, cx1 = cell3 - cy1 * Wp;
+                    PTap pt_;
+                    pt_.cx0 = (unsigned short)cx0; pt_.cx1 = (unsigned short)cx1; pt_.cy0 = (unsigned short)cy0; pt_.cy1 = (unsigned short)cy1;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) pt_.w[t] = live ? it.wp[t] : 0.f;
+                    if (live) bo.ptap[s] = pt_;
                 }
             }
             if constexpr (BINNED) {
@@ -798,10 +820,15 @@ __global__ __launch_bounds__(256, MM ? (CT <= 96 ? 3 : 2) : 1) void k_voxel_samp
                     for (int sl = ss; sl < VS_SAMPLES && s0 + sl < n; sl += 2) bo.rows_l[(s0 + sl) * ctot + ql] = dco[sl * STRD + ql] * pvs[sl * STRD + ql];
                 }
             }
+            if constexpr (XYDEF) {
+                if (ql < c0n) {
+                    for (int sl = ss; sl < VS_SAMPLES && s0 + sl < n; sl += 2) bo.rows_p[(s0 + sl) * c0n + ql] = dco[sl * STRD + ql] * lvs[sl * STRD + ql];
+                }
+            }
             for (int sl = ss; sl < VS_SAMPLES; sl += 2) {
 #pragma unroll
                 for (int m = 0; m < MQ; ++m) {
-                    if (!q_ptr[m] || (HYBRID && !q_plane[m])) continue;
+                    if (!q_ptr[m] || (HYBRID && !q_plane[m]) || (XYDEF && q_slot[m] < 4)) continue;
                     const float w = tw[sl * VSB_TAPS + q_slot[m]];
                     if (w == 0.f) continue;
                     const int c = q_c[m];
@@ -1131,7 +1158,8 @@ int launch_voxel_sample_bwd_planes(const GridParams& g, const float* pts, long n
     const bool mm = g.app_dim == 32 && (g.n_comp[0] + g.n_comp[1] + g.n_comp[2]) % 32 == 0;
     const int ct = g.n_comp[0] + g.n_comp[1] + g.n_comp[2];
     const unsigned blocks = (unsigned)(tiles < 3072 ? tiles : 3072);
-    if (mm && ct <= 96) k_voxel_sample_bwd<2, true, 96><<<blocks, 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo);
+    if (mm && ct <= 96 && bo.rows_p) k_voxel_sample_bwd<3, true, 96><<<blocks, 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo);
+    else if (mm && ct <= 96) k_voxel_sample_bwd<2, true, 96><<<blocks, 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo);
     else if (mm) k_voxel_sample_bwd<2, true, VS_MAXC><<<blocks, 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo);
     else k_voxel_sample_bwd<2, false, VS_MAXC><<<blocks, 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo);
     EVD_LAUNCH_CHECK();

@@ -304,11 +304,139 @@ int launch_voxel_sample_bwd_binned(const GridParams& g, const float* pts, long n
     return EVD_OK;
 }
 
-// ---- hybrid: the plane taps by direct atomics (k_voxel_sample_bwd<2>), the line taps through k_scatter_lines ------------------------
+// ---- the x-y plane's taps of the hybrid form ---------------------------------------------------------------------------------------------
+// A tile is 32 consecutive samples of one ray, and the rays of an NDC scene (every shipped LLFF-type config) run along z: the 128 x-y taps
+// of a tile address ~12 distinct cells.  The sum over the taps that share a cell is a small GEMM,
+//     Out[slot, channel] = sum_s M[slot, s] G[s, channel],   M[slot, s] = the bilinear weight with which sample s touches window cell `slot`
+// (an 8 x 8-cell window anchored at the tile's smallest cell: 64 x 32, built in LDS -- lane s writes its own column, no atomics) and G = the
+// rows k_voxel_sample_bwd<3> left (d coef x line value, 64 channels): 32-64 exact-float32 MFMAs per WAVEFRONT, which owns its tile from
+// the tap records to the adds (no block barrier), then ONE float atomic per occupied cell and channel: ~1.5 requests of 64 bytes per sample
+// instead of 16.  A tile whose taps do not fit the window (rays across the plane), or whose sums are not finite (an Inf / NaN must land on
+// the cells its sample touches, nowhere else), adds tap by tap with the lanes over the channels.
+constexpr int XY_W = 8, XY_SLOTS = XY_W * XY_W, XY_STR = 33, XY_C = 64;
+__global__ __launch_bounds__(256) void k_scatter_xy(const float* __restrict__ rows, const PTap* __restrict__ ptap, long n, float* __restrict__ grad, int Wp) {
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    __shared__ float wm_all[4][XY_SLOTS * XY_STR];
+    __shared__ int wi_all[4][8];
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63, mn = ln & 31, kb = ln >> 5;
+    float* wm = wm_all[wv];
+    int* wi = wi_all[wv];
+    const long t0 = ((long)blockIdx.x * 4 + wv) * 32;
+    if (t0 >= n) return;                                   // wavefront-uniform: there is no block barrier in this kernel
+    auto wave_sync = []() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    PTap tp;
+    tp.cx0 = tp.cx1 = tp.cy0 = tp.cy1 = 0;
+    tp.w[0] = tp.w[1] = tp.w[2] = tp.w[3] = 0.f;
+    if (ln < 32 && t0 + ln < n) tp = ptap[t0 + ln];
+    // the rows of the tile as MFMA B operands: b[ct][j] = G[sample 2 j + kb][channel 32 ct + mn]
+    float b0[16], b1[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const long sm = t0 + 2 * j + kb;
+        b0[j] = sm < n ? rows[sm * XY_C + mn] : 0.f;
+        b1[j] = sm < n ? rows[sm * XY_C + 32 + mn] : 0.f;
+    }
+    if (ln < 8) wi[ln] = ln < 2 ? 0x7fffffff : (ln < 4 ? -1 : 0);
+    for (int o = ln; o < XY_SLOTS * XY_STR; o += 64) wm[o] = 0.f;
+    wave_sync();
+    int cx[4], cy[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        cx[t] = (t & 1) ? tp.cx1 : tp.cx0;
+        cy[t] = (t & 2) ? tp.cy1 : tp.cy0;
+        if (tp.w[t] != 0.f) {
+            atomicMin(&wi[0], cx[t]); atomicMin(&wi[1], cy[t]);
+            atomicMax(&wi[2], cx[t]); atomicMax(&wi[3], cy[t]);
+        }
+    }
+    wave_sync();
+    const int x0 = wi[0], y0 = wi[1], x1 = wi[2], y1 = wi[3];
+    if (x1 < 0) return;                                    // no live tap in the tile
+    bool done = false;
+    if (x1 - x0 < XY_W && y1 - y0 < XY_W) {
+        unsigned lo = 0u, hi = 0u;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (tp.w[t] != 0.f) {
+                const int slot = (cy[t] - y0) * XY_W + (cx[t] - x0);
+                wm[slot * XY_STR + ln] += tp.w[t];         // column `ln` belongs to this lane (lanes >= 32 hold zero weights)
+                if (slot < 32) lo |= 1u << slot; else hi |= 1u << (slot - 32);
+            }
+        }
+        if (lo) atomicOr((unsigned*)&wi[5], lo);
+        if (hi) atomicOr((unsigned*)&wi[6], hi);
+        wave_sync();
+        const unsigned occ[2] = {(unsigned)wi[5], (unsigned)wi[6]};
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q >> 1][q & 1][r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float a0 = wm[mn * XY_STR + 2 * j + kb];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[j], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1[j], acc[0][1], 0, 0, 0);
+        }
+        if (occ[1]) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float a1 = wm[(32 + mn) * XY_STR + 2 * j + kb];
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0[j], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[j], acc[1][1], 0, 0, 0);
+            }
+        }
+        int bad = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bad |= !(fabsf(acc[q >> 1][q & 1][r]) <= 3.4028234e38f);
+        if (!__any(bad)) {
+            done = true;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                if (!occ[rt]) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int sr = (r & 3) + 8 * (r >> 2) + 4 * kb;          // slot inside this half (the 32 x 32 accumulator layout)
+                    if ((occ[rt] >> sr) & 1u) {
+                        const int slot = rt * 32 + sr;
+                        float* dst = grad + ((long)(y0 + slot / XY_W) * Wp + x0 + slot % XY_W) * XY_C + mn;
+                        unsafeAtomicAdd(dst, acc[rt][0][r]);
+                        unsafeAtomicAdd(dst + 32, acc[rt][1][r]);
+                    }
+                }
+            }
+        }
+    }
+    if (!done) {                                           // tap by tap, the lanes over the 64 channels
+        for (int s = 0; s < 32 && t0 + s < n; ++s) {
+            const float v = rows[(t0 + s) * XY_C + ln];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tp.w[t]), s));
+                if (w == 0.f) continue;
+                const int px = __builtin_amdgcn_readlane(cx[t], s), py = __builtin_amdgcn_readlane(cy[t], s);
+                unsafeAtomicAdd(grad + ((long)py * Wp + px) * XY_C + ln, w * v);
+            }
+        }
+    }
+}
+
+// the x-y plane leaves the main kernel's atomic path only on request (EVD_SCATTER_WIN=1: a gain on rays along z, a loss on oblique ones; the
+// numbers are at k_voxel_sample_bwd) and when it has the channel count k_scatter_xy is built for
+static bool xy_deferred(const GridParams& g, const GridGrads& gg) {
+    const char* e = getenv("EVD_SCATTER_WIN");
+    return (e && e[0] == '1') && g.n_comp[0] == XY_C && gg.plane[0] && g.grid[0] <= 65535 && g.grid[1] <= 65535 && g.app_dim == 32 &&
+           (g.n_comp[0] + g.n_comp[1] + g.n_comp[2]) % 32 == 0 && g.n_comp[0] + g.n_comp[1] + g.n_comp[2] <= 96;
+}
+
+// ---- hybrid: the 16-channel planes' taps by direct atomics (k_voxel_sample_bwd<2 / 3>), the line taps through k_scatter_lines, the x-y
+// plane's through k_scatter_xy ------------------------------------------------------------------------------------------------------------
 size_t voxel_scatter_hybrid_workspace_bytes(const GridParams& g, long n) {
     if (n <= 0) return 0;
     const size_t ctot = (size_t)(g.n_comp[0] + g.n_comp[1] + g.n_comp[2]);
-    return al256((size_t)n * ctot * 4) + al256((size_t)n * 3 * sizeof(LTap)) + 512;
+    return al256((size_t)n * ctot * 4) + al256((size_t)n * 3 * sizeof(LTap)) + al256((size_t)n * XY_C * 4) + al256((size_t)n * sizeof(PTap)) + 512;
 }
 
 int launch_voxel_sample_bwd_hybrid(const GridParams& g, const float* pts, long n, const float* d_out, int d_stride, int d_col, const GridGrads& gg,
@@ -320,8 +448,18 @@ int launch_voxel_sample_bwd_hybrid(const GridParams& g, const float* pts, long n
     BinOut bo{};
     bo.rows_l = (float*)w;
     bo.ltap = (LTap*)(w + al256((size_t)n * ctot * 4));
+    const bool xy = xy_deferred(g, gg);
+    if (xy) {
+        char* w2 = w + al256((size_t)n * ctot * 4) + al256((size_t)n * 3 * sizeof(LTap));
+        bo.rows_p = (float*)w2;
+        bo.ptap = (PTap*)(w2 + al256((size_t)n * XY_C * 4));
+    }
     int rc = launch_voxel_sample_bwd_planes(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo, st);
     if (rc) return rc;
+    if (xy) {
+        hipLaunchKernelGGL(k_scatter_xy, dim3((unsigned)cdiv(cdiv(n, 32L), 4L)), dim3(256), 0, st, (const float*)bo.rows_p, (const PTap*)bo.ptap, n, gg.plane[0], g.grid[0]);
+        EVD_LAUNCH_CHECK();
+    }
     return launch_lines(g, gg, (const float*)bo.rows_l, (const LTap*)bo.ltap, n, st);
 }
 

@@ -35,9 +35,9 @@ struct PTap { unsigned short cx0, cx1, cy0, cy1; float w[4]; };     // clamped c
 struct LTap { int c0, c1; float w0, w1; };                          // the 2 taps of one line
 constexpr int SC_TS = 16;                                           // plane tiles of 16 x 16 cells (+ 1 halo row / column in LDS)
 struct BinOut {
-    float* rows_p;          // [n, ctot]  d coef x line value: what every plane tap adds, times its weight
+    float* rows_p;          // [n, ctot]  d coef x line value: what every plane tap adds, times its weight ([n, n_comp[0]]: the x-y plane only, in the hybrid form)
     float* rows_l;          // [n, ctot]  d coef x plane value, for the line taps
-    PTap* ptap;             // [n, 3]
+    PTap* ptap;             // [n, 3]  ([n]: the x-y plane only, in the hybrid form)
     LTap* ltap;             // [n, 3]
     unsigned* keys[3];      // [n] tile of tap 0 in plane i
     unsigned* ids;          // [n] 0 .. n-1 (the sort's values)
