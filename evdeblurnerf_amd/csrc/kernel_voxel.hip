@@ -587,6 +587,11 @@ __global__ __launch_bounds__(64 * VW_WAVES) void k_voxel_sample_w(const GridPara
 // BINNED (kernel_voxel_scatter.hip): the atomics of phase B are replaced by one row of per-channel contributions per sample and the
 // tap records; a second pass adds them tile by tile in LDS.  d basis and d pts are computed here either way.
 constexpr int VSB_MAXF = 64, VSB_TAPS = 18;
+#ifdef EVD_VSB_BATCH
+constexpr int VSB_BATCH = EVD_VSB_BATCH;
+#else
+constexpr int VSB_BATCH = 4;            // samples whose taps are in flight together in the gather phase of k_voxel_sample_bwd (divides 16)
+#endif
 // CT: the channel capacity the LDS rows are laid out for (MM: ctot <= CT, a multiple of 32).  With the shipped 96 channels and
 // app_dim 32 the block needs 50 KB of LDS and 168 VGPRs = three blocks per CU.  (Measured: three blocks run at the speed of two,
 // 1.21 ms = 249 G adds/s; a bare kernel of coalesced float atomics on random 64-byte runs sustains 318 - 328 G adds/s = 20 G requests/s
@@ -671,6 +676,12 @@ __global__ __launch_bounds__(256, MM ? (CT <= 96 ? 3 : 2) : 1) void k_voxel_samp
         macc[r] = 0.f;
         bas_reg[r] = mm_wave ? g.basis[(long)(2 * r + kb) * ctot + 32 * wv + mn] : 0.f;
     }
+#ifdef EVD_SB_STAMP      // developer build: where does a tile's time go?  shader-clock cycles per phase, summed over the block's tiles (thread 0)
+    long long sb_t[6] = {0, 0, 0, 0, 0, 0}, sb_last = __builtin_readcyclecounter();
+#define SB_STAMP(k) { const long long now_ = __builtin_readcyclecounter(); sb_t[k] += now_ - sb_last; sb_last = now_; }
+#else
+#define SB_STAMP(k)
+#endif
     for (long tile = blockIdx.x; tile * VS_SAMPLES < n; tile += gridDim.x) {
         const long s0 = tile * VS_SAMPLES;
         for (int o = tid; o < VS_SAMPLES * F; o += 256) {
@@ -740,6 +751,7 @@ __global__ __launch_bounds__(256, MM ? (CT <= 96 ? 3 : 2) : 1) void k_voxel_samp
         }
         if (tid < VS_SAMPLES * 3) dpt[tid] = 0.f;
         __syncthreads();
+        SB_STAMP(0);                                // d out rows, points, tap table
         if (mm) {
             if (mm_wave) {                          // D[sample][channel] = sum_f d out[sample][f] basis[f][channel]
                 f32x16 a16;
@@ -759,16 +771,31 @@ __global__ __launch_bounds__(256, MM ? (CT <= 96 ? 3 : 2) : 1) void k_voxel_samp
             }
         }
         if (d_pts) __syncthreads();                 // the point gradient below reads d coef
+        SB_STAMP(1);                                // d coef GEMM
         if (chan_on) {                              // pv, lv: lanes over channels, two samples per sweep
-#pragma unroll 4
-            for (int sl = ss; sl < VS_SAMPLES; sl += 2) {
+            // The taps of VSB_BATCH samples are loaded before the first is used.  (As one loop with "#pragma unroll 4" hipcc left it rolled --
+            // the DPP row sums and LDS atomics of the d pts part are convergent operations --: six loads, then a wait for all six, 16 times
+            // per tile, and in-kernel stamps put half of a tile's time in this phase.)
+            for (int b0 = 0; b0 < VS_SAMPLES / 2; b0 += VSB_BATCH) {
+            float Pb[VSB_BATCH][4], Lb[VSB_BATCH][2];
+#pragma unroll
+            for (int j = 0; j < VSB_BATCH; ++j) {
+                const int* ti = tix + (ss + 2 * (b0 + j)) * VSB_TAPS;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) Pb[j][t] = gplane[ti[4 * cg + t] + cin];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) Lb[j][t] = gline[ti[12 + 2 * cg + t] + cin];
+            }
+#pragma unroll
+            for (int j = 0; j < VSB_BATCH; ++j) {
+                const int sl = ss + 2 * (b0 + j);
                 const int* ti = tix + sl * VSB_TAPS;
                 const float* w = tw + sl * VSB_TAPS;
                 float pv = 0.f, lv = 0.f, P[4], Lt[2];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) { P[t] = gplane[ti[4 * cg + t] + cin]; pv = fmaf(w[4 * cg + t], P[t], pv); }
+                for (int t = 0; t < 4; ++t) { P[t] = Pb[j][t]; pv = fmaf(w[4 * cg + t], P[t], pv); }
 #pragma unroll
-                for (int t = 0; t < 2; ++t) { Lt[t] = gline[ti[12 + 2 * cg + t] + cin]; lv = fmaf(w[12 + 2 * cg + t], Lt[t], lv); }
+                for (int t = 0; t < 2; ++t) { Lt[t] = Lb[j][t]; lv = fmaf(w[12 + 2 * cg + t], Lt[t], lv); }
                 pvs[sl * STRD + ql] = pv;
                 lvs[sl * STRD + ql] = lv;
                 if (d_pts) {
@@ -801,8 +828,10 @@ __global__ __launch_bounds__(256, MM ? (CT <= 96 ? 3 : 2) : 1) void k_voxel_samp
                     }
                 }
             }
+            }
         }
         __syncthreads();
+        SB_STAMP(2);                                // gathers, pv / lv, d pts
         // (Re-measured in round 2 with the half-tile walk that keeps a ray's runs together -- successive samples of an NDC ray address
         // ~12 distinct x-y cells and ~7 x / y line cells per 32 samples --: summing the run in a register before ONE atomic is 1.5-1.9x
         // SLOWER, 2.76 vs 1.46 ms at 2^19 samples: the walk is a chain of dependent LDS reads, the sweep below is not.)
@@ -837,6 +866,7 @@ __global__ __launch_bounds__(256, MM ? (CT <= 96 ? 3 : 2) : 1) void k_voxel_samp
                 }
             }
         }
+        SB_STAMP(3);                                // rows + the atomic sweep (issue only: nothing waits for the adds here)
         if (d_pts && tid < VS_SAMPLES * 3 && s0 + tid / 3 < n) d_pts[(s0 + tid / 3) * 3 + tid % 3] = dpt[tid];
         if (gg.basis && mm) {
             if (mm_wave) {                          // D[f][channel] += sum_s d out[s][f] coef[s][channel]
@@ -860,7 +890,16 @@ __global__ __launch_bounds__(256, MM ? (CT <= 96 ? 3 : 2) : 1) void k_voxel_samp
             }
         }
         __syncthreads();
+        SB_STAMP(4);                                // basis_mat gradient GEMM, d pts rows, the tile's last barrier
     }
+#ifdef EVD_SB_STAMP
+    if constexpr (HYBRID) {
+        if (tid == 0) {
+            for (int k = 0; k < 5; ++k) bo.rows_l[blockIdx.x * 8 + k] = (float)sb_t[k];
+            bo.rows_l[blockIdx.x * 8 + 5] = -7.f;
+        }
+    }
+#endif
     if (gg.basis && mm) {
         if (mm_wave) {
 #pragma unroll
