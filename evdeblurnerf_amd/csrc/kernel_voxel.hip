@@ -536,6 +536,8 @@ __global__ __launch_bounds__(64 * VW_WAVES) void k_voxel_sample_w(const GridPara
     const float* b0 = bs + min(col, g.app_dim - 1) * cstride + kh;
     const float* b1 = bs + min(16 + col, g.app_dim - 1) * cstride + kh;
     const float* cf = coef + col * cstride + kh;
+    // (hipcc refuses the unroll -- ctot is a runtime value -- and every step waits for its own three LDS reads; reading the operands of four
+    // steps together was measured: 0.139 -> 0.143 ms per 2^19 samples, the other wavefronts of the SIMD already fill those waits)
 #pragma unroll 4
     for (int kk = 0; kk < ctot; kk += 4) {
         const float c = cf[kk];
