@@ -919,3 +919,44 @@ def test_hybrid_scatter_propagates_non_finite_gradients():
     ws = torch.empty((nb,), dtype=torch.uint8, device="cuda")
     L.check(L.lib().evd_voxel_sample_bwd_ws(net._h, L.ptr(pts), n, L.ptr(d_out), 32, 0, C.byref(gs), None, L.ptr(ws), nb, L.stream_ptr()), "bwd_ws")
     assert all(torch.isnan(t).any().item() for t in grads[:6]), [torch.isnan(t).any().item() for t in grads]
+
+
+@pytest.mark.gpu
+def test_xy_window_scatter_equals_the_hybrid_scatter(monkeypatch):
+    """The opt-in form of the hybrid scatter that sums the x-y plane's taps through k_scatter_xy's 8 x 8-cell window (EVD_SCATTER_WIN=1)
+    gives the gradients of the default form: on rays along z (tiles fit the window: the GEMM path), on oblique rays (tiles overflow: its
+    tap-by-tap path), with a ragged last tile, and a NaN in the incoming gradient lands on the cells of its sample only."""
+    import ctypes as C
+    from evdeblurnerf_amd import _lib as L
+    from evdeblurnerf_amd.voxnerf import VoxelNeRFSampleFeatures, _grid_grads
+    nvox = 96 ** 3
+    g = W.pdrf_grid_size(AABB[0], AABB[1], nvox)
+    net = VoxelNeRFSampleFeatures(W.make_pdrf_state_dict(32, g, input_ch=127, hidden_dim=256, geo_feat_dim=128), "", AABB, num_layers=2, hidden_dim=256,
+                                  geo_feat_dim=128, num_layers_color=3, input_ch=127, app_dim=32, app_n_comp=(64, 16, 16), n_voxels=nvox)
+    grads, gs = _grid_grads(net, net.grid_params())
+    rs = np.random.RandomState(3)
+    R, S = 301, 64
+    for spread, bad in ((0.01, False), (0.7, False), (0.01, True)):
+        o = rs.uniform(-1.2, 1.2, (R, 1, 3)) * np.array([1, 1, 0]) + np.array([0, 0, 0.95])
+        d = rs.normal(size=(R, 1, 3)) * spread + np.array([0, 0, -1.0])
+        z = np.sort(rs.uniform(0.0, 2.1, (R, S, 1)), 1)                   # some samples leave the box
+        pts = torch.as_tensor((o + d * z).astype(np.float32), device="cuda").reshape(-1, 3)[:R * S - 13].contiguous()
+        n = pts.shape[0]
+        d_out = torch.randn((n, 32), device="cuda")
+        if bad:
+            d_out[777, 5] = float("nan")
+        d_pts = torch.empty((n, 3), device="cuda")
+        nb = int(L.lib().evd_voxel_sample_bwd_workspace_bytes(net._h, n))
+        ws = torch.empty((nb,), dtype=torch.uint8, device="cuda")
+        outs = []
+        for win in ("0", "1"):
+            monkeypatch.setenv("EVD_SCATTER_WIN", win)
+            for t in grads:
+                t.zero_()
+            L.check(L.lib().evd_voxel_sample_bwd_ws(net._h, L.ptr(pts), n, L.ptr(d_out), 32, 0, C.byref(gs), L.ptr(d_pts), L.ptr(ws), nb, L.stream_ptr()), "bwd_ws")
+            outs.append([t.clone() for t in grads] + [d_pts.clone()])
+        for a, b in zip(outs[1], outs[0]):
+            if bad:
+                assert torch.equal(torch.isnan(a), torch.isnan(b))
+                a, b = torch.nan_to_num(a), torch.nan_to_num(b)
+            assert ((a - b).norm() / b.norm().clamp_min(1e-30)).item() < 1e-5
