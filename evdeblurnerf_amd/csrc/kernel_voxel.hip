@@ -1163,13 +1163,28 @@ int launch_voxel_sample(const GridParams& g, bool half_grids, const float* pts, 
     return EVD_OK;
 }
 
+// Persistent blocks of the scatter's main kernel.  The 96-channel MFMA instantiation keeps three blocks per CU: exactly that many blocks
+// (768 on the 256 CUs of an MI355X), each walking its share of the tiles, measured best -- 0.98 / 0.79 ms per 2^19 samples (rays along z /
+// oblique) against 1.02 / 0.82 with 3072 blocks, 1.14 / 0.94 with 1024 (a ragged last round) and 1.07 / 0.97 with 512: every block pays
+// for its basis_mat column and flushes its basis_mat gradient (192 atomic requests) once.  EVD_SCATTER_BLOCKS overrides.
+static long scatter_blocks_cap(bool three_per_cu) {
+    const char* e = getenv("EVD_SCATTER_BLOCKS");
+    const long v = e ? atol(e) : 0;
+    if (v > 0) return v;
+    if (!three_per_cu) return 3072;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 3072;
+    return 3L * cus;
+}
+
 int launch_voxel_sample_bwd(const GridParams& g, const float* pts, long n, const float* d_out, int d_stride, int d_col, const GridGrads& gg,
                             float* d_pts, hipStream_t st) {
     if (g.app_dim > VSB_MAXF) return fail(EVD_E_INVALID, "evd_voxel_sample_bwd: app_dim %d > %d", g.app_dim, VSB_MAXF);
     const long tiles = cdiv(n, VS_SAMPLES);
     const bool mm = g.app_dim == 32 && (g.n_comp[0] + g.n_comp[1] + g.n_comp[2]) % 32 == 0;
     const int ct = g.n_comp[0] + g.n_comp[1] + g.n_comp[2];
-    const unsigned blocks = (unsigned)(tiles < 3072 ? tiles : 3072);
+    const long cap = scatter_blocks_cap(mm && ct <= 96);
+    const unsigned blocks = (unsigned)(tiles < cap ? tiles : cap);
     if (mm && ct <= 96) k_voxel_sample_bwd<0, true, 96><<<blocks, 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, BinOut{});
     else if (mm) k_voxel_sample_bwd<0, true, VS_MAXC><<<blocks, 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, BinOut{});
     else k_voxel_sample_bwd<0, false, VS_MAXC><<<blocks, 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, BinOut{});
@@ -1198,7 +1213,8 @@ int launch_voxel_sample_bwd_planes(const GridParams& g, const float* pts, long n
     const long tiles = cdiv(n, VS_SAMPLES);
     const bool mm = g.app_dim == 32 && (g.n_comp[0] + g.n_comp[1] + g.n_comp[2]) % 32 == 0;
     const int ct = g.n_comp[0] + g.n_comp[1] + g.n_comp[2];
-    const unsigned blocks = (unsigned)(tiles < 3072 ? tiles : 3072);
+    const long cap = scatter_blocks_cap(mm && ct <= 96);
+    const unsigned blocks = (unsigned)(tiles < cap ? tiles : cap);
     if (mm && ct <= 96 && bo.rows_p) k_voxel_sample_bwd<3, true, 96><<<blocks, 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo);
     else if (mm && ct <= 96) k_voxel_sample_bwd<2, true, 96><<<blocks, 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo);
     else if (mm) k_voxel_sample_bwd<2, true, VS_MAXC><<<blocks, 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo);
