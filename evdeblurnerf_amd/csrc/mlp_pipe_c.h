@@ -7,7 +7,7 @@
 // all three accumulating into the same float32 registers.  The float16 product carries the value, the two fp6 products remove the
 // rounding error of either operand down to the fp6 resolution of the RESIDUALS (2^-4 of 2^-11): operand error ~2^-15 instead of
 // 2^-11, for 1 + 2 x (1/4 the k-steps at 1.25x the rate) = 1.4x the matrix-pipe time of the float16 mode (the split-float16 mode,
-// three float16 products, costs 3x).  tools/experiments/precision_anatomy.py is the CPU emulation this design was chosen with:
+// three float16 products, costs 3x).  tools/precision_anatomy.py is the CPU emulation this design was chosen with:
 // RGB L-inf vs float64 on trained weights 2.9e-4 (f16) -> 7.6e-6 (this mode); tools/probes/mx_fp6_probe2.hip pins the hardware
 // semantics used here (operand k order of the two conversions, scale byte selection, rounding).
 //

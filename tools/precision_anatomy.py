@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """CPU emulation of the MLP arithmetic modes on the 8x256 NeRF: where does the half-precision RGB error come from, and what does a
 low-precision (fp6 e2m3, block-scaled) correction product buy?  float64 torch is the reference.  Used to choose the `f16c` mode.
-    python tools/experiments/precision_anatomy.py [--scale 1.4] [--weights file.npz] [--rays 256]"""
+    python tools/precision_anatomy.py [--scale 1.4] [--weights file.npz] [--rays 256]"""
 import argparse, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from evdeblurnerf_amd import weights as W
 

@@ -21,6 +21,7 @@ from __future__ import annotations
 import argparse
 import os
 import sys
+import time
 from types import SimpleNamespace
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -99,6 +100,22 @@ def train_nerf(iters=1000, rays_per_iter=4096, samples=128, seed=21, precision="
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=1000)
+    ap.add_argument("--save", default=None, help="write the trained state dict (.npz)")
+    ap.add_argument("--check", action="store_true", help="RGB L-inf of every mode vs the CPU oracle at 4096 x 128 on the trained weights")
     a = ap.parse_args()
+    t0 = time.time()
     sd, rep = train_nerf(a.iters, verbose=True)
+    rep["train_s"] = time.time() - t0
     print(rep)
+    if a.save:
+        np.savez(a.save, **sd)
+    if a.check:
+        from oracle import oracle as O
+        from evdeblurnerf_amd.renderer import NeRFAll
+        rays = W.synthetic_rays(100, 4096)
+        ref = O.render_nerf(O.Nerf(sd, "mlp_coarse."), None, O.make_cfg(N_samples=128), rays)["rgb"]
+        args = SimpleNamespace(N_importance=0, **NERF_ARGS)
+        for p in ("f32", "f16x3", "f16c", "f16", "bf16"):
+            out = NeRFAll(args, sd, precision=p).eval().render(400, 400, W.synthetic_camera(), rays=torch.as_tensor(rays, device="cuda"), N_samples=128,
+                                                               ndc=True, near=0., far=1., use_viewdirs=True, N_importance=0, retraw=False)[0]
+            print(f"trained {a.iters}: {p:6s} RGB L-inf vs oracle {float(np.abs(out.cpu().numpy() - ref).max()):.3e}", flush=True)
