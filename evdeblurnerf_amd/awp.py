@@ -174,6 +174,11 @@ class SampleFeatureEmbed:
         float32 tensor [..., 128] -> h_local [n, 64] with autograd to flat and to the geo features"""
         self.load_params(flat)
         if isinstance(geo, GeoFragments):
+            # the fragments are the level's own half-precision MFMA operands: reading a bf16 store as f16 (or the reverse) would
+            # reinterpret the bits silently -- the C entry can only check the store's size
+            if geo.precision not in ("f16", "bf16") or geo.precision != self.precision:
+                raise L.EvdError(f"SampleFeatureEmbed[{self.precision}] cannot read the geo fragments of a level trained in {geo.precision}: "
+                                 "the fragment coupling needs the same half-precision mode (f16 or bf16) on both sides")
             return _SampleEmbed.apply(geo.token, flat, self, geo)
         return _SampleEmbed.apply(geo, flat, self, None)
 

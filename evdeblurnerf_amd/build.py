@@ -27,7 +27,7 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=
 # the matrix core reads directly: f16c 5708 -> 4802 VALU instructions per wavefront, 0.879 -> 0.857 ms; f16x3 1.58 -> 1.53 ms
 # (tools/run_lib_variants.sh; the two-wavefront kernels and the training / scatter kernels do not change or get slower with it).
 VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
-PER_FILE = {"kernel_nerf_mlp_pipe_f16c.hip": VGPR_FORM, "kernel_nerf_mlp_pipe_f16x3.hip": VGPR_FORM}
+PER_FILE = {"kernel_nerf_mlp_pipe_f16c.hip": VGPR_FORM, "kernel_nerf_mlp_pipe_f16x3.hip": VGPR_FORM, "kernel_voxel_pipe_f16c.hip": VGPR_FORM}
 
 
 def hipcc() -> str:

@@ -103,8 +103,10 @@ struct DevBuf {
 };
 
 // Side stream + join event of a handle's backward entry (the wgrad launches overlap the dgrad chain; nerf_train.h BwdPlan::side).
-// PER-HANDLE state, created on first use under the handle's own mutex and destroyed with the handle: two host threads may run
-// their first backward concurrently, on the same or on different handles, and the library keeps no process-wide table.
+// PER-HANDLE state, created on first use and destroyed with the handle; the library keeps no process-wide table.  The mutex guards the
+// CREATION only.  A backward entry is NOT re-entrant per handle: the one side stream and the one join event are shared by every call on
+// that handle, so two host threads running evd_*_mlp_backward on the SAME handle at once would interleave their fork / join records.
+// Concurrent calls on DIFFERENT handles (one handle per device / per model, the intended use) are independent.
 struct SideStream {
     std::mutex mu;
     hipStream_t stream = nullptr;

@@ -12,7 +12,8 @@
 #include <cstdint>
 #include <cstdlib>
 
-// the PDRF level networks are built for the first four arithmetic modes (EVD_PREC_F16C is a NeRF-MLP mode: evd_nerf_mlp)
+// the PDRF level networks keep generic / pipelined / training streams for the first four arithmetic modes; EVD_PREC_F16C (compensated
+// float16) is an INFERENCE mode with its own stream (pipe_c) on the fine level; the 64-wide coarse level runs EVD_PREC_F16X3 next to it
 #define EVD_VOX_NUM_PREC EVD_PREC_F16C
 
 using namespace evd;
@@ -27,6 +28,12 @@ struct evd_voxel {
     // training path (bf16 / f16): the level's network on the software pipeline (the fine level shares `pipe`) and its W^T streams
     PackedStream train[EVD_VOX_NUM_PREC], bwd[EVD_VOX_NUM_PREC][VBWD_NSTREAMS];
     int train_chunks[EVD_VOX_NUM_PREC];
+    mutable PackedStreamC pipe_c; // compensated float16 mode (voxel_mlp_c_kernel.h): float16 + fp6 fragments and row scales; fine level only
+    int pipe_c_chunks = 0;
+    // its re-pack after evd_voxel_load_params is LAZY (a training loop re-loads every iteration and never renders in this mode): the new
+    // parameter values are kept in `arena_dev` (one stream-ordered device copy) and re-packed by the first f16c launch that follows
+    mutable DevBuf arena_dev;
+    mutable bool pipe_c_stale = false;
     long param_off[9];            // sigma_net.0, sigma_net.1, color_net.{0,1,2}.{weight,bias} in the parameter arena, [8] = total
     GridParams gp;
     RepackBatch batch;            // table of every fragment stream, for the one-launch re-pack of evd_voxel_load_params
@@ -45,6 +52,7 @@ void evd_voxel_destroy(evd_voxel* v) {
         for (int k = 0; k < VBWD_NSTREAMS; ++k) v->bwd[i][k].release();
     }
     v->basis.release(); v->bias.release(); v->bias_src.release(); v->tv_acc.release(); v->wmaps.release();
+    v->pipe_c.release(); v->arena_dev.release();
     v->side.release();
     v->batch.release();
     delete v;
@@ -228,6 +236,27 @@ int evd_voxel_create(const evd_voxel_desc* d, evd_voxel** out) {
         });
         if (rc) { evd_voxel_destroy(v); return rc; }
     }
+    if (voxel_mlp_c_chunks(HD, G, FT) > 0) {     // compensated float16 mode: the layer table of voxel_mlp_c_kernel.h VoxNetC (groups of two tiles, 64-input blocks)
+        auto c0p = [&](int j, int kk) {
+            if (j < GK) { const int c = 16 * j + phi(kk); return c < G ? c : -1; }
+            const int c = pe_src_col(PE_LV, 8 * (j - GK) + (kk & 7), kk >> 3);
+            return c < 0 ? -1 : G + c;
+        };
+        auto sig_at = [=](int r, int c) -> const float* { return c < HD ? sigma_w1 + (size_t)r * HD + c : nullptr; };
+        StreamBuilderC sc(PIPE_CB);
+        sc.arena = A;
+        sc.layer(sigma_w0, HD, d->input_ch, T, KF + PE_KS, 2, in0_col);
+        sc.layer_at(1, KS, 1, [](int, int r) { return r == 0 ? 0 : -1; }, hid_col, sig_at);
+        sc.layer_at(GT, KS, 2, [G](int t, int r) { return 32 * t + r < G ? 1 + 32 * t + r : -1; }, hid_col, sig_at);
+        sc.layer(color_w0, HD, G + ICV, T, GK + PEV_KS, 2, c0p);
+        sc.layer(color_w1, HD, HD, T, KS, 2, hid_col);
+        sc.layer(color_w2, 3, HD, 1, KS, 1, hid_col);
+        v->pipe_c_chunks = (int)(sc.bytes.size() / PIPE_CB);
+        if (v->pipe_c_chunks != voxel_mlp_c_chunks(HD, G, FT))
+            rc = fail(EVD_E_INVALID, "evd_voxel_create: f16c stream has %d chunks, kernel expects %d", v->pipe_c_chunks, voxel_mlp_c_chunks(HD, G, FT));
+        if (!rc) rc = v->pipe_c.upload(sc);
+        if (rc) { evd_voxel_destroy(v); return rc; }
+    }
     {   // wgrad index maps (voxel_train.h)
         std::vector<int> m(VMAP_TOTAL, -1);
         for (int i = 0; i < 256; ++i) { const int c = hid_col(i / 16, i % 16); m[VMAP_HID + i] = c < HD ? c : -1; }
@@ -282,7 +311,7 @@ static int sample_for(const evd_voxel* v, int precision, const float* pts, long 
 
 int evd_voxel_sample_prec(const evd_voxel* v, int precision, const float* pts, long n, float* out, int out_stride, int out_col, void* stream) {
     EVD_REQUIRE(v && out && n >= 0 && out_stride >= out_col + v->app_dim, "evd_voxel_sample_prec: bad arguments");
-    EVD_REQUIRE(precision >= 0 && precision < EVD_VOX_NUM_PREC, "evd_voxel_sample_prec: unknown precision %d", precision);
+    EVD_REQUIRE(precision >= 0 && precision <= EVD_PREC_F16C, "evd_voxel_sample_prec: unknown precision %d", precision);
     if (n == 0) return EVD_OK;
     return sample_for(v, precision, pts, n, out, out_stride, out_col, stream);
 }
@@ -300,12 +329,25 @@ static int voxel_pass(const evd_voxel* v, int precision, const float* pts, const
                       void* stream) {
     VoxMlpParams p;
     static const bool no_pipe = env_flag("EVD_NO_PIPE");
+    const bool comp = precision == EVD_PREC_F16C && v->pipe_c_chunks > 0;
+    if (precision == EVD_PREC_F16C && !comp) precision = EVD_PREC_F16X3;      // the 64-wide coarse level: float32-grade arithmetic (a few % of the render)
+    if (comp && feature) return fail(EVD_E_INVALID, "evd_voxel: per-sample feature rows are not built in EVD_PREC_F16C (use EVD_PREC_F16X3)");
     const bool piped = v->pipe_chunks[precision] > 0 && !no_pipe;
     p.wstream = (const char*)(piped ? v->pipe[precision].data.p : v->stream[precision].data.p);
     p.bias = (const float*)v->bias.p;
     p.pts = pts; p.viewdirs = viewdirs; p.fts = fts; p.nsamp = R * (long)S; p.S = S; p.vd_stride = vd_stride; p.ft_stride = ft_stride;
     p.nchunks = piped ? v->pipe_chunks[precision] : v->nchunks[precision]; p.nbias = (int)(v->bias.bytes / sizeof(float)); p.raw = raw; p.feature = feature; p.act = nullptr;
-    int rc = piped ? (precision == EVD_PREC_BF16 ? launch_voxel_pipe_bf16(feature != nullptr, p, as_stream(stream))
+    if (comp) {
+        if (v->pipe_c_stale) {
+            int rcc = repack_stream_c(v->pipe_c, (const float*)v->arena_dev.p, as_stream(stream));
+            if (rcc) return rcc;
+            v->pipe_c_stale = false;
+        }
+        p.wstream = (const char*)v->pipe_c.data.p;
+        p.wscale = (const unsigned*)v->pipe_c.scales.p;
+        p.nchunks = v->pipe_c_chunks;
+    }
+    int rc = comp ? launch_voxel_pipe_f16c(p, as_stream(stream)) : piped ? (precision == EVD_PREC_BF16 ? launch_voxel_pipe_bf16(feature != nullptr, p, as_stream(stream))
                       : precision == EVD_PREC_F16 ? launch_voxel_pipe_f16(feature != nullptr, p, as_stream(stream))
                                                   : launch_voxel_pipe_f16x3(feature != nullptr, p, as_stream(stream)))
                    : voxel_mlp_dispatch(precision, v->hidden_dim, v->geo, v->ft_dim, p, as_stream(stream));
@@ -320,7 +362,7 @@ int evd_voxel_forward(const evd_voxel* v, int precision, const float* pts, const
                       float* color, float* depth, float* acc, float* weights, float* feature,
                       void* workspace, size_t workspace_bytes, void* stream) {
     EVD_REQUIRE(v && pts && viewdirs && fts && z && rays_d, "evd_voxel_forward: null argument");
-    EVD_REQUIRE(precision >= 0 && precision < EVD_VOX_NUM_PREC, "evd_voxel_forward: unknown precision %d", precision);
+    EVD_REQUIRE(precision >= 0 && precision <= EVD_PREC_F16C, "evd_voxel_forward: unknown precision %d", precision);
     EVD_REQUIRE(F == v->ft_dim, "evd_voxel_forward: fts has %d channels, this level takes %d", F, v->ft_dim);
     EVD_REQUIRE(weights, "evd_voxel_forward: the weights output is required");
     if (R == 0) return EVD_OK;
@@ -471,6 +513,12 @@ int evd_voxel_load_params(evd_voxel* v, const float* params, void* stream) {
         for (int k = 0; k < VBWD_NSTREAMS; ++k) all.push_back(&v->bwd[i][k]);
     }
     if ((rc = repack_batch(v->batch, all, params, st))) return rc;
+    if (v->pipe_c_chunks > 0) {
+        const size_t bytes = (size_t)v->param_off[8] * sizeof(float);
+        if (!v->arena_dev.p && (rc = v->arena_dev.alloc(bytes))) return rc;
+        EVD_HIP(hipMemcpyAsync(v->arena_dev.p, params, bytes, hipMemcpyDeviceToDevice, st));
+        v->pipe_c_stale = true;
+    }
     const long nb = (long)(v->bias.bytes / sizeof(float));
     hipLaunchKernelGGL(k_gather_f32, dim3((unsigned)cdiv(nb, 256L)), dim3(256), 0, st, params, (const int*)v->bias_src.p, nb, (float*)v->bias.p);
     EVD_LAUNCH_CHECK();

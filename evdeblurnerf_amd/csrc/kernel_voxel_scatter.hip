@@ -165,6 +165,8 @@ __global__ __launch_bounds__(SC_NT) void k_scatter_lines(const LineJobs jobs, co
     if (!(m > 0.f)) return;                             // nothing to add
     int e;
     (void)frexpf(m, &e);                                // m = f 2^e, f in [0.5, 1)
+    if (e < -77) e = -77;                               // 2^(49 - e) must stay a finite float32: a chunk whose maximum is below 2^-78 keeps the scale 2^126
+                                                        // (its contributions are then resolved to 2^-126 instead of 2^-49 of the maximum: far below float32 atomics)
     const float up = ldexpf(1.f, 49 - e);               // |w v| up <= 2^49
     constexpr int UN = 4;
     for (long s0 = base + wave * spw + sub; s0 < end; s0 += UN * step) {

@@ -28,6 +28,7 @@ struct VoxMlpParams {
     float* raw;                 // [n,4] = (sigma, sigmoid(colour))  voxnerf.py:254
     float* feature;             // [n,G] or null
     char* act;                  // training kernels: activation store, else null
+    const unsigned* wscale = nullptr;   // compensated float16 mode: row-scale words, 32 per output tile in stream order (pack.h StreamBuilderC)
 };
 
 // ---- binned scatter (kernel_voxel_scatter.hip): what the first pass of the tri-plane backward leaves per sample for the second
@@ -70,5 +71,7 @@ int launch_f32_to_f16(const float* x, long n, _Float16* y, hipStream_t st);
 int launch_tv(const float* x, int H, int W, int C, double* partials, int* blocks, hipStream_t st);
 int launch_tv_finish(const double* acc, const TvShape& s, float* out, hipStream_t st);
 int voxel_mlp_dispatch(int prec, int HD, int G, int FT, const VoxMlpParams& p, hipStream_t st);
+int voxel_mlp_c_chunks(int HD, int G, int FT);              // compensated float16 mode (voxel_mlp_c_kernel.h): chunks of its stream, 0 = not built for this level
+int launch_voxel_pipe_f16c(const VoxMlpParams& p, hipStream_t st);
 
 }  // namespace evd

@@ -1,0 +1,132 @@
+// PDRF fine-level network (hidden 256, geo 128, 64 feature channels in; reference networks/pdrf/voxnerf.py:210-221,240-254 with the
+// blurfactory dimensions) in the COMPENSATED float16 mode (EVD_PREC_F16C): sigma net 127 -> 256 -> 1 + 128, colour net 155 -> 256 -> 256 -> 3
+// (sigmoid).  Machinery and arithmetic: mlp_pipe_c.h (one float16 MFMA product + two block-scaled fp6 products of the operands' rounding
+// residuals, one wavefront of 32 samples per SIMD).  This is the mode the shipped (mode='c2f') configurations are rendered in when the
+// 1e-4 RGB bound has to hold on trained weights: the single-product float16 mode measures 3.8e-4 there (tools/trained_c2f.py).
+// Inference only (no feature rows, no activation store); the coarse 64-wide level runs in EVD_PREC_F16X3 next to it (evd_voxel_api.hip).
+#pragma once
+
+#include "mlp_pipe_c.h"
+#include "voxel.h"
+
+namespace evd {
+
+// static layer table of one level: HD hidden width, G geo channels (a multiple of 64), FT feature channels in (64: one input block)
+template <int HD, int G, int FT> struct VoxNetC {
+    static constexpr int T = HD / 32, KB = HD / 64, GT = G / 32, GB = G / 64;
+    static_assert(FT == 64 && PE_KS == 4 && PEV_KS == 2 && T % 2 == 0 && G % 64 == 0 && KB >= 2, "block structure of the inputs");
+    // sigma_net.0 on cat([fts, PE(pts)]) (voxnerf.py:214): blocks [fts | pe]
+    typedef CLayer<2, 4, T, 2, true, false, 0, 0, 0, false, 0, 1> L0;
+    // sigma_net.1 row 0 = sigma (float32 out); drains L0's last group into the hidden block KB - 1
+    typedef CLayer<KB, 4, 1, 1, false, true, L0::NCHUNKS, L0::PAR_OUT, 2, true, KB - 1, 2> Sigma;
+    // sigma_net.1 rows 1..G = geo features, no activation (voxnerf.py:221)
+    typedef CLayer<KB, 4, GT, 2, false, false, Sigma::CHUNK0 + Sigma::NCHUNKS, Sigma::PAR_OUT, 0, false, 0, 2> Geo;
+    // color_net.0 on cat([geo, PE(dirs)]) (voxnerf.py:248): blocks [geo_0 .. geo_{GB-1} | dir (2 k-steps)]; drains geo's last group into block GB - 1
+    typedef CLayer<GB + 1, 2, T, 2, true, false, Geo::CHUNK0 + Geo::NCHUNKS, Geo::PAR_OUT, 2, false, GB - 1, 2> C0;
+    typedef CLayer<KB, 4, T, 2, true, false, C0::CHUNK0 + C0::NCHUNKS, C0::PAR_OUT, 2, true, KB - 1, 1> C1;
+    typedef CLayer<KB, 4, 1, 1, false, true, C1::CHUNK0 + C1::NCHUNKS, C1::PAR_OUT, 2, true, KB - 1, 0> C2;
+    static constexpr int NCH = C2::CHUNK0 + C2::NCHUNKS;
+    // LDS bias / row-scale image in stream order (the sigma net has no biases: zeros)
+    static constexpr int B_SIG = T * 32, B_GEO = B_SIG + 32, B_C0 = B_GEO + GT * 32, B_C1 = B_C0 + T * 32, B_C2 = B_C1 + T * 32, B_END = B_C2 + 32;
+    static constexpr int NTILES = B_END / 32;
+    static_assert(B_END <= CCfg::BIAS_WORDS / 2, "bias / row-scale block");
+};
+
+// one input block from 64 float32 values of a row: B position q = 8 j + e of lane half h <-> value 16 j + 8 h + e (the natural k-step order
+// of evd_voxel_api.hip in0_col), all three representations
+__device__ __forceinline__ void c_block_from_row(const float* f, XBlk& out) {
+    f32x16 r[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(f + 16 * j), b = *reinterpret_cast<const f32x4*>(f + 16 * j + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            r[j >> 1][8 * (j & 1) + e] = a[e];
+            r[j >> 1][8 * (j & 1) + 4 + e] = b[e];
+        }
+    }
+    unsigned m = 0u;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) c_drain_pair<false>(r[k >> 3], k & 7, out, k, m);
+    c_finish(out, m, r[0], r[1]);
+}
+
+template <int HD, int G, int FT>
+__global__ __launch_bounds__(CCfg::NT, 1) void k_voxel_mlp_c(const VoxMlpParams p) {
+    typedef VoxNetC<HD, G, FT> N;
+    typedef CStream<N::NCH> ST;
+    constexpr int KB = N::KB, GB = N::GB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    pipe_fp16_saturate<EVD_PREC_F16>();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, h = lane >> 5;
+    ST st;
+    st.start_issue(p.wstream, smem, tid);
+    float* bias = reinterpret_cast<float*>(smem + CCfg::RING);
+    // bias image (zeros for the sigma net, then the colour-net biases: p.bias = 512 zeros + colour biases, evd_voxel_api.hip) and row scales
+    for (int i = tid; i < N::B_END; i += CCfg::NT) {
+        bias[i] = i < N::B_C0 ? 0.f : p.bias[512 + (i - N::B_C0)];
+        reinterpret_cast<unsigned*>(bias)[CCfg::BIAS_WORDS / 2 + i] = p.wscale[i];
+    }
+    unsigned bias_off = lds_offset_of(bias);
+    asm volatile("" : "+v"(bias_off));     // opaque base: the bias / row-scale reads then take immediate offsets
+    const lds_f32_p lbias = (lds_f32_p)(unsigned long)bias_off;
+
+    const long smp = (long)blockIdx.x * CCfg::SAMPLES + wave * 32 + n;
+    const bool valid = smp < p.nsamp;
+    const long sidx = valid ? smp : p.nsamp - 1;
+    XBlk in0[2], pev;
+    {
+        float pts[3], vd[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            pts[c] = p.pts[sidx * 3 + c];
+            vd[c] = p.viewdirs[(sidx / p.S) * p.vd_stride + c];
+        }
+        c_block_from_row(p.fts + sidx * (long)p.ft_stride + 8 * h, in0[0]);
+        c_encode<PE_L, PE_KS>(pts, h, in0[1]);
+        c_encode<PE_LV, PEV_KS>(vd, h, pev);
+    }
+
+    st.start_wait();
+    CPipe pp;
+    c_prime<typename N::L0>(st, pp, lbias, lane);
+    XBlk hid[KB], none[1];
+    c_layer<typename N::L0, typename N::Sigma, ST, 2, KB>(st, pp, in0, hid, nullptr, lbias, lane);
+    float sig[4], col[4];
+    c_layer<typename N::Sigma, typename N::Geo, ST, KB, 1>(st, pp, hid, none, sig, lbias + N::B_SIG, lane);
+    XBlk cin[GB + 1];
+    c_layer<typename N::Geo, typename N::C0, ST, KB, GB + 1>(st, pp, hid, cin, nullptr, lbias + N::B_GEO, lane);
+    cin[GB] = pev;
+    XBlk c0[KB], c1[KB];
+    c_layer<typename N::C0, typename N::C1, ST, GB + 1, KB>(st, pp, cin, c0, nullptr, lbias + N::B_C0, lane);
+    c_layer<typename N::C1, typename N::C2, ST, KB, KB>(st, pp, c0, c1, nullptr, lbias + N::B_C1, lane);
+    c_layer<typename N::C2, void, ST, KB, 1>(st, pp, c1, none, col, lbias + N::B_C2, lane);
+
+    if (h == 0 && valid) {
+        f32x4 o;
+        o[0] = sig[0];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[1 + c] = 1.f / (1.f + expf(-col[c]));      // torch.sigmoid(h) voxnerf.py:252
+        *reinterpret_cast<f32x4*>(p.raw + sidx * 4) = o;
+    }
+}
+
+template <int HD, int G, int FT>
+static int launch_voxel_c(const VoxMlpParams& p, hipStream_t st) {
+    typedef VoxNetC<HD, G, FT> N;
+    const long blocks = cdiv(p.nsamp, CCfg::SAMPLES);
+    const size_t lds = CCfg::TOTAL;
+    EVD_SET_MAX_LDS((&k_voxel_mlp_c<HD, G, FT>), lds);
+    if (p.nchunks != N::NCH) return fail(EVD_E_INVALID, "evd_voxel (f16c): packed stream has %d chunks, kernel expects %d", p.nchunks, N::NCH);
+    if (!p.wscale) return fail(EVD_E_INVALID, "evd_voxel (f16c): no row scales");
+    if (p.feature || p.act) return fail(EVD_E_INVALID, "evd_voxel (f16c): feature rows / activation store are not built in this mode (use EVD_PREC_F16X3)");
+    hipLaunchKernelGGL((k_voxel_mlp_c<HD, G, FT>), dim3((unsigned)blocks), dim3(CCfg::NT), lds, st, p);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+constexpr bool voxel_c_built(int HD, int G, int FT) { return HD == 256 && G == 128 && FT == 64; }
+
+}  // namespace evd

@@ -18,9 +18,23 @@ def _np32(v):
     return np.ascontiguousarray(v, dtype=np.float32)
 
 
-# the grid gradients of the training path accumulate straight into the leaves' .grad (see _grid_grads); EVD_GRADS_IN_PLACE=0 restores
-# the plain autograd returns
-_GRADS_IN_PLACE = os.environ.get("EVD_GRADS_IN_PLACE", "1") != "0"
+# Grid gradients of the training path.  DEFAULT: plain autograd returns (torch.autograd.grad, backward(inputs=...), tensor hooks and
+# post-accumulate-grad hooks all work on the grid leaves).  OPT-IN (set_grads_in_place(True), or NeRFAll.enable_training(...,
+# grads_in_place=True), or EVD_GRADS_IN_PLACE=1): the scatter / TV backward kernels add straight into the leaves' .grad and return
+# None to autograd -- valid ONLY for a plain loss.backward() followed by optimizer.step() (what run_nerf.py:593-601 does); it saves
+# zeroing and re-adding 165 MB of gradient tensors eleven times per blurfactory iteration.
+_GRADS_IN_PLACE = os.environ.get("EVD_GRADS_IN_PLACE", "0") == "1"
+
+
+def set_grads_in_place(on: bool):
+    """Opt in to / out of the in-place accumulation of the grid gradients (see above).  Returns the previous setting."""
+    global _GRADS_IN_PLACE
+    prev, _GRADS_IN_PLACE = _GRADS_IN_PLACE, bool(on)
+    return prev
+
+
+def grads_in_place() -> bool:
+    return _GRADS_IN_PLACE
 
 
 def _grid_grads(net, like, in_place=False):
@@ -57,7 +71,7 @@ class _VoxelSample(torch.autograd.Function):
     def backward(ctx, d_out):
         net, pts = ctx.net, ctx.pts.reshape(-1, 3).contiguous().float()
         g = d_out.reshape(-1, net.app_dim).contiguous().float()
-        grads, gs = _grid_grads(net, ctx.saved_tensors, in_place=_GRADS_IN_PLACE)
+        grads, gs = _grid_grads(net, ctx.saved_tensors, in_place=_GRADS_IN_PLACE and not torch.is_grad_enabled())
         d_pts = torch.empty_like(pts) if ctx.needs_input_grad[0] else None
         # scratch for the hybrid form of the scatter (csrc/kernel_voxel_scatter.hip: plane taps by direct float atomics, line taps through
         # fixed-point LDS slices -- a third fewer atomic requests, 24-27 % faster); EVD_SCATTER=direct passes none: every tap an atomic
@@ -124,7 +138,7 @@ class _VoxelTV(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_loss):
         net = ctx.net
-        grads, gs = _grid_grads(net, ctx.saved_tensors, in_place=_GRADS_IN_PLACE)
+        grads, gs = _grid_grads(net, ctx.saved_tensors, in_place=_GRADS_IN_PLACE and not torch.is_grad_enabled())
         gs.basis = None
         d = d_loss.reshape(1).contiguous().float()
         L.check(L.lib().evd_voxel_tv_loss_bwd(net._h, L.ptr(d), C.byref(gs), L.stream_ptr()), "evd_voxel_tv_loss_bwd")
@@ -362,7 +376,8 @@ class VoxelNeRFBase:
         dev = p.device
         f32 = dict(dtype=torch.float32, device=dev)
         color, depth, acc = torch.empty((R, 3), **f32), torch.empty((R,), **f32), torch.empty((R,), **f32)
-        wts, feat = torch.empty((R, S), **f32), torch.empty((R, S, self.geo_feat_dim), **f32)
+        # (the compensated float16 mode is an inference mode without per-sample feature rows: feature_map is None there)
+        wts, feat = torch.empty((R, S), **f32), (torch.empty((R, S, self.geo_feat_dim), **f32) if (precision or self.precision) != "f16c" else None)
         need = int(L.lib().evd_voxel_forward_workspace_bytes(self._h, R, S))
         ws = torch.empty((need,), dtype=torch.uint8, device=dev)
         L.check(L.lib().evd_voxel_forward(self._h, L.PREC[precision or self.precision], L.ptr(p), L.ptr(vd), 3, L.ptr(ft), ft.shape[-1],

@@ -1,0 +1,130 @@
+"""GPU parity of the shipped PDRF configuration (mode='c2f', grids 293x293x195 / 586x586x390) on TRAINED parameters, and the compensated
+float16 mode (EVD_PREC_F16C) of the fine level's networks (csrc/voxel_mlp_c_kernel.h).  VERDICT r2 item 1: the single-product
+float16 mode holds north_star's 1e-4 RGB bound on seed-derived weights (7e-5) but not on trained ones (3.8e-4 fine / 2.3e-4 coarse after
+3000 iterations of the library's own training path, tools/trained_c2f.py); f32, f16x3 and f16c must hold it on both.  The oracle is
+oracle/evd_oracle.c (evo_render_c2f, reference renderer.py:182-217 + voxnerf.py), never another kernel of this library."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, maxabs
+from evdeblurnerf_amd import weights as W
+
+pytestmark = pytest.mark.gpu
+AABB = W.BLURFACTORY_AABB
+
+
+def T(x):
+    return torch.as_tensor(np.ascontiguousarray(x), device="cuda")
+
+
+def N(x):
+    return x.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def trained_c2f():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import trained_c2f as TC
+    sd, rep = TC.train_c2f(iters=3000)
+    print("trained c2f:", rep)
+    return TC, sd, rep
+
+
+def test_trained_c2f_every_mode_vs_oracle(O, trained_c2f):
+    """4096 event rays x (64 + 64) samples through both trained levels: RGB L-inf (fine and coarse output) of every arithmetic mode against
+    the oracle on 256 rays spread over the batch.  Bound 1e-4 for f32 / f16x3 / f16c (measured 5e-7 / 5e-7 / ~2e-5); the single-product modes
+    are reported and bounded loosely -- they are throughput modes, and the test pins that f16c is what closes their gap."""
+    TC, sd, rep = trained_c2f
+    assert rep["loss_last"] < 0.01 * rep["loss_first"]                    # it did train (0.28 -> 6e-5)
+    err, info = TC.c2f_parity(O, sd, ("f32", "f16x3", "f16c", "f16", "bf16"))
+    print("RGB L-inf vs the oracle, trained c2f, 4096 x (64 + 64):", {k: {a: f"{b:.2e}" for a, b in v.items()} for k, v in err.items()}, info)
+    assert info["rgb_std"] > 0.1                                           # a structured image, not the near-constant initial field
+    for p in ("f32", "f16x3", "f16c"):
+        assert err[p]["fine"] < 1e-4 and err[p]["coarse"] < 1e-4, (p, err[p])
+    assert err["f16c"]["fine"] < 0.5 * err["f16"]["fine"]
+    assert err["f16"]["fine"] < 5e-3 and err["bf16"]["fine"] < 5e-2
+
+
+def test_trained_c2f_full_frame_f16c_vs_oracle(O, trained_c2f):
+    """BASELINE config 5 on the trained parameters: one 400 x 400 view (160 000 rays, 64 + 128 samples, rays generated on the device) in the
+    compensated mode against the oracle on 256 rays of the frame: <= 1e-4."""
+    from evdeblurnerf_amd.rays import get_rays
+    TC, sd, _ = trained_c2f
+    K = W.synthetic_camera()
+    c2w = W.synthetic_pose(40)[:3, :4].astype(np.float32)
+    o, d = get_rays(400, 400, K, T(c2w))
+    rays = N(torch.stack([o, d], -1).reshape(-1, 3, 2))
+    err, _ = TC.c2f_parity(O, sd, ("f16c", "f16"), Ni=128, rays=rays)
+    print("RGB L-inf vs the oracle, trained c2f, full frame 64 + 128:", err)
+    assert err["f16c"]["fine"] < 1e-4 and err["f16c"]["coarse"] < 1e-4
+
+
+def _fine_level(seed, nvox=48 ** 3, bias=True):
+    from evdeblurnerf_amd.voxnerf import VoxelNeRFSampleFeatures
+    gsz = W.pdrf_grid_size(AABB[0], AABB[1], nvox)
+    sd = W.make_pdrf_state_dict(seed, gsz, input_ch=127, hidden_dim=256, geo_feat_dim=128, add_bias_color=bias)
+    net = VoxelNeRFSampleFeatures(sd, "", AABB, num_layers=2, hidden_dim=256, geo_feat_dim=128, num_layers_color=3, input_ch=127, app_dim=32,
+                                  app_n_comp=(64, 16, 16), n_voxels=nvox)
+    return net, sd
+
+
+def _level_inputs(rs, R, S, scale=0.3):
+    pts = rs.uniform(-1, 1, (R, S, 3)).astype(np.float32)
+    d = rs.normal(size=(R, 3))
+    vd = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32)
+    fts = (scale * rs.normal(size=(R, S, 64))).astype(np.float32)
+    z = np.sort(rs.uniform(0, 1, (R, S)).astype(np.float32), -1)
+    rd = rs.uniform(-1, 1, (R, 3)).astype(np.float32)
+    return T(pts), T(vd), T(fts), T(z), T(rd)
+
+
+def test_fine_level_f16c_ragged_sizes_repack_and_rejections():
+    """The fine level's networks alone (evd_voxel_forward) in the compensated mode against the exact-float32 kernel at sizes that are not
+    multiples of its 128-sample workgroups, with colour biases, with large feature magnitudes (block scales), after a device re-pack of new
+    parameters (lazy: bit-identical to a fresh handle), and its rejections."""
+    from evdeblurnerf_amd import _lib as L
+    net, sd = _fine_level(71)
+    rs = np.random.RandomState(11)
+    for R, S in ((1, 1), (1, 128), (3, 43), (70, 33), (129, 127)):
+        a = _level_inputs(rs, R, S)
+        ref = net.forward(*a, precision="f32")
+        got = net.forward(*a, precision="f16c")
+        e16 = maxabs(N(net.forward(*a, precision="f16")[0]), N(ref[0]))
+        ec = maxabs(N(got[0]), N(ref[0]))
+        assert got[4] is None and ec < 2e-5, (R, S, ec)
+        assert maxabs(N(got[3]), N(ref[3])) < 2e-5                      # compositing weights (the sigma head)
+        if R * S > 1000:
+            assert ec < 0.3 * e16, (ec, e16)
+    a = _level_inputs(rs, 64, 64, scale=30.0)                           # features of magnitude ~100: finite, and still close
+    ref, got = net.forward(*a, precision="f32"), net.forward(*a, precision="f16c")
+    assert torch.isfinite(got[0]).all() and maxabs(N(got[0]), N(ref[0])) < 1e-3
+    # device re-pack (evd_voxel_load_params keeps the values, the next f16c launch re-packs): equal to a handle created from those values
+    net2, sd2 = _fine_level(72)
+    a = _level_inputs(rs, 70, 33)
+    fresh = N(net2.forward(*a, precision="f16c")[0])
+    before = N(net.forward(*a, precision="f16c")[0])
+    net.load_params(net.flat_params(sd2).detach())
+    net.load_grids([g.detach() for g in net2.grid_params()])
+    again = N(net.forward(*a, precision="f16c")[0])
+    assert not np.array_equal(before, fresh) and np.array_equal(again, fresh)
+    # the coarse level has no compensated kernel: it runs float32-grade (f16x3) under the same mode name
+    from evdeblurnerf_amd.voxnerf import VoxelNeRFRayFeatures
+    gsz = W.pdrf_grid_size(AABB[0], AABB[1], 24 ** 3)
+    sdc = W.make_pdrf_state_dict(5, gsz, input_ch=95, hidden_dim=64, geo_feat_dim=15)
+    coarse = VoxelNeRFRayFeatures(sdc, "", AABB, n_voxels=24 ** 3)
+    pts, vd, _, z, rd = _level_inputs(rs, 40, 17)
+    ftc = T((0.3 * rs.normal(size=(40, 17, 32))).astype(np.float32))
+    assert torch.equal(coarse.forward(pts, vd, ftc, z, rd, precision="f16c")[0], coarse.forward(pts, vd, ftc, z, rd, precision="f16x3")[0])
+    # training is not built in this mode
+    with pytest.raises(L.EvdError):
+        net.mlpforward_train(a[0], a[1], a[2], precision="f16c")

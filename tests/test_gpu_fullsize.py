@@ -123,7 +123,7 @@ def _c2f_checks(O, model, vc, vf, rays, Ni, prec, tol, n_oracle=256):
     return rgb, kw
 
 
-@pytest.mark.parametrize("prec,tol", [("f32", 1e-4), ("f16x3", 1e-4), ("f16", 3e-4), ("bf16", 3e-2)])
+@pytest.mark.parametrize("prec,tol", [("f32", 1e-4), ("f16x3", 1e-4), ("f16c", 1e-4), ("f16", 3e-4), ("bf16", 3e-2)])
 def test_blurfactory_event_batch_at_real_grid_sizes(prec, tol, O, blurfactory):
     """BASELINE configs 2/3: 4096 event rays x (64 + 64) samples through both PDRF levels at grids 293x293x195 / 586x586x390."""
     from evdeblurnerf_amd.renderer import NeRFAll
@@ -139,7 +139,7 @@ def test_blurfactory_event_batch_at_real_grid_sizes(prec, tol, O, blurfactory):
         assert torch.equal(model.render(400, 400, K, chunk=1000, rays=T(rays), **kw)[0], rgb)          # chunking changes nothing
 
 
-@pytest.mark.parametrize("prec,tol", [("f16x3", 1e-4), ("f16", 3e-4)])
+@pytest.mark.parametrize("prec,tol", [("f16x3", 1e-4), ("f16c", 1e-4), ("f16", 3e-4)])
 def test_blurfactory_full_frame_at_real_grid_sizes(prec, tol, O, blurfactory):
     """BASELINE config 5: one 400 x 400 view = 160 000 rays, 64 + 128 samples (render_kwargs_test), get_rays on the device."""
     from evdeblurnerf_amd.rays import get_rays
