@@ -42,11 +42,11 @@ class NerfDesc(C.Structure):
 class NerfGrads(C.Structure):
     _fields_ = [("pts_w", _vp * MAXL), ("pts_b", _vp * MAXL),
                 ("views_w", _vp), ("views_b", _vp), ("feature_w", _vp), ("feature_b", _vp),
-                ("alpha_w", _vp), ("alpha_b", _vp), ("rgb_w", _vp), ("rgb_b", _vp)]
+                ("alpha_w", _vp), ("alpha_b", _vp), ("rgb_w", _vp), ("rgb_b", _vp), ("accumulate", C.c_int)]
 
 
 class VoxelGrads(C.Structure):
-    _fields_ = [("sigma_w", _vp * 2), ("color_w", _vp * 3), ("color_b", _vp * 3)]
+    _fields_ = [("sigma_w", _vp * 2), ("color_w", _vp * 3), ("color_b", _vp * 3), ("accumulate", C.c_int)]
 
 
 class AwpEmbedGrads(C.Structure):
@@ -104,6 +104,9 @@ SIGNATURES = {
     "evd_ndc_rays": (_I, [_I, _I, _F, _F, _vp, _vp, _L, _vp, _vp, _vp]),
     "evd_embed": (_I, [_vp, _L, _I, _I, _vp, _vp]),
     "evd_ray_batch": (_I, [C.POINTER(RenderCfg), _vp, _L, _vp, _vp]),
+    "evd_ray_batch_bwd": (_I, [C.POINTER(RenderCfg), _vp, _vp, _L, _vp, _vp]),
+    "evd_points": (_I, [_vp, _I, _vp, _L, _I, _vp, _vp]),
+    "evd_points_bwd": (_I, [_vp, _vp, _L, _I, _I, _vp, _vp]),
     "evd_sample_z": (_I, [C.POINTER(RenderCfg), _vp, _I, _L, _vp, _vp, _vp]),
     "evd_nerf_create": (_I, [C.POINTER(NerfDesc), C.POINTER(_vp)]),
     "evd_nerf_destroy": (None, [_vp]),

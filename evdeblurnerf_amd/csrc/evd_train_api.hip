@@ -84,6 +84,7 @@ int evd_nerf_mlp_backward(const evd_nerf* net, int precision, const float* d_raw
     for (int l = 0; l < EVD_MAX_LAYERS; ++l) { b.grads.pts_w[l] = l < net->D ? grads->pts_w[l] : nullptr; b.grads.pts_b[l] = l < net->D ? grads->pts_b[l] : nullptr; }
     b.grads.views_w = grads->views_w; b.grads.views_b = grads->views_b; b.grads.feature_w = grads->feature_w; b.grads.feature_b = grads->feature_b;
     b.grads.alpha_w = grads->alpha_w; b.grads.alpha_b = grads->alpha_b; b.grads.rgb_w = grads->rgb_w; b.grads.rgb_b = grads->rgb_b;
+    b.accumulate = grads->accumulate ? 1 : 0;
     return precision == EVD_PREC_F16 ? run_nerf_backward_f16(b, as_stream(stream))
            : precision == EVD_PREC_BF16 ? run_nerf_backward_bf16(b, as_stream(stream)) : run_nerf_backward_f16x3(b, as_stream(stream));
 }

@@ -472,6 +472,12 @@ int evd_c2f_render(const evd_voxel* coarse, const evd_voxel* fine, const evd_ren
     return evd_c2f_render_rays(coarse, fine, cfg, rb, R, t_rand, u, noise0, noise1, out, workspace, workspace_bytes, stream);
 }
 
+int evd_points(const float* ray_batch, int ncol, const float* z, long R, int S, float* pts, void* stream) {
+    EVD_REQUIRE(ray_batch && z && pts && ncol >= 6 && R >= 0 && S >= 1, "evd_points: bad arguments");
+    if (R == 0) return EVD_OK;
+    return launch_points(ray_batch, ncol, z, R * (long)S, S, pts, as_stream(stream));
+}
+
 // ---- the coarse feature rows of the merged sample set (renderer.py:209-213), as an operation of its own for the training path
 int evd_merge_features(const float* old, const float* fresh, const int* order, long R, int S, int N, int F, float* out, int out_stride, void* stream) {
     EVD_REQUIRE(old && fresh && order && out && R >= 0 && S >= 1 && N >= 1 && F >= 4 && F % 4 == 0 && out_stride >= F && out_stride % 4 == 0,
@@ -597,6 +603,7 @@ int evd_voxel_mlp_backward(const evd_voxel* v, int precision, const float* d_raw
     b.pts = pts; b.viewdirs = viewdirs; b.vd_stride = vd_stride; b.S = S; b.d_pts = d_pts; b.d_dirs = d_dirs;
     for (int i = 0; i < 2; ++i) b.grads.sigma_w[i] = grads->sigma_w[i];
     for (int i = 0; i < 3; ++i) { b.grads.color_w[i] = grads->color_w[i]; b.grads.color_b[i] = grads->color_b[i]; }
+    b.accumulate = grads->accumulate ? 1 : 0;
     return run_voxel_backward_dispatch(precision, v->hidden_dim, b, as_stream(stream));
 }
 
@@ -622,17 +629,48 @@ int evd_voxel_get_grids(const evd_voxel* v, float* const* plane, float* const* l
     return EVD_OK;
 }
 
+// the seven tensors of a level in ONE launch: every source value is read once and written twice, as the float32 copy the float32-grade modes
+// and the backward gather, and as the float16 copy the half-precision modes gather (13 launches and a second read of 165 MB before)
+struct GridLoadSeg { const float* src; float* dst; _Float16* dst_h; long n4, tail0, n; };
+struct GridLoadSegs { GridLoadSeg s[7]; };
+static __global__ __launch_bounds__(256) void k_load_grids(const GridLoadSegs segs) {
+    const GridLoadSeg s = segs.s[blockIdx.y];
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < s.n4; i += stride) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(s.src)[i];
+        reinterpret_cast<f32x4*>(s.dst)[i] = v;
+        if (s.dst_h) {
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            const h4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            reinterpret_cast<h4*>(s.dst_h)[i] = h;
+        }
+    }
+    for (long i = s.tail0 + (long)blockIdx.x * 256 + threadIdx.x; i < s.n; i += stride) {
+        s.dst[i] = s.src[i];
+        if (s.dst_h) s.dst_h[i] = (_Float16)s.src[i];
+    }
+}
+
 int evd_voxel_load_grids(evd_voxel* v, const float* const* plane, const float* const* line, const float* basis, void* stream) {
     EVD_REQUIRE(v && plane && line && basis, "evd_voxel_load_grids: null argument");
     hipStream_t st = as_stream(stream);
-    int rc;
+    GridLoadSegs segs;
+    long nmax = 0;
+    auto seg = [&](int k, const float* src, DevBuf& dst, DevBuf* dst_h) {
+        const long n = (long)(dst.bytes / sizeof(float));
+        const bool vec = ((uintptr_t)src % 16) == 0;            // device allocations are 256-byte aligned; a caller's slice may not be
+        segs.s[k] = GridLoadSeg{src, (float*)dst.p, dst_h ? (_Float16*)dst_h->p : nullptr, vec ? n / 4 : 0, vec ? (n / 4) * 4 : 0, n};
+        nmax = n > nmax ? n : nmax;
+    };
     for (int i = 0; i < 3; ++i) {
-        EVD_HIP(hipMemcpyAsync(v->plane[i].p, plane[i], v->plane[i].bytes, hipMemcpyDeviceToDevice, st));
-        EVD_HIP(hipMemcpyAsync(v->line[i].p, line[i], v->line[i].bytes, hipMemcpyDeviceToDevice, st));
-        if ((rc = launch_f32_to_f16((const float*)v->plane[i].p, (long)(v->plane[i].bytes / 4), (_Float16*)v->plane_h[i].p, st))) return rc;
-        if ((rc = launch_f32_to_f16((const float*)v->line[i].p, (long)(v->line[i].bytes / 4), (_Float16*)v->line_h[i].p, st))) return rc;
+        EVD_REQUIRE(plane[i] && line[i], "evd_voxel_load_grids: missing grid %d", i);
+        seg(i, plane[i], v->plane[i], &v->plane_h[i]);
+        seg(3 + i, line[i], v->line[i], &v->line_h[i]);
     }
-    EVD_HIP(hipMemcpyAsync(v->basis.p, basis, v->basis.bytes, hipMemcpyDeviceToDevice, st));
+    seg(6, basis, v->basis, nullptr);
+    const long bx = cdiv(nmax / 4 + 1, 256L) < 2048 ? cdiv(nmax / 4 + 1, 256L) : 2048;
+    hipLaunchKernelGGL(k_load_grids, dim3((unsigned)bx, 7), dim3(256), 0, st, segs);
+    EVD_LAUNCH_CHECK();
     return EVD_OK;
 }
 

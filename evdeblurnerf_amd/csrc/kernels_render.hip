@@ -187,6 +187,71 @@ __global__ void k_ray_batch(const float* __restrict__ rays, long R, int ndc, int
     out[7] = far;
 }
 
+// Backward of k_ray_batch (training: the loss reaches the blur kernel's camera motion through the packed rays, renderer.py:303-308):
+// d ray_batch [R,11] -> d rays [R,3,2].  One thread per ray; the forward's intermediate values are recomputed.  near / far columns carry
+// no gradient.  With o' = o + t d, t = -(1 + o_z) / d_z, a = o'_z:   o_out = (cw o'_x / a, ch o'_y / a, 1 + 2 / a),
+// d_out = (cw (d_x / d_z - o'_x / a), ch (d_y / d_z - o'_y / a), -2 / a),   viewdirs = d / |d|   (utils/rays.py:104-145, renderer.py:431).
+__global__ void k_ray_batch_bwd(const float* __restrict__ rays, const float* __restrict__ g, long R, int ndc, float cw, float ch, float* __restrict__ d_rays) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    float o[3], d[3], go[3], gd[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { o[c] = rays[i * 6 + c * 2]; d[c] = rays[i * 6 + c * 2 + 1]; }
+    const float* gr = g + i * 11;
+    const float goo[3] = {gr[0], gr[1], gr[2]}, gdo[3] = {gr[3], gr[4], gr[5]}, gv[3] = {gr[8], gr[9], gr[10]};
+    if (ndc) {
+        const float t = -(1.f + o[2]) / d[2];
+        const float px = o[0] + t * d[0], py = o[1] + t * d[1], a = o[2] + t * d[2];
+        const float ia = 1.f / a, idz = 1.f / d[2];
+        const float g_ox = cw * (goo[0] - gdo[0]), g_oy = ch * (goo[1] - gdo[1]);            // d loss / d (o'_x / a), d (o'_y / a)
+        const float gp[3] = {g_ox * ia, g_oy * ia, (2.f * (gdo[2] - goo[2]) - g_ox * px - g_oy * py) * ia * ia};   // d loss / d o'
+        const float g_t = gp[0] * d[0] + gp[1] * d[1] + gp[2] * d[2];
+        go[0] = gp[0]; go[1] = gp[1]; go[2] = gp[2] - g_t * idz;
+        gd[0] = t * gp[0] + cw * gdo[0] * idz;
+        gd[1] = t * gp[1] + ch * gdo[1] * idz;
+        gd[2] = t * gp[2] - (cw * gdo[0] * d[0] + ch * gdo[1] * d[1]) * idz * idz + g_t * (1.f + o[2]) * idz * idz;
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { go[c] = goo[c]; gd[c] = gdo[c]; }
+    }
+    const float n2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2], inr = 1.f / sqrtf(n2);
+    const float dot = (gv[0] * d[0] + gv[1] * d[1] + gv[2] * d[2]) / n2;                    // (viewdirs . g) / |d|
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        gd[c] += (gv[c] - d[c] * dot) * inr;
+        d_rays[i * 6 + c * 2] = go[c];
+        d_rays[i * 6 + c * 2 + 1] = gd[c];
+    }
+}
+
+// pts = o + d z under autograd: d pts [R,S,3] -> rows of d ray_batch (columns 0..2 += sum_s d pts, 3..5 += sum_s z d pts; the others are
+// left alone): one wavefront per ray, DPP-free shuffle reduction (S <= a few hundred)
+__global__ __launch_bounds__(256) void k_points_bwd(const float* __restrict__ z, const float* __restrict__ d_pts, long R, int S, int accumulate,
+                                                    float* __restrict__ d_rb) {
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= R) return;
+    float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s = lane; s < S; s += 64) {
+        const float zv = z[r * S + s];
+        const float* p = d_pts + (r * S + s) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { a[c] += p[c]; a[3 + c] += zv * p[c]; }
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) a[q] += __shfl_xor(a[q], off);
+    if (lane < 11) {                 // overwrite mode: the whole row (zeros in the near / far / viewdirs columns), so the caller needs no fill
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) v = lane == q ? a[q] : v;
+        float* out = d_rb + r * 11 + lane;
+        if (accumulate) { if (lane < 6) *out += v; }
+        else *out = v;
+    }
+}
+
 // reference networks/renderer.py:163-178
 __global__ void k_sample_z(const float* __restrict__ rb, int nc, long R, int S, int lindisp, int perturb,
                            const float* __restrict__ t_rand, float* __restrict__ z) {
@@ -761,6 +826,24 @@ int evd_ray_batch(const evd_render_cfg* cfg, const float* rays, long R, float* r
     float cw, ch;
     ndc_coeffs(cfg->H, cfg->W, cfg->focal, &cw, &ch);
     k_ray_batch<<<cdiv(R, 256), 256, 0, as_stream(stream)>>>(rays, R, cfg->ndc, cfg->use_viewdirs, cw, ch, cfg->near, cfg->far, ray_batch);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+int evd_ray_batch_bwd(const evd_render_cfg* cfg, const float* rays, const float* d_ray_batch, long R, float* d_rays, void* stream) {
+    EVD_REQUIRE(cfg && rays && d_ray_batch && d_rays && R >= 0 && cfg->use_viewdirs, "evd_ray_batch_bwd: bad arguments (11-column batch)");
+    if (R == 0) return EVD_OK;
+    float cw, ch;
+    ndc_coeffs(cfg->H, cfg->W, cfg->focal, &cw, &ch);
+    k_ray_batch_bwd<<<cdiv(R, 256), 256, 0, as_stream(stream)>>>(rays, d_ray_batch, R, cfg->ndc, cw, ch, d_rays);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+int evd_points_bwd(const float* z, const float* d_pts, long R, int S, int accumulate, float* d_ray_batch, void* stream) {
+    EVD_REQUIRE(z && d_pts && d_ray_batch && R >= 0 && S >= 1, "evd_points_bwd: bad arguments");
+    if (R == 0) return EVD_OK;
+    k_points_bwd<<<cdiv(R, 4), 256, 0, as_stream(stream)>>>(z, d_pts, R, S, accumulate, d_ray_batch);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }

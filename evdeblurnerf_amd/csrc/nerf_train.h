@@ -37,6 +37,7 @@ struct BwdPlan {
     hipStream_t side;                   // second stream for the wgrad launches (null: everything on the caller's stream)
     hipEvent_t ev;
     BwdGrads grads;
+    int accumulate = 0;                 // 1: the parameter gradients are ADDED into the caller's buffers (evd_nerf_grads.accumulate)
     const float *pts, *viewdirs;        // [nsamp,3] sample positions / rows of vd_stride floats per ray (the encodings' derivatives)
     int vd_stride, S;
     float *d_pts, *d_dirs;              // [nsamp,3] float32 out (through the positional encodings), or null

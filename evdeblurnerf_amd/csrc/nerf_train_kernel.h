@@ -342,6 +342,7 @@ struct WreduceParams {
     int ld;
     float* db;                         // or null
     const unsigned* maxbits;
+    int accum = 0;                     // 1: add into dW / db (the caller's persistent gradient buffers) instead of overwriting them
 };
 
 // A block sums 64 float4 columns of the partials (4 slices of the workgroup list, folded through LDS), then scatters
@@ -370,9 +371,12 @@ static __global__ __launch_bounds__(256) void k_wgrad_reduce(const WreduceParams
         if (row < 0) continue;
         if (c < p.CT) {
             const int col = p.colmap[c * 32 + nc];
-            if (col >= 0) p.dW[(long)row * p.ld + col] = s[k] * inv;
+            if (col >= 0) {            // (row, col) is hit by exactly one thread of one launch: a plain read-modify-write
+                float* w = p.dW + (long)row * p.ld + col;
+                *w = p.accum ? *w + s[k] * inv : s[k] * inv;
+            }
         } else if (nc == 0 && p.db) {
-            p.db[row] = s[k] * inv;
+            p.db[row] = p.accum ? p.db[row] + s[k] * inv : s[k] * inv;
         }
     }
 }
@@ -562,7 +566,7 @@ template <int PREC> static int run_nerf_backward(const BwdPlan& b, hipStream_t s
         if (r) return r;
         WreduceParams q;
         q.partial = b.partial; q.nparts = blocks; q.RT = RT; q.CT = CT; q.NC = CT + (bias ? 1 : 0);
-        q.rowmap = b.maps + ymap; q.colmap = b.maps + xmap; q.dW = dW; q.ld = ld; q.db = bias ? db : nullptr; q.maxbits = b.maxbits;
+        q.rowmap = b.maps + ymap; q.colmap = b.maps + xmap; q.dW = dW; q.ld = ld; q.db = bias ? db : nullptr; q.maxbits = b.maxbits; q.accum = b.accumulate;
         hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((long)RT * q.NC * 4)), dim3(256), 0, ws, q);
         EVD_LAUNCH_CHECK();
         return EVD_OK;

@@ -46,6 +46,7 @@ struct VoxBwdPlan {
     int vd_stride, S;
     float *d_pts, *d_dirs;              // [nsamp, 3] float32 out (through PE(pts) / PE(dirs) only), or null
     VoxBwdGrads grads;
+    int accumulate = 0;                 // 1: the parameter gradients are ADDED into the caller's buffers (evd_voxel_grads.accumulate)
 };
 
 int launch_voxel_train_fwd_f16(int HD, const VoxMlpParams& p, hipStream_t st);

@@ -94,28 +94,57 @@ class GradReducer:
 
         reducer = GradReducer(params)           # once
         loss.backward(); reducer.start(); ...; reducer.wait(); optimizer.step()
+
+    flat_buffers (NeRFAll.grad_buffers() of a model trained with enable_training(grads_in_place=True)): [(buffer, params)] -- persistent
+    flat gradient buffers whose slices ARE the .grad of `params`.  Such a buffer is all-reduced where it lies: no packing copy before
+    and no scatter copy after the collective (the 150 MB of PDRF grid gradients are two messages, the level networks two more).  If
+    the gradients of a group are not attached to its buffer at start() (the caller never ran a backward in place), the group falls
+    back to the bucket path for that step.
     """
 
-    def __init__(self, params, bucket_bytes=64 << 20):
-        self.params = [p for p in params if p is not None]
-        self.buckets, cur, size = [], [], 0
-        for p in self.params:
+    def __init__(self, params, bucket_bytes=64 << 20, flat_buffers=()):
+        self.flat_groups = [(buf, [p for p in ps if p is not None]) for buf, ps in flat_buffers]
+        in_flat = {id(p) for _, ps in self.flat_groups for p in ps}
+        self.bucket_bytes = bucket_bytes
+        self.params = [p for p in params if p is not None and id(p) not in in_flat]
+        self.buckets = self._make_buckets(self.params)
+        self._flat = [None] * len(self.buckets)
+        self._work = []
+        self._late = []
+
+    def _make_buckets(self, params):
+        bucket_bytes = self.bucket_bytes
+        buckets, cur, size = [], [], 0
+        for p in params:
             nb = p.numel() * 4
             if cur and size + nb > bucket_bytes:
-                self.buckets.append(cur)
+                buckets.append(cur)
                 cur, size = [], 0
             cur.append(p)
             size += nb
         if cur:
-            self.buckets.append(cur)
-        self._flat = [None] * len(self.buckets)
-        self._work = []
+            buckets.append(cur)
+        return buckets
+
+    @staticmethod
+    def _attached(buf, params):
+        """every parameter's .grad is a view of `buf` (same storage, inside its extent)"""
+        lo, hi = buf.data_ptr(), buf.data_ptr() + buf.numel() * buf.element_size()
+        return all(p.grad is not None and p.grad.is_contiguous() and lo <= p.grad.data_ptr() and p.grad.data_ptr() + p.grad.numel() * 4 <= hi
+                   for p in params)
 
     def start(self):
         import torch.distributed as dist
-        self._work = []
+        self._work, self._late = [], []
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
+        for buf, ps in self.flat_groups:            # in place: the largest messages first
+            if self._attached(buf, ps):
+                self._work.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True), None))
+            else:
+                self._late += ps
+        late_buckets = self._make_buckets(self._late) if self._late else []
+        self._late_buckets, self._late_flat = late_buckets, [None] * len(late_buckets)
         for i, bucket in enumerate(self.buckets):
             n = sum(p.numel() for p in bucket)
             if self._flat[i] is None or self._flat[i].numel() != n:
@@ -125,16 +154,28 @@ class GradReducer:
                 g = p.grad if p.grad is not None else torch.zeros_like(p)
                 self._flat[i][off:off + p.numel()].copy_(g.reshape(-1))
                 off += p.numel()
-            self._work.append(dist.all_reduce(self._flat[i], op=dist.ReduceOp.SUM, async_op=True))
+            self._work.append((dist.all_reduce(self._flat[i], op=dist.ReduceOp.SUM, async_op=True), (bucket, self._flat[i])))
+        for i, bucket in enumerate(late_buckets):
+            n = sum(p.numel() for p in bucket)
+            flat = torch.empty((n,), dtype=torch.float32, device=bucket[0].device)
+            off = 0
+            for p in bucket:
+                g = p.grad if p.grad is not None else torch.zeros_like(p)
+                flat[off:off + p.numel()].copy_(g.reshape(-1))
+                off += p.numel()
+            self._work.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), (bucket, flat)))
 
     def wait(self):
-        for i, w in enumerate(self._work):
+        for w, packed in self._work:
             w.wait()
+            if packed is None:
+                continue
+            bucket, flat = packed
             off = 0
-            for p in self.buckets[i]:
+            for p in bucket:
                 if p.grad is None:
                     p.grad = torch.empty_like(p)
-                p.grad.copy_(self._flat[i][off:off + p.numel()].reshape(p.shape))
+                p.grad.copy_(flat[off:off + p.numel()].reshape(p.shape))
                 off += p.numel()
         self._work = []
 

@@ -74,23 +74,25 @@ class _NerfMLP(torch.autograd.Function):
         raw, store = net.mlpforward_train(ray_batch, z_vals, precision)
         ctx.net, ctx.precision, ctx.store = net, precision, store
         ctx.rb, ctx.z = ray_batch, z_vals
+        ctx.accum = getattr(flat, "_evd_accum", None)          # in-place gradient accumulation (renderer._FlatParams), opt-in
         return raw
 
     @staticmethod
     def backward(ctx, d_raw):
         d_rb = None
+        acc = ctx.accum() if (ctx.accum is not None and ctx.needs_input_grad[0] and not torch.is_grad_enabled()) else None
         if ctx.needs_input_grad[1]:
             # rays: pts = o + d z enters PE(pts) (layer 0 and the skip layer), the view direction PE(dirs); z is a constant
             rb, z = ctx.rb.detach().contiguous().float(), ctx.z.detach().contiguous().float()
             pts = (rb[:, None, 0:3] + rb[:, None, 3:6] * z[..., None]).contiguous()
-            g, d_pts, d_dirs = ctx.net.mlp_backward_flat(d_raw, ctx.store, ctx.precision, pts=pts, ray_batch=rb)
+            g, d_pts, d_dirs = ctx.net.mlp_backward_flat(d_raw, ctx.store, ctx.precision, pts=pts, ray_batch=rb, accumulate_into=acc)
             d_rb = torch.zeros_like(rb)
             d_pts = d_pts.reshape(pts.shape)
             d_rb[:, 0:3] = d_pts.sum(1)
             d_rb[:, 3:6] = (d_pts * z[..., None]).sum(1)
             d_rb[:, 8:11] = d_dirs.reshape(pts.shape).sum(1)
         else:
-            g = ctx.net.mlp_backward_flat(d_raw, ctx.store, ctx.precision)
+            g = ctx.net.mlp_backward_flat(d_raw, ctx.store, ctx.precision, accumulate_into=acc)
         ctx.store = None
         return g, d_rb, None, None, None
 
@@ -225,14 +227,16 @@ class NeRF:
         return _NerfMLP.apply(flat, ray_batch, z_vals, self, precision or self.precision)
 
     # Backward of mlpforward_train: d_raw [R,S,4] -> flat gradient (what autograd gives for nerf.py:46-72)
-    def mlp_backward_flat(self, d_raw, store, precision=None, pts=None, ray_batch=None):
+    def mlp_backward_flat(self, d_raw, store, precision=None, pts=None, ray_batch=None, accumulate_into=None):
         """flat parameter gradient; with pts [R,S,3] and the ray batch also (flat, d pts [R*S,3], d dirs per sample [R*S,3]), the
-        gradients through the two positional encodings"""
+        gradients through the two positional encodings.  accumulate_into: a persistent flat float32 gradient buffer the kernels ADD
+        into (evd_nerf_grads.accumulate); the returned flat gradient is then None"""
         g = d_raw.contiguous().float()
         R, S = g.shape[:2]
         blocks = self.param_blocks()
-        flat = torch.zeros((self._nparam,), dtype=torch.float32, device=g.device)
+        flat = accumulate_into if accumulate_into is not None else torch.zeros((self._nparam,), dtype=torch.float32, device=g.device)
         gs = L.NerfGrads()
+        gs.accumulate = int(accumulate_into is not None)
         base = flat.data_ptr()
         for key, shape, off in blocks:
             name, kind = key.rsplit(".", 1)
@@ -251,6 +255,8 @@ class NeRF:
         L.check(L.lib().evd_nerf_mlp_backward(self._h, L.PREC[precision or self.precision], L.ptr(g), R, S, L.ptr(store), store.numel(),
                                                C.byref(gs), L.ptr(pts), C.c_void_p(vd.data_ptr()) if want else None, 11, L.ptr(d_pts), L.ptr(d_dirs),
                                                L.ptr(ws), nb, L.stream_ptr()), "evd_nerf_mlp_backward")
+        if accumulate_into is not None:
+            flat = None
         return (flat, d_pts, d_dirs) if want else flat
 
     def mlp_backward(self, d_raw, store, precision=None):

@@ -56,6 +56,116 @@ class _MergeFeatures(torch.autograd.Function):
         return d0, dn, None, g[..., F:]
 
 
+class _RayBatch(torch.autograd.Function):
+    """NeRFAll.render's ray packing (renderer.py:423-446) under autograd: evd_ray_batch / evd_ray_batch_bwd -- one launch each way instead
+    of ~25 small tensor operations and their autograd nodes per render"""
+
+    @staticmethod
+    def forward(ctx, rays, H, W, focal, ndc, near, far):
+        r = rays.contiguous().float()
+        cfg = L.RenderCfg()
+        cfg.H, cfg.W, cfg.focal, cfg.ndc, cfg.use_viewdirs, cfg.near, cfg.far = int(H), int(W), float(focal), int(bool(ndc)), 1, float(near), float(far)
+        rb = torch.empty((r.shape[0], 11), dtype=torch.float32, device=r.device)
+        L.check(L.lib().evd_ray_batch(C.byref(cfg), L.ptr(r), r.shape[0], L.ptr(rb), L.stream_ptr()), "evd_ray_batch")
+        ctx.cfg, ctx.rays = cfg, r
+        return rb
+
+    @staticmethod
+    def backward(ctx, g):
+        r = ctx.rays
+        d = torch.empty_like(r)
+        L.check(L.lib().evd_ray_batch_bwd(C.byref(ctx.cfg), L.ptr(r), L.ptr(g.contiguous().float()), r.shape[0], L.ptr(d), L.stream_ptr()), "evd_ray_batch_bwd")
+        return d, None, None, None, None, None, None
+
+
+class _Points(torch.autograd.Function):
+    """pts = rays_o + rays_d z (renderer.py:180,206,235) from the packed ray batch: evd_points / evd_points_bwd (z is a constant: the sample
+    positions are detached in the reference)"""
+
+    @staticmethod
+    def forward(ctx, rb, z):
+        if rb.shape[1] != 11:
+            raise L.EvdError("points under autograd needs the 11-column ray batch")
+        R, S = z.shape
+        pts = torch.empty((R, S, 3), dtype=torch.float32, device=rb.device)
+        L.check(L.lib().evd_points(L.ptr(rb), rb.shape[1], L.ptr(z), R, S, L.ptr(pts), L.stream_ptr()), "evd_points")
+        ctx.z, ctx.ncol = z, rb.shape[1]
+        return pts
+
+    @staticmethod
+    def backward(ctx, g):
+        z = ctx.z
+        R, S = z.shape
+        d_rb = torch.empty((R, 11), dtype=torch.float32, device=z.device)       # accumulate = 0: the kernel writes whole rows
+        L.check(L.lib().evd_points_bwd(L.ptr(z), L.ptr(g.contiguous().float()), R, S, 0, L.ptr(d_rb), L.stream_ptr()), "evd_points_bwd")
+        return d_rb, None
+
+
+def points(rb, z):
+    """[R,S,3] sample positions of a packed ray batch [R,11] at depths z [R,S]; differentiable w.r.t. the batch when it requires grad"""
+    rb, z = rb.contiguous().float(), z.contiguous().float()
+    if rb.requires_grad and torch.is_grad_enabled():
+        return _Points.apply(rb, z)
+    R, S = z.shape
+    pts = torch.empty((R, S, 3), dtype=torch.float32, device=rb.device)
+    L.check(L.lib().evd_points(L.ptr(rb), rb.shape[1], L.ptr(z), R, S, L.ptr(pts), L.stream_ptr()), "evd_points")
+    return pts
+
+
+class _FlatParams(torch.autograd.Function):
+    """A level's flat parameter tensor as a function of its per-tensor leaves.  The leaves ARE views of the flat tensor's storage
+    (enable_training), so the forward is an alias, not a torch.cat; the backward hands every leaf its slice of the flat gradient (views,
+    no kernels).  In the opt-in in-place mode the consuming node adds its gradient straight into the level's persistent flat gradient
+    buffer (whose slices are the leaves' .grad) and this node receives None."""
+
+    @staticmethod
+    def forward(ctx, flat, level, *leaves):
+        ctx.level = level
+        ctx.set_materialize_grads(False)
+        return flat.detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        lv = ctx.level
+        if g is None:
+            return (None, None) + (None,) * len(lv.blocks)
+        return (None, None) + tuple(g[o:o + n].view(shape) for (_, shape, o), n in zip(lv.blocks, lv.sizes))
+
+
+class _Level:
+    """Trainable state of one network / PDRF level: `flat` is the storage of its sigma / colour (or NeRF MLP) parameters in the library's
+    canonical order, `leaves` one autograd leaf per reference parameter, each a VIEW of `flat` (an optimizer's in-place update of a
+    leaf updates the storage the library re-packs from, and bumps its shared version counter); `grids` the tri-plane leaves."""
+
+    def __init__(self, net, prefix, flat, blocks, grids, in_place):
+        from collections import OrderedDict
+        self.net, self.prefix, self.flat, self.blocks, self.grids, self.in_place = net, prefix, flat, blocks, grids, in_place
+        self.sizes = [int(np.prod(shape)) for _, shape, _ in blocks]
+        self.leaves = OrderedDict((prefix + key, flat[o:o + n].view(shape).detach().requires_grad_(True)) for (key, shape, o), n in zip(blocks, self.sizes))
+        self.flat_grad = None
+
+    def params(self):
+        flat = _FlatParams.apply(self.flat, self, *self.leaves.values())
+        flat._evd_accum = self.attach_grads if self.in_place else None       # read by the consuming node (_VoxelMLP / _NerfMLP)
+        return {"net": flat, "grids": list(self.grids.values())} if self.grids is not None else flat
+
+    def attach_grads(self):
+        """in-place mode: the flat gradient buffer whose slices are the leaves' .grad.  When the optimizer dropped the gradients
+        (zero_grad(set_to_none=True), the default) the buffer is zeroed by ONE fill and re-attached."""
+        none = [t.grad is None for t in self.leaves.values()]
+        if self.flat_grad is None or all(none):
+            if self.flat_grad is None:
+                self.flat_grad = torch.zeros_like(self.flat)
+            else:
+                self.flat_grad.zero_()
+            for t, (_, shape, o), n in zip(self.leaves.values(), self.blocks, self.sizes):
+                t.grad = self.flat_grad[o:o + n].view(shape)
+        elif any(none):
+            raise L.EvdError(f"{self.prefix}: in-place gradient accumulation needs the gradients of ALL of a level's parameters dropped or kept "
+                             "together (optimizer.zero_grad() / model.zero_grad()); some are None")
+        return self.flat_grad
+
+
 class NeRFAll:
     """mode='nerf' (two NeRF MLPs, renderer.py:82-100) or mode='c2f' (PDRF coarse/fine levels, :46-81)."""
 
@@ -304,17 +414,17 @@ class NeRFAll:
         of the old and new points (:209-213), fine features are sampled at the merged points."""
         from .rays import sample_pdf_merge
         coarse, fine = self.mlp_coarse, self.mlp_fine
-        o, d, vd = rb[:, None, 0:3], rb[:, None, 3:6], rb[:, 8:11].contiguous()
+        vd = rb[:, 8:11].contiguous()
         rays_d = rb[:, 3:6].contiguous()
-        pts0 = o + d * z0[..., None]
+        pts0 = points(rb, z0)
         ft0 = coarse.sample_train(pts0, pc["grids"], self.precision)
         raw0 = coarse.mlp_train(pc["net"], pts0, vd, ft0, self.precision)
         rgb0, _, acc0, w0, depth0 = coarse.raw2outputs(raw0, z0, rays_d, is_train=True, noise=noise0)
         if Ni <= 0:
             return {"rgb_map": rgb0, "depth_map": depth0, "acc_map": acc0, "weights": w0, "z_vals": z0}
         zs, zm, order, zstd = sample_pdf_merge(z0, w0.detach(), Ni, det=(perturb == 0.), u=u, want_order=True)
-        ftn = coarse.sample_train(o + d * zs[..., None], pc["grids"], self.precision)
-        ptm = o + d * zm[..., None]
+        ftn = coarse.sample_train(points(rb, zs), pc["grids"], self.precision)
+        ptm = points(rb, zm)
         # cat([coarse features re-ordered by the sort (:209-213), fine features at the merged points]) in one row buffer: the merge is a
         # library kernel writing columns 0..fc-1 (a row permutation: its backward is one too), the fine features land behind them
         ft = _MergeFeatures.apply(ft0, ftn, order, fine.sample_train(ptm, pf["grids"], self.precision))
@@ -337,8 +447,14 @@ class NeRFAll:
     @staticmethod
     def ray_batch_train(H, W, K, rays, ndc=True, near=0., far=1.):
         """NeRFAll.render's ray packing (renderer.py:423-446: viewdirs = d / |d| BEFORE the NDC warp of utils/rays.py:104-145 with
-        near plane 1) in differentiable torch arithmetic: rays [R,3,2] -> ray batch [R,11].  Values equal evd_ray_batch to float32
-        rounding; this is what lets the loss reach the blur kernel's warped rays."""
+        near plane 1): rays [R,3,2] -> ray batch [R,11], differentiable w.r.t. the rays -- this is what lets the loss reach the blur
+        kernel's warped rays.  On the GPU: evd_ray_batch and its hand-written backward (one launch each); elsewhere (CPU tests of
+        the formula) the same arithmetic in torch."""
+        if rays.is_cuda:
+            if rays.requires_grad and torch.is_grad_enabled():
+                return _RayBatch.apply(rays, H, W, float(K[0][0]), ndc, near, far)
+            with torch.no_grad():
+                return _RayBatch.apply(rays, H, W, float(K[0][0]), ndc, near, far)
         o, d = rays[..., 0], rays[..., 1]
         vd = d / torch.linalg.norm(d, dim=-1, keepdim=True)
         if ndc:
@@ -502,15 +618,22 @@ class NeRFAll:
     # ------------------------------------------------------------------ forward, renderer.py:266-397
     # ---- the reference's nn.Module surface for a training loop (optimizer groups run_nerf.py:245-263, iteration :423-613,
     # ---- checkpoint :617-638) ---------------------------------------------------------------------------------------------
-    def enable_training(self, state_dict):
+    def enable_training(self, state_dict, grads_in_place=False):
         """Create the trainable tensors from a state dict and keep them in the model: ONE LEAF PER REFERENCE PARAMETER
         (`named_parameters()` yields the reference's names), so that `parameters()`, `get_parameters(type, match_re, not_match_re)`,
         `grad_vars` and `grad_vars_vol` feed optimizer groups exactly like renderer.py:58-79,112-127 / run_nerf.py:245-263, and
         `model(H, W, K, chunk, rays=..., **render_kwargs_train)` in training mode runs forward_train (autograd).  The library's
-        kernels consume one flat float32 tensor per network: it is the concatenation of the leaves (autograd's cat splits the
-        flat gradient back); the tri-plane tensors are leaves in the library's channel-last layout ([H,W,C], [L,C]; an
-        element-wise optimizer does not care, `state_dict()` returns the reference layouts)."""
+        kernels consume one flat float32 tensor per network: the leaves are VIEWS of it (no concatenation per forward; the backward
+        returns slices of the flat gradient); the tri-plane tensors are leaves in the library's channel-last layout ([H,W,C], [L,C];
+        an element-wise optimizer does not care, `state_dict()` returns the reference layouts).
+
+        grads_in_place=False (default): plain autograd semantics everywhere -- torch.autograd.grad, backward(inputs=...), hooks.
+        grads_in_place=True: the backward kernels ADD the parameter and grid gradients straight into persistent buffers whose slices
+        are the leaves' .grad, and return None to autograd.  Valid for the reference's loop only -- optimizer.zero_grad();
+        loss.backward(); optimizer.step() (run_nerf.py:593-601) -- and what it saves per blurfactory iteration is ~90 gradient
+        additions, ~50 copies and the zero-fill + re-add of 165 MB of grid gradients per scatter."""
         from collections import OrderedDict
+        self._grads_in_place = bool(grads_in_place)
         levels = []
         for prefix, net, p in (("mlp_coarse.", self.mlp_coarse, None), ("mlp_fine.", self.mlp_fine, None)):
             if net is None:
@@ -525,29 +648,47 @@ class NeRFAll:
                 off += int(np.prod(shape))
             if off != flat.numel():
                 raise L.EvdError(f"parameter blocks of {prefix} do not cover the flat tensor")
-            leaves = OrderedDict((prefix + key, flat[o:o + int(np.prod(shape))].reshape(shape).clone().requires_grad_(True))
-                                 for key, shape, o in blocks)
             grids = None
             if self.mode == "c2f":
                 g = net.grid_params()
                 grids = OrderedDict([(f"{prefix}app_plane.{i}", g[i]) for i in range(3)] + [(f"{prefix}app_line.{i}", g[3 + i]) for i in range(3)]
                                     + [(f"{prefix}basis_mat.weight", g[6])])
-            levels.append({"leaves": leaves, "grids": grids})
+                net._grads_in_place = self._grads_in_place
+                net._grid_grad_flat = (torch.empty((sum(t.numel() for t in g),), dtype=torch.float32, device=self.device)
+                                       if self._grads_in_place else None)
+            net._synced = net._synced_net = None
+            levels.append(_Level(net, prefix, flat, blocks, grids, self._grads_in_place))
         self._levels = levels
         return self
 
-    def _current_params(self):
-        """(params_coarse, params_fine) in the form forward_train / render_rays_train take, from the per-tensor leaves"""
+    def grad_buffers(self):
+        """[(flat gradient buffer, [parameters whose .grad are its slices])] of a model in the in-place mode, for
+        dist.GradReducer(flat_buffers=...): the collectives then run on the buffers themselves.  Empty in the default mode."""
+        self._require_training()
         out = []
         for lv in self._levels:
-            if lv is None:
-                out.append(None)
+            if lv is None or not lv.in_place:
                 continue
-            flat = torch.cat([t.reshape(-1) for t in lv["leaves"].values()])
-            net = self.mlp_coarse if len(out) == 0 else self.mlp_fine
-            net._synced = net._synced_net = None        # a fresh flat tensor: never trust an address / version match, re-pack
-            out.append({"net": flat, "grids": list(lv["grids"].values())} if lv["grids"] is not None else flat)
-        return tuple(out)
+            out.append((lv.attach_grads() if lv.flat_grad is None else lv.flat_grad, list(lv.leaves.values())))
+            gbuf = getattr(lv.net, "_grid_grad_flat", None)
+            if lv.grids is not None and gbuf is not None:
+                out.append((gbuf, list(lv.grids.values())))
+        return out
+
+    def zero_grad(self, set_to_none=True):
+        """drop (or zero) the gradients of every trainable tensor of the model, like nn.Module.zero_grad"""
+        for p in self.parameters():
+            if p.grad is not None:
+                if set_to_none:
+                    p.grad = None
+                else:
+                    p.grad.zero_()
+
+    def _current_params(self):
+        """(params_coarse, params_fine) in the form forward_train / render_rays_train take.  The flat tensors alias the levels' storage
+        (same address, shared version counter): the library re-packs its weight streams / reloads its grids only after an optimizer
+        step actually changed them, not once per forward."""
+        return tuple(lv.params() if lv is not None else None for lv in self._levels)
 
     @property
     def _train_params(self):
@@ -564,9 +705,9 @@ class NeRFAll:
         for lv in self._levels:
             if lv is None:
                 continue
-            out += list(lv["leaves"].items())
-            if lv["grids"] is not None:
-                out += list(lv["grids"].items())
+            out += list(lv.leaves.items())
+            if lv.grids is not None:
+                out += list(lv.grids.items())
         for name, m in self._torch_children():
             out += [(f"{name}.{k}", v) for k, v in m.named_parameters()]
         return out
@@ -599,8 +740,8 @@ class NeRFAll:
         self._require_training()
         out = []
         for lv in self._levels:
-            if lv is not None and lv["grids"] is not None:
-                g = list(lv["grids"].values())
+            if lv is not None and lv.grids is not None:
+                g = list(lv.grids.values())
                 out += g[3:6] + g[0:3]
         return out
 
@@ -610,10 +751,10 @@ class NeRFAll:
         the awpnet's parameters, then the fine level's"""
         self._require_training()
         def level(lv):
-            if lv is None or lv["grids"] is None:
+            if lv is None or lv.grids is None:
                 return []
-            names = lv["leaves"]
-            return ([list(lv["grids"].values())[6]] + [v for k, v in names.items() if ".color_net." in k] +
+            names = lv.leaves
+            return ([list(lv.grids.values())[6]] + [v for k, v in names.items() if ".color_net." in k] +
                     [v for k, v in names.items() if ".sigma_net." in k])
         out = level(self._levels[0])
         for m in (self.kernelsnet, self.awpnet):
@@ -628,9 +769,9 @@ class NeRFAll:
         for name, net, lv in (("mlp_coarse.", self.mlp_coarse, self._levels[0]), ("mlp_fine.", self.mlp_fine, self._levels[1])):
             if lv is None:
                 continue
-            sd.update({k: v.detach().clone() for k, v in lv["leaves"].items()})
-            if lv["grids"] is not None:
-                sd.update(net.grids_to_state_dict(list(lv["grids"].values()), name))
+            sd.update({k: v.detach().clone() for k, v in lv.leaves.items()})
+            if lv.grids is not None:
+                sd.update(net.grids_to_state_dict(list(lv.grids.values()), name))
         for name, m in self._torch_children():              # the reference's NeRFAll is an nn.Module: its state dict carries these too
             sd.update({f"{name}.{k}": v.detach().clone() for k, v in m.state_dict().items()})
         return sd

@@ -43,6 +43,13 @@ def _grid_grads(net, like, in_place=False):
     whole blurfactory iteration runs 9 scatters and 2 TV backwards, each of which would otherwise zero 7 fresh tensors (165 MB for
     the fine level) and have autograd add them to .grad again; the returned list is then all None (nothing left for autograd to do)."""
     if in_place and all(t.is_leaf and t.requires_grad and t.dtype == torch.float32 and t.is_contiguous() for t in like):
+        buf = getattr(net, "_grid_grad_flat", None)
+        if buf is not None and all(t.grad is None for t in like) and buf.numel() == sum(t.numel() for t in like):
+            buf.zero_()                 # ONE fill for the level's seven gradient tensors (165 MB for the fine level), then views of it
+            off = 0
+            for t in like:
+                t.grad = buf[off:off + t.numel()].view(t.shape)
+                off += t.numel()
         for t in like:
             if t.grad is None:
                 t.grad = torch.zeros_like(t)
@@ -71,7 +78,7 @@ class _VoxelSample(torch.autograd.Function):
     def backward(ctx, d_out):
         net, pts = ctx.net, ctx.pts.reshape(-1, 3).contiguous().float()
         g = d_out.reshape(-1, net.app_dim).contiguous().float()
-        grads, gs = _grid_grads(net, ctx.saved_tensors, in_place=_GRADS_IN_PLACE and not torch.is_grad_enabled())
+        grads, gs = _grid_grads(net, ctx.saved_tensors, in_place=getattr(net, "_grads_in_place", _GRADS_IN_PLACE) and not torch.is_grad_enabled())
         d_pts = torch.empty_like(pts) if ctx.needs_input_grad[0] else None
         # scratch for the hybrid form of the scatter (csrc/kernel_voxel_scatter.hip: plane taps by direct float atomics, line taps through
         # fixed-point LDS slices -- a third fewer atomic requests, 24-27 % faster); EVD_SCATTER=direct passes none: every tap an atomic
@@ -105,6 +112,7 @@ class _VoxelMLP(torch.autograd.Function):
         raw, store, feature = net.mlpforward_train(pts, viewdirs, fts, precision, want_feature=rows)
         ctx.net, ctx.precision, ctx.store, ctx.raw = net, precision, store, raw
         ctx.ft_shape, ctx.pts, ctx.viewdirs, ctx.has_feature, ctx.geo = fts.shape, pts, viewdirs, rows, geo
+        ctx.accum = getattr(flat, "_evd_accum", None)          # in-place gradient accumulation (renderer._FlatParams), opt-in
         ctx.set_materialize_grads(False)
         if geo is not None:
             geo.level, geo.store, geo.precision, geo.R, geo.S = net, store, precision, pts.shape[0], pts.shape[1]
@@ -117,9 +125,11 @@ class _VoxelMLP(torch.autograd.Function):
         if d_raw is None:
             d_raw = torch.zeros_like(ctx.raw)
         awp_store = ctx.geo.awp_store if ctx.geo is not None else None
+        acc = ctx.accum() if (ctx.accum is not None and need[0] and not torch.is_grad_enabled()) else None
         gflat, d_fts, d_pts, d_dirs = ctx.net.mlp_backward_flat(d_raw, ctx.raw, ctx.store, ctx.precision, want_fts=need[1],
                                                                 pts=ctx.pts if need[2] else None, viewdirs=ctx.viewdirs if need[3] else None,
-                                                                d_feature=d_feature if ctx.has_feature else None, awp_store=awp_store)
+                                                                d_feature=d_feature if ctx.has_feature else None, awp_store=awp_store,
+                                                                accumulate_into=acc)
         ctx.store = ctx.raw = None
         if ctx.geo is not None:
             ctx.geo.store = ctx.geo.awp_store = None
@@ -138,7 +148,7 @@ class _VoxelTV(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_loss):
         net = ctx.net
-        grads, gs = _grid_grads(net, ctx.saved_tensors, in_place=_GRADS_IN_PLACE and not torch.is_grad_enabled())
+        grads, gs = _grid_grads(net, ctx.saved_tensors, in_place=getattr(net, "_grads_in_place", _GRADS_IN_PLACE) and not torch.is_grad_enabled())
         gs.basis = None
         d = d_loss.reshape(1).contiguous().float()
         L.check(L.lib().evd_voxel_tv_loss_bwd(net._h, L.ptr(d), C.byref(gs), L.stream_ptr()), "evd_voxel_tv_loss_bwd")
@@ -286,14 +296,17 @@ class VoxelNeRFBase:
                                              R, S, L.ptr(raw), L.ptr(feature), L.ptr(store), nb, L.stream_ptr()), "evd_voxel_mlp_train")
         return raw, store, feature
 
-    def mlp_backward_flat(self, d_raw, raw, store, precision=None, want_fts=True, pts=None, viewdirs=None, d_feature=None, awp_store=None):
+    def mlp_backward_flat(self, d_raw, raw, store, precision=None, want_fts=True, pts=None, viewdirs=None, d_feature=None, awp_store=None,
+                          accumulate_into=None):
         """-> (flat parameter gradient, d fts | None, d pts | None, d dirs per sample | None); the last two (through the positional
-        encodings) are computed when the forward's pts / viewdirs are passed"""
+        encodings) are computed when the forward's pts / viewdirs are passed.  accumulate_into: a persistent flat float32 gradient buffer
+        the kernels ADD into (evd_voxel_grads.accumulate); the returned flat gradient is then None"""
         g = d_raw.contiguous().float()
         R, S = g.shape[:2]
         blocks = self.param_blocks()
-        flat = torch.zeros((self._nparam,), dtype=torch.float32, device=g.device)
+        flat = accumulate_into if accumulate_into is not None else torch.zeros((self._nparam,), dtype=torch.float32, device=g.device)
         gs, base = L.VoxelGrads(), flat.data_ptr()
+        gs.accumulate = int(accumulate_into is not None)
         for key, shape, off in blocks:
             name, idx, kind = key.split(".")
             arr = getattr(gs, ("sigma_" if name == "sigma_net" else "color_") + ("w" if kind == "weight" else "b"))
@@ -310,7 +323,7 @@ class VoxelNeRFBase:
                                                 awp_store.numel() if awp_store is not None else 0, R, S, L.ptr(store), store.numel(),
                                                 C.byref(gs), L.ptr(d_fts), self.ft_dim, L.ptr(p), L.ptr(vd), vd.shape[-1] if vd is not None else 0,
                                                 L.ptr(d_pts), L.ptr(d_dirs), L.ptr(ws), nb, L.stream_ptr()), "evd_voxel_mlp_backward")
-        return flat, d_fts, d_pts, d_dirs
+        return (None if accumulate_into is not None else flat), d_fts, d_pts, d_dirs
 
     def mlp_train(self, flat, pts, viewdirs, fts, precision=None, want_feature=False):
         """raw [R,S,4] = (sigma, sigmoid(colour)) with autograd to the flat parameters, the sampled features and the rays;

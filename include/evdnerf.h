@@ -94,6 +94,15 @@ typedef struct {
 /* NeRFAll.render ray packing, networks/renderer.py:423-446: rays dev [R,3,2] -> ray_batch dev [R,11]
  * = o(3) d(3) near far viewdir(3); viewdir = d/|d| before the NDC warp.  (8 columns when !use_viewdirs) */
 int evd_ray_batch(const evd_render_cfg* cfg, const float* rays, long R, float* ray_batch, void* stream);
+/* Backward of evd_ray_batch (the training branch of NeRFAll.forward, renderer.py:303-308: the loss reaches the blur kernel's warped
+ * rays through the packing, viewdirs normalisation :431 and the NDC warp utils/rays.py:104-145; the reference gets it from autograd):
+ * d_ray_batch dev [R,11] -> d_rays dev [R,3,2] (overwritten).  The near / far columns carry no gradient. */
+int evd_ray_batch_bwd(const evd_render_cfg* cfg, const float* rays, const float* d_ray_batch, long R, float* d_rays, void* stream);
+/* pts = rays_o + rays_d * z (renderer.py:180,206,235): ray_batch dev rows of ncol floats (o at 0..2, d at 3..5), z dev [R,S] -> pts dev [R,S,3];
+ * its backward: d_pts dev [R,S,3] -> columns 0..2 (sum_s d_pts) and 3..5 (sum_s z d_pts) of d_ray_batch dev [R,11], of every row: accumulate == 0 overwrites
+ * the WHOLE row (zeros in the other columns), != 0 adds into those six columns and leaves the others alone. */
+int evd_points(const float* ray_batch, int ncol, const float* z, long R, int S, float* pts, void* stream);
+int evd_points_bwd(const float* z, const float* d_pts, long R, int S, int accumulate, float* d_ray_batch, void* stream);
 /* z stratification, networks/renderer.py:163-178.  t_rand dev [R,S] is the explicit torch.rand draw
  * (required when cfg->perturb > 0).  -> z dev [R,S] */
 int evd_sample_z(const evd_render_cfg* cfg, const float* ray_batch, int ncol, long R, const float* t_rand,
@@ -144,10 +153,13 @@ int evd_nerf_mlp_train(const evd_nerf* net, int precision, const float* ray_batc
                        float* raw, void* store, size_t store_bytes, void* stream);
 
 /* Gradients of the network parameters, device float32 in the reference's nn.Linear layouts ([out, in] weights, [out] biases;
- * the same fields as evd_nerf_desc).  NULL = not wanted.  Every wanted block is overwritten, not accumulated into. */
+ * the same fields as evd_nerf_desc).  NULL = not wanted.  accumulate == 0: every wanted block is overwritten; != 0: the gradients are
+ * ADDED into it (a training loop's persistent .grad buffers, several backward calls per optimizer step: run_nerf.py:593-601 runs one
+ * loss.backward() over three renders). */
 typedef struct {
     float *pts_w[EVD_MAX_LAYERS], *pts_b[EVD_MAX_LAYERS];
     float *views_w, *views_b, *feature_w, *feature_b, *alpha_w, *alpha_b, *rgb_w, *rgb_b;
+    int accumulate;
 } evd_nerf_grads;
 
 /* Backward of evd_nerf_mlp_train: d_raw dev [R,S,4] (d loss / d raw) -> parameter gradients, what torch autograd computes for
@@ -277,7 +289,7 @@ int evd_voxel_tv_loss(const evd_voxel* v, float* out, void* stream);
  * to the geo features' gradient without ever becoming a float32 [R*S,128] tensor (below).
  * Built for EVD_PREC_F16 / EVD_PREC_BF16 and the float32-grade EVD_PREC_F16X3 (as evd_nerf_mlp_train; awp_store is a half-precision
  * coupling: in f16x3 the AWP consumer's gradient comes back as d_feature rows), both shipped levels (64/15/32 and 256/128/64). */
-typedef struct { float *sigma_w[2], *color_w[3], *color_b[3]; } evd_voxel_grads;
+typedef struct { float *sigma_w[2], *color_w[3], *color_b[3]; int accumulate; /* as in evd_nerf_grads */ } evd_voxel_grads;
 int evd_voxel_geo_feat_dim(const evd_voxel* v);
 long evd_voxel_param_count(const evd_voxel* v);
 int evd_voxel_param_blocks(const evd_voxel* v, long* offsets, int capacity);

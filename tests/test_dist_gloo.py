@@ -124,6 +124,65 @@ def test_two_rank_gradient_allreduce_equals_single_process():
         assert np.array_equal(grads[3], np.zeros(5, np.float32))        # a parameter without gradient on any rank stays zero
 
 
+def _flat_worker(rank, world, port, q):
+    """the training leg of bench.py --gpus N on CPU stand-ins: parameters whose .grad are slices of persistent flat buffers
+    (NeRFAll.enable_training(grads_in_place=True) -> grad_buffers()), reduced where they lie; one group is NOT attached (falls back
+    to the bucket path); plus ordinary parameters (the blur kernel's) in buckets"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from evdeblurnerf_amd import dist as D
+    D.init_from_env("gloo")
+    torch.manual_seed(3)
+    sizes = (700, 41, 5000)
+    buf_a, buf_b = torch.zeros(sum(sizes)), torch.zeros(123)
+    group_a, off = [], 0
+    for n in sizes:
+        p = torch.nn.Parameter(torch.randn(n))
+        p.grad = buf_a[off:off + n]
+        off += n
+        group_a.append(p)
+    group_b = [torch.nn.Parameter(torch.randn(123))]                 # its buffer exists, but the gradient was produced by plain autograd
+    other = [torch.nn.Parameter(torch.randn(n)) for n in (17, 300)]
+    g = torch.Generator().manual_seed(100 + rank)
+    for p in group_a:                                                # "backward kernels" add into the slices
+        p.grad += torch.randn(p.numel(), generator=g)
+    group_b[0].grad = torch.randn(123, generator=g)
+    for p in other:
+        p.grad = torch.randn(p.numel(), generator=g)
+    ptr = buf_a.data_ptr()
+    red = D.GradReducer(group_a + group_b + other, bucket_bytes=1000, flat_buffers=[(buf_a, group_a), (buf_b, group_b)])
+    red.start()
+    red.wait()
+    assert buf_a.data_ptr() == ptr and all(p.grad.data_ptr() >= ptr for p in group_a)          # reduced in place, still attached
+    q.put((rank, [p.grad.numpy().copy() for p in group_a + group_b + other]))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_on_flat_buffers_in_place():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_flat_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sizes = (700, 41, 5000, 123, 17, 300)
+    expect = [np.zeros(n, np.float32) for n in sizes]
+    for rank in range(world):
+        g = torch.Generator().manual_seed(100 + rank)
+        for i, n in enumerate(sizes):
+            expect[i] += torch.randn(n, generator=g).numpy()
+    for rank, grads in res:
+        for a, b in zip(grads, expect):
+            assert np.allclose(a, b, rtol=1e-6, atol=1e-6)
+
+
 def test_shard_range_partitions():
     from evdeblurnerf_amd.dist import shard_range
     for n in (0, 1, 7, 8, 4096, 160000):

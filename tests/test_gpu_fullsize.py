@@ -158,14 +158,23 @@ def test_blurfactory_full_frame_at_real_grid_sizes(prec, tol, O, blurfactory):
 
 # ----------------------------------------------------------------------------------------------- compensated float16 mode (f16c)
 
-def test_f16c_holds_the_bound_on_seed_and_trained_weights(O, trained):
+@pytest.fixture(scope="module")
+def trained_10k():
+    """tests/golden/trained/nerf_8x256_10k.npz: the 8x256 network after 10 000 Adam iterations of the library's own training path on the
+    analytic scene (`python tools/trained_weights.py --iters 10000 --save ...` on the GPU box, 54 s; mse 0.13 -> 1.5e-5, densities up to
+    24, hidden weights 1.1-1.3x their initial magnitude) -- VERDICT r2 asked for the margin of f16c on a longer-trained network."""
+    return dict(np.load(os.path.join(ROOT, "tests", "golden", "trained", "nerf_8x256_10k.npz")))
+
+
+def test_f16c_holds_the_bound_on_seed_and_trained_weights(O, trained, trained_10k):
     """EVD_PREC_F16C (float16 MFMA + two block-scaled fp6 MFMA products of the operands' rounding residuals, mlp_pipe_c.h): RGB L-inf
-    vs the oracle at 4096 x 128 <= 1e-4 on the seed-derived AND on the trained weights (where the single-product float16 mode
-    is at ~3e-4); measured 8e-7 / 1.8e-5.  Bound asserted with a 2x margin."""
+    vs the oracle at 4096 x 128 <= 1e-4 on the seed-derived weights, on weights trained in this session (1000 iterations) AND on the
+    committed 10 000-iteration network (where the single-product float16 mode is at 2.5e-4); measured 8e-7 / 1.8e-5 / 1.5e-5.
+    Bound asserted with a 2x margin."""
     from evdeblurnerf_amd.renderer import NeRFAll
     K = W.synthetic_camera()
     rays = W.synthetic_rays(100, 4096)
-    for name, sd in (("seed", W.prefixed(W.make_nerf_state_dict(21), "mlp_coarse")), ("trained", trained[0])):
+    for name, sd in (("seed", W.prefixed(W.make_nerf_state_dict(21), "mlp_coarse")), ("trained", trained[0]), ("trained 10k", trained_10k)):
         ref = O.render_nerf(O.Nerf(sd, "mlp_coarse."), None, O.make_cfg(N_samples=128), rays)["rgb"]
         got = {p: N(NeRFAll(_nerf_args(), sd, precision=p).eval().render(400, 400, K, rays=T(rays), N_samples=128, **NERF_KW)[0]) for p in ("f16c", "f16")}
         err = {p: maxabs(v, ref) for p, v in got.items()}

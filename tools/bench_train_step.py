@@ -51,6 +51,9 @@ def main():
     ap.add_argument("--awp", choices=["none", "fused", "torch"], default="none",
                     help="the shipped configs' adaptive weight proposal on the blur batch (kernel_use_awp): fused = evdeblurnerf_amd.awp.FusedAWP around a "
                          "module with the reference's surface (tools/awp_standin.py), torch = that module's plain PyTorch forward on depth_feature")
+    ap.add_argument("--plain-autograd", action="store_true",
+                    help="parameter / grid gradients returned to autograd (the library's default) instead of accumulated in place by the backward kernels "
+                         "(NeRFAll.enable_training(grads_in_place=True): what a run_nerf.py-style loop opts into)")
     ap.add_argument("--mam", choices=["mean", "corr"], default="corr",
                     help="the AWP module's motion aggregation: corr = the reference's MotionAggregationModule structure (MAMLike), mean = a small stand-in")
     a = ap.parse_args()
@@ -80,7 +83,7 @@ def run(a):
         awpnet = RefLikeAWP(P=a.P, view_ch=4, mam=getattr(a, "mam", "mean")).to(dev)
         if awp_mode == "fused":
             awpnet = FusedAWP(awpnet, precision=a.precision if a.precision in ("f16", "bf16") else "f16")
-    model = NeRFAll(args, sd, kernelsnet=kern, awpnet=awpnet, precision=a.precision).enable_training(sd).train()
+    model = NeRFAll(args, sd, kernelsnet=kern, awpnet=awpnet, precision=a.precision).enable_training(sd, grads_in_place=not getattr(a, "plain_autograd", False)).train()
     model.use_awp = awpnet is not None
     crf_rgb = CRF("gamma")
     crf_ev = CRF("learn", state_dict=W.make_crf_state_dict(5, extra_features=2), extra_features=2)
@@ -88,9 +91,22 @@ def run(a):
     opt = torch.optim.Adam([{"params": model.parameters(), "lr": 5e-4}, {"params": [crf_flat], "lr": 1e-4}])
     K = W.synthetic_camera()
     R, E = a.pixels, a.events
-    blur_rays = torch.as_tensor(W.synthetic_rays(1, R), device=dev)
-    ev_start = torch.as_tensor(W.synthetic_rays(2, E), device=dev)
-    ev_end = torch.as_tensor(W.synthetic_rays(3, E), device=dev)
+    # data-parallel mode (bench.py --gpus N, weak scaling: every rank trains on its OWN batch of this size): the packed loss partials are
+    # all-reduced through autograd (the path's one exchange, dist.all_reduce_partials), the parameter / grid gradients by dist.GradReducer --
+    # on the persistent flat gradient buffers themselves in the in-place mode (no packing copies around the 150 MB of grid gradients)
+    ddp = bool(getattr(a, "dist", False))
+    rank = 0
+    red = None
+    if ddp:
+        import torch.distributed as tdist
+        from evdeblurnerf_amd import dist as D
+        rank = tdist.get_rank()
+        red = D.GradReducer(list(model.parameters()) + [crf_flat], flat_buffers=model.grad_buffers())
+    blur_rays = torch.as_tensor(W.synthetic_rays(1 + 10 * rank, R), device=dev)
+    ev_start = torch.as_tensor(W.synthetic_rays(2 + 10 * rank, E), device=dev)
+    ev_end = torch.as_tensor(W.synthetic_rays(3 + 10 * rank, E), device=dev)
+    ar_ev = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)] if ddp else None
+    ar_ms = []
     tgt, tgt0 = torch.rand((R, 3), device=dev), torch.rand((R, 3), device=dev)
     cum_neg = -torch.randint(0, 4, (E,), device=dev).float()
     cum_pos = torch.randint(0, 4, (E,), device=dev).float()
@@ -104,14 +120,23 @@ def run(a):
         s1, s10, _, _ = model(400, 400, K, 1 << 22, rays=ev_start, force_naive=True, tv=False, **kw)
         s2, s20, _, _ = model(400, 400, K, 1 << 22, rays=ev_end, force_naive=True, tv=False, **kw)
         pe = event_loss_partials_autograd(crf_ev, crf_flat, s1, s2, cum_neg, cum_pos, 0.2, 0.2, start0=s10, end0=s20, add_bii="pos-neg")
+        if ddp:
+            pb, pe = D.all_reduce_partials(pb, pe)
         loss, _ = blur_loss_from_partials(pb, fine_loss_weight=0.5, w_pts0=0.1)
         if "rgb_awp" in tens:               # the AWP composition's image term (run_nerf.py:470-480)
             loss = loss + ((tens["rgb_awp"] - tgt) ** 2).mean()
         loss = loss + 0.1 * event_loss_from_partials(pe) + 0.01 * other["TV"].sum()
         opt.zero_grad(set_to_none=True)
         loss.backward()
+        if ddp:
+            ar_ev[0].record()
+            red.start()
+            red.wait()
+            ar_ev[1].record()
         opt.step()
         crf_ev.load_params(crf_flat)
+        if ddp:
+            ar_ms.append(ar_ev)
         return loss
 
     for _ in range(3):
@@ -124,6 +149,9 @@ def run(a):
     e1.record()
     e1.synchronize()
     ms = e0.elapsed_time(e1) / a.iters
+    if ddp:
+        a.allreduce_ms = ar_ev[0].elapsed_time(ar_ev[1])            # the last iteration's gradient exchange (start -> all buckets reduced)
+        a.grad_bytes = 4 * sum(p.numel() for p in list(model.parameters()) + [crf_flat])
     return ms, R * a.P + 2 * E, float(l.detach())
 
 

@@ -53,7 +53,7 @@ def main():
     teacher, _ = make(101, a.coarse_voxels, a.fine_voxels, a.precision)
     teacher.eval()
     student, sd = make(202, a.coarse_voxels, a.fine_voxels, a.precision)
-    student.enable_training(sd).train()
+    student.enable_training(sd, grads_in_place=True).train()
     nets = student.get_parameters("net", not_match_re=r"basis_mat")
     grids = student.grad_vars_vol + student.get_parameters("net", match_re=r"basis_mat")
     opt = torch.optim.Adam([{"params": nets, "lr": 1e-3}, {"params": grids, "lr": 2e-2}])

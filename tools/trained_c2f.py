@@ -53,7 +53,7 @@ def train_c2f(iters=3000, rays_per_iter=4096, seed=31, precision="f16", lr_net=1
     dev = "cuda"
     sd0 = W.make_blurfactory_state_dict(seed, sigma_gain=3.0)
     model = NeRFAll(W.blurfactory_args(64), sd0, precision=precision)
-    model.enable_training(sd0).train()
+    model.enable_training(sd0, grads_in_place=True).train()
     nets = model.get_parameters("net", not_match_re=r"basis_mat")
     grids = model.grad_vars_vol + model.get_parameters("net", match_re=r"basis_mat")
     opt = torch.optim.Adam([{"params": nets, "lr": lr_net}, {"params": grids, "lr": lr_grid}])
