@@ -194,12 +194,18 @@ class FusedAWP(torch.nn.Module):
     `depth_feature` is the GeoFragments handle NeRFAll.forward_train passes when its awpnet is a FusedAWP (a float32 tensor
     [R P, S, 128] is accepted too)."""
 
-    def __init__(self, awpnet, precision="f16"):
+    def __init__(self, awpnet, precision="f16", graph_per_ray=False):
+        """graph_per_ray: run the PER-RAY remainder (awp.py:105-117 + mam.py:35-53: ~100 launches of [R, 32, P] / [R, 32, S]-sized
+        tensors forward, twice that backward -- launch-bound, not compute-bound) as ONE captured hipGraph each way
+        (torch.cuda.make_graphed_callables on a module that shares the wrapped module's parameters; built per (rays, P, S) shape on
+        first use).  The arithmetic is the wrapped module's own; BatchNorm statistics update inside the graph."""
         super().__init__()
         self.ref = awpnet
         layers = list(awpnet.sample_feature_embed_layer)
         self.embed = SampleFeatureEmbed([l.weight for l in layers], [l.bias for l in layers], precision)
         self.output_ch = awpnet.output_ch
+        self.graph_per_ray = bool(graph_per_ray)
+        self._graphed = {}
 
     @property
     def ccw_fine_scale(self):
@@ -218,6 +224,12 @@ class FusedAWP(torch.nn.Module):
             return mam(x_global, h_local)
         F = torch.nn.functional
         h_inter, h_intra = mam_local(h_local, lin.weight, corr.line_conv_att.weight, n_ray, P, S)
+        return self._mam_tail(x_global, h_inter, h_intra)
+
+    def _mam_tail(self, x_global, h_inter, h_intra):
+        """the per-ray remainder of CorrelationModule.forward (mam.py:35-53) on the wrapped module's own layers"""
+        corr, lin = self.ref.MAM.Corr, self.ref.MAM.linear
+        F = torch.nn.functional
         k_inter = corr.conva(F.linear(h_inter, lin.weight, lin.bias).transpose(1, 2))         # [R, mid, P]
         k_intra = corr.convb(F.linear(h_intra, lin.weight, lin.bias).transpose(1, 2))         # [R, mid, S]
         x = x_global.transpose(1, 2)                                                          # [R, C, P]
@@ -235,12 +247,48 @@ class FusedAWP(torch.nn.Module):
         view = m.ray_dirs_embed_fn(dirs)                                          # awp.py:89-95
         if view_feature is not None:
             view = torch.cat([view_feature, view], dim=-1)
+        mam = m.MAM
+        known = getattr(mam, "Corr", None) is not None and getattr(mam, "linear", None) is not None and self.embed.width == 64 and P <= 16 and S <= 512
+        graphed = self.graph_per_ray and known and view.is_cuda and torch.is_grad_enabled()
+        if graphed:      # capture BEFORE this forward touches the module's parameters on the caller's stream (a live autograd graph that holds
+            # their AccumulateGrad nodes on another stream breaks the capture of the backward graph)
+            self._ensure_graph((n_ray, P, self.embed.width), tuple(view.shape), (n_ray, P, self.embed.width), (n_ray, S, self.embed.width), view.device)
         h_local = self.embed(self._flat(), depth_feature).reshape(n_ray * P, S, self.embed.width)     # awp.py:98-100
         h = feature_integration(h_local.reshape(n_ray, P, S, -1), z_vals, rays_d)                      # awp.py:102
+        if graphed:
+            h_inter, h_intra = mam_local(h_local, mam.linear.weight, mam.Corr.line_conv_att.weight, n_ray, P, S)
+            return self._graphed_tail(h, view, h_inter, h_intra)
+        return self._per_ray(h, view, h_local, n_ray, P, S)
+
+    def _per_ray(self, h, view, h_local, n_ray, P, S, h_inter=None, h_intra=None):
+        m = self.ref
         h = torch.cat([h, view.unsqueeze(1).repeat(1, P, 1)], dim=-1)
         for layer in m.motion_feature_embed_layer:                                # awp.py:107-109
             h = torch.relu(layer(h))
-        h = self._mam(h, h_local, n_ray, P, S)                                    # awp.py:111
+        h = self._mam(h, h_local, n_ray, P, S) if h_inter is None else self._mam_tail(h, h_inter, h_intra)      # awp.py:111
         h = torch.nn.functional.adaptive_avg_pool1d(h.transpose(1, 2), 1).squeeze(-1)
         w = torch.sigmoid(m.w_linear(h))
         return w / torch.sum(w, -1, keepdim=True)
+
+    def _ensure_graph(self, sh_h, sh_view, sh_inter, sh_intra, device):
+        key = (tuple(sh_h), tuple(sh_view), tuple(sh_inter), tuple(sh_intra), self.ref.training)
+        if key not in self._graphed:
+            outer = self
+
+            class _Tail(torch.nn.Module):             # shares the wrapped module's parameters: make_graphed_callables treats them as graph inputs
+                def __init__(self):
+                    super().__init__()
+                    self.ref = outer.ref
+
+                def forward(self, h, view, h_inter, h_intra):
+                    return outer._per_ray(h, view, None, h.shape[0], h.shape[1], h_intra.shape[1], h_inter, h_intra)
+
+            tail = _Tail().train(self.ref.training)
+            sample = tuple(torch.randn(sh, device=device).requires_grad_(True) for sh in (sh_h, sh_view, sh_inter, sh_intra))
+            self._graphed[key] = torch.cuda.make_graphed_callables(tail, sample, allow_unused_input=True)   # (the embedding's parameters are not in this graph)
+        return self._graphed[key]
+
+    def _graphed_tail(self, h, view, h_inter, h_intra):
+        fn = self._ensure_graph(h.shape, view.shape, h_inter.shape, h_intra.shape, h.device)
+        req = lambda t: t if t.requires_grad else t.detach().requires_grad_(True)     # the capture saw inputs that require grad
+        return fn(req(h.contiguous()), req(view.contiguous()), req(h_inter.contiguous()), req(h_intra.contiguous()))

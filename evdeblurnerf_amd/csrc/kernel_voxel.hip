@@ -916,6 +916,324 @@ __global__ __launch_bounds__(256, MM ? (CT <= 96 ? 3 : 2) : 1) void k_voxel_samp
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 3: the backward gather WAVEFRONT-AUTONOMOUS, like the forward's k_voxel_sample_w.  In-kernel stamps of the block-cooperative
+// kernel above put half of a tile's time in its gather phase and showed the whole kernel to be a per-tile latency chain (point load, tap
+// table, GEMM, gathers, four block barriers) that stays at ~0.72 ms per 2^19 samples even with two thirds of its atomics removed.  Here a
+// WAVEFRONT owns 16 consecutive samples (of one ray, as the renderer lays them out) from the point load to its last atomic; the one
+// block barrier orders the basis_mat image in LDS:
+//   0  tap geometry of its 48 (sample, component) pairs on 48 lanes -> its LDS slice (+ the line tap records for k_scatter_lines)
+//   1  d coef^T = basis^T . d out^T on v_mfma_f32_16x16x4_f32 (6 channel tiles x 8 steps; d out as the register-resident B operand)
+//   2  the gather exactly as the forward does it: 3 items (sample, 8 channels) per lane, 36 16-byte loads in flight, then per item
+//      pv, lv;  line rows d coef pv -> HBM (k_scatter_lines);  coef = pv lv -> HBM (k_basis_grad);  plane rows d coef lv -> LDS in place;
+//      the point gradient's per-item partial sums -> LDS
+//   3  the plane taps, lanes over channels (every atomic instruction covers whole 64-byte runs).  A 64-channel component (the x-y
+//      plane) is walked sample by sample with the sum kept in a REGISTER while successive samples address the same cell -- the rays of an
+//      NDC scene run along z, a tile's 16 samples touch 1-4 x-y cells -- and flushed by one atomic per (run, tap); the 16 / 32-channel
+//      components (their taps move with every sample) add tap by tap
+//   4  the point gradient: 48 lanes sum the partials of their (sample, axis)
+// The basis_mat gradient d out^T . coef is a plain GEMM over all samples and runs as its own small kernel (k_basis_grad) on the coefficient
+// rows written in phase 2; the line taps go through k_scatter_lines as in the hybrid form.
+constexpr int VBW_SAMPLES = 16, VBW_WAVES = 4;
+constexpr int VBW_BSTR = 112;                   // basis_mat row stride in LDS: 16 (mod 32) words, so that the MFMA A reads (lane = channel + 16 x row step) hit 64 banks
+constexpr int VBW_CSTR = 97;                    // d coef / plane-row stride (ctot <= 96), odd: lanes over channels read conflict-free
+constexpr int VBW_MAXG = 12;                    // 8-channel groups per sample
+struct VbwTaps {
+    int ip[4], il[2];                           // element offsets of channel 0 of the taps (clamped)
+    float wp[4], wl[2];                         // interpolation weights, 0 = outside (zero padding) or dead sample
+    float fw, fn, kx, ky, kl;                   // fractional position in the plane cell; d (pixel coordinate) / d (point coordinate)
+    int pad;
+};
+constexpr size_t VBW_SLICE = VBW_SAMPLES * 3 * sizeof(VbwTaps) + (size_t)VBW_SAMPLES * VBW_CSTR * 4 + (size_t)VBW_SAMPLES * VBW_MAXG * 3 * 4;
+constexpr size_t VBW_LDS = (size_t)32 * VBW_BSTR * 4 + VBW_WAVES * VBW_SLICE;
+static_assert(sizeof(VbwTaps) % 8 == 0 && VBW_SLICE % 16 == 0, "slice alignment");
+
+// vs_geometry + the quantities the point gradient needs; same formulas, same order (the forward's weights bit for bit)
+__device__ __forceinline__ void vbw_geometry(const GridParams& g, const float (&pt)[3], int i, bool live, VbwTaps& tp) {
+    float xyz[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) xyz[c] = __fsub_rn(__fmul_rn(__fsub_rn(pt[c], g.aabb_min[c]), g.inv[c]), 1.f);   // voxnerf.py:205
+    const int C = sel3(i, g.n_comp[0], g.n_comp[1], g.n_comp[2]);
+    const int Wp = sel3(i, g.grid[0], g.grid[0], g.grid[1]);
+    const int Hp = sel3(i, g.grid[1], g.grid[2], g.grid[2]);
+    const int Lp = sel3(i, g.grid[2], g.grid[1], g.grid[0]);
+    const float cx = sel3(i, xyz[0], xyz[0], xyz[1]), cy = sel3(i, xyz[1], xyz[2], xyz[2]), cl = sel3(i, xyz[2], xyz[1], xyz[0]);
+    const float ix = unnorm(cx, Wp), iy = unnorm(cy, Hp);
+    const float fx = fminf(fmaxf(floorf(ix), -2.f), (float)Wp), fy = fminf(fmaxf(floorf(iy), -2.f), (float)Hp);
+    const float ww = __fsub_rn(ix, floorf(ix)), ee = __fsub_rn(1.f, ww), nn = __fsub_rn(iy, floorf(iy)), ss = __fsub_rn(1.f, nn);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const bool vx0 = x0 >= 0 && x0 < Wp, vx1 = x1 >= 0 && x1 < Wp, vy0 = y0 >= 0 && y0 < Hp, vy1 = y1 >= 0 && y1 < Hp;
+    const int cx0 = min(max(x0, 0), Wp - 1), cx1 = min(max(x1, 0), Wp - 1), cy0 = min(max(y0, 0), Hp - 1), cy1 = min(max(y1, 0), Hp - 1);
+    tp.ip[0] = (cy0 * Wp + cx0) * C;
+    tp.ip[1] = (cy0 * Wp + cx1) * C;
+    tp.ip[2] = (cy1 * Wp + cx0) * C;
+    tp.ip[3] = (cy1 * Wp + cx1) * C;
+    tp.wp[0] = (live && vy0 && vx0) ? __fmul_rn(ee, ss) : 0.f;
+    tp.wp[1] = (live && vy0 && vx1) ? __fmul_rn(ww, ss) : 0.f;
+    tp.wp[2] = (live && vy1 && vx0) ? __fmul_rn(ee, nn) : 0.f;
+    tp.wp[3] = (live && vy1 && vx1) ? __fmul_rn(ww, nn) : 0.f;
+    const float il = unnorm(cl, Lp);
+    const float fl = fminf(fmaxf(floorf(il), -2.f), (float)Lp);
+    const float ln = __fsub_rn(il, floorf(il)), ls = __fsub_rn(1.f, ln);
+    const int l0 = (int)fl, l1 = l0 + 1;
+    tp.il[0] = min(max(l0, 0), Lp - 1) * C;
+    tp.il[1] = min(max(l1, 0), Lp - 1) * C;
+    tp.wl[0] = (live && l0 >= 0 && l0 < Lp) ? ls : 0.f;
+    tp.wl[1] = (live && l1 >= 0 && l1 < Lp) ? ln : 0.f;
+    tp.fw = ww; tp.fn = nn;
+    tp.kx = 0.5f * (float)(Wp - 1) * sel3(i, g.inv[0], g.inv[0], g.inv[1]);
+    tp.ky = 0.5f * (float)(Hp - 1) * sel3(i, g.inv[1], g.inv[2], g.inv[2]);
+    tp.kl = 0.5f * (float)(Lp - 1) * sel3(i, g.inv[2], g.inv[1], g.inv[0]);
+    tp.pad = 0;
+}
+
+template <bool DPTS>
+__global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const GridParams g, const float* __restrict__ pts, long n,
+                                                                          const float* __restrict__ d_out, int d_stride, int d_col, GridGrads gg,
+                                                                          float* __restrict__ d_pts, float* __restrict__ rows_l, LTap* __restrict__ ltap,
+                                                                          float* __restrict__ coef_out) {
+    extern __shared__ __attribute__((aligned(16))) char vbw_smem[];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c0n = g.n_comp[0], c1n = g.n_comp[1], c2n = g.n_comp[2], ctot = c0n + c1n + c2n, F = g.app_dim;
+    float* bs = reinterpret_cast<float*>(vbw_smem);                                  // basis_mat [32][VBW_BSTR], rows >= F are zero
+    char* slice = vbw_smem + (size_t)32 * VBW_BSTR * 4 + (size_t)wv * VBW_SLICE;
+    VbwTaps* taps = reinterpret_cast<VbwTaps*>(slice);
+    float* dco = reinterpret_cast<float*>(slice + VBW_SAMPLES * 3 * sizeof(VbwTaps));   // d coef [16][VBW_CSTR], later the plane rows d coef lv
+    float* dpart = dco + VBW_SAMPLES * VBW_CSTR;                                     // [16][ng][3]
+    const long s0 = ((long)blockIdx.x * VBW_WAVES + wv) * VBW_SAMPLES;
+    const int ng = ctot / 8;
+    for (int o = threadIdx.x; o < 32 * (ctot / 4); o += 64 * VBW_WAVES) {            // basis_mat -> LDS (the block's only shared state)
+        const int f = o / (ctot / 4), c4 = (o % (ctot / 4)) * 4;
+        const f32x4 v = f < F ? *reinterpret_cast<const f32x4*>(g.basis + (long)f * ctot + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(bs + f * VBW_BSTR + c4) = v;
+    }
+    // d out as the MFMA B operand: lane (col = sample, kh) holds d out[sample][4 step + kh]
+    const int col = lane & 15, kh = lane >> 4;
+    float dv[8];
+    {
+        const long s = s0 + col;
+        const float* r = d_out + (s < n ? s : n - 1) * (long)d_stride + d_col;
+#pragma unroll
+        for (int st = 0; st < 8; ++st) dv[st] = (s < n && 4 * st + kh < F) ? r[4 * st + kh] : 0.f;
+    }
+    if (s0 < n && lane < VBW_SAMPLES * 3) {       // phase 0: geometry of this wavefront's (sample, component) pairs
+        const int sl = lane / 3, i = lane % 3;
+        const bool live = s0 + sl < n;
+        const long s = live ? s0 + sl : n - 1;
+        const float pt[3] = {pts[s * 3], pts[s * 3 + 1], pts[s * 3 + 2]};
+        VbwTaps tp;
+        vbw_geometry(g, pt, i, live, tp);
+        taps[lane] = tp;
+        if (live && ltap) {
+            const int C = sel3(i, c0n, c1n, c2n);
+            LTap lt_;
+            lt_.c0 = tp.il[0] / C; lt_.c1 = tp.il[1] / C; lt_.w0 = tp.wl[0]; lt_.w1 = tp.wl[1];
+            ltap[s * 3 + i] = lt_;
+        }
+    }
+    __syncthreads();                              // the only block-wide barrier: basis_mat visible (also orders the tap tables)
+    if (s0 >= n) return;
+    auto wave_sync = []() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    // phase 1: D[channel 16 ct + 4 kh + r][sample col] = sum_f basis[f][channel] d out[sample][f]
+    for (int ct = 0; ct < ctot / 16; ++ct) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* bp = bs + kh * VBW_BSTR + 16 * ct + col;
+#pragma unroll
+        for (int st = 0; st < 8; ++st) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bp[4 * st * VBW_BSTR], dv[st], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dco[col * VBW_CSTR + 16 * ct + 4 * kh + r] = acc[r];
+    }
+    wave_sync();
+    // phase 2: gather, 3 items per lane in flight
+    const int items = VBW_SAMPLES * ng;
+    constexpr int UNR = 3;
+    for (int base = lane; base < items; base += UNR * 64) {
+        f32x4 rawp[UNR][4][2], rawl[UNR][2][2];
+        int sl[UNR], grp[UNR], comp[UNR];
+        bool on[UNR];
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) {
+            const int t = base + q * 64;
+            on[q] = t < items;
+            sl[q] = on[q] ? t / ng : 0;
+            grp[q] = on[q] ? t % ng : 0;
+            int i = 0, c8 = grp[q] * 8;
+            if (c8 >= c0n) { c8 -= c0n; i = 1; if (c8 >= c1n) { c8 -= c1n; i = 2; } }
+            comp[q] = i;
+            const VbwTaps& tp = taps[sl[q] * 3 + i];
+            const float* pl = sel3(i, g.plane[0], g.plane[1], g.plane[2]) + c8;
+            const float* li = sel3(i, g.line[0], g.line[1], g.line[2]) + c8;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int v = 0; v < 2; ++v) rawp[q][k][v] = *reinterpret_cast<const f32x4*>(pl + tp.ip[k] + 4 * v);
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int v = 0; v < 2; ++v) rawl[q][k][v] = *reinterpret_cast<const f32x4*>(li + tp.il[k] + 4 * v);
+        }
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) {
+            const VbwTaps& tp = taps[sl[q] * 3 + comp[q]];
+            const bool live = on[q] && s0 + sl[q] < n;
+            const int cb = grp[q] * 8;
+            float* drow = dco + sl[q] * VBW_CSTR + cb;
+            float gx = 0.f, gy = 0.f, gl = 0.f;
+            const float ww = tp.fw, nn = tp.fn, ee = 1.f - ww, sn = 1.f - nn;
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                f32x4 pv = {0.f, 0.f, 0.f, 0.f}, lv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) pv[k] = tp.wp[t] != 0.f ? __fadd_rn(pv[k], __fmul_rn(rawp[q][t][v][k], tp.wp[t])) : pv[k];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) lv[k] = tp.wl[t] != 0.f ? __fadd_rn(lv[k], __fmul_rn(rawl[q][t][v][k], tp.wl[t])) : lv[k];
+                f32x4 dc, rl, cf, rp;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    dc[k] = drow[4 * v + k];
+                    rl[k] = dc[k] * pv[k];
+                    cf[k] = pv[k] * lv[k];
+                    rp[k] = dc[k] * lv[k];
+                }
+                if (live) {
+                    if (rows_l) *reinterpret_cast<f32x4*>(rows_l + (s0 + sl[q]) * ctot + cb + 4 * v) = rl;
+                    if (coef_out) *reinterpret_cast<f32x4*>(coef_out + (s0 + sl[q]) * ctot + cb + 4 * v) = cf;
+                }
+                if (on[q]) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) drow[4 * v + k] = rp[k];
+                }
+                if (DPTS) {
+                    // d feature / d point through the interpolation weights (the ATen grid_sample backward: taps outside the grid contribute
+                    // nothing), chained with d coef
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float P0 = tp.wp[0] != 0.f ? rawp[q][0][v][k] : 0.f, P1 = tp.wp[1] != 0.f ? rawp[q][1][v][k] : 0.f;
+                        const float P2 = tp.wp[2] != 0.f ? rawp[q][2][v][k] : 0.f, P3 = tp.wp[3] != 0.f ? rawp[q][3][v][k] : 0.f;
+                        const float dpx = (P1 - P0) * sn + (P3 - P2) * nn, dpy = (P2 - P0) * ee + (P3 - P1) * ww;
+                        const float dl = (tp.wl[1] != 0.f ? rawl[q][1][v][k] : 0.f) - (tp.wl[0] != 0.f ? rawl[q][0][v][k] : 0.f);
+                        gx += dc[k] * lv[k] * dpx;
+                        gy += dc[k] * lv[k] * dpy;
+                        gl += dc[k] * pv[k] * dl;
+                    }
+                }
+            }
+            if (DPTS && on[q]) {
+                float* dp = dpart + (sl[q] * ng + grp[q]) * 3;
+                dp[0] = gx * tp.kx; dp[1] = gy * tp.ky; dp[2] = gl * tp.kl;
+            }
+        }
+    }
+    wave_sync();
+    // phase 3: plane taps.  dco now holds the plane rows d coef lv.
+    int coff = 0;
+#pragma unroll 1
+    for (int i = 0; i < 3; ++i) {
+        const int C = sel3(i, c0n, c1n, c2n);
+        float* gp = sel3(i, gg.plane[0], gg.plane[1], gg.plane[2]);
+        if (gp) {
+            if (C == 64) {                        // lanes = channels; the sum of a run of samples on one cell stays in a register
+#pragma unroll 1
+                for (int t = 0; t < 4; ++t) {
+                    float acc = 0.f;
+                    bool any = false;
+#pragma unroll 4
+                    for (int s = 0; s < VBW_SAMPLES; ++s) {
+                        const VbwTaps& tp = taps[s * 3 + i];
+                        const float w = tp.wp[t];
+                        const int cell = tp.ip[t];
+                        if (w != 0.f) { acc += w * dco[s * VBW_CSTR + coff + lane]; any = true; }
+                        const bool flush = s == VBW_SAMPLES - 1 || taps[(s + 1) * 3 + i].ip[t] != cell;
+                        if (flush) {
+                            if (any) unsafeAtomicAdd(gp + cell + lane, acc);
+                            acc = 0.f;
+                            any = false;
+                        }
+                    }
+                }
+            } else {                              // C = 8, 16 or 32: 64 / C (sample, tap) pairs per instruction
+                const int ppi = 64 / C, j = lane / C, c = lane % C;
+#pragma unroll 4
+                for (int p0 = 0; p0 < VBW_SAMPLES * 4; p0 += ppi) {
+                    const int p = p0 + j, s = p >> 2, t = p & 3;
+                    const VbwTaps& tp = taps[s * 3 + i];
+                    const float w = tp.wp[t];
+                    if (w != 0.f) unsafeAtomicAdd(gp + tp.ip[t] + c, w * dco[s * VBW_CSTR + coff + c]);
+                }
+            }
+        }
+        coff += C;
+    }
+    // phase 4: the point gradient of (sample, axis): component i feeds the axes (ax, ay | al) = (0, 1 | 2), (0, 2 | 1), (1, 2 | 0)
+    if (DPTS && lane < VBW_SAMPLES * 3) {
+        const int sl = lane / 3, a = lane % 3;
+        float sum = 0.f;
+        for (int gq = 0; gq < ng; ++gq) {
+            const int c8 = gq * 8, i = c8 < c0n ? 0 : (c8 < c0n + c1n ? 1 : 2);
+            const int ax = sel3(i, 0, 0, 1), ay = sel3(i, 1, 2, 2), al = sel3(i, 2, 1, 0);
+            const float* dp = dpart + (sl * ng + gq) * 3;
+            sum += (ax == a ? dp[0] : 0.f) + (ay == a ? dp[1] : 0.f) + (al == a ? dp[2] : 0.f);
+        }
+        if (s0 + sl < n) d_pts[(s0 + sl) * 3 + a] = sum;
+    }
+}
+
+// d basis_mat[f][c] += sum_s d out[s][f] coef[s][c] over all samples: exact-float32 MFMA (32 x 32 x 2 per sample pair and 32-channel
+// tile), every wavefront a strided share of the sample pairs, one atomic flush per wavefront.  HBM-bound: it reads d out and the
+// coefficient rows once (512 B per sample).
+template <int NCT>
+__global__ __launch_bounds__(256) void k_basis_grad(const float* __restrict__ d_out, int d_stride, int d_col, const float* __restrict__ coef, long n, int ctot, int F,
+                                                    float* __restrict__ d_basis) {
+    const int lane = threadIdx.x & 63, mn = lane & 31, kb = lane >> 5;
+    const long gw = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long)gridDim.x * 4, pairs = (n + 1) / 2;
+    f32x16 acc[NCT];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+    constexpr int UN = 4;
+    for (long p0 = gw * UN; p0 < pairs; p0 += nw * UN) {
+        float a[UN], b[UN][NCT];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const long s = 2 * (p0 + u) + kb;
+            const bool ok = p0 + u < pairs && s < n;
+            a[u] = (ok && mn < F) ? d_out[s * (long)d_stride + d_col + mn] : 0.f;
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) b[u][c] = (ok && 32 * c + mn < ctot) ? coef[s * ctot + 32 * c + mn] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][c], acc[c], 0, 0, 0);
+    }
+    // the block's four wavefronts fold their sums in LDS (plain stores + one barrier each, no LDS atomics), then ONE atomic flush per block:
+    // the grid fills every wavefront slot of the chip (the loads are 4-byte lane loads: bandwidth comes from the number of wavefronts)
+    __shared__ float fold[32 * 97];
+    const int wv = threadIdx.x >> 6;
+    for (int w = 0; w < 4; ++w) {
+        if (wv == w) {
+#pragma unroll
+            for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int f = (r & 3) + 8 * (r >> 2) + 4 * kb, ch = 32 * c + mn;
+                    fold[f * 97 + ch] = w == 0 ? acc[c][r] : fold[f * 97 + ch] + acc[c][r];
+                }
+        }
+        __syncthreads();
+    }
+    for (int o = threadIdx.x; o < F * ctot; o += 256) {
+        const int f = o / ctot, ch = o % ctot;
+        const float v = fold[f * 97 + ch];
+        if (v != 0.f) unsafeAtomicAdd(d_basis + o, v);
+    }
+}
+
 // d (TV_loss_app) / d grid, added into `grad` scaled by d loss (a device scalar) x weight (1e-2 planes | 1e-3 lines) (voxnerf.py:126-130, 306-324):
 // reg = 2 (sum dh^2 / count_h + sum dw^2 / count_w)  =>  d reg / d x = 4 ((dh_prev - dh_next) / count_h + (dw_prev - dw_next) / count_w)
 __global__ __launch_bounds__(256) void k_tv_bwd(const float* __restrict__ x, int H, int W, int C, const float* __restrict__ d_loss, float weight, float* __restrict__ grad) {
@@ -1220,6 +1538,40 @@ int launch_voxel_sample_bwd_planes(const GridParams& g, const float* pts, long n
     else if (mm) k_voxel_sample_bwd<2, true, VS_MAXC><<<blocks, 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo);
     else k_voxel_sample_bwd<2, false, VS_MAXC><<<blocks, 256, 0, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo);
     EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+// the wavefront-autonomous form (k_voxel_sample_bwd_w + k_basis_grad); the caller runs k_scatter_lines on rows_l / ltap afterwards
+bool voxel_sample_bwd_w_ok(const GridParams& g) {
+    const int ct = g.n_comp[0] + g.n_comp[1] + g.n_comp[2];
+    auto okc = [](int c) { return c == 8 || c == 16 || c == 32 || c == 64; };
+    const long pmax = (long)g.grid[0] * g.grid[1] > (long)g.grid[0] * g.grid[2] ? (long)g.grid[0] * g.grid[1] : (long)g.grid[0] * g.grid[2];
+    const long pm2 = (long)g.grid[1] * g.grid[2] > pmax ? (long)g.grid[1] * g.grid[2] : pmax;
+    return g.app_dim >= 4 && g.app_dim <= 32 && g.app_dim % 4 == 0 && ct % 16 == 0 && ct <= 96 && okc(g.n_comp[0]) && okc(g.n_comp[1]) && okc(g.n_comp[2]) &&
+           pm2 * 64 < (1L << 31) && g.app_act == EVD_ACT_NONE;
+}
+int launch_voxel_sample_bwd_w(const GridParams& g, const float* pts, long n, const float* d_out, int d_stride, int d_col, const GridGrads& gg,
+                              float* d_pts, float* rows_l, LTap* ltap, float* coef, hipStream_t st) {
+    const unsigned blocks = (unsigned)cdiv(n, (long)VBW_SAMPLES * VBW_WAVES);
+    float* coef_w = gg.basis ? coef : nullptr;
+    if (d_pts) {
+        EVD_SET_MAX_LDS((&k_voxel_sample_bwd_w<true>), VBW_LDS);
+        k_voxel_sample_bwd_w<true><<<blocks, 64 * VBW_WAVES, VBW_LDS, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, rows_l, ltap, coef_w);
+    } else {
+        EVD_SET_MAX_LDS((&k_voxel_sample_bwd_w<false>), VBW_LDS);
+        k_voxel_sample_bwd_w<false><<<blocks, 64 * VBW_WAVES, VBW_LDS, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, rows_l, ltap, coef_w);
+    }
+    EVD_LAUNCH_CHECK();
+    if (gg.basis) {
+        const int ct = g.n_comp[0] + g.n_comp[1] + g.n_comp[2];
+        int cus = 256;
+        { int dev = 0, v = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
+        const unsigned gb = (unsigned)(cdiv(n, 64L) < 8L * cus ? cdiv(n, 64L) : 8L * cus);     // 8 blocks of 4 wavefronts per CU: every wavefront slot
+        if (ct <= 32) k_basis_grad<1><<<gb, 256, 0, st>>>(d_out, d_stride, d_col, coef, n, ct, g.app_dim, gg.basis);
+        else if (ct <= 64) k_basis_grad<2><<<gb, 256, 0, st>>>(d_out, d_stride, d_col, coef, n, ct, g.app_dim, gg.basis);
+        else k_basis_grad<3><<<gb, 256, 0, st>>>(d_out, d_stride, d_col, coef, n, ct, g.app_dim, gg.basis);
+        EVD_LAUNCH_CHECK();
+    }
     return EVD_OK;
 }
 

@@ -438,8 +438,14 @@ static bool xy_deferred(const GridParams& g, const GridGrads& gg) {
 size_t voxel_scatter_hybrid_workspace_bytes(const GridParams& g, long n) {
     if (n <= 0) return 0;
     const size_t ctot = (size_t)(g.n_comp[0] + g.n_comp[1] + g.n_comp[2]);
-    return al256((size_t)n * ctot * 4) + al256((size_t)n * 3 * sizeof(LTap)) + al256((size_t)n * XY_C * 4) + al256((size_t)n * sizeof(PTap)) + 512;
+    // rows_l, ltap, then EITHER the coefficient rows of the wavefront-autonomous form OR the x-y rows + tap records of the windowed form
+    const size_t tail = al256((size_t)n * ctot * 4) > al256((size_t)n * XY_C * 4) + al256((size_t)n * sizeof(PTap)) ? al256((size_t)n * ctot * 4)
+                                                                                                                   : al256((size_t)n * XY_C * 4) + al256((size_t)n * sizeof(PTap));
+    return al256((size_t)n * ctot * 4) + al256((size_t)n * 3 * sizeof(LTap)) + tail + 512;
 }
+
+// developer switch: EVD_SCATTER_FORM=block selects round 2's block-cooperative main kernel (k_voxel_sample_bwd<2>) behind the hybrid entry
+static bool scatter_form_block() { static const bool b = [] { const char* e = getenv("EVD_SCATTER_FORM"); return e && !strcmp(e, "block"); }(); return b; }
 
 int launch_voxel_sample_bwd_hybrid(const GridParams& g, const float* pts, long n, const float* d_out, int d_stride, int d_col, const GridGrads& gg,
                                    float* d_pts, void* workspace, size_t workspace_bytes, hipStream_t st) {
@@ -450,6 +456,13 @@ int launch_voxel_sample_bwd_hybrid(const GridParams& g, const float* pts, long n
     BinOut bo{};
     bo.rows_l = (float*)w;
     bo.ltap = (LTap*)(w + al256((size_t)n * ctot * 4));
+    if (voxel_sample_bwd_w_ok(g) && !scatter_form_block() && !xy_deferred(g, gg)) {
+        // round 3: wavefront-autonomous pass (plane taps incl. the run-length x-y walk, rows for the lines, coefficient rows for the basis GEMM)
+        float* coef = (float*)(w + al256((size_t)n * ctot * 4) + al256((size_t)n * 3 * sizeof(LTap)));
+        int rc = launch_voxel_sample_bwd_w(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo.rows_l, bo.ltap, coef, st);
+        if (rc) return rc;
+        return launch_lines(g, gg, (const float*)bo.rows_l, (const LTap*)bo.ltap, n, st);
+    }
     const bool xy = xy_deferred(g, gg);
     if (xy) {
         char* w2 = w + al256((size_t)n * ctot * 4) + al256((size_t)n * 3 * sizeof(LTap));

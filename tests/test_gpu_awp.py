@@ -385,3 +385,42 @@ def test_fused_awp_with_the_reference_mam_structure_equals_plain_torch():
     print("[FusedAWP, reference MAM structure, vs torch]", f"all {_rel(ga, gb):.1e}", {k: f"{v:.1e}" for k, v in errs.items()})
     # the MAM's own path is pinned to 5e-5 by test_mam_local_against_the_reference_golden; this is the wiring, through a float16 embedding
     assert _rel(ga, gb) < 5e-2 and max(errs.values()) < 0.15, errs
+
+
+def test_fused_awp_per_ray_tail_as_a_captured_graph():
+    """FusedAWP(graph_per_ray=True): the per-ray remainder (awp.py:105-117, mam.py:35-53; ~100 small launches forward, twice that
+    backward) replayed as one hipGraph each way.  Same module, same inputs: output and the gradients of every parameter equal the
+    eager path's (the captured kernels ARE the eager kernels), over two steps with an optimizer update in between."""
+    from evdeblurnerf_amd.awp import FusedAWP
+    torch.manual_seed(5)
+    rs = np.random.RandomState(17)
+    R, P, S = 64, 5, 32
+    ref = _RefLikeAWP(P=P, mam="corr").cuda()
+    ref2 = _RefLikeAWP(P=P, mam="corr").cuda()
+    ref2.load_state_dict(ref.state_dict())
+    eager, graphed = FusedAWP(ref, "f16"), FusedAWP(ref2, "f16", graph_per_ray=True)
+    opts = [torch.optim.SGD(m.parameters(), lr=1e-2) for m in (ref, ref2)]
+    for step in range(3):
+        df = _t((0.5 * rs.standard_normal((R * P, S, 128))).astype(np.float32))
+        z = _t(np.sort(rs.uniform(0, 1, (R * P, S)).astype(np.float32), -1))
+        d = _t(rs.standard_normal((R * P, 3)).astype(np.float32))
+        vf = _t(rs.standard_normal((R, 4)).astype(np.float32))
+        proj = _t(rs.standard_normal((R, P)).astype(np.float32))
+        outs, grads = [], []
+        for fused, m, opt in ((eager, ref, opts[0]), (graphed, ref2, opts[1])):
+            opt.zero_grad(set_to_none=True)
+            df_ = df.clone().requires_grad_(True)
+            out = fused(df_, z, d.clone().requires_grad_(True), vf)
+            (out * proj).sum().backward()
+            outs.append(out.detach().clone())
+            grads.append({n_: (p.grad.detach().clone() if p.grad is not None else None) for n_, p in m.named_parameters()})
+            grads[-1]["d depth_feature"] = df_.grad.detach().clone()
+            opt.step()
+        assert graphed._graphed, "the graph was not built"
+        assert float((outs[0] - outs[1]).abs().max()) < 1e-5, step
+        for n_ in grads[0]:
+            a, b = grads[0][n_], grads[1][n_]
+            if a is None or b is None:
+                assert (a is None or float(a.abs().max()) == 0.0) and (b is None or float(b.abs().max()) == 0.0), n_
+                continue
+            assert float((a - b).abs().max()) <= 2e-4 * (float(a.abs().max()) + 1e-6), (step, n_, float((a - b).abs().max()), float(a.abs().max()))
