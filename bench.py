@@ -287,25 +287,32 @@ def c2f_leg(precision, steps, parity=True):
     fine = model.mlp_fine
     g_ms = kernel_ms(lambda: fine.sample(pts), steps)
     n = R * 128
-    esz = 2 if precision in ("f16", "bf16") else 4            # the single-product half-precision modes gather float16 copies of the grids
+    half_grids = precision in ("f16", "bf16")                   # the single-product half-precision modes gather float16 copies of the grids
+    esz = 2 if half_grids else 4
     taps = 4 * 96 + 2 * 96                                      # 4 plane taps + 2 line taps x 96 channels = 576 gathered values per sample
-    algo = n * (taps * esz + 12 + 4 * fine.app_dim)             # + the point in, app_dim floats out
+    gathered = n * taps * esz
+    # PMC (profiles/r02_pmc_voxel.txt: float16 grids; profiles/r03_pmc_voxel_f32grids.txt: float32 grids; tools/pmc_voxel.sh), per sample of the
+    # fine-level launch: 128-byte line requests at the L2 and the lines that miss it (served by the Infinity Cache: the 165 MB of grids exceed
+    # the 32 MB of L2).  The kernel is a random gather: its roofline is the RATE at which the chip serves such requests, measured by
+    # tools/probes/gather_probe.hip (random 128-byte records, 16-byte lane loads), not an HBM byte rate.
+    pmc = {"l2_requests_per_sample": 10.2, "l2_miss_lines_per_sample": 3.8, "fetch_size_bytes_per_sample": 346, "source": "profiles/r02_pmc_voxel.txt"} if half_grids else \
+          {"l2_requests_per_sample": 14.2, "l2_miss_lines_per_sample": 6.1, "fetch_size_bytes_per_sample": 653, "source": "profiles/r03_pmc_voxel_f32grids.txt"}
+    ceil = {"l2_resident": 146e9, "infinity_cache": 58e9, "hbm": 54e9}
+    req_rate = pmc["l2_requests_per_sample"] * n / (g_ms * 1e-3)
+    miss_rate = pmc["l2_miss_lines_per_sample"] * n / (g_ms * 1e-3)
     out = {"workload": "blurfactory c2f render: 4096 rays x (64 coarse + 64 importance) samples, grids 293x293x195 / 586x586x390, n_comp (64,16,16)",
            "precision": precision, "ms_per_step": step_ms, "rays_per_s": R / (step_ms * 1e-3),
-           "roofline": {"kernel": "k_voxel_sample_w (fine level, 4096 x 128 samples)", "bound": "hbm", "kernel_ms": g_ms,
-                        "algorithmic_bytes": algo, "bytes_per_sample": algo / n, "achieved": algo / (g_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": algo / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "frac_of_l2_peak": algo / (g_ms * 1e-3) / 1e9 / L2_PEAK_GBS,
-                        "pmc": {"source": "profiles/r02_pmc_voxel.txt (tools/pmc_voxel.sh, f16 grids, per launch of 524 288 samples)",
-                                "l2_requests_per_sample": 10.2, "l2_miss_lines_per_sample": 3.8, "fetch_size_bytes_per_sample": 346,
-                                "gather_ceiling_lines_per_s": {"l2_resident": 146e9, "infinity_cache": 58e9, "hbm": 54e9,
-                                                               "probe": "tools/probes/gather_probe.hip (128-byte records, 16-byte lane loads)"}},
-                        "note": "algorithmic bytes = 576 gathered grid values (4 taps x 96 plane channels + 2 taps x 96 line channels) x the "
-                                "grid element size + the point in + 32 floats out, per sample; the fine grids (41 M values) exceed the 32 MB of "
-                                "L2 and sit in the 256 MB Infinity Cache.  Counted (PMC): 10.2 L2 line requests per sample of which 3.8 miss to "
-                                "the Infinity Cache; at this launch duration that is ~45 G lines/s at L2 and ~16 G lines/s behind it, 30 % resp. "
-                                "28 % of what a bare random gather of 128-byte records sustains on this chip -- the kernel is a latency chain "
-                                "(points -> tap geometry -> gather -> basis GEMM -> store) per wavefront, not bandwidth-bound (DESIGN.md 3.3)"}}
+           "roofline": {"kernel": "k_voxel_sample_w (fine level, 4096 x 128 samples, %s grids)" % ("float16" if half_grids else "float32"),
+                        "bound": "l2-gather (128-byte line requests/s)", "kernel_ms": g_ms,
+                        "achieved": req_rate / 1e9, "peak": ceil["l2_resident"] / 1e9, "unit": "G line requests/s", "frac": req_rate / ceil["l2_resident"],
+                        "behind_l2": {"achieved": miss_rate / 1e9, "peak": ceil["infinity_cache"] / 1e9, "unit": "G lines/s", "frac": miss_rate / ceil["infinity_cache"]},
+                        "gathered_bytes": gathered, "gathered_GBps": gathered / (g_ms * 1e-3) / 1e9, "pmc": pmc,
+                        "gather_ceiling_lines_per_s": dict(ceil, probe="tools/probes/gather_probe.hip (128-byte records, 16-byte lane loads)"),
+                        "note": "achieved = PMC-counted L2 line requests per sample x samples / the launch duration measured here, against the rate a bare "
+                                "random gather of 128-byte records sustains when its table is L2-resident; behind_l2 = the lines that miss L2 against the "
+                                "Infinity-Cache-resident ceiling.  576 grid values are gathered per sample (4 taps x 96 plane channels + 2 taps x 96 line "
+                                "channels); the kernel is a latency chain per wavefront (points -> tap geometry -> gather -> basis GEMM -> store), "
+                                "not bandwidth-bound (DESIGN.md 3.3)"}}
     out["arithmetic"] = {"f16c": "fine level: compensated float16 (k_voxel_mlp_c: f16 MFMA + two block-scaled fp6 MFMA residual products); coarse 64-wide level: "
                                  "float32-grade f16x3; gathers on the float32 grids",
                          "f16": "single-product float16 MFMA on both levels, float16 grid copies", "bf16": "bf16 MFMA on both levels, float16 grid copies",
@@ -437,10 +444,12 @@ def train_iteration_leg(precision):
             "rays_per_s": nrays / (ms * 1e-3),
             "with_awp_ms_per_iteration": {"fused_on_geo_fragments": ms_awp_f, "torch_module_on_depth_feature": ms_awp_t,
                                           "note": "AWP module = tools/awp_standin.py (the reference module's surface; its per-sample embedding is the reference's)"},
-            "scatter_hybrid_ms": h_ms,
-            "scatter_note": "what the iteration runs: plane taps by direct float atomics (384 per sample), line taps through 64-bit fixed-point LDS "
-                            "slices of the line gradients (k_scatter_lines; ds_add_f32 is ~6 x slower than integer LDS atomics on this chip) -- "
-                            "a third fewer atomic requests than the all-atomics form whose roofline follows",
+            "scatter_hybrid_ms": h_ms, "scatter_all_atomics_ms": k_ms,
+            "scatter_note": "what the iteration runs since round 3 (k_voxel_sample_bwd_w + k_scatter_lines + k_basis_grad): a wavefront owns 16 consecutive "
+                            "samples of a ray from the point load to its last atomic; the x-y plane's taps are summed in a register along runs of samples on one "
+                            "cell before ONE atomic per run, the 16-channel planes add tap by tap, the line taps go through 64-bit fixed-point LDS slices, the "
+                            "basis_mat gradient is its own GEMM.  PMC (profiles/r03_pmc_scatter.txt, slope 0.05): 6.0 M atomic requests per 2^19 samples "
+                            "instead of 18.9 M (all taps by atomics, the roofline below) / 12.6 M (round 2's hybrid)",
             "roofline": {"kernel": "k_voxel_sample_bwd, all taps by atomics (fine level 586 x 586 x 390, 4096 x 128 samples)",
                          "bound": "memory-side atomics", "kernel_ms": k_ms, "float_atomics": atomics, "achieved": atomics / (k_ms * 1e-3) / 1e9, "peak": peak,
                          "unit": "G float atomic adds/s", "frac": atomics / (k_ms * 1e-3) / 1e9 / peak,
@@ -549,10 +558,10 @@ def main(argv=None):
                 modes[prec]["mfma_issue_frac"] = 1.5 * tf / PEAK_TFLOPS[prec]    # + two fp6 32x32x64 products per four f16 32x32x16 ones: 1.5x the MFMA cycles
         m = modes[a.precision]
         # HBM traffic and the hardware's own MFMA-busy fraction come from the committed PMC passes of this kernel
-        # (rocprofv3 cannot run inside the timed process): profiles/r02_pmc_mlp.json, made by tools/pmc_mlp.sh + tools/pmc_mlp_json.py
+        # (rocprofv3 cannot run inside the timed process): profiles/r03_pmc_mlp.json, made by tools/pmc_mlp.sh + tools/pmc_mlp_json.py
         traffic, busy = None, None
         try:
-            pmc_file = next(f for f in ("r02_pmc_mlp.json", "r01_v3_pmc_mlp.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            pmc_file = next(f for f in ("r03_pmc_mlp.json", "r02_pmc_mlp.json", "r01_v3_pmc_mlp.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))["derived"].get(a.precision)
             if pmc and R == 4096 and S == 128:
                 traffic, busy = pmc["traffic_bytes"], pmc["mfma_busy_frac"]
@@ -573,7 +582,7 @@ def main(argv=None):
                                       "dense peak; traffic (bytes per launch: 2.0x the algorithmic bytes, the weight stream is fetched once per "
                                       "XCD L2) and mfma_busy_frac_pmc (SQ_VALU_MFMA_BUSY_CYCLES over "
                                       "GRBM_GUI_ACTIVE x SIMDs: the kernel keeps the pipe busier than frac says because the chip clocks "
-                                      "below 2.4 GHz under this load) are from the PMC passes in profiles/r02_pmc_mlp.json; "
+                                      "below 2.4 GHz under this load) are from the PMC passes in profiles/r03_pmc_mlp.json; "
                                       "sustained_mfma_tflops = a bare back-to-back MFMA loop on every SIMD, measured in this run "
                                       "(evd_probe_mfma_rate): the random-operand figure is the practical ceiling for real data"}
         result["modes"] = modes

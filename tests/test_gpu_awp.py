@@ -423,4 +423,5 @@ def test_fused_awp_per_ray_tail_as_a_captured_graph():
             if a is None or b is None:
                 assert (a is None or float(a.abs().max()) == 0.0) and (b is None or float(b.abs().max()) == 0.0), n_
                 continue
-            assert float((a - b).abs().max()) <= 2e-4 * (float(a.abs().max()) + 1e-6), (step, n_, float((a - b).abs().max()), float(a.abs().max()))
+            # (two models, each with float16 fragments + float atomics in its own embedding: rounding-level differences)
+            assert float((a - b).abs().max()) <= 2e-3 * (float(a.abs().max()) + 1e-6), (step, n_, float((a - b).abs().max()), float(a.abs().max()))
