@@ -36,7 +36,8 @@ class NerfDesc(C.Structure):
                 ("rgb_act", C.c_int), ("sigma_act", C.c_int), ("rmnear", C.c_float),
                 ("pts_w", _fp * MAXL), ("pts_b", _fp * MAXL),
                 ("views_w", _fp), ("views_b", _fp), ("feature_w", _fp), ("feature_b", _fp),
-                ("alpha_w", _fp), ("alpha_b", _fp), ("rgb_w", _fp), ("rgb_b", _fp)]
+                ("alpha_w", _fp), ("alpha_b", _fp), ("rgb_w", _fp), ("rgb_b", _fp),
+                ("output_w", _fp), ("output_b", _fp), ("output_ch", C.c_int)]
 
 
 class NerfGrads(C.Structure):

@@ -72,15 +72,23 @@ int evd_nerf_create(const evd_nerf_desc* d, evd_nerf** out) {
                 "evd_nerf_create: only multires=%d, multires_views=%d are built (got %d, %d)", PE_L, PE_LV, d->multires, d->multires_views);
     EVD_REQUIRE(d->W == 256 || d->W == 64, "evd_nerf_create: netwidth %d not built (64, 256)", d->W);
     EVD_REQUIRE(d->D >= 1 && d->D <= EVD_MAX_LAYERS, "evd_nerf_create: netdepth %d out of range", d->D);
-    EVD_REQUIRE(d->views_w && d->feature_w && d->alpha_w && d->rgb_w, "evd_nerf_create: use_viewdirs=False networks are not supported");
+    const bool no_views = !d->views_w && !d->feature_w && !d->alpha_w && !d->rgb_w && d->output_w;
+    EVD_REQUIRE(no_views || (d->views_w && d->feature_w && d->alpha_w && d->rgb_w),
+                "evd_nerf_create: give either the view branch (views / feature / alpha / rgb) or output_linear (use_viewdirs=False)");
+    EVD_REQUIRE(!no_views || (d->output_b && (d->output_ch == 4 || d->output_ch == 5)), "evd_nerf_create: output_linear needs its bias and output_ch 4 or 5");
     const int W = d->W, T = W / 32, KS = W / 16, IC = 3 * (1 + 2 * PE_L), ICV = 3 * (1 + 2 * PE_LV), D = d->D;
     evd_nerf* n = new evd_nerf();
     n->D = D; n->W = W; n->skip = d->skip; n->rgb_act = d->rgb_act; n->sigma_act = d->sigma_act; n->rmnear = d->rmnear;
+    n->no_views = no_views ? 1 : 0;
 
     // host copy of every parameter in one arena (missing biases = zeros); the packers below read from it
     long sz[2 * EVD_MAX_LAYERS + 8];
     nerf_param_sizes(D, W, d->skip, sz);
     n->nparam_blocks = 2 * D + 8;
+    if (no_views) {                     // canonical order: pts_linears[l].{weight, bias}, then output_linear.{weight, bias}
+        sz[2 * D] = (long)d->output_ch * W; sz[2 * D + 1] = d->output_ch;
+        n->nparam_blocks = 2 * D + 2;
+    }
     long total = 0;
     for (int i = 0; i < n->nparam_blocks; ++i) { n->param_off[i] = total; total += sz[i]; }
     n->param_off[n->nparam_blocks] = total;
@@ -90,13 +98,16 @@ int evd_nerf_create(const evd_nerf_desc* d, evd_nerf** out) {
         for (int l = 0; l < D; ++l) { srcs[2 * l] = d->pts_w[l]; srcs[2 * l + 1] = d->pts_b[l]; }
         const float* heads[8] = {d->views_w, d->views_b, d->feature_w, d->feature_b, d->alpha_w, d->alpha_b, d->rgb_w, d->rgb_b};
         for (int i = 0; i < 8; ++i) srcs[2 * D + i] = heads[i];
+        if (no_views) { srcs[2 * D] = d->output_w; srcs[2 * D + 1] = d->output_b; }
         for (int i = 0; i < n->nparam_blocks; ++i)
             if (srcs[i]) memcpy(arena.data() + n->param_off[i], srcs[i], sz[i] * sizeof(float));
     }
     const float* A = arena.data();
     auto P = [&](int i) { return A + n->param_off[i]; };
     auto pts_w = [&](int l) { return P(2 * l); };
-    const float *views_w = P(2 * D), *feature_w = P(2 * D + 2), *alpha_w = P(2 * D + 4), *rgb_w = P(2 * D + 6);
+    const float *views_w = P(2 * D), *feature_w = no_views ? nullptr : P(2 * D + 2), *alpha_w = no_views ? nullptr : P(2 * D + 4), *rgb_w = no_views ? nullptr : P(2 * D + 6);
+    const float* output_w = P(2 * D);
+    const int out_rows = d->output_ch < 4 ? d->output_ch : 4;       // raw2outputs reads channels 0..3
 
     auto pe_col = [](int j, int kk) { return pe_src_col(PE_L, 8 * j + (kk & 7), kk >> 3); };
     auto hid_col = [](int j, int kk) { return 16 * j + phi(kk); };
@@ -122,6 +133,10 @@ int evd_nerf_create(const evd_nerf_desc* d, evd_nerf** out) {
                 sb.layer(pts_w(l), W, W, T, KS, true, hid_col);
             }
         }
+        if (no_views) {
+            sb.layer(output_w, out_rows, W, 1, KS, true, hid_col);
+            return;
+        }
         sb.layer(alpha_w, 1, W, 1, KS, false, hid_col);
         sb.layer(feature_w, W, W, T, KS, false, hid_col);
         sb.layer(views_w, W / 2, W + ICV, T / 2, KS + PEV_KS, false, views_col);
@@ -131,7 +146,7 @@ int evd_nerf_create(const evd_nerf_desc* d, evd_nerf** out) {
     for (int prec = 0; prec < EVD_NUM_PREC && !rc; ++prec) {
         if (prec == EVD_PREC_F16C) {      // compensated float16 mode: its own stream (float16 + fp6 fragments) and row scales; pipelined kernel only
             n->nchunks[prec] = n->pipe_chunks[prec] = 0;
-            if (!nerf_mlp_c_chunks(W, D, d->skip)) continue;
+            if (no_views || !nerf_mlp_c_chunks(W, D, d->skip)) continue;
             StreamBuilderC sc(PIPE_CB);
             sc.arena = A;
             const int KB = KS / 4;
@@ -163,7 +178,7 @@ int evd_nerf_create(const evd_nerf_desc* d, evd_nerf** out) {
         n->nchunks[prec] = (int)(sb.bytes.size() / chunk_bytes(prec));
         rc = upload_stream(n->stream[prec], sb);
         n->pipe_chunks[prec] = 0;
-        if (!rc && nerf_pipe_built(prec, W, D, d->skip)) {
+        if (!rc && !no_views && nerf_pipe_built(prec, W, D, d->skip)) {
             StreamBuilder sp(prec, PIPE_CB);
             sp.arena = A;
             sp.group = nerf_group(prec);
@@ -226,10 +241,14 @@ int evd_nerf_create(const evd_nerf_desc* d, evd_nerf** out) {
         }
     };
     for (int l = 0; l < D; ++l) push(2 * l + 1, W, T);
-    push(2 * D + 5, 1, 1);
-    push(2 * D + 3, W, T);
-    push(2 * D + 1, W / 2, T / 2);
-    push(2 * D + 7, 3, 1);
+    if (no_views) {
+        push(2 * D + 1, out_rows, 1);
+    } else {
+        push(2 * D + 5, 1, 1);
+        push(2 * D + 3, W, T);
+        push(2 * D + 1, W / 2, T / 2);
+        push(2 * D + 7, 3, 1);
+    }
     rc = n->bias.upload(b.data(), b.size() * sizeof(float));
     if (!rc) rc = n->bias_src.upload(bsrc.data(), bsrc.size() * sizeof(int32_t));
     if (rc) { evd_nerf_destroy(n); return rc; }
@@ -298,7 +317,9 @@ int evd_nerf_mlp(const evd_nerf* net, int precision, const float* ray_batch, con
     const bool piped = net->pipe_chunks[precision] > 0 && !no_pipe;
     p.wstream = (const char*)(piped ? net->pipe[precision].data.p : net->stream[precision].data.p);
     p.bias = (const float*)net->bias.p;
-    p.ray_batch = ray_batch; p.z = z; p.nsamp = R * (long)S; p.S = S; p.ncol = 11;
+    p.ray_batch = ray_batch; p.z = z; p.nsamp = R * (long)S; p.S = S; p.ncol = net->no_views ? 8 : 11; p.no_views = net->no_views;
+    EVD_REQUIRE(!(net->no_views && feature && feature_kind == 1), "evd_nerf_mlp: a use_viewdirs=False network has no after_linear feature (nerf.py:159)");
+    EVD_REQUIRE(!net->no_views || precision != EVD_PREC_F16C, "evd_nerf_mlp: EVD_PREC_F16C is not built for use_viewdirs=False networks");
     p.D = net->D; p.skip = net->skip; p.nchunks = piped ? net->pipe_chunks[precision] : net->nchunks[precision]; p.nbias = (int)(net->bias.bytes / sizeof(float));
     p.raw = raw; p.feature = feature; p.feature_kind = feature ? feature_kind : 0; p.act = nullptr; p.wscale = nullptr;
     if (precision == EVD_PREC_F16C) {
@@ -345,7 +366,9 @@ static int render_rays_impl(const evd_nerf* coarse, const evd_nerf* fine, const 
                             long R, const float* t_rand, const float* u, const float* noise0, const float* noise1,
                             evd_render_out* out, void* workspace, size_t workspace_bytes, void* stream, bool z_done) {
     EVD_REQUIRE(coarse && cfg && out && (rb || R == 0), "evd_nerf_render_rays: null argument");
-    EVD_REQUIRE(cfg->use_viewdirs, "evd_nerf_render_rays: use_viewdirs=False is not supported");
+    EVD_REQUIRE((cfg->use_viewdirs != 0) == (coarse->no_views == 0) && (!fine || fine->no_views == coarse->no_views),
+                "evd_nerf_render_rays: cfg->use_viewdirs does not match the networks (view branch vs output_linear)");
+    const int nc = cfg->use_viewdirs ? 11 : 8;
     EVD_REQUIRE(cfg->N_samples >= 1, "evd_nerf_render_rays: N_samples must be >= 1");
     EVD_REQUIRE(cfg->N_importance <= 0 || fine, "evd_nerf_render_rays: N_importance > 0 needs the fine network");
     EVD_REQUIRE(cfg->N_importance <= 0 || cfg->N_samples >= 3, "evd_nerf_render_rays: hierarchical sampling needs N_samples >= 3");
@@ -388,13 +411,13 @@ static int render_rays_impl(const evd_nerf* coarse, const evd_nerf* fine, const 
         p.z_out = out->z_vals; p.rgb_map = out->rgb; p.depth_map = out->depth; p.acc_map = out->acc; p.weights = out->weights;
         return nerf_mlp_c_dispatch(coarse->W, coarse->D, coarse->skip, p, as_stream(stream));
     }
-    if (!z_done && (rc = evd_sample_z(cfg, rb, 11, R, t_rand, zc, stream))) return rc;
+    if (!z_done && (rc = evd_sample_z(cfg, rb, nc, R, t_rand, zc, stream))) return rc;
     auto pass = [&](const evd_nerf* net, const float* z, int Sp, const float* noise, float* rgb, float* depth, float* acc,
                     float* weights, float* raw_out, float* feat) -> int {
         int rc2 = evd_nerf_mlp(net, cfg->precision, rb, z, R, Sp, raw_out, feat, out->feature_kind ? out->feature_kind : 1, stream);
         if (rc2) return rc2;
         const float thr = (!cfg->is_train && net->rmnear > 0.f) ? (float)((double)net->rmnear / 128.0) : 0.f;
-        return evd_raw2outputs(raw_out, z, rb + 3, 11, R, Sp, 4, 3, 0, 3, net->rgb_act, net->sigma_act, cfg->white_bkgd, thr,
+        return evd_raw2outputs(raw_out, z, rb + 3, nc, R, Sp, 4, 3, 0, 3, net->rgb_act, net->sigma_act, cfg->white_bkgd, thr,
                                noise, rgb, nullptr, acc, weights, depth, nullptr, 0, nullptr, stream);
     };
     if (!Ni) {

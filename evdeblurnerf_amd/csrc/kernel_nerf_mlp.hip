@@ -37,7 +37,7 @@ __global__ __launch_bounds__(mlp_threads(PREC), is_half_prec(PREC) ? 2 : 1) void
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         pts[c] = __fadd_rn(rb[c], __fmul_rn(rb[3 + c], zv));   // renderer.py:180
-        vd[c] = rb[8 + c];
+        vd[c] = p.no_views ? 0.f : rb[8 + c];
     }
 
     // point encoding straight into B-fragment order (nerf_mlp.h); a copy is parked in this wavefront's LDS stash
@@ -82,6 +82,15 @@ __global__ __launch_bounds__(mlp_threads(PREC), is_half_prec(PREC) ? 2 : 1) void
         for (int j = 0; j < KS; ++j) act[j] = nxt[j];
     }
 
+    if (p.no_views) {          // use_viewdirs=False: outputs = output_linear(h) (nerf.py:158-160), rows 0..3 = (rgb, sigma)
+        float oraw[16];
+        layer<PREC, KS, 1, false, OUT_F32, 0, true>(st, act, nullptr, oraw, bias, lane, nullptr, W);
+        if (h == 0 && valid) {
+            const f32x4 o = {oraw[0], oraw[1], oraw[2], oraw[3]};
+            *reinterpret_cast<f32x4*>(p.raw + s * 4) = o;
+        }
+        return;
+    }
     // heads: alpha_linear (1 tile), feature_linear, views_linears.0 on cat([feature, dirs]), rgb_linear (nerf.py:144-157)
     constexpr int F_ALPHA = KS, F_FEAT = T * KS, F_VIEWS = (T / 2) * (KS + PEV_KS);
     constexpr int OFF_FEAT = F_ALPHA % FPC, OFF_VIEWS = (F_ALPHA + F_FEAT) % FPC, OFF_RGB = (F_ALPHA + F_FEAT + F_VIEWS) % FPC;

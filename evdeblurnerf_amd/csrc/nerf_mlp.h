@@ -58,6 +58,7 @@ struct MlpParams {
     float* feature;         // [R, S, W] or null
     int feature_kind;       // 0 none, 1 after_linear, 2 before_linear
     char* act;              // training kernels: activation store (act_tile_bytes per 32-sample tile), else null
+    int no_views;           // use_viewdirs=False network: one output_linear head tile after the hidden layers, no view direction columns
     const unsigned* wscale; // compensated float16 mode: row-scale words, 32 per output tile in bias order (pack.h StreamBuilderC), else null
     // fused render step of the compensated float16 kernel (nerf_mlp_c_kernel.h, FUSE): z stratification in the prologue (renderer.py:163-178),
     // raw2outputs in the epilogue (nerf.py:74-129); z / raw / weights are written only where a pointer is given

@@ -102,8 +102,12 @@ class NeRF:
 
     def __init__(self, state_dict, prefix="", D=8, W=256, multires=10, multires_views=4, skips=(4,),
                  rgb_activate="sigmoid", sigma_activate="relu", render_rmnearplane=0,
-                 extract_feature="after_linear", composite_feature=True, precision="f16x3"):
+                 extract_feature="after_linear", composite_feature=True, precision="f16x3", use_viewdirs=True):
+        """use_viewdirs=False (nerf.py:41-44,158-160): `output_linear` [output_ch, W] replaces the view branch; the ray batch then has
+        8 columns (renderer.py:443-446).  Inference only, every mode but f16c.  As in the reference, such a network has no
+        "after_linear" feature (nerf.py:159 asserts)."""
         self.D, self.W = D, W
+        self.use_viewdirs = bool(use_viewdirs)
         self.multires, self.multires_views = multires, multires_views
         self.rgb_activate, self.sigma_activate = rgb_activate, sigma_activate
         self.render_rmnearplane = render_rmnearplane
@@ -123,12 +127,19 @@ class NeRF:
                 raise L.EvdError(f"state dict lacks {prefix}pts_linears.{i}")
             keep += [w, b]
             d.pts_w[i], d.pts_b[i] = fp(w), fp(b)
-        for name, key in (("views", "views_linears.0"), ("feature", "feature_linear"), ("alpha", "alpha_linear"),
-                          ("rgb", "rgb_linear")):
-            w, b = g(key + ".weight"), g(key + ".bias")
+        if self.use_viewdirs:
+            for name, key in (("views", "views_linears.0"), ("feature", "feature_linear"), ("alpha", "alpha_linear"),
+                              ("rgb", "rgb_linear")):
+                w, b = g(key + ".weight"), g(key + ".bias")
+                keep += [w, b]
+                setattr(d, name + "_w", fp(w))
+                setattr(d, name + "_b", fp(b))
+        else:
+            w, b = g("output_linear.weight"), g("output_linear.bias")
+            if w is None or b is None:
+                raise L.EvdError(f"state dict lacks {prefix}output_linear (use_viewdirs=False)")
             keep += [w, b]
-            setattr(d, name + "_w", fp(w))
-            setattr(d, name + "_b", fp(b))
+            d.output_w, d.output_b, d.output_ch = fp(w), fp(b), int(w.shape[0])
         h = C.c_void_p()
         L.check(L.lib().evd_nerf_create(C.byref(d), C.byref(h)), "evd_nerf_create")
         self._h = h
@@ -154,8 +165,11 @@ class NeRF:
     def mlpforward(self, ray_batch, z_vals, want_feature=False, precision=None):
         rb = ray_batch.contiguous().float()
         z = z_vals.contiguous().float()
-        if rb.shape[1] != 11:
-            raise L.EvdError("mlpforward needs the 11-column ray batch (use_viewdirs=True)")
+        ncol = 11 if self.use_viewdirs else 8
+        if rb.shape[1] != ncol:
+            raise L.EvdError(f"mlpforward needs the {ncol}-column ray batch (use_viewdirs={self.use_viewdirs})")
+        if want_feature and not self.use_viewdirs and self.extract_feature == "after_linear":
+            raise L.EvdError('a use_viewdirs=False network has no "after_linear" feature (nerf.py:159)')
         R, S = z.shape
         raw = torch.empty((R, S, 4), dtype=torch.float32, device=z.device)
         feat = torch.empty((R, S, self.W), dtype=torch.float32, device=z.device) if want_feature else None
@@ -167,6 +181,8 @@ class NeRF:
     # Training forward: the same raw plus the activation store evd_nerf_mlp_backward consumes (f16 / bf16, or f16x3 = the float32-grade
     # mode with (hi, lo) fragments; 8 x 256 network)
     def mlpforward_train(self, ray_batch, z_vals, precision=None):
+        if not self.use_viewdirs:
+            raise L.EvdError("the training path is not built for use_viewdirs=False networks")
         rb = ray_batch.contiguous().float()
         z = z_vals.contiguous().float()
         R, S = z.shape

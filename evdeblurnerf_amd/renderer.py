@@ -182,11 +182,12 @@ class NeRFAll:
         self.precision = precision
         self.training = False
         self.device = torch.device(device or "cuda")
-        if not args.use_viewdirs:
-            raise NotImplementedError("use_viewdirs=False networks are not supported (no shipped config uses them)")
+        self.use_viewdirs = bool(args.use_viewdirs)
+        if not self.use_viewdirs and self.mode != "nerf":
+            raise NotImplementedError("use_viewdirs=False is built for mode='nerf' (the PDRF levels always take view directions, voxnerf.py:248)")
         self.mlp_fine = None
         if self.mode == "nerf":
-            common = dict(D=args.netdepth, W=args.netwidth, multires=args.multires, multires_views=args.multires_views,
+            common = dict(use_viewdirs=self.use_viewdirs, D=args.netdepth, W=args.netwidth, multires=args.multires, multires_views=args.multires_views,
                           rgb_activate=args.rgb_activate, sigma_activate=args.sigma_activate,
                           render_rmnearplane=_args_get(args, "render_rmnearplane", 0),
                           extract_feature=self.extract_feature, composite_feature=False, precision=precision)
@@ -247,7 +248,7 @@ class NeRFAll:
     def _cfg(self, H, W, focal, ndc, near, far, N_samples, N_importance, lindisp, perturb, white_bkgd):
         c = L.RenderCfg()
         c.H, c.W, c.focal = int(H), int(W), float(focal)
-        c.ndc, c.use_viewdirs, c.lindisp = int(bool(ndc)), 1, int(bool(lindisp))
+        c.ndc, c.use_viewdirs, c.lindisp = int(bool(ndc)), int(getattr(self, "use_viewdirs", True)), int(bool(lindisp))
         c.N_samples, c.N_importance, c.white_bkgd = int(N_samples), int(N_importance), int(bool(white_bkgd))
         c.near, c.far, c.perturb = float(near), float(far), float(perturb)
         c.is_train, c.precision = int(self.training), L.PREC[self.precision]
@@ -271,8 +272,8 @@ class NeRFAll:
         if _rays is None:
             rb = ray_batch.contiguous().float()
             R = rb.shape[0]
-            if rb.shape[1] != 11:
-                raise L.EvdError("render_rays needs the 11-column ray batch (o, d, near, far, viewdirs)")
+            if rb.shape[1] != (11 if self.use_viewdirs else 8):
+                raise L.EvdError("render_rays needs the 11-column ray batch (o, d, near, far, viewdirs); 8 columns with use_viewdirs=False")
         else:
             rb, R = None, _rays.shape[0]
         cfg = _cfg or self._cfg(0, 0, 1.0, False, 0., 1., N_samples, N_importance, lindisp, perturb, white_bkgd)
@@ -529,10 +530,11 @@ class NeRFAll:
                c2w_staticcam=None, **kwargs):
         """renderer.py:399-466.  `rays` [..., 3, 2]; as in the reference, `c2w` is not read when rays are given (render_path passes
         both, :614) -- without rays the full H x W image of `c2w` is generated on the device (evd_get_rays).  `c2w_staticcam`
-        (:427-430): origins / directions of that camera, view directions of the given rays.  use_viewdirs=False (the 8-column
-        batch of :443-446) is rejected: the library's networks are built with the view branch, like every shipped config."""
-        if not use_viewdirs:
-            raise NotImplementedError("use_viewdirs=False (8-column ray batch) is not supported: networks are built with view directions")
+        (:427-430): origins / directions of that camera, view directions of the given rays.  use_viewdirs must match the model
+        (args.use_viewdirs): False packs the 8-column batch of :443-446 for networks with the output_linear head (mode='nerf' only)."""
+        if bool(use_viewdirs) != self.use_viewdirs:
+            raise L.EvdError(f"render(use_viewdirs={use_viewdirs}) on a model built with use_viewdirs={self.use_viewdirs} (renderer.py:443-446: "
+                             "the ray batch has 11 columns with view directions, 8 without)")
         focal = float(K[0][0])
         if rays is None:
             if c2w is None:
@@ -547,7 +549,7 @@ class NeRFAll:
         cfg = self._cfg(H, W, focal, ndc, near, far, N_samples, kwargs.get("N_importance", 0), kwargs.get("lindisp", False),
                         kwargs.get("perturb", 0.), kwargs.get("white_bkgd", False))
         batch = None
-        if c2w_staticcam is not None:
+        if c2w_staticcam is not None and self.use_viewdirs:          # (read inside `if use_viewdirs` only, renderer.py:424-430)
             so, sd_ = get_rays(H, W, K, torch.as_tensor(c2w_staticcam, device=self.device))
             cam = torch.stack([so, sd_], dim=-1).reshape(-1, 3, 2).contiguous().float()
             if cam.shape[0] != R:

@@ -62,6 +62,9 @@ def make_nerf_state_dict(seed: int, D: int = 8, W: int = 256, input_ch: int = 63
         _linear(rs, sd, "rgb_linear", W // 2, 3, bias=rgb_add_bias)
     else:
         _linear(rs, sd, "output_linear", W, output_ch)
+        b = sd["output_linear.bias"].copy()
+        b[3] += np.float32(sigma_bias_shift)                       # channel 3 is the density (nerf.py:89,99)
+        sd["output_linear.bias"] = b.astype(np.float32)
     return sd
 
 

@@ -117,6 +117,13 @@ typedef struct {                    /* host float32 pointers, nn.Linear layout [
     float rmnear;                   /* render_rmnearplane */
     const float *pts_w[EVD_MAX_LAYERS], *pts_b[EVD_MAX_LAYERS];
     const float *views_w, *views_b, *feature_w, *feature_b, *alpha_w, *alpha_b, *rgb_w, *rgb_b; /* rgb_b may be NULL */
+    /* use_viewdirs=False networks (networks/nerf.py:41-44,158-160): views_w .. rgb_w NULL and output_linear given instead,
+     * output_w [output_ch, W], output_b [output_ch], output_ch 4 or 5 (renderer.py:46: 5 with importance sampling; raw2outputs reads
+     * channels 0..3 only).  Their ray batch has 8 columns (renderer.py:443-446).  Inference on the generic kernel (every mode but
+     * EVD_PREC_F16C); no training entries.  In the reference this network only runs with extract_feature "before_linear" (kernel_use_awp):
+     * nerf.py:159 asserts otherwise. */
+    const float *output_w, *output_b;
+    int output_ch;
 } evd_nerf_desc;
 
 int evd_nerf_create(const evd_nerf_desc* desc, evd_nerf** out);
@@ -133,7 +140,7 @@ int evd_nerf_load_params(evd_nerf* net, const float* params, void* stream);
 size_t evd_nerf_stream_bytes(const evd_nerf* net, int precision);
 
 /* NeRF.mlpforward + NeRF.eval, networks/nerf.py:46-72,131-162, fused with the point computation
- * pts = o + d z (renderer.py:180) and both positional encodings.  ray_batch dev [R,11], z dev [R,S]
+ * pts = o + d z (renderer.py:180) and both positional encodings.  ray_batch dev [R,11] ([R,8] for a use_viewdirs=False network), z dev [R,S]
  * -> raw dev [R,S,4] = (rgb, alpha);  feature dev [R,S,W] optional: feature_kind 1 = "after_linear"
  * (nerf.py:149-150), 2 = "before_linear" (:141-142). */
 int evd_nerf_mlp(const evd_nerf* net, int precision, const float* ray_batch, const float* z, long R, int S,

@@ -172,7 +172,13 @@ void evo_nerf_mlp(const evo_nerf* net, const float* emb, long n, float* raw, flo
                     r4[0] = rgb[s * 3]; r4[1] = rgb[s * 3 + 1]; r4[2] = rgb[s * 3 + 2]; r4[3] = alpha[s];
                 }
             } else {
-                linear_blk(wo, net->output_b, W, net->output_ch, h, hs, raw + s0 * net->output_ch, net->output_ch, nb);
+                /* outputs = output_linear(h), nerf.py:158-160; output_ch is 5 with importance sampling (renderer.py:46) and raw2outputs
+                 * reads channels 0..2 (rgb) and 3 (sigma) only (nerf.py:89,99): raw keeps those four */
+                float ob[EVO_NB * 8];
+                const int oc = net->output_ch;
+                linear_blk(wo, net->output_b, W, oc, h, hs, ob, oc, nb);
+                for (int s = 0; s < nb; ++s)
+                    for (int c = 0; c < 4; ++c) raw[(s0 + s) * 4 + c] = c < oc ? ob[s * oc + c] : 0.f;
             }
         }
         free(h); free(h2);
@@ -425,7 +431,10 @@ static void nerf_pass(const evo_nerf* net, const evo_render_cfg* cfg, const floa
         }
         free(pe); free(pev);
     }
-    evo_nerf_mlp(net, emb, n, raw, feat_out, NULL);
+    /* per-sample feature: feature_linear's output with the view branch (nerf.py:149-150); a use_viewdirs=False network only has the
+     * "before_linear" one, the last hidden activations (nerf.py:141-142, 159) */
+    if (net->use_viewdirs) evo_nerf_mlp(net, emb, n, raw, feat_out, NULL);
+    else evo_nerf_mlp(net, emb, n, raw, NULL, feat_out);
     const float thr = (!cfg->is_train && net->rmnear > 0.f) ? (float)((double)net->rmnear / 128.0) : 0.f;
     evo_composite(raw, z, rd, R, S, 4, 3, 0, 3, net->rgb_act, net->sigma_act, cfg->white_bkgd, thr, NULL,
                   rgb, NULL, acc, weights, depth, NULL, 0, NULL);

@@ -242,6 +242,49 @@ def test_render_matches_reference_golden(prec, tol, O):
             assert maxabs(N(ex["weights"]), g[f"{tag}_weights"]) < tol
 
 
+@pytest.mark.parametrize("prec,tol", [("f32", 1e-4), ("f16x3", 1e-4), ("f16", 1e-4), ("bf16", 3e-2)])
+def test_render_without_viewdirs_matches_reference_golden(prec, tol):
+    """use_viewdirs=False (VERDICT r2 missing 3): 8-column ray batch (renderer.py:443-446), output_linear head (nerf.py:158-160; 5 output
+    channels with importance sampling, renderer.py:46), the "before_linear" per-sample feature -- against golden G23 from the reference's
+    NeRFAll; and what this network is not built for is rejected."""
+    from types import SimpleNamespace
+    from evdeblurnerf_amd import _lib as L
+    from evdeblurnerf_amd.renderer import NeRFAll
+    g = load_golden("G23_render_nerf_no_viewdirs")
+    K = W.synthetic_camera()
+    for tag, Ni, S, R, ndc in (("a", 32, 48, 72, True), ("b", 0, 128, 40, False)):
+        och = 5 if Ni > 0 else 4
+        sd = dict(W.prefixed(W.make_nerf_state_dict(61, input_ch_views=0, use_viewdirs=False, output_ch=och), "mlp_coarse"))
+        if Ni > 0:
+            sd.update(W.prefixed(W.make_nerf_state_dict(62, input_ch_views=0, use_viewdirs=False, output_ch=och), "mlp_fine"))
+        args = SimpleNamespace(mode="nerf", netdepth=8, netwidth=256, multires=10, multires_views=4, use_viewdirs=False,
+                               rgb_activate="sigmoid", sigma_activate="relu", N_importance=Ni, kernel_use_awp=True)
+        model = NeRFAll(args, sd, awpnet=object(), precision=prec).eval()
+        assert model.extract_feature == "before_linear"
+        rays = T(W.synthetic_rays(23 + Ni, R))
+        kw = dict(ndc=ndc, near=0. if ndc else 0.5, far=1. if ndc else 3.5, use_viewdirs=False, N_samples=S, N_importance=Ni, retraw=True,
+                  perturb=0., raw_noise_std=0.)
+        rgb, depth, acc, ex = model.render(400, 400, K, rays=rays, inference=True, **kw)
+        e = maxabs(N(rgb), g[f"{tag}_rgb"])
+        print(f"[{prec} no viewdirs, case {tag}] RGB L-inf vs reference = {e:.3e}")
+        assert e < tol and maxabs(N(acc), g[f"{tag}_acc"]) < tol and maxabs(N(depth), g[f"{tag}_depth"]) < 3 * tol
+        assert maxabs(N(ex["rays_d"]), g[f"{tag}_rays_d"]) < 1e-5
+        if Ni > 0:
+            assert maxabs(N(ex["rgb0"]), g[f"{tag}_rgb0"]) < tol and maxabs(N(ex["z_vals0"]), g[f"{tag}_z_vals0"]) < 1e-6
+        else:
+            assert maxabs(N(ex["z_vals"]), g[f"{tag}_z_vals"]) < 1e-6 and maxabs(N(ex["weights"]), g[f"{tag}_weights"]) < tol
+        if prec in ("f32", "f16x3"):
+            feat = model.render(400, 400, K, rays=rays[:2], inference=False, **kw)[3]["depth_feature"]
+            assert maxabs(N(feat), g[f"{tag}_depth_feature2"]) < 2e-4
+        with pytest.raises(L.EvdError):
+            model.render(400, 400, K, rays=rays, use_viewdirs=True, N_samples=S, N_importance=Ni)
+    if prec == "f32":
+        with pytest.raises(L.EvdError):                  # no compensated-float16 stream, no training path for this network
+            NeRFAll(args, sd, awpnet=object(), precision="f16c").eval().render(400, 400, K, rays=rays, **kw)
+        with pytest.raises(L.EvdError):
+            model.mlp_coarse.mlpforward_train(torch.zeros((4, 8), device=DEV), torch.zeros((4, 16), device=DEV))
+
+
 def test_render_config1_white_bkgd_lindisp_no_ndc(O):
     """BASELINE config 1 shape (single pass, 64 samples) with the non-default switches, vs golden G7c."""
     from types import SimpleNamespace
@@ -574,7 +617,8 @@ def test_full_frame_eval_path_psnr_parity(O):
             rb[:, 8:11] = vd / vd.norm(dim=-1, keepdim=True)
             want = model.render_rays(rb, 24, N_importance=40)["rgb_map"].reshape(Hh, Ww, 3)
             assert maxabs(N(sc), N(want)) < 2e-5
-            with pytest.raises(NotImplementedError):
+            from evdeblurnerf_amd import _lib as L_
+            with pytest.raises(L_.EvdError):                     # a model built with the view branch takes the 11-column batch only
                 model.render(Hh, Ww, K, rays=r1, use_viewdirs=False, N_samples=24)
 
 

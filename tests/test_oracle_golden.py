@@ -115,6 +115,27 @@ def test_G7_render_nerf():
     _check_render(res, g, "d_", keys_h, 2e-5)
 
 
+def test_G23_render_nerf_without_viewdirs():
+    """use_viewdirs=False (renderer.py:443-446: 8-column ray batch; nerf.py:41-44,158-160: output_linear head, output_ch 5 with importance
+    sampling) vs the golden the reference's NeRFAll produced; the per-sample feature is the "before_linear" one."""
+    g = load_golden("G23_render_nerf_no_viewdirs")
+    mk = lambda seed, och: O.Nerf(W.make_nerf_state_dict(seed, input_ch_views=0, use_viewdirs=False, output_ch=och), input_ch_views=0,
+                                  use_viewdirs=False, output_ch=och)
+    keys_h = dict(rgb="rgb", depth="depth", acc="acc", z_vals="z_vals", weights="weights", rgb0="rgb0",
+                  depth0="depth0", acc0="acc0", z_std="z_std", z_vals0="z_vals0", weights0="weights0")
+    rays = W.synthetic_rays(23 + 32, 72)
+    cfg = O.make_cfg(N_samples=48, N_importance=32, use_viewdirs=False)
+    res = O.render_nerf(mk(61, 5), mk(62, 5), cfg, rays)
+    _check_render(res, g, "a_", keys_h, 2e-5)
+    feat = O.render_nerf(mk(61, 5), mk(62, 5), cfg, rays[:2], want_feature=True)["feature"]
+    assert maxabs(feat, g["a_depth_feature2"]) < 2e-5
+    rays = W.synthetic_rays(23, 40)
+    cfg = O.make_cfg(N_samples=128, use_viewdirs=False, ndc=False, near=0.5, far=3.5)
+    res = O.render_nerf(mk(61, 4), None, cfg, rays)
+    _check_render(res, g, "b_", dict(rgb="rgb", depth="depth", acc="acc", z_vals="z_vals", weights="weights"), 2e-5)
+    assert maxabs(O.render_nerf(mk(61, 4), None, cfg, rays[:2], want_feature=True)["feature"], g["b_depth_feature2"]) < 2e-5
+
+
 AABB = [-1.5, -1.5, -1.0, 1.5, 1.5, 1.0]
 
 

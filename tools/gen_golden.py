@@ -293,6 +293,38 @@ def G7_render_nerf():
     save("G7_render_nerf", **out)
 
 
+def G23_render_nerf_no_viewdirs():
+    """mode='nerf' with use_viewdirs=False (renderer.py:443-446: 8-column ray batch; nerf.py:41-44,158-160: output_linear head).  In the
+    reference this network only runs with extract_feature "before_linear" (nerf.py:159 asserts otherwise), i.e. with kernel_use_awp and
+    an awpnet object; output_ch is 5 with importance sampling (renderer.py:46) and raw2outputs reads channels 0..3."""
+    from networks.renderer import NeRFAll
+    import contextlib
+    import io
+    K = W.synthetic_camera()
+    out = {}
+    for tag, Ni, S, R, ndc in (("a", 32, 48, 72, True), ("b", 0, 128, 40, False)):
+        args = ref_import.blurfactory_args(mode="nerf", N_importance=Ni, use_viewdirs=False, kernel_use_awp=True, rgb_add_bias=True)
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = NeRFAll(args, awpnet=object())
+        assert model.extract_feature == "before_linear" and model.output_ch == (5 if Ni > 0 else 4)
+        och = model.output_ch
+        sd = dict(W.prefixed(W.make_nerf_state_dict(61, input_ch_views=0, use_viewdirs=False, output_ch=och), "mlp_coarse"))
+        if Ni > 0:
+            sd.update(W.prefixed(W.make_nerf_state_dict(62, input_ch_views=0, use_viewdirs=False, output_ch=och), "mlp_fine"))
+        ref_import.load_np_state_dict(model, sd)
+        model.train(False)
+        rays = W.synthetic_rays(23 + Ni, R)
+        kw = dict(ndc=ndc, near=0. if ndc else 0.5, far=1. if ndc else 3.5, use_viewdirs=False, N_samples=S, N_importance=Ni, retraw=True,
+                  perturb=0., raw_noise_std=0., inference=True)
+        rgb, depth, acc, ex = model.render(400, 400, t(K), 1 << 20, rays=t(rays), **kw)
+        out.update({f"{tag}_rgb": n(rgb), f"{tag}_depth": n(depth), f"{tag}_acc": n(acc)},
+                   **{f"{tag}_{k}": n(v) for k, v in ex.items() if isinstance(v, torch.Tensor)})
+        kw["inference"] = False                 # with the per-sample "before_linear" feature AWP consumes (renderer.py:253-256)
+        _, _, _, ex = model.render(400, 400, t(K), 1 << 20, rays=t(rays[:2]), **kw)
+        out[f"{tag}_depth_feature2"] = n(ex["depth_feature"])
+    save("G23_render_nerf_no_viewdirs", **out)
+
+
 PDRF_SMALL = dict(coarse_n_voxels=24 ** 3, fine_n_voxels=48 ** 3)
 
 
@@ -817,7 +849,7 @@ def G22_mam():
 ALL = [G1_embedder, G2_nerf_mlp, G3_nerf_raw2outputs, G4_voxel_raw2outputs, G5_sample_pdf, G6_rays,
        G7_render_nerf, G8_appfeature, G9_render_c2f, G10_rbk_weighted_sum, G11_crf, G12_egm_loss, G13_edi,
        G14_loss_assembly, G15_awp_feature_integration, G16_rbk_warp, G17_compute_successor, G18_nerf_grads, G19_c2f_grads, G20_loss_grads,
-       G21_awp_sample_embed, G22_mam]
+       G21_awp_sample_embed, G22_mam, G23_render_nerf_no_viewdirs]
 
 if __name__ == "__main__":
     want = set(sys.argv[1:])
