@@ -347,7 +347,17 @@ static int voxel_pass(const evd_voxel* v, int precision, const float* pts, const
         p.wscale = (const unsigned*)v->pipe_c.scales.p;
         p.nchunks = v->pipe_c_chunks;
     }
-    int rc = comp ? launch_voxel_pipe_f16c(p, as_stream(stream)) : piped ? (precision == EVD_PREC_BF16 ? launch_voxel_pipe_bf16(feature != nullptr, p, as_stream(stream))
+    // the 64-wide coarse level on the software pipeline (its training forward's stream and layer table), where that is built
+    const bool coarse_pipe = !comp && !piped && !no_pipe && !feature && v->hidden_dim == 64 && v->geo == 15 && v->ft_dim == 32 &&
+                             is_train_prec(precision) && v->train_chunks[precision] > 0;
+    if (coarse_pipe) {
+        p.wstream = (const char*)v->train[precision].data.p;
+        p.nchunks = v->train_chunks[precision];
+    }
+    int rc = comp ? launch_voxel_pipe_f16c(p, as_stream(stream))
+             : coarse_pipe ? (precision == EVD_PREC_BF16 ? launch_voxel_coarse_pipe_bf16(p, as_stream(stream))
+                              : precision == EVD_PREC_F16 ? launch_voxel_coarse_pipe_f16(p, as_stream(stream)) : launch_voxel_coarse_pipe_f16x3(p, as_stream(stream)))
+             : piped ? (precision == EVD_PREC_BF16 ? launch_voxel_pipe_bf16(feature != nullptr, p, as_stream(stream))
                       : precision == EVD_PREC_F16 ? launch_voxel_pipe_f16(feature != nullptr, p, as_stream(stream))
                                                   : launch_voxel_pipe_f16x3(feature != nullptr, p, as_stream(stream)))
                    : voxel_mlp_dispatch(precision, v->hidden_dim, v->geo, v->ft_dim, p, as_stream(stream));

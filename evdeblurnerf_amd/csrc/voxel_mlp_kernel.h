@@ -196,6 +196,29 @@ static int launch_voxel_train_fwd(const VoxMlpParams& p, hipStream_t st) {
     return EVD_OK;
 }
 
+// inference on the software pipeline for ANY level, on the stream the level's training forward uses (same layer table, no activation store):
+// the 64-wide coarse level's render pass (the generic kernel took 86 us per 4096 x 64 samples in f16x3 -- 11 % of a c2f render in the
+// compensated mode, whose coarse level runs float32-grade)
+template <int PREC, int HD, int G, int FT>
+static int launch_voxel_pipe_level(const VoxMlpParams& p, hipStream_t st) {
+    // (split-float16: one wavefront per SIMD as in the fine level -- with 512 threads the ring + stash of PipeCfg exceed the 160 KiB of LDS;
+    // measured 86 us per 4096 x 64 samples either way, the same as the generic kernel: the 64-wide level is prologue-bound, not MFMA-bound)
+    constexpr int NT = is_half_prec(PREC) ? 512 : 256, OCC = is_half_prec(PREC) ? 2 : 1;
+    typedef PipeCfg<PREC, 1, NT> C;
+    typedef VoxNet<C, HD, G, FT, false, false> N;
+    const long blocks = cdiv(p.nsamp, C::SAMPLES);
+    const size_t lds = C::TOTAL;
+    EVD_SET_MAX_LDS((&k_voxel_mlp_pipe<PREC, HD, G, FT, 1, NT, false, PIPE_CB, OCC, false>), lds);
+    if (p.nchunks != N::NCH) return fail(EVD_E_INVALID, "evd_voxel: packed stream has %d chunks, kernel expects %d", p.nchunks, N::NCH);
+    if (p.feature || p.act) return fail(EVD_E_INVALID, "evd_voxel: the level's pipelined inference pass writes raw only");
+    hipLaunchKernelGGL((k_voxel_mlp_pipe<PREC, HD, G, FT, 1, NT, false, PIPE_CB, OCC, false>), dim3((unsigned)blocks), dim3(NT), lds, st, p);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+int launch_voxel_coarse_pipe_bf16(const VoxMlpParams& p, hipStream_t st);
+int launch_voxel_coarse_pipe_f16(const VoxMlpParams& p, hipStream_t st);
+int launch_voxel_coarse_pipe_f16x3(const VoxMlpParams& p, hipStream_t st);
+
 constexpr bool voxel_pipe_built(int prec, int HD, int G, int FT) {
     return (prec == EVD_PREC_BF16 || prec == EVD_PREC_F16 || prec == EVD_PREC_F16X3) && HD == 256 && G == 128 && FT == 64;
 }

@@ -416,12 +416,17 @@ def test_fused_awp_per_ray_tail_as_a_captured_graph():
             grads.append({n_: (p.grad.detach().clone() if p.grad is not None else None) for n_, p in m.named_parameters()})
             grads[-1]["d depth_feature"] = df_.grad.detach().clone()
             opt.step()
+        ref2.load_state_dict(ref.state_dict())      # (in place: the captured graph keeps reading these tensors) both sides start every step equal --
+        # left alone, the two float16 embeddings' rounding-level differences grow through the ReLU flips of later steps
         assert graphed._graphed, "the graph was not built"
         assert float((outs[0] - outs[1]).abs().max()) < 1e-5, step
         for n_ in grads[0]:
             a, b = grads[0][n_], grads[1][n_]
             if a is None or b is None:
                 assert (a is None or float(a.abs().max()) == 0.0) and (b is None or float(b.abs().max()) == 0.0), n_
+                continue
+            if n_ == "MAM.linear.bias":      # analytically zero (a constant added to every curve is removed by the training-mode BatchNorm): rounding noise
+                assert float(a.abs().max()) < 1e-4 and float(b.abs().max()) < 1e-4
                 continue
             # (two models, each with float16 fragments + float atomics in its own embedding: rounding-level differences)
             assert float((a - b).abs().max()) <= 2e-3 * (float(a.abs().max()) + 1e-6), (step, n_, float((a - b).abs().max()), float(a.abs().max()))
