@@ -944,7 +944,9 @@ struct VbwTaps {
     float fw, fn, kx, ky, kl;                   // fractional position in the plane cell; d (pixel coordinate) / d (point coordinate)
     int pad;
 };
-constexpr size_t VBW_SLICE = VBW_SAMPLES * 3 * sizeof(VbwTaps) + (size_t)VBW_SAMPLES * VBW_CSTR * 4 + (size_t)VBW_SAMPLES * VBW_MAXG * 3 * 4;
+constexpr int VBW_LROW = 33;                    // line rows of components 1 and 2 kept in LDS ([16][33]: n_comp[1] + n_comp[2] <= 32)
+constexpr size_t VBW_SLICE = VBW_SAMPLES * 3 * sizeof(VbwTaps) + (size_t)VBW_SAMPLES * VBW_CSTR * 4 + (size_t)VBW_SAMPLES * VBW_MAXG * 3 * 4 +
+                             (size_t)VBW_SAMPLES * (VBW_LROW + 3) * 4;
 constexpr size_t VBW_LDS = (size_t)32 * VBW_BSTR * 4 + VBW_WAVES * VBW_SLICE;
 static_assert(sizeof(VbwTaps) % 8 == 0 && VBW_SLICE % 16 == 0, "slice alignment");
 
@@ -987,7 +989,9 @@ __device__ __forceinline__ void vbw_geometry(const GridParams& g, const float (&
     tp.pad = 0;
 }
 
-template <bool DPTS>
+// LINES12: the line taps of components 1 and 2 (the x / y lines of an NDC scene: one cell for a whole run of samples) are summed along
+// runs and added here, like the plane taps; only component 0's line (the z line, a new cell every sample) leaves as rows for k_scatter_lines
+template <bool DPTS, bool LINES12>
 __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const GridParams g, const float* __restrict__ pts, long n,
                                                                           const float* __restrict__ d_out, int d_stride, int d_col, GridGrads gg,
                                                                           float* __restrict__ d_pts, float* __restrict__ rows_l, LTap* __restrict__ ltap,
@@ -1000,6 +1004,7 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
     VbwTaps* taps = reinterpret_cast<VbwTaps*>(slice);
     float* dco = reinterpret_cast<float*>(slice + VBW_SAMPLES * 3 * sizeof(VbwTaps));   // d coef [16][VBW_CSTR], later the plane rows d coef lv
     float* dpart = dco + VBW_SAMPLES * VBW_CSTR;                                     // [16][ng][3]
+    float* lrow = dpart + VBW_SAMPLES * VBW_MAXG * 3;                                // [16][VBW_LROW] line rows d coef pv of components 1, 2
     const long s0 = ((long)blockIdx.x * VBW_WAVES + wv) * VBW_SAMPLES;
     const int ng = ctot / 8;
     for (int o = threadIdx.x; o < 32 * (ctot / 4); o += 64 * VBW_WAVES) {            // basis_mat -> LDS (the block's only shared state)
@@ -1024,7 +1029,7 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
         VbwTaps tp;
         vbw_geometry(g, pt, i, live, tp);
         taps[lane] = tp;
-        if (live && ltap) {
+        if (live && ltap && !(LINES12 && i > 0)) {
             const int C = sel3(i, c0n, c1n, c2n);
             LTap lt_;
             lt_.c0 = tp.il[0] / C; lt_.c1 = tp.il[1] / C; lt_.w0 = tp.wl[0]; lt_.w1 = tp.wl[1];
@@ -1099,10 +1104,15 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
                     cf[k] = pv[k] * lv[k];
                     rp[k] = dc[k] * lv[k];
                 }
-                if (live) {
-                    if (rows_l) *reinterpret_cast<f32x4*>(rows_l + (s0 + sl[q]) * ctot + cb + 4 * v) = rl;
-                    if (coef_out) *reinterpret_cast<f32x4*>(coef_out + (s0 + sl[q]) * ctot + cb + 4 * v) = cf;
+                if (LINES12 && comp[q] > 0) {
+                    if (on[q]) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) lrow[sl[q] * VBW_LROW + cb - c0n + 4 * v + k] = rl[k];
+                    }
+                } else if (live && rows_l) {
+                    *reinterpret_cast<f32x4*>(rows_l + (s0 + sl[q]) * ctot + cb + 4 * v) = rl;
                 }
+                if (live && coef_out) *reinterpret_cast<f32x4*>(coef_out + (s0 + sl[q]) * ctot + cb + 4 * v) = cf;
                 if (on[q]) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) drow[4 * v + k] = rp[k];
@@ -1136,37 +1146,55 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
         const int C = sel3(i, c0n, c1n, c2n);
         float* gp = sel3(i, gg.plane[0], gg.plane[1], gg.plane[2]);
         if (gp) {
-            if (C == 64) {                        // lanes = channels; the sum of a run of samples on one cell stays in a register
+            // lanes = (tap, channel): 64 / C taps of the component per pass (one for the 64-channel x-y plane, all four for a 16-channel
+            // plane).  Every lane walks the tile's 16 samples with the sum of a RUN of samples on one cell in a register and adds it once
+            // per run: the x-y cell of an NDC ray changes every ~10 samples, and where the importance samples cluster at a surface the
+            // x-z / y-z cells repeat as well
+            const int tpp = 64 / C < 4 ? 64 / C : 4, j = lane / C, c = lane % C;
 #pragma unroll 1
-                for (int t = 0; t < 4; ++t) {
-                    float acc = 0.f;
-                    bool any = false;
+            for (int t0 = 0; t0 < 4; t0 += tpp) {
+                const int t = t0 + (j < tpp ? j : 0);
+                float acc = 0.f;
+                bool any = false;
 #pragma unroll 4
-                    for (int s = 0; s < VBW_SAMPLES; ++s) {
-                        const VbwTaps& tp = taps[s * 3 + i];
-                        const float w = tp.wp[t];
-                        const int cell = tp.ip[t];
-                        if (w != 0.f) { acc += w * dco[s * VBW_CSTR + coff + lane]; any = true; }
-                        const bool flush = s == VBW_SAMPLES - 1 || taps[(s + 1) * 3 + i].ip[t] != cell;
-                        if (flush) {
-                            if (any) unsafeAtomicAdd(gp + cell + lane, acc);
-                            acc = 0.f;
-                            any = false;
-                        }
-                    }
-                }
-            } else {                              // C = 8, 16 or 32: 64 / C (sample, tap) pairs per instruction
-                const int ppi = 64 / C, j = lane / C, c = lane % C;
-#pragma unroll 4
-                for (int p0 = 0; p0 < VBW_SAMPLES * 4; p0 += ppi) {
-                    const int p = p0 + j, s = p >> 2, t = p & 3;
+                for (int s = 0; s < VBW_SAMPLES; ++s) {
                     const VbwTaps& tp = taps[s * 3 + i];
                     const float w = tp.wp[t];
-                    if (w != 0.f) unsafeAtomicAdd(gp + tp.ip[t] + c, w * dco[s * VBW_CSTR + coff + c]);
+                    const int cell = tp.ip[t];
+                    if (w != 0.f) { acc += w * dco[s * VBW_CSTR + coff + c]; any = true; }
+                    const bool flush = s == VBW_SAMPLES - 1 || taps[(s + 1) * 3 + i].ip[t] != cell;
+                    if (flush) {
+                        if (any && j < tpp) unsafeAtomicAdd(gp + cell + c, acc);
+                        acc = 0.f;
+                        any = false;
+                    }
                 }
             }
         }
         coff += C;
+    }
+    if (LINES12) {
+        // line taps of components 1 and 2: lanes = (tap, channel of comp 1 | comp 2), 2 x (n_comp[1] + n_comp[2]) <= 64 lanes, one walk
+        const int c12 = c1n + c2n, tq = lane / c12, cc = lane % c12;
+        if (lane < 2 * c12) {
+            const int i = cc < c1n ? 1 : 2, c = cc < c1n ? cc : cc - c1n;
+            float* gl = i == 1 ? gg.line[1] : gg.line[2];
+            float acc = 0.f;
+            bool any = false;
+#pragma unroll 4
+            for (int s = 0; s < VBW_SAMPLES; ++s) {
+                const VbwTaps& tp = taps[s * 3 + i];
+                const float w = tp.wl[tq];
+                const int cell = tp.il[tq];
+                if (w != 0.f) { acc += w * lrow[s * VBW_LROW + cc]; any = true; }
+                const bool flush = s == VBW_SAMPLES - 1 || taps[(s + 1) * 3 + i].il[tq] != cell;
+                if (flush) {
+                    if (any && gl) unsafeAtomicAdd(gl + cell + c, acc);
+                    acc = 0.f;
+                    any = false;
+                }
+            }
+        }
     }
     // phase 4: the point gradient of (sample, axis): component i feeds the axes (ax, ay | al) = (0, 1 | 2), (0, 2 | 1), (1, 2 | 0)
     if (DPTS && lane < VBW_SAMPLES * 3) {
@@ -1550,17 +1578,26 @@ bool voxel_sample_bwd_w_ok(const GridParams& g) {
     return g.app_dim >= 4 && g.app_dim <= 32 && g.app_dim % 4 == 0 && ct % 16 == 0 && ct <= 96 && okc(g.n_comp[0]) && okc(g.n_comp[1]) && okc(g.n_comp[2]) &&
            pm2 * 64 < (1L << 31) && g.app_act == EVD_ACT_NONE;
 }
+// OPT-IN (EVD_SCATTER_LINES_INKERNEL=1): the line taps of components 1 and 2 added inside the kernel (run-length walk) when their channels
+// fit one pass of 64 lanes.  Measured: 0.725 -> 0.691 ms per 2^19 samples on the micro-benchmark's rays, but the whole blurfactory iteration
+// 19.7 -> 20.3 ms: every ray of a batch adds to the same few hundred x / y line cells, and same-address float atomics serialise at the
+// memory side (the LDS slices of k_scatter_lines exist for exactly that).
+bool voxel_sample_bwd_w_lines12(const GridParams& g) {
+    static const bool on = env_flag("EVD_SCATTER_LINES_INKERNEL");
+    return on && 2 * (g.n_comp[1] + g.n_comp[2]) <= 64 && g.n_comp[1] + g.n_comp[2] <= 32;
+}
 int launch_voxel_sample_bwd_w(const GridParams& g, const float* pts, long n, const float* d_out, int d_stride, int d_col, const GridGrads& gg,
                               float* d_pts, float* rows_l, LTap* ltap, float* coef, hipStream_t st) {
     const unsigned blocks = (unsigned)cdiv(n, (long)VBW_SAMPLES * VBW_WAVES);
     float* coef_w = gg.basis ? coef : nullptr;
-    if (d_pts) {
-        EVD_SET_MAX_LDS((&k_voxel_sample_bwd_w<true>), VBW_LDS);
-        k_voxel_sample_bwd_w<true><<<blocks, 64 * VBW_WAVES, VBW_LDS, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, rows_l, ltap, coef_w);
-    } else {
-        EVD_SET_MAX_LDS((&k_voxel_sample_bwd_w<false>), VBW_LDS);
-        k_voxel_sample_bwd_w<false><<<blocks, 64 * VBW_WAVES, VBW_LDS, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, rows_l, ltap, coef_w);
-    }
+    const bool l12 = voxel_sample_bwd_w_lines12(g);
+#define EVD_VBW(DP, L12) { EVD_SET_MAX_LDS((&k_voxel_sample_bwd_w<DP, L12>), VBW_LDS); \
+        k_voxel_sample_bwd_w<DP, L12><<<blocks, 64 * VBW_WAVES, VBW_LDS, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, rows_l, ltap, coef_w); }
+    if (d_pts && l12) EVD_VBW(true, true)
+    else if (d_pts) EVD_VBW(true, false)
+    else if (l12) EVD_VBW(false, true)
+    else EVD_VBW(false, false)
+#undef EVD_VBW
     EVD_LAUNCH_CHECK();
     if (gg.basis) {
         const int ct = g.n_comp[0] + g.n_comp[1] + g.n_comp[2];

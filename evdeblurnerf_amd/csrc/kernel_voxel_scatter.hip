@@ -461,7 +461,9 @@ int launch_voxel_sample_bwd_hybrid(const GridParams& g, const float* pts, long n
         float* coef = (float*)(w + al256((size_t)n * ctot * 4) + al256((size_t)n * 3 * sizeof(LTap)));
         int rc = launch_voxel_sample_bwd_w(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo.rows_l, bo.ltap, coef, st);
         if (rc) return rc;
-        return launch_lines(g, gg, (const float*)bo.rows_l, (const LTap*)bo.ltap, n, st);
+        GridGrads gl = gg;
+        if (voxel_sample_bwd_w_lines12(g)) gl.line[1] = gl.line[2] = nullptr;      // added inside the kernel: only the z line is left for the LDS slices
+        return launch_lines(g, gl, (const float*)bo.rows_l, (const LTap*)bo.ltap, n, st);
     }
     const bool xy = xy_deferred(g, gg);
     if (xy) {
