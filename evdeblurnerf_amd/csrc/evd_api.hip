@@ -53,8 +53,8 @@ static int upload_stream(evd_nerf::Packed& dst, const StreamBuilder& sb) { retur
 
 // canonical parameter order of the arena: pts_linears[l].{weight, bias} for l < D, then views_linears.0, feature_linear,
 // alpha_linear, rgb_linear ({weight, bias} each)
-static void nerf_param_sizes(int D, int W, int skip, long* sz) {
-    const int IC = 3 * (1 + 2 * PE_L), ICV = 3 * (1 + 2 * PE_LV);
+static void nerf_param_sizes(int D, int W, int skip, int L, int Lv, long* sz) {
+    const int IC = 3 * (1 + 2 * L), ICV = 3 * (1 + 2 * Lv);
     for (int l = 0; l < D; ++l) {
         sz[2 * l] = (long)W * (l == 0 ? IC : (l - 1 == skip ? W + IC : W));
         sz[2 * l + 1] = W;
@@ -68,22 +68,26 @@ static void nerf_param_sizes(int D, int W, int skip, long* sz) {
 
 int evd_nerf_create(const evd_nerf_desc* d, evd_nerf** out) {
     EVD_REQUIRE(d && out, "evd_nerf_create: null argument");
-    EVD_REQUIRE(d->multires == PE_L && d->multires_views == PE_LV,
-                "evd_nerf_create: only multires=%d, multires_views=%d are built (got %d, %d)", PE_L, PE_LV, d->multires, d->multires_views);
+    // frequency counts other than (PE_L, PE_LV) run in the generic kernel only (no pipelined / f16c / training streams)
+    EVD_REQUIRE(d->multires >= 0 && d->multires <= PE_L_MAX && d->multires_views >= 0 && pe_ksteps(d->multires_views) <= 4,
+                "evd_nerf_create: multires %d / multires_views %d out of range (0..%d / 0..10)", d->multires, d->multires_views, PE_L_MAX);
+    const int L = d->multires, Lv = d->multires_views, VKS = pe_ksteps(Lv) <= 2 ? 2 : 4;
+    const bool standard = L == PE_L && Lv == PE_LV;
     EVD_REQUIRE(d->W == 256 || d->W == 64, "evd_nerf_create: netwidth %d not built (64, 256)", d->W);
     EVD_REQUIRE(d->D >= 1 && d->D <= EVD_MAX_LAYERS, "evd_nerf_create: netdepth %d out of range", d->D);
     const bool no_views = !d->views_w && !d->feature_w && !d->alpha_w && !d->rgb_w && d->output_w;
     EVD_REQUIRE(no_views || (d->views_w && d->feature_w && d->alpha_w && d->rgb_w),
                 "evd_nerf_create: give either the view branch (views / feature / alpha / rgb) or output_linear (use_viewdirs=False)");
     EVD_REQUIRE(!no_views || (d->output_b && (d->output_ch == 4 || d->output_ch == 5)), "evd_nerf_create: output_linear needs its bias and output_ch 4 or 5");
-    const int W = d->W, T = W / 32, KS = W / 16, IC = 3 * (1 + 2 * PE_L), ICV = 3 * (1 + 2 * PE_LV), D = d->D;
+    const int W = d->W, T = W / 32, KS = W / 16, IC = 3 * (1 + 2 * L), ICV = 3 * (1 + 2 * Lv), D = d->D;
     evd_nerf* n = new evd_nerf();
+    n->multires = L; n->multires_views = Lv;
     n->D = D; n->W = W; n->skip = d->skip; n->rgb_act = d->rgb_act; n->sigma_act = d->sigma_act; n->rmnear = d->rmnear;
     n->no_views = no_views ? 1 : 0;
 
     // host copy of every parameter in one arena (missing biases = zeros); the packers below read from it
     long sz[2 * EVD_MAX_LAYERS + 8];
-    nerf_param_sizes(D, W, d->skip, sz);
+    nerf_param_sizes(D, W, d->skip, L, Lv, sz);
     n->nparam_blocks = 2 * D + 8;
     if (no_views) {                     // canonical order: pts_linears[l].{weight, bias}, then output_linear.{weight, bias}
         sz[2 * D] = (long)d->output_ch * W; sz[2 * D + 1] = d->output_ch;
@@ -109,11 +113,11 @@ int evd_nerf_create(const evd_nerf_desc* d, evd_nerf** out) {
     const float* output_w = P(2 * D);
     const int out_rows = d->output_ch < 4 ? d->output_ch : 4;       // raw2outputs reads channels 0..3
 
-    auto pe_col = [](int j, int kk) { return pe_src_col(PE_L, 8 * j + (kk & 7), kk >> 3); };
+    auto pe_col = [L](int j, int kk) { return pe_src_col(L, 8 * j + (kk & 7), kk >> 3); };
     auto hid_col = [](int j, int kk) { return 16 * j + phi(kk); };
     auto views_col = [&](int j, int kk) {
         if (j < KS) return hid_col(j, kk);
-        const int c = pe_src_col(PE_LV, 8 * (j - KS) + (kk & 7), kk >> 3);
+        const int c = pe_src_col(Lv, 8 * (j - KS) + (kk & 7), kk >> 3);
         return c < 0 ? -1 : W + c;
     };
     // pdh < 0: the skip layer's k-steps are [pe_0..3 | h_0..h_{KS-1}] (generic kernel);
@@ -139,14 +143,14 @@ int evd_nerf_create(const evd_nerf_desc* d, evd_nerf** out) {
         }
         sb.layer(alpha_w, 1, W, 1, KS, false, hid_col);
         sb.layer(feature_w, W, W, T, KS, false, hid_col);
-        sb.layer(views_w, W / 2, W + ICV, T / 2, KS + PEV_KS, false, views_col);
+        sb.layer(views_w, W / 2, W + ICV, T / 2, KS + VKS, false, views_col);
         sb.layer(rgb_w, 3, W / 2, 1, KS / 2, true, hid_col);
     };
     int rc = EVD_OK;
     for (int prec = 0; prec < EVD_NUM_PREC && !rc; ++prec) {
         if (prec == EVD_PREC_F16C) {      // compensated float16 mode: its own stream (float16 + fp6 fragments) and row scales; pipelined kernel only
             n->nchunks[prec] = n->pipe_chunks[prec] = 0;
-            if (no_views || !nerf_mlp_c_chunks(W, D, d->skip)) continue;
+            if (no_views || !standard || !nerf_mlp_c_chunks(W, D, d->skip)) continue;
             StreamBuilderC sc(PIPE_CB);
             sc.arena = A;
             const int KB = KS / 4;
@@ -178,7 +182,7 @@ int evd_nerf_create(const evd_nerf_desc* d, evd_nerf** out) {
         n->nchunks[prec] = (int)(sb.bytes.size() / chunk_bytes(prec));
         rc = upload_stream(n->stream[prec], sb);
         n->pipe_chunks[prec] = 0;
-        if (!rc && !no_views && nerf_pipe_built(prec, W, D, d->skip)) {
+        if (!rc && !no_views && standard && nerf_pipe_built(prec, W, D, d->skip)) {
             StreamBuilder sp(prec, PIPE_CB);
             sp.arena = A;
             sp.group = nerf_group(prec);
@@ -224,7 +228,7 @@ int evd_nerf_create(const evd_nerf_desc* d, evd_nerf** out) {
         }
         for (int i = 0; i < 64; ++i) m[MAP_PE + i] = pe_col(i / 16, i % 16);
         for (int i = 0; i < 32; ++i) {
-            const int c = pe_src_col(PE_LV, 8 * (i / 16) + (i % 16 & 7), (i % 16) >> 3);
+            const int c = pe_src_col(Lv, 8 * (i / 16) + (i % 16 & 7), (i % 16) >> 3);
             m[MAP_DIR + i] = c < 0 ? -1 : W + c;
         }
         for (int i = 0; i < 3; ++i) m[MAP_RGB + i] = i;
@@ -318,12 +322,13 @@ int evd_nerf_mlp(const evd_nerf* net, int precision, const float* ray_batch, con
     p.wstream = (const char*)(piped ? net->pipe[precision].data.p : net->stream[precision].data.p);
     p.bias = (const float*)net->bias.p;
     p.ray_batch = ray_batch; p.z = z; p.nsamp = R * (long)S; p.S = S; p.ncol = net->no_views ? 8 : 11; p.no_views = net->no_views;
+    p.pe_l = net->multires; p.pe_lv = net->multires_views;
     EVD_REQUIRE(!(net->no_views && feature && feature_kind == 1), "evd_nerf_mlp: a use_viewdirs=False network has no after_linear feature (nerf.py:159)");
     EVD_REQUIRE(!net->no_views || precision != EVD_PREC_F16C, "evd_nerf_mlp: EVD_PREC_F16C is not built for use_viewdirs=False networks");
     p.D = net->D; p.skip = net->skip; p.nchunks = piped ? net->pipe_chunks[precision] : net->nchunks[precision]; p.nbias = (int)(net->bias.bytes / sizeof(float));
     p.raw = raw; p.feature = feature; p.feature_kind = feature ? feature_kind : 0; p.act = nullptr; p.wscale = nullptr;
     if (precision == EVD_PREC_F16C) {
-        EVD_REQUIRE(net->pipe_chunks[precision] > 0, "evd_nerf_mlp: EVD_PREC_F16C is built for netdepth 8, netwidth 256, skips [4] only");
+        EVD_REQUIRE(net->pipe_chunks[precision] > 0, "evd_nerf_mlp: EVD_PREC_F16C is built for netdepth 8, netwidth 256, skips [4], multires 10 / 4 only");
         EVD_REQUIRE(!feature, "evd_nerf_mlp: EVD_PREC_F16C has no feature-row variant (use EVD_PREC_F16X3)");
         p.wstream = (const char*)net->pipe_c.data.p;
         p.nchunks = net->pipe_chunks[precision];

@@ -22,6 +22,7 @@ struct evd_voxel {
     int num_layers, hidden_dim, geo, num_layers_color, input_ch, ft_dim, app_dim;
     int n_comp[3], grid[3], app_act, rgb_act, sigma_act, composite_feature;
     float aabb[6], rmnear;
+    int multires = PE_L, multires_views = PE_LV;
     DevBuf plane[3], line[3], plane_h[3], line_h[3], basis, bias, bias_src, tv_acc, wmaps;
     PackedStream stream[EVD_VOX_NUM_PREC], pipe[EVD_VOX_NUM_PREC];    // pipe: stream of the software-pipelined kernel, where built
     int nchunks[EVD_VOX_NUM_PREC], pipe_chunks[EVD_VOX_NUM_PREC];
@@ -60,10 +61,14 @@ void evd_voxel_destroy(evd_voxel* v) {
 
 int evd_voxel_create(const evd_voxel_desc* d, evd_voxel** out) {
     EVD_REQUIRE(d && out, "evd_voxel_create: null argument");
-    EVD_REQUIRE(d->multires == PE_L && d->multires_views == PE_LV, "evd_voxel_create: only multires=%d/%d are built", PE_L, PE_LV);
+    // frequency counts other than (PE_L, PE_LV) run in the generic kernel only (inference; no pipelined / f16c / training streams)
+    EVD_REQUIRE(d->multires >= 0 && d->multires <= PE_L_MAX && d->multires_views >= 0 && d->multires_views <= PE_LV,
+                "evd_voxel_create: multires %d / multires_views %d out of range (0..%d / 0..%d)", d->multires, d->multires_views, PE_L_MAX, PE_LV);
+    const int L = d->multires, Lv = d->multires_views;
+    const bool standard = L == PE_L && Lv == PE_LV;
     EVD_REQUIRE(d->num_layers == 2 && d->num_layers_color == 3, "evd_voxel_create: only 2 sigma + 3 colour layers are built (all shipped configs)");
     EVD_REQUIRE(!d->composite_feature, "evd_voxel_create: composite_feature=True (PBE kernel) is not built; shipped configs use RBK");
-    const int IC = 3 * (1 + 2 * PE_L), ICV = 3 * (1 + 2 * PE_LV);
+    const int IC = 3 * (1 + 2 * L), ICV = 3 * (1 + 2 * Lv);
     const int FT = d->input_ch - IC, HD = d->hidden_dim, G = d->geo_feat_dim;
     EVD_REQUIRE((HD == 64 && G == 15 && FT == 32) || (HD == 256 && G == 128 && FT == 64),
                 "evd_voxel_create: (hidden %d, geo %d, features %d) not built: coarse 64/15/32 or fine 256/128/64", HD, G, FT);
@@ -77,6 +82,7 @@ int evd_voxel_create(const evd_voxel_desc* d, evd_voxel** out) {
     v->num_layers = 2; v->hidden_dim = HD; v->geo = G; v->num_layers_color = 3; v->input_ch = d->input_ch; v->ft_dim = FT;
     v->app_dim = d->app_dim; v->app_act = d->app_act; v->rgb_act = d->rgb_act; v->sigma_act = d->sigma_act;
     v->composite_feature = 0; v->rmnear = d->rmnear;
+    v->multires = L; v->multires_views = Lv;
     memcpy(v->aabb, d->aabb, sizeof(v->aabb));
     int rc = EVD_OK;
     // planes/lines: [1,C,H,W] -> channel-last [H][W][C]
@@ -138,7 +144,7 @@ int evd_voxel_create(const evd_voxel_desc* d, evd_voxel** out) {
     auto hid_col = [](int j, int kk) { return 16 * j + phi(kk); };
     auto in0_col = [&](int j, int kk) {            // cat([fts, PE(pts)]): natural feature k-steps then the PE arrangement
         if (j < KF) return 16 * j + kk;
-        const int c = pe_src_col(PE_L, 8 * (j - KF) + (kk & 7), kk >> 3);
+        const int c = pe_src_col(L, 8 * (j - KF) + (kk & 7), kk >> 3);
         return c < 0 ? -1 : FT + c;
     };
     auto c0_col = [&](int j, int kk) {             // cat([h[...,1:], PE(dirs)]) voxnerf.py:248
@@ -147,7 +153,7 @@ int evd_voxel_create(const evd_voxel_desc* d, evd_voxel** out) {
             const int row = 16 * j + phi(kk);      // index into the sigma-layer output tile(s)
             return small ? (row >= 1 && row <= G ? row - 1 : -1) : row;
         }
-        const int c = pe_src_col(PE_LV, 8 * (j - gk) + (kk & 7), kk >> 3);
+        const int c = pe_src_col(Lv, 8 * (j - gk) + (kk & 7), kk >> 3);
         return c < 0 ? -1 : G + c;
     };
     auto build = [&](StreamBuilder& sb) {
@@ -167,7 +173,7 @@ int evd_voxel_create(const evd_voxel_desc* d, evd_voxel** out) {
     auto build_pipe = [&](StreamBuilder& sb) {
         auto c0p = [&](int j, int kk) {
             if (j < GK) { const int c = 16 * j + phi(kk); return c < G ? c : -1; }
-            const int c = pe_src_col(PE_LV, 8 * (j - GK) + (kk & 7), kk >> 3);
+            const int c = pe_src_col(Lv, 8 * (j - GK) + (kk & 7), kk >> 3);
             return c < 0 ? -1 : G + c;
         };
         sb.layer(sigma_w0, HD, d->input_ch, T, KF + PE_KS, false, in0_col);
@@ -186,7 +192,7 @@ int evd_voxel_create(const evd_voxel_desc* d, evd_voxel** out) {
         if (rc) { evd_voxel_destroy(v); return rc; }
         v->pipe_chunks[prec] = 0;
         v->train_chunks[prec] = 0;
-        if (voxel_pipe_built(prec, HD, G, FT)) {        // same layers, single-tile groups, 16 KiB chunks (voxel_mlp_kernel.h)
+        if (standard && voxel_pipe_built(prec, HD, G, FT)) {        // same layers, single-tile groups, 16 KiB chunks (voxel_mlp_kernel.h)
             StreamBuilder sp(prec, PIPE_CB);
             sp.arena = A;
             sp.group = 1;
@@ -195,7 +201,7 @@ int evd_voxel_create(const evd_voxel_desc* d, evd_voxel** out) {
             rc = v->pipe[prec].upload(sp);
             if (rc) { evd_voxel_destroy(v); return rc; }
         }
-        if (!is_train_prec(prec)) continue;
+        if (!is_train_prec(prec) || !standard) continue;
         {   // training: forward stream of the level (the coarse level has no pipelined inference kernel: its own copy) ...
             StreamBuilder sp(prec, PIPE_CB);
             sp.arena = A;
@@ -219,7 +225,7 @@ int evd_voxel_create(const evd_voxel_desc* d, evd_voxel** out) {
         auto enc_row = [](int L_, int idx) { const int j = idx / 16, kk = phi_inv(idx % 16); return pe_src_col(L_, 8 * j + (kk & 7), kk >> 3); };
         if (!rc) rc = put(VBWD_C0, [&](StreamBuilder& b) {       // [geo rows | direction-encoding rows] of color_net.0
             b.layer_at(GT + 1, KS, true,
-                       [&](int t, int r) { if (t < GT) return 32 * t + r < G ? 32 * t + r : -1; const int c = enc_row(PE_LV, r); return c < 0 ? -1 : G + c; },
+                       [&](int t, int r) { if (t < GT) return 32 * t + r < G ? 32 * t + r : -1; const int c = enc_row(Lv, r); return c < 0 ? -1 : G + c; },
                        hid_col, [&](int r, int c) { return color_w0 + (size_t)c * (G + ICV) + r; });
         });
         if (!rc) rc = put(VBWD_SIGGEO, [&](StreamBuilder& b) {
@@ -231,15 +237,15 @@ int evd_voxel_create(const evd_voxel_desc* d, evd_voxel** out) {
         if (!rc) rc = put(VBWD_L0, [&](StreamBuilder& b) {       // [feature rows | point-encoding rows] of sigma_net.0
             const int FTT = (FT + 31) / 32, in_dim = d->input_ch;
             b.layer_at(FTT + 2, KS, true,
-                       [&](int t, int r) { if (t < FTT) return 32 * t + r < FT ? 32 * t + r : -1; const int c = enc_row(PE_L, 32 * (t - FTT) + r); return c < 0 ? -1 : FT + c; },
+                       [&](int t, int r) { if (t < FTT) return 32 * t + r < FT ? 32 * t + r : -1; const int c = enc_row(L, 32 * (t - FTT) + r); return c < 0 ? -1 : FT + c; },
                        hid_col, [&](int r, int c) { return sigma_w0 + (size_t)c * in_dim + r; });
         });
         if (rc) { evd_voxel_destroy(v); return rc; }
     }
-    if (voxel_mlp_c_chunks(HD, G, FT) > 0) {     // compensated float16 mode: the layer table of voxel_mlp_c_kernel.h VoxNetC (groups of two tiles, 64-input blocks)
+    if (standard && voxel_mlp_c_chunks(HD, G, FT) > 0) {     // compensated float16 mode: the layer table of voxel_mlp_c_kernel.h VoxNetC (groups of two tiles, 64-input blocks)
         auto c0p = [&](int j, int kk) {
             if (j < GK) { const int c = 16 * j + phi(kk); return c < G ? c : -1; }
-            const int c = pe_src_col(PE_LV, 8 * (j - GK) + (kk & 7), kk >> 3);
+            const int c = pe_src_col(Lv, 8 * (j - GK) + (kk & 7), kk >> 3);
             return c < 0 ? -1 : G + c;
         };
         auto sig_at = [=](int r, int c) -> const float* { return c < HD ? sigma_w1 + (size_t)r * HD + c : nullptr; };
@@ -262,11 +268,11 @@ int evd_voxel_create(const evd_voxel_desc* d, evd_voxel** out) {
         for (int i = 0; i < 256; ++i) { const int c = hid_col(i / 16, i % 16); m[VMAP_HID + i] = c < HD ? c : -1; }
         for (int i = 0; i < 64; ++i) {
             m[VMAP_FTS + i] = i < FT ? i : -1;
-            const int c = pe_src_col(PE_L, 8 * (i / 16) + (i % 16 & 7), (i % 16) >> 3);
+            const int c = pe_src_col(L, 8 * (i / 16) + (i % 16 & 7), (i % 16) >> 3);
             m[VMAP_PE + i] = c < 0 ? -1 : FT + c;
         }
         for (int i = 0; i < 32; ++i) {
-            const int c = pe_src_col(PE_LV, 8 * (i / 16) + (i % 16 & 7), (i % 16) >> 3);
+            const int c = pe_src_col(Lv, 8 * (i / 16) + (i % 16 & 7), (i % 16) >> 3);
             m[VMAP_DIR + i] = c < 0 ? -1 : G + c;
         }
         for (int i = 0; i < 128; ++i) {
@@ -337,6 +343,7 @@ static int voxel_pass(const evd_voxel* v, int precision, const float* pts, const
     p.bias = (const float*)v->bias.p;
     p.pts = pts; p.viewdirs = viewdirs; p.fts = fts; p.nsamp = R * (long)S; p.S = S; p.vd_stride = vd_stride; p.ft_stride = ft_stride;
     p.nchunks = piped ? v->pipe_chunks[precision] : v->nchunks[precision]; p.nbias = (int)(v->bias.bytes / sizeof(float)); p.raw = raw; p.feature = feature; p.act = nullptr;
+    p.pe_l = v->multires; p.pe_lv = v->multires_views;
     if (comp) {
         if (v->pipe_c_stale) {
             int rcc = repack_stream_c(v->pipe_c, (const float*)v->arena_dev.p, as_stream(stream));

@@ -15,7 +15,8 @@
 
 namespace evd {
 
-template <int PREC, int W>
+// VKS: k-steps of the direction encoding (2: multires_views <= 4, 4: <= 10)
+template <int PREC, int W, int VKS>
 __global__ __launch_bounds__(mlp_threads(PREC), is_half_prec(PREC) ? 2 : 1) void k_nerf_mlp_generic(const MlpParams p) {
     typedef Ops<PREC> O;
     typedef typename O::B B;
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(mlp_threads(PREC), is_half_prec(PREC) ? 2 : 1) void
     B act[KS], nxt[KS];
     {
         B in_pe[PE_KS];
-        encode_b<PREC, PE_L, PE_KS>(pts, h, in_pe);
+        encode_b_rt<PREC, PE_KS>(pts, h, p.pe_l, in_pe);
 #pragma unroll
         for (int j = 0; j < PE_KS; ++j) stash[j * 64] = in_pe[j];
     }
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(mlp_threads(PREC), is_half_prec(PREC) ? 2 : 1) void
         return;
     }
     // heads: alpha_linear (1 tile), feature_linear, views_linears.0 on cat([feature, dirs]), rgb_linear (nerf.py:144-157)
-    constexpr int F_ALPHA = KS, F_FEAT = T * KS, F_VIEWS = (T / 2) * (KS + PEV_KS);
+    constexpr int F_ALPHA = KS, F_FEAT = T * KS, F_VIEWS = (T / 2) * (KS + VKS);
     constexpr int OFF_FEAT = F_ALPHA % FPC, OFF_VIEWS = (F_ALPHA + F_FEAT) % FPC, OFF_RGB = (F_ALPHA + F_FEAT + F_VIEWS) % FPC;
     float araw[16], rraw[16];
     layer<PREC, KS, 1, false, OUT_F32, 0, false>(st, act, nullptr, araw, bias, lane, nullptr, W);
@@ -100,16 +101,16 @@ __global__ __launch_bounds__(mlp_threads(PREC), is_half_prec(PREC) ? 2 : 1) void
     layer<PREC, KS, T, false, OUT_B, OFF_FEAT, false>(st, act, nxt, nullptr, bias, lane, p.feature_kind == 1 ? frow : nullptr, W);
     bias += T * 32;
     {
-        B vin[KS + PEV_KS];
+        B vin[KS + VKS];
 #pragma unroll
         for (int j = 0; j < KS; ++j) vin[j] = nxt[j];
         {
-            B in_dir[PEV_KS];
-            encode_b<PREC, PE_LV, PEV_KS>(vd, h, in_dir);
+            B in_dir[VKS];
+            encode_b_rt<PREC, VKS>(vd, h, p.pe_lv, in_dir);
 #pragma unroll
-            for (int j = 0; j < PEV_KS; ++j) vin[KS + j] = in_dir[j];
+            for (int j = 0; j < VKS; ++j) vin[KS + j] = in_dir[j];
         }
-        layer<PREC, KS + PEV_KS, T / 2, true, OUT_B, OFF_VIEWS, false>(st, vin, act, nullptr, bias, lane, nullptr, W);
+        layer<PREC, KS + VKS, T / 2, true, OUT_B, OFF_VIEWS, false>(st, vin, act, nullptr, bias, lane, nullptr, W);
         bias += (T / 2) * 32;
     }
     {
@@ -124,20 +125,23 @@ __global__ __launch_bounds__(mlp_threads(PREC), is_half_prec(PREC) ? 2 : 1) void
     }
 }
 
-template <int PREC, int W>
+template <int PREC, int W, int VKS>
 static int launch_mlp(const MlpParams& p, hipStream_t st) {
     constexpr int NT = mlp_threads(PREC);
     const long blocks = cdiv(p.nsamp, NT / 2);
     const size_t lds = MlpLds<PREC>::TOTAL;
-    EVD_SET_MAX_LDS((&k_nerf_mlp_generic<PREC, W>), lds);
+    EVD_SET_MAX_LDS((&k_nerf_mlp_generic<PREC, W, VKS>), lds);
     if (p.nbias > MlpLds<PREC>::BIAS_FLOATS) return fail(EVD_E_INVALID, "evd_nerf_mlp: %d bias floats exceed the LDS bias block", p.nbias);
-    hipLaunchKernelGGL((k_nerf_mlp_generic<PREC, W>), dim3((unsigned)blocks), dim3(NT), lds, st, p);
+    hipLaunchKernelGGL((k_nerf_mlp_generic<PREC, W, VKS>), dim3((unsigned)blocks), dim3(NT), lds, st, p);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }
 
 int nerf_mlp_generic_dispatch(int prec, int W, const MlpParams& p, hipStream_t st) {
-#define EVD_CASE(P, WW) if (prec == P && W == WW) return launch_mlp<P, WW>(p, st)
+    if (p.pe_l < 0 || p.pe_l > PE_L_MAX || p.pe_lv < 0 || pe_ksteps(p.pe_lv) > 4)
+        return fail(EVD_E_INVALID, "evd_nerf_mlp: multires %d / multires_views %d out of range (0..%d / 0..10)", p.pe_l, p.pe_lv, PE_L_MAX);
+    const bool widev = pe_ksteps(p.pe_lv) > 2;
+#define EVD_CASE(P, WW) if (prec == P && W == WW) return widev ? launch_mlp<P, WW, 4>(p, st) : launch_mlp<P, WW, 2>(p, st)
     EVD_CASE(EVD_PREC_BF16, 256);
     EVD_CASE(EVD_PREC_F16, 256);
     EVD_CASE(EVD_PREC_F16X3, 256);

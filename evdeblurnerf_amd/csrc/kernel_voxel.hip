@@ -1327,10 +1327,10 @@ __global__ __launch_bounds__(mlp_threads(PREC), is_half_prec(PREC) ? 2 : 1) void
             in0[j] = O::make_b(v);
         }
         B pe[PE_KS];
-        encode_b<PREC, PE_L, PE_KS>(pts, h, pe);
+        encode_b_rt<PREC, PE_KS>(pts, h, p.pe_l, pe);
 #pragma unroll
         for (int j = 0; j < PE_KS; ++j) in0[KF + j] = pe[j];
-        encode_b<PREC, PE_LV, PEV_KS>(vd, h, in_dir);
+        encode_b_rt<PREC, PEV_KS>(vd, h, p.pe_lv, in_dir);
     }
     const float* lbias = stage_bias<PREC>(smem, p.bias, p.nbias, tid);
     Stream<PREC> st;

@@ -326,4 +326,21 @@ __device__ __forceinline__ void encode_b(const float (&x)[3], int h, typename Op
     for (int j = 0; j < KSN; ++j) out[j] = Ops<PREC>::make_b(v[j]);
 }
 
+// encode_b with the frequency count L at run time (3 L + 2 <= 8 KSN): the same values at the same positions, the rest zero
+template <int PREC, int KSN>
+__device__ __forceinline__ void encode_b_rt(const float (&x)[3], int h, int L, typename Ops<PREC>::B (&out)[KSN]) {
+    f32x8 v[KSN];
+    const int q0 = 3 * L;
+#pragma unroll
+    for (int q = 0; q < KSN * 8; ++q) {
+        float y = 0.f;
+        if (q < q0) y = sin_or_cos(x[q % 3] * (float)(1 << (q / 3)), h);
+        else if (q == q0) y = h ? x[1] : x[0];
+        else if (q == q0 + 1) y = h ? 0.f : x[2];
+        v[q >> 3][q & 7] = y;
+    }
+#pragma unroll
+    for (int j = 0; j < KSN; ++j) out[j] = Ops<PREC>::make_b(v[j]);
+}
+
 }  // namespace evd

@@ -26,6 +26,10 @@ constexpr int PE_L = 10;        // multires (reference options.py: --multires 10
 constexpr int PE_LV = 4;        // multires_views
 constexpr int PE_KS = (3 * PE_L + 2 + 7) / 8;    // 4 k-steps hold the 63-wide point encoding
 constexpr int PEV_KS = (3 * PE_LV + 2 + 7) / 8;  // 2 k-steps hold the 27-wide direction encoding
+// Other frequency counts (options.py --multires / --multires_views) run in the generic kernels: the point encoding always takes PE_KS
+// k-steps (multires <= PE_L_MAX, unused positions are zero columns of the packed weights), the direction encoding 2 or 4 k-steps.
+constexpr int PE_L_MAX = (8 * PE_KS - 2) / 3;          // 10
+__host__ __device__ constexpr int pe_ksteps(int L) { return (3 * L + 2 + 7) / 8; }
 
 __host__ __device__ constexpr int phi(int kk) { return 8 * ((kk & 7) >> 2) + 4 * (kk >> 3) + (kk & 3); }
 __host__ __device__ constexpr int phi_inv(int p) { return (p & 3) | ((p >> 3) << 2) | (((p >> 2) & 1) << 3); }
@@ -58,6 +62,7 @@ struct MlpParams {
     float* feature;         // [R, S, W] or null
     int feature_kind;       // 0 none, 1 after_linear, 2 before_linear
     char* act;              // training kernels: activation store (act_tile_bytes per 32-sample tile), else null
+    int pe_l, pe_lv;        // multires / multires_views (generic kernels; the pipelined ones are built for PE_L / PE_LV)
     int no_views;           // use_viewdirs=False network: one output_linear head tile after the hidden layers, no view direction columns
     const unsigned* wscale; // compensated float16 mode: row-scale words, 32 per output tile in bias order (pack.h StreamBuilderC), else null
     // fused render step of the compensated float16 kernel (nerf_mlp_c_kernel.h, FUSE): z stratification in the prologue (renderer.py:163-178),

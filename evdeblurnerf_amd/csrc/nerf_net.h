@@ -10,6 +10,7 @@ enum { EVD_BWD_RGB = 0, EVD_BWD_VIEWS, EVD_BWD_HEAD, EVD_BWD_PE0, EVD_BWD_PESKIP
 struct evd_nerf {
     typedef evd::PackedStream Packed;
     int D, W, skip, rgb_act, sigma_act;
+    int multires = 10, multires_views = 4;   // frequency counts of the two encodings (others than 10 / 4: generic kernel only)
     int no_views = 0;                        // use_viewdirs=False: output_linear head, 8-column ray batch, generic kernel only
     float rmnear;
     Packed stream[EVD_NUM_PREC];             // generic kernel: fragment streams per precision

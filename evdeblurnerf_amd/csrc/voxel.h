@@ -28,6 +28,7 @@ struct VoxMlpParams {
     float* raw;                 // [n,4] = (sigma, sigmoid(colour))  voxnerf.py:254
     float* feature;             // [n,G] or null
     char* act;                  // training kernels: activation store, else null
+    int pe_l = 10, pe_lv = 4;           // multires / multires_views (generic kernel; the pipelined ones are built for nerf_mlp.h PE_L / PE_LV)
     const unsigned* wscale = nullptr;   // compensated float16 mode: row-scale words, 32 per output tile in stream order (pack.h StreamBuilderC)
 };
 

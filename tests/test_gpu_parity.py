@@ -285,6 +285,69 @@ def test_render_without_viewdirs_matches_reference_golden(prec, tol):
             model.mlp_coarse.mlpforward_train(torch.zeros((4, 8), device=DEV), torch.zeros((4, 16), device=DEV))
 
 
+@pytest.mark.parametrize("prec,tol", [("f32", 1e-4), ("f16x3", 1e-4), ("f16c", 1e-4), ("f16", 2e-4), ("bf16", 3e-2)])
+def test_render_other_multires_matches_reference_golden(prec, tol):
+    """--multires / --multires_views other than 10 / 4 (options.py:94-97, embedding.py:101-117): mode='nerf' (6, 2) hierarchical and
+    (3, 8) on a 4 x 64 network, mode='c2f' (7, 3) -- against golden G24 from the reference's NeRFAll.  These run in the generic kernels
+    (EVD_PREC_F16C falls back to the float32-grade arithmetic there); training them is rejected."""
+    from types import SimpleNamespace
+    from evdeblurnerf_amd import _lib as L
+    from evdeblurnerf_amd.renderer import NeRFAll
+    g = load_golden("G24_render_other_multires")
+    K = W.synthetic_camera()
+    base = dict(mode="nerf", use_viewdirs=True, rgb_activate="sigmoid", sigma_activate="relu")
+    # (a)
+    Lp, Lv = 6, 2
+    sd = dict(W.prefixed(W.make_nerf_state_dict(71, input_ch=W.pe_dim(Lp), input_ch_views=W.pe_dim(Lv)), "mlp_coarse"))
+    sd.update(W.prefixed(W.make_nerf_state_dict(72, input_ch=W.pe_dim(Lp), input_ch_views=W.pe_dim(Lv)), "mlp_fine"))
+    if prec == "f16c":
+        with pytest.raises(L.EvdError):             # the compensated mode of mode='nerf' exists for the (10, 4) 8 x 256 network only
+            NeRFAll(SimpleNamespace(netdepth=8, netwidth=256, multires=Lp, multires_views=Lv, N_importance=32, **base), sd, precision=prec).eval().render(
+                400, 400, K, rays=T(W.synthetic_rays(41, 56)), ndc=True, near=0., far=1., use_viewdirs=True, N_samples=48, N_importance=32)
+    else:
+        model = NeRFAll(SimpleNamespace(netdepth=8, netwidth=256, multires=Lp, multires_views=Lv, N_importance=32, **base), sd, precision=prec).eval()
+        rgb, depth, acc, ex = model.render(400, 400, K, rays=T(W.synthetic_rays(41, 56)), ndc=True, near=0., far=1., use_viewdirs=True, N_samples=48,
+                                           N_importance=32, retraw=True, perturb=0., raw_noise_std=0.)
+        e = maxabs(N(rgb), g["a_rgb"])
+        print(f"[{prec} multires (6, 2)] RGB L-inf vs reference = {e:.3e}")
+        assert e < tol and maxabs(N(ex["rgb0"]), g["a_rgb0"]) < tol and maxabs(N(acc), g["a_acc"]) < tol
+        assert maxabs(N(ex["z_vals0"]), g["a_z_vals0"]) < 1e-6
+        if prec == "f32":
+            with pytest.raises(L.EvdError):
+                model.mlp_coarse.mlpforward_train(torch.zeros((4, 11), device=DEV), torch.zeros((4, 16), device=DEV))
+        # (b) direction encoding on four k-steps
+        Lp, Lv = 3, 8
+        sd = W.prefixed(W.make_nerf_state_dict(73, D=4, W=64, input_ch=W.pe_dim(Lp), input_ch_views=W.pe_dim(Lv), skips=()), "mlp_coarse")
+        model = NeRFAll(SimpleNamespace(netdepth=4, netwidth=64, multires=Lp, multires_views=Lv, N_importance=0, **base), sd, precision=prec).eval()
+        rgb, depth, acc, ex = model.render(400, 400, K, rays=T(W.synthetic_rays(42, 40)), ndc=False, near=0.5, far=3.5, use_viewdirs=True,
+                                           N_samples=64, N_importance=0, retraw=True, perturb=0., raw_noise_std=0.)
+        e = maxabs(N(rgb), g["b_rgb"])
+        print(f"[{prec} multires (3, 8), 4 x 64] RGB L-inf vs reference = {e:.3e}")
+        assert e < tol and maxabs(N(ex["weights"]), g["b_weights"]) < tol and maxabs(N(depth), g["b_depth"]) < 3 * tol
+    # (c) c2f
+    Lp, Lv = 7, 3
+    ic, icv = W.pe_dim(Lp), W.pe_dim(Lv)
+    a = W.blurfactory_args(32, coarse_voxels=24 ** 3, fine_voxels=48 ** 3)
+    a.multires, a.multires_views = Lp, Lv
+    gc, gf = W.pdrf_grid_size(*W.BLURFACTORY_AABB, 24 ** 3), W.pdrf_grid_size(*W.BLURFACTORY_AABB, 48 ** 3)
+    sd = W.prefixed(W.make_pdrf_state_dict(74, gc, input_ch=32 + ic, input_ch_views=icv, hidden_dim=64, geo_feat_dim=15), "mlp_coarse")
+    sd.update(W.prefixed(W.make_pdrf_state_dict(75, gf, input_ch=64 + ic, input_ch_views=icv, hidden_dim=256, geo_feat_dim=128), "mlp_fine"))
+    model = NeRFAll(a, sd, precision=prec).eval()
+    rgb, depth, acc, ex = model.render(400, 400, K, rays=T(W.synthetic_rays(43, 48)), ndc=True, near=0., far=1., use_viewdirs=True, N_samples=64,
+                                       N_importance=32, retraw=True, perturb=0., raw_noise_std=0.)
+    e0 = maxabs(N(ex["rgb0"]), g["c_rgb0"])
+    same = np.abs(N(ex["z_vals"]) - g["c_z_vals"]).max(-1) < 5e-5           # rays whose importance samples agree (G9's rule)
+    e = maxabs(N(rgb)[same], g["c_rgb"][same])
+    print(f"[{prec} c2f multires (7, 3)] RGB L-inf vs reference: coarse {e0:.3e}, fine {e:.3e} on {same.mean():.0%} of the rays")
+    ctol = tol if prec in ("f32", "f16x3", "f16c") else 10 * tol
+    # (single-product modes: the coarse weights move the importance samples of most rays by more than 5e-5; compared where they agree)
+    assert e0 < ctol and (same.mean() > 0.8 or prec in ("f16", "bf16")) and (not same.any() or e < ctol)
+    if prec == "f32":
+        with pytest.raises(L.EvdError):
+            model.enable_training(sd).train()
+            model(400, 400, K, 1 << 20, rays=T(W.synthetic_rays(43, 48)), ndc=True, near=0., far=1., use_viewdirs=True, N_samples=64, N_importance=32, perturb=1.0)
+
+
 def test_render_config1_white_bkgd_lindisp_no_ndc(O):
     """BASELINE config 1 shape (single pass, 64 samples) with the non-default switches, vs golden G7c."""
     from types import SimpleNamespace

@@ -181,6 +181,38 @@ def test_G9_render_c2f():
     assert maxabs(O.ray_batch(cfg, rays[:16])[:, 3:6], g["f_rays_d"]) < 2e-6
 
 
+def test_G24_render_other_multires():
+    """frequency counts other than (10, 4) (options.py:94-97; embedding.py:101-117; renderer.py:18,44), nerf and c2f modes"""
+    g = load_golden("G24_render_other_multires")
+    keys_h = dict(rgb="rgb", depth="depth", acc="acc", z_vals="z_vals", weights="weights", rgb0="rgb0",
+                  depth0="depth0", acc0="acc0", z_std="z_std", z_vals0="z_vals0", weights0="weights0")
+    L, Lv = 6, 2
+    mk = lambda seed: O.Nerf(W.make_nerf_state_dict(seed, input_ch=W.pe_dim(L), input_ch_views=W.pe_dim(Lv)), input_ch=W.pe_dim(L),
+                             input_ch_views=W.pe_dim(Lv))
+    res = O.render_nerf(mk(71), mk(72), O.make_cfg(N_samples=48, N_importance=32, multires=L, multires_views=Lv), W.synthetic_rays(41, 56))
+    _check_render(res, g, "a_", keys_h, 2e-5)
+    L, Lv = 3, 8
+    m = O.Nerf(W.make_nerf_state_dict(73, D=4, W=64, input_ch=W.pe_dim(L), input_ch_views=W.pe_dim(Lv), skips=()), D=4, W=64,
+               input_ch=W.pe_dim(L), input_ch_views=W.pe_dim(Lv))
+    res = O.render_nerf(m, None, O.make_cfg(N_samples=64, ndc=False, near=0.5, far=3.5, multires=L, multires_views=Lv), W.synthetic_rays(42, 40))
+    _check_render(res, g, "b_", dict(rgb="rgb", depth="depth", acc="acc", z_vals="z_vals", weights="weights"), 2e-5)
+    L, Lv = 7, 3
+    gc = W.pdrf_grid_size(AABB[:3], AABB[3:], 24 ** 3)
+    gf = W.pdrf_grid_size(AABB[:3], AABB[3:], 48 ** 3)
+    ic, icv = W.pe_dim(L), W.pe_dim(Lv)
+    vc = O.Voxel(W.make_pdrf_state_dict(74, gc, input_ch=32 + ic, input_ch_views=icv, hidden_dim=64, geo_feat_dim=15), "", gc, AABB,
+                 input_ch=32 + ic, input_ch_views=icv, hidden_dim=64, geo_feat_dim=15, rgb_act="relu")
+    vf = O.Voxel(W.make_pdrf_state_dict(75, gf, input_ch=64 + ic, input_ch_views=icv, hidden_dim=256, geo_feat_dim=128), "", gf, AABB,
+                 input_ch=64 + ic, input_ch_views=icv, hidden_dim=256, geo_feat_dim=128, rgb_act="none")
+    res = O.render_c2f(vc, vf, O.make_cfg(N_samples=64, N_importance=32, multires=L, multires_views=Lv), W.synthetic_rays(43, 48))
+    for k in ("rgb0", "depth0", "acc0", "z_std", "z_vals0", "weights0"):
+        assert maxabs(res[k], g["c_" + k]) < 5e-5, k
+    same = np.abs(res["z_vals"] - g["c_z_vals"]).max(-1) < 5e-5           # rays whose importance samples agree (G9's rule)
+    assert same.mean() > 0.8
+    for k in ("rgb", "depth", "acc", "weights"):
+        assert maxabs(res[k][same], g["c_" + k][same]) < 5e-5, k
+
+
 def test_G10_rbk_weighted_sum():
     g = load_golden("G10_rbk_weighted_sum")
     ccw = g["ccw"]

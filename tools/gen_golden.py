@@ -339,6 +339,50 @@ def _pdrf_sds(model, seed_c, seed_f):
     return sd
 
 
+def G24_render_other_multires():
+    """frequency counts other than the default (options.py:94-97 --multires 10 --multires_views 4): embedding.py:101-117 builds the
+    encoders from them, renderer.py:18,44 sizes the networks' inputs."""
+    K = W.synthetic_camera()
+    out = {}
+    # (a) mode='nerf', multires 6 / multires_views 2, hierarchical 48 + 32
+    L, Lv = 6, 2
+    model, _ = _nerfall("nerf", 32, 0, multires=L, multires_views=Lv)
+    sd = {}
+    sd.update(W.prefixed(W.make_nerf_state_dict(71, input_ch=W.pe_dim(L), input_ch_views=W.pe_dim(Lv)), "mlp_coarse"))
+    sd.update(W.prefixed(W.make_nerf_state_dict(72, input_ch=W.pe_dim(L), input_ch_views=W.pe_dim(Lv)), "mlp_fine"))
+    ref_import.load_np_state_dict(model, sd)
+    model.train(False)
+    rays = W.synthetic_rays(41, 56)
+    rgb, depth, acc, ex = model.render(400, 400, t(K), 1024, rays=t(rays), ndc=True, near=0., far=1., use_viewdirs=True, N_samples=48,
+                                       N_importance=32, retraw=True, perturb=0., raw_noise_std=0.)
+    out.update(a_rgb=n(rgb), a_depth=n(depth), a_acc=n(acc), **{f"a_{k}": n(v) for k, v in ex.items()})
+    # (b) mode='nerf', multires 3 / multires_views 8 (direction encoding wider than the default's two k-steps), 4 x 64 network, skip at 1
+    L, Lv = 3, 8
+    model, _ = _nerfall("nerf", 0, 0, multires=L, multires_views=Lv, netdepth=4, netwidth=64)
+    # (skips = [4] is fixed in renderer.py:48: with D = 4 it never fires, nerf.py:24,137)
+    ref_import.load_np_state_dict(model, W.prefixed(W.make_nerf_state_dict(73, D=4, W=64, input_ch=W.pe_dim(L), input_ch_views=W.pe_dim(Lv), skips=()),
+                                                    "mlp_coarse"))
+    model.train(False)
+    rays = W.synthetic_rays(42, 40)
+    rgb, depth, acc, ex = model.render(400, 400, t(K), 1024, rays=t(rays), ndc=False, near=0.5, far=3.5, use_viewdirs=True, N_samples=64,
+                                       N_importance=0, retraw=True, perturb=0., raw_noise_std=0.)
+    out.update(b_rgb=n(rgb), b_depth=n(depth), b_acc=n(acc), **{f"b_{k}": n(v) for k, v in ex.items()})
+    # (c) mode='c2f', multires 7 / multires_views 3 on the small grids of G9
+    L, Lv = 7, 3
+    model, _ = _nerfall("c2f", 32, 0, rgb_add_bias=False, multires=L, multires_views=Lv, **PDRF_SMALL)
+    gc = [int(v) for v in model.mlp_coarse.gridSize]
+    gf = [int(v) for v in model.mlp_fine.gridSize]
+    sd = W.prefixed(W.make_pdrf_state_dict(74, gc, input_ch=32 + W.pe_dim(L), input_ch_views=W.pe_dim(Lv), hidden_dim=64, geo_feat_dim=15), "mlp_coarse")
+    sd.update(W.prefixed(W.make_pdrf_state_dict(75, gf, input_ch=64 + W.pe_dim(L), input_ch_views=W.pe_dim(Lv), hidden_dim=256, geo_feat_dim=128), "mlp_fine"))
+    ref_import.load_np_state_dict(model, sd)
+    model.train(False)
+    rays = W.synthetic_rays(43, 48)
+    rgb, depth, acc, ex = model.render(400, 400, t(K), 1024, rays=t(rays), ndc=True, near=0., far=1., use_viewdirs=True, N_samples=64,
+                                       N_importance=32, retraw=True, perturb=0., raw_noise_std=0.)
+    out.update(c_rgb=n(rgb), c_depth=n(depth), c_acc=n(acc), **{f"c_{k}": n(v) for k, v in ex.items()})
+    save("G24_render_other_multires", **out)
+
+
 def G8_appfeature():
     model, _ = _nerfall("c2f", 64, 0, rgb_add_bias=False, **PDRF_SMALL)
     sd = _pdrf_sds(model, 21, 22)
@@ -849,7 +893,7 @@ def G22_mam():
 ALL = [G1_embedder, G2_nerf_mlp, G3_nerf_raw2outputs, G4_voxel_raw2outputs, G5_sample_pdf, G6_rays,
        G7_render_nerf, G8_appfeature, G9_render_c2f, G10_rbk_weighted_sum, G11_crf, G12_egm_loss, G13_edi,
        G14_loss_assembly, G15_awp_feature_integration, G16_rbk_warp, G17_compute_successor, G18_nerf_grads, G19_c2f_grads, G20_loss_grads,
-       G21_awp_sample_embed, G22_mam, G23_render_nerf_no_viewdirs]
+       G21_awp_sample_embed, G22_mam, G23_render_nerf_no_viewdirs, G24_render_other_multires]
 
 if __name__ == "__main__":
     want = set(sys.argv[1:])
