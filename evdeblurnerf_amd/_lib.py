@@ -171,6 +171,8 @@ SIGNATURES = {
     "evd_crf_load_params": (_I, [_vp, _vp]),
     "evd_event_loss_bwd": (_I, [_vp, _I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _F, _F, _vp, _fp, _L, _F, _F, _vp, _vp, _vp, _vp, _vp, _vp]),
     "evd_blur_loss_bwd": (_I, [_vp, _I, _vp, _vp, _vp, _vp, _vp, _vp, _L, _I, _fp, _vp, _vp, _vp, _vp, _vp]),
+    "evd_blur_loss_bwd_dev": (_I, [_vp, _I, _vp, _vp, _vp, _vp, _vp, _vp, _L, _I, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "evd_event_loss_bwd_dev": (_I, [_vp, _I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _F, _F, _vp, _fp, _L, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "evd_event_loss_reduce": (_I, [_vp, _I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp, _F, _F, _vp, _fp, _L, _vp, _vp]),
     "evd_numerics_flags": (_I, [C.POINTER(_vp), C.POINTER(C.c_long), _I, _vp, _vp]),
     "evd_edi_deblur": (_I, [_vp, _vp, _I, _L, _vp, _vp]),

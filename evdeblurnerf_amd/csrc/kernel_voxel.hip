@@ -408,9 +408,11 @@ constexpr int VW_SAMPLES = 16;                  // samples per wavefront
 constexpr int VW_WAVES = 4;                     // wavefronts per block
 // LDS slice of one wavefront: tap table, then the coefficient rows [16][ctot + 1] (later the output tile [16][33])
 __host__ __device__ constexpr size_t vw_basis_bytes(int ctot) { return (size_t)32 * (ctot + 1) * 4 + 16 - ((size_t)32 * (ctot + 1) * 4) % 16; }
-__host__ __device__ constexpr size_t vw_slice_bytes(int ctot) { return ((VW_SAMPLES * 3 * sizeof(VsTaps) + (size_t)VW_SAMPLES * (ctot + 1 > 33 ? ctot + 1 : 33) * 4) + 15) & ~(size_t)15; }
-template <bool HALF>
-__global__ __launch_bounds__(64 * VW_WAVES) void k_voxel_sample_w(const GridParams g, const float* __restrict__ pts, long n,
+constexpr int VW_OS = 36;                       // row stride of the output tile in LDS (floats): 16-byte aligned rows
+__host__ __device__ constexpr size_t vw_slice_bytes(int ctot) { return ((VW_SAMPLES * 3 * sizeof(VsTaps) + (size_t)VW_SAMPLES * (ctot + 1 > VW_OS ? ctot + 1 : VW_OS) * 4) + 15) & ~(size_t)15; }
+// OCC: wavefronts per SIMD the kernel is compiled for (registers <= 512 / OCC)
+template <bool HALF, int OCC>
+__global__ __launch_bounds__(64 * VW_WAVES, OCC) void k_voxel_sample_w(const GridParams g, const float* __restrict__ pts, long n,
                                                                 float* __restrict__ out, int out_stride, int out_col) {
     extern __shared__ __attribute__((aligned(16))) char vw_smem[];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -536,25 +538,62 @@ __global__ __launch_bounds__(64 * VW_WAVES) void k_voxel_sample_w(const GridPara
     const float* b0 = bs + min(col, g.app_dim - 1) * cstride + kh;
     const float* b1 = bs + min(16 + col, g.app_dim - 1) * cstride + kh;
     const float* cf = coef + col * cstride + kh;
-    // (hipcc refuses the unroll -- ctot is a runtime value -- and every step waits for its own three LDS reads; reading the operands of four
-    // steps together was measured: 0.139 -> 0.143 ms per 2^19 samples, the other wavefronts of the SIMD already fill those waits)
-#pragma unroll 4
-    for (int kk = 0; kk < ctot; kk += 4) {
-        const float c = cf[kk];
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[kk], c, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[kk], c, acc[1], 0, 0, 0);
+    // The k loop runs in groups of four steps (ctot is a multiple of 8; a last half group where it is not one of 16): the twelve LDS
+    // operands of the NEXT group are read before the eight MFMAs of the current one are issued, so the matrix core never waits for a
+    // ds_read (in-kernel stamps, 16 samples: 4.2 k cycles for this phase with every step waiting for its own three reads).
+    {
+        float pb0[4], pb1[4], pc[4];
+        auto fetch = [&](int kk, int cnt) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < cnt) { pb0[j] = b0[kk + 4 * j]; pb1[j] = b1[kk + 4 * j]; pc[j] = cf[kk + 4 * j]; }
+        };
+        int kk = 0;
+        fetch(0, ctot >= 16 ? 4 : ctot / 4);
+        for (; kk + 16 <= ctot; kk += 16) {
+            float cb0[4], cb1[4], cc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { cb0[j] = pb0[j]; cb1[j] = pb1[j]; cc[j] = pc[j]; }
+            const int left = ctot - (kk + 16);
+            if (left > 0) fetch(kk + 16, left >= 16 ? 4 : left / 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(cb0[j], cc[j], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cb1[j], cc[j], acc[1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j)                          // the half group (its operands are in the prefetch registers)
+            if (kk + 4 * j < ctot) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pb0[j], pc[j], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pb1[j], pc[j], acc[1], 0, 0, 0);
+            }
     }
     VS_STAMP(3);
-    __builtin_amdgcn_wave_barrier();             // every lane has read its coefficients: the slice becomes the output tile [16][33]
+    __builtin_amdgcn_wave_barrier();             // every lane has read its coefficients: the slice becomes the output tile [16][VW_OS]
 #pragma unroll
-    for (int tile = 0; tile < 2; ++tile)
+    for (int tile = 0; tile < 2; ++tile) {
+        f32x4 v;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) coef[col * 33 + 16 * tile + 4 * kh + r] = (16 * tile + 4 * kh + r) < g.app_dim ? act(g.app_act, acc[tile][r]) : 0.f;
+        for (int r = 0; r < 4; ++r) v[r] = (16 * tile + 4 * kh + r) < g.app_dim ? act(g.app_act, acc[tile][r]) : 0.f;
+        *reinterpret_cast<f32x4*>(&coef[col * VW_OS + 16 * tile + 4 * kh]) = v;      // rows of 36 floats: 16-byte aligned
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    for (int t = lane; t < VW_SAMPLES * 32; t += 64) {
-        const int sl = t >> 5, f = t & 31;
-        if (s0 + sl < n && f < g.app_dim) out[(s0 + sl) * (long)out_stride + out_col + f] = coef[sl * 33 + f];
+    if (g.app_dim == 32) {                        // a lane stores 8 consecutive features of a sample: 128-byte runs per sample row, two 16-byte
+        const int sl = lane >> 2, f0 = 8 * (lane & 3);      // stores per lane (the rows of the level's input matrix are only 4-byte aligned)
+        if (s0 + sl < n) {
+            typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+            const f32x4 a = *reinterpret_cast<const f32x4*>(&coef[sl * VW_OS + f0]), b = *reinterpret_cast<const f32x4*>(&coef[sl * VW_OS + f0 + 4]);
+            float* o = out + (s0 + sl) * (long)out_stride + out_col + f0;
+            *reinterpret_cast<f32x4u*>(o) = a;
+            *reinterpret_cast<f32x4u*>(o + 4) = b;
+        }
+    } else {
+        for (int t = lane; t < VW_SAMPLES * 32; t += 64) {
+            const int sl = t >> 5, f = t & 31;
+            if (s0 + sl < n && f < g.app_dim) out[(s0 + sl) * (long)out_stride + out_col + f] = coef[sl * VW_OS + f];
+        }
     }
     VS_STAMP(4);
     VS_STAMP(5); VS_STAMP(6); VS_STAMP(7);
@@ -1496,8 +1535,11 @@ int launch_voxel_sample(const GridParams& g, bool half_grids, const float* pts, 
         const unsigned blocks = (unsigned)cdiv(n, (long)VW_SAMPLES * VW_WAVES);
         const int ct = g.n_comp[0] + g.n_comp[1] + g.n_comp[2];
         const size_t lds = vw_basis_bytes(ct) + VW_WAVES * vw_slice_bytes(ct);
-        if (half_grids) k_voxel_sample_w<true><<<blocks, 64 * VW_WAVES, lds, st>>>(g, pts, n, out, out_stride, out_col);
-        else k_voxel_sample_w<false><<<blocks, 64 * VW_WAVES, lds, st>>>(g, pts, n, out, out_stride, out_col);
+        // float32 grids: 174 registers by default = two blocks per CU; compiled for three (168 registers, 5 spilled) -- EVD_VW_F32_OCC=2 selects the former
+        static const bool occ2 = []{ const char* e = getenv("EVD_VW_F32_OCC"); return e && e[0] == '2'; }();
+        if (half_grids) k_voxel_sample_w<true, 4><<<blocks, 64 * VW_WAVES, lds, st>>>(g, pts, n, out, out_stride, out_col);
+        else if (occ2) k_voxel_sample_w<false, 2><<<blocks, 64 * VW_WAVES, lds, st>>>(g, pts, n, out, out_stride, out_col);
+        else k_voxel_sample_w<false, 3><<<blocks, 64 * VW_WAVES, lds, st>>>(g, pts, n, out, out_stride, out_col);
         EVD_LAUNCH_CHECK();
         return EVD_OK;
     }

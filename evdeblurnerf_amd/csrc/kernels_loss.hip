@@ -178,8 +178,9 @@ __global__ __launch_bounds__(64) void k_blur_loss_bwd(const CrfParams crf, int s
                                                       const float* __restrict__ rgb0_p, const float* __restrict__ w1,
                                                       const float* __restrict__ w2, const float* __restrict__ tgt,
                                                       const float* __restrict__ tgt0, long R, int P, float g0, float g1, float g2,
-                                                      float g3, float g4, float* __restrict__ d_rgb_p, float* __restrict__ d_rgb0_p,
-                                                      float* __restrict__ d_w1, float* __restrict__ d_w2) {
+                                                      float g3, float g4, const float* __restrict__ gdev, float* __restrict__ d_rgb_p,
+                                                      float* __restrict__ d_rgb0_p, float* __restrict__ d_w1, float* __restrict__ d_w2) {
+    if (gdev) { g0 = gdev[0]; g1 = gdev[1]; g2 = gdev[2]; g3 = gdev[3]; g4 = gdev[4]; }      // dL/d partial from device memory (no host copy)
     const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
     const long r = idx / 3;
     const int ch = (int)(idx % 3);
@@ -294,10 +295,11 @@ __global__ __launch_bounds__(256) void k_event_loss_bwd(const CrfParams crf, int
                                                         const float* __restrict__ cum_neg, const float* __restrict__ cum_pos,
                                                         float thr_neg, float thr_pos, const unsigned char* __restrict__ cmask,
                                                         float cw0, float cw1, float cw2, int has_cw, long N, float g_f, float g_c,
-                                                        float* __restrict__ d_start, float* __restrict__ d_end,
+                                                        const float* __restrict__ gdev, float* __restrict__ d_start, float* __restrict__ d_end,
                                                         float* __restrict__ d_start0, float* __restrict__ d_end0,
                                                         float* __restrict__ d_params) {
     __shared__ float pacc[CRF_NPARAM];
+    if (gdev) { g_f = gdev[0]; g_c = gdev[1]; }
     for (int i = threadIdx.x; i < CRF_NPARAM; i += blockDim.x) pacc[i] = 0.f;
     __syncthreads();
     const int lane = threadIdx.x & 63, sub = threadIdx.x & 15, which = sub >> 2, c = sub & 3;
@@ -700,19 +702,35 @@ int evd_blur_loss_reduce(const evd_crf* crf_rgb, int skip_learn, const float* rg
     return EVD_OK;
 }
 
-int evd_blur_loss_bwd(const evd_crf* crf_rgb, int skip_learn, const float* rgb_p, const float* rgb0_p, const float* w1, const float* w2,
-                      const float* tgt, const float* tgt0, long R, int P, const float* g_partial, float* d_rgb_p, float* d_rgb0_p,
-                      float* d_w1, float* d_w2, void* stream) {
-    EVD_REQUIRE(crf_rgb && rgb_p && w1 && tgt && g_partial && d_rgb_p && R >= 0 && P >= 1, "evd_blur_loss_bwd: bad arguments");
+static int blur_loss_bwd(const evd_crf* crf_rgb, int skip_learn, const float* rgb_p, const float* rgb0_p, const float* w1, const float* w2,
+                         const float* tgt, const float* tgt0, long R, int P, const float* g_partial, const float* g_dev, float* d_rgb_p,
+                         float* d_rgb0_p, float* d_w1, float* d_w2, void* stream) {
+    EVD_REQUIRE(crf_rgb && rgb_p && w1 && tgt && (g_partial || g_dev) && d_rgb_p && R >= 0 && P >= 1, "evd_blur_loss_bwd: bad arguments");
     EVD_REQUIRE(crf_rgb->p.map_type != 2 || skip_learn, "evd_blur_loss_bwd: learnable CRF on the image branch is not built (shipped configs: gamma / none)");
     if (R == 0) return EVD_OK;
     hipStream_t st = as_stream(stream);
     if (d_w1) EVD_HIP(hipMemsetAsync(d_w1, 0, sizeof(float) * (size_t)R * P, st));
     if (d_w2) EVD_HIP(hipMemsetAsync(d_w2, 0, sizeof(float) * (size_t)R * P, st));
-    k_blur_loss_bwd<<<cdiv(3 * R, 64), 64, 0, st>>>(crf_rgb->p, skip_learn, rgb_p, rgb0_p, w1, w2, tgt, tgt0, R, P, g_partial[0], g_partial[1],
-                                                    g_partial[2], g_partial[3], g_partial[4], d_rgb_p, rgb0_p ? d_rgb0_p : nullptr, d_w1, d_w2);
+    const float zero5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const float* g = g_partial ? g_partial : zero5;
+    k_blur_loss_bwd<<<cdiv(3 * R, 64), 64, 0, st>>>(crf_rgb->p, skip_learn, rgb_p, rgb0_p, w1, w2, tgt, tgt0, R, P, g[0], g[1], g[2], g[3], g[4], g_dev,
+                                                    d_rgb_p, rgb0_p ? d_rgb0_p : nullptr, d_w1, d_w2);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
+}
+
+int evd_blur_loss_bwd(const evd_crf* crf_rgb, int skip_learn, const float* rgb_p, const float* rgb0_p, const float* w1, const float* w2,
+                      const float* tgt, const float* tgt0, long R, int P, const float* g_partial, float* d_rgb_p, float* d_rgb0_p,
+                      float* d_w1, float* d_w2, void* stream) {
+    EVD_REQUIRE(g_partial, "evd_blur_loss_bwd: bad arguments");
+    return blur_loss_bwd(crf_rgb, skip_learn, rgb_p, rgb0_p, w1, w2, tgt, tgt0, R, P, g_partial, nullptr, d_rgb_p, d_rgb0_p, d_w1, d_w2, stream);
+}
+
+int evd_blur_loss_bwd_dev(const evd_crf* crf_rgb, int skip_learn, const float* rgb_p, const float* rgb0_p, const float* w1, const float* w2,
+                          const float* tgt, const float* tgt0, long R, int P, const float* g_partial_dev, float* d_rgb_p, float* d_rgb0_p,
+                          float* d_w1, float* d_w2, void* stream) {
+    EVD_REQUIRE(g_partial_dev, "evd_blur_loss_bwd_dev: bad arguments");
+    return blur_loss_bwd(crf_rgb, skip_learn, rgb_p, rgb0_p, w1, w2, tgt, tgt0, R, P, nullptr, g_partial_dev, d_rgb_p, d_rgb0_p, d_w1, d_w2, stream);
 }
 
 int evd_event_loss_reduce(const evd_crf* crf_ev, int skip_learn, int add_bii_feat, int tonemap_only,
@@ -769,11 +787,11 @@ int evd_crf_load_params(evd_crf* c, const float* host) {
     return EVD_OK;
 }
 
-int evd_event_loss_bwd(const evd_crf* crf_ev, int skip_learn, int add_bii_feat, int tonemap_only,
-                       const float* start, const float* end, const float* start0, const float* end0,
-                       const float* cum_neg, const float* cum_pos, float thr_neg, float thr_pos,
-                       const unsigned char* color_mask, const float* color_weight, long N, float g_fine, float g_coarse,
-                       float* d_start, float* d_end, float* d_start0, float* d_end0, float* d_params, void* stream) {
+static int event_loss_bwd(const evd_crf* crf_ev, int skip_learn, int add_bii_feat, int tonemap_only,
+                          const float* start, const float* end, const float* start0, const float* end0,
+                          const float* cum_neg, const float* cum_pos, float thr_neg, float thr_pos,
+                          const unsigned char* color_mask, const float* color_weight, long N, float g_fine, float g_coarse, const float* g_dev,
+                          float* d_start, float* d_end, float* d_start0, float* d_end0, float* d_params, void* stream) {
     EVD_REQUIRE(crf_ev && start && end && cum_neg && cum_pos && d_start && d_end && N >= 0, "evd_event_loss_bwd: bad arguments");
     EVD_REQUIRE(add_bii_feat >= 0 && add_bii_feat <= 2, "evd_event_loss_bwd: add_bii_feat %d", add_bii_feat);
     EVD_REQUIRE(!color_mask || tonemap_only, "evd_event_loss_bwd: a colour mask needs tonemap_only");
@@ -783,10 +801,29 @@ int evd_event_loss_bwd(const evd_crf* crf_ev, int skip_learn, int add_bii_feat, 
     if (N == 0) return EVD_OK;
     const float c0 = color_weight ? color_weight[0] : 1.f, c1 = color_weight ? color_weight[1] : 1.f, c2 = color_weight ? color_weight[2] : 1.f;
     k_event_loss_bwd<<<cdiv(N, 16), 256, 0, st>>>(crf_ev->p, skip_learn, add_bii_feat, tonemap_only, start, end, start0, end0, cum_neg, cum_pos,
-                                                  thr_neg, thr_pos, color_mask, c0, c1, c2, color_weight != nullptr, N, g_fine, g_coarse,
+                                                  thr_neg, thr_pos, color_mask, c0, c1, c2, color_weight != nullptr, N, g_fine, g_coarse, g_dev,
                                                   d_start, d_end, (start0 && end0) ? d_start0 : nullptr, (start0 && end0) ? d_end0 : nullptr, d_params);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
+}
+
+int evd_event_loss_bwd(const evd_crf* crf_ev, int skip_learn, int add_bii_feat, int tonemap_only,
+                       const float* start, const float* end, const float* start0, const float* end0,
+                       const float* cum_neg, const float* cum_pos, float thr_neg, float thr_pos,
+                       const unsigned char* color_mask, const float* color_weight, long N, float g_fine, float g_coarse,
+                       float* d_start, float* d_end, float* d_start0, float* d_end0, float* d_params, void* stream) {
+    return event_loss_bwd(crf_ev, skip_learn, add_bii_feat, tonemap_only, start, end, start0, end0, cum_neg, cum_pos, thr_neg, thr_pos, color_mask,
+                          color_weight, N, g_fine, g_coarse, nullptr, d_start, d_end, d_start0, d_end0, d_params, stream);
+}
+
+int evd_event_loss_bwd_dev(const evd_crf* crf_ev, int skip_learn, int add_bii_feat, int tonemap_only,
+                           const float* start, const float* end, const float* start0, const float* end0,
+                           const float* cum_neg, const float* cum_pos, float thr_neg, float thr_pos,
+                           const unsigned char* color_mask, const float* color_weight, long N, const float* g_partial_dev,
+                           float* d_start, float* d_end, float* d_start0, float* d_end0, float* d_params, void* stream) {
+    EVD_REQUIRE(g_partial_dev, "evd_event_loss_bwd_dev: bad arguments");
+    return event_loss_bwd(crf_ev, skip_learn, add_bii_feat, tonemap_only, start, end, start0, end0, cum_neg, cum_pos, thr_neg, thr_pos, color_mask,
+                          color_weight, N, 0.f, 0.f, g_partial_dev, d_start, d_end, d_start0, d_end0, d_params, stream);
 }
 
 int evd_awp_feature_integration(const float* feat, const float* z, const float* rays_d, long N, int S, int C, float* out, void* stream) {

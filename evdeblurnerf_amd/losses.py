@@ -73,14 +73,14 @@ class _BlurLoss(torch.autograd.Function):
         ts = [t.contiguous().float() if h else None for t, h in zip(ctx.saved_tensors, ctx.has)]
         rgb_p, rgb0_p, w1, w2, target, target_pts0 = ts
         R, P = w1.shape
-        g = np.ascontiguousarray(g_partial.detach().float().cpu().numpy()[:5], dtype=np.float32)     # 5 scalars: one small D2H copy
+        g = g_partial.detach().float().contiguous()              # dL/d partial stays on the device: no host copy in the backward
         d_rgb = torch.empty_like(rgb_p)
         d_rgb0 = torch.empty_like(rgb0_p) if rgb0_p is not None else None
         d_w1 = torch.empty_like(w1)
         d_w2 = torch.empty_like(w2) if w2 is not None else None
-        L.check(L.lib().evd_blur_loss_bwd(ctx.crf.handle, int(ctx.skip), L.ptr(rgb_p), L.ptr(rgb0_p), L.ptr(w1), L.ptr(w2), L.ptr(target),
-                                          L.ptr(target_pts0), R, P, g.ctypes.data_as(C.POINTER(C.c_float)), L.ptr(d_rgb), L.ptr(d_rgb0),
-                                          L.ptr(d_w1), L.ptr(d_w2), L.stream_ptr()), "evd_blur_loss_bwd")
+        L.check(L.lib().evd_blur_loss_bwd_dev(ctx.crf.handle, int(ctx.skip), L.ptr(rgb_p), L.ptr(rgb0_p), L.ptr(w1), L.ptr(w2), L.ptr(target),
+                                              L.ptr(target_pts0), R, P, L.ptr(g), L.ptr(d_rgb), L.ptr(d_rgb0),
+                                              L.ptr(d_w1), L.ptr(d_w2), L.stream_ptr()), "evd_blur_loss_bwd_dev")
         return None, None, d_rgb, d_rgb0, d_w1, d_w2, None, None
 
 
@@ -90,19 +90,29 @@ def blur_loss_partials_autograd(crf_rgb, rgb_p, w1, target, rgb0_p=None, w2=None
     return _BlurLoss.apply(crf_rgb, skip_learn_crf, c(rgb_p), c(rgb0_p), c(w1), c(w2), c(target), c(target_pts0))
 
 
+_COEF = {}
+
+
+def _coef(device, values):
+    """constant coefficient vector on the device, made once per (device, values)"""
+    key = (str(device), tuple(float(v) for v in values))
+    c = _COEF.get(key)
+    if c is None:
+        c = _COEF[key] = torch.tensor(key[1], dtype=torch.float32, device=device)
+    return c
+
+
 def blur_loss_from_partials(p, fine_loss_weight=None, w_pts0=0.0):
-    """Assemble run_nerf.py:451-497 from the (all-reduced) partial vector. Returns (loss, dict of terms)."""
-    n = p[5]
-    img = p[0] / n + p[1] / n
-    terms = {"img_loss": img}
-    loss = img
+    """Assemble run_nerf.py:451-497 from the (all-reduced) partial vector. Returns (loss, dict of terms).
+    loss = ((img + img0) (1 - flw) + fine flw + (pts0 + pts0_0) w_pts0) / n as ONE dot product with a constant coefficient vector (three
+    launches forward, instead of a dozen 0-dim tensor operations and their backward nodes); the terms are detached views for logging."""
+    flw = 0.0 if fine_loss_weight is None else float(fine_loss_weight)
+    c = _coef(p.device, (1.0 - flw, 1.0 - flw, flw, float(w_pts0), float(w_pts0)))
+    loss = (p[:5] * c).sum() / p.detach()[5]                 # the count is a constant of the batch
+    t = p.detach()[:5] / p.detach()[5]
+    terms = {"img_loss": t[0] + t[1], "pts0": t[3] + t[4]}
     if fine_loss_weight is not None:
-        fine = p[2] / n
-        terms["img_fine_loss"] = fine
-        loss = loss * (1 - fine_loss_weight) + fine * fine_loss_weight
-    pts0 = p[3] / n + p[4] / n
-    terms["pts0"] = pts0
-    loss = loss + pts0 * w_pts0
+        terms["img_fine_loss"] = t[2]
     return loss, terms
 
 
@@ -150,18 +160,18 @@ class _EventLoss(torch.autograd.Function):
         crf_ev, thr_neg, thr_pos, mode, tonemap_only, cw, skip, have0 = ctx.args
         start, end, start0, end0, cum_neg, cum_pos, cm = ctx.saved_tensors
         N = start.shape[0]
-        g = g_partial.detach().float().cpu().numpy()
+        g = g_partial.detach().float().contiguous()              # stays on the device
         d_start, d_end = torch.zeros_like(start), torch.zeros_like(end)
         d_start0 = torch.zeros_like(start0) if have0 else None
         d_end0 = torch.zeros_like(end0) if have0 else None
         d_params = torch.empty((int(L.lib().evd_crf_param_count()),), dtype=torch.float32, device=start.device)
         cwa = np.ascontiguousarray(cw, dtype=np.float32) if cw is not None else None
-        L.check(L.lib().evd_event_loss_bwd(crf_ev.handle, int(skip), mode, int(tonemap_only), L.ptr(start), L.ptr(end),
-                                           L.ptr(start0) if have0 else None, L.ptr(end0) if have0 else None, L.ptr(cum_neg), L.ptr(cum_pos),
-                                           thr_neg, thr_pos, L.ptr(cm) if ctx.has_cm else None,
-                                           cwa.ctypes.data_as(C.POINTER(C.c_float)) if cwa is not None else None, N, float(g[0]), float(g[1]),
-                                           L.ptr(d_start), L.ptr(d_end), L.ptr(d_start0), L.ptr(d_end0), L.ptr(d_params), L.stream_ptr()),
-                "evd_event_loss_bwd")
+        L.check(L.lib().evd_event_loss_bwd_dev(crf_ev.handle, int(skip), mode, int(tonemap_only), L.ptr(start), L.ptr(end),
+                                               L.ptr(start0) if have0 else None, L.ptr(end0) if have0 else None, L.ptr(cum_neg), L.ptr(cum_pos),
+                                               thr_neg, thr_pos, L.ptr(cm) if ctx.has_cm else None,
+                                               cwa.ctypes.data_as(C.POINTER(C.c_float)) if cwa is not None else None, N, L.ptr(g),
+                                               L.ptr(d_start), L.ptr(d_end), L.ptr(d_start0), L.ptr(d_end0), L.ptr(d_params), L.stream_ptr()),
+                "evd_event_loss_bwd_dev")
         return (None, d_params, d_start, d_end, d_start0, d_end0) + (None,) * 9
 
 
@@ -195,12 +205,13 @@ def crf_param_grads(flat, extra_features):
 
 def event_loss_from_partials(p, stages=("stage0", "stage1")):
     """extra_loss['event_egm'] of run_nerf.py:559-572 from the (all-reduced) partials."""
-    loss = 0.0
+    if "stage0" in stages and "stage1" in stages:
+        return p[:2].sum() / p.detach()[2]                   # sum of the event weights: a constant of the batch
     if "stage0" in stages:
-        loss = loss + p[1] / p[2]
+        return p[1] / p.detach()[2]
     if "stage1" in stages:
-        loss = loss + p[0] / p[2]
-    return loss
+        return p[0] / p.detach()[2]
+    return 0.0
 
 
 def img2mse(x, y):

@@ -50,6 +50,7 @@ class CRF:
 
     @property
     def handle(self):
+        self._take_pending()
         return self._h
 
     @staticmethod
@@ -90,13 +91,30 @@ class CRF:
     def flat_params(self, device="cuda"):
         n = int(L.lib().evd_crf_param_count())
         host = np.zeros((n,), np.float32)
-        L.check(L.lib().evd_crf_get_params(self._h, host.ctypes.data_as(C.c_void_p)), "evd_crf_get_params")
+        L.check(L.lib().evd_crf_get_params(self.handle, host.ctypes.data_as(C.c_void_p)), "evd_crf_get_params")
         return torch.tensor(host, device=device, requires_grad=True)
 
-    def load_params(self, flat):
-        """after optimizer.step(): 2.8 KB device -> host (the handle keeps the parameters on the host: one small synchronising copy)"""
-        host = np.ascontiguousarray(flat.detach().cpu().numpy(), dtype=np.float32)
-        L.check(L.lib().evd_crf_load_params(self._h, host.ctypes.data_as(C.c_void_p)), "evd_crf_load_params")
+    def load_params(self, flat, blocking=False):
+        """after optimizer.step(): 2.8 KB device -> host (the handle keeps the parameters on the host: they travel as a kernel argument).
+        The copy is queued into pinned memory and the handle takes the values at its NEXT use (``handle``), when the copy has long
+        completed: the training loop's stream is not drained after every optimizer step.  blocking=True copies at once."""
+        if blocking or not flat.is_cuda:
+            host = np.ascontiguousarray(flat.detach().cpu().numpy(), dtype=np.float32)
+            L.check(L.lib().evd_crf_load_params(self._h, host.ctypes.data_as(C.c_void_p)), "evd_crf_load_params")
+            self._pending = None
+            return
+        if getattr(self, "_pin", None) is None or self._pin.numel() != flat.numel():
+            self._pin = torch.empty(flat.numel(), dtype=torch.float32, pin_memory=True)
+            self._pin_ev = torch.cuda.Event()
+        self._pin.copy_(flat.detach().reshape(-1), non_blocking=True)
+        self._pin_ev.record()
+        self._pending = True
+
+    def _take_pending(self):
+        if getattr(self, "_pending", None):
+            self._pin_ev.synchronize()
+            L.check(L.lib().evd_crf_load_params(self._h, C.c_void_p(self._pin.data_ptr())), "evd_crf_load_params")
+            self._pending = None
 
     def forward(self, x, x_feat=None, skip_learn=False, _luma=-1):
         sh = x.shape
@@ -108,7 +126,7 @@ class CRF:
             ft = x_feat.to(xx.dtype).contiguous()
             per_ch = int(ft.ndim == 3)
         out = torch.empty((n, 3 if _luma < 0 else 1), dtype=torch.float32, device=xx.device)
-        L.check(L.lib().evd_crf_forward(self._h, L.ptr(xx), L.ptr(ft), per_ch, int(bool(skip_learn)), _luma, n,
+        L.check(L.lib().evd_crf_forward(self.handle, L.ptr(xx), L.ptr(ft), per_ch, int(bool(skip_learn)), _luma, n,
                                         L.ptr(out), L.stream_ptr()), "evd_crf_forward")
         return out.reshape(*sh[:-1], out.shape[-1])
 

@@ -378,6 +378,10 @@ int evd_blur_loss_reduce(const evd_crf* crf_rgb, int skip_learn, const float* rg
 int evd_blur_loss_bwd(const evd_crf* crf_rgb, int skip_learn, const float* rgb_p, const float* rgb0_p, const float* w1, const float* w2,
                       const float* tgt, const float* tgt0, long R, int P, const float* g_partial, float* d_rgb_p, float* d_rgb0_p,
                       float* d_w1, float* d_w2, void* stream);
+/* the same with dL/d partial read from DEVICE memory (g_partial_dev dev[>=5]): what an autograd node calls, no host copy in the backward */
+int evd_blur_loss_bwd_dev(const evd_crf* crf_rgb, int skip_learn, const float* rgb_p, const float* rgb0_p, const float* w1, const float* w2,
+                          const float* tgt, const float* tgt0, long R, int P, const float* g_partial_dev, float* d_rgb_p, float* d_rgb0_p,
+                          float* d_w1, float* d_w2, void* stream);
 
 /* Fused event-loss reduction (spec: run_nerf.py:518-570, utils/events.py:260-284):
  *   bii = thr_neg*cum_neg + thr_pos*cum_pos;  feat = (cum_neg, cum_pos) per event ("pos-neg") or scattered to the
@@ -407,6 +411,12 @@ int evd_event_loss_bwd(const evd_crf* crf_ev, int skip_learn, int add_bii_feat, 
                        const float* cum_neg, const float* cum_pos, float thr_neg, float thr_pos,
                        const unsigned char* color_mask, const float* color_weight, long N, float g_fine, float g_coarse,
                        float* d_start, float* d_end, float* d_start0, float* d_end0, float* d_params, void* stream);
+/* the same with (g_fine, g_coarse) = g_partial_dev[0], [1] read from DEVICE memory */
+int evd_event_loss_bwd_dev(const evd_crf* crf_ev, int skip_learn, int add_bii_feat, int tonemap_only,
+                           const float* start, const float* end, const float* start0, const float* end0,
+                           const float* cum_neg, const float* cum_pos, float thr_neg, float thr_pos,
+                           const unsigned char* color_mask, const float* color_weight, long N, const float* g_partial_dev,
+                           float* d_start, float* d_end, float* d_start0, float* d_end0, float* d_params, void* stream);
 
 /* AdaptiveWeightProposal.feature_integration, networks/dpnerf/awp.py:49-77 (the compositing scan of the AWP consumer of
  * the path's per-sample features): feat dev [N,S,C] (N = rays x sub-exposures; every channel is its own density),
