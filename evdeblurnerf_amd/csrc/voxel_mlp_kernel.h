@@ -14,7 +14,8 @@ namespace evd {
 // G geo channels and FT feature channels in: what the forward saves, then the gradients the dgrad chain hands to wgrad.
 template <int HD, int G, int FT> struct VStore {
     static constexpr int KS = HD / 16, KF = FT / 16, GT = (G + 31) / 32;
-    static constexpr int IN0 = 0, DIRPE = IN0 + KF + PE_KS, HID = DIRPE + PEV_KS, GEO = HID + KS, C0 = GEO + 2 * GT, C1 = C0 + KS, FWD_END = C1 + KS;
+    // (the direction encoding sits behind the geo fragments: color_net.0's input [geo | PE(dirs)] is one run of fragments for its wgrad)
+    static constexpr int IN0 = 0, HID = IN0 + KF + PE_KS, GEO = HID + KS, DIRPE = GEO + 2 * GT, C0 = DIRPE + PEV_KS, C1 = C0 + KS, FWD_END = C1 + KS;
     // gradient slots; D_GEO is followed by the 2 direction-encoding gradient fragments, D_FTS by the 4 point-encoding ones (both
     // produced by the same dgrad layer as their neighbours, in the encodings' own fragment arrangement)
     static constexpr int G_COL = FWD_END, G_SIG = G_COL + 1, D_C1 = G_SIG + 1, D_C0 = D_C1 + KS, D_GEO = D_C0 + KS, D_DIRPE = D_GEO + 2 * GT,

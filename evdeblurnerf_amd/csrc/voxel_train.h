@@ -13,9 +13,9 @@ enum { VBWD_C2 = 0, VBWD_C1, VBWD_C0, VBWD_SIGGEO, VBWD_L0, VBWD_NSTREAMS };
 enum { VMAP_HID = 0,                    // 256: hidden arrangement 16 j + phi(kk) (-1 beyond the hidden width)
        VMAP_FTS = VMAP_HID + 256,       // 64: input features, natural arrangement 16 j + kk
        VMAP_PE = VMAP_FTS + 64,         // 64: point encoding, behind the FT feature columns
-       VMAP_DIR = VMAP_PE + 64,         // 32: direction encoding, behind the G geo columns
-       VMAP_GEO_X = VMAP_DIR + 32,      // 128: geo channels as color_net.0 columns
-       VMAP_GEO_Y = VMAP_GEO_X + 128,   // 128: geo channels as sigma_net.1 rows (1 + channel)
+       VMAP_GEO_X = VMAP_PE + 64,       // 128: geo channels as color_net.0 columns
+       VMAP_DIR = VMAP_GEO_X + 128,     // 32: direction encoding, behind the G geo columns (adjacent to them when G = 128)
+       VMAP_GEO_Y = VMAP_DIR + 32,      // 128: geo channels as sigma_net.1 rows (1 + channel)
        VMAP_COL = VMAP_GEO_Y + 128,     // 32: d colour fragment
        VMAP_SIG = VMAP_COL + 32,        // 32: d sigma fragment (row 0 of sigma_net.1)
        VMAP_TOTAL = VMAP_SIG + 32 };

@@ -164,8 +164,14 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
     if ((rc = wgrad(launch_wgrad<PREC, T, T, false>, T, T, true, VS::D_C1, VS::C1 - KS, VMAP_HID, VMAP_HID, g.color_w[1], HD, g.color_b[1]))) return rc;
     if ((rc = launch_dgrad<PREC, KS, T, KS, false, 2>(dgrad(VBWD_C1, VS::D_C1, -1, VS::M_C0, VS::D_C0), b.tiles, st))) return rc;
     // color_net.0 on cat([geo, PE(dirs)])
-    if ((rc = wgrad(launch_wgrad<PREC, T, GT, false>, T, GT, true, VS::D_C0, VS::GEO, VMAP_HID, VMAP_GEO_X, g.color_w[0], G + ICV, g.color_b[0]))) return rc;
-    if ((rc = wgrad(launch_wgrad<PREC, T, 1, false>, T, 1, false, VS::D_C0, VS::DIRPE, VMAP_HID, VMAP_DIR, g.color_w[0], G + ICV, nullptr))) return rc;
+    if constexpr (is_half_prec(PREC) && G == 32 * GT) {
+        // geo and direction-encoding columns in ONE launch (adjacent fragments, adjacent index maps): d c0 is read once
+        static_assert(VS::DIRPE == VS::GEO + 2 * GT && VMAP_DIR == VMAP_GEO_X + 128 && (G == 128), "adjacent fragments and column maps");
+        if ((rc = wgrad(launch_wgrad<PREC, T, GT + 1, false>, T, GT + 1, true, VS::D_C0, VS::GEO, VMAP_HID, VMAP_GEO_X, g.color_w[0], G + ICV, g.color_b[0]))) return rc;
+    } else {
+        if ((rc = wgrad(launch_wgrad<PREC, T, GT, false>, T, GT, true, VS::D_C0, VS::GEO, VMAP_HID, VMAP_GEO_X, g.color_w[0], G + ICV, g.color_b[0]))) return rc;
+        if ((rc = wgrad(launch_wgrad<PREC, T, 1, false>, T, 1, false, VS::D_C0, VS::DIRPE, VMAP_HID, VMAP_DIR, g.color_w[0], G + ICV, nullptr))) return rc;
+    }
     if ((rc = launch_dgrad<PREC, KS, GT + 1, KS, false, 0>(dgrad(VBWD_C0, VS::D_C0, -1, -1, VS::D_GEO), b.tiles, st))) return rc;   // d geo | d PE(dirs)
     if (b.d_feature) {          // + the gradient of the geo features as an output of the level (voxnerf.py:221, consumed by AWP)
         if (G % 16) return fail(EVD_E_INVALID, "evd_voxel_mlp_backward: d_feature is built for the fine level (geo 128)");
@@ -190,8 +196,14 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
     if ((rc = wgrad(launch_wgrad<PREC, 1, T, true>, 1, T, false, VS::G_SIG, VS::HID, VMAP_SIG, VMAP_HID, g.sigma_w[1], HD, nullptr))) return rc;
     if ((rc = launch_dgrad<PREC, 2 * GT + 1, T, 2 * GT, true, 2>(dgrad(VBWD_SIGGEO, VS::D_GEO, VS::G_SIG, VS::M_HID, VS::D_HID), b.tiles, st))) return rc;
     // sigma_net.0 on cat([fts, PE(pts)])
-    if ((rc = wgrad(launch_wgrad<PREC, T, FTT, false>, T, FTT, false, VS::D_HID, VS::IN0, VMAP_HID, VMAP_FTS, g.sigma_w[0], FT + IC, nullptr))) return rc;
-    if ((rc = wgrad(launch_wgrad<PREC, T, 2, false>, T, 2, false, VS::D_HID, VS::IN0 + KF, VMAP_HID, VMAP_PE, g.sigma_w[0], FT + IC, nullptr))) return rc;
+    if constexpr (FTT == 2) {
+        // the feature and encoding columns in ONE launch (their fragments and their index maps are adjacent): d hid is read once, not twice
+        static_assert(VMAP_PE == VMAP_FTS + 32 * FTT, "adjacent column maps");
+        if ((rc = wgrad(launch_wgrad<PREC, T, FTT + 2, false>, T, FTT + 2, false, VS::D_HID, VS::IN0, VMAP_HID, VMAP_FTS, g.sigma_w[0], FT + IC, nullptr))) return rc;
+    } else {
+        if ((rc = wgrad(launch_wgrad<PREC, T, FTT, false>, T, FTT, false, VS::D_HID, VS::IN0, VMAP_HID, VMAP_FTS, g.sigma_w[0], FT + IC, nullptr))) return rc;
+        if ((rc = wgrad(launch_wgrad<PREC, T, 2, false>, T, 2, false, VS::D_HID, VS::IN0 + KF, VMAP_HID, VMAP_PE, g.sigma_w[0], FT + IC, nullptr))) return rc;
+    }
     if (b.d_fts || b.d_pts) {
         if ((rc = launch_dgrad<PREC, KS, FTT + 2, KS, false, 0>(dgrad(VBWD_L0, VS::D_HID, -1, -1, VS::D_FTS), b.tiles, st))) return rc;       // d fts | d PE(pts)
         if (b.d_fts) {

@@ -314,10 +314,10 @@ def test_pdrf_level_networks_backward_match_torch_autograd(level, prec, tol):
     loss.backward()
     n = R * S
     KS, KF, GT = HD // 16, FT // 16, (G + 31) // 32
-    IN0, DIRPE = 0, KF + 4
-    HID = DIRPE + 2
+    IN0, HID = 0, KF + 4                  # voxel_mlp_kernel.h VStore: [fts | PE(pts)], hidden, geo, PE(dirs), c0, c1
     GEO = HID + KS
-    C0 = GEO + 2 * GT
+    DIRPE = GEO + 2 * GT
+    C0 = DIRPE + 2
     C1 = C0 + KS
     TILE_FRAGS = C1 + KS + 2 + KS + KS + (2 * GT + 2) + KS + (2 * ((FT + 31) // 32) + 4) + 3   # VStore: + d PE(dirs), + d PE(pts) fragments, + 3 bit-mask fragments
     dt = torch.float16 if prec == "f16" else torch.bfloat16

@@ -175,8 +175,8 @@ def test_f16x3_pdrf_level_backward_matches_float64_autograd(level):
     # kernel's decision (decoded from its store) is taken, as float32 torch would differ from float64 on the same units.  The number
     # of such units is printed and bounded: the comparison stays a true-pattern one.
     KS, KF, GT = HD // 16, FT // 16, (G + 31) // 32
-    HID = KF + 4 + 2
-    C0 = HID + KS + 2 * GT
+    HID = KF + 4                          # voxel_mlp_kernel.h VStore: [fts | PE(pts)], hidden, geo, PE(dirs), c0, c1
+    C0 = HID + KS + 2 * GT + 2
     C1 = C0 + KS
     TILE_FRAGS = C1 + KS + 2 + KS + KS + (2 * GT + 2) + KS + (2 * ((FT + 31) // 32) + 4) + 3
     kmask = {"hid": (decode_split(store, n, TILE_FRAGS, HID, KS) > 0).cpu().double(), "c0": (decode_split(store, n, TILE_FRAGS, C0, KS) > 0).cpu().double(),
