@@ -183,6 +183,38 @@ class SampleFeatureEmbed:
         return _SampleEmbed.apply(geo, flat, self, None)
 
 
+class _SplitKLinear(torch.autograd.Function):
+    """y = x W^T (+ b) for TALL inputs ([rays x positions, <= 64 channels] against a 32..64-wide layer).  The weight gradient of such a layer
+    is a [out, in] = 32 x 64 result summed over 10^4 .. 10^5 rows: the BLAS library runs it on one or two workgroups (measured: 121 us per
+    call, 10 calls = 1.2 of the 2.0 ms the AWP's per-ray remainder took).  Here the rows are cut into up to 256 slabs, one batched product
+    gives the slabs' partial gradients and a sum folds them: two launches of ~10 us."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_b = b is not None
+        return torch.nn.functional.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        g2, x2 = gy.reshape(-1, gy.shape[-1]), x.reshape(-1, x.shape[-1])
+        n = x2.shape[0]
+        dx = (g2 @ w).reshape(x.shape) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            G = 256
+            while G > 1 and (n % G or n // G < 32):
+                G //= 2
+            dw = torch.bmm(g2.reshape(G, n // G, -1).transpose(1, 2), x2.reshape(G, n // G, -1)).sum(0) if G > 1 else g2.t() @ x2
+        db = g2.sum(0) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        return dx, dw, db
+
+
+def _lin(x, w, b=None):
+    return _SplitKLinear.apply(x, w, b)
+
+
 class FusedAWP(torch.nn.Module):
     """Drop-in for the reference's AdaptiveWeightProposal in NeRFAll(awpnet=...): wraps THAT module (its parameters stay where the
     optimizer and the state dict expect them) and runs awp.py:79-117 with the per-sample part on the library:
@@ -227,17 +259,29 @@ class FusedAWP(torch.nn.Module):
         return self._mam_tail(x_global, h_inter, h_intra)
 
     def _mam_tail(self, x_global, h_inter, h_intra):
-        """the per-ray remainder of CorrelationModule.forward (mam.py:35-53) on the wrapped module's own layers"""
+        """the per-ray remainder of CorrelationModule.forward (mam.py:35-53) with the wrapped module's own parameters, CHANNEL-LAST: every
+        Conv1d there has kernel_size 1, i.e. it is a matrix product over the channel axis -- written as such ([R, P or S, C] @ W^T, no
+        transposes, no convolution library: the module's own calls cost ~100 launches of layout shuffles and MIOpen kernels per
+        direction for [1024, 32, 10]-sized tensors).  BatchNorm1d of convd (mam.py:24-27) normalises over (ray, position) per channel:
+        F.batch_norm on the [R P, C] view is the same statistic, running estimates updated in training like the module does."""
         corr, lin = self.ref.MAM.Corr, self.ref.MAM.linear
         F = torch.nn.functional
-        k_inter = corr.conva(F.linear(h_inter, lin.weight, lin.bias).transpose(1, 2))         # [R, mid, P]
-        k_intra = corr.convb(F.linear(h_intra, lin.weight, lin.bias).transpose(1, 2))         # [R, mid, S]
-        x = x_global.transpose(1, 2)                                                          # [R, C, P]
-        q = corr.convc(x).transpose(1, 2)
-        a_inter = torch.softmax(torch.bmm(q, k_inter), dim=-1)
-        a_intra = torch.softmax(torch.bmm(q, k_intra), dim=-1)
-        f = torch.cat([torch.bmm(a_inter, corr.convn(k_inter).transpose(1, 2)), torch.bmm(a_intra, corr.convl(k_intra).transpose(1, 2))], dim=-1)
-        return F.leaky_relu(x + corr.convd(f.transpose(1, 2)), negative_slope=0.2).transpose(1, 2)
+        w = lambda conv: conv.weight.squeeze(-1)                                              # [out, in, 1] -> [out, in]
+        k_inter = _lin(_lin(h_inter, lin.weight, lin.bias), w(corr.conva))                    # [R, P, mid]
+        k_intra = _lin(_lin(h_intra, lin.weight, lin.bias), w(corr.convb))                    # [R, S, mid]
+        q = _lin(x_global, w(corr.convc))                                                     # [R, P, mid]
+        a_inter = torch.softmax(torch.bmm(q, k_inter.transpose(1, 2)), dim=-1)                # [R, P, P]
+        a_intra = torch.softmax(torch.bmm(q, k_intra.transpose(1, 2)), dim=-1)                # [R, P, S]
+        f = torch.cat([torch.bmm(a_inter, _lin(k_inter, w(corr.convn))), torch.bmm(a_intra, _lin(k_intra, w(corr.convl)))], dim=-1)
+        y = _lin(f, w(corr.convd[0]))                                                         # [R, P, C]
+        bn = corr.convd[1]
+        training = bn.training or bn.running_mean is None
+        if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        mom = bn.momentum if bn.momentum is not None else (1.0 / float(bn.num_batches_tracked) if bn.training and bn.track_running_stats else 0.0)
+        y = F.batch_norm(y.reshape(-1, y.shape[-1]), bn.running_mean if (not bn.training or bn.track_running_stats) else None,
+                         bn.running_var if (not bn.training or bn.track_running_stats) else None, bn.weight, bn.bias, training, mom, bn.eps).reshape(y.shape)
+        return F.leaky_relu(x_global + y, negative_slope=0.2)
 
     def forward(self, depth_feature, z_vals, rays_d, view_feature):
         m, P = self.ref, self.output_ch
@@ -264,9 +308,9 @@ class FusedAWP(torch.nn.Module):
         m = self.ref
         h = torch.cat([h, view.unsqueeze(1).repeat(1, P, 1)], dim=-1)
         for layer in m.motion_feature_embed_layer:                                # awp.py:107-109
-            h = torch.relu(layer(h))
+            h = torch.relu(_lin(h, layer.weight, layer.bias) if isinstance(layer, torch.nn.Linear) else layer(h))
         h = self._mam(h, h_local, n_ray, P, S) if h_inter is None else self._mam_tail(h, h_inter, h_intra)      # awp.py:111
-        h = torch.nn.functional.adaptive_avg_pool1d(h.transpose(1, 2), 1).squeeze(-1)
+        h = h.mean(dim=1)                                                         # adaptive_avg_pool1d over the P positions (awp.py:112)
         w = torch.sigmoid(m.w_linear(h))
         return w / torch.sum(w, -1, keepdim=True)
 

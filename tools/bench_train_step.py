@@ -51,7 +51,8 @@ def main():
     ap.add_argument("--awp", choices=["none", "fused", "torch"], default="none",
                     help="the shipped configs' adaptive weight proposal on the blur batch (kernel_use_awp): fused = evdeblurnerf_amd.awp.FusedAWP around a "
                          "module with the reference's surface (tools/awp_standin.py), torch = that module's plain PyTorch forward on depth_feature")
-    ap.add_argument("--no-graph", action="store_true", help="--awp fused: the per-ray remainder of the AWP module eagerly instead of as a captured hipGraph")
+    ap.add_argument("--graph", action="store_true", help="--awp fused: the per-ray remainder of the AWP module as a captured hipGraph each way (measured slower than eager)")
+    ap.add_argument("--no-graph", action="store_true", help="(the default now; kept for old command lines)")
     ap.add_argument("--plain-autograd", action="store_true",
                     help="parameter / grid gradients returned to autograd (the library's default) instead of accumulated in place by the backward kernels "
                          "(NeRFAll.enable_training(grads_in_place=True): what a run_nerf.py-style loop opts into)")
@@ -81,9 +82,9 @@ def run(a):
     if awp_mode != "none":
         from awp_standin import RefLikeAWP
         from evdeblurnerf_amd.awp import FusedAWP
-        awpnet = RefLikeAWP(P=a.P, view_ch=4, mam=getattr(a, "mam", "mean")).to(dev)
+        awpnet = RefLikeAWP(P=a.P, view_ch=4, mam=getattr(a, "mam", "corr")).to(dev)
         if awp_mode == "fused":
-            awpnet = FusedAWP(awpnet, precision=a.precision if a.precision in ("f16", "bf16") else "f16", graph_per_ray=not getattr(a, "no_graph", False))
+            awpnet = FusedAWP(awpnet, precision=a.precision if a.precision in ("f16", "bf16") else "f16", graph_per_ray=bool(getattr(a, "graph", False)))
     model = NeRFAll(args, sd, kernelsnet=kern, awpnet=awpnet, precision=a.precision).enable_training(sd, grads_in_place=not getattr(a, "plain_autograd", False)).train()
     model.use_awp = awpnet is not None
     crf_rgb = CRF("gamma")
