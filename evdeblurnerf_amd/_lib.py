@@ -227,3 +227,19 @@ def ptr(t):
 def stream_ptr():
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# Generation counter of the training path: every backward of the library's autograd nodes bumps it, and the parameter / grid re-pack checks
+# (nerf.py, voxnerf.py) treat "a backward ran since the last re-pack" like a changed tensor version.  tensor._version alone is not enough:
+# torch.optim.Adam(fused=True) updates the parameters WITHOUT bumping their version counters, and a library that went on rendering with
+# its stale packed copies would train nothing, silently.
+_BACKWARD_GEN = [0]
+
+
+def backward_generation():
+    return _BACKWARD_GEN[0]
+
+
+def note_backward():
+    _BACKWARD_GEN[0] += 1
+

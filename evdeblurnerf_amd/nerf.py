@@ -79,6 +79,7 @@ class _NerfMLP(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_raw):
+        L.note_backward()
         d_rb = None
         acc = ctx.accum() if (ctx.accum is not None and ctx.needs_input_grad[0] and not torch.is_grad_enabled()) else None
         if ctx.needs_input_grad[1]:
@@ -234,11 +235,11 @@ class NeRF:
         if f.numel() != self._nparam:
             raise L.EvdError(f"flat parameter tensor has {f.numel()} elements, the network {self._nparam}")
         L.check(L.lib().evd_nerf_load_params(self._h, L.ptr(f), L.stream_ptr()), "evd_nerf_load_params")
-        self._synced = (flat.data_ptr(), flat._version)
+        self._synced = (flat.data_ptr(), flat._version, L.backward_generation())
 
     def mlp_train(self, flat, ray_batch, z_vals, precision=None):
         """NeRF.mlpforward for training: raw [R,S,4] with autograd back to the flat parameter tensor (rays are constants)"""
-        if getattr(self, "_synced", None) != (flat.data_ptr(), flat._version):
+        if getattr(self, "_synced", None) != (flat.data_ptr(), flat._version, L.backward_generation()):
             self.load_params(flat)
         return _NerfMLP.apply(flat, ray_batch, z_vals, self, precision or self.precision)
 

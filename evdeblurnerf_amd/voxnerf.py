@@ -76,6 +76,7 @@ class _VoxelSample(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_out):
+        L.note_backward()
         net, pts = ctx.net, ctx.pts.reshape(-1, 3).contiguous().float()
         g = d_out.reshape(-1, net.app_dim).contiguous().float()
         grads, gs = _grid_grads(net, ctx.saved_tensors, in_place=getattr(net, "_grads_in_place", _GRADS_IN_PLACE) and not torch.is_grad_enabled())
@@ -121,6 +122,7 @@ class _VoxelMLP(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_raw, d_feature=None):
+        L.note_backward()
         need = ctx.needs_input_grad
         if d_raw is None:
             d_raw = torch.zeros_like(ctx.raw)
@@ -147,6 +149,7 @@ class _VoxelTV(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_loss):
+        L.note_backward()
         net = ctx.net
         grads, gs = _grid_grads(net, ctx.saved_tensors, in_place=getattr(net, "_grads_in_place", _GRADS_IN_PLACE) and not torch.is_grad_enabled())
         gs.basis = None
@@ -281,7 +284,7 @@ class VoxelNeRFBase:
         if f.numel() != self._nparam:
             raise L.EvdError(f"flat parameter tensor has {f.numel()} elements, the level {self._nparam}")
         L.check(L.lib().evd_voxel_load_params(self._h, L.ptr(f), L.stream_ptr()), "evd_voxel_load_params")
-        self._synced_net = (flat.data_ptr(), flat._version)
+        self._synced_net = (flat.data_ptr(), flat._version, L.backward_generation())
 
     def mlpforward_train(self, pts, viewdirs, fts, precision=None, want_feature=False):
         p, vd, ft = pts.contiguous().float(), viewdirs.contiguous().float(), fts.contiguous().float()
@@ -329,7 +332,7 @@ class VoxelNeRFBase:
         """raw [R,S,4] = (sigma, sigmoid(colour)) with autograd to the flat parameters, the sampled features and the rays;
         want_feature (fine level): also the per-sample geo features [R,S,geo] (voxnerf.py:221), an autograd output too; a
         GeoFragments instance instead of True: the features stay fragments in the level's store, the second output is its token"""
-        if getattr(self, "_synced_net", None) != (flat.data_ptr(), flat._version):
+        if getattr(self, "_synced_net", None) != (flat.data_ptr(), flat._version, L.backward_generation()):
             self.load_params(flat)
         return _VoxelMLP.apply(flat, fts, pts, viewdirs, self, precision or self.precision, want_feature)
 
@@ -351,10 +354,10 @@ class VoxelNeRFBase:
         ts = [t.detach().contiguous().float() for t in grids]
         pl, li = (C.c_void_p * 3)(*[t.data_ptr() for t in ts[:3]]), (C.c_void_p * 3)(*[t.data_ptr() for t in ts[3:6]])
         L.check(L.lib().evd_voxel_load_grids(self._h, pl, li, L.ptr(ts[6]), L.stream_ptr()), "evd_voxel_load_grids")
-        self._synced = tuple((t.data_ptr(), t._version) for t in grids)
+        self._synced = tuple((t.data_ptr(), t._version) for t in grids) + (L.backward_generation(),)
 
     def _sync(self, grids):
-        if getattr(self, "_synced", None) != tuple((t.data_ptr(), t._version) for t in grids):
+        if getattr(self, "_synced", None) != tuple((t.data_ptr(), t._version) for t in grids) + (L.backward_generation(),):
             self.load_grids(grids)
 
     def sample_train(self, pts, grids, precision=None):

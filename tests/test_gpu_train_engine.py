@@ -118,3 +118,31 @@ def test_leaves_are_views_of_the_flat_storage_and_no_reupload_between_forwards()
     assert set(sd2) == set(sd)                                      # the reference's keys, reference layouts
     for k in sd:
         assert tuple(sd2[k].shape) == tuple(np.asarray(sd[k]).shape), k
+
+
+@pytest.mark.parametrize("in_place", [True, False])
+def test_fused_adam_reaches_the_library(in_place):
+    """torch.optim.Adam(fused=True) changes the parameters without bumping their version counters: the re-pack check must not depend on
+    the counters alone (it also keys on "a backward ran since the last re-pack").  Two optimizers, same start, same data: the rendered
+    colours after three steps must agree -- with stale packed copies the fused run would still render the initial network."""
+    K = W.synthetic_camera()
+    rays = _rays(256, 9, requires_grad=False)
+    kw = dict(ndc=True, near=0., far=1., use_viewdirs=True, N_samples=24, N_importance=16, raw_noise_std=0., perturb=0.)
+    tgt = torch.rand((256, 3), device=DEV, generator=torch.Generator(device=DEV).manual_seed(4))
+    outs = []
+    for fused in (False, True):
+        model, sd = _c2f_model("f16x3", 16)
+        model.enable_training(sd, grads_in_place=in_place).train()
+        opt = torch.optim.Adam(model.parameters(), lr=2e-3, fused=fused)
+        first = None
+        for _ in range(3):
+            rgb, rgb0, _, _ = model(400, 400, K, 1 << 22, rays=rays, tv=False, **kw)
+            first = rgb.detach().clone() if first is None else first
+            loss = ((rgb - tgt) ** 2).mean() + ((rgb0 - tgt) ** 2).mean()
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+        rgb = model(400, 400, K, 1 << 22, rays=rays, tv=False, **kw)[0].detach()
+        assert (rgb - first).abs().max() > 1e-3                     # three steps moved the render
+        outs.append(rgb)
+    assert (outs[0] - outs[1]).abs().max() < 2e-4, float((outs[0] - outs[1]).abs().max())

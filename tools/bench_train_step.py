@@ -90,7 +90,8 @@ def run(a):
     crf_rgb = CRF("gamma")
     crf_ev = CRF("learn", state_dict=W.make_crf_state_dict(5, extra_features=2), extra_features=2)
     crf_flat = crf_ev.flat_params(dev)
-    opt = torch.optim.Adam([{"params": model.parameters(), "lr": 5e-4}, {"params": [crf_flat], "lr": 1e-4}])
+    # run_nerf.py:245-263 builds torch.optim.Adam over the same parameter groups; fused=True is that optimizer's single-kernel implementation
+    opt = torch.optim.Adam([{"params": model.parameters(), "lr": 5e-4}, {"params": [crf_flat], "lr": 1e-4}], fused=not bool(os.environ.get("EVD_ADAM_FOREACH")))
     K = W.synthetic_camera()
     R, E = a.pixels, a.events
     # data-parallel mode (bench.py --gpus N, weak scaling: every rank trains on its OWN batch of this size): the packed loss partials are

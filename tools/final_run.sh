@@ -11,5 +11,7 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof2 -- python $GRAFT_REPO_ROOT/tools/bench_train_step.py --iters 8 > $GRAFT_REPO_ROOT/$O/train_step_rocprof.log 2>&1
 cd $GRAFT_REPO_ROOT
 f=$(ls $O/prof2/*/*kernel_stats.csv | head -1); cp $f $O/train_step_kernel_stats.csv; rm -rf $O/prof2; head -6 $O/train_step_kernel_stats.csv | cut -c1-160
+python tools/profile_train_kernels.py --top 70 2>&1 | grep -v "Warn\|amdgpu.ids\|_warn_once" > $O/train_kernels_steady.txt; head -5 $O/train_kernels_steady.txt
+python tools/profile_train_kernels.py --awp fused --top 80 2>&1 | grep -v "Warn\|amdgpu.ids\|_warn_once" > $O/train_kernels_awp_steady.txt; head -5 $O/train_kernels_awp_steady.txt
 python tools/bench_train_step.py --iters 20 2>&1 | tail -1 | tee $O/train_step.log
 python tools/bench_train_step.py --iters 10 --awp fused 2>&1 | tail -1 | tee -a $O/train_step.log

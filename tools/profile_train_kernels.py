@@ -1,0 +1,35 @@
+"""Steady-state kernel breakdown of one blurfactory training iteration (tools/bench_train_step.py) by torch.profiler: the iterations are
+profiled AFTER the warm-up, so one-off library tuning launches do not pollute the table as they do under rocprofv3.  GPU box only.
+    python tools/profile_train_kernels.py [--awp fused]"""
+import argparse
+import os
+import sys
+from types import SimpleNamespace
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import bench_train_step as B  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--awp", default="none")
+ap.add_argument("--top", type=int, default=45)
+a = ap.parse_args()
+ns = SimpleNamespace(precision="f16", iters=6, pixels=1024, events=4096, P=10, awp=a.awp, mam="corr")
+from torch.profiler import profile, ProfilerActivity  # noqa: E402
+B.run(ns)                          # builds, tunes, caches
+ns.iters = 5
+with profile(activities=[ProfilerActivity.CUDA]) as prof:
+    ms, _, _ = B.run(ns)
+    torch.cuda.synchronize()
+n = ns.iters + 3                   # B.run: 3 untimed + iters timed iterations
+ka = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)
+tot = sum(e.device_time_total for e in ka)
+print(f"iteration {ms:.2f} ms; device time per iteration {tot / n / 1e3:.2f} ms in {sum(e.count for e in ka) / n:.0f} kernels")
+lib = [e for e in ka if "evd::" in e.key or e.key.startswith("k_")]
+mem = [e for e in ka if e.key.startswith(("Memcpy", "Memset"))]
+oth = [e for e in ka if e not in lib and e not in mem]
+for nme, grp in (("library kernels (evd::)", lib), ("other kernels (torch, BLAS, runtime copies)", oth), ("memcpy / memset records", mem)):
+    print(f"  {nme:46s} {sum(e.count for e in grp) / n:6.0f} launches  {sum(e.device_time_total for e in grp) / n / 1e3:7.2f} ms")
+for e in ka[:a.top]:
+    print(f"{e.device_time_total / n:9.1f} us  n={e.count / n:6.1f}  {e.key[:110]}")
