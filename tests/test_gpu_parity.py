@@ -874,6 +874,53 @@ def test_blur_loss_backward_matches_torch_autograd(crf_kind, with_all):
         assert rel < 2e-5, (name, rel)
 
 
+def test_loss_backward_entries_host_and_device_gradients_agree():
+    """evd_blur_loss_bwd / evd_event_loss_bwd take dL/d partial as host scalars, the *_dev entries read the same values from device memory
+    (what the autograd nodes call: no host copy inside a backward pass): the same outputs."""
+    import ctypes as C
+    from evdeblurnerf_amd import _lib as L
+    from evdeblurnerf_amd.tonemapping import CRF
+    rs = np.random.RandomState(77)
+    R, P, n = 129, 10, 93
+    mk = lambda *sh: T(rs.uniform(0.05, 0.95, sh).astype(np.float32))
+    rgb_p, rgb0_p, tgt, tgt0 = mk(R, P, 3), mk(R, P, 3), mk(R, 3), mk(R, 3)
+    w1, w2 = torch.softmax(mk(R, P), -1).contiguous(), torch.softmax(mk(R, P), -1).contiguous()
+    g = np.array([0.31, -0.12, 0.55, 0.07, 0.21, 0.0, 0.0, 0.0], np.float32)
+    crf = CRF("gamma")
+    outs = []
+    for dev in (False, True):
+        d = [torch.empty_like(rgb_p), torch.empty_like(rgb0_p), torch.empty_like(w1), torch.empty_like(w2)]
+        gd = T(g)
+        fn = L.lib().evd_blur_loss_bwd_dev if dev else L.lib().evd_blur_loss_bwd
+        garg = L.ptr(gd) if dev else g.ctypes.data_as(C.POINTER(C.c_float))
+        L.check(fn(crf.handle, 0, L.ptr(rgb_p), L.ptr(rgb0_p), L.ptr(w1), L.ptr(w2), L.ptr(tgt), L.ptr(tgt0), R, P, garg, L.ptr(d[0]), L.ptr(d[1]),
+                   L.ptr(d[2]), L.ptr(d[3]), L.stream_ptr()), "evd_blur_loss_bwd")
+        outs.append([N(t) for t in d])
+    for k, (a, b) in enumerate(zip(*outs)):
+        # d rgb: one lane each, bit for bit; d w1 / d w2: three channels summed by float atomics -- equal to rounding
+        assert np.array_equal(a, b) if k < 2 else np.abs(a - b).max() <= 1e-6 * np.abs(a).max()
+    sd = {k: (v * (3.0 if "weight" in k else 1.0)).astype(np.float32) for k, v in W.make_crf_state_dict(51, 2).items()}
+    crf_ev = CRF("learn", state_dict=sd, extra_features=2)
+    es, ee, es0, ee0 = mk(n, 3), mk(n, 3), mk(n, 3), mk(n, 3)
+    cn, cp = T(-rs.randint(0, 4, n).astype(np.float32)), T(rs.randint(0, 4, n).astype(np.float32))
+    npar = int(L.lib().evd_crf_param_count())
+    outs = []
+    for dev in (False, True):
+        d = [torch.zeros_like(es) for _ in range(4)] + [torch.empty((npar,), device=DEV)]
+        gd = T(g[:3])
+        if dev:
+            L.check(L.lib().evd_event_loss_bwd_dev(crf_ev.handle, 0, 1, 0, L.ptr(es), L.ptr(ee), L.ptr(es0), L.ptr(ee0), L.ptr(cn), L.ptr(cp), 0.2, 0.2, None, None,
+                                                   n, L.ptr(gd), L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]), L.ptr(d[3]), L.ptr(d[4]), L.stream_ptr()), "evd_event_loss_bwd_dev")
+        else:
+            L.check(L.lib().evd_event_loss_bwd(crf_ev.handle, 0, 1, 0, L.ptr(es), L.ptr(ee), L.ptr(es0), L.ptr(ee0), L.ptr(cn), L.ptr(cp), 0.2, 0.2, None, None,
+                                               n, float(g[0]), float(g[1]), L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]), L.ptr(d[3]), L.ptr(d[4]), L.stream_ptr()), "evd_event_loss_bwd")
+        outs.append([N(t) for t in d])
+    for a, b in zip(outs[0][:4], outs[1][:4]):
+        assert np.array_equal(a, b)
+    # (the CRF parameter gradient is a float atomic sum over the blocks: equal to rounding, not bit for bit)
+    assert np.abs(outs[0][4] - outs[1][4]).max() <= 1e-5 * max(1.0, np.abs(outs[0][4]).max())
+
+
 @pytest.mark.parametrize("cfg", ["blender", "cdavis"])
 def test_event_loss_backward_matches_torch_autograd(cfg):
     """Backward of the fused event-loss reduction (learnable event-CRF included) against torch autograd of a plain-torch
