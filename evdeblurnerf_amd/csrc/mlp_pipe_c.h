@@ -28,7 +28,8 @@
 namespace evd {
 
 // developer ablations (tools/ablate_c.sh compiles variants): 1 / 2 skip the first / second fp6 product, 4 drain every chunk end fully,
-// 8 no weight DMA, 16 no barrier, 32 no epilogue, 64 no float16 fragment reads, 128 no fp6 operand reads, 256 no fp6 conversions, 512 no epilogue pairs
+// 8 no weight DMA, 16 no barrier, 32 no epilogue, 64 no float16 fragment reads, 128 no fp6 operand reads, 256 no fp6 conversions, 512 no epilogue pairs,
+// 1024 the second fp6 operand is not read (the first one is used twice)
 #ifdef EVD_C_ABL
 constexpr int kAbl = EVD_C_ABL;
 #else
@@ -403,7 +404,7 @@ __device__ __forceinline__ void c_group(ST& st, CPipe& pp, XBlk (&in)[NIN], XBlk
 #pragma unroll
                 for (int q = 0; q < per_slot; ++q) {            // fp6 parts of this block, consumed by its last 2 G slots
                     const int c = i * per_slot + q;
-                    if (c < ncl && !(kAbl & 128)) {
+                    if (c < ncl && !(kAbl & 128) && !((kAbl & 1024) && (c >> 1) / G == 1)) {      // (1024: the second fp6 operand is not read: what deriving it from the float16 fragments would save)
                         const int kt = c >> 1, part = c & 1;    // kt = kind * G + tile
                         const int kind = kt / G, tt = kt % G;
                         if (part == 0) {
@@ -441,7 +442,7 @@ __device__ __forceinline__ void c_group(ST& st, CPipe& pp, XBlk (&in)[NIN], XBlk
                 else if (kind == 0)
                     pp.acc[cur][t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(pp.ac[0][t], in[b].qh, pp.acc[cur][t], 2, 2, 0, (int)pp.wsc[cur][t], 0, (int)in[b].sc);
                 else
-                    pp.acc[cur][t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(pp.ac[1][t], in[b].ql, pp.acc[cur][t], 2, 2, 1, (int)pp.wsc[cur][t], 1, (int)in[b].sc);
+                    pp.acc[cur][t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(pp.ac[(kAbl & 1024) ? 0 : 1][t], in[b].ql, pp.acc[cur][t], 2, 2, 1, (int)pp.wsc[cur][t], 1, (int)in[b].sc);
                 __builtin_amdgcn_sched_barrier(0);
                 const int last = 2 * G - 1;
                 chunks(lo16 + i, i == last ? hi8 + G : lo16 + i + 1);
