@@ -35,6 +35,7 @@ struct evd_voxel {
     // parameter values are kept in `arena_dev` (one stream-ordered device copy) and re-packed by the first f16c launch that follows
     mutable DevBuf arena_dev;
     mutable bool pipe_c_stale = false;
+    DevBuf cnet;                  // composite_feature levels: color_net.{0,1,2}.{weight,bias} as float32 in the reference layouts (k_color_rows)
     long param_off[9];            // sigma_net.0, sigma_net.1, color_net.{0,1,2}.{weight,bias} in the parameter arena, [8] = total
     GridParams gp;
     RepackBatch batch;            // table of every fragment stream, for the one-launch re-pack of evd_voxel_load_params
@@ -53,7 +54,7 @@ void evd_voxel_destroy(evd_voxel* v) {
         for (int k = 0; k < VBWD_NSTREAMS; ++k) v->bwd[i][k].release();
     }
     v->basis.release(); v->bias.release(); v->bias_src.release(); v->tv_acc.release(); v->wmaps.release();
-    v->pipe_c.release(); v->arena_dev.release();
+    v->pipe_c.release(); v->arena_dev.release(); v->cnet.release();
     v->side.release();
     v->batch.release();
     delete v;
@@ -67,7 +68,6 @@ int evd_voxel_create(const evd_voxel_desc* d, evd_voxel** out) {
     const int L = d->multires, Lv = d->multires_views;
     const bool standard = L == PE_L && Lv == PE_LV;
     EVD_REQUIRE(d->num_layers == 2 && d->num_layers_color == 3, "evd_voxel_create: only 2 sigma + 3 colour layers are built (all shipped configs)");
-    EVD_REQUIRE(!d->composite_feature, "evd_voxel_create: composite_feature=True (PBE kernel) is not built; shipped configs use RBK");
     const int IC = 3 * (1 + 2 * L), ICV = 3 * (1 + 2 * Lv);
     const int FT = d->input_ch - IC, HD = d->hidden_dim, G = d->geo_feat_dim;
     EVD_REQUIRE((HD == 64 && G == 15 && FT == 32) || (HD == 256 && G == 128 && FT == 64),
@@ -81,7 +81,7 @@ int evd_voxel_create(const evd_voxel_desc* d, evd_voxel** out) {
     evd_voxel* v = new evd_voxel();
     v->num_layers = 2; v->hidden_dim = HD; v->geo = G; v->num_layers_color = 3; v->input_ch = d->input_ch; v->ft_dim = FT;
     v->app_dim = d->app_dim; v->app_act = d->app_act; v->rgb_act = d->rgb_act; v->sigma_act = d->sigma_act;
-    v->composite_feature = 0; v->rmnear = d->rmnear;
+    v->composite_feature = d->composite_feature ? 1 : 0; v->rmnear = d->rmnear;
     v->multires = L; v->multires_views = Lv;
     memcpy(v->aabb, d->aabb, sizeof(v->aabb));
     int rc = EVD_OK;
@@ -135,6 +135,10 @@ int evd_voxel_create(const evd_voxel_desc* d, evd_voxel** out) {
         const float* srcs[8] = {d->sigma_w[0], d->sigma_w[1], d->color_w[0], d->color_b[0], d->color_w[1], d->color_b[1], d->color_w[2], d->color_b[2]};
         for (int i = 0; i < 8; ++i)
             if (srcs[i]) memcpy(arena.data() + v->param_off[i], srcs[i], psz[i] * sizeof(float));
+    }
+    if (v->composite_feature) {       // the colour network runs per RAY on the composited features (voxnerf.py:231-239): plain float32 rows
+        rc = v->cnet.upload(arena.data() + v->param_off[2], (size_t)(v->param_off[8] - v->param_off[2]) * sizeof(float));
+        if (rc) { evd_voxel_destroy(v); return rc; }
     }
     const float* A = arena.data();
     const float *sigma_w0 = A + v->param_off[0], *sigma_w1 = A + v->param_off[1], *color_w0 = A + v->param_off[2], *color_w1 = A + v->param_off[4],
@@ -324,15 +328,80 @@ int evd_voxel_sample_prec(const evd_voxel* v, int precision, const float* pts, l
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// composite_feature levels: the per-sample geo rows [R S, G] and the composited map [R, G]
+static size_t composite_scratch_bytes(const evd_voxel* v, long R, int S) {
+    return v->composite_feature ? align256((size_t)R * S * v->geo * 4) + align256((size_t)R * v->geo * 4) : 0;
+}
+
 size_t evd_voxel_forward_workspace_bytes(const evd_voxel* v, long R, int S) {
     if (!v || R < 0 || S < 1) return 0;
-    return align256((size_t)R * S * 16) + 512;
+    return align256((size_t)R * S * 16) + composite_scratch_bytes(v, R, S) + 512;
+}
+
+// activation of the geo rows before they are composited (voxnerf.py:172: rgb_activate(raw[..., 1:]))
+static __global__ __launch_bounds__(256) void k_act_inplace(float* __restrict__ x, long n, int code) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[i] = act(code, x[i]);
+}
+
+// colour network of a composite_feature level, per RAY (voxnerf.py:231-239): h = cat([feature_map, PE(dirs)]) -> Linear + ReLU
+// (num_layers_color - 1 times) -> Linear -> sigmoid.  A wavefront per ray, a lane per hidden unit (HD <= 256: up to 4 units per lane);
+// the weights are the reference's float32 [out, in] rows, read through the caches (7 k MACs per ray: nothing to optimise).
+static __global__ __launch_bounds__(256) void k_color_rows(const float* __restrict__ cnet, const float* __restrict__ fm, const float* __restrict__ viewdirs,
+                                                           int vd_stride, long R, int G, int HD, int Lv, float* __restrict__ color) {
+    __shared__ float in[4][160], h0[4][256], h1[4][256];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + w;
+    const int icv = 3 * (1 + 2 * Lv), nin = G + icv;
+    const float *w0 = cnet, *b0 = w0 + (long)HD * nin, *w1 = b0 + HD, *b1 = w1 + (long)HD * HD, *w2 = b1 + HD, *b2 = w2 + 3L * HD;
+    if (r < R) {
+        for (int i = lane; i < nin; i += 64) {
+            float x;
+            if (i < G) x = fm[r * G + i];
+            else {
+                const int c = i - G;              // embedding.py:88-98: [x, sin(x f0), cos(x f0), sin(x f1), ...], 3 values each
+                const float d = viewdirs[r * vd_stride + c % 3];
+                x = c < 3 ? d : ((c - 3) / 3 % 2 == 0 ? sinf(d * (float)(1 << ((c - 3) / 6))) : cosf(d * (float)(1 << ((c - 3) / 6))));
+            }
+            in[w][i] = x;
+        }
+    }
+    __syncthreads();
+    if (r < R)
+        for (int j = lane; j < HD; j += 64) {
+            float s = b0[j];
+            for (int i = 0; i < nin; ++i) s = fmaf(w0[(long)j * nin + i], in[w][i], s);
+            h0[w][j] = fmaxf(s, 0.f);
+        }
+    __syncthreads();
+    if (r < R)
+        for (int j = lane; j < HD; j += 64) {
+            float s = b1[j];
+            for (int i = 0; i < HD; ++i) s = fmaf(w1[(long)j * HD + i], h0[w][i], s);
+            h1[w][j] = fmaxf(s, 0.f);
+        }
+    __syncthreads();
+    if (r < R && lane < 3) {
+        float s = b2[lane];
+        for (int i = 0; i < HD; ++i) s = fmaf(w2[(long)lane * HD + i], h1[w][i], s);
+        color[r * 3 + lane] = 1.f / (1.f + expf(-s));            // torch.sigmoid(h) voxnerf.py:239
+    }
 }
 
 static int voxel_pass(const evd_voxel* v, int precision, const float* pts, const float* viewdirs, int vd_stride, const float* fts,
                       int ft_stride, const float* z, const float* rays_d, int rd_stride, long R, int S, int is_train,
                       const float* noise, float* color, float* depth, float* acc, float* weights, float* feature, float* raw,
-                      void* stream) {
+                      void* stream, float* cscratch = nullptr) {
+    // composite_feature (PBE, voxnerf.py:223-239): the per-sample geo rows are composited, the colour network runs per ray; `feature`
+    // is then the composited map [R, G] (NULL: not wanted) and cscratch holds the rows + the map
+    float* crows = nullptr;
+    float* cmap = nullptr;
+    if (v->composite_feature) {
+        if (!cscratch) return fail(EVD_E_WORKSPACE, "evd_voxel: a composite_feature level needs its scratch (workspace sized by the *_workspace_bytes query of this handle)");
+        crows = cscratch;
+        cmap = feature ? feature : (float*)((char*)cscratch + align256((size_t)R * S * v->geo * 4));
+        feature = crows;
+    }
     VoxMlpParams p;
     static const bool no_pipe = env_flag("EVD_NO_PIPE");
     const bool comp = precision == EVD_PREC_F16C && v->pipe_c_chunks > 0;
@@ -370,6 +439,22 @@ static int voxel_pass(const evd_voxel* v, int precision, const float* pts, const
                    : voxel_mlp_dispatch(precision, v->hidden_dim, v->geo, v->ft_dim, p, as_stream(stream));
     if (rc) return rc;
     const float thr = (!is_train && v->rmnear > 0.f) ? (float)((double)v->rmnear / 128.0) : 0.f;
+    if (v->composite_feature) {
+        hipStream_t st = as_stream(stream);
+        const long ng = R * (long)S * v->geo;
+        if (v->rgb_act != EVD_ACT_NONE) {
+            hipLaunchKernelGGL(k_act_inplace, dim3((unsigned)cdiv(ng, 256L)), dim3(256), 0, st, crows, ng, v->rgb_act);
+            EVD_LAUNCH_CHECK();
+        }
+        // weights / depth / acc from the densities; the geo rows ride along as the feature map (sum_s w feature); the per-sample colour
+        // composite written to `color` here is overwritten by the per-ray colour network below
+        if ((rc = evd_raw2outputs(raw, z, rays_d, rd_stride, R, S, 4, 0, 1, 3, v->rgb_act, v->sigma_act, 0, thr, noise,
+                                  color, nullptr, acc, weights, depth, crows, v->geo, cmap, stream))) return rc;
+        hipLaunchKernelGGL(k_color_rows, dim3((unsigned)cdiv(R, 4L)), dim3(256), 0, st, (const float*)v->cnet.p, cmap, viewdirs, vd_stride, R, v->geo,
+                           v->hidden_dim, v->multires_views, color);
+        EVD_LAUNCH_CHECK();
+        return EVD_OK;
+    }
     return evd_raw2outputs(raw, z, rays_d, rd_stride, R, S, 4, 0, 1, 3, v->rgb_act, v->sigma_act, 0, thr, noise,
                            color, nullptr, acc, weights, depth, nullptr, 0, nullptr, stream);
 }
@@ -386,8 +471,9 @@ int evd_voxel_forward(const evd_voxel* v, int precision, const float* pts, const
     const size_t need = evd_voxel_forward_workspace_bytes(v, R, S);
     if (!workspace || workspace_bytes < need) return fail(EVD_E_WORKSPACE, "evd_voxel_forward: workspace %zu < %zu bytes", workspace_bytes, need);
     float* raw = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    float* cs = v->composite_feature ? (float*)((char*)raw + align256((size_t)R * S * 16)) : nullptr;
     return voxel_pass(v, precision, pts, viewdirs, vd_stride, fts, F, z, rays_d, rays_d_stride, R, S, is_train, nullptr,
-                      color, depth, acc, weights, feature, raw, stream);
+                      color, depth, acc, weights, feature, raw, stream, cs);
 }
 
 size_t evd_c2f_render_workspace_bytes(const evd_voxel* coarse, const evd_voxel* fine, const evd_render_cfg* cfg, long R) {
@@ -407,6 +493,8 @@ size_t evd_c2f_render_workspace_bytes(const evd_voxel* coarse, const evd_voxel* 
     b += align256(r * S * 4);               // weights0
     b += align256(r * St * 4);              // weights
     b += align256(r * (Ni ? Ni : 1) * 4);   // z_samples
+    b += composite_scratch_bytes(coarse, R, (int)S);       // a composite_feature coarse level (kernel_type PBE): geo rows + composited map
+    if (fine && Ni) b += composite_scratch_bytes(fine, R, (int)St);
     return b + 512;
 }
 
@@ -441,6 +529,8 @@ int evd_c2f_render_rays(const evd_voxel* coarse, const evd_voxel* fine, const ev
     float* wts0 = take(r * S * 4);
     float* wts = take(r * St * 4);
     float* zs = take(r * (Ni ? Ni : 1) * 4);
+    float* cs0 = coarse->composite_feature ? (float*)take(composite_scratch_bytes(coarse, R, S)) : nullptr;
+    float* cs1 = (fine && Ni && fine->composite_feature) ? (float*)take(composite_scratch_bytes(fine, R, St)) : nullptr;
     const int FS = 64;      // feature row stride: coarse features at column 0, fine at column coarse->app_dim (renderer.py:195)
     int rc;
     float* zc = (Ni ? (out->z_vals0 ? out->z_vals0 : z0) : (out->z_vals ? out->z_vals : z0));
@@ -454,12 +544,12 @@ int evd_c2f_render_rays(const evd_voxel* coarse, const evd_voxel* fine, const ev
         if ((rc = sample_for(coarse, cfg->precision, pts, R * (long)S, ft, FS, 0, stream))) return rc;      // renderer.py:183
         float* wo = out->weights ? out->weights : wts;
         return voxel_pass(coarse, cfg->precision, pts, rb + 8, 11, ft, FS, zc, rb + 3, 11, R, S, cfg->is_train, noise0,
-                          out->rgb, out->depth, out->acc, wo, out->feature, out->raw ? out->raw : raw, stream);
+                          out->rgb, out->depth, out->acc, wo, out->feature, out->raw ? out->raw : raw, stream, cs0);
     }
     if ((rc = sample_for(coarse, cfg->precision, pts, R * (long)S, ft0, FC, 0, stream))) return rc;          // renderer.py:183
     float* w0 = out->weights0 ? out->weights0 : wts0;
     if ((rc = voxel_pass(coarse, cfg->precision, pts, rb + 8, 11, ft0, FC, zc, rb + 3, 11, R, S, cfg->is_train, noise0,
-                         out->rgb0, out->depth0, out->acc0, w0, nullptr, raw, stream))) return rc;
+                         out->rgb0, out->depth0, out->acc0, w0, nullptr, raw, stream, cs0))) return rc;
     float* zm = out->z_vals ? out->z_vals : z2;
     if ((rc = evd_sample_pdf_merge(zc, w0, R, S, Ni, cfg->perturb == 0.f, u, zs, zm, order, out->z_std, stream))) return rc;
     // merged sample set (renderer.py:205-213), as the reference does it: coarse features are sampled at the NEW points only
@@ -473,7 +563,7 @@ int evd_c2f_render_rays(const evd_voxel* coarse, const evd_voxel* fine, const ev
     if ((rc = sample_for(fine, cfg->precision, pts, n2, ft, FS, coarse->app_dim, stream))) return rc;
     float* wo = out->weights ? out->weights : wts;
     return voxel_pass(fine, cfg->precision, pts, rb + 8, 11, ft, FS, zm, rb + 3, 11, R, St, cfg->is_train, noise1,
-                      out->rgb, out->depth, out->acc, wo, out->feature, out->raw ? out->raw : raw, stream);
+                      out->rgb, out->depth, out->acc, wo, out->feature, out->raw ? out->raw : raw, stream, cs1);
 }
 
 int evd_c2f_render(const evd_voxel* coarse, const evd_voxel* fine, const evd_render_cfg* cfg, const float* rays, long R,
@@ -542,6 +632,7 @@ int evd_voxel_load_params(evd_voxel* v, const float* params, void* stream) {
         EVD_HIP(hipMemcpyAsync(v->arena_dev.p, params, bytes, hipMemcpyDeviceToDevice, st));
         v->pipe_c_stale = true;
     }
+    if (v->cnet.p) EVD_HIP(hipMemcpyAsync(v->cnet.p, params + v->param_off[2], v->cnet.bytes, hipMemcpyDeviceToDevice, st));
     const long nb = (long)(v->bias.bytes / sizeof(float));
     hipLaunchKernelGGL(k_gather_f32, dim3((unsigned)cdiv(nb, 256L)), dim3(256), 0, st, params, (const int*)v->bias_src.p, nb, (float*)v->bias.p);
     EVD_LAUNCH_CHECK();
@@ -561,6 +652,7 @@ size_t evd_voxel_backward_workspace_bytes(void) { return (size_t)VOX_WGRAD_BLOCK
 int evd_voxel_mlp_train(const evd_voxel* v, int precision, const float* pts, const float* viewdirs, int vd_stride, const float* fts, int ft_stride,
                         long R, int S, float* raw, float* feature, void* store, size_t store_bytes, void* stream) {
     EVD_REQUIRE(v && pts && viewdirs && fts && raw && store, "evd_voxel_mlp_train: null argument");
+    EVD_REQUIRE(!v->composite_feature, "evd_voxel_mlp_train: composite_feature levels (kernel_type PBE) are built for inference only");
     EVD_REQUIRE(precision >= 0 && precision < EVD_VOX_NUM_PREC && vox_train_built(v, precision), "evd_voxel_mlp_train: the training path is built for precision f16 / bf16 / f16x3");
     EVD_REQUIRE(R >= 0 && S >= 1 && ft_stride >= v->ft_dim && ft_stride % 4 == 0, "evd_voxel_mlp_train: bad shape");
     if (R == 0) return EVD_OK;

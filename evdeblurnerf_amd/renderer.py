@@ -197,8 +197,9 @@ class NeRFAll:
                 self.mlp_fine = NeRF(state_dict, "mlp_fine.", **common_f)
         else:
             from .voxnerf import VoxelNeRFRayFeatures, VoxelNeRFSampleFeatures
-            if self.kernel_type == "PBE":
-                raise NotImplementedError("kernel_type PBE (composite_feature=True) is not built; shipped configs use RBK")
+            # kernel_type PBE: the coarse level composites its geo features and runs its colour network per ray (renderer.py:30-34,
+            # voxnerf.py:223-239) -- built for inference (render / coarse_render); its training forward needs the PDRF blur model
+            # (networks/pdrf/blurmodel.py, out of scope: no shipped config uses it)
             ic = 3 * (1 + 2 * args.multires)
             rm = _args_get(args, "render_rmnearplane", 0)
             self.mlp_coarse = VoxelNeRFRayFeatures(
@@ -206,7 +207,7 @@ class NeRFAll:
                 geo_feat_dim=_args_get(args, "kernel_feat_cnl", 15), num_layers_color=args.coarse_num_layers_color,
                 input_ch=args.coarse_app_dim + ic, multires=args.multires, multires_views=args.multires_views,
                 render_rmnearplane=rm, app_dim=args.coarse_app_dim, app_n_comp=args.coarse_app_n_comp, n_voxels=args.coarse_n_voxels,
-                app_actfn=_args_get(args, "coarse_app_actfn", "none"), precision=precision)
+                app_actfn=_args_get(args, "coarse_app_actfn", "none"), composite_feature=self.kernel_type == "PBE", precision=precision)
             if args.N_importance > 0:
                 self.mlp_fine = VoxelNeRFSampleFeatures(
                     state_dict, "mlp_fine.", args.bounding_box, num_layers=args.fine_num_layers, hidden_dim=args.fine_hidden_dim,
@@ -313,7 +314,10 @@ class NeRFAll:
                 out.z_vals0, out.weights0 = L.ptr(ret["z_vals0"]), L.ptr(ret["weights0"])
         if want_feat:
             last = self.mlp_fine if (Ni > 0 and self.mlp_fine is not None) else self.mlp_coarse
-            ret["depth_feature"] = torch.empty((R, St, last.W if self.mode == "nerf" else last.geo_feat_dim), **f32)
+            if self.mode != "nerf" and getattr(last, "composite_feature", False):
+                ret["depth_feature"] = torch.empty((R, last.geo_feat_dim), **f32)          # the composited map of a PBE level (voxnerf.py:226)
+            else:
+                ret["depth_feature"] = torch.empty((R, St, last.W if self.mode == "nerf" else last.geo_feat_dim), **f32)
             out.feature = L.ptr(ret["depth_feature"])
         out.feature_kind = 2 if self.extract_feature == "before_linear" else 1
         ws, need = self._workspace(cfg, R)
@@ -591,6 +595,73 @@ class NeRFAll:
                 _, rd = get_ndc_rays(H, W, focal, 1., flat[..., 0].contiguous(), rd.contiguous())
             ret_dict["rays_d"] = rd.reshape(-1, 3)
         return ret_list + [ret_dict]
+
+    # ------------------------------------------------------------------ coarse_render, renderer.py:468-592
+    def coarse_render_rays(self, ray_batch, N_samples, retraw=False, lindisp=False, perturb=0., N_importance=0, white_bkgd=False,
+                           raw_noise_std=0., force_naive=False, inference=False, *, t_rand=None, noise0=None, _cfg=None, _rays=None):
+        """renderer.py:525-592: the COARSE level alone on N_samples stratified samples -> (rgb_map [R,3], feat); feat is what the coarse
+        backbone returns as its feature map: per-sample geo features [R,S,geo] (mode='c2f'), their composite [R,geo] for a PBE level
+        (voxnerf.py:226), the per-sample feature of NeRF.forward (mode='nerf').  N_importance is accepted and ignored, as there."""
+        dev = self.device
+        R = ray_batch.shape[0] if _rays is None else _rays.shape[0]
+        S = int(N_samples)
+        cfg = _cfg or self._cfg(0, 0, 1.0, False, 0., 1., S, 0, lindisp, perturb, white_bkgd)
+        cfg.N_samples, cfg.N_importance, cfg.lindisp = S, 0, int(bool(lindisp))
+        cfg.perturb, cfg.white_bkgd, cfg.is_train = float(perturb), int(bool(white_bkgd)), int(self.training)
+        f32 = dict(dtype=torch.float32, device=dev)
+        if perturb > 0. and t_rand is None:
+            t_rand = torch.rand((R, S), **f32)
+        if raw_noise_std > 0. and noise0 is None:
+            noise0 = torch.randn((R, S - 1), **f32) * raw_noise_std
+        c = self.mlp_coarse
+        rgb, depth, acc = torch.empty((R, 3), **f32), torch.empty((R,), **f32), torch.empty((R,), **f32)
+        if self.mode == "nerf":
+            feat = torch.empty((R, S, c.W), **f32)
+        else:
+            feat = torch.empty((R, c.geo_feat_dim) if c.composite_feature else (R, S, c.geo_feat_dim), **f32)
+        out = L.RenderOut()
+        out.rgb, out.depth, out.acc, out.feature = L.ptr(rgb), L.ptr(depth), L.ptr(acc), L.ptr(feat)
+        out.feature_kind = 2 if self.extract_feature == "before_linear" else 1
+        ws, need = self._workspace(cfg, R)
+        tr = t_rand.contiguous().float() if t_rand is not None else None
+        n0 = noise0.contiguous().float() if noise0 is not None else None
+        fn_rays, fn_render = ((L.lib().evd_nerf_render_rays, L.lib().evd_nerf_render) if self.mode == "nerf" else
+                              (L.lib().evd_c2f_render_rays, L.lib().evd_c2f_render))
+        if _rays is None:
+            rb = ray_batch.contiguous().float()
+            L.check(fn_rays(c.handle, None, C.byref(cfg), L.ptr(rb), R, L.ptr(tr), None, L.ptr(n0), None, C.byref(out), L.ptr(ws), need,
+                            L.stream_ptr()), "coarse_render_rays")
+        else:
+            L.check(fn_render(c.handle, None, C.byref(cfg), L.ptr(_rays), R, L.ptr(tr), None, L.ptr(n0), None, C.byref(out), L.ptr(ws), need,
+                              L.stream_ptr()), "coarse_render")
+        return rgb, feat
+
+    def coarse_render(self, H, W, K, chunk=1 << 22, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,
+                      c2w_staticcam=None, **kwargs):
+        """renderer.py:468-523: rays -> (rgb [R,3], feat) of the coarse level (what the PBE blur kernel consumes, renderer.py:296)."""
+        if bool(use_viewdirs) != self.use_viewdirs:
+            raise L.EvdError(f"coarse_render(use_viewdirs={use_viewdirs}) on a model built with use_viewdirs={self.use_viewdirs}")
+        if c2w_staticcam is not None:
+            raise NotImplementedError("coarse_render: c2w_staticcam goes through render()")
+        if rays is None:
+            if c2w is None:
+                raise L.EvdError("coarse_render needs rays or c2w")
+            o, d = get_rays(H, W, K, torch.as_tensor(c2w, device=self.device))
+            rays = torch.stack([o, d], dim=-1)
+        flat = rays.to(self.device).float().reshape(-1, 3, 2).contiguous()
+        cfg = self._cfg(H, W, float(K[0][0]), ndc, near, far, kwargs.get("N_samples"), 0, kwargs.get("lindisp", False),
+                        kwargs.get("perturb", 0.), kwargs.get("white_bkgd", False))
+        rgbs, feats = [], []
+        for i in range(0, max(1, flat.shape[0]), chunk):
+            kw = {k: v for k, v in kwargs.items() if k in ("N_samples", "retraw", "lindisp", "perturb", "N_importance", "white_bkgd", "raw_noise_std",
+                                                             "force_naive", "inference")}
+            for k in ("t_rand", "noise0"):
+                if kwargs.get(k) is not None:
+                    kw[k] = kwargs[k][i:i + chunk]
+            r, f = self.coarse_render_rays(None, _cfg=cfg, _rays=flat[i:i + chunk], **kw)
+            rgbs.append(r)
+            feats.append(f)
+        return (rgbs[0], feats[0]) if len(rgbs) == 1 else (torch.cat(rgbs, 0), torch.cat(feats, 0))
 
     # ------------------------------------------------------------------ render_path, renderer.py:594-626
     def render_path(self, H, W, K, chunk, render_poses, render_kwargs, render_factor=0, shard_rows=False):

@@ -226,12 +226,18 @@ class VoxelNeRFBase:
         from .nerf import _Raw2Outputs
         raw, z, rd = raw.contiguous().float(), z_vals.contiguous().float(), rays_d.contiguous().float()
         R, S, Cc = raw.shape
-        if Cc != 4:
-            raise NotImplementedError("composite_feature=True (PBE, 16-channel raw) is not built; shipped configs use RBK")
         if raw_noise_std > 0. and noise is None:
             noise = torch.randn((R, S - 1), dtype=torch.float32, device=raw.device) * raw_noise_std
         nz = noise.contiguous().float() if noise is not None else None
         thr = float(self.render_rmnearplane) / 128.0 if (not is_train and self.render_rmnearplane > 0) else 0.0
+        if Cc != 4:           # composite_feature=True (PBE): raw = [sigma | geo features], the map has Cc - 1 channels (:223-229); forward only
+            f32 = dict(dtype=torch.float32, device=raw.device)
+            fmap, dens, acc = torch.empty((R, Cc - 1), **f32), torch.empty((R, S - 1), **f32), torch.empty((R,), **f32)
+            wts, depth = torch.empty((R, S), **f32), torch.empty((R,), **f32)
+            L.check(L.lib().evd_raw2outputs(L.ptr(raw.detach()), L.ptr(z), L.ptr(rd), rd.shape[-1], R, S, Cc, 0, 1, Cc - 1, L.ACT[self.rgb_activate],
+                                            L.ACT[self.sigma_activate], 0, thr, L.ptr(nz), L.ptr(fmap), L.ptr(dens), L.ptr(acc), L.ptr(wts), L.ptr(depth),
+                                            None, 0, None, L.stream_ptr()), "evd_raw2outputs")
+            return fmap, dens, acc, wts, depth
         rgb, dens, acc, wts, depth = _Raw2Outputs.apply(raw, z, rd, nz, 0, 1, L.ACT[self.rgb_activate], L.ACT[self.sigma_activate], False, thr)
         return rgb, dens, acc, wts, depth
 
@@ -393,7 +399,11 @@ class VoxelNeRFBase:
         f32 = dict(dtype=torch.float32, device=dev)
         color, depth, acc = torch.empty((R, 3), **f32), torch.empty((R,), **f32), torch.empty((R,), **f32)
         # (the compensated float16 mode is an inference mode without per-sample feature rows: feature_map is None there)
-        wts, feat = torch.empty((R, S), **f32), (torch.empty((R, S, self.geo_feat_dim), **f32) if (precision or self.precision) != "f16c" else None)
+        # composite_feature (PBE): the returned feature map is the composited one [R, geo] (voxnerf.py:226)
+        if self.composite_feature:
+            wts, feat = torch.empty((R, S), **f32), torch.empty((R, self.geo_feat_dim), **f32)
+        else:
+            wts, feat = torch.empty((R, S), **f32), (torch.empty((R, S, self.geo_feat_dim), **f32) if (precision or self.precision) != "f16c" else None)
         need = int(L.lib().evd_voxel_forward_workspace_bytes(self._h, R, S))
         ws = torch.empty((need,), dtype=torch.uint8, device=dev)
         L.check(L.lib().evd_voxel_forward(self._h, L.PREC[precision or self.precision], L.ptr(p), L.ptr(vd), 3, L.ptr(ft), ft.shape[-1],

@@ -254,7 +254,9 @@ int evd_voxel_sample(const evd_voxel* v, const float* pts, long n, float* out, i
  * What the training forward calls, so that it is the inference render's arithmetic. */
 int evd_voxel_sample_prec(const evd_voxel* v, int precision, const float* pts, long n, float* out, int out_stride, int out_col, void* stream);
 /* VoxelNeRFBase.forward, voxnerf.py:210-259.  pts dev [R,S,3], viewdirs dev rows of vd_stride floats,
- * fts dev [R,S,F] -> color [R,3], depth [R], acc [R], weights [R,S], feature [R,S,geo] */
+ * fts dev [R,S,F] -> color [R,3], depth [R], acc [R], weights [R,S], feature [R,S,geo].
+ * A level created with composite_feature != 0 (kernel_type PBE, voxnerf.py:223-239) composites its geo features first and runs the
+ * colour network per ray: `feature` is then the COMPOSITED map [R,geo].  Inference only; the workspace query includes its scratch. */
 int evd_voxel_forward(const evd_voxel* v, int precision, const float* pts, const float* viewdirs, int vd_stride, const float* fts, int F,
                       const float* z, const float* rays_d, int rays_d_stride, long R, int S, int is_train,
                       float* color, float* depth, float* acc, float* weights, float* feature,

@@ -592,7 +592,7 @@ void evo_voxel_forward(const evo_voxel* v, const float* pts, const float* viewdi
                 float* t = a; a = b; b = t;
             }
             memcpy(hbuf + s * (1 + G), a, sizeof(float) * (1 + G));
-            if (feature) memcpy(feature + s * G, a + 1, sizeof(float) * G);      /* feature_map = h[...,1:] :221 */
+            if (feature && !v->composite_feature) memcpy(feature + s * G, a + 1, sizeof(float) * G);      /* feature_map = h[...,1:] :221 */
         }
         free(a); free(b);
     }
@@ -619,6 +619,7 @@ void evo_voxel_forward(const evo_voxel* v, const float* pts, const float* viewdi
             }
             free(a); free(b);
         }
+        if (feature) memcpy(feature, fm, sizeof(float) * (size_t)G * R);       /* the returned feature_map is the composited one [R,G] :226 */
         free(fm);
     } else {
         /* per-sample colour then composite (:240-257); raw = cat([sigma, sigmoid(colour)]) */

@@ -301,6 +301,19 @@ def render_c2f(coarse: Voxel, fine, cfg, rays, t_rand=None, u=None, want_feature
     return _render(lib().evo_render_c2f, coarse, fine, cfg, rays, t_rand, u, fd if want_feature else 0, False)
 
 
+def voxel_forward(v: Voxel, pts, viewdirs, fts, z, rays_d, multires=10, multires_views=4, is_train=False):
+    """VoxelNeRFBase.forward (voxnerf.py:210-259) on explicit inputs -> dict(color, depth, acc, weights, feature); the feature map is
+    [R,S,geo], or the composited [R,geo] of a composite_feature level"""
+    pts, viewdirs, fts, z, rays_d = _f(pts), _f(viewdirs), _f(fts), _f(z), _f(rays_d)
+    R, S = z.shape
+    G = v.s.geo_feat_dim
+    res = dict(color=np.empty((R, 3), np.float32), depth=np.empty((R,), np.float32), acc=np.empty((R,), np.float32),
+               weights=np.empty((R, S), np.float32), feature=np.empty((R, G) if v.s.composite_feature else (R, S, G), np.float32))
+    lib().evo_voxel_forward(C.byref(v.s), _p(pts), _p(viewdirs), _p(fts), fts.shape[-1], _p(z), _p(rays_d), C.c_long(R), S, multires, multires_views,
+                            int(bool(is_train)), _p(res["color"]), _p(res["depth"]), _p(res["acc"]), _p(res["weights"]), _p(res["feature"]))
+    return res
+
+
 def appfeature(v: Voxel, pts):
     pts = _f(pts).reshape(-1, 3)
     out = np.empty((pts.shape[0], v.s.app_dim), np.float32)

@@ -348,6 +348,52 @@ def test_render_other_multires_matches_reference_golden(prec, tol):
             model(400, 400, K, 1 << 20, rays=T(W.synthetic_rays(43, 48)), ndc=True, near=0., far=1., use_viewdirs=True, N_samples=64, N_importance=32, perturb=1.0)
 
 
+@pytest.mark.parametrize("prec,tol", [("f32", 1e-4), ("f16x3", 1e-4), ("f16c", 1e-4), ("f16", 5e-4)])
+def test_pbe_composite_feature_matches_reference_golden(prec, tol):
+    """kernel_type='PBE' (renderer.py:30-34; voxnerf.py:223-239): the coarse level composites its 15 geo features and runs its colour network
+    per ray.  Golden G25 from the reference: the level on explicit inputs (composited feature map returned), NeRFAll.render in eval
+    mode, NeRFAll.coarse_render (rgb + the feature map the PBE blur kernel consumes).  Training a PBE model is rejected (its blur model
+    is out of scope)."""
+    from evdeblurnerf_amd import _lib as L
+    from evdeblurnerf_amd.renderer import NeRFAll
+    g = load_golden("G25_pbe_composite_feature")
+    K = W.synthetic_camera()
+    a = W.blurfactory_args(32, coarse_voxels=24 ** 3, fine_voxels=48 ** 3)
+    a.kernel_type = "PBE"
+    gc, gf = W.pdrf_grid_size(*W.BLURFACTORY_AABB, 24 ** 3), W.pdrf_grid_size(*W.BLURFACTORY_AABB, 48 ** 3)
+    sd = W.prefixed(W.make_pdrf_state_dict(91, gc, input_ch=95, hidden_dim=64, geo_feat_dim=15), "mlp_coarse")
+    sd.update(W.prefixed(W.make_pdrf_state_dict(92, gf, input_ch=127, hidden_dim=256, geo_feat_dim=128), "mlp_fine"))
+    model = NeRFAll(a, sd, precision=prec).eval()
+    assert model.mlp_coarse.composite_feature and not model.mlp_fine.composite_feature
+    ltol = tol if prec != "f16" else 2e-3
+    col, dep, acc, wts, fm = model.mlp_coarse(T(g["l_pts"]), T(g["l_vd"]), T(g["l_fts"]), T(g["l_z"]), T(g["l_rd"]))
+    assert fm.shape == (24, 15)
+    e = {k: maxabs(N(v), g["l_" + k]) for k, v in (("color", col), ("depth", dep), ("acc", acc), ("weights", wts), ("feature", fm))}
+    print(f"[{prec} PBE level] " + ", ".join(f"{k} {v:.2e}" for k, v in e.items()))
+    assert all(v < ltol for v in e.values()), e
+    rays = T(W.synthetic_rays(51, 56))
+    crgb, cfeat = model.coarse_render(400, 400, K, rays=rays, ndc=True, near=0., far=1., use_viewdirs=True, N_samples=64, N_importance=32,
+                                      perturb=0., raw_noise_std=0.)
+    assert cfeat.shape == (56, 15)
+    assert maxabs(N(crgb), g["coarse_rgb"]) < ltol and maxabs(N(cfeat), g["coarse_feat"]) < ltol
+    rgb, depth, acc, ex = model.render(400, 400, K, rays=rays, ndc=True, near=0., far=1., use_viewdirs=True, N_samples=64, N_importance=32,
+                                       retraw=True, perturb=0., raw_noise_std=0.)
+    e0 = maxabs(N(ex["rgb0"]), g["rgb0"])
+    same = np.abs(N(ex["z_vals"]) - g["z_vals"]).max(-1) < 5e-5
+    efine = maxabs(N(rgb)[same], g["rgb"][same]) if same.any() else 0.0
+    print(f"[{prec} PBE render] rgb0 {e0:.2e}, rgb {efine:.2e} on {same.mean():.0%} of the rays")
+    assert e0 < ltol and efine < ltol and (same.mean() > 0.8 or prec == "f16")
+    assert maxabs(N(ex["z_vals0"]), g["z_vals0"]) < 1e-6
+    # the composed map through raw2outputs on a 16-channel raw (voxnerf.py:223-229)
+    raw16 = torch.cat([T(g["l_weights"])[..., None] * 0 + 1.0, torch.rand((24, 40, 15), device=DEV)], -1)
+    fmap, dens, acc2, wts2, dep2 = model.mlp_coarse.raw2outputs(raw16, T(g["l_z"]), T(g["l_rd"]))
+    assert fmap.shape == (24, 15) and torch.allclose((wts2[..., None] * torch.relu(raw16[..., 1:])).sum(1), fmap, atol=1e-5)
+    if prec == "f32":
+        with pytest.raises((L.EvdError, NotImplementedError)):
+            model.enable_training(sd).train()
+            model(400, 400, K, 1 << 20, rays=rays, ndc=True, near=0., far=1., use_viewdirs=True, N_samples=64, N_importance=32, perturb=1.0)
+
+
 def test_render_config1_white_bkgd_lindisp_no_ndc(O):
     """BASELINE config 1 shape (single pass, 64 samples) with the non-default switches, vs golden G7c."""
     from types import SimpleNamespace

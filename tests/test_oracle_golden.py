@@ -213,6 +213,33 @@ def test_G24_render_other_multires():
         assert maxabs(res[k][same], g["c_" + k][same]) < 5e-5, k
 
 
+def test_G25_pbe_composite_feature():
+    """kernel_type='PBE' (renderer.py:30-34): the coarse level composites its geo features and runs its colour network per ray
+    (voxnerf.py:223-239); eval render, coarse_render (renderer.py:468-592) and the level on explicit inputs vs the reference"""
+    g = load_golden("G25_pbe_composite_feature")
+    gc = W.pdrf_grid_size(AABB[:3], AABB[3:], 24 ** 3)
+    gf = W.pdrf_grid_size(AABB[:3], AABB[3:], 48 ** 3)
+    vc = O.Voxel(W.make_pdrf_state_dict(91, gc, input_ch=95, hidden_dim=64, geo_feat_dim=15), "", gc, AABB, input_ch=95, hidden_dim=64,
+                 geo_feat_dim=15, rgb_act="relu", composite_feature=True)
+    vf = O.Voxel(W.make_pdrf_state_dict(92, gf, input_ch=127, hidden_dim=256, geo_feat_dim=128), "", gf, AABB, input_ch=127, hidden_dim=256,
+                 geo_feat_dim=128, rgb_act="none")
+    lv = O.voxel_forward(vc, g["l_pts"], g["l_vd"], g["l_fts"], g["l_z"], g["l_rd"])
+    for k in ("color", "depth", "acc", "weights", "feature"):
+        assert maxabs(lv[k], g["l_" + k]) < 2e-5, k
+    assert lv["feature"].shape == (24, 15)
+    rays = W.synthetic_rays(51, 56)
+    res = O.render_c2f(vc, None, O.make_cfg(N_samples=64, N_importance=0), rays, want_feature=True)
+    assert maxabs(res["rgb"], g["coarse_rgb"]) < 2e-5
+    assert maxabs(res["feature"].reshape(-1)[:56 * 15].reshape(56, 15), g["coarse_feat"]) < 2e-5
+    res = O.render_c2f(vc, vf, O.make_cfg(N_samples=64, N_importance=32), rays)
+    for k in ("rgb0", "depth0", "acc0", "z_std", "z_vals0", "weights0"):
+        assert maxabs(res[k], g[k]) < 5e-5, k
+    same = np.abs(res["z_vals"] - g["z_vals"]).max(-1) < 5e-5
+    assert same.mean() > 0.8
+    for k in ("rgb", "depth", "acc", "weights"):
+        assert maxabs(res[k][same], g[k][same]) < 5e-5, k
+
+
 def test_G10_rbk_weighted_sum():
     g = load_golden("G10_rbk_weighted_sum")
     ccw = g["ccw"]

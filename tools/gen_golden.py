@@ -383,6 +383,36 @@ def G24_render_other_multires():
     save("G24_render_other_multires", **out)
 
 
+def G25_pbe_composite_feature():
+    """kernel_type='PBE': the coarse PDRF level composites its geo features before the colour network (renderer.py:30-34,
+    voxnerf.py:223-239).  Eval render (64 + 32) and coarse_render (renderer.py:468-592: rgb + the composited feature map the PBE
+    blur kernel consumes) on the small grids of G9."""
+    K = W.synthetic_camera()
+    model, _ = _nerfall("c2f", 32, 0, rgb_add_bias=False, kernel_type="PBE", **PDRF_SMALL)
+    assert model.mlp_coarse.composite_feature and not model.mlp_fine.composite_feature
+    ref_import.load_np_state_dict(model, _pdrf_sds(model, 91, 92))
+    model.train(False)
+    rays = W.synthetic_rays(51, 56)
+    rgb, depth, acc, ex = model.render(400, 400, t(K), 1024, rays=t(rays), ndc=True, near=0., far=1., use_viewdirs=True, N_samples=64,
+                                       N_importance=32, retraw=True, perturb=0., raw_noise_std=0.)
+    out = dict(rgb=n(rgb), depth=n(depth), acc=n(acc), **{k: n(v) for k, v in ex.items()})
+    crgb, cfeat = model.coarse_render(400, 400, t(K), 1024, rays=t(rays), ndc=True, near=0., far=1., use_viewdirs=True, N_samples=64,
+                                      N_importance=32, perturb=0., raw_noise_std=0.)
+    out.update(coarse_rgb=n(crgb), coarse_feat=n(cfeat))
+    # the level alone on explicit inputs (VoxelNeRFBase.forward, both outputs)
+    rs = np.random.RandomState(909)
+    R, S = 24, 40
+    pts = (rs.uniform(-1.0, 1.0, size=(R, S, 3)) * np.array([1.4, 1.4, 0.9])).astype(np.float32)
+    z = np.sort(rs.uniform(0.0, 1.0, size=(R, S)).astype(np.float32), -1)
+    vd = rs.normal(size=(R, 3)).astype(np.float32)
+    vd /= np.linalg.norm(vd, axis=-1, keepdims=True)
+    rd = (vd * rs.uniform(0.8, 1.3, size=(R, 1))).astype(np.float32)
+    fts = model.mlp_coarse.sample(t(pts))
+    col, dep, ac, wts, fm = model.mlp_coarse(t(pts), t(vd), fts, model.embed_fn, model.embeddirs_fn, t(z), t(rd), 0., False)
+    out.update(l_pts=pts, l_z=z, l_vd=vd, l_rd=rd, l_fts=n(fts), l_color=n(col), l_depth=n(dep), l_acc=n(ac), l_weights=n(wts), l_feature=n(fm))
+    save("G25_pbe_composite_feature", **out)
+
+
 def G8_appfeature():
     model, _ = _nerfall("c2f", 64, 0, rgb_add_bias=False, **PDRF_SMALL)
     sd = _pdrf_sds(model, 21, 22)
@@ -893,7 +923,7 @@ def G22_mam():
 ALL = [G1_embedder, G2_nerf_mlp, G3_nerf_raw2outputs, G4_voxel_raw2outputs, G5_sample_pdf, G6_rays,
        G7_render_nerf, G8_appfeature, G9_render_c2f, G10_rbk_weighted_sum, G11_crf, G12_egm_loss, G13_edi,
        G14_loss_assembly, G15_awp_feature_integration, G16_rbk_warp, G17_compute_successor, G18_nerf_grads, G19_c2f_grads, G20_loss_grads,
-       G21_awp_sample_embed, G22_mam, G23_render_nerf_no_viewdirs, G24_render_other_multires]
+       G21_awp_sample_embed, G22_mam, G23_render_nerf_no_viewdirs, G24_render_other_multires, G25_pbe_composite_feature]
 
 if __name__ == "__main__":
     want = set(sys.argv[1:])
