@@ -191,7 +191,8 @@ class NeRFAll:
                           rgb_activate=args.rgb_activate, sigma_activate=args.sigma_activate,
                           render_rmnearplane=_args_get(args, "render_rmnearplane", 0),
                           extract_feature=self.extract_feature, composite_feature=False, precision=precision)
-            self.mlp_coarse = NeRF(state_dict, "mlp_coarse.", **common)
+            # kernel_type PBE: the coarse network's feature map is composited (renderer.py:30-34,89; nerf.py:167-169)
+            self.mlp_coarse = NeRF(state_dict, "mlp_coarse.", **dict(common, composite_feature=self.kernel_type == "PBE"))
             if args.N_importance > 0:
                 common_f = dict(common, D=_args_get(args, "netdepth_fine", args.netdepth), W=_args_get(args, "netwidth_fine", args.netwidth))
                 self.mlp_fine = NeRF(state_dict, "mlp_fine.", **common_f)
@@ -622,6 +623,10 @@ class NeRFAll:
         out = L.RenderOut()
         out.rgb, out.depth, out.acc, out.feature = L.ptr(rgb), L.ptr(depth), L.ptr(acc), L.ptr(feat)
         out.feature_kind = 2 if self.extract_feature == "before_linear" else 1
+        wts = None
+        if self.mode == "nerf" and c.composite_feature:           # nerf.py:167-169: feature_map = sum_s w feature
+            wts = torch.empty((R, S), **f32)
+            out.weights = L.ptr(wts)
         ws, need = self._workspace(cfg, R)
         tr = t_rand.contiguous().float() if t_rand is not None else None
         n0 = noise0.contiguous().float() if noise0 is not None else None
@@ -634,6 +639,8 @@ class NeRFAll:
         else:
             L.check(fn_render(c.handle, None, C.byref(cfg), L.ptr(_rays), R, L.ptr(tr), None, L.ptr(n0), None, C.byref(out), L.ptr(ws), need,
                               L.stream_ptr()), "coarse_render")
+        if wts is not None:
+            feat = (wts[..., None] * feat).sum(1)
         return rgb, feat
 
     def coarse_render(self, H, W, K, chunk=1 << 22, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,

@@ -384,6 +384,15 @@ def test_pbe_composite_feature_matches_reference_golden(prec, tol):
     print(f"[{prec} PBE render] rgb0 {e0:.2e}, rgb {efine:.2e} on {same.mean():.0%} of the rays")
     assert e0 < ltol and efine < ltol and (same.mean() > 0.8 or prec == "f16")
     assert maxabs(N(ex["z_vals0"]), g["z_vals0"]) < 1e-6
+    # mode='nerf' with PBE: coarse_render composites the coarse network's per-sample feature (nerf.py:167-169)
+    from types import SimpleNamespace
+    an = SimpleNamespace(mode="nerf", netdepth=8, netwidth=256, multires=10, multires_views=4, use_viewdirs=True, rgb_activate="sigmoid",
+                         sigma_activate="relu", N_importance=0, kernel_type="PBE")
+    if prec != "f16c":
+        mn = NeRFAll(an, W.prefixed(W.make_nerf_state_dict(93), "mlp_coarse"), precision=prec).eval()
+        nrgb, nfeat = mn.coarse_render(400, 400, K, rays=rays[:24], ndc=True, near=0., far=1., use_viewdirs=True, N_samples=48, perturb=0., raw_noise_std=0.)
+        assert nfeat.shape == (24, 256)
+        assert maxabs(N(nrgb), g["nerf_coarse_rgb"]) < ltol and maxabs(N(nfeat), g["nerf_coarse_feat"]) < (ltol if prec != "f16" else 2e-2)
     # the composed map through raw2outputs on a 16-channel raw (voxnerf.py:223-229)
     raw16 = torch.cat([T(g["l_weights"])[..., None] * 0 + 1.0, torch.rand((24, 40, 15), device=DEV)], -1)
     fmap, dens, acc2, wts2, dep2 = model.mlp_coarse.raw2outputs(raw16, T(g["l_z"]), T(g["l_rd"]))

@@ -410,6 +410,14 @@ def G25_pbe_composite_feature():
     fts = model.mlp_coarse.sample(t(pts))
     col, dep, ac, wts, fm = model.mlp_coarse(t(pts), t(vd), fts, model.embed_fn, model.embeddirs_fn, t(z), t(rd), 0., False)
     out.update(l_pts=pts, l_z=z, l_vd=vd, l_rd=rd, l_fts=n(fts), l_color=n(col), l_depth=n(dep), l_acc=n(ac), l_weights=n(wts), l_feature=n(fm))
+    # mode='nerf' with kernel_type PBE: the coarse network's feature map is composited (nerf.py:167-169)
+    modeln, _ = _nerfall("nerf", 0, 0, kernel_type="PBE")
+    assert modeln.mlp_coarse.composite_feature
+    ref_import.load_np_state_dict(modeln, W.prefixed(W.make_nerf_state_dict(93), "mlp_coarse"))
+    modeln.train(False)
+    nrgb, nfeat = modeln.coarse_render(400, 400, t(K), 1024, rays=t(rays[:24]), ndc=True, near=0., far=1., use_viewdirs=True, N_samples=48,
+                                       perturb=0., raw_noise_std=0.)
+    out.update(nerf_coarse_rgb=n(nrgb), nerf_coarse_feat=n(nfeat))
     save("G25_pbe_composite_feature", **out)
 
 
