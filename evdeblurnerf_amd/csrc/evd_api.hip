@@ -158,19 +158,23 @@ int evd_nerf_create(const evd_nerf_desc* d, evd_nerf** out) {
             for (int l = 1; l < D; ++l) {
                 if (l - 1 == d->skip) {       // blocks [h_0 .. h_{KB-2} | pe | h_{KB-1}]
                     auto wide_col = [&](int j, int kk) {
-                        if (j < 4 * (KB - 1)) return IC + hid_col(j, kk);
+                        if (j < 4 * (KB - 1)) return IC + c_hid_col(j, kk);
                         if (j < 4 * (KB - 1) + PE_KS) return pe_col(j - 4 * (KB - 1), kk);
-                        return IC + hid_col(j - PE_KS, kk);
+                        return IC + c_hid_col(j - PE_KS, kk);
                     };
                     sc.layer(pts_w(l), W, W + IC, T, PE_KS + KS, 2, wide_col);
                 } else {
-                    sc.layer(pts_w(l), W, W, T, KS, 2, hid_col);
+                    sc.layer(pts_w(l), W, W, T, KS, 2, c_hid_col);
                 }
             }
-            sc.layer(alpha_w, 1, W, 1, KS, 1, hid_col);
-            sc.layer(feature_w, W, W, T, KS, 2, hid_col);
-            sc.layer(views_w, W / 2, W + ICV, T / 2, KS + PEV_KS, 2, views_col);
-            sc.layer(rgb_w, 3, W / 2, 1, KS / 2, 1, hid_col);
+            sc.layer(alpha_w, 1, W, 1, KS, 1, c_hid_col);
+            sc.layer(feature_w, W, W, T, KS, 2, c_hid_col);
+            sc.layer(views_w, W / 2, W + ICV, T / 2, KS + PEV_KS, 2, [&](int j, int kk) {
+                if (j < KS) return c_hid_col(j, kk);
+                const int c = pe_src_col(Lv, 8 * (j - KS) + (kk & 7), kk >> 3);
+                return c < 0 ? -1 : W + c;
+            });
+            sc.layer(rgb_w, 3, W / 2, 1, KS / 2, 1, c_hid_col);
             n->pipe_chunks[prec] = (int)(sc.bytes.size() / PIPE_CB);
             if (n->pipe_chunks[prec] != nerf_mlp_c_chunks(W, D, d->skip)) rc = fail(EVD_E_INVALID, "evd_nerf_create: f16c stream has %d chunks, kernel expects %d", n->pipe_chunks[prec], nerf_mlp_c_chunks(W, D, d->skip));
             if (!rc) rc = n->pipe_c.upload(sc);

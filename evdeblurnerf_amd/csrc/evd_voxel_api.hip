@@ -248,7 +248,7 @@ int evd_voxel_create(const evd_voxel_desc* d, evd_voxel** out) {
     }
     if (standard && voxel_mlp_c_chunks(HD, G, FT) > 0) {     // compensated float16 mode: the layer table of voxel_mlp_c_kernel.h VoxNetC (groups of two tiles, 64-input blocks)
         auto c0p = [&](int j, int kk) {
-            if (j < GK) { const int c = 16 * j + phi(kk); return c < G ? c : -1; }
+            if (j < GK) { const int c = c_hid_col(j, kk); return c < G ? c : -1; }
             const int c = pe_src_col(Lv, 8 * (j - GK) + (kk & 7), kk >> 3);
             return c < 0 ? -1 : G + c;
         };
@@ -256,11 +256,11 @@ int evd_voxel_create(const evd_voxel_desc* d, evd_voxel** out) {
         StreamBuilderC sc(PIPE_CB);
         sc.arena = A;
         sc.layer(sigma_w0, HD, d->input_ch, T, KF + PE_KS, 2, in0_col);
-        sc.layer_at(1, KS, 1, [](int, int r) { return r == 0 ? 0 : -1; }, hid_col, sig_at);
-        sc.layer_at(GT, KS, 2, [G](int t, int r) { return 32 * t + r < G ? 1 + 32 * t + r : -1; }, hid_col, sig_at);
+        sc.layer_at(1, KS, 1, [](int, int r) { return r == 0 ? 0 : -1; }, c_hid_col, sig_at);
+        sc.layer_at(GT, KS, 2, [G](int t, int r) { return 32 * t + r < G ? 1 + 32 * t + r : -1; }, c_hid_col, sig_at);
         sc.layer(color_w0, HD, G + ICV, T, GK + PEV_KS, 2, c0p);
-        sc.layer(color_w1, HD, HD, T, KS, 2, hid_col);
-        sc.layer(color_w2, 3, HD, 1, KS, 1, hid_col);
+        sc.layer(color_w1, HD, HD, T, KS, 2, c_hid_col);
+        sc.layer(color_w2, 3, HD, 1, KS, 1, c_hid_col);
         v->pipe_c_chunks = (int)(sc.bytes.size() / PIPE_CB);
         if (v->pipe_c_chunks != voxel_mlp_c_chunks(HD, G, FT))
             rc = fail(EVD_E_INVALID, "evd_voxel_create: f16c stream has %d chunks, kernel expects %d", v->pipe_c_chunks, voxel_mlp_c_chunks(HD, G, FT));

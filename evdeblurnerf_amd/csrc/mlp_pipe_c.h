@@ -209,9 +209,12 @@ __device__ __forceinline__ void c_finish(XBlk& x, unsigned m, const f32x16& r0, 
 // truncation error of the float16 product is what the second fp6 product removes; its residuals are one bit larger (c_scales).
 // -DEVD_C_RNE: round to nearest + explicit ReLU of the two floats (6 VALU): RGB error 9.5e-6 instead of 1.8e-5 on the trained weights,
 // kernel 3-5 % slower.
+// The pair is (value v of the group's tile 0, value v of tile 1): the block's float16 elements then run (t0 v0, t1 v0, t0 v1, ...), which is
+// the order v_cvt_scalef32_2xpk16_fp6_f32 reads its two sources in -- so both fp6 operands of the block (and the weight operands that pair
+// with them, pack.h) index k like the float16 fragments do.
 template <bool RELU>
-__device__ __forceinline__ void c_drain_pair(f32x16& a, int k, XBlk& x, int word, unsigned& m) {
-    float x0 = a[2 * k], x1 = a[2 * k + 1];
+__device__ __forceinline__ void c_drain_pair(f32x16& a0, f32x16& a1, int v, XBlk& x, unsigned& m) {
+    float x0 = a0[v], x1 = a1[v];
 #ifdef EVD_C_RNE
     if (RELU) { x0 = relu_f32(x0); x1 = relu_f32(x1); }
     const f32x2 v = {x0, x1};
@@ -225,7 +228,7 @@ __device__ __forceinline__ void c_drain_pair(f32x16& a, int k, XBlk& x, int word
     }
     constexpr bool CLAMP = RELU;
 #endif
-    x.h[word] = w;
+    x.h[v] = w;
     m = c_max_acc<!RELU>(m, w);
     float r0, r1;                                                  // x - float(f16(x)): v_fma_mix_f32 reads the half straight from the pair
     if (CLAMP) {
@@ -235,8 +238,8 @@ __device__ __forceinline__ void c_drain_pair(f32x16& a, int k, XBlk& x, int word
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(w), "v"(x0));
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(w), "v"(x1));
     }
-    a[2 * k] = r0;
-    a[2 * k + 1] = r1;
+    a0[v] = r0;
+    a1[v] = r1;
 }
 
 // Static description of one layer.
@@ -315,10 +318,10 @@ __device__ __forceinline__ void c_group(ST& st, CPipe& pp, XBlk (&in)[NIN], XBlk
                 XBlk& dst = FIRST ? in[L::PDB] : out[P > 0 ? P - 1 : 0];
                 if (u < DG * 8) {
                     if (kAbl & 512) continue;
-                    const int dt = u / 8, k = u % 8;
+                    static_assert(DG == 0 || DG == 2, "blocks are drained from groups of two tiles");
                     if (u == 0) pp.m = 0u;
-                    if (FIRST) c_drain_pair<L::PRELU>(pp.acc[oth][dt], k, dst, 8 * dt + k, pp.m);
-                    else c_drain_pair<L::RELU>(pp.acc[oth][dt], k, dst, 8 * dt + k, pp.m);
+                    if (FIRST) c_drain_pair<L::PRELU>(pp.acc[oth][0], pp.acc[oth][1], u, dst, pp.m);
+                    else c_drain_pair<L::RELU>(pp.acc[oth][0], pp.acc[oth][1], u, dst, pp.m);
                 } else if (!(kAbl & 256)) {
                     c_finish(dst, pp.m, pp.acc[oth][0], pp.acc[oth][1]);
                 }
@@ -554,14 +557,11 @@ template <int L, int KSN> __device__ __forceinline__ void c_encode(const float (
             else if (qq == 3 * L + 1) y[i] = h ? 0.f : x[2];
             else y[i] = 0.f;
         }
-        r[q >> 4][q & 15] = y[0];
-        r[q >> 4][(q & 15) + 1] = y[1];
+        r[0][q >> 1] = y[0];           // element i = position q of the encoding: pair v = q / 2 is (r[0][v], r[1][v]), as in the layers' epilogue
+        r[1][q >> 1] = y[1];
     }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {       // "tile" t = k / 8 holds k-steps 2t, 2t+1: the same unit as the layers' epilogue
-        const int t = k >> 3, kk = k & 7;
-        c_drain_pair<false>(r[t], kk, out, 8 * t + kk, m);
-    }
+    for (int v = 0; v < 16; ++v) c_drain_pair<false>(r[0], r[1], v, out, m);
     c_finish(out, m, r[0], r[1]);
 }
 

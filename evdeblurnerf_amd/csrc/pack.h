@@ -129,10 +129,17 @@ __host__ __device__ static inline int e8m0_for_max(float amax) {
 }
 __host__ __device__ static inline float e8m0_value(int byte) { return ldexpf(1.f, byte - 127); }
 // position i (0..31) of an fp6 operand of lane half h  ->  (k-step inside the 4-k-step block, position kk = 8 h + e of that k-step)
-//   kind 0 (pairs with fp6(f16(x)), v_cvt_scalef32_pk32_fp6_f16 of the block's four float16 fragments): sequential
-//   kind 1 (pairs with fp6(x - f16(x)), v_cvt_scalef32_2xpk16_fp6_f32 of two 16-value float32 sources): the two sources interleave
-__host__ __device__ constexpr int c_pos_kstep(int kind, int i) { return kind == 0 ? (i >> 3) : 2 * (i & 1) + (i >> 4); }
-__host__ __device__ constexpr int c_pos_elem(int kind, int i) { return kind == 0 ? (i & 7) : ((i >> 1) & 7); }
+//   both kinds are sequential: the block's elements are drained as pairs across the two source tiles (c_hid_col below), which is the order
+//   v_cvt_scalef32_2xpk16_fp6_f32 interleaves its two float32 sources in, and v_cvt_scalef32_pk32_fp6_f16 reads the float16 fragments in
+__host__ __device__ constexpr int c_pos_kstep(int kind, int i) { (void)kind; return i >> 3; }
+__host__ __device__ constexpr int c_pos_elem(int kind, int i) { (void)kind; return i & 7; }
+// input channel of a HIDDEN block's position (k-step j, position kk = 8 h + e) in this mode: the block is drained from a group of two
+// output tiles in pairs (tile 0 value v, tile 1 value v) (mlp_pipe_c.h c_drain_pair), so element i = 8 (j & 3) + e is value i / 2 of tile
+// i & 1, and value v of lane half h is row (v & 3) + 8 (v / 4) + 4 h of its 32-row tile (the MFMA's D layout)
+__host__ __device__ constexpr int c_hid_col(int j, int kk) {
+    const int b = j >> 2, e = kk & 7, h = kk >> 3, i = 8 * (j & 3) + e, v = i >> 1;
+    return 64 * b + 32 * (i & 1) + (v & 3) + 8 * (v >> 2) + 4 * h;
+}
 
 // one lane's 32 values of an fp6 operand (kind 0: the float16 rounding residuals of the weights, kind 1: the weights) -> 24 packed bytes,
 // the first 16 at lo16, the last 8 at hi8; shared by the host packer and the device re-packer

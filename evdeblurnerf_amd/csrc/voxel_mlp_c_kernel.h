@@ -35,19 +35,19 @@ template <int HD, int G, int FT> struct VoxNetC {
 // one input block from 64 float32 values of a row: B position q = 8 j + e of lane half h <-> value 16 j + 8 h + e (the natural k-step order
 // of evd_voxel_api.hip in0_col), all three representations
 __device__ __forceinline__ void c_block_from_row(const float* f, XBlk& out) {
-    f32x16 r[2];
+    f32x16 r[2];               // element i = 8 j + e of the block is pair i / 2, member i & 1 (mlp_pipe_c.h c_drain_pair)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(f + 16 * j), b = *reinterpret_cast<const f32x4*>(f + 16 * j + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            r[j >> 1][8 * (j & 1) + e] = a[e];
-            r[j >> 1][8 * (j & 1) + 4 + e] = b[e];
+        for (int e = 0; e < 8; ++e) {
+            const int i = 8 * j + e;
+            r[i & 1][i >> 1] = e < 4 ? a[e] : b[e - 4];
         }
     }
     unsigned m = 0u;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) c_drain_pair<false>(r[k >> 3], k & 7, out, k, m);
+    for (int v = 0; v < 16; ++v) c_drain_pair<false>(r[0], r[1], v, out, m);
     c_finish(out, m, r[0], r[1]);
 }
 
