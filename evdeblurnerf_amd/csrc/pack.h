@@ -140,6 +140,18 @@ __host__ __device__ constexpr int c_hid_col(int j, int kk) {
     const int b = j >> 2, e = kk & 7, h = kk >> 3, i = 8 * (j & 3) + e, v = i >> 1;
     return 64 * b + 32 * (i & 1) + (v & 3) + 8 * (v >> 2) + 4 * h;
 }
+// (every channel of a 256-wide layer is hit exactly once by the 16 k-steps x 16 positions)
+constexpr bool c_hid_col_is_permutation() {
+    bool seen[256] = {};
+    for (int j = 0; j < 16; ++j)
+        for (int kk = 0; kk < 16; ++kk) {
+            const int c = c_hid_col(j, kk);
+            if (c < 0 || c >= 256 || seen[c]) return false;
+            seen[c] = true;
+        }
+    return true;
+}
+static_assert(c_hid_col_is_permutation(), "c_hid_col");
 
 // one lane's 32 values of an fp6 operand (kind 0: the float16 rounding residuals of the weights, kind 1: the weights) -> 24 packed bytes,
 // the first 16 at lo16, the last 8 at hi8; shared by the host packer and the device re-packer
