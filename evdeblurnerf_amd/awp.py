@@ -159,8 +159,9 @@ class SampleFeatureEmbed:
         self._synced = None
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            L.lib().evd_awp_embed_destroy(self._h)
+        h = getattr(self, "_h", None)
+        if h and L is not None and getattr(L, "lib", None) is not None:     # module globals may be gone at interpreter shutdown
+            L.lib().evd_awp_embed_destroy(h)
             self._h = None
 
     def load_params(self, flat):
