@@ -23,6 +23,8 @@
 //     row scales (one e8m0 byte per weight row, layer and fp6 operand) sit next to the biases in LDS.
 #pragma once
 
+#include <cstdlib>
+
 #include "mlp_pipe.h"
 
 namespace evd {
@@ -68,6 +70,18 @@ struct CCfg {
     static_assert((NSLOT & (NSLOT - 1)) == 0 && NSLOT >= 4 && NSLOT - BARP >= BARP + 1 && NSLOT - BARP >= 3 && TOTAL <= 160 * 1024, "ring geometry");
 };
 
+// workgroups of a persistent launch of the f16c kernels: one per CU (one wavefront per SIMD; EVD_C_BLOCKS overrides, 0 = one per tile)
+static inline int c_persistent_blocks() {
+    static const int n = [] {
+        if (const char* e = getenv("EVD_C_BLOCKS")) { const int v = atoi(e); return v > 0 ? v : 0x7fffffff; }
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        return cus;
+    }();
+    return n;
+}
+static inline long cmin_l(long a, long b) { return a < b ? a : b; }
+
 // Weight stream of this mode: the ring protocol of mlp_pipe.h's PStream (two chunks resident, counted vmcnt, one barrier per 16 KiB
 // chunk) with a deeper ring and a cheaper issue.  NSLOT slots: at the top of chunk c (behind the barrier that ended chunk c-1) chunks
 // c and c+1 are resident, c+2 .. c+NSLOT-2 in flight, the slot of c-1 is free; chunk_begin(c) issues chunk c+NSLOT-1 into it,
@@ -108,13 +122,19 @@ template <int NCH> struct CStream {
         // M0 (the LDS base of the chunk's slot) is set by the chunk's first piece and stays: nothing else in these kernels touches M0, and the
         // instruction offset moves the global and the LDS address together (as in issue()) -- 6 scalar instructions per chunk fewer in a
         // kernel whose issue slots are as full as its matrix pipe (measured on one box: 0.904 -> 0.890 ms)
+        // ... and M0 for chunk c is written BEHIND the last piece of chunk c - 1 (the pieces go out in stream order; start_issue /
+        // restart_issue leave M0 at the first chunk issued here), so that no piece waits on the s_mov -> LDS-DMA hazard slot
         const unsigned off = voff + (unsigned)c * CCfg::CB;
-        const unsigned dst = dst0 + (unsigned)(c & (NSLOT - 1)) * CCfg::CB;
-        if (k == 0) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(gbase), "s"(dst) : "memory");
+        const unsigned dst_next = dst0 + (unsigned)((c + 1) & (NSLOT - 1)) * CCfg::CB;
+        if (k == 0) asm volatile("global_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(gbase) : "memory");
         else if (k == 1) asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" : : "v"(off), "s"(gbase) : "memory");
         else if (k == 2) asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" : : "v"(off), "s"(gbase) : "memory");
-        else asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" : : "v"(off), "s"(gbase) : "memory");
+        else asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072\n\ts_mov_b32 m0, %2" : : "v"(off), "s"(gbase), "s"(dst_next) : "memory");
 #endif
+    }
+    __device__ __forceinline__ void set_m0_for(int c) {       // M0 = LDS base of chunk c's slot (see issue_piece)
+        const unsigned dst = dst0 + (unsigned)(c & (NSLOT - 1)) * CCfg::CB;
+        asm volatile("s_mov_b32 m0, %0" : : "s"(dst) : "memory");
     }
     // wait until at most `chunks` chunks (PIECES loads each) of this wavefront are outstanding
     static __device__ __forceinline__ void wait_chunks(int chunks) {
@@ -138,6 +158,14 @@ template <int NCH> struct CStream {
 #pragma unroll
         for (int c = 0; c < AHEAD; ++c)
             if (c < NCH) issue(c);
+        set_m0_for(AHEAD);
+    }
+    // a persistent workgroup's next pass over the stream; the caller guarantees that every wavefront has crossed the barrier of the last chunk
+    __device__ __forceinline__ void restart_issue() {
+#pragma unroll
+        for (int c = 0; c < AHEAD; ++c)
+            if (c < NCH) issue(c);
+        set_m0_for(AHEAD);
     }
     __device__ __forceinline__ void start_wait() {      // chunks 0 .. BARP landed
         wait_chunks(cmax(0, cmin(AHEAD, NCH) - (BARP + 1)));
@@ -235,13 +263,22 @@ __device__ __forceinline__ void c_drain_pair(f32x16& a0, f32x16& a1, int v, XBlk
 #else
     unsigned w = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
     if (RELU) {
+        // running maximum on the RAW pair as signed 16-bit integers (a negative half is a negative int16 and never raises m >= 0): it does
+        // not read the ReLU's result, so it fills the wait state hipcc puts between a packed instruction and the first reader of its
+        // result (544 s_nop per wavefront in a kernel whose issue slots are full)
         const s16x2 zero = {0, 0};
-        w = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, w), zero));
+        const unsigned wraw = w;
+        w = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, wraw), zero));
+        m = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, m), __builtin_bit_cast(s16x2, wraw)));
     }
     constexpr bool CLAMP = RELU;
 #endif
     x.h[v] = w;
+#ifdef EVD_C_RNE
     m = c_max_acc<!RELU>(m, w);
+#else
+    if (!RELU) m = c_max_acc<true>(m, w);
+#endif
     float r0, r1;                                                  // x - float(f16(x)): v_fma_mix_f32 reads the half straight from the pair
     if (CLAMP) {
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0] clamp" : "=v"(r0) : "v"(w), "v"(x0));

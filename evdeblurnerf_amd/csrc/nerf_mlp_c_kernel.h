@@ -107,8 +107,8 @@ __global__ __launch_bounds__(CCfg::NT, 1) void k_nerf_mlp_c(const MlpParams p) {
 #endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, h = lane >> 5;
-    NerfCtxC<N, ST> cx;
-    cx.st.start_issue(p.wstream, smem, tid);
+    ST st0;
+    st0.start_issue(p.wstream, smem, tid);
     float* bias = reinterpret_cast<float*>(smem + CCfg::RING);
     {   // biases and row-scale words -> LDS
         constexpr int NB = (CCfg::BIAS_WORDS / 2 / 4 + CCfg::NT - 1) / CCfg::NT;
@@ -132,10 +132,18 @@ __global__ __launch_bounds__(CCfg::NT, 1) void k_nerf_mlp_c(const MlpParams p) {
     unsigned bias_off = lds_offset_of(bias);
     asm volatile("" : "+v"(bias_off));     // opaque base: the bias / row-scale reads then take immediate offsets (the block sits above 64 KiB)
     const lds_f32_p lbias = (lds_f32_p)(unsigned long)bias_off;
+
+    // PERSISTENT workgroups (one per CU, launch_nerf_c): a workgroup walks the 128-sample tiles blockIdx.x, blockIdx.x + gridDim.x, ...
+    // With one workgroup resident per CU nothing covers the hand-over between two workgroups (dispatch, the bias block, the cold ring):
+    // here the bias block is loaded once, and the weight stream of the next tile is re-issued behind the last barrier of this one, in
+    // front of the tile's output, so that it lands while the next tile's rays are loaded and encoded.
+    const long ntile = (p.nsamp + CCfg::SAMPLES - 1) / CCfg::SAMPLES;
+    for (long tile = blockIdx.x;;) {
+    NerfCtxC<N, ST> cx;                        // per tile: nothing of it but the stream's four address words is carried around the loop
+    cx.st = st0;
     cx.bias = lbias;
     cx.lane = lane;
-
-    const long smp = (long)blockIdx.x * CCfg::SAMPLES + wave * 32 + n;
+    const long smp = tile * CCfg::SAMPLES + wave * 32 + n;
     const bool valid = smp < p.nsamp;
     const long sidx = valid ? smp : p.nsamp - 1;
     float z_own = 0.f, z_next = 0.f, dnorm = 0.f;
@@ -187,6 +195,8 @@ __global__ __launch_bounds__(CCfg::NT, 1) void k_nerf_mlp_c(const MlpParams p) {
     c_layer<typename N::Views, typename N::Rgb, ST, KB + 1, KB / 2>(cx.st, cx.pp, vin, hbuf, nullptr, lb, lane);
     lb += (T / 2) * 32;
     c_layer<typename N::Rgb, void, ST, KB / 2, 1>(cx.st, cx.pp, hbuf, none, rraw, lb, lane);
+    const bool more = tile + gridDim.x < ntile;
+    if (more) cx.st.restart_issue();            // every wavefront is behind the barrier that ended the stream's last chunk: all slots are free
 
     if (h == 0 && valid && (!FUSE || p.raw)) {
         f32x4 o = {rraw[0], rraw[1], rraw[2], araw[0]};   // cat([rgb, alpha]) nerf.py:157
@@ -241,6 +251,12 @@ __global__ __launch_bounds__(CCfg::NT, 1) void k_nerf_mlp_c(const MlpParams p) {
             }
         }
     }
+#ifdef EVD_C_STAMP
+    st0.tw = cx.st.tw; st0.tb = cx.st.tb;
+#endif
+    if (!more) break;
+    tile += gridDim.x;
+    }
 }
 
 template <int W, int D, int SKIP> constexpr int nerf_c_chunks() { return NerfNetC<W, D, SKIP>::NCH; }
@@ -248,7 +264,7 @@ template <int W, int D, int SKIP> constexpr int nerf_c_chunks() { return NerfNet
 template <int W, int D, int SKIP, bool FUSE>
 static int launch_nerf_c(const MlpParams& p, hipStream_t st) {
     typedef NerfNetC<W, D, SKIP> N;
-    const long blocks = cdiv(p.nsamp, CCfg::SAMPLES);
+    const long blocks = cmin_l(cdiv(p.nsamp, CCfg::SAMPLES), (long)c_persistent_blocks());
     const size_t lds = CCfg::TOTAL;
     EVD_SET_MAX_LDS((&k_nerf_mlp_c<W, D, SKIP, FUSE>), lds);
     if (p.nbias != N::NTILES * 32) return fail(EVD_E_INVALID, "evd_nerf_mlp (f16c): %d bias floats, kernel expects %d", p.nbias, N::NTILES * 32);

@@ -73,7 +73,11 @@ __global__ __launch_bounds__(CCfg::NT, 1) void k_voxel_mlp_c(const VoxMlpParams 
     asm volatile("" : "+v"(bias_off));     // opaque base: the bias / row-scale reads then take immediate offsets
     const lds_f32_p lbias = (lds_f32_p)(unsigned long)bias_off;
 
-    const long smp = (long)blockIdx.x * CCfg::SAMPLES + wave * 32 + n;
+    // persistent workgroups, one per CU (nerf_mlp_c_kernel.h: the hand-over between two workgroups of a one-workgroup-per-CU kernel is
+    // uncovered; a pass of this network is only ~19 us long)
+    const long ntile = (p.nsamp + CCfg::SAMPLES - 1) / CCfg::SAMPLES;
+    for (long tile = blockIdx.x;;) {
+    const long smp = tile * CCfg::SAMPLES + wave * 32 + n;
     const bool valid = smp < p.nsamp;
     const long sidx = valid ? smp : p.nsamp - 1;
     XBlk in0[2], pev;
@@ -103,6 +107,8 @@ __global__ __launch_bounds__(CCfg::NT, 1) void k_voxel_mlp_c(const VoxMlpParams 
     c_layer<typename N::C0, typename N::C1, ST, GB + 1, KB>(st, pp, cin, c0, nullptr, lbias + N::B_C0, lane);
     c_layer<typename N::C1, typename N::C2, ST, KB, KB>(st, pp, c0, c1, nullptr, lbias + N::B_C1, lane);
     c_layer<typename N::C2, void, ST, KB, 1>(st, pp, c1, none, col, lbias + N::B_C2, lane);
+    const bool more = tile + gridDim.x < ntile;
+    if (more) st.restart_issue();               // behind the barrier of the stream's last chunk: all slots are free
 
     if (h == 0 && valid) {
         f32x4 o;
@@ -111,12 +117,15 @@ __global__ __launch_bounds__(CCfg::NT, 1) void k_voxel_mlp_c(const VoxMlpParams 
         for (int c = 0; c < 3; ++c) o[1 + c] = 1.f / (1.f + expf(-col[c]));      // torch.sigmoid(h) voxnerf.py:252
         *reinterpret_cast<f32x4*>(p.raw + sidx * 4) = o;
     }
+    if (!more) break;
+    tile += gridDim.x;
+    }
 }
 
 template <int HD, int G, int FT>
 static int launch_voxel_c(const VoxMlpParams& p, hipStream_t st) {
     typedef VoxNetC<HD, G, FT> N;
-    const long blocks = cdiv(p.nsamp, CCfg::SAMPLES);
+    const long blocks = cmin_l(cdiv(p.nsamp, CCfg::SAMPLES), (long)c_persistent_blocks());
     const size_t lds = CCfg::TOTAL;
     EVD_SET_MAX_LDS((&k_voxel_mlp_c<HD, G, FT>), lds);
     if (p.nchunks != N::NCH) return fail(EVD_E_INVALID, "evd_voxel (f16c): packed stream has %d chunks, kernel expects %d", p.nchunks, N::NCH);
