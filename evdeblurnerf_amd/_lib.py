@@ -140,6 +140,7 @@ SIGNATURES = {
     "evd_raw2outputs": (_I, [_vp, _vp, _vp, _I, _L, _I, _I, _I, _I, _I, _I, _I, _I, _F, _vp,
                              _vp, _vp, _vp, _vp, _vp, _vp, _I, _vp, _vp]),
     "evd_raw2outputs_bwd": (_I, [_vp, _vp, _vp, _I, _L, _I, _I, _I, _I, _I, _I, _I, _I, _F, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "evd_raw2outputs_bwd_rays": (_I, [_vp, _vp, _vp, _I, _L, _I, _I, _I, _I, _I, _I, _I, _I, _F, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _I, _vp]),
     "evd_sample_pdf_merge": (_I, [_vp, _vp, _L, _I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp]),
     "evd_nerf_render_workspace_bytes": (_S, [C.POINTER(RenderCfg), _L]),
     "evd_nerf_render_rays": (_I, [_vp, _vp, C.POINTER(RenderCfg), _vp, _L, _vp, _vp, _vp, _vp,

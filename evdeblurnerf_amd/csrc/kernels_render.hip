@@ -553,7 +553,7 @@ __global__ __launch_bounds__(256) void k_composite_rows_bwd(const float* __restr
                                                             float rmnear, const float* __restrict__ noise,
                                                             const float* __restrict__ g_map, const float* __restrict__ g_depth,
                                                             const float* __restrict__ g_acc, const float* __restrict__ g_w,
-                                                            float* __restrict__ d_raw) {
+                                                            float* __restrict__ d_raw, float* __restrict__ d_rays_d, int d_rd_stride) {
     const int lane = threadIdx.x & 63;
     const long r = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r >= R) return;
@@ -575,17 +575,18 @@ __global__ __launch_bounds__(256) void k_composite_rows_bwd(const float* __restr
     const float gd = g_depth ? g_depth[r] : 0.f;
     const float ga = (g_acc ? g_acc[r] : 0.f) - (white_bkgd ? gm[0] + gm[1] + gm[2] : 0.f);
     zi[SPL] = dpp_f32<0x130>(0.f, zi[0]);
-    float alpha[SPL], om[SPL], dist[SPL], spre[SPL], mask[SPL];
+    float alpha[SPL], om[SPL], dist[SPL], spre[SPL], mask[SPL], densm[SPL];
 #pragma unroll
     for (int j = 0; j < SPL; ++j) {
         const int i = i0 + j;
         const float vv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
-        dist[j] = 0.f; spre[j] = 0.f; mask[j] = 1.f;
+        dist[j] = 0.f; spre[j] = 0.f; mask[j] = 1.f; densm[j] = 0.f;
         if (i < S - 1) {
             dist[j] = __fmul_rn(__fsub_rn(zi[j + 1], zi[j]), norm);
             spre[j] = vv[sigma_ch] + (noise ? noise[r * (long)(S - 1) + i] : 0.f);
             float dens = act(sigma_act, spre[j]);
             if (rmnear > 0.f) { mask[j] = zi[j + 1] > rmnear ? 1.f : 0.f; dens *= mask[j]; }
+            densm[j] = dens;
             alpha[j] = __fadd_rn(-expf(-__fmul_rn(dens, dist[j])), 1.f);
         } else {
             alpha[j] = i == S - 1 ? 1.f : 0.f;
@@ -612,6 +613,7 @@ __global__ __launch_bounds__(256) void k_composite_rows_bwd(const float* __restr
     const float pre_incl = wave_scan_add_dpp(lsum);          // inclusive prefix of the lanes' sums of G w
     const float total = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pre_incl), 63));
     float run = pre_incl - lsum;                             // exclusive prefix at this lane's first sample
+    float dn = 0.f;                                          // this lane's share of |d| dL/d|d|
 #pragma unroll
     for (int j = 0; j < SPL; ++j) {
         const int i = i0 + j;
@@ -623,9 +625,21 @@ __global__ __launch_bounds__(256) void k_composite_rows_bwd(const float* __restr
             for (int c = 0; c < 3; ++c) o[rgb_ch0 + c] = gm[c] * w[j] * act_grad(rgb_act, vv[rgb_ch0 + c]);
             if (i < S - 1) {
                 const float suffix = total - run;            // sum_{j > i} G_j w_j
-                o[sigma_ch] = dist[j] * (G[j] * Tn[j] - suffix) * mask[j] * act_grad(sigma_act, spre[j]);
+                const float q = dist[j] * (G[j] * Tn[j] - suffix);      // dL / d density_i
+                o[sigma_ch] = q * mask[j] * act_grad(sigma_act, spre[j]);
+                dn += q * densm[j];
             }
             reinterpret_cast<float4*>(d_raw + r * (long)S * 4)[i] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    // alpha_i depends on the ray direction through dist_i = dz_i |d| only: dL/d|d| = sum_i (dL/d density_i) density_i / |d|, and
+    // d|d| / d d = d / |d|
+    if (d_rays_d) {
+        dn = wave_sum_dpp(dn);
+        if (lane == 0) {
+            const float k = dn / (norm * norm);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) d_rays_d[r * d_rd_stride + c] = k * d[c];
         }
     }
 }
@@ -918,14 +932,23 @@ int evd_raw2outputs_bwd(const float* raw, const float* z, const float* rays_d, i
                         int sigma_ch, int rgb_ch0, int n_rgb, int rgb_act, int sigma_act, int white_bkgd, float rmnear_thresh,
                         const float* noise, const float* g_map, const float* g_depth, const float* g_acc, const float* g_weights,
                         float* d_raw, void* stream) {
+    return evd_raw2outputs_bwd_rays(raw, z, rays_d, rays_d_stride, R, S, C, sigma_ch, rgb_ch0, n_rgb, rgb_act, sigma_act, white_bkgd, rmnear_thresh,
+                                    noise, g_map, g_depth, g_acc, g_weights, d_raw, nullptr, 0, stream);
+}
+
+int evd_raw2outputs_bwd_rays(const float* raw, const float* z, const float* rays_d, int rays_d_stride, long R, int S, int C,
+                             int sigma_ch, int rgb_ch0, int n_rgb, int rgb_act, int sigma_act, int white_bkgd, float rmnear_thresh,
+                             const float* noise, const float* g_map, const float* g_depth, const float* g_acc, const float* g_weights,
+                             float* d_raw, float* d_rays_d, int d_rays_d_stride, void* stream) {
     EVD_REQUIRE(raw && z && rays_d && d_raw && R >= 0 && S >= 1, "evd_raw2outputs_bwd: bad arguments");
+    EVD_REQUIRE(!d_rays_d || d_rays_d_stride >= 3, "evd_raw2outputs_bwd_rays: d_rays_d needs a row stride >= 3");
     EVD_REQUIRE(C == 4 && n_rgb == 3 && S <= 256, "evd_raw2outputs_bwd: built for [R,S,4] raw with three colour channels and S <= 256 (got C=%d n_rgb=%d S=%d)", C, n_rgb, S);
     EVD_REQUIRE(sigma_ch >= 0 && sigma_ch < 4 && rgb_ch0 >= 0 && rgb_ch0 + 3 <= 4 && (sigma_ch < rgb_ch0 || sigma_ch >= rgb_ch0 + 3),
                 "evd_raw2outputs_bwd: channel layout out of range");
     if (R == 0) return EVD_OK;
     hipStream_t st = as_stream(stream);
 #define EVD_BWD(SPL) k_composite_rows_bwd<SPL><<<cdiv(R, 4), 256, 0, st>>>(raw, z, rays_d, rays_d_stride, R, S, sigma_ch, rgb_ch0, rgb_act, sigma_act, \
-                                                                          white_bkgd, rmnear_thresh, noise, g_map, g_depth, g_acc, g_weights, d_raw)
+                                                                          white_bkgd, rmnear_thresh, noise, g_map, g_depth, g_acc, g_weights, d_raw, d_rays_d, d_rays_d_stride)
     if (S <= 64) EVD_BWD(1);
     else if (S <= 128) EVD_BWD(2);
     else if (S <= 192) EVD_BWD(3);

@@ -50,19 +50,13 @@ class _Raw2Outputs(torch.autograd.Function):
         R, S, Cc = raw.shape
         c = lambda g: g.contiguous().float() if g is not None else None
         d_raw = torch.empty_like(raw)
-        L.check(L.lib().evd_raw2outputs_bwd(L.ptr(raw), L.ptr(z), L.ptr(rd), rd.shape[-1], R, S, Cc, sigma_ch, rgb_ch0, 3, rgb_act, sigma_act,
-                                            white, thr, L.ptr(noise) if has_noise else None, L.ptr(c(g_rgb)), L.ptr(c(g_depth)),
-                                            L.ptr(c(g_acc)), L.ptr(c(g_wts)), L.ptr(d_raw), L.stream_ptr()), "evd_raw2outputs_bwd")
-        d_rd = None
-        if ctx.needs_input_grad[2]:
-            # alpha_i depends on sigma_i dz_i |d| only: d / d|d| = sum_i (d loss / d sigma_i) sigma_i / |d|, with relu
-            # d loss / d sigma_i = d_raw[i, sigma] wherever sigma_i > 0 (and both sides vanish elsewhere)
-            if sigma_act != L.ACT["relu"]:
-                raise NotImplementedError("rays_d gradient through raw2outputs is built for sigma_activate relu")
-            pre = raw[..., :-1, sigma_ch] + (noise if has_noise else 0.)
-            nrm = rd.norm(dim=-1, keepdim=True)
-            d_nrm = (d_raw[..., :-1, sigma_ch] * torch.relu(pre)).sum(-1, keepdim=True) / nrm
-            d_rd = d_nrm * rd / nrm
+        # the ray directions enter through dists * |d| only; their gradient (the blur batch's warped rays) is a per-ray sum the kernel
+        # has in registers (eight small tensor operations per level before)
+        d_rd = torch.empty_like(rd) if ctx.needs_input_grad[2] else None
+        L.check(L.lib().evd_raw2outputs_bwd_rays(L.ptr(raw), L.ptr(z), L.ptr(rd), rd.shape[-1], R, S, Cc, sigma_ch, rgb_ch0, 3, rgb_act, sigma_act,
+                                                 white, thr, L.ptr(noise) if has_noise else None, L.ptr(c(g_rgb)), L.ptr(c(g_depth)),
+                                                 L.ptr(c(g_acc)), L.ptr(c(g_wts)), L.ptr(d_raw), L.ptr(d_rd), rd.shape[-1], L.stream_ptr()),
+                "evd_raw2outputs_bwd_rays")
         return (d_raw, None, d_rd) + (None,) * 7
 
 

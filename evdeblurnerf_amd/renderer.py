@@ -34,13 +34,18 @@ class _MergeFeatures(torch.autograd.Function):
     (evd_merge_features / _bwd; the fine columns are a strided copy)"""
 
     @staticmethod
-    def forward(ctx, ft0, ftn, order, ft_fine):
-        a, b, f = ft0.contiguous().float(), ftn.contiguous().float(), ft_fine.contiguous().float()
+    def forward(ctx, ft0, ftn, order, ft_fine, rows=None):
+        a, b = ft0.contiguous().float(), ftn.contiguous().float()
         R, S, F = a.shape
-        N, Ff = b.shape[1], f.shape[-1]
-        out = torch.empty((R, S + N, F + Ff), dtype=torch.float32, device=a.device)
+        N, Ff = b.shape[1], ft_fine.shape[-1]
+        # `rows`: the caller's [R, S + N, F + Ff] buffer whose columns F.. the fine gather has already written (ft_fine is that window)
+        placed = rows is not None and rows.shape == (R, S + N, F + Ff) and rows.is_contiguous() and ft_fine.data_ptr() == rows.data_ptr() + 4 * F
+        out = rows if placed else torch.empty((R, S + N, F + Ff), dtype=torch.float32, device=a.device)
         L.check(L.lib().evd_merge_features(L.ptr(a), L.ptr(b), L.ptr(order), R, S, N, F, L.ptr(out), F + Ff, L.stream_ptr()), "evd_merge_features")
-        out[..., F:] = f
+        if placed:
+            ctx.mark_dirty(rows)
+        else:
+            out[..., F:] = ft_fine.float()
         ctx.save_for_backward(order)
         ctx.dims = (R, S, N, F, Ff)
         return out
@@ -53,7 +58,14 @@ class _MergeFeatures(torch.autograd.Function):
         d0 = torch.empty((R, S, F), dtype=torch.float32, device=g.device)
         dn = torch.empty((R, N, F), dtype=torch.float32, device=g.device)
         L.check(L.lib().evd_merge_features_bwd(L.ptr(g), F + Ff, L.ptr(order), R, S, N, F, L.ptr(d0), L.ptr(dn), L.stream_ptr()), "evd_merge_features_bwd")
-        return d0, dn, None, g[..., F:]
+        return d0, dn, None, g[..., F:], None          # (the fine columns stay a strided window: the scatter reads them where they are)
+
+
+def _window(rows, col, width):
+    """columns col .. col + width - 1 of a contiguous [R, S, C] float32 buffer as a tensor of its own on the same storage (not an autograd
+    view of `rows`: a kernel writes it through its pointer)"""
+    R, S, Cc = rows.shape
+    return torch.empty(0, dtype=rows.dtype, device=rows.device).set_(rows.untyped_storage(), rows.storage_offset() + col, (R, S, width), (S * Cc, Cc, 1))
 
 
 class _RayBatch(torch.autograd.Function):
@@ -391,6 +403,9 @@ class NeRFAll:
         cfg = self._cfg(0, 0, 1.0, False, 0., 1., S, Ni, lindisp, perturb, white_bkgd)
         cfg.is_train = 1
         if perturb > 0.:
+            if t_rand is None and u is None and Ni > 0:           # one draw for both (renderer.py:171 t_rand, utils/rays.py:166 u)
+                rnd = torch.rand((R * (S + Ni),), **f32)
+                t_rand, u = rnd[:R * S].view(R, S), rnd[R * S:].view(R, Ni)
             t_rand = torch.rand((R, S), **f32) if t_rand is None else t_rand
             u = torch.rand((R, Ni), **f32) if (Ni > 0 and u is None) else u
         if raw_noise_std > 0.:
@@ -433,7 +448,10 @@ class NeRFAll:
         ptm = points(rb, zm)
         # cat([coarse features re-ordered by the sort (:209-213), fine features at the merged points]) in one row buffer: the merge is a
         # library kernel writing columns 0..fc-1 (a row permutation: its backward is one too), the fine features land behind them
-        ft = _MergeFeatures.apply(ft0, ftn, order, fine.sample_train(ptm, pf["grids"], self.precision))
+        # -- and the fine gather writes them there itself (its output is a strided window of the row buffer; no copy either way)
+        fc, ff = ft0.shape[-1], fine.app_dim
+        rows = torch.empty((ptm.shape[0], ptm.shape[1], fc + ff), dtype=torch.float32, device=ptm.device)
+        ft = _MergeFeatures.apply(ft0, ftn, order, fine.sample_train(ptm, pf["grids"], self.precision, out=_window(rows, fc, ff)), rows)
         feat = None
         if want_feature == "fragments":                     # fused AWP consumer: the geo features stay in the level's store (awp.FusedAWP)
             from .voxnerf import GeoFragments

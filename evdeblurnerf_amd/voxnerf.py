@@ -72,20 +72,25 @@ class _VoxelSample(torch.autograd.Function):
     def forward(ctx, pts, net, precision, *grids):
         ctx.net, ctx.pts = net, pts
         ctx.save_for_backward(*grids)
-        return net.sample(pts, precision)
+        out, net._sample_out = getattr(net, "_sample_out", None), None        # a strided window to write into (sample_train(out=...))
+        return net.sample(pts, precision, out=out)
 
     @staticmethod
     def backward(ctx, d_out):
         L.note_backward()
         net, pts = ctx.net, ctx.pts.reshape(-1, 3).contiguous().float()
-        g = d_out.reshape(-1, net.app_dim).contiguous().float()
+        # the gradient rows as they arrive: a window of a wider row buffer (renderer._MergeFeatures) is read in place through its row stride
+        if d_out.dtype == torch.float32 and d_out.dim() == 3 and d_out.stride(2) == 1 and d_out.stride(0) == d_out.shape[1] * d_out.stride(1):
+            g, g_stride = d_out, d_out.stride(1)
+        else:
+            g, g_stride = d_out.reshape(-1, net.app_dim).contiguous().float(), net.app_dim
         grads, gs = _grid_grads(net, ctx.saved_tensors, in_place=getattr(net, "_grads_in_place", _GRADS_IN_PLACE) and not torch.is_grad_enabled())
         d_pts = torch.empty_like(pts) if ctx.needs_input_grad[0] else None
         # scratch for the hybrid form of the scatter (csrc/kernel_voxel_scatter.hip: plane taps by direct float atomics, line taps through
         # fixed-point LDS slices -- a third fewer atomic requests, 24-27 % faster); EVD_SCATTER=direct passes none: every tap an atomic
         nb = int(L.lib().evd_voxel_sample_bwd_workspace_bytes(net._h, pts.shape[0])) if os.environ.get("EVD_SCATTER") != "direct" else 0
         ws = torch.empty((nb,), dtype=torch.uint8, device=pts.device) if nb else None
-        L.check(L.lib().evd_voxel_sample_bwd_ws(net._h, L.ptr(pts), pts.shape[0], L.ptr(g), net.app_dim, 0, C.byref(gs), L.ptr(d_pts), L.ptr(ws), nb,
+        L.check(L.lib().evd_voxel_sample_bwd_ws(net._h, L.ptr(pts), pts.shape[0], C.c_void_p(g.data_ptr()), g_stride, 0, C.byref(gs), L.ptr(d_pts), L.ptr(ws), nb,
                                                 L.stream_ptr()), "evd_voxel_sample_bwd_ws")
         return (d_pts.reshape(ctx.pts.shape) if d_pts is not None else None, None, None, *grads)
 
@@ -242,18 +247,27 @@ class VoxelNeRFBase:
         return rgb, dens, acc, wts, depth
 
     # voxnerf.py:203-208
-    def sample(self, pts, precision=None):
+    def sample(self, pts, precision=None, out=None):
         """voxnerf.py:203-208.  precision None: the float32 grids (the reference's arithmetic); a mode name: as the c2f renderer samples
-        in that mode (f16 / bf16 read the float16 copies of the grids)"""
+        in that mode (f16 / bf16 read the float16 copies of the grids).  out: a float32 [R, S, app_dim] tensor to write instead of a new
+        one -- rows of unit channel stride and ONE row stride (a column window of a wider row buffer)"""
         sh = pts.shape
         p = pts.reshape(-1, 3).contiguous().float()
-        out = torch.empty((p.shape[0], self.app_dim), dtype=torch.float32, device=p.device)
-        if precision is None:
-            L.check(L.lib().evd_voxel_sample(self._h, L.ptr(p), p.shape[0], L.ptr(out), self.app_dim, 0, L.stream_ptr()), "evd_voxel_sample")
+        if out is not None:
+            if not (len(sh) == 3 and out.dtype == torch.float32 and out.shape == (sh[0], sh[1], self.app_dim) and out.stride(2) == 1
+                    and out.stride(0) == sh[1] * out.stride(1) and out.stride(1) >= self.app_dim):
+                raise L.EvdError("sample(out=...): [R, S, app_dim] float32 rows with unit channel stride and one row stride")
+            dst, stride = out, out.stride(1)
         else:
-            L.check(L.lib().evd_voxel_sample_prec(self._h, L.PREC[precision], L.ptr(p), p.shape[0], L.ptr(out), self.app_dim, 0, L.stream_ptr()),
+            dst, stride = torch.empty((p.shape[0], self.app_dim), dtype=torch.float32, device=p.device), self.app_dim
+        if precision is None:
+            L.check(L.lib().evd_voxel_sample(self._h, L.ptr(p), p.shape[0], C.c_void_p(dst.data_ptr()), stride, 0, L.stream_ptr()), "evd_voxel_sample")
+        else:
+            L.check(L.lib().evd_voxel_sample_prec(self._h, L.PREC[precision], L.ptr(p), p.shape[0], C.c_void_p(dst.data_ptr()), stride, 0, L.stream_ptr()),
                     "evd_voxel_sample_prec")
-        return out.reshape(sh[0], sh[1], self.app_dim) if len(sh) == 3 else out
+        if out is not None:
+            return out
+        return dst.reshape(sh[0], sh[1], self.app_dim) if len(sh) == 3 else dst
 
     # ---- training the sigma / colour networks (f16 / bf16): one flat float32 parameter tensor, library order ----------------
     PARAM_KEYS = ["sigma_net.0.weight", "sigma_net.1.weight", "color_net.0.weight", "color_net.0.bias", "color_net.1.weight",
@@ -366,12 +380,13 @@ class VoxelNeRFBase:
         if getattr(self, "_synced", None) != tuple((t.data_ptr(), t._version) for t in grids) + (L.backward_generation(),):
             self.load_grids(grids)
 
-    def sample_train(self, pts, grids, precision=None):
+    def sample_train(self, pts, grids, precision=None, out=None):
         """sample(pts) with autograd to the grid parameters (re-loads them into the library after an optimizer step).  precision: the
         arithmetic mode of the training forward -- f16 / bf16 gather the float16 grid copies exactly as the inference render of that mode
         does (the copies are refreshed by the re-load); None / the float32-grade modes read the float32 grids.  The backward (scatter-add,
         the interpolation-weight derivative) always works on the float32 grids."""
         self._sync(grids)
+        self._sample_out = out
         return _VoxelSample.apply(pts, self, precision, *grids)
 
     def tv_loss_train(self, grids):

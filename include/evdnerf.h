@@ -200,6 +200,13 @@ int evd_raw2outputs_bwd(const float* raw, const float* z, const float* rays_d, i
                         int sigma_ch, int rgb_ch0, int n_rgb, int rgb_act, int sigma_act, int white_bkgd, float rmnear_thresh,
                         const float* noise, const float* g_map, const float* g_depth, const float* g_acc, const float* g_weights,
                         float* d_raw, void* stream);
+/* The same with the gradient w.r.t. the ray directions, d_rays_d dev [R, >= 3] (row stride d_rays_d_stride) or NULL: alpha depends on
+ * rays_d through dists * |rays_d| (nerf.py:104, voxnerf.py:179), which the blur batch's learnable ray warp differentiates
+ * (run_nerf.py:593): dL/d rays_d = (sum_i dL/d density_i * density_i) * rays_d / |rays_d|^2. */
+int evd_raw2outputs_bwd_rays(const float* raw, const float* z, const float* rays_d, int rays_d_stride, long R, int S, int C,
+                             int sigma_ch, int rgb_ch0, int n_rgb, int rgb_act, int sigma_act, int white_bkgd, float rmnear_thresh,
+                             const float* noise, const float* g_map, const float* g_depth, const float* g_acc, const float* g_weights,
+                             float* d_raw, float* d_rays_d, int d_rays_d_stride, void* stream);
 
 /* sample_pdf, utils/rays.py:149-193, called as in renderer.py:200-201,230-231 with bins = z_mid and
  * weights[...,1:-1]: z dev [R,S], weights dev [R,S] -> z_samples dev [R,N].  det != 0 => u = linspace;

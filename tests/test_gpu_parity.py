@@ -815,8 +815,8 @@ def test_raw2outputs_backward_matches_torch_autograd(S, white):
     rd_np = rs.standard_normal((R, 3)).astype(np.float32)
     g = [torch.as_tensor(rs.standard_normal(sh).astype(np.float32), device=DEV) for sh in ((R, 3), (R,), (R,), (R, S))]
 
-    def ref(raw):
-        raw, z, rd = raw.double(), T(z_np).double(), T(rd_np).double()
+    def ref(raw, rd=None):
+        raw, z, rd = raw.double(), T(z_np).double(), (T(rd_np) if rd is None else rd).double()
         rgb = torch.sigmoid(raw[..., :3])
         dists = (z[:, 1:] - z[:, :-1]) * rd.norm(dim=-1, keepdim=True)
         dens = torch.relu(raw[:, :-1, 3])
@@ -828,10 +828,12 @@ def test_raw2outputs_backward_matches_torch_autograd(S, white):
         return rgb_map, (w * z).sum(-1), acc, w
 
     raw_a = T(raw_np).requires_grad_(True)
-    rgb, dens, acc, wts, depth, _ = net.raw2outputs(raw_a, T(z_np), T(rd_np), white_bkgd=white)
+    rd_a = T(rd_np).requires_grad_(True)          # the ray directions get a gradient too (evd_raw2outputs_bwd_rays: through dists * |d|)
+    rgb, dens, acc, wts, depth, _ = net.raw2outputs(raw_a, T(z_np), rd_a, white_bkgd=white)
     (rgb * g[0]).sum().add((depth * g[1]).sum()).add((acc * g[2]).sum()).add((wts * g[3]).sum()).backward()
     raw_b = T(raw_np).requires_grad_(True)
-    r_rgb, r_depth, r_acc, r_w = ref(raw_b)
+    rd_b = T(rd_np).requires_grad_(True)
+    r_rgb, r_depth, r_acc, r_w = ref(raw_b, rd_b)
     assert maxabs(N(rgb), N(r_rgb.float())) < 2e-6 and maxabs(N(wts), N(r_w.float())) < 2e-6
     ((r_rgb * g[0]).sum() + (r_depth * g[1]).sum() + (r_acc * g[2]).sum() + (r_w * g[3]).sum()).backward()
     ga, gb = raw_a.grad.double(), raw_b.grad.double()
@@ -839,6 +841,10 @@ def test_raw2outputs_backward_matches_torch_autograd(S, white):
     print(f"[raw2outputs bwd S={S}] relative L2 error of d raw vs torch autograd (f64) = {rel:.2e}, L-inf {float((ga - gb).abs().max()):.2e}")
     assert rel < 2e-5
     assert float((ga - gb).abs().max()) < 1e-4 * max(1.0, float(gb.abs().max()))
+    da, db = rd_a.grad.double(), rd_b.grad.double()
+    rel_d = float((da - db).norm() / db.norm())
+    print(f"[raw2outputs bwd S={S}] relative L2 error of d rays_d vs torch autograd (f64) = {rel_d:.2e}")
+    assert rd_a.grad.shape == (R, 3) and rel_d < 2e-5
 
 
 def test_sample_pdf_merge_properties_at_scale():
