@@ -414,9 +414,9 @@ class NeRFAll:
         z0 = torch.empty((R, S), **f32)
         tr = t_rand.contiguous().float() if t_rand is not None else None
         L.check(L.lib().evd_sample_z(C.byref(cfg), L.ptr(rb), 11, R, L.ptr(tr), L.ptr(z0), L.stream_ptr()), "evd_sample_z")
-        rays_d = rb[:, 3:6].contiguous()
         if self.mode == "c2f":
             return self._render_rays_train_c2f(rb, z0, flat_coarse, flat_fine, S, Ni, perturb, u, noise0, noise1, want_feature)
+        rays_d = rb[:, 3:6].contiguous()
         if want_feature:
             raise NotImplementedError("depth_feature under autograd is built for mode='c2f' (the shipped AWP configs)")
         raw0 = self.mlp_coarse.mlp_train(flat_coarse, rb, z0, self.precision)
