@@ -130,3 +130,48 @@ def test_fine_level_f16c_ragged_sizes_repack_and_rejections():
     # training is not built in this mode
     with pytest.raises(L.EvdError):
         net.mlpforward_train(a[0], a[1], a[2], precision="f16c")
+
+
+def test_gather_into_a_row_window_and_merge_in_place():
+    """The training render lets the fine gather write its features straight into columns 32.. of the merged row buffer and scatters the
+    gradient from there (renderer._MergeFeatures with `rows`, VoxelNeRFSampleFeatures.sample(out=window)): values and every gradient
+    (grids, coarse features, sample positions) equal the path that gathers into its own tensor and copies; bad windows are rejected."""
+    from evdeblurnerf_amd import _lib as L
+    from evdeblurnerf_amd.renderer import _MergeFeatures, _window
+    net, sd = _fine_level(73)
+    rs = np.random.RandomState(5)
+    R, S, Nn, Fc = 37, 20, 13, 32
+    pts = T(rs.uniform(-1, 1, (R, S + Nn, 3)).astype(np.float32))
+    order = T(np.stack([rs.permutation(S + Nn) for _ in range(R)]).astype(np.int32))
+    g_out = T(rs.standard_normal((R, S + Nn, Fc + net.app_dim)).astype(np.float32))
+
+    def run(placed):
+        grids = [g.detach().clone().requires_grad_(True) for g in net.grid_params()]
+        ft0 = T(rs0.standard_normal((R, S, Fc)).astype(np.float32)).requires_grad_(True)
+        ftn = T(rs0.standard_normal((R, Nn, Fc)).astype(np.float32)).requires_grad_(True)
+        p = pts.clone().requires_grad_(True)
+        if placed:
+            rows = torch.empty((R, S + Nn, Fc + net.app_dim), dtype=torch.float32, device=pts.device)
+            out = _MergeFeatures.apply(ft0, ftn, order, net.sample_train(p, grids, None, out=_window(rows, Fc, net.app_dim)), rows)
+            assert out.data_ptr() == rows.data_ptr()
+        else:
+            out = _MergeFeatures.apply(ft0, ftn, order, net.sample_train(p, grids, None))
+        (out * g_out).sum().backward()
+        return [N(out.detach())] + [N(t.grad) for t in [ft0, ftn, p] + grids]
+
+    res = []
+    for placed in (False, True):
+        rs0 = np.random.RandomState(9)
+        res.append(run(placed))
+    assert np.array_equal(res[0][0], res[1][0])
+    for a, b in zip(res[0][1:], res[1][1:]):
+        assert maxabs(a, b) <= 1e-5 * max(1.0, float(np.abs(a).max()))          # the scatter sums in a non-deterministic order
+    # plain sample() into a window == sample() into its own tensor; windows the kernel cannot write are refused
+    rows = torch.zeros((R, S + Nn, 80), dtype=torch.float32, device=pts.device)
+    with torch.no_grad():
+        w = net.sample(pts, None, out=_window(rows, 48, net.app_dim))
+        assert torch.equal(w, net.sample(pts, None)) and torch.equal(rows[..., 48:], w) and float(rows[..., :48].abs().max()) == 0.0
+        with pytest.raises(L.EvdError):
+            net.sample(pts, None, out=rows[:, :, :net.app_dim].transpose(0, 1))
+        with pytest.raises(L.EvdError):
+            net.sample(pts, None, out=torch.empty((R, S + Nn, net.app_dim), dtype=torch.float64, device=pts.device))
