@@ -386,8 +386,11 @@ class VoxelNeRFBase:
         does (the copies are refreshed by the re-load); None / the float32-grade modes read the float32 grids.  The backward (scatter-add,
         the interpolation-weight derivative) always works on the float32 grids."""
         self._sync(grids)
-        self._sample_out = out
-        return _VoxelSample.apply(pts, self, precision, *grids)
+        self._sample_out = out              # taken (and cleared) by _VoxelSample.forward; not an autograd input: it is written through its pointer
+        try:
+            return _VoxelSample.apply(pts, self, precision, *grids)
+        finally:
+            self._sample_out = None
 
     def tv_loss_train(self, grids):
         self._sync(grids)
