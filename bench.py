@@ -285,9 +285,11 @@ def c2f_leg(precision, steps, parity=True):
     z = torch.linspace(0, 1, 128, device="cuda")
     pts = (rb[:, None, 0:3] + rb[:, None, 3:6] * z[None, :, None]).contiguous()
     fine = model.mlp_fine
-    g_ms = kernel_ms(lambda: fine.sample(pts), steps)
+    # the single-product half-precision modes gather float16 copies of the grids, and so does the FINE level of the compensated mode
+    # (evd_voxel_api.hip sample_for: its rounding costs nothing measurable there; the coarse level, which places the importance samples, stays float32)
+    half_grids = precision in ("f16", "bf16", "f16c")
+    g_ms = kernel_ms(lambda: fine.sample(pts, precision if half_grids else None), steps)
     n = R * 128
-    half_grids = precision in ("f16", "bf16")                   # the single-product half-precision modes gather float16 copies of the grids
     esz = 2 if half_grids else 4
     taps = 4 * 96 + 2 * 96                                      # 4 plane taps + 2 line taps x 96 channels = 576 gathered values per sample
     gathered = n * taps * esz
@@ -314,7 +316,7 @@ def c2f_leg(precision, steps, parity=True):
                                 "channels); the kernel is a latency chain per wavefront (points -> tap geometry -> gather -> basis GEMM -> store), "
                                 "not bandwidth-bound (DESIGN.md 3.3)"}}
     out["arithmetic"] = {"f16c": "fine level: compensated float16 (k_voxel_mlp_c: f16 MFMA + two block-scaled fp6 MFMA residual products); coarse 64-wide level: "
-                                 "float32-grade f16x3; gathers on the float32 grids",
+                                 "float32-grade f16x3 on the float32 grids; the fine level gathers the float16 copies of its grids",
                          "f16": "single-product float16 MFMA on both levels, float16 grid copies", "bf16": "bf16 MFMA on both levels, float16 grid copies",
                          "f16x3": "three float16 MFMA products per MAC on both levels, float32 grids", "f32": "exact float32 MFMA, float32 grids"}[precision]
     if parity:
@@ -658,7 +660,7 @@ def main(argv=None):
     # ---- the shipped configuration (every rank builds the model: the strong-scaling leg shards one frame's rows over the ranks)
     c2f_model = None
     if not a.no_c2f or not a.no_strong:
-        c2f_prec = a.precision                                          # f16c: fine level compensated, coarse level float32-grade, float32 grids
+        c2f_prec = a.precision                                          # f16c: fine level compensated (float16 grid copies), coarse level float32-grade on float32 grids
         train_prec = a.precision if a.precision in ("f16", "bf16", "f16x3") else "f16"     # training kernels: throughput mode f16 (f16x3 = float32-grade)
         # the informational legs below must never cost the contract line: a failure is recorded in its place
         def guarded(name, fn):
