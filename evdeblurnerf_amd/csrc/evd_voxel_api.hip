@@ -313,7 +313,9 @@ int evd_voxel_sample(const evd_voxel* v, const float* pts, long n, float* out, i
 }
 
 // sampling inside the c2f render: the half-precision arithmetic modes read the float16 copies of the grids
-static int sample_for(const evd_voxel* v, int precision, const float* pts, long n, float* out, int out_stride, int out_col, void* stream) {
+// feeds_only: the features go to the NEXT level's networks and to nothing that places samples (-1: decide by the level -- a level fed
+// by the previous one is the last of a c2f render)
+static int sample_for(const evd_voxel* v, int precision, const float* pts, long n, float* out, int out_stride, int out_col, void* stream, int feeds_only = -1) {
     static const bool f32_grids = env_flag("EVD_F32_GRIDS");   // developer switch: float32 grids in every mode
     bool half = (precision == EVD_PREC_BF16 || precision == EVD_PREC_F16) && !f32_grids;
     if (precision == EVD_PREC_F16C && !f32_grids) {
@@ -322,10 +324,14 @@ static int sample_for(const evd_voxel* v, int precision, const float* pts, long 
         // channels and six taps and costs nothing measurable (trained blurfactory-size model: RGB L-inf 8.4e-6 against 7.9e-6 on the
         // float32 grids, bound 1e-4), and the gather moves half the bytes (c2f render 0.708 -> 0.683 ms).  The coarse level keeps the
         // float32 grids: its weights place the importance samples, and with float16 grids there the FINE image is at 1.0e-4.
-        // EVD_F16C_HALF_GRIDS (developer switch, read per call): bit 0 the coarse level, bit 1 the fine one; default 2.
+        // The coarse features AT THE IMPORTANCE SAMPLES (renderer.py:209) also feed the fine networks only (bit 2) -- but there the
+        // float16 grids cost 3.4e-5 of the fine image for ~1 % of the render: left on the float32 grids.
+        // EVD_F16C_HALF_GRIDS (developer switch, read per call): bit 0 the coarse level's first gather, bit 1 the fine level, bit 2 the
+        // coarse level's gather at the importance samples; default 2.
         const char* e = getenv("EVD_F16C_HALF_GRIDS");
         const int m = e ? atoi(e) : 2;
-        half = (m & (v->ft_dim > v->app_dim ? 2 : 1)) != 0;
+        const bool last = v->ft_dim > v->app_dim;
+        half = (m & (last ? 2 : (feeds_only == 1 ? 4 : 1))) != 0;
     }
     return launch_voxel_sample(v->gp, half, pts, n, out, out_stride, out_col, as_stream(stream));
 }
@@ -568,7 +574,7 @@ int evd_c2f_render_rays(const evd_voxel* coarse, const evd_voxel* fine, const ev
     // all merged points (:211 samples the new ones and :194 the old ones -- a pure function of the point either way).
     const long n2 = R * (long)St;
     if ((rc = launch_points(rb, 11, zs, R * (long)Ni, Ni, ptn, st))) return rc;
-    if ((rc = sample_for(coarse, cfg->precision, ptn, R * (long)Ni, ftn, FC, 0, stream))) return rc;
+    if ((rc = sample_for(coarse, cfg->precision, ptn, R * (long)Ni, ftn, FC, 0, stream, 1))) return rc;
     if ((rc = launch_merge_features(ft0, ftn, order, R, S, Ni, FC, ft, FS, st))) return rc;
     if ((rc = launch_points(rb, 11, zm, n2, St, pts, st))) return rc;
     if ((rc = sample_for(fine, cfg->precision, pts, n2, ft, FS, coarse->app_dim, stream))) return rc;
