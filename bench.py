@@ -575,18 +575,31 @@ def main(argv=None):
             tfv = C.c_double()
             L.check(L.lib().evd_probe_mfma_rate(rnd, 2000, C.byref(tfv), L.stream_ptr()))
             sustained[name] = tfv.value
+        # the same binary on all-zero weights and rays: identical instruction stream, no switching activity -- what the kernel's STRUCTURE
+        # costs at full clock; the difference to kernel_ms is the chip clocking down to its power budget on real data
+        zero_ms = None
+        if not lean:
+            from evdeblurnerf_amd.nerf import NeRF
+            znet = NeRF({k: np.zeros_like(v) for k, v in W.make_nerf_state_dict(21).items()})
+            rb0, z0 = torch.zeros_like(rb), torch.zeros_like(z)
+            rb0[:, 7] = 1.0
+            zero_ms = kernel_ms(lambda: znet.mlpforward(rb0, z0, precision=a.precision), max(3, a.steps))
+            del znet
         result["roofline"] = {"bound": "mfma", "achieved": m["achieved"], "peak": m["peak"], "unit": "TFLOP/s",
                               "frac": m["frac"], "traffic": traffic, "kernel": m["kernel"], "kernel_ms": m["ms"],
                               "algorithmic_flop": R * S * FLOP_PER_SAMPLE, "algorithmic_hbm_bytes": R * S * 20 + R * 44,
                               "mfma_busy_frac_pmc": busy,
                               "sustained_mfma_tflops": sustained, "frac_of_sustained_random": m["achieved"] / sustained["random_operands"],
+                              "kernel_ms_on_all_zero_data": zero_ms,
                               "note": "achieved = algorithmic GEMM flops (1 186 816/sample) / HIP-event launch duration, against the 2.4 GHz "
                                       "dense peak; traffic (bytes per launch: 2.0x the algorithmic bytes, the weight stream is fetched once per "
                                       "XCD L2) and mfma_busy_frac_pmc (SQ_VALU_MFMA_BUSY_CYCLES over "
                                       "GRBM_GUI_ACTIVE x SIMDs: the kernel keeps the pipe busier than frac says because the chip clocks "
                                       "below 2.4 GHz under this load) are from the PMC passes in profiles/r03_pmc_mlp.json; "
                                       "sustained_mfma_tflops = a bare back-to-back MFMA loop on every SIMD, measured in this run "
-                                      "(evd_probe_mfma_rate): the random-operand figure is the practical ceiling for real data"}
+                                      "(evd_probe_mfma_rate): the random-operand figure is the practical ceiling for real data; "
+                                      "kernel_ms_on_all_zero_data = the same launch on all-zero weights and rays (same instruction stream, no "
+                                      "switching power): kernel_ms above it is the power-limited clock, not the kernel's structure"}
         result["modes"] = modes
         if not a.no_parity and not lean:
             # ---- parity of EVERY arithmetic mode at the full metric size against the CPU oracle (not against another kernel of
