@@ -97,7 +97,7 @@ def test_fine_level_f16c_ragged_sizes_repack_and_rejections():
     from evdeblurnerf_amd import _lib as L
     net, sd = _fine_level(71)
     rs = np.random.RandomState(11)
-    for R, S in ((1, 1), (1, 128), (3, 43), (70, 33), (129, 127), (531, 131)):       # the last one: several tiles per persistent workgroup, ragged end
+    for R, S in ((1, 1), (1, 128), (3, 43), (70, 33), (129, 127), (531, 131), (258, 128)):       # the last one: several tiles per persistent workgroup, ragged end
         a = _level_inputs(rs, R, S)
         ref = net.forward(*a, precision="f32")
         got = net.forward(*a, precision="f16c")

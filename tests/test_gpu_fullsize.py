@@ -194,7 +194,7 @@ def test_f16c_ragged_sizes_goldens_and_rejections(O):
     net = NeRF(sd)
     rs = np.random.RandomState(3)
     # (700 x 97 = 530.5 tiles: the persistent workgroups -- one per CU -- walk several tiles each and the last one is ragged)
-    for R, S in ((1, 1), (1, 128), (3, 43), (37, 65), (129, 127), (700, 97)):
+    for R, S in ((1, 1), (1, 128), (3, 43), (37, 65), (129, 127), (700, 97), (257, 128), (1000, 66)):      # 257 tiles: one workgroup walks two
         rb = np.zeros((R, 11), np.float32)
         rb[:, :3] = rs.uniform(-1, 1, (R, 3)); rb[:, 3:6] = rs.uniform(-1, 1, (R, 3)); rb[:, 7] = 1
         vd = rs.standard_normal((R, 3)); rb[:, 8:11] = vd / np.linalg.norm(vd, axis=1, keepdims=True)
