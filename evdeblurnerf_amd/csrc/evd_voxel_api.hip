@@ -568,15 +568,14 @@ int evd_c2f_render_rays(const evd_voxel* coarse, const evd_voxel* fine, const ev
     if ((rc = voxel_pass(coarse, cfg->precision, pts, rb + 8, 11, ft0, FC, zc, rb + 3, 11, R, S, cfg->is_train, noise0,
                          out->rgb0, out->depth0, out->acc0, w0, nullptr, raw, stream, cs0))) return rc;
     float* zm = out->z_vals ? out->z_vals : z2;
-    if ((rc = evd_sample_pdf_merge(zc, w0, R, S, Ni, cfg->perturb == 0.f, u, zs, zm, order, out->z_std, stream))) return rc;
+    // (+ the positions of the new and of the merged samples: the coarse pass is done with `pts`)
+    if ((rc = launch_sample_pdf_merge_pts(zc, w0, R, S, Ni, cfg->perturb == 0.f, u, zs, zm, order, out->z_std, rb, 11, ptn, pts, st))) return rc;
     // merged sample set (renderer.py:205-213), as the reference does it: coarse features are sampled at the NEW points only
     // (:209) and the rows of the old and new points are gathered by the sort order (:212-213); the fine level is sampled at
     // all merged points (:211 samples the new ones and :194 the old ones -- a pure function of the point either way).
     const long n2 = R * (long)St;
-    if ((rc = launch_points(rb, 11, zs, R * (long)Ni, Ni, ptn, st))) return rc;
     if ((rc = sample_for(coarse, cfg->precision, ptn, R * (long)Ni, ftn, FC, 0, stream, 1))) return rc;
     if ((rc = launch_merge_features(ft0, ftn, order, R, S, Ni, FC, ft, FS, st))) return rc;
-    if ((rc = launch_points(rb, 11, zm, n2, St, pts, st))) return rc;
     if ((rc = sample_for(fine, cfg->precision, pts, n2, ft, FS, coarse->app_dim, stream))) return rc;
     float* wo = out->weights ? out->weights : wts;
     return voxel_pass(fine, cfg->precision, pts, rb + 8, 11, ft, FS, zm, rb + 3, 11, R, St, cfg->is_train, noise1,

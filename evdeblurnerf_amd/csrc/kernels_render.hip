@@ -668,7 +668,11 @@ __global__ void k_weighted_channels(const float* __restrict__ x, const float* __
 __global__ __launch_bounds__(256) void k_sample_pdf_merge(const float* __restrict__ z, const float* __restrict__ wts, long R, int S,
                                                           int N, int det, const float* __restrict__ u,
                                                           float* __restrict__ z_samples, float* __restrict__ z_merged,
-                                                          int* __restrict__ order, float* __restrict__ z_std) {
+                                                          int* __restrict__ order, float* __restrict__ z_std,
+                                                          const float* __restrict__ rb, int rb_cols, float* __restrict__ pts_new,
+                                                          float* __restrict__ pts_merged) {
+    // rb (the ray batch: o at columns 0..2, d at 3..5) + pts_new / pts_merged: the positions o + d z of the new / the merged samples are
+    // written here as well (renderer.py:206: the arithmetic of k_points, bit for bit) -- two launches less in a c2f render
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long r = blockIdx.x * (long)(blockDim.x >> 6) + wv;
@@ -680,6 +684,11 @@ __global__ __launch_bounds__(256) void k_sample_pdf_merge(const float* __restric
     if (r >= R) return;
     const float* zr = z + r * (long)S;
     const float* wr = wts + r * (long)S;
+    float ro[3] = {0.f, 0.f, 0.f}, rd3[3] = {0.f, 0.f, 0.f};
+    if (rb) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { ro[c] = rb[r * rb_cols + c]; rd3[c] = rb[r * rb_cols + 3 + c]; }
+    }
     for (int i = lane; i < S; i += 64) zs0[i] = zr[i];
     // sum of (w + 1e-5) over weights[1:-1]
     double part = 0.0;
@@ -712,6 +721,10 @@ __global__ __launch_bounds__(256) void k_sample_pdf_merge(const float* __restric
         const float s = __fadd_rn(b0, __fmul_rn(t, __fsub_rn(b1, b0)));
         zsm[j] = s;
         if (z_samples) z_samples[r * (long)N + j] = s;
+        if (pts_new) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) pts_new[(r * (long)N + j) * 3 + c] = __fadd_rn(ro[c], __fmul_rn(rd3[c], s));
+        }
         m1 += (double)s;
     }
     __builtin_amdgcn_wave_barrier();
@@ -733,6 +746,10 @@ __global__ __launch_bounds__(256) void k_sample_pdf_merge(const float* __restric
             for (int k = 0; k < N; ++k) { const float o = zsm[k]; rank += (o < v) || (o == v && (k + S) < e); }
             if (z_merged) z_merged[r * (long)St + rank] = v;
             if (order) order[r * (long)St + rank] = e;
+            if (pts_merged) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) pts_merged[(r * (long)St + rank) * 3 + c] = __fadd_rn(ro[c], __fmul_rn(rd3[c], v));
+            }
         }
     }
 }
@@ -958,17 +975,36 @@ int evd_raw2outputs_bwd_rays(const float* raw, const float* z, const float* rays
     return EVD_OK;
 }
 
+}  // extern "C"
+namespace evd {
+int launch_sample_pdf_merge_pts(const float* z, const float* weights, long R, int S, int N, int det, const float* u,
+                                float* z_samples, float* z_merged, int* order, float* z_std,
+                                const float* rb, int rb_cols, float* pts_new, float* pts_merged, hipStream_t stream);      // (also declared in voxel.h)
+}
+extern "C" {
 int evd_sample_pdf_merge(const float* z, const float* weights, long R, int S, int N, int det, const float* u,
                          float* z_samples, float* z_merged, int* order, float* z_std, void* stream) {
+    return evd::launch_sample_pdf_merge_pts(z, weights, R, S, N, det, u, z_samples, z_merged, order, z_std, nullptr, 0, nullptr, nullptr, as_stream(stream));
+}
+
+}  // extern "C"
+namespace evd {
+// evd_sample_pdf_merge + the positions of the new and of the merged samples (internal: evd_c2f_render_rays)
+int launch_sample_pdf_merge_pts(const float* z, const float* weights, long R, int S, int N, int det, const float* u,
+                                float* z_samples, float* z_merged, int* order, float* z_std,
+                                const float* rb, int rb_cols, float* pts_new, float* pts_merged, hipStream_t stream) {
     EVD_REQUIRE(z && weights && R >= 0 && S >= 3 && N >= 1, "evd_sample_pdf_merge: bad arguments");
+    EVD_REQUIRE(rb || (!pts_new && !pts_merged), "evd_sample_pdf_merge: sample positions need the ray batch");
     EVD_REQUIRE(det || u, "evd_sample_pdf_merge: det == 0 needs the explicit u draw");
     if (R == 0) return EVD_OK;
     const size_t lds = 4 * sizeof(float) * (size_t)(2 * S + N + 2);
     EVD_REQUIRE(lds <= 64 * 1024, "evd_sample_pdf_merge: S + N too large for the LDS staging (%zu bytes)", lds);
-    k_sample_pdf_merge<<<cdiv(R, 4), 256, lds, as_stream(stream)>>>(z, weights, R, S, N, det, u, z_samples, z_merged, order, z_std);
+    k_sample_pdf_merge<<<cdiv(R, 4), 256, lds, stream>>>(z, weights, R, S, N, det, u, z_samples, z_merged, order, z_std, rb, rb_cols, pts_new, pts_merged);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }
+}  // namespace evd
+extern "C" {
 
 int evd_numerics_flags(const float* const* ptrs, const long* counts, int n_keys, unsigned* flags, void* stream) {
     using namespace evd;

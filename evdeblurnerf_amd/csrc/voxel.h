@@ -65,6 +65,10 @@ constexpr int TV_MAX_BLOCKS = 4096;     // partial (dh^2, dw^2) pairs per tensor
 struct TvShape { int C[6], H[6], W[6], blocks[6]; };
 
 int launch_points(const float* rb, int nc, const float* z, long n, int S, float* pts, hipStream_t st);
+// evd_sample_pdf_merge + the positions o + d z of the new / of the merged samples (kernels_render.hip)
+int launch_sample_pdf_merge_pts(const float* z, const float* weights, long R, int S, int N, int det, const float* u,
+                                float* z_samples, float* z_merged, int* order, float* z_std,
+                                const float* rb, int rb_cols, float* pts_new, float* pts_merged, hipStream_t stream);
 int launch_merge_features(const float* old, const float* fresh, const int* order, long R, int S, int N, int F, float* out, int out_stride,
                           hipStream_t st);
 int launch_merge_features_bwd(const float* d_out, int d_stride, const int* order, long R, int S, int N, int F, float* d_old, float* d_fresh, hipStream_t st);
