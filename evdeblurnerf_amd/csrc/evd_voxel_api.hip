@@ -551,8 +551,7 @@ int evd_c2f_render_rays(const evd_voxel* coarse, const evd_voxel* fine, const ev
     const int FS = 64;      // feature row stride: coarse features at column 0, fine at column coarse->app_dim (renderer.py:195)
     int rc;
     float* zc = (Ni ? (out->z_vals0 ? out->z_vals0 : z0) : (out->z_vals ? out->z_vals : z0));
-    if ((rc = evd_sample_z(cfg, rb, 11, R, t_rand, zc, stream))) return rc;
-    if ((rc = launch_points(rb, 11, zc, R * (long)S, S, pts, st))) return rc;
+    if ((rc = launch_sample_z_pts(cfg, rb, 11, R, t_rand, zc, pts, st))) return rc;       // z stratification + pts = o + d z (renderer.py:163-180)
     const int FC = coarse->app_dim;
     EVD_REQUIRE(!Ni || (FC == 32 && FC % 4 == 0), "evd_c2f_render_rays: coarse app_dim %d (workspace is sized for 32)", FC);
     EVD_REQUIRE(FC <= FS && (!Ni || !fine || FC + fine->app_dim <= FS),

@@ -254,7 +254,8 @@ __global__ __launch_bounds__(256) void k_points_bwd(const float* __restrict__ z,
 
 // reference networks/renderer.py:163-178
 __global__ void k_sample_z(const float* __restrict__ rb, int nc, long R, int S, int lindisp, int perturb,
-                           const float* __restrict__ t_rand, float* __restrict__ z) {
+                           const float* __restrict__ t_rand, float* __restrict__ z, float* __restrict__ pts) {
+    // pts (or null): the sample positions o + d z as k_points writes them (renderer.py:180), one launch less in a c2f render
     const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (idx >= R * S) return;
     const long r = idx / S;
@@ -272,6 +273,10 @@ __global__ void k_sample_z(const float* __restrict__ rb, int nc, long R, int S, 
         zi = __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), t_rand[idx]));
     }
     z[idx] = zi;
+    if (pts) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pts[idx * 3 + c] = __fadd_rn(rb[r * nc + c], __fmul_rn(rb[r * nc + 3 + c], zi));
+    }
 }
 
 // k_ray_batch + k_sample_z in one launch (evd_nerf_render: near / far are the configuration's scalars, so z does not depend on the packed
@@ -793,6 +798,9 @@ __global__ void k_numerics_flags(const NumericsKeys a, unsigned* __restrict__ fl
 
 
 }  // namespace evd
+namespace evd {      // internal forms of two entries below, also used by evd_voxel_api.hip (declared in voxel.h)
+int launch_sample_z_pts(const evd_render_cfg* cfg, const float* ray_batch, int ncol, long R, const float* t_rand, float* z, float* pts, hipStream_t stream);
+}
 
 using namespace evd;
 
@@ -895,14 +903,22 @@ int evd_ray_batch_z(const evd_render_cfg* cfg, const float* rays, long R, const 
 extern "C" {
 
 int evd_sample_z(const evd_render_cfg* cfg, const float* ray_batch, int ncol, long R, const float* t_rand, float* z, void* stream) {
+    return evd::launch_sample_z_pts(cfg, ray_batch, ncol, R, t_rand, z, nullptr, as_stream(stream));
+}
+}  // extern "C"
+namespace evd {
+// evd_sample_z + the sample positions (internal: evd_c2f_render_rays)
+int launch_sample_z_pts(const evd_render_cfg* cfg, const float* ray_batch, int ncol, long R, const float* t_rand, float* z, float* pts, hipStream_t stream) {
     EVD_REQUIRE(cfg && R >= 0 && z && cfg->N_samples > 0, "evd_sample_z: bad arguments");
     EVD_REQUIRE(!(cfg->perturb > 0.f) || t_rand, "evd_sample_z: perturb > 0 needs the explicit t_rand draw");
+    EVD_REQUIRE(!pts || ncol >= 6, "evd_sample_z: sample positions need the origin and direction columns");
     if (R == 0) return EVD_OK;
-    k_sample_z<<<cdiv(R * cfg->N_samples, 256), 256, 0, as_stream(stream)>>>(ray_batch, ncol, R, cfg->N_samples, cfg->lindisp,
-                                                                           cfg->perturb > 0.f, t_rand, z);
+    k_sample_z<<<cdiv(R * cfg->N_samples, 256), 256, 0, stream>>>(ray_batch, ncol, R, cfg->N_samples, cfg->lindisp, cfg->perturb > 0.f, t_rand, z, pts);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }
+}  // namespace evd
+extern "C" {
 
 int evd_raw2outputs(const float* raw, const float* z, const float* rays_d, int rays_d_stride, long R, int S, int C,
                     int sigma_ch, int rgb_ch0, int n_rgb, int rgb_act, int sigma_act, int white_bkgd,

@@ -65,6 +65,8 @@ constexpr int TV_MAX_BLOCKS = 4096;     // partial (dh^2, dw^2) pairs per tensor
 struct TvShape { int C[6], H[6], W[6], blocks[6]; };
 
 int launch_points(const float* rb, int nc, const float* z, long n, int S, float* pts, hipStream_t st);
+// evd_sample_z + the sample positions (kernels_render.hip)
+int launch_sample_z_pts(const evd_render_cfg* cfg, const float* ray_batch, int ncol, long R, const float* t_rand, float* z, float* pts, hipStream_t stream);
 // evd_sample_pdf_merge + the positions o + d z of the new / of the merged samples (kernels_render.hip)
 int launch_sample_pdf_merge_pts(const float* z, const float* weights, long R, int S, int N, int det, const float* u,
                                 float* z_samples, float* z_merged, int* order, float* z_std,
