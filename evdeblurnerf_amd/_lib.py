@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EVD_LIB_PATH") or os.path.join(_HERE, "lib", "libevdnerf.so")
 MAXL = 16
 
-PREC = {"f32": 0, "f16x3": 1, "bf16": 2, "f16": 3, "f16c": 4}
+PREC = {"f32": 0, "f16x3": 1, "bf16": 2, "f16": 3, "f16c": 4, "f16m": 5}     # f16m: training entries only (include/evdnerf.h)
 ACT = {"none": 0, "relu": 1, "sigmoid": 2, "exp": 3, "sigmoid1": 4, "softplus": 5, "tanh": 6}
 
 _fp = C.POINTER(C.c_float)

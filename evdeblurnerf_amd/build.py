@@ -27,7 +27,12 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=
 # the matrix core reads directly: f16c 5708 -> 4802 VALU instructions per wavefront, 0.879 -> 0.857 ms; f16x3 1.58 -> 1.53 ms
 # (tools/run_lib_variants.sh; the two-wavefront kernels and the training / scatter kernels do not change or get slower with it).
 VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
-PER_FILE = {"kernel_nerf_mlp_pipe_f16c.hip": VGPR_FORM, "kernel_nerf_mlp_pipe_f16x3.hip": VGPR_FORM, "kernel_voxel_pipe_f16c.hip": VGPR_FORM}
+# The TRAIN variants of the f16c kernels add ~70 stores and the fragment permutations to a body that hipcc unrolls completely (#pragma unroll
+# over the static layer table): past the default pragma-unroll threshold it leaves the loops rolled, indexes the register arrays dynamically
+# and the kernel runs out of scratch memory (1900 branches, 4000 scratch accesses).  The inference units are compiled without the flag.
+UNROLL = ["-mllvm", "-pragma-unroll-threshold=1000000"]
+PER_FILE = {"kernel_nerf_mlp_pipe_f16c.hip": VGPR_FORM, "kernel_nerf_mlp_pipe_f16x3.hip": VGPR_FORM, "kernel_voxel_pipe_f16c.hip": VGPR_FORM,
+            "kernel_voxel_train_f16c.hip": VGPR_FORM + UNROLL, "kernel_nerf_train_fwd_f16c.hip": VGPR_FORM + UNROLL}
 
 
 def hipcc() -> str:

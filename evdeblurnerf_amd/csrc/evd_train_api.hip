@@ -13,7 +13,14 @@ using namespace evd;
 namespace evd {
 constexpr int TRAIN_WG_SAMPLES = 256;       // samples per workgroup of the training kernels (8 wavefronts x 32)
 static long train_tiles(long nsamp) { return cdiv(nsamp, (long)TRAIN_WG_SAMPLES) * (TRAIN_WG_SAMPLES / 32); }
-static bool train_built(const evd_nerf* n, int prec) { return is_train_prec(prec) && n->pipe_chunks[prec] > 0; }
+// the mixed modes (include/evdnerf.h): EVD_PREC_F16C = compensated forward, EVD_PREC_F16M = split-float16 forward; both on the
+// float16 mode's store and backward
+static bool train_built(const evd_nerf* n, int prec) {
+    if (prec == EVD_PREC_F16C) return n->pipe_chunks[EVD_PREC_F16] > 0 && n->pipe_chunks[EVD_PREC_F16C] > 0;
+    if (prec == EVD_PREC_F16M) return n->pipe_chunks[EVD_PREC_F16] > 0 && n->pipe_chunks[EVD_PREC_F16X3] > 0;
+    return prec >= 0 && prec < EVD_NUM_PREC && is_train_prec(prec) && n->pipe_chunks[prec] > 0;
+}
+static int store_prec(int prec) { return (prec == EVD_PREC_F16C || prec == EVD_PREC_F16M) ? EVD_PREC_F16 : prec; }
 }  // namespace evd
 
 
@@ -21,25 +28,33 @@ extern "C" {
 
 size_t evd_nerf_train_store_bytes(long nsamp) { return nsamp < 0 ? 0 : (size_t)train_tiles(nsamp) * astore::TILE_BYTES; }
 size_t evd_nerf_train_store_bytes_prec(int precision, long nsamp) {
-    return (nsamp < 0 || precision < 0 || precision >= EVD_NUM_PREC || !is_train_prec(precision)) ? 0 : (size_t)train_tiles(nsamp) * astore::tile_bytes(precision);
+    const int sp = store_prec(precision);
+    return (nsamp < 0 || sp < 0 || sp >= EVD_NUM_PREC || !is_train_prec(sp)) ? 0 : (size_t)train_tiles(nsamp) * astore::tile_bytes(sp);
 }
 
 int evd_nerf_mlp_train(const evd_nerf* net, int precision, const float* ray_batch, const float* z, long R, int S, float* raw,
                        void* store, size_t store_bytes, void* stream) {
     EVD_REQUIRE(net && ray_batch && z && raw && store, "evd_nerf_mlp_train: null argument");
-    EVD_REQUIRE(precision >= 0 && precision < EVD_NUM_PREC && train_built(net, precision),
-                "evd_nerf_mlp_train: the training path is built for precision f16 / bf16 / f16x3 on the netdepth 8, netwidth 256, skips [4] network");
+    EVD_REQUIRE(train_built(net, precision),
+                "evd_nerf_mlp_train: the training path is built for precision f16 / bf16 / f16x3 / f16c / f16m on the netdepth 8, netwidth 256, skips [4] network");
     EVD_REQUIRE(R >= 0 && S >= 1, "evd_nerf_mlp_train: bad shape R=%ld S=%d", R, S);
     if (R == 0) return EVD_OK;
     const long nsamp = R * (long)S;
     if (store_bytes < evd_nerf_train_store_bytes_prec(precision, nsamp))
         return fail(EVD_E_WORKSPACE, "evd_nerf_mlp_train: store %zu < %zu bytes", store_bytes, evd_nerf_train_store_bytes_prec(precision, nsamp));
     MlpParams p{};
-    p.wstream = (const char*)net->pipe[precision].data.p;
+    const int fwd = precision == EVD_PREC_F16M ? EVD_PREC_F16X3 : precision;      // the forward's stream
+    p.wstream = (const char*)(fwd == EVD_PREC_F16C ? net->pipe_c.data.p : net->pipe[fwd].data.p);
     p.bias = (const float*)net->bias.p;
     p.ray_batch = ray_batch; p.z = z; p.nsamp = nsamp; p.S = S; p.ncol = 11;
-    p.D = net->D; p.skip = net->skip; p.nchunks = net->pipe_chunks[precision]; p.nbias = (int)(net->bias.bytes / sizeof(float));
+    p.D = net->D; p.skip = net->skip; p.nchunks = net->pipe_chunks[fwd]; p.nbias = (int)(net->bias.bytes / sizeof(float));
     p.raw = raw; p.feature = nullptr; p.feature_kind = 0; p.act = (char*)store;
+    if (precision == EVD_PREC_F16C) {
+        p.wscale = (const unsigned*)net->pipe_c.scales.p;
+        p.pe_l = PE_L; p.pe_lv = PE_LV;
+        return launch_nerf_train_fwd_f16c(p, as_stream(stream));
+    }
+    if (precision == EVD_PREC_F16M) return launch_nerf_train_fwd_f16x3_hi(p, as_stream(stream));
     return precision == EVD_PREC_F16 ? launch_nerf_train_fwd_f16(p, as_stream(stream))
            : precision == EVD_PREC_BF16 ? launch_nerf_train_fwd_bf16(p, as_stream(stream)) : launch_nerf_train_fwd_f16x3(p, as_stream(stream));
 }
@@ -53,8 +68,8 @@ int evd_nerf_mlp_backward(const evd_nerf* net, int precision, const float* d_raw
                           void* workspace, size_t workspace_bytes, void* stream) {
     EVD_REQUIRE((!d_pts || pts) && (!d_dirs || viewdirs), "evd_nerf_mlp_backward: d_pts / d_dirs need the forward's pts / viewdirs");
     EVD_REQUIRE(net && d_raw && store && grads && workspace, "evd_nerf_mlp_backward: null argument");
-    EVD_REQUIRE(precision >= 0 && precision < EVD_NUM_PREC && train_built(net, precision),
-                "evd_nerf_mlp_backward: the training path is built for precision f16 / bf16 / f16x3 on the netdepth 8, netwidth 256, skips [4] network");
+    EVD_REQUIRE(train_built(net, precision),
+                "evd_nerf_mlp_backward: the training path is built for precision f16 / bf16 / f16x3 / f16c / f16m on the netdepth 8, netwidth 256, skips [4] network");
     EVD_REQUIRE(R >= 0 && S >= 1, "evd_nerf_mlp_backward: bad shape R=%ld S=%d", R, S);
     if (R == 0) return EVD_OK;
     const long nsamp = R * (long)S;
@@ -62,6 +77,7 @@ int evd_nerf_mlp_backward(const evd_nerf* net, int precision, const float* d_raw
         return fail(EVD_E_WORKSPACE, "evd_nerf_mlp_backward: store %zu < %zu bytes", store_bytes, evd_nerf_train_store_bytes_prec(precision, nsamp));
     if (workspace_bytes < evd_nerf_backward_workspace_bytes())
         return fail(EVD_E_WORKSPACE, "evd_nerf_mlp_backward: workspace %zu < %zu bytes", workspace_bytes, evd_nerf_backward_workspace_bytes());
+    precision = store_prec(precision);          // the mixed modes: the float16 mode's store, W^T streams and kernels
     BwdPlan b;
     int rc0;
     b.d_raw = d_raw; b.nsamp = nsamp; b.tiles = train_tiles(nsamp); b.store = (char*)store;

@@ -338,7 +338,7 @@ static int sample_for(const evd_voxel* v, int precision, const float* pts, long 
 
 int evd_voxel_sample_prec(const evd_voxel* v, int precision, const float* pts, long n, float* out, int out_stride, int out_col, void* stream) {
     EVD_REQUIRE(v && out && n >= 0 && out_stride >= out_col + v->app_dim, "evd_voxel_sample_prec: bad arguments");
-    EVD_REQUIRE(precision >= 0 && precision <= EVD_PREC_F16C, "evd_voxel_sample_prec: unknown precision %d", precision);
+    EVD_REQUIRE(precision >= 0 && precision <= EVD_PREC_F16M, "evd_voxel_sample_prec: unknown precision %d", precision);     // (F16M: the float32 grids)
     if (n == 0) return EVD_OK;
     return sample_for(v, precision, pts, n, out, out_stride, out_col, stream);
 }
@@ -618,7 +618,15 @@ int evd_merge_features_bwd(const float* d_out, int d_stride, const int* order, l
 // ---- training: the level's sigma / colour networks -----------------------------------------------------
 static const int VOX_WGRAD_BLOCKS = 256;
 static long vox_tiles(long nsamp) { return cdiv(nsamp, 256L) * 8; }
-static bool vox_train_built(const evd_voxel* v, int prec) { return is_train_prec(prec) && v->train_chunks[prec] > 0; }
+// EVD_PREC_F16C trains on the single-product float16 store and backward behind a compensated forward: the level's f16c kernel where
+// that is built (fine level), else the split-float16 forward writing the float16 store (coarse level)
+// EVD_PREC_F16M: the split-float16 forward on every level, same store and backward
+static bool vox_train_built(const evd_voxel* v, int prec) {
+    if (prec == EVD_PREC_F16C) return v->train_chunks[EVD_PREC_F16] > 0 && (v->pipe_c_chunks > 0 || v->train_chunks[EVD_PREC_F16X3] > 0);
+    if (prec == EVD_PREC_F16M) return v->train_chunks[EVD_PREC_F16] > 0 && v->train_chunks[EVD_PREC_F16X3] > 0;
+    return prec >= 0 && prec < EVD_VOX_NUM_PREC && is_train_prec(prec) && v->train_chunks[prec] > 0;
+}
+static int vox_store_prec(int prec) { return (prec == EVD_PREC_F16C || prec == EVD_PREC_F16M) ? EVD_PREC_F16 : prec; }
 
 long evd_voxel_param_count(const evd_voxel* v) { return v ? v->param_off[8] : 0; }
 
@@ -658,8 +666,8 @@ size_t evd_voxel_train_store_bytes(const evd_voxel* v, long nsamp) {
     return (!v || nsamp < 0) ? 0 : (size_t)vox_tiles(nsamp) * voxel_store_tile_bytes(v->hidden_dim);
 }
 size_t evd_voxel_train_store_bytes_prec(const evd_voxel* v, int precision, long nsamp) {
-    return (!v || nsamp < 0 || precision < 0 || precision >= EVD_VOX_NUM_PREC || !is_train_prec(precision)) ? 0
-           : (size_t)vox_tiles(nsamp) * voxel_store_tile_bytes_prec(v->hidden_dim, precision);
+    return (!v || nsamp < 0 || !vox_train_built(v, precision)) ? 0
+           : (size_t)vox_tiles(nsamp) * voxel_store_tile_bytes_prec(v->hidden_dim, vox_store_prec(precision));
 }
 
 size_t evd_voxel_backward_workspace_bytes(void) { return (size_t)VOX_WGRAD_BLOCKS * 8 * 9 * 4096 + 512; }
@@ -668,17 +676,35 @@ int evd_voxel_mlp_train(const evd_voxel* v, int precision, const float* pts, con
                         long R, int S, float* raw, float* feature, void* store, size_t store_bytes, void* stream) {
     EVD_REQUIRE(v && pts && viewdirs && fts && raw && store, "evd_voxel_mlp_train: null argument");
     EVD_REQUIRE(!v->composite_feature, "evd_voxel_mlp_train: composite_feature levels (kernel_type PBE) are built for inference only");
-    EVD_REQUIRE(precision >= 0 && precision < EVD_VOX_NUM_PREC && vox_train_built(v, precision), "evd_voxel_mlp_train: the training path is built for precision f16 / bf16 / f16x3");
+    EVD_REQUIRE(vox_train_built(v, precision), "evd_voxel_mlp_train: the training path is built for precision f16 / bf16 / f16x3 / f16c / f16m");
     EVD_REQUIRE(R >= 0 && S >= 1 && ft_stride >= v->ft_dim && ft_stride % 4 == 0, "evd_voxel_mlp_train: bad shape");
     if (R == 0) return EVD_OK;
     const long nsamp = R * (long)S;
     if (store_bytes < evd_voxel_train_store_bytes_prec(v, precision, nsamp))
         return fail(EVD_E_WORKSPACE, "evd_voxel_mlp_train: store %zu < %zu bytes", store_bytes, evd_voxel_train_store_bytes_prec(v, precision, nsamp));
     VoxMlpParams p;
-    p.wstream = (const char*)v->train[precision].data.p;
     p.bias = (const float*)v->bias.p;
     p.pts = pts; p.viewdirs = viewdirs; p.fts = fts; p.nsamp = nsamp; p.S = S; p.vd_stride = vd_stride; p.ft_stride = ft_stride;
-    p.nchunks = v->train_chunks[precision]; p.nbias = (int)(v->bias.bytes / sizeof(float)); p.raw = raw; p.feature = feature; p.act = (char*)store;
+    p.nbias = (int)(v->bias.bytes / sizeof(float)); p.raw = raw; p.feature = feature; p.act = (char*)store;
+    if (precision == EVD_PREC_F16C || precision == EVD_PREC_F16M) {
+        if (feature) return fail(EVD_E_INVALID, "evd_voxel_mlp_train: float32 feature rows are not built in EVD_PREC_F16C / EVD_PREC_F16M (the geo features stay fragments in the store)");
+        if (precision == EVD_PREC_F16C && v->pipe_c_chunks > 0) {        // the level's compensated kernel (fine level)
+            if (v->pipe_c_stale) {
+                int rcc = repack_stream_c(v->pipe_c, (const float*)v->arena_dev.p, as_stream(stream));
+                if (rcc) return rcc;
+                v->pipe_c_stale = false;
+            }
+            p.wstream = (const char*)v->pipe_c.data.p;
+            p.wscale = (const unsigned*)v->pipe_c.scales.p;
+            p.nchunks = v->pipe_c_chunks;
+            return launch_voxel_train_fwd_f16c(p, as_stream(stream));
+        }
+        p.wstream = (const char*)v->train[EVD_PREC_F16X3].data.p;
+        p.nchunks = v->train_chunks[EVD_PREC_F16X3];
+        return launch_voxel_train_fwd_f16x3_hi(v->hidden_dim, p, as_stream(stream));
+    }
+    p.wstream = (const char*)v->train[precision].data.p;
+    p.nchunks = v->train_chunks[precision];
     return launch_voxel_train_fwd_dispatch(precision, v->hidden_dim, p, as_stream(stream));
 }
 
@@ -690,13 +716,14 @@ int evd_voxel_mlp_backward(const evd_voxel* v, int precision, const float* d_raw
                            float* d_pts, float* d_dirs, void* workspace, size_t workspace_bytes, void* stream) {
     EVD_REQUIRE((!d_pts || pts) && (!d_dirs || viewdirs), "evd_voxel_mlp_backward: d_pts / d_dirs need the forward's pts / viewdirs");
     EVD_REQUIRE(v && d_raw && raw && store && grads && workspace, "evd_voxel_mlp_backward: null argument");
-    EVD_REQUIRE(precision >= 0 && precision < EVD_VOX_NUM_PREC && vox_train_built(v, precision), "evd_voxel_mlp_backward: the training path is built for precision f16 / bf16 / f16x3");
+    EVD_REQUIRE(vox_train_built(v, precision), "evd_voxel_mlp_backward: the training path is built for precision f16 / bf16 / f16x3 / f16c / f16m");
     EVD_REQUIRE(R >= 0 && S >= 1 && (!d_fts || d_fts_stride >= v->ft_dim), "evd_voxel_mlp_backward: bad shape");
     if (R == 0) return EVD_OK;
     const long nsamp = R * (long)S;
     if (store_bytes < evd_voxel_train_store_bytes_prec(v, precision, nsamp))
         return fail(EVD_E_WORKSPACE, "evd_voxel_mlp_backward: store %zu < %zu bytes", store_bytes, evd_voxel_train_store_bytes_prec(v, precision, nsamp));
     if (workspace_bytes < evd_voxel_backward_workspace_bytes()) return fail(EVD_E_WORKSPACE, "evd_voxel_mlp_backward: workspace %zu < %zu bytes", workspace_bytes, evd_voxel_backward_workspace_bytes());
+    precision = vox_store_prec(precision);      // EVD_PREC_F16C: the float16 mode's store, W^T streams and kernels
     VoxBwdPlan b;
     b.d_raw = d_raw; b.raw = raw; b.d_feature = d_feature; b.nsamp = nsamp; b.tiles = vox_tiles(nsamp); b.store = (char*)store;
     b.awp_store = nullptr; b.awp_tile_bytes = 0; b.awp_slot = 0; b.awp_words = nullptr;

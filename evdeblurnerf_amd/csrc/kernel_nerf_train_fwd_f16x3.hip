@@ -7,4 +7,7 @@ namespace evd {
 
 int launch_nerf_train_fwd_f16x3(const MlpParams& p, hipStream_t st) { return launch_pipe_mlp<EVD_PREC_F16X3, 256, 8, 4, 1, 256, false, true>(p, st); }
 
+// EVD_PREC_F16M: this arithmetic in front of the single-product float16 backward -- the float16 mode's store (hi halves, bit masks)
+int launch_nerf_train_fwd_f16x3_hi(const MlpParams& p, hipStream_t st) { return launch_pipe_mlp<EVD_PREC_F16X3, 256, 8, 4, 1, 256, false, true, true>(p, st); }
+
 }  // namespace evd

@@ -179,8 +179,13 @@ template <> struct POps<EVD_PREC_F32> {
 // ---------------------------------------------------------------------------------------------
 // CB_: chunk bytes of the LDS ring (the packed streams are padded to PIPE_CB = 16 KiB; every layer of the built networks is a
 // whole number of 8 KiB chunks too, so a kernel may walk the same stream in 8 KiB chunks: half the ring, two workgroups per CU)
-template <int PREC, int NS_, int NT_, int CB_ = PIPE_CB> struct PipeCfg {
+// HI_ONLY_ (training forward of the split-float16 arithmetic in front of the SINGLE-product float16 backward, EVD_PREC_F16C training):
+// the activation store is the float16 mode's -- 1 KiB slots holding the hi halves (the value rounded to float16) of the fragments.
+template <int PREC, int NS_, int NT_, int CB_ = PIPE_CB, bool HI_ONLY_ = false> struct PipeCfg {
     typedef POps<PREC> O;
+    static constexpr bool HI_ONLY = HI_ONLY_;
+    static constexpr int STORE_PREC = HI_ONLY_ ? 3 /*EVD_PREC_F16*/ : PREC;
+    static_assert(!HI_ONLY_ || PREC == 1 /*EVD_PREC_F16X3*/, "hi-only stores belong to the split-float16 forward");
     static constexpr int PRECISION = PREC, NS = NS_, NT = NT_, NW = NT_ / 64;
     static constexpr int FB = frag_bytes(PREC);
     static constexpr int CB = CB_;
@@ -378,6 +383,18 @@ template <int FB = 1024, class F> __device__ __forceinline__ void act_store(char
     }
 }
 
+// ... of a kernel with configuration C: its own fragment format, or (C::HI_ONLY) the hi halves in the float16 mode's 1 KiB slots
+template <class C, class F> __device__ __forceinline__ void pipe_act_store(char* act_lane, int slot, const F& frag) {
+    if constexpr (C::HI_ONLY && sizeof(F) == 32) {
+        struct Two { f32x4 a, b; };
+        *reinterpret_cast<f32x4*>(act_lane + (long)slot * 1024) = __builtin_bit_cast(Two, frag).a;
+    } else if constexpr (C::HI_ONLY) {
+        act_store<1024>(act_lane, slot, frag);
+    } else {
+        act_store<C::FB>(act_lane, slot, frag);
+    }
+}
+
 // gradient word . [activation != 0], both halves (activations are post-ReLU: masked <=> the stored half is +0)
 __device__ __forceinline__ unsigned mask_word(unsigned g, unsigned a) {
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -460,7 +477,7 @@ __device__ __forceinline__ void pipe_group(ST& st, Pipe<C>& pp, typename C::O::B
                             if constexpr (TRAIN && L::PSLOT >= 0)
                                 if ((k & 3) == 3) {
                                     const auto& pf = in[ds][(L::PG > 0 ? L::PDOFF : 0) + 2 * dt + (k >> 2)];
-                                    act_store<FB>(act[ds], L::PSLOT + 2 * dt + (k >> 2), pf);
+                                    pipe_act_store<C>(act[ds], L::PSLOT + 2 * dt + (k >> 2), pf);
                                     if constexpr (L::PMSLOT >= 0) {
                                         const int fi = L::PFRAG0 + 2 * dt + (k >> 2);
                                         pp.mbits[ds][fi >> 2] |= O::bits(pf) << (8 * (fi & 3));
@@ -468,7 +485,7 @@ __device__ __forceinline__ void pipe_group(ST& st, Pipe<C>& pp, typename C::O::B
                                             MaskFrag mf;
 #pragma unroll
                                             for (int e = 0; e < 4; ++e) { mf.w[e] = pp.mbits[ds][e]; pp.mbits[ds][e] = 0u; }
-                                            act_store<FB>(act[ds], L::PMSLOT, mf);
+                                            pipe_act_store<C>(act[ds], L::PMSLOT, mf);
                                         }
                                     }
                                 }
@@ -481,7 +498,7 @@ __device__ __forceinline__ void pipe_group(ST& st, Pipe<C>& pp, typename C::O::B
                                     const int fo = 2 * (tile0 + dt) + (k >> 2);
                                     if constexpr (OMASK == 1) O::mask_act(out[ds][fo], static_cast<const typename O::B*>(omask)[ds * NOUT + fo]);
                                     else if constexpr (OMASK == 2) O::mask_bits(out[ds][fo], static_cast<const MaskFrag*>(omask)[ds], fo);
-                                    act_store<FB>(act[ds], L::OSLOT + fo, out[ds][fo]);
+                                    pipe_act_store<C>(act[ds], L::OSLOT + fo, out[ds][fo]);
                                     if constexpr (L::MSLOT >= 0) pp.mbits[ds][fo >> 2] |= O::bits(out[ds][fo]) << (8 * (fo & 3));
                                 }
                         }

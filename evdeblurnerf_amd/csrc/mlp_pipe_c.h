@@ -257,8 +257,8 @@ __device__ __forceinline__ void c_drain_pair(f32x16& a0, f32x16& a1, int v, XBlk
     float x0 = a0[v], x1 = a1[v];
 #ifdef EVD_C_RNE
     if (RELU) { x0 = relu_f32(x0); x1 = relu_f32(x1); }
-    const f32x2 v = {x0, x1};
-    const unsigned w = __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));     // MODE.FP16_OVFL: saturates at +-65504
+    const f32x2 xv = {x0, x1};
+    const unsigned w = __builtin_bit_cast(unsigned, __builtin_convertvector(xv, f16x2));     // MODE.FP16_OVFL: saturates at +-65504
     constexpr bool CLAMP = false;
 #else
     unsigned w = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
@@ -297,9 +297,18 @@ __device__ __forceinline__ void c_drain_pair(f32x16& a0, f32x16& a1, int v, XBlk
 //   CHUNK0  first chunk of the layer (every layer is chunk-aligned)               PAR  accumulator set of the first group
 //   PG      tiles of the pending group handed over by the previous layer (0 / 2); PRELU its activation; PDB the input block it becomes
 //   NEXT_G  group size of the next layer (0: last layer)                          NCHUNKS chunks of this layer
-template <int NBLK_, int LASTK_, int TILES_, int G_, bool RELU_, bool F32OUT_, int CHUNK0_, int PAR_, int PG_, bool PRELU_, int PDB_, int NEXT_G_>
+//   training kernels (TRAIN): OSLOT  first fragment slot of this layer's output in the activation store (-1: not stored); PSLOT slot of
+//   the pending block handed over by the previous layer; MSLOT >= 0: the ReLU pattern of this layer's output is collected as a bit mask;
+//   PMSLOT >= 0: the mask fragment of the PREVIOUS layer's output is stored there once its pending block is complete.  The store is
+//   the one of the single-product float16 mode (mlp_pipe.h act_store, masks as frag_bits): the backward kernels are that mode's.
+template <int NBLK_, int LASTK_, int TILES_, int G_, bool RELU_, bool F32OUT_, int CHUNK0_, int PAR_, int PG_, bool PRELU_, int PDB_, int NEXT_G_,
+          int OSLOT_ = -1, int PSLOT_ = -1, int MSLOT_ = -1, int PMSLOT_ = -1, int PFRAG0_ = -1>
 struct CLayer {
     static constexpr int NBLK = NBLK_, LASTK = LASTK_, TILES = TILES_, G = G_, CHUNK0 = CHUNK0_, PAR = PAR_, PG = PG_, PDB = PDB_, NEXT_G = NEXT_G_;
+    static constexpr int OSLOT = OSLOT_, PSLOT = PSLOT_, MSLOT = MSLOT_, PMSLOT = PMSLOT_;
+    // index of the pending block's first fragment inside the PRODUCING layer's output (its byte of the mask fragment): 4 x the block the
+    // pending group becomes, unless this layer's input blocks are not the producer's output blocks (the skip layer: [h .. | pe | h_last])
+    static constexpr int PFRAG0 = PFRAG0_ >= 0 ? PFRAG0_ : 4 * PDB_;
     static constexpr bool RELU = RELU_, F32OUT = F32OUT_, PRELU = PRELU_;
     static constexpr int NG = TILES_ / G_;
     static constexpr int KSTEPS = 4 * (NBLK_ - 1) + LASTK_;
@@ -326,7 +335,57 @@ struct CPipe {
     f32x16 acc[2][2];        // two accumulator sets of up to two tiles
     unsigned wsc[2][2];      // row-scale words of the tiles in acc[set][t]
     unsigned m;              // running maximum of the block being drained
+    unsigned mbits[4];       // training kernels: bit mask of the layer output being completed (CLayer MSLOT)
 };
+
+// Training kernels: the activation store of one 32-sample tile as the wavefront addresses it -- a wave-uniform base in SGPRs + this
+// lane's 16-byte column + an immediate: fragment slot s lives at base + 1024 s.  (With plain 64-bit lane pointers hipcc computes the ~70
+// store addresses of a pass up front and keeps them in VGPRs: the kernel spilled its accumulators to scratch.)  One SGPR base per 4 KiB
+// (the instruction's immediate offset reaches 4095), derived by scalar adds.
+struct CAct {
+    const char* base;       // wave-uniform: store + tile * TILE_BYTES
+    unsigned voff;          // lane * 16
+};
+// (s_nop 1: a VMEM store of more than 8 bytes must be two wait states away from a VALU write of its data registers -- hipcc pads its own
+// stores, it cannot see inside the asm; without it the last quad of every 16 lanes stored the NEXT fragment's first word)
+__device__ __forceinline__ void c_act_store(const CAct& a, int slot, const u32x4& v) {        // slot is a compile-time constant at every call site
+    const char* sb = a.base + (long)(slot >> 2) * 4096;
+    switch (slot & 3) {
+    case 0: asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(a.voff), "v"(v), "s"(sb) : "memory"); break;
+    case 1: asm volatile("global_store_dwordx4 %0, %1, %2 offset:1024\n\ts_nop 1" : : "v"(a.voff), "v"(v), "s"(sb) : "memory"); break;
+    case 2: asm volatile("global_store_dwordx4 %0, %1, %2 offset:2048\n\ts_nop 1" : : "v"(a.voff), "v"(v), "s"(sb) : "memory"); break;
+    default: asm volatile("global_store_dwordx4 %0, %1, %2 offset:3072\n\ts_nop 1" : : "v"(a.voff), "v"(v), "s"(sb) : "memory"); break;
+    }
+}
+
+// A finished HIDDEN block (64 channels drained from two output tiles in (tile 0, tile 1) pairs) goes to the activation
+// store as the FOUR fragments the single-product float16 mode keeps for the same channels (fragment 2 t + f of tile t = values 8 f .. 8 f + 7
+// of the tile's accumulator as pairs, mlp_pipe.h drain_pair): one v_perm_b32 per word picks the tile's halves out of two pairs.  fi0 =
+// index of the block's first fragment inside the producing layer's output (the byte of the mask fragment, mlp_pipe.h frag_bits).
+template <bool MASK>
+__device__ __forceinline__ void c_store_block(const CAct& act, int slot, const XBlk& x, unsigned (&mbits)[4], int fi0) {
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            unsigned w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = __builtin_amdgcn_perm(x.h[8 * f + 2 * e + 1], x.h[8 * f + 2 * e], tt ? 0x07060302u : 0x05040100u);
+            const int fo = 2 * tt + f;
+            const u32x4 v = {w[0], w[1], w[2], w[3]};
+            c_act_store(act, slot + fo, v);
+            if (MASK) mbits[(fi0 + fo) >> 2] |= bits_of_words(w) << (8 * ((fi0 + fo) & 3));
+        }
+    }
+}
+// an INPUT block (features / encodings: k-steps in the float16 mode's own order): its four (NK) fragments as they are
+template <int NK> __device__ __forceinline__ void c_store_input(const CAct& act, int slot, const XBlk& x) {
+#pragma unroll
+    for (int jj = 0; jj < NK; ++jj) {
+        const u32x4 v = {x.h[4 * jj], x.h[4 * jj + 1], x.h[4 * jj + 2], x.h[4 * jj + 3]};
+        c_act_store(act, slot + jj, v);
+    }
+}
 
 // byte offset of unit u of a layer (units count from the layer's first chunk) inside the ring, for this lane's rd_base
 template <class L> __device__ __forceinline__ constexpr int c_ring_off(int u) { return ((L::CHUNK0 + u / CCfg::UPC) & (CCfg::NSLOT - 1)) * CCfg::CB + (u % CCfg::UPC) * 1024; }
@@ -334,8 +393,8 @@ template <class L> __device__ __forceinline__ constexpr int c_ring_off(int u) { 
 // One tile group P of layer L.  in[]: input blocks; the pending group of the previous layer is drained into in[L::PDB]; this layer's
 // groups are drained into out[p].  bias: LDS bias block of this layer (tile-major, 32 floats per tile) with the row-scale words
 // SC_OFF words behind it.  NXT: the next layer (for the prefetch across the layer boundary), void for the last.
-template <class L, class NXT, class ST, int NIN, int NOUT, int P>
-__device__ __forceinline__ void c_group(ST& st, CPipe& pp, XBlk (&in)[NIN], XBlk (&out)[NOUT], lds_f32_p bias, int lane) {
+template <class L, class NXT, class ST, int NIN, int NOUT, int P, bool TRAIN = false>
+__device__ __forceinline__ void c_group(ST& st, CPipe& pp, XBlk (&in)[NIN], XBlk (&out)[NOUT], lds_f32_p bias, int lane, const CAct& act = CAct{}) {
     constexpr int G = L::G, NS = L::GROUP_SLOTS;
     constexpr int cur = (L::PAR + P) & 1, oth = cur ^ 1;
     constexpr bool FIRST = P == 0, LAST = P == L::NG - 1;
@@ -373,6 +432,20 @@ __device__ __forceinline__ void c_group(ST& st, CPipe& pp, XBlk (&in)[NIN], XBlk
                     else c_drain_pair<L::RELU>(pp.acc[oth][0], pp.acc[oth][1], u, dst, pp.m);
                 } else if (!(kAbl & 256)) {
                     c_finish(dst, pp.m, pp.acc[oth][0], pp.acc[oth][1]);
+                    if constexpr (TRAIN) {
+                        if constexpr (FIRST) {
+                            if constexpr (L::PSLOT >= 0) {
+                                c_store_block<(L::PMSLOT >= 0)>(act, L::PSLOT, dst, pp.mbits, L::PFRAG0);
+                                if constexpr (L::PMSLOT >= 0) {      // the producing layer's output is complete: its mask fragment
+                                    const u32x4 mv = {pp.mbits[0], pp.mbits[1], pp.mbits[2], pp.mbits[3]};
+                                    c_act_store(act, L::PMSLOT, mv);
+                                    pp.mbits[0] = pp.mbits[1] = pp.mbits[2] = pp.mbits[3] = 0u;
+                                }
+                            }
+                        } else if constexpr (L::OSLOT >= 0) {
+                            c_store_block<(L::MSLOT >= 0)>(act, L::OSLOT + 4 * (P > 0 ? P - 1 : 0), dst, pp.mbits, 4 * (P > 0 ? P - 1 : 0));
+                        }
+                    }
                 }
             }
         }
@@ -489,12 +562,16 @@ __device__ __forceinline__ void c_group(ST& st, CPipe& pp, XBlk (&in)[NIN], XBlk
                 filler(s);
                 __builtin_amdgcn_sched_barrier(0);
                 // kind 0: fp6(Wl) x fp6(f16(x)), scale bytes 0 / 0; kind 1: fp6(W) x fp6(x - f16(x)), scale bytes 1 / 1
+                // (the two scale operands pinned to VGPRs: with the larger register footprint of the TRAIN variant hipcc's AGPR rewrite
+                // otherwise parks a block's scale word in an AGPR and then emits the MFMA with it -- "Operand has incorrect register class")
+                int sca = (int)pp.wsc[cur][t], scb = (int)in[b].sc;
+                if (TRAIN) asm("" : "+v"(sca), "+v"(scb));
                 if (kind == 0 && (kAbl & 1)) {}
                 else if (kind == 1 && (kAbl & 2)) {}
                 else if (kind == 0)
-                    pp.acc[cur][t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(pp.ac[0][t], in[b].qh, pp.acc[cur][t], 2, 2, 0, (int)pp.wsc[cur][t], 0, (int)in[b].sc);
+                    pp.acc[cur][t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(pp.ac[0][t], in[b].qh, pp.acc[cur][t], 2, 2, 0, sca, 0, scb);
                 else
-                    pp.acc[cur][t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(pp.ac[(kAbl & 1024) ? 0 : 1][t], in[b].ql, pp.acc[cur][t], 2, 2, 1, (int)pp.wsc[cur][t], 1, (int)in[b].sc);
+                    pp.acc[cur][t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(pp.ac[(kAbl & 1024) ? 0 : 1][t], in[b].ql, pp.acc[cur][t], 2, 2, 1, sca, 1, scb);
                 __builtin_amdgcn_sched_barrier(0);
                 const int last = 2 * G - 1;
                 chunks(lo16 + i, i == last ? hi8 + G : lo16 + i + 1);
@@ -519,19 +596,19 @@ __device__ __forceinline__ void c_group(ST& st, CPipe& pp, XBlk (&in)[NIN], XBlk
     }
 }
 
-template <class L, class NXT, class ST, int NIN, int NOUT, int P> struct CGroupLoop {
-    static __device__ __forceinline__ void run(ST& st, CPipe& pp, XBlk (&in)[NIN], XBlk (&out)[NOUT], lds_f32_p bias, int lane) {
-        c_group<L, NXT, ST, NIN, NOUT, P>(st, pp, in, out, bias, lane);
-        if constexpr (P + 1 < L::NG) CGroupLoop<L, NXT, ST, NIN, NOUT, P + 1>::run(st, pp, in, out, bias, lane);
+template <class L, class NXT, class ST, int NIN, int NOUT, int P, bool TRAIN = false> struct CGroupLoop {
+    static __device__ __forceinline__ void run(ST& st, CPipe& pp, XBlk (&in)[NIN], XBlk (&out)[NOUT], lds_f32_p bias, int lane, const CAct& act = CAct{}) {
+        c_group<L, NXT, ST, NIN, NOUT, P, TRAIN>(st, pp, in, out, bias, lane, act);
+        if constexpr (P + 1 < L::NG) CGroupLoop<L, NXT, ST, NIN, NOUT, P + 1, TRAIN>::run(st, pp, in, out, bias, lane, act);
     }
 };
 
 // One linear layer on the wavefront's 32 samples.  `out` receives the blocks of every group but the last, which stays pending in the
 // accumulators (F32OUT: rows 0..3 of the single tile are returned in out_f32).
-template <class L, class NXT, class ST, int NIN, int NOUT>
-__device__ __forceinline__ void c_layer(ST& st, CPipe& pp, XBlk (&in)[NIN], XBlk (&out)[NOUT], float* out_f32, lds_f32_p bias, int lane) {
+template <class L, class NXT, class ST, int NIN, int NOUT, bool TRAIN = false>
+__device__ __forceinline__ void c_layer(ST& st, CPipe& pp, XBlk (&in)[NIN], XBlk (&out)[NOUT], float* out_f32, lds_f32_p bias, int lane, const CAct& act = CAct{}) {
     static_assert(NIN >= L::NBLK, "input blocks");
-    CGroupLoop<L, NXT, ST, NIN, NOUT, 0>::run(st, pp, in, out, bias, lane);
+    CGroupLoop<L, NXT, ST, NIN, NOUT, 0, TRAIN>::run(st, pp, in, out, bias, lane, act);
     if (L::UNITS % CCfg::UPC != 0) {             // the zero-padded tail of the layer's last chunk
 #ifndef EVD_C_NOSPREAD
         constexpr int c = L::CHUNK0 + L::UNITS / CCfg::UPC, k0 = cmin(CCfg::PIECES, (L::UNITS % CCfg::UPC + 1) / 3);
@@ -574,6 +651,7 @@ template <class L, class ST> __device__ __forceinline__ void c_prime(ST& st, CPi
         pp.wsc[L::PAR][t] = ((lds_u32_p)bias)[CCfg::BIAS_WORDS / 2 + t * 32 + (lane & 31)];
     }
     pp.m = 0u;
+    pp.mbits[0] = pp.mbits[1] = pp.mbits[2] = pp.mbits[3] = 0u;
 }
 
 // sin(2 pi t) / cos(2 pi t) of the revolution count t = (frac + lo): v_sin_f32 takes revolutions

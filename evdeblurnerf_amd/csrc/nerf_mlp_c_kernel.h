@@ -1,7 +1,8 @@
 // Fused NeRF backbone in the compensated float16 mode (EVD_PREC_F16C): pts = o + d z -> positional encodings -> 8 x 256 MLP (skip +
 // view branch) -> raw.  reference: networks/nerf.py:46-72 (mlpforward), :131-162 (eval), networks/embedding.py:88-98, renderer.py:180.
-// Machinery and arithmetic: mlp_pipe_c.h.  Built for the reference network (netdepth 8, netwidth 256, skips [4]); no feature rows,
-// no training variant (those run in the other modes).
+// Machinery and arithmetic: mlp_pipe_c.h.  Built for the reference network (netdepth 8, netwidth 256, skips [4]); no feature rows.
+// TRAIN variant (round 4): + the activation store of the single-product float16 mode (nerf_mlp.h astore: float16 fragments in that
+// mode's arrangement, ReLU patterns as bit masks from the COMPENSATED pre-activations); the backward is that mode's.
 #pragma once
 
 #include "mlp_pipe_c.h"
@@ -10,11 +11,16 @@
 namespace evd {
 
 // static layer table: width W (T tiles, KB k-blocks), depth D, skip index SKIP
-template <int W, int D, int SKIP> struct NerfNetC {
+template <int W, int D, int SKIP, bool TRAIN = false> struct NerfNetC {
     static constexpr int T = W / 32, KB = W / 64;
+    static constexpr int slot(int s) { return TRAIN ? s : -1; }
+    static constexpr int oslot(int l) { return slot(astore::H0 + 16 * l); }                       // hidden layer l's output ...
+    static constexpr int pslot(int l) { return slot(astore::H0 + 16 * l + 4 * (KB - 1)); }        // ... its last (pending) block
+    static constexpr int mslot(int l) { return slot(astore::M_H0 + l); }
+    static_assert(!TRAIN || (W == 256 && D == 8), "the activation store is laid out for the 8 x 256 network");
     static_assert(PE_KS == 4 && PEV_KS == 2 && T % 2 == 0 && KB >= 2, "block structure of the encodings and the hidden width");
     static constexpr bool is_wide(int l) { return l - 1 == SKIP; }
-    typedef CLayer<1, 4, T, 2, true, false, 0, 0, 0, false, 0, 2> L0;
+    typedef CLayer<1, 4, T, 2, true, false, 0, 0, 0, false, 0, 2, oslot(0), -1, mslot(0)> L0;
     static constexpr int CH_HID = CLayer<KB, 4, T, 2, true, false, 0, 0, 2, true, KB - 1, 2>::NCHUNKS;
     static constexpr int CH_WIDE = CLayer<KB + 1, 4, T, 2, true, false, 0, 0, 2, true, KB, 2>::NCHUNKS;
     static constexpr int chunk0(int l) {                           // first chunk of hidden layer l (l == D: the heads)
@@ -26,13 +32,15 @@ template <int W, int D, int SKIP> struct NerfNetC {
     static_assert((T / 2) % 2 == 0, "accumulator parity");
     // hidden layer l (1 .. D-1); the skip layer's blocks are [h_0 .. h_{KB-2} | pe | h_{KB-1}]
     template <int l> using Hidden = std::conditional_t<is_wide(l),
-        CLayer<KB + 1, 4, T, 2, true, false, chunk0(l), PARH, 2, true, KB, l == D - 1 ? 1 : 2>,
-        CLayer<KB, 4, T, 2, true, false, chunk0(l), PARH, 2, true, KB - 1, l == D - 1 ? 1 : 2>>;
+        CLayer<KB + 1, 4, T, 2, true, false, chunk0(l), PARH, 2, true, KB, l == D - 1 ? 1 : 2, oslot(l), pslot(l - 1), mslot(l), mslot(l - 1), 4 * (KB - 1)>,
+        CLayer<KB, 4, T, 2, true, false, chunk0(l), PARH, 2, true, KB - 1, l == D - 1 ? 1 : 2, oslot(l), pslot(l - 1), mslot(l), mslot(l - 1)>>;
     // heads (nerf.py:144-157): alpha_linear, feature_linear, views_linears.0 on cat([feature, PE(dir)]), rgb_linear
-    typedef CLayer<KB, 4, 1, 1, false, true, chunk0(D), PARH, 2, true, KB - 1, 2> Alpha;
-    typedef CLayer<KB, 4, T, 2, false, false, Alpha::CHUNK0 + Alpha::NCHUNKS, Alpha::PAR_OUT, 0, false, 0, 2> Feature;
-    typedef CLayer<KB + 1, 2, T / 2, 2, true, false, Feature::CHUNK0 + Feature::NCHUNKS, Feature::PAR_OUT, 2, false, KB - 1, 1> Views;
-    typedef CLayer<KB / 2, 4, 1, 1, false, true, Views::CHUNK0 + Views::NCHUNKS, Views::PAR_OUT, 2, true, KB / 2 - 1, 0> Rgb;
+    typedef CLayer<KB, 4, 1, 1, false, true, chunk0(D), PARH, 2, true, KB - 1, 2, -1, pslot(D - 1), -1, mslot(D - 1)> Alpha;
+    typedef CLayer<KB, 4, T, 2, false, false, Alpha::CHUNK0 + Alpha::NCHUNKS, Alpha::PAR_OUT, 0, false, 0, 2, slot(astore::F)> Feature;
+    typedef CLayer<KB + 1, 2, T / 2, 2, true, false, Feature::CHUNK0 + Feature::NCHUNKS, Feature::PAR_OUT, 2, false, KB - 1, 1, slot(astore::HV),
+                   slot(astore::F + 4 * (KB - 1)), slot(astore::M_HV)> Views;
+    typedef CLayer<KB / 2, 4, 1, 1, false, true, Views::CHUNK0 + Views::NCHUNKS, Views::PAR_OUT, 2, true, KB / 2 - 1, 0, -1, slot(astore::HV + 4 * (KB / 2 - 1)), -1,
+                   slot(astore::M_HV)> Rgb;
     static constexpr int NCH = Rgb::CHUNK0 + Rgb::NCHUNKS;
     static constexpr int NTILES = D * T + 1 + T + T / 2 + 1;
     static_assert(D >= 2 && NTILES * 32 <= CCfg::BIAS_WORDS / 2, "bias / row-scale block");
@@ -45,9 +53,10 @@ template <class N, class ST> struct NerfCtxC {
     XBlk pe, pev;                   // the two positional encodings as input blocks (registers: one wavefront per SIMD has room)
     lds_f32_p bias;                 // LDS bias block
     int lane;
+    CAct act;                       // training kernels: this wavefront's tile of the activation store
 };
 
-template <class N, class ST, int l, int D> struct HiddenLoopC {
+template <class N, class ST, int l, int D, bool TRAIN = false> struct HiddenLoopC {
     static __device__ __forceinline__ void run(NerfCtxC<N, ST>& cx) {
         typedef typename N::template Hidden<l> L;
         constexpr int KB = N::KB, T = N::T;
@@ -55,7 +64,7 @@ template <class N, class ST, int l, int D> struct HiddenLoopC {
         if constexpr (l + 1 < D) {
             typedef typename N::template Hidden<l + 1> NX;
             step<L, NX>(cx, lb);
-            HiddenLoopC<N, ST, l + 1, D>::run(cx);
+            HiddenLoopC<N, ST, l + 1, D, TRAIN>::run(cx);
         } else {
             step<L, typename N::Alpha>(cx, lb);
         }
@@ -67,9 +76,9 @@ template <class N, class ST, int l, int D> struct HiddenLoopC {
 #pragma unroll
             for (int j = 0; j < KB - 1; ++j) wide[j] = cx.buf[(l - 1) & 1][j];
             wide[KB - 1] = cx.pe;
-            c_layer<L, NX, ST, KB + 1, KB>(cx.st, cx.pp, wide, cx.buf[l & 1], nullptr, lb, cx.lane);
+            c_layer<L, NX, ST, KB + 1, KB, TRAIN>(cx.st, cx.pp, wide, cx.buf[l & 1], nullptr, lb, cx.lane, cx.act);
         } else {
-            c_layer<L, NX, ST, KB, KB>(cx.st, cx.pp, cx.buf[(l - 1) & 1], cx.buf[l & 1], nullptr, lb, cx.lane);
+            c_layer<L, NX, ST, KB, KB, TRAIN>(cx.st, cx.pp, cx.buf[(l - 1) & 1], cx.buf[l & 1], nullptr, lb, cx.lane, cx.act);
         }
     }
 };
@@ -94,9 +103,10 @@ __device__ __forceinline__ float c_z_sample(float near, float far, int S, int li
 // samples are whole rays): z stratification in the prologue, raw2outputs in the epilogue -- the per-sample (rgb, sigma) never leave
 // registers unless `raw` is wanted; transmittance = DPP product scan over a wavefront's 32 samples, carried across the ray's wavefronts
 // through 4 words of LDS.
-template <int W, int D, int SKIP, bool FUSE>
+template <int W, int D, int SKIP, bool FUSE, bool TRAIN = false>
 __global__ __launch_bounds__(CCfg::NT, 1) void k_nerf_mlp_c(const MlpParams p) {
-    typedef NerfNetC<W, D, SKIP> N;
+    typedef NerfNetC<W, D, SKIP, TRAIN> N;
+    static_assert(!(FUSE && TRAIN), "the training forward writes raw; the compositing scan runs under autograd");
     typedef CStream<N::NCH> ST;
     constexpr int T = N::T, KB = N::KB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -137,7 +147,8 @@ __global__ __launch_bounds__(CCfg::NT, 1) void k_nerf_mlp_c(const MlpParams p) {
     // With one workgroup resident per CU nothing covers the hand-over between two workgroups (dispatch, the bias block, the cold ring):
     // here the bias block is loaded once, and the weight stream of the next tile is re-issued behind the last barrier of this one, in
     // front of the tile's output, so that it lands while the next tile's rays are loaded and encoded.
-    const long ntile = (p.nsamp + CCfg::SAMPLES - 1) / CCfg::SAMPLES;
+    // (TRAIN: the store is tiled in groups of 8 sample tiles and the backward walks all of them -- the padding tiles are written too)
+    const long ntile = TRAIN ? (p.nsamp + 255) / 256 * (256 / CCfg::SAMPLES) : (p.nsamp + CCfg::SAMPLES - 1) / CCfg::SAMPLES;
     for (long tile = blockIdx.x;;) {
     NerfCtxC<N, ST> cx;                        // per tile: nothing of it but the stream's four address words is carried around the loop
     cx.st = st0;
@@ -170,31 +181,39 @@ __global__ __launch_bounds__(CCfg::NT, 1) void k_nerf_mlp_c(const MlpParams p) {
         c_encode<PE_L, PE_KS>(pts, h, cx.pe);
         c_encode<PE_LV, PEV_KS>(vd, h, cx.pev);
     }
+    cx.act = CAct{};
+    if constexpr (TRAIN) {
+        const long t32 = __builtin_amdgcn_readfirstlane((int)(tile * (CCfg::SAMPLES / 32) + wave));      // this wavefront's 32-sample tile
+        cx.act.base = p.act + t32 * astore::TILE_BYTES;
+        cx.act.voff = lane * 16;
+        c_store_input<PE_KS>(cx.act, astore::PE, cx.pe);
+        c_store_input<PEV_KS>(cx.act, astore::DIR, cx.pev);
+    }
 
     cx.st.start_wait();
     c_prime<typename N::L0>(cx.st, cx.pp, lbias, lane);
     {
         XBlk in_pe[1];
         in_pe[0] = cx.pe;
-        c_layer<typename N::L0, typename N::template Hidden<1>, ST, 1, KB>(cx.st, cx.pp, in_pe, cx.buf[0], nullptr, lbias, lane);
+        c_layer<typename N::L0, typename N::template Hidden<1>, ST, 1, KB, TRAIN>(cx.st, cx.pp, in_pe, cx.buf[0], nullptr, lbias, lane, cx.act);
     }
-    HiddenLoopC<N, ST, 1, D>::run(cx);
+    HiddenLoopC<N, ST, 1, D, TRAIN>::run(cx);
 
     // heads
     XBlk (&hact)[KB] = cx.buf[(D - 1) & 1];
     lds_f32_p lb = lbias + D * T * 32;
     float araw[4], rraw[4];
     XBlk none[1];
-    c_layer<typename N::Alpha, typename N::Feature, ST, KB, 1>(cx.st, cx.pp, hact, none, araw, lb, lane);
+    c_layer<typename N::Alpha, typename N::Feature, ST, KB, 1, TRAIN>(cx.st, cx.pp, hact, none, araw, lb, lane, cx.act);
     lb += 32;
     XBlk vin[KB + 1];
-    c_layer<typename N::Feature, typename N::Views, ST, KB, KB + 1>(cx.st, cx.pp, hact, vin, nullptr, lb, lane);
+    c_layer<typename N::Feature, typename N::Views, ST, KB, KB + 1, TRAIN>(cx.st, cx.pp, hact, vin, nullptr, lb, lane, cx.act);
     lb += T * 32;
     vin[KB] = cx.pev;
     XBlk hbuf[KB / 2];
-    c_layer<typename N::Views, typename N::Rgb, ST, KB + 1, KB / 2>(cx.st, cx.pp, vin, hbuf, nullptr, lb, lane);
+    c_layer<typename N::Views, typename N::Rgb, ST, KB + 1, KB / 2, TRAIN>(cx.st, cx.pp, vin, hbuf, nullptr, lb, lane, cx.act);
     lb += (T / 2) * 32;
-    c_layer<typename N::Rgb, void, ST, KB / 2, 1>(cx.st, cx.pp, hbuf, none, rraw, lb, lane);
+    c_layer<typename N::Rgb, void, ST, KB / 2, 1, TRAIN>(cx.st, cx.pp, hbuf, none, rraw, lb, lane, cx.act);
     const bool more = tile + gridDim.x < ntile;
     if (more) cx.st.restart_issue();            // every wavefront is behind the barrier that ended the stream's last chunk: all slots are free
 
@@ -261,17 +280,19 @@ __global__ __launch_bounds__(CCfg::NT, 1) void k_nerf_mlp_c(const MlpParams p) {
 
 template <int W, int D, int SKIP> constexpr int nerf_c_chunks() { return NerfNetC<W, D, SKIP>::NCH; }
 
-template <int W, int D, int SKIP, bool FUSE>
+template <int W, int D, int SKIP, bool FUSE, bool TRAIN = false>
 static int launch_nerf_c(const MlpParams& p, hipStream_t st) {
-    typedef NerfNetC<W, D, SKIP> N;
-    const long blocks = cmin_l(cdiv(p.nsamp, CCfg::SAMPLES), (long)c_persistent_blocks());
+    typedef NerfNetC<W, D, SKIP, TRAIN> N;
+    const long tiles = TRAIN ? cdiv(p.nsamp, 256L) * (256 / CCfg::SAMPLES) : cdiv(p.nsamp, CCfg::SAMPLES);
+    const long blocks = cmin_l(tiles, (long)c_persistent_blocks());
     const size_t lds = CCfg::TOTAL;
-    EVD_SET_MAX_LDS((&k_nerf_mlp_c<W, D, SKIP, FUSE>), lds);
+    EVD_SET_MAX_LDS((&k_nerf_mlp_c<W, D, SKIP, FUSE, TRAIN>), lds);
+    if (TRAIN != (p.act != nullptr)) return fail(EVD_E_INVALID, "evd_nerf_mlp (f16c): the activation store goes with the training launch");
     if (p.nbias != N::NTILES * 32) return fail(EVD_E_INVALID, "evd_nerf_mlp (f16c): %d bias floats, kernel expects %d", p.nbias, N::NTILES * 32);
     if (p.nchunks != N::NCH) return fail(EVD_E_INVALID, "evd_nerf_mlp (f16c): packed stream has %d chunks, kernel expects %d", p.nchunks, N::NCH);
     if (!p.wscale) return fail(EVD_E_INVALID, "evd_nerf_mlp (f16c): no row scales");
     if (FUSE && !(p.S == 32 || p.S == 64 || p.S == 128)) return fail(EVD_E_INVALID, "evd_nerf_mlp (f16c, fused step): N_samples must be 32, 64 or 128");
-    hipLaunchKernelGGL((k_nerf_mlp_c<W, D, SKIP, FUSE>), dim3((unsigned)blocks), dim3(CCfg::NT), lds, st, p);
+    hipLaunchKernelGGL((k_nerf_mlp_c<W, D, SKIP, FUSE, TRAIN>), dim3((unsigned)blocks), dim3(CCfg::NT), lds, st, p);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }

@@ -99,9 +99,9 @@ template <class C, class N, bool FEAT, bool TRAIN, int l, int D> struct HiddenLo
     }
 };
 
-template <int PREC, int W, int D, int SKIP, int NS, int NT, bool FEAT, bool TRAIN = false>
+template <int PREC, int W, int D, int SKIP, int NS, int NT, bool FEAT, bool TRAIN = false, bool HI_ONLY = false>
 __global__ __launch_bounds__(NT, NT / 256) void k_nerf_mlp(const MlpParams p) {
-    typedef PipeCfg<PREC, NS, NT> C;
+    typedef PipeCfg<PREC, NS, NT, PIPE_CB, HI_ONLY> C;
     typedef typename C::O O;
     typedef typename O::B B;
     typedef NerfNet<C, W, D, SKIP, FEAT, TRAIN> N;
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(NT, NT / 256) void k_nerf_mlp(const MlpParams p) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const long smp = (long)blockIdx.x * C::SAMPLES + wave * (NS * 32) + s * 32 + n;
-        actl[s] = TRAIN ? p.act + (smp >> 5) * astore::tile_bytes(PREC) + lane * 16 : nullptr;
+        actl[s] = TRAIN ? p.act + (smp >> 5) * astore::tile_bytes(C::STORE_PREC) + lane * 16 : nullptr;
         valid[s] = smp < p.nsamp;
         sidx[s] = valid[s] ? smp : p.nsamp - 1;
         const long ray = sidx[s] / p.S;
@@ -161,9 +161,9 @@ __global__ __launch_bounds__(NT, NT / 256) void k_nerf_mlp(const MlpParams p) {
         for (int j = 0; j < PEV_KS; ++j) cx.stash[(s * C::STASH_FRAGS + PE_KS + j) * 64] = pev[j];
         if constexpr (TRAIN) {
 #pragma unroll
-            for (int j = 0; j < PE_KS; ++j) act_store<C::FB>(actl[s], astore::PE + j, pe[j]);
+            for (int j = 0; j < PE_KS; ++j) pipe_act_store<C>(actl[s], astore::PE + j, pe[j]);
 #pragma unroll
-            for (int j = 0; j < PEV_KS; ++j) act_store<C::FB>(actl[s], astore::DIR + j, pev[j]);
+            for (int j = 0; j < PEV_KS; ++j) pipe_act_store<C>(actl[s], astore::DIR + j, pev[j]);
         }
     }
     cx.act = actl;
@@ -231,20 +231,20 @@ template <int PREC, int W, int D, int SKIP> constexpr int nerf_pipe_chunks() {
     return NerfNet<PipeCfg<PREC, 1, 256>, W, D, SKIP, false>::NCH;
 }
 
-template <int PREC, int W, int D, int SKIP, int NS, int NT, bool FEAT, bool TRAIN = false>
+template <int PREC, int W, int D, int SKIP, int NS, int NT, bool FEAT, bool TRAIN = false, bool HI_ONLY = false>
 static int launch_pipe_mlp(const MlpParams& p, hipStream_t st) {
-    typedef PipeCfg<PREC, NS, NT> C;
+    typedef PipeCfg<PREC, NS, NT, PIPE_CB, HI_ONLY> C;
     // training: the store is tiled in groups of 8 tiles (256 samples, evd_train_api.hip train_tiles) and the backward kernels walk ALL of
     // them, so the forward fills the padding tiles too (clamped copies of the last sample), whatever its own workgroup size
     const long blocks = TRAIN ? cdiv(p.nsamp, 256L) * (256 / C::SAMPLES) : cdiv(p.nsamp, C::SAMPLES);
     static_assert(256 % C::SAMPLES == 0 || !TRAIN, "training workgroups tile the 256-sample groups of the store");
     const size_t lds = C::TOTAL;
-    EVD_SET_MAX_LDS((&k_nerf_mlp<PREC, W, D, SKIP, NS, NT, FEAT, TRAIN>), lds);
+    EVD_SET_MAX_LDS((&k_nerf_mlp<PREC, W, D, SKIP, NS, NT, FEAT, TRAIN, HI_ONLY>), lds);
     if (p.nbias > C::BIAS_FLOATS) return fail(EVD_E_INVALID, "evd_nerf_mlp: %d bias floats exceed the LDS bias block", p.nbias);
     if (p.nchunks != NerfNet<C, W, D, SKIP, FEAT>::NCH)
         return fail(EVD_E_INVALID, "evd_nerf_mlp: packed stream has %d chunks, kernel expects %d", p.nchunks, NerfNet<C, W, D, SKIP, FEAT>::NCH);
     if (TRAIN && !p.act) return fail(EVD_E_INVALID, "evd_nerf_mlp: training launch without an activation store");
-    hipLaunchKernelGGL((k_nerf_mlp<PREC, W, D, SKIP, NS, NT, FEAT, TRAIN>), dim3((unsigned)blocks), dim3(NT), lds, st, p);
+    hipLaunchKernelGGL((k_nerf_mlp<PREC, W, D, SKIP, NS, NT, FEAT, TRAIN, HI_ONLY>), dim3((unsigned)blocks), dim3(NT), lds, st, p);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }

@@ -10,6 +10,8 @@ namespace evd {
 int launch_nerf_train_fwd_f16(const MlpParams& p, hipStream_t st);
 int launch_nerf_train_fwd_bf16(const MlpParams& p, hipStream_t st);
 int launch_nerf_train_fwd_f16x3(const MlpParams& p, hipStream_t st);
+int launch_nerf_train_fwd_f16x3_hi(const MlpParams& p, hipStream_t st);     // EVD_PREC_F16M: split-float16 forward, the float16 mode's store
+int launch_nerf_train_fwd_f16c(const MlpParams& p, hipStream_t st);         // EVD_PREC_F16C: compensated forward, the float16 mode's store
 
 // index maps of the wgrad reduction (fragment column -> parameter row / column, -1 = padding), offsets into one int32 array
 enum { MAP_HID = 0,                    // 256: hidden arrangement, channel 16 j + phi(kk)

@@ -84,5 +84,6 @@ int launch_tv_finish(const double* acc, const TvShape& s, float* out, hipStream_
 int voxel_mlp_dispatch(int prec, int HD, int G, int FT, const VoxMlpParams& p, hipStream_t st);
 int voxel_mlp_c_chunks(int HD, int G, int FT);              // compensated float16 mode (voxel_mlp_c_kernel.h): chunks of its stream, 0 = not built for this level
 int launch_voxel_pipe_f16c(const VoxMlpParams& p, hipStream_t st);
+int launch_voxel_train_fwd_f16c(const VoxMlpParams& p, hipStream_t st);   // fine level; writes the float16 mode's activation store
 
 }  // namespace evd

@@ -3,28 +3,38 @@
 // (sigmoid).  Machinery and arithmetic: mlp_pipe_c.h (one float16 MFMA product + two block-scaled fp6 products of the operands' rounding
 // residuals, one wavefront of 32 samples per SIMD).  This is the mode the shipped (mode='c2f') configurations are rendered in when the
 // 1e-4 RGB bound has to hold on trained weights: the single-product float16 mode measures 3.8e-4 there (tools/trained_c2f.py).
-// Inference only (no feature rows, no activation store); the coarse 64-wide level runs in EVD_PREC_F16X3 next to it (evd_voxel_api.hip).
+// No feature rows; the coarse 64-wide level runs in EVD_PREC_F16X3 next to it (evd_voxel_api.hip).
+// TRAIN variant (round 4): the same arithmetic, and every completed input / hidden / geo block also goes to the activation store of the
+// single-product float16 mode (voxel_mlp_kernel.h VStore: float16 fragments in that mode's arrangement + the ReLU patterns as bit masks,
+// both taken from the COMPENSATED pre-activations), so that the level's backward is that mode's dgrad / wgrad chain unchanged.  This is
+// the training forward that holds the reference's float32 numbers (run_nerf.py:593-601 trains in float32): rendered colours, the
+// resampled positions and the ReLU patterns are the float32 ones to ~2^-15 instead of 2^-11.
 #pragma once
 
 #include "mlp_pipe_c.h"
 #include "voxel.h"
+#include "voxel_mlp_kernel.h"
 
 namespace evd {
 
 // static layer table of one level: HD hidden width, G geo channels (a multiple of 64), FT feature channels in (64: one input block)
-template <int HD, int G, int FT> struct VoxNetC {
+template <int HD, int G, int FT, bool TRAIN = false> struct VoxNetC {
+    typedef VStore<HD, G, FT> VS;
+    static constexpr int slot(int s) { return TRAIN ? s : -1; }
     static constexpr int T = HD / 32, KB = HD / 64, GT = G / 32, GB = G / 64;
     static_assert(FT == 64 && PE_KS == 4 && PEV_KS == 2 && T % 2 == 0 && G % 64 == 0 && KB >= 2, "block structure of the inputs");
     // sigma_net.0 on cat([fts, PE(pts)]) (voxnerf.py:214): blocks [fts | pe]
-    typedef CLayer<2, 4, T, 2, true, false, 0, 0, 0, false, 0, 1> L0;
+    typedef CLayer<2, 4, T, 2, true, false, 0, 0, 0, false, 0, 1, slot(VS::HID), -1, slot(VS::M_HID)> L0;
     // sigma_net.1 row 0 = sigma (float32 out); drains L0's last group into the hidden block KB - 1
-    typedef CLayer<KB, 4, 1, 1, false, true, L0::NCHUNKS, L0::PAR_OUT, 2, true, KB - 1, 2> Sigma;
+    typedef CLayer<KB, 4, 1, 1, false, true, L0::NCHUNKS, L0::PAR_OUT, 2, true, KB - 1, 2, -1, slot(VS::HID + 4 * (KB - 1)), -1, slot(VS::M_HID)> Sigma;
     // sigma_net.1 rows 1..G = geo features, no activation (voxnerf.py:221)
-    typedef CLayer<KB, 4, GT, 2, false, false, Sigma::CHUNK0 + Sigma::NCHUNKS, Sigma::PAR_OUT, 0, false, 0, 2> Geo;
+    typedef CLayer<KB, 4, GT, 2, false, false, Sigma::CHUNK0 + Sigma::NCHUNKS, Sigma::PAR_OUT, 0, false, 0, 2, slot(VS::GEO)> Geo;
     // color_net.0 on cat([geo, PE(dirs)]) (voxnerf.py:248): blocks [geo_0 .. geo_{GB-1} | dir (2 k-steps)]; drains geo's last group into block GB - 1
-    typedef CLayer<GB + 1, 2, T, 2, true, false, Geo::CHUNK0 + Geo::NCHUNKS, Geo::PAR_OUT, 2, false, GB - 1, 2> C0;
-    typedef CLayer<KB, 4, T, 2, true, false, C0::CHUNK0 + C0::NCHUNKS, C0::PAR_OUT, 2, true, KB - 1, 1> C1;
-    typedef CLayer<KB, 4, 1, 1, false, true, C1::CHUNK0 + C1::NCHUNKS, C1::PAR_OUT, 2, true, KB - 1, 0> C2;
+    typedef CLayer<GB + 1, 2, T, 2, true, false, Geo::CHUNK0 + Geo::NCHUNKS, Geo::PAR_OUT, 2, false, GB - 1, 2, slot(VS::C0), slot(VS::GEO + 4 * (GB - 1)),
+                   slot(VS::M_C0)> C0;
+    typedef CLayer<KB, 4, T, 2, true, false, C0::CHUNK0 + C0::NCHUNKS, C0::PAR_OUT, 2, true, KB - 1, 1, slot(VS::C1), slot(VS::C0 + 4 * (KB - 1)), slot(VS::M_C1),
+                   slot(VS::M_C0)> C1;
+    typedef CLayer<KB, 4, 1, 1, false, true, C1::CHUNK0 + C1::NCHUNKS, C1::PAR_OUT, 2, true, KB - 1, 0, -1, slot(VS::C1 + 4 * (KB - 1)), -1, slot(VS::M_C1)> C2;
     static constexpr int NCH = C2::CHUNK0 + C2::NCHUNKS;
     // LDS bias / row-scale image in stream order (the sigma net has no biases: zeros)
     static constexpr int B_SIG = T * 32, B_GEO = B_SIG + 32, B_C0 = B_GEO + GT * 32, B_C1 = B_C0 + T * 32, B_C2 = B_C1 + T * 32, B_END = B_C2 + 32;
@@ -51,9 +61,10 @@ __device__ __forceinline__ void c_block_from_row(const float* f, XBlk& out) {
     c_finish(out, m, r[0], r[1]);
 }
 
-template <int HD, int G, int FT>
+template <int HD, int G, int FT, bool TRAIN>
 __global__ __launch_bounds__(CCfg::NT, 1) void k_voxel_mlp_c(const VoxMlpParams p) {
-    typedef VoxNetC<HD, G, FT> N;
+    typedef VoxNetC<HD, G, FT, TRAIN> N;
+    typedef typename N::VS VS;
     typedef CStream<N::NCH> ST;
     constexpr int KB = N::KB, GB = N::GB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -75,7 +86,8 @@ __global__ __launch_bounds__(CCfg::NT, 1) void k_voxel_mlp_c(const VoxMlpParams 
 
     // persistent workgroups, one per CU (nerf_mlp_c_kernel.h: the hand-over between two workgroups of a one-workgroup-per-CU kernel is
     // uncovered; a pass of this network is only ~19 us long)
-    const long ntile = (p.nsamp + CCfg::SAMPLES - 1) / CCfg::SAMPLES;
+    // (TRAIN: the store is tiled in groups of 8 sample tiles and the backward walks all of them -- the padding tiles are written too)
+    const long ntile = TRAIN ? (p.nsamp + 255) / 256 * (256 / CCfg::SAMPLES) : (p.nsamp + CCfg::SAMPLES - 1) / CCfg::SAMPLES;
     for (long tile = blockIdx.x;;) {
     const long smp = tile * CCfg::SAMPLES + wave * 32 + n;
     const bool valid = smp < p.nsamp;
@@ -92,21 +104,32 @@ __global__ __launch_bounds__(CCfg::NT, 1) void k_voxel_mlp_c(const VoxMlpParams 
         c_encode<PE_L, PE_KS>(pts, h, in0[1]);
         c_encode<PE_LV, PEV_KS>(vd, h, pev);
     }
+    CAct act{};
+    if constexpr (TRAIN) {
+        const long t32 = __builtin_amdgcn_readfirstlane((int)(tile * (CCfg::SAMPLES / 32) + wave));      // this wavefront's 32-sample tile (< 2^31)
+        act.base = p.act + t32 * VS::TILE_BYTES;
+        act.voff = lane * 16;
+    }
+    if constexpr (TRAIN) {          // the network's inputs, in the float16 mode's own fragment order (voxel_mlp_kernel.h)
+        c_store_input<4>(act, VS::IN0, in0[0]);
+        c_store_input<PE_KS>(act, VS::IN0 + 4, in0[1]);
+        c_store_input<PEV_KS>(act, VS::DIRPE, pev);
+    }
 
     st.start_wait();
     CPipe pp;
     c_prime<typename N::L0>(st, pp, lbias, lane);
     XBlk hid[KB], none[1];
-    c_layer<typename N::L0, typename N::Sigma, ST, 2, KB>(st, pp, in0, hid, nullptr, lbias, lane);
+    c_layer<typename N::L0, typename N::Sigma, ST, 2, KB, TRAIN>(st, pp, in0, hid, nullptr, lbias, lane, act);
     float sig[4], col[4];
-    c_layer<typename N::Sigma, typename N::Geo, ST, KB, 1>(st, pp, hid, none, sig, lbias + N::B_SIG, lane);
+    c_layer<typename N::Sigma, typename N::Geo, ST, KB, 1, TRAIN>(st, pp, hid, none, sig, lbias + N::B_SIG, lane, act);
     XBlk cin[GB + 1];
-    c_layer<typename N::Geo, typename N::C0, ST, KB, GB + 1>(st, pp, hid, cin, nullptr, lbias + N::B_GEO, lane);
+    c_layer<typename N::Geo, typename N::C0, ST, KB, GB + 1, TRAIN>(st, pp, hid, cin, nullptr, lbias + N::B_GEO, lane, act);
     cin[GB] = pev;
     XBlk c0[KB], c1[KB];
-    c_layer<typename N::C0, typename N::C1, ST, GB + 1, KB>(st, pp, cin, c0, nullptr, lbias + N::B_C0, lane);
-    c_layer<typename N::C1, typename N::C2, ST, KB, KB>(st, pp, c0, c1, nullptr, lbias + N::B_C1, lane);
-    c_layer<typename N::C2, void, ST, KB, 1>(st, pp, c1, none, col, lbias + N::B_C2, lane);
+    c_layer<typename N::C0, typename N::C1, ST, GB + 1, KB, TRAIN>(st, pp, cin, c0, nullptr, lbias + N::B_C0, lane, act);
+    c_layer<typename N::C1, typename N::C2, ST, KB, KB, TRAIN>(st, pp, c0, c1, nullptr, lbias + N::B_C1, lane, act);
+    c_layer<typename N::C2, void, ST, KB, 1, TRAIN>(st, pp, c1, none, col, lbias + N::B_C2, lane, act);
     const bool more = tile + gridDim.x < ntile;
     if (more) st.restart_issue();               // behind the barrier of the stream's last chunk: all slots are free
 
@@ -122,16 +145,18 @@ __global__ __launch_bounds__(CCfg::NT, 1) void k_voxel_mlp_c(const VoxMlpParams 
     }
 }
 
-template <int HD, int G, int FT>
+template <int HD, int G, int FT, bool TRAIN = false>
 static int launch_voxel_c(const VoxMlpParams& p, hipStream_t st) {
-    typedef VoxNetC<HD, G, FT> N;
-    const long blocks = cmin_l(cdiv(p.nsamp, CCfg::SAMPLES), (long)c_persistent_blocks());
+    typedef VoxNetC<HD, G, FT, TRAIN> N;
+    const long tiles = TRAIN ? cdiv(p.nsamp, 256L) * (256 / CCfg::SAMPLES) : cdiv(p.nsamp, CCfg::SAMPLES);
+    const long blocks = cmin_l(tiles, (long)c_persistent_blocks());
     const size_t lds = CCfg::TOTAL;
-    EVD_SET_MAX_LDS((&k_voxel_mlp_c<HD, G, FT>), lds);
+    EVD_SET_MAX_LDS((&k_voxel_mlp_c<HD, G, FT, TRAIN>), lds);
     if (p.nchunks != N::NCH) return fail(EVD_E_INVALID, "evd_voxel (f16c): packed stream has %d chunks, kernel expects %d", p.nchunks, N::NCH);
     if (!p.wscale) return fail(EVD_E_INVALID, "evd_voxel (f16c): no row scales");
-    if (p.feature || p.act) return fail(EVD_E_INVALID, "evd_voxel (f16c): feature rows / activation store are not built in this mode (use EVD_PREC_F16X3)");
-    hipLaunchKernelGGL((k_voxel_mlp_c<HD, G, FT>), dim3((unsigned)blocks), dim3(CCfg::NT), lds, st, p);
+    if (p.feature) return fail(EVD_E_INVALID, "evd_voxel (f16c): feature rows are not built in this mode (use EVD_PREC_F16X3)");
+    if (TRAIN != (p.act != nullptr)) return fail(EVD_E_INVALID, "evd_voxel (f16c): the activation store goes with the training launch");
+    hipLaunchKernelGGL((k_voxel_mlp_c<HD, G, FT, TRAIN>), dim3((unsigned)blocks), dim3(CCfg::NT), lds, st, p);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }

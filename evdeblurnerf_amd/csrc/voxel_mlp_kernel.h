@@ -59,9 +59,9 @@ template <class C, int HD_, int G_, int FT_, bool FEAT, bool TRAIN = false> stru
 };
 template <class C, bool FEAT> using VoxFineNet = VoxNet<C, 256, 128, 64, FEAT, false>;
 
-template <int PREC, int HD, int G, int FT, int NS, int NT, bool FEAT, int CB, int OCC, bool TRAIN>
+template <int PREC, int HD, int G, int FT, int NS, int NT, bool FEAT, int CB, int OCC, bool TRAIN, bool HI_ONLY = false>
 __global__ __launch_bounds__(NT, OCC) void k_voxel_mlp_pipe(const VoxMlpParams p) {
-    typedef PipeCfg<PREC, NS, NT, CB> C;
+    typedef PipeCfg<PREC, NS, NT, CB, HI_ONLY> C;
     typedef typename C::O O;
     typedef typename O::B B;
     typedef VoxNet<C, HD, G, FT, FEAT, TRAIN> N;
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(NT, OCC) void k_voxel_mlp_pipe(const VoxMlpParams p
         const long smp = (long)blockIdx.x * C::SAMPLES + wave * (NS * 32) + s * 32 + n;
         valid[s] = smp < p.nsamp;
         sidx[s] = valid[s] ? smp : p.nsamp - 1;
-        actl[s] = TRAIN ? p.act + (smp >> 5) * VS::tile_bytes(PREC) + lane * 16 : nullptr;
+        actl[s] = TRAIN ? p.act + (smp >> 5) * VS::tile_bytes(C::STORE_PREC) + lane * 16 : nullptr;
         float pts[3], vd[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -115,9 +115,9 @@ __global__ __launch_bounds__(NT, OCC) void k_voxel_mlp_pipe(const VoxMlpParams p
         for (int j = 0; j < PEV_KS; ++j) stash[(s * C::STASH_FRAGS + j) * 64] = pev[j];   // parked until the colour net
         if constexpr (TRAIN) {
 #pragma unroll
-            for (int j = 0; j < KF + PE_KS; ++j) act_store<C::FB>(actl[s], VS::IN0 + j, in0[s][j]);
+            for (int j = 0; j < KF + PE_KS; ++j) pipe_act_store<C>(actl[s], VS::IN0 + j, in0[s][j]);
 #pragma unroll
-            for (int j = 0; j < PEV_KS; ++j) act_store<C::FB>(actl[s], VS::DIRPE + j, pev[j]);
+            for (int j = 0; j < PEV_KS; ++j) pipe_act_store<C>(actl[s], VS::DIRPE + j, pev[j]);
         }
     }
     float* frow[NS];
@@ -182,17 +182,19 @@ static int launch_voxel_pipe(const VoxMlpParams& p, hipStream_t st) {
 
 // training variant (keeps the activations), either level; the stream is the level's pipe stream (evd_voxel_api.hip).  The store is
 // tiled in groups of 8 tiles (256 samples) and the backward walks all of them: the grid covers the padding tiles too.
-template <int PREC, int HD, int G, int FT, bool FEAT = false>
+// HI_ONLY (PREC = EVD_PREC_F16X3): the store is the single-product float16 mode's (mlp_pipe.h PipeCfg) -- the coarse level of a
+// training forward in EVD_PREC_F16C
+template <int PREC, int HD, int G, int FT, bool FEAT = false, bool HI_ONLY = false>
 static int launch_voxel_train_fwd(const VoxMlpParams& p, hipStream_t st) {
     constexpr int NT = is_half_prec(PREC) ? 512 : 256, OCC = is_half_prec(PREC) ? 2 : 1;     // split-float16: one wavefront per SIMD
-    typedef PipeCfg<PREC, 1, NT> C;
+    typedef PipeCfg<PREC, 1, NT, PIPE_CB, HI_ONLY> C;
     typedef VoxNet<C, HD, G, FT, FEAT, true> N;
     const long blocks = cdiv(p.nsamp, 256L) * (256 / C::SAMPLES);
     const size_t lds = C::TOTAL;
-    EVD_SET_MAX_LDS((&k_voxel_mlp_pipe<PREC, HD, G, FT, 1, NT, FEAT, PIPE_CB, OCC, true>), lds);
+    EVD_SET_MAX_LDS((&k_voxel_mlp_pipe<PREC, HD, G, FT, 1, NT, FEAT, PIPE_CB, OCC, true, HI_ONLY>), lds);
     if (p.nchunks != N::NCH) return fail(EVD_E_INVALID, "evd_voxel: packed stream has %d chunks, kernel expects %d", p.nchunks, N::NCH);
     if (!p.act) return fail(EVD_E_INVALID, "evd_voxel: training launch without an activation store");
-    hipLaunchKernelGGL((k_voxel_mlp_pipe<PREC, HD, G, FT, 1, NT, FEAT, PIPE_CB, OCC, true>), dim3((unsigned)blocks), dim3(NT), lds, st, p);
+    hipLaunchKernelGGL((k_voxel_mlp_pipe<PREC, HD, G, FT, 1, NT, FEAT, PIPE_CB, OCC, true, HI_ONLY>), dim3((unsigned)blocks), dim3(NT), lds, st, p);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }

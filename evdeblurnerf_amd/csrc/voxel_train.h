@@ -52,6 +52,7 @@ struct VoxBwdPlan {
 int launch_voxel_train_fwd_f16(int HD, const VoxMlpParams& p, hipStream_t st);
 int launch_voxel_train_fwd_bf16(int HD, const VoxMlpParams& p, hipStream_t st);
 int launch_voxel_train_fwd_f16x3(int HD, const VoxMlpParams& p, hipStream_t st);
+int launch_voxel_train_fwd_f16x3_hi(int HD, const VoxMlpParams& p, hipStream_t st);   // split-float16 arithmetic, the float16 mode's store
 int run_voxel_backward_f16(int HD, const VoxBwdPlan& b, hipStream_t st);
 int run_voxel_backward_bf16(int HD, const VoxBwdPlan& b, hipStream_t st);
 int run_voxel_backward_f16x3(int HD, const VoxBwdPlan& b, hipStream_t st);

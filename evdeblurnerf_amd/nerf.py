@@ -184,7 +184,7 @@ class NeRF:
         raw = torch.empty((R, S, 4), dtype=torch.float32, device=z.device)
         nb = int(L.lib().evd_nerf_train_store_bytes_prec(L.PREC[precision or self.precision], R * S))
         if nb == 0 and R * S > 0:
-            raise L.EvdError(f"the training path is built for precision f16 / bf16 / f16x3, not {precision or self.precision}")
+            raise L.EvdError(f"the training path is built for precision f16 / bf16 / f16x3 / f16c / f16m, not {precision or self.precision}")
         store = torch.empty((nb,), dtype=torch.uint8, device=z.device)
         L.check(L.lib().evd_nerf_mlp_train(self._h, L.PREC[precision or self.precision], L.ptr(rb), L.ptr(z), R, S, L.ptr(raw),
                                             L.ptr(store), nb, L.stream_ptr()), "evd_nerf_mlp_train")

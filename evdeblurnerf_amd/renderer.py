@@ -191,6 +191,10 @@ class NeRFAll:
         self.awpnet = awpnet
         self.use_awp = bool(_args_get(args, "kernel_use_awp", False)) and awpnet is not None
         self.extract_feature = "before_linear" if self.use_awp else "after_linear"
+        # precision: the arithmetic of the MLP GEMMs (include/evdnerf.h EVD_PREC_*).  "f16m" is a TRAINING mode (split-float16 forward, float16
+        # backward); a model built with it renders its inference passes in "f16x3", the same forward arithmetic
+        self.train_precision = precision
+        precision = "f16x3" if precision == "f16m" else precision
         self.precision = precision
         self.training = False
         self.device = torch.device(device or "cuda")
@@ -419,12 +423,12 @@ class NeRFAll:
         rays_d = rb[:, 3:6].contiguous()
         if want_feature:
             raise NotImplementedError("depth_feature under autograd is built for mode='c2f' (the shipped AWP configs)")
-        raw0 = self.mlp_coarse.mlp_train(flat_coarse, rb, z0, self.precision)
+        raw0 = self.mlp_coarse.mlp_train(flat_coarse, rb, z0, self.train_precision)
         rgb0, _, acc0, w0, depth0, _ = self.mlp_coarse.raw2outputs(raw0, z0, rays_d, None, 0., white_bkgd, noise=noise0)
         if Ni <= 0:
             return {"rgb_map": rgb0, "depth_map": depth0, "acc_map": acc0, "weights": w0, "z_vals": z0}
         _, zm, _, zstd = sample_pdf_merge(z0, w0.detach(), Ni, det=(perturb == 0.), u=u)
-        raw1 = self.mlp_fine.mlp_train(flat_fine, rb, zm, self.precision)
+        raw1 = self.mlp_fine.mlp_train(flat_fine, rb, zm, self.train_precision)
         rgb, _, acc, w1, depth, _ = self.mlp_fine.raw2outputs(raw1, zm, rays_d, None, 0., white_bkgd, noise=noise1)
         return {"rgb_map": rgb, "depth_map": depth, "acc_map": acc, "weights": w1, "z_vals": zm, "rgb0": rgb0, "depth0": depth0,
                 "acc0": acc0, "z_std": zstd}
@@ -438,29 +442,29 @@ class NeRFAll:
         vd = rb[:, 8:11].contiguous()
         rays_d = rb[:, 3:6].contiguous()
         pts0 = points(rb, z0)
-        ft0 = coarse.sample_train(pts0, pc["grids"], self.precision)
-        raw0 = coarse.mlp_train(pc["net"], pts0, vd, ft0, self.precision)
+        ft0 = coarse.sample_train(pts0, pc["grids"], self.train_precision)
+        raw0 = coarse.mlp_train(pc["net"], pts0, vd, ft0, self.train_precision)
         rgb0, _, acc0, w0, depth0 = coarse.raw2outputs(raw0, z0, rays_d, is_train=True, noise=noise0)
         if Ni <= 0:
             return {"rgb_map": rgb0, "depth_map": depth0, "acc_map": acc0, "weights": w0, "z_vals": z0}
         zs, zm, order, zstd = sample_pdf_merge(z0, w0.detach(), Ni, det=(perturb == 0.), u=u, want_order=True)
-        ftn = coarse.sample_train(points(rb, zs), pc["grids"], self.precision)
+        ftn = coarse.sample_train(points(rb, zs), pc["grids"], self.train_precision)
         ptm = points(rb, zm)
         # cat([coarse features re-ordered by the sort (:209-213), fine features at the merged points]) in one row buffer: the merge is a
         # library kernel writing columns 0..fc-1 (a row permutation: its backward is one too), the fine features land behind them
         # -- and the fine gather writes them there itself (its output is a strided window of the row buffer; no copy either way)
         fc, ff = ft0.shape[-1], fine.app_dim
         rows = torch.empty((ptm.shape[0], ptm.shape[1], fc + ff), dtype=torch.float32, device=ptm.device)
-        ft = _MergeFeatures.apply(ft0, ftn, order, fine.sample_train(ptm, pf["grids"], self.precision, out=_window(rows, fc, ff)), rows)
+        ft = _MergeFeatures.apply(ft0, ftn, order, fine.sample_train(ptm, pf["grids"], self.train_precision, out=_window(rows, fc, ff)), rows)
         feat = None
         if want_feature == "fragments":                     # fused AWP consumer: the geo features stay in the level's store (awp.FusedAWP)
             from .voxnerf import GeoFragments
             feat = GeoFragments()
-            raw1, feat.token = fine.mlp_train(pf["net"], ptm, vd, ft, self.precision, want_feature=feat)
+            raw1, feat.token = fine.mlp_train(pf["net"], ptm, vd, ft, self.train_precision, want_feature=feat)
         elif want_feature:
-            raw1, feat = fine.mlp_train(pf["net"], ptm, vd, ft, self.precision, want_feature=True)
+            raw1, feat = fine.mlp_train(pf["net"], ptm, vd, ft, self.train_precision, want_feature=True)
         else:
-            raw1 = fine.mlp_train(pf["net"], ptm, vd, ft, self.precision)
+            raw1 = fine.mlp_train(pf["net"], ptm, vd, ft, self.train_precision)
         rgb, _, acc, w1, depth = fine.raw2outputs(raw1, zm, rays_d, is_train=True, noise=noise1)
         ret = {"rgb_map": rgb, "depth_map": depth, "acc_map": acc, "weights": w1, "z_vals": zm, "rgb0": rgb0, "depth0": depth0,
                "acc0": acc0, "z_std": zstd}
@@ -513,8 +517,10 @@ class NeRFAll:
         awp = use_kernel and self.use_awp
         from .awp import FusedAWP
         # (the fragment coupling is a half-precision one: in the float32-grade mode the fused module takes the feature rows)
-        fused = awp and isinstance(self.awpnet, FusedAWP) and self.mode == "c2f" and self.precision in ("f16", "bf16") and \
-            self.awpnet.embed.precision == self.precision
+        # (... in the float16 mode's fragment format, which the mixed training modes f16c / f16m keep too)
+        store_prec = "f16" if self.train_precision in ("f16c", "f16m") else self.train_precision
+        fused = awp and isinstance(self.awpnet, FusedAWP) and self.mode == "c2f" and store_prec in ("f16", "bf16") and \
+            self.awpnet.embed.precision == store_prec
         out = self.render_rays_train(rb, params_coarse, params_fine, N_samples, N_importance, want_feature="fragments" if fused else awp, **kw)
         rgb, rgb0 = out["rgb_map"], out.get("rgb0")
         if awp:         # adaptive weight proposal on the fine level's per-sample features (renderer.py:310-316): a second composition

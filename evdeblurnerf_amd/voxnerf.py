@@ -121,7 +121,9 @@ class _VoxelMLP(torch.autograd.Function):
         ctx.accum = getattr(flat, "_evd_accum", None)          # in-place gradient accumulation (renderer._FlatParams), opt-in
         ctx.set_materialize_grads(False)
         if geo is not None:
-            geo.level, geo.store, geo.precision, geo.R, geo.S = net, store, precision, pts.shape[0], pts.shape[1]
+            # (the mixed training modes f16c / f16m keep the float16 mode's store: that is the fragment format a consumer reads)
+            geo.level, geo.store, geo.R, geo.S = net, store, pts.shape[0], pts.shape[1]
+            geo.precision = "f16" if precision in ("f16c", "f16m") else precision
             return raw, torch.zeros((1,), dtype=torch.float32, device=raw.device)
         return (raw, feature) if rows else raw
 
@@ -313,7 +315,7 @@ class VoxelNeRFBase:
         feature = torch.empty((R, S, self.geo_feat_dim), dtype=torch.float32, device=p.device) if want_feature else None
         nb = int(L.lib().evd_voxel_train_store_bytes_prec(self._h, L.PREC[precision or self.precision], R * S))
         if nb == 0 and R * S > 0:
-            raise L.EvdError(f"the training path is built for precision f16 / bf16 / f16x3, not {precision or self.precision}")
+            raise L.EvdError(f"the training path is built for precision f16 / bf16 / f16x3 / f16c / f16m, not {precision or self.precision}")
         store = torch.empty((nb,), dtype=torch.uint8, device=p.device)
         L.check(L.lib().evd_voxel_mlp_train(self._h, L.PREC[precision or self.precision], L.ptr(p), L.ptr(vd), vd.shape[-1], L.ptr(ft), ft.shape[-1],
                                              R, S, L.ptr(raw), L.ptr(feature), L.ptr(store), nb, L.stream_ptr()), "evd_voxel_mlp_train")

@@ -41,7 +41,16 @@ extern "C" {
 #define EVD_PREC_F16C 4     /* compensated float16: the float16 product + two block-scaled fp6 (e2m3) products of the operands' rounding
                              * residuals on v_mfma_scale_f32_32x32x64_f8f6f4: ~2^-15 operands at 1.4x the matrix-pipe time of EVD_PREC_F16.
                              * Built for the netdepth 8, netwidth 256, skips [4] NeRF network without feature rows; EVD_E_INVALID otherwise. */
-#define EVD_NUM_PREC 5
+#define EVD_NUM_PREC 5      /* arithmetic modes with weight streams of their own */
+/* TRAINING entries only (evd_*_mlp_train / _backward / _train_store_bytes_prec, evd_voxel_sample_prec), round 4.  The reference trains in
+ * float32 (run_nerf.py:593-601); both mixed modes below keep the single-product float16 mode's activation store and run ITS backward
+ * (loss-scaled float16 operands, float32 accumulation), behind a forward that holds the float32 numbers:
+ *   EVD_PREC_F16C (above) as a training mode: the compensated forward where a level / network has that kernel (PDRF fine level, 8 x 256
+ *     NeRF), the split-float16 forward elsewhere (PDRF coarse level).  Forward ~2^-15; ReLU patterns differ from float32 in ~5e-6 of the
+ *     units, which bounds the gradients at ~sqrt(5e-6) = a few 1e-3 of their norm whatever the batch size.
+ *   EVD_PREC_F16M: the split-float16 (EVD_PREC_F16X3) forward everywhere: forward ~2^-21, float32's own ReLU patterns; gradients within
+ *     the float16 backward's rounding (~1e-3).  Inference entries reject it (render in EVD_PREC_F16X3). */
+#define EVD_PREC_F16M 5
 
 /* activation codes: reference networks/nerf.py:31-33, networks/pdrf/voxnerf.py:28-30 */
 #define EVD_ACT_NONE 0

@@ -127,9 +127,9 @@ def test_fine_level_f16c_ragged_sizes_repack_and_rejections():
     pts, vd, _, z, rd = _level_inputs(rs, 40, 17)
     ftc = T((0.3 * rs.normal(size=(40, 17, 32))).astype(np.float32))
     assert torch.equal(coarse.forward(pts, vd, ftc, z, rd, precision="f16c")[0], coarse.forward(pts, vd, ftc, z, rd, precision="f16x3")[0])
-    # training is not built in this mode
+    # training in this mode (round 4: tests/test_gpu_train_f16c.py) keeps the geo features as fragments: float32 feature rows are rejected
     with pytest.raises(L.EvdError):
-        net.mlpforward_train(a[0], a[1], a[2], precision="f16c")
+        net.mlpforward_train(a[0], a[1], a[2], precision="f16c", want_feature=True)
 
 
 def test_gather_into_a_row_window_and_merge_in_place():

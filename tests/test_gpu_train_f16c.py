@@ -1,0 +1,294 @@
+"""Training in the MIXED modes: the COMPENSATED float16 forward (EVD_PREC_F16C in evd_voxel_mlp_train / evd_nerf_mlp_train and their
+backward entries) and the split-float16 forward (EVD_PREC_F16M), both in front of the single-product float16 backward.
+
+The reference trains in float32 (run_nerf.py:593-601; forwards networks/pdrf/voxnerf.py:210-259, networks/nerf.py:131-162).  In this
+mode the training FORWARD runs the compensated arithmetic of the inference render (float16 product + two fp6 products of the rounding
+residuals; the 64-wide coarse PDRF level float32-grade, as in inference), so rendered colours, resampled positions and ReLU patterns
+are the float32 ones to ~2^-15; the stored activations are float16 fragments in the single-product float16 mode's store and the
+BACKWARD is that mode's dgrad / wgrad chain (loss-scaled float16 operands, float32 accumulation).  Bounds written here:
+training-forward RGB <= 1e-4 against the reference goldens / the float64 pipeline in both modes.  Gradients: a forward whose
+pre-activations carry a relative error eps decides ~eps of the ReLU units differently from float32, and a fraction p of flipped units
+moves a gradient by ~sqrt(p) of its norm WHATEVER the batch size (flips and norm^2 both grow with the sample count): measured
+p = 4.6e-6 per unit in f16c -> 2..7e-3 of the norm on a 65 536-sample batch (single-product float16: p ~ 1e-3 -> 3e-2), while on the
+768 samples of golden G19 one flipped unit of a dominant sample shows as several %.  f16m (float32's own patterns) is held to the
+goldens at 2e-3 of the norm; f16c to the float64 pipeline with the kernel's patterns at 4e-3 and to the goldens at the measured
+flip bound."""
+import numpy as np
+import pytest
+import torch
+
+from evdeblurnerf_amd import weights as W
+from test_gpu_train import AABB, rel_l2, vdecode
+from torch_restatement import TorchVoxLevel
+
+pytestmark = pytest.mark.gpu
+
+
+def _level(level, prec):
+    from evdeblurnerf_amd.voxnerf import VoxelNeRFRayFeatures, VoxelNeRFSampleFeatures
+    if level == "coarse":
+        HD, G, FT, nvox, cls = 64, 15, 32, 24 ** 3, VoxelNeRFRayFeatures
+    else:
+        HD, G, FT, nvox, cls = 256, 128, 64, 48 ** 3, VoxelNeRFSampleFeatures
+    gsz = W.pdrf_grid_size(AABB[0], AABB[1], nvox)
+    sd = W.make_pdrf_state_dict(71, gsz, input_ch=FT + 63, hidden_dim=HD, geo_feat_dim=G, add_bias_color=True)
+    net = cls(sd, "", AABB, num_layers=2, hidden_dim=HD, geo_feat_dim=G, num_layers_color=3, input_ch=FT + 63, app_dim=32,
+              app_n_comp=(64, 16, 16), n_voxels=nvox, precision=prec)
+    return net, sd, HD, G, FT
+
+
+def _slots(HD, G, FT):
+    KS, KF, GT = HD // 16, FT // 16, (G + 31) // 32
+    IN0, HID = 0, KF + 4                  # voxel_mlp_kernel.h VStore
+    GEO = HID + KS
+    DIRPE = GEO + 2 * GT
+    C0 = DIRPE + 2
+    C1 = C0 + KS
+    TILE_FRAGS = C1 + KS + 2 + KS + KS + (2 * GT + 2) + KS + (2 * ((FT + 31) // 32) + 4) + 3
+    return dict(KS=KS, KF=KF, GT=GT, IN0=IN0, HID=HID, GEO=GEO, DIRPE=DIRPE, C0=C0, C1=C1, TILE_FRAGS=TILE_FRAGS)
+
+
+@pytest.mark.parametrize("prec", ["f16c", "f16m"])
+@pytest.mark.parametrize("R,S", [(70, 33), (5, 3), (1, 1), (129, 64)])
+@pytest.mark.parametrize("level", ["coarse", "fine"])
+def test_mixed_level_training_forward_store_and_backward(level, R, S, prec):
+    """One PDRF level: (1) raw of the training forward vs float64 (own ReLU pattern) at the inference bound of the mode; (2) the
+    store it leaves is the float16 mode's -- hidden / geo fragments equal the float64 activations to float16 resolution, in that mode's
+    arrangement; (3) the ReLU patterns in it are the float64 ones except for units within the mode's error of zero; (4) the float16
+    backward on that store: parameter / feature / encoding gradients vs float64 autograd -- with the kernel's pattern (the float16
+    backward's own bound, 4e-3) and with the TRUE float64 pattern (what a float32 training run would compute)."""
+    net, sd, HD, G, FT = _level(level, "f16x3" if prec == "f16m" else prec)
+    rs = np.random.RandomState(11)
+    pts = rs.uniform(-1, 1, (R, S, 3)).astype(np.float32)
+    d = rs.normal(size=(R, 3))
+    vd = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32)
+    fts = (0.3 * rs.normal(size=(R, S, FT))).astype(np.float32)
+    d_raw = (rs.normal(size=(R, S, 4)) * 1e-3 * np.exp(rs.uniform(-3, 0, (R, S, 1)))).astype(np.float32)
+    dev, n = "cuda", R * S
+    flat = net.flat_params(sd)
+    ft_t = torch.tensor(fts, device=dev, requires_grad=True)
+    pts_t, vd_t = torch.tensor(pts, device=dev, requires_grad=True), torch.tensor(vd, device=dev, requires_grad=True)
+    raw = net.mlp_train(flat, pts_t, vd_t, ft_t, precision=prec)
+    store = raw.grad_fn.store
+    (raw * torch.tensor(d_raw, device=dev)).sum().backward()
+    sl = _slots(HD, G, FT)
+    import evdeblurnerf_amd._lib as L
+    assert store.numel() == int(L.lib().evd_voxel_train_store_bytes_prec(net._h, L.PREC["f16"], n)), "the float16 mode's store"
+    dec = lambda slot, nf: vdecode(store, n, sl["TILE_FRAGS"], slot, nf, torch.float16).cpu().double()
+    act = {"hid": dec(sl["HID"], sl["KS"]), "c0": dec(sl["C0"], sl["KS"]), "c1": dec(sl["C1"], sl["KS"])}
+    kmask = {k: (v > 0).double() for k, v in act.items()}
+    ref = TorchVoxLevel(sd)
+    p64 = torch.tensor(pts, dtype=torch.float64).reshape(-1, 3).requires_grad_(True)
+    v64 = torch.tensor(vd, dtype=torch.float64, requires_grad=True)
+    d64 = v64[:, None].expand(-1, S, -1).reshape(-1, 3)
+    f64 = torch.tensor(fts, dtype=torch.float64).reshape(-1, FT).requires_grad_(True)
+    keep = {}
+    with torch.no_grad():
+        rraw0, rgeo0 = ref(p64, d64, f64, want_geo=True, keep=keep)
+    # (1) forward
+    err_raw = (raw.detach().reshape(n, 4).cpu().double() - rraw0).abs().max().item()
+    assert err_raw < 5e-5, err_raw
+    # (2) stored activations: relu(pre-activation) to float16 resolution (truncated: one ulp)
+    for k in ("hid", "c0", "c1"):
+        want = keep[k].clamp(min=0)
+        got = act[k][:, :want.shape[1]]
+        scale = float(want.abs().max().item())
+        assert (got - want).abs().max().item() < 1.2e-3 * max(scale, 1.0), (k, (got - want).abs().max().item(), scale)
+    geo = dec(sl["GEO"], 2 * sl["GT"])[:, :G]
+    assert (geo - rgeo0).abs().max().item() < 1.2e-3 * max(1.0, float(rgeo0.abs().max().item()))
+    # (3) ReLU patterns
+    own = {k: (keep[k] > 0).double() for k in ("hid", "c0", "c1")}
+    flips = {k: int((own[k] != kmask[k][:, :own[k].shape[1]]).sum().item()) for k in own}
+    near = {k: float(keep[k][own[k] != kmask[k][:, :own[k].shape[1]]].abs().max().item()) if flips[k] else 0.0 for k in own}
+    total = sum(int(own[k].numel()) for k in own)
+    print(f"[{level} {prec} {R}x{S}] raw err {err_raw:.1e}; pattern flips vs float64 {flips} of {total} units, largest |pre-activation| among them {near}")
+    assert sum(flips.values()) <= max(8, total // 20000) and max(near.values()) < 2e-4
+    # (4) gradients
+    def run(masks):
+        for t in (p64, v64, f64):
+            t.grad = None
+        for prm in ref.p.values():
+            prm.grad = None
+        rraw, _ = ref(p64, d64, f64, masks=masks, want_geo=True)
+        (rraw * torch.tensor(d_raw, dtype=torch.float64).reshape(-1, 4)).sum().backward()
+        errs = {k: rel_l2(v.cpu().double(), ref.p[k.replace(".", "_")].grad) for k, v in net.unflatten(flat.grad).items()}
+        errs["fts"] = rel_l2(ft_t.grad.reshape(n, FT).cpu().double(), f64.grad)
+        errs["pts (through PE)"] = rel_l2(pts_t.grad.reshape(n, 3).cpu().double(), p64.grad)
+        errs["viewdirs (through PE)"] = rel_l2(vd_t.grad.cpu().double(), v64.grad)
+        return errs
+    same = run({k: kmask[k][:, :own[k].shape[1]] for k in own})
+    true = run(None)
+    print(f"[{level} {prec} {R}x{S}] worst gradient error vs float64 autograd: kernel's pattern {max(same.values()):.2e}, TRUE pattern {max(true.values()):.2e}")
+    assert max(same.values()) < 4e-3, {k: f"{v:.1e}" for k, v in same.items()}
+    if n >= 1000:       # (a flipped unit of a handful of samples is a visible fraction of a tiny batch's gradient)
+        assert max(true.values()) < 1e-2, {k: f"{v:.1e}" for k, v in true.items()}
+
+
+def test_f16c_training_forward_is_the_inference_arithmetic():
+    """mode='c2f': the f16c training forward renders what the f16c inference entry renders (the fine level runs the same kernel body;
+    the coarse level's training forward is the float32-grade pipeline kernel, its inference too)."""
+    from test_gpu_train import _c2f_model, _c2f_rays
+    model, sd = _c2f_model("f16c", 16)
+    pc, pf = model.trainable_parameters(sd)
+    rb = torch.tensor(_c2f_rays(200, 3), device="cuda")
+    model.train()
+    out = model.render_rays_train(rb, pc, pf, 24, 16)
+    ref = model.render_rays(rb, 24, N_importance=16, retraw=True)
+    for k in ("rgb_map", "acc_map", "rgb0", "depth_map"):
+        err = (out[k].detach() - ref[k]).abs().max().item()
+        assert err < (40 if k == "depth_map" else 1) * 5e-6 * max(1.0, ref[k].abs().max().item()), (k, err)
+
+
+def test_mixed_c2f_training_gradients_against_the_reference_golden():
+    """G19 -- torch.autograd ON THE REFERENCE's whole mode='c2f' training forward (24 rays, 768 fine samples).  f16m: rendered colours
+    within 2e-5, all 30 parameter gradients and the ray gradient within 2e-3 of the gradient norm (single-product float16: 3e-3 /
+    15 %).  f16c: colours within 1e-4; gradients within the flip bound of this tiny batch (module docstring; one flipped unit of a
+    dominant sample: measured 9e-2 on the rays, 7e-2 on one plane), the layers behind no ReLU within 2e-3."""
+    from test_gpu_train import _g19_check
+    w = _g19_check("f16m", 2e-3, 2e-3, 2e-5)
+    print("G19 f16m worst:", max(w.values()))
+    _g19_check("f16c", 0.15, 2e-3, 1e-4)
+
+
+@pytest.mark.parametrize("prec", ["f16c", "f16m"])
+def test_mixed_c2f_end_to_end_gradients(prec):
+    """The whole c2f training forward + backward against the float64 torch pipeline on the same sample positions (small grids):
+    measured 8e-4 of the norm in both modes (single-product float16: bounded at 15 %)."""
+    from test_gpu_train import _c2f_end_to_end
+    _c2f_end_to_end(prec, 24 ** 3, 48 ** 3, 1e-4, 4e-3)
+
+
+@pytest.mark.parametrize("prec", ["f16c", "f16m"])
+def test_mixed_c2f_end_to_end_gradients_at_the_blurfactory_grid_sizes(prec):
+    from test_gpu_train import _c2f_end_to_end
+    _c2f_end_to_end(prec, 16777248, 134217984, 1e-4, 4e-3)
+
+
+@pytest.mark.parametrize("prec,tol", [("f16c", 1e-2), ("f16m", 2e-3)])
+def test_mixed_c2f_gradients_on_a_65536_sample_batch(prec, tol):
+    """The G19 loss on 2048 rays x (16 + 16) samples, every gradient tensor ELEMENT-WISE against the float32-grade mode (f16x3: equal to
+    the reference's autograd to 2e-5 on G19): the flip bound at a real batch size -- f16c measured 7e-3 (rays, fine lines), f16m 7e-4;
+    the single-product float16 mode: 3e-2."""
+    from types import SimpleNamespace
+    from evdeblurnerf_amd.renderer import NeRFAll
+    from conftest import load_golden
+    g = load_golden("G19_c2f_grads")
+    gc, gf = [int(v) for v in g["grid_coarse"]], [int(v) for v in g["grid_fine"]]
+    sd = dict(W.prefixed(W.make_pdrf_state_dict(91, gc, input_ch=95, hidden_dim=64, geo_feat_dim=15, add_bias_color=True), "mlp_coarse"))
+    sd.update(W.prefixed(W.make_pdrf_state_dict(92, gf, input_ch=127, hidden_dim=256, geo_feat_dim=128, add_bias_color=True), "mlp_fine"))
+    args = SimpleNamespace(mode="c2f", multires=10, multires_views=4, use_viewdirs=True, N_importance=16, kernel_type="RBK", kernel_use_awp=False,
+                           rgb_activate="sigmoid", sigma_activate="relu", bounding_box=AABB, coarse_num_layers=2, coarse_num_layers_color=3,
+                           coarse_hidden_dim=64, coarse_hidden_dim_color=64, coarse_app_dim=32, coarse_app_n_comp=[64, 16, 16], coarse_n_voxels=24 ** 3,
+                           kernel_feat_cnl=15, fine_num_layers=2, fine_num_layers_color=3, fine_hidden_dim=256, fine_hidden_dim_color=256,
+                           fine_geo_feat_dim=128, fine_app_dim=32, fine_app_n_comp=[64, 16, 16], fine_n_voxels=48 ** 3)
+    R = 2048
+    rs = np.random.RandomState(1901)
+    w_rgb, w_rgb0 = rs.standard_normal((R, 3)).astype(np.float32), rs.standard_normal((R, 3)).astype(np.float32)
+
+    def run(p):
+        model = NeRFAll(args, sd, precision=p).enable_training(sd).train()
+        rays = torch.tensor(W.synthetic_rays(19, R), device="cuda", requires_grad=True)
+        rgb, rgb0, other, _ = model(400, 400, W.synthetic_camera(), 1 << 20, rays=rays, ndc=True, near=0., far=1., N_samples=16, N_importance=16,
+                                    perturb=0., raw_noise_std=0.)
+        ((rgb * torch.tensor(w_rgb, device="cuda")).sum() + (rgb0 * torch.tensor(w_rgb0, device="cuda")).sum() + 0.1 * other["TV"].sum()).backward()
+        out = {"rays": rays.grad.detach().clone()}
+        out.update({k: v.grad.detach().clone() for k, v in model.named_parameters()})
+        return out, rgb.detach()
+    ref, rgb_ref = run("f16x3")
+    got, rgb = run(prec)
+    assert (rgb - rgb_ref).abs().max().item() < 1e-4
+    errs = {k: rel_l2(got[k].double(), ref[k].double()) for k in ref}
+    print(f"[{prec}] 65 536 fine samples, worst element-wise gradient error vs f16x3:", {k: f"{v:.1e}" for k, v in sorted(errs.items(), key=lambda kv: -kv[1])[:5]})
+    assert max(errs.values()) < tol, errs
+
+
+@pytest.mark.parametrize("prec,tol,rgb_tol", [("f16c", 1e-2, 3e-5), ("f16m", 2e-3, 2e-5)])
+def test_mixed_nerf_training_gradients_against_the_reference_golden(prec, tol, rgb_tol):
+    """G18 (w256 part): torch.autograd ON THE REFERENCE NeRF (8 x 256) + raw2outputs vs evd_nerf_mlp_train / _backward in the mixed
+    modes + the compositing scan's backward kernel (single-product float16: 3e-3 colours, 15 % gradients; f16x3: 2e-5 / 1e-3)."""
+    from conftest import load_golden
+    from evdeblurnerf_amd.nerf import NeRF
+    from torch_restatement import grad_summary
+    g = load_golden("G18_nerf_grads")
+    sd = W.make_nerf_state_dict(19, D=8, W=256, rgb_add_bias=True)
+    net = NeRF(sd, precision="f16x3").train()
+    flat = net.flat_params(sd)
+    o = torch.tensor(g["o"], device="cuda", requires_grad=True)
+    d = torch.tensor(g["d"], device="cuda", requires_grad=True)
+    z = torch.tensor(g["z"], device="cuda")
+    R = o.shape[0]
+    vd = d / d.norm(dim=-1, keepdim=True)
+    rb = torch.cat([o, d, torch.zeros((R, 1), device="cuda"), torch.ones((R, 1), device="cuda"), vd], -1)
+    raw = net.mlp_train(flat, rb, z, precision=prec)
+    rgb_map = net.raw2outputs(raw, z, d)[0]
+    err_rgb = np.abs(rgb_map.detach().cpu().numpy() - g["rgb_map_w256"]).max()
+    (rgb_map * torch.tensor(g["w_rgb"], device="cuda")).sum().backward()
+    got = dict(net.unflatten(flat.grad))
+    got["rays_o"], got["rays_d"] = o.grad, d.grad
+    keys = [k[5:-8] for k in g if k.startswith("w256.") and k.endswith(".summary")]
+    assert set(keys) == set(got)
+    worst = {}
+    for idx, key in enumerate(keys):
+        sm, _ = grad_summary(got[key].detach().cpu().numpy(), 7000 + idx)
+        ref = g[f"w256.{key}.summary"]
+        worst[key] = max(abs(sm[0] - ref[0]), abs(sm[1] - ref[1])) / float(ref[0])
+    print(f"G18 (w256) vs the {prec} training path: rgb {err_rgb:.1e}; worst (norm / projection error) / norm:",
+          {k: f"{v:.1e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:5]})
+    assert err_rgb < rgb_tol
+    assert max(worst.values()) < tol, worst
+
+
+@pytest.mark.parametrize("prec", ["f16c", "f16m"])
+@pytest.mark.parametrize("R,S", [(64, 64), (37, 9), (1, 1)])
+def test_mixed_nerf_training_forward_and_store(prec, R, S):
+    """8 x 256 NeRF: the mixed training forwards return the raw of the inference kernel of their arithmetic bit for bit, and the store
+    they leave drives the float16 backward to the gradients of float64 autograd with the kernel's ReLU patterns (4e-3, the float16
+    backward's bound) -- ragged sizes included (padding tiles of the 256-sample store groups)."""
+    from evdeblurnerf_amd.nerf import NeRF
+    from test_gpu_train import make_inputs, decode, H0, HV
+    from torch_restatement import TorchNerf
+    sd = W.make_nerf_state_dict(21)
+    rb, z = make_inputs(R, S, 5)
+    net = NeRF(sd, precision="f16x3")
+    rbt, zt = torch.tensor(rb, device="cuda"), torch.tensor(z, device="cuda")
+    raw, store = net.mlpforward_train(rbt, zt, precision=prec)
+    inf = net.mlpforward(rbt, zt, precision="f16c" if prec == "f16c" else "f16x3")[0]
+    assert torch.equal(raw, inf)
+    import evdeblurnerf_amd._lib as L
+    assert store.numel() == int(L.lib().evd_nerf_train_store_bytes(R * S))
+    d_raw = (np.random.RandomState(9).normal(size=(R, S, 4)) * 1e-3).astype(np.float32)
+    grads = net.mlp_backward(torch.tensor(d_raw, device="cuda"), store, precision=prec)
+    n = R * S
+    masks = {f"h{l}": (decode(store, n, H0 + 16 * l, 16, torch.float16) > 0).cpu().double() for l in range(8)}
+    masks["hv"] = (decode(store, n, HV, 8, torch.float16) > 0).cpu().double()
+    pts = torch.tensor(rb[:, None, 0:3] + rb[:, None, 3:6] * z[..., None], dtype=torch.float64).reshape(-1, 3)
+    dirs = torch.tensor(np.repeat(rb[:, None, 8:11], S, 1), dtype=torch.float64).reshape(-1, 3)
+    ref = TorchNerf(sd)
+    out = ref(pts, dirs, masks=masks)
+    assert (raw.reshape(-1, 4).cpu().double() - out).abs().max().item() < 5e-5
+    (out * torch.tensor(d_raw, dtype=torch.float64).reshape(-1, 4)).sum().backward()
+    errs = {key: rel_l2(gv.cpu().double(), ref.p[key.replace(".", "_")].grad) for key, gv in grads.items()}
+    print(f"[nerf {prec} {R}x{S}] worst parameter-gradient error vs float64 autograd (kernel's patterns): {max(errs.values()):.2e}")
+    assert max(errs.values()) < 4e-3, {k: f"{v:.1e}" for k, v in errs.items()}
+
+
+@pytest.mark.parametrize("prec", ["f16c", "f16m"])
+def test_mixed_training_iteration_reduces_the_image_loss(prec):
+    """a few Adam steps through the mixed training paths (forward, float16 backward, re-pack of the streams) lower the loss"""
+    from test_gpu_train import _c2f_model, _c2f_rays
+    model, sd = _c2f_model(prec, 16)
+    model.enable_training(sd).train()
+    opt = torch.optim.Adam(list(model.parameters()), lr=1e-2)
+    rays_np = W.synthetic_rays(3, 256)
+    rays = torch.tensor(rays_np, device="cuda")
+    tgt = torch.tensor(np.random.RandomState(2).uniform(0.2, 0.8, (256, 3)).astype(np.float32), device="cuda")
+    losses = []
+    for it in range(40):
+        opt.zero_grad()
+        rgb, rgb0, other, _ = model(400, 400, W.synthetic_camera(), 1 << 20, rays=rays, ndc=True, near=0., far=1., N_samples=24, N_importance=16,
+                                    perturb=0., raw_noise_std=0.)
+        loss = ((rgb - tgt) ** 2).mean() + ((rgb0 - tgt) ** 2).mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.item()))
+    assert all(np.isfinite(losses)) and losses[-1] < 0.8 * losses[0], losses
