@@ -85,6 +85,7 @@ SIGNATURES = {
     "evd_version": (_I, []),
     "evd_compute_successor_workspace_bytes": (_S, [_L]),
     "evd_compute_successor": (_I, [_vp, _L, _L, _vp, _vp, _vp, _vp, _vp, _S, _vp]),
+    "evd_sample_events": (_I, [_vp, _L, _I, _vp, _vp, _vp, _vp, _vp, _L, _fp, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "evd_rbk_warp": (_I, [_vp, _vp, _vp, _L, _I, _I, _vp, _vp, _vp]),
     "evd_awp_feature_integration": (_I, [_vp, _vp, _vp, _L, _I, _I, _vp, _vp]),
     "evd_awp_feature_integration_bwd": (_I, [_vp, _vp, _vp, _vp, _L, _I, _I, _vp, _vp, _vp, _vp]),

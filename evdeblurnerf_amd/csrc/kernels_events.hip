@@ -47,6 +47,64 @@ __global__ void k_succ_write(const int* __restrict__ keys, const int* __restrict
     if (last) first_seen[keys[k]] = e;                                     // last event of the pixel (:114-115)
 }
 
+// EventsDataset.sample_events (data/loader_events.py:259-304) for one event id per thread: the reference's gathers, gather_successor
+// (utils/events.py:221-257), and get_rays_pix (utils/rays.py:25-36, the arithmetic of k_get_rays_pix) on the start and the end pose
+__global__ __launch_bounds__(256) void k_sample_events(const double* __restrict__ ev, long N, int ncol, const float* __restrict__ id_to_coords,
+                                                       const unsigned char* __restrict__ cmap, const float* __restrict__ poses,
+                                                       const long long* __restrict__ ids, const long long* __restrict__ hops, long n,
+                                                       float k00, float k02, float k11, float k12, float halfpix,
+                                                       float* __restrict__ rays_start, float* __restrict__ rays_end, float* __restrict__ pos_out,
+                                                       float* __restrict__ neg_out, long long* __restrict__ coords_ids, unsigned char* __restrict__ cmap_out,
+                                                       long long* __restrict__ succ_out, int* __restrict__ mismatch) {
+    const long i = blockIdx.x * 256L + threadIdx.x;
+    if (i >= n) return;
+    const long long id = ids[i];
+    const double* row = ev + id * ncol;
+    const long long pix = (long long)row[0];
+    long long end;
+    float pos = 0.f, neg = 0.f;
+    if (!hops) {                                   // loader_events.py:272-276
+        end = (long long)row[ncol - 1];
+        const double p = ev[end * ncol + ncol - 2];
+        if (p > 0) pos = (float)p; else neg = (float)p;
+    } else {                                       // gather_successor: hops + 1 steps (h <= query_hops, events.py:242-243)
+        end = id;
+        bool invalid = false;
+        const long long nh = hops[i];
+        for (long long h = 0; h <= nh; ++h) {
+            const long long nxt = (long long)ev[end * ncol + ncol - 1];
+            if (nxt < 0 || nxt >= N) { invalid = true; break; }
+            end = nxt;
+            const int p = (int)ev[end * ncol + ncol - 2];      // polarities as int32 (loader_events.py:271)
+            if (p > 0) pos += (float)p;
+            if (p < 0) neg += (float)p;
+        }
+        if (invalid) { end = -1; pos = neg = 0.f; }
+    }
+    pos_out[i] = pos;
+    neg_out[i] = neg;
+    coords_ids[i] = pix;
+    if (succ_out) succ_out[i] = end;
+    if (cmap_out) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) cmap_out[i * 3 + c] = cmap[pix * 3 + c];
+    }
+    const float cx = id_to_coords[pix * 2], cy = id_to_coords[pix * 2 + 1];
+    const float d0 = (cx + (halfpix - k02)) / k00, d1 = -(cy + (halfpix - k12)) / k11, d2 = -1.f;
+    const long long e2 = end < 0 ? id : end;       // an invalid chain: the start pose twice (the reference would index events[-1])
+    if (mismatch && end >= 0 && (long long)ev[end * ncol] != pix) atomicExch(mismatch, 1);
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        const float* c2w = poses + (which ? e2 : id) * 12;
+        float* out = (which ? rays_end : rays_start) + i * 6;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            out[r * 2] = c2w[r * 4 + 3];
+            out[r * 2 + 1] = __fadd_rn(__fadd_rn(__fmul_rn(d0, c2w[r * 4]), __fmul_rn(d1, c2w[r * 4 + 1])), __fmul_rn(d2, c2w[r * 4 + 2]));
+        }
+    }
+}
+
 }  // namespace evd
 
 using namespace evd;
@@ -91,6 +149,24 @@ int evd_compute_successor(const int* pixel_ids, long N, long HW, long long* succ
         int* t = ja; ja = jb; jb = t;
     }
     k_succ_write<<<cdiv(N, 256), 256, 0, st>>>(keys, idx, ja, N, successor, num_successors, latest_seen, first_seen);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+int evd_sample_events(const double* events, long N, int ncol, const float* id_to_coords, const unsigned char* id_to_color_map,
+                      const float* poses, const long long* events_ids, const long long* hops, long n, const float* K, int add_halfpix,
+                      float* rays_start, float* rays_end, float* pos_cumsum, float* neg_cumsum, long long* coords_ids,
+                      unsigned char* color_map, long long* successor, int* mismatch, void* stream) {
+    EVD_REQUIRE(n >= 0 && N >= 0 && ncol >= 4 && K, "evd_sample_events: bad arguments (the event table has >= 4 columns: id, .., t, p, successor)");
+    if (n == 0) return EVD_OK;
+    EVD_REQUIRE(events && id_to_coords && poses && events_ids && rays_start && rays_end && pos_cumsum && neg_cumsum && coords_ids,
+                "evd_sample_events: null argument");
+    EVD_REQUIRE(!color_map || id_to_color_map, "evd_sample_events: a colour map output needs id_to_color_map");
+    hipStream_t st = as_stream(stream);
+    if (mismatch) EVD_HIP(hipMemsetAsync(mismatch, 0, sizeof(int), st));
+    hipLaunchKernelGGL(k_sample_events, dim3((unsigned)cdiv(n, 256L)), dim3(256), 0, st, events, N, ncol, id_to_coords, id_to_color_map, poses,
+                       events_ids, hops, n, K[0], K[2], K[4], K[5], add_halfpix ? 0.5f : 0.f, rays_start, rays_end, pos_cumsum, neg_cumsum,
+                       coords_ids, color_map, successor, mismatch);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }

@@ -505,6 +505,31 @@ size_t evd_compute_successor_workspace_bytes(long N);
 int evd_compute_successor(const int* pixel_ids, long N, long HW, long long* successor, int* num_successors,
                           long long* latest_seen, long long* first_seen, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------- event batch assembly (second half)
+ * EventsDataset.sample_events, data/loader_events.py:259-304: for a batch of event ids the start / end event pair, the polarity sums
+ * between them and the two rays of each pair -- the reference gathers on the device, round-trips the timestamps through
+ * .cpu().numpy() for the pose interpolation (:280-283) and calls get_rays_pix twice (:292-295, utils/rays.py:25-36); here ONE launch on
+ * resident tables.
+ *   events        dev float64 [N, ncol], the reference's augmented table (:247): column 0 = coordinate id, ncol-3 = timestamp,
+ *                 ncol-2 = polarity, ncol-1 = successor index (compute_successor)
+ *   id_to_coords  dev float32 [Ncoords, 2] (x, y)             id_to_color_map  dev uint8 [Ncoords, 3] or NULL (colour events)
+ *   poses         dev float32 [N, 3, 4]: c2w of EVERY event at its own timestamp (the reference's interpolate_poses -- scipy Slerp +
+ *                 cubic spline on the CPU, out of scope -- evaluated once per dataset instead of once per batch; 48 bytes per event)
+ *   events_ids    dev int64 [n]          hops  dev int64 [n] or NULL
+ *   hops == NULL: the branch of every shipped config (event_accumulate_step_range [0, 0], :272-276): end = the successor,
+ *                 pos / neg = its polarity where positive / where not.
+ *   hops != NULL: gather_successor (utils/events.py:221-257): hops[i] + 1 successor steps, the polarities of the visited events summed
+ *                 by sign; a step that leaves [0, N) gives successor -1 and zero sums (:252-255).  The random hop counts of :265-268 are
+ *                 the caller's draw.
+ *   add_halfpix   the reference passes integer_coords (:292)
+ * outputs (dev): rays_start / rays_end float32 [n, 3, 2] (origin, direction in the last axis, :296-297), pos_cumsum / neg_cumsum
+ * float32 [n], coords_ids int64 [n], color_map uint8 [n, 3] (NULL with id_to_color_map NULL), successor int64 [n] or NULL (the end event),
+ * mismatch int32 [1] or NULL: set to 1 when an end event is not on its start event's coordinate id (the reference asserts, :284). */
+int evd_sample_events(const double* events, long N, int ncol, const float* id_to_coords, const unsigned char* id_to_color_map,
+                      const float* poses, const long long* events_ids, const long long* hops, long n, const float* K, int add_halfpix,
+                      float* rays_start, float* rays_end, float* pos_cumsum, float* neg_cumsum, long long* coords_ids,
+                      unsigned char* color_map, long long* successor, int* mismatch, void* stream);
+
 /* ---------------------------------------------------------------- measurement aid (no reference counterpart)
  * Sustained rate of back-to-back v_mfma_f32_32x32x16_bf16 issue on every SIMD of the current device, in dense
  * TFLOP/s, with constant (random_operands == 0) or random operands.  The chip clocks to its power budget, so the

@@ -1092,3 +1092,51 @@ void evo_compute_successor(const int* ids, long N, long HW, long long* successor
         if (first_seen[x] == -1) first_seen[x] = i;
     }
 }
+
+/* ------------------------------------------------------------------ event batch assembly
+ * data/loader_events.py:259-304 (EventsDataset.sample_events) with the per-event poses as a table: the start / end event of every id
+ * (hops == NULL: :272-276, the successor and its polarity; else gather_successor, utils/events.py:221-257: hops + 1 steps, polarity sums
+ * by sign, -1 / 0 / 0 for a chain that leaves the table), coordinates by id (:286-287), get_rays_pix on both poses (:292-297,
+ * utils/rays.py:25-36; unfused float32 like the tensor ops). */
+void evo_sample_events(const double* ev, long N, int ncol, const float* id_to_coords, const unsigned char* cmap, const float* poses,
+                       const long long* ids, const long long* hops, long n, const float* K, int add_halfpix, float* rays_start, float* rays_end,
+                       float* pos_out, float* neg_out, long long* coords_ids, unsigned char* cmap_out, long long* succ_out) {
+    const float halfpix = add_halfpix ? 0.5f : 0.f;
+    for (long i = 0; i < n; ++i) {
+        const long long id = ids[i];
+        const long long pix = (long long)ev[id * ncol];
+        long long end;
+        float pos = 0.f, neg = 0.f;
+        if (!hops) {
+            end = (long long)ev[id * ncol + ncol - 1];
+            const double p = ev[end * ncol + ncol - 2];
+            if (p > 0) pos = (float)p; else neg = (float)p;
+        } else {
+            int invalid = 0;
+            end = id;
+            for (long long h = 0; h <= hops[i]; ++h) {
+                const long long nxt = (long long)ev[end * ncol + ncol - 1];
+                if (nxt < 0 || nxt >= N) { invalid = 1; break; }
+                end = nxt;
+                const int p = (int)ev[end * ncol + ncol - 2];
+                if (p > 0) pos += (float)p;
+                if (p < 0) neg += (float)p;
+            }
+            if (invalid) { end = -1; pos = neg = 0.f; }
+        }
+        pos_out[i] = pos; neg_out[i] = neg; coords_ids[i] = pix;
+        if (succ_out) succ_out[i] = end;
+        if (cmap_out) for (int c = 0; c < 3; ++c) cmap_out[i * 3 + c] = cmap[pix * 3 + c];
+        const float cx = id_to_coords[pix * 2], cy = id_to_coords[pix * 2 + 1];
+        const float d0 = (cx + (halfpix - K[2])) / K[0], d1 = -(cy + (halfpix - K[5])) / K[4], d2 = -1.f;
+        const long long e2 = end < 0 ? id : end;
+        for (int which = 0; which < 2; ++which) {
+            const float* c2w = poses + (which ? e2 : id) * 12;
+            float* out = (which ? rays_end : rays_start) + i * 6;
+            for (int r = 0; r < 3; ++r) {
+                out[r * 2] = c2w[r * 4 + 3];
+                out[r * 2 + 1] = d0 * c2w[r * 4 + 0] + d1 * c2w[r * 4 + 1] + d2 * c2w[r * 4 + 2];
+            }
+        }
+    }
+}

@@ -342,6 +342,28 @@ def compute_successor(ids, hw):
     return succ, nsucc, latest, first
 
 
+def sample_events(events, id_to_coords, poses, events_ids, K, hops=None, id_to_color_map=None, add_halfpix=True):
+    """data/loader_events.py:259-304 on tables: events float64 [N, ncol], id_to_coords [Nc, 2], poses [N, 3, 4], ids int64 [n]
+    -> dict with the reference's keys (+ 'successor')"""
+    ev = np.ascontiguousarray(events, dtype=np.float64)
+    ids = np.ascontiguousarray(events_ids, dtype=np.int64)
+    co, po, Kf = _f(id_to_coords), _f(poses), _f(np.asarray(K).reshape(-1))
+    n, N, ncol = ids.shape[0], ev.shape[0], ev.shape[1]
+    hp = np.ascontiguousarray(hops, dtype=np.int64) if hops is not None else None
+    cm = np.ascontiguousarray(id_to_color_map, dtype=np.uint8) if id_to_color_map is not None else None
+    rs, re = np.empty((n, 3, 2), np.float32), np.empty((n, 3, 2), np.float32)
+    pos, neg = np.empty(n, np.float32), np.empty(n, np.float32)
+    cid, succ = np.empty(n, np.int64), np.empty(n, np.int64)
+    cmo = np.empty((n, 3), np.uint8) if cm is not None else None
+    lp, bp, dp = C.POINTER(C.c_longlong), C.POINTER(C.c_ubyte), C.POINTER(C.c_double)
+    lib().evo_sample_events(ev.ctypes.data_as(dp), C.c_long(N), ncol, _p(co), cm.ctypes.data_as(bp) if cm is not None else None, _p(po),
+                            ids.ctypes.data_as(lp), hp.ctypes.data_as(lp) if hp is not None else None, C.c_long(n), _p(Kf), int(add_halfpix),
+                            _p(rs), _p(re), _p(pos), _p(neg), cid.ctypes.data_as(lp), cmo.ctypes.data_as(bp) if cmo is not None else None,
+                            succ.ctypes.data_as(lp))
+    return {"events_pos_pol_cumsum": pos, "events_neg_pol_cumsum": neg, "events_rays_start": rs, "events_rays_end": re,
+            "events_coords_ids": cid, "events_color_map": cmo.astype(bool) if cmo is not None else None, "successor": succ}
+
+
 def rbk_warp(rays, r, v, num_motion, use_origin=True, want_transform=False):
     """blurmodel.py:51-82: rays [R,3,2], r/v [R, 3*M] -> new_rays [R, M(+1), 3, 2] (, transforms [R, M(+1), 4, 4])"""
     rays, r, v = _f(rays), _f(r), _f(v)

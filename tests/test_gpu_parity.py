@@ -761,6 +761,50 @@ def test_compute_successor_bit_exact(O):
     assert empty[0].shape == (0,) and (N(empty[2]) == -1).all()
 
 
+def test_sample_events_matches_golden_and_oracle(O):
+    """Event batch assembly (EventsDataset.sample_events, data/loader_events.py:259-304) in one launch on resident tables: golden G26
+    (the reference's gather_successor / get_rays_pix composed as the method composes them) -- polarity sums, ids, colour maps
+    bit-exact, rays within 1e-6; the oracle on 2 M events / a 65 536-event batch bit for bit (same unfused float32 arithmetic);
+    properties: the end event lies on the start event's coordinate, hop count = chain distance; an empty batch; the mismatch flag."""
+    from evdeblurnerf_amd.events import EventSampler, compute_successor
+    from test_oracle_golden import _check_sample_events
+    g = load_golden("G26_sample_events")
+
+    def run(tag, hops, K):
+        smp = EventSampler(g[f"{tag}_events"], g[f"{tag}_coords"], g[f"{tag}_poses"], K, id_to_color_map=g[f"{tag}_cmap"] if f"{tag}_cmap" in g else None,
+                           integer_coords=bool(g[f"{tag}_halfpix"]))
+        out = smp.sample_events(T(g[f"{tag}_ids"]), hops=T(hops) if hops is not None else None, check=True)
+        return {k: (N(v) if v is not None else None) for k, v in out.items()}
+    _check_sample_events(run, g, exact_rays=False)
+    # full size: 2 M events on a 346 x 260 sensor, batch of 65 536
+    rs = np.random.RandomState(12)
+    hw, n, nq = 346 * 260, 2_000_000, 65536
+    ids = rs.randint(0, hw, size=n).astype(np.int32)
+    succ, nsucc, _, _ = [N(v) for v in compute_successor(T(ids), hw)]
+    events = np.stack([ids.astype(np.float64), np.sort(rs.uniform(0, 1e7, n)), rs.choice([-1.0, 1.0], n), succ.astype(np.float64)], -1)
+    coords = np.stack([np.arange(hw) % 346, np.arange(hw) // 346], -1).astype(np.float32)
+    poses = rs.standard_normal((n, 3, 4)).astype(np.float32)
+    K = W.synthetic_camera()
+    smp = EventSampler(events, coords, poses, K)
+    q = np.where(nsucc > 0)[0][rs.randint(0, int((nsucc > 0).sum()), nq)]
+    hops = np.minimum(rs.randint(0, 9, nq), nsucc[q] - 1)
+    hops[:50] = nsucc[q[:50]] + 3                                      # beyond the chain: the last event is its own successor, sums keep adding it
+    for hp in (None, hops):
+        got = {k: N(v) for k, v in smp.sample_events(T(q), hops=T(hp) if hp is not None else None, check=True).items() if v is not None}
+        ref = O.sample_events(events, coords, poses, q, K, hops=hp)
+        for k in got:
+            assert np.array_equal(got[k], ref[k]), k
+    assert (ids[succ[q]] == ids[q]).all()
+    empty = smp.sample_events(torch.empty((0,), dtype=torch.int64, device=DEV))
+    assert empty["events_rays_start"].shape == (0, 3, 2)
+    bad = events.copy()
+    bad[q[0], -1] = float((q[0] + 1) % n if ids[(q[0] + 1) % n] != ids[q[0]] else (q[0] + 2) % n)      # a successor on another pixel
+    if ids[int(bad[q[0], -1])] != ids[q[0]]:
+        from evdeblurnerf_amd import _lib as L_
+        with pytest.raises(L_.EvdError):
+            EventSampler(bad, coords, poses, K).sample_events(T(q[:4]), check=True)
+
+
 def test_precision_modes_under_larger_weights():
     """What the single-product float16 mode can and cannot promise.  The hidden-layer weights of the seed-derived network are
     scaled by 1.4 (activations and raw outputs grow ~10x, densities saturate more rays): the split-float16 mode must stay

@@ -397,6 +397,34 @@ def test_G17_compute_successor():
         assert np.array_equal(latest, g[f"{tag}_latest"]) and np.array_equal(first, g[f"{tag}_first"])
 
 
+def _check_sample_events(fn, g, exact_rays):
+    """fn(tag, hops) -> dict of numpy arrays; against golden G26 (both branches of sample_events)"""
+    K = W.synthetic_camera()
+    for tag in ("a", "b"):
+        for branch, hops in (("1", None), ("2", g[f"{tag}_hops"])):
+            out = fn(tag, hops, K)
+            assert np.array_equal(out["events_pos_pol_cumsum"], g[f"{tag}_pos{branch}"]) and np.array_equal(out["events_neg_pol_cumsum"], g[f"{tag}_neg{branch}"]), (tag, branch)
+            assert np.array_equal(out["events_coords_ids"], g[f"{tag}_cid"])
+            for key, ref in (("events_rays_start", g[f"{tag}_rays_start"]), ("events_rays_end", g[f"{tag}_rays_end{branch}"])):
+                assert out[key].shape == ref.shape == (g[f"{tag}_ids"].shape[0], 3, 2)
+                if exact_rays:
+                    assert np.array_equal(out[key], ref), (tag, branch, key)
+                else:
+                    assert np.abs(out[key] - ref).max() < 1e-6, (tag, branch, key)
+            if branch == "2" and "successor" in out:
+                assert np.array_equal(out["successor"], g[f"{tag}_succ2"])
+            if f"{tag}_cmap" in g:
+                assert np.array_equal(out["events_color_map"], g[f"{tag}_cmap_out"])
+
+
+def test_G26_sample_events():
+    """data/loader_events.py:259-304 on tables: polarity sums, ids and successors bit-exact; rays to float32 rounding of a 3-term sum"""
+    g = load_golden("G26_sample_events")
+    _check_sample_events(lambda tag, hops, K: O.sample_events(g[f"{tag}_events"], g[f"{tag}_coords"], g[f"{tag}_poses"], g[f"{tag}_ids"], K, hops=hops,
+                                                             id_to_color_map=g[f"{tag}_cmap"] if f"{tag}_cmap" in g else None,
+                                                             add_halfpix=bool(g[f"{tag}_halfpix"])), g, exact_rays=False)
+
+
 # ---- gradients: the float64 torch restatements the GPU training tests compare against (tests/torch_restatement.py) are pinned
 # here to gradients computed by torch.autograd ON THE REFERENCE MODULES (tools/gen_golden.py G18, G19)
 def _check_grad(got, g, key, idx):

@@ -928,10 +928,74 @@ def G22_mam():
     save("G22_mam", **res)
 
 
+def G26_sample_events():
+    """EventsDataset.sample_events (data/loader_events.py:259-304).  The class itself cannot be imported (np.bool under numpy 2, h5py);
+    its two branches are the reference's own functions composed as the method composes them: compute_successor for the table's last
+    column (:241-247), plain indexing for the single-successor branch (:272-276), gather_successor (utils/events.py:221-257) for the
+    multi-hop branch (:262-271), get_rays_pix (utils/rays.py:25-36) on the start / end poses with add_halfpix = integer_coords
+    (:292-297).  The per-event poses stand in for interpolate_poses (scipy, CPU): random rigid poses, an INPUT of the fixture."""
+    from utils.events import compute_successor, gather_successor
+    from utils.rays import get_rays_pix
+    rs = np.random.RandomState(2601)
+    out = {}
+    K = W.synthetic_camera()
+    for tag, (N, ncoord, nq, color, halfpix) in {"a": (1500, 37 * 23, 256, False, True), "b": (400, 11, 97, True, False)}.items():
+        ids = rs.randint(0, ncoord, size=N).astype(np.int64)
+        ids[:60] = 3                                                   # a long chain at one coordinate
+        ids[-1] = ncoord - 1
+        tms = np.sort(rs.uniform(0, 1e6, N))
+        pol = rs.choice([-1.0, 1.0], N)
+        ev3 = np.stack([ids, tms, pol], -1).astype(np.float64)
+        succ, nsucc, _, _ = compute_successor(ev3, flat_xy=True)
+        events = np.concatenate([ev3, succ.reshape(-1, 1)], -1)        # loader_events.py:247
+        coords = np.stack([rs.uniform(0, 399, ncoord), rs.uniform(0, 399, ncoord)], -1).astype(np.float32)
+        if halfpix:
+            coords = np.floor(coords)
+        cmap = None
+        if color:
+            cmap = np.zeros((ncoord, 3), bool)
+            cmap[np.arange(ncoord), rs.randint(0, 3, ncoord)] = True
+        # one rigid pose per event (what interpolate_poses returns for the event's timestamp)
+        ax = rs.standard_normal((N, 3)) * 0.2
+        th = np.linalg.norm(ax, axis=-1, keepdims=True)
+        kx = ax / th
+        Km = np.zeros((N, 3, 3))
+        Km[:, 0, 1], Km[:, 0, 2], Km[:, 1, 0], Km[:, 1, 2], Km[:, 2, 0], Km[:, 2, 1] = -kx[:, 2], kx[:, 1], kx[:, 2], -kx[:, 0], -kx[:, 1], kx[:, 0]
+        Rm = np.eye(3)[None] + np.sin(th)[..., None] * Km + (1 - np.cos(th))[..., None] * (Km @ Km)
+        poses = np.concatenate([Rm, rs.uniform(-0.3, 0.3, (N, 3, 1))], -1).astype(np.float32)
+        with_succ = np.where(nsucc > 0)[0]
+        q = with_succ[rs.randint(0, with_succ.shape[0], nq)].astype(np.int64)
+        ev_t, poses_t, coords_t = torch.tensor(events), t(poses), t(coords)
+        start = ev_t[q]
+        # ---- branch 1 (:272-276)
+        end = ev_t[start[:, -1].long()]
+        pmask = end[:, -2] > 0
+        pos1 = torch.where(pmask, end[:, -2], 0)
+        neg1 = torch.where(~pmask, end[:, -2], 0)
+        cid = start[:, 0].long()
+        cc = coords_t[cid]
+
+        def rays(idx):
+            return torch.stack(get_rays_pix(cc, t(K), poses_t[idx][:, :3, :4], add_halfpix=halfpix), 1).permute(0, 2, 1)
+        out.update({f"{tag}_events": events, f"{tag}_coords": coords, f"{tag}_poses": poses, f"{tag}_ids": q, f"{tag}_halfpix": np.array(int(halfpix)),
+                    f"{tag}_pos1": n(pos1).astype(np.float32), f"{tag}_neg1": n(neg1).astype(np.float32), f"{tag}_cid": n(cid).astype(np.int64),
+                    f"{tag}_rays_start": n(rays(torch.tensor(q))), f"{tag}_rays_end1": n(rays(start[:, -1].long()))})
+        if cmap is not None:
+            out[f"{tag}_cmap"] = cmap
+            out[f"{tag}_cmap_out"] = cmap[n(cid)]
+        # ---- branch 2 (:262-271): hops in [0, num_successors - 1] (the caller's random draw), plus a few beyond the chain's end
+        hops = np.minimum(rs.randint(0, 6, nq), nsucc[q] - 1).astype(np.int64)
+        si, negp, posp = gather_successor(torch.tensor(q), torch.tensor(hops), ev_t[:, -1].long(), ev_t[:, -2].int())
+        out.update({f"{tag}_hops": hops, f"{tag}_succ2": n(si).astype(np.int64), f"{tag}_pos2": n(posp).astype(np.float32), f"{tag}_neg2": n(negp).astype(np.float32),
+                    f"{tag}_rays_end2": n(rays(si))})
+    save("G26_sample_events", **out)
+
+
 ALL = [G1_embedder, G2_nerf_mlp, G3_nerf_raw2outputs, G4_voxel_raw2outputs, G5_sample_pdf, G6_rays,
        G7_render_nerf, G8_appfeature, G9_render_c2f, G10_rbk_weighted_sum, G11_crf, G12_egm_loss, G13_edi,
        G14_loss_assembly, G15_awp_feature_integration, G16_rbk_warp, G17_compute_successor, G18_nerf_grads, G19_c2f_grads, G20_loss_grads,
-       G21_awp_sample_embed, G22_mam, G23_render_nerf_no_viewdirs, G24_render_other_multires, G25_pbe_composite_feature]
+       G21_awp_sample_embed, G22_mam, G23_render_nerf_no_viewdirs, G24_render_other_multires, G25_pbe_composite_feature,
+       G26_sample_events]
 
 if __name__ == "__main__":
     want = set(sys.argv[1:])

@@ -42,8 +42,9 @@ class Watch(TorchDispatchMode):
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--awp", default="none")
+ap.add_argument("--precision", default="f16")
 a = ap.parse_args()
-ns = SimpleNamespace(precision="f16", iters=1, pixels=1024, events=4096, P=10, awp=a.awp, mam="corr")
+ns = SimpleNamespace(precision=a.precision, iters=1, pixels=1024, events=4096, P=10, awp=a.awp, mam="corr")
 B.run(ns)
 w = Watch()
 ns.iters = 2
