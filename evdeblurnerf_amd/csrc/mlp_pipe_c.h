@@ -136,7 +136,12 @@ template <int NCH> struct CStream {
         const unsigned dst = dst0 + (unsigned)(c & (NSLOT - 1)) * CCfg::CB;
         asm volatile("s_mov_b32 m0, %0" : : "s"(dst) : "memory");
     }
-    // wait until at most `chunks` chunks (PIECES loads each) of this wavefront are outstanding
+    // wait until at most `chunks` chunks (PIECES loads each) of this wavefront are outstanding.
+    // (Round 4, built and removed: the kernel's own loads in flight across chunk ends -- a persistent kernel fetching its next tile's
+    // inputs behind the current tile's last layers.  The VM counter retires in issue order, so every wait for a DMA piece issued BEHIND such
+    // a load implies the load: a feature row from the Infinity Cache must land within the ring's AHEAD - 1 chunk times or the stall just
+    // moves into the layer (measured: prologue -3.7 k cycles, colour layer 0 +4.0 k), and hipcc drains the queue wherever it copies a
+    // destination register of a load it tracks (a deeper ring ran 6x slower for that).)
     static __device__ __forceinline__ void wait_chunks(int chunks) {
         switch (chunks) {
         case 0: wait_vmcnt<0>(); break;

@@ -61,6 +61,23 @@ __device__ __forceinline__ void c_block_from_row(const float* f, XBlk& out) {
     c_finish(out, m, r[0], r[1]);
 }
 
+// ... from the row's 32 values of this lane half already in registers (a[2 j], a[2 j + 1] = values 16 j + 8 h + 0..7)
+__device__ __forceinline__ void c_block_from_regs(const f32x4 (&a)[8], XBlk& out) {
+    f32x16 r[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int i = 8 * j + e;
+            r[i & 1][i >> 1] = e < 4 ? a[2 * j][e] : a[2 * j + 1][e - 4];
+        }
+    }
+    unsigned m = 0u;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) c_drain_pair<false>(r[0], r[1], v, out, m);
+    c_finish(out, m, r[0], r[1]);
+}
+
 template <int HD, int G, int FT, bool TRAIN>
 __global__ __launch_bounds__(CCfg::NT, 1) void k_voxel_mlp_c(const VoxMlpParams p) {
     typedef VoxNetC<HD, G, FT, TRAIN> N;
@@ -89,47 +106,73 @@ __global__ __launch_bounds__(CCfg::NT, 1) void k_voxel_mlp_c(const VoxMlpParams 
     // (TRAIN: the store is tiled in groups of 8 sample tiles and the backward walks all of them -- the padding tiles are written too)
     const long ntile = TRAIN ? (p.nsamp + 255) / 256 * (256 / CCfg::SAMPLES) : (p.nsamp + CCfg::SAMPLES - 1) / CCfg::SAMPLES;
     for (long tile = blockIdx.x;;) {
+#ifdef EVD_C_STAMP      // developer build (tools/dev/stamp_voxel_c.py): shader-clock stamps of this pass, written by lanes 0..2 in place of their samples
+    long long ts[10];
+    ts[0] = __builtin_readcyclecounter();
+    st.tw = 0; st.tb = 0;
+#define EVD_VSTAMP(i) ts[i] = __builtin_readcyclecounter()
+#else
+#define EVD_VSTAMP(i)
+#endif
     const long smp = tile * CCfg::SAMPLES + wave * 32 + n;
     const bool valid = smp < p.nsamp;
     const long sidx = valid ? smp : p.nsamp - 1;
     XBlk in0[2], pev;
     {
+        // All loads first, the 256-byte feature row (Infinity Cache / HBM: the gather kernel wrote 134 MB of them) LAST in the queue and
+        // FIRST in need of time: the two positional encodings (~500 VALU instructions on six floats) run while it is in flight, the
+        // feature block is built behind them.  (Stamps, profiles/r04_voxel_c_stamps.log: inputs + encode + the wait in front of the first
+        // chunk were 10.3 k of a pass's 42 k cycles with the feature block built first.)
         float pts[3], vd[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             pts[c] = p.pts[sidx * 3 + c];
             vd[c] = p.viewdirs[(sidx / p.S) * p.vd_stride + c];
         }
-        c_block_from_row(p.fts + sidx * (long)p.ft_stride + 8 * h, in0[0]);
+        const float* f = p.fts + sidx * (long)p.ft_stride + 8 * h;
+        f32x4 fr[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            fr[2 * j] = *reinterpret_cast<const f32x4*>(f + 16 * j);
+            fr[2 * j + 1] = *reinterpret_cast<const f32x4*>(f + 16 * j + 4);
+        }
+        asm volatile("" ::: "memory");       // the loads stay in front of the encodings
         c_encode<PE_L, PE_KS>(pts, h, in0[1]);
         c_encode<PE_LV, PEV_KS>(vd, h, pev);
+        c_block_from_regs(fr, in0[0]);
     }
     CAct act{};
     if constexpr (TRAIN) {
         const long t32 = __builtin_amdgcn_readfirstlane((int)(tile * (CCfg::SAMPLES / 32) + wave));      // this wavefront's 32-sample tile (< 2^31)
         act.base = p.act + t32 * VS::TILE_BYTES;
         act.voff = lane * 16;
-    }
-    if constexpr (TRAIN) {          // the network's inputs, in the float16 mode's own fragment order (voxel_mlp_kernel.h)
+        // the network's inputs, in the float16 mode's own fragment order (voxel_mlp_kernel.h)
         c_store_input<4>(act, VS::IN0, in0[0]);
         c_store_input<PE_KS>(act, VS::IN0 + 4, in0[1]);
         c_store_input<PEV_KS>(act, VS::DIRPE, pev);
     }
-
+    EVD_VSTAMP(1);
     st.start_wait();
     CPipe pp;
     c_prime<typename N::L0>(st, pp, lbias, lane);
+    EVD_VSTAMP(2);
     XBlk hid[KB], none[1];
     c_layer<typename N::L0, typename N::Sigma, ST, 2, KB, TRAIN>(st, pp, in0, hid, nullptr, lbias, lane, act);
+    EVD_VSTAMP(3);
     float sig[4], col[4];
     c_layer<typename N::Sigma, typename N::Geo, ST, KB, 1, TRAIN>(st, pp, hid, none, sig, lbias + N::B_SIG, lane, act);
+    EVD_VSTAMP(4);
     XBlk cin[GB + 1];
     c_layer<typename N::Geo, typename N::C0, ST, KB, GB + 1, TRAIN>(st, pp, hid, cin, nullptr, lbias + N::B_GEO, lane, act);
+    EVD_VSTAMP(5);
     cin[GB] = pev;
     XBlk c0[KB], c1[KB];
     c_layer<typename N::C0, typename N::C1, ST, GB + 1, KB, TRAIN>(st, pp, cin, c0, nullptr, lbias + N::B_C0, lane, act);
+    EVD_VSTAMP(6);
     c_layer<typename N::C1, typename N::C2, ST, KB, KB, TRAIN>(st, pp, c0, c1, nullptr, lbias + N::B_C1, lane, act);
+    EVD_VSTAMP(7);
     c_layer<typename N::C2, void, ST, KB, 1, TRAIN>(st, pp, c1, none, col, lbias + N::B_C2, lane, act);
+    EVD_VSTAMP(8);
     const bool more = tile + gridDim.x < ntile;
     if (more) st.restart_issue();               // behind the barrier of the stream's last chunk: all slots are free
 
@@ -138,6 +181,13 @@ __global__ __launch_bounds__(CCfg::NT, 1) void k_voxel_mlp_c(const VoxMlpParams 
         o[0] = sig[0];
 #pragma unroll
         for (int c = 0; c < 3; ++c) o[1 + c] = 1.f / (1.f + expf(-col[c]));      // torch.sigmoid(h) voxnerf.py:252
+#ifdef EVD_C_STAMP
+        ts[9] = __builtin_readcyclecounter();
+        if (lane == 0) o = f32x4{(float)(ts[1] - ts[0]), (float)(ts[2] - ts[1]), (float)(ts[3] - ts[2]), (float)(ts[4] - ts[3])};
+        if (lane == 1) o = f32x4{(float)(ts[5] - ts[4]), (float)(ts[6] - ts[5]), (float)(ts[7] - ts[6]), (float)(ts[8] - ts[7])};
+        if (lane == 2) o = f32x4{(float)(ts[9] - ts[8]), (float)st.tw, (float)st.tb, -7.f};
+        if (lane == 3) o = f32x4{(float)(ts[0] & 0xffffff), (float)((ts[0] >> 24) & 0xffffff), (float)blockIdx.x, (float)tile};
+#endif
         *reinterpret_cast<f32x4*>(p.raw + sidx * 4) = o;
     }
     if (!more) break;
