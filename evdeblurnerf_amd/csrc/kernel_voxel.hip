@@ -9,6 +9,7 @@
 //   k_tv            TVLoss.forward over one plane/line                 (voxnerf.py:306-324)
 #include "mlp_device.h"
 #include "voxel.h"
+#include "wave_ops.h"
 
 namespace evd {
 
@@ -984,8 +985,12 @@ struct VbwTaps {
     int pad;
 };
 constexpr int VBW_LROW = 33;                    // line rows of components 1 and 2 kept in LDS ([16][33]: n_comp[1] + n_comp[2] <= 32)
-constexpr size_t VBW_SLICE = VBW_SAMPLES * 3 * sizeof(VbwTaps) + (size_t)VBW_SAMPLES * VBW_CSTR * 4 + (size_t)VBW_SAMPLES * VBW_MAXG * 3 * 4 +
-                             (size_t)VBW_SAMPLES * (VBW_LROW + 3) * 4;
+// a wavefront's slice: tap tables | d coef -> plane rows [16][CSTR] | point-gradient partial sums [16][3 quads][3] | the coefficient rows
+// pv lv [16][96] of the in-kernel basis gradient (the LINES12 form keeps its line rows [16][LROW] there and the coefficients in registers).
+// 16 KiB per wavefront: two workgroups of four per CU (2 x 78 KiB of the 160 KiB)
+constexpr int VBW_FSTR = 96;                    // coefficient row stride: the MFMA B reads (32 channels x 2 samples per step) cover the 64 banks
+constexpr size_t VBW_SLICE = VBW_SAMPLES * 3 * sizeof(VbwTaps) + (size_t)VBW_SAMPLES * VBW_CSTR * 4 + (size_t)VBW_SAMPLES * 9 * 4 + (size_t)VBW_SAMPLES * VBW_FSTR * 4;
+static_assert((size_t)VBW_SAMPLES * VBW_LROW * 4 <= (size_t)VBW_SAMPLES * VBW_FSTR * 4 && VBW_MAXG * 8 <= VBW_FSTR, "line rows alias the coefficient rows");
 constexpr size_t VBW_LDS = (size_t)32 * VBW_BSTR * 4 + VBW_WAVES * VBW_SLICE;
 static_assert(sizeof(VbwTaps) % 8 == 0 && VBW_SLICE % 16 == 0, "slice alignment");
 
@@ -1030,7 +1035,13 @@ __device__ __forceinline__ void vbw_geometry(const GridParams& g, const float (&
 
 // LINES12: the line taps of components 1 and 2 (the x / y lines of an NDC scene: one cell for a whole run of samples) are summed along
 // runs and added here, like the plane taps; only component 0's line (the z line, a new cell every sample) leaves as rows for k_scatter_lines
-template <bool DPTS, bool LINES12>
+// BAS (round 4): the basis_mat gradient d out^T . coef INSIDE this kernel.  The workgroups are persistent (a wavefront walks tiles
+// blockIdx.x, blockIdx.x + gridDim.x, ...: basis_mat is staged in LDS once per workgroup instead of once per 64 samples), a wavefront keeps
+// the 8 coefficients of each of its three gather items in registers over the plane-tap phase, puts them where the plane rows were
+// (its slice's d coef array is free by then) and adds its 16 samples' [F x ctot] product to 3 x 16 accumulator registers on
+// v_mfma_f32_32x32x2_f32 (d out rows as the A operand straight from L2); one fold through LDS + one atomic flush per workgroup at the end.
+// Gone: the coefficient rows [n, ctot] (201 MB written and read back per 2^19 samples) and the k_basis_grad launch.
+template <bool DPTS, bool LINES12, bool BAS>
 __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const GridParams g, const float* __restrict__ pts, long n,
                                                                           const float* __restrict__ d_out, int d_stride, int d_col, GridGrads gg,
                                                                           float* __restrict__ d_pts, float* __restrict__ rows_l, LTap* __restrict__ ltap,
@@ -1042,15 +1053,29 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
     char* slice = vbw_smem + (size_t)32 * VBW_BSTR * 4 + (size_t)wv * VBW_SLICE;
     VbwTaps* taps = reinterpret_cast<VbwTaps*>(slice);
     float* dco = reinterpret_cast<float*>(slice + VBW_SAMPLES * 3 * sizeof(VbwTaps));   // d coef [16][VBW_CSTR], later the plane rows d coef lv
-    float* dpart = dco + VBW_SAMPLES * VBW_CSTR;                                     // [16][ng][3]
-    float* lrow = dpart + VBW_SAMPLES * VBW_MAXG * 3;                                // [16][VBW_LROW] line rows d coef pv of components 1, 2
-    const long s0 = ((long)blockIdx.x * VBW_WAVES + wv) * VBW_SAMPLES;
+    float* dpart = dco + VBW_SAMPLES * VBW_CSTR;                                     // [16][3 quads of 8-channel groups][3 axes] d pts partial sums
+    float* cfl = dpart + VBW_SAMPLES * 9;                                            // [16][VBW_FSTR] coefficients pv lv (BAS)
+    float* lrow = cfl;                                                               // [16][VBW_LROW] line rows d coef pv of components 1, 2 (LINES12)
+    constexpr bool CF_LDS = BAS && !LINES12;
     const int ng = ctot / 8;
     for (int o = threadIdx.x; o < 32 * (ctot / 4); o += 64 * VBW_WAVES) {            // basis_mat -> LDS (the block's only shared state)
         const int f = o / (ctot / 4), c4 = (o % (ctot / 4)) * 4;
         const f32x4 v = f < F ? *reinterpret_cast<const f32x4*>(g.basis + (long)f * ctot + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<f32x4*>(bs + f * VBW_BSTR + c4) = v;
     }
+    __syncthreads();                              // the only block-wide barrier in front of the tiles: basis_mat visible
+    auto wave_sync = []() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    constexpr int NCT = 3;                        // 32-channel tiles of the basis gradient (ctot <= 96)
+    f32x16 bacc[NCT];
+    if (BAS) {
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bacc[c][r] = 0.f;
+    }
+    const long wtiles = (n + VBW_SAMPLES - 1) / VBW_SAMPLES;
+    for (long wt = (long)blockIdx.x * VBW_WAVES + wv; wt < wtiles; wt += (long)gridDim.x * VBW_WAVES) {
+    const long s0 = wt * VBW_SAMPLES;
     // d out as the MFMA B operand: lane (col = sample, kh) holds d out[sample][4 step + kh]
     const int col = lane & 15, kh = lane >> 4;
     float dv[8];
@@ -1060,7 +1085,7 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
 #pragma unroll
         for (int st = 0; st < 8; ++st) dv[st] = (s < n && 4 * st + kh < F) ? r[4 * st + kh] : 0.f;
     }
-    if (s0 < n && lane < VBW_SAMPLES * 3) {       // phase 0: geometry of this wavefront's (sample, component) pairs
+    if (lane < VBW_SAMPLES * 3) {                 // phase 0: geometry of this wavefront's (sample, component) pairs
         const int sl = lane / 3, i = lane % 3;
         const bool live = s0 + sl < n;
         const long s = live ? s0 + sl : n - 1;
@@ -1075,9 +1100,7 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
             ltap[s * 3 + i] = lt_;
         }
     }
-    __syncthreads();                              // the only block-wide barrier: basis_mat visible (also orders the tap tables)
-    if (s0 >= n) return;
-    auto wave_sync = []() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    wave_sync();                                  // the tap tables are the wavefront's own
     // phase 1: D[channel 16 ct + 4 kh + r][sample col] = sum_f basis[f][channel] d out[sample][f]
     for (int ct = 0; ct < ctot / 16; ++ct) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -1090,8 +1113,14 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
     wave_sync();
     // phase 2: gather, 3 items per lane in flight
     const int items = VBW_SAMPLES * ng;
-    constexpr int UNR = 3;
-    for (int base = lane; base < items; base += UNR * 64) {
+    // items in flight per lane and trip: three (144 registers of raw taps) -- two where the wavefront also carries the basis accumulators
+    // (48 registers) AND the point gradient's operands: at three that form spills 27 registers into the tile loop
+    constexpr int UNR = (BAS && DPTS) ? 2 : 3, TRIPS = 3 / UNR + (3 % UNR ? 1 : 0);
+    f32x4 cfk[TRIPS * UNR][2];                    // BAS: the coefficients of this lane's items (ng <= 12: items <= 3 x 64)
+#pragma unroll
+    for (int trip = 0; trip < TRIPS; ++trip) {
+        const int base = lane + trip * UNR * 64;
+        if (base >= items) break;
         f32x4 rawp[UNR][4][2], rawl[UNR][2][2];
         int sl[UNR], grp[UNR], comp[UNR];
         bool on[UNR];
@@ -1151,7 +1180,13 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
                 } else if (live && rows_l) {
                     *reinterpret_cast<f32x4*>(rows_l + (s0 + sl[q]) * ctot + cb + 4 * v) = rl;
                 }
-                if (live && coef_out) *reinterpret_cast<f32x4*>(coef_out + (s0 + sl[q]) * ctot + cb + 4 * v) = cf;
+                if (CF_LDS) {
+                    if (on[q]) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) cfl[sl[q] * VBW_FSTR + cb + 4 * v + k] = cf[k];
+                    }
+                } else if (BAS) cfk[trip * UNR + q][v] = cf;
+                else if (live && coef_out) *reinterpret_cast<f32x4*>(coef_out + (s0 + sl[q]) * ctot + cb + 4 * v) = cf;
                 if (on[q]) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) drow[4 * v + k] = rp[k];
@@ -1171,9 +1206,19 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
                     }
                 }
             }
-            if (DPTS && on[q]) {
-                float* dp = dpart + (sl[q] * ng + grp[q]) * 3;
-                dp[0] = gx * tp.kx; dp[1] = gy * tp.ky; dp[2] = gl * tp.kl;
+            if (DPTS) {
+                // component i feeds the axes (ax, ay | al) = (0, 1 | 2), (0, 2 | 1), (1, 2 | 0): into axis space, then summed over the quad
+                // (four consecutive 8-channel groups of one sample: ng = 12 groups are three whole quads, items and lanes are quad-aligned)
+                // in registers -- a quarter of the partial sums go through LDS
+                const int i = comp[q];
+                const float a0 = on[q] ? gx * tp.kx : 0.f, a1 = on[q] ? gy * tp.ky : 0.f, a2 = on[q] ? gl * tp.kl : 0.f;
+                float vx = i == 2 ? a2 : a0, vy = i == 0 ? a1 : (i == 1 ? a2 : a0), vz = i == 0 ? a2 : a1;
+                vx += dpp_f32<0xb1>(0.f, vx); vy += dpp_f32<0xb1>(0.f, vy); vz += dpp_f32<0xb1>(0.f, vz);
+                vx += dpp_f32<0x4e>(0.f, vx); vy += dpp_f32<0x4e>(0.f, vy); vz += dpp_f32<0x4e>(0.f, vz);
+                if (on[q] && (lane & 3) == 0) {
+                    float* dp = dpart + (sl[q] * 3 + (grp[q] >> 2)) * 3;
+                    dp[0] = vx; dp[1] = vy; dp[2] = vz;
+                }
             }
         }
     }
@@ -1235,17 +1280,67 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
             }
         }
     }
-    // phase 4: the point gradient of (sample, axis): component i feeds the axes (ax, ay | al) = (0, 1 | 2), (0, 2 | 1), (1, 2 | 0)
+    // phase 4: the point gradient of (sample, axis): the three quads' partial sums
     if (DPTS && lane < VBW_SAMPLES * 3) {
         const int sl = lane / 3, a = lane % 3;
         float sum = 0.f;
-        for (int gq = 0; gq < ng; ++gq) {
-            const int c8 = gq * 8, i = c8 < c0n ? 0 : (c8 < c0n + c1n ? 1 : 2);
-            const int ax = sel3(i, 0, 0, 1), ay = sel3(i, 1, 2, 2), al = sel3(i, 2, 1, 0);
-            const float* dp = dpart + (sl * ng + gq) * 3;
-            sum += (ax == a ? dp[0] : 0.f) + (ay == a ? dp[1] : 0.f) + (al == a ? dp[2] : 0.f);
-        }
+        for (int qd = 0; qd < (ng + 3) / 4; ++qd) sum += dpart[(sl * 3 + qd) * 3 + a];
         if (s0 + sl < n) d_pts[(s0 + sl) * 3 + a] = sum;
+    }
+    if (BAS) {
+        // phase 5: d basis_mat += d out^T . coef over the tile's 16 samples (coefficient rows: written to the slice by phase 2; the
+        // LINES12 form kept them in registers and puts them where the consumed plane rows were)
+        const float* crows = CF_LDS ? cfl : dco;
+        if (!CF_LDS) {
+            wave_sync();
+#pragma unroll
+            for (int q = 0; q < TRIPS * UNR; ++q) {
+                const int t = lane + q * 64;
+                if (t < items) {
+                    float* crow = dco + (t / ng) * VBW_CSTR + (t % ng) * 8;
+#pragma unroll
+                    for (int v = 0; v < 2; ++v)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) crow[4 * v + k] = cfk[q][v][k];
+                }
+            }
+            wave_sync();
+        }
+        const int mn = lane & 31, kb = lane >> 5;
+#pragma unroll
+        for (int u = 0; u < VBW_SAMPLES / 2; ++u) {
+            const long s = s0 + 2 * u + kb;
+            const float av = (s < n && mn < F) ? d_out[s * (long)d_stride + d_col + mn] : 0.f;
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                const float bv = 32 * c + mn < ctot ? crows[(2 * u + kb) * (CF_LDS ? VBW_FSTR : VBW_CSTR) + 32 * c + mn] : 0.f;
+                bacc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, bacc[c], 0, 0, 0);
+            }
+        }
+    }
+    wave_sync();                                  // the slice is rewritten by the next tile
+    }
+    if (BAS && gg.basis) {
+        // the block's four wavefronts fold their sums through LDS (the basis_mat image is no longer needed), then ONE atomic flush per block
+        const int mn = lane & 31, kb = lane >> 5;
+        __syncthreads();
+        for (int w = 0; w < VBW_WAVES; ++w) {
+            if (wv == w) {
+#pragma unroll
+                for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int f = (r & 3) + 8 * (r >> 2) + 4 * kb, ch = 32 * c + mn;
+                        if (ch < ctot) bs[f * VBW_BSTR + ch] = w == 0 ? bacc[c][r] : bs[f * VBW_BSTR + ch] + bacc[c][r];
+                    }
+            }
+            __syncthreads();
+        }
+        for (int o = threadIdx.x; o < F * ctot; o += 64 * VBW_WAVES) {
+            const int f = o / ctot, ch = o % ctot;
+            const float v = bs[f * VBW_BSTR + ch];
+            if (v != 0.f) unsafeAtomicAdd(gg.basis + o, v);
+        }
     }
 }
 
@@ -1617,7 +1712,8 @@ bool voxel_sample_bwd_w_ok(const GridParams& g) {
     auto okc = [](int c) { return c == 8 || c == 16 || c == 32 || c == 64; };
     const long pmax = (long)g.grid[0] * g.grid[1] > (long)g.grid[0] * g.grid[2] ? (long)g.grid[0] * g.grid[1] : (long)g.grid[0] * g.grid[2];
     const long pm2 = (long)g.grid[1] * g.grid[2] > pmax ? (long)g.grid[1] * g.grid[2] : pmax;
-    return g.app_dim >= 4 && g.app_dim <= 32 && g.app_dim % 4 == 0 && ct % 16 == 0 && ct <= 96 && okc(g.n_comp[0]) && okc(g.n_comp[1]) && okc(g.n_comp[2]) &&
+    // (ct % 32: a sample's 8-channel groups are whole quads of lanes -- the point gradient's quad sums; other widths take the block-cooperative kernel)
+    return g.app_dim >= 4 && g.app_dim <= 32 && g.app_dim % 4 == 0 && ct % 32 == 0 && ct <= 96 && okc(g.n_comp[0]) && okc(g.n_comp[1]) && okc(g.n_comp[2]) &&
            pm2 * 64 < (1L << 31) && g.app_act == EVD_ACT_NONE;
 }
 // OPT-IN (EVD_SCATTER_LINES_INKERNEL=1): the line taps of components 1 and 2 added inside the kernel (run-length walk) when their channels
@@ -1630,21 +1726,33 @@ bool voxel_sample_bwd_w_lines12(const GridParams& g) {
 }
 int launch_voxel_sample_bwd_w(const GridParams& g, const float* pts, long n, const float* d_out, int d_stride, int d_col, const GridGrads& gg,
                               float* d_pts, float* rows_l, LTap* ltap, float* coef, hipStream_t st) {
-    const unsigned blocks = (unsigned)cdiv(n, (long)VBW_SAMPLES * VBW_WAVES);
-    float* coef_w = gg.basis ? coef : nullptr;
+    // EVD_SCATTER_BASIS=separate (developer switch): round 3's form -- coefficient rows to HBM + the k_basis_grad launch
+    static const bool bas_sep = [] { const char* e = getenv("EVD_SCATTER_BASIS"); return e && !strcmp(e, "separate"); }();
+    const bool bas = gg.basis && !bas_sep;
+    int cus = 256;
+    { int dev = 0, v = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
+    const long tiles = cdiv(n, (long)VBW_SAMPLES * VBW_WAVES);
+    // persistent workgroups with the basis gradient in registers: two per CU (the LDS slices allow no more); else one tile per wavefront
+    const unsigned blocks = (unsigned)(bas ? (tiles < 2L * cus ? tiles : 2L * cus) : tiles);
+    float* coef_w = (gg.basis && !bas) ? coef : nullptr;
     const bool l12 = voxel_sample_bwd_w_lines12(g);
-#define EVD_VBW(DP, L12) { EVD_SET_MAX_LDS((&k_voxel_sample_bwd_w<DP, L12>), VBW_LDS); \
-        k_voxel_sample_bwd_w<DP, L12><<<blocks, 64 * VBW_WAVES, VBW_LDS, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, rows_l, ltap, coef_w); }
-    if (d_pts && l12) EVD_VBW(true, true)
-    else if (d_pts) EVD_VBW(true, false)
-    else if (l12) EVD_VBW(false, true)
-    else EVD_VBW(false, false)
+#define EVD_VBW(DP, L12, BAS) { EVD_SET_MAX_LDS((&k_voxel_sample_bwd_w<DP, L12, BAS>), VBW_LDS); \
+        k_voxel_sample_bwd_w<DP, L12, BAS><<<blocks, 64 * VBW_WAVES, VBW_LDS, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, rows_l, ltap, coef_w); }
+    if (bas) {
+        if (d_pts && l12) EVD_VBW(true, true, true)
+        else if (d_pts) EVD_VBW(true, false, true)
+        else if (l12) EVD_VBW(false, true, true)
+        else EVD_VBW(false, false, true)
+    } else {
+        if (d_pts && l12) EVD_VBW(true, true, false)
+        else if (d_pts) EVD_VBW(true, false, false)
+        else if (l12) EVD_VBW(false, true, false)
+        else EVD_VBW(false, false, false)
+    }
 #undef EVD_VBW
     EVD_LAUNCH_CHECK();
-    if (gg.basis) {
+    if (gg.basis && !bas) {
         const int ct = g.n_comp[0] + g.n_comp[1] + g.n_comp[2];
-        int cus = 256;
-        { int dev = 0, v = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
         const unsigned gb = (unsigned)(cdiv(n, 64L) < 8L * cus ? cdiv(n, 64L) : 8L * cus);     // 8 blocks of 4 wavefronts per CU: every wavefront slot
         if (ct <= 32) k_basis_grad<1><<<gb, 256, 0, st>>>(d_out, d_stride, d_col, coef, n, ct, g.app_dim, gg.basis);
         else if (ct <= 64) k_basis_grad<2><<<gb, 256, 0, st>>>(d_out, d_stride, d_col, coef, n, ct, g.app_dim, gg.basis);
