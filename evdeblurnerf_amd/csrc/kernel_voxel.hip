@@ -1073,9 +1073,18 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
 #pragma unroll
             for (int r = 0; r < 16; ++r) bacc[c][r] = 0.f;
     }
+#ifdef EVD_VBW_STAMP    // developer build (tools/dev/stamp_scatter_w.py): shader-clock cycles of this wavefront's phases, summed over its tiles
+    long long tph[7] = {0, 0, 0, 0, 0, 0, 0}, tq0, tq1;
+#define EVD_VBW_T0() tq0 = __builtin_readcyclecounter()
+#define EVD_VBW_T(i) { tq1 = __builtin_readcyclecounter(); tph[i] += tq1 - tq0; tq0 = tq1; }
+#else
+#define EVD_VBW_T0()
+#define EVD_VBW_T(i)
+#endif
     const long wtiles = (n + VBW_SAMPLES - 1) / VBW_SAMPLES;
     for (long wt = (long)blockIdx.x * VBW_WAVES + wv; wt < wtiles; wt += (long)gridDim.x * VBW_WAVES) {
     const long s0 = wt * VBW_SAMPLES;
+    EVD_VBW_T0();
     // d out as the MFMA B operand: lane (col = sample, kh) holds d out[sample][4 step + kh]
     const int col = lane & 15, kh = lane >> 4;
     float dv[8];
@@ -1101,6 +1110,7 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
         }
     }
     wave_sync();                                  // the tap tables are the wavefront's own
+    EVD_VBW_T(0);
     // phase 1: D[channel 16 ct + 4 kh + r][sample col] = sum_f basis[f][channel] d out[sample][f]
     for (int ct = 0; ct < ctot / 16; ++ct) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -1111,6 +1121,7 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
         for (int r = 0; r < 4; ++r) dco[col * VBW_CSTR + 16 * ct + 4 * kh + r] = acc[r];
     }
     wave_sync();
+    EVD_VBW_T(1);
     // phase 2: gather, 3 items per lane in flight
     const int items = VBW_SAMPLES * ng;
     // items in flight per lane and trip: three (144 registers of raw taps) -- two where the wavefront also carries the basis accumulators
@@ -1223,6 +1234,24 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
         }
     }
     wave_sync();
+    EVD_VBW_T(2);
+    // the A operand of the basis gradient's MFMAs (d out[sample 2 u + kb][f = lane & 31]) is fetched HERE, in front of the plane taps'
+    // atomics: the VM counter retires in order, a load issued behind them waits for every one of them (stamps: the 24 MFMAs of phase 5 took
+    // 14 k cycles with their eight loads issued one by one behind the atomics, a fifth of the tile)
+    float bav[VBW_SAMPLES / 2];
+    if (BAS) {
+        const int mn = lane & 31, kb = lane >> 5;
+#pragma unroll
+        for (int u = 0; u < VBW_SAMPLES / 2; ++u) {
+            const long sa = s0 + 2 * u + kb;
+            bav[u] = (sa < n && mn < F) ? d_out[sa * (long)d_stride + d_col + mn] : 0.f;
+        }
+        // ... and waited for here (an L2 hit: the rows were read for phase 1): hipcc cannot count the atomics of the loops below, at the
+        // MFMAs it would wait for vmcnt(0).  (Also tried: the NEXT tile's d out / point loads issued here as well -- 0.556 ms either way:
+        // the kernel runs at the rate its atomics retire, a wait moved is not a wait removed.)
+#pragma unroll
+        for (int u = 0; u < VBW_SAMPLES / 2; ++u) asm volatile("" : "+v"(bav[u]));
+    }
     // phase 3: plane taps.  dco now holds the plane rows d coef lv.
     int coff = 0;
 #pragma unroll 1
@@ -1280,6 +1309,7 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
             }
         }
     }
+    EVD_VBW_T(3);
     // phase 4: the point gradient of (sample, axis): the three quads' partial sums
     if (DPTS && lane < VBW_SAMPLES * 3) {
         const int sl = lane / 3, a = lane % 3;
@@ -1287,6 +1317,7 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
         for (int qd = 0; qd < (ng + 3) / 4; ++qd) sum += dpart[(sl * 3 + qd) * 3 + a];
         if (s0 + sl < n) d_pts[(s0 + sl) * 3 + a] = sum;
     }
+    EVD_VBW_T(4);
     if (BAS) {
         // phase 5: d basis_mat += d out^T . coef over the tile's 16 samples (coefficient rows: written to the slice by phase 2; the
         // LINES12 form kept them in registers and puts them where the consumed plane rows were)
@@ -1309,8 +1340,7 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
         const int mn = lane & 31, kb = lane >> 5;
 #pragma unroll
         for (int u = 0; u < VBW_SAMPLES / 2; ++u) {
-            const long s = s0 + 2 * u + kb;
-            const float av = (s < n && mn < F) ? d_out[s * (long)d_stride + d_col + mn] : 0.f;
+            const float av = bav[u];
 #pragma unroll
             for (int c = 0; c < NCT; ++c) {
                 const float bv = 32 * c + mn < ctot ? crows[(2 * u + kb) * (CF_LDS ? VBW_FSTR : VBW_CSTR) + 32 * c + mn] : 0.f;
@@ -1319,7 +1349,15 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
         }
     }
     wave_sync();                                  // the slice is rewritten by the next tile
+    EVD_VBW_T(5);
     }
+#ifdef EVD_VBW_STAMP
+    if (lane == 0 && rows_l) {
+        float* o = rows_l + ((long)blockIdx.x * VBW_WAVES + wv) * 8;
+        for (int i = 0; i < 6; ++i) o[i] = (float)tph[i];
+        o[6] = -7.f; o[7] = (float)((wtiles - ((long)blockIdx.x * VBW_WAVES + wv) + (long)gridDim.x * VBW_WAVES - 1) / ((long)gridDim.x * VBW_WAVES));
+    }
+#endif
     if (BAS && gg.basis) {
         // the block's four wavefronts fold their sums through LDS (the basis_mat image is no longer needed), then ONE atomic flush per block
         const int mn = lane & 31, kb = lane >> 5;

@@ -1,0 +1,42 @@
+"""Developer probe: where does a tile of the persistent tri-plane scatter kernel (k_voxel_sample_bwd_w, basis gradient inside) spend its
+cycles?  Needs kernel_voxel.hip built with -DEVD_VBW_STAMP (lane 0 of every wavefront writes its per-phase cycle sums over the head of the
+line rows; the line gradients of such a build are garbage).  EVD_LIB_PATH=.../libevd_vbwstamp.so python tools/dev/stamp_scatter_w.py"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+import numpy as np, torch
+from evdeblurnerf_amd import _lib as L, weights as W
+from evdeblurnerf_amd.voxnerf import VoxelNeRFSampleFeatures, _grid_grads
+
+AABB = ([-1.5, -1.5, -1.0], [1.5, 1.5, 1.0])
+voxels = 134217984
+g = W.pdrf_grid_size(AABB[0], AABB[1], voxels)
+sd = W.make_pdrf_state_dict(32, g, input_ch=127, hidden_dim=256, geo_feat_dim=128)
+net = VoxelNeRFSampleFeatures(sd, "", AABB, num_layers=2, hidden_dim=256, geo_feat_dim=128, num_layers_color=3, input_ch=127, app_dim=32, app_n_comp=(64, 16, 16), n_voxels=voxels)
+R, S = 4096, 128
+rs = np.random.RandomState(0)
+grads, gs = _grid_grads(net, net.grid_params())
+names = ["d out, points, tap tables", "d coef MFMA (48 x 16x16x4)", "gather + pv / lv / rows / d pts partials", "plane taps (run-length walk, atomics)", "point gradient",
+         "basis gradient MFMA + slice hand-over"]
+for slope in (0.05, 0.35):
+    for dpts in (False, True):
+        o = rs.uniform(-0.3, 0.3, (R, 1, 3)) + np.array([0, 0, 0.9])
+        d = rs.normal(size=(R, 1, 3)) * slope * np.array([1.0, 1.0, 0.0]) + np.array([0, 0, -1.0])
+        z = np.sort(rs.uniform(0.1, 1.7, (R, S, 1)), 1)
+        pts = torch.as_tensor((o + d * z).astype(np.float32), device="cuda").reshape(-1, 3).contiguous()
+        n = pts.shape[0]
+        d_out = torch.randn((n, 32), device="cuda")
+        d_pts = torch.empty((n, 3), device="cuda") if dpts else None
+        nb = int(L.lib().evd_voxel_sample_bwd_workspace_bytes(net._h, n))
+        ws = torch.empty((nb + 256,), dtype=torch.uint8, device="cuda")
+        for _ in range(3):
+            L.check(L.lib().evd_voxel_sample_bwd_ws(net._h, L.ptr(pts), n, L.ptr(d_out), 32, 0, C.byref(gs), L.ptr(d_pts), L.ptr(ws), nb, L.stream_ptr()), "bwd_ws")
+        torch.cuda.synchronize()
+        off = (-ws.data_ptr()) % 256
+        t = ws[off:off + 2048 * 32].view(torch.float32).reshape(2048, 8).cpu().numpy().astype(np.float64)
+        t = t[t[:, 6] == -7]
+        assert len(t), "library was not built with -DEVD_VBW_STAMP"
+        tiles = t[:, 7].mean()
+        tot = t[:, :6].sum(1)
+        print(f"slope {slope}, d pts {dpts}: {len(t)} wavefronts x {tiles:.1f} tiles; cycles per tile {tot.mean() / tiles:.0f}")
+        for k in range(6):
+            print(f"    {names[k]:48s} {t[:, k].mean() / tiles:8.0f} cycles  {100 * t[:, k].mean() / tot.mean():5.1f} %")
