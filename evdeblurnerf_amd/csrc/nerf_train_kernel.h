@@ -333,6 +333,177 @@ __global__ __launch_bounds__(WGRAD_NT) void k_wgrad(const WgradParams p) {
     if (bias_own) put(CT, accb);
 }
 
+// ------------------------------------------------------------------------------------------------
+// wgrad(l) WITH dgrad(l) (round 4; asked for since round 1).  Both read the layer's gradient fragments G = d loss / d pre-activation
+// [OUT = 256 channels x 32 samples] of every tile: k_wgrad to add G X^T to dW, k_dgrad_layer to form d X = W^T G.  Here the wgrad
+// workgroup (8 wavefronts, wavefront w = row tile w of dW, RT = 8) also produces d X: after the tile's barrier all 16 gradient
+// fragments lie in the LDS-DMA ring in exactly the form the matrix core takes as its B operand; wavefront w (< TO) multiplies them by
+// the 16 A fragments of rows 32 w .. 32 w + 31 of W^T, which it keeps IN REGISTERS for its whole life (64 registers: no weight traffic
+// at all), applies the ReLU bit mask of the layer below and stores its two fragments of d X.  Per tile the pair moved 65 KiB
+// (dgrad: G in, mask, d X out; wgrad: G, X in); fused it is 49 KiB.  A second barrier per tile orders the ring: the DMA issued at the
+// top of iteration i overwrites the slot every wavefront read G from in iteration i - 1.
+struct WgradFusedParams {
+    WgradParams w;
+    const char* wt;         // W^T fragment stream of the layer (tile-major, 16 k-steps per tile: pack.h layer_transposed)
+    char* out_store;        // the store again, writable
+    int mask_slot, out_slot;
+};
+
+constexpr int FUSED_WL = 6;        // W^T fragments per wavefront kept in LDS instead of registers (k_wgrad_dgrad)
+
+template <int PREC, int CT, int TO, int OMASK>
+__global__ __launch_bounds__(WGRAD_NT) void k_wgrad_dgrad(const WgradFusedParams fp) {
+    static_assert(is_half_prec(PREC) && CT <= 8 && TO <= 8 && (OMASK == 0 || TO <= CT), "half-precision fragments, 8 x 32 gradient rows; a masked d X tile is a column tile of X");
+    constexpr int RT = 8, CPG = wgrad_cpg(RT, CT), KD = 16, WL = FUSED_WL;
+    typedef POps<PREC> O;
+    const WgradParams& p = fp.w;
+    extern __shared__ __attribute__((aligned(16))) char wsm[];
+    char* raw = wsm;                                          // [WG_RING][8 wavefronts][4 fragments][1 KiB]
+    char* xs = wsm + WG_RING * 8 * 4 * 1024;                  // [CT][2][1 KiB] transposed activation blocks (single: two barriers per tile)
+    char* wl = xs + CT * 2048;                                // [8 wavefronts][WL][1 KiB]: the last WL of a wavefront's 16 W^T fragments
+    pipe_fp16_saturate<PREC>();
+    const int NC = CT + (p.bias ? 1 : 0);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = lane & 31, h = lane >> 5;
+    const int rt = wave, c0 = 0;
+    const bool xown = wave < CT, bias_own = p.bias != 0, down = wave < TO;
+    const unsigned one = half_one_pair<PREC>();
+    f32x16 acc[CPG], accb;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        accb[i] = 0.f;
+#pragma unroll
+        for (int c = 0; c < CPG; ++c) acc[c][i] = 0.f;
+    }
+    // rows 32 w .. of W^T: 16 A fragments, resident -- KD - WL in registers, the last WL in this wavefront's own LDS slots (the kernel
+    // needs 128 + 16 accumulators: with all 64 registers of W^T it spilled into its loop, and a scratch reload drains the VM counter)
+    W4 wt[KD - WL];
+#pragma unroll
+    for (int j = 0; j < KD; ++j) {
+        const W4 f = *reinterpret_cast<const W4*>(fp.wt + ((long)(down ? wave : 0) * KD + j) * 1024 + lane * 16);    // (wavefronts beyond TO: tile 0 again, unused)
+        if (j < KD - WL) wt[j] = f;
+        else *reinterpret_cast<W4*>(wl + (wave * WL + (j - (KD - WL))) * 1024 + lane * 16) = f;
+    }
+    // the tile's four fragments of this wavefront: y0, y1 (adjacent: one address, immediates 0 / 1024) and x0, x1 (wavefronts beyond CT:
+    // the y pair again) -- two address registers (the instruction's immediate moves the source and the LDS destination together)
+    const long oy = (long)(p.y_slot + 2 * rt) * 1024 + lane * 16;
+    const long ox = (xown ? (long)(p.x_slot + 2 * wave) * 1024 : (long)(p.y_slot + 2 * rt) * 1024) + lane * 16 - 2048;
+    const unsigned ring0 = lds_offset_of(raw) + wave * 4096;
+    auto issue = [&](long t, int stage) {
+        if (t >= p.tiles) return;
+        const char* g = p.store + t * p.tile_bytes;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(ring0 + stage * (8 * 4096));
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                     "global_load_lds_dwordx4 %2, off offset:2048\n\tglobal_load_lds_dwordx4 %2, off offset:3072\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(g + oy), "v"(g + ox), "s"(dst) : "memory");
+    };
+    const long stride = gridDim.x;
+    long t = blockIdx.x;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the weight fragments have landed: the counted waits below count the ring's DMA only
+#pragma unroll
+    for (int j = 0; j < KD - WL; ++j) asm volatile("" : "+v"(wt[j].w[0]), "+v"(wt[j].w[1]), "+v"(wt[j].w[2]), "+v"(wt[j].w[3]));
+#pragma unroll
+    for (int k = 0; k < WG_RING - 1; ++k) issue(t + k * stride, k);
+    for (int it = 0; t < p.tiles; t += stride, ++it) {
+        issue(t + (WG_RING - 1) * stride, (it + WG_RING - 1) % WG_RING);
+        const int later = (t + stride < p.tiles ? 1 : 0) + (t + 2 * stride < p.tiles ? 1 : 0);
+        if (later == 2) wait_vmcnt<8>();
+        else if (later == 1) wait_vmcnt<4>();
+        else wait_vmcnt<0>();
+        // the transposition selectors and the bias column are re-made per tile (a dozen VALU instructions) instead of living in 12 registers
+        // next to 128 + 16 accumulators and the 64 registers of W^T: the kernel spilled into its loop, and scratch loads drain the VM counter
+        W4 sel0, sel1, ones;
+        {
+            int nn = n, hh = h;
+            asm volatile("" : "+v"(nn), "+v"(hh));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int kk = 8 * hh + 2 * e;
+                sel0.w[e] = (nn == kk ? (one & 0xffffu) : 0u) | (nn == kk + 1 ? (one & 0xffff0000u) : 0u);
+                sel1.w[e] = (nn == 16 + kk ? (one & 0xffffu) : 0u) | (nn == 17 + kk ? (one & 0xffff0000u) : 0u);
+                ones.w[e] = nn == 0 ? one : 0u;
+            }
+        }
+        const char* rw = raw + ((it % WG_RING) * 8 + wave) * 4096 + lane * 16;
+        const W4 y0 = *reinterpret_cast<const W4*>(rw), y1 = *reinterpret_cast<const W4*>(rw + 1024);
+        W4 yt[2];
+        transpose_block<PREC>(y0, y1, sel0, sel1, yt);
+        char* xb = xs;
+        if (xown) {
+            const W4 x0 = *reinterpret_cast<const W4*>(rw + 2048), x1 = *reinterpret_cast<const W4*>(rw + 3072);
+            W4 xt[2];
+            transpose_block<PREC>(x0, x1, sel0, sel1, xt);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) *reinterpret_cast<W4*>(xb + (wave * 2 + q) * 1024 + lane * 16) = xt[q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CPG; ++c) {
+            if (c0 + c < CT) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const W4 xq = *reinterpret_cast<const W4*>(xb + ((c0 + c) * 2 + q) * 1024 + lane * 16);
+                    acc[c] = mfma_half<PREC>(yt[q], xq, acc[c]);
+                }
+            }
+        }
+        if (bias_own) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) accb = mfma_half<PREC>(yt[q], ones, accb);
+        }
+        // d X tile `wave` = W^T rows . G: gradient fragment j sits in wavefront j / 2's ring slot, fragment j & 1
+        if (down) {
+            f32x16 d = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const char* gb = raw + ((it % WG_RING) * 8) * 4096 + lane * 16;
+#pragma unroll
+            for (int j = 0; j < KD; ++j) {
+                const W4 gj = *reinterpret_cast<const W4*>(gb + (j >> 1) * 4096 + (j & 1) * 1024);
+                const W4 wj = j < KD - WL ? wt[j] : *reinterpret_cast<const W4*>(wl + (wave * WL + (j - (KD - WL))) * 1024 + lane * 16);
+                d = mfma_half<PREC>(wj, gj, d);
+            }
+            typename O::B o2[2];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) O::template set_pair<false>(o2[k >> 2], k & 3, d[2 * k], d[2 * k + 1]);
+            char* dst = fp.out_store + t * p.tile_bytes + (long)(fp.out_slot + 2 * wave) * 1024 + lane * 16;
+            // The ReLU pattern of the layer below = [its stored activation != 0], and the activation fragments 2 w, 2 w + 1 are the X operand
+            // this wavefront fetched for its column tile: still in its ring slot.  (The separate dgrad kernel reads the bit-mask fragment; a
+            // load of it here -- tracked by the compiler or not -- either drains the ring's prefetch or races with its own wait.)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                if (OMASK != 0) {
+                    const typename O::B xa = __builtin_bit_cast(typename O::B, *reinterpret_cast<const W4*>(rw + 2048 + f * 1024));
+                    O::mask_act(o2[f], xa);
+                }
+                *reinterpret_cast<f32x4*>(dst + f * 1024) = __builtin_bit_cast(f32x4, o2[f]);
+            }
+        }
+        __syncthreads();            // every wavefront is done with this tile's ring slots before any of them issues into the oldest one
+    }
+    float* out = p.partial + (((long)blockIdx.x * RT + rt) * NC) * 1024 + lane * 16;
+    auto put = [&](int c, const f32x16& a) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = {a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+            *reinterpret_cast<f32x4*>(out + c * 1024 + 4 * q) = v;
+        }
+    };
+#pragma unroll
+    for (int c = 0; c < CPG; ++c)
+        if (c0 + c < CT) put(c0 + c, acc[c]);
+    if (bias_own) put(CT, accb);
+}
+
+template <int PREC, int CT, int TO, int OMASK>
+static int launch_wgrad_dgrad(const WgradFusedParams& p, int blocks, hipStream_t st) {
+    const size_t lds = (size_t)WG_RING * 8 * 4 * 1024 + (size_t)CT * 2048 + (size_t)8 * FUSED_WL * 1024;
+    EVD_SET_MAX_LDS((&k_wgrad_dgrad<PREC, CT, TO, OMASK>), lds);
+    hipLaunchKernelGGL((k_wgrad_dgrad<PREC, CT, TO, OMASK>), dim3(blocks), dim3(WGRAD_NT), lds, st, p);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
 struct WreduceParams {
     const float* partial;
     int nparts, RT, NC, CT;            // NC = CT + 1 when the bias column rides along
@@ -571,6 +742,27 @@ template <int PREC> static int run_nerf_backward(const BwdPlan& b, hipStream_t s
         EVD_LAUNCH_CHECK();
         return EVD_OK;
     };
+    // wgrad(l) with dgrad(l) in one launch (k_wgrad_dgrad above): the seven 256 x 256 trunk layers in the half-precision modes;
+    // EVD_BWD_FUSE=0 keeps the separate launches (A/B)
+    static const bool fuse_on = [] { const char* e = getenv("EVD_BWD_FUSE"); return !(e && e[0] == '0'); }();
+    auto fused = [&](auto launch, int CT, bool bias, int y_slot, int x_slot, int ymap, int xmap, float* dW, int ld, float* db, int stream, int out_slot) -> int {
+        const int blocks = (int)(b.tiles < b.wgrad_blocks ? b.tiles : b.wgrad_blocks);
+        WgradFusedParams p;
+        p.w.store = b.store; p.w.tiles = b.tiles; p.w.tile_bytes = astore::tile_bytes(PREC); p.w.y_slot = y_slot; p.w.x_slot = x_slot; p.w.bias = bias ? 1 : 0; p.w.partial = b.partial;
+        p.wt = b.wt[stream]; p.out_store = b.store; p.mask_slot = -1; p.out_slot = out_slot;
+        if (b.side) {                           // wgrad launches in flight on the side stream use the partial scratch (and read what this one writes next): join
+            EVD_HIP(hipEventRecord(b.ev, b.side));
+            EVD_HIP(hipStreamWaitEvent(st, b.ev, 0));
+        }
+        int r = launch(p, blocks, st);
+        if (r) return r;
+        WreduceParams q;
+        q.partial = b.partial; q.nparts = blocks; q.RT = 8; q.CT = CT; q.NC = CT + (bias ? 1 : 0);
+        q.rowmap = b.maps + ymap; q.colmap = b.maps + xmap; q.dW = dW; q.ld = ld; q.db = bias ? db : nullptr; q.maxbits = b.maxbits; q.accum = b.accumulate;
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((long)8 * q.NC * 4)), dim3(256), 0, st, q);
+        EVD_LAUNCH_CHECK();
+        return EVD_OK;
+    };
     const BwdGrads& g = b.grads;
     // Every wgrad is issued BEFORE the dgrad layer that reads the same two arrays (incoming gradient, saved activation): the two are
     // independent, and with a side stream (b.side: developer switch EVD_BWD_OVERLAP) they run concurrently and share those reads in
@@ -589,6 +781,14 @@ template <int PREC> static int run_nerf_backward(const BwdPlan& b, hipStream_t s
     // pts_linears[l], l = 7 .. 1
     for (int l = D - 1; l >= 1; --l) {
         const bool wide = l - 1 == b.skip;
+        if constexpr (is_half_prec(PREC)) {
+            if (fuse_on && g.pts_w[l]) {
+                if (wide && (rc = wgrad(launch_wgrad<PREC, 8, 2, false>, 8, 2, false, D_H0 + 16 * l, PE, MAP_HID, MAP_PE, g.pts_w[l], 256 + 63, nullptr))) return rc;
+                if ((rc = fused(launch_wgrad_dgrad<PREC, 8, 8, 1>, 8, true, D_H0 + 16 * l, H0 + 16 * (l - 1), MAP_HID, wide ? MAP_HID_SKIP : MAP_HID, g.pts_w[l],
+                                wide ? 256 + 63 : 256, g.pts_b[l], EVD_BWD_HIDDEN1 + l - 1, D_H0 + 16 * (l - 1)))) return rc;
+                continue;
+            }
+        }
         if ((rc = wgrad(launch_wgrad<PREC, 8, 8, false>, 8, 8, true, D_H0 + 16 * l, H0 + 16 * (l - 1), MAP_HID, wide ? MAP_HID_SKIP : MAP_HID,
                         g.pts_w[l], wide ? 256 + 63 : 256, g.pts_b[l]))) return rc;
         if (wide && (rc = wgrad(launch_wgrad<PREC, 8, 2, false>, 8, 2, false, D_H0 + 16 * l, PE, MAP_HID, MAP_PE, g.pts_w[l], 256 + 63, nullptr))) return rc;

@@ -155,16 +155,57 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
         EVD_LAUNCH_CHECK();
         return EVD_OK;
     };
+    // wgrad(l) with dgrad(l) in one launch (nerf_train_kernel.h k_wgrad_dgrad): the 256-wide layers of the fine level in the
+    // half-precision modes; EVD_BWD_FUSE=0 keeps the separate launches (A/B)
+    static const bool fuse_on = [] { const char* e = getenv("EVD_BWD_FUSE"); return !(e && e[0] == '0'); }();
+    constexpr bool FUSABLE = is_half_prec(PREC) && T == 8;
+    auto fused = [&](auto launch, int CT, bool bias, int y_slot, int x_slot, int ymap, int xmap, float* dW, int ld, float* db, int stream, int mask_slot, int out_slot) -> int {
+        const int blocks = (int)(b.tiles < b.wgrad_blocks ? b.tiles : b.wgrad_blocks);
+        WgradFusedParams p;
+        p.w.store = b.store; p.w.tiles = b.tiles; p.w.tile_bytes = VS::tile_bytes(PREC); p.w.y_slot = y_slot; p.w.x_slot = x_slot; p.w.bias = bias ? 1 : 0; p.w.partial = b.partial;
+        p.wt = b.wt[stream]; p.out_store = b.store; p.mask_slot = mask_slot; p.out_slot = out_slot;
+        if (b.side) {                           // the wgrad launches in flight on the side stream use the partial scratch: join first
+            EVD_HIP(hipEventRecord(b.ev, b.side));
+            EVD_HIP(hipStreamWaitEvent(st, b.ev, 0));
+        }
+        int r = launch(p, blocks, st);
+        if (r) return r;
+        if (!dW) return EVD_OK;
+        WreduceParams q;
+        q.partial = b.partial; q.nparts = blocks; q.RT = 8; q.CT = CT; q.NC = CT + (bias ? 1 : 0);
+        q.rowmap = b.maps + ymap; q.colmap = b.maps + xmap; q.dW = dW; q.ld = ld; q.db = bias ? db : nullptr; q.maxbits = b.maxbits; q.accum = b.accumulate;
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((long)8 * q.NC * 4)), dim3(256), 0, st, q);
+        EVD_LAUNCH_CHECK();
+        return EVD_OK;
+    };
     const VoxBwdGrads& g = b.grads;
     // (each wgrad is issued before the dgrad layer that reads the same arrays: independent, concurrent on the side stream)
     // color_net.2 (+ sigmoid, folded into the gradient fragment)
     if ((rc = wgrad(launch_wgrad<PREC, 1, T, true>, 1, T, true, VS::G_COL, VS::C1, VMAP_COL, VMAP_HID, g.color_w[2], HD, g.color_b[2]))) return rc;
     if ((rc = launch_dgrad<PREC, 1, T, 1, false, 2>(dgrad(VBWD_C2, VS::G_COL, -1, VS::M_C1, VS::D_C1), b.tiles, st))) return rc;
     // color_net.1
-    if ((rc = wgrad(launch_wgrad<PREC, T, T, false>, T, T, true, VS::D_C1, VS::C1 - KS, VMAP_HID, VMAP_HID, g.color_w[1], HD, g.color_b[1]))) return rc;
-    if ((rc = launch_dgrad<PREC, KS, T, KS, false, 2>(dgrad(VBWD_C1, VS::D_C1, -1, VS::M_C0, VS::D_C0), b.tiles, st))) return rc;
+    if constexpr (FUSABLE) {
+        if (fuse_on && g.color_w[1]) {
+            if ((rc = fused(launch_wgrad_dgrad<PREC, 8, 8, 1>, 8, true, VS::D_C1, VS::C1 - KS, VMAP_HID, VMAP_HID, g.color_w[1], HD, g.color_b[1], VBWD_C1, VS::M_C0, VS::D_C0))) return rc;
+        } else {
+            if ((rc = wgrad(launch_wgrad<PREC, T, T, false>, T, T, true, VS::D_C1, VS::C1 - KS, VMAP_HID, VMAP_HID, g.color_w[1], HD, g.color_b[1]))) return rc;
+            if ((rc = launch_dgrad<PREC, KS, T, KS, false, 2>(dgrad(VBWD_C1, VS::D_C1, -1, VS::M_C0, VS::D_C0), b.tiles, st))) return rc;
+        }
+    } else {
+        if ((rc = wgrad(launch_wgrad<PREC, T, T, false>, T, T, true, VS::D_C1, VS::C1 - KS, VMAP_HID, VMAP_HID, g.color_w[1], HD, g.color_b[1]))) return rc;
+        if ((rc = launch_dgrad<PREC, KS, T, KS, false, 2>(dgrad(VBWD_C1, VS::D_C1, -1, VS::M_C0, VS::D_C0), b.tiles, st))) return rc;
+    }
     // color_net.0 on cat([geo, PE(dirs)])
-    if constexpr (is_half_prec(PREC) && G == 32 * GT) {
+    bool c0_fused = false;
+    if constexpr (FUSABLE && G == 32 * GT) {
+        if (fuse_on && g.color_w[0]) {     // wgrad + dgrad of color_net.0 in one launch: d c0 read once; writes d geo | d PE(dirs) (no ReLU on geo)
+            static_assert(VS::D_DIRPE == VS::D_GEO + 2 * GT, "d PE(dirs) behind d geo");
+            if ((rc = fused(launch_wgrad_dgrad<PREC, GT + 1, GT + 1, 0>, GT + 1, true, VS::D_C0, VS::GEO, VMAP_HID, VMAP_GEO_X, g.color_w[0], G + ICV, g.color_b[0], VBWD_C0, -1, VS::D_GEO))) return rc;
+            c0_fused = true;
+        }
+    }
+    if (c0_fused) {
+    } else if constexpr (is_half_prec(PREC) && G == 32 * GT) {
         // geo and direction-encoding columns in ONE launch (adjacent fragments, adjacent index maps): d c0 is read once
         static_assert(VS::DIRPE == VS::GEO + 2 * GT && VMAP_DIR == VMAP_GEO_X + 128 && (G == 128), "adjacent fragments and column maps");
         if ((rc = wgrad(launch_wgrad<PREC, T, GT + 1, false>, T, GT + 1, true, VS::D_C0, VS::GEO, VMAP_HID, VMAP_GEO_X, g.color_w[0], G + ICV, g.color_b[0]))) return rc;
@@ -172,7 +213,7 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
         if ((rc = wgrad(launch_wgrad<PREC, T, GT, false>, T, GT, true, VS::D_C0, VS::GEO, VMAP_HID, VMAP_GEO_X, g.color_w[0], G + ICV, g.color_b[0]))) return rc;
         if ((rc = wgrad(launch_wgrad<PREC, T, 1, false>, T, 1, false, VS::D_C0, VS::DIRPE, VMAP_HID, VMAP_DIR, g.color_w[0], G + ICV, nullptr))) return rc;
     }
-    if ((rc = launch_dgrad<PREC, KS, GT + 1, KS, false, 0>(dgrad(VBWD_C0, VS::D_C0, -1, -1, VS::D_GEO), b.tiles, st))) return rc;   // d geo | d PE(dirs)
+    if (!c0_fused && (rc = launch_dgrad<PREC, KS, GT + 1, KS, false, 0>(dgrad(VBWD_C0, VS::D_C0, -1, -1, VS::D_GEO), b.tiles, st))) return rc;   // d geo | d PE(dirs)
     if (b.d_feature) {          // + the gradient of the geo features as an output of the level (voxnerf.py:221, consumed by AWP)
         if (G % 16) return fail(EVD_E_INVALID, "evd_voxel_mlp_backward: d_feature is built for the fine level (geo 128)");
         hipLaunchKernelGGL((k_rows_add_to_frags<PREC>), dim3((unsigned)cdiv(b.tiles * 64 * (G / 16), 256L)), dim3(256), 0, st, b.store, VS::tile_bytes(PREC), VS::D_GEO,
@@ -196,7 +237,16 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
     if ((rc = wgrad(launch_wgrad<PREC, 1, T, true>, 1, T, false, VS::G_SIG, VS::HID, VMAP_SIG, VMAP_HID, g.sigma_w[1], HD, nullptr))) return rc;
     if ((rc = launch_dgrad<PREC, 2 * GT + 1, T, 2 * GT, true, 2>(dgrad(VBWD_SIGGEO, VS::D_GEO, VS::G_SIG, VS::M_HID, VS::D_HID), b.tiles, st))) return rc;
     // sigma_net.0 on cat([fts, PE(pts)])
-    if constexpr (FTT == 2) {
+    bool l0_fused = false;
+    if constexpr (FUSABLE && FTT == 2) {
+        if (fuse_on && g.sigma_w[0] && (b.d_fts || b.d_pts)) {     // ... with its dgrad (d fts | d PE(pts)) in one launch
+            static_assert(VS::D_PE == VS::D_FTS + 2 * FTT, "d PE(pts) behind d fts");
+            if ((rc = fused(launch_wgrad_dgrad<PREC, FTT + 2, FTT + 2, 0>, FTT + 2, false, VS::D_HID, VS::IN0, VMAP_HID, VMAP_FTS, g.sigma_w[0], FT + IC, nullptr, VBWD_L0, -1, VS::D_FTS))) return rc;
+            l0_fused = true;
+        }
+    }
+    if (l0_fused) {
+    } else if constexpr (FTT == 2) {
         // the feature and encoding columns in ONE launch (their fragments and their index maps are adjacent): d hid is read once, not twice
         static_assert(VMAP_PE == VMAP_FTS + 32 * FTT, "adjacent column maps");
         if ((rc = wgrad(launch_wgrad<PREC, T, FTT + 2, false>, T, FTT + 2, false, VS::D_HID, VS::IN0, VMAP_HID, VMAP_FTS, g.sigma_w[0], FT + IC, nullptr))) return rc;
@@ -205,7 +255,7 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
         if ((rc = wgrad(launch_wgrad<PREC, T, 2, false>, T, 2, false, VS::D_HID, VS::IN0 + KF, VMAP_HID, VMAP_PE, g.sigma_w[0], FT + IC, nullptr))) return rc;
     }
     if (b.d_fts || b.d_pts) {
-        if ((rc = launch_dgrad<PREC, KS, FTT + 2, KS, false, 0>(dgrad(VBWD_L0, VS::D_HID, -1, -1, VS::D_FTS), b.tiles, st))) return rc;       // d fts | d PE(pts)
+        if (!l0_fused && (rc = launch_dgrad<PREC, KS, FTT + 2, KS, false, 0>(dgrad(VBWD_L0, VS::D_HID, -1, -1, VS::D_FTS), b.tiles, st))) return rc;       // d fts | d PE(pts)
         if (b.d_fts) {
             hipLaunchKernelGGL((k_frags_to_rows<PREC>), dim3((unsigned)cdiv(b.tiles * 64 * KF, 256L)), dim3(256), 0, st, (const char*)b.store, VS::tile_bytes(PREC),
                                VS::D_FTS, KF, b.nsamp, b.maxbits, b.d_fts, b.d_fts_stride);
