@@ -57,6 +57,8 @@ def parse(argv=None):
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--train-iters", type=int, default=1000, help="iterations of the in-run training that makes the 'trained' weights")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-zero-probe", action="store_true", help="skip the all-zero-data launches of the headline kernel (a run under rocprofv3 whose per-kernel "
+                                                                    "average is to be the real-data average: tools/final_run.sh)")
     ap.add_argument("--no-modes", action="store_true")
     ap.add_argument("--no-composite", action="store_true")
     ap.add_argument("--no-train", action="store_true")
@@ -175,11 +177,13 @@ def time_steps(fn, steps, warmup, dist=None, drain=None, device="cuda", settle_s
     return dt
 
 
-def headline(rays_per_rank, samples, world, steps, warmup, dt, precision):
+def headline(rays_per_rank, samples, world, steps, warmup, dt, precision, settle=0):
     """the contract keys of the JSON line (value = whole-job rays/s over all ranks)"""
     return {
         "metric": "rays/sec (4096x128 samples, 8x256 MLP)", "value": world * rays_per_rank * steps / dt, "unit": "rays/s",
-        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps,
+        "n_gpus": world, "steps": steps, "warmup": warmup, "settle": settle, "ms_per_step": 1e3 * dt / steps,
+        "protocol": f"{settle} untimed settle steps (clock / allocator; --settle), then the {warmup} warm-up steps, then exactly {steps} timed steps "
+                    "between barrier + device synchronize",
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": DTYPE_NAME[precision],
         "data": "synthetic",
@@ -293,12 +297,14 @@ def c2f_leg(precision, steps, parity=True):
     esz = 2 if half_grids else 4
     taps = 4 * 96 + 2 * 96                                      # 4 plane taps + 2 line taps x 96 channels = 576 gathered values per sample
     gathered = n * taps * esz
-    # PMC (profiles/r02_pmc_voxel.txt: float16 grids; profiles/r03_pmc_voxel_f32grids.txt: float32 grids; tools/pmc_voxel.sh), per sample of the
-    # fine-level launch: 128-byte line requests at the L2 and the lines that miss it (served by the Infinity Cache: the 165 MB of grids exceed
-    # the 32 MB of L2).  The kernel is a random gather: its roofline is the RATE at which the chip serves such requests, measured by
-    # tools/probes/gather_probe.hip (random 128-byte records, 16-byte lane loads), not an HBM byte rate.
-    pmc = {"l2_requests_per_sample": 10.2, "l2_miss_lines_per_sample": 3.8, "fetch_size_bytes_per_sample": 346, "source": "profiles/r02_pmc_voxel.txt"} if half_grids else \
-          {"l2_requests_per_sample": 14.2, "l2_miss_lines_per_sample": 6.1, "fetch_size_bytes_per_sample": 653, "source": "profiles/r03_pmc_voxel_f32grids.txt"}
+    # PMC of THIS kernel build (profiles/r04_pmc_voxel.json, made by tools/pmc_voxel.sh this round: rocprofv3 cannot run inside the timed
+    # process), per sample of the fine-level launch: 128-byte line READ requests at the L2 and the lines that miss it (served by the Infinity
+    # Cache: the 165 MB of grids exceed the 32 MB of L2).  The kernel is a random gather: its roofline is the RATE at which the chip serves
+    # such requests, measured by tools/probes/gather_probe.hip (random 128-byte records, 16-byte lane loads), not an HBM byte rate.
+    pj = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_voxel.json")))["f16_grids" if half_grids else "f32_grids"]
+    pmc = {"l2_requests_per_sample": pj["l2_read_requests_per_sample"], "l2_miss_lines_per_sample": pj["l2_miss_lines_per_sample"],
+           "fetch_size_bytes_per_sample": pj["fetch_size_bytes_per_sample"], "source": pj["file"] + " (committed profile of this round's kernel; the "
+           "fraction below is counter-derived requests x the launch duration measured in this run)"}
     ceil = {"l2_resident": 146e9, "infinity_cache": 58e9, "hbm": 54e9}
     req_rate = pmc["l2_requests_per_sample"] * n / (g_ms * 1e-3)
     miss_rate = pmc["l2_miss_lines_per_sample"] * n / (g_ms * 1e-3)
@@ -345,7 +351,8 @@ def awp_leg(precision):
     esd = W.make_awp_embed_state_dict(211)
     ws = [esd[f"sample_feature_embed_layer.{l}.weight"] for l in range(4)]
     bs = [esd[f"sample_feature_embed_layer.{l}.bias"] for l in range(4)]
-    emb = SampleFeatureEmbed(ws, bs, precision=precision)
+    rows_ok = precision in ("f16", "bf16", "f16x3")            # (the mixed training modes f16c / f16m keep the geo features as float16 fragments only)
+    emb = SampleFeatureEmbed(ws, bs, precision=precision if rows_ok and precision != "f16x3" else "f16")
     eflat = torch.cat([torch.tensor(t).reshape(-1) for l in range(4) for t in (ws[l], bs[l])]).to(dev).requires_grad_(True)
     lin = torch.nn.ModuleList([torch.nn.Linear(128, 64)] + [torch.nn.Linear(64, 64) for _ in range(3)]).to(dev)
     rs = np.random.RandomState(0)
@@ -372,7 +379,7 @@ def awp_leg(precision):
         raw, geo.token = net.mlp_train(flat, pts, vd, fts, want_feature=geo)
         ((raw * graw).sum() + (feature_integration(emb(eflat, geo).reshape(R, 1, S, 64), z, rd).reshape(R, 64) * gh).sum()).backward()
 
-    t0, t1, t2 = kernel_ms(level_only, 5), kernel_ms(torch_path, 5), kernel_ms(fused_path, 5)
+    t0, t1, t2 = kernel_ms(level_only, 5), (kernel_ms(torch_path, 5) if rows_ok else None), kernel_ms(fused_path, 5)
     geo = GeoFragments()
     with torch.no_grad():
         _, geo.token = net.mlp_train(flat.detach().requires_grad_(True), pts, vd, fts, want_feature=geo)
@@ -392,7 +399,7 @@ def awp_leg(precision):
     return {"workload": "AWP consumer, blurfactory blur batch: 10 240 sub-exposure rays x 128 samples, sample_feature_embed_layer 128-64-64-64-64 + feature_integration",
             "mam_per_sample_part": mam,
             "precision": precision, "fine_level_fwd_bwd_ms": t0, "with_awp_torch_linear_on_depth_feature_ms": t1, "with_awp_fused_on_geo_fragments_ms": t2,
-            "awp_addon_ms": {"torch": t1 - t0, "fused": t2 - t0}, "depth_feature_tensor_avoided_bytes": n * 128 * 4,
+            "awp_addon_ms": {"torch": (t1 - t0) if t1 is not None else None, "fused": t2 - t0}, "depth_feature_tensor_avoided_bytes": n * 128 * 4,
             "roofline": {"kernel": "k_awp_embed (training forward, geo fragments in)", "bound": "hbm", "kernel_ms": k_ms, "algorithmic_bytes": algo,
                          "achieved": algo / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "note": "per 32-sample tile: 8 KiB geo fragments read from the fine level's store; 8 KiB geo copy + 16 KiB activation "
@@ -401,25 +408,36 @@ def awp_leg(precision):
 
 def train_iteration_leg(precision):
     """One WHOLE blurfactory training iteration (tools/bench_train_step.py: blur batch of 1024 pixels x 10 sub-exposure rays + 2 x 4096
-    event rays, 64 + 64 samples, fused losses, TV, backward on the hand-written kernels, Adam, parameter re-pack) and the roofline of its
-    dominant kernel, the tri-plane scatter: bound by the rate of float atomics at the L2 (one dword per clock and channel)."""
+    event rays, 64 + 64 samples, fused losses, TV, backward on the hand-written kernels, Adam, parameter re-pack) in the training modes,
+    with the parity of each mode next to its time, and the roofline of its dominant kernel, the tri-plane scatter AS SHIPPED: atomic
+    requests at the L2 (PMC) over the launch duration, against the rate of a bare atomic kernel."""
     import ctypes as C
     import types
     import numpy as np
     import torch
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
     import bench_train_step as BT
+    import train_parity as TP
     from evdeblurnerf_amd import _lib as L, weights as W
     from evdeblurnerf_amd.voxnerf import VoxelNeRFSampleFeatures, _grid_grads
     ms, nrays, _ = BT.run(types.SimpleNamespace(precision=precision, iters=10, pixels=1024, events=4096, P=10))
+    torch.cuda.empty_cache()
+    modes = {precision: ms}
+    for other in ("f16", "f16c", "f16m"):
+        if other != precision:
+            modes[other], _, _ = BT.run(types.SimpleNamespace(precision=other, iters=8, pixels=1024, events=4096, P=10))
+            torch.cuda.empty_cache()
+    par = TP.c2f_gradient_parity(tuple(modes))
     torch.cuda.empty_cache()
     # the same iteration with the shipped configs' adaptive weight proposal on the blur batch (kernel_use_awp): the per-sample part fused
     # on the fine level's geo fragments (awp.FusedAWP: embedding MLP, scan, the MotionAggregationModule's per-sample part) vs the module's
     # plain PyTorch forward on depth_feature [R P, S, 128]; the module has the reference's structure (tools/awp_standin.py, mam="corr")
     ms_awp_f, _, _ = BT.run(types.SimpleNamespace(precision=precision, iters=5, pixels=1024, events=4096, P=10, awp="fused", mam="corr"))
     torch.cuda.empty_cache()
-    ms_awp_t, _, _ = BT.run(types.SimpleNamespace(precision=precision, iters=5, pixels=1024, events=4096, P=10, awp="torch", mam="corr"))
-    torch.cuda.empty_cache()
+    ms_awp_t = None
+    if precision in ("f16", "bf16", "f16x3"):        # (the torch module takes float32 feature rows, which the mixed modes do not write)
+        ms_awp_t, _, _ = BT.run(types.SimpleNamespace(precision=precision, iters=5, pixels=1024, events=4096, P=10, awp="torch", mam="corr"))
+        torch.cuda.empty_cache()
     aabb = ([-1.5, -1.5, -1.0], [1.5, 1.5, 1.0])
     fv = 134217984
     g = W.pdrf_grid_size(aabb[0], aabb[1], fv)
@@ -428,7 +446,7 @@ def train_iteration_leg(precision):
     rs = np.random.RandomState(0)
     R, S = 4096, 128
     o = rs.uniform(-0.3, 0.3, (R, 1, 3)) + np.array([0, 0, 0.9])
-    d = rs.normal(size=(R, 1, 3)) * 0.35 + np.array([0, 0, -1.0])
+    d = rs.normal(size=(R, 1, 3)) * np.array([0.05, 0.05, 0.0]) + np.array([0, 0, -1.0])       # slope 0.05: the PMC pass's rays (tools/pmc_scatter.sh)
     z = np.sort(rs.uniform(0.1, 1.7, (R, S, 1)), 1)
     pts = torch.as_tensor((o + d * z).astype(np.float32), device="cuda").reshape(-1, 3).contiguous()
     n = pts.shape[0]
@@ -439,25 +457,37 @@ def train_iteration_leg(precision):
     ws = torch.empty((nb,), dtype=torch.uint8, device="cuda")
     h_ms = kernel_ms(lambda: L.check(L.lib().evd_voxel_sample_bwd_ws(net._h, L.ptr(pts), n, L.ptr(d_out), 32, 0, C.byref(gs), None, L.ptr(ws), nb,
                                                                       L.stream_ptr()), "bwd_ws"), 10)
-    atomics = n * 6 * 96                                        # (4 plane + 2 line taps) x 96 channels float adds per sample
-    peak = 320.0                                                # G adds/s: what a bare kernel of coalesced float atomics sustains (tools/probes/atomic_probe.hip: 318-328)
-    return {"workload": "blurfactory training iteration: 1024 pixels x 10 sub-exposure rays + 2 x 4096 event rays, 64 + 64 samples, losses, TV, "
-                        "backward, Adam, parameter re-pack", "precision": precision, "ms_per_iteration": ms, "rays_per_iteration": nrays,
+    # atomic requests of the shipped form per 2^19 samples at this slope: profiles/r04_pmc_scatter.txt (TCC_ATOMIC_sum: main kernel + line slices)
+    req = {"k_voxel_sample_bwd_w": 5430262, "k_scatter_lines": 452665}
+    peak = 20.0                                                 # G atomic requests/s: a bare kernel of coalesced float atomics (tools/probes/atomic_probe.hip: 320 G adds/s in 64-byte requests)
+    achieved = sum(req.values()) / (h_ms * 1e-3) / 1e9
+    return {"workload": "blurfactory training iteration: 1024 pixels x 10 sub-exposure rays (stand-in RBK weights: a small learnable rigid kernel, "
+                        "tools/bench_train_step.py RigidKernel, in place of RigidBlurringModel.forward's MLPs) + 2 x 4096 event rays, 64 + 64 samples, "
+                        "losses, TV, backward, Adam, parameter re-pack", "precision": precision, "ms_per_iteration": ms, "rays_per_iteration": nrays,
             "rays_per_s": nrays / (ms * 1e-3),
+            "ms_per_iteration_by_mode": modes,
+            "parity_by_mode": {"what": "tools/train_parity.py: 2048 rays x (16 + 16) samples, the G19 loss; rendered colours and every gradient tensor "
+                                       "(30 parameters + rays) against the float32-grade mode f16x3 (= the reference's autograd to 2e-5 on golden G19)",
+                               **par,
+                               "note": "f16m = float32-grade forward (float32's own ReLU patterns) + float16 backward; f16c = compensated forward: ~5e-6 of the "
+                                       "units flip against float32, which bounds the gradients at ~sqrt(5e-6) of their norm whatever the batch size; f16 = "
+                                       "single-product float16 forward (1e-3 of the units flip)"},
             "with_awp_ms_per_iteration": {"fused_on_geo_fragments": ms_awp_f, "torch_module_on_depth_feature": ms_awp_t,
                                           "note": "AWP module = tools/awp_standin.py (the reference module's surface; its per-sample embedding is the reference's)"},
             "scatter_hybrid_ms": h_ms, "scatter_all_atomics_ms": k_ms,
-            "scatter_note": "what the iteration runs since round 3 (k_voxel_sample_bwd_w + k_scatter_lines + k_basis_grad): a wavefront owns 16 consecutive "
-                            "samples of a ray from the point load to its last atomic; the x-y plane's taps are summed in a register along runs of samples on one "
-                            "cell before ONE atomic per run, the 16-channel planes add tap by tap, the line taps go through 64-bit fixed-point LDS slices, the "
-                            "basis_mat gradient is its own GEMM.  PMC (profiles/r03_pmc_scatter.txt, slope 0.05): 6.0 M atomic requests per 2^19 samples "
-                            "instead of 18.9 M (all taps by atomics, the roofline below) / 12.6 M (round 2's hybrid)",
-            "roofline": {"kernel": "k_voxel_sample_bwd, all taps by atomics (fine level 586 x 586 x 390, 4096 x 128 samples)",
-                         "bound": "memory-side atomics", "kernel_ms": k_ms, "float_atomics": atomics, "achieved": atomics / (k_ms * 1e-3) / 1e9, "peak": peak,
-                         "unit": "G float atomic adds/s", "frac": atomics / (k_ms * 1e-3) / 1e9 / peak,
-                         "note": "the scatter-add of the tri-plane gather's backward issues 576 global float atomics per sample = 18.6 M 64-byte requests "
-                                 "per 2^19 samples, every one forwarded to the memory side (PMC: TCC_EA0_ATOMIC == TCC_ATOMIC, profiles/r02_pmc_scatter.txt); "
-                                 "peak = the rate of a bare atomic kernel on this chip (tools/probes/atomic_probe.hip, 20 G requests/s whatever the table size)"}}
+            "scatter_note": "what the iteration runs (round 4): k_voxel_sample_bwd_w persistent, a wavefront owns 16 consecutive samples of a ray from the point load "
+                            "to its last atomic; x-y plane taps summed in a register along runs of samples on one cell, the 16-channel planes add tap by tap, the "
+                            "basis_mat gradient accumulated in registers by MFMA (no coefficient rows, no second kernel), line taps through the 64-bit "
+                            "fixed-point LDS slices of k_scatter_lines",
+            "roofline": {"kernel": "k_voxel_sample_bwd_w<., ., true> + k_scatter_lines: the shipped hybrid (fine level 586 x 586 x 390, 4096 x 128 samples, slope 0.05)",
+                         "bound": "memory-side atomics (requests/s)", "kernel_ms": h_ms, "atomic_requests": req, "achieved": achieved, "peak": peak,
+                         "unit": "G atomic requests/s", "frac": achieved / peak,
+                         "bytes_written": 562e6, "write_GBps": 562e6 / (h_ms * 1e-3) / 1e9,
+                         "pmc_source": "profiles/r04_pmc_scatter.txt (TCC_ATOMIC_sum, WRITE_SIZE of this round's kernels)",
+                         "all_atomics_form": {"kernel_ms": k_ms, "atomic_requests": 18937705, "achieved": 18937705 / (k_ms * 1e-3) / 1e9, "frac": 18937705 / (k_ms * 1e-3) / 1e9 / peak},
+                         "note": "achieved = PMC-counted atomic requests of the two launches / their duration measured here; peak = the request rate of a bare "
+                                 "atomic kernel on this chip (20 G/s whatever the table size).  The all-atomics form (every tap a float atomic, 18.9 M requests) "
+                                 "runs at 84 % of that rate and takes 2.4x as long: the shipped form removes requests instead of chasing the rate"}}
 
 
 def strong_leg(model_c2f, precision, world, rank, frames=3):
@@ -531,7 +561,7 @@ def main(argv=None):
 
     dt = time_steps(step, a.steps, a.warmup, dist, drain=lambda: [w.wait() for w in pending], settle_steps=a.settle)
     med = per_step_ms(lambda: model.render(400, 400, K, rays=rays, **kw), max(20, min(a.steps, 200)))
-    result = headline(R, S, world, a.steps, a.warmup, dt, a.precision)
+    result = headline(R, S, world, a.steps, a.warmup, dt, a.precision, a.settle)
     result["ms_per_step_median"] = med[len(med) // 2]
     result["ranks"] = {"world_size": world, "backend": backend,
                        "launcher": ("bench.py self-launch" if os.environ.get("EVD_BENCH_SELF_LAUNCH") else
@@ -578,7 +608,7 @@ def main(argv=None):
         # the same binary on all-zero weights and rays: identical instruction stream, no switching activity -- what the kernel's STRUCTURE
         # costs at full clock; the difference to kernel_ms is the chip clocking down to its power budget on real data
         zero_ms = None
-        if not lean:
+        if not lean and not a.no_zero_probe:
             from evdeblurnerf_amd.nerf import NeRF
             znet = NeRF({k: np.zeros_like(v) for k, v in W.make_nerf_state_dict(21).items()})
             rb0, z0 = torch.zeros_like(rb), torch.zeros_like(z)
@@ -592,8 +622,8 @@ def main(argv=None):
                               "sustained_mfma_tflops": sustained, "frac_of_sustained_random": m["achieved"] / sustained["random_operands"],
                               "kernel_ms_on_all_zero_data": zero_ms,
                               "note": "achieved = algorithmic GEMM flops (1 186 816/sample) / HIP-event launch duration, against the 2.4 GHz "
-                                      "dense peak; traffic (bytes per launch: 2.0x the algorithmic bytes, the weight stream is fetched once per "
-                                      "XCD L2) and mfma_busy_frac_pmc (SQ_VALU_MFMA_BUSY_CYCLES over "
+                                      "dense peak; traffic (bytes per launch: 2.8x the algorithmic bytes -- 30 MB against 10.7 MB: the 2.1 MB weight stream "
+                                      "is fetched by every workgroup and served once per XCD L2) and mfma_busy_frac_pmc (SQ_VALU_MFMA_BUSY_CYCLES over "
                                       "GRBM_GUI_ACTIVE x SIMDs: the kernel keeps the pipe busier than frac says because the chip clocks "
                                       "below 2.4 GHz under this load) are from the PMC passes in profiles/r03_pmc_mlp.json; "
                                       "sustained_mfma_tflops = a bare back-to-back MFMA loop on every SIMD, measured in this run "
@@ -658,6 +688,17 @@ def main(argv=None):
                                "note": "evd_nerf_mlp_train / evd_nerf_mlp_backward on the metric workload (one network); HBM-bound by "
                                        "construction (per-layer dgrad + wgrad over the stored fragments), DESIGN.md 7"}
             del store_t
+            # the mixed training modes (round 4): compensated (f16c) / split-float16 (f16m) forward, the float16 mode's store and backward
+            mixed = {}
+            for mp in ("f16c", "f16m"):
+                fm = kernel_ms(lambda: tnet.mlpforward_train(rb_t, z_t, precision=mp), 10)
+                _, st_m = tnet.mlpforward_train(rb_t, z_t, precision=mp)
+                bm = kernel_ms(lambda: tnet.mlp_backward_flat(d_raw_t, st_m, precision=mp), 10)
+                mixed[mp] = {"forward_keeping_activations_ms": fm, "backward_params_ms": bm}
+                del st_m
+            result["train"]["mixed_modes"] = dict(mixed, note="forward in the mode's arithmetic (bit-identical to its inference kernel), float16 store and "
+                                                              "float16 dgrad / wgrad: G18 gradient summaries within 1.4e-3 (f16c) / 1.0e-3 (f16m) of the norm, "
+                                                              "rendered colours within 1e-6 (tests/test_gpu_train_f16c.py); single-product f16: 15 % / 3e-3")
             # the float32-grade training mode (EVD_PREC_F16X3: (hi, lo) fragments, 3-MFMA products; the reference trains in float32)
             f32g = NeRF(sd, "mlp_coarse.", precision="f16x3")
             fwd3_ms = kernel_ms(lambda: f32g.mlpforward_train(rb_t, z_t), 5)
@@ -674,7 +715,8 @@ def main(argv=None):
     c2f_model = None
     if not a.no_c2f or not a.no_strong:
         c2f_prec = a.precision                                          # f16c: fine level compensated (float16 grid copies), coarse level float32-grade on float32 grids
-        train_prec = a.precision if a.precision in ("f16", "bf16", "f16x3") else "f16"     # training kernels: throughput mode f16 (f16x3 = float32-grade)
+        # training: f16c = the compensated forward (the headline's arithmetic) in front of the float16 backward; f16m / f16 / f16x3 beside it
+        train_prec = a.precision if a.precision in ("f16", "bf16", "f16x3", "f16c") else "f16"
         # the informational legs below must never cost the contract line: a failure is recorded in its place
         def guarded(name, fn):
             try:

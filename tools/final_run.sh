@@ -1,10 +1,10 @@
 #!/bin/bash
 # the round's closing GPU run: whole GPU suite, the bench line, the same bench under rocprofv3 (kernel stats), the training iteration under rocprofv3
-O=${1:-gpurun_out/r3_final}; mkdir -p $O
+O=${1:-gpurun_out/r4_final}; mkdir -p $O
 python -m pytest tests -m gpu -q > $O/gputest.log 2>&1; tail -3 $O/gputest.log
 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.json
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-train --no-parity --no-c2f --no-strong > $GRAFT_REPO_ROOT/$O/bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$O/rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-train --no-parity --no-c2f --no-strong --no-zero-probe > $GRAFT_REPO_ROOT/$O/bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$O/rocprof.err
 cd $GRAFT_REPO_ROOT
 f=$(ls $O/prof/*/*kernel_stats.csv | head -1); cp $f $O/bench_kernel_stats.csv; rm -rf $O/prof; head -4 $O/bench_kernel_stats.csv | cut -c1-160
 cd /tmp
