@@ -330,7 +330,19 @@ class FusedAWP(torch.nn.Module):
 
             tail = _Tail().train(self.ref.training)
             sample = tuple(torch.randn(sh, device=device).requires_grad_(True) for sh in (sh_h, sh_view, sh_inter, sh_intra))
+            # make_graphed_callables warms the module up and captures it on these RANDOM inputs: the BatchNorm layers of the wrapped module
+            # (MAM.Corr.convd) would take the random batches into running_mean / running_var / num_batches_tracked -- statistics that are
+            # checkpointed.  They are put back afterwards; momentum=None (cumulative average: num_batches_tracked is read on the host inside the
+            # capture) is rejected.
+            bns = [m for m in self.ref.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+            if any(m.momentum is None for m in bns):
+                raise L.EvdError("FusedAWP(graph_per_ray=True): BatchNorm with momentum=None cannot be captured (its average reads num_batches_tracked on the host)")
+            saved = [{k: v.clone() for k, v in m._buffers.items() if v is not None} for m in bns]
             self._graphed[key] = torch.cuda.make_graphed_callables(tail, sample, allow_unused_input=True)   # (the embedding's parameters are not in this graph)
+            with torch.no_grad():
+                for m, sv in zip(bns, saved):
+                    for k, v in sv.items():
+                        m._buffers[k].copy_(v)
         return self._graphed[key]
 
     def _graphed_tail(self, h, view, h_inter, h_intra):

@@ -32,7 +32,11 @@ VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 # and the kernel runs out of scratch memory (1900 branches, 4000 scratch accesses).  The inference units are compiled without the flag.
 UNROLL = ["-mllvm", "-pragma-unroll-threshold=1000000"]
 PER_FILE = {"kernel_nerf_mlp_pipe_f16c.hip": VGPR_FORM, "kernel_nerf_mlp_pipe_f16x3.hip": VGPR_FORM, "kernel_voxel_pipe_f16c.hip": VGPR_FORM,
-            "kernel_voxel_train_f16c.hip": VGPR_FORM + UNROLL, "kernel_nerf_train_fwd_f16c.hip": VGPR_FORM + UNROLL}
+            "kernel_voxel_train_f16c.hip": VGPR_FORM + UNROLL + ["-DEVD_C_RNE"], "kernel_nerf_train_fwd_f16c.hip": VGPR_FORM + UNROLL + ["-DEVD_C_RNE"]}
+# -DEVD_C_RNE on the TRAIN units: the float16 part of an activation rounded to nearest instead of truncated (mlp_pipe_c.h c_drain_pair; the
+# inference kernels truncate: one VALU instruction less per pair).  The fp6 residual is then half as large, the pre-activations twice as
+# accurate -- half as many ReLU units decided differently from float32: gradient error (median over the 31 tensors of
+# tools/train_parity.py) 3.6e-3 -> 2.5e-3 of the norm at the same iteration time (the training forward is 10 % of the iteration).
 
 
 def hipcc() -> str:

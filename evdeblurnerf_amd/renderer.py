@@ -251,6 +251,15 @@ class NeRFAll:
             else:
                 net.load_params(p)
 
+    def invalidate_packed(self):
+        """Mark the library's packed copies of the trainable tensors stale: the next training forward (or sync_parameters / eval) re-packs the
+        weight streams and reloads the grids.  The re-pack check sees a changed tensor address or version counter and any backward of the
+        library's nodes -- NOT a write that bumps no version and follows no backward: `p.data.copy_(...)` (a checkpoint or EMA restore),
+        a second fused optimizer step, a manual reload.  Call this after such a write (load_state_dict-style helpers of a training loop)."""
+        for net in (self.mlp_coarse, self.mlp_fine):
+            if net is not None:
+                net._synced = net._synced_net = None
+
     def train(self, mode=True):
         if not mode:
             self.sync_parameters()
