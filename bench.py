@@ -748,9 +748,12 @@ def main(argv=None):
                 return {"workload": "blurfactory training iteration per GPU (1024 pixels x 10 sub-exposure rays + 2 x 4096 event rays, 64 + 64 samples, "
                                     "losses, TV, backward, gradient all-reduce, Adam, re-pack)", "scaling": "weak", "n_gpus": world, "precision": train_prec,
                         "ms_per_iteration": ms, "rays_per_s": world * nrays / (ms * 1e-3), "rays_per_iteration_per_gpu": nrays,
-                        "gradient_allreduce_ms": ar, "gradient_allreduce_share": ar / ms, "gradient_bytes": ns.grad_bytes,
+                        "gradient_allreduce_exposed_ms": ar, "gradient_allreduce_exposed_share": ar / ms, "gradient_bytes": ns.grad_bytes,
+                        "gradient_messages_started_inside_backward": getattr(ns, "allreduce_early_starts", 0),
                         "note": "max over ranks; the gradient exchange runs on the persistent flat gradient buffers of the in-place mode "
-                                "(4 messages: 2 levels x {networks, grids}) + one bucket for the blur kernel / CRF parameters"}
+                                "(4 messages: 2 levels x {networks, grids}) + one bucket for the blur kernel / CRF parameters; a level's "
+                                "messages start as soon as that level's last backward node has run (dist.GradReducer.attach), "
+                                "gradient_allreduce_exposed_ms = what is still waited for after loss.backward() returned"}
             r = guarded("train_scaling", train_dp)
             if rank == 0:
                 result["train_scaling"] = r

@@ -111,6 +111,35 @@ class GradReducer:
         self._flat = [None] * len(self.buckets)
         self._work = []
         self._late = []
+        self._early = set()         # flat groups whose all-reduce was started from a level's "gradients complete" callback (attach)
+        self.early_starts = 0
+
+    def attach(self, model):
+        """Start a level's in-place gradient buffers as soon as that level's LAST backward node of the iteration has run (voxnerf._bwd_done)
+        instead of at start(): in the blurfactory iteration the fine level -- 150 MB of grid gradients, the largest message -- is complete
+        while the coarse level's last scatter and networks still run (~1.5 ms), and the coarse level while the blur kernel's own backward
+        runs.  model.grad_buffers() order: per level [network buffer, grid buffer]; levels whose nets have no callback slot are left to start()."""
+        lv = [n for n in (getattr(model, "mlp_coarse", None), getattr(model, "mlp_fine", None)) if n is not None]
+        per = len(self.flat_groups) // max(len(lv), 1) if lv else 0
+        if not lv or per * len(lv) != len(self.flat_groups):
+            return self
+        for i, net in enumerate(lv):
+            idx = list(range(i * per, (i + 1) * per))
+            net._pending_bwd = 0
+            net._grads_ready_cb = (lambda ids=idx: self._start_groups(ids))
+        self._attached_nets = lv
+        return self
+
+    def _start_groups(self, ids):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        for i in ids:
+            buf, ps = self.flat_groups[i]
+            if i not in self._early and self._attached(buf, ps):
+                self._work.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True), None))
+                self._early.add(i)
+                self.early_starts += 1
 
     def _make_buckets(self, params):
         bucket_bytes = self.bucket_bytes
@@ -135,10 +164,12 @@ class GradReducer:
 
     def start(self):
         import torch.distributed as dist
-        self._work, self._late = [], []
+        self._work, self._late = list(self._work) if self._early else [], []
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
-        for buf, ps in self.flat_groups:            # in place: the largest messages first
+        for gi, (buf, ps) in enumerate(self.flat_groups):            # in place: the largest messages first
+            if gi in self._early:
+                continue                              # already in flight (attach)
             if self._attached(buf, ps):
                 self._work.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True), None))
             else:
@@ -178,6 +209,9 @@ class GradReducer:
                 p.grad.copy_(flat[off:off + p.numel()].reshape(p.shape))
                 off += p.numel()
         self._work = []
+        self._early = set()
+        for net in getattr(self, "_attached_nets", ()):     # a forward whose output never reached the loss leaves a count behind
+            net._pending_bwd = 0
 
 
 def gather_rows(local_rows: torch.Tensor, n_total: int):

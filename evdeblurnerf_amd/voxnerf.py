@@ -65,6 +65,23 @@ def _grid_grads(net, like, in_place=False):
     return ret, gs
 
 
+# ---- "this level's gradients are complete" (data-parallel training, dist.GradReducer.attach): every training-forward call of a level
+# (gather, networks, TV) counts one pending backward node; the node that brings the count back to zero fires the level's callback --
+# its gradient buffers can be all-reduced while the backward of the levels / modules in front of it still runs.
+def _fwd_noted(net):
+    if torch.is_grad_enabled() and getattr(net, "_grads_ready_cb", None) is not None:
+        net._pending_bwd = getattr(net, "_pending_bwd", 0) + 1
+
+
+def _bwd_done(net):
+    cb = getattr(net, "_grads_ready_cb", None)
+    if cb is None:
+        return
+    net._pending_bwd = getattr(net, "_pending_bwd", 0) - 1
+    if net._pending_bwd == 0:
+        cb()
+
+
 class _VoxelSample(torch.autograd.Function):
     """VoxelNeRFBase.sample with gradients to the (channel-last) planes, lines and basis_mat: evd_voxel_sample / _bwd"""
 
@@ -92,6 +109,7 @@ class _VoxelSample(torch.autograd.Function):
         ws = torch.empty((nb,), dtype=torch.uint8, device=pts.device) if nb else None
         L.check(L.lib().evd_voxel_sample_bwd_ws(net._h, L.ptr(pts), pts.shape[0], C.c_void_p(g.data_ptr()), g_stride, 0, C.byref(gs), L.ptr(d_pts), L.ptr(ws), nb,
                                                 L.stream_ptr()), "evd_voxel_sample_bwd_ws")
+        _bwd_done(net)
         return (d_pts.reshape(ctx.pts.shape) if d_pts is not None else None, None, None, *grads)
 
 
@@ -142,6 +160,7 @@ class _VoxelMLP(torch.autograd.Function):
         ctx.store = ctx.raw = None
         if ctx.geo is not None:
             ctx.geo.store = ctx.geo.awp_store = None
+        _bwd_done(ctx.net)
         R, S = ctx.pts.shape[:2]
         return (gflat, d_fts.reshape(ctx.ft_shape) if d_fts is not None else None, d_pts.reshape(ctx.pts.shape) if d_pts is not None else None,
                 d_dirs.reshape(R, S, 3).sum(1) if d_dirs is not None else None, None, None, None)
@@ -162,6 +181,7 @@ class _VoxelTV(torch.autograd.Function):
         gs.basis = None
         d = d_loss.reshape(1).contiguous().float()
         L.check(L.lib().evd_voxel_tv_loss_bwd(net._h, L.ptr(d), C.byref(gs), L.stream_ptr()), "evd_voxel_tv_loss_bwd")
+        _bwd_done(net)
         return (None, *grads)
 
 
@@ -356,6 +376,7 @@ class VoxelNeRFBase:
         GeoFragments instance instead of True: the features stay fragments in the level's store, the second output is its token"""
         if getattr(self, "_synced_net", None) != (flat.data_ptr(), flat._version, L.backward_generation()):
             self.load_params(flat)
+        _fwd_noted(self)
         return _VoxelMLP.apply(flat, fts, pts, viewdirs, self, precision or self.precision, want_feature)
 
     # ---- training the grids (the library's channel-last layout; a permute away from the state dict) ---------------------
@@ -388,6 +409,7 @@ class VoxelNeRFBase:
         does (the copies are refreshed by the re-load); None / the float32-grade modes read the float32 grids.  The backward (scatter-add,
         the interpolation-weight derivative) always works on the float32 grids."""
         self._sync(grids)
+        _fwd_noted(self)
         self._sample_out = out              # taken (and cleared) by _VoxelSample.forward; not an autograd input: it is written through its pointer
         try:
             return _VoxelSample.apply(pts, self, precision, *grids)
@@ -396,6 +418,7 @@ class VoxelNeRFBase:
 
     def tv_loss_train(self, grids):
         self._sync(grids)
+        _fwd_noted(self)
         return _VoxelTV.apply(self, *grids)
 
     @staticmethod

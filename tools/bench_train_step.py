@@ -104,7 +104,11 @@ def run(a):
         import torch.distributed as tdist
         from evdeblurnerf_amd import dist as D
         rank = tdist.get_rank()
+        # .attach: a level's buffers are all-reduced as soon as its last backward node of the iteration has run (behind them: the coarse
+        # level's last scatter / networks, the blur kernel's backward); what is still waited for after loss.backward() is the exposed part
         red = D.GradReducer(list(model.parameters()) + [crf_flat], flat_buffers=model.grad_buffers())
+        if not os.environ.get("EVD_NO_EARLY_ALLREDUCE"):
+            red.attach(model)
     blur_rays = torch.as_tensor(W.synthetic_rays(1 + 10 * rank, R), device=dev)
     ev_start = torch.as_tensor(W.synthetic_rays(2 + 10 * rank, E), device=dev)
     ev_end = torch.as_tensor(W.synthetic_rays(3 + 10 * rank, E), device=dev)
@@ -158,7 +162,8 @@ def run(a):
         e1.synchronize()
     ms = e0.elapsed_time(e1) / a.iters
     if ddp:
-        a.allreduce_ms = ar_ev[0].elapsed_time(ar_ev[1])            # the last iteration's gradient exchange (start -> all buckets reduced)
+        a.allreduce_ms = ar_ev[0].elapsed_time(ar_ev[1])            # the last iteration's gradient exchange AFTER loss.backward() returned: the exposed part
+        a.allreduce_early_starts = red.early_starts
         a.grad_bytes = 4 * sum(p.numel() for p in list(model.parameters()) + [crf_flat])
     return ms, R * a.P + 2 * E, float(l.detach())
 
