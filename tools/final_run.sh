@@ -13,5 +13,7 @@ cd $GRAFT_REPO_ROOT
 f=$(ls $O/prof2/*/*kernel_stats.csv | head -1); cp $f $O/train_step_kernel_stats.csv; rm -rf $O/prof2; head -6 $O/train_step_kernel_stats.csv | cut -c1-160
 python tools/profile_train_kernels.py --top 70 2>&1 | grep -v "Warn\|amdgpu.ids\|_warn_once" > $O/train_kernels_steady.txt; head -5 $O/train_kernels_steady.txt
 python tools/profile_train_kernels.py --awp fused --top 80 2>&1 | grep -v "Warn\|amdgpu.ids\|_warn_once" > $O/train_kernels_awp_steady.txt; head -5 $O/train_kernels_awp_steady.txt
+for m in f16c f16m; do python tools/profile_train_kernels.py --precision $m --top 70 2>&1 | grep -v "Warn\|amdgpu.ids\|_warn_once" > $O/train_kernels_${m}_steady.txt; head -2 $O/train_kernels_${m}_steady.txt; done
 python tools/bench_train_step.py --iters 20 2>&1 | tail -1 | tee $O/train_step.log
+for m in f16c f16m; do python tools/bench_train_step.py --iters 20 --precision $m 2>&1 | tail -1 | tee -a $O/train_step.log; done
 python tools/bench_train_step.py --iters 10 --awp fused 2>&1 | tail -1 | tee -a $O/train_step.log
