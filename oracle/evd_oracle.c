@@ -1014,6 +1014,140 @@ void evo_mam_local(const float* x_local, const float* W, const float* b, const f
     }
 }
 
+/* The per-ray remainder of the adaptive weight proposal, AS WRITTEN:
+ *   awp.py:104-109   h = cat(h_integrated [R, P, Ws], view_embedded [R, VC] repeated over P); n_mot x (Linear + ReLU) -> x_global [R, P, Cm]
+ *   mam.py:35-53     CorrelationModule.forward behind the per-sample part (curver_inter [R, Cm, P] and curves_intra [R, Cm, S] are INPUTS,
+ *                    evo_mam_local's outputs): conva / convb (Cm -> Cm/2), convc on x, the two softmax(bmm) attention maps, convn / convl,
+ *                    the two bmm, concatenation, convd = Conv1d(Cm -> Cm, no bias) + BatchNorm1d over (ray, position) per channel --
+ *                    batch statistics (biased variance) when `training`, the running estimates otherwise --, residual, leaky_relu(0.2)
+ *   awp.py:112-115   mean over the P positions, w_linear, sigmoid, division by the sum
+ * Every Conv1d has kernel size 1: a matrix product over the channel axis.  batch_stats [2 Cm] (may be NULL): the batch mean and the
+ * UNBIASED batch variance (what BatchNorm blends into its running estimates).  float32 accumulation in input order, double for the
+ * batch statistics. */
+void evo_awp_per_ray(const float* h, const float* view, const float* inter, const float* intra, const float* const* mot_w,
+                     const float* const* mot_b, int n_mot, const float* conva, const float* convb, const float* convc, const float* convn,
+                     const float* convl, const float* convd, const float* bn_w, const float* bn_b, const float* bn_mean,
+                     const float* bn_var, float bn_eps, int training, const float* wl_w, const float* wl_b, long R, int P, int S, int Ws,
+                     int VC, int Cm, float* out, float* batch_stats) {
+    const int mid = Cm / 2, in0 = Ws + VC;
+    float* xg = (float*)malloc(sizeof(float) * (size_t)R * P * Cm);
+    float* y = (float*)malloc(sizeof(float) * (size_t)R * P * Cm);
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < R; ++r) {
+        float* a = (float*)malloc(sizeof(float) * (size_t)(in0 > Cm ? in0 : Cm));
+        float* b = (float*)malloc(sizeof(float) * (size_t)Cm);
+        float* kP = (float*)malloc(sizeof(float) * (size_t)P * mid), *nP = (float*)malloc(sizeof(float) * (size_t)P * mid);
+        float* kS = (float*)malloc(sizeof(float) * (size_t)S * mid), *nS = (float*)malloc(sizeof(float) * (size_t)S * mid);
+        float* lg = (float*)malloc(sizeof(float) * (size_t)(S > P ? S : P));
+        float* f = (float*)malloc(sizeof(float) * (size_t)Cm);
+        for (int p = 0; p < P; ++p) {                                          /* awp.py:104-109 */
+            for (int k = 0; k < Ws; ++k) a[k] = h[((size_t)r * P + p) * Ws + k];
+            for (int k = 0; k < VC; ++k) a[Ws + k] = view[(size_t)r * VC + k];
+            int K = in0;
+            for (int l = 0; l < n_mot; ++l) {
+                for (int o = 0; o < Cm; ++o) {
+                    float acc = 0.f;
+                    for (int k = 0; k < K; ++k) acc += a[k] * mot_w[l][(size_t)o * K + k];
+                    acc += mot_b[l][o];
+                    b[o] = acc > 0.f ? acc : 0.f;
+                }
+                for (int o = 0; o < Cm; ++o) a[o] = b[o];
+                K = Cm;
+            }
+            for (int o = 0; o < Cm; ++o) xg[((size_t)r * P + p) * Cm + o] = a[o];
+        }
+        for (int p = 0; p < P; ++p)                                            /* mam.py:38, 46: conva, convn on curver_inter[:, :, p] */
+            for (int m = 0; m < mid; ++m) {
+                float acc = 0.f;
+                for (int c = 0; c < Cm; ++c) acc += conva[m * Cm + c] * inter[((size_t)r * Cm + c) * P + p];
+                kP[p * mid + m] = acc;
+            }
+        for (int p = 0; p < P; ++p)
+            for (int m = 0; m < mid; ++m) {
+                float acc = 0.f;
+                for (int c = 0; c < mid; ++c) acc += convn[m * mid + c] * kP[p * mid + c];
+                nP[p * mid + m] = acc;
+            }
+        for (int s = 0; s < S; ++s)                                            /* mam.py:39, 47: convb, convl on curves_intra[:, :, s] */
+            for (int m = 0; m < mid; ++m) {
+                float acc = 0.f;
+                for (int c = 0; c < Cm; ++c) acc += convb[m * Cm + c] * intra[((size_t)r * Cm + c) * S + s];
+                kS[s * mid + m] = acc;
+            }
+        for (int s = 0; s < S; ++s)
+            for (int m = 0; m < mid; ++m) {
+                float acc = 0.f;
+                for (int c = 0; c < mid; ++c) acc += convl[m * mid + c] * kS[s * mid + c];
+                nS[s * mid + m] = acc;
+            }
+        for (int p = 0; p < P; ++p) {
+            const float* x = xg + ((size_t)r * P + p) * Cm;
+            for (int m = 0; m < mid; ++m) {                                    /* mam.py:41: x_logits */
+                float acc = 0.f;
+                for (int c = 0; c < Cm; ++c) acc += convc[m * Cm + c] * x[c];
+                b[m] = acc;
+            }
+            for (int half = 0; half < 2; ++half) {                             /* mam.py:42-43, 49-50 */
+                const int n = half ? S : P;
+                const float* kk = half ? kS : kP;
+                const float* nn = half ? nS : nP;
+                float mx = -INFINITY, den = 0.f;
+                for (int j = 0; j < n; ++j) {
+                    float acc = 0.f;
+                    for (int m = 0; m < mid; ++m) acc += b[m] * kk[j * mid + m];
+                    lg[j] = acc;
+                    mx = fmaxf(mx, acc);
+                }
+                for (int j = 0; j < n; ++j) den += expf(lg[j] - mx);
+                for (int m = 0; m < mid; ++m) {
+                    float acc = 0.f;
+                    for (int j = 0; j < n; ++j) acc += (expf(lg[j] - mx) / den) * nn[j * mid + m];
+                    f[half * mid + m] = acc;
+                }
+            }
+            for (int o = 0; o < Cm; ++o) {                                     /* mam.py:52-53: convd[0] */
+                float acc = 0.f;
+                for (int c = 0; c < Cm; ++c) acc += convd[o * Cm + c] * f[c];
+                y[((size_t)r * P + p) * Cm + o] = acc;
+            }
+        }
+        free(a); free(b); free(kP); free(nP); free(kS); free(nS); free(lg); free(f);
+    }
+    const double cnt = (double)R * P;
+    float* mean = (float*)malloc(sizeof(float) * (size_t)Cm), *rstd = (float*)malloc(sizeof(float) * (size_t)Cm);
+    for (int c = 0; c < Cm; ++c) {                                             /* BatchNorm1d(Cm) on [R, Cm, P]: statistics over (R, P) */
+        double s1 = 0.0, s2 = 0.0;
+        for (long i = 0; i < R * P; ++i) s1 += y[(size_t)i * Cm + c];
+        const double mu = s1 / cnt;
+        for (long i = 0; i < R * P; ++i) { const double d = y[(size_t)i * Cm + c] - mu; s2 += d * d; }
+        if (batch_stats) { batch_stats[c] = (float)mu; batch_stats[Cm + c] = (float)(s2 / (cnt > 1.0 ? cnt - 1.0 : 1.0)); }
+        mean[c] = training ? (float)mu : bn_mean[c];
+        rstd[c] = 1.0f / sqrtf((training ? (float)(s2 / cnt) : bn_var[c]) + bn_eps);
+    }
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < R; ++r) {
+        float hm[512], w[64];
+        for (int c = 0; c < Cm; ++c) {
+            float acc = 0.f;
+            for (int p = 0; p < P; ++p) {
+                const size_t at = ((size_t)r * P + p) * Cm + c;
+                const float v = xg[at] + ((y[at] - mean[c]) * rstd[c] * bn_w[c] + bn_b[c]);
+                acc += v > 0.f ? v : 0.2f * v;                                 /* mam.py:53 */
+            }
+            hm[c] = acc / (float)P;                                            /* awp.py:112 */
+        }
+        float tot = 0.f;
+        for (int j = 0; j < P; ++j) {                                          /* awp.py:114-115 */
+            float acc = 0.f;
+            for (int c = 0; c < Cm; ++c) acc += wl_w[j * Cm + c] * hm[c];
+            w[j] = 1.0f / (1.0f + expf(-(acc + wl_b[j])));
+            tot += w[j];
+        }
+        for (int j = 0; j < P; ++j) out[(size_t)r * P + j] = w[j] / tot;
+    }
+    free(mean); free(rstd); free(xg); free(y);
+}
+
 /* ------------------------------------------------------------------ RBK ray warp
  * SE3Field.get_transform (rigid_warping.py:18-30): theta = |rot| + 1e-10, screw axis (rot, trans) / theta;
  * RigidBody.exp_se3 (:72-91): R = I + sin(theta) W + (1 - cos(theta)) W^2 (Rodrigues, :93-107),

@@ -411,6 +411,31 @@ def mam_local(x_local, W, b, v, P):
     return inter, intra
 
 
+def awp_per_ray(h, view, inter, intra, sd, training=True, eps=1e-5):
+    """The adaptive weight proposal behind its per-sample part (awp.py:104-117, mam.py:35-53 as written).  h [R, P, Ws] integrated features,
+    view [R, VC] = view_embedded (view_feature + direction encoding, awp.py:89-95), inter [R, Cm, P] / intra [R, Cm, S] = mam_local's outputs,
+    sd: the module's state dict (reference names).  -> (out [R, P], batch mean [Cm], unbiased batch variance [Cm])"""
+    h, view, inter, intra = _f(h), _f(view), _f(inter), _f(intra)
+    R, P, Ws = h.shape
+    Cm, S, VC = inter.shape[1], intra.shape[2], view.shape[1]
+    g = lambda k: _f(np.asarray(sd[k]).reshape(np.asarray(sd[k]).shape[0], -1) if np.asarray(sd[k]).ndim > 1 else np.asarray(sd[k]))
+    n_mot = len([k for k in sd if k.startswith("motion_feature_embed_layer.") and k.endswith(".weight")])
+    mw, mb = [g(f"motion_feature_embed_layer.{l}.weight") for l in range(n_mot)], [g(f"motion_feature_embed_layer.{l}.bias") for l in range(n_mot)]
+    if P > 64 or Cm > 512:
+        raise ValueError("evo_awp_per_ray: P <= 64, Cm <= 512")
+    fp = C.POINTER(C.c_float)
+    wa, ba = (fp * n_mot)(*[w.ctypes.data_as(fp) for w in mw]), (fp * n_mot)(*[b.ctypes.data_as(fp) for b in mb])
+    cv = {k: g(f"MAM.Corr.{k}.weight") for k in ("conva", "convb", "convc", "convn", "convl")}
+    cd, bw, bb = g("MAM.Corr.convd.0.weight"), g("MAM.Corr.convd.1.weight"), g("MAM.Corr.convd.1.bias")
+    rm, rv = g("MAM.Corr.convd.1.running_mean"), g("MAM.Corr.convd.1.running_var")
+    ww, wb = g("w_linear.weight"), g("w_linear.bias")
+    out, stats = np.empty((R, P), np.float32), np.empty((2 * Cm,), np.float32)
+    lib().evo_awp_per_ray(_p(h), _p(view), _p(inter), _p(intra), wa, ba, n_mot, _p(cv["conva"]), _p(cv["convb"]), _p(cv["convc"]), _p(cv["convn"]),
+                          _p(cv["convl"]), _p(cd), _p(bw), _p(bb), _p(rm), _p(rv), C.c_float(eps), int(bool(training)), _p(ww), _p(wb), C.c_long(R), P, S,
+                          Ws, VC, Cm, _p(out), _p(stats))
+    return out, stats[:Cm], stats[Cm:]
+
+
 def crf_forward(crf: Crf, x, feat=None, skip_learn=False):
     x = _f(x)
     n = x.shape[0]

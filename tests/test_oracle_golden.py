@@ -541,3 +541,57 @@ def test_G22_mam():
             assert np.abs(got.numpy()).max() < 1e-4 and np.abs(g[key]).max() < 1e-4
             continue
         assert np.linalg.norm(got.numpy() - g[key]) < 2e-5 * np.linalg.norm(g[key]), key
+
+
+def _g27_standin(g):
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from awp_standin import RefLikeAWP
+    P, VF = g["out"].shape[1], g["view_feature"].shape[1]
+    awp = RefLikeAWP(P=P, view_ch=VF, mam="corr")
+    sd = {k[3:]: torch.tensor(g[k]) for k in g if k.startswith("sd.")}
+    missing, unexpected = awp.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith("sample_feature_embed_layer") for k in missing), (missing, unexpected)
+    return awp
+
+
+def test_G27_awp_per_ray():
+    """G27: the reference's AdaptiveWeightProposal.forward with the real MotionAggregationModule, training mode.  (a) the oracle chain
+    evo_awp_feature_integration -> evo_mam_local -> evo_awp_per_ray on the h_local the real forward produced: the proposal weights, the
+    BatchNorm running estimates after the step, the eval-mode output; (b) tools/awp_standin.py RefLikeAWP(mam="corr") -- what the GPU tests
+    compare the kernels with at real sizes -- loads the reference's state dict and reproduces the output and every autograd gradient."""
+    import torch
+    g = load_golden("G27_awp_per_ray")
+    R, P = g["out"].shape
+    S = g["z"].shape[1]
+    sd = {k[3:]: g[k] for k in g if k.startswith("sd.")}
+    h = O.awp_feature_integration(g["h_local"], g["z"], g["rays_d"]).reshape(R, P, -1)
+    d0 = g["rays_d"].reshape(R, P, 3)[:, 0]
+    view = np.concatenate([g["view_feature"], O.embed(d0 / np.linalg.norm(d0, axis=-1, keepdims=True), 2)], -1)
+    inter, intra = O.mam_local(g["h_local"], sd["MAM.linear.weight"], sd["MAM.linear.bias"], sd["MAM.Corr.line_conv_att.weight"], P)
+    out, mean, var = O.awp_per_ray(h, view, inter, intra, sd, training=True)
+    assert maxabs(out, g["out"]) < 2e-6, maxabs(out, g["out"])
+    rm = 0.9 * sd["MAM.Corr.convd.1.running_mean"] + 0.1 * mean          # BatchNorm1d momentum 0.1 (torch default, mam.py:26)
+    rv = 0.9 * sd["MAM.Corr.convd.1.running_var"] + 0.1 * var
+    assert maxabs(rm, g["after.running_mean"]) < 1e-6 and maxabs(rv, g["after.running_var"]) < 1e-6
+    sd2 = dict(sd)
+    sd2["MAM.Corr.convd.1.running_mean"], sd2["MAM.Corr.convd.1.running_var"] = g["after.running_mean"], g["after.running_var"]
+    out_e, _, _ = O.awp_per_ray(h, view, inter, intra, sd2, training=False)
+    assert maxabs(out_e, g["out_eval"]) < 2e-6
+    # (b)
+    awp = _g27_standin(g).train()
+    hl, rd, vf = (torch.tensor(g[k], requires_grad=True) for k in ("h_local", "rays_d", "view_feature"))
+    o = awp.forward_from_local(hl, torch.tensor(g["z"]), rd, vf)
+    assert maxabs(o.detach().numpy(), g["out"]) < 2e-6
+    names = [k[2:] for k in g if k.startswith("g.") and k[2:] not in ("h_local", "rays_d", "view_feature")]
+    pd = dict(awp.named_parameters())
+    grads = torch.autograd.grad((o * torch.tensor(g["proj"])).sum(), [hl, rd, vf] + [pd[k] for k in names])
+    for got, key in zip(grads, ["h_local", "rays_d", "view_feature"] + names):
+        ref = g["g." + key]
+        if key == "MAM.linear.bias":     # analytically zero (the training-mode BatchNorm removes a constant added to every curve)
+            assert np.abs(got.numpy()).max() < 1e-4 and np.abs(ref).max() < 1e-4
+            continue
+        assert np.linalg.norm(got.numpy() - ref) < 3e-5 * np.linalg.norm(ref), (key, np.linalg.norm(got.numpy() - ref) / np.linalg.norm(ref))
+    assert maxabs(awp.MAM.Corr.convd[1].running_mean.numpy(), g["after.running_mean"]) < 1e-6

@@ -60,7 +60,7 @@ class RefLikeAWP(torch.nn.Module):
 
     def __init__(self, P=5, W_mot=32, view_ch=4, mam="mean"):
         super().__init__()
-        self.output_ch, self.ccw_fine_scale = P, 0.05
+        self.output_ch, self.ccw_fine_scale, self.ray_dir_freq = P, 0.05, 2
         ch = 3 * (1 + 2 * 2)            # a differentiable 2-frequency encoding (the reference's get_embedder(ray_dir_freq) is torch too)
         self.ray_dirs_embed_fn = lambda x: torch.cat([x] + [f(x * 2.0 ** k) for k in range(2) for f in (torch.sin, torch.cos)], -1)
         self.sample_feature_embed_layer = torch.nn.ModuleList([torch.nn.Linear(128, 64)] + [torch.nn.Linear(64, 64) for _ in range(3)])
@@ -78,14 +78,18 @@ class RefLikeAWP(torch.nn.Module):
 
     def forward(self, depth_feature, z_vals, rays_d, view_feature):         # awp.py:79-117 in plain torch (float32 reference of the test)
         P = self.output_ch
-        n_ray = depth_feature.shape[0] // P
-        dirs = rays_d.reshape(n_ray, P, -1)[:, 0, :]
-        view = torch.cat([view_feature, self.ray_dirs_embed_fn(dirs / torch.norm(dirs, dim=-1, keepdim=True))], -1)
         h = depth_feature
         for l in self.sample_feature_embed_layer:
             h = torch.relu(l(h))
-        h_local = h
-        h = scan_as_written(h, z_vals, rays_d).reshape(n_ray, P, -1)
+        return self.forward_from_local(h, z_vals, rays_d, view_feature)
+
+    def forward_from_local(self, h_local, z_vals, rays_d, view_feature):    # awp.py:89-95, 102-117 behind the per-sample embedding
+        P = self.output_ch
+        n_ray = h_local.shape[0] // P
+        dirs = rays_d.reshape(n_ray, P, -1)[:, 0, :]
+        enc = self.ray_dirs_embed_fn(dirs / torch.norm(dirs, dim=-1, keepdim=True))
+        view = enc if view_feature is None else torch.cat([view_feature, enc], -1)
+        h = scan_as_written(h_local, z_vals, rays_d).reshape(n_ray, P, -1)
         h = torch.cat([h, view.unsqueeze(1).repeat(1, P, 1)], -1)
         for l in self.motion_feature_embed_layer:
             h = torch.relu(l(h))

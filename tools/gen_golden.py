@@ -928,6 +928,60 @@ def G22_mam():
     save("G22_mam", **res)
 
 
+def G27_awp_per_ray():
+    """AdaptiveWeightProposal.forward (networks/dpnerf/awp.py:79-117) in training mode with the REAL MotionAggregationModule
+    (mam.py:56-83): the whole forward as the reference runs it, from depth_feature.  A forward pre-hook on MAM captures its two inputs
+    (x_global = the motion embedding's output, x_local = h_local, the ReLU output of the per-sample embedding); torch.autograd gradients
+    of a fixed projection of the proposal weights w.r.t. h_local, rays_d, view_feature and every parameter behind the per-sample
+    embedding (motion_feature_embed_layer, MAM.*, w_linear).  BatchNorm (Corr.convd.1) runs on the batch statistics and updates its
+    running estimates (stored after the step); `out_eval` is the same module in eval mode afterwards (running estimates)."""
+    from networks.dpnerf.awp import AdaptiveWeightProposal
+    torch.manual_seed(27)
+    M, VF = 3, 5
+    awp = AdaptiveWeightProposal(input_ch=128, num_motion=M, D_sam=4, W_sam=64, D_mot=1, W_mot=32, dir_freq=2, rgb_freq=2,
+                                 depth_freq=3, ray_dir_freq=2, view_feature_ch=VF)
+    awp.load_state_dict({k: t(v) for k, v in W.make_awp_embed_state_dict(271).items()}, strict=False)
+    rs = np.random.RandomState(272)
+    bn = awp.MAM.Corr.convd[1]
+    with torch.no_grad():                                      # a BatchNorm that is not at its initial values
+        bn.weight.copy_(t(rs.uniform(0.5, 1.5, 32).astype(np.float32)))
+        bn.bias.copy_(t((rs.standard_normal(32) * 0.2).astype(np.float32)))
+        bn.running_mean.copy_(t((rs.standard_normal(32) * 0.1).astype(np.float32)))
+        bn.running_var.copy_(t(rs.uniform(0.5, 2.0, 32).astype(np.float32)))
+        for conv, k in ((awp.MAM.Corr.conva, 8.0), (awp.MAM.Corr.convb, 8.0), (awp.MAM.Corr.convc, 8.0), (awp.MAM.Corr.line_conv_att, 30.0)):
+            conv.weight.mul_(k)                                # attention logits of order 1 (at the initial scale both softmaxes are uniform to 1e-3)
+    sd_before = {k: n(v).copy() for k, v in awp.state_dict().items() if not k.startswith("sample_feature_embed_layer")}
+    awp.train()
+    R, P, S = 7, M + 1, 24
+    depth_feature = (rs.standard_normal((R * P, S, 128)) * 2.5).astype(np.float32)
+    z = np.sort(rs.uniform(0, 1, (R * P, S)).astype(np.float32), -1)
+    rays_d = rs.standard_normal((R * P, 3)).astype(np.float32)
+    view_feature = rs.standard_normal((R, VF)).astype(np.float32)
+    proj = rs.standard_normal((R, P)).astype(np.float32)
+    cap = {}
+    hk = awp.MAM.register_forward_pre_hook(lambda m, i: cap.update(x_global=i[0], h_local=i[1]))
+    names = [k for k, _ in awp.named_parameters() if not k.startswith("sample_feature_embed_layer") and not k.startswith("MAM.conv.")]
+    pd = dict(awp.named_parameters())
+    with torch.enable_grad():
+        rd, vf = t(rays_d).requires_grad_(True), t(view_feature).requires_grad_(True)
+        out = awp(t(depth_feature), t(z), rd, vf)
+        loss = (out * t(proj)).sum()
+        grads = torch.autograd.grad(loss, [cap["h_local"], rd, vf] + [pd[k] for k in names], allow_unused=True)
+    hk.remove()
+    res = {"z": z, "rays_d": rays_d, "view_feature": view_feature, "proj": proj, "h_local": n(cap["h_local"]), "x_global": n(cap["x_global"]),
+           "out": n(out), "g.h_local": n(grads[0]), "g.rays_d": n(grads[1]), "g.view_feature": n(grads[2])}
+    for k, g in zip(names, grads[3:]):
+        if g is not None:                                      # (Corr.line_conv_att, MAM.linear: reached through the per-sample part too)
+            res["g." + k] = n(g)
+    for k, v in sd_before.items():
+        res["sd." + k] = v
+    for k in ("running_mean", "running_var", "num_batches_tracked"):
+        res["after." + k] = n(getattr(bn, k))
+    awp.eval()
+    res["out_eval"] = n(awp(t(depth_feature), t(z), t(rays_d), t(view_feature)))
+    save("G27_awp_per_ray", **res)
+
+
 def G26_sample_events():
     """EventsDataset.sample_events (data/loader_events.py:259-304).  The class itself cannot be imported (np.bool under numpy 2, h5py);
     its two branches are the reference's own functions composed as the method composes them: compute_successor for the table's last
@@ -995,7 +1049,7 @@ ALL = [G1_embedder, G2_nerf_mlp, G3_nerf_raw2outputs, G4_voxel_raw2outputs, G5_s
        G7_render_nerf, G8_appfeature, G9_render_c2f, G10_rbk_weighted_sum, G11_crf, G12_egm_loss, G13_edi,
        G14_loss_assembly, G15_awp_feature_integration, G16_rbk_warp, G17_compute_successor, G18_nerf_grads, G19_c2f_grads, G20_loss_grads,
        G21_awp_sample_embed, G22_mam, G23_render_nerf_no_viewdirs, G24_render_other_multires, G25_pbe_composite_feature,
-       G26_sample_events]
+       G26_sample_events, G27_awp_per_ray]
 
 if __name__ == "__main__":
     want = set(sys.argv[1:])
