@@ -54,6 +54,11 @@ class AwpEmbedGrads(C.Structure):
     _fields_ = [("w", _vp * 4), ("b", _vp * 4)]
 
 
+class AwpTailDesc(C.Structure):
+    _fields_ = [("P", C.c_int), ("S", C.c_int), ("VF", C.c_int), ("dir_freqs", C.c_int), ("n_mot", C.c_int), ("training", C.c_int),
+                ("bn_eps", C.c_float), ("bn_momentum", C.c_float)]
+
+
 class VoxelGridGrads(C.Structure):
     _fields_ = [("plane", _vp * 3), ("line", _vp * 3), ("basis", _vp)]
 
@@ -91,6 +96,12 @@ SIGNATURES = {
     "evd_awp_feature_integration_bwd": (_I, [_vp, _vp, _vp, _vp, _L, _I, _I, _vp, _vp, _vp, _vp]),
     "evd_mam_local_forward": (_I, [_vp, _vp, _L, _I, _I, _I, _vp, _vp, _vp, _vp, _vp]),
     "evd_mam_local_backward": (_I, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _L, _I, _I, _I, _vp, _vp, _vp]),
+    "evd_awp_tail_num_params": (_I, [_I]),
+    "evd_awp_tail_param_count": (_L, [C.POINTER(AwpTailDesc)]),
+    "evd_awp_tail_workspace_bytes": (_S, [C.POINTER(AwpTailDesc), _L, _I]),
+    "evd_awp_tail_forward": (_I, [C.POINTER(AwpTailDesc), C.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _L, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _S, _vp]),
+    "evd_awp_tail_backward": (_I, [C.POINTER(AwpTailDesc), C.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _L, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                   _vp, _vp, _vp, _S, _vp]),
     "evd_awp_embed_create": (_I, [C.POINTER(_fp), C.POINTER(_fp), _I, _I, _I, C.POINTER(_vp)]),
     "evd_awp_embed_destroy": (None, [_vp]),
     "evd_awp_embed_param_count": (_L, [_vp]),

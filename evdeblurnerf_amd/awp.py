@@ -138,6 +138,73 @@ def mam_local(h_local, linear_weight, att_weight, R, P, S):
     return _MamLocal.apply(h_local, u.reshape(-1), R, P, S)
 
 
+class _AwpTail(torch.autograd.Function):
+    """evd_awp_tail_forward / _backward: the per-ray remainder of the proposal (awp.py:89-95, 104-117; mam.py:35-53) on the library's
+    kernels.  cfg = (P, S, VF, dir_freqs, n_mot, training, eps, momentum); bn = (running_mean, running_var, num_batches_tracked) or
+    Nones; params in the order include/evdnerf.h documents."""
+
+    @staticmethod
+    def forward(ctx, cfg, bn, h, view_feature, rays_d, h_inter, h_intra, *params):
+        P, S, VF, F, n_mot, training, eps, mom = cfg
+        desc = L.AwpTailDesc(P=P, S=S, VF=VF, dir_freqs=F, n_mot=n_mot, training=int(training), bn_eps=eps, bn_momentum=mom)
+        dev = h.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        hh, rd, hi, hs = (t.contiguous().float() for t in (h, rays_d, h_inter, h_intra))
+        vf = view_feature.contiguous().float() if VF else None
+        R = hh.shape[0]
+        ps = [t.detach().contiguous().float() for t in params]
+        arr = (C.c_void_p * len(ps))(*[t.data_ptr() for t in ps])
+        lib = L.lib()
+        out, y, xg = torch.empty((R, P), **f32), torch.empty((R, P, 32), **f32), torch.empty((R, P, 32), **f32)
+        stats = torch.empty((64,), **f32)
+        need = lib.evd_awp_tail_workspace_bytes(C.byref(desc), R, 0)
+        ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+        rm, rv, nb = bn
+        L.check(lib.evd_awp_tail_forward(C.byref(desc), arr, L.ptr(hh), L.ptr(vf), L.ptr(rd), L.ptr(hi), L.ptr(hs), R, L.ptr(rm), L.ptr(rv),
+                                         L.ptr(nb), L.ptr(out), L.ptr(y), L.ptr(xg), L.ptr(stats), L.ptr(ws), need, L.stream_ptr()),
+                "evd_awp_tail_forward")
+        ctx.save_for_backward(hh, vf, rd, hi, hs, y, xg, stats, *ps)
+        ctx.desc, ctx.shapes = desc, (h.shape, None if view_feature is None else view_feature.shape, rays_d.shape, h_inter.shape, h_intra.shape,
+                                      [t.shape for t in params])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        hh, vf, rd, hi, hs, y, xg, stats, *ps = ctx.saved_tensors
+        desc, lib, dev = ctx.desc, L.lib(), hh.device
+        R = hh.shape[0]
+        arr = (C.c_void_p * len(ps))(*[t.data_ptr() for t in ps])
+        total = lib.evd_awp_tail_param_count(C.byref(desc))
+        d_h, d_rd, d_hi, d_hs = torch.empty_like(hh), torch.empty_like(rd), torch.empty_like(hi), torch.empty_like(hs)
+        d_vf = torch.empty_like(vf) if vf is not None else None
+        d_par = torch.empty((total,), dtype=torch.float32, device=dev)
+        need = lib.evd_awp_tail_workspace_bytes(C.byref(desc), R, 1)
+        ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+        L.check(lib.evd_awp_tail_backward(C.byref(desc), arr, L.ptr(hh), L.ptr(vf), L.ptr(rd), L.ptr(hi), L.ptr(hs), R, L.ptr(y), L.ptr(xg),
+                                          L.ptr(stats), L.ptr(g.contiguous().float()), L.ptr(d_h), L.ptr(d_vf), L.ptr(d_rd), L.ptr(d_hi),
+                                          L.ptr(d_hs), L.ptr(d_par), L.ptr(ws), need, L.stream_ptr()), "evd_awp_tail_backward")
+        sh = ctx.shapes
+        grads = [t.reshape(s) for t, s in zip(d_par.split([int(torch.Size(s).numel()) for s in sh[5]]), sh[5])]
+        return (None, None, d_h.reshape(sh[0]), None if d_vf is None else d_vf.reshape(sh[1]), d_rd.reshape(sh[2]), d_hi.reshape(sh[3]),
+                d_hs.reshape(sh[4]), *grads)
+
+
+def _dir_freqs(fn):
+    """number of frequencies F if fn is the reference's get_embedder encoding of a direction (embedding.py:65-113: [d, sin(2^k d), cos(2^k d)
+    for k < F]), found by evaluating it on a probe; None for anything else (the encoding then runs in torch, its columns go in as view_feature)"""
+    try:
+        with torch.no_grad():
+            x = torch.tensor([[0.3, -0.5, 0.8], [-0.1, 0.7, 0.2]])
+            e = fn(x)
+            F = (e.shape[-1] // 3 - 1) // 2
+            if e.shape[-1] != 3 + 6 * F or not 0 <= F <= 4:
+                return None
+            want = torch.cat([x] + [f(x * 2.0 ** k) for k in range(F) for f in (torch.sin, torch.cos)], -1)
+            return F if torch.allclose(e.float().cpu(), want, atol=1e-6) else None
+    except Exception:
+        return None
+
+
 class SampleFeatureEmbed:
     """sample_feature_embed_layer (awp.py:36-37) as a library handle: weights[l] [64, in_l], biases[l] [64] (nn.Linear layouts)."""
 
@@ -227,8 +294,12 @@ class FusedAWP(torch.nn.Module):
     `depth_feature` is the GeoFragments handle NeRFAll.forward_train passes when its awpnet is a FusedAWP (a float32 tensor
     [R P, S, 128] is accepted too)."""
 
-    def __init__(self, awpnet, precision="f16", graph_per_ray=False):
-        """graph_per_ray: run the PER-RAY remainder (awp.py:105-117 + mam.py:35-53: ~100 launches of [R, 32, P] / [R, 32, S]-sized
+    def __init__(self, awpnet, precision="f16", graph_per_ray=False, tail_kernels=True):
+        """tail_kernels (default): the per-ray remainder (awp.py:89-95, 104-117, mam.py:35-53) on evd_awp_tail_forward / _backward -- two
+        launches forward, three backward -- whenever the wrapped module has the reference's structure (Linear motion embedding of width 32,
+        MotionAggregationModule with Corr / linear, BatchNorm1d with a momentum) and the ray's working set fits the LDS; otherwise, and with
+        tail_kernels=False, the channel-last torch path below.
+        graph_per_ray: run the PER-RAY remainder (awp.py:105-117 + mam.py:35-53: ~100 launches of [R, 32, P] / [R, 32, S]-sized
         tensors forward, twice that backward -- launch-bound, not compute-bound) as ONE captured hipGraph each way
         (torch.cuda.make_graphed_callables on a module that shares the wrapped module's parameters; built per (rays, P, S) shape on
         first use).  The arithmetic is the wrapped module's own; BatchNorm statistics update inside the graph."""
@@ -239,6 +310,60 @@ class FusedAWP(torch.nn.Module):
         self.output_ch = awpnet.output_ch
         self.graph_per_ray = bool(graph_per_ray)
         self._graphed = {}
+        self.tail_kernels = bool(tail_kernels) and not self.graph_per_ray and self._tail_structure()
+        self._F = _dir_freqs(awpnet.ray_dirs_embed_fn) if self.tail_kernels else None
+        self._tail_refused = set()
+
+    def _tail_structure(self):
+        """does the wrapped module have the layers evd_awp_tail_* is built for (the shipped configs' AdaptiveWeightProposal)?"""
+        m, nn = self.ref, torch.nn
+        try:
+            mot, corr, lin = list(m.motion_feature_embed_layer), m.MAM.Corr, m.MAM.linear
+            bn = corr.convd[1]
+            ok = 1 <= len(mot) <= 4 and all(isinstance(l, nn.Linear) and l.out_features == 32 and l.bias is not None for l in mot)
+            ok = ok and all(l.in_features == 32 for l in mot[1:]) and self.embed.width == 64 and mot[0].in_features >= 64
+            ok = ok and isinstance(lin, nn.Linear) and tuple(lin.weight.shape) == (32, 64) and lin.bias is not None
+            ok = ok and all(tuple(getattr(corr, k).weight.shape) == (16, 32, 1) and getattr(corr, k).bias is None for k in ("conva", "convb", "convc"))
+            ok = ok and all(tuple(getattr(corr, k).weight.shape) == (16, 16, 1) and getattr(corr, k).bias is None for k in ("convn", "convl"))
+            ok = ok and tuple(corr.convd[0].weight.shape) == (32, 32, 1) and corr.convd[0].bias is None
+            ok = ok and isinstance(bn, nn.BatchNorm1d) and bn.num_features == 32 and bn.affine and bn.momentum is not None
+            ok = ok and isinstance(m.w_linear, nn.Linear) and tuple(m.w_linear.weight.shape) == (self.ref.output_ch, 32) and m.w_linear.bias is not None
+            return bool(ok) and self.ref.output_ch <= 16
+        except (AttributeError, IndexError, TypeError):
+            return False
+
+    def _tail_params(self):
+        m = self.ref
+        corr = m.MAM.Corr
+        ps = [t for l in m.motion_feature_embed_layer for t in (l.weight, l.bias)] + [m.MAM.linear.weight, m.MAM.linear.bias]
+        ps += [getattr(corr, k).weight for k in ("conva", "convb", "convc", "convn", "convl")]
+        return ps + [corr.convd[0].weight, corr.convd[1].weight, corr.convd[1].bias, m.w_linear.weight, m.w_linear.bias]
+
+    def _tail(self, h, view_feature, rays_d, h_inter, h_intra, n_ray, P, S):
+        """-> the proposal weights [R, P] on the kernels, or None when the library refuses the shape (then the caller runs the torch path)"""
+        m = self.ref
+        bn = m.MAM.Corr.convd[1]
+        vf, F = view_feature, self._F
+        if F is None:                                                       # an encoding the kernel does not know: its columns as view_feature
+            dirs = rays_d.reshape(n_ray, P, -1)[:, 0, :]
+            enc = m.ray_dirs_embed_fn((dirs / torch.norm(dirs, dim=-1, keepdim=True)).reshape(-1, 3).float())
+            vf, F = (enc if vf is None else torch.cat([vf, enc], dim=-1)), -1
+        VF = 0 if vf is None else vf.shape[-1]
+        n_mot = len(m.motion_feature_embed_layer)
+        training = bn.training or bn.running_mean is None
+        key = (P, S, VF, F, n_mot)
+        if key in self._tail_refused or VF > 64 or m.motion_feature_embed_layer[0].in_features != 64 + VF + (3 + 6 * F if F >= 0 else 0):
+            return None
+        track = bn.running_mean is not None and (not training or bn.track_running_stats)
+        bufs = (bn.running_mean, bn.running_var, bn.num_batches_tracked if training else None) if track else (None, None, None)
+        cfg = (P, S, VF, F, n_mot, training, float(bn.eps), float(bn.momentum))
+        try:
+            return _AwpTail.apply(cfg, bufs, h, vf, rays_d, h_inter, h_intra, *self._tail_params())
+        except L.EvdError as e:
+            if "LDS" not in str(e):
+                raise
+            self._tail_refused.add(key)                                     # (the check runs before any launch: nothing was computed)
+            return None
 
     @property
     def ccw_fine_scale(self):
@@ -287,13 +412,22 @@ class FusedAWP(torch.nn.Module):
     def forward(self, depth_feature, z_vals, rays_d, view_feature):
         m, P = self.ref, self.output_ch
         n_ray, S = z_vals.shape[0] // P, z_vals.shape[-1]
+        mam = m.MAM
+        known = getattr(mam, "Corr", None) is not None and getattr(mam, "linear", None) is not None and self.embed.width == 64 and P <= 16 and S <= 512
+        if self.tail_kernels and known and rays_d.is_cuda:                        # everything behind the embedding on the library
+            h_local = self.embed(self._flat(), depth_feature).reshape(n_ray * P, S, self.embed.width)
+            h = feature_integration(h_local.reshape(n_ray, P, S, -1), z_vals, rays_d)
+            h_inter, h_intra = mam_local(h_local, mam.linear.weight, mam.Corr.line_conv_att.weight, n_ray, P, S)
+            out = self._tail(h, view_feature, rays_d, h_inter, h_intra, n_ray, P, S)
+            if out is not None:
+                return out
         dirs = rays_d.reshape(n_ray, P, -1)[:, 0, :]
         dirs = (dirs / torch.norm(dirs, dim=-1, keepdim=True)).reshape(-1, 3).float()
         view = m.ray_dirs_embed_fn(dirs)                                          # awp.py:89-95
         if view_feature is not None:
             view = torch.cat([view_feature, view], dim=-1)
-        mam = m.MAM
-        known = getattr(mam, "Corr", None) is not None and getattr(mam, "linear", None) is not None and self.embed.width == 64 and P <= 16 and S <= 512
+        if self.tail_kernels and known and rays_d.is_cuda:                        # (the library refused the shape: the torch remainder)
+            return self._per_ray(h, view, None, n_ray, P, S, h_inter, h_intra)
         graphed = self.graph_per_ray and known and view.is_cuda and torch.is_grad_enabled()
         if graphed:      # capture BEFORE this forward touches the module's parameters on the caller's stream (a live autograd graph that holds
             # their AccumulateGrad nodes on another stream breaks the capture of the backward graph)

@@ -21,7 +21,7 @@ LIB = os.path.join(LIBDIR, "libevdnerf.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
-# Per-file flags.  The one-wavefront-per-SIMD MLP kernels (f16c: 386 registers, f16x3: 420) keep part of their state in AGPRs; by default
+# Per-file flags.  The one-wavefront-per-SIMD MLP kernels (f16c: 494 registers, f16x3: 420) keep part of their state in AGPRs; by default
 # hipcc puts the MFMA accumulators there, and every epilogue value then costs a v_accvgpr_read (plus a write-back for the values that stay).
 # With the MFMAs in VGPR form the accumulators live in VGPRs and the MFMA-only operands (fp6 blocks, weight fragments) go to the AGPRs, which
 # the matrix core reads directly: f16c 5708 -> 4802 VALU instructions per wavefront, 0.879 -> 0.857 ms; f16x3 1.58 -> 1.53 ms

@@ -1,0 +1,891 @@
+// AWP consumer, the PER-RAY remainder of the adaptive weight proposal: reference networks/dpnerf/awp.py:89-95 (direction
+// encoding), :104-109 (motion_feature_embed_layer), networks/dpnerf/mam.py:35-53 (CorrelationModule.forward behind its per-sample part)
+// and awp.py:112-115 (mean over the sub-exposures, w_linear, sigmoid, normalisation).  The reference runs ~100 launches of
+// [R, 32, P]- and [R, 32, S]-sized tensors each way; here a workgroup owns a ray, keeps every intermediate of that ray in LDS
+// (P <= 16 sub-exposures x 32 channels, S samples x 32 / 16 channels) and walks the whole chain:
+//
+//   forward   k_awp_tail_fwd     per ray: x_global, attention over P and over S, convd -> y [R,P,32]; per-workgroup sums of y, y^2 (double)
+//             k_awp_tail_finish  folds the sums into the BatchNorm statistics (over ALL rays), running estimates, then per ray:
+//                                normalise, residual, leaky_relu, mean over P, w_linear, sigmoid, normalise -> out [R,P]
+//   backward  k_awp_tail_bwd0    per ray: d out -> d z [R,P,32]; partial sums of d gamma, d beta, d w_linear
+//             k_awp_tail_bwd     per ray: BatchNorm backward with the folded sums, the forward recomputed in LDS, the chain backwards;
+//                                input gradients to HBM, parameter gradients added into the workgroup's partial row
+//             k_awp_tail_reduce  the partial rows -> d_params
+//
+// float32 on the vector ALU throughout (0.45 M multiply-adds per ray forward: the matrix cores have nothing to win at these shapes);
+// the per-sample-sized products (MAM.linear / convb / convl on [S, 64 -> 32 -> 16 -> 16]) run one sample row per lane pair with the row
+// in registers and the weights as LDS broadcasts; everything P-sized goes through one strided helper.
+#include "evd_common.h"
+#include "wave_ops.h"
+
+namespace evd {
+
+constexpr int AT_WS = 64, AT_CM = 32, AT_MID = 16, AT_MAXP = 16, AT_MAXMOT = 4, AT_NT = 256, AT_MAXW = 2 * AT_MAXMOT + 12;
+constexpr int AT_LS = AT_CM + 1, AT_LK = AT_MID + 1;      // padded row strides of the per-sample LDS arrays (conflict-free row writes)
+
+struct TailDims {
+    int P, S, VF, F, VC, IN0, n_mot, SA;                  // VC = view columns (VF + direction encoding), IN0 = 64 + VC, SA = S + 1
+};
+
+__host__ __device__ inline TailDims tail_dims(int P, int S, int VF, int F, int n_mot) {
+    TailDims d;
+    d.P = P; d.S = S; d.VF = VF; d.F = F; d.n_mot = n_mot;
+    d.VC = VF + (F >= 0 ? 3 + 6 * F : 0);
+    d.IN0 = AT_WS + d.VC;
+    d.SA = S + 1;
+    return d;
+}
+
+// parameter tensors in API order; sizes in floats
+__host__ __device__ inline int tail_param_size(const TailDims& d, int i) {
+    if (i < 2 * d.n_mot) return (i & 1) ? AT_CM : AT_CM * (i == 0 ? d.IN0 : AT_CM);
+    switch (i - 2 * d.n_mot) {
+        case 0: return AT_CM * AT_WS;      // MAM.linear.weight
+        case 1: return AT_CM;              // MAM.linear.bias
+        case 2: case 3: case 4: return AT_MID * AT_CM;      // conva, convb, convc
+        case 5: case 6: return AT_MID * AT_MID;             // convn, convl
+        case 7: return AT_CM * AT_CM;      // convd.0
+        case 8: case 9: return AT_CM;      // convd.1 weight, bias
+        case 10: return d.P * AT_CM;       // w_linear.weight
+        default: return d.P;               // w_linear.bias
+    }
+}
+enum { TW_LIN_W = 0, TW_LIN_B, TW_CONVA, TW_CONVB, TW_CONVC, TW_CONVN, TW_CONVL, TW_CONVD, TW_BN_W, TW_BN_B, TW_WL_W, TW_WL_B, TW_COUNT };
+
+struct TailLds {
+    float *mw0, *mb0, *mwr, *lin_w, *lin_b, *conva, *convb, *convc, *convn, *convl, *convd;      // mwr: layers 1.. as (W [32,32], b [32]) records
+    float *x0, *xs0, *hi, *li, *kP, *nP, *q, *aP, *f, *yb;                                         // xs0: the layers' outputs, [n_mot][P][32]
+    int xs_stride;
+    __host__ __device__ float* mw(int l) const { return l == 0 ? mw0 : mwr + (l - 1) * (AT_CM * AT_CM + AT_CM); }
+    __host__ __device__ float* mb(int l) const { return l == 0 ? mb0 : mwr + (l - 1) * (AT_CM * AT_CM + AT_CM) + AT_CM * AT_CM; }
+    __host__ __device__ float* xs(int l) const { return xs0 + l * xs_stride; }
+    float *ls, *kI, *nI, *aS;
+    float *df, *daP, *dnP, *dkP, *dq, *dli, *dxa, *dxb, *daS, *dkI, *dls, *tmp;
+};
+
+// one layout for the host (size) and the device (pointers); every array starts 16-byte aligned
+__host__ __device__ inline size_t tail_lds_layout(float* base, const TailDims& d, bool bwd, TailLds& L) {
+    size_t at = 0;
+    auto take = [&](size_t n) { float* p = base + at; at += (n + 3) & ~(size_t)3; return p; };
+    L.mw0 = take((size_t)AT_CM * d.IN0); L.mb0 = take(AT_CM);
+    L.mwr = take((size_t)(d.n_mot - 1) * (AT_CM * AT_CM + AT_CM));
+    L.lin_w = take(AT_CM * AT_WS); L.lin_b = take(AT_CM);
+    L.conva = take(AT_MID * AT_CM); L.convb = take(AT_MID * AT_CM); L.convc = take(AT_MID * AT_CM);
+    L.convn = take(AT_MID * AT_MID); L.convl = take(AT_MID * AT_MID); L.convd = take(AT_CM * AT_CM);
+    const size_t P = d.P;
+    L.x0 = take(P * d.IN0);
+    L.xs_stride = (int)(P * AT_CM);
+    L.xs0 = take((size_t)d.n_mot * P * AT_CM);
+    L.hi = take(P * AT_WS); L.li = take(P * AT_CM); L.kP = take(P * AT_MID); L.nP = take(P * AT_MID); L.q = take(P * AT_MID);
+    L.aP = take(P * P); L.f = take(P * AT_CM); L.yb = take(P * AT_CM);
+    L.ls = take((size_t)d.S * AT_LS); L.kI = take((size_t)d.S * AT_LK); L.nI = take((size_t)d.S * AT_LK); L.aS = take(P * d.SA);
+    L.df = L.daP = L.dnP = L.dkP = L.dq = L.dli = L.dxa = L.dxb = L.daS = L.dkI = L.dls = L.tmp = nullptr;
+    if (bwd) {
+        const size_t wide = d.IN0 > AT_WS ? d.IN0 : AT_WS;
+        L.df = take(P * AT_CM); L.daP = take(P * P); L.dnP = take(P * AT_MID); L.dkP = take(P * AT_MID); L.dq = take(P * AT_MID);
+        L.dli = take(P * AT_CM); L.dxa = take(P * wide); L.dxb = take(P * wide);
+        L.daS = take(P * d.SA); L.dkI = take((size_t)d.S * AT_LK); L.dls = take((size_t)d.S * AT_LS); L.tmp = take(64);
+    }
+    return at;
+}
+
+struct TailKParams {
+    const float* w[AT_MAXW];
+    long off[AT_MAXW + 1];             // offsets of the tensors in the flat gradient buffer; [nw] = total
+    TailDims d;
+    int training, nw;
+    float eps, momentum;
+    long R;
+    const float *h, *vf, *rays_d, *h_inter, *h_intra;
+    float *y, *xg;                     // [R, P, 32] (forward: written; backward: read)
+    double* bn_part;                   // forward: [grid][64] sums of y, y^2
+    const float *dz, *stats, *partB;   // backward
+    int nblkB, partB_stride;
+    float *d_h, *d_vf, *d_rays, *d_hi, *d_hs, *partA;
+};
+
+// out[m som + n] (+)= act(bias[n] + sum_k A[m sam + k sak] B[n sbn + k sbk]);  rot: lane n starts its k loop at n mod K, so that lanes reading
+// consecutive rows of a row-major B whose row length is even hit different LDS banks
+template <int ACT, bool ACC>
+__device__ __forceinline__ void mm(float* out, int som, const float* A, int sam, int sak, const float* B, int sbn, int sbk, const float* bias,
+                                   int M, int N, int K, bool rot = false) {
+    for (int i = threadIdx.x; i < M * N; i += AT_NT) {
+        const int m = i / N, n = i - m * N;
+        float acc = bias ? bias[n] : 0.f;
+        int k = rot ? n % K : 0;
+        for (int kk = 0; kk < K; ++kk) {
+            acc = fmaf(A[m * sam + k * sak], B[n * sbn + k * sbk], acc);
+            if (++k == K) k = 0;
+        }
+        if (ACT == 1) acc = fmaxf(acc, 0.f);
+        if (ACC) out[m * som + n] += acc;
+        else out[m * som + n] = acc;
+    }
+}
+// y = x W^T (+ b) with W [N, K] row-major (nn.Linear / 1x1 convolution)
+template <int ACT>
+__device__ __forceinline__ void lin(float* out, int som, const float* x, int ldx, const float* W, const float* b, int M, int N, int K) {
+    mm<ACT, false>(out, som, x, ldx, 1, W, K, 1, b, M, N, K, !(K & 1));
+}
+// part[n K + k] += sum_m G[m sgm + n] X[m sxm + k]  (weight gradient of y = x W^T; an element is always added by the same lane)
+__device__ __forceinline__ void wacc(float* part, const float* G, int sgm, const float* X, int sxm, int M, int N, int K) {
+    for (int i = threadIdx.x; i < N * K; i += AT_NT) {
+        const int n = i / K, k = i - n * K;
+        float acc = 0.f;
+        for (int m = 0; m < M; ++m) acc = fmaf(G[m * sgm + n], X[m * sxm + k], acc);
+        part[i] += acc;
+    }
+}
+__device__ __forceinline__ void bacc(float* part, const float* G, int sgm, int M, int N) {
+    for (int n = threadIdx.x; n < N; n += AT_NT) {
+        float acc = 0.f;
+        for (int m = 0; m < M; ++m) acc += G[m * sgm + n];
+        part[n] += acc;
+    }
+}
+__device__ __forceinline__ float wave_max(float v) {
+    for (int o = 32; o; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+// softmax of every row, in place; a wavefront per row
+__device__ __forceinline__ void softmax_row(float* a, int n) {
+    const int lane = threadIdx.x & 63;
+    float m = -INFINITY, t = 0.f;
+    for (int j = lane; j < n; j += 64) m = fmaxf(m, a[j]);
+    m = wave_max(m);
+    for (int j = lane; j < n; j += 64) t += expf(a[j] - m);
+    t = wave_sum_dpp(t);
+    for (int j = lane; j < n; j += 64) a[j] = expf(a[j] - m) / t;
+}
+// d logit = a (d a - sum a d a), in place of d a
+__device__ __forceinline__ void softmax_row_bwd(const float* a, float* da, int n) {
+    const int lane = threadIdx.x & 63;
+    float c = 0.f;
+    for (int j = lane; j < n; j += 64) c = fmaf(a[j], da[j], c);
+    c = wave_sum_dpp(c);
+    for (int j = lane; j < n; j += 64) da[j] = a[j] * (da[j] - c);
+}
+
+__device__ __forceinline__ void tail_stage_weights(const TailKParams& p, const TailLds& L) {
+    const TailDims& d = p.d;
+    auto copy = [&](float* dst, const float* src, int n) { for (int i = threadIdx.x; i < n; i += AT_NT) dst[i] = src[i]; };
+    for (int l = 0; l < d.n_mot; ++l) {
+        copy(L.mw(l), p.w[2 * l], tail_param_size(d, 2 * l));
+        copy(L.mb(l), p.w[2 * l + 1], AT_CM);
+    }
+    const float* const* w = p.w + 2 * d.n_mot;
+    copy(L.lin_w, w[TW_LIN_W], AT_CM * AT_WS); copy(L.lin_b, w[TW_LIN_B], AT_CM);
+    copy(L.conva, w[TW_CONVA], AT_MID * AT_CM); copy(L.convb, w[TW_CONVB], AT_MID * AT_CM); copy(L.convc, w[TW_CONVC], AT_MID * AT_CM);
+    copy(L.convn, w[TW_CONVN], AT_MID * AT_MID); copy(L.convl, w[TW_CONVL], AT_MID * AT_MID); copy(L.convd, w[TW_CONVD], AT_CM * AT_CM);
+}
+
+// The forward of one ray into LDS (both the forward kernel and the backward, which recomputes it).  On return (after the final
+// barrier): x0, xs[], hi, li, kP, nP, q, aP, ls, kI, nI, aS, f, yb (= convd f, the BatchNorm's input).
+__device__ __forceinline__ void tail_forward_ray(const TailKParams& p, const TailLds& L, long r) {
+    const TailDims& d = p.d;
+    const int tid = threadIdx.x, P = d.P, S = d.S;
+    // awp.py:89-95, 104-105: [integrated features | view_feature | direction encoding of the first sub-exposure's ray]
+    for (int i = tid; i < P * AT_WS; i += AT_NT) {
+        const int pp = i >> 6, k = i & 63;
+        L.x0[pp * d.IN0 + k] = p.h[r * P * AT_WS + i];
+        L.hi[i] = p.h_inter[r * P * AT_WS + i];
+    }
+    for (int i = tid; i < P * d.VC; i += AT_NT) {
+        const int pp = i / d.VC, j = i - pp * d.VC;
+        float v;
+        if (j < d.VF) v = p.vf[r * d.VF + j];
+        else {
+            const int e = j - d.VF, axis = e % 3, blk = e / 3;          // blk 0: the direction; 1 + 2 k: sin(2^k d); 2 + 2 k: cos(2^k d)
+            const float* rd = p.rays_d + r * P * 3;
+            const float dn = rd[axis] / sqrtf(rd[0] * rd[0] + rd[1] * rd[1] + rd[2] * rd[2]);
+            if (blk == 0) v = dn;
+            else {
+                const float arg = dn * (float)(1 << ((blk - 1) >> 1));
+                v = ((blk - 1) & 1) ? cosf(arg) : sinf(arg);
+            }
+        }
+        L.x0[pp * d.IN0 + AT_WS + j] = v;
+    }
+    __syncthreads();
+    // awp.py:107-109 (layer 0) and mam.py:72-74 applied to the per-sample part's inter sums
+    lin<1>(L.xs(0), AT_CM, L.x0, d.IN0, L.mw(0), L.mb(0), P, AT_CM, d.IN0);
+    lin<0>(L.li, AT_CM, L.hi, AT_WS, L.lin_w, L.lin_b, P, AT_CM, AT_WS);
+    // ... and to the intra sums: one sample row per lane pair, 16 of the 32 outputs each
+    const int sl = tid >> 1, hf = tid & 1;
+    for (int s0 = 0; s0 < S; s0 += AT_NT / 2) {
+        const int s = s0 + sl;
+        if (s < S) {
+            float x[AT_WS];
+            const float4* x4 = reinterpret_cast<const float4*>(p.h_intra + (r * S + s) * AT_WS);
+#pragma unroll
+            for (int j = 0; j < AT_WS / 4; ++j) {
+                const float4 v = x4[j];
+                x[4 * j] = v.x; x[4 * j + 1] = v.y; x[4 * j + 2] = v.z; x[4 * j + 3] = v.w;
+            }
+#pragma unroll 4
+            for (int j = 0; j < 16; ++j) {
+                const int c = hf * 16 + j;
+                const float4* w4 = reinterpret_cast<const float4*>(L.lin_w + c * AT_WS);
+                float acc = L.lin_b[c];
+#pragma unroll
+                for (int k = 0; k < AT_WS / 4; ++k) {
+                    const float4 w = w4[k];
+                    acc = fmaf(w.x, x[4 * k], acc); acc = fmaf(w.y, x[4 * k + 1], acc);
+                    acc = fmaf(w.z, x[4 * k + 2], acc); acc = fmaf(w.w, x[4 * k + 3], acc);
+                }
+                L.ls[s * AT_LS + c] = acc;
+            }
+        }
+    }
+    __syncthreads();
+    for (int l = 1; l < d.n_mot; ++l) {
+        lin<1>(L.xs(l), AT_CM, L.xs(l - 1), AT_CM, L.mw(l), L.mb(l), P, AT_CM, AT_CM);
+        if (l == 1) lin<0>(L.kP, AT_MID, L.li, AT_CM, L.conva, nullptr, P, AT_MID, AT_CM);            // mam.py:38
+        __syncthreads();
+    }
+    if (d.n_mot == 1) {
+        lin<0>(L.kP, AT_MID, L.li, AT_CM, L.conva, nullptr, P, AT_MID, AT_CM);
+        __syncthreads();
+    }
+    const float* xg = L.xs(d.n_mot - 1);
+    lin<0>(L.q, AT_MID, xg, AT_CM, L.convc, nullptr, P, AT_MID, AT_CM);                               // mam.py:41
+    lin<0>(L.nP, AT_MID, L.kP, AT_MID, L.convn, nullptr, P, AT_MID, AT_MID);                          // mam.py:46
+    for (int s0 = 0; s0 < S; s0 += AT_NT / 2) {                                                       // mam.py:39: convb
+        const int s = s0 + sl;
+        if (s < S) {
+            float x[AT_CM];
+#pragma unroll
+            for (int c = 0; c < AT_CM; ++c) x[c] = L.ls[s * AT_LS + c];
+#pragma unroll 2
+            for (int j = 0; j < 8; ++j) {
+                const int m = hf * 8 + j;
+                const float4* w4 = reinterpret_cast<const float4*>(L.convb + m * AT_CM);
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < AT_CM / 4; ++k) {
+                    const float4 w = w4[k];
+                    acc = fmaf(w.x, x[4 * k], acc); acc = fmaf(w.y, x[4 * k + 1], acc);
+                    acc = fmaf(w.z, x[4 * k + 2], acc); acc = fmaf(w.w, x[4 * k + 3], acc);
+                }
+                L.kI[s * AT_LK + m] = acc;
+            }
+        }
+    }
+    __syncthreads();
+    mm<0, false>(L.aP, P, L.q, AT_MID, 1, L.kP, AT_MID, 1, nullptr, P, P, AT_MID);                   // mam.py:42: logits over the sub-exposures
+    for (int s0 = 0; s0 < S; s0 += AT_NT / 2) {                                                       // mam.py:47 (convl), :43 (logits over the samples)
+        const int s = s0 + sl;
+        if (s < S) {
+            float x[AT_MID];
+#pragma unroll
+            for (int c = 0; c < AT_MID; ++c) x[c] = L.kI[s * AT_LK + c];
+#pragma unroll 2
+            for (int j = 0; j < 8; ++j) {
+                const int m = hf * 8 + j;
+                const float4* w4 = reinterpret_cast<const float4*>(L.convl + m * AT_MID);
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < AT_MID / 4; ++k) {
+                    const float4 w = w4[k];
+                    acc = fmaf(w.x, x[4 * k], acc); acc = fmaf(w.y, x[4 * k + 1], acc);
+                    acc = fmaf(w.z, x[4 * k + 2], acc); acc = fmaf(w.w, x[4 * k + 3], acc);
+                }
+                L.nI[s * AT_LK + m] = acc;
+            }
+            for (int pp = hf; pp < P; pp += 2) {
+                const float4* q4 = reinterpret_cast<const float4*>(L.q + pp * AT_MID);
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < AT_MID / 4; ++k) {
+                    const float4 w = q4[k];
+                    acc = fmaf(w.x, x[4 * k], acc); acc = fmaf(w.y, x[4 * k + 1], acc);
+                    acc = fmaf(w.z, x[4 * k + 2], acc); acc = fmaf(w.w, x[4 * k + 3], acc);
+                }
+                L.aS[pp * d.SA + s] = acc;
+            }
+        }
+    }
+    __syncthreads();
+    for (int row = tid >> 6; row < 2 * P; row += AT_NT / 64) {                                        // mam.py:42-43: the softmaxes
+        if (row < P) softmax_row(L.aP + row * P, P);
+        else softmax_row(L.aS + (row - P) * d.SA, S);
+    }
+    __syncthreads();
+    mm<0, false>(L.f, AT_CM, L.aP, P, 1, L.nP, 1, AT_MID, nullptr, P, AT_MID, P);                     // mam.py:49
+    mm<0, false>(L.f + AT_MID, AT_CM, L.aS, d.SA, 1, L.nI, 1, AT_LK, nullptr, P, AT_MID, S);          // mam.py:50 (:52: the concatenation)
+    __syncthreads();
+    lin<0>(L.yb, AT_CM, L.f, AT_CM, L.convd, nullptr, P, AT_CM, AT_CM);                               // mam.py:53: convd[0]
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(AT_NT) void k_awp_tail_fwd(TailKParams p) {
+    extern __shared__ float lds[];
+    TailLds L;
+    tail_lds_layout(lds, p.d, false, L);
+    tail_stage_weights(p, L);
+    __syncthreads();
+    const int tid = threadIdx.x, P = p.d.P;
+    double s1 = 0.0, s2 = 0.0;                                   // lanes 0..31: the sums of this workgroup's y, y^2 of channel tid
+    for (long r = blockIdx.x; r < p.R; r += gridDim.x) {
+        tail_forward_ray(p, L, r);
+        const float* xg = L.xs(p.d.n_mot - 1);
+        for (int i = tid; i < P * AT_CM; i += AT_NT) {
+            p.y[r * P * AT_CM + i] = L.yb[i];
+            p.xg[r * P * AT_CM + i] = xg[i];
+        }
+        if (tid < AT_CM) {
+            float a = 0.f, b = 0.f;
+            for (int pp = 0; pp < P; ++pp) {
+                const float v = L.yb[pp * AT_CM + tid];
+                a += v;
+                b = fmaf(v, v, b);
+            }
+            s1 += (double)a;
+            s2 += (double)b;
+        }
+        __syncthreads();
+    }
+    if (tid < AT_CM) {
+        p.bn_part[(long)blockIdx.x * 2 * AT_CM + tid] = s1;
+        p.bn_part[(long)blockIdx.x * 2 * AT_CM + AT_CM + tid] = s2;
+    }
+}
+
+struct TailFinishParams {
+    const double* bn_part;
+    int nparts, P, training, nblk;
+    long R;
+    float eps, momentum;
+    const float *bn_w, *bn_b, *wl_w, *wl_b, *y, *xg;
+    float *run_mean, *run_var;
+    long long* num_batches;
+    float *stats, *out;                // stats [64]: mean, 1 / sqrt(var + eps)
+    // backward
+    const float* d_out;
+    float *dz, *partB;                 // partB [nblk][stride]: d beta [32], d gamma [32], d w_linear.weight [P, 32], d w_linear.bias [P]
+    int partB_stride;
+};
+
+constexpr int AT_FR = 8;               // rays per workgroup of the finish kernels (a ray per 32 lanes)
+
+// mam.py:53 (BatchNorm, residual, leaky_relu) and awp.py:112-115 of one ray on 32 lanes (lane = channel; called by every lane of the
+// workgroup, rays past the end compute on the last ray and write nothing); returns through LDS: sh_hm[32] the mean over P, sh_w[P] the
+// sigmoids, tot their sum
+template <bool KEEP>
+__device__ __forceinline__ void finish_ray(const TailFinishParams& p, long r, int c, const float* stat, float* sh_hm, float* sh_w, float& tot,
+                                           float (&zkeep)[AT_MAXP]) {
+    const int P = p.P;
+    const float mean = stat[c], rstd = stat[AT_CM + c], g = p.bn_w[c], b = p.bn_b[c];
+    float acc = 0.f;
+#pragma unroll
+    for (int pp = 0; pp < AT_MAXP; ++pp)
+        if (pp < P) {
+            const long at = (r * P + pp) * AT_CM + c;
+            const float z = p.xg[at] + ((p.y[at] - mean) * rstd * g + b);
+            if (KEEP) zkeep[pp] = z;
+            acc += z > 0.f ? z : 0.2f * z;
+        }
+    sh_hm[c] = acc / (float)P;
+    __syncthreads();
+    if (c < P) {
+        float a = p.wl_b[c];
+        for (int k = 0; k < AT_CM; ++k) a = fmaf(p.wl_w[c * AT_CM + k], sh_hm[k], a);
+        sh_w[c] = 1.0f / (1.0f + expf(-a));
+    }
+    __syncthreads();
+    tot = 0.f;
+    for (int j = 0; j < P; ++j) tot += sh_w[j];
+}
+
+__global__ __launch_bounds__(AT_NT) void k_awp_tail_finish(TailFinishParams p) {
+    __shared__ double red[4][2 * AT_CM];
+    __shared__ float stat[2 * AT_CM], hm[AT_FR][AT_CM], sw[AT_FR][AT_MAXP];
+    const int tid = threadIdx.x, col = tid & 63, grp = tid >> 6;
+    if (p.training) {
+        double a = 0.0;
+        for (int i = grp; i < p.nparts; i += 4) a += p.bn_part[(long)i * 2 * AT_CM + col];
+        red[grp][col] = a;
+        __syncthreads();
+        if (tid < AT_CM) {
+            const double n = (double)p.R * p.P;
+            const double s1 = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+            const double s2 = red[0][AT_CM + tid] + red[1][AT_CM + tid] + red[2][AT_CM + tid] + red[3][AT_CM + tid];
+            const double mu = s1 / n;
+            double var = s2 / n - mu * mu;
+            var = var > 0.0 ? var : 0.0;
+            stat[tid] = (float)mu;
+            stat[AT_CM + tid] = 1.0f / sqrtf((float)var + p.eps);
+            if (blockIdx.x == 0) {
+                if (p.run_mean) {                                           // BatchNorm1d's running estimates (momentum blend, unbiased variance)
+                    p.run_mean[tid] = (1.0f - p.momentum) * p.run_mean[tid] + p.momentum * (float)mu;
+                    p.run_var[tid] = (1.0f - p.momentum) * p.run_var[tid] + p.momentum * (float)(var * (n > 1.0 ? n / (n - 1.0) : 1.0));
+                }
+                if (tid == 0 && p.num_batches) *p.num_batches += 1;
+            }
+        }
+    } else if (tid < AT_CM) {
+        stat[tid] = p.run_mean[tid];
+        stat[AT_CM + tid] = 1.0f / sqrtf(p.run_var[tid] + p.eps);
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && tid < 2 * AT_CM) p.stats[tid] = stat[tid];
+    const int slot = tid >> 5, c = tid & 31;
+    const long r = (long)blockIdx.x * AT_FR + slot;
+    float tot, unused[AT_MAXP];
+    finish_ray<false>(p, r < p.R ? r : p.R - 1, c, stat, hm[slot], sw[slot], tot, unused);
+    if (r < p.R && c < p.P) p.out[r * p.P + c] = sw[slot][c] / tot;
+}
+
+// d out -> d z, and this workgroup's partial sums of d beta, d gamma (BatchNorm) and d w_linear
+__global__ __launch_bounds__(AT_NT) void k_awp_tail_bwd0(TailFinishParams p) {
+    __shared__ float stat[2 * AT_CM], hm[AT_FR][AT_CM], sw[AT_FR][AT_MAXP], dpre[AT_FR][AT_MAXP], red[AT_FR][2 * AT_CM];
+    const int tid = threadIdx.x, P = p.P;
+    if (tid < 2 * AT_CM) stat[tid] = p.stats[tid];
+    __syncthreads();
+    const int slot = tid >> 5, c = tid & 31;
+    const long r = (long)blockIdx.x * AT_FR + slot;
+    float dbeta = 0.f, dgamma = 0.f;
+    for (int j = tid; j < AT_FR * AT_MAXP; j += AT_NT) (&dpre[0][0])[j] = 0.f;
+    float tot, z[AT_MAXP];
+    finish_ray<true>(p, r < p.R ? r : p.R - 1, c, stat, hm[slot], sw[slot], tot, z);
+    if (r >= p.R) hm[slot][c] = 0.f;                           // (rays past the end add nothing to d w_linear)
+    if (r < p.R) {
+        // out_j = w_j / tot:  d w_j = (g_j - sum_k g_k out_k) / tot;  d pre_j = d w_j w_j (1 - w_j)
+        float dot = 0.f;
+        for (int j = 0; j < P; ++j) dot = fmaf(p.d_out[r * P + j], sw[slot][j] / tot, dot);
+        if (c < P) {
+            const float w = sw[slot][c];
+            dpre[slot][c] = (p.d_out[r * P + c] - dot) / tot * w * (1.0f - w);
+        }
+    }
+    __syncthreads();
+    if (r < p.R) {
+        float dhm = 0.f;
+        for (int j = 0; j < P; ++j) dhm = fmaf(dpre[slot][j], p.wl_w[j * AT_CM + c], dhm);
+        dhm /= (float)P;
+        const float mean = stat[c], rstd = stat[AT_CM + c];
+#pragma unroll
+        for (int pp = 0; pp < AT_MAXP; ++pp)
+            if (pp < P) {
+                const long at = (r * P + pp) * AT_CM + c;
+                const float dzv = z[pp] > 0.f ? dhm : 0.2f * dhm;
+                p.dz[at] = dzv;
+                dbeta += dzv;
+                dgamma = fmaf(dzv, (p.y[at] - mean) * rstd, dgamma);
+            }
+    }
+    red[slot][c] = dbeta;
+    red[slot][AT_CM + c] = dgamma;
+    __syncthreads();
+    float* part = p.partB + (long)blockIdx.x * p.partB_stride;
+    if (tid < 2 * AT_CM) {
+        float a = 0.f;
+        for (int s = 0; s < AT_FR; ++s) a += red[s][tid];
+        part[tid] = a;
+    }
+    for (int i = tid; i < P * AT_CM + P; i += AT_NT) {          // d w_linear.weight[j][k] = sum_rays d pre_j hm_k;  .bias[j] = sum d pre_j
+        float a = 0.f;
+        if (i < P * AT_CM) {
+            const int j = i / AT_CM, k = i - j * AT_CM;
+            for (int s = 0; s < AT_FR; ++s) a = fmaf(dpre[s][j], hm[s][k], a);
+        } else {
+            for (int s = 0; s < AT_FR; ++s) a += dpre[s][i - P * AT_CM];
+        }
+        part[2 * AT_CM + i] = a;
+    }
+}
+
+__global__ __launch_bounds__(AT_NT) void k_awp_tail_bwd(TailKParams p) {
+    extern __shared__ float lds[];
+    __shared__ double redd[4][2 * AT_CM];
+    __shared__ float sums[2 * AT_CM], stat[2 * AT_CM];
+    TailLds L;
+    tail_lds_layout(lds, p.d, true, L);
+    tail_stage_weights(p, L);
+    const TailDims& d = p.d;
+    const int tid = threadIdx.x, P = d.P, S = d.S, nm = d.n_mot;
+    {   // d beta, d gamma over all rays (k_awp_tail_bwd0's partial rows)
+        const int col = tid & 63, grp = tid >> 6;
+        double a = 0.0;
+        for (int i = grp; i < p.nblkB; i += 4) a += (double)p.partB[(long)i * p.partB_stride + col];
+        redd[grp][col] = a;
+        if (tid < 2 * AT_CM) stat[tid] = p.stats[tid];
+    }
+    float* part = p.partA + (long)blockIdx.x * p.off[p.nw];
+    for (long i = tid; i < p.off[p.nw]; i += AT_NT) part[i] = 0.f;
+    __syncthreads();
+    if (tid < 2 * AT_CM) sums[tid] = (float)((redd[0][tid] + redd[1][tid] + redd[2][tid] + redd[3][tid]) / ((double)p.R * P));
+    __syncthreads();
+    const long* off = p.off;
+    const int wb = 2 * nm;
+    const int sl = tid >> 1, hf = tid & 1;
+    for (long r = blockIdx.x; r < p.R; r += gridDim.x) {
+        tail_forward_ray(p, L, r);
+        const float* xg = L.xs(nm - 1);
+        // BatchNorm backward (mam.py:24-27 in training: batch statistics; eval: the running estimates are constants), and the residual
+        for (int i = tid; i < P * AT_CM; i += AT_NT) {
+            const int c = i & 31;
+            const float dzv = p.dz[r * P * AT_CM + i];
+            const float g = p.w[wb + TW_BN_W][c] * stat[AT_CM + c];
+            const float yh = (L.yb[i] - stat[c]) * stat[AT_CM + c];
+            L.yb[i] = p.training ? g * (dzv - sums[c] - yh * sums[AT_CM + c]) : g * dzv;          // d y
+            L.dxa[i] = dzv;                                                                         // d x_global, the residual's share
+        }
+        __syncthreads();
+        wacc(part + off[wb + TW_CONVD], L.yb, AT_CM, L.f, AT_CM, P, AT_CM, AT_CM);
+        mm<0, false>(L.df, AT_CM, L.yb, AT_CM, 1, L.convd, 1, AT_CM, nullptr, P, AT_CM, AT_CM);      // d f = d y convd
+        __syncthreads();
+        // attention over the sub-exposures (mam.py:42, 46, 49) and over the samples (:43, 47, 50)
+        mm<0, false>(L.daP, P, L.df, AT_CM, 1, L.nP, AT_MID, 1, nullptr, P, P, AT_MID);              // d aP[p][p'] = d fP[p] . nP[p']
+        mm<0, false>(L.dnP, AT_MID, L.aP, 1, P, L.df, 1, AT_CM, nullptr, P, AT_MID, P);              // d nP[p'][m] = sum_p aP[p][p'] d fP[p][m]
+        for (int s0 = 0; s0 < S; s0 += AT_NT / 2) {
+            const int s = s0 + sl;
+            if (s < S) {
+                float x[AT_MID];
+#pragma unroll
+                for (int c = 0; c < AT_MID; ++c) x[c] = L.nI[s * AT_LK + c];
+                for (int pp = hf; pp < P; pp += 2) {                                                 // d aS[p][s] = d fI[p] . nI[s]
+                    const float4* g4 = reinterpret_cast<const float4*>(L.df + pp * AT_CM + AT_MID);
+                    float acc = 0.f;
+#pragma unroll
+                    for (int k = 0; k < AT_MID / 4; ++k) {
+                        const float4 w = g4[k];
+                        acc = fmaf(w.x, x[4 * k], acc); acc = fmaf(w.y, x[4 * k + 1], acc);
+                        acc = fmaf(w.z, x[4 * k + 2], acc); acc = fmaf(w.w, x[4 * k + 3], acc);
+                    }
+                    L.daS[pp * d.SA + s] = acc;
+                }
+            }
+        }
+        __syncthreads();
+        for (int s0 = 0; s0 < S; s0 += AT_NT / 2) {                                                  // d nI[s][m] = sum_p aS[p][s] d fI[p][m]  (into nI's place)
+            const int s = s0 + sl;
+            if (s < S) {
+                float acc[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+                for (int pp = 0; pp < P; ++pp) {
+                    const float a = L.aS[pp * d.SA + s];
+                    const float4* g4 = reinterpret_cast<const float4*>(L.df + pp * AT_CM + AT_MID + hf * 8);
+                    const float4 g0 = g4[0], g1 = g4[1];
+                    acc[0] = fmaf(a, g0.x, acc[0]); acc[1] = fmaf(a, g0.y, acc[1]); acc[2] = fmaf(a, g0.z, acc[2]); acc[3] = fmaf(a, g0.w, acc[3]);
+                    acc[4] = fmaf(a, g1.x, acc[4]); acc[5] = fmaf(a, g1.y, acc[5]); acc[6] = fmaf(a, g1.z, acc[6]); acc[7] = fmaf(a, g1.w, acc[7]);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) L.nI[s * AT_LK + hf * 8 + j] = acc[j];
+            }
+        }
+        for (int row = tid >> 6; row < 2 * P; row += AT_NT / 64) {
+            if (row < P) softmax_row_bwd(L.aP + row * P, L.daP + row * P, P);
+            else softmax_row_bwd(L.aS + (row - P) * d.SA, L.daS + (row - P) * d.SA, S);
+        }
+        __syncthreads();
+        float* dnI = L.nI;
+        // d q = d lgP kP + d lgS kI;  d kP = d lgP^T q + d nP convn;  d kI = d lgS^T q + d nI convl
+        mm<0, false>(L.dq, AT_MID, L.daP, P, 1, L.kP, 1, AT_MID, nullptr, P, AT_MID, P);
+        mm<0, true>(L.dq, AT_MID, L.daS, d.SA, 1, L.kI, 1, AT_LK, nullptr, P, AT_MID, S);
+        mm<0, false>(L.dkP, AT_MID, L.daP, 1, P, L.q, 1, AT_MID, nullptr, P, AT_MID, P);
+        mm<0, true>(L.dkP, AT_MID, L.dnP, AT_MID, 1, L.convn, 1, AT_MID, nullptr, P, AT_MID, AT_MID);
+        wacc(part + off[wb + TW_CONVN], L.dnP, AT_MID, L.kP, AT_MID, P, AT_MID, AT_MID);
+        wacc(part + off[wb + TW_CONVL], dnI, AT_LK, L.kI, AT_LK, S, AT_MID, AT_MID);
+        for (int s0 = 0; s0 < S; s0 += AT_NT / 2) {
+            const int s = s0 + sl;
+            if (s < S) {
+                float acc[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+                for (int pp = 0; pp < P; ++pp) {
+                    const float a = L.daS[pp * d.SA + s];
+                    const float4* g4 = reinterpret_cast<const float4*>(L.q + pp * AT_MID + hf * 8);
+                    const float4 g0 = g4[0], g1 = g4[1];
+                    acc[0] = fmaf(a, g0.x, acc[0]); acc[1] = fmaf(a, g0.y, acc[1]); acc[2] = fmaf(a, g0.z, acc[2]); acc[3] = fmaf(a, g0.w, acc[3]);
+                    acc[4] = fmaf(a, g1.x, acc[4]); acc[5] = fmaf(a, g1.y, acc[5]); acc[6] = fmaf(a, g1.z, acc[6]); acc[7] = fmaf(a, g1.w, acc[7]);
+                }
+                for (int m = 0; m < AT_MID; ++m) {
+                    const float a = dnI[s * AT_LK + m];
+                    const float4* g4 = reinterpret_cast<const float4*>(L.convl + m * AT_MID + hf * 8);
+                    const float4 g0 = g4[0], g1 = g4[1];
+                    acc[0] = fmaf(a, g0.x, acc[0]); acc[1] = fmaf(a, g0.y, acc[1]); acc[2] = fmaf(a, g0.z, acc[2]); acc[3] = fmaf(a, g0.w, acc[3]);
+                    acc[4] = fmaf(a, g1.x, acc[4]); acc[5] = fmaf(a, g1.y, acc[5]); acc[6] = fmaf(a, g1.z, acc[6]); acc[7] = fmaf(a, g1.w, acc[7]);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) L.dkI[s * AT_LK + hf * 8 + j] = acc[j];
+            }
+        }
+        __syncthreads();
+        // conva / convb / convc, and back through MAM.linear
+        wacc(part + off[wb + TW_CONVA], L.dkP, AT_MID, L.li, AT_CM, P, AT_MID, AT_CM);
+        wacc(part + off[wb + TW_CONVB], L.dkI, AT_LK, L.ls, AT_LS, S, AT_MID, AT_CM);
+        wacc(part + off[wb + TW_CONVC], L.dq, AT_MID, xg, AT_CM, P, AT_MID, AT_CM);
+        mm<0, false>(L.dli, AT_CM, L.dkP, AT_MID, 1, L.conva, 1, AT_CM, nullptr, P, AT_CM, AT_MID);
+        mm<0, true>(L.dxa, AT_CM, L.dq, AT_MID, 1, L.convc, 1, AT_CM, nullptr, P, AT_CM, AT_MID);   // d x_global += d q convc
+        for (int s0 = 0; s0 < S; s0 += AT_NT / 2) {                                                  // d ls[s] = d kI[s] convb
+            const int s = s0 + sl;
+            if (s < S) {
+                float acc[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+                for (int m = 0; m < AT_MID; ++m) {
+                    const float a = L.dkI[s * AT_LK + m];
+                    const float4* g4 = reinterpret_cast<const float4*>(L.convb + m * AT_CM + hf * 16);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float4 g = g4[k];
+                        acc[4 * k] = fmaf(a, g.x, acc[4 * k]); acc[4 * k + 1] = fmaf(a, g.y, acc[4 * k + 1]);
+                        acc[4 * k + 2] = fmaf(a, g.z, acc[4 * k + 2]); acc[4 * k + 3] = fmaf(a, g.w, acc[4 * k + 3]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) L.dls[s * AT_LS + hf * 16 + j] = acc[j];
+            }
+        }
+        __syncthreads();
+        wacc(part + off[wb + TW_LIN_W], L.dli, AT_CM, L.hi, AT_WS, P, AT_CM, AT_WS);
+        wacc(part + off[wb + TW_LIN_W], L.dls, AT_LS, p.h_intra + r * S * AT_WS, AT_WS, S, AT_CM, AT_WS);
+        bacc(part + off[wb + TW_LIN_B], L.dli, AT_CM, P, AT_CM);
+        bacc(part + off[wb + TW_LIN_B], L.dls, AT_LS, S, AT_CM);
+        mm<0, false>(p.d_hi + r * P * AT_WS, AT_WS, L.dli, AT_CM, 1, L.lin_w, 1, AT_WS, nullptr, P, AT_WS, AT_CM);
+        for (int s0 = 0; s0 < S; s0 += AT_NT / 2) {                                                  // d h_intra[s] = d ls[s] MAM.linear.weight
+            const int s = s0 + sl;
+            if (s < S) {
+                float acc[32];
+#pragma unroll
+                for (int j = 0; j < 32; ++j) acc[j] = 0.f;
+                for (int c = 0; c < AT_CM; ++c) {
+                    const float a = L.dls[s * AT_LS + c];
+                    const float4* g4 = reinterpret_cast<const float4*>(L.lin_w + c * AT_WS + hf * 32);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float4 g = g4[k];
+                        acc[4 * k] = fmaf(a, g.x, acc[4 * k]); acc[4 * k + 1] = fmaf(a, g.y, acc[4 * k + 1]);
+                        acc[4 * k + 2] = fmaf(a, g.z, acc[4 * k + 2]); acc[4 * k + 3] = fmaf(a, g.w, acc[4 * k + 3]);
+                    }
+                }
+                float4* o4 = reinterpret_cast<float4*>(p.d_hs + (r * S + s) * AT_WS + hf * 32);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o4[k] = make_float4(acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3]);
+            }
+        }
+        // the motion embedding backwards (awp.py:107-109)
+        float *dx = L.dxa, *dprev = L.dxb;
+        for (int l = nm - 1; l >= 0; --l) {
+            __syncthreads();
+            for (int i = tid; i < P * AT_CM; i += AT_NT) dx[i] = L.xs(l)[i] > 0.f ? dx[i] : 0.f;
+            __syncthreads();
+            const int K = l == 0 ? d.IN0 : AT_CM;
+            const float* xin = l == 0 ? L.x0 : L.xs(l - 1);
+            wacc(part + off[2 * l], dx, AT_CM, xin, K, P, AT_CM, K);
+            bacc(part + off[2 * l + 1], dx, AT_CM, P, AT_CM);
+            mm<0, false>(dprev, K, dx, AT_CM, 1, L.mw(l), 1, K, nullptr, P, K, AT_CM);
+            float* t = dx; dx = dprev; dprev = t;
+        }
+        __syncthreads();
+        // dx: d [integrated features | view_feature | direction encoding] of every sub-exposure, [P][IN0]
+        for (int i = tid; i < P * AT_WS; i += AT_NT) p.d_h[r * P * AT_WS + i] = dx[(i >> 6) * d.IN0 + (i & 63)];
+        for (int j = tid; j < d.VC; j += AT_NT) {
+            float a = 0.f;
+            for (int pp = 0; pp < P; ++pp) a += dx[pp * d.IN0 + AT_WS + j];
+            if (j < d.VF) p.d_vf[r * d.VF + j] = a;
+            else L.tmp[j - d.VF] = a;
+        }
+        __syncthreads();
+        if (tid < 3 * P) {
+            float out = 0.f;
+            if (tid < 3 && d.F >= 0) {                                 // awp.py:89-92: d (d / |d|) of the first sub-exposure's ray
+                const float* rd = p.rays_d + r * P * 3;
+                const float nrm = sqrtf(rd[0] * rd[0] + rd[1] * rd[1] + rd[2] * rd[2]);
+                float mine = 0.f, dotv = 0.f;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const float dn = rd[a] / nrm;
+                    float g = L.tmp[a];
+                    for (int k = 0; k < d.F; ++k) {
+                        const float fr = (float)(1 << k), arg = dn * fr;
+                        g = fmaf(L.tmp[3 + 6 * k + a], fr * cosf(arg), g);
+                        g = fmaf(L.tmp[6 + 6 * k + a], -fr * sinf(arg), g);
+                    }
+                    mine = a == tid ? g : mine;
+                    dotv = fmaf(g, dn, dotv);
+                }
+                out = (mine - rd[tid] / nrm * dotv) / nrm;
+            }
+            p.d_rays[r * P * 3 + tid] = out;
+        }
+        __syncthreads();
+    }
+}
+
+struct TailReduceParams {
+    const float *partA, *partB;
+    int nA, nB, partB_stride, n_tail, P;          // n_tail: elements of d_params in front of convd.1.weight
+    long total;
+    float* d_params;
+};
+// d_params[i] = sum over the partial rows; the BatchNorm and w_linear gradients come from k_awp_tail_bwd0's rows (d beta, d gamma, d W, d b)
+__global__ __launch_bounds__(256) void k_awp_tail_reduce(TailReduceParams p) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.total) return;
+    float a = 0.f;
+    if (i < p.n_tail) {
+        for (int b = 0; b < p.nA; ++b) a += p.partA[(long)b * p.total + i];
+    } else {
+        const long j = i - p.n_tail;                                   // 0..31 d gamma, 32..63 d beta, then w_linear
+        const long col = j < AT_CM ? AT_CM + j : (j < 2 * AT_CM ? j - AT_CM : j);
+        for (int b = 0; b < p.nB; ++b) a += p.partB[(long)b * p.partB_stride + col];
+    }
+    p.d_params[i] = a;
+}
+
+}  // namespace evd
+
+using namespace evd;
+
+static int tail_check(const char* who, const evd_awp_tail_desc* d, long R, bool bwd, TailDims& dims, size_t& lds_bytes) {
+    EVD_REQUIRE(d, "%s: null descriptor", who);
+    EVD_REQUIRE(R >= 0 && d->P >= 1 && d->P <= AT_MAXP && d->S >= 1, "%s: P = %d (built: 1..%d), S = %d", who, d->P, AT_MAXP, d->S);
+    EVD_REQUIRE(d->n_mot >= 1 && d->n_mot <= AT_MAXMOT, "%s: %d motion embedding layers (built: 1..%d)", who, d->n_mot, AT_MAXMOT);
+    EVD_REQUIRE(d->VF >= 0 && d->VF <= 64 && d->dir_freqs >= -1 && d->dir_freqs <= 4, "%s: view_feature width %d (<= 64), dir_freqs %d (-1..4)",
+                who, d->VF, d->dir_freqs);
+    dims = tail_dims(d->P, d->S, d->VF, d->dir_freqs, d->n_mot);
+    TailLds L;
+    lds_bytes = sizeof(float) * tail_lds_layout(nullptr, dims, bwd, L);
+    const size_t fixed = bwd ? 4 * 128 * sizeof(double) + 1024 : 0;       // the backward kernel's static arrays
+    EVD_REQUIRE(lds_bytes + fixed <= 160 * 1024, "%s: P = %d, S = %d needs %zu bytes of LDS per ray (the CU has 160 KiB)", who, d->P, d->S,
+                lds_bytes + fixed);
+    return EVD_OK;
+}
+
+static int tail_grid(long R) {
+    int cus = 256;
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    return (int)std::min<long>(R, cus);
+}
+
+static void tail_fill(TailKParams& k, const TailDims& dims, const evd_awp_tail_desc* d, const float* const* params, long R) {
+    k.d = dims;
+    k.nw = 2 * dims.n_mot + TW_COUNT;
+    long at = 0;
+    for (int i = 0; i < k.nw; ++i) {
+        k.w[i] = params[i];
+        k.off[i] = at;
+        at += tail_param_size(dims, i);
+    }
+    k.off[k.nw] = at;
+    k.training = d->training;
+    k.eps = d->bn_eps;
+    k.momentum = d->bn_momentum;
+    k.R = R;
+}
+
+static int tail_nblk(long R) { return (int)((R + AT_FR - 1) / AT_FR); }
+static int tail_partB_stride(int P) { return 2 * AT_CM + P * AT_CM + P; }
+
+extern "C" {
+
+int evd_awp_tail_num_params(int n_mot) { return 2 * n_mot + TW_COUNT; }
+
+long evd_awp_tail_param_count(const evd_awp_tail_desc* d) {
+    if (!d || d->n_mot < 1 || d->n_mot > AT_MAXMOT) return -1;
+    const TailDims dims = tail_dims(d->P, d->S, d->VF, d->dir_freqs, d->n_mot);
+    long at = 0;
+    for (int i = 0; i < 2 * d->n_mot + TW_COUNT; ++i) at += tail_param_size(dims, i);
+    return at;
+}
+
+size_t evd_awp_tail_workspace_bytes(const evd_awp_tail_desc* d, long R, int backward) {
+    if (!d || R < 0) return 0;
+    const int grid = tail_grid(R > 0 ? R : 1);
+    if (!backward) return sizeof(double) * 2 * AT_CM * (size_t)grid + 256;
+    const long total = evd_awp_tail_param_count(d);
+    return sizeof(float) * ((size_t)R * d->P * AT_CM + (size_t)tail_nblk(R) * tail_partB_stride(d->P) + (size_t)grid * (size_t)total) + 1024;
+}
+
+int evd_awp_tail_forward(const evd_awp_tail_desc* d, const float* const* params, const float* h, const float* view_feature,
+                         const float* rays_d, const float* h_inter, const float* h_intra, long R, float* bn_running_mean,
+                         float* bn_running_var, long long* bn_num_batches, float* out, float* saved_y, float* saved_xg, float* saved_stats,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+    TailDims dims;
+    size_t lds = 0;
+    if (d && d->training) {          // a training-mode forward is followed by the backward: refuse here what that kernel's working set cannot hold
+        if (int e = tail_check("evd_awp_tail_forward", d, R, true, dims, lds)) return e;
+    }
+    if (int e = tail_check("evd_awp_tail_forward", d, R, false, dims, lds)) return e;
+    EVD_REQUIRE(params && h && rays_d && h_inter && h_intra && out && saved_y && saved_xg && saved_stats && workspace,
+                "evd_awp_tail_forward: null argument");
+    EVD_REQUIRE(dims.VF == 0 || view_feature, "evd_awp_tail_forward: view_feature missing (VF = %d)", dims.VF);
+    EVD_REQUIRE(d->training || (bn_running_mean && bn_running_var), "evd_awp_tail_forward: eval mode needs the BatchNorm running estimates");
+    EVD_REQUIRE(!bn_running_mean == !bn_running_var, "evd_awp_tail_forward: bn_running_mean and bn_running_var go together");
+    for (int i = 0; i < evd_awp_tail_num_params(dims.n_mot); ++i) EVD_REQUIRE(params[i], "evd_awp_tail_forward: parameter %d missing", i);
+    EVD_REQUIRE(workspace_bytes >= evd_awp_tail_workspace_bytes(d, R, 0), "evd_awp_tail_forward: workspace too small");
+    if (R == 0) return EVD_OK;
+    TailKParams k{};
+    tail_fill(k, dims, d, params, R);
+    k.h = h; k.vf = view_feature; k.rays_d = rays_d; k.h_inter = h_inter; k.h_intra = h_intra;
+    k.y = saved_y; k.xg = saved_xg;
+    k.bn_part = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(workspace) + 63) & ~(uintptr_t)63);
+    const int grid = tail_grid(R);
+    EVD_SET_MAX_LDS(k_awp_tail_fwd, 160 * 1024);
+    k_awp_tail_fwd<<<grid, AT_NT, lds, as_stream(stream)>>>(k);
+    EVD_HIP(hipGetLastError());
+    TailFinishParams f{};
+    f.bn_part = k.bn_part; f.nparts = grid; f.P = dims.P; f.training = d->training; f.R = R; f.eps = d->bn_eps; f.momentum = d->bn_momentum;
+    const float* const* w = params + 2 * dims.n_mot;
+    f.bn_w = w[TW_BN_W]; f.bn_b = w[TW_BN_B]; f.wl_w = w[TW_WL_W]; f.wl_b = w[TW_WL_B];
+    f.y = saved_y; f.xg = saved_xg; f.run_mean = bn_running_mean; f.run_var = bn_running_var; f.num_batches = bn_num_batches;
+    f.stats = saved_stats; f.out = out;
+    k_awp_tail_finish<<<tail_nblk(R), AT_NT, 0, as_stream(stream)>>>(f);
+    EVD_HIP(hipGetLastError());
+    return EVD_OK;
+}
+
+int evd_awp_tail_backward(const evd_awp_tail_desc* d, const float* const* params, const float* h, const float* view_feature,
+                          const float* rays_d, const float* h_inter, const float* h_intra, long R, const float* saved_y,
+                          const float* saved_xg, const float* saved_stats, const float* d_out, float* d_h, float* d_view_feature,
+                          float* d_rays_d, float* d_h_inter, float* d_h_intra, float* d_params, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+    TailDims dims;
+    size_t lds = 0;
+    if (int e = tail_check("evd_awp_tail_backward", d, R, true, dims, lds)) return e;
+    EVD_REQUIRE(params && h && rays_d && h_inter && h_intra && saved_y && saved_xg && saved_stats && d_out && d_h && d_rays_d && d_h_inter &&
+                    d_h_intra && d_params && workspace,
+                "evd_awp_tail_backward: null argument");
+    EVD_REQUIRE(dims.VF == 0 || (view_feature && d_view_feature), "evd_awp_tail_backward: view_feature / d_view_feature missing (VF = %d)", dims.VF);
+    for (int i = 0; i < evd_awp_tail_num_params(dims.n_mot); ++i) EVD_REQUIRE(params[i], "evd_awp_tail_backward: parameter %d missing", i);
+    EVD_REQUIRE(workspace_bytes >= evd_awp_tail_workspace_bytes(d, R, 1), "evd_awp_tail_backward: workspace too small");
+    const long total = evd_awp_tail_param_count(d);
+    if (R == 0) {
+        EVD_HIP(hipMemsetAsync(d_params, 0, sizeof(float) * (size_t)total, as_stream(stream)));
+        return EVD_OK;
+    }
+    const int grid = tail_grid(R), nblk = tail_nblk(R), strideB = tail_partB_stride(dims.P);
+    float* dz = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 63) & ~(uintptr_t)63);
+    float* partB = dz + (size_t)R * dims.P * AT_CM;
+    float* partA = partB + (size_t)nblk * strideB;
+    const float* const* w = params + 2 * dims.n_mot;
+    TailFinishParams f{};
+    f.P = dims.P; f.training = d->training; f.R = R; f.eps = d->bn_eps; f.nblk = nblk;
+    f.bn_w = w[TW_BN_W]; f.bn_b = w[TW_BN_B]; f.wl_w = w[TW_WL_W]; f.wl_b = w[TW_WL_B];
+    f.y = saved_y; f.xg = saved_xg; f.stats = const_cast<float*>(saved_stats); f.d_out = d_out; f.dz = dz; f.partB = partB; f.partB_stride = strideB;
+    k_awp_tail_bwd0<<<nblk, AT_NT, 0, as_stream(stream)>>>(f);
+    EVD_HIP(hipGetLastError());
+    TailKParams k{};
+    tail_fill(k, dims, d, params, R);
+    k.h = h; k.vf = view_feature; k.rays_d = rays_d; k.h_inter = h_inter; k.h_intra = h_intra;
+    k.y = const_cast<float*>(saved_y); k.xg = const_cast<float*>(saved_xg);
+    k.dz = dz; k.stats = saved_stats; k.partB = partB; k.nblkB = nblk; k.partB_stride = strideB;
+    k.d_h = d_h; k.d_vf = d_view_feature; k.d_rays = d_rays_d; k.d_hi = d_h_inter; k.d_hs = d_h_intra; k.partA = partA;
+    EVD_SET_MAX_LDS(k_awp_tail_bwd, 160 * 1024 - 4 * 128 * sizeof(double) - 1024);
+    k_awp_tail_bwd<<<grid, AT_NT, lds, as_stream(stream)>>>(k);
+    EVD_HIP(hipGetLastError());
+    TailReduceParams rp{};
+    rp.partA = partA; rp.partB = partB; rp.nA = grid; rp.nB = nblk; rp.partB_stride = strideB; rp.P = dims.P; rp.total = total;
+    rp.n_tail = (int)k.off[2 * dims.n_mot + TW_BN_W];
+    rp.d_params = d_params;
+    k_awp_tail_reduce<<<(unsigned)((total + 255) / 256), 256, 0, as_stream(stream)>>>(rp);
+    EVD_HIP(hipGetLastError());
+    return EVD_OK;
+}
+
+}  // extern "C"

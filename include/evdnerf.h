@@ -461,6 +461,45 @@ int evd_mam_local_backward(const float* h_local, const float* u, const float* al
                            const float* h_intra, const float* d_inter, const float* d_intra, long R, int P, int S, int C, float* d_h_local,
                            float* d_u_partial, void* stream);
 
+/* The PER-RAY remainder of the adaptive weight proposal as kernels: networks/dpnerf/awp.py:89-95 (direction encoding of the first
+ * sub-exposure's normalised ray direction, concatenated behind view_feature), :104-109 (motion_feature_embed_layer: n_mot x Linear + ReLU on
+ * [integrated features | view_embedded]), networks/dpnerf/mam.py:35-53 (CorrelationModule.forward behind its per-sample part: conva /
+ * convb / convc, the two softmax(bmm) attention maps over the P sub-exposures and the S samples, convn / convl, convd = Conv1d +
+ * BatchNorm1d, residual, leaky_relu 0.2) and awp.py:112-115 (mean over P, w_linear, sigmoid, normalisation) -- in the reference ~100 small
+ * launches each way.  Two launches forward (the BatchNorm statistics are over ALL rays: per-workgroup partial sums in the first, folded by
+ * the second), three backward.  Inputs per ray: h dev [R,P,64] (evd_awp_feature_integration's output), view_feature dev [R,VF] (NULL when
+ * VF = 0), rays_d dev [R P,3], h_inter dev [R,P,64] / h_intra dev [R,S,64] (evd_mam_local_forward's outputs; MAM.linear is applied here).
+ * Built for W_sam 64, W_mot 32 (kernel_awp_sam_emb_width / kernel_awp_mot_emb_width of the shipped configs), n_mot <= 4, P <= 16,
+ * dir_freqs 0..4 (get_embedder(ray_dir_freq): [d, sin(2^k d), cos(2^k d)...], 3 + 6 dir_freqs columns; -1: no direction columns), VF <= 64,
+ * and S as far as the per-ray working set fits the 160 KiB LDS (S <= 128 for the backward at P = 10); EVD_E_INVALID otherwise.
+ *
+ * params: HOST array of evd_awp_tail_num_params(n_mot) DEVICE pointers, float32, nn.Module layouts ([out, in]):
+ *   motion_feature_embed_layer.{l}.weight, .bias (l = 0..n_mot-1; layer 0 is [32, 64 + VF + 3 + 6 dir_freqs]),  MAM.linear.weight [32,64],
+ *   .bias,  Corr.conva / convb / convc .weight [16,32],  Corr.convn / convl .weight [16,16],  Corr.convd.0.weight [32,32],
+ *   Corr.convd.1.weight, .bias [32],  w_linear.weight [P,32], .bias [P].
+ * d_params (backward): ONE flat dev float32 buffer of evd_awp_tail_param_count elements, the same tensors in the same order.
+ * BatchNorm: training != 0 normalises with the batch statistics (biased variance) and, when bn_running_mean / _var are given, blends the
+ * batch mean / UNBIASED variance into them with bn_momentum and adds 1 to *bn_num_batches (int64, may be NULL); training == 0 uses the
+ * running estimates.  saved_y, saved_xg dev [R,P,32] and saved_stats dev [64] (mean, 1/sqrt(var + eps)) are kept for the backward. */
+typedef struct {
+    int P, S, VF, dir_freqs, n_mot, training;
+    float bn_eps, bn_momentum;
+} evd_awp_tail_desc;
+int evd_awp_tail_num_params(int n_mot);
+long evd_awp_tail_param_count(const evd_awp_tail_desc* d);
+size_t evd_awp_tail_workspace_bytes(const evd_awp_tail_desc* d, long R, int backward);
+int evd_awp_tail_forward(const evd_awp_tail_desc* d, const float* const* params, const float* h, const float* view_feature,
+                         const float* rays_d, const float* h_inter, const float* h_intra, long R, float* bn_running_mean,
+                         float* bn_running_var, long long* bn_num_batches, float* out, float* saved_y, float* saved_xg, float* saved_stats,
+                         void* workspace, size_t workspace_bytes, void* stream);
+/* d_out dev [R,P] -> d_h dev [R,P,64], d_view_feature dev [R,VF] (NULL when VF = 0), d_rays_d dev [R P,3] (rows other than a ray's first
+ * are written as zeros), d_h_inter dev [R,P,64], d_h_intra dev [R,S,64], d_params (above); all written, not accumulated. */
+int evd_awp_tail_backward(const evd_awp_tail_desc* d, const float* const* params, const float* h, const float* view_feature,
+                          const float* rays_d, const float* h_inter, const float* h_intra, long R, const float* saved_y,
+                          const float* saved_xg, const float* saved_stats, const float* d_out, float* d_h, float* d_view_feature,
+                          float* d_rays_d, float* d_h_inter, float* d_h_intra, float* d_params, void* workspace, size_t workspace_bytes,
+                          void* stream);
+
 /* AdaptiveWeightProposal.sample_feature_embed_layer (networks/dpnerf/awp.py:36-37: D_sam x nn.Linear; :98-100: each followed by ReLU)
  * fused into one MFMA kernel that reads the fine level's geo features WHERE THEY ALREADY ARE: the reference writes them as
  * depth_feature [R P, S, 128] float32 (renderer.py:253-256) and runs four torch Linear + ReLU passes over it (:314); here the
