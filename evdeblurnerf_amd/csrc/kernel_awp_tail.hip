@@ -20,7 +20,11 @@
 
 namespace evd {
 
-constexpr int AT_WS = 64, AT_CM = 32, AT_MID = 16, AT_MAXP = 16, AT_MAXMOT = 4, AT_NT = 256, AT_MAXW = 2 * AT_MAXMOT + 12;
+constexpr int AT_WS = 64, AT_CM = 32, AT_MID = 16, AT_MAXP = 16, AT_MAXMOT = 4, AT_MAXW = 2 * AT_MAXMOT + 12;
+// threads of a ray's workgroup, and how many of them share a sample row in the per-sample phases.  The working set of a ray allows one
+// workgroup per CU, so the wavefronts that hide each other's LDS latency all come from here: 256 threads (one wavefront per SIMD) measured
+// 66 k cycles per ray forward, 207 k backward
+constexpr int AT_NT = 512, AT_LPS = 4, AT_O64 = AT_WS / AT_LPS, AT_O32 = AT_CM / AT_LPS, AT_O16 = AT_MID / AT_LPS;
 constexpr int AT_LS = AT_CM + 1, AT_LK = AT_MID + 1;      // padded row strides of the per-sample LDS arrays (conflict-free row writes)
 
 struct TailDims {
@@ -101,22 +105,75 @@ struct TailKParams {
     double* bn_part;                   // forward: [grid][64] sums of y, y^2
     const float *dz, *stats, *partB;   // backward
     int nblkB, partB_stride;
+    long partA_stride;                 // floats between the workgroups' partial rows (a multiple of 4: the rows are 16-byte aligned)
     float *d_h, *d_vf, *d_rays, *d_hi, *d_hs, *partA;
+    long long* stamps;                 // developer build (-DEVD_AT_STAMP): per-phase shader-clock sums of workgroup 0
 };
+
+// developer build (-DEVD_AT_STAMP, tools/dev/stamp_awp_tail.py): thread 0 of workgroup 0 sums the shader-clock cycles between marks
+struct AtClock {
+#ifdef EVD_AT_STAMP
+    long long t[32], last;
+    __device__ __forceinline__ void start() {
+        for (int i = 0; i < 32; ++i) t[i] = 0;
+        last = __builtin_readcyclecounter();
+    }
+    __device__ __forceinline__ void mark(int i) {
+        const long long now = __builtin_readcyclecounter();
+        t[i] += now - last;
+        last = now;
+    }
+    __device__ __forceinline__ void flush(long long* out) const {
+        if (out && blockIdx.x == 0 && threadIdx.x == 0)
+            for (int i = 0; i < 32; ++i) out[i] = t[i];
+    }
+#else
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void flush(long long*) const {}
+#endif
+};
+
+// threadIdx.x behind an opaque barrier: hipcc otherwise hoists every helper's per-thread index arithmetic (i / N, n % K, the strided
+// offsets of ~40 calls) out of the ray loop and spills it (measured: 278 / 368 spilled registers at 512 threads)
+__device__ __forceinline__ int at_tid() {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
 
 // out[m som + n] (+)= act(bias[n] + sum_k A[m sam + k sak] B[n sbn + k sbk]);  rot: lane n starts its k loop at n mod K, so that lanes reading
 // consecutive rows of a row-major B whose row length is even hit different LDS banks
 template <int ACT, bool ACC>
 __device__ __forceinline__ void mm(float* out, int som, const float* A, int sam, int sak, const float* B, int sbn, int sbk, const float* bias,
                                    int M, int N, int K, bool rot = false) {
-    for (int i = threadIdx.x; i < M * N; i += AT_NT) {
+    for (int i = at_tid(); i < M * N; i += AT_NT) {
         const int m = i / N, n = i - m * N;
-        float acc = bias ? bias[n] : 0.f;
-        int k = rot ? n % K : 0;
-        for (int kk = 0; kk < K; ++kk) {
-            acc = fmaf(A[m * sam + k * sak], B[n * sbn + k * sbk], acc);
+        const float* a = A + m * sam;
+        const float* b = B + n * sbn;
+        float acc0 = bias ? bias[n] : 0.f, acc1 = 0.f;
+        int k = rot ? n % K : 0, kk = 0;
+        for (; kk + 8 <= K; kk += 8) {                     // eight independent LDS read pairs in flight (one wavefront per SIMD: nothing else hides them)
+            float av[8], bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                int ku = k + u;
+                ku -= ku >= K ? K : 0;
+                av[u] = a[ku * sak];
+                bv[u] = b[ku * sbk];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                acc0 = fmaf(av[u], bv[u], acc0);
+                acc1 = fmaf(av[u + 1], bv[u + 1], acc1);
+            }
+            k += 8; k -= k >= K ? K : 0;
+        }
+        for (; kk < K; ++kk) {
+            acc0 = fmaf(a[k * sak], b[k * sbk], acc0);
             if (++k == K) k = 0;
         }
+        float acc = acc0 + acc1;
         if (ACT == 1) acc = fmaxf(acc, 0.f);
         if (ACC) out[m * som + n] += acc;
         else out[m * som + n] = acc;
@@ -129,15 +186,64 @@ __device__ __forceinline__ void lin(float* out, int som, const float* x, int ldx
 }
 // part[n K + k] += sum_m G[m sgm + n] X[m sxm + k]  (weight gradient of y = x W^T; an element is always added by the same lane)
 __device__ __forceinline__ void wacc(float* part, const float* G, int sgm, const float* X, int sxm, int M, int N, int K) {
-    for (int i = threadIdx.x; i < N * K; i += AT_NT) {
+    for (int i = at_tid(); i < N * K; i += AT_NT) {
         const int n = i / K, k = i - n * K;
-        float acc = 0.f;
-        for (int m = 0; m < M; ++m) acc = fmaf(G[m * sgm + n], X[m * sxm + k], acc);
-        part[i] += acc;
+        float acc0 = 0.f, acc1 = 0.f;
+        int m = 0;
+        for (; m + 8 <= M; m += 8) {
+            float gv[8], xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                gv[u] = G[(m + u) * sgm + n];
+                xv[u] = X[(m + u) * sxm + k];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                acc0 = fmaf(gv[u], xv[u], acc0);
+                acc1 = fmaf(gv[u + 1], xv[u + 1], acc1);
+            }
+        }
+        for (; m < M; ++m) acc0 = fmaf(G[m * sgm + n], X[m * sxm + k], acc0);
+        part[i] += acc0 + acc1;
+    }
+}
+// d MAM.linear.weight [32][64] += d li^T hi + d ls^T h_intra: a lane owns (c, 4 consecutive k) -- 512 items, the sample rows as 16-byte loads
+__device__ __forceinline__ void wacc_lin(float* part, const float* dli, const float* hi, int P, const float* dls, const float* xs, int S) {
+    for (int i = at_tid(); i < AT_CM * AT_WS / 4; i += AT_NT) {
+        const int c = i >> 4, k4 = i & 15;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int pp = 0; pp < P; ++pp) {
+            const float g = dli[pp * AT_CM + c];
+            const float4 x = reinterpret_cast<const float4*>(hi + pp * AT_WS)[k4];
+            acc.x = fmaf(g, x.x, acc.x); acc.y = fmaf(g, x.y, acc.y); acc.z = fmaf(g, x.z, acc.z); acc.w = fmaf(g, x.w, acc.w);
+        }
+        int sm = 0;
+        for (; sm + 4 <= S; sm += 4) {
+            float g[4];
+            float4 x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                g[u] = dls[(sm + u) * AT_LS + c];
+                x[u] = reinterpret_cast<const float4*>(xs + (long)(sm + u) * AT_WS)[k4];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc.x = fmaf(g[u], x[u].x, acc.x); acc.y = fmaf(g[u], x[u].y, acc.y); acc.z = fmaf(g[u], x[u].z, acc.z); acc.w = fmaf(g[u], x[u].w, acc.w);
+            }
+        }
+        for (; sm < S; ++sm) {
+            const float g = dls[sm * AT_LS + c];
+            const float4 x = reinterpret_cast<const float4*>(xs + (long)sm * AT_WS)[k4];
+            acc.x = fmaf(g, x.x, acc.x); acc.y = fmaf(g, x.y, acc.y); acc.z = fmaf(g, x.z, acc.z); acc.w = fmaf(g, x.w, acc.w);
+        }
+        float4* o = reinterpret_cast<float4*>(part) + i;
+        float4 v = *o;
+        v.x += acc.x; v.y += acc.y; v.z += acc.z; v.w += acc.w;
+        *o = v;
     }
 }
 __device__ __forceinline__ void bacc(float* part, const float* G, int sgm, int M, int N) {
-    for (int n = threadIdx.x; n < N; n += AT_NT) {
+    for (int n = at_tid(); n < N; n += AT_NT) {
         float acc = 0.f;
         for (int m = 0; m < M; ++m) acc += G[m * sgm + n];
         part[n] += acc;
@@ -147,28 +253,158 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     return v;
 }
-// softmax of every row, in place; a wavefront per row
+// softmax of a row, in place, by one wavefront; the row (n <= 256) stays in registers between the two reductions
 __device__ __forceinline__ void softmax_row(float* a, int n) {
-    const int lane = threadIdx.x & 63;
-    float m = -INFINITY, t = 0.f;
-    for (int j = lane; j < n; j += 64) m = fmaxf(m, a[j]);
+    const int lane = at_tid() & 63;
+    float v[4], m = -INFINITY, t = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        v[u] = lane + 64 * u < n ? a[lane + 64 * u] : -INFINITY;
+        m = fmaxf(m, v[u]);
+    }
     m = wave_max(m);
-    for (int j = lane; j < n; j += 64) t += expf(a[j] - m);
-    t = wave_sum_dpp(t);
-    for (int j = lane; j < n; j += 64) a[j] = expf(a[j] - m) / t;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        v[u] = lane + 64 * u < n ? expf(v[u] - m) : 0.f;
+        t += v[u];
+    }
+    t = 1.0f / wave_sum_dpp(t);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (lane + 64 * u < n) a[lane + 64 * u] = v[u] * t;
 }
 // d logit = a (d a - sum a d a), in place of d a
 __device__ __forceinline__ void softmax_row_bwd(const float* a, float* da, int n) {
-    const int lane = threadIdx.x & 63;
-    float c = 0.f;
-    for (int j = lane; j < n; j += 64) c = fmaf(a[j], da[j], c);
+    const int lane = at_tid() & 63;
+    float av[4], dv[4], c = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const bool in = lane + 64 * u < n;
+        av[u] = in ? a[lane + 64 * u] : 0.f;
+        dv[u] = in ? da[lane + 64 * u] : 0.f;
+        c = fmaf(av[u], dv[u], c);
+    }
     c = wave_sum_dpp(c);
-    for (int j = lane; j < n; j += 64) da[j] = a[j] * (da[j] - c);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (lane + 64 * u < n) da[lane + 64 * u] = av[u] * (dv[u] - c);
+}
+// the P x P attention map: a row per lane, serially (10 elements; a wavefront per row would cost a row of the S-sized map each)
+__device__ __forceinline__ void softmax_small(float* a, int n) {
+    float m = -INFINITY, t = 0.f;
+    for (int j = 0; j < n; ++j) m = fmaxf(m, a[j]);
+    for (int j = 0; j < n; ++j) {
+        const float e = expf(a[j] - m);
+        a[j] = e;
+        t += e;
+    }
+    t = 1.0f / t;
+    for (int j = 0; j < n; ++j) a[j] *= t;
+}
+__device__ __forceinline__ void softmax_small_bwd(const float* a, float* da, int n) {
+    float c = 0.f;
+    for (int j = 0; j < n; ++j) c = fmaf(a[j], da[j], c);
+    for (int j = 0; j < n; ++j) da[j] = a[j] * (da[j] - c);
+}
+
+// Register-row products of the per-sample phases: a lane holds a sample's row in registers, the weights are LDS broadcasts.  The loads of a
+// batch of weight rows are issued together IN FRONT of their multiply-adds: hipcc otherwise emits load, wait, four multiply-adds, load, ...
+// (measured: 40 k cycles for the MAM.linear step instead of 6 k -- every ds_read's latency exposed, with one wavefront per SIMD).
+// o[j] += sum_k W[j K + k] x[k], j < NO
+template <int K, int NO, int NJ>
+__device__ __forceinline__ void rows_dot(const float* W, const float (&x)[K], float (&o)[NO]) {
+#pragma unroll
+    for (int j0 = 0; j0 < NO; j0 += NJ) {
+        float4 w[NJ][K / 4];
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+            for (int k = 0; k < K / 4; ++k) w[jj][k] = reinterpret_cast<const float4*>(W + (j0 + jj) * K)[k];
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < K / 4; ++k) {
+                a0 = fmaf(w[jj][k].x, x[4 * k], a0); a1 = fmaf(w[jj][k].y, x[4 * k + 1], a1);
+                a0 = fmaf(w[jj][k].z, x[4 * k + 2], a0); a1 = fmaf(w[jj][k].w, x[4 * k + 3], a1);
+            }
+            o[j0 + jj] += a0 + a1;
+        }
+    }
+}
+// o[n] += sum_m g[m] W[m ldw + n], n < NO (the transposed product in outer-product form: NM rows of W at a time)
+template <int M, int NO, int NM>
+__device__ __forceinline__ void cols_acc(const float* W, int ldw, const float (&g)[M], float (&o)[NO]) {
+#pragma unroll
+    for (int m0 = 0; m0 < M; m0 += NM) {
+        float4 w[NM][NO / 4];
+#pragma unroll
+        for (int mm_ = 0; mm_ < NM; ++mm_)
+#pragma unroll
+            for (int n = 0; n < NO / 4; ++n) w[mm_][n] = reinterpret_cast<const float4*>(W + (m0 + mm_) * ldw)[n];
+#pragma unroll
+        for (int mm_ = 0; mm_ < NM; ++mm_)
+#pragma unroll
+            for (int n = 0; n < NO / 4; ++n) {
+                o[4 * n] = fmaf(g[m0 + mm_], w[mm_][n].x, o[4 * n]); o[4 * n + 1] = fmaf(g[m0 + mm_], w[mm_][n].y, o[4 * n + 1]);
+                o[4 * n + 2] = fmaf(g[m0 + mm_], w[mm_][n].z, o[4 * n + 2]); o[4 * n + 3] = fmaf(g[m0 + mm_], w[mm_][n].w, o[4 * n + 3]);
+            }
+    }
+}
+// the same over the P sub-exposures (a run-time count <= 16): o[n] += sum_p col[p cs] rows[p ld + n], n < NO
+template <int NO>
+__device__ __forceinline__ void p_acc(const float* col, int cs, const float* rows, int ld, int P, float (&o)[NO]) {
+    for (int p0 = 0; p0 < P; p0 += 4) {
+        float g[4];
+        float4 w[4][NO / 4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int pp = p0 + u < P ? p0 + u : P - 1;
+            g[u] = p0 + u < P ? col[pp * cs] : 0.f;
+#pragma unroll
+            for (int n = 0; n < NO / 4; ++n) w[u][n] = reinterpret_cast<const float4*>(rows + pp * ld)[n];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int n = 0; n < NO / 4; ++n) {
+                o[4 * n] = fmaf(g[u], w[u][n].x, o[4 * n]); o[4 * n + 1] = fmaf(g[u], w[u][n].y, o[4 * n + 1]);
+                o[4 * n + 2] = fmaf(g[u], w[u][n].z, o[4 * n + 2]); o[4 * n + 3] = fmaf(g[u], w[u][n].w, o[4 * n + 3]);
+            }
+    }
+}
+// out[p so] = rows[p ld .. + 16] . x for p = p0, p0 + AT_LPS, ... (the logits / their gradients of a sample against the sub-exposures' rows)
+__device__ __forceinline__ void p_dot16(float* out, int so, const float* rows, int ld, int p0, int P, const float (&x)[AT_MID]) {
+    for (int pa = p0; pa < P; pa += 2 * AT_LPS) {
+        const int pb = pa + AT_LPS < P ? pa + AT_LPS : pa;
+        float4 wa[4], wb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            wa[k] = reinterpret_cast<const float4*>(rows + pa * ld)[k];
+            wb[k] = reinterpret_cast<const float4*>(rows + pb * ld)[k];
+        }
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a = fmaf(wa[k].x, x[4 * k], a); a = fmaf(wa[k].y, x[4 * k + 1], a); a = fmaf(wa[k].z, x[4 * k + 2], a); a = fmaf(wa[k].w, x[4 * k + 3], a);
+            b = fmaf(wb[k].x, x[4 * k], b); b = fmaf(wb[k].y, x[4 * k + 1], b); b = fmaf(wb[k].z, x[4 * k + 2], b); b = fmaf(wb[k].w, x[4 * k + 3], b);
+        }
+        out[pa * so] = a;
+        if (pa + AT_LPS < P) out[pb * so] = b;
+    }
 }
 
 __device__ __forceinline__ void tail_stage_weights(const TailKParams& p, const TailLds& L) {
     const TailDims& d = p.d;
-    auto copy = [&](float* dst, const float* src, int n) { for (int i = threadIdx.x; i < n; i += AT_NT) dst[i] = src[i]; };
+    auto copy = [&](float* dst, const float* src, int n) {           // n is a multiple of 4 here except for the odd-width layer 0
+        if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+#pragma unroll 4
+            for (int i = threadIdx.x; i < n / 4; i += AT_NT) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+        } else {
+#pragma unroll 4
+            for (int i = threadIdx.x; i < n; i += AT_NT) dst[i] = src[i];
+        }
+    };
     for (int l = 0; l < d.n_mot; ++l) {
         copy(L.mw(l), p.w[2 * l], tail_param_size(d, 2 * l));
         copy(L.mb(l), p.w[2 * l + 1], AT_CM);
@@ -181,9 +417,9 @@ __device__ __forceinline__ void tail_stage_weights(const TailKParams& p, const T
 
 // The forward of one ray into LDS (both the forward kernel and the backward, which recomputes it).  On return (after the final
 // barrier): x0, xs[], hi, li, kP, nP, q, aP, ls, kI, nI, aS, f, yb (= convd f, the BatchNorm's input).
-__device__ __forceinline__ void tail_forward_ray(const TailKParams& p, const TailLds& L, long r) {
+__device__ __forceinline__ void tail_forward_ray(const TailKParams& p, const TailLds& L, long r, AtClock& clk) {
     const TailDims& d = p.d;
-    const int tid = threadIdx.x, P = d.P, S = d.S;
+    const int tid = at_tid(), P = d.P, S = d.S;
     // awp.py:89-95, 104-105: [integrated features | view_feature | direction encoding of the first sub-exposure's ray]
     for (int i = tid; i < P * AT_WS; i += AT_NT) {
         const int pp = i >> 6, k = i & 63;
@@ -207,12 +443,13 @@ __device__ __forceinline__ void tail_forward_ray(const TailKParams& p, const Tai
         L.x0[pp * d.IN0 + AT_WS + j] = v;
     }
     __syncthreads();
+    clk.mark(1);
     // awp.py:107-109 (layer 0) and mam.py:72-74 applied to the per-sample part's inter sums
     lin<1>(L.xs(0), AT_CM, L.x0, d.IN0, L.mw(0), L.mb(0), P, AT_CM, d.IN0);
     lin<0>(L.li, AT_CM, L.hi, AT_WS, L.lin_w, L.lin_b, P, AT_CM, AT_WS);
     // ... and to the intra sums: one sample row per lane pair, 16 of the 32 outputs each
-    const int sl = tid >> 1, hf = tid & 1;
-    for (int s0 = 0; s0 < S; s0 += AT_NT / 2) {
+    const int sl = tid / AT_LPS, hf = tid % AT_LPS;
+    for (int s0 = 0; s0 < S; s0 += AT_NT / AT_LPS) {
         const int s = s0 + sl;
         if (s < S) {
             float x[AT_WS];
@@ -222,112 +459,86 @@ __device__ __forceinline__ void tail_forward_ray(const TailKParams& p, const Tai
                 const float4 v = x4[j];
                 x[4 * j] = v.x; x[4 * j + 1] = v.y; x[4 * j + 2] = v.z; x[4 * j + 3] = v.w;
             }
-#pragma unroll 4
-            for (int j = 0; j < 16; ++j) {
-                const int c = hf * 16 + j;
-                const float4* w4 = reinterpret_cast<const float4*>(L.lin_w + c * AT_WS);
-                float acc = L.lin_b[c];
+            float o[AT_O32];
 #pragma unroll
-                for (int k = 0; k < AT_WS / 4; ++k) {
-                    const float4 w = w4[k];
-                    acc = fmaf(w.x, x[4 * k], acc); acc = fmaf(w.y, x[4 * k + 1], acc);
-                    acc = fmaf(w.z, x[4 * k + 2], acc); acc = fmaf(w.w, x[4 * k + 3], acc);
-                }
-                L.ls[s * AT_LS + c] = acc;
-            }
+            for (int j = 0; j < AT_O32; ++j) o[j] = L.lin_b[hf * AT_O32 + j];
+            rows_dot<AT_WS, AT_O32, 1>(L.lin_w + hf * AT_O32 * AT_WS, x, o);
+#pragma unroll
+            for (int j = 0; j < AT_O32; ++j) L.ls[s * AT_LS + hf * AT_O32 + j] = o[j];
         }
     }
     __syncthreads();
+    clk.mark(2);
     for (int l = 1; l < d.n_mot; ++l) {
         lin<1>(L.xs(l), AT_CM, L.xs(l - 1), AT_CM, L.mw(l), L.mb(l), P, AT_CM, AT_CM);
         if (l == 1) lin<0>(L.kP, AT_MID, L.li, AT_CM, L.conva, nullptr, P, AT_MID, AT_CM);            // mam.py:38
         __syncthreads();
+        clk.mark(3);
     }
     if (d.n_mot == 1) {
         lin<0>(L.kP, AT_MID, L.li, AT_CM, L.conva, nullptr, P, AT_MID, AT_CM);
         __syncthreads();
+        clk.mark(3);
     }
     const float* xg = L.xs(d.n_mot - 1);
     lin<0>(L.q, AT_MID, xg, AT_CM, L.convc, nullptr, P, AT_MID, AT_CM);                               // mam.py:41
     lin<0>(L.nP, AT_MID, L.kP, AT_MID, L.convn, nullptr, P, AT_MID, AT_MID);                          // mam.py:46
-    for (int s0 = 0; s0 < S; s0 += AT_NT / 2) {                                                       // mam.py:39: convb
+    for (int s0 = 0; s0 < S; s0 += AT_NT / AT_LPS) {                                                       // mam.py:39: convb
         const int s = s0 + sl;
         if (s < S) {
             float x[AT_CM];
 #pragma unroll
             for (int c = 0; c < AT_CM; ++c) x[c] = L.ls[s * AT_LS + c];
-#pragma unroll 2
-            for (int j = 0; j < 8; ++j) {
-                const int m = hf * 8 + j;
-                const float4* w4 = reinterpret_cast<const float4*>(L.convb + m * AT_CM);
-                float acc = 0.f;
+            float o[AT_O16] = {};
+            rows_dot<AT_CM, AT_O16, AT_O16>(L.convb + hf * AT_O16 * AT_CM, x, o);
 #pragma unroll
-                for (int k = 0; k < AT_CM / 4; ++k) {
-                    const float4 w = w4[k];
-                    acc = fmaf(w.x, x[4 * k], acc); acc = fmaf(w.y, x[4 * k + 1], acc);
-                    acc = fmaf(w.z, x[4 * k + 2], acc); acc = fmaf(w.w, x[4 * k + 3], acc);
-                }
-                L.kI[s * AT_LK + m] = acc;
-            }
+            for (int j = 0; j < AT_O16; ++j) L.kI[s * AT_LK + hf * AT_O16 + j] = o[j];
         }
     }
     __syncthreads();
+    clk.mark(5);
     mm<0, false>(L.aP, P, L.q, AT_MID, 1, L.kP, AT_MID, 1, nullptr, P, P, AT_MID);                   // mam.py:42: logits over the sub-exposures
-    for (int s0 = 0; s0 < S; s0 += AT_NT / 2) {                                                       // mam.py:47 (convl), :43 (logits over the samples)
+    for (int s0 = 0; s0 < S; s0 += AT_NT / AT_LPS) {                                                       // mam.py:47 (convl), :43 (logits over the samples)
         const int s = s0 + sl;
         if (s < S) {
             float x[AT_MID];
 #pragma unroll
             for (int c = 0; c < AT_MID; ++c) x[c] = L.kI[s * AT_LK + c];
-#pragma unroll 2
-            for (int j = 0; j < 8; ++j) {
-                const int m = hf * 8 + j;
-                const float4* w4 = reinterpret_cast<const float4*>(L.convl + m * AT_MID);
-                float acc = 0.f;
+            float o[AT_O16] = {};
+            rows_dot<AT_MID, AT_O16, AT_O16>(L.convl + hf * AT_O16 * AT_MID, x, o);
 #pragma unroll
-                for (int k = 0; k < AT_MID / 4; ++k) {
-                    const float4 w = w4[k];
-                    acc = fmaf(w.x, x[4 * k], acc); acc = fmaf(w.y, x[4 * k + 1], acc);
-                    acc = fmaf(w.z, x[4 * k + 2], acc); acc = fmaf(w.w, x[4 * k + 3], acc);
-                }
-                L.nI[s * AT_LK + m] = acc;
-            }
-            for (int pp = hf; pp < P; pp += 2) {
-                const float4* q4 = reinterpret_cast<const float4*>(L.q + pp * AT_MID);
-                float acc = 0.f;
-#pragma unroll
-                for (int k = 0; k < AT_MID / 4; ++k) {
-                    const float4 w = q4[k];
-                    acc = fmaf(w.x, x[4 * k], acc); acc = fmaf(w.y, x[4 * k + 1], acc);
-                    acc = fmaf(w.z, x[4 * k + 2], acc); acc = fmaf(w.w, x[4 * k + 3], acc);
-                }
-                L.aS[pp * d.SA + s] = acc;
-            }
+            for (int j = 0; j < AT_O16; ++j) L.nI[s * AT_LK + hf * AT_O16 + j] = o[j];
+            p_dot16(L.aS + s, d.SA, L.q, AT_MID, hf, P, x);
         }
     }
     __syncthreads();
-    for (int row = tid >> 6; row < 2 * P; row += AT_NT / 64) {                                        // mam.py:42-43: the softmaxes
-        if (row < P) softmax_row(L.aP + row * P, P);
-        else softmax_row(L.aS + (row - P) * d.SA, S);
-    }
+    clk.mark(6);
+    for (int row = tid >> 6; row < P; row += AT_NT / 64) softmax_row(L.aS + row * d.SA, S);          // mam.py:42-43: the softmaxes
+    if (tid >= AT_NT - 64 && tid - (AT_NT - 64) < P) softmax_small(L.aP + (tid - (AT_NT - 64)) * P, P);
     __syncthreads();
+    clk.mark(7);
     mm<0, false>(L.f, AT_CM, L.aP, P, 1, L.nP, 1, AT_MID, nullptr, P, AT_MID, P);                     // mam.py:49
     mm<0, false>(L.f + AT_MID, AT_CM, L.aS, d.SA, 1, L.nI, 1, AT_LK, nullptr, P, AT_MID, S);          // mam.py:50 (:52: the concatenation)
     __syncthreads();
+    clk.mark(8);
     lin<0>(L.yb, AT_CM, L.f, AT_CM, L.convd, nullptr, P, AT_CM, AT_CM);                               // mam.py:53: convd[0]
     __syncthreads();
+    clk.mark(9);
 }
 
 __global__ __launch_bounds__(AT_NT) void k_awp_tail_fwd(TailKParams p) {
     extern __shared__ float lds[];
     TailLds L;
     tail_lds_layout(lds, p.d, false, L);
+    AtClock clk;
+    clk.start();
     tail_stage_weights(p, L);
     __syncthreads();
+    clk.mark(0);
     const int tid = threadIdx.x, P = p.d.P;
     double s1 = 0.0, s2 = 0.0;                                   // lanes 0..31: the sums of this workgroup's y, y^2 of channel tid
     for (long r = blockIdx.x; r < p.R; r += gridDim.x) {
-        tail_forward_ray(p, L, r);
+        tail_forward_ray(p, L, r, clk);
         const float* xg = L.xs(p.d.n_mot - 1);
         for (int i = tid; i < P * AT_CM; i += AT_NT) {
             p.y[r * P * AT_CM + i] = L.yb[i];
@@ -344,7 +555,9 @@ __global__ __launch_bounds__(AT_NT) void k_awp_tail_fwd(TailKParams p) {
             s2 += (double)b;
         }
         __syncthreads();
+        clk.mark(10);
     }
+    clk.flush(p.stamps);
     if (tid < AT_CM) {
         p.bn_part[(long)blockIdx.x * 2 * AT_CM + tid] = s1;
         p.bn_part[(long)blockIdx.x * 2 * AT_CM + AT_CM + tid] = s2;
@@ -366,7 +579,7 @@ struct TailFinishParams {
     int partB_stride;
 };
 
-constexpr int AT_FR = 8;               // rays per workgroup of the finish kernels (a ray per 32 lanes)
+constexpr int AT_FT = 256, AT_FR = AT_FT / 32;      // threads and rays per workgroup of the finish kernels (a ray per 32 lanes)
 
 // mam.py:53 (BatchNorm, residual, leaky_relu) and awp.py:112-115 of one ray on 32 lanes (lane = channel; called by every lane of the
 // workgroup, rays past the end compute on the last ray and write nothing); returns through LDS: sh_hm[32] the mean over P, sh_w[P] the
@@ -397,7 +610,7 @@ __device__ __forceinline__ void finish_ray(const TailFinishParams& p, long r, in
     for (int j = 0; j < P; ++j) tot += sh_w[j];
 }
 
-__global__ __launch_bounds__(AT_NT) void k_awp_tail_finish(TailFinishParams p) {
+__global__ __launch_bounds__(AT_FT) void k_awp_tail_finish(TailFinishParams p) {
     __shared__ double red[4][2 * AT_CM];
     __shared__ float stat[2 * AT_CM], hm[AT_FR][AT_CM], sw[AT_FR][AT_MAXP];
     const int tid = threadIdx.x, col = tid & 63, grp = tid >> 6;
@@ -437,7 +650,7 @@ __global__ __launch_bounds__(AT_NT) void k_awp_tail_finish(TailFinishParams p) {
 }
 
 // d out -> d z, and this workgroup's partial sums of d beta, d gamma (BatchNorm) and d w_linear
-__global__ __launch_bounds__(AT_NT) void k_awp_tail_bwd0(TailFinishParams p) {
+__global__ __launch_bounds__(AT_FT) void k_awp_tail_bwd0(TailFinishParams p) {
     __shared__ float stat[2 * AT_CM], hm[AT_FR][AT_CM], sw[AT_FR][AT_MAXP], dpre[AT_FR][AT_MAXP], red[AT_FR][2 * AT_CM];
     const int tid = threadIdx.x, P = p.P;
     if (tid < 2 * AT_CM) stat[tid] = p.stats[tid];
@@ -445,7 +658,7 @@ __global__ __launch_bounds__(AT_NT) void k_awp_tail_bwd0(TailFinishParams p) {
     const int slot = tid >> 5, c = tid & 31;
     const long r = (long)blockIdx.x * AT_FR + slot;
     float dbeta = 0.f, dgamma = 0.f;
-    for (int j = tid; j < AT_FR * AT_MAXP; j += AT_NT) (&dpre[0][0])[j] = 0.f;
+    for (int j = tid; j < AT_FR * AT_MAXP; j += AT_FT) (&dpre[0][0])[j] = 0.f;
     float tot, z[AT_MAXP];
     finish_ray<true>(p, r < p.R ? r : p.R - 1, c, stat, hm[slot], sw[slot], tot, z);
     if (r >= p.R) hm[slot][c] = 0.f;                           // (rays past the end add nothing to d w_linear)
@@ -483,7 +696,7 @@ __global__ __launch_bounds__(AT_NT) void k_awp_tail_bwd0(TailFinishParams p) {
         for (int s = 0; s < AT_FR; ++s) a += red[s][tid];
         part[tid] = a;
     }
-    for (int i = tid; i < P * AT_CM + P; i += AT_NT) {          // d w_linear.weight[j][k] = sum_rays d pre_j hm_k;  .bias[j] = sum d pre_j
+    for (int i = tid; i < P * AT_CM + P; i += AT_FT) {          // d w_linear.weight[j][k] = sum_rays d pre_j hm_k;  .bias[j] = sum d pre_j
         float a = 0.f;
         if (i < P * AT_CM) {
             const int j = i / AT_CM, k = i - j * AT_CM;
@@ -497,30 +710,36 @@ __global__ __launch_bounds__(AT_NT) void k_awp_tail_bwd0(TailFinishParams p) {
 
 __global__ __launch_bounds__(AT_NT) void k_awp_tail_bwd(TailKParams p) {
     extern __shared__ float lds[];
-    __shared__ double redd[4][2 * AT_CM];
+    __shared__ double redd[AT_NT / 64][2 * AT_CM];
     __shared__ float sums[2 * AT_CM], stat[2 * AT_CM];
     TailLds L;
     tail_lds_layout(lds, p.d, true, L);
+    AtClock clk;
+    clk.start();
     tail_stage_weights(p, L);
     const TailDims& d = p.d;
-    const int tid = threadIdx.x, P = d.P, S = d.S, nm = d.n_mot;
+    const int tid0 = threadIdx.x, P = d.P, S = d.S, nm = d.n_mot;
     {   // d beta, d gamma over all rays (k_awp_tail_bwd0's partial rows)
-        const int col = tid & 63, grp = tid >> 6;
+        const int col = tid0 & 63, grp = tid0 >> 6;
         double a = 0.0;
-        for (int i = grp; i < p.nblkB; i += 4) a += (double)p.partB[(long)i * p.partB_stride + col];
+        for (int i = grp; i < p.nblkB; i += AT_NT / 64) a += (double)p.partB[(long)i * p.partB_stride + col];
         redd[grp][col] = a;
-        if (tid < 2 * AT_CM) stat[tid] = p.stats[tid];
+        if (tid0 < 2 * AT_CM) stat[tid0] = p.stats[tid0];
     }
-    float* part = p.partA + (long)blockIdx.x * p.off[p.nw];
-    for (long i = tid; i < p.off[p.nw]; i += AT_NT) part[i] = 0.f;
+    float* part = p.partA + (long)blockIdx.x * p.partA_stride;
+    for (long i = tid0; i < p.off[p.nw]; i += AT_NT) part[i] = 0.f;
     __syncthreads();
-    if (tid < 2 * AT_CM) sums[tid] = (float)((redd[0][tid] + redd[1][tid] + redd[2][tid] + redd[3][tid]) / ((double)p.R * P));
+    if (tid0 < 2 * AT_CM) {
+        double a = 0.0;
+        for (int g = 0; g < AT_NT / 64; ++g) a += redd[g][tid0];
+        sums[tid0] = (float)(a / ((double)p.R * P));
+    }
     __syncthreads();
     const long* off = p.off;
     const int wb = 2 * nm;
-    const int sl = tid >> 1, hf = tid & 1;
     for (long r = blockIdx.x; r < p.R; r += gridDim.x) {
-        tail_forward_ray(p, L, r);
+        tail_forward_ray(p, L, r, clk);
+        const int tid = at_tid(), sl = tid / AT_LPS, hf = tid % AT_LPS;      // (per ray: see at_tid)
         const float* xg = L.xs(nm - 1);
         // BatchNorm backward (mam.py:24-27 in training: batch statistics; eval: the running estimates are constants), and the residual
         for (int i = tid; i < P * AT_CM; i += AT_NT) {
@@ -532,54 +751,38 @@ __global__ __launch_bounds__(AT_NT) void k_awp_tail_bwd(TailKParams p) {
             L.dxa[i] = dzv;                                                                         // d x_global, the residual's share
         }
         __syncthreads();
+        clk.mark(11);
         wacc(part + off[wb + TW_CONVD], L.yb, AT_CM, L.f, AT_CM, P, AT_CM, AT_CM);
         mm<0, false>(L.df, AT_CM, L.yb, AT_CM, 1, L.convd, 1, AT_CM, nullptr, P, AT_CM, AT_CM);      // d f = d y convd
         __syncthreads();
+        clk.mark(12);
         // attention over the sub-exposures (mam.py:42, 46, 49) and over the samples (:43, 47, 50)
         mm<0, false>(L.daP, P, L.df, AT_CM, 1, L.nP, AT_MID, 1, nullptr, P, P, AT_MID);              // d aP[p][p'] = d fP[p] . nP[p']
         mm<0, false>(L.dnP, AT_MID, L.aP, 1, P, L.df, 1, AT_CM, nullptr, P, AT_MID, P);              // d nP[p'][m] = sum_p aP[p][p'] d fP[p][m]
-        for (int s0 = 0; s0 < S; s0 += AT_NT / 2) {
+        for (int s0 = 0; s0 < S; s0 += AT_NT / AT_LPS) {
             const int s = s0 + sl;
             if (s < S) {
                 float x[AT_MID];
 #pragma unroll
                 for (int c = 0; c < AT_MID; ++c) x[c] = L.nI[s * AT_LK + c];
-                for (int pp = hf; pp < P; pp += 2) {                                                 // d aS[p][s] = d fI[p] . nI[s]
-                    const float4* g4 = reinterpret_cast<const float4*>(L.df + pp * AT_CM + AT_MID);
-                    float acc = 0.f;
-#pragma unroll
-                    for (int k = 0; k < AT_MID / 4; ++k) {
-                        const float4 w = g4[k];
-                        acc = fmaf(w.x, x[4 * k], acc); acc = fmaf(w.y, x[4 * k + 1], acc);
-                        acc = fmaf(w.z, x[4 * k + 2], acc); acc = fmaf(w.w, x[4 * k + 3], acc);
-                    }
-                    L.daS[pp * d.SA + s] = acc;
-                }
+                p_dot16(L.daS + s, d.SA, L.df + AT_MID, AT_CM, hf, P, x);                            // d aS[p][s] = d fI[p] . nI[s]
             }
         }
         __syncthreads();
-        for (int s0 = 0; s0 < S; s0 += AT_NT / 2) {                                                  // d nI[s][m] = sum_p aS[p][s] d fI[p][m]  (into nI's place)
+        clk.mark(13);
+        for (int s0 = 0; s0 < S; s0 += AT_NT / AT_LPS) {                                                  // d nI[s][m] = sum_p aS[p][s] d fI[p][m]  (into nI's place)
             const int s = s0 + sl;
             if (s < S) {
-                float acc[8];
+                float acc[AT_O16] = {};
+                p_acc<AT_O16>(L.aS + s, d.SA, L.df + AT_MID + hf * AT_O16, AT_CM, P, acc);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-                for (int pp = 0; pp < P; ++pp) {
-                    const float a = L.aS[pp * d.SA + s];
-                    const float4* g4 = reinterpret_cast<const float4*>(L.df + pp * AT_CM + AT_MID + hf * 8);
-                    const float4 g0 = g4[0], g1 = g4[1];
-                    acc[0] = fmaf(a, g0.x, acc[0]); acc[1] = fmaf(a, g0.y, acc[1]); acc[2] = fmaf(a, g0.z, acc[2]); acc[3] = fmaf(a, g0.w, acc[3]);
-                    acc[4] = fmaf(a, g1.x, acc[4]); acc[5] = fmaf(a, g1.y, acc[5]); acc[6] = fmaf(a, g1.z, acc[6]); acc[7] = fmaf(a, g1.w, acc[7]);
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) L.nI[s * AT_LK + hf * 8 + j] = acc[j];
+                for (int j = 0; j < AT_O16; ++j) L.nI[s * AT_LK + hf * AT_O16 + j] = acc[j];
             }
         }
-        for (int row = tid >> 6; row < 2 * P; row += AT_NT / 64) {
-            if (row < P) softmax_row_bwd(L.aP + row * P, L.daP + row * P, P);
-            else softmax_row_bwd(L.aS + (row - P) * d.SA, L.daS + (row - P) * d.SA, S);
-        }
+        for (int row = tid >> 6; row < P; row += AT_NT / 64) softmax_row_bwd(L.aS + row * d.SA, L.daS + row * d.SA, S);
+        if (tid >= AT_NT - 64 && tid - (AT_NT - 64) < P) softmax_small_bwd(L.aP + (tid - (AT_NT - 64)) * P, L.daP + (tid - (AT_NT - 64)) * P, P);
         __syncthreads();
+        clk.mark(14);
         float* dnI = L.nI;
         // d q = d lgP kP + d lgS kI;  d kP = d lgP^T q + d nP convn;  d kI = d lgS^T q + d nI convl
         mm<0, false>(L.dq, AT_MID, L.daP, P, 1, L.kP, 1, AT_MID, nullptr, P, AT_MID, P);
@@ -588,90 +791,63 @@ __global__ __launch_bounds__(AT_NT) void k_awp_tail_bwd(TailKParams p) {
         mm<0, true>(L.dkP, AT_MID, L.dnP, AT_MID, 1, L.convn, 1, AT_MID, nullptr, P, AT_MID, AT_MID);
         wacc(part + off[wb + TW_CONVN], L.dnP, AT_MID, L.kP, AT_MID, P, AT_MID, AT_MID);
         wacc(part + off[wb + TW_CONVL], dnI, AT_LK, L.kI, AT_LK, S, AT_MID, AT_MID);
-        for (int s0 = 0; s0 < S; s0 += AT_NT / 2) {
+        for (int s0 = 0; s0 < S; s0 += AT_NT / AT_LPS) {
             const int s = s0 + sl;
             if (s < S) {
-                float acc[8];
+                float acc[AT_O16] = {}, g[AT_MID];
+                p_acc<AT_O16>(L.daS + s, d.SA, L.q + hf * AT_O16, AT_MID, P, acc);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-                for (int pp = 0; pp < P; ++pp) {
-                    const float a = L.daS[pp * d.SA + s];
-                    const float4* g4 = reinterpret_cast<const float4*>(L.q + pp * AT_MID + hf * 8);
-                    const float4 g0 = g4[0], g1 = g4[1];
-                    acc[0] = fmaf(a, g0.x, acc[0]); acc[1] = fmaf(a, g0.y, acc[1]); acc[2] = fmaf(a, g0.z, acc[2]); acc[3] = fmaf(a, g0.w, acc[3]);
-                    acc[4] = fmaf(a, g1.x, acc[4]); acc[5] = fmaf(a, g1.y, acc[5]); acc[6] = fmaf(a, g1.z, acc[6]); acc[7] = fmaf(a, g1.w, acc[7]);
-                }
-                for (int m = 0; m < AT_MID; ++m) {
-                    const float a = dnI[s * AT_LK + m];
-                    const float4* g4 = reinterpret_cast<const float4*>(L.convl + m * AT_MID + hf * 8);
-                    const float4 g0 = g4[0], g1 = g4[1];
-                    acc[0] = fmaf(a, g0.x, acc[0]); acc[1] = fmaf(a, g0.y, acc[1]); acc[2] = fmaf(a, g0.z, acc[2]); acc[3] = fmaf(a, g0.w, acc[3]);
-                    acc[4] = fmaf(a, g1.x, acc[4]); acc[5] = fmaf(a, g1.y, acc[5]); acc[6] = fmaf(a, g1.z, acc[6]); acc[7] = fmaf(a, g1.w, acc[7]);
-                }
+                for (int m = 0; m < AT_MID; ++m) g[m] = dnI[s * AT_LK + m];
+                cols_acc<AT_MID, AT_O16, 8>(L.convl + hf * AT_O16, AT_MID, g, acc);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) L.dkI[s * AT_LK + hf * 8 + j] = acc[j];
+                for (int j = 0; j < AT_O16; ++j) L.dkI[s * AT_LK + hf * AT_O16 + j] = acc[j];
             }
         }
         __syncthreads();
+        clk.mark(15);
         // conva / convb / convc, and back through MAM.linear
         wacc(part + off[wb + TW_CONVA], L.dkP, AT_MID, L.li, AT_CM, P, AT_MID, AT_CM);
         wacc(part + off[wb + TW_CONVB], L.dkI, AT_LK, L.ls, AT_LS, S, AT_MID, AT_CM);
         wacc(part + off[wb + TW_CONVC], L.dq, AT_MID, xg, AT_CM, P, AT_MID, AT_CM);
         mm<0, false>(L.dli, AT_CM, L.dkP, AT_MID, 1, L.conva, 1, AT_CM, nullptr, P, AT_CM, AT_MID);
         mm<0, true>(L.dxa, AT_CM, L.dq, AT_MID, 1, L.convc, 1, AT_CM, nullptr, P, AT_CM, AT_MID);   // d x_global += d q convc
-        for (int s0 = 0; s0 < S; s0 += AT_NT / 2) {                                                  // d ls[s] = d kI[s] convb
+        for (int s0 = 0; s0 < S; s0 += AT_NT / AT_LPS) {                                                  // d ls[s] = d kI[s] convb
             const int s = s0 + sl;
             if (s < S) {
-                float acc[16];
+                float acc[AT_O32] = {}, g[AT_MID];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-                for (int m = 0; m < AT_MID; ++m) {
-                    const float a = L.dkI[s * AT_LK + m];
-                    const float4* g4 = reinterpret_cast<const float4*>(L.convb + m * AT_CM + hf * 16);
+                for (int m = 0; m < AT_MID; ++m) g[m] = L.dkI[s * AT_LK + m];
+                cols_acc<AT_MID, AT_O32, 8>(L.convb + hf * AT_O32, AT_CM, g, acc);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float4 g = g4[k];
-                        acc[4 * k] = fmaf(a, g.x, acc[4 * k]); acc[4 * k + 1] = fmaf(a, g.y, acc[4 * k + 1]);
-                        acc[4 * k + 2] = fmaf(a, g.z, acc[4 * k + 2]); acc[4 * k + 3] = fmaf(a, g.w, acc[4 * k + 3]);
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 16; ++j) L.dls[s * AT_LS + hf * 16 + j] = acc[j];
+                for (int j = 0; j < AT_O32; ++j) L.dls[s * AT_LS + hf * AT_O32 + j] = acc[j];
             }
         }
         __syncthreads();
-        wacc(part + off[wb + TW_LIN_W], L.dli, AT_CM, L.hi, AT_WS, P, AT_CM, AT_WS);
-        wacc(part + off[wb + TW_LIN_W], L.dls, AT_LS, p.h_intra + r * S * AT_WS, AT_WS, S, AT_CM, AT_WS);
+        clk.mark(16);
+        wacc_lin(part + off[wb + TW_LIN_W], L.dli, L.hi, P, L.dls, p.h_intra + r * S * AT_WS, S);
         bacc(part + off[wb + TW_LIN_B], L.dli, AT_CM, P, AT_CM);
         bacc(part + off[wb + TW_LIN_B], L.dls, AT_LS, S, AT_CM);
         mm<0, false>(p.d_hi + r * P * AT_WS, AT_WS, L.dli, AT_CM, 1, L.lin_w, 1, AT_WS, nullptr, P, AT_WS, AT_CM);
-        for (int s0 = 0; s0 < S; s0 += AT_NT / 2) {                                                  // d h_intra[s] = d ls[s] MAM.linear.weight
+        for (int s0 = 0; s0 < S; s0 += AT_NT / AT_LPS) {                                                  // d h_intra[s] = d ls[s] MAM.linear.weight
             const int s = s0 + sl;
             if (s < S) {
-                float acc[32];
+                float acc[AT_O64] = {}, g[AT_CM];
 #pragma unroll
-                for (int j = 0; j < 32; ++j) acc[j] = 0.f;
-                for (int c = 0; c < AT_CM; ++c) {
-                    const float a = L.dls[s * AT_LS + c];
-                    const float4* g4 = reinterpret_cast<const float4*>(L.lin_w + c * AT_WS + hf * 32);
+                for (int c = 0; c < AT_CM; ++c) g[c] = L.dls[s * AT_LS + c];
+                cols_acc<AT_CM, AT_O64, 4>(L.lin_w + hf * AT_O64, AT_WS, g, acc);
+                float4* o4 = reinterpret_cast<float4*>(p.d_hs + (r * S + s) * AT_WS + hf * AT_O64);
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const float4 g = g4[k];
-                        acc[4 * k] = fmaf(a, g.x, acc[4 * k]); acc[4 * k + 1] = fmaf(a, g.y, acc[4 * k + 1]);
-                        acc[4 * k + 2] = fmaf(a, g.z, acc[4 * k + 2]); acc[4 * k + 3] = fmaf(a, g.w, acc[4 * k + 3]);
-                    }
-                }
-                float4* o4 = reinterpret_cast<float4*>(p.d_hs + (r * S + s) * AT_WS + hf * 32);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) o4[k] = make_float4(acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3]);
+                for (int k = 0; k < AT_O64 / 4; ++k) o4[k] = make_float4(acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3]);
             }
         }
         // the motion embedding backwards (awp.py:107-109)
         float *dx = L.dxa, *dprev = L.dxb;
         for (int l = nm - 1; l >= 0; --l) {
             __syncthreads();
+            clk.mark(l == nm - 1 ? 17 : 19);
             for (int i = tid; i < P * AT_CM; i += AT_NT) dx[i] = L.xs(l)[i] > 0.f ? dx[i] : 0.f;
             __syncthreads();
+            clk.mark(18);
             const int K = l == 0 ? d.IN0 : AT_CM;
             const float* xin = l == 0 ? L.x0 : L.xs(l - 1);
             wacc(part + off[2 * l], dx, AT_CM, xin, K, P, AT_CM, K);
@@ -680,6 +856,7 @@ __global__ __launch_bounds__(AT_NT) void k_awp_tail_bwd(TailKParams p) {
             float* t = dx; dx = dprev; dprev = t;
         }
         __syncthreads();
+        clk.mark(19);
         // dx: d [integrated features | view_feature | direction encoding] of every sub-exposure, [P][IN0]
         for (int i = tid; i < P * AT_WS; i += AT_NT) p.d_h[r * P * AT_WS + i] = dx[(i >> 6) * d.IN0 + (i & 63)];
         for (int j = tid; j < d.VC; j += AT_NT) {
@@ -689,6 +866,7 @@ __global__ __launch_bounds__(AT_NT) void k_awp_tail_bwd(TailKParams p) {
             else L.tmp[j - d.VF] = a;
         }
         __syncthreads();
+        clk.mark(20);
         if (tid < 3 * P) {
             float out = 0.f;
             if (tid < 3 && d.F >= 0) {                                 // awp.py:89-92: d (d / |d|) of the first sub-exposure's ray
@@ -712,13 +890,15 @@ __global__ __launch_bounds__(AT_NT) void k_awp_tail_bwd(TailKParams p) {
             p.d_rays[r * P * 3 + tid] = out;
         }
         __syncthreads();
+        clk.mark(21);
     }
+    clk.flush(p.stamps);
 }
 
 struct TailReduceParams {
     const float *partA, *partB;
     int nA, nB, partB_stride, n_tail, P;          // n_tail: elements of d_params in front of convd.1.weight
-    long total;
+    long total, partA_stride;
     float* d_params;
 };
 // d_params[i] = sum over the partial rows; the BatchNorm and w_linear gradients come from k_awp_tail_bwd0's rows (d beta, d gamma, d W, d b)
@@ -727,7 +907,7 @@ __global__ __launch_bounds__(256) void k_awp_tail_reduce(TailReduceParams p) {
     if (i >= p.total) return;
     float a = 0.f;
     if (i < p.n_tail) {
-        for (int b = 0; b < p.nA; ++b) a += p.partA[(long)b * p.total + i];
+        for (int b = 0; b < p.nA; ++b) a += p.partA[(long)b * p.partA_stride + i];
     } else {
         const long j = i - p.n_tail;                                   // 0..31 d gamma, 32..63 d beta, then w_linear
         const long col = j < AT_CM ? AT_CM + j : (j < 2 * AT_CM ? j - AT_CM : j);
@@ -749,7 +929,7 @@ static int tail_check(const char* who, const evd_awp_tail_desc* d, long R, bool 
     dims = tail_dims(d->P, d->S, d->VF, d->dir_freqs, d->n_mot);
     TailLds L;
     lds_bytes = sizeof(float) * tail_lds_layout(nullptr, dims, bwd, L);
-    const size_t fixed = bwd ? 4 * 128 * sizeof(double) + 1024 : 0;       // the backward kernel's static arrays
+    const size_t fixed = bwd ? (AT_NT / 64) * 64 * sizeof(double) + 1024 : 0;       // the backward kernel's static arrays
     EVD_REQUIRE(lds_bytes + fixed <= 160 * 1024, "%s: P = %d, S = %d needs %zu bytes of LDS per ray (the CU has 160 KiB)", who, d->P, d->S,
                 lds_bytes + fixed);
     return EVD_OK;
@@ -797,9 +977,9 @@ long evd_awp_tail_param_count(const evd_awp_tail_desc* d) {
 size_t evd_awp_tail_workspace_bytes(const evd_awp_tail_desc* d, long R, int backward) {
     if (!d || R < 0) return 0;
     const int grid = tail_grid(R > 0 ? R : 1);
-    if (!backward) return sizeof(double) * 2 * AT_CM * (size_t)grid + 256;
+    if (!backward) return sizeof(double) * 2 * AT_CM * (size_t)grid + 1024;
     const long total = evd_awp_tail_param_count(d);
-    return sizeof(float) * ((size_t)R * d->P * AT_CM + (size_t)tail_nblk(R) * tail_partB_stride(d->P) + (size_t)grid * (size_t)total) + 1024;
+    return sizeof(float) * ((size_t)R * d->P * AT_CM + (size_t)tail_nblk(R) * tail_partB_stride(d->P) + (size_t)grid * (size_t)((total + 3) & ~3L)) + 2048;
 }
 
 int evd_awp_tail_forward(const evd_awp_tail_desc* d, const float* const* params, const float* h, const float* view_feature,
@@ -825,6 +1005,7 @@ int evd_awp_tail_forward(const evd_awp_tail_desc* d, const float* const* params,
     k.h = h; k.vf = view_feature; k.rays_d = rays_d; k.h_inter = h_inter; k.h_intra = h_intra;
     k.y = saved_y; k.xg = saved_xg;
     k.bn_part = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(workspace) + 63) & ~(uintptr_t)63);
+    k.stamps = reinterpret_cast<long long*>(static_cast<char*>(workspace) + evd_awp_tail_workspace_bytes(d, R, 0) - 512);
     const int grid = tail_grid(R);
     EVD_SET_MAX_LDS(k_awp_tail_fwd, 160 * 1024);
     k_awp_tail_fwd<<<grid, AT_NT, lds, as_stream(stream)>>>(k);
@@ -835,7 +1016,7 @@ int evd_awp_tail_forward(const evd_awp_tail_desc* d, const float* const* params,
     f.bn_w = w[TW_BN_W]; f.bn_b = w[TW_BN_B]; f.wl_w = w[TW_WL_W]; f.wl_b = w[TW_WL_B];
     f.y = saved_y; f.xg = saved_xg; f.run_mean = bn_running_mean; f.run_var = bn_running_var; f.num_batches = bn_num_batches;
     f.stats = saved_stats; f.out = out;
-    k_awp_tail_finish<<<tail_nblk(R), AT_NT, 0, as_stream(stream)>>>(f);
+    k_awp_tail_finish<<<tail_nblk(R), AT_FT, 0, as_stream(stream)>>>(f);
     EVD_HIP(hipGetLastError());
     return EVD_OK;
 }
@@ -862,25 +1043,28 @@ int evd_awp_tail_backward(const evd_awp_tail_desc* d, const float* const* params
     const int grid = tail_grid(R), nblk = tail_nblk(R), strideB = tail_partB_stride(dims.P);
     float* dz = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 63) & ~(uintptr_t)63);
     float* partB = dz + (size_t)R * dims.P * AT_CM;
-    float* partA = partB + (size_t)nblk * strideB;
+    float* partA = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(partB + (size_t)nblk * strideB) + 63) & ~(uintptr_t)63);
     const float* const* w = params + 2 * dims.n_mot;
     TailFinishParams f{};
     f.P = dims.P; f.training = d->training; f.R = R; f.eps = d->bn_eps; f.nblk = nblk;
     f.bn_w = w[TW_BN_W]; f.bn_b = w[TW_BN_B]; f.wl_w = w[TW_WL_W]; f.wl_b = w[TW_WL_B];
     f.y = saved_y; f.xg = saved_xg; f.stats = const_cast<float*>(saved_stats); f.d_out = d_out; f.dz = dz; f.partB = partB; f.partB_stride = strideB;
-    k_awp_tail_bwd0<<<nblk, AT_NT, 0, as_stream(stream)>>>(f);
+    k_awp_tail_bwd0<<<nblk, AT_FT, 0, as_stream(stream)>>>(f);
     EVD_HIP(hipGetLastError());
     TailKParams k{};
     tail_fill(k, dims, d, params, R);
     k.h = h; k.vf = view_feature; k.rays_d = rays_d; k.h_inter = h_inter; k.h_intra = h_intra;
     k.y = const_cast<float*>(saved_y); k.xg = const_cast<float*>(saved_xg);
     k.dz = dz; k.stats = saved_stats; k.partB = partB; k.nblkB = nblk; k.partB_stride = strideB;
+    k.partA_stride = (total + 3) & ~3L;
+    k.stamps = reinterpret_cast<long long*>(static_cast<char*>(workspace) + evd_awp_tail_workspace_bytes(d, R, 1) - 512);
     k.d_h = d_h; k.d_vf = d_view_feature; k.d_rays = d_rays_d; k.d_hi = d_h_inter; k.d_hs = d_h_intra; k.partA = partA;
-    EVD_SET_MAX_LDS(k_awp_tail_bwd, 160 * 1024 - 4 * 128 * sizeof(double) - 1024);
+    EVD_SET_MAX_LDS(k_awp_tail_bwd, 160 * 1024 - (AT_NT / 64) * 64 * sizeof(double) - 1024);
     k_awp_tail_bwd<<<grid, AT_NT, lds, as_stream(stream)>>>(k);
     EVD_HIP(hipGetLastError());
     TailReduceParams rp{};
     rp.partA = partA; rp.partB = partB; rp.nA = grid; rp.nB = nblk; rp.partB_stride = strideB; rp.P = dims.P; rp.total = total;
+    rp.partA_stride = k.partA_stride;
     rp.n_tail = (int)k.off[2 * dims.n_mot + TW_BN_W];
     rp.d_params = d_params;
     k_awp_tail_reduce<<<(unsigned)((total + 255) / 256), 256, 0, as_stream(stream)>>>(rp);
