@@ -99,8 +99,9 @@ SIGNATURES = {
     "evd_awp_tail_num_params": (_I, [_I]),
     "evd_awp_tail_param_count": (_L, [C.POINTER(AwpTailDesc)]),
     "evd_awp_tail_workspace_bytes": (_S, [C.POINTER(AwpTailDesc), _L, _I]),
-    "evd_awp_tail_forward": (_I, [C.POINTER(AwpTailDesc), C.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _L, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _S, _vp]),
-    "evd_awp_tail_backward": (_I, [C.POINTER(AwpTailDesc), C.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _L, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+    "evd_awp_tail_saved_floats": (_L, [C.POINTER(AwpTailDesc)]),
+    "evd_awp_tail_forward": (_I, [C.POINTER(AwpTailDesc), C.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _L, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _S, _vp]),
+    "evd_awp_tail_backward": (_I, [C.POINTER(AwpTailDesc), C.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _L, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                    _vp, _vp, _vp, _S, _vp]),
     "evd_awp_embed_create": (_I, [C.POINTER(_fp), C.POINTER(_fp), _I, _I, _I, C.POINTER(_vp)]),
     "evd_awp_embed_destroy": (None, [_vp]),

@@ -7,6 +7,7 @@ of the CorrelationModule, ``w_linear``: [R, P, 32] / [R, 32, S]-sized tensors) s
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -160,9 +161,12 @@ class _AwpTail(torch.autograd.Function):
         need = lib.evd_awp_tail_workspace_bytes(C.byref(desc), R, 0)
         ws = torch.empty((need,), dtype=torch.uint8, device=dev)
         rm, rv, nb = bn
+        keep = any(ctx.needs_input_grad)
+        rays = torch.empty((R, lib.evd_awp_tail_saved_floats(C.byref(desc))), **f32) if keep else None     # the rays' forward state
         L.check(lib.evd_awp_tail_forward(C.byref(desc), arr, L.ptr(hh), L.ptr(vf), L.ptr(rd), L.ptr(hi), L.ptr(hs), R, L.ptr(rm), L.ptr(rv),
-                                         L.ptr(nb), L.ptr(out), L.ptr(y), L.ptr(xg), L.ptr(stats), L.ptr(ws), need, L.stream_ptr()),
+                                         L.ptr(nb), L.ptr(out), L.ptr(y), L.ptr(xg), L.ptr(stats), L.ptr(rays), L.ptr(ws), need, L.stream_ptr()),
                 "evd_awp_tail_forward")
+        ctx.rays = rays
         ctx.save_for_backward(hh, vf, rd, hi, hs, y, xg, stats, *ps)
         ctx.desc, ctx.shapes = desc, (h.shape, None if view_feature is None else view_feature.shape, rays_d.shape, h_inter.shape, h_intra.shape,
                                       [t.shape for t in params])
@@ -181,8 +185,9 @@ class _AwpTail(torch.autograd.Function):
         need = lib.evd_awp_tail_workspace_bytes(C.byref(desc), R, 1)
         ws = torch.empty((need,), dtype=torch.uint8, device=dev)
         L.check(lib.evd_awp_tail_backward(C.byref(desc), arr, L.ptr(hh), L.ptr(vf), L.ptr(rd), L.ptr(hi), L.ptr(hs), R, L.ptr(y), L.ptr(xg),
-                                          L.ptr(stats), L.ptr(g.contiguous().float()), L.ptr(d_h), L.ptr(d_vf), L.ptr(d_rd), L.ptr(d_hi),
+                                          L.ptr(stats), L.ptr(ctx.rays), L.ptr(g.contiguous().float()), L.ptr(d_h), L.ptr(d_vf), L.ptr(d_rd), L.ptr(d_hi),
                                           L.ptr(d_hs), L.ptr(d_par), L.ptr(ws), need, L.stream_ptr()), "evd_awp_tail_backward")
+        ctx.rays = None
         sh = ctx.shapes
         grads = [t.reshape(s) for t, s in zip(d_par.split([int(torch.Size(s).numel()) for s in sh[5]]), sh[5])]
         return (None, None, d_h.reshape(sh[0]), None if d_vf is None else d_vf.reshape(sh[1]), d_rd.reshape(sh[2]), d_hi.reshape(sh[3]),
@@ -310,7 +315,7 @@ class FusedAWP(torch.nn.Module):
         self.output_ch = awpnet.output_ch
         self.graph_per_ray = bool(graph_per_ray)
         self._graphed = {}
-        self.tail_kernels = bool(tail_kernels) and not self.graph_per_ray and self._tail_structure()
+        self.tail_kernels = bool(tail_kernels) and not self.graph_per_ray and os.environ.get("EVD_AWP_TAIL", "1") != "0" and self._tail_structure()
         self._F = _dir_freqs(awpnet.ray_dirs_embed_fn) if self.tail_kernels else None
         self._tail_refused = set()
 

@@ -59,7 +59,7 @@ enum { TW_LIN_W = 0, TW_LIN_B, TW_CONVA, TW_CONVB, TW_CONVC, TW_CONVN, TW_CONVL,
 struct TailLds {
     float *mw0, *mb0, *mwr, *lin_w, *lin_b, *conva, *convb, *convc, *convn, *convl, *convd;      // mwr: layers 1.. as (W [32,32], b [32]) records
     float *x0, *xs0, *hi, *li, *kP, *nP, *q, *aP, *f, *yb;                                         // xs0: the layers' outputs, [n_mot][P][32]
-    int xs_stride;
+    int xs_stride, ray_floats;                 // ray_floats: x0 .. aS, the ray's forward state (one contiguous block)
     __host__ __device__ float* mw(int l) const { return l == 0 ? mw0 : mwr + (l - 1) * (AT_CM * AT_CM + AT_CM); }
     __host__ __device__ float* mb(int l) const { return l == 0 ? mb0 : mwr + (l - 1) * (AT_CM * AT_CM + AT_CM) + AT_CM * AT_CM; }
     __host__ __device__ float* xs(int l) const { return xs0 + l * xs_stride; }
@@ -83,6 +83,7 @@ __host__ __device__ inline size_t tail_lds_layout(float* base, const TailDims& d
     L.hi = take(P * AT_WS); L.li = take(P * AT_CM); L.kP = take(P * AT_MID); L.nP = take(P * AT_MID); L.q = take(P * AT_MID);
     L.aP = take(P * P); L.f = take(P * AT_CM); L.yb = take(P * AT_CM);
     L.ls = take((size_t)d.S * AT_LS); L.kI = take((size_t)d.S * AT_LK); L.nI = take((size_t)d.S * AT_LK); L.aS = take(P * d.SA);
+    L.ray_floats = (int)(base + at - L.x0);
     L.df = L.daP = L.dnP = L.dkP = L.dq = L.dli = L.dxa = L.dxb = L.daS = L.dkI = L.dls = L.tmp = nullptr;
     if (bwd) {
         const size_t wide = d.IN0 > AT_WS ? d.IN0 : AT_WS;
@@ -102,6 +103,7 @@ struct TailKParams {
     long R;
     const float *h, *vf, *rays_d, *h_inter, *h_intra;
     float *y, *xg;                     // [R, P, 32] (forward: written; backward: read)
+    float* saved;                      // [R, ray_floats]: every ray's forward state (NULL: the backward recomputes it)
     double* bn_part;                   // forward: [grid][64] sums of y, y^2
     const float *dz, *stats, *partB;   // backward
     int nblkB, partB_stride;
@@ -539,6 +541,12 @@ __global__ __launch_bounds__(AT_NT) void k_awp_tail_fwd(TailKParams p) {
     double s1 = 0.0, s2 = 0.0;                                   // lanes 0..31: the sums of this workgroup's y, y^2 of channel tid
     for (long r = blockIdx.x; r < p.R; r += gridDim.x) {
         tail_forward_ray(p, L, r, clk);
+        if (p.saved) {                                           // the ray's forward state for the backward: 55 KB instead of a second forward
+            float4* dst = reinterpret_cast<float4*>(p.saved + r * L.ray_floats);
+            const float4* src = reinterpret_cast<const float4*>(L.x0);
+#pragma unroll 4
+            for (int i = tid; i < L.ray_floats / 4; i += AT_NT) dst[i] = src[i];
+        }
         const float* xg = L.xs(p.d.n_mot - 1);
         for (int i = tid; i < P * AT_CM; i += AT_NT) {
             p.y[r * P * AT_CM + i] = L.yb[i];
@@ -738,8 +746,17 @@ __global__ __launch_bounds__(AT_NT) void k_awp_tail_bwd(TailKParams p) {
     const long* off = p.off;
     const int wb = 2 * nm;
     for (long r = blockIdx.x; r < p.R; r += gridDim.x) {
-        tail_forward_ray(p, L, r, clk);
         const int tid = at_tid(), sl = tid / AT_LPS, hf = tid % AT_LPS;      // (per ray: see at_tid)
+        if (p.saved) {
+            const float4* src = reinterpret_cast<const float4*>(p.saved + r * L.ray_floats);
+            float4* dst = reinterpret_cast<float4*>(L.x0);
+#pragma unroll 4
+            for (int i = tid; i < L.ray_floats / 4; i += AT_NT) dst[i] = src[i];
+            __syncthreads();
+            clk.mark(1);
+        } else {
+            tail_forward_ray(p, L, r, clk);
+        }
         const float* xg = L.xs(nm - 1);
         // BatchNorm backward (mam.py:24-27 in training: batch statistics; eval: the running estimates are constants), and the residual
         for (int i = tid; i < P * AT_CM; i += AT_NT) {
@@ -974,6 +991,13 @@ long evd_awp_tail_param_count(const evd_awp_tail_desc* d) {
     return at;
 }
 
+long evd_awp_tail_saved_floats(const evd_awp_tail_desc* d) {
+    if (!d || d->n_mot < 1 || d->n_mot > AT_MAXMOT || d->P < 1 || d->P > AT_MAXP || d->S < 1) return -1;
+    TailLds L;
+    tail_lds_layout(nullptr, tail_dims(d->P, d->S, d->VF, d->dir_freqs, d->n_mot), false, L);
+    return L.ray_floats;
+}
+
 size_t evd_awp_tail_workspace_bytes(const evd_awp_tail_desc* d, long R, int backward) {
     if (!d || R < 0) return 0;
     const int grid = tail_grid(R > 0 ? R : 1);
@@ -985,7 +1009,7 @@ size_t evd_awp_tail_workspace_bytes(const evd_awp_tail_desc* d, long R, int back
 int evd_awp_tail_forward(const evd_awp_tail_desc* d, const float* const* params, const float* h, const float* view_feature,
                          const float* rays_d, const float* h_inter, const float* h_intra, long R, float* bn_running_mean,
                          float* bn_running_var, long long* bn_num_batches, float* out, float* saved_y, float* saved_xg, float* saved_stats,
-                         void* workspace, size_t workspace_bytes, void* stream) {
+                         float* saved_rays, void* workspace, size_t workspace_bytes, void* stream) {
     TailDims dims;
     size_t lds = 0;
     if (d && d->training) {          // a training-mode forward is followed by the backward: refuse here what that kernel's working set cannot hold
@@ -1003,7 +1027,7 @@ int evd_awp_tail_forward(const evd_awp_tail_desc* d, const float* const* params,
     TailKParams k{};
     tail_fill(k, dims, d, params, R);
     k.h = h; k.vf = view_feature; k.rays_d = rays_d; k.h_inter = h_inter; k.h_intra = h_intra;
-    k.y = saved_y; k.xg = saved_xg;
+    k.y = saved_y; k.xg = saved_xg; k.saved = saved_rays;
     k.bn_part = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(workspace) + 63) & ~(uintptr_t)63);
     k.stamps = reinterpret_cast<long long*>(static_cast<char*>(workspace) + evd_awp_tail_workspace_bytes(d, R, 0) - 512);
     const int grid = tail_grid(R);
@@ -1023,7 +1047,7 @@ int evd_awp_tail_forward(const evd_awp_tail_desc* d, const float* const* params,
 
 int evd_awp_tail_backward(const evd_awp_tail_desc* d, const float* const* params, const float* h, const float* view_feature,
                           const float* rays_d, const float* h_inter, const float* h_intra, long R, const float* saved_y,
-                          const float* saved_xg, const float* saved_stats, const float* d_out, float* d_h, float* d_view_feature,
+                          const float* saved_xg, const float* saved_stats, const float* saved_rays, const float* d_out, float* d_h, float* d_view_feature,
                           float* d_rays_d, float* d_h_inter, float* d_h_intra, float* d_params, void* workspace, size_t workspace_bytes,
                           void* stream) {
     TailDims dims;
@@ -1054,7 +1078,7 @@ int evd_awp_tail_backward(const evd_awp_tail_desc* d, const float* const* params
     TailKParams k{};
     tail_fill(k, dims, d, params, R);
     k.h = h; k.vf = view_feature; k.rays_d = rays_d; k.h_inter = h_inter; k.h_intra = h_intra;
-    k.y = const_cast<float*>(saved_y); k.xg = const_cast<float*>(saved_xg);
+    k.y = const_cast<float*>(saved_y); k.xg = const_cast<float*>(saved_xg); k.saved = const_cast<float*>(saved_rays);
     k.dz = dz; k.stats = saved_stats; k.partB = partB; k.nblkB = nblk; k.partB_stride = strideB;
     k.partA_stride = (total + 3) & ~3L;
     k.stamps = reinterpret_cast<long long*>(static_cast<char*>(workspace) + evd_awp_tail_workspace_bytes(d, R, 1) - 512);

@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) void k_awp_integrate(const float* __restrict__
     float acc[CPL], Q[CPL];
 #pragma unroll
     for (int q = 0; q < CPL; ++q) { acc[q] = 0.f; Q[q] = 1.f; }
-    constexpr int UN = 4;
+    constexpr int UN = CPL == 1 ? 8 : 4;                 // sample rows of loads in flight (a row is 256 bytes per wavefront)
     for (int s0 = 0; s0 < S; s0 += UN) {
         float f[UN][CPL], dist[UN];
 #pragma unroll
@@ -531,67 +531,94 @@ __global__ __launch_bounds__(256) void k_awp_integrate_bwd(const float* __restri
     const float norm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
     const float* fr = feat + n * (long)S * C;
     const float* zz = z + n * (long)S;
-    float g[CPL], Q[CPL], fc[CPL], fn[CPL];
+    constexpr int PF = CPL == 1 ? 4 : 2;                 // rows per block; the NEXT block's rows are loaded while this one is processed
+    float g[CPL], Q[CPL], cur[PF + 1][CPL], nxt[PF][CPL], ec[CPL];
+    auto row = [&](int s, float (&dst)[CPL]) {
+        const int sc = s < S ? s : S - 1;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) { const int c = lane * CPL + q; dst[q] = c < C ? fr[(long)sc * C + c] : 0.f; }
+    };
 #pragma unroll
     for (int q = 0; q < CPL; ++q) {
         const int c = lane * CPL + q;
         g[q] = c < C ? d_out[n * C + c] : 0.f;
         Q[q] = 1.f;
-        fc[q] = c < C ? fr[c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u <= PF; ++u) row(u, cur[u]);
+    {   // e of row 0 (every row's exponential is evaluated once: as "the next row's" in the iteration before)
+        const float dist0 = S > 1 ? __fmul_rn(__fsub_rn(zz[1], zz[0]), norm) : 0.f;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) ec[q] = S > 1 ? expf(-__fmul_rn(cur[0][q], dist0)) : 1.f;
     }
     float dnorm = 0.f, dz_prev = 0.f;                    // d z[s] carried from the previous interval (+ d dist[s-1] |d|)
-    for (int s = 0; s < S; ++s) {
-        const bool last = s == S - 1;
-        const float dz = last ? 0.f : __fsub_rn(zz[s + 1], zz[s]);
-        const float dist = __fmul_rn(dz, norm);
+    for (int s0 = 0; s0 < S; s0 += PF) {
 #pragma unroll
-        for (int q = 0; q < CPL; ++q) { const int c = lane * CPL + q; fn[q] = (!last && c < C) ? fr[(long)(s + 1) * C + c] : 0.f; }
-        const float dist_n = s + 2 < S ? __fmul_rn(__fsub_rn(zz[s + 2], zz[s + 1]), norm) : 0.f;
-        // this row: e, a, om; Q of the next row
-        float e[CPL], om[CPL], Qn[CPL], local = 1.f;
+        for (int u = 0; u < PF; ++u) row(s0 + PF + 1 + u, nxt[u]);
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int s = s0 + u;
+            if (s < S) {
+                const float (&fc)[CPL] = cur[u];
+                const float (&fn)[CPL] = cur[u + 1];
+                const bool last = s == S - 1;
+                const float dz = last ? 0.f : __fsub_rn(zz[s + 1], zz[s]);
+                const float dist = __fmul_rn(dz, norm);
+                const float dist_n = s + 2 < S ? __fmul_rn(__fsub_rn(zz[s + 2], zz[s + 1]), norm) : 0.f;
+                // this row: e, a, om; Q of the next row
+                float e[CPL], en[CPL], om[CPL], Qn[CPL], local = 1.f;
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) {
+                    const int c = lane * CPL + q;
+                    e[q] = last ? 1.f : ec[q];
+                    om[q] = c < C ? __fadd_rn(last ? 1.f : e[q], 1e-10f) : 1.f;      // the last row's alpha is 0
+                    local *= om[q];
+                }
+                const float incl = awp_scan_mul(local);
+                float excl = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, 1.f), __builtin_bit_cast(int, incl), 0x138, 0xf, 0xf, false));
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) { excl *= om[q]; Qn[q] = excl; }
+                // suffix sums over the channels of G[s+1, c] = g a f Q of the next row
+                float G[CPL], lsum = 0.f;
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) {
+                    en[q] = s + 2 < S ? expf(-__fmul_rn(fn[q], dist_n)) : 1.f;         // e of row s+1 (its alpha is 0 when it is the last row)
+                    const float an = s + 2 < S ? __fadd_rn(-en[q], 1.f) : 0.f;
+                    G[q] = last ? 0.f : g[q] * an * fn[q] * Qn[q];
+                    lsum += G[q];
+                }
+                const float pre_incl = awp_scan_add(lsum);                                   // sum over lanes <= this one
+                const float total = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pre_incl), 63));
+                float sfx = total - pre_incl;                                                 // lanes > this one
+                float ddist = 0.f;
+#pragma unroll
+                for (int q = CPL - 1; q >= 0; --q) {
+                    const int c = lane * CPL + q;
+                    sfx += G[q];                                                              // channels >= c
+                    const float a = last ? 0.f : __fadd_rn(-e[q], 1.f);
+                    const float through = last ? 0.f : sfx / om[q];
+                    const float ga = g[q] * Q[q] * fc[q] - through;                           // d out / d a[s,c]
+                    const float df = last ? 0.f : g[q] * Q[q] * a + ga * dist * e[q];
+                    if (c < C) d_feat[(n * (long)S + s) * C + c] = df;
+                    ddist += last ? 0.f : ga * fc[q] * e[q];
+                }
+                if (d_z || d_rays_d) {
+                    ddist = awp_scan_add(ddist);
+                    ddist = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ddist), 63));
+                    if (d_z && lane == 0) d_z[n * (long)S + s] = dz_prev - ddist * norm;
+                    dz_prev = ddist * norm;
+                    dnorm += ddist * dz;
+                }
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) { Q[q] = Qn[q]; ec[q] = en[q]; }
+            }
+        }
 #pragma unroll
         for (int q = 0; q < CPL; ++q) {
-            const int c = lane * CPL + q;
-            e[q] = last ? 1.f : expf(-__fmul_rn(fc[q], dist));
-            om[q] = c < C ? __fadd_rn(last ? 1.f : e[q], 1e-10f) : 1.f;      // the last row's alpha is 0
-            local *= om[q];
-        }
-        const float incl = awp_scan_mul(local);
-        float excl = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, 1.f), __builtin_bit_cast(int, incl), 0x138, 0xf, 0xf, false));
+            cur[0][q] = cur[PF][q];
 #pragma unroll
-        for (int q = 0; q < CPL; ++q) { excl *= om[q]; Qn[q] = excl; }
-        // suffix sums over the channels of G[s+1, c] = g a f Q of the next row
-        float G[CPL], lsum = 0.f;
-#pragma unroll
-        for (int q = 0; q < CPL; ++q) {
-            const float an = s + 2 < S ? __fadd_rn(-expf(-__fmul_rn(fn[q], dist_n)), 1.f) : 0.f;     // alpha of row s+1 (0 when it is the last row)
-            G[q] = last ? 0.f : g[q] * an * fn[q] * Qn[q];
-            lsum += G[q];
+            for (int u = 0; u < PF; ++u) cur[u + 1][q] = nxt[u][q];
         }
-        const float pre_incl = awp_scan_add(lsum);                                   // sum over lanes <= this one
-        const float total = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pre_incl), 63));
-        float sfx = total - pre_incl;                                                 // lanes > this one
-        float ddist = 0.f;
-#pragma unroll
-        for (int q = CPL - 1; q >= 0; --q) {
-            const int c = lane * CPL + q;
-            sfx += G[q];                                                              // channels >= c
-            const float a = last ? 0.f : __fadd_rn(-e[q], 1.f);
-            const float through = last ? 0.f : sfx / om[q];
-            const float ga = g[q] * Q[q] * fc[q] - through;                           // d out / d a[s,c]
-            const float df = last ? 0.f : g[q] * Q[q] * a + ga * dist * e[q];
-            if (c < C) d_feat[(n * (long)S + s) * C + c] = df;
-            ddist += last ? 0.f : ga * fc[q] * e[q];
-        }
-        if (d_z || d_rays_d) {
-            ddist = awp_scan_add(ddist);
-            ddist = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ddist), 63));
-            if (d_z && lane == 0) d_z[n * (long)S + s] = dz_prev - ddist * norm;
-            dz_prev = ddist * norm;
-            dnorm += ddist * dz;
-        }
-#pragma unroll
-        for (int q = 0; q < CPL; ++q) { Q[q] = Qn[q]; fc[q] = fn[q]; }
     }
     if (d_rays_d && lane < 3) d_rays_d[n * 3 + lane] = norm > 0.f ? dnorm * d[lane] / norm : 0.f;
 }

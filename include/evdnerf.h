@@ -480,7 +480,9 @@ int evd_mam_local_backward(const float* h_local, const float* u, const float* al
  * d_params (backward): ONE flat dev float32 buffer of evd_awp_tail_param_count elements, the same tensors in the same order.
  * BatchNorm: training != 0 normalises with the batch statistics (biased variance) and, when bn_running_mean / _var are given, blends the
  * batch mean / UNBIASED variance into them with bn_momentum and adds 1 to *bn_num_batches (int64, may be NULL); training == 0 uses the
- * running estimates.  saved_y, saved_xg dev [R,P,32] and saved_stats dev [64] (mean, 1/sqrt(var + eps)) are kept for the backward. */
+ * running estimates.  saved_y, saved_xg dev [R,P,32] and saved_stats dev [64] (mean, 1/sqrt(var + eps)) are kept for the backward;
+ * saved_rays dev [R, evd_awp_tail_saved_floats(d)] (optional in both calls) takes every ray's forward state -- 55 KB per ray at P = 10,
+ * S = 128 -- so that the backward does not run the forward a second time (measured: a third of its time). */
 typedef struct {
     int P, S, VF, dir_freqs, n_mot, training;
     float bn_eps, bn_momentum;
@@ -488,15 +490,17 @@ typedef struct {
 int evd_awp_tail_num_params(int n_mot);
 long evd_awp_tail_param_count(const evd_awp_tail_desc* d);
 size_t evd_awp_tail_workspace_bytes(const evd_awp_tail_desc* d, long R, int backward);
+long evd_awp_tail_saved_floats(const evd_awp_tail_desc* d);
 int evd_awp_tail_forward(const evd_awp_tail_desc* d, const float* const* params, const float* h, const float* view_feature,
                          const float* rays_d, const float* h_inter, const float* h_intra, long R, float* bn_running_mean,
                          float* bn_running_var, long long* bn_num_batches, float* out, float* saved_y, float* saved_xg, float* saved_stats,
-                         void* workspace, size_t workspace_bytes, void* stream);
+                         float* saved_rays, void* workspace, size_t workspace_bytes, void* stream);
 /* d_out dev [R,P] -> d_h dev [R,P,64], d_view_feature dev [R,VF] (NULL when VF = 0), d_rays_d dev [R P,3] (rows other than a ray's first
  * are written as zeros), d_h_inter dev [R,P,64], d_h_intra dev [R,S,64], d_params (above); all written, not accumulated. */
 int evd_awp_tail_backward(const evd_awp_tail_desc* d, const float* const* params, const float* h, const float* view_feature,
                           const float* rays_d, const float* h_inter, const float* h_intra, long R, const float* saved_y,
-                          const float* saved_xg, const float* saved_stats, const float* d_out, float* d_h, float* d_view_feature,
+                          const float* saved_xg, const float* saved_stats, const float* saved_rays, const float* d_out, float* d_h,
+                          float* d_view_feature,
                           float* d_rays_d, float* d_h_inter, float* d_h_intra, float* d_params, void* workspace, size_t workspace_bytes,
                           void* stream);
 

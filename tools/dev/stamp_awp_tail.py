@@ -20,6 +20,7 @@ h, vf, rd = torch.randn((R, P, 64), **f32), torch.randn((R, VF), **f32), torch.r
 hi, hs = torch.randn((R, P, 64), **f32).relu(), torch.randn((R, S, 64), **f32).relu()
 out, y, xg, stats = torch.empty((R, P), **f32), torch.empty((R, P, 32), **f32), torch.empty((R, P, 32), **f32), torch.empty((64,), **f32)
 lib = L.lib()
+rays = None if os.environ.get("RECOMPUTE") else torch.empty((R, lib.evd_awp_tail_saved_floats(C.byref(desc))), **f32)
 nf, nb = lib.evd_awp_tail_workspace_bytes(C.byref(desc), R, 0), lib.evd_awp_tail_workspace_bytes(C.byref(desc), R, 1)
 wf, wb = torch.zeros((nf,), dtype=torch.uint8, device="cuda"), torch.zeros((nb,), dtype=torch.uint8, device="cuda")
 g = torch.randn((R, P), **f32)
@@ -29,11 +30,11 @@ d_par = torch.empty((lib.evd_awp_tail_param_count(C.byref(desc)),), **f32)
 
 def fwd():
     L.check(lib.evd_awp_tail_forward(C.byref(desc), arr, L.ptr(h), L.ptr(vf), L.ptr(rd), L.ptr(hi), L.ptr(hs), R, None, None, None, L.ptr(out), L.ptr(y),
-                                     L.ptr(xg), L.ptr(stats), L.ptr(wf), nf, L.stream_ptr()), "fwd")
+                                     L.ptr(xg), L.ptr(stats), L.ptr(rays), L.ptr(wf), nf, L.stream_ptr()), "fwd")
 
 
 def bwd():
-    L.check(lib.evd_awp_tail_backward(C.byref(desc), arr, L.ptr(h), L.ptr(vf), L.ptr(rd), L.ptr(hi), L.ptr(hs), R, L.ptr(y), L.ptr(xg), L.ptr(stats), L.ptr(g),
+    L.check(lib.evd_awp_tail_backward(C.byref(desc), arr, L.ptr(h), L.ptr(vf), L.ptr(rd), L.ptr(hi), L.ptr(hs), R, L.ptr(y), L.ptr(xg), L.ptr(stats), L.ptr(rays), L.ptr(g),
                                       L.ptr(d_h), L.ptr(d_vf), L.ptr(d_rd), L.ptr(d_hi), L.ptr(d_hs), L.ptr(d_par), L.ptr(wb), nb, L.stream_ptr()), "bwd")
 
 
