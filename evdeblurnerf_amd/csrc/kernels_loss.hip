@@ -449,6 +449,10 @@ __device__ __forceinline__ float awp_scan_mul(float v) {
     return v;
 }
 
+// e^x for x <= 0 on the hardware exp2 (v_exp_f32, 1 ulp) behind one multiply: relative error <= 1e-6 for |x| <= 16 against ~20 instructions of
+// the IEEE expf -- the two scans evaluate one exponential per (sample, channel) and were bound by the instruction count, not by HBM
+__device__ __forceinline__ float awp_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+
 template <int CPL>
 __global__ __launch_bounds__(256) void k_awp_integrate(const float* __restrict__ feat, const float* __restrict__ z,
                                                        const float* __restrict__ rays_d, long N, int S, int C, float* __restrict__ out) {
@@ -480,7 +484,7 @@ __global__ __launch_bounds__(256) void k_awp_integrate(const float* __restrict__
 #pragma unroll
                 for (int q = 0; q < CPL; ++q) {
                     const int c = lane * CPL + q;
-                    const float alpha = s < S - 1 ? __fadd_rn(-expf(-__fmul_rn(f[u][q], dist[u])), 1.f) : 0.f;   // awp.py:66-67
+                    const float alpha = s < S - 1 ? __fadd_rn(-awp_exp(-__fmul_rn(f[u][q], dist[u])), 1.f) : 0.f;   // awp.py:66-67
                     acc[q] = __fadd_rn(acc[q], __fmul_rn(__fmul_rn(alpha, Q[q]), f[u][q]));
                     om[q] = c < C ? __fadd_rn(-alpha, 1.f + 1e-10f) : 1.f;
                     local *= om[q];
@@ -549,7 +553,7 @@ __global__ __launch_bounds__(256) void k_awp_integrate_bwd(const float* __restri
     {   // e of row 0 (every row's exponential is evaluated once: as "the next row's" in the iteration before)
         const float dist0 = S > 1 ? __fmul_rn(__fsub_rn(zz[1], zz[0]), norm) : 0.f;
 #pragma unroll
-        for (int q = 0; q < CPL; ++q) ec[q] = S > 1 ? expf(-__fmul_rn(cur[0][q], dist0)) : 1.f;
+        for (int q = 0; q < CPL; ++q) ec[q] = S > 1 ? awp_exp(-__fmul_rn(cur[0][q], dist0)) : 1.f;
     }
     float dnorm = 0.f, dz_prev = 0.f;                    // d z[s] carried from the previous interval (+ d dist[s-1] |d|)
     for (int s0 = 0; s0 < S; s0 += PF) {
@@ -582,7 +586,7 @@ __global__ __launch_bounds__(256) void k_awp_integrate_bwd(const float* __restri
                 float G[CPL], lsum = 0.f;
 #pragma unroll
                 for (int q = 0; q < CPL; ++q) {
-                    en[q] = s + 2 < S ? expf(-__fmul_rn(fn[q], dist_n)) : 1.f;         // e of row s+1 (its alpha is 0 when it is the last row)
+                    en[q] = s + 2 < S ? awp_exp(-__fmul_rn(fn[q], dist_n)) : 1.f;         // e of row s+1 (its alpha is 0 when it is the last row)
                     const float an = s + 2 < S ? __fadd_rn(-en[q], 1.f) : 0.f;
                     G[q] = last ? 0.f : g[q] * an * fn[q] * Qn[q];
                     lsum += G[q];
@@ -621,6 +625,164 @@ __global__ __launch_bounds__(256) void k_awp_integrate_bwd(const float* __restri
         }
     }
     if (d_rays_d && lane < 3) d_rays_d[n * 3 + lane] = norm > 0.f ? dnorm * d[lane] / norm : 0.f;
+}
+
+// The same two scans for C = 64 (the AWP embedding's width, every shipped config): 16 lanes per ray with 4 consecutive channels each (one
+// 16-byte load per sample row), FOUR rays per wavefront.  The 64-lane form above spends one wavefront instruction per (ray, sample,
+// operation) on 64 channels and was bound by its instruction count (2.0 TB/s); here an instruction serves four rays and the cumulative
+// product / suffix sum over the channels is a 4-step scan inside a DPP row.
+template <int CTRL>
+__device__ __forceinline__ float awp_dpp(float old, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float awp_row_scan_mul(float v) {         // inclusive product over lanes <= this one of the 16-lane row
+    v *= awp_dpp<0x111>(1.f, v);
+    v *= awp_dpp<0x112>(1.f, v);
+    v *= awp_dpp<0x114>(1.f, v);
+    v *= awp_dpp<0x118>(1.f, v);
+    return v;
+}
+__device__ __forceinline__ float awp_row_scan_add_right(float v) {   // inclusive sum over lanes >= this one of the row
+    v += awp_dpp<0x101>(0.f, v);
+    v += awp_dpp<0x102>(0.f, v);
+    v += awp_dpp<0x104>(0.f, v);
+    v += awp_dpp<0x108>(0.f, v);
+    return v;
+}
+__device__ __forceinline__ float awp_row_sum(float v) {              // the row's sum in every lane
+    v += awp_dpp<0xb1>(0.f, v);
+    v += awp_dpp<0x4e>(0.f, v);
+    v += awp_dpp<0x141>(0.f, v);
+    v += awp_dpp<0x140>(0.f, v);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_awp_integrate_c64(const float* __restrict__ feat, const float* __restrict__ z,
+                                                           const float* __restrict__ rays_d, long N, int S, float* __restrict__ out) {
+    const int l16 = threadIdx.x & 15;
+    const long n0 = blockIdx.x * 16L + (threadIdx.x >> 4);
+    const long n = n0 < N ? n0 : N - 1;                   // (rays past the end compute on the last ray and write nothing: the DPP rows stay whole)
+    const float* d = rays_d + n * 3;
+    const float norm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
+    const float4* fr = reinterpret_cast<const float4*>(feat + n * (long)S * 64) + l16;
+    const float* zz = z + n * (long)S;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f}, Q[4] = {1.f, 1.f, 1.f, 1.f};
+    constexpr int UN = 4;
+    for (int s0 = 0; s0 < S; s0 += UN) {
+        float4 f4[UN];
+        float dist[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int s = min(s0 + u, S - 1);
+            f4[u] = fr[(long)s * 16];
+            dist[u] = s < S - 1 ? __fmul_rn(__fsub_rn(zz[s + 1], zz[s]), norm) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int s = s0 + u;
+            if (s < S) {
+                const float f[4] = {f4[u].x, f4[u].y, f4[u].z, f4[u].w};
+                float om[4], local = 1.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float alpha = s < S - 1 ? __fadd_rn(-awp_exp(-__fmul_rn(f[q], dist[u])), 1.f) : 0.f;   // awp.py:66-67
+                    acc[q] = __fadd_rn(acc[q], __fmul_rn(__fmul_rn(alpha, Q[q]), f[q]));
+                    om[q] = __fadd_rn(-alpha, 1.f + 1e-10f);
+                    local *= om[q];
+                }
+                float excl = awp_dpp<0x111>(1.f, awp_row_scan_mul(local));       // product over the channels of the lanes to the left
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { excl *= om[q]; Q[q] = excl; }
+            }
+        }
+    }
+    if (n0 < N) reinterpret_cast<float4*>(out + n * 64)[l16] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+__global__ __launch_bounds__(256) void k_awp_integrate_bwd_c64(const float* __restrict__ feat, const float* __restrict__ z,
+                                                               const float* __restrict__ rays_d, const float* __restrict__ d_out, long N, int S,
+                                                               float* __restrict__ d_feat, float* __restrict__ d_z, float* __restrict__ d_rays_d) {
+    const int l16 = threadIdx.x & 15;
+    const long n0 = blockIdx.x * 16L + (threadIdx.x >> 4);
+    const bool live = n0 < N;
+    const long n = live ? n0 : N - 1;
+    const float* d = rays_d + n * 3;
+    const float norm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
+    const float4* fr = reinterpret_cast<const float4*>(feat + n * (long)S * 64) + l16;
+    float4* dfr = reinterpret_cast<float4*>(d_feat + n * (long)S * 64) + l16;
+    const float* zz = z + n * (long)S;
+    constexpr int PF = 4;                                 // rows per block; the NEXT block's rows are loaded while this one is processed
+    float4 cur[PF + 1], nxt[PF];
+    const float4 g4 = reinterpret_cast<const float4*>(d_out + n * 64)[l16];
+    const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+    float Q[4] = {1.f, 1.f, 1.f, 1.f}, ec[4];
+#pragma unroll
+    for (int u = 0; u <= PF; ++u) cur[u] = fr[(long)min(u, S - 1) * 16];
+    {
+        const float dist0 = S > 1 ? __fmul_rn(__fsub_rn(zz[1], zz[0]), norm) : 0.f;
+        const float f0[4] = {cur[0].x, cur[0].y, cur[0].z, cur[0].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ec[q] = S > 1 ? awp_exp(-__fmul_rn(f0[q], dist0)) : 1.f;
+    }
+    float dnorm = 0.f, dz_prev = 0.f;
+    for (int s0 = 0; s0 < S; s0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) nxt[u] = fr[(long)min(s0 + PF + 1 + u, S - 1) * 16];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int s = s0 + u;
+            if (s < S) {
+                const float fc[4] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w};
+                const float fn[4] = {cur[u + 1].x, cur[u + 1].y, cur[u + 1].z, cur[u + 1].w};
+                const bool last = s == S - 1;
+                const float dz = last ? 0.f : __fsub_rn(zz[s + 1], zz[s]);
+                const float dist = __fmul_rn(dz, norm);
+                const float dist_n = s + 2 < S ? __fmul_rn(__fsub_rn(zz[s + 2], zz[s + 1]), norm) : 0.f;
+                float e[4], en[4], om[4], Qn[4], local = 1.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    e[q] = last ? 1.f : ec[q];
+                    om[q] = __fadd_rn(e[q], 1e-10f);                                   // the last row's alpha is 0
+                    local *= om[q];
+                }
+                float excl = awp_dpp<0x111>(1.f, awp_row_scan_mul(local));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { excl *= om[q]; Qn[q] = excl; }
+                float G[4], lsum = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    en[q] = s + 2 < S ? awp_exp(-__fmul_rn(fn[q], dist_n)) : 1.f;      // e of row s+1 (its alpha is 0 when it is the last row)
+                    const float an = s + 2 < S ? __fadd_rn(-en[q], 1.f) : 0.f;
+                    G[q] = last ? 0.f : g[q] * an * fn[q] * Qn[q];
+                    lsum += G[q];
+                }
+                float sfx = awp_row_scan_add_right(lsum) - lsum;                        // the lanes to the right
+                float ddist = 0.f, df[4];
+#pragma unroll
+                for (int q = 3; q >= 0; --q) {
+                    sfx += G[q];                                                          // channels >= this one
+                    const float a = last ? 0.f : __fadd_rn(-e[q], 1.f);
+                    const float through = last ? 0.f : sfx / om[q];
+                    const float ga = g[q] * Q[q] * fc[q] - through;                       // d out / d a[s,c]
+                    df[q] = last ? 0.f : g[q] * Q[q] * a + ga * dist * e[q];
+                    ddist += last ? 0.f : ga * fc[q] * e[q];
+                }
+                if (live) dfr[(long)s * 16] = make_float4(df[0], df[1], df[2], df[3]);
+                if (d_z || d_rays_d) {
+                    ddist = awp_row_sum(ddist);
+                    if (d_z && live && l16 == 0) d_z[n * (long)S + s] = dz_prev - ddist * norm;
+                    dz_prev = ddist * norm;
+                    dnorm += ddist * dz;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { Q[q] = Qn[q]; ec[q] = en[q]; }
+            }
+        }
+        cur[0] = cur[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) cur[u + 1] = nxt[u];
+    }
+    if (d_rays_d && live && l16 < 3) d_rays_d[n * 3 + l16] = norm > 0.f ? dnorm * d[l16] / norm : 0.f;
 }
 
 // utils/edi.py:73-95: E_k = -sum_{j=k}^{N-1} bii_j (k<N), 0 (k=N), +sum_{j=N}^{k-1} bii_j (k>N); sharp = (2N+1) blurry / sum exp(E_k)
@@ -858,7 +1020,8 @@ int evd_awp_feature_integration(const float* feat, const float* z, const float* 
     EVD_REQUIRE(C <= 256, "evd_awp_feature_integration: %d channels (built: <= 256)", C);
     if (N == 0) return EVD_OK;
     hipStream_t st = as_stream(stream);
-    if (C <= 64) k_awp_integrate<1><<<cdiv(N, 4), 256, 0, st>>>(feat, z, rays_d, N, S, C, out);
+    if (C == 64 && !getenv("EVD_AWP_SCAN64")) k_awp_integrate_c64<<<cdiv(N, 16), 256, 0, st>>>(feat, z, rays_d, N, S, out);
+    else if (C <= 64) k_awp_integrate<1><<<cdiv(N, 4), 256, 0, st>>>(feat, z, rays_d, N, S, C, out);
     else if (C <= 128) k_awp_integrate<2><<<cdiv(N, 4), 256, 0, st>>>(feat, z, rays_d, N, S, C, out);
     else k_awp_integrate<4><<<cdiv(N, 4), 256, 0, st>>>(feat, z, rays_d, N, S, C, out);
     EVD_LAUNCH_CHECK();
@@ -871,7 +1034,8 @@ int evd_awp_feature_integration_bwd(const float* feat, const float* z, const flo
     EVD_REQUIRE(C <= 256, "evd_awp_feature_integration_bwd: %d channels (built: <= 256)", C);
     if (N == 0) return EVD_OK;
     hipStream_t st = as_stream(stream);
-    if (C <= 64) k_awp_integrate_bwd<1><<<cdiv(N, 4), 256, 0, st>>>(feat, z, rays_d, d_out, N, S, C, d_feat, d_z, d_rays_d);
+    if (C == 64 && !getenv("EVD_AWP_SCAN64")) k_awp_integrate_bwd_c64<<<cdiv(N, 16), 256, 0, st>>>(feat, z, rays_d, d_out, N, S, d_feat, d_z, d_rays_d);
+    else if (C <= 64) k_awp_integrate_bwd<1><<<cdiv(N, 4), 256, 0, st>>>(feat, z, rays_d, d_out, N, S, C, d_feat, d_z, d_rays_d);
     else if (C <= 128) k_awp_integrate_bwd<2><<<cdiv(N, 4), 256, 0, st>>>(feat, z, rays_d, d_out, N, S, C, d_feat, d_z, d_rays_d);
     else k_awp_integrate_bwd<4><<<cdiv(N, 4), 256, 0, st>>>(feat, z, rays_d, d_out, N, S, C, d_feat, d_z, d_rays_d);
     EVD_LAUNCH_CHECK();
