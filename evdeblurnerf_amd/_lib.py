@@ -95,7 +95,7 @@ SIGNATURES = {
     "evd_awp_feature_integration": (_I, [_vp, _vp, _vp, _L, _I, _I, _vp, _vp]),
     "evd_awp_feature_integration_bwd": (_I, [_vp, _vp, _vp, _vp, _L, _I, _I, _vp, _vp, _vp, _vp]),
     "evd_mam_local_forward": (_I, [_vp, _vp, _L, _I, _I, _I, _vp, _vp, _vp, _vp, _vp]),
-    "evd_mam_local_backward": (_I, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _L, _I, _I, _I, _vp, _vp, _vp]),
+    "evd_mam_local_backward": (_I, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _L, _I, _I, _I, _vp, _vp, _I, _vp]),
     "evd_awp_tail_num_params": (_I, [_I]),
     "evd_awp_tail_param_count": (_L, [C.POINTER(AwpTailDesc)]),
     "evd_awp_tail_workspace_bytes": (_S, [C.POINTER(AwpTailDesc), _L, _I]),

@@ -127,8 +127,50 @@ class _MamLocal(torch.autograd.Function):
         d_u = torch.empty((R, Cc), dtype=torch.float32, device=h.device)
         L.check(L.lib().evd_mam_local_backward(L.ptr(h), L.ptr(uu), L.ptr(alpha), L.ptr(beta), L.ptr(h_inter), L.ptr(h_intra),
                                                L.ptr(g_inter.contiguous().float()), L.ptr(g_intra.contiguous().float()), R, P, S, Cc,
-                                               L.ptr(d_h), L.ptr(d_u), L.stream_ptr()), "evd_mam_local_backward")
+                                               L.ptr(d_h), L.ptr(d_u), 0, L.stream_ptr()), "evd_mam_local_backward")
         return d_h.reshape(ctx.h_shape), d_u.sum(0), None, None, None
+
+
+class _LocalConsumers(torch.autograd.Function):
+    """h_local's two consumers behind the embedding -- the feature integration (awp.py:102) and the MAM's per-sample part (mam.py:29-33,
+    72-74) -- as ONE autograd node: its backward lets the second kernel ADD into the d h_local the first one wrote, where two nodes hand
+    autograd two [R P, S, 64] tensors to sum (a pass over 3 x 335 MB at the blurfactory shape).  -> (h [R P, 64], h_inter, h_intra)"""
+
+    @staticmethod
+    def forward(ctx, h_local, z, d, u, R, P, S):
+        f, zz, dd, uu = h_local.contiguous().float(), z.contiguous().float(), d.contiguous().float(), u.contiguous().float()
+        N, Cc, dev = R * P, f.shape[-1], f.device
+        if f.numel() != N * S * Cc or zz.shape[0] != N or dd.shape[0] != N:
+            raise L.EvdError("FusedAWP: h_local [R P, S, C], z_vals [R P, S] and rays_d [R P, 3] do not agree")
+        f32 = dict(dtype=torch.float32, device=dev)
+        h = torch.empty((N, Cc), **f32)
+        h_inter, h_intra = torch.empty((R, P, Cc), **f32), torch.empty((R, S, Cc), **f32)
+        alpha, beta = torch.empty((R, P, S), **f32), torch.empty((R, P, S), **f32)
+        lib = L.lib()
+        L.check(lib.evd_awp_feature_integration(L.ptr(f), L.ptr(zz), L.ptr(dd), N, S, Cc, L.ptr(h), L.stream_ptr()), "evd_awp_feature_integration")
+        L.check(lib.evd_mam_local_forward(L.ptr(f), L.ptr(uu), R, P, S, Cc, L.ptr(h_inter), L.ptr(h_intra), L.ptr(alpha), L.ptr(beta),
+                                          L.stream_ptr()), "evd_mam_local_forward")
+        ctx.save_for_backward(f, zz, dd, uu, alpha, beta, h_inter, h_intra)
+        ctx.dims, ctx.shapes = (R, P, S, Cc), (h_local.shape, z.shape, d.shape)
+        return h, h_inter, h_intra
+
+    @staticmethod
+    def backward(ctx, g_h, g_inter, g_intra):
+        f, zz, dd, uu, alpha, beta, h_inter, h_intra = ctx.saved_tensors
+        R, P, S, Cc = ctx.dims
+        N, lib = R * P, L.lib()
+        d_f = torch.empty_like(f)
+        d_z = torch.empty_like(zz) if ctx.needs_input_grad[1] else None
+        d_d = torch.empty_like(dd) if ctx.needs_input_grad[2] else None
+        d_u = torch.empty((R, Cc), dtype=torch.float32, device=f.device)
+        L.check(lib.evd_awp_feature_integration_bwd(L.ptr(f), L.ptr(zz), L.ptr(dd), L.ptr(g_h.contiguous().float()), N, S, Cc, L.ptr(d_f), L.ptr(d_z),
+                                                    L.ptr(d_d), L.stream_ptr()), "evd_awp_feature_integration_bwd")
+        L.check(lib.evd_mam_local_backward(L.ptr(f), L.ptr(uu), L.ptr(alpha), L.ptr(beta), L.ptr(h_inter), L.ptr(h_intra),
+                                           L.ptr(g_inter.contiguous().float()), L.ptr(g_intra.contiguous().float()), R, P, S, Cc, L.ptr(d_f), L.ptr(d_u),
+                                           1, L.stream_ptr()), "evd_mam_local_backward")
+        sh = ctx.shapes
+        return (d_f.reshape(sh[0]), None if d_z is None else d_z.reshape(sh[1]), None if d_d is None else d_d.reshape(sh[2]), d_u.sum(0),
+                None, None, None)
 
 
 def mam_local(h_local, linear_weight, att_weight, R, P, S):
@@ -421,8 +463,9 @@ class FusedAWP(torch.nn.Module):
         known = getattr(mam, "Corr", None) is not None and getattr(mam, "linear", None) is not None and self.embed.width == 64 and P <= 16 and S <= 512
         if self.tail_kernels and known and rays_d.is_cuda:                        # everything behind the embedding on the library
             h_local = self.embed(self._flat(), depth_feature).reshape(n_ray * P, S, self.embed.width)
-            h = feature_integration(h_local.reshape(n_ray, P, S, -1), z_vals, rays_d)
-            h_inter, h_intra = mam_local(h_local, mam.linear.weight, mam.Corr.line_conv_att.weight, n_ray, P, S)
+            u = (mam.Corr.line_conv_att.weight.reshape(1, -1) @ mam.linear.weight).reshape(-1)      # the logit of a sample is (W^T v) . h + const
+            h, h_inter, h_intra = _LocalConsumers.apply(h_local, z_vals.reshape(-1, S), rays_d.reshape(-1, 3), u, n_ray, P, S)
+            h = h.reshape(n_ray, P, -1)
             out = self._tail(h, view_feature, rays_d, h_inter, h_intra, n_ray, P, S)
             if out is not None:
                 return out

@@ -919,12 +919,18 @@ struct TailReduceParams {
     float* d_params;
 };
 // d_params[i] = sum over the partial rows; the BatchNorm and w_linear gradients come from k_awp_tail_bwd0's rows (d beta, d gamma, d W, d b)
-__global__ __launch_bounds__(256) void k_awp_tail_reduce(TailReduceParams p) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(64) void k_awp_tail_reduce(TailReduceParams p) {
+    const long i = (long)blockIdx.x * 64 + threadIdx.x;
     if (i >= p.total) return;
     float a = 0.f;
     if (i < p.n_tail) {
-        for (int b = 0; b < p.nA; ++b) a += p.partA[(long)b * p.partA_stride + i];
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // eight rows in flight: a thread walks up to 256 rows, 42 workgroups in all
+        int b = 0;
+        for (; b + 8 <= p.nA; b += 8)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += p.partA[(long)(b + u) * p.partA_stride + i];
+        for (; b < p.nA; ++b) acc[0] += p.partA[(long)b * p.partA_stride + i];
+        a = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     } else {
         const long j = i - p.n_tail;                                   // 0..31 d gamma, 32..63 d beta, then w_linear
         const long col = j < AT_CM ? AT_CM + j : (j < 2 * AT_CM ? j - AT_CM : j);
@@ -1091,7 +1097,7 @@ int evd_awp_tail_backward(const evd_awp_tail_desc* d, const float* const* params
     rp.partA_stride = k.partA_stride;
     rp.n_tail = (int)k.off[2 * dims.n_mot + TW_BN_W];
     rp.d_params = d_params;
-    k_awp_tail_reduce<<<(unsigned)((total + 255) / 256), 256, 0, as_stream(stream)>>>(rp);
+    k_awp_tail_reduce<<<(unsigned)((total + 63) / 64), 64, 0, as_stream(stream)>>>(rp);
     EVD_HIP(hipGetLastError());
     return EVD_OK;
 }

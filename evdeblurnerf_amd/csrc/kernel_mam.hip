@@ -118,6 +118,7 @@ __global__ __launch_bounds__(256) void k_mam_local_fwd(const float* __restrict__
 // Backward.  With gA[p,s] = d_inter[p] . h[p,s], gB[p,s] = d_intra[s] . h[p,s] the two softmax backwards need sum_s alpha gA = d_inter[p] .
 // h_inter[p] and sum_p beta gB = d_intra[s] . h_intra[s]: dots of the SAVED outputs, so h_local is read once:
 //      d logit = alpha (gA - cP[p]) + beta (gB - cI[s]);   d h = alpha d_inter[p] + beta d_intra[s] + d logit u;   d u = sum d logit h
+template <bool ACC>
 __global__ __launch_bounds__(256) void k_mam_local_bwd(const float* __restrict__ h, const float* __restrict__ u,
                                                        const float* __restrict__ alpha, const float* __restrict__ beta,
                                                        const float* __restrict__ h_inter, const float* __restrict__ h_intra,
@@ -158,6 +159,10 @@ __global__ __launch_bounds__(256) void k_mam_local_bwd(const float* __restrict__
                 o.y = al * dp.y + be * dI.y + da * u4.y;
                 o.z = al * dp.z + be * dI.z + da * u4.z;
                 o.w = al * dp.w + be * dI.w + da * u4.w;
+                if (ACC) {                   // d h_local already holds another consumer's share (the feature integration's): add to it here
+                    const float4 prev = dh4[at];  // instead of in a separate pass over 2 x 335 MB
+                    o.x += prev.x; o.y += prev.y; o.z += prev.z; o.w += prev.w;
+                }
                 dh4[at] = o;
                 fma4(du, da, v);
             }
@@ -195,14 +200,18 @@ int evd_mam_local_forward(const float* h_local, const float* u, long R, int P, i
 
 int evd_mam_local_backward(const float* h_local, const float* u, const float* alpha, const float* beta, const float* h_inter,
                            const float* h_intra, const float* d_inter, const float* d_intra, long R, int P, int S, int C, float* d_h_local,
-                           float* d_u_partial, void* stream) {
+                           float* d_u_partial, int accumulate, void* stream) {
     EVD_REQUIRE(h_local && u && alpha && beta && h_inter && h_intra && d_inter && d_intra && d_h_local && d_u_partial,
                 "evd_mam_local_backward: null argument");
     if (int e = mam_check("evd_mam_local_backward", R, P, S, C)) return e;
     if (R == 0) return EVD_OK;
     const size_t lds = sizeof(float) * (MAM_MAXP * MAM_C + MAM_MAXP + 4 * MAM_C);
-    k_mam_local_bwd<<<(unsigned)R, 256, lds, as_stream(stream)>>>(h_local, u, alpha, beta, h_inter, h_intra, d_inter, d_intra, P, S, d_h_local,
-                                                                  d_u_partial);
+    if (accumulate)
+        k_mam_local_bwd<true><<<(unsigned)R, 256, lds, as_stream(stream)>>>(h_local, u, alpha, beta, h_inter, h_intra, d_inter, d_intra, P, S,
+                                                                            d_h_local, d_u_partial);
+    else
+        k_mam_local_bwd<false><<<(unsigned)R, 256, lds, as_stream(stream)>>>(h_local, u, alpha, beta, h_inter, h_intra, d_inter, d_intra, P, S,
+                                                                             d_h_local, d_u_partial);
     EVD_HIP(hipGetLastError());
     return EVD_OK;
 }

@@ -456,10 +456,11 @@ int evd_awp_feature_integration_bwd(const float* feat, const float* z, const flo
 int evd_mam_local_forward(const float* h_local, const float* u, long R, int P, int S, int C, float* h_inter, float* h_intra, float* alpha,
                           float* beta, void* stream);
 /* Its backward (torch.autograd behind mam.py:29-33,72-74 in training, run_nerf.py:593-601): d h_inter dev [R,P,64], d h_intra dev
- * [R,S,64] -> d h_local dev [R P, S, 64] (written, not accumulated) and d u as per-ray partials dev [R,64] (the caller sums them). */
+ * [R,S,64] -> d h_local dev [R P, S, 64] (accumulate = 0: written; != 0: ADDED to what is there -- h_local has a second consumer, the
+ * feature integration, whose backward writes the buffer first) and d u as per-ray partials dev [R,64] (the caller sums them). */
 int evd_mam_local_backward(const float* h_local, const float* u, const float* alpha, const float* beta, const float* h_inter,
                            const float* h_intra, const float* d_inter, const float* d_intra, long R, int P, int S, int C, float* d_h_local,
-                           float* d_u_partial, void* stream);
+                           float* d_u_partial, int accumulate, void* stream);
 
 /* The PER-RAY remainder of the adaptive weight proposal as kernels: networks/dpnerf/awp.py:89-95 (direction encoding of the first
  * sub-exposure's normalised ray direction, concatenated behind view_feature), :104-109 (motion_feature_embed_layer: n_mot x Linear + ReLU on
