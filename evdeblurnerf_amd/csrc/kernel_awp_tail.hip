@@ -209,41 +209,6 @@ __device__ __forceinline__ void wacc(float* part, const float* G, int sgm, const
         part[i] += acc0 + acc1;
     }
 }
-// d MAM.linear.weight [32][64] += d li^T hi + d ls^T h_intra: a lane owns (c, 4 consecutive k) -- 512 items, the sample rows as 16-byte loads
-__device__ __forceinline__ void wacc_lin(float* part, const float* dli, const float* hi, int P, const float* dls, const float* xs, int S) {
-    for (int i = at_tid(); i < AT_CM * AT_WS / 4; i += AT_NT) {
-        const int c = i >> 4, k4 = i & 15;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int pp = 0; pp < P; ++pp) {
-            const float g = dli[pp * AT_CM + c];
-            const float4 x = reinterpret_cast<const float4*>(hi + pp * AT_WS)[k4];
-            acc.x = fmaf(g, x.x, acc.x); acc.y = fmaf(g, x.y, acc.y); acc.z = fmaf(g, x.z, acc.z); acc.w = fmaf(g, x.w, acc.w);
-        }
-        int sm = 0;
-        for (; sm + 4 <= S; sm += 4) {
-            float g[4];
-            float4 x[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                g[u] = dls[(sm + u) * AT_LS + c];
-                x[u] = reinterpret_cast<const float4*>(xs + (long)(sm + u) * AT_WS)[k4];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                acc.x = fmaf(g[u], x[u].x, acc.x); acc.y = fmaf(g[u], x[u].y, acc.y); acc.z = fmaf(g[u], x[u].z, acc.z); acc.w = fmaf(g[u], x[u].w, acc.w);
-            }
-        }
-        for (; sm < S; ++sm) {
-            const float g = dls[sm * AT_LS + c];
-            const float4 x = reinterpret_cast<const float4*>(xs + (long)sm * AT_WS)[k4];
-            acc.x = fmaf(g, x.x, acc.x); acc.y = fmaf(g, x.y, acc.y); acc.z = fmaf(g, x.z, acc.z); acc.w = fmaf(g, x.w, acc.w);
-        }
-        float4* o = reinterpret_cast<float4*>(part) + i;
-        float4 v = *o;
-        v.x += acc.x; v.y += acc.y; v.z += acc.z; v.w += acc.w;
-        *o = v;
-    }
-}
 __device__ __forceinline__ void bacc(float* part, const float* G, int sgm, int M, int N) {
     for (int n = at_tid(); n < N; n += AT_NT) {
         float acc = 0.f;
@@ -396,6 +361,42 @@ __device__ __forceinline__ void p_dot16(float* out, int so, const float* rows, i
     }
 }
 
+// The sample-sized products on the exact-float32 matrix core (v_mfma_f32_16x16x4_f32 = an fmaf chain in k order): one wavefront, one
+// 16 x 16 tile  D[m][n] += sum_k A[m sa_m + k sa_k] B[k sb_k + n sb_n],  m < Mv, n < Nv, k < K (operands outside are zeros); four
+// k-steps of operands are loaded in front of their four MFMAs.  Lane l holds A[m = l % 16][k = l / 16], B[k = l / 16][n = l % 16] and
+// the results D[4 (l / 16) + i][l % 16] in acc[i].  On the vector ALU these were the lane-serial loops over the 128 samples of a ray:
+// the attention sums (8 k cycles of a 64 k-cycle forward), MAM.linear on the intra sums (28 k), its two transposes in the backward (35 k).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+static_assert(AT_NT == 512, "the MAM.linear weight gradient is eight 16 x 16 tiles, one per wavefront");
+__device__ __forceinline__ f32x4v tile16(f32x4v acc, const float* A, int sa_m, int sa_k, int Mv, const float* B, int sb_k, int sb_n, int Nv,
+                                         int K) {
+    const int lane = at_tid() & 63, mn = lane & 15, kq = lane >> 4;
+    const bool am = mn < Mv, bn = mn < Nv;
+    const float* a = A + (am ? mn : 0) * sa_m;
+    const float* b = B + (bn ? mn : 0) * sb_n;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + 4 * u + kq;
+            const bool in = k < K;
+            const int kc = in ? k : 0;
+            av[u] = a[kc * sa_k];
+            bv[u] = b[kc * sb_k];
+            av[u] = (am && in) ? av[u] : 0.f;
+            bv[u] = (bn && in) ? bv[u] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+    }
+    return acc;
+}
+__device__ __forceinline__ f32x4v zero4() {
+    f32x4v z;
+    z[0] = z[1] = z[2] = z[3] = 0.f;
+    return z;
+}
+
 __device__ __forceinline__ void tail_stage_weights(const TailKParams& p, const TailLds& L) {
     const TailDims& d = p.d;
     auto copy = [&](float* dst, const float* src, int n) {           // n is a multiple of 4 here except for the odd-width layer 0
@@ -449,26 +450,37 @@ __device__ __forceinline__ void tail_forward_ray(const TailKParams& p, const Tai
     // awp.py:107-109 (layer 0) and mam.py:72-74 applied to the per-sample part's inter sums
     lin<1>(L.xs(0), AT_CM, L.x0, d.IN0, L.mw(0), L.mb(0), P, AT_CM, d.IN0);
     lin<0>(L.li, AT_CM, L.hi, AT_WS, L.lin_w, L.lin_b, P, AT_CM, AT_WS);
-    // ... and to the intra sums: one sample row per lane pair, 16 of the 32 outputs each
-    const int sl = tid / AT_LPS, hf = tid % AT_LPS;
-    for (int s0 = 0; s0 < S; s0 += AT_NT / AT_LPS) {
-        const int s = s0 + sl;
-        if (s < S) {
-            float x[AT_WS];
-            const float4* x4 = reinterpret_cast<const float4*>(p.h_intra + (r * S + s) * AT_WS);
+    // ... and to the intra sums [S, 64] -> ls [S, 32]: 16 x 16 tiles over (samples, channels), a wavefront per tile; a lane's four k-steps
+    // of a sample row / a weight row are one 16-byte load (k = 16 jj + 4 (l / 16) + component on both operands)
+    {
+        const int wave = tid >> 6, lane = tid & 63, mn = lane & 15, kq = lane >> 4;
+        const float* Wg = p.w[2 * d.n_mot + TW_LIN_W];
+        const int nst = (S + 15) >> 4;
+        for (int tt = wave; tt < 2 * nst; tt += AT_NT / 64) {
+            const int st = tt >> 1, ct = tt & 1;
+            const int srow = min(16 * st + mn, S - 1);
+            const float4* xa = reinterpret_cast<const float4*>(p.h_intra + (r * S + srow) * AT_WS) + kq;
+            const float4* wbp = reinterpret_cast<const float4*>(Wg + (16 * ct + mn) * AT_WS) + kq;
+            float4 a[4], b[4];
 #pragma unroll
-            for (int j = 0; j < AT_WS / 4; ++j) {
-                const float4 v = x4[j];
-                x[4 * j] = v.x; x[4 * j + 1] = v.y; x[4 * j + 2] = v.z; x[4 * j + 3] = v.w;
+            for (int jj = 0; jj < 4; ++jj) { a[jj] = xa[4 * jj]; b[jj] = wbp[4 * jj]; }
+            f32x4v acc = zero4();
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj].x, b[jj].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj].y, b[jj].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj].z, b[jj].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[jj].w, b[jj].w, acc, 0, 0, 0);
             }
-            float o[AT_O32];
+            const float bias = L.lin_b[16 * ct + mn];
 #pragma unroll
-            for (int j = 0; j < AT_O32; ++j) o[j] = L.lin_b[hf * AT_O32 + j];
-            rows_dot<AT_WS, AT_O32, 1>(L.lin_w + hf * AT_O32 * AT_WS, x, o);
-#pragma unroll
-            for (int j = 0; j < AT_O32; ++j) L.ls[s * AT_LS + hf * AT_O32 + j] = o[j];
+            for (int i = 0; i < 4; ++i) {
+                const int so = 16 * st + 4 * kq + i;
+                if (so < S) L.ls[so * AT_LS + 16 * ct + mn] = acc[i] + bias;
+            }
         }
     }
+    const int sl = tid / AT_LPS, hf = tid % AT_LPS;
     __syncthreads();
     clk.mark(2);
     for (int l = 1; l < d.n_mot; ++l) {
@@ -520,7 +532,13 @@ __device__ __forceinline__ void tail_forward_ray(const TailKParams& p, const Tai
     __syncthreads();
     clk.mark(7);
     mm<0, false>(L.f, AT_CM, L.aP, P, 1, L.nP, 1, AT_MID, nullptr, P, AT_MID, P);                     // mam.py:49
-    mm<0, false>(L.f + AT_MID, AT_CM, L.aS, d.SA, 1, L.nI, 1, AT_LK, nullptr, P, AT_MID, S);          // mam.py:50 (:52: the concatenation)
+    if ((tid >> 6) == AT_NT / 64 - 1) {                                                               // mam.py:50 (:52: the concatenation)
+        const f32x4v acc = tile16(zero4(), L.aS, d.SA, 1, P, L.nI, AT_LK, 1, AT_MID, S);
+        const int lane = tid & 63;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (4 * (lane >> 4) + i < P) L.f[(4 * (lane >> 4) + i) * AT_CM + AT_MID + (lane & 15)] = acc[i];
+    }
     __syncthreads();
     clk.mark(8);
     lin<0>(L.yb, AT_CM, L.f, AT_CM, L.convd, nullptr, P, AT_CM, AT_CM);                               // mam.py:53: convd[0]
@@ -802,12 +820,22 @@ __global__ __launch_bounds__(AT_NT) void k_awp_tail_bwd(TailKParams p) {
         clk.mark(14);
         float* dnI = L.nI;
         // d q = d lgP kP + d lgS kI;  d kP = d lgP^T q + d nP convn;  d kI = d lgS^T q + d nI convl
-        mm<0, false>(L.dq, AT_MID, L.daP, P, 1, L.kP, 1, AT_MID, nullptr, P, AT_MID, P);
-        mm<0, true>(L.dq, AT_MID, L.daS, d.SA, 1, L.kI, 1, AT_LK, nullptr, P, AT_MID, S);
+        const int wave = tid >> 6, lane = tid & 63, tr = 4 * (lane >> 4), tc = lane & 15;       // a tile16 result: rows tr .. tr + 3, column tc
+        if (wave == 0) {
+            f32x4v acc = tile16(zero4(), L.daS, d.SA, 1, P, L.kI, AT_LK, 1, AT_MID, S);
+            acc = tile16(acc, L.daP, P, 1, P, L.kP, AT_MID, 1, AT_MID, P);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (tr + i < P) L.dq[(tr + i) * AT_MID + tc] = acc[i];
+        }
         mm<0, false>(L.dkP, AT_MID, L.daP, 1, P, L.q, 1, AT_MID, nullptr, P, AT_MID, P);
         mm<0, true>(L.dkP, AT_MID, L.dnP, AT_MID, 1, L.convn, 1, AT_MID, nullptr, P, AT_MID, AT_MID);
         wacc(part + off[wb + TW_CONVN], L.dnP, AT_MID, L.kP, AT_MID, P, AT_MID, AT_MID);
-        wacc(part + off[wb + TW_CONVL], dnI, AT_LK, L.kI, AT_LK, S, AT_MID, AT_MID);
+        if (wave == 1) {                                                                              // d convl[m'][m] = sum_s d nI[s][m'] kI[s][m]
+            const f32x4v acc = tile16(zero4(), dnI, 1, AT_LK, AT_MID, L.kI, AT_LK, 1, AT_MID, S);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) part[off[wb + TW_CONVL] + (tr + i) * AT_MID + tc] += acc[i];
+        }
         for (int s0 = 0; s0 < S; s0 += AT_NT / AT_LPS) {
             const int s = s0 + sl;
             if (s < S) {
@@ -824,7 +852,12 @@ __global__ __launch_bounds__(AT_NT) void k_awp_tail_bwd(TailKParams p) {
         clk.mark(15);
         // conva / convb / convc, and back through MAM.linear
         wacc(part + off[wb + TW_CONVA], L.dkP, AT_MID, L.li, AT_CM, P, AT_MID, AT_CM);
-        wacc(part + off[wb + TW_CONVB], L.dkI, AT_LK, L.ls, AT_LS, S, AT_MID, AT_CM);
+        if (wave == 2 || wave == 3) {                                                                 // d convb[m][c] = sum_s d kI[s][m] ls[s][c]
+            const int ct = wave - 2;
+            const f32x4v acc = tile16(zero4(), L.dkI, 1, AT_LK, AT_MID, L.ls + 16 * ct, AT_LS, 1, 16, S);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) part[off[wb + TW_CONVB] + (tr + i) * AT_CM + 16 * ct + tc] += acc[i];
+        }
         wacc(part + off[wb + TW_CONVC], L.dq, AT_MID, xg, AT_CM, P, AT_MID, AT_CM);
         mm<0, false>(L.dli, AT_CM, L.dkP, AT_MID, 1, L.conva, 1, AT_CM, nullptr, P, AT_CM, AT_MID);
         mm<0, true>(L.dxa, AT_CM, L.dq, AT_MID, 1, L.convc, 1, AT_CM, nullptr, P, AT_CM, AT_MID);   // d x_global += d q convc
@@ -841,20 +874,26 @@ __global__ __launch_bounds__(AT_NT) void k_awp_tail_bwd(TailKParams p) {
         }
         __syncthreads();
         clk.mark(16);
-        wacc_lin(part + off[wb + TW_LIN_W], L.dli, L.hi, P, L.dls, p.h_intra + r * S * AT_WS, S);
+        {   // d MAM.linear.weight [32][64] += d ls^T h_intra + d li^T h_inter: eight 16 x 16 tiles, one per wavefront (AT_NT / 64 == 8)
+            const int ct = wave & 1, kt = wave >> 1;
+            f32x4v acc = tile16(zero4(), L.dls + 16 * ct, 1, AT_LS, 16, p.h_intra + r * S * AT_WS + 16 * kt, AT_WS, 1, 16, S);
+            acc = tile16(acc, L.dli + 16 * ct, 1, AT_CM, 16, L.hi + 16 * kt, AT_WS, 1, 16, P);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) part[off[wb + TW_LIN_W] + (16 * ct + tr + i) * AT_WS + 16 * kt + tc] += acc[i];
+        }
         bacc(part + off[wb + TW_LIN_B], L.dli, AT_CM, P, AT_CM);
         bacc(part + off[wb + TW_LIN_B], L.dls, AT_LS, S, AT_CM);
         mm<0, false>(p.d_hi + r * P * AT_WS, AT_WS, L.dli, AT_CM, 1, L.lin_w, 1, AT_WS, nullptr, P, AT_WS, AT_CM);
-        for (int s0 = 0; s0 < S; s0 += AT_NT / AT_LPS) {                                                  // d h_intra[s] = d ls[s] MAM.linear.weight
-            const int s = s0 + sl;
-            if (s < S) {
-                float acc[AT_O64] = {}, g[AT_CM];
+        {   // d h_intra [S][64] = d ls MAM.linear.weight: tiles over (samples, k), K = 32
+            const int nst = (S + 15) >> 4;
+            for (int tt = wave; tt < 4 * nst; tt += AT_NT / 64) {
+                const int st = tt >> 2, kt = tt & 3;
+                const f32x4v acc = tile16(zero4(), L.dls + 16 * st * AT_LS, AT_LS, 1, min(16, S - 16 * st), L.lin_w + 16 * kt, AT_WS, 1, 16, AT_CM);
 #pragma unroll
-                for (int c = 0; c < AT_CM; ++c) g[c] = L.dls[s * AT_LS + c];
-                cols_acc<AT_CM, AT_O64, 4>(L.lin_w + hf * AT_O64, AT_WS, g, acc);
-                float4* o4 = reinterpret_cast<float4*>(p.d_hs + (r * S + s) * AT_WS + hf * AT_O64);
-#pragma unroll
-                for (int k = 0; k < AT_O64 / 4; ++k) o4[k] = make_float4(acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3]);
+                for (int i = 0; i < 4; ++i) {
+                    const int so = 16 * st + tr + i;
+                    if (so < S) p.d_hs[(r * S + so) * AT_WS + 16 * kt + tc] = acc[i];
+                }
             }
         }
         // the motion embedding backwards (awp.py:107-109)
