@@ -144,76 +144,99 @@ __device__ __forceinline__ int at_tid() {
     return t;
 }
 
-// out[m som + n] (+)= act(bias[n] + sum_k A[m sam + k sak] B[n sbn + k sbk]);  rot: lane n starts its k loop at n mod K, so that lanes reading
-// consecutive rows of a row-major B whose row length is even hit different LDS banks
+// The sample-sized products on the exact-float32 matrix core (v_mfma_f32_16x16x4_f32 = an fmaf chain in k order): one wavefront, one
+// 16 x 16 tile  D[m][n] += sum_k A[m sa_m + k sa_k] B[k sb_k + n sb_n],  m < Mv, n < Nv, k < K (operands outside are zeros); four
+// k-steps of operands are loaded in front of their four MFMAs.  Lane l holds A[m = l % 16][k = l / 16], B[k = l / 16][n = l % 16] and
+// the results D[4 (l / 16) + i][l % 16] in acc[i].  On the vector ALU these were the lane-serial loops over the 128 samples of a ray:
+// the attention sums (8 k cycles of a 64 k-cycle forward), MAM.linear on the intra sums (28 k), its two transposes in the backward (35 k).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+static_assert(AT_NT == 512, "the MAM.linear weight gradient is eight 16 x 16 tiles, one per wavefront");
+__device__ __forceinline__ f32x4v tile16(f32x4v acc, const float* A, int sa_m, int sa_k, int Mv, const float* B, int sb_k, int sb_n, int Nv,
+                                         int K) {
+    const int lane = at_tid() & 63, mn = lane & 15, kq = lane >> 4;
+    const bool am = mn < Mv, bn = mn < Nv;
+    const float* a = A + (am ? mn : 0) * sa_m;
+    const float* b = B + (bn ? mn : 0) * sb_n;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + 4 * u + kq;
+            const bool in = k < K;
+            const int kc = in ? k : 0;
+            av[u] = a[kc * sa_k];
+            bv[u] = b[kc * sb_k];
+            av[u] = (am && in) ? av[u] : 0.f;
+            bv[u] = (bn && in) ? bv[u] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+    }
+    return acc;
+}
+__device__ __forceinline__ f32x4v zero4() {
+    f32x4v z;
+    z[0] = z[1] = z[2] = z[3] = 0.f;
+    return z;
+}
+
+// Every product of the chain is a handful of 16 x 16 tiles; a tile goes to the wavefront whose number the running job counter names (the
+// same sequence in every thread and for every ray: a parameter's gradient tile is always added by the same lanes).
+struct TileJobs {
+    int next;
+    __device__ __forceinline__ bool mine() { return ((next++) & (AT_NT / 64 - 1)) == (at_tid() >> 6); }
+};
+// out[m som + n] (+)= act(bias[n] + sum_k A[m sam + k sak] B[n sbn + k sbk]),  m < M <= 16
 template <int ACT, bool ACC>
-__device__ __forceinline__ void mm(float* out, int som, const float* A, int sam, int sak, const float* B, int sbn, int sbk, const float* bias,
-                                   int M, int N, int K, bool rot = false) {
-    for (int i = at_tid(); i < M * N; i += AT_NT) {
-        const int m = i / N, n = i - m * N;
-        const float* a = A + m * sam;
-        const float* b = B + n * sbn;
-        float acc0 = bias ? bias[n] : 0.f, acc1 = 0.f;
-        int k = rot ? n % K : 0, kk = 0;
-        for (; kk + 8 <= K; kk += 8) {                     // eight independent LDS read pairs in flight (one wavefront per SIMD: nothing else hides them)
-            float av[8], bv[8];
+__device__ __forceinline__ void mm(TileJobs& jobs, float* out, int som, const float* A, int sam, int sak, const float* B, int sbn, int sbk,
+                                   const float* bias, int M, int N, int K) {
+    const int lane = at_tid() & 63, tr = 4 * (lane >> 4), tc = lane & 15;
+    for (int n0 = 0; n0 < N; n0 += 16) {
+        if (!jobs.mine()) continue;
+        const f32x4v acc = tile16(zero4(), A, sam, sak, M, B + n0 * sbn, sbk, sbn, min(16, N - n0), K);
+        if (n0 + tc < N) {
+            const float bv = bias ? bias[n0 + tc] : 0.f;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                int ku = k + u;
-                ku -= ku >= K ? K : 0;
-                av[u] = a[ku * sak];
-                bv[u] = b[ku * sbk];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u += 2) {
-                acc0 = fmaf(av[u], bv[u], acc0);
-                acc1 = fmaf(av[u + 1], bv[u + 1], acc1);
-            }
-            k += 8; k -= k >= K ? K : 0;
+            for (int i = 0; i < 4; ++i)
+                if (tr + i < M) {
+                    float v = acc[i] + bv;
+                    if (ACT == 1) v = fmaxf(v, 0.f);
+                    if (ACC) out[(tr + i) * som + n0 + tc] += v;
+                    else out[(tr + i) * som + n0 + tc] = v;
+                }
         }
-        for (; kk < K; ++kk) {
-            acc0 = fmaf(a[k * sak], b[k * sbk], acc0);
-            if (++k == K) k = 0;
-        }
-        float acc = acc0 + acc1;
-        if (ACT == 1) acc = fmaxf(acc, 0.f);
-        if (ACC) out[m * som + n] += acc;
-        else out[m * som + n] = acc;
     }
 }
 // y = x W^T (+ b) with W [N, K] row-major (nn.Linear / 1x1 convolution)
 template <int ACT>
-__device__ __forceinline__ void lin(float* out, int som, const float* x, int ldx, const float* W, const float* b, int M, int N, int K) {
-    mm<ACT, false>(out, som, x, ldx, 1, W, K, 1, b, M, N, K, !(K & 1));
+__device__ __forceinline__ void lin(TileJobs& jobs, float* out, int som, const float* x, int ldx, const float* W, const float* b, int M, int N, int K) {
+    mm<ACT, false>(jobs, out, som, x, ldx, 1, W, K, 1, b, M, N, K);
 }
-// part[n K + k] += sum_m G[m sgm + n] X[m sxm + k]  (weight gradient of y = x W^T; an element is always added by the same lane)
-__device__ __forceinline__ void wacc(float* part, const float* G, int sgm, const float* X, int sxm, int M, int N, int K) {
-    for (int i = at_tid(); i < N * K; i += AT_NT) {
-        const int n = i / K, k = i - n * K;
-        float acc0 = 0.f, acc1 = 0.f;
-        int m = 0;
-        for (; m + 8 <= M; m += 8) {
-            float gv[8], xv[8];
+// part[n K + k] += sum_m G[m sgm + n] X[m sxm + k]  (weight gradient of y = x W^T)
+__device__ __forceinline__ void wacc(TileJobs& jobs, float* part, const float* G, int sgm, const float* X, int sxm, int M, int N, int K) {
+    const int lane = at_tid() & 63, tr = 4 * (lane >> 4), tc = lane & 15;
+    for (int n0 = 0; n0 < N; n0 += 16)
+        for (int k0 = 0; k0 < K; k0 += 16) {
+            if (!jobs.mine()) continue;
+            const f32x4v acc = tile16(zero4(), G + n0, 1, sgm, min(16, N - n0), X + k0, sxm, 1, min(16, K - k0), M);
+            if (k0 + tc < K) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                gv[u] = G[(m + u) * sgm + n];
-                xv[u] = X[(m + u) * sxm + k];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u += 2) {
-                acc0 = fmaf(gv[u], xv[u], acc0);
-                acc1 = fmaf(gv[u + 1], xv[u + 1], acc1);
+                for (int i = 0; i < 4; ++i)
+                    if (n0 + tr + i < N) part[(n0 + tr + i) * K + k0 + tc] += acc[i];
             }
         }
-        for (; m < M; ++m) acc0 = fmaf(G[m * sgm + n], X[m * sxm + k], acc0);
-        part[i] += acc0 + acc1;
-    }
 }
-__device__ __forceinline__ void bacc(float* part, const float* G, int sgm, int M, int N) {
-    for (int n = at_tid(); n < N; n += AT_NT) {
-        float acc = 0.f;
-        for (int m = 0; m < M; ++m) acc += G[m * sgm + n];
-        part[n] += acc;
+// part[n] += sum_m G[m sgm + n]: the same tile against a column of ones (`one` points at a 1.0f in LDS)
+__device__ __forceinline__ void bacc(TileJobs& jobs, float* part, const float* G, int sgm, int M, int N, const float* one) {
+    const int lane = at_tid() & 63, tr = 4 * (lane >> 4), tc = lane & 15;
+    for (int n0 = 0; n0 < N; n0 += 16) {
+        if (!jobs.mine()) continue;
+        const f32x4v acc = tile16(zero4(), G + n0, 1, sgm, min(16, N - n0), one, 0, 0, 16, M);
+        if (tc == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (n0 + tr + i < N) part[n0 + tr + i] += acc[i];
+        }
     }
 }
 __device__ __forceinline__ float wave_max(float v) {
@@ -361,42 +384,6 @@ __device__ __forceinline__ void p_dot16(float* out, int so, const float* rows, i
     }
 }
 
-// The sample-sized products on the exact-float32 matrix core (v_mfma_f32_16x16x4_f32 = an fmaf chain in k order): one wavefront, one
-// 16 x 16 tile  D[m][n] += sum_k A[m sa_m + k sa_k] B[k sb_k + n sb_n],  m < Mv, n < Nv, k < K (operands outside are zeros); four
-// k-steps of operands are loaded in front of their four MFMAs.  Lane l holds A[m = l % 16][k = l / 16], B[k = l / 16][n = l % 16] and
-// the results D[4 (l / 16) + i][l % 16] in acc[i].  On the vector ALU these were the lane-serial loops over the 128 samples of a ray:
-// the attention sums (8 k cycles of a 64 k-cycle forward), MAM.linear on the intra sums (28 k), its two transposes in the backward (35 k).
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-static_assert(AT_NT == 512, "the MAM.linear weight gradient is eight 16 x 16 tiles, one per wavefront");
-__device__ __forceinline__ f32x4v tile16(f32x4v acc, const float* A, int sa_m, int sa_k, int Mv, const float* B, int sb_k, int sb_n, int Nv,
-                                         int K) {
-    const int lane = at_tid() & 63, mn = lane & 15, kq = lane >> 4;
-    const bool am = mn < Mv, bn = mn < Nv;
-    const float* a = A + (am ? mn : 0) * sa_m;
-    const float* b = B + (bn ? mn : 0) * sb_n;
-    for (int k0 = 0; k0 < K; k0 += 16) {
-        float av[4], bv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = k0 + 4 * u + kq;
-            const bool in = k < K;
-            const int kc = in ? k : 0;
-            av[u] = a[kc * sa_k];
-            bv[u] = b[kc * sb_k];
-            av[u] = (am && in) ? av[u] : 0.f;
-            bv[u] = (bn && in) ? bv[u] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
-    }
-    return acc;
-}
-__device__ __forceinline__ f32x4v zero4() {
-    f32x4v z;
-    z[0] = z[1] = z[2] = z[3] = 0.f;
-    return z;
-}
-
 __device__ __forceinline__ void tail_stage_weights(const TailKParams& p, const TailLds& L) {
     const TailDims& d = p.d;
     auto copy = [&](float* dst, const float* src, int n) {           // n is a multiple of 4 here except for the odd-width layer 0
@@ -423,6 +410,7 @@ __device__ __forceinline__ void tail_stage_weights(const TailKParams& p, const T
 __device__ __forceinline__ void tail_forward_ray(const TailKParams& p, const TailLds& L, long r, AtClock& clk) {
     const TailDims& d = p.d;
     const int tid = at_tid(), P = d.P, S = d.S;
+    TileJobs jobs{0};
     // awp.py:89-95, 104-105: [integrated features | view_feature | direction encoding of the first sub-exposure's ray]
     for (int i = tid; i < P * AT_WS; i += AT_NT) {
         const int pp = i >> 6, k = i & 63;
@@ -448,8 +436,8 @@ __device__ __forceinline__ void tail_forward_ray(const TailKParams& p, const Tai
     __syncthreads();
     clk.mark(1);
     // awp.py:107-109 (layer 0) and mam.py:72-74 applied to the per-sample part's inter sums
-    lin<1>(L.xs(0), AT_CM, L.x0, d.IN0, L.mw(0), L.mb(0), P, AT_CM, d.IN0);
-    lin<0>(L.li, AT_CM, L.hi, AT_WS, L.lin_w, L.lin_b, P, AT_CM, AT_WS);
+    lin<1>(jobs, L.xs(0), AT_CM, L.x0, d.IN0, L.mw(0), L.mb(0), P, AT_CM, d.IN0);
+    lin<0>(jobs, L.li, AT_CM, L.hi, AT_WS, L.lin_w, L.lin_b, P, AT_CM, AT_WS);
     // ... and to the intra sums [S, 64] -> ls [S, 32]: 16 x 16 tiles over (samples, channels), a wavefront per tile; a lane's four k-steps
     // of a sample row / a weight row are one 16-byte load (k = 16 jj + 4 (l / 16) + component on both operands)
     {
@@ -484,19 +472,19 @@ __device__ __forceinline__ void tail_forward_ray(const TailKParams& p, const Tai
     __syncthreads();
     clk.mark(2);
     for (int l = 1; l < d.n_mot; ++l) {
-        lin<1>(L.xs(l), AT_CM, L.xs(l - 1), AT_CM, L.mw(l), L.mb(l), P, AT_CM, AT_CM);
-        if (l == 1) lin<0>(L.kP, AT_MID, L.li, AT_CM, L.conva, nullptr, P, AT_MID, AT_CM);            // mam.py:38
+        lin<1>(jobs, L.xs(l), AT_CM, L.xs(l - 1), AT_CM, L.mw(l), L.mb(l), P, AT_CM, AT_CM);
+        if (l == 1) lin<0>(jobs, L.kP, AT_MID, L.li, AT_CM, L.conva, nullptr, P, AT_MID, AT_CM);            // mam.py:38
         __syncthreads();
         clk.mark(3);
     }
     if (d.n_mot == 1) {
-        lin<0>(L.kP, AT_MID, L.li, AT_CM, L.conva, nullptr, P, AT_MID, AT_CM);
+        lin<0>(jobs, L.kP, AT_MID, L.li, AT_CM, L.conva, nullptr, P, AT_MID, AT_CM);
         __syncthreads();
         clk.mark(3);
     }
     const float* xg = L.xs(d.n_mot - 1);
-    lin<0>(L.q, AT_MID, xg, AT_CM, L.convc, nullptr, P, AT_MID, AT_CM);                               // mam.py:41
-    lin<0>(L.nP, AT_MID, L.kP, AT_MID, L.convn, nullptr, P, AT_MID, AT_MID);                          // mam.py:46
+    lin<0>(jobs, L.q, AT_MID, xg, AT_CM, L.convc, nullptr, P, AT_MID, AT_CM);                               // mam.py:41
+    lin<0>(jobs, L.nP, AT_MID, L.kP, AT_MID, L.convn, nullptr, P, AT_MID, AT_MID);                          // mam.py:46
     for (int s0 = 0; s0 < S; s0 += AT_NT / AT_LPS) {                                                       // mam.py:39: convb
         const int s = s0 + sl;
         if (s < S) {
@@ -511,7 +499,7 @@ __device__ __forceinline__ void tail_forward_ray(const TailKParams& p, const Tai
     }
     __syncthreads();
     clk.mark(5);
-    mm<0, false>(L.aP, P, L.q, AT_MID, 1, L.kP, AT_MID, 1, nullptr, P, P, AT_MID);                   // mam.py:42: logits over the sub-exposures
+    mm<0, false>(jobs, L.aP, P, L.q, AT_MID, 1, L.kP, AT_MID, 1, nullptr, P, P, AT_MID);                   // mam.py:42: logits over the sub-exposures
     for (int s0 = 0; s0 < S; s0 += AT_NT / AT_LPS) {                                                       // mam.py:47 (convl), :43 (logits over the samples)
         const int s = s0 + sl;
         if (s < S) {
@@ -531,7 +519,7 @@ __device__ __forceinline__ void tail_forward_ray(const TailKParams& p, const Tai
     if (tid >= AT_NT - 64 && tid - (AT_NT - 64) < P) softmax_small(L.aP + (tid - (AT_NT - 64)) * P, P);
     __syncthreads();
     clk.mark(7);
-    mm<0, false>(L.f, AT_CM, L.aP, P, 1, L.nP, 1, AT_MID, nullptr, P, AT_MID, P);                     // mam.py:49
+    mm<0, false>(jobs, L.f, AT_CM, L.aP, P, 1, L.nP, 1, AT_MID, nullptr, P, AT_MID, P);                     // mam.py:49
     if ((tid >> 6) == AT_NT / 64 - 1) {                                                               // mam.py:50 (:52: the concatenation)
         const f32x4v acc = tile16(zero4(), L.aS, d.SA, 1, P, L.nI, AT_LK, 1, AT_MID, S);
         const int lane = tid & 63;
@@ -541,7 +529,7 @@ __device__ __forceinline__ void tail_forward_ray(const TailKParams& p, const Tai
     }
     __syncthreads();
     clk.mark(8);
-    lin<0>(L.yb, AT_CM, L.f, AT_CM, L.convd, nullptr, P, AT_CM, AT_CM);                               // mam.py:53: convd[0]
+    lin<0>(jobs, L.yb, AT_CM, L.f, AT_CM, L.convd, nullptr, P, AT_CM, AT_CM);                               // mam.py:53: convd[0]
     __syncthreads();
     clk.mark(9);
 }
@@ -753,6 +741,7 @@ __global__ __launch_bounds__(AT_NT) void k_awp_tail_bwd(TailKParams p) {
         if (tid0 < 2 * AT_CM) stat[tid0] = p.stats[tid0];
     }
     float* part = p.partA + (long)blockIdx.x * p.partA_stride;
+    if (tid0 == 0) L.tmp[63] = 1.0f;                        // the column of ones of the bias-gradient tiles
     for (long i = tid0; i < p.off[p.nw]; i += AT_NT) part[i] = 0.f;
     __syncthreads();
     if (tid0 < 2 * AT_CM) {
@@ -765,6 +754,7 @@ __global__ __launch_bounds__(AT_NT) void k_awp_tail_bwd(TailKParams p) {
     const int wb = 2 * nm;
     for (long r = blockIdx.x; r < p.R; r += gridDim.x) {
         const int tid = at_tid(), sl = tid / AT_LPS, hf = tid % AT_LPS;      // (per ray: see at_tid)
+        TileJobs jobs{0};
         if (p.saved) {
             const float4* src = reinterpret_cast<const float4*>(p.saved + r * L.ray_floats);
             float4* dst = reinterpret_cast<float4*>(L.x0);
@@ -787,13 +777,13 @@ __global__ __launch_bounds__(AT_NT) void k_awp_tail_bwd(TailKParams p) {
         }
         __syncthreads();
         clk.mark(11);
-        wacc(part + off[wb + TW_CONVD], L.yb, AT_CM, L.f, AT_CM, P, AT_CM, AT_CM);
-        mm<0, false>(L.df, AT_CM, L.yb, AT_CM, 1, L.convd, 1, AT_CM, nullptr, P, AT_CM, AT_CM);      // d f = d y convd
+        wacc(jobs, part + off[wb + TW_CONVD], L.yb, AT_CM, L.f, AT_CM, P, AT_CM, AT_CM);
+        mm<0, false>(jobs, L.df, AT_CM, L.yb, AT_CM, 1, L.convd, 1, AT_CM, nullptr, P, AT_CM, AT_CM);      // d f = d y convd
         __syncthreads();
         clk.mark(12);
         // attention over the sub-exposures (mam.py:42, 46, 49) and over the samples (:43, 47, 50)
-        mm<0, false>(L.daP, P, L.df, AT_CM, 1, L.nP, AT_MID, 1, nullptr, P, P, AT_MID);              // d aP[p][p'] = d fP[p] . nP[p']
-        mm<0, false>(L.dnP, AT_MID, L.aP, 1, P, L.df, 1, AT_CM, nullptr, P, AT_MID, P);              // d nP[p'][m] = sum_p aP[p][p'] d fP[p][m]
+        mm<0, false>(jobs, L.daP, P, L.df, AT_CM, 1, L.nP, AT_MID, 1, nullptr, P, P, AT_MID);              // d aP[p][p'] = d fP[p] . nP[p']
+        mm<0, false>(jobs, L.dnP, AT_MID, L.aP, 1, P, L.df, 1, AT_CM, nullptr, P, AT_MID, P);              // d nP[p'][m] = sum_p aP[p][p'] d fP[p][m]
         for (int s0 = 0; s0 < S; s0 += AT_NT / AT_LPS) {
             const int s = s0 + sl;
             if (s < S) {
@@ -828,9 +818,14 @@ __global__ __launch_bounds__(AT_NT) void k_awp_tail_bwd(TailKParams p) {
             for (int i = 0; i < 4; ++i)
                 if (tr + i < P) L.dq[(tr + i) * AT_MID + tc] = acc[i];
         }
-        mm<0, false>(L.dkP, AT_MID, L.daP, 1, P, L.q, 1, AT_MID, nullptr, P, AT_MID, P);
-        mm<0, true>(L.dkP, AT_MID, L.dnP, AT_MID, 1, L.convn, 1, AT_MID, nullptr, P, AT_MID, AT_MID);
-        wacc(part + off[wb + TW_CONVN], L.dnP, AT_MID, L.kP, AT_MID, P, AT_MID, AT_MID);
+        if (jobs.mine()) {                                                                            // d kP = d lgP^T q + d nP convn (one tile, one owner)
+            f32x4v acc = tile16(zero4(), L.daP, 1, P, P, L.q, AT_MID, 1, AT_MID, P);
+            acc = tile16(acc, L.dnP, AT_MID, 1, P, L.convn, AT_MID, 1, AT_MID, AT_MID);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (tr + i < P) L.dkP[(tr + i) * AT_MID + tc] = acc[i];
+        }
+        wacc(jobs, part + off[wb + TW_CONVN], L.dnP, AT_MID, L.kP, AT_MID, P, AT_MID, AT_MID);
         if (wave == 1) {                                                                              // d convl[m'][m] = sum_s d nI[s][m'] kI[s][m]
             const f32x4v acc = tile16(zero4(), dnI, 1, AT_LK, AT_MID, L.kI, AT_LK, 1, AT_MID, S);
 #pragma unroll
@@ -851,16 +846,16 @@ __global__ __launch_bounds__(AT_NT) void k_awp_tail_bwd(TailKParams p) {
         __syncthreads();
         clk.mark(15);
         // conva / convb / convc, and back through MAM.linear
-        wacc(part + off[wb + TW_CONVA], L.dkP, AT_MID, L.li, AT_CM, P, AT_MID, AT_CM);
+        wacc(jobs, part + off[wb + TW_CONVA], L.dkP, AT_MID, L.li, AT_CM, P, AT_MID, AT_CM);
         if (wave == 2 || wave == 3) {                                                                 // d convb[m][c] = sum_s d kI[s][m] ls[s][c]
             const int ct = wave - 2;
             const f32x4v acc = tile16(zero4(), L.dkI, 1, AT_LK, AT_MID, L.ls + 16 * ct, AT_LS, 1, 16, S);
 #pragma unroll
             for (int i = 0; i < 4; ++i) part[off[wb + TW_CONVB] + (tr + i) * AT_CM + 16 * ct + tc] += acc[i];
         }
-        wacc(part + off[wb + TW_CONVC], L.dq, AT_MID, xg, AT_CM, P, AT_MID, AT_CM);
-        mm<0, false>(L.dli, AT_CM, L.dkP, AT_MID, 1, L.conva, 1, AT_CM, nullptr, P, AT_CM, AT_MID);
-        mm<0, true>(L.dxa, AT_CM, L.dq, AT_MID, 1, L.convc, 1, AT_CM, nullptr, P, AT_CM, AT_MID);   // d x_global += d q convc
+        wacc(jobs, part + off[wb + TW_CONVC], L.dq, AT_MID, xg, AT_CM, P, AT_MID, AT_CM);
+        mm<0, false>(jobs, L.dli, AT_CM, L.dkP, AT_MID, 1, L.conva, 1, AT_CM, nullptr, P, AT_CM, AT_MID);
+        mm<0, true>(jobs, L.dxa, AT_CM, L.dq, AT_MID, 1, L.convc, 1, AT_CM, nullptr, P, AT_CM, AT_MID);   // d x_global += d q convc
         for (int s0 = 0; s0 < S; s0 += AT_NT / AT_LPS) {                                                  // d ls[s] = d kI[s] convb
             const int s = s0 + sl;
             if (s < S) {
@@ -881,9 +876,16 @@ __global__ __launch_bounds__(AT_NT) void k_awp_tail_bwd(TailKParams p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) part[off[wb + TW_LIN_W] + (16 * ct + tr + i) * AT_WS + 16 * kt + tc] += acc[i];
         }
-        bacc(part + off[wb + TW_LIN_B], L.dli, AT_CM, P, AT_CM);
-        bacc(part + off[wb + TW_LIN_B], L.dls, AT_LS, S, AT_CM);
-        mm<0, false>(p.d_hi + r * P * AT_WS, AT_WS, L.dli, AT_CM, 1, L.lin_w, 1, AT_WS, nullptr, P, AT_WS, AT_CM);
+        for (int n0 = 0; n0 < AT_CM; n0 += 16)                                                        // d MAM.linear.bias = the column sums of d li and d ls
+            if (jobs.mine()) {
+                f32x4v acc = tile16(zero4(), L.dli + n0, 1, AT_CM, 16, L.tmp + 63, 0, 0, 16, P);
+                acc = tile16(acc, L.dls + n0, 1, AT_LS, 16, L.tmp + 63, 0, 0, 16, S);
+                if (tc == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) part[off[wb + TW_LIN_B] + n0 + tr + i] += acc[i];
+                }
+            }
+        mm<0, false>(jobs, p.d_hi + r * P * AT_WS, AT_WS, L.dli, AT_CM, 1, L.lin_w, 1, AT_WS, nullptr, P, AT_WS, AT_CM);
         {   // d h_intra [S][64] = d ls MAM.linear.weight: tiles over (samples, k), K = 32
             const int nst = (S + 15) >> 4;
             for (int tt = wave; tt < 4 * nst; tt += AT_NT / 64) {
@@ -906,9 +908,9 @@ __global__ __launch_bounds__(AT_NT) void k_awp_tail_bwd(TailKParams p) {
             clk.mark(18);
             const int K = l == 0 ? d.IN0 : AT_CM;
             const float* xin = l == 0 ? L.x0 : L.xs(l - 1);
-            wacc(part + off[2 * l], dx, AT_CM, xin, K, P, AT_CM, K);
-            bacc(part + off[2 * l + 1], dx, AT_CM, P, AT_CM);
-            mm<0, false>(dprev, K, dx, AT_CM, 1, L.mw(l), 1, K, nullptr, P, K, AT_CM);
+            wacc(jobs, part + off[2 * l], dx, AT_CM, xin, K, P, AT_CM, K);
+            bacc(jobs, part + off[2 * l + 1], dx, AT_CM, P, AT_CM, L.tmp + 63);
+            mm<0, false>(jobs, dprev, K, dx, AT_CM, 1, L.mw(l), 1, K, nullptr, P, K, AT_CM);
             float* t = dx; dx = dprev; dprev = t;
         }
         __syncthreads();
