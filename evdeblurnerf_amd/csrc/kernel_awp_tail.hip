@@ -157,7 +157,21 @@ __device__ __forceinline__ f32x4v tile16(f32x4v acc, const float* A, int sa_m, i
     const bool am = mn < Mv, bn = mn < Nv;
     const float* a = A + (am ? mn : 0) * sa_m;
     const float* b = B + (bn ? mn : 0) * sb_n;
-    for (int k0 = 0; k0 < K; k0 += 16) {
+    int k0 = 0;
+    for (; k0 + 32 <= K; k0 += 32) {                       // eight k-steps of operands in flight (a trip costs one LDS round trip, whatever its width)
+        float av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + 4 * u + kq;
+            av[u] = a[k * sa_k];
+            bv[u] = b[k * sb_k];
+            av[u] = am ? av[u] : 0.f;
+            bv[u] = bn ? bv[u] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+    }
+    for (; k0 < K; k0 += 16) {
         float av[4], bv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -218,11 +232,14 @@ __device__ __forceinline__ void wacc(TileJobs& jobs, float* part, const float* G
     for (int n0 = 0; n0 < N; n0 += 16)
         for (int k0 = 0; k0 < K; k0 += 16) {
             if (!jobs.mine()) continue;
+            float old[4];                                   // (the partial row lives in L2: its read is in flight while the tile is computed)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) old[i] = (k0 + tc < K && n0 + tr + i < N) ? part[(n0 + tr + i) * K + k0 + tc] : 0.f;
             const f32x4v acc = tile16(zero4(), G + n0, 1, sgm, min(16, N - n0), X + k0, sxm, 1, min(16, K - k0), M);
             if (k0 + tc < K) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (n0 + tr + i < N) part[(n0 + tr + i) * K + k0 + tc] += acc[i];
+                    if (n0 + tr + i < N) part[(n0 + tr + i) * K + k0 + tc] = old[i] + acc[i];
             }
         }
 }
@@ -758,8 +775,20 @@ __global__ __launch_bounds__(AT_NT) void k_awp_tail_bwd(TailKParams p) {
         if (p.saved) {
             const float4* src = reinterpret_cast<const float4*>(p.saved + r * L.ray_floats);
             float4* dst = reinterpret_cast<float4*>(L.x0);
-#pragma unroll 4
-            for (int i = tid; i < L.ray_floats / 4; i += AT_NT) dst[i] = src[i];
+            const int n4 = L.ray_floats / 4;
+            for (int i0 = 0; i0 < n4; i0 += 8 * AT_NT) {         // eight 16-byte loads per thread in flight (the block is one trip at P = 10, S = 128)
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + tid + u * AT_NT;
+                    v[u] = src[i < n4 ? i : 0];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + tid + u * AT_NT;
+                    if (i < n4) dst[i] = v[u];
+                }
+            }
             __syncthreads();
             clk.mark(1);
         } else {
@@ -871,10 +900,29 @@ __global__ __launch_bounds__(AT_NT) void k_awp_tail_bwd(TailKParams p) {
         clk.mark(16);
         {   // d MAM.linear.weight [32][64] += d ls^T h_intra + d li^T h_inter: eight 16 x 16 tiles, one per wavefront (AT_NT / 64 == 8)
             const int ct = wave & 1, kt = wave >> 1;
-            f32x4v acc = tile16(zero4(), L.dls + 16 * ct, 1, AT_LS, 16, p.h_intra + r * S * AT_WS + 16 * kt, AT_WS, 1, 16, S);
+            float* dst = part + off[wb + TW_LIN_W] + (16 * ct + tr) * AT_WS + 16 * kt + tc;
+            float old[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) old[i] = dst[i * AT_WS];
+            f32x4v acc = zero4();
+            const float* xg_ = p.h_intra + r * S * AT_WS + 16 * kt + tc;          // B[k = sample][n]: 64 contiguous bytes per sample and tile
+            for (int s0 = 0; s0 < S; s0 += 128) {                                 // 32 samples-of-four: every global operand requested first
+                float bv[32];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) {
+                    const int sx = s0 + 4 * u + (lane >> 4);
+                    bv[u] = xg_[(long)(sx < S ? sx : S - 1) * AT_WS];
+                }
+#pragma unroll
+                for (int u = 0; u < 32; ++u) {
+                    const int sx = s0 + 4 * u + (lane >> 4);
+                    const float av = sx < S ? L.dls[sx * AT_LS + 16 * ct + tc] : 0.f;
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, sx < S ? bv[u] : 0.f, acc, 0, 0, 0);
+                }
+            }
             acc = tile16(acc, L.dli + 16 * ct, 1, AT_CM, 16, L.hi + 16 * kt, AT_WS, 1, 16, P);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) part[off[wb + TW_LIN_W] + (16 * ct + tr + i) * AT_WS + 16 * kt + tc] += acc[i];
+            for (int i = 0; i < 4; ++i) dst[i * AT_WS] = old[i] + acc[i];
         }
         for (int n0 = 0; n0 < AT_CM; n0 += 16)                                                        // d MAM.linear.bias = the column sums of d li and d ls
             if (jobs.mine()) {
