@@ -396,8 +396,10 @@ def awp_leg(precision):
                        "achieved": [mam["fwd_GBps"], mam["bwd_GBps"]], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": [mam["fwd_GBps"] / HBM_PEAK_GBS, mam["bwd_GBps"] / HBM_PEAK_GBS],
                        "note": "forward: h_local read twice (logits, then the two softmax-weighted sums); backward: read once, d h_local written once"}
+    import bench_awp_tail
     return {"workload": "AWP consumer, blurfactory blur batch: 10 240 sub-exposure rays x 128 samples, sample_feature_embed_layer 128-64-64-64-64 + feature_integration",
             "mam_per_sample_part": mam,
+            "per_ray_remainder": bench_awp_tail.run(),      # awp.py:89-95, 104-117 + mam.py:35-53 on evd_awp_tail_* vs the channel-last torch path
             "precision": precision, "fine_level_fwd_bwd_ms": t0, "with_awp_torch_linear_on_depth_feature_ms": t1, "with_awp_fused_on_geo_fragments_ms": t2,
             "awp_addon_ms": {"torch": (t1 - t0) if t1 is not None else None, "fused": t2 - t0}, "depth_feature_tensor_avoided_bytes": n * 128 * 4,
             "roofline": {"kernel": "k_awp_embed (training forward, geo fragments in)", "bound": "hbm", "kernel_ms": k_ms, "algorithmic_bytes": algo,

@@ -202,3 +202,46 @@ def test_fused_awp_whole_forward_kernels_vs_torch_remainder():
     out2 = big(df2, z2, rd[:8 * P].detach(), vf[:8].detach())
     assert out2.shape == (8, P) and (P, S2, 32, 2, 2) in big._tail_refused
     assert (out2.sum(-1) - 1).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("variant", ["eval_mode", "one_layer", "four_layers", "foreign_encoding"])
+def test_tail_variants_vs_float64_autograd(variant):
+    """eval mode (the BatchNorm's running estimates are constants of the backward), a motion embedding of one and of four layers
+    (kernel_awp_mot_emb_depth 0 / 3), and a direction encoding the kernel does not know (its columns then arrive as view_feature)"""
+    import copy
+    from evdeblurnerf_amd.awp import FusedAWP
+    R, P, S, VF = 70, 6, 48, 7
+    awp, h_local, z, rays_d, vf, proj = _random_case(R, P, S, VF, seed=77, n_extra_layers=2 if variant == "four_layers" else 0)
+    if variant == "one_layer":
+        awp.motion_feature_embed_layer = torch.nn.ModuleList([awp.motion_feature_embed_layer[0]])
+    if variant == "foreign_encoding":       # three frequencies, cosines first: not get_embedder's layout
+        awp.ray_dirs_embed_fn = lambda x: torch.cat([x] + [f(x * 2.0 ** k) for k in range(2) for f in (torch.cos, torch.sin)], -1)
+    with torch.no_grad():
+        bn = awp.MAM.Corr.convd[1]
+        bn.running_mean.normal_(0, 0.05)
+        bn.running_var.uniform_(0.01, 0.05)
+    ref = copy.deepcopy(awp).double()
+    awp = awp.cuda()
+    (awp.eval(), ref.eval()) if variant == "eval_mode" else (awp.train(), ref.train())
+    fused = FusedAWP(awp)
+    assert fused.tail_kernels and (fused._F is None) == (variant == "foreign_encoding")
+    dev = lambda a: torch.tensor(a).cuda().requires_grad_(True)
+    hl, rd, v = dev(h_local), dev(rays_d), dev(vf)
+    out = _kernel_chain(fused, hl, torch.tensor(z).cuda(), rd, v, R, P, S)
+    pk = [p_ for n_, p_ in awp.named_parameters() if not n_.startswith(("sample_feature_embed_layer", "MAM.conv."))]
+    grads = torch.autograd.grad((out * torch.tensor(proj).cuda()).sum(), [hl, rd, v] + pk)
+    c64 = lambda a: torch.tensor(a, dtype=torch.float64, requires_grad=True)
+    hl64, rd64, v64 = c64(h_local), c64(rays_d), c64(vf)
+    out64 = ref.forward_from_local(hl64, torch.tensor(z, dtype=torch.float64), rd64, v64)
+    names = [n_ for n_, _ in ref.named_parameters() if not n_.startswith(("sample_feature_embed_layer", "MAM.conv."))]
+    pr = dict(ref.named_parameters())
+    grads64 = torch.autograd.grad((out64 * torch.tensor(proj, dtype=torch.float64)).sum(), [hl64, rd64, v64] + [pr[n_] for n_ in names])
+    assert (out.detach().cpu().double() - out64.detach()).abs().max().item() < 2e-6
+    scale = max(float(g_.norm()) for g_ in grads64)
+    for key, a, b in zip(["h_local", "rays_d", "view_feature"] + names, grads, grads64):
+        if float(b.norm()) < 1e-6 * scale:            # analytically (near) zero: MAM.linear.bias behind the training-mode BatchNorm
+            assert float(a.norm()) < 1e-4 * scale, key
+            continue
+        assert rel(a, b) < 1e-4, (variant, key, rel(a, b))
+    if variant == "eval_mode":                        # the estimates are read, not written
+        assert torch.equal(awp.MAM.Corr.convd[1].running_mean.cpu().double(), ref.MAM.Corr.convd[1].running_mean)
