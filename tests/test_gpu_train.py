@@ -693,7 +693,7 @@ def test_c2f_training_gradients_against_the_reference_golden():
     _g19_check("f16", 0.15, 0.01, 3e-3)
 
 
-def _g19_check(prec, tol, tol_tight, rgb_tol):
+def _g19_check(prec, tol, tol_tight, rgb_tol, elem_tol=None):
     """G19: gradients computed by torch.autograd ON THE REFERENCE (its whole mode='c2f' training forward: NDC ray packing, both
     levels, resampling, TV) vs the HIP training path run on the same rays and weights.  Bounded by the half-precision ReLU flips and
     the slightly different resampled positions (the kernels' own coarse weights feed sample_pdf): norms and seeded projections of all
@@ -731,12 +731,19 @@ def _g19_check(prec, tol, tol_tight, rgb_tol):
             got[k] = v.grad
     keys = [k[2:-8] for k in g if k.startswith("g.") and k.endswith(".summary")]
     assert set(keys) == set(got)
-    worst = {}
+    worst, elem = {}, {}
     for idx, key in enumerate(keys):
         sm, head = grad_summary(got[key].detach().cpu().numpy(), 7000 + idx)
         ref = g[f"g.{key}.summary"]
         norm = float(ref[0])
         worst[key] = max(abs(sm[0] - ref[0]), abs(sm[1] - ref[1])) / norm
+        if elem_tol is not None:              # element level: the reference gradient's 256 largest elements and 256 seeded random ones
+            from torch_restatement import check_grad_elements
+            err, _ = check_grad_elements(got[key].detach().cpu().numpy(), g[f"g.{key}.elem_idx"], g[f"g.{key}.elem_val"], elem_tol)
+            elem[key] = err
+    if elem_tol is not None:
+        print(f"G19 vs kernels ({prec}), worst element error / largest pinned element:", {k: f"{v:.1e}" for k, v in sorted(elem.items(), key=lambda kv: -kv[1])[:6]})
+        assert max(elem.values()) < elem_tol, {k: f"{v:.1e}" for k, v in sorted(elem.items(), key=lambda kv: -kv[1])[:8]}
     tight = [k for k in keys if k.endswith("color_net.2.weight") or k.endswith("color_net.2.bias")]
     print(f"G19 vs kernels ({prec}), worst (norm / projection error) / norm:", {k: f"{v:.1e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:6]})
     assert max(worst.values()) < tol, {k: f"{v:.1e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])}

@@ -111,6 +111,10 @@ def test_f16x3_nerf_training_gradients_against_the_reference_golden():
         sm, _ = grad_summary(got[key].detach().cpu().numpy(), 7000 + idx)
         ref = g[f"w256.{key}.summary"]
         worst[key] = max(abs(sm[0] - ref[0]), abs(sm[1] - ref[1])) / float(ref[0])
+    from torch_restatement import check_grad_elements
+    elem = {key: check_grad_elements(got[key].detach().cpu().numpy(), g[f"w256.{key}.elem_idx"], g[f"w256.{key}.elem_val"], 1.0)[0] for key in keys}
+    print("G18 (w256) element level, worst error / largest pinned element:", {k: f"{v:.1e}" for k, v in sorted(elem.items(), key=lambda kv: -kv[1])[:5]})
+    assert max(elem.values()) < 5e-4, elem          # (measured 1.6e-4 on the sigma head, 2e-6 elsewhere)
     print("G18 (w256) vs the float32-grade kernels, worst (norm / projection error) / norm:",
           {k: f"{v:.1e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:5]})
     assert max(worst.values()) < 1e-3, worst
@@ -212,7 +216,7 @@ def test_f16x3_c2f_training_gradients_against_the_reference_golden():
     """G19 (torch.autograd on the reference's whole mode='c2f' training forward) in the float32-grade mode: all 30 parameter tensors
     and the rays within 1e-3 of the gradient norm (the half-precision run of the same check: 15 %), rendered colours within 2e-5."""
     from test_gpu_train import _g19_check
-    _g19_check("f16x3", 1e-3, 1e-3, 2e-5)
+    _g19_check("f16x3", 1e-3, 1e-3, 2e-5, elem_tol=1e-4)      # + element level: 512 pinned elements of every tensor (measured 1.8e-5 of the largest)
 
 
 def test_f16x3_c2f_end_to_end_gradients_at_the_blurfactory_grid_sizes():

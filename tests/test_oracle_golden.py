@@ -435,6 +435,10 @@ def _check_grad(got, g, key, idx):
     assert abs(sm[0] - ref_sm[0]) < 2e-4 * norm, (key, sm[0], ref_sm[0])
     assert abs(sm[1] - ref_sm[1]) < 1e-3 * norm, (key, sm[1], ref_sm[1])                     # random projection: an O(norm) number
     assert np.abs(head - ref_head).max() < 2e-4 * max(np.abs(ref_head).max(), norm / np.sqrt(max(np.asarray(got).size, 1))), key
+    if f"g.{key}.elem_idx" in g:             # element level: the 256 largest elements and 256 seeded random ones of the reference's gradient
+        from torch_restatement import check_grad_elements
+        err, ok = check_grad_elements(got, g[f"g.{key}.elem_idx"], g[f"g.{key}.elem_val"], 2e-4)
+        assert ok, (key, err)
 
 
 def test_G18_nerf_gradients_of_the_restatement_match_the_reference():

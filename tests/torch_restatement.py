@@ -139,6 +139,24 @@ def c2f_pipeline(levels, grids, rb, z0, zm, aabb):
     return rgb0, rgb1
 
 
+def grad_elements(g, seed, k=256):
+    """element-level pins of a gradient tensor: (flat indices, values) of its k largest-magnitude elements and of k seeded random ones"""
+    g = np.asarray(g, dtype=np.float64).reshape(-1)
+    k = min(k, g.size)
+    top = np.argsort(-np.abs(g), kind="stable")[:k]
+    rnd = np.random.RandomState(seed).choice(g.size, size=k, replace=g.size < k)
+    idx = np.concatenate([top, rnd]).astype(np.int64)
+    return idx, g[idx].copy()
+
+
+def check_grad_elements(got, idx, val, tol):
+    """max |got[idx] - val| relative to the largest pinned element"""
+    got = np.asarray(got, dtype=np.float64).reshape(-1)
+    scale = max(float(np.abs(val).max()), 1e-30)
+    err = float(np.abs(got[idx] - val).max()) / scale
+    return err, err < tol
+
+
 def grad_summary(g, seed):
     """(L2 norm, projection on a seeded random direction, first 32 elements) of a gradient tensor: what the goldens store"""
     g = np.asarray(g, dtype=np.float64).reshape(-1)

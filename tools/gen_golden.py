@@ -704,11 +704,14 @@ def G17_compute_successor():
 def _grad_summaries(named_grads, out, prefix):
     """store (norm, seeded projection) + the first 32 elements of every gradient: full gradients would not fit a small fixture"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from torch_restatement import grad_summary
+    from torch_restatement import grad_elements, grad_summary
     for i, (name, g) in enumerate(named_grads):
         sm, head = grad_summary(n(g), 7000 + i)
         out[f"{prefix}{name}.summary"] = sm.astype(np.float64)
         out[f"{prefix}{name}.head"] = head.astype(np.float64)
+        idx, val = grad_elements(n(g), 9000 + i)                # element-level pins: the 256 largest elements + 256 seeded random ones
+        out[f"{prefix}{name}.elem_idx"] = idx
+        out[f"{prefix}{name}.elem_val"] = val.astype(np.float64)
 
 
 def G18_nerf_grads():
