@@ -398,7 +398,10 @@ def test_fused_awp_per_ray_tail_as_a_captured_graph():
     ref = _RefLikeAWP(P=P, mam="corr").cuda()
     ref2 = _RefLikeAWP(P=P, mam="corr").cuda()
     ref2.load_state_dict(ref.state_dict())
-    eager, graphed = FusedAWP(ref, "f16", tail_kernels=False), FusedAWP(ref2, "f16", graph_per_ray=True)      # (the same torch remainder, eager and captured)
+    # (the same torch remainder, eager and captured.  Against the KERNEL remainder this loop differs by 7e-3 at its second step: one
+    # element of the 10 240 of z = x_global + BatchNorm(...) lies within rounding of the leaky ReLU's kink there, the two float32 paths put it
+    # on different sides, and one element's whole gradient is 1e-2 of the norm at this batch size -- float64 sides with the kernels)
+    eager, graphed = FusedAWP(ref, "f16", tail_kernels=False), FusedAWP(ref2, "f16", graph_per_ray=True)
     opts = [torch.optim.SGD(m.parameters(), lr=1e-2) for m in (ref, ref2)]
     for step in range(3):
         df = _t((0.5 * rs.standard_normal((R * P, S, 128))).astype(np.float32))
