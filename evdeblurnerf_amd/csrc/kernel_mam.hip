@@ -115,6 +115,94 @@ __global__ __launch_bounds__(256) void k_mam_local_fwd(const float* __restrict__
         h_inter[b * P * MAM_C + i] = red[i] + red[P * MAM_C + i] + red[2 * P * MAM_C + i] + red[3 * P * MAM_C + i];
 }
 
+// The same with the ray's rows REGISTER-RESIDENT between the two phases (P <= PR sub-exposures, S <= 16 NSR samples: 80 sixteen-byte loads
+// per thread at the blurfactory shape, all issued in front of the first logit): h_local is read once instead of twice -- the kernel is
+// HBM-bound, and a ray's 320 KiB do not fit the LDS but do fit the workgroup's register file (one workgroup of 256 threads per CU).
+template <int PR, int NSR>
+__global__ __launch_bounds__(256) void k_mam_local_fwd_r(const float* __restrict__ h, const float* __restrict__ u, int P, int S,
+                                                         float* __restrict__ h_inter, float* __restrict__ h_intra,
+                                                         float* __restrict__ alpha, float* __restrict__ beta) {
+    extern __shared__ float lds[];
+    float* A = lds;                         // [P][S] logits, then alpha
+    float* Bt = A + P * S;                  // [P][S] beta
+    float* rmax = Bt + P * S;               // [P] row max, [P] row sum
+    float* rsum = rmax + MAM_MAXP;
+    float* red = rsum + MAM_MAXP;           // [4 waves][P][64] partial inter sums
+    const long b = blockIdx.x;
+    const int tid = threadIdx.x, g = tid >> 4, l = tid & 15, wave = tid >> 6, lane = tid & 63;
+    const float4* h4 = reinterpret_cast<const float4*>(h) + b * (long)P * S * 16;
+    const float4 u4 = reinterpret_cast<const float4*>(u)[l];
+    float4 hr[PR][NSR];
+#pragma unroll
+    for (int p = 0; p < PR; ++p)
+#pragma unroll
+        for (int j = 0; j < NSR; ++j) {
+            const int s = g + 16 * j;
+            hr[p][j] = (p < P && s < S) ? h4[((long)p * S + s) * 16 + l] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+    for (int j = 0; j < NSR; ++j)
+#pragma unroll
+        for (int p = 0; p < PR; ++p) {
+            const float d = row_sum16(dot4(hr[p][j], u4));
+            if (l == 0 && p < P && g + 16 * j < S) A[p * S + g + 16 * j] = d;
+        }
+    __syncthreads();
+    for (int p = wave; p < P; p += 4) {      // the softmax along the samples: one wavefront per sub-exposure
+        float m = -INFINITY;
+        for (int s = lane; s < S; s += 64) m = fmaxf(m, A[p * S + s]);
+        for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float t = 0.f;
+        for (int s = lane; s < S; s += 64) t += __expf(A[p * S + s] - m);
+        t = wave_sum_dpp(t);
+        if (lane == 0) { rmax[p] = m; rsum[p] = t; }
+    }
+    __syncthreads();
+    for (int s = tid; s < S; s += 256) {     // the softmax along the sub-exposures: one thread per sample
+        float m = -INFINITY, t = 0.f;
+        for (int p = 0; p < P; ++p) m = fmaxf(m, A[p * S + s]);
+        for (int p = 0; p < P; ++p) t += __expf(A[p * S + s] - m);
+        const float it = 1.f / t;
+        for (int p = 0; p < P; ++p) {
+            const float a = A[p * S + s];
+            const float al = __expf(a - rmax[p]) / rsum[p], be = __expf(a - m) * it;
+            A[p * S + s] = al;
+            Bt[p * S + s] = be;
+            alpha[(b * P + p) * S + s] = al;
+            beta[(b * P + p) * S + s] = be;
+        }
+    }
+    __syncthreads();
+    float4 accP[PR];
+#pragma unroll
+    for (int p = 0; p < PR; ++p) accP[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < NSR; ++j) {
+        const int s = g + 16 * j;
+        if (s < S) {
+            float4 accI = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int p = 0; p < PR; ++p)
+                if (p < P) {
+                    fma4(accI, Bt[p * S + s], hr[p][j]);
+                    fma4(accP[p], A[p * S + s], hr[p][j]);
+                }
+            reinterpret_cast<float4*>(h_intra)[(b * S + s) * 16 + l] = accI;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PR; ++p)
+        if (p < P) {
+            float4 a = accP[p];
+            a.x += __shfl_xor(a.x, 16); a.y += __shfl_xor(a.y, 16); a.z += __shfl_xor(a.z, 16); a.w += __shfl_xor(a.w, 16);
+            a.x += __shfl_xor(a.x, 32); a.y += __shfl_xor(a.y, 32); a.z += __shfl_xor(a.z, 32); a.w += __shfl_xor(a.w, 32);
+            if (lane < 16) reinterpret_cast<float4*>(red)[(wave * P + p) * 16 + l] = a;
+        }
+    __syncthreads();
+    for (int i = tid; i < P * MAM_C; i += 256)
+        h_inter[b * P * MAM_C + i] = red[i] + red[P * MAM_C + i] + red[2 * P * MAM_C + i] + red[3 * P * MAM_C + i];
+}
+
 // Backward.  With gA[p,s] = d_inter[p] . h[p,s], gB[p,s] = d_intra[s] . h[p,s] the two softmax backwards need sum_s alpha gA = d_inter[p] .
 // h_inter[p] and sum_p beta gB = d_intra[s] . h_intra[s]: dots of the SAVED outputs, so h_local is read once:
 //      d logit = alpha (gA - cP[p]) + beta (gB - cI[s]);   d h = alpha d_inter[p] + beta d_intra[s] + d logit u;   d u = sum d logit h
@@ -193,7 +281,12 @@ int evd_mam_local_forward(const float* h_local, const float* u, long R, int P, i
     const size_t lds = sizeof(float) * ((size_t)2 * P * S + 2 * MAM_MAXP + (size_t)4 * P * MAM_C);
     constexpr size_t lds_max = sizeof(float) * ((size_t)2 * MAM_MAXP * MAM_MAXS + 2 * MAM_MAXP + (size_t)4 * MAM_MAXP * MAM_C);
     EVD_SET_MAX_LDS(k_mam_local_fwd, lds_max);
-    k_mam_local_fwd<<<(unsigned)R, 256, lds, as_stream(stream)>>>(h_local, u, P, S, h_inter, h_intra, alpha, beta);
+    static const bool two_pass = getenv("EVD_MAM_TWO_PASS") != nullptr;       // developer switch: round 3's kernel
+    if (!two_pass && P <= 10 && S <= 128) {
+        EVD_SET_MAX_LDS((k_mam_local_fwd_r<10, 8>), lds_max);
+        k_mam_local_fwd_r<10, 8><<<(unsigned)R, 256, lds, as_stream(stream)>>>(h_local, u, P, S, h_inter, h_intra, alpha, beta);
+    } else
+        k_mam_local_fwd<<<(unsigned)R, 256, lds, as_stream(stream)>>>(h_local, u, P, S, h_inter, h_intra, alpha, beta);
     EVD_HIP(hipGetLastError());
     return EVD_OK;
 }
