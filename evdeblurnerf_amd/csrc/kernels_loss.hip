@@ -762,7 +762,7 @@ __global__ __launch_bounds__(256) void k_awp_integrate_bwd_c64(const float* __re
                 for (int q = 3; q >= 0; --q) {
                     sfx += G[q];                                                          // channels >= this one
                     const float a = last ? 0.f : __fadd_rn(-e[q], 1.f);
-                    const float through = last ? 0.f : sfx / om[q];
+                    const float through = last ? 0.f : sfx * __builtin_amdgcn_rcpf(om[q]);      // (v_rcp_f32, 1 ulp: the IEEE division is ~10 instructions)
                     const float ga = g[q] * Q[q] * fc[q] - through;                       // d out / d a[s,c]
                     df[q] = last ? 0.f : g[q] * Q[q] * a + ga * dist * e[q];
                     ddist += last ? 0.f : ga * fc[q] * e[q];
