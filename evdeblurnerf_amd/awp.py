@@ -2,8 +2,10 @@
 ``AdaptiveWeightProposal`` -- ``sample_feature_embed_layer`` (awp.py:36-37,98-100: 4 x Linear + ReLU over every sample of every
 sub-exposure ray) and the ``feature_integration`` scan (awp.py:49-77) -- on hand-written kernels, forward and backward, as autograd
 nodes, and the per-sample part of the ``MotionAggregationModule`` (mam.py:72-74 ``linear`` on h_local, :29-33 attention logit, the two
-softmaxes and weighted sums) as one more.  ``FusedAWP`` wraps the reference's module: the per-ray remainder (motion embedding, the rest
-of the CorrelationModule, ``w_linear``: [R, P, 32] / [R, 32, S]-sized tensors) stays its PyTorch submodules, as in the reference's caller."""
+softmaxes and weighted sums) as one more, and the per-ray remainder (direction encoding, motion embedding, the rest of the
+CorrelationModule incl. its BatchNorm over all rays, ``w_linear``, the normalisation: awp.py:89-95, 104-117, mam.py:35-53) as a third
+(``evd_awp_tail_forward`` / ``_backward``).  ``FusedAWP`` wraps the reference's module, whose parameters and buffers stay where the optimizer
+and the state dict expect them; a module or a shape the kernels are not built for runs the remainder on its own PyTorch layers."""
 from __future__ import annotations
 
 import ctypes as C
@@ -336,7 +338,9 @@ class FusedAWP(torch.nn.Module):
 
         sample_feature_embed_layer   awp.py:98-100   -> evd_awp_embed_forward / _backward (reads the fine level's geo fragments)
         feature_integration          awp.py:102      -> evd_awp_feature_integration / _bwd
-        motion embedding, MAM, w_linear, normalisation  awp.py:104-117 -> the wrapped module's own submodules (per-ray sized)
+        MAM, per-sample part         mam.py:29-33,72-74 -> evd_mam_local_forward / _backward (one autograd node with the integration)
+        motion embedding, rest of the MAM, w_linear, normalisation  awp.py:89-95,104-117, mam.py:35-53 -> evd_awp_tail_forward / _backward
+                                     (tail_kernels=True and the reference's structure; else the wrapped module's own layers)
 
     `depth_feature` is the GeoFragments handle NeRFAll.forward_train passes when its awpnet is a FusedAWP (a float32 tensor
     [R P, S, 128] is accepted too)."""
