@@ -210,10 +210,12 @@ template <int PREC> static int run_awp_backward(const AwpBwdPlan& b, hipStream_t
         if ((rc = launch_dgrad<PREC, KW, T, KW, false, 1>(dgrad(l, D_E0 + KW * l, E0 + KW * (l - 1), D_E0 + KW * (l - 1)), b.tiles, st))) return rc;
     }
     if ((rc = wgrad(launch_wgrad<PREC, T, AWP_IN / 32, false>, T, AWP_IN / 32, D_E0, GEO, AMAP_GEO, g.w[0], AWP_IN, g.b[0]))) return rc;
-    if ((rc = launch_dgrad<PREC, KW, AWP_IN / 32, KW, false, 0>(dgrad(0, D_E0, -1, D_GEO), b.tiles, st))) return rc;     // d geo (no activation)
-    hipLaunchKernelGGL((k_frag_absmax<PREC>), dim3((unsigned)(cdiv(b.tiles * 64 * (AWP_IN / 16), 256L) < 2048 ? cdiv(b.tiles * 64 * (AWP_IN / 16), 256L) : 2048)), dim3(256), 0, st, (const char*)b.store, TILE_BYTES, D_GEO,
-                       AWP_IN / 16, b.tiles, words, words + 1);
-    EVD_LAUNCH_CHECK();
+    {   // d geo (no activation); its maximum (true units, for the fine level's rescaling) is taken by the kernel that forms it
+        DgradParams dp = dgrad(0, D_E0, -1, D_GEO);
+        dp.absmax_out = words + 1;
+        dp.maxbits = words;
+        if ((rc = launch_dgrad<PREC, KW, AWP_IN / 32, KW, false, 0>(dp, b.tiles, st))) return rc;
+    }
     if (b.d_geo_rows) {
         hipLaunchKernelGGL((k_frags_to_rows<PREC>), dim3((unsigned)cdiv(b.tiles * 64 * (AWP_IN / 16), 256L)), dim3(256), 0, st, (const char*)b.store, TILE_BYTES,
                            D_GEO, AWP_IN / 16, b.nsamp, words, b.d_geo_rows, AWP_IN);

@@ -112,11 +112,16 @@ template <int PREC> __device__ __forceinline__ void frag_values(const char* lane
     }
 }
 
+struct W4 { unsigned w[4]; };
+
 struct DgradParams {
     const char* wstream;    // W^T as a fragment stream (pack.h), one layer
     char* store;
     long tile_bytes;        // stride of a 32-sample tile in the store
     int in_slot, extra_slot, mask_slot, out_slot;
+    // optional: max |output| in true units (the loss scale behind *maxbits removed) -> atomicMax on *absmax_out (float bits), one per workgroup
+    unsigned* absmax_out = nullptr;
+    const unsigned* maxbits = nullptr;
 };
 
 // One dgrad layer: KTOT k-steps in (NIN contiguous fragments from in_slot, already masked by their producer, plus one more
@@ -166,6 +171,36 @@ __global__ __launch_bounds__(NT, NT / 256) void k_dgrad_layer(const DgradParams 
         else if constexpr (OMASK == 2) O::mask_bits(out[0][j], omb[0], j);
         act_store<FB>(actl[0], j, out[0][j]);
     }
+    if constexpr (is_half_prec(PREC)) {
+        if (p.absmax_out) {              // (what a separate pass over the stored fragments computed: k_frag_absmax, 110 us at 1.3 M samples x 128)
+            float m = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2 * TILES; ++j) {
+                const W4 f = __builtin_bit_cast(W4, out[0][j]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned short bits = (unsigned short)(f.w[e >> 1] >> (16 * (e & 1)));
+                    float v;
+                    if constexpr (PREC == EVD_PREC_BF16) v = __uint_as_float((unsigned)bits << 16);
+                    else v = (float)__builtin_bit_cast(_Float16, bits);
+                    m = fmaxf(m, fabsf(v));
+                }
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            __syncthreads();             // (the ring is not read any more: its first words carry the wavefronts' maxima)
+            float* part = reinterpret_cast<float*>(smem);
+            if (lane == 0) part[wave] = m;
+            __syncthreads();
+            if (tid == 0) {
+                for (int w = 1; w < NT / 64; ++w) m = fmaxf(m, part[w]);
+                // (thousands of atomicMax on one word serialise at the L2 -- 75 -> 309 us for this launch --: only a workgroup that would raise
+                // the word as it reads it now sends one; positive floats order like their bit patterns)
+                const unsigned mb = __float_as_uint(m * grad_scale(*p.maxbits, true));
+                if (m > 0.f && mb > *reinterpret_cast<volatile unsigned*>(p.absmax_out)) atomicMax(p.absmax_out, mb);
+            }
+        }
+    }
 }
 
 template <int PREC, int KTOT, int TILES, int NIN, bool EXTRA, int OMASK>
@@ -190,7 +225,6 @@ struct WgradParams {
 constexpr int WGRAD_NT = 512, WGRAD_TPI = 1;      // 8 wavefronts; sample tiles per iteration (one barrier each)
 constexpr int wgrad_cpg(int RT, int CT) { return cceil(CT, 8 / RT); }      // column tiles per wavefront group
 
-struct W4 { unsigned w[4]; };
 
 template <int PREC> __device__ __forceinline__ f32x16 mfma_half(const W4& a, const W4& b, const f32x16& c) {
     if constexpr (PREC == EVD_PREC_BF16) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
