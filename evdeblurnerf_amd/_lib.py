@@ -95,7 +95,7 @@ SIGNATURES = {
     "evd_awp_feature_integration": (_I, [_vp, _vp, _vp, _L, _I, _I, _vp, _vp]),
     "evd_awp_feature_integration_bwd": (_I, [_vp, _vp, _vp, _vp, _L, _I, _I, _vp, _vp, _vp, _vp]),
     "evd_mam_local_forward": (_I, [_vp, _vp, _L, _I, _I, _I, _vp, _vp, _vp, _vp, _vp]),
-    "evd_mam_local_backward": (_I, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _L, _I, _I, _I, _vp, _vp, _I, _vp]),
+    "evd_mam_local_backward": (_I, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _L, _I, _I, _I, _vp, _vp, _I, _vp, _vp]),
     "evd_awp_tail_num_params": (_I, [_I]),
     "evd_awp_tail_param_count": (_L, [C.POINTER(AwpTailDesc)]),
     "evd_awp_tail_workspace_bytes": (_S, [C.POINTER(AwpTailDesc), _L, _I]),
@@ -110,7 +110,7 @@ SIGNATURES = {
     "evd_awp_embed_store_bytes": (_S, [_vp, _L]),
     "evd_awp_embed_backward_workspace_bytes": (_S, []),
     "evd_awp_embed_forward": (_I, [_vp, _I, _vp, _vp, _vp, _S, _L, _vp, _vp, _S, _vp]),
-    "evd_awp_embed_backward": (_I, [_vp, _I, _vp, _L, _vp, _S, C.POINTER(AwpEmbedGrads), _vp, _vp, _S, _vp]),
+    "evd_awp_embed_backward": (_I, [_vp, _I, _vp, _L, _vp, _S, C.POINTER(AwpEmbedGrads), _vp, _vp, _vp, _S, _vp]),
     "evd_probe_mfma_rate": (_I, [_I, _I, C.POINTER(C.c_double), _vp]),
     "evd_device_count": (_I, []),
     "evd_get_rays": (_I, [_I, _I, _fp, _fp, _vp, _vp, _vp]),

@@ -17,6 +17,9 @@ from . import _lib as L
 from .voxnerf import GeoFragments
 
 
+_DH_ABSMAX = {}       # data_ptr of a d h_local tensor -> device word with the float bits of its max |.| (_LocalConsumers.backward -> _SampleEmbed.backward)
+
+
 class _FeatureIntegration(torch.autograd.Function):
     """evd_awp_feature_integration / evd_awp_feature_integration_bwd as one autograd node: gradients to the per-sample features (the
     AWP embedding MLP and, through it, the fine level), to z_vals and to rays_d (the blur kernel's ray directions)."""
@@ -89,8 +92,10 @@ class _SampleEmbed(torch.autograd.Function):
         d_rows = torch.empty((n, embed.input_ch), dtype=torch.float32, device=g.device) if (ctx.geo is None and ctx.needs_input_grad[0]) else None
         nb = int(lib.evd_awp_embed_backward_workspace_bytes())
         ws = torch.empty((nb,), dtype=torch.uint8, device=g.device)
+        amax = _DH_ABSMAX.pop(g.data_ptr(), None)     # the producer of d h_local took its maximum (same storage: nothing was added to it since)
+        _DH_ABSMAX.clear()
         L.check(lib.evd_awp_embed_backward(embed._h, L.PREC[embed.precision], L.ptr(g), n, L.ptr(ctx.store), ctx.store.numel(), C.byref(gs),
-                                           L.ptr(d_rows), L.ptr(ws), nb, L.stream_ptr()), "evd_awp_embed_backward")
+                                           L.ptr(d_rows), L.ptr(amax), L.ptr(ws), nb, L.stream_ptr()), "evd_awp_embed_backward")
         if ctx.geo is not None:
             ctx.geo.awp_store = ctx.store          # the level's backward (which autograd runs after this node) adds the d geo fragments
             d_src = torch.zeros(ctx.src_shape, dtype=torch.float32, device=g.device)
@@ -129,7 +134,7 @@ class _MamLocal(torch.autograd.Function):
         d_u = torch.empty((R, Cc), dtype=torch.float32, device=h.device)
         L.check(L.lib().evd_mam_local_backward(L.ptr(h), L.ptr(uu), L.ptr(alpha), L.ptr(beta), L.ptr(h_inter), L.ptr(h_intra),
                                                L.ptr(g_inter.contiguous().float()), L.ptr(g_intra.contiguous().float()), R, P, S, Cc,
-                                               L.ptr(d_h), L.ptr(d_u), 0, L.stream_ptr()), "evd_mam_local_backward")
+                                               L.ptr(d_h), L.ptr(d_u), 0, None, L.stream_ptr()), "evd_mam_local_backward")
         return d_h.reshape(ctx.h_shape), d_u.sum(0), None, None, None
 
 
@@ -165,11 +170,13 @@ class _LocalConsumers(torch.autograd.Function):
         d_z = torch.empty_like(zz) if ctx.needs_input_grad[1] else None
         d_d = torch.empty_like(dd) if ctx.needs_input_grad[2] else None
         d_u = torch.empty((R, Cc), dtype=torch.float32, device=f.device)
+        amax = torch.zeros((1,), dtype=torch.int32, device=f.device)
         L.check(lib.evd_awp_feature_integration_bwd(L.ptr(f), L.ptr(zz), L.ptr(dd), L.ptr(g_h.contiguous().float()), N, S, Cc, L.ptr(d_f), L.ptr(d_z),
                                                     L.ptr(d_d), L.stream_ptr()), "evd_awp_feature_integration_bwd")
         L.check(lib.evd_mam_local_backward(L.ptr(f), L.ptr(uu), L.ptr(alpha), L.ptr(beta), L.ptr(h_inter), L.ptr(h_intra),
                                            L.ptr(g_inter.contiguous().float()), L.ptr(g_intra.contiguous().float()), R, P, S, Cc, L.ptr(d_f), L.ptr(d_u),
-                                           1, L.stream_ptr()), "evd_mam_local_backward")
+                                           1, L.ptr(amax), L.stream_ptr()), "evd_mam_local_backward")
+        _DH_ABSMAX[d_f.data_ptr()] = amax
         sh = ctx.shapes
         return (d_f.reshape(sh[0]), None if d_z is None else d_z.reshape(sh[1]), None if d_d is None else d_d.reshape(sh[2]), d_u.sum(0),
                 None, None, None)

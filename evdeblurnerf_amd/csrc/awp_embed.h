@@ -47,6 +47,7 @@ struct AwpBwdGrads { float *w[AWP_D], *b[AWP_D]; };     // device float32, nn.Li
 
 struct AwpBwdPlan {
     const float* d_h_local;     // [n, 64]
+    const unsigned* d_h_absmax; // float bits of max |d_h_local| when the producer took it, or null
     long nsamp, tiles;
     char* store;
     const char* wt[AWP_D];      // W_l^T fragment streams

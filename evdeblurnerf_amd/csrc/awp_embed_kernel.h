@@ -180,8 +180,12 @@ template <int PREC> static int run_awp_backward(const AwpBwdPlan& b, hipStream_t
     int rc;
     unsigned* words = reinterpret_cast<unsigned*>(b.store + b.tiles * TILE_BYTES);       // trailer: loss-scale word, max |d geo|
     EVD_HIP(hipMemsetAsync(words, 0, 2 * sizeof(unsigned), st));
-    hipLaunchKernelGGL(k_absmax, dim3(512), dim3(256), 0, st, b.d_h_local, b.nsamp * AWP_W, words);
-    EVD_LAUNCH_CHECK();
+    if (b.d_h_absmax) {
+        EVD_HIP(hipMemcpyAsync(words, b.d_h_absmax, sizeof(unsigned), hipMemcpyDeviceToDevice, st));
+    } else {
+        hipLaunchKernelGGL(k_absmax, dim3(512), dim3(256), 0, st, b.d_h_local, b.nsamp * AWP_W, words);
+        EVD_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL((k_awp_rows_to_frags<PREC>), dim3((unsigned)cdiv(b.tiles * 64 * KW, 256L)), dim3(256), 0, st, b.d_h_local, b.nsamp, b.tiles, words, b.store);
     EVD_LAUNCH_CHECK();
     auto dgrad = [&](int l, int in_slot, int mask_slot, int out_slot) {

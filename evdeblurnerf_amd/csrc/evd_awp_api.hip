@@ -147,7 +147,8 @@ int evd_awp_embed_forward(const evd_awp_embed* a, int precision, const float* ge
 }
 
 int evd_awp_embed_backward(const evd_awp_embed* a, int precision, const float* d_h_local, long nsamp, void* store, size_t store_bytes,
-                           const evd_awp_embed_grads* grads, float* d_geo_rows, void* workspace, size_t workspace_bytes, void* stream) {
+                           const evd_awp_embed_grads* grads, float* d_geo_rows, const unsigned* d_h_absmax, void* workspace,
+                           size_t workspace_bytes, void* stream) {
     EVD_REQUIRE(a && d_h_local && store && grads && workspace && nsamp >= 0, "evd_awp_embed_backward: null argument");
     const int pi = prec_index(precision);
     EVD_REQUIRE(pi >= 0, "evd_awp_embed_backward: built for precision f16 / bf16");
@@ -156,7 +157,7 @@ int evd_awp_embed_backward(const evd_awp_embed* a, int precision, const float* d
     if (workspace_bytes < evd_awp_embed_backward_workspace_bytes())
         return fail(EVD_E_WORKSPACE, "evd_awp_embed_backward: workspace %zu < %zu bytes", workspace_bytes, evd_awp_embed_backward_workspace_bytes());
     AwpBwdPlan b;
-    b.d_h_local = d_h_local; b.nsamp = nsamp; b.tiles = awp_tiles(nsamp); b.store = (char*)store;
+    b.d_h_local = d_h_local; b.d_h_absmax = d_h_absmax; b.nsamp = nsamp; b.tiles = awp_tiles(nsamp); b.store = (char*)store;
     for (int l = 0; l < AWP_D; ++l) {
         b.wt[l] = (const char*)a->bwd[pi][l].data.p;
         b.grads.w[l] = grads->w[l]; b.grads.b[l] = grads->b[l];

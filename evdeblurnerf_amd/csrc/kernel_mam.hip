@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void k_mam_local_bwd(const float* __restrict__
                                                        const float* __restrict__ alpha, const float* __restrict__ beta,
                                                        const float* __restrict__ h_inter, const float* __restrict__ h_intra,
                                                        const float* __restrict__ d_inter, const float* __restrict__ d_intra, int P, int S,
-                                                       float* __restrict__ d_h, float* __restrict__ d_u_partial) {
+                                                       float* __restrict__ d_h, float* __restrict__ d_u_partial, unsigned* __restrict__ absmax) {
     extern __shared__ float lds[];
     float* dP = lds;                        // [P][64]
     float* cP = dP + MAM_MAXP * MAM_C;      // [P]
@@ -230,6 +230,7 @@ __global__ __launch_bounds__(256) void k_mam_local_bwd(const float* __restrict__
     }
     __syncthreads();
     float4 du = make_float4(0.f, 0.f, 0.f, 0.f);
+    float amax = 0.f;
     for (int s = g; s < S; s += 16) {
         const float4 dI = reinterpret_cast<const float4*>(d_intra)[(b * S + s) * 16 + l];
         const float cI = row_sum16(dot4(dI, reinterpret_cast<const float4*>(h_intra)[(b * S + s) * 16 + l]));
@@ -252,6 +253,7 @@ __global__ __launch_bounds__(256) void k_mam_local_bwd(const float* __restrict__
                     o.x += prev.x; o.y += prev.y; o.z += prev.z; o.w += prev.w;
                 }
                 dh4[at] = o;
+                amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
                 fma4(du, da, v);
             }
     }
@@ -260,6 +262,16 @@ __global__ __launch_bounds__(256) void k_mam_local_bwd(const float* __restrict__
     if (lane < 16) reinterpret_cast<float4*>(red)[wave * 16 + l] = du;
     __syncthreads();
     if (tid < MAM_C) d_u_partial[b * MAM_C + tid] = red[tid] + red[MAM_C + tid] + red[2 * MAM_C + tid] + red[3 * MAM_C + tid];
+    if (absmax) {                        // max |d h_local| of this ray -> the caller's word (guarded: one atomic per raising workgroup, not per ray)
+        for (int o = 32; o; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+        __syncthreads();
+        if (lane == 0) red[wave] = amax;
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned mb = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+            if (mb > *reinterpret_cast<volatile unsigned*>(absmax)) atomicMax(absmax, mb);
+        }
+    }
 }
 
 }  // namespace evd
@@ -293,7 +305,7 @@ int evd_mam_local_forward(const float* h_local, const float* u, long R, int P, i
 
 int evd_mam_local_backward(const float* h_local, const float* u, const float* alpha, const float* beta, const float* h_inter,
                            const float* h_intra, const float* d_inter, const float* d_intra, long R, int P, int S, int C, float* d_h_local,
-                           float* d_u_partial, int accumulate, void* stream) {
+                           float* d_u_partial, int accumulate, unsigned* d_h_absmax, void* stream) {
     EVD_REQUIRE(h_local && u && alpha && beta && h_inter && h_intra && d_inter && d_intra && d_h_local && d_u_partial,
                 "evd_mam_local_backward: null argument");
     if (int e = mam_check("evd_mam_local_backward", R, P, S, C)) return e;
@@ -301,10 +313,10 @@ int evd_mam_local_backward(const float* h_local, const float* u, const float* al
     const size_t lds = sizeof(float) * (MAM_MAXP * MAM_C + MAM_MAXP + 4 * MAM_C);
     if (accumulate)
         k_mam_local_bwd<true><<<(unsigned)R, 256, lds, as_stream(stream)>>>(h_local, u, alpha, beta, h_inter, h_intra, d_inter, d_intra, P, S,
-                                                                            d_h_local, d_u_partial);
+                                                                            d_h_local, d_u_partial, d_h_absmax);
     else
         k_mam_local_bwd<false><<<(unsigned)R, 256, lds, as_stream(stream)>>>(h_local, u, alpha, beta, h_inter, h_intra, d_inter, d_intra, P, S,
-                                                                             d_h_local, d_u_partial);
+                                                                             d_h_local, d_u_partial, d_h_absmax);
     EVD_HIP(hipGetLastError());
     return EVD_OK;
 }

@@ -457,10 +457,12 @@ int evd_mam_local_forward(const float* h_local, const float* u, long R, int P, i
                           float* beta, void* stream);
 /* Its backward (torch.autograd behind mam.py:29-33,72-74 in training, run_nerf.py:593-601): d h_inter dev [R,P,64], d h_intra dev
  * [R,S,64] -> d h_local dev [R P, S, 64] (accumulate = 0: written; != 0: ADDED to what is there -- h_local has a second consumer, the
- * feature integration, whose backward writes the buffer first) and d u as per-ray partials dev [R,64] (the caller sums them). */
+ * feature integration, whose backward writes the buffer first) and d u as per-ray partials dev [R,64] (the caller sums them).
+ * d_h_absmax (optional): dev word, zeroed by the caller, raised to the float bits of max |d h_local| as written here (the loss scale the
+ * embedding's backward needs: saves it a pass over the tensor). */
 int evd_mam_local_backward(const float* h_local, const float* u, const float* alpha, const float* beta, const float* h_inter,
                            const float* h_intra, const float* d_inter, const float* d_intra, long R, int P, int S, int C, float* d_h_local,
-                           float* d_u_partial, int accumulate, void* stream);
+                           float* d_u_partial, int accumulate, unsigned* d_h_absmax, void* stream);
 
 /* The PER-RAY remainder of the adaptive weight proposal as kernels: networks/dpnerf/awp.py:89-95 (direction encoding of the first
  * sub-exposure's normalised ray direction, concatenated behind view_feature), :104-109 (motion_feature_embed_layer: n_mot x Linear + ReLU on
@@ -517,7 +519,8 @@ int evd_awp_tail_backward(const evd_awp_tail_desc* d, const float* const* params
  *   evd_awp_embed_forward: geo features EITHER as geo_rows dev [n,128] float32 OR as (fine, fine_store) = the fine level and the
  *     store its evd_voxel_mlp_train filled for the same n = R*S samples.  store (NULL: inference) keeps the activations for
  *     evd_awp_embed_backward (evd_awp_embed_store_bytes).
- *   evd_awp_embed_backward: d_h_local dev [n, W_sam] -> parameter gradients (overwritten; NULL = not wanted) and the geo features'
+ *   evd_awp_embed_backward: d_h_local dev [n, W_sam] (d_h_absmax: dev word holding the float bits of max |d_h_local| when the producer
+ *     took it -- evd_mam_local_backward does --, NULL = a pass over d_h_local finds it) -> parameter gradients (overwritten; NULL = not wanted) and the geo features'
  *     gradient, left as fragments in `store` for evd_voxel_mlp_backward(awp_store = store) and, where wanted, written as
  *     d_geo_rows dev [n,128] float32 (NULL = not wanted). */
 typedef struct evd_awp_embed evd_awp_embed;
@@ -531,7 +534,8 @@ size_t evd_awp_embed_backward_workspace_bytes(void);
 int evd_awp_embed_forward(const evd_awp_embed* a, int precision, const float* geo_rows, const evd_voxel* fine, const void* fine_store,
                           size_t fine_store_bytes, long nsamp, float* h_local, void* store, size_t store_bytes, void* stream);
 int evd_awp_embed_backward(const evd_awp_embed* a, int precision, const float* d_h_local, long nsamp, void* store, size_t store_bytes,
-                           const evd_awp_embed_grads* grads, float* d_geo_rows, void* workspace, size_t workspace_bytes, void* stream);
+                           const evd_awp_embed_grads* grads, float* d_geo_rows, const unsigned* d_h_absmax, void* workspace,
+                           size_t workspace_bytes, void* stream);
 
 /* EDI prior (utils/edi.py:73-95): bii dev [steps-1, npix], blurry dev [npix] -> sharp dev [npix] */
 int evd_edi_deblur(const float* blurry, const float* bii, int steps, long npix, float* sharp, void* stream);
