@@ -103,6 +103,7 @@ SIGNATURES = {
     "evd_awp_tail_forward": (_I, [C.POINTER(AwpTailDesc), C.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _L, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _S, _vp]),
     "evd_awp_tail_backward": (_I, [C.POINTER(AwpTailDesc), C.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _L, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                    _vp, _vp, _vp, _S, _vp]),
+    "evd_awp_local_consumers_backward": (_I, [_vp] * 11 + [_L, _I, _I, _I, _vp, _vp, _vp, _vp, _vp, _vp]),
     "evd_awp_embed_create": (_I, [C.POINTER(_fp), C.POINTER(_fp), _I, _I, _I, C.POINTER(_vp)]),
     "evd_awp_embed_destroy": (None, [_vp]),
     "evd_awp_embed_param_count": (_L, [_vp]),

@@ -171,11 +171,17 @@ class _LocalConsumers(torch.autograd.Function):
         d_d = torch.empty_like(dd) if ctx.needs_input_grad[2] else None
         d_u = torch.empty((R, Cc), dtype=torch.float32, device=f.device)
         amax = torch.zeros((1,), dtype=torch.int32, device=f.device)
-        L.check(lib.evd_awp_feature_integration_bwd(L.ptr(f), L.ptr(zz), L.ptr(dd), L.ptr(g_h.contiguous().float()), N, S, Cc, L.ptr(d_f), L.ptr(d_z),
-                                                    L.ptr(d_d), L.stream_ptr()), "evd_awp_feature_integration_bwd")
-        L.check(lib.evd_mam_local_backward(L.ptr(f), L.ptr(uu), L.ptr(alpha), L.ptr(beta), L.ptr(h_inter), L.ptr(h_intra),
-                                           L.ptr(g_inter.contiguous().float()), L.ptr(g_intra.contiguous().float()), R, P, S, Cc, L.ptr(d_f), L.ptr(d_u),
-                                           1, L.ptr(amax), L.stream_ptr()), "evd_mam_local_backward")
+        if os.environ.get("EVD_AWP_LOCAL_BWD") == "separate":      # developer switch: the two kernels, the second adding into the first one's result
+            L.check(lib.evd_awp_feature_integration_bwd(L.ptr(f), L.ptr(zz), L.ptr(dd), L.ptr(g_h.contiguous().float()), N, S, Cc, L.ptr(d_f), L.ptr(d_z),
+                                                        L.ptr(d_d), L.stream_ptr()), "evd_awp_feature_integration_bwd")
+            L.check(lib.evd_mam_local_backward(L.ptr(f), L.ptr(uu), L.ptr(alpha), L.ptr(beta), L.ptr(h_inter), L.ptr(h_intra),
+                                               L.ptr(g_inter.contiguous().float()), L.ptr(g_intra.contiguous().float()), R, P, S, Cc, L.ptr(d_f), L.ptr(d_u),
+                                               1, L.ptr(amax), L.stream_ptr()), "evd_mam_local_backward")
+        else:                                                       # one launch: h_local read once, d h_local written once
+            L.check(lib.evd_awp_local_consumers_backward(L.ptr(f), L.ptr(uu), L.ptr(alpha), L.ptr(beta), L.ptr(h_inter), L.ptr(h_intra),
+                                                         L.ptr(g_inter.contiguous().float()), L.ptr(g_intra.contiguous().float()), L.ptr(zz), L.ptr(dd),
+                                                         L.ptr(g_h.contiguous().float()), R, P, S, Cc, L.ptr(d_f), L.ptr(d_u), L.ptr(d_z), L.ptr(d_d),
+                                                         L.ptr(amax), L.stream_ptr()), "evd_awp_local_consumers_backward")
         _DH_ABSMAX[d_f.data_ptr()] = amax
         sh = ctx.shapes
         return (d_f.reshape(sh[0]), None if d_z is None else d_z.reshape(sh[1]), None if d_d is None else d_d.reshape(sh[2]), d_u.sum(0),

@@ -507,6 +507,15 @@ int evd_awp_tail_backward(const evd_awp_tail_desc* d, const float* const* params
                           float* d_rays_d, float* d_h_inter, float* d_h_intra, float* d_params, void* workspace, size_t workspace_bytes,
                           void* stream);
 
+/* The backward of h_local's two consumers in one launch -- evd_awp_feature_integration_bwd (awp.py:49-77; feat = h_local, N = R P rows,
+ * d_integrated dev [R P, 64] = d out) and evd_mam_local_backward (above) --: h_local is read once and d h_local dev [R P, S, 64] written
+ * once with the SUM of both shares; d_z dev [R P, S] and d_rays_d dev [R P, 3] (the integration's; null = not wanted), d_u_partial dev
+ * [R, 64], d_h_absmax as in evd_mam_local_backward.  C must be 64, P <= 16, S <= 512. */
+int evd_awp_local_consumers_backward(const float* h_local, const float* u, const float* alpha, const float* beta, const float* h_inter,
+                                     const float* h_intra, const float* d_inter, const float* d_intra, const float* z, const float* rays_d,
+                                     const float* d_integrated, long R, int P, int S, int C, float* d_h_local, float* d_u_partial, float* d_z,
+                                     float* d_rays_d, unsigned* d_h_absmax, void* stream);
+
 /* AdaptiveWeightProposal.sample_feature_embed_layer (networks/dpnerf/awp.py:36-37: D_sam x nn.Linear; :98-100: each followed by ReLU)
  * fused into one MFMA kernel that reads the fine level's geo features WHERE THEY ALREADY ARE: the reference writes them as
  * depth_feature [R P, S, 128] float32 (renderer.py:253-256) and runs four torch Linear + ReLU passes over it (:314); here the

@@ -245,3 +245,31 @@ def test_tail_variants_vs_float64_autograd(variant):
         assert rel(a, b) < 1e-4, (variant, key, rel(a, b))
     if variant == "eval_mode":                        # the estimates are read, not written
         assert torch.equal(awp.MAM.Corr.convd[1].running_mean.cpu().double(), ref.MAM.Corr.convd[1].running_mean)
+
+
+@pytest.mark.parametrize("R,P,S", [(40, 10, 128), (7, 5, 33), (3, 16, 17)])
+def test_local_consumers_one_launch_backward_equals_the_two_kernels(R, P, S):
+    """evd_awp_local_consumers_backward (the integration's and the MAM per-sample part's backwards in one pass over h_local) against
+    evd_awp_feature_integration_bwd + evd_mam_local_backward: d h_local, d z_vals, d rays_d, d u within float32 rounding of the sums"""
+    from evdeblurnerf_amd.awp import _LocalConsumers
+    rs = np.random.RandomState(R + S)
+    res = {}
+    for mode in ("separate", "fused"):
+        os.environ["EVD_AWP_LOCAL_BWD"] = mode
+        try:
+            hl = torch.tensor(np.abs(rs.standard_normal((R * P, S, 64))).astype(np.float32) * (0.6 if mode else 1)).cuda().requires_grad_(True) if mode == "separate" else res["in"][0].detach().clone().requires_grad_(True)
+            if mode == "separate":
+                z = torch.tensor(np.sort(rs.uniform(0, 1, (R * P, S)).astype(np.float32), -1)).cuda().requires_grad_(True)
+                d = torch.tensor(rs.standard_normal((R * P, 3)).astype(np.float32)).cuda().requires_grad_(True)
+                u = torch.tensor(rs.standard_normal(64).astype(np.float32)).cuda().requires_grad_(True)
+                pr = [torch.tensor(rs.standard_normal(sh).astype(np.float32)).cuda() for sh in ((R * P, 64), (R, P, 64), (R, S, 64))]
+                res["in"] = (hl, z, d, u, pr)
+            else:
+                _, z, d, u, pr = res["in"]
+                z, d, u = (t.detach().clone().requires_grad_(True) for t in (z, d, u))
+            h, hi, hs = _LocalConsumers.apply(hl, z, d, u, R, P, S)
+            res[mode] = torch.autograd.grad((h * pr[0]).sum() + (hi * pr[1]).sum() + (hs * pr[2]).sum(), [hl, z, d, u])
+        finally:
+            os.environ.pop("EVD_AWP_LOCAL_BWD", None)
+    for name, a, b in zip(("d h_local", "d z_vals", "d rays_d", "d u"), res["fused"], res["separate"]):
+        assert rel(a, b) < 5e-6, (name, rel(a, b))
