@@ -646,9 +646,13 @@ __global__ __launch_bounds__(AT_FT) void k_awp_tail_finish(TailFinishParams p) {
     __shared__ float stat[2 * AT_CM], hm[AT_FR][AT_CM], sw[AT_FR][AT_MAXP];
     const int tid = threadIdx.x, col = tid & 63, grp = tid >> 6;
     if (p.training) {
-        double a = 0.0;
-        for (int i = grp; i < p.nparts; i += 4) a += p.bn_part[(long)i * 2 * AT_CM + col];
-        red[grp][col] = a;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};                   // four rows in flight per thread (every workgroup folds all the partial rows)
+        int i = grp;
+        for (; i + 12 < p.nparts; i += 16)
+#pragma unroll
+            for (int u2 = 0; u2 < 4; ++u2) acc[u2] += p.bn_part[(long)(i + 4 * u2) * 2 * AT_CM + col];
+        for (; i < p.nparts; i += 4) acc[0] += p.bn_part[(long)i * 2 * AT_CM + col];
+        red[grp][col] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
         __syncthreads();
         if (tid < AT_CM) {
             const double n = (double)p.R * p.P;
@@ -1007,25 +1011,31 @@ struct TailReduceParams {
     long total, partA_stride;
     float* d_params;
 };
-// d_params[i] = sum over the partial rows; the BatchNorm and w_linear gradients come from k_awp_tail_bwd0's rows (d beta, d gamma, d W, d b)
-__global__ __launch_bounds__(64) void k_awp_tail_reduce(TailReduceParams p) {
-    const long i = (long)blockIdx.x * 64 + threadIdx.x;
-    if (i >= p.total) return;
+// d_params[i] = sum over the partial rows; the BatchNorm and w_linear gradients come from k_awp_tail_bwd0's rows (d beta, d gamma, d W, d b).
+// 64 parameters per workgroup, its four wavefronts each a quarter of the rows (four rows in flight per thread), folded through LDS.
+__global__ __launch_bounds__(256) void k_awp_tail_reduce(TailReduceParams p) {
+    __shared__ float fold[4][64];
+    const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + col;
     float a = 0.f;
-    if (i < p.n_tail) {
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // eight rows in flight: a thread walks up to 256 rows, 42 workgroups in all
-        int b = 0;
-        for (; b + 8 <= p.nA; b += 8)
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc[u] += p.partA[(long)(b + u) * p.partA_stride + i];
-        for (; b < p.nA; ++b) acc[0] += p.partA[(long)b * p.partA_stride + i];
-        a = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
-    } else {
+    if (i < p.total) {
+        const bool tail = i < p.n_tail;
         const long j = i - p.n_tail;                                   // 0..31 d gamma, 32..63 d beta, then w_linear
-        const long col = j < AT_CM ? AT_CM + j : (j < 2 * AT_CM ? j - AT_CM : j);
-        for (int b = 0; b < p.nB; ++b) a += p.partB[(long)b * p.partB_stride + col];
+        const long c = tail ? i : (j < AT_CM ? AT_CM + j : (j < 2 * AT_CM ? j - AT_CM : j));
+        const float* src = tail ? p.partA : p.partB;
+        const long stride = tail ? p.partA_stride : p.partB_stride;
+        const int n = tail ? p.nA : p.nB;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        int b = grp;
+        for (; b + 12 < n; b += 16)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] += src[(long)(b + 4 * u) * stride + c];
+        for (; b < n; b += 4) acc[0] += src[(long)b * stride + c];
+        a = (acc[0] + acc[1]) + (acc[2] + acc[3]);
     }
-    p.d_params[i] = a;
+    fold[grp][col] = a;
+    __syncthreads();
+    if (grp == 0 && i < p.total) p.d_params[i] = (fold[0][col] + fold[1][col]) + (fold[2][col] + fold[3][col]);
 }
 
 }  // namespace evd
@@ -1186,7 +1196,7 @@ int evd_awp_tail_backward(const evd_awp_tail_desc* d, const float* const* params
     rp.partA_stride = k.partA_stride;
     rp.n_tail = (int)k.off[2 * dims.n_mot + TW_BN_W];
     rp.d_params = d_params;
-    k_awp_tail_reduce<<<(unsigned)((total + 63) / 64), 64, 0, as_stream(stream)>>>(rp);
+    k_awp_tail_reduce<<<(unsigned)((total + 63) / 64), 256, 0, as_stream(stream)>>>(rp);
     EVD_HIP(hipGetLastError());
     return EVD_OK;
 }
