@@ -1045,7 +1045,7 @@ template <bool DPTS, bool LINES12, bool BAS>
 __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const GridParams g, const float* __restrict__ pts, long n,
                                                                           const float* __restrict__ d_out, int d_stride, int d_col, GridGrads gg,
                                                                           float* __restrict__ d_pts, float* __restrict__ rows_l, LTap* __restrict__ ltap,
-                                                                          float* __restrict__ coef_out) {
+                                                                          float* __restrict__ coef_out, unsigned* __restrict__ lmax) {
     extern __shared__ __attribute__((aligned(16))) char vbw_smem[];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c0n = g.n_comp[0], c1n = g.n_comp[1], c2n = g.n_comp[2], ctot = c0n + c1n + c2n, F = g.app_dim;
@@ -1081,6 +1081,7 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
 #define EVD_VBW_T0()
 #define EVD_VBW_T(i)
 #endif
+    float rmaxv = 0.f;                            // max |line row value| this lane wrote (k_scatter_lines' fixed-point scale: saves it a pass over the rows)
     const long wtiles = (n + VBW_SAMPLES - 1) / VBW_SAMPLES;
     for (long wt = (long)blockIdx.x * VBW_WAVES + wv; wt < wtiles; wt += (long)gridDim.x * VBW_WAVES) {
     const long s0 = wt * VBW_SAMPLES;
@@ -1190,6 +1191,13 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
                     }
                 } else if (live && rows_l) {
                     *reinterpret_cast<f32x4*>(rows_l + (s0 + sl[q]) * ctot + cb + 4 * v) = rl;
+                    if (lmax) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float a = fabsf(rl[k]);
+                            rmaxv = a != a ? __builtin_huge_valf() : fmaxf(rmaxv, a);       // (a NaN is recorded as +inf)
+                        }
+                    }
                 }
                 if (CF_LDS) {
                     if (on[q]) {
@@ -1358,6 +1366,12 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
         o[6] = -7.f; o[7] = (float)((wtiles - ((long)blockIdx.x * VBW_WAVES + wv) + (long)gridDim.x * VBW_WAVES - 1) / ((long)gridDim.x * VBW_WAVES));
     }
 #endif
+    if (lmax) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) rmaxv = fmaxf(rmaxv, __shfl_xor(rmaxv, o));
+        const unsigned mb = __float_as_uint(rmaxv);                    // (non-negative floats order like their bit patterns; +inf above all)
+        if (lane == 0 && mb > *reinterpret_cast<volatile unsigned*>(lmax)) atomicMax(lmax, mb);
+    }
     if (BAS && gg.basis) {
         // the block's four wavefronts fold their sums through LDS (the basis_mat image is no longer needed), then ONE atomic flush per block
         const int mn = lane & 31, kb = lane >> 5;
@@ -1763,7 +1777,7 @@ bool voxel_sample_bwd_w_lines12(const GridParams& g) {
     return on && 2 * (g.n_comp[1] + g.n_comp[2]) <= 64 && g.n_comp[1] + g.n_comp[2] <= 32;
 }
 int launch_voxel_sample_bwd_w(const GridParams& g, const float* pts, long n, const float* d_out, int d_stride, int d_col, const GridGrads& gg,
-                              float* d_pts, float* rows_l, LTap* ltap, float* coef, hipStream_t st) {
+                              float* d_pts, float* rows_l, LTap* ltap, float* coef, hipStream_t st, unsigned* lmax) {
     // EVD_SCATTER_BASIS=separate (developer switch): round 3's form -- coefficient rows to HBM + the k_basis_grad launch
     static const bool bas_sep = [] { const char* e = getenv("EVD_SCATTER_BASIS"); return e && !strcmp(e, "separate"); }();
     const bool bas = gg.basis && !bas_sep;
@@ -1775,7 +1789,7 @@ int launch_voxel_sample_bwd_w(const GridParams& g, const float* pts, long n, con
     float* coef_w = (gg.basis && !bas) ? coef : nullptr;
     const bool l12 = voxel_sample_bwd_w_lines12(g);
 #define EVD_VBW(DP, L12, BAS) { EVD_SET_MAX_LDS((&k_voxel_sample_bwd_w<DP, L12, BAS>), VBW_LDS); \
-        k_voxel_sample_bwd_w<DP, L12, BAS><<<blocks, 64 * VBW_WAVES, VBW_LDS, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, rows_l, ltap, coef_w); }
+        k_voxel_sample_bwd_w<DP, L12, BAS><<<blocks, 64 * VBW_WAVES, VBW_LDS, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, rows_l, ltap, coef_w, lmax); }
     if (bas) {
         if (d_pts && l12) EVD_VBW(true, true, true)
         else if (d_pts) EVD_VBW(true, false, true)

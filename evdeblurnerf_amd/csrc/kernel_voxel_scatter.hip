@@ -123,7 +123,10 @@ struct LineJobs { LineJob j[12]; };
 // LDS atomics run 6 x faster.  The scale is a power of two chosen per workgroup from the largest contribution of its chunk
 // (max |row| 2^k < 2^49, at most 2^13 terms per accumulator: no overflow), so a float32 contribution converts EXACTLY unless it is
 // below 2^-49 of the chunk's maximum: the sums are more accurate than float32 atomics, and deterministic inside the workgroup.
-__global__ __launch_bounds__(SC_NT) void k_scatter_lines(const LineJobs jobs, const float* __restrict__ rows_l, const LTap* __restrict__ ltap, long n, int ctot) {
+// gmax (optional): the float bits of max |rows_l| over ALL samples, taken by the kernel that wrote the rows: the fixed-point scale is then that
+// one instead of this chunk's own maximum, and the chunk's rows are read once (123 -> 89 us per 2^19 samples)
+__global__ __launch_bounds__(SC_NT) void k_scatter_lines(const LineJobs jobs, const float* __restrict__ rows_l, const LTap* __restrict__ ltap, long n, int ctot,
+                                                       const unsigned* __restrict__ gmax) {
     const LineJob jb = jobs.j[blockIdx.y];
     if (!jb.grad) return;
     extern __shared__ __attribute__((aligned(16))) unsigned long long lacc[];       // [Lp][cg]
@@ -134,8 +137,8 @@ __global__ __launch_bounds__(SC_NT) void k_scatter_lines(const LineJobs jobs, co
     // a lane owns 4 consecutive channels of a sample (one 16-byte load): cg / 4 lanes per sample
     const int lps = cg >> 2, spw = 64 / lps, c4 = (lane % lps) * 4, sub = lane / lps, step = (SC_NT / 64) * spw;
     const float* col = rows_l + jb.coff + jb.c_lo + c4;
-    float m = 0.f;
-    for (long s = base + wave * spw + sub; s < end; s += step) {
+    float m = gmax ? __uint_as_float(*gmax) : 0.f;
+    for (long s = base + wave * spw + sub; s < (gmax ? base : end); s += step) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(col + s * ctot);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(SC_NT) void k_scatter_lines(const LineJobs jobs, co
 static const int kM0[3] = {0, 0, 1}, kM1[3] = {1, 2, 2}, kV[3] = {2, 1, 0};
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-static int launch_lines(const GridParams& g, const GridGrads& gg, const float* rows_l, const LTap* ltap, long n, hipStream_t st) {
+static int launch_lines(const GridParams& g, const GridGrads& gg, const float* rows_l, const LTap* ltap, long n, hipStream_t st, const unsigned* gmax = nullptr) {
     const int ctot = g.n_comp[0] + g.n_comp[1] + g.n_comp[2];
     LineJobs lj;
     int nj = 0, coff = 0;
@@ -226,7 +229,7 @@ static int launch_lines(const GridParams& g, const GridGrads& gg, const float* r
     for (int k = nj; k < 12; ++k) lj.j[k].grad = nullptr;
     if (nj) {
         EVD_SET_MAX_LDS(k_scatter_lines, (size_t)SC_LDS_MAX);
-        hipLaunchKernelGGL(k_scatter_lines, dim3((unsigned)cdiv(n, (long)SC_LCH), nj), dim3(SC_NT), llds, st, lj, rows_l, ltap, n, ctot);
+        hipLaunchKernelGGL(k_scatter_lines, dim3((unsigned)cdiv(n, (long)SC_LCH), nj), dim3(SC_NT), llds, st, lj, rows_l, ltap, n, ctot, gmax);
         EVD_LAUNCH_CHECK();
     }
     return EVD_OK;
@@ -459,11 +462,15 @@ int launch_voxel_sample_bwd_hybrid(const GridParams& g, const float* pts, long n
     if (voxel_sample_bwd_w_ok(g) && !scatter_form_block() && !xy_deferred(g, gg)) {
         // round 3: wavefront-autonomous pass (plane taps incl. the run-length x-y walk, rows for the lines, coefficient rows for the basis GEMM)
         float* coef = (float*)(w + al256((size_t)n * ctot * 4) + al256((size_t)n * 3 * sizeof(LTap)));
-        int rc = launch_voxel_sample_bwd_w(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo.rows_l, bo.ltap, coef, st);
+        // the last 256 bytes of the workspace: max |line row| of the whole batch, taken by the main kernel (k_scatter_lines' scale)
+        static const bool own_max = getenv("EVD_SCATTER_LINES_OWN_MAX") != nullptr;     // developer switch: every chunk finds its own maximum (round 3)
+        unsigned* lmax = own_max ? nullptr : (unsigned*)(w + voxel_scatter_hybrid_workspace_bytes(g, n) - 512);
+        if (lmax) EVD_HIP(hipMemsetAsync(lmax, 0, sizeof(unsigned), st));
+        int rc = launch_voxel_sample_bwd_w(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo.rows_l, bo.ltap, coef, st, lmax);
         if (rc) return rc;
         GridGrads gl = gg;
         if (voxel_sample_bwd_w_lines12(g)) gl.line[1] = gl.line[2] = nullptr;      // added inside the kernel: only the z line is left for the LDS slices
-        return launch_lines(g, gl, (const float*)bo.rows_l, (const LTap*)bo.ltap, n, st);
+        return launch_lines(g, gl, (const float*)bo.rows_l, (const LTap*)bo.ltap, n, st, lmax);
     }
     const bool xy = xy_deferred(g, gg);
     if (xy) {
