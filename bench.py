@@ -143,6 +143,23 @@ def init_ranks():
     return rank, world, local, dist, backend, ("cuda" if have_gpu else "cpu")
 
 
+def rank_devices(dist, world):
+    """one entry per rank: the device it computes on (index, name, UUID, PCI bus) -- a scaling record shows N distinct GPUs by N distinct
+    UUIDs (two ranks sharing a device under EVD_BENCH_SHARE_GPU=1 show the same one twice)"""
+    import torch
+    if not torch.cuda.is_available():
+        return []
+    i = torch.cuda.current_device()
+    pr = torch.cuda.get_device_properties(i)
+    me = {"rank": int(os.environ.get("RANK", "0")), "device": i, "name": pr.name, "uuid": str(getattr(pr, "uuid", "")),
+          "pci_bus_id": getattr(pr, "pci_bus_id", None)}
+    if dist is None or world == 1:
+        return [me]
+    out = [None] * world
+    dist.all_gather_object(out, me)
+    return out
+
+
 def time_steps(fn, steps, warmup, dist=None, drain=None, device="cuda", settle_steps=0):
     """W untimed warm-up steps, then EXACTLY `steps` steps bracketed by barrier + device synchronize on both sides;
     returns the MAX over ranks of the elapsed seconds."""
@@ -567,7 +584,8 @@ def main(argv=None):
     result["ms_per_step_median"] = med[len(med) // 2]
     result["ranks"] = {"world_size": world, "backend": backend,
                        "launcher": ("bench.py self-launch" if os.environ.get("EVD_BENCH_SELF_LAUNCH") else
-                                    "external torchrun" if world > 1 else "none")}
+                                    "external torchrun" if world > 1 else "none"),
+                       "devices": rank_devices(dist, world)}
     lean = world > 1          # N > 1 runs: headline kernel + the strong-scaling leg (the other legs are N = 1 measurements)
 
     if rank == 0:
@@ -592,10 +610,10 @@ def main(argv=None):
                 modes[prec]["mfma_issue_frac"] = 1.5 * tf / PEAK_TFLOPS[prec]    # + two fp6 32x32x64 products per four f16 32x32x16 ones: 1.5x the MFMA cycles
         m = modes[a.precision]
         # HBM traffic and the hardware's own MFMA-busy fraction come from the committed PMC passes of this kernel
-        # (rocprofv3 cannot run inside the timed process): profiles/r03_pmc_mlp.json, made by tools/pmc_mlp.sh + tools/pmc_mlp_json.py
+        # (rocprofv3 cannot run inside the timed process): profiles/r05_pmc_mlp.json, made by tools/pmc_mlp.sh + tools/pmc_mlp_json.py (newest round first)
         traffic, busy = None, None
         try:
-            pmc_file = next(f for f in ("r03_pmc_mlp.json", "r02_pmc_mlp.json", "r01_v3_pmc_mlp.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            pmc_file = next(f for f in ("r05_pmc_mlp.json", "r03_pmc_mlp.json", "r02_pmc_mlp.json", "r01_v3_pmc_mlp.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))["derived"].get(a.precision)
             if pmc and R == 4096 and S == 128:
                 traffic, busy = pmc["traffic_bytes"], pmc["mfma_busy_frac"]
@@ -627,7 +645,7 @@ def main(argv=None):
                                       "dense peak; traffic (bytes per launch: 2.8x the algorithmic bytes -- 30 MB against 10.7 MB: the 2.1 MB weight stream "
                                       "is fetched by every workgroup and served once per XCD L2) and mfma_busy_frac_pmc (SQ_VALU_MFMA_BUSY_CYCLES over "
                                       "GRBM_GUI_ACTIVE x SIMDs: the kernel keeps the pipe busier than frac says because the chip clocks "
-                                      "below 2.4 GHz under this load) are from the PMC passes in profiles/r03_pmc_mlp.json; "
+                                      "below 2.4 GHz under this load) are from the PMC passes in profiles/r05_pmc_mlp.json (re-collected on the round-5 build); "
                                       "sustained_mfma_tflops = a bare back-to-back MFMA loop on every SIMD, measured in this run "
                                       "(evd_probe_mfma_rate): the random-operand figure is the practical ceiling for real data; "
                                       "kernel_ms_on_all_zero_data = the same launch on all-zero weights and rays (same instruction stream, no "

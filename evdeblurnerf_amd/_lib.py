@@ -78,6 +78,11 @@ class CrfDesc(C.Structure):
                 ("w", _fp * 4), ("b", _fp * 4)]
 
 
+class PoseTrack(C.Structure):
+    _fields_ = [("n_keys", C.c_int), ("key_t", _vp), ("key_quat", _vp), ("key_rotvec", _vp), ("trans_coef", _vp),
+                ("bd_scale", C.c_float), ("recenter", C.c_int), ("recenter_inv", C.c_double * 12)]
+
+
 class RenderOut(C.Structure):
     _fields_ = [(k, _vp) for k in ("rgb", "depth", "acc", "z_vals", "weights", "rgb0", "depth0", "acc0", "z_std",
                                    "z_vals0", "weights0", "feature", "raw")] + [("feature_kind", C.c_int)]
@@ -91,6 +96,9 @@ SIGNATURES = {
     "evd_compute_successor_workspace_bytes": (_S, [_L]),
     "evd_compute_successor": (_I, [_vp, _L, _L, _vp, _vp, _vp, _vp, _vp, _S, _vp]),
     "evd_sample_events": (_I, [_vp, _L, _I, _vp, _vp, _vp, _vp, _vp, _L, _fp, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "evd_sample_events_track": (_I, [_vp, _L, _I, _vp, _vp, C.POINTER(PoseTrack), _vp, _vp, _L, _fp, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "evd_interpolate_poses": (_I, [C.POINTER(PoseTrack), _vp, _L, _vp, _vp]),
+    "evd_image_batch": (_I, [_vp, _L, _vp, _vp, _vp, _I, _I, _I, _fp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "evd_rbk_warp": (_I, [_vp, _vp, _vp, _L, _I, _I, _vp, _vp, _vp]),
     "evd_awp_feature_integration": (_I, [_vp, _vp, _vp, _L, _I, _I, _vp, _vp]),
     "evd_awp_feature_integration_bwd": (_I, [_vp, _vp, _vp, _vp, _L, _I, _I, _vp, _vp, _vp, _vp]),
@@ -114,8 +122,8 @@ SIGNATURES = {
     "evd_awp_embed_backward": (_I, [_vp, _I, _vp, _L, _vp, _S, C.POINTER(AwpEmbedGrads), _vp, _vp, _vp, _S, _vp]),
     "evd_probe_mfma_rate": (_I, [_I, _I, C.POINTER(C.c_double), _vp]),
     "evd_device_count": (_I, []),
-    "evd_get_rays": (_I, [_I, _I, _fp, _fp, _vp, _vp, _vp]),
-    "evd_get_rays_pix": (_I, [_vp, _fp, _vp, _L, _vp, _vp, _vp]),
+    "evd_get_rays": (_I, [_I, _I, _fp, _fp, _I, _vp, _vp, _vp]),
+    "evd_get_rays_pix": (_I, [_vp, _fp, _vp, _L, _I, _vp, _vp, _vp]),
     "evd_ndc_rays": (_I, [_I, _I, _F, _F, _vp, _vp, _L, _vp, _vp, _vp]),
     "evd_embed": (_I, [_vp, _L, _I, _I, _vp, _vp]),
     "evd_ray_batch": (_I, [C.POINTER(RenderCfg), _vp, _L, _vp, _vp]),

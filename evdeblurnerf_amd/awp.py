@@ -11,13 +11,31 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import weakref
+
 import torch
 
 from . import _lib as L
 from .voxnerf import GeoFragments
 
 
-_DH_ABSMAX = {}       # data_ptr of a d h_local tensor -> device word with the float bits of its max |.| (_LocalConsumers.backward -> _SampleEmbed.backward)
+# data_ptr of a d h_local tensor -> (device word with the float bits of its max |.|, weak reference to the tensor, its version counter):
+# _LocalConsumers.backward -> _SampleEmbed.backward.  The word is only valid for the very values the producer wrote, so the consumer
+# checks that the producer's tensor is still alive (its address cannot have been handed to another tensor) and unmodified (autograd adds
+# a second consumer's gradient IN PLACE, which bumps the version); anything else falls back to the kernel's own maximum pass.
+_DH_ABSMAX = {}
+
+
+def _take_dh_absmax(g):
+    ent = _DH_ABSMAX.pop(g.data_ptr(), None)
+    _DH_ABSMAX.clear()
+    if ent is None:
+        return None
+    amax, ref, version = ent
+    src = ref()
+    if src is None or src.data_ptr() != g.data_ptr() or src.numel() != g.numel() or src._version != version or g._version != version:
+        return None
+    return amax
 
 
 class _FeatureIntegration(torch.autograd.Function):
@@ -92,8 +110,7 @@ class _SampleEmbed(torch.autograd.Function):
         d_rows = torch.empty((n, embed.input_ch), dtype=torch.float32, device=g.device) if (ctx.geo is None and ctx.needs_input_grad[0]) else None
         nb = int(lib.evd_awp_embed_backward_workspace_bytes())
         ws = torch.empty((nb,), dtype=torch.uint8, device=g.device)
-        amax = _DH_ABSMAX.pop(g.data_ptr(), None)     # the producer of d h_local took its maximum (same storage: nothing was added to it since)
-        _DH_ABSMAX.clear()
+        amax = _take_dh_absmax(g)                    # the producer of d h_local took its maximum; None: evd_awp_embed_backward takes it itself
         L.check(lib.evd_awp_embed_backward(embed._h, L.PREC[embed.precision], L.ptr(g), n, L.ptr(ctx.store), ctx.store.numel(), C.byref(gs),
                                            L.ptr(d_rows), L.ptr(amax), L.ptr(ws), nb, L.stream_ptr()), "evd_awp_embed_backward")
         if ctx.geo is not None:
@@ -182,7 +199,8 @@ class _LocalConsumers(torch.autograd.Function):
                                                          L.ptr(g_inter.contiguous().float()), L.ptr(g_intra.contiguous().float()), L.ptr(zz), L.ptr(dd),
                                                          L.ptr(g_h.contiguous().float()), R, P, S, Cc, L.ptr(d_f), L.ptr(d_u), L.ptr(d_z), L.ptr(d_d),
                                                          L.ptr(amax), L.stream_ptr()), "evd_awp_local_consumers_backward")
-        _DH_ABSMAX[d_f.data_ptr()] = amax
+        _DH_ABSMAX.clear()
+        _DH_ABSMAX[d_f.data_ptr()] = (amax, weakref.ref(d_f), d_f._version)
         sh = ctx.shapes
         return (d_f.reshape(sh[0]), None if d_z is None else d_z.reshape(sh[1]), None if d_d is None else d_d.reshape(sh[2]), d_u.sum(0),
                 None, None, None)

@@ -254,6 +254,8 @@ __global__ __launch_bounds__(256) void k_mam_local_bwd(const float* __restrict__
                 }
                 dh4[at] = o;
                 amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+                const float nan_probe = (o.x + o.y) + (o.z + o.w);      // fmaxf drops a NaN: record it as +inf like the scatter's maximum does
+                amax = nan_probe != nan_probe ? __builtin_huge_valf() : amax;
                 fma4(du, da, v);
             }
     }
@@ -390,6 +392,8 @@ __global__ __launch_bounds__(256) void k_local_consumers_bwd(const LocalBwdParam
             if (l == 0) dd[p * S + s] = ddist;
             dh4[at] = make_float4(o[0], o[1], o[2], o[3]);
             amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+            const float nan_probe = (o[0] + o[1]) + (o[2] + o[3]);      // a NaN (or inf - inf) in d h_local: +inf, not a finite scale word
+            amax = nan_probe != nan_probe ? __builtin_huge_valf() : amax;
         }
     }
     du.x += __shfl_xor(du.x, 16); du.y += __shfl_xor(du.y, 16); du.z += __shfl_xor(du.z, 16); du.w += __shfl_xor(du.w, 16);
@@ -461,6 +465,7 @@ int evd_mam_local_backward(const float* h_local, const float* u, const float* al
                 "evd_mam_local_backward: null argument");
     if (int e = mam_check("evd_mam_local_backward", R, P, S, C)) return e;
     if (R == 0) return EVD_OK;
+    if (d_h_absmax) EVD_HIP(hipMemsetAsync(d_h_absmax, 0, sizeof(unsigned), as_stream(stream)));     // the kernel raises the word; the entry owns its start value
     const size_t lds = sizeof(float) * (MAM_MAXP * MAM_C + MAM_MAXP + 4 * MAM_C);
     if (accumulate)
         k_mam_local_bwd<true><<<(unsigned)R, 256, lds, as_stream(stream)>>>(h_local, u, alpha, beta, h_inter, h_intra, d_inter, d_intra, P, S,
@@ -480,6 +485,7 @@ int evd_awp_local_consumers_backward(const float* h_local, const float* u, const
                 "evd_awp_local_consumers_backward: null argument");
     if (int e = mam_check("evd_awp_local_consumers_backward", R, P, S, C)) return e;
     if (R == 0) return EVD_OK;
+    if (d_h_absmax) EVD_HIP(hipMemsetAsync(d_h_absmax, 0, sizeof(unsigned), as_stream(stream)));
     LocalBwdParams q{};
     q.h = h_local; q.u = u; q.alpha = alpha; q.beta = beta; q.h_inter = h_inter; q.h_intra = h_intra; q.d_inter = d_inter; q.d_intra = d_intra;
     q.z = z; q.rays_d = rays_d; q.d_int = d_integrated; q.P = P; q.S = S;

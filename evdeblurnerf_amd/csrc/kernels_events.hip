@@ -6,6 +6,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include "evd_common.h"
+#include "pose_track.h"
 
 namespace evd {
 
@@ -48,9 +49,14 @@ __global__ void k_succ_write(const int* __restrict__ keys, const int* __restrict
 }
 
 // EventsDataset.sample_events (data/loader_events.py:259-304) for one event id per thread: the reference's gathers, gather_successor
-// (utils/events.py:221-257), and get_rays_pix (utils/rays.py:25-36, the arithmetic of k_get_rays_pix) on the start and the end pose
+// (utils/events.py:221-257), and get_rays_pix (utils/rays.py:25-36, the arithmetic of k_get_rays_pix) on the start and the end pose.
+// TRACK: the two poses are interpolate_poses(timestamp) evaluated here (pose_track.h; the reference's scipy round trip :280-283);
+// else rows of a per-event pose table.  An id outside [0, N), or a successor outside it in the single-hop branch (an event without
+// successor carries -1: the reference would wrap to events[-1]), gives zero polarity sums, successor -1, the start pose twice, and sets
+// the flag word like a coordinate mismatch does.
+template <bool TRACK>
 __global__ __launch_bounds__(256) void k_sample_events(const double* __restrict__ ev, long N, int ncol, const float* __restrict__ id_to_coords,
-                                                       const unsigned char* __restrict__ cmap, const float* __restrict__ poses,
+                                                       const unsigned char* __restrict__ cmap, const float* __restrict__ poses, const PoseTrackDev trk,
                                                        const long long* __restrict__ ids, const long long* __restrict__ hops, long n,
                                                        float k00, float k02, float k11, float k12, float halfpix,
                                                        float* __restrict__ rays_start, float* __restrict__ rays_end, float* __restrict__ pos_out,
@@ -59,17 +65,30 @@ __global__ __launch_bounds__(256) void k_sample_events(const double* __restrict_
     const long i = blockIdx.x * 256L + threadIdx.x;
     if (i >= n) return;
     const long long id = ids[i];
+    if (id < 0 || id >= N) {                       // nothing of this event can be read
+        pos_out[i] = neg_out[i] = 0.f;
+        coords_ids[i] = -1;
+        if (succ_out) succ_out[i] = -1;
+        if (cmap_out) cmap_out[i * 3] = cmap_out[i * 3 + 1] = cmap_out[i * 3 + 2] = 0;
+        for (int k = 0; k < 6; ++k) rays_start[i * 6 + k] = rays_end[i * 6 + k] = 0.f;
+        if (mismatch) atomicExch(mismatch, 1);
+        return;
+    }
     const double* row = ev + id * ncol;
     const long long pix = (long long)row[0];
     long long end;
     float pos = 0.f, neg = 0.f;
+    bool invalid = false;
     if (!hops) {                                   // loader_events.py:272-276
         end = (long long)row[ncol - 1];
-        const double p = ev[end * ncol + ncol - 2];
-        if (p > 0) pos = (float)p; else neg = (float)p;
+        if (end < 0 || end >= N) {
+            invalid = true;
+        } else {
+            const double p = ev[end * ncol + ncol - 2];
+            if (p > 0) pos = (float)p; else neg = (float)p;
+        }
     } else {                                       // gather_successor: hops + 1 steps (h <= query_hops, events.py:242-243)
         end = id;
-        bool invalid = false;
         const long long nh = hops[i];
         for (long long h = 0; h <= nh; ++h) {
             const long long nxt = (long long)ev[end * ncol + ncol - 1];
@@ -79,7 +98,11 @@ __global__ __launch_bounds__(256) void k_sample_events(const double* __restrict_
             if (p > 0) pos += (float)p;
             if (p < 0) neg += (float)p;
         }
-        if (invalid) { end = -1; pos = neg = 0.f; }
+    }
+    if (invalid) {
+        end = -1;
+        pos = neg = 0.f;
+        if (mismatch && !hops) atomicExch(mismatch, 1);        // the multi-hop branch returns -1 / 0 / 0 by the reference's own rule (:252-255)
     }
     pos_out[i] = pos;
     neg_out[i] = neg;
@@ -95,7 +118,15 @@ __global__ __launch_bounds__(256) void k_sample_events(const double* __restrict_
     if (mismatch && end >= 0 && (long long)ev[end * ncol] != pix) atomicExch(mismatch, 1);
 #pragma unroll
     for (int which = 0; which < 2; ++which) {
-        const float* c2w = poses + (which ? e2 : id) * 12;
+        const long long e = which ? e2 : id;
+        float pose[12];
+        const float* c2w;
+        if (TRACK) {
+            pose_at(trk, ev[e * ncol + ncol - 3], pose);
+            c2w = pose;
+        } else {
+            c2w = poses + e * 12;
+        }
         float* out = (which ? rays_end : rays_start) + i * 6;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -103,6 +134,16 @@ __global__ __launch_bounds__(256) void k_sample_events(const double* __restrict_
             out[r * 2 + 1] = __fadd_rn(__fadd_rn(__fmul_rn(d0, c2w[r * 4]), __fmul_rn(d1, c2w[r * 4 + 1])), __fmul_rn(d2, c2w[r * 4 + 2]));
         }
     }
+}
+
+// interpolate_poses (data/loader_events.py:133-148) for one timestamp per thread
+__global__ __launch_bounds__(256) void k_interpolate_poses(const PoseTrackDev trk, const double* __restrict__ t, long n, float* __restrict__ out) {
+    const long i = blockIdx.x * 256L + threadIdx.x;
+    if (i >= n) return;
+    float c2w[12];
+    pose_at(trk, t[i], c2w);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) out[i * 12 + k] = c2w[k];
 }
 
 }  // namespace evd
@@ -153,20 +194,58 @@ int evd_compute_successor(const int* pixel_ids, long N, long HW, long long* succ
     return EVD_OK;
 }
 
+static int sample_events_launch(const char* who, const double* events, long N, int ncol, const float* id_to_coords, const unsigned char* id_to_color_map,
+                                const float* poses, const evd_pose_track* track, const long long* events_ids, const long long* hops, long n,
+                                const float* K, int add_halfpix, float* rays_start, float* rays_end, float* pos_cumsum, float* neg_cumsum,
+                                long long* coords_ids, unsigned char* color_map, long long* successor, int* mismatch, void* stream) {
+    EVD_REQUIRE(n >= 0 && N >= 0 && ncol >= 4 && K, "%s: bad arguments (the event table has >= 4 columns: id, .., t, p, successor)", who);
+    if (track) {
+        const char* why = pose_track_invalid(track);
+        EVD_REQUIRE(!why, "%s: %s", who, why);
+    }
+    if (n == 0) return EVD_OK;
+    EVD_REQUIRE(events && id_to_coords && (poses || track) && events_ids && rays_start && rays_end && pos_cumsum && neg_cumsum && coords_ids,
+                "%s: null argument", who);
+    EVD_REQUIRE(!color_map || id_to_color_map, "%s: a colour map output needs id_to_color_map", who);
+    hipStream_t st = as_stream(stream);
+    if (mismatch) EVD_HIP(hipMemsetAsync(mismatch, 0, sizeof(int), st));
+    const float hp = add_halfpix ? 0.5f : 0.f;
+    if (track)
+        hipLaunchKernelGGL(k_sample_events<true>, dim3((unsigned)cdiv(n, 256L)), dim3(256), 0, st, events, N, ncol, id_to_coords, id_to_color_map,
+                           (const float*)nullptr, pose_track_dev(track), events_ids, hops, n, K[0], K[2], K[4], K[5], hp, rays_start, rays_end,
+                           pos_cumsum, neg_cumsum, coords_ids, color_map, successor, mismatch);
+    else
+        hipLaunchKernelGGL(k_sample_events<false>, dim3((unsigned)cdiv(n, 256L)), dim3(256), 0, st, events, N, ncol, id_to_coords, id_to_color_map,
+                           poses, PoseTrackDev{}, events_ids, hops, n, K[0], K[2], K[4], K[5], hp, rays_start, rays_end, pos_cumsum, neg_cumsum,
+                           coords_ids, color_map, successor, mismatch);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
 int evd_sample_events(const double* events, long N, int ncol, const float* id_to_coords, const unsigned char* id_to_color_map,
                       const float* poses, const long long* events_ids, const long long* hops, long n, const float* K, int add_halfpix,
                       float* rays_start, float* rays_end, float* pos_cumsum, float* neg_cumsum, long long* coords_ids,
                       unsigned char* color_map, long long* successor, int* mismatch, void* stream) {
-    EVD_REQUIRE(n >= 0 && N >= 0 && ncol >= 4 && K, "evd_sample_events: bad arguments (the event table has >= 4 columns: id, .., t, p, successor)");
+    return sample_events_launch("evd_sample_events", events, N, ncol, id_to_coords, id_to_color_map, poses, nullptr, events_ids, hops, n, K, add_halfpix,
+                                rays_start, rays_end, pos_cumsum, neg_cumsum, coords_ids, color_map, successor, mismatch, stream);
+}
+
+int evd_sample_events_track(const double* events, long N, int ncol, const float* id_to_coords, const unsigned char* id_to_color_map,
+                            const evd_pose_track* track, const long long* events_ids, const long long* hops, long n, const float* K,
+                            int add_halfpix, float* rays_start, float* rays_end, float* pos_cumsum, float* neg_cumsum, long long* coords_ids,
+                            unsigned char* color_map, long long* successor, int* mismatch, void* stream) {
+    EVD_REQUIRE(track, "evd_sample_events_track: null track");
+    return sample_events_launch("evd_sample_events_track", events, N, ncol, id_to_coords, id_to_color_map, nullptr, track, events_ids, hops, n, K,
+                                add_halfpix, rays_start, rays_end, pos_cumsum, neg_cumsum, coords_ids, color_map, successor, mismatch, stream);
+}
+
+int evd_interpolate_poses(const evd_pose_track* track, const double* t, long n, float* poses, void* stream) {
+    const char* why = pose_track_invalid(track);
+    EVD_REQUIRE(!why, "evd_interpolate_poses: %s", why);
+    EVD_REQUIRE(n >= 0, "evd_interpolate_poses: n < 0");
     if (n == 0) return EVD_OK;
-    EVD_REQUIRE(events && id_to_coords && poses && events_ids && rays_start && rays_end && pos_cumsum && neg_cumsum && coords_ids,
-                "evd_sample_events: null argument");
-    EVD_REQUIRE(!color_map || id_to_color_map, "evd_sample_events: a colour map output needs id_to_color_map");
-    hipStream_t st = as_stream(stream);
-    if (mismatch) EVD_HIP(hipMemsetAsync(mismatch, 0, sizeof(int), st));
-    hipLaunchKernelGGL(k_sample_events, dim3((unsigned)cdiv(n, 256L)), dim3(256), 0, st, events, N, ncol, id_to_coords, id_to_color_map, poses,
-                       events_ids, hops, n, K[0], K[2], K[4], K[5], add_halfpix ? 0.5f : 0.f, rays_start, rays_end, pos_cumsum, neg_cumsum,
-                       coords_ids, color_map, successor, mismatch);
+    EVD_REQUIRE(t && poses, "evd_interpolate_poses: null argument");
+    hipLaunchKernelGGL(k_interpolate_poses, dim3((unsigned)cdiv(n, 256L)), dim3(256), 0, as_stream(stream), pose_track_dev(track), t, n, poses);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }

@@ -44,13 +44,13 @@ __device__ __forceinline__ double wave_scan_add_d(double v, int lane) {
 // ------------------------------------------------------------------------------------------------
 // reference utils/rays.py:8-22
 struct Pose34 { float m[12]; };
-__global__ void k_get_rays(int H, int W, float k00, float k02, float k11, float k12, const Pose34 pose,
+__global__ void k_get_rays(int H, int W, float k00, float k02, float k11, float k12, float halfpix, const Pose34 pose,
                            float* __restrict__ ro, float* __restrict__ rd) {
     const float* c2w = pose.m;
     const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (idx >= (long)H * W) return;
     const int j = idx / W, i = idx % W;
-    const float d0 = ((float)i + (0.5f - k02)) / k00, d1 = -((float)j + (0.5f - k12)) / k11, d2 = -1.f;
+    const float d0 = ((float)i + (halfpix - k02)) / k00, d1 = -((float)j + (halfpix - k12)) / k11, d2 = -1.f;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         rd[idx * 3 + r] = __fadd_rn(__fadd_rn(__fmul_rn(d0, c2w[r * 4]), __fmul_rn(d1, c2w[r * 4 + 1])), __fmul_rn(d2, c2w[r * 4 + 2]));
@@ -59,12 +59,12 @@ __global__ void k_get_rays(int H, int W, float k00, float k02, float k11, float 
 }
 
 // reference utils/rays.py:25-36
-__global__ void k_get_rays_pix(const float* __restrict__ coords, float k00, float k02, float k11, float k12,
+__global__ void k_get_rays_pix(const float* __restrict__ coords, float k00, float k02, float k11, float k12, float halfpix,
                                const float* __restrict__ c2ws, long n, float* __restrict__ ro, float* __restrict__ rd) {
     const long p = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (p >= n) return;
     const float* c2w = c2ws + p * 12;
-    const float d0 = (coords[p * 2] + (0.5f - k02)) / k00, d1 = -(coords[p * 2 + 1] + (0.5f - k12)) / k11, d2 = -1.f;
+    const float d0 = (coords[p * 2] + (halfpix - k02)) / k00, d1 = -(coords[p * 2 + 1] + (halfpix - k12)) / k11, d2 = -1.f;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         rd[p * 3 + r] = __fadd_rn(__fadd_rn(__fmul_rn(d0, c2w[r * 4]), __fmul_rn(d1, c2w[r * 4 + 1])), __fmul_rn(d2, c2w[r * 4 + 2]));
@@ -806,20 +806,20 @@ using namespace evd;
 
 extern "C" {
 
-int evd_get_rays(int H, int W, const float* K, const float* c2w, float* rays_o, float* rays_d, void* stream) {
+int evd_get_rays(int H, int W, const float* K, const float* c2w, int add_halfpix, float* rays_o, float* rays_d, void* stream) {
     EVD_REQUIRE(H > 0 && W > 0 && K && c2w && rays_o && rays_d, "evd_get_rays: bad arguments");
     Pose34 pose;
     memcpy(pose.m, c2w, sizeof(pose.m));
     const long n = (long)H * W;
-    k_get_rays<<<cdiv(n, 256), 256, 0, as_stream(stream)>>>(H, W, K[0], K[2], K[4], K[5], pose, rays_o, rays_d);
+    k_get_rays<<<cdiv(n, 256), 256, 0, as_stream(stream)>>>(H, W, K[0], K[2], K[4], K[5], add_halfpix ? 0.5f : 0.f, pose, rays_o, rays_d);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }
 
-int evd_get_rays_pix(const float* coords, const float* K, const float* c2ws, long n, float* rays_o, float* rays_d, void* stream) {
+int evd_get_rays_pix(const float* coords, const float* K, const float* c2ws, long n, int add_halfpix, float* rays_o, float* rays_d, void* stream) {
     EVD_REQUIRE(n >= 0 && K && rays_o && rays_d, "evd_get_rays_pix: bad arguments");
     if (n == 0) return EVD_OK;
-    k_get_rays_pix<<<cdiv(n, 256), 256, 0, as_stream(stream)>>>(coords, K[0], K[2], K[4], K[5], c2ws, n, rays_o, rays_d);
+    k_get_rays_pix<<<cdiv(n, 256), 256, 0, as_stream(stream)>>>(coords, K[0], K[2], K[4], K[5], add_halfpix ? 0.5f : 0.f, c2ws, n, rays_o, rays_d);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }

@@ -766,6 +766,7 @@ template <int PREC> static int run_nerf_backward(const BwdPlan& b, hipStream_t s
             EVD_HIP(hipEventRecord(b.ev, st));
             EVD_HIP(hipStreamWaitEvent(b.side, b.ev, 0));
             ws = b.side;
+            test_side_spin(ws);
         }
         int r = launch(p, blocks, ws);
         if (r) return r;

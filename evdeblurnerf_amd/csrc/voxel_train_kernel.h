@@ -145,6 +145,7 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
             EVD_HIP(hipEventRecord(b.ev, st));
             EVD_HIP(hipStreamWaitEvent(b.side, b.ev, 0));
             ws = b.side;
+            test_side_spin(ws);
         }
         int r = launch(p, blocks, ws);
         if (r) return r;

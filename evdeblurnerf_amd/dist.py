@@ -113,12 +113,31 @@ class GradReducer:
         self._late = []
         self._early = set()         # flat groups whose all-reduce was started from a level's "gradients complete" callback (attach)
         self.early_starts = 0
+        self._armed = True          # False inside no_sync()
 
     def attach(self, model):
         """Start a level's in-place gradient buffers as soon as that level's LAST backward node of the iteration has run (voxnerf._bwd_done)
         instead of at start(): in the blurfactory iteration the fine level -- 150 MB of grid gradients, the largest message -- is complete
         while the coarse level's last scatter and networks still run (~1.5 ms), and the coarse level while the blur kernel's own backward
-        runs.  model.grad_buffers() order: per level [network buffer, grid buffer]; levels whose nets have no callback slot are left to start()."""
+        runs.  model.grad_buffers() order: per level [network buffer, grid buffer]; levels whose nets have no callback slot are left to start().
+
+        PRECONDITIONS (checked where they can be):
+        * one optimizer step = forward(s) ... backward(s) ... start() ... wait().  Several forwards whose backwards all run before
+          start() are counted per level (the callback fires when the LAST pending node of the level has run).  A step that accumulates
+          gradients over micro-batches -- forward, backward, forward, backward, ... -- must run all but the last backward inside
+          ``with reducer.no_sync():``; otherwise the first backward already starts the all-reduce on partial sums.  A forward of an
+          attached level under autograd while one of its all-reduces is in flight raises RuntimeError (before any kernel of the second
+          micro-batch adds into a buffer the collective is reading).
+        * every gradient contribution to the attached levels' parameters comes from the library's autograd nodes (gather, level
+          networks, TV).  A torch-side term on those leaves (e.g. a weight-decay loss written as (p ** 2).sum()) reaches .grad through
+          AccumulateGrad, possibly after the level's last library node: use no_sync() for such a step, or do not attach.
+        * ordering against the backward entries' side streams: evd_*_mlp_backward joins its per-handle side stream into the caller's
+          stream before it returns (csrc/voxel_train_kernel.h, nerf_train_kernel.h: hipEventRecord(side) + hipStreamWaitEvent(stream)),
+          and the process group orders the collective behind the work already enqueued on the current stream, so a collective started
+          here sees the complete buffers (tests/test_gpu_dist.py delays the side stream to prove the edge).
+        EVD_NO_EARLY_ALLREDUCE=1: attach() installs nothing (every message starts at start())."""
+        if os.environ.get("EVD_NO_EARLY_ALLREDUCE", "0") not in ("", "0"):
+            return self
         lv = [n for n in (getattr(model, "mlp_coarse", None), getattr(model, "mlp_fine", None)) if n is not None]
         per = len(self.flat_groups) // max(len(lv), 1) if lv else 0
         if not lv or per * len(lv) != len(self.flat_groups):
@@ -127,16 +146,54 @@ class GradReducer:
             idx = list(range(i * per, (i + 1) * per))
             net._pending_bwd = 0
             net._grads_ready_cb = (lambda ids=idx: self._start_groups(ids))
+            net._fwd_guard_cb = (lambda ids=idx: self._guard_forward(ids))
         self._attached_nets = lv
         return self
 
+    def detach(self):
+        """undo attach(): the levels' callbacks are removed"""
+        for net in getattr(self, "_attached_nets", ()):
+            net._grads_ready_cb = net._fwd_guard_cb = None
+            net._pending_bwd = 0
+        self._attached_nets = []
+
+    class _NoSync:
+        def __init__(self, red):
+            self.red = red
+
+        def __enter__(self):
+            self.red._armed = False
+            return self.red
+
+        def __exit__(self, *exc):
+            self.red._armed = True
+            for net in getattr(self.red, "_attached_nets", ()):      # the next micro-batch counts its own nodes
+                net._pending_bwd = 0
+            return False
+
+    def no_sync(self):
+        """Context for the backward passes of all micro-batches but the last of a gradient-accumulation step (the name DDP uses): inside
+        it no level starts its all-reduce, the in-place buffers keep accumulating.  start() inside the context raises."""
+        return GradReducer._NoSync(self)
+
+    def _guard_forward(self, ids):
+        if any(i in self._early for i in ids):
+            raise RuntimeError("GradReducer: a forward of a level whose gradient all-reduce of THIS step is already in flight -- a second "
+                               "micro-batch after the first backward.  Run all but the last backward of a step inside reducer.no_sync() "
+                               "(and call wait() before the next step's forward)")
+
     def _start_groups(self, ids):
         import torch.distributed as dist
+        if not self._armed:
+            return
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
         for i in ids:
             buf, ps = self.flat_groups[i]
-            if i not in self._early and self._attached(buf, ps):
+            if i in self._early:
+                raise RuntimeError("GradReducer: a level finished a second backward after its all-reduce was started; gradients of this "
+                                   "step are invalid.  Use reducer.no_sync() around all but the last backward of a step")
+            if self._attached(buf, ps):
                 self._work.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True), None))
                 self._early.add(i)
                 self.early_starts += 1
@@ -164,6 +221,8 @@ class GradReducer:
 
     def start(self):
         import torch.distributed as dist
+        if not self._armed:
+            raise RuntimeError("GradReducer.start() inside no_sync(): the last micro-batch's backward runs outside the context")
         self._work, self._late = list(self._work) if self._early else [], []
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return

@@ -31,28 +31,45 @@ def compute_successor(pixel_ids, num_pixels):
 
 class EventSampler:
     """The tables EventsDataset keeps on the device (data/loader_events.py:60-75: events [N, ncol] float64 with the successor index in the
-    last column, id_to_coords, id_to_color_map) + the c2w pose of every event at its own timestamp, and ``sample_events`` on them.
+    last column, id_to_coords, id_to_color_map) and ``sample_events`` on them.
 
-    The reference interpolates the start / end poses per batch on the CPU (scipy Slerp + cubic spline through
-    ``interpolate_poses(timestamps.cpu().numpy())``, :280-283); a pose is a pure function of the event's timestamp, so the same values
-    are evaluated ONCE per dataset (``poses``: [N, 3, 4] float32, 48 bytes per event) and the batch needs no host round trip."""
+    The start / end poses: the reference interpolates them per batch on the CPU (scipy Slerp + cubic spline through
+    ``interpolate_poses(timestamps.cpu().numpy())``, :280-283).  With ``pose_track`` (poses.PoseTrack) the same interpolation runs
+    inside the batch kernel at the events' own timestamps; with ``poses`` ([N, 3, 4] float32, 48 bytes per event) the caller supplies
+    one pose per event, evaluated once per dataset (a pose is a pure function of the timestamp)."""
 
-    def __init__(self, events, id_to_coords, poses, K, id_to_color_map=None, integer_coords=True, device="cuda"):
+    def __init__(self, events, id_to_coords, poses=None, K=None, id_to_color_map=None, integer_coords=True, device="cuda", pose_track=None):
         dev = torch.device(device)
+        if K is None:
+            raise L.EvdError("EventSampler: K is required")
+        if (poses is None) == (pose_track is None):
+            raise L.EvdError("EventSampler: exactly one of poses ([N, 3, 4]) and pose_track (poses.PoseTrack)")
         self.events = torch.as_tensor(events, dtype=torch.float64, device=dev).contiguous()
         self.id_to_coords = torch.as_tensor(id_to_coords, dtype=torch.float32, device=dev).contiguous()
-        self.poses = torch.as_tensor(poses, dtype=torch.float32, device=dev).reshape(-1, 3, 4).contiguous()
-        if self.poses.shape[0] != self.events.shape[0] or self.events.dim() != 2 or self.events.shape[1] < 4:
-            raise L.EvdError("EventSampler: events [N, >= 4] float64 and one pose [3, 4] per event")
+        if self.events.dim() != 2 or self.events.shape[1] < 4:
+            raise L.EvdError("EventSampler: events [N, >= 4] float64")
+        self.pose_track = pose_track
+        self.poses = None
+        if poses is not None:
+            self.poses = torch.as_tensor(poses, dtype=torch.float32, device=dev).reshape(-1, 3, 4).contiguous()
+            if self.poses.shape[0] != self.events.shape[0]:
+                raise L.EvdError("EventSampler: one pose [3, 4] per event")
         self.id_to_color_map = None if id_to_color_map is None else torch.as_tensor(np.asarray(id_to_color_map), device=dev).to(torch.uint8).contiguous()
         self.K = np.ascontiguousarray(np.asarray(K, dtype=np.float32).reshape(-1))
         self.integer_coords = bool(integer_coords)
         self._mismatch = torch.zeros((1,), dtype=torch.int32, device=dev)
 
+    def interpolate_poses(self, t):
+        """loader_events.py:133-148 (needs pose_track)."""
+        if self.pose_track is None:
+            raise L.EvdError("EventSampler.interpolate_poses: constructed with a pose table, not a pose_track")
+        return self.pose_track.interpolate_poses(t)
+
     def sample_events(self, events_ids, hops=None, check=False):
         """loader_events.py:259-304.  hops None: the branch of the shipped configs (event_accumulate_step_range [0, 0]); else the number of
         successor hops per event (the reference draws them, :265-268; gather_successor follows hops + 1 links).  Returns the reference's
-        dict (rays [n, 3, 2], polarity sums float32).  check=True reads the device flag back (the reference's assert :284)."""
+        dict (rays [n, 3, 2], polarity sums float32).  check=True reads the device flag back (the reference's assert :284; also set by an
+        id outside the table or, in the single-hop branch, an event without successor)."""
         ids = events_ids.to(device=self.events.device, dtype=torch.int64).contiguous()
         n, dev = ids.shape[0], self.events.device
         hp = hops.to(device=dev, dtype=torch.int64).contiguous() if hops is not None else None
@@ -61,11 +78,15 @@ class EventSampler:
         pos, neg = torch.empty((n,), **f32), torch.empty((n,), **f32)
         cid = torch.empty((n,), dtype=torch.int64, device=dev)
         cm = torch.empty((n, 3), dtype=torch.uint8, device=dev) if self.id_to_color_map is not None else None
-        L.check(L.lib().evd_sample_events(L.ptr(self.events), self.events.shape[0], self.events.shape[1], L.ptr(self.id_to_coords), L.ptr(self.id_to_color_map),
-                                          L.ptr(self.poses), L.ptr(ids), L.ptr(hp), n, self.K.ctypes.data_as(C.POINTER(C.c_float)), int(self.integer_coords),
-                                          L.ptr(rs), L.ptr(re), L.ptr(pos), L.ptr(neg), L.ptr(cid), L.ptr(cm), None, L.ptr(self._mismatch), L.stream_ptr()),
-                "evd_sample_events")
+        head = (L.ptr(self.events), self.events.shape[0], self.events.shape[1], L.ptr(self.id_to_coords), L.ptr(self.id_to_color_map))
+        tail = (L.ptr(ids), L.ptr(hp), n, self.K.ctypes.data_as(C.POINTER(C.c_float)), int(self.integer_coords),
+                L.ptr(rs), L.ptr(re), L.ptr(pos), L.ptr(neg), L.ptr(cid), L.ptr(cm), None, L.ptr(self._mismatch), L.stream_ptr())
+        if self.pose_track is not None:
+            L.check(L.lib().evd_sample_events_track(*head, C.byref(self.pose_track.struct), *tail), "evd_sample_events_track")
+        else:
+            L.check(L.lib().evd_sample_events(*head, L.ptr(self.poses), *tail), "evd_sample_events")
         if check and int(self._mismatch.item()):
-            raise L.EvdError("sample_events: an end event is not on its start event's coordinate id")
+            raise L.EvdError("sample_events: an id outside the event table, an event without successor, or an end event that is not on "
+                             "its start event's coordinate id")
         return {"events_pos_pol_cumsum": pos, "events_neg_pol_cumsum": neg, "events_rays_start": rs, "events_rays_end": re,
                 "events_coords_ids": cid, "events_color_map": cm.bool() if cm is not None else None}

@@ -22,29 +22,26 @@ def _fp(a):
 
 def get_rays(H, W, K, c2w, add_halfpix=True):
     """utils/rays.py:8-22 -> (rays_o [H,W,3], rays_d [H,W,3])."""
-    if not add_halfpix:
-        raise NotImplementedError("add_halfpix=False is never used by the reference callers")
     k = _k9(K)
     pose = np.ascontiguousarray(c2w.detach().cpu().numpy() if isinstance(c2w, torch.Tensor) else c2w,
                                 dtype=np.float32)[:3, :4].copy()
     dev = c2w.device if isinstance(c2w, torch.Tensor) and c2w.is_cuda else torch.device("cuda")
     o = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
     d = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
-    L.check(L.lib().evd_get_rays(H, W, _fp(k), _fp(pose), L.ptr(o), L.ptr(d), L.stream_ptr()), "evd_get_rays")
+    L.check(L.lib().evd_get_rays(H, W, _fp(k), _fp(pose), int(bool(add_halfpix)), L.ptr(o), L.ptr(d), L.stream_ptr()), "evd_get_rays")
     return o, d
 
 
 def get_rays_pix(coords, K, c2ws, add_halfpix=True):
-    """utils/rays.py:25-36: coords [n,2] (x,y), c2ws [n,3,4] -> (rays_o [n,3], rays_d [n,3])."""
-    if not add_halfpix:
-        raise NotImplementedError("add_halfpix=False is never used by the reference callers")
+    """utils/rays.py:25-36: coords [n,2] (x,y), c2ws [n,3,4] -> (rays_o [n,3], rays_d [n,3]).  add_halfpix=False: the coordinates are
+    sub-pixel positions already (the event loader passes integer_coords, data/loader_events.py:290-293)."""
     k = _k9(K)
     coords = coords.contiguous().float()
     c2ws = c2ws[..., :3, :4].contiguous().float()
     n = coords.shape[0]
     o = torch.empty((n, 3), dtype=torch.float32, device=coords.device)
     d = torch.empty((n, 3), dtype=torch.float32, device=coords.device)
-    L.check(L.lib().evd_get_rays_pix(L.ptr(coords), _fp(k), L.ptr(c2ws), n, L.ptr(o), L.ptr(d), L.stream_ptr()),
+    L.check(L.lib().evd_get_rays_pix(L.ptr(coords), _fp(k), L.ptr(c2ws), n, int(bool(add_halfpix)), L.ptr(o), L.ptr(d), L.stream_ptr()),
             "evd_get_rays_pix")
     return o, d
 

@@ -70,6 +70,9 @@ def _grid_grads(net, like, in_place=False):
 # its gradient buffers can be all-reduced while the backward of the levels / modules in front of it still runs.
 def _fwd_noted(net):
     if torch.is_grad_enabled() and getattr(net, "_grads_ready_cb", None) is not None:
+        guard = getattr(net, "_fwd_guard_cb", None)
+        if guard is not None:
+            guard()                 # dist.GradReducer: raises if this level's all-reduce of the running step is already in flight
         net._pending_bwd = getattr(net, "_pending_bwd", 0) + 1
 
 

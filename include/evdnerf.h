@@ -67,10 +67,12 @@ int evd_version(void);
 int evd_device_count(void);
 
 /* ---------------------------------------------------------------- rays (reference utils/rays.py) */
-/* get_rays, utils/rays.py:8-22.  K host[9], c2w host[12] -> rays_o/rays_d dev [H,W,3] */
-int evd_get_rays(int H, int W, const float* K, const float* c2w, float* rays_o, float* rays_d, void* stream);
-/* get_rays_pix, utils/rays.py:25-36.  coords dev [n,2], c2ws dev [n,3,4], K host[9] */
-int evd_get_rays_pix(const float* coords, const float* K, const float* c2ws, long n,
+/* get_rays, utils/rays.py:8-22.  K host[9], c2w host[12] -> rays_o/rays_d dev [H,W,3].  add_halfpix: the reference's keyword
+ * (:8-9; HALF_PIX = 0.5 added to the pixel index when non-zero). */
+int evd_get_rays(int H, int W, const float* K, const float* c2w, int add_halfpix, float* rays_o, float* rays_d, void* stream);
+/* get_rays_pix, utils/rays.py:25-36.  coords dev [n,2], c2ws dev [n,3,4], K host[9].  add_halfpix 0: the coordinates are already
+ * sub-pixel positions (rectified event coordinates, data/loader_events.py:290-293 passes integer_coords). */
+int evd_get_rays_pix(const float* coords, const float* K, const float* c2ws, long n, int add_halfpix,
                      float* rays_o, float* rays_d, void* stream);
 /* get_ndc_rays, utils/rays.py:104-145 */
 int evd_ndc_rays(int H, int W, float focal, float near, const float* rays_o, const float* rays_d, long n,
@@ -458,7 +460,7 @@ int evd_mam_local_forward(const float* h_local, const float* u, long R, int P, i
 /* Its backward (torch.autograd behind mam.py:29-33,72-74 in training, run_nerf.py:593-601): d h_inter dev [R,P,64], d h_intra dev
  * [R,S,64] -> d h_local dev [R P, S, 64] (accumulate = 0: written; != 0: ADDED to what is there -- h_local has a second consumer, the
  * feature integration, whose backward writes the buffer first) and d u as per-ray partials dev [R,64] (the caller sums them).
- * d_h_absmax (optional): dev word, zeroed by the caller, raised to the float bits of max |d h_local| as written here (the loss scale the
+ * d_h_absmax (optional): dev word, set to 0 by this entry (on the stream) and raised to the float bits of max |d h_local| as written here (the loss scale the
  * embedding's backward needs: saves it a pass over the tensor). */
 int evd_mam_local_backward(const float* h_local, const float* u, const float* alpha, const float* beta, const float* h_inter,
                            const float* h_intra, const float* d_inter, const float* d_intra, long R, int P, int S, int C, float* d_h_local,
@@ -586,6 +588,52 @@ int evd_sample_events(const double* events, long N, int ncol, const float* id_to
                       const float* poses, const long long* events_ids, const long long* hops, long n, const float* K, int add_halfpix,
                       float* rays_start, float* rays_end, float* pos_cumsum, float* neg_cumsum, long long* coords_ids,
                       unsigned char* color_map, long long* successor, int* mismatch, void* stream);
+
+/* ---------------------------------------------------------------- camera trajectory on the device
+ * LLFFEventsDataset.interpolate_poses, data/loader_events.py:133-148: the pose of an event camera at a timestamp = scipy Slerp of the
+ * key rotations + a cubic (not-a-knot) spline of the key translations (utils/data.py:34-62 _get_slerp_interpolator, built at
+ * loader_events.py:175-182, queries clipped to the key range), the LLFF column change [r1, -r0, r2, t] (:137), float32, translation
+ * x bd_scale (:140), then recenter_poses with the image dataset's average pose (:142-143, utils/data.py:167-183: inv(c2w) @ pose in
+ * float64, stored float32).  The reference evaluates it on the CPU for every batch (scipy, .cpu().numpy() round trip at :280-283).
+ * Here the HOST prepares, once per dataset, what does not depend on the query (evdeblurnerf_amd/poses.py, plain numpy): the key
+ * rotations as unit quaternions (scipy's from_matrix: orthogonalised, then the largest-diagonal branch), the rotation vectors
+ * log(q_i^-1 q_i+1) between neighbours, and the spline as one cubic per interval in u = (t - t_i) / (t_i+1 - t_i); the device evaluates
+ * one pose per timestamp in float64 with the reference's float32 roundings at the same places.
+ * --spherify (utils/data.py:189-252) is not covered: no shipped config sets it, and the reference's event path returns float64 there. */
+typedef struct evd_pose_track {
+    int n_keys;                 /* M >= 4 key poses (scipy's cubic interp1d needs 4) */
+    const double* key_t;        /* dev [M] strictly ascending timestamps */
+    const double* key_quat;     /* dev [M, 4] unit quaternions (x, y, z, w) of the key rotations */
+    const double* key_rotvec;   /* dev [M-1, 3] rotation vector of q_i^-1 * q_i+1 */
+    const double* trans_coef;   /* dev [M-1, 4, 3] c0..c3 of the translation on interval i, polynomial in u */
+    float bd_scale;             /* loader_events.py:140 (float32 product, like the reference's in-place multiply) */
+    int recenter;               /* non-zero: left-multiply by recenter_inv (loader_events.py:142-143) */
+    double recenter_inv[12];    /* rows 0..2 of inv(c2w 4x4), row-major [3, 4] */
+} evd_pose_track;
+/* interpolate_poses(t): t dev float64 [n] -> poses dev float32 [n, 3, 4] (rows 0..2 of the reference's [n, 4, 4]; the fourth row is
+ * 0 0 0 1) */
+int evd_interpolate_poses(const evd_pose_track* track, const double* t, long n, float* poses, void* stream);
+/* evd_sample_events with the start / end poses evaluated from the track at the events' own timestamps (column ncol-3) inside the
+ * same launch, i.e. EventsDataset.sample_events as the reference runs it (loader_events.py:280-283) without a per-event pose table.
+ * All other arguments as evd_sample_events. */
+int evd_sample_events_track(const double* events, long N, int ncol, const float* id_to_coords, const unsigned char* id_to_color_map,
+                            const evd_pose_track* track, const long long* events_ids, const long long* hops, long n, const float* K,
+                            int add_halfpix, float* rays_start, float* rays_end, float* pos_cumsum, float* neg_cumsum, long long* coords_ids,
+                            unsigned char* color_map, long long* successor, int* mismatch, void* stream);
+
+/* ---------------------------------------------------------------- image batch assembly (first half)
+ * LLFFDataset.__getitem__, data/loader.py:325-356: a batch of flat ray ids in [0, n_img * H * W) -> image id / pixel
+ * (unravel_idx_from_rayid :118-123, C order), the image's pose, the pixel's colour (and the EDI prior's colour, set_pts0_prior :110-116),
+ * the pixel-centre ray (get_rays_pix on the integer pixel with add_halfpix, utils/rays.py:25-36).  One launch on the resident dataset.
+ *   ray_ids dev int64 [n]; images dev float32 [n_img, H, W, 3]; pts0_images the same shape or NULL; poses dev float32 [n_img, 3, 4];
+ *   K host[9].
+ * outputs (dev, the keys of the reference's dict): rays float32 [n, 3, 2] (origin, direction in the last axis), rays_x / rays_y
+ * float32 [n] (pixel + 0.5), images_idx int64 [n], rgbsf float32 [n, 3], poses_out float32 [n, 3, 4], rgbsf_pts0 float32 [n, 3]
+ * (NULL with pts0_images NULL), invalid int32 [1] or NULL: set to 1 when an id lies outside [0, n_img * H * W) (the reference raises
+ * an IndexError; such a ray is written as zeros with images_idx -1). */
+int evd_image_batch(const long long* ray_ids, long n, const float* images, const float* pts0_images, const float* poses, int n_img, int H,
+                    int W, const float* K, float* rays, float* rays_x, float* rays_y, long long* images_idx, float* rgbsf, float* poses_out,
+                    float* rgbsf_pts0, int* invalid, void* stream);
 
 /* ---------------------------------------------------------------- measurement aid (no reference counterpart)
  * Sustained rate of back-to-back v_mfma_f32_32x32x16_bf16 issue on every SIMD of the current device, in dense

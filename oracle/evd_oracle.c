@@ -1274,3 +1274,211 @@ void evo_sample_events(const double* ev, long N, int ncol, const float* id_to_co
         }
     }
 }
+
+/* ------------------------------------------------------------------ camera trajectory
+ * data/loader_events.py:133-148 interpolate_poses on top of utils/data.py:34-62 _get_slerp_interpolator (built at
+ * loader_events.py:175-182): scipy Slerp of the key rotations, cubic interp1d (make_interp_spline k = 3, not-a-knot ends) of the key
+ * translations, queries clipped to the key range; then the LLFF column change [r1, -r0, r2, t] (:137), float32 (:138), translation x
+ * bd_scale in float32 (:140), recenter_poses = inv(c2w) @ pose in float64 stored float32 (utils/data.py:167-183).
+ * scipy is a third-party dependency absent from /root/reference (pinned 1.9.1 in environment.yml; the build container has 1.15.3,
+ * whose from_matrix orthogonalises its input first): its published algorithms are restated from the raw key poses --
+ *   Rotation.from_matrix: nearest rotation (polar factor; here by Newton's iteration X <- (X + X^-T) / 2), then the quaternion branch
+ *     chosen by the largest of (m00, m11, m22, trace), normalised;
+ *   Slerp: rotvec_i = as_rotvec(q_i^-1 q_i+1) (w >= 0; series below 1e-3), result = q_ind * from_rotvec(alpha * rotvec_ind) with
+ *     ind = searchsorted(times, t, 'left') - 1 (0 for t == times[0]), alpha = (t - t_ind) / (t_ind+1 - t_ind); as_matrix;
+ *   not-a-knot cubic: second derivatives from the tridiagonal system with the end unknowns eliminated by continuity of the third
+ *     derivative at x_1 and x_M-2.
+ * Pinned by golden G29 (the reference's own interpolate_poses / sample_events run on scipy 1.15.3). */
+static void evo_polar3(const double* m, double* r) {
+    double x[9];
+    memcpy(x, m, sizeof(x));
+    for (int it = 0; it < 12; ++it) {
+        const double c00 = x[4] * x[8] - x[5] * x[7], c01 = x[5] * x[6] - x[3] * x[8], c02 = x[3] * x[7] - x[4] * x[6];
+        const double c10 = x[2] * x[7] - x[1] * x[8], c11 = x[0] * x[8] - x[2] * x[6], c12 = x[1] * x[6] - x[0] * x[7];
+        const double c20 = x[1] * x[5] - x[2] * x[4], c21 = x[2] * x[3] - x[0] * x[5], c22 = x[0] * x[4] - x[1] * x[3];
+        const double det = x[0] * c00 + x[1] * c01 + x[2] * c02;
+        const double cof[9] = {c00, c01, c02, c10, c11, c12, c20, c21, c22};      /* cofactor matrix = det * X^-T */
+        double delta = 0;
+        for (int k = 0; k < 9; ++k) {
+            const double nx = 0.5 * (x[k] + cof[k] / det);
+            delta = fmax(delta, fabs(nx - x[k]));
+            x[k] = nx;
+        }
+        if (delta < 1e-17) break;
+    }
+    memcpy(r, x, sizeof(x));
+}
+
+static void evo_quat_from_matrix(const double* m, double* q) {
+    const double dec[4] = {m[0], m[4], m[8], m[0] + m[4] + m[8]};
+    int c = 0;
+    for (int k = 1; k < 4; ++k) if (dec[k] > dec[c]) c = k;
+    if (c != 3) {
+        const int i = c, j = (c + 1) % 3, k = (c + 2) % 3;
+        q[i] = 1 - dec[3] + 2 * m[i * 3 + i];
+        q[j] = m[j * 3 + i] + m[i * 3 + j];
+        q[k] = m[k * 3 + i] + m[i * 3 + k];
+        q[3] = m[k * 3 + j] - m[j * 3 + k];
+    } else {
+        q[0] = m[7] - m[5]; q[1] = m[2] - m[6]; q[2] = m[3] - m[1]; q[3] = 1 + dec[3];
+    }
+    const double nrm = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int k = 0; k < 4; ++k) q[k] /= nrm;
+}
+
+static void evo_qmul(const double* p, const double* q, double* o) {
+    o[0] = p[3] * q[0] + p[0] * q[3] + p[1] * q[2] - p[2] * q[1];
+    o[1] = p[3] * q[1] - p[0] * q[2] + p[1] * q[3] + p[2] * q[0];
+    o[2] = p[3] * q[2] + p[0] * q[1] - p[1] * q[0] + p[2] * q[3];
+    o[3] = p[3] * q[3] - p[0] * q[0] - p[1] * q[1] - p[2] * q[2];
+}
+
+/* key_t [M] ascending, key_poses [M, 3, 4] (all_poses of loader_events.py:171), recenter_c2w host [3 or 4, 4] row-major 4 x 4 or NULL,
+ * t [n] -> poses float32 [n, 3, 4].  Returns 0, or -1 for M < 4 / non-ascending timestamps. */
+int evo_interpolate_poses(const double* key_t, const double* key_poses, int M, float bd_scale, const double* recenter_c2w44,
+                          const double* t, long n, float* poses) {
+    if (M < 4) return -1;
+    for (int i = 0; i + 1 < M; ++i) if (!(key_t[i + 1] > key_t[i])) return -1;
+    double* q = (double*)malloc(sizeof(double) * 4 * M);
+    double* rv = (double*)malloc(sizeof(double) * 3 * (M - 1));
+    double* m2 = (double*)calloc((size_t)3 * M, sizeof(double));        /* second derivatives of the translation spline, [M, 3] */
+    for (int i = 0; i < M; ++i) {
+        double R[9], Rp[9];
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R[r * 3 + c] = key_poses[i * 12 + r * 4 + c];
+        evo_polar3(R, Rp);
+        evo_quat_from_matrix(Rp, q + i * 4);
+    }
+    for (int i = 0; i + 1 < M; ++i) {
+        const double qi[4] = {-q[i * 4], -q[i * 4 + 1], -q[i * 4 + 2], q[i * 4 + 3]};
+        double d[4];
+        evo_qmul(qi, q + (i + 1) * 4, d);
+        if (d[3] < 0) for (int k = 0; k < 4; ++k) d[k] = -d[k];
+        const double nv = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        const double ang = 2 * atan2(nv, d[3]);
+        const double sc = ang <= 1e-3 ? 2 + ang * ang / 12 + 7 * ang * ang * ang * ang / 2880 : ang / sin(ang / 2);
+        for (int k = 0; k < 3; ++k) rv[i * 3 + k] = d[k] * sc;
+    }
+    {   /* not-a-knot cubic through (key_t, translation) */
+        const int nn = M - 2;
+        double* h = (double*)malloc(sizeof(double) * (M - 1));
+        double* a = (double*)malloc(sizeof(double) * nn);
+        double* b = (double*)malloc(sizeof(double) * nn);
+        double* c = (double*)malloc(sizeof(double) * nn);
+        double* cp = (double*)malloc(sizeof(double) * nn);
+        double* rp = (double*)malloc(sizeof(double) * nn);
+        for (int i = 0; i + 1 < M; ++i) h[i] = key_t[i + 1] - key_t[i];
+        for (int i = 0; i < nn; ++i) { a[i] = h[i]; b[i] = 2 * (h[i] + h[i + 1]); c[i] = h[i + 1]; }
+        b[0] += h[0] * (1 + h[0] / h[1]);
+        c[0] -= h[0] * h[0] / h[1];
+        b[nn - 1] += h[M - 2] * (1 + h[M - 2] / h[M - 3]);
+        a[nn - 1] -= h[M - 2] * h[M - 2] / h[M - 3];
+        for (int dim = 0; dim < 3; ++dim) {
+#define YV(i) key_poses[(i) * 12 + dim * 4 + 3]
+            for (int i = 0; i < nn; ++i) {
+                const double d0 = (YV(i + 1) - YV(i)) / h[i], d1 = (YV(i + 2) - YV(i + 1)) / h[i + 1];
+                const double r = 6 * (d1 - d0);
+                if (i == 0) { cp[0] = c[0] / b[0]; rp[0] = r / b[0]; }
+                else { const double den = b[i] - a[i] * cp[i - 1]; cp[i] = c[i] / den; rp[i] = (r - a[i] * rp[i - 1]) / den; }
+            }
+            m2[nn * 3 + dim] = rp[nn - 1];
+            for (int i = nn - 2; i >= 0; --i) m2[(i + 1) * 3 + dim] = rp[i] - cp[i] * m2[(i + 2) * 3 + dim];
+            m2[dim] = (1 + h[0] / h[1]) * m2[3 + dim] - (h[0] / h[1]) * m2[6 + dim];
+            m2[(M - 1) * 3 + dim] = (1 + h[M - 2] / h[M - 3]) * m2[(M - 2) * 3 + dim] - (h[M - 2] / h[M - 3]) * m2[(M - 3) * 3 + dim];
+        }
+        free(h); free(a); free(b); free(c); free(cp); free(rp);
+    }
+    double inv[16];
+    if (recenter_c2w44) {       /* np.linalg.inv(c2w) of the rigid-or-not 4 x 4: Gauss-Jordan with partial pivoting */
+        double aug[4][8];
+        for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { aug[r][c] = recenter_c2w44[r * 4 + c]; aug[r][4 + c] = r == c; }
+        for (int col = 0; col < 4; ++col) {
+            int piv = col;
+            for (int r = col + 1; r < 4; ++r) if (fabs(aug[r][col]) > fabs(aug[piv][col])) piv = r;
+            for (int c = 0; c < 8; ++c) { const double tmp = aug[col][c]; aug[col][c] = aug[piv][c]; aug[piv][c] = tmp; }
+            const double d = aug[col][col];
+            for (int c = 0; c < 8; ++c) aug[col][c] /= d;
+            for (int r = 0; r < 4; ++r) if (r != col) { const double f = aug[r][col]; for (int c = 0; c < 8; ++c) aug[r][c] -= f * aug[col][c]; }
+        }
+        for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) inv[r * 4 + c] = aug[r][4 + c];
+    }
+    for (long i = 0; i < n; ++i) {
+        double tq = t[i];
+        if (tq < key_t[0]) tq = key_t[0];
+        if (tq > key_t[M - 1]) tq = key_t[M - 1];
+        int lo = 0, hi = M;
+        while (lo < hi) { const int mid = (lo + hi) / 2; if (key_t[mid] < tq) lo = mid + 1; else hi = mid; }
+        int ind = lo - 1;
+        if (ind < 0) ind = 0;
+        if (ind > M - 2) ind = M - 2;
+        const double hh = key_t[ind + 1] - key_t[ind], alpha = (tq - key_t[ind]) / hh;
+        const double r3[3] = {rv[ind * 3] * alpha, rv[ind * 3 + 1] * alpha, rv[ind * 3 + 2] * alpha};
+        const double ang = sqrt(r3[0] * r3[0] + r3[1] * r3[1] + r3[2] * r3[2]);
+        const double sc = ang <= 1e-3 ? 0.5 - ang * ang / 48 + ang * ang * ang * ang / 3840 : sin(ang / 2) / ang;
+        const double dq[4] = {r3[0] * sc, r3[1] * sc, r3[2] * sc, cos(ang / 2)};
+        double qq[4];
+        evo_qmul(q + ind * 4, dq, qq);
+        const double x = qq[0], y = qq[1], z = qq[2], w = qq[3];
+        const double R[9] = {x * x - y * y - z * z + w * w, 2 * (x * y - z * w), 2 * (x * z + y * w),
+                             2 * (x * y + z * w), -x * x + y * y - z * z + w * w, 2 * (y * z - x * w),
+                             2 * (x * z - y * w), 2 * (y * z + x * w), -x * x - y * y + z * z + w * w};
+        double T[3];
+        for (int dim = 0; dim < 3; ++dim) {      /* the interval's cubic from its end values and second derivatives */
+            const double y0 = key_poses[ind * 12 + dim * 4 + 3], y1 = key_poses[(ind + 1) * 12 + dim * 4 + 3];
+            const double ma = m2[ind * 3 + dim], mb = m2[(ind + 1) * 3 + dim], dd = (y1 - y0) / hh;
+            const double c1 = hh * dd - hh * hh * (2 * ma + mb) / 6, c2 = hh * hh * ma / 2, c3 = hh * hh * (mb - ma) / 6;
+            T[dim] = y0 + alpha * (c1 + alpha * (c2 + alpha * c3));
+        }
+        float P[12];
+        for (int r = 0; r < 3; ++r) {
+            P[r * 4] = (float)R[r * 3 + 1];
+            P[r * 4 + 1] = (float)(-R[r * 3]);
+            P[r * 4 + 2] = (float)R[r * 3 + 2];
+            P[r * 4 + 3] = (float)T[r] * bd_scale;
+        }
+        float* out = poses + i * 12;
+        if (!recenter_c2w44) { memcpy(out, P, sizeof(P)); continue; }
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 4; ++c) {
+                double acc = inv[r * 4] * (double)P[c] + inv[r * 4 + 1] * (double)P[4 + c] + inv[r * 4 + 2] * (double)P[8 + c];
+                if (c == 3) acc += inv[r * 4 + 3];
+                out[r * 4 + c] = (float)acc;
+            }
+    }
+    free(q); free(rv); free(m2);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ image batch assembly
+ * data/loader.py:325-356 LLFFDataset.__getitem__: unravel_index in C order (:118-123), poses[img_id], images[img_id, y, x],
+ * get_rays_pix on the integer pixel with the half-pixel offset (utils/rays.py:25-36: (x + (0.5 - K02)) / K00, the bracket a Python double
+ * rounded to float32 when it meets the tensor), rays_x / rays_y = pixel + HALF_PIX.  Returns the number of ids outside the dataset
+ * (the reference raises an IndexError for those; their outputs are zeros, image id -1). */
+long evo_image_batch(const long long* ids, long n, const float* images, const float* pts0, const float* poses, int n_img, int H, int W,
+                     const float* K, float* rays, float* rays_x, float* rays_y, long long* img_idx, float* rgb, float* poses_out, float* rgb0) {
+    const long long hw = (long long)H * W;
+    const float hx = (float)(0.5 - (double)K[2]), hy = (float)(0.5 - (double)K[5]);
+    long bad = 0;
+    for (long i = 0; i < n; ++i) {
+        const long long id = ids[i];
+        if (id < 0 || id >= hw * n_img) {
+            ++bad;
+            for (int k = 0; k < 6; ++k) rays[i * 6 + k] = 0.f;
+            rays_x[i] = rays_y[i] = 0.f; img_idx[i] = -1;
+            for (int k = 0; k < 3; ++k) { rgb[i * 3 + k] = 0.f; if (rgb0) rgb0[i * 3 + k] = 0.f; }
+            if (poses_out) for (int k = 0; k < 12; ++k) poses_out[i * 12 + k] = 0.f;
+            continue;
+        }
+        const long long im = id / hw, rem = id % hw;
+        const int y = (int)(rem / W), x = (int)(rem % W);
+        const float* c2w = poses + im * 12;
+        const float d0 = ((float)x + hx) / K[0], d1 = -((float)y + hy) / K[4], d2 = -1.f;
+        for (int r = 0; r < 3; ++r) {
+            rays[i * 6 + r * 2] = c2w[r * 4 + 3];
+            rays[i * 6 + r * 2 + 1] = d0 * c2w[r * 4] + d1 * c2w[r * 4 + 1] + d2 * c2w[r * 4 + 2];
+        }
+        rays_x[i] = (float)x + 0.5f; rays_y[i] = (float)y + 0.5f; img_idx[i] = im;
+        for (int k = 0; k < 3; ++k) { rgb[i * 3 + k] = images[id * 3 + k]; if (rgb0) rgb0[i * 3 + k] = pts0[id * 3 + k]; }
+        if (poses_out) memcpy(poses_out + i * 12, c2w, sizeof(float) * 12);
+    }
+    return bad;
+}

@@ -220,20 +220,20 @@ def sample_pdf(bins, w, N, det=True, u=None):
     return out
 
 
-def get_rays(H, W, K, c2w):
+def get_rays(H, W, K, c2w, add_halfpix=True):
     K, c2w = _f(K), _f(c2w)
     o = np.empty((H, W, 3), np.float32)
     d = np.empty((H, W, 3), np.float32)
-    lib().evo_get_rays(H, W, _p(K), _p(c2w), 1, _p(o), _p(d))
+    lib().evo_get_rays(H, W, _p(K), _p(c2w), int(bool(add_halfpix)), _p(o), _p(d))
     return o, d
 
 
-def get_rays_pix(coords, K, c2ws):
+def get_rays_pix(coords, K, c2ws, add_halfpix=True):
     coords, K, c2ws = _f(coords), _f(K), _f(c2ws)
     n = coords.shape[0]
     o = np.empty((n, 3), np.float32)
     d = np.empty((n, 3), np.float32)
-    lib().evo_get_rays_pix(_p(coords), _p(K), _p(c2ws), C.c_long(n), 1, _p(o), _p(d))
+    lib().evo_get_rays_pix(_p(coords), _p(K), _p(c2ws), C.c_long(n), int(bool(add_halfpix)), _p(o), _p(d))
     return o, d
 
 
@@ -362,6 +362,56 @@ def sample_events(events, id_to_coords, poses, events_ids, K, hops=None, id_to_c
                             succ.ctypes.data_as(lp))
     return {"events_pos_pol_cumsum": pos, "events_neg_pol_cumsum": neg, "events_rays_start": rs, "events_rays_end": re,
             "events_coords_ids": cid, "events_color_map": cmo.astype(bool) if cmo is not None else None, "successor": succ}
+
+
+def interpolate_poses(key_t, key_poses, t, bd_scale=1.0, recenter_c2w=None):
+    """data/loader_events.py:133-148: key_t [M], key_poses [M, 3, 4] float64, t [n] -> [n, 4, 4] float32 (fourth row 0 0 0 1)"""
+    kt = np.ascontiguousarray(key_t, dtype=np.float64)
+    kp = np.ascontiguousarray(np.asarray(key_poses, dtype=np.float64)[:, :3, :4])
+    tt = np.ascontiguousarray(t, dtype=np.float64).reshape(-1)
+    dp = C.POINTER(C.c_double)
+    c44 = None
+    if recenter_c2w is not None:
+        c = np.asarray(recenter_c2w, dtype=np.float64)
+        c44 = np.ascontiguousarray(np.concatenate([c[:3, :4], np.array([[0, 0, 0, 1.0]])], 0))
+    out = np.empty((tt.shape[0], 3, 4), np.float32)
+    fn = lib().evo_interpolate_poses
+    fn.restype = C.c_int
+    rc = fn(kt.ctypes.data_as(dp), kp.ctypes.data_as(dp), int(kt.shape[0]), C.c_float(bd_scale), c44.ctypes.data_as(dp) if c44 is not None else None,
+            tt.ctypes.data_as(dp), C.c_long(tt.shape[0]), _p(out))
+    if rc != 0:
+        raise ValueError("interpolate_poses: >= 4 key poses with strictly ascending timestamps")
+    full = np.zeros((tt.shape[0], 4, 4), np.float32)
+    full[:, :3] = out
+    full[:, 3, 3] = 1.0
+    return full
+
+
+def sample_events_track(events, id_to_coords, key_t, key_poses, events_ids, K, bd_scale=1.0, recenter_c2w=None, **kw):
+    """sample_events with the per-event poses from interpolate_poses at the events' timestamps (column ncol-3), loader_events.py:280-283"""
+    ev = np.asarray(events, dtype=np.float64)
+    poses = interpolate_poses(key_t, key_poses, ev[:, -3], bd_scale, recenter_c2w)[:, :3, :4]
+    return sample_events(ev, id_to_coords, poses, events_ids, K, **kw)
+
+
+def image_batch(ray_ids, images, poses, K, pts0_images=None):
+    """data/loader.py:325-356 -> the reference's dict (+ 'n_invalid')"""
+    ids = np.ascontiguousarray(ray_ids, dtype=np.int64).reshape(-1)
+    im, po, Kf = _f(images), _f(np.asarray(poses)[:, :3, :4]), _f(np.asarray(K).reshape(-1))
+    p0 = _f(pts0_images) if pts0_images is not None else None
+    n = ids.shape[0]
+    n_img, H, W = im.shape[:3]
+    rays, rx, ry = np.empty((n, 3, 2), np.float32), np.empty((n, 1), np.float32), np.empty((n, 1), np.float32)
+    idx, rgb, pout = np.empty((n, 1), np.int64), np.empty((n, 3), np.float32), np.empty((n, 3, 4), np.float32)
+    rgb0 = np.empty((n, 3), np.float32) if p0 is not None else None
+    fn = lib().evo_image_batch
+    fn.restype = C.c_long
+    bad = fn(ids.ctypes.data_as(C.POINTER(C.c_longlong)), C.c_long(n), _p(im), _p(p0) if p0 is not None else None, _p(po), int(n_img), int(H), int(W),
+             _p(Kf), _p(rays), _p(rx), _p(ry), idx.ctypes.data_as(C.POINTER(C.c_longlong)), _p(rgb), _p(pout), _p(rgb0) if rgb0 is not None else None)
+    out = {"rays": rays, "rays_x": rx, "rays_y": ry, "images_idx": idx, "rgbsf": rgb, "poses": pout, "n_invalid": int(bad)}
+    if rgb0 is not None:
+        out["rgbsf_pts0"] = rgb0
+    return out
 
 
 def rbk_warp(rays, r, v, num_motion, use_origin=True, want_transform=False):

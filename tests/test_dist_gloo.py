@@ -183,6 +183,97 @@ def test_two_rank_gradient_allreduce_on_flat_buffers_in_place():
             assert np.allclose(a, b, rtol=1e-6, atol=1e-6)
 
 
+def _accum_worker(rank, world, port, q):
+    """GradReducer.attach with gradient accumulation: stand-in levels drive voxnerf's counting hooks the way the
+    library's autograd nodes do (_fwd_noted at a forward under autograd, _bwd_done when a backward node has added into the level's
+    in-place buffer).  Two micro-batches per step: the first backward inside no_sync() must NOT start a collective, the second one
+    does, and the reduced buffers hold the sum over both micro-batches and both ranks.  Without no_sync() the second micro-batch's
+    forward raises before anything is added."""
+    import types
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.pop("EVD_NO_EARLY_ALLREDUCE", None)
+    from evdeblurnerf_amd import dist as D
+    from evdeblurnerf_amd.voxnerf import _bwd_done, _fwd_noted
+    D.init_from_env("gloo")
+    bufs = [torch.zeros(n) for n in (300, 5000, 200, 900)]             # per level [networks, grids]
+    groups = []
+    for b in bufs:
+        p = torch.nn.Parameter(torch.zeros(b.numel()))
+        p.grad = b[:]
+        groups.append((b, [p]))
+    model = types.SimpleNamespace(mlp_coarse=types.SimpleNamespace(), mlp_fine=types.SimpleNamespace())
+    red = D.GradReducer([], flat_buffers=groups).attach(model)
+    g = torch.Generator().manual_seed(50 + rank)
+
+    def micro_batch(levels=(model.mlp_fine, model.mlp_coarse)):
+        with torch.enable_grad():
+            for lv in levels:                                          # gather + networks of each level
+                _fwd_noted(lv)
+                _fwd_noted(lv)
+        for li, lv in ((1, model.mlp_fine), (0, model.mlp_coarse)):   # backward: fine level first
+            for k in range(2):
+                bufs[li * 2 + k] += torch.randn(bufs[li * 2 + k].numel(), generator=g)
+                _bwd_done(lv)
+    with red.no_sync():
+        micro_batch()
+        assert red.early_starts == 0
+        try:
+            red.start()
+            raise AssertionError("start() inside no_sync() must raise")
+        except RuntimeError:
+            pass
+    micro_batch()
+    assert red.early_starts == 4                                      # both levels' two buffers started from inside the "backward"
+    red.start()
+    red.wait()
+    out = [b.clone() for b in bufs]
+    # misuse: a second micro-batch after an armed backward
+    for b in bufs:
+        b.zero_()
+    micro_batch()
+    raised = False
+    try:
+        micro_batch()
+    except RuntimeError as e:
+        raised = "no_sync" in str(e)
+    red.start()
+    red.wait()
+    # EVD_NO_EARLY_ALLREDUCE: attach installs nothing
+    os.environ["EVD_NO_EARLY_ALLREDUCE"] = "1"
+    m2 = types.SimpleNamespace(mlp_coarse=types.SimpleNamespace(), mlp_fine=types.SimpleNamespace())
+    D.GradReducer([], flat_buffers=groups).attach(m2)
+    q.put((rank, [o.numpy() for o in out], raised, getattr(m2.mlp_fine, "_grads_ready_cb", None) is None))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_accumulation_with_no_sync():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_accum_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sizes = (300, 5000, 200, 900)
+    expect = [np.zeros(n, np.float32) for n in sizes]
+    for rank in range(world):
+        g = torch.Generator().manual_seed(50 + rank)
+        for _ in range(2):                                             # two micro-batches, fine level (buffers 2, 3) first
+            for i in (2, 3, 0, 1):
+                expect[i] += torch.randn(sizes[i], generator=g).numpy()
+    for rank, out, raised, env_off in res:
+        assert raised and env_off
+        for a, b in zip(out, expect):
+            assert np.allclose(a, b, rtol=1e-6, atol=1e-6)
+
+
 def test_shard_range_partitions():
     from evdeblurnerf_amd.dist import shard_range
     for n in (0, 1, 7, 8, 4096, 160000):

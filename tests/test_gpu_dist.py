@@ -84,7 +84,9 @@ def _step(rank, world):
     return float(loss.detach()), {k: v.grad.detach().cpu().numpy() for k, v in model.named_parameters()}
 
 
-def _worker(rank, world, port, q, backend="gloo", mode="nerf"):
+def _worker(rank, world, port, q, backend="gloo", mode="nerf", side_spin_us=0):
+    if side_spin_us:
+        os.environ["EVD_TEST_SIDE_SPIN_US"] = str(side_spin_us)          # read once, when the library first forks to a side stream
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     dev = rank if backend == "nccl" else 0            # RCCL: one GPU per rank; gloo: the ranks share GPU 0
@@ -99,14 +101,14 @@ def _worker(rank, world, port, q, backend="gloo", mode="nerf"):
     dist.destroy_process_group()
 
 
-def _two_ranks(backend, mode):
+def _two_ranks(backend, mode, side_spin_us=0):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, backend, mode)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, backend, mode, side_spin_us)) for r in range(2)]
     for p in procs:
         p.start()
     got = [q.get(timeout=600) for _ in range(2)]
@@ -135,6 +137,21 @@ def test_two_rank_training_step_equals_single_process():
 def test_two_rank_c2f_step_with_early_allreduce_equals_single_process():
     """mode='c2f', in-place gradient buffers, a level's all-reduce started from inside the backward (dist.GradReducer.attach)"""
     _two_ranks("gloo", "c2f")
+
+
+def test_early_allreduce_is_ordered_behind_a_delayed_side_stream():
+    """the level's all-reduce is started from inside the backward pass while the backward entry ran its wgrad
+    launches on a per-handle side stream.  Every side-stream launch is delayed by 2 ms here (EVD_TEST_SIDE_SPIN_US, a spin kernel in
+    front of it): the reduced buffers still equal the single-process gradient, i.e. the entry's join of the side stream into the
+    caller's stream (hipEventRecord(side) + hipStreamWaitEvent(stream) before it returns) orders the collective behind them."""
+    _two_ranks("gloo", "c2f", side_spin_us=2000)
+
+
+@pytest.mark.parametrize("spin", [0, 2000])
+def test_early_allreduce_over_rccl_with_a_delayed_side_stream(spin):
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL: one device per rank)")
+    _two_ranks("nccl", "c2f", side_spin_us=spin)
 
 
 @pytest.mark.parametrize("mode", ["nerf", "c2f"])

@@ -693,7 +693,7 @@ def test_c2f_training_gradients_against_the_reference_golden():
     _g19_check("f16", 0.15, 0.01, 3e-3)
 
 
-def _g19_check(prec, tol, tol_tight, rgb_tol, elem_tol=None):
+def _g19_check(prec, tol, tol_tight, rgb_tol, elem_tol=None, golden="G19_c2f_grads", median_tol=None):
     """G19: gradients computed by torch.autograd ON THE REFERENCE (its whole mode='c2f' training forward: NDC ray packing, both
     levels, resampling, TV) vs the HIP training path run on the same rays and weights.  Bounded by the half-precision ReLU flips and
     the slightly different resampled positions (the kernels' own coarse weights feed sample_pdf): norms and seeded projections of all
@@ -703,7 +703,7 @@ def _g19_check(prec, tol, tol_tight, rgb_tol, elem_tol=None):
     from types import SimpleNamespace
     from evdeblurnerf_amd.renderer import NeRFAll
     from torch_restatement import grad_summary
-    g = load_golden("G19_c2f_grads")
+    g = load_golden(golden)
     gc, gf = [int(v) for v in g["grid_coarse"]], [int(v) for v in g["grid_fine"]]
     sd = dict(W.prefixed(W.make_pdrf_state_dict(91, gc, input_ch=95, hidden_dim=64, geo_feat_dim=15, add_bias_color=True), "mlp_coarse"))
     sd.update(W.prefixed(W.make_pdrf_state_dict(92, gf, input_ch=127, hidden_dim=256, geo_feat_dim=128, add_bias_color=True), "mlp_fine"))
@@ -745,8 +745,12 @@ def _g19_check(prec, tol, tol_tight, rgb_tol, elem_tol=None):
         print(f"G19 vs kernels ({prec}), worst element error / largest pinned element:", {k: f"{v:.1e}" for k, v in sorted(elem.items(), key=lambda kv: -kv[1])[:6]})
         assert max(elem.values()) < elem_tol, {k: f"{v:.1e}" for k, v in sorted(elem.items(), key=lambda kv: -kv[1])[:8]}
     tight = [k for k in keys if k.endswith("color_net.2.weight") or k.endswith("color_net.2.bias")]
-    print(f"G19 vs kernels ({prec}), worst (norm / projection error) / norm:", {k: f"{v:.1e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:6]})
-    assert max(worst.values()) < tol, {k: f"{v:.1e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])}
+    med = float(np.median(list(worst.values())))
+    print(f"{golden} vs kernels ({prec}), (norm / projection error) / norm: median {med:.1e}, worst:", {k: f"{v:.1e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:6]})
+    if tol is not None:
+        assert max(worst.values()) < tol, {k: f"{v:.1e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])}
+    if median_tol is not None:
+        assert med < median_tol, med
     assert max(worst[k] for k in tight) < tol_tight
     return worst
 

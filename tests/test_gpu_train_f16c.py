@@ -142,12 +142,24 @@ def test_f16c_training_forward_is_the_inference_arithmetic():
 def test_mixed_c2f_training_gradients_against_the_reference_golden():
     """G19 -- torch.autograd ON THE REFERENCE's whole mode='c2f' training forward (24 rays, 768 fine samples).  f16m: rendered colours
     within 2e-5, all 30 parameter gradients and the ray gradient within 2e-3 of the gradient norm (single-product float16: 3e-3 /
-    15 %).  f16c: colours within 1e-4; gradients within the flip bound of this tiny batch (module docstring; one flipped unit of a
-    dominant sample: measured 9e-2 on the rays, 7e-2 on one plane), the layers behind no ReLU within 2e-3."""
+    15 %).  f16c: colours within 1e-4 and the layers behind no ReLU within 2e-3; on 768 samples one flipped ReLU unit of a dominant
+    sample is several % of a small tensor's gradient, so f16c's gradient BOUND is asserted on G30 (16 384 samples, next test), not here."""
     from test_gpu_train import _g19_check
     w = _g19_check("f16m", 2e-3, 2e-3, 2e-5)
     print("G19 f16m worst:", max(w.values()))
-    _g19_check("f16c", 0.15, 2e-3, 1e-4)
+    w = _g19_check("f16c", None, 2e-3, 1e-4)
+    print("G19 f16c worst (reported, bounded on G30):", max(w.values()))
+
+
+@pytest.mark.parametrize("prec,tol,median_tol,rgb_tol", [("f16x3", 1e-4, 3e-5, 5e-6), ("f16m", 2e-3, 1.5e-3, 2e-5), ("f16c", 1e-2, 4e-3, 1e-4)])
+def test_c2f_training_gradients_against_the_reference_at_16384_samples(prec, tol, median_tol, rgb_tol):
+    """G30 -- the G19 measurement on 512 rays x (16 + 16) = 16 384 fine samples, against torch.autograd ON THE REFERENCE (not against
+    another kernel mode): norm and seeded projection of all 30 parameter gradients and of the ray gradient.  The bounds of the three
+    training modes (INTEGRATION.md "Training modes"): f16x3 the float32-grade parity mode; f16m <= 2e-3 -- the mode that HOLDS the
+    reference's gradients; f16c <= 1e-2 worst / <= 4e-3 median -- the ReLU-flip floor of a forward good to 2^-15."""
+    from test_gpu_train import _g19_check
+    w = _g19_check(prec, tol, max(tol, 2e-3) if prec != "f16x3" else 1e-4, rgb_tol, golden="G30_c2f_grads_16k", median_tol=median_tol)
+    print(f"G30 {prec}: worst {max(w.values()):.2e}")
 
 
 @pytest.mark.parametrize("prec", ["f16c", "f16m"])

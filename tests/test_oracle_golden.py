@@ -425,6 +425,99 @@ def test_G26_sample_events():
                                                              add_halfpix=bool(g[f"{tag}_halfpix"])), g, exact_rays=False)
 
 
+def check_image_batch(out, g, exact_rays):
+    """out: dict of numpy arrays with the reference's keys; against golden G28 (LLFFDataset.__getitem__, data/loader.py:325-356)"""
+    for k in ("images_idx", "rgbsf", "rgbsf_pts0", "poses", "rays_x", "rays_y"):             # gathers and integer work: bit-exact
+        ref = g["out_" + k]
+        assert out[k].shape == ref.shape and out[k].dtype == ref.dtype, (k, out[k].shape, ref.shape, out[k].dtype, ref.dtype)
+        assert np.array_equal(out[k], ref), k
+    assert out["rays"].shape == g["out_rays"].shape
+    assert np.array_equal(out["rays"][..., 0], g["out_rays"][..., 0])                      # origins: a gather
+    err = np.abs(out["rays"][..., 1] - g["out_rays"][..., 1]).max()
+    assert (err == 0) if exact_rays else (err < 1e-6), err
+
+
+def test_G28_image_batch():
+    g = load_golden("G28_image_batch")
+    out = O.image_batch(g["ids"], g["images"], g["poses"], g["K"], pts0_images=g["pts0"])
+    assert out["n_invalid"] == 0
+    check_image_batch(out, g, exact_rays=False)
+    assert "rgbsf_pts0" not in O.image_batch(g["ids"], g["images"], g["poses"], g["K"])
+    bad = O.image_batch(np.array([-1, 5, g["images"][..., 0].size]), g["images"], g["poses"], g["K"])
+    assert bad["n_invalid"] == 2 and list(bad["images_idx"][:, 0]) == [-1, 0, -1]
+
+
+def test_G28_rays_without_the_half_pixel():
+    """utils/rays.py:8-36 with add_halfpix=False (rectified event coordinates, data/loader_events.py:290-293)"""
+    g = load_golden("G28_image_batch")
+    o, d = O.get_rays_pix(g["nohalf_coords"], g["K"], g["nohalf_c2ws"], add_halfpix=False)
+    assert np.array_equal(o, g["nohalf_pix_o"]) and np.abs(d - g["nohalf_pix_d"]).max() < 1e-6
+    H, Wd = g["images"].shape[1:3]
+    o, d = O.get_rays(H, Wd, g["K"], g["poses"][1], add_halfpix=False)
+    assert np.array_equal(o, g["nohalf_full_o"]) and np.abs(d - g["nohalf_full_d"]).max() < 1e-6
+    o1, d1 = O.get_rays_pix(g["nohalf_coords"], g["K"], g["nohalf_c2ws"])                  # the default differs
+    assert np.abs(d1 - g["nohalf_pix_d"]).max() > 1e-3
+
+
+POSE_TOL = 5e-7     # one float32 ulp of a pose entry in [2, 4): the float64 evaluations agree to ~1e-15, so at most the final rounding differs (the C oracle: 0 on both tracks)
+
+
+def check_pose_track(interp, sample, g):
+    """interp(tag, t) -> [n, 4, 4]; sample(tag) -> sample_events dict; against golden G29 (the reference's interpolate_poses and
+    sample_events run on scipy)"""
+    worst = 0.0
+    for tag in ("a", "b"):
+        got = interp(tag, g[f"{tag}_tq"])
+        ref = g[f"{tag}_poses"]
+        assert got.shape == ref.shape and got.dtype == np.float32
+        assert np.array_equal(got[:, 3], ref[:, 3])
+        err = np.abs(got - ref).max()
+        worst = max(worst, err)
+        assert err < POSE_TOL, (tag, err)
+        out = sample(tag)
+        assert np.array_equal(out["events_pos_pol_cumsum"], g[f"{tag}_pos"]) and np.array_equal(out["events_neg_pol_cumsum"], g[f"{tag}_neg"])
+        assert np.array_equal(out["events_coords_ids"], g[f"{tag}_cid"])
+        for key in ("events_rays_start", "events_rays_end"):
+            ref = g[key.replace("events_", f"{tag}_")]
+            assert out[key].shape == ref.shape
+            assert np.abs(out[key] - ref).max() < 1e-5, (tag, key, np.abs(out[key] - ref).max())     # the ray direction scales a pose entry by up to ~1.2
+    return worst
+
+
+def test_G29_pose_track():
+    g = load_golden("G29_pose_track")
+    rc = lambda tag: g[f"{tag}_recenter_c2w"] if f"{tag}_recenter_c2w" in g else None
+    K = W.synthetic_camera()
+    check_pose_track(lambda tag, t: O.interpolate_poses(g[f"{tag}_key_t"], g[f"{tag}_key_poses"], t, float(g[f"{tag}_bd_scale"]), rc(tag)),
+                     lambda tag: O.sample_events_track(g[f"{tag}_events"], g[f"{tag}_coords"], g[f"{tag}_key_t"], g[f"{tag}_key_poses"], g[f"{tag}_ids"], K,
+                                                       bd_scale=float(g[f"{tag}_bd_scale"]), recenter_c2w=rc(tag), add_halfpix=bool(g[f"{tag}_intc"])), g)
+    with pytest.raises(ValueError):
+        O.interpolate_poses(g["a_key_t"][:3], g["a_key_poses"][:3], g["a_tq"][:4])
+
+
+def test_pose_track_host_tables_against_the_oracle():
+    """The product's host-side preparation (evdeblurnerf_amd/poses.py: quaternions, rotation vectors, spline polynomials -- numpy,
+    no GPU) evaluated in numpy equals the oracle's from-raw-keys evaluation: the two restatements are independent code."""
+    from evdeblurnerf_amd import poses as P
+    g = load_golden("G29_pose_track")
+    for tag in ("a", "b"):
+        kt, kp = g[f"{tag}_key_t"], g[f"{tag}_key_poses"]
+        q = P.quat_from_matrix(P._orthogonalize(kp[:, :, :3]))
+        rv = P._as_rotvec(P._qmul(q[:-1] * np.array([-1.0, -1, -1, 1]), q[1:]))
+        cf = P.notaknot_cubic(kt, kp[:, :, 3])
+        t = np.clip(g[f"{tag}_tq"], kt[0], kt[-1])
+        ind = np.clip(np.searchsorted(kt, t) - 1, 0, kt.shape[0] - 2)
+        u = (t - kt[ind]) / np.diff(kt)[ind]
+        T = cf[ind, 0] + u[:, None] * (cf[ind, 1] + u[:, None] * (cf[ind, 2] + u[:, None] * cf[ind, 3]))
+        ref = O.interpolate_poses(kt, kp, g[f"{tag}_tq"], 1.0, None)
+        assert np.abs(T.astype(np.float32) - ref[:, :3, 3]).max() < 1e-6
+        ang = np.linalg.norm(rv[ind] * u[:, None], axis=-1)
+        dq = np.concatenate([rv[ind] * u[:, None] * (np.sin(ang / 2) / np.maximum(ang, 1e-300))[:, None], np.cos(ang / 2)[:, None]], -1)
+        qq = P._qmul(q[ind], dq)
+        r00 = qq[:, 0] ** 2 - qq[:, 1] ** 2 - qq[:, 2] ** 2 + qq[:, 3] ** 2                  # R[0, 0] -> column 1 negated in the LLFF layout
+        assert np.abs((-r00).astype(np.float32) - ref[:, 0, 1]).max() < 1e-6
+
+
 # ---- gradients: the float64 torch restatements the GPU training tests compare against (tests/torch_restatement.py) are pinned
 # here to gradients computed by torch.autograd ON THE REFERENCE MODULES (tools/gen_golden.py G18, G19)
 def _check_grad(got, g, key, idx):

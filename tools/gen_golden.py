@@ -54,6 +54,13 @@ def save(name, **arrays):
     print(f"  wrote {os.path.relpath(path, ROOT)}  ({os.path.getsize(path) / 1024:.1f} KiB)")
 
 
+def save64(name, **arrays):
+    """like save(), keeping float64 arrays (timestamps in microseconds do not fit float32)"""
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print(f"  wrote {os.path.relpath(path, ROOT)}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
 # ---------------------------------------------------------------------------
 def G1_embedder():
     from networks.embedding import get_embedder
@@ -757,9 +764,7 @@ def G18_nerf_grads():
     save("G18_nerf_grads", o=o, d=d, z=z, w_rgb=w_rgb, rgb_map=n(rgb_map), loss=np.float64(loss.item()), rgb_map_w256=n(rgb_map2), **out)
 
 
-def G19_c2f_grads():
-    """Gradients of the reference's mode='c2f' training forward (NeRFAll.render in train mode: NDC ray packing, both PDRF levels,
-    hierarchical resampling, TV regulariser) w.r.t. every parameter of both levels and the rays."""
+def _c2f_grads(name, R, ray_seed, rs_seed):
     K = W.synthetic_camera()
     model, _ = _nerfall("c2f", 16, 0, rgb_add_bias=True, **PDRF_SMALL)
     gc = [int(v) for v in model.mlp_coarse.gridSize]
@@ -768,13 +773,12 @@ def G19_c2f_grads():
     sd.update(W.prefixed(W.make_pdrf_state_dict(92, gf, input_ch=64 + 63, hidden_dim=256, geo_feat_dim=128, add_bias_color=True), "mlp_fine"))
     ref_import.load_np_state_dict(model, sd)
     model.train(True)
-    R = 24
-    rays = W.synthetic_rays(19, R)
-    rs = np.random.RandomState(1901)
+    rays = W.synthetic_rays(ray_seed, R)
+    rs = np.random.RandomState(rs_seed)
     w_rgb, w_rgb0 = rs.standard_normal((R, 3)).astype(np.float32), rs.standard_normal((R, 3)).astype(np.float32)
     with torch.enable_grad():
         rt = t(rays).requires_grad_(True)
-        rgb, depth, acc, ex = model.render(400, 400, t(K), 1024, rays=rt, ndc=True, near=0., far=1., use_viewdirs=True, N_samples=16,
+        rgb, depth, acc, ex = model.render(400, 400, t(K), 1 << 20, rays=rt, ndc=True, near=0., far=1., use_viewdirs=True, N_samples=16,
                                            N_importance=16, retraw=True, perturb=0., raw_noise_std=0.)
         tv = (model.mlp_coarse.TV_loss_app() + model.mlp_fine.TV_loss_app()) * 5
         loss = (rgb * t(w_rgb)).sum() + (ex["rgb0"] * t(w_rgb0)).sum() + 0.1 * tv
@@ -783,8 +787,22 @@ def G19_c2f_grads():
     out = {}
     named = [(k, g) for (k, _), g in zip(params, grads) if g is not None] + [("rays", grads[-1])]
     _grad_summaries(named, out, "g.")
-    save("G19_c2f_grads", rays=rays, w_rgb=w_rgb, w_rgb0=w_rgb0, rgb=n(rgb), rgb0=n(ex["rgb0"]), z_vals=n(ex["z_vals"]), z_vals0=n(ex["z_vals0"]),
+    extra = dict(z_vals=n(ex["z_vals"]), z_vals0=n(ex["z_vals0"])) if R <= 64 else {}
+    save(name, rays=rays, w_rgb=w_rgb, w_rgb0=w_rgb0, rgb=n(rgb), rgb0=n(ex["rgb0"]), **extra,
          tv=np.float64(tv.item()), loss=np.float64(loss.item()), grid_coarse=np.array(gc), grid_fine=np.array(gf), **out)
+
+
+def G19_c2f_grads():
+    """Gradients of the reference's mode='c2f' training forward (NeRFAll.render in train mode: NDC ray packing, both PDRF levels,
+    hierarchical resampling, TV regulariser) w.r.t. every parameter of both levels and the rays."""
+    _c2f_grads("G19_c2f_grads", 24, 19, 1901)
+
+
+def G30_c2f_grads_16k():
+    """The G19 measurement at a batch where the ReLU-flip floor of a reduced-precision forward is visible as a statistic, not as one
+    unlucky unit: 512 rays x (16 + 16) = 16 384 fine-level samples through the reference's whole mode='c2f' training forward under
+    torch.autograd.  Same weights and grids as G19; summaries + 512 element pins per tensor."""
+    _c2f_grads("G30_c2f_grads_16k", 512, 30, 3001)
 
 
 def G20_loss_grads():
@@ -1047,12 +1065,126 @@ def G26_sample_events():
                     f"{tag}_rays_end2": n(rays(si))})
     save("G26_sample_events", **out)
 
+def _stub_voxels():
+    """data/loader.py imports utils/voxels.py, whose module-level tensor is created on 'cuda' (:7): not importable without a GPU.  The
+    loader only takes get_bbox3d_for_llff from it (used in __init__, not in the methods called here)."""
+    import types
+    if "utils.voxels" not in sys.modules:
+        m = types.ModuleType("utils.voxels")
+        m.get_bbox3d_for_llff = None
+        sys.modules["utils.voxels"] = m
+
+
+def G28_image_batch():
+    """LLFFDataset.__getitem__ (data/loader.py:325-356) called UNBOUND on an object that carries the attributes the method reads
+    (device, n_imgs, h, w, poses, images, K, pts0_images): the reference's own method body runs, the constructor (disk I/O) does not.
+    Also get_rays / get_rays_pix with add_halfpix=False (utils/rays.py:8-36), the case of rectified event coordinates."""
+    import types
+    _stub_voxels()
+    from data.loader import LLFFDataset
+    from utils.rays import get_rays, get_rays_pix
+    rs = np.random.RandomState(2801)
+    n_img, H, W = 4, 23, 31
+    images = rs.uniform(0, 1, (n_img, H, W, 3)).astype(np.float32)
+    pts0 = rs.uniform(0, 1, (n_img, H, W, 3)).astype(np.float32)
+    ax = rs.standard_normal((n_img, 3)) * 0.2
+    from scipy.spatial.transform import Rotation as Rot
+    poses = np.concatenate([Rot.from_rotvec(ax).as_matrix(), rs.uniform(-0.3, 0.3, (n_img, 3, 1))], -1).astype(np.float32)
+    K = np.array([[61.7, 0, 0.5 * W], [0, 61.7, 0.5 * H], [0, 0, 1]])           # float64, like load_intrinsics (:134-138)
+    fake = types.SimpleNamespace(device="cpu", n_imgs=n_img, h=H, w=W, poses=t(poses), images=t(images), K=K, pts0_images=None)
+    fake.unravel_idx_from_rayid = lambda ray_id: LLFFDataset.unravel_idx_from_rayid(fake, ray_id)
+    ids = rs.randint(0, n_img * H * W, 300).astype(np.int64)
+    ids[:4] = [0, n_img * H * W - 1, W - 1, H * W]                            # corners / first pixel of the second image
+    out = {"images": images, "pts0": pts0, "poses": poses, "K": K.astype(np.float32), "ids": ids}
+    r1 = LLFFDataset.__getitem__(fake, ids.tolist())
+    assert "rgbsf_pts0" not in r1
+    fake.pts0_images = t(pts0)
+    r2 = LLFFDataset.__getitem__(fake, ids.tolist())
+    for k, v in r2.items():
+        out["out_" + k] = n(v)
+        if k in r1:
+            assert np.array_equal(n(r1[k]), n(v))
+    assert out["out_images_idx"].dtype == np.int64 and out["out_rays_x"].dtype == np.float32
+    # add_halfpix=False
+    coords = rs.uniform(0, 30, (64, 2)).astype(np.float32)
+    c2ws = poses[rs.randint(0, n_img, 64)]
+    o, d = get_rays_pix(t(coords), t(K.astype(np.float32)), t(c2ws), add_halfpix=False)
+    o2, d2 = get_rays(H, W, t(K.astype(np.float32)), t(poses[1]), add_halfpix=False)
+    out.update(nohalf_coords=coords, nohalf_c2ws=c2ws, nohalf_pix_o=n(o), nohalf_pix_d=n(d), nohalf_full_o=n(o2), nohalf_full_d=n(d2))
+    save("G28_image_batch", **out)
+
+
+def G29_pose_track():
+    """LLFFEventsDataset.interpolate_poses (data/loader_events.py:133-148) and .sample_events (:259-304) called UNBOUND on an object
+    with the attributes they read.  events_pose_bspl is built as load_event_data builds it (:175-182) from the reference's
+    _get_slerp_interpolator (utils/data.py:34-62; scipy 1.15.3 here).  Two tracks: 'a' 40 keys, recentred with a c2w from the
+    reference's poses_avg, integer coordinates; 'b' 5 keys, no recentring, bd_scale 1, float coordinates (add_halfpix False)."""
+    import types
+    from data.loader_events import LLFFEventsDataset as EV
+    from utils.data import _get_slerp_interpolator, poses_avg
+    from utils.events import compute_successor
+    from scipy.spatial.transform import Rotation as Rot
+    rs = np.random.RandomState(2901)
+    Kc = W.synthetic_camera()
+    out = {}
+    for tag, (M, N, ncoord, nq, recenter, bd_scale, intc) in {"a": (40, 1200, 31 * 17, 200, True, 0.7312, True),
+                                                               "b": (5, 300, 13, 64, False, 1.0, False)}.items():
+        key_t = np.cumsum(rs.uniform(4e3, 3e4, M)) + 1.7e9
+        rv = np.cumsum(rs.standard_normal((M, 3)) * 0.04, 0)
+        Rk = Rot.from_rotvec(rv).as_matrix()
+        Rk = Rk + rs.standard_normal(Rk.shape) * 2e-8                      # a file's rounding: within the loader's 5e-7 purity check
+        Tk = np.cumsum(rs.standard_normal((M, 3)) * 0.03, 0)
+        all_poses = np.concatenate([Rk, Tk[..., None]], -1)               # [M, 3, 4] float64 (all_poses_bounds.npy)
+        interpolator = _get_slerp_interpolator(key_t, all_poses[:, :3, :3], all_poses[:, :3, 3])
+
+        def events_pose_bspl(tq, key_t=key_t, interpolator=interpolator):   # loader_events.py:176-182
+            tq = np.clip(tq, a_min=key_t.min(), a_max=key_t.max())
+            irots, itrans = interpolator(tq)
+            bottom = np.array([0, 0, 0, 1]).reshape(1, 1, -1).repeat(tq.shape[0], axis=0)
+            return np.block([[irots, itrans[..., np.newaxis]], [bottom]]), None
+        c2w = None
+        if recenter:
+            llff = np.concatenate([all_poses[..., 1:2], -all_poses[..., 0:1], all_poses[..., 2:]], -1)
+            llff[:, :3, 3] *= bd_scale
+            hwf = np.tile(np.array([400.0, 400.0, 400.0]).reshape(1, 3, 1), (M, 1, 1))
+            avg = poses_avg(np.concatenate([llff, hwf], -1))              # what recenter_poses(return_c2w=True) computes (utils/data.py:170-172)
+            c2w = np.concatenate([avg[:3, :4], np.array([[0, 0, 0, 1.0]])], 0)
+        # an event stream inside (and slightly beyond) the key range
+        ids = rs.randint(0, ncoord, N).astype(np.int64)
+        tms = np.sort(rs.uniform(key_t[0] - 2e3, key_t[-1] + 2e3, N))
+        pol = rs.choice([-1.0, 1.0], N)
+        ev3 = np.stack([ids, tms, pol], -1)
+        succ, nsucc, _, _ = compute_successor(ev3, flat_xy=True)
+        events = np.concatenate([ev3, succ.reshape(-1, 1)], -1)
+        coords = np.stack([rs.uniform(0, 399, ncoord), rs.uniform(0, 399, ncoord)], -1).astype(np.float32)
+        if intc:
+            coords = np.floor(coords)
+        fake = types.SimpleNamespace(events_pose_bspl=events_pose_bspl, bd_scale=bd_scale, recenter=recenter, recenter_partial=c2w, spherify=False,
+                                     events=torch.tensor(events), device="cpu", K=t(Kc), integer_coords=intc, color_events=False,
+                                     id_to_coords=t(coords), id_to_color_map=None,
+                                     event_accum_min_step=lambda g: 0, event_accum_max_step=lambda g: 0)
+        fake.interpolate_poses = lambda tq, fake=fake: EV.interpolate_poses(fake, tq)
+        tq = np.concatenate([rs.uniform(key_t[0] - 5e3, key_t[-1] + 5e3, 400), key_t, [key_t[0] - 1.0, key_t[-1] + 1.0]])
+        ip = EV.interpolate_poses(fake, tq)
+        assert ip.dtype == np.float32 and ip.shape == (tq.shape[0], 4, 4)
+        with_succ = np.where(nsucc > 0)[0]
+        q = with_succ[rs.randint(0, with_succ.shape[0], nq)].astype(np.int64)
+        se = EV.sample_events(fake, torch.tensor(q), 0)
+        out.update({f"{tag}_key_t": key_t, f"{tag}_key_poses": all_poses, f"{tag}_bd_scale": np.array(bd_scale), f"{tag}_intc": np.array(int(intc)),
+                    f"{tag}_tq": tq, f"{tag}_poses": ip, f"{tag}_events": events, f"{tag}_coords": coords, f"{tag}_ids": q,
+                    f"{tag}_rays_start": n(se["events_rays_start"]), f"{tag}_rays_end": n(se["events_rays_end"]),
+                    f"{tag}_pos": n(se["events_pos_pol_cumsum"]).astype(np.float32), f"{tag}_neg": n(se["events_neg_pol_cumsum"]).astype(np.float32),
+                    f"{tag}_cid": n(se["events_coords_ids"]).astype(np.int64)})
+        if c2w is not None:
+            out[f"{tag}_recenter_c2w"] = c2w
+    save64("G29_pose_track", **out)
+
 
 ALL = [G1_embedder, G2_nerf_mlp, G3_nerf_raw2outputs, G4_voxel_raw2outputs, G5_sample_pdf, G6_rays,
        G7_render_nerf, G8_appfeature, G9_render_c2f, G10_rbk_weighted_sum, G11_crf, G12_egm_loss, G13_edi,
        G14_loss_assembly, G15_awp_feature_integration, G16_rbk_warp, G17_compute_successor, G18_nerf_grads, G19_c2f_grads, G20_loss_grads,
        G21_awp_sample_embed, G22_mam, G23_render_nerf_no_viewdirs, G24_render_other_multires, G25_pbe_composite_feature,
-       G26_sample_events, G27_awp_per_ray]
+       G26_sample_events, G27_awp_per_ray, G28_image_batch, G29_pose_track, G30_c2f_grads_16k]
 
 if __name__ == "__main__":
     want = set(sys.argv[1:])
