@@ -485,6 +485,10 @@ def train_iteration_leg(precision):
                         "losses, TV, backward, Adam, parameter re-pack", "precision": precision, "ms_per_iteration": ms, "rays_per_iteration": nrays,
             "rays_per_s": nrays / (ms * 1e-3),
             "ms_per_iteration_by_mode": modes,
+            "parity_holding_mode": {"mode": "f16m", "ms_per_iteration": modes.get("f16m"),
+                                    "what": "the fastest mode whose GRADIENTS stay within 2e-3 of the norm of the reference's autograd (goldens G19, G30 at 16 384 "
+                                            "samples; tests/test_gpu_train_f16c.py); 'precision' above (f16c) holds the rendered colours to 1e-4 (north_star's bound) "
+                                            "and its gradients to 1e-2 -- the ReLU flip floor of DESIGN 3.6 -- and is NOT the gradient-parity mode"},
             "parity_by_mode": {"what": "tools/train_parity.py: 2048 rays x (16 + 16) samples, the G19 loss; rendered colours and every gradient tensor "
                                        "(30 parameters + rays) against the float32-grade mode f16x3 (= the reference's autograd to 2e-5 on golden G19)",
                                **par,
@@ -685,9 +689,13 @@ def main(argv=None):
                                                 0, 0.0, None, L.ptr(o3), None, L.ptr(o2), L.ptr(ow), L.ptr(o1), None, 0, None, L.stream_ptr()))
             cms = kernel_ms(comp, 10)
             cbytes = Rc * (S * 24 + 32)
-            result["composite"] = {"kernel": "k_composite_rows", "rays": Rc, "samples": S, "ms": cms, "bound": "hbm",
+            result["composite"] = {"kernel": "k_composite_il<2, 4, 3, sigmoid, relu, nt> (round 5: lanes interleaved over the row, non-temporal streams; "
+                                             "EVD_COMPOSITE_FORM=rows restores k_composite_rows)", "rays": Rc, "samples": S, "ms": cms, "bound": "hbm",
                                    "achieved": cbytes / (cms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": cbytes / (cms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": cbytes}
+                                   "frac": cbytes / (cms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": cbytes,
+                                   "traffic_mix_ceiling": {"GBps": 6090, "frac_of_peak": 0.761, "what": "a bare kernel moving the same bytes in the same pattern "
+                                                           "(20 B read + 4 B written per sample, non-temporal, no arithmetic): tools/probes/hbm_mix_probe.hip, "
+                                                           "profiles/r05_composite_ab.log; read-only it reaches 7.05 TB/s, a float4 copy 6.22 TB/s"}}
             del raw_c, z_c, rd_c, o3, o1, o2, ow
         if not a.no_train and not lean:
             # ---- the training kernels on the same workload (next row): forward that keeps the activations and the
@@ -806,6 +814,9 @@ def main(argv=None):
                 n_cpu += R
                 t_cpu = time.perf_counter() - t0
             result["cpu_baseline"] = {"value": n_cpu / t_cpu, "unit": "rays/s", "cores": O.num_threads(), "kind": "port",
+                                      "true_reference": {"rays_per_s": [379, 720], "threads": 8, "where": "the reference's NeRFAll.render (PyTorch, CPU) on this workload, "
+                                                         "timed in the build container (tools/time_reference_cpu.py, BASELINE.md section 2); it cannot travel to the GPU "
+                                                         "box, so it is quoted, not re-timed here", "gpu_over_reference": [result["value"] / 720, result["value"] / 379]},
                                       "sample": f"{n_cpu} rays (the workload's {R} rays x {S} samples, cycled for {t_cpu:.1f} s) through the C oracle, OpenMP over rays on all host cores",
                                       "build": "-O3 -march=native -ffp-contract=fast (throughput build of oracle/evd_oracle.c, compiled on this host)" if fast
                                                else "-O2 -march=x86-64-v3 -ffp-contract=off (the parity-checker build)"}

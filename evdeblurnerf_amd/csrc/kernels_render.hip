@@ -523,6 +523,112 @@ __global__ __launch_bounds__(256) void k_composite_rows(const float* __restrict_
     }
 }
 
+typedef float cs_f4 __attribute__((ext_vector_type(4)));     // native vectors: the non-temporal builtins do not take HIP's float4 / float2
+
+// raw2outputs, interleaved form (round 5): lane l owns samples l, 64 + l, ... (NCH chunks of 64), so that every load / store instruction
+// of the wavefront covers ONE contiguous run (k_composite_rows' lane owns consecutive samples: its 16-byte loads are 32 B apart and every
+// 128-byte line is requested by two instructions).  The transmittance is one DPP product scan per chunk with the running product carried
+// across chunks; channel layout and activations are template constants (k_composite_rows selects them at run time: a select chain per
+// dynamic register index and a switch per activation).  All loads of the wavefront's RPW rays are issued before the first dependent
+// instruction; the streamed raw / z / weights rows move with non-temporal accesses (NT).  A persistent form with the next group's loads
+// in flight under the current group's arithmetic (k_composite_stream) measured 0.55 of 8 TB/s against 0.64 (rows) and 0.72 (this): removed.
+// sum over the 64 lanes, valid in LANE 63 only (row sums, then the two row broadcasts of the scan): 6 DPP adds, no readlane
+__device__ __forceinline__ float wave_sum_to63(float v) {
+    v += dpp_f32<0xb1>(0.f, v);
+    v += dpp_f32<0x4e>(0.f, v);
+    v += dpp_f32<0x141>(0.f, v);
+    v += dpp_f32<0x140>(0.f, v);
+    v += dpp_f32<0x142, 0xa>(0.f, v);
+    v += dpp_f32<0x143, 0xc>(0.f, v);
+    return v;
+}
+
+template <int NCH, int RPW, int SIGMA_CH, int RGB_ACT, int SIGMA_ACT, bool NT>
+__global__ __launch_bounds__(256) void k_composite_il(const float* __restrict__ raw, const float* __restrict__ z,
+                                                      const float* __restrict__ rays_d, int rd_stride, long R, int S, int white_bkgd,
+                                                      float* __restrict__ out_map, float* __restrict__ acc, float* __restrict__ weights,
+                                                      float* __restrict__ depth, const float* __restrict__ noise, float* __restrict__ density) {
+    constexpr int RGB0 = SIGMA_CH == 0 ? 1 : 0;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);              // scalar: the ray index and every row base stay in SGPRs
+    const long r0 = (blockIdx.x * (long)(blockDim.x >> 6) + wave) * RPW;
+    if (r0 >= R) return;
+    cs_f4 v[RPW][NCH];
+    float zi[RPW][NCH];
+    float dd[RPW][3];
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {
+        const long r = min(r0 + q, R - 1);
+        const cs_f4* rw = reinterpret_cast<const cs_f4*>(raw + r * (long)S * 4);
+        const float* zz = z + r * (long)S;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int i = c + 1 < NCH ? c * 64 + lane : min(c * 64 + lane, S - 1);     // only the last chunk can run past the row
+            v[q][c] = NT ? __builtin_nontemporal_load(rw + i) : rw[i];
+            zi[q][c] = NT ? __builtin_nontemporal_load(zz + i) : zz[i];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dd[q][c] = rays_d[r * rd_stride + c];
+    }
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {
+        const long r = r0 + q;
+        if (r >= R) break;
+        const float* d = dd[q];
+        const float norm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
+        float carry = 1.f, a_sum = 0.f, d_sum = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int i = c * 64 + lane;
+            // the next sample's z: the next lane's, and for lane 63 the next chunk's lane 0
+            const float z_up = c + 1 < NCH ? __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, zi[q][c + 1 < NCH ? c + 1 : 0]))) : 0.f;
+            const float zn = dpp_f32<0x130>(z_up, zi[q][c]);              // wave_shl:1, lane 63 keeps `old`
+            const cs_f4 v4 = v[q][c];
+            float sraw = SIGMA_CH == 0 ? v4.x : v4.w;
+            const float dist = __fmul_rn(__fsub_rn(zn, zi[q][c]), norm);
+            // the training node's optional extras (nerf.py:106-111 raw noise; the activated density it returns): S - 1 columns per ray
+            if (noise && i < S - 1) sraw = __fadd_rn(sraw, noise[r * (long)(S - 1) + i]);
+            const float dens = act_fast(SIGMA_ACT, sraw);
+            if (density && i < S - 1) density[r * (long)(S - 1) + i] = dens;
+            // 1 - exp(-sigma dist) with the hardware exp2 (absolute error of alpha <= 1e-7, the size of its own float32 rounding)
+            float alpha = __fadd_rn(-__expf(-__fmul_rn(dens, dist)), 1.f);
+            float om = __fadd_rn(-alpha, 1.f);
+            if (c + 1 == NCH) {                                           // the row's last sample (alpha forced to 1, nerf.py:113-114) and the lanes behind it
+                alpha = i < S - 1 ? alpha : (i == S - 1 ? 1.f : 0.f);
+                om = i < S - 1 ? om : (i == S - 1 ? 0.f : 1.f);
+            }
+            const float incl = wave_scan_mul_dpp(om);
+            const float T = carry * dpp_f32<0x138>(1.f, incl);            // wave_shr:1 -> exclusive product; lane 0 keeps 1
+            if (c + 1 < NCH) carry *= __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, incl), 63));
+            const float w = alpha * T;                                    // (alpha = 0 behind the row's end)
+            if (weights && (c + 1 < NCH || i < S)) {
+                float* wo = weights + r * (long)S + i;
+                if (NT) __builtin_nontemporal_store(w, wo); else *wo = w;
+            }
+            a_sum += w;
+            d_sum += w * zi[q][c];
+            c0 += w * act_fast(RGB_ACT, RGB0 ? v4.y : v4.x);
+            c1 += w * act_fast(RGB_ACT, RGB0 ? v4.z : v4.y);
+            c2 += w * act_fast(RGB_ACT, RGB0 ? v4.w : v4.z);
+        }
+        a_sum = wave_sum_to63(a_sum);
+        d_sum = wave_sum_to63(d_sum);
+        c0 = wave_sum_to63(c0);
+        c1 = wave_sum_to63(c1);
+        c2 = wave_sum_to63(c2);
+        if (lane == 63) {
+            if (acc) acc[r] = a_sum;
+            if (depth) depth[r] = d_sum;
+            if (out_map) {
+                const float bg = white_bkgd ? 1.f - a_sum : 0.f;
+                out_map[r * 3] = white_bkgd ? c0 + bg : c0;
+                out_map[r * 3 + 1] = white_bkgd ? c1 + bg : c1;
+                out_map[r * 3 + 2] = white_bkgd ? c2 + bg : c2;
+            }
+        }
+    }
+}
+
 // derivative of evd::act / act_fast at x (y = the activation's value where that is cheaper)
 __device__ __forceinline__ float act_grad(int code, float x) {
     switch (code) {
@@ -930,6 +1036,34 @@ int evd_raw2outputs(const float* raw, const float* z, const float* rays_d, int r
     EVD_REQUIRE(!(fmap || (n_rgb != 3 && out_map)) || weights, "evd_raw2outputs: weights output required for feature maps");
     if (R == 0) return EVD_OK;
     hipStream_t st = as_stream(stream);
+    // interleaved form: the two channel layouts / activation sets the renderer produces (NeRF: rgb sigmoid, sigma last; PDRF levels: sigma
+    // first, colour already sigmoided -> relu (coarse) / none (fine)), with the training node's raw noise / density output (not rmnear).  EVD_COMPOSITE_FORM=rows:
+    // round 4's kernel; EVD_COMPOSITE_NT=0: plain loads / stores; EVD_COMPOSITE_RPW=1|2|4: rays per wavefront (default by R)
+    static const bool il_form = [] { const char* e = getenv("EVD_COMPOSITE_FORM"); return !e || e[0] == 'i'; }();
+    static const bool il_nt = [] { const char* e = getenv("EVD_COMPOSITE_NT"); return !e || e[0] != '0'; }();
+    static const int il_rpw_env = [] { const char* e = getenv("EVD_COMPOSITE_RPW"); return e ? atoi(e) : 0; }();
+    const int il_rpw = il_rpw_env ? il_rpw_env : (R >= (1L << 17) ? 4 : R >= (1L << 14) ? 2 : 1);     // >= 4 workgroups per CU before rays share a wavefront
+    if (il_form && n_rgb == 3 && C == 4 && S <= 256 && !(rmnear_thresh > 0.f) && sigma_act == EVD_ACT_RELU &&
+        ((sigma_ch == 3 && rgb_ch0 == 0 && rgb_act == EVD_ACT_SIGMOID) ||
+         (sigma_ch == 0 && rgb_ch0 == 1 && (rgb_act == EVD_ACT_RELU || rgb_act == EVD_ACT_NONE)))) {
+#define EVD_IL3(NCH, RPW, SC, RA, NT) k_composite_il<NCH, RPW, SC, RA, EVD_ACT_RELU, NT><<<(unsigned)cdiv(R, 4 * RPW), 256, 0, st>>>(raw, z, rays_d, rays_d_stride, R, S, white_bkgd, out_map, acc, weights, depth, noise, density)
+#define EVD_IL2(NCH, SC, RA, NT) do { if (il_rpw == 4) EVD_IL3(NCH, 4, SC, RA, NT); else if (il_rpw == 1) EVD_IL3(NCH, 1, SC, RA, NT); else EVD_IL3(NCH, 2, SC, RA, NT); } while (0)
+#define EVD_IL1(SC, RA, NT) do { if (S <= 64) EVD_IL2(1, SC, RA, NT); else if (S <= 128) EVD_IL2(2, SC, RA, NT); else if (S <= 192) EVD_IL2(3, SC, RA, NT); else EVD_IL2(4, SC, RA, NT); } while (0)
+#define EVD_IL0(SC, RA) do { if (il_nt) EVD_IL1(SC, RA, true); else EVD_IL1(SC, RA, false); } while (0)
+        if (sigma_ch == 3) EVD_IL0(3, EVD_ACT_SIGMOID);
+        else if (rgb_act == EVD_ACT_RELU) EVD_IL0(0, EVD_ACT_RELU);
+        else EVD_IL0(0, EVD_ACT_NONE);
+#undef EVD_IL0
+#undef EVD_IL1
+#undef EVD_IL2
+#undef EVD_IL3
+        EVD_LAUNCH_CHECK();
+        if (fmap && feature && F > 0) {
+            k_weighted_channels<<<R, F >= 256 ? 256 : 64, 0, st>>>(feature, weights, R, S, F, 0, F, EVD_ACT_NONE, 0, fmap);
+            EVD_LAUNCH_CHECK();
+        }
+        return EVD_OK;
+    }
     if (n_rgb == 3 && C == 4 && S <= 256) {
         // bandwidth form: every lane owns SPL consecutive samples
         static const int rpw = [] { const char* e = getenv("EVD_COMPOSITE_RPW"); return e ? atoi(e) : 2; }();

@@ -151,7 +151,7 @@ def test_mixed_c2f_training_gradients_against_the_reference_golden():
     print("G19 f16c worst (reported, bounded on G30):", max(w.values()))
 
 
-@pytest.mark.parametrize("prec,tol,median_tol,rgb_tol", [("f16x3", 1e-4, 3e-5, 5e-6), ("f16m", 2e-3, 1.5e-3, 2e-5), ("f16c", 1e-2, 4e-3, 1e-4)])
+@pytest.mark.parametrize("prec,tol,median_tol,rgb_tol", [("f16x3", 1e-3, 1e-4, 5e-6), ("f16m", 2e-3, 1.5e-3, 2e-5), ("f16c", 1e-2, 4e-3, 1e-4)])
 def test_c2f_training_gradients_against_the_reference_at_16384_samples(prec, tol, median_tol, rgb_tol):
     """G30 -- the G19 measurement on 512 rays x (16 + 16) = 16 384 fine samples, against torch.autograd ON THE REFERENCE (not against
     another kernel mode): norm and seeded projection of all 30 parameter gradients and of the ray gradient.  The bounds of the three
