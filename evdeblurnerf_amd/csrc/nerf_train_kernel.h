@@ -548,19 +548,21 @@ struct WreduceParams {
     float* db;                         // or null
     const unsigned* maxbits;
     int accum = 0;                     // 1: add into dW / db (the caller's persistent gradient buffers) instead of overwriting them
+    long part_stride = 0;              // floats between two workgroups' block sets (0: RT * NC * 1024, the sets of ONE layer back to back)
 };
 
 // A block sums 64 float4 columns of the partials (4 slices of the workgroup list, folded through LDS), then scatters
 // the 256 sums: accumulator element (rt, c, lane, i) -> dW[rowmap[..]][colmap[..]]
-static __global__ __launch_bounds__(256) void k_wgrad_reduce(const WreduceParams p) {
+static __device__ __forceinline__ void wgrad_reduce_block(const WreduceParams& p, int bx) {
     __shared__ f32x4 fold[4][64];
-    const long per = (long)p.RT * p.NC * 1024, v4 = (long)blockIdx.x * 64 + (threadIdx.x & 63);
+    const long per = (long)p.RT * p.NC * 1024, v4 = (long)bx * 64 + (threadIdx.x & 63);
+    const long pstride = p.part_stride ? p.part_stride : per;
     const int slice = threadIdx.x >> 6;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (v4 * 4 < per) {
         const f32x4* src = reinterpret_cast<const f32x4*>(p.partial) + v4;
 #pragma unroll 4
-        for (int q = slice; q < p.nparts; q += 4) s += src[(long)q * (per / 4)];
+        for (int q = slice; q < p.nparts; q += 4) s += src[(long)q * (pstride / 4)];
     }
     fold[slice][threadIdx.x & 63] = s;
     __syncthreads();
@@ -585,6 +587,13 @@ static __global__ __launch_bounds__(256) void k_wgrad_reduce(const WreduceParams
         }
     }
 }
+static __global__ __launch_bounds__(256) void k_wgrad_reduce(const WreduceParams p) { wgrad_reduce_block(p, blockIdx.x); }
+
+// several layers' reductions in one launch (blockIdx.y = layer; the fused backward of voxel_bwd_fused64.h leaves all its layers' blocks
+// in one set per workgroup); a layer whose gradient is not wanted has RT = 0
+constexpr int WREDUCE_MAX_JOBS = 5;
+struct WreduceJobs { WreduceParams j[WREDUCE_MAX_JOBS]; };
+static __global__ __launch_bounds__(256) void k_wgrad_reduce_jobs(const WreduceJobs jobs) { wgrad_reduce_block(jobs.j[blockIdx.y], blockIdx.x); }
 
 // The split-float16 (float32-grade) form: both operands are (hi, lo) pairs; each half is transposed on its own (exact), the products
 // are yh xh into acc and yh xl + yl xh into a second accumulator (scaled by 2^11, like the forward's cross terms).  Plain global loads

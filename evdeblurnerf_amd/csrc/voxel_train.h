@@ -18,7 +18,11 @@ enum { VMAP_HID = 0,                    // 256: hidden arrangement 16 j + phi(kk
        VMAP_GEO_Y = VMAP_DIR + 32,      // 128: geo channels as sigma_net.1 rows (1 + channel)
        VMAP_COL = VMAP_GEO_Y + 128,     // 32: d colour fragment
        VMAP_SIG = VMAP_COL + 32,        // 32: d sigma fragment (row 0 of sigma_net.1)
-       VMAP_TOTAL = VMAP_SIG + 32 };
+       // blocks of the fused 64-wide backward (voxel_bwd_fused64.h): 32-position blocks that pair fragments the maps above keep apart
+       VMAP_F64_SG = VMAP_SIG + 32,     // 32: rows of the gradient block [d geo fragment 0 | d sigma fragment] of sigma_net.1
+       VMAP_F64_C0 = VMAP_F64_SG + 32,  // 64: columns of color_net.0: [geo fragments 0, 1 | direction encoding]
+       VMAP_F64_L0 = VMAP_F64_C0 + 64,  // 96: columns of sigma_net.0: [feature fragments 0, 1 | point encoding]
+       VMAP_TOTAL = VMAP_F64_L0 + 96 };
 
 struct VoxBwdGrads {                    // device float32, reference nn.Linear layouts; null = not wanted
     float *sigma_w[2], *color_w[3], *color_b[3];

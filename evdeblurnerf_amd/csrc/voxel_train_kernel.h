@@ -9,6 +9,7 @@
 #include "nerf_train_kernel.h"
 #include "voxel_mlp_kernel.h"
 #include "voxel_train.h"
+#include "voxel_bwd_fused64.h"
 
 namespace evd {
 
@@ -125,6 +126,59 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
     if (b.awp_store) {          // ... and the d geo fragments of the AWP embedding's backward (true-unit maximum in its trailer)
         hipLaunchKernelGGL(k_max_word, dim3(1), dim3(1), 0, st, b.maxbits, b.awp_words + 1);
         EVD_LAUNCH_CHECK();
+    }
+    // the 64-wide level: the whole chain in one launch, the tile's gradient resident in registers (voxel_bwd_fused64.h); EVD_BWD_FUSE64=0
+    // keeps the per-layer chain below (A/B, and the reference the fused kernel is tested against)
+    if constexpr (is_half_prec(PREC) && HD == 64 && G == 15 && FT == 32) {
+        static const bool fuse64 = [] { const char* e = getenv("EVD_BWD_FUSE64"); return !(e && e[0] == '0'); }();
+        if (fuse64 && !b.d_feature && !b.awp_store) {
+            const int blocks = (int)(cdiv(b.tiles, 4L) < 256 ? cdiv(b.tiles, 4L) : 256);
+            VoxBwdFusedParams fp;
+            fp.d_raw = b.d_raw; fp.raw = b.raw; fp.nsamp = b.nsamp; fp.tiles = b.tiles; fp.store = b.store; fp.maxbits = b.maxbits; fp.partial = b.partial;
+            for (int k = 0; k < VBWD_NSTREAMS; ++k) fp.wt[k] = b.wt[k];
+            EVD_SET_MAX_LDS((&k_voxel_bwd_fused64<PREC>), (size_t)f64::LDS_BYTES);
+            hipLaunchKernelGGL((k_voxel_bwd_fused64<PREC>), dim3((unsigned)blocks), dim3(256), (size_t)f64::LDS_BYTES, st, fp);
+            EVD_LAUNCH_CHECK();
+            const VoxBwdGrads& g = b.grads;
+            WreduceJobs jobs;
+            auto job = [&](int i, int a0, int RT, int CT, bool bias, int ymap, int xmap, float* dW, int ld, float* db) {
+                WreduceParams& q = jobs.j[i];
+                q.partial = b.partial + (long)a0 * 1024; q.nparts = blocks; q.RT = dW ? RT : 0; q.CT = CT; q.NC = CT + (bias ? 1 : 0);
+                q.rowmap = b.maps + ymap; q.colmap = b.maps + xmap; q.dW = dW; q.ld = ld; q.db = bias ? db : nullptr; q.maxbits = b.maxbits;
+                q.accum = b.accumulate; q.part_stride = (long)f64::NBLK * 1024;
+            };
+            job(0, f64::A_C2, 1, 2, false, VMAP_COL, VMAP_HID, g.color_w[2], HD, nullptr);
+            job(1, f64::A_C1, 2, 2, false, VMAP_HID, VMAP_HID, g.color_w[1], HD, nullptr);
+            job(2, f64::A_C0, 2, 2, false, VMAP_HID, VMAP_F64_C0, g.color_w[0], G + ICV, nullptr);
+            job(3, f64::A_SG, 1, 2, false, VMAP_F64_SG, VMAP_HID, g.sigma_w[1], HD, nullptr);
+            job(4, f64::A_L0, 2, 3, false, VMAP_HID, VMAP_F64_L0, g.sigma_w[0], FT + IC, nullptr);
+            hipLaunchKernelGGL(k_wgrad_reduce_jobs, dim3(2 * 3 * 4, WREDUCE_MAX_JOBS), dim3(256), 0, st, jobs);
+            EVD_LAUNCH_CHECK();
+            if (g.color_b[0] || g.color_b[1] || g.color_b[2]) {        // the shared bias block (columns: colour_net.2, .1 x 2 row tiles, .0 x 2)
+                F64BiasParams bp;
+                bp.partial = b.partial + (long)f64::A_BIAS * 1024; bp.nparts = blocks; bp.part_stride = (long)f64::NBLK * 1024; bp.maps = b.maps;
+                for (int i = 0; i < 3; ++i) bp.db[i] = g.color_b[i];
+                bp.maxbits = b.maxbits; bp.accum = b.accumulate;
+                hipLaunchKernelGGL(k_f64_bias_reduce, dim3(5 * 32 / 4), dim3(256), 0, st, bp);
+                EVD_LAUNCH_CHECK();
+            }
+            if (b.d_dirs) {
+                hipLaunchKernelGGL((k_pe_bwd<PREC, PE_LV, PEV_KS>), dim3((unsigned)cdiv(b.tiles * 64, 256L)), dim3(256), 0, st, (const char*)b.store, VS::tile_bytes(PREC),
+                                   VS::D_DIRPE, b.nsamp, b.viewdirs, b.vd_stride, b.S, b.maxbits, b.d_dirs, 0);
+                EVD_LAUNCH_CHECK();
+            }
+            if (b.d_fts) {
+                hipLaunchKernelGGL((k_frags_to_rows<PREC>), dim3((unsigned)cdiv(b.tiles * 64 * KF, 256L)), dim3(256), 0, st, (const char*)b.store, VS::tile_bytes(PREC),
+                                   VS::D_FTS, KF, b.nsamp, b.maxbits, b.d_fts, b.d_fts_stride);
+                EVD_LAUNCH_CHECK();
+            }
+            if (b.d_pts) {
+                hipLaunchKernelGGL((k_pe_bwd<PREC, PE_L, PE_KS>), dim3((unsigned)cdiv(b.tiles * 64, 256L)), dim3(256), 0, st, (const char*)b.store, VS::tile_bytes(PREC),
+                                   VS::D_PE, b.nsamp, b.pts, 3, 1, b.maxbits, b.d_pts, 0);
+                EVD_LAUNCH_CHECK();
+            }
+            return EVD_OK;
+        }
     }
     hipLaunchKernelGGL((k_voxel_grad_frags<PREC>), dim3((unsigned)cdiv(b.tiles * 64, 256L)), dim3(256), 0, st, b.d_raw, b.raw, b.nsamp, b.maxbits, b.store,
                        b.tiles, VS::tile_bytes(PREC), VS::G_COL, VS::G_SIG);

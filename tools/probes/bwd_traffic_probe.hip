@@ -13,18 +13,18 @@
 
 constexpr long TILE_BYTES = 338944;        // the 8x256 NeRF's record per 32-sample tile (331 KiB)
 constexpr int Y_SLOT = 40, X_SLOT = 120, O_SLOT = 200;      // three 16-slot groups somewhere in the record
+struct Lay { long off[3], stride[3]; };    // operand g (y, x, out) of tile t at off[g] + t * stride[g]
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int LAYOUT, int RING, int NBAR, bool STORE, bool DMA>
-__global__ __launch_bounds__(512) void k_traffic(char* __restrict__ store, long tiles, unsigned* __restrict__ sink) {
+__global__ __launch_bounds__(512) void k_traffic(char* __restrict__ store, long tiles, unsigned* __restrict__ sink, const Lay L) {
     extern __shared__ __attribute__((aligned(16))) char ring[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const unsigned ring0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)ring + wave * 4096);
     auto base = [&](long t, int slot0) -> char* {
-        if (LAYOUT == 0) return store + t * TILE_BYTES + (long)(slot0 + 2 * wave) * 1024 + lane * 16;
         const int g = slot0 == Y_SLOT ? 0 : slot0 == X_SLOT ? 1 : 2;
-        return store + (long)g * tiles * 16384 + t * 16384 + (long)(2 * wave) * 1024 + lane * 16;
+        return store + L.off[g] + t * L.stride[g] + (long)(2 * wave) * 1024 + lane * 16;
     };
     unsigned acc = 0;
     uint4 regs[RING][4];
@@ -88,29 +88,38 @@ __global__ __launch_bounds__(512) void k_traffic(char* __restrict__ store, long 
 }
 
 template <int LAYOUT, int RING, int NBAR, bool STORE, bool DMA>
-static void run(char* store, long tiles, unsigned* sink, int blocks, size_t lds, const char* name) {
+static void run(char* store, long tiles, unsigned* sink, int blocks, size_t lds, const char* name, Lay L = Lay{{0, 0, 0}, {0, 0, 0}}) {
+    if (L.stride[0] == 0) {
+        if (LAYOUT == 0) L = Lay{{Y_SLOT * 1024L, X_SLOT * 1024L, O_SLOT * 1024L}, {TILE_BYTES, TILE_BYTES, TILE_BYTES}};
+        else L = Lay{{0, tiles * 16384, 2 * tiles * 16384}, {16384, 16384, 16384}};
+    }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     auto k = k_traffic<LAYOUT, RING, NBAR, STORE, DMA>;
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    for (int i = 0; i < 2; ++i) k<<<blocks, 512, lds>>>(store, tiles, sink);
+    for (int i = 0; i < 2; ++i) k<<<blocks, 512, lds>>>(store, tiles, sink, L);
     hipEventRecord(e0);
     const int iters = 10;
-    for (int i = 0; i < iters; ++i) k<<<blocks, 512, lds>>>(store, tiles, sink);
+    for (int i = 0; i < iters; ++i) k<<<blocks, 512, lds>>>(store, tiles, sink, L);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     ms /= iters;
     const double bytes = (double)tiles * (32768 + (STORE ? 16384 : 0));
-    printf("  %-86s %.3f ms  %5.2f TB/s\n", name, ms, bytes / ms / 1e9);
-    if (hipGetLastError() != hipSuccess) printf("  (launch error)\n");
+    fprintf(stderr, "  %-86s %.3f ms  %5.2f TB/s\n", name, ms, bytes / ms / 1e9);
+    const hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) { fprintf(stderr, "  (error: %s)\n", hipGetErrorString(e)); exit(1); }
 }
 
 int main() {
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    fprintf(stderr, "start\n");
     const long tiles = 16384;                    // 4096 x 128 samples
     char* store; unsigned* sink;
-    hipMalloc(&store, tiles * TILE_BYTES); hipMalloc(&sink, 64);
-    hipMemset(store, 1, tiles * TILE_BYTES);
+    if (hipMalloc(&store, tiles * TILE_BYTES) != hipSuccess || hipMalloc(&sink, 64) != hipSuccess) { fprintf(stderr, "hipMalloc failed\n"); return 1; }
+    fprintf(stderr, "allocated %p\n", (void*)store);
+    for (long o = 0; o < tiles * TILE_BYTES; o += 1L << 30) hipMemset(store + o, 1, tiles * TILE_BYTES - o < (1L << 30) ? tiles * TILE_BYTES - o : 1L << 30);   // (one memset of > 4 GiB faulted)
+    fprintf(stderr, "store ready: %s\n", hipGetErrorString(hipDeviceSynchronize()));
     const size_t big = 160 * 1024, half = 80 * 1024;
-    printf("k_wgrad_dgrad traffic, %ld tiles (record %ld B): 32 KiB read (+ 16 KiB written) per tile\n", tiles, TILE_BYTES);
+    fprintf(stderr, "k_wgrad_dgrad traffic, %ld tiles (record %ld B): 32 KiB read (+ 16 KiB written) per tile\n", tiles, TILE_BYTES);
     run<0, 3, 2, true, true>(store, tiles, sink, 256, big, "tile-major, ring 3, 2 barriers, store, 1 workgroup per CU (as shipped)");
     run<0, 3, 0, true, true>(store, tiles, sink, 256, big, "tile-major, ring 3, no barrier, store");
     run<0, 3, 2, false, true>(store, tiles, sink, 256, big, "tile-major, ring 3, 2 barriers, no store");
@@ -122,8 +131,17 @@ int main() {
     run<1, 3, 2, true, true>(store, tiles, sink, 256, big, "group-major, ring 3, 2 barriers, store");
     run<1, 3, 0, false, true>(store, tiles, sink, 256, big, "group-major, ring 3, no barrier, no store");
     run<1, 5, 2, true, true>(store, tiles, sink, 256, big, "group-major, ring 5, 2 barriers, store");
-    run<0, 3, 2, true, false>(store, tiles, sink, 256, big, "tile-major, ring 3 in registers (plain loads), 1 barrier, store");
-    run<0, 3, 0, false, false>(store, tiles, sink, 256, big, "tile-major, ring 3 in registers, no barrier, no store");
-    run<0, 3, 0, false, false>(store, tiles, sink, 512, half, "tile-major, ring 3 in registers, no barrier, no store, 2 workgroups per CU");
+    const long T = TILE_BYTES, G = 16384, far = tiles * T - tiles * G;        // a group-major region at the end of the allocation
+    run<0, 3, 2, true, true>(store, tiles, sink, 256, big, "y, x tile-major; OUT group-major (own buffer)", Lay{{40 * 1024, 120 * 1024, far}, {T, T, G}});
+    run<0, 3, 2, true, true>(store, tiles, sink, 256, big, "x tile-major; y and OUT group-major (gradients in their own buffers)", Lay{{far - tiles * G, 120 * 1024, far}, {G, T, G}});
+    run<0, 3, 2, true, true>(store, tiles, sink, 256, big, "tile-major, out slot next to y (56)", Lay{{40 * 1024, 120 * 1024, 56 * 1024}, {T, T, T}});
+    run<0, 3, 2, true, true>(store, tiles, sink, 256, big, "tile-major, out slot 201 (1 KiB off)", Lay{{40 * 1024, 120 * 1024, 201 * 1024}, {T, T, T}});
+    run<0, 3, 2, true, true>(store, tiles, sink, 256, big, "tile-major, out = y (in place)", Lay{{40 * 1024, 120 * 1024, 40 * 1024}, {T, T, T}});
+    for (long rec : {336L * 1024, 344L * 1024, 352L * 1024, 384L * 1024, 512L * 1024, 331L * 1024 + 256, 331L * 1024 + 512}) {
+        if (rec * tiles > tiles * T + 0) { /* larger records need a larger allocation */ }
+        char nm[128]; snprintf(nm, sizeof nm, "tile-major, record %ld B (%.2f KiB)", rec, rec / 1024.0);
+        if (rec <= T) run<0, 3, 2, true, true>(store, tiles, sink, 256, big, nm, Lay{{40 * 1024, 120 * 1024, 200 * 1024}, {rec, rec, rec}});
+        else run<0, 3, 2, true, true>(store, tiles * T / rec, sink, 256, big, nm, Lay{{40 * 1024, 120 * 1024, 200 * 1024}, {rec, rec, rec}});
+    }
     return 0;
 }
