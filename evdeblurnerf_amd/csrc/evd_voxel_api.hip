@@ -290,6 +290,8 @@ int evd_voxel_create(const evd_voxel_desc* d, evd_voxel** out) {
         for (int i = 0; i < 32; ++i) { m[VMAP_F64_C0 + i] = m[VMAP_GEO_X + i]; m[VMAP_F64_C0 + 32 + i] = m[VMAP_DIR + i]; }
         for (int i = 0; i < 32; ++i) m[VMAP_F64_L0 + i] = m[VMAP_FTS + i];
         for (int i = 0; i < 64; ++i) m[VMAP_F64_L0 + 32 + i] = m[VMAP_PE + i];
+        for (int i = 0; i < 128; ++i) m[VMAP_SG5 + i] = m[VMAP_GEO_Y + i];
+        for (int i = 0; i < 32; ++i) m[VMAP_SG5 + 128 + i] = m[VMAP_SIG + i];
         if ((rc = v->wmaps.upload(m.data(), m.size() * sizeof(int)))) { evd_voxel_destroy(v); return rc; }
     }
     std::vector<float> b(32 * 16, 0.f);            // zero block shared by the bias-free sigma layers

@@ -381,14 +381,18 @@ struct WgradFusedParams {
     const char* wt;         // W^T fragment stream of the layer (tile-major, 16 k-steps per tile: pack.h layer_transposed)
     char* out_store;        // the store again, writable
     int mask_slot, out_slot;
+    int y_last_slot = -1;   // RT < 8: the slot of the LAST row tile's fragment pair when it does not follow the others (-1: it does)
 };
 
 constexpr int FUSED_WL = 6;        // W^T fragments per wavefront kept in LDS instead of registers (k_wgrad_dgrad)
 
-template <int PREC, int CT, int TO, int OMASK>
+// RT_ < 8 (round 5: sigma_net.1 = [geo rows | sigma row], 4 + 1 row tiles): wavefronts RT_ .. 7 own no gradient rows (no wgrad products,
+// no partial blocks), the dgrad runs over the first KD_ gradient fragments (the last row tile may be a single fragment: KD_ = 2 RT_ - 1).
+template <int PREC, int CT, int TO, int OMASK, int RT_ = 8, int KD_ = 16>
 __global__ __launch_bounds__(WGRAD_NT) void k_wgrad_dgrad(const WgradFusedParams fp) {
     static_assert(is_half_prec(PREC) && CT <= 8 && TO <= 8 && (OMASK == 0 || TO <= CT), "half-precision fragments, 8 x 32 gradient rows; a masked d X tile is a column tile of X");
-    constexpr int RT = 8, CPG = wgrad_cpg(RT, CT), KD = 16, WL = FUSED_WL;
+    static_assert(RT_ <= 8 && KD_ <= 2 * RT_ && KD_ > 2 * (RT_ - 1), "k-steps of the dgrad = the gradient fragments of the RT_ row tiles");
+    constexpr int RT = 8, CPG = wgrad_cpg(RT, CT), KD = KD_, WL = KD_ > FUSED_WL + 2 ? FUSED_WL : 0;
     typedef POps<PREC> O;
     const WgradParams& p = fp.w;
     extern __shared__ __attribute__((aligned(16))) char wsm[];
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(WGRAD_NT) void k_wgrad_dgrad(const WgradFusedParams
     const int NC = CT + (p.bias ? 1 : 0);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = lane & 31, h = lane >> 5;
     const int rt = wave, c0 = 0;
-    const bool xown = wave < CT, bias_own = p.bias != 0, down = wave < TO;
+    const bool xown = wave < CT, yown = wave < RT_, bias_own = p.bias != 0 && yown, down = wave < TO;
     const unsigned one = half_one_pair<PREC>();
     f32x16 acc[CPG], accb;
 #pragma unroll
@@ -419,8 +423,10 @@ __global__ __launch_bounds__(WGRAD_NT) void k_wgrad_dgrad(const WgradFusedParams
     }
     // the tile's four fragments of this wavefront: y0, y1 (adjacent: one address, immediates 0 / 1024) and x0, x1 (wavefronts beyond CT:
     // the y pair again) -- two address registers (the instruction's immediate moves the source and the LDS destination together)
-    const long oy = (long)(p.y_slot + 2 * rt) * 1024 + lane * 16;
-    const long ox = (xown ? (long)(p.x_slot + 2 * wave) * 1024 : (long)(p.y_slot + 2 * rt) * 1024) + lane * 16 - 2048;
+    // (wavefronts beyond RT_: row tile 0's pair again, unused -- every tile costs every wavefront the same four DMA instructions)
+    const int ys = !yown ? p.y_slot : (RT_ < 8 && rt == RT_ - 1 && fp.y_last_slot >= 0) ? fp.y_last_slot : p.y_slot + 2 * rt;
+    const long oy = (long)ys * 1024 + lane * 16;
+    const long ox = (xown ? (long)(p.x_slot + 2 * wave) * 1024 : (long)ys * 1024) + lane * 16 - 2048;
     const unsigned ring0 = lds_offset_of(raw) + wave * 4096;
     auto issue = [&](long t, int stage) {
         if (t >= p.tiles) return;
@@ -463,7 +469,7 @@ __global__ __launch_bounds__(WGRAD_NT) void k_wgrad_dgrad(const WgradFusedParams
         const char* rw = raw + ((it % WG_RING) * 8 + wave) * 4096 + lane * 16;
         const W4 y0 = *reinterpret_cast<const W4*>(rw), y1 = *reinterpret_cast<const W4*>(rw + 1024);
         W4 yt[2];
-        transpose_block<PREC>(y0, y1, sel0, sel1, yt);
+        if (RT_ == 8 || yown) transpose_block<PREC>(y0, y1, sel0, sel1, yt);
         char* xb = xs;
         if (xown) {
             const W4 x0 = *reinterpret_cast<const W4*>(rw + 2048), x1 = *reinterpret_cast<const W4*>(rw + 3072);
@@ -475,7 +481,7 @@ __global__ __launch_bounds__(WGRAD_NT) void k_wgrad_dgrad(const WgradFusedParams
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < CPG; ++c) {
-            if (c0 + c < CT) {
+            if (c0 + c < CT && (RT_ == 8 || yown)) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const W4 xq = *reinterpret_cast<const W4*>(xb + ((c0 + c) * 2 + q) * 1024 + lane * 16);
@@ -515,6 +521,7 @@ __global__ __launch_bounds__(WGRAD_NT) void k_wgrad_dgrad(const WgradFusedParams
         }
         __syncthreads();            // every wavefront is done with this tile's ring slots before any of them issues into the oldest one
     }
+    if (RT_ < 8 && !yown) return;           // (the reduce reads RT_ row tiles of every workgroup's 8-tile set: WreduceParams::part_stride)
     float* out = p.partial + (((long)blockIdx.x * RT + rt) * NC) * 1024 + lane * 16;
     auto put = [&](int c, const f32x16& a) {
 #pragma unroll
@@ -529,11 +536,11 @@ __global__ __launch_bounds__(WGRAD_NT) void k_wgrad_dgrad(const WgradFusedParams
     if (bias_own) put(CT, accb);
 }
 
-template <int PREC, int CT, int TO, int OMASK>
+template <int PREC, int CT, int TO, int OMASK, int RT_ = 8, int KD_ = 16>
 static int launch_wgrad_dgrad(const WgradFusedParams& p, int blocks, hipStream_t st) {
     const size_t lds = (size_t)WG_RING * 8 * 4 * 1024 + (size_t)CT * 2048 + (size_t)8 * FUSED_WL * 1024;
-    EVD_SET_MAX_LDS((&k_wgrad_dgrad<PREC, CT, TO, OMASK>), lds);
-    hipLaunchKernelGGL((k_wgrad_dgrad<PREC, CT, TO, OMASK>), dim3(blocks), dim3(WGRAD_NT), lds, st, p);
+    EVD_SET_MAX_LDS((&k_wgrad_dgrad<PREC, CT, TO, OMASK, RT_, KD_>), lds);
+    hipLaunchKernelGGL((k_wgrad_dgrad<PREC, CT, TO, OMASK, RT_, KD_>), dim3(blocks), dim3(WGRAD_NT), lds, st, p);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }

@@ -22,7 +22,8 @@ enum { VMAP_HID = 0,                    // 256: hidden arrangement 16 j + phi(kk
        VMAP_F64_SG = VMAP_SIG + 32,     // 32: rows of the gradient block [d geo fragment 0 | d sigma fragment] of sigma_net.1
        VMAP_F64_C0 = VMAP_F64_SG + 32,  // 64: columns of color_net.0: [geo fragments 0, 1 | direction encoding]
        VMAP_F64_L0 = VMAP_F64_C0 + 64,  // 96: columns of sigma_net.0: [feature fragments 0, 1 | point encoding]
-       VMAP_TOTAL = VMAP_F64_L0 + 96 };
+       VMAP_SG5 = VMAP_F64_L0 + 96,     // 160: rows of sigma_net.1 as ONE gradient of 4 + 1 row tiles: [geo rows | the d sigma fragment] (fused wgrad + dgrad)
+       VMAP_TOTAL = VMAP_SG5 + 160 };
 
 struct VoxBwdGrads {                    // device float32, reference nn.Linear layouts; null = not wanted
     float *sigma_w[2], *color_w[3], *color_b[3];

@@ -214,11 +214,12 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
     // half-precision modes; EVD_BWD_FUSE=0 keeps the separate launches (A/B)
     static const bool fuse_on = [] { const char* e = getenv("EVD_BWD_FUSE"); return !(e && e[0] == '0'); }();
     constexpr bool FUSABLE = is_half_prec(PREC) && T == 8;
-    auto fused = [&](auto launch, int CT, bool bias, int y_slot, int x_slot, int ymap, int xmap, float* dW, int ld, float* db, int stream, int mask_slot, int out_slot) -> int {
+    auto fused = [&](auto launch, int CT, bool bias, int y_slot, int x_slot, int ymap, int xmap, float* dW, int ld, float* db, int stream, int mask_slot, int out_slot,
+                     int RTr = 8, int y_last_slot = -1) -> int {
         const int blocks = (int)(b.tiles < b.wgrad_blocks ? b.tiles : b.wgrad_blocks);
         WgradFusedParams p;
         p.w.store = b.store; p.w.tiles = b.tiles; p.w.tile_bytes = VS::tile_bytes(PREC); p.w.y_slot = y_slot; p.w.x_slot = x_slot; p.w.bias = bias ? 1 : 0; p.w.partial = b.partial;
-        p.wt = b.wt[stream]; p.out_store = b.store; p.mask_slot = mask_slot; p.out_slot = out_slot;
+        p.wt = b.wt[stream]; p.out_store = b.store; p.mask_slot = mask_slot; p.out_slot = out_slot; p.y_last_slot = y_last_slot;
         if (b.side) {                           // the wgrad launches in flight on the side stream use the partial scratch: join first
             EVD_HIP(hipEventRecord(b.ev, b.side));
             EVD_HIP(hipStreamWaitEvent(st, b.ev, 0));
@@ -227,9 +228,10 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
         if (r) return r;
         if (!dW) return EVD_OK;
         WreduceParams q;
-        q.partial = b.partial; q.nparts = blocks; q.RT = 8; q.CT = CT; q.NC = CT + (bias ? 1 : 0);
+        q.partial = b.partial; q.nparts = blocks; q.RT = RTr; q.CT = CT; q.NC = CT + (bias ? 1 : 0);
         q.rowmap = b.maps + ymap; q.colmap = b.maps + xmap; q.dW = dW; q.ld = ld; q.db = bias ? db : nullptr; q.maxbits = b.maxbits; q.accum = b.accumulate;
-        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((long)8 * q.NC * 4)), dim3(256), 0, st, q);
+        q.part_stride = RTr < 8 ? (long)8 * q.NC * 1024 : 0;       // the kernel lays every workgroup's set out as 8 row tiles
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((long)RTr * q.NC * 4)), dim3(256), 0, st, q);
         EVD_LAUNCH_CHECK();
         return EVD_OK;
     };
@@ -288,9 +290,22 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
         EVD_LAUNCH_CHECK();
     }
     // sigma_net.1 = [sigma row | geo rows] on hid
-    if ((rc = wgrad(launch_wgrad<PREC, GT, T, false>, GT, T, false, VS::D_GEO, VS::HID, VMAP_GEO_Y, VMAP_HID, g.sigma_w[1], HD, nullptr))) return rc;
-    if ((rc = wgrad(launch_wgrad<PREC, 1, T, true>, 1, T, false, VS::G_SIG, VS::HID, VMAP_SIG, VMAP_HID, g.sigma_w[1], HD, nullptr))) return rc;
-    if ((rc = launch_dgrad<PREC, 2 * GT + 1, T, 2 * GT, true, 2>(dgrad(VBWD_SIGGEO, VS::D_GEO, VS::G_SIG, VS::M_HID, VS::D_HID), b.tiles, st))) return rc;
+    bool sg_fused = false;
+    if constexpr (FUSABLE && GT == 4) {
+        // round 5: both wgrads and the dgrad in one launch -- the gradient as 4 geo row tiles + the d sigma fragment (k_wgrad_dgrad RT_ = 5,
+        // 9 k-steps): hid and d geo are read once instead of three / two times (42 KiB per tile instead of 67); EVD_BWD_FUSE_SG=0: the three launches
+        static const bool sg_on = [] { const char* e = getenv("EVD_BWD_FUSE_SG"); return !(e && e[0] == '0'); }();
+        if (fuse_on && sg_on && g.sigma_w[1]) {
+            if ((rc = fused(launch_wgrad_dgrad<PREC, 8, 8, 1, GT + 1, 2 * GT + 1>, T, false, VS::D_GEO, VS::HID, VMAP_SG5, VMAP_HID, g.sigma_w[1], HD, nullptr, VBWD_SIGGEO,
+                            VS::M_HID, VS::D_HID, GT + 1, VS::G_SIG))) return rc;
+            sg_fused = true;
+        }
+    }
+    if (!sg_fused) {
+        if ((rc = wgrad(launch_wgrad<PREC, GT, T, false>, GT, T, false, VS::D_GEO, VS::HID, VMAP_GEO_Y, VMAP_HID, g.sigma_w[1], HD, nullptr))) return rc;
+        if ((rc = wgrad(launch_wgrad<PREC, 1, T, true>, 1, T, false, VS::G_SIG, VS::HID, VMAP_SIG, VMAP_HID, g.sigma_w[1], HD, nullptr))) return rc;
+        if ((rc = launch_dgrad<PREC, 2 * GT + 1, T, 2 * GT, true, 2>(dgrad(VBWD_SIGGEO, VS::D_GEO, VS::G_SIG, VS::M_HID, VS::D_HID), b.tiles, st))) return rc;
+    }
     // sigma_net.0 on cat([fts, PE(pts)])
     bool l0_fused = false;
     if constexpr (FUSABLE && FTT == 2) {
