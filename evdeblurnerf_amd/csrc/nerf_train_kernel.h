@@ -382,14 +382,21 @@ struct WgradFusedParams {
     char* out_store;        // the store again, writable
     int mask_slot, out_slot;
     int y_last_slot = -1;   // RT < 8: the slot of the LAST row tile's fragment pair when it does not follow the others (-1: it does)
+    const char* ygen_wt = nullptr;      // YGEN: W^T stream of the 16-row layer ABOVE (8 output tiles x 1 k-step), see k_wgrad_dgrad
 };
 
 constexpr int FUSED_WL = 6;        // W^T fragments per wavefront kept in LDS instead of registers (k_wgrad_dgrad)
 
 // RT_ < 8 (round 5: sigma_net.1 = [geo rows | sigma row], 4 + 1 row tiles): wavefronts RT_ .. 7 own no gradient rows (no wgrad products,
 // no partial blocks), the dgrad runs over the first KD_ gradient fragments (the last row tile may be a single fragment: KD_ = 2 RT_ - 1).
-template <int PREC, int CT, int TO, int OMASK, int RT_ = 8, int KD_ = 16>
+// YGEN (round 5: color_net.1 under the 3-row color_net.2): the layer's gradient G is not read but FORMED -- every wavefront fetches the pair
+// [gradient fragment of the layer above (16 rows) | ReLU bit-mask fragment of this layer's output] at y_slot (2 KiB, the same for all
+// eight: L2 hits) in place of its 2 KiB of G, multiplies its 32 rows of the upper layer's W^T (one resident A fragment) with it, masks,
+// and puts the two fragments where the DMA would have put them.  The upper layer's dgrad launch, its 16 KiB write and this kernel's
+// 16 KiB read of G per tile are gone.
+template <int PREC, int CT, int TO, int OMASK, int RT_ = 8, int KD_ = 16, bool YGEN = false>
 __global__ __launch_bounds__(WGRAD_NT) void k_wgrad_dgrad(const WgradFusedParams fp) {
+    static_assert(!YGEN || (RT_ == 8 && KD_ == 16), "a formed gradient has all 8 row tiles");
     static_assert(is_half_prec(PREC) && CT <= 8 && TO <= 8 && (OMASK == 0 || TO <= CT), "half-precision fragments, 8 x 32 gradient rows; a masked d X tile is a column tile of X");
     static_assert(RT_ <= 8 && KD_ <= 2 * RT_ && KD_ > 2 * (RT_ - 1), "k-steps of the dgrad = the gradient fragments of the RT_ row tiles");
     constexpr int RT = 8, CPG = wgrad_cpg(RT, CT), KD = KD_, WL = KD_ > FUSED_WL + 2 ? FUSED_WL : 0;
@@ -424,7 +431,7 @@ __global__ __launch_bounds__(WGRAD_NT) void k_wgrad_dgrad(const WgradFusedParams
     // the tile's four fragments of this wavefront: y0, y1 (adjacent: one address, immediates 0 / 1024) and x0, x1 (wavefronts beyond CT:
     // the y pair again) -- two address registers (the instruction's immediate moves the source and the LDS destination together)
     // (wavefronts beyond RT_: row tile 0's pair again, unused -- every tile costs every wavefront the same four DMA instructions)
-    const int ys = !yown ? p.y_slot : (RT_ < 8 && rt == RT_ - 1 && fp.y_last_slot >= 0) ? fp.y_last_slot : p.y_slot + 2 * rt;
+    const int ys = (YGEN || !yown) ? p.y_slot : (RT_ < 8 && rt == RT_ - 1 && fp.y_last_slot >= 0) ? fp.y_last_slot : p.y_slot + 2 * rt;
     const long oy = (long)ys * 1024 + lane * 16;
     const long ox = (xown ? (long)(p.x_slot + 2 * wave) * 1024 : (long)ys * 1024) + lane * 16 - 2048;
     const unsigned ring0 = lds_offset_of(raw) + wave * 4096;
@@ -439,9 +446,12 @@ __global__ __launch_bounds__(WGRAD_NT) void k_wgrad_dgrad(const WgradFusedParams
                      "s_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(g + oy), "v"(g + ox), "s"(dst) : "memory");
     };
+    W4 w2 = {{0u, 0u, 0u, 0u}};
+    if constexpr (YGEN) w2 = *reinterpret_cast<const W4*>(fp.ygen_wt + (long)wave * 1024 + lane * 16);       // rows 32 w .. of the upper layer's W^T
     const long stride = gridDim.x;
     long t = blockIdx.x;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the weight fragments have landed: the counted waits below count the ring's DMA only
+    if constexpr (YGEN) asm volatile("" : "+v"(w2.w[0]), "+v"(w2.w[1]), "+v"(w2.w[2]), "+v"(w2.w[3]));
 #pragma unroll
     for (int j = 0; j < KD - WL; ++j) asm volatile("" : "+v"(wt[j].w[0]), "+v"(wt[j].w[1]), "+v"(wt[j].w[2]), "+v"(wt[j].w[3]));
 #pragma unroll
@@ -466,8 +476,30 @@ __global__ __launch_bounds__(WGRAD_NT) void k_wgrad_dgrad(const WgradFusedParams
                 ones.w[e] = nn == 0 ? one : 0u;
             }
         }
-        const char* rw = raw + ((it % WG_RING) * 8 + wave) * 4096 + lane * 16;
-        const W4 y0 = *reinterpret_cast<const W4*>(rw), y1 = *reinterpret_cast<const W4*>(rw + 1024);
+        char* rw = raw + ((it % WG_RING) * 8 + wave) * 4096 + lane * 16;
+        W4 y0 = *reinterpret_cast<const W4*>(rw), y1 = *reinterpret_cast<const W4*>(rw + 1024);
+        if constexpr (YGEN) {           // (y0, y1) = (gradient fragment of the layer above, this layer's ReLU bits) -> this wavefront's two fragments of G
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const f32x16 d = mfma_half<PREC>(w2, y0, zero);
+            // byte j of a lane's 16 mask bytes = the ReLU bits of fragment j (mlp_pipe.h mask_from_bits): fragments 2 w, 2 w + 1 are one half
+            // of word w / 2 -- read as ONE dword (indexing the four words by the wavefront number would go through scratch)
+            const unsigned mw = *reinterpret_cast<const unsigned*>(rw + 1024 + 4 * (wave >> 1)) >> (16 * (wave & 1));
+            typename O::B g2[2];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) O::template set_pair<false>(g2[k >> 2], k & 3, d[2 * k], d[2 * k + 1]);
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned two = (mw >> (8 * f + 2 * e)) & 3u;
+                    g2[f].w[e] &= ((0u - (two & 1u)) & 0xffffu) | ((0u - (two >> 1)) & 0xffff0000u);
+                }
+            y0 = __builtin_bit_cast(W4, g2[0]);
+            y1 = __builtin_bit_cast(W4, g2[1]);
+            *reinterpret_cast<W4*>(rw) = y0;                 // where the dgrad of all eight wavefronts reads G (behind the barrier below)
+            *reinterpret_cast<W4*>(rw + 1024) = y1;
+        }
+        if (KD_ == 2 * RT_ - 1 && rt == RT_ - 1) y1 = W4{{0u, 0u, 0u, 0u}};       // the last row tile is ONE fragment: what lies behind it in the store is not this layer's (0 x inf = nan)
         W4 yt[2];
         if (RT_ == 8 || yown) transpose_block<PREC>(y0, y1, sel0, sel1, yt);
         char* xb = xs;
@@ -536,11 +568,11 @@ __global__ __launch_bounds__(WGRAD_NT) void k_wgrad_dgrad(const WgradFusedParams
     if (bias_own) put(CT, accb);
 }
 
-template <int PREC, int CT, int TO, int OMASK, int RT_ = 8, int KD_ = 16>
+template <int PREC, int CT, int TO, int OMASK, int RT_ = 8, int KD_ = 16, bool YGEN = false>
 static int launch_wgrad_dgrad(const WgradFusedParams& p, int blocks, hipStream_t st) {
     const size_t lds = (size_t)WG_RING * 8 * 4 * 1024 + (size_t)CT * 2048 + (size_t)8 * FUSED_WL * 1024;
-    EVD_SET_MAX_LDS((&k_wgrad_dgrad<PREC, CT, TO, OMASK, RT_, KD_>), lds);
-    hipLaunchKernelGGL((k_wgrad_dgrad<PREC, CT, TO, OMASK, RT_, KD_>), dim3(blocks), dim3(WGRAD_NT), lds, st, p);
+    EVD_SET_MAX_LDS((&k_wgrad_dgrad<PREC, CT, TO, OMASK, RT_, KD_, YGEN>), lds);
+    hipLaunchKernelGGL((k_wgrad_dgrad<PREC, CT, TO, OMASK, RT_, KD_, YGEN>), dim3(blocks), dim3(WGRAD_NT), lds, st, p);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }

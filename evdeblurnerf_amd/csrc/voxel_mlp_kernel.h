@@ -18,10 +18,12 @@ template <int HD, int G, int FT> struct VStore {
     static constexpr int IN0 = 0, HID = IN0 + KF + PE_KS, GEO = HID + KS, DIRPE = GEO + 2 * GT, C0 = DIRPE + PEV_KS, C1 = C0 + KS, FWD_END = C1 + KS;
     // gradient slots; D_GEO is followed by the 2 direction-encoding gradient fragments, D_FTS by the 4 point-encoding ones (both
     // produced by the same dgrad layer as their neighbours, in the encodings' own fragment arrangement)
-    static constexpr int G_COL = FWD_END, G_SIG = G_COL + 1, D_C1 = G_SIG + 1, D_C0 = D_C1 + KS, D_GEO = D_C0 + KS, D_DIRPE = D_GEO + 2 * GT,
+    // (M_C1 sits right behind G_COL: the fused backward of color_net.1 fetches [d colour fragment | c1's ReLU bits] as ONE pair of
+    // DMA pieces and forms d c1 from them in registers, nerf_train_kernel.h k_wgrad_dgrad YGEN)
+    static constexpr int G_COL = FWD_END, M_C1 = G_COL + 1, G_SIG = M_C1 + 1, D_C1 = G_SIG + 1, D_C0 = D_C1 + KS, D_GEO = D_C0 + KS, D_DIRPE = D_GEO + 2 * GT,
                          D_HID = D_DIRPE + PEV_KS, D_FTS = D_HID + KS, D_PE = D_FTS + 2 * ((FT + 31) / 32),
-                         M_HID = D_PE + PE_KS, M_C0 = M_HID + 1, M_C1 = M_C0 + 1,      // ReLU patterns as bit masks (mlp_pipe.h frag_bits)
-                         TILE_FRAGS = M_C1 + 1;
+                         M_HID = D_PE + PE_KS, M_C0 = M_HID + 1,      // ReLU patterns as bit masks (mlp_pipe.h frag_bits)
+                         TILE_FRAGS = M_C0 + 1;
     static constexpr long TILE_BYTES = (long)TILE_FRAGS * 1024;          // the single-product half-precision modes
     static constexpr long tile_bytes(int prec) { return (long)TILE_FRAGS * frag_bytes(prec); }   // split-float16: (hi, lo) pairs in 2 KiB slots
 };

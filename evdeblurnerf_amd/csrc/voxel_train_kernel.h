@@ -215,11 +215,11 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
     static const bool fuse_on = [] { const char* e = getenv("EVD_BWD_FUSE"); return !(e && e[0] == '0'); }();
     constexpr bool FUSABLE = is_half_prec(PREC) && T == 8;
     auto fused = [&](auto launch, int CT, bool bias, int y_slot, int x_slot, int ymap, int xmap, float* dW, int ld, float* db, int stream, int mask_slot, int out_slot,
-                     int RTr = 8, int y_last_slot = -1) -> int {
+                     int RTr = 8, int y_last_slot = -1, const char* ygen_wt = nullptr) -> int {
         const int blocks = (int)(b.tiles < b.wgrad_blocks ? b.tiles : b.wgrad_blocks);
         WgradFusedParams p;
         p.w.store = b.store; p.w.tiles = b.tiles; p.w.tile_bytes = VS::tile_bytes(PREC); p.w.y_slot = y_slot; p.w.x_slot = x_slot; p.w.bias = bias ? 1 : 0; p.w.partial = b.partial;
-        p.wt = b.wt[stream]; p.out_store = b.store; p.mask_slot = mask_slot; p.out_slot = out_slot; p.y_last_slot = y_last_slot;
+        p.wt = b.wt[stream]; p.out_store = b.store; p.mask_slot = mask_slot; p.out_slot = out_slot; p.y_last_slot = y_last_slot; p.ygen_wt = ygen_wt;
         if (b.side) {                           // the wgrad launches in flight on the side stream use the partial scratch: join first
             EVD_HIP(hipEventRecord(b.ev, b.side));
             EVD_HIP(hipStreamWaitEvent(st, b.ev, 0));
@@ -239,10 +239,17 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
     // (each wgrad is issued before the dgrad layer that reads the same arrays: independent, concurrent on the side stream)
     // color_net.2 (+ sigmoid, folded into the gradient fragment)
     if ((rc = wgrad(launch_wgrad<PREC, 1, T, true>, 1, T, true, VS::G_COL, VS::C1, VMAP_COL, VMAP_HID, g.color_w[2], HD, g.color_b[2]))) return rc;
-    if ((rc = launch_dgrad<PREC, 1, T, 1, false, 2>(dgrad(VBWD_C2, VS::G_COL, -1, VS::M_C1, VS::D_C1), b.tiles, st))) return rc;
-    // color_net.1
+    // color_net.1; in the fused form d c1 = (W2^T d colour) . [c1 > 0] is formed inside the launch from the pair [G_COL | M_C1]
+    // (k_wgrad_dgrad YGEN: color_net.2's dgrad launch and the D_C1 round trip are gone; EVD_BWD_YGEN=0: the separate launch)
+    static const bool ygen_on = [] { const char* e = getenv("EVD_BWD_YGEN"); return !(e && e[0] == '0'); }();
+    const bool ygen = FUSABLE && fuse_on && ygen_on && g.color_w[1];
+    static_assert(VS::M_C1 == VS::G_COL + 1, "the formed gradient's two inputs are one fragment pair");
+    if (!ygen && (rc = launch_dgrad<PREC, 1, T, 1, false, 2>(dgrad(VBWD_C2, VS::G_COL, -1, VS::M_C1, VS::D_C1), b.tiles, st))) return rc;
     if constexpr (FUSABLE) {
-        if (fuse_on && g.color_w[1]) {
+        if (ygen) {
+            if ((rc = fused(launch_wgrad_dgrad<PREC, 8, 8, 1, 8, 16, true>, 8, true, VS::G_COL, VS::C1 - KS, VMAP_HID, VMAP_HID, g.color_w[1], HD, g.color_b[1], VBWD_C1, VS::M_C0,
+                            VS::D_C0, 8, -1, b.wt[VBWD_C2]))) return rc;
+        } else if (fuse_on && g.color_w[1]) {
             if ((rc = fused(launch_wgrad_dgrad<PREC, 8, 8, 1>, 8, true, VS::D_C1, VS::C1 - KS, VMAP_HID, VMAP_HID, g.color_w[1], HD, g.color_b[1], VBWD_C1, VS::M_C0, VS::D_C0))) return rc;
         } else {
             if ((rc = wgrad(launch_wgrad<PREC, T, T, false>, T, T, true, VS::D_C1, VS::C1 - KS, VMAP_HID, VMAP_HID, g.color_w[1], HD, g.color_b[1]))) return rc;
