@@ -5,6 +5,7 @@
 
 #include "awp_embed.h"
 #include "voxel_train_kernel.h"
+#include "awp_bwd_fused.h"
 
 namespace evd {
 
@@ -185,6 +186,57 @@ template <int PREC> static int run_awp_backward(const AwpBwdPlan& b, hipStream_t
     } else {
         hipLaunchKernelGGL(k_absmax, dim3(512), dim3(256), 0, st, b.d_h_local, b.nsamp * AWP_W, words);
         EVD_LAUNCH_CHECK();
+    }
+    // round 5: the whole chain in one launch with the tile's gradient resident in registers (awp_bwd_fused.h); EVD_AWP_BWD_FUSE=0: the
+    // per-layer chain below (A/B, and what the fused kernel is tested against)
+    static const bool fuse = [] { const char* e = getenv("EVD_AWP_BWD_FUSE"); return !(e && e[0] == '0'); }();
+    if (fuse) {
+        const int blocks = (int)(cdiv(b.tiles, 4L) < b.wgrad_blocks ? cdiv(b.tiles, 4L) : b.wgrad_blocks);
+        AwpBwdFusedParams fp;
+        fp.d_h_local = b.d_h_local; fp.nsamp = b.nsamp; fp.tiles = b.tiles; fp.store = b.store; fp.words = words; fp.partial = b.partial;
+        for (int l = 0; l < AWP_D; ++l) fp.wt[l] = b.wt[l];
+        EVD_SET_MAX_LDS((&k_awp_bwd_fused<PREC>), (size_t)awpf::LDS_BYTES);
+        hipLaunchKernelGGL((k_awp_bwd_fused<PREC>), dim3((unsigned)blocks), dim3(256), (size_t)awpf::LDS_BYTES, st, fp);
+        EVD_LAUNCH_CHECK();
+        const AwpBwdGrads& g = b.grads;
+        WreduceJobs jobs;
+        for (int i = 0; i < WREDUCE_MAX_JOBS; ++i) {
+            const int l = i < 3 ? 3 - i : 1;            // jobs 0, 1, 2: layers 3, 2, 1; the rest empty
+            WreduceParams& q = jobs.j[i];
+            q.partial = b.partial + (long)awpf::acc0(l) * 1024; q.nparts = blocks; q.RT = (i < 3 && g.w[l]) ? 2 : 0; q.CT = 2; q.NC = 2;
+            q.rowmap = b.maps + AMAP_H; q.colmap = b.maps + AMAP_H; q.dW = g.w[l]; q.ld = AWP_W; q.db = nullptr;
+            q.maxbits = words; q.accum = 0; q.part_stride = (long)awpf::NBLK * 1024;
+        }
+        hipLaunchKernelGGL(k_wgrad_reduce_jobs, dim3(2 * 2 * 4, WREDUCE_MAX_JOBS), dim3(256), 0, st, jobs);
+        EVD_LAUNCH_CHECK();
+        BiasColsParams bp;
+        bp.partial = b.partial + (long)awpf::A_BIAS * 1024; bp.nparts = blocks; bp.part_stride = (long)awpf::NBLK * 1024; bp.ncols = 6;
+        for (int l = 1; l < AWP_D; ++l)
+            for (int yb = 0; yb < 2; ++yb) { bp.rowmap[2 * (3 - l) + yb] = b.maps + AMAP_H + 32 * yb; bp.db[2 * (3 - l) + yb] = g.b[l]; }
+        bp.maxbits = words; bp.accum = 0;
+        hipLaunchKernelGGL(k_bias_cols_reduce, dim3(6 * 32 / 4), dim3(256), 0, st, bp);
+        EVD_LAUNCH_CHECK();
+        // layer 0's weight gradient from the stored (d e0, geo) fragments: the per-layer kernel (behind the reduces above: they share `partial`)
+        {
+            if (g.w[0]) {
+                const int wb = (int)(b.tiles < b.wgrad_blocks ? b.tiles : b.wgrad_blocks);
+                WgradParams wp;
+                wp.store = b.store; wp.tiles = b.tiles; wp.tile_bytes = TILE_BYTES; wp.y_slot = D_E0; wp.x_slot = GEO; wp.bias = 1; wp.partial = b.partial;
+                int r = launch_wgrad<PREC, T, AWP_IN / 32, false>(wp, wb, st);
+                if (r) return r;
+                WreduceParams q;
+                q.partial = b.partial; q.nparts = wb; q.RT = T; q.CT = AWP_IN / 32; q.NC = q.CT + 1;
+                q.rowmap = b.maps + AMAP_H; q.colmap = b.maps + AMAP_GEO; q.dW = g.w[0]; q.ld = AWP_IN; q.db = g.b[0]; q.maxbits = words;
+                hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((long)T * q.NC * 4)), dim3(256), 0, st, q);
+                EVD_LAUNCH_CHECK();
+            }
+        }
+        if (b.d_geo_rows) {
+            hipLaunchKernelGGL((k_frags_to_rows<PREC>), dim3((unsigned)cdiv(b.tiles * 64 * (AWP_IN / 16), 256L)), dim3(256), 0, st, (const char*)b.store, TILE_BYTES,
+                               D_GEO, AWP_IN / 16, b.nsamp, words, b.d_geo_rows, AWP_IN);
+            EVD_LAUNCH_CHECK();
+        }
+        return EVD_OK;
     }
     hipLaunchKernelGGL((k_awp_rows_to_frags<PREC>), dim3((unsigned)cdiv(b.tiles * 64 * KW, 256L)), dim3(256), 0, st, b.d_h_local, b.nsamp, b.tiles, words, b.store);
     EVD_LAUNCH_CHECK();

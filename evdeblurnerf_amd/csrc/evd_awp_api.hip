@@ -121,7 +121,7 @@ size_t evd_awp_embed_store_bytes(const evd_awp_embed* a, long nsamp) {
 }
 
 static const int AWP_WGRAD_BLOCKS = 256;
-size_t evd_awp_embed_backward_workspace_bytes(void) { return (size_t)AWP_WGRAD_BLOCKS * 2 * 5 * 4096 + 512; }
+size_t evd_awp_embed_backward_workspace_bytes(void) { return (size_t)AWP_WGRAD_BLOCKS * 13 * 4096 + 512; }     // the fused backward's 13 blocks per workgroup (awp_bwd_fused.h); a per-layer wgrad needs 2 x 5
 
 int evd_awp_embed_forward(const evd_awp_embed* a, int precision, const float* geo_rows, const evd_voxel* fine, const void* fine_store,
                           size_t fine_store_bytes, long nsamp, float* h_local, void* store, size_t store_bytes, void* stream) {

@@ -328,32 +328,32 @@ __global__ __launch_bounds__(256, 1) void k_voxel_bwd_fused64(const VoxBwdFusedP
     }
 }
 
-// the shared bias block: column c of the workgroups' partial blocks summed -> the bias gradient it belongs to (rows through the index maps)
-struct F64BiasParams {
+// the shared bias block: column c of the workgroups' partial blocks summed -> the bias gradient it belongs to (rows through an index map)
+struct BiasColsParams {
     const float* partial;               // the bias block of workgroup 0
     int nparts;
     long part_stride;
-    const int* maps;
-    float* db[3];                       // colour_net.0, .1, .2 biases (null: not wanted)
+    int ncols;                          // <= 8 columns in use
+    const int* rowmap[8];               // column c: accumulator row nr -> row of db[c] (or -1)
+    float* db[8];                       // null: not wanted
     const unsigned* maxbits;
     int accum;
 };
-// one wavefront per used element (5 columns x 32 rows): its lanes share the workgroups' partial blocks
-static __global__ __launch_bounds__(256) void k_f64_bias_reduce(const F64BiasParams p) {
-    using namespace f64;
+// one wavefront per used element (ncols columns x 32 rows): its lanes share the workgroups' partial blocks
+static __global__ __launch_bounds__(256) void k_bias_cols_reduce(const BiasColsParams p) {
     const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (e >= 5 * 32) return;
-    const int nc = e % 5, nr = e / 5;                             // accumulator element (lane', i): column nc = lane' & 31, row nr = (i & 3) + 8 (i >> 2) + 4 (lane' >> 5)
+    if (e >= p.ncols * 32) return;
+    const int nc = e % p.ncols, nr = e / p.ncols;                 // accumulator element (lane', i): column nc = lane' & 31, row nr = (i & 3) + 8 (i >> 2) + 4 (lane' >> 5)
     const int idx = (nc + 32 * ((nr >> 2) & 1)) * 16 + (nr & 3) + 4 * (nr >> 3);
     float s = 0.f;
     for (int q = lane; q < p.nparts; q += 64) s += p.partial[(long)q * p.part_stride + idx];
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
     if (lane != 0) return;
-    const int layer = nc == B_C2 ? 2 : (nc < B_C0 ? 1 : 0);
-    const int row = nc == B_C2 ? p.maps[VMAP_COL + nr] : p.maps[VMAP_HID + 32 * (nc < B_C0 ? nc - B_C1 : nc - B_C0) + nr];
-    float* db = p.db[layer];
-    if (row < 0 || !db) return;
+    float* db = p.db[nc];
+    if (!db) return;
+    const int row = p.rowmap[nc][nr];
+    if (row < 0) return;
     const float v = s * grad_scale(*p.maxbits, true);
     db[row] = p.accum ? db[row] + v : v;
 }

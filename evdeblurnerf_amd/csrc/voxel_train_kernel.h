@@ -155,11 +155,15 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
             hipLaunchKernelGGL(k_wgrad_reduce_jobs, dim3(2 * 3 * 4, WREDUCE_MAX_JOBS), dim3(256), 0, st, jobs);
             EVD_LAUNCH_CHECK();
             if (g.color_b[0] || g.color_b[1] || g.color_b[2]) {        // the shared bias block (columns: colour_net.2, .1 x 2 row tiles, .0 x 2)
-                F64BiasParams bp;
-                bp.partial = b.partial + (long)f64::A_BIAS * 1024; bp.nparts = blocks; bp.part_stride = (long)f64::NBLK * 1024; bp.maps = b.maps;
-                for (int i = 0; i < 3; ++i) bp.db[i] = g.color_b[i];
+                BiasColsParams bp;
+                bp.partial = b.partial + (long)f64::A_BIAS * 1024; bp.nparts = blocks; bp.part_stride = (long)f64::NBLK * 1024; bp.ncols = 5;
+                bp.rowmap[f64::B_C2] = b.maps + VMAP_COL; bp.db[f64::B_C2] = g.color_b[2];
+                for (int yb = 0; yb < 2; ++yb) {
+                    bp.rowmap[f64::B_C1 + yb] = b.maps + VMAP_HID + 32 * yb; bp.db[f64::B_C1 + yb] = g.color_b[1];
+                    bp.rowmap[f64::B_C0 + yb] = b.maps + VMAP_HID + 32 * yb; bp.db[f64::B_C0 + yb] = g.color_b[0];
+                }
                 bp.maxbits = b.maxbits; bp.accum = b.accumulate;
-                hipLaunchKernelGGL(k_f64_bias_reduce, dim3(5 * 32 / 4), dim3(256), 0, st, bp);
+                hipLaunchKernelGGL(k_bias_cols_reduce, dim3(5 * 32 / 4), dim3(256), 0, st, bp);
                 EVD_LAUNCH_CHECK();
             }
             if (b.d_dirs) {
