@@ -693,6 +693,8 @@ def main(argv=None):
                                              "EVD_COMPOSITE_FORM=rows restores k_composite_rows)", "rays": Rc, "samples": S, "ms": cms, "bound": "hbm",
                                    "achieved": cbytes / (cms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": cbytes / (cms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": cbytes,
+                                   "traffic": {"read_bytes": 2 * 1323072.1e3 * 1.024, "write_bytes": 544893.2e3 * 1.024, "over_algorithmic": 1.004,
+                                               "source": "profiles/r05_pmc_composite.txt (FETCH_SIZE x 2 per the gfx950 correction of MI355X_MICROARCH.md, WRITE_SIZE; KB of 1024 B)"},
                                    "traffic_mix_ceiling": {"GBps": 6090, "frac_of_peak": 0.761, "what": "a bare kernel moving the same bytes in the same pattern "
                                                            "(20 B read + 4 B written per sample, non-temporal, no arithmetic): tools/probes/hbm_mix_probe.hip, "
                                                            "profiles/r05_composite_ab.log; read-only it reaches 7.05 TB/s, a float4 copy 6.22 TB/s"}}

@@ -16,9 +16,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob(root + "/" + c + "/**/*counter_collection.csv", recursive=True):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "k_composite_rows" in r["Kernel_Name"]: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-        for k, v in agg.items(): print(f"k_composite_rows {k}: median {sorted(v)[len(v)//2]:.1f} KB per dispatch ({len(v)} dispatches; first = with weights store)")
+            if "k_composite" in r["Kernel_Name"]: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, v in agg.items(): print(f"k_composite* {k}: median {sorted(v)[len(v)//2]:.1f} KB per dispatch, min {min(v):.1f}, max {max(v):.1f} ({len(v)} dispatches: full / no weights store / pdrf layout)")
 for f in glob.glob(root + "/trace/**/*kernel_stats.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_composite_rows" in r["Name"]: print("duration:", r["Name"][:40], r["Calls"], "calls avg", float(r["AverageNs"]) / 1e3, "us  min", float(r["MinNs"]) / 1e3)
+        if "k_composite" in r["Name"]: print("duration:", r["Name"][:60], r["Calls"], "calls avg", float(r["AverageNs"]) / 1e3, "us  min", float(r["MinNs"]) / 1e3)
 PY
