@@ -114,6 +114,28 @@ template <int PREC> __device__ __forceinline__ void frag_values(const char* lane
 
 struct W4 { unsigned w[4]; };
 
+// The two fragments of a 32-row dgrad output tile (accumulator rows (i & 3) + 8 (i >> 2) + 4 h as pairs, already rounded to half
+// precision) written as float32 ROWS: this lane's sample, features 16 f + 8 g + 4 h + 0..3 of the tile for fragment f, half g -- what
+// k_frags_to_rows makes of the stored fragments (voxel_train_kernel.h), without the round trip.  row = the sample's row + the tile's
+// first feature; 16-byte aligned (checked by the launcher).
+template <int PREC> __device__ __forceinline__ void frag_pair_to_row(const W4& f0, const W4& f1, float* row, int h, float inv) {
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const W4& fr = f ? f1 : f0;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            f32x4 v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned short bits = (unsigned short)(fr.w[2 * g + (k >> 1)] >> (16 * (k & 1)));
+                if constexpr (PREC == EVD_PREC_BF16) v[k] = __uint_as_float((unsigned)bits << 16) * inv;
+                else v[k] = (float)__builtin_bit_cast(_Float16, bits) * inv;
+            }
+            *reinterpret_cast<f32x4*>(row + 16 * f + 8 * g + 4 * h) = v;
+        }
+    }
+}
+
 struct DgradParams {
     const char* wstream;    // W^T as a fragment stream (pack.h), one layer
     char* store;
@@ -383,6 +405,11 @@ struct WgradFusedParams {
     int mask_slot, out_slot;
     int y_last_slot = -1;   // RT < 8: the slot of the LAST row tile's fragment pair when it does not follow the others (-1: it does)
     const char* ygen_wt = nullptr;      // YGEN: W^T stream of the 16-row layer ABOVE (8 output tiles x 1 k-step), see k_wgrad_dgrad
+    // optional: the first rows_tiles output tiles of d X leave as float32 rows [nsamp, rows_stride] (loss scale removed) instead of fragments
+    float* rows = nullptr;
+    int rows_stride = 0, rows_tiles = 0;
+    long nsamp = 0;
+    const unsigned* maxbits = nullptr;
 };
 
 constexpr int FUSED_WL = 6;        // W^T fragments per wavefront kept in LDS instead of registers (k_wgrad_dgrad)
@@ -394,7 +421,8 @@ constexpr int FUSED_WL = 6;        // W^T fragments per wavefront kept in LDS in
 // eight: L2 hits) in place of its 2 KiB of G, multiplies its 32 rows of the upper layer's W^T (one resident A fragment) with it, masks,
 // and puts the two fragments where the DMA would have put them.  The upper layer's dgrad launch, its 16 KiB write and this kernel's
 // 16 KiB read of G per tile are gone.
-template <int PREC, int CT, int TO, int OMASK, int RT_ = 8, int KD_ = 16, bool YGEN = false>
+// ROWS: the first rows_tiles output tiles of d X leave as float32 rows (WgradFusedParams::rows) instead of fragments.
+template <int PREC, int CT, int TO, int OMASK, int RT_ = 8, int KD_ = 16, bool YGEN = false, bool ROWS = false>
 __global__ __launch_bounds__(WGRAD_NT) void k_wgrad_dgrad(const WgradFusedParams fp) {
     static_assert(!YGEN || (RT_ == 8 && KD_ == 16), "a formed gradient has all 8 row tiles");
     static_assert(is_half_prec(PREC) && CT <= 8 && TO <= 8 && (OMASK == 0 || TO <= CT), "half-precision fragments, 8 x 32 gradient rows; a masked d X tile is a column tile of X");
@@ -548,7 +576,13 @@ __global__ __launch_bounds__(WGRAD_NT) void k_wgrad_dgrad(const WgradFusedParams
                     const typename O::B xa = __builtin_bit_cast(typename O::B, *reinterpret_cast<const W4*>(rw + 2048 + f * 1024));
                     O::mask_act(o2[f], xa);
                 }
-                *reinterpret_cast<f32x4*>(dst + f * 1024) = __builtin_bit_cast(f32x4, o2[f]);
+                if (!(ROWS && wave < fp.rows_tiles)) *reinterpret_cast<f32x4*>(dst + f * 1024) = __builtin_bit_cast(f32x4, o2[f]);
+            }
+            if (ROWS && wave < fp.rows_tiles) {
+                const long smp = t * 32 + n;
+                if (smp < fp.nsamp)
+                    frag_pair_to_row<PREC>(__builtin_bit_cast(W4, o2[0]), __builtin_bit_cast(W4, o2[1]), fp.rows + smp * fp.rows_stride + 32 * wave, h,
+                                           grad_scale(*fp.maxbits, true));
             }
         }
         __syncthreads();            // every wavefront is done with this tile's ring slots before any of them issues into the oldest one
@@ -568,11 +602,12 @@ __global__ __launch_bounds__(WGRAD_NT) void k_wgrad_dgrad(const WgradFusedParams
     if (bias_own) put(CT, accb);
 }
 
-template <int PREC, int CT, int TO, int OMASK, int RT_ = 8, int KD_ = 16, bool YGEN = false>
+template <int PREC, int CT, int TO, int OMASK, int RT_ = 8, int KD_ = 16, bool YGEN = false, bool ROWS = false>
 static int launch_wgrad_dgrad(const WgradFusedParams& p, int blocks, hipStream_t st) {
     const size_t lds = (size_t)WG_RING * 8 * 4 * 1024 + (size_t)CT * 2048 + (size_t)8 * FUSED_WL * 1024;
-    EVD_SET_MAX_LDS((&k_wgrad_dgrad<PREC, CT, TO, OMASK, RT_, KD_, YGEN>), lds);
-    hipLaunchKernelGGL((k_wgrad_dgrad<PREC, CT, TO, OMASK, RT_, KD_, YGEN>), dim3(blocks), dim3(WGRAD_NT), lds, st, p);
+    if (ROWS != (p.rows != nullptr)) return fail(EVD_E_INVALID, "k_wgrad_dgrad: the row output goes with the ROWS instantiation");
+    EVD_SET_MAX_LDS((&k_wgrad_dgrad<PREC, CT, TO, OMASK, RT_, KD_, YGEN, ROWS>), lds);
+    hipLaunchKernelGGL((k_wgrad_dgrad<PREC, CT, TO, OMASK, RT_, KD_, YGEN, ROWS>), dim3(blocks), dim3(WGRAD_NT), lds, st, p);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }

@@ -48,6 +48,8 @@ struct VoxBwdFusedParams {
     const char* wt[VBWD_NSTREAMS];
     const unsigned* maxbits;
     float* partial;                     // [gridDim.x][f64::NBLK][64 lanes][16] float32
+    float* d_fts;                       // [nsamp, d_fts_stride] float32 out (loss scale removed; 16-byte aligned rows), or null: fragments at D_FTS
+    int d_fts_stride;
 };
 
 // one stored fragment (one 32 x 16 block) transposed: transpose_block with an all-zero second fragment, one MFMA
@@ -305,6 +307,11 @@ __global__ __launch_bounds__(256, 1) void k_voxel_bwd_fused64(const VoxBwdFusedP
                 for (int j = 0; j < 4; ++j) d = mfma_half<PREC>(WT(W_L0 + 4 * r + j), dhid[j], d);
                 W4 o0, o1;
                 frags(d, o0, o1);
+                if (r == 0 && p.d_fts) {         // the feature gradient leaves as the float32 rows the tri-plane scatter reads (k_frags_to_rows' output)
+                    const long smp = t * 32 + n;
+                    if (smp < p.nsamp) frag_pair_to_row<PREC>(o0, o1, p.d_fts + smp * p.d_fts_stride, h, grad_scale(*p.maxbits, true));
+                    continue;
+                }
                 *reinterpret_cast<W4*>(out + (long)(VS::D_FTS + 2 * r) * 1024) = o0;
                 *reinterpret_cast<W4*>(out + (long)(VS::D_FTS + 2 * r + 1) * 1024) = o1;
             }

@@ -136,6 +136,10 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
             VoxBwdFusedParams fp;
             fp.d_raw = b.d_raw; fp.raw = b.raw; fp.nsamp = b.nsamp; fp.tiles = b.tiles; fp.store = b.store; fp.maxbits = b.maxbits; fp.partial = b.partial;
             for (int k = 0; k < VBWD_NSTREAMS; ++k) fp.wt[k] = b.wt[k];
+            // d fts straight as rows when they can be written with 16-byte stores (EVD_BWD_ROWS=0: fragments + k_frags_to_rows)
+            static const bool rows_on = [] { const char* e = getenv("EVD_BWD_ROWS"); return !(e && e[0] == '0'); }();
+            const bool rows_direct = rows_on && b.d_fts && b.d_fts_stride % 4 == 0 && ((uintptr_t)b.d_fts & 15) == 0;
+            fp.d_fts = rows_direct ? b.d_fts : nullptr; fp.d_fts_stride = b.d_fts_stride;
             EVD_SET_MAX_LDS((&k_voxel_bwd_fused64<PREC>), (size_t)f64::LDS_BYTES);
             hipLaunchKernelGGL((k_voxel_bwd_fused64<PREC>), dim3((unsigned)blocks), dim3(256), (size_t)f64::LDS_BYTES, st, fp);
             EVD_LAUNCH_CHECK();
@@ -171,7 +175,7 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
                                    VS::D_DIRPE, b.nsamp, b.viewdirs, b.vd_stride, b.S, b.maxbits, b.d_dirs, 0);
                 EVD_LAUNCH_CHECK();
             }
-            if (b.d_fts) {
+            if (b.d_fts && !rows_direct) {
                 hipLaunchKernelGGL((k_frags_to_rows<PREC>), dim3((unsigned)cdiv(b.tiles * 64 * KF, 256L)), dim3(256), 0, st, (const char*)b.store, VS::tile_bytes(PREC),
                                    VS::D_FTS, KF, b.nsamp, b.maxbits, b.d_fts, b.d_fts_stride);
                 EVD_LAUNCH_CHECK();
@@ -219,11 +223,12 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
     static const bool fuse_on = [] { const char* e = getenv("EVD_BWD_FUSE"); return !(e && e[0] == '0'); }();
     constexpr bool FUSABLE = is_half_prec(PREC) && T == 8;
     auto fused = [&](auto launch, int CT, bool bias, int y_slot, int x_slot, int ymap, int xmap, float* dW, int ld, float* db, int stream, int mask_slot, int out_slot,
-                     int RTr = 8, int y_last_slot = -1, const char* ygen_wt = nullptr) -> int {
+                     int RTr = 8, int y_last_slot = -1, const char* ygen_wt = nullptr, float* rows = nullptr, int rows_tiles = 0) -> int {
         const int blocks = (int)(b.tiles < b.wgrad_blocks ? b.tiles : b.wgrad_blocks);
         WgradFusedParams p;
         p.w.store = b.store; p.w.tiles = b.tiles; p.w.tile_bytes = VS::tile_bytes(PREC); p.w.y_slot = y_slot; p.w.x_slot = x_slot; p.w.bias = bias ? 1 : 0; p.w.partial = b.partial;
         p.wt = b.wt[stream]; p.out_store = b.store; p.mask_slot = mask_slot; p.out_slot = out_slot; p.y_last_slot = y_last_slot; p.ygen_wt = ygen_wt;
+        p.rows = rows; p.rows_stride = b.d_fts_stride; p.rows_tiles = rows_tiles; p.nsamp = b.nsamp; p.maxbits = b.maxbits;
         if (b.side) {                           // the wgrad launches in flight on the side stream use the partial scratch: join first
             EVD_HIP(hipEventRecord(b.ev, b.side));
             EVD_HIP(hipStreamWaitEvent(st, b.ev, 0));
@@ -318,11 +323,17 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
         if ((rc = launch_dgrad<PREC, 2 * GT + 1, T, 2 * GT, true, 2>(dgrad(VBWD_SIGGEO, VS::D_GEO, VS::G_SIG, VS::M_HID, VS::D_HID), b.tiles, st))) return rc;
     }
     // sigma_net.0 on cat([fts, PE(pts)])
-    bool l0_fused = false;
+    bool l0_fused = false, l0_rows = false;
     if constexpr (FUSABLE && FTT == 2) {
         if (fuse_on && g.sigma_w[0] && (b.d_fts || b.d_pts)) {     // ... with its dgrad (d fts | d PE(pts)) in one launch
             static_assert(VS::D_PE == VS::D_FTS + 2 * FTT, "d PE(pts) behind d fts");
-            if ((rc = fused(launch_wgrad_dgrad<PREC, FTT + 2, FTT + 2, 0>, FTT + 2, false, VS::D_HID, VS::IN0, VMAP_HID, VMAP_FTS, g.sigma_w[0], FT + IC, nullptr, VBWD_L0, -1, VS::D_FTS))) return rc;
+            // round 5: the feature tiles of d X leave as the float32 rows the scatter reads (EVD_BWD_ROWS=0: fragments + k_frags_to_rows)
+            static const bool rows_on = [] { const char* e = getenv("EVD_BWD_ROWS"); return !(e && e[0] == '0'); }();
+            l0_rows = rows_on && b.d_fts && b.d_fts_stride % 4 == 0 && ((uintptr_t)b.d_fts & 15) == 0;
+            if (l0_rows) rc = fused(launch_wgrad_dgrad<PREC, FTT + 2, FTT + 2, 0, 8, 16, false, true>, FTT + 2, false, VS::D_HID, VS::IN0, VMAP_HID, VMAP_FTS, g.sigma_w[0], FT + IC, nullptr,
+                                    VBWD_L0, -1, VS::D_FTS, 8, -1, nullptr, b.d_fts, FTT);
+            else rc = fused(launch_wgrad_dgrad<PREC, FTT + 2, FTT + 2, 0>, FTT + 2, false, VS::D_HID, VS::IN0, VMAP_HID, VMAP_FTS, g.sigma_w[0], FT + IC, nullptr, VBWD_L0, -1, VS::D_FTS);
+            if (rc) return rc;
             l0_fused = true;
         }
     }
@@ -337,7 +348,7 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
     }
     if (b.d_fts || b.d_pts) {
         if (!l0_fused && (rc = launch_dgrad<PREC, KS, FTT + 2, KS, false, 0>(dgrad(VBWD_L0, VS::D_HID, -1, -1, VS::D_FTS), b.tiles, st))) return rc;       // d fts | d PE(pts)
-        if (b.d_fts) {
+        if (b.d_fts && !l0_rows) {
             hipLaunchKernelGGL((k_frags_to_rows<PREC>), dim3((unsigned)cdiv(b.tiles * 64 * KF, 256L)), dim3(256), 0, st, (const char*)b.store, VS::tile_bytes(PREC),
                                VS::D_FTS, KF, b.nsamp, b.maxbits, b.d_fts, b.d_fts_stride);
             EVD_LAUNCH_CHECK();

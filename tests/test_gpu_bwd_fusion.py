@@ -1,6 +1,6 @@
 """Round 5's fused backward kernels against the per-layer chains they replace, through the library's own switches:
 k_voxel_bwd_fused64 (EVD_BWD_FUSE64), k_wgrad_dgrad<..., 5, 9> (EVD_BWD_FUSE_SG), YGEN (EVD_BWD_YGEN), k_awp_bwd_fused
-(EVD_AWP_BWD_FUSE).  The switches are read once per process, so tools/dev/bwd_fusion_ab.py runs in two subprocesses."""
+(EVD_AWP_BWD_FUSE), the feature gradient written as rows by the dgrad kernels (EVD_BWD_ROWS).  The switches are read once per process, so tools/dev/bwd_fusion_ab.py runs in two subprocesses."""
 import os
 import subprocess
 import sys
@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 def _run(path, off):
     env = dict(os.environ)
-    for k in ("EVD_BWD_FUSE64", "EVD_BWD_FUSE_SG", "EVD_BWD_YGEN", "EVD_AWP_BWD_FUSE"):
+    for k in ("EVD_BWD_FUSE64", "EVD_BWD_FUSE_SG", "EVD_BWD_YGEN", "EVD_AWP_BWD_FUSE", "EVD_BWD_ROWS"):
         env.pop(k, None)
         if off:
             env[k] = "0"
