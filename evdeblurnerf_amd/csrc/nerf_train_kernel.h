@@ -804,7 +804,11 @@ __global__ __launch_bounds__(256) void k_pe_bwd(const char* __restrict__ store, 
             const float v = fv[e];
             if (q < 3 * L) {
                 const float fr = (float)(1 << (q / 3)), a = xv[q % 3] * fr;
-                g[q % 3] += h == 0 ? v * cosf(a) * fr : -v * sinf(a) * fr;
+                // d sin = cos, d cos = -sin.  The half-precision modes take them from the hardware unit, as their forward does (sin_or_cos_hw:
+                // absolute error ~2^-20 against gradient fragments rounded at 2^-11; libm's cosf / sinf with their range reduction were 57 M VALU
+                // instructions per launch -- profiles/r05_pmc_train_step.txt --, the float32-grade mode keeps them)
+                const float tr = POps<PREC>::kFastTrig ? sin_or_cos_hw(a, h == 0 ? 1 : 0) : (h == 0 ? cosf(a) : sinf(a));
+                g[q % 3] += h == 0 ? v * tr * fr : -v * tr * fr;
             } else if (q == 3 * L) {
                 g[h] += v;                       // (x_0 | x_1)
             } else if (q == 3 * L + 1 && h == 0) {
