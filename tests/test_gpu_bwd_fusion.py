@@ -12,8 +12,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _run(path, off):
+def _run(path, off, small=False):
     env = dict(os.environ)
+    env.pop("AB_SMALL", None)
+    if small:
+        env["AB_SMALL"] = "1"
     for k in ("EVD_BWD_FUSE64", "EVD_BWD_FUSE_SG", "EVD_BWD_YGEN", "EVD_AWP_BWD_FUSE", "EVD_BWD_ROWS"):
         env.pop(k, None)
         if off:
@@ -22,10 +25,12 @@ def _run(path, off):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-def test_fused_backward_forms_equal_the_per_layer_chains(tmp_path):
+@pytest.mark.parametrize("small", [False, True])
+def test_fused_backward_forms_equal_the_per_layer_chains(tmp_path, small):
+    """small: at most one tile per wavefront; otherwise ~2 (64-wide level) / ~5 (AWP embedding) tiles per wavefront of the persistent kernels"""
     a, b = str(tmp_path / "fused.npz"), str(tmp_path / "chain.npz")
-    _run(a, off=False)
-    _run(b, off=True)
+    _run(a, off=False, small=small)
+    _run(b, off=True, small=small)
     fa, fb = np.load(a), np.load(b)
     assert set(fa.files) == set(fb.files) and len(fa.files) >= 30
     worst = {}

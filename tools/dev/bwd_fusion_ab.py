@@ -19,7 +19,9 @@ def c2f_grads(prec, out):
     model, sd = T._c2f_model(prec, 32, 24 ** 3, 48 ** 3)
     model.train()
     pc, pf = model.trainable_parameters(sd)
-    R, S, Ni = 333, 24, 16                       # 333 x 24 = 7992 coarse samples: a ragged last tile on both levels
+    # 2501 x 24 = 60 024 coarse samples = 1876 tiles (ragged last one): more tiles than the fused kernel has wavefronts (1024), so its
+    # persistent loop with the loads of the NEXT tile in flight runs; small: one tile per wavefront at most
+    R, S, Ni = (333 if os.environ.get("AB_SMALL") else 2501), 24, 16
     rb = torch.tensor(T._c2f_rays(R, 4), device="cuda", requires_grad=True)
     tgt = torch.tensor(np.random.RandomState(5).uniform(0, 1, (R, 3)).astype(np.float32), device="cuda")
     res = model.render_rays_train(rb, pc, pf, S, Ni)
@@ -40,7 +42,7 @@ def awp_grads(prec, out):
     emb = SampleFeatureEmbed(ws, bs, precision=prec)
     flat = torch.cat([torch.tensor(t).reshape(-1) for l in range(4) for t in (ws[l], bs[l])]).cuda().requires_grad_(True)
     rs = np.random.RandomState(7)
-    n = 40 * 128 - 19                            # ragged last tile
+    n = (40 if os.environ.get("AB_SMALL") else 1200) * 128 - 19      # ragged last tile; 4800 tiles: several per wavefront
     x = torch.tensor((rs.standard_normal((n, 128)) * 0.7).astype(np.float32), device="cuda", requires_grad=True)
     w = torch.tensor((rs.standard_normal((n, 64)) * 1e-3).astype(np.float32), device="cuda")
     h = emb(flat, x)
