@@ -314,13 +314,13 @@ def c2f_leg(precision, steps, parity=True):
     esz = 2 if half_grids else 4
     taps = 4 * 96 + 2 * 96                                      # 4 plane taps + 2 line taps x 96 channels = 576 gathered values per sample
     gathered = n * taps * esz
-    # PMC of THIS kernel build (profiles/r04_pmc_voxel.json, made by tools/pmc_voxel.sh this round: rocprofv3 cannot run inside the timed
+    # PMC of THIS kernel build (profiles/r04_pmc_voxel.json, made by tools/pmc_voxel.sh; the gather kernel is unchanged since round 4: rocprofv3 cannot run inside the timed
     # process), per sample of the fine-level launch: 128-byte line READ requests at the L2 and the lines that miss it (served by the Infinity
     # Cache: the 165 MB of grids exceed the 32 MB of L2).  The kernel is a random gather: its roofline is the RATE at which the chip serves
     # such requests, measured by tools/probes/gather_probe.hip (random 128-byte records, 16-byte lane loads), not an HBM byte rate.
     pj = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_voxel.json")))["f16_grids" if half_grids else "f32_grids"]
     pmc = {"l2_requests_per_sample": pj["l2_read_requests_per_sample"], "l2_miss_lines_per_sample": pj["l2_miss_lines_per_sample"],
-           "fetch_size_bytes_per_sample": pj["fetch_size_bytes_per_sample"], "source": pj["file"] + " (committed profile of this round's kernel; the "
+           "fetch_size_bytes_per_sample": pj["fetch_size_bytes_per_sample"], "source": pj["file"] + " (committed profile of this kernel, unchanged since round 4; the "
            "fraction below is counter-derived requests x the launch duration measured in this run)"}
     ceil = {"l2_resident": 146e9, "infinity_cache": 58e9, "hbm": 54e9}
     req_rate = pmc["l2_requests_per_sample"] * n / (g_ms * 1e-3)
@@ -495,6 +495,10 @@ def train_iteration_leg(precision):
                                "note": "f16m = float32-grade forward (float32's own ReLU patterns) + float16 backward; f16c = compensated forward: ~5e-6 of the "
                                        "units flip against float32, which bounds the gradients at ~sqrt(5e-6) of their norm whatever the batch size; f16 = "
                                        "single-product float16 forward (1e-3 of the units flip)"},
+            "backward_forms": "round 5: the 64-wide level's whole backward in one launch (k_voxel_bwd_fused64), sigma_net.1 as one fused launch (k_wgrad_dgrad RT_ = 5), "
+                              "d c1 formed inside color_net.1's launch (YGEN), d fts as rows from the dgrad kernels, the AWP embedding's backward in one launch "
+                              "(k_awp_bwd_fused); each has a switch back to the per-layer chain (INTEGRATION.md section 5) and equals it to 5e-7 "
+                              "(tests/test_gpu_bwd_fusion.py)",
             "with_awp_ms_per_iteration": {"fused_on_geo_fragments": ms_awp_f, "torch_module_on_depth_feature": ms_awp_t,
                                           "note": "AWP module = tools/awp_standin.py (the reference module's surface; its per-sample embedding is the reference's)"},
             "scatter_hybrid_ms": h_ms, "scatter_all_atomics_ms": k_ms,
@@ -506,7 +510,7 @@ def train_iteration_leg(precision):
                          "bound": "memory-side atomics (requests/s)", "kernel_ms": h_ms, "atomic_requests": req, "achieved": achieved, "peak": peak,
                          "unit": "G atomic requests/s", "frac": achieved / peak,
                          "bytes_written": 562e6, "write_GBps": 562e6 / (h_ms * 1e-3) / 1e9,
-                         "pmc_source": "profiles/r04_pmc_scatter.txt (TCC_ATOMIC_sum, WRITE_SIZE of this round's kernels)",
+                         "pmc_source": "profiles/r04_pmc_scatter.txt (TCC_ATOMIC_sum, WRITE_SIZE; the scatter kernels are unchanged since round 4)",
                          "all_atomics_form": {"kernel_ms": k_ms, "atomic_requests": 18937705, "achieved": 18937705 / (k_ms * 1e-3) / 1e9, "frac": 18937705 / (k_ms * 1e-3) / 1e9 / peak},
                          "note": "achieved = PMC-counted atomic requests of the two launches / their duration measured here; peak = the request rate of a bare "
                                  "atomic kernel on this chip (20 G/s whatever the table size).  The all-atomics form (every tap a float atomic, 18.9 M requests) "
