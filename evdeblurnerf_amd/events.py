@@ -29,6 +29,43 @@ def compute_successor(pixel_ids, num_pixels):
     return succ, nsucc, latest, first
 
 
+def annealing_interpolator(start_value, end_value, end_step, method="linear", start_step=0):
+    """utils/misc.py:15-55 restated: step -> a value between start_value and end_value ('linear', 'cosine', 'constant'); the reference's
+    linear branch multiplies the slope by `step`, not by `step - start_step` (:38) -- kept."""
+    import math
+    if method == "linear":
+        def f(step):
+            if step >= end_step:
+                return end_value
+            if step < start_step:
+                return start_value
+            return start_value + (end_value - start_value) / (end_step - start_step) * step
+        return f
+    if method == "cosine":
+        def f(step):
+            if step >= end_step:
+                return end_value
+            if step < start_step:
+                return start_value
+            c = (1 + math.cos(math.pi * (step - start_step) / (end_step - start_step))) / 2
+            return start_value * c + end_value * (1 - c)
+        return f
+    if method == "constant":
+        return lambda step: start_value
+    raise ValueError("Unsupported method: {}".format(method))
+
+
+def draw_hops(num_successors, min_step, max_step):
+    """loader_events.py:262-268 + utils/misc.py:87-92 (torch_randint_vec): per event a uniform draw in [min_step - 1,
+    min(max_step, num_successors) - 1 + 1e-5], rounded to int64 -- the same torch calls in the same order, so a seeded generator gives the
+    reference's hops.  num_successors [n] (of the batch's events), on the device the draw should run on."""
+    dev = num_successors.device
+    mins = torch.tensor(min_step, device=dev) - 1
+    maxs = torch.minimum(torch.tensor(max_step, device=dev), num_successors) - 1 + 1e-5
+    values = torch.distributions.uniform.Uniform(mins.float(), maxs.float()).sample()
+    return torch.round(values).to(torch.int64)
+
+
 class EventSampler:
     """The tables EventsDataset keeps on the device (data/loader_events.py:60-75: events [N, ncol] float64 with the successor index in the
     last column, id_to_coords, id_to_color_map) and ``sample_events`` on them.
@@ -58,6 +95,25 @@ class EventSampler:
         self.K = np.ascontiguousarray(np.asarray(K, dtype=np.float32).reshape(-1))
         self.integer_coords = bool(integer_coords)
         self._mismatch = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.num_successors = None
+        self._hop_schedule = None
+
+    def set_hop_schedule(self, events_num_successors, step_range, step_range_end, step_end, scheduler="linear"):
+        """loader_events.py:53-70: the tables / schedules behind the multi-hop branch of sample_events (event_accumulate_step_range,
+        _range_end, _step_end, _step_scheduler).  After this, sample_events(events_ids, global_step=...) draws the hops as the reference."""
+        self.num_successors = torch.as_tensor(events_num_successors, device=self.events.device)
+        self._hop_schedule = (annealing_interpolator(step_range[0], step_range_end[0], step_end, scheduler),
+                              annealing_interpolator(step_range[1], step_range_end[1], step_end, scheduler))
+
+    def hops_for(self, events_ids, global_step):
+        """-> hops [n] int64, or None in the single-hop branch ((min_step, max_step) == (0, 0), loader_events.py:262-264)"""
+        if self._hop_schedule is None:
+            return None
+        min_step, max_step = int(self._hop_schedule[0](global_step)), int(self._hop_schedule[1](global_step))
+        if (min_step, max_step) == (0, 0):
+            return None
+        ids = events_ids.to(device=self.events.device, dtype=torch.int64)
+        return draw_hops(self.num_successors[ids], min_step, max_step)
 
     def interpolate_poses(self, t):
         """loader_events.py:133-148 (needs pose_track)."""
@@ -65,11 +121,13 @@ class EventSampler:
             raise L.EvdError("EventSampler.interpolate_poses: constructed with a pose table, not a pose_track")
         return self.pose_track.interpolate_poses(t)
 
-    def sample_events(self, events_ids, hops=None, check=False):
+    def sample_events(self, events_ids, hops=None, check=False, global_step=None):
         """loader_events.py:259-304.  hops None: the branch of the shipped configs (event_accumulate_step_range [0, 0]); else the number of
         successor hops per event (the reference draws them, :265-268; gather_successor follows hops + 1 links).  Returns the reference's
         dict (rays [n, 3, 2], polarity sums float32).  check=True reads the device flag back (the reference's assert :284; also set by an
         id outside the table or, in the single-hop branch, an event without successor)."""
+        if hops is None and global_step is not None:          # the reference's signature: sample_events(events_ids, global_step)
+            hops = self.hops_for(events_ids, global_step)
         ids = events_ids.to(device=self.events.device, dtype=torch.int64).contiguous()
         n, dev = ids.shape[0], self.events.device
         hp = hops.to(device=dev, dtype=torch.int64).contiguous() if hops is not None else None

@@ -692,3 +692,19 @@ def test_G27_awp_per_ray():
             continue
         assert np.linalg.norm(got.numpy() - ref) < 3e-5 * np.linalg.norm(ref), (key, np.linalg.norm(got.numpy() - ref) / np.linalg.norm(ref))
     assert maxabs(awp.MAM.Corr.convd[1].running_mean.numpy(), g["after.running_mean"]) < 1e-6
+
+
+def test_G31_event_hop_schedule_and_draw():
+    """evdeblurnerf_amd.events.annealing_interpolator / draw_hops (host logic of EventSampler.sample_events(events_ids, global_step=...))
+    against the reference's utils/misc.py functions as loader_events.py:259-268 composes them (golden G31; no GPU: the draw runs on
+    the CPU generator)."""
+    import torch
+    from evdeblurnerf_amd.events import annealing_interpolator, draw_hops
+    g = load_golden("G31_event_hops")
+    for m in ("linear", "cosine", "constant"):
+        got = np.array([[float(annealing_interpolator(int(a), int(b), int(e), m)(int(st))) for st in g["steps"]] for a, b, e in g["cases"]])
+        assert np.array_equal(got, g[f"interp_{m}"]), m
+    for i, (mn, mx) in enumerate(g["draws"]):
+        torch.manual_seed(3100 + i)
+        hops = draw_hops(torch.tensor(g[f"ns_{i}"]), int(mn), int(mx))
+        assert hops.dtype == torch.int64 and np.array_equal(hops.numpy(), g[f"hops_{i}"]), (i, mn, mx)

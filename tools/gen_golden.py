@@ -1180,11 +1180,33 @@ def G29_pose_track():
     save64("G29_pose_track", **out)
 
 
+def G31_event_hops():
+    """The hop schedule of EventsDataset.sample_events (data/loader_events.py:53-70,259-268): utils/misc.py annealing_interpolator (linear /
+    cosine / constant) on a grid of steps, and torch_randint_vec (utils/misc.py:87-92) for seeded draws on the CPU generator (torch
+    2.10: the fixture pins this version's stream), as sample_events composes them."""
+    from utils.misc import annealing_interpolator, torch_randint_vec
+    out = {}
+    steps = np.array([0, 1, 17, 49, 50, 51, 999, 1000, 5000], dtype=np.int64)
+    cases = [(1, 8, 1000), (4, 2, 50), (0, 0, 10), (2, 30, 777)]
+    out["steps"], out["cases"] = steps, np.array(cases, dtype=np.int64)
+    for m in ("linear", "cosine", "constant"):
+        out[f"interp_{m}"] = np.array([[float(annealing_interpolator(a, b, e, m)(int(st))) for st in steps] for a, b, e in cases], dtype=np.float64)
+    rs = np.random.RandomState(3101)
+    draws = [(1, 8), (2, 30), (1, 1), (3, 3)]
+    out["draws"] = np.array(draws, dtype=np.int64)
+    for i, (mn, mx) in enumerate(draws):
+        ns = torch.tensor(rs.randint(mn + 1, 40, 4096))
+        torch.manual_seed(3100 + i)
+        hops = torch_randint_vec(torch.tensor(mn) - 1, torch.minimum(torch.tensor(mx), ns) - 1 + 1e-5, torch.int64)      # loader_events.py:265-268
+        out[f"ns_{i}"], out[f"hops_{i}"] = ns.numpy().astype(np.int64), hops.numpy().astype(np.int64)
+    save64("G31_event_hops", **out)
+
+
 ALL = [G1_embedder, G2_nerf_mlp, G3_nerf_raw2outputs, G4_voxel_raw2outputs, G5_sample_pdf, G6_rays,
        G7_render_nerf, G8_appfeature, G9_render_c2f, G10_rbk_weighted_sum, G11_crf, G12_egm_loss, G13_edi,
        G14_loss_assembly, G15_awp_feature_integration, G16_rbk_warp, G17_compute_successor, G18_nerf_grads, G19_c2f_grads, G20_loss_grads,
        G21_awp_sample_embed, G22_mam, G23_render_nerf_no_viewdirs, G24_render_other_multires, G25_pbe_composite_feature,
-       G26_sample_events, G27_awp_per_ray, G28_image_batch, G29_pose_track, G30_c2f_grads_16k]
+       G26_sample_events, G27_awp_per_ray, G28_image_batch, G29_pose_track, G30_c2f_grads_16k, G31_event_hops]
 
 if __name__ == "__main__":
     want = set(sys.argv[1:])
