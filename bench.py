@@ -446,6 +446,10 @@ def train_iteration_leg(precision):
         if other != precision:
             modes[other], _, _ = BT.run(types.SimpleNamespace(precision=other, iters=8, pixels=1024, events=4096, P=10))
             torch.cuda.empty_cache()
+    # integration option: the event batch's start and end rays rendered in ONE call (run_nerf.py:534,547 calls nerf() twice; a ray's colour does
+    # not depend on its batch): fewer, larger launches.  Reported beside the figure of the reference's own call pattern, which stays `ms`.
+    ms_merged, _, _ = BT.run(types.SimpleNamespace(precision=precision, iters=8, pixels=1024, events=4096, P=10, merge_events=True))
+    torch.cuda.empty_cache()
     par = TP.c2f_gradient_parity(tuple(modes))
     torch.cuda.empty_cache()
     # the same iteration with the shipped configs' adaptive weight proposal on the blur batch (kernel_use_awp): the per-sample part fused
@@ -485,6 +489,7 @@ def train_iteration_leg(precision):
                         "losses, TV, backward, Adam, parameter re-pack", "precision": precision, "ms_per_iteration": ms, "rays_per_iteration": nrays,
             "rays_per_s": nrays / (ms * 1e-3),
             "ms_per_iteration_by_mode": modes,
+            "ms_per_iteration_event_rays_in_one_call": ms_merged,
             "parity_holding_mode": {"mode": "f16m", "ms_per_iteration": modes.get("f16m"),
                                     "what": "the fastest mode whose GRADIENTS stay within 2e-3 of the norm of the reference's autograd (goldens G19, G30 at 16 384 "
                                             "samples; tests/test_gpu_train_f16c.py); 'precision' above (f16c) holds the rendered colours to 1e-4 (north_star's bound) "

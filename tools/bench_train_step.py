@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--plain-autograd", action="store_true",
                     help="parameter / grid gradients returned to autograd (the library's default) instead of accumulated in place by the backward kernels "
                          "(NeRFAll.enable_training(grads_in_place=True): what a run_nerf.py-style loop opts into)")
+    ap.add_argument("--merge-events", action="store_true", help="render the event batch's start and end rays in one call (integration option; the reference calls nerf() twice)")
     ap.add_argument("--mam", choices=["mean", "corr"], default="corr",
                     help="the AWP module's motion aggregation: corr = the reference's MotionAggregationModule structure (MAMLike), mean = a small stand-in")
     a = ap.parse_args()
@@ -124,8 +125,15 @@ def run(a):
         # the fused blur loss takes the per-sub-exposure colours and the weights; here the composed colours with unit weights
         ones = torch.ones((R, 1), device=dev)
         pb = blur_loss_partials_autograd(crf_rgb, rgb[:, None], ones, tgt, rgb0_p=rgb0[:, None], w2=ones, target_pts0=tgt0)
-        s1, s10, _, _ = model(400, 400, K, 1 << 22, rays=ev_start, force_naive=True, tv=False, **kw)
-        s2, s20, _, _ = model(400, 400, K, 1 << 22, rays=ev_end, force_naive=True, tv=False, **kw)
+        if getattr(a, "merge_events", False):
+            # the start and end rays of the event batch as ONE render call (a ray's colour does not depend on the other rays of its batch:
+            # the same numbers as two calls up to the draw order of the stratification randoms); what a maintainer's integration can do
+            # where run_nerf.py:534,547 calls nerf() twice -- fewer, larger launches
+            s12, s120, _, _ = model(400, 400, K, 1 << 22, rays=torch.cat([ev_start, ev_end], 0), force_naive=True, tv=False, **kw)
+            s1, s2, s10, s20 = s12[:E], s12[E:], s120[:E], s120[E:]
+        else:
+            s1, s10, _, _ = model(400, 400, K, 1 << 22, rays=ev_start, force_naive=True, tv=False, **kw)
+            s2, s20, _, _ = model(400, 400, K, 1 << 22, rays=ev_end, force_naive=True, tv=False, **kw)
         pe = event_loss_partials_autograd(crf_ev, crf_flat, s1, s2, cum_neg, cum_pos, 0.2, 0.2, start0=s10, end0=s20, add_bii="pos-neg")
         if ddp:
             pb, pe = D.all_reduce_partials(pb, pe)
