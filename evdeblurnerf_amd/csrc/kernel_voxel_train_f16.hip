@@ -20,3 +20,9 @@ long voxel_store_tile_bytes(int HD) { return HD == 256 ? VStore<256, 128, 64>::T
 int launch_voxel_coarse_pipe_f16(const VoxMlpParams& p, hipStream_t st) { return launch_voxel_pipe_level<EVD_PREC_F16, 64, 15, 32>(p, st); }
 
 }  // namespace evd
+
+#ifdef EVD_WD_STAMP     // developer build (tools/dev/stamp_wgrad_dgrad.sh): the phase stamps of the last k_wgrad_dgrad launch of a kind
+extern "C" int evd_debug_wd_stamps(float* host_out, int kind) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(evd::g_wd_stamp), 2048 * 8 * sizeof(float), (size_t)kind * 2048 * 8 * sizeof(float), hipMemcpyDeviceToHost);
+}
+#endif

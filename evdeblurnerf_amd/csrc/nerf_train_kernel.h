@@ -413,6 +413,9 @@ struct WgradFusedParams {
 };
 
 constexpr int FUSED_WL = 6;        // W^T fragments per wavefront kept in LDS instead of registers (k_wgrad_dgrad)
+#ifdef EVD_WD_STAMP
+__device__ float g_wd_stamp[32 * 2048 * 8];
+#endif
 
 // RT_ < 8 (round 5: sigma_net.1 = [geo rows | sigma row], 4 + 1 row tiles): wavefronts RT_ .. 7 own no gradient rows (no wgrad products,
 // no partial blocks), the dgrad runs over the first KD_ gradient fragments (the last row tile may be a single fragment: KD_ = 2 RT_ - 1).
@@ -438,7 +441,11 @@ __global__ __launch_bounds__(WGRAD_NT) void k_wgrad_dgrad(const WgradFusedParams
     const int NC = CT + (p.bias ? 1 : 0);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = lane & 31, h = lane >> 5;
     const int rt = wave, c0 = 0;
-    const bool xown = wave < CT, yown = wave < RT_, bias_own = p.bias != 0 && yown, down = wave < TO;
+    // (activation block w belongs to wavefront w.  Also measured, round 5: with no mask the LAST CT wavefronts taking the blocks, so that in
+    // the 8 x 4 / 8 x 5 launches the dgrad wavefronts do not transpose as well -- same box 13.55 / 13.56 / 13.56 against 13.52 / 13.58 / 13.56 ms
+    // per iteration: the wait moves between the two barriers, removed)
+    const int xw = wave;
+    const bool xown = xw >= 0 && xw < CT, yown = wave < RT_, bias_own = p.bias != 0 && yown, down = wave < TO;
     const unsigned one = half_one_pair<PREC>();
     f32x16 acc[CPG], accb;
 #pragma unroll
@@ -461,7 +468,7 @@ __global__ __launch_bounds__(WGRAD_NT) void k_wgrad_dgrad(const WgradFusedParams
     // (wavefronts beyond RT_: row tile 0's pair again, unused -- every tile costs every wavefront the same four DMA instructions)
     const int ys = (YGEN || !yown) ? p.y_slot : (RT_ < 8 && rt == RT_ - 1 && fp.y_last_slot >= 0) ? fp.y_last_slot : p.y_slot + 2 * rt;
     const long oy = (long)ys * 1024 + lane * 16;
-    const long ox = (xown ? (long)(p.x_slot + 2 * wave) * 1024 : (long)ys * 1024) + lane * 16 - 2048;
+    const long ox = (xown ? (long)(p.x_slot + 2 * xw) * 1024 : (long)ys * 1024) + lane * 16 - 2048;
     const unsigned ring0 = lds_offset_of(raw) + wave * 4096;
     auto issue = [&](long t, int stage) {
         if (t >= p.tiles) return;
@@ -484,12 +491,23 @@ __global__ __launch_bounds__(WGRAD_NT) void k_wgrad_dgrad(const WgradFusedParams
     for (int j = 0; j < KD - WL; ++j) asm volatile("" : "+v"(wt[j].w[0]), "+v"(wt[j].w[1]), "+v"(wt[j].w[2]), "+v"(wt[j].w[3]));
 #pragma unroll
     for (int k = 0; k < WG_RING - 1; ++k) issue(t + k * stride, k);
+#ifdef EVD_WD_STAMP     // developer build (tools/dev/stamp_wgrad_dgrad.sh): shader-clock cycles of this wavefront's phases summed over its tiles
+    long long wph[6] = {0, 0, 0, 0, 0, 0}, wq0, wq1;
+    int wtiles = 0;
+#define EVD_WD_T0() wq0 = __builtin_readcyclecounter()
+#define EVD_WD_T(i) { wq1 = __builtin_readcyclecounter(); wph[i] += wq1 - wq0; wq0 = wq1; }
+#else
+#define EVD_WD_T0()
+#define EVD_WD_T(i)
+#endif
     for (int it = 0; t < p.tiles; t += stride, ++it) {
+        EVD_WD_T0();
         issue(t + (WG_RING - 1) * stride, (it + WG_RING - 1) % WG_RING);
         const int later = (t + stride < p.tiles ? 1 : 0) + (t + 2 * stride < p.tiles ? 1 : 0);
         if (later == 2) wait_vmcnt<8>();
         else if (later == 1) wait_vmcnt<4>();
         else wait_vmcnt<0>();
+        EVD_WD_T(0);
         // the transposition selectors and the bias column are re-made per tile (a dozen VALU instructions) instead of living in 12 registers
         // next to 128 + 16 accumulators and the 64 registers of W^T: the kernel spilled into its loop, and scratch loads drain the VM counter
         W4 sel0, sel1, ones;
@@ -536,9 +554,11 @@ __global__ __launch_bounds__(WGRAD_NT) void k_wgrad_dgrad(const WgradFusedParams
             W4 xt[2];
             transpose_block<PREC>(x0, x1, sel0, sel1, xt);
 #pragma unroll
-            for (int q = 0; q < 2; ++q) *reinterpret_cast<W4*>(xb + (wave * 2 + q) * 1024 + lane * 16) = xt[q];
+            for (int q = 0; q < 2; ++q) *reinterpret_cast<W4*>(xb + (xw * 2 + q) * 1024 + lane * 16) = xt[q];
         }
+        EVD_WD_T(1);
         __syncthreads();
+        EVD_WD_T(2);
 #pragma unroll
         for (int c = 0; c < CPG; ++c) {
             if (c0 + c < CT && (RT_ == 8 || yown)) {
@@ -553,6 +573,7 @@ __global__ __launch_bounds__(WGRAD_NT) void k_wgrad_dgrad(const WgradFusedParams
 #pragma unroll
             for (int q = 0; q < 2; ++q) accb = mfma_half<PREC>(yt[q], ones, accb);
         }
+        EVD_WD_T(3);
         // d X tile `wave` = W^T rows . G: gradient fragment j sits in wavefront j / 2's ring slot, fragment j & 1
         if (down) {
             f32x16 d = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -585,8 +606,20 @@ __global__ __launch_bounds__(WGRAD_NT) void k_wgrad_dgrad(const WgradFusedParams
                                            grad_scale(*fp.maxbits, true));
             }
         }
+        EVD_WD_T(4);
         __syncthreads();            // every wavefront is done with this tile's ring slots before any of them issues into the oldest one
+        EVD_WD_T(5);
+#ifdef EVD_WD_STAMP
+        ++wtiles;
+#endif
     }
+#ifdef EVD_WD_STAMP
+    if (lane == 0) {                // [kind = CT + 8 YGEN ...][block][wavefront][8] floats, read back by evd_debug_wd_stamps
+        float* sp = g_wd_stamp + ((long)(CT + (YGEN ? 8 : 0) + (RT_ < 8 ? 16 : 0)) * 2048 + (long)blockIdx.x * 8 + wave) * 8;
+        for (int i = 0; i < 6; ++i) sp[i] = (float)wph[i];
+        sp[6] = (float)wtiles; sp[7] = -7.f;
+    }
+#endif
     if (RT_ < 8 && !yown) return;           // (the reduce reads RT_ row tiles of every workgroup's 8-tile set: WreduceParams::part_stride)
     float* out = p.partial + (((long)blockIdx.x * RT + rt) * NC) * 1024 + lane * 16;
     auto put = [&](int c, const f32x16& a) {
