@@ -149,8 +149,13 @@ class _Level:
     canonical order, `leaves` one autograd leaf per reference parameter, each a VIEW of `flat` (an optimizer's in-place update of a
     leaf updates the storage the library re-packs from, and bumps its shared version counter); `grids` the tri-plane leaves."""
 
-    def __init__(self, net, prefix, flat, blocks, grids, in_place):
+    def __init__(self, net, prefix, flat, blocks, grids, in_place, absent=()):
+        """absent: parameter blocks of the library's layout that the reference model does NOT have (the colour networks' biases with
+        rgb_add_bias off, voxnerf.py:60,80 / nerf.py:37 -- every shipped config): they stay zero in `flat`, get no leaf, appear in no
+        optimizer group or state dict, and whatever the backward kernels write into their gradient slices is never read."""
         from collections import OrderedDict
+        self.all_blocks = blocks
+        blocks = [b for b in blocks if b[0] not in absent]
         self.net, self.prefix, self.flat, self.blocks, self.grids, self.in_place = net, prefix, flat, blocks, grids, in_place
         self.sizes = [int(np.prod(shape)) for _, shape, _ in blocks]
         self.leaves = OrderedDict((prefix + key, flat[o:o + n].view(shape).detach().requires_grad_(True)) for (key, shape, o), n in zip(blocks, self.sizes))
@@ -770,7 +775,10 @@ class NeRFAll:
                 net._grid_grad_flat = (torch.empty((sum(t.numel() for t in g),), dtype=torch.float32, device=self.device)
                                        if self._grads_in_place else None)
             net._synced = net._synced_net = None
-            levels.append(_Level(net, prefix, flat, blocks, grids, self._grads_in_place))
+            absent = {key for key, _, _ in blocks if prefix + key not in state_dict}
+            if any(not key.endswith(".bias") for key in absent):
+                raise L.EvdError(f"state dict lacks {sorted(prefix + k for k in absent if not k.endswith('.bias'))}")
+            levels.append(_Level(net, prefix, flat, blocks, grids, self._grads_in_place, absent))
         self._levels = levels
         return self
 

@@ -135,6 +135,22 @@ def prefixed(sd, prefix: str):
     return OrderedDict((f"{prefix}.{k}", v) for k, v in sd.items())
 
 
+def make_train_call_state_dict(seed: int, grid_coarse, grid_fine):
+    """Both PDRF levels of the training-call goldens G32 / G33 (tools/gen_golden.py ``_train_call_model``): the default initialisation
+    with denser fields (sigma_net.1 x 2: weights that vary along the ray and importance samples that move, while sample_pdf's
+    (u - cdf) / pdf stays conditioned well enough that reference and kernels agree to 1e-5 on every pixel -- at x 3 a third of the
+    rays carry a sample that moves by 4e-4 between two float32 implementations and a colour by 7e-5) and colours away from sigmoid(0)
+    (color_net.2 x 8: the P sub-exposure rays of a pixel differ by a few 1e-2); rgb_add_bias off as in every shipped config."""
+    sd = prefixed(make_pdrf_state_dict(seed * 10 + 3, grid_coarse, input_ch=32 + 63, hidden_dim=64, geo_feat_dim=15), "mlp_coarse")
+    sd.update(prefixed(make_pdrf_state_dict(seed * 10 + 4, grid_fine, input_ch=64 + 63, hidden_dim=256, geo_feat_dim=128), "mlp_fine"))
+    for k in list(sd):
+        if k.endswith("sigma_net.1.weight"):
+            sd[k] = sd[k] * np.float32(2.0)
+        elif k.endswith("color_net.2.weight"):
+            sd[k] = sd[k] * np.float32(8.0)
+    return sd
+
+
 # ---------------------------------------------------------------------------
 # synthetic LLFF-shaped inputs (SURVEY.md 8d)
 # ---------------------------------------------------------------------------

@@ -550,5 +550,48 @@ def tv_loss(x):
     return lib().evo_tv_loss(_p(x), Cc, H, W)
 
 
+def tv_loss_app(sd, prefix=""):
+    """VoxelNeRFBase.TV_loss_app (voxnerf.py:126-130): sum over the three axes of reg(plane) 1e-2 + reg(line) 1e-3"""
+    tot = 0.0
+    for i in range(3):
+        tot += tv_loss(np.asarray(sd[f"{prefix}app_plane.{i}"])) * 1e-2 + tv_loss(np.asarray(sd[f"{prefix}app_line.{i}"])) * 1e-3
+    return tot
+
+
+def train_forward(coarse: Voxel, fine: Voxel, cfg, new_rays, weight, img_embed, awp_sd, sd_levels, ccw_fine_scale=0.05, ray_dir_freq=2):
+    """The training branch of NeRFAll.forward behind the blur kernel (networks/renderer.py:303-376, kernel_type RBK, use_awp, mode
+    c2f, N_importance > 0) composed from the oracle's functions on the kernel's recorded outputs:
+      render (:306) of new_rays [R,P,3,2] flattened -> rgb [R P,3], rgb0, depth_feature [R P,S,G], z_vals, NDC rays_d (:464-465);
+      awpnet (:314-315, awp.py:79-117) = sample embedding -> feature integration -> MAM per-sample sums -> per-ray remainder, with
+        view_embedded = [img_embed | PE(first sub-exposure's normalised NDC direction)] (awp.py:87-95);
+      ccw_fine + ccw_fine * 0.05, renormalised (:316-317); rbk_weighted_sum with weight1 and with ccw_fine (:327-330, blurmodel.py:112-127);
+      rgb1 = the weighted extras['rgb0'] (:341); TV = (coarse + fine TV_loss_app) * 5 (:361-365); the pts0 tensors (:371-376).
+    awp_sd: the AdaptiveWeightProposal's state dict (numpy, reference names); sd_levels: the model's state dict (for the TV term).
+    -> dict(rgb, rgb1, rgb_awp, stage1_rgb_pts0, stage1_rgb1_pts0, tv, ccw_fine, bn_mean, bn_var, render=<the render's dict>)"""
+    new_rays, weight = _f(new_rays), _f(weight)
+    R, P = weight.shape
+    flat = new_rays.reshape(R * P, 3, 2)
+    res = render_c2f(coarse, fine, cfg, flat, want_feature=True)
+    rb = ray_batch(cfg, flat)
+    rays_d = rb[:, 3:6].copy()
+    S = res["z_vals"].shape[1]
+    n_emb = len([k for k in awp_sd if k.startswith("sample_feature_embed_layer.") and k.endswith(".weight")])
+    h_local = awp_sample_embed(res["feature"].reshape(R * P * S, -1), [awp_sd[f"sample_feature_embed_layer.{l}.weight"] for l in range(n_emb)],
+                               [awp_sd[f"sample_feature_embed_layer.{l}.bias"] for l in range(n_emb)]).reshape(R * P, S, -1)
+    h = awp_feature_integration(h_local, res["z_vals"], rays_d).reshape(R, P, -1)
+    d0 = rays_d.reshape(R, P, 3)[:, 0]
+    enc = embed(d0 / np.linalg.norm(d0, axis=-1, keepdims=True), ray_dir_freq)
+    view = enc if img_embed is None else np.concatenate([_f(img_embed), enc], -1)
+    inter, intra = mam_local(h_local, awp_sd["MAM.linear.weight"], awp_sd["MAM.linear.bias"], awp_sd["MAM.Corr.line_conv_att.weight"], P)
+    ccw, mean, var = awp_per_ray(h, view, inter, intra, awp_sd, training=True)
+    ccw = ccw + ccw * np.float32(ccw_fine_scale)
+    ccw = ccw / ccw.sum(-1, keepdims=True)
+    out = dict(rgb=weighted_sum(res["rgb"], weight), rgb1=weighted_sum(res["rgb0"], weight), rgb_awp=weighted_sum(res["rgb"], ccw),
+               stage1_rgb_pts0=res["rgb"].reshape(R, P, 3)[:, 0].copy(), stage1_rgb1_pts0=res["rgb0"].reshape(R, P, 3)[:, 0].copy(),
+               ccw_fine=ccw, bn_mean=mean, bn_var=var, render=res)
+    out["tv"] = (tv_loss_app(sd_levels, "mlp_coarse.") + tv_loss_app(sd_levels, "mlp_fine.")) * 5
+    return out
+
+
 def num_threads():
     return lib().evo_num_threads()

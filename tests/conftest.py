@@ -76,3 +76,15 @@ def z_mismatch(z, zref, tol=5e-5):
     """
     d = np.abs(np.asarray(z, np.float64) - np.asarray(zref, np.float64))
     return float((d > tol).mean()), float(d.max()) if d.size else 0.0
+
+
+def train_call_errors(out, z_vals, g, z_tol=5e-6):
+    """G32: (mask of the pixels whose P rays carry the golden's sample positions to z_tol, errors of the five outputs on those pixels,
+    errors on all pixels).  out: dict with rgb, rgb1, rgb_awp, stage1_rgb_pts0, stage1_rgb1_pts0 [R,3]; z_vals [R P, S]."""
+    R, P = g["weight"].shape
+    dz = np.abs(np.asarray(z_vals, np.float64) - g["awp_in_z_vals"]).max(-1).reshape(R, P).max(-1)
+    tight = dz < z_tol
+    keys = ("rgb", "rgb1", "rgb_awp", "stage1_rgb_pts0", "stage1_rgb1_pts0")
+    e_t = {k: maxabs(np.asarray(out[k])[tight], g["out." + k][tight]) for k in keys}
+    e_a = {k: maxabs(np.asarray(out[k]), g["out." + k]) for k in keys}
+    return tight, e_t, e_a

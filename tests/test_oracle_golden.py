@@ -4,7 +4,7 @@ summation order and libm vs SLEEF transcendentals, so 2e-6 absolute on O(1) valu
 import numpy as np
 import pytest
 
-from conftest import load_golden, maxabs, sample_pdf_flip_report, z_mismatch
+from conftest import load_golden, maxabs, sample_pdf_flip_report, train_call_errors, z_mismatch
 from evdeblurnerf_amd import weights as W
 from oracle import oracle as O
 
@@ -708,3 +708,47 @@ def test_G31_event_hop_schedule_and_draw():
         torch.manual_seed(3100 + i)
         hops = draw_hops(torch.tensor(g[f"ns_{i}"]), int(mn), int(mx))
         assert hops.dtype == torch.int64 and np.array_equal(hops.numpy(), g[f"hops_{i}"]), (i, mn, mx)
+
+
+def _train_call_voxels(seed, g):
+    gc, gf = [int(v) for v in g["grid_coarse"]], [int(v) for v in g["grid_fine"]]
+    assert gc == W.pdrf_grid_size(AABB[:3], AABB[3:], 24 ** 3) and gf == W.pdrf_grid_size(AABB[:3], AABB[3:], 48 ** 3)
+    sd = W.make_train_call_state_dict(seed, gc, gf)
+    vc = O.Voxel(sd, "mlp_coarse.", gc, AABB, input_ch=95, hidden_dim=64, geo_feat_dim=15, rgb_act="relu")
+    vf = O.Voxel(sd, "mlp_fine.", gf, AABB, input_ch=127, hidden_dim=256, geo_feat_dim=128, rgb_act="none")
+    return vc, vf, sd
+
+
+def _train_call_awp_sd(seed, g):
+    sd = {k[len("awp.sd."):]: g[k] for k in g if k.startswith("awp.sd.")}
+    sd.update(W.make_awp_embed_state_dict(seed * 10 + 1))
+    return sd
+
+
+def test_G32_train_forward():
+    """G32: the reference's NeRFAll.forward in training mode with its real RigidBlurringModel and AdaptiveWeightProposal
+    (networks/renderer.py:277-392).  The oracle's composition (oracle.train_forward) on the kernel's recorded outputs reproduces every
+    output of the call: rgb, rgb1, rgb_awp, both pts0 tensors, the TV term, and the BatchNorm estimates the AWP leaves behind.
+    Tolerances: sample_pdf's (u - cdf) / denom amplifies the cdf's rounding by 1 / pdf (conftest.sample_pdf_flip_report), and with 16 + 16
+    samples on dense fields an importance sample that moves by 4e-4 moves a colour by 7e-5: pixels whose P rays carry the golden's sample
+    positions to 5e-6 hold 2e-5 on every output, all others 5e-4; the proposal weights (BatchNorm over ALL pixels) 3e-4."""
+    g = load_golden("G32_train_forward")
+    vc, vf, sd = _train_call_voxels(32, g)
+    awp_sd = _train_call_awp_sd(32, g)
+    cfg = O.make_cfg(N_samples=16, N_importance=16, is_train=True)
+    out = O.train_forward(vc, vf, cfg, g["new_rays"], g["weight"], g["img_embed"], awp_sd, sd)
+    tight, errs_tight, errs_all = train_call_errors(out, out["render"]["z_vals"], g)
+    assert tight.sum() >= 8, tight.sum()
+    assert max(errs_tight.values()) < 2e-5, errs_tight
+    assert max(errs_all.values()) < 5e-4, errs_all
+    assert maxabs(O.ray_batch(cfg, g["new_rays"].reshape(-1, 3, 2))[:, 3:6], g["awp_in_rays_d"]) < 2e-6     # the AWP sees the NDC directions (:464-465)
+    assert abs(out["tv"] - float(g["tv"])) < 2e-6 * max(1.0, abs(float(g["tv"])))
+    assert maxabs(g["stage1_img_embed"], g["img_embed"]) == 0.0               # other_tensors carries the kernel's extras under stage1_ (:368)
+    ref_ccw = g["awp_out"] + g["awp_out"] * np.float32(0.05)
+    assert maxabs(out["ccw_fine"], ref_ccw / ref_ccw.sum(-1, keepdims=True)) < 3e-4
+    rm = 0.9 * awp_sd["MAM.Corr.convd.1.running_mean"] + 0.1 * out["bn_mean"]
+    rv = 0.9 * awp_sd["MAM.Corr.convd.1.running_var"] + 0.1 * out["bn_var"]
+    assert maxabs(rm, g["awp.after.running_mean"]) < 1e-4 and maxabs(rv, g["awp.after.running_var"]) < 1e-4
+    # the projection the gradients were taken of (a second, independent check of the recorded loss)
+    loss = sum(float((out[k].astype(np.float64) * g["proj." + k]).sum()) for k in errs_all) + 0.1 * out["tv"]
+    assert abs(loss - float(g["loss"])) < 5e-3, (loss, float(g["loss"]))

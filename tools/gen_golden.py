@@ -708,7 +708,7 @@ def G17_compute_successor():
     save("G17_compute_successor", **out)
 
 
-def _grad_summaries(named_grads, out, prefix):
+def _grad_summaries(named_grads, out, prefix, elements=True):
     """store (norm, seeded projection) + the first 32 elements of every gradient: full gradients would not fit a small fixture"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from torch_restatement import grad_elements, grad_summary
@@ -716,6 +716,8 @@ def _grad_summaries(named_grads, out, prefix):
         sm, head = grad_summary(n(g), 7000 + i)
         out[f"{prefix}{name}.summary"] = sm.astype(np.float64)
         out[f"{prefix}{name}.head"] = head.astype(np.float64)
+        if not elements:
+            continue
         idx, val = grad_elements(n(g), 9000 + i)                # element-level pins: the 256 largest elements + 256 seeded random ones
         out[f"{prefix}{name}.elem_idx"] = idx
         out[f"{prefix}{name}.elem_val"] = val.astype(np.float64)
@@ -1202,11 +1204,225 @@ def G31_event_hops():
     save64("G31_event_hops", **out)
 
 
+# --------------------------------------------------------------------------- G32 / G33: the whole training call
+def _train_call_model(P=5, n_imgs=6, seed=32):
+    """The model run_nerf.py:120-243 builds for the shipped RBK + AWP configs (ViewEmbedding 'param' of width 32, RigidBlurringModel with
+    the config's branch sizes, AdaptiveWeightProposal with the config's widths) around the two PDRF levels at PDRF_SMALL grid sizes,
+    rgb_add_bias off as shipped.  The blur kernel's rotation / translation heads are scaled from their 1e-5 initialisation to the size a
+    trained kernel has (a few 1e-2), the image embeddings drawn normal and the attention logits of the MAM scaled to order 1 (as in G27):
+    at the initial values all P rays of a pixel coincide and both softmaxes are uniform, which would pin nothing."""
+    from networks.dpnerf.awp import AdaptiveWeightProposal
+    from networks.dpnerf.blurmodel import RigidBlurringModel
+    from networks.embedding import ViewEmbedding
+    from networks.renderer import NeRFAll
+    import contextlib
+    import io
+    torch.manual_seed(seed)
+    view_embed = ViewEmbedding(num_embed=n_imgs, embed_dim=32, init_params="normal")
+    kern = RigidBlurringModel(feat_ch=0, num_motion=P - 1, D_r=1, W_r=32, D_v=1, W_v=32, D_w=1, W_w=32, output_ch_r=3, output_ch_v=3,
+                              rv_window=0.1, use_origin=True, view_embed=view_embed, W=view_embed.out_channels)
+    awp = AdaptiveWeightProposal(input_ch=128, num_motion=P - 1, use_origin=True, D_sam=4, W_sam=64, D_mot=1, W_mot=32, dir_freq=2,
+                                 rgb_freq=2, depth_freq=3, ray_dir_freq=2, view_feature_ch=view_embed.out_channels)
+    awp.load_state_dict({k: t(v) for k, v in W.make_awp_embed_state_dict(seed * 10 + 1).items()}, strict=False)
+    rs = np.random.RandomState(seed * 10 + 2)
+    bn = awp.MAM.Corr.convd[1]
+    with torch.no_grad():
+        kern.r_linear.weight.mul_(2e4)
+        kern.v_linear.weight.mul_(2e4)
+        bn.weight.copy_(t(rs.uniform(0.5, 1.5, 32).astype(np.float32)))
+        bn.bias.copy_(t((rs.standard_normal(32) * 0.2).astype(np.float32)))
+        bn.running_mean.copy_(t((rs.standard_normal(32) * 0.1).astype(np.float32)))
+        bn.running_var.copy_(t(rs.uniform(0.5, 2.0, 32).astype(np.float32)))
+        for conv, k in ((awp.MAM.Corr.conva, 8.0), (awp.MAM.Corr.convb, 8.0), (awp.MAM.Corr.convc, 8.0), (awp.MAM.Corr.line_conv_att, 30.0)):
+            conv.weight.mul_(k)
+    args = ref_import.blurfactory_args(mode="c2f", N_importance=16, N_samples=16, kernel_use_awp=True, kernel_ptnum=P, rgb_add_bias=False, **PDRF_SMALL)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = NeRFAll(args, kern, awp)
+    gc = [int(v) for v in model.mlp_coarse.gridSize]
+    gf = [int(v) for v in model.mlp_fine.gridSize]
+    sd = W.make_train_call_state_dict(seed, gc, gf)
+    for k in model.state_dict():            # the level parameters only: the kernel and the AWP keep the values set above
+        if k.startswith(("mlp_coarse.", "mlp_fine.")) and k not in sd:
+            raise KeyError(k)
+    model.load_state_dict({k: t(np.asarray(v).copy()) for k, v in sd.items()}, strict=False)
+    return model, kern, awp, gc, gf
+
+
+def _awp_sd(awp):
+    return {"awp.sd." + k: n(v).copy() for k, v in awp.state_dict().items() if not k.startswith("sample_feature_embed_layer")}
+
+
+def _capture_kernel(kern):
+    """forward hook on the blur kernel: what it returned (the tensors the GPU-side stub replays), kept in the graph"""
+    cap = {}
+    def hook(m, i, o):
+        cap["new_rays"], cap["weight"], cap["img_embed"] = o[0], o[1], o[3]["img_embed"]
+    return cap, kern.register_forward_hook(hook)
+
+
+TRAIN_CALL_KW = dict(retraw=True, perturb=0., N_importance=16, N_samples=16, use_viewdirs=True, white_bkgd=False, raw_noise_std=0., inference=False)
+
+
+def G32_train_forward():
+    """NeRFAll.forward IN TRAINING MODE as run_nerf.py:438-442 calls it behind kernel_start_iter (networks/renderer.py:277-392): the real
+    RigidBlurringModel (dpnerf/blurmodel.py:129-173) -> render of the P warped rays per pixel (mode='c2f') -> the real
+    AdaptiveWeightProposal (dpnerf/awp.py:79-117) on depth_feature / z_vals / the NDC rays_d / img_embed -> ccw_fine + ccw_fine * 0.05
+    renormalised -> the two rbk_weighted_sums -> TV x 5 -> other_tensors.  32 pixels x P = 5, 16 + 16 samples, perturb = 0, raw noise 0.
+    Recorded: the kernel's outputs (new_rays, weight, img_embed: a stub kernelsnet replays them where the reference cannot travel), every
+    output of the call, and torch.autograd gradients of a fixed projection of ALL outputs w.r.t. every level parameter (summaries +
+    element pins), every AWP parameter, new_rays, weight and img_embed (full; img_embed's gradient both as it arrives through the AWP and in
+    total, i.e. with the part through the kernel's own branches)."""
+    P, R = 5, 32
+    model, kern, awp, gc, gf = _train_call_model(P)
+    model.train(True)
+    K = W.synthetic_camera()
+    rays = W.synthetic_rays(32, R)
+    rs = np.random.RandomState(3201)
+    images_idx = rs.randint(0, 6, (R, 1)).astype(np.int64)
+    proj = {k: rs.standard_normal((R, 3)).astype(np.float32) for k in ("rgb", "rgb1", "rgb_awp", "stage1_rgb_pts0", "stage1_rgb1_pts0")}
+    awp_before = _awp_sd(awp)
+    cap, hk = _capture_kernel(kern)
+    seen = {}
+    hk2 = awp.register_forward_hook(lambda m, i, o: seen.update(z_vals=n(i[1]).copy(), rays_d=n(i[2]).copy(), awp_out=n(o).copy()))
+    # the kernel's img_embed output IS its own branches' input (blurmodel.py:133-136,171): an identity node in front of the AWP separates the
+    # gradient that arrives through the AWP (what a replayed kernel output can receive) from the total
+    hk3 = awp.register_forward_pre_hook(lambda m, i: (seen.update(vf_awp=i[3] * 1.0), (i[0], i[1], i[2], seen["vf_awp"]))[1])
+    with torch.enable_grad():
+        rgb, rgb1, other_loss, other_tensors = model(400, 400, t(K), chunk=1 << 20, rays=t(rays), rays_info={"images_idx": t(images_idx)},
+                                                     force_naive=False, return_pts0_rgb=True, **TRAIN_CALL_KW)
+        outs = dict(rgb=rgb, rgb1=rgb1, rgb_awp=other_tensors["rgb_awp"], stage1_rgb_pts0=other_tensors["stage1_rgb_pts0"],
+                    stage1_rgb1_pts0=other_tensors["stage1_rgb1_pts0"])
+        tv = other_loss["TV"]
+        loss = sum((outs[k] * t(proj[k])).sum() for k in proj) + 0.1 * tv.sum()
+        lv = [(k, p) for k, p in model.named_parameters() if k.startswith(("mlp_coarse.", "mlp_fine."))]
+        ap = [(k, p) for k, p in awp.named_parameters() if not k.startswith("MAM.conv.")]
+        kp = list(kern.named_parameters())
+        grads = torch.autograd.grad(loss, [p for _, p in lv] + [p for _, p in ap] + [cap["new_rays"], cap["weight"], seen["vf_awp"]] + [p for _, p in kp] +
+                                    [cap["img_embed"]], allow_unused=True)
+    hk.remove()
+    hk2.remove()
+    hk3.remove()
+    g_img_embed_total, grads = grads[-1], grads[:-1]
+    assert set(other_loss) == {"TV"} and set(other_tensors) == {"rgb_awp", "stage1_img_embed", "stage1_rgb_pts0", "stage1_rgb1_pts0"}, (set(other_loss), set(other_tensors))
+    out = {}
+    _grad_summaries([(k, g) for (k, _), g in zip(lv, grads) if g is not None], out, "g.")
+    o = len(lv)
+    for (k, _), g in zip(ap, grads[o:o + len(ap)]):
+        if g is not None:
+            out["g.awp." + k] = n(g)
+    o += len(ap)
+    out["g.new_rays"], out["g.weight"], out["g.img_embed"] = n(grads[o]), n(grads[o + 1]), n(grads[o + 2])       # (img_embed: through the AWP)
+    out["g.img_embed_total"] = n(g_img_embed_total)                                                                 # (+ through the kernel's own branches)
+    for (k, _), g in zip(kp, grads[o + 3:]):            # (for a maintainer who runs the real kernel module: what its parameters receive)
+        if g is not None:
+            out["g.kernel." + k] = n(g)
+    bn = awp.MAM.Corr.convd[1]
+    for k in ("running_mean", "running_var", "num_batches_tracked"):
+        out["awp.after." + k] = n(getattr(bn, k))
+    save("G32_train_forward", rays=rays, images_idx=images_idx, new_rays=n(cap["new_rays"]), weight=n(cap["weight"]), img_embed=n(cap["img_embed"]),
+         **{"out." + k: n(v) for k, v in outs.items()}, **{"proj." + k: v for k, v in proj.items()}, tv=np.float64(tv.sum().item()),
+         loss=np.float64(loss.item()), stage1_img_embed=n(other_tensors["stage1_img_embed"]), awp_in_z_vals=seen["z_vals"], awp_in_rays_d=seen["rays_d"],
+         awp_out=seen["awp_out"], grid_coarse=np.array(gc), grid_fine=np.array(gf),
+         **awp_before, **out)
+
+
+def G33_train_trajectory():
+    """K = 5 iterations of the reference's optimisation loop on the G32 model (run_nerf.py:423-613 with the blurfactory config's switches:
+    blur batch through kernel + AWP, loss = (img + img0) (1 - flw) + img_awp flw + w_pts0 (pts0 terms) + TV + w_egm event_egm with the event
+    batch's start / end rays rendered force_naive=True, gamma CRF on colours, learnable event-CRF with the 'pos-neg' features; Adam
+    betas (0.9, 0.999) over the groups of run_nerf.py:252-263 {grad_vars, grad_vars_vol, crf} + the exponential decay of :603-613 with
+    lrate_decay 10).  lrate is 5e-4, not the config's 5e-3: five steps at 5e-3 move the 64-wide coarse networks by their own size.
+    Recorded per step: the kernel's outputs (replayed by the stub on the GPU side -- the kernel's own parameters are trained by the
+    reference loop and not compared), the loss, and (norm, projection, element pins) of every level / AWP / CRF parameter AFTER the step."""
+    from utils.events import egm_loss
+    sys.modules.setdefault("skimage", type(sys)("skimage"))
+    sys.modules["skimage"].metrics = None
+    sys.modules.setdefault("networks.lpips", type(sys)("networks.lpips"))
+    sys.modules["networks.lpips"].LPIPS = None
+    from utils.metrics import img2mse
+    P, R, NE, STEPS = 5, 32, 48, 5
+    lrate, lrate_decay, flw, w_pts0, w_egm, w_tv, thr = 5e-4, 10, 0.1, 0.01, 0.1, 1.0, 0.2
+    model, kern, awp, gc, gf = _train_call_model(P, seed=33)
+    tm = _tonemap("gamma", "learn", 2, 331)
+    for prm in tm.tonemapping_event.parameters():
+        if prm.dim() == 2:
+            prm.data.mul_(3.0)
+    K = W.synthetic_camera()
+    rs = np.random.RandomState(3301)
+    rays = W.synthetic_rays(33, R)
+    ev_start, ev_end = W.synthetic_rays(34, NE), W.synthetic_rays(35, NE)
+    images_idx = rs.randint(0, 6, (R, 1)).astype(np.int64)
+    target = rs.uniform(0, 1, (R, 3)).astype(np.float32)
+    target_pts0 = rs.uniform(0, 1, (R, 3)).astype(np.float32)
+    cn = -rs.randint(0, 4, NE).astype(np.float32)
+    cp = rs.randint(0, 4, NE).astype(np.float32)
+    awp_before = _awp_sd(awp)
+    optim_params = [{"params": model.grad_vars, "lr": lrate}, {"params": model.grad_vars_vol, "lr": lrate}, {"params": tm.parameters(), "lr": lrate}]
+    for g in optim_params:
+        g.setdefault("initial_lr", g["lr"])
+    opt = torch.optim.Adam(params=optim_params, lr=lrate, betas=(0.9, 0.999))
+    crf = lambda x, **k: tm(x, **k)
+    cap, hk = _capture_kernel(kern)
+    out = {}
+    losses = []
+    model.train(True)
+    tm.train()
+    tracked = lambda: ([(k, p) for k, p in model.named_parameters() if k.startswith(("mlp_coarse.", "mlp_fine."))] +
+                       [("awp." + k, p) for k, p in awp.named_parameters() if not k.startswith("MAM.conv.")] +
+                       [("crf." + k, p) for k, p in tm.tonemapping_event.named_parameters()])
+    p0 = {k: n(p).copy() for k, p in tracked()}
+    global_step = 0
+    for i in range(STEPS):
+        with torch.enable_grad():
+            rgb, rgb0, extra_loss, extra_tensor = model(400, 400, t(K), chunk=1 << 20, rays=t(rays), rays_info={"images_idx": t(images_idx)},
+                                                        force_naive=False, return_pts0_rgb=True, **TRAIN_CALL_KW)
+            rgb, rgb0 = crf(rgb, mode="encode_rgb"), crf(rgb0, mode="encode_rgb")
+            loss = img2mse(rgb, t(target)) + img2mse(rgb0, t(target))
+            img_fine = img2mse(crf(extra_tensor["rgb_awp"], mode="encode_rgb"), t(target))
+            loss = loss * (1 - flw) + img_fine * flw
+            pts0 = 0.0
+            for name in ("stage0_rgb_pts0", "stage1_rgb_pts0", "stage1_rgb1_pts0"):
+                if name in extra_tensor:
+                    pts0 = pts0 + img2mse(crf(extra_tensor[name], mode="encode_rgb"), t(target_pts0))
+            loss = loss + pts0 * w_pts0
+            extra_loss.update({k: torch.mean(v) for k, v in extra_loss.items()})
+            loss = loss + extra_loss["TV"] * w_tv
+            bii = (t(np.array([thr, thr], np.float32)) * torch.stack([t(cn), t(cp)], -1)).sum(-1)
+            feat = torch.stack([t(cn), t(cp)], -1)
+            s, s0, _, _ = model(400, 400, t(K), chunk=1 << 20, rays=t(ev_start), rays_info=None, force_naive=True, **TRAIN_CALL_KW)
+            e, e0, _, _ = model(400, 400, t(K), chunk=1 << 20, rays=t(ev_end), rays_info=None, force_naive=True, **TRAIN_CALL_KW)
+            lum = lambda x: crf(x, mode="encode_luma", ev_extra_feat=feat)
+            egm = egm_loss(lum(s0), lum(e0), bii, color_mask=None, color_weight=None) + egm_loss(lum(s), lum(e), bii, color_mask=None, color_weight=None)
+            loss = loss + egm * w_egm
+            opt.zero_grad()
+            loss.backward()
+        opt.step()
+        decay_rate, decay_steps = 0.1, lrate_decay * 1000
+        for g in opt.param_groups:
+            g["lr"] = g["initial_lr"] * (decay_rate ** (global_step / decay_steps))
+        global_step += 1
+        losses.append(loss.item())
+        out[f"s{i}.new_rays"], out[f"s{i}.weight"], out[f"s{i}.img_embed"] = n(cap["new_rays"]).copy(), n(cap["weight"]).copy(), n(cap["img_embed"]).copy()
+        _grad_summaries([(k, t(n(p) - p0[k])) for k, p in tracked()], out, f"s{i}.d.", elements=i in (0, STEPS - 1))
+        for k, p in tracked():              # small tensors in full (AWP per-ray layers, CRF)
+            if p.numel() <= 4096 and i in (0, STEPS - 1):
+                out[f"s{i}.p.{k}"] = n(p).copy()
+    hk.remove()
+    bn = awp.MAM.Corr.convd[1]
+    for k in ("running_mean", "running_var", "num_batches_tracked"):
+        out["awp.after." + k] = n(getattr(bn, k))
+    print("   losses:", ["%.6f" % v for v in losses])
+    save("G33_train_trajectory", rays=rays, ev_start=ev_start, ev_end=ev_end, images_idx=images_idx, target=target, target_pts0=target_pts0, cn=cn, cp=cp,
+         losses=np.array(losses, np.float64), scalars=np.array([lrate, lrate_decay, flw, w_pts0, w_egm, w_tv, thr], np.float64),
+         grid_coarse=np.array(gc), grid_fine=np.array(gf), **awp_before, **out)
+
+
 ALL = [G1_embedder, G2_nerf_mlp, G3_nerf_raw2outputs, G4_voxel_raw2outputs, G5_sample_pdf, G6_rays,
        G7_render_nerf, G8_appfeature, G9_render_c2f, G10_rbk_weighted_sum, G11_crf, G12_egm_loss, G13_edi,
        G14_loss_assembly, G15_awp_feature_integration, G16_rbk_warp, G17_compute_successor, G18_nerf_grads, G19_c2f_grads, G20_loss_grads,
        G21_awp_sample_embed, G22_mam, G23_render_nerf_no_viewdirs, G24_render_other_multires, G25_pbe_composite_feature,
-       G26_sample_events, G27_awp_per_ray, G28_image_batch, G29_pose_track, G30_c2f_grads_16k, G31_event_hops]
+       G26_sample_events, G27_awp_per_ray, G28_image_batch, G29_pose_track, G30_c2f_grads_16k, G31_event_hops, G32_train_forward,
+       G33_train_trajectory]
 
 if __name__ == "__main__":
     want = set(sys.argv[1:])
