@@ -23,13 +23,15 @@ from evdeblurnerf_amd.renderer import NeRFAll  # noqa: E402
 AABB = ([-1.5, -1.5, -1.0], [1.5, 1.5, 1.0])
 
 
-def make(seed, cv, fv, precision):
+def make(seed, cv, fv, precision, colourful=False):
     gc, gf = W.pdrf_grid_size(AABB[0], AABB[1], cv), W.pdrf_grid_size(AABB[0], AABB[1], fv)
     sd = dict(W.prefixed(W.make_pdrf_state_dict(seed, gc, input_ch=95, hidden_dim=64, geo_feat_dim=15, add_bias_color=False), "mlp_coarse"))
     sd.update(W.prefixed(W.make_pdrf_state_dict(seed + 1, gf, input_ch=127, hidden_dim=256, geo_feat_dim=128, add_bias_color=False), "mlp_fine"))
     for k in list(sd):                        # denser, more colourful fields than the default initialisation: something to learn
         if k.endswith("sigma_net.1.weight"):
             sd[k] = sd[k] * 3.0
+        if colourful and k.endswith("color_net.2.weight"):          # the teacher: colours over the whole range (the initialisation alone is sigmoid(~0))
+            sd[k] = sd[k] * 12.0
     args = SimpleNamespace(mode="c2f", multires=10, multires_views=4, use_viewdirs=True, N_importance=64, kernel_type="RBK", kernel_use_awp=False,
                            rgb_activate="sigmoid", sigma_activate="relu", bounding_box=AABB, coarse_num_layers=2, coarse_num_layers_color=3,
                            coarse_hidden_dim=64, coarse_hidden_dim_color=64, coarse_app_dim=32, coarse_app_n_comp=[64, 16, 16], coarse_n_voxels=cv,
@@ -82,7 +84,7 @@ def train_one(a, precision, teacher, K, kw, held, held_t, log_every):
         if it % log_every == 0 or it == a.iters:
             rows.append((it, acc / nacc, evaluate()))
             acc, nacc = 0.0, 0
-            print(f"[{precision}] iter {it:5d}: mean loss {rows[-1][1]:.6f}  held-out PSNR vs teacher {rows[-1][2]:.2f} dB", flush=True)
+            print(f"[{precision}] iter {it:5d}: mean loss {rows[-1][1]:.4e}  held-out PSNR vs teacher {rows[-1][2]:.2f} dB", flush=True)
     torch.cuda.synchronize()
     return p0, rows, time.time() - t0
 
@@ -98,7 +100,7 @@ def main():
     a = ap.parse_args()
     modes = a.precision.split(",")
     K = W.synthetic_camera()
-    teacher, _ = make(101, a.coarse_voxels, a.fine_voxels, "f16x3" if len(modes) > 1 else modes[0])
+    teacher, _ = make(101, a.coarse_voxels, a.fine_voxels, "f16x3" if len(modes) > 1 else modes[0], colourful=True)
     teacher.eval()
     kw = dict(ndc=True, near=0., far=1., use_viewdirs=True, N_samples=64, N_importance=64, raw_noise_std=0.)
     held = torch.as_tensor(W.synthetic_rays(999, 4096), device="cuda")
@@ -113,7 +115,7 @@ def main():
         print("          | " + " | ".join(f"{'mean loss':>12s} {'PSNR dB':>9s}" for _ in modes))
         print(f"{0:9d} | " + " | ".join(f"{'':>12s} {res[m][0]:9.2f}" for m in modes))
         for r in range(len(res[modes[0]][1])):
-            print(f"{res[modes[0]][1][r][0]:9d} | " + " | ".join(f"{res[m][1][r][1]:12.6f} {res[m][1][r][2]:9.2f}" for m in modes))
+            print(f"{res[modes[0]][1][r][0]:9d} | " + " | ".join(f"{res[m][1][r][1]:12.4e} {res[m][1][r][2]:9.2f}" for m in modes))
         print("seconds   | " + " | ".join(f"{res[m][2]:22.1f}" for m in modes))
         ref = res[modes[-1]][1][-1][2]
         print("final PSNR relative to the last mode listed: " + ", ".join(f"{m} {res[m][1][-1][2] - ref:+.2f} dB" for m in modes))
