@@ -992,6 +992,19 @@ constexpr int VBW_FSTR = 96;                    // coefficient row stride: the M
 constexpr size_t VBW_SLICE = VBW_SAMPLES * 3 * sizeof(VbwTaps) + (size_t)VBW_SAMPLES * VBW_CSTR * 4 + (size_t)VBW_SAMPLES * 9 * 4 + (size_t)VBW_SAMPLES * VBW_FSTR * 4;
 static_assert((size_t)VBW_SAMPLES * VBW_LROW * 4 <= (size_t)VBW_SAMPLES * VBW_FSTR * 4 && VBW_MAXG * 8 <= VBW_FSTR, "line rows alias the coefficient rows");
 constexpr size_t VBW_LDS = (size_t)32 * VBW_BSTR * 4 + VBW_WAVES * VBW_SLICE;
+// ISS (round 6): the last wavefront of the workgroup ISSUES the plane taps' atomics of the other three.  The VM counter retires in order, so a
+// wavefront that adds its own taps cannot start the next tile's loads before its ~40 atomic instructions have retired: with everything else
+// removed the kernel's atomics take 0.20 ms per 2^19 samples, everything but the atomics 0.2x ms, together 0.42 ms (profiles/r06_scatter_ablation.log)
+// -- the two do not overlap inside a wavefront.  A compute wavefront now leaves a tile's plane rows and tap cells in a hand-off buffer in LDS
+// ([16][96] rows | cells | weights: 7.5 KiB) and goes on; the issuer walks the buffers of its three producers (run-length merge as before) and
+// is the only wavefront whose VM counter carries atomics.  The coefficients pv lv of the basis gradient replace d coef in place (no separate
+// rows): the slice shrinks to 10 KiB, 66.5 KiB per workgroup, two workgroups per CU as before.
+constexpr int VBI_CW = VBW_WAVES - 1;                                                                // compute wavefronts of an issuer-form workgroup
+constexpr int VBI_HROW = 96;                                                                          // hand-off row stride (ctot <= 96)
+constexpr size_t VBI_SLICE = VBW_SAMPLES * 3 * sizeof(VbwTaps) + (size_t)VBW_SAMPLES * VBW_CSTR * 4 + (size_t)VBW_SAMPLES * 9 * 4 + 64;
+constexpr size_t VBI_HAND = (size_t)VBW_SAMPLES * VBI_HROW * 4 + (size_t)VBW_SAMPLES * 3 * 4 * 8;   // rows | int cell[48][4] | float weight[48][4]
+constexpr size_t VBI_LDS = (size_t)32 * VBW_BSTR * 4 + VBI_CW * (VBI_SLICE + VBI_HAND) + 64;
+static_assert(VBI_SLICE % 16 == 0 && VBI_HAND % 16 == 0 && 2 * VBI_LDS <= 160 * 1024, "two issuer-form workgroups per CU");
 static_assert(sizeof(VbwTaps) % 8 == 0 && VBW_SLICE % 16 == 0, "slice alignment");
 
 // vs_geometry + the quantities the point gradient needs; same formulas, same order (the forward's weights bit for bit)
@@ -1041,7 +1054,80 @@ __device__ __forceinline__ void vbw_geometry(const GridParams& g, const float (&
 // (its slice's d coef array is free by then) and adds its 16 samples' [F x ctot] product to 3 x 16 accumulator registers on
 // v_mfma_f32_32x32x2_f32 (d out rows as the A operand straight from L2); one fold through LDS + one atomic flush per workgroup at the end.
 // Gone: the coefficient rows [n, ctot] (201 MB written and read back per 2^19 samples) and the k_basis_grad launch.
-template <bool DPTS, bool LINES12, bool BAS>
+// The plane-tap walk (phase 3 of k_voxel_sample_bwd_w): a lane owns a (tap, channel), walks the tile's 16 samples with the sum of a RUN of
+// samples on one cell in a register and adds it once per run.  Round 6 -- the kernel is bound by the number of instructions its two wavefronts per
+// SIMD issue (~5.5 k per tile and wavefront, 4 cycles each; a build WITHOUT the atomics showed the walk alone at 33.6 k of a tile's 51.8 k
+// cycles, profiles/r06_scatter_stamps_before_walk_rewrite.log: the "atomic phase" was this loop, not the atomics), so the walk is cut to what
+// it needs:
+//   * all LDS operands of a pass are fetched first (independent reads), the walk runs on registers;
+//   * weight x row with the legacy multiply (0 x anything = 0): the same sums as the guarded form `w != 0 ? w * r : 0` of rounds 3-5 -- a tap
+//     outside the grid (weight 0) adds nothing even where the row is not finite -- without a compare and a select per step;
+//   * a run whose sum is exactly 0 in a lane adds nothing (x + 0 = x): the flag `any sample live` of rounds 3-5 is that test.
+typedef float vbw_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float vbw_mul_legacy(float a, float b) {          // a x b with 0 x anything = 0 (v_mul_legacy_f32: VOP3 only, no builtin in this hipcc)
+    float d;
+    asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// vbw_walk_pass: one tap per lane group (a 16-channel plane: all four taps in one pass of 64 lanes).
+template <class FW, class FC, class FR>
+__device__ __forceinline__ void vbw_walk_pass(float* __restrict__ gp, int c, bool act, FW fw, FC fc, FR fr) {
+    float w[VBW_SAMPLES], r[VBW_SAMPLES];
+    int cell[VBW_SAMPLES];
+#pragma unroll
+    for (int sm = 0; sm < VBW_SAMPLES; ++sm) { w[sm] = fw(sm); cell[sm] = fc(sm); r[sm] = fr(sm); }
+    float acc = 0.f;
+#pragma unroll
+    for (int sm = 0; sm < VBW_SAMPLES; ++sm) {
+        acc += vbw_mul_legacy(w[sm], r[sm]);
+        const bool flush = sm == VBW_SAMPLES - 1 || cell[sm + 1 < VBW_SAMPLES ? sm + 1 : sm] != cell[sm];
+        if (flush) {
+#ifdef EVD_VBW_NO_ATOMICS     // developer ablation: everything but the plane taps' atomics (the sum is kept alive)
+            if (act && acc == 1.2345e38f) gp[cell[sm] + c] = acc;
+#else
+            if (act && acc != 0.f) unsafeAtomicAdd(gp + cell[sm] + c, acc);
+#endif
+            acc = 0.f;
+        }
+    }
+}
+
+// vbw_walk_plane64: the 64-channel plane, lane = channel, ALL FOUR taps in one pass.  The taps of a sample are the corners of one cell, so
+// the four cell indices change together: the run ends are the steps where tap 0's or tap 3's index changes (both unchanged <=> the
+// clamped corner pairs (x0, y0) and (x1, y1) unchanged <=> all four unchanged), decided on two scalar registers per sample.  Per step: four
+// multiplies and four adds; the row value is read once instead of four times.
+template <class FW4, class FC, class FR>
+__device__ __forceinline__ void vbw_walk_plane64(float* __restrict__ gp, int c, FW4 fw4, FC fc, FR fr) {
+    float r[VBW_SAMPLES];
+    f32x4 w[VBW_SAMPLES];
+    int c0[VBW_SAMPLES], c3[VBW_SAMPLES];
+#pragma unroll
+    for (int sm = 0; sm < VBW_SAMPLES; ++sm) { w[sm] = fw4(sm); c0[sm] = fc(sm, 0); c3[sm] = fc(sm, 3); r[sm] = fr(sm); }
+#pragma unroll
+    for (int sm = 0; sm < VBW_SAMPLES; ++sm) { c0[sm] = __builtin_amdgcn_readfirstlane(c0[sm]); c3[sm] = __builtin_amdgcn_readfirstlane(c3[sm]); }
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sm = 0; sm < VBW_SAMPLES; ++sm) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] += vbw_mul_legacy(w[sm][t], r[sm]);
+        const int nx = sm + 1 < VBW_SAMPLES ? sm + 1 : sm;
+        const bool flush = sm == VBW_SAMPLES - 1 || c0[nx] != c0[sm] || c3[nx] != c3[sm];
+        if (flush) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int cell = fc(sm, t);
+#ifdef EVD_VBW_NO_ATOMICS
+                if (acc[t] == 1.2345e38f) gp[cell + c] = acc[t];
+#else
+                if (acc[t] != 0.f) unsafeAtomicAdd(gp + cell + c, acc[t]);
+#endif
+                acc[t] = 0.f;
+            }
+        }
+    }
+}
+
+template <bool DPTS, bool LINES12, bool BAS, bool ISS = false>
 __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const GridParams g, const float* __restrict__ pts, long n,
                                                                           const float* __restrict__ d_out, int d_stride, int d_col, GridGrads gg,
                                                                           float* __restrict__ d_pts, float* __restrict__ rows_l, LTap* __restrict__ ltap,
@@ -1049,14 +1135,24 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
     extern __shared__ __attribute__((aligned(16))) char vbw_smem[];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c0n = g.n_comp[0], c1n = g.n_comp[1], c2n = g.n_comp[2], ctot = c0n + c1n + c2n, F = g.app_dim;
+    static_assert(!ISS || (BAS && !LINES12), "the issuer form is the persistent kernel with the basis gradient inside, lines through k_scatter_lines");
+    constexpr int NCW = ISS ? VBI_CW : VBW_WAVES;                                    // wavefronts that own tiles
     float* bs = reinterpret_cast<float*>(vbw_smem);                                  // basis_mat [32][VBW_BSTR], rows >= F are zero
-    char* slice = vbw_smem + (size_t)32 * VBW_BSTR * 4 + (size_t)wv * VBW_SLICE;
+    char* slice = vbw_smem + (size_t)32 * VBW_BSTR * 4 + (size_t)(wv < NCW ? wv : 0) * (ISS ? VBI_SLICE : VBW_SLICE);
     VbwTaps* taps = reinterpret_cast<VbwTaps*>(slice);
     float* dco = reinterpret_cast<float*>(slice + VBW_SAMPLES * 3 * sizeof(VbwTaps));   // d coef [16][VBW_CSTR], later the plane rows d coef lv
     float* dpart = dco + VBW_SAMPLES * VBW_CSTR;                                     // [16][3 quads of 8-channel groups][3 axes] d pts partial sums
-    float* cfl = dpart + VBW_SAMPLES * 9;                                            // [16][VBW_FSTR] coefficients pv lv (BAS)
+    float* cfl = ISS ? dco : dpart + VBW_SAMPLES * 9;                                // [16][VBW_FSTR] coefficients pv lv (BAS); ISS: in place of d coef
     float* lrow = cfl;                                                               // [16][VBW_LROW] line rows d coef pv of components 1, 2 (LINES12)
     constexpr bool CF_LDS = BAS && !LINES12;
+    constexpr int CFSTR = ISS ? VBW_CSTR : VBW_FSTR;                                 // row stride of the coefficient rows
+    // ISS: hand-off buffers [NCW] behind the slices, then the flags (0 free, 1 full, 2 producer finished)
+    char* hand0 = vbw_smem + (size_t)32 * VBW_BSTR * 4 + (size_t)VBI_CW * VBI_SLICE;
+    float* hrow = reinterpret_cast<float*>(hand0 + (size_t)(wv < NCW ? wv : 0) * VBI_HAND);
+    int* hcell = reinterpret_cast<int*>(hrow + VBW_SAMPLES * VBI_HROW);
+    float* hwgt = reinterpret_cast<float*>(hcell + VBW_SAMPLES * 3 * 4);
+    volatile int* flags = reinterpret_cast<volatile int*>(hand0 + (size_t)VBI_CW * VBI_HAND);
+    if (ISS && threadIdx.x < 16) flags[threadIdx.x] = 0;
     const int ng = ctot / 8;
     for (int o = threadIdx.x; o < 32 * (ctot / 4); o += 64 * VBW_WAVES) {            // basis_mat -> LDS (the block's only shared state)
         const int f = o / (ctot / 4), c4 = (o % (ctot / 4)) * 4;
@@ -1083,7 +1179,53 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
 #endif
     float rmaxv = 0.f;                            // max |line row value| this lane wrote (k_scatter_lines' fixed-point scale: saves it a pass over the rows)
     const long wtiles = (n + VBW_SAMPLES - 1) / VBW_SAMPLES;
-    for (long wt = (long)blockIdx.x * VBW_WAVES + wv; wt < wtiles; wt += (long)gridDim.x * VBW_WAVES) {
+    auto lds_done = []() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+    if (ISS && wv >= NCW) {
+        // the issuer: polls its producers' flags; a full buffer's taps are walked exactly like phase 3 below (lanes = (tap, channel), the sum
+        // of a run of samples on one cell in a register, one atomic per run), then the buffer is handed back.  No load of this wavefront ever
+        // waits behind its atomics: it has none but LDS reads.
+        int fin = 0;
+        while (fin != (1 << NCW) - 1) {
+            bool idle = true;
+#pragma unroll 1
+            for (int w = 0; w < NCW; ++w) {
+                if (fin >> w & 1) continue;
+                const int f = __builtin_amdgcn_readfirstlane(flags[w]);
+                if (f == 2) { fin |= 1 << w; continue; }
+                if (f != 1) continue;
+                asm volatile("" ::: "memory");      // (no read of the buffer may be moved in front of the flag's)
+                idle = false;
+                const float* hr = reinterpret_cast<const float*>(hand0 + (size_t)w * VBI_HAND);
+                const int* hc = reinterpret_cast<const int*>(hr + VBW_SAMPLES * VBI_HROW);
+                const float* hw = reinterpret_cast<const float*>(hc + VBW_SAMPLES * 3 * 4);
+                int coff = 0;
+#pragma unroll 1
+                for (int i = 0; i < 3; ++i) {
+                    const int C = sel3(i, c0n, c1n, c2n);
+                    float* gp = sel3(i, gg.plane[0], gg.plane[1], gg.plane[2]);
+                    if (gp) {
+                        const int tpp = 64 / C < 4 ? 64 / C : 4, j = lane / C, c = lane % C;
+                        if (C == 64) {
+                            vbw_walk_plane64(gp, lane, [&](int sm) { return *reinterpret_cast<const f32x4*>(hw + (sm * 3 + i) * 4); },
+                                             [&](int sm, int t) { return hc[(sm * 3 + i) * 4 + t]; }, [&](int sm) { return hr[sm * VBI_HROW + coff + lane]; });
+                        } else {
+#pragma unroll 1
+                            for (int t0 = 0; t0 < 4; t0 += tpp) {
+                                const int t = t0 + (j < tpp ? j : 0);
+                                vbw_walk_pass(gp, c, j < tpp, [&](int sm) { return hw[(sm * 3 + i) * 4 + t]; }, [&](int sm) { return hc[(sm * 3 + i) * 4 + t]; },
+                                              [&](int sm) { return hr[sm * VBI_HROW + coff + c]; });
+                            }
+                        }
+                    }
+                    coff += C;
+                }
+                lds_done();                           // every read of the buffer has returned
+                if (lane == 0) flags[w] = 0;
+            }
+            if (idle) __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    for (long wt = (long)blockIdx.x * NCW + wv; wv < NCW && wt < wtiles; wt += (long)gridDim.x * NCW) {
     const long s0 = wt * VBW_SAMPLES;
     EVD_VBW_T0();
     // d out as the MFMA B operand: lane (col = sample, kh) holds d out[sample][4 step + kh]
@@ -1112,6 +1254,12 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
     }
     wave_sync();                                  // the tap tables are the wavefront's own
     EVD_VBW_T(0);
+#ifdef EVD_VBW_ATOMICS_ONLY      // developer ablation (tools/dev/scatter_atomics_only.sh): geometry + the plane-tap phase on constant rows -- what the atomics of the REAL address stream cost alone
+    for (int o = lane; o < VBW_SAMPLES * VBW_CSTR; o += 64) dco[o] = 1.f;
+    f32x4 cfk[1][2];
+    constexpr int UNR = 1, TRIPS = 1;
+    const int items = 0;
+#else
     // phase 1: D[channel 16 ct + 4 kh + r][sample col] = sum_f basis[f][channel] d out[sample][f]
     for (int ct = 0; ct < ctot / 16; ++ct) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -1157,6 +1305,9 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
 #pragma unroll
                 for (int v = 0; v < 2; ++v) rawl[q][k][v] = *reinterpret_cast<const f32x4*>(li + tp.il[k] + 4 * v);
         }
+        if (ISS && trip == 0) {                   // (the gather's loads are in flight) the issuer is done with the previous tile's buffer
+            while (__builtin_amdgcn_readfirstlane(flags[wv]) != 0) __builtin_amdgcn_s_sleep(2);
+        }
 #pragma unroll
         for (int q = 0; q < UNR; ++q) {
             const VbwTaps& tp = taps[sl[q] * 3 + comp[q]];
@@ -1199,6 +1350,15 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
                         }
                     }
                 }
+                if (ISS) {                        // the plane rows into the hand-off buffer, the coefficients in place of d coef
+                    if (on[q]) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            hrow[sl[q] * VBI_HROW + cb + 4 * v + k] = rp[k];
+                            drow[4 * v + k] = cf[k];
+                        }
+                    }
+                } else {
                 if (CF_LDS) {
                     if (on[q]) {
 #pragma unroll
@@ -1209,6 +1369,7 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
                 if (on[q]) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) drow[4 * v + k] = rp[k];
+                }
                 }
                 if (DPTS) {
                     // d feature / d point through the interpolation weights (the ATen grid_sample backward: taps outside the grid contribute
@@ -1241,13 +1402,19 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
             }
         }
     }
+#endif
     wave_sync();
     EVD_VBW_T(2);
     // the A operand of the basis gradient's MFMAs (d out[sample 2 u + kb][f = lane & 31]) is fetched HERE, in front of the plane taps'
     // atomics: the VM counter retires in order, a load issued behind them waits for every one of them (stamps: the 24 MFMAs of phase 5 took
     // 14 k cycles with their eight loads issued one by one behind the atomics, a fifth of the tile)
     float bav[VBW_SAMPLES / 2];
-    if (BAS) {
+#ifdef EVD_VBW_ATOMICS_ONLY
+    constexpr bool BASX = false;
+#else
+    constexpr bool BASX = BAS;
+#endif
+    if (BASX) {
         const int mn = lane & 31, kb = lane >> 5;
 #pragma unroll
         for (int u = 0; u < VBW_SAMPLES / 2; ++u) {
@@ -1260,10 +1427,20 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
 #pragma unroll
         for (int u = 0; u < VBW_SAMPLES / 2; ++u) asm volatile("" : "+v"(bav[u]));
     }
+    if (ISS) {                                    // hand the tile's plane taps to the issuer: cells and weights next to the rows phase 2 wrote
+        if (lane < VBW_SAMPLES * 3) {
+            const VbwTaps& tp = taps[lane];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { hcell[lane * 4 + t] = tp.ip[t]; hwgt[lane * 4 + t] = tp.wp[t]; }
+        }
+        lds_done();
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) flags[wv] = 1;
+    }
     // phase 3: plane taps.  dco now holds the plane rows d coef lv.
     int coff = 0;
 #pragma unroll 1
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 3 && !ISS; ++i) {
         const int C = sel3(i, c0n, c1n, c2n);
         float* gp = sel3(i, gg.plane[0], gg.plane[1], gg.plane[2]);
         if (gp) {
@@ -1272,23 +1449,16 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
             // per run: the x-y cell of an NDC ray changes every ~10 samples, and where the importance samples cluster at a surface the
             // x-z / y-z cells repeat as well
             const int tpp = 64 / C < 4 ? 64 / C : 4, j = lane / C, c = lane % C;
+            if (C == 64) {
+                vbw_walk_plane64(gp, lane, [&](int sm) { const vbw_f32x2 a = *reinterpret_cast<const vbw_f32x2*>(taps[sm * 3 + i].wp), b = *reinterpret_cast<const vbw_f32x2*>(taps[sm * 3 + i].wp + 2);
+                                                         return f32x4{a[0], a[1], b[0], b[1]}; },
+                                 [&](int sm, int t) { return taps[sm * 3 + i].ip[t]; }, [&](int sm) { return dco[sm * VBW_CSTR + coff + lane]; });
+            } else {
 #pragma unroll 1
-            for (int t0 = 0; t0 < 4; t0 += tpp) {
-                const int t = t0 + (j < tpp ? j : 0);
-                float acc = 0.f;
-                bool any = false;
-#pragma unroll 4
-                for (int s = 0; s < VBW_SAMPLES; ++s) {
-                    const VbwTaps& tp = taps[s * 3 + i];
-                    const float w = tp.wp[t];
-                    const int cell = tp.ip[t];
-                    if (w != 0.f) { acc += w * dco[s * VBW_CSTR + coff + c]; any = true; }
-                    const bool flush = s == VBW_SAMPLES - 1 || taps[(s + 1) * 3 + i].ip[t] != cell;
-                    if (flush) {
-                        if (any && j < tpp) unsafeAtomicAdd(gp + cell + c, acc);
-                        acc = 0.f;
-                        any = false;
-                    }
+                for (int t0 = 0; t0 < 4; t0 += tpp) {
+                    const int t = t0 + (j < tpp ? j : 0);
+                    vbw_walk_pass(gp, c, j < tpp, [&](int sm) { return taps[sm * 3 + i].wp[t]; }, [&](int sm) { return taps[sm * 3 + i].ip[t]; },
+                                  [&](int sm) { return dco[sm * VBW_CSTR + coff + c]; });
                 }
             }
         }
@@ -1326,7 +1496,7 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
         if (s0 + sl < n) d_pts[(s0 + sl) * 3 + a] = sum;
     }
     EVD_VBW_T(4);
-    if (BAS) {
+    if (BASX) {
         // phase 5: d basis_mat += d out^T . coef over the tile's 16 samples (coefficient rows: written to the slice by phase 2; the
         // LINES12 form kept them in registers and puts them where the consumed plane rows were)
         const float* crows = CF_LDS ? cfl : dco;
@@ -1351,13 +1521,17 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
             const float av = bav[u];
 #pragma unroll
             for (int c = 0; c < NCT; ++c) {
-                const float bv = 32 * c + mn < ctot ? crows[(2 * u + kb) * (CF_LDS ? VBW_FSTR : VBW_CSTR) + 32 * c + mn] : 0.f;
+                const float bv = 32 * c + mn < ctot ? crows[(2 * u + kb) * (CF_LDS ? CFSTR : VBW_CSTR) + 32 * c + mn] : 0.f;
                 bacc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, bacc[c], 0, 0, 0);
             }
         }
     }
     wave_sync();                                  // the slice is rewritten by the next tile
     EVD_VBW_T(5);
+    }
+    if (ISS && wv < NCW) {                        // the last tile has been taken; tell the issuer this producer is finished
+        while (__builtin_amdgcn_readfirstlane(flags[wv]) != 0) __builtin_amdgcn_s_sleep(2);
+        if (lane == 0) flags[wv] = 2;
     }
 #ifdef EVD_VBW_STAMP
     if (lane == 0 && rows_l) {
@@ -1377,7 +1551,7 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
         const int mn = lane & 31, kb = lane >> 5;
         __syncthreads();
         for (int w = 0; w < VBW_WAVES; ++w) {
-            if (wv == w) {
+            if (wv == w && w < NCW) {
 #pragma unroll
                 for (int c = 0; c < NCT; ++c)
 #pragma unroll
@@ -1783,14 +1957,25 @@ int launch_voxel_sample_bwd_w(const GridParams& g, const float* pts, long n, con
     const bool bas = gg.basis && !bas_sep;
     int cus = 256;
     { int dev = 0, v = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
-    const long tiles = cdiv(n, (long)VBW_SAMPLES * VBW_WAVES);
+    const bool l12 = voxel_sample_bwd_w_lines12(g);
+    // EVD_SCATTER_ISSUER=1 (developer switch, OFF by default): one wavefront of four issues the others' atomics.  Measured with the walk of
+    // round 6 (profiles/r06_scatter_issuer_ab.log): 0.444 against 0.433 ms per 2^19 samples -- the kernel is bound by the instructions it
+    // issues and, since the walk was cut, by the rate at which atomics retire (17 of 20.5 G requests/s), not by a wavefront's loads waiting
+    // behind its own atomics; a quarter fewer compute wavefronts cost what the decoupling buys.
+    static const bool iss_on = [] { const char* e = getenv("EVD_SCATTER_ISSUER"); return e && e[0] == '1'; }();
+    const bool iss = bas && !l12 && iss_on;
+    const long tiles = cdiv(n, (long)VBW_SAMPLES * (iss ? VBI_CW : VBW_WAVES));
     // persistent workgroups with the basis gradient in registers: two per CU (the LDS slices allow no more); else one tile per wavefront
     const unsigned blocks = (unsigned)(bas ? (tiles < 2L * cus ? tiles : 2L * cus) : tiles);
     float* coef_w = (gg.basis && !bas) ? coef : nullptr;
-    const bool l12 = voxel_sample_bwd_w_lines12(g);
 #define EVD_VBW(DP, L12, BAS) { EVD_SET_MAX_LDS((&k_voxel_sample_bwd_w<DP, L12, BAS>), VBW_LDS); \
         k_voxel_sample_bwd_w<DP, L12, BAS><<<blocks, 64 * VBW_WAVES, VBW_LDS, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, rows_l, ltap, coef_w, lmax); }
-    if (bas) {
+#define EVD_VBI(DP) { EVD_SET_MAX_LDS((&k_voxel_sample_bwd_w<DP, false, true, true>), VBI_LDS); \
+        k_voxel_sample_bwd_w<DP, false, true, true><<<blocks, 64 * VBW_WAVES, VBI_LDS, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, rows_l, ltap, coef_w, lmax); }
+    if (iss) {
+        if (d_pts) EVD_VBI(true)
+        else EVD_VBI(false)
+    } else if (bas) {
         if (d_pts && l12) EVD_VBW(true, true, true)
         else if (d_pts) EVD_VBW(true, false, true)
         else if (l12) EVD_VBW(false, true, true)
@@ -1802,6 +1987,7 @@ int launch_voxel_sample_bwd_w(const GridParams& g, const float* pts, long n, con
         else EVD_VBW(false, false, false)
     }
 #undef EVD_VBW
+#undef EVD_VBI
     EVD_LAUNCH_CHECK();
     if (gg.basis && !bas) {
         const int ct = g.n_comp[0] + g.n_comp[1] + g.n_comp[2];

@@ -371,15 +371,21 @@ template <class C, class L, bool FIRST, bool LAST> struct GroupSched {
 // One tile group p of a layer (see pipe_layer).
 // a completed B fragment of the training kernels goes to the activation store (lane-linear: 16 bytes per lane, 1 KiB per fragment;
 // the split-float16 mode's fragments are two such halves, hi then lo, in a 2 KiB slot).  FB: bytes of a fragment slot of the store.
+// EVD_ACT_NT (developer A/B, round 6): the fragment stores non-temporal
+#ifdef EVD_ACT_NT
+#define EVD_ACT_ST(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define EVD_ACT_ST(ptr, val) (*(ptr) = (val))
+#endif
 template <int FB = 1024, class F> __device__ __forceinline__ void act_store(char* act_lane, int slot, const F& frag) {
     static_assert(sizeof(F) == 16 || (sizeof(F) == 32 && FB == 2048), "16-byte fragments, or hi / lo pairs in 2 KiB slots");
     if constexpr (sizeof(F) == 16) {
-        *reinterpret_cast<f32x4*>(act_lane + (long)slot * FB) = __builtin_bit_cast(f32x4, frag);
+        EVD_ACT_ST(reinterpret_cast<f32x4*>(act_lane + (long)slot * FB), __builtin_bit_cast(f32x4, frag));
     } else {
         struct Two { f32x4 a, b; };
         const Two t = __builtin_bit_cast(Two, frag);
-        *reinterpret_cast<f32x4*>(act_lane + (long)slot * FB) = t.a;
-        *reinterpret_cast<f32x4*>(act_lane + (long)slot * FB + 1024) = t.b;
+        EVD_ACT_ST(reinterpret_cast<f32x4*>(act_lane + (long)slot * FB), t.a);
+        EVD_ACT_ST(reinterpret_cast<f32x4*>(act_lane + (long)slot * FB + 1024), t.b);
     }
 }
 
@@ -387,7 +393,7 @@ template <int FB = 1024, class F> __device__ __forceinline__ void act_store(char
 template <class C, class F> __device__ __forceinline__ void pipe_act_store(char* act_lane, int slot, const F& frag) {
     if constexpr (C::HI_ONLY && sizeof(F) == 32) {
         struct Two { f32x4 a, b; };
-        *reinterpret_cast<f32x4*>(act_lane + (long)slot * 1024) = __builtin_bit_cast(Two, frag).a;
+        EVD_ACT_ST(reinterpret_cast<f32x4*>(act_lane + (long)slot * 1024), __builtin_bit_cast(Two, frag).a);
     } else if constexpr (C::HI_ONLY) {
         act_store<1024>(act_lane, slot, frag);
     } else {
