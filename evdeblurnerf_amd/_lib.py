@@ -93,10 +93,17 @@ _L, _I, _F, _S = C.c_long, C.c_int, C.c_float, C.c_size_t
 SIGNATURES = {
     "evd_last_error": (C.c_char_p, []),
     "evd_version": (_I, []),
+    "evd_debug_side_spin_count": (_L, []),
     "evd_compute_successor_workspace_bytes": (_S, [_L]),
     "evd_compute_successor": (_I, [_vp, _L, _L, _vp, _vp, _vp, _vp, _vp, _S, _vp]),
-    "evd_sample_events": (_I, [_vp, _L, _I, _vp, _vp, _vp, _vp, _vp, _L, _fp, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "evd_sample_events_track": (_I, [_vp, _L, _I, _vp, _vp, C.POINTER(PoseTrack), _vp, _vp, _L, _fp, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "evd_event_coord_ids_workspace_bytes": (_S, [_L, _I, _I]),
+    "evd_event_coord_ids": (_I, [_vp, _vp, _L, _I, _I, _vp, _vp, _vp, _vp, _vp, _S, _vp]),
+    "evd_event_filter_workspace_bytes": (_S, [_L]),
+    "evd_event_filter": (_I, [_vp, _vp, _vp, _L, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _S, _vp]),
+    "evd_event_color_map_workspace_bytes": (_S, [_L]),
+    "evd_event_color_map": (_I, [_vp, _L, _I, _I, _vp, _vp, _vp, _L, _vp, _vp, _vp, _S, _vp]),
+    "evd_sample_events": (_I, [_vp, _L, _I, _vp, _L, _vp, _vp, _vp, _vp, _L, _fp, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "evd_sample_events_track": (_I, [_vp, _L, _I, _vp, _L, _vp, C.POINTER(PoseTrack), _vp, _vp, _L, _fp, _I, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "evd_interpolate_poses": (_I, [C.POINTER(PoseTrack), _vp, _L, _vp, _vp]),
     "evd_image_batch": (_I, [_vp, _L, _vp, _vp, _vp, _I, _I, _I, _fp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "evd_rbk_warp": (_I, [_vp, _vp, _vp, _L, _I, _I, _vp, _vp, _vp]),

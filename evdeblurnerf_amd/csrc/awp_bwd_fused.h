@@ -191,8 +191,10 @@ __global__ __launch_bounds__(256, 1) void k_awp_bwd_fused(const AwpBwdFusedParam
                 frags(d, o0, o1);
                 *reinterpret_cast<W4*>(out + (long)(D_GEO + 2 * r) * 1024) = o0;
                 *reinterpret_cast<W4*>(out + (long)(D_GEO + 2 * r + 1) * 1024) = o1;
+                float nan_probe = 0.f;               // fmaxf drops a NaN (and inf - inf): record it as +inf, like k_mam_local_bwd does for |d h_local|
 #pragma unroll
-                for (int i = 0; i < 16; ++i) gmax = fmaxf(gmax, fabsf(d[i]));       // (the fragments hold these values rounded to half precision)
+                for (int i = 0; i < 16; ++i) { gmax = fmaxf(gmax, fabsf(d[i])); nan_probe += d[i]; }       // (the fragments hold these values rounded to half precision)
+                gmax = nan_probe != nan_probe ? __builtin_huge_valf() : gmax;
             }
         }
     }

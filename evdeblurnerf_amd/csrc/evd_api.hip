@@ -1,3 +1,4 @@
+#include <atomic>
 // C-ABI entry points of the NeRF backbone: weight packing, fused MLP launch, render_rays orchestration.
 #include "evd_common.h"
 #include "nerf_mlp.h"
@@ -32,6 +33,25 @@ int nerf_mlp_pipe_dispatch(int prec, const MlpParams& p, hipStream_t st);
 int nerf_mlp_c_dispatch(int W, int D, int skip, const MlpParams& p, hipStream_t st);       // kernel_nerf_mlp.hip: compensated float16 mode
 int nerf_mlp_c_chunks(int W, int D, int skip);                                             // 0: not built for this network
 
+// the side-stream test hook (evd_common.h): ONE copy of the spin kernel in the library, the launch checked, launches counted
+static std::atomic<long> g_side_spins{0};
+static __global__ void k_test_spin(long long ticks) {          // wall_clock64: the constant 100 MHz counter
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+int test_side_spin(hipStream_t side) {
+    static const int us = [] { const char* e = getenv("EVD_TEST_SIDE_SPIN_US"); return e ? atoi(e) : 0; }();
+    if (us <= 0) return EVD_OK;
+    hipLaunchKernelGGL(k_test_spin, dim3(1), dim3(64), 0, side, (long long)us * 100);
+    EVD_LAUNCH_CHECK();
+    g_side_spins.fetch_add(1, std::memory_order_relaxed);
+    return EVD_OK;
+}
+bool test_skip_side_join() {
+    static const bool skip = [] { const char* e = getenv("EVD_TEST_SKIP_SIDE_JOIN"); return e && e[0] == '1'; }();
+    return skip;
+}
+
 }  // namespace evd
 
 using namespace evd;
@@ -39,6 +59,7 @@ using namespace evd;
 extern "C" {
 
 const char* evd_last_error(void) { return evd::err_buf(); }
+long evd_debug_side_spin_count(void) { return evd::g_side_spins.load(std::memory_order_relaxed); }
 int evd_version(void) { return 120; }      // 110: training entries (evd_*_train, evd_*_backward, evd_*_load_params, ...); 120: evd_awp_embed_*, the f16x3 training mode (evd_*_train_store_bytes_prec), evd_voxel_mlp_backward(awp_store), evd_voxel_sample_bwd_ws, evd_merge_features
 
 int evd_device_count(void) {

@@ -143,20 +143,13 @@ inline int bwd_overlap_blocks(int cap) {
     return want <= 0 ? 0 : (want > cap ? cap : want);
 }
 
-// TEST HOOK (tests/test_gpu_dist.py): EVD_TEST_SIDE_SPIN_US=N makes every wgrad launch on a handle's side stream start N microseconds
-// late (a spin kernel in front of it), so that a missing join of the side stream into the caller's stream -- the edge the early gradient
-// all-reduce of dist.GradReducer.attach relies on -- shows as wrong sums instead of passing by luck of timing.  0 / unset: nothing.
-inline int test_side_spin_us() {
-    static const int us = [] { const char* e = getenv("EVD_TEST_SIDE_SPIN_US"); return e ? atoi(e) : 0; }();
-    return us;
-}
-static __global__ void k_test_spin(long long ticks) {          // wall_clock64: the constant 100 MHz counter
-    const long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
-}
-inline void test_side_spin(hipStream_t side) {
-    const int us = test_side_spin_us();
-    if (us > 0) hipLaunchKernelGGL(k_test_spin, dim3(1), dim3(64), 0, side, (long long)us * 100);
-}
+// TEST HOOK (tests/test_gpu_dist.py), defined once in evd_api.hip: EVD_TEST_SIDE_SPIN_US=N makes every wgrad launch on a handle's side
+// stream start N microseconds late (a spin kernel in front of it), so that a missing join of the side stream into the caller's stream --
+// the edge the early gradient all-reduce of dist.GradReducer.attach relies on -- shows as wrong sums instead of passing by luck of
+// timing.  0 / unset: one predictable branch per backward entry, no launch.  evd_debug_side_spin_count() reports how many spin kernels were
+// launched (the test asserts that the hook fired); EVD_TEST_SKIP_SIDE_JOIN=1 is the test's NEGATIVE control: the entry returns without
+// joining the side stream, and the delayed launches must then show as wrong gradients.
+int test_side_spin(hipStream_t side);          // EVD_OK, or the launch error
+bool test_skip_side_join();
 
 }  // namespace evd

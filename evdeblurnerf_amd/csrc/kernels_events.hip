@@ -55,7 +55,7 @@ __global__ void k_succ_write(const int* __restrict__ keys, const int* __restrict
 // successor carries -1: the reference would wrap to events[-1]), gives zero polarity sums, successor -1, the start pose twice, and sets
 // the flag word like a coordinate mismatch does.
 template <bool TRACK>
-__global__ __launch_bounds__(256) void k_sample_events(const double* __restrict__ ev, long N, int ncol, const float* __restrict__ id_to_coords,
+__global__ __launch_bounds__(256) void k_sample_events(const double* __restrict__ ev, long N, int ncol, const float* __restrict__ id_to_coords, long n_coords,
                                                        const unsigned char* __restrict__ cmap, const float* __restrict__ poses, const PoseTrackDev trk,
                                                        const long long* __restrict__ ids, const long long* __restrict__ hops, long n,
                                                        float k00, float k02, float k11, float k12, float halfpix,
@@ -65,7 +65,10 @@ __global__ __launch_bounds__(256) void k_sample_events(const double* __restrict_
     const long i = blockIdx.x * 256L + threadIdx.x;
     if (i >= n) return;
     const long long id = ids[i];
-    if (id < 0 || id >= N) {                       // nothing of this event can be read
+    // an id outside the event table, or an event whose coordinate id lies outside the coordinate tables (a corrupt column 0): nothing of
+    // this event can be read
+    const long long pix0 = (id >= 0 && id < N) ? (long long)ev[id * ncol] : -1;
+    if (id < 0 || id >= N || pix0 < 0 || pix0 >= n_coords) {
         pos_out[i] = neg_out[i] = 0.f;
         coords_ids[i] = -1;
         if (succ_out) succ_out[i] = -1;
@@ -122,7 +125,9 @@ __global__ __launch_bounds__(256) void k_sample_events(const double* __restrict_
         float pose[12];
         const float* c2w;
         if (TRACK) {
-            pose_at(trk, ev[e * ncol + ncol - 3], pose);
+            const double te = ev[e * ncol + ncol - 3];
+            if (mismatch && !(te == te && te - te == 0.0)) atomicExch(mismatch, 1);      // a non-finite timestamp gives NaN poses: flagged
+            pose_at(trk, te, pose);
             c2w = pose;
         } else {
             c2w = poses + e * 12;
@@ -194,11 +199,11 @@ int evd_compute_successor(const int* pixel_ids, long N, long HW, long long* succ
     return EVD_OK;
 }
 
-static int sample_events_launch(const char* who, const double* events, long N, int ncol, const float* id_to_coords, const unsigned char* id_to_color_map,
+static int sample_events_launch(const char* who, const double* events, long N, int ncol, const float* id_to_coords, long n_coords, const unsigned char* id_to_color_map,
                                 const float* poses, const evd_pose_track* track, const long long* events_ids, const long long* hops, long n,
                                 const float* K, int add_halfpix, float* rays_start, float* rays_end, float* pos_cumsum, float* neg_cumsum,
                                 long long* coords_ids, unsigned char* color_map, long long* successor, int* mismatch, void* stream) {
-    EVD_REQUIRE(n >= 0 && N >= 0 && ncol >= 4 && K, "%s: bad arguments (the event table has >= 4 columns: id, .., t, p, successor)", who);
+    EVD_REQUIRE(n >= 0 && N >= 0 && n_coords >= 0 && ncol >= 4 && K, "%s: bad arguments (the event table has >= 4 columns: id, .., t, p, successor)", who);
     if (track) {
         const char* why = pose_track_invalid(track);
         EVD_REQUIRE(!why, "%s: %s", who, why);
@@ -211,31 +216,31 @@ static int sample_events_launch(const char* who, const double* events, long N, i
     if (mismatch) EVD_HIP(hipMemsetAsync(mismatch, 0, sizeof(int), st));
     const float hp = add_halfpix ? 0.5f : 0.f;
     if (track)
-        hipLaunchKernelGGL(k_sample_events<true>, dim3((unsigned)cdiv(n, 256L)), dim3(256), 0, st, events, N, ncol, id_to_coords, id_to_color_map,
+        hipLaunchKernelGGL(k_sample_events<true>, dim3((unsigned)cdiv(n, 256L)), dim3(256), 0, st, events, N, ncol, id_to_coords, n_coords, id_to_color_map,
                            (const float*)nullptr, pose_track_dev(track), events_ids, hops, n, K[0], K[2], K[4], K[5], hp, rays_start, rays_end,
                            pos_cumsum, neg_cumsum, coords_ids, color_map, successor, mismatch);
     else
-        hipLaunchKernelGGL(k_sample_events<false>, dim3((unsigned)cdiv(n, 256L)), dim3(256), 0, st, events, N, ncol, id_to_coords, id_to_color_map,
+        hipLaunchKernelGGL(k_sample_events<false>, dim3((unsigned)cdiv(n, 256L)), dim3(256), 0, st, events, N, ncol, id_to_coords, n_coords, id_to_color_map,
                            poses, PoseTrackDev{}, events_ids, hops, n, K[0], K[2], K[4], K[5], hp, rays_start, rays_end, pos_cumsum, neg_cumsum,
                            coords_ids, color_map, successor, mismatch);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }
 
-int evd_sample_events(const double* events, long N, int ncol, const float* id_to_coords, const unsigned char* id_to_color_map,
+int evd_sample_events(const double* events, long N, int ncol, const float* id_to_coords, long n_coords, const unsigned char* id_to_color_map,
                       const float* poses, const long long* events_ids, const long long* hops, long n, const float* K, int add_halfpix,
                       float* rays_start, float* rays_end, float* pos_cumsum, float* neg_cumsum, long long* coords_ids,
                       unsigned char* color_map, long long* successor, int* mismatch, void* stream) {
-    return sample_events_launch("evd_sample_events", events, N, ncol, id_to_coords, id_to_color_map, poses, nullptr, events_ids, hops, n, K, add_halfpix,
+    return sample_events_launch("evd_sample_events", events, N, ncol, id_to_coords, n_coords, id_to_color_map, poses, nullptr, events_ids, hops, n, K, add_halfpix,
                                 rays_start, rays_end, pos_cumsum, neg_cumsum, coords_ids, color_map, successor, mismatch, stream);
 }
 
-int evd_sample_events_track(const double* events, long N, int ncol, const float* id_to_coords, const unsigned char* id_to_color_map,
+int evd_sample_events_track(const double* events, long N, int ncol, const float* id_to_coords, long n_coords, const unsigned char* id_to_color_map,
                             const evd_pose_track* track, const long long* events_ids, const long long* hops, long n, const float* K,
                             int add_halfpix, float* rays_start, float* rays_end, float* pos_cumsum, float* neg_cumsum, long long* coords_ids,
                             unsigned char* color_map, long long* successor, int* mismatch, void* stream) {
     EVD_REQUIRE(track, "evd_sample_events_track: null track");
-    return sample_events_launch("evd_sample_events_track", events, N, ncol, id_to_coords, id_to_color_map, nullptr, track, events_ids, hops, n, K,
+    return sample_events_launch("evd_sample_events_track", events, N, ncol, id_to_coords, n_coords, id_to_color_map, nullptr, track, events_ids, hops, n, K,
                                 add_halfpix, rays_start, rays_end, pos_cumsum, neg_cumsum, coords_ids, color_map, successor, mismatch, stream);
 }
 

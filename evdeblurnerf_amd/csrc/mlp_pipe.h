@@ -371,11 +371,16 @@ template <class C, class L, bool FIRST, bool LAST> struct GroupSched {
 // One tile group p of a layer (see pipe_layer).
 // a completed B fragment of the training kernels goes to the activation store (lane-linear: 16 bytes per lane, 1 KiB per fragment;
 // the split-float16 mode's fragments are two such halves, hi then lo, in a 2 KiB slot).  FB: bytes of a fragment slot of the store.
-// EVD_ACT_NT (developer A/B, round 6): the fragment stores non-temporal
-#ifdef EVD_ACT_NT
+// The fragment stores of the training kernels are NON-TEMPORAL (round 6): the store is written once and read again by the backward a
+// millisecond later, from HBM either way (2.36 M fine-level samples x 66 KiB per 32 = 4.9 GB per iteration against 32 MB of L2); without the
+// cache allocation the fine level's training forward runs 1.446 -> 1.259 ms per iteration, the coarse one 0.231 -> 0.190, the backward
+// kernels that read the fragments unchanged (profiles/r06_act_nt_ab.log).  -DEVD_ACT_NO_NT restores the plain stores.
+#ifndef EVD_ACT_NO_NT
 #define EVD_ACT_ST(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#define EVD_ACT_NT_ASM " nt"
 #else
 #define EVD_ACT_ST(ptr, val) (*(ptr) = (val))
+#define EVD_ACT_NT_ASM ""
 #endif
 template <int FB = 1024, class F> __device__ __forceinline__ void act_store(char* act_lane, int slot, const F& frag) {
     static_assert(sizeof(F) == 16 || (sizeof(F) == 32 && FB == 2048), "16-byte fragments, or hi / lo pairs in 2 KiB slots");

@@ -356,10 +356,10 @@ struct CAct {
 __device__ __forceinline__ void c_act_store(const CAct& a, int slot, const u32x4& v) {        // slot is a compile-time constant at every call site
     const char* sb = a.base + (long)(slot >> 2) * 4096;
     switch (slot & 3) {
-    case 0: asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(a.voff), "v"(v), "s"(sb) : "memory"); break;
-    case 1: asm volatile("global_store_dwordx4 %0, %1, %2 offset:1024\n\ts_nop 1" : : "v"(a.voff), "v"(v), "s"(sb) : "memory"); break;
-    case 2: asm volatile("global_store_dwordx4 %0, %1, %2 offset:2048\n\ts_nop 1" : : "v"(a.voff), "v"(v), "s"(sb) : "memory"); break;
-    default: asm volatile("global_store_dwordx4 %0, %1, %2 offset:3072\n\ts_nop 1" : : "v"(a.voff), "v"(v), "s"(sb) : "memory"); break;
+    case 0: asm volatile("global_store_dwordx4 %0, %1, %2" EVD_ACT_NT_ASM "\n\ts_nop 1" : : "v"(a.voff), "v"(v), "s"(sb) : "memory"); break;
+    case 1: asm volatile("global_store_dwordx4 %0, %1, %2 offset:1024" EVD_ACT_NT_ASM "\n\ts_nop 1" : : "v"(a.voff), "v"(v), "s"(sb) : "memory"); break;
+    case 2: asm volatile("global_store_dwordx4 %0, %1, %2 offset:2048" EVD_ACT_NT_ASM "\n\ts_nop 1" : : "v"(a.voff), "v"(v), "s"(sb) : "memory"); break;
+    default: asm volatile("global_store_dwordx4 %0, %1, %2 offset:3072" EVD_ACT_NT_ASM "\n\ts_nop 1" : : "v"(a.voff), "v"(v), "s"(sb) : "memory"); break;
     }
 }
 

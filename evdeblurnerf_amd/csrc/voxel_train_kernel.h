@@ -207,7 +207,7 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
             EVD_HIP(hipEventRecord(b.ev, st));
             EVD_HIP(hipStreamWaitEvent(b.side, b.ev, 0));
             ws = b.side;
-            test_side_spin(ws);
+            if (int rcs = test_side_spin(ws)) return rcs;
         }
         int r = launch(p, blocks, ws);
         if (r) return r;
@@ -359,7 +359,7 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
             EVD_LAUNCH_CHECK();
         }
     }
-    if (b.side) {                               // join
+    if (b.side && !test_skip_side_join()) {     // join
         EVD_HIP(hipEventRecord(b.ev, b.side));
         EVD_HIP(hipStreamWaitEvent(st, b.ev, 0));
     }

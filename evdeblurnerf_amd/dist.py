@@ -134,7 +134,9 @@ class GradReducer:
         * ordering against the backward entries' side streams: evd_*_mlp_backward joins its per-handle side stream into the caller's
           stream before it returns (csrc/voxel_train_kernel.h, nerf_train_kernel.h: hipEventRecord(side) + hipStreamWaitEvent(stream)),
           and the process group orders the collective behind the work already enqueued on the current stream, so a collective started
-          here sees the complete buffers (tests/test_gpu_dist.py delays the side stream to prove the edge).
+          here sees the complete buffers.  tests/test_gpu_dist.py delays every side-stream launch by 2 ms (with the voxel levels' side
+          stream switched on, asserting that the delay kernels ran) and has a negative control with the join disabled, whose gradients
+          must come out wrong; over RCCL itself the test needs a second GPU and has not run yet.
         EVD_NO_EARLY_ALLREDUCE=1: attach() installs nothing (every message starts at start())."""
         if os.environ.get("EVD_NO_EARLY_ALLREDUCE", "0") not in ("", "0"):
             return self

@@ -91,7 +91,9 @@ class EventSampler:
             self.poses = torch.as_tensor(poses, dtype=torch.float32, device=dev).reshape(-1, 3, 4).contiguous()
             if self.poses.shape[0] != self.events.shape[0]:
                 raise L.EvdError("EventSampler: one pose [3, 4] per event")
-        self.id_to_color_map = None if id_to_color_map is None else torch.as_tensor(np.asarray(id_to_color_map), device=dev).to(torch.uint8).contiguous()
+        if id_to_color_map is not None and not isinstance(id_to_color_map, torch.Tensor):
+            id_to_color_map = torch.as_tensor(np.asarray(id_to_color_map))
+        self.id_to_color_map = None if id_to_color_map is None else id_to_color_map.to(device=dev, dtype=torch.uint8).contiguous()
         self.K = np.ascontiguousarray(np.asarray(K, dtype=np.float32).reshape(-1))
         self.integer_coords = bool(integer_coords)
         self._mismatch = torch.zeros((1,), dtype=torch.int32, device=dev)
@@ -136,7 +138,7 @@ class EventSampler:
         pos, neg = torch.empty((n,), **f32), torch.empty((n,), **f32)
         cid = torch.empty((n,), dtype=torch.int64, device=dev)
         cm = torch.empty((n, 3), dtype=torch.uint8, device=dev) if self.id_to_color_map is not None else None
-        head = (L.ptr(self.events), self.events.shape[0], self.events.shape[1], L.ptr(self.id_to_coords), L.ptr(self.id_to_color_map))
+        head = (L.ptr(self.events), self.events.shape[0], self.events.shape[1], L.ptr(self.id_to_coords), self.id_to_coords.shape[0], L.ptr(self.id_to_color_map))
         tail = (L.ptr(ids), L.ptr(hp), n, self.K.ctypes.data_as(C.POINTER(C.c_float)), int(self.integer_coords),
                 L.ptr(rs), L.ptr(re), L.ptr(pos), L.ptr(neg), L.ptr(cid), L.ptr(cm), None, L.ptr(self._mismatch), L.stream_ptr())
         if self.pose_track is not None:
@@ -148,3 +150,126 @@ class EventSampler:
                              "its start event's coordinate id")
         return {"events_pos_pol_cumsum": pos, "events_neg_pol_cumsum": neg, "events_rays_start": rs, "events_rays_end": re,
                 "events_coords_ids": cid, "events_color_map": cm.bool() if cm is not None else None}
+
+
+class EventTables:
+    """The once-per-dataset half of the reference's event loader -- ``LLFFEventsDataset.load_event_data`` (data/loader_events.py:150-257)
+    and ``load_events_h5`` (utils/events.py:11-69) -- on the arrays the files hold, computed on the device.  Reading ``events.h5`` /
+    ``*.npy`` / ``*.npz`` stays with the caller (on-disk formats are out of scope; h5py is not in this image): pass the arrays.
+
+    Attributes, under the keys of the reference's ``retvals``: ``events`` [N', 4] float64 (coordinate id, timestamp in microseconds, polarity
+    -1 / 1, successor index), ``id_to_coords`` [Ncoords, 2] float64, ``coords_to_id`` ([h, w] int32 table for integer coordinates, else
+    None: ``id_to_coords`` is in the byte order the ids were assigned in and is searched directly), ``id_to_color_map`` [Ncoords, 3] bool or
+    None, ``events_num_successors`` [N'] int32, ``events_with_successor_idx`` int64, ``intcoords``, ``noev_coord_ids`` (the ids of the pixels
+    no event rounds to), ``allknown_poses`` [M, 3, 4], ``allknown_poses_timestamps``, ``images_*`` timestamps, ``pose_track`` (poses.PoseTrack: the
+    reference's ``events_pose_bspl`` inside ``interpolate_poses``).  ``sampler(K)`` returns the ready ``EventSampler``."""
+
+    @classmethod
+    def from_arrays(cls, x, y, t, p, h, w, all_timestamps, all_poses_bounds, img_timestamps=None, img_timestamps_start=None, img_timestamps_end=None,
+                    ev_map=None, color_events=False, events_tms_unit="ns", events_tms_files_unit="us", event_accumulate_step_range=(0, 0),
+                    event_accumulate_step_range_end=(0, 0), bd_scale=1.0, recenter=True, recenter_partial=None, device="cuda", check=True):
+        """x, y, t, p: the four datasets of events.h5 (any numeric dtypes; t in ``events_tms_unit``); all_timestamps [M] and the
+        img_timestamps* in ``events_tms_files_unit`` (all_timestamps.npy, images_1/timestamps.npz); all_poses_bounds [M, 17]
+        (all_poses_bounds.npy); ev_map: None, or (inv_mapx, inv_mapy) [h, w] (ev_map.npz: rectified float coordinates).  check=True reads the
+        two device flags back and raises where the reference asserts (polarities not {-1, 1}, a coordinate without colour)."""
+        self = cls()
+        dev = torch.device(device)
+        powers = {"s": 0, "ms": -3, "us": -6, "ns": -9}                       # utils/misc.py:108-110 convert_unit(unit, "us")
+        ev_scale = 10 ** (powers[events_tms_unit] - powers["us"])
+        file_scale = 10 ** (powers[events_tms_files_unit] - powers["us"])
+        key_t = np.asarray(all_timestamps).astype(np.float64) * file_scale     # :158-163 (the integer dtype games of possibly_smallest_int do not change values)
+        apb = np.asarray(all_poses_bounds, dtype=np.float64)
+        self.allknown_poses = apb[:, :-2].reshape(-1, 3, 5)[:, :3, :4].copy()  # :170-172
+        self.allknown_poses_timestamps = key_t
+        sc = lambda a: None if a is None else np.asarray(a, dtype=np.float64) * file_scale
+        self.images_poses_timestamps, self.images_timestamps_start, self.images_timestamps_end = sc(img_timestamps), sc(img_timestamps_start), sc(img_timestamps_end)
+        xs = torch.as_tensor(np.asarray(x), device=dev).to(torch.float32).contiguous()          # utils/events.py:35-36
+        ys = torch.as_tensor(np.asarray(y), device=dev).to(torch.float32).contiguous()
+        ts = (torch.as_tensor(np.asarray(t), device=dev).to(torch.float64) * ev_scale).contiguous()
+        ps = torch.as_tensor(np.asarray(p), device=dev).to(torch.float64).contiguous()
+        N, h, w = int(xs.shape[0]), int(h), int(w)
+        lib = L.lib()
+        # ---- coordinate ids (utils/events.py:39-66)
+        ev_ids = torch.empty((max(N, 1),), dtype=torch.int64, device=dev)
+        noev = torch.empty((h * w,), dtype=torch.int64, device=dev)
+        i2c = torch.empty((N + h * w, 2), dtype=torch.float64, device=dev)
+        counts = torch.zeros((2,), dtype=torch.int64, device=dev)
+        nb = int(lib.evd_event_coord_ids_workspace_bytes(N, h, w))
+        ws = torch.empty((nb,), dtype=torch.uint8, device=dev)
+        L.check(lib.evd_event_coord_ids(L.ptr(xs), L.ptr(ys), N, h, w, L.ptr(ev_ids), L.ptr(noev), L.ptr(i2c), L.ptr(counts), L.ptr(ws), nb, L.stream_ptr()),
+                "evd_event_coord_ids")
+        n_coords, n_noev = (int(v) for v in counts.tolist())                  # (the one host read-back of the data-dependent sizes)
+        self.id_to_coords = i2c[:n_coords].clone()
+        self.noev_coord_ids = noev[:n_noev].clone()
+        # ---- events inside the range of the known poses, polarity in {-1, 1} (:191, 203-206)
+        ev3 = torch.empty((max(N, 1), 3), dtype=torch.float64, device=dev)
+        cnt = torch.zeros((1,), dtype=torch.int64, device=dev)
+        bad = torch.zeros((2,), dtype=torch.int32, device=dev)
+        nb = int(lib.evd_event_filter_workspace_bytes(N))
+        ws = torch.empty((nb,), dtype=torch.uint8, device=dev)
+        L.check(lib.evd_event_filter(L.ptr(ev_ids), L.ptr(ts), L.ptr(ps), N, float(key_t.min()), float(key_t.max()), L.ptr(ev3), L.ptr(cnt), L.ptr(bad[0:1]),
+                                     L.ptr(ws), nb, L.stream_ptr()), "evd_event_filter")
+        n_ev = int(cnt.item())
+        ev3 = ev3[:n_ev]
+        self.intcoords = bool(torch.all(self.id_to_coords == torch.trunc(self.id_to_coords)).item()) if n_coords else True       # :194
+        self.coords_to_id = None
+        if self.intcoords:                                                     # :195-197
+            c2i = torch.full((h, w), -1, dtype=torch.int32, device=dev)
+            c2i[self.id_to_coords[:, 1].long(), self.id_to_coords[:, 0].long()] = torch.arange(n_coords, dtype=torch.int32, device=dev)
+            self.coords_to_id = c2i
+        # ---- colour of a coordinate id (:208-236)
+        self.id_to_color_map = None
+        if color_events:
+            if self.intcoords and ev_map is not None:
+                raise L.EvdError("Int coordinates but an ev_map was given. Are coordinates rectified?")          # (:216-217)
+            if not self.intcoords and ev_map is None:
+                raise L.EvdError("Float coordinates but no ev_map given. Are coordinates not rectified?")      # (:221-222)
+            cmap = torch.zeros((max(n_coords, 1), 3), dtype=torch.uint8, device=dev)
+            mx = my = None
+            if ev_map is not None:
+                mx = torch.as_tensor(np.asarray(ev_map[0]), device=dev).to(torch.float32).contiguous()
+                my = torch.as_tensor(np.asarray(ev_map[1]), device=dev).to(torch.float32).contiguous()
+                if tuple(mx.shape) != (h, w) or tuple(my.shape) != (h, w):
+                    raise L.EvdError("ev_map: inv_mapx / inv_mapy [h, w]")
+            nb = int(lib.evd_event_color_map_workspace_bytes(n_coords))
+            ws = torch.empty((nb,), dtype=torch.uint8, device=dev)
+            L.check(lib.evd_event_color_map(L.ptr(self.id_to_coords), n_coords, h, w, L.ptr(mx), L.ptr(my), L.ptr(self.noev_coord_ids), n_noev, L.ptr(cmap),
+                                            L.ptr(bad[1:2]), L.ptr(ws), nb, L.stream_ptr()), "evd_event_color_map")
+            self.id_to_color_map = cmap[:n_coords].bool()
+        # ---- successor graph (:239), the augmented table (:245), the events a batch may start from (:248-255)
+        succ, nsucc, _, _ = compute_successor(ev3[:, 0].to(torch.int32), max(n_coords, 1))
+        self.events = torch.cat([ev3, succ[:n_ev, None].to(torch.float64)], dim=1)
+        self.events_num_successors = nsucc[:n_ev]
+        lo, hi = tuple(event_accumulate_step_range), tuple(event_accumulate_step_range_end)
+        min_step = max(lo[0], hi[0]) if lo != (0, 0) else 0
+        self.events_with_successor_idx = torch.nonzero(self.events_num_successors > min_step).reshape(-1)
+        if check:
+            flags = bad.tolist()
+            if flags[0]:
+                raise L.EvdError("polarities must be {0, 1} or {-1, 1} (loader_events.py:203-206)")
+            if flags[1]:
+                raise L.EvdError("a coordinate that carries events has no entry in the ev_map inverse maps (loader_events.py:231-234)")
+        from .poses import PoseTrack
+        self.pose_track = None
+        if recenter_partial is not None or not recenter:
+            self.pose_track = PoseTrack(key_t, self.allknown_poses, bd_scale=bd_scale, recenter=recenter, recenter_partial=recenter_partial, device=device)
+        self.h, self.w, self.device = h, w, dev
+        self._hops = (lo, hi)
+        return self
+
+    def interpolate_poses(self, t):
+        """LLFFEventsDataset.interpolate_poses (:133-148) = events_pose_bspl (:175-182: Slerp + cubic spline of the known poses, clipped to
+        their time range) + the LLFF column change, bd_scale and recentring: float32 [n, 4, 4] on the device"""
+        if self.pose_track is None:
+            raise L.EvdError("EventTables.interpolate_poses: built with recenter=True but without the image dataset's recenter_partial")
+        return self.pose_track.interpolate_poses(t)
+
+    def sampler(self, K, step_end=0, scheduler="constant"):
+        """-> the EventSampler of this dataset (integer_coords, colour map, pose track, hop schedule when an accumulation range was given)"""
+        if self.pose_track is None:
+            raise L.EvdError("EventTables.sampler: built with recenter=True but without the image dataset's recenter_partial")
+        s = EventSampler(self.events, self.id_to_coords.to(torch.float32), K=K, id_to_color_map=self.id_to_color_map, integer_coords=self.intcoords,
+                         device=str(self.device), pose_track=self.pose_track)
+        if self._hops[0] != (0, 0):
+            s.set_hop_schedule(self.events_num_successors, self._hops[0], self._hops[1], step_end, scheduler)
+        return s

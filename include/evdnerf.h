@@ -63,6 +63,10 @@ extern "C" {
 
 const char* evd_last_error(void);
 int evd_version(void);
+/* test support (tests/test_gpu_dist.py; no reference counterpart): the number of delay kernels the side-stream test hook launched in this
+ * process (EVD_TEST_SIDE_SPIN_US=N in the environment puts an N-microsecond spin in front of every backward launch on a handle's side
+ * stream; 0 when the variable is unset -- the hook is then one branch per backward entry) */
+long evd_debug_side_spin_count(void);
 /* number of gfx950 devices visible; <0 on error */
 int evd_device_count(void);
 
@@ -583,8 +587,10 @@ int evd_compute_successor(const int* pixel_ids, long N, long HW, long long* succ
  *   add_halfpix   the reference passes integer_coords (:292)
  * outputs (dev): rays_start / rays_end float32 [n, 3, 2] (origin, direction in the last axis, :296-297), pos_cumsum / neg_cumsum
  * float32 [n], coords_ids int64 [n], color_map uint8 [n, 3] (NULL with id_to_color_map NULL), successor int64 [n] or NULL (the end event),
- * mismatch int32 [1] or NULL: set to 1 when an end event is not on its start event's coordinate id (the reference asserts, :284). */
-int evd_sample_events(const double* events, long N, int ncol, const float* id_to_coords, const unsigned char* id_to_color_map,
+ * mismatch int32 [1] or NULL: set to 1 when an end event is not on its start event's coordinate id (the reference asserts, :284), when an
+ * id / successor / coordinate id (column 0, checked against n_coords = Ncoords) lies outside its table -- such an event gives zero outputs
+ * --, or (track form) when an event's timestamp is not finite. */
+int evd_sample_events(const double* events, long N, int ncol, const float* id_to_coords, long n_coords, const unsigned char* id_to_color_map,
                       const float* poses, const long long* events_ids, const long long* hops, long n, const float* K, int add_halfpix,
                       float* rays_start, float* rays_end, float* pos_cumsum, float* neg_cumsum, long long* coords_ids,
                       unsigned char* color_map, long long* successor, int* mismatch, void* stream);
@@ -616,10 +622,38 @@ int evd_interpolate_poses(const evd_pose_track* track, const double* t, long n, 
 /* evd_sample_events with the start / end poses evaluated from the track at the events' own timestamps (column ncol-3) inside the
  * same launch, i.e. EventsDataset.sample_events as the reference runs it (loader_events.py:280-283) without a per-event pose table.
  * All other arguments as evd_sample_events. */
-int evd_sample_events_track(const double* events, long N, int ncol, const float* id_to_coords, const unsigned char* id_to_color_map,
+int evd_sample_events_track(const double* events, long N, int ncol, const float* id_to_coords, long n_coords, const unsigned char* id_to_color_map,
                             const evd_pose_track* track, const long long* events_ids, const long long* hops, long n, const float* K,
                             int add_halfpix, float* rays_start, float* rays_end, float* pos_cumsum, float* neg_cumsum, long long* coords_ids,
                             unsigned char* color_map, long long* successor, int* mismatch, void* stream);
+
+/* ---------------------------------------------------------------- once-per-dataset event tables (last clause)
+ * What LLFFEventsDataset.load_event_data (data/loader_events.py:150-257) and load_events_h5 (utils/events.py:11-69) compute on the CPU
+ * from the ARRAYS of events.h5 (reading the file stays with the caller).  Data-dependent sizes are returned in device words; outputs are
+ * sized for the worst case.  Mirror: evdeblurnerf_amd.events.EventTables.from_arrays.
+ *
+ * evd_event_coord_ids -- utils/events.py:39-66 with optimize_ids=True (what load_event_data passes, :186-188): the pixels no event
+ *   rounds to (np.round, clipped; :39-42), then np.unique(return_index, return_inverse) over the float64 rows [event (x, y) ; silent
+ *   pixel (x, y)] viewed as 16 raw bytes (utils/misc.py:143-149 to_flattenvoid): the ids follow the BYTE order of the little-endian pairs.
+ *   x, y dev float32 [N]  ->  ev_coord_ids dev int64 [N], noev_coord_ids dev int64 [h w] (the first counts[1] valid, raster order of the
+ *   silent pixels), id_to_coords dev float64 [N + h w, 2] (the first counts[0] rows valid), counts dev int64 [2] = (Ncoords, Nsilent).
+ * evd_event_filter -- loader_events.py:191 (events with tmin <= t <= tmax, order kept) and :203-206 (if the smallest kept polarity is 0,
+ *   zeros become -1): coord_ids int64 [N], t / p float64 [N] -> events_out dev float64 [N, 3] (id, t, p; the first *count rows valid),
+ *   count dev int64 [1], bad_polarity dev int32 [1] or NULL: set when the kept polarities are not {-1, 1} afterwards (the reference asserts).
+ * evd_event_color_map -- loader_events.py:208-236: id_to_color_map dev uint8 [Ncoords, 3], one-hot r / g / b of the Bayer pattern
+ *   (r g / g b).  inv_mapx == NULL: integer coordinates, the colour of the pixel itself (:215-218).  Else inv_mapx / inv_mapy dev
+ *   float32 [h, w] (ev_map.npz): the colour of the LAST pixel in raster order whose map entry equals the coordinate (:226-230; id_to_coords
+ *   must be the table evd_event_coord_ids wrote -- it is searched in its byte order); unmapped dev int32 [1] or NULL: set when a coordinate
+ *   that is not a silent pixel's (noev_coord_ids [n_noev]) got no colour (the reference asserts, :231-234). */
+size_t evd_event_coord_ids_workspace_bytes(long N, int h, int w);
+int evd_event_coord_ids(const float* x, const float* y, long N, int h, int w, long long* ev_coord_ids, long long* noev_coord_ids, double* id_to_coords,
+                        long long* counts, void* workspace, size_t workspace_bytes, void* stream);
+size_t evd_event_filter_workspace_bytes(long N);
+int evd_event_filter(const long long* coord_ids, const double* t, const double* p, long N, double tmin, double tmax, double* events_out, long long* count,
+                     int* bad_polarity, void* workspace, size_t workspace_bytes, void* stream);
+size_t evd_event_color_map_workspace_bytes(long n_coords);
+int evd_event_color_map(const double* id_to_coords, long n_coords, int h, int w, const float* inv_mapx, const float* inv_mapy, const long long* noev_coord_ids,
+                        long n_noev, unsigned char* id_to_color_map, int* unmapped, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------- image batch assembly (first half)
  * LLFFDataset.__getitem__, data/loader.py:325-356: a batch of flat ray ids in [0, n_img * H * W) -> image id / pixel

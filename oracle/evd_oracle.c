@@ -16,6 +16,99 @@
 #include <omp.h>
 #endif
 
+/* ---------------------------------------------------------------------------------------------------------------------------------------
+ * the once-per-dataset event tables: reference utils/events.py:11-69 (load_events_h5) and data/loader_events.py:186-236 */
+typedef struct { unsigned char b[16]; long idx; } evo_crow;
+static int evo_crow_cmp(const void* pa, const void* pb) {
+    const evo_crow *a = (const evo_crow*)pa, *b = (const evo_crow*)pb;
+    const int c = memcmp(a->b, b->b, 16);                      /* np.unique on a void dtype orders by the raw bytes (utils/misc.py:143-149) */
+    if (c) return c;
+    return a->idx < b->idx ? -1 : (a->idx > b->idx ? 1 : 0);   /* return_index: the first occurrence leads its group */
+}
+
+long evo_event_coord_ids(const float* x, const float* y, long N, int h, int w, long long* ev_ids, long long* noev_ids, double* id_to_coords, long* n_noev) {
+    const long HW = (long)h * w;
+    unsigned char* silent = (unsigned char*)malloc((size_t)HW);
+    memset(silent, 1, (size_t)HW);
+    for (long i = 0; i < N; ++i) {                              /* utils/events.py:39-41: np.round (half to even), int32, clip */
+        long yy = (long)rintf(y[i]), xx = (long)rintf(x[i]);
+        yy = yy < 0 ? 0 : (yy > h - 1 ? h - 1 : yy);
+        xx = xx < 0 ? 0 : (xx > w - 1 ? w - 1 : xx);
+        silent[yy * w + xx] = 0;
+    }
+    long nz = 0;
+    for (long j = 0; j < HW; ++j) nz += silent[j];
+    const long M = N + nz;
+    evo_crow* rows = (evo_crow*)malloc(sizeof(evo_crow) * (size_t)(M > 0 ? M : 1));
+    double* all = (double*)malloc(sizeof(double) * 2 * (size_t)(M > 0 ? M : 1));
+    for (long i = 0; i < N; ++i) { all[2 * i] = (double)x[i]; all[2 * i + 1] = (double)y[i]; }      /* float32 + int64 -> float64 rows (:52) */
+    long k = N;
+    for (long j = 0; j < HW; ++j)                               /* np.where order, [:, ::-1] -> (x, y) (:42) */
+        if (silent[j]) { all[2 * k] = (double)(j % w); all[2 * k + 1] = (double)(j / w); ++k; }
+    for (long i = 0; i < M; ++i) { memcpy(rows[i].b, all + 2 * i, 16); rows[i].idx = i; }
+    qsort(rows, (size_t)M, sizeof(evo_crow), evo_crow_cmp);
+    long uid = -1;
+    for (long q = 0; q < M; ++q) {
+        if (q == 0 || memcmp(rows[q].b, rows[q - 1].b, 16) != 0) {
+            ++uid;
+            id_to_coords[2 * uid] = all[2 * rows[q].idx];
+            id_to_coords[2 * uid + 1] = all[2 * rows[q].idx + 1];
+        }
+        if (rows[q].idx < N) ev_ids[rows[q].idx] = uid; else noev_ids[rows[q].idx - N] = uid;
+    }
+    *n_noev = nz;
+    free(rows); free(all); free(silent);
+    return uid + 1;
+}
+
+long evo_event_filter(const long long* ids, const double* t, const double* p, long N, double tmin, double tmax, double* events_out) {
+    long n = 0;
+    double pmin = 1e300, pmax = -1e300;
+    for (long i = 0; i < N; ++i)
+        if (t[i] >= tmin && t[i] <= tmax) {                     /* loader_events.py:191 */
+            events_out[3 * n] = (double)ids[i]; events_out[3 * n + 1] = t[i]; events_out[3 * n + 2] = p[i];
+            if (p[i] < pmin) pmin = p[i];
+            if (p[i] > pmax) pmax = p[i];
+            ++n;
+        }
+    if (n > 0 && pmin == 0.0) {                                 /* :203-205 */
+        for (long i = 0; i < n; ++i) if (events_out[3 * i + 2] == 0.0) events_out[3 * i + 2] = -1.0;
+        pmin = -1.0;
+    }
+    if (n > 0 && !(pmax == 1.0 && pmin == -1.0)) return -n - 1; /* :206 */
+    return n;
+}
+
+static int evo_bayer(int j, int i) { return (j % 2 == 0) ? (i % 2 == 0 ? 0 : 1) : (i % 2 == 0 ? 1 : 2); }        /* :209-213 r g / g b */
+
+long evo_event_color_map(const double* id_to_coords, long Nc, int h, int w, const float* inv_mapx, const float* inv_mapy, const long long* noev_ids, long n_noev,
+                         unsigned char* cmap) {
+    memset(cmap, 0, (size_t)Nc * 3);
+    if (!inv_mapx) {                                            /* :215-218 */
+        for (long id = 0; id < Nc; ++id) {
+            const long xi = (long)id_to_coords[2 * id], yi = (long)id_to_coords[2 * id + 1];
+            if (xi >= 0 && xi < w && yi >= 0 && yi < h) cmap[3 * id + evo_bayer((int)yi, (int)xi)] = 1;
+        }
+        return 0;
+    }
+    for (int j = 0; j < h; ++j)                                 /* :226-230: the dict lookup by value, later pixels overwrite */
+        for (int i = 0; i < w; ++i) {
+            const double qx = (double)inv_mapx[(long)j * w + i], qy = (double)inv_mapy[(long)j * w + i];
+            for (long id = 0; id < Nc; ++id)
+                if (id_to_coords[2 * id] == qx && id_to_coords[2 * id + 1] == qy) {
+                    cmap[3 * id] = cmap[3 * id + 1] = cmap[3 * id + 2] = 0;
+                    cmap[3 * id + evo_bayer(j, i)] = 1;
+                }
+        }
+    unsigned char* noev = (unsigned char*)calloc((size_t)(Nc > 0 ? Nc : 1), 1);
+    for (long q = 0; q < n_noev; ++q) noev[noev_ids[q]] = 1;
+    long badn = 0;
+    for (long id = 0; id < Nc; ++id)                            /* :231-234 */
+        if (!noev[id] && cmap[3 * id] + cmap[3 * id + 1] + cmap[3 * id + 2] != 1) ++badn;
+    free(noev);
+    return badn;
+}
+
 int evo_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

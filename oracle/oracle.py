@@ -414,6 +414,44 @@ def image_batch(ray_ids, images, poses, K, pts0_images=None):
     return out
 
 
+def event_tables(x, y, t, p, h, w, tmin, tmax, ev_map=None, color_events=True, min_step=0):
+    """The array-level part of LLFFEventsDataset.load_event_data (data/loader_events.py:186-255 with utils/events.py:39-66, 72-120): ->
+    dict(events [N', 4], id_to_coords, noev_coord_ids, id_to_color_map, events_num_successors, events_with_successor_idx, intcoords)"""
+    x, y = _f(x), _f(y)
+    t, p = np.ascontiguousarray(t, dtype=np.float64), np.ascontiguousarray(p, dtype=np.float64)
+    N, HW = x.shape[0], int(h) * int(w)
+    ll = C.POINTER(C.c_longlong)
+    dp = C.POINTER(C.c_double)
+    ev_ids, noev, i2c = np.empty((max(N, 1),), np.int64), np.empty((HW,), np.int64), np.empty((N + HW, 2), np.float64)
+    nn = C.c_long(0)
+    fn = lib().evo_event_coord_ids
+    fn.restype = C.c_long
+    nc = int(fn(_p(x), _p(y), C.c_long(N), int(h), int(w), ev_ids.ctypes.data_as(ll), noev.ctypes.data_as(ll), i2c.ctypes.data_as(dp), C.byref(nn)))
+    i2c, noev = i2c[:nc].copy(), noev[:nn.value].copy()
+    ev3 = np.empty((max(N, 1), 3), np.float64)
+    fn = lib().evo_event_filter
+    fn.restype = C.c_long
+    n = int(fn(ev_ids.ctypes.data_as(ll), t.ctypes.data_as(dp), p.ctypes.data_as(dp), C.c_long(N), C.c_double(tmin), C.c_double(tmax), ev3.ctypes.data_as(dp)))
+    if n < 0:
+        raise ValueError("polarities are not {-1, 1} after the normalisation (loader_events.py:206)")
+    ev3 = ev3[:n]
+    cmap = None
+    if color_events:
+        cmap = np.zeros((max(nc, 1), 3), np.uint8)
+        fn = lib().evo_event_color_map
+        fn.restype = C.c_long
+        mx, my = (None, None) if ev_map is None else (_f(ev_map[0]), _f(ev_map[1]))
+        bad = int(fn(i2c.ctypes.data_as(dp), C.c_long(nc), int(h), int(w), _p(mx) if mx is not None else None, _p(my) if my is not None else None,
+                     noev.ctypes.data_as(ll), C.c_long(noev.shape[0]), cmap.ctypes.data_as(C.POINTER(C.c_ubyte))))
+        if bad:
+            raise ValueError(f"{bad} event coordinates without exactly one colour (loader_events.py:231-234)")
+        cmap = cmap[:nc]
+    succ, nsucc, _, _ = compute_successor(ev3[:, 0].astype(np.int64), max(nc, 1))
+    events = np.concatenate([ev3, np.asarray(succ, dtype=np.float64).reshape(-1, 1)], -1)
+    return {"events": events, "id_to_coords": i2c, "noev_coord_ids": noev, "id_to_color_map": cmap, "events_num_successors": np.asarray(nsucc),
+            "events_with_successor_idx": np.where(np.asarray(nsucc) > min_step)[0], "intcoords": bool(np.all(i2c.astype(np.int32) == i2c))}
+
+
 def rbk_warp(rays, r, v, num_motion, use_origin=True, want_transform=False):
     """blurmodel.py:51-82: rays [R,3,2], r/v [R, 3*M] -> new_rays [R, M(+1), 3, 2] (, transforms [R, M(+1), 4, 4])"""
     rays, r, v = _f(rays), _f(r), _f(v)

@@ -84,9 +84,14 @@ def _step(rank, world):
     return float(loss.detach()), {k: v.grad.detach().cpu().numpy() for k, v in model.named_parameters()}
 
 
-def _worker(rank, world, port, q, backend="gloo", mode="nerf", side_spin_us=0):
+def _worker(rank, world, port, q, backend="gloo", mode="nerf", side_spin_us=0, skip_join=False):
     if side_spin_us:
         os.environ["EVD_TEST_SIDE_SPIN_US"] = str(side_spin_us)          # read once, when the library first forks to a side stream
+        # the PDRF levels' backward forks to the side stream only with this switch (off by default: no gain for the level networks) --
+        # without it the hook never fires in mode='c2f' and the test would prove nothing
+        os.environ["EVD_BWD_OVERLAP_VOXEL"] = "1"
+    if skip_join:
+        os.environ["EVD_TEST_SKIP_SIDE_JOIN"] = "1"                       # negative control: the entry returns without joining its side stream
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     dev = rank if backend == "nccl" else 0            # RCCL: one GPU per rank; gloo: the ranks share GPU 0
@@ -96,19 +101,20 @@ def _worker(rank, world, port, q, backend="gloo", mode="nerf", side_spin_us=0):
     torch.cuda.set_device(dev)
     dist.init_process_group(backend, rank=rank, world_size=world)
     loss, grads = (_step_c2f if mode == "c2f" else _step)(rank, world)
-    q.put((rank, loss, grads))
+    from evdeblurnerf_amd import _lib as L
+    q.put((rank, loss, grads, int(L.lib().evd_debug_side_spin_count())))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _two_ranks(backend, mode, side_spin_us=0):
+def _two_ranks(backend, mode, side_spin_us=0, skip_join=False):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, backend, mode, side_spin_us)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, backend, mode, side_spin_us, skip_join)) for r in range(2)]
     for p in procs:
         p.start()
     got = [q.get(timeout=600) for _ in range(2)]
@@ -117,6 +123,10 @@ def _two_ranks(backend, mode, side_spin_us=0):
         assert p.exitcode == 0
     loss1, grads1 = (_step_c2f if mode == "c2f" else _step)(0, 1)                      # the whole batch in this process
     got.sort(key=lambda t: t[0])
+    if side_spin_us:
+        assert all(g[3] > 0 for g in got), [g[3] for g in got]        # the delay kernels were really launched on the side stream
+    if skip_join:               # negative control: -> the worst relative gradient error (the caller asserts that it is LARGE)
+        return max(float(np.linalg.norm(got[0][2][k] - g1) / (np.linalg.norm(g1) + 1e-12)) for k, g1 in grads1.items())
     assert abs(got[0][1] - got[1][1]) < 1e-7         # every rank holds the same global loss
     assert abs(got[0][1] - loss1) < 2e-6 * max(1.0, abs(loss1))
     worst = 0.0
@@ -141,10 +151,20 @@ def test_two_rank_c2f_step_with_early_allreduce_equals_single_process():
 
 def test_early_allreduce_is_ordered_behind_a_delayed_side_stream():
     """the level's all-reduce is started from inside the backward pass while the backward entry ran its wgrad
-    launches on a per-handle side stream.  Every side-stream launch is delayed by 2 ms here (EVD_TEST_SIDE_SPIN_US, a spin kernel in
-    front of it): the reduced buffers still equal the single-process gradient, i.e. the entry's join of the side stream into the
+    launches on a per-handle side stream (EVD_BWD_OVERLAP_VOXEL=1 for the PDRF levels).  Every side-stream launch is delayed by 2 ms here
+    (EVD_TEST_SIDE_SPIN_US, a spin kernel in front of it; the worker reports evd_debug_side_spin_count() > 0, and the next test is the
+    negative control): the reduced buffers still equal the single-process gradient, i.e. the entry's join of the side stream into the
     caller's stream (hipEventRecord(side) + hipStreamWaitEvent(stream) before it returns) orders the collective behind them."""
     _two_ranks("gloo", "c2f", side_spin_us=2000)
+
+
+def test_delayed_side_stream_without_the_join_gives_wrong_gradients():
+    """The negative control of the test above: the same run with the join disabled (EVD_TEST_SKIP_SIDE_JOIN=1) -- the collective
+    (and the gradient read-back) then race the delayed side-stream launches and the summed gradients are WRONG.  If this test ever passes
+    its `>` the hook no longer exercises the edge and the positive test proves nothing."""
+    worst = _two_ranks("gloo", "c2f", side_spin_us=2000, skip_join=True)
+    print(f"join disabled: worst relative gradient error {worst:.2e}")
+    assert worst > 0.1, worst
 
 
 @pytest.mark.parametrize("spin", [0, 2000])

@@ -163,3 +163,94 @@ def test_sample_events_rejects_ids_outside_the_table():
         assert int(smp._mismatch.item()) == 1
         with pytest.raises(L.EvdError):
             smp.sample_events(T(np.array([1] + bad)), check=True)
+    # a coordinate id (column 0) outside the coordinate tables is rejected like an id outside the event table
+    for bad_pix in (-1.0, 5.0, 1e9):
+        ev2 = ev.copy()
+        ev2[7, 0] = bad_pix
+        smp2 = EventSampler(ev2, coords, poses, W.synthetic_camera(), id_to_color_map=np.eye(3, dtype=bool)[rs.randint(0, 3, 5)])
+        out = smp2.sample_events(T(np.array([1, 7])))
+        assert int(smp2._mismatch.item()) == 1 and int(out["events_coords_ids"][1]) == -1
+        assert float(out["events_rays_start"][1].abs().max()) == 0 and not bool(out["events_color_map"][1].any())
+        assert int(out["events_coords_ids"][0]) == 2 and float(out["events_rays_start"][0].abs().max()) > 0
+
+
+# ------------------------------------------------------------------------------------------------ the once-per-dataset event tables
+def _tables_from_golden(g, tag, **kw):
+    from evdeblurnerf_amd.events import EventTables
+    h, w = (int(v) for v in g[f"{tag}_hw"])
+    acc = [int(v) for v in g[f"{tag}_acc"]]
+    ev_map = (g["flt_inv_mapx"], g["flt_inv_mapy"]) if tag == "flt" else None
+    return EventTables.from_arrays(g[f"{tag}_x"], g[f"{tag}_y"], g[f"{tag}_t"], g[f"{tag}_p"], h, w, g[f"{tag}_key_t"], g[f"{tag}_apb"], img_timestamps=g[f"{tag}_img_t"],
+                                   ev_map=ev_map, color_events=True, events_tms_unit="us", events_tms_files_unit="us", event_accumulate_step_range=acc[:2],
+                                   event_accumulate_step_range_end=acc[2:], recenter=False, **kw)
+
+
+@pytest.mark.parametrize("tag", ["int", "flt"])
+def test_event_tables_match_golden_G34(tag):
+    """EventTables.from_arrays (evd_event_coord_ids / evd_event_filter / evd_event_color_map / evd_compute_successor) against golden G34 =
+    the reference's LLFFEventsDataset.load_event_data run on the same arrays: every table bit for bit; the pose track built from
+    all_poses_bounds reproduces events_pose_bspl (after the LLFF column change interpolate_poses applies, :137) to float32 rounding; and the
+    ready EventSampler draws a batch whose start / end events are the table's."""
+    from test_oracle_golden import check_event_tables
+    g = load_golden("G34_event_tables")
+    tb = _tables_from_golden(g, tag)
+    got = {k: N(getattr(tb, k)) for k in ("events", "id_to_coords", "id_to_color_map", "events_num_successors", "events_with_successor_idx")}
+    got["intcoords"] = tb.intcoords
+    check_event_tables(got, g, tag)
+    assert np.array_equal(tb.allknown_poses, g[f"{tag}_allknown_poses"])
+    if tag == "int":
+        c2i = N(tb.coords_to_id)
+        assert np.array_equal(c2i, g["int_coords_to_id"])
+    raw = g[f"{tag}_pose_bspl"]                                               # [n, 4, 4] float64, the raw interpolator (:175-182)
+    ref = np.concatenate([raw[..., 1:2], -raw[..., 0:1], raw[..., 2:]], -1).astype(np.float32)
+    ip = N(tb.interpolate_poses(g[f"{tag}_tq"]))
+    assert np.abs(ip - ref).max() < 5e-6
+    smp = tb.sampler(W.synthetic_camera())
+    ids = tb.events_with_successor_idx[:32]
+    out = smp.sample_events(ids, check=True) if tag == "int" else smp.sample_events(ids, hops=torch.zeros_like(ids), check=True)
+    ev = g[f"{tag}_events"]
+    assert np.array_equal(N(out["events_coords_ids"]), ev[N(ids), 0].astype(np.int64))
+    assert np.array_equal(N(out["events_color_map"]).astype(np.uint8), g[f"{tag}_id_to_color_map"][ev[N(ids), 0].astype(np.int64)])
+
+
+def test_event_tables_at_size_equal_the_oracle(O):
+    """2 M events on a 260 x 346 sensor (the CDAVIS size), rectified float coordinates with an ev_map, polarities 0 / 1, a tenth of the
+    stream outside the pose range: every table bit-equal to the oracle's array-level restatement of load_event_data."""
+    from evdeblurnerf_amd.events import EventTables
+    rs = np.random.RandomState(77)
+    h, w, n = 260, 346, 2_000_000
+    act = rs.rand(h, w) < 0.9
+    ys, xs = np.where(act)
+    pick = rs.randint(0, ys.shape[0], n)
+    rect = lambda X, Y: ((X + 0.31 * np.sin(0.04 * Y) + 0.25).astype(np.float32), (Y + 0.27 * np.cos(0.03 * X) - 0.125).astype(np.float32))
+    ex, ey = rect(xs[pick].astype(np.float32), ys[pick].astype(np.float32))
+    gx, gy = np.meshgrid(np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32))
+    ev_map = rect(gx, gy)
+    key_t = np.arange(20, dtype=np.float64) * 1e5 + 1e6
+    et = np.sort(rs.randint(int(key_t[0]) - 100_000, int(key_t[-1]) + 100_000, n)).astype(np.int64)
+    ep = rs.randint(0, 2, n)
+    from scipy.spatial.transform import Rotation as Rot
+    Rk = Rot.from_rotvec(np.cumsum(rs.standard_normal((20, 3)) * 0.03, 0)).as_matrix()
+    apb = np.concatenate([np.concatenate([Rk, rs.standard_normal((20, 3, 1)), np.ones((20, 3, 1))], -1).reshape(20, 15), np.ones((20, 2))], -1)
+    tb = EventTables.from_arrays(ex, ey, et, ep, h, w, key_t, apb, ev_map=ev_map, color_events=True, events_tms_unit="us", events_tms_files_unit="us", recenter=False)
+    ref = O.event_tables(ex, ey, et, ep, h, w, float(key_t.min()), float(key_t.max()), ev_map=ev_map, color_events=True)
+    assert np.array_equal(N(tb.events), ref["events"]) and np.array_equal(N(tb.id_to_coords), ref["id_to_coords"])
+    assert np.array_equal(N(tb.noev_coord_ids), ref["noev_coord_ids"]) and np.array_equal(N(tb.id_to_color_map).astype(np.uint8), ref["id_to_color_map"])
+    assert np.array_equal(N(tb.events_num_successors), ref["events_num_successors"]) and np.array_equal(N(tb.events_with_successor_idx), ref["events_with_successor_idx"])
+    assert not tb.intcoords and 0.85 * n < tb.events.shape[0] < 0.95 * n
+
+
+def test_event_tables_flag_what_the_reference_asserts():
+    from evdeblurnerf_amd import _lib as L
+    from evdeblurnerf_amd.events import EventTables
+    g = load_golden("G34_event_tables")
+    bad_p = g["int_p"].copy()
+    bad_p[len(bad_p) // 2] = 3                                # a polarity outside {0, 1} / {-1, 1}, on an event inside the pose range
+    h, w = (int(v) for v in g["int_hw"])
+    with pytest.raises(L.EvdError):
+        EventTables.from_arrays(g["int_x"], g["int_y"], g["int_t"], bad_p, h, w, g["int_key_t"], g["int_apb"], events_tms_unit="us", recenter=False)
+    mx = g["flt_inv_mapx"] + np.float32(0.5)                  # no map entry equals an event coordinate any more
+    h, w = (int(v) for v in g["flt_hw"])
+    with pytest.raises(L.EvdError):
+        EventTables.from_arrays(g["flt_x"], g["flt_y"], g["flt_t"], g["flt_p"], h, w, g["flt_key_t"], g["flt_apb"], ev_map=(mx, g["flt_inv_mapy"]), color_events=True,
+                                events_tms_unit="us", recenter=False)

@@ -752,3 +752,46 @@ def test_G32_train_forward():
     # the projection the gradients were taken of (a second, independent check of the recorded loss)
     loss = sum(float((out[k].astype(np.float64) * g["proj." + k]).sum()) for k in errs_all) + 0.1 * out["tv"]
     assert abs(loss - float(g["loss"])) < 5e-3, (loss, float(g["loss"]))
+
+
+def test_G35_llff_pose_preparation():
+    """G35: LLFFDataset.load_poses + recenter_poses (data/loader.py:178-216, utils/data.py:115-183) -- host numpy in the reference and
+    here (a few dozen 3 x 5 matrices): evdeblurnerf_amd.loader.load_poses / recenter_poses / poses_avg, bit-equal (same numpy calls)."""
+    from evdeblurnerf_amd import loader as LD
+    g = load_golden("G35_llff_poses")
+    for tag in ("a", "b"):
+        factor, bdf, H, Wd = g[f"{tag}_args"]
+        poses, bds, sc = LD.load_poses(g[f"{tag}_poses_bounds"], int(factor), (int(H), int(Wd), 3), bd_factor=None if bdf < 0 else float(bdf))
+        assert poses.dtype == np.float32 and np.array_equal(poses, g[f"{tag}_poses"]) and np.array_equal(bds, g[f"{tag}_bds"]) and float(sc) == float(g[f"{tag}_sc"])
+        rec, c2w = LD.recenter_poses(poses, return_c2w=True)
+        assert maxabs(c2w, g[f"{tag}_c2w"]) < 1e-12 and maxabs(rec, g[f"{tag}_recentered"]) < 1e-6
+        assert maxabs(LD.recenter_poses(poses, c2w=g[f"{tag}_c2w"]), g[f"{tag}_recentered"]) < 1e-6
+
+
+def check_event_tables(got, g, tag):
+    """the tables of load_event_data, bit for bit (integer / index work)"""
+    ev = np.asarray(got["events"], np.float64)
+    assert ev.shape == g[f"{tag}_events"].shape and np.array_equal(ev, g[f"{tag}_events"])
+    assert np.array_equal(np.asarray(got["id_to_coords"], np.float64), g[f"{tag}_id_to_coords"])
+    assert np.array_equal(np.asarray(got["id_to_color_map"]).astype(np.uint8), g[f"{tag}_id_to_color_map"])
+    assert np.array_equal(np.asarray(got["events_num_successors"]).astype(np.int64), g[f"{tag}_num_successors"])
+    assert np.array_equal(np.asarray(got["events_with_successor_idx"]).astype(np.int64), g[f"{tag}_with_successor_idx"])
+    assert bool(got["intcoords"]) == (tag == "int")
+
+
+@pytest.mark.parametrize("tag", ["int", "flt"])
+def test_G34_event_tables(tag):
+    """G34: LLFFEventsDataset.load_event_data run by the generator on arrays (data/loader_events.py:150-257): the oracle's array-level
+    restatement gives the same event table, coordinate ids in np.unique's byte order, Bayer colour map (integer pixels / ev_map inverse
+    maps), successor counts and the start-event list."""
+    g = load_golden("G34_event_tables")
+    h, w = (int(v) for v in g[f"{tag}_hw"])
+    acc = [int(v) for v in g[f"{tag}_acc"]]
+    min_step = max(acc[0], acc[2]) if tuple(acc[:2]) != (0, 0) else 0
+    ev_map = (g["flt_inv_mapx"], g["flt_inv_mapy"]) if tag == "flt" else None
+    got = O.event_tables(g[f"{tag}_x"], g[f"{tag}_y"], g[f"{tag}_t"], g[f"{tag}_p"], h, w, float(g[f"{tag}_key_t"].min()), float(g[f"{tag}_key_t"].max()),
+                         ev_map=ev_map, color_events=True, min_step=min_step)
+    check_event_tables(got, g, tag)
+    if tag == "flt":            # coords_to_id of :201 (a dict for float coordinates): the same (x, y) -> id pairs
+        c2i = g["flt_coords_to_id"]
+        assert np.array_equal(got["id_to_coords"][c2i[:, 2].astype(np.int64)], c2i[:, :2])

@@ -1417,12 +1417,150 @@ def G33_train_trajectory():
          grid_coarse=np.array(gc), grid_fine=np.array(gf), **awp_before, **out)
 
 
+# --------------------------------------------------------------------------- G34 / G35: the once-per-dataset tables of the loaders
+def _patched_numpy_for_reference():
+    """The reference was written for numpy < 1.24 (np.bool, and np.unique's 1-D inverse for an [M, 1] void view): both restored for the
+    duration of a call.  Nothing of the reference's arithmetic is touched."""
+    import contextlib
+
+    @contextlib.contextmanager
+    def ctx():
+        had_bool = hasattr(np, "bool")
+        old_unique = np.unique
+        if not had_bool:
+            np.bool = bool
+
+        def unique(*a, **k):
+            r = old_unique(*a, **k)
+            if k.get("return_inverse") and isinstance(r, tuple):
+                r = tuple(x.reshape(-1) if i == (2 if k.get("return_index") else 1) else x for i, x in enumerate(r))
+            return r
+        np.unique = unique
+        try:
+            yield
+        finally:
+            np.unique = old_unique
+            if not had_bool:
+                del np.bool
+    return ctx()
+
+
+def G34_event_tables():
+    """LLFFEventsDataset.load_event_data (data/loader_events.py:150-257, with utils/events.py:11-69 load_events_h5 and compute_successor)
+    called UNBOUND on an object with the attributes it reads.  The files it opens are replaced by arrays IN THIS GENERATOR ONLY: np.load is
+    dispatched on the file name (timestamps.npz, all_timestamps.npy, all_poses_bounds.npy, ev_map.npz), h5py.File returns the x / y / t / p
+    arrays, os.path.exists answers for ev_map.npz.  Two streams: 'int' -- integer pixel coordinates on a 12 x 16 sensor, polarities 0 / 1
+    (normalised to -1 / 1), events before and after the pose range (filtered), colour events with the Bayer pattern, single-hop successor
+    filter; 'flt' -- rectified float coordinates with the ev_map inverse maps (the id_to_color_map loop of :219-236), multi-hop
+    accumulation range [1, 3] -> [2, 4] (events_with_successor_idx keeps num_successors > 2)."""
+    import types
+    import data.loader_events as LE
+    import utils.events as UE
+    from scipy.spatial.transform import Rotation as Rot
+    rs = np.random.RandomState(3401)
+    out = {}
+    for tag, (h, w, N, M, flt, acc, acc_end) in {"int": (12, 16, 700, 9, False, [0, 0], [0, 0]), "flt": (10, 14, 500, 7, True, [1, 3], [2, 4])}.items():
+        key_t = (np.cumsum(rs.randint(4000, 30000, M)) + 100000).astype(np.int64)          # all_timestamps.npy, microseconds
+        rv = np.cumsum(rs.standard_normal((M, 3)) * 0.04, 0)
+        Rk = Rot.from_rotvec(rv).as_matrix()
+        Tk = np.cumsum(rs.standard_normal((M, 3)) * 0.03, 0)
+        p35 = np.concatenate([Rk, Tk[..., None], np.tile(np.array([h, w, 20.0]).reshape(1, 3, 1), (M, 1, 1))], -1)
+        apb = np.concatenate([p35.reshape(M, 15), rs.uniform(0.5, 4.0, (M, 2))], -1)                 # all_poses_bounds.npy [M, 17]
+        n_img = 3
+        it = np.linspace(key_t[1], key_t[-2], n_img)
+        tms_npz = {"timestamps": it, "timestamps_start": it - 1500.0, "timestamps_end": it + 1500.0}
+        # the stream: most pixels active, a few silent; timestamps partly outside the pose range
+        act = rs.rand(h, w) < 0.85
+        ys, xs = np.where(act)
+        pick = rs.randint(0, ys.shape[0], N)
+        px, py = xs[pick].astype(np.float32), ys[pick].astype(np.float32)
+        if flt:                                       # a smooth rectification of the pixel grid: the coordinates the events carry
+            rect = lambda X, Y: ((X + 0.31 * np.sin(0.4 * Y) + 0.25).astype(np.float32), (Y + 0.27 * np.cos(0.3 * X) - 0.125).astype(np.float32))
+            ex, ey = rect(px, py)
+            gx, gy = np.meshgrid(np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32))
+            inv_mapx, inv_mapy = rect(gx, gy)
+            ev_map = {"inv_mapx": inv_mapx, "inv_mapy": inv_mapy}
+        else:
+            ex, ey, ev_map = px, py, None
+        et = np.sort(rs.randint(key_t[0] - 9000, key_t[-1] + 9000, N)).astype(np.int64)
+        ep = rs.randint(0, 2, N).astype(np.int64)                                                    # 0 / 1 in the file
+
+        def np_load(path, *a, _k=key_t, _apb=apb, _t=tms_npz, _m=ev_map, **kw):
+            name = os.path.basename(path)
+            return {"timestamps.npz": _t, "all_timestamps.npy": _k.copy(), "all_poses_bounds.npy": _apb.copy(), "ev_map.npz": _m}[name]
+        fake = types.SimpleNamespace(events_tms_files_unit="us", events_tms_unit="us", basedir="/nowhere", h=h, w=w, color_events=True,
+                                     event_accumulate_step_range=acc, event_accumulate_step_range_end=acc_end)
+        real_load, real_exists, real_h5 = np.load, os.path.exists, sys.modules["h5py"]
+        try:
+            np.load = np_load
+            os.path.exists = lambda pth, _f=flt: _f if pth.endswith("ev_map.npz") else real_exists(pth)
+            h5 = types.ModuleType("h5py")
+            h5.File = lambda path, mode="r", _d={"x": ex, "y": ey, "t": et, "p": ep}: {k: v.copy() for k, v in _d.items()}
+            sys.modules["h5py"] = UE.h5py = h5
+            import io
+            import contextlib
+            with _patched_numpy_for_reference(), contextlib.redirect_stdout(io.StringIO()):
+                ret = LE.LLFFEventsDataset.load_event_data(fake)
+        finally:
+            np.load, os.path.exists = real_load, real_exists
+            sys.modules["h5py"] = UE.h5py = real_h5
+        assert bool(ret["intcoords"]) == (not flt)
+        c2i = ret["coords_to_id"]
+        if flt:                                      # the dict of :201: keys (x, y) -> id, stored as arrays
+            c2i = np.array([[k[0], k[1], v] for k, v in c2i.items()], dtype=np.float64)
+        out.update({f"{tag}_x": ex, f"{tag}_y": ey, f"{tag}_t": et, f"{tag}_p": ep, f"{tag}_hw": np.array([h, w]), f"{tag}_key_t": key_t, f"{tag}_apb": apb,
+                    f"{tag}_acc": np.array(acc + acc_end), f"{tag}_img_t": it,
+                    f"{tag}_events": np.asarray(ret["events"]).astype(np.float64), f"{tag}_id_to_coords": np.asarray(ret["id_to_coords"]).astype(np.float64),
+                    f"{tag}_id_to_color_map": np.asarray(ret["id_to_color_map"]).astype(np.uint8), f"{tag}_coords_to_id": np.asarray(c2i),
+                    f"{tag}_num_successors": np.asarray(ret["events_num_successors"]).astype(np.int64),
+                    f"{tag}_with_successor_idx": np.asarray(ret["events_with_successor_idx"]).astype(np.int64),
+                    f"{tag}_allknown_poses": np.asarray(ret["allknown_poses"]).astype(np.float64)})
+        if flt:
+            out.update({f"{tag}_inv_mapx": inv_mapx, f"{tag}_inv_mapy": inv_mapy})
+        tq = rs.uniform(key_t[0] - 100, key_t[-1] + 100, 40)
+        ip, _ = ret["events_pose_bspl"](tq)
+        out[f"{tag}_tq"], out[f"{tag}_pose_bspl"] = tq, np.asarray(ip).astype(np.float64)
+        print(f"   {tag}: {np.asarray(ret['events']).shape[0]} of {N} events inside the pose range, {np.asarray(ret['id_to_coords']).shape[0]} coordinate ids, "
+              f"{np.asarray(ret['events_with_successor_idx']).shape[0]} events with enough successors")
+    save64("G34_event_tables", **out)
+
+
+def G35_llff_poses():
+    """LLFFDataset.load_poses (data/loader.py:178-203) + the recentring branch of recenter_spherify_poses (:205-216, utils/data.py:167-183
+    recenter_poses / poses_avg) called UNBOUND, np.load replaced by the array: poses_bounds [N, 17] -> LLFF column change, float32 cast,
+    bd_factor rescale of translations and bounds, recentred poses + the average pose (recenter_partial, what the event loader re-applies)."""
+    import types
+    _stub_voxels()
+    import data.loader as DL
+    from utils.data import recenter_poses
+    from scipy.spatial.transform import Rotation as Rot
+    rs = np.random.RandomState(3501)
+    out = {}
+    for tag, (N, factor, bd_factor) in {"a": (7, 1, 0.75), "b": (4, 2, None)}.items():
+        Rk = Rot.from_rotvec(rs.standard_normal((N, 3)) * 0.2).as_matrix()
+        Tk = rs.standard_normal((N, 3)) * 0.5
+        p35 = np.concatenate([Rk, Tk[..., None], np.tile(np.array([600.0, 800.0, 415.0]).reshape(1, 3, 1), (N, 1, 1))], -1)
+        pb = np.concatenate([p35.reshape(N, 15), rs.uniform(1.5, 9.0, (N, 2))], -1)
+        fake = types.SimpleNamespace(basedir="/nowhere")
+        real_load = np.load
+        try:
+            np.load = lambda path, *a, _pb=pb, **k: _pb.copy()
+            poses, bds, sc = DL.LLFFDataset.load_poses(fake, factor, (600 // factor, 800 // factor, 3), bd_factor=bd_factor)
+        finally:
+            np.load = real_load
+        rec, c2w = recenter_poses(poses, return_c2w=True)
+        out.update({f"{tag}_poses_bounds": pb, f"{tag}_args": np.array([factor, -1.0 if bd_factor is None else bd_factor, 600 // factor, 800 // factor]),
+                    f"{tag}_poses": np.asarray(poses), f"{tag}_bds": np.asarray(bds), f"{tag}_sc": np.array(sc, dtype=np.float64),
+                    f"{tag}_recentered": np.asarray(rec), f"{tag}_c2w": np.asarray(c2w).astype(np.float64)})
+    save64("G35_llff_poses", **out)
+
+
 ALL = [G1_embedder, G2_nerf_mlp, G3_nerf_raw2outputs, G4_voxel_raw2outputs, G5_sample_pdf, G6_rays,
        G7_render_nerf, G8_appfeature, G9_render_c2f, G10_rbk_weighted_sum, G11_crf, G12_egm_loss, G13_edi,
        G14_loss_assembly, G15_awp_feature_integration, G16_rbk_warp, G17_compute_successor, G18_nerf_grads, G19_c2f_grads, G20_loss_grads,
        G21_awp_sample_embed, G22_mam, G23_render_nerf_no_viewdirs, G24_render_other_multires, G25_pbe_composite_feature,
        G26_sample_events, G27_awp_per_ray, G28_image_batch, G29_pose_track, G30_c2f_grads_16k, G31_event_hops, G32_train_forward,
-       G33_train_trajectory]
+       G33_train_trajectory, G34_event_tables, G35_llff_poses]
 
 if __name__ == "__main__":
     want = set(sys.argv[1:])
