@@ -1319,14 +1319,16 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
 #pragma unroll
             for (int v = 0; v < 2; ++v) {
                 f32x4 pv = {0.f, 0.f, 0.f, 0.f}, lv = {0.f, 0.f, 0.f, 0.f};
+                // (round 6: w != 0 ? pv + raw w : pv as pv + legacy(w, raw) -- the same value, a tap outside the grid (w = 0) adds 0 whatever
+                // lies at its clamped address -- one instruction less per element in a kernel bound by the instructions it issues)
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) pv[k] = tp.wp[t] != 0.f ? __fadd_rn(pv[k], __fmul_rn(rawp[q][t][v][k], tp.wp[t])) : pv[k];
+                    for (int k = 0; k < 4; ++k) pv[k] = __fadd_rn(pv[k], vbw_mul_legacy(tp.wp[t], rawp[q][t][v][k]));
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) lv[k] = tp.wl[t] != 0.f ? __fadd_rn(lv[k], __fmul_rn(rawl[q][t][v][k], tp.wl[t])) : lv[k];
+                    for (int k = 0; k < 4; ++k) lv[k] = __fadd_rn(lv[k], vbw_mul_legacy(tp.wl[t], rawl[q][t][v][k]));
                 f32x4 dc, rl, cf, rp;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {

@@ -906,7 +906,7 @@ template <int PREC> static int run_nerf_backward(const BwdPlan& b, hipStream_t s
         WgradFusedParams p;
         p.w.store = b.store; p.w.tiles = b.tiles; p.w.tile_bytes = astore::tile_bytes(PREC); p.w.y_slot = y_slot; p.w.x_slot = x_slot; p.w.bias = bias ? 1 : 0; p.w.partial = b.partial;
         p.wt = b.wt[stream]; p.out_store = b.store; p.mask_slot = -1; p.out_slot = out_slot;
-        if (b.side) {                           // wgrad launches in flight on the side stream use the partial scratch (and read what this one writes next): join
+        if (b.side && !test_skip_side_join()) { // wgrad launches in flight on the side stream use the partial scratch (and read what this one writes next): join
             EVD_HIP(hipEventRecord(b.ev, b.side));
             EVD_HIP(hipStreamWaitEvent(st, b.ev, 0));
         }

@@ -229,7 +229,7 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
         p.w.store = b.store; p.w.tiles = b.tiles; p.w.tile_bytes = VS::tile_bytes(PREC); p.w.y_slot = y_slot; p.w.x_slot = x_slot; p.w.bias = bias ? 1 : 0; p.w.partial = b.partial;
         p.wt = b.wt[stream]; p.out_store = b.store; p.mask_slot = mask_slot; p.out_slot = out_slot; p.y_last_slot = y_last_slot; p.ygen_wt = ygen_wt;
         p.rows = rows; p.rows_stride = b.d_fts_stride; p.rows_tiles = rows_tiles; p.nsamp = b.nsamp; p.maxbits = b.maxbits;
-        if (b.side) {                           // the wgrad launches in flight on the side stream use the partial scratch: join first
+        if (b.side && !test_skip_side_join()) { // the wgrad launches in flight on the side stream use the partial scratch: join first
             EVD_HIP(hipEventRecord(b.ev, b.side));
             EVD_HIP(hipStreamWaitEvent(st, b.ev, 0));
         }
