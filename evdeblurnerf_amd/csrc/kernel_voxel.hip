@@ -473,6 +473,18 @@ __global__ __launch_bounds__(64 * VW_WAVES, OCC) void k_voxel_sample_w(const Gri
             if (c8 >= g.n_comp[0]) { c8 -= g.n_comp[0]; i = 1; if (c8 >= g.n_comp[1]) { c8 -= g.n_comp[1]; i = 2; } }
             comp[q] = i;
             const VsTaps& tp = taps[sl[q] * 3 + i];
+#ifdef EVD_VS_NO_LOADS        // developer ablation (tools/dev/gather_ablation.sh): everything but the grid loads (values made from the tap offsets)
+            if (true) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int v = 0; v < NRAW; ++v) rawp[q][k][v] = f32x4{(float)tp.ip[k], 1.f, 2.f, (float)c8};
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int v = 0; v < NRAW; ++v) rawl[q][k][v] = f32x4{(float)tp.il[k], 1.f, 2.f, (float)c8};
+            } else
+#endif
             if (HALF) {
                 const _Float16* plh = sel3(i, g.plane_h[0], g.plane_h[1], g.plane_h[2]) + c8;
                 const _Float16* lih = sel3(i, g.line_h[0], g.line_h[1], g.line_h[2]) + c8;
@@ -598,6 +610,204 @@ __global__ __launch_bounds__(64 * VW_WAVES, OCC) void k_voxel_sample_w(const Gri
     }
     VS_STAMP(4);
     VS_STAMP(5); VS_STAMP(6); VS_STAMP(7);
+}
+
+typedef float vbw_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float vbw_mul_legacy(float a, float b) {          // a x b with 0 x anything = 0 (v_mul_legacy_f32: VOP3 only, no builtin in this hipcc)
+    float d;
+    asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// ------------------------------------------------------------------------------------------------------------------------------------------------
+// k_voxel_sample_m (round 6): the gather rebuilt around what actually bounds it.  An ablation build of k_voxel_sample_w WITHOUT its grid loads
+// runs at 70.1 us against 74.0 us with them (profiles/r06_gather_ablation.log): the kernel was never bound by the gather -- it issues ~3000
+// vector instructions per wavefront and 16 samples (static count of its ISA: interpolation with compare / select per element, float16 ->
+// float32 conversions, 64-bit tap offsets, the coefficient round trip through LDS for a float32 16 x 16 x 4 GEMM of 48 MFMAs with three LDS
+// reads each, the output transposed through LDS), and at four wavefronts per SIMD that IS its duration.  Here:
+//   * a lane's work item is (sample = lane % 16, 8-channel group = 4 q + lane / 16), q = 0 .. ctot / 32 - 1: exactly the B-operand layout of
+//     v_mfma_f32_16x16x32_f16 (lane holds k = 8 (lane / 16) .. + 7 of column lane % 16) -- the eight coefficients a lane computes ARE its
+//     operand, nothing goes through LDS;
+//   * out^T[f, sample] = sum_k basis[f, k] coef[sample, k] on the float16 matrix core in the split form the float32-grade modes use everywhere
+//     (hi = f16(x), lo = f16(x - hi); A_hi B_hi + A_hi B_lo + A_lo B_hi, float32 accumulate: 2^-21 relative per product): 18 MFMAs of 16 cycles
+//     instead of 48 of 32; the split basis_mat operands are made once per workgroup in LDS (12 KiB), the workgroups are persistent;
+//   * the D layout (feature 4 (lane / 16) + r of sample lane % 16) is four consecutive floats of a sample's output row: stored straight from the
+//     accumulators, no transposition;
+//   * 32-bit tap offsets; HALF: weight x float16 value + sum as ONE v_fma_mix_f32 (no conversion, no separate multiply; the float16 grids are
+//     finite, so a zero weight needs no guard); float32 grids: v_mul_legacy_f32 + add (the guarded sum of rounds 1-5, exactly).
+struct VmTaps { int ip[4], il[2]; float wp[4], wl[2]; };          // 48 bytes: element offsets of channel 0 (clamped) and weights (0 = outside)
+constexpr int VM_WAVES = 4;
+typedef _Float16 vm_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 vm_h2 __attribute__((ext_vector_type(2)));
+typedef float vm_f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void vm_geometry(const GridParams& g, const float (&pt)[3], int i, VmTaps& tp) {       // vs_geometry, 32-bit offsets
+    VsTaps t;
+    vs_geometry(g, pt, i, t);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { tp.ip[k] = (int)t.ip[k]; tp.wp[k] = t.wp[k]; }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { tp.il[k] = (int)t.il[k]; tp.wl[k] = t.wl[k]; }
+}
+
+template <bool HALF, int OCC>
+__global__ __launch_bounds__(64 * VM_WAVES, OCC) void k_voxel_sample_m(const GridParams g, const float* __restrict__ pts, long n,
+                                                                       float* __restrict__ out, int out_stride, int out_col) {
+    __shared__ __attribute__((aligned(16))) vm_h8 a_hi[2 * 3 * 64], a_lo[2 * 3 * 64];        // [feature tile][k step][lane]
+    __shared__ __attribute__((aligned(16))) VmTaps taps_all[VM_WAVES][16 * 3];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c0n = g.n_comp[0], c1n = g.n_comp[1], ctot = c0n + c1n + g.n_comp[2], steps = ctot / 32, F = g.app_dim;
+    // the split A operands: entry (tile, step, lane) = basis[16 tile + lane % 16][32 step + 8 (lane / 16) .. + 7]
+    for (int e = threadIdx.x; e < 2 * 3 * 64; e += 64 * VM_WAVES) {
+        const int l = e & 63, st = (e >> 6) % 3, tl = e / 192, f = 16 * tl + (l & 15), k0 = 32 * st + 8 * (l >> 4);
+        vm_h8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = (f < F && st < steps) ? g.basis[(long)f * ctot + k0 + j] : 0.f;
+            hi[j] = (_Float16)v;
+            lo[j] = (_Float16)(v - (float)hi[j]);
+        }
+        a_hi[e] = hi;
+        a_lo[e] = lo;
+    }
+    __syncthreads();
+    VmTaps* taps = taps_all[wv];
+    const int col = lane & 15, kb = lane >> 4;
+    const long tiles = (n + 15) / 16;
+    for (long tile = (long)blockIdx.x * VM_WAVES + wv; tile < tiles; tile += (long)gridDim.x * VM_WAVES) {
+        const long s0 = tile * 16;
+        VS_STAMP(0);
+        // (measured and dropped: the NEXT tile's points fetched here, one tile ahead -- 57.8 vs 56.7 us: their latency is not what the tile waits for)
+        if (lane < 48) {                              // geometry of this wavefront's (sample, component) pairs, once each
+            const int sl = lane / 3, i = lane % 3;
+            const long s = s0 + sl < n ? s0 + sl : n - 1;
+            const float pt[3] = {pts[s * 3], pts[s * 3 + 1], pts[s * 3 + 2]};
+            VmTaps tp;
+            vm_geometry(g, pt, i, tp);
+            taps[lane] = tp;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        VS_STAMP(1);
+        constexpr int NRAW = HALF ? 1 : 2;
+        f32x4 rawp[3][4][NRAW], rawl[3][2][NRAW];
+        int tix[3];                                   // the item's row of the tap table: the weights are read again when the values have landed
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            if (q < steps) {
+                int c8 = 32 * q + 8 * kb, i = 0;
+                if (c8 >= c0n) { c8 -= c0n; i = 1; if (c8 >= c1n) { c8 -= c1n; i = 2; } }
+                tix[q] = col * 3 + i;
+                struct { int ip[4], il[2]; } tq[3];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) tq[q].ip[k] = taps[tix[q]].ip[k];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) tq[q].il[k] = taps[tix[q]].il[k];
+                if (HALF) {
+                    const _Float16* plh = sel3(i, g.plane_h[0], g.plane_h[1], g.plane_h[2]) + c8;
+                    const _Float16* lih = sel3(i, g.line_h[0], g.line_h[1], g.line_h[2]) + c8;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) rawp[q][k][0] = *reinterpret_cast<const f32x4*>(plh + tq[q].ip[k]);
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) rawl[q][k][0] = *reinterpret_cast<const f32x4*>(lih + tq[q].il[k]);
+                } else {
+                    const float* pl = sel3(i, g.plane[0], g.plane[1], g.plane[2]) + c8;
+                    const float* li = sel3(i, g.line[0], g.line[1], g.line[2]) + c8;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int v = 0; v < NRAW; ++v) rawp[q][k][v] = *reinterpret_cast<const f32x4*>(pl + tq[q].ip[k] + 4 * v);
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+#pragma unroll
+                        for (int v = 0; v < NRAW; ++v) rawl[q][k][v] = *reinterpret_cast<const f32x4*>(li + tq[q].il[k] + 4 * v);
+                }
+            }
+        }
+        VS_STAMP(2);
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            if (q < steps) {
+                float cf[8];
+                struct { float wp[4], wl[2]; } tq[3];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) tq[q].wp[k] = taps[tix[q]].wp[k];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) tq[q].wl[k] = taps[tix[q]].wl[k];
+                if (HALF) {
+                    float pv[8], lv[8];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const vm_h8 h = __builtin_bit_cast(vm_h8, rawp[q][k][0]);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) pv[e] = k == 0 ? (float)h[e] * tq[q].wp[0] : __builtin_fmaf((float)h[e], tq[q].wp[k], pv[e]);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const vm_h8 h = __builtin_bit_cast(vm_h8, rawl[q][k][0]);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) lv[e] = k == 0 ? (float)h[e] * tq[q].wl[0] : __builtin_fmaf((float)h[e], tq[q].wl[k], lv[e]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) cf[e] = pv[e] * lv[e];
+                } else {
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) {
+                        f32x4 pv = {0.f, 0.f, 0.f, 0.f}, lv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) pv[e] = __fadd_rn(pv[e], vbw_mul_legacy(tq[q].wp[k], rawp[q][k][v][e]));
+#pragma unroll
+                        for (int k = 0; k < 2; ++k)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) lv[e] = __fadd_rn(lv[e], vbw_mul_legacy(tq[q].wl[k], rawl[q][k][v][e]));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) cf[4 * v + e] = __fmul_rn(pv[e], lv[e]);
+                    }
+                }
+                vm_h8 bh, bl;
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const vm_h2 h2 = __builtin_convertvector(vm_f2{cf[e], cf[e + 1]}, vm_h2);
+                    const vm_h2 l2 = __builtin_convertvector(vm_f2{cf[e] - (float)h2[0], cf[e + 1] - (float)h2[1]}, vm_h2);
+                    bh[e] = h2[0]; bh[e + 1] = h2[1];
+                    bl[e] = l2[0]; bl[e + 1] = l2[1];
+                }
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl) {
+                    const vm_h8 ah = a_hi[(tl * 3 + q) * 64 + lane], al = a_lo[(tl * 3 + q) * 64 + lane];
+                    acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[tl], 0, 0, 0);
+                    acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[tl], 0, 0, 0);
+                    acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[tl], 0, 0, 0);
+                }
+#ifdef EVD_VM_SERIAL
+                __builtin_amdgcn_sched_barrier(0);        // one item after the other: the next item's values stay in their load registers
+#endif
+            }
+        }
+        VS_STAMP(3);
+        // D: lane (col = sample, kb), register r = feature 16 tl + 4 kb + r: four consecutive floats of the sample's output row
+        if (s0 + col < n) {
+            typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+            float* o = out + (s0 + col) * (long)out_stride + out_col;
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl) {
+                const int f0 = 16 * tl + 4 * kb;
+                f32x4 v = acc[tl];
+                if (g.app_act != EVD_ACT_NONE) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = act(g.app_act, acc[tl][r]);
+                }
+                if (f0 + 3 < F) *reinterpret_cast<f32x4u*>(o + f0) = v;
+                else
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (f0 + r < F) o[f0 + r] = v[r];
+            }
+        }
+        VS_STAMP(4);
+        __builtin_amdgcn_wave_barrier();              // the tap table is rewritten by the next tile
+    }
 }
 
 // Backward of k_voxel_sample (app_act none): d out [n, app_dim] -> gradients of the planes, lines (scatter-add, the transpose of
@@ -1063,12 +1273,6 @@ __device__ __forceinline__ void vbw_geometry(const GridParams& g, const float (&
 //   * weight x row with the legacy multiply (0 x anything = 0): the same sums as the guarded form `w != 0 ? w * r : 0` of rounds 3-5 -- a tap
 //     outside the grid (weight 0) adds nothing even where the row is not finite -- without a compare and a select per step;
 //   * a run whose sum is exactly 0 in a lane adds nothing (x + 0 = x): the flag `any sample live` of rounds 3-5 is that test.
-typedef float vbw_f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float vbw_mul_legacy(float a, float b) {          // a x b with 0 x anything = 0 (v_mul_legacy_f32: VOP3 only, no builtin in this hipcc)
-    float d;
-    asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
 // vbw_walk_pass: one tap per lane group (a 16-channel plane: all four taps in one pass of 64 lanes).
 template <class FW, class FC, class FR>
 __device__ __forceinline__ void vbw_walk_pass(float* __restrict__ gp, int c, bool act, FW fw, FC fc, FR fr) {
@@ -1860,6 +2064,28 @@ int launch_voxel_sample(const GridParams& g, bool half_grids, const float* pts, 
         const size_t lds = vw_basis_bytes(ct) + VW_WAVES * vw_slice_bytes(ct);
         // float32 grids: 174 registers by default = two blocks per CU; compiled for three (168 registers, 5 spilled) -- EVD_VW_F32_OCC=2 selects the former
         static const bool occ2 = []{ const char* e = getenv("EVD_VW_F32_OCC"); return e && e[0] == '2'; }();
+        // round 6: k_voxel_sample_m (coefficients straight into the float16 matrix core's operand layout); EVD_GATHER_FORM=w: rounds 3-5's kernel
+        static const bool form_w = []{ const char* e = getenv("EVD_GATHER_FORM"); return e && e[0] == 'w'; }();
+        long pmax_h = 0;
+        for (int i = 0; i < 3; ++i) {
+            const long pe = (long)g.grid[i == 2 ? 1 : 0] * g.grid[i == 0 ? 1 : 2] * g.n_comp[i];
+            pmax_h = pe > pmax_h ? pe : pmax_h;
+        }
+        // float16 grids only: on float32 grids (the float32-grade levels) the new form measures equal (67.1 vs 67.0 us) and the old kernel's
+        // float32 matrix product is exact -- it stays
+        if (half_grids && !form_w && ct % 32 == 0 && ct <= 96 && pmax_h < (1L << 31)) {
+            int cus = 256;
+            { int dev = 0, v = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
+            const long tiles = cdiv(n, 16L * VM_WAVES), cap = 8L * cus;
+            const unsigned mb = (unsigned)(tiles < cap ? tiles : cap);
+#ifndef EVD_VM_OCC
+#define EVD_VM_OCC 3
+#endif
+            // (three wavefronts per SIMD, 164 registers, no spills; compiled for four -- 128 registers, 34 spilled -- it runs 70 instead of 57 us)
+            k_voxel_sample_m<true, EVD_VM_OCC><<<mb, 64 * VM_WAVES, 0, st>>>(g, pts, n, out, out_stride, out_col);
+            EVD_LAUNCH_CHECK();
+            return EVD_OK;
+        }
         if (half_grids) k_voxel_sample_w<true, 4><<<blocks, 64 * VW_WAVES, lds, st>>>(g, pts, n, out, out_stride, out_col);
         else if (occ2) k_voxel_sample_w<false, 2><<<blocks, 64 * VW_WAVES, lds, st>>>(g, pts, n, out, out_stride, out_col);
         else k_voxel_sample_w<false, 3><<<blocks, 64 * VW_WAVES, lds, st>>>(g, pts, n, out, out_stride, out_col);
