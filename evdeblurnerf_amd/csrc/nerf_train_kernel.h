@@ -636,10 +636,226 @@ __global__ __launch_bounds__(WGRAD_NT) void k_wgrad_dgrad(const WgradFusedParams
     if (bias_own) put(CT, accb);
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_wgrad_dgrad_p (round 6): the same launch for a layer WITHOUT a bias gradient (the PDRF levels of every shipped config:
+// rgb_add_bias off, sigma_net has none), software-pipelined by one tile with ONE barrier per tile.
+// The stamps of k_wgrad_dgrad (profiles/r05_wgrad_dgrad_stamps.log) show a tile as: [transposes, exchange write: 19-27 %] barrier [products:
+// MFMA-bound] [dgrad: MFMA-bound] barrier -- all eight wavefronts in the same phase at the same time, so the two wavefronts of a SIMD fight
+// for the matrix pipe in the product phases and leave it idle in the others (the pipe is busy 28-39 %).  Here
+//   * the transposed activation blocks are double-buffered and the DMA for tile t + 2 is issued BEHIND the tile's barrier: the barrier at the
+//     top of tile t proves that every wavefront has left tile t - 1, which is what both the ring slot and the exchange buffer wait for -- the
+//     second barrier is gone;
+//   * phase A of tile t + 1 (gradient forming, both transposes, exchange write) runs INSIDE tile t, and the two halves of the workgroup take
+//     it at different places: wavefronts 0-3 (one per SIMD) run products -> A -> dgrad, wavefronts 4-7 A -> products -> dgrad, so that a
+//     SIMD's two wavefronts are in complementary phases (matrix pipe beside LDS / VALU work);
+//   * no bias accumulator: its 16 registers hold two more W^T fragments (4 instead of 6 per wavefront in LDS: 32 KiB) and the second set of
+//     transposed gradient fragments; LDS = 96 (ring) + 32 (exchange, CT = 8) + 32 = 160 KiB.
+constexpr int FUSED_WL_P = 4;
+template <int PREC, int CT, int TO, int OMASK, int RT_ = 8, int KD_ = 16, bool YGEN = false, bool ROWS = false>
+__global__ __launch_bounds__(WGRAD_NT) void k_wgrad_dgrad_p(const WgradFusedParams fp) {
+    static_assert(!YGEN || (RT_ == 8 && KD_ == 16), "a formed gradient has all 8 row tiles");
+    static_assert(is_half_prec(PREC) && CT <= 8 && TO <= 8 && (OMASK == 0 || TO <= CT), "half-precision fragments, 8 x 32 gradient rows; a masked d X tile is a column tile of X");
+    static_assert(RT_ <= 8 && KD_ <= 2 * RT_ && KD_ > 2 * (RT_ - 1), "k-steps of the dgrad = the gradient fragments of the RT_ row tiles");
+    constexpr int RT = 8, CPG = wgrad_cpg(RT, CT), KD = KD_, WL = KD_ > FUSED_WL_P + 2 ? FUSED_WL_P : 0;
+    typedef POps<PREC> O;
+    const WgradParams& p = fp.w;
+    extern __shared__ __attribute__((aligned(16))) char wsm[];
+    char* raw = wsm;                                          // [WG_RING][8 wavefronts][4 fragments][1 KiB]
+    char* xs = wsm + WG_RING * 8 * 4 * 1024;                  // [2][CT][2][1 KiB] transposed activation blocks, double-buffered
+    char* wl = xs + 2 * CT * 2048;                            // [8 wavefronts][WL][1 KiB]
+    pipe_fp16_saturate<PREC>();
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = lane & 31, h = lane >> 5;
+    const int rt = wave, xw = wave;
+    const bool xown = xw < CT, yown = wave < RT_, down = wave < TO;
+    const unsigned one = half_one_pair<PREC>();
+    f32x16 acc[CPG];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int c = 0; c < CPG; ++c) acc[c][i] = 0.f;
+    W4 wt[KD - WL];
+#pragma unroll
+    for (int j = 0; j < KD; ++j) {
+        const W4 f = *reinterpret_cast<const W4*>(fp.wt + ((long)(down ? wave : 0) * KD + j) * 1024 + lane * 16);
+        if (j < KD - WL) wt[j] = f;
+        else *reinterpret_cast<W4*>(wl + (wave * WL + (j - (KD - WL))) * 1024 + lane * 16) = f;
+    }
+    const int ys = (YGEN || !yown) ? p.y_slot : (RT_ < 8 && rt == RT_ - 1 && fp.y_last_slot >= 0) ? fp.y_last_slot : p.y_slot + 2 * rt;
+    const long oy = (long)ys * 1024 + lane * 16;
+    const long ox = (xown ? (long)(p.x_slot + 2 * xw) * 1024 : (long)ys * 1024) + lane * 16 - 2048;
+    const unsigned ring0 = lds_offset_of(raw) + wave * 4096;
+    auto issue = [&](long t, int stage) {
+        if (t >= p.tiles) return;
+        const char* g = p.store + t * p.tile_bytes;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(ring0 + stage * (8 * 4096));
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                     "global_load_lds_dwordx4 %2, off offset:2048\n\tglobal_load_lds_dwordx4 %2, off offset:3072\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(g + oy), "v"(g + ox), "s"(dst) : "memory");
+    };
+    W4 w2 = {{0u, 0u, 0u, 0u}};
+    if constexpr (YGEN) w2 = *reinterpret_cast<const W4*>(fp.ygen_wt + (long)wave * 1024 + lane * 16);
+    const long stride = gridDim.x;
+    long t = blockIdx.x;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (YGEN) asm volatile("" : "+v"(w2.w[0]), "+v"(w2.w[1]), "+v"(w2.w[2]), "+v"(w2.w[3]));
+#pragma unroll
+    for (int j = 0; j < KD - WL; ++j) asm volatile("" : "+v"(wt[j].w[0]), "+v"(wt[j].w[1]), "+v"(wt[j].w[2]), "+v"(wt[j].w[3]));
+
+    // phase A of the tile in ring slot `slot`, exchange buffer `buf`: this wavefront's gradient pair (formed, if YGEN) transposed into yt_out,
+    // its activation pair transposed into the exchange buffer
+    auto phase_a = [&](int slot, int buf, W4 (&yt_out)[2]) {
+        W4 sel0, sel1;
+        {
+            int nn = n, hh = h;
+            asm volatile("" : "+v"(nn), "+v"(hh));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int kk = 8 * hh + 2 * e;
+                sel0.w[e] = (nn == kk ? (one & 0xffffu) : 0u) | (nn == kk + 1 ? (one & 0xffff0000u) : 0u);
+                sel1.w[e] = (nn == 16 + kk ? (one & 0xffffu) : 0u) | (nn == 17 + kk ? (one & 0xffff0000u) : 0u);
+            }
+        }
+        char* rw = raw + (slot * 8 + wave) * 4096 + lane * 16;
+        W4 y0 = *reinterpret_cast<const W4*>(rw), y1 = *reinterpret_cast<const W4*>(rw + 1024);
+        if constexpr (YGEN) {
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const f32x16 d = mfma_half<PREC>(w2, y0, zero);
+            const unsigned mw = *reinterpret_cast<const unsigned*>(rw + 1024 + 4 * (wave >> 1)) >> (16 * (wave & 1));
+            typename O::B g2[2];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) O::template set_pair<false>(g2[k >> 2], k & 3, d[2 * k], d[2 * k + 1]);
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned two = (mw >> (8 * f + 2 * e)) & 3u;
+                    g2[f].w[e] &= ((0u - (two & 1u)) & 0xffffu) | ((0u - (two >> 1)) & 0xffff0000u);
+                }
+            y0 = __builtin_bit_cast(W4, g2[0]);
+            y1 = __builtin_bit_cast(W4, g2[1]);
+            *reinterpret_cast<W4*>(rw) = y0;                 // where the dgrad of all eight wavefronts reads G (behind the next barrier)
+            *reinterpret_cast<W4*>(rw + 1024) = y1;
+        }
+        if (KD_ == 2 * RT_ - 1 && rt == RT_ - 1) y1 = W4{{0u, 0u, 0u, 0u}};
+        if (RT_ == 8 || yown) transpose_block<PREC>(y0, y1, sel0, sel1, yt_out);
+        if (xown) {
+            const W4 x0 = *reinterpret_cast<const W4*>(rw + 2048), x1 = *reinterpret_cast<const W4*>(rw + 3072);
+            W4 xt[2];
+            transpose_block<PREC>(x0, x1, sel0, sel1, xt);
+            char* xb = xs + buf * (CT * 2048);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) *reinterpret_cast<W4*>(xb + (xw * 2 + q) * 1024 + lane * 16) = xt[q];
+        }
+    };
+    auto products = [&](int buf, const W4 (&yt)[2]) {
+        const char* xb = xs + buf * (CT * 2048);
+#pragma unroll
+        for (int c = 0; c < CPG; ++c) {
+            if (c < CT && (RT_ == 8 || yown)) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const W4 xq = *reinterpret_cast<const W4*>(xb + (c * 2 + q) * 1024 + lane * 16);
+                    acc[c] = mfma_half<PREC>(yt[q], xq, acc[c]);
+                }
+            }
+        }
+    };
+    auto dgrad = [&](int slot, long tt) {
+        if (!down) return;
+        f32x16 d = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const char* gb = raw + (slot * 8) * 4096 + lane * 16;
+        const char* rw = raw + (slot * 8 + wave) * 4096 + lane * 16;
+#pragma unroll
+        for (int j = 0; j < KD; ++j) {
+            const W4 gj = *reinterpret_cast<const W4*>(gb + (j >> 1) * 4096 + (j & 1) * 1024);
+            const W4 wj = j < KD - WL ? wt[j] : *reinterpret_cast<const W4*>(wl + (wave * WL + (j - (KD - WL))) * 1024 + lane * 16);
+            d = mfma_half<PREC>(wj, gj, d);
+        }
+        typename O::B o2[2];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) O::template set_pair<false>(o2[k >> 2], k & 3, d[2 * k], d[2 * k + 1]);
+        char* dst = fp.out_store + tt * p.tile_bytes + (long)(fp.out_slot + 2 * wave) * 1024 + lane * 16;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            if (OMASK != 0) {
+                const typename O::B xa = __builtin_bit_cast(typename O::B, *reinterpret_cast<const W4*>(rw + 2048 + f * 1024));
+                O::mask_act(o2[f], xa);
+            }
+            if (!(ROWS && wave < fp.rows_tiles)) *reinterpret_cast<f32x4*>(dst + f * 1024) = __builtin_bit_cast(f32x4, o2[f]);
+        }
+        if (ROWS && wave < fp.rows_tiles) {
+            const long smp = tt * 32 + n;
+            if (smp < fp.nsamp)
+                frag_pair_to_row<PREC>(__builtin_bit_cast(W4, o2[0]), __builtin_bit_cast(W4, o2[1]), fp.rows + smp * fp.rows_stride + 32 * wave, h,
+                                       grad_scale(*fp.maxbits, true));
+        }
+    };
+
+    // prologue: tiles 0 and 1 in flight, phase A of tile 0
+    issue(t, 0);
+    issue(t + stride, 1);
+    W4 yt[2] = {{{0u, 0u, 0u, 0u}}, {{0u, 0u, 0u, 0u}}};
+    if (t < p.tiles) {
+        if (t + stride < p.tiles) wait_vmcnt<4>(); else wait_vmcnt<0>();
+        phase_a(0, 0, yt);
+    }
+    for (int it = 0; t < p.tiles; t += stride, ++it) {
+        __syncthreads();                // exchange buffer it & 1 and (YGEN) the formed gradient of tile `it` are complete; every wavefront has left tile it - 1
+        issue(t + 2 * stride, (it + 2) % WG_RING);
+        const bool has_next = t + stride < p.tiles;
+        const int slot = it % WG_RING, nslot = (it + 1) % WG_RING, buf = it & 1;
+        W4 ytn[2] = {{{0u, 0u, 0u, 0u}}, {{0u, 0u, 0u, 0u}}};
+        // the DMA of tile it + 1 has landed when at most the four pieces of tile it + 2 (issued above) are outstanding; the stores of tile
+        // it - 1 are older than those and complete with it
+        // (each phase's code exists ONCE, in a two-trip loop whose trips a wavefront takes in its own order: with the two orders written out
+        // hipcc spilled 130-150 registers beside the 128 accumulators + 48 registers of W^T)
+#pragma unroll 1
+        for (int ph = 0; ph < 2; ++ph) {
+            const bool do_products = (wave < 4) == (ph == 0);
+            if (do_products) {
+                products(buf, yt);
+            } else if (has_next) {
+                if (t + 2 * stride < p.tiles) wait_vmcnt<4>(); else wait_vmcnt<0>();
+                phase_a(nslot, buf ^ 1, ytn);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        dgrad(slot, t);
+        __builtin_amdgcn_sched_barrier(0);
+        yt[0] = ytn[0];
+        yt[1] = ytn[1];
+    }
+    if (RT_ < 8 && !yown) return;
+    float* out = p.partial + (((long)blockIdx.x * RT + rt) * CT) * 1024 + lane * 16;
+#pragma unroll
+    for (int c = 0; c < CPG; ++c)
+        if (c < CT) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = {acc[c][4 * q], acc[c][4 * q + 1], acc[c][4 * q + 2], acc[c][4 * q + 3]};
+                *reinterpret_cast<f32x4*>(out + c * 1024 + 4 * q) = v;
+            }
+        }
+}
+
 template <int PREC, int CT, int TO, int OMASK, int RT_ = 8, int KD_ = 16, bool YGEN = false, bool ROWS = false>
 static int launch_wgrad_dgrad(const WgradFusedParams& p, int blocks, hipStream_t st) {
-    const size_t lds = (size_t)WG_RING * 8 * 4 * 1024 + (size_t)CT * 2048 + (size_t)8 * FUSED_WL * 1024;
     if (ROWS != (p.rows != nullptr)) return fail(EVD_E_INVALID, "k_wgrad_dgrad: the row output goes with the ROWS instantiation");
+    // a layer without a bias gradient: the pipelined one-barrier form (EVD_BWD_PIPE=0: the two-barrier kernel for every layer)
+    static const bool pipe_on = [] { const char* e = getenv("EVD_BWD_PIPE"); return !(e && e[0] == '0'); }();
+    if (pipe_on && !p.w.bias && CT <= 5) {
+        const size_t ldsp = (size_t)WG_RING * 8 * 4 * 1024 + (size_t)2 * CT * 2048 + (size_t)8 * FUSED_WL_P * 1024;
+        if constexpr (CT <= 5) {
+            EVD_SET_MAX_LDS((&k_wgrad_dgrad_p<PREC, CT, TO, OMASK, RT_, KD_, YGEN, ROWS>), ldsp);
+            hipLaunchKernelGGL((k_wgrad_dgrad_p<PREC, CT, TO, OMASK, RT_, KD_, YGEN, ROWS>), dim3(blocks), dim3(WGRAD_NT), ldsp, st, p);
+            EVD_LAUNCH_CHECK();
+            return EVD_OK;
+        }
+    }
+    const size_t lds = (size_t)WG_RING * 8 * 4 * 1024 + (size_t)CT * 2048 + (size_t)8 * FUSED_WL * 1024;
     EVD_SET_MAX_LDS((&k_wgrad_dgrad<PREC, CT, TO, OMASK, RT_, KD_, YGEN, ROWS>), lds);
     hipLaunchKernelGGL((k_wgrad_dgrad<PREC, CT, TO, OMASK, RT_, KD_, YGEN, ROWS>), dim3(blocks), dim3(WGRAD_NT), lds, st, p);
     EVD_LAUNCH_CHECK();

@@ -247,7 +247,7 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
     const VoxBwdGrads& g = b.grads;
     // (each wgrad is issued before the dgrad layer that reads the same arrays: independent, concurrent on the side stream)
     // color_net.2 (+ sigmoid, folded into the gradient fragment)
-    if ((rc = wgrad(launch_wgrad<PREC, 1, T, true>, 1, T, true, VS::G_COL, VS::C1, VMAP_COL, VMAP_HID, g.color_w[2], HD, g.color_b[2]))) return rc;
+    if ((rc = wgrad(launch_wgrad<PREC, 1, T, true>, 1, T, g.color_b[2] != nullptr, VS::G_COL, VS::C1, VMAP_COL, VMAP_HID, g.color_w[2], HD, g.color_b[2]))) return rc;
     // color_net.1; in the fused form d c1 = (W2^T d colour) . [c1 > 0] is formed inside the launch from the pair [G_COL | M_C1]
     // (k_wgrad_dgrad YGEN: color_net.2's dgrad launch and the D_C1 round trip are gone; EVD_BWD_YGEN=0: the separate launch)
     static const bool ygen_on = [] { const char* e = getenv("EVD_BWD_YGEN"); return !(e && e[0] == '0'); }();
@@ -256,16 +256,16 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
     if (!ygen && (rc = launch_dgrad<PREC, 1, T, 1, false, 2>(dgrad(VBWD_C2, VS::G_COL, -1, VS::M_C1, VS::D_C1), b.tiles, st))) return rc;
     if constexpr (FUSABLE) {
         if (ygen) {
-            if ((rc = fused(launch_wgrad_dgrad<PREC, 8, 8, 1, 8, 16, true>, 8, true, VS::G_COL, VS::C1 - KS, VMAP_HID, VMAP_HID, g.color_w[1], HD, g.color_b[1], VBWD_C1, VS::M_C0,
+            if ((rc = fused(launch_wgrad_dgrad<PREC, 8, 8, 1, 8, 16, true>, 8, g.color_b[1] != nullptr, VS::G_COL, VS::C1 - KS, VMAP_HID, VMAP_HID, g.color_w[1], HD, g.color_b[1], VBWD_C1, VS::M_C0,
                             VS::D_C0, 8, -1, b.wt[VBWD_C2]))) return rc;
         } else if (fuse_on && g.color_w[1]) {
-            if ((rc = fused(launch_wgrad_dgrad<PREC, 8, 8, 1>, 8, true, VS::D_C1, VS::C1 - KS, VMAP_HID, VMAP_HID, g.color_w[1], HD, g.color_b[1], VBWD_C1, VS::M_C0, VS::D_C0))) return rc;
+            if ((rc = fused(launch_wgrad_dgrad<PREC, 8, 8, 1>, 8, g.color_b[1] != nullptr, VS::D_C1, VS::C1 - KS, VMAP_HID, VMAP_HID, g.color_w[1], HD, g.color_b[1], VBWD_C1, VS::M_C0, VS::D_C0))) return rc;
         } else {
-            if ((rc = wgrad(launch_wgrad<PREC, T, T, false>, T, T, true, VS::D_C1, VS::C1 - KS, VMAP_HID, VMAP_HID, g.color_w[1], HD, g.color_b[1]))) return rc;
+            if ((rc = wgrad(launch_wgrad<PREC, T, T, false>, T, T, g.color_b[1] != nullptr, VS::D_C1, VS::C1 - KS, VMAP_HID, VMAP_HID, g.color_w[1], HD, g.color_b[1]))) return rc;
             if ((rc = launch_dgrad<PREC, KS, T, KS, false, 2>(dgrad(VBWD_C1, VS::D_C1, -1, VS::M_C0, VS::D_C0), b.tiles, st))) return rc;
         }
     } else {
-        if ((rc = wgrad(launch_wgrad<PREC, T, T, false>, T, T, true, VS::D_C1, VS::C1 - KS, VMAP_HID, VMAP_HID, g.color_w[1], HD, g.color_b[1]))) return rc;
+        if ((rc = wgrad(launch_wgrad<PREC, T, T, false>, T, T, g.color_b[1] != nullptr, VS::D_C1, VS::C1 - KS, VMAP_HID, VMAP_HID, g.color_w[1], HD, g.color_b[1]))) return rc;
         if ((rc = launch_dgrad<PREC, KS, T, KS, false, 2>(dgrad(VBWD_C1, VS::D_C1, -1, VS::M_C0, VS::D_C0), b.tiles, st))) return rc;
     }
     // color_net.0 on cat([geo, PE(dirs)])
@@ -273,7 +273,7 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
     if constexpr (FUSABLE && G == 32 * GT) {
         if (fuse_on && g.color_w[0]) {     // wgrad + dgrad of color_net.0 in one launch: d c0 read once; writes d geo | d PE(dirs) (no ReLU on geo)
             static_assert(VS::D_DIRPE == VS::D_GEO + 2 * GT, "d PE(dirs) behind d geo");
-            if ((rc = fused(launch_wgrad_dgrad<PREC, GT + 1, GT + 1, 0>, GT + 1, true, VS::D_C0, VS::GEO, VMAP_HID, VMAP_GEO_X, g.color_w[0], G + ICV, g.color_b[0], VBWD_C0, -1, VS::D_GEO))) return rc;
+            if ((rc = fused(launch_wgrad_dgrad<PREC, GT + 1, GT + 1, 0>, GT + 1, g.color_b[0] != nullptr, VS::D_C0, VS::GEO, VMAP_HID, VMAP_GEO_X, g.color_w[0], G + ICV, g.color_b[0], VBWD_C0, -1, VS::D_GEO))) return rc;
             c0_fused = true;
         }
     }
@@ -281,9 +281,9 @@ template <int PREC, int HD, int G, int FT> static int run_voxel_backward(const V
     } else if constexpr (is_half_prec(PREC) && G == 32 * GT) {
         // geo and direction-encoding columns in ONE launch (adjacent fragments, adjacent index maps): d c0 is read once
         static_assert(VS::DIRPE == VS::GEO + 2 * GT && VMAP_DIR == VMAP_GEO_X + 128 && (G == 128), "adjacent fragments and column maps");
-        if ((rc = wgrad(launch_wgrad<PREC, T, GT + 1, false>, T, GT + 1, true, VS::D_C0, VS::GEO, VMAP_HID, VMAP_GEO_X, g.color_w[0], G + ICV, g.color_b[0]))) return rc;
+        if ((rc = wgrad(launch_wgrad<PREC, T, GT + 1, false>, T, GT + 1, g.color_b[0] != nullptr, VS::D_C0, VS::GEO, VMAP_HID, VMAP_GEO_X, g.color_w[0], G + ICV, g.color_b[0]))) return rc;
     } else {
-        if ((rc = wgrad(launch_wgrad<PREC, T, GT, false>, T, GT, true, VS::D_C0, VS::GEO, VMAP_HID, VMAP_GEO_X, g.color_w[0], G + ICV, g.color_b[0]))) return rc;
+        if ((rc = wgrad(launch_wgrad<PREC, T, GT, false>, T, GT, g.color_b[0] != nullptr, VS::D_C0, VS::GEO, VMAP_HID, VMAP_GEO_X, g.color_w[0], G + ICV, g.color_b[0]))) return rc;
         if ((rc = wgrad(launch_wgrad<PREC, T, 1, false>, T, 1, false, VS::D_C0, VS::DIRPE, VMAP_HID, VMAP_DIR, g.color_w[0], G + ICV, nullptr))) return rc;
     }
     if (!c0_fused && (rc = launch_dgrad<PREC, KS, GT + 1, KS, false, 0>(dgrad(VBWD_C0, VS::D_C0, -1, -1, VS::D_GEO), b.tiles, st))) return rc;   // d geo | d PE(dirs)

@@ -204,6 +204,7 @@ class VoxelNeRFBase:
         self.training = False
         g = lambda k: _np32(state_dict[prefix + k]) if (prefix + k) in state_dict else None
         fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
+        self.has_color_bias = (prefix + "color_net.0.bias") in state_dict          # voxnerf.py:80 add_bias_color (off in every shipped config)
         keep = []
         d = L.VoxelDesc()
         d.num_layers, d.hidden_dim, d.geo_feat_dim, d.num_layers_color = num_layers, hidden_dim, geo_feat_dim, num_layers_color
@@ -357,6 +358,8 @@ class VoxelNeRFBase:
         gs.accumulate = int(accumulate_into is not None)
         for key, shape, off in blocks:
             name, idx, kind = key.split(".")
+            if kind == "bias" and not self.has_color_bias:
+                continue            # rgb_add_bias off: the reference model has no such parameter -- a NULL gradient pointer lets the library skip the bias column
             arr = getattr(gs, ("sigma_" if name == "sigma_net" else "color_") + ("w" if kind == "weight" else "b"))
             arr[int(idx)] = base + 4 * off
         d_fts = torch.empty((R * S, self.ft_dim), dtype=torch.float32, device=g.device) if want_fts else None      # every column is written (k_frags_to_rows)
