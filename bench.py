@@ -396,7 +396,16 @@ def awp_leg(precision):
         raw, geo.token = net.mlp_train(flat, pts, vd, fts, want_feature=geo)
         ((raw * graw).sum() + (feature_integration(emb(eflat, geo).reshape(R, 1, S, 64), z, rd).reshape(R, 64) * gh).sum()).backward()
 
-    t0, t1, t2 = kernel_ms(level_only, 5), (kernel_ms(torch_path, 5) if rows_ok else None), kernel_ms(fused_path, 5)
+    # (medians of per-step HIP-event times after a warm-up, the allocator's cache dropped first: behind the c2f leg's allocations the first
+    # fused steps can run into the caching allocator re-growing 5 GB of stores -- a mean over five steps once reported 24 ms for a 4.2 ms path)
+    import statistics
+    torch.cuda.empty_cache()
+
+    def med(fn):
+        for _ in range(3):
+            fn()
+        return statistics.median(per_step_ms(fn, 7))
+    t0, t1, t2 = med(level_only), (med(torch_path) if rows_ok else None), med(fused_path)
     geo = GeoFragments()
     with torch.no_grad():
         _, geo.token = net.mlp_train(flat.detach().requires_grad_(True), pts, vd, fts, want_feature=geo)
