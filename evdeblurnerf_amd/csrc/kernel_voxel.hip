@@ -613,6 +613,15 @@ __global__ __launch_bounds__(64 * VW_WAVES, OCC) void k_voxel_sample_w(const Gri
 }
 
 typedef float vbw_f32x2 __attribute__((ext_vector_type(2)));
+// Power of two that brings a magnitude m into [2^13, 2^14) (float16's largest binades, so that hi / lo splits of values up to m keep
+// 2^-22 of m), and its inverse; m = 0, denormal or tiny: the scale of 2^-113; non-finite m passes through (the scaled values are then
+// non-finite as well and so is the product, as in float32).
+__device__ __forceinline__ float vbw_pow2_scale(float m, float* inv) {
+    int E = (int)((__float_as_uint(m) >> 23) & 0xffu);
+    E = E < 14 ? 14 : E;
+    *inv = __uint_as_float((unsigned)(E - 13) << 23);
+    return __uint_as_float((unsigned)(267 - E) << 23);
+}
 __device__ __forceinline__ float vbw_mul_legacy(float a, float b) {          // a x b with 0 x anything = 0 (v_mul_legacy_f32: VOP3 only, no builtin in this hipcc)
     float d;
     asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
@@ -1358,10 +1367,38 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
     volatile int* flags = reinterpret_cast<volatile int*>(hand0 + (size_t)VBI_CW * VBI_HAND);
     if (ISS && threadIdx.x < 16) flags[threadIdx.x] = 0;
     const int ng = ctot / 8;
-    for (int o = threadIdx.x; o < 32 * (ctot / 4); o += 64 * VBW_WAVES) {            // basis_mat -> LDS (the block's only shared state)
-        const int f = o / (ctot / 4), c4 = (o % (ctot / 4)) * 4;
-        const f32x4 v = f < F ? *reinterpret_cast<const f32x4*>(g.basis + (long)f * ctot + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(bs + f * VBW_BSTR + c4) = v;
+    // basis_mat -> LDS (the block's only shared state) as the A operands of phase 1 (round 6): d coef^T = basis^T . d out^T on
+    // v_mfma_f32_16x16x32_f16 in the split form (hi = f16(x), lo = f16(x - hi): A_hi B_hi + A_hi B_lo + A_lo B_hi, 2^-21 per product) --
+    // 18 MFMAs of 16 cycles per tile instead of 48 float32 16 x 16 x 4 of 32.  Entry (channel tile ct, lane): basis[8 (lane / 16) + j][16 ct + lane % 16],
+    // j = 0 .. 7; the region is the one the block's fold of the basis gradient uses at the end (bs).  float16 has 5 exponent bits and gradients
+    // are small, so both operands are brought to [2^13, 2^14) by a power of two first -- one per channel (row of A, kept in a1_inv) and
+    // one per sample (column of B, vbw_pow2_scale on the row's largest magnitude) -- and the product is scaled back exactly.
+    vm_h8* a1_hi = reinterpret_cast<vm_h8*>(bs);                                     // [6][64]
+    vm_h8* a1_lo = a1_hi + 6 * 64;
+    float* a1_inv = reinterpret_cast<float*>(a1_lo + 6 * 64);                        // [96]
+    static_assert((size_t)2 * 6 * 64 * 16 + 96 * 4 <= (size_t)32 * VBW_BSTR * 4, "the split operands fit the fold buffer");
+    for (int e = threadIdx.x; e < 6 * 64; e += 64 * VBW_WAVES) {                     // whole wavefronts: the shuffles below see all four k groups of a channel
+        const int l = e & 63, ct = e >> 6, ch = 16 * ct + (l & 15), f0 = 8 * (l >> 4);
+        float v[8], m = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[j] = (f0 + j < F && ch < ctot) ? g.basis[(long)(f0 + j) * ctot + ch] : 0.f;
+            m = fmaxf(m, fabsf(v[j]));
+        }
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float inv;
+        const float sc = vbw_pow2_scale(m, &inv);
+        vm_h8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = v[j] * sc;
+            hi[j] = (_Float16)x;
+            lo[j] = (_Float16)(x - (float)hi[j]);
+        }
+        a1_hi[e] = hi;
+        a1_lo[e] = lo;
+        if (l < 16) a1_inv[ch] = inv;
     }
     __syncthreads();                              // the only block-wide barrier in front of the tiles: basis_mat visible
     auto wave_sync = []() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); };
@@ -1434,12 +1471,12 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
     EVD_VBW_T0();
     // d out as the MFMA B operand: lane (col = sample, kh) holds d out[sample][4 step + kh]
     const int col = lane & 15, kh = lane >> 4;
-    float dv[8];
+    float dv[8];                                  // lane (col = sample, kh): d out[sample][8 kh .. 8 kh + 7]
     {
         const long s = s0 + col;
         const float* r = d_out + (s < n ? s : n - 1) * (long)d_stride + d_col;
 #pragma unroll
-        for (int st = 0; st < 8; ++st) dv[st] = (s < n && 4 * st + kh < F) ? r[4 * st + kh] : 0.f;
+        for (int j = 0; j < 8; ++j) dv[j] = (s < n && 8 * kh + j < F) ? r[8 * kh + j] : 0.f;
     }
     if (lane < VBW_SAMPLES * 3) {                 // phase 0: geometry of this wavefront's (sample, component) pairs
         const int sl = lane / 3, i = lane % 3;
@@ -1465,13 +1502,32 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
     const int items = 0;
 #else
     // phase 1: D[channel 16 ct + 4 kh + r][sample col] = sum_f basis[f][channel] d out[sample][f]
-    for (int ct = 0; ct < ctot / 16; ++ct) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const float* bp = bs + kh * VBW_BSTR + 16 * ct + col;
+    {
+        float m = 0.f, binv;
 #pragma unroll
-        for (int st = 0; st < 8; ++st) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bp[4 * st * VBW_BSTR], dv[st], acc, 0, 0, 0);
+        for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(dv[j]));
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        const float bsc = vbw_pow2_scale(m, &binv);
+        vm_h8 bh, bl;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dco[col * VBW_CSTR + 16 * ct + 4 * kh + r] = acc[r];
+        for (int j = 0; j < 8; ++j) {
+            const float x = dv[j] * bsc;
+            bh[j] = (_Float16)x;
+            bl[j] = (_Float16)(x - (float)bh[j]);
+        }
+        for (int ct = 0; ct < ctot / 16; ++ct) {
+            const vm_h8 ah = a1_hi[ct * 64 + lane], al = a1_lo[ct * 64 + lane];
+            const f32x4 ai = *reinterpret_cast<const f32x4*>(a1_inv + 16 * ct + 4 * kh);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = acc[r] * ai[r] * binv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dco[col * VBW_CSTR + 16 * ct + 4 * kh + r] = acc[r];
+        }
     }
     wave_sync();
     EVD_VBW_T(1);
