@@ -314,20 +314,21 @@ def c2f_leg(precision, steps, parity=True):
     esz = 2 if half_grids else 4
     taps = 4 * 96 + 2 * 96                                      # 4 plane taps + 2 line taps x 96 channels = 576 gathered values per sample
     gathered = n * taps * esz
-    # PMC of THIS kernel build (profiles/r04_pmc_voxel.json, made by tools/pmc_voxel.sh; the gather kernel is unchanged since round 4: rocprofv3 cannot run inside the timed
-    # process), per sample of the fine-level launch: 128-byte line READ requests at the L2 and the lines that miss it (served by the Infinity
-    # Cache: the 165 MB of grids exceed the 32 MB of L2).  The kernel is a random gather: its roofline is the RATE at which the chip serves
-    # such requests, measured by tools/probes/gather_probe.hip (random 128-byte records, 16-byte lane loads), not an HBM byte rate.
-    pj = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_voxel.json")))["f16_grids" if half_grids else "f32_grids"]
+    # PMC of THIS kernel build (profiles/r06_pmc_voxel.json, made by tools/pmc_voxel.sh: rocprofv3 cannot run inside the timed process; float16 grids:
+    # k_voxel_sample_m, collected in round 6; float32 grids: k_voxel_sample_w, unchanged since round 4), per sample of the fine-level launch: 128-byte
+    # line READ requests at the L2 and the lines that miss it (served by the Infinity Cache: the 165 MB of grids exceed the 32 MB of L2).  The kernel
+    # is a random gather: its roofline is the RATE at which the chip serves such requests, measured by tools/probes/gather_probe.hip (random 128-byte
+    # records, 16-byte lane loads), not an HBM byte rate.
+    pj = json.load(open(os.path.join(ROOT, "profiles", "r06_pmc_voxel.json")))["f16_grids" if half_grids else "f32_grids"]
     pmc = {"l2_requests_per_sample": pj["l2_read_requests_per_sample"], "l2_miss_lines_per_sample": pj["l2_miss_lines_per_sample"],
-           "fetch_size_bytes_per_sample": pj["fetch_size_bytes_per_sample"], "source": pj["file"] + " (committed profile of this kernel, unchanged since round 4; the "
+           "fetch_size_bytes_per_sample": pj["fetch_size_bytes_per_sample"], "source": pj["file"] + " (committed profile of this kernel; the "
            "fraction below is counter-derived requests x the launch duration measured in this run)"}
     ceil = {"l2_resident": 146e9, "infinity_cache": 58e9, "hbm": 54e9}
     req_rate = pmc["l2_requests_per_sample"] * n / (g_ms * 1e-3)
     miss_rate = pmc["l2_miss_lines_per_sample"] * n / (g_ms * 1e-3)
     out = {"workload": "blurfactory c2f render: 4096 rays x (64 coarse + 64 importance) samples, grids 293x293x195 / 586x586x390, n_comp (64,16,16)",
            "precision": precision, "ms_per_step": step_ms, "rays_per_s": R / (step_ms * 1e-3),
-           "roofline": {"kernel": "k_voxel_sample_w (fine level, 4096 x 128 samples, %s grids)" % ("float16" if half_grids else "float32"),
+           "roofline": {"kernel": "%s (fine level, 4096 x 128 samples, %s grids)" % (pj["kernel"], "float16" if half_grids else "float32"),
                         "bound": "l2-gather (128-byte line requests/s)", "kernel_ms": g_ms,
                         "achieved": req_rate / 1e9, "peak": ceil["l2_resident"] / 1e9, "unit": "G line requests/s", "frac": req_rate / ceil["l2_resident"],
                         "behind_l2": {"achieved": miss_rate / 1e9, "peak": ceil["infinity_cache"] / 1e9, "unit": "G lines/s", "frac": miss_rate / ceil["infinity_cache"]},
@@ -336,8 +337,8 @@ def c2f_leg(precision, steps, parity=True):
                         "note": "achieved = PMC-counted L2 line requests per sample x samples / the launch duration measured here, against the rate a bare "
                                 "random gather of 128-byte records sustains when its table is L2-resident; behind_l2 = the lines that miss L2 against the "
                                 "Infinity-Cache-resident ceiling.  576 grid values are gathered per sample (4 taps x 96 plane channels + 2 taps x 96 line "
-                                "channels); the kernel is a latency chain per wavefront (points -> tap geometry -> gather -> basis GEMM -> store), "
-                                "not bandwidth-bound (DESIGN.md 3.3)"}}
+                                "channels); not bandwidth-bound: k_voxel_sample_w is a latency chain per wavefront (points -> tap geometry -> gather -> basis GEMM -> "
+                                "store), k_voxel_sample_m (float16 grids, round 6) is bound by the instructions its three wavefronts per SIMD issue (DESIGN.md 3.3)"}}
     out["arithmetic"] = {"f16c": "fine level: compensated float16 (k_voxel_mlp_c: f16 MFMA + two block-scaled fp6 MFMA residual products); coarse 64-wide level: "
                                  "float32-grade f16x3 on the float32 grids; the fine level gathers the float16 copies of its grids",
                          "f16": "single-product float16 MFMA on both levels, float16 grid copies", "bf16": "bf16 MFMA on both levels, float16 grid copies",

@@ -105,6 +105,9 @@ __global__ __launch_bounds__(CCfg::NT, 1) void k_voxel_mlp_c(const VoxMlpParams 
     // uncovered; a pass of this network is only ~19 us long)
     // (TRAIN: the store is tiled in groups of 8 sample tiles and the backward walks all of them -- the padding tiles are written too)
     const long ntile = TRAIN ? (p.nsamp + 255) / 256 * (256 / CCfg::SAMPLES) : (p.nsamp + CCfg::SAMPLES - 1) / CCfg::SAMPLES;
+#ifdef EVD_VC_ABL       // developer ablation (tools/dev/voxel_c_prologue_ablation.sh; results wrong by construction): bit 0 -- the two positional encodings,
+    XBlk in0[2], pev;   // bit 1 -- the feature block too, are built on the workgroup's FIRST pass only and kept: what hiding that work could gain at most
+#endif
     for (long tile = blockIdx.x;;) {
 #ifdef EVD_C_STAMP      // developer build (tools/dev/stamp_voxel_c.py): shader-clock stamps of this pass, written by lanes 0..2 in place of their samples
     long long ts[10];
@@ -117,7 +120,9 @@ __global__ __launch_bounds__(CCfg::NT, 1) void k_voxel_mlp_c(const VoxMlpParams 
     const long smp = tile * CCfg::SAMPLES + wave * 32 + n;
     const bool valid = smp < p.nsamp;
     const long sidx = valid ? smp : p.nsamp - 1;
+#ifndef EVD_VC_ABL
     XBlk in0[2], pev;
+#endif
     {
         // All loads first, the 256-byte feature row (Infinity Cache / HBM: the gather kernel wrote 134 MB of them) LAST in the queue and
         // FIRST in need of time: the two positional encodings (~500 VALU instructions on six floats) run while it is in flight, the
@@ -137,9 +142,17 @@ __global__ __launch_bounds__(CCfg::NT, 1) void k_voxel_mlp_c(const VoxMlpParams 
             fr[2 * j + 1] = *reinterpret_cast<const f32x4*>(f + 16 * j + 4);
         }
         asm volatile("" ::: "memory");       // the loads stay in front of the encodings
+#ifdef EVD_VC_ABL
+        if (tile == blockIdx.x) {
+            c_encode<PE_L, PE_KS>(pts, h, in0[1]);
+            c_encode<PE_LV, PEV_KS>(vd, h, pev);
+        }
+        if (tile == blockIdx.x || !(EVD_VC_ABL & 2)) c_block_from_regs(fr, in0[0]);
+#else
         c_encode<PE_L, PE_KS>(pts, h, in0[1]);
         c_encode<PE_LV, PEV_KS>(vd, h, pev);
         c_block_from_regs(fr, in0[0]);
+#endif
     }
     CAct act{};
     if constexpr (TRAIN) {
