@@ -165,6 +165,7 @@ SIGNATURES = {
     "evd_voxel_sample_bwd": (_I, [_vp, _vp, _L, _vp, _I, _I, C.POINTER(VoxelGridGrads), _vp, _vp]),
     "evd_voxel_sample_bwd_workspace_bytes": (_S, [_vp, _L]),
     "evd_voxel_sample_bwd_ws": (_I, [_vp, _vp, _L, _vp, _I, _I, C.POINTER(VoxelGridGrads), _vp, _vp, _S, _vp]),
+    "evd_voxel_sample_bwd_prec": (_I, [_vp, _I, _vp, _L, _vp, _I, _I, C.POINTER(VoxelGridGrads), _vp, _vp, _S, _vp]),
     "evd_voxel_tv_loss_bwd": (_I, [_vp, _vp, C.POINTER(VoxelGridGrads), _vp]),
     "evd_raw2outputs": (_I, [_vp, _vp, _vp, _I, _L, _I, _I, _I, _I, _I, _I, _I, _I, _F, _vp,
                              _vp, _vp, _vp, _vp, _vp, _vp, _I, _vp, _vp]),

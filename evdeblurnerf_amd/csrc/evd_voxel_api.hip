@@ -321,7 +321,7 @@ int evd_voxel_sample(const evd_voxel* v, const float* pts, long n, float* out, i
 // sampling inside the c2f render: the half-precision arithmetic modes read the float16 copies of the grids
 // feeds_only: the features go to the NEXT level's networks and to nothing that places samples (-1: decide by the level -- a level fed
 // by the previous one is the last of a c2f render)
-static int sample_for(const evd_voxel* v, int precision, const float* pts, long n, float* out, int out_stride, int out_col, void* stream, int feeds_only = -1) {
+static bool grids_half_for(const evd_voxel* v, int precision, int feeds_only = -1) {
     static const bool f32_grids = env_flag("EVD_F32_GRIDS");   // developer switch: float32 grids in every mode
     bool half = (precision == EVD_PREC_BF16 || precision == EVD_PREC_F16) && !f32_grids;
     if (precision == EVD_PREC_F16C && !f32_grids) {
@@ -339,7 +339,10 @@ static int sample_for(const evd_voxel* v, int precision, const float* pts, long 
         const bool last = v->ft_dim > v->app_dim;
         half = (m & (last ? 2 : (feeds_only == 1 ? 4 : 1))) != 0;
     }
-    return launch_voxel_sample(v->gp, half, pts, n, out, out_stride, out_col, as_stream(stream));
+    return half;
+}
+static int sample_for(const evd_voxel* v, int precision, const float* pts, long n, float* out, int out_stride, int out_col, void* stream, int feeds_only = -1) {
+    return launch_voxel_sample(v->gp, grids_half_for(v, precision, feeds_only), pts, n, out, out_stride, out_col, as_stream(stream));
 }
 
 int evd_voxel_sample_prec(const evd_voxel* v, int precision, const float* pts, long n, float* out, int out_stride, int out_col, void* stream) {
@@ -849,8 +852,19 @@ size_t evd_voxel_sample_bwd_workspace_bytes(const evd_voxel* v, long n) {
     return scatter_binned() ? voxel_scatter_workspace_bytes(v->gp, n) : voxel_scatter_hybrid_workspace_bytes(v->gp, n);
 }
 
+static int sample_bwd_ws(const evd_voxel* v, bool half_grids, const float* pts, long n, const float* d_out, int d_stride, int d_col,
+                         const evd_voxel_grid_grads* g, float* d_pts, void* workspace, size_t workspace_bytes, void* stream);
 int evd_voxel_sample_bwd_ws(const evd_voxel* v, const float* pts, long n, const float* d_out, int d_stride, int d_col,
                             const evd_voxel_grid_grads* g, float* d_pts, void* workspace, size_t workspace_bytes, void* stream) {
+    return sample_bwd_ws(v, false, pts, n, d_out, d_stride, d_col, g, d_pts, workspace, workspace_bytes, stream);
+}
+int evd_voxel_sample_bwd_prec(const evd_voxel* v, int precision, const float* pts, long n, const float* d_out, int d_stride, int d_col,
+                              const evd_voxel_grid_grads* g, float* d_pts, void* workspace, size_t workspace_bytes, void* stream) {
+    EVD_REQUIRE(precision >= 0 && precision <= EVD_PREC_F16M, "evd_voxel_sample_bwd_prec: unknown precision %d", precision);
+    return sample_bwd_ws(v, v && grids_half_for(v, precision), pts, n, d_out, d_stride, d_col, g, d_pts, workspace, workspace_bytes, stream);
+}
+static int sample_bwd_ws(const evd_voxel* v, bool half_grids, const float* pts, long n, const float* d_out, int d_stride, int d_col,
+                         const evd_voxel_grid_grads* g, float* d_pts, void* workspace, size_t workspace_bytes, void* stream) {
     EVD_REQUIRE(v && pts && d_out && g && n >= 0 && d_stride >= d_col + v->app_dim, "evd_voxel_sample_bwd_ws: bad arguments");
     EVD_REQUIRE(v->app_act == EVD_ACT_NONE, "evd_voxel_sample_bwd_ws: only app_actfn none is built (all shipped configs)");
     if (n == 0) return EVD_OK;
@@ -859,7 +873,7 @@ int evd_voxel_sample_bwd_ws(const evd_voxel* v, const float* pts, long n, const 
     gg.basis = g->basis;
     if (workspace && workspace_bytes > 0 && voxel_scatter_binned_ok(v->gp, gg, n)) {
         if (scatter_binned()) return launch_voxel_sample_bwd_binned(v->gp, pts, n, d_out, d_stride, d_col, gg, d_pts, workspace, workspace_bytes, as_stream(stream));
-        return launch_voxel_sample_bwd_hybrid(v->gp, pts, n, d_out, d_stride, d_col, gg, d_pts, workspace, workspace_bytes, as_stream(stream));
+        return launch_voxel_sample_bwd_hybrid(v->gp, pts, n, d_out, d_stride, d_col, gg, d_pts, workspace, workspace_bytes, as_stream(stream), half_grids);
     }
     return launch_voxel_sample_bwd(v->gp, pts, n, d_out, d_stride, d_col, gg, d_pts, as_stream(stream));
 }

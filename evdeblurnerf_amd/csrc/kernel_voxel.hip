@@ -622,6 +622,15 @@ __device__ __forceinline__ float vbw_pow2_scale(float m, float* inv) {
     *inv = __uint_as_float((unsigned)(E - 13) << 23);
     return __uint_as_float((unsigned)(267 - E) << 23);
 }
+typedef unsigned vbw_u32x4 __attribute__((ext_vector_type(4)));
+// acc + w x (one float16 of a packed pair) in ONE instruction: v_fma_mix_f32 (op_sel_hi marks the float16 source, op_sel picks its high half);
+// hipcc does not form it from fmaf(w, (float)h, acc) here (a conversion + a fused multiply-add: 48 more instructions per gathered item)
+template <int HI> __device__ __forceinline__ float vbw_fma_mix(float w, unsigned pair, float acc) {
+    float d;
+    if (HI) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(d) : "v"(w), "v"(pair), "v"(acc));
+    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]" : "=v"(d) : "v"(w), "v"(pair), "v"(acc));
+    return d;
+}
 __device__ __forceinline__ float vbw_mul_legacy(float a, float b) {          // a x b with 0 x anything = 0 (v_mul_legacy_f32: VOP3 only, no builtin in this hipcc)
     float d;
     asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
@@ -1340,7 +1349,10 @@ __device__ __forceinline__ void vbw_walk_plane64(float* __restrict__ gp, int c, 
     }
 }
 
-template <bool DPTS, bool LINES12, bool BAS, bool ISS = false>
+// HALF (round 6): phase 2 re-gathers the grid values from the FLOAT16 copies (GridParams::plane_h / line_h) -- the values the forward of the
+// half-precision arithmetic modes interpolated (evd_voxel_api.hip grids_half_for), so the products d coef x value are the gradient of the function
+// that forward computed; half the gather's loads and bytes, weight x value + sum as one v_fma_mix_f32 on the float16 value (as k_voxel_sample_m).
+template <bool DPTS, bool LINES12, bool BAS, bool ISS = false, bool HALF = false>
 __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const GridParams g, const float* __restrict__ pts, long n,
                                                                           const float* __restrict__ d_out, int d_stride, int d_col, GridGrads gg,
                                                                           float* __restrict__ d_pts, float* __restrict__ rows_l, LTap* __restrict__ ltap,
@@ -1535,13 +1547,14 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
     const int items = VBW_SAMPLES * ng;
     // items in flight per lane and trip: three (144 registers of raw taps) -- two where the wavefront also carries the basis accumulators
     // (48 registers) AND the point gradient's operands: at three that form spills 27 registers into the tile loop
-    constexpr int UNR = (BAS && DPTS) ? 2 : 3, TRIPS = 3 / UNR + (3 % UNR ? 1 : 0);
+    constexpr int UNR = (BAS && DPTS && !HALF) ? 2 : 3, TRIPS = 3 / UNR + (3 % UNR ? 1 : 0);      // (HALF: 24 instead of 48 registers of raw taps per item)
     f32x4 cfk[TRIPS * UNR][2];                    // BAS: the coefficients of this lane's items (ng <= 12: items <= 3 x 64)
 #pragma unroll
     for (int trip = 0; trip < TRIPS; ++trip) {
         const int base = lane + trip * UNR * 64;
         if (base >= items) break;
         f32x4 rawp[UNR][4][2], rawl[UNR][2][2];
+        vm_h8 hfp[UNR][4], hfl[UNR][2];           // HALF: the taps' eight float16 values (one 16-byte load each)
         int sl[UNR], grp[UNR], comp[UNR];
         bool on[UNR];
 #pragma unroll
@@ -1554,16 +1567,25 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
             if (c8 >= c0n) { c8 -= c0n; i = 1; if (c8 >= c1n) { c8 -= c1n; i = 2; } }
             comp[q] = i;
             const VbwTaps& tp = taps[sl[q] * 3 + i];
-            const float* pl = sel3(i, g.plane[0], g.plane[1], g.plane[2]) + c8;
-            const float* li = sel3(i, g.line[0], g.line[1], g.line[2]) + c8;
+            if (HALF) {
+                const _Float16* plh = sel3(i, g.plane_h[0], g.plane_h[1], g.plane_h[2]) + c8;
+                const _Float16* lih = sel3(i, g.line_h[0], g.line_h[1], g.line_h[2]) + c8;
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+                for (int k = 0; k < 4; ++k) hfp[q][k] = *reinterpret_cast<const vm_h8*>(plh + tp.ip[k]);
 #pragma unroll
-                for (int v = 0; v < 2; ++v) rawp[q][k][v] = *reinterpret_cast<const f32x4*>(pl + tp.ip[k] + 4 * v);
+                for (int k = 0; k < 2; ++k) hfl[q][k] = *reinterpret_cast<const vm_h8*>(lih + tp.il[k]);
+            } else {
+                const float* pl = sel3(i, g.plane[0], g.plane[1], g.plane[2]) + c8;
+                const float* li = sel3(i, g.line[0], g.line[1], g.line[2]) + c8;
 #pragma unroll
-            for (int k = 0; k < 2; ++k)
+                for (int k = 0; k < 4; ++k)
 #pragma unroll
-                for (int v = 0; v < 2; ++v) rawl[q][k][v] = *reinterpret_cast<const f32x4*>(li + tp.il[k] + 4 * v);
+                    for (int v = 0; v < 2; ++v) rawp[q][k][v] = *reinterpret_cast<const f32x4*>(pl + tp.ip[k] + 4 * v);
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) rawl[q][k][v] = *reinterpret_cast<const f32x4*>(li + tp.il[k] + 4 * v);
+            }
         }
         if (ISS && trip == 0) {                   // (the gather's loads are in flight) the issuer is done with the previous tile's buffer
             while (__builtin_amdgcn_readfirstlane(flags[wv]) != 0) __builtin_amdgcn_s_sleep(2);
@@ -1581,14 +1603,46 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
                 f32x4 pv = {0.f, 0.f, 0.f, 0.f}, lv = {0.f, 0.f, 0.f, 0.f};
                 // (round 6: w != 0 ? pv + raw w : pv as pv + legacy(w, raw) -- the same value, a tap outside the grid (w = 0) adds 0 whatever
                 // lies at its clamped address -- one instruction less per element in a kernel bound by the instructions it issues)
+                auto plane_val = [&](int t, int k) __attribute__((always_inline)) { return HALF ? (float)hfp[q][t][4 * v + k] : rawp[q][t][v][k]; };
+                auto line_val = [&](int t, int k) __attribute__((always_inline)) { return HALF ? (float)hfl[q][t][4 * v + k] : rawl[q][t][v][k]; };
+                if (HALF && DPTS) {               // the converted values are needed for the point gradient anyway: conversions + packed FMAs
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                    for (int t = 0; t < 4; ++t)
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) pv[k] = __fadd_rn(pv[k], vbw_mul_legacy(tp.wp[t], rawp[q][t][v][k]));
+                        for (int k = 0; k < 4; ++k) pv[k] = __builtin_fmaf(tp.wp[t], plane_val(t, k), pv[k]);
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                    for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) lv[k] = __fadd_rn(lv[k], vbw_mul_legacy(tp.wl[t], rawl[q][t][v][k]));
+                        for (int k = 0; k < 4; ++k) lv[k] = __builtin_fmaf(tp.wl[t], line_val(t, k), lv[k]);
+                } else if (HALF) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const vbw_u32x4 pw = __builtin_bit_cast(vbw_u32x4, hfp[q][t]);
+#pragma unroll
+                        for (int k = 0; k < 4; k += 2) {
+                            pv[k] = vbw_fma_mix<0>(tp.wp[t], pw[2 * v + (k >> 1)], pv[k]);
+                            pv[k + 1] = vbw_fma_mix<1>(tp.wp[t], pw[2 * v + (k >> 1)], pv[k + 1]);
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const vbw_u32x4 lw = __builtin_bit_cast(vbw_u32x4, hfl[q][t]);
+#pragma unroll
+                        for (int k = 0; k < 4; k += 2) {
+                            lv[k] = vbw_fma_mix<0>(tp.wl[t], lw[2 * v + (k >> 1)], lv[k]);
+                            lv[k + 1] = vbw_fma_mix<1>(tp.wl[t], lw[2 * v + (k >> 1)], lv[k + 1]);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) pv[k] = __fadd_rn(pv[k], vbw_mul_legacy(tp.wp[t], plane_val(t, k)));
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) lv[k] = __fadd_rn(lv[k], vbw_mul_legacy(tp.wl[t], line_val(t, k)));
+                }
                 f32x4 dc, rl, cf, rp;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -1638,10 +1692,10 @@ __global__ __launch_bounds__(64 * VBW_WAVES, 2) void k_voxel_sample_bwd_w(const 
                     // nothing), chained with d coef
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const float P0 = tp.wp[0] != 0.f ? rawp[q][0][v][k] : 0.f, P1 = tp.wp[1] != 0.f ? rawp[q][1][v][k] : 0.f;
-                        const float P2 = tp.wp[2] != 0.f ? rawp[q][2][v][k] : 0.f, P3 = tp.wp[3] != 0.f ? rawp[q][3][v][k] : 0.f;
+                        const float P0 = tp.wp[0] != 0.f ? plane_val(0, k) : 0.f, P1 = tp.wp[1] != 0.f ? plane_val(1, k) : 0.f;
+                        const float P2 = tp.wp[2] != 0.f ? plane_val(2, k) : 0.f, P3 = tp.wp[3] != 0.f ? plane_val(3, k) : 0.f;
                         const float dpx = (P1 - P0) * sn + (P3 - P2) * nn, dpy = (P2 - P0) * ee + (P3 - P1) * ww;
-                        const float dl = (tp.wl[1] != 0.f ? rawl[q][1][v][k] : 0.f) - (tp.wl[0] != 0.f ? rawl[q][0][v][k] : 0.f);
+                        const float dl = (tp.wl[1] != 0.f ? line_val(1, k) : 0.f) - (tp.wl[0] != 0.f ? line_val(0, k) : 0.f);
                         gx += dc[k] * lv[k] * dpx;
                         gy += dc[k] * lv[k] * dpy;
                         gl += dc[k] * pv[k] * dl;
@@ -2235,7 +2289,7 @@ bool voxel_sample_bwd_w_lines12(const GridParams& g) {
     return on && 2 * (g.n_comp[1] + g.n_comp[2]) <= 64 && g.n_comp[1] + g.n_comp[2] <= 32;
 }
 int launch_voxel_sample_bwd_w(const GridParams& g, const float* pts, long n, const float* d_out, int d_stride, int d_col, const GridGrads& gg,
-                              float* d_pts, float* rows_l, LTap* ltap, float* coef, hipStream_t st, unsigned* lmax) {
+                              float* d_pts, float* rows_l, LTap* ltap, float* coef, hipStream_t st, unsigned* lmax, bool half_grids) {
     // EVD_SCATTER_BASIS=separate (developer switch): round 3's form -- coefficient rows to HBM + the k_basis_grad launch
     static const bool bas_sep = [] { const char* e = getenv("EVD_SCATTER_BASIS"); return e && !strcmp(e, "separate"); }();
     const bool bas = gg.basis && !bas_sep;
@@ -2256,7 +2310,16 @@ int launch_voxel_sample_bwd_w(const GridParams& g, const float* pts, long n, con
         k_voxel_sample_bwd_w<DP, L12, BAS><<<blocks, 64 * VBW_WAVES, VBW_LDS, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, rows_l, ltap, coef_w, lmax); }
 #define EVD_VBI(DP) { EVD_SET_MAX_LDS((&k_voxel_sample_bwd_w<DP, false, true, true>), VBI_LDS); \
         k_voxel_sample_bwd_w<DP, false, true, true><<<blocks, 64 * VBW_WAVES, VBI_LDS, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, rows_l, ltap, coef_w, lmax); }
-    if (iss) {
+#define EVD_VBH(DP) { EVD_SET_MAX_LDS((&k_voxel_sample_bwd_w<DP, false, true, false, true>), VBW_LDS); \
+        k_voxel_sample_bwd_w<DP, false, true, false, true><<<blocks, 64 * VBW_WAVES, VBW_LDS, st>>>(g, pts, n, d_out, d_stride, d_col, gg, d_pts, rows_l, ltap, coef_w, lmax); }
+    // the float16 copies of the grids for the re-gather (the default form of the kernel only): EVD_SCATTER_HALF=0 keeps the float32 grids (A/B)
+    static const bool half_on = [] { const char* e = getenv("EVD_SCATTER_HALF"); return !(e && e[0] == '0'); }();
+    bool have_h = true;
+    for (int i = 0; i < 3; ++i) have_h = have_h && g.plane_h[i] && g.line_h[i];
+    if (half_grids && half_on && have_h && bas && !l12 && !iss) {
+        if (d_pts) EVD_VBH(true)
+        else EVD_VBH(false)
+    } else if (iss) {
         if (d_pts) EVD_VBI(true)
         else EVD_VBI(false)
     } else if (bas) {
@@ -2272,6 +2335,7 @@ int launch_voxel_sample_bwd_w(const GridParams& g, const float* pts, long n, con
     }
 #undef EVD_VBW
 #undef EVD_VBI
+#undef EVD_VBH
     EVD_LAUNCH_CHECK();
     if (gg.basis && !bas) {
         const int ct = g.n_comp[0] + g.n_comp[1] + g.n_comp[2];

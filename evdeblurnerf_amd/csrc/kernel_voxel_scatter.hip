@@ -451,7 +451,7 @@ size_t voxel_scatter_hybrid_workspace_bytes(const GridParams& g, long n) {
 static bool scatter_form_block() { static const bool b = [] { const char* e = getenv("EVD_SCATTER_FORM"); return e && !strcmp(e, "block"); }(); return b; }
 
 int launch_voxel_sample_bwd_hybrid(const GridParams& g, const float* pts, long n, const float* d_out, int d_stride, int d_col, const GridGrads& gg,
-                                   float* d_pts, void* workspace, size_t workspace_bytes, hipStream_t st) {
+                                   float* d_pts, void* workspace, size_t workspace_bytes, hipStream_t st, bool half_grids) {
     if (workspace_bytes < voxel_scatter_hybrid_workspace_bytes(g, n))
         return fail(EVD_E_WORKSPACE, "evd_voxel_sample_bwd: workspace %zu < %zu bytes", workspace_bytes, voxel_scatter_hybrid_workspace_bytes(g, n));
     const size_t ctot = (size_t)(g.n_comp[0] + g.n_comp[1] + g.n_comp[2]);
@@ -466,7 +466,7 @@ int launch_voxel_sample_bwd_hybrid(const GridParams& g, const float* pts, long n
         static const bool own_max = getenv("EVD_SCATTER_LINES_OWN_MAX") != nullptr;     // developer switch: every chunk finds its own maximum (round 3)
         unsigned* lmax = own_max ? nullptr : (unsigned*)(w + voxel_scatter_hybrid_workspace_bytes(g, n) - 512);
         if (lmax) EVD_HIP(hipMemsetAsync(lmax, 0, sizeof(unsigned), st));
-        int rc = launch_voxel_sample_bwd_w(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo.rows_l, bo.ltap, coef, st, lmax);
+        int rc = launch_voxel_sample_bwd_w(g, pts, n, d_out, d_stride, d_col, gg, d_pts, bo.rows_l, bo.ltap, coef, st, lmax, half_grids);
         if (rc) return rc;
         GridGrads gl = gg;
         if (voxel_sample_bwd_w_lines12(g)) gl.line[1] = gl.line[2] = nullptr;      // added inside the kernel: only the z line is left for the LDS slices

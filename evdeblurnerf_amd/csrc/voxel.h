@@ -54,10 +54,11 @@ int launch_voxel_sample_bwd_planes(const GridParams& g, const float* pts, long n
 bool voxel_sample_bwd_w_ok(const GridParams& g);
 bool voxel_sample_bwd_w_lines12(const GridParams& g);
 int launch_voxel_sample_bwd_w(const GridParams& g, const float* pts, long n, const float* d_out, int d_stride, int d_col, const GridGrads& gg,
-                              float* d_pts, float* rows_l, LTap* ltap, float* coef, hipStream_t st, unsigned* lmax = nullptr);
+                              float* d_pts, float* rows_l, LTap* ltap, float* coef, hipStream_t st, unsigned* lmax = nullptr, bool half_grids = false);
 size_t voxel_scatter_hybrid_workspace_bytes(const GridParams& g, long n);
+// half_grids: the re-gather of the grid values reads the float16 copies (the forward of the half-precision modes did: kernel_voxel.hip HALF)
 int launch_voxel_sample_bwd_hybrid(const GridParams& g, const float* pts, long n, const float* d_out, int d_stride, int d_col, const GridGrads& gg,
-                                   float* d_pts, void* workspace, size_t workspace_bytes, hipStream_t st);
+                                   float* d_pts, void* workspace, size_t workspace_bytes, hipStream_t st, bool half_grids = false);
 int launch_voxel_sample_bwd_binned(const GridParams& g, const float* pts, long n, const float* d_out, int d_stride, int d_col, const GridGrads& gg,
                                    float* d_pts, void* workspace, size_t workspace_bytes, hipStream_t st);
 

@@ -90,7 +90,7 @@ class _VoxelSample(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pts, net, precision, *grids):
-        ctx.net, ctx.pts = net, pts
+        ctx.net, ctx.pts, ctx.precision = net, pts, precision
         ctx.save_for_backward(*grids)
         out, net._sample_out = getattr(net, "_sample_out", None), None        # a strided window to write into (sample_train(out=...))
         return net.sample(pts, precision, out=out)
@@ -110,8 +110,10 @@ class _VoxelSample(torch.autograd.Function):
         # fixed-point LDS slices -- a third fewer atomic requests, 24-27 % faster); EVD_SCATTER=direct passes none: every tap an atomic
         nb = int(L.lib().evd_voxel_sample_bwd_workspace_bytes(net._h, pts.shape[0])) if os.environ.get("EVD_SCATTER") != "direct" else 0
         ws = torch.empty((nb,), dtype=torch.uint8, device=pts.device) if nb else None
-        L.check(L.lib().evd_voxel_sample_bwd_ws(net._h, L.ptr(pts), pts.shape[0], C.c_void_p(g.data_ptr()), g_stride, 0, C.byref(gs), L.ptr(d_pts), L.ptr(ws), nb,
-                                                L.stream_ptr()), "evd_voxel_sample_bwd_ws")
+        # in the forward's arithmetic mode: where it interpolated the float16 grid copies, the re-gather of the backward reads them too
+        prec = L.PREC[ctx.precision] if ctx.precision is not None else L.PREC["f32"]
+        L.check(L.lib().evd_voxel_sample_bwd_prec(net._h, prec, L.ptr(pts), pts.shape[0], C.c_void_p(g.data_ptr()), g_stride, 0, C.byref(gs), L.ptr(d_pts), L.ptr(ws), nb,
+                                                  L.stream_ptr()), "evd_voxel_sample_bwd_prec")
         _bwd_done(net)
         return (d_pts.reshape(ctx.pts.shape) if d_pts is not None else None, None, None, *grads)
 

@@ -362,6 +362,12 @@ int evd_voxel_sample_bwd(const evd_voxel* v, const float* pts, long n, const flo
 size_t evd_voxel_sample_bwd_workspace_bytes(const evd_voxel* v, long n);
 int evd_voxel_sample_bwd_ws(const evd_voxel* v, const float* pts, long n, const float* d_out, int d_stride, int d_col,
                             const evd_voxel_grid_grads* g, float* d_pts, void* workspace, size_t workspace_bytes, void* stream);
+/* The same in the arithmetic mode `precision` of the forward gather (evd_voxel_sample_prec): where that forward interpolated the FLOAT16
+ * copies of the grids (f16 / bf16 on every level, f16c on the fine level of a c2f pair), the backward's re-gather of the plane / line values
+ * (d plane = d coef x line value, d line = d coef x plane value, d pts) reads the same copies -- the gradient of the function the forward
+ * computed, at half the gather's loads and bytes; the other modes are evd_voxel_sample_bwd_ws. */
+int evd_voxel_sample_bwd_prec(const evd_voxel* v, int precision, const float* pts, long n, const float* d_out, int d_stride, int d_col,
+                              const evd_voxel_grid_grads* g, float* d_pts, void* workspace, size_t workspace_bytes, void* stream);
 /* d_loss[0] * d TV_loss_app / d grid added into g (voxnerf.py:126-130, 306-324); d_loss is a DEVICE scalar (no host sync) */
 int evd_voxel_tv_loss_bwd(const evd_voxel* v, const float* d_loss, const evd_voxel_grid_grads* g, void* stream);
 

@@ -894,6 +894,44 @@ def test_binned_scatter_equals_the_direct_scatter():
     assert rel_l2(dp_b.double(), dp_a.double()) < 1e-5          # (the point gradient is summed over channels with LDS atomics: order-dependent rounding)
 
 
+@pytest.mark.parametrize("with_pts", [False, True])
+def test_scatter_on_the_float16_grid_copies_is_the_scatter_of_the_rounded_grids(with_pts):
+    """evd_voxel_sample_bwd_prec in a mode whose forward gathers the float16 copies (f16): the re-gather of the backward reads the copies.
+    On grids whose values ARE float16 numbers the copies equal the grids, so the result must be the float32-grid backward's to the rounding of
+    the summation order (the interpolation is a fused multiply-add there, separate products here) -- incl. zero-weight taps outside the box, a ragged
+    count and the point gradient; on unrounded grids the two differ by the grids' 2^-11 rounding (checked to be present: the copies are in use)."""
+    import ctypes as C
+    from evdeblurnerf_amd import _lib as L
+    from evdeblurnerf_amd.voxnerf import VoxelNeRFSampleFeatures, _grid_grads
+    nvox = 96 ** 3
+    g = W.pdrf_grid_size(AABB[0], AABB[1], nvox)
+    sd0 = W.make_pdrf_state_dict(32, g, input_ch=127, hidden_dim=256, geo_feat_dim=128)
+    rs = np.random.RandomState(5)
+    n = 30000 - 7
+    pts = torch.tensor(rs.uniform(-1.7, 1.7, (n, 3)).astype(np.float32) * np.array([1.0, 1.0, 0.7], np.float32), device="cuda")
+    d_out = torch.tensor((rs.normal(size=(n, 32)) * 1e-6 * np.exp(rs.uniform(-6, 0, (n, 1)))).astype(np.float32), device="cuda")     # gradient-sized values
+
+    def run(sd, prec):
+        net = VoxelNeRFSampleFeatures(sd, "", AABB, num_layers=2, hidden_dim=256, geo_feat_dim=128, num_layers_color=3, input_ch=127, app_dim=32,
+                                      app_n_comp=(64, 16, 16), n_voxels=nvox)
+        grads, gs = _grid_grads(net, net.grid_params())
+        dp = torch.zeros_like(pts)
+        nb = int(L.lib().evd_voxel_sample_bwd_workspace_bytes(net._h, n))
+        ws = torch.empty((nb,), dtype=torch.uint8, device="cuda")
+        L.check(L.lib().evd_voxel_sample_bwd_prec(net._h, L.PREC[prec], L.ptr(pts), n, L.ptr(d_out), 32, 0, C.byref(gs), L.ptr(dp) if with_pts else None, L.ptr(ws), nb,
+                                                  L.stream_ptr()), "bwd_prec")
+        torch.cuda.synchronize()
+        return [t.double() for t in grads] + ([dp.double()] if with_pts else [])
+
+    rounded = {k: (np.asarray(v).astype(np.float16).astype(np.float32) if k.startswith(("app_plane", "app_line")) else v) for k, v in sd0.items()}
+    a, b = run(rounded, "f16"), run(rounded, "f16x3")
+    errs = [rel_l2(x, y) for x, y in zip(a, b)]
+    assert max(errs) < 2e-6, errs
+    c, d = run(sd0, "f16"), run(sd0, "f16x3")
+    errs = [rel_l2(x, y) for x, y in zip(c, d)]
+    assert 1e-5 < max(errs[:6]) < 1e-3, errs          # the float16 rounding of the grid values (2^-11 per value, averaged over taps), nothing more
+
+
 @pytest.mark.parametrize("prec,tol", [("f16", 5e-5), ("f16x3", 5e-6)])
 def test_c2f_render_rays_train_equals_inference_render_rays(prec, tol):
     """mode='c2f': the training forward (gathers in the mode's grid precision -- the float16 grid copies in f16, like the inference
