@@ -1,6 +1,7 @@
 """Developer probe: where does a tile of the persistent tri-plane scatter kernel (k_voxel_sample_bwd_w, basis gradient inside) spend its
 cycles?  Needs kernel_voxel.hip built with -DEVD_VBW_STAMP (lane 0 of every wavefront writes its per-phase cycle sums over the head of the
-line rows; the line gradients of such a build are garbage).  EVD_LIB_PATH=.../libevd_vbwstamp.so python tools/dev/stamp_scatter_w.py"""
+line rows; the line gradients of such a build are garbage).  EVD_LIB_PATH=.../libevd_vbwstamp.so python tools/dev/stamp_scatter_w.py
+EVD_STAMP_PREC=f16: the call in the float16 mode (evd_voxel_sample_bwd_prec: the re-gather on the float16 grid copies)."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np, torch
@@ -29,7 +30,8 @@ for slope in (0.05, 0.35):
         nb = int(L.lib().evd_voxel_sample_bwd_workspace_bytes(net._h, n))
         ws = torch.empty((nb + 256,), dtype=torch.uint8, device="cuda")
         for _ in range(3):
-            L.check(L.lib().evd_voxel_sample_bwd_ws(net._h, L.ptr(pts), n, L.ptr(d_out), 32, 0, C.byref(gs), L.ptr(d_pts), L.ptr(ws), nb, L.stream_ptr()), "bwd_ws")
+            L.check(L.lib().evd_voxel_sample_bwd_prec(net._h, L.PREC[os.environ.get("EVD_STAMP_PREC", "f32")], L.ptr(pts), n, L.ptr(d_out), 32, 0, C.byref(gs), L.ptr(d_pts), L.ptr(ws), nb,
+                                                      L.stream_ptr()), "bwd_prec")
         torch.cuda.synchronize()
         off = (-ws.data_ptr()) % 256
         t = ws[off:off + 2048 * 32].view(torch.float32).reshape(2048, 8).cpu().numpy().astype(np.float64)
