@@ -125,15 +125,37 @@ struct LineJobs { LineJob j[12]; };
 // below 2^-49 of the chunk's maximum: the sums are more accurate than float32 atomics, and deterministic inside the workgroup.
 // gmax (optional): the float bits of max |rows_l| over ALL samples, taken by the kernel that wrote the rows: the fixed-point scale is then that
 // one instead of this chunk's own maximum, and the chunk's rows are read once (123 -> 89 us per 2^19 samples)
+// Workgroup order (round 6): a job reads a 64-byte (16-channel) slice of every row of its chunk, i.e. HALF of each 128-byte line it pulls;
+// the other half belongs to the next job of the same chunk.  With the jobs as the grid's y dimension the six jobs of a chunk ran a whole
+// x sweep apart and every line came from HBM / the Infinity Cache twice (the kernel moved ~2 GB of rows per iteration at 3.0 TB/s while its LDS
+// atomics, ablated, were worth 12 %).  Now the grid is one-dimensional and decoded so that ALL jobs of a chunk are neighbours in time ON ONE XCD
+// (workgroup ids go round-robin over the 8 XCDs: id % 8): id = ((chunk / 8) nj + job) 8 + chunk % 8 -- the first job's miss fills that
+// XCD's L2 for the others (and the four z-line jobs share their tap records the same way): 769 -> 684 us per iteration; the jobs of a chunk on
+// consecutive ids, i.e. on different XCDs: 798 (profiles/r06_scatter_lines_order_ab.log).  Chunks of 4096 / 8192 samples (a quarter of the
+// end-of-chunk atomics) change nothing (r06_scatter_lines_chunk_ab.log).
 __global__ __launch_bounds__(SC_NT) void k_scatter_lines(const LineJobs jobs, const float* __restrict__ rows_l, const LTap* __restrict__ ltap, long n, int ctot,
-                                                       const unsigned* __restrict__ gmax) {
-    const LineJob jb = jobs.j[blockIdx.y];
+                                                       const unsigned* __restrict__ gmax, int nj, int order) {
+    int job, chunk;
+    if (order == 1) {
+        const int q = blockIdx.x >> 3;
+        job = q % nj;
+        chunk = (q / nj) * 8 + (blockIdx.x & 7);
+    } else if (order == 0) {                        // the chunk's jobs consecutive in id: spread over the XCDs
+        job = blockIdx.x % nj;
+        chunk = blockIdx.x / nj;
+    } else {                                        // rounds 3-5: job-major
+        const int chunks = (int)((n + SC_LCH - 1) / SC_LCH);
+        job = blockIdx.x / chunks;
+        chunk = blockIdx.x % chunks;
+    }
+    if ((long)chunk * SC_LCH >= n) return;
+    const LineJob jb = jobs.j[job];
     if (!jb.grad) return;
     extern __shared__ __attribute__((aligned(16))) unsigned long long lacc[];       // [Lp][cg]
     __shared__ float wmax[SC_NT / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cg = jb.cg, total = jb.Lp * cg;
     for (int o = tid; o < total; o += SC_NT) lacc[o] = 0ull;
-    const long base = (long)blockIdx.x * SC_LCH, end = base + SC_LCH < n ? base + SC_LCH : n;
+    const long base = (long)chunk * SC_LCH, end = base + SC_LCH < n ? base + SC_LCH : n;
     // a lane owns 4 consecutive channels of a sample (one 16-byte load): cg / 4 lanes per sample
     const int lps = cg >> 2, spw = 64 / lps, c4 = (lane % lps) * 4, sub = lane / lps, step = (SC_NT / 64) * spw;
     const float* col = rows_l + jb.coff + jb.c_lo + c4;
@@ -185,6 +207,15 @@ __global__ __launch_bounds__(SC_NT) void k_scatter_lines(const LineJobs jobs, co
                 t[u].c0 = t[u].c1 = 0; t[u].w0 = t[u].w1 = 0.f; v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
+#ifdef EVD_SL_NO_ATOMICS        // developer ablation (tools/dev/scatter_lines_ablation.sh; results wrong): the loads and conversions without the LDS atomics
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned long long a = (unsigned long long)__float2ll_rn((t[u].w0 * v[u][k]) * up) + (unsigned long long)__float2ll_rn((t[u].w1 * v[u][k]) * up);
+                if (a == 0x123456789abcdefull) lacc[t[u].c0 * cg + c4 + k] = a;
+            }
+#else
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             if (t[u].w0 != 0.f) {
@@ -196,6 +227,7 @@ __global__ __launch_bounds__(SC_NT) void k_scatter_lines(const LineJobs jobs, co
                 for (int k = 0; k < 4; ++k) atomicAdd(&lacc[t[u].c1 * cg + c4 + k], (unsigned long long)__float2ll_rn((t[u].w1 * v[u][k]) * up));
             }
         }
+#endif
     }
     __syncthreads();
     const double down = ldexp(1.0, e - 49);
@@ -229,7 +261,10 @@ static int launch_lines(const GridParams& g, const GridGrads& gg, const float* r
     for (int k = nj; k < 12; ++k) lj.j[k].grad = nullptr;
     if (nj) {
         EVD_SET_MAX_LDS(k_scatter_lines, (size_t)SC_LDS_MAX);
-        hipLaunchKernelGGL(k_scatter_lines, dim3((unsigned)cdiv(n, (long)SC_LCH), nj), dim3(SC_NT), llds, st, lj, rows_l, ltap, n, ctot, gmax);
+        // EVD_SCATTER_LINES_ORDER (developer switch, A/B of the order above): job = the chunk's jobs on consecutive ids, old = job-major (rounds 3-5)
+        static const int order = [] { const char* e = getenv("EVD_SCATTER_LINES_ORDER"); return !e ? 1 : (!strcmp(e, "job") ? 0 : (!strcmp(e, "old") ? 2 : 1)); }();
+        const long chunks = cdiv(n, (long)SC_LCH), chunks8 = cdiv(chunks, 8L) * 8;
+        hipLaunchKernelGGL(k_scatter_lines, dim3((unsigned)((order == 1 ? chunks8 : chunks) * nj)), dim3(SC_NT), llds, st, lj, rows_l, ltap, n, ctot, gmax, nj, order);
         EVD_LAUNCH_CHECK();
     }
     return EVD_OK;
