@@ -488,8 +488,11 @@ def train_iteration_leg(precision):
     k_ms = kernel_ms(lambda: L.check(L.lib().evd_voxel_sample_bwd(net._h, L.ptr(pts), n, L.ptr(d_out), 32, 0, C.byref(gs), None, L.stream_ptr()), "bwd"), 10)
     nb = int(L.lib().evd_voxel_sample_bwd_workspace_bytes(net._h, n))
     ws = torch.empty((nb,), dtype=torch.uint8, device="cuda")
-    h_ms = kernel_ms(lambda: L.check(L.lib().evd_voxel_sample_bwd_ws(net._h, L.ptr(pts), n, L.ptr(d_out), 32, 0, C.byref(gs), None, L.ptr(ws), nb,
-                                                                      L.stream_ptr()), "bwd_ws"), 10)
+    h32_ms = kernel_ms(lambda: L.check(L.lib().evd_voxel_sample_bwd_ws(net._h, L.ptr(pts), n, L.ptr(d_out), 32, 0, C.byref(gs), None, L.ptr(ws), nb,
+                                                                        L.stream_ptr()), "bwd_ws"), 10)
+    # what the iteration calls: the scatter in the forward's mode (the fine level of f16c / f16 re-gathers the float16 grid copies, round 6)
+    h_ms = kernel_ms(lambda: L.check(L.lib().evd_voxel_sample_bwd_prec(net._h, L.PREC[precision], L.ptr(pts), n, L.ptr(d_out), 32, 0, C.byref(gs), None, L.ptr(ws), nb,
+                                                                       L.stream_ptr()), "bwd_prec"), 10)
     # atomic requests of the shipped form per 2^19 samples at this slope: profiles/r06_pmc_scatter.txt (TCC_ATOMIC_sum: main kernel + line slices)
     req = {"k_voxel_sample_bwd_w": 5416452, "k_scatter_lines": 452665}
     peak = 20.0                                                 # G atomic requests/s: a bare kernel of coalesced float atomics (tools/probes/atomic_probe.hip: 320 G adds/s in 64-byte requests)
@@ -518,14 +521,17 @@ def train_iteration_leg(precision):
                               "(tests/test_gpu_bwd_fusion.py)",
             "with_awp_ms_per_iteration": {"fused_on_geo_fragments": ms_awp_f, "torch_module_on_depth_feature": ms_awp_t,
                                           "note": "AWP module = tools/awp_standin.py (the reference module's surface; its per-sample embedding is the reference's)"},
-            "scatter_hybrid_ms": h_ms, "scatter_all_atomics_ms": k_ms,
+            "scatter_hybrid_ms": h_ms, "scatter_hybrid_float32_grids_ms": h32_ms, "scatter_all_atomics_ms": k_ms,
             "scatter_note": "what the iteration runs: k_voxel_sample_bwd_w persistent, a wavefront owns 16 consecutive samples of a ray from the point load "
                             "to its last atomic; plane taps summed in a register along runs of samples on one cell, the basis_mat gradient accumulated in "
                             "registers by MFMA, line taps through the 64-bit fixed-point LDS slices of k_scatter_lines.  Round 6: the plane-tap walk rebuilt "
                             "(a pass's LDS operands fetched first, the 64-channel plane's four taps in one pass with scalar run ends, legacy multiply): "
                             "ablation builds had shown the walk ALONE at 33.6 k of a tile's 51.8 k cycles without any atomic "
                             "(profiles/r06_scatter_stamps_before_walk_rewrite.log); 0.543 -> 0.43 ms per 2^19 samples here, the iteration's nine scatters "
-                            "5.2 -> 2.8 ms (profiles/r06_train_kernels_after_walk.txt)",
+                            "5.2 -> 2.8 ms (profiles/r06_train_kernels_after_walk.txt).  Then: d coef on split-float16 MFMAs, the backward's re-gather of the grid "
+                            "values on the float16 copies where the forward gathered them (evd_voxel_sample_bwd_prec; scatter_hybrid_float32_grids_ms is the "
+                            "float32 re-gather), k_scatter_lines' workgroups ordered so that a chunk's jobs share one XCD's L2: the nine main launches "
+                            "2.8 -> 2.45 ms, the line launches 0.77 -> 0.68 ms (profiles/r06_scatter_half_ab.log, r06_scatter_lines_order_ab.log)",
             "fastest_mode_that_trains_like_f32": {"mode": "f16", "ms_per_iteration": modes.get("f16"), "rays_per_s": nrays / (modes["f16"] * 1e-3) if modes.get("f16") else None,
                                                   "why": "converges_like_f32 below: on a fixed budget the plain float16 mode reaches the float32-grade mode's loss curve and "
                                                          "PSNR; `precision` (f16c) stays the line's primary mode because its RENDER holds north_star's 1e-4 bound"},
