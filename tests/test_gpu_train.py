@@ -923,6 +923,15 @@ def test_scatter_on_the_float16_grid_copies_is_the_scatter_of_the_rounded_grids(
         torch.cuda.synchronize()
         return [t.double() for t in grads] + ([dp.double()] if with_pts else [])
 
+    if not with_pts:        # the boundary's edge cases: an empty batch is a no-op, an unknown mode is rejected
+        net = VoxelNeRFSampleFeatures(sd0, "", AABB, num_layers=2, hidden_dim=256, geo_feat_dim=128, num_layers_color=3, input_ch=127, app_dim=32,
+                                      app_n_comp=(64, 16, 16), n_voxels=nvox)
+        grads, gs = _grid_grads(net, net.grid_params())
+        assert L.lib().evd_voxel_sample_bwd_prec(net._h, L.PREC["f16"], L.ptr(pts), 0, L.ptr(d_out), 32, 0, C.byref(gs), None, None, 0, L.stream_ptr()) == 0
+        assert all(float(t.abs().max()) == 0.0 for t in grads)
+        assert L.lib().evd_voxel_sample_bwd_prec(net._h, 17, L.ptr(pts), n, L.ptr(d_out), 32, 0, C.byref(gs), None, None, 0, L.stream_ptr()) != 0
+        assert "unknown precision" in L.lib().evd_last_error().decode()
+        del net, grads
     rounded = {k: (np.asarray(v).astype(np.float16).astype(np.float32) if k.startswith(("app_plane", "app_line")) else v) for k, v in sd0.items()}
     a, b = run(rounded, "f16"), run(rounded, "f16x3")
     errs = [rel_l2(x, y) for x, y in zip(a, b)]
