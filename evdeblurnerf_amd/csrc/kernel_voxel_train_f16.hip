@@ -17,7 +17,7 @@ int voxel_store_geo_slot(int HD) { return HD == 256 ? VStore<256, 128, 64>::GEO 
 long voxel_store_tile_bytes_prec(int HD, int prec) { return HD == 256 ? VStore<256, 128, 64>::tile_bytes(prec) : VStore<64, 15, 32>::tile_bytes(prec); }
 long voxel_store_tile_bytes(int HD) { return HD == 256 ? VStore<256, 128, 64>::TILE_BYTES : VStore<64, 15, 32>::TILE_BYTES; }
 
-int launch_voxel_coarse_pipe_f16(const VoxMlpParams& p, hipStream_t st) { return launch_voxel_pipe_level<EVD_PREC_F16, 64, 15, 32>(p, st); }
+int launch_voxel_coarse_pipe_f16(const VoxMlpParams& p, hipStream_t st) { return launch_voxel_resident_level<EVD_PREC_F16, 64, 15, 32>(p, st); }
 
 }  // namespace evd
 

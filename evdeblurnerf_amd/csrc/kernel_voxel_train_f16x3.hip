@@ -21,6 +21,6 @@ int run_voxel_backward_f16x3(int HD, const VoxBwdPlan& b, hipStream_t st) {
     return HD == 256 ? run_voxel_backward<EVD_PREC_F16X3, 256, 128, 64>(b, st) : run_voxel_backward<EVD_PREC_F16X3, 64, 15, 32>(b, st);
 }
 
-int launch_voxel_coarse_pipe_f16x3(const VoxMlpParams& p, hipStream_t st) { return launch_voxel_pipe_level<EVD_PREC_F16X3, 64, 15, 32>(p, st); }
+int launch_voxel_coarse_pipe_f16x3(const VoxMlpParams& p, hipStream_t st) { return launch_voxel_resident_level<EVD_PREC_F16X3, 64, 15, 32>(p, st); }
 
 }  // namespace evd

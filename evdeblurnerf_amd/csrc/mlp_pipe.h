@@ -290,6 +290,23 @@ template <class C, bool STORES, int NCH> struct PStream {
     }
 };
 
+// The same interface on a stream that is RESIDENT in LDS (round 6: the 64-wide PDRF level -- its whole packed stream is 5 chunks in the
+// split-float16 mode, 3 in float16): the persistent workgroup copies all NCH chunks once, after that a chunk boundary costs nothing (no DMA,
+// no counted wait, no barrier: the wavefronts of the workgroup run their tiles independently).
+template <class C, int NCH> struct PResident {
+    const char* rd_base;    // stream base in LDS + 16 * lane
+    static constexpr int kChunks = NCH;
+    static constexpr int BYTES = NCH * C::CB;
+    __device__ __forceinline__ void start_issue(const char* g, char* lds, int tid) {
+        rd_base = lds + (tid & 63) * 16;
+        for (int i = tid; i < BYTES / 16; i += C::NT) *reinterpret_cast<f32x4*>(lds + (size_t)i * 16) = *reinterpret_cast<const f32x4*>(g + (size_t)i * 16);
+    }
+    __device__ __forceinline__ void start_wait() { __syncthreads(); }
+    __device__ __forceinline__ const char* frag(int c, int fc) const { return rd_base + c * C::CB + fc * C::FB; }
+    __device__ __forceinline__ void chunk_begin(int) {}
+    __device__ __forceinline__ void chunk_end(int) {}
+};
+
 // register state that flows from layer to layer: prefetched A fragments and the two accumulator sets
 template <class C> struct Pipe {
     typename C::O::A abuf[C::PD];

@@ -7,6 +7,9 @@
 
 #include "mlp_pipe.h"
 #include "voxel.h"
+#ifndef EVD_RES_NT
+#define EVD_RES_NT 512      // threads of k_voxel_mlp_resident: two wavefronts per SIMD (198 registers in the split-float16 mode); -DEVD_RES_NT=256: one (A/B)
+#endif
 
 namespace evd {
 
@@ -217,6 +220,105 @@ static int launch_voxel_pipe_level(const VoxMlpParams& p, hipStream_t st) {
     if (p.nchunks != N::NCH) return fail(EVD_E_INVALID, "evd_voxel: packed stream has %d chunks, kernel expects %d", p.nchunks, N::NCH);
     if (p.feature || p.act) return fail(EVD_E_INVALID, "evd_voxel: the level's pipelined inference pass writes raw only");
     hipLaunchKernelGGL((k_voxel_mlp_pipe<PREC, HD, G, FT, 1, NT, false, PIPE_CB, OCC, false>), dim3((unsigned)blocks), dim3(NT), lds, st, p);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+// Round 6: the same layer table, arithmetic and order of operations (results bit for bit those of k_voxel_mlp_pipe) for a level whose whole
+// weight stream fits LDS -- the 64-wide coarse level of the shipped c2f configs.  k_voxel_mlp_pipe is built for 256-wide layers: every
+// workgroup streams the weights through a 4-slot ring with a counted wait and a barrier per 16 KiB chunk and lives for ONE group of sample
+// tiles, so this level's render pass was all prologue and hand-over (86-90 us per 4096 x 64 samples, 14 % of a c2f render, whatever the
+// arithmetic mode).  Here the workgroups are persistent (one per CU), copy the stream ONCE (mlp_pipe.h PResident) and walk the sample tiles
+// without a barrier; the direction encoding stays in registers (no stash).
+template <int PREC, int HD, int G, int FT, int NT>
+__global__ __launch_bounds__(NT, 1) void k_voxel_mlp_resident(const VoxMlpParams p) {
+    typedef PipeCfg<PREC, 1, NT> C;
+    typedef typename C::O O;
+    typedef typename O::B B;
+    typedef VoxNet<C, HD, G, FT, false, false> N;
+    constexpr int KS = N::KS, KF = N::KF, GK = N::GK;
+    typedef PResident<C, N::NCH> ST;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    pipe_fp16_saturate<PREC>();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, h = lane >> 5;
+    ST st;
+    st.start_issue(p.wstream, smem, tid);
+    float* bias = reinterpret_cast<float*>(smem + ST::BYTES);
+    for (int i = tid; i < N::B_END; i += NT) bias[i] = i < N::B_C0 ? 0.f : p.bias[512 + (i - N::B_C0)];
+    st.start_wait();
+    const long ngroups = (p.nsamp + C::SAMPLES - 1) / C::SAMPLES;
+    for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const long smp = grp * C::SAMPLES + wave * 32 + n;
+        const bool valid = smp < p.nsamp;
+        const long sidx = valid ? smp : p.nsamp - 1;
+        B in0[1][KF + PE_KS], pev[PEV_KS];
+        {
+            float pts[3], vd[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                pts[c] = p.pts[sidx * 3 + c];
+                vd[c] = p.viewdirs[(sidx / p.S) * p.vd_stride + c];
+            }
+            const float* f = p.fts + sidx * (long)p.ft_stride + 8 * h;
+#pragma unroll
+            for (int j = 0; j < KF; ++j) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(f + 16 * j), b = *reinterpret_cast<const f32x4*>(f + 16 * j + 4);
+                O::template set_pair<false>(in0[0][j], 0, a[0], a[1]);
+                O::template set_pair<false>(in0[0][j], 1, a[2], a[3]);
+                O::template set_pair<false>(in0[0][j], 2, b[0], b[1]);
+                O::template set_pair<false>(in0[0][j], 3, b[2], b[3]);
+            }
+            B pe[PE_KS];
+            encode_pairs<C, PE_L, PE_KS>(pts, h, pe);
+            encode_pairs<C, PE_LV, PEV_KS>(vd, h, pev);
+#pragma unroll
+            for (int j = 0; j < PE_KS; ++j) in0[0][KF + j] = pe[j];
+        }
+        float* nofrow[1] = {nullptr};
+        char* actl[1] = {nullptr};
+        Pipe<C> pp;
+        pipe_prime<C, typename N::L0>(st, pp, bias, lane);
+        B hid[1][KS], none[1][1];
+        pipe_layer<C, typename N::L0, ST, KS, false>(st, pp, in0, hid, nullptr, bias, lane, nofrow, actl);
+        float sig[1][4], col[1][4];
+        pipe_layer<C, typename N::Sigma, ST, 1, false>(st, pp, hid, none, sig, bias + N::B_SIG, lane, nofrow, actl);
+        B cin[1][GK + PEV_KS];
+        pipe_layer<C, typename N::Geo, ST, GK + PEV_KS, false>(st, pp, hid, cin, nullptr, bias + N::B_GEO, lane, nofrow, actl);
+#pragma unroll
+        for (int j = 0; j < PEV_KS; ++j) cin[0][GK + j] = pev[j];
+        B c0[1][KS], c1[1][KS];
+        pipe_layer<C, typename N::C0, ST, KS, false>(st, pp, cin, c0, nullptr, bias + N::B_C0, lane, nofrow, actl);
+        pipe_layer<C, typename N::C1, ST, KS, false>(st, pp, c0, c1, nullptr, bias + N::B_C1, lane, nofrow, actl);
+        pipe_layer<C, typename N::C2, ST, 1, false>(st, pp, c1, none, col, bias + N::B_C2, lane, nofrow, actl);
+        if (h == 0 && valid) {
+            f32x4 o;
+            o[0] = sig[0][0];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[1 + c] = 1.f / (1.f + expf(-col[0][c]));      // torch.sigmoid(h) voxnerf.py:252
+            *reinterpret_cast<f32x4*>(p.raw + sidx * 4) = o;
+        }
+    }
+}
+
+template <int PREC, int HD, int G, int FT>
+static int launch_voxel_resident_level(const VoxMlpParams& p, hipStream_t st) {
+    // EVD_COARSE_FORM=pipe (developer switch): the streaming kernel of rounds 3-5 (A/B)
+    static const bool pipe_form = [] { const char* e = getenv("EVD_COARSE_FORM"); return e && !strcmp(e, "pipe"); }();
+    if (pipe_form) return launch_voxel_pipe_level<PREC, HD, G, FT>(p, st);
+    constexpr int NT = EVD_RES_NT;
+    typedef PipeCfg<PREC, 1, NT> C;
+    typedef VoxNet<C, HD, G, FT, false, false> N;
+    typedef PResident<C, N::NCH> ST;
+    constexpr size_t lds = (size_t)ST::BYTES + (size_t)C::BIAS_FLOATS * 4;
+    static_assert(lds <= 160 * 1024, "the level's stream is resident in LDS");
+    if (p.nchunks != N::NCH) return fail(EVD_E_INVALID, "evd_voxel: packed stream has %d chunks, kernel expects %d", p.nchunks, N::NCH);
+    if (p.feature || p.act) return fail(EVD_E_INVALID, "evd_voxel: the level's inference pass writes raw only");
+    int cus = 256;
+    { int dev = 0, v = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
+    const long groups = cdiv(p.nsamp, (long)C::SAMPLES);
+    EVD_SET_MAX_LDS((&k_voxel_mlp_resident<PREC, HD, G, FT, NT>), lds);
+    hipLaunchKernelGGL((k_voxel_mlp_resident<PREC, HD, G, FT, NT>), dim3((unsigned)(groups < cus ? groups : cus)), dim3(NT), lds, st, p);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }
