@@ -189,8 +189,16 @@ static int launch_voxel_pipe(const VoxMlpParams& p, hipStream_t st) {
 // tiled in groups of 8 tiles (256 samples) and the backward walks all of them: the grid covers the padding tiles too.
 // HI_ONLY (PREC = EVD_PREC_F16X3): the store is the single-product float16 mode's (mlp_pipe.h PipeCfg) -- the coarse level of a
 // training forward in EVD_PREC_F16C
+template <int PREC, int HD, int G, int FT, bool HI_ONLY> static int launch_voxel_resident_train(const VoxMlpParams& p, hipStream_t st);
 template <int PREC, int HD, int G, int FT, bool FEAT = false, bool HI_ONLY = false>
 static int launch_voxel_train_fwd(const VoxMlpParams& p, hipStream_t st) {
+    // the 64-wide level in the split-float16 arithmetic (the coarse level of the f16c / f16m / f16x3 training modes): weight stream resident in
+    // LDS, persistent workgroups -- iteration f16c 11.37 -> 11.24 ms, f16m 12.93 -> 12.81; in the single-product modes this kernel already runs two
+    // workgroups per CU and the resident form measures 197 against 189 us: not used there (profiles/r06_coarse_train_ab.log).  EVD_COARSE_FORM=pipe: this kernel
+    if constexpr (HD == 64 && !FEAT && PREC == EVD_PREC_F16X3) {
+        static const bool pipe_form = [] { const char* e = getenv("EVD_COARSE_FORM"); return e && !strcmp(e, "pipe"); }();
+        if (!pipe_form && p.nsamp >= 65536) return launch_voxel_resident_train<PREC, HD, G, FT, HI_ONLY>(p, st);
+    }
     constexpr int NT = is_half_prec(PREC) ? 512 : 256, OCC = is_half_prec(PREC) ? 2 : 1;     // split-float16: one wavefront per SIMD
     typedef PipeCfg<PREC, 1, NT, PIPE_CB, HI_ONLY> C;
     typedef VoxNet<C, HD, G, FT, FEAT, true> N;
@@ -229,12 +237,14 @@ static int launch_voxel_pipe_level(const VoxMlpParams& p, hipStream_t st) {
 // tiles, so this level's render pass was all prologue and hand-over (86-90 us per 4096 x 64 samples, 14 % of a c2f render, whatever the
 // arithmetic mode).  Here the workgroups are persistent (one per CU), copy the stream ONCE (mlp_pipe.h PResident) and walk the sample tiles
 // without a barrier; the direction encoding stays in registers (no stash).
-template <int PREC, int HD, int G, int FT, int NT>
+// TRAIN / HI_ONLY: the training forward of the level (k_voxel_mlp_pipe's TRAIN variant: every completed block also goes to the activation store).
+template <int PREC, int HD, int G, int FT, int NT, bool TRAIN = false, bool HI_ONLY = false>
 __global__ __launch_bounds__(NT, 1) void k_voxel_mlp_resident(const VoxMlpParams p) {
-    typedef PipeCfg<PREC, 1, NT> C;
+    typedef PipeCfg<PREC, 1, NT, PIPE_CB, HI_ONLY> C;
     typedef typename C::O O;
     typedef typename O::B B;
-    typedef VoxNet<C, HD, G, FT, false, false> N;
+    typedef VoxNet<C, HD, G, FT, false, TRAIN> N;
+    typedef typename N::VS VS;
     constexpr int KS = N::KS, KF = N::KF, GK = N::GK;
     typedef PResident<C, N::NCH> ST;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -247,11 +257,13 @@ __global__ __launch_bounds__(NT, 1) void k_voxel_mlp_resident(const VoxMlpParams
     float* bias = reinterpret_cast<float*>(smem + ST::BYTES);
     for (int i = tid; i < N::B_END; i += NT) bias[i] = i < N::B_C0 ? 0.f : p.bias[512 + (i - N::B_C0)];
     st.start_wait();
-    const long ngroups = (p.nsamp + C::SAMPLES - 1) / C::SAMPLES;
+    // (TRAIN: the store is tiled in groups of 8 sample tiles and the backward walks all of them -- the padding tiles are written too)
+    const long ngroups = TRAIN ? (p.nsamp + 255) / 256 * (256 / C::SAMPLES) : (p.nsamp + C::SAMPLES - 1) / C::SAMPLES;
     for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const long smp = grp * C::SAMPLES + wave * 32 + n;
         const bool valid = smp < p.nsamp;
         const long sidx = valid ? smp : p.nsamp - 1;
+        char* actl[1] = {TRAIN ? p.act + (smp >> 5) * VS::tile_bytes(C::STORE_PREC) + lane * 16 : nullptr};
         B in0[1][KF + PE_KS], pev[PEV_KS];
         {
             float pts[3], vd[3];
@@ -274,23 +286,28 @@ __global__ __launch_bounds__(NT, 1) void k_voxel_mlp_resident(const VoxMlpParams
             encode_pairs<C, PE_LV, PEV_KS>(vd, h, pev);
 #pragma unroll
             for (int j = 0; j < PE_KS; ++j) in0[0][KF + j] = pe[j];
+            if constexpr (TRAIN) {
+#pragma unroll
+                for (int j = 0; j < KF + PE_KS; ++j) pipe_act_store<C>(actl[0], VS::IN0 + j, in0[0][j]);
+#pragma unroll
+                for (int j = 0; j < PEV_KS; ++j) pipe_act_store<C>(actl[0], VS::DIRPE + j, pev[j]);
+            }
         }
         float* nofrow[1] = {nullptr};
-        char* actl[1] = {nullptr};
         Pipe<C> pp;
         pipe_prime<C, typename N::L0>(st, pp, bias, lane);
         B hid[1][KS], none[1][1];
-        pipe_layer<C, typename N::L0, ST, KS, false>(st, pp, in0, hid, nullptr, bias, lane, nofrow, actl);
+        pipe_layer<C, typename N::L0, ST, KS, TRAIN>(st, pp, in0, hid, nullptr, bias, lane, nofrow, actl);
         float sig[1][4], col[1][4];
-        pipe_layer<C, typename N::Sigma, ST, 1, false>(st, pp, hid, none, sig, bias + N::B_SIG, lane, nofrow, actl);
+        pipe_layer<C, typename N::Sigma, ST, 1, TRAIN>(st, pp, hid, none, sig, bias + N::B_SIG, lane, nofrow, actl);
         B cin[1][GK + PEV_KS];
-        pipe_layer<C, typename N::Geo, ST, GK + PEV_KS, false>(st, pp, hid, cin, nullptr, bias + N::B_GEO, lane, nofrow, actl);
+        pipe_layer<C, typename N::Geo, ST, GK + PEV_KS, TRAIN>(st, pp, hid, cin, nullptr, bias + N::B_GEO, lane, nofrow, actl);
 #pragma unroll
         for (int j = 0; j < PEV_KS; ++j) cin[0][GK + j] = pev[j];
         B c0[1][KS], c1[1][KS];
-        pipe_layer<C, typename N::C0, ST, KS, false>(st, pp, cin, c0, nullptr, bias + N::B_C0, lane, nofrow, actl);
-        pipe_layer<C, typename N::C1, ST, KS, false>(st, pp, c0, c1, nullptr, bias + N::B_C1, lane, nofrow, actl);
-        pipe_layer<C, typename N::C2, ST, 1, false>(st, pp, c1, none, col, bias + N::B_C2, lane, nofrow, actl);
+        pipe_layer<C, typename N::C0, ST, KS, TRAIN>(st, pp, cin, c0, nullptr, bias + N::B_C0, lane, nofrow, actl);
+        pipe_layer<C, typename N::C1, ST, KS, TRAIN>(st, pp, c0, c1, nullptr, bias + N::B_C1, lane, nofrow, actl);
+        pipe_layer<C, typename N::C2, ST, 1, TRAIN>(st, pp, c1, none, col, bias + N::B_C2, lane, nofrow, actl);
         if (h == 0 && valid) {
             f32x4 o;
             o[0] = sig[0][0];
@@ -299,6 +316,26 @@ __global__ __launch_bounds__(NT, 1) void k_voxel_mlp_resident(const VoxMlpParams
             *reinterpret_cast<f32x4*>(p.raw + sidx * 4) = o;
         }
     }
+}
+
+// the level's TRAINING forward on the resident stream (HD = 64 levels; the caller falls back to k_voxel_mlp_pipe's TRAIN variant otherwise)
+template <int PREC, int HD, int G, int FT, bool HI_ONLY>
+static int launch_voxel_resident_train(const VoxMlpParams& p, hipStream_t st) {
+    constexpr int NT = EVD_RES_NT;
+    typedef PipeCfg<PREC, 1, NT, PIPE_CB, HI_ONLY> C;
+    typedef VoxNet<C, HD, G, FT, false, true> N;
+    typedef PResident<C, N::NCH> ST;
+    constexpr size_t lds = (size_t)ST::BYTES + (size_t)C::BIAS_FLOATS * 4;
+    static_assert(lds <= 160 * 1024, "the level's stream is resident in LDS");
+    if (p.nchunks != N::NCH) return fail(EVD_E_INVALID, "evd_voxel: packed stream has %d chunks, kernel expects %d", p.nchunks, N::NCH);
+    if (!p.act) return fail(EVD_E_INVALID, "evd_voxel: training launch without an activation store");
+    int cus = 256;
+    { int dev = 0, v = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
+    const long groups = cdiv(p.nsamp, 256L) * (256 / C::SAMPLES);
+    EVD_SET_MAX_LDS((&k_voxel_mlp_resident<PREC, HD, G, FT, NT, true, HI_ONLY>), lds);
+    hipLaunchKernelGGL((k_voxel_mlp_resident<PREC, HD, G, FT, NT, true, HI_ONLY>), dim3((unsigned)(groups < cus ? groups : cus)), dim3(NT), lds, st, p);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
 }
 
 template <int PREC, int HD, int G, int FT>
