@@ -175,3 +175,25 @@ def test_gather_into_a_row_window_and_merge_in_place():
             net.sample(pts, None, out=rows[:, :, :net.app_dim].transpose(0, 1))
         with pytest.raises(L.EvdError):
             net.sample(pts, None, out=torch.empty((R, S + Nn, net.app_dim), dtype=torch.float64, device=pts.device))
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "f16"])
+def test_resident_coarse_level_equals_the_streaming_kernel(prec, tmp_path):
+    """The 64-wide level's render pass on the weight stream resident in LDS (k_voxel_mlp_resident, round 6: persistent workgroups, no ring, no
+    barrier) keeps the streaming kernel's layer table, arithmetic and order of operations: colour, depth, acc and weights of 4096 x 64 samples are
+    BIT FOR BIT those of k_voxel_mlp_pipe (EVD_COARSE_FORM=pipe; the switch is read once per process, hence the two subprocesses)."""
+    import subprocess
+    outs = []
+    for form in ("resident", "pipe"):
+        env = dict(os.environ)
+        env.pop("EVD_COARSE_FORM", None)
+        if form == "pipe":
+            env["EVD_COARSE_FORM"] = "pipe"
+        out = tmp_path / f"{form}.npy"
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dev", "coarse_form_check.py"), str(out), prec], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert f"[{form}, {prec}] 4096 x 64" in r.stdout, r.stdout
+        outs.append(np.load(out))
+    a, b = outs
+    assert a.size == b.size == 4096 * (3 + 1 + 1 + 64) and np.isfinite(a).all()
+    assert (a.view(np.uint32) == b.view(np.uint32)).all(), float(np.abs(a - b).max())
