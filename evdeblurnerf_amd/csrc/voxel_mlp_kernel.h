@@ -2,7 +2,9 @@
 // coarse 64 / 15 / 32 level on it; reference
 // networks/pdrf/voxnerf.py:210-221,240-254 with the blurfactory dimensions): sigma net 127 -> 256 -> 1 + 128,
 // colour net 155 -> 256 -> 256 -> 3 (sigmoid), on the machinery of mlp_pipe.h.  One straight-line stream of 368
-// MFMAs per wavefront; layer table below.  The coarse level (64-wide) stays on kernel_voxel.hip's generic kernel.
+// MFMAs per wavefront; layer table below.  The coarse level (64-wide) runs the same table: its training forward on k_voxel_mlp_pipe (TRAIN), its
+// render pass -- and its training forward in the split-float16 modes -- on k_voxel_mlp_resident (round 6: the whole weight stream resident in LDS,
+// persistent workgroups, no barrier); with per-sample feature rows wanted it takes kernel_voxel.hip's generic kernel.
 #pragma once
 
 #include "mlp_pipe.h"
