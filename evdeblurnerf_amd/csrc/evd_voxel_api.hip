@@ -431,7 +431,8 @@ static int voxel_pass(const evd_voxel* v, int precision, const float* pts, const
     VoxMlpParams p;
     static const bool no_pipe = env_flag("EVD_NO_PIPE");
     const bool comp = precision == EVD_PREC_F16C && v->pipe_c_chunks > 0;
-    if (precision == EVD_PREC_F16C && !comp) precision = EVD_PREC_F16X3;      // the 64-wide coarse level: float32-grade arithmetic (a few % of the render)
+    const bool coarse_of_f16c = precision == EVD_PREC_F16C && !comp;
+    if (coarse_of_f16c) precision = EVD_PREC_F16X3;      // the 64-wide coarse level: float32-grade arithmetic (a few % of the render)
     if (comp && feature) return fail(EVD_E_INVALID, "evd_voxel: per-sample feature rows are not built in EVD_PREC_F16C (use EVD_PREC_F16X3)");
     const bool piped = v->pipe_chunks[precision] > 0 && !no_pipe;
     p.wstream = (const char*)(piped ? v->pipe[precision].data.p : v->stream[precision].data.p);
@@ -455,6 +456,7 @@ static int voxel_pass(const evd_voxel* v, int precision, const float* pts, const
     if (coarse_pipe) {
         p.wstream = (const char*)v->train[precision].data.p;
         p.nchunks = v->train_chunks[precision];
+        p.rev_trig = coarse_of_f16c ? 1 : 0;       // an f16c render: this level's encodings as the fine level's kernel computes them (voxel_mlp_kernel.h)
     }
     int rc = comp ? launch_voxel_pipe_f16c(p, as_stream(stream))
              : coarse_pipe ? (precision == EVD_PREC_BF16 ? launch_voxel_coarse_pipe_bf16(p, as_stream(stream))

@@ -645,6 +645,33 @@ __device__ __forceinline__ float sin_or_cos_hw(float a, int h) {
 #endif
 }
 
+// ... with the compensated float16 mode's sines (mlp_pipe_c.h c_sin_rev): x / 2 pi in two floats, 2^k (hi part) exact, its fract exact, the
+// hardware unit on the reduced revolution count -- ~1e-6 absolute instead of the float32-grade polynomial's ~1e-7, a fifth of its instructions
+template <class C, int L, int KSN>
+__device__ __forceinline__ void encode_pairs_rev(const float (&x)[3], int h, typename C::O::B (&out)[KSN]) {
+    float thi[3], tlo[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        thi[c] = x[c] * 0.15915494309189535f;
+        tlo[c] = fmaf(x[c], 0.15915494309189535f, -thi[c]) + x[c] * 6.4206383e-09f;
+    }
+#pragma unroll
+    for (int q = 0; q < KSN * 8; q += 2) {
+        float y[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int qq = q + i;
+            if (qq < 3 * L) {
+                const float sc = (float)(1 << (qq / 3));
+                y[i] = __builtin_amdgcn_sinf(fmaf(tlo[qq % 3], sc, __builtin_amdgcn_fractf(thi[qq % 3] * sc) + (h ? 0.25f : 0.f)));
+            } else if (qq == 3 * L) y[i] = h ? x[1] : x[0];
+            else if (qq == 3 * L + 1) y[i] = h ? 0.f : x[2];
+            else y[i] = 0.f;
+        }
+        C::O::template set_pair<false>(out[q >> 3], (q & 7) >> 1, y[0], y[1]);
+    }
+}
+
 // positional encoding of a 3-vector straight into B-fragment order (arrangement of nerf_mlp.h)
 template <class C, int L, int KSN>
 __device__ __forceinline__ void encode_pairs(const float (&x)[3], int h, typename C::O::B (&out)[KSN]) {

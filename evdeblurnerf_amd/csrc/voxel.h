@@ -30,6 +30,7 @@ struct VoxMlpParams {
     char* act;                  // training kernels: activation store, else null
     int pe_l = 10, pe_lv = 4;           // multires / multires_views (generic kernel; the pipelined ones are built for nerf_mlp.h PE_L / PE_LV)
     const unsigned* wscale = nullptr;   // compensated float16 mode: row-scale words, 32 per output tile in stream order (pack.h StreamBuilderC)
+    int rev_trig = 0;                   // k_voxel_mlp_resident: the encodings' sines on the hardware unit behind the two-float revolution reduction (the f16c render's coarse level)
 };
 
 // ---- binned scatter (kernel_voxel_scatter.hip): what the first pass of the tri-plane backward leaves per sample for the second

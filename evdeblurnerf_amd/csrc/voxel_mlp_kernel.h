@@ -240,7 +240,7 @@ static int launch_voxel_pipe_level(const VoxMlpParams& p, hipStream_t st) {
 // arithmetic mode).  Here the workgroups are persistent (one per CU), copy the stream ONCE (mlp_pipe.h PResident) and walk the sample tiles
 // without a barrier; the direction encoding stays in registers (no stash).
 // TRAIN / HI_ONLY: the training forward of the level (k_voxel_mlp_pipe's TRAIN variant: every completed block also goes to the activation store).
-template <int PREC, int HD, int G, int FT, int NT, bool TRAIN = false, bool HI_ONLY = false>
+template <int PREC, int HD, int G, int FT, int NT, bool TRAIN = false, bool HI_ONLY = false, bool REV = false>
 __global__ __launch_bounds__(NT, 1) void k_voxel_mlp_resident(const VoxMlpParams p) {
     typedef PipeCfg<PREC, 1, NT, PIPE_CB, HI_ONLY> C;
     typedef typename C::O O;
@@ -284,8 +284,13 @@ __global__ __launch_bounds__(NT, 1) void k_voxel_mlp_resident(const VoxMlpParams
                 O::template set_pair<false>(in0[0][j], 3, b[2], b[3]);
             }
             B pe[PE_KS];
-            encode_pairs<C, PE_L, PE_KS>(pts, h, pe);
-            encode_pairs<C, PE_LV, PEV_KS>(vd, h, pev);
+            if constexpr (REV) {
+                encode_pairs_rev<C, PE_L, PE_KS>(pts, h, pe);
+                encode_pairs_rev<C, PE_LV, PEV_KS>(vd, h, pev);
+            } else {
+                encode_pairs<C, PE_L, PE_KS>(pts, h, pe);
+                encode_pairs<C, PE_LV, PEV_KS>(vd, h, pev);
+            }
 #pragma unroll
             for (int j = 0; j < PE_KS; ++j) in0[0][KF + j] = pe[j];
             if constexpr (TRAIN) {
@@ -357,6 +362,16 @@ static int launch_voxel_resident_level(const VoxMlpParams& p, hipStream_t st) {
     int cus = 256;
     { int dev = 0, v = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
     const long groups = cdiv(p.nsamp, (long)C::SAMPLES);
+    if constexpr (PREC == EVD_PREC_F16X3) {
+        // the coarse level of an f16c RENDER (p.rev_trig, evd_voxel_api.hip): sines as in that mode's fine-level kernel; EVD_COARSE_TRIG=exact (developer switch): the polynomial
+        static const bool exact = [] { const char* e = getenv("EVD_COARSE_TRIG"); return e && !strcmp(e, "exact"); }();
+        if (p.rev_trig && !exact) {
+            EVD_SET_MAX_LDS((&k_voxel_mlp_resident<PREC, HD, G, FT, NT, false, false, true>), lds);
+            hipLaunchKernelGGL((k_voxel_mlp_resident<PREC, HD, G, FT, NT, false, false, true>), dim3((unsigned)(groups < cus ? groups : cus)), dim3(NT), lds, st, p);
+            EVD_LAUNCH_CHECK();
+            return EVD_OK;
+        }
+    }
     EVD_SET_MAX_LDS((&k_voxel_mlp_resident<PREC, HD, G, FT, NT>), lds);
     hipLaunchKernelGGL((k_voxel_mlp_resident<PREC, HD, G, FT, NT>), dim3((unsigned)(groups < cus ? groups : cus)), dim3(NT), lds, st, p);
     EVD_LAUNCH_CHECK();
