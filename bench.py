@@ -340,7 +340,8 @@ def c2f_leg(precision, steps, parity=True):
                                 "channels); not bandwidth-bound: k_voxel_sample_w is a latency chain per wavefront (points -> tap geometry -> gather -> basis GEMM -> "
                                 "store), k_voxel_sample_m (float16 grids, round 6) is bound by the instructions its three wavefronts per SIMD issue (DESIGN.md 3.3)"}}
     out["arithmetic"] = {"f16c": "fine level: compensated float16 (k_voxel_mlp_c: f16 MFMA + two block-scaled fp6 MFMA residual products); coarse 64-wide level: "
-                                 "float32-grade f16x3 on the float32 grids; the fine level gathers the float16 copies of its grids",
+                                 "float32-grade f16x3 products on the float32 grids (k_voxel_mlp_resident: weight stream resident in LDS; its encodings' sines on the "
+                                 "hardware unit behind the two-float revolution reduction, as in the fine level's kernel); the fine level gathers the float16 copies of its grids",
                          "f16": "single-product float16 MFMA on both levels, float16 grid copies", "bf16": "bf16 MFMA on both levels, float16 grid copies",
                          "f16x3": "three float16 MFMA products per MAC on both levels, float32 grids", "f32": "exact float32 MFMA, float32 grids"}[precision]
     if parity:
