@@ -1,5 +1,7 @@
 """NeRF-mode training path on the GPU: the forward that keeps its activations and the backward of the fused MLP, against a
 float64 torch restatement of NeRF.mlpforward (networks/nerf.py:46-72) differentiated by torch autograd."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -938,7 +940,9 @@ def test_scatter_on_the_float16_grid_copies_is_the_scatter_of_the_rounded_grids(
     assert max(errs) < 2e-6, errs
     c, d = run(sd0, "f16"), run(sd0, "f16x3")
     errs = [rel_l2(x, y) for x, y in zip(c, d)]
-    assert 1e-5 < max(errs[:6]) < 1e-3, errs          # the float16 rounding of the grid values (2^-11 per value, averaged over taps), nothing more
+    # (developer switches that take the float32 re-gather in every mode: then the two calls are the same kernel)
+    off = os.environ.get("EVD_SCATTER_HALF") == "0" or os.environ.get("EVD_SCATTER_ISSUER") == "1" or os.environ.get("EVD_SCATTER_FORM") == "block"
+    assert (0.0 if off else 1e-5) <= max(errs[:6]) < 1e-3, errs          # the float16 rounding of the grid values (2^-11 per value, averaged over taps), nothing more
 
 
 @pytest.mark.parametrize("prec,tol", [("f16", 5e-5), ("f16x3", 5e-6)])
