@@ -883,13 +883,14 @@ static int sample_bwd_ws(const evd_voxel* v, bool half_grids, const float* pts, 
 int evd_voxel_tv_loss_bwd(const evd_voxel* v, const float* d_loss, const evd_voxel_grid_grads* g, void* stream) {
     EVD_REQUIRE(v && g && d_loss, "evd_voxel_tv_loss_bwd: null argument");
     hipStream_t st = as_stream(stream);
+    TvJobs jobs;
+    jobs.n = 6;
     for (int i = 0; i < 3; ++i) {
         const int C = v->n_comp[i], Wp = v->grid[kMat0[i]], Hp = v->grid[kMat1[i]], Lp = v->grid[kVec[i]];
-        int rc = g->plane[i] ? launch_tv_bwd((const float*)v->plane[i].p, Hp, Wp, C, d_loss, 1e-2f, g->plane[i], st) : EVD_OK;
-        if (!rc && g->line[i]) rc = launch_tv_bwd((const float*)v->line[i].p, Lp, 1, C, d_loss, 1e-3f, g->line[i], st);
-        if (rc) return rc;
+        jobs.j[i] = TvJob{(const float*)v->plane[i].p, g->plane[i], Hp, Wp, C, 1e-2f, 0, 0};
+        jobs.j[3 + i] = TvJob{(const float*)v->line[i].p, g->line[i], Lp, 1, C, 1e-3f, 0, 0};
     }
-    return EVD_OK;
+    return launch_tv_bwd_level(jobs, d_loss, st);
 }
 
 int evd_voxel_tv_loss(const evd_voxel* v, float* out, void* stream) {
@@ -897,14 +898,15 @@ int evd_voxel_tv_loss(const evd_voxel* v, float* out, void* stream) {
     hipStream_t st = as_stream(stream);
     double* acc = (double*)v->tv_acc.p;
     TvShape s;
+    TvJobs jobs;
+    jobs.n = 6;
     for (int i = 0; i < 3; ++i) {
         const int C = v->n_comp[i], Wp = v->grid[kMat0[i]], Hp = v->grid[kMat1[i]], Lp = v->grid[kVec[i]];
-        s.C[i] = C; s.H[i] = Hp; s.W[i] = Wp;
-        s.C[3 + i] = C; s.H[3 + i] = Lp; s.W[3 + i] = 1;
-        int rc = launch_tv((const float*)v->plane[i].p, Hp, Wp, C, acc + (size_t)i * 2 * TV_MAX_BLOCKS, &s.blocks[i], st);
-        if (!rc) rc = launch_tv((const float*)v->line[i].p, Lp, 1, C, acc + (size_t)(3 + i) * 2 * TV_MAX_BLOCKS, &s.blocks[3 + i], st);
-        if (rc) return rc;
+        jobs.j[i] = TvJob{(const float*)v->plane[i].p, nullptr, Hp, Wp, C, 1e-2f, 0, 0};
+        jobs.j[3 + i] = TvJob{(const float*)v->line[i].p, nullptr, Lp, 1, C, 1e-3f, 0, 0};
     }
+    int rc = launch_tv_level(jobs, acc, &s, st);
+    if (rc) return rc;
     return launch_tv_finish(acc, s, out, st);
 }
 

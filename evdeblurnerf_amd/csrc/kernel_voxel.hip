@@ -1940,12 +1940,13 @@ __global__ __launch_bounds__(256) void k_basis_grad(const float* __restrict__ d_
 
 // d (TV_loss_app) / d grid, added into `grad` scaled by d loss (a device scalar) x weight (1e-2 planes | 1e-3 lines) (voxnerf.py:126-130, 306-324):
 // reg = 2 (sum dh^2 / count_h + sum dw^2 / count_w)  =>  d reg / d x = 4 ((dh_prev - dh_next) / count_h + (dw_prev - dw_next) / count_w)
-__global__ __launch_bounds__(256) void k_tv_bwd(const float* __restrict__ x, int H, int W, int C, const float* __restrict__ d_loss, float weight, float* __restrict__ grad) {
+__device__ __forceinline__ void tv_bwd_body(const float* __restrict__ x, int H, int W, int C, const float* __restrict__ d_loss, float weight, float* __restrict__ grad,
+                                            int block, int nblocks) {
     const float scale = d_loss[0] * weight;
     const long per_row = (long)W * (C / 4), total = per_row * H;
     const float kh = H > 1 ? 4.f * scale / ((float)C * (H - 1) * W) : 0.f;
     const float cw = fmaxf((float)C * H * (W - 1), 1.f), kw = 4.f * scale / cw;
-    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < total; v += (long)gridDim.x * 256) {
+    for (long v = (long)block * 256 + threadIdx.x; v < total; v += (long)nblocks * 256) {
         const int hh = (int)(v / per_row);
         const long r = v % per_row;
         const int wq = (int)(r / (C / 4));
@@ -1959,6 +1960,16 @@ __global__ __launch_bounds__(256) void k_tv_bwd(const float* __restrict__ x, int
         f32x4* gd = reinterpret_cast<f32x4*>(grad + v * 4);
         *gd = *gd + gsum;
     }
+}
+__global__ __launch_bounds__(256) void k_tv_bwd(const float* __restrict__ x, int H, int W, int C, const float* __restrict__ d_loss, float weight, float* __restrict__ grad) {
+    tv_bwd_body(x, H, W, C, d_loss, weight, grad, blockIdx.x, gridDim.x);
+}
+// the six tensors of a level in one launch (voxel.h TvJobs)
+__global__ __launch_bounds__(256) void k_tv_bwd_level(const TvJobs jobs, const float* __restrict__ d_loss) {
+    int i = 0;
+    while (i + 1 < jobs.n && (int)blockIdx.x >= jobs.j[i + 1].blk0) ++i;
+    const TvJob jb = jobs.j[i];
+    if (jb.grad) tv_bwd_body(jb.x, jb.H, jb.W, jb.C, d_loss, jb.weight, jb.grad, (int)blockIdx.x - jb.blk0, jb.nblk);
 }
 
 __global__ __launch_bounds__(256) void k_f32_to_f16(const float* __restrict__ x, long n4, _Float16* __restrict__ y) {
@@ -2089,13 +2100,13 @@ int voxel_mlp_dispatch(int prec, int HD, int G, int FT, const VoxMlpParams& p, h
 // HBM-bound (every grid value is read once per training iteration): one thread = 4 channels of one texel, float4
 // loads of the texel, its lower and its right neighbour (both re-read from L1/L2), rows strided over blockIdx.y,
 // double accumulators, one partial pair per block (summed by k_tv_finish).
-__global__ __launch_bounds__(256) void k_tv(const float* __restrict__ x, int H, int W, int C, double* __restrict__ acc2) {
+__device__ __forceinline__ void tv_body(const float* __restrict__ x, int H, int W, int C, double* __restrict__ acc2, int bxi, int byi, int bx, int by) {
     __shared__ double red[2][4];
     const int vec_per_row = W * (C / 4);
     double sh = 0.0, sw = 0.0;
-    for (int hh = blockIdx.y; hh < H; hh += gridDim.y) {
+    for (int hh = byi; hh < H; hh += by) {
         const float* row = x + (long)hh * W * C;
-        for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < vec_per_row; t += gridDim.x * blockDim.x) {
+        for (int t = bxi * 256 + threadIdx.x; t < vec_per_row; t += bx * 256) {
             const int wq = t / (C / 4);
             const f32x4 v = *reinterpret_cast<const f32x4*>(row + 4 * (long)t);
             float ph = 0.f, pw = 0.f;
@@ -2116,10 +2127,23 @@ __global__ __launch_bounds__(256) void k_tv(const float* __restrict__ x, int H, 
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sh; red[1][threadIdx.x >> 6] = sw; }
     __syncthreads();
     if (threadIdx.x == 0) {         // one partial pair per block (4096 same-address double atomics serialise for ~0.2 ms)
-        const int b = blockIdx.y * gridDim.x + blockIdx.x;
+        const int b = byi * bx + bxi;
         acc2[2 * b] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
         acc2[2 * b + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     }
+}
+__global__ __launch_bounds__(256) void k_tv(const float* __restrict__ x, int H, int W, int C, double* __restrict__ acc2) {
+    tv_body(x, H, W, C, acc2, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
+}
+__host__ __device__ inline int tv_bx(int W, int C) { const long v = ((long)W * (C / 4) + 255) / 256; return (int)(v < 64 ? v : 64); }
+__host__ __device__ inline int tv_by(int H) { return H < 64 ? H : 64; }
+// the six tensors of a level in one launch: job i's partial pairs at acc + i * 2 * TV_MAX_BLOCKS, as k_tv_finish reads them
+__global__ __launch_bounds__(256) void k_tv_level(const TvJobs jobs, double* __restrict__ acc) {
+    int i = 0;
+    while (i + 1 < jobs.n && (int)blockIdx.x >= jobs.j[i + 1].blk0) ++i;
+    const TvJob jb = jobs.j[i];
+    const int lb = (int)blockIdx.x - jb.blk0, bx = tv_bx(jb.W, jb.C), by = tv_by(jb.H);
+    tv_body(jb.x, jb.H, jb.W, jb.C, acc + (size_t)i * 2 * TV_MAX_BLOCKS, lb % bx, lb / bx, bx, by);
 }
 
 __global__ __launch_bounds__(256) void k_tv_finish(const double* __restrict__ part, TvShape s, float* __restrict__ out) {
@@ -2368,6 +2392,36 @@ int launch_tv(const float* x, int H, int W, int C, double* acc2, int* blocks, hi
     const unsigned by = (unsigned)(H < 64 ? H : 64);
     *blocks = (int)(bx * by);
     k_tv<<<dim3(bx, by), 256, 0, st>>>(x, H, W, C, acc2);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+int launch_tv_level(TvJobs& jobs, double* partials, TvShape* shape, hipStream_t st) {
+    int total = 0;
+    for (int i = 0; i < jobs.n; ++i) {
+        TvJob& j = jobs.j[i];
+        if (j.C % 4) return fail(EVD_E_INVALID, "evd_voxel_tv_loss: component count %d is not a multiple of 4", j.C);
+        j.blk0 = total;
+        j.nblk = tv_bx(j.W, j.C) * tv_by(j.H);
+        shape->C[i] = j.C; shape->H[i] = j.H; shape->W[i] = j.W; shape->blocks[i] = j.nblk;
+        total += j.nblk;
+    }
+    k_tv_level<<<(unsigned)total, 256, 0, st>>>(jobs, partials);
+    EVD_LAUNCH_CHECK();
+    return EVD_OK;
+}
+
+int launch_tv_bwd_level(TvJobs& jobs, const float* d_loss, hipStream_t st) {
+    int total = 0;
+    for (int i = 0; i < jobs.n; ++i) {
+        TvJob& j = jobs.j[i];
+        const long vecs = (long)j.H * j.W * (j.C / 4);
+        j.blk0 = total;
+        j.nblk = j.grad ? (int)(cdiv(vecs, 256L) < 4096 ? cdiv(vecs, 256L) : 4096) : 0;
+        total += j.nblk;
+    }
+    if (total == 0) return EVD_OK;
+    k_tv_bwd_level<<<(unsigned)total, 256, 0, st>>>(jobs, d_loss);
     EVD_LAUNCH_CHECK();
     return EVD_OK;
 }

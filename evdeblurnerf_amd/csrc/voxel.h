@@ -65,6 +65,12 @@ int launch_voxel_sample_bwd_binned(const GridParams& g, const float* pts, long n
 
 constexpr int TV_MAX_BLOCKS = 4096;     // partial (dh^2, dw^2) pairs per tensor
 struct TvShape { int C[6], H[6], W[6], blocks[6]; };
+// one launch for the six tensors of a level (round 6: twelve launches per iteration -- half of them on 586 x 64 line grids, whose kernels are
+// all launch -- became two, for the value and for the gradient): the launch's blocks are dealt to the jobs in order
+struct TvJob { const float* x; float* grad; int H, W, C; float weight; int blk0, nblk; };
+struct TvJobs { TvJob j[6]; int n; };
+int launch_tv_level(TvJobs& jobs, double* partials /* job i at i * 2 * TV_MAX_BLOCKS */, TvShape* shape, hipStream_t st);
+int launch_tv_bwd_level(TvJobs& jobs, const float* d_loss, hipStream_t st);
 
 int launch_points(const float* rb, int nc, const float* z, long n, int S, float* pts, hipStream_t st);
 // evd_sample_z + the sample positions (kernels_render.hip)
